@@ -1,0 +1,87 @@
+"""TEST INFRASTRUCTURE ONLY -- generate `tests/golden/*.npz` from the REAL reference.
+
+Run in the authoring container (where `/root/reference` exists):
+
+    python -m oracle.make_golden
+
+For every case it builds the reference `wesep.models.bsrnn.BSRNN`
+(`joint_training=False`), loads the deterministic parameter set
+`oracle.bsrnn_oracle.synth_params(cfg, seed)` into it with a strict
+`load_state_dict`, runs forward + restated SI-SDR loss + backward on the
+synthetic batch `synth_batch(R, T, seed)`, and stores: the inputs, the
+estimated waveform, the loss, and for every parameter gradient its L2 norm
+plus its first 16 values (full gradient for tensors <= 4096 elements).
+The fixtures pin `oracle/bsrnn_oracle.py` (tests/test_oracle_golden.py) and,
+through it, the HIP path.  The reference cannot travel to the GPU box; the
+fixtures can.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from oracle import bsrnn_oracle as O
+from oracle.ref_import import import_reference
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+CASES = {
+    # name: (cfg kwargs, R, T, seed)
+    "bsrnn_multiply_r2_t4000": (dict(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False), 2, 4000, 11),
+    "bsrnn_film_multi_r2_t3000": (dict(num_repeat=2, spk_fuse_type="FiLM", multi_fuse=True), 2, 3000, 12),
+    "bsrnn_additive_xform_r4_t2048": (dict(num_repeat=1, spk_fuse_type="additive", multi_fuse=False,
+                                           use_spk_transform=True), 4, 2048, 13),
+    "bsrnn_concat_r2_t2500": (dict(num_repeat=1, spk_fuse_type="concat", multi_fuse=True), 2, 2500, 14),
+}
+
+
+def run_case(name, kw, R, T, seed):
+    get_model = import_reference()
+    cfg = O.BSRNNConfig(**kw)
+    ref = get_model("BSRNN")(
+        spk_emb_dim=cfg.spk_emb_dim, sr=cfg.sr, win=cfg.win, stride=cfg.stride,
+        feature_dim=cfg.feature_dim, num_repeat=cfg.num_repeat,
+        use_spk_transform=cfg.use_spk_transform, spk_fuse_type=cfg.spk_fuse_type,
+        multi_fuse=cfg.multi_fuse, joint_training=False)
+    params = O.synth_params(cfg, seed)
+    ref_sd = ref.state_dict()
+    assert list(ref_sd.keys()) == list(params.keys()), "oracle param_shapes() order != reference state_dict"
+    for k in ref_sd:
+        assert tuple(ref_sd[k].shape) == tuple(params[k].shape), k
+    ref.load_state_dict(params, strict=True)
+    ref.train()
+    wav, tgt, emb = O.synth_batch(R, T, seed)
+    est, _ = ref(wav, emb)
+    loss = O.sisdr_loss(est, tgt)
+    loss.backward()
+    # independent cross-check of the loss restatement: reference's numpy SI-SNR metric
+    sisnr_np = np.mean([O.cal_sisnr_np(tgt[r].numpy(), est[r].detach().numpy()) for r in range(R)])
+    assert abs(-float(loss) - sisnr_np) < 1e-3, (float(loss), sisnr_np)
+    out = {
+        "wav": wav.numpy(), "tgt": tgt.numpy(), "emb": emb.numpy(),
+        "est": est.detach().numpy(), "loss": np.float64(loss.item()),
+        "param_checksum": np.float64(sum(float(v.double().abs().sum()) for v in params.values())),
+    }
+    names = []
+    for k, prm in ref.named_parameters():
+        g = prm.grad.detach().reshape(-1)
+        names.append(k)
+        out["gnorm/" + k] = np.float64(g.double().norm().item())
+        out["ghead/" + k] = g[:16].numpy().copy()
+        if g.numel() <= 4096:
+            out["gfull/" + k] = g.numpy().copy()
+    out["names"] = np.array(names)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.6f} sisnr_np={sisnr_np:.6f} est_rms={est.pow(2).mean().sqrt().item():.4e}")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    only = sys.argv[1:]
+    for name, (kw, R, T, seed) in CASES.items():
+        if only and name not in only:
+            continue
+        run_case(name, kw, R, T, seed)

@@ -1,0 +1,89 @@
+"""CPU: pin `oracle/bsrnn_oracle.py` against fixtures produced by the REAL reference
+(`oracle/make_golden.py`).  Tolerances: the oracle and the reference execute the
+same torch CPU kernels in (almost) the same order, so agreement is ~1e-6."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bsrnn_oracle as O
+from oracle.make_golden import CASES
+
+
+def _run_oracle(name):
+    kw, R, T, seed = CASES[name]
+    cfg = O.BSRNNConfig(**kw)
+    params = {k: v.requires_grad_(True) for k, v in O.synth_params(cfg, seed).items()}
+    wav, tgt, emb = O.synth_batch(R, T, seed)
+    est = O.bsrnn_forward(params, cfg, wav, emb)
+    loss = O.sisdr_loss(est, tgt)
+    loss.backward()
+    return cfg, params, wav, tgt, emb, est, loss
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_reference_fixture(name, golden_dir):
+    path = os.path.join(golden_dir, name + ".npz")
+    assert os.path.exists(path), "fixture missing: run python -m oracle.make_golden"
+    g = np.load(path)
+    cfg, params, wav, tgt, emb, est, loss = _run_oracle(name)
+    # inputs and weights regenerate bit-identically
+    assert np.array_equal(g["wav"], wav.numpy())
+    assert np.array_equal(g["emb"], emb.numpy())
+    chk = sum(float(v.detach().double().abs().sum()) for v in params.values())
+    assert abs(chk - float(g["param_checksum"])) <= 1e-9 * abs(chk)
+    # forward
+    ref = g["est"]
+    rel = np.linalg.norm(est.detach().numpy() - ref) / np.linalg.norm(ref)
+    assert rel < 1e-5, rel
+    assert abs(loss.item() - float(g["loss"])) < 1e-4          # dB
+    # backward: every parameter gradient
+    assert list(g["names"]) == list(params.keys())
+    for k, p in params.items():
+        gn = float(g["gnorm/" + k])
+        mine = p.grad.reshape(-1)
+        assert abs(float(mine.double().norm()) - gn) <= 2e-4 * gn + 1e-9, k
+        head = g["ghead/" + k]
+        assert np.allclose(mine[:16].numpy(), head, rtol=2e-3, atol=2e-4 * gn / np.sqrt(mine.numel()) + 1e-10), k
+        if "gfull/" + k in g.files:
+            full = g["gfull/" + k]
+            err = np.linalg.norm(mine.numpy() - full) / (np.linalg.norm(full) + 1e-30)
+            assert err < 2e-4, (k, err)
+
+
+def test_fixture_set_complete(golden_dir):
+    have = {os.path.basename(p)[:-4] for p in glob.glob(os.path.join(golden_dir, "*.npz"))}
+    assert set(CASES) <= have
+
+
+def test_sisdr_matches_numpy_metric():
+    """auraloss restatement vs the reference's own numpy SI-SNR (score.py:7-21)."""
+    g = torch.Generator().manual_seed(3)
+    t = torch.randn(3, 16000, generator=g)
+    for snr_db in (-5.0, 0.0, 10.0, 30.0):
+        n = torch.randn(3, 16000, generator=g) * (10 ** (-snr_db / 20))
+        x = 0.7 * t + n
+        a = -O.sisdr_loss(x, t).item()
+        b = np.mean([O.cal_sisnr_np(t[i].numpy(), x[i].numpy()) for i in range(3)])
+        assert abs(a - b) < 1e-3
+
+
+def test_adam_restatement_matches_torch():
+    torch.manual_seed(0)
+    p = torch.randn(300)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=1e-4)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        g = torch.randn(300)
+        ref.grad = g.clone()
+        opt.step()
+        O.adam_l2_step_(p, g, m, v, step, 1e-3, weight_decay=1e-4)
+    assert torch.allclose(p, ref.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_lr_schedule_endpoints():
+    assert abs(O.exponential_decrease_lr(0, 1000, 1e-3, 2.5e-5) - 1e-3) < 1e-12
+    assert abs(O.exponential_decrease_lr(1000, 1000, 1e-3, 2.5e-5) - 2.5e-5) < 1e-12
