@@ -1,0 +1,230 @@
+/* wesep_hip.h -- C ABI of libwesep_hip.so, the MI355X (gfx950) device library behind
+ * wesep_amd's pBSRNN training path.
+ *
+ * wesep (the reference) has no FFI/operator interface of its own: its device boundary is
+ * the set of stock ATen operators its Python modules call.  Each entry
+ * point below replaces the ATen operator sequence of the reference lines it cites.  All
+ * pointers are DEVICE pointers to fp32 unless stated; all tensors are caller-allocated;
+ * `stream` is a hipStream_t (the caller's current stream); no call allocates, frees or
+ * synchronises.  Return value: WS_OK or a negative WS_ERR_* code, message via
+ * ws_last_error().  Host-side binding: wesep_amd/_lib.py (ctypes); see INTEGRATION.md.
+ *
+ * Activation layout ("Z layout"): [R][K][Tf][N] fp32, N = feature_dim contiguous, one
+ * "position" p = (r*K + k)*Tf + t per row.  The reference's [B, K*N, T] / [B*K, N, T] /
+ * [B*T, N, K] views (bsrnn.py:73-81) are strided row sets of this one buffer, so its two
+ * permute().contiguous() copies per BSNet do not exist here.
+ */
+#ifndef WESEP_HIP_H_
+#define WESEP_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WS_ABI_VERSION 1
+#define WS_OK 0
+#define WS_ERR_INVALID (-1)
+#define WS_ERR_LAUNCH (-2)
+
+int ws_abi_version(void);
+const char* ws_last_error(void);
+
+/* ---- profiling: HIP-event brackets recorded on the launch stream ------------------- */
+#define WS_PROF_LSTM_FWD 0
+#define WS_PROF_LSTM_BWD 1
+#define WS_PROF_GEMM_NT 2
+#define WS_PROF_GEMM_TN 3
+#define WS_PROF_NKINDS 4
+int ws_prof_enable(int on);                       /* 1: bracket every launch of the kinds above */
+int ws_prof_collect(int kind, double* total_ms, long long* launches); /* syncs the events; resets */
+
+/* ---- row addressing used by the GEMMs ---------------------------------------------------
+ * row m of a matrix lives at  base + (m / div) * s1 + (m % div) * s2   (elements).       */
+
+/* Per-group overrides for grouped (per-band) launches; array lives in DEVICE memory.      */
+typedef struct ws_group_nt {
+  const float* W;
+  const float* bias;
+  const float* gamma;
+  const float* beta;
+  long long a_off;    /* added to A                                     */
+  long long c_off;    /* added to C (and to R, T)                       */
+  long long st_base;  /* stat-index base                                */
+  int K, N, ldw, pad_;
+} ws_group_nt;
+
+/* C[m][n] = epi( sum_k pro(A[m][k]) * W[n][k] )        (torch Linear / Conv1d(k=1) layout)
+ *   pro : optional GroupNorm-on-load  a' = (a - mean[s]) * rstd[s] * gamma[k] + beta[k],
+ *         s = (m / st_div1) * st_m1 + (m % st_div2) * st_m2 + st_base, stats = [S][2]
+ *   epi : + bias[n]; act (0 none, 1 tanh); * (1 - T^2) if T; + R if R   (T, R addressed like C)
+ * Replaces: F.group_norm + F.linear / Conv1d(k=1) (+tanh, +residual) at bsrnn.py:38-46,
+ * 252-258, 271-282 and their autograd data-gradients.                                      */
+typedef struct ws_gemm_nt_args {
+  const float* A;
+  const float* W;
+  const float* bias;
+  float* C;
+  const float* R;
+  const float* T;
+  const float* stats;
+  const float* gamma;
+  const float* beta;
+  const ws_group_nt* groups; /* NULL or device array [ngroups] */
+  long long a_s1, a_s2, c_s1, c_s2, st_m1, st_m2, st_base;
+  int a_div, c_div, st_div1, st_div2;
+  int M, N, K, ldw;
+  int act, ngroups, max_n, vec; /* max_n: max N over groups; vec bit0: A float4-loadable, bit1: W */
+} ws_gemm_nt_args;
+int ws_gemm_nt(const ws_gemm_nt_args* a, void* stream);
+
+typedef struct ws_group_tn {
+  const float* gamma;
+  const float* beta;
+  long long g_off, a_off, st_base, out_off, bout_off;
+  int Nn, Kk, pad0_, pad1_;
+} ws_group_tn;
+
+/* Weight gradients: slab[split][out_off + n*Kk + k] = sum_{m in split} G[m][n] * pro(A[m'][k]),
+ * bslab[split][bout_off + n] = sum_m G[m][n]; the caller then sums the splits with
+ * ws_reduce_slabs (deterministic, no atomics).  m' = m + shift_rows with the row zeroed
+ * when the step index ((m / seq_div) % seq_len) +/- 1 leaves [0, seq_len) (h_{t-1} for dW_hh).
+ * Replaces the autograd weight-gradient of the same reference lines as ws_gemm_nt.         */
+typedef struct ws_gemm_tn_args {
+  const float* G;
+  const float* A;
+  float* slab;
+  float* bslab;              /* NULL: no bias gradient */
+  const float* stats;
+  const float* gamma;
+  const float* beta;
+  const ws_group_tn* groups; /* NULL or device array [ngroups] */
+  long long g_s1, g_s2, a_s1, a_s2, st_m1, st_m2, st_base;
+  long long slab_stride, bslab_stride, out_off, bout_off;
+  int g_div, a_div, st_div1, st_div2;
+  int M, Nn, Kk, rows_per_split, nsplit;
+  int shift_rows, seq_div, seq_len;
+  int ngroups, max_n, max_k, vec; /* vec bit0: A float4-loadable */
+} ws_gemm_tn_args;
+int ws_gemm_tn(const ws_gemm_tn_args* a, void* stream);
+
+/* out[(i / w) * ldo + (i % w)] = sum_s slab[s * stride + i],  i < count                    */
+int ws_reduce_slabs(const float* slab, int nsplit, long long stride, long long count,
+                    float* out, int w, long long ldo, void* stream);
+
+/* dst[c][r] = src[r][c]  (src [rows][cols] with leading dim lds)                           */
+int ws_transpose(const float* src, int rows, int cols, long long lds, float* dst, void* stream);
+
+/* ---- GroupNorm(1, C, eps) pieces (bsrnn.py:26,256,275; eps = FLT_EPSILON) ---------------
+ * A "group" g covers L rows x W contiguous floats:
+ *   base(g) = (g / gdiv) * gs1 + (g % gdiv) * gs2 (+ band_off[g % gdiv]),  row stride rs,
+ *   W = band_w ? band_w[g % nbands] : W.                                                   */
+typedef struct ws_groups_geom {
+  const int* band_w;   /* device int[nbands], or NULL */
+  const int* band_off; /* device int[nbands], or NULL */
+  long long gs1, gs2, rs;
+  int ngroups, gdiv, L, W; /* W: width (max width when band_w is given), <= 128 */
+  int nbands, pad_;        /* band of group g = g % nbands (per-band widths / gammas) */
+} ws_groups_geom;
+int ws_group_stats(const float* x, const ws_groups_geom* geo, float eps, float* stats, void* stream);
+
+/* GroupNorm backward, two passes over the same geometry:
+ *   pass 1  ab[g] = (mean_g(dxn*gamma), mean_g(dxn*gamma*xhat))
+ *   pass 2  dx = rstd*(dxn*gamma - ab0 - xhat*ab1) (+ res)          (dx may alias dxn)
+ * gamma_tab: NULL -> `gamma` (per column); else device table of per-band pointers indexed
+ * by g % nbands.                                                                            */
+int ws_gn_bwd_reduce(const float* x, const float* dxn, const float* stats, const float* gamma,
+                     const float* const* gamma_tab, const ws_groups_geom* geo, float* ab,
+                     void* stream);
+int ws_gn_bwd_apply(const float* x, const float* dxn, const float* stats, const float* ab,
+                    const float* gamma, const float* const* gamma_tab, const float* res,
+                    const ws_groups_geom* geo, float* dx, void* stream);
+/* dgamma/dbeta partials: slab[split][band][2][W]; band b owns groups {g : g % nbands == b}
+ * (nbands = 1: every group).  Caller reduces the splits.                                    */
+int ws_gn_param_grad(const float* x, const float* dxn, const float* stats,
+                     const ws_groups_geom* geo, int nsplit, float* slab, void* stream);
+
+/* ---- bidirectional LSTM recurrence (nn.LSTM inside ResRNN, bsrnn.py:27-33,40) -----------
+ * Sequence s, step t lives at row  p = (s / sq_div) * sq_s1 + (s % sq_div) * sq_s2 + t * step_rows.
+ * gates [P][2][4H] holds x-projection + biases on entry (gate order i,f,g,o) and the
+ * ACTIVATED gates on exit; cbuf/hcat [P][2H] (dir-major halves).  H = 256 only.            */
+typedef struct ws_lstm_args {
+  float* gates;
+  float* cbuf;
+  float* hcat;
+  const float* dhcat;   /* bwd only: dL/dhcat [P][2H]                         */
+  const float* wpack;   /* ws_lstm_pack output for this pass (fwd or bwd)     */
+  long long sq_s1, sq_s2, step_rows;
+  int nseq, sq_div, L, mtiles; /* mtiles: 16-sequence MFMA row tiles per workgroup (1 or 2) */
+} ws_lstm_args;
+#define WS_LSTM_H 256
+#define WS_LSTM_PACK_FLOATS (2 * 4 * WS_LSTM_H * WS_LSTM_H) /* per pass, both directions */
+/* Packs weight_hh_l0 / _reverse [4H][H] into MFMA B-fragment order for the fwd and bwd pass. */
+int ws_lstm_pack(const float* whh_f, const float* whh_r, float* pack_fwd, float* pack_bwd,
+                 void* stream);
+int ws_lstm_fwd(const ws_lstm_args* a, void* stream);
+/* On exit gates holds dL/d(pre-activation gates).                                           */
+int ws_lstm_bwd(const ws_lstm_args* a, void* stream);
+/* wcat[2][4H][N] <- (w_ih_f, w_ih_r);  bcat[2][4H] <- b_ih + b_hh per direction             */
+int ws_lstm_cat_ih(const float* wih_f, const float* wih_r, const float* bih_f, const float* bhh_f,
+                   const float* bih_r, const float* bhh_r, int n_in, float* wcat, float* bcat,
+                   void* stream);
+
+/* ---- STFT / iSTFT (torch.stft / torch.istft at bsrnn.py:309-316, 382-389) ---------------
+ * n_fft = 512, hop = 128, periodic Hann, center + reflect pad.  Band-split spectrogram
+ * layout xbs [R*Tf][2*F]: band g (first bin f0, width bw) occupies columns
+ * [2*f0, 2*f0 + 2*bw) as [re(bw) | im(bw)]  == the reference's subband_spec (bsrnn.py:319-328).
+ * band_of_bin: device int[F] -> band id; band_f0/band_bw: device int[nband].               */
+typedef struct ws_bands {
+  const int* band_of_bin;
+  const int* band_f0;
+  const int* band_bw;
+  int nband, nbins;
+} ws_bands;
+int ws_stft_bandsplit(const float* wav, int R, int T, const ws_bands* b, float* xbs, void* stream);
+/* mask3 [R*Tf][4*F]: band g occupies columns [4*f0, 4*f0+4*bw) in the reference's channel
+ * order c = glu*2*bw + ri*bw + f (bsrnn.py:366-370).  frames [R*Tf][512] = windowed irfft of
+ * (mask * X)  (bsrnn.py:371-381 + the first half of istft).                                */
+int ws_mask_istft_frames(const float* xbs, const float* mask3, int R, int Tf, const ws_bands* b,
+                         float* frames, void* stream);
+/* overlap-add + window-envelope normalisation + centre trim -> wav [R][T]                  */
+int ws_istft_ola(const float* frames, int R, int Tf, int T, float* wav, void* stream);
+/* backward of the two calls above: dwav [R][T] -> dmask3 [R*Tf][4*F]                        */
+int ws_mask_istft_bwd(const float* dwav, const float* xbs, const float* mask3, int R, int Tf,
+                      int T, const ws_bands* b, float* dmask3, void* stream);
+
+/* ---- speaker fusion (speaker.py:81-125, norm.py:118-139) ---------------------------------
+ * out[p][n] = z[p][n] * (a0 + a[r][n]) + b[r][n],  r = p / rows_per_r; a or b may be NULL. */
+int ws_affine_fwd(const float* z, const float* a, const float* b, float a0, long long rows,
+                  int rows_per_r, int N, float* out, void* stream);
+/* dz_in = dz*(a0+a) (dz_in may be NULL); da_slab[split][r][n] = sum dz*z_in; db_slab likewise sum dz            */
+int ws_affine_bwd(const float* dz, const float* z_in, const float* a, float a0, long long rows,
+                  int rows_per_r, int N, int nsplit, float* dz_in, float* da_slab, float* db_slab,
+                  void* stream);
+
+/* ---- SI-SDR loss (auraloss.time.SISDRLoss via wesep/utils/losses.py:24-25) ---------------
+ * loss = -mean_r 10 log10(|a t|^2 / (|x - a t|^2 + eps) + eps), zero-mean, eps = 1e-8.
+ * rowstat [R][8] keeps (mean_x, mean_t, alpha, c1, c2, sisdr_dB, 0, 0) for the backward.   */
+int ws_sisdr_fwd(const float* est, const float* tgt, int R, int T, float eps, float* rowstat,
+                 float* loss, void* stream);
+int ws_sisdr_bwd(const float* est, const float* tgt, const float* rowstat, const float* gout,
+                 int R, int T, float* dest, void* stream);
+
+/* ---- per-tensor clip (funcs.py:79-88) + Adam with coupled L2 (train.py:237-238) ----------
+ * tab: device array of ws_tensor_ref, one per parameter tensor.                            */
+typedef struct ws_tensor_ref {
+  float* param;
+  float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  long long numel;
+} ws_tensor_ref;
+int ws_grad_norms(const ws_tensor_ref* tab, int ntensors, float* norms, void* stream);
+/* if clip > 0: coef = clip / (norm + 1e-6); grad *= coef when coef < 1  (per tensor)       */
+int ws_clip_adam_step(const ws_tensor_ref* tab, int ntensors, const float* norms, float clip,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                      int clip_only, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WESEP_HIP_H_ */

@@ -1,0 +1,175 @@
+"""CPU: the C-ABI library loads and exports every declared symbol, ctypes mirrors the C structs,
+the Python surface mirrors the reference (state_dict keys, factory, schedulers, checkpoints),
+and the product path refuses to run without the GPU (no fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "wesep_hip.h")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    from wesep_amd.build import build
+    build(verbose=False)
+    from wesep_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    src = open(HEADER).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(ws_\w+)\s*\(", src, flags=re.M))
+    assert declared, "header parse failed"
+    assert declared == set(built_lib.EXPORTED_SYMBOLS)
+    lib = built_lib.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.ws_abi_version() == 1
+
+
+def test_ctypes_structs_match_c_layout(built_lib):
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "wesep_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ws_gemm_nt_args), sizeof(ws_gemm_tn_args),
+         sizeof(ws_groups_geom), sizeof(ws_lstm_args), sizeof(ws_bands), sizeof(ws_group_nt),
+         sizeof(ws_group_tn), sizeof(ws_tensor_ref), offsetof(ws_gemm_tn_args, g_div));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "t.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    L = built_lib
+    assert sizes[:8] == [ctypes.sizeof(L.GemmNTArgs), ctypes.sizeof(L.GemmTNArgs), ctypes.sizeof(L.GroupsGeom),
+                         ctypes.sizeof(L.LstmArgs), ctypes.sizeof(L.Bands), L.GROUP_NT_DTYPE.itemsize,
+                         L.GROUP_TN_DTYPE.itemsize, L.TENSOR_REF_DTYPE.itemsize]
+    assert sizes[8] == L.GemmTNArgs.g_div.offset
+
+
+@pytest.mark.parametrize("kw", [
+    dict(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False),
+    dict(num_repeat=2, spk_fuse_type="FiLM", multi_fuse=True),
+    dict(num_repeat=1, spk_fuse_type="additive", multi_fuse=False, use_spk_transform=True),
+    dict(num_repeat=1, spk_fuse_type="concat", multi_fuse=True),
+    dict(num_repeat=6, spk_fuse_type="multiply", multi_fuse=False),
+])
+def test_state_dict_keys_match_reference(kw):
+    from oracle import bsrnn_oracle as O
+    from wesep_amd.models import get_model
+    cfg = O.BSRNNConfig(**kw)
+    m = get_model("BSRNN")(joint_training=False, use_spk_transform=cfg.use_spk_transform,
+                           **{k: v for k, v in kw.items() if k != "use_spk_transform"})
+    shapes = O.param_shapes(cfg)     # pinned to the real reference by oracle/make_golden.py
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == shapes[k] for k in sd)
+    assert not list(m.buffers())
+    if kw["num_repeat"] == 6:        # 21.435 M parameters, 530 tensors
+        assert len(sd) == 530
+        assert abs(sum(v.numel() for v in sd.values()) / 1e6 - 21.435) < 1e-3
+
+
+def test_film_zero_init_and_factory_errors():
+    from wesep_amd.models import get_model
+    m = get_model("BSRNN")(num_repeat=1, spk_fuse_type="FiLM", multi_fuse=True, joint_training=False)
+    fc = m.separator.separation[0].fc
+    assert float(fc.gamma_fcs[0].weight.abs().sum()) == 0 and float(fc.beta_fcs[0].bias.abs().sum()) == 0
+    with pytest.raises(NotImplementedError):
+        get_model("BSRNN")(joint_training=True)
+    with pytest.raises(NotImplementedError):
+        get_model("TFGridNet")
+
+
+def test_no_cpu_fallback():
+    from wesep_amd._lib import WesepHipError
+    from wesep_amd.models import get_model
+    from wesep_amd.utils.losses import parse_loss
+    m = get_model("BSRNN")(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, joint_training=False,
+                           use_spk_transform=False)
+    with pytest.raises(WesepHipError):
+        m(torch.randn(2, 4000), torch.randn(2, 256))
+    with pytest.raises(WesepHipError):
+        parse_loss("SISDR")[0](torch.randn(2, 100), torch.randn(2, 100))
+    with pytest.raises(NotImplementedError):
+        parse_loss("STFT")
+
+
+def test_product_package_never_imports_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "wesep_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_schedulers_match_oracle_formula():
+    from oracle import bsrnn_oracle as O
+    from wesep_amd.utils.schedulers import ExponentialDecrease
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+    s = ExponentialDecrease(opt, num_epochs=150, epoch_iter=100, initial_lr=1e-3, final_lr=2.5e-5,
+                            warm_up_epoch=0, scale_ratio=1.0)
+    for it in (0, 1, 777, 14999):
+        s.step(it)
+        assert abs(opt.param_groups[0]["lr"] - O.exponential_decrease_lr(it, 15000, 1e-3, 2.5e-5)) < 1e-15
+    s2 = ExponentialDecrease(opt, 10, 10, 1e-3, 1e-4, warm_up_epoch=2, scale_ratio=4.0)
+    s2.step(5)
+    assert abs(opt.param_groups[0]["lr"] - O.exponential_decrease_lr(5, 100, 1e-3, 1e-4, 20, 4.0)) < 1e-15
+    sd = s2.state_dict()
+    assert "optimizer" not in sd and sd["current_iter"] == 6
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    from wesep_amd.models import get_model
+    from wesep_amd.optim import FusedClipAdam
+    from wesep_amd.utils.checkpoint import load_checkpoint, load_pretrained_model, save_checkpoint
+    from wesep_amd.utils.schedulers import ExponentialDecrease
+    mk = lambda: get_model("BSRNN")(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False,
+                                    joint_training=False, use_spk_transform=False)
+    m1, m2 = mk(), mk()
+    o1 = FusedClipAdam(m1.parameters(), lr=1e-3, weight_decay=1e-4)
+    s1 = ExponentialDecrease(o1, 2, 10, 1e-3, 1e-4)
+    s1.step(3)
+    path = str(tmp_path / "model_1.pt")
+    save_checkpoint([m1], [o1], [s1], None, path)
+    st = torch.load(path, map_location="cpu")
+    assert set(st) == {"models", "optimizers", "schedulers", "scaler"} and len(st["models"]) == 1
+    o2 = FusedClipAdam(m2.parameters(), lr=5e-4)
+    s2 = ExponentialDecrease(o2, 2, 10, 1e-3, 1e-4)
+    load_checkpoint([m2], [o2], [s2], None, path)
+    assert all(torch.equal(a, b) for a, b in zip(m1.state_dict().values(), m2.state_dict().values()))
+    assert s2.current_iter == 4
+    load_pretrained_model(mk(), path)
+
+
+def test_tn_splits_cover_rows():
+    from wesep_amd.dev import tn_splits
+    for M in (1, 31, 32, 33, 2048, 2049, 4100, 513024, 16032):
+        n, rps = tn_splits(M)
+        assert n >= 1 and rps % 32 == 0 and n * rps >= M and (n - 1) * rps < M
+
+
+def test_band_plan_offsets():
+    from oracle import bsrnn_oracle as O
+    from wesep_amd.functional import BandPlan
+    bw = O.band_widths(16000, 512)
+    plan = BandPlan(bw, 128, torch.device("cpu"))
+    assert plan.K == 32 and sum(bw) == 257
+    assert int(plan.bn_woff[-1]) == 128 * 2 * 257
+    assert int(plan.m_w3off[-1]) == 4 * 257 * 512 and int(plan.m_b3off[-1]) == 4 * 257
+    assert plan.bands.band_of_bin.tolist()[:4] == [0, 0, 0, 1]

@@ -1,0 +1,408 @@
+"""GPU parity of every C-ABI kernel against plain torch fp32 computed on the CPU.
+All calls go through the C ABI (wesep_amd.dev -> libwesep_hip.so)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMM NT
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,vec", [(300, 200, 70, 0), (300, 200, 72, 3), (128, 128, 32, 3),
+                                       (1000, 2048, 128, 3), (77, 12, 512, 3), (513, 128, 6, 0)])
+def test_gemm_nt_plain(M, N, K, vec):
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W, b = rnd(g, M, K), rnd(g, N, K), rnd(g, N)
+    C = torch.full((M, N), float("nan"), device=d)
+    dev.gemm_nt(A=A.to(d), a_rows=dev.flat(K), M=M, N=N, K=K, W=W.to(d), ldw=K, bias=b.to(d), C_out=C,
+                c_rows=dev.flat(N), vec=vec)
+    ref = A @ W.t() + b
+    assert rel(C, ref) < 2e-6
+
+
+def test_gemm_nt_epilogues_and_norm():
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(5)
+    M, N, K, S = 260, 136, 128, 13   # rows grouped in S stat groups of 20
+    A, W, b = rnd(g, M, K), rnd(g, N, K, scale=0.1), rnd(g, N)
+    Rr, Tt = rnd(g, M, N), torch.tanh(rnd(g, M, N))
+    stats = torch.stack([rnd(g, S), rnd(g, S).abs() + 0.5], 1).contiguous()
+    gamma, beta = rnd(g, K), rnd(g, K)
+    C = torch.empty(M, N, device=d)
+    dev.gemm_nt(A=A.to(d), a_rows=dev.flat(K), M=M, N=N, K=K, W=W.to(d), ldw=K, bias=b.to(d), C_out=C,
+                c_rows=dev.flat(N), R=Rr.to(d), T=Tt.to(d), stats=stats.to(d), gamma=gamma.to(d),
+                beta=beta.to(d), stat_map=dev.StatMap(20, 1, 1, 0, 0), act=1)
+    s = torch.arange(M) // 20
+    An = (A - stats[s, 0:1]) * stats[s, 1:2] * gamma + beta
+    ref = torch.tanh(An @ W.t() + b) * (1 - Tt * Tt) + Rr
+    assert rel(C, ref) < 3e-6
+
+
+def test_gemm_nt_two_level_rows_and_groups():
+    """Grouped launch over 3 'bands' with ragged N/K, 2-level A rows and strided C columns."""
+    from wesep_amd import dev, _lib as L
+    d = _cuda()
+    g = torch.Generator().manual_seed(9)
+    Rb, Kb, Tf, N = 3, 3, 20, 128          # Z layout [Rb, Kb, Tf, N]
+    M = Rb * Tf
+    Z = rnd(g, Rb, Kb, Tf, N)
+    widths = [12, 64, 24]
+    offs = [0, 12, 76]
+    Ws = [rnd(g, w, N, scale=0.1) for w in widths]
+    bs = [rnd(g, w) for w in widths]
+    Wd, bd = [w.to(d) for w in Ws], [b.to(d) for b in bs]
+    C = torch.zeros(M, 100, device=d)
+    desc = np.zeros(3, dtype=L.GROUP_NT_DTYPE)
+    for k in range(3):
+        desc[k] = (Wd[k].data_ptr(), bd[k].data_ptr(), 0, 0, k * Tf * N, offs[k], 0, N, widths[k], N, 0)
+    gd = L.upload_struct_array(desc, d)
+    dev.gemm_nt(A=Z.to(d), a_rows=dev.Rows(Tf, Kb * Tf * N, N), M=M, C_out=C, c_rows=dev.flat(100),
+                groups=gd, ngroups=3, max_n=64)
+    ref = torch.zeros(M, 100)
+    for k in range(3):
+        Ak = Z[:, k].reshape(M, N)
+        ref[:, offs[k]:offs[k] + widths[k]] = Ak @ Ws[k].t() + bs[k]
+    assert rel(C, ref) < 2e-6
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMM TN
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,Nn,Kk,vec", [(5000, 200, 72, 1), (300, 12, 512, 1), (4100, 128, 6, 0),
+                                         (9000, 1024, 256, 1)])
+def test_gemm_tn_plain_and_bias(M, Nn, Kk, vec):
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(M + Nn)
+    G, A = rnd(g, M, Nn), rnd(g, M, Kk)
+    nsplit, rps = dev.tn_splits(M)
+    slab = torch.full((nsplit, Nn * Kk), float("nan"), device=d)
+    bslab = torch.full((nsplit, Nn), float("nan"), device=d)
+    dev.gemm_tn(G=G.to(d), g_rows=dev.flat(Nn), A=A.to(d), a_rows=dev.flat(Kk), M=M, Nn=Nn, Kk=Kk,
+                slab=slab, slab_stride=Nn * Kk, bslab=bslab, bslab_stride=Nn, nsplit=nsplit,
+                rows_per_split=rps, vec=vec)
+    out = torch.empty(Nn, Kk, device=d)
+    bo = torch.empty(Nn, device=d)
+    dev.reduce_slabs(slab, nsplit, Nn * Kk, Nn * Kk, out)
+    dev.reduce_slabs(bslab, nsplit, Nn, Nn, bo)
+    assert rel(out, G.double().t() @ A.double()) < 5e-6
+    assert rel(bo, G.double().sum(0)) < 5e-6
+
+
+@pytest.mark.parametrize("seq_div,seq_len,sign", [(1, 25, -1), (1, 25, 1), (10, 4, -1), (10, 4, 1)])
+def test_gemm_tn_shift_and_norm(seq_div, seq_len, sign):
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(17)
+    M, Nn, Kk = 400, 64, 128
+    G, A = rnd(g, M, Nn), rnd(g, M, Kk)
+    shift = sign * seq_div
+    slab = torch.empty(1, Nn * Kk, device=d)
+    dev.gemm_tn(G=G.to(d), g_rows=dev.flat(Nn), A=A.to(d), a_rows=dev.flat(Kk), M=M, Nn=Nn, Kk=Kk,
+                slab=slab, slab_stride=Nn * Kk, nsplit=1, rows_per_split=416, shift_rows=shift,
+                seq_div=seq_div, seq_len=seq_len)
+    m = torch.arange(M)
+    t = (m // seq_div) % seq_len
+    ok = ((t + sign) >= 0) & ((t + sign) < seq_len)
+    As = torch.zeros_like(A)
+    idx = m[ok] + shift
+    As[ok] = A[idx]
+    assert rel(slab.view(Nn, Kk), G.double().t() @ As.double()) < 5e-6
+    # norm prologue
+    S = 20
+    stats = torch.stack([rnd(g, S), rnd(g, S).abs() + 0.5], 1).contiguous()
+    gamma, beta = rnd(g, Kk), rnd(g, Kk)
+    dev.gemm_tn(G=G.to(d), g_rows=dev.flat(Nn), A=A.to(d), a_rows=dev.flat(Kk), M=M, Nn=Nn, Kk=Kk,
+                slab=slab, slab_stride=Nn * Kk, nsplit=1, rows_per_split=416, stats=stats.to(d),
+                gamma=gamma.to(d), beta=beta.to(d), stat_map=dev.StatMap(20, 1, 1, 0, 0))
+    s = m // 20
+    An = (A - stats[s, 0:1]) * stats[s, 1:2] * gamma + beta
+    assert rel(slab.view(Nn, Kk), G.double().t() @ An.double()) < 5e-6
+
+
+def test_transpose_and_reduce_ld():
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(3)
+    src = rnd(g, 70, 384)
+    dst = torch.empty(100, 70, device=d)
+    dev.transpose(src.to(d), 70, 100, 384, dst, src_off=128)
+    assert torch.equal(dst.cpu(), src[:, 128:228].t().contiguous())
+    slab = rnd(g, 3, 50)
+    out = torch.zeros(5, 24, device=d)
+    dev.reduce_slabs(slab.to(d), 3, 50, 50, out, w=10, ldo=24, out_off=4)
+    ref = torch.zeros(5, 24)
+    ref[:, 4:14] = slab.sum(0).view(5, 10)
+    assert rel(out, ref) < 1e-6
+
+
+# ----------------------------------------------------------------------------------------------
+# GroupNorm pieces
+# ----------------------------------------------------------------------------------------------
+def _geoms(R, K, Tf, N, d):
+    from wesep_amd import dev
+    time = dev.Geom(R * K, 1, Tf * N, 0, N, Tf, N)
+    band = dev.Geom(R * Tf, Tf, K * Tf * N, N, Tf * N, K, N)
+    return time, band
+
+
+@pytest.mark.parametrize("view", ["time", "band"])
+def test_group_stats_and_gn_backward(view):
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(21)
+    R, K, Tf, N = 2, 5, 9, 128
+    z = rnd(g, R, K, Tf, N) + 0.3
+    dxn = rnd(g, R, K, Tf, N)
+    gamma = rnd(g, N) + 1.0
+    res = rnd(g, R, K, Tf, N)
+    geo = _geoms(R, K, Tf, N, d)[0 if view == "time" else 1]
+    # torch reference: groups as [G, N, L]
+    if view == "time":
+        x3 = z.reshape(R * K, Tf, N).transpose(1, 2)
+        d3 = dxn.reshape(R * K, Tf, N).transpose(1, 2)
+    else:
+        x3 = z.permute(0, 2, 3, 1).reshape(R * Tf, N, K)
+        d3 = dxn.permute(0, 2, 3, 1).reshape(R * Tf, N, K)
+    x3 = x3.clone().requires_grad_(True)
+    gam = gamma.clone().requires_grad_(True)
+    bet = torch.zeros(N, requires_grad=True)
+    eps = float(np.finfo(np.float32).eps)
+    y = torch.nn.functional.group_norm(x3, 1, gam, bet, eps)
+    y.backward(d3)
+    mean = x3.detach().mean((1, 2))
+    rstd = 1 / torch.sqrt(x3.detach().var((1, 2), unbiased=False) + eps)
+    stats = torch.empty(geo.ngroups, 2, device=d)
+    zd, dd = z.to(d), dxn.to(d)
+    dev.group_stats(zd, geo, stats)
+    assert rel(stats[:, 0], mean) < 1e-5 and rel(stats[:, 1], rstd) < 1e-5
+    ab = torch.empty(geo.ngroups, 2, device=d)
+    dev.gn_bwd_reduce(zd, dd, stats, geo, ab, gamma=gamma.to(d))
+    dz = torch.empty_like(zd)
+    dev.gn_bwd_apply(zd, dd, stats, ab, geo, dz, gamma=gamma.to(d), res=res.to(d))
+    if view == "time":
+        gref = x3.grad.transpose(1, 2).reshape(R, K, Tf, N)
+    else:
+        gref = x3.grad.reshape(R, Tf, N, K).permute(0, 3, 1, 2)
+    assert rel(dz, gref + res) < 1e-5
+    ns = 3
+    slab = torch.empty(ns, 1, 2, N, device=d)
+    dev.gn_param_grad(zd, dd, stats, geo, ns, slab)
+    out = slab.sum(0)[0]
+    assert rel(out[0], gam.grad) < 1e-5 and rel(out[1], bet.grad) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------
+# LSTM recurrence
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("view,mt", [("time", 1), ("band", 1), ("time", 2), ("band", 2)])
+def test_lstm_fwd_bwd_vs_torch(view, mt):
+    from wesep_amd import dev, _lib as L
+    from wesep_amd.functional import _view_maps
+    d = _cuda()
+    g = torch.Generator().manual_seed(31)
+    R, K, Tf, N, H = 2, 5, 11, 128, 256
+    P = R * K * Tf
+    geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+    lstm = torch.nn.LSTM(N, H, 1, batch_first=True, bidirectional=True)
+    x = rnd(g, R, K, Tf, N)
+    if view == "time":
+        xs = x.reshape(R * K, Tf, N)
+    else:
+        xs = x.permute(0, 2, 1, 3).reshape(R * Tf, K, N)
+    xs = xs.clone().requires_grad_(True)
+    out, _ = lstm(xs)
+    dout_seq = rnd(g, *out.shape)
+    out.backward(dout_seq)
+    # gates_x = x W_ih^T + b_ih + b_hh computed on the CPU, laid out [P][2][4H]
+    with torch.no_grad():
+        gx = []
+        for sfx in ("", "_reverse"):
+            w, bi, bh = (getattr(lstm, n + sfx) for n in ("weight_ih_l0", "bias_ih_l0", "bias_hh_l0"))
+            gx.append(x.reshape(P, N) @ w.t() + bi + bh)
+        gates = torch.stack(gx, 1).contiguous().to(d)           # [P, 2, 4H]
+    pf, pb = torch.empty(L.LSTM_PACK_FLOATS, device=d), torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack(lstm.weight_hh_l0.detach().to(d).contiguous(),
+                  lstm.weight_hh_l0_reverse.detach().to(d).contiguous(), pf, pb)
+    cbuf, hcat = torch.zeros(P, 2 * H, device=d), torch.zeros(P, 2 * H, device=d)
+    dev.lstm_fwd(gates, cbuf, hcat, pf, seq, mt)
+    if view == "time":
+        href = out.detach().reshape(R, K, Tf, 2 * H)
+        dref = dout_seq.reshape(R, K, Tf, 2 * H)
+    else:
+        href = out.detach().reshape(R, Tf, K, 2 * H).permute(0, 2, 1, 3)
+        dref = dout_seq.reshape(R, Tf, K, 2 * H).permute(0, 2, 1, 3)
+    assert rel(hcat.view(R, K, Tf, 2 * H), href) < 1e-5
+    dh = dref.contiguous().reshape(P, 2 * H).to(d)
+    dev.lstm_bwd(gates, cbuf, hcat, dh, pb, seq, mt)
+    # d gates_x -> dx = dgates @ W_ih (both dirs), dW_hh via autograd comparisons
+    dg = gates.cpu()
+    dx = dg[:, 0] @ lstm.weight_ih_l0.detach() + dg[:, 1] @ lstm.weight_ih_l0_reverse.detach()
+    if view == "time":
+        dxref = xs.grad.reshape(R, K, Tf, N)
+    else:
+        dxref = xs.grad.reshape(R, Tf, K, N).permute(0, 2, 1, 3)
+    assert rel(dx.view(R, K, Tf, N), dxref) < 2e-5
+    assert rel(dg[:, 0].sum(0), lstm.bias_ih_l0.grad) < 2e-5
+    assert rel(dg[:, 1].sum(0), lstm.bias_ih_l0_reverse.grad) < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------
+# STFT / iSTFT
+# ----------------------------------------------------------------------------------------------
+def _bands(d):
+    from wesep_amd import dev
+    from oracle.bsrnn_oracle import band_widths
+    bw = band_widths(16000, 512)
+    return bw, dev.BandTables(bw, d)
+
+
+@pytest.mark.parametrize("T", [4000, 3000, 777])
+def test_stft_bandsplit_vs_torch(T):
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(T)
+    R = 3
+    wav = rnd(g, R, T, scale=0.1)
+    bw, bt = _bands(d)
+    Tf = 1 + T // 128
+    xbs = torch.full((R * Tf, 514), float("nan"), device=d)
+    dev.stft_bandsplit(wav.to(d), bt, xbs)
+    spec = torch.stft(wav, 512, 128, window=torch.hann_window(512), return_complex=True)  # [R,257,Tf]
+    ref = torch.empty(R, Tf, 514)
+    f0 = 0
+    for b in bw:
+        ref[:, :, 2 * f0:2 * f0 + b] = spec.real[:, f0:f0 + b].transpose(1, 2)
+        ref[:, :, 2 * f0 + b:2 * f0 + 2 * b] = spec.imag[:, f0:f0 + b].transpose(1, 2)
+        f0 += b
+    assert rel(xbs.view(R, Tf, 514), ref) < 2e-6
+
+
+@pytest.mark.parametrize("T", [4000, 3000])
+def test_mask_istft_fwd_bwd_vs_torch(T):
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(T + 1)
+    R = 2
+    bw, bt = _bands(d)
+    Tf = 1 + T // 128
+    wav = rnd(g, R, T, scale=0.1)
+    spec = torch.stft(wav, 512, 128, window=torch.hann_window(512), return_complex=True)
+    m3 = rnd(g, R * Tf, 1028).requires_grad_(True)
+    # torch reference of mask apply + istft
+    est_bands, f0 = [], 0
+    m3v = m3.view(R, Tf, 1028)
+    for b in bw:
+        o = m3v[:, :, 4 * f0:4 * f0 + 4 * b].reshape(R, Tf, 2, 2, b).permute(0, 2, 3, 4, 1)  # R,2,2,b,Tf
+        m = o[:, 0] * torch.sigmoid(o[:, 1])
+        xb = spec[:, f0:f0 + b]
+        est_bands.append(torch.complex(xb.real * m[:, 0] - xb.imag * m[:, 1],
+                                       xb.real * m[:, 1] + xb.imag * m[:, 0]))
+        f0 += b
+    est_ref = torch.istft(torch.cat(est_bands, 1), 512, 128, window=torch.hann_window(512), length=T)
+    dwav = rnd(g, R, T)
+    est_ref.backward(dwav)
+    xbs = torch.empty(R * Tf, 514, device=d)
+    dev.stft_bandsplit(wav.to(d), bt, xbs)
+    m3d = m3.detach().to(d)
+    frames = torch.empty(R * Tf, 512, device=d)
+    dev.mask_istft_frames(xbs, m3d, R, Tf, bt, frames)
+    est = torch.empty(R, T, device=d)
+    dev.istft_ola(frames, R, Tf, T, est)
+    assert rel(est, est_ref) < 5e-6
+    dm3 = torch.full((R * Tf, 1028), float("nan"), device=d)
+    dev.mask_istft_bwd(dwav.to(d), xbs, m3d, R, Tf, T, bt, dm3)
+    assert rel(dm3, m3.grad) < 5e-6
+
+
+# ----------------------------------------------------------------------------------------------
+# elementwise: affine, SI-SDR, clip + Adam
+# ----------------------------------------------------------------------------------------------
+def test_affine_fwd_bwd():
+    from wesep_amd.functional import AffineFn
+    d = _cuda()
+    g = torch.Generator().manual_seed(41)
+    R, K, Tf, N = 3, 4, 70, 128
+    z, a, b, go = rnd(g, R, K, Tf, N), rnd(g, R, N), rnd(g, R, N), rnd(g, R, K, Tf, N)
+    for a0, use_a, use_b in ((0.0, True, False), (1.0, False, True), (1.0, True, True)):
+        zc, ac, bc = (t.clone().requires_grad_(True) for t in (z, a, b))
+        ref = zc * (a0 + (ac[:, None, None, :] if use_a else 0)) + (bc[:, None, None, :] if use_b else 0)
+        ref.backward(go)
+        zd = z.to(d).requires_grad_(True)
+        ad = a.to(d).requires_grad_(True) if use_a else None
+        bd = b.to(d).requires_grad_(True) if use_b else None
+        out = AffineFn.apply(zd, ad, bd, a0)
+        out.backward(go.to(d))
+        assert rel(out, ref) < 1e-6 and rel(zd.grad, zc.grad) < 1e-6
+        if use_a:
+            assert rel(ad.grad, ac.grad) < 1e-5
+        if use_b:
+            assert rel(bd.grad, bc.grad) < 1e-5
+
+
+@pytest.mark.parametrize("snr_db", [-5.0, 10.0, 30.0])
+def test_sisdr_fwd_bwd(snr_db):
+    from oracle import bsrnn_oracle as O
+    from wesep_amd.functional import SISDRFn
+    d = _cuda()
+    g = torch.Generator().manual_seed(7)
+    R, T = 4, 64000
+    t = rnd(g, R, T, scale=0.1) + 0.01
+    x = (0.7 * t + rnd(g, R, T, scale=0.1 * 10 ** (-snr_db / 20)) + 0.02).requires_grad_(True)
+    ref = O.sisdr_loss(x, t)
+    ref.backward()
+    xd = x.detach().to(d).requires_grad_(True)
+    loss = SISDRFn.apply(xd, t.to(d), 1e-8)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-2       # dB (north_star tolerance)
+    assert abs(loss.item() - ref.item()) < 2e-4
+    assert rel(xd.grad, x.grad) < 1e-4
+
+
+def test_clip_adam_matches_reference_semantics():
+    from oracle import bsrnn_oracle as O
+    from wesep_amd.optim import FusedClipAdam
+    d = _cuda()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(1024, 128), (7,), (300, 5), (128,)]
+    ps = [rnd(g, *s) for s in shapes]
+    pd = [torch.nn.Parameter(p.clone().to(d)) for p in ps]
+    opt = FusedClipAdam(pd, lr=1e-3, weight_decay=1e-4, clip_grad=5.0)
+    pc = [p.clone() for p in ps]
+    ms, vs = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+    for step in range(1, 4):
+        gs = [rnd(g, *s, scale=(3.0 if i == 0 else 0.1)) for i, s in enumerate(shapes)]
+        for p, gr in zip(pd, gs):
+            p.grad = gr.clone().to(d)
+        lr = 1e-3 * (0.9 ** step)
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        opt.step()
+        norms = opt.last_grad_norms()
+        gdict = {i: gr.clone() for i, gr in enumerate(gs)}
+        nref = O.clip_gradients_(gdict, 5.0)
+        for i in range(len(ps)):
+            assert abs(norms[i] - nref[i]) < 1e-4 * max(1.0, nref[i])
+            O.adam_l2_step_(pc[i], gdict[i], ms[i], vs[i], step, lr, weight_decay=1e-4)
+            assert rel(pd[i], pc[i]) < 1e-6, (step, i)
+            assert rel(pd[i].grad, gdict[i]) < 1e-6   # clipped in place like funcs.py:86-87

@@ -1,0 +1,146 @@
+"""ctypes binding of libwesep_hip.so (C ABI declared in include/wesep_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+fails, this module raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+(or `python -m wesep_amd.build`)."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwesep_hip.so")
+
+WS_OK = 0
+PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
+LSTM_H = 256
+LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
+
+_p = C.c_void_p
+_ll = C.c_longlong
+_i = C.c_int
+_f = C.c_float
+
+
+class GemmNTArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("A", "W", "bias", "C", "R", "T", "stats", "gamma", "beta", "groups")] + \
+               [(n, _ll) for n in ("a_s1", "a_s2", "c_s1", "c_s2", "st_m1", "st_m2", "st_base")] + \
+               [(n, _i) for n in ("a_div", "c_div", "st_div1", "st_div2", "M", "N", "K", "ldw",
+                                  "act", "ngroups", "max_n", "vec")]
+
+
+class GemmTNArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("G", "A", "slab", "bslab", "stats", "gamma", "beta", "groups")] + \
+               [(n, _ll) for n in ("g_s1", "g_s2", "a_s1", "a_s2", "st_m1", "st_m2", "st_base",
+                                   "slab_stride", "bslab_stride", "out_off", "bout_off")] + \
+               [(n, _i) for n in ("g_div", "a_div", "st_div1", "st_div2", "M", "Nn", "Kk",
+                                  "rows_per_split", "nsplit", "shift_rows", "seq_div", "seq_len",
+                                  "ngroups", "max_n", "max_k", "vec")]
+
+
+class GroupsGeom(C.Structure):
+    _fields_ = [("band_w", _p), ("band_off", _p), ("gs1", _ll), ("gs2", _ll), ("rs", _ll),
+                ("ngroups", _i), ("gdiv", _i), ("L", _i), ("W", _i), ("nbands", _i), ("pad_", _i)]
+
+
+class LstmArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "dhcat", "wpack")] + \
+               [(n, _ll) for n in ("sq_s1", "sq_s2", "step_rows")] + \
+               [(n, _i) for n in ("nseq", "sq_div", "L", "mtiles")]
+
+
+class Bands(C.Structure):
+    _fields_ = [("band_of_bin", _p), ("band_f0", _p), ("band_bw", _p), ("nband", _i), ("nbins", _i)]
+
+
+# device-resident descriptor arrays are built with numpy and uploaded as bytes
+GROUP_NT_DTYPE = np.dtype([("W", "<u8"), ("bias", "<u8"), ("gamma", "<u8"), ("beta", "<u8"),
+                           ("a_off", "<i8"), ("c_off", "<i8"), ("st_base", "<i8"),
+                           ("K", "<i4"), ("N", "<i4"), ("ldw", "<i4"), ("pad_", "<i4")])
+GROUP_TN_DTYPE = np.dtype([("gamma", "<u8"), ("beta", "<u8"), ("g_off", "<i8"), ("a_off", "<i8"),
+                           ("st_base", "<i8"), ("out_off", "<i8"), ("bout_off", "<i8"),
+                           ("Nn", "<i4"), ("Kk", "<i4"), ("pad0_", "<i4"), ("pad1_", "<i4")])
+TENSOR_REF_DTYPE = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"),
+                             ("exp_avg_sq", "<u8"), ("numel", "<i8")])
+assert GROUP_NT_DTYPE.itemsize == 72 and GROUP_TN_DTYPE.itemsize == 72 and TENSOR_REF_DTYPE.itemsize == 40
+
+_SIGS = {
+    "ws_abi_version": (_i, []),
+    "ws_last_error": (C.c_char_p, []),
+    "ws_prof_enable": (_i, [_i]),
+    "ws_prof_collect": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_ll)]),
+    "ws_gemm_nt": (_i, [C.POINTER(GemmNTArgs), _p]),
+    "ws_gemm_tn": (_i, [C.POINTER(GemmTNArgs), _p]),
+    "ws_reduce_slabs": (_i, [_p, _i, _ll, _ll, _p, _i, _ll, _p]),
+    "ws_transpose": (_i, [_p, _i, _i, _ll, _p, _p]),
+    "ws_group_stats": (_i, [_p, C.POINTER(GroupsGeom), _f, _p, _p]),
+    "ws_gn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _p, _p]),
+    "ws_gn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _p, _p]),
+    "ws_gn_param_grad": (_i, [_p, _p, _p, C.POINTER(GroupsGeom), _i, _p, _p]),
+    "ws_lstm_pack": (_i, [_p, _p, _p, _p, _p]),
+    "ws_lstm_fwd": (_i, [C.POINTER(LstmArgs), _p]),
+    "ws_lstm_bwd": (_i, [C.POINTER(LstmArgs), _p]),
+    "ws_lstm_cat_ih": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "ws_stft_bandsplit": (_i, [_p, _i, _i, C.POINTER(Bands), _p, _p]),
+    "ws_mask_istft_frames": (_i, [_p, _p, _i, _i, C.POINTER(Bands), _p, _p]),
+    "ws_istft_ola": (_i, [_p, _i, _i, _i, _p, _p]),
+    "ws_mask_istft_bwd": (_i, [_p, _p, _p, _i, _i, _i, C.POINTER(Bands), _p, _p]),
+    "ws_affine_fwd": (_i, [_p, _p, _p, _f, _ll, _i, _i, _p, _p]),
+    "ws_affine_bwd": (_i, [_p, _p, _p, _f, _ll, _i, _i, _i, _p, _p, _p, _p]),
+    "ws_sisdr_fwd": (_i, [_p, _p, _i, _i, _f, _p, _p, _p]),
+    "ws_sisdr_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
+    "ws_grad_norms": (_i, [_p, _i, _p, _p]),
+    "ws_clip_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+_lib = None
+
+
+class WesepHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WesepHipError(
+                f"{LIB_PATH} is missing: the HIP extension is not built and wesep_amd has no "
+                "CPU fallback. Run `python -m wesep_amd.build` (needs hipcc).")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.ws_abi_version() != 1:
+            raise WesepHipError("libwesep_hip.so ABI version mismatch; rebuild")
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != WS_OK:
+        msg = lib().ws_last_error().decode("utf-8", "replace")
+        raise WesepHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a float32/int32 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise WesepHipError("wesep_amd ops need CUDA (ROCm) tensors; there is no CPU path")
+    return C.c_void_p(t.data_ptr())
+
+
+def upload_struct_array(arr: np.ndarray, device) -> torch.Tensor:
+    """numpy structured array -> uint8 device tensor holding the same bytes."""
+    host = torch.from_numpy(np.frombuffer(arr.tobytes(), dtype=np.uint8).copy())
+    return host.to(device)

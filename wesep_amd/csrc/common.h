@@ -1,0 +1,57 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of wesep_amd.
+// wave = 64 lanes everywhere in this tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/wesep_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WS_WAVE 64
+
+// ---- error plumbing ---------------------------------------------------------
+void ws_set_error(const char* fmt, ...);
+int ws_check_launch(const char* what);
+
+#define WS_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      ws_set_error(__VA_ARGS__);         \
+      return WS_ERR_INVALID;             \
+    }                                    \
+  } while (0)
+
+// ---- profiling hooks (HIP events on the launch stream; see prof.hip) ---------
+void ws_prof_begin(int kind, hipStream_t s);
+void ws_prof_end(int kind, hipStream_t s);
+
+// ---- device helpers -----------------------------------------------------------
+__device__ __forceinline__ float ws_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64). `red` = >= 16 floats of LDS.
+// Every thread gets the total.  Contains two barriers.
+__device__ __forceinline__ float ws_block_sum(float v, float* red) {
+  v = ws_wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ float ws_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// row index -> element offset under the two-level row addressing used across the C ABI:
+//   off(m) = (m / div) * s1 + (m % div) * s2
+__device__ __forceinline__ long long ws_row_off(int m, int div, long long s1, long long s2) {
+  const int q = m / div;
+  return (long long)q * s1 + (long long)(m - q * div) * s2;
+}

@@ -1,0 +1,184 @@
+// GroupNorm(1, C, eps) statistics and backward for the strided "group" geometries of pBSRNN
+// (wesep/models/bsrnn.py:26 ResRNN.norm, :256 BN[i][0], :275 mask[i][0]).  The forward
+// normalisation itself is fused into the consuming GEMM's operand load (gemm.hip); here are
+// the reductions: two-pass mean/variance (eps = FLT_EPSILON makes a one-pass E[x^2]-E[x]^2
+// unsafe), the two backward group means, and the dgamma/dbeta column sums.  All HBM-bound:
+// one workgroup per group, coalesced row reads, wave-shuffle + LDS reductions.
+#include "common.h"
+
+struct GroupView {
+  long long base;
+  int W;
+  int band;
+};
+
+__device__ __forceinline__ GroupView group_view(const ws_groups_geom& geo, int g) {
+  GroupView v;
+  v.band = g % geo.nbands;
+  v.W = geo.band_w ? geo.band_w[v.band] : geo.W;
+  v.base = (long long)(g / geo.gdiv) * geo.gs1 + (long long)(g % geo.gdiv) * geo.gs2 +
+           (geo.band_off ? geo.band_off[v.band] : 0);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void group_stats_kernel(const float* __restrict__ x,
+                                                          const ws_groups_geom geo, float eps,
+                                                          float* __restrict__ stats) {
+  __shared__ float red[16];
+  const int g = blockIdx.x;
+  const GroupView v = group_view(geo, g);
+  const int n = geo.L * v.W;
+  const float* xb = x + v.base;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int row = i / v.W, col = i - row * v.W;
+    s += xb[(long long)row * geo.rs + col];
+  }
+  const float mean = ws_block_sum(s, red) / (float)n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int row = i / v.W, col = i - row * v.W;
+    const float dv = xb[(long long)row * geo.rs + col] - mean;
+    q += dv * dv;
+  }
+  const float var = ws_block_sum(q, red) / (float)n;
+  if (threadIdx.x == 0) {
+    stats[2 * (long long)g] = mean;
+    stats[2 * (long long)g + 1] = 1.f / sqrtf(var + eps);
+  }
+}
+
+static int geom_check(const ws_groups_geom* geo, const char* who) {
+  WS_REQUIRE(geo && geo->ngroups > 0 && geo->gdiv > 0 && geo->L > 0 && geo->W > 0 && geo->nbands > 0,
+             "%s: bad geometry", who);
+  WS_REQUIRE(geo->W <= 128, "%s: W=%d > 128", who, geo->W);
+  return WS_OK;
+}
+
+extern "C" int ws_group_stats(const float* x, const ws_groups_geom* geo, float eps, float* stats,
+                              void* stream) {
+  int rc = geom_check(geo, "ws_group_stats");
+  if (rc != WS_OK) return rc;
+  WS_REQUIRE(x && stats, "ws_group_stats: null pointer");
+  hipLaunchKernelGGL(group_stats_kernel, dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream, x,
+                     *geo, eps, stats);
+  return ws_check_launch("ws_group_stats");
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
+    const float* __restrict__ x, const float* __restrict__ dxn, const float* __restrict__ stats,
+    const float* __restrict__ gamma, const float* const* __restrict__ gamma_tab,
+    const ws_groups_geom geo, float* __restrict__ ab) {
+  __shared__ float red[16];
+  const int g = blockIdx.x;
+  const GroupView v = group_view(geo, g);
+  const float* gm = gamma_tab ? gamma_tab[v.band] : gamma;
+  const int n = geo.L * v.W;
+  const float mean = stats[2 * (long long)g], rstd = stats[2 * (long long)g + 1];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int row = i / v.W, col = i - row * v.W;
+    const long long o = v.base + (long long)row * geo.rs + col;
+    const float dg = dxn[o] * gm[col];
+    s1 += dg;
+    s2 += dg * (x[o] - mean) * rstd;
+  }
+  s1 = ws_block_sum(s1, red);
+  s2 = ws_block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    ab[2 * (long long)g] = s1 / (float)n;
+    ab[2 * (long long)g + 1] = s2 / (float)n;
+  }
+}
+
+extern "C" int ws_gn_bwd_reduce(const float* x, const float* dxn, const float* stats,
+                                const float* gamma, const float* const* gamma_tab,
+                                const ws_groups_geom* geo, float* ab, void* stream) {
+  int rc = geom_check(geo, "ws_gn_bwd_reduce");
+  if (rc != WS_OK) return rc;
+  WS_REQUIRE(x && dxn && stats && ab && (gamma || gamma_tab), "ws_gn_bwd_reduce: null pointer");
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream,
+                     x, dxn, stats, gamma, gamma_tab, *geo, ab);
+  return ws_check_launch("ws_gn_bwd_reduce");
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
+    const float* __restrict__ x, const float* dxn, const float* __restrict__ stats,
+    const float* __restrict__ ab, const float* __restrict__ gamma,
+    const float* const* __restrict__ gamma_tab, const float* __restrict__ res,
+    const ws_groups_geom geo, float* dx) {
+  const int g = blockIdx.x;
+  const GroupView v = group_view(geo, g);
+  const float* gm = gamma_tab ? gamma_tab[v.band] : gamma;
+  const int n = geo.L * v.W;
+  const float mean = stats[2 * (long long)g], rstd = stats[2 * (long long)g + 1];
+  const float a0 = ab[2 * (long long)g], a1 = ab[2 * (long long)g + 1];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int row = i / v.W, col = i - row * v.W;
+    const long long o = v.base + (long long)row * geo.rs + col;
+    const float xh = (x[o] - mean) * rstd;
+    float r = rstd * (dxn[o] * gm[col] - a0 - xh * a1);
+    if (res) r += res[o];
+    dx[o] = r;
+  }
+}
+
+extern "C" int ws_gn_bwd_apply(const float* x, const float* dxn, const float* stats,
+                               const float* ab, const float* gamma, const float* const* gamma_tab,
+                               const float* res, const ws_groups_geom* geo, float* dx,
+                               void* stream) {
+  int rc = geom_check(geo, "ws_gn_bwd_apply");
+  if (rc != WS_OK) return rc;
+  WS_REQUIRE(x && dxn && stats && ab && dx && (gamma || gamma_tab), "ws_gn_bwd_apply: null pointer");
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream, x,
+                     dxn, stats, ab, gamma, gamma_tab, res, *geo, dx);
+  return ws_check_launch("ws_gn_bwd_apply");
+}
+
+// dgamma[col] = sum dxn*xhat, dbeta[col] = sum dxn over every row of every group of a band.
+// grid (nbands, nsplit); 256 threads = 128 columns x 2 row lanes.
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ dxn,
+                                                            const float* __restrict__ stats,
+                                                            const ws_groups_geom geo, int nsplit,
+                                                            float* __restrict__ slab) {
+  __shared__ float sh[2][128];
+  const int band = blockIdx.x, split = blockIdx.y;
+  const int col = threadIdx.x & 127, rl = threadIdx.x >> 7;
+  const int per_band = geo.ngroups / geo.nbands;
+  float sg = 0.f, sb = 0.f;
+  for (int j = split; j < per_band; j += nsplit) {
+    const int g = j * geo.nbands + band;
+    const GroupView v = group_view(geo, g);
+    if (col >= v.W) continue;
+    const float mean = stats[2 * (long long)g], rstd = stats[2 * (long long)g + 1];
+    for (int row = rl; row < geo.L; row += 2) {
+      const long long o = v.base + (long long)row * geo.rs + col;
+      const float dv = dxn[o];
+      sg += dv * (x[o] - mean) * rstd;
+      sb += dv;
+    }
+  }
+  if (rl == 1) {
+    sh[0][col] = sg;
+    sh[1][col] = sb;
+  }
+  __syncthreads();
+  if (rl == 0 && col < geo.W) {
+    float* out = slab + ((long long)(split * geo.nbands + band) * 2) * geo.W;
+    out[col] = sg + sh[0][col];
+    out[geo.W + col] = sb + sh[1][col];
+  }
+}
+
+extern "C" int ws_gn_param_grad(const float* x, const float* dxn, const float* stats,
+                                const ws_groups_geom* geo, int nsplit, float* slab, void* stream) {
+  int rc = geom_check(geo, "ws_gn_param_grad");
+  if (rc != WS_OK) return rc;
+  WS_REQUIRE(x && dxn && stats && slab && nsplit > 0, "ws_gn_param_grad: bad args");
+  WS_REQUIRE(geo->ngroups % geo->nbands == 0, "ws_gn_param_grad: ngroups %% nbands != 0");
+  WS_REQUIRE(geo->W <= 128, "ws_gn_param_grad: W > 128");
+  hipLaunchKernelGGL(gn_param_grad_kernel, dim3(geo->nbands, nsplit), dim3(256), 0,
+                     (hipStream_t)stream, x, dxn, stats, *geo, nsplit, slab);
+  return ws_check_launch("ws_gn_param_grad");
+}

@@ -1,0 +1,94 @@
+// Host-side runtime of libwesep_hip.so: error reporting + HIP-event kernel profiler.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void ws_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int ws_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ws_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return WS_ERR_LAUNCH;
+  }
+  return WS_OK;
+}
+
+extern "C" const char* ws_last_error(void) { return g_err; }
+extern "C" int ws_abi_version(void) { return WS_ABI_VERSION; }
+
+// ---- profiler ---------------------------------------------------------------------------
+// When enabled, every launch of a profiled kind is bracketed by two hipEvents recorded on the
+// launch stream; ws_prof_collect() synchronises them and returns the summed elapsed time.
+namespace {
+struct Pair {
+  hipEvent_t a, b;
+};
+struct Prof {
+  std::mutex mu;
+  bool on = false;
+  std::vector<Pair> used[WS_PROF_NKINDS];
+  std::vector<Pair> pool;
+  hipEvent_t open[WS_PROF_NKINDS] = {};
+  hipEvent_t open_b[WS_PROF_NKINDS] = {};
+} g_prof;
+}  // namespace
+
+extern "C" int ws_prof_enable(int on) {
+  std::lock_guard<std::mutex> l(g_prof.mu);
+  g_prof.on = on != 0;
+  return WS_OK;
+}
+
+void ws_prof_begin(int kind, hipStream_t s) {
+  if (!g_prof.on) return;
+  std::lock_guard<std::mutex> l(g_prof.mu);
+  Pair p;
+  if (!g_prof.pool.empty()) {
+    p = g_prof.pool.back();
+    g_prof.pool.pop_back();
+  } else {
+    hipEventCreate(&p.a);
+    hipEventCreate(&p.b);
+  }
+  hipEventRecord(p.a, s);
+  g_prof.open[kind] = p.a;
+  g_prof.open_b[kind] = p.b;
+}
+
+void ws_prof_end(int kind, hipStream_t s) {
+  if (!g_prof.on) return;
+  std::lock_guard<std::mutex> l(g_prof.mu);
+  if (!g_prof.open[kind]) return;
+  hipEventRecord(g_prof.open_b[kind], s);
+  g_prof.used[kind].push_back(Pair{g_prof.open[kind], g_prof.open_b[kind]});
+  g_prof.open[kind] = nullptr;
+}
+
+extern "C" int ws_prof_collect(int kind, double* total_ms, long long* launches) {
+  WS_REQUIRE(kind >= 0 && kind < WS_PROF_NKINDS && total_ms && launches, "ws_prof_collect: bad args");
+  std::lock_guard<std::mutex> l(g_prof.mu);
+  double tot = 0.0;
+  for (auto& p : g_prof.used[kind]) {
+    hipEventSynchronize(p.b);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, p.a, p.b);
+    tot += ms;
+    g_prof.pool.push_back(p);
+  }
+  *total_ms = tot;
+  *launches = (long long)g_prof.used[kind].size();
+  g_prof.used[kind].clear();
+  return WS_OK;
+}

@@ -1,0 +1,319 @@
+"""Typed Python wrappers over the C ABI (include/wesep_hip.h): torch tensors in, raw device
+pointers + the current HIP stream out.  No arithmetic happens here."""
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+BIG = 1 << 30  # divisor meaning "never wraps" (flat row addressing)
+GN_EPS = float(np.finfo(np.float32).eps)  # bsrnn.py:23
+
+
+class Rows(NamedTuple):
+    """row m -> (m // div) * s1 + (m % div) * s2 elements."""
+    div: int
+    s1: int
+    s2: int
+
+
+def flat(ld: int) -> Rows:
+    return Rows(BIG, 0, ld)
+
+
+class StatMap(NamedTuple):
+    """row m -> stat index (m // div1) * m1 + (m % div2) * m2 + base."""
+    div1: int
+    m1: int
+    div2: int
+    m2: int
+    base: int = 0
+
+
+def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise L.WesepHipError(f"{name}: expected a contiguous {dtype} CUDA tensor, got "
+                              f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+def _p(t: Optional[torch.Tensor], off: int = 0):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + 4 * off)
+
+
+def gemm_nt(*, A, a_rows: Rows, M: int, C_out, c_rows: Rows, N=0, K=0, W=None, ldw=0, bias=None,
+            R=None, T=None, stats=None, gamma=None, beta=None, stat_map: Optional[StatMap] = None,
+            act=0, groups=None, ngroups=0, max_n=0, vec=3, a_off=0, c_off=0, w_off=0):
+    for n, t in (("A", A), ("W", W), ("bias", bias), ("C", C_out), ("R", R), ("T", T),
+                 ("stats", stats), ("gamma", gamma), ("beta", beta)):
+        _chk(t, n)
+    a = L.GemmNTArgs()
+    a.A, a.W, a.bias, a.C = _p(A, a_off), _p(W, w_off), _p(bias), _p(C_out, c_off)
+    a.R, a.T = _p(R, c_off), _p(T, c_off)
+    a.stats, a.gamma, a.beta = _p(stats), _p(gamma), _p(beta)
+    a.groups = C.c_void_p(groups.data_ptr()) if groups is not None else None
+    a.a_div, a.a_s1, a.a_s2 = a_rows
+    a.c_div, a.c_s1, a.c_s2 = c_rows
+    sm = stat_map or StatMap(1, 0, 1, 0, 0)
+    a.st_div1, a.st_m1, a.st_div2, a.st_m2, a.st_base = sm
+    a.M, a.N, a.K, a.ldw = M, N, K, ldw
+    a.act, a.ngroups, a.max_n, a.vec = act, ngroups, max_n, vec
+    L.check(L.lib().ws_gemm_nt(C.byref(a), L.stream_ptr()), "ws_gemm_nt")
+
+
+def tn_splits(M: int):
+    nsplit = max(1, min(64, M // 2048))
+    rows = -(-M // nsplit)
+    rows = -(-rows // 32) * 32
+    nsplit = -(-M // rows)
+    return nsplit, rows
+
+
+def gemm_tn(*, G, g_rows: Rows, A, a_rows: Rows, M: int, slab, slab_stride: int, nsplit: int,
+            rows_per_split: int, Nn=0, Kk=0, bslab=None, bslab_stride=0, out_off=0, bout_off=0,
+            stats=None, gamma=None, beta=None, stat_map: Optional[StatMap] = None,
+            shift_rows=0, seq_div=1, seq_len=1, groups=None, ngroups=0, max_n=0, max_k=0, vec=1,
+            g_off=0, a_off=0):
+    for n, t in (("G", G), ("A", A), ("slab", slab), ("bslab", bslab), ("stats", stats),
+                 ("gamma", gamma), ("beta", beta)):
+        _chk(t, n)
+    a = L.GemmTNArgs()
+    a.G, a.A, a.slab, a.bslab = _p(G, g_off), _p(A, a_off), _p(slab), _p(bslab)
+    a.stats, a.gamma, a.beta = _p(stats), _p(gamma), _p(beta)
+    a.groups = C.c_void_p(groups.data_ptr()) if groups is not None else None
+    a.g_div, a.g_s1, a.g_s2 = g_rows
+    a.a_div, a.a_s1, a.a_s2 = a_rows
+    sm = stat_map or StatMap(1, 0, 1, 0, 0)
+    a.st_div1, a.st_m1, a.st_div2, a.st_m2, a.st_base = sm
+    a.slab_stride, a.bslab_stride, a.out_off, a.bout_off = slab_stride, bslab_stride, out_off, bout_off
+    a.M, a.Nn, a.Kk, a.rows_per_split, a.nsplit = M, Nn, Kk, rows_per_split, nsplit
+    a.shift_rows, a.seq_div, a.seq_len = shift_rows, seq_div, seq_len
+    a.ngroups, a.max_n, a.max_k, a.vec = ngroups, max_n, max_k, vec
+    L.check(L.lib().ws_gemm_tn(C.byref(a), L.stream_ptr()), "ws_gemm_tn")
+
+
+def reduce_slabs(slab, nsplit: int, stride: int, count: int, out, w=0, ldo=0, out_off=0):
+    _chk(slab, "slab")
+    _chk(out, "out")
+    L.check(L.lib().ws_reduce_slabs(_p(slab), nsplit, stride, count, _p(out, out_off), w, ldo,
+                                    L.stream_ptr()), "ws_reduce_slabs")
+
+
+def transpose(src, rows: int, cols: int, lds: int, dst, src_off=0, dst_off=0):
+    _chk(src, "src")
+    _chk(dst, "dst")
+    L.check(L.lib().ws_transpose(_p(src, src_off), rows, cols, lds, _p(dst, dst_off), L.stream_ptr()),
+            "ws_transpose")
+
+
+class Geom(NamedTuple):
+    ngroups: int
+    gdiv: int
+    gs1: int
+    gs2: int
+    rs: int
+    L: int
+    W: int
+    nbands: int = 1
+    band_w: Optional[torch.Tensor] = None
+    band_off: Optional[torch.Tensor] = None
+
+    def c(self):
+        g = L.GroupsGeom()
+        g.band_w = C.c_void_p(self.band_w.data_ptr()) if self.band_w is not None else None
+        g.band_off = C.c_void_p(self.band_off.data_ptr()) if self.band_off is not None else None
+        g.gs1, g.gs2, g.rs = self.gs1, self.gs2, self.rs
+        g.ngroups, g.gdiv, g.L, g.W, g.nbands = self.ngroups, self.gdiv, self.L, self.W, self.nbands
+        return g
+
+
+def group_stats(x, geo: Geom, stats, eps=GN_EPS):
+    _chk(x, "x")
+    _chk(stats, "stats")
+    g = geo.c()
+    L.check(L.lib().ws_group_stats(_p(x), C.byref(g), eps, _p(stats), L.stream_ptr()), "ws_group_stats")
+
+
+def _tab(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def gn_bwd_reduce(x, dxn, stats, geo: Geom, ab, gamma=None, gamma_tab=None):
+    for n, t in (("x", x), ("dxn", dxn), ("stats", stats), ("ab", ab), ("gamma", gamma)):
+        _chk(t, n)
+    g = geo.c()
+    L.check(L.lib().ws_gn_bwd_reduce(_p(x), _p(dxn), _p(stats), _p(gamma), _tab(gamma_tab),
+                                     C.byref(g), _p(ab), L.stream_ptr()), "ws_gn_bwd_reduce")
+
+
+def gn_bwd_apply(x, dxn, stats, ab, geo: Geom, dx, gamma=None, gamma_tab=None, res=None):
+    for n, t in (("x", x), ("dxn", dxn), ("stats", stats), ("ab", ab), ("gamma", gamma),
+                 ("res", res), ("dx", dx)):
+        _chk(t, n)
+    g = geo.c()
+    L.check(L.lib().ws_gn_bwd_apply(_p(x), _p(dxn), _p(stats), _p(ab), _p(gamma), _tab(gamma_tab),
+                                    _p(res), C.byref(g), _p(dx), L.stream_ptr()), "ws_gn_bwd_apply")
+
+
+def gn_param_grad(x, dxn, stats, geo: Geom, nsplit: int, slab):
+    for n, t in (("x", x), ("dxn", dxn), ("stats", stats), ("slab", slab)):
+        _chk(t, n)
+    g = geo.c()
+    L.check(L.lib().ws_gn_param_grad(_p(x), _p(dxn), _p(stats), C.byref(g), nsplit, _p(slab),
+                                     L.stream_ptr()), "ws_gn_param_grad")
+
+
+class SeqMap(NamedTuple):
+    """sequence s, step t -> row (s // div) * s1 + (s % div) * s2 + t * step_rows."""
+    nseq: int
+    div: int
+    s1: int
+    s2: int
+    step_rows: int
+    L: int
+
+
+def lstm_pack(whh_f, whh_r, pack_fwd, pack_bwd):
+    for n, t in (("whh_f", whh_f), ("whh_r", whh_r), ("pack_fwd", pack_fwd), ("pack_bwd", pack_bwd)):
+        _chk(t, n)
+    L.check(L.lib().ws_lstm_pack(_p(whh_f), _p(whh_r), _p(pack_fwd), _p(pack_bwd), L.stream_ptr()),
+            "ws_lstm_pack")
+
+
+def lstm_cat_ih(wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, n_in, wcat, bcat):
+    for t in (wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, wcat, bcat):
+        _chk(t, "lstm_cat_ih arg")
+    L.check(L.lib().ws_lstm_cat_ih(_p(wih_f), _p(wih_r), _p(bih_f), _p(bhh_f), _p(bih_r), _p(bhh_r),
+                                   n_in, _p(wcat), _p(bcat), L.stream_ptr()), "ws_lstm_cat_ih")
+
+
+def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mtiles, dhcat=None):
+    for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("wpack", wpack), ("dhcat", dhcat)):
+        _chk(t, n)
+    a = L.LstmArgs()
+    a.gates, a.cbuf, a.hcat, a.dhcat, a.wpack = _p(gates), _p(cbuf), _p(hcat), _p(dhcat), _p(wpack)
+    a.sq_s1, a.sq_s2, a.step_rows = sm.s1, sm.s2, sm.step_rows
+    a.nseq, a.sq_div, a.L, a.mtiles = sm.nseq, sm.div, sm.L, mtiles
+    return a
+
+
+def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mtiles=1):
+    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mtiles)
+    L.check(L.lib().ws_lstm_fwd(C.byref(a), L.stream_ptr()), "ws_lstm_fwd")
+
+
+def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mtiles=1):
+    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mtiles, dhcat)
+    L.check(L.lib().ws_lstm_bwd(C.byref(a), L.stream_ptr()), "ws_lstm_bwd")
+
+
+class BandTables:
+    """Device-resident band tables shared by the STFT / norm / GEMM launches."""
+
+    def __init__(self, band_width, device):
+        bw = np.asarray(band_width, dtype=np.int32)
+        f0 = np.concatenate([[0], np.cumsum(bw)[:-1]]).astype(np.int32)
+        self.nband = len(bw)
+        self.nbins = int(bw.sum())
+        self.bw_host, self.f0_host = bw, f0
+        bob = np.repeat(np.arange(self.nband, dtype=np.int32), bw)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.band_of_bin, self.f0, self.bw = to(bob), to(f0), to(bw)
+        self.bw2, self.off2 = to(2 * bw), to(2 * f0)
+
+    def c(self):
+        b = L.Bands()
+        b.band_of_bin = C.c_void_p(self.band_of_bin.data_ptr())
+        b.band_f0 = C.c_void_p(self.f0.data_ptr())
+        b.band_bw = C.c_void_p(self.bw.data_ptr())
+        b.nband, b.nbins = self.nband, self.nbins
+        return b
+
+
+def stft_bandsplit(wav, bands: BandTables, xbs):
+    _chk(wav, "wav")
+    _chk(xbs, "xbs")
+    R, T = wav.shape
+    b = bands.c()
+    L.check(L.lib().ws_stft_bandsplit(_p(wav), R, T, C.byref(b), _p(xbs), L.stream_ptr()),
+            "ws_stft_bandsplit")
+
+
+def mask_istft_frames(xbs, mask3, R, Tf, bands: BandTables, frames):
+    for n, t in (("xbs", xbs), ("mask3", mask3), ("frames", frames)):
+        _chk(t, n)
+    b = bands.c()
+    L.check(L.lib().ws_mask_istft_frames(_p(xbs), _p(mask3), R, Tf, C.byref(b), _p(frames),
+                                         L.stream_ptr()), "ws_mask_istft_frames")
+
+
+def istft_ola(frames, R, Tf, T, wav):
+    _chk(frames, "frames")
+    _chk(wav, "wav")
+    L.check(L.lib().ws_istft_ola(_p(frames), R, Tf, T, _p(wav), L.stream_ptr()), "ws_istft_ola")
+
+
+def mask_istft_bwd(dwav, xbs, mask3, R, Tf, T, bands: BandTables, dmask3):
+    for n, t in (("dwav", dwav), ("xbs", xbs), ("mask3", mask3), ("dmask3", dmask3)):
+        _chk(t, n)
+    b = bands.c()
+    L.check(L.lib().ws_mask_istft_bwd(_p(dwav), _p(xbs), _p(mask3), R, Tf, T, C.byref(b), _p(dmask3),
+                                      L.stream_ptr()), "ws_mask_istft_bwd")
+
+
+def affine_fwd(z, a, b, a0, rows, rows_per_r, N, out):
+    for n, t in (("z", z), ("a", a), ("b", b), ("out", out)):
+        _chk(t, n)
+    L.check(L.lib().ws_affine_fwd(_p(z), _p(a), _p(b), a0, rows, rows_per_r, N, _p(out),
+                                  L.stream_ptr()), "ws_affine_fwd")
+
+
+def affine_bwd(dz, z_in, a, a0, rows, rows_per_r, N, nsplit, dz_in, da_slab, db_slab):
+    for n, t in (("dz", dz), ("z_in", z_in), ("a", a), ("dz_in", dz_in), ("da_slab", da_slab),
+                 ("db_slab", db_slab)):
+        _chk(t, n)
+    L.check(L.lib().ws_affine_bwd(_p(dz), _p(z_in), _p(a), a0, rows, rows_per_r, N, nsplit, _p(dz_in),
+                                  _p(da_slab), _p(db_slab), L.stream_ptr()), "ws_affine_bwd")
+
+
+def sisdr_fwd(est, tgt, rowstat, loss, eps=1e-8):
+    for n, t in (("est", est), ("tgt", tgt), ("rowstat", rowstat), ("loss", loss)):
+        _chk(t, n)
+    R, T = est.shape
+    L.check(L.lib().ws_sisdr_fwd(_p(est), _p(tgt), R, T, eps, _p(rowstat), _p(loss), L.stream_ptr()),
+            "ws_sisdr_fwd")
+
+
+def sisdr_bwd(est, tgt, rowstat, gout, dest):
+    for n, t in (("est", est), ("tgt", tgt), ("rowstat", rowstat), ("gout", gout), ("dest", dest)):
+        _chk(t, n)
+    R, T = est.shape
+    L.check(L.lib().ws_sisdr_bwd(_p(est), _p(tgt), _p(rowstat), _p(gout), R, T, _p(dest),
+                                 L.stream_ptr()), "ws_sisdr_bwd")
+
+
+def grad_norms(tab, ntensors, norms):
+    L.check(L.lib().ws_grad_norms(C.c_void_p(tab.data_ptr()), ntensors, _p(norms), L.stream_ptr()),
+            "ws_grad_norms")
+
+
+def clip_adam_step(tab, ntensors, norms, clip, lr, beta1, beta2, eps, weight_decay, step, clip_only=False):
+    L.check(L.lib().ws_clip_adam_step(C.c_void_p(tab.data_ptr()), ntensors, _p(norms), clip, lr, beta1,
+                                      beta2, eps, weight_decay, step, int(clip_only), L.stream_ptr()),
+            "ws_clip_adam_step")
+
+
+def prof_enable(on: bool):
+    L.check(L.lib().ws_prof_enable(int(on)), "ws_prof_enable")
+
+
+def prof_collect(kind: int):
+    ms = C.c_double(0.0)
+    n = C.c_longlong(0)
+    L.check(L.lib().ws_prof_collect(kind, C.byref(ms), C.byref(n)), "ws_prof_collect")
+    return ms.value, n.value

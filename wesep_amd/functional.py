@@ -1,0 +1,624 @@
+"""Autograd boundary of the pBSRNN hot path: torch.autograd.Function shims whose forward and
+backward are sequences of C-ABI launches (wesep_amd/dev.py).  PyTorch supplies device memory,
+the stream, and the autograd graph between these coarse ops (so DistributedDataParallel's
+bucket hooks fire on the registered Parameters); every FLOP runs in libwesep_hip.so.
+
+Activation layout everywhere: Z = [R, K, Tf, N] fp32 (see include/wesep_hip.h)."""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import dev
+from .dev import BIG, Geom, Rows, SeqMap, StatMap, flat
+
+H = L.LSTM_H          # LSTM hidden size the recurrent kernels are built for
+G4 = 4 * H
+NBIN = 257
+HOP = 128
+
+
+def _empty(dev_, *shape):
+    return torch.empty(*shape, device=dev_, dtype=torch.float32)
+
+
+def _need_cuda(t, who):
+    if not t.is_cuda:
+        raise L.WesepHipError(f"{who}: wesep_amd has no CPU path; move the model and inputs to the GPU")
+
+
+def _lstm_mtiles(nseq: int) -> int:
+    env = os.environ.get("WESEP_LSTM_MTILES")
+    return int(env) if env else 1
+
+
+def _reduce_new(slab, nsplit, stride, shape):
+    out = _empty(slab.device, *shape)
+    dev.reduce_slabs(slab, nsplit, stride, int(np.prod(shape)), out)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# ResRNN: GroupNorm -> BLSTM -> Linear -> +residual   (wesep/models/bsrnn.py:38-46)
+# ---------------------------------------------------------------------------------------------
+def _view_maps(view, R, K, Tf, N):
+    if view == "time":      # band_rnn: sequences (r,k), steps over t  (bsrnn.py:73-75)
+        geo = Geom(R * K, 1, Tf * N, 0, N, Tf, N)
+        smap = StatMap(Tf, 1, 1, 0, 0)
+        seq = SeqMap(R * K, BIG, 0, Tf, 1, Tf)
+        shift = (1, Tf)                     # (seq_div, seq_len) of the h_{t-1} row shift
+    elif view == "band":    # band_comm: sequences (r,t), steps over k  (bsrnn.py:78-81)
+        geo = Geom(R * Tf, Tf, K * Tf * N, N, Tf * N, K, N)
+        smap = StatMap(K * Tf, Tf, Tf, 1, 0)
+        seq = SeqMap(R * Tf, Tf, K * Tf, 1, Tf, K)
+        shift = (Tf, K)
+    else:
+        raise ValueError(view)
+    return geo, smap, seq, shift
+
+
+class ResRNNFn(torch.autograd.Function):
+    """inputs: z, view, norm.weight, norm.bias, weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0,
+    the four *_reverse tensors, proj.weight, proj.bias."""
+
+    @staticmethod
+    def forward(ctx, z, view, norm_w, norm_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r,
+                bhh_r, proj_w, proj_b):
+        _need_cuda(z, "ResRNN")
+        z = z.contiguous()
+        R, K, Tf, N = z.shape
+        if tuple(whh_f.shape) != (G4, H) or tuple(wih_f.shape) != (G4, N):
+            raise L.WesepHipError(f"ResRNN kernels are built for hidden {H}; got {tuple(whh_f.shape)}")
+        P = R * K * Tf
+        d = z.device
+        geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+        stats = _empty(d, geo.ngroups, 2)
+        dev.group_stats(z, geo, stats)
+        wcat, bcat = _empty(d, 2 * G4, N), _empty(d, 2 * G4)
+        dev.lstm_cat_ih(wih_f.contiguous(), wih_r.contiguous(), bih_f, bhh_f, bih_r, bhh_r, N, wcat, bcat)
+        pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
+        dev.lstm_pack(whh_f.contiguous(), whh_r.contiguous(), pack_f, pack_b)
+        gates = _empty(d, P, 2 * G4)
+        dev.gemm_nt(A=z, a_rows=flat(N), M=P, N=2 * G4, K=N, W=wcat, ldw=N, bias=bcat, C_out=gates,
+                    c_rows=flat(2 * G4), stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap)
+        cbuf, hcat = _empty(d, P, 2 * H), _empty(d, P, 2 * H)
+        mt = _lstm_mtiles(seq.nseq)
+        dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, mt)
+        out = torch.empty_like(z)
+        pw = proj_w.contiguous()
+        dev.gemm_nt(A=hcat, a_rows=flat(2 * H), M=P, N=N, K=2 * H, W=pw, ldw=2 * H, bias=proj_b,
+                    R=z, C_out=out, c_rows=flat(N))
+        ctx.save_for_backward(z, stats, gates, cbuf, hcat, wcat, pack_b, norm_w, norm_b, pw)
+        ctx.view, ctx.mt = view, mt
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, stats, gates, cbuf, hcat, wcat, pack_b, norm_w, norm_b, pw = ctx.saved_tensors
+        dout = dout.contiguous()
+        R, K, Tf, N = z.shape
+        P = R * K * Tf
+        d = z.device
+        geo, smap, seq, (seq_div, seq_len) = _view_maps(ctx.view, R, K, Tf, N)
+        nsplit, rps = dev.tn_splits(P)
+        # projection: data + weight gradients
+        projT = _empty(d, 2 * H, N)
+        dev.transpose(pw, N, 2 * H, 2 * H, projT)
+        dhcat = _empty(d, P, 2 * H)
+        dev.gemm_nt(A=dout, a_rows=flat(N), M=P, N=2 * H, K=N, W=projT, ldw=N, C_out=dhcat,
+                    c_rows=flat(2 * H))
+        slab, bslab = _empty(d, nsplit, N * 2 * H), _empty(d, nsplit, N)
+        dev.gemm_tn(G=dout, g_rows=flat(N), A=hcat, a_rows=flat(2 * H), M=P, Nn=N, Kk=2 * H, slab=slab,
+                    slab_stride=N * 2 * H, bslab=bslab, bslab_stride=N, nsplit=nsplit, rows_per_split=rps)
+        dproj_w = _reduce_new(slab, nsplit, N * 2 * H, (N, 2 * H))
+        dproj_b = _reduce_new(bslab, nsplit, N, (N,))
+        # BPTT: gates (activated) -> d(pre-activation gates), in place
+        dev.lstm_bwd(gates, cbuf, hcat, dhcat, pack_b, seq, ctx.mt)
+        del dhcat
+        # recurrent weight gradients: dW_hh[d] = dgates_d^T h_{t-1}
+        dwhh = []
+        slab = _empty(d, nsplit, G4 * H)
+        for di in (0, 1):
+            dev.gemm_tn(G=gates, g_rows=flat(2 * G4), g_off=di * G4, A=hcat, a_rows=flat(2 * H),
+                        a_off=di * H, M=P, Nn=G4, Kk=H, slab=slab, slab_stride=G4 * H, nsplit=nsplit,
+                        rows_per_split=rps, shift_rows=(-seq.step_rows if di == 0 else seq.step_rows),
+                        seq_div=seq_div, seq_len=seq_len)
+            dwhh.append(_reduce_new(slab, nsplit, G4 * H, (G4, H)))
+        # input weight / bias gradients against the re-normalised input
+        slab, bslab = _empty(d, nsplit, 2 * G4 * N), _empty(d, nsplit, 2 * G4)
+        dev.gemm_tn(G=gates, g_rows=flat(2 * G4), A=z, a_rows=flat(N), M=P, Nn=2 * G4, Kk=N, slab=slab,
+                    slab_stride=2 * G4 * N, bslab=bslab, bslab_stride=2 * G4, nsplit=nsplit,
+                    rows_per_split=rps, stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap)
+        dwcat = _reduce_new(slab, nsplit, 2 * G4 * N, (2 * G4, N))
+        dbcat = _reduce_new(bslab, nsplit, 2 * G4, (2 * G4,))
+        del slab, bslab
+        # d(normalised input) -> GroupNorm backward (+ residual path)
+        wcatT = _empty(d, N, 2 * G4)
+        dev.transpose(wcat, 2 * G4, N, N, wcatT)
+        dxn = _empty(d, P, N)
+        dev.gemm_nt(A=gates, a_rows=flat(2 * G4), M=P, N=N, K=2 * G4, W=wcatT, ldw=2 * G4, C_out=dxn,
+                    c_rows=flat(N))
+        ab = _empty(d, geo.ngroups, 2)
+        dev.gn_bwd_reduce(z, dxn, stats, geo, ab, gamma=norm_w)
+        ns2 = min(256, geo.ngroups)
+        pslab = _empty(d, ns2, 2, N)
+        dev.gn_param_grad(z, dxn, stats, geo, ns2, pslab)
+        dgb = _reduce_new(pslab, ns2, 2 * N, (2, N))
+        dz = torch.empty_like(z)
+        dev.gn_bwd_apply(z, dxn, stats, ab, geo, dz, gamma=norm_w, res=dout)
+        # b_ih and b_hh receive the same gradient; clone so their .grad never alias
+        return (dz, None, dgb[0], dgb[1],
+                dwcat[:G4], dwhh[0], dbcat[:G4], dbcat[:G4].clone(),
+                dwcat[G4:], dwhh[1], dbcat[G4:], dbcat[G4:].clone(),
+                dproj_w, dproj_b)
+
+
+# ---------------------------------------------------------------------------------------------
+# small dense layers on [R, *] (speaker embedding side): y = x W^T + b
+# ---------------------------------------------------------------------------------------------
+def _w2d(w):
+    return w.reshape(w.shape[0], -1).contiguous()
+
+
+def _lin_fwd(x, W, b, act=0, w_off=0, ldw=None, K=None):
+    M = x.shape[0]
+    Nout = W.shape[0]
+    K = K if K is not None else W.shape[1]
+    ldw = ldw if ldw is not None else W.shape[1]
+    y = _empty(x.device, M, Nout)
+    vec = 3 if (K % 4 == 0 and ldw % 4 == 0 and w_off % 4 == 0 and x.shape[1] % 4 == 0) else 0
+    dev.gemm_nt(A=x, a_rows=flat(x.shape[1]), M=M, N=Nout, K=K, W=W, ldw=ldw, bias=b, C_out=y,
+                c_rows=flat(Nout), act=act, vec=vec, w_off=w_off)
+    return y
+
+
+def _lin_bwd_w(dy, x, with_bias=True):
+    """dW [Nout, K] = dy^T x, db = colsum(dy); single split (M = R is tiny)."""
+    M, Nout = dy.shape
+    K = x.shape[1]
+    rps = -(-M // 32) * 32
+    dW = _empty(dy.device, Nout, K)
+    db = _empty(dy.device, Nout) if with_bias else None
+    dev.gemm_tn(G=dy, g_rows=flat(Nout), A=x, a_rows=flat(K), M=M, Nn=Nout, Kk=K, slab=dW,
+                slab_stride=Nout * K, bslab=db, bslab_stride=Nout, nsplit=1, rows_per_split=rps,
+                vec=1 if K % 4 == 0 else 0)
+    return dW, db
+
+
+def _lin_bwd_x(dy, W, T=None, src_off=0, rows=None, cols=None, lds=None):
+    """dx = dy W (optionally * (1 - T^2)); W [rows, cols] with leading dim lds."""
+    rows = rows if rows is not None else W.shape[0]
+    cols = cols if cols is not None else W.shape[1]
+    lds = lds if lds is not None else W.shape[1]
+    WT = _empty(dy.device, cols, rows)
+    dev.transpose(W, rows, cols, lds, WT, src_off=src_off)
+    dx = _empty(dy.device, dy.shape[0], cols)
+    vec = 3 if rows % 4 == 0 else 0
+    dev.gemm_nt(A=dy, a_rows=flat(rows), M=dy.shape[0], N=cols, K=rows, W=WT, ldw=rows, C_out=dx,
+                c_rows=flat(cols), T=T, vec=vec)
+    return dx
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b):
+        _need_cuda(x, "Linear")
+        x, W2 = x.contiguous(), _w2d(W)
+        ctx.save_for_backward(x, W2)
+        ctx.wshape = W.shape
+        return _lin_fwd(x, W2, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dW, db = _lin_bwd_w(dy, x)
+        dx = _lin_bwd_x(dy, W2) if ctx.needs_input_grad[0] else None
+        return dx, dW.view(ctx.wshape), db
+
+
+class SpkTransformFn(torch.autograd.Function):
+    """SpeakerTransform (speaker.py:26-49): Conv1d(k=1) 256->128, 128->128 + Tanh, 128->256."""
+
+    @staticmethod
+    def forward(ctx, e, w0, b0, w1, b1, w3, b3):
+        _need_cuda(e, "SpeakerTransform")
+        e = e.contiguous()
+        W0, W1, W3 = _w2d(w0), _w2d(w1), _w2d(w3)
+        h0 = _lin_fwd(e, W0, b0)
+        h1 = _lin_fwd(h0, W1, b1, act=1)
+        y = _lin_fwd(h1, W3, b3)
+        ctx.save_for_backward(e, h0, h1, W0, W1, W3)
+        ctx.shapes = (w0.shape, w1.shape, w3.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        e, h0, h1, W0, W1, W3 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dW3, db3 = _lin_bwd_w(dy, h1)
+        dp1 = _lin_bwd_x(dy, W3, T=h1)           # d(pre-tanh) of layer 1
+        dW1, db1 = _lin_bwd_w(dp1, h0)
+        dh0 = _lin_bwd_x(dp1, W1)
+        dW0, db0 = _lin_bwd_w(dh0, e)
+        de = _lin_bwd_x(dh0, W0) if ctx.needs_input_grad[0] else None
+        s0, s1, s3 = ctx.shapes
+        return de, dW0.view(s0), db0, dW1.view(s1), db1, dW3.view(s3), db3
+
+
+# ---------------------------------------------------------------------------------------------
+# speaker fusion on Z: out = z * (a0 + a[r]) + b[r]      (speaker.py:81-125, norm.py:118-139)
+# ---------------------------------------------------------------------------------------------
+def _affine_splits(rows_per_r):
+    return max(1, min(64, rows_per_r // 256))
+
+
+class AffineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, a, b, a0):
+        _need_cuda(z, "SpeakerFuse")
+        z = z.contiguous()
+        R, K, Tf, N = z.shape
+        a = a.contiguous() if a is not None else None
+        b = b.contiguous() if b is not None else None
+        out = torch.empty_like(z)
+        dev.affine_fwd(z, a, b, a0, R * K * Tf, K * Tf, N, out)
+        ctx.save_for_backward(z, a)
+        ctx.a0, ctx.has_b = a0, b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, a = ctx.saved_tensors
+        dout = dout.contiguous()
+        R, K, Tf, N = z.shape
+        ns = _affine_splits(K * Tf)
+        da_slab = _empty(z.device, ns, R, N) if a is not None else None
+        db_slab = _empty(z.device, ns, R, N) if ctx.has_b else None
+        dz = torch.empty_like(z)
+        dev.affine_bwd(dout, z, a, ctx.a0, R * K * Tf, K * Tf, N, ns, dz, da_slab, db_slab)
+        da = _reduce_new(da_slab, ns, R * N, (R, N)) if a is not None else None
+        db = _reduce_new(db_slab, ns, R * N, (R, N)) if ctx.has_b else None
+        return dz, da, db, None
+
+
+class ConcatFuseFn(torch.autograd.Function):
+    """SpeakerFuseLayer 'concat' (speaker.py:90-102): Linear(cat[x, e]) = x Wx^T + (e We^T + b)."""
+
+    @staticmethod
+    def forward(ctx, z, e, W, b):
+        _need_cuda(z, "SpeakerFuse(concat)")
+        z, e, W = z.contiguous(), e.contiguous(), W.contiguous()
+        R, K, Tf, N = z.shape
+        E = e.shape[1]
+        P = R * K * Tf
+        c = _lin_fwd(e, W, b, w_off=N, ldw=N + E, K=E)                     # [R, N]
+        out = torch.empty_like(z)
+        dev.gemm_nt(A=z, a_rows=flat(N), M=P, N=N, K=N, W=W, ldw=N + E, C_out=out, c_rows=flat(N))
+        dev.affine_fwd(out, None, c, 1.0, P, K * Tf, N, out)
+        ctx.save_for_backward(z, e, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, e, W = ctx.saved_tensors
+        dout = dout.contiguous()
+        R, K, Tf, N = z.shape
+        E = e.shape[1]
+        P = R * K * Tf
+        d = z.device
+        ns = _affine_splits(K * Tf)
+        dc_slab = _empty(d, ns, R, N)
+        dev.affine_bwd(dout, None, None, 1.0, P, K * Tf, N, ns, None, None, dc_slab)
+        dc = _reduce_new(dc_slab, ns, R * N, (R, N))
+        dW = _empty(d, N, N + E)
+        # dWx = dout^T z  -> columns [0, N)
+        nsplit, rps = dev.tn_splits(P)
+        slab = _empty(d, nsplit, N * N)
+        dev.gemm_tn(G=dout, g_rows=flat(N), A=z, a_rows=flat(N), M=P, Nn=N, Kk=N, slab=slab,
+                    slab_stride=N * N, nsplit=nsplit, rows_per_split=rps)
+        dev.reduce_slabs(slab, nsplit, N * N, N * N, dW, w=N, ldo=N + E)
+        # dWe = dc^T e -> columns [N, N+E);  db = colsum(dc)
+        dWe, db = _lin_bwd_w(dc, e)
+        dev.reduce_slabs(dWe, 1, N * E, N * E, dW, w=E, ldo=N + E, out_off=N)
+        dz = _empty(d, R, K, Tf, N)
+        WxT = _empty(d, N, N)
+        dev.transpose(W, N, N, N + E, WxT)
+        dev.gemm_nt(A=dout, a_rows=flat(N), M=P, N=N, K=N, W=WxT, ldw=N, C_out=dz, c_rows=flat(N))
+        de = _lin_bwd_x(dc, W, src_off=N, rows=N, cols=E, lds=N + E) if ctx.needs_input_grad[1] else None
+        return dz, de, dW, db
+
+
+# ---------------------------------------------------------------------------------------------
+# per-band plans: device descriptor tables for the grouped (32-band) launches
+# ---------------------------------------------------------------------------------------------
+class BandPlan:
+    """Band tables + cached group descriptors for BN[i] (bsrnn.py:252-258) and mask[i]
+    (bsrnn.py:271-282).  Descriptors hold parameter pointers, so they are rebuilt only when a
+    parameter's storage moves (e.g. .cuda(), load of a new module) or the batch geometry changes."""
+
+    def __init__(self, band_width, feature_dim, device):
+        self.dev = device
+        self.bands = dev.BandTables(band_width, device)
+        self.bw = [int(b) for b in band_width]
+        self.f0 = [int(f) for f in self.bands.f0_host]
+        self.K = len(self.bw)
+        self.N = feature_dim
+        N = feature_dim
+        H1 = 4 * N
+        # flat-gradient offsets
+        self.bn_woff = np.concatenate([[0], np.cumsum([N * 2 * b for b in self.bw])]).astype(np.int64)
+        self.m_w3off = np.concatenate([[0], np.cumsum([4 * b * H1 for b in self.bw])]).astype(np.int64)
+        self.m_b3off = np.concatenate([[0], np.cumsum([4 * b for b in self.bw])]).astype(np.int64)
+        # persistent transposed-weight workspaces (descriptors point into them)
+        self.bn_wT = _empty(device, int(self.bn_woff[-1]))
+        self.m_w1T = _empty(device, self.K * N * H1)
+        self.m_w2T = _empty(device, self.K * H1 * H1)
+        self.m_w3T = _empty(device, int(self.m_w3off[-1]))
+        self._cache = {}
+
+    def _up(self, arr):
+        return L.upload_struct_array(arr, self.dev)
+
+    def _key(self, params, R, Tf):
+        return (R, Tf) + tuple(p.data_ptr() for p in params)
+
+    # ---- BN ------------------------------------------------------------------------------
+    def bn_desc(self, params, R, Tf):
+        key = ("bn",) + self._key(params, R, Tf)
+        if key not in self._cache:
+            K, N = self.K, self.N
+            nt = np.zeros(K, dtype=L.GROUP_NT_DTYPE)
+            tn = np.zeros(K, dtype=L.GROUP_TN_DTYPE)
+            dx = np.zeros(K, dtype=L.GROUP_NT_DTYPE)
+            for g in range(K):
+                gw, gb, cw, cb = params[4 * g:4 * g + 4]
+                bw2 = 2 * self.bw[g]
+                nt[g] = (cw.data_ptr(), cb.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                         2 * self.f0[g], g * Tf * N, g, bw2, N, bw2, 0)
+                tn[g] = (gw.data_ptr(), gb.data_ptr(), g * Tf * N, 2 * self.f0[g], g,
+                         int(self.bn_woff[g]), g * N, N, bw2, 0, 0)
+                dx[g] = (self.bn_wT.data_ptr() + 4 * int(self.bn_woff[g]), 0, 0, 0,
+                         g * Tf * N, 2 * self.f0[g], 0, N, bw2, N, 0)
+            self._cache = {k: v for k, v in self._cache.items() if k[0] != "bn"}
+            self._cache[key] = (self._up(nt), self._up(tn), self._up(dx))
+        return self._cache[key]
+
+    # ---- mask ----------------------------------------------------------------------------
+    def mask_desc(self, params, R, Tf):
+        key = ("mask",) + self._key(params, R, Tf)
+        if key not in self._cache:
+            K, N = self.K, self.N
+            H1 = 4 * N
+            M = R * Tf
+            d = {n: np.zeros(K, dtype=L.GROUP_NT_DTYPE) for n in ("l1", "l2", "l3", "dh2", "dh1", "dxn")}
+            t = {n: np.zeros(K, dtype=L.GROUP_TN_DTYPE) for n in ("w3", "w2", "w1")}
+            gtab = np.zeros(K, dtype=np.uint64)
+            for g in range(K):
+                gw, gb, w1, b1, w2, b2, w3, b3 = params[8 * g:8 * g + 8]
+                bw4 = 4 * self.bw[g]
+                hoff = g * M * H1
+                zoff = g * Tf * N
+                gtab[g] = gw.data_ptr()
+                d["l1"][g] = (w1.data_ptr(), b1.data_ptr(), gw.data_ptr(), gb.data_ptr(), zoff, hoff, g, N, H1, N, 0)
+                d["l2"][g] = (w2.data_ptr(), b2.data_ptr(), 0, 0, hoff, hoff, 0, H1, H1, H1, 0)
+                d["l3"][g] = (w3.data_ptr(), b3.data_ptr(), 0, 0, hoff, 4 * self.f0[g], 0, H1, bw4, H1, 0)
+                d["dh2"][g] = (self.m_w3T.data_ptr() + 4 * int(self.m_w3off[g]), 0, 0, 0,
+                               4 * self.f0[g], hoff, 0, bw4, H1, bw4, 0)
+                d["dh1"][g] = (self.m_w2T.data_ptr() + 4 * g * H1 * H1, 0, 0, 0, hoff, hoff, 0, H1, H1, H1, 0)
+                d["dxn"][g] = (self.m_w1T.data_ptr() + 4 * g * N * H1, 0, 0, 0, hoff, zoff, 0, H1, N, H1, 0)
+                t["w3"][g] = (0, 0, 4 * self.f0[g], hoff, 0, int(self.m_w3off[g]), int(self.m_b3off[g]), bw4, H1, 0, 0)
+                t["w2"][g] = (0, 0, hoff, hoff, 0, g * H1 * H1, g * H1, H1, H1, 0, 0)
+                t["w1"][g] = (gw.data_ptr(), gb.data_ptr(), hoff, zoff, g, g * H1 * N, g * H1, H1, N, 0, 0)
+            self._cache = {k: v for k, v in self._cache.items() if k[0] != "mask"}
+            out = {k: self._up(v) for k, v in d.items()}
+            out.update({"t" + k: self._up(v) for k, v in t.items()})
+            out["gamma_tab"] = torch.from_numpy(gtab.view(np.int64)).to(self.dev)
+            self._cache[key] = out
+        return self._cache[key]
+
+
+# ---------------------------------------------------------------------------------------------
+# STFT + band split + per-band GroupNorm + 1x1 conv     (bsrnn.py:309-336)
+# ---------------------------------------------------------------------------------------------
+class BandSplitFn(torch.autograd.Function):
+    """inputs: wav [R, T], plan, then per band (gn.weight, gn.bias, conv.weight, conv.bias).
+    outputs: z0 [R, K, Tf, N], xbs [R*Tf, 2F] (band-split mixture spectrogram, no grad)."""
+
+    @staticmethod
+    def forward(ctx, wav, plan, *params):
+        _need_cuda(wav, "BSRNN")
+        wav = wav.contiguous()
+        R, T = wav.shape
+        K, N = plan.K, plan.N
+        Tf = 1 + T // HOP
+        M = R * Tf
+        d = wav.device
+        xbs = _empty(d, M, 2 * NBIN)
+        dev.stft_bandsplit(wav, plan.bands, xbs)
+        geo = Geom(R * K, K, Tf * 2 * NBIN, 0, 2 * NBIN, Tf, 128, K, plan.bands.bw2, plan.bands.off2)
+        stats = _empty(d, R * K, 2)
+        dev.group_stats(xbs, geo, stats)
+        nt, _, _ = plan.bn_desc(params, R, Tf)
+        z0 = _empty(d, R, K, Tf, N)
+        dev.gemm_nt(A=xbs, a_rows=flat(2 * NBIN), M=M, C_out=z0, c_rows=Rows(Tf, K * Tf * N, N),
+                    stats=stats, stat_map=StatMap(Tf, K, 1, 0, 0), groups=nt, ngroups=K, max_n=N, vec=0)
+        ctx.save_for_backward(xbs, stats, *params)
+        ctx.plan, ctx.dims = plan, (R, T, Tf)
+        ctx.mark_non_differentiable(xbs)
+        return z0, xbs
+
+    @staticmethod
+    def backward(ctx, dz0, _dxbs):
+        xbs, stats = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        plan = ctx.plan
+        R, T, Tf = ctx.dims
+        K, N = plan.K, plan.N
+        M = R * Tf
+        d = xbs.device
+        dz0 = dz0.contiguous()
+        _, tn, dxd = plan.bn_desc(params, R, Tf)
+        geo = Geom(R * K, K, Tf * 2 * NBIN, 0, 2 * NBIN, Tf, 128, K, plan.bands.bw2, plan.bands.off2)
+        smap = StatMap(Tf, K, 1, 0, 0)
+        # conv weight / bias gradients (A = re-normalised band spectrogram)
+        nsplit, rps = dev.tn_splits(M)
+        wtot = int(plan.bn_woff[-1])
+        slab, bslab = _empty(d, nsplit, wtot), _empty(d, nsplit, K * N)
+        dev.gemm_tn(G=dz0, g_rows=Rows(Tf, K * Tf * N, N), A=xbs, a_rows=flat(2 * NBIN), M=M, slab=slab,
+                    slab_stride=wtot, bslab=bslab, bslab_stride=K * N, nsplit=nsplit, rows_per_split=rps,
+                    stats=stats, stat_map=smap, groups=tn, ngroups=K, max_n=N, max_k=128, vec=0)
+        dW = _reduce_new(slab, nsplit, wtot, (wtot,))
+        dB = _reduce_new(bslab, nsplit, K * N, (K * N,))
+        # d(normalised spectrogram) -> GroupNorm affine gradients (dX itself is never needed)
+        for g in range(K):
+            bw2 = 2 * plan.bw[g]
+            dev.transpose(params[4 * g + 2].reshape(N, bw2), N, bw2, bw2, plan.bn_wT,
+                          dst_off=int(plan.bn_woff[g]))
+        dxn = _empty(d, M, 2 * NBIN)
+        dev.gemm_nt(A=dz0, a_rows=Rows(Tf, K * Tf * N, N), M=M, C_out=dxn, c_rows=flat(2 * NBIN),
+                    groups=dxd, ngroups=K, max_n=128, vec=3)
+        ns2 = min(64, R)
+        pslab = _empty(d, ns2, K, 2, 128)
+        dev.gn_param_grad(xbs, dxn, stats, geo, ns2, pslab)
+        dgb = _reduce_new(pslab, ns2, K * 2 * 128, (K, 2, 128))
+        grads = []
+        for g in range(K):
+            bw2 = 2 * plan.bw[g]
+            o = int(plan.bn_woff[g])
+            grads += [dgb[g, 0, :bw2], dgb[g, 1, :bw2], dW[o:o + N * bw2].view(N, bw2, 1), dB[g * N:(g + 1) * N]]
+        return (None, None) + tuple(grads)
+
+
+# ---------------------------------------------------------------------------------------------
+# mask MLP + GLU complex mask + iSTFT     (bsrnn.py:366-389)
+# ---------------------------------------------------------------------------------------------
+class MaskDecodeFn(torch.autograd.Function):
+    """inputs: z [R,K,Tf,N], xbs, plan, T, then per band (gn.w, gn.b, w1, b1, w2, b2, w3, b3).
+    output: est [R, T]."""
+
+    @staticmethod
+    def forward(ctx, z, xbs, plan, T, *params):
+        _need_cuda(z, "BSRNN")
+        z = z.contiguous()
+        R, K, Tf, N = z.shape
+        H1 = 4 * N
+        M = R * Tf
+        d = z.device
+        D = plan.mask_desc(params, R, Tf)
+        geo = Geom(R * K, 1, Tf * N, 0, N, Tf, N, K)
+        stats = _empty(d, R * K, 2)
+        dev.group_stats(z, geo, stats)
+        h1, h2 = _empty(d, K, M, H1), _empty(d, K, M, H1)
+        dev.gemm_nt(A=z, a_rows=Rows(Tf, K * Tf * N, N), M=M, C_out=h1, c_rows=flat(H1), stats=stats,
+                    stat_map=StatMap(Tf, K, 1, 0, 0), act=1, groups=D["l1"], ngroups=K, max_n=H1)
+        dev.gemm_nt(A=h1, a_rows=flat(H1), M=M, C_out=h2, c_rows=flat(H1), act=1, groups=D["l2"],
+                    ngroups=K, max_n=H1)
+        m3 = _empty(d, M, 4 * NBIN)
+        dev.gemm_nt(A=h2, a_rows=flat(H1), M=M, C_out=m3, c_rows=flat(4 * NBIN), groups=D["l3"],
+                    ngroups=K, max_n=4 * max(plan.bw))
+        frames = _empty(d, M, 512)
+        dev.mask_istft_frames(xbs, m3, R, Tf, plan.bands, frames)
+        est = _empty(d, R, T)
+        dev.istft_ola(frames, R, Tf, T, est)
+        ctx.save_for_backward(z, xbs, stats, h1, h2, m3, *params)
+        ctx.plan, ctx.T = plan, T
+        return est
+
+    @staticmethod
+    def backward(ctx, dest):
+        z, xbs, stats, h1, h2, m3 = ctx.saved_tensors[:6]
+        params = ctx.saved_tensors[6:]
+        plan, T = ctx.plan, ctx.T
+        R, K, Tf, N = z.shape
+        H1 = 4 * N
+        M = R * Tf
+        d = z.device
+        D = plan.mask_desc(params, R, Tf)
+        dest = dest.contiguous()
+        dm3 = _empty(d, M, 4 * NBIN)
+        dev.mask_istft_bwd(dest, xbs, m3, R, Tf, T, plan.bands, dm3)
+        nsplit, rps = dev.tn_splits(M)
+        maxb4 = 4 * max(plan.bw)
+        # layer 3
+        w3tot, b3tot = int(plan.m_w3off[-1]), int(plan.m_b3off[-1])
+        slab, bslab = _empty(d, nsplit, w3tot), _empty(d, nsplit, b3tot)
+        dev.gemm_tn(G=dm3, g_rows=flat(4 * NBIN), A=h2, a_rows=flat(H1), M=M, slab=slab, slab_stride=w3tot,
+                    bslab=bslab, bslab_stride=b3tot, nsplit=nsplit, rows_per_split=rps, groups=D["tw3"],
+                    ngroups=K, max_n=maxb4, max_k=H1)
+        dW3 = _reduce_new(slab, nsplit, w3tot, (w3tot,))
+        dB3 = _reduce_new(bslab, nsplit, b3tot, (b3tot,))
+        for g in range(K):
+            bw4 = 4 * plan.bw[g]
+            dev.transpose(params[8 * g + 6].reshape(bw4, H1), bw4, H1, H1, plan.m_w3T,
+                          dst_off=int(plan.m_w3off[g]))
+            dev.transpose(params[8 * g + 4].reshape(H1, H1), H1, H1, H1, plan.m_w2T, dst_off=g * H1 * H1)
+            dev.transpose(params[8 * g + 2].reshape(H1, N), H1, N, N, plan.m_w1T, dst_off=g * N * H1)
+        dh2 = _empty(d, K, M, H1)
+        dev.gemm_nt(A=dm3, a_rows=flat(4 * NBIN), M=M, C_out=dh2, c_rows=flat(H1), T=h2, groups=D["dh2"],
+                    ngroups=K, max_n=H1)
+        # layer 2
+        slab, bslab = _empty(d, nsplit, K * H1 * H1), _empty(d, nsplit, K * H1)
+        dev.gemm_tn(G=dh2, g_rows=flat(H1), A=h1, a_rows=flat(H1), M=M, slab=slab, slab_stride=K * H1 * H1,
+                    bslab=bslab, bslab_stride=K * H1, nsplit=nsplit, rows_per_split=rps, groups=D["tw2"],
+                    ngroups=K, max_n=H1, max_k=H1)
+        dW2 = _reduce_new(slab, nsplit, K * H1 * H1, (K, H1, H1, 1))
+        dB2 = _reduce_new(bslab, nsplit, K * H1, (K, H1))
+        dh1 = _empty(d, K, M, H1)
+        dev.gemm_nt(A=dh2, a_rows=flat(H1), M=M, C_out=dh1, c_rows=flat(H1), T=h1, groups=D["dh1"],
+                    ngroups=K, max_n=H1)
+        del dh2
+        # layer 1 (A = re-normalised z band rows)
+        slab, bslab = _empty(d, nsplit, K * H1 * N), _empty(d, nsplit, K * H1)
+        dev.gemm_tn(G=dh1, g_rows=flat(H1), A=z, a_rows=Rows(Tf, K * Tf * N, N), M=M, slab=slab,
+                    slab_stride=K * H1 * N, bslab=bslab, bslab_stride=K * H1, nsplit=nsplit,
+                    rows_per_split=rps, stats=stats, stat_map=StatMap(Tf, K, 1, 0, 0), groups=D["tw1"],
+                    ngroups=K, max_n=H1, max_k=N)
+        dW1 = _reduce_new(slab, nsplit, K * H1 * N, (K, H1, N, 1))
+        dB1 = _reduce_new(bslab, nsplit, K * H1, (K, H1))
+        del slab, bslab
+        dxn = _empty(d, R, K, Tf, N)
+        dev.gemm_nt(A=dh1, a_rows=flat(H1), M=M, C_out=dxn, c_rows=Rows(Tf, K * Tf * N, N), groups=D["dxn"],
+                    ngroups=K, max_n=N)
+        del dh1
+        # GroupNorm backward with per-band gamma
+        geo = Geom(R * K, 1, Tf * N, 0, N, Tf, N, K)
+        ab = _empty(d, R * K, 2)
+        dev.gn_bwd_reduce(z, dxn, stats, geo, ab, gamma_tab=D["gamma_tab"])
+        ns2 = min(64, R)
+        pslab = _empty(d, ns2, K, 2, N)
+        dev.gn_param_grad(z, dxn, stats, geo, ns2, pslab)
+        dgb = _reduce_new(pslab, ns2, K * 2 * N, (K, 2, N))
+        dz = torch.empty_like(z)
+        dev.gn_bwd_apply(z, dxn, stats, ab, geo, dz, gamma_tab=D["gamma_tab"])
+        grads = []
+        for g in range(K):
+            bw4 = 4 * plan.bw[g]
+            o3, ob3 = int(plan.m_w3off[g]), int(plan.m_b3off[g])
+            grads += [dgb[g, 0], dgb[g, 1], dW1[g], dB1[g], dW2[g], dB2[g],
+                      dW3[o3:o3 + bw4 * H1].view(bw4, H1, 1), dB3[ob3:ob3 + bw4]]
+        return (dz, None, None, None) + tuple(grads)
+
+
+# ---------------------------------------------------------------------------------------------
+# SI-SDR loss (auraloss.time.SISDRLoss, losses.py:24-25)
+# ---------------------------------------------------------------------------------------------
+class SISDRFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, est, tgt, eps):
+        _need_cuda(est, "SISDRLoss")
+        est, tgt = est.contiguous().float(), tgt.contiguous().float()
+        R = est.shape[0]
+        rowstat = _empty(est.device, R, 8)
+        loss = _empty(est.device, 1)
+        dev.sisdr_fwd(est, tgt, rowstat, loss, eps)
+        ctx.save_for_backward(est, tgt, rowstat)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        est, tgt, rowstat = ctx.saved_tensors
+        dest = torch.empty_like(est)
+        dev.sisdr_bwd(est, tgt, rowstat, gout.contiguous().view(1).float(), dest)
+        return dest, None, None

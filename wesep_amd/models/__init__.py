@@ -1,0 +1,13 @@
+"""Model factory with the reference's contract (wesep/models/__init__.py:10-27)."""
+from . import bsrnn
+
+
+def get_model(model_name: str):
+    if model_name.startswith(("BSRNN_Multi", "BSRNN_Feats")):
+        raise NotImplementedError(f"{model_name}: research variant outside the built hot path (SURVEY.md section 8)")
+    if model_name.startswith("BSRNN"):
+        return getattr(bsrnn, model_name)
+    if model_name.startswith(("ConvTasNet", "DPCCN", "TFGridNet")):
+        raise NotImplementedError(f"{model_name}: SURVEY.md section 8 rows a15-a17, not built in this round")
+    print(model_name + " not found !!!")
+    exit(1)

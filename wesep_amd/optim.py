@@ -1,0 +1,93 @@
+"""Per-tensor gradient clip + Adam (coupled L2) as two multi-tensor HIP launches.
+
+Reference semantics reproduced exactly: `clip_gradients` clips EACH parameter tensor by its
+own L2 norm with eps 1e-6 (wesep/utils/funcs.py:79-88, ~640 `.item()` host syncs per step in
+the reference, zero here) and torch.optim.Adam(weight_decay=wd) adds wd*p to the gradient
+(wesep/bin/train.py:237-238).  State keys (`step`, `exp_avg`, `exp_avg_sq`) match
+torch.optim.Adam so optimizer checkpoints interchange (wesep/utils/checkpoint.py)."""
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import dev
+
+
+def _table(refs, device):
+    arr = np.zeros(len(refs), dtype=L.TENSOR_REF_DTYPE)
+    for i, (p, g, m, v) in enumerate(refs):
+        arr[i] = (p.data_ptr(), g.data_ptr() if g is not None else 0,
+                  m.data_ptr() if m is not None else 0, v.data_ptr() if v is not None else 0, p.numel())
+    return L.upload_struct_array(arr, device)
+
+
+def clip_gradients(model, clip):
+    """Drop-in for `wesep.utils.funcs.clip_gradients`: clips in place, returns the list of
+    per-parameter norms (one device->host copy for all of them)."""
+    ps = [p for _, p in model.named_parameters() if p.grad is not None]
+    if not ps:
+        return []
+    device = ps[0].device
+    for p in ps:
+        if not (p.is_cuda and p.grad.is_contiguous() and p.grad.dtype == torch.float32):
+            raise L.WesepHipError("clip_gradients: fp32 contiguous CUDA gradients required")
+    tab = _table([(p, p.grad, None, None) for p in ps], device)
+    norms = torch.empty(len(ps), device=device, dtype=torch.float32)
+    dev.grad_norms(tab, len(ps), norms)
+    dev.clip_adam_step(tab, len(ps), norms, float(clip), 0.0, 0.9, 0.999, 1e-8, 0.0, 1, clip_only=True)
+    return norms.tolist()
+
+
+class FusedClipAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad=0.0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_grad=clip_grad)
+        super().__init__(params, defaults)
+        self._norms = None
+        self._norm_params = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._norms, self._norm_params = [], []
+        for group in self.param_groups:
+            refs = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise L.WesepHipError("FusedClipAdam: parameters must live on the GPU (no CPU path)")
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = int(st["step"]) + 1
+                refs.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"]))
+            if not refs:
+                continue
+            steps = {int(self.state[r[0]]["step"]) for r in refs}
+            if len(steps) != 1:
+                raise L.WesepHipError("FusedClipAdam: parameters of one group must share the step count")
+            device = refs[0][0].device
+            tab = _table(refs, device)
+            clip = float(group["clip_grad"])
+            norms = None
+            if clip > 0:
+                norms = torch.empty(len(refs), device=device, dtype=torch.float32)
+                dev.grad_norms(tab, len(refs), norms)
+                self._norms.append(norms)
+                self._norm_params += [r[0] for r in refs]
+            b1, b2 = group["betas"]
+            dev.clip_adam_step(tab, len(refs), norms, clip, float(group["lr"]), b1, b2, group["eps"],
+                               group["weight_decay"], steps.pop())
+        return loss
+
+    def last_grad_norms(self):
+        """Per-parameter gradient norms of the last step (syncs)."""
+        if not self._norms:
+            return []
+        return torch.cat(self._norms).tolist()

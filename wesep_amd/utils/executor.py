@@ -1,0 +1,117 @@
+"""Train / validation step loop with the reference's `Executor` interface
+(wesep/utils/executor.py:27-203) for the pBSRNN hot path on MI355X.
+
+Same call signature, same loss composition (`se_loss_weight = (positions, weights)`), same
+lr-before-step ordering and same return value `(mean_loss, 0)`.  Host-side differences, all
+invisible to the caller: the batch is moved with non-blocking copies; the per-step
+`loss.item()` (executor.py:124) is replaced by a device-side running sum that is read only
+when a log row is due and at the end of the epoch; per-tensor clipping + Adam are two
+multi-tensor launches when the optimizer is `FusedClipAdam` (no per-parameter host syncs).
+The SSA self-enrollment branch (executor.py:89-100) needs the fbank front-end (SURVEY.md
+section 8f-2) and raises until that row is built."""
+from contextlib import nullcontext
+
+import torch
+
+from ..optim import FusedClipAdam, clip_gradients
+
+
+def _row(*cells):
+    return " | ".join(f"{c:>10}" if not isinstance(c, float) else f"{c:10.4g}" for c in cells)
+
+
+class Executor:
+    def __init__(self):
+        self.step = 0
+
+    @staticmethod
+    def _to_device(batch, device):
+        mv = lambda t: t.float().to(device, non_blocking=True)
+        spk = batch.get("spk_label")
+        if isinstance(spk, torch.Tensor):
+            spk = spk.to(device, non_blocking=True)
+        return mv(batch["wav_mix"]), mv(batch["wav_targets"]), mv(batch["spk_embeds"]), spk
+
+    @staticmethod
+    def _loss(outputs, targets, spk_label, criterion, se_loss_weight, multi_task):
+        if not isinstance(outputs, (list, tuple)):
+            outputs = [outputs]
+        if not isinstance(se_loss_weight, (list, tuple)):   # reference default 1.0: one loss on output 0
+            se_loss_weight = ([[0]] * len(criterion), [[float(se_loss_weight)]] * len(criterion))
+        positions, weights = se_loss_weight
+        loss = 0
+        for ii, crit in enumerate(criterion):
+            is_ce = multi_task and crit.__class__.__name__ == "CrossEntropyLoss"
+            for ji, pos in enumerate(positions[ii]):
+                ref = spk_label if is_ce else targets
+                loss = loss + weights[ii][ji] * crit(outputs[pos], ref).mean()
+        return loss
+
+    def train(self, dataloader, models, epoch_iter, optimizers, criterion, schedulers, scaler, epoch,
+              enable_amp, logger, clip_grad=5.0, log_batch_interval=100, device=torch.device("cuda"),
+              se_loss_weight=1.0, multi_task=False, SSA_enroll_prob=0, fbank_args=None,
+              sample_rate=16000, speaker_feat=True):
+        """Train one epoch."""
+        if enable_amp:
+            raise NotImplementedError("enable_amp: the HIP path computes in fp32 (all shipped configs use False)")
+        if SSA_enroll_prob > 0:
+            raise NotImplementedError("SSA self-enrollment needs the fbank front-end (SURVEY.md 8f-2)")
+        model, optimizer, scheduler = models[0], optimizers[0], schedulers[0]
+        model.train()
+        ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)
+        fused = isinstance(optimizer, FusedClipAdam)
+        loss_sum = torch.zeros((), device=device)
+        n_steps = 0
+        with (model.join() if ddp else nullcontext()):
+            for i, batch in enumerate(dataloader):
+                cur_iter = (epoch - 1) * epoch_iter + i
+                scheduler.step(cur_iter)
+                features, targets, enroll, spk_label = self._to_device(batch, device)
+                outputs = model(features, enroll)
+                loss = self._loss(outputs, targets, spk_label, criterion, se_loss_weight, multi_task)
+                loss_sum += loss.detach()
+                n_steps += 1
+                optimizer.zero_grad()
+                if scaler is not None:
+                    scaler.scale(loss).backward()
+                    scaler.unscale_(optimizer)
+                else:
+                    loss.backward()
+                if fused:
+                    for group in optimizer.param_groups:
+                        group["clip_grad"] = clip_grad
+                else:
+                    clip_gradients(model, clip_grad)
+                if scaler is not None:
+                    scaler.step(optimizer)
+                    scaler.update()
+                else:
+                    optimizer.step()
+                self.step += 1
+                if (i + 1) % log_batch_interval == 0 and logger is not None:
+                    logger.info(_row("TRAIN", epoch, i + 1, float(loss_sum.item() / n_steps),
+                                     float(optimizer.param_groups[0]["lr"])))
+                if (i + 1) == epoch_iter:
+                    break
+        return float(loss_sum.item() / max(n_steps, 1)), 0
+
+    def cv(self, dataloader, models, val_iter, criterion, epoch, enable_amp, logger,
+           log_batch_interval=100, device=torch.device("cuda")):
+        """Cross validation: criterion[0] on outputs[0] (executor.py:189)."""
+        model = models[0]
+        model.eval()
+        loss_sum = torch.zeros((), device=device)
+        n_steps = 0
+        with torch.no_grad():
+            for i, batch in enumerate(dataloader):
+                features, targets, enroll, _ = self._to_device(batch, device)
+                outputs = model(features, enroll)
+                if not isinstance(outputs, (list, tuple)):
+                    outputs = [outputs]
+                loss_sum += criterion[0](outputs[0], targets).mean()
+                n_steps += 1
+                if (i + 1) % log_batch_interval == 0 and logger is not None:
+                    logger.info(_row("VAL", epoch, i + 1, float(loss_sum.item() / n_steps), "-"))
+                if (i + 1) == val_iter:
+                    break
+        return float(loss_sum.item() / max(n_steps, 1)), 0
