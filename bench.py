@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""Headline benchmark: utterances/sec (4 s, 16 kHz, 2-speaker rows) of one pBSRNN training
+step -- forward, SI-SDR, backward, per-tensor clip, Adam -- on N MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] / north_star "batch 32 x 4 s"): pBSRNN, FiLM multi-fuse,
+6 repeats, feature_dim 128, fixed [R,256] embeddings, R = 32 rows (16 two-speaker mixtures) of
+64000 samples per GPU, fp32 (the reference's precision; its shipped configs set
+enable_amp false).  Weak scaling: every rank runs the same per-GPU batch on its own synthetic
+rows (seed 42 + rank); DDP all-reduces gradients over RCCL.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS = 32
+T = 64000
+MODEL_KW = dict(spk_emb_dim=256, sr=16000, win=512, stride=128, feature_dim=128, num_repeat=6,
+                use_spk_transform=False, spk_fuse_type="FiLM", multi_fuse=True, joint_training=False)
+LR0, LR1, WD, CLIP = 1e-3, 2.5e-5, 1e-4, 5.0          # confs/bsrnn.yaml:95-114
+FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md chip table
+
+
+def _cpu_baseline_worker(threads, budget_s):
+    """Runs in a child process (hard wall-clock limit enforced by the parent)."""
+    from oracle import bsrnn_oracle as O
+    torch.set_num_threads(threads)
+    cfg = O.BSRNNConfig(num_repeat=6, spk_fuse_type="FiLM", multi_fuse=True)
+    params = O.synth_params(cfg, 0)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    R = 2
+    wav, tgt, emb = O.synth_batch(R, T, 42)
+
+    def step(i):
+        for t_ in p.values():
+            t_.grad = None
+        est = O.bsrnn_forward(p, cfg, wav, emb)
+        loss = O.sisdr_loss(est, tgt)
+        loss.backward()
+        grads = {k: t_.grad for k, t_ in p.items()}
+        O.clip_gradients_(grads, CLIP)
+        with torch.no_grad():
+            for k in p:
+                O.adam_l2_step_(p[k], grads[k], m[k], v2[k], i, LR0, weight_decay=WD)
+
+    t0 = time.perf_counter()
+    step(1)                                  # warm-up (thread pools, oneDNN primitives)
+    warm = time.perf_counter() - t0
+    n = max(1, min(3, int(budget_s / max(warm, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for i in range(n):
+        step(i + 2)
+    dt = (time.perf_counter() - t0) / n
+    print(json.dumps({"value": R / dt, "unit": "utterances/s", "cores": torch.get_num_threads(),
+                      "kind": "port",
+                      "sample": f"oracle (torch CPU fp32 restatement of the reference step), R={R} rows x 4 s, "
+                                f"1 warm-up + {n} timed steps of fwd+SI-SDR+bwd+clip+Adam, {dt:.2f} s/step, "
+                                f"{threads} of {os.cpu_count()} host cores (reference recipe: OMP_NUM_THREADS=8)"}))
+
+
+def cpu_baseline(budget_s=30.0, hard_limit_s=240.0):
+    """Oracle (CPU port of the reference step) timed on this host's cores in a child process so a
+    pathological host (hundreds of cores, oversubscription) cannot stall the benchmark."""
+    import subprocess
+    threads = min(os.cpu_count() or 1, 16)
+    cmd = [sys.executable, "-c",
+           f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench._cpu_baseline_worker({threads}, {budget_s})"]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_limit_s, env=env, cwd=ROOT)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # timeout or failure: report it rather than hiding it
+        return {"value": None, "unit": "utterances/s", "cores": threads, "kind": "port",
+                "sample": f"cpu baseline did not finish within {hard_limit_s:.0f} s ({type(e).__name__})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=ROWS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from wesep_amd import dev
+    from wesep_amd import _lib as L
+    from wesep_amd.models import get_model
+    from wesep_amd.optim import FusedClipAdam
+    from wesep_amd.parallel import barrier, init_distributed, max_over_ranks, rank_seed, wrap_ddp
+    from wesep_amd.utils.losses import parse_loss
+    from wesep_amd.utils.schedulers import ExponentialDecrease
+    from wesep_amd.utils.synthetic import synth_batch
+
+    rank, local_rank, world = init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    d = torch.device("cuda", local_rank)
+
+    torch.manual_seed(0)                      # identical default-init weights on every rank
+    model = get_model("BSRNN")(**MODEL_KW)
+    with torch.no_grad():                     # FiLM is zero-init in the reference; make it do work
+        for mod in model.separator.separation:
+            if hasattr(mod, "fc") and hasattr(mod.fc, "gamma_fcs"):
+                torch.nn.init.normal_(mod.fc.gamma_fcs[0].weight, std=0.02)
+                torch.nn.init.normal_(mod.fc.beta_fcs[0].weight, std=0.02)
+    model = model.to(d).train()
+    ddp = wrap_ddp(model, local_rank)
+    opt = FusedClipAdam(model.parameters(), lr=LR0, weight_decay=WD, clip_grad=CLIP)
+    sched = ExponentialDecrease(opt, num_epochs=150, epoch_iter=1000, initial_lr=LR0, final_lr=LR1,
+                                warm_up_epoch=0)
+    crit = parse_loss("SISDR")[0]
+    R = args.rows
+    wav, tgt, emb = (t.to(d) for t in synth_batch(R, T, rank_seed(42, rank)))
+
+    def step(i):
+        sched.step(i)
+        est, _ = ddp(wav, emb)
+        loss = crit(est, tgt).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    dev.prof_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev.prof_enable(False)
+    elapsed = max_over_ranks(elapsed, d)
+    final_loss = float(loss.item())
+
+    # dominant kernels: the two BLSTM recurrences (HIP events on the launch stream)
+    K, Tf = 32, 1 + T // 128
+    P = R * K * Tf
+    flops_per_launch = 2.0 * P * 2 * L.LSTM_H * 4 * L.LSTM_H        # both directions, one ResRNN
+    prof = {}
+    for name, kind in (("lstm_fwd", L.PROF_LSTM_FWD), ("lstm_bwd", L.PROF_LSTM_BWD),
+                       ("gemm_nt", L.PROF_GEMM_NT), ("gemm_tn", L.PROF_GEMM_TN)):
+        ms, n = dev.prof_collect(kind)
+        prof[name] = {"ms_total": ms, "launches": n, "ms_avg": ms / max(n, 1)}
+    dom = "lstm_bwd" if prof["lstm_bwd"]["ms_total"] >= prof["lstm_fwd"]["ms_total"] else "lstm_fwd"
+    achieved = flops_per_launch / (prof[dom]["ms_avg"] * 1e-3) / 1e12 if prof[dom]["launches"] else 0.0
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "utterances/sec (4 s, 16 kHz, 2-spk) fwd+bwd, pBSRNN",
+            "value": world * R * args.steps / elapsed, "unit": "utterances/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "pBSRNN FiLM multi-fuse, 6 repeats, feature_dim 128, fixed 256-d "
+                                   "embeddings; fwd + SI-SDR + bwd + per-tensor clip + Adam-L2",
+                       "rows_per_gpu": R, "global_rows": world * R, "samples_per_row": T,
+                       "parallelism": f"dp{world}", "final_loss_dB": final_loss},
+            "roofline": {"bound": "mfma", "kernel": dom + "_kernel<1>", "achieved": achieved,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "flops_per_launch": flops_per_launch, "ms_per_launch": prof[dom]["ms_avg"]},
+            "kernel_ms_per_step": {k: v["ms_total"] / args.steps for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -173,3 +173,10 @@ def test_band_plan_offsets():
     assert int(plan.bn_woff[-1]) == 128 * 2 * 257
     assert int(plan.m_w3off[-1]) == 4 * 257 * 512 and int(plan.m_b3off[-1]) == 4 * 257
     assert plan.bands.band_of_bin.tolist()[:4] == [0, 0, 0, 1]
+
+
+def test_product_and_oracle_synthetic_rows_agree():
+    from oracle.bsrnn_oracle import synth_batch as a
+    from wesep_amd.utils.synthetic import synth_batch as b
+    for x, y in zip(a(4, 1000, 7), b(4, 1000, 7)):
+        assert torch.equal(x, y)
