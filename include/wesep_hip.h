@@ -73,7 +73,8 @@ typedef struct ws_gemm_nt_args {
   long long a_s1, a_s2, c_s1, c_s2, st_m1, st_m2, st_base;
   int a_div, c_div, st_div1, st_div2;
   int M, N, K, ldw;
-  int act, ngroups, max_n, vec; /* max_n: max N over groups; vec bit0: A float4-loadable, bit1: W */
+  int act, ngroups, max_n, vec; /* max_n: max N over groups; vec bit0: A float4-loadable, bit1: W,
+                                   bit2: split-bf16 (hi/lo, 3 MFMAs, fp32 accumulate) products */
 } ws_gemm_nt_args;
 int ws_gemm_nt(const ws_gemm_nt_args* a, void* stream);
 
@@ -103,7 +104,7 @@ typedef struct ws_gemm_tn_args {
   int g_div, a_div, st_div1, st_div2;
   int M, Nn, Kk, rows_per_split, nsplit;
   int shift_rows, seq_div, seq_len;
-  int ngroups, max_n, max_k, vec; /* vec bit0: A float4-loadable */
+  int ngroups, max_n, max_k, vec; /* vec bit0: A float4-loadable, bit2: split-bf16 products */
 } ws_gemm_tn_args;
 int ws_gemm_tn(const ws_gemm_tn_args* a, void* stream);
 

@@ -25,21 +25,27 @@ def rnd(g, *shape, scale=1.0):
 # ----------------------------------------------------------------------------------------------
 # GEMM NT
 # ----------------------------------------------------------------------------------------------
+MODES = ["f32", "bf16x3"]
+TOL = {"f32": 3e-6, "bf16x3": 4e-5}   # bf16x3 drops the lo*lo term: <= 2^-16 per product
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("M,N,K,vec", [(300, 200, 70, 0), (300, 200, 72, 3), (128, 128, 32, 3),
                                        (1000, 2048, 128, 3), (77, 12, 512, 3), (513, 128, 6, 0)])
-def test_gemm_nt_plain(M, N, K, vec):
+def test_gemm_nt_plain(M, N, K, vec, mode):
     from wesep_amd import dev
     d = _cuda()
     g = torch.Generator().manual_seed(M + N + K)
     A, W, b = rnd(g, M, K), rnd(g, N, K), rnd(g, N)
     C = torch.full((M, N), float("nan"), device=d)
     dev.gemm_nt(A=A.to(d), a_rows=dev.flat(K), M=M, N=N, K=K, W=W.to(d), ldw=K, bias=b.to(d), C_out=C,
-                c_rows=dev.flat(N), vec=vec)
-    ref = A @ W.t() + b
-    assert rel(C, ref) < 2e-6
+                c_rows=dev.flat(N), vec=vec, mode=mode)
+    ref = A.double() @ W.double().t() + b.double()
+    assert rel(C, ref) < TOL[mode]
 
 
-def test_gemm_nt_epilogues_and_norm():
+@pytest.mark.parametrize("mode", MODES)
+def test_gemm_nt_epilogues_and_norm(mode):
     from wesep_amd import dev
     d = _cuda()
     g = torch.Generator().manual_seed(5)
@@ -51,14 +57,15 @@ def test_gemm_nt_epilogues_and_norm():
     C = torch.empty(M, N, device=d)
     dev.gemm_nt(A=A.to(d), a_rows=dev.flat(K), M=M, N=N, K=K, W=W.to(d), ldw=K, bias=b.to(d), C_out=C,
                 c_rows=dev.flat(N), R=Rr.to(d), T=Tt.to(d), stats=stats.to(d), gamma=gamma.to(d),
-                beta=beta.to(d), stat_map=dev.StatMap(20, 1, 1, 0, 0), act=1)
+                beta=beta.to(d), stat_map=dev.StatMap(20, 1, 1, 0, 0), act=1, mode=mode)
     s = torch.arange(M) // 20
     An = (A - stats[s, 0:1]) * stats[s, 1:2] * gamma + beta
     ref = torch.tanh(An @ W.t() + b) * (1 - Tt * Tt) + Rr
-    assert rel(C, ref) < 3e-6
+    assert rel(C, ref) < TOL[mode]
 
 
-def test_gemm_nt_two_level_rows_and_groups():
+@pytest.mark.parametrize("mode", MODES)
+def test_gemm_nt_two_level_rows_and_groups(mode):
     """Grouped launch over 3 'bands' with ragged N/K, 2-level A rows and strided C columns."""
     from wesep_amd import dev, _lib as L
     d = _cuda()
@@ -77,20 +84,21 @@ def test_gemm_nt_two_level_rows_and_groups():
         desc[k] = (Wd[k].data_ptr(), bd[k].data_ptr(), 0, 0, k * Tf * N, offs[k], 0, N, widths[k], N, 0)
     gd = L.upload_struct_array(desc, d)
     dev.gemm_nt(A=Z.to(d), a_rows=dev.Rows(Tf, Kb * Tf * N, N), M=M, C_out=C, c_rows=dev.flat(100),
-                groups=gd, ngroups=3, max_n=64)
+                groups=gd, ngroups=3, max_n=64, mode=mode)
     ref = torch.zeros(M, 100)
     for k in range(3):
         Ak = Z[:, k].reshape(M, N)
         ref[:, offs[k]:offs[k] + widths[k]] = Ak @ Ws[k].t() + bs[k]
-    assert rel(C, ref) < 2e-6
+    assert rel(C, ref) < TOL[mode]
 
 
 # ----------------------------------------------------------------------------------------------
 # GEMM TN
 # ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("M,Nn,Kk,vec", [(5000, 200, 72, 1), (300, 12, 512, 1), (4100, 128, 6, 0),
                                          (9000, 1024, 256, 1)])
-def test_gemm_tn_plain_and_bias(M, Nn, Kk, vec):
+def test_gemm_tn_plain_and_bias(M, Nn, Kk, vec, mode):
     from wesep_amd import dev
     d = _cuda()
     g = torch.Generator().manual_seed(M + Nn)
@@ -100,17 +108,18 @@ def test_gemm_tn_plain_and_bias(M, Nn, Kk, vec):
     bslab = torch.full((nsplit, Nn), float("nan"), device=d)
     dev.gemm_tn(G=G.to(d), g_rows=dev.flat(Nn), A=A.to(d), a_rows=dev.flat(Kk), M=M, Nn=Nn, Kk=Kk,
                 slab=slab, slab_stride=Nn * Kk, bslab=bslab, bslab_stride=Nn, nsplit=nsplit,
-                rows_per_split=rps, vec=vec)
+                rows_per_split=rps, vec=vec, mode=mode)
     out = torch.empty(Nn, Kk, device=d)
     bo = torch.empty(Nn, device=d)
     dev.reduce_slabs(slab, nsplit, Nn * Kk, Nn * Kk, out)
     dev.reduce_slabs(bslab, nsplit, Nn, Nn, bo)
-    assert rel(out, G.double().t() @ A.double()) < 5e-6
+    assert rel(out, G.double().t() @ A.double()) < TOL[mode]
     assert rel(bo, G.double().sum(0)) < 5e-6
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("seq_div,seq_len,sign", [(1, 25, -1), (1, 25, 1), (10, 4, -1), (10, 4, 1)])
-def test_gemm_tn_shift_and_norm(seq_div, seq_len, sign):
+def test_gemm_tn_shift_and_norm(seq_div, seq_len, sign, mode):
     from wesep_amd import dev
     d = _cuda()
     g = torch.Generator().manual_seed(17)
@@ -120,24 +129,24 @@ def test_gemm_tn_shift_and_norm(seq_div, seq_len, sign):
     slab = torch.empty(1, Nn * Kk, device=d)
     dev.gemm_tn(G=G.to(d), g_rows=dev.flat(Nn), A=A.to(d), a_rows=dev.flat(Kk), M=M, Nn=Nn, Kk=Kk,
                 slab=slab, slab_stride=Nn * Kk, nsplit=1, rows_per_split=416, shift_rows=shift,
-                seq_div=seq_div, seq_len=seq_len)
+                seq_div=seq_div, seq_len=seq_len, mode=mode)
     m = torch.arange(M)
     t = (m // seq_div) % seq_len
     ok = ((t + sign) >= 0) & ((t + sign) < seq_len)
     As = torch.zeros_like(A)
     idx = m[ok] + shift
     As[ok] = A[idx]
-    assert rel(slab.view(Nn, Kk), G.double().t() @ As.double()) < 5e-6
+    assert rel(slab.view(Nn, Kk), G.double().t() @ As.double()) < TOL[mode]
     # norm prologue
     S = 20
     stats = torch.stack([rnd(g, S), rnd(g, S).abs() + 0.5], 1).contiguous()
     gamma, beta = rnd(g, Kk), rnd(g, Kk)
     dev.gemm_tn(G=G.to(d), g_rows=dev.flat(Nn), A=A.to(d), a_rows=dev.flat(Kk), M=M, Nn=Nn, Kk=Kk,
                 slab=slab, slab_stride=Nn * Kk, nsplit=1, rows_per_split=416, stats=stats.to(d),
-                gamma=gamma.to(d), beta=beta.to(d), stat_map=dev.StatMap(20, 1, 1, 0, 0))
+                gamma=gamma.to(d), beta=beta.to(d), stat_map=dev.StatMap(20, 1, 1, 0, 0), mode=mode)
     s = m // 20
     An = (A - stats[s, 0:1]) * stats[s, 1:2] * gamma + beta
-    assert rel(slab.view(Nn, Kk), G.double().t() @ An.double()) < 5e-6
+    assert rel(slab.view(Nn, Kk), G.double().t() @ An.double()) < TOL[mode]
 
 
 def test_transpose_and_reduce_ld():

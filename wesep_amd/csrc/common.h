@@ -27,6 +27,10 @@ int ws_check_launch(const char* what);
 void ws_prof_begin(int kind, hipStream_t s);
 void ws_prof_end(int kind, hipStream_t s);
 
+// ---- split-bf16 GEMM launchers (gemm_bf16.hip), selected by bit 2 of the `vec` argument ------
+int ws_launch_gemm_nt_bf16(const ws_gemm_nt_args* a, dim3 grid, hipStream_t s);
+int ws_launch_gemm_tn_bf16(const ws_gemm_tn_args* a, dim3 grid, hipStream_t s);
+
 // ---- device helpers -----------------------------------------------------------
 __device__ __forceinline__ float ws_wave_sum(float v) {
 #pragma unroll

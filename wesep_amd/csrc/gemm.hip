@@ -199,7 +199,9 @@ extern "C" int ws_gemm_nt(const ws_gemm_nt_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ws_prof_begin(WS_PROF_GEMM_NT, s);
   const bool va = a->vec & 1, vw = a->vec & 2;
-  if (va && vw)
+  if ((a->vec & 4) && va && vw)
+    ws_launch_gemm_nt_bf16(a, grid, s);
+  else if (va && vw)
     hipLaunchKernelGGL((gemm_nt_kernel<true, true>), grid, block, 0, s, *a);
   else if (va)
     hipLaunchKernelGGL((gemm_nt_kernel<true, false>), grid, block, 0, s, *a);
@@ -378,7 +380,9 @@ extern "C" int ws_gemm_tn(const ws_gemm_tn_args* a, void* stream) {
   dim3 grid(((maxn + 127) / 128) * ((maxk + 127) / 128), a->nsplit, ng), block(256);
   hipStream_t s = (hipStream_t)stream;
   ws_prof_begin(WS_PROF_GEMM_TN, s);
-  if (a->vec & 1)
+  if (a->vec & 4)
+    ws_launch_gemm_tn_bf16(a, grid, s);
+  else if (a->vec & 1)
     hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, s, *a);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, s, *a);

@@ -1,0 +1,380 @@
+// Split-bf16 ("bf16x3") MFMA variants of the two GEMM families in gemm.hip, same arguments.
+//
+// fp32 operands are split on the way into LDS into hi = bf16(x) and lo = bf16(x - hi); the product
+// is accumulated in fp32 as  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  on v_mfma_f32_32x32x16_bf16
+// (dense bf16 matrix rate, 16x the fp32 MFMA rate -> ~5.3x per fp32-equivalent product).  The
+// dropped a_lo*b_lo term is <= 2^-16 relative per product; accumulation stays fp32.  Whether that
+// holds the path's 1e-3 waveform bound is decided by tests/test_bsrnn_gpu.py, not assumed.
+//
+// LDS image: 4 planes (A_hi, A_lo, B_hi, B_lo) of [128 rows][32 k] bf16, row stride 40 elements
+// (80 B): the MFMA fragment (8 consecutive k of one row per lane) is ONE ds_read_b128, and the
+// 80-B stride spreads a 16-lane group over all 64 banks (conflict-free).  Single LDS buffer
+// (40 KB -> 3 workgroups/CU for latency hiding), next k-tile's global loads in flight in
+// registers under the current tile's MFMAs.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define BT_BK 32
+#define BT_LD 40               // bf16 elements per LDS row
+#define BT_PLANE (128 * BT_LD)  // elements per plane
+
+__device__ __forceinline__ int frag_row32b(int reg, int half) {
+  return (reg & 3) + 8 * (reg >> 2) + 4 * half;
+}
+
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi[j] = (__bf16)v[j];
+    lo[j] = (__bf16)(v[j] - (float)hi[j]);
+  }
+}
+
+// one 128x128x32 tile step for a wave's 64x64 sub-tile; A planes hold the "row" operand
+// (MFMA A, rows -> D rows), B planes the "column" operand (MFMA B, rows -> D columns).
+__device__ __forceinline__ void tile_mma(const __bf16* __restrict__ lds, int arow0, int brow0, int l31,
+                                         int half, f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11) {
+  const __bf16* Ah = lds;
+  const __bf16* Al = lds + BT_PLANE;
+  const __bf16* Bh = lds + 2 * BT_PLANE;
+  const __bf16* Bl = lds + 3 * BT_PLANE;
+#pragma unroll
+  for (int ks = 0; ks < BT_BK; ks += 16) {
+    const int ka = ks + 8 * half;
+    const int ra0 = (arow0 + l31) * BT_LD + ka, ra1 = (arow0 + 32 + l31) * BT_LD + ka;
+    const int rb0 = (brow0 + l31) * BT_LD + ka, rb1 = (brow0 + 32 + l31) * BT_LD + ka;
+    const bf16x8 a0h = *reinterpret_cast<const bf16x8*>(Ah + ra0);
+    const bf16x8 a1h = *reinterpret_cast<const bf16x8*>(Ah + ra1);
+    const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(Bh + rb0);
+    const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(Bh + rb1);
+    const bf16x8 a0l = *reinterpret_cast<const bf16x8*>(Al + ra0);
+    const bf16x8 a1l = *reinterpret_cast<const bf16x8*>(Al + ra1);
+    const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(Bl + rb0);
+    const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(Bl + rb1);
+    c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, c00, 0, 0, 0);
+    c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, c01, 0, 0, 0);
+    c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, c10, 0, 0, 0);
+    c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, c11, 0, 0, 0);
+    c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, c00, 0, 0, 0);
+    c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, c01, 0, 0, 0);
+    c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, c10, 0, 0, 0);
+    c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, c11, 0, 0, 0);
+    c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, c00, 0, 0, 0);
+    c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, c01, 0, 0, 0);
+    c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, c10, 0, 0, 0);
+    c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, c11, 0, 0, 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT: C[M][N] = epi(pro(A)[M][K] * W[N][K]^T).  Requires float4-loadable A and W (vec bits 0,1).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[4 * BT_PLANE];  // 40 KB
+  const float* A = p.A;
+  const float* W = p.W;
+  const float* bias = p.bias;
+  const float* gamma = p.gamma;
+  const float* beta = p.beta;
+  float* C = p.C;
+  const float* R = p.R;
+  const float* T = p.T;
+  int K = p.K, N = p.N, ldw = p.ldw;
+  long long st_base = p.st_base;
+  if (p.groups) {
+    const ws_group_nt g = p.groups[blockIdx.z];
+    A += g.a_off;
+    W = g.W;
+    bias = g.bias;
+    gamma = g.gamma;
+    beta = g.beta;
+    C += g.c_off;
+    if (R) R += g.c_off;
+    if (T) T += g.c_off;
+    st_base = g.st_base;
+    K = g.K;
+    N = g.N;
+    ldw = g.ldw;
+  }
+  const int M = p.M;
+  const int m_blk = blockIdx.x * 128, n_blk = blockIdx.y * 128;
+  if (n_blk >= N) return;
+  const int tid = threadIdx.x;
+  const int lrow = tid >> 3, lk = (tid & 7) * 4;
+  const bool has_norm = p.stats != nullptr;
+
+  long long aoff[4], woff[4];
+  bool vm[4], vn[4];
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_blk + lrow + 32 * i;
+    vm[i] = m < M;
+    const int mm = vm[i] ? m : 0;
+    aoff[i] = ws_row_off(mm, p.a_div, p.a_s1, p.a_s2);
+    mean[i] = 0.f;
+    rstd[i] = 1.f;
+    if (has_norm) {
+      const long long s = (long long)(mm / p.st_div1) * p.st_m1 + (long long)(mm % p.st_div2) * p.st_m2 + st_base;
+      mean[i] = p.stats[2 * s];
+      rstd[i] = p.stats[2 * s + 1];
+    }
+    const int n = n_blk + lrow + 32 * i;
+    vn[i] = n < N;
+    woff[i] = (long long)(vn[i] ? n : 0) * ldw;
+  }
+
+  f32x4 ra[4], rw[4];
+  auto load_tile = [&](int kt) {
+    const int k = kt * BT_BK + lk;
+    f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
+    if (has_norm && k < K) {
+      gm = *reinterpret_cast<const f32x4*>(gamma + k);
+      bt = *reinterpret_cast<const f32x4*>(beta + k);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (vm[i] && k < K) {
+        v = *reinterpret_cast<const f32x4*>(A + aoff[i] + k);
+        if (has_norm) v = (v - mean[i]) * rstd[i] * gm + bt;
+      }
+      ra[i] = v;
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (vn[i] && k < K) w = *reinterpret_cast<const f32x4*>(W + woff[i] + k);
+      rw[i] = w;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x4 hi, lo;
+      const int o = (lrow + 32 * i) * BT_LD + lk;
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(lds + o) = hi;
+      *reinterpret_cast<bf16x4*>(lds + BT_PLANE + o) = lo;
+      split4(rw[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(lds + 2 * BT_PLANE + o) = hi;
+      *reinterpret_cast<bf16x4*>(lds + 3 * BT_PLANE + o) = lo;
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
+
+  const int nk = (K + BT_BK - 1) / BT_BK;
+  load_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // previous tile's fragment reads are done
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile(kt + 1);
+    tile_mma(lds, wm * 64, wn * 64, l31, half, acc00, acc01, acc10, acc11);
+  }
+
+  const bool flat_c = p.c_div >= M;  // (m / c_div) == 0 for every row: no division needed
+  auto epilogue = [&](const f32x16& acc, int tm, int tn) {
+    const int n = n_blk + wn * 64 + tn * 32 + l31;
+    if (n >= N) return;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m_blk + wm * 64 + tm * 32 + frag_row32b(r, half);
+      if (m >= M) continue;
+      const long long off = (flat_c ? (long long)m * p.c_s2 : ws_row_off(m, p.c_div, p.c_s1, p.c_s2)) + n;
+      float v = acc[r] + bv;
+      if (p.act == 1) v = tanhf(v);
+      if (T) {
+        const float t = T[off];
+        v *= (1.f - t * t);
+      }
+      if (R) v += R[off];
+      C[off] = v;
+    }
+  };
+  epilogue(acc00, 0, 0);
+  epilogue(acc01, 0, 1);
+  epilogue(acc10, 1, 0);
+  epilogue(acc11, 1, 1);
+}
+
+int ws_launch_gemm_nt_bf16(const ws_gemm_nt_args* a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 0, s, *a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN: slab[n][k] = sum_m G[m][n] * pro(A[m'][k]).  The MFMA wants 8 consecutive m per lane for a
+// fixed n (and k), i.e. the TRANSPOSE of both global tiles: each thread owns one column (n or k)
+// and gathers 16 consecutive rows with scalar loads (coalesced across lanes), then writes two
+// 16-B fragments per plane.  Row metadata (offsets, validity, norm stats) for the 32 rows of a
+// tile is computed once by 32 threads into LDS instead of 16x per thread.
+// ---------------------------------------------------------------------------------------------
+struct RowMeta {
+  long long goff, aoff;
+  float mean, rstd;
+  int gvalid, avalid;
+};
+
+__global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[4 * BT_PLANE];  // 40 KB
+  __shared__ RowMeta meta[2][32];
+  __shared__ float bred[128];
+  const float* G = p.G;
+  const float* A = p.A;
+  const float* gamma = p.gamma;
+  const float* beta = p.beta;
+  int Nn = p.Nn, Kk = p.Kk;
+  long long st_base = p.st_base, out_off = p.out_off, bout_off = p.bout_off;
+  if (p.groups) {
+    const ws_group_tn g = p.groups[blockIdx.z];
+    G += g.g_off;
+    A += g.a_off;
+    gamma = g.gamma;
+    beta = g.beta;
+    st_base = g.st_base;
+    out_off = g.out_off;
+    bout_off = g.bout_off;
+    Nn = g.Nn;
+    Kk = g.Kk;
+  }
+  const int tiles_k = (Kk + 127) / 128, tiles_n = (Nn + 127) / 128;
+  if ((int)blockIdx.x >= tiles_k * tiles_n) return;
+  const int n_blk = (blockIdx.x / tiles_k) * 128, k_blk = (blockIdx.x % tiles_k) * 128;
+  const int split = blockIdx.y;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int tid = threadIdx.x;
+  const int col = tid & 127, mg = (tid >> 7) * 16;  // this thread: column `col`, rows mg..mg+15
+  const bool has_norm = p.stats != nullptr;
+  const bool do_bias = p.bslab != nullptr && k_blk == 0;
+  const bool gcol_ok = n_blk + col < Nn, acol_ok = k_blk + col < Kk;
+  float gm = 1.f, bt = 0.f;
+  if (has_norm && acol_ok) {
+    gm = gamma[k_blk + col];
+    bt = beta[k_blk + col];
+  }
+
+  auto make_meta = [&](int m0, int slot) {
+    if (tid < 32) {
+      const int m = m0 + tid;
+      RowMeta r;
+      r.gvalid = m < m_end;
+      r.avalid = r.gvalid;
+      r.goff = r.aoff = 0;
+      r.mean = 0.f;
+      r.rstd = 1.f;
+      if (r.gvalid) {
+        r.goff = ws_row_off(m, p.g_div, p.g_s1, p.g_s2);
+        int ma = m;
+        if (p.shift_rows != 0) {
+          const int t = (m / p.seq_div) % p.seq_len;
+          const int t2 = t + (p.shift_rows > 0 ? 1 : -1);
+          r.avalid = (t2 >= 0) && (t2 < p.seq_len);
+          ma = m + p.shift_rows;
+        }
+        if (r.avalid) r.aoff = ws_row_off(ma, p.a_div, p.a_s1, p.a_s2);
+        if (has_norm) {
+          const long long s = (long long)(m / p.st_div1) * p.st_m1 + (long long)(m % p.st_div2) * p.st_m2 + st_base;
+          r.mean = p.stats[2 * s];
+          r.rstd = p.stats[2 * s + 1];
+        }
+      }
+      meta[slot][tid] = r;
+    }
+  };
+
+  float rg[16], ra[16];
+  auto load_tile = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const RowMeta& r = meta[slot][mg + j];
+      float g = 0.f, a = 0.f;
+      if (r.gvalid && gcol_ok) g = G[r.goff + n_blk + col];
+      if (r.avalid && acol_ok) {
+        a = A[r.aoff + k_blk + col];
+        if (has_norm) a = (a - r.mean) * r.rstd * gm + bt;
+      }
+      rg[j] = g;
+      ra[j] = a;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) {
+      bf16x8 ghi, glo, ahi, alo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float g = rg[h8 * 8 + j], a = ra[h8 * 8 + j];
+        ghi[j] = (__bf16)g;
+        glo[j] = (__bf16)(g - (float)ghi[j]);
+        ahi[j] = (__bf16)a;
+        alo[j] = (__bf16)(a - (float)ahi[j]);
+      }
+      const int o = col * BT_LD + mg + h8 * 8;
+      *reinterpret_cast<bf16x8*>(lds + o) = ghi;
+      *reinterpret_cast<bf16x8*>(lds + BT_PLANE + o) = glo;
+      *reinterpret_cast<bf16x8*>(lds + 2 * BT_PLANE + o) = ahi;
+      *reinterpret_cast<bf16x8*>(lds + 3 * BT_PLANE + o) = alo;
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
+  float bsum = 0.f;
+
+  int it = 0;
+  if (m_begin < m_end) {
+    make_meta(m_begin, 0);
+    __syncthreads();
+    load_tile(0);
+  }
+  for (int m0 = m_begin; m0 < m_end; m0 += 32, ++it) {
+    const bool more = m0 + 32 < m_end;
+    if (more) make_meta(m0 + 32, (it + 1) & 1);
+    if (do_bias) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bsum += rg[j];
+    }
+    __syncthreads();  // previous tile's fragment reads done; next meta visible
+    store_tile();
+    __syncthreads();
+    if (more) load_tile((it + 1) & 1);
+    tile_mma(lds, wm * 64, wn * 64, l31, half, acc00, acc01, acc10, acc11);
+  }
+
+  float* out = p.slab + (long long)split * p.slab_stride + out_off;
+  auto write = [&](const f32x16& acc, int tm, int tn) {
+    const int k = k_blk + wn * 64 + tn * 32 + l31;
+    if (k >= Kk) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n_blk + wm * 64 + tm * 32 + frag_row32b(r, half);
+      if (n < Nn) out[(long long)n * Kk + k] = acc[r];
+    }
+  };
+  write(acc00, 0, 0);
+  write(acc01, 0, 1);
+  write(acc10, 1, 0);
+  write(acc11, 1, 1);
+  if (do_bias) {
+    __syncthreads();
+    if (tid >= 128) bred[col] = bsum;
+    __syncthreads();
+    if (tid < 128 && gcol_ok)
+      p.bslab[(long long)split * p.bslab_stride + bout_off + n_blk + col] = bsum + bred[col];
+  }
+}
+
+int ws_launch_gemm_tn_bf16(const ws_gemm_tn_args* a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(256), 0, s, *a);
+  return 0;
+}

@@ -9,8 +9,11 @@
 // one (sequence, unit) land in the same lane and register index -> the cell update is
 // lane-local.  W_hh (1 MB fp32 per direction) cannot live in a CU (160 KB LDS + 512 KB VGPR),
 // so it is streamed every step from the XCD's L2 in a pre-packed B-fragment order (one
-// coalesced 16-B load per lane per 4 k-steps); h_{t-1} sits in LDS in A-fragment order
-// (ds_read_b128, row stride 68/260 floats = conflict-free).  Cell state c stays in registers.
+// coalesced 16-B load per lane per 4 k-steps; MT sequence tiles share each fragment); the
+// first fragment block of a step never changes, so it stays resident in registers and the
+// step boundary exposes no load.  h_{t-1} sits in LDS in A-fragment order (ds_read_b128, row
+// stride 68/260 floats = conflict-free).  Cell state c stays in registers.  The next step's
+// x-projection is loaded straight into the (dead) accumulators before this step's stores.
 #include "common.h"
 
 #define LH WS_LSTM_H  // 256
@@ -20,6 +23,18 @@
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// v_exp_f32 / v_rcp_f32 based activations (~1e-7 absolute error; the cell math tolerates it,
+// tests/test_kernels_gpu.py::test_lstm_fwd_bwd_vs_torch holds 1e-5 against torch's LSTM).
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __expf(-x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float ax = fabsf(x);
+  const float e = __expf(-2.f * ax);                      // in (0, 1]: no overflow
+  const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+  return copysignf(t, x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -125,9 +140,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(const ws_lstm_args p) {
       for (int r = 0; r < 4; ++r) c[mt][s][r] = 0.f;
 
   const f32x4* wp = reinterpret_cast<const f32x4*>(p.wpack) + (long long)(d * 8 + w) * (16 * 8 * 64) + lane;
+  f32x4 b0[8];  // fragment block ks4 = 0: identical every step, kept resident
+#pragma unroll
+  for (int tile = 0; tile < 8; ++tile) b0[tile] = wp[tile * 64];
 
-  f32x4 gxn[MT][8];
-  auto load_gx = [&](int t) {
+  f32x4 acc[MT][8];
+  auto load_gx = [&](int t) {  // x-projection of step t straight into the accumulators
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -135,7 +153,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(const ws_lstm_args p) {
         const long long row = rowbase[mt][r] + (long long)t * p.step_rows;
         const float* g = p.gates + (row * 2 + d) * LG + ubase;
 #pragma unroll
-        for (int tile = 0; tile < 8; ++tile) gxn[mt][tile][r] = g[(tile >> 1) * 256 + 16 * (tile & 1)];
+        for (int tile = 0; tile < 8; ++tile) acc[mt][tile][r] = g[(tile >> 1) * 256 + 16 * (tile & 1)];
       }
   };
   load_gx(d == 0 ? 0 : L - 1);
@@ -144,17 +162,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(const ws_lstm_args p) {
   for (int step = 0; step < L; ++step) {
     const int t = d == 0 ? step : L - 1 - step;
     const int cur = step & 1;
-    f32x4 acc[MT][8];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int tile = 0; tile < 8; ++tile) acc[mt][tile] = gxn[mt][tile];
-    if (step + 1 < L) load_gx(d == 0 ? step + 1 : L - 2 - step);
-
     const float* hcur = hl + cur * (MT * 64 * HL_LD) + (lq * 16 + l15) * HL_LD;
     f32x4 bcur[8], bnxt[8];
 #pragma unroll
-    for (int tile = 0; tile < 8; ++tile) bcur[tile] = wp[tile * 64];
+    for (int tile = 0; tile < 8; ++tile) bcur[tile] = b0[tile];
 #pragma unroll 2
     for (int ks4 = 0; ks4 < 16; ++ks4) {
       if (ks4 + 1 < 16) {
@@ -175,6 +186,29 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(const ws_lstm_args p) {
       for (int tile = 0; tile < 8; ++tile) bcur[tile] = bnxt[tile];
     }
 
+    // cell update into registers; accumulators are dead afterwards
+    f32x4 gi[MT][2], gf[MT][2], gg[MT][2], go[MT][2], hv[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ig = fast_sigmoid(acc[mt][0 + s][r]);
+          const float fg = fast_sigmoid(acc[mt][2 + s][r]);
+          const float g_ = fast_tanh(acc[mt][4 + s][r]);
+          const float og = fast_sigmoid(acc[mt][6 + s][r]);
+          const float cn = fg * c[mt][s][r] + ig * g_;
+          c[mt][s][r] = cn;
+          gi[mt][s][r] = ig;
+          gf[mt][s][r] = fg;
+          gg[mt][s][r] = g_;
+          go[mt][s][r] = og;
+          hv[mt][s][r] = og * fast_tanh(cn);
+        }
+    // next step's x-projection: issued BEFORE this step's stores so its wait never covers them
+    if (step + 1 < L) load_gx(d == 0 ? step + 1 : L - 2 - step);
+
     float* hnext = hl + (cur ^ 1) * (MT * 64 * HL_LD);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -183,23 +217,16 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(const ws_lstm_args p) {
         const int u = ubase + 16 * s;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float ig = ws_sigmoid(acc[mt][0 + s][r]);
-          const float fg = ws_sigmoid(acc[mt][2 + s][r]);
-          const float gg = tanhf(acc[mt][4 + s][r]);
-          const float og = ws_sigmoid(acc[mt][6 + s][r]);
-          const float cn = fg * c[mt][s][r] + ig * gg;
-          c[mt][s][r] = cn;
-          const float h = og * tanhf(cn);
-          hnext[((mt * 4 + (u & 3)) * 16 + 4 * lq + r) * HL_LD + (u >> 2)] = h;
+          hnext[((mt * 4 + (u & 3)) * 16 + 4 * lq + r) * HL_LD + (u >> 2)] = hv[mt][s][r];
           if (valid[mt][r]) {
             const long long row = rowbase[mt][r] + (long long)t * p.step_rows;
             float* g = p.gates + (row * 2 + d) * LG + u;
-            g[0] = ig;
-            g[256] = fg;
-            g[512] = gg;
-            g[768] = og;
-            p.cbuf[row * (2 * LH) + d * LH + u] = cn;
-            p.hcat[row * (2 * LH) + d * LH + u] = h;
+            g[0] = gi[mt][s][r];
+            g[256] = gf[mt][s][r];
+            g[512] = gg[mt][s][r];
+            g[768] = go[mt][s][r];
+            p.cbuf[row * (2 * LH) + d * LH + u] = c[mt][s][r];
+            p.hcat[row * (2 * LH) + d * LH + u] = hv[mt][s][r];
           }
         }
       }
@@ -241,6 +268,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(const ws_lstm_args p) {
       for (int r = 0; r < 4; ++r) dh[mt][s][r] = dc[mt][s][r] = 0.f;
 
   const f32x4* wp = reinterpret_cast<const f32x4*>(p.wpack) + (long long)(d * 8 + w) * (64 * 2 * 64) + lane;
+  const f32x4 b00 = wp[0], b01 = wp[64];  // fragment block ks4 = 0, resident
 
   // prefetched step inputs
   f32x4 n_i[MT][2], n_f[MT][2], n_g[MT][2], n_o[MT][2], n_c[MT][2], n_cp[MT][2], n_dh[MT][2];
@@ -278,7 +306,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(const ws_lstm_args p) {
         for (int r = 0; r < 4; ++r) {
           const float ig = n_i[mt][s][r], fg = n_f[mt][s][r], gg = n_g[mt][s][r], og = n_o[mt][s][r];
           const float dhv = n_dh[mt][s][r] + dh[mt][s][r];
-          const float tc = tanhf(n_c[mt][s][r]);
+          const float tc = fast_tanh(n_c[mt][s][r]);
           const float dov = dhv * tc;
           const float dcv = dc[mt][s][r] + dhv * og * (1.f - tc * tc);
           dc[mt][s][r] = dcv * fg;
@@ -315,8 +343,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(const ws_lstm_args p) {
         for (int r = 0; r < 4; ++r) dh[mt][s][r] = 0.f;
     const float* arow = dgl + (lq * 16 + l15) * DG_LD;
     f32x4 bcur[2], bnxt[2];
-    bcur[0] = wp[0];
-    bcur[1] = wp[64];
+    bcur[0] = b00;
+    bcur[1] = b01;
 #pragma unroll 4
     for (int ks4 = 0; ks4 < 64; ++ks4) {
       if (ks4 + 1 < 64) {

@@ -1,6 +1,7 @@
 """Typed Python wrappers over the C ABI (include/wesep_hip.h): torch tensors in, raw device
 pointers + the current HIP stream out.  No arithmetic happens here."""
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import numpy as np
@@ -9,6 +10,16 @@ import torch
 from . import _lib as L
 
 BIG = 1 << 30  # divisor meaning "never wraps" (flat row addressing)
+
+
+def gemm_mode() -> str:
+    """'bf16x3' (default): GEMM products as 3 bf16 MFMAs on hi/lo splits, fp32 accumulate;
+    'f32': exact fp32 MFMA.  Set WESEP_GEMM=f32 to force the exact kernels."""
+    return os.environ.get("WESEP_GEMM", "bf16x3")
+
+
+def _mode_bit(mode):
+    return 4 if (mode or gemm_mode()) == "bf16x3" else 0
 GN_EPS = float(np.finfo(np.float32).eps)  # bsrnn.py:23
 
 
@@ -48,7 +59,7 @@ def _p(t: Optional[torch.Tensor], off: int = 0):
 
 def gemm_nt(*, A, a_rows: Rows, M: int, C_out, c_rows: Rows, N=0, K=0, W=None, ldw=0, bias=None,
             R=None, T=None, stats=None, gamma=None, beta=None, stat_map: Optional[StatMap] = None,
-            act=0, groups=None, ngroups=0, max_n=0, vec=3, a_off=0, c_off=0, w_off=0):
+            act=0, groups=None, ngroups=0, max_n=0, vec=3, a_off=0, c_off=0, w_off=0, mode=None):
     for n, t in (("A", A), ("W", W), ("bias", bias), ("C", C_out), ("R", R), ("T", T),
                  ("stats", stats), ("gamma", gamma), ("beta", beta)):
         _chk(t, n)
@@ -62,7 +73,7 @@ def gemm_nt(*, A, a_rows: Rows, M: int, C_out, c_rows: Rows, N=0, K=0, W=None, l
     sm = stat_map or StatMap(1, 0, 1, 0, 0)
     a.st_div1, a.st_m1, a.st_div2, a.st_m2, a.st_base = sm
     a.M, a.N, a.K, a.ldw = M, N, K, ldw
-    a.act, a.ngroups, a.max_n, a.vec = act, ngroups, max_n, vec
+    a.act, a.ngroups, a.max_n, a.vec = act, ngroups, max_n, vec | _mode_bit(mode)
     L.check(L.lib().ws_gemm_nt(C.byref(a), L.stream_ptr()), "ws_gemm_nt")
 
 
@@ -78,7 +89,7 @@ def gemm_tn(*, G, g_rows: Rows, A, a_rows: Rows, M: int, slab, slab_stride: int,
             rows_per_split: int, Nn=0, Kk=0, bslab=None, bslab_stride=0, out_off=0, bout_off=0,
             stats=None, gamma=None, beta=None, stat_map: Optional[StatMap] = None,
             shift_rows=0, seq_div=1, seq_len=1, groups=None, ngroups=0, max_n=0, max_k=0, vec=1,
-            g_off=0, a_off=0):
+            g_off=0, a_off=0, mode=None):
     for n, t in (("G", G), ("A", A), ("slab", slab), ("bslab", bslab), ("stats", stats),
                  ("gamma", gamma), ("beta", beta)):
         _chk(t, n)
@@ -93,7 +104,7 @@ def gemm_tn(*, G, g_rows: Rows, A, a_rows: Rows, M: int, slab, slab_stride: int,
     a.slab_stride, a.bslab_stride, a.out_off, a.bout_off = slab_stride, bslab_stride, out_off, bout_off
     a.M, a.Nn, a.Kk, a.rows_per_split, a.nsplit = M, Nn, Kk, rows_per_split, nsplit
     a.shift_rows, a.seq_div, a.seq_len = shift_rows, seq_div, seq_len
-    a.ngroups, a.max_n, a.max_k, a.vec = ngroups, max_n, max_k, vec
+    a.ngroups, a.max_n, a.max_k, a.vec = ngroups, max_n, max_k, vec | _mode_bit(mode)
     L.check(L.lib().ws_gemm_tn(C.byref(a), L.stream_ptr()), "ws_gemm_tn")
 
 

@@ -29,8 +29,12 @@ def _need_cuda(t, who):
 
 
 def _lstm_mtiles(nseq: int) -> int:
+    """16-sequence MFMA row tiles per workgroup.  2 halves the per-step L2 stream of W_hh per
+    sequence; only worth it once 32-sequence workgroups still cover all 256 CUs (both dirs)."""
     env = os.environ.get("WESEP_LSTM_MTILES")
-    return int(env) if env else 1
+    if env:
+        return int(env)
+    return 2 if nseq >= 8192 else 1
 
 
 def _reduce_new(slab, nsplit, stride, shape):
