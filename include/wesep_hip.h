@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 1
+#define WS_ABI_VERSION 2
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -155,13 +155,17 @@ typedef struct ws_lstm_args {
   const float* dhcat;   /* bwd only: dL/dhcat [P][2H]                         */
   const float* wpack;   /* ws_lstm_pack output for this pass (fwd or bwd)     */
   long long sq_s1, sq_s2, step_rows;
-  int nseq, sq_div, L, mtiles; /* mtiles: 16-sequence MFMA row tiles per workgroup (1 or 2) */
+  int nseq, sq_div, L, mode;   /* WS_LSTM_* below; must match the mode wpack was packed with */
 } ws_lstm_args;
+#define WS_LSTM_F32_MT1 1 /* exact-fp32 MFMA, 16 sequences per workgroup                       */
+#define WS_LSTM_F32_MT2 2 /* exact-fp32 MFMA, 32 sequences per workgroup                       */
+#define WS_LSTM_BF16X3 3  /* split-bf16 (hi/lo, 3 bf16 MFMAs per product, fp32 accumulate), 32 */
 #define WS_LSTM_H 256
 #define WS_LSTM_PACK_FLOATS (2 * 4 * WS_LSTM_H * WS_LSTM_H) /* per pass, both directions */
-/* Packs weight_hh_l0 / _reverse [4H][H] into MFMA B-fragment order for the fwd and bwd pass. */
+/* Packs weight_hh_l0 / _reverse [4H][H] into MFMA fragment order for the fwd and bwd pass
+ * (fp32 for WS_LSTM_F32_*, bf16 hi/lo pairs for WS_LSTM_BF16X3; same byte size).           */
 int ws_lstm_pack(const float* whh_f, const float* whh_r, float* pack_fwd, float* pack_bwd,
-                 void* stream);
+                 int mode, void* stream);
 int ws_lstm_fwd(const ws_lstm_args* a, void* stream);
 /* On exit gates holds dL/d(pre-activation gates).                                           */
 int ws_lstm_bwd(const ws_lstm_args* a, void* stream);

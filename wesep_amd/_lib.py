@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libwesep_hip.so")
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
+ABI_VERSION = 2
+LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3 = 1, 2, 3
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
 _p = C.c_void_p
@@ -47,7 +49,7 @@ class GroupsGeom(C.Structure):
 class LstmArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "dhcat", "wpack")] + \
                [(n, _ll) for n in ("sq_s1", "sq_s2", "step_rows")] + \
-               [(n, _i) for n in ("nseq", "sq_div", "L", "mtiles")]
+               [(n, _i) for n in ("nseq", "sq_div", "L", "mode")]
 
 
 class Bands(C.Structure):
@@ -78,7 +80,7 @@ _SIGS = {
     "ws_gn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _p, _p]),
     "ws_gn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _p, _p]),
     "ws_gn_param_grad": (_i, [_p, _p, _p, C.POINTER(GroupsGeom), _i, _p, _p]),
-    "ws_lstm_pack": (_i, [_p, _p, _p, _p, _p]),
+    "ws_lstm_pack": (_i, [_p, _p, _p, _p, _i, _p]),
     "ws_lstm_fwd": (_i, [C.POINTER(LstmArgs), _p]),
     "ws_lstm_bwd": (_i, [C.POINTER(LstmArgs), _p]),
     "ws_lstm_cat_ih": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
@@ -115,7 +117,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.ws_abi_version() != 1:
+        if l.ws_abi_version() != ABI_VERSION:
             raise WesepHipError("libwesep_hip.so ABI version mismatch; rebuild")
         _lib = l
     return _lib

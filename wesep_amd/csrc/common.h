@@ -31,6 +31,12 @@ void ws_prof_end(int kind, hipStream_t s);
 int ws_launch_gemm_nt_bf16(const ws_gemm_nt_args* a, dim3 grid, hipStream_t s);
 int ws_launch_gemm_tn_bf16(const ws_gemm_tn_args* a, dim3 grid, hipStream_t s);
 
+// ---- split-bf16 LSTM launchers (lstm_bf16.hip), selected by ws_lstm_args.mode ----------------
+int ws_launch_lstm_pack_bf16(const float* whh_f, const float* whh_r, float* pack_fwd, float* pack_bwd,
+                             hipStream_t s);
+int ws_launch_lstm_fwd_bf16(const ws_lstm_args* a, hipStream_t s);
+int ws_launch_lstm_bwd_bf16(const ws_lstm_args* a, hipStream_t s);
+
 // ---- device helpers -----------------------------------------------------------
 __device__ __forceinline__ float ws_wave_sum(float v) {
 #pragma unroll

@@ -78,8 +78,13 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh_f, const float* _
 }
 
 extern "C" int ws_lstm_pack(const float* whh_f, const float* whh_r, float* pack_fwd,
-                            float* pack_bwd, void* stream) {
+                            float* pack_bwd, int mode, void* stream) {
   WS_REQUIRE(whh_f && whh_r && pack_fwd && pack_bwd, "ws_lstm_pack: null pointer");
+  WS_REQUIRE(mode >= WS_LSTM_F32_MT1 && mode <= WS_LSTM_BF16X3, "ws_lstm_pack: bad mode %d", mode);
+  if (mode == WS_LSTM_BF16X3) {
+    ws_launch_lstm_pack_bf16(whh_f, whh_r, pack_fwd, pack_bwd, (hipStream_t)stream);
+    return ws_check_launch("ws_lstm_pack");
+  }
   hipLaunchKernelGGL(lstm_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, whh_f, whh_r,
                      pack_fwd, pack_bwd);
   return ws_check_launch("ws_lstm_pack");
@@ -372,7 +377,8 @@ static int lstm_check(const ws_lstm_args* a, bool bwd, const char* who) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->wpack, "%s: null pointer", who);
   WS_REQUIRE(!bwd || a->dhcat, "%s: null dhcat", who);
   WS_REQUIRE(a->nseq > 0 && a->L > 0 && a->sq_div > 0, "%s: bad nseq/L/sq_div", who);
-  WS_REQUIRE(a->mtiles == 1 || a->mtiles == 2, "%s: mtiles must be 1 or 2", who);
+  WS_REQUIRE((a->mode & 255) >= WS_LSTM_F32_MT1 && (a->mode & 255) <= WS_LSTM_BF16X3, "%s: bad mode %d", who,
+             a->mode);
   return WS_OK;
 }
 
@@ -380,10 +386,12 @@ extern "C" int ws_lstm_fwd(const ws_lstm_args* a, void* stream) {
   int rc = lstm_check(a, false, "ws_lstm_fwd");
   if (rc != WS_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int per = 16 * a->mtiles;
+  const int per = 16 * a->mode;
   dim3 grid((a->nseq + per - 1) / per, 2), block(512);
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
-  if (a->mtiles == 1)
+  if ((a->mode & 255) == WS_LSTM_BF16X3)
+    ws_launch_lstm_fwd_bf16(a, s);
+  else if (a->mode == WS_LSTM_F32_MT1)
     hipLaunchKernelGGL((lstm_fwd_kernel<1>), grid, block, 0, s, *a);
   else
     hipLaunchKernelGGL((lstm_fwd_kernel<2>), grid, block, 0, s, *a);
@@ -395,10 +403,12 @@ extern "C" int ws_lstm_bwd(const ws_lstm_args* a, void* stream) {
   int rc = lstm_check(a, true, "ws_lstm_bwd");
   if (rc != WS_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int per = 16 * a->mtiles;
+  const int per = 16 * a->mode;
   dim3 grid((a->nseq + per - 1) / per, 2), block(512);
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
-  if (a->mtiles == 1)
+  if ((a->mode & 255) == WS_LSTM_BF16X3)
+    ws_launch_lstm_bwd_bf16(a, s);
+  else if (a->mode == WS_LSTM_F32_MT1)
     hipLaunchKernelGGL((lstm_bwd_kernel<1>), grid, block, 0, s, *a);
   else
     hipLaunchKernelGGL((lstm_bwd_kernel<2>), grid, block, 0, s, *a);

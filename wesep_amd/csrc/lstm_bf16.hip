@@ -1,0 +1,422 @@
+// Split-bf16 ("bf16x3") bidirectional LSTM recurrence for gfx950 (nn.LSTM inside ResRNN,
+// wesep/models/bsrnn.py:27-33,40): fp32 operands are carried as hi = bf16(x), lo = bf16(x - hi)
+// and every product is  W_hi*h_hi + W_lo*h_hi + W_hi*h_lo  on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation (the dropped lo*lo term is <= 2^-16 relative); 16x the fp32-MFMA rate per
+// instruction, 5.3x per fp32-equivalent product.
+//
+// The product is computed TRANSPOSED:  G^T[gate col][seq] = W_hh[gate col][k] * h^T[k][seq].
+//   * A operand = weight fragments, pre-split and pre-ordered once per layer by
+//     ws_lstm_pack(mode 3); they cannot live in a CU (1 MB per direction), so each wave streams
+//     its 128 KB slice from the XCD's L2 every step through a 2-slot register ring that never
+//     drains across step boundaries (the stream is the same every step).
+//   * B operand = h_{t-1} (fwd) / d(gates) (bwd) of the workgroup's 32 sequences, bf16 hi/lo in
+//     LDS, one ds_read_b128 per fragment, row stride = 4 banks mod 64 -> conflict-free.
+//   * D: lane = one sequence (lane & 31), registers = 16 hidden units in 4 runs of 4 consecutive
+//     units; wave w owns units [32w, 32w+32) of all four gates, so the cell update is lane-local
+//     and every global load/store of gates / c / h is a 16-byte vector per lane.
+// Sequences are columns of the MFMA, so they cannot contaminate each other; a padded lane simply
+// duplicates the last valid sequence of its workgroup (same wave, same instruction, same address,
+// same value), which keeps the step body free of branches -- a single basic block, so the
+// compiler's s_waitcnt counting stays exact and the one-step-ahead HBM prefetches never drain.
+//
+// Per step a 32-sequence workgroup needs 1 MB from L2 (~7.5 us at the per-CU L1 fill rate) against
+// ~5 us of MFMA: the kernel is L2-stream bound in the time view, by design -- see DESIGN.md.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define LH WS_LSTM_H  // 256
+#define LG (4 * LH)   // 1024
+#define SQ 32         // sequences per workgroup (MFMA N)
+#define HROW 264      // bf16 per LDS row of h      (256 + 8: 528 B = 4 banks mod 64)
+#define DROW 1032     // bf16 per LDS row of dgates (1024 + 8: 2064 B = 4 banks mod 64)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Weight stream: raw buffer loads (SGPR descriptor + SGPR step offset + one VGPR lane offset), so the
+// stream costs no 64-bit VGPR address arithmetic.  `soff` carries an opaque zero so the compiler
+// cannot see that the addresses repeat every step (hoisting 128 fragments out of the loop = spills).
+__device__ __forceinline__ bf16x8 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) {
+  const float ax = fabsf(x);
+  const float e = __expf(-2.f * ax);  // in (0, 1]: no overflow
+  const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+  return copysignf(t, x);
+}
+
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi[j] = (__bf16)v[j];
+    lo[j] = (__bf16)(v[j] - (float)hi[j]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing (16-byte units of 8 bf16; `lane` = the MFMA lane that will load the unit)
+//   fwd: unit ((((d*8 + w)*16 + ks)*4 + g)*2 + part)*64 + lane, element j
+//          = part( W_hh[d][ g*256 + 32w + (lane&31) ][ 16ks + 8(lane>>5) + j ] )
+//   bwd: unit (((d*8 + w)*64 + ks)*2 + part)*64 + lane, element j
+//          = part( W_hh[d][ 16ks + 8(lane>>5) + j ][ 32w + (lane&31) ] )
+// ---------------------------------------------------------------------------------------------
+__global__ void lstm_pack_bf16_kernel(const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                      __bf16* __restrict__ pf, __bf16* __restrict__ pb) {
+  const int total = 2 * LG * LH;  // weights per pass
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    {
+      int r = idx;
+      const int j = r & 7; r >>= 3;
+      const int lane = r & 63; r >>= 6;
+      const int g = r & 3; r >>= 2;
+      const int ks = r & 15; r >>= 4;
+      const int w = r & 7; r >>= 3;
+      const int d = r;
+      const float* W = d ? whh_r : whh_f;
+      const int row = g * 256 + 32 * w + (lane & 31);
+      const int k = 16 * ks + 8 * (lane >> 5) + j;
+      const float v = W[row * LH + k];
+      const __bf16 hi = (__bf16)v;
+      const long long unit = ((((long long)(d * 8 + w) * 16 + ks) * 4 + g) * 2) * 64 + lane;
+      pf[unit * 8 + j] = hi;
+      pf[(unit + 64) * 8 + j] = (__bf16)(v - (float)hi);
+    }
+    {
+      int r = idx;
+      const int j = r & 7; r >>= 3;
+      const int lane = r & 63; r >>= 6;
+      const int ks = r & 63; r >>= 6;
+      const int w = r & 7; r >>= 3;
+      const int d = r;
+      const float* W = d ? whh_r : whh_f;
+      const int row = 16 * ks + 8 * (lane >> 5) + j;  // gate column = contraction index
+      const int u = 32 * w + (lane & 31);
+      const float v = W[row * LH + u];
+      const __bf16 hi = (__bf16)v;
+      const long long unit = (((long long)(d * 8 + w) * 64 + ks) * 2) * 64 + lane;
+      pb[unit * 8 + j] = hi;
+      pb[(unit + 64) * 8 + j] = (__bf16)(v - (float)hi);
+    }
+  }
+}
+
+int ws_launch_lstm_pack_bf16(const float* whh_f, const float* whh_r, float* pack_fwd, float* pack_bwd,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(lstm_pack_bf16_kernel, dim3(512), dim3(256), 0, s, whh_f, whh_r,
+                     reinterpret_cast<__bf16*>(pack_fwd), reinterpret_cast<__bf16*>(pack_bwd));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward recurrence
+// ---------------------------------------------------------------------------------------------
+// DBG (probe builds only, mode bits 8..10): 1 = skip global stores, 2 = skip the x-projection /
+// step-input prefetch, 4 = skip the weight-stream refills.  DBG = 0 is the product kernel.
+template <int DBG>
+__global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 hl[2][2][SQ * HROW];  // [buf][part][seq][k] 66 KB
+  __shared__ __attribute__((aligned(16))) float cl[SQ * (LH + 4)];     // cell state [seq][unit] 33 KB
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = p.L;
+
+  {  // h_{-1} = 0
+    uint32_t* z = reinterpret_cast<uint32_t*>(&hl[0][0][0]);
+    for (int i = tid; i < 2 * SQ * HROW / 2; i += 512) z[i] = 0u;
+  }
+  const int ss = min((int)blockIdx.x * SQ + l31, p.nseq - 1);  // padded lanes duplicate the last sequence
+  const long long rowbase = (long long)(ss / p.sq_div) * p.sq_s1 + (long long)(ss % p.sq_div) * p.sq_s2;
+  const int ubase = 32 * w + 4 * half;  // unit of register 4j + r: ubase + 8j + r
+
+  float* cme = &cl[l31 * (LH + 4) + ubase];  // this lane's 4 runs of 4 units: cme + 8j (private)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(cme + 8 * j) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // weight stream: per k-step 8 fragments (4 gates x {hi, lo}), 1 KB each per wave
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.wpack) + (long long)(d * 8 + w) * (16 * 8 * 64 * 4), 0, 16 * 8 * 1024, 0x00020000);
+  const int wlane = lane * 16;
+  bf16x8 wr[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
+
+  // x-projection (+biases) of the next step, prefetched one step ahead
+  f32x4 xg[4][4];  // [gate][run]
+  {
+    const int t0 = d == 0 ? 0 : L - 1;
+    const float* g = p.gates + ((rowbase + (long long)t0 * p.step_rows) * 2 + d) * LG + ubase;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xg[gi][j] = *reinterpret_cast<const f32x4*>(g + gi * 256 + 8 * j);
+  }
+  __syncthreads();
+
+  for (int step = 0; step < L; ++step) {
+    const int t = d == 0 ? step : L - 1 - step;
+    const int cur = step & 1;
+    int zo = 0;
+    asm volatile("" : "+s"(zo));
+    const __bf16* hhi = &hl[cur][0][l31 * HROW + 8 * half];
+    const __bf16* hlo = &hl[cur][1][l31 * HROW + 8 * half];
+    f32x16 acc[4];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int s = ks & 1;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hhi + 16 * ks);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(hlo + 16 * ks);
+      if (ks == 0) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g], bh, zero);
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g], bh, acc[g]);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g + 1], bh, acc[g]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g], bl, acc[g]);
+      // refill this slot with k-step ks+2 (wraps into the next step: the stream never drains)
+      const int kn = (ks + 2) & 15;
+      if (!(DBG & 4)) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+          wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the k-steps in program order: loads stay 2 k-steps ahead
+    }
+
+    // cell update, lane-local; global traffic as 16-byte vectors
+    const long long row = rowbase + (long long)t * p.step_rows;
+    float* gout = p.gates + (row * 2 + d) * LG + ubase;
+    float* cout = p.cbuf + row * (2 * LH) + d * LH + ubase;
+    float* hout = p.hcat + row * (2 * LH) + d * LH + ubase;
+    const int sn = min(step + 1, L - 1);  // last step: harmless reload of its own row
+    const int tn = d == 0 ? sn : L - 1 - sn;
+    const float* gnext = p.gates + ((rowbase + (long long)tn * p.step_rows) * 2 + d) * LG + ubase;
+    __bf16* nhi = &hl[cur ^ 1][0][l31 * HROW + ubase];
+    __bf16* nlo = &hl[cur ^ 1][1][l31 * HROW + ubase];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 pre[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pre[g][r] = acc[g][4 * j + r] + xg[g][j][r];
+      // next step's x-projection into the registers just consumed
+      if (!(DBG & 2)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xg[g][j] = *reinterpret_cast<const f32x4*>(gnext + g * 256 + 8 * j);
+      }
+      f32x4 vi, vf, vg, vo, vc, vh;
+      const f32x4 cold = *reinterpret_cast<const f32x4*>(cme + 8 * j);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ig = fsig(pre[0][r]);
+        const float fg = fsig(pre[1][r]);
+        const float gg = ftanh(pre[2][r]);
+        const float og = fsig(pre[3][r]);
+        const float cn = fg * cold[r] + ig * gg;
+        vi[r] = ig;
+        vf[r] = fg;
+        vg[r] = gg;
+        vo[r] = og;
+        vc[r] = cn;
+        vh[r] = og * ftanh(cn);
+      }
+      bf16x4 h_hi, h_lo;
+      split4(vh, h_hi, h_lo);
+      *reinterpret_cast<bf16x4*>(nhi + 8 * j) = h_hi;
+      *reinterpret_cast<bf16x4*>(nlo + 8 * j) = h_lo;
+      *reinterpret_cast<f32x4*>(cme + 8 * j) = vc;
+      if (!(DBG & 1) || step == L - 1) {
+        *reinterpret_cast<f32x4*>(gout + 8 * j) = vi;
+        *reinterpret_cast<f32x4*>(gout + 256 + 8 * j) = vf;
+        *reinterpret_cast<f32x4*>(gout + 512 + 8 * j) = vg;
+        *reinterpret_cast<f32x4*>(gout + 768 + 8 * j) = vo;
+        *reinterpret_cast<f32x4*>(cout + 8 * j) = vc;
+        *reinterpret_cast<f32x4*>(hout + 8 * j) = vh;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one run at a time: bounds the live temporaries
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward recurrence (BPTT): walks the steps in the reverse of the forward order.
+//   dh_{t-1}^T[unit][seq] = W_hh^T[unit][gate col] * dgates_t^T[gate col][seq]   (K = 1024)
+// ---------------------------------------------------------------------------------------------
+template <int DBG>
+__global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 dgl[2][SQ * DROW];  // [part][seq][gate col] 129 KB
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = p.L;
+  const int ss = min((int)blockIdx.x * SQ + l31, p.nseq - 1);  // padded lanes duplicate the last sequence
+  const long long rowbase = (long long)(ss / p.sq_div) * p.sq_s1 + (long long)(ss % p.sq_div) * p.sq_s2;
+  const int ubase = 32 * w + 4 * half;
+  const long long prev_rows = (d == 0 ? -1 : 1) * p.step_rows;  // row offset of the forward-previous step
+
+  // weight stream: per k-step 2 fragments (hi, lo); ring slots hold 4 k-steps
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.wpack) + (long long)(d * 8 + w) * (64 * 2 * 64 * 4), 0, 64 * 2 * 1024, 0x00020000);
+  const int wlane = lane * 16;
+  bf16x8 wr[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
+
+  f32x4 n_i[4], n_f[4], n_g[4], n_o[4], n_dh[4], n_cp[4], c_cur[4], dc[4];  // [run]
+  f32x16 dhr;
+  const f32x4 zero4v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dc[j] = zero4v;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dhr[i] = 0.f;
+
+  auto load4 = [&](f32x4* dst, const float* src, int j) { dst[j] = *reinterpret_cast<const f32x4*>(src); };
+  // inputs of step `t` for register run j (c_cur is carried: c_t = the previous step's c_{prev})
+  auto load_step = [&](int t, int j) {
+    const long long row = rowbase + (long long)t * p.step_rows;
+    const float* g = p.gates + (row * 2 + d) * LG + ubase + 8 * j;
+    load4(n_i, g, j);
+    load4(n_f, g + 256, j);
+    load4(n_g, g + 512, j);
+    load4(n_o, g + 768, j);
+    const long long hc = row * (2 * LH) + d * LH + ubase + 8 * j;
+    load4(n_dh, p.dhcat + hc, j);
+    // c_{t-1}; at the sequence start the row is clamped and the value is masked at its use
+    const bool has_prev = d == 0 ? (t > 0) : (t < L - 1);
+    load4(n_cp, p.cbuf + hc + (has_prev ? prev_rows : 0) * (2 * LH), j);
+  };
+  {
+    const int t0 = d == 0 ? L - 1 : 0;
+    const long long row = rowbase + (long long)t0 * p.step_rows;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      load_step(t0, j);
+      load4(c_cur, p.cbuf + row * (2 * LH) + d * LH + ubase + 8 * j, j);
+    }
+  }
+
+  for (int step = 0; step < L; ++step) {
+    const int t = d == 0 ? L - 1 - step : step;
+    const int sn = min(step + 1, L - 1);  // last step: harmless reload of its own row
+    const int tn = d == 0 ? L - 1 - sn : sn;
+    const bool has_prev = d == 0 ? (t > 0) : (t < L - 1);  // uniform
+    int zo = 0;  // see wload()
+    asm volatile("" : "+s"(zo));
+    const long long row = rowbase + (long long)t * p.step_rows;
+    float* gout = p.gates + (row * 2 + d) * LG + ubase;
+    __bf16* dhi = &dgl[0][l31 * DROW + ubase];
+    __bf16* dlo = &dgl[1][l31 * DROW + ubase];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 pi, pf, pg, po;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ig = n_i[j][r], fg = n_f[j][r], gg = n_g[j][r], og = n_o[j][r];
+        const float dhv = n_dh[j][r] + dhr[4 * j + r];
+        const float tc = ftanh(c_cur[j][r]);
+        const float dov = dhv * tc;
+        const float dcv = dc[j][r] + dhv * og * (1.f - tc * tc);
+        dc[j][r] = dcv * fg;
+        pi[r] = dcv * gg * ig * (1.f - ig);
+        pf[r] = dcv * (has_prev ? n_cp[j][r] : 0.f) * fg * (1.f - fg);
+        pg[r] = dcv * ig * (1.f - gg * gg);
+        po[r] = dov * og * (1.f - og);
+      }
+      c_cur[j] = n_cp[j];
+      if (!(DBG & 1) || step == L - 1) {
+        *reinterpret_cast<f32x4*>(gout + 8 * j) = pi;
+        *reinterpret_cast<f32x4*>(gout + 256 + 8 * j) = pf;
+        *reinterpret_cast<f32x4*>(gout + 512 + 8 * j) = pg;
+        *reinterpret_cast<f32x4*>(gout + 768 + 8 * j) = po;
+      }
+      bf16x4 hi, lo;
+      split4(pi, hi, lo);
+      *reinterpret_cast<bf16x4*>(dhi + 8 * j) = hi;
+      *reinterpret_cast<bf16x4*>(dlo + 8 * j) = lo;
+      split4(pf, hi, lo);
+      *reinterpret_cast<bf16x4*>(dhi + 256 + 8 * j) = hi;
+      *reinterpret_cast<bf16x4*>(dlo + 256 + 8 * j) = lo;
+      split4(pg, hi, lo);
+      *reinterpret_cast<bf16x4*>(dhi + 512 + 8 * j) = hi;
+      *reinterpret_cast<bf16x4*>(dlo + 512 + 8 * j) = lo;
+      split4(po, hi, lo);
+      *reinterpret_cast<bf16x4*>(dhi + 768 + 8 * j) = hi;
+      *reinterpret_cast<bf16x4*>(dlo + 768 + 8 * j) = lo;
+      if (!(DBG & 2)) load_step(tn, j);  // into the registers just consumed
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+
+    const __bf16* bhi = &dgl[0][l31 * DROW + 8 * half];
+    const __bf16* blo = &dgl[1][l31 * DROW + 8 * half];
+    f32x16 acc0;  // one accumulator: the other wave of the SIMD fills the dependent-issue gaps
+#pragma unroll
+    for (int ch = 0; ch < 16; ++ch) {
+      const int s = ch & 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ks = 4 * ch + q;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bhi + 16 * ks);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(blo + 16 * ks);
+        if (ks == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc0 = mfma32(wr[s][2 * q], bh, zero);
+        } else {
+          acc0 = mfma32(wr[s][2 * q], bh, acc0);
+        }
+        acc0 = mfma32(wr[s][2 * q + 1], bh, acc0);
+        acc0 = mfma32(wr[s][2 * q], bl, acc0);
+      }
+      const int cn = (ch + 2) & 15;  // wraps into the next step
+      if (!(DBG & 4)) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+          wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + cn * 8192 + (f >> 2) * 4096);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    dhr = acc0;
+    __syncthreads();
+  }
+}
+
+#define WS_DBG_DISPATCH(KERNEL)                                                     \
+  switch ((a->mode >> 8) & 7) {                                                     \
+    case 0: hipLaunchKernelGGL((KERNEL<0>), grid, block, 0, s, *a); break;          \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), grid, block, 0, s, *a); break;          \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), grid, block, 0, s, *a); break;          \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), grid, block, 0, s, *a); break;          \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, s, *a); break;          \
+    default: hipLaunchKernelGGL((KERNEL<7>), grid, block, 0, s, *a); break;         \
+  }
+
+int ws_launch_lstm_fwd_bf16(const ws_lstm_args* a, hipStream_t s) {
+  dim3 grid((a->nseq + SQ - 1) / SQ, 2), block(512);
+  WS_DBG_DISPATCH(lstm_fwd_bf16_kernel)
+  return 0;
+}
+
+int ws_launch_lstm_bwd_bf16(const ws_lstm_args* a, hipStream_t s) {
+  dim3 grid((a->nseq + SQ - 1) / SQ, 2), block(512);
+  WS_DBG_DISPATCH(lstm_bwd_bf16_kernel)
+  return 0;
+}

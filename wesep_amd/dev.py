@@ -189,11 +189,19 @@ class SeqMap(NamedTuple):
     L: int
 
 
-def lstm_pack(whh_f, whh_r, pack_fwd, pack_bwd):
+def lstm_mode(nseq: int) -> int:
+    """'bf16x3' (default): split-bf16 recurrence, 32 sequences per workgroup; WESEP_LSTM=f32 selects
+    the exact-fp32 MFMA kernels (32-sequence workgroups once they still cover the chip)."""
+    if os.environ.get("WESEP_LSTM", "bf16x3") == "bf16x3":
+        return L.LSTM_BF16X3
+    return L.LSTM_F32_MT2 if nseq >= 8192 else L.LSTM_F32_MT1
+
+
+def lstm_pack(whh_f, whh_r, pack_fwd, pack_bwd, mode=L.LSTM_BF16X3):
     for n, t in (("whh_f", whh_f), ("whh_r", whh_r), ("pack_fwd", pack_fwd), ("pack_bwd", pack_bwd)):
         _chk(t, n)
-    L.check(L.lib().ws_lstm_pack(_p(whh_f), _p(whh_r), _p(pack_fwd), _p(pack_bwd), L.stream_ptr()),
-            "ws_lstm_pack")
+    L.check(L.lib().ws_lstm_pack(_p(whh_f), _p(whh_r), _p(pack_fwd), _p(pack_bwd), mode,
+                                 L.stream_ptr()), "ws_lstm_pack")
 
 
 def lstm_cat_ih(wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, n_in, wcat, bcat):
@@ -203,23 +211,23 @@ def lstm_cat_ih(wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, n_in, wcat, bcat):
                                    n_in, _p(wcat), _p(bcat), L.stream_ptr()), "ws_lstm_cat_ih")
 
 
-def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mtiles, dhcat=None):
+def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None):
     for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("wpack", wpack), ("dhcat", dhcat)):
         _chk(t, n)
     a = L.LstmArgs()
     a.gates, a.cbuf, a.hcat, a.dhcat, a.wpack = _p(gates), _p(cbuf), _p(hcat), _p(dhcat), _p(wpack)
     a.sq_s1, a.sq_s2, a.step_rows = sm.s1, sm.s2, sm.step_rows
-    a.nseq, a.sq_div, a.L, a.mtiles = sm.nseq, sm.div, sm.L, mtiles
+    a.nseq, a.sq_div, a.L, a.mode = sm.nseq, sm.div, sm.L, mode
     return a
 
 
-def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mtiles=1):
-    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mtiles)
+def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3):
+    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode)
     L.check(L.lib().ws_lstm_fwd(C.byref(a), L.stream_ptr()), "ws_lstm_fwd")
 
 
-def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mtiles=1):
-    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mtiles, dhcat)
+def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3):
+    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat)
     L.check(L.lib().ws_lstm_bwd(C.byref(a), L.stream_ptr()), "ws_lstm_bwd")
 
 

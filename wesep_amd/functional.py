@@ -28,15 +28,6 @@ def _need_cuda(t, who):
         raise L.WesepHipError(f"{who}: wesep_amd has no CPU path; move the model and inputs to the GPU")
 
 
-def _lstm_mtiles(nseq: int) -> int:
-    """16-sequence MFMA row tiles per workgroup.  2 halves the per-step L2 stream of W_hh per
-    sequence; only worth it once 32-sequence workgroups still cover all 256 CUs (both dirs)."""
-    env = os.environ.get("WESEP_LSTM_MTILES")
-    if env:
-        return int(env)
-    return 2 if nseq >= 8192 else 1
-
-
 def _reduce_new(slab, nsplit, stride, shape):
     out = _empty(slab.device, *shape)
     dev.reduce_slabs(slab, nsplit, stride, int(np.prod(shape)), out)
@@ -82,12 +73,12 @@ class ResRNNFn(torch.autograd.Function):
         wcat, bcat = _empty(d, 2 * G4, N), _empty(d, 2 * G4)
         dev.lstm_cat_ih(wih_f.contiguous(), wih_r.contiguous(), bih_f, bhh_f, bih_r, bhh_r, N, wcat, bcat)
         pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
-        dev.lstm_pack(whh_f.contiguous(), whh_r.contiguous(), pack_f, pack_b)
+        mt = dev.lstm_mode(seq.nseq)
+        dev.lstm_pack(whh_f.contiguous(), whh_r.contiguous(), pack_f, pack_b, mt)
         gates = _empty(d, P, 2 * G4)
         dev.gemm_nt(A=z, a_rows=flat(N), M=P, N=2 * G4, K=N, W=wcat, ldw=N, bias=bcat, C_out=gates,
                     c_rows=flat(2 * G4), stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap)
         cbuf, hcat = _empty(d, P, 2 * H), _empty(d, P, 2 * H)
-        mt = _lstm_mtiles(seq.nseq)
         dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, mt)
         out = torch.empty_like(z)
         pw = proj_w.contiguous()
