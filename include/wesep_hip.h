@@ -160,6 +160,9 @@ typedef struct ws_lstm_args {
 #define WS_LSTM_F32_MT1 1 /* exact-fp32 MFMA, 16 sequences per workgroup                       */
 #define WS_LSTM_F32_MT2 2 /* exact-fp32 MFMA, 32 sequences per workgroup                       */
 #define WS_LSTM_BF16X3 3  /* split-bf16 (hi/lo, 3 bf16 MFMAs per product, fp32 accumulate), 32 */
+#define WS_LSTM_BF16X3_BLK 4 /* as 3, but gates / cbuf / hcat / dhcat are in the blocked layout BL
+                                (below): block b = tile * L + step, tile = 32 consecutive sequences;
+                                the sq_* / step_rows fields are ignored                           */
 #define WS_LSTM_H 256
 #define WS_LSTM_PACK_FLOATS (2 * 4 * WS_LSTM_H * WS_LSTM_H) /* per pass, both directions */
 /* Packs weight_hh_l0 / _reverse [4H][H] into MFMA fragment order for the fwd and bwd pass
@@ -173,6 +176,76 @@ int ws_lstm_bwd(const ws_lstm_args* a, void* stream);
 int ws_lstm_cat_ih(const float* wih_f, const float* wih_r, const float* bih_f, const float* bhh_f,
                    const float* bih_r, const float* bhh_r, int n_in, float* wcat, float* bcat,
                    void* stream);
+
+/* ---- blocked layout BL and the GEMMs around the recurrence (bsrnn.py:38-46) ----------------
+ * BL(C): a [rows][C] matrix whose rows are grouped in blocks of 32; block b = tile * L + step
+ * holds the 32 consecutive sequences of an LSTM workgroup (`tile`) at one `step`;
+ *   element (b, slot i, column c)  at  b*32*C + ((c >> 2)*32 + i)*4 + (c & 3).
+ * Slots whose sequence index tile*32 + i >= nseq are padding: producers write zeros there.
+ * ws_seqmap maps a slot to its position (row) in the plain Z-layout tensors:
+ *   pos = (seq / sq_div) * sq_s1 + (seq % sq_div) * sq_s2 + step * step_rows.              */
+typedef struct ws_seqmap {
+  long long sq_s1, sq_s2, step_rows;
+  int nseq, sq_div, L, pad_;
+} ws_seqmap;
+
+/* out (bf16 pairs, N*K*4 bytes) <- W'[n][k] = trans ? W[k*ldw + n] : W[n*ldw + k], split into
+ * bf16 hi/lo and ordered for ws_gemm_p2b (order 0) or ws_gemm_b2p (order 1).                */
+int ws_pack_w(const float* W, int N, int K, long long ldw, int trans, int order, float* out,
+              void* stream);
+
+/* plain -> BL:  C[(b,i)][n] = sum_k pro(A[pos(b,i)][k]) * W'[n][k] + bias[n]   (K = 128, N % 64 == 0)
+ * pro = optional GroupNorm-on-load as in ws_gemm_nt (stat index computed from pos).  If A_bl is
+ * given, the (normalised) operand is also written in BL(K).  Replaces F.group_norm + the
+ * nn.LSTM input projection (bsrnn.py:39-40) and autograd's d(hcat) of proj (bsrnn.py:42-44). */
+typedef struct ws_gemm_p2b_args {
+  const float* A;
+  const float* Wpack;
+  const float* bias;
+  float* C;          /* BL(N) */
+  float* A_bl;       /* BL(K) or NULL */
+  const float* stats;
+  const float* gamma;
+  const float* beta;
+  ws_seqmap sm;
+  long long lda, st_m1, st_m2, st_base;
+  int st_div1, st_div2, N, K;
+} ws_gemm_p2b_args;
+int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream);
+
+/* BL -> plain:  C[pos(b,i)][n] = sum_k A[(b,i)][k] * W'[n][k] + bias[n] + R[pos][n]   (N = 128, K % 64 == 0)
+ * Replaces ResRNN.proj + residual (bsrnn.py:42-46) and autograd's d(normalised input).      */
+typedef struct ws_gemm_b2p_args {
+  const float* A;    /* BL(K) */
+  const float* Wpack;
+  const float* bias; /* or NULL */
+  const float* R;    /* plain, addressed like C, or NULL */
+  float* C;          /* plain rows, leading dimension ldc */
+  ws_seqmap sm;
+  long long ldc;
+  int N, K;
+} ws_gemm_b2p_args;
+int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream);
+
+/* BL x BL -> weight gradients, one pass over G:
+ *   slab[split][g][a] = sum_{b in split} sum_i G[(b,i)][g_off + g] * Acat[(b + shift,i)][a]
+ *   bslab[split][g]   = sum G[(b,i)][g_off + g]                                  (if bslab)
+ * Acat = columns [a0_off, a0_off + a0_cols) of A0 (BL(a0_width), shifted by a0_shift steps
+ * inside the tile, zero outside [0, L)) followed by a1_cols columns of A1 likewise.  All column
+ * counts are multiples of 128.  Replaces autograd's dW_ih / dW_hh / db (nn.LSTM) and dW_proj.  */
+typedef struct ws_gemm_tnb_args {
+  const float* G;
+  const float* A0;
+  const float* A1;   /* or NULL */
+  float* slab;
+  float* bslab;      /* or NULL */
+  long long slab_stride, bslab_stride;
+  int g_width, g_off, g_cols;
+  int a0_width, a0_off, a0_cols, a0_shift;
+  int a1_width, a1_off, a1_cols, a1_shift;
+  int nblk, L, nsplit, blocks_per_split;
+} ws_gemm_tnb_args;
+int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream);
 
 /* ---- STFT / iSTFT (torch.stft / torch.istft at bsrnn.py:309-316, 382-389) ---------------
  * n_fft = 512, hop = 128, periodic Hann, center + reflect pad.  Band-split spectrogram

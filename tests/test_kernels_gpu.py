@@ -224,11 +224,12 @@ def test_group_stats_and_gn_backward(view):
 # ----------------------------------------------------------------------------------------------
 # LSTM recurrence
 # ----------------------------------------------------------------------------------------------
-LSTM_TOL = {1: (1e-5, 2e-5), 2: (1e-5, 2e-5), 3: (4e-5, 8e-5)}   # mode 3 = split-bf16 (drops lo*lo)
+LSTM_TOL = {1: (1e-5, 2e-5), 2: (1e-5, 2e-5), 3: (4e-5, 8e-5), 4: (4e-5, 8e-5)}   # 3/4 = split-bf16 (drops lo*lo)
 
 
 @pytest.mark.parametrize("dims", [(2, 5, 11), (3, 7, 37)])
-@pytest.mark.parametrize("view,mt", [("time", 1), ("band", 1), ("time", 2), ("band", 2), ("time", 3), ("band", 3)])
+@pytest.mark.parametrize("view,mt", [("time", 1), ("band", 1), ("time", 2), ("band", 2), ("time", 3), ("band", 3),
+                                     ("time", 4), ("band", 4)])
 def test_lstm_fwd_bwd_vs_torch(view, mt, dims):
     from wesep_amd import dev, _lib as L
     from wesep_amd.functional import _view_maps
@@ -259,7 +260,14 @@ def test_lstm_fwd_bwd_vs_torch(view, mt, dims):
     dev.lstm_pack(lstm.weight_hh_l0.detach().to(d).contiguous(),
                   lstm.weight_hh_l0_reverse.detach().to(d).contiguous(), pf, pb, mt)
     cbuf, hcat = torch.zeros(P, 2 * H, device=d), torch.zeros(P, 2 * H, device=d)
+    blocked = mt == 4            # mode 4: the same kernels on the blocked layout BL
+    if blocked:
+        gates = dev.to_blocked(gates.view(P, 8 * H), seq)
+        nb = dev.bl_num_blocks(seq)
+        cbuf, hcat = torch.zeros(nb, 2 * H // 4, 32, 4, device=d), torch.zeros(nb, 2 * H // 4, 32, 4, device=d)
     dev.lstm_fwd(gates, cbuf, hcat, pf, seq, mt)
+    if blocked:
+        hcat_b, hcat = hcat, dev.from_blocked(hcat, seq, P)
     if view == "time":
         href = out.detach().reshape(R, K, Tf, 2 * H)
         dref = dout_seq.reshape(R, K, Tf, 2 * H)
@@ -268,7 +276,11 @@ def test_lstm_fwd_bwd_vs_torch(view, mt, dims):
         dref = dout_seq.reshape(R, Tf, K, 2 * H).permute(0, 2, 1, 3)
     assert rel(hcat.view(R, K, Tf, 2 * H), href) < tol_f
     dh = dref.contiguous().reshape(P, 2 * H).to(d)
-    dev.lstm_bwd(gates, cbuf, hcat, dh, pb, seq, mt)
+    if blocked:
+        dev.lstm_bwd(gates, cbuf, hcat_b, dev.to_blocked(dh, seq), pb, seq, mt)
+        gates = dev.from_blocked(gates, seq, P).view(P, 2, 4 * H)
+    else:
+        dev.lstm_bwd(gates, cbuf, hcat, dh, pb, seq, mt)
     # d gates_x -> dx = dgates @ W_ih (both dirs), dW_hh via autograd comparisons
     dg = gates.cpu()
     dx = dg[:, 0] @ lstm.weight_ih_l0.detach() + dg[:, 1] @ lstm.weight_ih_l0_reverse.detach()
@@ -420,3 +432,119 @@ def test_clip_adam_matches_reference_semantics():
             O.adam_l2_step_(pc[i], gdict[i], ms[i], vs[i], step, lr, weight_decay=1e-4)
             assert rel(pd[i], pc[i]) < 1e-6, (step, i)
             assert rel(pd[i].grad, gdict[i]) < 1e-6   # clipped in place like funcs.py:86-87
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMMs between the plain Z layout and the blocked layout BL (gemm_blk.hip)
+# ----------------------------------------------------------------------------------------------
+BLK_DIMS = [(2, 5, 11), (3, 32, 37)]   # (R, K, Tf): padded tiles in both views / full tiles in the time view
+
+
+def _blk_setup(view, dims):
+    from wesep_amd.functional import _view_maps
+    R, K, Tf = dims
+    N = 128
+    geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+    return R, K, Tf, N, R * K * Tf, geo, smap, seq
+
+
+@pytest.mark.parametrize("dims", BLK_DIMS)
+@pytest.mark.parametrize("view", ["time", "band"])
+@pytest.mark.parametrize("norm", [False, True])
+def test_gemm_p2b_vs_torch(view, dims, norm):
+    from wesep_amd import dev
+    d = _cuda()
+    R, K, Tf, N, P, geo, smap, seq = _blk_setup(view, dims)
+    g = torch.Generator().manual_seed(3)
+    Nout = 192
+    A, W, b = rnd(g, P, N), rnd(g, Nout, N, scale=0.1), rnd(g, Nout)
+    kw, An = {}, A
+    if norm:
+        stats = torch.stack([rnd(g, geo.ngroups) * 0.1, rnd(g, geo.ngroups).abs() + 0.5], 1).contiguous()
+        gamma, beta = rnd(g, N), rnd(g, N)
+        kw = dict(stats=stats.to(d), gamma=gamma.to(d), beta=beta.to(d), stat_map=smap)
+        m = torch.arange(P)
+        sidx = (m // smap.div1) * smap.m1 + (m % smap.div2) * smap.m2 + smap.base
+        An = (A - stats[sidx, 0:1]) * stats[sidx, 1:2] * gamma + beta
+    wp = torch.empty(Nout * N, device=d)
+    dev.pack_w(W.to(d), Nout, N, N, wp, order=0)
+    nb = dev.bl_num_blocks(seq)
+    outs = []
+    for _ in range(2):
+        C = torch.full((nb, 32 * Nout), float("nan"), device=d)
+        Ab = torch.full((nb, 32 * N), float("nan"), device=d)
+        dev.gemm_p2b(A=A.to(d), lda=N, sm=seq, Wpack=wp, N=Nout, C_out=C, bias=b.to(d), A_bl=Ab, **kw)
+        outs.append((C, Ab))
+    assert torch.equal(outs[0][0], outs[1][0])                      # deterministic
+    C, Ab = outs[0]
+    assert not torch.isnan(C).any() and not torch.isnan(Ab).any()   # padded slots are written (zeros)
+    ref = An.double() @ W.double().t() + b.double()
+    assert rel(dev.from_blocked(C.view(nb, Nout // 4, 32, 4), seq, P), ref) < 4e-5
+    assert rel(dev.from_blocked(Ab.view(nb, N // 4, 32, 4), seq, P), An) < 1e-6
+    assert torch.equal(C.view(nb, Nout // 4, 32, 4), dev.to_blocked(dev.from_blocked(C.view(nb, Nout // 4, 32, 4), seq, P), seq))
+
+
+@pytest.mark.parametrize("dims", BLK_DIMS)
+@pytest.mark.parametrize("view", ["time", "band"])
+@pytest.mark.parametrize("Kd", [512, 2048])
+def test_gemm_b2p_vs_torch(view, dims, Kd):
+    from wesep_amd import dev
+    d = _cuda()
+    R, K, Tf, N, P, geo, smap, seq = _blk_setup(view, dims)
+    g = torch.Generator().manual_seed(4)
+    A, W, b, Rr = rnd(g, P, Kd), rnd(g, N, Kd, scale=0.05), rnd(g, N), rnd(g, P, N)
+    wp = torch.empty(N * Kd, device=d)
+    dev.pack_w(W.to(d), N, Kd, Kd, wp, order=1)
+    Ab = dev.to_blocked(A.to(d), seq)
+    outs = []
+    for _ in range(2):
+        C = torch.full((P, N), float("nan"), device=d)
+        dev.gemm_b2p(A=Ab, K=Kd, sm=seq, Wpack=wp, C_out=C, ldc=N, bias=b.to(d), R=Rr.to(d))
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    ref = A.double() @ W.double().t() + b.double() + Rr.double()
+    assert rel(outs[0], ref) < 4e-5
+    # transposed packing (the data-gradient form): W'[n][k] = W2[k][n]
+    W2 = W.t().contiguous()                       # [Kd][N]
+    dev.pack_w(W2.to(d), N, Kd, N, wp, trans=True, order=1)
+    C = torch.empty(P, N, device=d)
+    dev.gemm_b2p(A=Ab, K=Kd, sm=seq, Wpack=wp, C_out=C, ldc=N)
+    assert rel(C, A.double() @ W.double().t()) < 4e-5
+
+
+@pytest.mark.parametrize("dims", BLK_DIMS)
+@pytest.mark.parametrize("view", ["time", "band"])
+def test_gemm_tnb_vs_torch(view, dims):
+    """[dW_ih | dW_hh] form: G column range, two A sources, the second shifted by one step."""
+    from wesep_amd import dev
+    d = _cuda()
+    R, K, Tf, N, P, geo, smap, seq = _blk_setup(view, dims)
+    g = torch.Generator().manual_seed(5)
+    GW, g_off, g_cols = 512, 256, 256
+    G, A0, A1 = rnd(g, P, GW), rnd(g, P, N), rnd(g, P, 512)
+    Gb, A0b, A1b = (dev.to_blocked(t.to(d), seq) for t in (G, A0, A1))
+    nb = dev.bl_num_blocks(seq)
+    for shift in (-1, 1):
+        ns, bps = dev.tnb_splits(nb, seq.L, (g_cols // 128) * 3)
+        slab, bslab = torch.empty(ns, g_cols * 384, device=d), torch.empty(ns, g_cols, device=d)
+        dev.gemm_tnb(G=Gb, g_width=GW, g_off=g_off, g_cols=g_cols, A0=A0b, a0_width=N, a0_off=0, a0_cols=N,
+                     A1=A1b, a1_width=512, a1_off=256, a1_cols=256, a1_shift=shift, nblk=nb, L_=seq.L,
+                     slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab)
+        out = slab.sum(0).view(g_cols, 384)
+        # reference: shift the A1 rows by one step inside each sequence
+        pos, valid = dev.bl_positions(seq, torch.device("cpu"))
+        nt = -(-seq.nseq // 32)
+        posv = pos.view(nt, seq.L, 32)
+        val = valid.view(nt, seq.L, 32)
+        A1s = torch.zeros(P, 256)
+        src = torch.roll(posv, shifts=-shift, dims=1)          # position of step + shift
+        ok = val.clone()
+        if shift == -1:
+            ok[:, 0] = False
+        else:
+            ok[:, -1] = False
+        A1s[posv[ok]] = A1[src[ok]][:, 256:512]
+        Gs = G[:, g_off:g_off + g_cols].double()
+        ref = torch.cat([Gs.t() @ A0.double(), Gs.t() @ A1s.double()], 1)
+        assert rel(out, ref) < 4e-5
+        assert rel(bslab.sum(0), Gs.sum(0)) < 1e-5

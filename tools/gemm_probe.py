@@ -57,3 +57,41 @@ probe_nt("xproj", P, 2048, 128, norm=True)
 probe_nt("proj", P, 128, 512, res=True)
 probe_nt("dhcat", P, 512, 128)
 probe_nt("dxn", P, 128, 2048)
+
+# ---- blocked-layout kernels (time view) -----------------------------------------------------
+from wesep_amd.functional import _view_maps  # noqa: E402
+
+for view in ("time", "band"):
+    _, smap, seq, _ = _view_maps(view, R, K, Tf, 128)
+    nb = dev.bl_num_blocks(seq)
+    z = torch.randn(P, 128, device=d)
+    for name, Nout in (("xproj", 2048), ("dhcat", 512)):
+        W = torch.randn(Nout, 128, device=d) * 0.05
+        wp = torch.empty(Nout * 128, device=d)
+        dev.pack_w(W, Nout, 128, 128, wp, order=0)
+        C1, Ab = torch.empty(nb, 32 * Nout, device=d), torch.empty(nb, 32 * 128, device=d)
+        t = timeit(lambda: dev.gemm_p2b(A=z, lda=128, sm=seq, Wpack=wp, N=Nout, C_out=C1, A_bl=Ab))
+        gb = (z.numel() + C1.numel() + Ab.numel()) * 4 / 1e9
+        print(f"p2b {view} {name}: {t:7.3f} ms  {gb / t * 1e3:7.1f} GB/s", flush=True)
+        del C1, Ab
+    for name, Kd in (("proj", 512), ("dxn", 2048)):
+        W = torch.randn(128, Kd, device=d) * 0.05
+        wp = torch.empty(128 * Kd, device=d)
+        dev.pack_w(W, 128, Kd, Kd, wp, order=1)
+        Ab = torch.randn(nb, 32 * Kd, device=d)
+        C1 = torch.empty(P, 128, device=d)
+        t = timeit(lambda: dev.gemm_b2p(A=Ab, K=Kd, sm=seq, Wpack=wp, C_out=C1, ldc=128, R=z))
+        gb = (Ab.numel() + 2 * C1.numel()) * 4 / 1e9
+        print(f"b2p {view} {name}: {t:7.3f} ms  {gb / t * 1e3:7.1f} GB/s", flush=True)
+        del Ab, C1
+    G = torch.randn(nb, 32 * 2048, device=d)
+    xn = torch.randn(nb, 32 * 128, device=d)
+    h = torch.randn(nb, 32 * 512, device=d)
+    ns, bps = dev.tnb_splits(nb, seq.L, 8 * 3)
+    slab, bslab = torch.empty(ns, 1024 * 384, device=d), torch.empty(ns, 1024, device=d)
+    t = timeit(lambda: dev.gemm_tnb(G=G, g_width=2048, g_off=0, g_cols=1024, A0=xn, a0_width=128, a0_off=0, a0_cols=128,
+                                    A1=h, a1_width=512, a1_off=0, a1_cols=256, a1_shift=-1, nblk=nb, L_=seq.L,
+                                    slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab))
+    gb = (G.numel() / 2 + xn.numel() + h.numel() / 2) * 4 / 1e9
+    print(f"tnb {view} dW(dir): {t:7.3f} ms  {gb / t * 1e3:7.1f} GB/s (unique bytes)  nsplit={ns}", flush=True)
+    del G, xn, h, slab

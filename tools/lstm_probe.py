@@ -34,7 +34,7 @@ def timeit(fn, n=2):
     return a.elapsed_time(b) / n
 
 
-modes = [int(m) for m in os.environ.get("PROBE_MODES", "3,259,515,1027,1795").split(",")]
+modes = [int(m) for m in os.environ.get("PROBE_MODES", "3,4,260,516,1028,1796").split(",")]
 for view in ("time", "band"):
     _, _, seq, _ = _view_maps(view, R, K, Tf, N)
     for mode in modes:

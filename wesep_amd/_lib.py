@@ -16,7 +16,7 @@ WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
 ABI_VERSION = 2
-LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3 = 1, 2, 3
+LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK = 1, 2, 3, 4
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
 _p = C.c_void_p
@@ -52,6 +52,28 @@ class LstmArgs(C.Structure):
                [(n, _i) for n in ("nseq", "sq_div", "L", "mode")]
 
 
+class SeqMapC(C.Structure):
+    _fields_ = [("sq_s1", _ll), ("sq_s2", _ll), ("step_rows", _ll), ("nseq", _i), ("sq_div", _i), ("L", _i), ("pad_", _i)]
+
+
+class GemmP2BArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("A", "Wpack", "bias", "C", "A_bl", "stats", "gamma", "beta")] + \
+               [("sm", SeqMapC)] + [(n, _ll) for n in ("lda", "st_m1", "st_m2", "st_base")] + \
+               [(n, _i) for n in ("st_div1", "st_div2", "N", "K")]
+
+
+class GemmB2PArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("A", "Wpack", "bias", "R", "C")] + [("sm", SeqMapC), ("ldc", _ll), ("N", _i), ("K", _i)]
+
+
+class GemmTNBArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("G", "A0", "A1", "slab", "bslab")] + \
+               [(n, _ll) for n in ("slab_stride", "bslab_stride")] + \
+               [(n, _i) for n in ("g_width", "g_off", "g_cols", "a0_width", "a0_off", "a0_cols", "a0_shift",
+                                  "a1_width", "a1_off", "a1_cols", "a1_shift", "nblk", "L", "nsplit",
+                                  "blocks_per_split")]
+
+
 class Bands(C.Structure):
     _fields_ = [("band_of_bin", _p), ("band_f0", _p), ("band_bw", _p), ("nband", _i), ("nbins", _i)]
 
@@ -84,6 +106,10 @@ _SIGS = {
     "ws_lstm_fwd": (_i, [C.POINTER(LstmArgs), _p]),
     "ws_lstm_bwd": (_i, [C.POINTER(LstmArgs), _p]),
     "ws_lstm_cat_ih": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "ws_pack_w": (_i, [_p, _i, _i, _ll, _i, _i, _p, _p]),
+    "ws_gemm_p2b": (_i, [C.POINTER(GemmP2BArgs), _p]),
+    "ws_gemm_b2p": (_i, [C.POINTER(GemmB2PArgs), _p]),
+    "ws_gemm_tnb": (_i, [C.POINTER(GemmTNBArgs), _p]),
     "ws_stft_bandsplit": (_i, [_p, _i, _i, C.POINTER(Bands), _p, _p]),
     "ws_mask_istft_frames": (_i, [_p, _p, _i, _i, C.POINTER(Bands), _p, _p]),
     "ws_istft_ola": (_i, [_p, _i, _i, _i, _p, _p]),

@@ -1,0 +1,486 @@
+// Split-bf16 GEMMs between the plain Z layout and the blocked layout BL (include/wesep_hip.h) --
+// the dense layers around the BLSTM recurrence of ResRNN (wesep/models/bsrnn.py:38-46) and their
+// gradients.  All are HBM-bound by construction (huge M = positions, small weights), so the design
+// goal is: every activation byte crosses HBM once, as part of a fully used, contiguous wave-level
+// access, and lands directly in MFMA fragment registers.
+//
+//   ws_gemm_p2b  plain rows -> BL   C[(b,i)][n] = sum_k pro(A[pos(b,i)][k]) W[n][k] + bias[n]
+//                (x-projection with GroupNorm-on-load; d(hcat) = dout Wp).  K = 128.
+//   ws_gemm_b2p  BL -> plain rows   C[pos(b,i)][n] = sum_k A[(b,i)][k] W[n][k] + bias[n] + R
+//                (projection + residual; d(xn) = dgates Wcat).  N = 128.
+//   ws_gemm_tnb  BL x BL -> weights out[g][a] = sum_(b,i) G[(b,i)][g] A[(b',i)][a]
+//                (dW_ih | dW_hh in one pass over dgates, dW_proj, bias gradients).
+//
+// BL(C): rows in blocks of 32 (block b = tile*L + step: the 32 sequences of an LSTM workgroup at
+// one step), element (b, i, c) at  b*32*C + ((c>>2)*32 + i)*4 + (c&3).  A 32-lane group that
+// moves 16 bytes per lane for consecutive slots i touches one contiguous 512-byte run; a
+// [32 slots x 128 columns] sub-block is one contiguous 16 KB.  Products are split-bf16 (hi/lo,
+// 3 MFMAs, fp32 accumulate) on v_mfma_f32_32x32x16_bf16; weights are pre-split and pre-ordered
+// into fragment order by ws_pack_w.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    hi[j] = (__bf16)v[j];
+    lo[j] = (__bf16)(v[j] - (float)hi[j]);
+  }
+}
+
+// position (row of the plain layout) of slot i of block b; `valid` false for padded slots
+__device__ __forceinline__ long long seq_pos(const ws_seqmap& sm, int b, int i, bool& valid) {
+  const int tile = b / sm.L, step = b - tile * sm.L;
+  const int seq = tile * 32 + i;
+  valid = seq < sm.nseq;
+  const int s = valid ? seq : sm.nseq - 1;
+  return (long long)(s / sm.sq_div) * sm.sq_s1 + (long long)(s % sm.sq_div) * sm.sq_s2 +
+         (long long)step * sm.step_rows;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: W'[n][k] = trans ? W[k*ldw + n] : W[n*ldw + k], split into bf16 hi/lo, in
+// 16-byte units of 8 consecutive k for the MFMA lane that will load them:
+//   element j of unit u*64 + lane = part( W'[32*nt + (lane&31)][16*ks + 8*(lane>>5) + j] )
+//   order 0 (p2b): u = (nt*(K/16) + ks)*2 + part      order 1 (b2p): u = (ks*(N/32) + nt)*2 + part
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_w_kernel(const float* __restrict__ W, int N, int K, long long ldw, int trans,
+                              int order, __bf16* __restrict__ out) {
+  const int nks = K / 16, nnt = N / 32;
+  const long long total = (long long)N * K;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    long long r = idx;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    int nt, ks;
+    if (order == 0) {
+      ks = r % nks;
+      nt = r / nks;
+    } else {
+      nt = r % nnt;
+      ks = r / nnt;
+    }
+    const int n = 32 * nt + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+    const float v = trans ? W[(long long)k * ldw + n] : W[(long long)n * ldw + k];
+    const __bf16 hi = (__bf16)v;
+    const long long u = (order == 0 ? ((long long)nt * nks + ks) : ((long long)ks * nnt + nt)) * 2;
+    out[(u * 64 + lane) * 8 + j] = hi;
+    out[((u + 1) * 64 + lane) * 8 + j] = (__bf16)(v - (float)hi);
+  }
+}
+
+extern "C" int ws_pack_w(const float* W, int N, int K, long long ldw, int trans, int order, float* out,
+                         void* stream) {
+  WS_REQUIRE(W && out && N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, "ws_pack_w: N %% 32, K %% 16 (N=%d K=%d)",
+             N, K);
+  WS_REQUIRE(order == 0 || order == 1, "ws_pack_w: order");
+  hipLaunchKernelGGL(pack_w_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, W, N, K, ldw, trans, order,
+                     reinterpret_cast<__bf16*>(out));
+  return ws_check_launch("ws_pack_w");
+}
+
+// ---------------------------------------------------------------------------------------------
+// p2b: one wave = one block (32 positions); its activation fragments (K = 128: 8 k-steps x
+// {hi, lo}) stay in registers for the whole sweep over N; weight tiles (2 x 32 columns = 32 KB of
+// fragments per stage) go global -> registers -> LDS once per workgroup and are read by all 8
+// waves.  Output orientation D[m = column][n = slot]: a lane holds 4 consecutive columns of its
+// slot = one 16-byte BL cell, 32 lanes = 512 contiguous bytes.
+// ---------------------------------------------------------------------------------------------
+#define P2B_K 128
+__global__ __launch_bounds__(512, 4) void gemm_p2b_kernel(const ws_gemm_p2b_args p) {
+  __shared__ __attribute__((aligned(16))) u32x4 wl[2][2048];  // 2 stages x 32 KB
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = ((p.sm.nseq + 31) / 32) * p.sm.L;
+  const int b = blockIdx.x * 8 + w;
+  const bool active = b < nblk;
+  const int bb = active ? b : nblk - 1;
+  bool valid;
+  const long long pos = seq_pos(p.sm, bb, i, valid);
+
+  // ---- activation fragments ---------------------------------------------------------------
+  bf16x8 xh[8], xl[8];
+  {
+    const float* arow = p.A + pos * p.lda;
+    float mean = 0.f, rstd = 1.f;
+    if (p.stats) {
+      const long long s = (pos / p.st_div1) * p.st_m1 + (pos % p.st_div2) * p.st_m2 + p.st_base;
+      mean = p.stats[2 * s];
+      rstd = p.stats[2 * s + 1];
+    }
+    float* eb = p.A_bl ? p.A_bl + (long long)bb * (32 * P2B_K) + i * 4 : nullptr;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k0 = 16 * ks + 8 * half;
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(arow + k0);
+      f32x4 v1 = *reinterpret_cast<const f32x4*>(arow + k0 + 4);
+      if (p.stats) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + k0), g1 = *reinterpret_cast<const f32x4*>(p.gamma + k0 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + k0), b1 = *reinterpret_cast<const f32x4*>(p.beta + k0 + 4);
+        v0 = (v0 - mean) * rstd * g0 + b0;
+        v1 = (v1 - mean) * rstd * g1 + b1;
+      }
+      if (!valid) {
+        v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        v1 = v0;
+      }
+      if (eb && active) {  // the (normalised) operand itself, in BL(K), for the weight-gradient pass
+        *reinterpret_cast<f32x4*>(eb + (k0 / 4) * 128) = v0;
+        *reinterpret_cast<f32x4*>(eb + (k0 / 4 + 1) * 128) = v1;
+      }
+      const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      split8(v, xh[ks], xl[ks]);
+    }
+  }
+
+  // ---- sweep over N in stages of 64 columns ---------------------------------------------------
+  const int nstage = p.N / 64;
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.Wpack);  // 2048 units of 16 B per stage
+  u32x4 wreg[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wreg[q] = wsrc[tid + 512 * q];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wl[0][tid + 512 * q] = wreg[q];
+  __syncthreads();
+  float* cblk = p.C + (long long)bb * 32 * p.N + i * 4;
+  for (int st = 0; st < nstage; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nstage) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wreg[q] = wsrc[(long long)(st + 1) * 2048 + tid + 512 * q];
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const u32x4* wt = &wl[cur][t2 * 1024 + lane];  // [ks][part][lane]
+      f32x16 acc;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, wt[(ks * 2) * 64]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, wt[(ks * 2 + 1) * 64]);
+        if (ks == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc = mfma32(ah, xh[ks], zero);
+        } else {
+          acc = mfma32(ah, xh[ks], acc);
+        }
+        acc = mfma32(al, xh[ks], acc);
+        acc = mfma32(ah, xl[ks], acc);
+      }
+      if (active) {
+        const int n0 = st * 64 + t2 * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + 8 * j + 4 * half;  // 4 consecutive columns = BL cell (n/4, i)
+          f32x4 v = {acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+          if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(cblk + (n / 4) * 128) = v;
+        }
+      }
+    }
+    if (st + 1 < nstage) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wl[cur ^ 1][tid + 512 * q] = wreg[q];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream) {
+  WS_REQUIRE(a && a->A && a->Wpack && a->C, "ws_gemm_p2b: null pointer");
+  WS_REQUIRE(a->K == P2B_K, "ws_gemm_p2b: K must be %d (got %d)", P2B_K, a->K);
+  WS_REQUIRE(a->N > 0 && a->N % 64 == 0, "ws_gemm_p2b: N %% 64 (N=%d)", a->N);
+  WS_REQUIRE(a->lda >= a->K && a->lda % 4 == 0, "ws_gemm_p2b: lda");
+  WS_REQUIRE(a->sm.nseq > 0 && a->sm.L > 0 && a->sm.sq_div > 0, "ws_gemm_p2b: bad sequence map");
+  WS_REQUIRE(!a->stats || (a->gamma && a->beta && a->st_div1 > 0 && a->st_div2 > 0), "ws_gemm_p2b: norm args");
+  const int nblk = ((a->sm.nseq + 31) / 32) * a->sm.L;
+  hipStream_t s = (hipStream_t)stream;
+  ws_prof_begin(WS_PROF_GEMM_NT, s);
+  hipLaunchKernelGGL(gemm_p2b_kernel, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
+  ws_prof_end(WS_PROF_GEMM_NT, s);
+  return ws_check_launch("ws_gemm_p2b");
+}
+
+// ---------------------------------------------------------------------------------------------
+// b2p: N = 128.  One wave = one block; activations come straight from BL into A-operand
+// fragments (lane = slot, 8 consecutive k = two 16-byte cells, each 512 contiguous bytes per 32
+// lanes) and are split in registers; weights (4 k-steps x 4 column tiles x {hi, lo} = 32 KB per
+// stage) are shared through LDS.  Output orientation D[m = slot][n = column]: a 32-lane group
+// writes one full 128-byte row segment per register.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args p) {
+  __shared__ __attribute__((aligned(16))) u32x4 wl[2][2048];
+  __shared__ long long posl[8][32];
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = ((p.sm.nseq + 31) / 32) * p.sm.L;
+  const int b = blockIdx.x * 8 + w;
+  const bool active = b < nblk;
+  const int bb = active ? b : nblk - 1;
+  {
+    bool valid;
+    const long long pos = seq_pos(p.sm, bb, i, valid);
+    if (half == 0) posl[w][i] = valid ? pos : -1;
+  }
+  const int K = p.K, nstage = K / 64;
+  // A-operand source: cell (quad, slot) of block bb; lane reads quads 4ks + 2half, +1
+  const float* ab = p.A + (long long)bb * 32 * K + i * 4 + 2 * half * 128;
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.Wpack);
+  u32x4 wreg[4];
+  f32x4 an[8];  // next stage's activations (4 k-steps x 2 cells)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wreg[q] = wsrc[tid + 512 * q];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    an[2 * ks] = *reinterpret_cast<const f32x4*>(ab + (4 * ks) * 128);
+    an[2 * ks + 1] = *reinterpret_cast<const f32x4*>(ab + (4 * ks + 1) * 128);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wl[0][tid + 512 * q] = wreg[q];
+  __syncthreads();
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (int st = 0; st < nstage; ++st) {
+    const int cur = st & 1;
+    f32x4 ac[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ac[q] = an[q];
+    if (st + 1 < nstage) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wreg[q] = wsrc[(long long)(st + 1) * 2048 + tid + 512 * q];
+      const float* a2 = ab + (long long)(st + 1) * 16 * 128;  // 16 quads per stage
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        an[2 * ks] = *reinterpret_cast<const f32x4*>(a2 + (4 * ks) * 128);
+        an[2 * ks + 1] = *reinterpret_cast<const f32x4*>(a2 + (4 * ks + 1) * 128);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float v[8] = {ac[2 * ks][0], ac[2 * ks][1], ac[2 * ks][2], ac[2 * ks][3],
+                          ac[2 * ks + 1][0], ac[2 * ks + 1][1], ac[2 * ks + 1][2], ac[2 * ks + 1][3]};
+      bf16x8 ah, al;
+      split8(v, ah, al);
+      const u32x4* wt = &wl[cur][ks * 512 + lane];  // [nt][part][lane]
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, wt[(nt * 2) * 64]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, wt[(nt * 2 + 1) * 64]);
+        acc[nt] = mfma32(ah, bh, acc[nt]);
+        acc[nt] = mfma32(al, bh, acc[nt]);
+        acc[nt] = mfma32(ah, bl, acc[nt]);
+      }
+    }
+    if (st + 1 < nstage) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wl[cur ^ 1][tid + 512 * q] = wreg[q];
+    }
+    __syncthreads();
+  }
+
+  if (active) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = nt * 32 + i;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const long long pos = posl[w][m];
+        if (pos >= 0) {
+          float v = acc[nt][r] + bv;
+          if (p.R) v += p.R[pos * p.ldc + n];
+          p.C[pos * p.ldc + n] = v;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream) {
+  WS_REQUIRE(a && a->A && a->Wpack && a->C, "ws_gemm_b2p: null pointer");
+  WS_REQUIRE(a->N == 128, "ws_gemm_b2p: N must be 128 (got %d)", a->N);
+  WS_REQUIRE(a->K > 0 && a->K % 64 == 0, "ws_gemm_b2p: K %% 64 (K=%d)", a->K);
+  WS_REQUIRE(a->ldc >= a->N, "ws_gemm_b2p: ldc");
+  WS_REQUIRE(a->sm.nseq > 0 && a->sm.L > 0 && a->sm.sq_div > 0, "ws_gemm_b2p: bad sequence map");
+  const int nblk = ((a->sm.nseq + 31) / 32) * a->sm.L;
+  hipStream_t s = (hipStream_t)stream;
+  ws_prof_begin(WS_PROF_GEMM_NT, s);
+  hipLaunchKernelGGL(gemm_b2p_kernel, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
+  ws_prof_end(WS_PROF_GEMM_NT, s);
+  return ws_check_launch("ws_gemm_b2p");
+}
+
+// ---------------------------------------------------------------------------------------------
+// tnb: out[g][a] = sum over blocks b in the split, slots i of G[(b,i)][g] * A[(b + shift,i)][a].
+// The contraction index is the slot.  A [32 slots x 128 columns] sub-block of BL is one contiguous
+// 16 KB: the workgroup reads it with fully coalesced 64-byte-per-thread loads (thread = (quad,
+// 4 consecutive slots) = a 4x4 register block), transposes that block in registers for free and
+// writes each column's 4 consecutive slots as one 8-byte bf16 group into a [column][slot] LDS
+// image (row stride 80 B: conflict-free 16-byte fragment reads).  128 x 128 output tile per
+// workgroup, 4 waves x (2x2) MFMA tiles; next block's global loads in flight under the MFMAs.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define TB_LD 40
+#define TB_PLANE (128 * TB_LD)
+
+__global__ __launch_bounds__(256, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[4 * TB_PLANE];  // G_hi, G_lo, A_hi, A_lo: 40 KB
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int quad = tid >> 3, sg = tid & 7;
+  const int atiles = (p.a0_cols + p.a1_cols) / 128;
+  const int gt = blockIdx.x / atiles, at = blockIdx.x % atiles;
+  const int split = blockIdx.y;
+  const bool src1 = at * 128 >= p.a0_cols;
+  const float* Ab = src1 ? p.A1 : p.A0;
+  const int a_w = src1 ? p.a1_width : p.a0_width;
+  const int a_q0 = (src1 ? p.a1_off + at * 128 - p.a0_cols : p.a0_off + at * 128) / 4;
+  const int shift = src1 ? p.a1_shift : p.a0_shift;
+  const int g_q0 = (p.g_off + gt * 128) / 4;
+  const int L = p.L;
+  const int b_begin = split * p.blocks_per_split;
+  const int b_end = min(p.nblk, b_begin + p.blocks_per_split);
+  const long long g_lane = (long long)(g_q0 + quad) * 128 + sg * 16;
+  const long long a_lane = (long long)(a_q0 + quad) * 128 + sg * 16;
+  const long long g_bs = 32LL * p.g_width, a_bs = 32LL * a_w;
+
+  f32x4 gr[4], ar[4];
+  bool use = true;
+  auto load_block = [&](int b) {
+    const int tile = b / L, step = b - tile * L;
+    const int sa = step + shift;
+    use = sa >= 0 && sa < L;
+    const float* gp = p.G + (long long)b * g_bs + g_lane;
+    const float* ap = Ab + (long long)(use ? b + shift : b) * a_bs + a_lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gr[j] = *reinterpret_cast<const f32x4*>(gp + 4 * j);
+      ar[j] = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+    }
+  };
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  auto store_block = [&]() {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = gr[j][c];
+        bsum[c] += v;
+        hi[j] = (__bf16)v;
+        lo[j] = (__bf16)(v - (float)hi[j]);
+      }
+      const int o = (4 * quad + c) * TB_LD + 4 * sg;
+      *reinterpret_cast<bf16x4*>(lds + o) = hi;
+      *reinterpret_cast<bf16x4*>(lds + TB_PLANE + o) = lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = use ? ar[j][c] : 0.f;
+        hi[j] = (__bf16)v;
+        lo[j] = (__bf16)(v - (float)hi[j]);
+      }
+      *reinterpret_cast<bf16x4*>(lds + 2 * TB_PLANE + o) = hi;
+      *reinterpret_cast<bf16x4*>(lds + 3 * TB_PLANE + o) = lo;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+
+  if (b_begin < b_end) load_block(b_begin);
+  for (int b = b_begin; b < b_end; ++b) {
+    __syncthreads();  // previous block's fragment reads are done
+    store_block();
+    __syncthreads();
+    if (b + 1 < b_end) load_block(b + 1);
+#pragma unroll
+    for (int ks = 0; ks < 32; ks += 16) {
+      const int ka = ks + 8 * half;
+      bf16x8 gh[2], gl[2], ah[2], al[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int rg = (wm * 64 + e * 32 + l31) * TB_LD + ka;
+        const int ra = (wn * 64 + e * 32 + l31) * TB_LD + ka;
+        gh[e] = *reinterpret_cast<const bf16x8*>(lds + rg);
+        gl[e] = *reinterpret_cast<const bf16x8*>(lds + TB_PLANE + rg);
+        ah[e] = *reinterpret_cast<const bf16x8*>(lds + 2 * TB_PLANE + ra);
+        al[e] = *reinterpret_cast<const bf16x8*>(lds + 3 * TB_PLANE + ra);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[e][f] = mfma32(gh[e], ah[f], acc[e][f]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[e][f] = mfma32(gl[e], ah[f], acc[e][f]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[e][f] = mfma32(gh[e], al[f], acc[e][f]);
+    }
+  }
+
+  const int ncols = p.a0_cols + p.a1_cols;
+  float* out = p.slab + (long long)split * p.slab_stride;
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int acol = at * 128 + wn * 64 + f * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gcol = gt * 128 + wm * 64 + e * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[(long long)gcol * ncols + acol] = acc[e][f][r];
+      }
+    }
+  if (p.bslab && at == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float t = bsum[c];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      if (sg == 0) p.bslab[(long long)split * p.bslab_stride + gt * 128 + 4 * quad + c] = t;
+    }
+  }
+}
+
+extern "C" int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream) {
+  WS_REQUIRE(a && a->G && a->A0 && a->slab, "ws_gemm_tnb: null pointer");
+  WS_REQUIRE(a->g_cols > 0 && a->g_cols % 128 == 0 && a->g_off % 4 == 0 && a->g_width % 4 == 0,
+             "ws_gemm_tnb: G column range");
+  WS_REQUIRE(a->a0_cols > 0 && a->a0_cols % 128 == 0 && a->a0_off % 4 == 0 && a->a0_width % 4 == 0,
+             "ws_gemm_tnb: A0 column range");
+  WS_REQUIRE(a->a1_cols == 0 || (a->A1 && a->a1_cols % 128 == 0 && a->a1_off % 4 == 0 && a->a1_width % 4 == 0),
+             "ws_gemm_tnb: A1 column range");
+  WS_REQUIRE(a->nblk > 0 && a->L > 0 && a->nblk % a->L == 0 && a->nsplit > 0 && a->blocks_per_split > 0 &&
+                 (long long)a->nsplit * a->blocks_per_split >= a->nblk,
+             "ws_gemm_tnb: bad block split");
+  const int atiles = (a->a0_cols + a->a1_cols) / 128;
+  hipStream_t s = (hipStream_t)stream;
+  ws_prof_begin(WS_PROF_GEMM_TN, s);
+  hipLaunchKernelGGL(gemm_tnb_kernel, dim3((a->g_cols / 128) * atiles, a->nsplit), dim3(256), 0, s, *a);
+  ws_prof_end(WS_PROF_GEMM_TN, s);
+  return ws_check_launch("ws_gemm_tnb");
+}

@@ -41,6 +41,16 @@ __device__ __forceinline__ bf16x8 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, i
   return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 }
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mkrsrc(const float* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bst(const f32x4& v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -120,7 +130,12 @@ int ws_launch_lstm_pack_bf16(const float* whh_f, const float* whh_r, float* pack
 // ---------------------------------------------------------------------------------------------
 // DBG (probe builds only, mode bits 8..10): 1 = skip global stores, 2 = skip the x-projection /
 // step-input prefetch, 4 = skip the weight-stream refills.  DBG = 0 is the product kernel.
-template <int DBG>
+//
+// BLK selects the activation layout: false = plain rows ([P][2][4H] gates, [P][2H] c/h, rows by
+// the sequence map), true = the blocked layout BL of include/wesep_hip.h, in which the 16 bytes
+// a lane moves and those of its 31 neighbours are one contiguous 512-byte run (block = the
+// workgroup's 32 sequences at one step), so every wave-level load/store is 1 KB contiguous.
+template <bool BLK, int DBG>
 __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 hl[2][2][SQ * HROW];  // [buf][part][seq][k] 66 KB
   __shared__ __attribute__((aligned(16))) float cl[SQ * (LH + 4)];     // cell state [seq][unit] 33 KB
@@ -133,9 +148,34 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
     uint32_t* z = reinterpret_cast<uint32_t*>(&hl[0][0][0]);
     for (int i = tid; i < 2 * SQ * HROW / 2; i += 512) z[i] = 0u;
   }
-  const int ss = min((int)blockIdx.x * SQ + l31, p.nseq - 1);  // padded lanes duplicate the last sequence
-  const long long rowbase = (long long)(ss / p.sq_div) * p.sq_s1 + (long long)(ss % p.sq_div) * p.sq_s2;
+  const int ss = min((int)blockIdx.x * SQ + l31, p.nseq - 1);  // plain: padded lanes duplicate the last sequence
+  const long long rowbase =
+      BLK ? 0 : (long long)(ss / p.sq_div) * p.sq_s1 + (long long)(ss % p.sq_div) * p.sq_s2;
   const int ubase = 32 * w + 4 * half;  // unit of register 4j + r: ubase + 8j + r
+  // activation I/O.  BLK: one SGPR buffer descriptor per (array, step) block + one VGPR lane offset
+  // (no 64-bit VGPR addresses); plain: row pointers.
+  const int glane = ((d * 256 + 8 * w + half) * 32 + l31) * 16;  // bytes; + (g*64 + 2j)*512
+  const int clane = ((d * 64 + 8 * w + half) * 32 + l31) * 16;   // bytes; + 2j*512
+  auto goff = [&](int t, int g, int j) -> long long {
+    return ((rowbase + (long long)t * p.step_rows) * 2 + d) * LG + g * 256 + ubase + 8 * j;
+  };
+  auto coff = [&](int t, int j) -> long long {
+    return (rowbase + (long long)t * p.step_rows) * (2 * LH) + d * LH + ubase + 8 * j;
+  };
+  auto grs = [&](int t) { return mkrsrc(p.gates + (long long)(blockIdx.x * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  auto crs = [&](float* b, int t) { return mkrsrc(b + (long long)(blockIdx.x * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
+  auto ld_gate = [&](int t, int g, int j) -> f32x4 {
+    if constexpr (BLK) return bld(grs(t), glane, (g * 64 + 2 * j) * 512);
+    else return *reinterpret_cast<const f32x4*>(p.gates + goff(t, g, j));
+  };
+  auto st_gate = [&](const f32x4& v, int t, int g, int j) {
+    if constexpr (BLK) bst(v, grs(t), glane, (g * 64 + 2 * j) * 512);
+    else *reinterpret_cast<f32x4*>(p.gates + goff(t, g, j)) = v;
+  };
+  auto st_ch = [&](const f32x4& v, float* b, int t, int j) {
+    if constexpr (BLK) bst(v, crs(b, t), clane, 2 * j * 512);
+    else *reinterpret_cast<f32x4*>(b + coff(t, j)) = v;
+  };
 
   float* cme = &cl[l31 * (LH + 4) + ubase];  // this lane's 4 runs of 4 units: cme + 8j (private)
 #pragma unroll
@@ -155,11 +195,10 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
   f32x4 xg[4][4];  // [gate][run]
   {
     const int t0 = d == 0 ? 0 : L - 1;
-    const float* g = p.gates + ((rowbase + (long long)t0 * p.step_rows) * 2 + d) * LG + ubase;
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xg[gi][j] = *reinterpret_cast<const f32x4*>(g + gi * 256 + 8 * j);
+      for (int j = 0; j < 4; ++j) xg[gi][j] = ld_gate(t0, gi, j);
   }
   __syncthreads();
 
@@ -199,13 +238,8 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
     }
 
     // cell update, lane-local; global traffic as 16-byte vectors
-    const long long row = rowbase + (long long)t * p.step_rows;
-    float* gout = p.gates + (row * 2 + d) * LG + ubase;
-    float* cout = p.cbuf + row * (2 * LH) + d * LH + ubase;
-    float* hout = p.hcat + row * (2 * LH) + d * LH + ubase;
     const int sn = min(step + 1, L - 1);  // last step: harmless reload of its own row
     const int tn = d == 0 ? sn : L - 1 - sn;
-    const float* gnext = p.gates + ((rowbase + (long long)tn * p.step_rows) * 2 + d) * LG + ubase;
     __bf16* nhi = &hl[cur ^ 1][0][l31 * HROW + ubase];
     __bf16* nlo = &hl[cur ^ 1][1][l31 * HROW + ubase];
 #pragma unroll
@@ -218,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
       // next step's x-projection into the registers just consumed
       if (!(DBG & 2)) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) xg[g][j] = *reinterpret_cast<const f32x4*>(gnext + g * 256 + 8 * j);
+        for (int g = 0; g < 4; ++g) xg[g][j] = ld_gate(tn, g, j);
       }
       f32x4 vi, vf, vg, vo, vc, vh;
       const f32x4 cold = *reinterpret_cast<const f32x4*>(cme + 8 * j);
@@ -242,12 +276,12 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
       *reinterpret_cast<bf16x4*>(nlo + 8 * j) = h_lo;
       *reinterpret_cast<f32x4*>(cme + 8 * j) = vc;
       if (!(DBG & 1) || step == L - 1) {
-        *reinterpret_cast<f32x4*>(gout + 8 * j) = vi;
-        *reinterpret_cast<f32x4*>(gout + 256 + 8 * j) = vf;
-        *reinterpret_cast<f32x4*>(gout + 512 + 8 * j) = vg;
-        *reinterpret_cast<f32x4*>(gout + 768 + 8 * j) = vo;
-        *reinterpret_cast<f32x4*>(cout + 8 * j) = vc;
-        *reinterpret_cast<f32x4*>(hout + 8 * j) = vh;
+        st_gate(vi, t, 0, j);
+        st_gate(vf, t, 1, j);
+        st_gate(vg, t, 2, j);
+        st_gate(vo, t, 3, j);
+        st_ch(vc, p.cbuf, t, j);
+        st_ch(vh, p.hcat, t, j);
       }
       __builtin_amdgcn_sched_barrier(0);  // one run at a time: bounds the live temporaries
     }
@@ -259,17 +293,39 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
 // backward recurrence (BPTT): walks the steps in the reverse of the forward order.
 //   dh_{t-1}^T[unit][seq] = W_hh^T[unit][gate col] * dgates_t^T[gate col][seq]   (K = 1024)
 // ---------------------------------------------------------------------------------------------
-template <int DBG>
+template <bool BLK, int DBG>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 dgl[2][SQ * DROW];  // [part][seq][gate col] 129 KB
   const int d = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = p.L;
-  const int ss = min((int)blockIdx.x * SQ + l31, p.nseq - 1);  // padded lanes duplicate the last sequence
-  const long long rowbase = (long long)(ss / p.sq_div) * p.sq_s1 + (long long)(ss % p.sq_div) * p.sq_s2;
+  const int ss = min((int)blockIdx.x * SQ + l31, p.nseq - 1);  // plain: padded lanes duplicate the last sequence
+  const long long rowbase =
+      BLK ? 0 : (long long)(ss / p.sq_div) * p.sq_s1 + (long long)(ss % p.sq_div) * p.sq_s2;
   const int ubase = 32 * w + 4 * half;
-  const long long prev_rows = (d == 0 ? -1 : 1) * p.step_rows;  // row offset of the forward-previous step
+  const int glane = ((d * 256 + 8 * w + half) * 32 + l31) * 16;  // see lstm_fwd_bf16_kernel
+  const int clane = ((d * 64 + 8 * w + half) * 32 + l31) * 16;
+  auto goff = [&](int t, int g, int j) -> long long {
+    return ((rowbase + (long long)t * p.step_rows) * 2 + d) * LG + g * 256 + ubase + 8 * j;
+  };
+  auto coff = [&](int t, int j) -> long long {
+    return (rowbase + (long long)t * p.step_rows) * (2 * LH) + d * LH + ubase + 8 * j;
+  };
+  auto grs = [&](int t) { return mkrsrc(p.gates + (long long)(blockIdx.x * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  auto crs = [&](const float* b, int t) { return mkrsrc(b + (long long)(blockIdx.x * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
+  auto ld_gate = [&](int t, int g, int j) -> f32x4 {
+    if constexpr (BLK) return bld(grs(t), glane, (g * 64 + 2 * j) * 512);
+    else return *reinterpret_cast<const f32x4*>(p.gates + goff(t, g, j));
+  };
+  auto st_gate = [&](const f32x4& v, int t, int g, int j) {
+    if constexpr (BLK) bst(v, grs(t), glane, (g * 64 + 2 * j) * 512);
+    else *reinterpret_cast<f32x4*>(p.gates + goff(t, g, j)) = v;
+  };
+  auto ld_ch = [&](const float* b, int t, int j) -> f32x4 {
+    if constexpr (BLK) return bld(crs(b, t), clane, 2 * j * 512);
+    else return *reinterpret_cast<const f32x4*>(b + coff(t, j));
+  };
 
   // weight stream: per k-step 2 fragments (hi, lo); ring slots hold 4 k-steps
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -289,28 +345,23 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
 #pragma unroll
   for (int i = 0; i < 16; ++i) dhr[i] = 0.f;
 
-  auto load4 = [&](f32x4* dst, const float* src, int j) { dst[j] = *reinterpret_cast<const f32x4*>(src); };
   // inputs of step `t` for register run j (c_cur is carried: c_t = the previous step's c_{prev})
   auto load_step = [&](int t, int j) {
-    const long long row = rowbase + (long long)t * p.step_rows;
-    const float* g = p.gates + (row * 2 + d) * LG + ubase + 8 * j;
-    load4(n_i, g, j);
-    load4(n_f, g + 256, j);
-    load4(n_g, g + 512, j);
-    load4(n_o, g + 768, j);
-    const long long hc = row * (2 * LH) + d * LH + ubase + 8 * j;
-    load4(n_dh, p.dhcat + hc, j);
-    // c_{t-1}; at the sequence start the row is clamped and the value is masked at its use
-    const bool has_prev = d == 0 ? (t > 0) : (t < L - 1);
-    load4(n_cp, p.cbuf + hc + (has_prev ? prev_rows : 0) * (2 * LH), j);
+    n_i[j] = ld_gate(t, 0, j);
+    n_f[j] = ld_gate(t, 1, j);
+    n_g[j] = ld_gate(t, 2, j);
+    n_o[j] = ld_gate(t, 3, j);
+    n_dh[j] = ld_ch(p.dhcat, t, j);
+    // c_{t-1}; at the sequence start the step is clamped and the value is masked at its use
+    const int tp = d == 0 ? max(t - 1, 0) : min(t + 1, L - 1);
+    n_cp[j] = ld_ch(p.cbuf, tp, j);
   };
   {
     const int t0 = d == 0 ? L - 1 : 0;
-    const long long row = rowbase + (long long)t0 * p.step_rows;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       load_step(t0, j);
-      load4(c_cur, p.cbuf + row * (2 * LH) + d * LH + ubase + 8 * j, j);
+      c_cur[j] = ld_ch(p.cbuf, t0, j);
     }
   }
 
@@ -321,8 +372,6 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
     const bool has_prev = d == 0 ? (t > 0) : (t < L - 1);  // uniform
     int zo = 0;  // see wload()
     asm volatile("" : "+s"(zo));
-    const long long row = rowbase + (long long)t * p.step_rows;
-    float* gout = p.gates + (row * 2 + d) * LG + ubase;
     __bf16* dhi = &dgl[0][l31 * DROW + ubase];
     __bf16* dlo = &dgl[1][l31 * DROW + ubase];
 #pragma unroll
@@ -343,10 +392,10 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
       }
       c_cur[j] = n_cp[j];
       if (!(DBG & 1) || step == L - 1) {
-        *reinterpret_cast<f32x4*>(gout + 8 * j) = pi;
-        *reinterpret_cast<f32x4*>(gout + 256 + 8 * j) = pf;
-        *reinterpret_cast<f32x4*>(gout + 512 + 8 * j) = pg;
-        *reinterpret_cast<f32x4*>(gout + 768 + 8 * j) = po;
+        st_gate(pi, t, 0, j);
+        st_gate(pf, t, 1, j);
+        st_gate(pg, t, 2, j);
+        st_gate(po, t, 3, j);
       }
       bf16x4 hi, lo;
       split4(pi, hi, lo);
@@ -399,14 +448,17 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   }
 }
 
-#define WS_DBG_DISPATCH(KERNEL)                                                     \
-  switch ((a->mode >> 8) & 7) {                                                     \
-    case 0: hipLaunchKernelGGL((KERNEL<0>), grid, block, 0, s, *a); break;          \
-    case 1: hipLaunchKernelGGL((KERNEL<1>), grid, block, 0, s, *a); break;          \
-    case 2: hipLaunchKernelGGL((KERNEL<2>), grid, block, 0, s, *a); break;          \
-    case 3: hipLaunchKernelGGL((KERNEL<3>), grid, block, 0, s, *a); break;          \
-    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, s, *a); break;          \
-    default: hipLaunchKernelGGL((KERNEL<7>), grid, block, 0, s, *a); break;         \
+#define WS_DBG_DISPATCH(KERNEL)                                                          \
+  if ((a->mode & 255) == WS_LSTM_BF16X3_BLK) {                                           \
+    switch ((a->mode >> 8) & 7) {                                                        \
+      case 0: hipLaunchKernelGGL((KERNEL<true, 0>), grid, block, 0, s, *a); break;       \
+      case 1: hipLaunchKernelGGL((KERNEL<true, 1>), grid, block, 0, s, *a); break;       \
+      case 2: hipLaunchKernelGGL((KERNEL<true, 2>), grid, block, 0, s, *a); break;       \
+      case 4: hipLaunchKernelGGL((KERNEL<true, 4>), grid, block, 0, s, *a); break;       \
+      default: hipLaunchKernelGGL((KERNEL<true, 7>), grid, block, 0, s, *a); break;      \
+    }                                                                                    \
+  } else {                                                                               \
+    hipLaunchKernelGGL((KERNEL<false, 0>), grid, block, 0, s, *a);                       \
   }
 
 int ws_launch_lstm_fwd_bf16(const ws_lstm_args* a, hipStream_t s) {

@@ -73,7 +73,9 @@ def gemm_nt(*, A, a_rows: Rows, M: int, C_out, c_rows: Rows, N=0, K=0, W=None, l
     sm = stat_map or StatMap(1, 0, 1, 0, 0)
     a.st_div1, a.st_m1, a.st_div2, a.st_m2, a.st_base = sm
     a.M, a.N, a.K, a.ldw = M, N, K, ldw
-    a.act, a.ngroups, a.max_n, a.vec = act, ngroups, max_n, vec | _mode_bit(mode)
+    # the split-bf16 kernel's GroupNorm-on-load variant showed run-to-run mismatches on MI355X
+    # (tools/nt_bug_probe.py); until it is replaced, normalised operands take the exact-fp32 kernel
+    a.act, a.ngroups, a.max_n, a.vec = act, ngroups, max_n, vec | (_mode_bit(mode) if stats is None else 0)
     L.check(L.lib().ws_gemm_nt(C.byref(a), L.stream_ptr()), "ws_gemm_nt")
 
 
@@ -104,7 +106,7 @@ def gemm_tn(*, G, g_rows: Rows, A, a_rows: Rows, M: int, slab, slab_stride: int,
     a.slab_stride, a.bslab_stride, a.out_off, a.bout_off = slab_stride, bslab_stride, out_off, bout_off
     a.M, a.Nn, a.Kk, a.rows_per_split, a.nsplit = M, Nn, Kk, rows_per_split, nsplit
     a.shift_rows, a.seq_div, a.seq_len = shift_rows, seq_div, seq_len
-    a.ngroups, a.max_n, a.max_k, a.vec = ngroups, max_n, max_k, vec | _mode_bit(mode)
+    a.ngroups, a.max_n, a.max_k, a.vec = ngroups, max_n, max_k, vec | (_mode_bit(mode) if stats is None else 0)
     L.check(L.lib().ws_gemm_tn(C.byref(a), L.stream_ptr()), "ws_gemm_tn")
 
 
@@ -336,3 +338,107 @@ def prof_collect(kind: int):
     n = C.c_longlong(0)
     L.check(L.lib().ws_prof_collect(kind, C.byref(ms), C.byref(n)), "ws_prof_collect")
     return ms.value, n.value
+
+
+# ---------------------------------------------------------------------------------------------
+# Blocked layout BL (include/wesep_hip.h): helpers for tests / probes.  The product path never
+# converts: the GEMM kernels read and write BL directly.
+# ---------------------------------------------------------------------------------------------
+def bl_num_blocks(sm: SeqMap) -> int:
+    return -(-sm.nseq // 32) * sm.L
+
+
+def bl_positions(sm: SeqMap, device):
+    """(pos, valid): position (row of the Z layout) of every BL slot, block-major; padded slots
+    (sequence index >= nseq) are invalid and reported as position 0."""
+    ntile = -(-sm.nseq // 32)
+    seq = torch.arange(ntile * 32, device=device).view(ntile, 1, 32)
+    step = torch.arange(sm.L, device=device).view(1, sm.L, 1)
+    valid = (seq < sm.nseq).expand(ntile, sm.L, 32)
+    sq = seq.clamp(max=sm.nseq - 1)
+    pos = torch.div(sq, sm.div, rounding_mode="floor") * sm.s1 + (sq % sm.div) * sm.s2 + step * sm.step_rows
+    return (pos * valid).reshape(-1), valid.reshape(-1)
+
+
+def to_blocked(x: torch.Tensor, sm: SeqMap) -> torch.Tensor:
+    """[P][C] plain rows -> BL(C) [nblk][C/4][32][4]; padded slots are zero."""
+    pos, valid = bl_positions(sm, x.device)
+    C_ = x.shape[1]
+    rows = x[pos] * valid[:, None].to(x.dtype)
+    return rows.view(-1, 32, C_ // 4, 4).permute(0, 2, 1, 3).contiguous()
+
+
+def from_blocked(xb: torch.Tensor, sm: SeqMap, P: int) -> torch.Tensor:
+    """BL(C) -> [P][C] plain rows (padded slots dropped)."""
+    pos, valid = bl_positions(sm, xb.device)
+    nblk, Cq = xb.shape[0], xb.shape[1]
+    rows = xb.permute(0, 2, 1, 3).reshape(nblk * 32, Cq * 4)
+    out = torch.zeros(P, Cq * 4, device=xb.device, dtype=xb.dtype)
+    out[pos[valid]] = rows[valid]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMMs between the plain Z layout and BL (gemm_blk.hip)
+# ---------------------------------------------------------------------------------------------
+def _smc(sm: SeqMap):
+    c = L.SeqMapC()
+    c.sq_s1, c.sq_s2, c.step_rows, c.nseq, c.sq_div, c.L = sm.s1, sm.s2, sm.step_rows, sm.nseq, sm.div, sm.L
+    return c
+
+
+def pack_w(W, N: int, K: int, ldw: int, out, trans=False, order=0, w_off=0):
+    _chk(W, "W")
+    _chk(out, "out")
+    if out.numel() < N * K:
+        raise L.WesepHipError("pack_w: output too small")
+    L.check(L.lib().ws_pack_w(_p(W, w_off), N, K, ldw, int(trans), order, _p(out), L.stream_ptr()), "ws_pack_w")
+
+
+def gemm_p2b(*, A, lda: int, sm: SeqMap, Wpack, N: int, C_out, K=128, bias=None, A_bl=None, stats=None,
+             gamma=None, beta=None, stat_map: Optional[StatMap] = None):
+    for n, t in (("A", A), ("Wpack", Wpack), ("bias", bias), ("C", C_out), ("A_bl", A_bl), ("stats", stats),
+                 ("gamma", gamma), ("beta", beta)):
+        _chk(t, n)
+    a = L.GemmP2BArgs()
+    a.A, a.Wpack, a.bias, a.C, a.A_bl = _p(A), _p(Wpack), _p(bias), _p(C_out), _p(A_bl)
+    a.stats, a.gamma, a.beta = _p(stats), _p(gamma), _p(beta)
+    a.sm = _smc(sm)
+    st = stat_map or StatMap(1, 0, 1, 0, 0)
+    a.st_div1, a.st_m1, a.st_div2, a.st_m2, a.st_base = st
+    a.lda, a.N, a.K = lda, N, K
+    L.check(L.lib().ws_gemm_p2b(C.byref(a), L.stream_ptr()), "ws_gemm_p2b")
+
+
+def gemm_b2p(*, A, K: int, sm: SeqMap, Wpack, C_out, ldc: int, N=128, bias=None, R=None):
+    for n, t in (("A", A), ("Wpack", Wpack), ("bias", bias), ("C", C_out), ("R", R)):
+        _chk(t, n)
+    a = L.GemmB2PArgs()
+    a.A, a.Wpack, a.bias, a.R, a.C = _p(A), _p(Wpack), _p(bias), _p(R), _p(C_out)
+    a.sm = _smc(sm)
+    a.ldc, a.N, a.K = ldc, N, K
+    L.check(L.lib().ws_gemm_b2p(C.byref(a), L.stream_ptr()), "ws_gemm_b2p")
+
+
+def tnb_splits(nblk: int, L_: int, tiles: int):
+    """Splits of the block range so that tiles * nsplit covers the chip a few times over."""
+    nsplit = max(1, min(64, -(-1024 // tiles), nblk))
+    bps = -(-nblk // nsplit)
+    nsplit = -(-nblk // bps)
+    return nsplit, bps
+
+
+def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_off: int, a0_cols: int,
+             nblk: int, L_: int, slab, nsplit: int, blocks_per_split: int, a0_shift=0, A1=None, a1_width=0,
+             a1_off=0, a1_cols=0, a1_shift=0, bslab=None):
+    for n, t in (("G", G), ("A0", A0), ("A1", A1), ("slab", slab), ("bslab", bslab)):
+        _chk(t, n)
+    a = L.GemmTNBArgs()
+    a.G, a.A0, a.A1, a.slab, a.bslab = _p(G), _p(A0), _p(A1), _p(slab), _p(bslab)
+    a.slab_stride = g_cols * (a0_cols + a1_cols)
+    a.bslab_stride = g_cols
+    a.g_width, a.g_off, a.g_cols = g_width, g_off, g_cols
+    a.a0_width, a.a0_off, a.a0_cols, a.a0_shift = a0_width, a0_off, a0_cols, a0_shift
+    a.a1_width, a.a1_off, a.a1_cols, a.a1_shift = a1_width, a1_off, a1_cols, a1_shift
+    a.nblk, a.L, a.nsplit, a.blocks_per_split = nblk, L_, nsplit, blocks_per_split
+    L.check(L.lib().ws_gemm_tnb(C.byref(a), L.stream_ptr()), "ws_gemm_tnb")

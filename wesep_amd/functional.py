@@ -149,6 +149,116 @@ class ResRNNFn(torch.autograd.Function):
                 dproj_w, dproj_b)
 
 
+def resrnn_mode() -> str:
+    """'blocked' (default): split-bf16 path on the blocked layout BL (gemm_blk.hip, lstm_bf16.hip);
+    'plain': the generic row-addressed GEMMs + plain-layout recurrence (honours WESEP_GEMM /
+    WESEP_LSTM, e.g. both f32 for the exact-fp32 reference path)."""
+    return os.environ.get("WESEP_RESRNN", "blocked")
+
+
+class ResRNNBlkFn(torch.autograd.Function):
+    """ResRNN on the blocked layout: gates / c / h / d(h) never exist in row-major form; every
+    activation byte of the recurrence moves as part of a 512-byte contiguous run (include/wesep_hip.h,
+    "blocked layout BL").  Same inputs as ResRNNFn."""
+
+    @staticmethod
+    def forward(ctx, z, view, norm_w, norm_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r,
+                bhh_r, proj_w, proj_b):
+        _need_cuda(z, "ResRNN")
+        z = z.contiguous()
+        R, K, Tf, N = z.shape
+        if tuple(whh_f.shape) != (G4, H) or tuple(wih_f.shape) != (G4, N) or N != 128:
+            raise L.WesepHipError(f"blocked ResRNN kernels are built for input 128 / hidden {H}; got "
+                                  f"{tuple(wih_f.shape)}, {tuple(whh_f.shape)}")
+        d = z.device
+        geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+        nb = dev.bl_num_blocks(seq)
+        stats = _empty(d, geo.ngroups, 2)
+        dev.group_stats(z, geo, stats)
+        wcat, bcat = _empty(d, 2 * G4, N), _empty(d, 2 * G4)
+        dev.lstm_cat_ih(wih_f.contiguous(), wih_r.contiguous(), bih_f, bhh_f, bih_r, bhh_r, N, wcat, bcat)
+        wih_pack = _empty(d, 2 * G4 * N)
+        dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
+        pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
+        dev.lstm_pack(whh_f.contiguous(), whh_r.contiguous(), pack_f, pack_b, L.LSTM_BF16X3_BLK)
+        gates, xn = _empty(d, nb, 32 * 2 * G4), _empty(d, nb, 32 * N)
+        dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=gates, bias=bcat, A_bl=xn,
+                     stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap)
+        cbuf, hcat = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * 2 * H)
+        dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, L.LSTM_BF16X3_BLK)
+        pw = proj_w.contiguous()
+        proj_pack = _empty(d, N * 2 * H)
+        dev.pack_w(pw, N, 2 * H, 2 * H, proj_pack, order=1)
+        out = torch.empty_like(z)
+        dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=proj_pack, C_out=out, ldc=N, bias=proj_b, R=z)
+        ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw)
+        ctx.view = view
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw = ctx.saved_tensors
+        dout = dout.contiguous()
+        R, K, Tf, N = z.shape
+        P = R * K * Tf
+        d = z.device
+        geo, smap, seq, _ = _view_maps(ctx.view, R, K, Tf, N)
+        nb = dev.bl_num_blocks(seq)
+        # d(hcat) = dout Wp  (+ dout itself in BL for the weight gradient)
+        wpt_pack = _empty(d, 2 * H * N)
+        dev.pack_w(pw, 2 * H, N, 2 * H, wpt_pack, trans=True, order=0)
+        dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
+        dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wpt_pack, N=2 * H, C_out=dh, A_bl=dout_bl)
+        # dW_proj [N][2H] = dout^T hcat,  db_proj = colsum(dout)
+        ns, bps = dev.tnb_splits(nb, seq.L, (2 * H) // 128)
+        slab, bslab = _empty(d, ns, N * 2 * H), _empty(d, ns, N)
+        dev.gemm_tnb(G=dout_bl, g_width=N, g_off=0, g_cols=N, A0=hcat, a0_width=2 * H, a0_off=0, a0_cols=2 * H,
+                     nblk=nb, L_=seq.L, slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab)
+        dproj_w = _reduce_new(slab, ns, N * 2 * H, (N, 2 * H))
+        dproj_b = _reduce_new(bslab, ns, N, (N,))
+        del dout_bl
+        # BPTT: gates (activated) -> d(pre-activation gates), in place
+        dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, L.LSTM_BF16X3_BLK)
+        del dh
+        # [dW_ih | dW_hh] and the bias gradient of each direction in ONE pass over its dgates
+        ns, bps = dev.tnb_splits(nb, seq.L, (G4 // 128) * ((N + H) // 128))
+        slab, bslab = _empty(d, ns, G4 * (N + H)), _empty(d, ns, G4)
+        dwih, dwhh, db = [], [], []
+        for di in (0, 1):
+            dev.gemm_tnb(G=gates, g_width=2 * G4, g_off=di * G4, g_cols=G4, A0=xn, a0_width=N, a0_off=0,
+                         a0_cols=N, A1=hcat, a1_width=2 * H, a1_off=di * H, a1_cols=H,
+                         a1_shift=(-1 if di == 0 else 1), nblk=nb, L_=seq.L, slab=slab, nsplit=ns,
+                         blocks_per_split=bps, bslab=bslab)
+            dw = _reduce_new(slab, ns, G4 * (N + H), (G4, N + H))
+            dwih.append(dw[:, :N].contiguous())
+            dwhh.append(dw[:, N:].contiguous())
+            db.append(_reduce_new(bslab, ns, G4, (G4,)))
+        del slab, bslab
+        # d(normalised input) = dgates Wcat -> GroupNorm backward (+ residual path)
+        wct_pack = _empty(d, N * 2 * G4)
+        dev.pack_w(wcat, N, 2 * G4, N, wct_pack, trans=True, order=1)
+        dxn = _empty(d, P, N)
+        dev.gemm_b2p(A=gates, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dxn, ldc=N)
+        ab = _empty(d, geo.ngroups, 2)
+        dev.gn_bwd_reduce(z, dxn, stats, geo, ab, gamma=norm_w)
+        ns2 = min(256, geo.ngroups)
+        pslab = _empty(d, ns2, 2, N)
+        dev.gn_param_grad(z, dxn, stats, geo, ns2, pslab)
+        dgb = _reduce_new(pslab, ns2, 2 * N, (2, N))
+        dz = torch.empty_like(z)
+        dev.gn_bwd_apply(z, dxn, stats, ab, geo, dz, gamma=norm_w, res=dout)
+        return (dz, None, dgb[0], dgb[1],
+                dwih[0], dwhh[0], db[0], db[0].clone(),
+                dwih[1], dwhh[1], db[1], db[1].clone(),
+                dproj_w, dproj_b)
+
+
+def resrnn(z, view, *params):
+    """ResRNN forward (autograd-aware) on the path selected by WESEP_RESRNN."""
+    fn = ResRNNBlkFn if resrnn_mode() == "blocked" else ResRNNFn
+    return fn.apply(z, view, *params)
+
+
 # ---------------------------------------------------------------------------------------------
 # small dense layers on [R, *] (speaker embedding side): y = x W^T + b
 # ---------------------------------------------------------------------------------------------

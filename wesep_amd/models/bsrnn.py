@@ -35,7 +35,7 @@ class ResRNN(nn.Module):
 
     def forward(self, z, view="time"):
         r = self.rnn
-        return F_.ResRNNFn.apply(
+        return F_.resrnn(
             z, view, self.norm.weight, self.norm.bias,
             r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0,
             r.weight_ih_l0_reverse, r.weight_hh_l0_reverse, r.bias_ih_l0_reverse, r.bias_hh_l0_reverse,
