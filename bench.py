@@ -8,8 +8,9 @@ step -- forward, SI-SDR, backward, per-tensor clip, Adam -- on N MI355X.
 
 Workload (BASELINE.json configs[1] / north_star "batch 32 x 4 s"): pBSRNN, FiLM multi-fuse,
 6 repeats, feature_dim 128, fixed [R,256] embeddings, R = 32 rows (16 two-speaker mixtures) of
-64000 samples per GPU, fp32 (the reference's precision; its shipped configs set
-enable_amp false).  Weak scaling: every rank runs the same per-GPU batch on its own synthetic
+64000 samples per GPU.  Arithmetic: split-bf16 ("bf16x3": fp32 operands as bf16 hi+lo, three bf16
+MFMAs per product, fp32 accumulation and fp32 storage) -- holds the reference's fp32 results to
+~1e-4 on the separated waveforms (tests/test_bsrnn_gpu.py; tolerance 1e-3).  Weak scaling: every rank runs the same per-GPU batch on its own synthetic
 rows (seed 42 + rank); DDP all-reduces gradients over RCCL.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -28,7 +29,8 @@ T = 64000
 MODEL_KW = dict(spk_emb_dim=256, sr=16000, win=512, stride=128, feature_dim=128, num_repeat=6,
                 use_spk_transform=False, spk_fuse_type="FiLM", multi_fuse=True, joint_training=False)
 LR0, LR1, WD, CLIP = 1e-3, 2.5e-5, 1e-4, 5.0          # confs/bsrnn.yaml:95-114
-FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md chip table
+BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md chip table (dense)
+HBM_PEAK_GBS = 8000.0                                  # HBM3E spec peak (6.3 TB/s measured copy)
 
 
 def _cpu_baseline_worker(threads, budget_s):
@@ -151,17 +153,23 @@ def main():
     elapsed = max_over_ranks(elapsed, d)
     final_loss = float(loss.item())
 
-    # dominant kernels: the two BLSTM recurrences (HIP events on the launch stream)
+    # dominant kernels: the two BLSTM recurrences (HIP events on the launch stream, see runtime.hip)
     K, Tf = 32, 1 + T // 128
     P = R * K * Tf
-    flops_per_launch = 2.0 * P * 2 * L.LSTM_H * 4 * L.LSTM_H        # both directions, one ResRNN
+    flops_per_launch = 2.0 * P * 2 * L.LSTM_H * 4 * L.LSTM_H        # fp32-equivalent, both directions
+    # algorithmic HBM bytes of one recurrence launch: per position, direction and
+    # hidden unit: fwd reads 4 gate pre-activations, writes 4 activated gates + c + h; bwd reads 4 gates,
+    # c, d(h) (c_{t-1} is the next step's c: L2), writes 4 d(gates): 10 fp32 either way
+    bytes_per_launch = 10.0 * 4 * P * 2 * L.LSTM_H
     prof = {}
     for name, kind in (("lstm_fwd", L.PROF_LSTM_FWD), ("lstm_bwd", L.PROF_LSTM_BWD),
                        ("gemm_nt", L.PROF_GEMM_NT), ("gemm_tn", L.PROF_GEMM_TN)):
         ms, n = dev.prof_collect(kind)
         prof[name] = {"ms_total": ms, "launches": n, "ms_avg": ms / max(n, 1)}
     dom = "lstm_bwd" if prof["lstm_bwd"]["ms_total"] >= prof["lstm_fwd"]["ms_total"] else "lstm_fwd"
-    achieved = flops_per_launch / (prof[dom]["ms_avg"] * 1e-3) / 1e12 if prof[dom]["launches"] else 0.0
+    sec = prof[dom]["ms_avg"] * 1e-3 if prof[dom]["launches"] else float("inf")
+    gbs = bytes_per_launch / sec / 1e9
+    tfl = flops_per_launch / sec / 1e12
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -169,16 +177,22 @@ def main():
             "metric": "utterances/sec (4 s, 16 kHz, 2-spk) fwd+bwd, pBSRNN",
             "value": world * R * args.steps / elapsed, "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3",
             "data": "synthetic",
             "config": {"workload": "pBSRNN FiLM multi-fuse, 6 repeats, feature_dim 128, fixed 256-d "
-                                   "embeddings; fwd + SI-SDR + bwd + per-tensor clip + Adam-L2",
+                                   "embeddings; fwd + SI-SDR + bwd + per-tensor clip + Adam-L2; split-bf16 "
+                                   "products (3 bf16 MFMAs), fp32 accumulate + storage",
                        "rows_per_gpu": R, "global_rows": world * R, "samples_per_row": T,
                        "parallelism": f"dp{world}", "final_loss_dB": final_loss},
-            "roofline": {"bound": "mfma", "kernel": dom + "_kernel<1>", "achieved": achieved,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "flops_per_launch": flops_per_launch, "ms_per_launch": prof[dom]["ms_avg"]},
+            # the recurrence kernels are bound by memory paths (HBM activations + the per-step L2 weight
+            # stream), not by the matrix cores: HBM is the roof they are priced against
+            "roofline": {"bound": "hbm", "kernel": dom + "_bf16_kernel<BLK> (avg of time/band views)",
+                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": None, "bytes_per_launch": bytes_per_launch,
+                         "ms_per_launch": prof[dom]["ms_avg"],
+                         "mfma": {"alg_tflops": tfl, "executed_bf16_tflops": 3 * tfl,
+                                  "peak_bf16_tflops": BF16_MFMA_PEAK_TFLOPS,
+                                  "frac_executed": 3 * tfl / BF16_MFMA_PEAK_TFLOPS}},
             "kernel_ms_per_step": {k: v["ms_total"] / args.steps for k, v in prof.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

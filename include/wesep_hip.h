@@ -231,19 +231,21 @@ int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream);
  *   slab[split][g][a] = sum_{b in split} sum_i G[(b,i)][g_off + g] * Acat[(b + shift,i)][a]
  *   bslab[split][g]   = sum G[(b,i)][g_off + g]                                  (if bslab)
  * Acat = columns [a0_off, a0_off + a0_cols) of A0 (BL(a0_width), shifted by a0_shift steps
- * inside the tile, zero outside [0, L)) followed by a1_cols columns of A1 likewise.  All column
- * counts are multiples of 128.  Replaces autograd's dW_ih / dW_hh / db (nn.LSTM) and dW_proj.  */
+ * inside the tile, zero outside [0, L)) followed by a1_cols columns of A1 likewise; Acat has 128
+ * or 384 columns, g_cols is a multiple of 128.  aslab[split][a] (optional) = column sums of Acat.
+ * Replaces autograd's dW_ih / dW_hh / db (nn.LSTM) and dW_proj / db_proj.                       */
 typedef struct ws_gemm_tnb_args {
   const float* G;
   const float* A0;
   const float* A1;   /* or NULL */
   float* slab;
   float* bslab;      /* or NULL */
-  long long slab_stride, bslab_stride;
+  float* aslab;      /* or NULL */
+  long long slab_stride, bslab_stride, aslab_stride;
   int g_width, g_off, g_cols;
   int a0_width, a0_off, a0_cols, a0_shift;
   int a1_width, a1_off, a1_cols, a1_shift;
-  int nblk, L, nsplit, blocks_per_split;
+  int nblk, L, nsplit, blocks_per_split, pad_;
 } ws_gemm_tnb_args;
 int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream);
 

@@ -195,3 +195,25 @@ def test_training_step_matches_oracle_step():
     # Adam's early steps are ~ -lr*sign(g): a 1e-4 relative gradient error flips the sign of the
     # few elements whose gradient is ~0, each flip costing 2*lr -> a few 1e-2 relative on the update.
     assert worst < 5e-2, worst
+
+
+def test_side_stream_weight_gradients_are_identical(monkeypatch):
+    """The weight-gradient GEMMs run on a side stream and reach autograd through carrier nodes
+    (functional.WGradCarrierFn); the result must be bit-identical to the single-stream path."""
+    from oracle import bsrnn_oracle as O
+    from wesep_amd.functional import SISDRFn
+    d = _cuda()
+    kw = dict(num_repeat=2, spk_fuse_type="FiLM", multi_fuse=True)
+    wav, tgt, emb = O.synth_batch(4, 16000, 11)
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("WESEP_WGRAD_OVERLAP", mode)
+        cfg, params, model = _build(kw, 8, d)
+        model.train()
+        est, _ = model(wav.to(d), emb.to(d))
+        SISDRFn.apply(est, tgt.to(d), 1e-8).backward()
+        torch.cuda.synchronize()
+        grads[mode] = {n: p.grad.clone() for n, p in model.named_parameters()}
+        assert all(g is not None for g in grads[mode].values())
+    for n in grads["1"]:
+        assert torch.equal(grads["1"][n], grads["0"][n]), n

@@ -525,11 +525,12 @@ def test_gemm_tnb_vs_torch(view, dims):
     Gb, A0b, A1b = (dev.to_blocked(t.to(d), seq) for t in (G, A0, A1))
     nb = dev.bl_num_blocks(seq)
     for shift in (-1, 1):
-        ns, bps = dev.tnb_splits(nb, seq.L, (g_cols // 128) * 3)
+        ns, bps = dev.tnb_splits(nb, g_cols // 128)
         slab, bslab = torch.empty(ns, g_cols * 384, device=d), torch.empty(ns, g_cols, device=d)
+        aslab = torch.empty(ns, 384, device=d)
         dev.gemm_tnb(G=Gb, g_width=GW, g_off=g_off, g_cols=g_cols, A0=A0b, a0_width=N, a0_off=0, a0_cols=N,
                      A1=A1b, a1_width=512, a1_off=256, a1_cols=256, a1_shift=shift, nblk=nb, L_=seq.L,
-                     slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab)
+                     slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab, aslab=aslab)
         out = slab.sum(0).view(g_cols, 384)
         # reference: shift the A1 rows by one step inside each sequence
         pos, valid = dev.bl_positions(seq, torch.device("cpu"))
@@ -548,3 +549,11 @@ def test_gemm_tnb_vs_torch(view, dims):
         ref = torch.cat([Gs.t() @ A0.double(), Gs.t() @ A1s.double()], 1)
         assert rel(out, ref) < 4e-5
         assert rel(bslab.sum(0), Gs.sum(0)) < 1e-5
+        assert rel(aslab.sum(0), torch.cat([A0.double().sum(0), A1s.double().sum(0)])) < 1e-5
+    # single A tile (dW_proj^T form): G = A1 (512 columns), A = A0
+    ns, bps = dev.tnb_splits(nb, 4)
+    slab, aslab = torch.empty(ns, 512 * 128, device=d), torch.empty(ns, 128, device=d)
+    dev.gemm_tnb(G=A1b, g_width=512, g_off=0, g_cols=512, A0=A0b, a0_width=N, a0_off=0, a0_cols=N, nblk=nb,
+                 L_=seq.L, slab=slab, nsplit=ns, blocks_per_split=bps, aslab=aslab)
+    assert rel(slab.sum(0).view(512, 128), A1.double().t() @ A0.double()) < 4e-5
+    assert rel(aslab.sum(0), A0.double().sum(0)) < 1e-5

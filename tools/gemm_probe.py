@@ -87,7 +87,7 @@ for view in ("time", "band"):
     G = torch.randn(nb, 32 * 2048, device=d)
     xn = torch.randn(nb, 32 * 128, device=d)
     h = torch.randn(nb, 32 * 512, device=d)
-    ns, bps = dev.tnb_splits(nb, seq.L, 8 * 3)
+    ns, bps = dev.tnb_splits(nb, 8)
     slab, bslab = torch.empty(ns, 1024 * 384, device=d), torch.empty(ns, 1024, device=d)
     t = timeit(lambda: dev.gemm_tnb(G=G, g_width=2048, g_off=0, g_cols=1024, A0=xn, a0_width=128, a0_off=0, a0_cols=128,
                                     A1=h, a1_width=512, a1_off=0, a1_cols=256, a1_shift=-1, nblk=nb, L_=seq.L,

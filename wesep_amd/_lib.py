@@ -67,11 +67,11 @@ class GemmB2PArgs(C.Structure):
 
 
 class GemmTNBArgs(C.Structure):
-    _fields_ = [(n, _p) for n in ("G", "A0", "A1", "slab", "bslab")] + \
-               [(n, _ll) for n in ("slab_stride", "bslab_stride")] + \
+    _fields_ = [(n, _p) for n in ("G", "A0", "A1", "slab", "bslab", "aslab")] + \
+               [(n, _ll) for n in ("slab_stride", "bslab_stride", "aslab_stride")] + \
                [(n, _i) for n in ("g_width", "g_off", "g_cols", "a0_width", "a0_off", "a0_cols", "a0_shift",
                                   "a1_width", "a1_off", "a1_cols", "a1_shift", "nblk", "L", "nsplit",
-                                  "blocks_per_split")]
+                                  "blocks_per_split", "pad_")]
 
 
 class Bands(C.Structure):

@@ -327,117 +327,138 @@ extern "C" int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream) {
 // ---------------------------------------------------------------------------------------------
 // tnb: out[g][a] = sum over blocks b in the split, slots i of G[(b,i)][g] * A[(b + shift,i)][a].
 // The contraction index is the slot.  A [32 slots x 128 columns] sub-block of BL is one contiguous
-// 16 KB: the workgroup reads it with fully coalesced 64-byte-per-thread loads (thread = (quad,
-// 4 consecutive slots) = a 4x4 register block), transposes that block in registers for free and
-// writes each column's 4 consecutive slots as one 8-byte bf16 group into a [column][slot] LDS
-// image (row stride 80 B: conflict-free 16-byte fragment reads).  128 x 128 output tile per
-// workgroup, 4 waves x (2x2) MFMA tiles; next block's global loads in flight under the MFMAs.
+// 16 KB: the workgroup reads it with fully coalesced 64-byte-per-thread loads (a thread owns one
+// "group" = (quad, 4 consecutive slots) = a 4x4 register block), transposes that block in registers
+// for free and writes each column's 4 consecutive slots as one 8-byte bf16 group into a
+// [column][slot] LDS image (row stride 80 B: conflict-free 16-byte fragment reads).
+// One workgroup (8 waves, 2 x 4) owns 128 G columns x ALL A columns (TA tiles of 128; TA = 3 for
+// [dW_ih | dW_hh], 1 otherwise), so G -- the big operand -- crosses L2/HBM exactly once.  Global
+// loads run TWO blocks ahead of the MFMAs (the block loop is HBM-latency-bound otherwise).
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define TB_LD 40
-#define TB_PLANE (128 * TB_LD)
 
-__global__ __launch_bounds__(256, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args p) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[4 * TB_PLANE];  // G_hi, G_lo, A_hi, A_lo: 40 KB
+template <int TA>
+__global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args p) {
+  constexpr int NCOL = 128 * (1 + TA);   // LDS columns: G tile, then the A tiles
+  constexpr int PLANE = NCOL * TB_LD;    // bf16 elements per part
+  constexpr int NG = (1 + TA) / 2;       // groups per thread (512 threads, 256 groups per 128 columns)
+  constexpr int TN = TA == 1 ? 1 : TA;   // 32-column MFMA tiles per wave along A (wave owns 32*TA columns)
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * PLANE];  // [hi | lo][column][slot]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 1, wn = w & 1;
-  const int quad = tid >> 3, sg = tid & 7;
-  const int atiles = (p.a0_cols + p.a1_cols) / 128;
-  const int gt = blockIdx.x / atiles, at = blockIdx.x % atiles;
-  const int split = blockIdx.y;
-  const bool src1 = at * 128 >= p.a0_cols;
-  const float* Ab = src1 ? p.A1 : p.A0;
-  const int a_w = src1 ? p.a1_width : p.a0_width;
-  const int a_q0 = (src1 ? p.a1_off + at * 128 - p.a0_cols : p.a0_off + at * 128) / 4;
-  const int shift = src1 ? p.a1_shift : p.a0_shift;
-  const int g_q0 = (p.g_off + gt * 128) / 4;
+  const int wm = w >> 2, wn = w & 3;
+  // x = split: workgroups that share the A operand (same split, different G tile) differ by a
+  // multiple of gridDim.x (a multiple of 8 when nsplit is) in dispatch order -> same XCD -> one L2
+  const int gt = blockIdx.y, split = blockIdx.x;
   const int L = p.L;
   const int b_begin = split * p.blocks_per_split;
   const int b_end = min(p.nblk, b_begin + p.blocks_per_split);
-  const long long g_lane = (long long)(g_q0 + quad) * 128 + sg * 16;
-  const long long a_lane = (long long)(a_q0 + quad) * 128 + sg * 16;
-  const long long g_bs = 32LL * p.g_width, a_bs = 32LL * a_w;
 
-  f32x4 gr[4], ar[4];
-  bool use = true;
-  auto load_block = [&](int b) {
+  // this thread's groups: g = tid + 512*r -> part (0 = G, 1.. = A tile), quad, slot group
+  const float* gbase[NG];
+  long long gstride[NG];
+  int gshift[NG], gcol[NG];
+#pragma unroll
+  for (int r = 0; r < NG; ++r) {
+    const int g = tid + 512 * r;
+    const int part = g >> 8, quad = (g >> 3) & 31, sg = g & 7;
+    gcol[r] = part * 128 + 4 * quad;
+    if (part == 0) {
+      gbase[r] = p.G + (long long)((p.g_off + gt * 128) / 4 + quad) * 128 + sg * 16;
+      gstride[r] = 32LL * p.g_width;
+      gshift[r] = 0;
+    } else {
+      const int c0 = (part - 1) * 128;  // first column of this A tile in Acat
+      const bool s1 = c0 >= p.a0_cols;
+      const float* base = s1 ? p.A1 : p.A0;
+      const int off = s1 ? p.a1_off + c0 - p.a0_cols : p.a0_off + c0;
+      gbase[r] = base + (long long)(off / 4 + quad) * 128 + sg * 16;
+      gstride[r] = 32LL * (s1 ? p.a1_width : p.a0_width);
+      gshift[r] = s1 ? p.a1_shift : p.a0_shift;
+    }
+  }
+  const int sg = tid & 7;
+
+  f32x4 rq[2][NG][4];  // two blocks in flight
+  bool use[2][NG];
+  auto load_block = [&](int b, int slot) {
     const int tile = b / L, step = b - tile * L;
-    const int sa = step + shift;
-    use = sa >= 0 && sa < L;
-    const float* gp = p.G + (long long)b * g_bs + g_lane;
-    const float* ap = Ab + (long long)(use ? b + shift : b) * a_bs + a_lane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      gr[j] = *reinterpret_cast<const f32x4*>(gp + 4 * j);
-      ar[j] = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+    for (int r = 0; r < NG; ++r) {
+      const int sa = step + gshift[r];
+      use[slot][r] = sa >= 0 && sa < L;
+      const float* src = gbase[r] + (long long)(use[slot][r] ? b + gshift[r] : b) * gstride[r];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rq[slot][r][j] = *reinterpret_cast<const f32x4*>(src + 4 * j);
     }
   };
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  auto store_block = [&]() {
+  float csum[NG][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      bf16x4 hi, lo;
+  for (int r = 0; r < NG; ++r)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float v = gr[j][c];
-        bsum[c] += v;
-        hi[j] = (__bf16)v;
-        lo[j] = (__bf16)(v - (float)hi[j]);
+    for (int c = 0; c < 4; ++c) csum[r][c] = 0.f;
+  auto store_block = [&](int slot) {
+#pragma unroll
+    for (int r = 0; r < NG; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = use[slot][r] ? rq[slot][r][j][c] : 0.f;
+          csum[r][c] += v;
+          hi[j] = (__bf16)v;
+          lo[j] = (__bf16)(v - (float)hi[j]);
+        }
+        const int o = (gcol[r] + c) * TB_LD + 4 * sg;
+        *reinterpret_cast<bf16x4*>(lds + o) = hi;
+        *reinterpret_cast<bf16x4*>(lds + PLANE + o) = lo;
       }
-      const int o = (4 * quad + c) * TB_LD + 4 * sg;
-      *reinterpret_cast<bf16x4*>(lds + o) = hi;
-      *reinterpret_cast<bf16x4*>(lds + TB_PLANE + o) = lo;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float v = use ? ar[j][c] : 0.f;
-        hi[j] = (__bf16)v;
-        lo[j] = (__bf16)(v - (float)hi[j]);
-      }
-      *reinterpret_cast<bf16x4*>(lds + 2 * TB_PLANE + o) = hi;
-      *reinterpret_cast<bf16x4*>(lds + 3 * TB_PLANE + o) = lo;
-    }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][TN];
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < TN; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
 
-  if (b_begin < b_end) load_block(b_begin);
-  for (int b = b_begin; b < b_end; ++b) {
-    __syncthreads();  // previous block's fragment reads are done
-    store_block();
-    __syncthreads();
-    if (b + 1 < b_end) load_block(b + 1);
+  if (b_begin < b_end) load_block(b_begin, 0);
+  if (b_begin + 1 < b_end) load_block(b_begin + 1, 1);
+  for (int b = b_begin; b < b_end; b += 2) {
 #pragma unroll
-    for (int ks = 0; ks < 32; ks += 16) {
-      const int ka = ks + 8 * half;
-      bf16x8 gh[2], gl[2], ah[2], al[2];
+    for (int s = 0; s < 2; ++s) {
+      if (b + s < b_end) {  // uniform
+        __syncthreads();    // previous block's fragment reads are done
+        store_block(s);
+        __syncthreads();
+        if (b + s + 2 < b_end) load_block(b + s + 2, s);
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int rg = (wm * 64 + e * 32 + l31) * TB_LD + ka;
-        const int ra = (wn * 64 + e * 32 + l31) * TB_LD + ka;
-        gh[e] = *reinterpret_cast<const bf16x8*>(lds + rg);
-        gl[e] = *reinterpret_cast<const bf16x8*>(lds + TB_PLANE + rg);
-        ah[e] = *reinterpret_cast<const bf16x8*>(lds + 2 * TB_PLANE + ra);
-        al[e] = *reinterpret_cast<const bf16x8*>(lds + 3 * TB_PLANE + ra);
+        for (int ks = 0; ks < 32; ks += 16) {
+          const int ka = ks + 8 * half;
+          bf16x8 gh[2], gl[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int rg = (wm * 64 + e * 32 + l31) * TB_LD + ka;
+            gh[e] = *reinterpret_cast<const bf16x8*>(lds + rg);
+            gl[e] = *reinterpret_cast<const bf16x8*>(lds + PLANE + rg);
+          }
+#pragma unroll
+          for (int f = 0; f < TN; ++f) {
+            const int ra = (128 + wn * 32 * TN + f * 32 + l31) * TB_LD + ka;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + ra);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + PLANE + ra);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(gh[e], ah, acc[e][f]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(gl[e], ah, acc[e][f]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(gh[e], al, acc[e][f]);
+          }
+        }
       }
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int f = 0; f < 2; ++f) acc[e][f] = mfma32(gh[e], ah[f], acc[e][f]);
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int f = 0; f < 2; ++f) acc[e][f] = mfma32(gl[e], ah[f], acc[e][f]);
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int f = 0; f < 2; ++f) acc[e][f] = mfma32(gh[e], al[f], acc[e][f]);
     }
   }
 
@@ -446,22 +467,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int acol = at * 128 + wn * 64 + f * 32 + l31;
+    for (int f = 0; f < TN; ++f) {
+      const int acol = wn * 32 * TN + f * 32 + l31;
+      if (acol < ncols) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gcol = gt * 128 + wm * 64 + e * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        out[(long long)gcol * ncols + acol] = acc[e][f][r];
+        for (int r = 0; r < 16; ++r) {
+          const int grow = gt * 128 + wm * 64 + e * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          out[(long long)grow * ncols + acol] = acc[e][f][r];
+        }
       }
     }
-  if (p.bslab && at == 0) {
+  // column sums: of G (bias gradient) and, on request, of the A columns (gt == 0 only)
+#pragma unroll
+  for (int r = 0; r < NG; ++r) {
+    const int part = (tid + 512 * r) >> 8;
+    float* dst = part == 0 ? p.bslab : (gt == 0 ? p.aslab : nullptr);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      float t = bsum[c];
+      float t = csum[r][c];
       t += __shfl_xor(t, 1, 64);
       t += __shfl_xor(t, 2, 64);
       t += __shfl_xor(t, 4, 64);
-      if (sg == 0) p.bslab[(long long)split * p.bslab_stride + gt * 128 + 4 * quad + c] = t;
+      if (dst && sg == 0) {
+        if (part == 0)
+          dst[(long long)split * p.bslab_stride + gt * 128 + gcol[r] + c] = t;
+        else
+          dst[(long long)split * p.aslab_stride + gcol[r] - 128 + c] = t;
+      }
     }
   }
 }
@@ -474,13 +506,18 @@ extern "C" int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream) {
              "ws_gemm_tnb: A0 column range");
   WS_REQUIRE(a->a1_cols == 0 || (a->A1 && a->a1_cols % 128 == 0 && a->a1_off % 4 == 0 && a->a1_width % 4 == 0),
              "ws_gemm_tnb: A1 column range");
+  const int ta = (a->a0_cols + a->a1_cols) / 128;
+  WS_REQUIRE(ta == 1 || ta == 3, "ws_gemm_tnb: A columns must total 128 or 384 (got %d)", ta * 128);
   WS_REQUIRE(a->nblk > 0 && a->L > 0 && a->nblk % a->L == 0 && a->nsplit > 0 && a->blocks_per_split > 0 &&
                  (long long)a->nsplit * a->blocks_per_split >= a->nblk,
              "ws_gemm_tnb: bad block split");
-  const int atiles = (a->a0_cols + a->a1_cols) / 128;
   hipStream_t s = (hipStream_t)stream;
+  dim3 grid(a->nsplit, a->g_cols / 128), block(512);
   ws_prof_begin(WS_PROF_GEMM_TN, s);
-  hipLaunchKernelGGL(gemm_tnb_kernel, dim3((a->g_cols / 128) * atiles, a->nsplit), dim3(256), 0, s, *a);
+  if (ta == 3)
+    hipLaunchKernelGGL((gemm_tnb_kernel<3>), grid, block, 0, s, *a);
+  else
+    hipLaunchKernelGGL((gemm_tnb_kernel<1>), grid, block, 0, s, *a);
   ws_prof_end(WS_PROF_GEMM_TN, s);
   return ws_check_launch("ws_gemm_tnb");
 }

@@ -242,18 +242,29 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
     const int tn = d == 0 ? sn : L - 1 - sn;
     __bf16* nhi = &hl[cur ^ 1][0][l31 * HROW + ubase];
     __bf16* nlo = &hl[cur ^ 1][1][l31 * HROW + ubase];
+    // pre-activations = recurrent part + x-projection; then ALL of the next step's x-projection
+    // loads at once, as early as possible: every later load of this wave (the weight stream of the
+    // next step) returns behind them, so their HBM latency has to start running now
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[g][4 * j + r] += xg[g][j][r];
+    if (!(DBG & 2)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xg[g][j] = ld_gate(tn, g, j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 pre[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pre[g][r] = acc[g][4 * j + r] + xg[g][j][r];
-      // next step's x-projection into the registers just consumed
-      if (!(DBG & 2)) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xg[g][j] = ld_gate(tn, g, j);
-      }
+        for (int r = 0; r < 4; ++r) pre[g][r] = acc[g][4 * j + r];
       f32x4 vi, vf, vg, vo, vc, vh;
       const f32x4 cold = *reinterpret_cast<const f32x4*>(cme + 8 * j);
 #pragma unroll

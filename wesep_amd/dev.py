@@ -420,23 +420,25 @@ def gemm_b2p(*, A, K: int, sm: SeqMap, Wpack, C_out, ldc: int, N=128, bias=None,
     L.check(L.lib().ws_gemm_b2p(C.byref(a), L.stream_ptr()), "ws_gemm_b2p")
 
 
-def tnb_splits(nblk: int, L_: int, tiles: int):
-    """Splits of the block range so that tiles * nsplit covers the chip a few times over."""
-    nsplit = max(1, min(64, -(-1024 // tiles), nblk))
+def tnb_splits(nblk: int, gtiles: int):
+    """Splits of the block range: gtiles * nsplit workgroups ~ one per CU (256), at most 64 slabs."""
+    nsplit = max(1, min(64, 256 // gtiles, nblk))
+    if nsplit >= 8:
+        nsplit -= nsplit % 8          # multiple of 8: same-split workgroups share an XCD (and its L2)
     bps = -(-nblk // nsplit)
-    nsplit = -(-nblk // bps)
-    return nsplit, bps
+    return nsplit, bps                # trailing splits may be empty (they write zero slabs)
 
 
 def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_off: int, a0_cols: int,
              nblk: int, L_: int, slab, nsplit: int, blocks_per_split: int, a0_shift=0, A1=None, a1_width=0,
-             a1_off=0, a1_cols=0, a1_shift=0, bslab=None):
-    for n, t in (("G", G), ("A0", A0), ("A1", A1), ("slab", slab), ("bslab", bslab)):
+             a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None):
+    for n, t in (("G", G), ("A0", A0), ("A1", A1), ("slab", slab), ("bslab", bslab), ("aslab", aslab)):
         _chk(t, n)
     a = L.GemmTNBArgs()
-    a.G, a.A0, a.A1, a.slab, a.bslab = _p(G), _p(A0), _p(A1), _p(slab), _p(bslab)
+    a.G, a.A0, a.A1, a.slab, a.bslab, a.aslab = _p(G), _p(A0), _p(A1), _p(slab), _p(bslab), _p(aslab)
     a.slab_stride = g_cols * (a0_cols + a1_cols)
     a.bslab_stride = g_cols
+    a.aslab_stride = a0_cols + a1_cols
     a.g_width, a.g_off, a.g_cols = g_width, g_off, g_cols
     a.a0_width, a.a0_off, a.a0_cols, a.a0_shift = a0_width, a0_off, a0_cols, a0_shift
     a.a1_width, a.a1_off, a.a1_cols, a.a1_shift = a1_width, a1_off, a1_cols, a1_shift

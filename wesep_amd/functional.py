@@ -156,14 +156,100 @@ def resrnn_mode() -> str:
     return os.environ.get("WESEP_RESRNN", "blocked")
 
 
+def wgrad_overlap() -> bool:
+    """Weight-gradient GEMMs of the blocked ResRNN on a side stream (default on; WESEP_WGRAD_OVERLAP=0
+    keeps everything on the current stream)."""
+    return os.environ.get("WESEP_WGRAD_OVERLAP", "1") != "0"
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+_PENDING = {}   # device key -> deferred weight-gradient jobs (closures), oldest first
+
+
+def _pending(device):
+    return _PENDING.setdefault((device.type, device.index), [])
+
+
+def reset_deferred_wgrads(device):
+    """Drop deferred jobs (start of a step: a failed backward may have left some behind)."""
+    _pending(device).clear()
+
+
+def flush_deferred_wgrads(device):
+    """Launch every deferred weight-gradient job on the side stream, ordered after everything
+    enqueued so far on the current stream.  Called right before a TIME-VIEW recurrence is launched
+    (64 of 256 CUs busy for ~7 ms: the jobs fill the other 192) and by the carriers for leftovers."""
+    jobs = _pending(device)
+    if not jobs:
+        return
+    main, side = torch.cuda.current_stream(), _side_stream(device)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        for job in jobs:
+            job(side)
+    jobs.clear()
+
+
+class WGradBox:
+    """Hand-over slot between a ResRNN's backward (producer, side stream) and its carrier node."""
+    __slots__ = ("event", "grads")
+
+    def __init__(self):
+        self.event, self.grads = None, None
+
+
+class WGradCarrierFn(torch.autograd.Function):
+    """Delivers the LSTM / proj weight gradients of one ResRNN to autograd.
+
+    The time-view recurrences occupy 64 of the 256 CUs for ~7 ms each; the weight-gradient GEMMs are
+    a side branch of the backward graph (nothing downstream reads them), so ResRNNBlkFn.backward
+    launches them on a side HIP stream where they fill the idle CUs under the NEXT layers'
+    recurrences.  Autograd, however, wants a node's gradients when its backward returns.  This node
+    is the way out: it is created BEFORE every ResRNN of the step (lowest sequence numbers, so the
+    engine runs it after all of them), takes the weights as inputs and hands their gradients over
+    once the current stream has waited for the side stream's event."""
+
+    @staticmethod
+    def forward(ctx, box, *params):
+        ctx.box = box
+        return params[0].new_zeros(())
+
+    @staticmethod
+    def backward(ctx, _g):
+        box = ctx.box
+        if box.grads is None:
+            flush_deferred_wgrads(_g.device)   # leftovers of the last layers
+        if box.grads is None:
+            raise L.WesepHipError("weight-gradient carrier ran before its ResRNN backward")
+        cur = torch.cuda.current_stream()
+        cur.wait_event(box.event)
+        grads, box.grads = box.grads, None
+        for g in grads:
+            g.record_stream(cur)
+        return (None,) + tuple(grads)
+
+
 class ResRNNBlkFn(torch.autograd.Function):
     """ResRNN on the blocked layout: gates / c / h / d(h) never exist in row-major form; every
     activation byte of the recurrence moves as part of a 512-byte contiguous run (include/wesep_hip.h,
     "blocked layout BL").  Same inputs as ResRNNFn."""
 
     @staticmethod
-    def forward(ctx, z, view, norm_w, norm_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r,
+    def forward(ctx, z, dummy, box, view, norm_w, norm_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r,
                 bhh_r, proj_w, proj_b):
+        """dummy/box: None, or the output and the box of this ResRNN's WGradCarrierFn -- then the ten
+        LSTM / proj tensors are passed detached and their gradients travel through the box."""
         _need_cuda(z, "ResRNN")
         z = z.contiguous()
         R, K, Tf, N = z.shape
@@ -192,36 +278,22 @@ class ResRNNBlkFn(torch.autograd.Function):
         out = torch.empty_like(z)
         dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=proj_pack, C_out=out, ldc=N, bias=proj_b, R=z)
         ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw)
-        ctx.view = view
+        ctx.view, ctx.box = view, box
         return out
 
     @staticmethod
-    def backward(ctx, dout):
-        z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw = ctx.saved_tensors
-        dout = dout.contiguous()
-        R, K, Tf, N = z.shape
-        P = R * K * Tf
-        d = z.device
-        geo, smap, seq, _ = _view_maps(ctx.view, R, K, Tf, N)
-        nb = dev.bl_num_blocks(seq)
-        # d(hcat) = dout Wp  (+ dout itself in BL for the weight gradient)
-        wpt_pack = _empty(d, 2 * H * N)
-        dev.pack_w(pw, 2 * H, N, 2 * H, wpt_pack, trans=True, order=0)
-        dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
-        dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wpt_pack, N=2 * H, C_out=dh, A_bl=dout_bl)
-        # dW_proj [N][2H] = dout^T hcat,  db_proj = colsum(dout)
-        ns, bps = dev.tnb_splits(nb, seq.L, (2 * H) // 128)
-        slab, bslab = _empty(d, ns, N * 2 * H), _empty(d, ns, N)
-        dev.gemm_tnb(G=dout_bl, g_width=N, g_off=0, g_cols=N, A0=hcat, a0_width=2 * H, a0_off=0, a0_cols=2 * H,
-                     nblk=nb, L_=seq.L, slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab)
-        dproj_w = _reduce_new(slab, ns, N * 2 * H, (N, 2 * H))
-        dproj_b = _reduce_new(bslab, ns, N, (N,))
-        del dout_bl
-        # BPTT: gates (activated) -> d(pre-activation gates), in place
-        dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, L.LSTM_BF16X3_BLK)
-        del dh
-        # [dW_ih | dW_hh] and the bias gradient of each direction in ONE pass over its dgates
-        ns, bps = dev.tnb_splits(nb, seq.L, (G4 // 128) * ((N + H) // 128))
+    def _weight_grads(gates, xn, hcat, dout_bl, seq, nb, N):
+        """[dW_ih | dW_hh | db] of both directions in one pass over each direction's dgates, and
+        dW_proj / db_proj; launched on the current stream.  Returns them in parameter order."""
+        d = gates.device
+        # dW_proj^T [2H][N] = hcat^T dout (hcat as the streamed-once operand), db_proj = colsum(dout)
+        ns, bps = dev.tnb_splits(nb, (2 * H) // 128)
+        slab, aslab = _empty(d, ns, 2 * H * N), _empty(d, ns, N)
+        dev.gemm_tnb(G=hcat, g_width=2 * H, g_off=0, g_cols=2 * H, A0=dout_bl, a0_width=N, a0_off=0, a0_cols=N,
+                     nblk=nb, L_=seq.L, slab=slab, nsplit=ns, blocks_per_split=bps, aslab=aslab)
+        dproj_w = _reduce_new(slab, ns, 2 * H * N, (2 * H, N)).t().contiguous()
+        dproj_b = _reduce_new(aslab, ns, N, (N,))
+        ns, bps = dev.tnb_splits(nb, G4 // 128)
         slab, bslab = _empty(d, ns, G4 * (N + H)), _empty(d, ns, G4)
         dwih, dwhh, db = [], [], []
         for di in (0, 1):
@@ -233,7 +305,45 @@ class ResRNNBlkFn(torch.autograd.Function):
             dwih.append(dw[:, :N].contiguous())
             dwhh.append(dw[:, N:].contiguous())
             db.append(_reduce_new(bslab, ns, G4, (G4,)))
-        del slab, bslab
+        # b_ih and b_hh receive the same gradient; clone so their .grad never alias
+        return [dwih[0], dwhh[0], db[0], db[0].clone(), dwih[1], dwhh[1], db[1], db[1].clone(),
+                dproj_w, dproj_b]
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw = ctx.saved_tensors
+        dout = dout.contiguous()
+        R, K, Tf, N = z.shape
+        P = R * K * Tf
+        d = z.device
+        geo, smap, seq, _ = _view_maps(ctx.view, R, K, Tf, N)
+        nb = dev.bl_num_blocks(seq)
+        box = ctx.box
+        # d(hcat) = dout Wp  (+ dout itself in BL for the weight gradient)
+        wpt_pack = _empty(d, 2 * H * N)
+        dev.pack_w(pw, 2 * H, N, 2 * H, wpt_pack, trans=True, order=0)
+        dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
+        dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wpt_pack, N=2 * H, C_out=dh, A_bl=dout_bl)
+        # BPTT: gates (activated) -> d(pre-activation gates), in place.  A time-view recurrence leaves
+        # 3/4 of the chip idle: release the weight-gradient jobs deferred by the previous layers first
+        if ctx.view == "time":
+            flush_deferred_wgrads(d)
+        dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, L.LSTM_BF16X3_BLK)
+        del dh
+        # weight gradients: a side branch of the graph -> deferred to the side stream when a carrier
+        # will deliver them
+        if box is not None:
+            def job(side, gates=gates, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, N=N, box=box):
+                box.grads = ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N)
+                box.event = torch.cuda.Event()
+                box.event.record(side)
+                for t in (gates, xn, hcat, dout_bl):
+                    t.record_stream(side)
+            _pending(d).append(job)
+            wg = [None] * 10
+        else:
+            wg = ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N)
+        del dout_bl
         # d(normalised input) = dgates Wcat -> GroupNorm backward (+ residual path)
         wct_pack = _empty(d, N * 2 * G4)
         dev.pack_w(wcat, N, 2 * G4, N, wct_pack, trans=True, order=1)
@@ -247,16 +357,29 @@ class ResRNNBlkFn(torch.autograd.Function):
         dgb = _reduce_new(pslab, ns2, 2 * N, (2, N))
         dz = torch.empty_like(z)
         dev.gn_bwd_apply(z, dxn, stats, ab, geo, dz, gamma=norm_w, res=dout)
-        return (dz, None, dgb[0], dgb[1],
-                dwih[0], dwhh[0], db[0], db[0].clone(),
-                dwih[1], dwhh[1], db[1], db[1].clone(),
-                dproj_w, dproj_b)
+        gd = torch.zeros((), device=d) if box is not None else None
+        return (dz, gd, None, None, dgb[0], dgb[1]) + tuple(wg)
 
 
-def resrnn(z, view, *params):
+def make_wgrad_carrier(params):
+    """(dummy, box) for one ResRNN, or None when the side-stream hand-over does not apply.  `params`:
+    the ten LSTM / proj tensors in ResRNNFn order.  Must be called BEFORE the forward of every ResRNN
+    of the step (see WGradCarrierFn)."""
+    if not (wgrad_overlap() and resrnn_mode() == "blocked" and torch.is_grad_enabled()
+            and params[0].is_cuda and all(p.requires_grad for p in params)):
+        return None
+    box = WGradBox()
+    return WGradCarrierFn.apply(box, *params), box
+
+
+def resrnn(z, view, norm_w, norm_b, *params, carrier=None):
     """ResRNN forward (autograd-aware) on the path selected by WESEP_RESRNN."""
-    fn = ResRNNBlkFn if resrnn_mode() == "blocked" else ResRNNFn
-    return fn.apply(z, view, *params)
+    if resrnn_mode() != "blocked":
+        return ResRNNFn.apply(z, view, norm_w, norm_b, *params)
+    if carrier is None:
+        return ResRNNBlkFn.apply(z, None, None, view, norm_w, norm_b, *params)
+    dummy, box = carrier
+    return ResRNNBlkFn.apply(z, dummy, box, view, norm_w, norm_b, *(p.detach() for p in params))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -33,13 +33,18 @@ class ResRNN(nn.Module):
         self.rnn = nn.LSTM(input_size, hidden_size, 1, batch_first=True, bidirectional=True)
         self.proj = nn.Linear(hidden_size * 2, input_size)
 
-    def forward(self, z, view="time"):
+    def _wparams(self):
         r = self.rnn
-        return F_.resrnn(
-            z, view, self.norm.weight, self.norm.bias,
-            r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0,
-            r.weight_ih_l0_reverse, r.weight_hh_l0_reverse, r.bias_ih_l0_reverse, r.bias_hh_l0_reverse,
-            self.proj.weight, self.proj.bias)
+        return (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0,
+                r.weight_ih_l0_reverse, r.weight_hh_l0_reverse, r.bias_ih_l0_reverse, r.bias_hh_l0_reverse,
+                self.proj.weight, self.proj.bias)
+
+    def make_carrier(self):
+        """Weight-gradient carrier of this layer (functional.WGradCarrierFn) or None."""
+        return F_.make_wgrad_carrier(self._wparams())
+
+    def forward(self, z, view="time", carrier=None):
+        return F_.resrnn(z, view, self.norm.weight, self.norm.bias, *self._wparams(), carrier=carrier)
 
 
 class BSNet(nn.Module):
@@ -52,8 +57,9 @@ class BSNet(nn.Module):
         self.band_rnn = ResRNN(self.feature_dim, self.feature_dim * 2, bidirectional)
         self.band_comm = ResRNN(self.feature_dim, self.feature_dim * 2, bidirectional)
 
-    def forward(self, z, dummy: Optional[torch.Tensor] = None):
-        return self.band_comm(self.band_rnn(z, "time"), "band")
+    def forward(self, z, dummy: Optional[torch.Tensor] = None, carriers=None):
+        c_t, c_b = carriers if carriers is not None else (None, None)
+        return self.band_comm(self.band_rnn(z, "time", c_t), "band", c_b)
 
 
 class FuseSeparation(nn.Module):
@@ -75,8 +81,17 @@ class FuseSeparation(nn.Module):
                 self.separation.append(BSNet(nband * feature_dim, nband))
 
     def forward(self, z, spk_embedding, nch=None):
-        for layer in self.separation:
-            z = layer(z, spk_embedding)
+        # weight-gradient carriers first: autograd then runs them after every ResRNN's backward, so the
+        # side-stream weight-gradient GEMMs overlap the following layers (functional.WGradCarrierFn)
+        if z.is_cuda:
+            F_.reset_deferred_wgrads(z.device)
+        carriers = {i: (l.band_rnn.make_carrier(), l.band_comm.make_carrier())
+                    for i, l in enumerate(self.separation) if isinstance(l, BSNet)}
+        for i, layer in enumerate(self.separation):
+            if isinstance(layer, BSNet):
+                z = layer(z, spk_embedding, carriers[i])
+            else:
+                z = layer(z, spk_embedding)
         return z
 
 
