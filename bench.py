@@ -170,6 +170,15 @@ def main():
     sec = prof[dom]["ms_avg"] * 1e-3 if prof[dom]["launches"] else float("inf")
     gbs = bytes_per_launch / sec / 1e9
     tfl = flops_per_launch / sec / 1e12
+    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/pmc_summary.py);
+    # bench.py cannot collect counters itself, so this is the profile of the same command, or null
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        hit = [v for k, v in pmc.items() if k.startswith(f"void {dom}_bf16_kernel<true")]
+        traffic = hit[0]["hbm_bytes_per_launch_corrected"] if hit else None
+    except (OSError, KeyError, ValueError):
+        pass
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -188,7 +197,7 @@ def main():
             # stream), not by the matrix cores: HBM is the roof they are priced against
             "roofline": {"bound": "hbm", "kernel": dom + "_bf16_kernel<BLK> (avg of time/band views)",
                          "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_launch": bytes_per_launch,
+                         "traffic": traffic, "bytes_per_launch": bytes_per_launch,
                          "ms_per_launch": prof[dom]["ms_avg"],
                          "mfma": {"alg_tflops": tfl, "executed_bf16_tflops": 3 * tfl,
                                   "peak_bf16_tflops": BF16_MFMA_PEAK_TFLOPS,
