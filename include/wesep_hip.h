@@ -163,6 +163,8 @@ typedef struct ws_lstm_args {
 #define WS_LSTM_BF16X3_BLK 4 /* as 3, but gates / cbuf / hcat / dhcat are in the blocked layout BL
                                 (below): block b = tile * L + step, tile = 32 consecutive sequences;
                                 the sq_* / step_rows fields are ignored                           */
+#define WS_LSTM_BF16X3_BLK16 5 /* as 4 with 16-sequence workgroups (two per tile): for views with too few
+                                  sequences to fill the chip with 32-sequence workgroups         */
 #define WS_LSTM_H 256
 #define WS_LSTM_PACK_FLOATS (2 * 4 * WS_LSTM_H * WS_LSTM_H) /* per pass, both directions */
 /* Packs weight_hh_l0 / _reverse [4H][H] into MFMA fragment order for the fwd and bwd pass
@@ -172,6 +174,23 @@ int ws_lstm_pack(const float* whh_f, const float* whh_r, float* pack_fwd, float*
 int ws_lstm_fwd(const ws_lstm_args* a, void* stream);
 /* On exit gates holds dL/d(pre-activation gates).                                           */
 int ws_lstm_bwd(const ws_lstm_args* a, void* stream);
+/* Weight-stationary forward recurrence over clusters of 8 co-resident workgroups (blocked layout,
+ * same gates / cbuf / hcat contract as WS_LSTM_BF16X3_BLK): W_hh stays in registers, h_t is exchanged
+ * through `xchg` each step.  nseq % 64 == 0 and (nseq / 32) * 8 <= CUs of the device (checked).
+ * xchg: (nseq / 32) * 128 KB scratch; flags: (nseq / 32) * 8 words (zeroed by the call on `stream`);
+ * status (optional): set to 1 if a bounded wait timed out (outputs are then NaN).               */
+typedef struct ws_lstm_cluster_args {
+  float* gates;
+  float* cbuf;
+  float* hcat;
+  const float* whh_f;   /* weight_hh_l0          [4H][H] fp32 */
+  const float* whh_r;   /* weight_hh_l0_reverse  [4H][H] fp32 */
+  void* xchg;
+  unsigned* flags;
+  unsigned* status;
+  int nseq, L;
+} ws_lstm_cluster_args;
+int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream);
 /* wcat[2][4H][N] <- (w_ih_f, w_ih_r);  bcat[2][4H] <- b_ih + b_hh per direction             */
 int ws_lstm_cat_ih(const float* wih_f, const float* wih_r, const float* bih_f, const float* bhh_f,
                    const float* bih_r, const float* bhh_r, int n_in, float* wcat, float* bcat,

@@ -224,12 +224,12 @@ def test_group_stats_and_gn_backward(view):
 # ----------------------------------------------------------------------------------------------
 # LSTM recurrence
 # ----------------------------------------------------------------------------------------------
-LSTM_TOL = {1: (1e-5, 2e-5), 2: (1e-5, 2e-5), 3: (4e-5, 8e-5), 4: (4e-5, 8e-5)}   # 3/4 = split-bf16 (drops lo*lo)
+LSTM_TOL = {1: (1e-5, 2e-5), 2: (1e-5, 2e-5), 3: (4e-5, 8e-5), 4: (4e-5, 8e-5), 5: (4e-5, 8e-5)}   # 3/4 = split-bf16 (drops lo*lo)
 
 
 @pytest.mark.parametrize("dims", [(2, 5, 11), (3, 7, 37)])
 @pytest.mark.parametrize("view,mt", [("time", 1), ("band", 1), ("time", 2), ("band", 2), ("time", 3), ("band", 3),
-                                     ("time", 4), ("band", 4)])
+                                     ("time", 4), ("band", 4), ("time", 5), ("band", 5)])
 def test_lstm_fwd_bwd_vs_torch(view, mt, dims):
     from wesep_amd import dev, _lib as L
     from wesep_amd.functional import _view_maps
@@ -260,7 +260,7 @@ def test_lstm_fwd_bwd_vs_torch(view, mt, dims):
     dev.lstm_pack(lstm.weight_hh_l0.detach().to(d).contiguous(),
                   lstm.weight_hh_l0_reverse.detach().to(d).contiguous(), pf, pb, mt)
     cbuf, hcat = torch.zeros(P, 2 * H, device=d), torch.zeros(P, 2 * H, device=d)
-    blocked = mt == 4            # mode 4: the same kernels on the blocked layout BL
+    blocked = mt >= 4            # modes 4/5: the blocked layout BL (32- / 16-sequence workgroups)
     if blocked:
         gates = dev.to_blocked(gates.view(P, 8 * H), seq)
         nb = dev.bl_num_blocks(seq)
@@ -557,3 +557,48 @@ def test_gemm_tnb_vs_torch(view, dims):
                  L_=seq.L, slab=slab, nsplit=ns, blocks_per_split=bps, aslab=aslab)
     assert rel(slab.sum(0).view(512, 128), A1.double().t() @ A0.double()) < 4e-5
     assert rel(aslab.sum(0), A0.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("view,dims", [("time", (2, 32, 70)), ("time", (4, 32, 11)), ("band", (4, 9, 16))])
+def test_lstm_fwd_cluster_vs_torch(view, dims):
+    """Weight-stationary cluster recurrence (lstm_cluster.hip): same contract as the blocked forward;
+    checked against torch's LSTM, for run-to-run identity, and against the streaming kernel."""
+    from wesep_amd import dev, _lib as L
+    from wesep_amd.functional import _view_maps
+    d = _cuda()
+    g = torch.Generator().manual_seed(41)
+    (R, K, Tf), N, H = dims, 128, 256
+    P = R * K * Tf
+    geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+    assert seq.nseq % 64 == 0
+    lstm = torch.nn.LSTM(N, H, 1, batch_first=True, bidirectional=True)
+    x = rnd(g, R, K, Tf, N)
+    xs = x.reshape(R * K, Tf, N) if view == "time" else x.permute(0, 2, 1, 3).reshape(R * Tf, K, N)
+    with torch.no_grad():
+        out, _ = lstm(xs)
+        gx = []
+        for sfx in ("", "_reverse"):
+            w, bi, bh = (getattr(lstm, n + sfx) for n in ("weight_ih_l0", "bias_ih_l0", "bias_hh_l0"))
+            gx.append(x.reshape(P, N) @ w.t() + bi + bh)
+    gates0 = dev.to_blocked(torch.stack(gx, 1).reshape(P, 8 * H).to(d), seq)
+    nb = dev.bl_num_blocks(seq)
+    whf, whr = lstm.weight_hh_l0.detach().to(d).contiguous(), lstm.weight_hh_l0_reverse.detach().to(d).contiguous()
+    res = []
+    status = torch.zeros(1, device=d, dtype=torch.int32)
+    for _ in range(2):
+        gates = gates0.clone()
+        cbuf, hcat = torch.zeros(nb, 2 * H // 4, 32, 4, device=d), torch.zeros(nb, 2 * H // 4, 32, 4, device=d)
+        dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq, status=status)
+        res.append((gates, cbuf, hcat))
+    assert int(status.item()) == 0                                   # no bounded wait timed out
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))    # deterministic
+    href = out.reshape(R, K, Tf, 2 * H) if view == "time" else out.reshape(R, Tf, K, 2 * H).permute(0, 2, 1, 3)
+    assert rel(dev.from_blocked(res[0][2], seq, P).view(R, K, Tf, 2 * H), href) < 4e-5
+    # the streaming kernel computes the same thing (different MFMA order: compare, do not equate)
+    pf, pb = torch.empty(L.LSTM_PACK_FLOATS, device=d), torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack(whf, whr, pf, pb, L.LSTM_BF16X3_BLK)
+    gates = gates0.clone()
+    cbuf, hcat = torch.zeros_like(res[0][1]), torch.zeros_like(res[0][2])
+    dev.lstm_fwd(gates, cbuf, hcat, pf, seq, L.LSTM_BF16X3_BLK)
+    for a, b in zip(res[0], (gates, cbuf, hcat)):
+        assert rel(dev.from_blocked(a, seq, P), dev.from_blocked(b, seq, P)) < 4e-5

@@ -16,7 +16,7 @@ WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
 ABI_VERSION = 2
-LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK = 1, 2, 3, 4
+LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
 _p = C.c_void_p
@@ -74,6 +74,11 @@ class GemmTNBArgs(C.Structure):
                                   "blocks_per_split", "pad_")]
 
 
+class LstmClusterArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "whh_f", "whh_r", "xchg", "flags", "status")] + \
+               [("nseq", _i), ("L", _i)]
+
+
 class Bands(C.Structure):
     _fields_ = [("band_of_bin", _p), ("band_f0", _p), ("band_bw", _p), ("nband", _i), ("nbins", _i)]
 
@@ -105,6 +110,7 @@ _SIGS = {
     "ws_lstm_pack": (_i, [_p, _p, _p, _p, _i, _p]),
     "ws_lstm_fwd": (_i, [C.POINTER(LstmArgs), _p]),
     "ws_lstm_bwd": (_i, [C.POINTER(LstmArgs), _p]),
+    "ws_lstm_fwd_cluster": (_i, [C.POINTER(LstmClusterArgs), _p]),
     "ws_lstm_cat_ih": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "ws_pack_w": (_i, [_p, _i, _i, _ll, _i, _i, _p, _p]),
     "ws_gemm_p2b": (_i, [C.POINTER(GemmP2BArgs), _p]),

@@ -36,6 +36,11 @@ int ws_launch_lstm_pack_bf16(const float* whh_f, const float* whh_r, float* pack
                              hipStream_t s);
 int ws_launch_lstm_fwd_bf16(const ws_lstm_args* a, hipStream_t s);
 int ws_launch_lstm_bwd_bf16(const ws_lstm_args* a, hipStream_t s);
+// 16-sequence workgroups on the blocked layout (lstm_bf16_s16.hip), mode WS_LSTM_BF16X3_BLK16
+int ws_launch_lstm_pack_s16(const float* whh_f, const float* whh_r, float* pack_fwd, float* pack_bwd,
+                            hipStream_t s);
+int ws_launch_lstm_fwd_s16(const ws_lstm_args* a, hipStream_t s);
+int ws_launch_lstm_bwd_s16(const ws_lstm_args* a, hipStream_t s);
 
 // ---- device helpers -----------------------------------------------------------
 __device__ __forceinline__ float ws_wave_sum(float v) {

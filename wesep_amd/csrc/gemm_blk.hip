@@ -344,7 +344,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
   constexpr int PLANE = NCOL * TB_LD;    // bf16 elements per part
   constexpr int NG = (1 + TA) / 2;       // groups per thread (512 threads, 256 groups per 128 columns)
   constexpr int TN = TA == 1 ? 1 : TA;   // 32-column MFMA tiles per wave along A (wave owns 32*TA columns)
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * PLANE];  // [hi | lo][column][slot]
+  // two LDS images [buf][hi | lo][column][slot]: block b+1 is converted and written while block b's
+  // fragments are read, one barrier per block (TA = 3: 2 x 80 KB = the whole LDS of the CU)
+  __shared__ __attribute__((aligned(16))) __bf16 lds2[2][2 * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 2, wn = w & 3;
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
   for (int r = 0; r < NG; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) csum[r][c] = 0.f;
-  auto store_block = [&](int slot) {
+  auto store_block = [&](int slot, __bf16* lds) {
 #pragma unroll
     for (int r = 0; r < NG; ++r)
 #pragma unroll
@@ -427,14 +429,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
 
   if (b_begin < b_end) load_block(b_begin, 0);
   if (b_begin + 1 < b_end) load_block(b_begin + 1, 1);
+  if (b_begin < b_end) store_block(0, lds2[0]);
+  __syncthreads();
   for (int b = b_begin; b < b_end; b += 2) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       if (b + s < b_end) {  // uniform
-        __syncthreads();    // previous block's fragment reads are done
-        store_block(s);
-        __syncthreads();
-        if (b + s + 2 < b_end) load_block(b + s + 2, s);
+        // registers of slot s (block b+s) were consumed by the previous store: refill them 2 blocks ahead
+        if (b + s + 2 < b_end && !(p.pad_ & 1)) load_block(b + s + 2, s);
+        // block b+s+1 (register slot s^1) -> the other LDS image, under this block's MFMAs
+        if (b + s + 1 < b_end && !(p.pad_ & 2)) store_block(s ^ 1, lds2[s ^ 1]);
+        const __bf16* lds = lds2[s];
+        if (!(p.pad_ & 4))
 #pragma unroll
         for (int ks = 0; ks < 32; ks += 16) {
           const int ka = ks + 8 * half;
@@ -458,6 +464,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
             for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(gh[e], al, acc[e][f]);
           }
         }
+        __syncthreads();  // image s fully read, image s^1 fully written
       }
     }
   }

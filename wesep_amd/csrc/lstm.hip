@@ -80,7 +80,11 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh_f, const float* _
 extern "C" int ws_lstm_pack(const float* whh_f, const float* whh_r, float* pack_fwd,
                             float* pack_bwd, int mode, void* stream) {
   WS_REQUIRE(whh_f && whh_r && pack_fwd && pack_bwd, "ws_lstm_pack: null pointer");
-  WS_REQUIRE(mode >= WS_LSTM_F32_MT1 && mode <= WS_LSTM_BF16X3_BLK, "ws_lstm_pack: bad mode %d", mode);
+  WS_REQUIRE(mode >= WS_LSTM_F32_MT1 && mode <= WS_LSTM_BF16X3_BLK16, "ws_lstm_pack: bad mode %d", mode);
+  if (mode == WS_LSTM_BF16X3_BLK16) {
+    ws_launch_lstm_pack_s16(whh_f, whh_r, pack_fwd, pack_bwd, (hipStream_t)stream);
+    return ws_check_launch("ws_lstm_pack");
+  }
   if (mode >= WS_LSTM_BF16X3) {
     ws_launch_lstm_pack_bf16(whh_f, whh_r, pack_fwd, pack_bwd, (hipStream_t)stream);
     return ws_check_launch("ws_lstm_pack");
@@ -377,7 +381,7 @@ static int lstm_check(const ws_lstm_args* a, bool bwd, const char* who) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->wpack, "%s: null pointer", who);
   WS_REQUIRE(!bwd || a->dhcat, "%s: null dhcat", who);
   WS_REQUIRE(a->nseq > 0 && a->L > 0 && a->sq_div > 0, "%s: bad nseq/L/sq_div", who);
-  WS_REQUIRE((a->mode & 255) >= WS_LSTM_F32_MT1 && (a->mode & 255) <= WS_LSTM_BF16X3_BLK, "%s: bad mode %d", who,
+  WS_REQUIRE((a->mode & 255) >= WS_LSTM_F32_MT1 && (a->mode & 255) <= WS_LSTM_BF16X3_BLK16, "%s: bad mode %d", who,
              a->mode);
   return WS_OK;
 }
@@ -389,7 +393,9 @@ extern "C" int ws_lstm_fwd(const ws_lstm_args* a, void* stream) {
   const int per = 16 * a->mode;
   dim3 grid((a->nseq + per - 1) / per, 2), block(512);
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
-  if ((a->mode & 255) >= WS_LSTM_BF16X3)
+  if ((a->mode & 255) == WS_LSTM_BF16X3_BLK16)
+    ws_launch_lstm_fwd_s16(a, s);
+  else if ((a->mode & 255) >= WS_LSTM_BF16X3)
     ws_launch_lstm_fwd_bf16(a, s);
   else if (a->mode == WS_LSTM_F32_MT1)
     hipLaunchKernelGGL((lstm_fwd_kernel<1>), grid, block, 0, s, *a);
@@ -406,7 +412,9 @@ extern "C" int ws_lstm_bwd(const ws_lstm_args* a, void* stream) {
   const int per = 16 * a->mode;
   dim3 grid((a->nseq + per - 1) / per, 2), block(512);
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
-  if ((a->mode & 255) >= WS_LSTM_BF16X3)
+  if ((a->mode & 255) == WS_LSTM_BF16X3_BLK16)
+    ws_launch_lstm_bwd_s16(a, s);
+  else if ((a->mode & 255) >= WS_LSTM_BF16X3)
     ws_launch_lstm_bwd_bf16(a, s);
   else if (a->mode == WS_LSTM_F32_MT1)
     hipLaunchKernelGGL((lstm_bwd_kernel<1>), grid, block, 0, s, *a);

@@ -21,55 +21,7 @@
 //
 // Per step a 32-sequence workgroup needs 1 MB from L2 (~7.5 us at the per-CU L1 fill rate) against
 // ~5 us of MFMA: the kernel is L2-stream bound in the time view, by design -- see DESIGN.md.
-#include "common.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-#define LH WS_LSTM_H  // 256
-#define LG (4 * LH)   // 1024
-#define SQ 32         // sequences per workgroup (MFMA N)
-#define HROW 264      // bf16 per LDS row of h      (256 + 8: 528 B = 4 banks mod 64)
-#define DROW 1032     // bf16 per LDS row of dgates (1024 + 8: 2064 B = 4 banks mod 64)
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// Weight stream: raw buffer loads (SGPR descriptor + SGPR step offset + one VGPR lane offset), so the
-// stream costs no 64-bit VGPR address arithmetic.  `soff` carries an opaque zero so the compiler
-// cannot see that the addresses repeat every step (hoisting 128 fragments out of the loop = spills).
-__device__ __forceinline__ bf16x8 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
-}
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t mkrsrc(const float* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 bld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void bst(const f32x4& v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
-}
-
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float ftanh(float x) {
-  const float ax = fabsf(x);
-  const float e = __expf(-2.f * ax);  // in (0, 1]: no overflow
-  const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
-  return copysignf(t, x);
-}
-
-__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    hi[j] = (__bf16)v[j];
-    lo[j] = (__bf16)(v[j] - (float)hi[j]);
-  }
-}
+#include "lstm_bf16_common.h"
 
 // ---------------------------------------------------------------------------------------------
 // weight packing (16-byte units of 8 bf16; `lane` = the MFMA lane that will load the unit)

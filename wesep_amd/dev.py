@@ -199,6 +199,15 @@ def lstm_mode(nseq: int) -> int:
     return L.LSTM_F32_MT2 if nseq >= 8192 else L.LSTM_F32_MT1
 
 
+def lstm_blk_mode(nseq: int) -> int:
+    """Blocked-layout recurrence: 16-sequence workgroups when 32-sequence ones would cover well under
+    the 256 CUs (pBSRNN's time view: 1024 sequences), else 32.  WESEP_LSTM_SEQS=16|32 overrides."""
+    env = os.environ.get("WESEP_LSTM_SEQS")
+    if env:
+        return L.LSTM_BF16X3_BLK16 if env == "16" else L.LSTM_BF16X3_BLK
+    return L.LSTM_BF16X3_BLK16 if 2 * (-(-nseq // 32)) <= 128 else L.LSTM_BF16X3_BLK
+
+
 def lstm_pack(whh_f, whh_r, pack_fwd, pack_bwd, mode=L.LSTM_BF16X3):
     for n, t in (("whh_f", whh_f), ("whh_r", whh_r), ("pack_fwd", pack_fwd), ("pack_bwd", pack_bwd)):
         _chk(t, n)
@@ -231,6 +240,41 @@ def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3):
 def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3):
     a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat)
     L.check(L.lib().ws_lstm_bwd(C.byref(a), L.stream_ptr()), "ws_lstm_bwd")
+
+
+_CU_COUNT = {}
+
+
+def cu_count(device) -> int:
+    key = (device.type, device.index)
+    if key not in _CU_COUNT:
+        _CU_COUNT[key] = torch.cuda.get_device_properties(device).multi_processor_count
+    return _CU_COUNT[key]
+
+
+def lstm_cluster_ok(sm: SeqMap, device) -> bool:
+    """The weight-stationary cluster recurrence needs 64-sequence clusters that are all co-resident
+    (8 workgroups per 64 sequences per direction <= CUs) and pays off for long sequences only.
+    WESEP_LSTM_CLUSTER=0 disables it."""
+    if os.environ.get("WESEP_LSTM_CLUSTER", "1") == "0":
+        return False
+    return sm.nseq % 64 == 0 and (sm.nseq // 32) * 8 <= cu_count(device) and sm.L >= 64
+
+
+def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None):
+    """Forward recurrence on the blocked layout with W_hh resident in registers across clusters of 8
+    workgroups (lstm_cluster.hip).  Allocates its exchange scratch (4 MB at R = 32)."""
+    for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("whh_f", whh_f), ("whh_r", whh_r)):
+        _chk(t, n)
+    ncl = sm.nseq // 32
+    xchg = torch.empty(ncl * 2 * 8 * 8192 // 4, device=gates.device, dtype=torch.float32)
+    flags = torch.empty(ncl * 8, device=gates.device, dtype=torch.int32)
+    a = L.LstmClusterArgs()
+    a.gates, a.cbuf, a.hcat, a.whh_f, a.whh_r = _p(gates), _p(cbuf), _p(hcat), _p(whh_f), _p(whh_r)
+    a.xchg, a.flags = C.c_void_p(xchg.data_ptr()), C.c_void_p(flags.data_ptr())
+    a.status = C.c_void_p(status.data_ptr()) if status is not None else None
+    a.nseq, a.L = sm.nseq, sm.L
+    L.check(L.lib().ws_lstm_fwd_cluster(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_cluster")
 
 
 class BandTables:
@@ -431,7 +475,7 @@ def tnb_splits(nblk: int, gtiles: int):
 
 def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_off: int, a0_cols: int,
              nblk: int, L_: int, slab, nsplit: int, blocks_per_split: int, a0_shift=0, A1=None, a1_width=0,
-             a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None):
+             a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, dbg=0):
     for n, t in (("G", G), ("A0", A0), ("A1", A1), ("slab", slab), ("bslab", bslab), ("aslab", aslab)):
         _chk(t, n)
     a = L.GemmTNBArgs()
@@ -442,5 +486,5 @@ def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_
     a.g_width, a.g_off, a.g_cols = g_width, g_off, g_cols
     a.a0_width, a.a0_off, a.a0_cols, a.a0_shift = a0_width, a0_off, a0_cols, a0_shift
     a.a1_width, a.a1_off, a.a1_cols, a.a1_shift = a1_width, a1_off, a1_cols, a1_shift
-    a.nblk, a.L, a.nsplit, a.blocks_per_split = nblk, L_, nsplit, blocks_per_split
+    a.nblk, a.L, a.nsplit, a.blocks_per_split, a.pad_ = nblk, L_, nsplit, blocks_per_split, dbg
     L.check(L.lib().ws_gemm_tnb(C.byref(a), L.stream_ptr()), "ws_gemm_tnb")

@@ -266,19 +266,23 @@ class ResRNNBlkFn(torch.autograd.Function):
         wih_pack = _empty(d, 2 * G4 * N)
         dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
         pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
-        dev.lstm_pack(whh_f.contiguous(), whh_r.contiguous(), pack_f, pack_b, L.LSTM_BF16X3_BLK)
+        lmode = dev.lstm_blk_mode(seq.nseq)
+        dev.lstm_pack(whh_f.contiguous(), whh_r.contiguous(), pack_f, pack_b, lmode)
         gates, xn = _empty(d, nb, 32 * 2 * G4), _empty(d, nb, 32 * N)
         dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=gates, bias=bcat, A_bl=xn,
                      stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap)
         cbuf, hcat = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * 2 * H)
-        dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, L.LSTM_BF16X3_BLK)
+        if dev.lstm_cluster_ok(seq, d):
+            dev.lstm_fwd_cluster(gates, cbuf, hcat, whh_f.contiguous(), whh_r.contiguous(), seq)
+        else:
+            dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode)
         pw = proj_w.contiguous()
         proj_pack = _empty(d, N * 2 * H)
         dev.pack_w(pw, N, 2 * H, 2 * H, proj_pack, order=1)
         out = torch.empty_like(z)
         dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=proj_pack, C_out=out, ldc=N, bias=proj_b, R=z)
         ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw)
-        ctx.view, ctx.box = view, box
+        ctx.view, ctx.box, ctx.lmode = view, box, lmode
         return out
 
     @staticmethod
@@ -328,7 +332,7 @@ class ResRNNBlkFn(torch.autograd.Function):
         # 3/4 of the chip idle: release the weight-gradient jobs deferred by the previous layers first
         if ctx.view == "time":
             flush_deferred_wgrads(d)
-        dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, L.LSTM_BF16X3_BLK)
+        dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, ctx.lmode)
         del dh
         # weight gradients: a side branch of the graph -> deferred to the side stream when a carrier
         # will deliver them
