@@ -189,6 +189,7 @@ typedef struct ws_lstm_cluster_args {
   unsigned* flags;
   unsigned* status;
   int nseq, L;
+  int dbg, pad_;        /* probe builds only: 1 skip the flag wait, 2 skip the gather, 4 skip the publish */
 } ws_lstm_cluster_args;
 int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream);
 /* wcat[2][4H][N] <- (w_ih_f, w_ih_r);  bcat[2][4H] <- b_ih + b_hh per direction             */

@@ -76,7 +76,7 @@ class GemmTNBArgs(C.Structure):
 
 class LstmClusterArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "whh_f", "whh_r", "xchg", "flags", "status")] + \
-               [("nseq", _i), ("L", _i)]
+               [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i)]
 
 
 class Bands(C.Structure):

@@ -74,11 +74,16 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
   const int gs = tid >> 3, gq = tid & 7;                                 // ... = (seq, quad) for the LDS fill
   gu32* flags = (gu32*)(p.flags) + c * 8;
 
-  f32x4 xg[4], c4 = {0.f, 0.f, 0.f, 0.f};
+  // x-projection prefetched TWO steps ahead (xg = this step, xn = next): the loads are issued behind the
+  // payload gather of a step and would otherwise be needed one short MFMA phase later
+  f32x4 xg[4], xn[4], c4 = {0.f, 0.f, 0.f, 0.f};
   {
-    const int t0 = d == 0 ? 0 : L - 1;
+    const int t0 = d == 0 ? 0 : L - 1, t1 = d == 0 ? min(1, L - 1) : max(L - 2, 0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) xg[g] = bld(grs(t0), glane, g * 64 * 512);
+    for (int g = 0; g < 4; ++g) {
+      xg[g] = bld(grs(t0), glane, g * 64 * 512);
+      xn[g] = bld(grs(t1), glane, g * 64 * 512);
+    }
   }
   __syncthreads();
 
@@ -127,13 +132,13 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
       bf16x4 hi, lo;
       split4(vh, hi, lo);
       struct { bf16x4 a, b; } pk = {hi, lo};
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), xrs, xpub, par * (8 * 8192), SC1);
+      if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), xrs, xpub, par * (8 * 8192), SC1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flags + j, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- wait for the other seven (one wave polls, relaxed; bounded) ---------------------------------
-    if (w == 0 && !dead) {
+    if (w == 0 && !dead && !(p.dbg & 1)) {
       unsigned spins = 0;
       while (true) {
         const unsigned v = lane < 8 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -156,9 +161,10 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
     u32x4 pv[8];
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
-      pv[jj] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xget + jj * 8192, par * (8 * 8192), SC1);
+      pv[jj] = (p.dbg & 2) ? u32x4{0u, 0u, 0u, 0u}
+                           : __builtin_amdgcn_raw_buffer_load_b128(xrs, xget + jj * 8192, par * (8 * 8192), SC1);
     {
-      const int sn = min(step + 1, L - 1);
+      const int sn = min(step + 2, L - 1);
       const int tn = d == 0 ? sn : L - 1 - sn;
       bst(vi, grs(t), glane, 0);
       bst(vf, grs(t), glane, 64 * 512);
@@ -167,7 +173,10 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
       bst(c4, crs(p.cbuf, t), clane, 0);
       bst(vh, crs(p.hcat, t), clane, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) xg[g] = bld(grs(tn), glane, g * 64 * 512);
+      for (int g = 0; g < 4; ++g) {
+        xg[g] = xn[g];
+        xn[g] = bld(grs(tn), glane, g * 64 * 512);
+      }
     }
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {

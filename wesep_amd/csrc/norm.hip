@@ -21,6 +21,13 @@ __device__ __forceinline__ GroupView group_view(const ws_groups_geom& geo, int g
   return v;
 }
 
+// V4: uniform width, W and every stride multiples of 4 floats -> 16-byte accesses (the ResRNN / mask
+// geometries); the scalar path serves the ragged per-band widths of the band-split norm.
+static bool geom_vec4(const ws_groups_geom* g) {
+  return !g->band_w && !g->band_off && g->W % 4 == 0 && g->rs % 4 == 0 && g->gs1 % 4 == 0 && g->gs2 % 4 == 0;
+}
+
+template <bool V4>
 __global__ __launch_bounds__(256) void group_stats_kernel(const float* __restrict__ x,
                                                           const ws_groups_geom geo, float eps,
                                                           float* __restrict__ stats) {
@@ -30,12 +37,29 @@ __global__ __launch_bounds__(256) void group_stats_kernel(const float* __restric
   const int n = geo.L * v.W;
   const float* xb = x + v.base;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int row = i / v.W, col = i - row * v.W;
-    s += xb[(long long)row * geo.rs + col];
+  if (V4) {
+    const int w4 = v.W >> 2;
+    for (int i = threadIdx.x; i < (n >> 2); i += 256) {
+      const int row = i / w4, c4 = i - row * w4;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(xb + (long long)row * geo.rs + 4 * c4);
+      s += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int row = i / v.W, col = i - row * v.W;
+      s += xb[(long long)row * geo.rs + col];
+    }
   }
   const float mean = ws_block_sum(s, red) / (float)n;
   float q = 0.f;
+  if (V4) {
+    const int w4 = v.W >> 2;
+    for (int i = threadIdx.x; i < (n >> 2); i += 256) {
+      const int row = i / w4, c4 = i - row * w4;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(xb + (long long)row * geo.rs + 4 * c4) - mean;
+      q += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+    }
+  } else
   for (int i = threadIdx.x; i < n; i += 256) {
     const int row = i / v.W, col = i - row * v.W;
     const float dv = xb[(long long)row * geo.rs + col] - mean;
@@ -60,11 +84,16 @@ extern "C" int ws_group_stats(const float* x, const ws_groups_geom* geo, float e
   int rc = geom_check(geo, "ws_group_stats");
   if (rc != WS_OK) return rc;
   WS_REQUIRE(x && stats, "ws_group_stats: null pointer");
-  hipLaunchKernelGGL(group_stats_kernel, dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream, x,
-                     *geo, eps, stats);
+  if (geom_vec4(geo))
+    hipLaunchKernelGGL((group_stats_kernel<true>), dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream, x,
+                       *geo, eps, stats);
+  else
+    hipLaunchKernelGGL((group_stats_kernel<false>), dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream, x,
+                       *geo, eps, stats);
   return ws_check_launch("ws_group_stats");
 }
 
+template <bool V4>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
     const float* __restrict__ x, const float* __restrict__ dxn, const float* __restrict__ stats,
     const float* __restrict__ gamma, const float* const* __restrict__ gamma_tab,
@@ -76,6 +105,17 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
   const int n = geo.L * v.W;
   const float mean = stats[2 * (long long)g], rstd = stats[2 * (long long)g + 1];
   float s1 = 0.f, s2 = 0.f;
+  if (V4) {
+    const int w4 = v.W >> 2;
+    for (int i = threadIdx.x; i < (n >> 2); i += 256) {
+      const int row = i / w4, c4 = i - row * w4;
+      const long long o = v.base + (long long)row * geo.rs + 4 * c4;
+      const f32x4 dg = *reinterpret_cast<const f32x4*>(dxn + o) * *reinterpret_cast<const f32x4*>(gm + 4 * c4);
+      const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mean) * rstd;
+      s1 += (dg[0] + dg[1]) + (dg[2] + dg[3]);
+      s2 += (dg[0] * xh[0] + dg[1] * xh[1]) + (dg[2] * xh[2] + dg[3] * xh[3]);
+    }
+  } else
   for (int i = threadIdx.x; i < n; i += 256) {
     const int row = i / v.W, col = i - row * v.W;
     const long long o = v.base + (long long)row * geo.rs + col;
@@ -97,11 +137,16 @@ extern "C" int ws_gn_bwd_reduce(const float* x, const float* dxn, const float* s
   int rc = geom_check(geo, "ws_gn_bwd_reduce");
   if (rc != WS_OK) return rc;
   WS_REQUIRE(x && dxn && stats && ab && (gamma || gamma_tab), "ws_gn_bwd_reduce: null pointer");
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream,
-                     x, dxn, stats, gamma, gamma_tab, *geo, ab);
+  if (geom_vec4(geo))
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<true>), dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream,
+                       x, dxn, stats, gamma, gamma_tab, *geo, ab);
+  else
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<false>), dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream,
+                       x, dxn, stats, gamma, gamma_tab, *geo, ab);
   return ws_check_launch("ws_gn_bwd_reduce");
 }
 
+template <bool V4>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const float* __restrict__ x, const float* dxn, const float* __restrict__ stats,
     const float* __restrict__ ab, const float* __restrict__ gamma,
@@ -113,6 +158,18 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
   const int n = geo.L * v.W;
   const float mean = stats[2 * (long long)g], rstd = stats[2 * (long long)g + 1];
   const float a0 = ab[2 * (long long)g], a1 = ab[2 * (long long)g + 1];
+  if (V4) {
+    const int w4 = v.W >> 2;
+    for (int i = threadIdx.x; i < (n >> 2); i += 256) {
+      const int row = i / w4, c4 = i - row * w4;
+      const long long o = v.base + (long long)row * geo.rs + 4 * c4;
+      const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mean) * rstd;
+      f32x4 r = (*reinterpret_cast<const f32x4*>(dxn + o) * *reinterpret_cast<const f32x4*>(gm + 4 * c4) - a0 - xh * a1) * rstd;
+      if (res) r += *reinterpret_cast<const f32x4*>(res + o);
+      *reinterpret_cast<f32x4*>(dx + o) = r;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < n; i += 256) {
     const int row = i / v.W, col = i - row * v.W;
     const long long o = v.base + (long long)row * geo.rs + col;
@@ -130,8 +187,12 @@ extern "C" int ws_gn_bwd_apply(const float* x, const float* dxn, const float* st
   int rc = geom_check(geo, "ws_gn_bwd_apply");
   if (rc != WS_OK) return rc;
   WS_REQUIRE(x && dxn && stats && ab && dx && (gamma || gamma_tab), "ws_gn_bwd_apply: null pointer");
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream, x,
-                     dxn, stats, ab, gamma, gamma_tab, res, *geo, dx);
+  if (geom_vec4(geo))
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream, x,
+                       dxn, stats, ab, gamma, gamma_tab, res, *geo, dx);
+  else
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<false>), dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream, x,
+                       dxn, stats, ab, gamma, gamma_tab, res, *geo, dx);
   return ws_check_launch("ws_gn_bwd_apply");
 }
 
@@ -171,6 +232,38 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restr
   }
 }
 
+// Same sums for the single-band, 128-wide geometries (ResRNN norms): 32 threads x float4 cover a row,
+// 8 row lanes per workgroup, groups strided over the splits.
+__global__ __launch_bounds__(256) void gn_param_grad128_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ dxn,
+                                                               const float* __restrict__ stats,
+                                                               const ws_groups_geom geo, int nsplit,
+                                                               float* __restrict__ slab) {
+  __shared__ f32x4 sh[2][8][32];
+  const int split = blockIdx.x;
+  const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+  for (int g = split; g < geo.ngroups; g += nsplit) {
+    const GroupView v = group_view(geo, g);
+    const float mean = stats[2 * (long long)g], rstd = stats[2 * (long long)g + 1];
+    for (int row = rl; row < geo.L; row += 8) {
+      const long long o = v.base + (long long)row * geo.rs + 4 * c4;
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(dxn + o);
+      sg += dv * ((*reinterpret_cast<const f32x4*>(x + o) - mean) * rstd);
+      sb += dv;
+    }
+  }
+  sh[0][rl][c4] = sg;
+  sh[1][rl][c4] = sb;
+  __syncthreads();
+  if (rl < 2) {  // rl 0 -> dgamma, rl 1 -> dbeta
+    f32x4 t = sh[rl][0][c4];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) t += sh[rl][r][c4];
+    *reinterpret_cast<f32x4*>(slab + ((long long)split * 2 + rl) * 128 + 4 * c4) = t;
+  }
+}
+
 extern "C" int ws_gn_param_grad(const float* x, const float* dxn, const float* stats,
                                 const ws_groups_geom* geo, int nsplit, float* slab, void* stream) {
   int rc = geom_check(geo, "ws_gn_param_grad");
@@ -178,7 +271,11 @@ extern "C" int ws_gn_param_grad(const float* x, const float* dxn, const float* s
   WS_REQUIRE(x && dxn && stats && slab && nsplit > 0, "ws_gn_param_grad: bad args");
   WS_REQUIRE(geo->ngroups % geo->nbands == 0, "ws_gn_param_grad: ngroups %% nbands != 0");
   WS_REQUIRE(geo->W <= 128, "ws_gn_param_grad: W > 128");
-  hipLaunchKernelGGL(gn_param_grad_kernel, dim3(geo->nbands, nsplit), dim3(256), 0,
-                     (hipStream_t)stream, x, dxn, stats, *geo, nsplit, slab);
+  if (geo->nbands == 1 && geo->W == 128 && geom_vec4(geo))
+    hipLaunchKernelGGL(gn_param_grad128_kernel, dim3(nsplit), dim3(256), 0, (hipStream_t)stream, x, dxn, stats,
+                       *geo, nsplit, slab);
+  else
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(geo->nbands, nsplit), dim3(256), 0,
+                       (hipStream_t)stream, x, dxn, stats, *geo, nsplit, slab);
   return ws_check_launch("ws_gn_param_grad");
 }

@@ -261,7 +261,7 @@ def lstm_cluster_ok(sm: SeqMap, device) -> bool:
     return sm.nseq % 64 == 0 and (sm.nseq // 32) * 8 <= cu_count(device) and sm.L >= 64
 
 
-def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None):
+def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0):
     """Forward recurrence on the blocked layout with W_hh resident in registers across clusters of 8
     workgroups (lstm_cluster.hip).  Allocates its exchange scratch (4 MB at R = 32)."""
     for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("whh_f", whh_f), ("whh_r", whh_r)):
@@ -273,7 +273,7 @@ def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None):
     a.gates, a.cbuf, a.hcat, a.whh_f, a.whh_r = _p(gates), _p(cbuf), _p(hcat), _p(whh_f), _p(whh_r)
     a.xchg, a.flags = C.c_void_p(xchg.data_ptr()), C.c_void_p(flags.data_ptr())
     a.status = C.c_void_p(status.data_ptr()) if status is not None else None
-    a.nseq, a.L = sm.nseq, sm.L
+    a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
     L.check(L.lib().ws_lstm_fwd_cluster(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_cluster")
 
 

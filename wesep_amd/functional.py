@@ -355,7 +355,7 @@ class ResRNNBlkFn(torch.autograd.Function):
         dev.gemm_b2p(A=gates, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dxn, ldc=N)
         ab = _empty(d, geo.ngroups, 2)
         dev.gn_bwd_reduce(z, dxn, stats, geo, ab, gamma=norm_w)
-        ns2 = min(256, geo.ngroups)
+        ns2 = min(1024, geo.ngroups)
         pslab = _empty(d, ns2, 2, N)
         dev.gn_param_grad(z, dxn, stats, geo, ns2, pslab)
         dgb = _reduce_new(pslab, ns2, 2 * N, (2, N))
