@@ -182,7 +182,8 @@ int ws_lstm_bwd(const ws_lstm_args* a, void* stream);
 typedef struct ws_lstm_cluster_args {
   float* gates;
   float* cbuf;
-  float* hcat;
+  float* hcat;          /* fwd: output */
+  const float* dhcat;   /* bwd: dL/dhcat, BL(512) */
   const float* whh_f;   /* weight_hh_l0          [4H][H] fp32 */
   const float* whh_r;   /* weight_hh_l0_reverse  [4H][H] fp32 */
   void* xchg;
@@ -192,6 +193,9 @@ typedef struct ws_lstm_cluster_args {
   int dbg, pad_;        /* probe builds only: 1 skip the flag wait, 2 skip the gather, 4 skip the publish */
 } ws_lstm_cluster_args;
 int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream);
+/* BPTT over the same clusters (reduce-scatter of partial dh each step): gates holds the activated
+ * gates on entry and d(pre-activation gates) on exit; xchg: (nseq / 32) * 1 MB.                 */
+int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream);
 /* wcat[2][4H][N] <- (w_ih_f, w_ih_r);  bcat[2][4H] <- b_ih + b_hh per direction             */
 int ws_lstm_cat_ih(const float* wih_f, const float* wih_r, const float* bih_f, const float* bhh_f,
                    const float* bih_r, const float* bhh_r, int n_in, float* wcat, float* bcat,

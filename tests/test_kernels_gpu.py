@@ -560,7 +560,7 @@ def test_gemm_tnb_vs_torch(view, dims):
 
 
 @pytest.mark.parametrize("view,dims", [("time", (2, 32, 70)), ("time", (4, 32, 11)), ("band", (4, 9, 16))])
-def test_lstm_fwd_cluster_vs_torch(view, dims):
+def test_lstm_cluster_fwd_bwd_vs_torch(view, dims):
     """Weight-stationary cluster recurrence (lstm_cluster.hip): same contract as the blocked forward;
     checked against torch's LSTM, for run-to-run identity, and against the streaming kernel."""
     from wesep_amd import dev, _lib as L
@@ -574,8 +574,12 @@ def test_lstm_fwd_cluster_vs_torch(view, dims):
     lstm = torch.nn.LSTM(N, H, 1, batch_first=True, bidirectional=True)
     x = rnd(g, R, K, Tf, N)
     xs = x.reshape(R * K, Tf, N) if view == "time" else x.permute(0, 2, 1, 3).reshape(R * Tf, K, N)
+    xs = xs.clone().requires_grad_(True)
+    out, _ = lstm(xs)
+    dout_seq = rnd(g, *out.shape)
+    out.backward(dout_seq)
+    out = out.detach()
     with torch.no_grad():
-        out, _ = lstm(xs)
         gx = []
         for sfx in ("", "_reverse"):
             w, bi, bh = (getattr(lstm, n + sfx) for n in ("weight_ih_l0", "bias_ih_l0", "bias_hh_l0"))
@@ -602,3 +606,19 @@ def test_lstm_fwd_cluster_vs_torch(view, dims):
     dev.lstm_fwd(gates, cbuf, hcat, pf, seq, L.LSTM_BF16X3_BLK)
     for a, b in zip(res[0], (gates, cbuf, hcat)):
         assert rel(dev.from_blocked(a, seq, P), dev.from_blocked(b, seq, P)) < 4e-5
+    # ---- BPTT over the same clusters --------------------------------------------------------------
+    dref = dout_seq.reshape(R, K, Tf, 2 * H) if view == "time" else dout_seq.reshape(R, Tf, K, 2 * H).permute(0, 2, 1, 3)
+    dh = dev.to_blocked(dref.contiguous().reshape(P, 2 * H).to(d), seq)
+    outs = []
+    for _ in range(2):
+        g2 = res[0][0].clone()
+        dev.lstm_bwd_cluster(g2, res[0][1], dh, whf, whr, seq, status=status)
+        outs.append(g2)
+    assert int(status.item()) == 0
+    assert torch.equal(outs[0], outs[1])
+    dg = dev.from_blocked(outs[0], seq, P).view(P, 2, 4 * H).cpu()
+    dx = dg[:, 0] @ lstm.weight_ih_l0.detach() + dg[:, 1] @ lstm.weight_ih_l0_reverse.detach()
+    dxref = xs.grad.reshape(R, K, Tf, N) if view == "time" else xs.grad.reshape(R, Tf, K, N).permute(0, 2, 1, 3)
+    assert rel(dx.view(R, K, Tf, N), dxref) < 8e-5
+    assert rel(dg[:, 0].sum(0), lstm.bias_ih_l0.grad) < 8e-5
+    assert rel(dg[:, 1].sum(0), lstm.bias_ih_l0_reverse.grad) < 8e-5

@@ -50,6 +50,12 @@ for view in ("time", "band"):
                 gates.copy_(gates0)
                 tc = timeit(lambda: dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq, dbg=dbg))
                 print(f"{view} CLUSTER fwd dbg={dbg} {tc:8.3f} ms ({tc * 1e3 / seq.L:6.2f} us/step)", flush=True)
+        if base == 4 and dev.lstm_cluster_ok(seq, d):
+            for dbg in (0, 1):
+                gates.copy_(gates0)
+                dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq)
+                tc = timeit(lambda: dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq, dbg=dbg))
+                print(f"{view} CLUSTER bwd dbg={dbg} {tc:8.3f} ms ({tc * 1e3 / seq.L:6.2f} us/step)", flush=True)
         steps = seq.L * (1 if view == "time" else -(-seq.nseq // 32 * 2) // 256)
         print(f"{view} mode={base} dbg={mode >> 8} fwd {tf:8.3f} ms  bwd {tb:8.3f} ms  "
               f"(nseq {seq.nseq}, L {seq.L}; per step-slot fwd {tf * 1e3 / steps:6.2f} us, bwd {tb * 1e3 / steps:6.2f} us)",

@@ -75,7 +75,7 @@ class GemmTNBArgs(C.Structure):
 
 
 class LstmClusterArgs(C.Structure):
-    _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "whh_f", "whh_r", "xchg", "flags", "status")] + \
+    _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "dhcat", "whh_f", "whh_r", "xchg", "flags", "status")] + \
                [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i)]
 
 
@@ -111,6 +111,7 @@ _SIGS = {
     "ws_lstm_fwd": (_i, [C.POINTER(LstmArgs), _p]),
     "ws_lstm_bwd": (_i, [C.POINTER(LstmArgs), _p]),
     "ws_lstm_fwd_cluster": (_i, [C.POINTER(LstmClusterArgs), _p]),
+    "ws_lstm_bwd_cluster": (_i, [C.POINTER(LstmClusterArgs), _p]),
     "ws_lstm_cat_ih": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "ws_pack_w": (_i, [_p, _i, _i, _ll, _i, _i, _p, _p]),
     "ws_gemm_p2b": (_i, [C.POINTER(GemmP2BArgs), _p]),

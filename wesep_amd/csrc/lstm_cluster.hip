@@ -205,3 +205,248 @@ extern "C" int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream) 
   ws_prof_end(WS_PROF_LSTM_FWD, s);
   return ws_check_launch("ws_lstm_fwd_cluster");
 }
+
+// =============================================================================================
+// Backward (BPTT) over the same clusters.
+//   dh_{t-1}[seq][u'] = sum_k dgates_t[seq][k] * W_hh[k][u'],  k over all 1024 gate columns.
+// Workgroup j owns the gate columns of ITS 32 units (128 rows of W_hh, resident in registers) and
+// computes, from its own dgates only, a PARTIAL dh for all 256 units; the eight partials are
+// exchanged as a reduce-scatter (partial rows of units 32i.. go to workgroup i: 8 x 8 KB fp32 out,
+// 8 x 8 KB in, per step) and summed in fixed order (deterministic).
+// Waves are specialised so that the latency-critical exchange never queues behind HBM traffic
+// (VMEM operations of one wave complete in order):
+//   M-waves (4..7): all HBM traffic -- saved gates / c / d(h) prefetched two steps ahead, the
+//                   element-wise BPTT update of the workgroup's 512 (seq, 4-unit) cells, d(gates)
+//                   stores, and the bf16 B-operand image of d(gates) in LDS;
+//   X-waves (0..3): the MFMAs (weights resident: 128 VGPRs), the write-through publish, the flag,
+//                   the poll, the gather + sum, and the reduced dh back to LDS for the M-waves.
+// =============================================================================================
+#define BK_ROW 136  // bf16 per LDS row of the local d(gates) image (128 + 8: 272 B = 4 banks mod 64)
+
+__global__ __launch_bounds__(512, 2) void lstm_bwd_cluster_kernel(const ws_lstm_cluster_args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 dgl[2][CL_SEQ * BK_ROW];  // [part][seq][local gate col] 34 KB
+  __shared__ __attribute__((aligned(16))) f32x4 rec[512];                  // reduced dh per cell, 8 KB
+  __shared__ int dead_s;
+  const int ntile = p.nseq / 32, ncl_dir = ntile / 2, ncl = 2 * ncl_dir;
+  const int c = blockIdx.x % ncl, j = blockIdx.x / ncl;
+  const int d = c / ncl_dir, cc = c % ncl_dir;
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool xrole = w < 4;
+  const int L = p.L;
+  const long long gblk = (long long)SQ * 2 * LG, cblk = (long long)SQ * 2 * LH;  // floats per block
+  for (int i = tid; i < 512; i += 512) rec[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid == 0) dead_s = 0;
+
+  // exchange: X[cluster][parity][dest][src][cell 512] x 16 B
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(p.xchg) + (long long)c * (2 * 64 * 8192), 0, 2 * 64 * 8192, 0x00020000);
+  gu32* flags = (gu32*)(p.flags) + c * 8;
+
+  auto step_t = [&](int step) { return d == 0 ? L - 1 - step : step; };
+  __syncthreads();
+
+  // The two roles are separate code paths with their own step loops (and matching barrier sequences
+  // A, A2, A3, B), so each gets its own register allocation: 128 VGPRs of resident weights for the
+  // X-waves, the two-deep HBM prefetch for the M-waves.
+  if (xrole) {
+    // ---- resident W^T fragments of unit tiles 2w, 2w+1 (rows = out unit, k = local gate column) ----
+    bf16x8 wh[2][8], wl[2][8];
+    {
+      const float* W = d ? p.whh_r : p.whh_f;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int u = 32 * (2 * w + e) + n;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int kl = 16 * ks + 8 * half + q;  // local gate column -> W_hh row
+            v[q] = W[(long long)((kl >> 5) * LH + 32 * j + (kl & 31)) * LH + u];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            wh[e][ks][q] = (__bf16)v[q];
+            wl[e][ks][q] = (__bf16)(v[q] - (float)wh[e][ks][q]);
+          }
+        }
+      }
+    }
+    for (int step = 0; step < L; ++step) {
+      const int par = step & 1;
+      __syncthreads();  // A: d(gates) image of this step complete
+      const bool dead = dead_s != 0;
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[e][st][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const int o = (st * 32 + n) * BK_ROW + 16 * ks + 8 * half;
+          bh[st] = *reinterpret_cast<const bf16x8*>(&dgl[0][o]);
+          bl[st] = *reinterpret_cast<const bf16x8*>(&dgl[1][o]);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int st = 0; st < 2; ++st) acc[e][st] = mfma32(wh[e][ks], bh[st], acc[e][st]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int st = 0; st < 2; ++st) acc[e][st] = mfma32(wl[e][ks], bh[st], acc[e][st]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int st = 0; st < 2; ++st) acc[e][st] = mfma32(wh[e][ks], bl[st], acc[e][st]);
+      }
+      // tile (e, st): rows = units 32(2w+e) + 8q4 + 4half + r -> destination workgroup 2w+e,
+      // cell (quad 2q4 + half, seq 32st + n)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            f32x4 v = {acc[e][st][4 * q4], acc[e][st][4 * q4 + 1], acc[e][st][4 * q4 + 2], acc[e][st][4 * q4 + 3]};
+            if (dead) v = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+            const int dest = 2 * w + e, cell = (2 * q4 + half) * 64 + 32 * st + n;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xrs, cell * 16,
+                                                   ((par * 8 + dest) * 8 + j) * 8192, SC1);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // A2: every publishing wave has drained
+      if (tid == 0) __hip_atomic_store(flags + j, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w == 0 && !dead && !(p.dbg & 1)) {
+        unsigned spins = 0;
+        while (true) {
+          const unsigned v = lane < 8 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0xffffffffu;
+          if (__all((int)(v >= (unsigned)(step + 1)))) break;
+          if (++spins > CL_SPIN_LIMIT) {
+            if (lane == 0) {
+              dead_s = 1;
+              if (p.status) __hip_atomic_store((gu32*)(p.status), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __syncthreads();  // A3: all eight partials of this step are visible
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ce = tid + 256 * e;  // tid < 256 for X-waves
+        u32x4 pv[8];
+#pragma unroll
+        for (int src = 0; src < 8; ++src)
+          pv[src] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ce * 16, ((par * 8 + j) * 8 + src) * 8192, SC1);
+        f32x4 sum = __builtin_bit_cast(f32x4, pv[0]);
+#pragma unroll
+        for (int src = 1; src < 8; ++src) sum += __builtin_bit_cast(f32x4, pv[src]);
+        rec[ce] = sum;
+      }
+      __syncthreads();  // B: reduced dh of this step in LDS
+    }
+  } else {
+    // ---- M-waves: two cells per thread, inputs prefetched two steps ahead ---------------------------
+    const int mt = tid & 255;
+    const float* hin = p.dhcat;  // BL(512) d(hcat)
+    f32x4 pin[2][2][6];          // [slot][cell e][i, f, g, o, dh_in, c_prev]
+    f32x4 c_cur[2], dc[2];
+    // BL cells through buffer descriptors: base = block (tile 2cc, t) of the array (SGPRs), one VGPR
+    // byte offset per cell = tile-in-cluster * (L blocks) + cell, + a scalar gate offset
+    int gvo[2], cvo[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ce = mt + 256 * e, s = ce & 63, q = ce >> 6;
+      gvo[e] = (s >> 5) * (int)(L * gblk * 4) + ((d * 256 + 8 * j + q) * 32 + (s & 31)) * 16;
+      cvo[e] = (s >> 5) * (int)(L * cblk * 4) + ((d * 64 + 8 * j + q) * 32 + (s & 31)) * 16;
+    }
+    auto grs = [&](int t) { return mkrsrc(p.gates + ((long long)2 * cc * L + t) * gblk, 0x7fffffffu); };
+    auto crs = [&](const float* b, int t) { return mkrsrc(b + ((long long)2 * cc * L + t) * cblk, 0x7fffffffu); };
+    auto load_cell = [&](int slot, int e, int t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pin[slot][e][g] = bld(grs(t), gvo[e], g * 64 * 512);
+      pin[slot][e][4] = bld(crs(hin, t), cvo[e], 0);
+      const int tp = d == 0 ? max(t - 1, 0) : min(t + 1, L - 1);  // clamped; masked at its use
+      pin[slot][e][5] = bld(crs(p.cbuf, tp), cvo[e], 0);
+    };
+    {
+      const int t0 = step_t(0);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        load_cell(0, e, t0);
+        load_cell(1, e, step_t(min(1, L - 1)));
+        c_cur[e] = bld(crs(p.cbuf, t0), cvo[e], 0);
+        dc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    for (int step = 0; step < L; ++step) {
+      const int t = step_t(step);
+      const bool has_prev = d == 0 ? (t > 0) : (t < L - 1);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ce = mt + 256 * e;
+        const int s = ce & 63, q = ce >> 6;
+        const f32x4 dhr = rec[ce];
+        f32x4 pg[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ig = pin[0][e][0][r], fg = pin[0][e][1][r], gg = pin[0][e][2][r], og = pin[0][e][3][r];
+          const float dhv = pin[0][e][4][r] + dhr[r];
+          const float tc = ftanh(c_cur[e][r]);
+          const float dov = dhv * tc;
+          const float dcv = dc[e][r] + dhv * og * (1.f - tc * tc);
+          dc[e][r] = dcv * fg;
+          pg[0][r] = dcv * gg * ig * (1.f - ig);
+          pg[1][r] = dcv * (has_prev ? pin[0][e][5][r] : 0.f) * fg * (1.f - fg);
+          pg[2][r] = dcv * ig * (1.f - gg * gg);
+          pg[3][r] = dov * og * (1.f - og);
+        }
+        c_cur[e] = pin[0][e][5];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bst(pg[g], grs(t), gvo[e], g * 64 * 512);
+          bf16x4 hi, lo;
+          split4(pg[g], hi, lo);
+          const int o = s * BK_ROW + g * 32 + 4 * q;
+          *reinterpret_cast<bf16x4*>(&dgl[0][o]) = hi;
+          *reinterpret_cast<bf16x4*>(&dgl[1][o]) = lo;
+        }
+        // rotate the two-deep prefetch and refill it two steps ahead
+#pragma unroll
+        for (int a = 0; a < 6; ++a) pin[0][e][a] = pin[1][e][a];
+        load_cell(1, e, step_t(min(step + 2, L - 1)));
+      }
+      __syncthreads();  // A
+      __syncthreads();  // A2
+      __syncthreads();  // A3
+      __syncthreads();  // B
+    }
+  }
+}
+
+extern "C" int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream) {
+  WS_REQUIRE(a && a->gates && a->cbuf && a->dhcat && a->whh_f && a->whh_r && a->xchg && a->flags,
+             "ws_lstm_bwd_cluster: null pointer");
+  WS_REQUIRE(a->nseq > 0 && a->nseq % 64 == 0 && a->L > 0, "ws_lstm_bwd_cluster: nseq must be a multiple of 64");
+  const int nwg = (a->nseq / 32) * 8;
+  int dev = 0, cus = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  WS_REQUIRE(nwg <= cus, "ws_lstm_bwd_cluster: %d workgroups must be co-resident but the device has %d CUs", nwg, cus);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(a->flags, 0, (size_t)(a->nseq / 32) * 8 * sizeof(unsigned), s);
+  WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_cluster: hipMemsetAsync failed");
+  ws_prof_begin(WS_PROF_LSTM_BWD, s);
+  hipLaunchKernelGGL(lstm_bwd_cluster_kernel, dim3(nwg), dim3(512), 0, s, *a);
+  ws_prof_end(WS_PROF_LSTM_BWD, s);
+  return ws_check_launch("ws_lstm_bwd_cluster");
+}

@@ -277,6 +277,22 @@ def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None, d
     L.check(L.lib().ws_lstm_fwd_cluster(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_cluster")
 
 
+def lstm_bwd_cluster(gates, cbuf, dhcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0):
+    """BPTT on the blocked layout over clusters of 8 workgroups (lstm_cluster.hip); gates: activated
+    gates in, d(pre-activation gates) out.  Allocates its exchange scratch (32 MB at R = 32)."""
+    for n, t in (("gates", gates), ("cbuf", cbuf), ("dhcat", dhcat), ("whh_f", whh_f), ("whh_r", whh_r)):
+        _chk(t, n)
+    ncl = sm.nseq // 32
+    xchg = torch.empty(ncl * 2 * 64 * 8192 // 4, device=gates.device, dtype=torch.float32)
+    flags = torch.empty(ncl * 8, device=gates.device, dtype=torch.int32)
+    a = L.LstmClusterArgs()
+    a.gates, a.cbuf, a.dhcat, a.whh_f, a.whh_r = _p(gates), _p(cbuf), _p(dhcat), _p(whh_f), _p(whh_r)
+    a.xchg, a.flags = C.c_void_p(xchg.data_ptr()), C.c_void_p(flags.data_ptr())
+    a.status = C.c_void_p(status.data_ptr()) if status is not None else None
+    a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
+    L.check(L.lib().ws_lstm_bwd_cluster(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_cluster")
+
+
 class BandTables:
     """Device-resident band tables shared by the STFT / norm / GEMM launches."""
 

@@ -272,8 +272,10 @@ class ResRNNBlkFn(torch.autograd.Function):
         dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=gates, bias=bcat, A_bl=xn,
                      stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap)
         cbuf, hcat = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * 2 * H)
-        if dev.lstm_cluster_ok(seq, d):
-            dev.lstm_fwd_cluster(gates, cbuf, hcat, whh_f.contiguous(), whh_r.contiguous(), seq)
+        cluster = dev.lstm_cluster_ok(seq, d)
+        whf, whr = whh_f.contiguous(), whh_r.contiguous()
+        if cluster:
+            dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq)
         else:
             dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode)
         pw = proj_w.contiguous()
@@ -281,8 +283,8 @@ class ResRNNBlkFn(torch.autograd.Function):
         dev.pack_w(pw, N, 2 * H, 2 * H, proj_pack, order=1)
         out = torch.empty_like(z)
         dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=proj_pack, C_out=out, ldc=N, bias=proj_b, R=z)
-        ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw)
-        ctx.view, ctx.box, ctx.lmode = view, box, lmode
+        ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw, whf, whr)
+        ctx.view, ctx.box, ctx.lmode, ctx.cluster = view, box, lmode, cluster
         return out
 
     @staticmethod
@@ -315,7 +317,7 @@ class ResRNNBlkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw = ctx.saved_tensors
+        z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw, whf, whr = ctx.saved_tensors
         dout = dout.contiguous()
         R, K, Tf, N = z.shape
         P = R * K * Tf
@@ -332,7 +334,13 @@ class ResRNNBlkFn(torch.autograd.Function):
         # 3/4 of the chip idle: release the weight-gradient jobs deferred by the previous layers first
         if ctx.view == "time":
             flush_deferred_wgrads(d)
-        dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, ctx.lmode)
+        # the cluster BPTT (4.8 ms vs 5.8 ms per time-view launch) fills all 256 CUs and so evicts the
+        # side-stream weight-gradient GEMMs that otherwise run under the 128-CU streaming kernel: net loss
+        # today, hence opt-in (WESEP_LSTM_CLUSTER_BWD=1)
+        if ctx.cluster and os.environ.get("WESEP_LSTM_CLUSTER_BWD", "0") == "1":
+            dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
+        else:
+            dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, ctx.lmode)
         del dh
         # weight gradients: a side branch of the graph -> deferred to the side stream when a carrier
         # will deliver them
