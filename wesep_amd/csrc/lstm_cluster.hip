@@ -34,16 +34,25 @@ __device__ __forceinline__ void split8r(const f32x4& a, const f32x4& b, bf16x8& 
 }
 
 __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_cluster_args p) {
+  // VMEM operations of one wave complete in order, so an exchange wave must never have HBM traffic in
+  // its queue (measured: +3.2 us per step when it does).  All 8 waves run the MFMAs and the cell
+  // update of their own tile; then the traffic is split by role through LDS staging:
+  //   X-waves (0..3): publish (from PUB), drain, flag, poll, gather -> h image
+  //   M-waves (4..7): HBM stores of gates / c / h (from OUT), x-projection prefetch (-> XIN)
   __shared__ __attribute__((aligned(16))) __bf16 hl[2][CL_SEQ * HROW];  // [part][seq][k] 66 KB
+  __shared__ __attribute__((aligned(16))) f32x4 xin[4][512];             // x-projection of the step, 32 KB
+  __shared__ __attribute__((aligned(16))) f32x4 outl[6][512];            // i, f, g, o, c, h of the step, 48 KB
+  __shared__ __attribute__((aligned(16))) u32x4 publ[512];               // h chunks (bf16 hi x4 | lo x4), 8 KB
   __shared__ int dead_s;
   const int ntile = p.nseq / 32, ncl_dir = ntile / 2, ncl = 2 * ncl_dir;
   const int c = blockIdx.x % ncl, j = blockIdx.x / ncl;  // member j of cluster c (same c -> same XCD when ncl % 8 == 0)
   const int d = c / ncl_dir, cc = c % ncl_dir;
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool xrole = w < 4;
   const int uo = w & 3, st = w >> 2;
-  const int tile = 2 * cc + st;
   const int L = p.L;
+  const long long gblk = (long long)SQ * 2 * LG, cblk = (long long)SQ * 2 * LH;  // floats per block
 
   // ---- resident weights: rows m = lane&31 -> (gate = m>>3, unit 32j + 8uo + (m&7)) ----------------
   bf16x8 wh[16], wl[16];
@@ -61,35 +70,58 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
     for (int i = tid; i < 2 * CL_SEQ * HROW / 2; i += 512) z[i] = 0u;
     if (tid == 0) dead_s = 0;
   }
-  // ---- activation I/O in BL: this lane's cell = (quad 8j + 2uo + half, slot n) of block (tile, t) --
-  const int glane = ((d * 256 + 8 * j + 2 * uo + half) * 32 + n) * 16;  // bytes; + g*64*512
-  const int clane = ((d * 64 + 8 * j + 2 * uo + half) * 32 + n) * 16;
-  auto grs = [&](int t) { return mkrsrc(p.gates + (long long)(tile * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
-  auto crs = [&](float* b, int t) { return mkrsrc(b + (long long)(tile * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
-  // ---- exchange: X[cluster][parity][producer][seq 64][quad 8] x 16 B (hi x4 | lo x4) ---------------
+  // ---- HBM side (M-waves): thread mt serves the cells of threads mt (tile 2cc) and mt + 256 (tile 2cc+1):
+  //      same BL cell position, blocks one tile apart
+  const int mt = tid & 255;
+  const int m_uo = (mt >> 6) & 3, m_n = mt & 31, m_half = (mt >> 5) & 1;
+  const int gvo = ((d * 256 + 8 * j + 2 * m_uo + m_half) * 32 + m_n) * 16;  // bytes; + g*64*512; + e * tile stride
+  const int cvo = ((d * 64 + 8 * j + 2 * m_uo + m_half) * 32 + m_n) * 16;
+  const int gts = (int)(L * gblk * 4), cts = (int)(L * cblk * 4);             // bytes between the two tiles
+  auto grs = [&](int t) { return mkrsrc(p.gates + ((long long)2 * cc * L + t) * gblk, 0x7fffffffu); };
+  auto crs = [&](float* b, int t) { return mkrsrc(b + ((long long)2 * cc * L + t) * cblk, 0x7fffffffu); };
+  // ---- exchange side (X-waves): X[cluster][parity][producer][chunk 512] x 16 B ----------------------
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(p.xchg) + (long long)c * (2 * 8 * 8192), 0, 2 * 8 * 8192, 0x00020000);
-  const int xpub = (j * 512 + (st * 32 + n) * 8 + 2 * uo + half) * 16;  // my published chunk (bytes, parity 0)
-  const int xget = tid * 16;                                             // chunk tid of each producer
-  const int gs = tid >> 3, gq = tid & 7;                                 // ... = (seq, quad) for the LDS fill
+  const int mychunk = (st * 32 + n) * 8 + 2 * uo + half;  // chunk of this thread's h in a producer's slice
   gu32* flags = (gu32*)(p.flags) + c * 8;
 
-  // x-projection prefetched TWO steps ahead (xg = this step, xn = next): the loads are issued behind the
-  // payload gather of a step and would otherwise be needed one short MFMA phase later
-  f32x4 xg[4], xn[4], c4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 xpre[2][4];  // M-waves: x-projection of the NEXT step for their two cells
   {
     const int t0 = d == 0 ? 0 : L - 1, t1 = d == 0 ? min(1, L - 1) : max(L - 2, 0);
+    if (!xrole) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      xg[g] = bld(grs(t0), glane, g * 64 * 512);
-      xn[g] = bld(grs(t1), glane, g * 64 * 512);
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          xin[g][mt + 256 * e] = bld(grs(t0), gvo + e * gts, g * 64 * 512);
+          xpre[e][g] = bld(grs(t1), gvo + e * gts, g * 64 * 512);
+        }
     }
   }
   __syncthreads();
 
+  // HBM traffic is issued at the top of the NEXT step, under the MFMAs, not under the exchange: a CU's
+  // hand-off latency doubles when its memory queue is streaming.  The outputs wait in the LDS stage
+  // (barrier 0 below keeps the next cell update from overwriting it first).
+  auto hbm_io = [&](int tprev, int stepn) {  // stores of step tprev, x-projection prefetch of step `stepn`
+    const int sn = min(stepn, L - 1);
+    const int tn = d == 0 ? sn : L - 1 - sn;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ct = mt + 256 * e;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bst(outl[g][ct], grs(tprev), gvo + e * gts, g * 64 * 512);
+      bst(outl[4][ct], crs(p.cbuf, tprev), cvo + e * cts, 0);
+      bst(outl[5][ct], crs(p.hcat, tprev), cvo + e * cts, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xpre[e][g] = bld(grs(tn), gvo + e * gts, g * 64 * 512);
+    }
+  };
   for (int step = 0; step < L; ++step) {
     const int t = d == 0 ? step : L - 1 - step;
     const int par = step & 1;
+    if (!xrole && step > 0) hbm_io(d == 0 ? step - 1 : L - step, step + 1);
     // ---- G^T tile [4 gates x 8 units][32 seqs] = W slice * h^T --------------------------------------
     const __bf16* hhi = &hl[0][(st * 32 + n) * HROW + 8 * half];
     const __bf16* hlo = &hl[1][(st * 32 + n) * HROW + 8 * half];
@@ -109,36 +141,55 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
       acc0 = mfma32(wh[ks], bl0, acc0);
       acc1 = mfma32(wh[ks + 1], bl1, acc1);
     }
-    // ---- cell update (register 4q + r = gate q, unit r of this lane's 4) ----------------------------
-    f32x4 vi, vf, vg, vo, vh;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float ig = fsig(acc0[r] + acc1[r] + xg[0][r]);
-      const float fg = fsig(acc0[4 + r] + acc1[4 + r] + xg[1][r]);
-      const float gg = ftanh(acc0[8 + r] + acc1[8 + r] + xg[2][r]);
-      const float og = fsig(acc0[12 + r] + acc1[12 + r] + xg[3][r]);
-      const float cn = fg * c4[r] + ig * gg;
-      c4[r] = cn;
-      vi[r] = ig;
-      vf[r] = fg;
-      vg[r] = gg;
-      vo[r] = og;
-      vh[r] = og * ftanh(cn);
-    }
-    const bool dead = dead_s != 0;
-    if (dead) vh = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-    // ---- publish my slice of h_t: write-through store, drain, barrier, one flag store ----------------
+    __syncthreads();  // 0: the previous step's outputs have left the LDS stage
+    // ---- cell update (register 4q + r = gate q, unit r of this lane's 4); results to the LDS stages --
     {
+      const f32x4 x0 = xin[0][tid], x1 = xin[1][tid], x2 = xin[2][tid], x3 = xin[3][tid];
+      f32x4 vi, vf, vg, vo, vh;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ig = fsig(acc0[r] + acc1[r] + x0[r]);
+        const float fg = fsig(acc0[4 + r] + acc1[4 + r] + x1[r]);
+        const float gg = ftanh(acc0[8 + r] + acc1[8 + r] + x2[r]);
+        const float og = fsig(acc0[12 + r] + acc1[12 + r] + x3[r]);
+        const float cn = fg * c4[r] + ig * gg;
+        c4[r] = cn;
+        vi[r] = ig;
+        vf[r] = fg;
+        vg[r] = gg;
+        vo[r] = og;
+        vh[r] = og * ftanh(cn);
+      }
+      if (dead_s != 0) vh = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+      outl[0][tid] = vi;
+      outl[1][tid] = vf;
+      outl[2][tid] = vg;
+      outl[3][tid] = vo;
+      outl[4][tid] = c4;
+      outl[5][tid] = vh;
       bf16x4 hi, lo;
       split4(vh, hi, lo);
       struct { bf16x4 a, b; } pk = {hi, lo};
-      if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), xrs, xpub, par * (8 * 8192), SC1);
+      publ[mychunk] = __builtin_bit_cast(u32x4, pk);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();  // 1: stages complete, xin consumed, h image no longer read
+    if (xrole) {
+      // publish both halves of the slice: write-through stores, then drain
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        __builtin_amdgcn_raw_buffer_store_b128(publ[mt + 256 * e], xrs, (j * 512 + mt + 256 * e) * 16,
+                                               par * (8 * 8192), SC1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      // next step's x-projection into place (LDS only; the HBM traffic waits for the next MFMA phase)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xin[g][mt + 256 * e] = xpre[e][g];
+    }
+    __syncthreads();  // 2: every publishing wave has drained; xin holds the next step
     if (tid == 0) __hip_atomic_store(flags + j, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ---- wait for the other seven (one wave polls, relaxed; bounded) ---------------------------------
-    if (w == 0 && !dead && !(p.dbg & 1)) {
+    if (w == 0 && dead_s == 0 && !(p.dbg & 1)) {
       unsigned spins = 0;
       while (true) {
         const unsigned v = lane < 8 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -147,45 +198,34 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
         if (++spins > CL_SPIN_LIMIT) {
           if (lane == 0) {
             dead_s = 1;
-            if (p.status) __hip_atomic_store((gu32*)(p.status), 1u, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
+            if (p.status) __hip_atomic_store((gu32*)(p.status), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           break;
         }
         __builtin_amdgcn_s_sleep(2);
       }
     }
-    __syncthreads();
-    // ---- gather all eight slices (sc1 loads: L1 bypassed), THEN the HBM traffic of this step, so the
-    //      payload's return is not queued behind it (VMEM returns in order per wave) ------------------
-    u32x4 pv[8];
+    __syncthreads();  // 3: all eight slices of h_t are visible
+    if (xrole) {
+      // gather (sc1 loads: L1 bypassed) and rebuild the h image: chunk -> (seq, unit quad) of producer jj
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj)
-      pv[jj] = (p.dbg & 2) ? u32x4{0u, 0u, 0u, 0u}
-                           : __builtin_amdgcn_raw_buffer_load_b128(xrs, xget + jj * 8192, par * (8 * 8192), SC1);
-    {
-      const int sn = min(step + 2, L - 1);
-      const int tn = d == 0 ? sn : L - 1 - sn;
-      bst(vi, grs(t), glane, 0);
-      bst(vf, grs(t), glane, 64 * 512);
-      bst(vg, grs(t), glane, 128 * 512);
-      bst(vo, grs(t), glane, 192 * 512);
-      bst(c4, crs(p.cbuf, t), clane, 0);
-      bst(vh, crs(p.hcat, t), clane, 0);
+      for (int e = 0; e < 2; ++e) {
+        const int ch = mt + 256 * e, gs = ch >> 3, gq = ch & 7;
+        u32x4 pv[8];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        xg[g] = xn[g];
-        xn[g] = bld(grs(tn), glane, g * 64 * 512);
+        for (int jj = 0; jj < 8; ++jj)
+          pv[jj] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (jj * 512 + ch) * 16, par * (8 * 8192), SC1);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int o = gs * HROW + 32 * jj + 4 * gq;
+          *reinterpret_cast<uint2*>(&hl[0][o]) = uint2{pv[jj][0], pv[jj][1]};
+          *reinterpret_cast<uint2*>(&hl[1][o]) = uint2{pv[jj][2], pv[jj][3]};
+        }
       }
     }
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      const int o = gs * HROW + 32 * jj + 4 * gq;
-      *reinterpret_cast<uint2*>(&hl[0][o]) = uint2{pv[jj][0], pv[jj][1]};
-      *reinterpret_cast<uint2*>(&hl[1][o]) = uint2{pv[jj][2], pv[jj][3]};
-    }
-    __syncthreads();
+    __syncthreads();  // 4: h image of the next step complete
   }
+  if (!xrole) hbm_io(d == 0 ? L - 1 : 0, L);  // the last step's stores
 }
 
 extern "C" int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream) {
