@@ -175,8 +175,9 @@ def main():
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        hit = [v for k, v in pmc.items() if k.startswith(f"void {dom}_bf16_kernel<true")]
-        traffic = hit[0]["hbm_bytes_per_launch_corrected"] if hit else None
+        hit = [v for k, v in pmc.items() if dom in k]      # streaming (32/16-sequence) and cluster variants
+        n = sum(v["launches"] for v in hit)
+        traffic = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in hit) / n if n else None
     except (OSError, KeyError, ValueError):
         pass
 
@@ -195,7 +196,9 @@ def main():
                        "parallelism": f"dp{world}", "final_loss_dB": final_loss},
             # the recurrence kernels are bound by memory paths (HBM activations + the per-step L2 weight
             # stream), not by the matrix cores: HBM is the roof they are priced against
-            "roofline": {"bound": "hbm", "kernel": dom + "_bf16_kernel<BLK> (avg of time/band views)",
+            "roofline": {"bound": "hbm", "kernel": dom + " recurrence kernels, launch average over the time view (" +
+                                   ("lstm_fwd_cluster_kernel" if dom == "lstm_fwd" else "lstm_bwd_s16_kernel") +
+                                   ") and the band view (" + dom + "_bf16_kernel<BLK>)",
                          "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": bytes_per_launch,
                          "ms_per_launch": prof[dom]["ms_avg"],

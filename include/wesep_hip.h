@@ -269,7 +269,8 @@ typedef struct ws_gemm_tnb_args {
   int g_width, g_off, g_cols;
   int a0_width, a0_off, a0_cols, a0_shift;
   int a1_width, a1_off, a1_cols, a1_shift;
-  int nblk, L, nsplit, blocks_per_split, pad_;
+  int nblk, L, nsplit, blocks_per_split;
+  int pad_;          /* probe builds only: 1 skip the global loads, 2 skip the LDS image, 4 skip the MFMAs */
 } ws_gemm_tnb_args;
 int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream);
 

@@ -292,6 +292,9 @@ class ResRNNBlkFn(torch.autograd.Function):
         """[dW_ih | dW_hh | db] of both directions in one pass over each direction's dgates, and
         dW_proj / db_proj; launched on the current stream.  Returns them in parameter order."""
         d = gates.device
+        if os.environ.get("WESEP_PROBE_SKIP_WGRAD") == "1":   # measurement only: how much of this is exposed?
+            z_ = lambda *s_: torch.zeros(*s_, device=d)
+            return [z_(G4, N), z_(G4, H), z_(G4), z_(G4), z_(G4, N), z_(G4, H), z_(G4), z_(G4), z_(N, 2 * H), z_(N)]
         # dW_proj^T [2H][N] = hcat^T dout (hcat as the streamed-once operand), db_proj = colsum(dout)
         ns, bps = dev.tnb_splits(nb, (2 * H) // 128)
         slab, aslab = _empty(d, ns, 2 * H * N), _empty(d, ns, N)
