@@ -53,28 +53,33 @@ __device__ __forceinline__ long long seq_pos(const ws_seqmap& sm, int b, int i, 
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_w_kernel(const float* __restrict__ W, int N, int K, long long ldw, int trans,
                               int order, __bf16* __restrict__ out) {
+  // one thread per 16-byte unit pair (hi, lo): 8 consecutive k of one row n
   const int nks = K / 16, nnt = N / 32;
-  const long long total = (long long)N * K;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    long long r = idx;
-    const int j = r & 7; r >>= 3;
-    const int lane = r & 63; r >>= 6;
-    int nt, ks;
-    if (order == 0) {
-      ks = r % nks;
-      nt = r / nks;
-    } else {
-      nt = r % nnt;
-      ks = r / nnt;
-    }
-    const int n = 32 * nt + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
-    const float v = trans ? W[(long long)k * ldw + n] : W[(long long)n * ldw + k];
-    const __bf16 hi = (__bf16)v;
-    const long long u = (order == 0 ? ((long long)nt * nks + ks) : ((long long)ks * nnt + nt)) * 2;
-    out[(u * 64 + lane) * 8 + j] = hi;
-    out[((u + 1) * 64 + lane) * 8 + j] = (__bf16)(v - (float)hi);
+  const int units = N * K / 8;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= units) return;
+  const int lane = idx & 63;
+  const int r = idx >> 6;
+  int nt, ks;
+  if (order == 0) {
+    ks = r % nks;
+    nt = r / nks;
+  } else {
+    nt = r % nnt;
+    ks = r / nnt;
   }
+  const int n = 32 * nt + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+  bf16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = trans ? W[(long long)(k0 + j) * ldw + n] : W[(long long)n * ldw + k0 + j];
+    hi[j] = (__bf16)v;
+    lo[j] = (__bf16)(v - (float)hi[j]);
+  }
+  const long long u = (order == 0 ? ((long long)nt * nks + ks) : ((long long)ks * nnt + nt)) * 2;
+  bf16x8* o = reinterpret_cast<bf16x8*>(out);
+  o[u * 64 + lane] = hi;
+  o[(u + 1) * 64 + lane] = lo;
 }
 
 extern "C" int ws_pack_w(const float* W, int N, int K, long long ldw, int trans, int order, float* out,
@@ -82,8 +87,8 @@ extern "C" int ws_pack_w(const float* W, int N, int K, long long ldw, int trans,
   WS_REQUIRE(W && out && N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, "ws_pack_w: N %% 32, K %% 16 (N=%d K=%d)",
              N, K);
   WS_REQUIRE(order == 0 || order == 1, "ws_pack_w: order");
-  hipLaunchKernelGGL(pack_w_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, W, N, K, ldw, trans, order,
-                     reinterpret_cast<__bf16*>(out));
+  hipLaunchKernelGGL(pack_w_kernel, dim3((N * K / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, N, K, ldw,
+                     trans, order, reinterpret_cast<__bf16*>(out));
   return ws_check_launch("ws_pack_w");
 }
 
