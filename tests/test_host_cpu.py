@@ -180,3 +180,21 @@ def test_product_and_oracle_synthetic_rows_agree():
     from wesep_amd.utils.synthetic import synth_batch as b
     for x, y in zip(a(4, 1000, 7), b(4, 1000, 7)):
         assert torch.equal(x, y)
+
+
+def test_score_matches_training_loss_definition():
+    """cal_SISNR (score.py:7-21) against the oracle's SI-SDR on well-conditioned signals: the two eps
+    placements agree to 1e-3 dB, and SI-SNRi is the difference to the unprocessed mixture."""
+    import numpy as np
+    import torch
+    from oracle import bsrnn_oracle as O
+    from wesep_amd.utils.score import cal_SISNR, cal_SISNRi
+    g = np.random.default_rng(3)
+    ref = g.standard_normal(16000).astype(np.float32)
+    for snr in (-5.0, 0.0, 12.0, 30.0):
+        est = ref + g.standard_normal(16000).astype(np.float32) * 10 ** (-snr / 20)
+        want = -float(O.sisdr_loss(torch.from_numpy(est)[None], torch.from_numpy(ref)[None]))
+        assert abs(cal_SISNR(est, ref) - want) < 1e-3
+    mix = ref + g.standard_normal(16000).astype(np.float32)
+    s, si = cal_SISNRi(est, ref, mix)
+    assert abs(si - (s - cal_SISNR(mix, ref))) < 1e-12

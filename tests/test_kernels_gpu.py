@@ -622,3 +622,36 @@ def test_lstm_cluster_fwd_bwd_vs_torch(view, dims):
     assert rel(dx.view(R, K, Tf, N), dxref) < 8e-5
     assert rel(dg[:, 0].sum(0), lstm.bias_ih_l0.grad) < 8e-5
     assert rel(dg[:, 1].sum(0), lstm.bias_ih_l0_reverse.grad) < 8e-5
+
+
+@pytest.mark.parametrize("kind", ["nt", "tn"])
+def test_generic_bf16_gemms_have_no_outliers_at_scale(kind):
+    """The split-bf16 generic GEMMs (mask MLP / speaker path) at a many-workgroup size: element-wise
+    error bound (a relative-L2 check would hide a handful of corrupted elements) and run-to-run
+    identity.  (The norm-on-load variant failed exactly this and is routed to the fp32 kernel.)"""
+    from wesep_amd import dev
+    d = _cuda()
+    torch.manual_seed(7)
+    M, N, K = 131072, 512, 512
+    A = torch.randn(M, K, device=d)
+    if kind == "nt":
+        W = torch.randn(N, K, device=d) * 0.05
+        outs = []
+        for _ in range(2):
+            C = torch.empty(M, N, device=d)
+            dev.gemm_nt(A=A, a_rows=dev.flat(K), M=M, N=N, K=K, W=W, ldw=K, C_out=C, c_rows=dev.flat(N), mode="bf16x3")
+            outs.append(C)
+        ref = torch.empty(M, N, device=d)
+        dev.gemm_nt(A=A, a_rows=dev.flat(K), M=M, N=N, K=K, W=W, ldw=K, C_out=ref, c_rows=dev.flat(N), mode="f32")
+    else:
+        G = torch.randn(M, N, device=d) * 0.05
+        ns, rps = dev.tn_splits(M)
+        outs = []
+        for mode in ("bf16x3", "bf16x3", "f32"):
+            slab = torch.empty(ns, N * K, device=d)
+            dev.gemm_tn(G=G, g_rows=dev.flat(N), A=A, a_rows=dev.flat(K), M=M, Nn=N, Kk=K, slab=slab,
+                        slab_stride=N * K, nsplit=ns, rows_per_split=rps, mode=mode)
+            outs.append(slab.sum(0))
+        ref = outs.pop()
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] - ref).abs().max()) < 2e-4 * float(ref.abs().max())
