@@ -241,3 +241,52 @@ def test_whole_utterance_inference_matches_oracle(T):
         assert abs(cal_SISNR(est[r], tgt[r].numpy()) - cal_SISNR(ref[r].numpy(), tgt[r].numpy())) < DB_TOL
     s, si, n = evaluate(model, [dict(wav_mix=wav, wav_targets=tgt, spk_embeds=emb)], device=d)
     assert n == 2 and np.isfinite(s) and np.isfinite(si)
+
+
+def test_ddp_wrapped_step_equals_plain_step():
+    """DistributedDataParallel (nccl = RCCL, one rank) around the model: its gradient hooks must fire
+    once per parameter although the ResRNN weight gradients arrive late through the side-stream carrier
+    nodes; three optimiser steps must equal the un-wrapped run bit for bit."""
+    import torch.distributed as dist
+    from oracle import bsrnn_oracle as O
+    from wesep_amd.functional import SISDRFn
+    from wesep_amd.models import get_model
+    from wesep_amd.optim import FusedClipAdam
+    d = _cuda()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    torch.cuda.set_device(0)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        kw = dict(num_repeat=2, spk_fuse_type="FiLM", multi_fuse=True)
+        cfg = O.BSRNNConfig(**kw)
+        params = O.synth_params(cfg, 3)
+        wav, tgt, emb = (t.to(d) for t in O.synth_batch(4, 16000, 5))
+
+        def run(ddp):
+            model = get_model("BSRNN")(use_spk_transform=False, joint_training=False, **kw)
+            model.load_state_dict(params)
+            model.to(d).train()
+            net = (torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True)
+                   if ddp else model)
+            opt = FusedClipAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, clip_grad=5.0)
+            losses = []
+            for _ in range(3):
+                est, _ = net(wav, emb)
+                loss = SISDRFn.apply(est, tgt, 1e-8)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            return losses, {n: p.detach().clone() for n, p in model.named_parameters()}
+
+        l0, p0 = run(False)
+        l1, p1 = run(True)
+        assert l0 == l1
+        assert all(torch.equal(p0[n], p1[n]) for n in p0)
+    finally:
+        if created:
+            dist.destroy_process_group()
