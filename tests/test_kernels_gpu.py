@@ -655,3 +655,36 @@ def test_generic_bf16_gemms_have_no_outliers_at_scale(kind):
         ref = outs.pop()
     assert torch.equal(outs[0], outs[1])
     assert float((outs[0] - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("kind", ["nt", "tn"])
+def test_generic_bf16_norm_on_load_gemms_at_scale(kind):
+    """GroupNorm-on-load variants of the generic split-bf16 GEMMs at a many-workgroup size: run-to-run
+    identity and an element-wise bound against the exact-fp32 kernel (the first, branchy version of
+    the NT kernel failed this with sparse O(1) errors)."""
+    from wesep_amd import dev
+    d = _cuda()
+    torch.manual_seed(11)
+    M, N, K, L_ = 120240, 512, 128, 501          # 240 norm groups of 501 rows
+    A = torch.randn(M, K, device=d)
+    stats = torch.stack([torch.randn(M // L_, device=d) * 0.1, torch.rand(M // L_, device=d) + 0.5], 1).contiguous()
+    kw = dict(stats=stats, gamma=torch.randn(K, device=d), beta=torch.randn(K, device=d),
+              stat_map=dev.StatMap(L_, 1, 1, 0, 0))
+    outs = []
+    if kind == "nt":
+        W = torch.randn(N, K, device=d) * 0.05
+        for mode in ("bf16x3", "bf16x3", "f32"):
+            C = torch.empty(M, N, device=d)
+            dev.gemm_nt(A=A, a_rows=dev.flat(K), M=M, N=N, K=K, W=W, ldw=K, C_out=C, c_rows=dev.flat(N), mode=mode, **kw)
+            outs.append(C)
+    else:
+        G = torch.randn(M, N, device=d) * 0.05
+        ns, rps = dev.tn_splits(M)
+        for mode in ("bf16x3", "bf16x3", "f32"):
+            slab = torch.empty(ns, N * K, device=d)
+            dev.gemm_tn(G=G, g_rows=dev.flat(N), A=A, a_rows=dev.flat(K), M=M, Nn=N, Kk=K, slab=slab,
+                        slab_stride=N * K, nsplit=ns, rows_per_split=rps, mode=mode, **kw)
+            outs.append(slab.sum(0))
+    ref = outs.pop()
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] - ref).abs().max()) < 3e-4 * float(ref.abs().max())

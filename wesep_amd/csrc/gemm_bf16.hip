@@ -71,13 +71,22 @@ __device__ __forceinline__ void tile_mma(const __bf16* __restrict__ lds, int aro
 // ---------------------------------------------------------------------------------------------
 // NT: C[M][N] = epi(pro(A)[M][K] * W[N][K]^T).  Requires float4-loadable A and W (vec bits 0,1).
 // ---------------------------------------------------------------------------------------------
+// The k-loop body is branch-free (out-of-range rows / columns / k are clamped to a valid address and
+// zeroed by a select; GroupNorm is a template parameter): with exec-masked loads the compiler's
+// s_waitcnt placement drained every load before the MFMAs (no overlap at all), and the
+// norm-on-load variant built that way produced run-to-run mismatches on MI355X
+// (tools/nt_bug_probe.py).  Pointers taken from the group table are cast to the global address
+// space so they do not decay to flat loads.
+typedef const __attribute__((address_space(1))) float* gfp;
+
+template <bool NORM>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[4 * BT_PLANE];  // 40 KB
-  const float* A = p.A;
-  const float* W = p.W;
+  const float* A_ = p.A;
+  const float* W_ = p.W;
   const float* bias = p.bias;
-  const float* gamma = p.gamma;
-  const float* beta = p.beta;
+  const float* gamma_ = p.gamma;
+  const float* beta_ = p.beta;
   float* C = p.C;
   const float* R = p.R;
   const float* T = p.T;
@@ -85,11 +94,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
   long long st_base = p.st_base;
   if (p.groups) {
     const ws_group_nt g = p.groups[blockIdx.z];
-    A += g.a_off;
-    W = g.W;
+    A_ += g.a_off;
+    W_ = g.W;
     bias = g.bias;
-    gamma = g.gamma;
-    beta = g.beta;
+    gamma_ = g.gamma;
+    beta_ = g.beta;
     C += g.c_off;
     if (R) R += g.c_off;
     if (T) T += g.c_off;
@@ -98,12 +107,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
     N = g.N;
     ldw = g.ldw;
   }
+  const gfp A = (gfp)A_, W = (gfp)W_, gamma = (gfp)gamma_, beta = (gfp)beta_, stats = (gfp)p.stats;
   const int M = p.M;
   const int m_blk = blockIdx.x * 128, n_blk = blockIdx.y * 128;
   if (n_blk >= N) return;
   const int tid = threadIdx.x;
   const int lrow = tid >> 3, lk = (tid & 7) * 4;
-  const bool has_norm = p.stats != nullptr;
 
   long long aoff[4], woff[4];
   bool vm[4], vn[4];
@@ -112,50 +121,52 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
   for (int i = 0; i < 4; ++i) {
     const int m = m_blk + lrow + 32 * i;
     vm[i] = m < M;
-    const int mm = vm[i] ? m : 0;
+    const int mm = vm[i] ? m : M - 1;
     aoff[i] = ws_row_off(mm, p.a_div, p.a_s1, p.a_s2);
     mean[i] = 0.f;
     rstd[i] = 1.f;
-    if (has_norm) {
+    if (NORM) {
       const long long s = (long long)(mm / p.st_div1) * p.st_m1 + (long long)(mm % p.st_div2) * p.st_m2 + st_base;
-      mean[i] = p.stats[2 * s];
-      rstd[i] = p.stats[2 * s + 1];
+      mean[i] = stats[2 * s];
+      rstd[i] = stats[2 * s + 1];
     }
     const int n = n_blk + lrow + 32 * i;
     vn[i] = n < N;
-    woff[i] = (long long)(vn[i] ? n : 0) * ldw;
+    woff[i] = (long long)(vn[i] ? n : N - 1) * ldw;
   }
 
-  f32x4 ra[4], rw[4];
+  // load_tile only ISSUES the loads (raw values stay in registers under the MFMAs of the current tile);
+  // normalisation, range masking and the bf16 split happen in store_tile, one iteration later
+  f32x4 ra[4], rw[4], gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
+  bool vk = true;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_tile = [&](int kt) {
     const int k = kt * BT_BK + lk;
-    f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
-    if (has_norm && k < K) {
-      gm = *reinterpret_cast<const f32x4*>(gamma + k);
-      bt = *reinterpret_cast<const f32x4*>(beta + k);
+    vk = k < K;                       // K % 4 == 0 on this path: a float4 is in or out as a whole
+    const int kc = vk ? k : 0;
+    if (NORM) {
+      gm = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(gamma + kc);
+      bt = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(beta + kc);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (vm[i] && k < K) {
-        v = *reinterpret_cast<const f32x4*>(A + aoff[i] + k);
-        if (has_norm) v = (v - mean[i]) * rstd[i] * gm + bt;
-      }
-      ra[i] = v;
-      f32x4 w = {0.f, 0.f, 0.f, 0.f};
-      if (vn[i] && k < K) w = *reinterpret_cast<const f32x4*>(W + woff[i] + k);
-      rw[i] = w;
+      ra[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(A + aoff[i] + kc);
+      rw[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(W + woff[i] + kc);
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      f32x4 v = ra[i];
+      if (NORM) v = (v - mean[i]) * rstd[i] * gm + bt;
+      v = (vm[i] && vk) ? v : zero4;
+      const f32x4 wv = (vn[i] && vk) ? rw[i] : zero4;
       bf16x4 hi, lo;
       const int o = (lrow + 32 * i) * BT_LD + lk;
-      split4(ra[i], hi, lo);
+      split4(v, hi, lo);
       *reinterpret_cast<bf16x4*>(lds + o) = hi;
       *reinterpret_cast<bf16x4*>(lds + BT_PLANE + o) = lo;
-      split4(rw[i], hi, lo);
+      split4(wv, hi, lo);
       *reinterpret_cast<bf16x4*>(lds + 2 * BT_PLANE + o) = hi;
       *reinterpret_cast<bf16x4*>(lds + 3 * BT_PLANE + o) = lo;
     }
@@ -173,8 +184,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
     __syncthreads();  // previous tile's fragment reads are done
     store_tile();
     __syncthreads();
-    if (kt + 1 < nk) load_tile(kt + 1);
+    load_tile(min(kt + 1, nk - 1));  // branch-free: the last iteration reloads its own tile (unused)
+    __builtin_amdgcn_sched_barrier(0);  // issue the loads HERE: they must fly under the MFMAs below
     tile_mma(lds, wm * 64, wn * 64, l31, half, acc00, acc01, acc10, acc11);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   const bool flat_c = p.c_div >= M;  // (m / c_div) == 0 for every row: no division needed
@@ -204,7 +217,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
 }
 
 int ws_launch_gemm_nt_bf16(const ws_gemm_nt_args* a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 0, s, *a);
+  if (a->stats)
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<true>), grid, dim3(256), 0, s, *a);
+  else
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<false>), grid, dim3(256), 0, s, *a);
   return 0;
 }
 
@@ -289,22 +305,28 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
     }
   };
 
+  // Branch-free tile loads (see gemm_nt_bf16_kernel): invalid rows carry offset 0 in the meta table and
+  // out-of-range columns are clamped, so every load is unconditional; masking, normalisation and the
+  // bf16 split happen in store_tile one iteration later, with the loads in flight under the MFMAs.
+  const gfp Gg = (gfp)G + n_blk + (gcol_ok ? col : 0), Ag = (gfp)A + k_blk + (acol_ok ? col : 0);
   float rg[16], ra[16];
   auto load_tile = [&](int slot) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const RowMeta& r = meta[slot][mg + j];
-      float g = 0.f, a = 0.f;
-      if (r.gvalid && gcol_ok) g = G[r.goff + n_blk + col];
-      if (r.avalid && acol_ok) {
-        a = A[r.aoff + k_blk + col];
-        if (has_norm) a = (a - r.mean) * r.rstd * gm + bt;
-      }
-      rg[j] = g;
-      ra[j] = a;
+      rg[j] = Gg[r.goff];
+      ra[j] = Ag[r.aoff];
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const RowMeta& r = meta[slot][mg + j];
+      rg[j] = (r.gvalid && gcol_ok) ? rg[j] : 0.f;
+      float a = ra[j];
+      if (has_norm) a = (a - r.mean) * r.rstd * gm + bt;
+      ra[j] = (r.avalid && acol_ok) ? a : 0.f;
+    }
 #pragma unroll
     for (int h8 = 0; h8 < 2; ++h8) {
       bf16x8 ghi, glo, ahi, alo;
@@ -338,17 +360,20 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
     load_tile(0);
   }
   for (int m0 = m_begin; m0 < m_end; m0 += 32, ++it) {
-    const bool more = m0 + 32 < m_end;
-    if (more) make_meta(m0 + 32, (it + 1) & 1);
-    if (do_bias) {
+    // meta of the NEXT tile (rows past m_end are marked invalid, offset 0), so the prefetch below is
+    // unconditional; slot it&1 still describes the tile now in registers
+    make_meta(m0 + 32, (it + 1) & 1);
+    __syncthreads();  // previous tile's fragment reads done; next meta visible
+    store_tile(it & 1);
+    if (do_bias) {  // after masking: invalid rows contribute 0
 #pragma unroll
       for (int j = 0; j < 16; ++j) bsum += rg[j];
     }
-    __syncthreads();  // previous tile's fragment reads done; next meta visible
-    store_tile();
     __syncthreads();
-    if (more) load_tile((it + 1) & 1);
+    load_tile((it + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);  // the loads are issued here and fly under the MFMAs
     tile_mma(lds, wm * 64, wn * 64, l31, half, acc00, acc01, acc10, acc11);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   float* out = p.slab + (long long)split * p.slab_stride + out_off;

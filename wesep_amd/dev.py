@@ -73,9 +73,7 @@ def gemm_nt(*, A, a_rows: Rows, M: int, C_out, c_rows: Rows, N=0, K=0, W=None, l
     sm = stat_map or StatMap(1, 0, 1, 0, 0)
     a.st_div1, a.st_m1, a.st_div2, a.st_m2, a.st_base = sm
     a.M, a.N, a.K, a.ldw = M, N, K, ldw
-    # the split-bf16 kernel's GroupNorm-on-load variant showed run-to-run mismatches on MI355X
-    # (tools/nt_bug_probe.py); until it is replaced, normalised operands take the exact-fp32 kernel
-    a.act, a.ngroups, a.max_n, a.vec = act, ngroups, max_n, vec | (_mode_bit(mode) if stats is None else 0)
+    a.act, a.ngroups, a.max_n, a.vec = act, ngroups, max_n, vec | _mode_bit(mode)
     L.check(L.lib().ws_gemm_nt(C.byref(a), L.stream_ptr()), "ws_gemm_nt")
 
 
@@ -106,7 +104,7 @@ def gemm_tn(*, G, g_rows: Rows, A, a_rows: Rows, M: int, slab, slab_stride: int,
     a.slab_stride, a.bslab_stride, a.out_off, a.bout_off = slab_stride, bslab_stride, out_off, bout_off
     a.M, a.Nn, a.Kk, a.rows_per_split, a.nsplit = M, Nn, Kk, rows_per_split, nsplit
     a.shift_rows, a.seq_div, a.seq_len = shift_rows, seq_div, seq_len
-    a.ngroups, a.max_n, a.max_k, a.vec = ngroups, max_n, max_k, vec | (_mode_bit(mode) if stats is None else 0)
+    a.ngroups, a.max_n, a.max_k, a.vec = ngroups, max_n, max_k, vec | _mode_bit(mode)
     L.check(L.lib().ws_gemm_tn(C.byref(a), L.stream_ptr()), "ws_gemm_tn")
 
 
