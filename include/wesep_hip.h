@@ -270,7 +270,7 @@ typedef struct ws_gemm_tnb_args {
   int a0_width, a0_off, a0_cols, a0_shift;
   int a1_width, a1_off, a1_cols, a1_shift;
   int nblk, L, nsplit, blocks_per_split;
-  int pad_;          /* probe builds only: 1 skip the global loads, 2 skip the LDS image, 4 skip the MFMAs */
+  int pad_;
 } ws_gemm_tnb_args;
 int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream);
 

@@ -351,7 +351,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
   constexpr int TN = TA == 1 ? 1 : TA;   // 32-column MFMA tiles per wave along A (wave owns 32*TA columns)
   // two LDS images [buf][hi | lo][column][slot]: block b+1 is converted and written while block b's
   // fragments are read, one barrier per block (TA = 3: 2 x 80 KB = the whole LDS of the CU)
-  __shared__ __attribute__((aligned(16))) __bf16 lds2[2][2 * PLANE];
+  // two distinct objects (not one [2][..] array) so alias analysis can move image-A reads past image-B writes
+  __shared__ __attribute__((aligned(16))) __bf16 ldsA[2 * PLANE];
+  __shared__ __attribute__((aligned(16))) __bf16 ldsB[2 * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 2, wn = w & 3;
@@ -405,23 +407,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
   for (int r = 0; r < NG; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) csum[r][c] = 0.f;
-  auto store_block = [&](int slot, __bf16* lds) {
+  // one piece = one (group r, column c) of a block: 4 slots -> hi/lo bf16x4 -> LDS; pc = 4*r + c
+  auto store_piece = [&](int slot, __bf16* lds, float live, int pc) {  // live = 0: tail iteration, sums untouched
+    const int r = pc >> 2, c = pc & 3;
+    bf16x4 hi, lo;
 #pragma unroll
-    for (int r = 0; r < NG; ++r)
+    for (int j = 0; j < 4; ++j) {
+      const float v = use[slot][r] ? rq[slot][r][j][c] : 0.f;
+      csum[r][c] += v * live;
+      hi[j] = (__bf16)v;
+      lo[j] = (__bf16)(v - (float)hi[j]);
+    }
+    const int o = (gcol[r] + c) * TB_LD + 4 * sg;
+    *reinterpret_cast<bf16x4*>(lds + o) = hi;
+    *reinterpret_cast<bf16x4*>(lds + PLANE + o) = lo;
+  };
+  auto store_block = [&](int slot, __bf16* lds, float live) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        bf16x4 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float v = use[slot][r] ? rq[slot][r][j][c] : 0.f;
-          csum[r][c] += v;
-          hi[j] = (__bf16)v;
-          lo[j] = (__bf16)(v - (float)hi[j]);
-        }
-        const int o = (gcol[r] + c) * TB_LD + 4 * sg;
-        *reinterpret_cast<bf16x4*>(lds + o) = hi;
-        *reinterpret_cast<bf16x4*>(lds + PLANE + o) = lo;
-      }
+    for (int pc = 0; pc < 4 * NG; ++pc) store_piece(slot, lds, live, pc);
   };
 
   f32x16 acc[2][TN];
@@ -432,41 +435,62 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
 
-  if (b_begin < b_end) load_block(b_begin, 0);
-  if (b_begin + 1 < b_end) load_block(b_begin + 1, 1);
-  if (b_begin < b_end) store_block(0, lds2[0]);
+  // The block loop body is ONE basic block (tail iterations reload / reconvert the last block instead of
+  // branching), so the conversion of block b+1 (VALU + LDS writes) can be interleaved with the MFMAs
+  // of block b by the scheduler hints below -- both waves of a SIMD are in phase after each barrier,
+  // so without it the two phases simply add up.
+  const int nb = b_end - b_begin;
+  if (nb > 0) {
+    load_block(b_begin, 0);
+    load_block(min(b_begin + 1, b_end - 1), 1);
+    store_block(0, ldsA, 1.f);
+  }
   __syncthreads();
-  for (int b = b_begin; b < b_end; b += 2) {
+  for (int ib = 0; ib < nb; ib += 2) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      if (b + s < b_end) {  // uniform
-        // registers of slot s (block b+s) were consumed by the previous store: refill them 2 blocks ahead
-        if (b + s + 2 < b_end && !(p.pad_ & 1)) load_block(b + s + 2, s);
-        // block b+s+1 (register slot s^1) -> the other LDS image, under this block's MFMAs
-        if (b + s + 1 < b_end && !(p.pad_ & 2)) store_block(s ^ 1, lds2[s ^ 1]);
-        const __bf16* lds = lds2[s];
-        if (!(p.pad_ & 4))
+      const int i = ib + s;
+      if (i < nb) {  // uniform; only the odd tail skips
+        // registers of slot s (block i) were consumed by the previous store: refill them 2 blocks ahead
+        load_block(b_begin + min(i + 2, nb - 1), s);
+        __builtin_amdgcn_sched_barrier(0);
+        // block i+1 (register slot s^1) -> the other LDS image, one piece per MFMA pair of this
+        // block; scheduling fences keep each piece beside its pair (a wave issues in order, so VALU
+        // work only overlaps the matrix pipe when it sits between MFMAs in program order)
+        const __bf16* lds = s ? ldsB : ldsA;
+        __bf16* ldsw = s ? ldsA : ldsB;
+        const float live = i + 1 < nb ? 1.f : 0.f;
+        constexpr int NSUB = 6 * TN, NPC = 4 * NG, EVERY = NSUB / NPC;
+        auto lda = [&](int ks, int f, bf16x8& h, bf16x8& l) {
+          const int ra = (128 + wn * 32 * TN + f * 32 + l31) * TB_LD + ks + 8 * half;
+          h = *reinterpret_cast<const bf16x8*>(lds + ra);
+          l = *reinterpret_cast<const bf16x8*>(lds + PLANE + ra);
+        };
+        bf16x8 ah, al, ahn, aln;
+        lda(0, 0, ah, al);
+        int sub = 0;
 #pragma unroll
         for (int ks = 0; ks < 32; ks += 16) {
-          const int ka = ks + 8 * half;
           bf16x8 gh[2], gl[2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            const int rg = (wm * 64 + e * 32 + l31) * TB_LD + ka;
+            const int rg = (wm * 64 + e * 32 + l31) * TB_LD + ks + 8 * half;
             gh[e] = *reinterpret_cast<const bf16x8*>(lds + rg);
             gl[e] = *reinterpret_cast<const bf16x8*>(lds + PLANE + rg);
           }
 #pragma unroll
           for (int f = 0; f < TN; ++f) {
-            const int ra = (128 + wn * 32 * TN + f * 32 + l31) * TB_LD + ka;
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + ra);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + PLANE + ra);
+            const bool last = ks == 16 && f == TN - 1;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(gh[e], ah, acc[e][f]);
+            for (int term = 0; term < 3; ++term, ++sub) {
+              if (term == 0 && !last) lda(f + 1 < TN ? ks : 16, f + 1 < TN ? f + 1 : 0, ahn, aln);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(gl[e], ah, acc[e][f]);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(gh[e], al, acc[e][f]);
+              for (int e = 0; e < 2; ++e)
+                acc[e][f] = mfma32(term == 1 ? gl[e] : gh[e], term == 2 ? al : ah, acc[e][f]);
+              if (sub % EVERY == 0 && sub / EVERY < NPC) store_piece(s ^ 1, ldsw, live, sub / EVERY);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            ah = ahn; al = aln;
           }
         }
         __syncthreads();  // image s fully read, image s^1 fully written
