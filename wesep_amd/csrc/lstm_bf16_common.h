@@ -23,11 +23,15 @@ __device__ __forceinline__ bf16x8 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, i
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mkrsrc(const float* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
 }
+// cache policy of the once-through activation streams (gates, cells, h): 2 = nt (stream, evict first)
+#ifndef WS_STREAM_AUX
+#define WS_STREAM_AUX 2
+#endif
 __device__ __forceinline__ f32x4 bld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, WS_STREAM_AUX));
 }
 __device__ __forceinline__ void bst(const f32x4& v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, WS_STREAM_AUX);
 }
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
