@@ -213,6 +213,10 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_s16_kernel(const ws_lstm_args
 // ---------------------------------------------------------------------------------------------
 // backward (BPTT): dh_{t-1}^T[unit][seq] = W_hh^T[unit][gate col] * dgates_t^T[gate col][seq]
 // ---------------------------------------------------------------------------------------------
+
+#ifndef S16_DBG
+#define S16_DBG 0  // probe builds: 1 no next-step loads, 2 no gate-gradient stores, 4 no weight reloads
+#endif
 __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 dgl[2][S16 * DROW];  // [part][seq][gate col] 66 KB
   const int d = blockIdx.y;
@@ -287,10 +291,12 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
         po[r] = dov * og * (1.f - og);
       }
       c_cur[tu] = n_cp[tu];
+      if (!(S16_DBG & 2)) {
       st_gate(pi, t, 0, tu);
       st_gate(pf, t, 1, tu);
       st_gate(pg, t, 2, tu);
       st_gate(po, t, 3, tu);
+      }
       bf16x4 hi, lo;
       split4(pi, hi, lo);
       *reinterpret_cast<bf16x4*>(dhi + 16 * tu) = hi;
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
       split4(po, hi, lo);
       *reinterpret_cast<bf16x4*>(dhi + 768 + 16 * tu) = hi;
       *reinterpret_cast<bf16x4*>(dlo + 768 + 16 * tu) = lo;
-      load_step(tn, tu);  // into the registers just consumed
+      if (!(S16_DBG & 1)) load_step(tn, tu);  // into the registers just consumed
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -334,9 +340,11 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
         for (int tu = 0; tu < 2; ++tu) acc[tu] = mfma16(wr[s][(q * 2 + tu) * 2], bl, acc[tu]);
       }
       const int cn = (ch + 2) & 7;  // wraps into the next step
+      if (!(S16_DBG & 4)) {
 #pragma unroll
       for (int f = 0; f < 16; ++f)
         wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + cn * 16384 + (f >> 2) * 4096);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     dhr[0] = acc[0];

@@ -184,16 +184,28 @@ def reset_deferred_wgrads(device):
     _pending(device).clear()
 
 
-def flush_deferred_wgrads(device):
-    """Launch every deferred weight-gradient job on the side stream, ordered after everything
-    enqueued so far on the current stream.  Called right before a TIME-VIEW recurrence is launched
-    (64 of 256 CUs busy for ~7 ms: the jobs fill the other 192) and by the carriers for leftovers."""
+def mark_wgrads_ready(device):
+    """Event on the current stream after which every deferred job's operands are complete (None when
+    nothing is pending)."""
+    if not _pending(device):
+        return None
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream())
+    return ready
+
+
+def flush_deferred_wgrads(device, ready=None):
+    """Launch every deferred weight-gradient job on the side stream, ordered after `ready` (default:
+    everything enqueued so far on the current stream).  A TIME-VIEW recurrence keeps 128 of 256 CUs
+    busy for ~5 ms: its backward marks `ready`, launches the recurrence FIRST -- so its workgroups
+    take their CUs at once instead of queueing behind a full-chip GEMM wave -- and then releases the
+    jobs into the other half of the chip.  The carriers flush the leftovers."""
     jobs = _pending(device)
     if not jobs:
         return
-    main, side = torch.cuda.current_stream(), _side_stream(device)
-    ready = torch.cuda.Event()
-    ready.record(main)
+    side = _side_stream(device)
+    if ready is None:
+        ready = mark_wgrads_ready(device)
     with torch.cuda.stream(side):
         side.wait_event(ready)
         for job in jobs:
@@ -334,9 +346,9 @@ class ResRNNBlkFn(torch.autograd.Function):
         dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
         dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wpt_pack, N=2 * H, C_out=dh, A_bl=dout_bl)
         # BPTT: gates (activated) -> d(pre-activation gates), in place.  A time-view recurrence leaves
-        # 3/4 of the chip idle: release the weight-gradient jobs deferred by the previous layers first
-        if ctx.view == "time":
-            flush_deferred_wgrads(d)
+        # half of the chip idle: the weight-gradient jobs deferred by the previous layers are released
+        # right after it is launched
+        ready = mark_wgrads_ready(d) if ctx.view == "time" else None
         # the cluster BPTT (4.8 ms vs 5.8 ms per time-view launch) fills all 256 CUs and so evicts the
         # side-stream weight-gradient GEMMs that otherwise run under the 128-CU streaming kernel: net loss
         # today, hence opt-in (WESEP_LSTM_CLUSTER_BWD=1)
@@ -344,6 +356,8 @@ class ResRNNBlkFn(torch.autograd.Function):
             dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
         else:
             dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, ctx.lmode)
+        if ready is not None:
+            flush_deferred_wgrads(d, ready)
         del dh
         # weight gradients: a side branch of the graph -> deferred to the side stream when a carrier
         # will deliver them
