@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from oracle import bsrnn_oracle as O
+from oracle import convtasnet_oracle as CT
 from oracle.ref_import import import_reference
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -78,6 +79,56 @@ def run_case(name, kw, R, T, seed):
     print(f"{name}: loss={loss.item():.6f} sisnr_np={sisnr_np:.6f} est_rms={est.pow(2).mean().sqrt().item():.4e}")
 
 
+TASNET_CASES = {
+    # name: (ConvTasNetConfig kwargs, rows, T (multiple of the stride), seed)
+    "convtasnet_gln_r2_t1600": (dict(N=32, L=20, B=32, H=64, P=3, X=3, R=2), 2, 1600, 21),
+    "convtasnet_cln_xform_r4_t2000": (dict(N=16, L=20, B=24, H=40, P=3, X=2, R=1, norm="cLN",
+                                           use_spk_transform=True), 4, 2000, 22),
+    "convtasnet_gln_l16_r2_t1200": (dict(N=24, L=16, B=16, H=32, P=3, X=4, R=1), 2, 1200, 23),
+}
+
+
+def run_tasnet_case(name, kw, R, T, seed):
+    """Conv-TasNet / SpEx+ with fixed embeddings (`joint_training=False`), multi-scale SI-SDR loss."""
+    get_model = import_reference()
+    cfg = CT.ConvTasNetConfig(**kw)
+    ref = get_model("ConvTasNet")(
+        N=cfg.N, L=cfg.L, B=cfg.B, H=cfg.H, P=cfg.P, X=cfg.X, R=cfg.R, spk_emb_dim=cfg.spk_emb_dim,
+        norm=cfg.norm, activate="relu", causal=False, skip_con=False, spk_fuse_type="concatConv",
+        multi_fuse=cfg.multi_fuse, use_spk_transform=cfg.use_spk_transform, encoder_type="Multi",
+        decoder_type="Multi", joint_training=False)
+    params = CT.synth_params(cfg, seed)
+    ref_sd = ref.state_dict()
+    assert list(ref_sd.keys()) == list(params.keys()), "oracle param_shapes() order != reference state_dict"
+    for k in ref_sd:
+        assert tuple(ref_sd[k].shape) == tuple(params[k].shape), k
+    ref.load_state_dict(params, strict=True)
+    ref.train()
+    wav, tgt, emb = O.synth_batch(R, T, seed)
+    ests = ref(wav, emb)
+    assert all(e.shape == tgt.shape for e in ests), [tuple(e.shape) for e in ests]
+    loss = CT.multiscale_sisdr_loss(ests, tgt)
+    loss.backward()
+    out = {
+        "wav": wav.numpy(), "tgt": tgt.numpy(), "emb": emb.numpy(), "loss": np.float64(loss.item()),
+        "param_checksum": np.float64(sum(float(v.double().abs().sum()) for v in params.values())),
+    }
+    for i, e in enumerate(ests):
+        out[f"est{i + 1}"] = e.detach().numpy()
+    names = []
+    for k, prm in ref.named_parameters():
+        g = prm.grad.detach().reshape(-1)
+        names.append(k)
+        out["gnorm/" + k] = np.float64(g.double().norm().item())
+        out["ghead/" + k] = g[:16].numpy().copy()
+        if g.numel() <= 4096:
+            out["gfull/" + k] = g.numpy().copy()
+    out["names"] = np.array(names)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.6f} est1_rms={ests[0].pow(2).mean().sqrt().item():.4e}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
@@ -85,3 +136,7 @@ if __name__ == "__main__":
         if only and name not in only:
             continue
         run_case(name, kw, R, T, seed)
+    for name, (kw, R, T, seed) in TASNET_CASES.items():
+        if only and name not in only:
+            continue
+        run_tasnet_case(name, kw, R, T, seed)

@@ -87,3 +87,45 @@ def test_adam_restatement_matches_torch():
 def test_lr_schedule_endpoints():
     assert abs(O.exponential_decrease_lr(0, 1000, 1e-3, 2.5e-5) - 1e-3) < 1e-12
     assert abs(O.exponential_decrease_lr(1000, 1000, 1e-3, 2.5e-5) - 2.5e-5) < 1e-12
+
+
+# ---- Conv-TasNet / SpEx+ ----------------------------------------------
+from oracle import convtasnet_oracle as CT  # noqa: E402
+from oracle.make_golden import TASNET_CASES  # noqa: E402
+
+
+def run_tasnet_oracle(name):
+    kw, R, T, seed = TASNET_CASES[name]
+    cfg = CT.ConvTasNetConfig(**kw)
+    params = {k: v.requires_grad_(True) for k, v in CT.synth_params(cfg, seed).items()}
+    wav, tgt, emb = O.synth_batch(R, T, seed)
+    ests = CT.convtasnet_forward(params, cfg, wav, emb)
+    loss = CT.multiscale_sisdr_loss(ests, tgt)
+    loss.backward()
+    return cfg, params, wav, tgt, emb, ests, loss
+
+
+@pytest.mark.parametrize("name", sorted(TASNET_CASES))
+def test_tasnet_oracle_matches_reference_fixture(name, golden_dir):
+    path = os.path.join(golden_dir, name + ".npz")
+    assert os.path.exists(path), "fixture missing: run python -m oracle.make_golden"
+    g = np.load(path)
+    cfg, params, wav, tgt, emb, ests, loss = run_tasnet_oracle(name)
+    assert np.array_equal(g["wav"], wav.numpy())
+    assert np.array_equal(g["emb"], emb.numpy())
+    chk = sum(float(v.detach().double().abs().sum()) for v in params.values())
+    assert abs(chk - float(g["param_checksum"])) <= 1e-9 * abs(chk)
+    for i, est in enumerate(ests):
+        ref = g[f"est{i + 1}"]
+        rel = np.linalg.norm(est.detach().numpy() - ref) / np.linalg.norm(ref)
+        assert rel < 1e-5, (i, rel)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4          # dB
+    assert list(g["names"]) == list(params.keys())
+    for k, p in params.items():
+        gn = float(g["gnorm/" + k])
+        mine = p.grad.reshape(-1)
+        assert abs(float(mine.double().norm()) - gn) <= 2e-4 * gn + 1e-9, k
+        if "gfull/" + k in g.files:
+            full = g["gfull/" + k]
+            err = np.linalg.norm(mine.numpy() - full) / (np.linalg.norm(full) + 1e-30)
+            assert err < 2e-4, (k, err)
