@@ -121,11 +121,14 @@ def test_tasnet_oracle_matches_reference_fixture(name, golden_dir):
         assert rel < 1e-5, (i, rel)
     assert abs(loss.item() - float(g["loss"])) < 1e-4          # dB
     assert list(g["names"]) == list(params.keys())
+    # the loss is invariant to a DC offset of the estimate, so d/d(decoder bias) is pure rounding noise:
+    # gradients are compared with an absolute floor of 1e-6 of the largest gradient norm
+    floor = 1e-6 * max(float(g["gnorm/" + k]) for k in params)
     for k, p in params.items():
         gn = float(g["gnorm/" + k])
         mine = p.grad.reshape(-1)
-        assert abs(float(mine.double().norm()) - gn) <= 2e-4 * gn + 1e-9, k
+        assert abs(float(mine.double().norm()) - gn) <= 2e-4 * gn + floor, k
         if "gfull/" + k in g.files:
             full = g["gfull/" + k]
-            err = np.linalg.norm(mine.numpy() - full) / (np.linalg.norm(full) + 1e-30)
-            assert err < 2e-4, (k, err)
+            err = np.linalg.norm(mine.numpy() - full)
+            assert err < 2e-4 * np.linalg.norm(full) + floor, (k, err)
