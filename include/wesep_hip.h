@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 2
+#define WS_ABI_VERSION 3
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -56,7 +56,8 @@ typedef struct ws_group_nt {
 /* C[m][n] = epi( sum_k pro(A[m][k]) * W[n][k] )        (torch Linear / Conv1d(k=1) layout)
  *   pro : optional GroupNorm-on-load  a' = (a - mean[s]) * rstd[s] * gamma[k] + beta[k],
  *         s = (m / st_div1) * st_m1 + (m % st_div2) * st_m2 + st_base, stats = [S][2]
- *   epi : + bias[n]; act (0 none, 1 tanh); * (1 - T^2) if T; + R if R   (T, R addressed like C)
+ *   epi : + bias[n]; act (0 none, 1 tanh, 2 ReLU); * (1 - T^2) if T (act 4: * (T > 0), the ReLU
+ *         derivative from the saved output); + R if R                 (T, R addressed like C)
  * Replaces: F.group_norm + F.linear / Conv1d(k=1) (+tanh, +residual) at bsrnn.py:38-46,
  * 252-258, 271-282 and their autograd data-gradients.                                      */
 typedef struct ws_gemm_nt_args {
@@ -328,6 +329,61 @@ int ws_grad_norms(const ws_tensor_ref* tab, int ntensors, float* norms, void* st
 int ws_clip_adam_step(const ws_tensor_ref* tab, int ntensors, const float* norms, float clip,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                       int clip_only, void* stream);
+
+/* ---- Conv-TasNet / SpEx+, channels-last activations [R*T'][C] ----------
+ * Everything that is not a 1x1 / framing convolution (those are ws_gemm_nt / ws_gemm_tn on row views).
+ * Replaces, with their autograd: nn.PReLU (convs.py:60,73,123,137), GlobalChannelLayerNorm /
+ * ChannelWiseLayerNorm (norm.py:7-59), the depthwise dilated Conv1d (convs.py:63-70,125-133), the
+ * concatConv speaker fusion's broadcast half (convs.py:143-148), the decoder's mask product and
+ * ConvTranspose1d overlap-add (decoder.py:92-114).                                                   */
+
+/* mean / rstd of `ngroups` contiguous groups of n_per_group floats (gLN: one row's T'*C), chunked over
+ * nchunk workgroups per group; scratch [ngroups][nchunk][4]; stats [ngroups][2] = (mean, 1/sqrt(var+eps)) */
+int ws_flat_stats(const float* x, int ngroups, long long n_per_group, float eps, int nchunk,
+                  float* scratch, float* stats, void* stream);
+/* x += rb[m / rows_per_r] (rb may be NULL; x is updated in place = the saved pre-activation);
+ * y = x > 0 ? x : a[0] * x                                                                         */
+int ws_prelu_fwd(float* x, const float* rb, const float* a, long long rows, int C, int rows_per_r,
+                 float* y, void* stream);
+/* dx = dy * (pre > 0 ? 1 : a[0]) (dx may alias dy); slab[i < nslab] partial sums of dy * min(pre, 0)  */
+int ws_prelu_bwd(const float* pre, const float* dy, const float* a, long long n, float* dx, float* slab,
+                 int nslab, void* stream);
+/* y = b + depthwise_conv(norm(x)), norm applied on load with stats index m / st_div, zero "same" padding,
+ * w [C][P] (odd P <= 7), dilation dil                                                               */
+int ws_dwconv_fwd(const float* x, const float* stats, const float* gamma, const float* beta,
+                  const float* w, const float* b, int R, int Tp, int C, int P, int dil, int st_div,
+                  float* y, void* stream);
+/* dxn = d(norm(x)); slab[split][P + 1][C]: rows 0..P-1 = dw[.][p] partials, row P = db partials       */
+int ws_dwconv_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
+                  const float* beta, const float* w, int R, int Tp, int C, int P, int dil, int st_div,
+                  float* dxn, int nsplit, int rows_per_split, float* slab, void* stream);
+/* slab[split * ngroups + grp][2][C]: per-channel sums of g and of g * xhat over the rows of group grp
+ * (rows_per_group consecutive rows) that fall into the split; xhat = (x - mean_s) * rstd_s, s = m / st_div
+ * (stats NULL: xhat = x; x NULL: second row zero)                                                    */
+int ws_chan_sums(const float* g, const float* x, const float* stats, int st_div, int rows_per_group,
+                 int ngroups, int nsplit, int C, float* slab, void* stream);
+/* ab[grp] = (sum_c gamma[c] * S0[grp][c], sum_c gamma[c] * S1[grp][c]) / n_per_group, sums [ngroups][2][C] */
+int ws_norm_ab(const float* sums, const float* gamma, int ngroups, int C, long long n_per_group,
+               float* ab, void* stream);
+/* dx = rstd_s * (dxn * gamma - ab0_s - xhat * ab1_s) (+ res), s = m / st_div (dx may alias dxn)        */
+int ws_norm_bwd_apply_cl(const float* x, const float* dxn, const float* stats, const float* ab,
+                         const float* gamma, const float* res, long long rows, int C, int st_div,
+                         float* dx, void* stream);
+/* s = w * m (w with leading dimension ldw); backward: dw = ds * m (leading dimension ld_dw),
+ * dm = ds * w * (m > 0)  (m is the ReLU output of the mask GEMM)                                     */
+int ws_maskmul_fwd(const float* w, long long ldw, const float* m, long long rows, int N, float* s,
+                   void* stream);
+int ws_maskmul_bwd(const float* ds, const float* w, long long ldw, const float* m, long long rows, int N,
+                   float* dw, long long ld_dw, float* dm, void* stream);
+/* d *= (y > 0), in place                                                                            */
+int ws_relu_mask(float* d, const float* y, long long n, void* stream);
+/* est[r][j] = bias[0] + sum_t frames[r*Tp + t][j - hop*t], j < Tout <= (Tp-1)*hop + L; and the adjoint
+ * gather dframes[m][k] = hop*t + k < Tout ? dest[r][hop*t + k] : 0                                     */
+int ws_ola_fwd(const float* frames, const float* bias, int R, int Tp, int L, int hop, int Tout,
+               float* est, void* stream);
+int ws_ola_bwd(const float* dest, int R, int Tp, int L, int hop, int Tout, float* dframes, void* stream);
+/* slab[i < nslab] = partial sums of x[0..n)                                                          */
+int ws_sum_partial(const float* x, long long n, float* slab, int nslab, void* stream);
 
 #ifdef __cplusplus
 }

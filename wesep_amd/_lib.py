@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 2
+ABI_VERSION = 3
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
@@ -126,6 +126,21 @@ _SIGS = {
     "ws_affine_bwd": (_i, [_p, _p, _p, _f, _ll, _i, _i, _i, _p, _p, _p, _p]),
     "ws_sisdr_fwd": (_i, [_p, _p, _i, _i, _f, _p, _p, _p]),
     "ws_sisdr_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
+    # Conv-TasNet / SpEx+ (tasnet.hip)
+    "ws_flat_stats": (_i, [_p, _i, _ll, C.c_float, _i, _p, _p, _p]),
+    "ws_prelu_fwd": (_i, [_p, _p, _p, _ll, _i, _i, _p, _p]),
+    "ws_prelu_bwd": (_i, [_p, _p, _p, _ll, _p, _p, _i, _p]),
+    "ws_dwconv_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_dwconv_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p]),
+    "ws_chan_sums": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_norm_ab": (_i, [_p, _p, _i, _i, _ll, _p, _p]),
+    "ws_norm_bwd_apply_cl": (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _p]),
+    "ws_maskmul_fwd": (_i, [_p, _ll, _p, _ll, _i, _p, _p]),
+    "ws_maskmul_bwd": (_i, [_p, _p, _ll, _p, _ll, _i, _p, _ll, _p, _p]),
+    "ws_relu_mask": (_i, [_p, _p, _ll, _p]),
+    "ws_ola_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_ola_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_sum_partial": (_i, [_p, _ll, _p, _i, _p]),
     "ws_grad_norms": (_i, [_p, _i, _p, _p]),
     "ws_clip_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p]),
 }

@@ -171,9 +171,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const ws_gemm_nt_args p) {
       const long long off = ws_row_off(m, p.c_div, p.c_s1, p.c_s2) + n;
       float v = acc[r] + bv;
       if (p.act == 1) v = tanhf(v);
-      if (T) {
+      if (p.act == 2) v = fmaxf(v, 0.f);
+      if (T) {  // derivative of the activation from its saved OUTPUT: tanh' (default) or ReLU' (act 4)
         const float t = T[off];
-        v *= (1.f - t * t);
+        v *= p.act == 4 ? (t > 0.f ? 1.f : 0.f) : (1.f - t * t);
       }
       if (R) v += R[off];
       C[off] = v;

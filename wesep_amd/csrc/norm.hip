@@ -75,7 +75,6 @@ __global__ __launch_bounds__(256) void group_stats_kernel(const float* __restric
 static int geom_check(const ws_groups_geom* geo, const char* who) {
   WS_REQUIRE(geo && geo->ngroups > 0 && geo->gdiv > 0 && geo->L > 0 && geo->W > 0 && geo->nbands > 0,
              "%s: bad geometry", who);
-  WS_REQUIRE(geo->W <= 128, "%s: W=%d > 128", who, geo->W);
   return WS_OK;
 }
 

@@ -502,3 +502,130 @@ def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_
     a.a1_width, a.a1_off, a.a1_cols, a.a1_shift = a1_width, a1_off, a1_cols, a1_shift
     a.nblk, a.L, a.nsplit, a.blocks_per_split, a.pad_ = nblk, L_, nsplit, blocks_per_split, dbg
     L.check(L.lib().ws_gemm_tnb(C.byref(a), L.stream_ptr()), "ws_gemm_tnb")
+
+
+# ---- Conv-TasNet / SpEx+ pieces (tasnet.hip), channels-last [R*T'][C] -----------------------------
+LN_EPS = 1e-5  # norm.py:18 (gLN), nn.LayerNorm default (cLN)
+
+
+def _call(name, *args):
+    L.check(getattr(L.lib(), name)(*args, L.stream_ptr()), name)
+
+
+def flat_stats(x, ngroups: int, n_per_group: int, stats, eps=LN_EPS):
+    """(mean, rstd) of contiguous groups, chunked over the chip."""
+    nchunk = max(1, min(256, n_per_group // 16384))
+    scratch = torch.empty(ngroups, nchunk, 4, device=x.device, dtype=torch.float32)
+    for n, t in (("x", x), ("stats", stats)):
+        _chk(t, n)
+    _call("ws_flat_stats", _p(x), ngroups, n_per_group, eps, nchunk, _p(scratch), _p(stats))
+
+
+def prelu_fwd(x, rb, a, rows: int, Cc: int, rows_per_r: int, y):
+    for n, t in (("x", x), ("rb", rb), ("a", a), ("y", y)):
+        _chk(t, n)
+    _call("ws_prelu_fwd", _p(x), _p(rb), _p(a), rows, Cc, rows_per_r, _p(y))
+
+
+def prelu_bwd(pre, dy, a, dx):
+    """returns d(slope) as a [1] tensor"""
+    for n, t in (("pre", pre), ("dy", dy), ("a", a), ("dx", dx)):
+        _chk(t, n)
+    n = pre.numel()
+    nslab = max(1, min(1024, n // 4096))
+    slab = torch.empty(nslab, device=pre.device, dtype=torch.float32)
+    _call("ws_prelu_bwd", _p(pre), _p(dy), _p(a), n, _p(dx), _p(slab), nslab)
+    da = torch.empty(1, device=pre.device, dtype=torch.float32)
+    reduce_slabs(slab, nslab, 1, 1, da)
+    return da
+
+
+def dwconv_fwd(x, stats, gamma, beta, w, b, R: int, Tp: int, Cc: int, P: int, dil: int, st_div: int, y):
+    for n, t in (("x", x), ("stats", stats), ("gamma", gamma), ("beta", beta), ("w", w), ("b", b), ("y", y)):
+        _chk(t, n)
+    _call("ws_dwconv_fwd", _p(x), _p(stats), _p(gamma), _p(beta), _p(w), _p(b), R, Tp, Cc, P, dil, st_div, _p(y))
+
+
+def row_splits(M: int, target=512):
+    nsplit = max(1, min(target, M // 64))
+    rows = -(-M // nsplit)
+    return -(-M // rows), rows
+
+
+def dwconv_bwd(dy, x, stats, gamma, beta, w, R: int, Tp: int, Cc: int, P: int, dil: int, st_div: int, dxn):
+    """returns (dw [C, P], db [C])"""
+    for n, t in (("dy", dy), ("x", x), ("stats", stats), ("gamma", gamma), ("beta", beta), ("w", w), ("dxn", dxn)):
+        _chk(t, n)
+    nsplit, rows = row_splits(R * Tp)
+    slab = torch.empty(nsplit, P + 1, Cc, device=dy.device, dtype=torch.float32)
+    _call("ws_dwconv_bwd", _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(w), R, Tp, Cc, P, dil, st_div,
+          _p(dxn), nsplit, rows, _p(slab))
+    out = torch.empty(P + 1, Cc, device=dy.device, dtype=torch.float32)
+    reduce_slabs(slab, nsplit, (P + 1) * Cc, (P + 1) * Cc, out)
+    return out[:P].t().contiguous(), out[P].contiguous()
+
+
+def chan_sums(g, x, stats, st_div: int, rows_per_group: int, ngroups: int, Cc: int):
+    """[ngroups, 2, C]: per-channel sums of g and g * xhat over each group of rows_per_group rows."""
+    for n, t in (("g", g), ("x", x), ("stats", stats)):
+        _chk(t, n)
+    nsplit = max(1, min(max(1, 1024 // ngroups), rows_per_group // 32))
+    slab = torch.empty(nsplit, ngroups, 2, Cc, device=g.device, dtype=torch.float32)
+    _call("ws_chan_sums", _p(g), _p(x), _p(stats), st_div, rows_per_group, ngroups, nsplit, Cc, _p(slab))
+    out = torch.empty(ngroups, 2, Cc, device=g.device, dtype=torch.float32)
+    reduce_slabs(slab, nsplit, ngroups * 2 * Cc, ngroups * 2 * Cc, out)
+    return out
+
+
+def norm_ab(sums, gamma, ngroups: int, Cc: int, n_per_group: int, ab):
+    for n, t in (("sums", sums), ("gamma", gamma), ("ab", ab)):
+        _chk(t, n)
+    _call("ws_norm_ab", _p(sums), _p(gamma), ngroups, Cc, n_per_group, _p(ab))
+
+
+def norm_bwd_apply_cl(x, dxn, stats, ab, gamma, res, rows: int, Cc: int, st_div: int, dx):
+    for n, t in (("x", x), ("dxn", dxn), ("stats", stats), ("ab", ab), ("gamma", gamma), ("res", res), ("dx", dx)):
+        _chk(t, n)
+    _call("ws_norm_bwd_apply_cl", _p(x), _p(dxn), _p(stats), _p(ab), _p(gamma), _p(res), rows, Cc, st_div, _p(dx))
+
+
+def maskmul_fwd(w, w_off: int, ldw: int, m, rows: int, N: int, s):
+    for n, t in (("w", w), ("m", m), ("s", s)):
+        _chk(t, n)
+    _call("ws_maskmul_fwd", _p(w, w_off), ldw, _p(m), rows, N, _p(s))
+
+
+def maskmul_bwd(ds, w, w_off: int, ldw: int, m, rows: int, N: int, dw, dw_off: int, ld_dw: int, dm):
+    for n, t in (("ds", ds), ("w", w), ("m", m), ("dw", dw), ("dm", dm)):
+        _chk(t, n)
+    _call("ws_maskmul_bwd", _p(ds), _p(w, w_off), ldw, _p(m), rows, N, _p(dw, dw_off), ld_dw, _p(dm))
+
+
+def relu_mask(d, y):
+    for n, t in (("d", d), ("y", y)):
+        _chk(t, n)
+    _call("ws_relu_mask", _p(d), _p(y), d.numel())
+
+
+def ola_fwd(frames, bias, R: int, Tp: int, Lk: int, hop: int, Tout: int, est):
+    for n, t in (("frames", frames), ("bias", bias), ("est", est)):
+        _chk(t, n)
+    _call("ws_ola_fwd", _p(frames), _p(bias), R, Tp, Lk, hop, Tout, _p(est))
+
+
+def ola_bwd(dest, R: int, Tp: int, Lk: int, hop: int, Tout: int, dframes):
+    for n, t in (("dest", dest), ("dframes", dframes)):
+        _chk(t, n)
+    _call("ws_ola_bwd", _p(dest), R, Tp, Lk, hop, Tout, _p(dframes))
+
+
+def total_sum(x):
+    """sum of all elements as a [1] tensor (deterministic two-stage reduction)"""
+    _chk(x, "x")
+    n = x.numel()
+    nslab = max(1, min(1024, n // 4096))
+    slab = torch.empty(nslab, device=x.device, dtype=torch.float32)
+    _call("ws_sum_partial", _p(x), n, _p(slab), nslab)
+    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    reduce_slabs(slab, nslab, 1, 1, out)
+    return out

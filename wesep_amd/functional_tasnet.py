@@ -1,0 +1,305 @@
+"""Autograd shims of the Conv-TasNet / SpEx+ path over the C ABI.
+
+Activations are CHANNELS-LAST: a reference tensor [R, C, T'] lives here as [R*T', C] (row m = r*T' + t),
+so every 1x1 convolution is one row-major GEMM (`ws_gemm_nt` / `ws_gemm_tn`, split-bf16 MFMA) and the
+framing convolutions of the encoder / decoder are GEMMs over overlapping row views of the waveform.
+Everything else (PReLU, gLN / cLN, depthwise dilated convolution, concatConv broadcast, mask product,
+overlap-add) is in csrc/tasnet.hip.  Three autograd nodes per model: encoder, one per conv block, decoder.
+
+Reference lines: `wesep/modules/tasnet/encoder.py:66-114`, `convs.py:41-160`, `decoder.py:66-114`,
+`wesep/modules/common/norm.py:7-76`.
+"""
+import torch
+
+from . import _lib as L
+from . import dev
+from .dev import Geom, Rows, StatMap, flat
+from .functional import _empty, _need_cuda, _reduce_new
+
+LN_EPS = dev.LN_EPS
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM helpers on big-M channels-last operands
+# ---------------------------------------------------------------------------------------------
+def _vec(*dims):
+    return 3 if all(d % 4 == 0 for d in dims) else 0
+
+
+def _stat_map(norm, Tp):
+    """row -> statistics index: gLN one pair per utterance row, cLN one pair per frame."""
+    return StatMap(Tp, 1, 1, 0, 0) if norm == "gLN" else StatMap(1, 1, 1, 0, 0)
+
+
+def _gemm(x, M, K, W, Nout, *, ldw=None, w_off=0, bias=None, act=0, R=None, T=None, norm=None,
+          a_rows=None, a_off=0, out=None, c_ld=None, c_off=0, vec=None, mode=None):
+    """out[m, c_off + n] = epi(sum_k pro(x[m, k]) W[n, k]); norm = (stats, gamma, beta, stat_map)."""
+    ldw = ldw if ldw is not None else K
+    c_ld = c_ld if c_ld is not None else Nout
+    if out is None:
+        out = _empty(x.device, M, c_ld)
+    st, gm, bt, sm = norm if norm is not None else (None, None, None, None)
+    if vec is None:
+        vec = _vec(K, ldw, w_off, a_off) if a_rows is None else 0
+    dev.gemm_nt(A=x, a_rows=a_rows or flat(K), M=M, N=Nout, K=K, W=W, ldw=ldw, w_off=w_off, bias=bias,
+                C_out=out, c_rows=flat(c_ld), c_off=c_off, a_off=a_off, act=act, R=R, T=T, stats=st,
+                gamma=gm, beta=bt, stat_map=sm, vec=vec, mode=mode)
+    return out
+
+
+def _wgrad(G, M, Nn, A, Kk, *, g_ld=None, g_off=0, a_rows=None, norm=None, with_bias=True, vec=None, mode=None):
+    """dW [Nn, Kk] = G^T pro(A), db [Nn] = colsum(G): split slabs + deterministic reduce."""
+    nsplit, rps = dev.tn_splits(M)
+    d = G.device
+    slab = _empty(d, nsplit, Nn * Kk)
+    bslab = _empty(d, nsplit, Nn) if with_bias else None
+    st, gm, bt, sm = norm if norm is not None else (None, None, None, None)
+    if vec is None:
+        vec = 1 if (a_rows is None and Kk % 4 == 0) else 0
+    dev.gemm_tn(G=G, g_rows=flat(g_ld if g_ld is not None else Nn), g_off=g_off, A=A, a_rows=a_rows or flat(Kk),
+                M=M, Nn=Nn, Kk=Kk, slab=slab, slab_stride=Nn * Kk, bslab=bslab, bslab_stride=Nn, nsplit=nsplit,
+                rows_per_split=rps, stats=st, gamma=gm, beta=bt, stat_map=sm, vec=vec, mode=mode)
+    dW = _reduce_new(slab, nsplit, Nn * Kk, (Nn, Kk))
+    db = _reduce_new(bslab, nsplit, Nn, (Nn,)) if with_bias else None
+    return dW, db
+
+
+def _transposed(W, rows, cols, lds=None, src_off=0):
+    WT = _empty(W.device, cols, rows)
+    dev.transpose(W, rows, cols, lds if lds is not None else cols, WT, src_off=src_off)
+    return WT
+
+
+# ---------------------------------------------------------------------------------------------
+# channel-affine norms on channels-last tensors
+# ---------------------------------------------------------------------------------------------
+def _cln_geom(M, Cc):
+    return Geom(M, 1, Cc, 0, Cc, 1, Cc, 1)
+
+
+def norm_stats(x, norm, R, Tp, Cc):
+    """(mean, rstd) pairs: gLN [R, 2] over (T', C) (norm.py:39-40), cLN [R*T', 2] over C (norm.py:51-59)."""
+    if norm == "gLN":
+        st = _empty(x.device, R, 2)
+        dev.flat_stats(x, R, Tp * Cc, st, LN_EPS)
+    elif norm == "cLN":
+        st = _empty(x.device, R * Tp, 2)
+        dev.group_stats(x, _cln_geom(R * Tp, Cc), st, LN_EPS)
+    else:
+        raise NotImplementedError(f"norm {norm!r}: only gLN and cLN are built")
+    return st
+
+
+def norm_backward(x, dxn, stats, gamma, norm, R, Tp, Cc, res=None):
+    """dx (written over dxn), dgamma [C], dbeta [C] of y = gamma * xhat + beta."""
+    M = R * Tp
+    d = x.device
+    if norm == "gLN":
+        sums = dev.chan_sums(dxn, x, stats, Tp, Tp, R, Cc)            # [R, 2, C]
+        ab = _empty(d, R, 2)
+        dev.norm_ab(sums, gamma, R, Cc, Tp * Cc, ab)
+        tot = _empty(d, 2, Cc)
+        dev.reduce_slabs(sums, R, 2 * Cc, 2 * Cc, tot)
+        st_div = Tp
+    else:
+        ab = _empty(d, M, 2)
+        dev.gn_bwd_reduce(x, dxn, stats, _cln_geom(M, Cc), ab, gamma=gamma)
+        tot = dev.chan_sums(dxn, x, stats, 1, M, 1, Cc).view(2, Cc)
+        st_div = 1
+    dev.norm_bwd_apply_cl(x, dxn, stats, ab, gamma, res, M, Cc, st_div, dxn)
+    return dxn, tot[1].contiguous(), tot[0].contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# MultiEncoder (encoder.py:66-114)
+# ---------------------------------------------------------------------------------------------
+class MultiEncoderFn(torch.autograd.Function):
+    """wav [R, T] -> (e [R*T', B], cat [R*T', 3N]); cat = ReLU outputs w1 | w2 | w3, kept for the decoder."""
+
+    @staticmethod
+    def forward(ctx, wav, stride, w1, b1, w2, b2, w3, b3, ln_w, ln_b, pw, pb):
+        _need_cuda(wav, "ConvTasNet")
+        R, T = wav.shape
+        N = w1.shape[0]
+        Ls = (w1.shape[-1], w2.shape[-1], w3.shape[-1])
+        if T < Ls[0]:
+            raise RuntimeError(f"ConvTasNet: input of {T} samples is shorter than the encoder window {Ls[0]}")
+        Tp = (T - Ls[0]) // stride + 1
+        Tpad = max(T, (Tp - 1) * stride + max(Ls))          # zero extension of encoder.py:106-111
+        Tpad = -(-Tpad // 4) * 4
+        d = wav.device
+        xp = torch.zeros(R, Tpad, device=d, dtype=torch.float32)
+        xp[:, :T] = wav
+        M = R * Tp
+        frames = Rows(Tp, Tpad, stride)                      # row m -> xp[r, t*stride : t*stride + L]
+        cat = _empty(d, M, 3 * N)
+        for i, (w, b) in enumerate(((w1, b1), (w2, b2), (w3, b3))):
+            Lk = Ls[i]
+            _gemm(xp, M, Lk, w.reshape(N, Lk).contiguous(), N, bias=b, act=2, a_rows=frames, out=cat,
+                  c_ld=3 * N, c_off=i * N, vec=2 if Lk % 4 == 0 else 0)
+        st = _empty(d, M, 2)
+        dev.group_stats(cat, _cln_geom(M, 3 * N), st, LN_EPS)
+        B = pw.shape[0]
+        W2 = pw.reshape(B, 3 * N).contiguous()
+        e = _gemm(cat, M, 3 * N, W2, B, bias=pb, norm=(st, ln_w, ln_b, StatMap(1, 1, 1, 0, 0)))
+        ctx.save_for_backward(xp, cat, st, w1, w2, w3, ln_w, ln_b, W2)
+        ctx.geo = (R, Tp, Tpad, stride, N, B, Ls)
+        return e, cat
+
+    @staticmethod
+    def backward(ctx, de, dcat_dec):
+        xp, cat, st, w1, w2, w3, ln_w, ln_b, W2 = ctx.saved_tensors
+        R, Tp, Tpad, stride, N, B, Ls = ctx.geo
+        M = R * Tp
+        de = de.contiguous()
+        sm = StatMap(1, 1, 1, 0, 0)
+        dpw, dpb = _wgrad(de, M, B, cat, 3 * N, norm=(st, ln_w, ln_b, sm))
+        dxn = _gemm(de, M, B, _transposed(W2, B, 3 * N), 3 * N)
+        res = dcat_dec.contiguous() if dcat_dec is not None else None
+        dcat, dlnw, dlnb = norm_backward(cat, dxn, st, ln_w, "cLN", R, Tp, 3 * N, res=res)
+        dev.relu_mask(dcat, cat)
+        frames = Rows(Tp, Tpad, stride)
+        grads = []
+        for i, w in enumerate((w1, w2, w3)):
+            Lk = Ls[i]
+            dW, db = _wgrad(dcat, M, N, xp, Lk, g_ld=3 * N, g_off=i * N, a_rows=frames, vec=0)
+            grads += [dW.view(N, 1, Lk), db]
+        return (None, None, *grads, dlnw, dlnb, dpw.view(B, 3 * N, 1), dpb)
+
+
+# ---------------------------------------------------------------------------------------------
+# Conv1DBlock / Conv1DBlock4Fuse (convs.py:41-160), non-causal, no skip connection
+# ---------------------------------------------------------------------------------------------
+class ConvBlockFn(torch.autograd.Function):
+    """x [R*T', B] -> x + sconv(norm2(prelu2(dconv(norm1(prelu1(conv1x1(x) + rb))))));
+    rb [R, H] = W_e e + b (concatConv fusion, convs.py:143-148) or None (then the conv1x1 bias is used)."""
+
+    @staticmethod
+    def forward(ctx, x, rb, geo, w1, b1, a1, g1, be1, wd, bd, a2, g2, be2, w3, b3):
+        _need_cuda(x, "ConvTasNet")
+        R, Tp, norm, dil = geo
+        M, B = x.shape
+        H, P = wd.shape[0], wd.shape[-1]
+        x = x.contiguous()
+        ldw = w1.shape[1]
+        W1 = w1.reshape(H, ldw).contiguous()
+        c = _gemm(x, M, B, W1, H, ldw=ldw, bias=None if rb is not None else b1)
+        y1 = _empty(x.device, M, H)
+        dev.prelu_fwd(c, rb.contiguous() if rb is not None else None, a1, M, H, Tp, y1)
+        st1 = norm_stats(y1, norm, R, Tp, H)
+        g1f, be1f, g2f, be2f = (t.reshape(H).contiguous() for t in (g1, be1, g2, be2))
+        wdf = wd.reshape(H, P).contiguous()
+        z = _empty(x.device, M, H)
+        st_div = Tp if norm == "gLN" else 1
+        dev.dwconv_fwd(y1, st1, g1f, be1f, wdf, bd, R, Tp, H, P, dil, st_div, z)
+        y2 = _empty(x.device, M, H)
+        dev.prelu_fwd(z, None, a2, M, H, Tp, y2)
+        st2 = norm_stats(y2, norm, R, Tp, H)
+        W3 = w3.reshape(B, H).contiguous()
+        out = _gemm(y2, M, H, W3, B, bias=b3, R=x, norm=(st2, g2f, be2f, _stat_map(norm, Tp)))
+        ctx.save_for_backward(x, c, y1, st1, z, y2, st2, W1, a1, g1f, be1f, wdf, a2, g2f, be2f, W3)
+        ctx.geo = (R, Tp, norm, dil, B, H, P, ldw, rb is not None)
+        ctx.shapes = (w1.shape, g1.shape, wd.shape, w3.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, c, y1, st1, z, y2, st2, W1, a1, g1f, be1f, wdf, a2, g2f, be2f, W3 = ctx.saved_tensors
+        R, Tp, norm, dil, B, H, P, ldw, has_rb = ctx.geo
+        M = R * Tp
+        d = x.device
+        dout = dout.contiguous()
+        st_div = Tp if norm == "gLN" else 1
+        sm = _stat_map(norm, Tp)
+        dW3, db3 = _wgrad(dout, M, B, y2, H, norm=(st2, g2f, be2f, sm))
+        dyn2 = _gemm(dout, M, B, _transposed(W3, B, H), H)
+        dy2, dg2, dbe2 = norm_backward(y2, dyn2, st2, g2f, norm, R, Tp, H)
+        da2 = dev.prelu_bwd(z, dy2, a2, dy2)                                   # dy2 -> dz in place
+        dyn1 = _empty(d, M, H)
+        dwd, dbd = dev.dwconv_bwd(dy2, y1, st1, g1f, be1f, wdf, R, Tp, H, P, dil, st_div, dyn1)
+        dy1, dg1, dbe1 = norm_backward(y1, dyn1, st1, g1f, norm, R, Tp, H)
+        da1 = dev.prelu_bwd(c, dy1, a1, dy1)                                   # dy1 -> dc in place
+        drb = None
+        if has_rb:
+            drb = dev.chan_sums(dy1, None, None, 1, Tp, R, H)[:, 0, :].contiguous()   # [R, H]
+        dW1x, db1 = _wgrad(dy1, M, H, x, B, with_bias=not has_rb)
+        if ldw != B:                                                          # speaker columns: via rb's producer
+            dW1 = torch.zeros(H, ldw, device=d, dtype=torch.float32)
+            dW1[:, :B] = dW1x
+        else:
+            dW1 = dW1x
+        W1xT = _transposed(W1, H, B, lds=ldw)
+        dx = _gemm(dy1, M, H, W1xT, B, R=dout)
+        s1, sg, sd, s3 = ctx.shapes
+        return (dx, drb, None, dW1.view(s1), db1, da1, dg1.view(sg), dbe1.view(sg), dwd.reshape(sd), dbd, da2,
+                dg2.view(sg), dbe2.view(sg), dW3.view(s3), db3)
+
+
+# ---------------------------------------------------------------------------------------------
+# MultiDecoder (decoder.py:66-114), actLayer = ReLU
+# ---------------------------------------------------------------------------------------------
+class MultiDecoderFn(torch.autograd.Function):
+    """(e [R*T', B], cat [R*T', 3N]) -> est1, est2, est3 [R, (T'-1)*stride + L1]."""
+
+    @staticmethod
+    def forward(ctx, e, cat, geo, *params):
+        _need_cuda(e, "ConvTasNet")
+        R, Tp, stride = geo
+        M, B = e.shape
+        N = cat.shape[1] // 3
+        e, cat = e.contiguous(), cat.contiguous()
+        d = e.device
+        L1 = params[6].shape[-1]
+        xlen = (Tp - 1) * stride + L1
+        ests, masks = [], []
+        for i in range(3):
+            wm, bm = params[2 * i], params[2 * i + 1]
+            wdec, bdec = params[6 + 2 * i], params[7 + 2 * i]
+            Lk = wdec.shape[-1]
+            m = _gemm(e, M, B, wm.reshape(N, B).contiguous(), N, bias=bm, act=2)
+            s = _empty(d, M, N)
+            dev.maskmul_fwd(cat, i * N, 3 * N, m, M, N, s)
+            WT = _transposed(wdec.reshape(N, Lk).contiguous(), N, Lk)            # [Lk, N]
+            fr = _gemm(s, M, N, WT, Lk)
+            est = _empty(d, R, xlen)
+            dev.ola_fwd(fr, bdec, R, Tp, Lk, stride, xlen, est)
+            ests.append(est)
+            masks.append(m)
+        ctx.save_for_backward(e, cat, *masks, *params)
+        ctx.geo = (R, Tp, stride, B, N, xlen)
+        return tuple(ests)
+
+    @staticmethod
+    def backward(ctx, *dests):
+        e, cat = ctx.saved_tensors[:2]
+        masks = ctx.saved_tensors[2:5]
+        params = ctx.saved_tensors[5:]
+        R, Tp, stride, B, N, xlen = ctx.geo
+        M = R * Tp
+        d = e.device
+        dcat = torch.zeros(M, 3 * N, device=d, dtype=torch.float32)
+        de = None
+        gm = [None] * 6
+        gd = [None] * 6
+        for i in range(3):
+            if dests[i] is None:
+                continue
+            dest = dests[i].contiguous()
+            wm = params[2 * i]
+            wdec = params[6 + 2 * i]
+            Lk = wdec.shape[-1]
+            W2 = wdec.reshape(N, Lk).contiguous()
+            dfr = _empty(d, M, Lk)
+            dev.ola_bwd(dest, R, Tp, Lk, stride, xlen, dfr)
+            s = _empty(d, M, N)
+            dev.maskmul_fwd(cat, i * N, 3 * N, masks[i], M, N, s)                # recomputed, not saved
+            dWd, _ = _wgrad(s, M, N, dfr, Lk, with_bias=False)
+            ds = _gemm(dfr, M, Lk, W2, N)
+            dm = s                                                               # reuse the buffer
+            dev.maskmul_bwd(ds, cat, i * N, 3 * N, masks[i], M, N, dcat, i * N, 3 * N, dm)
+            Wm = wm.reshape(N, B).contiguous()
+            dWm, dbm = _wgrad(dm, M, N, e, B)
+            de = _gemm(dm, M, N, _transposed(Wm, N, B), B, R=de)
+            gm[2 * i], gm[2 * i + 1] = dWm.view(N, B, 1), dbm
+            gd[2 * i], gd[2 * i + 1] = dWd.view(N, 1, Lk), dev.total_sum(dest)
+        return (de, dcat, None, *gm, *gd)

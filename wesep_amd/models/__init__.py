@@ -1,5 +1,5 @@
 """Model factory with the reference's contract (wesep/models/__init__.py:10-27)."""
-from . import bsrnn
+from . import bsrnn, convtasnet
 
 
 def get_model(model_name: str):
@@ -7,7 +7,9 @@ def get_model(model_name: str):
         raise NotImplementedError(f"{model_name}: research variant outside the built hot path (SURVEY.md section 8)")
     if model_name.startswith("BSRNN"):
         return getattr(bsrnn, model_name)
-    if model_name.startswith(("ConvTasNet", "DPCCN", "TFGridNet")):
-        raise NotImplementedError(f"{model_name}: SURVEY.md section 8 rows a15-a17, not built in this round")
+    if model_name.startswith("ConvTasNet"):
+        return getattr(convtasnet, model_name)
+    if model_name.startswith(("DPCCN", "TFGridNet")):
+        raise NotImplementedError(f"{model_name}: SURVEY.md section 8 rows a16-a17, not built in this round")
     print(model_name + " not found !!!")
     exit(1)
