@@ -216,3 +216,20 @@ def test_unbuilt_variants_fail_loudly():
     model = cls(N=16, L=20, B=16, H=32, X=2, R=1, joint_training=False, use_spk_transform=False)
     with pytest.raises(Exception):
         model(torch.randn(2, 400), torch.randn(2, 256))        # CPU tensors: no CPU path
+
+
+def test_full_size_forward_matches_oracle():
+    """SpEx+ size (N=B=256, H=512, X=8, R=4 -> 32 blocks), 2 rows x 4 s: waveforms vs the CPU oracle."""
+    from oracle import bsrnn_oracle as O
+    from oracle import convtasnet_oracle as CT
+    d = _cuda()
+    kw = dict(N=256, L=20, B=256, H=512, P=3, X=8, R=4)
+    cfg, params, model = _build(kw, 31, d)
+    wav, tgt, emb = O.synth_batch(2, 64000, 31)
+    with torch.no_grad():
+        ests = model(wav.to(d), emb.to(d))
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        ref = CT.convtasnet_forward(params, cfg, wav, emb)
+    for e, r in zip(ests, ref):
+        assert e.shape == r.shape == wav.shape
+        assert rel(e, r) < WAV_TOL
