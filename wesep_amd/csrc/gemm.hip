@@ -404,14 +404,51 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slab, int nsplit, 
   }
 }
 
+// Few outputs, many splits (column sums, scalar reductions): the plain kernel would walk the splits
+// serially in a handful of threads.  (a) count <= 8: one workgroup per output, splits strided over 256
+// threads, block sum.  (b) 64 outputs x 4 split lanes per workgroup, lanes summed in fixed order through LDS.
+__global__ __launch_bounds__(256) void reduce_slabs_few_kernel(const float* __restrict__ slab, int nsplit,
+                                                               long long stride, float* __restrict__ out, int w,
+                                                               long long ldo) {
+  __shared__ float red[16];
+  const long long i = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < nsplit; k += 256) s += slab[k * stride + i];
+  s = ws_block_sum(s, red);
+  if (threadIdx.x == 0) out[(w > 0) ? (i / w) * ldo + (i % w) : i] = s;
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_2d_kernel(const float* __restrict__ slab, int nsplit,
+                                                              long long stride, long long count,
+                                                              float* __restrict__ out, int w, long long ldo) {
+  __shared__ float part[4][64];
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const long long i = blockIdx.x * 64LL + x;
+  float s = 0.f;
+  if (i < count)
+    for (int k = y; k < nsplit; k += 4) s += slab[k * stride + i];
+  part[y][x] = s;
+  __syncthreads();
+  if (y == 0 && i < count) out[(w > 0) ? (i / w) * ldo + (i % w) : i] = (part[0][x] + part[1][x]) + (part[2][x] + part[3][x]);
+}
+
 extern "C" int ws_reduce_slabs(const float* slab, int nsplit, long long stride, long long count,
                                float* out, int w, long long ldo, void* stream) {
   WS_REQUIRE(slab && out && nsplit > 0 && count > 0, "ws_reduce_slabs: bad args");
-  const int threads = 256;
-  long long blocks = (count + threads - 1) / threads;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(threads), 0,
-                     (hipStream_t)stream, slab, nsplit, stride, count, out, w, ldo);
+  hipStream_t s = (hipStream_t)stream;
+  if (count <= 8 && nsplit >= 64) {
+    hipLaunchKernelGGL(reduce_slabs_few_kernel, dim3((unsigned)count), dim3(256), 0, s, slab, nsplit, stride, out, w,
+                       ldo);
+  } else if (count <= 16384 && nsplit >= 16) {
+    hipLaunchKernelGGL(reduce_slabs_2d_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, s, slab, nsplit,
+                       stride, count, out, w, ldo);
+  } else {
+    const int threads = 256;
+    long long blocks = (count + threads - 1) / threads;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, slab, nsplit, stride, count,
+                       out, w, ldo);
+  }
   return ws_check_launch("ws_reduce_slabs");
 }
 

@@ -48,22 +48,39 @@ __global__ __launch_bounds__(256) void flat_stats_chunk_kernel(const float* __re
   }
 }
 
-__global__ void flat_stats_final_kernel(const float* __restrict__ scratch, int ngroups, int nchunk, float eps,
-                                        float* __restrict__ stats) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= ngroups) return;
+// one wave per group: lane l merges chunks l, l+64, ... serially, then the 64 partial triples are merged
+// by a shuffle butterfly (the pairwise merge is associative; the order is fixed, so results are reproducible)
+__device__ __forceinline__ void chan_merge(double& n, double& mean, double& m2, double nb, double mb, double qb) {
+  if (nb <= 0.0) return;
+  const double nt = n + nb, d = mb - mean;
+  mean += d * nb / nt;
+  m2 += qb + d * d * n * nb / nt;
+  n = nt;
+}
+
+__global__ __launch_bounds__(64) void flat_stats_final_kernel(const float* __restrict__ scratch, int ngroups,
+                                                              int nchunk, float eps, float* __restrict__ stats) {
+  const int g = blockIdx.x, lane = threadIdx.x;
   double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c = lane; c < nchunk; c += 64) {
     const float* s = scratch + ((long long)g * nchunk + c) * 4;
-    const double nb = s[0], mb = s[1], qb = s[2];
-    if (nb <= 0.0) continue;
-    const double nt = n + nb, d = mb - mean;
-    mean += d * nb / nt;
-    m2 += qb + d * d * n * nb / nt;
-    n = nt;
+    chan_merge(n, mean, m2, s[0], s[1], s[2]);
   }
-  stats[2 * g] = (float)mean;
-  stats[2 * g + 1] = 1.f / sqrtf((float)(m2 / n) + eps);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
+    // both partners must compute the same merged triple: merge (lower lane's, upper lane's) in that order
+    double an = n, am = mean, aq = m2, bn = nb, bm = mb, bq = qb;
+    if (lane & o) {
+      an = nb; am = mb; aq = qb; bn = n; bm = mean; bq = m2;
+    }
+    chan_merge(an, am, aq, bn, bm, bq);
+    n = an; mean = am; m2 = aq;
+  }
+  if (lane == 0) {
+    stats[2 * g] = (float)mean;
+    stats[2 * g + 1] = 1.f / sqrtf((float)(m2 / n) + eps);
+  }
 }
 
 extern "C" int ws_flat_stats(const float* x, int ngroups, long long n_per_group, float eps, int nchunk,
@@ -72,8 +89,8 @@ extern "C" int ws_flat_stats(const float* x, int ngroups, long long n_per_group,
              "ws_flat_stats: bad args (n_per_group %% 4)");
   hipLaunchKernelGGL(flat_stats_chunk_kernel, dim3(nchunk, ngroups), dim3(256), 0, (hipStream_t)stream, x,
                      n_per_group, nchunk, scratch);
-  hipLaunchKernelGGL(flat_stats_final_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, (hipStream_t)stream,
-                     scratch, ngroups, nchunk, eps, stats);
+  hipLaunchKernelGGL(flat_stats_final_kernel, dim3(ngroups), dim3(64), 0, (hipStream_t)stream, scratch, ngroups,
+                     nchunk, eps, stats);
   return ws_check_launch("ws_flat_stats");
 }
 

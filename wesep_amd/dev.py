@@ -514,7 +514,7 @@ def _call(name, *args):
 
 def flat_stats(x, ngroups: int, n_per_group: int, stats, eps=LN_EPS):
     """(mean, rstd) of contiguous groups, chunked over the chip."""
-    nchunk = max(1, min(256, n_per_group // 16384))
+    nchunk = max(1, min(max(1, 512 // ngroups), n_per_group // 16384))
     scratch = torch.empty(ngroups, nchunk, 4, device=x.device, dtype=torch.float32)
     for n, t in (("x", x), ("stats", stats)):
         _chk(t, n)
@@ -546,7 +546,7 @@ def dwconv_fwd(x, stats, gamma, beta, w, b, R: int, Tp: int, Cc: int, P: int, di
     _call("ws_dwconv_fwd", _p(x), _p(stats), _p(gamma), _p(beta), _p(w), _p(b), R, Tp, Cc, P, dil, st_div, _p(y))
 
 
-def row_splits(M: int, target=512):
+def row_splits(M: int, target=1024):
     nsplit = max(1, min(target, M // 64))
     rows = -(-M // nsplit)
     return -(-M // rows), rows

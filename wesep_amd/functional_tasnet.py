@@ -49,7 +49,11 @@ def _gemm(x, M, K, W, Nout, *, ldw=None, w_off=0, bias=None, act=0, R=None, T=No
 
 def _wgrad(G, M, Nn, A, Kk, *, g_ld=None, g_off=0, a_rows=None, norm=None, with_bias=True, vec=None, mode=None):
     """dW [Nn, Kk] = G^T pro(A), db [Nn] = colsum(G): split slabs + deterministic reduce."""
-    nsplit, rps = dev.tn_splits(M)
+    # enough (split x tile) workgroups to fill 256 CUs; a split keeps >= 256 rows
+    tiles = -(-Nn // 128) * -(-Kk // 128)
+    nsplit = max(1, min(64, M // 256, -(-512 // tiles)))
+    rps = -(-(-(-M // nsplit)) // 32) * 32
+    nsplit = -(-M // rps)
     d = G.device
     slab = _empty(d, nsplit, Nn * Kk)
     bslab = _empty(d, nsplit, Nn) if with_bias else None
