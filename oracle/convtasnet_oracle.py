@@ -2,7 +2,8 @@
 (BASELINE.json configs[0]).
 
 Functional re-statement (plain torch CPU ops, parameters passed as a dict keyed by the
-reference's `state_dict` names) of, in fixed-embedding mode (`joint_training=False`):
+reference's `state_dict` names) of, in fixed-embedding mode (`joint_training=False`) and in the SpEx+
+joint mode (`joint_training=True, spk_feat=False`, enrollment waveform through the shared encoder):
 
   * `wesep/models/convtasnet.py:162-219`           ConvTasNet.forward (Multi encoder / decoder)
   * `wesep/modules/tasnet/encoder.py:66-114`        MultiEncoder (three Conv1d + ReLU, cLN, 1x1 proj)
@@ -11,13 +12,15 @@ reference's `state_dict` names) of, in fixed-embedding mode (`joint_training=Fal
   * `wesep/modules/tasnet/separation.py:7-54,57-186` Separation / FuseSeparation (multi_fuse or not)
   * `wesep/modules/common/norm.py:7-76`             GlobalChannelLayerNorm (gLN), ChannelWiseLayerNorm (cLN)
   * `wesep/modules/tasnet/decoder.py:66-114`        MultiDecoder (3 x (1x1 mask, ReLU, multiply, ConvTranspose1d))
+  * `wesep/modules/tasnet/speaker.py:7-64`         ResBlock / ResNet4SpExplus (joint training on the shared
+    encoder, BatchNorm1d in training mode with running-statistics update) and the multi-task speaker head
   * the multi-scale SI-SDR objective of `spexplus.yaml:27-30` (loss_posi [0,1,2], weights .8/.1/.1),
     summed by `wesep/utils/executor.py:108-122`
 
 Pinning: fixtures produced by the REAL reference (`oracle/make_golden.py`, cases `convtasnet_*`),
 checked by `tests/test_oracle_golden.py`.  Out of this restatement (the product raises
 `NotImplementedError` for them): Deep / plain encoders, `skip_con=True`, causal blocks, `norm="BN"`,
-fusion types other than concatConv, joint training with `ResNet4SpExplus`.
+fusion types other than concatConv, joint training with a wespeaker model (`spk_feat=True`).
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module.
 """
@@ -46,6 +49,9 @@ class ConvTasNetConfig:
     norm: str = "gLN"
     multi_fuse: bool = True
     use_spk_transform: bool = False
+    joint_training: bool = False   # True: SpEx+ speaker encoder on the shared encoder (tasnet/speaker.py)
+    multi_task: bool = False       # True: speaker-classification head on the embedding (convtasnet.py:116-117)
+    spksInTrain: int = 251
 
     @property
     def stride(self):
@@ -79,6 +85,31 @@ def param_shapes(cfg: ConvTasNetConfig) -> Dict[str, tuple]:
     s["encoder.ln.bias"] = (3 * N,)
     s["encoder.proj.weight"] = (B, 3 * N, 1)
     s["encoder.proj.bias"] = (B,)
+    if cfg.joint_training:  # ResNet4SpExplus(in_channel=N), tasnet/speaker.py:49-64 (hard-wired to N = 256)
+        assert cfg.N == 256, "ResNet4SpExplus hard-codes 3*256 input channels (tasnet/speaker.py:55)"
+        q = "spk_model.aux_enc3."
+        s[q + "0.weight"] = (3 * N,)
+        s[q + "0.bias"] = (3 * N,)
+        s[q + "1.weight"] = (256, 3 * 256, 1)
+        s[q + "1.bias"] = (256,)
+        for i, (ci, co) in zip((2, 3, 4), ((256, 256), (256, 512), (512, 512))):
+            s[q + f"{i}.conv1.weight"] = (co, ci, 1)
+            s[q + f"{i}.conv2.weight"] = (co, co, 1)
+            for bn in ("batch_norm1", "batch_norm2"):
+                s[q + f"{i}.{bn}.weight"] = (co,)
+                s[q + f"{i}.{bn}.bias"] = (co,)
+                s[q + f"{i}.{bn}.running_mean"] = (co,)
+                s[q + f"{i}.{bn}.running_var"] = (co,)
+                s[q + f"{i}.{bn}.num_batches_tracked"] = ()
+            s[q + f"{i}.prelu1.weight"] = (1,)
+            s[q + f"{i}.prelu2.weight"] = (1,)
+            if ci != co:
+                s[q + f"{i}.conv_downsample.weight"] = (co, ci, 1)
+        s[q + "5.weight"] = (E, 512, 1)
+        s[q + "5.bias"] = (E,)
+        if cfg.multi_task:
+            s["pred_linear.weight"] = (cfg.spksInTrain, E)
+            s["pred_linear.bias"] = (cfg.spksInTrain,)
     if cfg.use_spk_transform:  # speaker.py:26-43
         s["spk_transform.transforms.0.weight"] = (128, E, 1)
         s["spk_transform.transforms.0.bias"] = (128,)
@@ -128,7 +159,15 @@ def synth_params(cfg: ConvTasNetConfig, seed: int) -> Dict[str, torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
     out = {}
     for k, shp in param_shapes(cfg).items():
-        if "norm" in k or ".ln." in k:
+        if k.endswith("running_mean"):
+            v = torch.zeros(shp)
+        elif k.endswith("running_var"):
+            v = torch.ones(shp)
+        elif k.endswith("num_batches_tracked"):
+            v = torch.zeros(shp, dtype=torch.long)
+        elif k.startswith("pred_linear") and k.endswith("weight"):
+            v = torch.randn(shp, generator=g) / shp[1] ** 0.5
+        elif "norm" in k or ".ln." in k or k.startswith("spk_model.aux_enc3.0."):
             v = (1.0 + 0.1 * torch.randn(shp, generator=g)) if k.endswith("weight") else 0.1 * torch.randn(shp, generator=g)
         elif "prelu" in k.lower():
             v = 0.25 + 0.05 * torch.randn(shp, generator=g)
@@ -200,16 +239,67 @@ def multi_decoder(p, cfg, e, ws) -> List[torch.Tensor]:
     return [outs[0], outs[1][:, :xlen], outs[2][:, :xlen]]
 
 
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1  # nn.BatchNorm1d defaults (tasnet/speaker.py:19-20)
+
+
+def is_buffer(name: str) -> bool:
+    return name.endswith(("running_mean", "running_var", "num_batches_tracked"))
+
+
+def _res_block(p, q, x, training, new_buffers):
+    """ResBlock (`tasnet/speaker.py:31-44`): conv1x1 - BN - PReLU - conv1x1 - BN - (+ residual) - PReLU - MaxPool1d(3)."""
+    def bn(name, y):
+        rm, rv = p[q + name + ".running_mean"].clone(), p[q + name + ".running_var"].clone()
+        out = F.batch_norm(y, rm, rv, p[q + name + ".weight"], p[q + name + ".bias"], training, BN_MOMENTUM, BN_EPS)
+        if new_buffers is not None and training:
+            new_buffers[q + name + ".running_mean"], new_buffers[q + name + ".running_var"] = rm, rv
+        return out
+    res = x
+    y = F.prelu(bn("batch_norm1", F.conv1d(x, p[q + "conv1.weight"])), p[q + "prelu1.weight"])
+    y = bn("batch_norm2", F.conv1d(y, p[q + "conv2.weight"]))
+    if (q + "conv_downsample.weight") in p:
+        res = F.conv1d(res, p[q + "conv_downsample.weight"])
+    return F.max_pool1d(F.prelu(y + res, p[q + "prelu2.weight"]), 3)
+
+
+def spk_encoder(p, cfg, aux_cat, training=True, new_buffers=None):
+    """ResNet4SpExplus (`tasnet/speaker.py:49-64`) on the shared encoder's [w1 | w2 | w3] of the enrollment
+    (`convtasnet.py:179-187`): [R, 3N, Te'] -> [R, E]."""
+    q = "spk_model.aux_enc3."
+    y = F.layer_norm(aux_cat.transpose(1, 2), (aux_cat.shape[1],), p[q + "0.weight"], p[q + "0.bias"],
+                     LN_EPS).transpose(1, 2)
+    y = F.conv1d(y, p[q + "1.weight"], p[q + "1.bias"])
+    for i in (2, 3, 4):
+        y = _res_block(p, q + f"{i}.", y, training, new_buffers)
+    y = F.conv1d(y, p[q + "5.weight"], p[q + "5.bias"])
+    return y.mean(-1)
+
+
 def convtasnet_forward(p: Dict[str, torch.Tensor], cfg: ConvTasNetConfig, wav: torch.Tensor,
-                       emb: torch.Tensor) -> List[torch.Tensor]:
-    """`convtasnet.py:162-219`, joint_training=False: wav [R, T], emb [R, E] -> [est1, est2, est3]."""
+                       emb: torch.Tensor, training=True, new_buffers=None) -> List[torch.Tensor]:
+    """`convtasnet.py:162-219`: wav [R, T]; emb [R, E] (fixed embeddings) or, with joint_training, the
+    enrollment waveform [R, Tw] -> [est1, est2, est3] (+ [speaker logits] with multi_task)."""
     e, w1, w2, w3 = multi_encoder(p, cfg, wav)
+    logits = None
+    if cfg.joint_training:
+        _, a1, a2, a3 = multi_encoder(p, cfg, emb)
+        emb = spk_encoder(p, cfg, torch.cat([a1, a2, a3], 1), training, new_buffers)
+        if cfg.multi_task:
+            logits = F.linear(emb, p["pred_linear.weight"], p["pred_linear.bias"])
     if cfg.use_spk_transform:  # Conv1d(k=1) chain: the [R, E] form is the same map (speaker.py:45-49)
         emb = spk_transform(p, emb)
     aux = emb.unsqueeze(-1)
     for kind, pre, dil in _block_names(cfg):
         e = conv_block(p, cfg, kind, pre, dil, e, aux)
-    return multi_decoder(p, cfg, e, (w1, w2, w3))
+    outs = multi_decoder(p, cfg, e, (w1, w2, w3))
+    if logits is not None:
+        outs.append(logits)
+    return outs
+
+
+def spexplus_loss(outs: List[torch.Tensor], target: torch.Tensor, spk_label: torch.Tensor):
+    """`spexplus.yaml:27-30` through `executor.py:108-122`: .8/.1/.1 SI-SDR + 0.5 CrossEntropy(logits, label)."""
+    return multiscale_sisdr_loss(outs[:3], target) + 0.5 * F.cross_entropy(outs[3], spk_label)
 
 
 def multiscale_sisdr_loss(ests: List[torch.Tensor], target: torch.Tensor, weights=(0.8, 0.1, 0.1)):
@@ -219,3 +309,9 @@ def multiscale_sisdr_loss(ests: List[torch.Tensor], target: torch.Tensor, weight
         n = min(est.shape[-1], target.shape[-1])
         loss = loss + w * sisdr_loss(est[:, :n], target[:, :n])
     return loss
+
+
+def synth_enrollment(R: int, Tw: int, nspk: int, seed: int):
+    """Enrollment waveforms [R, Tw] and speaker labels [R] for the joint mode (deterministic)."""
+    g = torch.Generator().manual_seed(seed + 1000)
+    return 0.1 * torch.randn(R, Tw, generator=g), torch.randint(0, nspk, (R,), generator=g)

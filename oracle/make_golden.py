@@ -85,7 +85,12 @@ TASNET_CASES = {
     "convtasnet_cln_xform_r4_t2000": (dict(N=16, L=20, B=24, H=40, P=3, X=2, R=1, norm="cLN",
                                            use_spk_transform=True), 4, 2000, 22),
     "convtasnet_gln_l16_r2_t1200": (dict(N=24, L=16, B=16, H=32, P=3, X=4, R=1), 2, 1200, 23),
+    # SpEx+ joint mode: enrollment waveform through the shared encoder + ResNet4SpExplus (N must be 256),
+    # multi-task speaker head; loss = .8/.1/.1 SI-SDR + .5 CE; BatchNorm running statistics are pinned too
+    "spexplus_joint_r4_t1600": (dict(N=256, L=20, B=32, H=48, P=3, X=2, R=2, joint_training=True,
+                                     multi_task=True, spksInTrain=11), 4, 1600, 24),
 }
+ENROLL_LEN = 2400
 
 
 def run_tasnet_case(name, kw, R, T, seed):
@@ -96,7 +101,8 @@ def run_tasnet_case(name, kw, R, T, seed):
         N=cfg.N, L=cfg.L, B=cfg.B, H=cfg.H, P=cfg.P, X=cfg.X, R=cfg.R, spk_emb_dim=cfg.spk_emb_dim,
         norm=cfg.norm, activate="relu", causal=False, skip_con=False, spk_fuse_type="concatConv",
         multi_fuse=cfg.multi_fuse, use_spk_transform=cfg.use_spk_transform, encoder_type="Multi",
-        decoder_type="Multi", joint_training=False)
+        decoder_type="Multi", joint_training=cfg.joint_training, multi_task=cfg.multi_task,
+        spksInTrain=cfg.spksInTrain, spk_feat=False, feat_type="consistent")
     params = CT.synth_params(cfg, seed)
     ref_sd = ref.state_dict()
     assert list(ref_sd.keys()) == list(params.keys()), "oracle param_shapes() order != reference state_dict"
@@ -105,16 +111,25 @@ def run_tasnet_case(name, kw, R, T, seed):
     ref.load_state_dict(params, strict=True)
     ref.train()
     wav, tgt, emb = O.synth_batch(R, T, seed)
+    label = None
+    if cfg.joint_training:
+        emb, label = CT.synth_enrollment(R, ENROLL_LEN, cfg.spksInTrain, seed)
     ests = ref(wav, emb)
-    assert all(e.shape == tgt.shape for e in ests), [tuple(e.shape) for e in ests]
-    loss = CT.multiscale_sisdr_loss(ests, tgt)
+    assert all(e.shape == tgt.shape for e in ests[:3]), [tuple(e.shape) for e in ests]
+    loss = CT.spexplus_loss(ests, tgt, label) if cfg.multi_task else CT.multiscale_sisdr_loss(ests, tgt)
     loss.backward()
     out = {
         "wav": wav.numpy(), "tgt": tgt.numpy(), "emb": emb.numpy(), "loss": np.float64(loss.item()),
         "param_checksum": np.float64(sum(float(v.double().abs().sum()) for v in params.values())),
     }
-    for i, e in enumerate(ests):
+    for i, e in enumerate(ests[:3]):
         out[f"est{i + 1}"] = e.detach().numpy()
+    if cfg.multi_task:
+        out["logits"] = ests[3].detach().numpy()
+        out["label"] = label.numpy()
+    for k, v in ref.state_dict().items():          # BatchNorm running statistics after this one training step
+        if k.endswith(("running_mean", "running_var")):
+            out["buf/" + k] = v.numpy().copy()
     names = []
     for k, prm in ref.named_parameters():
         g = prm.grad.detach().reshape(-1)
