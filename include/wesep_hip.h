@@ -385,6 +385,28 @@ int ws_ola_bwd(const float* dest, int R, int Tp, int L, int hop, int Tout, float
 /* slab[i < nslab] = partial sums of x[0..n)                                                          */
 int ws_sum_partial(const float* x, long long n, float* slab, int nslab, void* stream);
 
+/* ---- SpEx+ speaker encoder (wesep/modules/tasnet/speaker.py:7-64), channels-last [M][C] ------------------
+ * nn.BatchNorm1d in training mode: stats [2][C] = (batch mean, 1/sqrt(biased var + eps)), two passes;
+ * running_mean / running_var (both or neither) are updated with `momentum` (unbiased variance tracked).
+ * scratch: nsplit * C floats.                                                                          */
+int ws_bn_stats(const float* x, long long M, int C, float eps, float momentum, float* running_mean,
+                float* running_var, int nsplit, float* scratch, float* stats, void* stream);
+/* u = gamma * (x - mean_c) * rstd_c + beta (+ res);  y = PReLU(u, a[0])                                  */
+int ws_bn_prelu_fwd(const float* x, const float* stats, const float* gamma, const float* beta,
+                    const float* res, const float* a, long long M, int C, float* u, float* y, void* stream);
+/* BatchNorm backward from du: sums [2][C] = (sum du, sum du * xhat) = (dbeta, dgamma);
+ * dx = gamma * rstd * (du - sums0/M - xhat * sums1/M) (dx may alias du); slab: nsplit * 2 * C floats     */
+int ws_bn_bwd(const float* x, const float* du, const float* stats, const float* gamma, long long M, int C,
+              int nsplit, float* slab, float* sums, float* dx, void* stream);
+/* nn.MaxPool1d(3) over time on [R][T][C] -> [R][T/3][C]; backward to the first maximal position        */
+int ws_maxpool3_fwd(const float* x, int R, int T, int C, float* y, void* stream);
+int ws_maxpool3_bwd(const float* x, const float* dy, int R, int T, int C, float* dx, void* stream);
+/* out[m][c] = scale * src[m / rows_per_r][c]                                                            */
+int ws_bcast_rows(const float* src, float scale, int rows_per_r, long long M, int C, float* out, void* stream);
+/* nn.CrossEntropyLoss (mean) on [R][S] logits, int64 labels: loss[0] and dlogits = d loss / d logits     */
+int ws_cross_entropy(const float* logits, const long long* label, int R, int S, float* loss, float* dlogits,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

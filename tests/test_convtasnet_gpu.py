@@ -208,7 +208,7 @@ def test_model_matches_oracle_and_reference_fixture(name, golden_dir):
 def test_unbuilt_variants_fail_loudly():
     from wesep_amd.models import get_model
     cls = get_model("ConvTasNet")
-    for kw in (dict(joint_training=True), dict(joint_training=False, encoder_type="Deep"),
+    for kw in (dict(joint_training=True, spk_feat=True), dict(joint_training=False, encoder_type="Deep"),
                dict(joint_training=False, skip_con=True), dict(joint_training=False, norm="BN"),
                dict(joint_training=False, spk_fuse_type="FiLM"), dict(joint_training=False, causal=True)):
         with pytest.raises(NotImplementedError):
@@ -233,3 +233,147 @@ def test_full_size_forward_matches_oracle():
     for e, r in zip(ests, ref):
         assert e.shape == r.shape == wav.shape
         assert rel(e, r) < WAV_TOL
+
+
+def test_speaker_encoder_kernels():
+    """BatchNorm1d (training) + PReLU, MaxPool1d(3), cross entropy against torch."""
+    from wesep_amd import dev
+    d = _cuda()
+    torch.manual_seed(5)
+    R, T, Cc = 3, 50, 24
+    M = R * T
+    x = torch.randn(M, Cc, device=d) * 2 + 1
+    gamma, beta = torch.rand(Cc, device=d) + 0.5, torch.randn(Cc, device=d) * 0.1
+    res = torch.randn(M, Cc, device=d)
+    a = torch.tensor([0.3], device=d)
+    rm, rv = torch.zeros(Cc, device=d), torch.ones(Cc, device=d)
+    st = torch.empty(2, Cc, device=d)
+    dev.bn_stats(x, M, Cc, rm, rv, st)
+    u, y = torch.empty_like(x), torch.empty_like(x)
+    dev.bn_prelu_fwd(x, st, gamma, beta, res, a, M, Cc, u, y)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm2, rv2 = torch.zeros(Cc, device=d), torch.ones(Cc, device=d)
+    ur = F.batch_norm(xr, rm2, rv2, gr, br, True, 0.1, 1e-5) + res
+    yr = F.prelu(ur, a)
+    assert rel(u, ur) < 1e-5 and rel(y, yr) < 1e-5
+    assert torch.allclose(rm, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-5, atol=1e-6)
+    du = torch.randn(M, Cc, device=d)
+    ur.backward(du)
+    dx = torch.empty_like(x)
+    sums = dev.bn_bwd(x, du, st, gamma, M, Cc, dx)
+    assert rel(dx, xr.grad) < 1e-4
+    assert rel(sums[0], br.grad) < 1e-4 and rel(sums[1], gr.grad) < 1e-4
+    # max pool
+    z = torch.randn(R, T, Cc, device=d)
+    z[0, 3:6, :4] = 1.5                                        # ties: the first position wins
+    zr = z.permute(0, 2, 1).contiguous().requires_grad_(True)
+    pr = F.max_pool1d(zr, 3)
+    p = torch.empty(R * (T // 3), Cc, device=d)
+    dev.maxpool3_fwd(z.view(M, Cc), R, T, Cc, p)
+    assert torch.equal(p.view(R, T // 3, Cc).permute(0, 2, 1), pr)
+    dp = torch.randn(R * (T // 3), Cc, device=d)
+    pr.backward(dp.view(R, T // 3, Cc).permute(0, 2, 1))
+    dz = torch.empty(M, Cc, device=d)
+    dev.maxpool3_bwd(z.view(M, Cc), dp, R, T, Cc, dz)
+    assert torch.equal(dz.view(R, T, Cc).permute(0, 2, 1), zr.grad)
+    # cross entropy
+    from wesep_amd.utils.losses import parse_loss
+    logits = torch.randn(5, 37, device=d, requires_grad=True)
+    label = torch.randint(0, 37, (5,), device=d)
+    loss = parse_loss("CE")[0](logits, label)
+    (2.0 * loss).backward()
+    lr = logits.detach().clone().requires_grad_(True)
+    ref = F.cross_entropy(lr, label)
+    (2.0 * ref).backward()
+    assert abs(loss.item() - ref.item()) < 1e-5
+    assert rel(logits.grad, lr.grad) < 1e-5
+
+
+def _joint_setup(d):
+    from oracle import bsrnn_oracle as O
+    from oracle import convtasnet_oracle as CT
+    from oracle.make_golden import ENROLL_LEN, TASNET_CASES
+    from wesep_amd.models import get_model
+    name = "spexplus_joint_r4_t1600"
+    kw, R, T, seed = TASNET_CASES[name]
+    cfg = CT.ConvTasNetConfig(**kw)
+    params = CT.synth_params(cfg, seed)
+    model = get_model("ConvTasNet")(**kw, use_spk_transform=False)
+    model.load_state_dict(params, strict=True)
+    wav, tgt, _ = O.synth_batch(R, T, seed)
+    enroll, label = CT.synth_enrollment(R, ENROLL_LEN, cfg.spksInTrain, seed)
+    return name, cfg, params, model.to(d).train(), wav, tgt, enroll, label
+
+
+def _check_grads(model, p, tol, CT, floor_rel=1e-5):
+    gn = {k: float(v.grad.norm()) for k, v in p.items() if not CT.is_buffer(k)}
+    floor = floor_rel * max(gn.values())
+    bad = []
+    for k, prm in model.named_parameters():
+        assert prm.grad is not None, k
+        err = float((prm.grad.detach().cpu().double() - p[k].grad.double()).norm())
+        if err > tol * gn[k] + floor:
+            bad.append((k, err / (gn[k] + 1e-30), gn[k]))
+    assert not bad, sorted(bad, key=lambda t: -t[1])[:12]
+    return floor
+
+
+def test_spexplus_joint_forward_and_backward_kernels():
+    """SpEx+ joint mode (enrollment through the shared encoder + ResNet4SpExplus, multi-task head), default
+    split-bf16 products: forward against the reference fixture (waveforms, logits, loss, BatchNorm running
+    statistics after the step), backward against the oracle's autograd under a WELL-CONDITIONED objective --
+    a fixed random linear functional of the four outputs.  (The SI-SDR gradient itself is hypersensitive at
+    random initialisation: est and target are uncorrelated, <est, target> is a near-total cancellation, and a
+    1e-4 perturbation of est moves alpha -- and with it some gradients -- by percents.  That objective is
+    checked with the exact-fp32 kernels in the next test.)"""
+    from oracle import convtasnet_oracle as CT
+    from wesep_amd.utils.losses import parse_loss
+    d = _cuda()
+    name, cfg, params, model, wav, tgt, enroll, label = _joint_setup(d)
+    outs = model(wav.to(d), enroll.to(d))
+    assert len(outs) == 4
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    for i in range(3):
+        assert rel(outs[i], torch.from_numpy(g[f"est{i + 1}"])) < WAV_TOL, i
+    assert rel(outs[3], torch.from_numpy(g["logits"])) < WAV_TOL
+    sisdr, ce = parse_loss(["SISDR", "CE"])
+    loss = sum(w * sisdr(e, tgt.to(d)) for w, e in zip((0.8, 0.1, 0.1), outs[:3])) + 0.5 * ce(outs[3], label.to(d))
+    assert abs(loss.item() - float(g["loss"])) < DB_TOL
+    sd = model.state_dict()
+    nbuf = 0
+    for k in g.files:                                   # BatchNorm running statistics after the step
+        if k.startswith("buf/"):
+            assert torch.allclose(sd[k[4:]].cpu(), torch.from_numpy(g[k]), rtol=1e-3, atol=1e-5), k
+            nbuf += 1
+    assert nbuf == 12 and int(sd["spk_model.aux_enc3.2.batch_norm1.num_batches_tracked"]) == 1
+    gen = torch.Generator().manual_seed(7)
+    probes = [torch.randn(o.shape, generator=gen) for o in outs]
+    sum((o * q.to(d)).sum() for o, q in zip(outs, probes)).backward()
+    p = {k: (v.clone() if CT.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in params.items()}
+    sum((o * q).sum() for o, q in zip(CT.convtasnet_forward(p, cfg, wav, enroll), probes)).backward()
+    # 1e-2 with a floor of 1e-3 of the largest gradient: ReLU / PReLU / MaxPool kinks (a 1e-4 perturbation flips
+    # the side of entries near zero: measured 7.6e-3 on decoder.mask2) and scalar PReLU-slope gradients that are
+    # near-total cancellations; kernel bugs show up as O(1) errors, and the next test holds 3e-3 with exact products
+    _check_grads(model, p, 1e-2, CT, floor_rel=1e-3)
+
+
+def test_spexplus_joint_training_loss_gradients_fp32(monkeypatch):
+    """Same model, the training objective of spexplus.yaml (.8/.1/.1 SI-SDR + .5 CE), exact-fp32 products:
+    every parameter gradient against the oracle and against the reference fixture's gradient norms."""
+    from oracle import convtasnet_oracle as CT
+    from wesep_amd.utils.losses import parse_loss
+    monkeypatch.setenv("WESEP_GEMM", "f32")
+    d = _cuda()
+    name, cfg, params, model, wav, tgt, enroll, label = _joint_setup(d)
+    outs = model(wav.to(d), enroll.to(d))
+    sisdr, ce = parse_loss(["SISDR", "CE"])
+    loss = sum(w * sisdr(e, tgt.to(d)) for w, e in zip((0.8, 0.1, 0.1), outs[:3])) + 0.5 * ce(outs[3], label.to(d))
+    loss.backward()
+    p = {k: (v.clone() if CT.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in params.items()}
+    CT.spexplus_loss(CT.convtasnet_forward(p, cfg, wav, enroll), tgt, label).backward()
+    floor = _check_grads(model, p, 3e-3, CT)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    assert abs(loss.item() - float(g["loss"])) < DB_TOL
+    for k, prm in model.named_parameters():
+        assert abs(float(prm.grad.norm()) - float(g["gnorm/" + k])) <= 3e-3 * float(g["gnorm/" + k]) + floor, k

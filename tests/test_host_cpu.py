@@ -213,5 +213,12 @@ def test_convtasnet_state_dict_keys_match_reference():
         sd = model.state_dict()
         assert list(sd.keys()) == list(shapes.keys())
         assert all(tuple(sd[k].shape) == shapes[k] for k in sd)
+    # SpEx+ joint mode (reference default joint_training=True, spk_feat=False): shared encoder + ResNet4SpExplus
+    kw = dict(N=256, L=20, B=32, H=48, P=3, X=2, R=2, joint_training=True, multi_task=True, spksInTrain=11)
+    model = get_model("ConvTasNet")(**kw, use_spk_transform=False)
+    shapes = CT.param_shapes(CT.ConvTasNetConfig(**kw))
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == shapes[k] for k in sd)
     with pytest.raises(NotImplementedError):
-        get_model("ConvTasNet")()                 # joint_training=True is the reference default: not built
+        get_model("ConvTasNet")(spk_feat=True)    # wespeaker encoder on fbank features: SURVEY 8 row a12

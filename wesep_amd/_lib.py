@@ -141,6 +141,13 @@ _SIGS = {
     "ws_ola_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "ws_ola_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "ws_sum_partial": (_i, [_p, _ll, _p, _i, _p]),
+    "ws_bn_stats": (_i, [_p, _ll, _i, C.c_float, C.c_float, _p, _p, _i, _p, _p, _p]),
+    "ws_bn_prelu_fwd": (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _p, _p, _p]),
+    "ws_bn_bwd": (_i, [_p, _p, _p, _p, _ll, _i, _i, _p, _p, _p, _p]),
+    "ws_maxpool3_fwd": (_i, [_p, _i, _i, _i, _p, _p]),
+    "ws_maxpool3_bwd": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "ws_bcast_rows": (_i, [_p, C.c_float, _i, _ll, _i, _p, _p]),
+    "ws_cross_entropy": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "ws_grad_norms": (_i, [_p, _i, _p, _p]),
     "ws_clip_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p]),
 }

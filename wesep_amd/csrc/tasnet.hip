@@ -540,3 +540,266 @@ extern "C" int ws_sum_partial(const float* x, long long n, float* slab, int nsla
   hipLaunchKernelGGL(sum_partial_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)stream, x, n, slab);
   return ws_check_launch("ws_sum_partial");
 }
+
+// =============================================================================================
+// SpEx+ speaker encoder pieces (wesep/modules/tasnet/speaker.py:7-64), channels-last [M][C]
+// =============================================================================================
+
+// slab[split][c] = sum over the split's rows of (shift ? (x - shift[c])^2 : x)
+__global__ void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ shift, long long M, int C,
+                                  int rows_per_split, float* __restrict__ slab) {
+  const int c = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
+  if (c >= C) return;
+  const long long lo = (long long)blockIdx.x * rows_per_split, hi = min(M, lo + rows_per_split);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (shift) {
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+    for (long long r = lo; r < hi; ++r) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(x + r * C + c) - sh;
+      s += d * d;
+    }
+  } else {
+    for (long long r = lo; r < hi; ++r) s += *reinterpret_cast<const f32x4*>(x + r * C + c);
+  }
+  *reinterpret_cast<f32x4*>(slab + (long long)blockIdx.x * C + c) = s;
+}
+
+// phase 0: stats[0][c] = mean.  phase 1: stats[1][c] = 1/sqrt(var + eps) and the running statistics
+// (nn.BatchNorm1d training mode: biased variance normalises, unbiased variance is tracked)
+__global__ void bn_final_kernel(const float* __restrict__ slab, int nsplit, int C, long long M, int phase, float eps,
+                                float momentum, float* __restrict__ stats, float* running_mean,
+                                float* running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += slab[(long long)k * C + c];
+  if (phase == 0) {
+    stats[c] = s / (float)M;
+  } else {
+    const float var = s / (float)M;
+    stats[C + c] = 1.f / sqrtf(var + eps);
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * stats[c];
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (M > 1 ? s / (float)(M - 1) : var);
+    }
+  }
+}
+
+extern "C" int ws_bn_stats(const float* x, long long M, int C, float eps, float momentum, float* running_mean,
+                           float* running_var, int nsplit, float* scratch, float* stats, void* stream) {
+  WS_REQUIRE(x && scratch && stats && M > 0 && C > 0 && C % 4 == 0 && nsplit > 0 && (!running_mean == !running_var),
+             "ws_bn_stats: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const int rps = (int)((M + nsplit - 1) / nsplit);
+  const int threads = C / 4 >= 256 ? 256 : ((C / 4 + 63) / 64) * 64;
+  const dim3 grid(nsplit, (C / 4 + threads - 1) / threads);
+  hipLaunchKernelGGL(bn_partial_kernel, grid, dim3(threads), 0, s, x, (const float*)nullptr, M, C, rps, scratch);
+  hipLaunchKernelGGL(bn_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, nsplit, C, M, 0, eps, momentum,
+                     stats, running_mean, running_var);
+  hipLaunchKernelGGL(bn_partial_kernel, grid, dim3(threads), 0, s, x, (const float*)stats, M, C, rps, scratch);
+  hipLaunchKernelGGL(bn_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, nsplit, C, M, 1, eps, momentum,
+                     stats, running_mean, running_var);
+  return ws_check_launch("ws_bn_stats");
+}
+
+// u = gamma * (x - mean_c) * rstd_c + beta (+ res);  y = u > 0 ? u : a * u      (stats = [mean | rstd], [2][C])
+__global__ void bn_prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ res, const float* __restrict__ a, long long M, int C,
+                                    float* __restrict__ u, float* __restrict__ y) {
+  const float slope = a[0];
+  const int c4n = C >> 2;
+  const long long total = M * c4n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    f32x4 v = (*reinterpret_cast<const f32x4*>(x + i * 4) - *reinterpret_cast<const f32x4*>(stats + c)) *
+                  *reinterpret_cast<const f32x4*>(stats + C + c) * *reinterpret_cast<const f32x4*>(gamma + c) +
+              *reinterpret_cast<const f32x4*>(beta + c);
+    if (res) v += *reinterpret_cast<const f32x4*>(res + i * 4);
+    *reinterpret_cast<f32x4*>(u + i * 4) = v;
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = v[j] > 0.f ? v[j] : slope * v[j];
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+  }
+}
+
+extern "C" int ws_bn_prelu_fwd(const float* x, const float* stats, const float* gamma, const float* beta,
+                               const float* res, const float* a, long long M, int C, float* u, float* y,
+                               void* stream) {
+  WS_REQUIRE(x && stats && gamma && beta && a && u && y && M > 0 && C > 0 && C % 4 == 0, "ws_bn_prelu_fwd: bad args");
+  hipLaunchKernelGGL(bn_prelu_fwd_kernel, dim3(ew_blocks(M * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     stats, gamma, beta, res, a, M, C, u, y);
+  return ws_check_launch("ws_bn_prelu_fwd");
+}
+
+// slab[split][0][c] = sum du, slab[split][1][c] = sum du * xhat,  xhat = (x - mean_c) * rstd_c
+__global__ void bn_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ du,
+                                   const float* __restrict__ stats, long long M, int C, int rows_per_split,
+                                   float* __restrict__ slab) {
+  const int c = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
+  if (c >= C) return;
+  const long long lo = (long long)blockIdx.x * rows_per_split, hi = min(M, lo + rows_per_split);
+  const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + c), rstd = *reinterpret_cast<const f32x4*>(stats + C + c);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  for (long long r = lo; r < hi; ++r) {
+    const f32x4 d = *reinterpret_cast<const f32x4*>(du + r * C + c);
+    s0 += d;
+    s1 += d * ((*reinterpret_cast<const f32x4*>(x + r * C + c) - mean) * rstd);
+  }
+  float* o = slab + (long long)blockIdx.x * 2 * C;
+  *reinterpret_cast<f32x4*>(o + c) = s0;
+  *reinterpret_cast<f32x4*>(o + C + c) = s1;
+}
+
+// dx = gamma * rstd * (du - sums[0]/M - xhat * sums[1]/M)     (dx may alias du)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* du, const float* __restrict__ stats,
+                                    const float* __restrict__ gamma, const float* __restrict__ sums, long long M,
+                                    int C, float* dx) {
+  const int c4n = C >> 2;
+  const long long total = M * c4n;
+  const float inv = 1.f / (float)M;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const f32x4 rstd = *reinterpret_cast<const f32x4*>(stats + C + c);
+    const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + i * 4) - *reinterpret_cast<const f32x4*>(stats + c)) * rstd;
+    const f32x4 r = *reinterpret_cast<const f32x4*>(gamma + c) * rstd *
+                    (*reinterpret_cast<const f32x4*>(du + i * 4) - *reinterpret_cast<const f32x4*>(sums + c) * inv -
+                     xh * (*reinterpret_cast<const f32x4*>(sums + C + c) * inv));
+    *reinterpret_cast<f32x4*>(dx + i * 4) = r;
+  }
+}
+
+extern "C" int ws_bn_bwd(const float* x, const float* du, const float* stats, const float* gamma, long long M, int C,
+                         int nsplit, float* slab, float* sums, float* dx, void* stream) {
+  WS_REQUIRE(x && du && stats && gamma && slab && sums && dx && M > 0 && C > 0 && C % 4 == 0 && nsplit > 0,
+             "ws_bn_bwd: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const int rps = (int)((M + nsplit - 1) / nsplit);
+  const int threads = C / 4 >= 256 ? 256 : ((C / 4 + 63) / 64) * 64;
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(nsplit, (C / 4 + threads - 1) / threads), dim3(threads), 0, s, x, du,
+                     stats, M, C, rps, slab);
+  int rc = ws_reduce_slabs(slab, nsplit, 2LL * C, 2LL * C, sums, 0, 0, stream);
+  if (rc != WS_OK) return rc;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * (C / 4), 256)), dim3(256), 0, s, x, du, stats, gamma,
+                     sums, M, C, dx);
+  return ws_check_launch("ws_bn_bwd");
+}
+
+// MaxPool1d(3) over time (stride 3, floor): y[r][t'][c] = max_j x[r][3t'+j][c];  backward routes the gradient
+// to the first maximal position (torch's tie rule), zero elsewhere and on the dropped tail rows.
+__global__ void maxpool3_fwd_kernel(const float* __restrict__ x, int R, int T, int C, float* __restrict__ y) {
+  const int To = T / 3, c4n = C >> 2;
+  const long long total = (long long)R * To * c4n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / c4n;
+    const int c = (int)(i - row * c4n) * 4;
+    const int r = (int)(row / To), t = (int)(row - (long long)r * To);
+    const float* b = x + ((long long)r * T + 3 * t) * C + c;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(b), v1 = *reinterpret_cast<const f32x4*>(b + C),
+                v2 = *reinterpret_cast<const f32x4*>(b + 2 * C);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaxf(v0[j], v1[j]), v2[j]);
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+  }
+}
+
+__global__ void maxpool3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int R, int T, int C,
+                                    float* __restrict__ dx) {
+  const int To = T / 3, c4n = C >> 2;
+  const long long total = (long long)R * T * c4n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / c4n;
+    const int c = (int)(i - row * c4n) * 4;
+    const int r = (int)(row / T), t = (int)(row - (long long)r * T);
+    const int to = t / 3, j = t - 3 * to;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (to < To) {
+      const float* b = x + ((long long)r * T + 3 * to) * C + c;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(b), v1 = *reinterpret_cast<const f32x4*>(b + C),
+                  v2 = *reinterpret_cast<const f32x4*>(b + 2 * C);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + ((long long)r * To + to) * C + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int arg = (v0[k] >= v1[k] && v0[k] >= v2[k]) ? 0 : (v1[k] >= v2[k] ? 1 : 2);
+        o[k] = arg == j ? g[k] : 0.f;
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+  }
+}
+
+extern "C" int ws_maxpool3_fwd(const float* x, int R, int T, int C, float* y, void* stream) {
+  WS_REQUIRE(x && y && R > 0 && T >= 3 && C > 0 && C % 4 == 0, "ws_maxpool3_fwd: bad args (T >= 3, C %% 4)");
+  hipLaunchKernelGGL(maxpool3_fwd_kernel, dim3(ew_blocks((long long)R * (T / 3) * (C / 4), 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, R, T, C, y);
+  return ws_check_launch("ws_maxpool3_fwd");
+}
+
+extern "C" int ws_maxpool3_bwd(const float* x, const float* dy, int R, int T, int C, float* dx, void* stream) {
+  WS_REQUIRE(x && dy && dx && R > 0 && T >= 3 && C > 0 && C % 4 == 0, "ws_maxpool3_bwd: bad args");
+  hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(ew_blocks((long long)R * T * (C / 4), 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, dy, R, T, C, dx);
+  return ws_check_launch("ws_maxpool3_bwd");
+}
+
+// out[m][c] = scale * src[m / rows_per_r][c]   (adjoint of the mean over time, speaker.py:62-63)
+__global__ void bcast_rows_kernel(const float* __restrict__ src, float scale, int rows_per_r, long long M, int C,
+                                  float* __restrict__ out) {
+  const int c4n = C >> 2;
+  const long long total = M * c4n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / c4n;
+    const int c = (int)(i - row * c4n) * 4;
+    *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(src + (row / rows_per_r) * C + c) * scale;
+  }
+}
+
+extern "C" int ws_bcast_rows(const float* src, float scale, int rows_per_r, long long M, int C, float* out,
+                             void* stream) {
+  WS_REQUIRE(src && out && rows_per_r > 0 && M > 0 && C > 0 && C % 4 == 0, "ws_bcast_rows: bad args");
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3(ew_blocks(M * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     scale, rows_per_r, M, C, out);
+  return ws_check_launch("ws_bcast_rows");
+}
+
+// nn.CrossEntropyLoss (mean reduction) on [R][S] logits with int64 labels (losses.py:11, executor.py:112-118):
+// loss = mean_r (logsumexp_r - logit_r[label_r]);  dlogits = (softmax - onehot) / R.  One workgroup.
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
+                                                 int R, int S, float* __restrict__ loss, float* __restrict__ dlogits) {
+  __shared__ float red[16];
+  float total = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const float* z = logits + (long long)r * S;
+    float mx = -3.4e38f;
+    for (int j = threadIdx.x; j < S; j += 256) mx = fmaxf(mx, z[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float se = 0.f;
+    for (int j = threadIdx.x; j < S; j += 256) se += expf(z[j] - mx);
+    se = ws_block_sum(se, red);
+    const int lb = (int)label[r];
+    const float lse = mx + logf(se);
+    total += lse - z[lb];
+    for (int j = threadIdx.x; j < S; j += 256)
+      dlogits[(long long)r * S + j] = (expf(z[j] - lse) - (j == lb ? 1.f : 0.f)) / (float)R;
+  }
+  if (threadIdx.x == 0) loss[0] = total / (float)R;
+}
+
+extern "C" int ws_cross_entropy(const float* logits, const long long* label, int R, int S, float* loss,
+                                float* dlogits, void* stream) {
+  WS_REQUIRE(logits && label && loss && dlogits && R > 0 && S > 0, "ws_cross_entropy: bad args");
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, label, R, S, loss, dlogits);
+  return ws_check_launch("ws_cross_entropy");
+}

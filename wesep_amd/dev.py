@@ -629,3 +629,64 @@ def total_sum(x):
     out = torch.empty(1, device=x.device, dtype=torch.float32)
     reduce_slabs(slab, nslab, 1, 1, out)
     return out
+
+
+# ---- SpEx+ speaker encoder pieces -------------------------------------------------------------------
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1  # nn.BatchNorm1d defaults
+
+
+def _bn_splits(M: int):
+    return max(1, min(256, M // 32))
+
+
+def bn_stats(x, M: int, Cc: int, running_mean, running_var, stats, eps=BN_EPS, momentum=BN_MOMENTUM):
+    for n, t in (("x", x), ("running_mean", running_mean), ("running_var", running_var), ("stats", stats)):
+        _chk(t, n)
+    ns = _bn_splits(M)
+    scratch = torch.empty(ns, Cc, device=x.device, dtype=torch.float32)
+    _call("ws_bn_stats", _p(x), M, Cc, eps, momentum, _p(running_mean), _p(running_var), ns, _p(scratch), _p(stats))
+
+
+def bn_prelu_fwd(x, stats, gamma, beta, res, a, M: int, Cc: int, u, y):
+    for n, t in (("x", x), ("stats", stats), ("gamma", gamma), ("beta", beta), ("res", res), ("a", a), ("u", u),
+                 ("y", y)):
+        _chk(t, n)
+    _call("ws_bn_prelu_fwd", _p(x), _p(stats), _p(gamma), _p(beta), _p(res), _p(a), M, Cc, _p(u), _p(y))
+
+
+def bn_bwd(x, du, stats, gamma, M: int, Cc: int, dx):
+    """returns sums [2, C] = (dbeta, dgamma)"""
+    for n, t in (("x", x), ("du", du), ("stats", stats), ("gamma", gamma), ("dx", dx)):
+        _chk(t, n)
+    ns = _bn_splits(M)
+    slab = torch.empty(ns, 2, Cc, device=x.device, dtype=torch.float32)
+    sums = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
+    _call("ws_bn_bwd", _p(x), _p(du), _p(stats), _p(gamma), M, Cc, ns, _p(slab), _p(sums), _p(dx))
+    return sums
+
+
+def maxpool3_fwd(x, R: int, T: int, Cc: int, y):
+    _chk(x, "x")
+    _chk(y, "y")
+    _call("ws_maxpool3_fwd", _p(x), R, T, Cc, _p(y))
+
+
+def maxpool3_bwd(x, dy, R: int, T: int, Cc: int, dx):
+    for n, t in (("x", x), ("dy", dy), ("dx", dx)):
+        _chk(t, n)
+    _call("ws_maxpool3_bwd", _p(x), _p(dy), R, T, Cc, _p(dx))
+
+
+def bcast_rows(src, scale: float, rows_per_r: int, M: int, Cc: int, out):
+    _chk(src, "src")
+    _chk(out, "out")
+    _call("ws_bcast_rows", _p(src), scale, rows_per_r, M, Cc, _p(out))
+
+
+def cross_entropy(logits, label, loss, dlogits):
+    _chk(logits, "logits")
+    _chk(label, "label", torch.int64)
+    _chk(loss, "loss")
+    _chk(dlogits, "dlogits")
+    R, S = logits.shape
+    _call("ws_cross_entropy", _p(logits), C.c_void_p(label.data_ptr()), R, S, _p(loss), _p(dlogits))

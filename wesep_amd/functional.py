@@ -434,12 +434,21 @@ def _lin_bwd_w(dy, x, with_bias=True):
     """dW [Nout, K] = dy^T x, db = colsum(dy); single split (M = R is tiny)."""
     M, Nout = dy.shape
     K = x.shape[1]
+    pad = (-Nout) % 4                      # the kernel wants 16-byte G rows (e.g. 251 speaker classes)
+    if pad:
+        dyp = torch.zeros(M, Nout + pad, device=dy.device, dtype=torch.float32)
+        dyp[:, :Nout] = dy
+        dy = dyp
+    Np = Nout + pad
     rps = -(-M // 32) * 32
-    dW = _empty(dy.device, Nout, K)
-    db = _empty(dy.device, Nout) if with_bias else None
-    dev.gemm_tn(G=dy, g_rows=flat(Nout), A=x, a_rows=flat(K), M=M, Nn=Nout, Kk=K, slab=dW,
-                slab_stride=Nout * K, bslab=db, bslab_stride=Nout, nsplit=1, rows_per_split=rps,
+    dW = _empty(dy.device, Np, K)
+    db = _empty(dy.device, Np) if with_bias else None
+    dev.gemm_tn(G=dy, g_rows=flat(Np), A=x, a_rows=flat(K), M=M, Nn=Np, Kk=K, slab=dW,
+                slab_stride=Np * K, bslab=db, bslab_stride=Np, nsplit=1, rows_per_split=rps,
                 vec=1 if K % 4 == 0 else 0)
+    if pad:
+        dW = dW[:Nout].contiguous()
+        db = db[:Nout].contiguous() if with_bias else None
     return dW, db
 
 

@@ -148,6 +148,7 @@ class MultiEncoderFn(torch.autograd.Function):
         e = _gemm(cat, M, 3 * N, W2, B, bias=pb, norm=(st, ln_w, ln_b, StatMap(1, 1, 1, 0, 0)))
         ctx.save_for_backward(xp, cat, st, w1, w2, w3, ln_w, ln_b, W2)
         ctx.geo = (R, Tp, Tpad, stride, N, B, Ls)
+        ctx.set_materialize_grads(False)     # the enrollment pass uses `cat` only: de arrives as None
         return e, cat
 
     @staticmethod
@@ -155,12 +156,18 @@ class MultiEncoderFn(torch.autograd.Function):
         xp, cat, st, w1, w2, w3, ln_w, ln_b, W2 = ctx.saved_tensors
         R, Tp, Tpad, stride, N, B, Ls = ctx.geo
         M = R * Tp
-        de = de.contiguous()
-        sm = StatMap(1, 1, 1, 0, 0)
-        dpw, dpb = _wgrad(de, M, B, cat, 3 * N, norm=(st, ln_w, ln_b, sm))
-        dxn = _gemm(de, M, B, _transposed(W2, B, 3 * N), 3 * N)
         res = dcat_dec.contiguous() if dcat_dec is not None else None
-        dcat, dlnw, dlnb = norm_backward(cat, dxn, st, ln_w, "cLN", R, Tp, 3 * N, res=res)
+        if de is not None:
+            de = de.contiguous()
+            sm = StatMap(1, 1, 1, 0, 0)
+            dpw, dpb = _wgrad(de, M, B, cat, 3 * N, norm=(st, ln_w, ln_b, sm))
+            dxn = _gemm(de, M, B, _transposed(W2, B, 3 * N), 3 * N)
+            dcat, dlnw, dlnb = norm_backward(cat, dxn, st, ln_w, "cLN", R, Tp, 3 * N, res=res)
+            dpw = dpw.view(B, 3 * N, 1)
+        else:                                  # only the ReLU outputs were used (speaker-encoder input)
+            if res is None:
+                return (None,) * 12
+            dcat, dlnw, dlnb, dpw, dpb = res.clone(), None, None, None, None
         dev.relu_mask(dcat, cat)
         frames = Rows(Tp, Tpad, stride)
         grads = []
@@ -168,7 +175,7 @@ class MultiEncoderFn(torch.autograd.Function):
             Lk = Ls[i]
             dW, db = _wgrad(dcat, M, N, xp, Lk, g_ld=3 * N, g_off=i * N, a_rows=frames, vec=0)
             grads += [dW.view(N, 1, Lk), db]
-        return (None, None, *grads, dlnw, dlnb, dpw.view(B, 3 * N, 1), dpb)
+        return (None, None, *grads, dlnw, dlnb, dpw, dpb)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -307,3 +314,151 @@ class MultiDecoderFn(torch.autograd.Function):
             gm[2 * i], gm[2 * i + 1] = dWm.view(N, B, 1), dbm
             gd[2 * i], gd[2 * i + 1] = dWd.view(N, 1, Lk), dev.total_sum(dest)
         return (de, dcat, None, *gm, *gd)
+
+
+# ---------------------------------------------------------------------------------------------
+# ResNet4SpExplus (tasnet/speaker.py:49-64) on the shared encoder's [w1 | w2 | w3] of the enrollment
+# ---------------------------------------------------------------------------------------------
+# GEMM mode of the speaker-encoder branch.  Exact-fp32 MFMA: three BatchNorm stages over T0/3, T0/9, T0/27 frames
+# amplify operand rounding in the backward (measured: split-bf16 products give 5e-3 relative gradient error on the
+# first ResBlock at a 2.4 k-sample enrollment), and the branch is < 1 % of the step's FLOPs.
+SPK_MODE = "f32"
+
+
+class SpkEncoderFn(torch.autograd.Function):
+    """cat_aux [R*T0, 768] -> speaker embedding [R, E].
+    cLN - 1x1 conv - 3 x ResBlock(conv1x1, BN, PReLU, conv1x1, BN, + residual, PReLU, MaxPool1d(3)) - 1x1 conv - mean
+    over time (the last convolution is applied after the mean: both are linear).  BatchNorm1d runs in training mode
+    (batch statistics, running buffers updated in place) or, with training=False, on the running statistics.
+    params: ln_w, ln_b, w1, b1, then per block (conv1.w, conv2.w, bn1.w, bn1.b, bn2.w, bn2.b, prelu1, prelu2,
+    downsample.w or None), then w5, b5.  buffers: per block (rm1, rv1, rm2, rv2).
+    """
+
+    @staticmethod
+    def forward(ctx, cat, geo, buffers, *params):
+        _need_cuda(cat, "ConvTasNet speaker encoder")
+        R, T0, training = geo
+        cat = cat.contiguous()
+        d = cat.device
+        M0, C0 = cat.shape
+        ln_w, ln_b, w1, b1 = params[:4]
+        w5, b5 = params[-2:]
+        st0 = _empty(d, M0, 2)
+        dev.group_stats(cat, _cln_geom(M0, C0), st0, LN_EPS)
+        W1 = w1.reshape(w1.shape[0], C0).contiguous()
+        x = _gemm(cat, M0, C0, W1, W1.shape[0], bias=b1, norm=(st0, ln_w, ln_b, StatMap(1, 1, 1, 0, 0)))
+        saved, meta = [cat, st0, W1, ln_w, ln_b], []
+        T = T0
+        for i in range(3):
+            wc1, wc2, g1, be1, g2, be2, a1, a2, wds = params[4 + 9 * i: 13 + 9 * i]
+            rm1, rv1, rm2, rv2 = buffers[4 * i: 4 * i + 4]
+            co, ci = wc1.shape[0], wc1.shape[1]
+            M = R * T
+            Wc1, Wc2 = wc1.reshape(co, ci).contiguous(), wc2.reshape(co, co).contiguous()
+            c1 = _gemm(x, M, ci, Wc1, co, mode=SPK_MODE)
+            s1 = SpkEncoderFn._bn_stats(c1, M, co, rm1, rv1, training)
+            u1, y1 = _empty(d, M, co), _empty(d, M, co)
+            dev.bn_prelu_fwd(c1, s1, g1, be1, None, a1, M, co, u1, y1)
+            c2 = _gemm(y1, M, co, Wc2, co, mode=SPK_MODE)
+            s2 = SpkEncoderFn._bn_stats(c2, M, co, rm2, rv2, training)
+            Wds = wds.reshape(co, ci).contiguous() if wds is not None else None
+            res = _gemm(x, M, ci, Wds, co, mode=SPK_MODE) if Wds is not None else x
+            u2, y2 = _empty(d, M, co), _empty(d, M, co)
+            dev.bn_prelu_fwd(c2, s2, g2, be2, res, a2, M, co, u2, y2)
+            To = T // 3
+            if To < 1:
+                raise RuntimeError("ConvTasNet speaker encoder: enrollment too short for three MaxPool1d(3) stages")
+            p = _empty(d, R * To, co)
+            dev.maxpool3_fwd(y2, R, T, co, p)
+            saved += [x, c1, s1, u1, y1, c2, s2, u2, y2, Wc1, Wc2, g1, g2, a1, a2] + ([Wds] if Wds is not None else [])
+            meta.append((T, ci, co, Wds is not None, wc1.shape, wc2.shape, wds.shape if wds is not None else None))
+            x, T = p, To
+        C3 = x.shape[1]
+        mean = dev.chan_sums(x, None, None, 1, T, R, C3)[:, 0, :].contiguous()
+        dev.affine_fwd(mean, None, None, 1.0 / T, R, 1, C3, mean)
+        W5 = w5.reshape(w5.shape[0], C3).contiguous()
+        emb = _gemm(mean, R, C3, W5, W5.shape[0], bias=b5, mode=SPK_MODE)
+        ctx.save_for_backward(*saved, mean, W5)
+        ctx.meta = (R, T0, T, C0, meta, (w1.shape, w5.shape), training)
+        return emb
+
+    @staticmethod
+    def _bn_stats(c, M, Cc, rm, rv, training):
+        st = _empty(c.device, 2, Cc)
+        if training:
+            dev.bn_stats(c, M, Cc, rm, rv, st)
+        else:
+            st[0].copy_(rm)
+            st[1].copy_(torch.rsqrt(rv + dev.BN_EPS))
+        return st
+
+    @staticmethod
+    def backward(ctx, demb):
+        from .functional import _lin_bwd_w
+        R, T0, T3, C0, meta, (s1shape, s5shape), training = ctx.meta
+        if not training:
+            raise L.WesepHipError("speaker encoder backward in eval mode (running statistics) is not built")
+        sv = list(ctx.saved_tensors)
+        cat, st0, W1, ln_w, ln_b = sv[:5]
+        mean, W5 = sv[-2:]
+        d = cat.device
+        demb = demb.contiguous()
+        dW5, db5 = _lin_bwd_w(demb, mean)
+        C3 = W5.shape[1]
+        dmean = _gemm(demb, R, W5.shape[0], _transposed(W5, W5.shape[0], C3), C3, mode=SPK_MODE)
+        dp = _empty(d, R * T3, C3)
+        dev.bcast_rows(dmean, 1.0 / T3, T3, R * T3, C3, dp)
+        grads_blocks = []
+        pos = len(sv) - 2
+        for (T, ci, co, has_ds, sh1, sh2, shd) in reversed(meta):
+            n = 15 + (1 if has_ds else 0)
+            blk = sv[pos - n: pos]
+            pos -= n
+            x, c1, s1, u1, y1, c2, s2, u2, y2, Wc1, Wc2, g1, g2, a1, a2 = blk[:15]
+            Wds = blk[15] if has_ds else None
+            M = R * T
+            dy2 = _empty(d, M, co)
+            dev.maxpool3_bwd(y2, dp, R, T, co, dy2)
+            da2 = dev.prelu_bwd(u2, dy2, a2, dy2)                      # -> du2 (also the residual gradient)
+            dc2 = _empty(d, M, co)
+            sums2 = dev.bn_bwd(c2, dy2, s2, g2, M, co, dc2)
+            dWc2, _ = _wgrad(dc2, M, co, y1, co, with_bias=False, mode=SPK_MODE)
+            dy1 = _gemm(dc2, M, co, _transposed(Wc2, co, co), co, mode=SPK_MODE)
+            da1 = dev.prelu_bwd(u1, dy1, a1, dy1)                      # -> du1
+            sums1 = dev.bn_bwd(c1, dy1, s1, g1, M, co, dy1)            # -> dc1 in place
+            dWc1, _ = _wgrad(dy1, M, co, x, ci, with_bias=False, mode=SPK_MODE)
+            if has_ds:
+                dWds, _ = _wgrad(dy2, M, co, x, ci, with_bias=False, mode=SPK_MODE)
+                dres = _gemm(dy2, M, co, _transposed(Wds, co, ci), ci, mode=SPK_MODE)
+            else:
+                dWds, dres = None, dy2
+            dp = _gemm(dy1, M, co, _transposed(Wc1, co, ci), ci, R=dres, mode=SPK_MODE)
+            grads_blocks.append([dWc1.view(sh1), dWc2.view(sh2), sums1[1].contiguous(), sums1[0].contiguous(),
+                                 sums2[1].contiguous(), sums2[0].contiguous(), da1, da2,
+                                 dWds.view(shd) if has_ds else None])
+        M0 = R * T0
+        sm = StatMap(1, 1, 1, 0, 0)
+        dW1, db1 = _wgrad(dp, M0, W1.shape[0], cat, C0, norm=(st0, ln_w, ln_b, sm), mode=SPK_MODE)
+        dxn = _gemm(dp, M0, W1.shape[0], _transposed(W1, W1.shape[0], C0), C0, mode=SPK_MODE)
+        dcat, dlnw, dlnb = norm_backward(cat, dxn, st0, ln_w, "cLN", R, T0, C0)
+        flat_blocks = [g for blk in reversed(grads_blocks) for g in blk]
+        return (dcat, None, None, dlnw, dlnb, dW1.view(s1shape), db1, *flat_blocks, dW5.view(s5shape), db5)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss (mean) on [R, S] logits with int64 labels."""
+
+    @staticmethod
+    def forward(ctx, logits, label):
+        _need_cuda(logits, "CrossEntropyLoss")
+        logits = logits.contiguous().float()
+        loss = _empty(logits.device, 1)
+        dlogits = torch.empty_like(logits)
+        dev.cross_entropy(logits, label.contiguous().long(), loss, dlogits)
+        ctx.save_for_backward(dlogits)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * gout, None

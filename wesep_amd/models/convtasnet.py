@@ -1,17 +1,19 @@
 """Conv-TasNet / SpEx+ on MI355X: constructor arguments, module tree and `state_dict` keys of the
-reference `wesep.models.convtasnet.ConvTasNet` (wesep/models/convtasnet.py:14-219) in its
-fixed-embedding mode (`joint_training=False`: `forward(wav [R, T], emb [R, E])`), the configuration of
-BASELINE.json configs[0].  `forward` is a chain of C-ABI launches (wesep_amd/functional_tasnet.py).
+reference `wesep.models.convtasnet.ConvTasNet` (wesep/models/convtasnet.py:14-219): the fixed-embedding
+mode (`joint_training=False`: `forward(wav [R, T], emb [R, E])`, BASELINE.json configs[0]) and the SpEx+
+joint mode (`joint_training=True, spk_feat=False`: `forward(wav, enrollment wav [R, Tw])`, speaker encoder
+`ResNet4SpExplus` on the shared encoder, optional multi-task speaker logits as a fourth output).  `forward` is a chain of C-ABI launches (wesep_amd/functional_tasnet.py).
 
 Built: Multi encoder / decoder, concatConv fusion with multi_fuse, gLN / cLN, ReLU masks, optional
 SpeakerTransform.  Everything else of the reference constructor raises NotImplementedError (see
-DESIGN.md): Deep / plain encoders, skip connections, causal blocks, BatchNorm, other fusion types, and
-joint training (ResNet4SpExplus / wespeaker encoders)."""
+DESIGN.md): Deep / plain encoders, skip connections, causal blocks, norm='BN' in the separator, other
+fusion types, and joint training with a wespeaker encoder on fbank features."""
 import torch
 import torch.nn as nn
 
 from ..modules.common.speaker import SpeakerTransform
-from ..modules.tasnet import FuseSeparation, MultiDecoder, MultiEncoder
+from ..functional import LinearFn
+from ..modules.tasnet import FuseSeparation, MultiDecoder, MultiEncoder, ResNet4SpExplus
 
 
 class ConvTasNet(nn.Module):
@@ -21,9 +23,10 @@ class ConvTasNet(nn.Module):
                  multi_task=False, spksInTrain=251, spk_model=None, spk_model_init=None, spk_model_freeze=False,
                  spk_args=None, spk_feat=False, feat_type="consistent"):
         super().__init__()
-        if joint_training:
-            raise NotImplementedError("ConvTasNet joint_training=True (speaker encoder trained jointly, SURVEY "
-                                      "section 8 row a12) is not built; pass fixed [R, E] embeddings")
+        if joint_training and (spk_feat or feat_type != "consistent"):
+            raise NotImplementedError("ConvTasNet joint training with a wespeaker model on fbank features (SURVEY "
+                                      "section 8 row a12) is not built; the SpEx+ speaker encoder on the shared "
+                                      "encoder (spk_feat=False, feat_type='consistent') is")
         if encoder_type != "Multi" or decoder_type != "Multi":
             raise NotImplementedError("ConvTasNet: only encoder_type = decoder_type = 'Multi' (SpEx+) is built")
         if activate != "relu":
@@ -31,6 +34,10 @@ class ConvTasNet(nn.Module):
         self.encoder_type, self.decoder_type = encoder_type, decoder_type
         self.joint_training, self.multi_task = joint_training, multi_task
         self.encoder = MultiEncoder(in_channels=1, middle_channels=N, out_channels=B, kernel_size=L, stride=L // 2)
+        if joint_training:                 # registration order of the reference: encoder, spk_model, pred_linear
+            self.spk_model = ResNet4SpExplus(in_channel=N, C_embedding=spk_emb_dim)
+            if multi_task:
+                self.pred_linear = nn.Linear(spk_emb_dim, spksInTrain)
         self.spk_transform = SpeakerTransform() if use_spk_transform else nn.Identity()
         self.separation = FuseSeparation(R, X, B, H, P, norm=norm, causal=causal, skip_con=skip_con,
                                          C_embedding=spk_emb_dim, spk_fuse_type=spk_fuse_type,
@@ -47,6 +54,16 @@ class ConvTasNet(nn.Module):
         x = x.contiguous().float()
         e, cat, Tp = self.encoder(x)
         geo = (x.shape[0], Tp)
-        emb = self.spk_transform(embeddings.contiguous().float())
+        logits = None
+        embeddings = embeddings.contiguous().float()
+        if self.joint_training:            # enrollment waveform through the SHARED encoder (convtasnet.py:179-187)
+            _, cat_aux, Tpa = self.encoder(embeddings)
+            embeddings = self.spk_model(cat_aux, (x.shape[0], Tpa))
+            if self.multi_task:
+                logits = LinearFn.apply(embeddings, self.pred_linear.weight, self.pred_linear.bias)
+        emb = self.spk_transform(embeddings)
         e = self.separation(e, emb, geo)
-        return self.decoder(e, cat, geo)
+        s = self.decoder(e, cat, geo)
+        if logits is not None:
+            s.append(logits)
+        return s

@@ -170,3 +170,58 @@ class MultiDecoder(nn.Module):
             e, cat, (R, Tp, self.stride), self.mask1.weight, self.mask1.bias, self.mask2.weight, self.mask2.bias,
             self.mask3.weight, self.mask3.bias, self.decoder_1d_1.weight, self.decoder_1d_1.bias,
             self.decoder_1d_2.weight, self.decoder_1d_2.bias, self.decoder_1d_3.weight, self.decoder_1d_3.bias))
+
+
+class ResBlock(nn.Module):
+    """tasnet/speaker.py:7-44 (parameter container)."""
+
+    def __init__(self, in_dims, out_dims):
+        super().__init__()
+        self.conv1 = nn.Conv1d(in_dims, out_dims, kernel_size=1, bias=False)
+        self.conv2 = nn.Conv1d(out_dims, out_dims, kernel_size=1, bias=False)
+        self.batch_norm1 = nn.BatchNorm1d(out_dims)
+        self.batch_norm2 = nn.BatchNorm1d(out_dims)
+        self.prelu1 = nn.PReLU()
+        self.prelu2 = nn.PReLU()
+        self.downsample = in_dims != out_dims
+        if self.downsample:
+            self.conv_downsample = nn.Conv1d(in_dims, out_dims, kernel_size=1, bias=False)
+
+    def tensors(self):
+        params = [self.conv1.weight, self.conv2.weight, self.batch_norm1.weight, self.batch_norm1.bias,
+                  self.batch_norm2.weight, self.batch_norm2.bias, self.prelu1.weight, self.prelu2.weight,
+                  self.conv_downsample.weight if self.downsample else None]
+        buffers = [self.batch_norm1.running_mean, self.batch_norm1.running_var, self.batch_norm2.running_mean,
+                   self.batch_norm2.running_var]
+        return params, buffers
+
+
+class ResNet4SpExplus(nn.Module):
+    """tasnet/speaker.py:47-64: speaker encoder of SpEx+ on the shared encoder's [w1 | w2 | w3] (hard-wired to
+    3 * 256 input channels like the reference)."""
+
+    def __init__(self, in_channel=256, C_embedding=256):
+        super().__init__()
+        self.aux_enc3 = nn.Sequential(
+            nn.LayerNorm(3 * in_channel, elementwise_affine=True),
+            nn.Conv1d(3 * 256, 256, 1),
+            ResBlock(256, 256),
+            ResBlock(256, 512),
+            ResBlock(512, 512),
+            nn.Conv1d(512, C_embedding, 1),
+        )
+
+    def forward(self, cat_aux, geo):
+        """cat_aux [R*T', 768] (channels-last ReLU outputs of the shared encoder), geo = (R, T')."""
+        R, Tp = geo
+        seq = self.aux_enc3
+        params, buffers = [seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias], []
+        for i in (2, 3, 4):
+            p, b = seq[i].tensors()
+            params += p
+            buffers += b
+            if self.training:
+                seq[i].batch_norm1.num_batches_tracked += 1
+                seq[i].batch_norm2.num_batches_tracked += 1
+        params += [seq[5].weight, seq[5].bias]
+        return FT.SpkEncoderFn.apply(cat_aux, (R, Tp, self.training), buffers, *params)

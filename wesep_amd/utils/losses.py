@@ -1,7 +1,7 @@
 """Loss registry with the reference's contract (`parse_loss`, wesep/utils/losses.py:8-41):
 name -> instantiated callable `c(est, target) -> Tensor`.  SISDR/SISNR run on the HIP path;
-CE stays torch.nn.CrossEntropyLoss (class name is what the executor dispatches on,
-executor.py:112-113).  Losses the hot path does not cover raise instead of silently falling
+CE is `CrossEntropyLoss` below (the class NAME is what the executor dispatches on,
+executor.py:112-113), also on the HIP path.  Losses the hot path does not cover raise instead of silently falling
 back."""
 import torch.nn as nn
 
@@ -21,10 +21,18 @@ class SISDRLoss(nn.Module):
         return F_.SISDRFn.apply(input, target, self.eps)
 
 
+class CrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss() (mean reduction, class-index targets) on gfx950 (losses.py:11)."""
+
+    def forward(self, input, target):
+        from ..functional_tasnet import CrossEntropyFn
+        return CrossEntropyFn.apply(input, target)
+
+
 valid_losses = {
     "SISDR": SISDRLoss(),
     "SISNR": SISDRLoss(),
-    "CE": nn.CrossEntropyLoss(),
+    "CE": CrossEntropyLoss(),
 }
 
 
