@@ -290,3 +290,18 @@ def test_ddp_wrapped_step_equals_plain_step():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_device_prefetcher_copies_one_batch_ahead():
+    """pinned non-blocking H2D on a copy stream; values and order survive, tensors land on the GPU."""
+    from wesep_amd.utils.prefetch import DevicePrefetcher
+    d = _cuda()
+    torch.manual_seed(0)
+    batches = [{"wav_mix": torch.randn(4, 64000), "wav_targets": torch.randn(4, 64000),
+                "spk_embeds": torch.randn(4, 256), "spk_label": torch.arange(4) + i, "key": i} for i in range(5)]
+    acc = []
+    for b in DevicePrefetcher(batches, d):
+        assert b["wav_mix"].is_cuda and b["spk_label"].is_cuda and b["spk_label"].dtype == torch.int64
+        acc.append((b["wav_mix"].double().sum() + b["spk_embeds"].double().sum()).item())   # consumes on the main stream
+    ref = [(x["wav_mix"].double().sum() + x["spk_embeds"].double().sum()).item() for x in batches]
+    assert np.allclose(acc, ref, rtol=1e-9, atol=1e-6)

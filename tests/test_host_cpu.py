@@ -222,3 +222,18 @@ def test_convtasnet_state_dict_keys_match_reference():
     assert all(tuple(sd[k].shape) == shapes[k] for k in sd)
     with pytest.raises(NotImplementedError):
         get_model("ConvTasNet")(spk_feat=True)    # wespeaker encoder on fbank features: SURVEY 8 row a12
+
+
+def test_device_prefetcher_passthrough_on_cpu():
+    """Datapipe hand-off: order, dtype conversion and pass-through of non-tensor entries."""
+    import torch
+    from wesep_amd.utils.prefetch import DevicePrefetcher
+    batches = [{"wav_mix": torch.full((2, 5), float(i), dtype=torch.float64), "wav_targets": torch.zeros(2, 5),
+                "spk_embeds": torch.ones(2, 3), "spk_label": torch.tensor([i, i + 1]), "key": [f"u{i}"]}
+               for i in range(4)]
+    got = list(DevicePrefetcher(batches, "cpu"))
+    assert len(got) == 4 and len(DevicePrefetcher(batches, "cpu")) == 4
+    for i, b in enumerate(got):
+        assert b["wav_mix"].dtype == torch.float32 and float(b["wav_mix"][0, 0]) == float(i)
+        assert b["spk_label"].dtype == torch.int64 and b["key"] == [f"u{i}"]
+    assert list(DevicePrefetcher([], "cpu")) == []

@@ -3,7 +3,8 @@
 
 Same call signature, same loss composition (`se_loss_weight = (positions, weights)`), same
 lr-before-step ordering and same return value `(mean_loss, 0)`.  Host-side differences, all
-invisible to the caller: the batch is moved with non-blocking copies; the per-step
+invisible to the caller: batches are pinned and copied one step ahead on a copy stream
+(`utils/prefetch.DevicePrefetcher`); the per-step
 `loss.item()` (executor.py:124) is replaced by a device-side running sum that is read only
 when a log row is due and at the end of the epoch; per-tensor clipping + Adam are two
 multi-tensor launches when the optimizer is `FusedClipAdam` (no per-parameter host syncs).
@@ -14,6 +15,7 @@ from contextlib import nullcontext
 import torch
 
 from ..optim import FusedClipAdam, clip_gradients
+from .prefetch import DevicePrefetcher
 
 
 def _row(*cells):
@@ -63,10 +65,11 @@ class Executor:
         loss_sum = torch.zeros((), device=device)
         n_steps = 0
         with (model.join() if ddp else nullcontext()):
-            for i, batch in enumerate(dataloader):
+            # batch i+1 is pinned and copied on a side stream while step i computes (utils/prefetch.py)
+            for i, batch in enumerate(DevicePrefetcher(dataloader, device)):
                 cur_iter = (epoch - 1) * epoch_iter + i
                 scheduler.step(cur_iter)
-                features, targets, enroll, spk_label = self._to_device(batch, device)
+                features, targets, enroll, spk_label = self._to_device(batch, device)   # no-ops after the prefetch
                 outputs = model(features, enroll)
                 loss = self._loss(outputs, targets, spk_label, criterion, se_loss_weight, multi_task)
                 loss_sum += loss.detach()
