@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 3
+#define WS_ABI_VERSION 4
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -406,6 +406,25 @@ int ws_bcast_rows(const float* src, float scale, int rows_per_r, long long M, in
 /* nn.CrossEntropyLoss (mean) on [R][S] logits, int64 labels: loss[0] and dlogits = d loss / d logits     */
 int ws_cross_entropy(const float* logits, const long long* label, int R, int S, float* loss, float* dlogits,
                      void* stream);
+
+/* ---- forward recurrence with the input projection fused in (blocked layout, 32-sequence workgroups) --------
+ * Replaces ws_gemm_p2b(x-projection) + ws_lstm_fwd(WS_LSTM_BF16X3_BLK) for views with many sequences:
+ * xn is the normalised ResRNN input in BL(128); gates (BL(2048)) receives the ACTIVATED gates, cbuf / hcat
+ * (BL(512)) as in ws_lstm_fwd; bias [2][4H] = b_ih + b_hh per direction.  wpack: ws_lstm_pack_fused output,
+ * WS_LSTM_FUSED_PACK_FLOATS floats ([W_ih | W_hh] as one K = 384 stream of bf16 hi/lo MFMA fragments).       */
+typedef struct ws_lstm_fused_args {
+  float* gates;
+  float* cbuf;
+  float* hcat;
+  const float* xn;
+  const float* wpack;
+  const float* bias;
+  int nseq, L;
+} ws_lstm_fused_args;
+#define WS_LSTM_FUSED_PACK_FLOATS (2 * 8 * 24 * 4 * 2 * 64 * 4)
+int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
+                       float* pack, void* stream);
+int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream);
 
 #ifdef __cplusplus
 }

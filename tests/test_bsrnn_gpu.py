@@ -305,3 +305,32 @@ def test_device_prefetcher_copies_one_batch_ahead():
         acc.append((b["wav_mix"].double().sum() + b["spk_embeds"].double().sum()).item())   # consumes on the main stream
     ref = [(x["wav_mix"].double().sum() + x["spk_embeds"].double().sum()).item() for x in batches]
     assert np.allclose(acc, ref, rtol=1e-9, atol=1e-6)
+
+
+def test_fused_input_projection_recurrence_matches_two_kernel_path(monkeypatch):
+    """Band view at a size that selects 32-sequence workgroups (2505 sequences x 32 steps): the recurrence with
+    the x-projection fused in (lstm_fused.hip) against gemm_p2b + ws_lstm_fwd -- forward output, input gradient
+    and every parameter gradient (same split-bf16 products, different accumulation order)."""
+    from wesep_amd import dev
+    from wesep_amd.models.bsrnn import ResRNN
+    d = _cuda()
+    torch.manual_seed(11)
+    R, K, Tf, N = 5, 32, 501, 128
+    blk = ResRNN(N, 2 * N).to(d)
+    z0 = torch.randn(R, K, Tf, N, device=d)
+    gout = torch.randn(R, K, Tf, N, device=d)
+    res = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("WESEP_LSTM_FUSE", fuse)
+        assert dev.lstm_fuse_ok(R * Tf, False) == (fuse == "1")
+        z = z0.clone().requires_grad_(True)
+        for p_ in blk.parameters():
+            p_.grad = None
+        out = blk(z, "band")
+        out.backward(gout)
+        torch.cuda.synchronize()
+        res[fuse] = (out.detach(), z.grad.detach(), {k: v.grad.detach().clone() for k, v in blk.named_parameters()})
+    assert rel(res["1"][0], res["0"][0]) < 1e-4
+    assert rel(res["1"][1], res["0"][1]) < 5e-4
+    for k in res["0"][2]:
+        assert rel(res["1"][2][k], res["0"][2][k]) < 5e-4, k

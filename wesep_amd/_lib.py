@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 3
+ABI_VERSION = 4
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
@@ -95,6 +95,13 @@ TENSOR_REF_DTYPE = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8
                              ("exp_avg_sq", "<u8"), ("numel", "<i8")])
 assert GROUP_NT_DTYPE.itemsize == 72 and GROUP_TN_DTYPE.itemsize == 72 and TENSOR_REF_DTYPE.itemsize == 40
 
+class LstmFusedArgs(C.Structure):
+    _fields_ = [("gates", _p), ("cbuf", _p), ("hcat", _p), ("xn", _p), ("wpack", _p), ("bias", _p),
+                ("nseq", _i), ("L", _i)]
+
+
+LSTM_FUSED_PACK_FLOATS = 2 * 8 * 24 * 4 * 2 * 64 * 4
+
 _SIGS = {
     "ws_abi_version": (_i, []),
     "ws_last_error": (C.c_char_p, []),
@@ -148,6 +155,8 @@ _SIGS = {
     "ws_maxpool3_bwd": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "ws_bcast_rows": (_i, [_p, C.c_float, _i, _ll, _i, _p, _p]),
     "ws_cross_entropy": (_i, [_p, _p, _i, _i, _p, _p, _p]),
+    "ws_lstm_pack_fused": (_i, [_p, _p, _p, _p, _p, _p]),
+    "ws_lstm_fwd_fused": (_i, [C.POINTER(LstmFusedArgs), _p]),
     "ws_grad_norms": (_i, [_p, _i, _p, _p]),
     "ws_clip_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p]),
 }

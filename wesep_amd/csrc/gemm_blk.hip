@@ -148,6 +148,7 @@ __global__ __launch_bounds__(512, 4) void gemm_p2b_kernel(const ws_gemm_p2b_args
 
   // ---- sweep over N in stages of 64 columns ---------------------------------------------------
   const int nstage = p.N / 64;
+  if (nstage == 0) return;  // N = 0: the call only relays the (normalised) operand into BL(K)
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.Wpack);  // 2048 units of 16 B per stage
   u32x4 wreg[4];
 #pragma unroll
@@ -200,9 +201,9 @@ __global__ __launch_bounds__(512, 4) void gemm_p2b_kernel(const ws_gemm_p2b_args
 }
 
 extern "C" int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream) {
-  WS_REQUIRE(a && a->A && a->Wpack && a->C, "ws_gemm_p2b: null pointer");
+  WS_REQUIRE(a && a->A && ((a->Wpack && a->C) || (a->N == 0 && a->A_bl)), "ws_gemm_p2b: null pointer");
   WS_REQUIRE(a->K == P2B_K, "ws_gemm_p2b: K must be %d (got %d)", P2B_K, a->K);
-  WS_REQUIRE(a->N > 0 && a->N % 64 == 0, "ws_gemm_p2b: N %% 64 (N=%d)", a->N);
+  WS_REQUIRE(a->N >= 0 && a->N % 64 == 0, "ws_gemm_p2b: N %% 64 (N=%d)", a->N);
   WS_REQUIRE(a->lda >= a->K && a->lda % 4 == 0, "ws_gemm_p2b: lda");
   WS_REQUIRE(a->sm.nseq > 0 && a->sm.L > 0 && a->sm.sq_div > 0, "ws_gemm_p2b: bad sequence map");
   WS_REQUIRE(!a->stats || (a->gamma && a->beta && a->st_div1 > 0 && a->st_div2 > 0), "ws_gemm_p2b: norm args");

@@ -1,0 +1,212 @@
+// Band-view forward recurrence with the INPUT PROJECTION FUSED IN (blocked layout, 32 sequences per
+// workgroup).  The plain pipeline writes x W_ih^T + b to the 16E-byte `gates` buffer (gemm_p2b, 4.2 GB
+// at R = 32) and the recurrence reads it back; both kernels are HBM-bound.  Here the recurrence takes
+// the normalised input itself (BL(128), 1/16 of the bytes) and streams [W_ih | W_hh] as one K = 384
+// weight stream: the x part (8 of 24 k-steps) does not depend on h_{t-1}, the matrix cores were at
+// ~23 % in this view, and the per-step weight stream (1.5 MB at ~64 B/clk/CU = 10 us) stays under the
+// HBM time of the step's 288 KB of stores at 256 workgroups.  Everything else (transposed product,
+// lane-local cell update, 2-slot weight ring that never drains, single-basic-block step body,
+// non-temporal activation streams) is lstm_fwd_bf16_kernel<BLK = true> of lstm_bf16.hip.
+//   nn.LSTM forward inside ResRNN (bsrnn.py:27-33,40); replaces gemm_p2b(x-proj) + ws_lstm_fwd there.
+#include "lstm_bf16_common.h"
+
+#define XROW 136  // bf16 per LDS row of x (128 + 8: 272 B = 4 banks mod 64)
+#define FKS 24    // k-steps of the fused stream: 8 of W_ih (K = 128), 16 of W_hh (K = 256)
+
+// unit ((((d*8 + w)*24 + ks)*4 + g)*2 + part)*64 + lane, element j =
+//   part( ks < 8 ? W_ih[d][g*256 + 32w + (lane&31)][16ks + 8(lane>>5) + j]
+//                : W_hh[d][g*256 + 32w + (lane&31)][16(ks-8) + 8(lane>>5) + j] )
+__global__ void lstm_pack_fused_kernel(const float* __restrict__ wih_f, const float* __restrict__ wih_r,
+                                       const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                       __bf16* __restrict__ pf) {
+  const int total = 2 * 8 * FKS * 4 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int r = idx;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    const int g = r & 3; r >>= 2;
+    const int ks = r % FKS; r /= FKS;
+    const int w = r & 7; r >>= 3;
+    const int d = r;
+    const int row = g * 256 + 32 * w + (lane & 31);
+    float v;
+    if (ks < 8) {
+      const float* W = d ? wih_r : wih_f;
+      v = W[row * 128 + 16 * ks + 8 * (lane >> 5) + j];
+    } else {
+      const float* W = d ? whh_r : whh_f;
+      v = W[row * LH + 16 * (ks - 8) + 8 * (lane >> 5) + j];
+    }
+    const __bf16 hi = (__bf16)v;
+    const long long unit = ((((long long)(d * 8 + w) * FKS + ks) * 4 + g) * 2) * 64 + lane;
+    pf[unit * 8 + j] = hi;
+    pf[(unit + 64) * 8 + j] = (__bf16)(v - (float)hi);
+  }
+}
+
+extern "C" int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
+                                  float* pack, void* stream) {
+  WS_REQUIRE(wih_f && wih_r && whh_f && whh_r && pack, "ws_lstm_pack_fused: null pointer");
+  hipLaunchKernelGGL(lstm_pack_fused_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, wih_f, wih_r, whh_f, whh_r,
+                     reinterpret_cast<__bf16*>(pack));
+  return ws_check_launch("ws_lstm_pack_fused");
+}
+
+__global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fused_args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 hl[2][2][SQ * HROW];  // [buf][part][seq][k]  66 KB
+  __shared__ __attribute__((aligned(16))) __bf16 xl[2][2][SQ * XROW];  // [buf][part][seq][k]  34 KB
+  __shared__ __attribute__((aligned(16))) float cl[SQ * (LH + 4)];     // cell state [seq][unit] 33 KB
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = p.L;
+
+  {  // h_{-1} = 0
+    uint32_t* z = reinterpret_cast<uint32_t*>(&hl[0][0][0]);
+    for (int i = tid; i < 2 * SQ * HROW / 2; i += 512) z[i] = 0u;
+  }
+  const int ubase = 32 * w + 4 * half;  // unit of register 4j + r: ubase + 8j + r
+  const int glane = ((d * 256 + 8 * w + half) * 32 + l31) * 16;  // bytes; + (g*64 + 2j)*512
+  const int clane = ((d * 64 + 8 * w + half) * 32 + l31) * 16;   // bytes; + 2j*512
+  auto grs = [&](int t) { return mkrsrc(p.gates + (long long)(blockIdx.x * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  auto crs = [&](float* b, int t) { return mkrsrc(b + (long long)(blockIdx.x * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
+  auto xrs = [&](int t) { return mkrsrc(p.xn + (long long)(blockIdx.x * L + t) * (SQ * 128), SQ * 128 * 4); };
+  auto st_gate = [&](const f32x4& v, int t, int g, int j) { bst(v, grs(t), glane, (g * 64 + 2 * j) * 512); };
+  auto st_ch = [&](const f32x4& v, float* b, int t, int j) { bst(v, crs(b, t), clane, 2 * j * 512); };
+  // x tile of one step = one BL(128) block: 1024 cells of 16 B, cell u = quad * 32 + slot; thread: u = tid, tid + 512
+  auto ld_x = [&](int t, int q) -> f32x4 { return bld(xrs(t), tid * 16, q * 8192); };
+  auto st_x = [&](const f32x4& v, int buf, int q) {  // cell u -> row slot, columns 4*quad .. +3
+    const int u = tid + 512 * q, quad = u >> 5, slot = u & 31;
+    bf16x4 hi, lo;
+    split4(v, hi, lo);
+    *reinterpret_cast<bf16x4*>(&xl[buf][0][slot * XROW + 4 * quad]) = hi;
+    *reinterpret_cast<bf16x4*>(&xl[buf][1][slot * XROW + 4 * quad]) = lo;
+  };
+
+  float* cme = &cl[l31 * (LH + 4) + ubase];  // this lane's 4 runs of 4 units: cme + 8j (private)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(cme + 8 * j) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // biases b_ih + b_hh of this lane's units: the accumulators start from them
+  f32x4 bias[4][4];  // [gate][run]
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias[g][j] = *reinterpret_cast<const f32x4*>(p.bias + d * LG + g * 256 + ubase + 8 * j);
+
+  // weight stream: per k-step 8 fragments (4 gates x {hi, lo}), 1 KB each per wave; 24 k-steps per step
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.wpack) + (long long)(d * 8 + w) * (FKS * 8 * 64 * 4), 0, FKS * 8 * 1024, 0x00020000);
+  const int wlane = lane * 16;
+  bf16x8 wr[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
+
+  // inputs: x of the first step goes to LDS now, x of the second step waits in registers
+  f32x4 xr[2];
+  {
+    const int t0 = d == 0 ? 0 : L - 1;
+    const int t1 = d == 0 ? min(1, L - 1) : max(L - 2, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) st_x(ld_x(t0, q), 0, q);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) xr[q] = ld_x(t1, q);
+  }
+  __syncthreads();
+
+  for (int step = 0; step < L; ++step) {
+    const int t = d == 0 ? step : L - 1 - step;
+    const int cur = step & 1;
+    int zo = 0;
+    asm volatile("" : "+s"(zo));
+    const __bf16* xhi = &xl[cur][0][l31 * XROW + 8 * half];
+    const __bf16* xlo = &xl[cur][1][l31 * XROW + 8 * half];
+    const __bf16* hhi = &hl[cur][0][l31 * HROW + 8 * half];
+    const __bf16* hlo = &hl[cur][1][l31 * HROW + 8 * half];
+    f32x16 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[g][4 * j + r] = bias[g][j][r];
+#pragma unroll
+    for (int ks = 0; ks < FKS; ++ks) {
+      const int s = ks & 1;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(ks < 8 ? xhi + 16 * ks : hhi + 16 * (ks - 8));
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(ks < 8 ? xlo + 16 * ks : hlo + 16 * (ks - 8));
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g], bh, acc[g]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g + 1], bh, acc[g]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g], bl, acc[g]);
+      // refill this slot with k-step ks+2 (wraps into the next step: the stream never drains)
+      const int kn = (ks + 2) % FKS;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
+      __builtin_amdgcn_sched_barrier(0);  // keep the k-steps in program order: loads stay 2 k-steps ahead
+    }
+
+    // next step's x (loaded one step ago) -> LDS; x of the step after it -> registers (two steps of HBM latency
+    // budget, and only 2 loads per thread sit in front of the weight stream of the next step)
+    {
+      const int s2 = min(step + 2, L - 1);
+      const int t2 = d == 0 ? s2 : L - 1 - s2;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) st_x(xr[q], cur ^ 1, q);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) xr[q] = ld_x(t2, q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // cell update, lane-local; global traffic as 16-byte vectors
+    __bf16* nhi = &hl[cur ^ 1][0][l31 * HROW + ubase];
+    __bf16* nlo = &hl[cur ^ 1][1][l31 * HROW + ubase];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 vi, vf, vg, vo, vc, vh;
+      const f32x4 cold = *reinterpret_cast<const f32x4*>(cme + 8 * j);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ig = fsig(acc[0][4 * j + r]);
+        const float fg = fsig(acc[1][4 * j + r]);
+        const float gg = ftanh(acc[2][4 * j + r]);
+        const float og = fsig(acc[3][4 * j + r]);
+        const float cn = fg * cold[r] + ig * gg;
+        vi[r] = ig;
+        vf[r] = fg;
+        vg[r] = gg;
+        vo[r] = og;
+        vc[r] = cn;
+        vh[r] = og * ftanh(cn);
+      }
+      bf16x4 h_hi, h_lo;
+      split4(vh, h_hi, h_lo);
+      *reinterpret_cast<bf16x4*>(nhi + 8 * j) = h_hi;
+      *reinterpret_cast<bf16x4*>(nlo + 8 * j) = h_lo;
+      *reinterpret_cast<f32x4*>(cme + 8 * j) = vc;
+      st_gate(vi, t, 0, j);
+      st_gate(vf, t, 1, j);
+      st_gate(vg, t, 2, j);
+      st_gate(vo, t, 3, j);
+      st_ch(vc, p.cbuf, t, j);
+      st_ch(vh, p.hcat, t, j);
+      __builtin_amdgcn_sched_barrier(0);  // one run at a time: bounds the live temporaries
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
+  WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn && a->wpack && a->bias, "ws_lstm_fwd_fused: null pointer");
+  WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_fwd_fused: bad nseq/L");
+  dim3 grid((a->nseq + SQ - 1) / SQ, 2), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  ws_prof_begin(WS_PROF_LSTM_FWD, s);
+  hipLaunchKernelGGL(lstm_fwd_fused_kernel, grid, block, 0, s, *a);
+  ws_prof_end(WS_PROF_LSTM_FWD, s);
+  return ws_check_launch("ws_lstm_fwd_fused");
+}

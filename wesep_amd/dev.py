@@ -690,3 +690,27 @@ def cross_entropy(logits, label, loss, dlogits):
     _chk(dlogits, "dlogits")
     R, S = logits.shape
     _call("ws_cross_entropy", _p(logits), C.c_void_p(label.data_ptr()), R, S, _p(loss), _p(dlogits))
+
+
+# ---- forward recurrence with the input projection fused in (lstm_fused.hip) --------------------------
+def lstm_fuse_ok(nseq: int, cluster: bool) -> bool:
+    """Fused x-projection + recurrence for views with enough sequences to fill the chip with 32-sequence
+    workgroups (pBSRNN's band view); WESEP_LSTM_FUSE=0 keeps the two-kernel path."""
+    if os.environ.get("WESEP_LSTM_FUSE", "1") == "0" or cluster:
+        return False
+    return lstm_blk_mode(nseq) == L.LSTM_BF16X3_BLK
+
+
+def lstm_pack_fused(wih_f, wih_r, whh_f, whh_r, pack):
+    for n, t in (("wih_f", wih_f), ("wih_r", wih_r), ("whh_f", whh_f), ("whh_r", whh_r), ("pack", pack)):
+        _chk(t, n)
+    _call("ws_lstm_pack_fused", _p(wih_f), _p(wih_r), _p(whh_f), _p(whh_r), _p(pack))
+
+
+def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm: SeqMap):
+    for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("xn", xn), ("wpack", wpack), ("bias", bias)):
+        _chk(t, n)
+    a = L.LstmFusedArgs()
+    a.gates, a.cbuf, a.hcat, a.xn, a.wpack, a.bias = _p(gates), _p(cbuf), _p(hcat), _p(xn), _p(wpack), _p(bias)
+    a.nseq, a.L = sm.nseq, sm.L
+    L.check(L.lib().ws_lstm_fwd_fused(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_fused")

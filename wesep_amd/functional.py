@@ -275,21 +275,30 @@ class ResRNNBlkFn(torch.autograd.Function):
         dev.group_stats(z, geo, stats)
         wcat, bcat = _empty(d, 2 * G4, N), _empty(d, 2 * G4)
         dev.lstm_cat_ih(wih_f.contiguous(), wih_r.contiguous(), bih_f, bhh_f, bih_r, bhh_r, N, wcat, bcat)
-        wih_pack = _empty(d, 2 * G4 * N)
-        dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
         pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
         lmode = dev.lstm_blk_mode(seq.nseq)
-        dev.lstm_pack(whh_f.contiguous(), whh_r.contiguous(), pack_f, pack_b, lmode)
+        whf, whr = whh_f.contiguous(), whh_r.contiguous()
+        dev.lstm_pack(whf, whr, pack_f, pack_b, lmode)
         gates, xn = _empty(d, nb, 32 * 2 * G4), _empty(d, nb, 32 * N)
-        dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=gates, bias=bcat, A_bl=xn,
-                     stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap)
         cbuf, hcat = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * 2 * H)
         cluster = dev.lstm_cluster_ok(seq, d)
-        whf, whr = whh_f.contiguous(), whh_r.contiguous()
-        if cluster:
-            dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq)
+        if dev.lstm_fuse_ok(seq.nseq, cluster):
+            # band view: the recurrence computes x W_ih^T itself from the normalised input (BL(128)): the 16E-byte
+            # pre-activation buffer is never written and read back (lstm_fused.hip)
+            dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, stats=stats, gamma=norm_w,
+                         beta=norm_b, stat_map=smap)
+            fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
+            dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), whf, whr, fpack)
+            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq)
         else:
-            dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode)
+            wih_pack = _empty(d, 2 * G4 * N)
+            dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
+            dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=gates, bias=bcat, A_bl=xn,
+                         stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap)
+            if cluster:
+                dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq)
+            else:
+                dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode)
         pw = proj_w.contiguous()
         proj_pack = _empty(d, N * 2 * H)
         dev.pack_w(pw, N, 2 * H, 2 * H, proj_pack, order=1)
