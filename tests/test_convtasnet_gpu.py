@@ -377,3 +377,40 @@ def test_spexplus_joint_training_loss_gradients_fp32(monkeypatch):
     assert abs(loss.item() - float(g["loss"])) < DB_TOL
     for k, prm in model.named_parameters():
         assert abs(float(prm.grad.norm()) - float(g["gnorm/" + k])) <= 3e-3 * float(g["gnorm/" + k]) + floor, k
+
+
+@pytest.mark.parametrize("R,T", [(1, 1234), (3, 167), (2, 20)])
+def test_ragged_lengths_and_single_row(R, T):
+    """Edge cases of the reference's framing: T not a multiple of the stride (the tail that does not fill a
+    short-window frame is dropped, the middle / long windows see zero extension, encoder.py:104-111), the shortest
+    legal input (one frame), a single row and an odd row count -- forward and input-independent gradients vs the
+    oracle."""
+    from oracle import convtasnet_oracle as CT
+    d = _cuda()
+    kw = dict(N=16, L=20, B=16, H=24, P=3, X=3, R=1)
+    cfg, params, model = _build(kw, 41, d)
+    g = torch.Generator().manual_seed(R * 1000 + T)
+    wav, emb = torch.randn(R, T, generator=g) * 0.1, torch.randn(R, 256, generator=g)
+    ests = model(wav.to(d), emb.to(d))
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = CT.convtasnet_forward(p, cfg, wav, emb)
+    Tp = (T - 20) // 10 + 1
+    probes = [torch.randn(R, (Tp - 1) * 10 + 20, generator=g) for _ in range(3)]
+    for e, r in zip(ests, ref):
+        assert e.shape == r.shape == (R, (Tp - 1) * 10 + 20)
+        assert rel(e, r) < WAV_TOL
+    sum((e * q.to(d)).sum() for e, q in zip(ests, probes)).backward()
+    sum((r * q).sum() for r, q in zip(ref, probes)).backward()
+    gn = max(float(v.grad.norm()) for v in p.values())
+    for k, prm in model.named_parameters():
+        err = float((prm.grad.detach().cpu().double() - p[k].grad.double()).norm())
+        assert err <= 5e-3 * float(p[k].grad.norm()) + 1e-4 * gn, (k, err)
+
+
+def test_input_shorter_than_the_window_raises():
+    d = _cuda()
+    _, _, model = _build(dict(N=16, L=20, B=16, H=24, P=3, X=2, R=1), 42, d)
+    with pytest.raises(RuntimeError):
+        model(torch.randn(2, 12, device=d), torch.randn(2, 256, device=d))
+    with pytest.raises(RuntimeError):
+        model(torch.randn(2, 3, 100, device=d), torch.randn(2, 256, device=d))
