@@ -225,38 +225,59 @@ __global__ void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* 
 }
 
 // slab[split][p][c] = sum_{rows of split} dy[m][c] * xn[m + (p - ctr) * dil][c]  (p < P);  slab[split][P][c] = sum dy
-// One thread = one channel quad, rows of the split walked in order (coalesced along C).
-__global__ void dwconv_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                    const float* __restrict__ stats, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, DwGeom g, int rows_per_split,
-                                    float* __restrict__ slab) {
+// threadIdx.x = channel quad (coalesced along C), threadIdx.y = row lane: the split's rows are dealt round-robin
+// to the row lanes, whose partial sums meet in LDS in fixed order.
+#define DW_RY 4
+__global__ __launch_bounds__(1024) void dwconv_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, DwGeom g,
+                                                            int rows_per_split, float* __restrict__ slab) {
+  extern __shared__ f32x4 dw_part[];  // [DW_RY - 1][P + 1][blockDim.x]
   const int c = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
-  if (c >= g.C) return;
-  const int split = blockIdx.x;
+  const bool live = c < g.C;
+  const int cc = live ? c : 0;
+  const int split = blockIdx.x, ry = threadIdx.y;
   const long long M = (long long)g.R * g.Tp;
   const long long lo = (long long)split * rows_per_split, hi = min(M, lo + rows_per_split);
   const int ctr = (g.P - 1) / 2;
-  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + cc), bt = *reinterpret_cast<const f32x4*>(beta + cc);
   f32x4 acc[TN_MAXP + 1];
 #pragma unroll
   for (int p = 0; p <= TN_MAXP; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (long long row = lo; row < hi; ++row) {
+  for (long long row = lo + ry; row < hi; row += DW_RY) {
     const int t = (int)(row % g.Tp);
-    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * g.C + c);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * g.C + cc);
     acc[TN_MAXP] += d;
 #pragma unroll
     for (int p = 0; p < TN_MAXP; ++p) {
       if (p >= g.P) break;
       const int tt = t + (p - ctr) * g.dil;
       if (tt < 0 || tt >= g.Tp) continue;
-      acc[p] += d * dw_xn(x, stats, gm, bt, g, row + (tt - t), c);
+      acc[p] += d * dw_xn(x, stats, gm, bt, g, row + (tt - t), cc);
     }
   }
-  float* o = slab + (long long)split * (g.P + 1) * g.C;
+  const int np = g.P + 1, bx = blockDim.x;
+  if (ry > 0) {
+    f32x4* o = dw_part + ((long long)(ry - 1) * np) * bx + threadIdx.x;
 #pragma unroll
-  for (int p = 0; p < TN_MAXP; ++p)
-    if (p < g.P) *reinterpret_cast<f32x4*>(o + p * g.C + c) = acc[p];
-  *reinterpret_cast<f32x4*>(o + g.P * g.C + c) = acc[TN_MAXP];
+    for (int p = 0; p < TN_MAXP; ++p)
+      if (p < g.P) o[p * bx] = acc[p];
+    o[g.P * bx] = acc[TN_MAXP];
+  }
+  __syncthreads();
+  if (ry == 0 && live) {
+    float* o = slab + (long long)split * np * g.C;
+#pragma unroll
+    for (int p = 0; p <= TN_MAXP; ++p) {
+      if (p > g.P) break;
+      f32x4 v = p < g.P ? acc[p] : acc[TN_MAXP];
+      if (p < g.P || p == g.P) {
+        for (int k = 0; k < DW_RY - 1; ++k) v += dw_part[((long long)k * np + p) * bx + threadIdx.x];
+        *reinterpret_cast<f32x4*>(o + p * g.C + c) = v;
+      }
+    }
+  }
 }
 
 static int dw_check(const char* who, int R, int Tp, int C, int P, int dil, int st_div) {
@@ -290,8 +311,9 @@ extern "C" int ws_dwconv_bwd(const float* dy, const float* x, const float* stats
   hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3(ew_blocks((long long)R * Tp * (C / 4), 256)), dim3(256), 0, s, dy, w,
                      g, dxn);
   const int threads = C / 4 >= 256 ? 256 : ((C / 4 + 63) / 64) * 64;
-  hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(nsplit, (C / 4 + threads - 1) / threads), dim3(threads), 0, s, dy, x,
-                     stats, gamma, beta, g, rows_per_split, slab);
+  const size_t lds = (size_t)(DW_RY - 1) * (P + 1) * threads * sizeof(f32x4);
+  hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(nsplit, (C / 4 + threads - 1) / threads), dim3(threads, DW_RY), lds, s,
+                     dy, x, stats, gamma, beta, g, rows_per_split, slab);
   return ws_check_launch("ws_dwconv_bwd");
 }
 
