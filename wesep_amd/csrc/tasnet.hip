@@ -271,11 +271,9 @@ __global__ __launch_bounds__(1024) void dwconv_bwd_w_kernel(const float* __restr
 #pragma unroll
     for (int p = 0; p <= TN_MAXP; ++p) {
       if (p > g.P) break;
-      f32x4 v = p < g.P ? acc[p] : acc[TN_MAXP];
-      if (p < g.P || p == g.P) {
-        for (int k = 0; k < DW_RY - 1; ++k) v += dw_part[((long long)k * np + p) * bx + threadIdx.x];
-        *reinterpret_cast<f32x4*>(o + p * g.C + c) = v;
-      }
+      f32x4 v = p < g.P ? acc[p] : acc[TN_MAXP];  // row P of the slab = bias gradient
+      for (int k = 0; k < DW_RY - 1; ++k) v += dw_part[((long long)k * np + p) * bx + threadIdx.x];
+      *reinterpret_cast<f32x4*>(o + p * g.C + c) = v;
     }
   }
 }
