@@ -181,6 +181,16 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    # MFMA-busy fraction of the same kernels from the committed SQ_VALU_MFMA_BUSY_CYCLES pass (tools/pmc_mfma_summary.py)
+    mfma_busy = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")))["kernels"]
+        hit = [v for k, v in pm.items() if dom in k]
+        n = sum(v["launches"] for v in hit)
+        mfma_busy = sum(v["mfma_busy_frac"] * v["launches"] for v in hit) / n if n else None
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
@@ -204,7 +214,8 @@ def main():
                          "ms_per_launch": prof[dom]["ms_avg"],
                          "mfma": {"alg_tflops": tfl, "executed_bf16_tflops": 3 * tfl,
                                   "peak_bf16_tflops": BF16_MFMA_PEAK_TFLOPS,
-                                  "frac_executed": 3 * tfl / BF16_MFMA_PEAK_TFLOPS}},
+                                  "frac_executed": 3 * tfl / BF16_MFMA_PEAK_TFLOPS,
+                                  "busy_frac_pmc": mfma_busy}},
             "kernel_ms_per_step": {k: v["ms_total"] / args.steps for k, v in prof.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
