@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--joint", action="store_true",
+                    help="the shipped confs/bsrnn.yaml variant: speaker encoder (wespeaker ResNet34 on 80-d fbank, "
+                         "398 frames) trained jointly instead of fixed 256-d embeddings; not the headline line")
     args = ap.parse_args()
 
     from wesep_amd import dev
@@ -113,7 +116,11 @@ def main():
     d = torch.device("cuda", local_rank)
 
     torch.manual_seed(0)                      # identical default-init weights on every rank
-    model = get_model("BSRNN")(**MODEL_KW)
+    kw = dict(MODEL_KW)
+    if args.joint:
+        kw.update(joint_training=True, spk_model="ResNet34", spk_feat=True,
+                  spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
+    model = get_model("BSRNN")(**kw)
     with torch.no_grad():                     # FiLM is zero-init in the reference; make it do work
         for mod in model.separator.separation:
             if hasattr(mod, "fc") and hasattr(mod.fc, "gamma_fcs"):
@@ -127,6 +134,9 @@ def main():
     crit = parse_loss("SISDR")[0]
     R = args.rows
     wav, tgt, emb = (t.to(d) for t in synth_batch(R, T, rank_seed(42, rank)))
+    if args.joint:                            # fbank-like enrollment [R, 398, 80], CMN'd
+        fb = torch.randn(R, 398, 80, generator=torch.Generator().manual_seed(rank_seed(43, rank)))
+        emb = (fb - fb.mean(1, keepdim=True)).to(d)
 
     def step(i):
         sched.step(i)
@@ -199,8 +209,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3",
             "data": "synthetic",
-            "config": {"workload": "pBSRNN FiLM multi-fuse, 6 repeats, feature_dim 128, fixed 256-d "
-                                   "embeddings; fwd + SI-SDR + bwd + per-tensor clip + Adam-L2; split-bf16 "
+            "config": {"workload": "pBSRNN FiLM multi-fuse, 6 repeats, feature_dim 128, " +
+                                   ("jointly trained wespeaker ResNet34 speaker encoder on [R, 398, 80] fbank"
+                                    if args.joint else "fixed 256-d embeddings") +
+                                   "; fwd + SI-SDR + bwd + per-tensor clip + Adam-L2; split-bf16 "
                                    "products (3 bf16 MFMAs), fp32 accumulate + storage",
                        "rows_per_gpu": R, "global_rows": world * R, "samples_per_row": T,
                        "parallelism": f"dp{world}", "final_loss_dB": final_loss},

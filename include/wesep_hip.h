@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 4
+#define WS_ABI_VERSION 5
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -425,6 +425,20 @@ typedef struct ws_lstm_fused_args {
 int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
                        float* pack, void* stream);
 int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream);
+
+/* ---- wespeaker ResNet speaker encoder (third-party model, call sites
+ * wesep/models/bsrnn.py:9,217,352-356), channels-last [R][H][W][C] ------------------------------------------
+ * conv2d(k x k, stride s, padding p, bias-free) = ws_im2col + ws_gemm_nt (K = k*k*C); input gradient =
+ * ws_gemm_nt + ws_col2im (gather, deterministic); weight gradient = ws_gemm_tn on the patch matrix.
+ * patches [R*Ho*Wo][ldp], column (ky*k + kx)*C + c; Ho = (H + 2p - k)/s + 1.  C == 1 or C % 4 == 0
+ * (then ldp == k*k*C).  BatchNorm2d / ReLU / residual are the channels-last ws_bn_* / ws_prelu_* entry points. */
+int ws_im2col(const float* x, int R, int H, int W, int C, int k, int s, int p, long long ldp, float* patches,
+              void* stream);
+int ws_col2im(const float* dpatches, int R, int H, int W, int C, int k, int s, int p, float* dx, void* stream);
+/* TSTP pooling: x [R][F][T][C] -> stats [R][2][C*F] = (mean over T, sqrt(unbiased var + eps)), feature c*F + f */
+int ws_tstp_fwd(const float* x, int R, int F, int T, int C, float eps, float* stats, void* stream);
+int ws_tstp_bwd(const float* x, const float* stats, const float* dstats, int R, int F, int T, int C, float* dx,
+                void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,114 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU fp32 restatement of the wespeaker ResNet speaker encoder that wesep trains
+jointly with the separator.
+
+**Parity unpinned.**  The model lives in the third-party package `wespeaker` (`wespeaker.models.speaker_model
+.get_speaker_model`, imported at `wesep/models/bsrnn.py:9`, instantiated at `:217` with `spk_args` from
+`confs/bsrnn.yaml:58-64`: ResNet34, feat_dim 80, embed_dim 256, pooling TSTP, two_emb_layer False); the package is
+neither vendored under /root/reference nor pinned (`requirements.txt` does not list it) and is absent from this
+image, so there is no reference output to generate fixtures from.  This file restates the published architecture
+(wespeaker/models/resnet.py, pooling_layers.py -- from the upstream source as recalled):
+
+  x [B, T, F] -> permute -> [B, 1, F, T]
+  conv1 3x3(1 -> m) + BN + ReLU;  layer1..4 of BasicBlock(planes m, 2m, 4m, 8m; first stride 1, 2, 2, 2):
+      BasicBlock: conv3x3(stride) - BN - ReLU - conv3x3 - BN, + shortcut (1x1 conv(stride) + BN when the shape
+      changes), ReLU;  all convolutions bias-free
+  TSTP: mean over T and sqrt(unbiased var over T + 1e-7) of [B, C*F', T'], concatenated
+  seg_1 Linear(2 * C * F' -> embed_dim);  two_emb_layer False: returns (tensor(0.), embed_a)
+
+The HIP path is tested against this restatement; parameter names follow the upstream module tree so that wespeaker
+checkpoints (`spk_model_init`) load.  Only tests/ may import this module."""
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+NUM_BLOCKS = {"ResNet18": (2, 2, 2, 2), "ResNet34": (3, 4, 6, 3)}
+
+
+def _blocks(num_blocks, m):
+    """(prefix, in_planes, planes, stride) of every BasicBlock in order."""
+    out, inp = [], m
+    for li, (n, planes, stride) in enumerate(zip(num_blocks, (m, 2 * m, 4 * m, 8 * m), (1, 2, 2, 2)), start=1):
+        for bi in range(n):
+            out.append((f"layer{li}.{bi}.", inp, planes, stride if bi == 0 else 1))
+            inp = planes
+    return out
+
+
+def _bn_shapes(s, name, c):
+    s[name + ".weight"] = (c,)
+    s[name + ".bias"] = (c,)
+    s[name + ".running_mean"] = (c,)
+    s[name + ".running_var"] = (c,)
+    s[name + ".num_batches_tracked"] = ()
+
+
+def param_shapes(num_blocks=(3, 4, 6, 3), m=32, feat_dim=80, embed_dim=256, prefix="") -> Dict[str, tuple]:
+    s: Dict[str, tuple] = {}
+    s[prefix + "conv1.weight"] = (m, 1, 3, 3)
+    _bn_shapes(s, prefix + "bn1", m)
+    for q, inp, planes, stride in _blocks(num_blocks, m):
+        q = prefix + q
+        s[q + "conv1.weight"] = (planes, inp, 3, 3)
+        _bn_shapes(s, q + "bn1", planes)
+        s[q + "conv2.weight"] = (planes, planes, 3, 3)
+        _bn_shapes(s, q + "bn2", planes)
+        if stride != 1 or inp != planes:
+            s[q + "shortcut.0.weight"] = (planes, inp, 1, 1)
+            _bn_shapes(s, q + "shortcut.1", planes)
+    stats_dim = (feat_dim // 8) * m * 8
+    s[prefix + "seg_1.weight"] = (embed_dim, 2 * stats_dim)
+    s[prefix + "seg_1.bias"] = (embed_dim,)
+    return s
+
+
+def is_buffer(name: str) -> bool:
+    return name.endswith(("running_mean", "running_var", "num_batches_tracked"))
+
+
+def synth_params(seed: int, **kw) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, shp in param_shapes(**kw).items():
+        if k.endswith("running_mean"):
+            v = torch.zeros(shp)
+        elif k.endswith("running_var"):
+            v = torch.ones(shp)
+        elif k.endswith("num_batches_tracked"):
+            v = torch.zeros(shp, dtype=torch.long)
+        elif ".bn" in k or "bn1." in k or "shortcut.1" in k:
+            v = (1.0 + 0.1 * torch.randn(shp, generator=g)) if k.endswith("weight") else 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith("bias"):
+            v = 0.05 * torch.randn(shp, generator=g)
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            v = torch.randn(shp, generator=g) * (2.0 / fan_in) ** 0.5
+        out[k] = v
+    return out
+
+
+def resnet_forward(p, x, num_blocks=(3, 4, 6, 3), m=32, prefix="", training=True, new_buffers=None):
+    """x [B, T, F] -> embed_a [B, embed_dim]."""
+    def bn(name, y):
+        rm, rv = p[name + ".running_mean"].clone(), p[name + ".running_var"].clone()
+        out = F.batch_norm(y, rm, rv, p[name + ".weight"], p[name + ".bias"], training, BN_MOMENTUM, BN_EPS)
+        if new_buffers is not None and training:
+            new_buffers[name + ".running_mean"], new_buffers[name + ".running_var"] = rm, rv
+        return out
+    y = x.permute(0, 2, 1).unsqueeze(1)
+    y = F.relu(bn(prefix + "bn1", F.conv2d(y, p[prefix + "conv1.weight"], padding=1)))
+    for q, inp, planes, stride in _blocks(num_blocks, m):
+        q = prefix + q
+        o = F.relu(bn(q + "bn1", F.conv2d(y, p[q + "conv1.weight"], stride=stride, padding=1)))
+        o = bn(q + "bn2", F.conv2d(o, p[q + "conv2.weight"], padding=1))
+        sc = y
+        if (q + "shortcut.0.weight") in p:
+            sc = bn(q + "shortcut.1", F.conv2d(y, p[q + "shortcut.0.weight"], stride=stride))
+        y = F.relu(o + sc)
+    mean = y.mean(-1)
+    std = torch.sqrt(torch.var(y, dim=-1) + 1e-7)
+    stats = torch.cat((mean.flatten(1), std.flatten(1)), 1)
+    return F.linear(stats, p[prefix + "seg_1.weight"], p[prefix + "seg_1.bias"])

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 4
+ABI_VERSION = 5
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
@@ -155,6 +155,10 @@ _SIGS = {
     "ws_maxpool3_bwd": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "ws_bcast_rows": (_i, [_p, C.c_float, _i, _ll, _i, _p, _p]),
     "ws_cross_entropy": (_i, [_p, _p, _i, _i, _p, _p, _p]),
+    "ws_im2col": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _ll, _p, _p]),
+    "ws_col2im": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_tstp_fwd": (_i, [_p, _i, _i, _i, _i, C.c_float, _p, _p]),
+    "ws_tstp_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "ws_lstm_pack_fused": (_i, [_p, _p, _p, _p, _p, _p]),
     "ws_lstm_fwd_fused": (_i, [C.POINTER(LstmFusedArgs), _p]),
     "ws_grad_norms": (_i, [_p, _i, _p, _p]),

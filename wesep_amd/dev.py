@@ -714,3 +714,32 @@ def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm: SeqMap):
     a.gates, a.cbuf, a.hcat, a.xn, a.wpack, a.bias = _p(gates), _p(cbuf), _p(hcat), _p(xn), _p(wpack), _p(bias)
     a.nseq, a.L = sm.nseq, sm.L
     L.check(L.lib().ws_lstm_fwd_fused(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_fused")
+
+
+# ---- 2-D convolution pieces (conv2d.hip) -------------------------------------------------------------
+def conv_out(n: int, k: int, s: int, p: int) -> int:
+    return (n + 2 * p - k) // s + 1
+
+
+def im2col(x, R: int, H: int, W: int, Cc: int, k: int, s: int, p: int, patches, ldp: int):
+    _chk(x, "x")
+    _chk(patches, "patches")
+    _call("ws_im2col", _p(x), R, H, W, Cc, k, s, p, ldp, _p(patches))
+
+
+def col2im(dpatches, R: int, H: int, W: int, Cc: int, k: int, s: int, p: int, dx):
+    _chk(dpatches, "dpatches")
+    _chk(dx, "dx")
+    _call("ws_col2im", _p(dpatches), R, H, W, Cc, k, s, p, _p(dx))
+
+
+def tstp_fwd(x, R: int, F: int, T: int, Cc: int, stats, eps=1e-7):
+    _chk(x, "x")
+    _chk(stats, "stats")
+    _call("ws_tstp_fwd", _p(x), R, F, T, Cc, eps, _p(stats))
+
+
+def tstp_bwd(x, stats, dstats, R: int, F: int, T: int, Cc: int, dx):
+    for n, t in (("x", x), ("stats", stats), ("dstats", dstats), ("dx", dx)):
+        _chk(t, n)
+    _call("ws_tstp_bwd", _p(x), _p(stats), _p(dstats), R, F, T, Cc, _p(dx))

@@ -106,10 +106,11 @@ class BSRNN(nn.Module):
             raise NotImplementedError("wesep_amd STFT kernels are built for win=512, stride=128")
         if feature_dim != 128:
             raise NotImplementedError("wesep_amd LSTM kernels are built for feature_dim=128 (hidden 256)")
-        if joint_training:
+        if joint_training and not spk_feat:
             raise NotImplementedError(
-                "joint_training=True needs the wespeaker speaker encoder (SURVEY.md section 8 row a12), "
-                "which is not built yet; pass joint_training=False with [R, spk_emb_dim] embeddings")
+                "joint_training=True with spk_feat=False needs the in-model fbank front-end (SURVEY.md section 8 "
+                "row a13), which is not built; feed fbank features (spk_feat=True, the shipped configs) or fixed "
+                "embeddings (joint_training=False)")
         self.sr, self.win, self.stride = sr, win, stride
         self.group = win // 2
         self.enc_dim = win // 2 + 1
@@ -129,6 +130,25 @@ class BSRNN(nn.Module):
             raise NotImplementedError("band wider than 64 bins")
 
         self.spk_transform = SpeakerTransform() if use_spk_transform else nn.Identity()
+
+        if joint_training:                  # bsrnn.py:216-250, registration order of the reference
+            from .resnet import get_speaker_model
+            self.spk_model = get_speaker_model(spk_model)(**(spk_args or {}))
+            if spk_model_init:
+                pretrained = torch.load(spk_model_init, map_location="cpu")
+                state = self.spk_model.state_dict()
+                for key in state.keys():
+                    if key in pretrained.keys():
+                        state[key] = pretrained[key]
+                    else:
+                        print("not %s loaded" % key)
+                self.spk_model.load_state_dict(state)
+            if spk_model_freeze:
+                for param in self.spk_model.parameters():
+                    param.requires_grad = False
+            self.preEmphasis = nn.Identity()
+            self.spk_encoder = nn.Identity()
+            self.pred_linear = nn.Linear(spk_emb_dim, spksInTrain) if multi_task else nn.Identity()
 
         self.BN = nn.ModuleList([
             nn.Sequential(nn.GroupNorm(1, b * 2, self.eps), nn.Conv1d(b * 2, feature_dim, 1))
@@ -164,13 +184,19 @@ class BSRNN(nn.Module):
         return self._plans[key]
 
     def forward(self, input, embeddings):
-        """input: mixture [R, T] fp32; embeddings: [R, spk_emb_dim] -> (est [R, T], 0-d dummy)."""
+        """input: mixture [R, T] fp32; embeddings: [R, spk_emb_dim] (fixed) or fbank [R, Te, 80] (joint training)
+        -> (est [R, T], 0-d dummy or speaker logits)."""
         if input.dim() != 2:
             raise RuntimeError("BSRNN expects a [batch, samples] mixture")
         wav = input.float().contiguous()
         plan = self._plan(wav.device)
         z, xbs = F_.BandSplitFn.apply(wav, plan, *self._bn_params())
         predict_speaker_lable = torch.tensor(0.0, device=wav.device)  # dummy, bsrnn.py:339-340
+        if self.joint_training:             # fbank [R, Te, F] -> wespeaker encoder -> embedding (bsrnn.py:341-357)
+            out = self.spk_model(embeddings.float().contiguous())
+            embeddings = out[-1] if isinstance(out, tuple) else out
+            if self.multi_task:
+                predict_speaker_lable = F_.LinearFn.apply(embeddings, self.pred_linear.weight, self.pred_linear.bias)
         e = self.spk_transform(embeddings.float().contiguous())
         z = self.separator(z, e)
         est = F_.MaskDecodeFn.apply(z, xbs, plan, wav.shape[1], *self._mask_params())

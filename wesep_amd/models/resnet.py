@@ -1,0 +1,120 @@
+"""wespeaker ResNet speaker encoder on MI355X: module tree and `state_dict` keys of
+`wespeaker.models.resnet.ResNet` (BasicBlock variants: ResNet18 / ResNet34), so `spk_model_init` checkpoints load.
+The package itself is a third-party dependency absent from the reference tree: parity is against the restatement in
+oracle/resnet_oracle.py and is UNPINNED.  nn.Conv2d / nn.BatchNorm2d / nn.Linear objects are parameter
+containers only; forward is a chain of C-ABI launches (wesep_amd/functional_resnet.py)."""
+import torch
+import torch.nn as nn
+
+from .. import functional_resnet as FR
+from ..functional import LinearFn
+
+
+class TSTP(nn.Module):
+    """Temporal statistics pooling (no parameters)."""
+
+    def __init__(self, in_dim=0, **kwargs):
+        super().__init__()
+        self.in_dim = in_dim
+
+    def get_out_dim(self):
+        return self.in_dim * 2
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, in_planes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_planes != self.expansion * planes:
+            self.shortcut = nn.Sequential(
+                nn.Conv2d(in_planes, self.expansion * planes, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(self.expansion * planes))
+        self.stride = stride
+
+
+def _cba(x, res, R, H, W, stride, relu, conv, bn, training):
+    if training:
+        bn.num_batches_tracked += 1
+    return FR.ConvBnActFn.apply(x, res, (R, H, W, stride, relu, training), conv.weight, bn.weight, bn.bias,
+                                bn.running_mean, bn.running_var)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, num_blocks, m_channels=32, feat_dim=40, embed_dim=128, pooling_func="TSTP",
+                 two_emb_layer=True):
+        super().__init__()
+        if block is not BasicBlock:
+            raise NotImplementedError("wespeaker Bottleneck ResNets (50/101/152) are not built; ResNet18/34 are")
+        if pooling_func != "TSTP":
+            raise NotImplementedError(f"pooling_func {pooling_func!r}: only TSTP is built")
+        if two_emb_layer:
+            raise NotImplementedError("two_emb_layer=True is not built (wesep's configs use False)")
+        self.in_planes, self.feat_dim, self.embed_dim = m_channels, feat_dim, embed_dim
+        self.stats_dim = int(feat_dim / 8) * m_channels * 8
+        self.two_emb_layer = two_emb_layer
+        self.conv1 = nn.Conv2d(1, m_channels, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(m_channels)
+        self.layer1 = self._make_layer(block, m_channels, num_blocks[0], stride=1)
+        self.layer2 = self._make_layer(block, m_channels * 2, num_blocks[1], stride=2)
+        self.layer3 = self._make_layer(block, m_channels * 4, num_blocks[2], stride=2)
+        self.layer4 = self._make_layer(block, m_channels * 8, num_blocks[3], stride=2)
+        self.pool = TSTP(in_dim=self.stats_dim * block.expansion)
+        self.pool_out_dim = self.pool.get_out_dim()
+        self.seg_1 = nn.Linear(self.pool_out_dim, embed_dim)
+        self.seg_bn_1 = nn.Identity()
+        self.seg_2 = nn.Identity()
+
+    def _make_layer(self, block, planes, num_blocks, stride):
+        layers = []
+        for s in [stride] + [1] * (num_blocks - 1):
+            layers.append(block(self.in_planes, planes, s))
+            self.in_planes = planes * block.expansion
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        """x [R, T, F] fbank -> (tensor(0.), embed_a [R, embed_dim])  (two_emb_layer=False contract)."""
+        if not x.is_cuda:
+            from .._lib import WesepHipError
+            raise WesepHipError("ResNet speaker encoder: wesep_amd has no CPU path")
+        R, T, Fq = x.shape
+        tr = self.training
+        y = x.float().transpose(1, 2).contiguous().view(R * Fq * T, 1)      # [R, F, T, 1]
+        H, W = Fq, T
+        y = _cba(y, None, R, H, W, 1, True, self.conv1, self.bn1, tr)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                s = blk.stride
+                Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+                o = _cba(y, None, R, H, W, s, True, blk.conv1, blk.bn1, tr)
+                sc = y
+                if len(blk.shortcut) > 0:
+                    sc = _cba(y, None, R, H, W, s, False, blk.shortcut[0], blk.shortcut[1], tr)
+                y = _cba(o, sc, R, Ho, Wo, 1, True, blk.conv2, blk.bn2, tr)
+                H, W = Ho, Wo
+        stats = FR.TstpFn.apply(y, (R, H, W))
+        embed_a = LinearFn.apply(stats, self.seg_1.weight, self.seg_1.bias)
+        return torch.tensor(0.0), embed_a
+
+
+def ResNet18(feat_dim, embed_dim, pooling_func="TSTP", two_emb_layer=True):
+    return ResNet(BasicBlock, [2, 2, 2, 2], feat_dim=feat_dim, embed_dim=embed_dim, pooling_func=pooling_func,
+                  two_emb_layer=two_emb_layer)
+
+
+def ResNet34(feat_dim, embed_dim, pooling_func="TSTP", two_emb_layer=True):
+    return ResNet(BasicBlock, [3, 4, 6, 3], feat_dim=feat_dim, embed_dim=embed_dim, pooling_func=pooling_func,
+                  two_emb_layer=two_emb_layer)
+
+
+def get_speaker_model(model_name: str):
+    """`wespeaker.models.speaker_model.get_speaker_model` for the encoders built here."""
+    if model_name in ("ResNet18", "ResNet34"):
+        return {"ResNet18": ResNet18, "ResNet34": ResNet34}[model_name]
+    raise NotImplementedError(f"speaker model {model_name!r}: only the wespeaker BasicBlock ResNets (ResNet18, "
+                              "ResNet34) are built (SURVEY.md section 8 row a12)")
