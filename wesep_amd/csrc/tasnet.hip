@@ -565,34 +565,62 @@ extern "C" int ws_sum_partial(const float* x, long long n, float* slab, int nsla
 // SpEx+ speaker encoder pieces (wesep/modules/tasnet/speaker.py:7-64), channels-last [M][C]
 // =============================================================================================
 
+// Column reductions over M rows of a channels-last [M][C] tensor.  A 256-thread workgroup = LX channel quads
+// (LX = C/4 rounded up to a power of two, <= 256) x RY = 256/LX row lanes: with C = 32 (the first ResNet stage,
+// 1 M rows) a one-thread-per-quad layout would leave 7/8 of every wave idle.  A wave reads 64/LX consecutive
+// rows = one contiguous KB; the row lanes meet in LDS in fixed order.
+__device__ __forceinline__ int bn_lx(int C) {
+  int lx = 1;
+  while (lx < (C >> 2)) lx <<= 1;
+  return lx > 256 ? 256 : lx;
+}
+
 // slab[split][c] = sum over the split's rows of (shift ? (x - shift[c])^2 : x)
-__global__ void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ shift, long long M, int C,
-                                  int rows_per_split, float* __restrict__ slab) {
-  const int c = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                         long long M, int C, int rows_per_split,
+                                                         float* __restrict__ slab) {
+  __shared__ f32x4 part[256];
+  const int LX = bn_lx(C), RY = 256 / LX;
+  const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
+  const int c = (blockIdx.y * LX + lx) * 4;
+  const bool live = c < C;
+  const int cc = live ? c : 0;
   const long long lo = (long long)blockIdx.x * rows_per_split, hi = min(M, lo + rows_per_split);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (shift) {
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
-    for (long long r = lo; r < hi; ++r) {
-      const f32x4 d = *reinterpret_cast<const f32x4*>(x + r * C + c) - sh;
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + cc);
+    for (long long r = lo + ly; r < hi; r += RY) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(x + r * C + cc) - sh;
       s += d * d;
     }
   } else {
-    for (long long r = lo; r < hi; ++r) s += *reinterpret_cast<const f32x4*>(x + r * C + c);
+    for (long long r = lo + ly; r < hi; r += RY) s += *reinterpret_cast<const f32x4*>(x + r * C + cc);
   }
-  *reinterpret_cast<f32x4*>(slab + (long long)blockIdx.x * C + c) = s;
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (ly == 0 && live) {
+    for (int k = 1; k < RY; ++k) s += part[k * LX + lx];
+    *reinterpret_cast<f32x4*>(slab + (long long)blockIdx.x * C + c) = s;
+  }
 }
 
 // phase 0: stats[0][c] = mean.  phase 1: stats[1][c] = 1/sqrt(var + eps) and the running statistics
-// (nn.BatchNorm1d training mode: biased variance normalises, unbiased variance is tracked)
-__global__ void bn_final_kernel(const float* __restrict__ slab, int nsplit, int C, long long M, int phase, float eps,
-                                float momentum, float* __restrict__ stats, float* running_mean,
-                                float* running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// (nn.BatchNorm training mode: biased variance normalises, unbiased variance is tracked).
+// 64 channels x 4 split lanes per workgroup.
+__global__ __launch_bounds__(256) void bn_final_kernel(const float* __restrict__ slab, int nsplit, int C, long long M,
+                                                       int phase, float eps, float momentum,
+                                                       float* __restrict__ stats, float* running_mean,
+                                                       float* running_var) {
+  __shared__ float part[4][64];
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + x;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += slab[(long long)k * C + c];
+  if (c < C)
+    for (int k = y; k < nsplit; k += 4) s += slab[(long long)k * C + c];
+  part[y][x] = s;
+  __syncthreads();
+  if (y != 0 || c >= C) return;
+  s = (part[0][x] + part[1][x]) + (part[2][x] + part[3][x]);
   if (phase == 0) {
     stats[c] = s / (float)M;
   } else {
@@ -611,13 +639,15 @@ extern "C" int ws_bn_stats(const float* x, long long M, int C, float eps, float 
              "ws_bn_stats: bad args");
   hipStream_t s = (hipStream_t)stream;
   const int rps = (int)((M + nsplit - 1) / nsplit);
-  const int threads = C / 4 >= 256 ? 256 : ((C / 4 + 63) / 64) * 64;
-  const dim3 grid(nsplit, (C / 4 + threads - 1) / threads);
-  hipLaunchKernelGGL(bn_partial_kernel, grid, dim3(threads), 0, s, x, (const float*)nullptr, M, C, rps, scratch);
-  hipLaunchKernelGGL(bn_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, nsplit, C, M, 0, eps, momentum,
+  int lx = 1;
+  while (lx < C / 4) lx <<= 1;
+  if (lx > 256) lx = 256;
+  const dim3 grid(nsplit, (C / 4 + lx - 1) / lx);
+  hipLaunchKernelGGL(bn_partial_kernel, grid, dim3(256), 0, s, x, (const float*)nullptr, M, C, rps, scratch);
+  hipLaunchKernelGGL(bn_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, nsplit, C, M, 0, eps, momentum,
                      stats, running_mean, running_var);
-  hipLaunchKernelGGL(bn_partial_kernel, grid, dim3(threads), 0, s, x, (const float*)stats, M, C, rps, scratch);
-  hipLaunchKernelGGL(bn_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, nsplit, C, M, 1, eps, momentum,
+  hipLaunchKernelGGL(bn_partial_kernel, grid, dim3(256), 0, s, x, (const float*)stats, M, C, rps, scratch);
+  hipLaunchKernelGGL(bn_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, nsplit, C, M, 1, eps, momentum,
                      stats, running_mean, running_var);
   return ws_check_launch("ws_bn_stats");
 }
@@ -655,22 +685,36 @@ extern "C" int ws_bn_prelu_fwd(const float* x, const float* stats, const float* 
 }
 
 // slab[split][0][c] = sum du, slab[split][1][c] = sum du * xhat,  xhat = (x - mean_c) * rstd_c
-__global__ void bn_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ du,
-                                   const float* __restrict__ stats, long long M, int C, int rows_per_split,
-                                   float* __restrict__ slab) {
-  const int c = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
-  if (c >= C) return;
+// (same LX x RY workgroup shape as bn_partial_kernel)
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ du,
+                                                          const float* __restrict__ stats, long long M, int C,
+                                                          int rows_per_split, float* __restrict__ slab) {
+  __shared__ f32x4 part[2][256];
+  const int LX = bn_lx(C), RY = 256 / LX;
+  const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
+  const int c = (blockIdx.y * LX + lx) * 4;
+  const bool live = c < C;
+  const int cc = live ? c : 0;
   const long long lo = (long long)blockIdx.x * rows_per_split, hi = min(M, lo + rows_per_split);
-  const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + c), rstd = *reinterpret_cast<const f32x4*>(stats + C + c);
+  const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + cc), rstd = *reinterpret_cast<const f32x4*>(stats + C + cc);
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-  for (long long r = lo; r < hi; ++r) {
-    const f32x4 d = *reinterpret_cast<const f32x4*>(du + r * C + c);
+  for (long long r = lo + ly; r < hi; r += RY) {
+    const f32x4 d = *reinterpret_cast<const f32x4*>(du + r * C + cc);
     s0 += d;
-    s1 += d * ((*reinterpret_cast<const f32x4*>(x + r * C + c) - mean) * rstd);
+    s1 += d * ((*reinterpret_cast<const f32x4*>(x + r * C + cc) - mean) * rstd);
   }
-  float* o = slab + (long long)blockIdx.x * 2 * C;
-  *reinterpret_cast<f32x4*>(o + c) = s0;
-  *reinterpret_cast<f32x4*>(o + C + c) = s1;
+  part[0][threadIdx.x] = s0;
+  part[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (ly == 0 && live) {
+    for (int k = 1; k < RY; ++k) {
+      s0 += part[0][k * LX + lx];
+      s1 += part[1][k * LX + lx];
+    }
+    float* o = slab + (long long)blockIdx.x * 2 * C;
+    *reinterpret_cast<f32x4*>(o + c) = s0;
+    *reinterpret_cast<f32x4*>(o + C + c) = s1;
+  }
 }
 
 // dx = gamma * rstd * (du - sums[0]/M - xhat * sums[1]/M)     (dx may alias du)
@@ -698,9 +742,11 @@ extern "C" int ws_bn_bwd(const float* x, const float* du, const float* stats, co
              "ws_bn_bwd: bad args");
   hipStream_t s = (hipStream_t)stream;
   const int rps = (int)((M + nsplit - 1) / nsplit);
-  const int threads = C / 4 >= 256 ? 256 : ((C / 4 + 63) / 64) * 64;
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(nsplit, (C / 4 + threads - 1) / threads), dim3(threads), 0, s, x, du,
-                     stats, M, C, rps, slab);
+  int lx = 1;
+  while (lx < C / 4) lx <<= 1;
+  if (lx > 256) lx = 256;
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(nsplit, (C / 4 + lx - 1) / lx), dim3(256), 0, s, x, du, stats, M, C, rps,
+                     slab);
   int rc = ws_reduce_slabs(slab, nsplit, 2LL * C, 2LL * C, sums, 0, 0, stream);
   if (rc != WS_OK) return rc;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * (C / 4), 256)), dim3(256), 0, s, x, du, stats, gamma,

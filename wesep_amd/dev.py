@@ -636,7 +636,7 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1  # nn.BatchNorm1d defaults
 
 
 def _bn_splits(M: int):
-    return max(1, min(256, M // 32))
+    return max(1, min(512, M // 256))
 
 
 def bn_stats(x, M: int, Cc: int, running_mean, running_var, stats, eps=BN_EPS, momentum=BN_MOMENTUM):
