@@ -440,6 +440,15 @@ int ws_tstp_fwd(const float* x, int R, int F, int T, int C, float eps, float* st
 int ws_tstp_bwd(const float* x, const float* stats, const float* dstats, int R, int F, int T, int C, float* dx,
                 void* stream);
 
+/* ---- in-model enrollment front-end (bsrnn.py:231-242,343-350) -------------------
+ * out[r][j] = y[reflect(j - pad)], y = pre-emphasis of x (speaker.py:10-23), row stride ldo >= T + 2*pad:
+ * the centred, reflect-padded signal whose hop-strided row views are the STFT frames.                     */
+int ws_preemph_pad(const float* x, int R, int T, int pad, int ldo, float coef, float* out, void* stream);
+/* p[m][f] = re^2 + im^2 of interleaved spectra [M][lds] (nf bins); columns nf..ldp-1 zeroed               */
+int ws_power_spec(const float* spec, long long M, int nf, int lds, int ldp, float* p, void* stream);
+/* x = log(x + eps) in place                                                                               */
+int ws_log_eps(float* x, long long n, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,3 +112,31 @@ def resnet_forward(p, x, num_blocks=(3, 4, 6, 3), m=32, prefix="", training=True
     std = torch.sqrt(torch.var(y, dim=-1) + 1e-7)
     stats = torch.cat((mean.flatten(1), std.flatten(1)), 1)
     return F.linear(stats, p[prefix + "seg_1.weight"], p[prefix + "seg_1.bias"])
+
+
+# ---- in-model fbank front-end (bsrnn.py:231-242,343-350) ----------------------------
+def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale="htk"), restated (torchaudio is absent: unpinned)."""
+    import math
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    return torch.max(torch.zeros(1), torch.min((-1.0 * slopes[:, :-2]) / f_diff[:-1], slopes[:, 2:] / f_diff[1:]))
+
+
+def fbank_frontend(wav, sr=16000, n_fft=512, hop=128, n_mels=80, f_min=20.0, coef=0.97):
+    """PreEmphasis (speaker.py:10-23, reference code) -> MelSpectrogram (torchaudio defaults: centre, reflect,
+    power 2, HTK, no norm) -> log(+1e-8) -> minus the time mean -> [R, Tf, n_mels]  (bsrnn.py:343-350)."""
+    x = F.pad(wav.unsqueeze(1), (1, 0), "reflect")
+    y = F.conv1d(x, torch.tensor([[[-coef, 1.0]]])).squeeze(1)
+    spec = torch.stft(y, n_fft, hop, n_fft, window=torch.hamming_window(n_fft), center=True, pad_mode="reflect",
+                      normalized=False, onesided=True, return_complex=True).abs().pow(2.0)
+    fb = melscale_fbanks(n_fft // 2 + 1, f_min, float(sr // 2), n_mels, sr)
+    mel = torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)       # [R, n_mels, Tf]
+    feat = (mel + 1e-8).log()
+    feat = feat - feat.mean(dim=-1, keepdim=True)
+    return feat.permute(0, 2, 1)

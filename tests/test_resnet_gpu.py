@@ -159,3 +159,29 @@ def test_bsrnn_joint_training_with_resnet34_runs_and_matches_oracle():
     with pytest.raises(NotImplementedError):
         get_model("BSRNN")(joint_training=True, spk_model="ECAPA_TDNN_GLOB_c512", spk_feat=True,
                            spk_args=dict(feat_dim=80, embed_dim=192, pooling_func="ASTP"))
+
+
+def test_fbank_frontend_matches_restatement_and_joint_raw_audio_path():
+    """PreEmphasis + MelSpectrogram + log + CMN on the device against the torch.stft restatement
+    (torchaudio absent: unpinned for the MelSpectrogram half), then the spk_feat=False joint model end to end."""
+    from oracle import resnet_oracle as RO
+    from wesep_amd.models import get_model
+    from wesep_amd.modules.common.frontend import MelSpectrogram, PreEmphasis, fbank_frontend
+    d = _cuda()
+    g = torch.Generator().manual_seed(2)
+    wav = torch.randn(3, 16000, generator=g) * 0.1
+    wav[1, 4000:9000] = 0.0                                     # a silent stretch: log floor
+    pre, mel = PreEmphasis().to(d), MelSpectrogram().to(d)
+    feat = fbank_frontend(wav.to(d), pre, mel)
+    ref = RO.fbank_frontend(wav)
+    assert feat.shape == ref.shape == (3, 126, 80)
+    assert float((feat.cpu() - ref).abs().max()) < 2e-3 and rel(feat, ref) < 1e-4
+    model = get_model("BSRNN")(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                               joint_training=True, spk_model="ResNet18", spk_feat=False,
+                               spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
+    keys = list(model.state_dict().keys())
+    for k in ("preEmphasis.flipped_filter", "spk_encoder.spectrogram.window", "spk_encoder.mel_scale.fb"):
+        assert k in keys, k
+    model = model.to(d).train()
+    est, _ = model(torch.randn(2, 3000, device=d) * 0.1, wav[:2].to(d))
+    assert est.shape == (2, 3000) and torch.isfinite(est).all()

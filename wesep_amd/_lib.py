@@ -159,6 +159,9 @@ _SIGS = {
     "ws_col2im": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "ws_tstp_fwd": (_i, [_p, _i, _i, _i, _i, C.c_float, _p, _p]),
     "ws_tstp_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "ws_preemph_pad": (_i, [_p, _i, _i, _i, _i, C.c_float, _p, _p]),
+    "ws_power_spec": (_i, [_p, _ll, _i, _i, _i, _p, _p]),
+    "ws_log_eps": (_i, [_p, _ll, C.c_float, _p]),
     "ws_lstm_pack_fused": (_i, [_p, _p, _p, _p, _p, _p]),
     "ws_lstm_fwd_fused": (_i, [C.POINTER(LstmFusedArgs), _p]),
     "ws_grad_norms": (_i, [_p, _i, _p, _p]),

@@ -189,3 +189,68 @@ extern "C" int ws_tstp_bwd(const float* x, const float* stats, const float* dsta
                      stats, dstats, R, F, T, C, dx);
   return ws_check_launch("ws_tstp_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------
+// In-model enrollment front-end (wesep/models/bsrnn.py:231-242,343-350):
+// PreEmphasis (wesep/modules/common/speaker.py:10-23) + the framing half of
+// torchaudio.transforms.MelSpectrogram(n_fft = win_length = 512, hop 128, hamming, center, reflect, power 2).
+// The DFT and the mel projection are two exact-fp32 MFMA GEMMs (gemm.hip) on row views of these buffers.
+// ---------------------------------------------------------------------------------------------
+// out[r][j] = y[reflect(j - pad)],  y[i] = x[i] - coef * x[i-1]  (y[0] = x[0] - coef * x[1]: reflect pad of 1)
+__global__ void preemph_pad_kernel(const float* __restrict__ x, int R, int T, int pad, int ldo, float coef,
+                                   float* __restrict__ out) {
+  const int Tp = T + 2 * pad;
+  const long long total = (long long)R * Tp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / Tp), j = (int)(i - (long long)r * Tp);
+    int k = j - pad;
+    if (k < 0) k = -k;
+    if (k >= T) k = 2 * (T - 1) - k;
+    const float* xr = x + (long long)r * T;
+    out[(long long)r * ldo + j] = xr[k] - coef * (k > 0 ? xr[k - 1] : xr[1]);
+  }
+}
+
+// p[m][f] = re^2 + im^2 from interleaved spectra [M][2*nf (ld lds_)]; columns nf..ldp-1 of p are zeroed
+__global__ void power_spec_kernel(const float* __restrict__ spec, long long M, int nf, int lds_, int ldp,
+                                  float* __restrict__ p) {
+  const long long total = M * ldp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long m = i / ldp;
+    const int f = (int)(i - m * ldp);
+    float v = 0.f;
+    if (f < nf) {
+      const float re = spec[m * lds_ + 2 * f], im = spec[m * lds_ + 2 * f + 1];
+      v = re * re + im * im;
+    }
+    p[i] = v;
+  }
+}
+
+// x = log(x + eps), in place
+__global__ void log_eps_kernel(float* x, long long n, float eps) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    x[i] = logf(x[i] + eps);
+}
+
+extern "C" int ws_preemph_pad(const float* x, int R, int T, int pad, int ldo, float coef, float* out, void* stream) {
+  WS_REQUIRE(x && out && R > 0 && T > pad && pad >= 0 && ldo >= T + 2 * pad, "ws_preemph_pad: bad args (T > pad)");
+  hipLaunchKernelGGL(preemph_pad_kernel, dim3(cv_blocks((long long)R * (T + 2 * pad))), dim3(256), 0,
+                     (hipStream_t)stream, x, R, T, pad, ldo, coef, out);
+  return ws_check_launch("ws_preemph_pad");
+}
+
+extern "C" int ws_power_spec(const float* spec, long long M, int nf, int lds_, int ldp, float* p, void* stream) {
+  WS_REQUIRE(spec && p && M > 0 && nf > 0 && lds_ >= 2 * nf && ldp >= nf, "ws_power_spec: bad args");
+  hipLaunchKernelGGL(power_spec_kernel, dim3(cv_blocks(M * ldp)), dim3(256), 0, (hipStream_t)stream, spec, M, nf, lds_,
+                     ldp, p);
+  return ws_check_launch("ws_power_spec");
+}
+
+extern "C" int ws_log_eps(float* x, long long n, float eps, void* stream) {
+  WS_REQUIRE(x && n > 0, "ws_log_eps: bad args");
+  hipLaunchKernelGGL(log_eps_kernel, dim3(cv_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, n, eps);
+  return ws_check_launch("ws_log_eps");
+}

@@ -743,3 +743,21 @@ def tstp_bwd(x, stats, dstats, R: int, F: int, T: int, Cc: int, dx):
     for n, t in (("x", x), ("stats", stats), ("dstats", dstats), ("dx", dx)):
         _chk(t, n)
     _call("ws_tstp_bwd", _p(x), _p(stats), _p(dstats), R, F, T, Cc, _p(dx))
+
+
+# ---- in-model enrollment front-end (conv2d.hip) ---------------------------------------------------------
+def preemph_pad(x, R: int, T: int, pad: int, ldo: int, coef: float, out):
+    _chk(x, "x")
+    _chk(out, "out")
+    _call("ws_preemph_pad", _p(x), R, T, pad, ldo, coef, _p(out))
+
+
+def power_spec(spec, M: int, nf: int, lds: int, ldp: int, p):
+    _chk(spec, "spec")
+    _chk(p, "p")
+    _call("ws_power_spec", _p(spec), M, nf, lds, ldp, _p(p))
+
+
+def log_eps(x, eps: float):
+    _chk(x, "x")
+    _call("ws_log_eps", _p(x), x.numel(), eps)

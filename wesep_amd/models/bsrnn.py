@@ -106,11 +106,9 @@ class BSRNN(nn.Module):
             raise NotImplementedError("wesep_amd STFT kernels are built for win=512, stride=128")
         if feature_dim != 128:
             raise NotImplementedError("wesep_amd LSTM kernels are built for feature_dim=128 (hidden 256)")
-        if joint_training and not spk_feat:
-            raise NotImplementedError(
-                "joint_training=True with spk_feat=False needs the in-model fbank front-end (SURVEY.md section 8 "
-                "row a13), which is not built; feed fbank features (spk_feat=True, the shipped configs) or fixed "
-                "embeddings (joint_training=False)")
+        if joint_training and not spk_feat and feat_type != "consistent":
+            raise NotImplementedError("joint_training with spk_feat=False: only feat_type='consistent' exists in the "
+                                      "reference (bsrnn.py:231) and is built")
         self.sr, self.win, self.stride = sr, win, stride
         self.group = win // 2
         self.enc_dim = win // 2 + 1
@@ -146,8 +144,14 @@ class BSRNN(nn.Module):
             if spk_model_freeze:
                 for param in self.spk_model.parameters():
                     param.requires_grad = False
-            self.preEmphasis = nn.Identity()
-            self.spk_encoder = nn.Identity()
+            if not spk_feat:                # raw enrollment audio: in-model fbank front-end (bsrnn.py:231-242)
+                from ..modules.common.frontend import MelSpectrogram, PreEmphasis
+                self.preEmphasis = PreEmphasis()
+                self.spk_encoder = MelSpectrogram(sample_rate=sr, n_fft=win, win_length=win, hop_length=stride,
+                                                  f_min=20, n_mels=(spk_args or {})["feat_dim"])
+            else:
+                self.preEmphasis = nn.Identity()
+                self.spk_encoder = nn.Identity()
             self.pred_linear = nn.Linear(spk_emb_dim, spksInTrain) if multi_task else nn.Identity()
 
         self.BN = nn.ModuleList([
@@ -193,6 +197,9 @@ class BSRNN(nn.Module):
         z, xbs = F_.BandSplitFn.apply(wav, plan, *self._bn_params())
         predict_speaker_lable = torch.tensor(0.0, device=wav.device)  # dummy, bsrnn.py:339-340
         if self.joint_training:             # fbank [R, Te, F] -> wespeaker encoder -> embedding (bsrnn.py:341-357)
+            if not self.spk_feat:           # raw enrollment waveform [R, Tw] -> log-mel, CMN (no_grad, :343-350)
+                from ..modules.common.frontend import fbank_frontend
+                embeddings = fbank_frontend(embeddings, self.preEmphasis, self.spk_encoder)
             out = self.spk_model(embeddings.float().contiguous())
             embeddings = out[-1] if isinstance(out, tuple) else out
             if self.multi_task:
