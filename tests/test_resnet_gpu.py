@@ -154,7 +154,7 @@ def test_bsrnn_joint_training_with_resnet34_runs_and_matches_oracle():
     g = model.spk_model.conv1.weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.norm()) > 0
     with pytest.raises(NotImplementedError):
-        get_model("BSRNN")(joint_training=True, spk_model="ResNet34", spk_feat=False,
+        get_model("BSRNN")(joint_training=True, spk_model="ResNet34", spk_feat=False, feat_type="other",
                            spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
     with pytest.raises(NotImplementedError):
         get_model("BSRNN")(joint_training=True, spk_model="ECAPA_TDNN_GLOB_c512", spk_feat=True,
