@@ -23,6 +23,7 @@ import torch
 
 from oracle import bsrnn_oracle as O
 from oracle import convtasnet_oracle as CT
+from oracle import dpccn_oracle as DP
 from oracle.ref_import import import_reference
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -144,6 +145,48 @@ def run_tasnet_case(name, kw, R, T, seed):
     print(f"{name}: loss={loss.item():.6f} est1_rms={ests[0].pow(2).mean().sqrt().item():.4e}")
 
 
+DPCCN_CASES = {
+    # name: (DPCCNConfig kwargs, rows, T, seed) -- T >= 4352: the pyramid pooling needs >= 32 frames
+    "dpccn_multiply_r2_t4480": (dict(tcn_blocks=3, tcn_layers=1), 2, 4480, 31),
+    "dpccn_concat_xform_r2_t4352": (dict(tcn_blocks=2, tcn_layers=2, spk_fuse_type="concat", use_spk_transform=True),
+                                    2, 4352, 32),
+}
+
+
+def run_dpccn_case(name, kw, R, T, seed):
+    """DPCCN with fixed embeddings (`joint_training=False`), SI-SDR loss on the estimate."""
+    get_model = import_reference()
+    cfg = DP.DPCCNConfig(**kw)
+    ref = get_model("DPCCN")(win=cfg.win, stride=cfg.stride, spk_emb_dim=cfg.spk_emb_dim,
+                             use_spk_transform=cfg.use_spk_transform, spk_fuse_type=cfg.spk_fuse_type,
+                             feature_dim=cfg.feature_dim, tcn_dims=cfg.tcn_dims, tcn_blocks=cfg.tcn_blocks,
+                             tcn_layers=cfg.tcn_layers, pool_size=cfg.pool_size, joint_training=False)
+    params = DP.synth_params(cfg, seed)
+    ref_sd = ref.state_dict()
+    assert list(ref_sd.keys()) == list(params.keys()), "oracle param_shapes() order != reference state_dict"
+    for k in ref_sd:
+        assert tuple(ref_sd[k].shape) == tuple(params[k].shape), k
+    ref.load_state_dict(params, strict=True)
+    ref.train()
+    wav, tgt, emb = O.synth_batch(R, T, seed)
+    est, _ = ref(wav, emb)
+    loss = O.sisdr_loss(est, tgt)
+    loss.backward()
+    out = {"wav": wav.numpy(), "tgt": tgt.numpy(), "emb": emb.numpy(), "est": est.detach().numpy(),
+           "loss": np.float64(loss.item()),
+           "param_checksum": np.float64(sum(float(v.double().abs().sum()) for v in params.values()))}
+    names = []
+    for k, prm in ref.named_parameters():
+        g = prm.grad.detach().reshape(-1)
+        names.append(k)
+        out["gnorm/" + k] = np.float64(g.double().norm().item())
+        out["ghead/" + k] = g[:16].numpy().copy()
+    out["names"] = np.array(names)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.6f} est_rms={est.pow(2).mean().sqrt().item():.4e}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
@@ -155,3 +198,7 @@ if __name__ == "__main__":
         if only and name not in only:
             continue
         run_tasnet_case(name, kw, R, T, seed)
+    for name, (kw, R, T, seed) in DPCCN_CASES.items():
+        if only and name not in only:
+            continue
+        run_dpccn_case(name, kw, R, T, seed)
