@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 5
+#define WS_ABI_VERSION 6
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -448,6 +448,35 @@ int ws_preemph_pad(const float* x, int R, int T, int pad, int ldo, float coef, f
 int ws_power_spec(const float* spec, long long M, int nf, int lds, int ldp, float* p, void* stream);
 /* x = log(x + eps) in place                                                                               */
 int ws_log_eps(float* x, long long n, float eps, void* stream);
+
+/* ---- DPCCN pieces (wesep/modules/dpccn/convs.py, wesep/models/dpccn.py) -----------
+ * channels-last [B][H][W][C], H = frame, W = frequency bin.  Conv2d / ConvTranspose2d with per-axis strides:
+ * ws_im2col_hw + GEMM, and GEMM + ws_col2im_hw (the transposed convolution is the col2im gather of a GEMM output).*/
+int ws_im2col_hw(const float* x, int R, int H, int W, int C, int k, int sh, int sw, int p, long long ldp,
+                 float* patches, void* stream);
+int ws_col2im_hw(const float* dpatches, int R, int H, int W, int C, int k, int sh, int sw, int p, float* dx,
+                 void* stream);
+/* nn.ELU: y = x > 0 ? x : expm1(x);  dx = dy * (x > 0 ? 1 : exp(x)) (dx may alias dy)                        */
+int ws_elu_fwd(const float* x, long long n, float* y, void* stream);
+int ws_elu_bwd(const float* x, const float* dy, long long n, float* dx, void* stream);
+/* InstanceNorm{1,2}d without affine over the P positions of each of G batch rows ([G*P][C] channels-last):
+ * sums [G][2][C] = ws_chan_sums(g = x, x = x) -> stats [G][2][C] = (mean, rstd); y = (x - mean) * rstd;
+ * backward with sums = ws_chan_sums(g = dy, x = y): dx = rstd * (dy - S0/P - y * S1/P)                       */
+int ws_inorm_finalize(const float* sums, int G, int C, long long P, float eps, float* stats, void* stream);
+int ws_inorm_apply(const float* x, const float* stats, long long rows, int P, int C, float* y, void* stream);
+int ws_inorm_bwd_apply(const float* y, const float* dy, const float* stats, const float* sums, long long rows, int P,
+                       int C, float* dx, void* stream);
+/* nn.AvgPool2d(sz) and its adjoint; nn.Upsample(size = (H, W), mode = "bilinear") (align_corners False) and its
+ * adjoint (a gather over destination pixels)                                                                  */
+int ws_avgpool_fwd(const float* x, int B, int H, int W, int C, int sz, float* y, void* stream);
+int ws_avgpool_bwd(const float* dy, int B, int H, int W, int C, int sz, float* dx, void* stream);
+int ws_bilinear_fwd(const float* x, int B, int h, int w, int H, int W, int C, float* y, void* stream);
+int ws_bilinear_bwd(const float* dy, int B, int h, int w, int H, int W, int C, float* dx, void* stream);
+/* SpeakerFuseLayer multiply (mode 0) / additive (mode 1) on [B][T][F][C] with s [B][F] (speaker.py:102-121);
+ * backward: dx, and ds [B][F] = sum over (t, c) of dy * x (mode 0) or dy (mode 1)                             */
+int ws_scale_bf_fwd(const float* x, const float* s, int B, int T, int F, int C, int mode, float* y, void* stream);
+int ws_scale_bf_bwd(const float* x, const float* dy, const float* s, int B, int T, int F, int C, int mode, float* dx,
+                    float* ds, void* stream);
 
 #ifdef __cplusplus
 }

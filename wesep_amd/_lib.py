@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 5
+ABI_VERSION = 6
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
@@ -159,6 +159,19 @@ _SIGS = {
     "ws_col2im": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "ws_tstp_fwd": (_i, [_p, _i, _i, _i, _i, C.c_float, _p, _p]),
     "ws_tstp_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "ws_im2col_hw": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _p, _p]),
+    "ws_col2im_hw": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_elu_fwd": (_i, [_p, _ll, _p, _p]),
+    "ws_elu_bwd": (_i, [_p, _p, _ll, _p, _p]),
+    "ws_inorm_finalize": (_i, [_p, _i, _i, _ll, C.c_float, _p, _p]),
+    "ws_inorm_apply": (_i, [_p, _p, _ll, _i, _i, _p, _p]),
+    "ws_inorm_bwd_apply": (_i, [_p, _p, _p, _p, _ll, _i, _i, _p, _p]),
+    "ws_avgpool_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_avgpool_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_bilinear_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_bilinear_bwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_scale_bf_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_scale_bf_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ws_preemph_pad": (_i, [_p, _i, _i, _i, _i, C.c_float, _p, _p]),
     "ws_power_spec": (_i, [_p, _ll, _i, _i, _i, _p, _p]),
     "ws_log_eps": (_i, [_p, _ll, C.c_float, _p]),

@@ -10,7 +10,7 @@
 struct ConvGeom {
   int R, H, W, C;   // input  [R][H][W][C]
   int Ho, Wo;       // output spatial size
-  int k, s, p;      // kernel, stride, padding
+  int k, sh, sw, p; // kernel, stride along H / W, padding
 };
 
 // patches[m][(ky*k + kx)*C + c] = x[r][ho*s + ky - p][wo*s + kx - p][c] (0 outside), m = (r*Ho + ho)*Wo + wo
@@ -26,7 +26,7 @@ __global__ void im2col_kernel(const float* __restrict__ x, ConvGeom g, float* __
     const int wo = (int)(q % g.Wo);
     q /= g.Wo;
     const int ho = (int)(q % g.Ho), r = (int)(q / g.Ho);
-    const int hi = ho * g.s + tap / g.k - g.p, wi = wo * g.s + tap % g.k - g.p;
+    const int hi = ho * g.sh + tap / g.k - g.p, wi = wo * g.sw + tap % g.k - g.p;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W)
       v = *reinterpret_cast<const f32x4*>(x + (((long long)r * g.H + hi) * g.W + wi) * g.C + c);
@@ -46,7 +46,7 @@ __global__ void im2col_c1_kernel(const float* __restrict__ x, ConvGeom g, int ld
     const long long m = q;
     q /= g.Wo;
     const int ho = (int)(q % g.Ho), r = (int)(q / g.Ho);
-    const int hi = ho * g.s + tap / g.k - g.p, wi = wo * g.s + tap % g.k - g.p;
+    const int hi = ho * g.sh + tap / g.k - g.p, wi = wo * g.sw + tap % g.k - g.p;
     float v = 0.f;
     if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) v = x[((long long)r * g.H + hi) * g.W + wi];
     patches[m * ldp + tap] = v;
@@ -68,13 +68,13 @@ __global__ void col2im_kernel(const float* __restrict__ dpatches, ConvGeom g, fl
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int ky = 0; ky < g.k; ++ky) {
       const int hn = hi + g.p - ky;
-      if (hn < 0 || hn % g.s) continue;
-      const int ho = hn / g.s;
+      if (hn < 0 || hn % g.sh) continue;
+      const int ho = hn / g.sh;
       if (ho >= g.Ho) continue;
       for (int kx = 0; kx < g.k; ++kx) {
         const int wn = wi + g.p - kx;
-        if (wn < 0 || wn % g.s) continue;
-        const int wo = wn / g.s;
+        if (wn < 0 || wn % g.sw) continue;
+        const int wo = wn / g.sw;
         if (wo >= g.Wo) continue;
         const long long m = ((long long)r * g.Ho + ho) * g.Wo + wo;
         acc += *reinterpret_cast<const f32x4*>(dpatches + (m * kk + ky * g.k + kx) * g.C + c);
@@ -89,21 +89,21 @@ static inline unsigned cv_blocks(long long n) {
   return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
 }
 
-static int cv_check(const char* who, int R, int H, int W, int C, int k, int s, int p, int* Ho, int* Wo) {
-  WS_REQUIRE(R > 0 && H > 0 && W > 0 && C > 0 && k >= 1 && s >= 1 && p >= 0, "%s: bad geometry", who);
-  *Ho = (H + 2 * p - k) / s + 1;
-  *Wo = (W + 2 * p - k) / s + 1;
+static int cv_check(const char* who, int R, int H, int W, int C, int k, int sh, int sw, int p, int* Ho, int* Wo) {
+  WS_REQUIRE(R > 0 && H > 0 && W > 0 && C > 0 && k >= 1 && sh >= 1 && sw >= 1 && p >= 0, "%s: bad geometry", who);
+  *Ho = (H + 2 * p - k) / sh + 1;
+  *Wo = (W + 2 * p - k) / sw + 1;
   WS_REQUIRE(*Ho > 0 && *Wo > 0, "%s: empty output", who);
   return WS_OK;
 }
 
-extern "C" int ws_im2col(const float* x, int R, int H, int W, int C, int k, int s, int p, long long ldp,
-                         float* patches, void* stream) {
+extern "C" int ws_im2col_hw(const float* x, int R, int H, int W, int C, int k, int sh, int sw, int p, long long ldp,
+                            float* patches, void* stream) {
   int Ho, Wo;
-  int rc = cv_check("ws_im2col", R, H, W, C, k, s, p, &Ho, &Wo);
+  int rc = cv_check("ws_im2col", R, H, W, C, k, sh, sw, p, &Ho, &Wo);
   if (rc != WS_OK) return rc;
   WS_REQUIRE(x && patches, "ws_im2col: null pointer");
-  const ConvGeom g{R, H, W, C, Ho, Wo, k, s, p};
+  const ConvGeom g{R, H, W, C, Ho, Wo, k, sh, sw, p};
   if (C == 1) {
     WS_REQUIRE(ldp >= k * k, "ws_im2col: ldp < k*k");
     hipLaunchKernelGGL(im2col_c1_kernel, dim3(cv_blocks((long long)R * Ho * Wo * k * k)), dim3(256), 0,
@@ -116,16 +116,26 @@ extern "C" int ws_im2col(const float* x, int R, int H, int W, int C, int k, int 
   return ws_check_launch("ws_im2col");
 }
 
-extern "C" int ws_col2im(const float* dpatches, int R, int H, int W, int C, int k, int s, int p, float* dx,
-                         void* stream) {
+extern "C" int ws_im2col(const float* x, int R, int H, int W, int C, int k, int s, int p, long long ldp,
+                         float* patches, void* stream) {
+  return ws_im2col_hw(x, R, H, W, C, k, s, s, p, ldp, patches, stream);
+}
+
+extern "C" int ws_col2im_hw(const float* dpatches, int R, int H, int W, int C, int k, int sh, int sw, int p, float* dx,
+                            void* stream) {
   int Ho, Wo;
-  int rc = cv_check("ws_col2im", R, H, W, C, k, s, p, &Ho, &Wo);
+  int rc = cv_check("ws_col2im", R, H, W, C, k, sh, sw, p, &Ho, &Wo);
   if (rc != WS_OK) return rc;
   WS_REQUIRE(dpatches && dx && C % 4 == 0, "ws_col2im: null pointer / C %% 4");
-  const ConvGeom g{R, H, W, C, Ho, Wo, k, s, p};
+  const ConvGeom g{R, H, W, C, Ho, Wo, k, sh, sw, p};
   hipLaunchKernelGGL(col2im_kernel, dim3(cv_blocks((long long)R * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
                      dpatches, g, dx);
   return ws_check_launch("ws_col2im");
+}
+
+extern "C" int ws_col2im(const float* dpatches, int R, int H, int W, int C, int k, int s, int p, float* dx,
+                         void* stream) {
+  return ws_col2im_hw(dpatches, R, H, W, C, k, s, s, p, dx, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -253,4 +263,306 @@ extern "C" int ws_log_eps(float* x, long long n, float eps, void* stream) {
   WS_REQUIRE(x && n > 0, "ws_log_eps: bad args");
   hipLaunchKernelGGL(log_eps_kernel, dim3(cv_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, n, eps);
   return ws_check_launch("ws_log_eps");
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// DPCCN pieces (wesep/modules/dpccn/convs.py, wesep/models/dpccn.py), channels-last
+// [B][H][W][C] (H = frame, W = frequency bin):  ELU, InstanceNorm (no affine) over the positions of one batch row,
+// AvgPool2d(sz), bilinear upsampling (align_corners = False), and the speaker fusion's per-(row, bin) scale / shift.
+// 2-D convolutions / transposed convolutions are ws_im2col_hw / ws_col2im_hw + GEMM.
+// ---------------------------------------------------------------------------------------------
+__global__ void elu_fwd_kernel(const float* __restrict__ x, long long n4, float* __restrict__ y) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = v[j] > 0.f ? v[j] : expm1f(v[j]);
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+  }
+}
+
+// dx = dy * (x > 0 ? 1 : exp(x))   (dx may alias dy)
+__global__ void elu_bwd_kernel(const float* __restrict__ x, const float* dy, long long n4, float* dx) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4), g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = v[j] > 0.f ? g[j] : g[j] * expf(v[j]);
+    *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+  }
+}
+
+extern "C" int ws_elu_fwd(const float* x, long long n, float* y, void* stream) {
+  WS_REQUIRE(x && y && n > 0 && n % 4 == 0, "ws_elu_fwd: bad args");
+  hipLaunchKernelGGL(elu_fwd_kernel, dim3(cv_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, x, n / 4, y);
+  return ws_check_launch("ws_elu_fwd");
+}
+
+extern "C" int ws_elu_bwd(const float* x, const float* dy, long long n, float* dx, void* stream) {
+  WS_REQUIRE(x && dy && dx && n > 0 && n % 4 == 0, "ws_elu_bwd: bad args");
+  hipLaunchKernelGGL(elu_bwd_kernel, dim3(cv_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, x, dy, n / 4, dx);
+  return ws_check_launch("ws_elu_bwd");
+}
+
+// sums [G][2][C] = (sum x, sum x^2) over the P positions of group g (ws_chan_sums with g = x = the input)
+// -> stats [G][2][C] = (mean, 1/sqrt(max(E[x^2] - mean^2, 0) + eps))
+__global__ void inorm_finalize_kernel(const float* __restrict__ sums, long long n, int C, float inv_p, float eps,
+                                      float* __restrict__ stats) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long g = i / C;
+    const int c = (int)(i - g * C);
+    const float mean = sums[g * 2 * C + c] * inv_p;
+    const float var = fmaxf(sums[g * 2 * C + C + c] * inv_p - mean * mean, 0.f);
+    stats[g * 2 * C + c] = mean;
+    stats[g * 2 * C + C + c] = 1.f / sqrtf(var + eps);
+  }
+}
+
+// y = (x - mean[g][c]) * rstd[g][c],  g = row / P
+__global__ void inorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, long long rows, int P,
+                                   int C, float* __restrict__ y) {
+  const int c4n = C >> 2;
+  const long long total = rows * c4n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / c4n;
+    const int c = (int)(i - row * c4n) * 4;
+    const float* st = stats + (row / P) * 2 * C;
+    *reinterpret_cast<f32x4*>(y + i * 4) = (*reinterpret_cast<const f32x4*>(x + i * 4) -
+                                             *reinterpret_cast<const f32x4*>(st + c)) *
+                                            *reinterpret_cast<const f32x4*>(st + C + c);
+  }
+}
+
+// dx = rstd * (dy - S0/P - y * S1/P),  sums [G][2][C] = (sum dy, sum dy * y) (ws_chan_sums(g = dy, x = y))
+__global__ void inorm_bwd_apply_kernel(const float* __restrict__ y, const float* dy, const float* __restrict__ stats,
+                                       const float* __restrict__ sums, long long rows, int P, int C, float* dx) {
+  const int c4n = C >> 2;
+  const long long total = rows * c4n;
+  const float inv = 1.f / (float)P;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / c4n;
+    const int c = (int)(i - row * c4n) * 4;
+    const long long g = row / P;
+    const f32x4 rstd = *reinterpret_cast<const f32x4*>(stats + g * 2 * C + C + c);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + g * 2 * C + c) * inv;
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + g * 2 * C + C + c) * inv;
+    *reinterpret_cast<f32x4*>(dx + i * 4) =
+        rstd * (*reinterpret_cast<const f32x4*>(dy + i * 4) - s0 - *reinterpret_cast<const f32x4*>(y + i * 4) * s1);
+  }
+}
+
+extern "C" int ws_inorm_finalize(const float* sums, int G, int C, long long P, float eps, float* stats, void* stream) {
+  WS_REQUIRE(sums && stats && G > 0 && C > 0 && P > 0, "ws_inorm_finalize: bad args");
+  hipLaunchKernelGGL(inorm_finalize_kernel, dim3(cv_blocks((long long)G * C)), dim3(256), 0, (hipStream_t)stream, sums,
+                     (long long)G * C, C, 1.f / (float)P, eps, stats);
+  return ws_check_launch("ws_inorm_finalize");
+}
+
+extern "C" int ws_inorm_apply(const float* x, const float* stats, long long rows, int P, int C, float* y, void* stream) {
+  WS_REQUIRE(x && stats && y && rows > 0 && P > 0 && C > 0 && C % 4 == 0 && rows % P == 0, "ws_inorm_apply: bad args");
+  hipLaunchKernelGGL(inorm_apply_kernel, dim3(cv_blocks(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, stats,
+                     rows, P, C, y);
+  return ws_check_launch("ws_inorm_apply");
+}
+
+extern "C" int ws_inorm_bwd_apply(const float* y, const float* dy, const float* stats, const float* sums, long long rows,
+                                  int P, int C, float* dx, void* stream) {
+  WS_REQUIRE(y && dy && stats && sums && dx && rows > 0 && P > 0 && C > 0 && C % 4 == 0 && rows % P == 0,
+             "ws_inorm_bwd_apply: bad args");
+  hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3(cv_blocks(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, dy,
+                     stats, sums, rows, P, C, dx);
+  return ws_check_launch("ws_inorm_bwd_apply");
+}
+
+// AvgPool2d(sz) (stride sz, floor): [B][H][W][C] -> [B][H/sz][W/sz][C]; backward spreads dy / sz^2 (0 on the dropped tail)
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int sz,
+                                   float* __restrict__ y) {
+  const int Ho = H / sz, Wo = W / sz, c4n = C >> 2;
+  const long long total = (long long)B * Ho * Wo * c4n;
+  const float inv = 1.f / (float)(sz * sz);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    long long q = i / c4n;
+    const int wo = (int)(q % Wo);
+    q /= Wo;
+    const int ho = (int)(q % Ho), b = (int)(q / Ho);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int dy_ = 0; dy_ < sz; ++dy_)
+      for (int dx_ = 0; dx_ < sz; ++dx_)
+        acc += *reinterpret_cast<const f32x4*>(x + (((long long)b * H + ho * sz + dy_) * W + wo * sz + dx_) * C + c);
+    *reinterpret_cast<f32x4*>(y + i * 4) = acc * inv;
+  }
+}
+
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C, int sz,
+                                   float* __restrict__ dx) {
+  const int Ho = H / sz, Wo = W / sz, c4n = C >> 2;
+  const long long total = (long long)B * H * W * c4n;
+  const float inv = 1.f / (float)(sz * sz);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    long long q = i / c4n;
+    const int w = (int)(q % W);
+    q /= W;
+    const int h = (int)(q % H), b = (int)(q / H);
+    const int ho = h / sz, wo = w / sz;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ho < Ho && wo < Wo) v = *reinterpret_cast<const f32x4*>(dy + (((long long)b * Ho + ho) * Wo + wo) * C + c) * inv;
+    *reinterpret_cast<f32x4*>(dx + i * 4) = v;
+  }
+}
+
+extern "C" int ws_avgpool_fwd(const float* x, int B, int H, int W, int C, int sz, float* y, void* stream) {
+  WS_REQUIRE(x && y && B > 0 && sz > 0 && H >= sz && W >= sz && C > 0 && C % 4 == 0, "ws_avgpool_fwd: bad args");
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(cv_blocks((long long)B * (H / sz) * (W / sz) * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, B, H, W, C, sz, y);
+  return ws_check_launch("ws_avgpool_fwd");
+}
+
+extern "C" int ws_avgpool_bwd(const float* dy, int B, int H, int W, int C, int sz, float* dx, void* stream) {
+  WS_REQUIRE(dy && dx && B > 0 && sz > 0 && H >= sz && W >= sz && C > 0 && C % 4 == 0, "ws_avgpool_bwd: bad args");
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(cv_blocks((long long)B * H * W * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, dy, B, H, W, C, sz, dx);
+  return ws_check_launch("ws_avgpool_bwd");
+}
+
+// bilinear, align_corners = False (nn.Upsample(size = (H, W), mode = "bilinear"), dpccn.py:263):
+//   src = max((dst + 0.5) * (h / H) - 0.5, 0); i0 = floor(src), i1 = min(i0 + 1, h - 1), l = src - i0
+__device__ __forceinline__ void bl_src(int dst, float scale, int n, int& i0, int& i1, float& l) {
+  const float s = fmaxf(((float)dst + 0.5f) * scale - 0.5f, 0.f);
+  i0 = min((int)s, n - 1);
+  i1 = min(i0 + 1, n - 1);
+  l = s - (float)i0;
+}
+
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, int B, int h, int w, int H, int W, int C,
+                                    float* __restrict__ y) {
+  const int c4n = C >> 2;
+  const long long total = (long long)B * H * W * c4n;
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    long long q = i / c4n;
+    const int X = (int)(q % W);
+    q /= W;
+    const int Y = (int)(q % H), b = (int)(q / H);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bl_src(Y, sh, h, y0, y1, ly);
+    bl_src(X, sw, w, x0, x1, lx);
+    const float* base = x + (long long)b * h * w * C + c;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((long long)y0 * w + x0) * C);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((long long)y0 * w + x1) * C);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * w + x0) * C);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * w + x1) * C);
+    *reinterpret_cast<f32x4*>(y + i * 4) =
+        (v00 * (1.f - lx) + v01 * lx) * (1.f - ly) + (v10 * (1.f - lx) + v11 * lx) * ly;
+  }
+}
+
+// adjoint as a gather: one thread per (source pixel, channel quad) walks every destination pixel (deterministic;
+// the source grids are tiny: H/sz x W/sz)
+__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int B, int h, int w, int H, int W, int C,
+                                    float* __restrict__ dx) {
+  const int c4n = C >> 2;
+  const long long total = (long long)B * h * w * c4n;
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    long long q = i / c4n;
+    const int xs = (int)(q % w);
+    q /= w;
+    const int ys = (int)(q % h), b = (int)(q / h);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int Y = 0; Y < H; ++Y) {
+      int y0, y1;
+      float ly;
+      bl_src(Y, sh, h, y0, y1, ly);
+      const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int X = 0; X < W; ++X) {
+        int x0, x1;
+        float lx;
+        bl_src(X, sw, w, x0, x1, lx);
+        const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+        if (wx == 0.f) continue;
+        acc += *reinterpret_cast<const f32x4*>(dy + (((long long)b * H + Y) * W + X) * C + c) * (wy * wx);
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+  }
+}
+
+extern "C" int ws_bilinear_fwd(const float* x, int B, int h, int w, int H, int W, int C, float* y, void* stream) {
+  WS_REQUIRE(x && y && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ws_bilinear_fwd: bad args");
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(cv_blocks((long long)B * H * W * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, B, h, w, H, W, C, y);
+  return ws_check_launch("ws_bilinear_fwd");
+}
+
+extern "C" int ws_bilinear_bwd(const float* dy, int B, int h, int w, int H, int W, int C, float* dx, void* stream) {
+  WS_REQUIRE(dy && dx && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ws_bilinear_bwd: bad args");
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(cv_blocks((long long)B * h * w * (C / 4))), dim3(64), 0,
+                     (hipStream_t)stream, dy, B, h, w, H, W, C, dx);
+  return ws_check_launch("ws_bilinear_bwd");
+}
+
+// speaker fusion on [B][T][F][C] (speaker.py:102-121 on the [B, C, F, T] view): y = x * s[b][f] (mode 0) or x + s[b][f]
+// (mode 1); backward: dx = dy * s (or dy); ds[b][f] = sum over (t, c) of dy * x (or dy): one workgroup per (b, f)
+__global__ void scale_bf_fwd_kernel(const float* __restrict__ x, const float* __restrict__ s, int B, int T, int Fq,
+                                    int C, int mode, float* __restrict__ y) {
+  const int c4n = C >> 2;
+  const long long total = (long long)B * T * Fq * c4n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long q = i / c4n;
+    const int f = (int)(q % Fq);
+    const int b = (int)(q / ((long long)Fq * T));
+    const float sv = s[(long long)b * Fq + f];
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    *reinterpret_cast<f32x4*>(y + i * 4) = mode == 0 ? v * sv : v + sv;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_bf_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ s, int B, int T, int Fq, int C,
+                                                           int mode, float* __restrict__ dx, float* __restrict__ ds) {
+  __shared__ float red[16];
+  const int b = blockIdx.x / Fq, f = blockIdx.x % Fq;
+  const float sv = s[(long long)b * Fq + f];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < T * C; i += 256) {
+    const int t = i / C, c = i - t * C;
+    const long long o = (((long long)b * T + t) * Fq + f) * C + c;
+    const float g = dy[o];
+    acc += mode == 0 ? g * x[o] : g;
+    dx[o] = mode == 0 ? g * sv : g;
+  }
+  acc = ws_block_sum(acc, red);
+  if (threadIdx.x == 0) ds[blockIdx.x] = acc;
+}
+
+extern "C" int ws_scale_bf_fwd(const float* x, const float* s, int B, int T, int Fq, int C, int mode, float* y,
+                               void* stream) {
+  WS_REQUIRE(x && s && y && B > 0 && T > 0 && Fq > 0 && C > 0 && C % 4 == 0 && (mode == 0 || mode == 1),
+             "ws_scale_bf_fwd: bad args");
+  hipLaunchKernelGGL(scale_bf_fwd_kernel, dim3(cv_blocks((long long)B * T * Fq * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, s, B, T, Fq, C, mode, y);
+  return ws_check_launch("ws_scale_bf_fwd");
+}
+
+extern "C" int ws_scale_bf_bwd(const float* x, const float* dy, const float* s, int B, int T, int Fq, int C, int mode,
+                               float* dx, float* ds, void* stream) {
+  WS_REQUIRE(x && dy && s && dx && ds && B > 0 && T > 0 && Fq > 0 && C > 0 && (mode == 0 || mode == 1),
+             "ws_scale_bf_bwd: bad args");
+  hipLaunchKernelGGL(scale_bf_bwd_kernel, dim3(B * Fq), dim3(256), 0, (hipStream_t)stream, x, dy, s, B, T, Fq, C, mode,
+                     dx, ds);
+  return ws_check_launch("ws_scale_bf_bwd");
 }

@@ -761,3 +761,85 @@ def power_spec(spec, M: int, nf: int, lds: int, ldp: int, p):
 def log_eps(x, eps: float):
     _chk(x, "x")
     _call("ws_log_eps", _p(x), x.numel(), eps)
+
+
+# ---- DPCCN pieces (conv2d.hip) --------------------------------------------------------------------------
+IN_EPS = 1e-5  # nn.InstanceNorm{1,2}d default
+
+
+def im2col_hw(x, R: int, H: int, W: int, Cc: int, k: int, sh: int, sw: int, p: int, patches, ldp: int):
+    _chk(x, "x")
+    _chk(patches, "patches")
+    _call("ws_im2col_hw", _p(x), R, H, W, Cc, k, sh, sw, p, ldp, _p(patches))
+
+
+def col2im_hw(dpatches, R: int, H: int, W: int, Cc: int, k: int, sh: int, sw: int, p: int, dx):
+    _chk(dpatches, "dpatches")
+    _chk(dx, "dx")
+    _call("ws_col2im_hw", _p(dpatches), R, H, W, Cc, k, sh, sw, p, _p(dx))
+
+
+def elu_fwd(x, y):
+    _chk(x, "x")
+    _chk(y, "y")
+    _call("ws_elu_fwd", _p(x), x.numel(), _p(y))
+
+
+def elu_bwd(x, dy, dx):
+    for n, t in (("x", x), ("dy", dy), ("dx", dx)):
+        _chk(t, n)
+    _call("ws_elu_bwd", _p(x), _p(dy), x.numel(), _p(dx))
+
+
+def inorm_fwd(x, G: int, P: int, Cc: int, y, eps=IN_EPS):
+    """y = InstanceNorm(x) over the P positions of each of G rows; returns stats [G, 2, C] = (mean, rstd)."""
+    _chk(x, "x")
+    _chk(y, "y")
+    sums = chan_sums(x, x, None, 1, P, G, Cc)
+    stats = torch.empty(G, 2, Cc, device=x.device, dtype=torch.float32)
+    _call("ws_inorm_finalize", _p(sums), G, Cc, P, eps, _p(stats))
+    _call("ws_inorm_apply", _p(x), _p(stats), G * P, P, Cc, _p(y))
+    return stats
+
+
+def inorm_bwd(y, dy, stats, G: int, P: int, Cc: int, dx):
+    for n, t in (("y", y), ("dy", dy), ("stats", stats), ("dx", dx)):
+        _chk(t, n)
+    sums = chan_sums(dy, y, None, 1, P, G, Cc)
+    _call("ws_inorm_bwd_apply", _p(y), _p(dy), _p(stats), _p(sums), G * P, P, Cc, _p(dx))
+
+
+def avgpool_fwd(x, B: int, H: int, W: int, Cc: int, sz: int, y):
+    _chk(x, "x")
+    _chk(y, "y")
+    _call("ws_avgpool_fwd", _p(x), B, H, W, Cc, sz, _p(y))
+
+
+def avgpool_bwd(dy, B: int, H: int, W: int, Cc: int, sz: int, dx):
+    _chk(dy, "dy")
+    _chk(dx, "dx")
+    _call("ws_avgpool_bwd", _p(dy), B, H, W, Cc, sz, _p(dx))
+
+
+def bilinear_fwd(x, B: int, h: int, w: int, H: int, W: int, Cc: int, y):
+    _chk(x, "x")
+    _chk(y, "y")
+    _call("ws_bilinear_fwd", _p(x), B, h, w, H, W, Cc, _p(y))
+
+
+def bilinear_bwd(dy, B: int, h: int, w: int, H: int, W: int, Cc: int, dx):
+    _chk(dy, "dy")
+    _chk(dx, "dx")
+    _call("ws_bilinear_bwd", _p(dy), B, h, w, H, W, Cc, _p(dx))
+
+
+def scale_bf_fwd(x, s, B: int, T: int, Fq: int, Cc: int, mode: int, y):
+    for n, t in (("x", x), ("s", s), ("y", y)):
+        _chk(t, n)
+    _call("ws_scale_bf_fwd", _p(x), _p(s), B, T, Fq, Cc, mode, _p(y))
+
+
+def scale_bf_bwd(x, dy, s, B: int, T: int, Fq: int, Cc: int, mode: int, dx, ds):
+    for n, t in (("x", x), ("dy", dy), ("s", s), ("dx", dx), ("ds", ds)):
+        _chk(t, n)
+    _call("ws_scale_bf_bwd", _p(x), _p(dy), _p(s), B, T, Fq, Cc, mode, _p(dx), _p(ds))
