@@ -150,6 +150,8 @@ DPCCN_CASES = {
     "dpccn_multiply_r2_t4480": (dict(tcn_blocks=3, tcn_layers=1), 2, 4480, 31),
     "dpccn_concat_xform_r2_t4352": (dict(tcn_blocks=2, tcn_layers=2, spk_fuse_type="concat", use_spk_transform=True),
                                     2, 4352, 32),
+    "dpccn_additive_xform_r2_t4608": (dict(tcn_blocks=2, tcn_layers=2, spk_fuse_type="additive",
+                                           use_spk_transform=True), 2, 4608, 33),
 }
 
 

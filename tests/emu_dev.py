@@ -1,0 +1,250 @@
+"""TEST INFRASTRUCTURE ONLY -- torch-CPU emulation of the `wesep_amd.dev` entry points used by the composed model
+paths, so that the HOST LOGIC (shapes, row addressing, weight re-layouts, autograd wiring) of those paths can be
+checked against the oracle on a machine without a GPU.  It is installed by the `emulated_dev` fixture with
+monkeypatch and never imported by the product: wesep_amd itself has no CPU path (a CPU tensor raises).  The kernels
+themselves are only ever validated on the GPU (`-m gpu`) against torch and the oracle."""
+import torch
+import torch.nn.functional as F
+
+
+def _rows_off(M, rows):
+    div, s1, s2 = rows
+    m = torch.arange(M, dtype=torch.long)
+    return (m // div) * s1 + (m % div) * s2
+
+
+def _gather(t, off, M, rows, K):
+    flat_ = t.reshape(-1)
+    idx = (off + _rows_off(M, rows)).unsqueeze(1) + torch.arange(K).unsqueeze(0)
+    return flat_[idx]
+
+
+def gemm_nt(*, A, a_rows, M, C_out, c_rows, N=0, K=0, W=None, ldw=0, bias=None, R=None, T=None, stats=None,
+            gamma=None, beta=None, stat_map=None, act=0, groups=None, ngroups=0, max_n=0, vec=3, a_off=0, c_off=0,
+            w_off=0, mode=None):
+    assert groups is None
+    a = _gather(A, a_off, M, a_rows, K)
+    if stats is not None:
+        d1, m1, d2, m2, base = stat_map
+        m = torch.arange(M)
+        s = (m // d1) * m1 + (m % d2) * m2 + base
+        st = stats.reshape(-1, 2)
+        a = (a - st[s, 0:1]) * st[s, 1:2] * gamma.reshape(-1)[:K] + beta.reshape(-1)[:K]
+    w = W.reshape(-1)[w_off + (torch.arange(N).unsqueeze(1) * ldw + torch.arange(K).unsqueeze(0))]
+    v = a @ w.t()
+    if bias is not None:
+        v = v + bias.reshape(-1)[:N]
+    if act == 1:
+        v = torch.tanh(v)
+    if act == 2:
+        v = torch.relu(v)
+    cidx = (c_off + _rows_off(M, c_rows)).unsqueeze(1) + torch.arange(N).unsqueeze(0)
+    if T is not None:
+        t = T.reshape(-1)[cidx]
+        v = v * ((t > 0).float() if act == 4 else (1 - t * t))
+    if R is not None:
+        v = v + R.reshape(-1)[cidx]
+    C_out.reshape(-1)[cidx] = v
+
+
+def gemm_tn(*, G, g_rows, A, a_rows, M, slab, slab_stride, nsplit, rows_per_split, Nn=0, Kk=0, bslab=None,
+            bslab_stride=0, out_off=0, bout_off=0, stats=None, gamma=None, beta=None, stat_map=None, shift_rows=0,
+            seq_div=1, seq_len=1, groups=None, ngroups=0, max_n=0, max_k=0, vec=1, g_off=0, a_off=0, mode=None):
+    assert groups is None and shift_rows == 0
+    g = _gather(G, g_off, M, g_rows, Nn)
+    a = _gather(A, a_off, M, a_rows, Kk)
+    if stats is not None:
+        d1, m1, d2, m2, base = stat_map
+        m = torch.arange(M)
+        s = (m // d1) * m1 + (m % d2) * m2 + base
+        st = stats.reshape(-1, 2)
+        a = (a - st[s, 0:1]) * st[s, 1:2] * gamma.reshape(-1)[:Kk] + beta.reshape(-1)[:Kk]
+    sl = slab.reshape(-1)
+    for sp in range(nsplit):
+        lo, hi = sp * rows_per_split, min(M, (sp + 1) * rows_per_split)
+        blk = (g[lo:hi].t() @ a[lo:hi]).reshape(-1) if hi > lo else torch.zeros(Nn * Kk)
+        sl[sp * slab_stride + out_off: sp * slab_stride + out_off + Nn * Kk] = blk
+        if bslab is not None:
+            bslab.reshape(-1)[sp * bslab_stride + bout_off: sp * bslab_stride + bout_off + Nn] = \
+                g[lo:hi].sum(0) if hi > lo else 0.0
+
+
+def reduce_slabs(slab, nsplit, stride, count, out, w=0, ldo=0, out_off=0):
+    s = slab.reshape(-1)
+    tot = sum(s[k * stride: k * stride + count] for k in range(nsplit))
+    i = torch.arange(count)
+    o = (i // w) * ldo + (i % w) if w > 0 else i
+    out.reshape(-1)[out_off + o] = tot
+
+
+def transpose(src, rows, cols, lds, dst, src_off=0, dst_off=0):
+    idx = src_off + torch.arange(rows).unsqueeze(1) * lds + torch.arange(cols).unsqueeze(0)
+    dst.reshape(-1)[dst_off: dst_off + rows * cols] = src.reshape(-1)[idx].t().reshape(-1)
+
+
+def affine_fwd(z, a, b, a0, rows, rows_per_r, N, out):
+    zz = z.reshape(-1)[: rows * N].reshape(rows, N)
+    r = torch.arange(rows) // rows_per_r
+    sc = a0 + (a.reshape(-1, N)[r] if a is not None else 0.0)
+    res = zz * sc + (b.reshape(-1, N)[r] if b is not None else 0.0)
+    out.reshape(-1)[: rows * N] = res.reshape(-1)
+
+
+def chan_sums(g, x, stats, st_div, rows_per_group, ngroups, Cc):
+    gg = g.reshape(ngroups, rows_per_group, Cc)
+    out = torch.zeros(ngroups, 2, Cc)
+    out[:, 0] = gg.sum(1)
+    if x is not None:
+        xx = x.reshape(ngroups * rows_per_group, Cc)
+        if stats is not None:
+            s = torch.arange(ngroups * rows_per_group) // st_div
+            st = stats.reshape(-1, 2)
+            xx = (xx - st[s, 0:1]) * st[s, 1:2]
+        out[:, 1] = (gg * xx.reshape(ngroups, rows_per_group, Cc)).sum(1)
+    return out
+
+
+def _nchw(x, B, H, W):
+    return x.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def _cl(y):
+    B, C, H, W = y.shape
+    return y.permute(0, 2, 3, 1).reshape(B * H * W, C)
+
+
+def im2col_hw(x, R, H, W, Cc, k, sh, sw, p, patches, ldp):
+    u = F.unfold(_nchw(x.reshape(R * H * W, Cc), R, H, W), k, padding=p, stride=(sh, sw))   # [R, C*k*k, L]
+    L = u.shape[-1]
+    u = u.reshape(R, Cc, k * k, L).permute(0, 3, 2, 1).reshape(R * L, k * k * Cc)           # tap-major, channel-minor
+    patches.reshape(R * L, ldp)[:, : k * k * Cc] = u
+
+
+def col2im_hw(dpatches, R, H, W, Cc, k, sh, sw, p, dx):
+    Ho, Wo = (H + 2 * p - k) // sh + 1, (W + 2 * p - k) // sw + 1
+    u = dpatches.reshape(R, Ho * Wo, k * k, Cc).permute(0, 3, 2, 1).reshape(R, Cc * k * k, Ho * Wo)
+    y = F.fold(u, (H, W), k, padding=p, stride=(sh, sw))
+    dx.reshape(R * H * W, Cc)[:] = _cl(y)
+
+
+def elu_fwd(x, y):
+    y.copy_(F.elu(x))
+
+
+def elu_bwd(x, dy, dx):
+    dx.copy_(torch.where(x > 0, dy, dy * torch.exp(x)))
+
+
+def inorm_fwd(x, G, P, Cc, y, eps=1e-5):
+    xx = x.reshape(G, P, Cc)
+    mean = xx.mean(1)
+    var = (xx * xx).mean(1) - mean * mean
+    rstd = 1.0 / torch.sqrt(var.clamp_min(0) + eps)
+    y.reshape(G, P, Cc)[:] = (xx - mean.unsqueeze(1)) * rstd.unsqueeze(1)
+    return torch.stack([mean, rstd], 1).contiguous()
+
+
+def inorm_bwd(y, dy, stats, G, P, Cc, dx):
+    yy, dd = y.reshape(G, P, Cc), dy.reshape(G, P, Cc)
+    s0, s1 = dd.mean(1, keepdim=True), (dd * yy).mean(1, keepdim=True)
+    dx.reshape(G, P, Cc)[:] = stats[:, 1].unsqueeze(1) * (dd - s0 - yy * s1)
+
+
+def dwconv_fwd(x, stats, gamma, beta, w, b, R, Tp, Cc, P, dil, st_div, y):
+    s = torch.arange(R * Tp) // st_div
+    st = stats.reshape(-1, 2)
+    xn = (x.reshape(R * Tp, Cc) - st[s, 0:1]) * st[s, 1:2] * gamma + beta
+    xr = xn.reshape(R, Tp, Cc).permute(0, 2, 1)
+    o = F.conv1d(xr, w.reshape(Cc, 1, P), b, padding=dil * (P - 1) // 2, dilation=dil, groups=Cc)
+    y.reshape(R, Tp, Cc)[:] = o.permute(0, 2, 1)
+
+
+def dwconv_bwd(dy, x, stats, gamma, beta, w, R, Tp, Cc, P, dil, st_div, dxn):
+    s = torch.arange(R * Tp) // st_div
+    st = stats.reshape(-1, 2)
+    xn = ((x.reshape(R * Tp, Cc) - st[s, 0:1]) * st[s, 1:2] * gamma + beta).reshape(R, Tp, Cc).permute(0, 2, 1)
+    xn = xn.detach().requires_grad_(True)
+    wr = w.reshape(Cc, 1, P).detach().requires_grad_(True)
+    br = torch.zeros(Cc, requires_grad=True)
+    with torch.enable_grad():
+        o = F.conv1d(xn, wr, br, padding=dil * (P - 1) // 2, dilation=dil, groups=Cc)
+        o.backward(dy.reshape(R, Tp, Cc).permute(0, 2, 1))
+    dxn.reshape(R, Tp, Cc)[:] = xn.grad.permute(0, 2, 1)
+    return wr.grad.reshape(Cc, P).contiguous(), br.grad.contiguous()
+
+
+def avgpool_fwd(x, B, H, W, Cc, sz, y):
+    y.reshape(-1, Cc)[:] = _cl(F.avg_pool2d(_nchw(x, B, H, W), sz))
+
+
+def avgpool_bwd(dy, B, H, W, Cc, sz, dx):
+    xr = torch.zeros(B, Cc, H, W, requires_grad=True)
+    with torch.enable_grad():
+        F.avg_pool2d(xr, sz).backward(_nchw(dy, B, H // sz, W // sz))
+    dx.reshape(-1, Cc)[:] = _cl(xr.grad)
+
+
+def bilinear_fwd(x, B, h, w, H, W, Cc, y):
+    y.reshape(-1, Cc)[:] = _cl(F.interpolate(_nchw(x, B, h, w), size=(H, W), mode="bilinear"))
+
+
+def bilinear_bwd(dy, B, h, w, H, W, Cc, dx):
+    xr = torch.zeros(B, Cc, h, w, requires_grad=True)
+    with torch.enable_grad():
+        F.interpolate(xr, size=(H, W), mode="bilinear").backward(_nchw(dy, B, H, W))
+    dx.reshape(-1, Cc)[:] = _cl(xr.grad)
+
+
+def scale_bf_fwd(x, s, B, T, Fq, Cc, mode, y):
+    xx = x.reshape(B, T, Fq, Cc)
+    sv = s.reshape(B, 1, Fq, 1)
+    y.reshape(B, T, Fq, Cc)[:] = xx * sv if mode == 0 else xx + sv
+
+
+def scale_bf_bwd(x, dy, s, B, T, Fq, Cc, mode, dx, ds):
+    xx, dd = x.reshape(B, T, Fq, Cc), dy.reshape(B, T, Fq, Cc)
+    sv = s.reshape(B, 1, Fq, 1)
+    dx.reshape(B, T, Fq, Cc)[:] = dd * sv if mode == 0 else dd
+    ds.reshape(B, Fq)[:] = (dd * xx).sum((1, 3)) if mode == 0 else dd.sum((1, 3))
+
+
+def preemph_pad(x, R, T, pad, ldo, coef, out):
+    y = x.clone()
+    y[:, 1:] = x[:, 1:] - coef * x[:, :-1]
+    y[:, 0] = x[:, 0] - coef * x[:, 1]
+    out[:, : T + 2 * pad] = F.pad(y.unsqueeze(1), (pad, pad), "reflect").squeeze(1)
+
+
+def ola_fwd(frames, bias, R, Tp, Lk, hop, Tout, est):
+    full = torch.zeros(R, (Tp - 1) * hop + Lk)
+    fr = frames.reshape(R, Tp, Lk)
+    for t in range(Tp):
+        full[:, t * hop: t * hop + Lk] += fr[:, t]
+    est[:, :Tout] = full[:, :Tout] + (bias.reshape(-1)[0] if bias is not None else 0.0)
+
+
+def ola_bwd(dest, R, Tp, Lk, hop, Tout, dframes):
+    full = torch.zeros(R, (Tp - 1) * hop + Lk)
+    full[:, :Tout] = dest.reshape(R, -1)[:, :Tout]
+    dframes.reshape(R, Tp, Lk)[:] = full.unfold(1, Lk, hop)
+
+
+def total_sum(x):
+    return x.sum().reshape(1)
+
+
+EMULATED = [gemm_nt, gemm_tn, reduce_slabs, transpose, affine_fwd, chan_sums, im2col_hw, col2im_hw, elu_fwd, elu_bwd,
+            inorm_fwd, inorm_bwd, dwconv_fwd, dwconv_bwd, avgpool_fwd, avgpool_bwd, bilinear_fwd, bilinear_bwd,
+            scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum]
+
+
+def install(monkeypatch):
+    """Route the dev entry points above to the emulation and lift the CUDA-only guards (tests only)."""
+    import wesep_amd.dev as dev
+    import wesep_amd.functional as f0
+    import wesep_amd.functional_dpccn as fd
+    import wesep_amd.functional_tasnet as ft
+    for fn in EMULATED:
+        monkeypatch.setattr(dev, fn.__name__, fn)
+    for mod in (f0, fd, ft):
+        monkeypatch.setattr(mod, "_need_cuda", lambda t, who: None)

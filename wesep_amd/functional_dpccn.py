@@ -1,0 +1,379 @@
+"""Autograd shims of the DPCCN path over the C ABI.
+
+Channels-last grids: a reference tensor [B, C, T, F] lives here as [B*T*F, C] (H = frame t, W = frequency bin f).
+  * Conv2d            = im2col (per-axis strides) + one split-bf16 MFMA GEMM (K = 9*Cin) with the bias in the epilogue
+  * ConvTranspose2d   = GEMM to [rows, 9*Cout] + the col2im gather (deterministic), i.e. the adjoint pair of the above
+  * ELU, InstanceNorm (no affine, statistics per batch row and channel), AvgPool2d, bilinear upsampling, the speaker
+    fusion scale: csrc/conv2d.hip
+  * TCN block: InstanceNorm1d - ELU - depthwise dilated conv (the Conv-TasNet kernel with an identity norm) - IN - ELU -
+    1x1 conv (+ residual)
+  * STFT / iSTFT (hann, centred, reflect): framing kernel + windowed (inverse) DFT as exact-fp32 MFMA GEMMs on
+    hop-strided row views + overlap-add with the window envelope divided out
+Reference lines: wesep/models/dpccn.py:206-290, wesep/modules/dpccn/convs.py:28-152, speaker.py:102-121."""
+import math
+
+import torch
+
+from . import dev
+from .dev import Rows, flat
+from .functional import _empty, _need_cuda
+from .functional_tasnet import _gemm, _transposed, _wgrad
+
+
+def _pad4(n):
+    return -(-n // 4) * 4
+
+
+# ---------------------------------------------------------------------------------------------
+# convolutions
+# ---------------------------------------------------------------------------------------------
+class Conv2dFn(torch.autograd.Function):
+    """x [B*H*W, Cin] -> conv2d(k x k, stride (sh, sw), padding k//2) + bias: [B*Ho*Wo, Cout]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, geo):
+        _need_cuda(x, "DPCCN")
+        B, H, W, sh, sw = geo
+        Cout, Cin, k, _ = w.shape
+        p = k // 2
+        Ho, Wo = dev.conv_out(H, k, sh, p), dev.conv_out(W, k, sw, p)
+        M = B * Ho * Wo
+        x = x.contiguous()
+        Kk = k * k * Cin
+        ldp = _pad4(Kk)
+        W2 = torch.zeros(Cout, ldp, device=x.device, dtype=torch.float32)
+        W2[:, :Kk] = w.permute(0, 2, 3, 1).reshape(Cout, Kk)
+        patches = Conv2dFn._patches(x, B, H, W, Cin, k, sh, sw, p, M, ldp)
+        y = _gemm(patches, M, ldp, W2, Cout, bias=b)
+        ctx.save_for_backward(x, W2)
+        ctx.geo = (B, H, W, Cin, Cout, k, sh, sw, p, M, ldp, w.shape)
+        return y
+
+    @staticmethod
+    def _patches(x, B, H, W, Cin, k, sh, sw, p, M, ldp):
+        if k == 1 and sh == 1 and sw == 1 and ldp == Cin:
+            return x                                            # 1x1 convolution: the rows are the patches
+        patches = _empty(x.device, M, ldp) if ldp == k * k * Cin else torch.zeros(M, ldp, device=x.device)
+        dev.im2col_hw(x, B, H, W, Cin, k, sh, sw, p, patches, ldp)
+        return patches
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W2 = ctx.saved_tensors
+        B, H, W, Cin, Cout, k, sh, sw, p, M, ldp, wshape = ctx.geo
+        dy = dy.contiguous()
+        Kk = k * k * Cin
+        patches = Conv2dFn._patches(x, B, H, W, Cin, k, sh, sw, p, M, ldp)
+        dW2, db = _wgrad(dy, M, Cout, patches, ldp)
+        del patches
+        dw = dW2[:, :Kk].reshape(Cout, k, k, Cin).permute(0, 3, 1, 2).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dpatches = _gemm(dy, M, Cout, _transposed(W2, Cout, ldp), ldp)
+            if k == 1 and sh == 1 and sw == 1 and ldp == Cin:
+                dx = dpatches
+            else:
+                dx = _empty(x.device, B * H * W, Cin)
+                dev.col2im_hw(dpatches, B, H, W, Cin, k, sh, sw, p, dx)
+        return dx, dw.view(wshape), db, None
+
+
+class ConvTranspose2dFn(torch.autograd.Function):
+    """x [B*H*W, Cin] -> conv_transpose2d(w [Cin, Cout, k, k], stride (sh, sw), padding k//2) + bias:
+    [B*Ht*Wt, Cout], Ht = (H - 1) * sh - 2p + k."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, geo):
+        _need_cuda(x, "DPCCN")
+        B, H, W, sh, sw = geo
+        Cin, Cout, k, _ = w.shape
+        p = k // 2
+        Ht, Wt = (H - 1) * sh - 2 * p + k, (W - 1) * sw - 2 * p + k
+        Cp = _pad4(Cout)                                       # col2im moves 16-byte channel groups
+        x = x.contiguous()
+        d = x.device
+        Wm = torch.zeros(k * k * Cp, Cin, device=d, dtype=torch.float32)   # row (ky*k + kx)*Cp + co, column ci
+        Wm.view(k * k, Cp, Cin)[:, :Cout, :] = w.permute(2, 3, 1, 0).reshape(k * k, Cout, Cin)
+        M = B * H * W
+        P = _gemm(x, M, Cin, Wm, k * k * Cp)
+        y = _empty(d, B * Ht * Wt, Cp)
+        dev.col2im_hw(P, B, Ht, Wt, Cp, k, sh, sw, p, y)
+        bp = torch.zeros(1, Cp, device=d, dtype=torch.float32)
+        bp[0, :Cout] = b
+        dev.affine_fwd(y, None, bp, 1.0, B * Ht * Wt, B * Ht * Wt, Cp, y)
+        ctx.save_for_backward(x, Wm)
+        ctx.geo = (B, H, W, Ht, Wt, Cin, Cout, Cp, k, sh, sw, p, w.shape)
+        return y if Cp == Cout else y[:, :Cout].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wm = ctx.saved_tensors
+        B, H, W, Ht, Wt, Cin, Cout, Cp, k, sh, sw, p, wshape = ctx.geo
+        d = x.device
+        M = B * H * W
+        if Cp != Cout:
+            dyp = torch.zeros(B * Ht * Wt, Cp, device=d, dtype=torch.float32)
+            dyp[:, :Cout] = dy
+            dy = dyp
+        dy = dy.contiguous()
+        dP = _empty(d, M, k * k * Cp)
+        dev.im2col_hw(dy, B, Ht, Wt, Cp, k, sh, sw, p, dP, k * k * Cp)
+        dWm, _ = _wgrad(dP, M, k * k * Cp, x, Cin, with_bias=False)
+        dw = dWm.view(k * k, Cp, Cin)[:, :Cout, :].reshape(k, k, Cout, Cin).permute(3, 2, 0, 1).contiguous()
+        db = dev.chan_sums(dy, None, None, 1, B * Ht * Wt, 1, Cp)[0, 0, :Cout].contiguous()
+        dx = _gemm(dP, M, k * k * Cp, _transposed(Wm, k * k * Cp, Cin), Cin) if ctx.needs_input_grad[0] else None
+        return dx, dw.view(wshape), db, None
+
+
+class Conv1x1ResFn(torch.autograd.Function):
+    """x [M, K] -> x W^T + b (+ res): the TCN's pointwise convolution with the block's residual (convs.py:148-151)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res):
+        _need_cuda(x, "DPCCN")
+        x = x.contiguous()
+        N, K = w.shape[0], w.shape[1]
+        W2 = w.reshape(N, K).contiguous()
+        y = _gemm(x, x.shape[0], K, W2, N, bias=b, R=res.contiguous() if res is not None else None)
+        ctx.save_for_backward(x, W2)
+        ctx.wshape, ctx.has_res = w.shape, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, (N, K) = x.shape[0], W2.shape
+        dW, db = _wgrad(dy, M, N, x, K)
+        dx = _gemm(dy, M, N, _transposed(W2, N, K), K)
+        return dx, dW.view(ctx.wshape), db, (dy if ctx.has_res else None)
+
+
+class DwConvFn(torch.autograd.Function):
+    """Depthwise dilated Conv1d along the rows of each batch row ([B*L, C]; convs.py:134-143) + bias."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, geo):
+        _need_cuda(x, "DPCCN")
+        B, Lr, dil = geo
+        C, _, P = w.shape
+        x = x.contiguous()
+        d = x.device
+        ident = torch.tensor([[0.0, 1.0]], device=d).repeat(B, 1).contiguous()      # (mean 0, rstd 1) per row
+        ones, zeros = torch.ones(C, device=d), torch.zeros(C, device=d)
+        wf = w.reshape(C, P).contiguous()
+        y = _empty(d, B * Lr, C)
+        dev.dwconv_fwd(x, ident, ones, zeros, wf, b, B, Lr, C, P, dil, Lr, y)
+        ctx.save_for_backward(x, ident, ones, zeros, wf)
+        ctx.geo = (B, Lr, C, P, dil, w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ident, ones, zeros, wf = ctx.saved_tensors
+        B, Lr, C, P, dil, wshape = ctx.geo
+        dx = torch.empty_like(x)
+        dw, db = dev.dwconv_bwd(dy.contiguous(), x, ident, ones, zeros, wf, B, Lr, C, P, dil, Lr, dx)
+        return dx, dw.reshape(wshape), db, None
+
+
+# ---------------------------------------------------------------------------------------------
+# pointwise / normalisation / resampling
+# ---------------------------------------------------------------------------------------------
+class EluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x, "DPCCN")
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        dev.elu_fwd(x, y)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        dev.elu_bwd(x, dy.contiguous(), dx)
+        return dx
+
+
+class InstNormFn(torch.autograd.Function):
+    """InstanceNorm{1,2}d without affine: statistics per (batch row, channel) over the row's P positions."""
+
+    @staticmethod
+    def forward(ctx, x, geo):
+        _need_cuda(x, "DPCCN")
+        G, P = geo
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        st = dev.inorm_fwd(x, G, P, x.shape[1], y)
+        ctx.save_for_backward(y, st)
+        ctx.geo = (G, P)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, st = ctx.saved_tensors
+        G, P = ctx.geo
+        dx = torch.empty_like(y)
+        dev.inorm_bwd(y, dy.contiguous(), st, G, P, y.shape[1], dx)
+        return dx, None
+
+
+class AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, geo):
+        B, H, W, sz = geo
+        x = x.contiguous()
+        y = _empty(x.device, B * (H // sz) * (W // sz), x.shape[1])
+        dev.avgpool_fwd(x, B, H, W, x.shape[1], sz, y)
+        ctx.geo = (B, H, W, sz, x.shape[1])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, sz, C = ctx.geo
+        dx = _empty(dy.device, B * H * W, C)
+        dev.avgpool_bwd(dy.contiguous(), B, H, W, C, sz, dx)
+        return dx, None
+
+
+class BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, geo):
+        B, h, w, H, W = geo
+        x = x.contiguous()
+        y = _empty(x.device, B * H * W, x.shape[1])
+        dev.bilinear_fwd(x, B, h, w, H, W, x.shape[1], y)
+        ctx.geo = (B, h, w, H, W, x.shape[1])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, h, w, H, W, C = ctx.geo
+        dx = _empty(dy.device, B * h * w, C)
+        dev.bilinear_bwd(dy.contiguous(), B, h, w, H, W, C, dx)
+        return dx, None
+
+
+class ScaleBFFn(torch.autograd.Function):
+    """x [B*T*F, C] * s[b, f] (mode 0) or + s[b, f] (mode 1)."""
+
+    @staticmethod
+    def forward(ctx, x, s, geo):
+        B, T, Fq, mode = geo
+        x, s = x.contiguous(), s.contiguous()
+        y = torch.empty_like(x)
+        dev.scale_bf_fwd(x, s, B, T, Fq, x.shape[1], mode, y)
+        ctx.save_for_backward(x, s)
+        ctx.geo = geo
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s = ctx.saved_tensors
+        B, T, Fq, mode = ctx.geo
+        dx, ds = torch.empty_like(x), torch.empty_like(s)
+        dev.scale_bf_bwd(x, dy.contiguous(), s, B, T, Fq, x.shape[1], mode, dx, ds)
+        return dx, ds, None
+
+
+# ---------------------------------------------------------------------------------------------
+# STFT / iSTFT (torch.stft / torch.istft with a hann window, centre = True, reflect padding; dpccn.py:212-220,280-288)
+# ---------------------------------------------------------------------------------------------
+_TABLES = {}
+
+
+def _dft_tables(n, device):
+    """(analysis basis [2*nf padded, n], synthesis basis [n, 2*nf padded], window) for a periodic hann window."""
+    key = (n, device.type, device.index)
+    if key not in _TABLES:
+        nf = n // 2 + 1
+        win = torch.hann_window(n, dtype=torch.float64)
+        k = torch.arange(n, dtype=torch.float64)
+        ang = 2.0 * math.pi * torch.arange(nf, dtype=torch.float64).unsqueeze(1) * k.unsqueeze(0) / n
+        ld = _pad4(2 * nf)
+        ana = torch.zeros(ld, n, dtype=torch.float64)
+        ana[0:2 * nf:2] = torch.cos(ang) * win
+        ana[1:2 * nf:2] = -torch.sin(ang) * win
+        # irfft: x[m] = (1/n) * (X0 + (-1)^m X_{n/2} + 2 * sum_{k=1}^{n/2-1} (Re X_k cos - Im X_k sin)); times the window
+        ck = torch.full((nf, 1), 2.0, dtype=torch.float64)
+        ck[0], ck[-1] = 1.0, 1.0
+        syn = torch.zeros(n, ld, dtype=torch.float64)
+        syn[:, 0:2 * nf:2] = (ck * torch.cos(ang)).t() / n * win.unsqueeze(1)
+        sinp = (ck * torch.sin(ang)).t()
+        sinp[:, 0], sinp[:, -1] = 0.0, 0.0                     # imaginary parts of DC / Nyquist are ignored
+        syn[:, 1:2 * nf:2] = -sinp / n * win.unsqueeze(1)
+        _TABLES[key] = (ana.float().to(device).contiguous(), syn.float().to(device).contiguous(), win.float())
+    return _TABLES[key]
+
+
+def stft_ri(wav, n=512, hop=128):
+    """wav [B, T] -> (spec [B*Tf, ld] with columns (re, im) interleaved per bin, Tf); no gradient (mixture input)."""
+    _need_cuda(wav, "DPCCN")
+    with torch.no_grad():
+        wav = wav.float().contiguous()
+        B, T = wav.shape
+        pad = n // 2
+        ana, _, _ = _dft_tables(n, wav.device)
+        ldo = _pad4(T + 2 * pad)
+        xp = torch.zeros(B, ldo, device=wav.device, dtype=torch.float32)
+        dev.preemph_pad(wav, B, T, pad, ldo, 0.0, xp)           # coef 0: plain centred reflect padding
+        Tf = 1 + T // hop
+        spec = _empty(wav.device, B * Tf, ana.shape[0])
+        dev.gemm_nt(A=xp, a_rows=Rows(Tf, ldo, hop), M=B * Tf, N=ana.shape[0], K=n, W=ana, ldw=n, C_out=spec,
+                    c_rows=flat(ana.shape[0]), vec=3, mode="f32")
+    return spec, Tf
+
+
+class IstftFn(torch.autograd.Function):
+    """spec [B*Tf, ld] (re, im interleaved) -> wav [B, nsample]  (torch.istft, hann, centre, length = nsample)."""
+
+    @staticmethod
+    def forward(ctx, spec, geo):
+        B, Tf, nsample, n, hop = geo
+        d = spec.device
+        _, syn, win = _dft_tables(n, d)
+        pad = n // 2
+        spec = spec.contiguous()
+        fr = _gemm(spec, B * Tf, syn.shape[1], syn, n, mode="f32")
+        full = pad + nsample
+        if full > (Tf - 1) * hop + n:
+            raise RuntimeError("iSTFT: requested length exceeds the frames")
+        y = _empty(d, B, full)
+        dev.ola_fwd(fr, None, B, Tf, n, hop, full, y)
+        key = ("env", n, hop, Tf, nsample, d.type, d.index)
+        if key not in _TABLES:
+            env = torch.zeros((Tf - 1) * hop + n, dtype=torch.float64)
+            w2 = win.double() ** 2
+            for t in range(Tf):
+                env[t * hop: t * hop + n] += w2
+            inv = torch.zeros(1, _pad4(nsample))
+            inv[0, :nsample] = (1.0 / env[pad: pad + nsample]).float()
+            _TABLES[key] = inv.to(d).contiguous()
+        inv = _TABLES[key]
+        ld = inv.shape[1]
+        out = torch.zeros(B, ld, device=d, dtype=torch.float32)
+        out[:, :nsample] = y[:, pad:]
+        dev.affine_fwd(out, inv, None, 0.0, B, B, ld, out)
+        ctx.geo = (B, Tf, nsample, n, hop, ld)
+        ctx.save_for_backward(inv, syn)
+        return out[:, :nsample].contiguous()
+
+    @staticmethod
+    def backward(ctx, dwav):
+        inv, syn = ctx.saved_tensors
+        B, Tf, nsample, n, hop, ld = ctx.geo
+        d = dwav.device
+        pad = n // 2
+        g = torch.zeros(B, ld, device=d, dtype=torch.float32)
+        g[:, :nsample] = dwav
+        dev.affine_fwd(g, inv, None, 0.0, B, B, ld, g)
+        full = pad + nsample
+        dy = torch.zeros(B, full, device=d, dtype=torch.float32)
+        dy[:, pad:] = g[:, :nsample]
+        dfr = _empty(d, B * Tf, n)
+        dev.ola_bwd(dy, B, Tf, n, hop, full, dfr)
+        dspec = _gemm(dfr, B * Tf, n, _transposed(syn, n, syn.shape[1]), syn.shape[1], mode="f32")
+        return dspec, None

@@ -1,5 +1,5 @@
 """Model factory with the reference's contract (wesep/models/__init__.py:10-27)."""
-from . import bsrnn, convtasnet
+from . import bsrnn, convtasnet, dpccn
 
 
 def get_model(model_name: str):
@@ -9,7 +9,9 @@ def get_model(model_name: str):
         return getattr(bsrnn, model_name)
     if model_name.startswith("ConvTasNet"):
         return getattr(convtasnet, model_name)
-    if model_name.startswith(("DPCCN", "TFGridNet")):
-        raise NotImplementedError(f"{model_name}: SURVEY.md section 8 rows a16-a17, not built in this round")
+    if model_name.startswith("DPCCN"):
+        return getattr(dpccn, model_name)
+    if model_name.startswith("TFGridNet"):
+        raise NotImplementedError(f"{model_name}: SURVEY.md section 8 row a17, not built in this round")
     print(model_name + " not found !!!")
     exit(1)
