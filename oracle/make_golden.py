@@ -24,6 +24,7 @@ import torch
 from oracle import bsrnn_oracle as O
 from oracle import convtasnet_oracle as CT
 from oracle import dpccn_oracle as DP
+from oracle import tfgridnet_oracle as TG
 from oracle.ref_import import import_reference
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -189,6 +190,50 @@ def run_dpccn_case(name, kw, R, T, seed):
     print(f"{name}: loss={loss.item():.6f} est_rms={est.pow(2).mean().sqrt().item():.4e}")
 
 
+TFGRIDNET_CASES = {
+    # name: (TFGridNetConfig kwargs, rows, T, seed)
+    "tfgridnet_ks4_r2_t1600": (dict(n_layers=2, lstm_hidden_units=24, emb_dim=16, attn_approx_qk_dim=130), 2, 1600, 41),
+    "tfgridnet_ks1_additive_r2_t1280": (dict(n_layers=1, lstm_hidden_units=16, emb_dim=8, emb_ks=1, emb_hs=1,
+                                             attn_n_head=2, attn_approx_qk_dim=65, spk_fuse_type="additive",
+                                             use_spk_transform=True), 2, 1280, 42),
+}
+
+
+def run_tfgridnet_case(name, kw, R, T, seed):
+    """TF-GridNet with fixed embeddings (`joint_training=False`), SI-SDR loss on the estimate."""
+    get_model = import_reference()
+    cfg = TG.TFGridNetConfig(**kw)
+    ref = get_model("TFGridNet")(n_fft=cfg.n_fft, stride=cfg.stride, n_layers=cfg.n_layers,
+                                 lstm_hidden_units=cfg.lstm_hidden_units, attn_n_head=cfg.attn_n_head,
+                                 attn_approx_qk_dim=cfg.attn_approx_qk_dim, emb_dim=cfg.emb_dim, emb_ks=cfg.emb_ks,
+                                 emb_hs=cfg.emb_hs, eps=cfg.eps, spk_emb_dim=cfg.spk_emb_dim,
+                                 use_spk_transform=cfg.use_spk_transform, spk_fuse_type=cfg.spk_fuse_type,
+                                 joint_training=False)
+    params = TG.synth_params(cfg, seed)
+    ref_sd = ref.state_dict()
+    assert list(ref_sd.keys()) == list(params.keys()), "oracle param_shapes() order != reference state_dict"
+    for k in ref_sd:
+        assert tuple(ref_sd[k].shape) == tuple(params[k].shape), k
+    ref.load_state_dict(params, strict=True)
+    ref.train()
+    wav, tgt, emb = O.synth_batch(R, T, seed)
+    est, _ = ref(wav, emb)
+    loss = O.sisdr_loss(est, tgt)
+    loss.backward()
+    out = {"wav": wav.numpy(), "tgt": tgt.numpy(), "emb": emb.numpy(), "est": est.detach().numpy(),
+           "loss": np.float64(loss.item()),
+           "param_checksum": np.float64(sum(float(v.double().abs().sum()) for v in params.values()))}
+    names = []
+    for k, prm in ref.named_parameters():
+        g = prm.grad.detach().reshape(-1)
+        names.append(k)
+        out["gnorm/" + k] = np.float64(g.double().norm().item())
+    out["names"] = np.array(names)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.6f} est_rms={est.pow(2).mean().sqrt().item():.4e}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
@@ -204,3 +249,7 @@ if __name__ == "__main__":
         if only and name not in only:
             continue
         run_dpccn_case(name, kw, R, T, seed)
+    for name, (kw, R, T, seed) in TFGRIDNET_CASES.items():
+        if only and name not in only:
+            continue
+        run_tfgridnet_case(name, kw, R, T, seed)

@@ -174,3 +174,33 @@ def test_dpccn_oracle_matches_reference_fixture(name, golden_dir):
     for k, p in params.items():
         gn = float(g["gnorm/" + k])
         assert abs(float(p.grad.double().norm()) - gn) <= 2e-3 * gn + floor, k
+
+
+# ---- TF-GridNet: oracle pinned ahead of the HIP path -------------------------------
+from oracle import tfgridnet_oracle as TG  # noqa: E402
+from oracle.make_golden import TFGRIDNET_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(TFGRIDNET_CASES))
+def test_tfgridnet_oracle_matches_reference_fixture(name, golden_dir):
+    path = os.path.join(golden_dir, name + ".npz")
+    assert os.path.exists(path), "fixture missing: run python -m oracle.make_golden"
+    g = np.load(path)
+    kw, R, T, seed = TFGRIDNET_CASES[name]
+    cfg = TG.TFGridNetConfig(**kw)
+    params = {k: v.requires_grad_(True) for k, v in TG.synth_params(cfg, seed).items()}
+    wav, tgt, emb = O.synth_batch(R, T, seed)
+    assert np.array_equal(g["wav"], wav.numpy()) and np.array_equal(g["emb"], emb.numpy())
+    chk = sum(float(v.detach().double().abs().sum()) for v in params.values())
+    assert abs(chk - float(g["param_checksum"])) <= 1e-9 * abs(chk)
+    est = TG.tfgridnet_forward(params, cfg, wav, emb)
+    loss = O.sisdr_loss(est, tgt)
+    loss.backward()
+    ref = g["est"]
+    assert np.linalg.norm(est.detach().numpy() - ref) / np.linalg.norm(ref) < 1e-4
+    assert abs(loss.item() - float(g["loss"])) < 1e-3          # dB
+    assert list(g["names"]) == list(params.keys())
+    floor = 1e-5 * max(float(g["gnorm/" + k]) for k in params)
+    for k, p in params.items():
+        gn = float(g["gnorm/" + k])
+        assert abs(float(p.grad.double().norm()) - gn) <= 2e-3 * gn + floor, k
