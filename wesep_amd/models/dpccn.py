@@ -193,7 +193,6 @@ class DPCCN(nn.Module):
         x4[:, :2] = spec[:, :2 * Fq].reshape(B * Tf * Fq, 2)
         geo = (B, Tf, Fq)
         c2 = self.conv2d
-        w4 = torch.zeros(16, 4, 3, 3, device=d, dtype=torch.float32)
         w4 = torch.cat([c2.weight, torch.zeros(16, 2, 3, 3, device=d, dtype=torch.float32)], 1)
         out = FD.Conv2dFn.apply(x4, w4, c2.bias, (B, Tf, Fq, 1, 1))
         out, geo = self.encoder[0](out, geo)
