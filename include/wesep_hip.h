@@ -478,6 +478,11 @@ int ws_scale_bf_fwd(const float* x, const float* s, int B, int T, int F, int C, 
 int ws_scale_bf_bwd(const float* x, const float* dy, const float* s, int B, int T, int F, int C, int mode, float* dx,
                     float* ds, void* stream);
 
+/* ---- TF-GridNet: everything but this row softmax is composed from the entry points
+ * above (gridnet_block.py:212-213): y = softmax(scale * x) per row of n; dx = scale * y * (dy - sum(dy * y))   */
+int ws_softmax_rows_fwd(const float* x, long long rows, int n, float scale, float* y, void* stream);
+int ws_softmax_rows_bwd(const float* y, const float* dy, long long rows, int n, float scale, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -192,9 +192,9 @@ def run_dpccn_case(name, kw, R, T, seed):
 
 TFGRIDNET_CASES = {
     # name: (TFGridNetConfig kwargs, rows, T, seed)
-    "tfgridnet_ks4_r2_t1600": (dict(n_layers=2, lstm_hidden_units=24, emb_dim=16, attn_approx_qk_dim=130), 2, 1600, 41),
+    "tfgridnet_ks4_r2_t1600": (dict(n_layers=2, lstm_hidden_units=24, emb_dim=16, attn_approx_qk_dim=260), 2, 1600, 41),
     "tfgridnet_ks1_additive_r2_t1280": (dict(n_layers=1, lstm_hidden_units=16, emb_dim=8, emb_ks=1, emb_hs=1,
-                                             attn_n_head=2, attn_approx_qk_dim=65, spk_fuse_type="additive",
+                                             attn_n_head=2, attn_approx_qk_dim=260, spk_fuse_type="additive",
                                              use_spk_transform=True), 2, 1280, 42),
 }
 

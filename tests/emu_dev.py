@@ -50,9 +50,18 @@ def gemm_nt(*, A, a_rows, M, C_out, c_rows, N=0, K=0, W=None, ldw=0, bias=None, 
 def gemm_tn(*, G, g_rows, A, a_rows, M, slab, slab_stride, nsplit, rows_per_split, Nn=0, Kk=0, bslab=None,
             bslab_stride=0, out_off=0, bout_off=0, stats=None, gamma=None, beta=None, stat_map=None, shift_rows=0,
             seq_div=1, seq_len=1, groups=None, ngroups=0, max_n=0, max_k=0, vec=1, g_off=0, a_off=0, mode=None):
-    assert groups is None and shift_rows == 0
+    assert groups is None
     g = _gather(G, g_off, M, g_rows, Nn)
-    a = _gather(A, a_off, M, a_rows, Kk)
+    if shift_rows:      # m' = m + shift_rows, zeroed when the step index ((m // seq_div) % seq_len) leaves the sequence
+        m = torch.arange(M)
+        step = (m // seq_div) % seq_len + (1 if shift_rows > 0 else -1)
+        ok = (step >= 0) & (step < seq_len)
+        mm = torch.where(ok, m + shift_rows, m)
+        div, s1, s2 = a_rows
+        off = a_off + (mm // div) * s1 + (mm % div) * s2
+        a = A.reshape(-1)[off.unsqueeze(1) + torch.arange(Kk).unsqueeze(0)] * ok.unsqueeze(1)
+    else:
+        a = _gather(A, a_off, M, a_rows, Kk)
     if stats is not None:
         d1, m1, d2, m2, base = stat_map
         m = torch.arange(M)
@@ -233,9 +242,136 @@ def total_sum(x):
     return x.sum().reshape(1)
 
 
+# ---- recurrence (plain row layout, hidden 256; include/wesep_hip.h ws_lstm_*) ------------------------------------
+def lstm_pack(whh_f, whh_r, pack_fwd, pack_bwd, mode=3):
+    raw = torch.cat([whh_f.reshape(-1), whh_r.reshape(-1)])
+    pack_fwd.reshape(-1)[: raw.numel()] = raw
+    pack_bwd.reshape(-1)[: raw.numel()] = raw
+
+
+def _lstm_rows(sm, t):
+    s = torch.arange(sm.nseq)
+    return (s // sm.div) * sm.s1 + (s % sm.div) * sm.s2 + t * sm.step_rows
+
+
+def lstm_fwd(gates, cbuf, hcat, wpack, sm, mode=3):
+    H = 256
+    W = wpack.reshape(-1)[: 2 * 4 * H * H].reshape(2, 4 * H, H)
+    g2 = gates.reshape(-1, 2, 4 * H)
+    c2, h2 = cbuf.reshape(-1, 2, H), hcat.reshape(-1, 2, H)
+    for d in (0, 1):
+        h = torch.zeros(sm.nseq, H)
+        c = torch.zeros(sm.nseq, H)
+        order = range(sm.L) if d == 0 else range(sm.L - 1, -1, -1)
+        for t in order:
+            r = _lstm_rows(sm, t)
+            pre = g2[r, d] + h @ W[d].t()
+            i, f, g, o = pre[:, :H].sigmoid(), pre[:, H:2 * H].sigmoid(), pre[:, 2 * H:3 * H].tanh(), pre[:, 3 * H:].sigmoid()
+            c = f * c + i * g
+            h = o * c.tanh()
+            g2[r, d] = torch.cat([i, f, g, o], 1)
+            c2[r, d] = c
+            h2[r, d] = h
+
+
+def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode=3):
+    H = 256
+    W = wpack.reshape(-1)[: 2 * 4 * H * H].reshape(2, 4 * H, H)
+    g2 = gates.reshape(-1, 2, 4 * H)
+    c2, dh2 = cbuf.reshape(-1, 2, H), dhcat.reshape(-1, 2, H)
+    for d in (0, 1):
+        dh_rec = torch.zeros(sm.nseq, H)
+        dc = torch.zeros(sm.nseq, H)
+        order = list(range(sm.L)) if d == 0 else list(range(sm.L - 1, -1, -1))
+        for idx in range(sm.L - 1, -1, -1):
+            t = order[idx]
+            r = _lstm_rows(sm, t)
+            a = g2[r, d]
+            i, f, g, o = a[:, :H], a[:, H:2 * H], a[:, 2 * H:3 * H], a[:, 3 * H:]
+            c = c2[r, d]
+            cprev = c2[_lstm_rows(sm, order[idx - 1]), d] if idx > 0 else torch.zeros_like(c)
+            dh = dh2[r, d] + dh_rec
+            tc = c.tanh()
+            dcv = dc + dh * o * (1 - tc * tc)
+            dpre = torch.cat([dcv * g * i * (1 - i), dcv * cprev * f * (1 - f), dcv * i * (1 - g * g),
+                              dh * tc * o * (1 - o)], 1)
+            dc = dcv * f
+            dh_rec = dpre @ W[d]
+            g2[r, d] = dpre
+
+
+# ---- norms / activations of tasnet.hip, norm.hip ---------------------------------------------------------------
+def group_stats(x, geo, stats, eps=1.19e-7):
+    assert geo.L == 1 and geo.gdiv == 1 and geo.gs2 == 0        # the row-wise (cLN) geometry only
+    xx = x.reshape(-1)[: geo.ngroups * geo.gs1].reshape(geo.ngroups, geo.gs1)[:, : geo.W]
+    mean = xx.mean(1)
+    var = ((xx - mean.unsqueeze(1)) ** 2).mean(1)
+    stats.reshape(-1, 2)[:, 0] = mean
+    stats.reshape(-1, 2)[:, 1] = 1.0 / torch.sqrt(var + eps)
+
+
+def flat_stats(x, ngroups, n_per_group, stats, eps=1e-5):
+    xx = x.reshape(ngroups, n_per_group)
+    mean = xx.mean(1)
+    var = ((xx - mean.unsqueeze(1)) ** 2).mean(1)
+    stats.reshape(-1, 2)[:, 0] = mean
+    stats.reshape(-1, 2)[:, 1] = 1.0 / torch.sqrt(var + eps)
+
+
+def gn_bwd_reduce(x, dxn, stats, geo, ab, gamma=None, gamma_tab=None):
+    assert geo.L == 1 and geo.gdiv == 1 and gamma_tab is None
+    M, Wd = geo.ngroups, geo.W
+    st = stats.reshape(-1, 2)
+    xh = (x.reshape(M, Wd) - st[:, 0:1]) * st[:, 1:2]
+    dg = dxn.reshape(M, Wd) * gamma.reshape(-1)
+    ab.reshape(-1, 2)[:, 0] = dg.mean(1)
+    ab.reshape(-1, 2)[:, 1] = (dg * xh).mean(1)
+
+
+def norm_ab(sums, gamma, ngroups, Cc, n_per_group, ab):
+    s = sums.reshape(ngroups, 2, Cc)
+    ab.reshape(-1, 2)[:, 0] = (s[:, 0] * gamma).sum(1) / n_per_group
+    ab.reshape(-1, 2)[:, 1] = (s[:, 1] * gamma).sum(1) / n_per_group
+
+
+def norm_bwd_apply_cl(x, dxn, stats, ab, gamma, res, rows, Cc, st_div, dx):
+    s = torch.arange(rows) // st_div
+    st, a = stats.reshape(-1, 2), ab.reshape(-1, 2)
+    xh = (x.reshape(rows, Cc) - st[s, 0:1]) * st[s, 1:2]
+    r = (dxn.reshape(rows, Cc) * gamma.reshape(-1) - a[s, 0:1] - xh * a[s, 1:2]) * st[s, 1:2]
+    if res is not None:
+        r = r + res.reshape(rows, Cc)
+    dx.reshape(rows, Cc)[:] = r
+
+
+def prelu_fwd(x, rb, a, rows, Cc, rows_per_r, y):
+    v = x.reshape(rows, Cc)
+    if rb is not None:
+        v = v + rb.reshape(-1, Cc)[torch.arange(rows) // rows_per_r]
+        x.reshape(rows, Cc)[:] = v
+    y.reshape(rows, Cc)[:] = torch.where(v > 0, v, a.reshape(-1)[0] * v)
+
+
+def prelu_bwd(pre, dy, a, dx):
+    da = (dy * torch.clamp(pre, max=0)).sum().reshape(1)
+    dx.copy_(torch.where(pre > 0, dy, a.reshape(-1)[0] * dy))
+    return da
+
+
+def softmax_rows_fwd(x, rows, n, scale, y):
+    y.reshape(rows, n)[:] = torch.softmax(scale * x.reshape(rows, n), 1)
+
+
+def softmax_rows_bwd(y, dy, rows, n, scale, dx):
+    yy, dd = y.reshape(rows, n), dy.reshape(rows, n)
+    dx.reshape(rows, n)[:] = scale * yy * (dd - (dd * yy).sum(1, keepdim=True))
+
+
 EMULATED = [gemm_nt, gemm_tn, reduce_slabs, transpose, affine_fwd, chan_sums, im2col_hw, col2im_hw, elu_fwd, elu_bwd,
             inorm_fwd, inorm_bwd, dwconv_fwd, dwconv_bwd, avgpool_fwd, avgpool_bwd, bilinear_fwd, bilinear_bwd,
-            scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum]
+            scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum, lstm_pack, lstm_fwd, lstm_bwd,
+            group_stats, flat_stats, gn_bwd_reduce, norm_ab, norm_bwd_apply_cl, prelu_fwd, prelu_bwd, softmax_rows_fwd,
+            softmax_rows_bwd]
 
 
 def install(monkeypatch):
@@ -244,7 +380,8 @@ def install(monkeypatch):
     import wesep_amd.functional as f0
     import wesep_amd.functional_dpccn as fd
     import wesep_amd.functional_tasnet as ft
+    import wesep_amd.functional_tfgridnet as fg
     for fn in EMULATED:
         monkeypatch.setattr(dev, fn.__name__, fn)
-    for mod in (f0, fd, ft):
+    for mod in (f0, fd, ft, fg):
         monkeypatch.setattr(mod, "_need_cuda", lambda t, who: None)

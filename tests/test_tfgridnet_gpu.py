@@ -1,0 +1,74 @@
+"""GPU parity of the TF-GridNet path: the row-softmax kernel against torch, and the assembled
+model (zero-padded hidden-256 recurrences, window row views, flattened layer norms, per-head attention GEMMs) against
+the fixtures generated from the real reference (waveform <= 1e-3, loss <= 1e-2 dB, gradient norms)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_softmax_rows_matches_torch():
+    from wesep_amd import functional_tfgridnet as FG
+    d = _cuda()
+    torch.manual_seed(0)
+    x = (torch.randn(37, 301, device=d) * 3).requires_grad_(True)
+    y = FG.SoftmaxFn.apply(x, 0.37)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = torch.softmax(0.37 * xr, 1)
+    g = torch.randn_like(yr)
+    y.backward(g)
+    yr.backward(g)
+    assert rel(y, yr) < 1e-6 and rel(x.grad, xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["tfgridnet_ks4_r2_t1600", "tfgridnet_ks1_additive_r2_t1280"])
+def test_tfgridnet_model_matches_reference_fixture(name, golden_dir):
+    from oracle import bsrnn_oracle as O
+    from oracle import tfgridnet_oracle as TG
+    from oracle.make_golden import TFGRIDNET_CASES
+    from wesep_amd.models import get_model
+    from wesep_amd.utils.losses import parse_loss
+    d = _cuda()
+    kw, R, T, seed = TFGRIDNET_CASES[name]
+    cfg = TG.TFGridNetConfig(**kw)
+    params = TG.synth_params(cfg, seed)
+    model = get_model("TFGridNet")(**kw, joint_training=False)
+    model.load_state_dict(params, strict=True)
+    model = model.to(d).train()
+    wav, tgt, emb = O.synth_batch(R, T, seed)
+    est, dummy = model(wav.to(d), emb.to(d))
+    assert dummy.dim() == 0
+    loss = parse_loss("SISDR")[0](est, tgt.to(d))
+    loss.backward()
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    assert rel(est, torch.from_numpy(g["est"])) < 1e-3
+    assert abs(loss.item() - float(g["loss"])) < 1e-2
+    floor = 1e-3 * max(float(g["gnorm/" + k]) for k, _ in model.named_parameters())
+    bad = []
+    for k, prm in model.named_parameters():
+        gn = float(g["gnorm/" + k])
+        if prm.grad is None or abs(float(prm.grad.norm()) - gn) > 3e-2 * gn + floor:
+            bad.append((k, None if prm.grad is None else float(prm.grad.norm()), gn))
+    assert not bad, bad[:8]
+
+
+def test_tfgridnet_unbuilt_variants_fail_loudly():
+    from wesep_amd.models import get_model
+    for kw in (dict(joint_training=False, n_imics=2), dict(joint_training=False, n_srcs=2),
+               dict(joint_training=False, spk_fuse_type="concat"), dict(joint_training=False, lstm_hidden_units=320)):
+        with pytest.raises(NotImplementedError):
+            get_model("TFGridNet")(**kw)

@@ -172,6 +172,8 @@ _SIGS = {
     "ws_bilinear_bwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "ws_scale_bf_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "ws_scale_bf_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "ws_softmax_rows_fwd": (_i, [_p, _ll, _i, C.c_float, _p, _p]),
+    "ws_softmax_rows_bwd": (_i, [_p, _p, _ll, _i, C.c_float, _p, _p]),
     "ws_preemph_pad": (_i, [_p, _i, _i, _i, _i, C.c_float, _p, _p]),
     "ws_power_spec": (_i, [_p, _ll, _i, _i, _i, _p, _p]),
     "ws_log_eps": (_i, [_p, _ll, C.c_float, _p]),

@@ -566,3 +566,55 @@ extern "C" int ws_scale_bf_bwd(const float* x, const float* dy, const float* s, 
                      dx, ds);
   return ws_check_launch("ws_scale_bf_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax for the full-band self-attention of TF-GridNet (gridnet_block.py:212-213):
+//   y[r][:] = softmax(scale * x[r][:]);   dx = scale * y * (dy - sum(dy * y))      one workgroup per row
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const float* __restrict__ x, int n, float scale,
+                                                               float* __restrict__ y) {
+  __shared__ float red[16];
+  const float* xr = x + (long long)blockIdx.x * n;
+  float* yr = y + (long long)blockIdx.x * n;
+  float mx = -3.4e38f;
+  for (int j = threadIdx.x; j < n; j += 256) mx = fmaxf(mx, scale * xr[j]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float e = expf(scale * xr[j] - mx);
+    yr[j] = e;
+    se += e;
+  }
+  se = ws_block_sum(se, red);
+  const float inv = 1.f / se;
+  for (int j = threadIdx.x; j < n; j += 256) yr[j] *= inv;
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                               int n, float scale, float* __restrict__ dx) {
+  __shared__ float red[16];
+  const long long o = (long long)blockIdx.x * n;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) s += dy[o + j] * y[o + j];
+  s = ws_block_sum(s, red);
+  for (int j = threadIdx.x; j < n; j += 256) dx[o + j] = scale * y[o + j] * (dy[o + j] - s);
+}
+
+extern "C" int ws_softmax_rows_fwd(const float* x, long long rows, int n, float scale, float* y, void* stream) {
+  WS_REQUIRE(x && y && rows > 0 && rows < (1LL << 31) && n > 0, "ws_softmax_rows_fwd: bad args");
+  hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, n, scale, y);
+  return ws_check_launch("ws_softmax_rows_fwd");
+}
+
+extern "C" int ws_softmax_rows_bwd(const float* y, const float* dy, long long rows, int n, float scale, float* dx,
+                                   void* stream) {
+  WS_REQUIRE(y && dy && dx && rows > 0 && rows < (1LL << 31) && n > 0, "ws_softmax_rows_bwd: bad args");
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, y, dy, n, scale,
+                     dx);
+  return ws_check_launch("ws_softmax_rows_bwd");
+}

@@ -843,3 +843,15 @@ def scale_bf_bwd(x, dy, s, B: int, T: int, Fq: int, Cc: int, mode: int, dx, ds):
     for n, t in (("x", x), ("dy", dy), ("s", s), ("dx", dx), ("ds", ds)):
         _chk(t, n)
     _call("ws_scale_bf_bwd", _p(x), _p(dy), _p(s), B, T, Fq, Cc, mode, _p(dx), _p(ds))
+
+
+def softmax_rows_fwd(x, rows: int, n: int, scale: float, y):
+    _chk(x, "x")
+    _chk(y, "y")
+    _call("ws_softmax_rows_fwd", _p(x), rows, n, scale, _p(y))
+
+
+def softmax_rows_bwd(y, dy, rows: int, n: int, scale: float, dx):
+    for nm, t in (("y", y), ("dy", dy), ("dx", dx)):
+        _chk(t, nm)
+    _call("ws_softmax_rows_bwd", _p(y), _p(dy), rows, n, scale, _p(dx))

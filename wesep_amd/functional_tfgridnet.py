@@ -1,0 +1,263 @@
+"""Autograd shims of the TF-GridNet path over the C ABI.
+
+Channels-last grids [B*T*Q, C] (T frames, Q frequency bins).  Everything is composed from entry points that other rows
+already use, plus one row-softmax kernel:
+  * the BLSTMs (hidden 192, input emb_dim * emb_ks) run on the split-bf16 recurrence kernels built for hidden 256:
+    the weights are ZERO-PADDED to 256 units -- a padded unit has pre-activations 0, so i = f = o = 1/2, g = 0, c = h = 0
+    for ever, and its outgoing weights are zero: the padded network computes exactly the same function;
+  * `F.unfold(..., (emb_ks, 1), stride (emb_hs, 1))` in front of a BLSTM is an overlapping ROW VIEW of the layer-normed
+    sequence (window of emb_ks consecutive positions = emb_ks * C contiguous floats) fed to the input-projection GEMM; its
+    adjoint and the ConvTranspose1d behind the BLSTM are GEMM + the generic overlap-add kernel (hop = emb_hs * C floats);
+  * LayerNorm over C, LayerNormalization4DCF over (C, F) and AllHeadPReLULayerNormalization4DCF over (E, F) are all
+    "one mean/variance per row, affine per column" on a suitably flattened [rows, width] view -> the cLN kernels;
+  * the full-band self-attention is two GEMMs per (batch row, head) around the row softmax.
+Reference lines: wesep/models/tfgridnet.py:197-302, wesep/modules/tfgridnet/gridnet_block.py:118-284."""
+import torch
+
+from . import _lib as L
+from . import dev
+from .dev import BIG, Rows, SeqMap, flat
+from .functional import _empty, _need_cuda, _reduce_new
+from .functional_tasnet import _cln_geom, _gemm, _transposed, _wgrad, norm_backward
+
+HP = L.LSTM_H          # 256: hidden size the recurrence kernels are built for
+G4P = 4 * HP
+
+
+def pad_lstm(w_ih, w_hh, b_ih, b_hh, col_perm=None):
+    """nn.LSTM tensors of hidden size h <= 256 -> (w_ih [1024, K], w_hh [1024, 256], b [1024]) zero-padded to 256 units
+    (gate-major rows g*256 + u).  torch index ops on small weight tensors: gradients flow back through them."""
+    h = w_hh.shape[1]
+    if h > HP:
+        raise NotImplementedError(f"TF-GridNet lstm_hidden_units={h} > {HP}")
+    d = w_ih.device
+    rows = (torch.arange(4, device=d).unsqueeze(1) * HP + torch.arange(h, device=d).unsqueeze(0)).reshape(-1)
+    wi = w_ih if col_perm is None else w_ih[:, col_perm]
+    wi_p = torch.zeros(G4P, wi.shape[1], device=d, dtype=torch.float32).index_copy(0, rows, wi)
+    wh_c = torch.zeros(4 * h, HP, device=d, dtype=torch.float32)
+    wh_c = torch.cat([w_hh, wh_c[:, h:]], 1)
+    wh_p = torch.zeros(G4P, HP, device=d, dtype=torch.float32).index_copy(0, rows, wh_c)
+    b_p = torch.zeros(G4P, device=d, dtype=torch.float32).index_copy(0, rows, b_ih + b_hh)
+    return wi_p, wh_p, b_p
+
+
+def pad_hidden_cols(w, h):
+    """[N, 2h] (forward | reverse hidden) -> [N, 512] with each half zero-padded to 256 columns."""
+    N = w.shape[0]
+    z = torch.zeros(N, HP - h, device=w.device, dtype=torch.float32)
+    return torch.cat([w[:, :h], z, w[:, h:], z], 1)
+
+
+class BlstmFn(torch.autograd.Function):
+    """src [nseq*Lr, C] (layer-normed) -> hcat [nseq*n, 512]: windows of ks positions (hop hs) -> input projection ->
+    bidirectional recurrence.  Weights are the padded tensors of pad_lstm (both directions stacked)."""
+
+    @staticmethod
+    def forward(ctx, src, geo, wcat, bcat, whf, whr):
+        _need_cuda(src, "TF-GridNet")
+        nseq, Lr, C, ks, hs = geo
+        n = (Lr - ks) // hs + 1
+        P, K = nseq * n, ks * C
+        src = src.contiguous()
+        d = src.device
+        rows = Rows(n, Lr * C, hs * C)
+        gates = _empty(d, P, 2 * G4P)
+        dev.gemm_nt(A=src, a_rows=rows, M=P, N=2 * G4P, K=K, W=wcat, ldw=K, bias=bcat, C_out=gates, c_rows=flat(2 * G4P),
+                    vec=3 if (C % 4 == 0) else 0)
+        pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
+        mode = dev.lstm_mode(nseq)
+        dev.lstm_pack(whf.contiguous(), whr.contiguous(), pack_f, pack_b, mode)
+        cbuf, hcat = _empty(d, P, 2 * HP), _empty(d, P, 2 * HP)
+        seq = SeqMap(nseq, BIG, 0, n, 1, n)
+        dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, mode)
+        ctx.save_for_backward(src, gates, cbuf, hcat, wcat, pack_b)
+        ctx.geo = (nseq, Lr, C, ks, hs, n, mode)
+        return hcat
+
+    @staticmethod
+    def backward(ctx, dhcat):
+        src, gates, cbuf, hcat, wcat, pack_b = ctx.saved_tensors
+        nseq, Lr, C, ks, hs, n, mode = ctx.geo
+        P, K = nseq * n, ks * C
+        d = src.device
+        seq = SeqMap(nseq, BIG, 0, n, 1, n)
+        gates = gates.clone()                                    # BPTT works in place; keep the saved tensor intact
+        dev.lstm_bwd(gates, cbuf, hcat, dhcat.contiguous(), pack_b, seq, mode)
+        nsplit, rps = dev.tn_splits(P)
+        dwhh = []
+        slab = _empty(d, nsplit, G4P * HP)
+        for di in (0, 1):
+            dev.gemm_tn(G=gates, g_rows=flat(2 * G4P), g_off=di * G4P, A=hcat, a_rows=flat(2 * HP), a_off=di * HP, M=P,
+                        Nn=G4P, Kk=HP, slab=slab, slab_stride=G4P * HP, nsplit=nsplit, rows_per_split=rps,
+                        shift_rows=(-1 if di == 0 else 1), seq_div=1, seq_len=n)
+            dwhh.append(_reduce_new(slab, nsplit, G4P * HP, (G4P, HP)))
+        rows = Rows(n, Lr * C, hs * C)
+        dwcat, dbcat = _wgrad(gates, P, 2 * G4P, src, K, a_rows=rows, vec=1 if C % 4 == 0 else 0)
+        dxu = _gemm(gates, P, 2 * G4P, _transposed(wcat, 2 * G4P, K), K)
+        dsrc = _empty(d, nseq, Lr * C)
+        dev.ola_fwd(dxu, None, nseq, n, K, hs * C, Lr * C, dsrc)          # adjoint of the window view: overlap-add
+        return dsrc.view(nseq * Lr, C), None, dwcat, dbcat, dwhh[0], dwhh[1]
+
+
+class Deconv1dFn(torch.autograd.Function):
+    """hcat [nseq*n, 512] -> [nseq*Lr, C]: ConvTranspose1d(2h -> C, ks, stride hs) along the sequence
+    (gridnet_block.py:47-51): GEMM to frames (column i*C + c) + overlap-add with hop hs*C floats."""
+
+    @staticmethod
+    def forward(ctx, hcat, geo, Wt):
+        nseq, Lr, C, ks, hs, n = geo
+        hcat = hcat.contiguous()
+        fr = _gemm(hcat, nseq * n, 2 * HP, Wt, ks * C)
+        y = _empty(hcat.device, nseq, Lr * C)
+        dev.ola_fwd(fr, None, nseq, n, ks * C, hs * C, Lr * C, y)
+        ctx.save_for_backward(hcat, Wt)
+        ctx.geo = geo
+        return y.view(nseq * Lr, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        hcat, Wt = ctx.saved_tensors
+        nseq, Lr, C, ks, hs, n = ctx.geo
+        P = nseq * n
+        dfr = _empty(dy.device, P, ks * C)
+        dev.ola_bwd(dy.contiguous().view(nseq, Lr * C), nseq, n, ks * C, hs * C, Lr * C, dfr)
+        dWt, _ = _wgrad(dfr, P, ks * C, hcat, 2 * HP, with_bias=False)
+        dh = _gemm(dfr, P, ks * C, _transposed(Wt, ks * C, 2 * HP), 2 * HP)
+        return dh, None, dWt
+
+
+class AddRowVecFn(torch.autograd.Function):
+    """x [M, C] + b [C]."""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        M, C = x.shape
+        dev.affine_fwd(x, None, b.contiguous().view(1, C), 1.0, M, M, C, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        M, C = dy.shape
+        db = dev.chan_sums(dy, None, None, 1, M, 1, C)[0, 0].contiguous()
+        return dy, db
+
+
+class RowLNFn(torch.autograd.Function):
+    """y = gamma * (x - mean_row) * rstd_row + beta over the width of each row (eps 1e-5)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        _need_cuda(x, "TF-GridNet")
+        x = x.contiguous()
+        M, Wd = x.shape
+        d = x.device
+        st = _empty(d, M, 2)
+        dev.group_stats(x, _cln_geom(M, Wd), st, dev.LN_EPS)
+        y = torch.empty_like(x)
+        g, b = gamma.contiguous().view(-1), beta.contiguous().view(-1)
+        dev.dwconv_fwd(x, st, g, b, torch.ones(Wd, 1, device=d), torch.zeros(Wd, device=d), M, 1, Wd, 1, 1, 1, y)
+        ctx.save_for_backward(x, st, g)
+        ctx.shapes = (gamma.shape, beta.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st, g = ctx.saved_tensors
+        M, Wd = x.shape
+        dx, dg, db = norm_backward(x, dy.contiguous().clone(), st, g, "cLN", M, 1, Wd)
+        return dx, dg.view(ctx.shapes[0]), db.view(ctx.shapes[1])
+
+
+class GroupLNFn(torch.autograd.Function):
+    """nn.GroupNorm(1, C) on [B*P, C]: one mean/variance per batch row over (P, C), affine per channel."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, geo):
+        _need_cuda(x, "TF-GridNet")
+        B, P = geo
+        x = x.contiguous()
+        C = x.shape[1]
+        d = x.device
+        st = _empty(d, B, 2)
+        dev.flat_stats(x, B, P * C, st, dev.LN_EPS)
+        y = torch.empty_like(x)
+        dev.dwconv_fwd(x, st, gamma.contiguous(), beta.contiguous(), torch.ones(C, 1, device=d),
+                       torch.zeros(C, device=d), B, P, C, 1, 1, P, y)
+        ctx.save_for_backward(x, st, gamma.contiguous())
+        ctx.geo = (B, P, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st, g = ctx.saved_tensors
+        B, P, C = ctx.geo
+        dx, dg, db = norm_backward(x, dy.contiguous().clone(), st, g, "gLN", B, P, C)
+        return dx, dg, db, None
+
+
+class PReluFn(torch.autograd.Function):
+    """nn.PReLU with one slope a [1]."""
+
+    @staticmethod
+    def forward(ctx, x, a):
+        x = x.contiguous()
+        if x.numel() % 4:
+            raise L.WesepHipError("PReLU: the element count must be a multiple of 4")
+        y = torch.empty_like(x)
+        dev.prelu_fwd(x.view(-1, 4), None, a, x.numel() // 4, 4, x.numel() // 4, y.view(-1, 4))   # elementwise: any 16-byte view
+        ctx.save_for_backward(x, a)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        da = dev.prelu_bwd(x.view(-1), dy.contiguous().view(-1), a, dx.view(-1))
+        return dx, da.view(a.shape)
+
+
+class SoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        dev.softmax_rows_fwd(x, x.shape[0], x.shape[1], scale, y)
+        ctx.save_for_backward(y)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        dev.softmax_rows_bwd(y, dy.contiguous(), y.shape[0], y.shape[1], ctx.scale, dx)
+        return dx, None
+
+
+class MatmulNTFn(torch.autograd.Function):
+    """A [M, K] x B [N, K]^T -> [M, N] (both operands differentiable): the attention products."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        A, B = A.contiguous(), B.contiguous()
+        M, K = A.shape
+        N = B.shape[0]
+        ctx.save_for_backward(A, B)
+        return _gemm(A, M, K, B, N)
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        dC = dC.contiguous()
+        M, K = A.shape
+        N = B.shape[0]
+        dA = _gemm(dC, M, N, _transposed(B, N, K), K)
+        if N % 4 == 0:
+            dB, _ = _wgrad(dC, M, N, A, K, with_bias=False)                     # dC^T A
+        else:                                                                  # (A^T dC)^T: the TN kernel wants Nn % 4 == 0
+            dBt, _ = _wgrad(A, M, K, dC, N, with_bias=False, vec=0)
+            dB = _transposed(dBt, K, N)
+        return dA, dB

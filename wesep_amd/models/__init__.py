@@ -1,5 +1,5 @@
 """Model factory with the reference's contract (wesep/models/__init__.py:10-27)."""
-from . import bsrnn, convtasnet, dpccn
+from . import bsrnn, convtasnet, dpccn, tfgridnet
 
 
 def get_model(model_name: str):
@@ -12,6 +12,6 @@ def get_model(model_name: str):
     if model_name.startswith("DPCCN"):
         return getattr(dpccn, model_name)
     if model_name.startswith("TFGridNet"):
-        raise NotImplementedError(f"{model_name}: SURVEY.md section 8 row a17, not built in this round")
+        return getattr(tfgridnet, model_name)
     print(model_name + " not found !!!")
     exit(1)

@@ -1,0 +1,270 @@
+"""TF-GridNet on MI355X: constructor arguments, module tree and `state_dict` keys of the
+reference `wesep.models.tfgridnet.TFGridNet` (wesep/models/tfgridnet.py:23-302) and `GridNetBlock`
+(wesep/modules/tfgridnet/gridnet_block.py); `forward` is a chain of C-ABI launches (wesep_amd/functional_tfgridnet.py,
+functional_dpccn.py) on channels-last [B*T*Q, C] grids.  nn.LSTM / nn.Conv2d / nn.LayerNorm objects are parameter
+containers only.
+
+Built: single microphone, one source, multiply / additive fusion, PReLU activation, fixed embeddings or joint training
+with the wespeaker ResNet18/34 (fbank or raw enrollment audio), any emb_ks / emb_hs, lstm_hidden_units <= 256.
+Not built (raise): multi-microphone input, n_srcs > 1, concat / FiLM fusion, eps != 1e-5."""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+from torch.nn.parameter import Parameter
+
+from .. import functional as F_
+from .. import functional_dpccn as FD
+from .. import functional_tfgridnet as FG
+from ..modules.common.speaker import LinearLayer, SpeakerTransform
+
+
+class LayerNormalization4DCF(nn.Module):
+    """gridnet_block.py:230-255 (parameter container): gamma / beta [1, C, 1, F]."""
+
+    def __init__(self, input_dimension, eps=1e-5):
+        super().__init__()
+        assert len(input_dimension) == 2
+        param_size = [1, input_dimension[0], 1, input_dimension[1]]
+        self.gamma = Parameter(torch.Tensor(*param_size).to(torch.float32))
+        self.beta = Parameter(torch.Tensor(*param_size).to(torch.float32))
+        init.ones_(self.gamma)
+        init.zeros_(self.beta)
+        self.eps = eps
+
+
+class AllHeadPReLULayerNormalization4DCF(nn.Module):
+    """gridnet_block.py:258-284 (parameter container): gamma / beta [1, H, E, 1, F], act = PReLU(H)."""
+
+    def __init__(self, input_dimension, eps=1e-5):
+        super().__init__()
+        assert len(input_dimension) == 3
+        H, E, n_freqs = input_dimension
+        param_size = [1, H, E, 1, n_freqs]
+        self.gamma = Parameter(torch.Tensor(*param_size).to(torch.float32))
+        self.beta = Parameter(torch.Tensor(*param_size).to(torch.float32))
+        init.ones_(self.gamma)
+        init.zeros_(self.beta)
+        self.act = nn.PReLU(num_parameters=H, init=0.25)
+        self.eps, self.H, self.E, self.n_freqs = eps, H, E, n_freqs
+
+
+def _heads(x, B, T, Q, nh, ch, norm):
+    """x [B*T*Q, nh*ch] -> per head [B*T, Q*ch] rows after PReLU(head slope) + LN over (ch, Q) with the head's affine."""
+    xh = x.view(B, T, Q, nh, ch).permute(3, 0, 1, 2, 4).contiguous()            # [nh, B, T, Q, ch]
+    out = []
+    for h in range(nh):
+        v = FG.PReluFn.apply(xh[h].reshape(B * T * Q, ch), norm.act.weight[h:h + 1])
+        g = norm.gamma[0, h, :, 0, :].t().reshape(-1)                           # [Q*ch], index q*ch + e
+        b = norm.beta[0, h, :, 0, :].t().reshape(-1)
+        out.append(FG.RowLNFn.apply(v.view(B * T, Q * ch), g, b))
+    return out
+
+
+class GridNetBlock(nn.Module):
+    def __getitem__(self, key):
+        return getattr(self, key)
+
+    def __init__(self, emb_dim, emb_ks, emb_hs, n_freqs, hidden_channels, n_head=4, approx_qk_dim=512,
+                 activation="prelu", eps=1e-5):
+        super().__init__()
+        if activation != "prelu":
+            raise NotImplementedError("TF-GridNet: activation 'prelu' only (the reference asserts the same)")
+        if abs(eps - 1e-5) > 1e-12:
+            raise NotImplementedError("TF-GridNet: eps = 1e-5 only (norm kernels)")
+        in_channels = emb_dim * emb_ks
+        for path in ("intra", "inter"):
+            setattr(self, f"{path}_norm", nn.LayerNorm(emb_dim, eps=eps))
+            setattr(self, f"{path}_rnn", nn.LSTM(in_channels, hidden_channels, 1, batch_first=True, bidirectional=True))
+            if emb_ks == emb_hs:
+                setattr(self, f"{path}_linear", nn.Linear(hidden_channels * 2, in_channels))
+            else:
+                setattr(self, f"{path}_linear", nn.ConvTranspose1d(hidden_channels * 2, emb_dim, emb_ks, stride=emb_hs))
+        E = math.ceil(approx_qk_dim * 1.0 / n_freqs)
+        assert emb_dim % n_head == 0
+        if (E * n_freqs) % 4 or (emb_dim // n_head * n_freqs) % 4:
+            raise NotImplementedError("TF-GridNet: per-head widths E * n_freqs and (emb_dim / n_head) * n_freqs must be "
+                                      "multiples of 4 (16-byte rows of the norm kernels); the shipped configuration has 520 / 780")
+        self.add_module("attn_conv_Q", nn.Conv2d(emb_dim, n_head * E, 1))
+        self.add_module("attn_norm_Q", AllHeadPReLULayerNormalization4DCF((n_head, E, n_freqs), eps=eps))
+        self.add_module("attn_conv_K", nn.Conv2d(emb_dim, n_head * E, 1))
+        self.add_module("attn_norm_K", AllHeadPReLULayerNormalization4DCF((n_head, E, n_freqs), eps=eps))
+        self.add_module("attn_conv_V", nn.Conv2d(emb_dim, n_head * emb_dim // n_head, 1))
+        self.add_module("attn_norm_V", AllHeadPReLULayerNormalization4DCF((n_head, emb_dim // n_head, n_freqs), eps=eps))
+        self.add_module("attn_concat_proj", nn.Sequential(nn.Conv2d(emb_dim, emb_dim, 1), nn.PReLU(),
+                                                          LayerNormalization4DCF((emb_dim, n_freqs), eps=eps)))
+        self.emb_dim, self.emb_ks, self.emb_hs, self.n_head, self.E = emb_dim, emb_ks, emb_hs, n_head, E
+        self.hidden = hidden_channels
+
+    def _rnn_path(self, path, x, nseq, Lr):
+        """x [nseq*Lr, C]: LayerNorm -> windows -> BLSTM -> ConvTranspose1d / Linear -> + x  (gridnet_block.py:139-160)."""
+        C, ks, hs, h = self.emb_dim, self.emb_ks, self.emb_hs, self.hidden
+        norm, rnn, lin = self[f"{path}_norm"], self[f"{path}_rnn"], self[f"{path}_linear"]
+        y = FG.RowLNFn.apply(x, norm.weight, norm.bias)
+        perm = None
+        if ks != hs:      # F.unfold orders a window as (channel, position); the row view as (position, channel)
+            perm = (torch.arange(C, device=x.device).unsqueeze(0) * ks + torch.arange(ks, device=x.device).unsqueeze(1)).reshape(-1)
+        wf, hf, bf = FG.pad_lstm(rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, perm)
+        wr, hr, br = FG.pad_lstm(rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse, rnn.bias_ih_l0_reverse,
+                                 rnn.bias_hh_l0_reverse, perm)
+        hcat = FG.BlstmFn.apply(y, (nseq, Lr, C, ks, hs), torch.cat([wf, wr], 0), torch.cat([bf, br], 0), hf, hr)
+        n = (Lr - ks) // hs + 1
+        if ks == hs:      # Linear(2h -> ks*C): frames tile the sequence without overlap
+            W = FG.pad_hidden_cols(lin.weight, h)
+            o = FD.Conv1x1ResFn.apply(hcat, W, lin.bias, None).view(nseq * Lr, C)
+        else:             # ConvTranspose1d weight [2h, C, ks] -> rows i*C + c, columns = padded hidden
+            Wt = FG.pad_hidden_cols(lin.weight.permute(2, 1, 0).reshape(ks * C, 2 * h), h)
+            o = FG.Deconv1dFn.apply(hcat, (nseq, Lr, C, ks, hs, n), Wt)
+            o = FG.AddRowVecFn.apply(o, lin.bias)
+        return o + x
+
+    def forward(self, x, geo):
+        """x [B*T*Q, C], geo (B, T, Q) -> same."""
+        B, oT, oQ = geo
+        C, ks, hs, nh, E = self.emb_dim, self.emb_ks, self.emb_hs, self.n_head, self.E
+        olp = ks - hs
+        T = math.ceil((oT + 2 * olp - ks) / hs) * hs + ks
+        Q = math.ceil((oQ + 2 * olp - ks) / hs) * hs + ks
+        h = torch.nn.functional.pad(x.view(B, oT, oQ, C), (0, 0, olp, Q - oQ - olp, olp, T - oT - olp))
+        h = self._rnn_path("intra", h.reshape(B * T * Q, C), B * T, Q).view(B, T, Q, C)
+        h = h.transpose(1, 2).contiguous()                                      # [B, Q, T, C]
+        h = self._rnn_path("inter", h.view(B * Q * T, C), B * Q, T).view(B, Q, T, C)
+        inter = h.transpose(1, 2)[:, olp:olp + oT, olp:olp + oQ, :].contiguous().view(B * oT * oQ, C)
+        M = B * oT * oQ
+        cq, ck, cv = self["attn_conv_Q"], self["attn_conv_K"], self["attn_conv_V"]
+        q = FD.Conv1x1ResFn.apply(inter, cq.weight, cq.bias, None)
+        k = FD.Conv1x1ResFn.apply(inter, ck.weight, ck.bias, None)
+        v = FD.Conv1x1ResFn.apply(inter, cv.weight, cv.bias, None)
+        cp = C // nh
+        qh = _heads(q, B, oT, oQ, nh, E, self["attn_norm_Q"])
+        kh = _heads(k, B, oT, oQ, nh, E, self["attn_norm_K"])
+        vh = _heads(v, B, oT, oQ, nh, cp, self["attn_norm_V"])
+        D = oQ * E
+        outs = []
+        for hd in range(nh):
+            Qm, Km, Vm = qh[hd].view(B, oT, D), kh[hd].view(B, oT, D), vh[hd].view(B, oT, oQ * cp)
+            ob = []
+            for b in range(B):
+                att = FG.SoftmaxFn.apply(FG.MatmulNTFn.apply(Qm[b], Km[b]), 1.0 / math.sqrt(D))   # [T, T]
+                ob.append(FG.MatmulNTFn.apply(att, Vm[b].t().contiguous()))                         # [T, Q*cp]
+            outs.append(torch.stack(ob, 0).view(B, oT, oQ, cp))
+        o = torch.stack(outs, 3).reshape(M, C)                                                      # channel h*cp + c
+        proj = self["attn_concat_proj"]
+        o = FD.Conv1x1ResFn.apply(o, proj[0].weight, proj[0].bias, None)
+        o = FG.PReluFn.apply(o, proj[1].weight)
+        g = proj[2].gamma[0, :, 0, :].t().reshape(-1)                                               # [Q*C], index q*C + c
+        bt = proj[2].beta[0, :, 0, :].t().reshape(-1)
+        o = FG.RowLNFn.apply(o.view(B * oT, oQ * C), g, bt).view(M, C)
+        return o + inter
+
+
+class _Fuse(nn.Module):
+    def __init__(self, embed_dim, feat_dim, fuse_type):
+        super().__init__()
+        if fuse_type not in ("multiply", "additive"):
+            raise NotImplementedError(f"TF-GridNet spk_fuse_type={fuse_type!r}: multiply / additive are built")
+        self.fuse_type = fuse_type
+        self.fc = LinearLayer(embed_dim, feat_dim)
+
+
+class TFGridNet(nn.Module):
+    def __init__(self, n_srcs=1, sr=16000, n_fft=128, stride=64, window="hann", n_imics=1, n_layers=6,
+                 lstm_hidden_units=192, attn_n_head=4, attn_approx_qk_dim=512, emb_dim=48, emb_ks=4, emb_hs=1,
+                 activation="prelu", eps=1.0e-5, spk_emb_dim=256, use_spk_transform=False, spk_fuse_type="multiply",
+                 joint_training=True, multi_task=False, spksInTrain=251, spk_model=None, spk_model_init=None,
+                 spk_model_freeze=False, spk_args=None, spk_feat=False, feat_type="consistent"):
+        super().__init__()
+        if n_srcs != 1 or n_imics != 1 or window != "hann":
+            raise NotImplementedError("TF-GridNet: single microphone, one source, hann window are built")
+        if emb_dim % 4 or lstm_hidden_units > 256:
+            raise NotImplementedError("TF-GridNet: emb_dim % 4 == 0 and lstm_hidden_units <= 256")
+        if joint_training and not spk_feat and feat_type != "consistent":
+            raise NotImplementedError("TF-GridNet joint training with spk_feat=False: feat_type='consistent' only")
+        self.n_srcs, self.n_fft, self.stride, self.n_imics, self.n_layers = n_srcs, n_fft, stride, n_imics, n_layers
+        self.spk_emb_dim, self.joint_training, self.spk_feat, self.feat_type = spk_emb_dim, joint_training, spk_feat, feat_type
+        self.spk_model_freeze, self.multi_task = spk_model_freeze, multi_task
+        assert n_fft % 2 == 0
+        n_freqs = n_fft // 2 + 1
+        self.spk_transform = SpeakerTransform() if use_spk_transform else nn.Identity()
+        if joint_training:
+            from .resnet import get_speaker_model
+            self.spk_model = get_speaker_model(spk_model)(**(spk_args or {}))
+            if spk_model_init:
+                pretrained = torch.load(spk_model_init, map_location="cpu")
+                state = self.spk_model.state_dict()
+                for key in state.keys():
+                    if key in pretrained.keys():
+                        state[key] = pretrained[key]
+                    else:
+                        print("not %s loaded" % key)
+                self.spk_model.load_state_dict(state)
+            if spk_model_freeze:
+                for param in self.spk_model.parameters():
+                    param.requires_grad = False
+            if not spk_feat:
+                from ..modules.common.frontend import MelSpectrogram, PreEmphasis
+                self.preEmphasis = PreEmphasis()
+                self.spk_encoder = MelSpectrogram(sample_rate=sr, n_fft=n_fft, win_length=n_fft, hop_length=stride,
+                                                  f_min=20, n_mels=(spk_args or {})["feat_dim"])
+            else:
+                self.preEmphasis = nn.Identity()
+                self.spk_encoder = nn.Identity()
+            self.pred_linear = nn.Linear(spk_emb_dim, spksInTrain) if multi_task else nn.Identity()
+        self.spk_fuse = _Fuse(spk_emb_dim, n_freqs, spk_fuse_type)
+        self.conv = nn.Sequential(nn.Conv2d(2 * n_imics, emb_dim, (3, 3), padding=(1, 1)), nn.GroupNorm(1, emb_dim, eps=eps))
+        self.blocks = nn.ModuleList([GridNetBlock(emb_dim, emb_ks, emb_hs, n_freqs, lstm_hidden_units, n_head=attn_n_head,
+                                                  approx_qk_dim=attn_approx_qk_dim, activation=activation, eps=eps)
+                                     for _ in range(n_layers)])
+        self.deconv = nn.ConvTranspose2d(emb_dim, n_srcs * 2, (3, 3), padding=(1, 1))
+
+    def forward(self, input, embeddings):
+        """input [B, N] mixture; embeddings [B, E] (fixed) or fbank / raw audio (joint) -> (est [B, N], dummy or logits)
+        (tfgridnet.py:197-302)."""
+        if input.dim() != 2:
+            raise RuntimeError("TFGridNet expects a [batch, samples] mixture (single microphone)")
+        wav = input.float().contiguous()
+        B, n = wav.shape
+        d = wav.device
+        with torch.no_grad():                     # RMS normalisation by the (unbiased) standard deviation of each row
+            st = torch.empty(B, 2, device=d, dtype=torch.float32)
+            from .. import dev
+            dev.flat_stats(wav if n % 4 == 0 else wav[:, : n - n % 4].contiguous(), B, n - n % 4, st, 0.0)
+            if n % 4:
+                raise NotImplementedError("TF-GridNet: the number of samples must be a multiple of 4")
+            std = torch.sqrt(1.0 / (st[:, 1] ** 2) * (n / (n - 1.0)))                # [B]
+            inv = (1.0 / std).view(B, 1).contiguous()
+            x = torch.empty_like(wav)
+            dev.scale_bf_fwd(wav, inv, B, 1, 1, n, 0, x)
+        spec, Tf = FD.stft_ri(x, self.n_fft, self.stride)
+        Fq = self.n_fft // 2 + 1
+        x4 = torch.zeros(B * Tf * Fq, 4, device=d, dtype=torch.float32)
+        x4[:, :2] = spec[:, :2 * Fq].reshape(B * Tf * Fq, 2)
+        c0, gn = self.conv[0], self.conv[1]
+        C = c0.weight.shape[0]
+        w4 = torch.cat([c0.weight, torch.zeros(C, 2, 3, 3, device=d, dtype=torch.float32)], 1)
+        h = FD.Conv2dFn.apply(x4, w4, c0.bias, (B, Tf, Fq, 1, 1))
+        h = FG.GroupLNFn.apply(h, gn.weight, gn.bias, (B, Tf * Fq))
+        logits = torch.tensor(0.0, device=d)
+        emb = embeddings.float().contiguous()
+        if self.joint_training:
+            if not self.spk_feat:
+                from ..modules.common.frontend import fbank_frontend
+                emb = fbank_frontend(emb, self.preEmphasis, self.spk_encoder)
+            o = self.spk_model(emb)
+            emb = o[-1] if isinstance(o, tuple) else o
+            if self.multi_task:
+                logits = F_.LinearFn.apply(emb, self.pred_linear.weight, self.pred_linear.bias)
+        emb = self.spk_transform(emb)
+        s = F_.LinearFn.apply(emb, self.spk_fuse.fc.linear.weight, self.spk_fuse.fc.linear.bias)       # [B, F]
+        mode = 0 if self.spk_fuse.fuse_type == "multiply" else 1
+        for blk in self.blocks:
+            h = FD.ScaleBFFn.apply(h, s, (B, Tf, Fq, mode))
+            h = blk(h, (B, Tf, Fq))
+        out = FD.ConvTranspose2dFn.apply(h, self.deconv.weight, self.deconv.bias, (B, Tf, Fq, 1, 1))   # [B*T*F, 2]
+        ld = -(-2 * Fq // 4) * 4
+        est_spec = torch.zeros(B * Tf, ld, device=d, dtype=torch.float32)
+        est_spec[:, :2 * Fq] = out.reshape(B * Tf, 2 * Fq)
+        est = FD.IstftFn.apply(est_spec, (B, Tf, n, self.n_fft, self.stride))
+        est = FD.ScaleBFFn.apply(est.contiguous(), std.view(B, 1).contiguous(), (B, 1, 1, 0))
+        return est, logits
