@@ -226,12 +226,12 @@ class TFGridNet(nn.Module):
         wav = input.float().contiguous()
         B, n = wav.shape
         d = wav.device
+        if n % 4:
+            raise NotImplementedError("TF-GridNet: the number of samples must be a multiple of 4 (16-byte rows)")
         with torch.no_grad():                     # RMS normalisation by the (unbiased) standard deviation of each row
-            st = torch.empty(B, 2, device=d, dtype=torch.float32)
             from .. import dev
-            dev.flat_stats(wav if n % 4 == 0 else wav[:, : n - n % 4].contiguous(), B, n - n % 4, st, 0.0)
-            if n % 4:
-                raise NotImplementedError("TF-GridNet: the number of samples must be a multiple of 4")
+            st = torch.empty(B, 2, device=d, dtype=torch.float32)
+            dev.flat_stats(wav, B, n, st, 0.0)
             std = torch.sqrt(1.0 / (st[:, 1] ** 2) * (n / (n - 1.0)))                # [B]
             inv = (1.0 / std).view(B, 1).contiguous()
             x = torch.empty_like(wav)
