@@ -367,11 +367,117 @@ def softmax_rows_bwd(y, dy, rows, n, scale, dx):
     dx.reshape(rows, n)[:] = scale * yy * (dd - (dd * yy).sum(1, keepdim=True))
 
 
+# ---- Conv-TasNet / speaker-encoder pieces (tasnet.hip, conv2d.hip) -----------------------------------------------
+def maskmul_fwd(w, w_off, ldw, m, rows, N, s):
+    wv = w.reshape(-1)[w_off + torch.arange(rows).unsqueeze(1) * ldw + torch.arange(N).unsqueeze(0)]
+    s.reshape(rows, N)[:] = wv * m.reshape(rows, N)
+
+
+def maskmul_bwd(ds, w, w_off, ldw, m, rows, N, dw, dw_off, ld_dw, dm):
+    wv = w.reshape(-1)[w_off + torch.arange(rows).unsqueeze(1) * ldw + torch.arange(N).unsqueeze(0)]
+    mm, dd = m.reshape(rows, N), ds.reshape(rows, N)
+    dw.reshape(-1)[dw_off + torch.arange(rows).unsqueeze(1) * ld_dw + torch.arange(N).unsqueeze(0)] = dd * mm
+    dm.reshape(rows, N)[:] = torch.where(mm > 0, dd * wv, torch.zeros(()))
+
+
+def relu_mask(d, y):
+    d.mul_((y > 0).float())
+
+
+def bn_stats(x, M, Cc, running_mean, running_var, stats, eps=1e-5, momentum=0.1):
+    xx = x.reshape(M, Cc)
+    mean = xx.mean(0)
+    var = ((xx - mean) ** 2).mean(0)
+    stats.reshape(2, Cc)[0] = mean
+    stats.reshape(2, Cc)[1] = 1.0 / torch.sqrt(var + eps)
+    if running_mean is not None:
+        running_mean.mul_(1 - momentum).add_(momentum * mean)
+        running_var.mul_(1 - momentum).add_(momentum * var * (M / (M - 1.0) if M > 1 else 1.0))
+
+
+def bn_prelu_fwd(x, stats, gamma, beta, res, a, M, Cc, u, y):
+    st = stats.reshape(2, Cc)
+    v = (x.reshape(M, Cc) - st[0]) * st[1] * gamma + beta
+    if res is not None:
+        v = v + res.reshape(M, Cc)
+    u.reshape(M, Cc)[:] = v
+    y.reshape(M, Cc)[:] = torch.where(v > 0, v, a.reshape(-1)[0] * v)
+
+
+def bn_bwd(x, du, stats, gamma, M, Cc, dx):
+    st = stats.reshape(2, Cc)
+    xh = (x.reshape(M, Cc) - st[0]) * st[1]
+    dd = du.reshape(M, Cc)
+    s0, s1 = dd.sum(0), (dd * xh).sum(0)
+    dx.reshape(M, Cc)[:] = gamma * st[1] * (dd - s0 / M - xh * s1 / M)
+    return torch.stack([s0, s1], 0).contiguous()
+
+
+def maxpool3_fwd(x, R, T, Cc, y):
+    y.reshape(R, T // 3, Cc)[:] = F.max_pool1d(x.reshape(R, T, Cc).permute(0, 2, 1), 3).permute(0, 2, 1)
+
+
+def maxpool3_bwd(x, dy, R, T, Cc, dx):
+    xr = x.reshape(R, T, Cc).permute(0, 2, 1).detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        F.max_pool1d(xr, 3).backward(dy.reshape(R, T // 3, Cc).permute(0, 2, 1))
+    dx.reshape(R, T, Cc)[:] = xr.grad.permute(0, 2, 1)
+
+
+def bcast_rows(src, scale, rows_per_r, M, Cc, out):
+    out.reshape(M, Cc)[:] = scale * src.reshape(-1, Cc)[torch.arange(M) // rows_per_r]
+
+
+def cross_entropy(logits, label, loss, dlogits):
+    lr = logits.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        v = F.cross_entropy(lr, label)
+        v.backward()
+    loss.reshape(-1)[0] = v.detach()
+    dlogits.copy_(lr.grad)
+
+
+def im2col(x, R, H, W, Cc, k, s_, p, patches, ldp):
+    im2col_hw(x, R, H, W, Cc, k, s_, s_, p, patches, ldp)
+
+
+def col2im(dpatches, R, H, W, Cc, k, s_, p, dx):
+    col2im_hw(dpatches, R, H, W, Cc, k, s_, s_, p, dx)
+
+
+def tstp_fwd(x, R, Fq, T, Cc, stats, eps=1e-7):
+    xx = x.reshape(R, Fq, T, Cc)
+    mean = xx.mean(2)                                            # [R, F, C]
+    sd = torch.sqrt(xx.var(2, unbiased=True) + eps) if T > 1 else torch.full_like(mean, eps ** 0.5)
+    st = stats.reshape(R, 2, Cc, Fq)
+    st[:, 0] = mean.permute(0, 2, 1)
+    st[:, 1] = sd.permute(0, 2, 1)
+
+
+def tstp_bwd(x, stats, dstats, R, Fq, T, Cc, dx):
+    xx = x.reshape(R, Fq, T, Cc)
+    st, ds = stats.reshape(R, 2, Cc, Fq), dstats.reshape(R, 2, Cc, Fq)
+    mean, sd = st[:, 0].permute(0, 2, 1).unsqueeze(2), st[:, 1].permute(0, 2, 1).unsqueeze(2)
+    gm, gs = ds[:, 0].permute(0, 2, 1).unsqueeze(2), ds[:, 1].permute(0, 2, 1).unsqueeze(2)
+    dx.reshape(R, Fq, T, Cc)[:] = gm / T + (gs * (xx - mean) / ((T - 1) * sd) if T > 1 else 0.0)
+
+
+def power_spec(spec, M, nf, lds, ldp, p):
+    sp = spec.reshape(M, lds)
+    p.reshape(M, ldp)[:] = 0.0
+    p.reshape(M, ldp)[:, :nf] = sp[:, 0:2 * nf:2] ** 2 + sp[:, 1:2 * nf:2] ** 2
+
+
+def log_eps(x, eps):
+    x.copy_(torch.log(x + eps))
+
+
 EMULATED = [gemm_nt, gemm_tn, reduce_slabs, transpose, affine_fwd, chan_sums, im2col_hw, col2im_hw, elu_fwd, elu_bwd,
             inorm_fwd, inorm_bwd, dwconv_fwd, dwconv_bwd, avgpool_fwd, avgpool_bwd, bilinear_fwd, bilinear_bwd,
             scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum, lstm_pack, lstm_fwd, lstm_bwd,
             group_stats, flat_stats, gn_bwd_reduce, norm_ab, norm_bwd_apply_cl, prelu_fwd, prelu_bwd, softmax_rows_fwd,
-            softmax_rows_bwd]
+            softmax_rows_bwd, maskmul_fwd, maskmul_bwd, relu_mask, bn_stats, bn_prelu_fwd, bn_bwd, maxpool3_fwd, maxpool3_bwd,
+            bcast_rows, cross_entropy, im2col, col2im, tstp_fwd, tstp_bwd, power_spec, log_eps]
 
 
 def install(monkeypatch):
@@ -380,8 +486,9 @@ def install(monkeypatch):
     import wesep_amd.functional as f0
     import wesep_amd.functional_dpccn as fd
     import wesep_amd.functional_tasnet as ft
+    import wesep_amd.functional_resnet as fr
     import wesep_amd.functional_tfgridnet as fg
     for fn in EMULATED:
         monkeypatch.setattr(dev, fn.__name__, fn)
-    for mod in (f0, fd, ft, fg):
+    for mod in (f0, fd, ft, fg, fr):
         monkeypatch.setattr(mod, "_need_cuda", lambda t, who: None)

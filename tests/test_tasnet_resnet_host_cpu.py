@@ -1,0 +1,74 @@
+"""CPU: host logic of the Conv-TasNet / SpEx+ path (fixed embeddings and joint mode) and of the ResNet speaker encoder
+with the device entry points replaced by the torch emulation of tests/emu_dev.py, against the reference fixtures / the
+restatement.  (Their kernels are checked on the GPU in tests/test_convtasnet_gpu.py and tests/test_resnet_gpu.py.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bsrnn_oracle as O
+from oracle import convtasnet_oracle as CT
+from oracle import resnet_oracle as RO
+from oracle.make_golden import ENROLL_LEN, TASNET_CASES
+from tests import emu_dev
+
+
+def _grad_norms_match(model, g, tol=2e-2):
+    floor = 1e-4 * max(float(g["gnorm/" + k]) for k, _ in model.named_parameters())
+    for k, prm in model.named_parameters():
+        gn = float(g["gnorm/" + k])
+        assert prm.grad is not None, k
+        assert abs(float(prm.grad.norm()) - gn) <= tol * gn + floor, (k, float(prm.grad.norm()), gn)
+
+
+@pytest.mark.parametrize("name", ["convtasnet_gln_r2_t1600", "convtasnet_cln_xform_r4_t2000", "spexplus_joint_r4_t1600"])
+def test_convtasnet_host_logic_matches_reference_fixture(name, monkeypatch, golden_dir):
+    from wesep_amd.models import get_model
+    emu_dev.install(monkeypatch)
+    monkeypatch.setattr("wesep_amd.functional_tasnet.SPK_MODE", None)
+    kw, R, T, seed = TASNET_CASES[name]
+    cfg = CT.ConvTasNetConfig(**kw)
+    params = CT.synth_params(cfg, seed)
+    model = get_model("ConvTasNet")(**kw, **({} if "use_spk_transform" in kw else {"use_spk_transform": False}),
+                                    **({} if "joint_training" in kw else {"joint_training": False}))
+    model.load_state_dict(params, strict=True)
+    model.train()
+    wav, tgt, emb = O.synth_batch(R, T, seed)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    if cfg.joint_training:
+        enroll, label = CT.synth_enrollment(R, ENROLL_LEN, cfg.spksInTrain, seed)
+        outs = model(wav, enroll)
+        loss = CT.spexplus_loss(outs, tgt, label)
+        assert np.allclose(outs[3].detach().numpy(), g["logits"], rtol=1e-3, atol=1e-4)
+    else:
+        outs = model(wav, emb)
+        loss = CT.multiscale_sisdr_loss(outs, tgt)
+    loss.backward()
+    for i in range(3):
+        ref = g[f"est{i + 1}"]
+        assert np.linalg.norm(outs[i].detach().numpy() - ref) / np.linalg.norm(ref) < 1e-3
+    assert abs(loss.item() - float(g["loss"])) < 1e-2
+    _grad_norms_match(model, g)
+
+
+def test_resnet18_host_logic_matches_restatement(monkeypatch):
+    from wesep_amd.models.resnet import get_speaker_model
+    emu_dev.install(monkeypatch)
+    kw = dict(num_blocks=RO.NUM_BLOCKS["ResNet18"], m=32, feat_dim=16, embed_dim=64)
+    params = RO.synth_params(5, **kw)
+    model = get_speaker_model("ResNet18")(feat_dim=16, embed_dim=64, pooling_func="TSTP", two_emb_layer=False)
+    model.load_state_dict(params, strict=True)
+    model.train()
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))   # the model's own CUDA guard
+    g = torch.Generator().manual_seed(9)
+    x, probe = torch.randn(3, 40, 16, generator=g), torch.randn(3, 64, generator=g)
+    _, emb = model(x)
+    (emb * probe).sum().backward()
+    p = {k: (v.clone() if RO.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in params.items()}
+    ref = RO.resnet_forward(p, x, num_blocks=kw["num_blocks"], m=32)
+    (ref * probe).sum().backward()
+    assert float((emb.detach() - ref.detach()).norm() / ref.detach().norm()) < 1e-4
+    for k, prm in model.named_parameters():
+        gn = float(p[k].grad.norm())
+        assert abs(float(prm.grad.norm()) - gn) <= 2e-2 * gn + 1e-4, k
