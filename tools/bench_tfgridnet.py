@@ -1,0 +1,56 @@
+"""GPU bench of the TF-GridNet row (default reference configuration, fixed embeddings, 6 s utterances):
+fwd + SI-SDR + bwd + per-tensor clip + Adam on `--rows` rows of 4 s, one JSON line.  Not the headline metric."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    args = ap.parse_args()
+    from wesep_amd.functional import SISDRFn
+    from wesep_amd.models import get_model
+    from wesep_amd.optim import FusedClipAdam
+    from wesep_amd.utils.synthetic import synth_batch
+    d = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = get_model("TFGridNet")(joint_training=False).to(d).train()
+    opt = FusedClipAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, clip_grad=5.0)
+    wav, tgt, emb = (t.to(d) for t in synth_batch(args.rows, 96000, 42))
+
+    def step():
+        est, _ = model(wav, emb)
+        loss = SISDRFn.apply(est, tgt, 1e-8)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({"metric": "utterances/sec (6 s, 16 kHz) fwd+bwd, TF-GridNet (fixed embeddings), 6 s utterances",
+                      "value": args.rows * args.steps / el, "unit": "utterances/s",
+                      "ms_per_step": el / args.steps * 1e3, "rows": args.rows, "steps": args.steps, "dtype": "bf16x3",
+                      "data": "synthetic", "final_loss_dB": float(loss.item()),
+                      "params_M": sum(p.numel() for p in model.parameters()) / 1e6,
+                      "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
