@@ -234,6 +234,38 @@ def run_tfgridnet_case(name, kw, R, T, seed):
     print(f"{name}: loss={loss.item():.6f} est_rms={est.pow(2).mean().sqrt().item():.4e}")
 
 
+# ---- kaldi-style enrollment fbank: outputs of the reference's own C++ front-end --------
+# name -> (R, T, sample_rate, num_mel_bins, seed)
+FBANK_CASES = {
+    "fbank_r3_t6400_16k_80": (3, 6400, 16000, 80, 31),
+    "fbank_r2_t4000_8k_40": (2, 4000, 8000, 40, 32),
+}
+
+
+def synth_fbank_wave(R, T, sample_rate, seed):
+    """Seeded speech-like rows in [-1, 1]: a few harmonics under a slow envelope, noise and a small DC offset."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(T) / sample_rate
+    rows = []
+    for r in range(R):
+        f0 = 110.0 + 40.0 * r
+        x = sum(0.2 / (h + 1) * np.sin(2 * np.pi * f0 * (h + 1) * t + rng.uniform(0, 6.28)) for h in range(6))
+        x = x * (0.6 + 0.4 * np.sin(2 * np.pi * 3.0 * t)) + 0.02 * rng.standard_normal(T) + 0.01 * (r - 1)
+        rows.append(x)
+    return np.stack(rows, 0).astype(np.float32)
+
+
+def run_fbank_case(name, R, T, sample_rate, nb, seed):
+    from oracle import build_ref, fbank_oracle as FB
+    assert build_ref.build(), "reference runtime sources not found"
+    wav = synth_fbank_wave(R, T, sample_rate, seed)
+    feats = np.stack([FB.ref_fbank(row * np.float32(1 << 15), nb, sample_rate) for row in wav], 0)
+    cmn = np.stack([FB.ref_fbank(row * np.float32(1 << 15), nb, sample_rate, apply_mean=True) for row in wav], 0)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), wav=wav, fbank=feats, fbank_cmn=cmn)
+    print(f"{name}: feats {feats.shape} mean {feats.mean():.4f}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
@@ -253,3 +285,7 @@ if __name__ == "__main__":
         if only and name not in only:
             continue
         run_tfgridnet_case(name, kw, R, T, seed)
+    for name, (R, T, sr, nb, seed) in FBANK_CASES.items():
+        if only and name not in only:
+            continue
+        run_fbank_case(name, R, T, sr, nb, seed)

@@ -1,0 +1,139 @@
+"""CPU: argument-contract dry run of whole host paths into the real libwesep_hip.so (tests/abi_dryrun.py).
+
+Each case runs the product's forward + backward host code on CPU tensors; every `ws_*` call must pass its entry
+point's argument validation (shapes, leading dimensions, alignment flags, split counts) and fail only at the launch,
+because this machine has no GPU.  This catches the "bad args" class of defects (a width that is not a multiple of
+4, a split count over a limit, a leading dimension smaller than the row) for configurations the `-m gpu` tests do
+not reach -- the shipped recipe sizes in particular -- without computing anything."""
+import random
+
+import pytest
+import torch
+
+from tests import abi_dryrun
+
+if torch.cuda.is_available():        # on the GPU box the launches would succeed: covered by the -m gpu tests
+    pytest.skip("argument-contract dry run is for GPU-less machines", allow_module_level=True)
+
+# entry points that size themselves from the device and are expected to refuse a machine without CUs
+DEVICE_DEPENDENT = ("ws_lstm_fwd_cluster", "ws_lstm_bwd_cluster")
+
+SPK = dict(joint_training=True, spk_feat=True,
+           spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
+
+
+def _check(calls, at_least):
+    kept = [c for c in calls if not (c[0] in DEVICE_DEPENDENT and "CUs" in c[2])]
+    abi_dryrun.assert_contracts_hold(kept, at_least)
+    return {w for w, _, _ in kept}
+
+
+def _fwd_bwd(model, *inputs):
+    model.train()
+    out = model(*inputs)
+    outs = out if isinstance(out, (list, tuple)) else [out]
+    sum(o.sum() for o in outs if o.dim() > 0).backward()
+    assert all(p.grad is not None for p in model.parameters())
+    return outs
+
+
+@pytest.mark.parametrize("R,T", [(2, 16000), (6, 24000), (2, 12345)])
+@pytest.mark.parametrize("fuse,multi", [("multiply", False), ("FiLM", True), ("concat", True), ("additive", False)])
+def test_bsrnn_contracts(monkeypatch, R, T, fuse, multi):
+    from wesep_amd.models import get_model
+    calls = abi_dryrun.install(monkeypatch)
+    model = get_model("BSRNN")(num_repeat=2, spk_fuse_type=fuse, multi_fuse=multi, joint_training=False)
+    est, _ = _fwd_bwd(model, torch.randn(R, T), torch.randn(R, 256))
+    assert tuple(est.shape) == (R, T)
+    used = _check(calls, 50)
+    assert {"ws_stft_bandsplit", "ws_gemm_p2b", "ws_gemm_tnb", "ws_mask_istft_bwd"} <= used
+
+
+def test_bsrnn_headline_row_count_contracts(monkeypatch):
+    """R = 32 rows (BASELINE configs[1] per-GPU batch) at a short length: 1024 time-view / 32*Tf band-view sequences
+    take the cluster and fused band-view branches of the host code."""
+    from wesep_amd.models import get_model
+    calls = abi_dryrun.install(monkeypatch)
+    model = get_model("BSRNN")(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, joint_training=False)
+    _fwd_bwd(model, torch.randn(32, 8192), torch.randn(32, 256))
+    used = _check(calls, 30)
+    assert "ws_lstm_fwd_fused" in used or "ws_lstm_fwd" in used
+
+
+@pytest.mark.parametrize("spk_model", ["ResNet18", "ResNet34"])
+def test_joint_bsrnn_and_ssa_step_contracts(monkeypatch, spk_model):
+    """The jointly trained speaker encoder on fbank enrollment, then one Executor step with the SSA second pass and
+    the fused clip + Adam."""
+    from wesep_amd.models import get_model
+    from wesep_amd.optim import FusedClipAdam
+    from wesep_amd.utils.executor import Executor
+    from wesep_amd.utils.losses import parse_loss
+    from wesep_amd.utils.schedulers import ExponentialDecrease
+    calls = abi_dryrun.install(monkeypatch)
+    model = get_model("BSRNN")(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                               spk_model=spk_model, multi_task=True, spksInTrain=251, **SPK)
+    opt = FusedClipAdam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    sched = ExponentialDecrease(opt, num_epochs=1, epoch_iter=2, initial_lr=1e-3, final_lr=1e-4, warm_up_epoch=0)
+    batch = {"wav_mix": torch.randn(2, 16000), "wav_targets": torch.randn(2, 16000),
+             "spk_embeds": torch.randn(2, 98, 80), "spk_label": torch.tensor([3, 250])}
+    random.seed(0)
+    Executor().train([batch, batch], [model], 2, [opt], parse_loss(["SISDR", "CE"]), [sched], scaler=None, epoch=1,
+                     enable_amp=False, logger=None, device=torch.device("cpu"),
+                     se_loss_weight=([[0], [1]], [[1.0], [0.1]]), multi_task=True, SSA_enroll_prob=1.0,
+                     fbank_args=dict(num_mel_bins=80, frame_length=25, frame_shift=10, dither=1.0),
+                     sample_rate=16000, speaker_feat=True)
+    used = _check(calls, 200)
+    assert {"ws_power_spec", "ws_log_eps", "ws_chan_sums", "ws_bn_stats", "ws_tstp_fwd", "ws_cross_entropy",
+            "ws_sisdr_fwd", "ws_grad_norms", "ws_clip_adam_step"} <= used
+
+
+def test_fbank_contracts(monkeypatch):
+    from wesep_amd.utils.funcs import apply_cmvn, compute_fbank
+    calls = abi_dryrun.install(monkeypatch)
+    for R, T, sr, nb in ((32, 64000, 16000, 80), (2, 1203, 16000, 80), (3, 400, 16000, 40), (2, 4000, 8000, 40)):
+        f = compute_fbank(torch.zeros(R, T), num_mel_bins=nb, dither=1.0, sample_rate=sr)
+        win, shift = sr // 40, sr // 100
+        assert tuple(apply_cmvn(f).shape) == (R, 1 + (T - win) // shift, nb)
+    _check(calls, 40)
+
+
+@pytest.mark.parametrize("kw,R,T,Te", [
+    (dict(N=32, L=20, B=32, H=64, P=3, X=3, R=2, joint_training=False), 2, 1600, 0),
+    (dict(N=512, L=20, B=256, H=512, P=3, X=8, R=4, joint_training=False), 2, 8000, 0),       # confs/ size
+    (dict(N=16, L=16, B=24, H=40, P=3, X=2, R=1, norm="cLN", joint_training=False), 4, 2000, 0),
+    (dict(N=256, L=20, B=256, H=512, P=3, X=8, R=4, joint_training=True, multi_task=True, spksInTrain=251), 4, 8000,
+     24000),                                                                                  # SpEx+ recipe
+])
+def test_convtasnet_contracts(monkeypatch, kw, R, T, Te):
+    from wesep_amd.models import get_model
+    calls = abi_dryrun.install(monkeypatch)
+    model = get_model("ConvTasNet")(**kw)
+    enroll = torch.randn(R, Te) if Te else torch.randn(R, 256)
+    outs = _fwd_bwd(model, torch.randn(R, T), enroll)
+    assert tuple(outs[0].shape) == (R, T)
+    _check(calls, 40)
+
+
+def test_dpccn_recipe_contracts(monkeypatch):
+    """examples/librimix/tse/v2/confs/dpccn.yaml model_args with the ResNet34 encoder."""
+    from wesep_amd.models import get_model
+    calls = abi_dryrun.install(monkeypatch)
+    model = get_model("DPCCN")(win=512, stride=128, feature_dim=257, tcn_blocks=10, tcn_layers=2, causal=False,
+                               spk_fuse_type="multiply", use_spk_transform=False, spk_model="ResNet34", **SPK)
+    est, _ = _fwd_bwd(model, torch.randn(2, 16384), torch.randn(2, 100, 80))
+    assert tuple(est.shape) == (2, 16384)
+    _check(calls, 300)
+
+
+@pytest.mark.parametrize("ks,hs,T", [(1, 1, 8000), (4, 1, 6400), (4, 2, 6400)])
+def test_tfgridnet_recipe_contracts(monkeypatch, ks, hs, T):
+    """examples/librimix/tse/v2/confs/tfgridnet.yaml model_args (n_layers reduced to 2) with the ResNet34 encoder,
+    at the recipe's emb_ks/emb_hs = 1 and at unfold sizes > 1."""
+    from wesep_amd.models import get_model
+    calls = abi_dryrun.install(monkeypatch)
+    model = get_model("TFGridNet")(n_fft=128, stride=64, n_layers=2, lstm_hidden_units=192, attn_n_head=4,
+                                   attn_approx_qk_dim=512, emb_dim=128, emb_ks=ks, emb_hs=hs,
+                                   use_spk_transform=False, spk_fuse_type="multiply", spk_model="ResNet34", **SPK)
+    est, _ = _fwd_bwd(model, torch.randn(2, T), torch.randn(2, 100, 80))
+    assert tuple(est.shape) == (2, T)
+    _check(calls, 200)

@@ -8,13 +8,17 @@ invisible to the caller: batches are pinned and copied one step ahead on a copy 
 `loss.item()` (executor.py:124) is replaced by a device-side running sum that is read only
 when a log row is due and at the end of the epoch; per-tensor clipping + Adam are two
 multi-tensor launches when the optimizer is `FusedClipAdam` (no per-parameter host syncs).
-The SSA self-enrollment branch (executor.py:89-100) needs the fbank front-end (SURVEY.md
-section 8f-2) and raises until that row is built."""
+The SSA self-enrollment branch (executor.py:89-100: with probability `SSA_enroll_prob` a no-grad
+pass estimates the target, its kaldi fbank + CMN replaces the enrollment, and the step runs on
+that) computes the filterbank of the whole batch on the device (`utils/funcs.compute_fbank`,
+SURVEY section 8f-2) instead of the reference's per-row host loop."""
+import random
 from contextlib import nullcontext
 
 import torch
 
 from ..optim import FusedClipAdam, clip_gradients
+from .funcs import apply_cmvn, compute_fbank
 from .prefetch import DevicePrefetcher
 
 
@@ -56,8 +60,6 @@ class Executor:
         """Train one epoch."""
         if enable_amp:
             raise NotImplementedError("enable_amp: the HIP path computes in fp32 (all shipped configs use False)")
-        if SSA_enroll_prob > 0:
-            raise NotImplementedError("SSA self-enrollment needs the fbank front-end (SURVEY.md 8f-2)")
         model, optimizer, scheduler = models[0], optimizers[0], schedulers[0]
         model.train()
         ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)
@@ -70,6 +72,12 @@ class Executor:
                 cur_iter = (epoch - 1) * epoch_iter + i
                 scheduler.step(cur_iter)
                 features, targets, enroll, spk_label = self._to_device(batch, device)   # no-ops after the prefetch
+                if SSA_enroll_prob > 0 and SSA_enroll_prob > random.random():
+                    with torch.no_grad():
+                        self_fbank = model(features, enroll)[0]
+                        if fbank_args is not None and speaker_feat:
+                            self_fbank = apply_cmvn(compute_fbank(self_fbank, **fbank_args, sample_rate=sample_rate))
+                    enroll = self_fbank
                 outputs = model(features, enroll)
                 loss = self._loss(outputs, targets, spk_label, criterion, se_loss_weight, multi_task)
                 loss_sum += loss.detach()
