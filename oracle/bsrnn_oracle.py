@@ -241,11 +241,9 @@ def speaker_fuse(p, prefix, kind, x, e):
     raise ValueError("Fuse type not defined.")
 
 
-def bsrnn_forward(p: Dict[str, torch.Tensor], cfg: BSRNNConfig, wav: torch.Tensor,
-                  emb: torch.Tensor, return_intermediates: bool = False):
-    """`bsrnn.py:300-394`, `joint_training=False`: wav [R, T], emb [R, E] -> est [R, T]."""
+def band_split(p, cfg: BSRNNConfig, wav):
+    """`bsrnn.py:306-337`: wav [R, T] -> (complex spectrogram [R, F, Tf], band features z [R, K, N, Tf])."""
     R, T = wav.shape
-    K, N = cfg.nband, cfg.feature_dim
     window = torch.hann_window(cfg.win, dtype=wav.dtype)
     spec = torch.stft(wav, n_fft=cfg.win, hop_length=cfg.stride, window=window,
                       return_complex=True)                      # [R, F, Tf]
@@ -256,8 +254,12 @@ def bsrnn_forward(p: Dict[str, torch.Tensor], cfg: BSRNNConfig, wav: torch.Tenso
         sb = _group_norm1(sb, p[f"BN.{i}.0.weight"], p[f"BN.{i}.0.bias"])
         feats.append(F.conv1d(sb, p[f"BN.{i}.1.weight"], p[f"BN.{i}.1.bias"]))
         f0 += bw
-    z = torch.stack(feats, 1)                                   # [R, K, N, Tf]
-    inter = {"spec": spec, "z0": z}
+    return spec, torch.stack(feats, 1)                          # [R, K, N, Tf]
+
+
+def separate(p, cfg: BSRNNConfig, z, emb):
+    """`bsrnn.py:359-364`: spk_transform + FuseSeparation on z [R, K, N, Tf] with the embedding [R, E]."""
+    R, K, N = z.shape[0], cfg.nband, cfg.feature_dim
     e = spk_transform(p, emb) if cfg.use_spk_transform else emb
     fuse, nets = fuse_layer_indices(cfg)
     order = sorted([(i, "f") for i in fuse] + [(i, "n") for i in nets])
@@ -267,7 +269,13 @@ def bsrnn_forward(p: Dict[str, torch.Tensor], cfg: BSRNNConfig, wav: torch.Tenso
             z = speaker_fuse(p, pre, cfg.spk_fuse_type, z, e)
         else:
             z = bs_net(p, pre, z.reshape(R, K * N, -1), K).view(R, K, N, -1)
-    inter["z_sep"] = z
+    return z
+
+
+def mask_decode(p, cfg: BSRNNConfig, z, spec, T):
+    """`bsrnn.py:366-392`: mask MLP, GLU complex mask on the mixture's band spectra, iSTFT -> (est, est_spec)."""
+    R = z.shape[0]
+    window = torch.hann_window(cfg.win, dtype=z.dtype)
     est_bands, f0 = [], 0
     for i, bw in enumerate(cfg.band_width):
         h = _group_norm1(z[:, i], p[f"mask.{i}.0.weight"], p[f"mask.{i}.0.bias"])
@@ -281,11 +289,33 @@ def bsrnn_forward(p: Dict[str, torch.Tensor], cfg: BSRNNConfig, wav: torch.Tenso
         est_bands.append(torch.complex(er, ei))
         f0 += bw
     est_spec = torch.cat(est_bands, 1)
-    inter["est_spec"] = est_spec
-    est = torch.istft(est_spec, n_fft=cfg.win, hop_length=cfg.stride, window=window, length=T)
+    return torch.istft(est_spec, n_fft=cfg.win, hop_length=cfg.stride, window=window, length=T), est_spec
+
+
+def bsrnn_forward(p: Dict[str, torch.Tensor], cfg: BSRNNConfig, wav: torch.Tensor,
+                  emb: torch.Tensor, return_intermediates: bool = False):
+    """`bsrnn.py:300-394`, `joint_training=False`: wav [R, T], emb [R, E] -> est [R, T]."""
+    spec, z = band_split(p, cfg, wav)
+    inter = {"spec": spec, "z0": z}
+    z = separate(p, cfg, z, emb)
+    inter["z_sep"] = z
+    est, inter["est_spec"] = mask_decode(p, cfg, z, spec, wav.shape[1])
     if return_intermediates:
         return est, inter
     return est
+
+
+def bsrnn_multi_forward(p, cfg: BSRNNConfig, wav, enroll, embed_fn):
+    """`BSRNN_Multi.forward` in grad mode (bsrnn_multi_optim.py:300-470): two separator passes over one band split;
+    the second one is conditioned on the embedding of the first pass's detached estimate.  `embed_fn(waveform
+    [R, Tw]) -> [R, E]` is the jointly trained path (in-model fbank front-end + speaker encoder).
+    -> (s, self_s, embedding of the enrollment, embedding of s)."""
+    spec, z = band_split(p, cfg, wav)
+    e1 = embed_fn(enroll)
+    s, _ = mask_decode(p, cfg, separate(p, cfg, z, e1), spec, wav.shape[1])
+    e2 = embed_fn(s.detach())
+    self_s, _ = mask_decode(p, cfg, separate(p, cfg, z, e2), spec, wav.shape[1])
+    return s, self_s, e1, e2
 
 
 # --------------------------------------------------------------------------

@@ -266,6 +266,122 @@ def run_fbank_case(name, R, T, sample_rate, nb, seed):
     print(f"{name}: feats {feats.shape} mean {feats.mean():.4f}")
 
 
+# ---- BSRNN_Multi (SSA multi-optimisation): the REAL reference module tree and two-pass
+# forward; its two third-party halves (wespeaker ResNet, torchaudio MelSpectrogram -- both absent from this image) are
+# stood in for by the restatements of oracle/resnet_oracle.py, so the fixture pins the BSRNN_Multi structure, the
+# separator, PreEmphasis and the loss composition, and leaves those two halves unpinned as everywhere else.
+# name -> (BSRNNConfig kwargs, spk model, rows, T, enrollment samples, seed)
+MULTI_CASES = {
+    "bsrnn_multi_r2_t3000": (dict(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False), "ResNet18", 2, 3000,
+                             4000, 41),
+}
+MULTI_LOSS_WEIGHT = (0.4, 0.6)          # bsrnn_multi_optim.yaml: loss_posi [[0, 1]], loss_weight [[0.4, 0.6]]
+
+
+def multi_embed_fn(params, spk_model):
+    """enrollment waveform -> embedding through the restated front-end + speaker encoder (prefix spk_model.)."""
+    from oracle import resnet_oracle as RO
+    return lambda w: RO.resnet_forward(params, RO.fbank_frontend(w).detach(), num_blocks=RO.NUM_BLOCKS[spk_model],
+                                       prefix="spk_model.")
+
+
+def synth_multi_params(cfg, spk_model, seed):
+    from oracle import resnet_oracle as RO
+    p = dict(O.synth_params(cfg, seed))
+    p.update(RO.synth_params(seed + 1, num_blocks=RO.NUM_BLOCKS[spk_model], prefix="spk_model."))
+    return p
+
+
+def _install_third_party_stand_ins():
+    import torch.nn as nn
+    from oracle import resnet_oracle as RO
+
+    class StandInResNet(nn.Module):
+        """wespeaker ResNet stand-in: parameters under mangled upstream names, forward = the restatement."""
+
+        def __init__(self, num_blocks, feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False):
+            super().__init__()
+            assert pooling_func == "TSTP" and not two_emb_layer
+            self.num_blocks = num_blocks
+            shapes = RO.param_shapes(num_blocks=num_blocks, feat_dim=feat_dim, embed_dim=embed_dim)
+            self.keys = list(shapes)
+            for k, shp in shapes.items():
+                if RO.is_buffer(k):
+                    self.register_buffer(k.replace(".", "__"), torch.zeros(shp))
+                else:
+                    self.register_parameter(k.replace(".", "__"), nn.Parameter(torch.zeros(shp)))
+
+        def forward(self, x):
+            p = {k: getattr(self, k.replace(".", "__")) for k in self.keys}
+            return torch.tensor(0.0), RO.resnet_forward(p, x, num_blocks=self.num_blocks)
+
+    class StandInMelSpectrogram(nn.Module):
+        """torchaudio.transforms.MelSpectrogram stand-in (centre, reflect, power 2, HTK, no norm)."""
+
+        def __init__(self, sample_rate, n_fft, win_length, hop_length, f_min, window_fn, n_mels):
+            super().__init__()
+            assert win_length == n_fft
+            self.n_fft, self.hop = n_fft, hop_length
+            self.register_buffer("window", window_fn(n_fft))
+            self.register_buffer("fb", RO.melscale_fbanks(n_fft // 2 + 1, f_min, float(sample_rate // 2), n_mels,
+                                                          sample_rate))
+
+        def forward(self, y):
+            spec = torch.stft(y, self.n_fft, self.hop, self.n_fft, window=self.window, center=True,
+                              pad_mode="reflect", normalized=False, onesided=True, return_complex=True).abs().pow(2.0)
+            return torch.matmul(spec.transpose(-1, -2), self.fb).transpose(-1, -2)
+
+    import_reference()
+    import wesep.models.bsrnn_multi_optim as ref_multi
+    ref_multi.get_speaker_model = lambda name: (lambda **kw: StandInResNet(RO.NUM_BLOCKS[name], **kw))
+    ref_multi.torchaudio.transforms.MelSpectrogram = StandInMelSpectrogram
+    return ref_multi
+
+
+def run_multi_case(name, kw, spk_model, R, T, Tw, seed):
+    ref_multi = _install_third_party_stand_ins()
+    cfg = O.BSRNNConfig(**kw)
+    ref = ref_multi.BSRNN_Multi(
+        spk_emb_dim=cfg.spk_emb_dim, sr=cfg.sr, win=cfg.win, stride=cfg.stride, feature_dim=cfg.feature_dim,
+        num_repeat=cfg.num_repeat, use_spk_transform=cfg.use_spk_transform, spk_fuse_type=cfg.spk_fuse_type,
+        multi_fuse=cfg.multi_fuse, joint_training=True, multi_task=False, spk_model=spk_model, spk_model_init=False,
+        spk_model_freeze=False, spk_args=dict(feat_dim=80, embed_dim=cfg.spk_emb_dim, pooling_func="TSTP",
+                                              two_emb_layer=False), spk_feat=False, feat_type="consistent")
+    params = synth_multi_params(cfg, spk_model, seed)
+    sd = ref.state_dict()
+    for k in sd:                                    # separator / BN / mask by name; speaker stand-in by mangled name
+        if k.startswith("spk_model."):
+            src = "spk_model." + k[len("spk_model."):].replace("__", ".")
+            sd[k] = params[src].to(sd[k].dtype)
+        elif k in params:
+            sd[k] = params[k]
+    ref.load_state_dict(sd, strict=True)
+    loaded = {k for k in sd if k.startswith("spk_model.") or k in params}
+    assert len(loaded) == len(params), (len(loaded), len(params))
+    ref.train()
+    wav, tgt, _ = O.synth_batch(R, T, seed)
+    g = torch.Generator().manual_seed(seed + 2)
+    enroll = 0.1 * torch.randn(R, Tw, generator=g)
+    s, self_s, e1, e2 = ref(wav, enroll)
+    loss = MULTI_LOSS_WEIGHT[0] * O.sisdr_loss(s, tgt) + MULTI_LOSS_WEIGHT[1] * O.sisdr_loss(self_s, tgt)
+    loss.backward()
+    with torch.no_grad():
+        assert len(ref(wav, enroll)) == 2           # no-grad mode: the plain BSRNN outputs
+    out = {"wav": wav.numpy(), "tgt": tgt.numpy(), "enroll": enroll.numpy(), "est": s.detach().numpy(),
+           "self_est": self_s.detach().numpy(), "emb1": e1.detach().numpy(), "emb2": e2.detach().numpy(),
+           "loss": np.float64(loss.item()),
+           "param_checksum": np.float64(sum(float(v.double().abs().sum()) for v in params.values()))}
+    names = []
+    for k, prm in ref.named_parameters():
+        key = ("spk_model." + k[len("spk_model."):].replace("__", ".")) if k.startswith("spk_model.") else k
+        names.append(key)
+        out["gnorm/" + key] = np.float64(prm.grad.detach().double().norm().item())
+    out["names"] = np.array(names)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.6f} |s - self_s| / |s| = {float((s - self_s).norm() / s.norm()):.3e}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
@@ -289,3 +405,7 @@ if __name__ == "__main__":
         if only and name not in only:
             continue
         run_fbank_case(name, R, T, sr, nb, seed)
+    for name, (kw, spk_model, R, T, Tw, seed) in MULTI_CASES.items():
+        if only and name not in only:
+            continue
+        run_multi_case(name, kw, spk_model, R, T, Tw, seed)

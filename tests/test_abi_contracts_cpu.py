@@ -87,6 +87,34 @@ def test_joint_bsrnn_and_ssa_step_contracts(monkeypatch, spk_model):
             "ws_sisdr_fwd", "ws_grad_norms", "ws_clip_adam_step"} <= used
 
 
+def test_bsrnn_multi_recipe_contracts(monkeypatch):
+    """examples/librimix/tse/v2/confs/bsrnn_multi_optim.yaml model_args (num_repeat reduced to 2): both passes, the
+    raw-audio front-end twice, ResNet34, and the recipe's two-output loss through one Executor step."""
+    from wesep_amd.models import get_model
+    from wesep_amd.optim import FusedClipAdam
+    from wesep_amd.utils.executor import Executor
+    from wesep_amd.utils.losses import parse_loss
+    from wesep_amd.utils.schedulers import ExponentialDecrease
+    calls = abi_dryrun.install(monkeypatch)
+    model = get_model("BSRNN_Multi")(sr=16000, win=512, stride=128, feature_dim=128, num_repeat=2,
+                                     spk_fuse_type="multiply", use_spk_transform=False, multi_fuse=False,
+                                     joint_training=True, spk_model="ResNet34", spk_model_init=False,
+                                     spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP",
+                                                   two_emb_layer=False),
+                                     spk_emb_dim=256, spk_model_freeze=False, spk_feat=False, feat_type="consistent",
+                                     multi_task=False, spksInTrain=251)
+    opt = FusedClipAdam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    sched = ExponentialDecrease(opt, num_epochs=1, epoch_iter=1, initial_lr=1e-3, final_lr=1e-4, warm_up_epoch=0)
+    batch = {"wav_mix": torch.randn(4, 48000), "wav_targets": torch.randn(4, 48000),
+             "spk_embeds": torch.randn(4, 40000), "spk_label": torch.zeros(0)}
+    Executor().train([batch], [model], 1, [opt], parse_loss("SISDR"), [sched], scaler=None, epoch=1, enable_amp=False,
+                     logger=None, device=torch.device("cpu"), se_loss_weight=([[0, 1]], [[0.4, 0.6]]),
+                     speaker_feat=False)
+    used = _check(calls, 400)
+    assert {"ws_preemph_pad", "ws_power_spec", "ws_sisdr_fwd", "ws_clip_adam_step"} <= used
+    assert all(p.grad is not None for p in model.parameters())
+
+
 def test_fbank_contracts(monkeypatch):
     from wesep_amd.utils.funcs import apply_cmvn, compute_fbank
     calls = abi_dryrun.install(monkeypatch)

@@ -92,7 +92,9 @@ def test_film_zero_init_and_factory_errors():
     with pytest.raises(NotImplementedError):
         get_model("TFGridNet")(n_imics=2, joint_training=False)     # multi-microphone TF-GridNet is not built
     with pytest.raises(NotImplementedError):
-        get_model("BSRNN_Multi")
+        get_model("BSRNN_Feats")
+    with pytest.raises(NotImplementedError):                        # the self-enrollment pass needs raw-audio joint training
+        get_model("BSRNN_Multi")(num_repeat=1, joint_training=False)
 
 
 def test_no_cpu_fallback():

@@ -144,8 +144,8 @@ def test_bsrnn_joint_training_with_resnet34_runs_and_matches_oracle():
     model = model.to(d).train()
     wav, tgt, _ = O.synth_batch(2, 3000, 3)
     fbank = torch.randn(2, 40, 80, generator=torch.Generator().manual_seed(8))
-    est, dummy = model(wav.to(d), fbank.to(d))
-    assert dummy.dim() == 0
+    est, second = model(wav.to(d), fbank.to(d))
+    assert tuple(second.shape) == (2, 256)          # pred_linear = Identity without multi_task (bsrnn.py:357)
     emb = RO.resnet_forward({k: v.clone() for k, v in spk.items()}, fbank, prefix="spk_model.")
     ref = O.bsrnn_forward(sep, cfg, wav, emb)
     assert rel(est, ref) < 1e-3

@@ -187,24 +187,29 @@ class BSRNN(nn.Module):
             self._plans[key] = F_.BandPlan(self.band_width, self.feature_dim, device)
         return self._plans[key]
 
-    def forward(self, input, embeddings):
-        """input: mixture [R, T] fp32; embeddings: [R, spk_emb_dim] (fixed) or fbank [R, Te, 80] (joint training)
-        -> (est [R, T], 0-d dummy or speaker logits)."""
-        if input.dim() != 2:
-            raise RuntimeError("BSRNN expects a [batch, samples] mixture")
-        wav = input.float().contiguous()
-        plan = self._plan(wav.device)
-        z, xbs = F_.BandSplitFn.apply(wav, plan, *self._bn_params())
-        predict_speaker_lable = torch.tensor(0.0, device=wav.device)  # dummy, bsrnn.py:339-340
+    def _speaker(self, embeddings):
+        """enrollment -> (fused-in embedding [R, E], second output) (bsrnn.py:339-360)."""
+        predict_speaker_lable = torch.tensor(0.0, device=embeddings.device)  # dummy, bsrnn.py:339-340
         if self.joint_training:             # fbank [R, Te, F] -> wespeaker encoder -> embedding (bsrnn.py:341-357)
             if not self.spk_feat:           # raw enrollment waveform [R, Tw] -> log-mel, CMN (no_grad, :343-350)
                 from ..modules.common.frontend import fbank_frontend
                 embeddings = fbank_frontend(embeddings, self.preEmphasis, self.spk_encoder)
             out = self.spk_model(embeddings.float().contiguous())
             embeddings = out[-1] if isinstance(out, tuple) else out
-            if self.multi_task:
-                predict_speaker_lable = F_.LinearFn.apply(embeddings, self.pred_linear.weight, self.pred_linear.bias)
-        e = self.spk_transform(embeddings.float().contiguous())
+            # pred_linear is nn.Identity without multi_task: the reference then returns the embedding (bsrnn.py:357)
+            predict_speaker_lable = (F_.LinearFn.apply(embeddings, self.pred_linear.weight, self.pred_linear.bias)
+                                     if self.multi_task else embeddings)
+        return self.spk_transform(embeddings.float().contiguous()), predict_speaker_lable
+
+    def forward(self, input, embeddings):
+        """input: mixture [R, T] fp32; embeddings: [R, spk_emb_dim] (fixed) or fbank [R, Te, 80] (joint training)
+        -> (est [R, T], 0-d dummy | speaker logits (multi_task) | the embedding (joint, no multi_task))."""
+        if input.dim() != 2:
+            raise RuntimeError("BSRNN expects a [batch, samples] mixture")
+        wav = input.float().contiguous()
+        plan = self._plan(wav.device)
+        z, xbs = F_.BandSplitFn.apply(wav, plan, *self._bn_params())
+        e, predict_speaker_lable = self._speaker(embeddings)
         z = self.separator(z, e)
         est = F_.MaskDecodeFn.apply(z, xbs, plan, wav.shape[1], *self._mask_params())
         return est, predict_speaker_lable

@@ -204,8 +204,9 @@ class DPCCN(nn.Module):
                 emb = fbank_frontend(emb, self.preEmphasis, self.spk_encoder)
             o = self.spk_model(emb)
             emb = o[-1] if isinstance(o, tuple) else o
-            if self.multi_task:
-                logits = F_.LinearFn.apply(emb, self.pred_linear.weight, self.pred_linear.bias)
+            # pred_linear is nn.Identity without multi_task: the reference then returns the embedding (dpccn.py:247)
+            logits = (F_.LinearFn.apply(emb, self.pred_linear.weight, self.pred_linear.bias) if self.multi_task
+                      else emb)
         emb = self.spk_transform(emb)
         s = F_.LinearFn.apply(emb, self.spk_fuse.fc.linear.weight, self.spk_fuse.fc.linear.bias)   # [B, F]
         out = FD.ScaleBFFn.apply(out, s, (B, Tf, Fq, 0 if self.spk_fuse.fuse_type == "multiply" else 1))
