@@ -1,0 +1,1182 @@
+// libwesep_engine.so -- native inference runtime of wesep_amd (include/wesep_engine.h).
+//
+// MI355X counterpart of the reference's C++ runtime (runtime/separate/separate_engine.{h,cc}: a TorchScript module on
+// LibTorch-CPU plus a host kaldi fbank).  Here the pBSRNN forward (wesep/models/bsrnn.py:300-394) is a fixed launch
+// plan over the device library's C ABI (include/wesep_hip.h):
+//   * load: the weight container is read, uploaded once, and everything that the Python training path re-derives
+//     per step is derived once -- [W_ih_f | W_ih_r] concatenation, MFMA-fragment packs of W_ih / W_hh / proj for the
+//     blocked-layout GEMMs and recurrences, BatchNorm folded to (running mean, rstd), conv kernels permuted to the
+//     im2col column order, the folded kaldi fbank basis (see wesep_amd/utils/funcs.py);
+//   * forward: activations come from one grow-only device arena with stack discipline (per-layer scratch is released
+//     when the layer ends, so the peak is one ResRNN's working set, not the sum); the per-band grouped GEMMs get their
+//     descriptor tables rebuilt only when the frame count changes.
+// Host code only: no kernels in this file.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../include/wesep_engine.h"
+#include "../include/wesep_hip.h"
+
+namespace {
+
+thread_local char g_err[768] = "";
+
+void set_err(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+constexpr int kN = 128;                 // feature_dim
+constexpr int kH = 256;                 // LSTM hidden size
+constexpr int kG4 = 4 * kH;             // gate rows per direction
+constexpr int kNBin = 257;              // n_fft / 2 + 1
+constexpr int kHop = 128;
+constexpr int kBig = 1 << 30;           // row divisor meaning "never wraps"
+constexpr float kGnEps = 1.1920928955078125e-07f;   // torch.finfo(float32).eps, bsrnn.py:23
+constexpr float kBnEps = 1e-5f;
+constexpr float kTstpEps = 1e-7f;
+
+struct Tensor {
+  std::vector<int64_t> dims;
+  size_t off = 0;   // floats into the weight blob
+  size_t n = 0;
+};
+
+// ---- device memory: chunked bump allocator with stack discipline --------------------------------------------
+struct Arena {
+  struct Chunk {
+    char* base;
+    size_t cap;
+  };
+  std::vector<Chunk> chunks;
+  size_t cur = 0, top = 0;      // current chunk and offset inside it
+  size_t live_bytes = 0, peak_bytes = 0;
+  bool dry = false;
+
+  struct Mark {
+    size_t cur, top, live;
+  };
+
+  static size_t round_up(size_t b) { return (b + 255) & ~size_t(255); }
+
+  bool add_chunk(size_t bytes) {
+    Chunk c{nullptr, bytes};
+    if (dry) {
+      c.base = static_cast<char*>(malloc(bytes));
+    } else if (hipMalloc(reinterpret_cast<void**>(&c.base), bytes) != hipSuccess) {
+      c.base = nullptr;
+    }
+    if (!c.base) return false;
+    chunks.push_back(c);
+    return true;
+  }
+
+  float* alloc(size_t nfloats) {
+    const size_t bytes = round_up(nfloats * 4 + 4);
+    while (true) {
+      if (cur < chunks.size() && top + bytes <= chunks[cur].cap) break;
+      if (cur + 1 < chunks.size()) {           // move on to the next existing chunk
+        ++cur;
+        top = 0;
+        continue;
+      }
+      const size_t want = bytes > (size_t(256) << 20) ? bytes : (size_t(256) << 20);
+      if (!add_chunk(want)) {
+        set_err("engine: device allocation of %zu bytes failed", want);
+        return nullptr;
+      }
+      cur = chunks.size() - 1;
+      top = 0;
+    }
+    float* p = reinterpret_cast<float*>(chunks[cur].base + top);
+    top += bytes;
+    live_bytes += bytes;
+    if (live_bytes > peak_bytes) peak_bytes = live_bytes;
+    return p;
+  }
+
+  Mark mark() const { return Mark{cur, top, live_bytes}; }
+  void release(const Mark& m) {
+    cur = m.cur;
+    top = m.top;
+    live_bytes = m.live;
+  }
+  void reset() {
+    cur = 0;
+    top = 0;
+    live_bytes = 0;
+  }
+  // after a forward that had to add chunks: one chunk of the peak size for the next call
+  void consolidate() {
+    if (chunks.size() <= 1 || live_bytes != 0) return;
+    const size_t want = round_up(peak_bytes + (size_t(16) << 20));
+    free_all();
+    add_chunk(want);
+  }
+  void free_all() {
+    for (auto& c : chunks) {
+      if (dry)
+        free(c.base);
+      else
+        (void)hipFree(c.base);
+    }
+    chunks.clear();
+    reset();
+  }
+};
+
+struct RnnPrep {            // one ResRNN (bsrnn.py:26-46), everything the forward needs, device pointers
+  const float *norm_w, *norm_b, *whf, *whr, *proj_b;
+  float *bcat, *wih_pack, *proj_pack, *fpack, *pack16, *pack32;
+};
+
+struct ConvPrep {           // conv (bias-free) + BatchNorm(eval) (+ ReLU) of the speaker encoder
+  int cin, cout, k, stride, ldp;
+  bool relu;
+  const float *gamma, *beta;
+  float *w2, *st;           // [cout][ldp] in im2col column order; [2][cout] = (running mean, rstd)
+};
+
+struct BlockPrep {
+  ConvPrep c1, c2, sc;
+  bool has_sc;
+};
+
+}  // namespace
+
+struct ws_engine {
+  bool dry = false;
+  int device = 0, cu_count = 0;
+  hipStream_t stream = nullptr;
+  std::map<std::string, int64_t> meta;
+  std::map<std::string, Tensor> tensors;
+  std::vector<float> hw;          // host copy of the weight blob
+  float* dw = nullptr;            // device copy
+  Arena persist, work;
+  long long n_launches = 0;
+  // configuration
+  int sr = 16000, num_repeat = 6, E = 256, fuse = 2, multi_fuse = 0, use_xform = 0, joint = 0, feat_dim = 80;
+  int blocks[4] = {0, 0, 0, 0};
+  // band tables (bsrnn.py:190-209)
+  std::vector<int> bw, f0;
+  int K = 0;
+  int *d_band_of_bin = nullptr, *d_f0 = nullptr, *d_bw = nullptr, *d_bw2 = nullptr, *d_off2 = nullptr;
+  // prepared weights
+  std::vector<RnnPrep> rnn;       // 2 per BSNet: band_rnn (time view), band_comm (band view)
+  std::vector<int> sep_kind;      // per entry of separator.separation: 0 fuse layer, 1 BSNet
+  ConvPrep stem;
+  std::vector<BlockPrep> res_blocks;
+  float *slope0 = nullptr, *slope1 = nullptr;     // PReLU slopes 0 (ReLU) and 1 (identity)
+  float *fb_basis = nullptr, *fb_bank = nullptr, *fb_floor = nullptr;
+  int fb_win = 400, fb_shift = 160, fb_padded = 512;
+  // grouped-GEMM descriptor tables, rebuilt when (R, Tf) changes
+  int desc_R = -1, desc_Tf = -1;
+  ws_group_nt *d_bn = nullptr, *d_l1 = nullptr, *d_l2 = nullptr, *d_l3 = nullptr;
+
+  const Tensor* find(const std::string& name) const {
+    auto it = tensors.find(name);
+    return it == tensors.end() ? nullptr : &it->second;
+  }
+  const float* dev(const std::string& name) const {
+    const Tensor* t = find(name);
+    return t ? dw + t->off : nullptr;
+  }
+  const float* host(const std::string& name) const {
+    const Tensor* t = find(name);
+    return t ? hw.data() + t->off : nullptr;
+  }
+};
+
+namespace {
+
+// A launch "passes" when it succeeded, or -- in a dry run -- when it failed for any reason other than its
+// argument validation (there is no device to launch on).
+bool passes(ws_engine* e, int rc, const char* what) {
+  ++e->n_launches;
+  if (rc == WS_OK) return true;
+  if (e->dry && rc != WS_ERR_INVALID) return true;
+  set_err("engine: %s failed (rc=%d): %s", what, rc, ws_last_error());
+  return false;
+}
+
+#define WS_RUN(e, call)                              \
+  do {                                               \
+    const int rc__ = (call);                         \
+    if (!passes((e), rc__, #call)) return rc__ ? rc__ : WS_ERR_LAUNCH; \
+  } while (0)
+
+#define WS_PTR(p)                  \
+  do {                             \
+    if (!(p)) return WS_ERR_LAUNCH; \
+  } while (0)
+
+int to_device(ws_engine* e, void* dst, const void* src, size_t bytes) {
+  if (e->dry) {
+    memcpy(dst, src, bytes);
+    return WS_OK;
+  }
+  if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+      hipStreamSynchronize(e->stream) != hipSuccess) {
+    set_err("engine: host-to-device copy of %zu bytes failed", bytes);
+    return WS_ERR_LAUNCH;
+  }
+  return WS_OK;
+}
+
+int to_host(ws_engine* e, void* dst, const void* src, size_t bytes) {
+  if (e->dry) return WS_OK;    // nothing was computed: leave the caller's buffer untouched
+  if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+      hipStreamSynchronize(e->stream) != hipSuccess) {
+    set_err("engine: device-to-host copy of %zu bytes failed", bytes);
+    return WS_ERR_LAUNCH;
+  }
+  return WS_OK;
+}
+
+int zero_device(ws_engine* e, void* p, size_t bytes) {
+  if (e->dry) {
+    memset(p, 0, bytes);
+    return WS_OK;
+  }
+  if (hipMemsetAsync(p, 0, bytes, e->stream) != hipSuccess) {
+    set_err("engine: memset failed");
+    return WS_ERR_LAUNCH;
+  }
+  return WS_OK;
+}
+
+float* upload(ws_engine* e, Arena& a, const float* src, size_t n) {
+  float* d = a.alloc(n);
+  if (!d) return nullptr;
+  if (to_device(e, d, src, n * 4) != WS_OK) return nullptr;
+  return d;
+}
+
+int* upload_ints(ws_engine* e, Arena& a, const std::vector<int>& v) {
+  return reinterpret_cast<int*>(upload(e, a, reinterpret_cast<const float*>(v.data()), v.size()));
+}
+
+// ---- weight container (written by wesep_amd/bin/export_engine.py) ---------------------------------------------
+//   char magic[8] = "WSEPW001"
+//   u32 n_meta;    n_meta    x { char key[32]; i64 value }
+//   u32 n_tensors; n_tensors x { u32 name_len; char name[name_len]; u32 ndim; i64 dims[ndim]; u64 offset_floats }
+//   u64 n_floats;  float data[n_floats]
+bool read_exact(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n; }
+
+int load_container(ws_engine* e, const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) {
+    set_err("engine: cannot open %s", path);
+    return WS_ERR_INVALID;
+  }
+  char magic[8];
+  uint32_t n_meta = 0, n_tensors = 0;
+  bool ok = read_exact(f, magic, 8) && memcmp(magic, "WSEPW001", 8) == 0 && read_exact(f, &n_meta, 4) &&
+            n_meta < 4096;
+  for (uint32_t i = 0; ok && i < n_meta; ++i) {
+    char key[33] = {0};
+    int64_t v = 0;
+    ok = read_exact(f, key, 32) && read_exact(f, &v, 8);
+    if (ok) e->meta[key] = v;
+  }
+  ok = ok && read_exact(f, &n_tensors, 4) && n_tensors < (1u << 20);
+  for (uint32_t i = 0; ok && i < n_tensors; ++i) {
+    uint32_t name_len = 0, ndim = 0;
+    ok = read_exact(f, &name_len, 4) && name_len < 1024;
+    std::string name(name_len, '\0');
+    ok = ok && read_exact(f, &name[0], name_len) && read_exact(f, &ndim, 4) && ndim <= 8;
+    Tensor t;
+    t.n = 1;
+    for (uint32_t d = 0; ok && d < ndim; ++d) {
+      int64_t v = 0;
+      ok = read_exact(f, &v, 8) && v >= 0;
+      t.dims.push_back(v);
+      t.n *= static_cast<size_t>(v);
+    }
+    uint64_t off = 0;
+    ok = ok && read_exact(f, &off, 8);
+    t.off = off;
+    if (ok) e->tensors[name] = t;
+  }
+  uint64_t n_floats = 0;
+  ok = ok && read_exact(f, &n_floats, 8) && n_floats < (uint64_t(1) << 34);
+  if (ok) {
+    e->hw.resize(n_floats);
+    ok = read_exact(f, e->hw.data(), n_floats * 4);
+  }
+  fclose(f);
+  if (!ok) {
+    set_err("engine: %s is not a valid wesep_amd weight container", path);
+    return WS_ERR_INVALID;
+  }
+  for (auto& kv : e->tensors) {
+    if (kv.second.off + kv.second.n > e->hw.size()) {
+      set_err("engine: tensor %s exceeds the data section", kv.first.c_str());
+      return WS_ERR_INVALID;
+    }
+  }
+  return WS_OK;
+}
+
+int64_t meta_or(const ws_engine* e, const char* key, int64_t dflt) {
+  auto it = e->meta.find(key);
+  return it == e->meta.end() ? dflt : it->second;
+}
+
+bool require(ws_engine* e, const std::string& name, std::initializer_list<int64_t> dims) {
+  const Tensor* t = e->find(name);
+  if (!t) {
+    set_err("engine: tensor %s is missing from the container", name.c_str());
+    return false;
+  }
+  std::vector<int64_t> want(dims);
+  size_t n = 1;
+  for (auto d : want) n *= static_cast<size_t>(d);
+  if (t->n != n) {
+    set_err("engine: tensor %s has %zu elements, expected %zu", name.c_str(), t->n, n);
+    return false;
+  }
+  return true;
+}
+
+// ---- load-time preparation -----------------------------------------------------------------------------------
+void band_table(ws_engine* e) {         // bsrnn.py:190-209
+  const double nyq = e->sr / 2.0;
+  auto bwid = [&](double hz) { return static_cast<int>(floor(hz / nyq * kNBin)); };
+  e->bw.clear();
+  for (int i = 0; i < 15; ++i) e->bw.push_back(bwid(100));
+  for (int i = 0; i < 10; ++i) e->bw.push_back(bwid(200));
+  for (int i = 0; i < 5; ++i) e->bw.push_back(bwid(500));
+  e->bw.push_back(bwid(2000));
+  int sum = 0;
+  for (int b : e->bw) sum += b;
+  e->bw.push_back(kNBin - sum);
+  e->K = static_cast<int>(e->bw.size());
+  e->f0.assign(e->K, 0);
+  for (int g = 1; g < e->K; ++g) e->f0[g] = e->f0[g - 1] + e->bw[g - 1];
+}
+
+int prep_rnn(ws_engine* e, const std::string& pre, RnnPrep* r) {
+  static const char* names[] = {"rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0", "rnn.bias_hh_l0",
+                                "rnn.weight_ih_l0_reverse", "rnn.weight_hh_l0_reverse", "rnn.bias_ih_l0_reverse",
+                                "rnn.bias_hh_l0_reverse"};
+  const int64_t shapes[][2] = {{kG4, kN}, {kG4, kH}, {kG4, 1}, {kG4, 1}, {kG4, kN}, {kG4, kH}, {kG4, 1}, {kG4, 1}};
+  for (int i = 0; i < 8; ++i)
+    if (!require(e, pre + names[i], {shapes[i][0], shapes[i][1]})) return WS_ERR_INVALID;
+  if (!require(e, pre + "norm.weight", {kN}) || !require(e, pre + "norm.bias", {kN}) ||
+      !require(e, pre + "proj.weight", {kN, 2 * kH}) || !require(e, pre + "proj.bias", {kN}))
+    return WS_ERR_INVALID;
+  const float* wih_f = e->dev(pre + names[0]);
+  const float* wih_r = e->dev(pre + names[4]);
+  r->whf = e->dev(pre + names[1]);
+  r->whr = e->dev(pre + names[5]);
+  r->norm_w = e->dev(pre + "norm.weight");
+  r->norm_b = e->dev(pre + "norm.bias");
+  r->proj_b = e->dev(pre + "proj.bias");
+  Arena& a = e->persist;
+  float* wcat = a.alloc(size_t(2) * kG4 * kN);
+  r->bcat = a.alloc(2 * kG4);
+  r->wih_pack = a.alloc(size_t(2) * kG4 * kN);
+  r->proj_pack = a.alloc(size_t(kN) * 2 * kH);
+  r->fpack = a.alloc(WS_LSTM_FUSED_PACK_FLOATS);
+  r->pack16 = a.alloc(WS_LSTM_PACK_FLOATS);
+  r->pack32 = a.alloc(WS_LSTM_PACK_FLOATS);
+  float* bwd_scratch = a.alloc(WS_LSTM_PACK_FLOATS);   // the backward-pass pack is produced too; unused here
+  WS_PTR(wcat && r->bcat && r->wih_pack && r->proj_pack && r->fpack && r->pack16 && r->pack32 && bwd_scratch);
+  void* s = e->stream;
+  WS_RUN(e, ws_lstm_cat_ih(wih_f, wih_r, e->dev(pre + names[2]), e->dev(pre + names[3]), e->dev(pre + names[6]),
+                           e->dev(pre + names[7]), kN, wcat, r->bcat, s));
+  WS_RUN(e, ws_pack_w(wcat, 2 * kG4, kN, kN, 0, 0, r->wih_pack, s));
+  WS_RUN(e, ws_pack_w(e->dev(pre + "proj.weight"), kN, 2 * kH, 2 * kH, 0, 1, r->proj_pack, s));
+  WS_RUN(e, ws_lstm_pack_fused(wih_f, wih_r, r->whf, r->whr, r->fpack, s));
+  WS_RUN(e, ws_lstm_pack(r->whf, r->whr, r->pack16, bwd_scratch, WS_LSTM_BF16X3_BLK16, s));
+  WS_RUN(e, ws_lstm_pack(r->whf, r->whr, r->pack32, bwd_scratch, WS_LSTM_BF16X3_BLK, s));
+  return WS_OK;
+}
+
+int prep_conv(ws_engine* e, const std::string& conv, const std::string& bn, int cin, int cout, int k, int stride,
+              bool relu, ConvPrep* c) {
+  if (!require(e, conv + ".weight", {cout, cin, k, k}) || !require(e, bn + ".weight", {cout}) ||
+      !require(e, bn + ".bias", {cout}) || !require(e, bn + ".running_mean", {cout}) ||
+      !require(e, bn + ".running_var", {cout}))
+    return WS_ERR_INVALID;
+  c->cin = cin;
+  c->cout = cout;
+  c->k = k;
+  c->stride = stride;
+  c->relu = relu;
+  const int kk = k * k * cin;
+  c->ldp = (kk + 3) / 4 * 4;
+  // [cout][cin][ky][kx] -> [cout][(ky*k + kx)*cin + c], zero-padded to ldp columns (functional_resnet.py:29-31)
+  const float* w = e->host(conv + ".weight");
+  std::vector<float> w2(size_t(cout) * c->ldp, 0.f);
+  for (int o = 0; o < cout; ++o)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int t = 0; t < k * k; ++t) w2[size_t(o) * c->ldp + size_t(t) * cin + ci] = w[(size_t(o) * cin + ci) * k * k + t];
+  const float* rm = e->host(bn + ".running_mean");
+  const float* rv = e->host(bn + ".running_var");
+  std::vector<float> st(2 * size_t(cout));
+  for (int o = 0; o < cout; ++o) {
+    st[o] = rm[o];
+    st[cout + o] = 1.0f / sqrtf(rv[o] + kBnEps);
+  }
+  c->w2 = upload(e, e->persist, w2.data(), w2.size());
+  c->st = upload(e, e->persist, st.data(), st.size());
+  c->gamma = e->dev(bn + ".weight");
+  c->beta = e->dev(bn + ".bias");
+  WS_PTR(c->w2 && c->st);
+  return WS_OK;
+}
+
+int prep_resnet(ws_engine* e) {
+  const int m = 32;
+  const std::string p = "spk_model.";
+  int rc = prep_conv(e, p + "conv1", p + "bn1", 1, m, 3, 1, true, &e->stem);
+  if (rc != WS_OK) return rc;
+  int inp = m;
+  for (int li = 0; li < 4; ++li) {
+    const int planes = m << li, first_stride = li == 0 ? 1 : 2;
+    for (int bi = 0; bi < e->blocks[li]; ++bi) {
+      const std::string q = p + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+      const int stride = bi == 0 ? first_stride : 1;
+      BlockPrep b;
+      b.has_sc = stride != 1 || inp != planes;
+      if ((rc = prep_conv(e, q + "conv1", q + "bn1", inp, planes, 3, stride, true, &b.c1)) != WS_OK) return rc;
+      if ((rc = prep_conv(e, q + "conv2", q + "bn2", planes, planes, 3, 1, true, &b.c2)) != WS_OK) return rc;
+      if (b.has_sc && (rc = prep_conv(e, q + "shortcut.0", q + "shortcut.1", inp, planes, 1, stride, false, &b.sc)) != WS_OK)
+        return rc;
+      e->res_blocks.push_back(b);
+      inp = planes;
+    }
+  }
+  const int stats_dim = (e->feat_dim / 8) * m * 8;
+  if (!require(e, p + "seg_1.weight", {e->E, 2 * stats_dim}) || !require(e, p + "seg_1.bias", {e->E})) return WS_ERR_INVALID;
+  const float s0 = 0.f, s1 = 1.f;
+  e->slope0 = upload(e, e->persist, &s0, 1);
+  e->slope1 = upload(e, e->persist, &s1, 1);
+  WS_PTR(e->slope0 && e->slope1);
+  return WS_OK;
+}
+
+// kaldi fbank as two GEMMs: every per-frame step before the power spectrum (2^15 scaling, DC removal, 0.97
+// pre-emphasis with the first sample replicated, symmetric Hamming window, zero padding, real DFT) folded into one
+// [2 * padded/2][win] basis; triangular mel bank [feat_dim][padded/2]   (wesep_amd/utils/funcs.py, DESIGN 11a;
+// reference: runtime/frontend/fbank.h:31-222, wesep/utils/funcs.py:91-116)
+int prep_fbank(ws_engine* e) {
+  const int win = e->sr / 40, shift = e->sr / 100;
+  int padded = 1;
+  while (padded < win) padded <<= 1;
+  const int nf = padded / 2, nb = e->feat_dim;
+  e->fb_win = win;
+  e->fb_shift = shift;
+  e->fb_padded = padded;
+  // B = (DFT * window) P D  with P = pre-emphasis, D = I - 11^T/win, applied column by column in double
+  std::vector<double> bw_(size_t(2) * nf * win);
+  for (int k = 0; k < nf; ++k)
+    for (int n = 0; n < win; ++n) {
+      const double w = 0.54 - 0.46 * cos(2.0 * M_PI * n / (win - 1));
+      const double ang = 2.0 * M_PI * double(k) * n / padded;
+      bw_[(size_t(2) * k) * win + n] = cos(ang) * w;
+      bw_[(size_t(2) * k + 1) * win + n] = -sin(ang) * w;
+    }
+  std::vector<float> basis(size_t(2) * nf * win);
+  std::vector<double> row(win);
+  for (int r = 0; r < 2 * nf; ++r) {
+    const double* b = &bw_[size_t(r) * win];
+    // (b P)[j] = b[j] - 0.97 b[j+1]  (+ for j = 0: - 0.97 b[0], the replicated first sample)
+    for (int j = 0; j < win; ++j) row[j] = b[j] - (j + 1 < win ? 0.97 * b[j + 1] : 0.0);
+    row[0] -= 0.97 * b[0];
+    double mean = 0.0;
+    for (int j = 0; j < win; ++j) mean += row[j];
+    mean /= win;
+    for (int j = 0; j < win; ++j) basis[size_t(r) * win + j] = static_cast<float>((row[j] - mean) * 32768.0);
+  }
+  auto mel = [](double f) { return 1127.0 * log(1.0 + f / 700.0); };
+  const double lo = mel(20.0), hi = mel(0.5 * e->sr), delta = (hi - lo) / (nb + 1);
+  std::vector<float> bank(size_t(nb) * nf, 0.f);
+  for (int b = 0; b < nb; ++b) {
+    const double left = lo + b * delta, center = left + delta, right = center + delta;
+    for (int i = 0; i < nf; ++i) {
+      const double m = mel(double(e->sr) / padded * i);
+      const double up = (m - left) / (center - left), down = (right - m) / (right - center);
+      const double v = up < down ? up : down;
+      bank[size_t(b) * nf + i] = v > 0.0 ? static_cast<float>(v) : 0.f;
+    }
+  }
+  std::vector<float> floor_row(nb, -kGnEps);
+  e->fb_basis = upload(e, e->persist, basis.data(), basis.size());
+  e->fb_bank = upload(e, e->persist, bank.data(), bank.size());
+  e->fb_floor = upload(e, e->persist, floor_row.data(), floor_row.size());
+  WS_PTR(e->fb_basis && e->fb_bank && e->fb_floor);
+  return WS_OK;
+}
+
+int prepare(ws_engine* e) {
+  e->sr = static_cast<int>(meta_or(e, "sample_rate", 16000));
+  e->num_repeat = static_cast<int>(meta_or(e, "num_repeat", 6));
+  e->E = static_cast<int>(meta_or(e, "spk_emb_dim", 256));
+  e->fuse = static_cast<int>(meta_or(e, "spk_fuse_type", 2));
+  e->multi_fuse = static_cast<int>(meta_or(e, "multi_fuse", 0));
+  e->use_xform = static_cast<int>(meta_or(e, "use_spk_transform", 0));
+  e->joint = static_cast<int>(meta_or(e, "joint_training", 0));
+  e->feat_dim = static_cast<int>(meta_or(e, "feat_dim", 80));
+  for (int i = 0; i < 4; ++i) e->blocks[i] = static_cast<int>(meta_or(e, ("spk_blocks" + std::to_string(i)).c_str(), 0));
+  if (meta_or(e, "win", 512) != 512 || meta_or(e, "stride", 128) != kHop || meta_or(e, "feature_dim", kN) != kN) {
+    set_err("engine: built for win 512, stride 128, feature_dim 128");
+    return WS_ERR_INVALID;
+  }
+  if (e->fuse < 0 || e->fuse > 3 || e->num_repeat < 1 || e->E % 4 || e->feat_dim % 8) {
+    set_err("engine: unsupported configuration (fuse %d, num_repeat %d, spk_emb_dim %d, feat_dim %d)", e->fuse,
+            e->num_repeat, e->E, e->feat_dim);
+    return WS_ERR_INVALID;
+  }
+  band_table(e);
+  // weights to the device, once
+  e->dw = e->persist.alloc(e->hw.size());
+  WS_PTR(e->dw);
+  int rc = to_device(e, e->dw, e->hw.data(), e->hw.size() * 4);
+  if (rc != WS_OK) return rc;
+  std::vector<int> bob, bw2, off2;
+  for (int g = 0; g < e->K; ++g) {
+    for (int i = 0; i < e->bw[g]; ++i) bob.push_back(g);
+    bw2.push_back(2 * e->bw[g]);
+    off2.push_back(2 * e->f0[g]);
+  }
+  e->d_band_of_bin = upload_ints(e, e->persist, bob);
+  e->d_f0 = upload_ints(e, e->persist, e->f0);
+  e->d_bw = upload_ints(e, e->persist, e->bw);
+  e->d_bw2 = upload_ints(e, e->persist, bw2);
+  e->d_off2 = upload_ints(e, e->persist, off2);
+  WS_PTR(e->d_band_of_bin && e->d_f0 && e->d_bw && e->d_bw2 && e->d_off2);
+  // per-band BN / mask parameters
+  for (int g = 0; g < e->K; ++g) {
+    const std::string b = "BN." + std::to_string(g) + ".", m = "mask." + std::to_string(g) + ".";
+    const int bw = e->bw[g];
+    if (!require(e, b + "0.weight", {2 * bw}) || !require(e, b + "0.bias", {2 * bw}) ||
+        !require(e, b + "1.weight", {kN, 2 * bw}) || !require(e, b + "1.bias", {kN}) ||
+        !require(e, m + "0.weight", {kN}) || !require(e, m + "0.bias", {kN}) ||
+        !require(e, m + "1.weight", {4 * kN, kN}) || !require(e, m + "1.bias", {4 * kN}) ||
+        !require(e, m + "3.weight", {4 * kN, 4 * kN}) || !require(e, m + "3.bias", {4 * kN}) ||
+        !require(e, m + "5.weight", {4 * bw, 4 * kN}) || !require(e, m + "5.bias", {4 * bw}))
+      return WS_ERR_INVALID;
+  }
+  // separator.separation layout (bsrnn.py:106-125)
+  e->sep_kind.clear();
+  if (e->multi_fuse) {
+    for (int r = 0; r < e->num_repeat; ++r) {
+      e->sep_kind.push_back(0);
+      e->sep_kind.push_back(1);
+    }
+  } else {
+    e->sep_kind.push_back(0);
+    for (int r = 0; r < e->num_repeat; ++r) e->sep_kind.push_back(1);
+  }
+  for (size_t i = 0; i < e->sep_kind.size(); ++i) {
+    const std::string pre = "separator.separation." + std::to_string(i) + ".";
+    if (e->sep_kind[i] == 1) {
+      RnnPrep t, b;
+      if ((rc = prep_rnn(e, pre + "band_rnn.", &t)) != WS_OK) return rc;
+      if ((rc = prep_rnn(e, pre + "band_comm.", &b)) != WS_OK) return rc;
+      e->rnn.push_back(t);
+      e->rnn.push_back(b);
+    } else if (e->fuse == 3) {
+      if (!require(e, pre + "fc.gamma_fcs.0.weight", {kN, e->E}) || !require(e, pre + "fc.gamma_fcs.0.bias", {kN}) ||
+          !require(e, pre + "fc.beta_fcs.0.weight", {kN, e->E}) || !require(e, pre + "fc.beta_fcs.0.bias", {kN}))
+        return WS_ERR_INVALID;
+    } else {
+      const int in = e->fuse == 0 ? kN + e->E : e->E;
+      if (!require(e, pre + "fc.linear.weight", {kN, in}) || !require(e, pre + "fc.linear.bias", {kN})) return WS_ERR_INVALID;
+    }
+  }
+  if (e->use_xform) {
+    const Tensor* t0 = e->find("spk_transform.transforms.0.weight");
+    if (!t0 || t0->dims.size() < 2 || t0->dims[1] != e->E || !e->find("spk_transform.transforms.1.weight") ||
+        !e->find("spk_transform.transforms.3.weight")) {
+      set_err("engine: spk_transform tensors missing or mis-shaped");
+      return WS_ERR_INVALID;
+    }
+  }
+  if (e->joint) {
+    if ((rc = prep_resnet(e)) != WS_OK) return rc;
+    if ((rc = prep_fbank(e)) != WS_OK) return rc;
+  }
+  if (!e->dry && hipStreamSynchronize(e->stream) != hipSuccess) {
+    set_err("engine: weight preparation failed on the device");
+    return WS_ERR_LAUNCH;
+  }
+  return WS_OK;
+}
+
+// ---- forward pieces ---------------------------------------------------------------------------------------------
+int vec_bits(std::initializer_list<long long> dims, int base = 3) {
+  for (long long d : dims)
+    if (d % 4) return 4;                 // scalar loads, split-bf16 bit kept (falls back to the fp32 kernels)
+  return base | 4;
+}
+
+// y[M][nout] = act(x[M][k] W[nout][k]^T + bias)      (functional._lin_fwd)
+int linear(ws_engine* e, const float* x, int M, int k, const float* W, long long ldw, int nout, const float* bias,
+           int act, float* y) {
+  ws_gemm_nt_args a = {};
+  a.A = x;
+  a.W = W;
+  a.bias = bias;
+  a.C = y;
+  a.a_div = kBig;
+  a.a_s2 = k;
+  a.c_div = kBig;
+  a.c_s2 = nout;
+  a.st_div1 = 1;
+  a.st_div2 = 1;
+  a.M = M;
+  a.N = nout;
+  a.K = k;
+  a.ldw = static_cast<int>(ldw);
+  a.act = act;
+  a.vec = vec_bits({k, ldw});
+  WS_RUN(e, ws_gemm_nt(&a, e->stream));
+  return WS_OK;
+}
+
+int build_descriptors(ws_engine* e, int R, int Tf) {
+  if (e->desc_R == R && e->desc_Tf == Tf && e->d_bn) return WS_OK;
+  const int K = e->K, H1 = 4 * kN;
+  const long long M = (long long)R * Tf;
+  std::vector<ws_group_nt> bn(K), l1(K), l2(K), l3(K);
+  for (int g = 0; g < K; ++g) {
+    const std::string b = "BN." + std::to_string(g) + ".", m = "mask." + std::to_string(g) + ".";
+    const int bw = e->bw[g];
+    const long long zoff = (long long)g * Tf * kN, hoff = (long long)g * M * H1;
+    bn[g] = ws_group_nt{e->dev(b + "1.weight"), e->dev(b + "1.bias"), e->dev(b + "0.weight"), e->dev(b + "0.bias"),
+                        2LL * e->f0[g], zoff, g, 2 * bw, kN, 2 * bw, 0};
+    l1[g] = ws_group_nt{e->dev(m + "1.weight"), e->dev(m + "1.bias"), e->dev(m + "0.weight"), e->dev(m + "0.bias"),
+                        zoff, hoff, g, kN, H1, kN, 0};
+    l2[g] = ws_group_nt{e->dev(m + "3.weight"), e->dev(m + "3.bias"), nullptr, nullptr, hoff, hoff, 0, H1, H1, H1, 0};
+    l3[g] = ws_group_nt{e->dev(m + "5.weight"), e->dev(m + "5.bias"), nullptr, nullptr, hoff, 4LL * e->f0[g], 0, H1,
+                        4 * bw, H1, 0};
+  }
+  if (!e->d_bn) {
+    const size_t nf = (sizeof(ws_group_nt) * K + 3) / 4;
+    e->d_bn = reinterpret_cast<ws_group_nt*>(e->persist.alloc(nf));
+    e->d_l1 = reinterpret_cast<ws_group_nt*>(e->persist.alloc(nf));
+    e->d_l2 = reinterpret_cast<ws_group_nt*>(e->persist.alloc(nf));
+    e->d_l3 = reinterpret_cast<ws_group_nt*>(e->persist.alloc(nf));
+    WS_PTR(e->d_bn && e->d_l1 && e->d_l2 && e->d_l3);
+  }
+  const size_t bytes = sizeof(ws_group_nt) * K;
+  int rc;
+  if ((rc = to_device(e, e->d_bn, bn.data(), bytes)) != WS_OK || (rc = to_device(e, e->d_l1, l1.data(), bytes)) != WS_OK ||
+      (rc = to_device(e, e->d_l2, l2.data(), bytes)) != WS_OK || (rc = to_device(e, e->d_l3, l3.data(), bytes)) != WS_OK)
+    return rc;
+  e->desc_R = R;
+  e->desc_Tf = Tf;
+  return WS_OK;
+}
+
+// ResRNN (bsrnn.py:38-46) on the blocked layout; mirrors functional.ResRNNBlkFn.forward with the packs precomputed
+int resrnn(ws_engine* e, const RnnPrep& w, bool time_view, const float* z, int R, int Tf, float* out) {
+  const int K = e->K;
+  ws_groups_geom geo = {};
+  ws_seqmap sm = {};
+  long long st_m1, st_m2;
+  int st_div1, st_div2;
+  if (time_view) {                       // band_rnn: sequences (r, k), steps over t
+    geo.ngroups = R * K, geo.gdiv = 1, geo.gs1 = (long long)Tf * kN, geo.gs2 = 0, geo.rs = kN, geo.L = Tf;
+    st_div1 = Tf, st_m1 = 1, st_div2 = 1, st_m2 = 0;
+    sm.nseq = R * K, sm.sq_div = kBig, sm.sq_s1 = 0, sm.sq_s2 = Tf, sm.step_rows = 1, sm.L = Tf;
+  } else {                               // band_comm: sequences (r, t), steps over k
+    geo.ngroups = R * Tf, geo.gdiv = Tf, geo.gs1 = (long long)K * Tf * kN, geo.gs2 = kN, geo.rs = (long long)Tf * kN,
+    geo.L = K;
+    st_div1 = K * Tf, st_m1 = Tf, st_div2 = Tf, st_m2 = 1;
+    sm.nseq = R * Tf, sm.sq_div = Tf, sm.sq_s1 = (long long)K * Tf, sm.sq_s2 = 1, sm.step_rows = Tf, sm.L = K;
+  }
+  geo.W = kN, geo.nbands = 1;
+  const int ntile = (sm.nseq + 31) / 32;
+  const size_t nb = size_t(ntile) * sm.L;
+  const int lmode = 2 * ntile <= 128 ? WS_LSTM_BF16X3_BLK16 : WS_LSTM_BF16X3_BLK;
+  const bool cluster = sm.nseq % 64 == 0 && (sm.nseq / 32) * 8 <= e->cu_count && sm.L >= 64;
+  const bool fused = !cluster && lmode == WS_LSTM_BF16X3_BLK;
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  float* stats = a.alloc(size_t(geo.ngroups) * 2);
+  float* gates = a.alloc(nb * 32 * 2 * kG4);
+  float* cbuf = a.alloc(nb * 32 * 2 * kH);
+  float* hcat = a.alloc(nb * 32 * 2 * kH);
+  float* xn = a.alloc(nb * 32 * kN);      // normalised input in BL(128): operand of the fused recurrence
+  WS_PTR(stats && gates && cbuf && hcat && xn);
+  WS_RUN(e, ws_group_stats(z, &geo, kGnEps, stats, s));
+  ws_gemm_p2b_args p = {};
+  p.A = z;
+  p.stats = stats;
+  p.gamma = w.norm_w;
+  p.beta = w.norm_b;
+  p.sm = sm;
+  p.lda = kN;
+  p.st_div1 = st_div1, p.st_m1 = st_m1, p.st_div2 = st_div2, p.st_m2 = st_m2, p.st_base = 0;
+  p.K = kN;
+  p.A_bl = xn;
+  if (fused) {          // the recurrence computes x W_ih^T itself from the normalised input in BL(128)
+    p.N = 0;
+    WS_RUN(e, ws_gemm_p2b(&p, s));
+    ws_lstm_fused_args f = {};
+    f.gates = gates, f.cbuf = cbuf, f.hcat = hcat, f.xn = xn, f.wpack = w.fpack, f.bias = w.bcat;
+    f.nseq = sm.nseq, f.L = sm.L;
+    WS_RUN(e, ws_lstm_fwd_fused(&f, s));
+  } else {
+    p.Wpack = w.wih_pack;
+    p.bias = w.bcat;
+    p.C = gates;
+    p.N = 2 * kG4;
+    WS_RUN(e, ws_gemm_p2b(&p, s));
+    if (cluster) {
+      const int ncl = sm.nseq / 32;
+      float* xchg = a.alloc(size_t(ncl) * 2 * 8 * 8192 / 4);
+      unsigned* flags = reinterpret_cast<unsigned*>(a.alloc(size_t(ncl) * 8));
+      WS_PTR(xchg && flags);
+      ws_lstm_cluster_args c = {};
+      c.gates = gates, c.cbuf = cbuf, c.hcat = hcat, c.whh_f = w.whf, c.whh_r = w.whr;
+      c.xchg = xchg, c.flags = flags, c.nseq = sm.nseq, c.L = sm.L;
+      WS_RUN(e, ws_lstm_fwd_cluster(&c, s));
+    } else {
+      ws_lstm_args l = {};
+      l.gates = gates, l.cbuf = cbuf, l.hcat = hcat;
+      l.wpack = lmode == WS_LSTM_BF16X3_BLK16 ? w.pack16 : w.pack32;
+      l.sq_s1 = sm.sq_s1, l.sq_s2 = sm.sq_s2, l.step_rows = sm.step_rows;
+      l.nseq = sm.nseq, l.sq_div = sm.sq_div, l.L = sm.L, l.mode = lmode;
+      WS_RUN(e, ws_lstm_fwd(&l, s));
+    }
+  }
+  ws_gemm_b2p_args b = {};
+  b.A = hcat, b.Wpack = w.proj_pack, b.bias = w.proj_b, b.R = z, b.C = out, b.sm = sm, b.ldc = kN, b.N = kN, b.K = 2 * kH;
+  WS_RUN(e, ws_gemm_b2p(&b, s));
+  a.release(mk);
+  return WS_OK;
+}
+
+// speaker fusion on Z (speaker.py:81-125, norm.py:118-139), in place
+int fuse_layer(ws_engine* e, const std::string& pre, float* z, const float* emb, int R, int Tf) {
+  const int K = e->K, E = e->E;
+  const long long P = (long long)R * K * Tf;
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  float* v = a.alloc(size_t(R) * kN);
+  float* v2 = a.alloc(size_t(R) * kN);
+  WS_PTR(v && v2);
+  int rc;
+  if (e->fuse == 3) {          // FiLM: (1 + gamma(e)) z + beta(e)
+    if ((rc = linear(e, emb, R, E, e->dev(pre + "fc.gamma_fcs.0.weight"), E, kN, e->dev(pre + "fc.gamma_fcs.0.bias"), 0, v)) != WS_OK ||
+        (rc = linear(e, emb, R, E, e->dev(pre + "fc.beta_fcs.0.weight"), E, kN, e->dev(pre + "fc.beta_fcs.0.bias"), 0, v2)) != WS_OK)
+      return rc;
+    WS_RUN(e, ws_affine_fwd(z, v, v2, 1.0f, P, K * Tf, kN, z, s));
+  } else if (e->fuse == 0) {   // concat: Linear(cat[z, e]) = z Wz^T + (e We^T + b)
+    const float* W = e->dev(pre + "fc.linear.weight");
+    if ((rc = linear(e, emb, R, E, W + kN, kN + E, kN, e->dev(pre + "fc.linear.bias"), 0, v)) != WS_OK) return rc;
+    float* t = a.alloc(size_t(P) * kN);
+    WS_PTR(t);
+    ws_gemm_nt_args g = {};
+    g.A = z, g.W = W, g.C = t;
+    g.a_div = kBig, g.a_s2 = kN, g.c_div = kBig, g.c_s2 = kN, g.st_div1 = 1, g.st_div2 = 1;
+    g.M = static_cast<int>(P), g.N = kN, g.K = kN, g.ldw = kN + E, g.vec = 3 | 4;
+    WS_RUN(e, ws_gemm_nt(&g, s));
+    WS_RUN(e, ws_affine_fwd(t, nullptr, v, 1.0f, P, K * Tf, kN, z, s));
+  } else {
+    if ((rc = linear(e, emb, R, E, e->dev(pre + "fc.linear.weight"), E, kN, e->dev(pre + "fc.linear.bias"), 0, v)) != WS_OK)
+      return rc;
+    if (e->fuse == 2)
+      WS_RUN(e, ws_affine_fwd(z, v, nullptr, 0.0f, P, K * Tf, kN, z, s));     // multiply
+    else
+      WS_RUN(e, ws_affine_fwd(z, nullptr, v, 1.0f, P, K * Tf, kN, z, s));     // additive
+  }
+  a.release(mk);
+  return WS_OK;
+}
+
+// conv (im2col + GEMM) + BatchNorm(eval) + ReLU/identity (+ residual), channels-last (functional_resnet.py:15-46)
+int conv_bn_act(ws_engine* e, const ConvPrep& c, const float* x, const float* res, int R, int H, int W, float* y,
+                int* Ho_out, int* Wo_out) {
+  const int pad = c.k / 2;
+  const int Ho = (H + 2 * pad - c.k) / c.stride + 1, Wo = (W + 2 * pad - c.k) / c.stride + 1;
+  const long long M = (long long)R * Ho * Wo;
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  float* patches = a.alloc(size_t(M) * c.ldp);
+  float* conv = a.alloc(size_t(M) * c.cout);
+  float* u = a.alloc(size_t(M) * c.cout);
+  WS_PTR(patches && conv && u);
+  if (c.ldp != c.k * c.k * c.cin) {
+    const int rc = zero_device(e, patches, size_t(M) * c.ldp * 4);
+    if (rc != WS_OK) return rc;
+  }
+  WS_RUN(e, ws_im2col(x, R, H, W, c.cin, c.k, c.stride, pad, c.ldp, patches, s));
+  ws_gemm_nt_args g = {};
+  g.A = patches, g.W = c.w2, g.C = conv;
+  g.a_div = kBig, g.a_s2 = c.ldp, g.c_div = kBig, g.c_s2 = c.cout, g.st_div1 = 1, g.st_div2 = 1;
+  g.M = static_cast<int>(M), g.N = c.cout, g.K = c.ldp, g.ldw = c.ldp, g.vec = 3 | 4;
+  WS_RUN(e, ws_gemm_nt(&g, s));
+  WS_RUN(e, ws_bn_prelu_fwd(conv, c.st, c.gamma, c.beta, res, c.relu ? e->slope0 : e->slope1, M, c.cout, u, y, s));
+  a.release(mk);
+  *Ho_out = Ho;
+  *Wo_out = Wo;
+  return WS_OK;
+}
+
+// fbank [R][Te][F] (device) -> embedding [R][E]   (wespeaker ResNet, eval mode; models/resnet.py:80-102)
+int resnet_embed(ws_engine* e, const float* fbank, int R, int Te, float* emb) {
+  const int F = e->feat_dim;
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  // [R][Te][F] -> [R][F][Te][1]
+  float* x = a.alloc(size_t(R) * F * Te);
+  WS_PTR(x);
+  for (int r = 0; r < R; ++r)
+    WS_RUN(e, ws_transpose(fbank + size_t(r) * Te * F, Te, F, F, x + size_t(r) * F * Te, s));
+  int H = F, W = Te, Ho, Wo, rc;
+  // ping-pong activation buffers sized for the stem output (the largest activation)
+  const size_t act = size_t(R) * H * W * 32;
+  float* bufs[3] = {a.alloc(act), a.alloc(act), a.alloc(act)};
+  WS_PTR(bufs[0] && bufs[1] && bufs[2]);
+  if ((rc = conv_bn_act(e, e->stem, x, nullptr, R, H, W, bufs[0], &Ho, &Wo)) != WS_OK) return rc;
+  int cur = 0, C = 32;
+  for (const BlockPrep& b : e->res_blocks) {
+    float* y = bufs[cur];
+    float* o = bufs[(cur + 1) % 3];
+    float* sc = bufs[(cur + 2) % 3];
+    int H1, W1, H2, W2, Hs, Ws;
+    if ((rc = conv_bn_act(e, b.c1, y, nullptr, R, H, W, o, &H1, &W1)) != WS_OK) return rc;
+    const float* shortcut = y;
+    if (b.has_sc) {
+      if ((rc = conv_bn_act(e, b.sc, y, nullptr, R, H, W, sc, &Hs, &Ws)) != WS_OK) return rc;
+      shortcut = sc;
+    }
+    // conv2 writes over the block input unless that is the shortcut operand
+    float* dst = b.has_sc ? y : sc;
+    if ((rc = conv_bn_act(e, b.c2, o, shortcut, R, H1, W1, dst, &H2, &W2)) != WS_OK) return rc;
+    cur = b.has_sc ? cur : (cur + 2) % 3;
+    H = H2, W = W2, C = b.c2.cout;
+  }
+  float* stats = a.alloc(size_t(R) * 2 * C * H);
+  WS_PTR(stats);
+  WS_RUN(e, ws_tstp_fwd(bufs[cur], R, H, W, C, kTstpEps, stats, s));
+  rc = linear(e, stats, R, 2 * C * H, e->dev("spk_model.seg_1.weight"), 2 * C * H, e->E, e->dev("spk_model.seg_1.bias"), 0, emb);
+  a.release(mk);
+  return rc;
+}
+
+// waveform [R][Tw] in [-1, 1] (device) -> mean-normalised kaldi fbank [R][Te][F]  (utils/funcs.py compute_fbank +
+// apply_cmvn with dither 0; reference: SeparateEngine::ExtractFeature, separate_engine.cc:53-74)
+int kaldi_fbank(ws_engine* e, const float* wav, int R, int Tw, float* feats, int Te) {
+  const int win = e->fb_win, shift = e->fb_shift, nf = e->fb_padded / 2, nb = e->feat_dim;
+  const long long M = (long long)R * Te;
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  float* spec = a.alloc(size_t(M) * 2 * nf);
+  float* power = a.alloc(size_t(M) * nf);
+  float* mel = a.alloc(size_t(M) * nb);
+  WS_PTR(spec && power && mel);
+  ws_gemm_nt_args g = {};
+  g.A = wav, g.W = e->fb_basis, g.C = spec;
+  g.a_div = Te, g.a_s1 = Tw, g.a_s2 = shift;            // frame f of row r starts at r*Tw + f*shift: overlapping view
+  g.c_div = kBig, g.c_s2 = 2 * nf, g.st_div1 = 1, g.st_div2 = 1;
+  g.M = static_cast<int>(M), g.N = 2 * nf, g.K = win, g.ldw = win;
+  g.vec = (Tw % 4 == 0 && shift % 4 == 0 && win % 4 == 0) ? 3 : (win % 4 == 0 ? 2 : 0);     // exact-fp32 products
+  WS_RUN(e, ws_gemm_nt(&g, s));
+  WS_RUN(e, ws_power_spec(spec, M, nf, 2 * nf, nf, power, s));
+  ws_gemm_nt_args h = {};
+  h.A = power, h.W = e->fb_bank, h.C = mel;
+  h.a_div = kBig, h.a_s2 = nf, h.c_div = kBig, h.c_s2 = nb, h.st_div1 = 1, h.st_div2 = 1;
+  h.M = static_cast<int>(M), h.N = nb, h.K = nf, h.ldw = nf, h.vec = 3;
+  WS_RUN(e, ws_gemm_nt(&h, s));
+  // log(max(x, eps)) = log(relu(x - eps) + eps)
+  WS_RUN(e, ws_prelu_fwd(mel, e->fb_floor, e->slope0, M, nb, static_cast<int>(M), feats, s));
+  WS_RUN(e, ws_log_eps(feats, M * nb, kGnEps, s));
+  // CMN: minus the mean over the frames of each row
+  int nsplit = Te / 32;
+  const int cap = 1024 / R > 1 ? 1024 / R : 1;
+  if (nsplit > cap) nsplit = cap;
+  if (nsplit < 1) nsplit = 1;
+  float* slab = a.alloc(size_t(nsplit) * R * 2 * nb);
+  float* sums = a.alloc(size_t(R) * 2 * nb);
+  float* neg_mean = a.alloc(size_t(R) * nb);
+  WS_PTR(slab && sums && neg_mean);
+  WS_RUN(e, ws_chan_sums(feats, nullptr, nullptr, 1, Te, R, nsplit, nb, slab, s));
+  WS_RUN(e, ws_reduce_slabs(slab, nsplit, (long long)R * 2 * nb, (long long)R * 2 * nb, sums, 0, 0, s));
+  // rows of `sums` are [2][nb] per utterance: scale the first half of each by -1/Te into a dense [R][nb]
+  for (int r = 0; r < R; ++r)
+    WS_RUN(e, ws_affine_fwd(sums + size_t(r) * 2 * nb, nullptr, nullptr, -1.0f / Te, 1, 1, nb, neg_mean + size_t(r) * nb, s));
+  WS_RUN(e, ws_affine_fwd(feats, nullptr, neg_mean, 1.0f, M, Te, nb, feats, s));
+  a.release(mk);
+  return WS_OK;
+}
+
+// BSRNN.forward (bsrnn.py:300-394) with the embedding already computed: wav [R][T], emb [R][E] -> est [R][T] (device)
+int separate_device(ws_engine* e, const float* wav, int R, int T, const float* emb_in, float* est) {
+  const int K = e->K, Tf = 1 + T / kHop, H1 = 4 * kN;
+  const long long M = (long long)R * Tf;
+  void* s = e->stream;
+  Arena& a = e->work;
+  int rc = build_descriptors(e, R, Tf);
+  if (rc != WS_OK) return rc;
+  ws_bands bands = {e->d_band_of_bin, e->d_f0, e->d_bw, K, kNBin};
+  float* xbs = a.alloc(size_t(M) * 2 * kNBin);
+  float* zA = a.alloc(size_t(R) * K * Tf * kN);
+  float* zB = a.alloc(size_t(R) * K * Tf * kN);
+  WS_PTR(xbs && zA && zB);
+  // STFT + band split + per-band GroupNorm + Conv1d(k = 1)   (bsrnn.py:309-337)
+  WS_RUN(e, ws_stft_bandsplit(wav, R, T, &bands, xbs, s));
+  {
+    const Arena::Mark mk = a.mark();
+    float* stats = a.alloc(size_t(R) * K * 2);
+    WS_PTR(stats);
+    ws_groups_geom geo = {};
+    geo.band_w = e->d_bw2, geo.band_off = e->d_off2;
+    geo.gs1 = (long long)Tf * 2 * kNBin, geo.gs2 = 0, geo.rs = 2 * kNBin;
+    geo.ngroups = R * K, geo.gdiv = K, geo.L = Tf, geo.W = 128, geo.nbands = K;
+    WS_RUN(e, ws_group_stats(xbs, &geo, kGnEps, stats, s));
+    ws_gemm_nt_args g = {};
+    g.A = xbs, g.C = zA, g.stats = stats, g.groups = e->d_bn;
+    g.a_div = kBig, g.a_s2 = 2 * kNBin;
+    g.c_div = Tf, g.c_s1 = (long long)K * Tf * kN, g.c_s2 = kN;
+    g.st_div1 = Tf, g.st_m1 = K, g.st_div2 = 1, g.st_m2 = 0;
+    g.M = static_cast<int>(M), g.ngroups = K, g.max_n = kN, g.vec = 0 | 4;
+    WS_RUN(e, ws_gemm_nt(&g, s));
+    a.release(mk);
+  }
+  // speaker embedding -> (optional) SpeakerTransform (speaker.py:26-49)
+  const float* emb = emb_in;
+  if (e->use_xform) {
+    const Tensor* t0 = e->find("spk_transform.transforms.0.weight");
+    const int hid = static_cast<int>(t0->dims[0]);
+    float* h0 = a.alloc(size_t(R) * hid);
+    float* h1 = a.alloc(size_t(R) * hid);
+    float* eo = a.alloc(size_t(R) * e->E);
+    WS_PTR(h0 && h1 && eo);
+    if ((rc = linear(e, emb, R, e->E, e->dev("spk_transform.transforms.0.weight"), e->E, hid,
+                     e->dev("spk_transform.transforms.0.bias"), 0, h0)) != WS_OK ||
+        (rc = linear(e, h0, R, hid, e->dev("spk_transform.transforms.1.weight"), hid, hid,
+                     e->dev("spk_transform.transforms.1.bias"), 1, h1)) != WS_OK ||
+        (rc = linear(e, h1, R, hid, e->dev("spk_transform.transforms.3.weight"), hid, e->E,
+                     e->dev("spk_transform.transforms.3.bias"), 0, eo)) != WS_OK)
+      return rc;
+    emb = eo;
+  }
+  // separator (bsrnn.py:86-148)
+  float* z = zA;
+  float* other = zB;
+  size_t net = 0;
+  for (size_t i = 0; i < e->sep_kind.size(); ++i) {
+    if (e->sep_kind[i] == 0) {
+      if ((rc = fuse_layer(e, "separator.separation." + std::to_string(i) + ".", z, emb, R, Tf)) != WS_OK) return rc;
+    } else {
+      if ((rc = resrnn(e, e->rnn[2 * net], true, z, R, Tf, other)) != WS_OK) return rc;
+      if ((rc = resrnn(e, e->rnn[2 * net + 1], false, other, R, Tf, z)) != WS_OK) return rc;
+      ++net;
+    }
+  }
+  // mask MLP + GLU complex mask + iSTFT (bsrnn.py:366-392)
+  {
+    const Arena::Mark mk = a.mark();
+    float* stats = a.alloc(size_t(R) * K * 2);
+    float* h1 = a.alloc(size_t(K) * M * H1);
+    float* h2 = a.alloc(size_t(K) * M * H1);
+    float* m3 = a.alloc(size_t(M) * 4 * kNBin);
+    float* frames = a.alloc(size_t(M) * 512);
+    WS_PTR(stats && h1 && h2 && m3 && frames);
+    ws_groups_geom geo = {};
+    geo.gs1 = (long long)Tf * kN, geo.gs2 = 0, geo.rs = kN;
+    geo.ngroups = R * K, geo.gdiv = 1, geo.L = Tf, geo.W = kN, geo.nbands = K;
+    WS_RUN(e, ws_group_stats(z, &geo, kGnEps, stats, s));
+    int maxbw = 0;
+    for (int b : e->bw) maxbw = b > maxbw ? b : maxbw;
+    ws_gemm_nt_args g = {};
+    g.A = z, g.C = h1, g.stats = stats, g.groups = e->d_l1;
+    g.a_div = Tf, g.a_s1 = (long long)K * Tf * kN, g.a_s2 = kN;
+    g.c_div = kBig, g.c_s2 = H1;
+    g.st_div1 = Tf, g.st_m1 = K, g.st_div2 = 1, g.st_m2 = 0;
+    g.M = static_cast<int>(M), g.act = 1, g.ngroups = K, g.max_n = H1, g.vec = 3 | 4;
+    WS_RUN(e, ws_gemm_nt(&g, s));
+    ws_gemm_nt_args g2 = {};
+    g2.A = h1, g2.C = h2, g2.groups = e->d_l2;
+    g2.a_div = kBig, g2.a_s2 = H1, g2.c_div = kBig, g2.c_s2 = H1, g2.st_div1 = 1, g2.st_div2 = 1;
+    g2.M = static_cast<int>(M), g2.act = 1, g2.ngroups = K, g2.max_n = H1, g2.vec = 3 | 4;
+    WS_RUN(e, ws_gemm_nt(&g2, s));
+    ws_gemm_nt_args g3 = {};
+    g3.A = h2, g3.C = m3, g3.groups = e->d_l3;
+    g3.a_div = kBig, g3.a_s2 = H1, g3.c_div = kBig, g3.c_s2 = 4 * kNBin, g3.st_div1 = 1, g3.st_div2 = 1;
+    g3.M = static_cast<int>(M), g3.ngroups = K, g3.max_n = 4 * maxbw, g3.vec = 3 | 4;
+    WS_RUN(e, ws_gemm_nt(&g3, s));
+    WS_RUN(e, ws_mask_istft_frames(xbs, m3, R, Tf, &bands, frames, s));
+    WS_RUN(e, ws_istft_ola(frames, R, Tf, T, est, s));
+    a.release(mk);
+  }
+  return WS_OK;
+}
+
+int check_engine(const ws_engine* e, const char* who) {
+  if (!e) {
+    set_err("%s: null engine", who);
+    return WS_ERR_INVALID;
+  }
+  return WS_OK;
+}
+
+}  // namespace
+
+// ---- C ABI ----------------------------------------------------------------------------------------------------
+extern "C" int ws_engine_abi_version(void) { return WS_ENGINE_ABI_VERSION; }
+extern "C" const char* ws_engine_last_error(void) { return g_err; }
+
+extern "C" void ws_engine_destroy(ws_engine* e) {
+  if (!e) return;
+  e->work.free_all();
+  e->persist.free_all();
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+extern "C" int ws_engine_create(const char* weights_path, int device, int flags, ws_engine** out) {
+  if (!weights_path || !out) {
+    set_err("ws_engine_create: null argument");
+    return WS_ERR_INVALID;
+  }
+  *out = nullptr;
+  if (ws_abi_version() != WS_ABI_VERSION) {
+    set_err("ws_engine_create: libwesep_hip.so ABI %d, engine built for %d", ws_abi_version(), WS_ABI_VERSION);
+    return WS_ERR_INVALID;
+  }
+  ws_engine* e = new ws_engine();
+  e->dry = (flags & WS_ENGINE_DRY_RUN) != 0;
+  e->device = device;
+  e->persist.dry = e->work.dry = e->dry;
+  int rc = load_container(e, weights_path);
+  if (rc == WS_OK && e->dry) {
+    // with a device present the launches of a dry run would really execute -- on host pointers
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+      set_err("ws_engine_create: WS_ENGINE_DRY_RUN is for machines without a GPU (%d HIP device(s) visible)", ndev);
+      rc = WS_ERR_INVALID;
+    }
+  }
+  if (rc == WS_OK && !e->dry) {
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+      set_err("ws_engine_create: no usable HIP device %d (use WS_ENGINE_DRY_RUN to validate without a GPU)", device);
+      rc = WS_ERR_LAUNCH;
+    } else {
+      e->cu_count = prop.multiProcessorCount;
+    }
+  }
+  if (rc == WS_OK) rc = prepare(e);
+  if (rc != WS_OK) {
+    ws_engine_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return WS_OK;
+}
+
+extern "C" long long ws_engine_info(const ws_engine* e, const char* key) {
+  if (!e || !key) return -1;
+  const std::string k(key);
+  if (k == "n_tensors") return static_cast<long long>(e->tensors.size());
+  if (k == "n_launches") return e->n_launches;
+  if (k == "arena_bytes") return static_cast<long long>(e->work.peak_bytes);
+  if (k == "nband") return e->K;
+  auto it = e->meta.find(k);
+  return it == e->meta.end() ? -1 : it->second;
+}
+
+extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, const void* enroll, int enroll_kind,
+                                  int enroll_len, float* est) {
+  int rc = check_engine(e, "ws_engine_separate");
+  if (rc != WS_OK) return rc;
+  if (!mix || !enroll || !est || R < 1 || T < 512 || (long long)R * (1 + T / kHop) * 4 * kNBin > 0x7fffffffLL) {
+    set_err("ws_engine_separate: bad arguments (R=%d, T=%d; T >= 512)", R, T);
+    return WS_ERR_INVALID;
+  }
+  if ((enroll_kind == WS_ENROLL_EMBEDDING) == (e->joint != 0) || enroll_kind < 0 || enroll_kind > WS_ENROLL_WAVE) {
+    set_err("ws_engine_separate: enrollment kind %d does not fit this model (joint_training = %d)", enroll_kind, e->joint);
+    return WS_ERR_INVALID;
+  }
+  int Te = enroll_len;
+  if (enroll_kind == WS_ENROLL_WAVE) {
+    if (enroll_len < e->fb_win) {
+      set_err("ws_engine_separate: enrollment shorter than one %d-sample frame", e->fb_win);
+      return WS_ERR_INVALID;
+    }
+    Te = 1 + (enroll_len - e->fb_win) / e->fb_shift;
+  }
+  if (enroll_kind != WS_ENROLL_EMBEDDING && Te < 8) {
+    set_err("ws_engine_separate: enrollment of %d frames is too short for the speaker encoder", Te);
+    return WS_ERR_INVALID;
+  }
+  if (!e->dry && hipSetDevice(e->device) != hipSuccess) {
+    set_err("ws_engine_separate: hipSetDevice(%d) failed", e->device);
+    return WS_ERR_LAUNCH;
+  }
+  e->n_launches = 0;
+  Arena& a = e->work;
+  a.reset();
+  float* d_mix = a.alloc(size_t(R) * T);
+  float* d_est = a.alloc(size_t(R) * T);
+  float* d_emb = a.alloc(size_t(R) * e->E);
+  WS_PTR(d_mix && d_est && d_emb);
+  if ((rc = to_device(e, d_mix, mix, size_t(R) * T * 4)) != WS_OK) return rc;
+  if (enroll_kind == WS_ENROLL_EMBEDDING) {
+    if ((rc = to_device(e, d_emb, enroll, size_t(R) * e->E * 4)) != WS_OK) return rc;
+  } else {
+    const Arena::Mark mk = a.mark();
+    float* fb = a.alloc(size_t(R) * Te * e->feat_dim);
+    WS_PTR(fb);
+    if (enroll_kind == WS_ENROLL_FBANK) {
+      if ((rc = to_device(e, fb, enroll, size_t(R) * Te * e->feat_dim * 4)) != WS_OK) return rc;
+    } else {
+      float* d_wave = a.alloc(size_t(R) * enroll_len);
+      WS_PTR(d_wave);
+      if ((rc = to_device(e, d_wave, enroll, size_t(R) * enroll_len * 4)) != WS_OK) return rc;
+      if ((rc = kaldi_fbank(e, d_wave, R, enroll_len, fb, Te)) != WS_OK) return rc;
+    }
+    if ((rc = resnet_embed(e, fb, R, Te, d_emb)) != WS_OK) return rc;
+    a.release(mk);
+  }
+  if ((rc = separate_device(e, d_mix, R, T, d_emb, d_est)) != WS_OK) return rc;
+  if ((rc = to_host(e, est, d_est, size_t(R) * T * 4)) != WS_OK) return rc;
+  a.reset();
+  a.consolidate();
+  return WS_OK;
+}
+
+extern "C" int ws_engine_forward_pcm16(ws_engine* e, const int16_t* mix, int n, const int16_t* spk1, const int16_t* spk2,
+                                       int n_enroll, float* out) {
+  int rc = check_engine(e, "ws_engine_forward_pcm16");
+  if (rc != WS_OK) return rc;
+  if (!mix || !spk1 || !spk2 || !out || n < 512 || n_enroll < 1) {
+    set_err("ws_engine_forward_pcm16: bad arguments");
+    return WS_ERR_INVALID;
+  }
+  // separate_engine.cc:78-98: the mixture twice (one row per enrollment), scaled to [-1, 1]; the enrollment fbank is
+  // computed on int16-valued samples, which the folded basis' 2^15 factor reproduces from the [-1, 1] rows
+  std::vector<float> m(size_t(2) * n), enr(size_t(2) * n_enroll);
+  for (int i = 0; i < n; ++i) m[i] = m[size_t(n) + i] = static_cast<float>(mix[i]) / 32768.0f;
+  for (int i = 0; i < n_enroll; ++i) {
+    enr[i] = static_cast<float>(spk1[i]) / 32768.0f;
+    enr[size_t(n_enroll) + i] = static_cast<float>(spk2[i]) / 32768.0f;
+  }
+  return ws_engine_separate(e, m.data(), 2, n, enr.data(), WS_ENROLL_WAVE, n_enroll, out);
+}

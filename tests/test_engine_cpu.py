@@ -1,0 +1,183 @@
+"""CPU: the native runtime (include/wesep_engine.h, runtime/engine.cc) without a GPU -- library and symbols, the
+weight container written by `wesep_amd.bin.export_engine`, the engine's DRY RUN (every launch of the plan must pass
+its entry point's argument validation in the real libwesep_hip.so; nothing is computed), the wav reader / writer and
+the `separate_main` command-line tool."""
+import ctypes
+import os
+import struct
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from wesep_amd import engine as E
+from wesep_amd.bin.export_engine import export_engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+needs_no_gpu = pytest.mark.skipif(torch.cuda.is_available(), reason="the engine's dry run is refused when a GPU is visible")
+SPK = dict(joint_training=True, spk_feat=True,
+           spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
+FIXED = [dict(num_repeat=2, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False),
+         dict(num_repeat=2, spk_fuse_type="FiLM", multi_fuse=True, use_spk_transform=True),
+         dict(num_repeat=1, spk_fuse_type="concat", multi_fuse=True, use_spk_transform=False),
+         dict(num_repeat=1, spk_fuse_type="additive", multi_fuse=False, use_spk_transform=True)]
+
+
+def _model(**kw):
+    from wesep_amd.models import get_model
+    return get_model("BSRNN")(**kw)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(E.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "wesep_engine.h")).read()
+    for sym in E.SYMBOLS:
+        assert sym + "(" in header, sym
+        assert hasattr(lib, sym), sym
+    assert E.lib().ws_engine_abi_version() == E.ENGINE_ABI_VERSION
+
+
+@needs_no_gpu
+def test_container_layout_and_rejection(tmp_path):
+    m = _model(joint_training=False, **FIXED[0])
+    path = str(tmp_path / "m.wsw")
+    n, nf = export_engine(m, path)
+    sd = {k: v for k, v in m.state_dict().items()}
+    assert n == len(sd)
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"WSEPW001" and len(raw) > nf * 4
+    # the data section holds every tensor bit-exactly at a 16-byte aligned offset: spot-check through the header
+    n_meta = struct.unpack_from("<I", raw, 8)[0]
+    pos = 12 + n_meta * 40
+    n_t = struct.unpack_from("<I", raw, pos)[0]
+    pos += 4
+    table = {}
+    for _ in range(n_t):
+        ln = struct.unpack_from("<I", raw, pos)[0]
+        name = raw[pos + 4:pos + 4 + ln].decode()
+        pos += 4 + ln
+        nd = struct.unpack_from("<I", raw, pos)[0]
+        dims = struct.unpack_from(f"<{nd}q", raw, pos + 4)
+        off = struct.unpack_from("<Q", raw, pos + 4 + 8 * nd)[0]
+        pos += 4 + 8 * nd + 8
+        table[name] = (dims, off)
+    assert struct.unpack_from("<Q", raw, pos)[0] == nf
+    data = np.frombuffer(raw, dtype=np.float32, offset=pos + 8)
+    for k in ("BN.3.1.weight", "separator.separation.1.band_rnn.rnn.weight_hh_l0_reverse", "mask.31.5.bias"):
+        dims, off = table[k]
+        assert off % 4 == 0 and tuple(dims) == tuple(sd[k].shape)
+        assert np.array_equal(data[off:off + sd[k].numel()], sd[k].numpy().reshape(-1))
+    # a truncated file and a non-container are refused with a message, not a crash
+    bad = str(tmp_path / "bad.wsw")
+    open(bad, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(E.WesepHipError, match="not a valid"):
+        E.Engine(bad, dry_run=True)
+    open(bad, "wb").write(b"not a model")
+    with pytest.raises(E.WesepHipError):
+        E.Engine(bad, dry_run=True)
+    with pytest.raises(E.WesepHipError, match="cannot open"):
+        E.Engine(str(tmp_path / "missing.wsw"), dry_run=True)
+    # a container with a tensor missing is refused at load (names the tensor)
+    sd.pop("mask.7.3.weight")
+    from wesep_amd.bin.export_engine import engine_meta, write_container
+    write_container(bad, engine_meta(m), sd)
+    with pytest.raises(E.WesepHipError, match="mask.7.3.weight"):
+        E.Engine(bad, dry_run=True)
+
+
+@needs_no_gpu
+@pytest.mark.parametrize("kw", FIXED, ids=[k["spk_fuse_type"] for k in FIXED])
+def test_dry_run_launch_plan_fixed_embeddings(tmp_path, kw):
+    """Every fusion variant, ragged and long lengths, 1 / 2 / 32 rows: the whole plan passes argument validation."""
+    path = str(tmp_path / "m.wsw")
+    export_engine(_model(joint_training=False, **kw), path)
+    eng = E.Engine(path, dry_run=True)
+    assert eng.info("num_repeat") == kw["num_repeat"] and eng.info("joint_training") == 0 and eng.info("nband") == 32
+    counts = set()
+    for R, T in ((2, 16000), (2, 12345), (1, 64000), (32, 8192), (2, 512)):
+        est = eng.separate(np.ones((R, T), np.float32), np.zeros((R, 256), np.float32), E.ENROLL_EMBEDDING)
+        assert est.shape == (R, T) and not est.any()           # a dry run computes nothing
+        counts.add(eng.info("n_launches"))
+        assert eng.info("arena_bytes") > 0
+    assert len(counts) == 1                                    # the plan does not depend on the geometry
+    with pytest.raises(E.WesepHipError, match="T >= 512"):
+        eng.separate(np.zeros((2, 300), np.float32), np.zeros((2, 256), np.float32), E.ENROLL_EMBEDDING)
+    with pytest.raises(E.WesepHipError, match="does not fit"):
+        eng.separate(np.zeros((2, 4000), np.float32), np.zeros((2, 98, 80), np.float32), E.ENROLL_FBANK)
+    eng.close()
+
+
+@needs_no_gpu
+@pytest.mark.parametrize("spk_model", ["ResNet18", "ResNet34"])
+def test_dry_run_launch_plan_joint_model(tmp_path, spk_model):
+    path = str(tmp_path / "j.wsw")
+    export_engine(_model(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                         spk_model=spk_model, **SPK), path)
+    eng = E.Engine(path, dry_run=True)
+    assert eng.info("joint_training") == 1 and eng.info("feat_dim") == 80
+    eng.separate(np.zeros((2, 16000), np.float32), np.zeros((2, 98, 80), np.float32), E.ENROLL_FBANK)
+    n_fbank = eng.info("n_launches")
+    eng.separate(np.zeros((2, 16000), np.float32), np.zeros((2, 24001), np.float32), E.ENROLL_WAVE)
+    assert eng.info("n_launches") > n_fbank                    # + the kaldi fbank / CMN launches
+    out = eng.forward_pcm16(np.zeros(32000, np.int16), np.zeros(48000, np.int16), np.zeros(50001, np.int16))
+    assert out.shape == (2, 32000)
+    with pytest.raises(E.WesepHipError, match="does not fit"):
+        eng.separate(np.zeros((2, 16000), np.float32), np.zeros((2, 256), np.float32), E.ENROLL_EMBEDDING)
+    with pytest.raises(E.WesepHipError, match="shorter than one"):
+        eng.separate(np.zeros((2, 16000), np.float32), np.zeros((2, 300), np.float32), E.ENROLL_WAVE)
+    eng.close()
+
+
+def test_export_refuses_models_the_runtime_does_not_run():
+    from wesep_amd.models import get_model
+    with pytest.raises(NotImplementedError):
+        export_engine(_model(num_repeat=1, joint_training=True, spk_feat=False, spk_model="ResNet18",
+                             spk_args=SPK["spk_args"]), "/dev/null")
+    with pytest.raises(NotImplementedError):
+        export_engine(get_model("ConvTasNet")(N=32, L=20, B=32, H=64, P=3, X=2, R=1, joint_training=False), "/dev/null")
+
+
+def _write_wav(path, x, sr=16000):
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sr)
+        w.writeframes(np.asarray(x, dtype=np.int16).tobytes())
+
+
+@needs_no_gpu
+def test_separate_main_dry_run_and_argument_errors(tmp_path):
+    exe = os.path.join(ROOT, "runtime", "separate_main")
+    assert os.path.exists(exe), "run python -m wesep_amd.build"
+    model = str(tmp_path / "j.wsw")
+    export_engine(_model(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                         spk_model="ResNet18", **SPK), model)
+    rng = np.random.default_rng(0)
+    for name, n in (("mix", 24000), ("e1", 32000), ("e2", 40000)):
+        _write_wav(tmp_path / f"{name}.wav", rng.integers(-3000, 3000, n))
+    scp = tmp_path / "wav.scp"
+    scp.write_text(f"utt1 {tmp_path}/mix.wav {tmp_path}/e1.wav {tmp_path}/e2.wav\n"
+                   f"utt2 {tmp_path}/mix.wav {tmp_path}/e2.wav {tmp_path}/e1.wav\n")
+    r = subprocess.run([exe, "--wav_scp", str(scp), f"--model={model}", "--dry_run"], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("process: utt") == 2 and "[dry run]" in r.stdout and "RTF:" in r.stdout
+    assert "Total: process 3000ms audio" in r.stdout
+    # single-utterance flags of the reference tool
+    r = subprocess.run([exe, "--wav_path", f"{tmp_path}/mix.wav", "--spk1_emb", f"{tmp_path}/e1.wav", "--spk2_emb",
+                        f"{tmp_path}/e2.wav", "--model", model, "--dry_run"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "process: test" in r.stdout
+    # errors: missing model, bad scp line, wrong sample rate, missing output dir
+    assert subprocess.run([exe, "--wav_scp", str(scp)], capture_output=True).returncode == 1
+    bad = tmp_path / "bad.scp"
+    bad.write_text("utt1 only_two_fields\n")
+    r = subprocess.run([exe, "--wav_scp", str(bad), "--model", model, "--dry_run"], capture_output=True, text=True)
+    assert r.returncode == 1 and "4 fields" in r.stderr
+    _write_wav(tmp_path / "mix8k.wav", rng.integers(-3000, 3000, 8000), sr=8000)
+    r = subprocess.run([exe, "--wav_path", f"{tmp_path}/mix8k.wav", "--spk1_emb", f"{tmp_path}/e1.wav", "--spk2_emb",
+                        f"{tmp_path}/e2.wav", "--model", model, "--dry_run"], capture_output=True, text=True)
+    assert r.returncode == 1 and "sample rate" in r.stderr
+    r = subprocess.run([exe, "--wav_scp", str(scp), "--model", model], capture_output=True, text=True)
+    assert r.returncode == 1 and "Invalid output path" in r.stderr

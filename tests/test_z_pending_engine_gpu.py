@@ -1,0 +1,135 @@
+"""GPU: the native runtime (runtime/engine.cc behind include/wesep_engine.h) against the Python module tree on the
+same device (same kernels, weights packed once instead of per call -> agreement to rounding), against the CPU oracle,
+and the `separate_main` tool end to end."""
+import os
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bsrnn_oracle as O
+from wesep_amd import engine as E
+from wesep_amd.bin.export_engine import export_engine
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPK_ARGS = dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False)
+
+
+def _cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("kw,seed", [
+    (dict(num_repeat=2, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False), 11),
+    (dict(num_repeat=2, spk_fuse_type="FiLM", multi_fuse=True, use_spk_transform=False), 12),
+    (dict(num_repeat=1, spk_fuse_type="additive", multi_fuse=False, use_spk_transform=True), 13),
+    (dict(num_repeat=1, spk_fuse_type="concat", multi_fuse=True, use_spk_transform=False), 14)],
+    ids=["multiply", "FiLM", "additive_xform", "concat"])
+def test_engine_matches_python_model_and_oracle(tmp_path, kw, seed):
+    from wesep_amd.models import get_model
+    d = _cuda()
+    cfg = O.BSRNNConfig(**kw)
+    params = O.synth_params(cfg, seed)
+    model = get_model("BSRNN")(joint_training=False, **kw)
+    model.load_state_dict(params, strict=True)
+    path = str(tmp_path / "m.wsw")
+    export_engine(model, path)
+    eng = E.Engine(path)
+    model = model.to(d).eval()
+    first = None
+    for R, T in ((2, 16000), (3, 12345), (1, 4096), (2, 16000)):          # ragged, odd rows, repeat of the first geometry
+        wav, _, emb = O.synth_batch(2 * ((R + 1) // 2), T, seed + T)
+        wav, emb = wav[:R].contiguous(), emb[:R].contiguous()
+        est = eng.separate(wav.numpy(), emb.numpy(), E.ENROLL_EMBEDDING)
+        with torch.no_grad():
+            ref = model(wav.to(d), emb.to(d))[0]
+        assert rel(est, ref) < 1e-4, (R, T)
+        if T <= 12345:
+            assert rel(est, O.bsrnn_forward(params, cfg, wav, emb)) < 1e-3, (R, T)
+        if first is None:
+            first = est
+    assert eng.info("n_launches") > 0 and eng.info("arena_bytes") > 0
+    eng.close()
+
+
+def _joint(tmp_path, spk_model, d, seed=5):
+    from wesep_amd.models import get_model
+    torch.manual_seed(seed)
+    model = get_model("BSRNN")(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                               joint_training=True, spk_model=spk_model, spk_feat=True, spk_args=SPK_ARGS)
+    with torch.no_grad():                                   # non-trivial BatchNorm running statistics
+        for name, buf in model.named_buffers():
+            if name.endswith("running_mean"):
+                buf.normal_(0.0, 0.2)
+            elif name.endswith("running_var"):
+                buf.uniform_(0.5, 1.5)
+    path = str(tmp_path / "j.wsw")
+    export_engine(model, path)
+    return model.to(d).eval(), E.Engine(path)
+
+
+@pytest.mark.parametrize("spk_model", ["ResNet18", "ResNet34"])
+def test_engine_joint_model_fbank_and_waveform_enrollment(tmp_path, spk_model):
+    from wesep_amd.utils.funcs import apply_cmvn, compute_fbank
+    d = _cuda()
+    model, eng = _joint(tmp_path, spk_model, d)
+    g = torch.Generator().manual_seed(3)
+    wav = 0.1 * torch.randn(2, 20000, generator=g)
+    fbank = torch.randn(2, 120, 80, generator=g)
+    fbank = fbank - fbank.mean(1, keepdim=True)
+    with torch.no_grad():
+        ref = model(wav.to(d), fbank.to(d))[0]
+    assert rel(eng.separate(wav.numpy(), fbank.numpy(), E.ENROLL_FBANK), ref) < 1e-4
+    enroll = 0.1 * torch.randn(2, 30001, generator=g)       # length not a multiple of 4: scalar-load GEMM path
+    with torch.no_grad():
+        fb = apply_cmvn(compute_fbank(enroll.to(d), dither=0.0))
+        ref = model(wav.to(d), fb)[0]
+    est = eng.separate(wav.numpy(), enroll.numpy(), E.ENROLL_WAVE)
+    assert rel(est, ref) < 1e-4
+    # the reference runtime's call: int16 in, one mixture, two enrollments cut to the shorter one
+    mix16 = (wav[0] * 32768).round().clamp(-32768, 32767).to(torch.int16)
+    e16 = (enroll * 32768).round().clamp(-32768, 32767).to(torch.int16)
+    out = eng.forward_pcm16(mix16.numpy(), e16[0].numpy(), e16[1, :29000].numpy())
+    m = (mix16.float() / 32768).repeat(2, 1)
+    en = (e16[:, :29000].float() / 32768).contiguous()
+    assert rel(out, eng.separate(m.numpy(), en.numpy(), E.ENROLL_WAVE)) < 1e-6
+    eng.close()
+
+
+def test_separate_main_end_to_end(tmp_path):
+    d = _cuda()
+    model, eng = _joint(tmp_path, "ResNet18", d)
+    rng = np.random.default_rng(1)
+    sig = {"mix": rng.integers(-4000, 4000, 24000), "e1": rng.integers(-4000, 4000, 32000),
+           "e2": rng.integers(-4000, 4000, 36000)}
+    for name, x in sig.items():
+        with wave.open(str(tmp_path / f"{name}.wav"), "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(x.astype(np.int16).tobytes())
+    (tmp_path / "wav.scp").write_text(f"utt1 {tmp_path}/mix.wav {tmp_path}/e1.wav {tmp_path}/e2.wav\n")
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    r = subprocess.run([os.path.join(ROOT, "runtime", "separate_main"), "--wav_scp", str(tmp_path / "wav.scp"),
+                        "--model", str(tmp_path / "j.wsw"), "--output_dir", str(out_dir)], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "process: utt1 RTF:" in r.stdout and "Total: process 1500ms audio" in r.stdout
+    want = eng.forward_pcm16(sig["mix"].astype(np.int16), sig["e1"].astype(np.int16), sig["e2"].astype(np.int16))
+    for i, name in enumerate(("utt1-spk1.wav", "utt1-spk2.wav")):
+        with wave.open(str(out_dir / name), "rb") as w:
+            assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getnframes() == 24000
+            got = np.frombuffer(w.readframes(24000), dtype=np.int16).astype(np.float32)
+        assert np.abs(got - np.clip(np.round(want[i] * 32768), -32768, 32767)).max() <= 1.0
+    eng.close()

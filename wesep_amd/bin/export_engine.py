@@ -1,0 +1,104 @@
+"""Write a pBSRNN checkpoint as the flat weight container of the native runtime (include/wesep_engine.h,
+runtime/engine.cc) -- the counterpart of the reference's `wesep/bin/export_jit.py` (TorchScript archive for the
+LibTorch runtime).
+
+    python -m wesep_amd.bin.export_engine --config conf.yaml --checkpoint avg_model.pt --out model.wsw
+
+Container layout (little endian):
+    char magic[8] = "WSEPW001"
+    u32 n_meta;    n_meta    x { char key[32]; i64 value }
+    u32 n_tensors; n_tensors x { u32 name_len; char name[]; u32 ndim; i64 dims[ndim]; u64 offset_floats }
+    u64 n_floats;  float32 data[n_floats]
+Tensor names are the reference's `state_dict` keys, so any wesep BSRNN checkpoint exports unchanged."""
+import argparse
+import struct
+
+import numpy as np
+import torch
+
+FUSE = {"concat": 0, "additive": 1, "multiply": 2, "FiLM": 3}
+SKIP_PREFIXES = ("pred_linear.", "preEmphasis.", "spk_encoder.")
+
+
+def engine_meta(model):
+    sep = model.separator
+    fuse_layer = next(m for m in sep.separation if hasattr(m, "fuse_type"))
+    meta = {
+        "sample_rate": model.sr, "win": model.win, "stride": model.stride, "feature_dim": model.feature_dim,
+        "num_repeat": sum(1 for m in sep.separation if not hasattr(m, "fuse_type")),
+        "spk_emb_dim": model.spk_emb_dim, "spk_fuse_type": FUSE[fuse_layer.fuse_type],
+        "multi_fuse": int(sep.multi_fuse), "use_spk_transform": int(not isinstance(model.spk_transform, torch.nn.Identity)),
+        "joint_training": int(model.joint_training), "feat_dim": 80,
+    }
+    if model.joint_training:
+        if not model.spk_feat:
+            raise NotImplementedError("export_engine: joint models with spk_feat=False (in-model MelSpectrogram "
+                                      "front-end) are not built in the native runtime; it computes the kaldi fbank of "
+                                      "spk_feat=True models")
+        spk = model.spk_model
+        for i, layer in enumerate((spk.layer1, spk.layer2, spk.layer3, spk.layer4)):
+            meta[f"spk_blocks{i}"] = len(layer)
+        meta["feat_dim"] = int(spk.seg_1.weight.shape[1] // (2 * 32 * 8)) * 8
+    return meta
+
+
+def write_container(path, meta, state):
+    names, blobs, off = [], [], 0
+    for k, v in state.items():
+        if k.startswith(SKIP_PREFIXES) or k.endswith("num_batches_tracked") or not torch.is_floating_point(v):
+            continue
+        a = np.ascontiguousarray(v.detach().cpu().float().numpy())
+        names.append((k, a.shape, off))
+        blobs.append(a.reshape(-1))
+        off += -(-a.size // 4) * 4                      # every tensor starts on a 16-byte boundary
+    data = np.zeros(off, dtype=np.float32)
+    for (k, shape, o), b in zip(names, blobs):
+        data[o:o + b.size] = b
+    with open(path, "wb") as f:
+        f.write(b"WSEPW001")
+        f.write(struct.pack("<I", len(meta)))
+        for k, v in meta.items():
+            key = k.encode()
+            assert len(key) < 32, k
+            f.write(key.ljust(32, b"\0"))
+            f.write(struct.pack("<q", int(v)))
+        f.write(struct.pack("<I", len(names)))
+        for k, shape, o in names:
+            kb = k.encode()
+            f.write(struct.pack("<I", len(kb)))
+            f.write(kb)
+            f.write(struct.pack("<I", len(shape)))
+            for d in shape:
+                f.write(struct.pack("<q", int(d)))
+            f.write(struct.pack("<Q", o))
+        f.write(struct.pack("<Q", data.size))
+        f.write(data.tobytes())
+    return len(names), data.size
+
+
+def export_engine(model, path):
+    """model: a wesep_amd (or reference) `BSRNN` instance -> container at `path`; returns (n_tensors, n_floats)."""
+    if type(model).__name__ not in ("BSRNN", "BSRNN_Multi"):
+        raise NotImplementedError("export_engine: the native runtime runs pBSRNN (BSRNN / BSRNN_Multi checkpoints)")
+    return write_container(path, engine_meta(model), model.state_dict())
+
+
+def main():
+    import yaml
+    from ..models import get_model
+    ap = argparse.ArgumentParser(description="export a pBSRNN checkpoint for the native MI355X runtime")
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--checkpoint", required=True)
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+    with open(args.config) as f:
+        conf = yaml.safe_load(f)
+    model = get_model(conf["model"]["tse_model"])(**conf["model_args"]["tse_model"])
+    states = torch.load(args.checkpoint, map_location="cpu")
+    model.load_state_dict(states["models"][0] if "models" in states else states)
+    n, nf = export_engine(model, args.out)
+    print(f"{args.out}: {n} tensors, {nf * 4 / 2 ** 20:.1f} MiB")
+
+
+if __name__ == "__main__":
+    main()

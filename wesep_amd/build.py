@@ -48,6 +48,34 @@ def build(force=False, verbose=True):
     return OUT
 
 
+RUNTIME = os.path.join(os.path.dirname(HERE), "runtime")
+ENGINE_OUT = os.path.join(RUNTIME, "libwesep_engine.so")
+MAIN_OUT = os.path.join(RUNTIME, "separate_main")
+
+
+def build_runtime(force=False, verbose=True):
+    """libwesep_engine.so (native inference runtime over the C ABI, include/wesep_engine.h) and the `separate_main`
+    command-line tool.  Host code only; links libwesep_hip.so (built first)."""
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    deps = [os.path.join(RUNTIME, f) for f in ("engine.cc", "wav_io.h", "separate_main.cc")] + \
+        [os.path.join(inc, "wesep_engine.h"), os.path.join(inc, "wesep_hip.h"), OUT]
+    cmds = []
+    if force or _stale(ENGINE_OUT, deps):
+        cmds.append([hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", os.path.join(RUNTIME, "engine.cc"), "-o",
+                     ENGINE_OUT, "-L" + HERE, "-lwesep_hip", "-Wl,-rpath,$ORIGIN/../wesep_amd"])
+    if force or _stale(MAIN_OUT, deps + [ENGINE_OUT]) or cmds:
+        cmds.append([hipcc, "-O2", "-std=c++17", os.path.join(RUNTIME, "separate_main.cc"), "-o", MAIN_OUT,
+                     "-L" + RUNTIME, "-lwesep_engine", "-L" + HERE, "-lwesep_hip", "-Wl,-rpath,$ORIGIN",
+                     "-Wl,-rpath,$ORIGIN/../wesep_amd"])
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return ENGINE_OUT
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
-    print("built", OUT)
+    build_runtime(force="--force" in sys.argv)
+    print("built", OUT, ENGINE_OUT, MAIN_OUT)
