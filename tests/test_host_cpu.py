@@ -241,3 +241,34 @@ def test_device_prefetcher_passthrough_on_cpu():
         assert b["wav_mix"].dtype == torch.float32 and float(b["wav_mix"][0, 0]) == float(i)
         assert b["spk_label"].dtype == torch.int64 and b["key"] == [f"u{i}"]
     assert list(DevicePrefetcher([], "cpu")) == []
+
+
+def test_average_model_tool(tmp_path):
+    """wesep/bin/average_model.py semantics: last --num numbered checkpoints, true division, {"models": [sd]} out;
+    full checkpoints and bare state dicts both accepted; averaged / final / latest files are left out."""
+    import subprocess
+    import sys
+    from wesep_amd.bin.average_model import average_checkpoints, select_checkpoints
+    sds = []
+    for e in (3, 9, 10, 11):
+        sd = {"w": torch.full((2, 3), float(e)), "bn.num_batches_tracked": torch.tensor(e)}
+        sds.append(sd)
+        torch.save({"models": [sd], "optimizers": [], "schedulers": []} if e != 10 else sd,
+                   tmp_path / f"checkpoint_{e}.pt")
+    for name in ("avg_model.pt", "final_model.pt", "latest.pt", "checkpoint_avg.pt"):
+        torch.save({"models": [sds[0]]}, tmp_path / name)
+    picked = select_checkpoints(str(tmp_path), num=2)
+    assert [os.path.basename(p) for p in picked] == ["checkpoint_10.pt", "checkpoint_11.pt"]
+    assert [os.path.basename(p) for p in select_checkpoints(str(tmp_path), num=5, max_epoch=9)] == \
+        ["checkpoint_3.pt", "checkpoint_9.pt"]
+    avg = average_checkpoints(picked)
+    assert torch.equal(avg["w"], torch.full((2, 3), 10.5)) and float(avg["bn.num_batches_tracked"]) == 10.5
+    dst = tmp_path / "out.pt"
+    r = subprocess.run([sys.executable, "-m", "wesep_amd.bin.average_model", "--dst_model", str(dst), "--src_path",
+                        str(tmp_path), "--mode", "epochs", "--epochs", "3,9"], capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr
+    out = torch.load(dst)
+    assert list(out.keys()) == ["models"] and torch.equal(out["models"][0]["w"], torch.full((2, 3), 6.0))
+    with pytest.raises(ValueError):
+        average_checkpoints([])
