@@ -13,7 +13,15 @@ from oracle import fbank_oracle as FB
 from oracle.make_golden import FBANK_CASES, synth_fbank_wave
 
 pytestmark = pytest.mark.gpu
-REF_ATOL = 3e-4
+
+
+def _close(got, want, max_tol=2e-3, mean_tol=3e-5):
+    """Log-mel energies: the mean error is what a defect moves (CPU fp32 restatement: 5e-7 .. 5e-6 against float64 /
+    the C++ reference); the maximum has a heavy tail from the lowest filters, which span one or two FFT bins -- a
+    spectral null there turns fp32 summation-order differences into 1e-4-sized log errors (measured 1.4e-4 over 1 M
+    values with the CPU emulation), so it gets a loose bound only."""
+    err = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64))
+    assert err.mean() < mean_tol and err.max() < max_tol, (err.mean(), err.max())
 
 
 def _cuda():
@@ -30,8 +38,8 @@ def test_fbank_matches_reference_cpp_fixture(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     wav = torch.from_numpy(synth_fbank_wave(R, T, sr, seed)).to(d)
     feats = compute_fbank(wav, num_mel_bins=nb, dither=0.0, sample_rate=sr)
-    assert np.abs(feats.cpu().numpy() - g["fbank"]).max() < REF_ATOL
-    assert np.abs(apply_cmvn(feats).cpu().numpy() - g["fbank_cmn"]).max() < REF_ATOL
+    _close(feats.cpu().numpy(), g["fbank"])
+    _close(apply_cmvn(feats).cpu().numpy(), g["fbank_cmn"])
 
 
 def test_fbank_full_size_and_ragged_lengths():
@@ -44,7 +52,7 @@ def test_fbank_full_size_and_ragged_lengths():
         got = apply_cmvn(compute_fbank(torch.from_numpy(wav).to(d), dither=0.0)).cpu().numpy()
         want = FB.apply_cmvn(FB.compute_fbank(wav, dither=0.0))
         assert got.shape == want.shape == (R, 1 + (T - 400) // 160, 80)
-        assert np.abs(got - want).max() < REF_ATOL
+        _close(got, want)
     sil = compute_fbank(torch.zeros(1, 800, device=d), dither=0.0)
     assert torch.allclose(sil, torch.full_like(sil, float(np.log(FB.FLT_EPS))))
 
@@ -88,7 +96,7 @@ def test_executor_ssa_step_on_joint_model():
         fb = apply_cmvn(compute_fbank(est0, **args, sample_rate=16000))
     assert tuple(fb.shape) == (2, 98, 80)
     want = FB.apply_cmvn(FB.compute_fbank(est0.cpu().numpy(), dither=0.0))
-    assert np.abs(fb.cpu().numpy() - want).max() < REF_ATOL
+    _close(fb.cpu().numpy(), want)
     loss_manual = float(crit[0](model(wav.to(d), fb)[0], tgt.to(d)).mean())
     # executor (BatchNorm running statistics were advanced by the passes above: restore)
     model.load_state_dict(state)
