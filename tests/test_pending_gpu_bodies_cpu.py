@@ -1,0 +1,40 @@
+"""CPU: the bodies of the GPU tests that have not run on hardware yet (tests/test_z_pending_*_gpu.py), executed on
+the CPU emulations (tests/emu_dev.py entry points, tests/emu_bsrnn.py pBSRNN functions) with `cuda:0` replaced by the
+CPU.  This checks the tests themselves -- shapes, fixture keys, tolerances against emulated fp32 numerics, the manual
+two-pass compositions they compare with -- so that their first run on a GPU tests the kernels and not the test code.
+(The native-runtime GPU tests drive a C++ library and have no emulation; their plan is covered by
+tests/test_engine_cpu.py.)"""
+import pytest
+import torch
+
+from tests import emu_bsrnn, emu_dev
+
+if torch.cuda.is_available():
+    pytest.skip("CPU rehearsal of GPU tests: pointless where the real ones run", allow_module_level=True)
+
+
+@pytest.fixture
+def emu(monkeypatch):
+    import wesep_amd.utils.executor as ex
+    emu_dev.install(monkeypatch)
+    emu_bsrnn.install(monkeypatch)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(ex, "clip_gradients", lambda model, clip: None)      # the HIP clip is not under test
+
+
+def test_fbank_gpu_test_bodies(emu, monkeypatch, golden_dir):
+    import tests.test_z_pending_fbank_gpu as t
+    monkeypatch.setattr(t, "_cuda", lambda: torch.device("cpu"))
+    for name in sorted(t.FBANK_CASES):
+        t.test_fbank_matches_reference_cpp_fixture(name, golden_dir)
+    t.test_fbank_full_size_and_ragged_lengths()
+    t.test_fbank_dither_statistics()
+    t.test_executor_ssa_step_on_joint_model()
+
+
+def test_bsrnn_multi_gpu_test_bodies(emu, monkeypatch, golden_dir):
+    import tests.test_z_pending_bsrnn_multi_gpu as t
+    monkeypatch.setattr(t, "_cuda", lambda: torch.device("cpu"))
+    for name in sorted(t.MULTI_CASES):
+        t.test_bsrnn_multi_two_pass_forward_and_gradients(name, golden_dir)
