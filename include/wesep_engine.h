@@ -51,8 +51,10 @@ long long ws_engine_info(const ws_engine* e, const char* key);
 /* enrollment kinds */
 #define WS_ENROLL_EMBEDDING 0 /* float [R][spk_emb_dim]: fixed speaker embeddings (joint_training = False models) */
 #define WS_ENROLL_FBANK 1     /* float [R][enroll_len][feat_dim]: mean-normalised fbank (joint models, spk_feat True) */
-#define WS_ENROLL_WAVE 2      /* float [R][enroll_len] in [-1, 1]: kaldi fbank (dither 0) + CMN computed on the device
-                                 (what SeparateEngine::ExtractFeature does on the host, separate_engine.cc:53-74) */
+#define WS_ENROLL_WAVE 2      /* float [R][enroll_len] in [-1, 1].  spk_feat = True models: kaldi fbank (dither 0) + CMN
+                                 computed on the device (what SeparateEngine::ExtractFeature does on the host,
+                                 separate_engine.cc:53-74); spk_feat = False models: their in-model PreEmphasis +
+                                 MelSpectrogram + log + CMN front-end (bsrnn.py:343-350) */
 
 /* est[r][0..T) = target-speaker estimate for mix[r][0..T) given enrollment r.  All pointers are HOST pointers.
  * Replaces `model(features, enroll)[0]` of infer.py:101-103 (whole utterance, any T >= 512; no chunking). */

@@ -180,6 +180,10 @@ struct ws_engine {
   float *slope0 = nullptr, *slope1 = nullptr;     // PReLU slopes 0 (ReLU) and 1 (identity)
   float *fb_basis = nullptr, *fb_bank = nullptr, *fb_floor = nullptr;
   int fb_win = 400, fb_shift = 160, fb_padded = 512;
+  // in-model front-end of spk_feat = False models (bsrnn.py:231-242,343-350): PreEmphasis + MelSpectrogram
+  int spk_feat = 1;
+  float *mel_basis = nullptr, *mel_fbt = nullptr, mel_coef = 0.97f;
+  int mel_lds = 516, mel_ldp = 260;
   // grouped-GEMM descriptor tables, rebuilt when (R, Tf) changes
   int desc_R = -1, desc_Tf = -1;
   ws_group_nt *d_bn = nullptr, *d_l1 = nullptr, *d_l2 = nullptr, *d_l3 = nullptr;
@@ -522,8 +526,37 @@ int prep_fbank(ws_engine* e) {
   return WS_OK;
 }
 
+// PreEmphasis (speaker.py:10-23) + torchaudio MelSpectrogram(n_fft = win_length = 512, hop 128, hamming window buffer,
+// HTK filterbank buffer) of spk_feat = False models, as in modules/common/frontend.py: windowed DFT basis
+// [2 * 257 (padded to 516)][512] and fb^T [n_mels][257 (padded to 260)] built from the model's own buffers
+int prep_mel_frontend(ws_engine* e) {
+  const int n = 512, nf = n / 2 + 1, nm = e->feat_dim;
+  if (!require(e, "spk_encoder.spectrogram.window", {n}) || !require(e, "spk_encoder.mel_scale.fb", {nf, nm}) ||
+      !require(e, "preEmphasis.flipped_filter", {2}))
+    return WS_ERR_INVALID;
+  const float* win = e->host("spk_encoder.spectrogram.window");
+  const float* fb = e->host("spk_encoder.mel_scale.fb");
+  e->mel_coef = -e->host("preEmphasis.flipped_filter")[0];
+  e->mel_lds = (2 * nf + 3) / 4 * 4;
+  e->mel_ldp = (nf + 3) / 4 * 4;
+  std::vector<float> basis(size_t(e->mel_lds) * n, 0.f), fbt(size_t(nm) * e->mel_ldp, 0.f);
+  for (int k = 0; k < nf; ++k)
+    for (int j = 0; j < n; ++j) {
+      const double ang = 2.0 * M_PI * double(k) * j / n;
+      basis[(size_t(2) * k) * n + j] = static_cast<float>(cos(ang) * win[j]);
+      basis[(size_t(2) * k + 1) * n + j] = static_cast<float>(-sin(ang) * win[j]);
+    }
+  for (int m = 0; m < nm; ++m)
+    for (int k = 0; k < nf; ++k) fbt[size_t(m) * e->mel_ldp + k] = fb[size_t(k) * nm + m];
+  e->mel_basis = upload(e, e->persist, basis.data(), basis.size());
+  e->mel_fbt = upload(e, e->persist, fbt.data(), fbt.size());
+  WS_PTR(e->mel_basis && e->mel_fbt);
+  return WS_OK;
+}
+
 int prepare(ws_engine* e) {
   e->sr = static_cast<int>(meta_or(e, "sample_rate", 16000));
+  e->spk_feat = static_cast<int>(meta_or(e, "spk_feat", 1));
   e->num_repeat = static_cast<int>(meta_or(e, "num_repeat", 6));
   e->E = static_cast<int>(meta_or(e, "spk_emb_dim", 256));
   e->fuse = static_cast<int>(meta_or(e, "spk_fuse_type", 2));
@@ -609,7 +642,7 @@ int prepare(ws_engine* e) {
   }
   if (e->joint) {
     if ((rc = prep_resnet(e)) != WS_OK) return rc;
-    if ((rc = prep_fbank(e)) != WS_OK) return rc;
+    if ((rc = e->spk_feat ? prep_fbank(e) : prep_mel_frontend(e)) != WS_OK) return rc;
   }
   if (!e->dry && hipStreamSynchronize(e->stream) != hipSuccess) {
     set_err("engine: weight preparation failed on the device");
@@ -877,6 +910,28 @@ int resnet_embed(ws_engine* e, const float* fbank, int R, int Te, float* emb) {
   return rc;
 }
 
+// per-row CMN over the frames: feats [R][Te][nb] -= mean_t          (shared by both front-ends)
+int subtract_time_mean(ws_engine* e, float* feats, int R, int Te, int nb) {
+  const long long M = (long long)R * Te;
+  void* s = e->stream;
+  Arena& a = e->work;
+  int nsplit = Te / 32;
+  const int cap = 1024 / R > 1 ? 1024 / R : 1;
+  if (nsplit > cap) nsplit = cap;
+  if (nsplit < 1) nsplit = 1;
+  float* slab = a.alloc(size_t(nsplit) * R * 2 * nb);
+  float* sums = a.alloc(size_t(R) * 2 * nb);
+  float* neg_mean = a.alloc(size_t(R) * nb);
+  WS_PTR(slab && sums && neg_mean);
+  WS_RUN(e, ws_chan_sums(feats, nullptr, nullptr, 1, Te, R, nsplit, nb, slab, s));
+  WS_RUN(e, ws_reduce_slabs(slab, nsplit, (long long)R * 2 * nb, (long long)R * 2 * nb, sums, 0, 0, s));
+  // rows of `sums` are [2][nb] per utterance: scale the first half of each by -1/Te into a dense [R][nb]
+  for (int r = 0; r < R; ++r)
+    WS_RUN(e, ws_affine_fwd(sums + size_t(r) * 2 * nb, nullptr, nullptr, -1.0f / Te, 1, 1, nb, neg_mean + size_t(r) * nb, s));
+  WS_RUN(e, ws_affine_fwd(feats, nullptr, neg_mean, 1.0f, M, Te, nb, feats, s));
+  return WS_OK;
+}
+
 // waveform [R][Tw] in [-1, 1] (device) -> mean-normalised kaldi fbank [R][Te][F]  (utils/funcs.py compute_fbank +
 // apply_cmvn with dither 0; reference: SeparateEngine::ExtractFeature, separate_engine.cc:53-74)
 int kaldi_fbank(ws_engine* e, const float* wav, int R, int Tw, float* feats, int Te) {
@@ -905,21 +960,44 @@ int kaldi_fbank(ws_engine* e, const float* wav, int R, int Tw, float* feats, int
   // log(max(x, eps)) = log(relu(x - eps) + eps)
   WS_RUN(e, ws_prelu_fwd(mel, e->fb_floor, e->slope0, M, nb, static_cast<int>(M), feats, s));
   WS_RUN(e, ws_log_eps(feats, M * nb, kGnEps, s));
-  // CMN: minus the mean over the frames of each row
-  int nsplit = Te / 32;
-  const int cap = 1024 / R > 1 ? 1024 / R : 1;
-  if (nsplit > cap) nsplit = cap;
-  if (nsplit < 1) nsplit = 1;
-  float* slab = a.alloc(size_t(nsplit) * R * 2 * nb);
-  float* sums = a.alloc(size_t(R) * 2 * nb);
-  float* neg_mean = a.alloc(size_t(R) * nb);
-  WS_PTR(slab && sums && neg_mean);
-  WS_RUN(e, ws_chan_sums(feats, nullptr, nullptr, 1, Te, R, nsplit, nb, slab, s));
-  WS_RUN(e, ws_reduce_slabs(slab, nsplit, (long long)R * 2 * nb, (long long)R * 2 * nb, sums, 0, 0, s));
-  // rows of `sums` are [2][nb] per utterance: scale the first half of each by -1/Te into a dense [R][nb]
-  for (int r = 0; r < R; ++r)
-    WS_RUN(e, ws_affine_fwd(sums + size_t(r) * 2 * nb, nullptr, nullptr, -1.0f / Te, 1, 1, nb, neg_mean + size_t(r) * nb, s));
-  WS_RUN(e, ws_affine_fwd(feats, nullptr, neg_mean, 1.0f, M, Te, nb, feats, s));
+  {
+    const int rc = subtract_time_mean(e, feats, R, Te, nb);
+    if (rc != WS_OK) return rc;
+  }
+  a.release(mk);
+  return WS_OK;
+}
+
+// waveform [R][Tw] (device) -> log-mel features [R][Te][F], mean-normalised over time: the in-model front-end of
+// spk_feat = False models (bsrnn.py:343-350; modules/common/frontend.py fbank_frontend); Te = 1 + Tw / 128
+int mel_frontend(ws_engine* e, const float* wav, int R, int Tw, float* feats, int Te) {
+  const int n = 512, hop = kHop, pad = n / 2, nf = n / 2 + 1, nm = e->feat_dim;
+  const int ldo = (Tw + 2 * pad + 3) / 4 * 4;
+  const long long M = (long long)R * Te;
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  float* xp = a.alloc(size_t(R) * ldo);
+  float* spec = a.alloc(size_t(M) * e->mel_lds);
+  float* power = a.alloc(size_t(M) * e->mel_ldp);
+  WS_PTR(xp && spec && power);
+  int rc = zero_device(e, xp, size_t(R) * ldo * 4);
+  if (rc != WS_OK) return rc;
+  WS_RUN(e, ws_preemph_pad(wav, R, Tw, pad, ldo, e->mel_coef, xp, s));
+  ws_gemm_nt_args g = {};
+  g.A = xp, g.W = e->mel_basis, g.C = spec;
+  g.a_div = Te, g.a_s1 = ldo, g.a_s2 = hop;             // centred frames as an overlapping row view
+  g.c_div = kBig, g.c_s2 = e->mel_lds, g.st_div1 = 1, g.st_div2 = 1;
+  g.M = static_cast<int>(M), g.N = e->mel_lds, g.K = n, g.ldw = n, g.vec = 3;       // exact-fp32 products
+  WS_RUN(e, ws_gemm_nt(&g, s));
+  WS_RUN(e, ws_power_spec(spec, M, nf, e->mel_lds, e->mel_ldp, power, s));
+  ws_gemm_nt_args h = {};
+  h.A = power, h.W = e->mel_fbt, h.C = feats;
+  h.a_div = kBig, h.a_s2 = e->mel_ldp, h.c_div = kBig, h.c_s2 = nm, h.st_div1 = 1, h.st_div2 = 1;
+  h.M = static_cast<int>(M), h.N = nm, h.K = e->mel_ldp, h.ldw = e->mel_ldp, h.vec = 3;
+  WS_RUN(e, ws_gemm_nt(&h, s));
+  WS_RUN(e, ws_log_eps(feats, M * nm, 1e-8f, s));
+  if ((rc = subtract_time_mean(e, feats, R, Te, nm)) != WS_OK) return rc;
   a.release(mk);
   return WS_OK;
 }
@@ -1115,12 +1193,21 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
     return WS_ERR_INVALID;
   }
   int Te = enroll_len;
-  if (enroll_kind == WS_ENROLL_WAVE) {
+  if (enroll_kind == WS_ENROLL_WAVE && e->spk_feat) {          // kaldi fbank, snip-edges framing
     if (enroll_len < e->fb_win) {
       set_err("ws_engine_separate: enrollment shorter than one %d-sample frame", e->fb_win);
       return WS_ERR_INVALID;
     }
     Te = 1 + (enroll_len - e->fb_win) / e->fb_shift;
+  } else if (enroll_kind == WS_ENROLL_WAVE) {                  // in-model MelSpectrogram, centred framing
+    if (enroll_len <= 256) {
+      set_err("ws_engine_separate: enrollment must be longer than the 256-sample reflect padding");
+      return WS_ERR_INVALID;
+    }
+    Te = 1 + enroll_len / kHop;
+  } else if (enroll_kind == WS_ENROLL_FBANK && !e->spk_feat) {
+    set_err("ws_engine_separate: this model computes its own features (spk_feat = False): pass the waveform");
+    return WS_ERR_INVALID;
   }
   if (enroll_kind != WS_ENROLL_EMBEDDING && Te < 8) {
     set_err("ws_engine_separate: enrollment of %d frames is too short for the speaker encoder", Te);
@@ -1150,7 +1237,8 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
       float* d_wave = a.alloc(size_t(R) * enroll_len);
       WS_PTR(d_wave);
       if ((rc = to_device(e, d_wave, enroll, size_t(R) * enroll_len * 4)) != WS_OK) return rc;
-      if ((rc = kaldi_fbank(e, d_wave, R, enroll_len, fb, Te)) != WS_OK) return rc;
+      if ((rc = e->spk_feat ? kaldi_fbank(e, d_wave, R, enroll_len, fb, Te) : mel_frontend(e, d_wave, R, enroll_len, fb, Te)) != WS_OK)
+        return rc;
     }
     if ((rc = resnet_embed(e, fb, R, Te, d_emb)) != WS_OK) return rc;
     a.release(mk);

@@ -130,11 +130,29 @@ def test_dry_run_launch_plan_joint_model(tmp_path, spk_model):
     eng.close()
 
 
+@needs_no_gpu
+def test_dry_run_raw_audio_joint_model(tmp_path):
+    """spk_feat = False (bsrnn_multi_optim.yaml): the in-model PreEmphasis + MelSpectrogram front-end runs in the
+    engine from the model's own window / filterbank buffers; a `BSRNN_Multi` checkpoint exports like a `BSRNN`."""
+    from wesep_amd.models import get_model
+    path = str(tmp_path / "m.wsw")
+    model = get_model("BSRNN_Multi")(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                                     joint_training=True, spk_feat=False, spk_model="ResNet18",
+                                     spk_args=SPK["spk_args"])
+    export_engine(model, path)
+    eng = E.Engine(path, dry_run=True)
+    assert eng.info("spk_feat") == 0 and eng.info("joint_training") == 1
+    for Tw in (16000, 12345, 1100):
+        eng.separate(np.zeros((2, 8000), np.float32), np.zeros((2, Tw), np.float32), E.ENROLL_WAVE)
+    with pytest.raises(E.WesepHipError, match="computes its own features"):
+        eng.separate(np.zeros((2, 8000), np.float32), np.zeros((2, 98, 80), np.float32), E.ENROLL_FBANK)
+    with pytest.raises(E.WesepHipError, match="reflect padding"):
+        eng.separate(np.zeros((2, 8000), np.float32), np.zeros((2, 256), np.float32), E.ENROLL_WAVE)
+    eng.close()
+
+
 def test_export_refuses_models_the_runtime_does_not_run():
     from wesep_amd.models import get_model
-    with pytest.raises(NotImplementedError):
-        export_engine(_model(num_repeat=1, joint_training=True, spk_feat=False, spk_model="ResNet18",
-                             spk_args=SPK["spk_args"]), "/dev/null")
     with pytest.raises(NotImplementedError):
         export_engine(get_model("ConvTasNet")(N=32, L=20, B=32, H=64, P=3, X=2, R=1, joint_training=False), "/dev/null")
 

@@ -106,6 +106,27 @@ def test_engine_joint_model_fbank_and_waveform_enrollment(tmp_path, spk_model):
     eng.close()
 
 
+def test_engine_raw_audio_joint_model(tmp_path):
+    """spk_feat = False: the engine's in-model front-end (PreEmphasis + MelSpectrogram + log + CMN) vs the Python one."""
+    from wesep_amd.models import get_model
+    d = _cuda()
+    torch.manual_seed(7)
+    model = get_model("BSRNN")(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                               joint_training=True, spk_model="ResNet18", spk_feat=False, spk_args=SPK_ARGS)
+    path = str(tmp_path / "r.wsw")
+    export_engine(model, path)
+    eng = E.Engine(path)
+    model = model.to(d).eval()
+    g = torch.Generator().manual_seed(8)
+    wav = 0.1 * torch.randn(2, 12000, generator=g)
+    for Tw in (16000, 12345):
+        enroll = 0.1 * torch.randn(2, Tw, generator=g)
+        with torch.no_grad():
+            ref = model(wav.to(d), enroll.to(d))[0]
+        assert rel(eng.separate(wav.numpy(), enroll.numpy(), E.ENROLL_WAVE), ref) < 1e-4, Tw
+    eng.close()
+
+
 def test_separate_main_end_to_end(tmp_path):
     d = _cuda()
     model, eng = _joint(tmp_path, "ResNet18", d)

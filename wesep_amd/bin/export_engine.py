@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 FUSE = {"concat": 0, "additive": 1, "multiply": 2, "FiLM": 3}
-SKIP_PREFIXES = ("pred_linear.", "preEmphasis.", "spk_encoder.")
+SKIP_PREFIXES = ("pred_linear.",)
 
 
 def engine_meta(model):
@@ -28,13 +28,10 @@ def engine_meta(model):
         "num_repeat": sum(1 for m in sep.separation if not hasattr(m, "fuse_type")),
         "spk_emb_dim": model.spk_emb_dim, "spk_fuse_type": FUSE[fuse_layer.fuse_type],
         "multi_fuse": int(sep.multi_fuse), "use_spk_transform": int(not isinstance(model.spk_transform, torch.nn.Identity)),
-        "joint_training": int(model.joint_training), "feat_dim": 80,
+        "joint_training": int(model.joint_training), "feat_dim": 80, "spk_feat": 1,
     }
     if model.joint_training:
-        if not model.spk_feat:
-            raise NotImplementedError("export_engine: joint models with spk_feat=False (in-model MelSpectrogram "
-                                      "front-end) are not built in the native runtime; it computes the kaldi fbank of "
-                                      "spk_feat=True models")
+        meta["spk_feat"] = int(bool(model.spk_feat))      # False: the in-model front-end's buffers are exported too
         spk = model.spk_model
         for i, layer in enumerate((spk.layer1, spk.layer2, spk.layer3, spk.layer4)):
             meta[f"spk_blocks{i}"] = len(layer)
