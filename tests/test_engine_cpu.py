@@ -183,6 +183,14 @@ def test_separate_main_dry_run_and_argument_errors(tmp_path):
     assert r.returncode == 0, r.stderr
     assert r.stdout.count("process: utt") == 2 and "[dry run]" in r.stdout and "RTF:" in r.stdout
     assert "Total: process 3000ms audio" in r.stdout
+    # utterance-level concurrency: worker threads with one engine each
+    scp3 = tmp_path / "wav3.scp"
+    scp3.write_text("".join(f"u{i} {tmp_path}/mix.wav {tmp_path}/e1.wav {tmp_path}/e2.wav\n" for i in range(5)))
+    r = subprocess.run([exe, "--wav_scp", str(scp3), "--model", model, "--dry_run", "--jobs", "3", "--devices", "0,1"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert sorted(l.split()[1] for l in r.stdout.splitlines() if l.startswith("process:")) == [f"u{i}" for i in range(5)]
+    assert "Total: process 7500ms audio" in r.stdout
     # single-utterance flags of the reference tool
     r = subprocess.run([exe, "--wav_path", f"{tmp_path}/mix.wav", "--spk1_emb", f"{tmp_path}/e1.wav", "--spk2_emb",
                         f"{tmp_path}/e2.wav", "--model", model, "--dry_run"], capture_output=True, text=True, timeout=120)

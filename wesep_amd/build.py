@@ -65,7 +65,7 @@ def build_runtime(force=False, verbose=True):
         cmds.append([hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", os.path.join(RUNTIME, "engine.cc"), "-o",
                      ENGINE_OUT, "-L" + HERE, "-lwesep_hip", "-Wl,-rpath,$ORIGIN/../wesep_amd"])
     if force or _stale(MAIN_OUT, deps + [ENGINE_OUT]) or cmds:
-        cmds.append([hipcc, "-O2", "-std=c++17", os.path.join(RUNTIME, "separate_main.cc"), "-o", MAIN_OUT,
+        cmds.append([hipcc, "-O2", "-std=c++17", "-pthread", os.path.join(RUNTIME, "separate_main.cc"), "-o", MAIN_OUT,
                      "-L" + RUNTIME, "-lwesep_engine", "-L" + HERE, "-lwesep_hip", "-Wl,-rpath,$ORIGIN",
                      "-Wl,-rpath,$ORIGIN/../wesep_amd"])
     for cmd in cmds:
