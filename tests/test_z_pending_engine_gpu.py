@@ -153,4 +153,14 @@ def test_separate_main_end_to_end(tmp_path):
             assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getnframes() == 24000
             got = np.frombuffer(w.readframes(24000), dtype=np.int16).astype(np.float32)
         assert np.abs(got - np.clip(np.round(want[i] * 32768), -32768, 32767)).max() <= 1.0
+    # concurrent engines (one per worker thread) produce the same files
+    (tmp_path / "wav4.scp").write_text("".join(f"c{i} {tmp_path}/mix.wav {tmp_path}/e1.wav {tmp_path}/e2.wav\n"
+                                               for i in range(4)))
+    r = subprocess.run([os.path.join(ROOT, "runtime", "separate_main"), "--wav_scp", str(tmp_path / "wav4.scp"),
+                        "--model", str(tmp_path / "j.wsw"), "--output_dir", str(out_dir), "--jobs", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ref_bytes = (out_dir / "utt1-spk1.wav").read_bytes()
+    for i in range(4):
+        assert (out_dir / f"c{i}-spk1.wav").read_bytes() == ref_bytes
     eng.close()
