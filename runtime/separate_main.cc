@@ -13,6 +13,7 @@
 // utterance at two rows fills a fraction of an MI355X (its time view is 64 sequences = 16 of 256 CUs), so several
 // engines per GPU overlap on the chip.  The reference tool is single-threaded on CPU cores.
 // --dry_run validates the model file and the launch plan of every utterance without a GPU and writes nothing.
+// --raw_out additionally writes the unquantised estimates as <key>-spk{1,2}.f32 (float32, for parity checks).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -71,7 +72,7 @@ int main(int argc, char** argv) {
   const Args args = parse(argc, argv);
   const std::string model = args.get("model", ""), out_dir = args.get("output_dir", "");
   const int sample_rate = atoi(args.get("sample_rate", "16000").c_str());
-  const bool dry = args.has("dry_run");
+  const bool dry = args.has("dry_run"), raw_out = args.has("raw_out");
   if (model.empty()) return die("--model is required");
   if (out_dir.empty() && !dry) return die("Invalid output path.");
 
@@ -150,6 +151,13 @@ int main(int argc, char** argv) {
                    !wesep_rt::write_wav(out_dir + "/" + w[0] + "-spk2.wav", out.data() + n, n, sample_rate, &err))) {
         fail(err);
         break;
+      }
+      if (!dry && raw_out) {
+        for (int k = 0; k < 2; ++k) {
+          FILE* f = fopen((out_dir + "/" + w[0] + "-spk" + std::to_string(k + 1) + ".f32").c_str(), "wb");
+          if (!f || fwrite(out.data() + size_t(k) * n, 4, n, f) != size_t(n)) fail("cannot write raw output");
+          if (f) fclose(f);
+        }
       }
       std::lock_guard<std::mutex> l(io_mu);
       printf("process: %s RTF: %.4f (%lld launches, %lld MiB arena)%s\n", w[0].c_str(), ms / audio_ms,
