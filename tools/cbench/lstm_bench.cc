@@ -1,0 +1,176 @@
+// lstm_bench -- Python-free microbenchmark of the BLSTM recurrences through the C ABI (include/wesep_hip.h).
+// A GPU call that imports torch spends 1-2 minutes before the first kernel; this binary starts in milliseconds, so a
+// gpurun call can sweep many configurations inside a few GPU-seconds.  Not part of the product.
+//
+//   lstm_bench [--view time|band] [--rows 32] [--seconds 4] [--iters 5] [--what fwd,bwd,fused,cluster,cluster_bwd]
+//
+// Prints one line per (kernel, configuration): ms per launch, microseconds per recurrence step, and the algorithmic
+// HBM rate (bench.py's convention: 10 fp32 per position, direction and hidden unit) against the 8 TB/s peak.
+// Also the tanh-bounded checksum of h / d(gates) so that NaNs or an all-zero output are visible.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/wesep_hip.h"
+
+#define HIP_OK(x)                                                              \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e_));           \
+      exit(2);                                                                 \
+    }                                                                          \
+  } while (0)
+#define WS_OK_(x)                                                              \
+  do {                                                                         \
+    int r_ = (x);                                                              \
+    if (r_ != WS_OK) {                                                         \
+      fprintf(stderr, "%s failed (rc=%d): %s\n", #x, r_, ws_last_error());     \
+      exit(3);                                                                 \
+    }                                                                          \
+  } while (0)
+
+static float* dalloc(size_t n) {
+  float* p = nullptr;
+  HIP_OK(hipMalloc(reinterpret_cast<void**>(&p), n * 4));
+  return p;
+}
+
+static float* drandom(size_t n, float scale, unsigned seed) {
+  std::vector<float> h(n);
+  std::mt19937 rng(seed);
+  std::normal_distribution<float> nd(0.f, scale);
+  for (auto& v : h) v = nd(rng);
+  float* p = dalloc(n);
+  HIP_OK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice));
+  return p;
+}
+
+static double checksum(const float* d, size_t n) {
+  std::vector<float> h(n > (1u << 22) ? (1u << 22) : n);
+  HIP_OK(hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost));
+  double s = 0.0;
+  for (float v : h) s += fabs(static_cast<double>(v));
+  return s / h.size();
+}
+
+template <class F>
+static double time_ms(F&& launch, int iters, hipStream_t s) {
+  hipEvent_t a, b;
+  HIP_OK(hipEventCreate(&a));
+  HIP_OK(hipEventCreate(&b));
+  launch();
+  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipEventRecord(a, s));
+  for (int i = 0; i < iters; ++i) launch();
+  HIP_OK(hipEventRecord(b, s));
+  HIP_OK(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, a, b));
+  return ms / iters;
+}
+
+int main(int argc, char** argv) {
+  std::map<std::string, std::string> kv;
+  for (int i = 1; i + 1 < argc; i += 2) kv[argv[i]] = argv[i + 1];
+  auto get = [&](const char* k, const char* d) { return kv.count(k) ? kv[k] : std::string(d); };
+  const std::string view = get("--view", "time"), what = get("--what", "fwd,bwd");
+  const int R = atoi(get("--rows", "32").c_str()), iters = atoi(get("--iters", "5").c_str());
+  const int T = static_cast<int>(16000 * atof(get("--seconds", "4").c_str()));
+  const int K = 32, Tf = 1 + T / 128, H = WS_LSTM_H, G4 = 4 * H, N = 128;
+  const int nseq = view == "time" ? R * K : R * Tf, L = view == "time" ? Tf : K;
+  const int ntile = (nseq + 31) / 32;
+  const size_t nb = size_t(ntile) * L, P = size_t(nseq) * L;
+  const int mode_default = 2 * ntile <= 128 ? WS_LSTM_BF16X3_BLK16 : WS_LSTM_BF16X3_BLK;
+  const int mode = kv.count("--mode") ? atoi(kv["--mode"].c_str()) : mode_default;
+  hipStream_t s;
+  HIP_OK(hipStreamCreate(&s));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, 0));
+  printf("# %s, %d CUs; view %s: %d sequences x %d steps (%d tiles), mode %d\n", prop.name, prop.multiProcessorCount,
+         view.c_str(), nseq, L, ntile, mode);
+
+  float* whf = drandom(size_t(G4) * H, 0.06f, 1);
+  float* whr = drandom(size_t(G4) * H, 0.06f, 2);
+  float* wif = drandom(size_t(G4) * N, 0.08f, 3);
+  float* wir = drandom(size_t(G4) * N, 0.08f, 4);
+  float* bias = drandom(2 * G4, 0.05f, 5);
+  float* pack_f = dalloc(WS_LSTM_PACK_FLOATS);
+  float* pack_b = dalloc(WS_LSTM_PACK_FLOATS);
+  float* fpack = dalloc(WS_LSTM_FUSED_PACK_FLOATS);
+  float* gates0 = drandom(nb * 32 * 2 * G4, 1.0f, 6);     // pre-activations (x W_ih^T + b)
+  float* gates = dalloc(nb * 32 * 2 * G4);
+  float* cbuf = dalloc(nb * 32 * 2 * H);
+  float* hcat = dalloc(nb * 32 * 2 * H);
+  float* dh = drandom(nb * 32 * 2 * H, 1e-3f, 7);
+  float* xn = drandom(nb * 32 * N, 1.0f, 8);
+  const size_t gbytes = nb * 32 * 2 * G4 * 4;
+  WS_OK_(ws_lstm_pack(whf, whr, pack_f, pack_b, mode, s));
+  WS_OK_(ws_lstm_pack_fused(wif, wir, whf, whr, fpack, s));
+
+  ws_lstm_args a = {};
+  a.gates = gates, a.cbuf = cbuf, a.hcat = hcat, a.nseq = nseq, a.L = L, a.mode = mode, a.sq_div = 1 << 30;
+  const double bytes = 10.0 * 4 * double(P) * 2 * H;
+  auto report = [&](const char* name, double ms, const float* out, size_t n) {
+    printf("%-12s %8.3f ms/launch  %6.2f us/step  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)  mean|out| %.4e\n", name, ms,
+           1e3 * ms / L, bytes / ms * 1e-6, 100.0 * bytes / ms * 1e-6 / 8000.0, checksum(out, n));
+  };
+  auto reset_gates = [&]() { HIP_OK(hipMemcpyAsync(gates, gates0, gbytes, hipMemcpyDeviceToDevice, s)); };
+
+  // forward first (the backward consumes its activated gates / cells / h)
+  reset_gates();
+  a.wpack = pack_f;
+  if (what.find("fwd") != std::string::npos) {
+    // timing re-runs the forward on already activated gates: same memory traffic and arithmetic, values saturate
+    const double ms = time_ms([&] { WS_OK_(ws_lstm_fwd(&a, s)); }, iters, s);
+    report("fwd", ms, hcat, nb * 32 * 2 * H);
+  }
+  if (what.find("fused") != std::string::npos && mode == WS_LSTM_BF16X3_BLK) {
+    ws_lstm_fused_args f = {};
+    f.gates = gates, f.cbuf = cbuf, f.hcat = hcat, f.xn = xn, f.wpack = fpack, f.bias = bias, f.nseq = nseq, f.L = L;
+    const double ms = time_ms([&] { WS_OK_(ws_lstm_fwd_fused(&f, s)); }, iters, s);
+    report("fwd_fused", ms, hcat, nb * 32 * 2 * H);
+  }
+  const bool cluster_ok = nseq % 64 == 0 && (nseq / 32) * 8 <= prop.multiProcessorCount && L >= 64;
+  float* xchg = nullptr;
+  unsigned* flags = nullptr;
+  if (cluster_ok && what.find("cluster") != std::string::npos) {
+    xchg = dalloc(size_t(nseq / 32) * 2 * 64 * 8192 / 4);
+    flags = reinterpret_cast<unsigned*>(dalloc(size_t(nseq / 32) * 8));
+    ws_lstm_cluster_args c = {};
+    c.gates = gates, c.cbuf = cbuf, c.hcat = hcat, c.whh_f = whf, c.whh_r = whr, c.xchg = xchg, c.flags = flags;
+    c.nseq = nseq, c.L = L;
+    reset_gates();
+    const double ms = time_ms([&] { WS_OK_(ws_lstm_fwd_cluster(&c, s)); }, iters, s);
+    report("fwd_cluster", ms, hcat, nb * 32 * 2 * H);
+  }
+  // a clean forward, then the backward passes
+  reset_gates();
+  WS_OK_(ws_lstm_fwd(&a, s));
+  float* gates_act = dalloc(nb * 32 * 2 * G4);   // activated gates: the backward overwrites them with d(gates)
+  HIP_OK(hipMemcpyAsync(gates_act, gates, gbytes, hipMemcpyDeviceToDevice, s));
+  if (what.find("bwd") != std::string::npos) {
+    a.wpack = pack_b;
+    a.dhcat = dh;
+    HIP_OK(hipMemcpyAsync(gates, gates_act, gbytes, hipMemcpyDeviceToDevice, s));
+    const double ms = time_ms([&] { WS_OK_(ws_lstm_bwd(&a, s)); }, iters, s);
+    report("bwd", ms, gates, nb * 32 * 2 * G4);
+  }
+  if (cluster_ok && what.find("cluster_bwd") != std::string::npos) {
+    ws_lstm_cluster_args c = {};
+    c.gates = gates, c.cbuf = cbuf, c.dhcat = dh, c.whh_f = whf, c.whh_r = whr, c.xchg = xchg, c.flags = flags;
+    c.nseq = nseq, c.L = L;
+    HIP_OK(hipMemcpyAsync(gates, gates_act, gbytes, hipMemcpyDeviceToDevice, s));
+    const double ms = time_ms([&] { WS_OK_(ws_lstm_bwd_cluster(&c, s)); }, iters, s);
+    report("bwd_cluster", ms, gates, nb * 32 * 2 * G4);
+  }
+  HIP_OK(hipStreamSynchronize(s));
+  return 0;
+}

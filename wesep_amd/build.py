@@ -68,6 +68,11 @@ def build_runtime(force=False, verbose=True):
         cmds.append([hipcc, "-O2", "-std=c++17", "-pthread", os.path.join(RUNTIME, "separate_main.cc"), "-o", MAIN_OUT,
                      "-L" + RUNTIME, "-lwesep_engine", "-L" + HERE, "-lwesep_hip", "-Wl,-rpath,$ORIGIN",
                      "-Wl,-rpath,$ORIGIN/../wesep_amd"])
+    bench_src = os.path.join(os.path.dirname(HERE), "tools", "cbench", "lstm_bench.cc")
+    bench_out = bench_src[:-3]
+    if os.path.exists(bench_src) and (force or _stale(bench_out, [bench_src, OUT, os.path.join(inc, "wesep_hip.h")])):
+        cmds.append([hipcc, "-O2", "-std=c++17", bench_src, "-o", bench_out, "-L" + HERE, "-lwesep_hip",
+                     "-Wl,-rpath,$ORIGIN/../../wesep_amd"])      # Python-free microbenchmark (tools/cbench)
     for cmd in cmds:
         if verbose:
             print(" ".join(cmd), flush=True)
