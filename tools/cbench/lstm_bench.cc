@@ -6,7 +6,9 @@
 //
 // Prints one line per (kernel, configuration): ms per launch, microseconds per recurrence step, and the algorithmic
 // HBM rate (bench.py's convention: 10 fp32 per position, direction and hidden unit) against the 8 TB/s peak.
-// Also the tanh-bounded checksum of h / d(gates) so that NaNs or an all-zero output are visible.
+// Also the tanh-bounded checksum of h / d(gates) so that NaNs or an all-zero output are visible, and -- with
+// `--compare 1` -- the relative difference of h and d(gates) between the 16-sequence, 32-sequence and cluster kernels
+// on the same inputs (they share the blocked layout), a device-side parity check for kernel experiments.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -51,6 +53,22 @@ static float* drandom(size_t n, float scale, unsigned seed) {
   float* p = dalloc(n);
   HIP_OK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice));
   return p;
+}
+
+static std::vector<float> fetch(const float* d, size_t n) {
+  std::vector<float> h(n);
+  HIP_OK(hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost));
+  return h;
+}
+
+static double rel_diff(const std::vector<float>& a, const std::vector<float>& b) {
+  double num = 0.0, den = 0.0;
+  for (size_t i = 0; i < a.size(); ++i) {
+    const double d = double(a[i]) - b[i];
+    num += d * d;
+    den += double(b[i]) * b[i];
+  }
+  return sqrt(num / (den + 1e-300));
 }
 
 static double checksum(const float* d, size_t n) {
@@ -170,6 +188,47 @@ int main(int argc, char** argv) {
     HIP_OK(hipMemcpyAsync(gates, gates_act, gbytes, hipMemcpyDeviceToDevice, s));
     const double ms = time_ms([&] { WS_OK_(ws_lstm_bwd_cluster(&c, s)); }, iters, s);
     report("bwd_cluster", ms, gates, nb * 32 * 2 * G4);
+  }
+  if (atoi(get("--compare", "0").c_str())) {
+    // forward and backward of every applicable kernel family on identical inputs
+    const size_t nh = nb * 32 * 2 * H, ng = nb * 32 * 2 * G4;
+    std::vector<std::vector<float>> hs, gs;
+    std::vector<std::string> names;
+    for (int m : {WS_LSTM_BF16X3_BLK16, WS_LSTM_BF16X3_BLK}) {
+      WS_OK_(ws_lstm_pack(whf, whr, pack_f, pack_b, m, s));
+      ws_lstm_args c = a;
+      c.mode = m, c.dhcat = dh;
+      reset_gates();
+      c.wpack = pack_f;
+      WS_OK_(ws_lstm_fwd(&c, s));
+      HIP_OK(hipStreamSynchronize(s));
+      hs.push_back(fetch(hcat, nh));
+      c.wpack = pack_b;
+      WS_OK_(ws_lstm_bwd(&c, s));
+      HIP_OK(hipStreamSynchronize(s));
+      gs.push_back(fetch(gates, ng));
+      names.push_back(m == WS_LSTM_BF16X3_BLK16 ? "blk16" : "blk32");
+    }
+    if (cluster_ok) {
+      if (!xchg) {
+        xchg = dalloc(size_t(nseq / 32) * 2 * 64 * 8192 / 4);
+        flags = reinterpret_cast<unsigned*>(dalloc(size_t(nseq / 32) * 8));
+      }
+      ws_lstm_cluster_args c = {};
+      c.gates = gates, c.cbuf = cbuf, c.hcat = hcat, c.dhcat = dh, c.whh_f = whf, c.whh_r = whr, c.xchg = xchg;
+      c.flags = flags, c.nseq = nseq, c.L = L;
+      reset_gates();
+      WS_OK_(ws_lstm_fwd_cluster(&c, s));
+      HIP_OK(hipStreamSynchronize(s));
+      hs.push_back(fetch(hcat, nh));
+      WS_OK_(ws_lstm_bwd_cluster(&c, s));
+      HIP_OK(hipStreamSynchronize(s));
+      gs.push_back(fetch(gates, ng));
+      names.push_back("cluster");
+    }
+    for (size_t i = 1; i < names.size(); ++i)
+      printf("compare %-8s vs %s:  h rel %.3e   d(gates) rel %.3e\n", names[i].c_str(), names[0].c_str(),
+             rel_diff(hs[i], hs[0]), rel_diff(gs[i], gs[0]));
   }
   HIP_OK(hipStreamSynchronize(s));
   return 0;
