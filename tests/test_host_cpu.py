@@ -272,3 +272,63 @@ def test_average_model_tool(tmp_path):
     assert list(out.keys()) == ["models"] and torch.equal(out["models"][0]["w"], torch.full((2, 3), 6.0))
     with pytest.raises(ValueError):
         average_checkpoints([])
+
+
+def test_train_entry_host_flow(tmp_path, monkeypatch):
+    """wesep_amd.bin.train on CPU with a stand-in model: config parsing + `--key value` overrides, the synthetic
+    collated batches (keys / shapes of tse_collate_fn for fixed-embedding, fbank and raw-audio enrollment), epochs of
+    Executor.train / cv, the reference's checkpoint naming and saving rule, resume from a checkpoint."""
+    import yaml
+    import wesep_amd.bin.train as T
+    import wesep_amd.utils.executor as ex
+
+    class Stub(torch.nn.Module):
+        def __init__(self, **kw):
+            super().__init__()
+            self.gain = torch.nn.Parameter(torch.tensor(0.5))
+
+        def forward(self, mix, enroll):
+            return self.gain * mix + 0.0 * enroll.float().mean(), torch.zeros(())
+
+    monkeypatch.setattr(T, "get_model", lambda name: Stub)
+    monkeypatch.setattr(T, "parse_loss", lambda loss: [lambda est, ref: ((est - ref) ** 2).mean(1)])
+    monkeypatch.setattr(ex, "clip_gradients", lambda model, clip: None)
+    conf = {"exp_dir": str(tmp_path / "exp"), "seed": 3, "num_epochs": 3, "num_avg": 1, "save_epoch_interval": 2,
+            "log_batch_interval": 2, "clip_grad": 5.0, "enable_amp": False, "loss": "SISDR",
+            "loss_args": {"loss_posi": [[0]], "loss_weight": [[1.0]]},
+            "model": {"tse_model": "BSRNN"}, "model_init": {"tse_model": None},
+            "model_args": {"tse_model": {"joint_training": False, "spk_emb_dim": 256}},
+            "optimizer": {"tse_model": "Adam"}, "optimizer_args": {"tse_model": {"lr": 1.0, "weight_decay": 0.0}},
+            "scheduler": {"tse_model": "ExponentialDecrease"},
+            "scheduler_args": {"tse_model": {"initial_lr": 1e-3, "final_lr": 1e-4, "warm_up_epoch": 0}},
+            "dataloader_args": {"batch_size": 2}, "dataset_args": {"chunk_len": 1600, "resample_rate": 16000}}
+    path = tmp_path / "conf.yaml"
+    path.write_text(yaml.dump(conf))
+    configs, n = T.parse_config(["--config", str(path), "--synthetic", "4", "--dataloader_args.batch_size", "3",
+                                 "--clip_grad", "3.0"])
+    assert n == 4 and configs["dataloader_args"]["batch_size"] == 3 and configs["clip_grad"] == 3.0
+    batch = next(iter(T.SyntheticTseLoader(configs, 1, 0)))
+    assert batch["wav_mix"].shape == batch["wav_targets"].shape == (6, 1600) and batch["spk_embeds"].shape == (6, 256)
+    assert batch["spk_label"].dtype == torch.int64 and len(batch["key"]) == 6
+    joint = {**configs, "model_args": {"tse_model": {"joint_training": True, "spk_feat": True,
+                                                     "spk_args": {"feat_dim": 80}, "spksInTrain": 11}}}
+    b = next(iter(T.SyntheticTseLoader(joint, 1, 0)))
+    assert b["spk_embeds"].shape == (6, 398, 80) and b["spk_embeds"].mean(1).abs().max() < 1e-5
+    assert int(b["spk_label"].max()) < 11
+    joint["model_args"]["tse_model"]["spk_feat"] = False
+    assert next(iter(T.SyntheticTseLoader(joint, 1, 0)))["spk_embeds"].shape == (6, 64000)
+    executor = T.train(configs, n)
+    assert executor.step == 3 * 4
+    models = sorted(os.listdir(tmp_path / "exp" / "models"))
+    assert models == ["checkpoint_2.pt", "checkpoint_3.pt", "final_checkpoint.pt", "latest_checkpoint.pt"]
+    assert os.readlink(tmp_path / "exp" / "models" / "final_checkpoint.pt") == "checkpoint_3.pt"
+    ck = torch.load(tmp_path / "exp" / "models" / "checkpoint_3.pt", weights_only=False)
+    assert set(ck) == {"models", "optimizers", "schedulers", "scaler"} and "gain" in ck["models"][0]
+    assert os.path.exists(tmp_path / "exp" / "config.yaml") and os.path.exists(tmp_path / "exp" / "train.log")
+    # lr comes from the scheduler's initial_lr, not from optimizer_args (train.py:236-237)
+    assert ck["optimizers"][0]["param_groups"][0]["lr"] < 1.1e-3
+    # resume: starts after the checkpoint's epoch
+    configs["num_epochs"], configs["checkpoint"] = 4, str(tmp_path / "exp" / "models" / "checkpoint_3.pt")
+    assert T.train(configs, n).step == 4
+    with pytest.raises(SystemExit):
+        T.train(configs, 0)
