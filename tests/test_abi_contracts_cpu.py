@@ -5,6 +5,7 @@ point's argument validation (shapes, leading dimensions, alignment flags, split 
 because this machine has no GPU.  This catches the "bad args" class of defects (a width that is not a multiple of
 4, a split count over a limit, a leading dimension smaller than the row) for configurations the `-m gpu` tests do
 not reach -- the shipped recipe sizes in particular -- without computing anything."""
+import os
 import random
 
 import pytest
@@ -165,3 +166,27 @@ def test_tfgridnet_recipe_contracts(monkeypatch, ks, hs, T):
     est, _ = _fwd_bwd(model, torch.randn(2, T), torch.randn(2, 100, 80))
     assert tuple(est.shape) == (2, T)
     _check(calls, 200)
+
+
+def test_train_entry_with_real_models_contracts(monkeypatch, tmp_path):
+    """wesep_amd.bin.train end to end (config -> synthetic batches -> model -> Executor epochs -> checkpoints) with the
+    real pBSRNN module trees; every launch of the two epochs passes its argument validation."""
+    import wesep_amd.bin.train as T
+    calls = abi_dryrun.install(monkeypatch)
+    base = {"exp_dir": str(tmp_path / "exp"), "seed": 1, "num_epochs": 2, "num_avg": 2, "save_epoch_interval": 1,
+            "log_batch_interval": 1, "clip_grad": 5.0, "enable_amp": False, "loss": "SISDR",
+            "loss_args": {"loss_posi": [[0]], "loss_weight": [[1.0]]}, "model": {"tse_model": "BSRNN"},
+            "model_init": {"tse_model": None},
+            "model_args": {"tse_model": dict(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False,
+                                             use_spk_transform=False, spk_model="ResNet18", **SPK)},
+            "optimizer": {"tse_model": "Adam"}, "optimizer_args": {"tse_model": {"lr": 1e-3, "weight_decay": 1e-4}},
+            "scheduler": {"tse_model": "ExponentialDecrease"},
+            "scheduler_args": {"tse_model": {"initial_lr": 1e-3, "final_lr": 2.5e-5, "warm_up_epoch": 0}},
+            "dataloader_args": {"batch_size": 1}, "dataset_args": {"chunk_len": 8000, "resample_rate": 16000}}
+    assert T.train(base, 2).step == 4
+    assert sorted(os.listdir(tmp_path / "exp" / "models"))[:2] == ["checkpoint_1.pt", "checkpoint_2.pt"]
+    multi = {**base, "exp_dir": str(tmp_path / "exp2"), "model": {"tse_model": "BSRNN_Multi"},
+             "loss_args": {"loss_posi": [[0, 1]], "loss_weight": [[0.4, 0.6]]}}
+    multi["model_args"] = {"tse_model": {**base["model_args"]["tse_model"], "spk_feat": False, "feat_type": "consistent"}}
+    assert T.train(multi, 1).step == 2
+    _check(calls, 500)
