@@ -58,10 +58,12 @@ def setup_logger(rank, exp_dir):
     logger = logging.getLogger(f"wesep_amd.train.{rank}")
     logger.setLevel(logging.INFO if rank == 0 else logging.WARNING)
     fmt = logging.Formatter("[ %(levelname)s : %(asctime)s ] - %(message)s")
-    if not logger.handlers:
-        for h in (logging.StreamHandler(sys.stdout), logging.FileHandler(os.path.join(exp_dir, "train.log"))):
-            h.setFormatter(fmt)
-            logger.addHandler(h)
+    for h in list(logger.handlers):          # a second train() in the same process logs to its own exp_dir
+        logger.removeHandler(h)
+        h.close()
+    for h in (logging.StreamHandler(sys.stdout), logging.FileHandler(os.path.join(exp_dir, "train.log"))):
+        h.setFormatter(fmt)
+        logger.addHandler(h)
     return logger
 
 
