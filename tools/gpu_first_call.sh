@@ -4,6 +4,12 @@
 #   gpurun --timeout 1500 -- 'bash tools/gpu_first_call.sh'
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 mkdir -p gpurun_out
+# seconds, no Python: isolated recurrence timings + device-side parity between the kernel families
+for view in time band; do
+  timeout 120 tools/cbench/lstm_bench --view $view --rows 32 --what fwd,bwd,fused,cluster,cluster_bwd --compare 1 \
+    > "gpurun_out/lstm_bench_${view}.txt" 2>&1
+  echo "== lstm_bench ${view}: exit $?"; cat "gpurun_out/lstm_bench_${view}.txt"
+done
 for t in fbank bsrnn_multi engine; do
   timeout 600 python -m pytest "tests/test_z_pending_${t}_gpu.py" -q --tb=short -m gpu > "gpurun_out/pending_${t}.log" 2>&1
   echo "== pending ${t}: exit $?"; tail -n 15 "gpurun_out/pending_${t}.log"
