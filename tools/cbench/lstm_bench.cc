@@ -46,12 +46,15 @@ static float* dalloc(size_t n) {
 }
 
 static float* drandom(size_t n, float scale, unsigned seed) {
-  std::vector<float> h(n);
+  // a 1 M-sample Gaussian block tiled over the buffer: big buffers (GBs of gate pre-activations) in milliseconds
+  const size_t blk = n < (1u << 20) ? n : (1u << 20);
+  std::vector<float> h(blk);
   std::mt19937 rng(seed);
   std::normal_distribution<float> nd(0.f, scale);
   for (auto& v : h) v = nd(rng);
   float* p = dalloc(n);
-  HIP_OK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice));
+  for (size_t o = 0; o < n; o += blk)
+    HIP_OK(hipMemcpy(p + o, h.data(), (n - o < blk ? n - o : blk) * 4, hipMemcpyHostToDevice));
   return p;
 }
 
