@@ -194,7 +194,9 @@ int main(int argc, char** argv) {
   }
   if (atoi(get("--compare", "0").c_str())) {
     // forward and backward of every applicable kernel family on identical inputs
-    const size_t nh = nb * 32 * 2 * H, ng = nb * 32 * 2 * G4;
+    // the first 64 M elements are plenty for a parity signal (the band view's d(gates) is 1 G floats)
+    const size_t cap = size_t(1) << 26;
+    const size_t nh = nb * 32 * 2 * H < cap ? nb * 32 * 2 * H : cap, ng = nb * 32 * 2 * G4 < cap ? nb * 32 * 2 * G4 : cap;
     std::vector<std::vector<float>> hs, gs;
     std::vector<std::string> names;
     for (int m : {WS_LSTM_BF16X3_BLK16, WS_LSTM_BF16X3_BLK}) {
