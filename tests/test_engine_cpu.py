@@ -153,6 +153,19 @@ def test_dry_run_raw_audio_joint_model(tmp_path):
     eng.close()
 
 
+@needs_no_gpu
+def test_infer_extract_engine_rank_dispatch(tmp_path):
+    from wesep_amd.bin.infer import extract_engine
+    path = str(tmp_path / "m.wsw")
+    export_engine(_model(joint_training=False, **FIXED[0]), path)
+    eng = E.Engine(path, dry_run=True)
+    out = extract_engine(eng, np.ones((2, 4000)), np.zeros((2, 256)))         # float64 in: converted
+    assert out.shape == (2, 4000) and out.dtype == np.float32 and not out.any()   # all-zero rows: not normalised
+    with pytest.raises(E.WesepHipError, match="does not fit"):
+        extract_engine(eng, np.ones((2, 4000)), np.zeros((2, 98, 80)))       # 3-D enrollment = fbank
+    eng.close()
+
+
 def test_export_refuses_models_the_runtime_does_not_run():
     from wesep_amd.models import get_model
     with pytest.raises(NotImplementedError):

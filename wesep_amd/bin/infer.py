@@ -21,6 +21,21 @@ def extract(model, wav_mix, enroll):
     return outputs.cpu().numpy()
 
 
+def extract_engine(engine, wav_mix, enroll, kind=None):
+    """The same step on the native runtime (`wesep_amd.engine.Engine`, runtime/libwesep_engine.so): host arrays in,
+    numpy [B, T] out, peak-normalised by the same rule.  `kind`: an `ENROLL_*` constant; default by rank
+    (2-D embeddings for fixed-embedding models are ENROLL_EMBEDDING, 3-D is fbank; pass ENROLL_WAVE for audio)."""
+    from .. import engine as E
+    wav_mix = np.ascontiguousarray(wav_mix, dtype=np.float32)
+    enroll = np.ascontiguousarray(enroll, dtype=np.float32)
+    if kind is None:
+        kind = E.ENROLL_FBANK if enroll.ndim == 3 else E.ENROLL_EMBEDDING
+    outputs = engine.separate(wav_mix, enroll, kind)
+    if outputs.max(axis=1).min() > 0:
+        outputs = outputs / np.abs(outputs).max(axis=1, keepdims=True) * 0.9
+    return outputs
+
+
 def evaluate(model, batches, device="cuda"):
     """batches: iterable of dicts with `wav_mix` [B, T], `wav_targets` [B, T], `spk_embeds` [B, E]
     (what tse_collate_fn_2spk yields, infer.py:108-116).  Returns (mean SI-SNR, mean SI-SNRi, count):
