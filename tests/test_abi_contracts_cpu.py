@@ -190,3 +190,19 @@ def test_train_entry_with_real_models_contracts(monkeypatch, tmp_path):
     multi["model_args"] = {"tse_model": {**base["model_args"]["tse_model"], "spk_feat": False, "feat_type": "consistent"}}
     assert T.train(multi, 1).step == 2
     _check(calls, 500)
+
+
+@pytest.mark.parametrize("B,T", [(2, 8000), (8, 6400)])
+def test_tfgridnet_blocked_recurrence_path_contracts(monkeypatch, B, T):
+    """WESEP_TFGRID_BLOCKED=1: the recipe geometry (emb_dim 128, emb_ks = emb_hs = 1) on the pBSRNN blocked-layout
+    recurrence machinery, with the sequence count zero-padded to the cluster kernels' multiple of 64."""
+    from wesep_amd.models import get_model
+    monkeypatch.setenv("WESEP_TFGRID_BLOCKED", "1")
+    calls = abi_dryrun.install(monkeypatch)
+    model = get_model("TFGridNet")(n_fft=128, stride=64, n_layers=2, lstm_hidden_units=192, attn_n_head=4,
+                                   attn_approx_qk_dim=512, emb_dim=128, emb_ks=1, emb_hs=1, use_spk_transform=False,
+                                   spk_fuse_type="multiply", joint_training=False)
+    est, _ = _fwd_bwd(model, torch.randn(B, T), torch.randn(B, 256))
+    assert tuple(est.shape) == (B, T)
+    used = _check(calls, 100)
+    assert {"ws_gemm_p2b", "ws_gemm_b2p", "ws_gemm_tnb", "ws_lstm_bwd"} <= used

@@ -261,3 +261,106 @@ class MatmulNTFn(torch.autograd.Function):
             dBt, _ = _wgrad(A, M, K, dC, N, with_bias=False, vec=0)
             dB = _transposed(dBt, K, N)
         return dA, dB
+
+
+def blocked_path_ok(C, ks, hs):
+    """The blocked-layout recurrence machinery of the pBSRNN path (functional.ResRNNBlkFn: plain -> BL input
+    projection, 16-sequence / cluster / fused-projection recurrences, BL -> plain output projection with bias and
+    residual, BL x BL weight gradients) is built for 128 input features and one position per step -- which is the
+    shipped TF-GridNet recipe (emb_dim 128, emb_ks = emb_hs = 1; tfgridnet.yaml).  Opt-in until it has run on
+    hardware: WESEP_TFGRID_BLOCKED=1."""
+    import os
+    return os.environ.get("WESEP_TFGRID_BLOCKED", "0") == "1" and C == 128 and ks == 1 and hs == 1
+
+
+class BlstmLinearBlkFn(torch.autograd.Function):
+    """y [nseq*Lr, 128] (layer-normed), res [nseq*Lr, 128] -> res + Linear(BLSTM(y)) on the blocked layout.
+
+    gridnet_block.py:139-160 for emb_ks = emb_hs = 1.  Same kernels and call sequence as functional.ResRNNBlkFn
+    without its GroupNorm (the LayerNorm over C happens before, per row).  Sequences are the contiguous runs of Lr
+    rows; when the cluster recurrence applies apart from the sequence count (long sequences, few of them: the
+    inter-frame path), the sequences are zero-padded to a multiple of 64 -- padded sequences cost no latency and their
+    rows are dropped.  Weights: pad_lstm / pad_hidden_cols outputs (hidden zero-padded to 256)."""
+
+    @staticmethod
+    def forward(ctx, y, res, geo, wih_f, wih_r, b_f, b_r, whf, whr, lin_w, lin_b):
+        from . import functional as F0
+        _need_cuda(y, "TF-GridNet")
+        nseq, Lr = geo
+        N, H, G4 = 128, HP, G4P
+        d = y.device
+        pad = 0
+        if Lr >= 64 and nseq % 64 and (-(-nseq // 64) * 64 // 32) * 8 <= dev.cu_count(d):
+            pad = -(-nseq // 64) * 64 - nseq
+        ns = nseq + pad
+        if pad:
+            z = torch.zeros(pad * Lr, N, device=d, dtype=torch.float32)
+            y, res = torch.cat([y, z], 0), torch.cat([res, z], 0)
+        y, res = y.contiguous(), res.contiguous()
+        seq = SeqMap(ns, BIG, 0, Lr, 1, Lr)
+        nb = dev.bl_num_blocks(seq)
+        zero = torch.zeros(G4, device=d, dtype=torch.float32)
+        wcat, bcat = _empty(d, 2 * G4, N), _empty(d, 2 * G4)
+        dev.lstm_cat_ih(wih_f.contiguous(), wih_r.contiguous(), b_f.contiguous(), zero, b_r.contiguous(), zero, N, wcat,
+                        bcat)
+        pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
+        lmode = dev.lstm_blk_mode(ns)
+        whf, whr = whf.contiguous(), whr.contiguous()
+        dev.lstm_pack(whf, whr, pack_f, pack_b, lmode)
+        gates, xn = _empty(d, nb, 32 * 2 * G4), _empty(d, nb, 32 * N)
+        cbuf, hcat = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * 2 * H)
+        cluster = dev.lstm_cluster_ok(seq, d)
+        if dev.lstm_fuse_ok(ns, cluster):
+            dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn)
+            fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
+            dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), whf, whr, fpack)
+            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq)
+        else:
+            wih_pack = _empty(d, 2 * G4 * N)
+            dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
+            dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=gates, bias=bcat, A_bl=xn)
+            if cluster:
+                dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq)
+            else:
+                dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode)
+        lw = lin_w.contiguous()
+        lin_pack = _empty(d, N * 2 * H)
+        dev.pack_w(lw, N, 2 * H, 2 * H, lin_pack, order=1)
+        out = torch.empty_like(res)
+        dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=lin_pack, C_out=out, ldc=N, bias=lin_b.contiguous(), R=res)
+        ctx.save_for_backward(gates, cbuf, hcat, xn, wcat, pack_b, lw, whf, whr)
+        ctx.geo = (nseq, Lr, ns, lmode, cluster)
+        ctx.F0 = F0
+        return out[:nseq * Lr] if pad else out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import os
+        gates, cbuf, hcat, xn, wcat, pack_b, lw, whf, whr = ctx.saved_tensors
+        nseq, Lr, ns, lmode, cluster = ctx.geo
+        N, H, G4 = 128, HP, G4P
+        d = dout.device
+        dout = dout.contiguous()
+        dres = dout
+        if ns != nseq:
+            dout = torch.cat([dout, torch.zeros((ns - nseq) * Lr, N, device=d, dtype=torch.float32)], 0)
+        seq = SeqMap(ns, BIG, 0, Lr, 1, Lr)
+        nb = dev.bl_num_blocks(seq)
+        wlt_pack = _empty(d, 2 * H * N)
+        dev.pack_w(lw, 2 * H, N, 2 * H, wlt_pack, trans=True, order=0)
+        dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
+        dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wlt_pack, N=2 * H, C_out=dh, A_bl=dout_bl)
+        gates = gates.clone()                                    # BPTT works in place; keep the saved tensor intact
+        if cluster and os.environ.get("WESEP_LSTM_CLUSTER_BWD", "0") == "1":
+            dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
+        else:
+            dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, lmode)
+        wg = ctx.F0.ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N)
+        wct_pack = _empty(d, N * 2 * G4)
+        dev.pack_w(wcat, N, 2 * G4, N, wct_pack, trans=True, order=1)
+        dy = _empty(d, ns * Lr, N)
+        dev.gemm_b2p(A=gates, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dy, ldc=N)
+        if ns != nseq:
+            dy = dy[:nseq * Lr]
+        # wg: [dW_ih_f, dW_hh_f, db_f, db_f (clone), dW_ih_r, dW_hh_r, db_r, db_r (clone), dW_lin, db_lin]
+        return dy, dres, None, wg[0], wg[4], wg[2], wg[6], wg[1], wg[5], wg[8], wg[9]

@@ -108,6 +108,9 @@ class GridNetBlock(nn.Module):
         wf, hf, bf = FG.pad_lstm(rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, perm)
         wr, hr, br = FG.pad_lstm(rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse, rnn.bias_ih_l0_reverse,
                                  rnn.bias_hh_l0_reverse, perm)
+        if FG.blocked_path_ok(C, ks, hs):     # the recipe's geometry: the pBSRNN blocked-layout recurrences (opt-in)
+            return FG.BlstmLinearBlkFn.apply(y, x, (nseq, Lr), wf, wr, bf, br, hf, hr,
+                                             FG.pad_hidden_cols(lin.weight, h), lin.bias)
         hcat = FG.BlstmFn.apply(y, (nseq, Lr, C, ks, hs), torch.cat([wf, wr], 0), torch.cat([bf, br], 0), hf, hr)
         n = (Lr - ks) // hs + 1
         if ks == hs:      # Linear(2h -> ks*C): frames tile the sequence without overlap
