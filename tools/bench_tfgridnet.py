@@ -17,14 +17,22 @@ def main():
     ap.add_argument("--rows", type=int, default=2)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--recipe", action="store_true",
+                    help="model_args of examples/librimix/tse/v2/confs/tfgridnet.yaml (emb_dim 128, emb_ks = emb_hs = 1) "
+                         "instead of the constructor defaults (emb_dim 48, emb_ks 4)")
+    ap.add_argument("--blocked", action="store_true", help="WESEP_TFGRID_BLOCKED=1 (needs --recipe geometry)")
     args = ap.parse_args()
+    if args.blocked:
+        os.environ["WESEP_TFGRID_BLOCKED"] = "1"
     from wesep_amd.functional import SISDRFn
     from wesep_amd.models import get_model
     from wesep_amd.optim import FusedClipAdam
     from wesep_amd.utils.synthetic import synth_batch
     d = torch.device("cuda:0")
     torch.manual_seed(0)
-    model = get_model("TFGridNet")(joint_training=False).to(d).train()
+    kw = dict(n_fft=128, stride=64, n_layers=6, lstm_hidden_units=192, attn_n_head=4, attn_approx_qk_dim=512,
+              emb_dim=128, emb_ks=1, emb_hs=1, use_spk_transform=False, spk_fuse_type="multiply") if args.recipe else {}
+    model = get_model("TFGridNet")(joint_training=False, **kw).to(d).train()
     opt = FusedClipAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, clip_grad=5.0)
     wav, tgt, emb = (t.to(d) for t in synth_batch(args.rows, 96000, 42))
 
@@ -47,6 +55,7 @@ def main():
     print(json.dumps({"metric": "utterances/sec (6 s, 16 kHz) fwd+bwd, TF-GridNet (fixed embeddings), 6 s utterances",
                       "value": args.rows * args.steps / el, "unit": "utterances/s",
                       "ms_per_step": el / args.steps * 1e3, "rows": args.rows, "steps": args.steps, "dtype": "bf16x3",
+                      "config": "recipe" if args.recipe else "constructor defaults", "blocked_recurrence": bool(args.blocked),
                       "data": "synthetic", "final_loss_dB": float(loss.item()),
                       "params_M": sum(p.numel() for p in model.parameters()) / 1e6,
                       "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)

@@ -10,7 +10,7 @@ for view in time band; do
     > "gpurun_out/lstm_bench_${view}.txt" 2>&1
   echo "== lstm_bench ${view}: exit $?"; cat "gpurun_out/lstm_bench_${view}.txt"
 done
-for t in fbank bsrnn_multi engine; do
+for t in fbank bsrnn_multi engine tfgridnet_blocked; do
   timeout 600 python -m pytest "tests/test_z_pending_${t}_gpu.py" -q --tb=short -m gpu > "gpurun_out/pending_${t}.log" 2>&1
   echo "== pending ${t}: exit $?"; tail -n 15 "gpurun_out/pending_${t}.log"
 done
@@ -18,3 +18,7 @@ timeout 300 python tools/bench_engine.py > gpurun_out/engine_bench.json 2> gpuru
 echo "== engine bench: exit $?"; cat gpurun_out/engine_bench.json; tail -n 5 gpurun_out/engine_bench.err
 timeout 400 python bench.py --steps 5 --warmup 2 > gpurun_out/bench.json 2> gpurun_out/bench.err
 echo "== bench: exit $?"; cat gpurun_out/bench.json
+for flags in "--recipe" "--recipe --blocked"; do
+  timeout 600 python tools/bench_tfgridnet.py --rows 8 $flags > "gpurun_out/tfgridnet_${flags// /}.json" 2> gpurun_out/tfgridnet.err
+  echo "== tfgridnet ${flags}: exit $?"; cat "gpurun_out/tfgridnet_${flags// /}.json"
+done
