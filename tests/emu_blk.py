@@ -1,0 +1,227 @@
+"""TEST INFRASTRUCTURE.  CPU emulation of the blocked-layout (BL) entry points of gemm_blk.hip / lstm_bf16*.hip /
+lstm_cluster.hip / lstm_fused.hip, on top of tests/emu_dev.py: the plain <-> BL GEMMs, the recurrences on BL
+buffers (16-sequence, 32-sequence, cluster and fused-projection variants are one function here: they differ in
+scheduling, not in what they compute) and the BL x BL weight-gradient GEMM.  Packed-weight buffers are opaque on the
+device; here a registry keyed by the pack buffer's address keeps the logical matrix.
+
+Layout (include/wesep_hip.h): BL(C) block b = tile * L + step holds 32 consecutive sequences; element
+(b, slot i, column c) at b*32*C + ((c >> 2)*32 + i)*4 + (c & 3).  Only tests/ import this; the product has no CPU
+path."""
+import torch
+
+from wesep_amd import dev as real_dev
+
+H, G4 = 256, 1024
+_PACKS = {}          # pack buffer address -> logical content
+
+
+def _ntile(sm):
+    return -(-sm.nseq // 32)
+
+
+def bl_get(buf, ntile, L, C):
+    """BL(C) buffer -> [ntile*32 sequences, L steps, C] (padded sequences included)."""
+    v = buf.reshape(-1)[: ntile * L * 32 * C].reshape(ntile, L, C // 4, 32, 4)
+    return v.permute(0, 3, 1, 2, 4).reshape(ntile * 32, L, C)
+
+
+def bl_put(buf, x, ntile, L, C):
+    v = x.reshape(ntile, 32, L, C // 4, 4).permute(0, 2, 3, 1, 4)
+    buf.reshape(-1)[: ntile * L * 32 * C] = v.reshape(-1)
+
+
+def _valid(sm):
+    return (torch.arange(_ntile(sm) * 32) < sm.nseq).float().view(-1, 1, 1)
+
+
+def _positions(sm):
+    """row of the plain tensor for (sequence, step): [ntile*32, L] (padded sequences clamp to sequence nseq-1)."""
+    s = torch.arange(_ntile(sm) * 32).clamp(max=sm.nseq - 1).view(-1, 1)
+    t = torch.arange(sm.L).view(1, -1)
+    return (s // sm.div) * sm.s1 + (s % sm.div) * sm.s2 + t * sm.step_rows
+
+
+def pack_w(W, N, K, ldw, out, trans=False, order=0, w_off=0):
+    flat_ = W.reshape(-1)
+    n, k = torch.arange(N).view(-1, 1), torch.arange(K).view(1, -1)
+    _PACKS[out.data_ptr()] = flat_[w_off + (k * ldw + n if trans else n * ldw + k)].clone()      # W'[n][k]
+
+
+def lstm_cat_ih(wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, n_in, wcat, bcat):
+    wcat.reshape(2, G4, n_in)[0], wcat.reshape(2, G4, n_in)[1] = wih_f, wih_r
+    bcat.reshape(2, G4)[0], bcat.reshape(2, G4)[1] = bih_f + bhh_f, bih_r + bhh_r
+
+
+def lstm_pack_fused(wih_f, wih_r, whh_f, whh_r, pack):
+    _PACKS[pack.data_ptr()] = tuple(t.clone() for t in (wih_f, wih_r, whh_f, whh_r))
+
+
+def gemm_p2b(*, A, lda, sm, Wpack, N, C_out, K=128, bias=None, A_bl=None, stats=None, gamma=None, beta=None,
+             stat_map=None):
+    nt, L = _ntile(sm), sm.L
+    pos = _positions(sm)
+    rows = A.reshape(-1, lda)[pos.reshape(-1), :K].reshape(nt * 32, L, K)
+    if stats is not None:
+        d1, m1, d2, m2, base = stat_map
+        s = (pos // d1) * m1 + (pos % d2) * m2 + base
+        st = stats.reshape(-1, 2)
+        rows = (rows - st[s, 0].unsqueeze(-1)) * st[s, 1].unsqueeze(-1) * gamma.reshape(-1)[:K] + beta.reshape(-1)[:K]
+    rows = rows * _valid(sm)
+    if A_bl is not None:
+        bl_put(A_bl, rows, nt, L, K)
+    if N:
+        out = rows @ _PACKS[Wpack.data_ptr()].t()
+        if bias is not None:
+            out = out + bias.reshape(-1)[:N]
+        bl_put(C_out, out * _valid(sm), nt, L, N)
+
+
+def gemm_b2p(*, A, K, sm, Wpack, C_out, ldc, N=128, bias=None, R=None):
+    nt, L = _ntile(sm), sm.L
+    x = bl_get(A, nt, L, K)[: sm.nseq]
+    out = x @ _PACKS[Wpack.data_ptr()].t()
+    if bias is not None:
+        out = out + bias.reshape(-1)[:N]
+    pos = _positions(sm)[: sm.nseq].reshape(-1)
+    if R is not None:
+        out = out + R.reshape(-1, ldc)[pos, :N].reshape(sm.nseq, L, N)
+    C_out.reshape(-1, ldc)[pos, :N] = out.reshape(-1, N)
+
+
+def _recur_fwd(pre, whf, whr):
+    """pre [S, L, 2, 4H] pre-activations -> (activated gates, c, h) of the same leading shape."""
+    S, L = pre.shape[:2]
+    act, cs, hs = torch.zeros_like(pre), torch.zeros(S, L, 2, H), torch.zeros(S, L, 2, H)
+    for d, W in ((0, whf), (1, whr)):
+        h, c = torch.zeros(S, H), torch.zeros(S, H)
+        for t in (range(L) if d == 0 else range(L - 1, -1, -1)):
+            p = pre[:, t, d] + h @ W.t()
+            i, f, g, o = p[:, :H].sigmoid(), p[:, H:2 * H].sigmoid(), p[:, 2 * H:3 * H].tanh(), p[:, 3 * H:].sigmoid()
+            c = f * c + i * g
+            h = o * c.tanh()
+            act[:, t, d], cs[:, t, d], hs[:, t, d] = torch.cat([i, f, g, o], 1), c, h
+    return act, cs, hs
+
+
+def _recur_bwd(act, cs, dh_in, whf, whr):
+    S, L = act.shape[:2]
+    dpre = torch.zeros_like(act)
+    for d, W in ((0, whf), (1, whr)):
+        order = list(range(L)) if d == 0 else list(range(L - 1, -1, -1))
+        dh_rec, dc = torch.zeros(S, H), torch.zeros(S, H)
+        for idx in range(L - 1, -1, -1):
+            t = order[idx]
+            a = act[:, t, d]
+            i, f, g, o = a[:, :H], a[:, H:2 * H], a[:, 2 * H:3 * H], a[:, 3 * H:]
+            c = cs[:, t, d]
+            cprev = cs[:, order[idx - 1], d] if idx > 0 else torch.zeros_like(c)
+            dh = dh_in[:, t, d] + dh_rec
+            tc = c.tanh()
+            dcv = dc + dh * o * (1 - tc * tc)
+            dp = torch.cat([dcv * g * i * (1 - i), dcv * cprev * f * (1 - f), dcv * i * (1 - g * g),
+                            dh * tc * o * (1 - o)], 1)
+            dc = dcv * f
+            dh_rec = dp @ W
+            dpre[:, t, d] = dp
+    return dpre
+
+
+def _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm):
+    nt, L = _ntile(sm), sm.L
+    act, cs, hs = _recur_fwd(pre, whf, whr)
+    v = _valid(sm)
+    bl_put(gates, (act.reshape(nt * 32, L, 2 * G4)) * v, nt, L, 2 * G4)
+    bl_put(cbuf, cs.reshape(nt * 32, L, 2 * H) * v, nt, L, 2 * H)
+    bl_put(hcat, hs.reshape(nt * 32, L, 2 * H) * v, nt, L, 2 * H)
+
+
+def _whh_from_pack(wpack):
+    W = wpack.reshape(-1)[: 2 * G4 * H].reshape(2, G4, H)          # emu_dev.lstm_pack stores the raw weights
+    return W[0], W[1]
+
+
+def make_lstm_fwd(plain_fwd):
+    def lstm_fwd(gates, cbuf, hcat, wpack, sm, mode=3):
+        if mode not in (4, 5):
+            return plain_fwd(gates, cbuf, hcat, wpack, sm, mode)
+        nt, L = _ntile(sm), sm.L
+        whf, whr = _whh_from_pack(wpack)
+        _fwd_into(gates, cbuf, hcat, bl_get(gates, nt, L, 2 * G4).reshape(nt * 32, L, 2, G4), whf, whr, sm)
+    return lstm_fwd
+
+
+def make_lstm_bwd(plain_bwd):
+    def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode=3):
+        if mode not in (4, 5):
+            return plain_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode)
+        whf, whr = _whh_from_pack(wpack)
+        _bwd_into(gates, cbuf, dhcat, whf, whr, sm)
+    return lstm_bwd
+
+
+def _bwd_into(gates, cbuf, dhcat, whf, whr, sm):
+    nt, L = _ntile(sm), sm.L
+    act = bl_get(gates, nt, L, 2 * G4).reshape(nt * 32, L, 2, G4)
+    cs = bl_get(cbuf, nt, L, 2 * H).reshape(nt * 32, L, 2, H)
+    dh = bl_get(dhcat, nt, L, 2 * H).reshape(nt * 32, L, 2, H)
+    dpre = _recur_bwd(act, cs, dh, whf, whr)
+    bl_put(gates, dpre.reshape(nt * 32, L, 2 * G4) * _valid(sm), nt, L, 2 * G4)
+
+
+def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm, status=None, dbg=0):
+    nt, L = _ntile(sm), sm.L
+    _fwd_into(gates, cbuf, hcat, bl_get(gates, nt, L, 2 * G4).reshape(nt * 32, L, 2, G4), whh_f, whh_r, sm)
+
+
+def lstm_bwd_cluster(gates, cbuf, dhcat, whh_f, whh_r, sm, status=None, dbg=0):
+    _bwd_into(gates, cbuf, dhcat, whh_f, whh_r, sm)
+
+
+def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm):
+    nt, L = _ntile(sm), sm.L
+    wih_f, wih_r, whf, whr = _PACKS[wpack.data_ptr()]
+    x = bl_get(xn, nt, L, 128)
+    b = bias.reshape(2, G4)
+    pre = torch.stack([x @ wih_f.t() + b[0], x @ wih_r.t() + b[1]], 2)
+    _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm)
+
+
+def gemm_tnb(*, G, g_width, g_off, g_cols, A0, a0_width, a0_off, a0_cols, nblk, L_, slab, nsplit, blocks_per_split,
+             a0_shift=0, A1=None, a1_width=0, a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, dbg=0):
+    nt = nblk // L_
+
+    def shifted(buf, width, off, cols, shift):
+        x = bl_get(buf, nt, L_, width)[:, :, off:off + cols]
+        out = torch.zeros_like(x)
+        if shift == 0:
+            return x
+        if shift > 0:                      # Acat(b) = A(b + shift)
+            out[:, : L_ - shift] = x[:, shift:]
+        else:
+            out[:, -shift:] = x[:, : L_ + shift]
+        return out
+    g = bl_get(G, nt, L_, g_width)[:, :, g_off:g_off + g_cols]
+    a = shifted(A0, a0_width, a0_off, a0_cols, a0_shift)
+    if A1 is not None:
+        a = torch.cat([a, shifted(A1, a1_width, a1_off, a1_cols, a1_shift)], 2)
+    acols = a.shape[2]
+    slab.reshape(-1)[: nsplit * g_cols * acols] = 0.0
+    slab.reshape(-1)[: g_cols * acols] = torch.einsum("slg,sla->ga", g, a).reshape(-1)
+    if bslab is not None:
+        bslab.reshape(-1)[: nsplit * g_cols] = 0.0
+        bslab.reshape(-1)[:g_cols] = g.sum((0, 1))
+    if aslab is not None:
+        aslab.reshape(-1)[: nsplit * acols] = 0.0
+        aslab.reshape(-1)[:acols] = a.sum((0, 1))
+
+
+def install(monkeypatch):
+    """After emu_dev.install: adds the BL entry points (and BL modes of lstm_fwd / lstm_bwd)."""
+    import wesep_amd.dev as dev
+    monkeypatch.setattr(dev, "lstm_fwd", make_lstm_fwd(dev.lstm_fwd))
+    monkeypatch.setattr(dev, "lstm_bwd", make_lstm_bwd(dev.lstm_bwd))
+    for fn in (pack_w, lstm_cat_ih, lstm_pack_fused, gemm_p2b, gemm_b2p, lstm_fwd_cluster, lstm_bwd_cluster,
+               lstm_fwd_fused, gemm_tnb):
+        monkeypatch.setattr(dev, fn.__name__, fn)
+    monkeypatch.setattr(dev, "cu_count", lambda device: 256)
+    _PACKS.clear()

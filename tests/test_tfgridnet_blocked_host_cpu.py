@@ -1,0 +1,78 @@
+"""CPU: numerics of the TF-GridNet blocked-layout recurrence path (functional_tfgridnet.BlstmLinearBlkFn, opt-in
+WESEP_TFGRID_BLOCKED=1) on the blocked-layout emulation (tests/emu_blk.py): against plain torch autograd for the
+function itself -- outputs and every gradient, with sequence padding (cluster branch), the 16-sequence branch and the
+fused-projection branch -- and the whole recipe-geometry model against its default path."""
+import pytest
+import torch
+
+from tests import emu_blk, emu_dev
+
+
+@pytest.fixture
+def emu(monkeypatch):
+    emu_dev.install(monkeypatch)
+    emu_blk.install(monkeypatch)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    monkeypatch.setenv("WESEP_WGRAD_OVERLAP", "0")
+
+
+def _reference(y, res, nseq, Lr, lstm, lin):
+    out, _ = lstm(y.view(nseq, Lr, 128))
+    return res + lin(out.reshape(nseq * Lr, -1))
+
+
+@pytest.mark.parametrize("nseq,Lr,branch", [(5, 70, "cluster (padded to 64)"), (3, 9, "16-sequence"),
+                                            (40, 4, "16-sequence, two tiles"), (4100, 2, "fused projection")])
+def test_blstm_linear_blocked_matches_torch(emu, nseq, Lr, branch):
+    from wesep_amd import dev
+    from wesep_amd import functional_tfgridnet as FG
+    torch.manual_seed(nseq)
+    h = 192
+    lstm = torch.nn.LSTM(128, h, 1, batch_first=True, bidirectional=True)
+    lin = torch.nn.Linear(2 * h, 128)
+    y = torch.randn(nseq * Lr, 128, requires_grad=True)
+    res = torch.randn(nseq * Lr, 128, requires_grad=True)
+    probe = torch.randn(nseq * Lr, 128)
+    # which branch the host code takes (the emulation reports 256 CUs)
+    ns = nseq + ((-nseq) % 64 if Lr >= 64 else 0)
+    seq = dev.SeqMap(ns, dev.BIG, 0, Lr, 1, Lr)
+    cluster = dev.lstm_cluster_ok(seq, torch.device("cpu"))
+    assert ("cluster" in branch) == cluster and ("fused" in branch) == dev.lstm_fuse_ok(ns, cluster)
+    wf, hf, bf = FG.pad_lstm(lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
+    wr, hr, br = FG.pad_lstm(lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse,
+                             lstm.bias_hh_l0_reverse)
+    out = FG.BlstmLinearBlkFn.apply(y, res, (nseq, Lr), wf, wr, bf, br, hf, hr, FG.pad_hidden_cols(lin.weight, h),
+                                    lin.bias)
+    (out * probe).sum().backward()
+    got = {"y": y.grad.clone(), "res": res.grad.clone(),
+           **{k: p.grad.clone() for k, p in list(lstm.named_parameters()) + [("lin." + k, p) for k, p in lin.named_parameters()]}}
+    for t in [y, res] + list(lstm.parameters()) + list(lin.parameters()):
+        t.grad = None
+    ref = _reference(y, res, nseq, Lr, lstm, lin)
+    (ref * probe).sum().backward()
+    want = {"y": y.grad, "res": res.grad,
+            **{k: p.grad for k, p in list(lstm.named_parameters()) + [("lin." + k, p) for k, p in lin.named_parameters()]}}
+    assert float((out - ref).norm() / ref.norm()) < 1e-5
+    for k in want:
+        assert float((got[k] - want[k]).norm()) <= 1e-4 * float(want[k].norm()) + 1e-6, k
+
+
+def test_recipe_geometry_model_blocked_equals_default(emu, monkeypatch):
+    from wesep_amd.models import get_model
+    torch.manual_seed(0)
+    model = get_model("TFGridNet")(n_fft=128, stride=64, n_layers=1, lstm_hidden_units=192, attn_n_head=4,
+                                   attn_approx_qk_dim=512, emb_dim=128, emb_ks=1, emb_hs=1, use_spk_transform=False,
+                                   spk_fuse_type="multiply", joint_training=False).train()
+    g = torch.Generator().manual_seed(1)
+    wav, emb = 0.1 * torch.randn(2, 1280, generator=g), torch.randn(2, 256, generator=g)
+    probe = torch.randn(2, 1280, generator=g)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WESEP_TFGRID_BLOCKED", flag)
+        model.zero_grad(set_to_none=True)
+        est, _ = model(wav, emb)
+        (est * probe).sum().backward()
+        res[flag] = (est.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+    assert float((res["1"][0] - res["0"][0]).norm() / res["0"][0].norm()) < 1e-5
+    for k, g0 in res["0"][1].items():
+        assert float((res["1"][1][k] - g0).norm()) <= 1e-4 * float(g0.norm()) + 1e-7, k
