@@ -215,6 +215,62 @@ def gemm_tnb(*, G, g_width, g_off, g_cols, A0, a0_width, a0_off, a0_cols, nblk, 
         aslab.reshape(-1)[:acols] = a.sum((0, 1))
 
 
+# ---- GroupNorm(1, C) pieces on the general group geometry of norm.hip (no per-band widths) -------------------------
+def _group_index(geo):
+    """[ngroups, L, W] element offsets: base(g) = (g / gdiv) * gs1 + (g % gdiv) * gs2, row stride rs."""
+    assert geo.band_w is None and geo.nbands == 1
+    g = torch.arange(geo.ngroups).view(-1, 1, 1)
+    return (g // geo.gdiv) * geo.gs1 + (g % geo.gdiv) * geo.gs2 + torch.arange(geo.L).view(1, -1, 1) * geo.rs + \
+        torch.arange(geo.W).view(1, 1, -1)
+
+
+def make_group_stats(row_stats):
+    def group_stats(x, geo, stats, eps=1.1920928955078125e-07):
+        if geo.L == 1 and geo.gdiv == 1 and geo.gs2 == 0:
+            return row_stats(x, geo, stats, eps)
+        v = x.reshape(-1)[_group_index(geo)].reshape(geo.ngroups, -1)
+        mean = v.mean(1)
+        stats.reshape(-1, 2)[:, 0] = mean
+        stats.reshape(-1, 2)[:, 1] = 1.0 / torch.sqrt(((v - mean.unsqueeze(1)) ** 2).mean(1) + eps)
+    return group_stats
+
+
+def make_gn_bwd_reduce(row_reduce):
+    def gn_bwd_reduce(x, dxn, stats, geo, ab, gamma=None, gamma_tab=None):
+        if geo.L == 1 and geo.gdiv == 1:
+            return row_reduce(x, dxn, stats, geo, ab, gamma, gamma_tab)
+        assert gamma_tab is None
+        idx = _group_index(geo)
+        st = stats.reshape(-1, 2)
+        xh = (x.reshape(-1)[idx] - st[:, 0].view(-1, 1, 1)) * st[:, 1].view(-1, 1, 1)
+        dg = dxn.reshape(-1)[idx] * gamma.reshape(-1)[: geo.W]
+        ab.reshape(-1, 2)[:, 0] = dg.reshape(geo.ngroups, -1).mean(1)
+        ab.reshape(-1, 2)[:, 1] = (dg * xh).reshape(geo.ngroups, -1).mean(1)
+    return gn_bwd_reduce
+
+
+def gn_bwd_apply(x, dxn, stats, ab, geo, dx, gamma=None, gamma_tab=None, res=None):
+    assert gamma_tab is None
+    idx = _group_index(geo)
+    st, a = stats.reshape(-1, 2), ab.reshape(-1, 2)
+    xh = (x.reshape(-1)[idx] - st[:, 0].view(-1, 1, 1)) * st[:, 1].view(-1, 1, 1)
+    out = st[:, 1].view(-1, 1, 1) * (dxn.reshape(-1)[idx] * gamma.reshape(-1)[: geo.W] - a[:, 0].view(-1, 1, 1) -
+                                     xh * a[:, 1].view(-1, 1, 1))
+    if res is not None:
+        out = out + res.reshape(-1)[idx]
+    dx.reshape(-1)[idx] = out
+
+
+def gn_param_grad(x, dxn, stats, geo, nsplit, slab):
+    idx = _group_index(geo)
+    st = stats.reshape(-1, 2)
+    xh = (x.reshape(-1)[idx] - st[:, 0].view(-1, 1, 1)) * st[:, 1].view(-1, 1, 1)
+    d = dxn.reshape(-1)[idx]
+    slab.reshape(-1)[: nsplit * 2 * geo.W] = 0.0
+    slab.reshape(-1)[: geo.W] = (d * xh).sum((0, 1))            # d gamma
+    slab.reshape(-1)[geo.W: 2 * geo.W] = d.sum((0, 1))          # d beta
+
+
 def install(monkeypatch):
     """After emu_dev.install: adds the BL entry points (and BL modes of lstm_fwd / lstm_bwd)."""
     import wesep_amd.dev as dev
@@ -223,5 +279,9 @@ def install(monkeypatch):
     for fn in (pack_w, lstm_cat_ih, lstm_pack_fused, gemm_p2b, gemm_b2p, lstm_fwd_cluster, lstm_bwd_cluster,
                lstm_fwd_fused, gemm_tnb):
         monkeypatch.setattr(dev, fn.__name__, fn)
+    monkeypatch.setattr(dev, "group_stats", make_group_stats(dev.group_stats))
+    monkeypatch.setattr(dev, "gn_bwd_reduce", make_gn_bwd_reduce(dev.gn_bwd_reduce))
+    monkeypatch.setattr(dev, "gn_bwd_apply", gn_bwd_apply)
+    monkeypatch.setattr(dev, "gn_param_grad", gn_param_grad)
     monkeypatch.setattr(dev, "cu_count", lambda device: 256)
     _PACKS.clear()

@@ -1,0 +1,65 @@
+"""CPU: numerics of the pBSRNN ResRNN on the blocked layout (functional.ResRNNBlkFn -- the production path of the
+headline metric) on the blocked-layout emulation (tests/emu_blk.py), against the oracle's ResRNN with torch autograd:
+output, input gradient and all twelve parameter gradients, both views, in the 16-sequence, cluster and
+fused-projection branches.  The kernels are covered by tests/test_bsrnn_gpu.py; this pins the HOST composition
+(sequence / statistics maps, pack orders, gradient routing, weight-gradient shifts) so that it can be refactored
+without a GPU."""
+import pytest
+import torch
+
+from oracle import bsrnn_oracle as O
+from tests import emu_blk, emu_dev
+
+NAMES = ("rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0", "rnn.bias_hh_l0", "rnn.weight_ih_l0_reverse",
+         "rnn.weight_hh_l0_reverse", "rnn.bias_ih_l0_reverse", "rnn.bias_hh_l0_reverse", "proj.weight", "proj.bias")
+
+
+@pytest.fixture
+def emu(monkeypatch):
+    emu_dev.install(monkeypatch)
+    emu_blk.install(monkeypatch)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    monkeypatch.setenv("WESEP_WGRAD_OVERLAP", "0")
+
+
+def _params(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = {"norm.weight": (128,), "norm.bias": (128,), "rnn.weight_ih_l0": (1024, 128), "rnn.weight_hh_l0": (1024, 256),
+              "rnn.bias_ih_l0": (1024,), "rnn.bias_hh_l0": (1024,), "rnn.weight_ih_l0_reverse": (1024, 128),
+              "rnn.weight_hh_l0_reverse": (1024, 256), "rnn.bias_ih_l0_reverse": (1024,),
+              "rnn.bias_hh_l0_reverse": (1024,), "proj.weight": (128, 512), "proj.bias": (128,)}
+    p = {k: (0.06 * torch.randn(s, generator=g)) for k, s in shapes.items()}
+    p["norm.weight"] = 1.0 + 0.1 * torch.randn(128, generator=g)
+    return {k: v.requires_grad_(True) for k, v in p.items()}
+
+
+@pytest.mark.parametrize("view,R,K,Tf,branch", [
+    ("time", 1, 3, 9, "16-sequence"), ("time", 2, 32, 66, "cluster"), ("band", 2, 4, 5, "16-sequence"),
+    ("band", 2, 3, 2100, "fused projection")])
+def test_resrnn_blocked_matches_oracle(emu, view, R, K, Tf, branch):
+    from wesep_amd import dev
+    from wesep_amd import functional as F0
+    p = _params(R * 100 + K)
+    g = torch.Generator().manual_seed(Tf)
+    z = torch.randn(R, K, Tf, 128, generator=g).requires_grad_(True)
+    probe = torch.randn(R, K, Tf, 128, generator=g)
+    _, _, seq, _ = F0._view_maps(view, R, K, Tf, 128)
+    cluster = dev.lstm_cluster_ok(seq, torch.device("cpu"))
+    assert ("cluster" in branch) == cluster and ("fused" in branch) == dev.lstm_fuse_ok(seq.nseq, cluster)
+    out = F0.ResRNNBlkFn.apply(z, None, None, view, p["norm.weight"], p["norm.bias"], *(p[n] for n in NAMES))
+    (out * probe).sum().backward()
+    got = {"z": z.grad.clone(), **{k: v.grad.clone() for k, v in p.items()}}
+    z.grad = None
+    for v in p.values():
+        v.grad = None
+    if view == "time":          # sequences (r, k) over t
+        x = z.permute(0, 1, 3, 2).reshape(R * K, 128, Tf)
+        ref = O.res_rnn(p, "", x).view(R, K, 128, Tf).permute(0, 1, 3, 2)
+    else:                       # sequences (r, t) over k
+        x = z.permute(0, 2, 3, 1).reshape(R * Tf, 128, K)
+        ref = O.res_rnn(p, "", x).view(R, Tf, 128, K).permute(0, 3, 1, 2)
+    (ref * probe).sum().backward()
+    assert float((out - ref).norm() / ref.norm()) < 1e-5
+    want = {"z": z.grad, **{k: v.grad for k, v in p.items()}}
+    for k in want:
+        assert float((got[k] - want[k]).norm()) <= 2e-4 * float(want[k].norm()) + 1e-6, k
