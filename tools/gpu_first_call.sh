@@ -11,7 +11,7 @@ for view in time band; do
   echo "== lstm_bench ${view}: exit $?"; cat "gpurun_out/lstm_bench_${view}.txt"
 done
 for t in fbank bsrnn_multi engine tfgridnet_blocked; do
-  timeout 600 python -m pytest "tests/test_z_pending_${t}_gpu.py" -q --tb=short -m gpu > "gpurun_out/pending_${t}.log" 2>&1
+  timeout 600 python -m pytest "tests/test_z_pending_${t}_gpu.py" -q --tb=short -m gpu --runxfail > "gpurun_out/pending_${t}.log" 2>&1
   echo "== pending ${t}: exit $?"; tail -n 15 "gpurun_out/pending_${t}.log"
 done
 timeout 300 python tools/bench_engine.py > gpurun_out/engine_bench.json 2> gpurun_out/engine_bench.err
