@@ -87,11 +87,15 @@ class SISDRFn:
         return O.sisdr_loss(est, tgt, eps)
 
 
-def install(monkeypatch):
-    """On top of emu_dev.install (entry-point emulation for the speaker encoder / front-end / linear layers)."""
+def install(monkeypatch, real_resrnn=False):
+    """On top of emu_dev.install (entry-point emulation for the speaker encoder / front-end / linear layers).
+    `real_resrnn=True` keeps the product's blocked-layout ResRNN (functional.ResRNNBlkFn) in place -- it then needs
+    tests/emu_blk.py installed as well -- and only stands in for the band split, mask decode, fusion and loss."""
     import wesep_amd.functional as f0
     for name, obj in (("BandSplitFn", BandSplitFn), ("MaskDecodeFn", MaskDecodeFn), ("resrnn", resrnn),
                       ("AffineFn", AffineFn), ("ConcatFuseFn", ConcatFuseFn), ("SISDRFn", SISDRFn)):
+        if name == "resrnn" and real_resrnn:
+            continue
         monkeypatch.setattr(f0, name, obj)
     monkeypatch.setattr(f0, "make_wgrad_carrier", lambda params: None)
     monkeypatch.setattr(f0, "reset_deferred_wgrads", lambda device: None)
