@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 6
+#define WS_ABI_VERSION 7
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -157,6 +157,9 @@ typedef struct ws_lstm_args {
   const float* wpack;   /* ws_lstm_pack output for this pass (fwd or bwd)     */
   long long sq_s1, sq_s2, step_rows;
   int nseq, sq_div, L, mode;   /* WS_LSTM_* below; must match the mode wpack was packed with */
+  const unsigned* run_if;      /* ws_lstm_fwd, blocked-layout modes only: optional device word; when given, the
+                                  launch does nothing unless *run_if != 0 at kernel start (the predicated
+                                  fall-back behind ws_lstm_fwd_cluster, see there)                        */
 } ws_lstm_args;
 #define WS_LSTM_F32_MT1 1 /* exact-fp32 MFMA, 16 sequences per workgroup                       */
 #define WS_LSTM_F32_MT2 2 /* exact-fp32 MFMA, 32 sequences per workgroup                       */
@@ -178,8 +181,14 @@ int ws_lstm_bwd(const ws_lstm_args* a, void* stream);
 /* Weight-stationary forward recurrence over clusters of 8 co-resident workgroups (blocked layout,
  * same gates / cbuf / hcat contract as WS_LSTM_BF16X3_BLK): W_hh stays in registers, h_t is exchanged
  * through `xchg` each step.  nseq % 64 == 0 and (nseq / 32) * 8 <= CUs of the device (checked).
- * xchg: (nseq / 32) * 128 KB scratch; flags: (nseq / 32) * 8 words (zeroed by the call on `stream`);
- * status (optional): set to 1 if a bounded wait timed out (outputs are then NaN).               */
+ * xchg: (nseq / 32) * 128 KB scratch; flags: (nseq / 32) * 8 + 8 words (zeroed by the call on `stream`).
+ * Residency of the whole grid is a precondition the launcher can only check against the CU count, not
+ * against CUs held by other streams / processes, so every wait is bounded.  If one times out the outputs
+ * are NaN-poisoned AND the launch's own timeout word  flags[(nseq / 32) * 8]  is set to 1 (it is 0 after a
+ * clean launch); `status` (optional, sticky, never cleared by the library) is set to 1 as well.  Callers
+ * enqueue the streaming kernels behind this launch with  run_if = &flags[(nseq / 32) * 8]  (ws_gemm_p2b to
+ * rebuild the pre-activations, then ws_lstm_fwd): they cost an empty launch after a clean run and redo the
+ * layer after a timeout, without a host round trip.                                               */
 typedef struct ws_lstm_cluster_args {
   float* gates;
   float* cbuf;
@@ -191,11 +200,13 @@ typedef struct ws_lstm_cluster_args {
   unsigned* flags;
   unsigned* status;
   int nseq, L;
-  int dbg, pad_;        /* probe builds only: 1 skip the flag wait, 2 skip the gather, 4 skip the publish */
+  int dbg, pad_;        /* probes / tests only: 1 skip the flag wait, 2 skip the gather, 4 skip the publish,
+                           8 force a timeout in workgroup 0 at step 2 (exercises the fall-back)      */
 } ws_lstm_cluster_args;
 int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream);
 /* BPTT over the same clusters (reduce-scatter of partial dh each step): gates holds the activated
- * gates on entry and d(pre-activation gates) on exit; xchg: (nseq / 32) * 1 MB.                 */
+ * gates on entry and d(pre-activation gates) on exit; xchg: (nseq / 32) * 1 MB; flags / status as above
+ * (in place on `gates`: there is no device-side fall-back, the caller checks the timeout word).  */
 int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream);
 /* wcat[2][4H][N] <- (w_ih_f, w_ih_r);  bcat[2][4H] <- b_ih + b_hh per direction             */
 int ws_lstm_cat_ih(const float* wih_f, const float* wih_r, const float* bih_f, const float* bhh_f,
@@ -235,6 +246,7 @@ typedef struct ws_gemm_p2b_args {
   ws_seqmap sm;
   long long lda, st_m1, st_m2, st_base;
   int st_div1, st_div2, N, K;
+  const unsigned* run_if;   /* optional device word: the launch does nothing unless *run_if != 0 */
 } ws_gemm_p2b_args;
 int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream);
 

@@ -306,6 +306,8 @@ int load_container(ws_engine* e, const char* path) {
       int64_t v = 0;
       ok = read_exact(f, &v, 8) && v >= 0;
       t.dims.push_back(v);
+      // overflow-checked product: a crafted container must not wrap n (and pass the bounds check below)
+      if (ok && v != 0 && t.n > (uint64_t(1) << 40) / static_cast<uint64_t>(v)) ok = false;
       t.n *= static_cast<size_t>(v);
     }
     uint64_t off = 0;
@@ -325,7 +327,7 @@ int load_container(ws_engine* e, const char* path) {
     return WS_ERR_INVALID;
   }
   for (auto& kv : e->tensors) {
-    if (kv.second.off + kv.second.n > e->hw.size()) {
+    if (kv.second.n > e->hw.size() || kv.second.off > e->hw.size() - kv.second.n) {   // no wrap-around
       set_err("engine: tensor %s exceeds the data section", kv.first.c_str());
       return WS_ERR_INVALID;
     }
@@ -776,12 +778,24 @@ int resrnn(ws_engine* e, const RnnPrep& w, bool time_view, const float* z, int R
     if (cluster) {
       const int ncl = sm.nseq / 32;
       float* xchg = a.alloc(size_t(ncl) * 2 * 8 * 8192 / 4);
-      unsigned* flags = reinterpret_cast<unsigned*>(a.alloc(size_t(ncl) * 8));
+      unsigned* flags = reinterpret_cast<unsigned*>(a.alloc(size_t(ncl) * 8 + 8));
       WS_PTR(xchg && flags);
       ws_lstm_cluster_args c = {};
       c.gates = gates, c.cbuf = cbuf, c.hcat = hcat, c.whh_f = w.whf, c.whh_r = w.whr;
       c.xchg = xchg, c.flags = flags, c.nseq = sm.nseq, c.L = sm.L;
       WS_RUN(e, ws_lstm_fwd_cluster(&c, s));
+      // Several engines may share one GPU (separate_main --jobs): the cluster's workgroups are then not guaranteed to
+      // be co-resident and a bounded wait can time out.  The streaming pair below is predicated on this launch's
+      // timeout word: empty launches after a clean run, the whole layer again after a timeout -- never NaN.
+      p.run_if = flags + size_t(ncl) * 8;
+      WS_RUN(e, ws_gemm_p2b(&p, s));
+      ws_lstm_args l = {};
+      l.gates = gates, l.cbuf = cbuf, l.hcat = hcat;
+      l.wpack = lmode == WS_LSTM_BF16X3_BLK16 ? w.pack16 : w.pack32;
+      l.sq_s1 = sm.sq_s1, l.sq_s2 = sm.sq_s2, l.step_rows = sm.step_rows;
+      l.nseq = sm.nseq, l.sq_div = sm.sq_div, l.L = sm.L, l.mode = lmode;
+      l.run_if = p.run_if;
+      WS_RUN(e, ws_lstm_fwd(&l, s));
     } else {
       ws_lstm_args l = {};
       l.gates = gates, l.cbuf = cbuf, l.hcat = hcat;

@@ -51,7 +51,19 @@ inline bool read_wav(const std::string& path, Wav* out, std::string* err) {
     } else if (!memcmp(id, "data", 4)) {
       if (!have_fmt) return fail("data chunk before fmt chunk");
       if (format != 1 || bits != 16 || channels < 1) return fail("only 16-bit PCM is supported");
-      const size_t frames = size / (2u * channels);
+      // the header's size is untrusted (streamed files carry 0xFFFFFFFF, crafted ones anything): never allocate more
+      // than the file still holds
+      size_t remaining = 0;
+      {
+        const long here = ftell(f);
+        if (here >= 0 && fseek(f, 0, SEEK_END) == 0) {
+          const long end = ftell(f);
+          if (end > here) remaining = static_cast<size_t>(end - here);
+          fseek(f, here, SEEK_SET);
+        }
+      }
+      const size_t bytes = size < remaining ? size : remaining;
+      const size_t frames = bytes / (2u * channels);
       std::vector<int16_t> raw(frames * channels);
       const size_t got = fread(raw.data(), 2, raw.size(), f) / channels;   // tolerate truncated files
       out->samples.resize(got);

@@ -56,8 +56,15 @@ def lstm_pack_fused(wih_f, wih_r, whh_f, whh_r, pack):
     _PACKS[pack.data_ptr()] = tuple(t.clone() for t in (wih_f, wih_r, whh_f, whh_r))
 
 
+def _skip(run_if):
+    """Predicated launches (wesep_hip.h run_if): a no-op unless the word is non-zero."""
+    return run_if is not None and int(run_if.reshape(-1)[0]) == 0
+
+
 def gemm_p2b(*, A, lda, sm, Wpack, N, C_out, K=128, bias=None, A_bl=None, stats=None, gamma=None, beta=None,
-             stat_map=None):
+             stat_map=None, run_if=None):
+    if _skip(run_if):
+        return
     nt, L = _ntile(sm), sm.L
     pos = _positions(sm)
     rows = A.reshape(-1, lda)[pos.reshape(-1), :K].reshape(nt * 32, L, K)
@@ -141,7 +148,9 @@ def _whh_from_pack(wpack):
 
 
 def make_lstm_fwd(plain_fwd):
-    def lstm_fwd(gates, cbuf, hcat, wpack, sm, mode=3):
+    def lstm_fwd(gates, cbuf, hcat, wpack, sm, mode=3, run_if=None):
+        if _skip(run_if):
+            return
         if mode not in (4, 5):
             return plain_fwd(gates, cbuf, hcat, wpack, sm, mode)
         nt, L = _ntile(sm), sm.L
@@ -169,8 +178,15 @@ def _bwd_into(gates, cbuf, dhcat, whf, whr, sm):
 
 
 def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm, status=None, dbg=0):
+    """Returns the launch's timeout word like dev.lstm_fwd_cluster; dbg & 8 emulates a timeout: NaN-poisoned outputs
+    and a set word, so the caller's predicated fall-back has to produce the result."""
     nt, L = _ntile(sm), sm.L
+    if dbg & 8:
+        for t in (gates, cbuf, hcat):
+            t.fill_(float("nan"))
+        return torch.ones(1, dtype=torch.int32)
     _fwd_into(gates, cbuf, hcat, bl_get(gates, nt, L, 2 * G4).reshape(nt * 32, L, 2, G4), whh_f, whh_r, sm)
+    return torch.zeros(1, dtype=torch.int32)
 
 
 def lstm_bwd_cluster(gates, cbuf, dhcat, whh_f, whh_r, sm, status=None, dbg=0):

@@ -53,7 +53,7 @@ class MaskDecodeFn:
         return torch.istft(torch.cat(bands, 1), n_fft=WIN, hop_length=HOP, window=window, length=T)
 
 
-def resrnn(z, view, norm_w, norm_b, *params, carrier=None):
+def resrnn(z, view, norm_w, norm_b, *params, carrier=None, cache=None):
     R, K, Tf, N = z.shape
     names = ("rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0", "rnn.bias_hh_l0", "rnn.weight_ih_l0_reverse",
              "rnn.weight_hh_l0_reverse", "rnn.bias_ih_l0_reverse", "rnn.bias_hh_l0_reverse", "proj.weight", "proj.bias")

@@ -16,10 +16,7 @@ import torch
 from oracle import bsrnn_oracle as O
 from oracle.make_golden import MULTI_CASES, multi_embed_fn, synth_multi_params
 
-# Written without hardware access.  Until the first green run on an MI355X a failure here is reported as XFAIL (and a
-# pass as XPASS) instead of stopping the `-x` GPU suite in front of nothing; remove the marker -- and the `z_pending`
-# prefix -- after that run.
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(reason="first run on hardware pending", strict=False)]
+pytestmark = pytest.mark.gpu
 
 
 def _cuda():

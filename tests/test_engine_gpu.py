@@ -13,10 +13,7 @@ from oracle import bsrnn_oracle as O
 from wesep_amd import engine as E
 from wesep_amd.bin.export_engine import export_engine
 
-# Written without hardware access.  Until the first green run on an MI355X a failure here is reported as XFAIL (and a
-# pass as XPASS) instead of stopping the `-x` GPU suite in front of nothing; remove the marker -- and the `z_pending`
-# prefix -- after that run.
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(reason="first run on hardware pending", strict=False)]
+pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SPK_ARGS = dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False)
 

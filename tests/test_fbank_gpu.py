@@ -12,10 +12,7 @@ import torch
 from oracle import fbank_oracle as FB
 from oracle.make_golden import FBANK_CASES, synth_fbank_wave
 
-# Written without hardware access.  Until the first green run on an MI355X a failure here is reported as XFAIL (and a
-# pass as XPASS) instead of stopping the `-x` GPU suite in front of nothing; remove the marker -- and the `z_pending`
-# prefix -- after that run.
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(reason="first run on hardware pending", strict=False)]
+pytestmark = pytest.mark.gpu
 
 
 def _close(got, want, max_tol=2e-3, mean_tol=3e-5):

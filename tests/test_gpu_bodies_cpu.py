@@ -1,4 +1,4 @@
-"""CPU: the bodies of the GPU tests that have not run on hardware yet (tests/test_z_pending_*_gpu.py), executed on
+"""CPU: the bodies of the GPU tests that have not run on hardware yet (tests/test_*_gpu.py), executed on
 the CPU emulations (tests/emu_dev.py entry points, tests/emu_bsrnn.py pBSRNN functions) with `cuda:0` replaced by the
 CPU.  This checks the tests themselves -- shapes, fixture keys, tolerances against emulated fp32 numerics, the manual
 two-pass compositions they compare with -- so that their first run on a GPU tests the kernels and not the test code.
@@ -24,7 +24,7 @@ def emu(monkeypatch):
 
 
 def test_fbank_gpu_test_bodies(emu, monkeypatch, golden_dir):
-    import tests.test_z_pending_fbank_gpu as t
+    import tests.test_fbank_gpu as t
     monkeypatch.setattr(t, "_cuda", lambda: torch.device("cpu"))
     for name in sorted(t.FBANK_CASES):
         t.test_fbank_matches_reference_cpp_fixture(name, golden_dir)
@@ -34,7 +34,7 @@ def test_fbank_gpu_test_bodies(emu, monkeypatch, golden_dir):
 
 
 def test_bsrnn_multi_gpu_test_bodies(emu, monkeypatch, golden_dir):
-    import tests.test_z_pending_bsrnn_multi_gpu as t
+    import tests.test_bsrnn_multi_gpu as t
     monkeypatch.setattr(t, "_cuda", lambda: torch.device("cpu"))
     for name in sorted(t.MULTI_CASES):
         t.test_bsrnn_multi_two_pass_forward_and_gradients(name, golden_dir)

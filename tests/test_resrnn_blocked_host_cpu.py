@@ -46,7 +46,7 @@ def test_resrnn_blocked_matches_oracle(emu, view, R, K, Tf, branch):
     _, _, seq, _ = F0._view_maps(view, R, K, Tf, 128)
     cluster = dev.lstm_cluster_ok(seq, torch.device("cpu"))
     assert ("cluster" in branch) == cluster and ("fused" in branch) == dev.lstm_fuse_ok(seq.nseq, cluster)
-    out = F0.ResRNNBlkFn.apply(z, None, None, view, p["norm.weight"], p["norm.bias"], *(p[n] for n in NAMES))
+    out = F0.ResRNNBlkFn.apply(z, None, None, None, view, p["norm.weight"], p["norm.bias"], *(p[n] for n in NAMES))
     (out * probe).sum().backward()
     got = {"z": z.grad.clone(), **{k: v.grad.clone() for k, v in p.items()}}
     z.grad = None
@@ -63,3 +63,52 @@ def test_resrnn_blocked_matches_oracle(emu, view, R, K, Tf, branch):
     want = {"z": z.grad, **{k: v.grad for k, v in p.items()}}
     for k in want:
         assert float((got[k] - want[k]).norm()) <= 2e-4 * float(want[k].norm()) + 1e-6, k
+
+
+def _oracle_time(p, z, R, K, Tf):
+    x = z.permute(0, 1, 3, 2).reshape(R * K, 128, Tf)
+    return O.res_rnn(p, "", x).view(R, K, 128, Tf).permute(0, 1, 3, 2)
+
+
+def test_cluster_timeout_falls_back_to_the_streaming_kernels(emu, monkeypatch):
+    """A cluster launch that times out (emulated: NaN-poisoned outputs + its timeout word set, as lstm_cluster.hip does)
+    must be repaired by the predicated gemm_p2b + lstm_fwd launches behind it -- and those must be no-ops after a
+    clean launch (the emulation would otherwise apply the recurrence twice to the activated gates)."""
+    from wesep_amd import functional as F0
+    R, K, Tf = 2, 32, 66
+    p = _params(7)
+    z = torch.randn(R, K, Tf, 128, generator=torch.Generator().manual_seed(3))
+    ref = _oracle_time(p, z, R, K, Tf)
+    for force in ("0", "1"):
+        monkeypatch.setenv("WESEP_CLUSTER_FORCE_TIMEOUT", force)
+        with torch.no_grad():
+            out = F0.ResRNNBlkFn.apply(z, None, None, None, "time", p["norm.weight"], p["norm.bias"], *(p[n] for n in NAMES))
+        assert torch.isfinite(out).all()
+        assert float((out - ref).norm() / ref.norm()) < 1e-5, force
+
+
+def test_pack_cache_follows_the_weights_and_second_backward_is_refused(emu):
+    from wesep_amd import dev
+    from wesep_amd import functional as F0
+    from wesep_amd import _lib as L
+    R, K, Tf = 1, 3, 9
+    p = _params(11)
+    z = torch.randn(R, K, Tf, 128, generator=torch.Generator().manual_seed(5))
+    cache = F0.PackCache()
+    args = lambda: (z, None, None, cache, "time", p["norm.weight"], p["norm.bias"], *(p[n] for n in NAMES))
+    out1 = F0.ResRNNBlkFn.apply(*args())
+    items1 = dict(cache.items)
+    out2 = F0.ResRNNBlkFn.apply(*args())
+    assert torch.equal(out1, out2) and all(cache.items[k] is v for k, v in items1.items())     # packs reused
+    with torch.no_grad():
+        p["rnn.weight_hh_l0"].mul_(0.5)                                                        # version counter moves
+    out3 = F0.ResRNNBlkFn.apply(*args())
+    assert float((out3 - _oracle_time(p, z, R, K, Tf)).norm() / out3.norm()) < 1e-5            # rebuilt, not stale
+    p["proj.weight"].data.mul_(2.0)          # raw write, invisible to torch (what ws_clip_adam_step does) ...
+    dev.bump_weight_epoch()                  # ... announced the way dev.clip_adam_step announces it
+    out4 = F0.ResRNNBlkFn.apply(*args())
+    assert float((out4 - _oracle_time(p, z, R, K, Tf)).norm() / out4.norm()) < 1e-5
+    # a second backward through one graph would differentiate the d(gates) the first one left in the saved buffer
+    out4.sum().backward(retain_graph=True)
+    with pytest.raises(L.WesepHipError, match="second backward"):
+        out4.sum().backward()

@@ -1,15 +1,12 @@
-"""GPU: TF-GridNet's opt-in blocked-layout recurrence path (WESEP_TFGRID_BLOCKED=1, functional_tfgridnet
-.BlstmLinearBlkFn) against the default path on the same device: same module, same weights, the recipe geometry
+"""GPU: TF-GridNet's blocked-layout recurrence path (functional_tfgridnet.BlstmLinearBlkFn; WESEP_TFGRID_BLOCKED=0
+selects the row-major path) against that row-major path on the same device: same module, same weights, the recipe geometry
 (emb_dim 128, emb_ks = emb_hs = 1).  Both paths compute split-bf16 products with fp32 accumulation, in different
 orders: agreement to 1e-3 on the waveform and 2e-2 on gradient norms means the composition is right (a wrong sequence
 map, pack order or gradient routing is an O(1) error)."""
 import pytest
 import torch
 
-# Written without hardware access.  Until the first green run on an MI355X a failure here is reported as XFAIL (and a
-# pass as XPASS) instead of stopping the `-x` GPU suite in front of nothing; remove the marker -- and the `z_pending`
-# prefix -- after that run.
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(reason="first run on hardware pending", strict=False)]
+pytestmark = pytest.mark.gpu
 
 
 def _cuda():
@@ -43,8 +40,13 @@ def test_blocked_path_matches_default_path(monkeypatch, B, T):
     e1, g1 = results["1"]
     assert torch.isfinite(e1).all()
     assert float((e1 - e0).norm() / e0.norm()) < 1e-3
+    # Gradients that are zero in exact arithmetic are rounding noise in both paths and cannot be compared relatively:
+    # attn_norm_K.beta adds the same vector to every key of a head, which shifts all logits of a query equally and
+    # leaves the softmax unchanged (first hardware run, round 2: norm 9.9e-6 vs 9.5e-6 next to O(1) gradients).
+    # Hence a noise floor relative to the median gradient norm, and full-tensor differences instead of norms.
+    floor = 1e-4 * float(torch.stack([g.norm() for g in g0.values()]).median())
     for k in g0:
         n0 = float(g0[k].norm())
-        assert abs(float(g1[k].norm()) - n0) <= 2e-2 * n0 + 1e-7, k
+        assert float((g1[k] - g0[k]).norm()) <= 2e-3 * n0 + floor, (k, n0, float(g1[k].norm()))
     loss = parse_loss("SISDR")[0](e1, tgt)
     assert torch.isfinite(loss)

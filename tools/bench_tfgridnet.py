@@ -20,10 +20,10 @@ def main():
     ap.add_argument("--recipe", action="store_true",
                     help="model_args of examples/librimix/tse/v2/confs/tfgridnet.yaml (emb_dim 128, emb_ks = emb_hs = 1) "
                          "instead of the constructor defaults (emb_dim 48, emb_ks 4)")
-    ap.add_argument("--blocked", action="store_true", help="WESEP_TFGRID_BLOCKED=1 (needs --recipe geometry)")
+    ap.add_argument("--rowmajor", action="store_true",
+                    help="WESEP_TFGRID_BLOCKED=0: the row-major recurrence path instead of the blocked-layout default")
     args = ap.parse_args()
-    if args.blocked:
-        os.environ["WESEP_TFGRID_BLOCKED"] = "1"
+    os.environ["WESEP_TFGRID_BLOCKED"] = "0" if args.rowmajor else "1"
     from wesep_amd.functional import SISDRFn
     from wesep_amd.models import get_model
     from wesep_amd.optim import FusedClipAdam
@@ -55,7 +55,7 @@ def main():
     print(json.dumps({"metric": "utterances/sec (6 s, 16 kHz) fwd+bwd, TF-GridNet (fixed embeddings), 6 s utterances",
                       "value": args.rows * args.steps / el, "unit": "utterances/s",
                       "ms_per_step": el / args.steps * 1e3, "rows": args.rows, "steps": args.steps, "dtype": "bf16x3",
-                      "config": "recipe" if args.recipe else "constructor defaults", "blocked_recurrence": bool(args.blocked),
+                      "config": "recipe" if args.recipe else "constructor defaults", "blocked_recurrence": bool(args.recipe and not args.rowmajor),
                       "data": "synthetic", "final_loss_dB": float(loss.item()),
                       "params_M": sum(p.numel() for p in model.parameters()) / 1e6,
                       "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 6
+ABI_VERSION = 7
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
@@ -50,7 +50,7 @@ class GroupsGeom(C.Structure):
 class LstmArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "dhcat", "wpack")] + \
                [(n, _ll) for n in ("sq_s1", "sq_s2", "step_rows")] + \
-               [(n, _i) for n in ("nseq", "sq_div", "L", "mode")]
+               [(n, _i) for n in ("nseq", "sq_div", "L", "mode")] + [("run_if", _p)]
 
 
 class SeqMapC(C.Structure):
@@ -60,7 +60,7 @@ class SeqMapC(C.Structure):
 class GemmP2BArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("A", "Wpack", "bias", "C", "A_bl", "stats", "gamma", "beta")] + \
                [("sm", SeqMapC)] + [(n, _ll) for n in ("lda", "st_m1", "st_m2", "st_base")] + \
-               [(n, _i) for n in ("st_div1", "st_div2", "N", "K")]
+               [(n, _i) for n in ("st_div1", "st_div2", "N", "K")] + [("run_if", _p)]
 
 
 class GemmB2PArgs(C.Structure):

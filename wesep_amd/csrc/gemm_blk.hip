@@ -102,6 +102,7 @@ extern "C" int ws_pack_w(const float* W, int N, int K, long long ldw, int trans,
 #define P2B_K 128
 __global__ __launch_bounds__(512, 4) void gemm_p2b_kernel(const ws_gemm_p2b_args p) {
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][2048];  // 2 stages x 32 KB
+  if (p.run_if && *p.run_if == 0u) return;  // predicated fall-back launch (wesep_hip.h): uniform
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nblk = ((p.sm.nseq + 31) / 32) * p.sm.L;

@@ -383,6 +383,8 @@ static int lstm_check(const ws_lstm_args* a, bool bwd, const char* who) {
   WS_REQUIRE(a->nseq > 0 && a->L > 0 && a->sq_div > 0, "%s: bad nseq/L/sq_div", who);
   WS_REQUIRE((a->mode & 255) >= WS_LSTM_F32_MT1 && (a->mode & 255) <= WS_LSTM_BF16X3_BLK16, "%s: bad mode %d", who,
              a->mode);
+  WS_REQUIRE(!a->run_if || (!bwd && (a->mode & 255) >= WS_LSTM_BF16X3),
+             "%s: run_if is honoured by the split-bf16 forward kernels only", who);
   return WS_OK;
 }
 

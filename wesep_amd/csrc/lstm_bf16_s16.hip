@@ -79,6 +79,7 @@ int ws_launch_lstm_pack_s16(const float* whh_f, const float* whh_r, float* pack_
 __global__ __launch_bounds__(512, 2) void lstm_fwd_s16_kernel(const ws_lstm_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 hl[2][2][S16 * HROW];  // [buf][part][seq][k] 33 KB
   __shared__ __attribute__((aligned(16))) float cl[S16 * (LH + 4)];     // cell state [seq][unit]
+  if (p.run_if && *p.run_if == 0u) return;  // predicated fall-back launch (wesep_hip.h): uniform
   const int d = blockIdx.y;
   const int tile = blockIdx.x >> 1, hb = blockIdx.x & 1;
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, mq = lane >> 4;

@@ -13,7 +13,8 @@
 // relaxed from one wave, then reads the payload with sc1 loads (L1 bypassed: no acquire fence needed
 // because the producer stored sc1).  Exchange buffers are double-buffered by step parity (a workgroup
 // can publish step t+2 only after everyone published t+1, i.e. consumed t).  All spins are bounded;
-// a timeout poisons the output with NaN and sets *status instead of hanging the GPU.
+// a timeout poisons the output with NaN and sets the launch's timeout word (+ *status) instead of hanging the
+// GPU; the callers enqueue the streaming kernels predicated on that word behind every launch (wesep_hip.h).
 //
 // Residency: the grid (8 workgroups per 64 sequences per direction) must be co-resident, i.e.
 // <= 1 workgroup per CU of the device -- the launcher checks it against the CU count.
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
       reinterpret_cast<char*>(p.xchg) + (long long)c * (2 * 8 * 8192), 0, 2 * 8 * 8192, 0x00020000);
   const int mychunk = (st * 32 + n) * 8 + 2 * uo + half;  // chunk of this thread's h in a producer's slice
   gu32* flags = (gu32*)(p.flags) + c * 8;
+  gu32* tword = (gu32*)(p.flags) + ncl * 8;  // this launch's timeout word (zeroed with the flags)
 
   f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 xpre[2][4];  // M-waves: x-projection of the NEXT step for their two cells
@@ -191,13 +193,15 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
     if (tid == 0) __hip_atomic_store(flags + j, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (w == 0 && dead_s == 0 && !(p.dbg & 1)) {
       unsigned spins = 0;
+      const bool force = (p.dbg & 8) && step == 2 && blockIdx.x == 0;  // tests: a timeout on demand
       while (true) {
         const unsigned v = lane < 8 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                     : 0xffffffffu;
-        if (__all((int)(v >= (unsigned)(step + 1)))) break;
-        if (++spins > CL_SPIN_LIMIT) {
+        if (!force && __all((int)(v >= (unsigned)(step + 1)))) break;
+        if (force || ++spins > CL_SPIN_LIMIT) {
           if (lane == 0) {
             dead_s = 1;
+            __hip_atomic_store(tword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (p.status) __hip_atomic_store((gu32*)(p.status), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           break;
@@ -238,7 +242,7 @@ extern "C" int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream) 
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   WS_REQUIRE(nwg <= cus, "ws_lstm_fwd_cluster: %d workgroups must be co-resident but the device has %d CUs", nwg, cus);
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(a->flags, 0, (size_t)(a->nseq / 32) * 8 * sizeof(unsigned), s);
+  hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)(a->nseq / 32) * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_fwd_cluster: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
   hipLaunchKernelGGL(lstm_fwd_cluster_kernel, dim3(nwg), dim3(512), 0, s, *a);
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_cluster_kernel(const ws_lstm_
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(p.xchg) + (long long)c * (2 * 64 * 8192), 0, 2 * 64 * 8192, 0x00020000);
   gu32* flags = (gu32*)(p.flags) + c * 8;
+  gu32* tword = (gu32*)(p.flags) + ncl * 8;  // this launch's timeout word (zeroed with the flags)
 
   auto step_t = [&](int step) { return d == 0 ? L - 1 - step : step; };
   __syncthreads();
@@ -365,13 +370,15 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_cluster_kernel(const ws_lstm_
       if (tid == 0) __hip_atomic_store(flags + j, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (w == 0 && !dead && !(p.dbg & 1)) {
         unsigned spins = 0;
+        const bool force = (p.dbg & 8) && step == 2 && blockIdx.x == 0;  // tests: a timeout on demand
         while (true) {
           const unsigned v = lane < 8 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                       : 0xffffffffu;
-          if (__all((int)(v >= (unsigned)(step + 1)))) break;
-          if (++spins > CL_SPIN_LIMIT) {
+          if (!force && __all((int)(v >= (unsigned)(step + 1)))) break;
+          if (force || ++spins > CL_SPIN_LIMIT) {
             if (lane == 0) {
               dead_s = 1;
+              __hip_atomic_store(tword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if (p.status) __hip_atomic_store((gu32*)(p.status), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             break;
@@ -483,7 +490,7 @@ extern "C" int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream) 
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   WS_REQUIRE(nwg <= cus, "ws_lstm_bwd_cluster: %d workgroups must be co-resident but the device has %d CUs", nwg, cus);
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(a->flags, 0, (size_t)(a->nseq / 32) * 8 * sizeof(unsigned), s);
+  hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)(a->nseq / 32) * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_cluster: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
   hipLaunchKernelGGL(lstm_bwd_cluster_kernel, dim3(nwg), dim3(512), 0, s, *a);

@@ -220,18 +220,20 @@ def lstm_cat_ih(wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, n_in, wcat, bcat):
                                    n_in, _p(wcat), _p(bcat), L.stream_ptr()), "ws_lstm_cat_ih")
 
 
-def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None):
+def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None, run_if=None):
     for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("wpack", wpack), ("dhcat", dhcat)):
         _chk(t, n)
     a = L.LstmArgs()
     a.gates, a.cbuf, a.hcat, a.dhcat, a.wpack = _p(gates), _p(cbuf), _p(hcat), _p(dhcat), _p(wpack)
     a.sq_s1, a.sq_s2, a.step_rows = sm.s1, sm.s2, sm.step_rows
     a.nseq, a.sq_div, a.L, a.mode = sm.nseq, sm.div, sm.L, mode
+    a.run_if = C.c_void_p(run_if.data_ptr()) if run_if is not None else None
     return a
 
 
-def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3):
-    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode)
+def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, run_if=None):
+    """run_if: optional 1-element int32 device tensor; the launch is a no-op unless it is non-zero at kernel start."""
+    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, run_if=run_if)
     L.check(L.lib().ws_lstm_fwd(C.byref(a), L.stream_ptr()), "ws_lstm_fwd")
 
 
@@ -259,36 +261,119 @@ def lstm_cluster_ok(sm: SeqMap, device) -> bool:
     return sm.nseq % 64 == 0 and (sm.nseq // 32) * 8 <= cu_count(device) and sm.L >= 64
 
 
+class _ClusterScratch:
+    """Per (device, stream) scratch of the cluster recurrences: exchange buffer + flag words (grow-only; launches on
+    one stream are ordered, so they share it), and the sticky status words [forward, BPTT] with their pinned host
+    mirror for the asynchronous check."""
+
+    def __init__(self, device):
+        self.device = device
+        self.xchg = None
+        self.flags = None
+        self.status = torch.zeros(2, device=device, dtype=torch.int32)
+        self.host = torch.zeros(2, dtype=torch.int32)
+        if device.type == "cuda" and torch.cuda.is_available():   # (dry-run harnesses fake is_cuda on CPU tensors)
+            self.host = self.host.pin_memory()
+        self.event = None
+        self.fallbacks = 0
+
+    def get(self, xchg_floats: int, nflags: int):
+        if self.xchg is None or self.xchg.numel() < xchg_floats:
+            self.xchg = torch.empty(xchg_floats, device=self.device, dtype=torch.float32)
+        if self.flags is None or self.flags.numel() < nflags:
+            self.flags = torch.empty(nflags, device=self.device, dtype=torch.int32)
+        return self.xchg, self.flags
+
+
+_CLUSTER_SCRATCH = {}
+
+
+def _cluster_scratch(device) -> _ClusterScratch:
+    key = (device.type, device.index, L.stream_ptr().value)
+    if key not in _CLUSTER_SCRATCH:
+        _CLUSTER_SCRATCH[key] = _ClusterScratch(device)
+    return _CLUSTER_SCRATCH[key]
+
+
+def poll_cluster_status(device, block=False):
+    """Asynchronous check of the cluster recurrences' sticky status words on the current stream: evaluates the
+    8-byte device->pinned-host copy started by the previous call once its event has completed and starts the next
+    one (`block`: copy now and wait).  A forward timeout was already repaired on the device by the predicated
+    streaming kernels (wesep_hip.h, ws_lstm_fwd_cluster): it is counted and reported once.  A BPTT timeout has no
+    device-side repair (the kernel works in place): WesepHipError.  Returns the number of repaired forward timeouts."""
+    key = (device.type, device.index, L.stream_ptr().value)
+    if key not in _CLUSTER_SCRATCH or not torch.cuda.is_available():
+        return 0          # no cluster launch on this stream so far (or a GPU-less dry-run harness)
+    sc = _CLUSTER_SCRATCH[key]
+
+    def start():
+        sc.host.copy_(sc.status, non_blocking=True)
+        sc.event = torch.cuda.Event()
+        sc.event.record()
+
+    def evaluate():
+        sc.event.synchronize()
+        sc.event = None
+        fwd_to, bwd_to = int(sc.host[0]), int(sc.host[1])
+        if fwd_to or bwd_to:
+            sc.status.zero_()
+        if fwd_to:
+            if sc.fallbacks == 0:
+                import warnings
+                warnings.warn("lstm_fwd_cluster: a bounded wait timed out (workgroups not co-resident: another stream "
+                              "or process holds CUs); the layer was recomputed by the streaming kernels.  "
+                              "WESEP_LSTM_CLUSTER=0 avoids the cluster kernel altogether", RuntimeWarning)
+            sc.fallbacks += 1
+        if bwd_to:
+            raise L.WesepHipError(
+                "lstm_bwd_cluster: a bounded wait timed out (the workgroups were not co-resident: another stream or "
+                "process holds CUs); d(gates) of that launch are NaN-poisoned.  Unset WESEP_LSTM_CLUSTER_BWD to use "
+                "the streaming BPTT kernel")
+
+    if sc.event is not None and (block or sc.event.query()):
+        evaluate()
+    if block:
+        start()
+        evaluate()
+    elif sc.event is None:
+        start()
+    return sc.fallbacks
+
+
 def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0):
     """Forward recurrence on the blocked layout with W_hh resident in registers across clusters of 8
-    workgroups (lstm_cluster.hip).  Allocates its exchange scratch (4 MB at R = 32)."""
+    workgroups (lstm_cluster.hip).  Returns the launch's timeout word (a 1-element int32 view of the flag scratch):
+    pass it as `run_if` to gemm_p2b + lstm_fwd behind this call -- the predicated fall-back."""
     for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("whh_f", whh_f), ("whh_r", whh_r)):
         _chk(t, n)
     ncl = sm.nseq // 32
-    xchg = torch.empty(ncl * 2 * 8 * 8192 // 4, device=gates.device, dtype=torch.float32)
-    flags = torch.empty(ncl * 8, device=gates.device, dtype=torch.int32)
+    sc = _cluster_scratch(gates.device)
+    xchg, flags = sc.get(ncl * 2 * 8 * 8192 // 4, ncl * 8 + 8)
     a = L.LstmClusterArgs()
     a.gates, a.cbuf, a.hcat, a.whh_f, a.whh_r = _p(gates), _p(cbuf), _p(hcat), _p(whh_f), _p(whh_r)
     a.xchg, a.flags = C.c_void_p(xchg.data_ptr()), C.c_void_p(flags.data_ptr())
-    a.status = C.c_void_p(status.data_ptr()) if status is not None else None
+    a.status = C.c_void_p((status if status is not None else sc.status).data_ptr())
     a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
     L.check(L.lib().ws_lstm_fwd_cluster(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_cluster")
+    return flags[ncl * 8:ncl * 8 + 1]
 
 
 def lstm_bwd_cluster(gates, cbuf, dhcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0):
     """BPTT on the blocked layout over clusters of 8 workgroups (lstm_cluster.hip); gates: activated
-    gates in, d(pre-activation gates) out.  Allocates its exchange scratch (32 MB at R = 32)."""
+    gates in, d(pre-activation gates) out.  Returns the launch's timeout word (see lstm_fwd_cluster); there is no
+    device-side fall-back (in place), poll_cluster_status raises."""
     for n, t in (("gates", gates), ("cbuf", cbuf), ("dhcat", dhcat), ("whh_f", whh_f), ("whh_r", whh_r)):
         _chk(t, n)
     ncl = sm.nseq // 32
-    xchg = torch.empty(ncl * 2 * 64 * 8192 // 4, device=gates.device, dtype=torch.float32)
-    flags = torch.empty(ncl * 8, device=gates.device, dtype=torch.int32)
+    sc = _cluster_scratch(gates.device)
+    xchg, flags = sc.get(ncl * 2 * 64 * 8192 // 4, ncl * 8 + 8)
     a = L.LstmClusterArgs()
     a.gates, a.cbuf, a.dhcat, a.whh_f, a.whh_r = _p(gates), _p(cbuf), _p(dhcat), _p(whh_f), _p(whh_r)
     a.xchg, a.flags = C.c_void_p(xchg.data_ptr()), C.c_void_p(flags.data_ptr())
-    a.status = C.c_void_p(status.data_ptr()) if status is not None else None
+    a.status = C.c_void_p(status.data_ptr() if status is not None else sc.status.data_ptr() + 4)
     a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
     L.check(L.lib().ws_lstm_bwd_cluster(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_cluster")
+    return flags[ncl * 8:ncl * 8 + 1]
 
 
 class BandTables:
@@ -381,7 +466,22 @@ def grad_norms(tab, ntensors, norms):
             "ws_grad_norms")
 
 
+_WEIGHT_EPOCH = [0]
+
+
+def weight_epoch() -> int:
+    """Counter of raw-pointer parameter updates (ws_clip_adam_step writes parameters without touching torch's version
+    counters): part of the signature of every cached weight pack (functional.PackCache)."""
+    return _WEIGHT_EPOCH[0]
+
+
+def bump_weight_epoch():
+    _WEIGHT_EPOCH[0] += 1
+
+
 def clip_adam_step(tab, ntensors, norms, clip, lr, beta1, beta2, eps, weight_decay, step, clip_only=False):
+    if not clip_only:
+        bump_weight_epoch()
     L.check(L.lib().ws_clip_adam_step(C.c_void_p(tab.data_ptr()), ntensors, _p(norms), clip, lr, beta1,
                                       beta2, eps, weight_decay, step, int(clip_only), L.stream_ptr()),
             "ws_clip_adam_step")
@@ -454,7 +554,7 @@ def pack_w(W, N: int, K: int, ldw: int, out, trans=False, order=0, w_off=0):
 
 
 def gemm_p2b(*, A, lda: int, sm: SeqMap, Wpack, N: int, C_out, K=128, bias=None, A_bl=None, stats=None,
-             gamma=None, beta=None, stat_map: Optional[StatMap] = None):
+             gamma=None, beta=None, stat_map: Optional[StatMap] = None, run_if=None):
     for n, t in (("A", A), ("Wpack", Wpack), ("bias", bias), ("C", C_out), ("A_bl", A_bl), ("stats", stats),
                  ("gamma", gamma), ("beta", beta)):
         _chk(t, n)
@@ -465,6 +565,7 @@ def gemm_p2b(*, A, lda: int, sm: SeqMap, Wpack, N: int, C_out, K=128, bias=None,
     st = stat_map or StatMap(1, 0, 1, 0, 0)
     a.st_div1, a.st_m1, a.st_div2, a.st_m2, a.st_base = st
     a.lda, a.N, a.K = lda, N, K
+    a.run_if = C.c_void_p(run_if.data_ptr()) if run_if is not None else None
     L.check(L.lib().ws_gemm_p2b(C.byref(a), L.stream_ptr()), "ws_gemm_p2b")
 
 

@@ -252,16 +252,61 @@ class WGradCarrierFn(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
+class PackCache:
+    """Derived forms of one ResRNN's LSTM / proj weights -- concatenated W_ih, MFMA-fragment packs of W_hh (per
+    recurrence kernel family), W_ih, W_proj and their transposes -- built once per weight VALUE instead of once per
+    forward and once more per backward (round 1: 294 pack_w launches / 3.6 ms per step).  Owned by the module that
+    owns the parameters (models.bsrnn.ResRNN), so entries die with it.  Signature of the source weights: storage
+    addresses + torch version counters + dev.weight_epoch() (FusedClipAdam writes parameters through raw pointers
+    and bumps the epoch instead)."""
+
+    def __init__(self):
+        self.sig = None
+        self.items = {}
+
+    @staticmethod
+    def signature(params):
+        return (dev.weight_epoch(),) + tuple((p.data_ptr(), p._version) for p in params)
+
+    def begin(self, params):
+        """Signature of `params` now; drops the cached packs when it moved."""
+        sig = self.signature(params)
+        if sig != self.sig:
+            self.sig, self.items = sig, {}
+        return sig
+
+    def get(self, sig, kind, build):
+        """The pack `kind` for the weights of signature `sig`; built uncached when the cache has moved on (a
+        backward through a graph whose forward predates a weight update)."""
+        if sig != self.sig:
+            return build()
+        if kind not in self.items:
+            self.items[kind] = build()
+        return self.items[kind]
+
+
+class _NoCache(PackCache):
+    def begin(self, params):
+        return None
+
+    def get(self, sig, kind, build):
+        return build()
+
+
+_NO_CACHE = _NoCache()
+
+
 class ResRNNBlkFn(torch.autograd.Function):
     """ResRNN on the blocked layout: gates / c / h / d(h) never exist in row-major form; every
     activation byte of the recurrence moves as part of a 512-byte contiguous run (include/wesep_hip.h,
     "blocked layout BL").  Same inputs as ResRNNFn."""
 
     @staticmethod
-    def forward(ctx, z, dummy, box, view, norm_w, norm_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r,
+    def forward(ctx, z, dummy, box, cache, view, norm_w, norm_b, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r,
                 bhh_r, proj_w, proj_b):
         """dummy/box: None, or the output and the box of this ResRNN's WGradCarrierFn -- then the ten
-        LSTM / proj tensors are passed detached and their gradients travel through the box."""
+        LSTM / proj tensors are passed detached and their gradients travel through the box.  cache: the owning
+        module's PackCache or None."""
         _need_cuda(z, "ResRNN")
         z = z.contiguous()
         R, K, Tf, N = z.shape
@@ -273,12 +318,12 @@ class ResRNNBlkFn(torch.autograd.Function):
         nb = dev.bl_num_blocks(seq)
         stats = _empty(d, geo.ngroups, 2)
         dev.group_stats(z, geo, stats)
-        wcat, bcat = _empty(d, 2 * G4, N), _empty(d, 2 * G4)
-        dev.lstm_cat_ih(wih_f.contiguous(), wih_r.contiguous(), bih_f, bhh_f, bih_r, bhh_r, N, wcat, bcat)
-        pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
+        cache = cache if cache is not None else _NO_CACHE
+        sig = cache.begin((wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, proj_w, proj_b))
         lmode = dev.lstm_blk_mode(seq.nseq)
-        whf, whr = whh_f.contiguous(), whh_r.contiguous()
-        dev.lstm_pack(whf, whr, pack_f, pack_b, lmode)
+        W = _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, proj_w)
+        wcat, bcat = W("cat")
+        whf, whr = W("whh")
         gates, xn = _empty(d, nb, 32 * 2 * G4), _empty(d, nb, 32 * N)
         cbuf, hcat = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * 2 * H)
         cluster = dev.lstm_cluster_ok(seq, d)
@@ -287,25 +332,27 @@ class ResRNNBlkFn(torch.autograd.Function):
             # pre-activation buffer is never written and read back (lstm_fused.hip)
             dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, stats=stats, gamma=norm_w,
                          beta=norm_b, stat_map=smap)
-            fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
-            dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), whf, whr, fpack)
-            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq)
+            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, W("fused"), bcat, seq)
         else:
-            wih_pack = _empty(d, 2 * G4 * N)
-            dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
-            dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=gates, bias=bcat, A_bl=xn,
+            xproj = dict(A=z, lda=N, sm=seq, Wpack=W("wih"), N=2 * G4, C_out=gates, bias=bcat, A_bl=xn,
                          stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap)
+            dev.gemm_p2b(**xproj)
             if cluster:
-                dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq)
+                # weight-stationary cluster kernel; behind it the streaming pair predicated on the launch's timeout
+                # word: two empty launches after a clean run, the whole layer again if the cluster's workgroups
+                # were not co-resident (another stream / process on the GPU) -- never NaN (wesep_hip.h)
+                tw = dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq, dbg=_cluster_dbg())
+                dev.gemm_p2b(run_if=tw, **xproj)
+                dev.lstm_fwd(gates, cbuf, hcat, W("hh")[0], seq, lmode, run_if=tw)
             else:
-                dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode)
-        pw = proj_w.contiguous()
-        proj_pack = _empty(d, N * 2 * H)
-        dev.pack_w(pw, N, 2 * H, 2 * H, proj_pack, order=1)
+                dev.lstm_fwd(gates, cbuf, hcat, W("hh")[0], seq, lmode)
+        pw = W("pw")
         out = torch.empty_like(z)
-        dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=proj_pack, C_out=out, ldc=N, bias=proj_b, R=z)
-        ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw, whf, whr)
+        dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=W("proj"), C_out=out, ldc=N, bias=proj_b, R=z)
+        ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn, wcat, norm_w, norm_b, pw, whf, whr)
         ctx.view, ctx.box, ctx.lmode, ctx.cluster = view, box, lmode, cluster
+        ctx.packs = W
+        ctx.consumed = False
         return out
 
     @staticmethod
@@ -341,7 +388,14 @@ class ResRNNBlkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        z, stats, gates, cbuf, hcat, xn, wcat, pack_b, norm_w, norm_b, pw, whf, whr = ctx.saved_tensors
+        if ctx.consumed:
+            # BPTT turns the saved activated gates into d(gates) IN PLACE (and the deferred side-stream job reads
+            # them later): a second backward through this node would silently differentiate garbage
+            raise L.WesepHipError("ResRNN: second backward through the same graph (retain_graph / multi-loss loops): "
+                                  "the blocked path consumes its saved gates in place; run the forward again")
+        ctx.consumed = True
+        z, stats, gates, cbuf, hcat, xn, wcat, norm_w, norm_b, pw, whf, whr = ctx.saved_tensors
+        W = ctx.packs
         dout = dout.contiguous()
         R, K, Tf, N = z.shape
         P = R * K * Tf
@@ -350,21 +404,20 @@ class ResRNNBlkFn(torch.autograd.Function):
         nb = dev.bl_num_blocks(seq)
         box = ctx.box
         # d(hcat) = dout Wp  (+ dout itself in BL for the weight gradient)
-        wpt_pack = _empty(d, 2 * H * N)
-        dev.pack_w(pw, 2 * H, N, 2 * H, wpt_pack, trans=True, order=0)
         dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
-        dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wpt_pack, N=2 * H, C_out=dh, A_bl=dout_bl)
+        dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=W("projT"), N=2 * H, C_out=dh, A_bl=dout_bl)
         # BPTT: gates (activated) -> d(pre-activation gates), in place.  A time-view recurrence leaves
         # half of the chip idle: the weight-gradient jobs deferred by the previous layers are released
         # right after it is launched
         ready = mark_wgrads_ready(d) if ctx.view == "time" else None
         # the cluster BPTT (4.8 ms vs 5.8 ms per time-view launch) fills all 256 CUs and so evicts the
         # side-stream weight-gradient GEMMs that otherwise run under the 128-CU streaming kernel: net loss
-        # today, hence opt-in (WESEP_LSTM_CLUSTER_BWD=1)
+        # today, hence opt-in (WESEP_LSTM_CLUSTER_BWD=1; FusedClipAdam.step then checks its status word with a
+        # host sync before the update -- in place, so no device-side fall-back)
         if ctx.cluster and os.environ.get("WESEP_LSTM_CLUSTER_BWD", "0") == "1":
             dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
         else:
-            dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, ctx.lmode)
+            dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode)
         if ready is not None:
             flush_deferred_wgrads(d, ready)
         del dh
@@ -383,10 +436,8 @@ class ResRNNBlkFn(torch.autograd.Function):
             wg = ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N)
         del dout_bl
         # d(normalised input) = dgates Wcat -> GroupNorm backward (+ residual path)
-        wct_pack = _empty(d, N * 2 * G4)
-        dev.pack_w(wcat, N, 2 * G4, N, wct_pack, trans=True, order=1)
         dxn = _empty(d, P, N)
-        dev.gemm_b2p(A=gates, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dxn, ldc=N)
+        dev.gemm_b2p(A=gates, K=2 * G4, sm=seq, Wpack=W("wihT"), C_out=dxn, ldc=N)
         ab = _empty(d, geo.ngroups, 2)
         dev.gn_bwd_reduce(z, dxn, stats, geo, ab, gamma=norm_w)
         ns2 = min(1024, geo.ngroups)
@@ -396,7 +447,63 @@ class ResRNNBlkFn(torch.autograd.Function):
         dz = torch.empty_like(z)
         dev.gn_bwd_apply(z, dxn, stats, ab, geo, dz, gamma=norm_w, res=dout)
         gd = torch.zeros((), device=d) if box is not None else None
-        return (dz, gd, None, None, dgb[0], dgb[1]) + tuple(wg)
+        return (dz, gd, None, None, None, dgb[0], dgb[1]) + tuple(wg)
+
+
+def _cluster_dbg() -> int:
+    """WESEP_CLUSTER_FORCE_TIMEOUT=1 (tests): every forward cluster launch times out in workgroup 0 at step 2, so the
+    predicated streaming fall-back produces the layer's result."""
+    return 8 if os.environ.get("WESEP_CLUSTER_FORCE_TIMEOUT", "0") == "1" else 0
+
+
+def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, proj_w):
+    """W(kind): the derived weight forms of one ResRNN through its PackCache (built on first use, kept until the
+    weights change).  kinds: cat (wcat, bcat) | whh (contiguous W_hh pair) | hh (fwd, bwd recurrence packs of mode
+    `lmode`) | fused ([W_ih | W_hh] stream of lstm_fused.hip) | wih / wihT (p2b x-projection, b2p d(xn)) |
+    pw (contiguous proj.weight) | proj / projT (b2p projection, p2b d(hcat))."""
+    d = wih_f.device
+    N = wih_f.shape[1]
+
+    def build(kind):
+        if kind == "cat":
+            wcat, bcat = _empty(d, 2 * G4, N), _empty(d, 2 * G4)
+            dev.lstm_cat_ih(wih_f.contiguous(), wih_r.contiguous(), bih_f, bhh_f, bih_r, bhh_r, N, wcat, bcat)
+            return wcat, bcat
+        if kind == "whh":
+            return whh_f.contiguous(), whh_r.contiguous()
+        if kind == "hh":
+            pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
+            dev.lstm_pack(*W("whh"), pack_f, pack_b, lmode)
+            return pack_f, pack_b
+        if kind == "fused":
+            fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
+            dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), *W("whh"), fpack)
+            return fpack
+        if kind == "wih":
+            out = _empty(d, 2 * G4 * N)
+            dev.pack_w(W("cat")[0], 2 * G4, N, N, out, order=0)
+            return out
+        if kind == "wihT":
+            out = _empty(d, N * 2 * G4)
+            dev.pack_w(W("cat")[0], N, 2 * G4, N, out, trans=True, order=1)
+            return out
+        if kind == "pw":
+            return proj_w.contiguous()
+        if kind == "proj":
+            out = _empty(d, N * 2 * H)
+            dev.pack_w(W("pw"), N, 2 * H, 2 * H, out, order=1)
+            return out
+        if kind == "projT":
+            out = _empty(d, 2 * H * N)
+            dev.pack_w(W("pw"), 2 * H, N, 2 * H, out, trans=True, order=0)
+            return out
+        raise KeyError(kind)
+
+    def W(kind):
+        key = (kind, lmode) if kind == "hh" else kind
+        return cache.get(sig, key, lambda: build(kind))
+
+    return W
 
 
 def make_wgrad_carrier(params):
@@ -410,14 +517,14 @@ def make_wgrad_carrier(params):
     return WGradCarrierFn.apply(box, *params), box
 
 
-def resrnn(z, view, norm_w, norm_b, *params, carrier=None):
-    """ResRNN forward (autograd-aware) on the path selected by WESEP_RESRNN."""
+def resrnn(z, view, norm_w, norm_b, *params, carrier=None, cache=None):
+    """ResRNN forward (autograd-aware) on the path selected by WESEP_RESRNN.  cache: the owning module's PackCache."""
     if resrnn_mode() != "blocked":
         return ResRNNFn.apply(z, view, norm_w, norm_b, *params)
     if carrier is None:
-        return ResRNNBlkFn.apply(z, None, None, view, norm_w, norm_b, *params)
+        return ResRNNBlkFn.apply(z, None, None, cache, view, norm_w, norm_b, *params)
     dummy, box = carrier
-    return ResRNNBlkFn.apply(z, dummy, box, view, norm_w, norm_b, *(p.detach() for p in params))
+    return ResRNNBlkFn.apply(z, dummy, box, cache, view, norm_w, norm_b, *(p.detach() for p in params))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -267,10 +267,11 @@ def blocked_path_ok(C, ks, hs):
     """The blocked-layout recurrence machinery of the pBSRNN path (functional.ResRNNBlkFn: plain -> BL input
     projection, 16-sequence / cluster / fused-projection recurrences, BL -> plain output projection with bias and
     residual, BL x BL weight gradients) is built for 128 input features and one position per step -- which is the
-    shipped TF-GridNet recipe (emb_dim 128, emb_ks = emb_hs = 1; tfgridnet.yaml).  Opt-in until it has run on
-    hardware: WESEP_TFGRID_BLOCKED=1."""
+    shipped TF-GridNet recipe (emb_dim 128, emb_ks = emb_hs = 1; tfgridnet.yaml).  Default for that geometry since its
+    first hardware run (round 2: every stage within 1e-5 of an fp64 statement, tools/diag_tfgrid_blk.py);
+    WESEP_TFGRID_BLOCKED=0 selects the row-major path."""
     import os
-    return os.environ.get("WESEP_TFGRID_BLOCKED", "0") == "1" and C == 128 and ks == 1 and hs == 1
+    return os.environ.get("WESEP_TFGRID_BLOCKED", "1") != "0" and C == 128 and ks == 1 and hs == 1
 
 
 class BlstmLinearBlkFn(torch.autograd.Function):
@@ -318,9 +319,14 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         else:
             wih_pack = _empty(d, 2 * G4 * N)
             dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
-            dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=gates, bias=bcat, A_bl=xn)
+            xproj = dict(A=y, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=gates, bias=bcat, A_bl=xn)
+            dev.gemm_p2b(**xproj)
             if cluster:
-                dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq)
+                # the streaming pair behind the cluster launch is predicated on its timeout word (wesep_hip.h): empty
+                # launches after a clean run, the whole layer again if the workgroups were not co-resident
+                tw = dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq, dbg=F0._cluster_dbg())
+                dev.gemm_p2b(run_if=tw, **xproj)
+                dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode, run_if=tw)
             else:
                 dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode)
         lw = lin_w.contiguous()

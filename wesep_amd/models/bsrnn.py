@@ -32,6 +32,7 @@ class ResRNN(nn.Module):
         self.norm = nn.GroupNorm(1, input_size, self.eps)
         self.rnn = nn.LSTM(input_size, hidden_size, 1, batch_first=True, bidirectional=True)
         self.proj = nn.Linear(hidden_size * 2, input_size)
+        self._packs = F_.PackCache()     # derived weight forms, rebuilt when the weights change (not state)
 
     def _wparams(self):
         r = self.rnn
@@ -44,7 +45,8 @@ class ResRNN(nn.Module):
         return F_.make_wgrad_carrier(self._wparams())
 
     def forward(self, z, view="time", carrier=None):
-        return F_.resrnn(z, view, self.norm.weight, self.norm.bias, *self._wparams(), carrier=carrier)
+        return F_.resrnn(z, view, self.norm.weight, self.norm.bias, *self._wparams(), carrier=carrier,
+                         cache=self._packs)
 
 
 class BSNet(nn.Module):

@@ -5,6 +5,8 @@ own L2 norm with eps 1e-6 (wesep/utils/funcs.py:79-88, ~640 `.item()` host syncs
 the reference, zero here) and torch.optim.Adam(weight_decay=wd) adds wd*p to the gradient
 (wesep/bin/train.py:237-238).  State keys (`step`, `exp_avg`, `exp_avg_sq`) match
 torch.optim.Adam so optimizer checkpoints interchange (wesep/utils/checkpoint.py)."""
+import os
+
 import numpy as np
 import torch
 
@@ -51,6 +53,11 @@ class FusedClipAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         self._norms, self._norm_params = [], []
+        cuda_dev = next((p.device for g in self.param_groups for p in g["params"] if p.is_cuda), None)
+        if cuda_dev is not None and os.environ.get("WESEP_LSTM_CLUSTER_BWD", "0") == "1":
+            # the opt-in in-place cluster BPTT cannot be repaired on the device: look at its status word BEFORE the
+            # update (one host sync per step in this mode); raises WesepHipError on a timeout
+            dev.poll_cluster_status(cuda_dev, block=True)
         for group in self.param_groups:
             refs = []
             for p in group["params"]:
@@ -69,21 +76,27 @@ class FusedClipAdam(torch.optim.Optimizer):
                 refs.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"]))
             if not refs:
                 continue
-            steps = {int(self.state[r[0]]["step"]) for r in refs}
-            if len(steps) != 1:
-                raise L.WesepHipError("FusedClipAdam: parameters of one group must share the step count")
-            device = refs[0][0].device
-            tab = _table(refs, device)
+            # torch.optim.Adam keeps `step` per parameter: parameters that joined later (spk_model_freeze lifted
+            # after a resume, a head that only sometimes receives gradients) have their own bias corrections ->
+            # one launch per distinct step count (one in the usual case)
+            buckets = {}
+            for r in refs:
+                buckets.setdefault(int(self.state[r[0]]["step"]), []).append(r)
             clip = float(group["clip_grad"])
-            norms = None
-            if clip > 0:
-                norms = torch.empty(len(refs), device=device, dtype=torch.float32)
-                dev.grad_norms(tab, len(refs), norms)
-                self._norms.append(norms)
-                self._norm_params += [r[0] for r in refs]
             b1, b2 = group["betas"]
-            dev.clip_adam_step(tab, len(refs), norms, clip, float(group["lr"]), b1, b2, group["eps"],
-                               group["weight_decay"], steps.pop())
+            for step, brefs in sorted(buckets.items()):
+                device = brefs[0][0].device
+                tab = _table(brefs, device)
+                norms = None
+                if clip > 0:
+                    norms = torch.empty(len(brefs), device=device, dtype=torch.float32)
+                    dev.grad_norms(tab, len(brefs), norms)
+                    self._norms.append(norms)
+                    self._norm_params += [r[0] for r in brefs]
+                dev.clip_adam_step(tab, len(brefs), norms, clip, float(group["lr"]), b1, b2, group["eps"],
+                                   group["weight_decay"], step)
+        if cuda_dev is not None:
+            dev.poll_cluster_status(cuda_dev)   # asynchronous: evaluates the copy started one step ago
         return loss
 
     def last_grad_norms(self):
