@@ -72,21 +72,76 @@ def _cpu_baseline_worker(threads, budget_s):
                                 f"{threads} of {os.cpu_count()} host cores (reference recipe: OMP_NUM_THREADS=8)"}))
 
 
-def cpu_baseline(budget_s=30.0, hard_limit_s=240.0):
+def _cpu_reference_worker(threads, budget_s):
+    """The REFERENCE'S OWN modules timed on the host: wesep.models.bsrnn.BSRNN imported from
+    /root/reference (third-party imports stubbed, oracle/ref_import.py), its own clip_gradients, torch.optim.Adam; the
+    SI-SDR loss is the restatement (auraloss is absent everywhere).  Only possible where /root/reference exists -- the
+    authoring container, not the GPU box -- so it is an explicit flag (--cpu-baseline reference), used once to check
+    that the oracle port times like the code it restates."""
+    from oracle import bsrnn_oracle as O
+    from oracle.ref_import import import_reference
+    get_model = import_reference()
+    from wesep.utils.funcs import clip_gradients        # wesep/utils/funcs.py:79-88
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    kw = dict(MODEL_KW)
+    model = get_model("BSRNN")(**kw).train()
+    opt = torch.optim.Adam(model.parameters(), lr=LR0, weight_decay=WD)
+    R = 2
+    wav, tgt, emb = O.synth_batch(R, T, 42)
+
+    def step():
+        est, _ = model(wav, emb)
+        loss = O.sisdr_loss(est, tgt)
+        opt.zero_grad()
+        loss.backward()
+        clip_gradients(model, CLIP)
+        opt.step()
+
+    t0 = time.perf_counter()
+    step()
+    warm = time.perf_counter() - t0
+    n = max(1, min(3, int(budget_s / max(warm, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = (time.perf_counter() - t0) / n
+    print(json.dumps({"value": R / dt, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "reference",
+                      "sample": f"wesep.models.bsrnn.BSRNN imported from /root/reference (torch CPU fp32), R={R} rows x "
+                                f"4 s, 1 warm-up + {n} timed steps of fwd+SI-SDR+bwd+clip_gradients+Adam, {dt:.2f} "
+                                f"s/step, {threads} of {os.cpu_count()} host cores"}))
+
+
+def cpu_baseline(budget_s=30.0, hard_limit_s=240.0, kind="port"):
     """Oracle (CPU port of the reference step) timed on this host's cores in a child process so a
     pathological host (hundreds of cores, oversubscription) cannot stall the benchmark."""
     import subprocess
     threads = min(os.cpu_count() or 1, 16)
+    worker = "_cpu_reference_worker" if kind == "reference" else "_cpu_baseline_worker"
     cmd = [sys.executable, "-c",
-           f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench._cpu_baseline_worker({threads}, {budget_s})"]
+           f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.{worker}({threads}, {budget_s})"]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_limit_s, env=env, cwd=ROOT)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:  # timeout or failure: report it rather than hiding it
-        return {"value": None, "unit": "utterances/s", "cores": threads, "kind": "port",
+        return {"value": None, "unit": "utterances/s", "cores": threads, "kind": kind,
                 "sample": f"cpu baseline did not finish within {hard_limit_s:.0f} s ({type(e).__name__})"}
+
+
+def _latest_profile(kind):
+    """profiles/rNN_<kind>.json of the highest round."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{kind}.json")))
+    if not hits:
+        raise OSError(kind)
+    return hits[-1]
+
+
+def _sha16(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
 def main():
@@ -96,16 +151,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=("port", "reference"), default="port",
+                    help="port: the oracle (travels to the GPU box); reference: the reference's own modules imported "
+                         "from /root/reference (only where that exists)")
+    ap.add_argument("--cpu-only", action="store_true", help="print the CPU baseline object and exit (no GPU needed)")
     ap.add_argument("--joint", action="store_true",
                     help="the shipped confs/bsrnn.yaml variant: speaker encoder (wespeaker ResNet34 on 80-d fbank, "
                          "398 frames) trained jointly instead of fixed 256-d embeddings; not the headline line")
     args = ap.parse_args()
 
+    if args.cpu_only:
+        print(json.dumps(cpu_baseline(kind=args.cpu_baseline)), flush=True)
+        return
     from wesep_amd import dev
     from wesep_amd import _lib as L
     from wesep_amd.models import get_model
     from wesep_amd.optim import FusedClipAdam
-    from wesep_amd.parallel import barrier, init_distributed, max_over_ranks, rank_seed, wrap_ddp
+    from wesep_amd.parallel import all_ranks, all_ranks_tensor_spread, barrier, comm_info, init_distributed, max_over_ranks, rank_seed, wrap_ddp
     from wesep_amd.utils.losses import parse_loss
     from wesep_amd.utils.schedulers import ExponentialDecrease
     from wesep_amd.utils.synthetic import synth_batch
@@ -160,6 +222,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     dev.prof_enable(False)
+    per_rank_ms = all_ranks(elapsed / args.steps * 1e3, d)       # rank-ordered, for the SCALE record
+    # outside the timed region: do all replicas hold the same parameters?  (Data parallelism keeps them bit-identical;
+    # a disturbed all-reduce -- profiles/r02_kernel_race.md -- would not.)  Checksum of every parameter, max - min over ranks.
+    with torch.no_grad():
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()])
+    spread = all_ranks_tensor_spread(chk, d)
     elapsed = max_over_ranks(elapsed, d)
     final_loss = float(loss.item())
 
@@ -182,9 +250,12 @@ def main():
     tfl = flops_per_launch / sec / 1e12
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/pmc_summary.py);
     # bench.py cannot collect counters itself, so this is the profile of the same command, or null
-    traffic = None
+    traffic, pmc_src = None, {}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        pmc_file = _latest_profile("pmc_traffic")
+        doc = json.load(open(pmc_file))
+        pmc = doc["kernels"]
+        pmc_src["traffic"] = {"file": os.path.relpath(pmc_file, ROOT), **doc.get("collected", {})}
         hit = [v for k, v in pmc.items() if dom in k]      # streaming (32/16-sequence) and cluster variants
         n = sum(v["launches"] for v in hit)
         traffic = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in hit) / n if n else None
@@ -194,7 +265,10 @@ def main():
     # MFMA-busy fraction of the same kernels from the committed SQ_VALU_MFMA_BUSY_CYCLES pass (tools/pmc_mfma_summary.py)
     mfma_busy = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")))["kernels"]
+        pm_file = _latest_profile("pmc_mfma")
+        doc = json.load(open(pm_file))
+        pm = doc["kernels"]
+        pmc_src["mfma"] = {"file": os.path.relpath(pm_file, ROOT), **doc.get("collected", {})}
         hit = [v for k, v in pm.items() if dom in k]
         n = sum(v["launches"] for v in hit)
         mfma_busy = sum(v["mfma_busy_frac"] * v["launches"] for v in hit) / n if n else None
@@ -230,8 +304,29 @@ def main():
                                   "busy_frac_pmc": mfma_busy}},
             "kernel_ms_per_step": {k: v["ms_total"] / args.steps for k, v in prof.items()},
         }
+        # counters cannot be collected inside this run: say which run they come from (commit + bench.py hash at
+        # collection time, written by tools/pmc_summary.py), next to this run's own bench.py hash
+        out["roofline"]["counters_from"] = pmc_src
+        out["bench_py_sha16"] = _sha16(os.path.abspath(__file__))
+        # whole step against SURVEY 8d's algorithmic work (per row, 4 s, fwd+bwd): 1.017 TFLOP fp32-equivalent
+        # (x3 executed as split-bf16) and the layer-fused minimum of 2.26 GB of fp32 traffic
+        sec_step = elapsed / args.steps
+        alg_flops, alg_bytes = 1.017e12 * R, 2.26e9 * R
+        t_mfma = 3 * alg_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+        t_hbm = alg_bytes / (HBM_PEAK_GBS * 1e9)
+        out["step_roofline"] = {
+            "alg_flops_per_step": alg_flops, "alg_bytes_per_step": alg_bytes,
+            "alg_tflops": alg_flops / sec_step / 1e12, "executed_bf16_tflops": 3 * alg_flops / sec_step / 1e12,
+            "frac_mfma_executed": t_mfma / sec_step, "alg_gbs": alg_bytes / sec_step / 1e9,
+            "frac_hbm_alg": t_hbm / sec_step, "bound": "mfma" if t_mfma >= t_hbm else "hbm",
+            "frac": max(t_mfma, t_hbm) / sec_step,
+            "note": "per GPU; SURVEY 8d: achieved := max(bytes_alg / 8 TB/s, 3 * flops_alg / 2.5 PFLOP/s) / t_step"}
+        out["per_rank_ms_per_step"] = per_rank_ms
+        out["replicas_in_sync"] = bool(spread == 0.0)
+        out["replica_checksum_spread"] = spread
+        out["comm"] = comm_info()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(kind=args.cpu_baseline)
         print(json.dumps(out), flush=True)
     barrier()
 

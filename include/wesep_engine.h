@@ -44,8 +44,10 @@ int ws_engine_create(const char* weights_path, int device, int flags, ws_engine*
 void ws_engine_destroy(ws_engine* e);
 
 /* Model facts read from the container: key in {"sample_rate", "num_repeat", "spk_emb_dim", "joint_training",
- * "feat_dim", "n_tensors", "n_launches" (entry-point calls issued by the last forward), "arena_bytes"};
- * unknown key -> -1. */
+ * "feat_dim", "n_tensors", "n_launches" (entry-point calls issued by the last forward), "arena_bytes",
+ * "cluster_fallbacks" (forwards so far in which a weight-stationary cluster recurrence timed out -- its workgroups were
+ * not co-resident, e.g. several engines on one GPU -- and the predicated streaming kernels recomputed the layer;
+ * wesep_hip.h, ws_lstm_fwd_cluster)}; unknown key -> -1. */
 long long ws_engine_info(const ws_engine* e, const char* key);
 
 /* enrollment kinds */

@@ -37,6 +37,9 @@ const char* ws_last_error(void);
 #define WS_PROF_NKINDS 4
 int ws_prof_enable(int on);                       /* 1: bracket every launch of the kinds above */
 int ws_prof_collect(int kind, double* total_ms, long long* launches); /* syncs the events; resets */
+/* Test support: fills 60 KB of LDS per workgroup with `value` (NaN) on `stream` and keeps the workgroups alive for
+ * `spins` LDS reads per thread; beside product kernels on another stream it exposes reads of LDS a kernel never wrote. */
+int ws_debug_dirty_lds(float value, int nblocks, int spins, float* sink, void* stream);
 
 /* ---- row addressing used by the GEMMs ---------------------------------------------------
  * row m of a matrix lives at  base + (m / div) * s1 + (m % div) * s2   (elements).       */
@@ -144,6 +147,15 @@ int ws_gn_bwd_apply(const float* x, const float* dxn, const float* stats, const 
  * (nbands = 1: every group).  Caller reduces the splits.                                    */
 int ws_gn_param_grad(const float* x, const float* dxn, const float* stats,
                      const ws_groups_geom* geo, int nsplit, float* slab, void* stream);
+
+/* The three calls above in ONE pass for small single-band groups (the band view of ResRNN: L = K = 32 rows of
+ * W = 128 floats per group; L even, <= 32): a wave owns a group in registers.
+ *   dx = rstd * (dxn*gamma - mean(dxn*gamma) - xhat * mean(dxn*gamma*xhat)) (+ res);
+ *   pslab[wg][0][c] / [wg][1][c] = this workgroup's share of dgamma[c] / dbeta[c] (sum over wg = the gradient).
+ * Replaces autograd's GroupNorm backward of ResRNN.norm (bsrnn.py:26,39).                                  */
+int ws_gn_bwd_fused(const float* x, const float* dxn, const float* stats, const float* gamma,
+                    const float* res, const ws_groups_geom* geo, int nwg, float* dx, float* pslab,
+                    void* stream);
 
 /* ---- bidirectional LSTM recurrence (nn.LSTM inside ResRNN, bsrnn.py:27-33,40) -----------
  * Sequence s, step t lives at row  p = (s / sq_div) * sq_s1 + (s % sq_div) * sq_s2 + t * step_rows.

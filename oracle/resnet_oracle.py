@@ -90,8 +90,22 @@ def synth_params(seed: int, **kw) -> Dict[str, torch.Tensor]:
     return out
 
 
-def resnet_forward(p, x, num_blocks=(3, 4, 6, 3), m=32, prefix="", training=True, new_buffers=None):
-    """x [B, T, F] -> embed_a [B, embed_dim]."""
+def resnet_forward(p, x, num_blocks=(3, 4, 6, 3), m=32, prefix="", training=True, new_buffers=None, relu_masks=None):
+    """x [B, T, F] -> embed_a [B, embed_dim].
+    relu_masks: optional list of boolean [B, C, F', T'] tensors, one per ReLU in evaluation order (stem, then per block:
+    after bn1, after the residual sum): the ReLU then multiplies by the given mask instead of by (z > 0).  Tests use it
+    to differentiate the restatement on the SAME linear region as the implementation under test -- a pre-activation
+    within rounding distance of zero otherwise flips its whole downstream gradient (a ReLU kink, not an arithmetic
+    error)."""
+    masks = list(relu_masks) if relu_masks is not None else None
+
+    def relu(z):
+        if masks is None:
+            return F.relu(z)
+        mk = masks.pop(0)
+        assert mk.shape == z.shape, (mk.shape, z.shape)
+        return z * mk.to(z.dtype)
+
     def bn(name, y):
         rm, rv = p[name + ".running_mean"].clone(), p[name + ".running_var"].clone()
         out = F.batch_norm(y, rm, rv, p[name + ".weight"], p[name + ".bias"], training, BN_MOMENTUM, BN_EPS)
@@ -99,15 +113,15 @@ def resnet_forward(p, x, num_blocks=(3, 4, 6, 3), m=32, prefix="", training=True
             new_buffers[name + ".running_mean"], new_buffers[name + ".running_var"] = rm, rv
         return out
     y = x.permute(0, 2, 1).unsqueeze(1)
-    y = F.relu(bn(prefix + "bn1", F.conv2d(y, p[prefix + "conv1.weight"], padding=1)))
+    y = relu(bn(prefix + "bn1", F.conv2d(y, p[prefix + "conv1.weight"], padding=1)))
     for q, inp, planes, stride in _blocks(num_blocks, m):
         q = prefix + q
-        o = F.relu(bn(q + "bn1", F.conv2d(y, p[q + "conv1.weight"], stride=stride, padding=1)))
+        o = relu(bn(q + "bn1", F.conv2d(y, p[q + "conv1.weight"], stride=stride, padding=1)))
         o = bn(q + "bn2", F.conv2d(o, p[q + "conv2.weight"], padding=1))
         sc = y
         if (q + "shortcut.0.weight") in p:
             sc = bn(q + "shortcut.1", F.conv2d(y, p[q + "shortcut.0.weight"], stride=stride))
-        y = F.relu(o + sc)
+        y = relu(o + sc)
     mean = y.mean(-1)
     std = torch.sqrt(torch.var(y, dim=-1) + 1e-7)
     stats = torch.cat((mean.flatten(1), std.flatten(1)), 1)

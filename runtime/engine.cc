@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -63,6 +64,7 @@ struct Arena {
   size_t cur = 0, top = 0;      // current chunk and offset inside it
   size_t live_bytes = 0, peak_bytes = 0;
   bool dry = false;
+  bool poison = getenv("WS_ENGINE_POISON") != nullptr;
 
   struct Mark {
     size_t cur, top, live;
@@ -100,6 +102,14 @@ struct Arena {
       top = 0;
     }
     float* p = reinterpret_cast<float*>(chunks[cur].base + top);
+    // WS_ENGINE_POISON=1 (tests): every allocation starts as NaN (0xFF bytes), so a launch plan that reads memory no
+    // kernel has written shows up as NaN output instead of depending on what the arena held before (device-wide
+    // syncs around it: the engine's stream is non-blocking).
+    if (poison && !dry) {
+      (void)hipDeviceSynchronize();
+      (void)hipMemset(p, 0xFF, bytes);
+      (void)hipDeviceSynchronize();
+    }
     top += bytes;
     live_bytes += bytes;
     if (live_bytes > peak_bytes) peak_bytes = live_bytes;
@@ -155,6 +165,8 @@ struct BlockPrep {
 
 }  // namespace
 
+static std::mutex g_device_mutex[16];   // see ws_engine_separate
+
 struct ws_engine {
   bool dry = false;
   int device = 0, cu_count = 0;
@@ -165,6 +177,8 @@ struct ws_engine {
   float* dw = nullptr;            // device copy
   Arena persist, work;
   long long n_launches = 0;
+  long long cluster_fallbacks = 0;   // forwards in which a cluster recurrence timed out and the streaming kernels took over
+  unsigned* cl_status = nullptr;     // sticky device word set by ws_lstm_fwd_cluster on a timeout
   // configuration
   int sr = 16000, num_repeat = 6, E = 256, fuse = 2, multi_fuse = 0, use_xform = 0, joint = 0, feat_dim = 80;
   int blocks[4] = {0, 0, 0, 0};
@@ -740,7 +754,8 @@ int resrnn(ws_engine* e, const RnnPrep& w, bool time_view, const float* z, int R
   const int ntile = (sm.nseq + 31) / 32;
   const size_t nb = size_t(ntile) * sm.L;
   const int lmode = 2 * ntile <= 128 ? WS_LSTM_BF16X3_BLK16 : WS_LSTM_BF16X3_BLK;
-  const bool cluster = sm.nseq % 64 == 0 && (sm.nseq / 32) * 8 <= e->cu_count && sm.L >= 64;
+  static const bool no_cluster = getenv("WS_ENGINE_NO_CLUSTER") != nullptr;   // diagnostics: streaming kernels only
+  const bool cluster = !no_cluster && sm.nseq % 64 == 0 && (sm.nseq / 32) * 8 <= e->cu_count && sm.L >= 64;
   const bool fused = !cluster && lmode == WS_LSTM_BF16X3_BLK;
   void* s = e->stream;
   Arena& a = e->work;
@@ -780,9 +795,15 @@ int resrnn(ws_engine* e, const RnnPrep& w, bool time_view, const float* z, int R
       float* xchg = a.alloc(size_t(ncl) * 2 * 8 * 8192 / 4);
       unsigned* flags = reinterpret_cast<unsigned*>(a.alloc(size_t(ncl) * 8 + 8));
       WS_PTR(xchg && flags);
+      if (!e->cl_status) {
+        e->cl_status = reinterpret_cast<unsigned*>(e->persist.alloc(2));
+        WS_PTR(e->cl_status);
+        if (zero_device(e, e->cl_status, 8) != WS_OK) return WS_ERR_LAUNCH;
+      }
       ws_lstm_cluster_args c = {};
       c.gates = gates, c.cbuf = cbuf, c.hcat = hcat, c.whh_f = w.whf, c.whh_r = w.whr;
       c.xchg = xchg, c.flags = flags, c.nseq = sm.nseq, c.L = sm.L;
+      c.status = e->cl_status;
       WS_RUN(e, ws_lstm_fwd_cluster(&c, s));
       // Several engines may share one GPU (separate_main --jobs): the cluster's workgroups are then not guaranteed to
       // be co-resident and a bounded wait can time out.  The streaming pair below is predicated on this launch's
@@ -1189,6 +1210,7 @@ extern "C" long long ws_engine_info(const ws_engine* e, const char* key) {
   if (k == "n_tensors") return static_cast<long long>(e->tensors.size());
   if (k == "n_launches") return e->n_launches;
   if (k == "arena_bytes") return static_cast<long long>(e->work.peak_bytes);
+  if (k == "cluster_fallbacks") return e->cluster_fallbacks;
   if (k == "nband") return e->K;
   auto it = e->meta.find(k);
   return it == e->meta.end() ? -1 : it->second;
@@ -1231,6 +1253,13 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
     set_err("ws_engine_separate: hipSetDevice(%d) failed", e->device);
     return WS_ERR_LAUNCH;
   }
+  // One forward at a time per GPU across the engines of this process.  Round 2 found that some of the MFMA kernels of
+  // this plan (ws_gemm_b2p, the grouped ws_gemm_nt / ws_gemm_tn) disturb FFT-type kernels that run CONCURRENTLY on
+  // another HIP stream of the same GPU -- this plan's own STFT / iSTFT kernels, and even a vendor rocFFT launch that
+  // shares no memory with them (tools/kernel_race*.py, profiles/r02_kernel_race.md): results of overlapping engines
+  // were not reproducible (rare single-frame glitches).  Until that is understood, engines sharing a GPU take turns
+  // on the device; their host work (wav I/O, feature staging, result write-out) still overlaps.
+  std::unique_lock<std::mutex> device_turn(g_device_mutex[e->device & 15]);
   e->n_launches = 0;
   Arena& a = e->work;
   a.reset();
@@ -1259,6 +1288,14 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
   }
   if ((rc = separate_device(e, d_mix, R, T, d_emb, d_est)) != WS_OK) return rc;
   if ((rc = to_host(e, est, d_est, size_t(R) * T * 4)) != WS_OK) return rc;
+  if (e->cl_status && !e->dry) {   // did a cluster recurrence time out (and the predicated streaming pair repair it)?
+    unsigned st = 0;
+    if ((rc = to_host(e, &st, e->cl_status, 4)) != WS_OK) return rc;
+    if (st) {
+      ++e->cluster_fallbacks;
+      if ((rc = zero_device(e, e->cl_status, 4)) != WS_OK) return rc;
+    }
+  }
   a.reset();
   a.consolidate();
   return WS_OK;

@@ -8,10 +8,11 @@
 // wav_scp lines: "<key> <mixture.wav> <enroll_spk1.wav> <enroll_spk2.wav>".  For every line the mixture and the two
 // enrollment utterances go through ws_engine_forward_pcm16 (enrollments cut to the shorter one, as the reference does)
 // and <key>-spk1.wav / <key>-spk2.wav are written; the real-time factor is printed per utterance and in total.
-// Utterances are independent, so throughput scales by running them concurrently: --jobs J worker threads, each with
-// its own engine (own HIP stream, arena and weight copy -- 0.3 GB of 288), spread round-robin over --devices; one
-// utterance at two rows fills a fraction of an MI355X (its time view is 64 sequences = 16 of 256 CUs), so several
-// engines per GPU overlap on the chip.  The reference tool is single-threaded on CPU cores.
+// Utterances are independent: --jobs J worker threads, each with its own engine (own HIP stream, arena and weight
+// copy -- 0.3 GB of 288), spread round-robin over --devices.  Engines that share a GPU take turns on the device
+// (ws_engine_separate holds a per-device lock for its launches): round 2 found that overlapping forwards on one GPU
+// are not reproducible, so what overlaps is the host work -- wav reading, int16 conversion,
+// result write-out -- and different GPUs.  The reference tool is single-threaded on CPU cores.
 // --dry_run validates the model file and the launch plan of every utterance without a GPU and writes nothing.
 // --raw_out additionally writes the unquantised estimates as <key>-spk{1,2}.f32 (float32, for parity checks).
 #include <stdio.h>
@@ -117,6 +118,7 @@ int main(int argc, char** argv) {
   };
   auto worker = [&](int job) {
     ws_engine* engine = nullptr;
+    long long fallbacks_seen = 0;
     if (ws_engine_create(model.c_str(), devices[job % devices.size()], dry ? WS_ENGINE_DRY_RUN : 0, &engine) != 0)
       return fail(ws_engine_last_error());
     if (ws_engine_info(engine, "sample_rate") != sample_rate) {
@@ -162,6 +164,10 @@ int main(int argc, char** argv) {
       std::lock_guard<std::mutex> l(io_mu);
       printf("process: %s RTF: %.4f (%lld launches, %lld MiB arena)%s\n", w[0].c_str(), ms / audio_ms,
              ws_engine_info(engine, "n_launches"), ws_engine_info(engine, "arena_bytes") >> 20, dry ? " [dry run]" : "");
+      if (ws_engine_info(engine, "cluster_fallbacks") > fallbacks_seen) {
+        fallbacks_seen = ws_engine_info(engine, "cluster_fallbacks");
+        printf("note: %s: a cluster recurrence timed out (GPU shared); recomputed by the streaming kernels\n", w[0].c_str());
+      }
       total_audio_ms += audio_ms;
       total_busy_ms += ms;
     }

@@ -287,6 +287,14 @@ def gn_param_grad(x, dxn, stats, geo, nsplit, slab):
     slab.reshape(-1)[geo.W: 2 * geo.W] = d.sum((0, 1))          # d beta
 
 
+def gn_bwd_fused(x, dxn, stats, geo, gamma, dx, nwg, pslab, res=None):
+    """norm.hip gn_bwd_fused_kernel: reduce + apply + parameter sums in one call (pslab [nwg, 2, 128])."""
+    ab = torch.zeros(geo.ngroups, 2)
+    make_gn_bwd_reduce(None)(x, dxn, stats, geo, ab, gamma=gamma)
+    gn_bwd_apply(x, dxn, stats, ab, geo, dx, gamma=gamma, res=res)
+    gn_param_grad(x, dxn, stats, geo, nwg, pslab)
+
+
 def install(monkeypatch):
     """After emu_dev.install: adds the BL entry points (and BL modes of lstm_fwd / lstm_bwd)."""
     import wesep_amd.dev as dev
@@ -299,5 +307,6 @@ def install(monkeypatch):
     monkeypatch.setattr(dev, "gn_bwd_reduce", make_gn_bwd_reduce(dev.gn_bwd_reduce))
     monkeypatch.setattr(dev, "gn_bwd_apply", gn_bwd_apply)
     monkeypatch.setattr(dev, "gn_param_grad", gn_param_grad)
+    monkeypatch.setattr(dev, "gn_bwd_fused", gn_bwd_fused)
     monkeypatch.setattr(dev, "cu_count", lambda device: 256)
     _PACKS.clear()

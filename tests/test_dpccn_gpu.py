@@ -131,3 +131,52 @@ def test_dpccn_unbuilt_variants_fail_loudly():
     m = get_model("DPCCN")(joint_training=False, tcn_blocks=1, tcn_layers=1)
     with pytest.raises(Exception):
         m(torch.randn(2, 4480), torch.randn(2, 256))            # CPU tensors: no CPU path
+
+
+def test_baseline_config3_dpccn_with_joint_resnet34_vs_oracle_chain():
+    """BASELINE.json configs[2] -- pDPCCN + jointly-learned speaker encoder -- with the recipe's arguments
+    (examples/librimix/tse/v2/confs/dpccn.yaml: multiply fusion, ResNet34 on 80-d fbank, 256-d embedding) at 4 rows x
+    4 s, 398 enrollment frames: forward against oracle(ResNet restatement) -> oracle(DPCCN), loss, and gradient norms of
+    the separator AND of the speaker encoder (the chain is differentiated end to end on the CPU).  Gradients by norm at
+    3e-2 like the fixture tests: ELU / ReLU networks at random initialisation (see tests/test_resnet_gpu.py)."""
+    from oracle import bsrnn_oracle as O
+    from oracle import dpccn_oracle as DP
+    from oracle import resnet_oracle as RO
+    from wesep_amd.models import get_model
+    from wesep_amd.utils.losses import parse_loss
+    d = _cuda()
+    kw = dict(spk_fuse_type="multiply", use_spk_transform=False)
+    cfg = DP.DPCCNConfig(**kw)
+    sep = DP.synth_params(cfg, 21)
+    spk = RO.synth_params(22, prefix="spk_model.")
+    model = get_model("DPCCN")(**kw, joint_training=True, spk_model="ResNet34", spk_feat=True,
+                               spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
+    model.load_state_dict({**spk, **sep}, strict=True)
+    model = model.to(d).train()
+    R, T = 4, 64000
+    wav, tgt, _ = O.synth_batch(R, T, 21)
+    fbank = torch.randn(R, 398, 80, generator=torch.Generator().manual_seed(23))
+    fbank = fbank - fbank.mean(1, keepdim=True)
+    est, second = model(wav.to(d), fbank.to(d))
+    loss = parse_loss("SISDR")[0](est, tgt.to(d))
+    loss.backward()
+    torch.cuda.synchronize()
+    ps = {k: v.clone().requires_grad_(True) for k, v in sep.items()}
+    pk = {k: (v.clone() if RO.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in spk.items()}
+    emb = RO.resnet_forward(pk, fbank, prefix="spk_model.")
+    ref = DP.dpccn_forward(ps, cfg, wav, emb)
+    loss_o = O.sisdr_loss(ref, tgt)
+    loss_o.backward()
+    assert tuple(second.shape) == (R, 256) and rel(second, emb) < 1e-3
+    assert rel(est, ref) < 1e-3, rel(est, ref)
+    assert abs(loss.item() - loss_o.item()) < 1e-2
+    want = {**{k: v.grad for k, v in ps.items()}, **{k: v.grad for k, v in pk.items() if not RO.is_buffer(k)}}
+    floor = 1e-3 * max(float(v.norm()) for v in want.values())
+    bad = []
+    for k, prm in model.named_parameters():
+        gn = float(want[k].norm())
+        if prm.grad is None or abs(float(prm.grad.norm()) - gn) > 3e-2 * gn + floor:
+            bad.append((k, None if prm.grad is None else float(prm.grad.norm()), gn))
+    print(f"config 3 (DPCCN + joint ResNet34, R=4 x 4 s): est rel {rel(est, ref):.2e}, "
+          f"dloss {abs(loss.item() - loss_o.item()):.2e} dB, {len(want)} gradient norms")
+    assert not bad, bad[:8]

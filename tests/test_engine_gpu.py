@@ -160,7 +160,34 @@ def test_separate_main_end_to_end(tmp_path):
                         "--model", str(tmp_path / "j.wsw"), "--output_dir", str(out_dir), "--jobs", "2"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    ref_bytes = (out_dir / "utt1-spk1.wav").read_bytes()
+    # byte-identical: engines that share a GPU take turns on the device (ws_engine_separate's per-device lock; overlapping
+    # forwards were not reproducible, profiles/r02_kernel_race.md) -- unless a cluster recurrence timed out and the streaming
+    # kernels took over (different MFMA order, reported on stdout): then within one 16-bit step
+    ref = np.frombuffer((out_dir / "utt1-spk1.wav").read_bytes()[44:], dtype=np.int16).astype(np.int32)
     for i in range(4):
-        assert (out_dir / f"c{i}-spk1.wav").read_bytes() == ref_bytes
+        got = np.frombuffer((out_dir / f"c{i}-spk1.wav").read_bytes()[44:], dtype=np.int16).astype(np.int32)
+        if "a cluster recurrence timed out" in r.stdout:
+            assert np.abs(got - ref).max() <= 1, r.stdout
+        else:
+            assert np.array_equal(got, ref), (int(np.abs(got - ref).max()), int((got != ref).sum()), r.stdout)
     eng.close()
+
+
+def test_engine_reads_no_uninitialised_arena_memory(tmp_path, monkeypatch):
+    """WS_ENGINE_POISON=1 starts every arena allocation as NaN: a launch plan that reads memory no kernel has written
+    (padding slots, scratch, a stale stack frame) would turn the estimate into NaN instead of making it depend on what
+    the arena held before -- which is what two engines sharing a GPU see.  Same bits as the unpoisoned run."""
+    d = _cuda()
+    model, eng = _joint(tmp_path, "ResNet18", d)
+    g = torch.Generator().manual_seed(11)
+    wav = 0.1 * torch.randn(2, 24000, generator=g)          # time view: one 64-sequence cluster; band view: padded tiles
+    enroll = 0.1 * torch.randn(2, 30001, generator=g)
+    want = eng.separate(wav.numpy(), enroll.numpy(), E.ENROLL_WAVE)
+    eng.close()
+    monkeypatch.setenv("WS_ENGINE_POISON", "1")
+    eng2 = E.Engine(str(tmp_path / "j.wsw"))
+    for _ in range(2):                                       # second call: the consolidated arena
+        got = eng2.separate(wav.numpy(), enroll.numpy(), E.ENROLL_WAVE)
+        assert np.isfinite(got).all()
+        assert np.array_equal(got, want)
+    eng2.close()

@@ -221,6 +221,50 @@ def test_group_stats_and_gn_backward(view):
     assert rel(out[0], gam.grad) < 1e-5 and rel(out[1], bet.grad) < 1e-5
 
 
+@pytest.mark.parametrize("R,K,Tf", [(2, 32, 37), (3, 6, 11), (1, 2, 300)])
+def test_gn_backward_fused_small_groups(R, K, Tf):
+    """norm.hip gn_bwd_fused_kernel (one wave per band-view group: reduce + apply + dgamma / dbeta in one pass) against
+    torch's GroupNorm backward and against the three-kernel form."""
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(R * 100 + K)
+    N = 128
+    z = rnd(g, R, K, Tf, N) + 0.3
+    dxn = rnd(g, R, K, Tf, N)
+    gamma = rnd(g, N) + 1.0
+    res = rnd(g, R, K, Tf, N)
+    geo = _geoms(R, K, Tf, N, d)[1]
+    assert dev.gn_bwd_fused_ok(geo)
+    x3 = z.permute(0, 2, 3, 1).reshape(R * Tf, N, K).clone().requires_grad_(True)
+    d3 = dxn.permute(0, 2, 3, 1).reshape(R * Tf, N, K)
+    gam = gamma.clone().requires_grad_(True)
+    bet = torch.zeros(N, requires_grad=True)
+    eps = float(np.finfo(np.float32).eps)
+    torch.nn.functional.group_norm(x3, 1, gam, bet, eps).backward(d3)
+    gref = x3.grad.reshape(R, Tf, N, K).permute(0, 3, 1, 2) + res
+    zd, dd = z.to(d), dxn.to(d)
+    stats = torch.empty(geo.ngroups, 2, device=d)
+    dev.group_stats(zd, geo, stats)
+    outs = []
+    for nwg in (1, 7, min(1024, -(-geo.ngroups // 4))):
+        dz = torch.full_like(zd, float("nan"))
+        pslab = torch.full((nwg, 2, N), float("nan"), device=d)
+        dev.gn_bwd_fused(zd, dd, stats, geo, gamma.to(d), dz, nwg, pslab, res=res.to(d))
+        assert rel(dz, gref) < 1e-5, nwg
+        out = pslab.sum(0)
+        assert rel(out[0], gam.grad) < 1e-5 and rel(out[1], bet.grad) < 1e-5, nwg
+        outs.append(dz)
+    assert torch.equal(outs[0], outs[2])                      # dx does not depend on the launch geometry
+    ab = torch.empty(geo.ngroups, 2, device=d)
+    dev.gn_bwd_reduce(zd, dd, stats, geo, ab, gamma=gamma.to(d))
+    dz3 = torch.empty_like(zd)
+    dev.gn_bwd_apply(zd, dd, stats, ab, geo, dz3, gamma=gamma.to(d), res=res.to(d))
+    assert rel(outs[0], dz3) < 1e-6
+    dzn = torch.empty_like(zd)                                # without the residual term
+    dev.gn_bwd_fused(zd, dd, stats, geo, gamma.to(d), dzn, 5, torch.empty(5, 2, N, device=d))
+    assert rel(dzn, gref - res) < 1e-5
+
+
 # ----------------------------------------------------------------------------------------------
 # LSTM recurrence
 # ----------------------------------------------------------------------------------------------

@@ -185,3 +185,54 @@ def test_fbank_frontend_matches_restatement_and_joint_raw_audio_path():
     model = model.to(d).train()
     est, _ = model(torch.randn(2, 3000, device=d) * 0.1, wav[:2].to(d))
     assert est.shape == (2, 3000) and torch.isfinite(est).all()
+
+
+def _record_relu_masks(monkeypatch):
+    """Wraps models.resnet._cba: collects the ReLU masks (output > 0) of the device forward in evaluation order, as
+    [R, C, F', T'] boolean tensors on the CPU."""
+    import wesep_amd.models.resnet as MR
+    masks = []
+    real = MR._cba
+
+    def cba(x, res, R, H, W, stride, relu, conv, bn, training):
+        y = real(x, res, R, H, W, stride, relu, conv, bn, training)
+        if relu:
+            Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+            masks.append((y.detach() > 0).view(R, Ho, Wo, -1).permute(0, 3, 1, 2).cpu())
+        return y
+
+    monkeypatch.setattr(MR, "_cba", cba)
+    return masks
+
+
+@pytest.mark.parametrize("name,Tf,Fq,E", [("ResNet18", 64, 16, 64), ("ResNet34", 96, 80, 256)])
+def test_resnet_gradients_on_the_same_linear_region(monkeypatch, name, Tf, Fq, E):
+    """Every parameter gradient of the speaker encoder against the restatement at 2e-3 -- ResNet34 at the recipe's
+    geometry (80 mel bins, 256-d embedding, confs/bsrnn.yaml:58-64).  The restatement is differentiated on the SAME
+    linear region as the device forward (its ReLUs use the device's masks, oracle.resnet_oracle.resnet_forward
+    relu_masks): what remains is arithmetic, not the handful of pre-activations within rounding distance of zero whose
+    flipped masks dominate test_resnet18_matches_oracle's 3e-2."""
+    from oracle import resnet_oracle as RO
+    from wesep_amd.models.resnet import get_speaker_model
+    d = _cuda()
+    kw = dict(num_blocks=RO.NUM_BLOCKS[name], m=32, feat_dim=Fq, embed_dim=E)
+    params = RO.synth_params(7, **kw)
+    model = get_speaker_model(name)(feat_dim=Fq, embed_dim=E, pooling_func="TSTP", two_emb_layer=False)
+    model.load_state_dict(params, strict=True)
+    model = model.to(d).train()
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(3, Tf, Fq, generator=g)
+    probe = torch.randn(3, E, generator=g)
+    masks = _record_relu_masks(monkeypatch)
+    _, emb = model(x.to(d))
+    (emb * probe.to(d)).sum().backward()
+    torch.cuda.synchronize()
+    p = {k: (v.clone() if RO.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in params.items()}
+    ref = RO.resnet_forward(p, x, num_blocks=kw["num_blocks"], m=32, relu_masks=masks)
+    (ref * probe).sum().backward()
+    assert rel(emb, ref) < 1e-3
+    per = {k: rel(prm.grad, p[k].grad) for k, prm in model.named_parameters()}
+    worst = max(per, key=per.get)
+    print(f"{name}: emb rel {rel(emb, ref):.2e}; worst gradient {per[worst]:.2e} ({worst}); "
+          f"median {sorted(per.values())[len(per) // 2]:.2e}")
+    assert per[worst] < 2e-3, (worst, per[worst])

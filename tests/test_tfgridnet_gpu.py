@@ -72,3 +72,44 @@ def test_tfgridnet_unbuilt_variants_fail_loudly():
                dict(joint_training=False, spk_fuse_type="concat"), dict(joint_training=False, lstm_hidden_units=320)):
         with pytest.raises(NotImplementedError):
             get_model("TFGridNet")(**kw)
+
+
+def test_baseline_config5_geometry_recipe_6s_vs_oracle():
+    """BASELINE.json configs[4] geometry -- TF-GridNet, 6 s utterances -- with the recipe's model arguments
+    (examples/librimix/tse/v2/confs/tfgridnet.yaml:44-60: n_fft 128 / stride 64, 6 layers, hidden 192, 4 heads, qk 512,
+    emb_dim 128, emb_ks = emb_hs = 1) at 2 rows x 96 000 samples (Tf = 1501): waveform, loss and every gradient norm
+    against the oracle.  This is the geometry on which the blocked-layout recurrences (cluster kernel on the
+    zero-padded 130 -> 192 inter-frame sequences) and the grouped attention run."""
+    from oracle import bsrnn_oracle as O
+    from oracle import tfgridnet_oracle as TG
+    from wesep_amd.models import get_model
+    from wesep_amd.utils.losses import parse_loss
+    d = _cuda()
+    kw = dict(n_fft=128, stride=64, n_layers=6, lstm_hidden_units=192, attn_n_head=4, attn_approx_qk_dim=512, emb_dim=128,
+              emb_ks=1, emb_hs=1, use_spk_transform=False, spk_fuse_type="multiply")
+    cfg = TG.TFGridNetConfig(**kw)
+    params = TG.synth_params(cfg, 31)
+    model = get_model("TFGridNet")(**kw, joint_training=False)
+    model.load_state_dict(params, strict=True)
+    model = model.to(d).train()
+    wav, tgt, emb = O.synth_batch(2, 96000, 31)
+    est, _ = model(wav.to(d), emb.to(d))
+    loss = parse_loss("SISDR")[0](est, tgt.to(d))
+    loss.backward()
+    torch.cuda.synchronize()
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out = TG.tfgridnet_forward(p, cfg, wav, emb)
+    ref = out[0] if isinstance(out, (tuple, list)) else out
+    loss_o = O.sisdr_loss(ref, tgt)
+    loss_o.backward()
+    print(f"config 5 geometry (TF-GridNet recipe, R=2 x 6 s): est rel {rel(est, ref):.2e}, "
+          f"dloss {abs(loss.item() - loss_o.item()):.2e} dB")
+    assert rel(est, ref) < 1e-3, rel(est, ref)
+    assert abs(loss.item() - loss_o.item()) < 1e-2
+    floor = 1e-3 * max(float(v.grad.norm()) for v in p.values())
+    bad = []
+    for k, prm in model.named_parameters():
+        gn = float(p[k].grad.norm())
+        if prm.grad is None or abs(float(prm.grad.norm()) - gn) > 3e-2 * gn + floor:
+            bad.append((k, None if prm.grad is None else float(prm.grad.norm()), gn))
+    assert not bad, bad[:8]

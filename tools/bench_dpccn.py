@@ -17,6 +17,9 @@ def main():
     ap.add_argument("--rows", type=int, default=4)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--joint", action="store_true",
+                    help="BASELINE configs[2]: jointly trained wespeaker ResNet34 on [R, 398, 80] fbank enrollment "
+                         "(examples/librimix/tse/v2/confs/dpccn.yaml) instead of fixed embeddings")
     args = ap.parse_args()
     from wesep_amd.functional import SISDRFn
     from wesep_amd.models import get_model
@@ -24,9 +27,17 @@ def main():
     from wesep_amd.utils.synthetic import synth_batch
     d = torch.device("cuda:0")
     torch.manual_seed(0)
-    model = get_model("DPCCN")(joint_training=False).to(d).train()
+    if args.joint:
+        model = get_model("DPCCN")(joint_training=True, spk_model="ResNet34", spk_feat=True,
+                                   spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
+    else:
+        model = get_model("DPCCN")(joint_training=False)
+    model = model.to(d).train()
     opt = FusedClipAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, clip_grad=5.0)
     wav, tgt, emb = (t.to(d) for t in synth_batch(args.rows, 64000, 42))
+    if args.joint:
+        fb = torch.randn(args.rows, 398, 80, generator=torch.Generator().manual_seed(43))
+        emb = (fb - fb.mean(1, keepdim=True)).to(d)
 
     def step():
         est, _ = model(wav, emb)
@@ -44,7 +55,8 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"metric": "utterances/sec (4 s, 16 kHz) fwd+bwd, DPCCN (fixed embeddings)",
+    print(json.dumps({"metric": "utterances/sec (4 s, 16 kHz) fwd+bwd, DPCCN (" +
+                                ("joint ResNet34 speaker encoder" if args.joint else "fixed embeddings") + ")",
                       "value": args.rows * args.steps / el, "unit": "utterances/s",
                       "ms_per_step": el / args.steps * 1e3, "rows": args.rows, "steps": args.steps, "dtype": "bf16x3",
                       "data": "synthetic", "final_loss_dB": float(loss.item()),

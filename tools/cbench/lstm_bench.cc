@@ -164,7 +164,7 @@ int main(int argc, char** argv) {
   unsigned* flags = nullptr;
   if (cluster_ok && what.find("cluster") != std::string::npos) {
     xchg = dalloc(size_t(nseq / 32) * 2 * 64 * 8192 / 4);
-    flags = reinterpret_cast<unsigned*>(dalloc(size_t(nseq / 32) * 8));
+    flags = reinterpret_cast<unsigned*>(dalloc(size_t(nseq / 32) * 8 + 8));
     ws_lstm_cluster_args c = {};
     c.gates = gates, c.cbuf = cbuf, c.hcat = hcat, c.whh_f = whf, c.whh_r = whr, c.xchg = xchg, c.flags = flags;
     c.nseq = nseq, c.L = L;
@@ -217,7 +217,7 @@ int main(int argc, char** argv) {
     if (cluster_ok) {
       if (!xchg) {
         xchg = dalloc(size_t(nseq / 32) * 2 * 64 * 8192 / 4);
-        flags = reinterpret_cast<unsigned*>(dalloc(size_t(nseq / 32) * 8));
+        flags = reinterpret_cast<unsigned*>(dalloc(size_t(nseq / 32) * 8 + 8));
       }
       ws_lstm_cluster_args c = {};
       c.gates = gates, c.cbuf = cbuf, c.hcat = hcat, c.dhcat = dh, c.whh_f = whf, c.whh_r = whr, c.xchg = xchg;

@@ -14,7 +14,7 @@ import sys
 N_XCD, N_SIMD = 8, 1024
 
 
-def main(path, out_json):
+def main(path, out_json, commit="", bench_sha16="", command=""):
     busy, act, ns = collections.defaultdict(float), collections.defaultdict(float), collections.defaultdict(float)
     n = collections.Counter()
     for r in csv.DictReader(open(path)):
@@ -36,10 +36,11 @@ def main(path, out_json):
                   "mfma_busy_frac": busy[k] / (cyc * N_SIMD)}
     json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, bench.py --steps 1 --warmup 1",
                "formula": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)",
+               "collected": {"commit": commit, "bench_py_sha16": bench_sha16, "command": command},
                "kernels": out}, open(out_json, "w"), indent=1)
     for k, v in list(out.items())[:12]:
         print(f"{k[:56]:56s} n={v['launches']:3d} busy_frac={v['mfma_busy_frac']:.3f} cycles={v['kernel_cycles_per_launch']:.3e} us={v['avg_us_under_profiler']:.0f}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:6])

@@ -6,7 +6,8 @@ per kernel, average per-launch FETCH_SIZE / WRITE_SIZE (KiB as reported) and the
 write volumes exactly, e.g. lstm_fwd: 24 fp32 per position-direction-unit = 6.304 GB).
 
     python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE/pmc_counter_collection.csv \
-        gpurun_out/pmc_WRITE_SIZE/pmc_counter_collection.csv profiles/r01_pmc_traffic.json"""
+        gpurun_out/pmc_WRITE_SIZE/pmc_counter_collection.csv profiles/r01_pmc_traffic.json \
+        [commit bench_py_sha16 command]      (provenance recorded under "collected")"""
 import collections
 import csv
 import json
@@ -20,7 +21,7 @@ def per_kernel(path):
     return agg
 
 
-def main(fetch_csv, write_csv, out_json):
+def main(fetch_csv, write_csv, out_json, commit="", bench_sha16="", command=""):
     f, w = per_kernel(fetch_csv), per_kernel(write_csv)
     out = {}
     for k in sorted(set(f) | set(w), key=lambda k: -(sum(f.get(k, [0])) + sum(w.get(k, [0])))):
@@ -31,8 +32,9 @@ def main(fetch_csv, write_csv, out_json):
                   "hbm_bytes_per_launch_raw": fa * 1024 + wa * 1024}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 1",
                "correction": "traffic = 2*FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section)",
+               "collected": {"commit": commit, "bench_py_sha16": bench_sha16, "command": command},
                "kernels": out}, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:7])

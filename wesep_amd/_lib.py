@@ -107,6 +107,7 @@ _SIGS = {
     "ws_last_error": (C.c_char_p, []),
     "ws_prof_enable": (_i, [_i]),
     "ws_prof_collect": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_ll)]),
+    "ws_debug_dirty_lds": (_i, [_f, _i, _i, _p, _p]),
     "ws_gemm_nt": (_i, [C.POINTER(GemmNTArgs), _p]),
     "ws_gemm_tn": (_i, [C.POINTER(GemmTNArgs), _p]),
     "ws_reduce_slabs": (_i, [_p, _i, _ll, _ll, _p, _i, _ll, _p]),
@@ -115,6 +116,7 @@ _SIGS = {
     "ws_gn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _p, _p]),
     "ws_gn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _p, _p]),
     "ws_gn_param_grad": (_i, [_p, _p, _p, C.POINTER(GroupsGeom), _i, _p, _p]),
+    "ws_gn_bwd_fused": (_i, [_p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _i, _p, _p, _p]),
     "ws_lstm_pack": (_i, [_p, _p, _p, _p, _i, _p]),
     "ws_lstm_fwd": (_i, [C.POINTER(LstmArgs), _p]),
     "ws_lstm_bwd": (_i, [C.POINTER(LstmArgs), _p]),

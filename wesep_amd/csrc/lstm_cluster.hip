@@ -34,6 +34,34 @@ __device__ __forceinline__ void split8r(const f32x4& a, const f32x4& b, bf16x8& 
   }
 }
 
+// cold path of a bounded wait: poison from here on, set this launch's timeout word (flags[ncl * 8], zeroed with the
+// flags) and the caller's sticky status word
+__device__ __noinline__ void cluster_timed_out(unsigned* tword, unsigned* status, int* dead_s) {
+  *dead_s = 1;
+  __hip_atomic_store((gu32*)tword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (status) __hip_atomic_store((gu32*)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Cluster -> workgroup mapping.  Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8), each with its
+// own L2.  All 8 members of a cluster are placed on ONE XCD for every cluster count: XCD x hosts the clusters
+// c = x, x + 8, ..., member j of cluster c is block ((j * cpx + c / 8) * 8 + x) with cpx = ceil(ncl / 8) clusters per
+// XCD; the grid is 64 * cpx blocks and blocks whose cluster index is >= ncl exit at once.  (Round 1 used
+// c = blockIdx % ncl, which equals this mapping when ncl % 8 == 0 -- training at R = 32 -- but spread the members of
+// small launches -- inference, 2 rows: ncl = 2 -- over XCDs, where the sc1 payload / relaxed flag hand-off has no
+// ordering guarantee between two L2s: concurrent engines produced rare one-LSB differences, round 2.)
+__device__ __forceinline__ bool cluster_of_block(int ncl, int legacy, int& c, int& j) {
+  if (legacy) {
+    c = blockIdx.x % ncl, j = blockIdx.x / ncl;
+    return j < 8;
+  }
+  const int cpx = (ncl + 7) >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+  c = (q % cpx) * 8 + x;
+  j = q / cpx;
+  return c < ncl;
+}
+__host__ inline int cluster_grid(int ncl, int legacy) { return legacy ? ncl * 8 : 64 * ((ncl + 7) / 8); }
+
+template <bool FORCE>
 __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_cluster_args p) {
   // VMEM operations of one wave complete in order, so an exchange wave must never have HBM traffic in
   // its queue (measured: +3.2 us per step when it does).  All 8 waves run the MFMAs and the cell
@@ -46,7 +74,8 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
   __shared__ __attribute__((aligned(16))) u32x4 publ[512];               // h chunks (bf16 hi x4 | lo x4), 8 KB
   __shared__ int dead_s;
   const int ntile = p.nseq / 32, ncl_dir = ntile / 2, ncl = 2 * ncl_dir;
-  const int c = blockIdx.x % ncl, j = blockIdx.x / ncl;  // member j of cluster c (same c -> same XCD when ncl % 8 == 0)
+  int c, j;  // member j of cluster c
+  if (!cluster_of_block(ncl, p.dbg & 16, c, j)) return;
   const int d = c / ncl_dir, cc = c % ncl_dir;
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,7 +114,6 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
       reinterpret_cast<char*>(p.xchg) + (long long)c * (2 * 8 * 8192), 0, 2 * 8 * 8192, 0x00020000);
   const int mychunk = (st * 32 + n) * 8 + 2 * uo + half;  // chunk of this thread's h in a producer's slice
   gu32* flags = (gu32*)(p.flags) + c * 8;
-  gu32* tword = (gu32*)(p.flags) + ncl * 8;  // this launch's timeout word (zeroed with the flags)
 
   f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 xpre[2][4];  // M-waves: x-projection of the NEXT step for their two cells
@@ -193,17 +221,13 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
     if (tid == 0) __hip_atomic_store(flags + j, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (w == 0 && dead_s == 0 && !(p.dbg & 1)) {
       unsigned spins = 0;
-      const bool force = (p.dbg & 8) && step == 2 && blockIdx.x == 0;  // tests: a timeout on demand
       while (true) {
         const unsigned v = lane < 8 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                     : 0xffffffffu;
+        const bool force = FORCE && step == 2 && c == 0 && j == 0;  // test instantiation: a timeout on demand
         if (!force && __all((int)(v >= (unsigned)(step + 1)))) break;
         if (force || ++spins > CL_SPIN_LIMIT) {
-          if (lane == 0) {
-            dead_s = 1;
-            __hip_atomic_store(tword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (p.status) __hip_atomic_store((gu32*)(p.status), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+          if (lane == 0) cluster_timed_out(p.flags + ncl * 8, p.status, &dead_s);
           break;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -241,11 +265,15 @@ extern "C" int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream) 
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   WS_REQUIRE(nwg <= cus, "ws_lstm_fwd_cluster: %d workgroups must be co-resident but the device has %d CUs", nwg, cus);
+  const int grid = cluster_grid(a->nseq / 32, a->dbg & 16);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)(a->nseq / 32) * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_fwd_cluster: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
-  hipLaunchKernelGGL(lstm_fwd_cluster_kernel, dim3(nwg), dim3(512), 0, s, *a);
+  if (a->dbg & 8)
+    hipLaunchKernelGGL(lstm_fwd_cluster_kernel<true>, dim3(grid), dim3(512), 0, s, *a);
+  else
+    hipLaunchKernelGGL(lstm_fwd_cluster_kernel<false>, dim3(grid), dim3(512), 0, s, *a);
   ws_prof_end(WS_PROF_LSTM_FWD, s);
   return ws_check_launch("ws_lstm_fwd_cluster");
 }
@@ -267,12 +295,14 @@ extern "C" int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream) 
 // =============================================================================================
 #define BK_ROW 136  // bf16 per LDS row of the local d(gates) image (128 + 8: 272 B = 4 banks mod 64)
 
+template <bool FORCE>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_cluster_kernel(const ws_lstm_cluster_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 dgl[2][CL_SEQ * BK_ROW];  // [part][seq][local gate col] 34 KB
   __shared__ __attribute__((aligned(16))) f32x4 rec[512];                  // reduced dh per cell, 8 KB
   __shared__ int dead_s;
   const int ntile = p.nseq / 32, ncl_dir = ntile / 2, ncl = 2 * ncl_dir;
-  const int c = blockIdx.x % ncl, j = blockIdx.x / ncl;
+  int c, j;  // member j of cluster c
+  if (!cluster_of_block(ncl, p.dbg & 16, c, j)) return;
   const int d = c / ncl_dir, cc = c % ncl_dir;
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -286,7 +316,6 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_cluster_kernel(const ws_lstm_
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(p.xchg) + (long long)c * (2 * 64 * 8192), 0, 2 * 64 * 8192, 0x00020000);
   gu32* flags = (gu32*)(p.flags) + c * 8;
-  gu32* tword = (gu32*)(p.flags) + ncl * 8;  // this launch's timeout word (zeroed with the flags)
 
   auto step_t = [&](int step) { return d == 0 ? L - 1 - step : step; };
   __syncthreads();
@@ -370,17 +399,13 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_cluster_kernel(const ws_lstm_
       if (tid == 0) __hip_atomic_store(flags + j, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (w == 0 && !dead && !(p.dbg & 1)) {
         unsigned spins = 0;
-        const bool force = (p.dbg & 8) && step == 2 && blockIdx.x == 0;  // tests: a timeout on demand
         while (true) {
           const unsigned v = lane < 8 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                       : 0xffffffffu;
+          const bool force = FORCE && step == 2 && c == 0 && j == 0;  // test instantiation: a timeout on demand
           if (!force && __all((int)(v >= (unsigned)(step + 1)))) break;
           if (force || ++spins > CL_SPIN_LIMIT) {
-            if (lane == 0) {
-              dead_s = 1;
-              __hip_atomic_store(tword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (p.status) __hip_atomic_store((gu32*)(p.status), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (lane == 0) cluster_timed_out(p.flags + ncl * 8, p.status, &dead_s);
             break;
           }
           __builtin_amdgcn_s_sleep(2);
@@ -489,11 +514,15 @@ extern "C" int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream) 
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   WS_REQUIRE(nwg <= cus, "ws_lstm_bwd_cluster: %d workgroups must be co-resident but the device has %d CUs", nwg, cus);
+  const int grid = cluster_grid(a->nseq / 32, a->dbg & 16);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)(a->nseq / 32) * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_cluster: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
-  hipLaunchKernelGGL(lstm_bwd_cluster_kernel, dim3(nwg), dim3(512), 0, s, *a);
+  if (a->dbg & 8)
+    hipLaunchKernelGGL(lstm_bwd_cluster_kernel<true>, dim3(grid), dim3(512), 0, s, *a);
+  else
+    hipLaunchKernelGGL(lstm_bwd_cluster_kernel<false>, dim3(grid), dim3(512), 0, s, *a);
   ws_prof_end(WS_PROF_LSTM_BWD, s);
   return ws_check_launch("ws_lstm_bwd_cluster");
 }

@@ -278,3 +278,93 @@ extern "C" int ws_gn_param_grad(const float* x, const float* dxn, const float* s
                        (hipStream_t)stream, x, dxn, stats, *geo, nsplit, slab);
   return ws_check_launch("ws_gn_param_grad");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Fused GroupNorm backward for SMALL groups (the band view of ResRNN: a group = the K = 32 rows x 128 floats of one
+// (row, frame), 16 KB, rows Tf*N floats apart).  The three-kernel form above launches one 256-thread workgroup per
+// group, i.e. 16 032 workgroups that each touch 2 x 16 KB -- latency-bound (1.0 ms for the reduction alone at
+// R = 32) -- and reads x / dxn three times.  Here ONE WAVE owns a group: its x and dxn live in registers (16 float4
+// each per lane), the two group means are wave reductions, dx is written from the registers, and the per-column
+// dgamma / dbeta sums accumulate in the lane that owns the column across all groups of the wave: x, dxn and the
+// residual cross HBM exactly once.  Deterministic (fixed group -> wave assignment, fixed reduction order).
+//   lane = (row lane rl = lane >> 5, column quad c4 = lane & 31); rows rl, rl + 2, ...; L <= 32 and even, W = 128.
+// ---------------------------------------------------------------------------------------------
+#define GNF_ROWS 16  // rows per lane (L / 2 <= 16)
+__global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ dxn,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ res, const ws_groups_geom geo,
+                                                           float* __restrict__ dx, float* __restrict__ pslab) {
+  __shared__ f32x4 sh[2][4][32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c4 = lane & 31, rl = lane >> 5;
+  const int nrow = geo.L >> 1;  // rows per lane
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+  const float inv_n = 1.f / (float)(geo.L * 128);
+  f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+  const int nwave = gridDim.x * 4;
+  for (int g = blockIdx.x * 4 + w; g < geo.ngroups; g += nwave) {
+    const long long base = (long long)(g / geo.gdiv) * geo.gs1 + (long long)(g % geo.gdiv) * geo.gs2 + 4 * c4;
+    const float mean = stats[2 * (long long)g], rstd = stats[2 * (long long)g + 1];
+    f32x4 xh[GNF_ROWS], dg[GNF_ROWS];
+#pragma unroll
+    for (int j = 0; j < GNF_ROWS; ++j)
+      if (j < nrow) {
+        const long long o = base + (long long)(rl + 2 * j) * geo.rs;
+        xh[j] = *reinterpret_cast<const f32x4*>(x + o);
+        dg[j] = *reinterpret_cast<const f32x4*>(dxn + o);
+      }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < GNF_ROWS; ++j)
+      if (j < nrow) {
+        xh[j] = (xh[j] - mean) * rstd;
+        sg += dg[j] * xh[j];
+        sb += dg[j];
+        dg[j] = dg[j] * gm;
+        s1 += (dg[j][0] + dg[j][1]) + (dg[j][2] + dg[j][3]);
+        s2 += (dg[j][0] * xh[j][0] + dg[j][1] * xh[j][1]) + (dg[j][2] * xh[j][2] + dg[j][3] * xh[j][3]);
+      }
+    const float a0 = ws_wave_sum(s1) * inv_n, a1 = ws_wave_sum(s2) * inv_n;
+#pragma unroll
+    for (int j = 0; j < GNF_ROWS; ++j)
+      if (j < nrow) {
+        const long long o = base + (long long)(rl + 2 * j) * geo.rs;
+        f32x4 r = (dg[j] - a0 - xh[j] * a1) * rstd;
+        if (res) r += *reinterpret_cast<const f32x4*>(res + o);
+        *reinterpret_cast<f32x4*>(dx + o) = r;
+      }
+  }
+  // column sums: the two row lanes of a wave, then the four waves, in fixed order
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sg[q] += __shfl_xor(sg[q], 32, 64);
+    sb[q] += __shfl_xor(sb[q], 32, 64);
+  }
+  if (rl == 0) {
+    sh[0][w][c4] = sg;
+    sh[1][w][c4] = sb;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {  // lanes 0..31 -> dgamma, 32..63 -> dbeta
+    f32x4 t = sh[rl][0][c4];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) t += sh[rl][r][c4];
+    *reinterpret_cast<f32x4*>(pslab + ((long long)blockIdx.x * 2 + rl) * 128 + 4 * c4) = t;
+  }
+}
+
+extern "C" int ws_gn_bwd_fused(const float* x, const float* dxn, const float* stats, const float* gamma,
+                               const float* res, const ws_groups_geom* geo, int nwg, float* dx, float* pslab,
+                               void* stream) {
+  int rc = geom_check(geo, "ws_gn_bwd_fused");
+  if (rc != WS_OK) return rc;
+  WS_REQUIRE(x && dxn && stats && gamma && dx && pslab && nwg > 0, "ws_gn_bwd_fused: null pointer / nwg");
+  WS_REQUIRE(geom_vec4(geo) && geo->nbands == 1 && geo->W == 128 && geo->L >= 2 && geo->L <= 2 * GNF_ROWS &&
+                 geo->L % 2 == 0,
+             "ws_gn_bwd_fused: built for single-band groups of an even number (<= %d) of 128-float rows (L=%d, W=%d)",
+             2 * GNF_ROWS, geo->L, geo->W);
+  hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, dxn, stats, gamma, res,
+                     *geo, dx, pslab);
+  return ws_check_launch("ws_gn_bwd_fused");
+}

@@ -92,3 +92,22 @@ extern "C" int ws_prof_collect(int kind, double* total_ms, long long* launches) 
   g_prof.used[kind].clear();
   return WS_OK;
 }
+
+// ---- test support -------------------------------------------------------------------------
+// Leaves `value` in 60 KB of LDS of every CU it lands on (and keeps its waves alive for a few microseconds).  Run on a
+// second stream beside the product kernels it turns "a kernel read LDS it never wrote" from a silent dependence on
+// whatever ran before into NaN -- the LDS counterpart of NaN-filling uninitialised global memory.
+__global__ __launch_bounds__(256) void debug_dirty_lds_kernel(float value, int spins, float* sink) {
+  __shared__ float buf[15360];
+  for (int i = threadIdx.x; i < 15360; i += 256) buf[i] = value;
+  __syncthreads();
+  float acc = 0.f;
+  for (int s = 0; s < spins; ++s) acc += buf[(threadIdx.x * 7 + s * 13) % 15360];
+  if (sink && acc == 12345.678f) sink[0] = acc;   // never true for NaN / the test values: keeps the loop alive
+}
+
+extern "C" int ws_debug_dirty_lds(float value, int nblocks, int spins, float* sink, void* stream) {
+  WS_REQUIRE(nblocks > 0 && spins >= 0, "ws_debug_dirty_lds: bad args");
+  hipLaunchKernelGGL(debug_dirty_lds_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, value, spins, sink);
+  return ws_check_launch("ws_debug_dirty_lds");
+}

@@ -171,6 +171,24 @@ def gn_bwd_apply(x, dxn, stats, ab, geo: Geom, dx, gamma=None, gamma_tab=None, r
                                     _p(res), C.byref(g), _p(dx), L.stream_ptr()), "ws_gn_bwd_apply")
 
 
+def gn_bwd_fused_ok(geo: Geom) -> bool:
+    """Small single-band groups of 128-float rows (pBSRNN's band view): the one-pass GroupNorm backward applies.
+    WESEP_GN_FUSED=0 keeps the three-kernel form."""
+    return (os.environ.get("WESEP_GN_FUSED", "1") != "0" and geo.nbands == 1 and geo.W == 128 and geo.band_w is None
+            and geo.band_off is None and 2 <= geo.L <= 32 and geo.L % 2 == 0 and geo.rs % 4 == 0
+            and geo.gs1 % 4 == 0 and geo.gs2 % 4 == 0)
+
+
+def gn_bwd_fused(x, dxn, stats, geo: Geom, gamma, dx, nwg: int, pslab, res=None):
+    """reduce + apply + parameter sums of the GroupNorm backward in one pass (norm.hip gn_bwd_fused_kernel);
+    pslab [nwg, 2, 128]: per-workgroup shares of (dgamma, dbeta)."""
+    for n, t in (("x", x), ("dxn", dxn), ("stats", stats), ("gamma", gamma), ("res", res), ("dx", dx), ("pslab", pslab)):
+        _chk(t, n)
+    g = geo.c()
+    L.check(L.lib().ws_gn_bwd_fused(_p(x), _p(dxn), _p(stats), _p(gamma), _p(res), C.byref(g), nwg, _p(dx), _p(pslab),
+                                    L.stream_ptr()), "ws_gn_bwd_fused")
+
+
 def gn_param_grad(x, dxn, stats, geo: Geom, nsplit: int, slab):
     for n, t in (("x", x), ("dxn", dxn), ("stats", stats), ("slab", slab)):
         _chk(t, n)

@@ -438,14 +438,20 @@ class ResRNNBlkFn(torch.autograd.Function):
         # d(normalised input) = dgates Wcat -> GroupNorm backward (+ residual path)
         dxn = _empty(d, P, N)
         dev.gemm_b2p(A=gates, K=2 * G4, sm=seq, Wpack=W("wihT"), C_out=dxn, ldc=N)
-        ab = _empty(d, geo.ngroups, 2)
-        dev.gn_bwd_reduce(z, dxn, stats, geo, ab, gamma=norm_w)
-        ns2 = min(1024, geo.ngroups)
-        pslab = _empty(d, ns2, 2, N)
-        dev.gn_param_grad(z, dxn, stats, geo, ns2, pslab)
-        dgb = _reduce_new(pslab, ns2, 2 * N, (2, N))
         dz = torch.empty_like(z)
-        dev.gn_bwd_apply(z, dxn, stats, ab, geo, dz, gamma=norm_w, res=dout)
+        if dev.gn_bwd_fused_ok(geo):
+            # band view: 16 032 groups of 16 KB -- one wave per group, x / dxn / dout cross HBM once (norm.hip)
+            ns2 = min(1024, -(-geo.ngroups // 4))
+            pslab = _empty(d, ns2, 2, N)
+            dev.gn_bwd_fused(z, dxn, stats, geo, norm_w, dz, ns2, pslab, res=dout)
+        else:
+            ab = _empty(d, geo.ngroups, 2)
+            dev.gn_bwd_reduce(z, dxn, stats, geo, ab, gamma=norm_w)
+            ns2 = min(1024, geo.ngroups)
+            pslab = _empty(d, ns2, 2, N)
+            dev.gn_param_grad(z, dxn, stats, geo, ns2, pslab)
+            dev.gn_bwd_apply(z, dxn, stats, ab, geo, dz, gamma=norm_w, res=dout)
+        dgb = _reduce_new(pslab, ns2, 2 * N, (2, N))
         gd = torch.zeros((), device=d) if box is not None else None
         return (dz, gd, None, None, None, dgb[0], dgb[1]) + tuple(wg)
 

@@ -12,6 +12,7 @@ already use, plus one row-softmax kernel:
     "one mean/variance per row, affine per column" on a suitably flattened [rows, width] view -> the cLN kernels;
   * the full-band self-attention is two GEMMs per (batch row, head) around the row softmax.
 Reference lines: wesep/models/tfgridnet.py:197-302, wesep/modules/tfgridnet/gridnet_block.py:118-284."""
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -261,6 +262,59 @@ class MatmulNTFn(torch.autograd.Function):
             dBt, _ = _wgrad(A, M, K, dC, N, with_bias=False, vec=0)
             dB = _transposed(dBt, K, N)
         return dA, dB
+
+
+class BatchedMatmulNTFn(torch.autograd.Function):
+    """A [G, M, K] x B [G, N, K]^T (+ bias [N]) -> C [G, M, N], both operands differentiable: ONE grouped launch over
+    the G = heads x batch rows attention problems of a block (gridnet_block.py:176-206) instead of a host loop of G
+    launches, forward and backward (ws_gemm_nt / ws_gemm_tn with per-group descriptors).  bias carries no gradient (it
+    is the -inf mask of zero-padded key columns)."""
+
+    @staticmethod
+    def _nt(A, W, bias, G, M, K, N):
+        d = A.device
+        C_ = _empty(d, G, M, N)
+        tab = np.zeros(G, dtype=L.GROUP_NT_DTYPE)
+        wp, bp = W.data_ptr(), (bias.data_ptr() if bias is not None else 0)
+        for g in range(G):
+            tab[g] = (wp + 4 * g * N * K, bp, 0, 0, g * M * K, g * M * N, 0, K, N, K, 0)
+        desc = L.upload_struct_array(tab, d)
+        dev.gemm_nt(A=A, a_rows=flat(K), M=M, C_out=C_, c_rows=flat(N), groups=desc, ngroups=G, max_n=N,
+                    vec=3 if (K % 4 == 0 and (M * K) % 4 == 0) else 0)
+        return C_
+
+    @staticmethod
+    def forward(ctx, A, B, bias):
+        _need_cuda(A, "TF-GridNet attention")
+        A, B = A.contiguous(), B.contiguous()
+        G, M, K = A.shape
+        N = B.shape[1]
+        ctx.save_for_backward(A, B)
+        return BatchedMatmulNTFn._nt(A, B, bias, G, M, K, N)
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        dC = dC.contiguous()
+        G, M, K = A.shape
+        N = B.shape[1]
+        d = A.device
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            Bt = B.transpose(1, 2).contiguous()                                 # [G, K, N]: W'[k][n] of dA = dC B
+            dA = BatchedMatmulNTFn._nt(dC, Bt, None, G, M, N, K)
+        if ctx.needs_input_grad[1]:
+            # dB[g] = dC[g]^T A[g]: the TN kernel, one split (M rows), the slab IS the result
+            dB = _empty(d, G, N, K)
+            tab = np.zeros(G, dtype=L.GROUP_TN_DTYPE)
+            for g in range(G):
+                tab[g] = (0, 0, g * M * N, g * M * K, 0, g * N * K, 0, N, K, 0, 0)
+            desc = L.upload_struct_array(tab, d)
+            rps = -(-M // 32) * 32
+            dev.gemm_tn(G=dC, g_rows=flat(N), A=A, a_rows=flat(K), M=M, slab=dB, slab_stride=G * N * K, nsplit=1,
+                        rows_per_split=rps, groups=desc, ngroups=G, max_n=N, max_k=K,
+                        vec=1 if (K % 4 == 0 and (M * K) % 4 == 0) else 0)
+        return dA, dB, None
 
 
 def blocked_path_ok(C, ks, hs):

@@ -144,15 +144,20 @@ class GridNetBlock(nn.Module):
         kh = _heads(k, B, oT, oQ, nh, E, self["attn_norm_K"])
         vh = _heads(v, B, oT, oQ, nh, cp, self["attn_norm_V"])
         D = oQ * E
-        outs = []
-        for hd in range(nh):
-            Qm, Km, Vm = qh[hd].view(B, oT, D), kh[hd].view(B, oT, D), vh[hd].view(B, oT, oQ * cp)
-            ob = []
-            for b in range(B):
-                att = FG.SoftmaxFn.apply(FG.MatmulNTFn.apply(Qm[b], Km[b]), 1.0 / math.sqrt(D))   # [T, T]
-                ob.append(FG.MatmulNTFn.apply(att, Vm[b].t().contiguous()))                         # [T, Q*cp]
-            outs.append(torch.stack(ob, 0).view(B, oT, oQ, cp))
-        o = torch.stack(outs, 3).reshape(M, C)                                                      # channel h*cp + c
+        # all heads x batch rows of the block in one grouped launch per product (G = nh * B problems of [oT, oT]).
+        # The key / value time axis is zero-padded to a multiple of 4 floats (16-byte rows for the GEMM operand loads);
+        # padded key columns get a -1e30 bias in the logits' epilogue, i.e. exactly zero attention weight.
+        G = nh * B
+        Tp = -(-oT // 4) * 4
+        Qa = torch.stack(qh, 0).view(G, oT, D)                                                      # group h * B + b
+        Ka = torch.nn.functional.pad(torch.stack(kh, 0).view(G, oT, D), (0, 0, 0, Tp - oT))
+        Va = torch.nn.functional.pad(torch.stack(vh, 0).view(G, oT, oQ * cp), (0, 0, 0, Tp - oT))
+        mask = torch.zeros(Tp, device=x.device, dtype=torch.float32)
+        mask[oT:] = -1e30
+        logits = FG.BatchedMatmulNTFn.apply(Qa, Ka, mask)                                           # [G, oT, Tp]
+        att = FG.SoftmaxFn.apply(logits.view(G * oT, Tp), 1.0 / math.sqrt(D)).view(G, oT, Tp)
+        ov = FG.BatchedMatmulNTFn.apply(att, Va.transpose(1, 2).contiguous(), None)                 # [G, oT, oQ * cp]
+        o = ov.view(nh, B, oT, oQ, cp).permute(1, 2, 3, 0, 4).reshape(M, C)                         # channel h*cp + c
         proj = self["attn_concat_proj"]
         o = FD.Conv1x1ResFn.apply(o, proj[0].weight, proj[0].bias, None)
         o = FG.PReluFn.apply(o, proj[1].weight)

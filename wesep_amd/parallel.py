@@ -53,3 +53,36 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_ranks(value: float, device):
+    """[value of rank 0, ..., value of rank N-1] on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def comm_info():
+    """What the collectives of this run actually ran on (for the scaling record)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": 1}
+    info = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+    if info["backend"] == "nccl":
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            pass
+    return info
+
+
+def all_ranks_tensor_spread(t: torch.Tensor, device) -> float:
+    """max over elements of (max over ranks - min over ranks) of a small tensor; 0.0 when every rank holds the same."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0.0
+    hi, lo = t.clone().to(device), t.clone().to(device)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return float((hi - lo).abs().max().item())
