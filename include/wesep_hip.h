@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 7
+#define WS_ABI_VERSION 8
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -178,7 +178,8 @@ typedef struct ws_lstm_args {
 #define WS_LSTM_BF16X3 3  /* split-bf16 (hi/lo, 3 bf16 MFMAs per product, fp32 accumulate), 32 */
 #define WS_LSTM_BF16X3_BLK 4 /* as 3, but gates / cbuf / hcat / dhcat are in the blocked layout BL
                                 (below): block b = tile * L + step, tile = 32 consecutive sequences;
-                                the sq_* / step_rows fields are ignored                           */
+                                the sq_* / step_rows fields are ignored.  hcat (fwd) and the d(gates)
+                                left in `gates` (bwd) are written in split-bf16 storage BLS (below)  */
 #define WS_LSTM_BF16X3_BLK16 5 /* as 4 with 16-sequence workgroups (two per tile): for views with too few
                                   sequences to fill the chip with 32-sequence workgroups         */
 #define WS_LSTM_H 256
@@ -230,6 +231,13 @@ int ws_lstm_cat_ih(const float* wih_f, const float* wih_r, const float* bih_f, c
  * holds the 32 consecutive sequences of an LSTM workgroup (`tile`) at one `step`;
  *   element (b, slot i, column c)  at  b*32*C + ((c >> 2)*32 + i)*4 + (c & 3).
  * Slots whose sequence index tile*32 + i >= nseq are padding: producers write zeros there.
+ * Split-bf16 storage BLS (ABI v8): the BL buffers that are only ever consumed as MFMA operands -- hcat (h of the
+ * blocked-layout recurrences), the d(pre-activation gates) that BPTT leaves in `gates`, and A_bl of ws_gemm_p2b
+ * (normalised input / incoming gradient) -- hold each 4-byte element as the two terms of the split product:
+ *   bits 31..16 = bf16 hi = bf16(x),  bits 15..0 = bf16 lo = bf16(x - hi),  value = hi + lo  (|error| <= 2^-17 |x|).
+ * Producers have both terms at hand (they feed them to their own MFMAs); consumers (ws_gemm_b2p's A, all operands
+ * of ws_gemm_tnb, xn of ws_lstm_fwd_fused) rebuild fragments with byte permutes instead of converting again -- the
+ * products are bit-identical to splitting an fp32 copy.  Pre-activations / activated gates, cbuf and dhcat stay fp32.
  * ws_seqmap maps a slot to its position (row) in the plain Z-layout tensors:
  *   pos = (seq / sq_div) * sq_s1 + (seq % sq_div) * sq_s2 + step * step_rows.              */
 typedef struct ws_seqmap {
@@ -244,7 +252,7 @@ int ws_pack_w(const float* W, int N, int K, long long ldw, int trans, int order,
 
 /* plain -> BL:  C[(b,i)][n] = sum_k pro(A[pos(b,i)][k]) * W'[n][k] + bias[n]   (K = 128, N % 64 == 0)
  * pro = optional GroupNorm-on-load as in ws_gemm_nt (stat index computed from pos).  If A_bl is
- * given, the (normalised) operand is also written in BL(K).  Replaces F.group_norm + the
+ * given, the (normalised) operand is also written in BL(K), as BLS elements.  Replaces F.group_norm + the
  * nn.LSTM input projection (bsrnn.py:39-40) and autograd's d(hcat) of proj (bsrnn.py:42-44). */
 typedef struct ws_gemm_p2b_args {
   const float* A;
@@ -265,7 +273,7 @@ int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream);
 /* BL -> plain:  C[pos(b,i)][n] = sum_k A[(b,i)][k] * W'[n][k] + bias[n] + R[pos][n]   (N = 128, K % 64 == 0)
  * Replaces ResRNN.proj + residual (bsrnn.py:42-46) and autograd's d(normalised input).      */
 typedef struct ws_gemm_b2p_args {
-  const float* A;    /* BL(K) */
+  const float* A;    /* BL(K), BLS elements (hcat of the recurrences / d(gates) of BPTT) */
   const float* Wpack;
   const float* bias; /* or NULL */
   const float* R;    /* plain, addressed like C, or NULL */
@@ -282,6 +290,7 @@ int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream);
  * Acat = columns [a0_off, a0_off + a0_cols) of A0 (BL(a0_width), shifted by a0_shift steps
  * inside the tile, zero outside [0, L)) followed by a1_cols columns of A1 likewise; Acat has 128
  * or 384 columns, g_cols is a multiple of 128.  aslab[split][a] (optional) = column sums of Acat.
+ * G, A0 and A1 hold BLS elements; a0_shift must be 0 (only A1 is ever the step-shifted h).
  * Replaces autograd's dW_ih / dW_hh / db (nn.LSTM) and dW_proj / db_proj.                       */
 typedef struct ws_gemm_tnb_args {
   const float* G;

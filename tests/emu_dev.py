@@ -19,10 +19,31 @@ def _gather(t, off, M, rows, K):
     return flat_[idx]
 
 
+def _descs(groups, ngroups, kind):
+    import numpy as np
+    from wesep_amd import _lib as L
+    dt = L.GROUP_NT_DTYPE if kind == "nt" else L.GROUP_TN_DTYPE
+    return np.frombuffer(groups.cpu().numpy().tobytes(), dtype=dt)[:ngroups]
+
+
+def _at(ptr, n):
+    """n floats at a raw host address taken from a CPU tensor's data_ptr() (descriptor tables carry pointers)."""
+    import ctypes
+    import numpy as np
+    return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(int(ptr))))
+
+
 def gemm_nt(*, A, a_rows, M, C_out, c_rows, N=0, K=0, W=None, ldw=0, bias=None, R=None, T=None, stats=None,
             gamma=None, beta=None, stat_map=None, act=0, groups=None, ngroups=0, max_n=0, vec=3, a_off=0, c_off=0,
             w_off=0, mode=None):
-    assert groups is None
+    if groups is not None:   # grouped launch (per-group descriptors with raw pointers, _lib.GROUP_NT_DTYPE)
+        assert stats is None and R is None and T is None and W is None
+        for gd in _descs(groups, ngroups, "nt"):
+            Kg, Ng = int(gd["K"]), int(gd["N"])
+            gemm_nt(A=A, a_rows=a_rows, M=M, C_out=C_out, c_rows=c_rows, N=Ng, K=Kg, W=_at(gd["W"], Ng * int(gd["ldw"])),
+                    ldw=int(gd["ldw"]), bias=_at(gd["bias"], Ng) if gd["bias"] else None, act=act,
+                    a_off=a_off + int(gd["a_off"]), c_off=c_off + int(gd["c_off"]))
+        return
     a = _gather(A, a_off, M, a_rows, K)
     if stats is not None:
         d1, m1, d2, m2, base = stat_map
@@ -50,7 +71,13 @@ def gemm_nt(*, A, a_rows, M, C_out, c_rows, N=0, K=0, W=None, ldw=0, bias=None, 
 def gemm_tn(*, G, g_rows, A, a_rows, M, slab, slab_stride, nsplit, rows_per_split, Nn=0, Kk=0, bslab=None,
             bslab_stride=0, out_off=0, bout_off=0, stats=None, gamma=None, beta=None, stat_map=None, shift_rows=0,
             seq_div=1, seq_len=1, groups=None, ngroups=0, max_n=0, max_k=0, vec=1, g_off=0, a_off=0, mode=None):
-    assert groups is None
+    if groups is not None:   # grouped launch (_lib.GROUP_TN_DTYPE): one output block per group in every split's slab
+        assert stats is None and not shift_rows and bslab is None
+        for gd in _descs(groups, ngroups, "tn"):
+            gemm_tn(G=G, g_rows=g_rows, A=A, a_rows=a_rows, M=M, slab=slab, slab_stride=slab_stride, nsplit=nsplit,
+                    rows_per_split=rows_per_split, Nn=int(gd["Nn"]), Kk=int(gd["Kk"]), out_off=out_off + int(gd["out_off"]),
+                    g_off=g_off + int(gd["g_off"]), a_off=a_off + int(gd["a_off"]))
+        return
     g = _gather(G, g_off, M, g_rows, Nn)
     if shift_rows:      # m' = m + shift_rows, zeroed when the step index ((m // seq_div) % seq_len) leaves the sequence
         m = torch.arange(M)

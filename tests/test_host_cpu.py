@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = built_lib.lib()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ws_abi_version() == built_lib.ABI_VERSION == 7
+    assert lib.ws_abi_version() == built_lib.ABI_VERSION == 8
 
 
 def test_ctypes_structs_match_c_layout(built_lib):

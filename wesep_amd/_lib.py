@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 7
+ABI_VERSION = 8
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 

@@ -11,6 +11,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define WS_WAVE 64
 
+// v_perm_b32 selectors of the split-bf16 storage format BLS (include/wesep_hip.h: a 4-byte element = bf16 hi << 16 |
+// bf16 lo): __builtin_amdgcn_perm(S0, S1, sel) picks bytes from {S0 = bytes 7..4, S1 = bytes 3..0}
+#define WS_SEL_LO16 0x05040100u  // S1.lo16 | S0.lo16 << 16
+#define WS_SEL_HI16 0x07060302u  // S1.hi16 | S0.hi16 << 16
+
 // ---- error plumbing ---------------------------------------------------------
 void ws_set_error(const char* fmt, ...);
 int ws_check_launch(const char* what);

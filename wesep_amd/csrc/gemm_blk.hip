@@ -35,6 +35,33 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
   }
 }
 
+// BLS (split-bf16 storage, wesep_hip.h): 8 consecutive k of a slot = two 16-byte cells of packed hi|lo elements
+// <-> the hi / lo MFMA fragments; both directions are 8 v_perm_b32 (a 16-bit 2x2 transpose per element pair)
+__device__ __forceinline__ void unpack8(const u32x4& c0, const u32x4& c1, bf16x8& hi, bf16x8& lo) {
+  u32x4 h, l;
+  h[0] = __builtin_amdgcn_perm(c0[1], c0[0], WS_SEL_HI16);
+  h[1] = __builtin_amdgcn_perm(c0[3], c0[2], WS_SEL_HI16);
+  h[2] = __builtin_amdgcn_perm(c1[1], c1[0], WS_SEL_HI16);
+  h[3] = __builtin_amdgcn_perm(c1[3], c1[2], WS_SEL_HI16);
+  l[0] = __builtin_amdgcn_perm(c0[1], c0[0], WS_SEL_LO16);
+  l[1] = __builtin_amdgcn_perm(c0[3], c0[2], WS_SEL_LO16);
+  l[2] = __builtin_amdgcn_perm(c1[1], c1[0], WS_SEL_LO16);
+  l[3] = __builtin_amdgcn_perm(c1[3], c1[2], WS_SEL_LO16);
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+__device__ __forceinline__ void pack8(const bf16x8& hi, const bf16x8& lo, u32x4& c0, u32x4& c1) {
+  const u32x4 h = __builtin_bit_cast(u32x4, hi), l = __builtin_bit_cast(u32x4, lo);
+  c0[0] = __builtin_amdgcn_perm(h[0], l[0], WS_SEL_LO16);
+  c0[1] = __builtin_amdgcn_perm(h[0], l[0], WS_SEL_HI16);
+  c0[2] = __builtin_amdgcn_perm(h[1], l[1], WS_SEL_LO16);
+  c0[3] = __builtin_amdgcn_perm(h[1], l[1], WS_SEL_HI16);
+  c1[0] = __builtin_amdgcn_perm(h[2], l[2], WS_SEL_LO16);
+  c1[1] = __builtin_amdgcn_perm(h[2], l[2], WS_SEL_HI16);
+  c1[2] = __builtin_amdgcn_perm(h[3], l[3], WS_SEL_LO16);
+  c1[3] = __builtin_amdgcn_perm(h[3], l[3], WS_SEL_HI16);
+}
+
 // position (row of the plain layout) of slot i of block b; `valid` false for padded slots
 __device__ __forceinline__ long long seq_pos(const ws_seqmap& sm, int b, int i, bool& valid) {
   const int tile = b / sm.L, step = b - tile * sm.L;
@@ -138,12 +165,14 @@ __global__ __launch_bounds__(512, 4) void gemm_p2b_kernel(const ws_gemm_p2b_args
         v0 = f32x4{0.f, 0.f, 0.f, 0.f};
         v1 = v0;
       }
-      if (eb && active) {  // the (normalised) operand itself, in BL(K), for the weight-gradient pass
-        *reinterpret_cast<f32x4*>(eb + (k0 / 4) * 128) = v0;
-        *reinterpret_cast<f32x4*>(eb + (k0 / 4 + 1) * 128) = v1;
-      }
       const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       split8(v, xh[ks], xl[ks]);
+      if (eb && active) {  // the (normalised) operand itself, in BL(K) as split pairs (BLS): the fused recurrence
+        u32x4 c0, c1;      // and the weight-gradient pass take their fragments from it without converting again
+        pack8(xh[ks], xl[ks], c0, c1);
+        *reinterpret_cast<u32x4*>(eb + (k0 / 4) * 128) = c0;
+        *reinterpret_cast<u32x4*>(eb + (k0 / 4 + 1) * 128) = c1;
+      }
     }
   }
 
@@ -278,10 +307,8 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const float v[8] = {ac[2 * ks][0], ac[2 * ks][1], ac[2 * ks][2], ac[2 * ks][3],
-                          ac[2 * ks + 1][0], ac[2 * ks + 1][1], ac[2 * ks + 1][2], ac[2 * ks + 1][3]};
-      bf16x8 ah, al;
-      split8(v, ah, al);
+      bf16x8 ah, al;  // A arrives as split pairs (BLS): h from the recurrences, d(gates) from BPTT
+      unpack8(__builtin_bit_cast(u32x4, ac[2 * ks]), __builtin_bit_cast(u32x4, ac[2 * ks + 1]), ah, al);
       const u32x4* wt = &wl[cur][ks * 512 + lane];  // [nt][part][lane]
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -346,7 +373,9 @@ extern "C" int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream) {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define TB_LD 40
 
-template <int TA>
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int TA, bool ASUM>
 __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args p) {
   constexpr int NCOL = 128 * (1 + TA);   // LDS columns: G tile, then the A tiles
   constexpr int PLANE = NCOL * TB_LD;    // bf16 elements per part
@@ -410,22 +439,39 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
   for (int r = 0; r < NG; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) csum[r][c] = 0.f;
-  // one piece = one (group r, column c) of a block: 4 slots -> hi/lo bf16x4 -> LDS; pc = 4*r + c
-  auto store_piece = [&](int slot, __bf16* lds, float live, int pc) {  // live = 0: tail iteration, sums untouched
+  // one piece = one (group r, column c) of a block: 4 slots -> hi/lo bf16x4 -> LDS; pc = 4*r + c.
+  // Both operands arrive as split pairs (BLS): the 4x4 register transpose and the hi / lo separation are the same
+  // four v_perm_b32; the column sums (bias gradients) are v_dot2c_f32_bf16 with (1, 1).  Only groups r >= 1 can be a
+  // shifted operand (the launcher refuses a0_shift != 0), so only they are masked at the sequence ends.
+  auto store_piece = [&](int slot, __bf16* lds, unsigned live, int pc) {  // live = 0: tail iteration, sums untouched
     const int r = pc >> 2, c = pc & 3;
-    bf16x4 hi, lo;
+    unsigned e[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float v = use[slot][r] ? rq[slot][r][j][c] : 0.f;
-      csum[r][c] += v * live;
-      hi[j] = (__bf16)v;
-      lo[j] = (__bf16)(v - (float)hi[j]);
+      const float f = rq[slot][r][j][c];  // (bit_cast of a vector-element lvalue reads element 0 with this compiler)
+      e[j] = __float_as_uint(f);
     }
+    if (r > 0) {
+      const unsigned m = use[slot][r] ? 0xffffffffu : 0u;  // uniform
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[j] &= m;
+    }
+    if (r == 0 || ASUM) {
+      const bf16x2 ones = __builtin_bit_cast(bf16x2, live);  // 0x3f803f80 = (1, 1)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        csum[r][c] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, e[j]), ones, csum[r][c], false);
+    }
+    uint2 hi, lo;
+    hi.x = __builtin_amdgcn_perm(e[1], e[0], WS_SEL_HI16);
+    hi.y = __builtin_amdgcn_perm(e[3], e[2], WS_SEL_HI16);
+    lo.x = __builtin_amdgcn_perm(e[1], e[0], WS_SEL_LO16);
+    lo.y = __builtin_amdgcn_perm(e[3], e[2], WS_SEL_LO16);
     const int o = (gcol[r] + c) * TB_LD + 4 * sg;
-    *reinterpret_cast<bf16x4*>(lds + o) = hi;
-    *reinterpret_cast<bf16x4*>(lds + PLANE + o) = lo;
+    *reinterpret_cast<uint2*>(lds + o) = hi;
+    *reinterpret_cast<uint2*>(lds + PLANE + o) = lo;
   };
-  auto store_block = [&](int slot, __bf16* lds, float live) {
+  auto store_block = [&](int slot, __bf16* lds, unsigned live) {
 #pragma unroll
     for (int pc = 0; pc < 4 * NG; ++pc) store_piece(slot, lds, live, pc);
   };
@@ -446,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
   if (nb > 0) {
     load_block(b_begin, 0);
     load_block(min(b_begin + 1, b_end - 1), 1);
-    store_block(0, ldsA, 1.f);
+    store_block(0, ldsA, 0x3f803f80u);
   }
   __syncthreads();
   for (int ib = 0; ib < nb; ib += 2) {
@@ -462,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
         // work only overlaps the matrix pipe when it sits between MFMAs in program order)
         const __bf16* lds = s ? ldsB : ldsA;
         __bf16* ldsw = s ? ldsA : ldsB;
-        const float live = i + 1 < nb ? 1.f : 0.f;
+        const unsigned live = i + 1 < nb ? 0x3f803f80u : 0u;
         constexpr int NSUB = 6 * TN, NPC = 4 * NG, EVERY = NSUB / NPC;
         auto lda = [&](int ks, int f, bf16x8& h, bf16x8& l) {
           const int ra = (128 + wn * 32 * TN + f * 32 + l31) * TB_LD + ks + 8 * half;
@@ -520,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
 #pragma unroll
   for (int r = 0; r < NG; ++r) {
     const int part = (tid + 512 * r) >> 8;
-    float* dst = part == 0 ? p.bslab : (gt == 0 ? p.aslab : nullptr);
+    float* dst = part == 0 ? p.bslab : (gt == 0 && (r == 0 || ASUM) ? p.aslab : nullptr);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       float t = csum[r][c];
@@ -547,16 +593,19 @@ extern "C" int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream) {
              "ws_gemm_tnb: A1 column range");
   const int ta = (a->a0_cols + a->a1_cols) / 128;
   WS_REQUIRE(ta == 1 || ta == 3, "ws_gemm_tnb: A columns must total 128 or 384 (got %d)", ta * 128);
+  WS_REQUIRE(a->a0_shift == 0, "ws_gemm_tnb: only A1 can be shifted (a0_shift = %d)", a->a0_shift);
   WS_REQUIRE(a->nblk > 0 && a->L > 0 && a->nblk % a->L == 0 && a->nsplit > 0 && a->blocks_per_split > 0 &&
                  (long long)a->nsplit * a->blocks_per_split >= a->nblk,
              "ws_gemm_tnb: bad block split");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a->nsplit, a->g_cols / 128), block(512);
   ws_prof_begin(WS_PROF_GEMM_TN, s);
-  if (ta == 3)
-    hipLaunchKernelGGL((gemm_tnb_kernel<3>), grid, block, 0, s, *a);
+  if (ta == 3 && a->aslab)
+    hipLaunchKernelGGL((gemm_tnb_kernel<3, true>), grid, block, 0, s, *a);
+  else if (ta == 3)
+    hipLaunchKernelGGL((gemm_tnb_kernel<3, false>), grid, block, 0, s, *a);
   else
-    hipLaunchKernelGGL((gemm_tnb_kernel<1>), grid, block, 0, s, *a);
+    hipLaunchKernelGGL((gemm_tnb_kernel<1, true>), grid, block, 0, s, *a);
   ws_prof_end(WS_PROF_GEMM_TN, s);
   return ws_check_launch("ws_gemm_tnb");
 }

@@ -245,7 +245,8 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
         st_gate(vg, t, 2, j);
         st_gate(vo, t, 3, j);
         st_ch(vc, p.cbuf, t, j);
-        st_ch(vh, p.hcat, t, j);
+        if constexpr (BLK) st_ch(pack_hl4(h_hi, h_lo), p.hcat, t, j);  // BLS: h leaves as the split pair
+        else st_ch(vh, p.hcat, t, j);
       }
       __builtin_amdgcn_sched_barrier(0);  // one run at a time: bounds the live temporaries
     }
@@ -355,25 +356,23 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
         po[r] = dov * og * (1.f - og);
       }
       c_cur[j] = n_cp[j];
-      if (!(DBG & 1) || step == L - 1) {
-        st_gate(pi, t, 0, j);
-        st_gate(pf, t, 1, j);
-        st_gate(pg, t, 2, j);
-        st_gate(po, t, 3, j);
-      }
-      bf16x4 hi, lo;
-      split4(pi, hi, lo);
-      *reinterpret_cast<bf16x4*>(dhi + 8 * j) = hi;
-      *reinterpret_cast<bf16x4*>(dlo + 8 * j) = lo;
-      split4(pf, hi, lo);
-      *reinterpret_cast<bf16x4*>(dhi + 256 + 8 * j) = hi;
-      *reinterpret_cast<bf16x4*>(dlo + 256 + 8 * j) = lo;
-      split4(pg, hi, lo);
-      *reinterpret_cast<bf16x4*>(dhi + 512 + 8 * j) = hi;
-      *reinterpret_cast<bf16x4*>(dlo + 512 + 8 * j) = lo;
-      split4(po, hi, lo);
-      *reinterpret_cast<bf16x4*>(dhi + 768 + 8 * j) = hi;
-      *reinterpret_cast<bf16x4*>(dlo + 768 + 8 * j) = lo;
+      // d(gates) go to the LDS image (B operand of this step's product) and to HBM; blocked layout: as the same
+      // split pair (BLS) that the weight-gradient and d(x) GEMMs consume
+      const bool st = !(DBG & 1) || step == L - 1;
+      auto emit = [&](const f32x4& v, int g) {
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<bf16x4*>(dhi + 256 * g + 8 * j) = hi;
+        *reinterpret_cast<bf16x4*>(dlo + 256 * g + 8 * j) = lo;
+        if (st) {
+          if constexpr (BLK) st_gate(pack_hl4(hi, lo), t, g, j);
+          else st_gate(v, t, g, j);
+        }
+      };
+      emit(pi, 0);
+      emit(pf, 1);
+      emit(pg, 2);
+      emit(po, 3);
       if (!(DBG & 2)) load_step(tn, j);  // into the registers just consumed
       __builtin_amdgcn_sched_barrier(0);
     }

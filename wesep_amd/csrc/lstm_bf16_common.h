@@ -54,3 +54,28 @@ __device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
   }
 }
 
+// Split-bf16 storage ("BLS", include/wesep_hip.h): a 4-byte element holds the two terms of the split
+// product -- bits 31..16 = bf16 hi, bits 15..0 = bf16 lo, value = hi + lo -- so whoever consumes the
+// buffer as an MFMA operand (gemm_b2p / gemm_tnb / the fused recurrence) rebuilds its fragments with
+// two v_perm_b32 per element pair instead of two conversions and a subtraction per element.  Same
+// bytes as fp32; pack / unpack are the same 16-bit 2x2 transpose.
+__device__ __forceinline__ f32x4 pack_hl4(const bf16x4& hi, const bf16x4& lo) {
+  const uint2 h = __builtin_bit_cast(uint2, hi), l = __builtin_bit_cast(uint2, lo);
+  u32x4 r;
+  r[0] = __builtin_amdgcn_perm(h.x, l.x, WS_SEL_LO16);
+  r[1] = __builtin_amdgcn_perm(h.x, l.x, WS_SEL_HI16);
+  r[2] = __builtin_amdgcn_perm(h.y, l.y, WS_SEL_LO16);
+  r[3] = __builtin_amdgcn_perm(h.y, l.y, WS_SEL_HI16);
+  return __builtin_bit_cast(f32x4, r);
+}
+__device__ __forceinline__ void unpack_hl4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+  const u32x4 u = __builtin_bit_cast(u32x4, v);
+  uint2 h, l;
+  h.x = __builtin_amdgcn_perm(u[1], u[0], WS_SEL_HI16);
+  h.y = __builtin_amdgcn_perm(u[3], u[2], WS_SEL_HI16);
+  l.x = __builtin_amdgcn_perm(u[1], u[0], WS_SEL_LO16);
+  l.y = __builtin_amdgcn_perm(u[3], u[2], WS_SEL_LO16);
+  hi = __builtin_bit_cast(bf16x4, h);
+  lo = __builtin_bit_cast(bf16x4, l);
+}
+

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_s16_kernel(const ws_lstm_args
       st_gate(vg, t, 2, tu);
       st_gate(vo, t, 3, tu);
       st_ch(vc, p.cbuf, t, tu);
-      st_ch(vh, p.hcat, t, tu);
+      st_ch(pack_hl4(h_hi, h_lo), p.hcat, t, tu);  // BLS
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -292,25 +292,18 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
         po[r] = dov * og * (1.f - og);
       }
       c_cur[tu] = n_cp[tu];
-      if (!(S16_DBG & 2)) {
-      st_gate(pi, t, 0, tu);
-      st_gate(pf, t, 1, tu);
-      st_gate(pg, t, 2, tu);
-      st_gate(po, t, 3, tu);
-      }
-      bf16x4 hi, lo;
-      split4(pi, hi, lo);
-      *reinterpret_cast<bf16x4*>(dhi + 16 * tu) = hi;
-      *reinterpret_cast<bf16x4*>(dlo + 16 * tu) = lo;
-      split4(pf, hi, lo);
-      *reinterpret_cast<bf16x4*>(dhi + 256 + 16 * tu) = hi;
-      *reinterpret_cast<bf16x4*>(dlo + 256 + 16 * tu) = lo;
-      split4(pg, hi, lo);
-      *reinterpret_cast<bf16x4*>(dhi + 512 + 16 * tu) = hi;
-      *reinterpret_cast<bf16x4*>(dlo + 512 + 16 * tu) = lo;
-      split4(po, hi, lo);
-      *reinterpret_cast<bf16x4*>(dhi + 768 + 16 * tu) = hi;
-      *reinterpret_cast<bf16x4*>(dlo + 768 + 16 * tu) = lo;
+      // d(gates): LDS image (B operand) + HBM as the same split pair (BLS)
+      auto emit = [&](const f32x4& v, int g) {
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<bf16x4*>(dhi + 256 * g + 16 * tu) = hi;
+        *reinterpret_cast<bf16x4*>(dlo + 256 * g + 16 * tu) = lo;
+        if (!(S16_DBG & 2)) st_gate(pack_hl4(hi, lo), t, g, tu);
+      };
+      emit(pi, 0);
+      emit(pf, 1);
+      emit(pg, 2);
+      emit(po, 3);
       if (!(S16_DBG & 1)) load_step(tn, tu);  // into the registers just consumed
       __builtin_amdgcn_sched_barrier(0);
     }

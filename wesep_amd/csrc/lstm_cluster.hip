@@ -196,9 +196,9 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
       outl[2][tid] = vg;
       outl[3][tid] = vo;
       outl[4][tid] = c4;
-      outl[5][tid] = vh;
       bf16x4 hi, lo;
       split4(vh, hi, lo);
+      outl[5][tid] = pack_hl4(hi, lo);  // hcat in HBM carries the split pair (BLS); NaN poison survives in hi
       struct { bf16x4 a, b; } pk = {hi, lo};
       publ[mychunk] = __builtin_bit_cast(u32x4, pk);
     }
@@ -485,9 +485,9 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_cluster_kernel(const ws_lstm_
         c_cur[e] = pin[0][e][5];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          bst(pg[g], grs(t), gvo[e], g * 64 * 512);
           bf16x4 hi, lo;
           split4(pg[g], hi, lo);
+          bst(pack_hl4(hi, lo), grs(t), gvo[e], g * 64 * 512);  // BLS
           const int o = s * BK_ROW + g * 32 + 4 * q;
           *reinterpret_cast<bf16x4*>(&dgl[0][o]) = hi;
           *reinterpret_cast<bf16x4*>(&dgl[1][o]) = lo;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
   auto st_x = [&](const f32x4& v, int buf, int q) {  // cell u -> row slot, columns 4*quad .. +3
     const int u = tid + 512 * q, quad = u >> 5, slot = u & 31;
     bf16x4 hi, lo;
-    split4(v, hi, lo);
+    unpack_hl4(v, hi, lo);  // xn arrives as split pairs (BLS, written by gemm_p2b)
     *reinterpret_cast<bf16x4*>(&xl[buf][0][slot * XROW + 4 * quad]) = hi;
     *reinterpret_cast<bf16x4*>(&xl[buf][1][slot * XROW + 4 * quad]) = lo;
   };
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
       st_gate(vg, t, 2, j);
       st_gate(vo, t, 3, j);
       st_ch(vc, p.cbuf, t, j);
-      st_ch(vh, p.hcat, t, j);
+      st_ch(pack_hl4(h_hi, h_lo), p.hcat, t, j);  // BLS
       __builtin_amdgcn_sched_barrier(0);  // one run at a time: bounds the live temporaries
     }
     __syncthreads();

@@ -536,16 +536,35 @@ def bl_positions(sm: SeqMap, device):
     return (pos * valid).reshape(-1), valid.reshape(-1)
 
 
-def to_blocked(x: torch.Tensor, sm: SeqMap) -> torch.Tensor:
-    """[P][C] plain rows -> BL(C) [nblk][C/4][32][4]; padded slots are zero."""
+def bls_pack(x: torch.Tensor) -> torch.Tensor:
+    """fp32 values -> split-bf16 storage BLS (include/wesep_hip.h): same shape / dtype, each element's BITS are
+    bf16 hi << 16 | bf16 lo with hi = bf16(x), lo = bf16(x - hi) (round to nearest even, like the kernels)."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    bits = (hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xffff)
+    return bits.view(torch.float32)
+
+
+def bls_unpack(x: torch.Tensor) -> torch.Tensor:
+    """BLS -> fp32 values hi + lo (exact: the sum of the two terms is representable)."""
+    bits = x.contiguous().view(torch.int32)
+    return (bits & -65536).view(torch.float32) + (bits << 16).view(torch.float32)
+
+
+def to_blocked(x: torch.Tensor, sm: SeqMap, split=False) -> torch.Tensor:
+    """[P][C] plain rows -> BL(C) [nblk][C/4][32][4]; padded slots are zero.  split: elements in BLS form (h,
+    d(gates), the normalised input -- whatever the blocked GEMMs / the fused recurrence consume)."""
     pos, valid = bl_positions(sm, x.device)
     C_ = x.shape[1]
     rows = x[pos] * valid[:, None].to(x.dtype)
-    return rows.view(-1, 32, C_ // 4, 4).permute(0, 2, 1, 3).contiguous()
+    out = rows.view(-1, 32, C_ // 4, 4).permute(0, 2, 1, 3).contiguous()
+    return bls_pack(out) if split else out
 
 
-def from_blocked(xb: torch.Tensor, sm: SeqMap, P: int) -> torch.Tensor:
-    """BL(C) -> [P][C] plain rows (padded slots dropped)."""
+def from_blocked(xb: torch.Tensor, sm: SeqMap, P: int, split=False) -> torch.Tensor:
+    """BL(C) -> [P][C] plain rows (padded slots dropped).  split: the buffer holds BLS elements."""
+    if split:
+        xb = bls_unpack(xb)
     pos, valid = bl_positions(sm, xb.device)
     nblk, Cq = xb.shape[0], xb.shape[1]
     rows = xb.permute(0, 2, 1, 3).reshape(nblk * 32, Cq * 4)
