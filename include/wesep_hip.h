@@ -56,6 +56,24 @@ typedef struct ws_group_nt {
   int K, N, ldw, pad_;
 } ws_group_nt;
 
+/* Implicit patch matrix (ABI v8): with conv.on != 0 the A operand of ws_gemm_nt / ws_gemm_tn (split-bf16 kernels
+ * only) is the im2col matrix of a channels-last image x [R][H][W][C] that is never materialised -- A points to x and
+ *   A[m][(ky*k + kx)*C + c],  m = (r*Ho + ho)*Wo + wo,  is
+ *   mode 0 (convolution view):  x[r][ho*sh + ky - p][wo*sw + kx - p][c]
+ *   mode 1 (transposed view):   x[r][(ho + p - ky)/sh][(wo + p - kx)/sw][c] where both divisions are exact,
+ * and 0 outside the image.  K = k*k*C, C % 4 == 0, a_div / a_s1 / a_s2 are ignored; mode 1 needs sh, sw in {1, 2}.
+ * Conv2d = mode 0 on the input; its input gradient = mode 1 on the output gradient (K = k*k*Cout);
+ * ConvTranspose2d = mode 1 on the input, its input gradient = mode 0 on the output gradient; the weight gradients
+ * are ws_gemm_tn with the mode-0 view as A.  Replaces F.conv2d / F.conv_transpose2d of wesep/modules/dpccn/convs.py:28-110
+ * and of the wespeaker ResNet (round 1 wrote the 9x larger patch matrix to HBM and read it back).          */
+typedef struct ws_conv_view {
+  int on, mode;
+  int H, W, C;       /* the image A points to */
+  int Ho, Wo;        /* patch grid (rows of the implicit matrix per image: Ho*Wo) */
+  int k, sh, sw, p;
+  int pad_;
+} ws_conv_view;
+
 /* C[m][n] = epi( sum_k pro(A[m][k]) * W[n][k] )        (torch Linear / Conv1d(k=1) layout)
  *   pro : optional GroupNorm-on-load  a' = (a - mean[s]) * rstd[s] * gamma[k] + beta[k],
  *         s = (m / st_div1) * st_m1 + (m % st_div2) * st_m2 + st_base, stats = [S][2]
@@ -79,6 +97,7 @@ typedef struct ws_gemm_nt_args {
   int M, N, K, ldw;
   int act, ngroups, max_n, vec; /* max_n: max N over groups; vec bit0: A float4-loadable, bit1: W,
                                    bit2: split-bf16 (hi/lo, 3 MFMAs, fp32 accumulate) products */
+  ws_conv_view conv;            /* conv.on: A is an implicit patch matrix (above), either mode */
 } ws_gemm_nt_args;
 int ws_gemm_nt(const ws_gemm_nt_args* a, void* stream);
 
@@ -109,6 +128,7 @@ typedef struct ws_gemm_tn_args {
   int M, Nn, Kk, rows_per_split, nsplit;
   int shift_rows, seq_div, seq_len;
   int ngroups, max_n, max_k, vec; /* vec bit0: A float4-loadable, bit2: split-bf16 products */
+  ws_conv_view conv;              /* conv.on: A is an implicit patch matrix, mode 0 only (Kk = k*k*C) */
 } ws_gemm_tn_args;
 int ws_gemm_tn(const ws_gemm_tn_args* a, void* stream);
 

@@ -33,9 +33,40 @@ def _at(ptr, n):
     return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(int(ptr))))
 
 
+def _conv_matrix(x, M, conv):
+    """The implicit patch matrix of dev.ConvView, materialised: [M, k*k*C]."""
+    mode, H, W, C, Ho, Wo, k, sh, sw, p = conv
+    R = M // (Ho * Wo)
+    img = x.reshape(-1)[:R * H * W * C].reshape(R, H, W, C)
+    out = torch.zeros(R, Ho, Wo, k * k, C)
+
+    def src(o, n_out, tap, s, n_in):
+        i = torch.arange(n_out)
+        if mode == 0:
+            v = i * s + tap - p
+            ok = (v >= 0) & (v < n_in)
+        else:
+            q = i + p - tap
+            v = torch.div(q, s, rounding_mode="floor")
+            ok = (q >= 0) & (q % s == 0) & (v < n_in)
+        return v.clamp(0, n_in - 1), ok
+
+    for ky in range(k):
+        hh, okh = src(None, Ho, ky, sh, H)
+        for kx in range(k):
+            ww, okw = src(None, Wo, kx, sw, W)
+            g = img[:, hh][:, :, ww]                                    # [R, Ho, Wo, C]
+            out[:, :, :, ky * k + kx] = g * (okh[:, None] & okw[None, :])[None, :, :, None]
+    return out.reshape(M, k * k * C)
+
+
 def gemm_nt(*, A, a_rows, M, C_out, c_rows, N=0, K=0, W=None, ldw=0, bias=None, R=None, T=None, stats=None,
             gamma=None, beta=None, stat_map=None, act=0, groups=None, ngroups=0, max_n=0, vec=3, a_off=0, c_off=0,
-            w_off=0, mode=None):
+            w_off=0, mode=None, conv=None):
+    if conv is not None:
+        assert groups is None and stats is None and a_off == 0
+        A, a_rows = _conv_matrix(A, M, conv), (1 << 30, 0, K)
+        conv = None
     if groups is not None:   # grouped launch (per-group descriptors with raw pointers, _lib.GROUP_NT_DTYPE)
         assert stats is None and R is None and T is None and W is None
         for gd in _descs(groups, ngroups, "nt"):
@@ -70,7 +101,11 @@ def gemm_nt(*, A, a_rows, M, C_out, c_rows, N=0, K=0, W=None, ldw=0, bias=None, 
 
 def gemm_tn(*, G, g_rows, A, a_rows, M, slab, slab_stride, nsplit, rows_per_split, Nn=0, Kk=0, bslab=None,
             bslab_stride=0, out_off=0, bout_off=0, stats=None, gamma=None, beta=None, stat_map=None, shift_rows=0,
-            seq_div=1, seq_len=1, groups=None, ngroups=0, max_n=0, max_k=0, vec=1, g_off=0, a_off=0, mode=None):
+            seq_div=1, seq_len=1, groups=None, ngroups=0, max_n=0, max_k=0, vec=1, g_off=0, a_off=0, mode=None,
+            conv=None):
+    if conv is not None:
+        assert conv[0] == 0 and groups is None and stats is None and not shift_rows and a_off == 0
+        A, a_rows = _conv_matrix(A, M, conv), (1 << 30, 0, Kk)
     if groups is not None:   # grouped launch (_lib.GROUP_TN_DTYPE): one output block per group in every split's slab
         assert stats is None and not shift_rows and bslab is None
         for gd in _descs(groups, ngroups, "tn"):

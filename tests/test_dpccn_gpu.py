@@ -91,6 +91,52 @@ def test_dpccn_kernels_match_torch():
         assert rel(dxg, dxr) < 1e-6 and rel(dsg, dsr) < 1e-5
 
 
+@pytest.mark.parametrize("Cin,Cout,k,sh,sw", [(16, 16, 3, 1, 2), (32, 16, 3, 1, 1), (80, 16, 3, 1, 1), (4, 16, 3, 1, 1),
+                                              (16, 32, 3, 2, 2), (12, 8, 5, 1, 2)])
+def test_implicit_conv2d_and_transpose_match_torch(Cin, Cout, k, sh, sw):
+    """Conv2d / ConvTranspose2d as GEMMs on the implicit patch matrix (ws_conv_view, both views, NT and TN kernels)
+    against torch's convolutions: output, input gradient, weight and bias gradients, at a size with many row tiles,
+    partial tiles and borders on every side.  Run twice: bit-identical."""
+    from wesep_amd import functional_dpccn as FD
+    d = _cuda()
+    g = torch.Generator().manual_seed(100 * Cin + Cout + k + sh + sw)
+    B, H, W = 3, 13, 37
+    p = k // 2
+
+    def cl(t):      # [B, C, H, W] -> channels-last rows
+        return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+
+    for transpose in (False, True):
+        x = torch.randn(B, Cin, H, W, generator=g)
+        if transpose:
+            w = torch.randn(Cin, Cout, k, k, generator=g) * 0.1
+            ref_fn = lambda x_, w_, b_: torch.nn.functional.conv_transpose2d(x_, w_, b_, stride=(sh, sw), padding=p)
+            Fn = FD.ConvTranspose2dFn
+        else:
+            w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+            ref_fn = lambda x_, w_, b_: torch.nn.functional.conv2d(x_, w_, b_, stride=(sh, sw), padding=p)
+            Fn = FD.Conv2dFn
+        b = torch.randn(Cout, generator=g)
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+        yr = ref_fn(xr, wr, br)
+        dy = torch.randn(*yr.shape, generator=g)
+        yr.backward(dy.double())
+        outs = []
+        for _ in range(2):
+            xg = cl(x).to(d).requires_grad_(True)
+            wg, bg = w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+            yg = Fn.apply(xg, wg, bg, (B, H, W, sh, sw))
+            yg.backward(cl(dy).to(d))
+            outs.append((yg.detach(), xg.grad, wg.grad, bg.grad))
+        for a, c in zip(*outs):
+            assert torch.equal(a, c)
+        yg, dxg, dwg, dbg = outs[0]
+        assert rel(yg, cl(yr)) < 4e-5, ("fwd", transpose)
+        assert rel(dxg, cl(xr.grad)) < 4e-5, ("dx", transpose)
+        assert rel(dwg, wr.grad) < 4e-5, ("dw", transpose)
+        assert rel(dbg, br.grad) < 4e-5, ("db", transpose)
+
+
 @pytest.mark.parametrize("name", ["dpccn_multiply_r2_t4480", "dpccn_additive_xform_r2_t4608"])
 def test_dpccn_model_matches_reference_fixture(name, golden_dir):
     from oracle import bsrnn_oracle as O

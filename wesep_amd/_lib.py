@@ -26,11 +26,16 @@ _i = C.c_int
 _f = C.c_float
 
 
+class ConvView(C.Structure):
+    """ws_conv_view: the A operand of ws_gemm_nt / ws_gemm_tn as an implicit im2col matrix (include/wesep_hip.h)."""
+    _fields_ = [(n, _i) for n in ("on", "mode", "H", "W", "C", "Ho", "Wo", "k", "sh", "sw", "p", "pad_")]
+
+
 class GemmNTArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("A", "W", "bias", "C", "R", "T", "stats", "gamma", "beta", "groups")] + \
                [(n, _ll) for n in ("a_s1", "a_s2", "c_s1", "c_s2", "st_m1", "st_m2", "st_base")] + \
                [(n, _i) for n in ("a_div", "c_div", "st_div1", "st_div2", "M", "N", "K", "ldw",
-                                  "act", "ngroups", "max_n", "vec")]
+                                  "act", "ngroups", "max_n", "vec")] + [("conv", ConvView)]
 
 
 class GemmTNArgs(C.Structure):
@@ -39,7 +44,7 @@ class GemmTNArgs(C.Structure):
                                    "slab_stride", "bslab_stride", "out_off", "bout_off")] + \
                [(n, _i) for n in ("g_div", "a_div", "st_div1", "st_div2", "M", "Nn", "Kk",
                                   "rows_per_split", "nsplit", "shift_rows", "seq_div", "seq_len",
-                                  "ngroups", "max_n", "max_k", "vec")]
+                                  "ngroups", "max_n", "max_k", "vec")] + [("conv", ConvView)]
 
 
 class GroupsGeom(C.Structure):

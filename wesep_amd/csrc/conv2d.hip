@@ -481,13 +481,20 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int B, int h, 
     q /= w;
     const int ys = (int)(q % h), b = (int)(q / h);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int Y = 0; Y < H; ++Y) {
+    // destination pixels whose two source taps can include (ys, xs): source coordinate in (ys - 1, ys + 1), i.e.
+    // Y in ((ys - 0.5) / sh - 0.5, (ys + 1.5) / sh - 0.5) -- widened by one pixel; the exact weight test below decides
+    // (round 1 walked all H x W destination pixels per thread: 12 ms per call at the DPCCN recipe size)
+    const int Ylo = max(0, (int)floorf(((float)ys - 0.5f) / sh - 0.5f) - 1);
+    const int Yhi = min(H - 1, (int)ceilf(((float)ys + 1.5f) / sh - 0.5f) + 1);
+    const int Xlo = max(0, (int)floorf(((float)xs - 0.5f) / sw - 0.5f) - 1);
+    const int Xhi = min(W - 1, (int)ceilf(((float)xs + 1.5f) / sw - 0.5f) + 1);
+    for (int Y = Ylo; Y <= Yhi; ++Y) {
       int y0, y1;
       float ly;
       bl_src(Y, sh, h, y0, y1, ly);
       const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
       if (wy == 0.f) continue;
-      for (int X = 0; X < W; ++X) {
+      for (int X = Xlo; X <= Xhi; ++X) {
         int x0, x1;
         float lx;
         bl_src(X, sw, w, x0, x1, lx);

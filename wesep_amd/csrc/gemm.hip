@@ -196,6 +196,15 @@ extern "C" int ws_gemm_nt(const ws_gemm_nt_args* a, void* stream) {
   const int maxn = a->groups ? a->max_n : a->N;
   WS_REQUIRE(ng > 0 && maxn > 0, "ws_gemm_nt: ngroups=%d max_n=%d", ng, maxn);
   WS_REQUIRE(a->groups || (a->N > 0 && a->K > 0 && a->ldw >= a->K), "ws_gemm_nt: bad N/K/ldw");
+  if (a->conv.on) {
+    const ws_conv_view& c = a->conv;
+    WS_REQUIRE((a->vec & 7) == 7 && !a->groups && !a->stats, "ws_gemm_nt: the implicit patch matrix needs the split-bf16 "
+               "kernel (vec 7), no groups, no norm-on-load");
+    WS_REQUIRE((c.mode == 0 || c.mode == 1) && c.H > 0 && c.W > 0 && c.C > 0 && c.C % 4 == 0 && c.Ho > 0 && c.Wo > 0 &&
+                   c.k >= 1 && c.sh >= 1 && c.sw >= 1 && c.p >= 0 && a->K == c.k * c.k * c.C && a->M % (c.Ho * c.Wo) == 0,
+               "ws_gemm_nt: bad conv view (C %% 4, K == k*k*C, M %% (Ho*Wo))");
+    WS_REQUIRE(c.mode == 0 || (c.sh <= 2 && c.sw <= 2), "ws_gemm_nt: transposed view: strides 1 or 2");
+  }
   dim3 grid((a->M + 127) / 128, (maxn + 127) / 128, ng), block(256);
   hipStream_t s = (hipStream_t)stream;
   ws_prof_begin(WS_PROF_GEMM_NT, s);
@@ -378,6 +387,14 @@ extern "C" int ws_gemm_tn(const ws_gemm_tn_args* a, void* stream) {
   const int maxn = a->groups ? a->max_n : a->Nn, maxk = a->groups ? a->max_k : a->Kk;
   WS_REQUIRE(ng > 0 && maxn > 0 && maxk > 0, "ws_gemm_tn: bad group dims");
   WS_REQUIRE(a->groups || (a->Nn % 4 == 0), "ws_gemm_tn: Nn must be a multiple of 4");
+  if (a->conv.on) {
+    const ws_conv_view& c = a->conv;
+    WS_REQUIRE((a->vec & 4) && !a->groups && !a->stats && a->shift_rows == 0, "ws_gemm_tn: the implicit patch matrix "
+               "needs the split-bf16 kernel, no groups, no norm-on-load, no shift");
+    WS_REQUIRE(c.mode == 0 && c.H > 0 && c.W > 0 && c.C > 0 && c.Ho > 0 && c.Wo > 0 && c.k >= 1 && c.sh >= 1 &&
+                   c.sw >= 1 && c.p >= 0 && a->Kk == c.k * c.k * c.C && a->M % (c.Ho * c.Wo) == 0,
+               "ws_gemm_tn: bad conv view (mode 0, Kk == k*k*C, M %% (Ho*Wo))");
+  }
   dim3 grid(((maxn + 127) / 128) * ((maxk + 127) / 128), a->nsplit, ng), block(256);
   hipStream_t s = (hipStream_t)stream;
   ws_prof_begin(WS_PROF_GEMM_TN, s);

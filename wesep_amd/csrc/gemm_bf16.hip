@@ -79,7 +79,10 @@ __device__ __forceinline__ void tile_mma(const __bf16* __restrict__ lds, int aro
 // space so they do not decay to flat loads.
 typedef const __attribute__((address_space(1))) float* gfp;
 
-template <bool NORM>
+// CONV: the A operand is an implicit im2col matrix (ws_conv_view, wesep_hip.h): a row is an output pixel, a k-tile's
+// float4 lies inside one tap (C % 4 == 0), so the loader adds the tap's offset to the pixel's base and masks taps that
+// fall outside the image -- the patch matrix (k*k times the activation) never exists in HBM.
+template <bool NORM, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[4 * BT_PLANE];  // 40 KB
   const float* A_ = p.A;
@@ -117,12 +120,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
   long long aoff[4], woff[4];
   bool vm[4], vn[4];
   float mean[4], rstd[4];
+  int cbh[4], cbw[4];  // CONV: the pixel's base coordinates (mode 0: ho*sh - p; mode 1: ho + p); aoff = image base
+  const ws_conv_view cv = p.conv;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m_blk + lrow + 32 * i;
     vm[i] = m < M;
     const int mm = vm[i] ? m : M - 1;
-    aoff[i] = ws_row_off(mm, p.a_div, p.a_s1, p.a_s2);
+    if (CONV) {
+      const int hw = cv.Ho * cv.Wo;
+      const int r = mm / hw, q = mm - r * hw;
+      const int ho = q / cv.Wo, wo = q - ho * cv.Wo;
+      aoff[i] = (long long)r * cv.H * cv.W * cv.C;
+      cbh[i] = cv.mode == 0 ? ho * cv.sh - cv.p : ho + cv.p;
+      cbw[i] = cv.mode == 0 ? wo * cv.sw - cv.p : wo + cv.p;
+    } else {
+      aoff[i] = ws_row_off(mm, p.a_div, p.a_s1, p.a_s2);
+      cbh[i] = cbw[i] = 0;
+    }
     mean[i] = 0.f;
     rstd[i] = 1.f;
     if (NORM) {
@@ -139,7 +154,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
   // normalisation, range masking and the bf16 split happen in store_tile, one iteration later
   f32x4 ra[4], rw[4], gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
   bool vk = true;
+  bool vt[4] = {true, true, true, true};  // CONV: the tap of this tile's float4 lies inside the image for row i
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int csh = cv.sh - 1, csw = cv.sw - 1;  // mode 1: strides are 1 or 2 -> shift / mask instead of a division
   auto load_tile = [&](int kt) {
     const int k = kt * BT_BK + lk;
     vk = k < K;                       // K % 4 == 0 on this path: a float4 is in or out as a whole
@@ -148,9 +165,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
       gm = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(gamma + kc);
       bt = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(beta + kc);
     }
+    int ky = 0, kx = 0, cc = 0;
+    if (CONV) {
+      const int tap = kc / cv.C;
+      cc = kc - tap * cv.C;
+      ky = tap / cv.k;
+      kx = tap - ky * cv.k;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(A + aoff[i] + kc);
+      if (CONV) {
+        int hh, ww;
+        bool ok;
+        if (cv.mode == 0) {
+          hh = cbh[i] + ky;
+          ww = cbw[i] + kx;
+          ok = (unsigned)hh < (unsigned)cv.H && (unsigned)ww < (unsigned)cv.W;
+        } else {
+          const int hn = cbh[i] - ky, wn = cbw[i] - kx;
+          hh = hn >> csh;
+          ww = wn >> csw;
+          ok = hn >= 0 && wn >= 0 && (hn & csh) == 0 && (wn & csw) == 0 && hh < cv.H && ww < cv.W;
+        }
+        vt[i] = ok;
+        const long long o = ok ? aoff[i] + ((long long)hh * cv.W + ww) * cv.C + cc : 0;
+        ra[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(A + o);
+      } else {
+        ra[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(A + aoff[i] + kc);
+      }
       rw[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(W + woff[i] + kc);
     }
   };
@@ -159,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
     for (int i = 0; i < 4; ++i) {
       f32x4 v = ra[i];
       if (NORM) v = (v - mean[i]) * rstd[i] * gm + bt;
-      v = (vm[i] && vk) ? v : zero4;
+      v = (vm[i] && vk && vt[i]) ? v : zero4;
       const f32x4 wv = (vn[i] && vk) ? rw[i] : zero4;
       bf16x4 hi, lo;
       const int o = (lrow + 32 * i) * BT_LD + lk;
@@ -218,10 +260,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
 }
 
 int ws_launch_gemm_nt_bf16(const ws_gemm_nt_args* a, dim3 grid, hipStream_t s) {
-  if (a->stats)
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<true>), grid, dim3(256), 0, s, *a);
+  if (a->conv.on)
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, true>), grid, dim3(256), 0, s, *a);
+  else if (a->stats)
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, false>), grid, dim3(256), 0, s, *a);
   else
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<false>), grid, dim3(256), 0, s, *a);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, false>), grid, dim3(256), 0, s, *a);
   return 0;
 }
 
@@ -236,8 +280,11 @@ struct RowMeta {
   long long goff, aoff;
   float mean, rstd;
   int gvalid, avalid;
+  int bh, bw;  // CONV: base coordinates of the row's pixel (ho*sh - p, wo*sw - p); aoff = image base
 };
 
+// CONV: A is the implicit im2col matrix (mode 0) of the image p.A points to; this thread's column is one (tap, channel).
+template <bool CONV>
 __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[4 * BT_PLANE];  // 40 KB
   __shared__ RowMeta meta[2][32];
@@ -286,7 +333,17 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
       r.goff = r.aoff = 0;
       r.mean = 0.f;
       r.rstd = 1.f;
-      if (r.gvalid) {
+      r.bh = r.bw = 0;
+      if (CONV && r.gvalid) {
+        const ws_conv_view cv = p.conv;
+        const int hw = cv.Ho * cv.Wo;
+        const int rr = m / hw, q = m - rr * hw;
+        const int ho = q / cv.Wo, wo = q - ho * cv.Wo;
+        r.goff = ws_row_off(m, p.g_div, p.g_s1, p.g_s2);
+        r.aoff = (long long)rr * cv.H * cv.W * cv.C;
+        r.bh = ho * cv.sh - cv.p;
+        r.bw = wo * cv.sw - cv.p;
+      } else if (r.gvalid) {
         r.goff = ws_row_off(m, p.g_div, p.g_s1, p.g_s2);
         int ma = m;
         if (p.shift_rows != 0) {
@@ -309,15 +366,34 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
   // Branch-free tile loads (see gemm_nt_bf16_kernel): invalid rows carry offset 0 in the meta table and
   // out-of-range columns are clamped, so every load is unconditional; masking, normalisation and the
   // bf16 split happen in store_tile one iteration later, with the loads in flight under the MFMAs.
-  const gfp Gg = (gfp)G + n_blk + (gcol_ok ? col : 0), Ag = (gfp)A + k_blk + (acol_ok ? col : 0);
+  const gfp Gg = (gfp)G + n_blk + (gcol_ok ? col : 0);
+  gfp Ag = (gfp)A + k_blk + (acol_ok ? col : 0);
+  int cky = 0, ckx = 0;  // CONV: this thread's tap; Ag then points at its channel of pixel (0, 0)
+  if (CONV) {
+    const int kc = acol_ok ? k_blk + col : 0;
+    const int tap = kc / p.conv.C;
+    cky = tap / p.conv.k;
+    ckx = tap - cky * p.conv.k;
+    Ag = (gfp)A + (kc - tap * p.conv.C);
+  }
   float rg[16], ra[16];
+  unsigned tapok = 0xffffu;  // CONV: bit j = the tap lies inside the image for row j of the tile in registers
   auto load_tile = [&](int slot) {
+    unsigned okb = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const RowMeta& r = meta[slot][mg + j];
       rg[j] = Gg[r.goff];
-      ra[j] = Ag[r.aoff];
+      if (CONV) {
+        const int hh = r.bh + cky, ww = r.bw + ckx;
+        const bool ok = r.avalid && (unsigned)hh < (unsigned)p.conv.H && (unsigned)ww < (unsigned)p.conv.W;
+        okb |= ok ? 1u << j : 0u;
+        ra[j] = Ag[ok ? r.aoff + ((long long)hh * p.conv.W + ww) * p.conv.C : 0];
+      } else {
+        ra[j] = Ag[r.aoff];
+      }
     }
+    if (CONV) tapok = okb;
   };
   auto store_tile = [&](int slot) {
 #pragma unroll
@@ -326,7 +402,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
       rg[j] = (r.gvalid && gcol_ok) ? rg[j] : 0.f;
       float a = ra[j];
       if (has_norm) a = (a - r.mean) * r.rstd * gm + bt;
-      ra[j] = (r.avalid && acol_ok) ? a : 0.f;
+      ra[j] = (r.avalid && acol_ok && (!CONV || ((tapok >> j) & 1u))) ? a : 0.f;
     }
 #pragma unroll
     for (int h8 = 0; h8 < 2; ++h8) {
@@ -401,6 +477,9 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
 }
 
 int ws_launch_gemm_tn_bf16(const ws_gemm_tn_args* a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(256), 0, s, *a);
+  if (a->conv.on)
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, dim3(256), 0, s, *a);
+  else
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, grid, dim3(256), 0, s, *a);
   return 0;
 }

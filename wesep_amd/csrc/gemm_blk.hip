@@ -430,6 +430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
       const int sa = step + gshift[r];
       use[slot][r] = sa >= 0 && sa < L;
       const float* src = gbase[r] + (long long)(use[slot][r] ? b + gshift[r] : b) * gstride[r];
+      // (non-temporal loads of G and / or A measured neutral, alone and beside a recurrence: tools/overlap_probe.py)
 #pragma unroll
       for (int j = 0; j < 4; ++j) rq[slot][r][j] = *reinterpret_cast<const f32x4*>(src + 4 * j);
     }

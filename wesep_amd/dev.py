@@ -57,9 +57,33 @@ def _p(t: Optional[torch.Tensor], off: int = 0):
     return C.c_void_p(t.data_ptr() + 4 * off)
 
 
+class ConvView(NamedTuple):
+    """ws_conv_view (include/wesep_hip.h): the A operand of gemm_nt / gemm_tn is the never-materialised im2col matrix
+    of the channels-last image [R][H][W][C] that A points to; (Ho, Wo) = rows per image; mode 0 = convolution view
+    (input pixel = o*s + tap - p), mode 1 = transposed view (input pixel = (o + p - tap) / s, exact divisions only)."""
+    mode: int
+    H: int
+    W: int
+    C: int
+    Ho: int
+    Wo: int
+    k: int
+    sh: int
+    sw: int
+    p: int
+
+
+def _set_conv(a, conv: Optional[ConvView]):
+    if conv is not None:
+        a.conv.on = 1
+        (a.conv.mode, a.conv.H, a.conv.W, a.conv.C, a.conv.Ho, a.conv.Wo, a.conv.k, a.conv.sh, a.conv.sw,
+         a.conv.p) = conv
+
+
 def gemm_nt(*, A, a_rows: Rows, M: int, C_out, c_rows: Rows, N=0, K=0, W=None, ldw=0, bias=None,
             R=None, T=None, stats=None, gamma=None, beta=None, stat_map: Optional[StatMap] = None,
-            act=0, groups=None, ngroups=0, max_n=0, vec=3, a_off=0, c_off=0, w_off=0, mode=None):
+            act=0, groups=None, ngroups=0, max_n=0, vec=3, a_off=0, c_off=0, w_off=0, mode=None,
+            conv: Optional[ConvView] = None):
     for n, t in (("A", A), ("W", W), ("bias", bias), ("C", C_out), ("R", R), ("T", T),
                  ("stats", stats), ("gamma", gamma), ("beta", beta)):
         _chk(t, n)
@@ -74,6 +98,7 @@ def gemm_nt(*, A, a_rows: Rows, M: int, C_out, c_rows: Rows, N=0, K=0, W=None, l
     a.st_div1, a.st_m1, a.st_div2, a.st_m2, a.st_base = sm
     a.M, a.N, a.K, a.ldw = M, N, K, ldw
     a.act, a.ngroups, a.max_n, a.vec = act, ngroups, max_n, vec | _mode_bit(mode)
+    _set_conv(a, conv)
     L.check(L.lib().ws_gemm_nt(C.byref(a), L.stream_ptr()), "ws_gemm_nt")
 
 
@@ -89,7 +114,7 @@ def gemm_tn(*, G, g_rows: Rows, A, a_rows: Rows, M: int, slab, slab_stride: int,
             rows_per_split: int, Nn=0, Kk=0, bslab=None, bslab_stride=0, out_off=0, bout_off=0,
             stats=None, gamma=None, beta=None, stat_map: Optional[StatMap] = None,
             shift_rows=0, seq_div=1, seq_len=1, groups=None, ngroups=0, max_n=0, max_k=0, vec=1,
-            g_off=0, a_off=0, mode=None):
+            g_off=0, a_off=0, mode=None, conv: Optional[ConvView] = None):
     for n, t in (("G", G), ("A", A), ("slab", slab), ("bslab", bslab), ("stats", stats),
                  ("gamma", gamma), ("beta", beta)):
         _chk(t, n)
@@ -105,6 +130,7 @@ def gemm_tn(*, G, g_rows: Rows, A, a_rows: Rows, M: int, slab, slab_stride: int,
     a.M, a.Nn, a.Kk, a.rows_per_split, a.nsplit = M, Nn, Kk, rows_per_split, nsplit
     a.shift_rows, a.seq_div, a.seq_len = shift_rows, seq_div, seq_len
     a.ngroups, a.max_n, a.max_k, a.vec = ngroups, max_n, max_k, vec | _mode_bit(mode)
+    _set_conv(a, conv)
     L.check(L.lib().ws_gemm_tn(C.byref(a), L.stream_ptr()), "ws_gemm_tn")
 
 

@@ -1,0 +1,76 @@
+"""2-D convolutions on channels-last images [B*H*W, C] as ONE split-bf16 MFMA GEMM each, with the im2col patch matrix
+implicit in the GEMM's operand loader (`dev.ConvView`, include/wesep_hip.h ws_conv_view): forward, input gradient and
+weight gradient of Conv2d and ConvTranspose2d never write or read the k*k-times larger patch matrix (round 1 did:
+20 % of the DPCCN step was im2col and the GEMMs streamed 9x the activation bytes).
+
+  Conv2d           y  = view0(x)  W2^T          W2[co][(tap)*Cin + ci]  = w[co, ci, ky, kx]
+                   dx = view1(dy) Wd^T          Wd[ci][(tap)*Cout + co] = w[co, ci, ky, kx]
+                   dW2 = dy^T view0(x)
+  ConvTranspose2d  y  = view1(x)  Wt^T          Wt[co][(tap)*Cin + ci]  = w[ci, co, ky, kx]
+                   dx = view0(dy) Wx^T          Wx[ci][(tap)*Cout + co] = w[ci, co, ky, kx]
+                   dWx^T = x^T view0(dy)
+view0 = convolution view (input pixel o*s + tap - p), view1 = transposed view (input pixel (o + p - tap)/s when exact).
+Channel counts that are not a multiple of 4 (the single-channel first layer of the ResNet) use the explicit patch matrix.
+Reference lines: wesep/modules/dpccn/convs.py:28-110 (Conv2dBlock / ConvTrans2dBlock / DenseBlock)."""
+import torch
+
+from . import dev
+from .dev import ConvView
+from .functional_tasnet import _gemm, _wgrad
+
+MODE = "bf16x3"   # the implicit operand exists in the split-bf16 kernels only
+
+
+def implicit_ok(C):
+    return C % 4 == 0
+
+
+def conv2d_fwd(x, B, H, W, Cin, W2, Cout, k, sh, sw, p, bias=None):
+    """x [B*H*W, Cin], W2 [Cout, k*k*Cin] -> [B*Ho*Wo, Cout]."""
+    Ho, Wo = dev.conv_out(H, k, sh, p), dev.conv_out(W, k, sw, p)
+    return _gemm(x, B * Ho * Wo, k * k * Cin, W2, Cout, bias=bias, vec=3, mode=MODE,
+                 conv=ConvView(0, H, W, Cin, Ho, Wo, k, sh, sw, p))
+
+
+def conv2d_wgrad(dy, x, B, H, W, Cin, Cout, k, sh, sw, p, with_bias=True):
+    """dW2 [Cout, k*k*Cin] = dy^T view0(x) (+ db)."""
+    Ho, Wo = dev.conv_out(H, k, sh, p), dev.conv_out(W, k, sw, p)
+    return _wgrad(dy, B * Ho * Wo, Cout, x, k * k * Cin, with_bias=with_bias, vec=1, mode=MODE,
+                  conv=ConvView(0, H, W, Cin, Ho, Wo, k, sh, sw, p))
+
+
+def conv2d_dx(dy, B, H, W, Cin, Wd, Cout, k, sh, sw, p):
+    """dy [B*Ho*Wo, Cout], Wd [Cin, k*k*Cout] -> dx [B*H*W, Cin]: the transposed view of dy, one row per INPUT pixel."""
+    Ho, Wo = dev.conv_out(H, k, sh, p), dev.conv_out(W, k, sw, p)
+    return _gemm(dy, B * H * W, k * k * Cout, Wd, Cin, vec=3, mode=MODE,
+                 conv=ConvView(1, Ho, Wo, Cout, H, W, k, sh, sw, p))
+
+
+def conv2d_weights(w):
+    """w [Cout, Cin, k, k] -> (W2 [Cout, k*k*Cin], Wd [Cin, k*k*Cout])."""
+    Cout, Cin, k, _ = w.shape
+    W2 = w.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous()
+    Wd = w.permute(1, 2, 3, 0).reshape(Cin, k * k * Cout).contiguous()
+    return W2, Wd
+
+
+def convT2d_fwd(x, B, H, W, Cin, Wt, Cout, k, sh, sw, p, bias=None):
+    """x [B*H*W, Cin], Wt [Cout, k*k*Cin] -> [B*Ht*Wt, Cout], Ht = (H - 1)*sh - 2p + k."""
+    Ht, Wt_ = (H - 1) * sh - 2 * p + k, (W - 1) * sw - 2 * p + k
+    return _gemm(x, B * Ht * Wt_, k * k * Cin, Wt, Cout, bias=bias, vec=3, mode=MODE,
+                 conv=ConvView(1, H, W, Cin, Ht, Wt_, k, sh, sw, p))
+
+
+def convT2d_dx(dy, B, H, W, Cin, Wx, Cout, k, sh, sw, p):
+    """dy [B*Ht*Wt, Cout], Wx [Cin, k*k*Cout] -> dx [B*H*W, Cin]: the convolution view of dy."""
+    Ht, Wt_ = (H - 1) * sh - 2 * p + k, (W - 1) * sw - 2 * p + k
+    return _gemm(dy, B * H * W, k * k * Cout, Wx, Cin, vec=3, mode=MODE,
+                 conv=ConvView(0, Ht, Wt_, Cout, H, W, k, sh, sw, p))
+
+
+def convT2d_wgrad(x, dy, B, H, W, Cin, Cout, k, sh, sw, p):
+    """dWx^T [Cin, k*k*Cout] = x^T view0(dy)."""
+    Ht, Wt_ = (H - 1) * sh - 2 * p + k, (W - 1) * sw - 2 * p + k
+    dWxT, _ = _wgrad(x, B * H * W, Cin, dy, k * k * Cout, with_bias=False, vec=1, mode=MODE,
+                     conv=ConvView(0, Ht, Wt_, Cout, H, W, k, sh, sw, p))
+    return dWxT

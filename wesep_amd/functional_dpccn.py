@@ -15,6 +15,7 @@ import math
 import torch
 
 from . import dev
+from . import functional_conv as FC
 from .dev import Rows, flat
 from .functional import _empty, _need_cuda
 from .functional_tasnet import _gemm, _transposed, _wgrad
@@ -28,7 +29,8 @@ def _pad4(n):
 # convolutions
 # ---------------------------------------------------------------------------------------------
 class Conv2dFn(torch.autograd.Function):
-    """x [B*H*W, Cin] -> conv2d(k x k, stride (sh, sw), padding k//2) + bias: [B*Ho*Wo, Cout]."""
+    """x [B*H*W, Cin] -> conv2d(k x k, stride (sh, sw), padding k//2) + bias: [B*Ho*Wo, Cout].  One GEMM per pass on
+    the implicit patch matrix (functional_conv); 1x1 / stride-1 convolutions are plain GEMMs on the rows."""
 
     @staticmethod
     def forward(ctx, x, w, b, geo):
@@ -36,43 +38,39 @@ class Conv2dFn(torch.autograd.Function):
         B, H, W, sh, sw = geo
         Cout, Cin, k, _ = w.shape
         p = k // 2
-        Ho, Wo = dev.conv_out(H, k, sh, p), dev.conv_out(W, k, sw, p)
-        M = B * Ho * Wo
         x = x.contiguous()
-        Kk = k * k * Cin
-        ldp = _pad4(Kk)
-        W2 = torch.zeros(Cout, ldp, device=x.device, dtype=torch.float32)
-        W2[:, :Kk] = w.permute(0, 2, 3, 1).reshape(Cout, Kk)
-        patches = Conv2dFn._patches(x, B, H, W, Cin, k, sh, sw, p, M, ldp)
-        y = _gemm(patches, M, ldp, W2, Cout, bias=b)
-        ctx.save_for_backward(x, W2)
-        ctx.geo = (B, H, W, Cin, Cout, k, sh, sw, p, M, ldp, w.shape)
+        if not FC.implicit_ok(Cin):
+            raise dev.L.WesepHipError(f"DPCCN Conv2d: input channels must be a multiple of 4 (got {Cin})")
+        W2, Wd = FC.conv2d_weights(w)
+        if k == 1 and sh == 1 and sw == 1:
+            y = _gemm(x, B * H * W, Cin, W2, Cout, bias=b)
+        else:
+            y = FC.conv2d_fwd(x, B, H, W, Cin, W2, Cout, k, sh, sw, p, bias=b)
+        ctx.save_for_backward(x, Wd)
+        ctx.geo = (B, H, W, Cin, Cout, k, sh, sw, p, w.shape)
         return y
 
     @staticmethod
-    def _patches(x, B, H, W, Cin, k, sh, sw, p, M, ldp):
-        if k == 1 and sh == 1 and sw == 1 and ldp == Cin:
-            return x                                            # 1x1 convolution: the rows are the patches
-        patches = _empty(x.device, M, ldp) if ldp == k * k * Cin else torch.zeros(M, ldp, device=x.device)
-        dev.im2col_hw(x, B, H, W, Cin, k, sh, sw, p, patches, ldp)
-        return patches
-
-    @staticmethod
     def backward(ctx, dy):
-        x, W2 = ctx.saved_tensors
-        B, H, W, Cin, Cout, k, sh, sw, p, M, ldp, wshape = ctx.geo
+        x, Wd = ctx.saved_tensors
+        B, H, W, Cin, Cout, k, sh, sw, p, wshape = ctx.geo
         dy = dy.contiguous()
-        Kk = k * k * Cin
-        patches = Conv2dFn._patches(x, B, H, W, Cin, k, sh, sw, p, M, ldp)
-        dW2, db = _wgrad(dy, M, Cout, patches, ldp)
-        del patches
-        dw = dW2[:, :Kk].reshape(Cout, k, k, Cin).permute(0, 3, 1, 2).contiguous()
+        plain = k == 1 and sh == 1 and sw == 1
+        if plain:
+            dW2, db = _wgrad(dy, B * H * W, Cout, x, Cin)
+        else:
+            dW2, db = FC.conv2d_wgrad(dy, x, B, H, W, Cin, Cout, k, sh, sw, p)
+        dw = dW2.reshape(Cout, k, k, Cin).permute(0, 3, 1, 2).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dpatches = _gemm(dy, M, Cout, _transposed(W2, Cout, ldp), ldp)
-            if k == 1 and sh == 1 and sw == 1 and ldp == Cin:
-                dx = dpatches
-            else:
+            if plain:
+                dx = _gemm(dy, B * H * W, Cout, Wd, Cin)
+            elif FC.implicit_ok(Cout):
+                dx = FC.conv2d_dx(dy, B, H, W, Cin, Wd, Cout, k, sh, sw, p)
+            else:  # output channels not a multiple of 4: explicit patch gradients + the col2im gather
+                W2 = Wd.view(Cin, k * k, Cout).permute(2, 1, 0).reshape(Cout, k * k * Cin).contiguous()
+                M = dy.shape[0]
+                dpatches = _gemm(dy, M, Cout, _transposed(W2, Cout, k * k * Cin), k * k * Cin)
                 dx = _empty(x.device, B * H * W, Cin)
                 dev.col2im_hw(dpatches, B, H, W, Cin, k, sh, sw, p, dx)
         return dx, dw.view(wshape), db, None
@@ -80,7 +78,8 @@ class Conv2dFn(torch.autograd.Function):
 
 class ConvTranspose2dFn(torch.autograd.Function):
     """x [B*H*W, Cin] -> conv_transpose2d(w [Cin, Cout, k, k], stride (sh, sw), padding k//2) + bias:
-    [B*Ht*Wt, Cout], Ht = (H - 1) * sh - 2p + k."""
+    [B*Ht*Wt, Cout], Ht = (H - 1) * sh - 2p + k.  Forward = the transposed view of x, input gradient = the convolution
+    view of dy, weight gradient = x^T view0(dy): one GEMM each, nothing unfolded."""
 
     @staticmethod
     def forward(ctx, x, w, b, geo):
@@ -88,41 +87,35 @@ class ConvTranspose2dFn(torch.autograd.Function):
         B, H, W, sh, sw = geo
         Cin, Cout, k, _ = w.shape
         p = k // 2
-        Ht, Wt = (H - 1) * sh - 2 * p + k, (W - 1) * sw - 2 * p + k
-        Cp = _pad4(Cout)                                       # col2im moves 16-byte channel groups
+        if not FC.implicit_ok(Cin) or sh > 2 or sw > 2:
+            raise dev.L.WesepHipError(f"DPCCN ConvTranspose2d: Cin % 4 == 0 and strides <= 2 (got {Cin}, {sh}, {sw})")
         x = x.contiguous()
-        d = x.device
-        Wm = torch.zeros(k * k * Cp, Cin, device=d, dtype=torch.float32)   # row (ky*k + kx)*Cp + co, column ci
-        Wm.view(k * k, Cp, Cin)[:, :Cout, :] = w.permute(2, 3, 1, 0).reshape(k * k, Cout, Cin)
-        M = B * H * W
-        P = _gemm(x, M, Cin, Wm, k * k * Cp)
-        y = _empty(d, B * Ht * Wt, Cp)
-        dev.col2im_hw(P, B, Ht, Wt, Cp, k, sh, sw, p, y)
-        bp = torch.zeros(1, Cp, device=d, dtype=torch.float32)
-        bp[0, :Cout] = b
-        dev.affine_fwd(y, None, bp, 1.0, B * Ht * Wt, B * Ht * Wt, Cp, y)
-        ctx.save_for_backward(x, Wm)
-        ctx.geo = (B, H, W, Ht, Wt, Cin, Cout, Cp, k, sh, sw, p, w.shape)
-        return y if Cp == Cout else y[:, :Cout].contiguous()
+        Wt = w.permute(1, 2, 3, 0).reshape(Cout, k * k * Cin).contiguous()      # [co][(tap)*Cin + ci]
+        y = FC.convT2d_fwd(x, B, H, W, Cin, Wt, Cout, k, sh, sw, p, bias=b)
+        ctx.save_for_backward(x, w)
+        ctx.geo = (B, H, W, Cin, Cout, k, sh, sw, p)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, Wm = ctx.saved_tensors
-        B, H, W, Ht, Wt, Cin, Cout, Cp, k, sh, sw, p, wshape = ctx.geo
+        x, w = ctx.saved_tensors
+        B, H, W, Cin, Cout, k, sh, sw, p = ctx.geo
         d = x.device
-        M = B * H * W
+        Ht, Wt_ = (H - 1) * sh - 2 * p + k, (W - 1) * sw - 2 * p + k
+        Cp = _pad4(Cout)                                        # the implicit operand moves 16-byte channel groups
         if Cp != Cout:
-            dyp = torch.zeros(B * Ht * Wt, Cp, device=d, dtype=torch.float32)
+            dyp = torch.zeros(B * Ht * Wt_, Cp, device=d, dtype=torch.float32)
             dyp[:, :Cout] = dy
             dy = dyp
         dy = dy.contiguous()
-        dP = _empty(d, M, k * k * Cp)
-        dev.im2col_hw(dy, B, Ht, Wt, Cp, k, sh, sw, p, dP, k * k * Cp)
-        dWm, _ = _wgrad(dP, M, k * k * Cp, x, Cin, with_bias=False)
-        dw = dWm.view(k * k, Cp, Cin)[:, :Cout, :].reshape(k, k, Cout, Cin).permute(3, 2, 0, 1).contiguous()
-        db = dev.chan_sums(dy, None, None, 1, B * Ht * Wt, 1, Cp)[0, 0, :Cout].contiguous()
-        dx = _gemm(dP, M, k * k * Cp, _transposed(Wm, k * k * Cp, Cin), Cin) if ctx.needs_input_grad[0] else None
-        return dx, dw.view(wshape), db, None
+        db = dev.chan_sums(dy, None, None, 1, B * Ht * Wt_, 1, Cp)[0, 0, :Cout].contiguous()
+        Wx = torch.zeros(Cin, k * k, Cp, device=d, dtype=torch.float32)          # [ci][(tap)*Cp + co]
+        Wx[:, :, :Cout] = w.permute(0, 2, 3, 1).reshape(Cin, k * k, Cout)
+        dWxT = FC.convT2d_wgrad(x, dy, B, H, W, Cin, Cp, k, sh, sw, p)         # [Cin, k*k*Cp]
+        dw = dWxT.view(Cin, k, k, Cp)[:, :, :, :Cout].permute(0, 3, 1, 2).contiguous()
+        dx = FC.convT2d_dx(dy, B, H, W, Cin, Wx.view(Cin, k * k * Cp), Cp, k, sh, sw, p) \
+            if ctx.needs_input_grad[0] else None
+        return dx, dw, db, None
 
 
 class Conv1x1ResFn(torch.autograd.Function):

@@ -8,6 +8,7 @@ import torch
 
 from . import _lib as L
 from . import dev
+from . import functional_conv as FC
 from .functional import _empty, _need_cuda
 from .functional_tasnet import _gemm, _transposed, _wgrad
 
@@ -29,9 +30,13 @@ class ConvBnActFn(torch.autograd.Function):
         ldp = -(-Kk // 4) * 4                                   # first layer: 9 taps padded to 12 columns
         W2 = torch.zeros(Cout, ldp, device=d, dtype=torch.float32)
         W2[:, :Kk] = w.permute(0, 2, 3, 1).reshape(Cout, Kk)     # column (ky*k + kx)*Cin + c, like the patches
-        patches = ConvBnActFn._patches(x, R, H, W, Cin, k, stride, pad, M, ldp)
-        c = _gemm(patches, M, ldp, W2, Cout)
-        del patches
+        if FC.implicit_ok(Cin):
+            # the patch matrix stays implicit in the GEMM's operand loader (functional_conv): nothing is unfolded
+            c = FC.conv2d_fwd(x, R, H, W, Cin, W2, Cout, k, stride, stride, pad)
+        else:                                                   # single-channel first layer: 12-column patch rows
+            patches = ConvBnActFn._patches(x, R, H, W, Cin, k, stride, pad, M, ldp)
+            c = _gemm(patches, M, ldp, W2, Cout)
+            del patches
         st = _empty(d, 2, Cout)
         if training:
             dev.bn_stats(c, M, Cout, rm, rv, st)
@@ -68,15 +73,23 @@ class ConvBnActFn(torch.autograd.Function):
         dc = _empty(d, M, Cout)
         sums = dev.bn_bwd(c, du, st, gamma, M, Cout, dc)
         Kk = k * k * Cin
-        patches = ConvBnActFn._patches(x, R, H, W, Cin, k, stride, pad, M, ldp)
-        dW2, _ = _wgrad(dc, M, Cout, patches, ldp, with_bias=False)
-        del patches
+        if FC.implicit_ok(Cin):
+            dW2, _ = FC.conv2d_wgrad(dc, x, R, H, W, Cin, Cout, k, stride, stride, pad, with_bias=False)
+        else:
+            patches = ConvBnActFn._patches(x, R, H, W, Cin, k, stride, pad, M, ldp)
+            dW2, _ = _wgrad(dc, M, Cout, patches, ldp, with_bias=False)
+            del patches
         dw = dW2[:, :Kk].reshape(Cout, k, k, Cin).permute(0, 3, 1, 2).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dpatches = _gemm(dc, M, Cout, _transposed(W2, Cout, ldp), ldp)
-            dx = _empty(d, R * H * W, Cin)
-            dev.col2im(dpatches, R, H, W, Cin, k, stride, pad, dx)
+            if FC.implicit_ok(Cin) and FC.implicit_ok(Cout) and stride <= 2:
+                # transposed view of dc, one row per input pixel: Wd[ci][(tap)*Cout + co] = w[co, ci, ky, kx]
+                Wd = W2.view(Cout, k * k, Cin).permute(2, 1, 0).reshape(Cin, k * k * Cout).contiguous()
+                dx = FC.conv2d_dx(dc, R, H, W, Cin, Wd, Cout, k, stride, stride, pad)
+            else:
+                dpatches = _gemm(dc, M, Cout, _transposed(W2, Cout, ldp), ldp)
+                dx = _empty(d, R * H * W, Cin)
+                dev.col2im(dpatches, R, H, W, Cin, k, stride, pad, dx)
         return dx, dres, None, dw.view(wshape), sums[1].contiguous(), sums[0].contiguous(), None, None
 
 

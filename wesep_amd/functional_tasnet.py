@@ -32,8 +32,9 @@ def _stat_map(norm, Tp):
 
 
 def _gemm(x, M, K, W, Nout, *, ldw=None, w_off=0, bias=None, act=0, R=None, T=None, norm=None,
-          a_rows=None, a_off=0, out=None, c_ld=None, c_off=0, vec=None, mode=None):
-    """out[m, c_off + n] = epi(sum_k pro(x[m, k]) W[n, k]); norm = (stats, gamma, beta, stat_map)."""
+          a_rows=None, a_off=0, out=None, c_ld=None, c_off=0, vec=None, mode=None, conv=None):
+    """out[m, c_off + n] = epi(sum_k pro(x[m, k]) W[n, k]); norm = (stats, gamma, beta, stat_map); conv: x is an image
+    and the operand its implicit patch matrix (dev.ConvView)."""
     ldw = ldw if ldw is not None else K
     c_ld = c_ld if c_ld is not None else Nout
     if out is None:
@@ -43,11 +44,12 @@ def _gemm(x, M, K, W, Nout, *, ldw=None, w_off=0, bias=None, act=0, R=None, T=No
         vec = _vec(K, ldw, w_off, a_off) if a_rows is None else 0
     dev.gemm_nt(A=x, a_rows=a_rows or flat(K), M=M, N=Nout, K=K, W=W, ldw=ldw, w_off=w_off, bias=bias,
                 C_out=out, c_rows=flat(c_ld), c_off=c_off, a_off=a_off, act=act, R=R, T=T, stats=st,
-                gamma=gm, beta=bt, stat_map=sm, vec=vec, mode=mode)
+                gamma=gm, beta=bt, stat_map=sm, vec=vec, mode=mode, conv=conv)
     return out
 
 
-def _wgrad(G, M, Nn, A, Kk, *, g_ld=None, g_off=0, a_rows=None, norm=None, with_bias=True, vec=None, mode=None):
+def _wgrad(G, M, Nn, A, Kk, *, g_ld=None, g_off=0, a_rows=None, norm=None, with_bias=True, vec=None, mode=None,
+           conv=None):
     """dW [Nn, Kk] = G^T pro(A), db [Nn] = colsum(G): split slabs + deterministic reduce."""
     # enough (split x tile) workgroups to fill 256 CUs; a split keeps >= 256 rows
     tiles = -(-Nn // 128) * -(-Kk // 128)
@@ -62,7 +64,7 @@ def _wgrad(G, M, Nn, A, Kk, *, g_ld=None, g_off=0, a_rows=None, norm=None, with_
         vec = 1 if (a_rows is None and Kk % 4 == 0) else 0
     dev.gemm_tn(G=G, g_rows=flat(g_ld if g_ld is not None else Nn), g_off=g_off, A=A, a_rows=a_rows or flat(Kk),
                 M=M, Nn=Nn, Kk=Kk, slab=slab, slab_stride=Nn * Kk, bslab=bslab, bslab_stride=Nn, nsplit=nsplit,
-                rows_per_split=rps, stats=st, gamma=gm, beta=bt, stat_map=sm, vec=vec, mode=mode)
+                rows_per_split=rps, stats=st, gamma=gm, beta=bt, stat_map=sm, vec=vec, mode=mode, conv=conv)
     dW = _reduce_new(slab, nsplit, Nn * Kk, (Nn, Kk))
     db = _reduce_new(bslab, nsplit, Nn, (Nn,)) if with_bias else None
     return dW, db
