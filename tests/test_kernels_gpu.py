@@ -668,6 +668,36 @@ def test_lstm_cluster_fwd_bwd_vs_torch(view, dims):
     assert rel(dg[:, 1].sum(0), lstm.bias_ih_l0_reverse.grad) < 8e-5
 
 
+@pytest.mark.parametrize("N", [16, 24, 32, 48, 64, 96])
+def test_generic_bf16_gemms_narrow_column_tiles(N):
+    """Ungrouped split-bf16 launches with few output columns run narrow tiles (32 / 64 columns per workgroup in
+    ws_gemm_nt, 32 gradient columns in ws_gemm_tn): same results as fp64, run-to-run identical, partial row tiles."""
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(90 + N)
+    M, K = 1000 + N, 100
+    A, W, b, Rr = rnd(g, M, K), rnd(g, N, K, scale=0.1), rnd(g, N), rnd(g, M, N)
+    outs = []
+    for _ in range(2):
+        C = torch.full((M, N), float("nan"), device=d)
+        dev.gemm_nt(A=A.to(d), a_rows=dev.flat(K), M=M, N=N, K=K, W=W.to(d), ldw=K, bias=b.to(d), C_out=C,
+                    c_rows=dev.flat(N), R=Rr.to(d), mode="bf16x3")
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    assert rel(outs[0], A.double() @ W.double().t() + b.double() + Rr.double()) < 4e-5
+    G = rnd(g, M, N)
+    ns, rps = 3, 384
+    outs = []
+    for _ in range(2):
+        slab, bslab = torch.full((ns, N * K), float("nan"), device=d), torch.full((ns, N), float("nan"), device=d)
+        dev.gemm_tn(G=G.to(d), g_rows=dev.flat(N), A=A.to(d), a_rows=dev.flat(K), M=M, Nn=N, Kk=K, slab=slab,
+                    slab_stride=N * K, nsplit=ns, rows_per_split=rps, bslab=bslab, bslab_stride=N, mode="bf16x3")
+        outs.append((slab, bslab))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel(outs[0][0].sum(0).view(N, K), G.double().t() @ A.double()) < 4e-5
+    assert rel(outs[0][1].sum(0), G.double().sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("kind", ["nt", "tn"])
 def test_generic_bf16_gemms_have_no_outliers_at_scale(kind):
     """The split-bf16 generic GEMMs (mask MLP / speaker path) at a many-workgroup size: element-wise

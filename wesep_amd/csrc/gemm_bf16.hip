@@ -68,6 +68,34 @@ __device__ __forceinline__ void tile_mma(const __bf16* __restrict__ lds, int aro
   }
 }
 
+// narrow column tiles (NB = 1, 2 blocks of 32 columns): the four waves split the 128 rows, each owns 32 rows x 32*NB
+// columns -- a layer with 16 or 32 output channels (every DPCCN convolution) does a quarter / half of the MFMA work
+// of the 128-column tile instead of multiplying zero padding
+template <int NB>
+__device__ __forceinline__ void tile_mma_narrow(const __bf16* __restrict__ lds, int arow0, int l31, int half,
+                                                f32x16 (&c)[2]) {
+  const __bf16* Ah = lds;
+  const __bf16* Al = lds + BT_PLANE;
+  const __bf16* Bh = lds + 2 * BT_PLANE;
+  const __bf16* Bl = lds + 3 * BT_PLANE;
+#pragma unroll
+  for (int ks = 0; ks < BT_BK; ks += 16) {
+    const int ka = ks + 8 * half;
+    const int ra = (arow0 + l31) * BT_LD + ka;
+    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ah + ra);
+    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Al + ra);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int rb = (32 * nb + l31) * BT_LD + ka;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + rb);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + rb);
+      c[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c[nb], 0, 0, 0);
+      c[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c[nb], 0, 0, 0);
+      c[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c[nb], 0, 0, 0);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // NT: C[M][N] = epi(pro(A)[M][K] * W[N][K]^T).  Requires float4-loadable A and W (vec bits 0,1).
 // ---------------------------------------------------------------------------------------------
@@ -82,7 +110,8 @@ typedef const __attribute__((address_space(1))) float* gfp;
 // CONV: the A operand is an implicit im2col matrix (ws_conv_view, wesep_hip.h): a row is an output pixel, a k-tile's
 // float4 lies inside one tap (C % 4 == 0), so the loader adds the tap's offset to the pixel's base and masks taps that
 // fall outside the image -- the patch matrix (k*k times the activation) never exists in HBM.
-template <bool NORM, bool CONV>
+// NB: 32-column blocks per workgroup tile (4 = the 128 x 128 tile with 2 x 2 waves of 64 x 64; 1 / 2 = narrow, above).
+template <bool NORM, bool CONV, int NB>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[4 * BT_PLANE];  // 40 KB
   const float* A_ = p.A;
@@ -112,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
   }
   const gfp A = (gfp)A_, W = (gfp)W_, gamma = (gfp)gamma_, beta = (gfp)beta_, stats = (gfp)p.stats;
   const int M = p.M;
-  const int m_blk = blockIdx.x * 128, n_blk = blockIdx.y * 128;
+  const int m_blk = blockIdx.x * 128, n_blk = blockIdx.y * (32 * NB);
   if (n_blk >= N) return;
   const int tid = threadIdx.x;
   const int lrow = tid >> 3, lk = (tid & 7) * 4;
@@ -146,8 +175,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
       rstd[i] = stats[2 * s + 1];
     }
     const int n = n_blk + lrow + 32 * i;
-    vn[i] = n < N;
-    woff[i] = (long long)(vn[i] ? n : N - 1) * ldw;
+    vn[i] = n < N && i < NB;
+    woff[i] = (long long)(n < N ? n : N - 1) * ldw;
   }
 
   // load_tile only ISSUES the loads (raw values stay in registers under the MFMAs of the current tile);
@@ -188,12 +217,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
           ok = hn >= 0 && wn >= 0 && (hn & csh) == 0 && (wn & csw) == 0 && hh < cv.H && ww < cv.W;
         }
         vt[i] = ok;
-        const long long o = ok ? aoff[i] + ((long long)hh * cv.W + ww) * cv.C + cc : 0;
+        const long long o = ok ? aoff[i] + ((hh * cv.W + ww) * cv.C + cc) : 0;  // one image < 2^31 elements (checked)
         ra[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(A + o);
       } else {
         ra[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(A + aoff[i] + kc);
       }
-      rw[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(W + woff[i] + kc);
+      if (i < NB) rw[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(W + woff[i] + kc);
     }
   };
   auto store_tile = [&]() {
@@ -208,9 +237,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
       split4(v, hi, lo);
       *reinterpret_cast<bf16x4*>(lds + o) = hi;
       *reinterpret_cast<bf16x4*>(lds + BT_PLANE + o) = lo;
-      split4(wv, hi, lo);
-      *reinterpret_cast<bf16x4*>(lds + 2 * BT_PLANE + o) = hi;
-      *reinterpret_cast<bf16x4*>(lds + 3 * BT_PLANE + o) = lo;
+      if (i < NB) {
+        split4(wv, hi, lo);
+        *reinterpret_cast<bf16x4*>(lds + 2 * BT_PLANE + o) = hi;
+        *reinterpret_cast<bf16x4*>(lds + 3 * BT_PLANE + o) = lo;
+      }
     }
   };
 
@@ -219,6 +250,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
   f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
+  f32x16 accn[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accn[0][r] = accn[1][r] = 0.f;
 
   const int nk = (K + BT_BK - 1) / BT_BK;
   load_tile(0);
@@ -228,18 +262,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
     __syncthreads();
     load_tile(min(kt + 1, nk - 1));  // branch-free: the last iteration reloads its own tile (unused)
     __builtin_amdgcn_sched_barrier(0);  // issue the loads HERE: they must fly under the MFMAs below
-    tile_mma(lds, wm * 64, wn * 64, l31, half, acc00, acc01, acc10, acc11);
+    if constexpr (NB == 4) tile_mma(lds, wm * 64, wn * 64, l31, half, acc00, acc01, acc10, acc11);
+    else tile_mma_narrow<NB>(lds, wave * 32, l31, half, accn);
     __builtin_amdgcn_sched_barrier(0);
   }
 
   const bool flat_c = p.c_div >= M;  // (m / c_div) == 0 for every row: no division needed
+  // (row0, col0) of a 32 x 32 accumulator block inside the workgroup tile
   auto epilogue = [&](const f32x16& acc, int tm, int tn) {
-    const int n = n_blk + wn * 64 + tn * 32 + l31;
+    const int col0 = NB == 4 ? wn * 64 + tn * 32 : tn * 32, row0 = NB == 4 ? wm * 64 + tm * 32 : wave * 32;
+    const int n = n_blk + col0 + l31;
     if (n >= N) return;
     const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m_blk + wm * 64 + tm * 32 + frag_row32b(r, half);
+      const int m = m_blk + row0 + frag_row32b(r, half);
       if (m >= M) continue;
       const long long off = (flat_c ? (long long)m * p.c_s2 : ws_row_off(m, p.c_div, p.c_s1, p.c_s2)) + n;
       float v = acc[r] + bv;
@@ -253,19 +290,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
       C[off] = v;
     }
   };
-  epilogue(acc00, 0, 0);
-  epilogue(acc01, 0, 1);
-  epilogue(acc10, 1, 0);
-  epilogue(acc11, 1, 1);
+  if constexpr (NB == 4) {
+    epilogue(acc00, 0, 0);
+    epilogue(acc01, 0, 1);
+    epilogue(acc10, 1, 0);
+    epilogue(acc11, 1, 1);
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) epilogue(accn[nb], 0, nb);
+  }
+}
+
+// Column-tile width of a launch: ungrouped launches without norm-on-load and at most 64 output columns (the
+// convolutions and 1x1 convolutions of DPCCN / the ResNet stem) use the narrow tiles; everything else -- in particular
+// every launch of the pBSRNN path (grouped and / or normalising) -- keeps the 128-column tile of round 1.
+int ws_gemm_nt_bf16_nb(const ws_gemm_nt_args* a) {
+  if (a->groups || a->stats) return 4;
+  return a->N <= 32 ? 1 : (a->N <= 64 ? 2 : 4);
 }
 
 int ws_launch_gemm_nt_bf16(const ws_gemm_nt_args* a, dim3 grid, hipStream_t s) {
+  const int nb = ws_gemm_nt_bf16_nb(a);
+  if (nb != 4) grid.y = (a->N + 32 * nb - 1) / (32 * nb);
+#define WS_NT_LAUNCH(NORM_, CONV_)                                                                        \
+  do {                                                                                                    \
+    if (nb == 1) hipLaunchKernelGGL((gemm_nt_bf16_kernel<NORM_, CONV_, 1>), grid, dim3(256), 0, s, *a);      \
+    else if (nb == 2) hipLaunchKernelGGL((gemm_nt_bf16_kernel<NORM_, CONV_, 2>), grid, dim3(256), 0, s, *a); \
+    else hipLaunchKernelGGL((gemm_nt_bf16_kernel<NORM_, CONV_, 4>), grid, dim3(256), 0, s, *a);              \
+  } while (0)
   if (a->conv.on)
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, true>), grid, dim3(256), 0, s, *a);
+    WS_NT_LAUNCH(false, true);
   else if (a->stats)
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, false>), grid, dim3(256), 0, s, *a);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, false, 4>), grid, dim3(256), 0, s, *a);
   else
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, false>), grid, dim3(256), 0, s, *a);
+    WS_NT_LAUNCH(false, false);
+#undef WS_NT_LAUNCH
   return 0;
 }
 
@@ -280,11 +339,15 @@ struct RowMeta {
   long long goff, aoff;
   float mean, rstd;
   int gvalid, avalid;
-  int bh, bw;  // CONV: base coordinates of the row's pixel (ho*sh - p, wo*sw - p); aoff = image base
+  int tapmask, pad_;  // CONV: bit (ky*k + kx) = that tap of the row's pixel lies inside the image; aoff then addresses
+                      // tap (0, 0) of the pixel (possibly before the image: only dereferenced through a valid tap)
 };
 
 // CONV: A is the implicit im2col matrix (mode 0) of the image p.A points to; this thread's column is one (tap, channel).
-template <bool CONV>
+// NARROW: at most 32 gradient columns per tile (16 / 32 output channels): the four waves split the 128 A columns and
+// each runs one 32 x 32 accumulator -- a quarter of the MFMA work of the 128 x 128 tile, which is what bounds the
+// weight gradients of the DPCCN convolutions (M = 4.1 M rows, Nn = 16).
+template <bool CONV, bool NARROW>
 __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[4 * BT_PLANE];  // 40 KB
   __shared__ RowMeta meta[2][32];
@@ -307,9 +370,10 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
     Nn = g.Nn;
     Kk = g.Kk;
   }
-  const int tiles_k = (Kk + 127) / 128, tiles_n = (Nn + 127) / 128;
+  constexpr int TNW = NARROW ? 32 : 128;  // gradient columns per tile
+  const int tiles_k = (Kk + 127) / 128, tiles_n = (Nn + TNW - 1) / TNW;
   if ((int)blockIdx.x >= tiles_k * tiles_n) return;
-  const int n_blk = (blockIdx.x / tiles_k) * 128, k_blk = (blockIdx.x % tiles_k) * 128;
+  const int n_blk = (blockIdx.x / tiles_k) * TNW, k_blk = (blockIdx.x % tiles_k) * 128;
   const int split = blockIdx.y;
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
@@ -317,7 +381,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
   const int col = tid & 127, mg = (tid >> 7) * 16;  // this thread: column `col`, rows mg..mg+15
   const bool has_norm = p.stats != nullptr;
   const bool do_bias = p.bslab != nullptr && k_blk == 0;
-  const bool gcol_ok = n_blk + col < Nn, acol_ok = k_blk + col < Kk;
+  const bool gcol_ok = col < TNW && n_blk + col < Nn, acol_ok = k_blk + col < Kk;
   float gm = 1.f, bt = 0.f;
   if (has_norm && acol_ok) {
     gm = gamma[k_blk + col];
@@ -333,16 +397,20 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
       r.goff = r.aoff = 0;
       r.mean = 0.f;
       r.rstd = 1.f;
-      r.bh = r.bw = 0;
+      r.tapmask = r.pad_ = 0;
       if (CONV && r.gvalid) {
         const ws_conv_view cv = p.conv;
         const int hw = cv.Ho * cv.Wo;
         const int rr = m / hw, q = m - rr * hw;
         const int ho = q / cv.Wo, wo = q - ho * cv.Wo;
+        const int bh = ho * cv.sh - cv.p, bw = wo * cv.sw - cv.p;
         r.goff = ws_row_off(m, p.g_div, p.g_s1, p.g_s2);
-        r.aoff = (long long)rr * cv.H * cv.W * cv.C;
-        r.bh = ho * cv.sh - cv.p;
-        r.bw = wo * cv.sw - cv.p;
+        r.aoff = (long long)rr * cv.H * cv.W * cv.C + (long long)(bh * cv.W + bw) * cv.C;
+        int mask = 0;
+        for (int ky = 0; ky < cv.k; ++ky)
+          for (int kx = 0; kx < cv.k; ++kx)
+            if ((unsigned)(bh + ky) < (unsigned)cv.H && (unsigned)(bw + kx) < (unsigned)cv.W) mask |= 1 << (ky * cv.k + kx);
+        r.tapmask = mask;
       } else if (r.gvalid) {
         r.goff = ws_row_off(m, p.g_div, p.g_s1, p.g_s2);
         int ma = m;
@@ -368,13 +436,12 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
   // bf16 split happen in store_tile one iteration later, with the loads in flight under the MFMAs.
   const gfp Gg = (gfp)G + n_blk + (gcol_ok ? col : 0);
   gfp Ag = (gfp)A + k_blk + (acol_ok ? col : 0);
-  int cky = 0, ckx = 0;  // CONV: this thread's tap; Ag then points at its channel of pixel (0, 0)
+  int ctap = 0;  // CONV: this thread's tap; Ag then points at (tap, channel) relative to a pixel's tap (0, 0)
   if (CONV) {
     const int kc = acol_ok ? k_blk + col : 0;
-    const int tap = kc / p.conv.C;
-    cky = tap / p.conv.k;
-    ckx = tap - cky * p.conv.k;
-    Ag = (gfp)A + (kc - tap * p.conv.C);
+    ctap = kc / p.conv.C;
+    const int cky = ctap / p.conv.k, ckx = ctap - cky * p.conv.k;
+    Ag = (gfp)A + ((cky * p.conv.W + ckx) * p.conv.C + (kc - ctap * p.conv.C));
   }
   float rg[16], ra[16];
   unsigned tapok = 0xffffu;  // CONV: bit j = the tap lies inside the image for row j of the tile in registers
@@ -385,10 +452,9 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
       const RowMeta& r = meta[slot][mg + j];
       rg[j] = Gg[r.goff];
       if (CONV) {
-        const int hh = r.bh + cky, ww = r.bw + ckx;
-        const bool ok = r.avalid && (unsigned)hh < (unsigned)p.conv.H && (unsigned)ww < (unsigned)p.conv.W;
+        const bool ok = (r.tapmask >> ctap) & 1;   // (0 for rows past the split's end)
         okb |= ok ? 1u << j : 0u;
-        ra[j] = Ag[ok ? r.aoff + ((long long)hh * p.conv.W + ww) * p.conv.C : 0];
+        ra[j] = Ag[ok ? r.aoff : 0];               // unconditional load (offset 0 = this thread's tap of pixel (0, 0))
       } else {
         ra[j] = Ag[r.aoff];
       }
@@ -449,24 +515,41 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
     __syncthreads();
     load_tile((it + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);  // the loads are issued here and fly under the MFMAs
-    tile_mma(lds, wm * 64, wn * 64, l31, half, acc00, acc01, acc10, acc11);
+    if constexpr (NARROW) {
+      // D[n][k]: rows = the 32 gradient columns (G planes, rows 0..31), columns = this wave's 32 A columns
+#pragma unroll
+      for (int ks = 0; ks < BT_BK; ks += 16) {
+        const int ra_ = l31 * BT_LD + ks + 8 * half, rb_ = (wave * 32 + l31) * BT_LD + ks + 8 * half;
+        const bf16x8 gh = *reinterpret_cast<const bf16x8*>(lds + ra_);
+        const bf16x8 gl = *reinterpret_cast<const bf16x8*>(lds + BT_PLANE + ra_);
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds + 2 * BT_PLANE + rb_);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds + 3 * BT_PLANE + rb_);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, ah, acc00, 0, 0, 0);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, al, acc00, 0, 0, 0);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ah, acc00, 0, 0, 0);
+      }
+    } else {
+      tile_mma(lds, wm * 64, wn * 64, l31, half, acc00, acc01, acc10, acc11);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 
   float* out = p.slab + (long long)split * p.slab_stride + out_off;
   auto write = [&](const f32x16& acc, int tm, int tn) {
-    const int k = k_blk + wn * 64 + tn * 32 + l31;
+    const int k = k_blk + (NARROW ? wave * 32 : wn * 64 + tn * 32) + l31;
     if (k >= Kk) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = n_blk + wm * 64 + tm * 32 + frag_row32b(r, half);
+      const int n = n_blk + (NARROW ? 0 : wm * 64 + tm * 32) + frag_row32b(r, half);
       if (n < Nn) out[(long long)n * Kk + k] = acc[r];
     }
   };
   write(acc00, 0, 0);
-  write(acc01, 0, 1);
-  write(acc10, 1, 0);
-  write(acc11, 1, 1);
+  if constexpr (!NARROW) {
+    write(acc01, 0, 1);
+    write(acc10, 1, 0);
+    write(acc11, 1, 1);
+  }
   if (do_bias) {
     __syncthreads();
     if (tid >= 128) bred[col] = bsum;
@@ -477,9 +560,17 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
 }
 
 int ws_launch_gemm_tn_bf16(const ws_gemm_tn_args* a, dim3 grid, hipStream_t s) {
-  if (a->conv.on)
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, dim3(256), 0, s, *a);
+  // narrow gradient tiles for ungrouped launches with at most 32 gradient columns (see the kernel); the grouped /
+  // normalising launches of the pBSRNN path keep the 128 x 128 tile
+  const bool narrow = !a->groups && !a->stats && a->Nn <= 32;
+  if (narrow) grid.x = ((a->Nn + 31) / 32) * ((a->Kk + 127) / 128);
+  if (a->conv.on && narrow)
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, dim3(256), 0, s, *a);
+  else if (a->conv.on)
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, dim3(256), 0, s, *a);
+  else if (narrow)
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, true>), grid, dim3(256), 0, s, *a);
   else
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, grid, dim3(256), 0, s, *a);
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, dim3(256), 0, s, *a);
   return 0;
 }
