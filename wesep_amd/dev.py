@@ -57,6 +57,25 @@ def _p(t: Optional[torch.Tensor], off: int = 0):
     return C.c_void_p(t.data_ptr() + 4 * off)
 
 
+# Algorithmic work counters for the bench tools (None = off): kind -> [bytes, flops, launches] of what a launch must
+# move / compute at least (operands once, outputs once; an implicit patch matrix counts as its image), next to the
+# HIP-event time of the same kind (prof_collect) -> roofline fractions without a profiler.
+ALG = None
+
+
+def alg_reset(on=True):
+    global ALG
+    ALG = {} if on else None
+
+
+def _alg(kind, nbytes, flops):
+    if ALG is not None:
+        e = ALG.setdefault(kind, [0, 0, 0])
+        e[0] += int(nbytes)
+        e[1] += int(flops)
+        e[2] += 1
+
+
 class ConvView(NamedTuple):
     """ws_conv_view (include/wesep_hip.h): the A operand of gemm_nt / gemm_tn is the never-materialised im2col matrix
     of the channels-last image [R][H][W][C] that A points to; (Ho, Wo) = rows per image; mode 0 = convolution view
@@ -99,6 +118,9 @@ def gemm_nt(*, A, a_rows: Rows, M: int, C_out, c_rows: Rows, N=0, K=0, W=None, l
     a.M, a.N, a.K, a.ldw = M, N, K, ldw
     a.act, a.ngroups, a.max_n, a.vec = act, ngroups, max_n, vec | _mode_bit(mode)
     _set_conv(a, conv)
+    if ALG is not None and groups is None:
+        a_elems = (M // (conv.Ho * conv.Wo)) * conv.H * conv.W * conv.C if conv is not None else M * K
+        _alg("gemm_nt", 4 * (a_elems + M * N * (1 + (R is not None) + (T is not None)) + N * K), 2 * M * N * K)
     L.check(L.lib().ws_gemm_nt(C.byref(a), L.stream_ptr()), "ws_gemm_nt")
 
 
@@ -131,6 +153,9 @@ def gemm_tn(*, G, g_rows: Rows, A, a_rows: Rows, M: int, slab, slab_stride: int,
     a.shift_rows, a.seq_div, a.seq_len = shift_rows, seq_div, seq_len
     a.ngroups, a.max_n, a.max_k, a.vec = ngroups, max_n, max_k, vec | _mode_bit(mode)
     _set_conv(a, conv)
+    if ALG is not None and groups is None:
+        a_elems = (M // (conv.Ho * conv.Wo)) * conv.H * conv.W * conv.C if conv is not None else M * Kk
+        _alg("gemm_tn", 4 * (a_elems + M * Nn + nsplit * Nn * Kk), 2 * M * Nn * Kk)
     L.check(L.lib().ws_gemm_tn(C.byref(a), L.stream_ptr()), "ws_gemm_tn")
 
 
@@ -283,6 +308,8 @@ def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, run_if=No
 
 def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3):
     a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat)
+    # per (position, direction, unit): read 4 gates + c + dh, write 4 d(gates) = 10 floats; 2 * 4H * H MACs per position
+    _alg("lstm_bwd", 10 * 4 * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
     L.check(L.lib().ws_lstm_bwd(C.byref(a), L.stream_ptr()), "ws_lstm_bwd")
 
 
