@@ -132,6 +132,23 @@ typedef struct ws_gemm_tn_args {
 } ws_gemm_tn_args;
 int ws_gemm_tn(const ws_gemm_tn_args* a, void* stream);
 
+/* Weight gradient of a convolution with at most 32 output channels, one pass over the activation (conv_wgrad.hip):
+ *   slab[split][n * Kk + kk] = sum_{m in split} G[m * ldg + n] * P[m][kk],   bslab[split][n] = sum_m G[m * ldg + n]
+ * P = the mode-0 implicit patch matrix `conv` of the image X (Kk = k*k*C <= 768, C % 4 == 0, k <= 5); a split is
+ * tiles_per_split tiles of 32 consecutive rows.  Same result as ws_gemm_tn with conv.on, which sends every 128-column
+ * slice of P to another workgroup and so streams X k*k times; this one owns all of P's columns per tile.
+ * Replaces autograd's weight gradient of F.conv2d / F.conv_transpose2d (wesep/modules/dpccn/convs.py:28-110).     */
+typedef struct ws_conv_wgrad_args {
+  const float* G;      /* [M][ldg] output gradient (conv2d) or the layer input (conv_transpose2d) */
+  const float* X;      /* channels-last image the patch view is taken of */
+  float* slab;
+  float* bslab;        /* or NULL */
+  long long ldg, slab_stride, bslab_stride;
+  int M, Nn, nsplit, tiles_per_split;
+  ws_conv_view conv;
+} ws_conv_wgrad_args;
+int ws_conv_wgrad(const ws_conv_wgrad_args* a, void* stream);
+
 /* out[(i / w) * ldo + (i % w)] = sum_s slab[s * stride + i],  i < count                    */
 int ws_reduce_slabs(const float* slab, int nsplit, long long stride, long long count,
                     float* out, int w, long long ldo, void* stream);

@@ -534,7 +534,20 @@ def log_eps(x, eps):
     x.copy_(torch.log(x + eps))
 
 
-EMULATED = [gemm_nt, gemm_tn, reduce_slabs, transpose, affine_fwd, chan_sums, im2col_hw, col2im_hw, elu_fwd, elu_bwd,
+def conv_wgrad(*, G, ldg, X, M, Nn, conv, slab, nsplit, tiles_per_split, bslab=None):
+    """ws_conv_wgrad: slab[split][n][kk] = sum over the split's rows of G[m][n] * patches(X)[m][kk]."""
+    A = _conv_matrix(X, M, conv)
+    g = G.reshape(-1)[:M * ldg].reshape(M, ldg)[:, :Nn]
+    Kk = A.shape[1]
+    sl = slab.reshape(-1)
+    for sp in range(nsplit):
+        lo, hi = sp * tiles_per_split * 32, min(M, (sp + 1) * tiles_per_split * 32)
+        sl[sp * Nn * Kk:(sp + 1) * Nn * Kk] = (g[lo:hi].t() @ A[lo:hi]).reshape(-1) if hi > lo else 0.0
+        if bslab is not None:
+            bslab.reshape(-1)[sp * Nn:(sp + 1) * Nn] = g[lo:hi].sum(0) if hi > lo else 0.0
+
+
+EMULATED = [conv_wgrad, gemm_nt, gemm_tn, reduce_slabs, transpose, affine_fwd, chan_sums, im2col_hw, col2im_hw, elu_fwd, elu_bwd,
             inorm_fwd, inorm_bwd, dwconv_fwd, dwconv_bwd, avgpool_fwd, avgpool_bwd, bilinear_fwd, bilinear_bwd,
             scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum, lstm_pack, lstm_fwd, lstm_bwd,
             group_stats, flat_stats, gn_bwd_reduce, norm_ab, norm_bwd_apply_cl, prelu_fwd, prelu_bwd, softmax_rows_fwd,

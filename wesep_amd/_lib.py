@@ -47,6 +47,12 @@ class GemmTNArgs(C.Structure):
                                   "ngroups", "max_n", "max_k", "vec")] + [("conv", ConvView)]
 
 
+class ConvWgradArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("G", "X", "slab", "bslab")] + \
+               [(n, _ll) for n in ("ldg", "slab_stride", "bslab_stride")] + \
+               [(n, _i) for n in ("M", "Nn", "nsplit", "tiles_per_split")] + [("conv", ConvView)]
+
+
 class GroupsGeom(C.Structure):
     _fields_ = [("band_w", _p), ("band_off", _p), ("gs1", _ll), ("gs2", _ll), ("rs", _ll),
                 ("ngroups", _i), ("gdiv", _i), ("L", _i), ("W", _i), ("nbands", _i), ("pad_", _i)]
@@ -164,6 +170,7 @@ _SIGS = {
     "ws_cross_entropy": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "ws_im2col": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _ll, _p, _p]),
     "ws_col2im": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_conv_wgrad": (_i, [C.POINTER(ConvWgradArgs), _p]),
     "ws_tstp_fwd": (_i, [_p, _i, _i, _i, _i, C.c_float, _p, _p]),
     "ws_tstp_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "ws_im2col_hw": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _p, _p]),

@@ -159,6 +159,28 @@ def gemm_tn(*, G, g_rows: Rows, A, a_rows: Rows, M: int, slab, slab_stride: int,
     L.check(L.lib().ws_gemm_tn(C.byref(a), L.stream_ptr()), "ws_gemm_tn")
 
 
+CONV_WGRAD_MAXK = 768
+
+
+def conv_wgrad_ok(Nn: int, conv: ConvView) -> bool:
+    """The one-pass convolution weight-gradient kernel (conv_wgrad.hip) takes this shape."""
+    return (conv.mode == 0 and 4 <= Nn <= 32 and Nn % 4 == 0 and conv.C % 4 == 0 and conv.k <= 5 and
+            conv.k * conv.k * conv.C <= CONV_WGRAD_MAXK)
+
+
+def conv_wgrad(*, G, ldg: int, X, M: int, Nn: int, conv: ConvView, slab, nsplit: int, tiles_per_split: int, bslab=None):
+    for n, t in (("G", G), ("X", X), ("slab", slab), ("bslab", bslab)):
+        _chk(t, n)
+    a = L.ConvWgradArgs()
+    a.G, a.X, a.slab, a.bslab = _p(G), _p(X), _p(slab), _p(bslab)
+    Kk = conv.k * conv.k * conv.C
+    a.ldg, a.slab_stride, a.bslab_stride = ldg, Nn * Kk, Nn
+    a.M, a.Nn, a.nsplit, a.tiles_per_split = M, Nn, nsplit, tiles_per_split
+    _set_conv(a, conv)
+    _alg("gemm_tn", 4 * ((M // (conv.Ho * conv.Wo)) * conv.H * conv.W * conv.C + M * Nn + nsplit * Nn * Kk), 2 * M * Nn * Kk)
+    L.check(L.lib().ws_conv_wgrad(C.byref(a), L.stream_ptr()), "ws_conv_wgrad")
+
+
 def reduce_slabs(slab, nsplit: int, stride: int, count: int, out, w=0, ldo=0, out_off=0):
     _chk(slab, "slab")
     _chk(out, "out")

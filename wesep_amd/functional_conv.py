@@ -16,6 +16,7 @@ import torch
 
 from . import dev
 from .dev import ConvView
+from .functional import _empty, _reduce_new
 from .functional_tasnet import _gemm, _wgrad
 
 MODE = "bf16x3"   # the implicit operand exists in the split-bf16 kernels only
@@ -32,11 +33,29 @@ def conv2d_fwd(x, B, H, W, Cin, W2, Cout, k, sh, sw, p, bias=None):
                  conv=ConvView(0, H, W, Cin, Ho, Wo, k, sh, sw, p))
 
 
+def _one_pass_wgrad(G, M, Nn, X, conv, with_bias):
+    """G^T view0(X) through the one-pass kernel (few gradient columns, all patch columns per workgroup)."""
+    Kk = conv.k * conv.k * conv.C
+    tiles = -(-M // 32)
+    nsplit = max(1, min(512, tiles // 8))                  # >= 8 tiles per workgroup, up to two waves of workgroups
+    tps = -(-tiles // nsplit)
+    nsplit = -(-tiles // tps)
+    d = G.device
+    slab = _empty(d, nsplit, Nn * Kk)
+    bslab = _empty(d, nsplit, Nn) if with_bias else None
+    dev.conv_wgrad(G=G, ldg=Nn, X=X, M=M, Nn=Nn, conv=conv, slab=slab, nsplit=nsplit, tiles_per_split=tps, bslab=bslab)
+    dW = _reduce_new(slab, nsplit, Nn * Kk, (Nn, Kk))
+    db = _reduce_new(bslab, nsplit, Nn, (Nn,)) if with_bias else None
+    return dW, db
+
+
 def conv2d_wgrad(dy, x, B, H, W, Cin, Cout, k, sh, sw, p, with_bias=True):
     """dW2 [Cout, k*k*Cin] = dy^T view0(x) (+ db)."""
     Ho, Wo = dev.conv_out(H, k, sh, p), dev.conv_out(W, k, sw, p)
-    return _wgrad(dy, B * Ho * Wo, Cout, x, k * k * Cin, with_bias=with_bias, vec=1, mode=MODE,
-                  conv=ConvView(0, H, W, Cin, Ho, Wo, k, sh, sw, p))
+    conv = ConvView(0, H, W, Cin, Ho, Wo, k, sh, sw, p)
+    if dev.conv_wgrad_ok(Cout, conv):
+        return _one_pass_wgrad(dy, B * Ho * Wo, Cout, x, conv, with_bias)
+    return _wgrad(dy, B * Ho * Wo, Cout, x, k * k * Cin, with_bias=with_bias, vec=1, mode=MODE, conv=conv)
 
 
 def conv2d_dx(dy, B, H, W, Cin, Wd, Cout, k, sh, sw, p):
@@ -71,6 +90,8 @@ def convT2d_dx(dy, B, H, W, Cin, Wx, Cout, k, sh, sw, p):
 def convT2d_wgrad(x, dy, B, H, W, Cin, Cout, k, sh, sw, p):
     """dWx^T [Cin, k*k*Cout] = x^T view0(dy)."""
     Ht, Wt_ = (H - 1) * sh - 2 * p + k, (W - 1) * sw - 2 * p + k
-    dWxT, _ = _wgrad(x, B * H * W, Cin, dy, k * k * Cout, with_bias=False, vec=1, mode=MODE,
-                     conv=ConvView(0, Ht, Wt_, Cout, H, W, k, sh, sw, p))
+    conv = ConvView(0, Ht, Wt_, Cout, H, W, k, sh, sw, p)
+    if dev.conv_wgrad_ok(Cin, conv):
+        return _one_pass_wgrad(x, B * H * W, Cin, dy, conv, False)[0]
+    dWxT, _ = _wgrad(x, B * H * W, Cin, dy, k * k * Cout, with_bias=False, vec=1, mode=MODE, conv=conv)
     return dWxT
