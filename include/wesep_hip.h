@@ -134,8 +134,8 @@ int ws_gemm_tn(const ws_gemm_tn_args* a, void* stream);
 
 /* Weight gradient of a convolution with at most 32 output channels, one pass over the activation (conv_wgrad.hip):
  *   slab[split][n * Kk + kk] = sum_{m in split} G[m * ldg + n] * P[m][kk],   bslab[split][n] = sum_m G[m * ldg + n]
- * P = the mode-0 implicit patch matrix `conv` of the image X (Kk = k*k*C <= 768, C % 4 == 0, k <= 5); a split is
- * tiles_per_split tiles of 32 consecutive rows.  Same result as ws_gemm_tn with conv.on, which sends every 128-column
+ * P = the mode-0 implicit patch matrix `conv` of the image X (Kk = k*k*C, C % 4 == 0, k <= 5; a workgroup owns up to 768
+ * columns, wider matrices run one pass per 768-column chunk); a split is tiles_per_split tiles of 32 consecutive rows.  Same result as ws_gemm_tn with conv.on, which sends every 128-column
  * slice of P to another workgroup and so streams X k*k times; this one owns all of P's columns per tile.
  * Replaces autograd's weight gradient of F.conv2d / F.conv_transpose2d (wesep/modules/dpccn/convs.py:28-110).     */
 typedef struct ws_conv_wgrad_args {

@@ -92,7 +92,7 @@ def test_dpccn_kernels_match_torch():
 
 
 @pytest.mark.parametrize("Cin,Cout,k,sh,sw", [(16, 16, 3, 1, 2), (32, 16, 3, 1, 1), (80, 16, 3, 1, 1), (4, 16, 3, 1, 1),
-                                              (16, 32, 3, 2, 2), (12, 8, 5, 1, 2)])
+                                              (16, 32, 3, 2, 2), (12, 8, 5, 1, 2), (96, 16, 3, 1, 2), (176, 8, 3, 1, 1)])
 def test_implicit_conv2d_and_transpose_match_torch(Cin, Cout, k, sh, sw):
     """Conv2d / ConvTranspose2d as GEMMs on the implicit patch matrix (ws_conv_view, both views, NT and TN kernels)
     against torch's convolutions: output, input gradient, weight and bias gradients, at a size with many row tiles,

@@ -38,8 +38,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(const ws_conv_wgrad_
   __shared__ CwMeta meta[2][32];
   __shared__ float bred[8][32];
   const ws_conv_view cv = p.conv;
-  const int Kk = cv.k * cv.k * cv.C, Nn = p.Nn;
-  const int nblk = (Kk + 31) / 32;            // 32-column blocks of the patch matrix; wave w owns blocks w, w + 8, w + 16
+  // patch columns [kbase, kbase + Kk) of the K_all = k*k*C: blockIdx.y walks chunks of CW_MAXK columns (the image is
+  // then streamed once per chunk -- 2..4 times for the wide DPCCN layers instead of once per 128 columns)
+  const int K_all = cv.k * cv.k * cv.C, kbase = blockIdx.y * CW_MAXK, Nn = p.Nn;
+  const int Kk = min(CW_MAXK, K_all - kbase);
+  const int nblk = (Kk + 31) / 32;            // 32-column blocks of the chunk; wave w owns blocks w, w + 8, w + 16
   const int rows = 32 + 32 * nblk;            // LDS rows per plane: dy tile first, then the patch columns (whole blocks)
   __bf16* const Ph = lds;
   __bf16* const Pl = lds + rows * CW_LD;
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(const ws_conv_wgrad_
   const long long t_begin = (long long)split * p.tiles_per_split;
   const long long ntiles_all = ((long long)p.M + 31) / 32;
   const long long t_end = min(ntiles_all, t_begin + p.tiles_per_split);
-  const int c4n = cv.C >> 2, nitems = 8 * cv.k * cv.k * c4n;
+  const int c4n = cv.C >> 2, nitems = 8 * (Kk >> 2);
 
   // this thread's items (the same for every tile): pixel quad, tap, channel quad -> element offset inside a window
   int it_q[CW_ITEMS], it_tap[CW_ITEMS], it_off[CW_ITEMS], it_kk[CW_ITEMS];
@@ -60,12 +63,12 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(const ws_conv_wgrad_
     it_on[i] = it < nitems;
     const int itc = it_on[i] ? it : 0;
     it_q[i] = itc & 7;
-    const int rest = itc >> 3;
+    const int rest = (itc >> 3) + (kbase >> 2);   // (tap, channel quad) flattened = patch column / 4
     const int c4 = rest % c4n, tap = rest / c4n;
     const int ky = tap / cv.k, kx = tap - ky * cv.k;
     it_tap[i] = tap;
     it_off[i] = (ky * cv.W + kx) * cv.C + 4 * c4;
-    it_kk[i] = tap * cv.C + 4 * c4;
+    it_kk[i] = tap * cv.C + 4 * c4 - kbase;       // column inside the chunk
   }
   // dy tile: thread (row = tid / 8, channel quad = tid % 8) of the first 256 threads
   const int g_row = (tid >> 3) & 31, g_c4 = tid & 7;
@@ -205,11 +208,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(const ws_conv_wgrad_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (n < Nn) out[(long long)n * Kk + kk] = acc[b][r];
+        if (n < Nn) out[(long long)n * K_all + kbase + kk] = acc[b][r];
       }
     }
   }
-  if (p.bslab) {  // db[n] = sum over pixels of dy[m][n]: rows (tid / 8) of each channel quad through LDS
+  if (p.bslab && blockIdx.y == 0) {  // db[n] = sum over pixels of dy[m][n]: rows (tid / 8) of each channel quad through LDS
     __syncthreads();
     if (tid < 256) {
 #pragma unroll
@@ -233,14 +236,14 @@ extern "C" int ws_conv_wgrad(const ws_conv_wgrad_args* a, void* stream) {
                  c.sh >= 1 && c.sw >= 1 && c.p >= 0,
              "ws_conv_wgrad: bad conv view (mode 0, C %% 4, k <= 5)");
   const int Kk = c.k * c.k * c.C;
-  WS_REQUIRE(Kk <= CW_MAXK, "ws_conv_wgrad: k*k*C = %d exceeds %d patch columns per workgroup", Kk, CW_MAXK);
   WS_REQUIRE(a->Nn > 0 && a->Nn <= 32 && a->Nn % 4 == 0 && a->ldg >= a->Nn && a->ldg % 4 == 0,
              "ws_conv_wgrad: Nn in 4..32 step 4, ldg %% 4 (Nn=%d ldg=%lld)", a->Nn, (long long)a->ldg);
   WS_REQUIRE(a->M > 0 && a->M % (c.Ho * c.Wo) == 0 && a->nsplit > 0 && a->tiles_per_split > 0 &&
                  (long long)a->nsplit * a->tiles_per_split * 32 >= a->M,
              "ws_conv_wgrad: splits do not cover M");
   WS_REQUIRE((long long)(c.H + 2 * c.k) * c.W * c.C < (1LL << 31), "ws_conv_wgrad: one image below 2^31 elements");
-  const size_t lds_bytes = (size_t)2 * (32 + 32 * ((Kk + 31) / 32)) * CW_LD * sizeof(__bf16);
+  const int kchunk = Kk < CW_MAXK ? Kk : CW_MAXK, nchunks = (Kk + CW_MAXK - 1) / CW_MAXK;
+  const size_t lds_bytes = (size_t)2 * (32 + 32 * ((kchunk + 31) / 32)) * CW_LD * sizeof(__bf16);
   static bool attr_set = false;
   if (!attr_set) {
     // (a failure here -- no device -- shows up as the launch error below, not as an argument error)
@@ -250,7 +253,7 @@ extern "C" int ws_conv_wgrad(const ws_conv_wgrad_args* a, void* stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   ws_prof_begin(WS_PROF_GEMM_TN, s);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(a->nsplit), dim3(512), lds_bytes, s, *a);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(a->nsplit, nchunks), dim3(512), lds_bytes, s, *a);
   ws_prof_end(WS_PROF_GEMM_TN, s);
   return ws_check_launch("ws_conv_wgrad");
 }

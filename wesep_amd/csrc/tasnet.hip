@@ -325,31 +325,52 @@ extern "C" int ws_dwconv_bwd(const float* dy, const float* x, const float* stats
 // gLN:  dbeta = sum_grp S0, dgamma = sum_grp S1, and the two group means of the norm backward are
 //       sum_c gamma[c] * S{0,1}[grp][c] / n  (ws_norm_ab below).
 // ---------------------------------------------------------------------------------------------
-__global__ void chan_sums_kernel(const float* __restrict__ gsrc, const float* __restrict__ x,
-                                 const float* __restrict__ stats, int st_div, int rows_per_group, int ngroups,
-                                 int nsplit, int C, float* __restrict__ slab) {
-  const int c = (blockIdx.z * blockDim.x + threadIdx.x) * 4;
-  if (c >= C) return;
+// One workgroup per (split, group): thread = (row lane, channel quad), so a 16-channel tensor (DPCCN's dense blocks:
+// 4 quads) still uses all 256 threads -- round 1 ran one thread per quad and 4 of 64 lanes; the row lanes are summed
+// in fixed order through LDS (deterministic).
+__global__ __launch_bounds__(256) void chan_sums_kernel(const float* __restrict__ gsrc, const float* __restrict__ x,
+                                                        const float* __restrict__ stats, int st_div, int rows_per_group,
+                                                        int ngroups, int nsplit, int C, float* __restrict__ slab) {
+  __shared__ f32x4 red[2][256];
+  const int c4n = C >> 2;                      // <= 256 per z-slice
+  const int cz = blockIdx.z * 256;             // first quad of this slice
+  const int nq = min(256, c4n - cz);           // quads in this slice
+  const int nrl = 256 / nq;                    // row lanes
+  const int tid = threadIdx.x, rl = tid / nq, q = tid - rl * nq;
+  const bool on = rl < nrl;
+  const int c = (cz + q) * 4;
   const int split = blockIdx.x, grp = blockIdx.y;
   const int per = (rows_per_group + nsplit - 1) / nsplit;
   const int lo = split * per, hi = min(rows_per_group, lo + per);
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-  for (int j = lo; j < hi; ++j) {
-    const long long row = (long long)grp * rows_per_group + j;
-    const f32x4 d = *reinterpret_cast<const f32x4*>(gsrc + row * C + c);
-    s0 += d;
-    if (x) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(x + row * C + c);
-      if (stats) {
-        const long long s = row / st_div;
-        v = (v - stats[2 * s]) * stats[2 * s + 1];
+  if (on) {
+    for (int j = lo + rl; j < hi; j += nrl) {
+      const long long row = (long long)grp * rows_per_group + j;
+      const f32x4 d = *reinterpret_cast<const f32x4*>(gsrc + row * C + c);
+      s0 += d;
+      if (x) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + row * C + c);
+        if (stats) {
+          const long long s = row / st_div;
+          v = (v - stats[2 * s]) * stats[2 * s + 1];
+        }
+        s1 += d * v;
       }
-      s1 += d * v;
     }
   }
-  float* o = slab + ((long long)split * ngroups + grp) * 2 * C;
-  *reinterpret_cast<f32x4*>(o + c) = s0;
-  *reinterpret_cast<f32x4*>(o + C + c) = s1;
+  red[0][tid] = s0;
+  red[1][tid] = s1;
+  __syncthreads();
+  if (tid < nq) {
+    f32x4 t0 = red[0][tid], t1 = red[1][tid];
+    for (int r = 1; r < nrl; ++r) {
+      t0 += red[0][r * nq + tid];
+      t1 += red[1][r * nq + tid];
+    }
+    float* o = slab + ((long long)split * ngroups + grp) * 2 * C;
+    *reinterpret_cast<f32x4*>(o + (cz + tid) * 4) = t0;
+    *reinterpret_cast<f32x4*>(o + C + (cz + tid) * 4) = t1;
+  }
 }
 
 extern "C" int ws_chan_sums(const float* g, const float* x, const float* stats, int st_div, int rows_per_group,
@@ -357,8 +378,7 @@ extern "C" int ws_chan_sums(const float* g, const float* x, const float* stats, 
   WS_REQUIRE(g && slab && rows_per_group > 0 && ngroups > 0 && nsplit > 0 && C > 0 && C % 4 == 0 &&
                  (!stats || (x && st_div > 0)),
              "ws_chan_sums: bad args");
-  const int threads = C / 4 >= 256 ? 256 : ((C / 4 + 63) / 64) * 64;
-  hipLaunchKernelGGL(chan_sums_kernel, dim3(nsplit, ngroups, (C / 4 + threads - 1) / threads), dim3(threads), 0,
+  hipLaunchKernelGGL(chan_sums_kernel, dim3(nsplit, ngroups, (C / 4 + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, g, x, stats, st_div, rows_per_group, ngroups, nsplit, C, slab);
   return ws_check_launch("ws_chan_sums");
 }

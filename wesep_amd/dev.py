@@ -164,8 +164,7 @@ CONV_WGRAD_MAXK = 768
 
 def conv_wgrad_ok(Nn: int, conv: ConvView) -> bool:
     """The one-pass convolution weight-gradient kernel (conv_wgrad.hip) takes this shape."""
-    return (conv.mode == 0 and 4 <= Nn <= 32 and Nn % 4 == 0 and conv.C % 4 == 0 and conv.k <= 5 and
-            conv.k * conv.k * conv.C <= CONV_WGRAD_MAXK)
+    return conv.mode == 0 and 4 <= Nn <= 32 and Nn % 4 == 0 and conv.C % 4 == 0 and conv.k <= 5
 
 
 def conv_wgrad(*, G, ldg: int, X, M: int, Nn: int, conv: ConvView, slab, nsplit: int, tiles_per_split: int, bslab=None):
