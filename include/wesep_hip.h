@@ -59,9 +59,10 @@ typedef struct ws_group_nt {
 /* Implicit patch matrix (ABI v8): with conv.on != 0 the A operand of ws_gemm_nt / ws_gemm_tn (split-bf16 kernels
  * only) is the im2col matrix of a channels-last image x [R][H][W][C] that is never materialised -- A points to x and
  *   A[m][(ky*k + kx)*C + c],  m = (r*Ho + ho)*Wo + wo,  is
- *   mode 0 (convolution view):  x[r][ho*sh + ky - p][wo*sw + kx - p][c]
- *   mode 1 (transposed view):   x[r][(ho + p - ky)/sh][(wo + p - kx)/sw][c] where both divisions are exact,
- * and 0 outside the image.  K = k*k*C, C % 4 == 0, a_div / a_s1 / a_s2 are ignored; mode 1 needs sh, sw in {1, 2}.
+ *   mode 0 (convolution view):  x[r][ho*sh + ky*dil - p][wo*sw + kx*dil - p][c]
+ *   mode 1 (transposed view):   x[r][(ho + p - ky*dil)/sh][(wo + p - kx*dil)/sw][c] where both divisions are exact,
+ * and 0 outside the image (dil = 0 means 1).  A dilated Conv1d over [R][T][C] is the view H = 1, W = T, k x k taps,
+ * p = dil * (k / 2): the rows ky != k/2 fall outside the one-row image (ECAPA-TDNN's Res2Net branches).  K = k*k*C, C % 4 == 0, a_div / a_s1 / a_s2 are ignored; mode 1 needs sh, sw in {1, 2}.
  * Conv2d = mode 0 on the input; its input gradient = mode 1 on the output gradient (K = k*k*Cout);
  * ConvTranspose2d = mode 1 on the input, its input gradient = mode 0 on the output gradient; the weight gradients
  * are ws_gemm_tn with the mode-0 view as A.  Replaces F.conv2d / F.conv_transpose2d of wesep/modules/dpccn/convs.py:28-110
@@ -71,7 +72,7 @@ typedef struct ws_conv_view {
   int H, W, C;       /* the image A points to */
   int Ho, Wo;        /* patch grid (rows of the implicit matrix per image: Ho*Wo) */
   int k, sh, sw, p;
-  int pad_;
+  int dil;           /* tap spacing; 0 = 1 */
 } ws_conv_view;
 
 /* C[m][n] = epi( sum_k pro(A[m][k]) * W[n][k] )        (torch Linear / Conv1d(k=1) layout)
@@ -509,6 +510,18 @@ int ws_col2im(const float* dpatches, int R, int H, int W, int C, int k, int s, i
 int ws_tstp_fwd(const float* x, int R, int F, int T, int C, float eps, float* stats, void* stream);
 int ws_tstp_bwd(const float* x, const float* stats, const float* dstats, int R, int F, int T, int C, float* dx,
                 void* stream);
+/* ASTP (attentive statistics pooling, wespeaker ECAPA-TDNN; wesep/models/bsrnn.py:217,352-356 via bsrnn.yaml:66-71) on
+ * channels-last x, logits [R][T][C]: alpha = softmax_T(logits), out [R][2C] = sum alpha x || sqrt(max(sum alpha x^2 -
+ * mean^2, floor)), aux [R][4][C] = (max logit, sum exp, mean, sum alpha x^2) saved for ws_astp_bwd.               */
+int ws_astp_fwd(const float* x, const float* logits, int R, int T, int C, float floor_, float* out, float* aux,
+                void* stream);
+int ws_astp_bwd(const float* x, const float* logits, const float* out, const float* aux, const float* dout, int R, int T,
+                int C, float floor_, float* dx, float* dlogits, void* stream);
+/* y = act(x + rb[row / rows_per_r]) on [rows][C] (act 1 tanh, 3 sigmoid; rb NULL or [rows / rows_per_r][C]) and
+ * dx = dy * act'(y) from the saved output: ECAPA's attention bottleneck (tanh) and SE gate (sigmoid).            */
+int ws_rowbias_act_fwd(const float* x, const float* rb, long long rows, int C, int rows_per_r, int act, float* y,
+                       void* stream);
+int ws_act_bwd(const float* y, const float* dy, long long n, int act, float* dx, void* stream);
 
 /* ---- in-model enrollment front-end (bsrnn.py:231-242,343-350) -------------------
  * out[r][j] = y[reflect(j - pad)], y = pre-emphasis of x (speaker.py:10-23), row stride ldo >= T + 2*pad:

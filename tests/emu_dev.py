@@ -35,7 +35,8 @@ def _at(ptr, n):
 
 def _conv_matrix(x, M, conv):
     """The implicit patch matrix of dev.ConvView, materialised: [M, k*k*C]."""
-    mode, H, W, C, Ho, Wo, k, sh, sw, p = conv
+    mode, H, W, C, Ho, Wo, k, sh, sw, p = conv[:10]
+    dil = conv[10] if len(conv) > 10 and conv[10] else 1
     R = M // (Ho * Wo)
     img = x.reshape(-1)[:R * H * W * C].reshape(R, H, W, C)
     out = torch.zeros(R, Ho, Wo, k * k, C)
@@ -43,10 +44,10 @@ def _conv_matrix(x, M, conv):
     def src(o, n_out, tap, s, n_in):
         i = torch.arange(n_out)
         if mode == 0:
-            v = i * s + tap - p
+            v = i * s + tap * dil - p
             ok = (v >= 0) & (v < n_in)
         else:
-            q = i + p - tap
+            q = i + p - tap * dil
             v = torch.div(q, s, rounding_mode="floor")
             ok = (q >= 0) & (q % s == 0) & (v < n_in)
         return v.clamp(0, n_in - 1), ok
@@ -547,7 +548,45 @@ def conv_wgrad(*, G, ldg, X, M, Nn, conv, slab, nsplit, tiles_per_split, bslab=N
             bslab.reshape(-1)[sp * Nn:(sp + 1) * Nn] = g[lo:hi].sum(0) if hi > lo else 0.0
 
 
-EMULATED = [conv_wgrad, gemm_nt, gemm_tn, reduce_slabs, transpose, affine_fwd, chan_sums, im2col_hw, col2im_hw, elu_fwd, elu_bwd,
+def astp_fwd(x, logits, R, T, Cc, out, aux):
+    xx, ll = x.reshape(R, T, Cc), logits.reshape(R, T, Cc)
+    m = ll.max(1).values
+    e = torch.exp(ll - m[:, None])
+    z = e.sum(1)
+    mean, ex2 = (e * xx).sum(1) / z, (e * xx * xx).sum(1) / z
+    out.reshape(R, 2 * Cc)[:, :Cc] = mean
+    out.reshape(R, 2 * Cc)[:, Cc:] = torch.sqrt((ex2 - mean * mean).clamp(min=1e-7))
+    a = aux.reshape(R, 4, Cc)
+    a[:, 0], a[:, 1], a[:, 2], a[:, 3] = m, z, mean, ex2
+
+
+def astp_bwd(x, logits, out, aux, dout, R, T, Cc, dx, dlogits):
+    xx, ll = x.reshape(R, T, Cc), logits.reshape(R, T, Cc)
+    a = aux.reshape(R, 4, Cc)
+    m, z, mean, ex2 = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+    sd = out.reshape(R, 2 * Cc)[:, Cc:]
+    gmean, gstd = dout.reshape(R, 2 * Cc)[:, :Cc], dout.reshape(R, 2 * Cc)[:, Cc:]
+    gv = torch.where(ex2 - mean * mean > 1e-7, gstd / (2 * sd), torch.zeros_like(sd))
+    gm = gmean - 2 * mean * gv
+    al = torch.exp(ll - m[:, None]) / z[:, None]
+    da = gm[:, None] * xx + gv[:, None] * xx * xx
+    dbar = gm * mean + gv * ex2
+    dx.reshape(R, T, Cc)[:] = al * (gm[:, None] + 2 * gv[:, None] * xx)
+    dlogits.reshape(R, T, Cc)[:] = al * (da - dbar[:, None])
+
+
+def rowbias_act_fwd(x, rb, rows, Cc, rows_per_r, act, y):
+    v = x.reshape(rows, Cc)
+    if rb is not None:
+        v = v + rb.reshape(-1, Cc)[torch.arange(rows) // rows_per_r]
+    y.reshape(rows, Cc)[:] = torch.tanh(v) if act == 1 else torch.sigmoid(v)
+
+
+def act_bwd(y, dy, act, dx):
+    dx.reshape(-1)[:] = (dy * ((1 - y * y) if act == 1 else y * (1 - y))).reshape(-1)
+
+
+EMULATED = [astp_fwd, astp_bwd, rowbias_act_fwd, act_bwd, conv_wgrad, gemm_nt, gemm_tn, reduce_slabs, transpose, affine_fwd, chan_sums, im2col_hw, col2im_hw, elu_fwd, elu_bwd,
             inorm_fwd, inorm_bwd, dwconv_fwd, dwconv_bwd, avgpool_fwd, avgpool_bwd, bilinear_fwd, bilinear_bwd,
             scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum, lstm_pack, lstm_fwd, lstm_bwd,
             group_stats, flat_stats, gn_bwd_reduce, norm_ab, norm_bwd_apply_cl, prelu_fwd, prelu_bwd, softmax_rows_fwd,
@@ -563,6 +602,8 @@ def install(monkeypatch):
     import wesep_amd.functional_tasnet as ft
     import wesep_amd.functional_resnet as fr
     import wesep_amd.functional_tfgridnet as fg
+    import wesep_amd.functional_ecapa as fe
+    monkeypatch.setattr(fe, "_need_cuda", lambda t, who: None)
     for fn in EMULATED:
         monkeypatch.setattr(dev, fn.__name__, fn)
     for mod in (f0, fd, ft, fg, fr):

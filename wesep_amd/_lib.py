@@ -28,7 +28,7 @@ _f = C.c_float
 
 class ConvView(C.Structure):
     """ws_conv_view: the A operand of ws_gemm_nt / ws_gemm_tn as an implicit im2col matrix (include/wesep_hip.h)."""
-    _fields_ = [(n, _i) for n in ("on", "mode", "H", "W", "C", "Ho", "Wo", "k", "sh", "sw", "p", "pad_")]
+    _fields_ = [(n, _i) for n in ("on", "mode", "H", "W", "C", "Ho", "Wo", "k", "sh", "sw", "p", "dil")]
 
 
 class GemmNTArgs(C.Structure):
@@ -171,6 +171,10 @@ _SIGS = {
     "ws_im2col": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _ll, _p, _p]),
     "ws_col2im": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "ws_conv_wgrad": (_i, [C.POINTER(ConvWgradArgs), _p]),
+    "ws_astp_fwd": (_i, [_p, _p, _i, _i, _i, C.c_float, _p, _p, _p]),
+    "ws_astp_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, C.c_float, _p, _p, _p]),
+    "ws_rowbias_act_fwd": (_i, [_p, _p, _ll, _i, _i, _i, _p, _p]),
+    "ws_act_bwd": (_i, [_p, _p, _ll, _i, _p, _p]),
     "ws_tstp_fwd": (_i, [_p, _i, _i, _i, _i, C.c_float, _p, _p]),
     "ws_tstp_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "ws_im2col_hw": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _p, _p]),

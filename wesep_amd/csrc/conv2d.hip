@@ -201,6 +201,113 @@ extern "C" int ws_tstp_bwd(const float* x, const float* stats, const float* dsta
 }
 
 // ---------------------------------------------------------------------------------------------
+// ASTP (attentive statistics pooling of the wespeaker ECAPA-TDNN; call sites wesep/models/bsrnn.py:217,352-356, recipe
+// examples/librimix/tse/v2/confs/bsrnn.yaml:66-71) on channels-last x, logits [R][T][C]:
+//   alpha = softmax over T of logits;  mean = sum_t alpha x;  std = sqrt(max(sum_t alpha x^2 - mean^2, 1e-7))
+//   out [R][2C] = mean || std;  aux [R][4][C] = (max logit, sum exp, mean, sum alpha x^2) for the backward.
+// One thread per (r, c): lanes = consecutive channels (coalesced), three passes over T.
+// ---------------------------------------------------------------------------------------------
+__global__ void astp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ lg, int R, int T, int C,
+                                float floor_, float* __restrict__ out, float* __restrict__ aux) {
+  const long long total = (long long)R * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C), r = (int)(i / C);
+    const float* xb = x + (long long)r * T * C + c;
+    const float* lb = lg + (long long)r * T * C + c;
+    float m = -INFINITY;
+    for (int t = 0; t < T; ++t) m = fmaxf(m, lb[(long long)t * C]);
+    float z = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float e = expf(lb[(long long)t * C] - m), v = xb[(long long)t * C];
+      z += e;
+      s1 += e * v;
+      s2 += e * v * v;
+    }
+    const float mean = s1 / z, ex2 = s2 / z;
+    out[(long long)r * 2 * C + c] = mean;
+    out[(long long)r * 2 * C + C + c] = sqrtf(fmaxf(ex2 - mean * mean, floor_));
+    float* a = aux + (long long)r * 4 * C + c;
+    a[0] = m;
+    a[C] = z;
+    a[2 * C] = mean;
+    a[3 * C] = ex2;
+  }
+}
+
+// dx_t = alpha_t (gm + 2 gv x_t),  dlogit_t = alpha_t (da_t - sum_s alpha_s da_s),  da_t = gm x_t + gv x_t^2,
+// gv = dstd / (2 std) where the variance is above the floor (0 below), gm = dmean - 2 mean gv
+__global__ void astp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ lg, const float* __restrict__ out,
+                                const float* __restrict__ aux, const float* __restrict__ dout, int R, int T, int C,
+                                float floor_, float* __restrict__ dx, float* __restrict__ dlg) {
+  const long long total = (long long)R * T * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int r = (int)(i / ((long long)T * C));
+    const float* a = aux + (long long)r * 4 * C + c;
+    const float m = a[0], z = a[C], mean = a[2 * C], ex2 = a[3 * C];
+    const float sd = out[(long long)r * 2 * C + C + c];
+    const float gmean = dout[(long long)r * 2 * C + c], gstd = dout[(long long)r * 2 * C + C + c];
+    const float gv = (ex2 - mean * mean > floor_) ? gstd / (2.f * sd) : 0.f;
+    const float gm = gmean - 2.f * mean * gv;
+    const float v = x[i], al = expf(lg[i] - m) / z;
+    const float da = gm * v + gv * v * v, dbar = gm * mean + gv * ex2;
+    dx[i] = al * (gm + 2.f * gv * v);
+    dlg[i] = al * (da - dbar);
+  }
+}
+
+extern "C" int ws_astp_fwd(const float* x, const float* logits, int R, int T, int C, float floor_, float* out, float* aux,
+                           void* stream) {
+  WS_REQUIRE(x && logits && out && aux && R > 0 && T > 0 && C > 0, "ws_astp_fwd: bad args");
+  hipLaunchKernelGGL(astp_fwd_kernel, dim3(cv_blocks((long long)R * C)), dim3(256), 0, (hipStream_t)stream, x, logits, R,
+                     T, C, floor_, out, aux);
+  return ws_check_launch("ws_astp_fwd");
+}
+
+extern "C" int ws_astp_bwd(const float* x, const float* logits, const float* out, const float* aux, const float* dout,
+                           int R, int T, int C, float floor_, float* dx, float* dlogits, void* stream) {
+  WS_REQUIRE(x && logits && out && aux && dout && dx && dlogits && R > 0 && T > 0 && C > 0, "ws_astp_bwd: bad args");
+  hipLaunchKernelGGL(astp_bwd_kernel, dim3(cv_blocks((long long)R * T * C)), dim3(256), 0, (hipStream_t)stream, x, logits,
+                     out, aux, dout, R, T, C, floor_, dx, dlogits);
+  return ws_check_launch("ws_astp_bwd");
+}
+
+// y = act(x + rb[row / rows_per_r])  (act 1 tanh, 3 sigmoid) on [rows][C], and its backward from the saved output:
+// dx = dy * (1 - y^2) / dy * y (1 - y); the small bottleneck activations of ECAPA's attention and SE blocks
+__global__ void rowbias_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ rb, long long rows, int C,
+                                       int rows_per_r, int act, float* __restrict__ y) {
+  const long long total = rows * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / C;
+    const int c = (int)(i - row * C);
+    const float v = x[i] + (rb ? rb[(row / rows_per_r) * C + c] : 0.f);
+    y[i] = act == 1 ? tanhf(v) : 1.f / (1.f + expf(-v));
+  }
+}
+__global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, long long n, int act,
+                               float* __restrict__ dx) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float t = y[i];
+    dx[i] = dy[i] * (act == 1 ? 1.f - t * t : t * (1.f - t));
+  }
+}
+extern "C" int ws_rowbias_act_fwd(const float* x, const float* rb, long long rows, int C, int rows_per_r, int act, float* y,
+                                  void* stream) {
+  WS_REQUIRE(x && y && rows > 0 && C > 0 && rows_per_r > 0 && (act == 1 || act == 3), "ws_rowbias_act_fwd: bad args");
+  hipLaunchKernelGGL(rowbias_act_fwd_kernel, dim3(cv_blocks(rows * C)), dim3(256), 0, (hipStream_t)stream, x, rb, rows, C,
+                     rows_per_r, act, y);
+  return ws_check_launch("ws_rowbias_act_fwd");
+}
+extern "C" int ws_act_bwd(const float* y, const float* dy, long long n, int act, float* dx, void* stream) {
+  WS_REQUIRE(y && dy && dx && n > 0 && (act == 1 || act == 3), "ws_act_bwd: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(cv_blocks(n)), dim3(256), 0, (hipStream_t)stream, y, dy, n, act, dx);
+  return ws_check_launch("ws_act_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
 // In-model enrollment front-end (wesep/models/bsrnn.py:231-242,343-350):
 // PreEmphasis (wesep/modules/common/speaker.py:10-23) + the framing half of
 // torchaudio.transforms.MelSpectrogram(n_fft = win_length = 512, hop 128, hamming, center, reflect, power 2).

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(const ws_conv_wgrad_
     it_q[i] = itc & 7;
     const int rest = (itc >> 3) + (kbase >> 2);   // (tap, channel quad) flattened = patch column / 4
     const int c4 = rest % c4n, tap = rest / c4n;
-    const int ky = tap / cv.k, kx = tap - ky * cv.k;
+    const int dl = cv.dil > 0 ? cv.dil : 1;
+    const int ky = (tap / cv.k) * dl, kx = (tap % cv.k) * dl;
     it_tap[i] = tap;
     it_off[i] = (ky * cv.W + kx) * cv.C + 4 * c4;
     it_kk[i] = tap * cv.C + 4 * c4 - kbase;       // column inside the chunk
@@ -85,13 +86,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(const ws_conv_wgrad_
         const int hw = cv.Ho * cv.Wo;
         const int rr = (int)(m / hw), q = (int)(m - (long long)rr * hw);
         const int ho = q / cv.Wo, wo = q - ho * cv.Wo;
-        const int bh = ho * cv.sh - cv.p, bw = wo * cv.sw - cv.p;
+        const int bh = ho * cv.sh - cv.p, bw = wo * cv.sw - cv.p, dl = cv.dil > 0 ? cv.dil : 1;
         r.off = (long long)rr * cv.H * cv.W * cv.C + (long long)(bh * cv.W + bw) * cv.C;
         r.goff = m * p.ldg;
         int mask = 0;
         for (int ky = 0; ky < cv.k; ++ky)
           for (int kx = 0; kx < cv.k; ++kx)
-            if ((unsigned)(bh + ky) < (unsigned)cv.H && (unsigned)(bw + kx) < (unsigned)cv.W) mask |= 1 << (ky * cv.k + kx);
+            if ((unsigned)(bh + ky * dl) < (unsigned)cv.H && (unsigned)(bw + kx * dl) < (unsigned)cv.W)
+              mask |= 1 << (ky * cv.k + kx);
         r.tapmask = mask;
       }
       meta[slot][tid] = r;

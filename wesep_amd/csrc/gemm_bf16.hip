@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
   bool vt[4] = {true, true, true, true};  // CONV: the tap of this tile's float4 lies inside the image for row i
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const int csh = cv.sh - 1, csw = cv.sw - 1;  // mode 1: strides are 1 or 2 -> shift / mask instead of a division
+  const int cdil = cv.dil > 0 ? cv.dil : 1;
   auto load_tile = [&](int kt) {
     const int k = kt * BT_BK + lk;
     vk = k < K;                       // K % 4 == 0 on this path: a float4 is in or out as a whole
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
       const int tap = kc / cv.C;
       cc = kc - tap * cv.C;
       ky = tap / cv.k;
-      kx = tap - ky * cv.k;
+      kx = (tap - ky * cv.k) * cdil;
+      ky *= cdil;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -403,13 +405,14 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
         const int hw = cv.Ho * cv.Wo;
         const int rr = m / hw, q = m - rr * hw;
         const int ho = q / cv.Wo, wo = q - ho * cv.Wo;
-        const int bh = ho * cv.sh - cv.p, bw = wo * cv.sw - cv.p;
+        const int bh = ho * cv.sh - cv.p, bw = wo * cv.sw - cv.p, dl = cv.dil > 0 ? cv.dil : 1;
         r.goff = ws_row_off(m, p.g_div, p.g_s1, p.g_s2);
         r.aoff = (long long)rr * cv.H * cv.W * cv.C + (long long)(bh * cv.W + bw) * cv.C;
         int mask = 0;
         for (int ky = 0; ky < cv.k; ++ky)
           for (int kx = 0; kx < cv.k; ++kx)
-            if ((unsigned)(bh + ky) < (unsigned)cv.H && (unsigned)(bw + kx) < (unsigned)cv.W) mask |= 1 << (ky * cv.k + kx);
+            if ((unsigned)(bh + ky * dl) < (unsigned)cv.H && (unsigned)(bw + kx * dl) < (unsigned)cv.W)
+              mask |= 1 << (ky * cv.k + kx);
         r.tapmask = mask;
       } else if (r.gvalid) {
         r.goff = ws_row_off(m, p.g_div, p.g_s1, p.g_s2);
@@ -440,7 +443,8 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
   if (CONV) {
     const int kc = acol_ok ? k_blk + col : 0;
     ctap = kc / p.conv.C;
-    const int cky = ctap / p.conv.k, ckx = ctap - cky * p.conv.k;
+    const int dl = p.conv.dil > 0 ? p.conv.dil : 1;
+    const int cky = (ctap / p.conv.k) * dl, ckx = (ctap % p.conv.k) * dl;
     Ag = (gfp)A + ((cky * p.conv.W + ckx) * p.conv.C + (kc - ctap * p.conv.C));
   }
   float rg[16], ra[16];

@@ -90,13 +90,14 @@ class ConvView(NamedTuple):
     sh: int
     sw: int
     p: int
+    dil: int = 1
 
 
 def _set_conv(a, conv: Optional[ConvView]):
     if conv is not None:
         a.conv.on = 1
         (a.conv.mode, a.conv.H, a.conv.W, a.conv.C, a.conv.Ho, a.conv.Wo, a.conv.k, a.conv.sh, a.conv.sw,
-         a.conv.p) = conv
+         a.conv.p, a.conv.dil) = conv
 
 
 def gemm_nt(*, A, a_rows: Rows, M: int, C_out, c_rows: Rows, N=0, K=0, W=None, ldw=0, bias=None,
@@ -955,6 +956,34 @@ def tstp_bwd(x, stats, dstats, R: int, F: int, T: int, Cc: int, dx):
     for n, t in (("x", x), ("stats", stats), ("dstats", dstats), ("dx", dx)):
         _chk(t, n)
     _call("ws_tstp_bwd", _p(x), _p(stats), _p(dstats), R, F, T, Cc, _p(dx))
+
+
+ASTP_FLOOR = 1e-7
+
+
+def astp_fwd(x, logits, R: int, T: int, Cc: int, out, aux):
+    for n, t in (("x", x), ("logits", logits), ("out", out), ("aux", aux)):
+        _chk(t, n)
+    _call("ws_astp_fwd", _p(x), _p(logits), R, T, Cc, ASTP_FLOOR, _p(out), _p(aux))
+
+
+def astp_bwd(x, logits, out, aux, dout, R: int, T: int, Cc: int, dx, dlogits):
+    for n, t in (("x", x), ("logits", logits), ("out", out), ("aux", aux), ("dout", dout), ("dx", dx),
+                 ("dlogits", dlogits)):
+        _chk(t, n)
+    _call("ws_astp_bwd", _p(x), _p(logits), _p(out), _p(aux), _p(dout), R, T, Cc, ASTP_FLOOR, _p(dx), _p(dlogits))
+
+
+def rowbias_act_fwd(x, rb, rows: int, Cc: int, rows_per_r: int, act: int, y):
+    for n, t in (("x", x), ("rb", rb), ("y", y)):
+        _chk(t, n)
+    _call("ws_rowbias_act_fwd", _p(x), _p(rb), rows, Cc, rows_per_r, act, _p(y))
+
+
+def act_bwd(y, dy, act: int, dx):
+    for n, t in (("y", y), ("dy", dy), ("dx", dx)):
+        _chk(t, n)
+    _call("ws_act_bwd", _p(y), _p(dy), y.numel(), act, _p(dx))
 
 
 # ---- in-model enrollment front-end (conv2d.hip) ---------------------------------------------------------

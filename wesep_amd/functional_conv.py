@@ -26,11 +26,15 @@ def implicit_ok(C):
     return C % 4 == 0
 
 
-def conv2d_fwd(x, B, H, W, Cin, W2, Cout, k, sh, sw, p, bias=None):
-    """x [B*H*W, Cin], W2 [Cout, k*k*Cin] -> [B*Ho*Wo, Cout]."""
-    Ho, Wo = dev.conv_out(H, k, sh, p), dev.conv_out(W, k, sw, p)
-    return _gemm(x, B * Ho * Wo, k * k * Cin, W2, Cout, bias=bias, vec=3, mode=MODE,
-                 conv=ConvView(0, H, W, Cin, Ho, Wo, k, sh, sw, p))
+def _out(n, k, s, p, dil):
+    return (n + 2 * p - dil * (k - 1) - 1) // s + 1
+
+
+def conv2d_fwd(x, B, H, W, Cin, W2, Cout, k, sh, sw, p, bias=None, dil=1, act=0):
+    """x [B*H*W, Cin], W2 [Cout, k*k*Cin] -> [B*Ho*Wo, Cout] (act: the GEMM epilogue's activation, 2 = ReLU)."""
+    Ho, Wo = _out(H, k, sh, p, dil), _out(W, k, sw, p, dil)
+    return _gemm(x, B * Ho * Wo, k * k * Cin, W2, Cout, bias=bias, act=act, vec=3, mode=MODE,
+                 conv=ConvView(0, H, W, Cin, Ho, Wo, k, sh, sw, p, dil))
 
 
 def _one_pass_wgrad(G, M, Nn, X, conv, with_bias):
@@ -49,20 +53,20 @@ def _one_pass_wgrad(G, M, Nn, X, conv, with_bias):
     return dW, db
 
 
-def conv2d_wgrad(dy, x, B, H, W, Cin, Cout, k, sh, sw, p, with_bias=True):
+def conv2d_wgrad(dy, x, B, H, W, Cin, Cout, k, sh, sw, p, with_bias=True, dil=1):
     """dW2 [Cout, k*k*Cin] = dy^T view0(x) (+ db)."""
-    Ho, Wo = dev.conv_out(H, k, sh, p), dev.conv_out(W, k, sw, p)
-    conv = ConvView(0, H, W, Cin, Ho, Wo, k, sh, sw, p)
+    Ho, Wo = _out(H, k, sh, p, dil), _out(W, k, sw, p, dil)
+    conv = ConvView(0, H, W, Cin, Ho, Wo, k, sh, sw, p, dil)
     if dev.conv_wgrad_ok(Cout, conv):
         return _one_pass_wgrad(dy, B * Ho * Wo, Cout, x, conv, with_bias)
     return _wgrad(dy, B * Ho * Wo, Cout, x, k * k * Cin, with_bias=with_bias, vec=1, mode=MODE, conv=conv)
 
 
-def conv2d_dx(dy, B, H, W, Cin, Wd, Cout, k, sh, sw, p):
+def conv2d_dx(dy, B, H, W, Cin, Wd, Cout, k, sh, sw, p, dil=1):
     """dy [B*Ho*Wo, Cout], Wd [Cin, k*k*Cout] -> dx [B*H*W, Cin]: the transposed view of dy, one row per INPUT pixel."""
-    Ho, Wo = dev.conv_out(H, k, sh, p), dev.conv_out(W, k, sw, p)
+    Ho, Wo = _out(H, k, sh, p, dil), _out(W, k, sw, p, dil)
     return _gemm(dy, B * H * W, k * k * Cout, Wd, Cin, vec=3, mode=MODE,
-                 conv=ConvView(1, Ho, Wo, Cout, H, W, k, sh, sw, p))
+                 conv=ConvView(1, Ho, Wo, Cout, H, W, k, sh, sw, p, dil))
 
 
 def conv2d_weights(w):

@@ -116,5 +116,9 @@ def get_speaker_model(model_name: str):
     """`wespeaker.models.speaker_model.get_speaker_model` for the encoders built here."""
     if model_name in ("ResNet18", "ResNet34"):
         return {"ResNet18": ResNet18, "ResNet34": ResNet34}[model_name]
-    raise NotImplementedError(f"speaker model {model_name!r}: only the wespeaker BasicBlock ResNets (ResNet18, "
-                              "ResNet34) are built (SURVEY.md section 8 row a12)")
+    from .ecapa_tdnn import ECAPA_MODELS
+    if model_name in ECAPA_MODELS:
+        return ECAPA_MODELS[model_name]
+    raise NotImplementedError(f"speaker model {model_name!r}: the wespeaker BasicBlock ResNets (ResNet18, ResNet34) and "
+                              "ECAPA-TDNN (c512 / c1024, with or without global context) are built "
+                              "(SURVEY.md section 8 row a12); CAM++ and the Bottleneck ResNets are not")
