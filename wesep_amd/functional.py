@@ -349,6 +349,13 @@ class ResRNNBlkFn(torch.autograd.Function):
         pw = W("pw")
         out = torch.empty_like(z)
         dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=W("proj"), C_out=out, ldc=N, bias=proj_b, R=z)
+        if torch.is_grad_enabled():
+            # the backward's packs (transposed projections, BPTT weight stream) are built here, where the GPU has a
+            # single stream to serve: built lazily in the backward, these 10 us launches queue behind the side stream's
+            # chip-filling weight-gradient GEMMs for up to a millisecond each (round 2 profile: 4 ms per step)
+            W("projT"), W("wihT")
+            if not (cluster and os.environ.get("WESEP_LSTM_CLUSTER_BWD", "0") == "1"):
+                W("hh")
         ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn, wcat, norm_w, norm_b, pw, whf, whr)
         ctx.view, ctx.box, ctx.lmode, ctx.cluster = view, box, lmode, cluster
         ctx.packs = W
