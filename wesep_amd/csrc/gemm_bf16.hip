@@ -439,13 +439,14 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
   // bf16 split happen in store_tile one iteration later, with the loads in flight under the MFMAs.
   const gfp Gg = (gfp)G + n_blk + (gcol_ok ? col : 0);
   gfp Ag = (gfp)A + k_blk + (acol_ok ? col : 0);
-  int ctap = 0;  // CONV: this thread's tap; Ag then points at (tap, channel) relative to a pixel's tap (0, 0)
+  int ctap = 0, ctapo = 0;  // CONV: this thread's tap and its element offset from a pixel's tap (0, 0); Ag = its channel
   if (CONV) {
     const int kc = acol_ok ? k_blk + col : 0;
     ctap = kc / p.conv.C;
     const int dl = p.conv.dil > 0 ? p.conv.dil : 1;
     const int cky = (ctap / p.conv.k) * dl, ckx = (ctap % p.conv.k) * dl;
-    Ag = (gfp)A + ((cky * p.conv.W + ckx) * p.conv.C + (kc - ctap * p.conv.C));
+    ctapo = (cky * p.conv.W + ckx) * p.conv.C;
+    Ag = (gfp)A + (kc - ctap * p.conv.C);
   }
   float rg[16], ra[16];
   unsigned tapok = 0xffffu;  // CONV: bit j = the tap lies inside the image for row j of the tile in registers
@@ -458,7 +459,9 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
       if (CONV) {
         const bool ok = (r.tapmask >> ctap) & 1;   // (0 for rows past the split's end)
         okb |= ok ? 1u << j : 0u;
-        ra[j] = Ag[ok ? r.aoff : 0];               // unconditional load (offset 0 = this thread's tap of pixel (0, 0))
+        // unconditional load; a masked tap reads element 0 of the thread's channel -- NOT "its tap of pixel (0, 0)":
+        // with a dilated tap of a one-row image (ECAPA) that address lies k/2 * dil rows behind a small tensor's end
+        ra[j] = Ag[ok ? r.aoff + ctapo : 0];
       } else {
         ra[j] = Ag[r.aoff];
       }
