@@ -48,6 +48,17 @@ def _check(rc, what):
         raise WesepHipError(f"{what} failed (rc={rc}): {lib().ws_engine_last_error().decode('utf-8', 'replace')}")
 
 
+def _quiesce_torch():
+    """The engine launches on its own HIP stream.  Kernels of this library running concurrently on ANOTHER stream
+    disturb FFT-type kernels (profiles/r02_kernel_race.md: engines sharing a GPU therefore take turns inside
+    libwesep_engine.so); a Python process that also drives torch work on the same GPU gets the same guarantee here:
+    whatever torch has in flight finishes before the engine starts."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+
+
 class Engine:
     """One loaded model on one GPU.  `dry_run=True` needs no GPU: validates the container and every launch's
     argument contract, computes nothing."""
@@ -81,6 +92,7 @@ class Engine:
             raise ValueError("one enrollment per mixture row")
         est = np.zeros((R, T), dtype=np.float32)
         length = 0 if kind == ENROLL_EMBEDDING else enroll.shape[1]
+        _quiesce_torch()
         _check(lib().ws_engine_separate(self._h, mix.ctypes.data, R, T, enroll.ctypes.data, kind, length,
                                         est.ctypes.data), "ws_engine_separate")
         return est
@@ -90,6 +102,7 @@ class Engine:
         mix, spk1, spk2 = (np.ascontiguousarray(x, dtype=np.int16) for x in (mix, spk1, spk2))
         n_enroll = min(spk1.shape[0], spk2.shape[0])
         out = np.zeros((2, mix.shape[0]), dtype=np.float32)
+        _quiesce_torch()
         _check(lib().ws_engine_forward_pcm16(self._h, mix.ctypes.data, mix.shape[0], spk1.ctypes.data,
                                              spk2.ctypes.data, n_enroll, out.ctypes.data), "ws_engine_forward_pcm16")
         return out
