@@ -23,16 +23,18 @@ import torch
 import torch.nn.functional as F
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
-NUM_BLOCKS = {"ResNet18": (2, 2, 2, 2), "ResNet34": (3, 4, 6, 3)}
+NUM_BLOCKS = {"ResNet18": (2, 2, 2, 2), "ResNet34": (3, 4, 6, 3), "ResNet50": (3, 4, 6, 3), "ResNet101": (3, 4, 23, 3),
+              "ResNet152": (3, 8, 36, 3)}
+BOTTLENECK = ("ResNet50", "ResNet101", "ResNet152")   # Bottleneck blocks (1x1 - 3x3(stride) - 1x1, expansion 4)
 
 
-def _blocks(num_blocks, m):
-    """(prefix, in_planes, planes, stride) of every BasicBlock in order."""
+def _blocks(num_blocks, m, expansion=1):
+    """(prefix, in_planes, planes, stride) of every block in order; a block outputs expansion * planes channels."""
     out, inp = [], m
     for li, (n, planes, stride) in enumerate(zip(num_blocks, (m, 2 * m, 4 * m, 8 * m), (1, 2, 2, 2)), start=1):
         for bi in range(n):
             out.append((f"layer{li}.{bi}.", inp, planes, stride if bi == 0 else 1))
-            inp = planes
+            inp = planes * expansion
     return out
 
 
@@ -44,22 +46,36 @@ def _bn_shapes(s, name, c):
     s[name + ".num_batches_tracked"] = ()
 
 
-def param_shapes(num_blocks=(3, 4, 6, 3), m=32, feat_dim=80, embed_dim=256, prefix="") -> Dict[str, tuple]:
+def param_shapes(num_blocks=(3, 4, 6, 3), m=32, feat_dim=80, embed_dim=256, prefix="", bottleneck=False,
+                 two_emb_layer=False) -> Dict[str, tuple]:
     s: Dict[str, tuple] = {}
+    ex = 4 if bottleneck else 1
     s[prefix + "conv1.weight"] = (m, 1, 3, 3)
     _bn_shapes(s, prefix + "bn1", m)
-    for q, inp, planes, stride in _blocks(num_blocks, m):
+    for q, inp, planes, stride in _blocks(num_blocks, m, ex):
         q = prefix + q
-        s[q + "conv1.weight"] = (planes, inp, 3, 3)
-        _bn_shapes(s, q + "bn1", planes)
-        s[q + "conv2.weight"] = (planes, planes, 3, 3)
-        _bn_shapes(s, q + "bn2", planes)
-        if stride != 1 or inp != planes:
-            s[q + "shortcut.0.weight"] = (planes, inp, 1, 1)
-            _bn_shapes(s, q + "shortcut.1", planes)
-    stats_dim = (feat_dim // 8) * m * 8
+        if bottleneck:
+            s[q + "conv1.weight"] = (planes, inp, 1, 1)
+            _bn_shapes(s, q + "bn1", planes)
+            s[q + "conv2.weight"] = (planes, planes, 3, 3)
+            _bn_shapes(s, q + "bn2", planes)
+            s[q + "conv3.weight"] = (ex * planes, planes, 1, 1)
+            _bn_shapes(s, q + "bn3", ex * planes)
+        else:
+            s[q + "conv1.weight"] = (planes, inp, 3, 3)
+            _bn_shapes(s, q + "bn1", planes)
+            s[q + "conv2.weight"] = (planes, planes, 3, 3)
+            _bn_shapes(s, q + "bn2", planes)
+        if stride != 1 or inp != ex * planes:
+            s[q + "shortcut.0.weight"] = (ex * planes, inp, 1, 1)
+            _bn_shapes(s, q + "shortcut.1", ex * planes)
+    stats_dim = (feat_dim // 8) * m * 8 * ex
     s[prefix + "seg_1.weight"] = (embed_dim, 2 * stats_dim)
     s[prefix + "seg_1.bias"] = (embed_dim,)
+    if two_emb_layer:      # seg_bn_1 = BatchNorm1d(embed_dim, affine=False): buffers only
+        s[prefix + "seg_bn_1.running_mean"], s[prefix + "seg_bn_1.running_var"] = (embed_dim,), (embed_dim,)
+        s[prefix + "seg_bn_1.num_batches_tracked"] = ()
+        s[prefix + "seg_2.weight"], s[prefix + "seg_2.bias"] = (embed_dim, embed_dim), (embed_dim,)
     return s
 
 
@@ -77,7 +93,7 @@ def synth_params(seed: int, **kw) -> Dict[str, torch.Tensor]:
             v = torch.ones(shp)
         elif k.endswith("num_batches_tracked"):
             v = torch.zeros(shp, dtype=torch.long)
-        elif ".bn" in k or "bn1." in k or "shortcut.1" in k:
+        elif ".bn" in k or "bn1." in k or "shortcut.1" in k or "seg_bn_1" in k:
             v = (1.0 + 0.1 * torch.randn(shp, generator=g)) if k.endswith("weight") else 0.1 * torch.randn(shp, generator=g)
         elif k.endswith("bias"):
             v = 0.05 * torch.randn(shp, generator=g)
@@ -90,8 +106,9 @@ def synth_params(seed: int, **kw) -> Dict[str, torch.Tensor]:
     return out
 
 
-def resnet_forward(p, x, num_blocks=(3, 4, 6, 3), m=32, prefix="", training=True, new_buffers=None, relu_masks=None):
-    """x [B, T, F] -> embed_a [B, embed_dim].
+def resnet_forward(p, x, num_blocks=(3, 4, 6, 3), m=32, prefix="", training=True, new_buffers=None, relu_masks=None,
+                   bottleneck=False, two_emb_layer=False):
+    """x [B, T, F] -> embed_a [B, embed_dim]  (two_emb_layer: (embed_a, embed_b), embed_b = seg_2(BN(relu(embed_a)))).
     relu_masks: optional list of boolean [B, C, F', T'] tensors, one per ReLU in evaluation order (stem, then per block:
     after bn1, after the residual sum): the ReLU then multiplies by the given mask instead of by (z > 0).  Tests use it
     to differentiate the restatement on the SAME linear region as the implementation under test -- a pre-activation
@@ -114,10 +131,15 @@ def resnet_forward(p, x, num_blocks=(3, 4, 6, 3), m=32, prefix="", training=True
         return out
     y = x.permute(0, 2, 1).unsqueeze(1)
     y = relu(bn(prefix + "bn1", F.conv2d(y, p[prefix + "conv1.weight"], padding=1)))
-    for q, inp, planes, stride in _blocks(num_blocks, m):
+    for q, inp, planes, stride in _blocks(num_blocks, m, 4 if bottleneck else 1):
         q = prefix + q
-        o = relu(bn(q + "bn1", F.conv2d(y, p[q + "conv1.weight"], stride=stride, padding=1)))
-        o = bn(q + "bn2", F.conv2d(o, p[q + "conv2.weight"], padding=1))
+        if bottleneck:
+            o = relu(bn(q + "bn1", F.conv2d(y, p[q + "conv1.weight"])))
+            o = relu(bn(q + "bn2", F.conv2d(o, p[q + "conv2.weight"], stride=stride, padding=1)))
+            o = bn(q + "bn3", F.conv2d(o, p[q + "conv3.weight"]))
+        else:
+            o = relu(bn(q + "bn1", F.conv2d(y, p[q + "conv1.weight"], stride=stride, padding=1)))
+            o = bn(q + "bn2", F.conv2d(o, p[q + "conv2.weight"], padding=1))
         sc = y
         if (q + "shortcut.0.weight") in p:
             sc = bn(q + "shortcut.1", F.conv2d(y, p[q + "shortcut.0.weight"], stride=stride))
@@ -125,7 +147,15 @@ def resnet_forward(p, x, num_blocks=(3, 4, 6, 3), m=32, prefix="", training=True
     mean = y.mean(-1)
     std = torch.sqrt(torch.var(y, dim=-1) + 1e-7)
     stats = torch.cat((mean.flatten(1), std.flatten(1)), 1)
-    return F.linear(stats, p[prefix + "seg_1.weight"], p[prefix + "seg_1.bias"])
+    embed_a = F.linear(stats, p[prefix + "seg_1.weight"], p[prefix + "seg_1.bias"])
+    if not two_emb_layer:
+        return embed_a
+    q = prefix + "seg_bn_1"
+    rm, rv = p[q + ".running_mean"].clone(), p[q + ".running_var"].clone()
+    o = F.batch_norm(F.relu(embed_a), rm, rv, None, None, training, BN_MOMENTUM, BN_EPS)
+    if new_buffers is not None and training:
+        new_buffers[q + ".running_mean"], new_buffers[q + ".running_var"] = rm, rv
+    return embed_a, F.linear(o, p[prefix + "seg_2.weight"], p[prefix + "seg_2.bias"])
 
 
 # ---- in-model fbank front-end (bsrnn.py:231-242,343-350) ----------------------------

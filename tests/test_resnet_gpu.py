@@ -127,6 +127,40 @@ def test_resnet18_matches_oracle(monkeypatch, gemm, tol):
     assert not bad, bad[:10]
 
 
+def test_bottleneck_resnet_with_two_emb_layers_matches_oracle():
+    """Bottleneck blocks (ResNet50 / 101 / 152 geometry: 1x1 - 3x3(stride) - 1x1, expansion 4; block counts (1, 2, 1, 1)
+    keep the oracle short) and two_emb_layer=True: both embeddings, parameter gradients and running statistics against
+    the restatement.  Same tolerances as ResNet18 above (ReLU kinks between fp32 and split-bf16 products)."""
+    from oracle import resnet_oracle as RO
+    from wesep_amd.models import resnet as MR
+    d = _cuda()
+    nb = (1, 2, 1, 1)
+    kw = dict(num_blocks=nb, m=32, feat_dim=16, embed_dim=64, bottleneck=True, two_emb_layer=True)
+    params = RO.synth_params(15, **kw)
+    model = MR.ResNet(MR.Bottleneck, list(nb), feat_dim=16, embed_dim=64, pooling_func="TSTP", two_emb_layer=True)
+    model.load_state_dict(params, strict=True)
+    model = model.to(d).train()
+    g = torch.Generator().manual_seed(19)
+    x, probe = torch.randn(8, 64, 16, generator=g), torch.randn(8, 64, generator=g)
+    ea, eb = model(x.to(d))
+    ((ea + eb) * probe.to(d)).sum().backward()
+    p = {k: (v.clone() if RO.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in params.items()}
+    bufs = {}
+    ra, rb = RO.resnet_forward(p, x, num_blocks=nb, m=32, new_buffers=bufs, bottleneck=True, two_emb_layer=True)
+    ((ra + rb) * probe).sum().backward()
+    assert rel(ea, ra) < 1e-3 and rel(eb, rb) < 1e-3
+    sd = model.state_dict()
+    for k, v in bufs.items():
+        assert torch.allclose(sd[k].cpu(), v, rtol=2e-3, atol=1e-5), k
+    gn = max(float(v.grad.norm()) for k, v in p.items() if not RO.is_buffer(k))
+    bad = []
+    for k, prm in model.named_parameters():
+        err = float((prm.grad.detach().cpu().double() - p[k].grad.double()).norm())
+        if err > 3e-2 * float(p[k].grad.norm()) + 1e-3 * gn:
+            bad.append((k, err / float(p[k].grad.norm())))
+    assert not bad, bad[:10]
+
+
 def test_bsrnn_joint_training_with_resnet34_runs_and_matches_oracle():
     """The shipped configuration (confs/bsrnn.yaml: joint_training, ResNet34 on 80-d fbank, multiply fusion):
     separated waveform against oracle(ResNet restatement -> BSRNN oracle), and gradients reach the speaker encoder."""

@@ -107,3 +107,33 @@ def test_ecapa_tdnn_host_logic_matches_restatement(monkeypatch):
     for k, v in nb.items():
         assert float((sd[k] - v).norm()) <= 1e-4 * float(v.norm()) + 1e-6, k
     assert int(sd["bn.num_batches_tracked"]) == 1 and int(sd["layer2.se_res2block.1.bns.3.num_batches_tracked"]) == 1
+
+
+def test_bottleneck_resnet_and_two_emb_layer_host_logic_matches_restatement(monkeypatch):
+    """ResNet50 geometry (Bottleneck blocks, expansion 4; a (1, 1, 1, 1) stack keeps the CPU run short -- ResNet50 / 101 /
+    152 differ only in the block counts) with two_emb_layer=True (seg_1 -> ReLU -> BatchNorm1d(affine=False) -> seg_2):
+    strict state_dict load under wespeaker's names, both embeddings, every parameter gradient."""
+    from wesep_amd.models import resnet as MR
+    emu_dev.install(monkeypatch)
+    kw = dict(num_blocks=(1, 1, 1, 1), m=32, feat_dim=16, embed_dim=64, bottleneck=True, two_emb_layer=True)
+    params = RO.synth_params(6, **kw)
+    model = MR.ResNet(MR.Bottleneck, [1, 1, 1, 1], feat_dim=16, embed_dim=64, pooling_func="TSTP", two_emb_layer=True)
+    model.load_state_dict(params, strict=True)
+    model.train()
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    g = torch.Generator().manual_seed(10)
+    x, probe = torch.randn(8, 40, 16, generator=g), torch.randn(8, 64, generator=g)
+    ea, eb = model(x)
+    ((ea + eb) * probe).sum().backward()
+    p = {k: (v.clone() if RO.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in params.items()}
+    ra, rb = RO.resnet_forward(p, x, num_blocks=kw["num_blocks"], m=32, bottleneck=True, two_emb_layer=True)
+    ((ra + rb) * probe).sum().backward()
+    for a, b in ((ea, ra), (eb, rb)):
+        assert float((a.detach() - b.detach()).norm() / b.detach().norm()) < 1e-4
+    for k, prm in model.named_parameters():
+        gn = float(p[k].grad.norm())
+        assert abs(float(prm.grad.norm()) - gn) <= 2e-2 * gn + 1e-4, k
+    for name in ("ResNet50", "ResNet101", "ResNet152"):
+        m = MR.get_speaker_model(name)(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False)
+        want = RO.param_shapes(num_blocks=RO.NUM_BLOCKS[name], feat_dim=80, embed_dim=256, bottleneck=True)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in want.items()}

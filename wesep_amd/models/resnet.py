@@ -38,6 +38,26 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
 
+class Bottleneck(nn.Module):
+    """wespeaker Bottleneck (ResNet50 / 101 / 152): 1x1 - 3x3(stride) - 1x1, expansion 4."""
+    expansion = 4
+
+    def __init__(self, in_planes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, self.expansion * planes, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(self.expansion * planes)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_planes != self.expansion * planes:
+            self.shortcut = nn.Sequential(
+                nn.Conv2d(in_planes, self.expansion * planes, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(self.expansion * planes))
+        self.stride = stride
+
+
 def _cba(x, res, R, H, W, stride, relu, conv, bn, training):
     if training:
         bn.num_batches_tracked += 1
@@ -49,12 +69,8 @@ class ResNet(nn.Module):
     def __init__(self, block, num_blocks, m_channels=32, feat_dim=40, embed_dim=128, pooling_func="TSTP",
                  two_emb_layer=True):
         super().__init__()
-        if block is not BasicBlock:
-            raise NotImplementedError("wespeaker Bottleneck ResNets (50/101/152) are not built; ResNet18/34 are")
         if pooling_func != "TSTP":
             raise NotImplementedError(f"pooling_func {pooling_func!r}: only TSTP is built")
-        if two_emb_layer:
-            raise NotImplementedError("two_emb_layer=True is not built (wesep's configs use False)")
         self.in_planes, self.feat_dim, self.embed_dim = m_channels, feat_dim, embed_dim
         self.stats_dim = int(feat_dim / 8) * m_channels * 8
         self.two_emb_layer = two_emb_layer
@@ -67,8 +83,12 @@ class ResNet(nn.Module):
         self.pool = TSTP(in_dim=self.stats_dim * block.expansion)
         self.pool_out_dim = self.pool.get_out_dim()
         self.seg_1 = nn.Linear(self.pool_out_dim, embed_dim)
-        self.seg_bn_1 = nn.Identity()
-        self.seg_2 = nn.Identity()
+        if two_emb_layer:
+            self.seg_bn_1 = nn.BatchNorm1d(embed_dim, affine=False)
+            self.seg_2 = nn.Linear(embed_dim, embed_dim)
+        else:
+            self.seg_bn_1 = nn.Identity()
+            self.seg_2 = nn.Identity()
 
     def _make_layer(self, block, planes, num_blocks, stride):
         layers = []
@@ -78,7 +98,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        """x [R, T, F] fbank -> (tensor(0.), embed_a [R, embed_dim])  (two_emb_layer=False contract)."""
+        """x [R, T, F] fbank -> (tensor(0.), embed_a [R, embed_dim]), or (embed_a, embed_b) with two_emb_layer."""
         if not x.is_cuda:
             from .._lib import WesepHipError
             raise WesepHipError("ResNet speaker encoder: wesep_amd has no CPU path")
@@ -91,15 +111,29 @@ class ResNet(nn.Module):
             for blk in layer:
                 s = blk.stride
                 Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
-                o = _cba(y, None, R, H, W, s, True, blk.conv1, blk.bn1, tr)
                 sc = y
                 if len(blk.shortcut) > 0:
                     sc = _cba(y, None, R, H, W, s, False, blk.shortcut[0], blk.shortcut[1], tr)
-                y = _cba(o, sc, R, Ho, Wo, 1, True, blk.conv2, blk.bn2, tr)
+                if isinstance(blk, Bottleneck):
+                    o = _cba(y, None, R, H, W, 1, True, blk.conv1, blk.bn1, tr)
+                    o = _cba(o, None, R, H, W, s, True, blk.conv2, blk.bn2, tr)
+                    y = _cba(o, sc, R, Ho, Wo, 1, True, blk.conv3, blk.bn3, tr)
+                else:
+                    o = _cba(y, None, R, H, W, s, True, blk.conv1, blk.bn1, tr)
+                    y = _cba(o, sc, R, Ho, Wo, 1, True, blk.conv2, blk.bn2, tr)
                 H, W = Ho, Wo
         stats = FR.TstpFn.apply(y, (R, H, W))
         embed_a = LinearFn.apply(stats, self.seg_1.weight, self.seg_1.bias)
-        return torch.tensor(0.0), embed_a
+        if not self.two_emb_layer:
+            return torch.tensor(0.0), embed_a
+        from .. import functional_ecapa as FE
+        E = self.embed_dim
+        if tr:
+            self.seg_bn_1.num_batches_tracked += 1
+        ones, zeros = torch.ones(E, device=x.device), torch.zeros(E, device=x.device)
+        o = FE.BatchNormRowsFn.apply(torch.relu(embed_a), ones, zeros, self.seg_bn_1.running_mean,
+                                     self.seg_bn_1.running_var, tr)          # affine=False; [R, E]: a few thousand numbers
+        return embed_a, LinearFn.apply(o, self.seg_2.weight, self.seg_2.bias)
 
 
 def ResNet18(feat_dim, embed_dim, pooling_func="TSTP", two_emb_layer=True):
@@ -112,13 +146,25 @@ def ResNet34(feat_dim, embed_dim, pooling_func="TSTP", two_emb_layer=True):
                   two_emb_layer=two_emb_layer)
 
 
+def _bottleneck_resnet(num_blocks):
+    def make(feat_dim, embed_dim, pooling_func="TSTP", two_emb_layer=True):
+        return ResNet(Bottleneck, num_blocks, feat_dim=feat_dim, embed_dim=embed_dim, pooling_func=pooling_func,
+                      two_emb_layer=two_emb_layer)
+    return make
+
+
+ResNet50, ResNet101, ResNet152 = (_bottleneck_resnet(n) for n in ([3, 4, 6, 3], [3, 4, 23, 3], [3, 8, 36, 3]))
+
+
 def get_speaker_model(model_name: str):
     """`wespeaker.models.speaker_model.get_speaker_model` for the encoders built here."""
-    if model_name in ("ResNet18", "ResNet34"):
-        return {"ResNet18": ResNet18, "ResNet34": ResNet34}[model_name]
+    table = {"ResNet18": ResNet18, "ResNet34": ResNet34, "ResNet50": ResNet50, "ResNet101": ResNet101,
+             "ResNet152": ResNet152}
+    if model_name in table:
+        return table[model_name]
     from .ecapa_tdnn import ECAPA_MODELS
     if model_name in ECAPA_MODELS:
         return ECAPA_MODELS[model_name]
-    raise NotImplementedError(f"speaker model {model_name!r}: the wespeaker BasicBlock ResNets (ResNet18, ResNet34) and "
+    raise NotImplementedError(f"speaker model {model_name!r}: the wespeaker ResNets (18 / 34 / 50 / 101 / 152) and "
                               "ECAPA-TDNN (c512 / c1024, with or without global context) are built "
-                              "(SURVEY.md section 8 row a12); CAM++ and the Bottleneck ResNets are not")
+                              "(SURVEY.md section 8 row a12); CAM++ is not")
