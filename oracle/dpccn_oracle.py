@@ -70,6 +70,9 @@ def param_shapes(cfg: DPCCNConfig) -> Dict[str, tuple]:
     elif cfg.spk_fuse_type in ("additive", "multiply"):
         s["spk_fuse.fc.linear.weight"] = (Fd, E)
         s["spk_fuse.fc.linear.bias"] = (Fd,)
+    elif cfg.spk_fuse_type == "FiLM":          # norm.py:84-137, one layer: gamma and beta Linears embed -> feature
+        s["spk_fuse.fc.gamma_fcs.0.weight"], s["spk_fuse.fc.gamma_fcs.0.bias"] = (Fd, E), (Fd,)
+        s["spk_fuse.fc.beta_fcs.0.weight"], s["spk_fuse.fc.beta_fcs.0.bias"] = (Fd, E), (Fd,)
     else:
         raise NotImplementedError(cfg.spk_fuse_type)
     D = cfg.tcn_dims
@@ -146,6 +149,11 @@ def _tcn(p, q, x, dil):
 
 def _fuse(p, cfg, x, e):
     """SpeakerFuseLayer (speaker.py:81-125) on x [B, C, F, T] with e [B, 1, E, 1]: the Linear acts on dim 2."""
+    if cfg.spk_fuse_type == "FiLM":            # x = (1 + gamma(e)) x + beta(e), gamma / beta per frequency bin (norm.py:116-134)
+        ev = e.squeeze(-1)                                                                       # [B, 1, E]
+        gm = F.linear(ev, p["spk_fuse.fc.gamma_fcs.0.weight"], p["spk_fuse.fc.gamma_fcs.0.bias"]).unsqueeze(-1)
+        bt = F.linear(ev, p["spk_fuse.fc.beta_fcs.0.weight"], p["spk_fuse.fc.beta_fcs.0.bias"]).unsqueeze(-1)
+        return (1 + gm) * x + bt
     w, b = p["spk_fuse.fc.linear.weight"], p["spk_fuse.fc.linear.bias"]
     if cfg.spk_fuse_type == "concat":
         ee = e.expand(-1, x.shape[1], -1, x.shape[3])

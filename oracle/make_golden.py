@@ -153,6 +153,7 @@ DPCCN_CASES = {
                                     2, 4352, 32),
     "dpccn_additive_xform_r2_t4608": (dict(tcn_blocks=2, tcn_layers=2, spk_fuse_type="additive",
                                            use_spk_transform=True), 2, 4608, 33),
+    "dpccn_film_r2_t4352": (dict(tcn_blocks=2, tcn_layers=1, spk_fuse_type="FiLM"), 2, 4352, 34),
 }
 
 
@@ -196,6 +197,8 @@ TFGRIDNET_CASES = {
     "tfgridnet_ks1_additive_r2_t1280": (dict(n_layers=1, lstm_hidden_units=16, emb_dim=8, emb_ks=1, emb_hs=1,
                                              attn_n_head=2, attn_approx_qk_dim=260, spk_fuse_type="additive",
                                              use_spk_transform=True), 2, 1280, 42),
+    "tfgridnet_ks1_film_r2_t1280": (dict(n_layers=2, lstm_hidden_units=16, emb_dim=8, emb_ks=1, emb_hs=1,
+                                         attn_n_head=2, attn_approx_qk_dim=260, spk_fuse_type="FiLM"), 2, 1280, 43),
 }
 
 

@@ -54,10 +54,14 @@ def param_shapes(cfg: TFGridNetConfig) -> Dict[str, tuple]:
         s["spk_transform.transforms.1.bias"] = (128,)
         s["spk_transform.transforms.3.weight"] = (E, 128, 1)
         s["spk_transform.transforms.3.bias"] = (E,)
-    if cfg.spk_fuse_type not in ("multiply", "additive"):
+    if cfg.spk_fuse_type == "FiLM":            # norm.py:84-137
+        s["spk_fuse.fc.gamma_fcs.0.weight"], s["spk_fuse.fc.gamma_fcs.0.bias"] = (Fq, E), (Fq,)
+        s["spk_fuse.fc.beta_fcs.0.weight"], s["spk_fuse.fc.beta_fcs.0.bias"] = (Fq, E), (Fq,)
+    elif cfg.spk_fuse_type in ("multiply", "additive"):
+        s["spk_fuse.fc.linear.weight"] = (Fq, E)
+        s["spk_fuse.fc.linear.bias"] = (Fq,)
+    else:
         raise NotImplementedError(cfg.spk_fuse_type)
-    s["spk_fuse.fc.linear.weight"] = (Fq, E)
-    s["spk_fuse.fc.linear.bias"] = (Fq,)
     s["conv.0.weight"] = (C, 2, 3, 3)
     s["conv.0.bias"] = (C,)
     s["conv.1.weight"] = (C,)
@@ -204,9 +208,16 @@ def tfgridnet_forward(p: Dict[str, torch.Tensor], cfg: TFGridNetConfig, wav: tor
                      p["conv.1.bias"], cfg.eps)
     if cfg.use_spk_transform:
         emb = spk_transform(p, emb)
-    t = F.linear(emb, p["spk_fuse.fc.linear.weight"], p["spk_fuse.fc.linear.bias"]).view(B, 1, 1, nF)
+    if cfg.spk_fuse_type == "FiLM":
+        gm = F.linear(emb, p["spk_fuse.fc.gamma_fcs.0.weight"], p["spk_fuse.fc.gamma_fcs.0.bias"]).view(B, 1, 1, nF)
+        bt = F.linear(emb, p["spk_fuse.fc.beta_fcs.0.weight"], p["spk_fuse.fc.beta_fcs.0.bias"]).view(B, 1, 1, nF)
+    else:
+        t = F.linear(emb, p["spk_fuse.fc.linear.weight"], p["spk_fuse.fc.linear.bias"]).view(B, 1, 1, nF)
     for i in range(cfg.n_layers):
-        h = h * t if cfg.spk_fuse_type == "multiply" else h + t
+        if cfg.spk_fuse_type == "FiLM":
+            h = (1 + gm) * h + bt
+        else:
+            h = h * t if cfg.spk_fuse_type == "multiply" else h + t
         h = gridnet_block(p, cfg, f"blocks.{i}.", h)
     h = F.conv_transpose2d(h, p["deconv.weight"], p["deconv.bias"], padding=(1, 1))          # [B, 2, T, F]
     est = torch.complex(h[:, 0], h[:, 1]).transpose(1, 2)                                    # [B, F, T]

@@ -35,7 +35,8 @@ def test_softmax_rows_matches_torch():
     assert rel(y, yr) < 1e-6 and rel(x.grad, xr.grad) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["tfgridnet_ks4_r2_t1600", "tfgridnet_ks1_additive_r2_t1280"])
+@pytest.mark.parametrize("name", ["tfgridnet_ks4_r2_t1600", "tfgridnet_ks1_additive_r2_t1280",
+                                  "tfgridnet_ks1_film_r2_t1280"])
 def test_tfgridnet_model_matches_reference_fixture(name, golden_dir):
     from oracle import bsrnn_oracle as O
     from oracle import tfgridnet_oracle as TG

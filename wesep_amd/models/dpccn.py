@@ -99,15 +99,41 @@ class TCNBlock(nn.Module):
         return FD.Conv1x1ResFn.apply(y, self.dconv2.weight, self.dconv2.bias, x)
 
 
+class _FiLM(nn.Module):
+    """FiLM container (wesep/modules/common/norm.py:84-137, one layer): `gamma_fcs.0` / `beta_fcs.0` map the embedding to
+    one scale / shift per frequency bin, zero-initialised like the reference."""
+
+    def __init__(self, feat_size, embed_size):
+        super().__init__()
+        self.gamma_fcs = nn.ModuleList([nn.Linear(embed_size, feat_size)])
+        self.beta_fcs = nn.ModuleList([nn.Linear(embed_size, feat_size)])
+        for m in (self.gamma_fcs[0], self.beta_fcs[0]):
+            nn.init.zeros_(m.weight)
+            nn.init.zeros_(m.bias)
+
+
 class _Fuse(nn.Module):
-    """SpeakerFuseLayer container (speaker.py:63-79): `fc.linear` maps the embedding to one factor per frequency bin."""
+    """SpeakerFuseLayer container (speaker.py:63-79): `fc.linear` maps the embedding to one factor per frequency bin;
+    FiLM: `fc.gamma_fcs.0` / `fc.beta_fcs.0`."""
 
     def __init__(self, embed_dim, feat_dim, fuse_type):
         super().__init__()
-        if fuse_type not in ("multiply", "additive"):
-            raise NotImplementedError(f"DPCCN spk_fuse_type={fuse_type!r}: multiply / additive are built")
+        if fuse_type not in ("multiply", "additive", "FiLM"):
+            raise NotImplementedError(f"DPCCN spk_fuse_type={fuse_type!r}: multiply / additive / FiLM are built")
         self.fuse_type = fuse_type
-        self.fc = LinearLayer(embed_dim, feat_dim)
+        self.fc = _FiLM(feat_dim, embed_dim) if fuse_type == "FiLM" else LinearLayer(embed_dim, feat_dim)
+
+
+def fuse_bins(fuse, x, emb, geo):
+    """SpeakerFuseLayer on x [B*T*F, C] with one factor / offset per (row, frequency bin) (speaker.py:102-125 on the
+    [B, C, F, T] view; FiLM: norm.py:116-134, x = (1 + gamma(e)) x + beta(e))."""
+    B, T, Fq = geo
+    if fuse.fuse_type == "FiLM":
+        gm = F_.LinearFn.apply(emb, fuse.fc.gamma_fcs[0].weight, fuse.fc.gamma_fcs[0].bias) + 1.0    # [B, F]
+        bt = F_.LinearFn.apply(emb, fuse.fc.beta_fcs[0].weight, fuse.fc.beta_fcs[0].bias)
+        return FD.ScaleBFFn.apply(FD.ScaleBFFn.apply(x, gm, (B, T, Fq, 0)), bt, (B, T, Fq, 1))
+    s = F_.LinearFn.apply(emb, fuse.fc.linear.weight, fuse.fc.linear.bias)                         # [B, F]
+    return FD.ScaleBFFn.apply(x, s, (B, T, Fq, 0 if fuse.fuse_type == "multiply" else 1))
 
 
 class DPCCN(nn.Module):
@@ -208,8 +234,7 @@ class DPCCN(nn.Module):
             logits = (F_.LinearFn.apply(emb, self.pred_linear.weight, self.pred_linear.bias) if self.multi_task
                       else emb)
         emb = self.spk_transform(emb)
-        s = F_.LinearFn.apply(emb, self.spk_fuse.fc.linear.weight, self.spk_fuse.fc.linear.bias)   # [B, F]
-        out = FD.ScaleBFFn.apply(out, s, (B, Tf, Fq, 0 if self.spk_fuse.fuse_type == "multiply" else 1))
+        out = fuse_bins(self.spk_fuse, out, emb, (B, Tf, Fq))
         skips = [(out, geo)]
         for enc in list(self.encoder)[1:]:
             out, geo = enc(out, geo)

@@ -170,10 +170,11 @@ class GridNetBlock(nn.Module):
 class _Fuse(nn.Module):
     def __init__(self, embed_dim, feat_dim, fuse_type):
         super().__init__()
-        if fuse_type not in ("multiply", "additive"):
-            raise NotImplementedError(f"TF-GridNet spk_fuse_type={fuse_type!r}: multiply / additive are built")
+        if fuse_type not in ("multiply", "additive", "FiLM"):
+            raise NotImplementedError(f"TF-GridNet spk_fuse_type={fuse_type!r}: multiply / additive / FiLM are built")
         self.fuse_type = fuse_type
-        self.fc = LinearLayer(embed_dim, feat_dim)
+        from .dpccn import _FiLM
+        self.fc = _FiLM(feat_dim, embed_dim) if fuse_type == "FiLM" else LinearLayer(embed_dim, feat_dim)
 
 
 class TFGridNet(nn.Module):
@@ -265,10 +266,9 @@ class TFGridNet(nn.Module):
             logits = (F_.LinearFn.apply(emb, self.pred_linear.weight, self.pred_linear.bias) if self.multi_task
                       else emb)
         emb = self.spk_transform(emb)
-        s = F_.LinearFn.apply(emb, self.spk_fuse.fc.linear.weight, self.spk_fuse.fc.linear.bias)       # [B, F]
-        mode = 0 if self.spk_fuse.fuse_type == "multiply" else 1
+        from .dpccn import fuse_bins
         for blk in self.blocks:
-            h = FD.ScaleBFFn.apply(h, s, (B, Tf, Fq, mode))
+            h = fuse_bins(self.spk_fuse, h, emb, (B, Tf, Fq))        # the same fusion before every block (tfgridnet.py:272-276)
             h = blk(h, (B, Tf, Fq))
         out = FD.ConvTranspose2dFn.apply(h, self.deconv.weight, self.deconv.bias, (B, Tf, Fq, 1, 1))   # [B*T*F, 2]
         ld = -(-2 * Fq // 4) * 4
