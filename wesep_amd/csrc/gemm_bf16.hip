@@ -270,6 +270,64 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
   }
 
   const bool flat_c = p.c_div >= M;  // (m / c_div) == 0 for every row: no division needed
+  // Vector epilogue (round 2): the accumulators hold one COLUMN per lane; stored that way a row costs 4-byte accesses
+  // behind per-element branches, and the residual / activation-derivative loads cannot move above the stores (C may
+  // alias R) -- one exposed memory round trip per register (measured on gemm_b2p: 0.4 of 0.59 ms).  When every row piece
+  // is 16-byte addressable the tile is staged through the (now free) LDS planes, 10 KB per wave, and a lane moves
+  // float4 pieces of whole rows: all R / T loads of a pass are issued before its first store; a narrow tile (16 output
+  // channels) becomes 1 KB of contiguous stores per wave instead of 64-byte rows.
+  const bool vec_epi = (N & 3) == 0 && (p.c_s1 & 3) == 0 && (p.c_s2 & 3) == 0 && ((size_t)C & 15) == 0 &&
+                       (!R || ((size_t)R & 15) == 0) && (!T || ((size_t)T & 15) == 0);
+  if (vec_epi) {
+    constexpr int W = NB == 4 ? 64 : 32 * NB;  // columns per pass
+    constexpr int LDW = W + 4;                 // 32 x 68 floats = 8.5 KB of the wave's 10 KB
+    constexpr int NPASS = NB == 4 ? 2 : 1;
+    constexpr int C4 = W / 4, NI = 32 * C4 / 64;
+    __syncthreads();                            // the last tile's fragment reads are done: the planes are free
+    float* stg = reinterpret_cast<float*>(lds) + wave * 2560;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+      for (int tn = 0; tn < W / 32; ++tn) {
+        const f32x16& acc = NB == 4 ? (pass == 0 ? (tn ? acc01 : acc00) : (tn ? acc11 : acc10)) : accn[tn];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[frag_row32b(r, half) * LDW + tn * 32 + l31] = acc[r];
+      }
+      __syncthreads();
+      const int row0 = NB == 4 ? wm * 64 + pass * 32 : wave * 32, col0 = NB == 4 ? wn * 64 : 0;
+      f32x4 v[NI], tv[NI], rv[NI];
+      long long off[NI];
+#pragma unroll
+      for (int q = 0; q < NI; ++q) {
+        const int idx = lane + 64 * q, rr = idx / C4, c4 = idx - rr * C4;
+        const int m = m_blk + row0 + rr, n = n_blk + col0 + 4 * c4;
+        const bool ok = m < M && n < N;
+        off[q] = ok ? (flat_c ? (long long)m * p.c_s2 : ws_row_off(m, p.c_div, p.c_s1, p.c_s2)) + n : -1;
+        v[q] = *reinterpret_cast<const f32x4*>(stg + rr * LDW + 4 * c4);
+        if (bias && ok) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[q][j] += bias[n + j];
+        }
+        if (T && ok) tv[q] = *reinterpret_cast<const f32x4*>(T + off[q]);
+        if (R && ok) rv[q] = *reinterpret_cast<const f32x4*>(R + off[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < NI; ++q) {
+        if (off[q] < 0) continue;
+        f32x4 o = v[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p.act == 1) o[j] = tanhf(o[j]);
+          if (p.act == 2) o[j] = fmaxf(o[j], 0.f);
+          if (T) o[j] *= p.act == 4 ? (tv[q][j] > 0.f ? 1.f : 0.f) : (1.f - tv[q][j] * tv[q][j]);
+          if (R) o[j] += rv[q][j];
+        }
+        *reinterpret_cast<f32x4*>(C + off[q]) = o;
+      }
+      if (pass + 1 < NPASS) __syncthreads();    // staging area free for the second half of the wave's tile
+    }
+    return;
+  }
   // (row0, col0) of a 32 x 32 accumulator block inside the workgroup tile
   auto epilogue = [&](const f32x16& acc, int tm, int tn) {
     const int col0 = NB == 4 ? wn * 64 + tn * 32 : tn * 32, row0 = NB == 4 ? wm * 64 + tm * 32 : wave * 32;
