@@ -47,6 +47,7 @@ class ConvTasNetConfig:
     R: int = 4
     spk_emb_dim: int = 256
     norm: str = "gLN"
+    spk_fuse_type: str = "concatConv"   # or concat / additive / multiply / FiLM (separation.py:116-135)
     multi_fuse: bool = True
     use_spk_transform: bool = False
     joint_training: bool = False   # True: SpEx+ speaker encoder on the shared encoder (tasnet/speaker.py)
@@ -61,11 +62,19 @@ class ConvTasNetConfig:
 def _block_names(cfg: ConvTasNetConfig):
     """(kind, prefix, dilation) of every block in execution order (`separation.py:84-160,168-186`)."""
     out = []
-    if cfg.multi_fuse:
+    if cfg.multi_fuse and cfg.spk_fuse_type == "concatConv":
         for r in range(cfg.R):
             out.append(("fuse", f"separation.separation.{2 * r}.", 1))
             for j, x in enumerate(range(1, cfg.X)):
                 out.append(("plain", f"separation.separation.{2 * r + 1}.separation.{j}.", 2 ** x))
+    elif cfg.multi_fuse:
+        # SpeakerFuseLayer - PReLU - norm - Separation(1, X) with all X dilations, four list entries per repeat
+        for r in range(cfg.R):
+            out.append(("fuselayer", f"separation.separation.{4 * r}.", 0))
+            out.append(("prelu", f"separation.separation.{4 * r + 1}.", 0))
+            out.append(("norm", f"separation.separation.{4 * r + 2}.", 0))
+            for j, x in enumerate(range(0, cfg.X)):
+                out.append(("plain", f"separation.separation.{4 * r + 3}.separation.{j}.", 2 ** x))
     else:
         # the reference first appends the fuse block to a ModuleList and then REPLACES the list by one
         # Separation (`separation.py:146-160`): the fuse block is dropped and forward() would call
@@ -119,7 +128,19 @@ def param_shapes(cfg: ConvTasNetConfig) -> Dict[str, tuple]:
         s["spk_transform.transforms.3.bias"] = (E,)
     nshape = (H, 1) if cfg.norm == "gLN" else (H,)
     for kind, p, _ in _block_names(cfg):
-        if kind == "fuse":
+        if kind == "fuselayer":                       # speaker.py:63-79 (FiLM: norm.py:84-111)
+            if cfg.spk_fuse_type == "FiLM":
+                s[p + "fc.gamma_fcs.0.weight"], s[p + "fc.gamma_fcs.0.bias"] = (B, E), (B,)
+                s[p + "fc.beta_fcs.0.weight"], s[p + "fc.beta_fcs.0.bias"] = (B, E), (B,)
+            else:
+                s[p + "fc.linear.weight"] = (B, E + B) if cfg.spk_fuse_type == "concat" else (B, E)
+                s[p + "fc.linear.bias"] = (B,)
+        elif kind == "prelu":
+            s[p + "weight"] = (1,)
+        elif kind == "norm":
+            s[p + "weight"] = (B, 1) if cfg.norm == "gLN" else (B,)
+            s[p + "bias"] = (B, 1) if cfg.norm == "gLN" else (B,)
+        elif kind == "fuse":
             s[p + "conv1x1.weight"] = (H, B + E, 1)
             s[p + "conv1x1.bias"] = (H,)
             s[p + "prelu1.weight"] = (1,)
@@ -154,6 +175,11 @@ def param_shapes(cfg: ConvTasNetConfig) -> Dict[str, tuple]:
     return s
 
 
+import re as _re
+
+_TOP_ENTRY = _re.compile(r"^separation\.separation\.\d+\.(weight|bias)$")
+
+
 def synth_params(cfg: ConvTasNetConfig, seed: int) -> Dict[str, torch.Tensor]:
     """Deterministic parameter set (fan-in scaled normal; norm gains near 1, PReLU slopes near .25)."""
     g = torch.Generator().manual_seed(seed)
@@ -166,6 +192,13 @@ def synth_params(cfg: ConvTasNetConfig, seed: int) -> Dict[str, torch.Tensor]:
         elif k.endswith("num_batches_tracked"):
             v = torch.zeros(shp, dtype=torch.long)
         elif k.startswith("pred_linear") and k.endswith("weight"):
+            v = torch.randn(shp, generator=g) / shp[1] ** 0.5
+        elif _TOP_ENTRY.match(k):      # PReLU / norm entries of the non-concatConv FuseSeparation list
+            if tuple(shp) == (1,):
+                v = 0.25 + 0.05 * torch.randn(shp, generator=g)
+            else:
+                v = (1.0 + 0.1 * torch.randn(shp, generator=g)) if k.endswith("weight") else 0.1 * torch.randn(shp, generator=g)
+        elif ".fc." in k and k.endswith("weight"):   # SpeakerFuseLayer / FiLM linears [B, E (+ B)]
             v = torch.randn(shp, generator=g) / shp[1] ** 0.5
         elif "norm" in k or ".ln." in k or k.startswith("spk_model.aux_enc3.0."):
             v = (1.0 + 0.1 * torch.randn(shp, generator=g)) if k.endswith("weight") else 0.1 * torch.randn(shp, generator=g)
@@ -290,7 +323,24 @@ def convtasnet_forward(p: Dict[str, torch.Tensor], cfg: ConvTasNetConfig, wav: t
         emb = spk_transform(p, emb)
     aux = emb.unsqueeze(-1)
     for kind, pre, dil in _block_names(cfg):
-        e = conv_block(p, cfg, kind, pre, dil, e, aux)
+        if kind == "fuselayer":                       # speaker.py:81-125 on x [R, B, T'], embed [R, E, 1]
+            ft = cfg.spk_fuse_type
+            if ft == "FiLM":
+                gm = F.linear(emb, p[pre + "fc.gamma_fcs.0.weight"], p[pre + "fc.gamma_fcs.0.bias"]).unsqueeze(-1)
+                bt = F.linear(emb, p[pre + "fc.beta_fcs.0.weight"], p[pre + "fc.beta_fcs.0.bias"]).unsqueeze(-1)
+                e = (1 + gm) * e + bt
+            elif ft == "concat":
+                y = torch.cat([e, aux.expand(-1, -1, e.shape[-1])], 1).transpose(1, 2)
+                e = F.linear(y, p[pre + "fc.linear.weight"], p[pre + "fc.linear.bias"]).transpose(1, 2)
+            else:
+                t = F.linear(emb, p[pre + "fc.linear.weight"], p[pre + "fc.linear.bias"]).unsqueeze(-1)
+                e = e + t if ft == "additive" else e * t
+        elif kind == "prelu":
+            e = F.prelu(e, p[pre + "weight"])
+        elif kind == "norm":
+            e = _norm(cfg, e, p[pre + "weight"], p[pre + "bias"])
+        else:
+            e = conv_block(p, cfg, kind, pre, dil, e, aux)
     outs = multi_decoder(p, cfg, e, (w1, w2, w3))
     if logits is not None:
         outs.append(logits)

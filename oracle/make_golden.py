@@ -87,6 +87,12 @@ TASNET_CASES = {
     "convtasnet_cln_xform_r4_t2000": (dict(N=16, L=20, B=24, H=40, P=3, X=2, R=1, norm="cLN",
                                            use_spk_transform=True), 4, 2000, 22),
     "convtasnet_gln_l16_r2_t1200": (dict(N=24, L=16, B=16, H=32, P=3, X=4, R=1), 2, 1200, 23),
+    # the other speaker-fusion types of FuseSeparation (separation.py:116-135): SpeakerFuseLayer - PReLU - norm - blocks
+    "convtasnet_multiply_r2_t1600": (dict(N=32, L=20, B=32, H=64, P=3, X=3, R=2, spk_fuse_type="multiply"), 2, 1600, 25),
+    "convtasnet_additive_cln_r2_t1600": (dict(N=16, L=20, B=24, H=40, P=3, X=2, R=2, norm="cLN",
+                                              spk_fuse_type="additive"), 2, 1600, 26),
+    "convtasnet_film_r2_t1600": (dict(N=32, L=20, B=32, H=64, P=3, X=2, R=2, spk_fuse_type="FiLM"), 2, 1600, 27),
+    "convtasnet_concat_r2_t1600": (dict(N=32, L=20, B=32, H=64, P=3, X=2, R=1, spk_fuse_type="concat"), 2, 1600, 28),
     # SpEx+ joint mode: enrollment waveform through the shared encoder + ResNet4SpExplus (N must be 256),
     # multi-task speaker head; loss = .8/.1/.1 SI-SDR + .5 CE; BatchNorm running statistics are pinned too
     "spexplus_joint_r4_t1600": (dict(N=256, L=20, B=32, H=48, P=3, X=2, R=2, joint_training=True,
@@ -101,7 +107,7 @@ def run_tasnet_case(name, kw, R, T, seed):
     cfg = CT.ConvTasNetConfig(**kw)
     ref = get_model("ConvTasNet")(
         N=cfg.N, L=cfg.L, B=cfg.B, H=cfg.H, P=cfg.P, X=cfg.X, R=cfg.R, spk_emb_dim=cfg.spk_emb_dim,
-        norm=cfg.norm, activate="relu", causal=False, skip_con=False, spk_fuse_type="concatConv",
+        norm=cfg.norm, activate="relu", causal=False, skip_con=False, spk_fuse_type=cfg.spk_fuse_type,
         multi_fuse=cfg.multi_fuse, use_spk_transform=cfg.use_spk_transform, encoder_type="Multi",
         decoder_type="Multi", joint_training=cfg.joint_training, multi_task=cfg.multi_task,
         spksInTrain=cfg.spksInTrain, spk_feat=False, feat_type="consistent")

@@ -175,7 +175,9 @@ def _cases():
 
 
 @pytest.mark.parametrize("name", ["convtasnet_gln_r2_t1600", "convtasnet_cln_xform_r4_t2000",
-                                  "convtasnet_gln_l16_r2_t1200"])
+                                  "convtasnet_gln_l16_r2_t1200", "convtasnet_multiply_r2_t1600",
+                                  "convtasnet_additive_cln_r2_t1600", "convtasnet_film_r2_t1600",
+                                  "convtasnet_concat_r2_t1600"])
 def test_model_matches_oracle_and_reference_fixture(name, golden_dir):
     from oracle import bsrnn_oracle as O
     from oracle import convtasnet_oracle as CT
@@ -210,7 +212,7 @@ def test_unbuilt_variants_fail_loudly():
     cls = get_model("ConvTasNet")
     for kw in (dict(joint_training=True, spk_feat=True), dict(joint_training=False, encoder_type="Deep"),
                dict(joint_training=False, skip_con=True), dict(joint_training=False, norm="BN"),
-               dict(joint_training=False, spk_fuse_type="FiLM"), dict(joint_training=False, causal=True)):
+               dict(joint_training=False, spk_fuse_type="nope"), dict(joint_training=False, causal=True)):
         with pytest.raises(NotImplementedError):
             cls(**kw)
     model = cls(N=16, L=20, B=16, H=32, X=2, R=1, joint_training=False, use_spk_transform=False)

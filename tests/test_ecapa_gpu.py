@@ -76,7 +76,7 @@ def test_astp_and_gate_kernels_match_torch():
     assert rel(out, ref) < 1e-5
     assert rel(xg.grad, xr.grad.reshape(R * T, C)) < 1e-4 and rel(lgg.grad, lr.grad.reshape(R * T, C)) < 1e-4
     # SE gate and the squeeze mean
-    gate = torch.rand(R, C, generator=g)
+    gate = torch.randn(R, C, generator=g)             # signed: the multiply fusion of Conv-TasNet reuses this node
     xr2, gr2 = x.double().requires_grad_(True), gate.double().requires_grad_(True)
     (xr2 * gr2[:, None]).mul(lg.double()).sum().backward()
     xg2, gg2 = x.reshape(R * T, C).to(d).requires_grad_(True), gate.to(d).requires_grad_(True)

@@ -22,7 +22,9 @@ def _grad_norms_match(model, g, tol=2e-2):
         assert abs(float(prm.grad.norm()) - gn) <= tol * gn + floor, (k, float(prm.grad.norm()), gn)
 
 
-@pytest.mark.parametrize("name", ["convtasnet_gln_r2_t1600", "convtasnet_cln_xform_r4_t2000", "spexplus_joint_r4_t1600"])
+@pytest.mark.parametrize("name", ["convtasnet_gln_r2_t1600", "convtasnet_cln_xform_r4_t2000", "spexplus_joint_r4_t1600",
+                                  "convtasnet_multiply_r2_t1600", "convtasnet_additive_cln_r2_t1600",
+                                  "convtasnet_film_r2_t1600", "convtasnet_concat_r2_t1600"])
 def test_convtasnet_host_logic_matches_reference_fixture(name, monkeypatch, golden_dir):
     from wesep_amd.models import get_model
     emu_dev.install(monkeypatch)

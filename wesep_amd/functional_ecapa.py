@@ -230,6 +230,32 @@ class GateFn(torch.autograd.Function):
         gf = _empty(x.device, M, Cc)
         dev.bcast_rows(g, 1.0, T, M, Cc, gf)
         dx, dgf = _empty(x.device, M, Cc), _empty(x.device, M, Cc)
-        dev.maskmul_bwd(dy.contiguous(), x, 0, Cc, gf, M, Cc, dx, 0, Cc, dgf)
+        dy = dy.contiguous()
+        # two plain products (ws_maskmul_bwd folds a ReLU derivative of its mask operand in: a gate may be negative)
+        dev.maskmul_fwd(dy, 0, Cc, gf, M, Cc, dx)
+        dev.maskmul_fwd(dy, 0, Cc, x, M, Cc, dgf)
         dg = dev.chan_sums(dgf, None, None, 1, T, R, Cc)[:, 0].contiguous()
         return dx, dg, None
+
+
+class RowBiasAddFn(torch.autograd.Function):
+    """y[r, t, c] = x[r, t, c] + b[r, c] on [R*T, C] (additive speaker fusion / FiLM shift): the PReLU kernel with
+    slope 1 and a per-row-group bias."""
+
+    @staticmethod
+    def forward(ctx, x, b, geo):
+        _need_cuda(x, "speaker fusion")
+        R, T = geo
+        x, b = x.contiguous(), b.contiguous()
+        M, Cc = x.shape
+        y = _empty(x.device, M, Cc)
+        one = torch.ones(1, device=x.device, dtype=torch.float32)
+        dev.prelu_fwd(x, b, one, M, Cc, T, y)
+        ctx.geo = (R, T, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        R, T, Cc = ctx.geo
+        dy = dy.contiguous()
+        return dy, dev.chan_sums(dy, None, None, 1, T, R, Cc)[:, 0].contiguous(), None

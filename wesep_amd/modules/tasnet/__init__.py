@@ -105,27 +105,91 @@ class Separation(nn.Module):
         return x
 
 
+class _FuseLayer(nn.Module):
+    """SpeakerFuseLayer container on channels-last [R*T', B] (speaker.py:63-125, 3-D branch; FiLM: norm.py:84-137):
+    `fc.linear` (concat: over [x | e]; additive / multiply: e -> B) or `fc.gamma_fcs.0` / `fc.beta_fcs.0`."""
+
+    def __init__(self, embed_dim, feat_dim, fuse_type):
+        super().__init__()
+        from ..common.speaker import LinearLayer
+        self.fuse_type, self.feat_dim = fuse_type, feat_dim
+        if fuse_type == "FiLM":
+            from ...models.dpccn import _FiLM
+            self.fc = _FiLM(feat_dim, embed_dim)
+        else:
+            self.fc = LinearLayer(embed_dim + feat_dim if fuse_type == "concat" else embed_dim, feat_dim)
+
+    def forward(self, x, emb, geo):
+        from ...functional import LinearFn
+        from ... import functional_ecapa as FE
+        from ... import functional_dpccn as FD
+        B = self.feat_dim
+        if self.fuse_type == "FiLM":
+            gm = LinearFn.apply(emb, self.fc.gamma_fcs[0].weight, self.fc.gamma_fcs[0].bias) + 1.0
+            bt = LinearFn.apply(emb, self.fc.beta_fcs[0].weight, self.fc.beta_fcs[0].bias)
+            return FE.RowBiasAddFn.apply(FE.GateFn.apply(x, gm, geo), bt, geo)
+        w, b = self.fc.linear.weight, self.fc.linear.bias
+        if self.fuse_type == "concat":      # Linear(cat[x, e]) = x Wx^T + (e We^T + b): the second term is a per-row bias
+            rb = LinearFn.apply(emb, w[:, B:].contiguous(), b)
+            y = FD.Conv1x1ResFn.apply(x, w[:, :B].contiguous(), torch.zeros_like(b), None)
+            return FE.RowBiasAddFn.apply(y, rb, geo)
+        s = LinearFn.apply(emb, w, b)                                                   # [R, B]
+        return FE.GateFn.apply(x, s, geo) if self.fuse_type == "multiply" else FE.RowBiasAddFn.apply(x, s, geo)
+
+
+class _PReLU(nn.PReLU):
+    def forward(self, x, geo=None):
+        from ... import functional_tfgridnet as FG
+        return FG.PReluFn.apply(x, self.weight)
+
+
 class FuseSeparation(nn.Module):
-    """separation.py:57-186, concatConv + multi_fuse (the SpEx+ configuration)."""
+    """separation.py:57-186 with multi_fuse: concatConv (the SpEx+ configuration: a fusing first block per repeat), or
+    SpeakerFuseLayer (concat / additive / multiply / FiLM) - PReLU - norm - all X blocks per repeat."""
 
     def __init__(self, R, X, B, H, P, norm="gLN", causal=False, skip_con=False, C_embedding=256,
                  spk_fuse_type="concatConv", multi_fuse=True):
         super().__init__()
-        if spk_fuse_type != "concatConv":
-            raise NotImplementedError(f"ConvTasNet spk_fuse_type={spk_fuse_type!r}: only concatConv is built")
+        if spk_fuse_type not in ("concatConv", "concat", "additive", "multiply", "FiLM"):
+            raise NotImplementedError(f"ConvTasNet spk_fuse_type={spk_fuse_type!r}")
         if not multi_fuse:
             raise NotImplementedError("ConvTasNet multi_fuse=False is broken in the reference "
                                       "(separation.py:146-186 replaces the ModuleList); not built")
+        self.spk_fuse_type, self.norm_type, self.B = spk_fuse_type, norm, B
         self.separation = nn.ModuleList([])
         for _ in range(R):
-            self.separation.append(Conv1DBlock4Fuse(spk_embed_dim=C_embedding, in_channels=B, conv_channels=H,
-                                                    kernel_size=P, norm=norm, causal=causal, dilation=1))
-            self.separation.append(Separation(1, X, B, H, P, norm=norm, causal=causal, skip_con=skip_con,
-                                              start_dilation=1))
+            if spk_fuse_type == "concatConv":
+                self.separation.append(Conv1DBlock4Fuse(spk_embed_dim=C_embedding, in_channels=B, conv_channels=H,
+                                                        kernel_size=P, norm=norm, causal=causal, dilation=1))
+                self.separation.append(Separation(1, X, B, H, P, norm=norm, causal=causal, skip_con=skip_con,
+                                                  start_dilation=1))
+            else:
+                self.separation.append(_FuseLayer(C_embedding, B, spk_fuse_type))
+                self.separation.append(_PReLU())
+                self.separation.append(select_norm(norm, B))
+                self.separation.append(Separation(1, X, B, H, P, norm=norm, causal=causal, skip_con=skip_con))
+
+    def _norm(self, m, x, geo):
+        from ... import functional_tfgridnet as FG
+        if self.norm_type == "gLN":
+            return FG.GroupLNFn.apply(x, m.weight.view(-1), m.bias.view(-1), geo)
+        return FG.RowLNFn.apply(x, m.weight, m.bias)
 
     def forward(self, x, spk_embedding, geo):
+        if self.spk_fuse_type == "concatConv":
+            for i, m in enumerate(self.separation):
+                x = m(x, spk_embedding, geo) if i % 2 == 0 else m(x, geo)
+            return x
         for i, m in enumerate(self.separation):
-            x = m(x, spk_embedding, geo) if i % 2 == 0 else m(x, geo)
+            k = i % 4
+            if k == 0:
+                x = m(x, spk_embedding, geo)
+            elif k == 1:
+                x = m(x)
+            elif k == 2:
+                x = self._norm(m, x, geo)
+            else:
+                x = m(x, geo)
         return x
 
 
