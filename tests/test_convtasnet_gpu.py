@@ -159,7 +159,8 @@ def _build(cfg_kw, seed, d):
     params = CT.synth_params(cfg, seed)
     model = get_model("ConvTasNet")(
         N=cfg.N, L=cfg.L, B=cfg.B, H=cfg.H, P=cfg.P, X=cfg.X, R=cfg.R, spk_emb_dim=cfg.spk_emb_dim,
-        norm=cfg.norm, multi_fuse=cfg.multi_fuse, use_spk_transform=cfg.use_spk_transform, joint_training=False)
+        norm=cfg.norm, spk_fuse_type=cfg.spk_fuse_type, multi_fuse=cfg.multi_fuse,
+        use_spk_transform=cfg.use_spk_transform, joint_training=False)
     model.load_state_dict(params, strict=True)
     return cfg, params, model.to(d)
 
