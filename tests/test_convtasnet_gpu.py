@@ -204,8 +204,11 @@ def test_model_matches_oracle_and_reference_fixture(name, golden_dir):
     for k, prm in model.named_parameters():
         assert prm.grad is not None, k
         err = float((prm.grad.detach().cpu().double() - p[k].grad.double()).norm())
-        assert err <= GRAD_TOL * float(p[k].grad.norm()) + floor, (k, err, float(p[k].grad.norm()))
-        assert abs(float(prm.grad.norm()) - float(g["gnorm/" + k])) <= GRAD_TOL * float(g["gnorm/" + k]) + floor, k
+        # a PReLU slope's gradient is ONE scalar: a cancelling sum of dy * x over every negative element of the layer
+        # (split-bf16 vs fp32 moves it by up to 6e-3 of its value in the multiply-fusion fixture); tensors: 2e-3
+        tol = 1e-2 if prm.numel() == 1 else GRAD_TOL
+        assert err <= tol * float(p[k].grad.norm()) + floor, (k, err, float(p[k].grad.norm()))
+        assert abs(float(prm.grad.norm()) - float(g["gnorm/" + k])) <= tol * float(g["gnorm/" + k]) + floor, k
 
 
 def test_unbuilt_variants_fail_loudly():

@@ -4,10 +4,10 @@ mode (`joint_training=False`: `forward(wav [R, T], emb [R, E])`, BASELINE.json c
 joint mode (`joint_training=True, spk_feat=False`: `forward(wav, enrollment wav [R, Tw])`, speaker encoder
 `ResNet4SpExplus` on the shared encoder, optional multi-task speaker logits as a fourth output).  `forward` is a chain of C-ABI launches (wesep_amd/functional_tasnet.py).
 
-Built: Multi encoder / decoder, concatConv fusion with multi_fuse, gLN / cLN, ReLU masks, optional
-SpeakerTransform.  Everything else of the reference constructor raises NotImplementedError (see
-DESIGN.md): Deep / plain encoders, skip connections, causal blocks, norm='BN' in the separator, other
-fusion types, and joint training with a wespeaker encoder on fbank features."""
+Built: Multi encoder / decoder, every speaker-fusion type (concatConv / concat / additive / multiply / FiLM) with
+multi_fuse, gLN / cLN, ReLU masks, optional SpeakerTransform.  Everything else of the reference constructor raises
+NotImplementedError: Deep / plain encoders, skip connections, causal blocks, norm='BN' in the
+separator, and joint training with a wespeaker encoder on fbank features."""
 import torch
 import torch.nn as nn
 
