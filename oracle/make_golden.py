@@ -205,6 +205,8 @@ TFGRIDNET_CASES = {
                                              use_spk_transform=True), 2, 1280, 42),
     "tfgridnet_ks1_film_r2_t1280": (dict(n_layers=2, lstm_hidden_units=16, emb_dim=8, emb_ks=1, emb_hs=1,
                                          attn_n_head=2, attn_approx_qk_dim=260, spk_fuse_type="FiLM"), 2, 1280, 43),
+    "tfgridnet_ks1_concat_r2_t1280": (dict(n_layers=2, lstm_hidden_units=16, emb_dim=8, emb_ks=1, emb_hs=1,
+                                           attn_n_head=2, attn_approx_qk_dim=260, spk_fuse_type="concat"), 2, 1280, 44),
 }
 
 

@@ -57,8 +57,8 @@ def param_shapes(cfg: TFGridNetConfig) -> Dict[str, tuple]:
     if cfg.spk_fuse_type == "FiLM":            # norm.py:84-137
         s["spk_fuse.fc.gamma_fcs.0.weight"], s["spk_fuse.fc.gamma_fcs.0.bias"] = (Fq, E), (Fq,)
         s["spk_fuse.fc.beta_fcs.0.weight"], s["spk_fuse.fc.beta_fcs.0.bias"] = (Fq, E), (Fq,)
-    elif cfg.spk_fuse_type in ("multiply", "additive"):
-        s["spk_fuse.fc.linear.weight"] = (Fq, E)
+    elif cfg.spk_fuse_type in ("multiply", "additive", "concat"):
+        s["spk_fuse.fc.linear.weight"] = (Fq, E + Fq if cfg.spk_fuse_type == "concat" else E)
         s["spk_fuse.fc.linear.bias"] = (Fq,)
     else:
         raise NotImplementedError(cfg.spk_fuse_type)
@@ -211,11 +211,14 @@ def tfgridnet_forward(p: Dict[str, torch.Tensor], cfg: TFGridNetConfig, wav: tor
     if cfg.spk_fuse_type == "FiLM":
         gm = F.linear(emb, p["spk_fuse.fc.gamma_fcs.0.weight"], p["spk_fuse.fc.gamma_fcs.0.bias"]).view(B, 1, 1, nF)
         bt = F.linear(emb, p["spk_fuse.fc.beta_fcs.0.weight"], p["spk_fuse.fc.beta_fcs.0.bias"]).view(B, 1, 1, nF)
-    else:
+    elif cfg.spk_fuse_type != "concat":
         t = F.linear(emb, p["spk_fuse.fc.linear.weight"], p["spk_fuse.fc.linear.bias"]).view(B, 1, 1, nF)
     for i in range(cfg.n_layers):
         if cfg.spk_fuse_type == "FiLM":
             h = (1 + gm) * h + bt
+        elif cfg.spk_fuse_type == "concat":     # speaker.py:95-101 on the [B, C, F, T] view: Linear over cat[x, e] along F
+            ee = emb.view(B, 1, 1, -1).expand(-1, h.shape[1], h.shape[2], -1)                      # [B, C, T, E]
+            h = F.linear(torch.cat([h, ee], 3), p["spk_fuse.fc.linear.weight"], p["spk_fuse.fc.linear.bias"])
         else:
             h = h * t if cfg.spk_fuse_type == "multiply" else h + t
         h = gridnet_block(p, cfg, f"blocks.{i}.", h)

@@ -137,7 +137,8 @@ def test_implicit_conv2d_and_transpose_match_torch(Cin, Cout, k, sh, sw):
         assert rel(dbg, br.grad) < 4e-5, ("db", transpose)
 
 
-@pytest.mark.parametrize("name", ["dpccn_multiply_r2_t4480", "dpccn_additive_xform_r2_t4608", "dpccn_film_r2_t4352"])
+@pytest.mark.parametrize("name", ["dpccn_multiply_r2_t4480", "dpccn_additive_xform_r2_t4608", "dpccn_film_r2_t4352",
+                                  "dpccn_concat_xform_r2_t4352"])
 def test_dpccn_model_matches_reference_fixture(name, golden_dir):
     from oracle import bsrnn_oracle as O
     from oracle import dpccn_oracle as DP
@@ -170,7 +171,7 @@ def test_dpccn_model_matches_reference_fixture(name, golden_dir):
 
 def test_dpccn_unbuilt_variants_fail_loudly():
     from wesep_amd.models import get_model
-    for kw in (dict(joint_training=False, spk_fuse_type="concat"), dict(joint_training=False, causal=True),
+    for kw in (dict(joint_training=False, spk_fuse_type="nope"), dict(joint_training=False, causal=True),
                dict(joint_training=False, stride2=(1, 1))):
         with pytest.raises(NotImplementedError):
             get_model("DPCCN")(**kw)

@@ -31,7 +31,8 @@ def _run(name, monkeypatch, golden_dir):
     return model, est, loss, g
 
 
-@pytest.mark.parametrize("name", ["dpccn_multiply_r2_t4480", "dpccn_additive_xform_r2_t4608", "dpccn_film_r2_t4352"])
+@pytest.mark.parametrize("name", ["dpccn_multiply_r2_t4480", "dpccn_additive_xform_r2_t4608", "dpccn_film_r2_t4352",
+                                  "dpccn_concat_xform_r2_t4352"])
 def test_dpccn_host_logic_matches_reference_fixture(name, monkeypatch, golden_dir):
     model, est, loss, g = _run(name, monkeypatch, golden_dir)
     ref = g["est"]

@@ -36,7 +36,7 @@ def test_softmax_rows_matches_torch():
 
 
 @pytest.mark.parametrize("name", ["tfgridnet_ks4_r2_t1600", "tfgridnet_ks1_additive_r2_t1280",
-                                  "tfgridnet_ks1_film_r2_t1280"])
+                                  "tfgridnet_ks1_film_r2_t1280", "tfgridnet_ks1_concat_r2_t1280"])
 def test_tfgridnet_model_matches_reference_fixture(name, golden_dir):
     from oracle import bsrnn_oracle as O
     from oracle import tfgridnet_oracle as TG
@@ -70,7 +70,7 @@ def test_tfgridnet_model_matches_reference_fixture(name, golden_dir):
 def test_tfgridnet_unbuilt_variants_fail_loudly():
     from wesep_amd.models import get_model
     for kw in (dict(joint_training=False, n_imics=2), dict(joint_training=False, n_srcs=2),
-               dict(joint_training=False, spk_fuse_type="concat"), dict(joint_training=False, lstm_hidden_units=320)):
+               dict(joint_training=False, spk_fuse_type="nope"), dict(joint_training=False, lstm_hidden_units=320)):
         with pytest.raises(NotImplementedError):
             get_model("TFGridNet")(**kw)
 

@@ -118,16 +118,33 @@ class _Fuse(nn.Module):
 
     def __init__(self, embed_dim, feat_dim, fuse_type):
         super().__init__()
-        if fuse_type not in ("multiply", "additive", "FiLM"):
-            raise NotImplementedError(f"DPCCN spk_fuse_type={fuse_type!r}: multiply / additive / FiLM are built")
+        if fuse_type not in ("multiply", "additive", "FiLM", "concat"):
+            raise NotImplementedError(f"DPCCN spk_fuse_type={fuse_type!r}")
         self.fuse_type = fuse_type
-        self.fc = _FiLM(feat_dim, embed_dim) if fuse_type == "FiLM" else LinearLayer(embed_dim, feat_dim)
+        if fuse_type == "FiLM":
+            self.fc = _FiLM(feat_dim, embed_dim)
+        else:
+            self.fc = LinearLayer(embed_dim + feat_dim if fuse_type == "concat" else embed_dim, feat_dim)
 
 
 def fuse_bins(fuse, x, emb, geo):
     """SpeakerFuseLayer on x [B*T*F, C] with one factor / offset per (row, frequency bin) (speaker.py:102-125 on the
     [B, C, F, T] view; FiLM: norm.py:116-134, x = (1 + gamma(e)) x + beta(e))."""
     B, T, Fq = geo
+    if fuse.fuse_type == "concat":
+        # Linear over the FREQUENCY axis of cat[x, e] (speaker.py:95-101): out[b, c, :, t] = Wx x[b, c, :, t] + (We e + bias).
+        # The contraction index is the spatial axis of the channels-last layout, so the tile is transposed to rows
+        # (b, t, c) x F (zero-padded to a multiple of 4 floats), one GEMM + a per-row bias, and transposed back.
+        from .. import functional_ecapa as FE
+        C = x.shape[1]
+        Fp = -(-Fq // 4) * 4
+        w, b = fuse.fc.linear.weight, fuse.fc.linear.bias
+        xt = torch.nn.functional.pad(x.view(B, T, Fq, C).permute(0, 1, 3, 2).reshape(B * T * C, Fq), (0, Fp - Fq))
+        wx = torch.nn.functional.pad(w[:, :Fq], (0, Fp - Fq, 0, Fp - Fq))
+        y = FD.Conv1x1ResFn.apply(xt.contiguous(), wx.contiguous(), torch.zeros(Fp, device=x.device), None)
+        rb = torch.nn.functional.pad(F_.LinearFn.apply(emb, w[:, Fq:].contiguous(), b), (0, Fp - Fq))
+        y = FE.RowBiasAddFn.apply(y, rb, (B, T * C))
+        return y[:, :Fq].reshape(B, T, C, Fq).permute(0, 1, 3, 2).reshape(B * T * Fq, C).contiguous()
     if fuse.fuse_type == "FiLM":
         gm = F_.LinearFn.apply(emb, fuse.fc.gamma_fcs[0].weight, fuse.fc.gamma_fcs[0].bias) + 1.0    # [B, F]
         bt = F_.LinearFn.apply(emb, fuse.fc.beta_fcs[0].weight, fuse.fc.beta_fcs[0].bias)

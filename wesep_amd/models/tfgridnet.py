@@ -170,11 +170,14 @@ class GridNetBlock(nn.Module):
 class _Fuse(nn.Module):
     def __init__(self, embed_dim, feat_dim, fuse_type):
         super().__init__()
-        if fuse_type not in ("multiply", "additive", "FiLM"):
-            raise NotImplementedError(f"TF-GridNet spk_fuse_type={fuse_type!r}: multiply / additive / FiLM are built")
+        if fuse_type not in ("multiply", "additive", "FiLM", "concat"):
+            raise NotImplementedError(f"TF-GridNet spk_fuse_type={fuse_type!r}")
         self.fuse_type = fuse_type
         from .dpccn import _FiLM
-        self.fc = _FiLM(feat_dim, embed_dim) if fuse_type == "FiLM" else LinearLayer(embed_dim, feat_dim)
+        if fuse_type == "FiLM":
+            self.fc = _FiLM(feat_dim, embed_dim)
+        else:
+            self.fc = LinearLayer(embed_dim + feat_dim if fuse_type == "concat" else embed_dim, feat_dim)
 
 
 class TFGridNet(nn.Module):
