@@ -133,6 +133,40 @@ def test_dry_run_launch_plan_joint_model(tmp_path, spk_model):
 
 
 @needs_no_gpu
+@pytest.mark.parametrize("spk_model,emb_bn", [("ECAPA_TDNN_GLOB_c512", False), ("ECAPA_TDNN_c512", True),
+                                              ("ECAPA_TDNN_GLOB_c1024", False)])
+def test_dry_run_launch_plan_ecapa_joint_model(tmp_path, spk_model, emb_bn):
+    """The layout of the reference's published `bsrnn_ecapa_vox1` model (wesep/cli/hub.py:86-95): a pBSRNN with the
+    wespeaker ECAPA-TDNN speaker encoder exports to the native runtime and every launch of its plan (dilated Conv1d as
+    implicit-patch GEMMs, Res2Net branches, SE gates, attentive statistics pooling) passes argument validation."""
+    path = str(tmp_path / "e.wsw")
+    export_engine(_model(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                         spk_emb_dim=192, joint_training=True, spk_feat=True, spk_model=spk_model,
+                         spk_args=dict(feat_dim=80, embed_dim=192, pooling_func="ASTP", emb_bn=emb_bn)), path)
+    eng = E.Engine(path, dry_run=True)
+    assert eng.info("spk_kind") == 1 and eng.info("spk_glob") == int("GLOB" in spk_model)
+    assert eng.info("spk_channels") == (1024 if "1024" in spk_model else 512) and eng.info("spk_emb_bn") == int(emb_bn)
+    counts = set()
+    for R, Te in ((2, 98), (1, 301), (4, 37)):
+        eng.separate(np.zeros((R, 16000), np.float32), np.zeros((R, Te, 80), np.float32), E.ENROLL_FBANK)
+        counts.add(eng.info("n_launches"))
+    assert len(counts) == 1
+    eng.separate(np.zeros((2, 16000), np.float32), np.zeros((2, 24001), np.float32), E.ENROLL_WAVE)
+    assert eng.info("n_launches") > counts.pop()
+    with pytest.raises(E.WesepHipError, match="does not fit"):
+        eng.separate(np.zeros((2, 16000), np.float32), np.zeros((2, 192), np.float32), E.ENROLL_EMBEDDING)
+    eng.close()
+
+
+def test_export_refuses_speaker_encoders_without_a_launch_plan(tmp_path):
+    with pytest.raises(NotImplementedError, match="no launch plan"):
+        export_engine(_model(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                             joint_training=True, spk_feat=True, spk_model="ResNet18",
+                             spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=True)),
+                      str(tmp_path / "x.wsw"))
+
+
+@needs_no_gpu
 def test_dry_run_raw_audio_joint_model(tmp_path):
     """spk_feat = False (bsrnn_multi_optim.yaml): the in-model PreEmphasis + MelSpectrogram front-end runs in the
     engine from the model's own window / filterbank buffers; a `BSRNN_Multi` checkpoint exports like a `BSRNN`."""

@@ -62,11 +62,11 @@ def test_engine_matches_python_model_and_oracle(tmp_path, kw, seed):
     eng.close()
 
 
-def _joint(tmp_path, spk_model, d, seed=5):
+def _joint(tmp_path, spk_model, d, seed=5, spk_args=SPK_ARGS, **kw):
     from wesep_amd.models import get_model
     torch.manual_seed(seed)
     model = get_model("BSRNN")(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
-                               joint_training=True, spk_model=spk_model, spk_feat=True, spk_args=SPK_ARGS)
+                               joint_training=True, spk_model=spk_model, spk_feat=True, spk_args=spk_args, **kw)
     with torch.no_grad():                                   # non-trivial BatchNorm running statistics
         for name, buf in model.named_buffers():
             if name.endswith("running_mean"):
@@ -103,6 +103,32 @@ def test_engine_joint_model_fbank_and_waveform_enrollment(tmp_path, spk_model):
     m = (mix16.float() / 32768).repeat(2, 1)
     en = (e16[:, :29000].float() / 32768).contiguous()
     assert rel(out, eng.separate(m.numpy(), en.numpy(), E.ENROLL_WAVE)) < 1e-6
+    eng.close()
+
+
+@pytest.mark.parametrize("spk_model,emb_bn", [("ECAPA_TDNN_GLOB_c512", False), ("ECAPA_TDNN_c512", True)])
+def test_engine_ecapa_joint_model(tmp_path, spk_model, emb_bn):
+    """The published `bsrnn_ecapa_vox1` layout (wesep/cli/hub.py:86-95): pBSRNN + wespeaker ECAPA-TDNN through the native
+    runtime vs the Python module tree in eval mode (same kernels), fbank and raw-waveform enrollment, ragged lengths."""
+    from wesep_amd.utils.funcs import apply_cmvn, compute_fbank
+    d = _cuda()
+    model, eng = _joint(tmp_path, spk_model, d, seed=6, spk_emb_dim=192,
+                        spk_args=dict(feat_dim=80, embed_dim=192, pooling_func="ASTP", emb_bn=emb_bn))
+    assert eng.info("spk_kind") == 1
+    g = torch.Generator().manual_seed(4)
+    for R, Te in ((2, 120), (3, 77)):
+        wav = 0.1 * torch.randn(R, 12000, generator=g)
+        fbank = torch.randn(R, Te, 80, generator=g)
+        fbank = fbank - fbank.mean(1, keepdim=True)
+        with torch.no_grad():
+            ref, emb = model(wav.to(d), fbank.to(d))
+        assert float(emb.std()) > 1e-3                     # the embedding is alive (not a constant of the biases)
+        assert rel(eng.separate(wav.numpy(), fbank.numpy(), E.ENROLL_FBANK), ref) < 1e-4, (R, Te)
+    enroll = 0.1 * torch.randn(2, 20001, generator=g)
+    wav = 0.1 * torch.randn(2, 12000, generator=g)
+    with torch.no_grad():
+        ref = model(wav.to(d), apply_cmvn(compute_fbank(enroll.to(d), dither=0.0)))[0]
+    assert rel(eng.separate(wav.numpy(), enroll.numpy(), E.ENROLL_WAVE), ref) < 1e-4
     eng.close()
 
 

@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
 cd /root/repo
-timeout 900 python -m pytest tests/test_dpccn_gpu.py tests/test_tfgridnet_gpu.py -m gpu -x -q -k "fixture or unbuilt" 2>&1 | grep -v amdgpu.ids | tail -4 | cut -c1-260 | tee gpurun_out/t1.log
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -3 | cut -c1-700 | tee gpurun_out/torchrun1.log

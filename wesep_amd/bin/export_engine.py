@@ -33,9 +33,19 @@ def engine_meta(model):
     if model.joint_training:
         meta["spk_feat"] = int(bool(model.spk_feat))      # False: the in-model front-end's buffers are exported too
         spk = model.spk_model
-        for i, layer in enumerate((spk.layer1, spk.layer2, spk.layer3, spk.layer4)):
-            meta[f"spk_blocks{i}"] = len(layer)
-        meta["feat_dim"] = int(spk.seg_1.weight.shape[1] // (2 * 32 * 8)) * 8
+        if type(spk).__name__ == "ECAPA_TDNN":            # wespeaker ECAPA-TDNN (the published bsrnn_ecapa_vox1 model)
+            meta.update(spk_kind=1, spk_channels=spk.layer1.conv.out_channels, feat_dim=spk.layer1.conv.in_channels,
+                        spk_glob=int(spk.pool.linear1.in_channels == 3 * spk.pool.linear2.out_channels),
+                        spk_emb_bn=int(isinstance(getattr(spk, "bn2", None), torch.nn.BatchNorm1d)))
+        elif hasattr(spk, "seg_1") and type(spk.layer1[0]).__name__ == "BasicBlock" and not getattr(spk, "two_emb_layer", False):
+            meta["spk_kind"] = 0
+            for i, layer in enumerate((spk.layer1, spk.layer2, spk.layer3, spk.layer4)):
+                meta[f"spk_blocks{i}"] = len(layer)
+            meta["feat_dim"] = int(spk.seg_1.weight.shape[1] // (2 * 32 * 8)) * 8
+        else:
+            raise NotImplementedError(f"export_engine: speaker encoder {type(spk).__name__} (Bottleneck / two_emb_layer "
+                                      "ResNets included) has no launch plan in the native runtime; BasicBlock ResNets "
+                                      "and ECAPA-TDNN do")
     return meta
 
 
