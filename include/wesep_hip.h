@@ -523,6 +523,14 @@ int ws_rowbias_act_fwd(const float* x, const float* rb, long long rows, int C, i
                        void* stream);
 int ws_act_bwd(const float* y, const float* dy, long long n, int act, float* dx, void* stream);
 
+/* Segment pooling of the CAM++ context-aware mask (wespeaker `CAMPPlus`, the recipe's alternative speaker encoder:
+ * wesep/models/bsrnn.py:217 via examples/librimix/tse/v2/confs/bsrnn.yaml:66-74; F.avg_pool1d(seg_len, ceil_mode) expanded
+ * back over the frames) on channels-last [R][T][C], nseg = ceil(T / seg_len), last segment of an utterance shorter:
+ *   ws_seg_sums : out[r][s][c] = sum_{t in segment s} a[r][t][c] (* b[r][t][c] when b)
+ *   ws_seg_scale: out[r][t][c] = (x ? x[r][t][c] : 1) * m[r][t / seg_len][c]            (out may alias x)          */
+int ws_seg_sums(const float* a, const float* b, int R, int T, int C, int seg_len, float* out, void* stream);
+int ws_seg_scale(const float* x, const float* m, int R, int T, int C, int seg_len, float* out, void* stream);
+
 /* ---- in-model enrollment front-end (bsrnn.py:231-242,343-350) -------------------
  * out[r][j] = y[reflect(j - pad)], y = pre-emphasis of x (speaker.py:10-23), row stride ldo >= T + 2*pad:
  * the centred, reflect-padded signal whose hop-strided row views are the STFT frames.                     */

@@ -586,7 +586,27 @@ def act_bwd(y, dy, act, dx):
     dx.reshape(-1)[:] = (dy * ((1 - y * y) if act == 1 else y * (1 - y))).reshape(-1)
 
 
-EMULATED = [astp_fwd, astp_bwd, rowbias_act_fwd, act_bwd, conv_wgrad, gemm_nt, gemm_tn, reduce_slabs, transpose, affine_fwd, chan_sums, im2col_hw, col2im_hw, elu_fwd, elu_bwd,
+def _seg_index(T, seg_len):
+    return torch.arange(T) // seg_len
+
+
+def seg_sums(a, b, R, T, Cc, seg_len, out):
+    v = a.reshape(R, T, Cc) * (b.reshape(R, T, Cc) if b is not None else 1.0)
+    nseg = -(-T // seg_len)
+    o = torch.zeros(R, nseg, Cc)
+    o.index_add_(1, _seg_index(T, seg_len), v)
+    out.reshape(R, nseg, Cc)[:] = o
+
+
+def seg_scale(x, m, R, T, Cc, seg_len, out):
+    nseg = -(-T // seg_len)
+    v = m.reshape(R, nseg, Cc)[:, _seg_index(T, seg_len)]
+    if x is not None:
+        v = v * x.reshape(R, T, Cc)
+    out.reshape(R, T, Cc)[:] = v
+
+
+EMULATED = [seg_sums, seg_scale, astp_fwd, astp_bwd, rowbias_act_fwd, act_bwd, conv_wgrad, gemm_nt, gemm_tn, reduce_slabs, transpose, affine_fwd, chan_sums, im2col_hw, col2im_hw, elu_fwd, elu_bwd,
             inorm_fwd, inorm_bwd, dwconv_fwd, dwconv_bwd, avgpool_fwd, avgpool_bwd, bilinear_fwd, bilinear_bwd,
             scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum, lstm_pack, lstm_fwd, lstm_bwd,
             group_stats, flat_stats, gn_bwd_reduce, norm_ab, norm_bwd_apply_cl, prelu_fwd, prelu_bwd, softmax_rows_fwd,
@@ -603,7 +623,9 @@ def install(monkeypatch):
     import wesep_amd.functional_resnet as fr
     import wesep_amd.functional_tfgridnet as fg
     import wesep_amd.functional_ecapa as fe
+    import wesep_amd.functional_campplus as fc
     monkeypatch.setattr(fe, "_need_cuda", lambda t, who: None)
+    monkeypatch.setattr(fc, "_need_cuda", lambda t, who: None)
     for fn in EMULATED:
         monkeypatch.setattr(dev, fn.__name__, fn)
     for mod in (f0, fd, ft, fg, fr):

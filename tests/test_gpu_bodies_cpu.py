@@ -38,3 +38,16 @@ def test_bsrnn_multi_gpu_test_bodies(emu, monkeypatch, golden_dir):
     monkeypatch.setattr(t, "_cuda", lambda: torch.device("cpu"))
     for name in sorted(t.MULTI_CASES):
         t.test_bsrnn_multi_two_pass_forward_and_gradients(name, golden_dir)
+
+
+def test_campplus_gpu_test_bodies(emu, monkeypatch):
+    """tests/test_campplus_gpu.py (CAM++ speaker encoder) on the emulation, as written (a subset of the parametrisations)."""
+    import tests.test_campplus_gpu as t
+    monkeypatch.setattr(t, "_cuda", lambda: torch.device("cpu"))
+    for args in ((3, 230, 32, 100), (2, 100, 8, 100), (2, 301, 12, 7)):
+        t.test_segment_kernels_match_torch(*args)
+    for args in ((320, 128, 5, 1, 2, False), (128, 32, 3, 2, 1, False), (64, 32, 1, 1, 1, True), (32, 16, 3, 1, 2, True)):
+        t.test_conv1d_matches_torch(*args)
+    t.test_bn_act_and_mel_strided_conv_block_match_torch()
+    t.test_campplus_matches_oracle(monkeypatch)
+    t.test_bsrnn_joint_training_with_campplus_runs_and_matches_oracle()

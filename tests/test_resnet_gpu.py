@@ -191,7 +191,7 @@ def test_bsrnn_joint_training_with_resnet34_runs_and_matches_oracle():
         get_model("BSRNN")(joint_training=True, spk_model="ResNet34", spk_feat=False, feat_type="other",
                            spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
     with pytest.raises(NotImplementedError):
-        get_model("BSRNN")(joint_training=True, spk_model="CAMPPlus", spk_feat=True,
+        get_model("BSRNN")(joint_training=True, spk_model="XVEC", spk_feat=True,
                            spk_args=dict(feat_dim=80, embed_dim=192, pooling_func="TSTP"))
 
 

@@ -175,6 +175,8 @@ _SIGS = {
     "ws_astp_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, C.c_float, _p, _p, _p]),
     "ws_rowbias_act_fwd": (_i, [_p, _p, _ll, _i, _i, _i, _p, _p]),
     "ws_act_bwd": (_i, [_p, _p, _ll, _i, _p, _p]),
+    "ws_seg_sums": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "ws_seg_scale": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "ws_tstp_fwd": (_i, [_p, _i, _i, _i, _i, C.c_float, _p, _p]),
     "ws_tstp_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "ws_im2col_hw": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _p, _p]),

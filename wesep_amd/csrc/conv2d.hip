@@ -307,6 +307,76 @@ extern "C" int ws_act_bwd(const float* y, const float* dy, long long n, int act,
   return ws_check_launch("ws_act_bwd");
 }
 
+// Segment pooling of CAM++'s context-aware mask (wespeaker CAMLayer.seg_pooling: F.avg_pool1d(seg_len, ceil_mode) expanded
+// back over its frames; wesep/models/bsrnn.py:217 via the recipe's `CAMPPlus` alternative, bsrnn.yaml:66-74) on
+// channels-last [R][T][C], nseg = ceil(T / seg_len), the last segment of each utterance may be shorter:
+//   out[r][s][c] = sum_{t in segment s} a[r][t][c] (* b[r][t][c])                       (ws_seg_sums)
+//   out[r][t][c] = (x ? x[r][t][c] : 1) * m[r][t / seg_len][c]                          (ws_seg_scale)
+// The pair is the pooling and its adjoint, and the mask product with both of its gradients.
+__global__ void seg_sums_kernel(const float* __restrict__ a, const float* __restrict__ b, int R, int T, int C, int seg_len,
+                                int nseg, float* __restrict__ out) {
+  const int c4 = C / 4;
+  const long long total = (long long)R * nseg * c4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % c4);
+    const long long rs = i / c4;
+    const int sgm = (int)(rs % nseg);
+    const long long r = rs / nseg;
+    const int t0 = sgm * seg_len, t1 = min(T, t0 + seg_len);
+    const float* pa = a + (r * T + t0) * C + q * 4;
+    const float* pb = b ? b + (r * T + t0) * C + q * 4 : nullptr;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int t = t0;
+    for (; t + 1 < t1; t += 2) {
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(pa), v1 = *reinterpret_cast<const f32x4*>(pa + C);
+      if (pb) {
+        v0 *= *reinterpret_cast<const f32x4*>(pb);
+        v1 *= *reinterpret_cast<const f32x4*>(pb + C);
+        pb += 2 * C;
+      }
+      acc0 += v0;
+      acc1 += v1;
+      pa += 2 * C;
+    }
+    if (t < t1) {
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(pa);
+      if (pb) v0 *= *reinterpret_cast<const f32x4*>(pb);
+      acc0 += v0;
+    }
+    *reinterpret_cast<f32x4*>(out + rs * C + q * 4) = acc0 + acc1;
+  }
+}
+__global__ void seg_scale_kernel(const float* __restrict__ x, const float* __restrict__ m, int R, int T, int C, int seg_len,
+                                 int nseg, float* __restrict__ out) {
+  const int c4 = C / 4;
+  const long long total = (long long)R * T * c4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % c4);
+    const long long row = i / c4;
+    const int t = (int)(row % T);
+    const long long r = row / T;
+    f32x4 v = *reinterpret_cast<const f32x4*>(m + (r * nseg + t / seg_len) * C + q * 4);
+    if (x) v *= *reinterpret_cast<const f32x4*>(x + row * C + q * 4);
+    *reinterpret_cast<f32x4*>(out + row * C + q * 4) = v;
+  }
+}
+extern "C" int ws_seg_sums(const float* a, const float* b, int R, int T, int C, int seg_len, float* out, void* stream) {
+  WS_REQUIRE(a && out && R > 0 && T > 0 && C > 0 && C % 4 == 0 && seg_len > 0, "ws_seg_sums: bad args (C %% 4)");
+  const int nseg = (T + seg_len - 1) / seg_len;
+  hipLaunchKernelGGL(seg_sums_kernel, dim3(cv_blocks((long long)R * nseg * (C / 4))), dim3(256), 0, (hipStream_t)stream, a,
+                     b, R, T, C, seg_len, nseg, out);
+  return ws_check_launch("ws_seg_sums");
+}
+extern "C" int ws_seg_scale(const float* x, const float* m, int R, int T, int C, int seg_len, float* out, void* stream) {
+  WS_REQUIRE(m && out && R > 0 && T > 0 && C > 0 && C % 4 == 0 && seg_len > 0, "ws_seg_scale: bad args (C %% 4)");
+  const int nseg = (T + seg_len - 1) / seg_len;
+  hipLaunchKernelGGL(seg_scale_kernel, dim3(cv_blocks((long long)R * T * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, m,
+                     R, T, C, seg_len, nseg, out);
+  return ws_check_launch("ws_seg_scale");
+}
+
 // ---------------------------------------------------------------------------------------------
 // In-model enrollment front-end (wesep/models/bsrnn.py:231-242,343-350):
 // PreEmphasis (wesep/modules/common/speaker.py:10-23) + the framing half of

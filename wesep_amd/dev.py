@@ -986,6 +986,20 @@ def act_bwd(y, dy, act: int, dx):
     _call("ws_act_bwd", _p(y), _p(dy), y.numel(), act, _p(dx))
 
 
+def seg_sums(a, b, R: int, T: int, Cc: int, seg_len: int, out):
+    """out [R, ceil(T / seg_len), C] = per-segment sums of a (* b) over the frames of channels-last [R*T, C]."""
+    for n, t in (("a", a), ("b", b), ("out", out)):
+        _chk(t, n)
+    _call("ws_seg_sums", _p(a), _p(b), R, T, Cc, seg_len, _p(out))
+
+
+def seg_scale(x, m, R: int, T: int, Cc: int, seg_len: int, out):
+    """out[r, t] = (x[r, t] if x is not None else 1) * m[r, t // seg_len]."""
+    for n, t in (("x", x), ("m", m), ("out", out)):
+        _chk(t, n)
+    _call("ws_seg_scale", _p(x), _p(m), R, T, Cc, seg_len, _p(out))
+
+
 # ---- in-model enrollment front-end (conv2d.hip) ---------------------------------------------------------
 def preemph_pad(x, R: int, T: int, pad: int, ldo: int, coef: float, out):
     _chk(x, "x")

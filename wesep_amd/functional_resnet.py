@@ -14,7 +14,8 @@ from .functional_tasnet import _gemm, _transposed, _wgrad
 
 
 class ConvBnActFn(torch.autograd.Function):
-    """x [R*H*W, Cin] -> act(BN(conv2d(x, w)) (+ res)) [R*Ho*Wo, Cout]; act = ReLU or identity."""
+    """x [R*H*W, Cin] -> act(BN(conv2d(x, w)) (+ res)) [R*Ho*Wo, Cout]; act = ReLU or identity.  `stride` of geo: an int,
+    or (sh, sw) for the mel-axis-only strides of CAM++'s FCM head (implicit-patch path, Cin % 4 == 0)."""
 
     @staticmethod
     def forward(ctx, x, res, geo, w, gamma, beta, rm, rv):
@@ -22,7 +23,10 @@ class ConvBnActFn(torch.autograd.Function):
         R, H, W, stride, relu, training = geo
         Cout, Cin, k, _ = w.shape
         pad = k // 2
-        Ho, Wo = dev.conv_out(H, k, stride, pad), dev.conv_out(W, k, stride, pad)
+        sh, sw = stride if isinstance(stride, tuple) else (stride, stride)
+        if sh != sw and not (FC.implicit_ok(Cin) and FC.implicit_ok(Cout) and max(sh, sw) <= 2):
+            raise L.WesepHipError("ConvBnActFn: unequal strides need channel counts that are multiples of 4, strides <= 2")
+        Ho, Wo = dev.conv_out(H, k, sh, pad), dev.conv_out(W, k, sw, pad)
         M = R * Ho * Wo
         x = x.contiguous()
         d = x.device
@@ -32,9 +36,9 @@ class ConvBnActFn(torch.autograd.Function):
         W2[:, :Kk] = w.permute(0, 2, 3, 1).reshape(Cout, Kk)     # column (ky*k + kx)*Cin + c, like the patches
         if FC.implicit_ok(Cin):
             # the patch matrix stays implicit in the GEMM's operand loader (functional_conv): nothing is unfolded
-            c = FC.conv2d_fwd(x, R, H, W, Cin, W2, Cout, k, stride, stride, pad)
+            c = FC.conv2d_fwd(x, R, H, W, Cin, W2, Cout, k, sh, sw, pad)
         else:                                                   # single-channel first layer: 12-column patch rows
-            patches = ConvBnActFn._patches(x, R, H, W, Cin, k, stride, pad, M, ldp)
+            patches = ConvBnActFn._patches(x, R, H, W, Cin, k, sh, pad, M, ldp)
             c = _gemm(patches, M, ldp, W2, Cout)
             del patches
         st = _empty(d, 2, Cout)
@@ -47,7 +51,7 @@ class ConvBnActFn(torch.autograd.Function):
         u, y = _empty(d, M, Cout), _empty(d, M, Cout)
         dev.bn_prelu_fwd(c, st, gamma, beta, res.contiguous() if res is not None else None, slope, M, Cout, u, y)
         ctx.save_for_backward(x, c, st, u, W2, gamma, slope)
-        ctx.geo = (R, H, W, Cin, Cout, k, stride, pad, Ho, Wo, ldp, res is not None, training, w.shape)
+        ctx.geo = (R, H, W, Cin, Cout, k, (sh, sw), pad, Ho, Wo, ldp, res is not None, training, w.shape)
         return y
 
     @staticmethod
@@ -62,7 +66,8 @@ class ConvBnActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, c, st, u, W2, gamma, slope = ctx.saved_tensors
-        R, H, W, Cin, Cout, k, stride, pad, Ho, Wo, ldp, has_res, training, wshape = ctx.geo
+        R, H, W, Cin, Cout, k, (sh, sw), pad, Ho, Wo, ldp, has_res, training, wshape = ctx.geo
+        stride = sh
         if not training:
             raise L.WesepHipError("ResNet speaker encoder: backward in eval mode (running statistics) is not built")
         M = R * Ho * Wo
@@ -74,7 +79,7 @@ class ConvBnActFn(torch.autograd.Function):
         sums = dev.bn_bwd(c, du, st, gamma, M, Cout, dc)
         Kk = k * k * Cin
         if FC.implicit_ok(Cin):
-            dW2, _ = FC.conv2d_wgrad(dc, x, R, H, W, Cin, Cout, k, stride, stride, pad, with_bias=False)
+            dW2, _ = FC.conv2d_wgrad(dc, x, R, H, W, Cin, Cout, k, sh, sw, pad, with_bias=False)
         else:
             patches = ConvBnActFn._patches(x, R, H, W, Cin, k, stride, pad, M, ldp)
             dW2, _ = _wgrad(dc, M, Cout, patches, ldp, with_bias=False)
@@ -82,10 +87,10 @@ class ConvBnActFn(torch.autograd.Function):
         dw = dW2[:, :Kk].reshape(Cout, k, k, Cin).permute(0, 3, 1, 2).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            if FC.implicit_ok(Cin) and FC.implicit_ok(Cout) and stride <= 2:
+            if FC.implicit_ok(Cin) and FC.implicit_ok(Cout) and max(sh, sw) <= 2:
                 # transposed view of dc, one row per input pixel: Wd[ci][(tap)*Cout + co] = w[co, ci, ky, kx]
                 Wd = W2.view(Cout, k * k, Cin).permute(2, 1, 0).reshape(Cin, k * k * Cout).contiguous()
-                dx = FC.conv2d_dx(dc, R, H, W, Cin, Wd, Cout, k, stride, stride, pad)
+                dx = FC.conv2d_dx(dc, R, H, W, Cin, Wd, Cout, k, sh, sw, pad)
             else:
                 dpatches = _gemm(dc, M, Cout, _transposed(W2, Cout, ldp), ldp)
                 dx = _empty(d, R * H * W, Cin)

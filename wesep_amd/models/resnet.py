@@ -165,6 +165,9 @@ def get_speaker_model(model_name: str):
     from .ecapa_tdnn import ECAPA_MODELS
     if model_name in ECAPA_MODELS:
         return ECAPA_MODELS[model_name]
-    raise NotImplementedError(f"speaker model {model_name!r}: the wespeaker ResNets (18 / 34 / 50 / 101 / 152) and "
-                              "ECAPA-TDNN (c512 / c1024, with or without global context) are built "
-                              "(SURVEY.md section 8 row a12); CAM++ is not")
+    if model_name == "CAMPPlus":
+        from .campplus import CAMPPlus
+        return CAMPPlus
+    raise NotImplementedError(f"speaker model {model_name!r}: the wespeaker ResNets (18 / 34 / 50 / 101 / 152), "
+                              "ECAPA-TDNN (c512 / c1024, with or without global context) and CAM++ (CAMPPlus) are built "
+                              "(SURVEY.md section 8 row a12)")
