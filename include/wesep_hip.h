@@ -428,6 +428,14 @@ int ws_dwconv_fwd(const float* x, const float* stats, const float* gamma, const 
 int ws_dwconv_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
                   const float* beta, const float* w, int R, int Tp, int C, int P, int dil, int st_div,
                   float* dxn, int nsplit, int rows_per_split, float* slab, void* stream);
+/* The same pair with a `causal` flag: non-zero puts every tap at or before t (taps t - (P-1-p)*dil), the causal
+ * Conv1DBlock of wesep/modules/tasnet/convs.py:61-62,91-92 (padding dil*(P-1), last dil*(P-1) outputs cut)      */
+int ws_dwconv_ex_fwd(const float* x, const float* stats, const float* gamma, const float* beta,
+                     const float* w, const float* b, int R, int Tp, int C, int P, int dil, int st_div, int causal,
+                     float* y, void* stream);
+int ws_dwconv_ex_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
+                     const float* beta, const float* w, int R, int Tp, int C, int P, int dil, int st_div, int causal,
+                     float* dxn, int nsplit, int rows_per_split, float* slab, void* stream);
 /* slab[split * ngroups + grp][2][C]: per-channel sums of g and of g * xhat over the rows of group grp
  * (rows_per_group consecutive rows) that fall into the split; xhat = (x - mean_s) * rstd_s, s = m / st_div
  * (stats NULL: xhat = x; x NULL: second row zero)                                                    */

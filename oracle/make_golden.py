@@ -152,6 +152,83 @@ def run_tasnet_case(name, kw, R, T, seed):
     print(f"{name}: loss={loss.item():.6f} est1_rms={ests[0].pow(2).mean().sqrt().item():.4e}")
 
 
+TASNET_VARIANT_CASES = {
+    # name: (reference ConvTasNet constructor kwargs, rows, T, seed).  The constructor options outside the oracle's
+    # restatement (convtasnet.py:16-46: causal, skip_con, norm='BN', Deep / plain encoder-decoder pairs, sigmoid masks):
+    # the fixture carries the PARAMETERS too (the reference's own initialisation under the seed, norm gains / PReLU slopes /
+    # BatchNorm buffers perturbed to non-trivial values), so the HIP path is held to the reference directly.
+    "convtasnet_plain_skip_r2_t1600": (dict(N=32, L=20, B=24, H=48, P=3, X=3, R=2, skip_con=True, encoder_type=None,
+                                            decoder_type=None), 2, 1600, 51),
+    "convtasnet_deep_causal_cln_r2_t1600": (dict(N=32, L=20, B=24, H=48, P=3, X=3, R=1, norm="cLN", causal=True,
+                                                 encoder_type="Deep", decoder_type="Deep", activate="sigmoid",
+                                                 spk_fuse_type="multiply"), 2, 1600, 52),
+    "convtasnet_multi_bn_skip_r4_t1600": (dict(N=32, L=20, B=32, H=64, P=3, X=2, R=2, norm="BN", skip_con=True), 4, 1600, 53),
+    "convtasnet_multi_causal_gln_r2_t1600": (dict(N=32, L=20, B=32, H=64, P=3, X=3, R=1, causal=True), 2, 1600, 54),
+    "convtasnet_plain_bn_film_r4_t1200": (dict(N=32, L=16, B=24, H=40, P=3, X=2, R=2, norm="BN", encoder_type=None,
+                                               decoder_type=None, spk_fuse_type="FiLM"), 4, 1200, 55),
+}
+
+
+def variant_loss(out, tgt):
+    """Loss of a variant case: multi-scale SI-SDR for the Multi decoder's three estimates, plain SI-SDR otherwise
+    (the plain ConvTrans1D decoder returns [R, 1, T], convs.py:27-41)."""
+    if isinstance(out, (list, tuple)):
+        return CT.multiscale_sisdr_loss(list(out), tgt)
+    est = out.reshape(out.shape[0], -1)
+    n = min(est.shape[-1], tgt.shape[-1])
+    return O.sisdr_loss(est[:, :n], tgt[:, :n])
+
+
+def run_tasnet_variant_case(name, kw, R, T, seed):
+    get_model = import_reference()
+    torch.manual_seed(seed)
+    ref = get_model("ConvTasNet")(**{**dict(use_spk_transform=False, joint_training=False), **kw})
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, v in ref.state_dict().items():
+            last = k.split(".")[-1]
+            if k.endswith("num_batches_tracked"):
+                continue
+            if last == "running_mean":
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif last == "running_var":
+                v.copy_(1.0 + 0.2 * torch.rand(v.shape, generator=g))
+            elif v.numel() == 1 and last == "weight":                   # PReLU slope
+                v.copy_(0.25 + 0.05 * torch.randn(v.shape, generator=g))
+            elif ("norm" in k.lower() or "LayerN" in k or ".ln." in k) and v.dim() <= 2 and v.shape[-1] in (1, v.numel()):
+                v.copy_((1.0 + 0.1 * torch.randn(v.shape, generator=g)) if last == "weight"
+                        else 0.1 * torch.randn(v.shape, generator=g))
+            elif last == "bias":
+                v.copy_(0.05 * torch.randn(v.shape, generator=g))
+    ref.train()
+    params = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    wav, tgt, emb = O.synth_batch(R, T, seed)
+    res = ref(wav, emb)
+    loss = variant_loss(res, tgt)
+    loss.backward()
+    ests = list(res) if isinstance(res, (list, tuple)) else [res]
+    out = {"wav": wav.numpy(), "tgt": tgt.numpy(), "emb": emb.numpy(), "loss": np.float64(loss.item())}
+    for i, e in enumerate(ests):
+        out[f"est{i + 1}"] = e.detach().numpy()
+    for k, v in params.items():
+        out["param/" + k] = v.numpy()
+    for k, v in ref.state_dict().items():          # BatchNorm running statistics after this one training step
+        if k.endswith(("running_mean", "running_var")):
+            out["buf/" + k] = v.numpy().copy()
+    for k, prm in ref.named_parameters():
+        if prm.grad is None:       # skip_con: the last block's residual `Output` conv is never used (separation.py:43-49)
+            out["gnorm/" + k] = np.float64(-1.0)
+            continue
+        gr = prm.grad.detach().reshape(-1)
+        out["gnorm/" + k] = np.float64(gr.double().norm().item())
+        if gr.numel() <= 4096:
+            out["gfull/" + k] = gr.numpy().copy()
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.6f} est1_rms={ests[0].pow(2).mean().sqrt().item():.4e} "
+          f"params={sum(v.numel() for v in params.values())}")
+
+
 DPCCN_CASES = {
     # name: (DPCCNConfig kwargs, rows, T, seed) -- T >= 4352: the pyramid pooling needs >= 32 frames
     "dpccn_multiply_r2_t4480": (dict(tcn_blocks=3, tcn_layers=1), 2, 4480, 31),
@@ -404,6 +481,10 @@ if __name__ == "__main__":
         if only and name not in only:
             continue
         run_tasnet_case(name, kw, R, T, seed)
+    for name, (kw, R, T, seed) in TASNET_VARIANT_CASES.items():
+        if only and name not in only:
+            continue
+        run_tasnet_variant_case(name, kw, R, T, seed)
     for name, (kw, R, T, seed) in DPCCN_CASES.items():
         if only and name not in only:
             continue

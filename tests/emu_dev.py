@@ -222,16 +222,23 @@ def inorm_bwd(y, dy, stats, G, P, Cc, dx):
     dx.reshape(G, P, Cc)[:] = stats[:, 1].unsqueeze(1) * (dd - s0 - yy * s1)
 
 
-def dwconv_fwd(x, stats, gamma, beta, w, b, R, Tp, Cc, P, dil, st_div, y):
+def _dw(xr, w, b, P, dil, Cc, causal):
+    if causal:          # convs.py:61-62,91-92: pad dil*(P-1) on both sides, cut the tail
+        pad = dil * (P - 1)
+        return F.conv1d(xr, w, b, padding=pad, dilation=dil, groups=Cc)[:, :, :xr.shape[2]]
+    return F.conv1d(xr, w, b, padding=dil * (P - 1) // 2, dilation=dil, groups=Cc)
+
+
+def dwconv_fwd(x, stats, gamma, beta, w, b, R, Tp, Cc, P, dil, st_div, y, causal=False):
     s = torch.arange(R * Tp) // st_div
     st = stats.reshape(-1, 2)
     xn = (x.reshape(R * Tp, Cc) - st[s, 0:1]) * st[s, 1:2] * gamma + beta
     xr = xn.reshape(R, Tp, Cc).permute(0, 2, 1)
-    o = F.conv1d(xr, w.reshape(Cc, 1, P), b, padding=dil * (P - 1) // 2, dilation=dil, groups=Cc)
+    o = _dw(xr, w.reshape(Cc, 1, P), b, P, dil, Cc, causal)
     y.reshape(R, Tp, Cc)[:] = o.permute(0, 2, 1)
 
 
-def dwconv_bwd(dy, x, stats, gamma, beta, w, R, Tp, Cc, P, dil, st_div, dxn):
+def dwconv_bwd(dy, x, stats, gamma, beta, w, R, Tp, Cc, P, dil, st_div, dxn, causal=False):
     s = torch.arange(R * Tp) // st_div
     st = stats.reshape(-1, 2)
     xn = ((x.reshape(R * Tp, Cc) - st[s, 0:1]) * st[s, 1:2] * gamma + beta).reshape(R, Tp, Cc).permute(0, 2, 1)
@@ -239,7 +246,7 @@ def dwconv_bwd(dy, x, stats, gamma, beta, w, R, Tp, Cc, P, dil, st_div, dxn):
     wr = w.reshape(Cc, 1, P).detach().requires_grad_(True)
     br = torch.zeros(Cc, requires_grad=True)
     with torch.enable_grad():
-        o = F.conv1d(xn, wr, br, padding=dil * (P - 1) // 2, dilation=dil, groups=Cc)
+        o = _dw(xn, wr, br, P, dil, Cc, causal)
         o.backward(dy.reshape(R, Tp, Cc).permute(0, 2, 1))
     dxn.reshape(R, Tp, Cc)[:] = xn.grad.permute(0, 2, 1)
     return wr.grad.reshape(Cc, P).contiguous(), br.grad.contiguous()

@@ -211,12 +211,65 @@ def test_model_matches_oracle_and_reference_fixture(name, golden_dir):
         assert abs(float(prm.grad.norm()) - float(g["gnorm/" + k])) <= tol * float(g["gnorm/" + k]) + floor, k
 
 
+@pytest.mark.parametrize("dil,P", [(1, 3), (4, 3), (2, 5)])
+def test_causal_dwconv_fwd_bwd(dil, P):
+    """ws_dwconv_ex_*(causal = 1): every tap at or before t (convs.py:61-62,91-92: pad dil*(P-1), cut the tail) against
+    torch, with the norm applied on load."""
+    from wesep_amd import dev
+    from wesep_amd import functional_tasnet as FT
+    d = _cuda()
+    torch.manual_seed(3)
+    R, Tp, Cc = 3, 47, 16
+    M = R * Tp
+    x = torch.randn(M, Cc, device=d) * 1.5 + 0.3
+    gamma, beta = torch.rand(Cc, device=d) + 0.5, torch.randn(Cc, device=d) * 0.1
+    w, b = torch.randn(Cc, P, device=d) * 0.5, torch.randn(Cc, device=d) * 0.1
+    st = FT.norm_stats(x, "cLN", R, Tp, Cc)
+    y = torch.empty(M, Cc, device=d)
+    dev.dwconv_fwd(x, st, gamma, beta, w, b, R, Tp, Cc, P, dil, 1, y, causal=True)
+    xr = x.view(R, Tp, Cc).permute(0, 2, 1).contiguous()
+    xn = F.layer_norm(xr.transpose(1, 2), (Cc,), gamma, beta, 1e-5).transpose(1, 2).detach().requires_grad_(True)
+    wr, br = w.view(Cc, 1, P).clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pad = dil * (P - 1)
+    yr = F.conv1d(xn, wr, br, padding=pad, dilation=dil, groups=Cc)[:, :, :-pad]
+    assert rel(y.view(R, Tp, Cc).permute(0, 2, 1), yr) < 1e-5
+    dy = torch.randn(M, Cc, device=d)
+    yr.backward(dy.view(R, Tp, Cc).permute(0, 2, 1))
+    dxn = torch.empty(M, Cc, device=d)
+    dw, db = dev.dwconv_bwd(dy, x, st, gamma, beta, w, R, Tp, Cc, P, dil, 1, dxn, causal=True)
+    assert rel(dxn.view(R, Tp, Cc).permute(0, 2, 1), xn.grad) < 1e-5
+    assert rel(dw, wr.grad.view(Cc, P)) < 1e-4 and rel(db, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["convtasnet_plain_skip_r2_t1600", "convtasnet_deep_causal_cln_r2_t1600",
+                                  "convtasnet_multi_bn_skip_r4_t1600", "convtasnet_multi_causal_gln_r2_t1600",
+                                  "convtasnet_plain_bn_film_r4_t1200"])
+def test_variants_match_reference_fixture(name, golden_dir):
+    """The rest of the reference constructor (convtasnet.py:16-46): plain / Deep encoder-decoder pairs, skip connections,
+    causal blocks, norm = 'BN', sigmoid masks -- estimates, loss, every parameter gradient (element-wise where the tensor
+    has <= 4096 entries) and the BatchNorm buffers after the step, from fixtures the REFERENCE produced with its own
+    parameter initialisation (stored in the fixture)."""
+    from oracle.make_golden import variant_loss
+    from tests.test_tasnet_resnet_host_cpu import check_variant, load_variant
+    from wesep_amd.models import get_model
+    d = _cuda()
+    kw, g, params = load_variant(name, golden_dir)
+    model = get_model("ConvTasNet")(**kw)
+    model.load_state_dict(params, strict=True)
+    model = model.to(d).train()
+    outs = model(torch.from_numpy(g["wav"]).to(d), torch.from_numpy(g["emb"]).to(d))
+    loss = variant_loss(outs, torch.from_numpy(g["tgt"]).to(d))
+    loss.backward()
+    check_variant(model, g, outs, loss)
+
+
 def test_unbuilt_variants_fail_loudly():
     from wesep_amd.models import get_model
     cls = get_model("ConvTasNet")
     for kw in (dict(joint_training=True, spk_feat=True), dict(joint_training=False, encoder_type="Deep"),
-               dict(joint_training=False, skip_con=True), dict(joint_training=False, norm="BN"),
-               dict(joint_training=False, spk_fuse_type="nope"), dict(joint_training=False, causal=True)):
+               dict(joint_training=True, encoder_type="Deep", decoder_type="Deep"),
+               dict(joint_training=False, activate="softmax", encoder_type=None, decoder_type=None),
+               dict(joint_training=False, spk_fuse_type="nope"), dict(joint_training=False, multi_fuse=False)):
         with pytest.raises(NotImplementedError):
             cls(**kw)
     model = cls(N=16, L=20, B=16, H=32, X=2, R=1, joint_training=False, use_spk_transform=False)

@@ -51,3 +51,13 @@ def test_campplus_gpu_test_bodies(emu, monkeypatch):
     t.test_bn_act_and_mel_strided_conv_block_match_torch()
     t.test_campplus_matches_oracle(monkeypatch)
     t.test_bsrnn_joint_training_with_campplus_runs_and_matches_oracle()
+
+
+def test_convtasnet_variant_gpu_test_bodies(emu, monkeypatch, golden_dir):
+    """The causal depthwise convolution and reference-fixture variant tests of tests/test_convtasnet_gpu.py."""
+    import tests.test_convtasnet_gpu as t
+    monkeypatch.setattr(t, "_cuda", lambda: torch.device("cpu"))
+    for dil, P in ((1, 3), (4, 3), (2, 5)):
+        t.test_causal_dwconv_fwd_bwd(dil, P)
+    for name in ("convtasnet_plain_skip_r2_t1600", "convtasnet_multi_bn_skip_r4_t1600"):
+        t.test_variants_match_reference_fixture(name, golden_dir)

@@ -10,7 +10,7 @@ import torch
 from oracle import bsrnn_oracle as O
 from oracle import convtasnet_oracle as CT
 from oracle import resnet_oracle as RO
-from oracle.make_golden import ENROLL_LEN, TASNET_CASES
+from oracle.make_golden import ENROLL_LEN, TASNET_CASES, TASNET_VARIANT_CASES, variant_loss
 from tests import emu_dev
 
 
@@ -52,6 +52,58 @@ def test_convtasnet_host_logic_matches_reference_fixture(name, monkeypatch, gold
         assert np.linalg.norm(outs[i].detach().numpy() - ref) / np.linalg.norm(ref) < 1e-3
     assert abs(loss.item() - float(g["loss"])) < 1e-2
     _grad_norms_match(model, g)
+
+
+def load_variant(name, golden_dir):
+    """(model kwargs, fixture, parameters) of a TASNET_VARIANT_CASES fixture: parameters and buffers come from the file
+    (the reference's own initialisation), `num_batches_tracked` restarts at 0."""
+    kw, R, T, seed = TASNET_VARIANT_CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    params = {k[len("param/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param/")}
+    return {**dict(use_spk_transform=False, joint_training=False), **kw}, g, params
+
+
+def check_variant(model, g, outs, loss, tol_est=1e-3, tol_grad=2e-2):
+    ests = list(outs) if isinstance(outs, (list, tuple)) else [outs]
+    for i, e in enumerate(ests):
+        ref = g[f"est{i + 1}"]
+        assert tuple(e.shape) == ref.shape, (tuple(e.shape), ref.shape)
+        assert np.linalg.norm(e.detach().cpu().numpy() - ref) / np.linalg.norm(ref) < tol_est, i
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-2
+    top = max(float(g["gnorm/" + k]) for k, _ in model.named_parameters())
+    for k, prm in model.named_parameters():
+        gn = float(g["gnorm/" + k])
+        if gn < 0:                                   # no gradient in the reference either (unused Output conv)
+            assert prm.grad is None or float(prm.grad.norm()) == 0.0, k
+            continue
+        assert prm.grad is not None, k
+        if "gfull/" + k in g.files:
+            err = float(np.linalg.norm(prm.grad.detach().cpu().numpy().reshape(-1) - g["gfull/" + k]))
+            assert err <= tol_grad * gn + 1e-4 * top, (k, err, gn)
+        else:
+            assert abs(float(prm.grad.norm()) - gn) <= tol_grad * gn + 1e-4 * top, (k, float(prm.grad.norm()), gn)
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("buf/"):
+            assert np.allclose(sd[k[4:]].cpu().numpy(), g[k], rtol=2e-3, atol=1e-5), k
+
+
+@pytest.mark.parametrize("name", sorted(TASNET_VARIANT_CASES))
+def test_convtasnet_variants_host_logic_matches_reference_fixture(name, monkeypatch, golden_dir):
+    """The rest of the reference constructor (convtasnet.py:16-46): plain / Deep encoder-decoder pairs, skip connections,
+    causal blocks, norm = 'BN', sigmoid masks -- parameters, estimates, loss, every parameter gradient (element-wise
+    where the tensor has <= 4096 entries) and the BatchNorm buffers from fixtures the REFERENCE produced."""
+    from wesep_amd.models import get_model
+    emu_dev.install(monkeypatch)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    kw, g, params = load_variant(name, golden_dir)
+    model = get_model("ConvTasNet")(**kw)
+    model.load_state_dict(params, strict=True)
+    model.train()
+    outs = model(torch.from_numpy(g["wav"]), torch.from_numpy(g["emb"]))
+    loss = variant_loss(outs, torch.from_numpy(g["tgt"]))
+    loss.backward()
+    check_variant(model, g, outs, loss)
 
 
 def test_resnet18_host_logic_matches_restatement(monkeypatch):

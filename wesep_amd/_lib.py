@@ -152,6 +152,8 @@ _SIGS = {
     "ws_prelu_bwd": (_i, [_p, _p, _p, _ll, _p, _p, _i, _p]),
     "ws_dwconv_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "ws_dwconv_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p]),
+    "ws_dwconv_ex_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_dwconv_ex_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p]),
     "ws_chan_sums": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "ws_norm_ab": (_i, [_p, _p, _i, _i, _ll, _p, _p]),
     "ws_norm_bwd_apply_cl": (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _p]),

@@ -160,13 +160,15 @@ extern "C" int ws_prelu_bwd(const float* pre, const float* dy, const float* a, l
 }
 
 // ---------------------------------------------------------------------------------------------
-// Depthwise dilated convolution (convs.py:63-70,125-133; groups = channels, "same" padding,
-// non-causal) on the NORMALISED input, normalisation applied on load:
+// Depthwise dilated convolution (convs.py:63-70,125-133; groups = channels, "same" padding) on the NORMALISED input,
+// normalisation applied on load:
 //   xn[r][t][c] = (x - mean_s) * rstd_s * gamma[c] + beta[c],  s = m / st_div  (gLN: T', cLN: 1)
-//   y[r][t][c]  = b[c] + sum_p w[c][p] * xn[r][t + (p - (P-1)/2) * dil][c]      (zero outside [0, T'))
+//   y[r][t][c]  = b[c] + sum_p w[c][p] * xn[r][t + (p - ctr) * dil][c]          (zero outside [0, T'))
+// ctr = (P-1)/2 (non-causal), or P-1 for the causal blocks (convs.py:61-62,91-92: padding dil*(P-1) on both sides, the
+// last dil*(P-1) outputs cut -- every tap at or before t)
 // ---------------------------------------------------------------------------------------------
 struct DwGeom {
-  int R, Tp, C, P, dil, st_div;
+  int R, Tp, C, P, dil, st_div, ctr;
 };
 
 __device__ __forceinline__ f32x4 dw_xn(const float* __restrict__ x, const float* __restrict__ stats,
@@ -182,7 +184,7 @@ __global__ void dwconv_fwd_kernel(const float* __restrict__ x, const float* __re
                                   float* __restrict__ y) {
   const int c4n = g.C >> 2;
   const long long total = (long long)g.R * g.Tp * c4n;
-  const int ctr = (g.P - 1) / 2;
+  const int ctr = g.ctr;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long row = i / c4n;
@@ -206,7 +208,7 @@ __global__ void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* 
                                      float* __restrict__ dxn) {
   const int c4n = g.C >> 2;
   const long long total = (long long)g.R * g.Tp * c4n;
-  const int ctr = (g.P - 1) / 2;
+  const int ctr = g.ctr;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long row = i / c4n;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(1024) void dwconv_bwd_w_kernel(const float* __restr
   const int split = blockIdx.x, ry = threadIdx.y;
   const long long M = (long long)g.R * g.Tp;
   const long long lo = (long long)split * rows_per_split, hi = min(M, lo + rows_per_split);
-  const int ctr = (g.P - 1) / 2;
+  const int ctr = g.ctr;
   const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + cc), bt = *reinterpret_cast<const f32x4*>(beta + cc);
   f32x4 acc[TN_MAXP + 1];
 #pragma unroll
@@ -284,27 +286,32 @@ static int dw_check(const char* who, int R, int Tp, int C, int P, int dil, int s
   return WS_OK;
 }
 
-extern "C" int ws_dwconv_fwd(const float* x, const float* stats, const float* gamma, const float* beta,
-                             const float* w, const float* b, int R, int Tp, int C, int P, int dil, int st_div,
-                             float* y, void* stream) {
+extern "C" int ws_dwconv_ex_fwd(const float* x, const float* stats, const float* gamma, const float* beta,
+                                const float* w, const float* b, int R, int Tp, int C, int P, int dil, int st_div,
+                                int causal, float* y, void* stream) {
   int rc = dw_check("ws_dwconv_fwd", R, Tp, C, P, dil, st_div);
   if (rc != WS_OK) return rc;
   WS_REQUIRE(x && stats && gamma && beta && w && b && y, "ws_dwconv_fwd: null pointer");
-  const DwGeom g{R, Tp, C, P, dil, st_div};
+  const DwGeom g{R, Tp, C, P, dil, st_div, causal ? P - 1 : (P - 1) / 2};
   hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(ew_blocks((long long)R * Tp * (C / 4), 256)), dim3(256), 0,
                      (hipStream_t)stream, x, stats, gamma, beta, w, b, g, y);
   return ws_check_launch("ws_dwconv_fwd");
 }
+extern "C" int ws_dwconv_fwd(const float* x, const float* stats, const float* gamma, const float* beta,
+                             const float* w, const float* b, int R, int Tp, int C, int P, int dil, int st_div,
+                             float* y, void* stream) {
+  return ws_dwconv_ex_fwd(x, stats, gamma, beta, w, b, R, Tp, C, P, dil, st_div, 0, y, stream);
+}
 
-extern "C" int ws_dwconv_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
-                             const float* beta, const float* w, int R, int Tp, int C, int P, int dil, int st_div,
-                             float* dxn, int nsplit, int rows_per_split, float* slab, void* stream) {
+extern "C" int ws_dwconv_ex_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
+                                const float* beta, const float* w, int R, int Tp, int C, int P, int dil, int st_div,
+                                int causal, float* dxn, int nsplit, int rows_per_split, float* slab, void* stream) {
   int rc = dw_check("ws_dwconv_bwd", R, Tp, C, P, dil, st_div);
   if (rc != WS_OK) return rc;
   WS_REQUIRE(dy && x && stats && gamma && beta && w && dxn && slab && nsplit > 0 && rows_per_split > 0 &&
                  (long long)nsplit * rows_per_split >= (long long)R * Tp,
              "ws_dwconv_bwd: bad args");
-  const DwGeom g{R, Tp, C, P, dil, st_div};
+  const DwGeom g{R, Tp, C, P, dil, st_div, causal ? P - 1 : (P - 1) / 2};
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3(ew_blocks((long long)R * Tp * (C / 4), 256)), dim3(256), 0, s, dy, w,
                      g, dxn);
@@ -313,6 +320,12 @@ extern "C" int ws_dwconv_bwd(const float* dy, const float* x, const float* stats
   hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(nsplit, (C / 4 + threads - 1) / threads), dim3(threads, DW_RY), lds, s,
                      dy, x, stats, gamma, beta, g, rows_per_split, slab);
   return ws_check_launch("ws_dwconv_bwd");
+}
+extern "C" int ws_dwconv_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
+                             const float* beta, const float* w, int R, int Tp, int C, int P, int dil, int st_div,
+                             float* dxn, int nsplit, int rows_per_split, float* slab, void* stream) {
+  return ws_dwconv_ex_bwd(dy, x, stats, gamma, beta, w, R, Tp, C, P, dil, st_div, 0, dxn, nsplit, rows_per_split, slab,
+                          stream);
 }
 
 // ---------------------------------------------------------------------------------------------

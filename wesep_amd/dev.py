@@ -753,10 +753,11 @@ def prelu_bwd(pre, dy, a, dx):
     return da
 
 
-def dwconv_fwd(x, stats, gamma, beta, w, b, R: int, Tp: int, Cc: int, P: int, dil: int, st_div: int, y):
+def dwconv_fwd(x, stats, gamma, beta, w, b, R: int, Tp: int, Cc: int, P: int, dil: int, st_div: int, y, causal=False):
     for n, t in (("x", x), ("stats", stats), ("gamma", gamma), ("beta", beta), ("w", w), ("b", b), ("y", y)):
         _chk(t, n)
-    _call("ws_dwconv_fwd", _p(x), _p(stats), _p(gamma), _p(beta), _p(w), _p(b), R, Tp, Cc, P, dil, st_div, _p(y))
+    _call("ws_dwconv_ex_fwd", _p(x), _p(stats), _p(gamma), _p(beta), _p(w), _p(b), R, Tp, Cc, P, dil, st_div, int(causal),
+          _p(y))
 
 
 def row_splits(M: int, target=1024):
@@ -765,14 +766,14 @@ def row_splits(M: int, target=1024):
     return -(-M // rows), rows
 
 
-def dwconv_bwd(dy, x, stats, gamma, beta, w, R: int, Tp: int, Cc: int, P: int, dil: int, st_div: int, dxn):
+def dwconv_bwd(dy, x, stats, gamma, beta, w, R: int, Tp: int, Cc: int, P: int, dil: int, st_div: int, dxn, causal=False):
     """returns (dw [C, P], db [C])"""
     for n, t in (("dy", dy), ("x", x), ("stats", stats), ("gamma", gamma), ("beta", beta), ("w", w), ("dxn", dxn)):
         _chk(t, n)
     nsplit, rows = row_splits(R * Tp)
     slab = torch.empty(nsplit, P + 1, Cc, device=dy.device, dtype=torch.float32)
-    _call("ws_dwconv_bwd", _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(w), R, Tp, Cc, P, dil, st_div,
-          _p(dxn), nsplit, rows, _p(slab))
+    _call("ws_dwconv_ex_bwd", _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(w), R, Tp, Cc, P, dil, st_div,
+          int(causal), _p(dxn), nsplit, rows, _p(slab))
     out = torch.empty(P + 1, Cc, device=dy.device, dtype=torch.float32)
     reduce_slabs(slab, nsplit, (P + 1) * Cc, (P + 1) * Cc, out)
     return out[:P].t().contiguous(), out[P].contiguous()

@@ -181,16 +181,51 @@ class MultiEncoderFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
-# Conv1DBlock / Conv1DBlock4Fuse (convs.py:41-160), non-causal, no skip connection
+# Conv1DBlock / Conv1DBlock4Fuse (convs.py:41-160): gLN / cLN / BN, non-causal or causal, optional skip branch
 # ---------------------------------------------------------------------------------------------
+def _block_norm(y, norm, R, Tp, Cc, gamma, beta, bn):
+    """Statistics of one in-block norm over y [R*T', C] -> (kernel-facing (stats, gamma, beta, stat_map, st_div),
+    backward-facing (stats, gamma)).  gLN / cLN: (mean, rstd) per utterance / per frame, applied on load by the consumer
+    kernels.  BN (select_norm 'BN' = nn.BatchNorm1d, norm.py:62-76): per-CHANNEL statistics, i.e. a per-column affine
+    map -- folded into the consumer's gamma / beta with identity row statistics, so the same kernels serve it."""
+    if norm != "BN":
+        st = norm_stats(y, norm, R, Tp, Cc)
+        return (st, gamma, beta, _stat_map(norm, Tp), Tp if norm == "gLN" else 1), (st, gamma)
+    rm, rv, training = bn
+    M = R * Tp
+    st = _empty(y.device, 2, Cc)
+    if training:
+        dev.bn_stats(y, M, Cc, rm, rv, st)
+    else:
+        st[0].copy_(rm)
+        st[1].copy_(torch.rsqrt(rv + dev.BN_EPS))
+    gk = (st[1] * gamma).contiguous()
+    bk = (beta - st[0] * gk).contiguous()
+    ident = torch.tensor([[0.0, 1.0]], device=y.device, dtype=torch.float32)
+    return (ident, gk, bk, StatMap(1, 0, 1, 0, 0), M), (st, gamma)
+
+
+def _block_norm_backward(y, dyn, st, gamma, norm, R, Tp, Cc):
+    """dy (written over dyn), dgamma, dbeta."""
+    if norm != "BN":
+        return norm_backward(y, dyn, st, gamma, norm, R, Tp, Cc)
+    sums = dev.bn_bwd(y, dyn, st, gamma, R * Tp, Cc, dyn)
+    return dyn, sums[1].contiguous(), sums[0].contiguous()
+
+
 class ConvBlockFn(torch.autograd.Function):
     """x [R*T', B] -> x + sconv(norm2(prelu2(dconv(norm1(prelu1(conv1x1(x) + rb))))));
-    rb [R, H] = W_e e + b (concatConv fusion, convs.py:143-148) or None (then the conv1x1 bias is used)."""
+    rb [R, H] = W_e e + b (concatConv fusion, convs.py:143-148) or None (then the conv1x1 bias is used).
+    geo = (R, T', norm, dilation[, causal[, bn]]): causal puts every depthwise tap at or before t (convs.py:61-62,91-92);
+    bn = (rm1, rv1, rm2, rv2, training) are the BatchNorm1d buffers of norm = 'BN'.  With the skip branch's (wsc, bsc)
+    (skip_con, convs.py:73-75,98-101) the result is the pair (x + Output(c), Sc_conv(c))."""
 
     @staticmethod
-    def forward(ctx, x, rb, geo, w1, b1, a1, g1, be1, wd, bd, a2, g2, be2, w3, b3):
+    def forward(ctx, x, rb, geo, w1, b1, a1, g1, be1, wd, bd, a2, g2, be2, w3, b3, wsc=None, bsc=None):
         _need_cuda(x, "ConvTasNet")
-        R, Tp, norm, dil = geo
+        R, Tp, norm, dil = geo[:4]
+        causal = bool(geo[4]) if len(geo) > 4 else False
+        bn = geo[5] if len(geo) > 5 else None
         M, B = x.shape
         H, P = wd.shape[0], wd.shape[-1]
         x = x.contiguous()
@@ -199,38 +234,56 @@ class ConvBlockFn(torch.autograd.Function):
         c = _gemm(x, M, B, W1, H, ldw=ldw, bias=None if rb is not None else b1)
         y1 = _empty(x.device, M, H)
         dev.prelu_fwd(c, rb.contiguous() if rb is not None else None, a1, M, H, Tp, y1)
-        st1 = norm_stats(y1, norm, R, Tp, H)
         g1f, be1f, g2f, be2f = (t.reshape(H).contiguous() for t in (g1, be1, g2, be2))
+        (st1, g1k, be1k, _, st_div), (st1n, _) = _block_norm(y1, norm, R, Tp, H, g1f, be1f, bn and (bn[0], bn[1], bn[4]))
         wdf = wd.reshape(H, P).contiguous()
         z = _empty(x.device, M, H)
-        st_div = Tp if norm == "gLN" else 1
-        dev.dwconv_fwd(y1, st1, g1f, be1f, wdf, bd, R, Tp, H, P, dil, st_div, z)
+        dev.dwconv_fwd(y1, st1, g1k, be1k, wdf, bd, R, Tp, H, P, dil, st_div, z, causal=causal)
         y2 = _empty(x.device, M, H)
         dev.prelu_fwd(z, None, a2, M, H, Tp, y2)
-        st2 = norm_stats(y2, norm, R, Tp, H)
+        (st2, g2k, be2k, sm, _), (st2n, _) = _block_norm(y2, norm, R, Tp, H, g2f, be2f, bn and (bn[2], bn[3], bn[4]))
         W3 = w3.reshape(B, H).contiguous()
-        out = _gemm(y2, M, H, W3, B, bias=b3, R=x, norm=(st2, g2f, be2f, _stat_map(norm, Tp)))
-        ctx.save_for_backward(x, c, y1, st1, z, y2, st2, W1, a1, g1f, be1f, wdf, a2, g2f, be2f, W3)
-        ctx.geo = (R, Tp, norm, dil, B, H, P, ldw, rb is not None)
+        out = _gemm(y2, M, H, W3, B, bias=b3, R=x, norm=(st2, g2k, be2k, sm))
+        skip = wsc is not None
+        Wsc = wsc.reshape(B, H).contiguous() if skip else W3
+        sc = _gemm(y2, M, H, Wsc, B, bias=bsc, norm=(st2, g2k, be2k, sm)) if skip else None
+        ctx.save_for_backward(x, c, y1, st1, z, y2, st2, W1, a1, g1k, be1k, wdf, a2, g2k, be2k, W3, st1n, st2n, g1f, g2f,
+                              Wsc)
+        ctx.geo = (R, Tp, norm, dil, B, H, P, ldw, rb is not None, causal, skip, st_div, sm)
         ctx.shapes = (w1.shape, g1.shape, wd.shape, w3.shape)
+        if bn is not None and not bn[4]:
+            ctx.eval_bn = True
+        if skip:
+            ctx.set_materialize_grads(False)     # the last block's `out` is dropped by Separation: its gradient is None
+            return out, sc
         return out
 
     @staticmethod
-    def backward(ctx, dout):
-        x, c, y1, st1, z, y2, st2, W1, a1, g1f, be1f, wdf, a2, g2f, be2f, W3 = ctx.saved_tensors
-        R, Tp, norm, dil, B, H, P, ldw, has_rb = ctx.geo
+    def backward(ctx, dout, dsc=None):
+        (x, c, y1, st1, z, y2, st2, W1, a1, g1k, be1k, wdf, a2, g2k, be2k, W3, st1n, st2n, g1f, g2f,
+         Wsc) = ctx.saved_tensors
+        R, Tp, norm, dil, B, H, P, ldw, has_rb, causal, skip, st_div, sm = ctx.geo
+        if getattr(ctx, "eval_bn", False):
+            raise L.WesepHipError("ConvTasNet norm='BN': backward in eval mode (running statistics) is not built")
         M = R * Tp
         d = x.device
-        dout = dout.contiguous()
-        st_div = Tp if norm == "gLN" else 1
-        sm = _stat_map(norm, Tp)
-        dW3, db3 = _wgrad(dout, M, B, y2, H, norm=(st2, g2f, be2f, sm))
-        dyn2 = _gemm(dout, M, B, _transposed(W3, B, H), H)
-        dy2, dg2, dbe2 = norm_backward(y2, dyn2, st2, g2f, norm, R, Tp, H)
+        dout = dout.contiguous() if dout is not None else None
+        dsc = dsc.contiguous() if dsc is not None else None
+        if dout is None and dsc is None:
+            return (None,) * (17 if skip else 15)
+        nk = (st2, g2k, be2k, sm)
+        dW3 = db3 = dWsc = dbsc = dyn2 = None
+        if dout is not None:
+            dW3, db3 = _wgrad(dout, M, B, y2, H, norm=nk)
+            dyn2 = _gemm(dout, M, B, _transposed(W3, B, H), H)
+        if dsc is not None:
+            dWsc, dbsc = _wgrad(dsc, M, B, y2, H, norm=nk)
+            dyn2 = _gemm(dsc, M, B, _transposed(Wsc, B, H), H, R=dyn2)
+        dy2, dg2, dbe2 = _block_norm_backward(y2, dyn2, st2n, g2f, norm, R, Tp, H)
         da2 = dev.prelu_bwd(z, dy2, a2, dy2)                                   # dy2 -> dz in place
         dyn1 = _empty(d, M, H)
-        dwd, dbd = dev.dwconv_bwd(dy2, y1, st1, g1f, be1f, wdf, R, Tp, H, P, dil, st_div, dyn1)
-        dy1, dg1, dbe1 = norm_backward(y1, dyn1, st1, g1f, norm, R, Tp, H)
+        dwd, dbd = dev.dwconv_bwd(dy2, y1, st1, g1k, be1k, wdf, R, Tp, H, P, dil, st_div, dyn1, causal=causal)
+        dy1, dg1, dbe1 = _block_norm_backward(y1, dyn1, st1n, g1f, norm, R, Tp, H)
         da1 = dev.prelu_bwd(c, dy1, a1, dy1)                                   # dy1 -> dc in place
         drb = None
         if has_rb:
@@ -244,8 +297,11 @@ class ConvBlockFn(torch.autograd.Function):
         W1xT = _transposed(W1, H, B, lds=ldw)
         dx = _gemm(dy1, M, H, W1xT, B, R=dout)
         s1, sg, sd, s3 = ctx.shapes
-        return (dx, drb, None, dW1.view(s1), db1, da1, dg1.view(sg), dbe1.view(sg), dwd.reshape(sd), dbd, da2,
-                dg2.view(sg), dbe2.view(sg), dW3.view(s3), db3)
+        grads = (dx, drb, None, dW1.view(s1), db1, da1, dg1.view(sg), dbe1.view(sg), dwd.reshape(sd), dbd, da2,
+                 dg2.view(sg), dbe2.view(sg), dW3.view(s3) if dW3 is not None else None, db3)
+        if skip:
+            grads += (dWsc.view(s3) if dWsc is not None else None, dbsc)
+        return grads
 
 
 # ---------------------------------------------------------------------------------------------
@@ -316,6 +372,103 @@ class MultiDecoderFn(torch.autograd.Function):
             gm[2 * i], gm[2 * i + 1] = dWm.view(N, B, 1), dbm
             gd[2 * i], gd[2 * i + 1] = dWd.view(N, 1, Lk), dev.total_sum(dest)
         return (de, dcat, None, *gm, *gd)
+
+
+# ---------------------------------------------------------------------------------------------
+# The classic Conv-TasNet ends (convtasnet.py:79-85,147-153: encoder_type / decoder_type other than 'Multi'):
+# one strided Conv1d encoder, mask * encoder output, one ConvTranspose1d decoder
+# ---------------------------------------------------------------------------------------------
+class PlainEncoderFn(torch.autograd.Function):
+    """wav [R, T] -> conv1d(wav, w [N, 1, L], b; stride) (-> ReLU) as channels-last frames [R*T', N], T' = (T - L) // stride
+    + 1: one GEMM on the overlapping frame view of the waveform (no frames are materialised)."""
+
+    @staticmethod
+    def forward(ctx, wav, stride, relu, w, b):
+        _need_cuda(wav, "ConvTasNet")
+        R, T = wav.shape
+        N, _, Lk = w.shape
+        if T < Lk:
+            raise RuntimeError(f"ConvTasNet: input of {T} samples is shorter than the encoder window {Lk}")
+        Tp = (T - Lk) // stride + 1
+        Tpad = -(-T // 4) * 4
+        d = wav.device
+        xp = torch.zeros(R, Tpad, device=d, dtype=torch.float32)
+        xp[:, :T] = wav
+        M = R * Tp
+        frames = Rows(Tp, Tpad, stride)                      # row m -> xp[r, t*stride : t*stride + L]
+        y = _gemm(xp, M, Lk, w.reshape(N, Lk).contiguous(), N, bias=b, act=2 if relu else 0, a_rows=frames,
+                  vec=2 if Lk % 4 == 0 else 0)
+        ctx.save_for_backward(xp, y if relu else None)
+        ctx.geo = (R, Tp, Tpad, stride, N, Lk, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, y = ctx.saved_tensors
+        R, Tp, Tpad, stride, N, Lk, relu = ctx.geo
+        dy = dy.contiguous()
+        if relu:
+            dy = dy.clone()
+            dev.relu_mask(dy, y)
+        dW, db = _wgrad(dy, R * Tp, N, xp, Lk, a_rows=Rows(Tp, Tpad, stride), vec=0)
+        return None, None, None, dW.view(N, 1, Lk), db
+
+
+class TransDecoderFn(torch.autograd.Function):
+    """x [R*T', N] -> conv_transpose1d(x, w [N, 1, L], b [1]; stride) [R, (T' - 1) * stride + L]: frame synthesis GEMM +
+    overlap-add (decoder.py / convs.py:27-41 ConvTrans1D)."""
+
+    @staticmethod
+    def forward(ctx, x, geo, w, b):
+        _need_cuda(x, "ConvTasNet")
+        R, Tp, stride = geo
+        x = x.contiguous()
+        M, N = x.shape
+        Lk = w.shape[-1]
+        W2 = w.reshape(N, Lk).contiguous()
+        fr = _gemm(x, M, N, _transposed(W2, N, Lk), Lk)
+        xlen = (Tp - 1) * stride + Lk
+        est = _empty(x.device, R, xlen)
+        dev.ola_fwd(fr, b, R, Tp, Lk, stride, xlen, est)
+        ctx.save_for_backward(x, W2)
+        ctx.geo = (R, Tp, stride, N, Lk, xlen)
+        return est
+
+    @staticmethod
+    def backward(ctx, dest):
+        x, W2 = ctx.saved_tensors
+        R, Tp, stride, N, Lk, xlen = ctx.geo
+        M = R * Tp
+        dest = dest.contiguous()
+        dfr = _empty(x.device, M, Lk)
+        dev.ola_bwd(dest, R, Tp, Lk, stride, xlen, dfr)
+        dW, _ = _wgrad(x, M, N, dfr, Lk, with_bias=False)
+        dx = _gemm(dfr, M, Lk, W2, N) if ctx.needs_input_grad[0] else None
+        return dx, None, dW.view(N, 1, Lk), dev.total_sum(dest)
+
+
+class MulFn(torch.autograd.Function):
+    """a * b on [M, C] (mask times encoder output), both operands differentiable."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_cuda(a, "ConvTasNet")
+        a, b = a.contiguous(), b.contiguous()
+        M, Cc = a.shape
+        y = torch.empty_like(a)
+        dev.maskmul_fwd(a, 0, Cc, b, M, Cc, y)
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        M, Cc = a.shape
+        dy = dy.contiguous()
+        da, db = torch.empty_like(a), torch.empty_like(a)
+        dev.maskmul_fwd(dy, 0, Cc, b, M, Cc, da)
+        dev.maskmul_fwd(dy, 0, Cc, a, M, Cc, db)
+        return da, db
 
 
 # ---------------------------------------------------------------------------------------------

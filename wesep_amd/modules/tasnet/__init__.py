@@ -19,42 +19,72 @@ class GlobalChannelLayerNorm(nn.Module):
 
 
 def select_norm(norm, dim):
-    """norm.py:62-76.  BatchNorm is not built (needs running statistics kernels)."""
+    """norm.py:62-76."""
     if norm == "gLN":
         return GlobalChannelLayerNorm(dim)
     if norm == "cLN":
         return nn.LayerNorm(dim, elementwise_affine=True)
     if norm == "BN":
-        raise NotImplementedError("ConvTasNet norm='BN' is not built in wesep_amd (gLN / cLN only)")
+        return nn.BatchNorm1d(dim)
     raise RuntimeError("Unsupported normalize layer: {}".format(norm))
 
 
+def _bn_geo(norm, n1, n2, training):
+    """The BatchNorm1d buffers of a block's two norms for ConvBlockFn (None unless norm == 'BN')."""
+    if norm != "BN":
+        return None
+    if training:
+        n1.num_batches_tracked += 1
+        n2.num_batches_tracked += 1
+    return (n1.running_mean, n1.running_var, n2.running_mean, n2.running_var, training)
+
+
+def apply_norm(m, norm, x, geo, training):
+    """select_norm module `m` on channels-last x [R*T', C]."""
+    from ... import functional_campplus as FP
+    from ... import functional_tfgridnet as FG
+    if norm == "gLN":
+        return FG.GroupLNFn.apply(x, m.weight.view(-1), m.bias.view(-1), geo)
+    if norm == "cLN":
+        return FG.RowLNFn.apply(x, m.weight, m.bias)
+    if training:
+        m.num_batches_tracked += 1
+    return FP.BnActFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, training, False)
+
+
 class Conv1DBlock(nn.Module):
-    """convs.py:41-104 (non-causal, skip_con=False): names conv1x1 / PReLU_1 / norm_1 / dwconv / PReLU_2 /
-    norm_2 / Output."""
+    """convs.py:41-104: names conv1x1 / PReLU_1 / norm_1 / dwconv / PReLU_2 / norm_2 / (Sc_conv) / Output.  With
+    skip_con the block returns (skip, out) like the reference."""
 
     def __init__(self, in_channels=256, out_channels=512, kernel_size=3, dilation=1, norm="gLN", causal=False,
                  skip_con=False):
         super().__init__()
-        if causal or skip_con:
-            raise NotImplementedError("ConvTasNet causal / skip_con blocks are not built in wesep_amd")
         self.conv1x1 = nn.Conv1d(in_channels, out_channels, 1)
         self.PReLU_1 = nn.PReLU()
         self.norm_1 = select_norm(norm, out_channels)
-        pad = dilation * (kernel_size - 1) // 2
+        pad = dilation * (kernel_size - 1) // 2 if not causal else dilation * (kernel_size - 1)
         self.dwconv = nn.Conv1d(out_channels, out_channels, kernel_size, groups=out_channels, padding=pad,
                                 dilation=dilation)
         self.PReLU_2 = nn.PReLU()
         self.norm_2 = select_norm(norm, out_channels)
+        if skip_con:
+            self.Sc_conv = nn.Conv1d(out_channels, in_channels, 1, bias=True)
         self.Output = nn.Conv1d(out_channels, in_channels, 1, bias=True)
-        self.norm_type, self.dilation = norm, dilation
+        self.norm_type, self.dilation, self.causal, self.skip_con = norm, dilation, causal, skip_con
 
     def forward(self, x, geo):
         R, Tp = geo
-        return FT.ConvBlockFn.apply(
-            x, None, (R, Tp, self.norm_type, self.dilation), self.conv1x1.weight, self.conv1x1.bias,
+        g = (R, Tp, self.norm_type, self.dilation, self.causal, _bn_geo(self.norm_type, self.norm_1, self.norm_2,
+                                                                         self.training))
+        skip = (self.Sc_conv.weight, self.Sc_conv.bias) if self.skip_con else ()
+        res = FT.ConvBlockFn.apply(
+            x, None, g, self.conv1x1.weight, self.conv1x1.bias,
             self.PReLU_1.weight, self.norm_1.weight, self.norm_1.bias, self.dwconv.weight, self.dwconv.bias,
-            self.PReLU_2.weight, self.norm_2.weight, self.norm_2.bias, self.Output.weight, self.Output.bias)
+            self.PReLU_2.weight, self.norm_2.weight, self.norm_2.bias, self.Output.weight, self.Output.bias, *skip)
+        if self.skip_con:
+            out, sc = res
+            return sc, out
+        return res
 
 
 class Conv1DBlock4Fuse(nn.Module):
@@ -64,18 +94,16 @@ class Conv1DBlock4Fuse(nn.Module):
     def __init__(self, in_channels=256, spk_embed_dim=100, conv_channels=512, kernel_size=3, dilation=1,
                  norm="cLN", causal=False):
         super().__init__()
-        if causal:
-            raise NotImplementedError("ConvTasNet causal blocks are not built in wesep_amd")
         self.conv1x1 = nn.Conv1d(in_channels + spk_embed_dim, conv_channels, 1)
         self.prelu1 = nn.PReLU()
         self.lnorm1 = select_norm(norm, conv_channels)
-        pad = dilation * (kernel_size - 1) // 2
+        pad = dilation * (kernel_size - 1) // 2 if not causal else dilation * (kernel_size - 1)
         self.dconv = nn.Conv1d(conv_channels, conv_channels, kernel_size, groups=conv_channels, padding=pad,
                                dilation=dilation, bias=True)
         self.prelu2 = nn.PReLU()
         self.lnorm2 = select_norm(norm, conv_channels)
         self.sconv = nn.Conv1d(conv_channels, in_channels, 1, bias=True)
-        self.norm_type, self.dilation, self.in_channels = norm, dilation, in_channels
+        self.norm_type, self.dilation, self.in_channels, self.causal = norm, dilation, in_channels, causal
 
     def forward(self, x, aux, geo):
         """aux: speaker embedding [R, E]."""
@@ -83,14 +111,17 @@ class Conv1DBlock4Fuse(nn.Module):
         R, Tp = geo
         w = self.conv1x1.weight
         rb = LinearFn.apply(aux, w[:, self.in_channels:, 0], self.conv1x1.bias)       # [R, H]
+        g = (R, Tp, self.norm_type, self.dilation, self.causal, _bn_geo(self.norm_type, self.lnorm1, self.lnorm2,
+                                                                         self.training))
         return FT.ConvBlockFn.apply(
-            x, rb, (R, Tp, self.norm_type, self.dilation), w, self.conv1x1.bias, self.prelu1.weight,
+            x, rb, g, w, self.conv1x1.bias, self.prelu1.weight,
             self.lnorm1.weight, self.lnorm1.bias, self.dconv.weight, self.dconv.bias, self.prelu2.weight,
             self.lnorm2.weight, self.lnorm2.bias, self.sconv.weight, self.sconv.bias)
 
 
 class Separation(nn.Module):
-    """separation.py:7-54 without skip connections."""
+    """separation.py:7-54: with skip_con the sum of the blocks' skip outputs is returned (the last block's residual
+    output is dropped, as in the reference)."""
 
     def __init__(self, R, X, B, H, P, norm="gLN", causal=False, skip_con=False, start_dilation=0):
         super().__init__()
@@ -98,8 +129,15 @@ class Separation(nn.Module):
         for _ in range(R):
             for x in range(start_dilation, X):
                 self.separation.append(Conv1DBlock(B, H, P, 2 ** x, norm, causal, skip_con))
+        self.skip_con = skip_con
 
     def forward(self, x, geo):
+        if self.skip_con:
+            total = None
+            for blk in self.separation:
+                skip, x = blk(x, geo)
+                total = skip if total is None else total + skip
+            return total
         for blk in self.separation:
             x = blk(x, geo)
         return x
@@ -170,10 +208,7 @@ class FuseSeparation(nn.Module):
                 self.separation.append(Separation(1, X, B, H, P, norm=norm, causal=causal, skip_con=skip_con))
 
     def _norm(self, m, x, geo):
-        from ... import functional_tfgridnet as FG
-        if self.norm_type == "gLN":
-            return FG.GroupLNFn.apply(x, m.weight.view(-1), m.bias.view(-1), geo)
-        return FG.RowLNFn.apply(x, m.weight, m.bias)
+        return apply_norm(m, self.norm_type, x, geo, self.training)
 
     def forward(self, x, spk_embedding, geo):
         if self.spk_fuse_type == "concatConv":
@@ -214,6 +249,61 @@ class MultiEncoder(nn.Module):
             self.encoder_1d_middle.bias, self.encoder_1d_long.weight, self.encoder_1d_long.bias, self.ln.weight,
             self.ln.bias, self.proj.weight, self.proj.bias)
         return e, cat, (x.shape[-1] - self.L1) // self.stride + 1
+
+
+class DeepEncoder(nn.Module):
+    """encoder.py:10-63: strided Conv1d, then four dilated k = 3 convolutions (1 / 2 / 4 / 8) each followed by a PReLU --
+    on channels-last frames, every convolution one split-bf16 GEMM (functional_campplus.Conv1dFn)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride):
+        super().__init__()
+        if in_channels != 1:
+            raise NotImplementedError("DeepEncoder: single-channel input only")
+        layers = [nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride)]
+        for d in (1, 2, 4, 8):
+            layers += [nn.Conv1d(out_channels, out_channels, kernel_size=3, stride=1, dilation=d, padding=d), nn.PReLU()]
+        self.sequential = nn.Sequential(*layers)
+        self.stride = stride
+
+    def forward(self, x):
+        """x [R, T] -> ([R*T', N], T')."""
+        from ... import functional_campplus as FP
+        from ... import functional_tfgridnet as FG
+        seq = self.sequential
+        y = FT.PlainEncoderFn.apply(x, self.stride, False, seq[0].weight, seq[0].bias)
+        R = x.shape[0]
+        Tp = y.shape[0] // R
+        for i in (1, 3, 5, 7):
+            y = FP.Conv1dFn.apply(y, (R, Tp, 1, seq[i].dilation[0]), seq[i].weight, seq[i].bias)
+            y = FG.PReluFn.apply(y, seq[i + 1].weight)
+        return y, Tp
+
+
+class DeepDecoder(nn.Module):
+    """decoder.py:7-63: four dilated k = 3 ConvTranspose1d (8 / 4 / 2 / 1) each followed by a PReLU, then the strided
+    synthesis ConvTranspose1d.  A stride-1 transposed convolution is the convolution with the flipped, channel-swapped
+    kernel (same 'same' padding), so the same GEMM serves it."""
+
+    def __init__(self, N, kernel_size=16, stride=16 // 2):
+        super().__init__()
+        layers = []
+        for d in (8, 4, 2, 1):
+            layers += [nn.ConvTranspose1d(N, N, kernel_size=3, stride=1, dilation=d, padding=d), nn.PReLU()]
+        layers.append(nn.ConvTranspose1d(N, 1, kernel_size=kernel_size, stride=stride, bias=True))
+        self.sequential = nn.Sequential(*layers)
+        self.stride = stride
+
+    def forward(self, x, geo):
+        """x [R*T', N] -> [R, (T' - 1) * stride + L]."""
+        from ... import functional_campplus as FP
+        from ... import functional_tfgridnet as FG
+        R, Tp = geo
+        seq = self.sequential
+        for i in (0, 2, 4, 6):
+            w = seq[i].weight.permute(1, 0, 2).flip(2).contiguous()            # [out, in, k] of the equivalent Conv1d
+            x = FP.Conv1dFn.apply(x, (R, Tp, 1, seq[i].dilation[0]), w, seq[i].bias)
+            x = FG.PReluFn.apply(x, seq[i + 1].weight)
+        return FT.TransDecoderFn.apply(x, (R, Tp, self.stride), seq[8].weight, seq[8].bias)
 
 
 class MultiDecoder(nn.Module):
