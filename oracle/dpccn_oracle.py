@@ -34,6 +34,7 @@ class DPCCNConfig:
     tcn_blocks: int = 10
     tcn_layers: int = 2
     pool_size: tuple = (4, 8, 16, 32)
+    causal: bool = False            # TCN blocks pad dil * (k - 1) on both sides and cut the tail (convs.py:126-127,147-148)
 
 
 def _dense_shapes(s, p, cin, cout, mode):
@@ -138,11 +139,14 @@ def _dense(p, q, x):
     return feats[-1]
 
 
-def _tcn(p, q, x, dil):
-    """TCNBlock (convs.py:115-152), non-causal."""
+def _tcn(p, q, x, dil, causal=False):
+    """TCNBlock (convs.py:115-152)."""
     D = x.shape[1]
     y = F.elu(F.instance_norm(x))
-    y = F.conv1d(y, p[q + "dconv1.weight"], p[q + "dconv1.bias"], padding=dil, dilation=dil, groups=D)
+    if causal:
+        y = F.conv1d(y, p[q + "dconv1.weight"], p[q + "dconv1.bias"], padding=2 * dil, dilation=dil, groups=D)[:, :, :-2 * dil]
+    else:
+        y = F.conv1d(y, p[q + "dconv1.weight"], p[q + "dconv1.bias"], padding=dil, dilation=dil, groups=D)
     y = F.elu(F.instance_norm(y))
     return x + F.conv1d(y, p[q + "dconv2.weight"], p[q + "dconv2.bias"])
 
@@ -186,7 +190,7 @@ def dpccn_forward(p: Dict[str, torch.Tensor], cfg: DPCCNConfig, wav: torch.Tenso
     y = out.reshape(Bn, N, T * Fq)
     for l in range(cfg.tcn_layers):
         for b in range(cfg.tcn_blocks):
-            y = _tcn(p, f"tcn_layers.{l}.{b}.", y, 2 ** b)
+            y = _tcn(p, f"tcn_layers.{l}.{b}.", y, 2 ** b, cfg.causal)
     out = y.reshape(Bn, N, T, Fq)
     skips = skips[::-1]
     for j in range(3):

@@ -237,6 +237,7 @@ DPCCN_CASES = {
     "dpccn_additive_xform_r2_t4608": (dict(tcn_blocks=2, tcn_layers=2, spk_fuse_type="additive",
                                            use_spk_transform=True), 2, 4608, 33),
     "dpccn_film_r2_t4352": (dict(tcn_blocks=2, tcn_layers=1, spk_fuse_type="FiLM"), 2, 4352, 34),
+    "dpccn_causal_r2_t4480": (dict(tcn_blocks=3, tcn_layers=1, causal=True), 2, 4480, 35),
 }
 
 
@@ -247,7 +248,7 @@ def run_dpccn_case(name, kw, R, T, seed):
     ref = get_model("DPCCN")(win=cfg.win, stride=cfg.stride, spk_emb_dim=cfg.spk_emb_dim,
                              use_spk_transform=cfg.use_spk_transform, spk_fuse_type=cfg.spk_fuse_type,
                              feature_dim=cfg.feature_dim, tcn_dims=cfg.tcn_dims, tcn_blocks=cfg.tcn_blocks,
-                             tcn_layers=cfg.tcn_layers, pool_size=cfg.pool_size, joint_training=False)
+                             tcn_layers=cfg.tcn_layers, pool_size=cfg.pool_size, causal=cfg.causal, joint_training=False)
     params = DP.synth_params(cfg, seed)
     ref_sd = ref.state_dict()
     assert list(ref_sd.keys()) == list(params.keys()), "oracle param_shapes() order != reference state_dict"

@@ -138,7 +138,7 @@ def test_implicit_conv2d_and_transpose_match_torch(Cin, Cout, k, sh, sw):
 
 
 @pytest.mark.parametrize("name", ["dpccn_multiply_r2_t4480", "dpccn_additive_xform_r2_t4608", "dpccn_film_r2_t4352",
-                                  "dpccn_concat_xform_r2_t4352"])
+                                  "dpccn_concat_xform_r2_t4352", "dpccn_causal_r2_t4480"])
 def test_dpccn_model_matches_reference_fixture(name, golden_dir):
     from oracle import bsrnn_oracle as O
     from oracle import dpccn_oracle as DP
@@ -171,8 +171,7 @@ def test_dpccn_model_matches_reference_fixture(name, golden_dir):
 
 def test_dpccn_unbuilt_variants_fail_loudly():
     from wesep_amd.models import get_model
-    for kw in (dict(joint_training=False, spk_fuse_type="nope"), dict(joint_training=False, causal=True),
-               dict(joint_training=False, stride2=(1, 1))):
+    for kw in (dict(joint_training=False, spk_fuse_type="nope"), dict(joint_training=False, stride2=(1, 1))):
         with pytest.raises(NotImplementedError):
             get_model("DPCCN")(**kw)
     m = get_model("DPCCN")(joint_training=False, tcn_blocks=1, tcn_layers=1)

@@ -32,7 +32,7 @@ def _run(name, monkeypatch, golden_dir):
 
 
 @pytest.mark.parametrize("name", ["dpccn_multiply_r2_t4480", "dpccn_additive_xform_r2_t4608", "dpccn_film_r2_t4352",
-                                  "dpccn_concat_xform_r2_t4352"])
+                                  "dpccn_concat_xform_r2_t4352", "dpccn_causal_r2_t4480"])
 def test_dpccn_host_logic_matches_reference_fixture(name, monkeypatch, golden_dir):
     model, est, loss, g = _run(name, monkeypatch, golden_dir)
     ref = g["est"]

@@ -148,7 +148,8 @@ class DwConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, geo):
         _need_cuda(x, "DPCCN")
-        B, Lr, dil = geo
+        B, Lr, dil = geo[:3]
+        causal = bool(geo[3]) if len(geo) > 3 else False
         C, _, P = w.shape
         x = x.contiguous()
         d = x.device
@@ -156,17 +157,17 @@ class DwConvFn(torch.autograd.Function):
         ones, zeros = torch.ones(C, device=d), torch.zeros(C, device=d)
         wf = w.reshape(C, P).contiguous()
         y = _empty(d, B * Lr, C)
-        dev.dwconv_fwd(x, ident, ones, zeros, wf, b, B, Lr, C, P, dil, Lr, y)
+        dev.dwconv_fwd(x, ident, ones, zeros, wf, b, B, Lr, C, P, dil, Lr, y, causal=causal)
         ctx.save_for_backward(x, ident, ones, zeros, wf)
-        ctx.geo = (B, Lr, C, P, dil, w.shape)
+        ctx.geo = (B, Lr, C, P, dil, w.shape, causal)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, ident, ones, zeros, wf = ctx.saved_tensors
-        B, Lr, C, P, dil, wshape = ctx.geo
+        B, Lr, C, P, dil, wshape, causal = ctx.geo
         dx = torch.empty_like(x)
-        dw, db = dev.dwconv_bwd(dy.contiguous(), x, ident, ones, zeros, wf, B, Lr, C, P, dil, Lr, dx)
+        dw, db = dev.dwconv_bwd(dy.contiguous(), x, ident, ones, zeros, wf, B, Lr, C, P, dil, Lr, dx, causal=causal)
         return dx, dw.reshape(wshape), db, None
 
 

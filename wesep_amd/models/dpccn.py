@@ -5,7 +5,7 @@ are parameter containers only.
 
 Built: fixed embeddings (`joint_training=False`) and joint training with a wespeaker ResNet18/34 on fbank or raw
 enrollment audio (the same encoder / front-end as BSRNN, models/resnet.py); multiply / additive speaker fusion.
-Not built (raise NotImplementedError): concat / FiLM fusion, causal TCN, kernel sizes / strides other than the
+Not built (raise NotImplementedError): kernel sizes / strides other than the
 defaults the reference's `_build_*` helpers are written for."""
 import torch
 import torch.nn as nn
@@ -79,22 +79,21 @@ class _EncStage(nn.Sequential):
 
 
 class TCNBlock(nn.Module):
-    """IN - ELU - depthwise dilated conv - IN - ELU - 1x1 conv, + residual (convs.py:115-152); non-causal."""
+    """IN - ELU - depthwise dilated conv - IN - ELU - 1x1 conv, + residual (convs.py:115-152); causal: every depthwise
+    tap at or before t (padding dil * (k - 1), tail cut, convs.py:126-127,147-148)."""
 
     def __init__(self, in_dims=384, out_dims=384, kernel_size=3, dilation=1, causal=False):
         super().__init__()
-        if causal:
-            raise NotImplementedError("DPCCN causal TCN blocks are not built in wesep_amd")
-        pad = dilation * (kernel_size - 1) // 2
+        pad = dilation * (kernel_size - 1) // 2 if not causal else dilation * (kernel_size - 1)
         self.dconv1 = nn.Conv1d(in_dims, out_dims, kernel_size, padding=pad, dilation=dilation, groups=in_dims, bias=True)
         self.dconv2 = nn.Conv1d(in_dims, out_dims, 1, bias=True)
-        self.dilation = dilation
+        self.dilation, self.causal = dilation, causal
 
     def forward(self, x, geo):
         """x [B*L, D], geo (B, L)."""
         B, Lr = geo
         y = FD.EluFn.apply(FD.InstNormFn.apply(x, (B, Lr)))
-        y = FD.DwConvFn.apply(y, self.dconv1.weight, self.dconv1.bias, (B, Lr, self.dilation))
+        y = FD.DwConvFn.apply(y, self.dconv1.weight, self.dconv1.bias, (B, Lr, self.dilation, self.causal))
         y = FD.EluFn.apply(FD.InstNormFn.apply(y, (B, Lr)))
         return FD.Conv1x1ResFn.apply(y, self.dconv2.weight, self.dconv2.bias, x)
 
