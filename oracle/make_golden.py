@@ -285,7 +285,22 @@ TFGRIDNET_CASES = {
                                          attn_n_head=2, attn_approx_qk_dim=260, spk_fuse_type="FiLM"), 2, 1280, 43),
     "tfgridnet_ks1_concat_r2_t1280": (dict(n_layers=2, lstm_hidden_units=16, emb_dim=8, emb_ks=1, emb_hs=1,
                                            attn_n_head=2, attn_approx_qk_dim=260, spk_fuse_type="concat"), 2, 1280, 44),
+    # two output sources from a three-microphone mixture [R, T, 3] (tfgridnet.py:173,192-194,216-244,280-300)
+    "tfgridnet_ks1_srcs2_mics3_r2_t1280": (dict(n_layers=1, lstm_hidden_units=16, emb_dim=8, emb_ks=1, emb_hs=1,
+                                                attn_n_head=2, attn_approx_qk_dim=260, n_srcs=2, n_imics=3), 2, 1280, 45),
 }
+
+
+def tfgridnet_batch(cfg, R, T, seed):
+    """(mixture, target, embedding) of a TF-GridNet case: [R, T] / [R, T]; with n_imics = M > 1 the mixture is [R, T, M]
+    (microphone m = the synthetic mixture plus a delayed, scaled copy), with n_srcs = S > 1 the target is [R, S, T]."""
+    wav, tgt, emb = O.synth_batch(R, T, seed)
+    if cfg.n_imics > 1:
+        wav = torch.stack([wav if m == 0 else 0.8 ** m * torch.roll(wav, 3 * m, 1) + 0.05 * torch.roll(tgt, 7 * m, 1)
+                           for m in range(cfg.n_imics)], 2).contiguous()
+    if cfg.n_srcs > 1:
+        tgt = torch.stack([tgt if s == 0 else torch.roll(tgt, 11 * s, 1) * (1.0 - 0.2 * s) for s in range(cfg.n_srcs)], 1)
+    return wav, tgt, emb
 
 
 def run_tfgridnet_case(name, kw, R, T, seed):
@@ -297,7 +312,7 @@ def run_tfgridnet_case(name, kw, R, T, seed):
                                  attn_approx_qk_dim=cfg.attn_approx_qk_dim, emb_dim=cfg.emb_dim, emb_ks=cfg.emb_ks,
                                  emb_hs=cfg.emb_hs, eps=cfg.eps, spk_emb_dim=cfg.spk_emb_dim,
                                  use_spk_transform=cfg.use_spk_transform, spk_fuse_type=cfg.spk_fuse_type,
-                                 joint_training=False)
+                                 n_srcs=cfg.n_srcs, n_imics=cfg.n_imics, joint_training=False)
     params = TG.synth_params(cfg, seed)
     ref_sd = ref.state_dict()
     assert list(ref_sd.keys()) == list(params.keys()), "oracle param_shapes() order != reference state_dict"
@@ -305,7 +320,7 @@ def run_tfgridnet_case(name, kw, R, T, seed):
         assert tuple(ref_sd[k].shape) == tuple(params[k].shape), k
     ref.load_state_dict(params, strict=True)
     ref.train()
-    wav, tgt, emb = O.synth_batch(R, T, seed)
+    wav, tgt, emb = tfgridnet_batch(cfg, R, T, seed)
     est, _ = ref(wav, emb)
     loss = O.sisdr_loss(est, tgt)
     loss.backward()

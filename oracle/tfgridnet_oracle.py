@@ -38,6 +38,8 @@ class TFGridNetConfig:
     spk_emb_dim: int = 256
     use_spk_transform: bool = False
     spk_fuse_type: str = "multiply"
+    n_srcs: int = 1       # output sources: deconv to 2 * n_srcs channels, est [B, n_srcs, N] (tfgridnet.py:192-194,280-300)
+    n_imics: int = 1      # microphones: input [B, N, M], conv from 2 * n_imics channels (tfgridnet.py:173,216-244)
 
     @property
     def n_freqs(self):
@@ -62,7 +64,7 @@ def param_shapes(cfg: TFGridNetConfig) -> Dict[str, tuple]:
         s["spk_fuse.fc.linear.bias"] = (Fq,)
     else:
         raise NotImplementedError(cfg.spk_fuse_type)
-    s["conv.0.weight"] = (C, 2, 3, 3)
+    s["conv.0.weight"] = (C, 2 * cfg.n_imics, 3, 3)
     s["conv.0.bias"] = (C,)
     s["conv.1.weight"] = (C,)
     s["conv.1.bias"] = (C,)
@@ -95,8 +97,8 @@ def param_shapes(cfg: TFGridNetConfig) -> Dict[str, tuple]:
         s[q + "attn_concat_proj.1.weight"] = (1,)
         s[q + "attn_concat_proj.2.gamma"] = (1, C, 1, Fq)
         s[q + "attn_concat_proj.2.beta"] = (1, C, 1, Fq)
-    s["deconv.weight"] = (C, 2, 3, 3)
-    s["deconv.bias"] = (2,)
+    s["deconv.weight"] = (C, 2 * cfg.n_srcs, 3, 3)
+    s["deconv.bias"] = (2 * cfg.n_srcs,)
     return s
 
 
@@ -195,14 +197,18 @@ def gridnet_block(p, cfg: TFGridNetConfig, q, x):
 
 
 def tfgridnet_forward(p: Dict[str, torch.Tensor], cfg: TFGridNetConfig, wav: torch.Tensor, emb: torch.Tensor):
-    """`tfgridnet.py:197-302`, joint_training=False: wav [B, N], emb [B, E] -> est [B, N]."""
-    B, n = wav.shape
-    std = torch.std(wav.unsqueeze(-1), dim=(1, 2), keepdim=True)                             # [B, 1, 1]
-    x = wav / std.squeeze(-1)
+    """`tfgridnet.py:197-302`, joint_training=False: wav [B, N] (or [B, N, M] with n_imics = M > 1), emb [B, E] ->
+    est [B, N] (or [B, n_srcs, N] with n_srcs > 1)."""
+    B, n = wav.shape[0], wav.shape[1]
+    w3 = wav.unsqueeze(-1) if wav.dim() == 2 else wav                                        # [B, N, M]
+    M = w3.shape[2]
+    std = torch.std(w3, dim=(1, 2), keepdim=True)                                            # [B, 1, 1]
+    x = (w3 / std).transpose(1, 2).reshape(B * M, n)
     win = torch.hann_window(cfg.n_fft)
     spec = torch.stft(x, cfg.n_fft, cfg.stride, cfg.n_fft, window=win, return_complex=True, onesided=True)
-    spec = spec.transpose(1, 2)                                                              # [B, T, F]
-    h = torch.stack((spec.real, spec.imag), 1)                                               # [B, 2, T, F]
+    spec = spec.transpose(1, 2)                                                              # [B*M, T, F]
+    spec = spec.view(B, M, spec.shape[1], spec.shape[2])
+    h = torch.cat((spec.real, spec.imag), 1)                                                 # [B, 2M, T, F]
     _, _, nT, nF = h.shape
     h = F.group_norm(F.conv2d(h, p["conv.0.weight"], p["conv.0.bias"], padding=(1, 1)), 1, p["conv.1.weight"],
                      p["conv.1.bias"], cfg.eps)
@@ -222,7 +228,9 @@ def tfgridnet_forward(p: Dict[str, torch.Tensor], cfg: TFGridNetConfig, wav: tor
         else:
             h = h * t if cfg.spk_fuse_type == "multiply" else h + t
         h = gridnet_block(p, cfg, f"blocks.{i}.", h)
-    h = F.conv_transpose2d(h, p["deconv.weight"], p["deconv.bias"], padding=(1, 1))          # [B, 2, T, F]
-    est = torch.complex(h[:, 0], h[:, 1]).transpose(1, 2)                                    # [B, F, T]
+    h = F.conv_transpose2d(h, p["deconv.weight"], p["deconv.bias"], padding=(1, 1))          # [B, 2S, T, F]
+    S = cfg.n_srcs
+    h = h.view(B, S, 2, nT, nF)
+    est = torch.complex(h[:, :, 0], h[:, :, 1]).reshape(B * S, nT, nF).transpose(1, 2)       # [B*S, F, T]
     y = torch.istft(est, cfg.n_fft, cfg.stride, cfg.n_fft, window=win, onesided=True, length=n)
-    return y * std.view(B, 1)
+    return (y.view(B, S, n) * std.view(B, 1, 1)).squeeze(1)

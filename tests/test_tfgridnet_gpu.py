@@ -36,11 +36,12 @@ def test_softmax_rows_matches_torch():
 
 
 @pytest.mark.parametrize("name", ["tfgridnet_ks4_r2_t1600", "tfgridnet_ks1_additive_r2_t1280",
-                                  "tfgridnet_ks1_film_r2_t1280", "tfgridnet_ks1_concat_r2_t1280"])
+                                  "tfgridnet_ks1_film_r2_t1280", "tfgridnet_ks1_concat_r2_t1280",
+                                  "tfgridnet_ks1_srcs2_mics3_r2_t1280"])
 def test_tfgridnet_model_matches_reference_fixture(name, golden_dir):
     from oracle import bsrnn_oracle as O
     from oracle import tfgridnet_oracle as TG
-    from oracle.make_golden import TFGRIDNET_CASES
+    from oracle.make_golden import TFGRIDNET_CASES, tfgridnet_batch
     from wesep_amd.models import get_model
     from wesep_amd.utils.losses import parse_loss
     d = _cuda()
@@ -50,10 +51,10 @@ def test_tfgridnet_model_matches_reference_fixture(name, golden_dir):
     model = get_model("TFGridNet")(**kw, joint_training=False)
     model.load_state_dict(params, strict=True)
     model = model.to(d).train()
-    wav, tgt, emb = O.synth_batch(R, T, seed)
+    wav, tgt, emb = tfgridnet_batch(cfg, R, T, seed)      # [R, T, 3] mixture / [R, 2, T] target in the multi-source case
     est, dummy = model(wav.to(d), emb.to(d))
-    assert dummy.dim() == 0
-    loss = parse_loss("SISDR")[0](est, tgt.to(d))
+    assert dummy.dim() == 0 and est.shape == tgt.shape
+    loss = parse_loss("SISDR")[0](est.reshape(-1, T), tgt.to(d).reshape(-1, T))    # mean over rows (and sources)
     loss.backward()
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     assert rel(est, torch.from_numpy(g["est"])) < 1e-3
@@ -69,7 +70,7 @@ def test_tfgridnet_model_matches_reference_fixture(name, golden_dir):
 
 def test_tfgridnet_unbuilt_variants_fail_loudly():
     from wesep_amd.models import get_model
-    for kw in (dict(joint_training=False, n_imics=2), dict(joint_training=False, n_srcs=2),
+    for kw in (dict(joint_training=False, window="hamming"),
                dict(joint_training=False, spk_fuse_type="nope"), dict(joint_training=False, lstm_hidden_units=320)):
         with pytest.raises(NotImplementedError):
             get_model("TFGridNet")(**kw)

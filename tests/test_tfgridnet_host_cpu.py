@@ -9,7 +9,7 @@ import torch
 
 from oracle import bsrnn_oracle as O
 from oracle import tfgridnet_oracle as TG
-from oracle.make_golden import TFGRIDNET_CASES
+from oracle.make_golden import TFGRIDNET_CASES, tfgridnet_batch
 from tests import emu_dev
 
 
@@ -23,7 +23,7 @@ def test_tfgridnet_host_logic_matches_reference_fixture(name, monkeypatch, golde
     model = get_model("TFGridNet")(**kw, joint_training=False)
     model.load_state_dict(params, strict=True)
     model.train()
-    wav, tgt, emb = O.synth_batch(R, T, seed)
+    wav, tgt, emb = tfgridnet_batch(cfg, R, T, seed)
     est, dummy = model(wav, emb)
     loss = O.sisdr_loss(est, tgt)
     loss.backward()

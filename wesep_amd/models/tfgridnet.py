@@ -187,8 +187,8 @@ class TFGridNet(nn.Module):
                  joint_training=True, multi_task=False, spksInTrain=251, spk_model=None, spk_model_init=None,
                  spk_model_freeze=False, spk_args=None, spk_feat=False, feat_type="consistent"):
         super().__init__()
-        if n_srcs != 1 or n_imics != 1 or window != "hann":
-            raise NotImplementedError("TF-GridNet: single microphone, one source, hann window are built")
+        if n_srcs < 1 or n_imics < 1 or window != "hann":
+            raise NotImplementedError("TF-GridNet: the hann window is built")
         if emb_dim % 4 or lstm_hidden_units > 256:
             raise NotImplementedError("TF-GridNet: emb_dim % 4 == 0 and lstm_hidden_units <= 256")
         if joint_training and not spk_feat and feat_type != "consistent":
@@ -231,30 +231,34 @@ class TFGridNet(nn.Module):
         self.deconv = nn.ConvTranspose2d(emb_dim, n_srcs * 2, (3, 3), padding=(1, 1))
 
     def forward(self, input, embeddings):
-        """input [B, N] mixture; embeddings [B, E] (fixed) or fbank / raw audio (joint) -> (est [B, N], dummy or logits)
-        (tfgridnet.py:197-302)."""
-        if input.dim() != 2:
-            raise RuntimeError("TFGridNet expects a [batch, samples] mixture (single microphone)")
+        """input [B, N] mixture ([B, N, M] with n_imics = M > 1); embeddings [B, E] (fixed) or fbank / raw audio (joint)
+        -> (est [B, N] or [B, n_srcs, N], dummy or logits) (tfgridnet.py:197-302)."""
+        M, S = self.n_imics, self.n_srcs
+        if input.dim() != (2 if M == 1 else 3) or (M > 1 and input.shape[2] != M):
+            raise RuntimeError(f"TFGridNet expects a [batch, samples] mixture (n_imics = 1) or [batch, samples, {M}]")
         wav = input.float().contiguous()
-        B, n = wav.shape
+        B, n = wav.shape[0], wav.shape[1]
         d = wav.device
         if n % 4:
             raise NotImplementedError("TF-GridNet: the number of samples must be a multiple of 4 (16-byte rows)")
-        with torch.no_grad():                     # RMS normalisation by the (unbiased) standard deviation of each row
+        with torch.no_grad():   # RMS normalisation by the (unbiased) standard deviation over samples and microphones
             from .. import dev
             st = torch.empty(B, 2, device=d, dtype=torch.float32)
-            dev.flat_stats(wav, B, n, st, 0.0)
-            std = torch.sqrt(1.0 / (st[:, 1] ** 2) * (n / (n - 1.0)))                # [B]
-            inv = (1.0 / std).view(B, 1).contiguous()
-            x = torch.empty_like(wav)
-            dev.scale_bf_fwd(wav, inv, B, 1, 1, n, 0, x)
+            dev.flat_stats(wav.view(B, n * M), B, n * M, st, 0.0)
+            std = torch.sqrt(1.0 / (st[:, 1] ** 2) * (n * M / (n * M - 1.0)))        # [B]
+            inv = (1.0 / std).repeat_interleave(M).view(B * M, 1).contiguous()
+            rows = wav if M == 1 else wav.transpose(1, 2).contiguous().view(B * M, n)   # [B, N, M] -> [B*M, N]
+            x = torch.empty_like(rows)
+            dev.scale_bf_fwd(rows, inv, B * M, 1, 1, n, 0, x)
         spec, Tf = FD.stft_ri(x, self.n_fft, self.stride)
         Fq = self.n_fft // 2 + 1
-        x4 = torch.zeros(B * Tf * Fq, 4, device=d, dtype=torch.float32)
-        x4[:, :2] = spec[:, :2 * Fq].reshape(B * Tf * Fq, 2)
+        Cp = -(-2 * M // 4) * 4                  # the implicit-patch operand moves 16-byte channel groups
+        x4 = torch.zeros(B * Tf * Fq, Cp, device=d, dtype=torch.float32)
+        # channels (re_0 .. re_{M-1}, im_0 .. im_{M-1}) like cat((real, imag), 1) of [B, M, T, F] (tfgridnet.py:241-244)
+        x4[:, :2 * M] = spec[:, :2 * Fq].reshape(B, M, Tf, Fq, 2).permute(0, 2, 3, 4, 1).reshape(B * Tf * Fq, 2 * M)
         c0, gn = self.conv[0], self.conv[1]
         C = c0.weight.shape[0]
-        w4 = torch.cat([c0.weight, torch.zeros(C, 2, 3, 3, device=d, dtype=torch.float32)], 1)
+        w4 = torch.cat([c0.weight, torch.zeros(C, Cp - 2 * M, 3, 3, device=d, dtype=torch.float32)], 1)
         h = FD.Conv2dFn.apply(x4, w4, c0.bias, (B, Tf, Fq, 1, 1))
         h = FG.GroupLNFn.apply(h, gn.weight, gn.bias, (B, Tf * Fq))
         logits = torch.tensor(0.0, device=d)
@@ -273,10 +277,11 @@ class TFGridNet(nn.Module):
         for blk in self.blocks:
             h = fuse_bins(self.spk_fuse, h, emb, (B, Tf, Fq))        # the same fusion before every block (tfgridnet.py:272-276)
             h = blk(h, (B, Tf, Fq))
-        out = FD.ConvTranspose2dFn.apply(h, self.deconv.weight, self.deconv.bias, (B, Tf, Fq, 1, 1))   # [B*T*F, 2]
+        out = FD.ConvTranspose2dFn.apply(h, self.deconv.weight, self.deconv.bias, (B, Tf, Fq, 1, 1))   # [B*T*F, 2S]
         ld = -(-2 * Fq // 4) * 4
-        est_spec = torch.zeros(B * Tf, ld, device=d, dtype=torch.float32)
-        est_spec[:, :2 * Fq] = out.reshape(B * Tf, 2 * Fq)
-        est = FD.IstftFn.apply(est_spec, (B, Tf, n, self.n_fft, self.stride))
-        est = FD.ScaleBFFn.apply(est.contiguous(), std.view(B, 1).contiguous(), (B, 1, 1, 0))
-        return est, logits
+        est_spec = torch.zeros(B * S * Tf, ld, device=d, dtype=torch.float32)
+        # channel 2s + (0 re | 1 im) of source s (tfgridnet.py:280-282): one spectrogram row block per (b, s)
+        est_spec[:, :2 * Fq] = out.view(B, Tf, Fq, S, 2).permute(0, 3, 1, 2, 4).reshape(B * S * Tf, 2 * Fq)
+        est = FD.IstftFn.apply(est_spec, (B * S, Tf, n, self.n_fft, self.stride))
+        est = FD.ScaleBFFn.apply(est.contiguous(), std.repeat_interleave(S).view(B * S, 1).contiguous(), (B * S, 1, 1, 0))
+        return (est if S == 1 else est.view(B, S, n)), logits
