@@ -263,11 +263,47 @@ def test_variants_match_reference_fixture(name, golden_dir):
     check_variant(model, g, outs, loss)
 
 
+def test_joint_training_with_a_wespeaker_encoder_on_fbank(golden_dir):
+    """spk_feat = True (convtasnet.py:100-115,188-192): the enrollment is fbank [R, Te, F] through a wespeaker encoder of
+    models/resnet.py (ResNet18 here), its embedding conditions the separator, the multi-task head returns logits.  The
+    three estimates against oracle(ResNet restatement) -> oracle(Conv-TasNet on that embedding); the loss reaches the
+    encoder's first convolution."""
+    from oracle import bsrnn_oracle as O
+    from oracle import convtasnet_oracle as CT
+    from oracle import resnet_oracle as RO
+    from wesep_amd.models import get_model
+    d = _cuda()
+    kw = dict(N=32, L=20, B=32, H=64, P=3, X=2, R=2)
+    cfg = CT.ConvTasNetConfig(**kw, spk_emb_dim=64)
+    sep = CT.synth_params(cfg, 61)
+    rkw = dict(num_blocks=RO.NUM_BLOCKS["ResNet18"], m=32, feat_dim=16, embed_dim=64)
+    spk = {"spk_model." + k: v for k, v in RO.synth_params(62, **rkw).items()}
+    model = get_model("ConvTasNet")(**kw, spk_emb_dim=64, use_spk_transform=False, joint_training=True, spk_feat=True,
+                                    multi_task=True, spksInTrain=7, spk_model="ResNet18",
+                                    spk_args=dict(feat_dim=16, embed_dim=64, pooling_func="TSTP", two_emb_layer=False))
+    sd = model.state_dict()
+    head = {k: v for k, v in sd.items() if k.startswith("pred_linear.")}
+    model.load_state_dict({**sep, **spk, **head}, strict=True)
+    model = model.to(d).train()
+    wav, tgt, _ = O.synth_batch(4, 1600, 61)
+    fbank = torch.randn(4, 40, 16, generator=torch.Generator().manual_seed(63))
+    outs = model(wav.to(d), fbank.to(d))
+    assert len(outs) == 4 and tuple(outs[3].shape) == (4, 7)
+    emb = RO.resnet_forward({k[len("spk_model."):]: v.clone() for k, v in spk.items()}, fbank, num_blocks=rkw["num_blocks"], m=32)
+    ref = CT.convtasnet_forward({k: v.clone() for k, v in sep.items()}, cfg, wav, emb.detach())
+    for i in range(3):
+        assert rel(outs[i], ref[i]) < 2e-3, i
+    loss = _gpu_loss(outs[:3], tgt.to(d)) + outs[3].square().mean()
+    loss.backward()
+    gw = model.spk_model.conv1.weight.grad
+    assert gw is not None and torch.isfinite(gw).all() and float(gw.norm()) > 0
+
+
 def test_unbuilt_variants_fail_loudly():
     from wesep_amd.models import get_model
     cls = get_model("ConvTasNet")
-    for kw in (dict(joint_training=True, spk_feat=True), dict(joint_training=False, encoder_type="Deep"),
-               dict(joint_training=True, encoder_type="Deep", decoder_type="Deep"),
+    for kw in (dict(joint_training=True, spk_feat=False, feat_type="other"), dict(joint_training=False, encoder_type="Deep"),
+               dict(joint_training=True, spk_feat=False, encoder_type="Deep", decoder_type="Deep"),
                dict(joint_training=False, activate="softmax", encoder_type=None, decoder_type=None),
                dict(joint_training=False, spk_fuse_type="nope"), dict(joint_training=False, multi_fuse=False)):
         with pytest.raises(NotImplementedError):

@@ -61,3 +61,4 @@ def test_convtasnet_variant_gpu_test_bodies(emu, monkeypatch, golden_dir):
         t.test_causal_dwconv_fwd_bwd(dil, P)
     for name in ("convtasnet_plain_skip_r2_t1600", "convtasnet_multi_bn_skip_r4_t1600"):
         t.test_variants_match_reference_fixture(name, golden_dir)
+    t.test_joint_training_with_a_wespeaker_encoder_on_fbank(golden_dir)
