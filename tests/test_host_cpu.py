@@ -96,7 +96,7 @@ def test_film_zero_init_and_factory_errors():
     with pytest.raises(NotImplementedError):
         get_model("BSRNN")(joint_training=True)
     with pytest.raises(NotImplementedError):
-        get_model("TFGridNet")(n_imics=2, joint_training=False)     # multi-microphone TF-GridNet is not built
+        get_model("TFGridNet")(window="hamming", joint_training=False)     # only the hann window is built
     with pytest.raises(NotImplementedError):
         get_model("BSRNN_Feats")
     with pytest.raises(NotImplementedError):                        # the self-enrollment pass needs raw-audio joint training
