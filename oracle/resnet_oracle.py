@@ -47,7 +47,7 @@ def _bn_shapes(s, name, c):
 
 
 def param_shapes(num_blocks=(3, 4, 6, 3), m=32, feat_dim=80, embed_dim=256, prefix="", bottleneck=False,
-                 two_emb_layer=False) -> Dict[str, tuple]:
+                 two_emb_layer=False, pooling="TSTP") -> Dict[str, tuple]:
     s: Dict[str, tuple] = {}
     ex = 4 if bottleneck else 1
     s[prefix + "conv1.weight"] = (m, 1, 3, 3)
@@ -70,7 +70,10 @@ def param_shapes(num_blocks=(3, 4, 6, 3), m=32, feat_dim=80, embed_dim=256, pref
             s[q + "shortcut.0.weight"] = (ex * planes, inp, 1, 1)
             _bn_shapes(s, q + "shortcut.1", ex * planes)
     stats_dim = (feat_dim // 8) * m * 8 * ex
-    s[prefix + "seg_1.weight"] = (embed_dim, 2 * stats_dim)
+    if pooling == "ASTP":      # pooling_layers.ASTP(in_dim, bottleneck_dim=128): two 1x1 convolutions
+        s[prefix + "pool.linear1.weight"], s[prefix + "pool.linear1.bias"] = (128, stats_dim, 1), (128,)
+        s[prefix + "pool.linear2.weight"], s[prefix + "pool.linear2.bias"] = (stats_dim, 128, 1), (stats_dim,)
+    s[prefix + "seg_1.weight"] = (embed_dim, (1 if pooling in ("TAP", "TSDP") else 2) * stats_dim)
     s[prefix + "seg_1.bias"] = (embed_dim,)
     if two_emb_layer:      # seg_bn_1 = BatchNorm1d(embed_dim, affine=False): buffers only
         s[prefix + "seg_bn_1.running_mean"], s[prefix + "seg_bn_1.running_var"] = (embed_dim,), (embed_dim,)
@@ -107,7 +110,7 @@ def synth_params(seed: int, **kw) -> Dict[str, torch.Tensor]:
 
 
 def resnet_forward(p, x, num_blocks=(3, 4, 6, 3), m=32, prefix="", training=True, new_buffers=None, relu_masks=None,
-                   bottleneck=False, two_emb_layer=False):
+                   bottleneck=False, two_emb_layer=False, pooling="TSTP"):
     """x [B, T, F] -> embed_a [B, embed_dim]  (two_emb_layer: (embed_a, embed_b), embed_b = seg_2(BN(relu(embed_a)))).
     relu_masks: optional list of boolean [B, C, F', T'] tensors, one per ReLU in evaluation order (stem, then per block:
     after bn1, after the residual sum): the ReLU then multiplies by the given mask instead of by (z > 0).  Tests use it
@@ -144,9 +147,20 @@ def resnet_forward(p, x, num_blocks=(3, 4, 6, 3), m=32, prefix="", training=True
         if (q + "shortcut.0.weight") in p:
             sc = bn(q + "shortcut.1", F.conv2d(y, p[q + "shortcut.0.weight"], stride=stride))
         y = relu(o + sc)
-    mean = y.mean(-1)
-    std = torch.sqrt(torch.var(y, dim=-1) + 1e-7)
-    stats = torch.cat((mean.flatten(1), std.flatten(1)), 1)
+    # pooling_layers.py: TSTP mean || std, TAP mean, TSDP std (unbiased variance + 1e-7), ASTP attentive statistics on
+    # the [B, C * F', T] view (softmax over T of W2 tanh(W1 x); weighted mean || sqrt(clamp(weighted var, 1e-7)))
+    if pooling == "ASTP":
+        h = y.reshape(y.shape[0], y.shape[1] * y.shape[2], y.shape[3])
+        a = torch.tanh(F.conv1d(h, p[prefix + "pool.linear1.weight"], p[prefix + "pool.linear1.bias"]))
+        alpha = torch.softmax(F.conv1d(a, p[prefix + "pool.linear2.weight"], p[prefix + "pool.linear2.bias"]), dim=2)
+        mean = torch.sum(alpha * h, dim=2)
+        var = torch.sum(alpha * h ** 2, dim=2) - mean ** 2
+        stats = torch.cat([mean, torch.sqrt(var.clamp(min=1e-7))], 1)
+    else:
+        mean = y.mean(-1)
+        std = torch.sqrt(torch.var(y, dim=-1) + 1e-7)
+        stats = {"TSTP": torch.cat((mean.flatten(1), std.flatten(1)), 1), "TAP": mean.flatten(1),
+                 "TSDP": std.flatten(1)}[pooling]
     embed_a = F.linear(stats, p[prefix + "seg_1.weight"], p[prefix + "seg_1.bias"])
     if not two_emb_layer:
         return embed_a

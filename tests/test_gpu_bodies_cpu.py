@@ -62,3 +62,10 @@ def test_convtasnet_variant_gpu_test_bodies(emu, monkeypatch, golden_dir):
     for name in ("convtasnet_plain_skip_r2_t1600", "convtasnet_multi_bn_skip_r4_t1600"):
         t.test_variants_match_reference_fixture(name, golden_dir)
     t.test_joint_training_with_a_wespeaker_encoder_on_fbank(golden_dir)
+
+
+def test_resnet_pooling_gpu_test_bodies(emu, monkeypatch):
+    import tests.test_resnet_gpu as t
+    monkeypatch.setattr(t, "_cuda", lambda: torch.device("cpu"))
+    for pooling in ("TAP", "TSDP", "ASTP"):
+        t.test_resnet_pooling_variants_match_oracle(pooling)

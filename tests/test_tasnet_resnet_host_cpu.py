@@ -252,3 +252,31 @@ def _small_campplus(MC, blocks, feat_dim, embed_dim):
         return MC.CAMPPlus(feat_dim=feat_dim, embed_dim=embed_dim, pooling_func="TSTP")
     finally:
         del MC.zip
+
+
+@pytest.mark.parametrize("pooling", ["TAP", "TSDP", "ASTP"])
+def test_resnet_pooling_variants_host_logic_matches_restatement(pooling, monkeypatch):
+    """wespeaker pooling layers other than TSTP on the ResNet (`pooling_func`): temporal average, temporal standard
+    deviation, attentive statistics -- strict load under wespeaker's names (`pool.linear1/2` for ASTP), embedding and
+    every parameter gradient against the restatement."""
+    from wesep_amd.models import resnet as MR
+    emu_dev.install(monkeypatch)
+    kw = dict(num_blocks=(1, 1, 1, 1), m=32, feat_dim=16, embed_dim=64, pooling=pooling)
+    params = RO.synth_params(8, **kw)
+    model = MR.ResNet(MR.BasicBlock, [1, 1, 1, 1], feat_dim=16, embed_dim=64, pooling_func=pooling, two_emb_layer=False)
+    model.load_state_dict(params, strict=True)
+    model.train()
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    g = torch.Generator().manual_seed(14)
+    x, probe = torch.randn(4, 40, 16, generator=g), torch.randn(4, 64, generator=g)
+    _, emb = model(x)
+    (emb * probe).sum().backward()
+    p = {k: (v.clone() if RO.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in params.items()}
+    ref = RO.resnet_forward(p, x, num_blocks=kw["num_blocks"], m=32, pooling=pooling)
+    (ref * probe).sum().backward()
+    assert float((emb.detach() - ref.detach()).norm() / ref.detach().norm()) < 1e-4
+    for k, prm in model.named_parameters():
+        if k == "pool.linear2.bias":       # a per-channel shift of the attention logits: softmax over T ignores it
+            continue
+        gn = float(p[k].grad.norm())
+        assert abs(float(prm.grad.norm()) - gn) <= 2e-2 * gn + 1e-4, k

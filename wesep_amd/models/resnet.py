@@ -11,7 +11,7 @@ from ..functional import LinearFn
 
 
 class TSTP(nn.Module):
-    """Temporal statistics pooling (no parameters)."""
+    """Temporal statistics pooling (no parameters): mean || std."""
 
     def __init__(self, in_dim=0, **kwargs):
         super().__init__()
@@ -19,6 +19,31 @@ class TSTP(nn.Module):
 
     def get_out_dim(self):
         return self.in_dim * 2
+
+
+class TAP(TSTP):
+    """Temporal average pooling: the mean half of TSTP."""
+
+    def get_out_dim(self):
+        return self.in_dim
+
+
+class TSDP(TSTP):
+    """Temporal standard-deviation pooling: the std half of TSTP."""
+
+    def get_out_dim(self):
+        return self.in_dim
+
+
+def _pooling_layer(name, in_dim):
+    """wespeaker.models.pooling_layers by name: TSTP / TAP / TSDP (one statistics kernel) and ASTP (attentive statistics,
+    the ECAPA-TDNN module of models/ecapa_tdnn.py on the [R, C * F', T] view)."""
+    if name in ("TSTP", "TAP", "TSDP"):
+        return {"TSTP": TSTP, "TAP": TAP, "TSDP": TSDP}[name](in_dim=in_dim)
+    if name == "ASTP":
+        from .ecapa_tdnn import ASTP
+        return ASTP(in_dim=in_dim)
+    raise NotImplementedError(f"pooling_func {name!r}: TSTP, TAP, TSDP and ASTP are built (not MHASTP / MQMHASTP)")
 
 
 class BasicBlock(nn.Module):
@@ -69,8 +94,7 @@ class ResNet(nn.Module):
     def __init__(self, block, num_blocks, m_channels=32, feat_dim=40, embed_dim=128, pooling_func="TSTP",
                  two_emb_layer=True):
         super().__init__()
-        if pooling_func != "TSTP":
-            raise NotImplementedError(f"pooling_func {pooling_func!r}: only TSTP is built")
+        self.pooling_func = pooling_func
         self.in_planes, self.feat_dim, self.embed_dim = m_channels, feat_dim, embed_dim
         self.stats_dim = int(feat_dim / 8) * m_channels * 8
         self.two_emb_layer = two_emb_layer
@@ -80,7 +104,7 @@ class ResNet(nn.Module):
         self.layer2 = self._make_layer(block, m_channels * 2, num_blocks[1], stride=2)
         self.layer3 = self._make_layer(block, m_channels * 4, num_blocks[2], stride=2)
         self.layer4 = self._make_layer(block, m_channels * 8, num_blocks[3], stride=2)
-        self.pool = TSTP(in_dim=self.stats_dim * block.expansion)
+        self.pool = _pooling_layer(pooling_func, self.stats_dim * block.expansion)
         self.pool_out_dim = self.pool.get_out_dim()
         self.seg_1 = nn.Linear(self.pool_out_dim, embed_dim)
         if two_emb_layer:
@@ -122,7 +146,17 @@ class ResNet(nn.Module):
                     o = _cba(y, None, R, H, W, s, True, blk.conv1, blk.bn1, tr)
                     y = _cba(o, sc, R, Ho, Wo, 1, True, blk.conv2, blk.bn2, tr)
                 H, W = Ho, Wo
-        stats = FR.TstpFn.apply(y, (R, H, W))
+        if self.pooling_func == "ASTP":      # [R, F', T, C] -> frames [R*T, C * F'] (feature index c * F' + f), then ASTP
+            Cc = y.shape[1]
+            frames = y.view(R, H, W, Cc).permute(0, 2, 3, 1).reshape(R * W, Cc * H)
+            stats = self.pool.run(frames, R, W)
+        else:
+            stats = FR.TstpFn.apply(y, (R, H, W))                               # mean || std, each [C * F']
+            half = stats.shape[1] // 2
+            if self.pooling_func == "TAP":
+                stats = stats[:, :half].contiguous()
+            elif self.pooling_func == "TSDP":
+                stats = stats[:, half:].contiguous()
         embed_a = LinearFn.apply(stats, self.seg_1.weight, self.seg_1.bias)
         if not self.two_emb_layer:
             return torch.tensor(0.0), embed_a
