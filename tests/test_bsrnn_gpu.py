@@ -346,36 +346,23 @@ def test_fused_input_projection_recurrence_matches_two_kernel_path(monkeypatch):
     blk = ResRNN(N, 2 * N).to(d)
     z0 = torch.randn(R, K, Tf, N, device=d)
     gout = torch.randn(R, K, Tf, N, device=d)
-
-    def both():
-        res = {}
-        for fuse in ("0", "1"):
-            monkeypatch.setenv("WESEP_LSTM_FUSE", fuse)
-            assert dev.lstm_fuse_ok(R * Tf, False) == (fuse == "1")
-            z = z0.clone().requires_grad_(True)
-            for p_ in blk.parameters():
-                p_.grad = None
-            out = blk(z, "band")
-            out.backward(gout)
-            torch.cuda.synchronize()
-            res[fuse] = (out.detach(), z.grad.detach(), {k: v.grad.detach().clone() for k, v in blk.named_parameters()})
-        errs = {"out": rel(res["1"][0], res["0"][0]), "dz": rel(res["1"][1], res["0"][1])}
-        errs.update({k: rel(res["1"][2][k], res["0"][2][k]) for k in res["0"][2]})
-        return errs
-
-    def bad(errs):
-        return {k: v for k, v in errs.items() if not v < (1e-4 if k == "out" else 5e-4)}
-
-    errs = both()
-    if bad(errs):
-        # Inputs and kernels are deterministic (9 of 9 isolated runs and every earlier suite run agree bit for bit), yet
-        # ONE of five whole-suite runs on the MI355X failed here once, unreproduced since (status):
-        # evaluate again so that a report says whether a mismatch is systematic (fails) or transient (warns loudly).
-        first = bad(errs)
-        again = both()
-        assert not bad(again), (first, bad(again))
-        import warnings
-        warnings.warn(f"fused-vs-two-kernel mismatch on the first evaluation only (transient): {first}")
+    res = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("WESEP_LSTM_FUSE", fuse)
+        assert dev.lstm_fuse_ok(R * Tf, False) == (fuse == "1")
+        z = z0.clone().requires_grad_(True)
+        for p_ in blk.parameters():
+            p_.grad = None
+        out = blk(z, "band")
+        out.backward(gout)
+        torch.cuda.synchronize()
+        res[fuse] = (out.detach(), z.grad.detach(), {k: v.grad.detach().clone() for k, v in blk.named_parameters()})
+    # (this is the test that failed once, unreproduced, in the middle of a whole-suite run: DESIGN.md section 11b; a
+    # failing gpu test is evaluated a second time by tests/conftest.py and listed if only the first evaluation failed)
+    assert rel(res["1"][0], res["0"][0]) < 1e-4
+    assert rel(res["1"][1], res["0"][1]) < 5e-4
+    for k in res["0"][2]:
+        assert rel(res["1"][2][k], res["0"][2][k]) < 5e-4, k
 
 
 def test_training_step_reads_no_uninitialised_memory():
