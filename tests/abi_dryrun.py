@@ -20,6 +20,8 @@ def install(monkeypatch):
     import wesep_amd.functional_resnet as fr
     import wesep_amd.functional_tasnet as ft
     import wesep_amd.functional_tfgridnet as fg
+    import wesep_amd.functional_campplus as fc
+    import wesep_amd.functional_ecapa as fe
     calls = []
 
     def check(rc, what=""):
@@ -31,7 +33,7 @@ def install(monkeypatch):
     import wesep_amd.dev as dev
     monkeypatch.setattr(dev, "cu_count", lambda device: 256)          # MI355X
     monkeypatch.setenv("WESEP_WGRAD_OVERLAP", "0")                    # no side streams without a device
-    for mod in (f0, fd, ft, fg, fr):
+    for mod in (f0, fd, ft, fg, fr, fc, fe):
         monkeypatch.setattr(mod, "_need_cuda", lambda t, who: None)
     return calls
 

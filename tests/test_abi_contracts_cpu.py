@@ -206,3 +206,64 @@ def test_tfgridnet_blocked_recurrence_path_contracts(monkeypatch, B, T):
     assert tuple(est.shape) == (B, T)
     used = _check(calls, 100)
     assert {"ws_gemm_p2b", "ws_gemm_b2p", "ws_gemm_tnb", "ws_lstm_bwd"} <= used
+
+
+@pytest.mark.parametrize("spk_model,spk_args,E", [
+    ("ECAPA_TDNN_GLOB_c512", dict(feat_dim=80, embed_dim=192, pooling_func="ASTP"), 192),       # bsrnn.yaml:66-71
+    ("ECAPA_TDNN_c1024", dict(feat_dim=80, embed_dim=256, pooling_func="ASTP", emb_bn=True), 256),
+    ("CAMPPlus", dict(feat_dim=80, embed_dim=512, pooling_func="TSTP"), 512),                    # bsrnn.yaml:72-74
+    ("ResNet50", dict(feat_dim=80, embed_dim=256, pooling_func="ASTP", two_emb_layer=True), 256)])
+def test_joint_bsrnn_with_the_other_recipe_encoders_contracts(monkeypatch, spk_model, spk_args, E):
+    """The recipe's alternative speaker encoders at their full size (ECAPA-TDNN 6.2 M, CAM++ 7.2 M parameters, a
+    Bottleneck ResNet with attentive pooling and two embedding layers) inside a jointly trained pBSRNN: every launch of
+    forward + backward passes the real library's argument validation (250 enrollment frames: three mask segments after
+    CAM++'s stride-2 layer)."""
+    from wesep_amd.models import get_model
+    calls = abi_dryrun.install(monkeypatch)
+    model = get_model("BSRNN")(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                               joint_training=True, spk_feat=True, spk_emb_dim=E, spk_model=spk_model, spk_args=spk_args)
+    est, _ = _fwd_bwd(model, torch.randn(4, 8000), torch.randn(4, 250, 80))
+    assert tuple(est.shape) == (4, 8000)
+    seen = _check(calls, 300)
+    if spk_model == "CAMPPlus":
+        assert {"ws_seg_sums", "ws_seg_scale"} <= seen
+    if "ECAPA" in spk_model:
+        assert {"ws_astp_fwd", "ws_astp_bwd"} <= seen
+
+
+@pytest.mark.parametrize("kw", [
+    dict(N=512, L=16, B=128, H=512, P=3, X=8, R=3, encoder_type=None, decoder_type=None, skip_con=True),   # classic sizes
+    dict(N=256, L=20, B=256, H=512, P=3, X=4, R=2, encoder_type="Deep", decoder_type="Deep", causal=True, norm="cLN",
+         activate="sigmoid", spk_fuse_type="FiLM"),
+    dict(N=256, L=20, B=256, H=512, P=3, X=4, R=2, norm="BN", skip_con=True, causal=True)])
+def test_convtasnet_variant_contracts(monkeypatch, kw):
+    """The non-recipe halves of the ConvTasNet constructor (plain / Deep ends, skip, causal, BN) at production widths."""
+    from wesep_amd.models import get_model
+    calls = abi_dryrun.install(monkeypatch)
+    model = get_model("ConvTasNet")(joint_training=False, use_spk_transform=False, **kw)
+    model.train()
+    out = model(torch.randn(2, 8000), torch.randn(2, 256))
+    outs = out if isinstance(out, (list, tuple)) else [out]
+    sum(o.sum() for o in outs).backward()
+    unused = {n for n, p in model.named_parameters() if p.grad is None}
+    assert all(".Output." in n for n in unused), unused       # skip_con: only the last blocks' residual Output convs
+    seen = _check(calls, 100)
+    if kw.get("causal"):
+        assert "ws_dwconv_ex_fwd" in seen
+
+
+def test_tfgridnet_multi_source_and_dpccn_causal_contracts(monkeypatch):
+    from wesep_amd.models import get_model
+    calls = abi_dryrun.install(monkeypatch)
+    model = get_model("TFGridNet")(n_fft=128, stride=64, n_layers=1, lstm_hidden_units=192, attn_n_head=4,
+                                   attn_approx_qk_dim=512, emb_dim=48, emb_ks=4, emb_hs=1, n_srcs=3, n_imics=4,
+                                   use_spk_transform=False, spk_fuse_type="multiply", joint_training=False)
+    est, _ = _fwd_bwd(model, torch.randn(2, 6400, 4), torch.randn(2, 256))
+    assert tuple(est.shape) == (2, 3, 6400)
+    _check(calls, 100)
+    calls.clear()
+    model = get_model("DPCCN")(win=512, stride=128, feature_dim=257, tcn_blocks=10, tcn_layers=2, causal=True,
+                               spk_fuse_type="FiLM", use_spk_transform=False, joint_training=False)
+    est, _ = _fwd_bwd(model, torch.randn(2, 16384), torch.randn(2, 256))
+    assert tuple(est.shape) == (2, 16384)
+    _check(calls, 300)
