@@ -159,8 +159,8 @@ struct ConvPrep {           // conv (bias-free) + BatchNorm(eval) (+ ReLU) of th
   float *w2, *st;           // [cout][ldp] in im2col column order; [2][cout] = (running mean, rstd)
 };
 
-struct BlockPrep {
-  ConvPrep c1, c2, sc;
+struct BlockPrep {          // BasicBlock: c1 (3x3, stride) c2 (3x3); Bottleneck: c1 (1x1) c2 (3x3, stride) c3 (1x1, x4)
+  ConvPrep c1, c2, c3, sc;
   bool has_sc;
 };
 
@@ -206,6 +206,8 @@ struct ws_engine {
   std::vector<BlockPrep> res_blocks;
   // ECAPA-TDNN speaker encoder (spk_kind 1; wesep_amd/models/ecapa_tdnn.py)
   int spk_kind = 0, spk_channels = 512, spk_glob = 0, spk_emb_bn = 0;
+  int spk_bottleneck = 0, spk_two_emb = 0;        // wespeaker ResNet50 / 101 / 152 blocks; seg_1 -> ReLU -> BN -> seg_2
+  float* seg_bn_st = nullptr;
   TdnnPrep tdnn1;
   std::vector<SeRes2Prep> se_blocks;
   float *id_st = nullptr, *id_one = nullptr, *id_zero = nullptr;   // identity BatchNorm operands: y = x + res
@@ -478,8 +480,10 @@ int prep_conv(ws_engine* e, const std::string& conv, const std::string& bn, int 
   return WS_OK;
 }
 
+float* bn_eval_stats(ws_engine* e, const std::string& bn, int c);
+
 int prep_resnet(ws_engine* e) {
-  const int m = 32;
+  const int m = 32, ex = e->spk_bottleneck ? 4 : 1;
   const std::string p = "spk_model.";
   int rc = prep_conv(e, p + "conv1", p + "bn1", 1, m, 3, 1, true, &e->stem);
   if (rc != WS_OK) return rc;
@@ -490,21 +494,38 @@ int prep_resnet(ws_engine* e) {
       const std::string q = p + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
       const int stride = bi == 0 ? first_stride : 1;
       BlockPrep b;
-      b.has_sc = stride != 1 || inp != planes;
-      if ((rc = prep_conv(e, q + "conv1", q + "bn1", inp, planes, 3, stride, true, &b.c1)) != WS_OK) return rc;
-      if ((rc = prep_conv(e, q + "conv2", q + "bn2", planes, planes, 3, 1, true, &b.c2)) != WS_OK) return rc;
-      if (b.has_sc && (rc = prep_conv(e, q + "shortcut.0", q + "shortcut.1", inp, planes, 1, stride, false, &b.sc)) != WS_OK)
+      b.has_sc = stride != 1 || inp != ex * planes;
+      if (e->spk_bottleneck) {
+        if ((rc = prep_conv(e, q + "conv1", q + "bn1", inp, planes, 1, 1, true, &b.c1)) != WS_OK) return rc;
+        if ((rc = prep_conv(e, q + "conv2", q + "bn2", planes, planes, 3, stride, true, &b.c2)) != WS_OK) return rc;
+        if ((rc = prep_conv(e, q + "conv3", q + "bn3", planes, ex * planes, 1, 1, true, &b.c3)) != WS_OK) return rc;
+      } else {
+        if ((rc = prep_conv(e, q + "conv1", q + "bn1", inp, planes, 3, stride, true, &b.c1)) != WS_OK) return rc;
+        if ((rc = prep_conv(e, q + "conv2", q + "bn2", planes, planes, 3, 1, true, &b.c2)) != WS_OK) return rc;
+      }
+      if (b.has_sc &&
+          (rc = prep_conv(e, q + "shortcut.0", q + "shortcut.1", inp, ex * planes, 1, stride, false, &b.sc)) != WS_OK)
         return rc;
       e->res_blocks.push_back(b);
-      inp = planes;
+      inp = ex * planes;
     }
   }
-  const int stats_dim = (e->feat_dim / 8) * m * 8;
+  const int stats_dim = (e->feat_dim / 8) * m * 8 * ex;
   if (!require(e, p + "seg_1.weight", {e->E, 2 * stats_dim}) || !require(e, p + "seg_1.bias", {e->E})) return WS_ERR_INVALID;
   const float s0 = 0.f, s1 = 1.f;
   e->slope0 = upload(e, e->persist, &s0, 1);
   e->slope1 = upload(e, e->persist, &s1, 1);
   WS_PTR(e->slope0 && e->slope1);
+  if (e->spk_two_emb) {        // embed_b = seg_2(BatchNorm1d(affine = False)(relu(seg_1(stats)))): the separator takes it
+    if (!require(e, p + "seg_bn_1.running_mean", {e->E}) || !require(e, p + "seg_bn_1.running_var", {e->E}) ||
+        !require(e, p + "seg_2.weight", {e->E, e->E}) || !require(e, p + "seg_2.bias", {e->E}))
+      return WS_ERR_INVALID;
+    e->seg_bn_st = bn_eval_stats(e, p + "seg_bn_1", e->E);
+    std::vector<float> one(e->E, 1.f), zero(e->E, 0.f);
+    e->id_one = upload(e, e->persist, one.data(), one.size());
+    e->id_zero = upload(e, e->persist, zero.data(), zero.size());
+    WS_PTR(e->seg_bn_st && e->id_one && e->id_zero);
+  }
   return WS_OK;
 }
 
@@ -707,6 +728,8 @@ int prepare(ws_engine* e) {
   e->spk_channels = static_cast<int>(meta_or(e, "spk_channels", 512));
   e->spk_glob = static_cast<int>(meta_or(e, "spk_glob", 0));
   e->spk_emb_bn = static_cast<int>(meta_or(e, "spk_emb_bn", 0));
+  e->spk_bottleneck = static_cast<int>(meta_or(e, "spk_bottleneck", 0));
+  e->spk_two_emb = static_cast<int>(meta_or(e, "spk_two_emb", 0));
   if (e->spk_kind < 0 || e->spk_kind > 1) {
     set_err("engine: speaker encoder kind %d is not built (0 ResNet, 1 ECAPA-TDNN)", e->spk_kind);
     return WS_ERR_INVALID;
@@ -1043,9 +1066,10 @@ int conv_bn_act(ws_engine* e, const ConvPrep& c, const float* x, const float* re
   return WS_OK;
 }
 
-// fbank [R][Te][F] (device) -> embedding [R][E]   (wespeaker ResNet, eval mode; models/resnet.py:80-102)
+// fbank [R][Te][F] (device) -> embedding [R][E]   (wespeaker ResNet, eval mode; models/resnet.py: BasicBlock and
+// Bottleneck stacks, TSTP, one or two embedding layers)
 int resnet_embed(ws_engine* e, const float* fbank, int R, int Te, float* emb) {
-  const int F = e->feat_dim;
+  const int F = e->feat_dim, ex = e->spk_bottleneck ? 4 : 1;
   void* s = e->stream;
   Arena& a = e->work;
   const Arena::Mark mk = a.mark();
@@ -1055,33 +1079,61 @@ int resnet_embed(ws_engine* e, const float* fbank, int R, int Te, float* emb) {
   for (int r = 0; r < R; ++r)
     WS_RUN(e, ws_transpose(fbank + size_t(r) * Te * F, Te, F, F, x + size_t(r) * F * Te, s));
   int H = F, W = Te, Ho, Wo, rc;
-  // ping-pong activation buffers sized for the stem output (the largest activation)
-  const size_t act = size_t(R) * H * W * 32;
-  float* bufs[3] = {a.alloc(act), a.alloc(act), a.alloc(act)};
-  WS_PTR(bufs[0] && bufs[1] && bufs[2]);
+  // rotating activation buffers sized for the largest activation (the first stage's output: 32 * ex channels)
+  const size_t act = size_t(R) * H * W * 32 * ex;
+  float* bufs[4] = {a.alloc(act), a.alloc(act), a.alloc(act), nullptr};
+  bufs[3] = e->spk_bottleneck ? a.alloc(act) : bufs[0];        // BasicBlock stacks rotate through three
+  WS_PTR(bufs[0] && bufs[1] && bufs[2] && bufs[3]);
   if ((rc = conv_bn_act(e, e->stem, x, nullptr, R, H, W, bufs[0], &Ho, &Wo)) != WS_OK) return rc;
   int cur = 0, C = 32;
   for (const BlockPrep& b : e->res_blocks) {
     float* y = bufs[cur];
-    float* o = bufs[(cur + 1) % 3];
-    float* sc = bufs[(cur + 2) % 3];
+    float* t1 = bufs[(cur + 1) % 4];
+    float* t2 = bufs[(cur + 2) % 4];
+    float* t3 = bufs[(cur + 3) % 4];
     int H1, W1, H2, W2, Hs, Ws;
-    if ((rc = conv_bn_act(e, b.c1, y, nullptr, R, H, W, o, &H1, &W1)) != WS_OK) return rc;
     const float* shortcut = y;
-    if (b.has_sc) {
-      if ((rc = conv_bn_act(e, b.sc, y, nullptr, R, H, W, sc, &Hs, &Ws)) != WS_OK) return rc;
-      shortcut = sc;
+    if (e->spk_bottleneck) {
+      if ((rc = conv_bn_act(e, b.c1, y, nullptr, R, H, W, t1, &H1, &W1)) != WS_OK) return rc;
+      if ((rc = conv_bn_act(e, b.c2, t1, nullptr, R, H1, W1, t2, &H2, &W2)) != WS_OK) return rc;
+      if (b.has_sc) {
+        if ((rc = conv_bn_act(e, b.sc, y, nullptr, R, H, W, t1, &Hs, &Ws)) != WS_OK) return rc;
+        shortcut = t1;
+      }
+      if ((rc = conv_bn_act(e, b.c3, t2, shortcut, R, H2, W2, t3, &H2, &W2)) != WS_OK) return rc;
+      cur = (cur + 3) % 4;
+      C = b.c3.cout;
+    } else {                     // three of the buffers: conv2 writes over the block input unless that is the shortcut
+      float* o = bufs[(cur + 1) % 3];
+      float* sc = bufs[(cur + 2) % 3];
+      if ((rc = conv_bn_act(e, b.c1, y, nullptr, R, H, W, o, &H1, &W1)) != WS_OK) return rc;
+      if (b.has_sc) {
+        if ((rc = conv_bn_act(e, b.sc, y, nullptr, R, H, W, sc, &Hs, &Ws)) != WS_OK) return rc;
+        shortcut = sc;
+      }
+      float* dst = b.has_sc ? y : sc;
+      if ((rc = conv_bn_act(e, b.c2, o, shortcut, R, H1, W1, dst, &H2, &W2)) != WS_OK) return rc;
+      cur = b.has_sc ? cur : (cur + 2) % 3;
+      C = b.c2.cout;
     }
-    // conv2 writes over the block input unless that is the shortcut operand
-    float* dst = b.has_sc ? y : sc;
-    if ((rc = conv_bn_act(e, b.c2, o, shortcut, R, H1, W1, dst, &H2, &W2)) != WS_OK) return rc;
-    cur = b.has_sc ? cur : (cur + 2) % 3;
-    H = H2, W = W2, C = b.c2.cout;
+    H = H2, W = W2;
   }
   float* stats = a.alloc(size_t(R) * 2 * C * H);
   WS_PTR(stats);
   WS_RUN(e, ws_tstp_fwd(bufs[cur], R, H, W, C, kTstpEps, stats, s));
-  rc = linear(e, stats, R, 2 * C * H, e->dev("spk_model.seg_1.weight"), 2 * C * H, e->E, e->dev("spk_model.seg_1.bias"), 0, emb);
+  const std::string p = "spk_model.";
+  if (!e->spk_two_emb) {
+    rc = linear(e, stats, R, 2 * C * H, e->dev(p + "seg_1.weight"), 2 * C * H, e->E, e->dev(p + "seg_1.bias"), 0, emb);
+  } else {
+    float* t = a.alloc(size_t(R) * e->E);
+    float* u = a.alloc(size_t(R) * e->E);
+    float* v = a.alloc(size_t(R) * e->E);
+    WS_PTR(t && u && v);
+    if ((rc = linear(e, stats, R, 2 * C * H, e->dev(p + "seg_1.weight"), 2 * C * H, e->E, e->dev(p + "seg_1.bias"), 2, t)) != WS_OK)
+      return rc;
+    WS_RUN(e, ws_bn_prelu_fwd(t, e->seg_bn_st, e->id_one, e->id_zero, nullptr, e->slope1, R, e->E, u, v, s));
+    rc = linear(e, v, R, e->E, e->dev(p + "seg_2.weight"), e->E, e->E, e->dev(p + "seg_2.bias"), 0, emb);
+  }
   a.release(mk);
   return rc;
 }

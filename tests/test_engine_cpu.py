@@ -159,11 +159,34 @@ def test_dry_run_launch_plan_ecapa_joint_model(tmp_path, spk_model, emb_bn):
 
 
 def test_export_refuses_speaker_encoders_without_a_launch_plan(tmp_path):
-    with pytest.raises(NotImplementedError, match="no launch plan"):
-        export_engine(_model(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
-                             joint_training=True, spk_feat=True, spk_model="ResNet18",
-                             spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=True)),
-                      str(tmp_path / "x.wsw"))
+    for spk_model, args, E_ in (("CAMPPlus", dict(feat_dim=80, embed_dim=512, pooling_func="TSTP"), 512),
+                                ("ResNet18", dict(feat_dim=80, embed_dim=256, pooling_func="ASTP", two_emb_layer=False), 256)):
+        with pytest.raises(NotImplementedError, match="no launch plan"):
+            export_engine(_model(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                                 joint_training=True, spk_feat=True, spk_model=spk_model, spk_emb_dim=E_, spk_args=args),
+                          str(tmp_path / "x.wsw"))
+
+
+@needs_no_gpu
+@pytest.mark.parametrize("spk_model,two_emb", [("ResNet50", False), ("ResNet18", True), ("ResNet101", True)])
+def test_dry_run_launch_plan_bottleneck_and_two_emb_layer(tmp_path, spk_model, two_emb):
+    """Bottleneck ResNets (1x1 - 3x3(stride) - 1x1, expansion 4) and `two_emb_layer` (seg_1 -> ReLU -> BatchNorm1d(affine =
+    False) -> seg_2, the separator takes the second embedding) in the native runtime: export metadata and the launch
+    plan's argument validation for three geometries."""
+    path = str(tmp_path / "b.wsw")
+    export_engine(_model(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                         joint_training=True, spk_feat=True, spk_model=spk_model,
+                         spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=two_emb)), path)
+    eng = E.Engine(path, dry_run=True)
+    assert eng.info("spk_kind") == 0 and eng.info("spk_bottleneck") == int(spk_model != "ResNet18")
+    assert eng.info("spk_two_emb") == int(two_emb) and eng.info("feat_dim") == 80
+    counts = set()
+    for R, Te in ((2, 98), (2, 301), (2, 40)):
+        eng.separate(np.zeros((R, 16000), np.float32), np.zeros((R, Te, 80), np.float32), E.ENROLL_FBANK)
+        counts.add(eng.info("n_launches"))
+    assert len(counts) == 1                                    # (one fbank transpose per row: the plan depends on R only)
+    eng.separate(np.zeros((1, 16000), np.float32), np.zeros((1, 77, 80), np.float32), E.ENROLL_FBANK)
+    eng.close()
 
 
 @needs_no_gpu

@@ -37,15 +37,17 @@ def engine_meta(model):
             meta.update(spk_kind=1, spk_channels=spk.layer1.conv.out_channels, feat_dim=spk.layer1.conv.in_channels,
                         spk_glob=int(spk.pool.linear1.in_channels == 3 * spk.pool.linear2.out_channels),
                         spk_emb_bn=int(isinstance(getattr(spk, "bn2", None), torch.nn.BatchNorm1d)))
-        elif hasattr(spk, "seg_1") and type(spk.layer1[0]).__name__ == "BasicBlock" and not getattr(spk, "two_emb_layer", False):
-            meta["spk_kind"] = 0
+        elif hasattr(spk, "seg_1") and type(spk.layer1[0]).__name__ in ("BasicBlock", "Bottleneck") and \
+                getattr(spk, "pooling_func", "TSTP") == "TSTP":
+            ex = 4 if type(spk.layer1[0]).__name__ == "Bottleneck" else 1
+            meta.update(spk_kind=0, spk_bottleneck=int(ex == 4), spk_two_emb=int(bool(getattr(spk, "two_emb_layer", False))))
             for i, layer in enumerate((spk.layer1, spk.layer2, spk.layer3, spk.layer4)):
                 meta[f"spk_blocks{i}"] = len(layer)
-            meta["feat_dim"] = int(spk.seg_1.weight.shape[1] // (2 * 32 * 8)) * 8
+            meta["feat_dim"] = int(spk.seg_1.weight.shape[1] // (2 * 32 * 8 * ex)) * 8
         else:
-            raise NotImplementedError(f"export_engine: speaker encoder {type(spk).__name__} (Bottleneck / two_emb_layer "
-                                      "ResNets included) has no launch plan in the native runtime; BasicBlock ResNets "
-                                      "and ECAPA-TDNN do")
+            raise NotImplementedError(f"export_engine: speaker encoder {type(spk).__name__} (CAM++, or a ResNet with a "
+                                      "pooling layer other than TSTP) has no launch plan in the native runtime; the "
+                                      "wespeaker ResNets with TSTP and ECAPA-TDNN do")
     return meta
 
 
