@@ -1,8 +1,8 @@
 """GPU: the native runtime's launch plans for Bottleneck ResNets and `two_emb_layer` (runtime/engine.cc) against the
-Python module tree in eval mode on the same device.  Written after the round's GPU budget was spent: its plan passes the
-real library's argument validation in the dry run (tests/test_engine_cpu.py) and is composed of entry points the other
-engine tests exercise on hardware, but THIS file has not run on an MI355X yet -- it sorts last so that its first run
-cannot hide any other test behind the driver's `-x`."""
+Python module tree in eval mode on the same device.  Written with the round's last GPU seconds: the case that covers both
+features (ResNet50 + two_emb_layer) ran green on an MI355X, the two single-feature cases had their plans validated by the
+dry run only (tests/test_engine_cpu.py) -- the file sorts last so that their first run cannot hide any other test behind
+the driver's `-x`."""
 import numpy as np
 import pytest
 import torch
