@@ -60,7 +60,8 @@ class BnActFn(torch.autograd.Function):
 
 
 class Conv1dFn(torch.autograd.Function):
-    """x [R*T, Cin] -> conv1d(x, w [Cout, Cin, k], b; stride, dilation, padding dil * (k // 2)) [R*To, Cout]."""
+    """x [R*T, Cin] -> conv1d(x, w [Cout, Cin, k], b; stride, dilation, padding dil * (k // 2)) [R*To, Cout].  Also the
+    dilated convolutions of Conv-TasNet's Deep encoder / decoder (modules/tasnet)."""
 
     @staticmethod
     def forward(ctx, x, geo, w, b):
@@ -75,7 +76,7 @@ class Conv1dFn(torch.autograd.Function):
             y = _gemm(x, R * T, Cin, W2, Cout, bias=b)
         else:
             if Cin % 4 or Cout % 4 or k % 2 == 0 or stride > 2:
-                raise L.WesepHipError(f"CAM++ Conv1d: channels % 4, odd kernel, stride <= 2 (got {Cin}, {Cout}, {k}, {stride})")
+                raise L.WesepHipError(f"Conv1dFn: channels % 4, odd kernel, stride <= 2 (got {Cin}, {Cout}, {k}, {stride})")
             To = (T + 2 * p - dil * (k - 1) - 1) // stride + 1
             # the Conv1d as the middle kernel row of a k x k view of the one-row image; the other rows are masked taps
             W2 = torch.zeros(Cout, k, k, Cin, device=x.device, dtype=torch.float32)
