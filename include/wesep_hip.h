@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 8
+#define WS_ABI_VERSION 9
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -259,6 +259,30 @@ int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream);
  * gates on entry and d(pre-activation gates) on exit; xchg: (nseq / 32) * 1 MB; flags / status as above
  * (in place on `gates`: there is no device-side fall-back, the caller checks the timeout word).  */
 int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream);
+/* BPTT over PAIRS of workgroups (lstm_pair.hip; ABI v9): the two workgroups of a (32-sequence tile, direction) split
+ * W_hh by gate rows -- each keeps the hi plane of its 512 rows in registers, streams only the lo plane, multiplies its
+ * own d(gates) into a partial dh for all 256 units and hands the partner's half over (16 KB per step through `xchg`).
+ * Same gates / cbuf / dhcat contract as ws_lstm_bwd(WS_LSTM_BF16X3_BLK): blocked layout, any nseq (padded slots),
+ * gates = activated gates on entry, d(pre-activation gates) as BLS on exit -- replaces autograd through nn.LSTM for
+ * the time view (bsrnn.py:38-46) on half of the chip's CUs.  wpack: ws_lstm_pack_pair output (WS_LSTM_PACK_FLOATS).
+ * npair = 2 * ceil(nseq / 32); 2 * npair <= CUs of the device (checked).  xchg: npair * 64 KB scratch; flags:
+ * npair * 8 + 8 words (zeroed by the call on `stream`).  Every wait is bounded: on a timeout d(gates) are NaN-poisoned,
+ * flags[npair * 8] (0 after a clean launch) and *status (optional, sticky) are set to 1; in place, so there is no
+ * device-side repair.  dbg (probes / tests only): 1 skip the flag wait, 2 skip the exchange, 4 no weight reloads,
+ * 8 force a timeout in pair 0 at step 2, 32 no wave priorities.                                              */
+typedef struct ws_lstm_pair_args {
+  float* gates;
+  const float* cbuf;
+  const float* dhcat;
+  const float* wpack;
+  void* xchg;
+  unsigned* flags;
+  unsigned* status;
+  int nseq, L;
+  int dbg, pad_;
+} ws_lstm_pair_args;
+int ws_lstm_pack_pair(const float* whh_f, const float* whh_r, float* pack, void* stream);
+int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream);
 /* wcat[2][4H][N] <- (w_ih_f, w_ih_r);  bcat[2][4H] <- b_ih + b_hh per direction             */
 int ws_lstm_cat_ih(const float* wih_f, const float* wih_r, const float* bih_f, const float* bhh_f,
                    const float* bih_r, const float* bhh_r, int n_in, float* wcat, float* bcat,

@@ -193,6 +193,22 @@ def lstm_bwd_cluster(gates, cbuf, dhcat, whh_f, whh_r, sm, status=None, dbg=0):
     _bwd_into(gates, cbuf, dhcat, whh_f, whh_r, sm)
 
 
+def lstm_pack_pair(whh_f, whh_r, pack):
+    pack.reshape(-1)[: 2 * G4 * H] = torch.stack([whh_f, whh_r]).reshape(-1)      # raw weights, like emu_dev.lstm_pack
+
+
+def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0):
+    """Returns the launch's timeout word like dev.lstm_bwd_pair; dbg & 8 emulates the forced timeout (NaN-poisoned
+    d(gates), both words set)."""
+    if dbg & 8:
+        gates.fill_(float("nan"))
+        if status is not None:
+            status.fill_(1)
+        return torch.ones(1, dtype=torch.int32)
+    _bwd_into(gates, cbuf, dhcat, *_whh_from_pack(wpack), sm)
+    return torch.zeros(1, dtype=torch.int32)
+
+
 def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm):
     nt, L = _ntile(sm), sm.L
     wih_f, wih_r, whf, whr = _PACKS[wpack.data_ptr()]
@@ -301,7 +317,7 @@ def install(monkeypatch):
     monkeypatch.setattr(dev, "lstm_fwd", make_lstm_fwd(dev.lstm_fwd))
     monkeypatch.setattr(dev, "lstm_bwd", make_lstm_bwd(dev.lstm_bwd))
     for fn in (pack_w, lstm_cat_ih, lstm_pack_fused, gemm_p2b, gemm_b2p, lstm_fwd_cluster, lstm_bwd_cluster,
-               lstm_fwd_fused, gemm_tnb):
+               lstm_pack_pair, lstm_bwd_pair, lstm_fwd_fused, gemm_tnb):
         monkeypatch.setattr(dev, fn.__name__, fn)
     monkeypatch.setattr(dev, "group_stats", make_group_stats(dev.group_stats))
     monkeypatch.setattr(dev, "gn_bwd_reduce", make_gn_bwd_reduce(dev.gn_bwd_reduce))

@@ -69,3 +69,15 @@ def test_resnet_pooling_gpu_test_bodies(emu, monkeypatch):
     monkeypatch.setattr(t, "_cuda", lambda: torch.device("cpu"))
     for pooling in ("TAP", "TSDP", "ASTP"):
         t.test_resnet_pooling_variants_match_oracle(pooling)
+
+
+def test_pair_bptt_gpu_test_body(emu, monkeypatch):
+    """tests/test_kernels_gpu.py::test_lstm_pair_bwd_vs_torch on the blocked-layout emulation (small cases)."""
+    import tests.test_kernels_gpu as t
+    from tests import emu_blk
+    import wesep_amd.dev as dev
+    emu_blk.install(monkeypatch)
+    monkeypatch.setattr(dev, "bls_unpack", lambda x: x)      # the emulation keeps plain fp32 where the kernels keep BLS
+    monkeypatch.setattr(t, "_cuda", lambda: torch.device("cpu"))
+    t.test_lstm_pair_bwd_vs_torch("time", (3, 7, 37))
+    t.test_lstm_pair_bwd_vs_torch("band", (4, 9, 16))

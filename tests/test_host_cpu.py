@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = built_lib.lib()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ws_abi_version() == built_lib.ABI_VERSION == 8
+    assert lib.ws_abi_version() == built_lib.ABI_VERSION == 9
 
 
 def test_ctypes_structs_match_c_layout(built_lib):
@@ -47,6 +47,7 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ws_gemm_p2b_args), sizeof(ws_gemm_b2p_args),
          sizeof(ws_gemm_tnb_args), sizeof(ws_lstm_cluster_args), sizeof(ws_lstm_fused_args), sizeof(ws_seqmap),
          offsetof(ws_lstm_args, run_if), offsetof(ws_gemm_p2b_args, run_if));
+  printf("%zu %zu\n", sizeof(ws_lstm_pair_args), offsetof(ws_lstm_pair_args, nseq));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -60,7 +61,8 @@ int main(void) {
                          ctypes.sizeof(L.LstmArgs), ctypes.sizeof(L.Bands), L.GROUP_NT_DTYPE.itemsize,
                          L.GROUP_TN_DTYPE.itemsize, L.TENSOR_REF_DTYPE.itemsize]
     assert sizes[8] == L.GemmTNArgs.g_div.offset
-    assert sizes[9:] == [ctypes.sizeof(L.GemmP2BArgs), ctypes.sizeof(L.GemmB2PArgs), ctypes.sizeof(L.GemmTNBArgs),
+    assert sizes[17:] == [ctypes.sizeof(L.LstmPairArgs), L.LstmPairArgs.nseq.offset]
+    assert sizes[9:17] == [ctypes.sizeof(L.GemmP2BArgs), ctypes.sizeof(L.GemmB2PArgs), ctypes.sizeof(L.GemmTNBArgs),
                          ctypes.sizeof(L.LstmClusterArgs), ctypes.sizeof(L.LstmFusedArgs), ctypes.sizeof(L.SeqMapC),
                          L.LstmArgs.run_if.offset, L.GemmP2BArgs.run_if.offset]
 

@@ -668,6 +668,75 @@ def test_lstm_cluster_fwd_bwd_vs_torch(view, dims):
     assert rel(dg[:, 1].sum(0), lstm.bias_ih_l0_reverse.grad) < 8e-5
 
 
+@pytest.mark.parametrize("view,dims", [("time", (2, 32, 70)), ("time", (3, 7, 37)), ("time", (32, 32, 9)),
+                                       ("band", (4, 9, 16))])
+def test_lstm_pair_bwd_vs_torch(view, dims):
+    """Pair BPTT (lstm_pair.hip: two workgroups per (tile, direction), W_hh split by gate rows, hi plane resident, the
+    partner's half of the partial dh exchanged every step): same contract as the blocked streaming BPTT -- checked
+    against torch's LSTM autograd, against the streaming kernel on the same forward state, for run-to-run identity,
+    with padded tiles ((3, 7, 37): 21 sequences) and at the headline launch geometry (1024 sequences = 128
+    workgroups); then a forced timeout must poison d(gates) and raise the launch's word and the status word."""
+    from wesep_amd import dev, _lib as L
+    from wesep_amd.functional import _view_maps
+    d = _cuda()
+    g = torch.Generator().manual_seed(43)
+    (R, K, Tf), N, H = dims, 128, 256
+    P = R * K * Tf
+    geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+    lstm = torch.nn.LSTM(N, H, 1, batch_first=True, bidirectional=True)
+    x = rnd(g, R, K, Tf, N)
+    xs = x.reshape(R * K, Tf, N) if view == "time" else x.permute(0, 2, 1, 3).reshape(R * Tf, K, N)
+    xs = xs.clone().requires_grad_(True)
+    out, _ = lstm(xs)
+    dout_seq = rnd(g, *out.shape)
+    out.backward(dout_seq)
+    with torch.no_grad():
+        gx = []
+        for sfx in ("", "_reverse"):
+            w, bi, bh = (getattr(lstm, n + sfx) for n in ("weight_ih_l0", "bias_ih_l0", "bias_hh_l0"))
+            gx.append(x.reshape(P, N) @ w.t() + bi + bh)
+    gates = dev.to_blocked(torch.stack(gx, 1).reshape(P, 8 * H).to(d), seq)
+    nb = dev.bl_num_blocks(seq)
+    whf, whr = lstm.weight_hh_l0.detach().to(d).contiguous(), lstm.weight_hh_l0_reverse.detach().to(d).contiguous()
+    pf, pb = torch.empty(L.LSTM_PACK_FLOATS, device=d), torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack(whf, whr, pf, pb, L.LSTM_BF16X3_BLK)
+    cbuf, hcat = torch.zeros(nb, 2 * H // 4, 32, 4, device=d), torch.zeros(nb, 2 * H // 4, 32, 4, device=d)
+    dev.lstm_fwd(gates, cbuf, hcat, pf, seq, L.LSTM_BF16X3_BLK)
+    dref = dout_seq.reshape(R, K, Tf, 2 * H) if view == "time" else dout_seq.reshape(R, Tf, K, 2 * H).permute(0, 2, 1, 3)
+    dh = dev.to_blocked(dref.contiguous().reshape(P, 2 * H).to(d), seq)
+    g_stream = gates.clone()
+    dev.lstm_bwd(g_stream, cbuf, hcat, dh, pb, seq, L.LSTM_BF16X3_BLK)
+    pp = torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack_pair(whf, whr, pp)
+    status = torch.zeros(1, device=d, dtype=torch.int32)
+    outs = []
+    for _ in range(3):
+        g2 = gates.clone()
+        tw = dev.lstm_bwd_pair(g2, cbuf, dh, pp, seq, status=status)
+        assert int(tw.item()) == 0
+        outs.append(g2)
+    assert int(status.item()) == 0
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])      # deterministic
+    _, valid = dev.bl_positions(seq, d)
+    if not bool(valid.all()):                                                   # padded slots stay zero
+        rows = dev.bls_unpack(outs[0]).view(nb, -1, 32, 4).permute(0, 2, 1, 3).reshape(nb * 32, -1)
+        assert float(rows[~valid].abs().max()) == 0.0
+    dg_pair, dg_stream = (dev.from_blocked(t, seq, P, split=True) for t in (outs[0], g_stream))
+    assert rel(dg_pair, dg_stream) < 2e-5
+    dg = dg_pair.view(P, 2, 4 * H).cpu()
+    dx = dg[:, 0] @ lstm.weight_ih_l0.detach() + dg[:, 1] @ lstm.weight_ih_l0_reverse.detach()
+    dxref = xs.grad.reshape(R, K, Tf, N) if view == "time" else xs.grad.reshape(R, Tf, K, N).permute(0, 2, 1, 3)
+    assert rel(dx.view(R, K, Tf, N), dxref) < 8e-5
+    assert rel(dg[:, 0].sum(0), lstm.bias_ih_l0.grad) < 8e-5
+    assert rel(dg[:, 1].sum(0), lstm.bias_ih_l0_reverse.grad) < 8e-5
+    if seq.L > 3:
+        # a wait that times out (test build: pair 0, member 0, wave 0 at step 2): NaN from there on + both words
+        g3 = gates.clone()
+        tw = dev.lstm_bwd_pair(g3, cbuf, dh, pp, seq, status=status, dbg=8)
+        assert int(tw.item()) == 1 and int(status.item()) == 1
+        assert torch.isnan(g3).any()
+
+
 @pytest.mark.parametrize("N", [16, 24, 32, 48, 64, 96])
 def test_generic_bf16_gemms_narrow_column_tiles(N):
     """Ungrouped split-bf16 launches with few output columns run narrow tiles (32 / 64 columns per workgroup in

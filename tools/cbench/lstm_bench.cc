@@ -2,7 +2,7 @@
 // A GPU call that imports torch spends 1-2 minutes before the first kernel; this binary starts in milliseconds, so a
 // gpurun call can sweep many configurations inside a few GPU-seconds.  Not part of the product.
 //
-//   lstm_bench [--view time|band] [--rows 32] [--seconds 4] [--iters 5] [--what fwd,bwd,fused,cluster,cluster_bwd]
+//   lstm_bench [--view time|band] [--rows 32] [--seconds 4] [--iters 5] [--what fwd,bwd,fused,cluster,cluster_bwd,pair]
 //
 // Prints one line per (kernel, configuration): ms per launch, microseconds per recurrence step, and the algorithmic
 // HBM rate (bench.py's convention: 10 fp32 per position, direction and hidden unit) against the 8 TB/s peak.
@@ -192,6 +192,41 @@ int main(int argc, char** argv) {
     const double ms = time_ms([&] { WS_OK_(ws_lstm_bwd_cluster(&c, s)); }, iters, s);
     report("bwd_cluster", ms, gates, nb * 32 * 2 * G4);
   }
+  const int npair = 2 * ntile;
+  const bool pair_ok = 2 * npair <= prop.multiProcessorCount;
+  float* pack_p = nullptr;
+  float* xchg_p = nullptr;
+  unsigned* flags_p = nullptr;
+  unsigned* status_p = nullptr;
+  if (pair_ok) {
+    pack_p = dalloc(WS_LSTM_PACK_FLOATS);
+    xchg_p = dalloc(size_t(npair) * 65536 / 4);
+    flags_p = reinterpret_cast<unsigned*>(dalloc(size_t(npair) * 8 + 8));
+    status_p = reinterpret_cast<unsigned*>(dalloc(1));
+    HIP_OK(hipMemsetAsync(status_p, 0, 4, s));
+    WS_OK_(ws_lstm_pack_pair(whf, whr, pack_p, s));
+  }
+  auto pair_args = [&](int dbg) {
+    ws_lstm_pair_args c = {};
+    c.gates = gates, c.cbuf = cbuf, c.dhcat = dh, c.wpack = pack_p, c.xchg = xchg_p, c.flags = flags_p;
+    c.status = status_p, c.nseq = nseq, c.L = L, c.dbg = dbg;
+    return c;
+  };
+  if (pair_ok && what.find("pair") != std::string::npos) {
+    // dbg variants are timing probes (their results are wrong by construction): 1 no flag wait, 2 no exchange,
+    // 4 no lo-plane reloads, 32 no wave priorities
+    for (int dbg : {0, 32, 1, 2, 4}) {
+      ws_lstm_pair_args c = pair_args(dbg);
+      HIP_OK(hipMemcpyAsync(gates, gates_act, gbytes, hipMemcpyDeviceToDevice, s));
+      const double ms = time_ms([&] { WS_OK_(ws_lstm_bwd_pair(&c, s)); }, iters, s);
+      char name[32];
+      snprintf(name, sizeof name, "bwd_pair/%d", dbg);
+      report(name, ms, gates, nb * 32 * 2 * G4);
+    }
+    unsigned st = 0;
+    HIP_OK(hipMemcpy(&st, status_p, 4, hipMemcpyDeviceToHost));
+    printf("bwd_pair status word after the runs: %u\n", st);
+  }
   if (atoi(get("--compare", "0").c_str())) {
     // forward and backward of every applicable kernel family on identical inputs
     // the first 64 M elements are plenty for a parity signal (the band view's d(gates) is 1 G floats)
@@ -230,6 +265,30 @@ int main(int argc, char** argv) {
       HIP_OK(hipStreamSynchronize(s));
       gs.push_back(fetch(gates, ng));
       names.push_back("cluster");
+    }
+    if (pair_ok) {
+      // same forward state as the blk16 run: redo that forward, then the pair BPTT
+      WS_OK_(ws_lstm_pack(whf, whr, pack_f, pack_b, WS_LSTM_BF16X3_BLK16, s));
+      ws_lstm_args c = a;
+      c.mode = WS_LSTM_BF16X3_BLK16, c.wpack = pack_f;
+      reset_gates();
+      WS_OK_(ws_lstm_fwd(&c, s));
+      HIP_OK(hipStreamSynchronize(s));
+      hs.push_back(fetch(hcat, nh));
+      for (int rep = 0; rep < 2; ++rep) {
+        if (rep) {
+          reset_gates();
+          WS_OK_(ws_lstm_fwd(&c, s));
+        }
+        ws_lstm_pair_args pa = pair_args(0);
+        WS_OK_(ws_lstm_bwd_pair(&pa, s));
+        HIP_OK(hipStreamSynchronize(s));
+        gs.push_back(fetch(gates, ng));
+      }
+      const bool same = memcmp(gs[gs.size() - 1].data(), gs[gs.size() - 2].data(), ng * 4) == 0;
+      gs.pop_back();
+      names.push_back("pair");
+      printf("pair run-to-run identical: %s\n", same ? "yes" : "NO");
     }
     for (size_t i = 1; i < names.size(); ++i)
       printf("compare %-8s vs %s:  h rel %.3e   d(gates) rel %.3e\n", names[i].c_str(), names[0].c_str(),

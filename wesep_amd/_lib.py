@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 8
+ABI_VERSION = 9
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
@@ -91,6 +91,11 @@ class LstmClusterArgs(C.Structure):
                [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i)]
 
 
+class LstmPairArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("gates", "cbuf", "dhcat", "wpack", "xchg", "flags", "status")] + \
+               [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i)]
+
+
 class Bands(C.Structure):
     _fields_ = [("band_of_bin", _p), ("band_f0", _p), ("band_bw", _p), ("nband", _i), ("nbins", _i)]
 
@@ -133,6 +138,8 @@ _SIGS = {
     "ws_lstm_bwd": (_i, [C.POINTER(LstmArgs), _p]),
     "ws_lstm_fwd_cluster": (_i, [C.POINTER(LstmClusterArgs), _p]),
     "ws_lstm_bwd_cluster": (_i, [C.POINTER(LstmClusterArgs), _p]),
+    "ws_lstm_pack_pair": (_i, [_p, _p, _p, _p]),
+    "ws_lstm_bwd_pair": (_i, [C.POINTER(LstmPairArgs), _p]),
     "ws_lstm_cat_ih": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "ws_pack_w": (_i, [_p, _i, _i, _ll, _i, _i, _p, _p]),
     "ws_gemm_p2b": (_i, [C.POINTER(GemmP2BArgs), _p]),

@@ -1,0 +1,327 @@
+// Time-view BPTT of the split-bf16 BLSTM over PAIRS of co-operating workgroups (blocked layout BL).
+//
+// What bounds the streaming BPTT kernels (lstm_bf16*.hip) in the time view of pBSRNN (1024 sequences x 501
+// latency-bound steps) is the per-step stream of BOTH W_hh planes from L2 through one CU's L1: 1 MB per workgroup and
+// step.  The cluster BPTT (lstm_cluster.hip) removes the stream but needs all 256 CUs and a 56 KB + 56 KB reduce-scatter
+// per step.  This kernel sits between the two: a (32-sequence tile, direction) is owned by TWO workgroups on two CUs
+// (128 CUs at R = 32: the other half of the chip stays free for the side stream's weight-gradient GEMMs), split by
+// GATE ROWS:
+//   workgroup hs owns the hidden units U = [128 hs, 128 hs + 128): their cell backward, their 512 d(gates) columns
+//   (the kernel's output) and the matching 512 rows of W_hh, whose hi (bf16) plane lives in the REGISTERS of its 8
+//   waves for the whole launch (wave w: the 32 output units of m-tile w x all 512 local k = 128 VGPRs); only the lo
+//   plane is streamed (256 KB per step: a quarter of the streaming kernels' traffic through L1).
+//   dh_{t-1}[seq][u'] = sum_k dgates_t[seq][k] W_hh[k][u']  splits over k into the two workgroups' partial sums:
+//   each multiplies its own d(gates) (B operand: a bf16 hi/lo image in LDS) into a partial for ALL 256 units and hands
+//   the partner the half that belongs to the partner's units -- 16 KB fp32 out and 16 KB in per step (the cluster
+//   kernel: 56 + 56; a split by hidden slice would gather 64 KB of d(gates) instead).
+// The hand-off is hidden behind the other half of the MFMAs by wave roles:
+//   X-waves (0..3): the m-tiles of the PARTNER's units at s_setprio 1 (the SIMD's matrix pipe serves them first),
+//                   then publish (write-through sc1 16-byte stores, recipe R1 of cdna_hip_programming.md Guideline 16:
+//                   every storing wave drains vmcnt, one relaxed agent-scope flag per wave), poll the partner's flag for
+//                   the same m-tile and gather its partial (sc1 loads) into LDS;
+//   O-waves (4..7): the m-tiles of the workgroup's OWN units, running under and behind the X-waves' MFMAs, into LDS.
+// The exchange is per WAVE (four flags per workgroup and step): no workgroup barrier sits between a wave's last MFMA
+// and its publish.  Exchange slots are double-buffered by step parity (a workgroup can publish step s + 2 only after it
+// gathered the partner's step s + 1, which the partner published after it had consumed step s).  All spins are bounded;
+// a timeout poisons d(gates) with NaN and sets the launch's timeout word and *status (the kernel works in place: no
+// device-side repair, callers check the word -- dev.poll_cluster_status).  Sums are taken in a fixed order: results are
+// bit-identical run to run.
+//
+// Residency: both members of a pair must be resident at the same time: the launcher requires 2 workgroups per
+// (tile, direction) <= CUs (one workgroup per CU: 97 KB of LDS, 8 waves x <= 256 VGPRs).  Members of a pair are 8
+// apart in dispatch order, i.e. on the same XCD (blockIdx % 8) and behind the same L2 -- for speed; the protocol does
+// not depend on it.
+#include "lstm_bf16_common.h"
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+#define SC1 16          // aux bit of raw buffer ops: sc1 (write-through store / L1-bypassing load)
+#define PR_ROW 520      // bf16 per LDS row of the local d(gates) image (512 + 8: 1040 B = 4 banks mod 64)
+#define PR_SPIN_LIMIT (1u << 22)
+#define PR_XSLOT 16384  // bytes of one exchange slot: 1024 cells (32 unit quads x 32 sequences) x 16 B
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: 16-byte units, `lane` = the MFMA lane that loads the unit
+//   unit (((d*2 + hs)*8 + w)*2 + part)*32*64 + ks*64 + lane, element j
+//     = part( W_hh[d][ g*256 + 128 hs + ul ][ 32 mt(w, hs) + (lane & 31) ] ),  local k = 16 ks + 8 (lane >> 5) + j
+//       = g*128 + ul;  mt = m-tile of wave w: partner's units for w < 4 (4 (1 - hs) + w), own units else (4 hs + w - 4)
+// ---------------------------------------------------------------------------------------------
+__global__ void lstm_pack_pair_kernel(const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                      __bf16* __restrict__ out) {
+  const int total = 2 * LG * LH;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int r = idx;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    const int ks = r & 31; r >>= 5;
+    const int w = r & 7; r >>= 3;
+    const int hs = r & 1; r >>= 1;
+    const int d = r;
+    const float* W = d ? whh_r : whh_f;
+    const int mt = w < 4 ? 4 * (1 - hs) + w : 4 * hs + (w - 4);
+    const int u = 32 * mt + (lane & 31);
+    const int kl = 16 * ks + 8 * (lane >> 5) + j;
+    const int row = (kl >> 7) * LH + 128 * hs + (kl & 127);
+    const float v = W[row * LH + u];
+    const __bf16 hi = (__bf16)v;
+    const long long unit = ((long long)((d * 2 + hs) * 8 + w) * 2) * (32 * 64) + ks * 64 + lane;
+    out[unit * 8 + j] = hi;
+    out[(unit + 32 * 64) * 8 + j] = (__bf16)(v - (float)hi);
+  }
+}
+
+extern "C" int ws_lstm_pack_pair(const float* whh_f, const float* whh_r, float* pack, void* stream) {
+  WS_REQUIRE(whh_f && whh_r && pack, "ws_lstm_pack_pair: null pointer");
+  hipLaunchKernelGGL(lstm_pack_pair_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, whh_f, whh_r,
+                     reinterpret_cast<__bf16*>(pack));
+  return ws_check_launch("ws_lstm_pack_pair");
+}
+
+// cold path of a bounded wait: set this launch's timeout word and the caller's sticky status word
+__device__ __noinline__ void pair_timed_out(unsigned* tword, unsigned* status) {
+  __hip_atomic_store((gu32*)tword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (status) __hip_atomic_store((gu32*)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define PAIR_RING 4   // lo-plane fragments per ring slot (two slots)
+#define PAIR_LDSK 8   // k-steps whose lo fragments stay in LDS (the rest is streamed)
+
+// V: compile-time variant bits (the step body stays free of run-time branches): 8 = test build that forces a timeout
+// in pair 0 at step 2; probes: 4 = no weight reloads, 32 = no wave priorities
+template <int V>
+__global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pair_args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 bimg[2][SQ * PR_ROW];      // [part][seq][local gate col] 65 KB
+  __shared__ __attribute__((aligned(16))) bf16x8 whl[8 * PAIR_LDSK * 64];   // lo fragments of k-steps 0..7, 64 KB
+  __shared__ __attribute__((aligned(16))) f32x4 rec[2][512];                // the other role's partial dh, 16 KB
+  const int ntile = (p.nseq + SQ - 1) / SQ, npair = 2 * ntile;
+  // block -> (pair, member): members of a pair are 8 blocks apart (same XCD under round-robin dispatch)
+  const int pr = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), hs = ((int)blockIdx.x >> 3) & 1;
+  if (pr >= npair) return;
+  const int d = pr & 1, tile = pr >> 1;
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool xrole = w < 4;
+  const int wx = w & 3, role = w >> 2;
+  const int L = p.L;
+
+  // ---- cells.  The D fragment of m-tile wx holds, per lane (n = sequence slot, half), four cells of 4 units:
+  //      local unit quad 8 wx + 2 q4 + half, q4 = 0..3.  The cell backward of quads q4 = 0, 1 runs on the X-wave wx
+  //      (which RECEIVES the partner's partial of exactly these cells into registers), that of q4 = 2, 3 on the O-wave
+  //      4 + wx (which COMPUTES the own partial of exactly these cells): only the other half of each sum crosses LDS.
+  //      BL cell of (gate g, local quad q): ((d*256 + g*64 + 32 hs + q)*32 + slot)*16 bytes inside the block.
+  const int q0 = 8 * wx + 4 * role + half;                   // this thread's cells: quads q0 (e = 0) and q0 + 2 (e = 1)
+  const int gvo = ((d * 256 + 32 * hs + q0) * 32 + n) * 16;  // bytes; + g*64*512; cell e: + 2e*512
+  const int cvo = ((d * 64 + 32 * hs + q0) * 32 + n) * 16;   // bytes; cell e: + 2e*512
+  auto grs = [&](int t) { return mkrsrc(p.gates + (long long)(tile * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  auto crs = [&](const float* b, int t) { return mkrsrc(b + (long long)(tile * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
+  // ---- exchange: X[pair][parity][destination member][cell] x 16 B; flags[pair][source member][wave]
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(p.xchg) + (long long)pr * (4 * PR_XSLOT), 0, 4 * PR_XSLOT, 0x00020000);
+  gu32* flags = (gu32*)(p.flags) + pr * 8;
+  const int xc0 = ((8 * wx + half) * 32 + n) * 16;  // exchange byte offset of this lane's cell q4 = 0; q4: + q4*2*512
+
+  // ---- resident hi plane of this wave's m-tile: 32 k-steps x 16 B per lane; lo plane: k-steps 0..7 in LDS, the
+  //      rest streamed every step through a two-slot register ring (no load is in flight across the cell backward)
+  const char* wbase = reinterpret_cast<const char*>(p.wpack) + (long long)((d * 2 + hs) * 8 + w) * (2 * 32 * 1024);
+  bf16x8 wh[32];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) wh[ks] = *reinterpret_cast<const bf16x8*>(wbase + ks * 1024 + lane * 16);
+  bf16x8* wlds = &whl[w * PAIR_LDSK * 64 + lane];
+#pragma unroll
+  for (int ks = 0; ks < PAIR_LDSK; ++ks)
+    wlds[ks * 64] = *reinterpret_cast<const bf16x8*>(wbase + 32 * 1024 + ks * 1024 + lane * 16);
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase) + 32 * 1024, 0, 32 * 1024, 0x00020000);
+  const int wlane = lane * 16;
+  constexpr int NCH = 32 / PAIR_RING, CH0 = PAIR_LDSK / PAIR_RING;  // chunks per step; first streamed chunk
+
+  rec[0][tid] = rec[1][tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4* oth = &rec[role][(wx * 2) * 64 + lane];  // X-waves read what the O-waves wrote (rec[0]) and vice versa
+  f32x4* mineo = &rec[role ^ 1][(wx * 2) * 64 + lane];  // ... and write the half the other role's cells need
+
+  f32x4 n_i[2], n_f[2], n_g[2], n_o[2], n_dh[2], n_cp[2], c_cur[2], dc[2], mine[2];
+  const f32x4 zero4v = {0.f, 0.f, 0.f, 0.f};
+  auto load_step = [&](int t, int e) {
+    n_i[e] = bld(grs(t), gvo, (0 * 64 + 2 * e) * 512);
+    n_f[e] = bld(grs(t), gvo, (1 * 64 + 2 * e) * 512);
+    n_g[e] = bld(grs(t), gvo, (2 * 64 + 2 * e) * 512);
+    n_o[e] = bld(grs(t), gvo, (3 * 64 + 2 * e) * 512);
+    n_dh[e] = bld(crs(p.dhcat, t), cvo, 2 * e * 512);
+    const int tp = d == 0 ? max(t - 1, 0) : min(t + 1, L - 1);  // clamped; masked at its use
+    n_cp[e] = bld(crs(p.cbuf, tp), cvo, 2 * e * 512);
+  };
+  {
+    const int t0 = d == 0 ? L - 1 : 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      load_step(t0, e);
+      c_cur[e] = bld(crs(p.cbuf, t0), cvo, 2 * e * 512);
+      dc[e] = mine[e] = zero4v;
+    }
+  }
+  int dead = 0;  // wave-uniform: a bounded wait of this wave timed out
+  __syncthreads();
+
+  for (int step = 0; step < L; ++step) {
+    const int t = d == 0 ? L - 1 - step : step;
+    const int sn = min(step + 1, L - 1);
+    const int tn = d == 0 ? L - 1 - sn : sn;
+    const bool has_prev = d == 0 ? (t > 0) : (t < L - 1);
+    const int par = step & 1;
+    int zo = 0;
+    asm volatile("" : "+s"(zo));
+    // ---- phase C: cell backward of this thread's two cells -> d(gates): LDS image (B operand) + HBM (BLS) -----------
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int q = q0 + 2 * e;
+      const f32x4 dhr = mine[e] + oth[e * 64];
+      f32x4 pi, pf, pg, po;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ig = n_i[e][r], fg = n_f[e][r], gg = n_g[e][r], og = n_o[e][r];
+        const float dhv = n_dh[e][r] + dhr[r];
+        const float tc = ftanh(c_cur[e][r]);
+        const float dov = dhv * tc;
+        const float dcv = dc[e][r] + dhv * og * (1.f - tc * tc);
+        dc[e][r] = dcv * fg;
+        pi[r] = dcv * gg * ig * (1.f - ig);
+        pf[r] = dcv * (has_prev ? n_cp[e][r] : 0.f) * fg * (1.f - fg);
+        pg[r] = dcv * ig * (1.f - gg * gg);
+        po[r] = dov * og * (1.f - og);
+      }
+      c_cur[e] = n_cp[e];
+      auto emit = [&](const f32x4& v, int g) {
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<bf16x4*>(&bimg[0][n * PR_ROW + g * 128 + 4 * q]) = hi;
+        *reinterpret_cast<bf16x4*>(&bimg[1][n * PR_ROW + g * 128 + 4 * q]) = lo;
+        bst(pack_hl4(hi, lo), grs(t), gvo, (g * 64 + 2 * e) * 512);
+      };
+      emit(pi, 0);
+      emit(pf, 1);
+      emit(pg, 2);
+      emit(po, 3);
+    }
+    __syncthreads();  // S1: the d(gates) image of this step is complete; rec is consumed
+
+    // ---- partial dh^T [32 units of this wave's m-tile][32 sequences] = W_hh^T slice * dgates^T ----------------------
+    if (xrole && !(V & 32)) __builtin_amdgcn_s_setprio(1);
+    bf16x8 wl[2][PAIR_RING];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int f = 0; f < PAIR_RING; ++f)
+        wl[s][f] = wload(wrs, wlane + f * 1024, zo + (CH0 + s) * (PAIR_RING * 1024));
+    const __bf16* bhi = &bimg[0][n * PR_ROW + 8 * half];
+    const __bf16* blo = &bimg[1][n * PR_ROW + 8 * half];
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int s = ch & 1;
+#pragma unroll
+      for (int f = 0; f < PAIR_RING; ++f) {
+        const int ks = PAIR_RING * ch + f;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bhi + 16 * ks);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(blo + 16 * ks);
+        const bf16x8 al = ch < CH0 ? wlds[ks * 64] : wl[s][f];
+        if (ks & 1) {
+          acc1 = mfma32(wh[ks], bh, acc1);
+          acc0 = mfma32(al, bh, acc0);
+          acc1 = mfma32(wh[ks], bl, acc1);
+        } else {
+          acc0 = mfma32(wh[ks], bh, acc0);
+          acc1 = mfma32(al, bh, acc1);
+          acc0 = mfma32(wh[ks], bl, acc0);
+        }
+      }
+      if (ch >= CH0 && ch + 2 < NCH && !(V & 4)) {
+#pragma unroll
+        for (int f = 0; f < PAIR_RING; ++f) wl[s][f] = wload(wrs, wlane + f * 1024, zo + (ch + 2) * (PAIR_RING * 1024));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 sum[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+      sum[q4] = f32x4{acc0[4 * q4] + acc1[4 * q4], acc0[4 * q4 + 1] + acc1[4 * q4 + 1], acc0[4 * q4 + 2] + acc1[4 * q4 + 2],
+                      acc0[4 * q4 + 3] + acc1[4 * q4 + 3]};
+    if (xrole) {
+      __builtin_amdgcn_s_setprio(0);
+      // publish the partial of the PARTNER's units: write-through 16-byte stores, drain, one flag per wave
+      if (!(p.dbg & 2)) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum[q4]), xrs, xc0,
+                                                 (par * 2 + (1 - hs)) * PR_XSLOT + q4 * 1024, SC1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_store(flags + hs * 4 + wx, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // the partner's partial of OUR units (its X-wave wx computed our m-tile wx)
+      if (!dead && !(p.dbg & 3)) {
+        unsigned spins = 0;
+        const bool force = (V & 8) && step == 2 && pr == 0 && hs == 0 && wx == 0;  // test build: a timeout on demand
+        while (true) {
+          const unsigned v = __hip_atomic_load(flags + (1 - hs) * 4 + wx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!force && v >= (unsigned)(step + 1)) break;
+          if (force || ++spins > PR_SPIN_LIMIT) {
+            if (lane == 0) pair_timed_out(p.flags + npair * 8, p.status);
+            dead = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      u32x4 pv[4];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+        pv[q4] = (p.dbg & 2) ? u32x4{0u, 0u, 0u, 0u}
+                             : __builtin_amdgcn_raw_buffer_load_b128(xrs, xc0, (par * 2 + hs) * PR_XSLOT + q4 * 1024, SC1);
+      // the next step's saved activations: behind the gather in this wave's (in-order) memory queue
+      load_step(tn, 0);
+      load_step(tn, 1);
+      if (dead) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) pv[q4] = u32x4{0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u};
+      }
+      mine[0] = __builtin_bit_cast(f32x4, pv[0]);
+      mine[1] = __builtin_bit_cast(f32x4, pv[1]);
+      mineo[0] = __builtin_bit_cast(f32x4, pv[2]);
+      mineo[64] = __builtin_bit_cast(f32x4, pv[3]);
+    } else {
+      mineo[0] = sum[0];
+      mineo[64] = sum[1];
+      mine[0] = sum[2];
+      mine[1] = sum[3];
+      load_step(tn, 0);
+      load_step(tn, 1);
+    }
+    __syncthreads();  // S2: both halves of every cell's sum are in place; the image is no longer read
+  }
+}
+
+extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
+  WS_REQUIRE(a && a->gates && a->cbuf && a->dhcat && a->wpack && a->xchg && a->flags, "ws_lstm_bwd_pair: null pointer");
+  WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_bwd_pair: nseq and L must be positive");
+  const int npair = 2 * ((a->nseq + SQ - 1) / SQ);
+  int dev = 0, cus = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  WS_REQUIRE(2 * npair <= cus, "ws_lstm_bwd_pair: %d workgroups must be co-resident but the device has %d CUs", 2 * npair,
+             cus);
+  const int grid = 16 * ((npair + 7) / 8);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)npair * 8 + 8) * sizeof(unsigned), s);
+  WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_pair: hipMemsetAsync failed");
+  ws_prof_begin(WS_PROF_LSTM_BWD, s);
+  switch (a->dbg & (4 | 8 | 32)) {
+    case 0: hipLaunchKernelGGL(lstm_bwd_pair_kernel<0>, dim3(grid), dim3(512), 0, s, *a); break;
+    case 8: hipLaunchKernelGGL(lstm_bwd_pair_kernel<8>, dim3(grid), dim3(512), 0, s, *a); break;
+    case 4: hipLaunchKernelGGL(lstm_bwd_pair_kernel<4>, dim3(grid), dim3(512), 0, s, *a); break;
+    case 32: hipLaunchKernelGGL(lstm_bwd_pair_kernel<32>, dim3(grid), dim3(512), 0, s, *a); break;
+    default: WS_REQUIRE(false, "ws_lstm_bwd_pair: dbg bits 4, 8, 32 are exclusive");
+  }
+  ws_prof_end(WS_PROF_LSTM_BWD, s);
+  return ws_check_launch("ws_lstm_bwd_pair");
+}

@@ -419,9 +419,9 @@ def poll_cluster_status(device, block=False):
             sc.fallbacks += 1
         if bwd_to:
             raise L.WesepHipError(
-                "lstm_bwd_cluster: a bounded wait timed out (the workgroups were not co-resident: another stream or "
-                "process holds CUs); d(gates) of that launch are NaN-poisoned.  Unset WESEP_LSTM_CLUSTER_BWD to use "
-                "the streaming BPTT kernel")
+                "lstm_bwd_pair / lstm_bwd_cluster: a bounded wait timed out (the workgroups were not co-resident: another "
+                "stream or process holds CUs); d(gates) of that launch are NaN-poisoned.  WESEP_LSTM_PAIR_BWD=0 (and "
+                "WESEP_LSTM_CLUSTER_BWD unset) selects the streaming BPTT kernel")
 
     if sc.event is not None and (block or sc.event.query()):
         evaluate()
@@ -467,6 +467,41 @@ def lstm_bwd_cluster(gates, cbuf, dhcat, whh_f, whh_r, sm: SeqMap, status=None, 
     a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
     L.check(L.lib().ws_lstm_bwd_cluster(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_cluster")
     return flags[ncl * 8:ncl * 8 + 1]
+
+
+def lstm_pair_ok(sm: SeqMap, device) -> bool:
+    """The pair BPTT (lstm_pair.hip: two workgroups per (32-sequence tile, direction), W_hh split by gate rows, hi plane
+    resident) wants views with few, long sequences: both members of every pair co-resident on at most HALF of the CUs
+    (the other half is what the side stream's weight-gradient GEMMs run on) and enough steps to pay for loading the
+    resident plane.  WESEP_LSTM_PAIR_BWD=0 disables it (the 16-sequence streaming kernel then runs the time view)."""
+    if os.environ.get("WESEP_LSTM_PAIR_BWD", "1") == "0":
+        return False
+    return 4 * (-(-sm.nseq // 32)) <= cu_count(device) // 2 and sm.L >= 64
+
+
+def lstm_pack_pair(whh_f, whh_r, pack):
+    for n, t in (("whh_f", whh_f), ("whh_r", whh_r), ("pack", pack)):
+        _chk(t, n)
+    L.check(L.lib().ws_lstm_pack_pair(_p(whh_f), _p(whh_r), _p(pack), L.stream_ptr()), "ws_lstm_pack_pair")
+
+
+def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0):
+    """BPTT on the blocked layout over pairs of workgroups (lstm_pair.hip); gates: activated gates in,
+    d(pre-activation gates) (BLS) out.  Returns the launch's timeout word; in place, so there is no device-side
+    fall-back: poll_cluster_status raises (one step late, without a host sync) when a bounded wait timed out."""
+    for n, t in (("gates", gates), ("cbuf", cbuf), ("dhcat", dhcat), ("wpack", wpack)):
+        _chk(t, n)
+    npair = 2 * (-(-sm.nseq // 32))
+    sc = _cluster_scratch(gates.device)
+    xchg, flags = sc.get(npair * 65536 // 4, npair * 8 + 8)
+    a = L.LstmPairArgs()
+    a.gates, a.cbuf, a.dhcat, a.wpack = _p(gates), _p(cbuf), _p(dhcat), _p(wpack)
+    a.xchg, a.flags = C.c_void_p(xchg.data_ptr()), C.c_void_p(flags.data_ptr())
+    a.status = C.c_void_p(status.data_ptr() if status is not None else sc.status.data_ptr() + 4)
+    a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
+    _alg("lstm_bwd", 10 * 4 * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
+    L.check(L.lib().ws_lstm_bwd_pair(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_pair")
+    return flags[npair * 8:npair * 8 + 1]
 
 
 class BandTables:

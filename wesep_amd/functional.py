@@ -349,13 +349,13 @@ class ResRNNBlkFn(torch.autograd.Function):
         pw = W("pw")
         out = torch.empty_like(z)
         dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=W("proj"), C_out=out, ldc=N, bias=proj_b, R=z)
-        if torch.is_grad_enabled():
+        ctx.bptt = _bptt_kind(seq, d, cluster)
+        if any(ctx.needs_input_grad):     # (grad mode itself is always off inside a Function's forward)
             # the backward's packs (transposed projections, BPTT weight stream) are built here, where the GPU has a
             # single stream to serve: built lazily in the backward, these 10 us launches queue behind the side stream's
             # chip-filling weight-gradient GEMMs for up to a millisecond each (round 2 profile: 4 ms per step)
             W("projT"), W("wihT")
-            if not (cluster and os.environ.get("WESEP_LSTM_CLUSTER_BWD", "0") == "1"):
-                W("hh")
+            W("hhp") if ctx.bptt == "pair" else (W("hh") if ctx.bptt == "stream" else None)
         ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn, wcat, norm_w, norm_b, pw, whf, whr)
         ctx.view, ctx.box, ctx.lmode, ctx.cluster = view, box, lmode, cluster
         ctx.packs = W
@@ -417,12 +417,14 @@ class ResRNNBlkFn(torch.autograd.Function):
         # half of the chip idle: the weight-gradient jobs deferred by the previous layers are released
         # right after it is launched
         ready = mark_wgrads_ready(d) if ctx.view == "time" else None
-        # the cluster BPTT (4.8 ms vs 5.8 ms per time-view launch) fills all 256 CUs and so evicts the
-        # side-stream weight-gradient GEMMs that otherwise run under the 128-CU streaming kernel: net loss
-        # today, hence opt-in (WESEP_LSTM_CLUSTER_BWD=1; FusedClipAdam.step then checks its status word with a
-        # host sync before the update -- in place, so no device-side fall-back)
-        if ctx.cluster and os.environ.get("WESEP_LSTM_CLUSTER_BWD", "0") == "1":
+        # time view: the pair kernel (lstm_pair.hip) -- W_hh's hi plane resident across two workgroups per tile, on HALF
+        # of the CUs, so the side stream keeps the other half.  The cluster BPTT (all 256 CUs: it evicts the
+        # side-stream weight-gradient GEMMs) stays opt-in (WESEP_LSTM_CLUSTER_BWD=1).  Both work in place without a
+        # device-side fall-back: FusedClipAdam.step looks at their status word (asynchronously for the pair kernel)
+        if ctx.bptt == "cluster":
             dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
+        elif ctx.bptt == "pair":
+            dev.lstm_bwd_pair(gates, cbuf, dh, W("hhp"), seq)
         else:
             dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode)
         if ready is not None:
@@ -463,6 +465,14 @@ class ResRNNBlkFn(torch.autograd.Function):
         return (dz, gd, None, None, None, dgb[0], dgb[1]) + tuple(wg)
 
 
+def _bptt_kind(seq, device, cluster) -> str:
+    """Which BPTT kernel a blocked-layout ResRNN runs: 'cluster' (opt-in), 'pair' (views with few long sequences: the
+    time view), 'stream' (lstm_bf16*.hip)."""
+    if cluster and os.environ.get("WESEP_LSTM_CLUSTER_BWD", "0") == "1":
+        return "cluster"
+    return "pair" if dev.lstm_pair_ok(seq, device) else "stream"
+
+
 def _cluster_dbg() -> int:
     """WESEP_CLUSTER_FORCE_TIMEOUT=1 (tests): every forward cluster launch times out in workgroup 0 at step 2, so the
     predicated streaming fall-back produces the layer's result."""
@@ -472,7 +482,7 @@ def _cluster_dbg() -> int:
 def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, proj_w):
     """W(kind): the derived weight forms of one ResRNN through its PackCache (built on first use, kept until the
     weights change).  kinds: cat (wcat, bcat) | whh (contiguous W_hh pair) | hh (fwd, bwd recurrence packs of mode
-    `lmode`) | fused ([W_ih | W_hh] stream of lstm_fused.hip) | wih / wihT (p2b x-projection, b2p d(xn)) |
+    `lmode`) | hhp (pair-BPTT pack) | fused ([W_ih | W_hh] stream of lstm_fused.hip) | wih / wihT (p2b x-projection, b2p d(xn)) |
     pw (contiguous proj.weight) | proj / projT (b2p projection, p2b d(hcat))."""
     d = wih_f.device
     N = wih_f.shape[1]
@@ -488,6 +498,10 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
             pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
             dev.lstm_pack(*W("whh"), pack_f, pack_b, lmode)
             return pack_f, pack_b
+        if kind == "hhp":
+            pack = _empty(d, L.LSTM_PACK_FLOATS)
+            dev.lstm_pack_pair(*W("whh"), pack)
+            return pack
         if kind == "fused":
             fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
             dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), *W("whh"), fpack)

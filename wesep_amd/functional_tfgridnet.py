@@ -411,8 +411,13 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
         dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wlt_pack, N=2 * H, C_out=dh, A_bl=dout_bl)
         gates = gates.clone()                                    # BPTT works in place; keep the saved tensor intact
-        if cluster and os.environ.get("WESEP_LSTM_CLUSTER_BWD", "0") == "1":
+        kind = ctx.F0._bptt_kind(seq, d, cluster)
+        if kind == "cluster":
             dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
+        elif kind == "pair":                                    # few long sequences (the inter-frame path): lstm_pair.hip
+            ppack = _empty(d, L.LSTM_PACK_FLOATS)
+            dev.lstm_pack_pair(whf, whr, ppack)
+            dev.lstm_bwd_pair(gates, cbuf, dh, ppack, seq)
         else:
             dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, lmode)
         wg = ctx.F0.ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N)
