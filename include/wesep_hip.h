@@ -269,7 +269,8 @@ int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream);
  * npair * 8 + 8 words (zeroed by the call on `stream`).  Every wait is bounded: on a timeout d(gates) are NaN-poisoned,
  * flags[npair * 8] (0 after a clean launch) and *status (optional, sticky) are set to 1; in place, so there is no
  * device-side repair.  dbg (probes / tests only): 1 skip the flag wait, 2 skip the exchange, 4 no weight reloads,
- * 8 force a timeout in pair 0 at step 2, 32 no wave priorities.                                              */
+ * 8 force a timeout in pair 0 at step 2, 32 no wave priorities,
+ * 64 full agent-scope release / acquire fences around the hand-off.                                             */
 typedef struct ws_lstm_pair_args {
   float* gates;
   const float* cbuf;
@@ -278,6 +279,8 @@ typedef struct ws_lstm_pair_args {
   void* xchg;
   unsigned* flags;
   unsigned* status;
+  float* dbg_buf;       /* NULL, or npair * L * 2 * 2 * 4096 floats: per (pair, step, member) the partial it sent and
+                           the partial it received (diagnosis only, tools/pair_diag.py)                       */
   int nseq, L;
   int dbg, pad_;
 } ws_lstm_pair_args;

@@ -17,19 +17,17 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
-# ---- one repeat for GPU tests whose FIRST evaluation fails -----------------------------------------------------------
-# The driver runs `pytest tests/ -x -q -m gpu` in one process: with -x a single transient stops everything behind it.
-# One such transient was observed in round 2 ("One unexplained transient": a deterministic test
-# that passed in every other run and in 13 repetitions failed once in the middle of a whole-suite run), next to the
-# documented cross-stream interference of profiles/r02_kernel_race.md.  A `gpu` test that fails is therefore evaluated
-# ONE more time, from a fresh setup: a systematic failure fails again and is reported as usual (rc != 0); a
-# first-evaluation-only failure passes and is LISTED in the terminal summary with its original error, so it cannot go
-# unnoticed.  WESEP_TEST_NO_RERUN=1 switches this off.
+# ---- diagnosis aid (OPT-IN): a second evaluation of a failing GPU test ------------------------------------------------
+# Round 2 evaluated every failing `gpu` test a second time by default and let the session pass when the second try
+# passed -- a blanket mask over exactly the class of bug (races) this code base has shown (VERDICT / ADVICE round 2).
+# Now: nothing is re-evaluated unless WESEP_TEST_RERUN=1 is set by somebody who is diagnosing a transient, and even
+# then a first-evaluation failure (a) is listed with its original assertion, (b) is written to
+# gpurun_out/test_reruns.json, and (c) makes the session end with a non-zero exit status.  A failure is a failure.
 _RERUNS = []
 
 
 def pytest_runtest_protocol(item, nextitem):
-    if item.get_closest_marker("gpu") is None or os.environ.get("WESEP_TEST_NO_RERUN", "0") == "1":
+    if item.get_closest_marker("gpu") is None or os.environ.get("WESEP_TEST_RERUN", "0") != "1":
         return None
     from _pytest.runner import runtestprotocol
     item.ihook.pytest_runtest_logstart(nodeid=item.nodeid, location=item.location)
@@ -39,8 +37,8 @@ def pytest_runtest_protocol(item, nextitem):
         first = " | ".join(" ".join(ln.strip() for ln in str(r.longrepr).splitlines() if ln.startswith("E "))[:400]
                            for r in failed)
         again = runtestprotocol(item, nextitem=nextitem, log=False)
-        if not any(r.failed for r in again):
-            _RERUNS.append((item.nodeid, first))
+        _RERUNS.append({"nodeid": item.nodeid, "first_evaluation": first,
+                        "second_evaluation_failed": any(r.failed for r in again)})
         reports = again
     for r in reports:
         item.ihook.pytest_runtest_logreport(report=r)
@@ -50,6 +48,17 @@ def pytest_runtest_protocol(item, nextitem):
 
 def pytest_terminal_summary(terminalreporter):
     if _RERUNS:
-        terminalreporter.section("GPU tests that failed on their first evaluation only (transient)", sep="!")
-        for nodeid, first in _RERUNS:
-            terminalreporter.write_line(f"RERUN-PASSED {nodeid}: first evaluation: {first}")
+        terminalreporter.section("GPU tests that FAILED on their first evaluation (WESEP_TEST_RERUN=1)", sep="!")
+        for r in _RERUNS:
+            terminalreporter.write_line(f"FIRST-EVALUATION-FAILED {r['nodeid']}: {r['first_evaluation']}")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _RERUNS:
+        import json
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "test_reruns.json"), "w") as f:
+            json.dump(_RERUNS, f, indent=1)
+        if session.exitstatus == 0:
+            session.exitstatus = 1          # a transient is not a pass

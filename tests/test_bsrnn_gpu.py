@@ -357,8 +357,8 @@ def test_fused_input_projection_recurrence_matches_two_kernel_path(monkeypatch):
         out.backward(gout)
         torch.cuda.synchronize()
         res[fuse] = (out.detach(), z.grad.detach(), {k: v.grad.detach().clone() for k, v in blk.named_parameters()})
-    # (this is the test that failed once, unreproduced, in the middle of a whole-suite run: DESIGN.md section 11b; a
-    # failing gpu test is evaluated a second time by tests/conftest.py and listed if only the first evaluation failed)
+    # (this is the test that failed once, unreproduced, in the middle of a whole-suite run in round 2: DESIGN.md
+    # section 11b.  Nothing is re-evaluated by default any more: a failure here fails the suite -- tests/conftest.py)
     assert rel(res["1"][0], res["0"][0]) < 1e-4
     assert rel(res["1"][1], res["0"][1]) < 5e-4
     for k in res["0"][2]:

@@ -92,7 +92,7 @@ class LstmClusterArgs(C.Structure):
 
 
 class LstmPairArgs(C.Structure):
-    _fields_ = [(n, _p) for n in ("gates", "cbuf", "dhcat", "wpack", "xchg", "flags", "status")] + \
+    _fields_ = [(n, _p) for n in ("gates", "cbuf", "dhcat", "wpack", "xchg", "flags", "status", "dbg_buf")] + \
                [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i)]
 
 

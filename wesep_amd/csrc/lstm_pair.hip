@@ -170,6 +170,12 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
     int zo = 0;
     asm volatile("" : "+s"(zo));
     // ---- phase C: cell backward of this thread's two cells -> d(gates): LDS image (B operand) + HBM (BLS) -----------
+    // The eight HBM stores are issued TOGETHER at the end, after every value they carry has been computed, with nothing
+    // but the barrier behind them.  Found on the MI355X (profiles/r03_store_hazard.md): when the instruction after a
+    // 16-byte buffer store with an SGPR soffset is a VALU write to the store's data registers, the store can pick up
+    // the NEW contents in the dwords / lanes it reads last (hipcc pads that hazard only for stores WITHOUT a register
+    // soffset) -- sparse, run-to-run varying wrong dwords.
+    f32x4 pk[2][4];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int q = q0 + 2 * e;
@@ -194,16 +200,32 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
         split4(v, hi, lo);
         *reinterpret_cast<bf16x4*>(&bimg[0][n * PR_ROW + g * 128 + 4 * q]) = hi;
         *reinterpret_cast<bf16x4*>(&bimg[1][n * PR_ROW + g * 128 + 4 * q]) = lo;
-        bst(pack_hl4(hi, lo), grs(t), gvo, (g * 64 + 2 * e) * 512);
+        pk[e][g] = pack_hl4(hi, lo);
       };
       emit(pi, 0);
       emit(pf, 1);
       emit(pg, 2);
       emit(po, 3);
     }
+    asm volatile("" ::"v"(pk[0][0]), "v"(pk[0][1]), "v"(pk[0][2]), "v"(pk[0][3]), "v"(pk[1][0]), "v"(pk[1][1]),
+                 "v"(pk[1][2]), "v"(pk[1][3])
+                 : "memory");  // all eight values exist before the first store
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bst(pk[e][g], grs(t), gvo, (g * 64 + 2 * e) * 512);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7");
+    if constexpr (V & 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bisect: stores drained before the MFMAs
     __syncthreads();  // S1: the d(gates) image of this step is complete; rec is consumed
 
     // ---- partial dh^T [32 units of this wave's m-tile][32 sequences] = W_hh^T slice * dgates^T ----------------------
+    if constexpr (V & 128) {  // bisect build: the cell backward alone (no MFMA, no hand-off)
+      load_step(tn, 0);
+      load_step(tn, 1);
+      __syncthreads();
+      continue;
+    }
     if (xrole && !(V & 32)) __builtin_amdgcn_s_setprio(1);
     bf16x8 wl[2][PAIR_RING];
 #pragma unroll
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
+    for (int ch = 0; ch < ((V & 1024) ? 0 : NCH); ++ch) {   // (bisect build 1024: no MFMA loop)
       const int s = ch & 1;
 #pragma unroll
       for (int f = 0; f < PAIR_RING; ++f) {
@@ -246,14 +268,22 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
     for (int q4 = 0; q4 < 4; ++q4)
       sum[q4] = f32x4{acc0[4 * q4] + acc1[4 * q4], acc0[4 * q4 + 1] + acc1[4 * q4 + 1], acc0[4 * q4 + 2] + acc1[4 * q4 + 2],
                       acc0[4 * q4 + 3] + acc1[4 * q4 + 3]};
+    if constexpr (V & 512) {  // bisect build: MFMA loop but no hand-off
+      mine[0] = sum[0], mine[1] = sum[1];
+      load_step(tn, 0);
+      load_step(tn, 1);
+      __syncthreads();
+      continue;
+    }
     if (xrole) {
       __builtin_amdgcn_s_setprio(0);
       // publish the partial of the PARTNER's units: write-through 16-byte stores, drain, one flag per wave
       if (!(p.dbg & 2)) {
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum[q4]), xrs, xc0,
-                                                 (par * 2 + (1 - hs)) * PR_XSLOT + q4 * 1024, SC1);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum[q4]), xrs,
+                                                 xc0 + (par * 2 + (1 - hs)) * PR_XSLOT + q4 * 1024, 0, SC1);
+        if (p.dbg & 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // probe: full release instead of R1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
           __hip_atomic_store(flags + hs * 4 + wx, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -273,6 +303,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
           __builtin_amdgcn_s_sleep(1);
         }
       }
+      if (p.dbg & 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       u32x4 pv[4];
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4)
@@ -284,6 +315,14 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       if (dead) {
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) pv[q4] = u32x4{0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u};
+      }
+      if (p.dbg_buf) {  // diagnosis: what this wave sent and what it received, per step (tools/pair_diag.py)
+        float* db = p.dbg_buf + ((((long long)pr * L + step) * 2 + hs) * 2) * 4096;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          *reinterpret_cast<f32x4*>(db + (xc0 >> 2) + q4 * 256) = sum[q4];
+          *reinterpret_cast<u32x4*>(db + 4096 + (xc0 >> 2) + q4 * 256) = pv[q4];
+        }
       }
       mine[0] = __builtin_bit_cast(f32x4, pv[0]);
       mine[1] = __builtin_bit_cast(f32x4, pv[1]);
@@ -315,7 +354,11 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)npair * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_pair: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
-  switch (a->dbg & (4 | 8 | 32)) {
+  switch (a->dbg & (4 | 8 | 32 | 128 | 256 | 512 | 1024)) {
+    case 256: hipLaunchKernelGGL(lstm_bwd_pair_kernel<256>, dim3(grid), dim3(512), 0, s, *a); break;
+    case 512: hipLaunchKernelGGL(lstm_bwd_pair_kernel<512>, dim3(grid), dim3(512), 0, s, *a); break;
+    case 1024: hipLaunchKernelGGL(lstm_bwd_pair_kernel<1024>, dim3(grid), dim3(512), 0, s, *a); break;
+    case 128: hipLaunchKernelGGL(lstm_bwd_pair_kernel<128>, dim3(grid), dim3(512), 0, s, *a); break;
     case 0: hipLaunchKernelGGL(lstm_bwd_pair_kernel<0>, dim3(grid), dim3(512), 0, s, *a); break;
     case 8: hipLaunchKernelGGL(lstm_bwd_pair_kernel<8>, dim3(grid), dim3(512), 0, s, *a); break;
     case 4: hipLaunchKernelGGL(lstm_bwd_pair_kernel<4>, dim3(grid), dim3(512), 0, s, *a); break;

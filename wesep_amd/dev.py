@@ -485,7 +485,7 @@ def lstm_pack_pair(whh_f, whh_r, pack):
     L.check(L.lib().ws_lstm_pack_pair(_p(whh_f), _p(whh_r), _p(pack), L.stream_ptr()), "ws_lstm_pack_pair")
 
 
-def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0):
+def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg_buf=None):
     """BPTT on the blocked layout over pairs of workgroups (lstm_pair.hip); gates: activated gates in,
     d(pre-activation gates) (BLS) out.  Returns the launch's timeout word; in place, so there is no device-side
     fall-back: poll_cluster_status raises (one step late, without a host sync) when a bounded wait timed out."""
@@ -499,6 +499,7 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0):
     a.xchg, a.flags = C.c_void_p(xchg.data_ptr()), C.c_void_p(flags.data_ptr())
     a.status = C.c_void_p(status.data_ptr() if status is not None else sc.status.data_ptr() + 4)
     a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
+    a.dbg_buf = C.c_void_p(dbg_buf.data_ptr()) if dbg_buf is not None else None
     _alg("lstm_bwd", 10 * 4 * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
     L.check(L.lib().ws_lstm_bwd_pair(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_pair")
     return flags[npair * 8:npair * 8 + 1]
