@@ -26,9 +26,31 @@ def _row(*cells):
     return " | ".join(f"{c:>10}" if not isinstance(c, float) else f"{c:10.4g}" for c in cells)
 
 
+class ReplicaDivergence(RuntimeError):
+    """Data-parallel replicas no longer hold the same parameters (Executor.train's self-check)."""
+
+
 class Executor:
-    def __init__(self):
+    def __init__(self, trace_losses=False):
+        """trace_losses: keep every step's loss (device scalars, no host sync) in `self.loss_trace` -- tests and
+        diagnosis; the reference interface is unchanged."""
         self.step = 0
+        self.trace_losses = trace_losses
+        self.loss_trace = []
+
+    @staticmethod
+    def _replica_check(model, device, where):
+        """Every data-parallel replica must hold bit-identical parameters after an optimizer step (same averaged
+        gradients, same update).  One small all-reduce pair per log row (wesep_amd.parallel.all_ranks_tensor_spread
+        over a per-tensor checksum vector): a silent corruption on one rank -- a kernel fault, a bad collective -- is
+        reported where it happens instead of surfacing as a diverged model hours later."""
+        from ..parallel import all_ranks_tensor_spread
+        with torch.no_grad():
+            ps = [p for p in model.parameters()]
+            sums = torch.stack([p.detach().double().sum() for p in ps] + [p.detach().double().abs().sum() for p in ps])
+        spread = all_ranks_tensor_spread(sums, device)
+        if spread != 0.0:
+            raise ReplicaDivergence(f"data-parallel replicas diverged ({where}): parameter checksum spread {spread:.3e}")
 
     @staticmethod
     def _to_device(batch, device):
@@ -81,6 +103,8 @@ class Executor:
                 outputs = model(features, enroll)
                 loss = self._loss(outputs, targets, spk_label, criterion, se_loss_weight, multi_task)
                 loss_sum += loss.detach()
+                if self.trace_losses:
+                    self.loss_trace.append(loss.detach().clone())
                 n_steps += 1
                 optimizer.zero_grad()
                 if scaler is not None:
@@ -99,9 +123,12 @@ class Executor:
                 else:
                     optimizer.step()
                 self.step += 1
-                if (i + 1) % log_batch_interval == 0 and logger is not None:
-                    logger.info(_row("TRAIN", epoch, i + 1, float(loss_sum.item() / n_steps),
-                                     float(optimizer.param_groups[0]["lr"])))
+                if (i + 1) % log_batch_interval == 0:
+                    if ddp:
+                        self._replica_check(model, device, f"epoch {epoch}, batch {i + 1}")
+                    if logger is not None:
+                        logger.info(_row("TRAIN", epoch, i + 1, float(loss_sum.item() / n_steps),
+                                         float(optimizer.param_groups[0]["lr"])))
                 if (i + 1) == epoch_iter:
                     break
         return float(loss_sum.item() / max(n_steps, 1)), 0
