@@ -30,8 +30,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mkrsrc(const float* base, unsi
 __device__ __forceinline__ f32x4 bld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, WS_STREAM_AUX));
 }
+// Stores carry their whole offset in the VGPR address / the instruction's immediate and NO register soffset.  Found on
+// the MI355X in round 3 (profiles/r03_store_hazard.md, tools/store_hazard_repro.hip): a 16-byte buffer store needs one
+// wait state before a VALU instruction may overwrite its data registers ALSO when its soffset is an SGPR, but hipcc
+// (ROCm 7.2) pads that hazard only for stores without a register soffset (GCNHazardRecognizer::createsVALUHazard) -- the
+// store then writes the NEW register contents in the lanes it reads last (0.2 % of the dwords in the reproducer; the
+// round-2 recurrence kernels had 59 such sites).  With a constant-zero soffset the compiler inserts the wait states
+// itself; tools/scan_store_hazard.py checks the generated ISA of every kernel for the pattern.
 __device__ __forceinline__ void bst(const f32x4& v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, WS_STREAM_AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + soff, 0, WS_STREAM_AUX);
 }
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {

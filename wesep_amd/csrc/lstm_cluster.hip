@@ -207,8 +207,8 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
       // publish both halves of the slice: write-through stores, then drain
 #pragma unroll
       for (int e = 0; e < 2; ++e)
-        __builtin_amdgcn_raw_buffer_store_b128(publ[mt + 256 * e], xrs, (j * 512 + mt + 256 * e) * 16,
-                                               par * (8 * 8192), SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(publ[mt + 256 * e], xrs,  // (no register soffset: lstm_bf16_common.h bst)
+                                               (j * 512 + mt + 256 * e) * 16 + par * (8 * 8192), 0, SC1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       // next step's x-projection into place (LDS only; the HBM traffic waits for the next MFMA phase)
@@ -391,8 +391,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_cluster_kernel(const ws_lstm_
             f32x4 v = {acc[e][st][4 * q4], acc[e][st][4 * q4 + 1], acc[e][st][4 * q4 + 2], acc[e][st][4 * q4 + 3]};
             if (dead) v = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
             const int dest = 2 * w + e, cell = (2 * q4 + half) * 64 + 32 * st + n;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xrs, cell * 16,
-                                                   ((par * 8 + dest) * 8 + j) * 8192, SC1);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xrs,
+                                                   cell * 16 + ((par * 8 + dest) * 8 + j) * 8192, 0, SC1);
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // A2: every publishing wave has drained
