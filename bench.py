@@ -14,6 +14,7 @@ MFMAs per product, fp32 accumulation and fp32 storage) -- holds the reference's 
 rows (seed 42 + rank); DDP all-reduces gradients over RCCL.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -209,16 +210,20 @@ def main():
         opt.step()
         return loss
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    barrier()
-    dev.prof_enable(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    torch.cuda.synchronize()
+    # WESEP_MAIN_PRIORITY (experiment): run the step on a stream of that HIP priority instead of the default stream
+    main_pr = os.environ.get("WESEP_MAIN_PRIORITY")
+    main_ctx = torch.cuda.stream(torch.cuda.Stream(device=d, priority=int(main_pr))) if main_pr else contextlib.nullcontext()
+    with main_ctx:
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        dev.prof_enable(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss = step(args.warmup + i)
+        torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     dev.prof_enable(False)

@@ -18,12 +18,55 @@ from wesep_amd import _lib as L, dev  # noqa: E402
 from wesep_amd.functional import _view_maps  # noqa: E402
 
 
+def stamps(R, Tf=501):
+    """Phase stamps of one X-wave and one O-wave of pair 0 / member 0 (lstm_pair.hip, variant 2048)."""
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    H, N, K = 256, 128, 32
+    whf = (0.06 * torch.randn(4 * H, H, generator=g)).to(d)
+    whr = (0.06 * torch.randn(4 * H, H, generator=g)).to(d)
+    _, _, seq, _ = _view_maps("time", R, K, Tf, N)
+    nb = dev.bl_num_blocks(seq)
+    gates = torch.rand(nb, 32 * 8 * H, device=d) * 0.9 + 0.05
+    cbuf = torch.randn(nb, 2 * H // 4, 32, 4, device=d) * 0.5
+    dh = torch.randn(nb, 2 * H // 4, 32, 4, device=d) * 0.1
+    pp = torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack_pair(whf, whr, pp)
+    for rep in range(2):
+        dbuf = torch.zeros(Tf * 2 * 8 * 2, device=d)
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g2 = gates.clone()
+        t0.record()
+        dev.lstm_bwd_pair(g2, cbuf, dh, pp, seq, dbg=2048, dbg_buf=dbuf)
+        t1.record()
+        torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1)
+    ts = dbuf.view(torch.int64).view(Tf, 2, 8).cpu().double()
+    span = float(ts[-1, 0, 0] - ts[5, 0, 0]) / (Tf - 6)
+    us_per_tick = (ms * 1e3 / Tf) / span if span > 0 else float("nan")
+    print(f"launch {ms:.3f} ms = {ms * 1e3 / Tf:.2f} us/step with stamps; {span:.0f} ticks per step -> {us_per_tick * 1e3:.2f} ns per tick")
+    names = ["loop top", "cell backward done", "past S1", "MFMA loop done", "X: flagged / O: partial in LDS",
+             "X: next loads requested", "X: partner's flag seen", "X: gather arrived"]
+    for role, nm in ((0, "X-wave 0"), (1, "O-wave 4")):
+        t = ts[5:-1, role] - ts[5:-1, role, 0:1]
+        nxt = ts[6:, role, 0] - ts[5:-1, role, 0]
+        print(f"  {nm}: mean microseconds since the loop top")
+        for k in range(1, 8):
+            if role == 1 and k > 4:
+                continue
+            print(f"     {names[k]:34s} {float(t[:, k].mean()) * us_per_tick:6.2f}   (sd {float(t[:, k].std()) * us_per_tick:.2f})")
+        print(f"     {'next loop top (past S2)':34s} {float(nxt.mean()) * us_per_tick:6.2f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=2)
     ap.add_argument("--frames", default="1,2,3,4,8,70")
     ap.add_argument("--dbg", default="0,32,64")
+    ap.add_argument("--ts", type=int, default=0, help="rows: print the in-kernel phase stamps (variant 2048) at that size")
     a = ap.parse_args()
+    if a.ts:
+        return stamps(a.ts)
     d = torch.device("cuda:0")
     g = torch.Generator().manual_seed(7)
     H, N, K = 256, 128, 32

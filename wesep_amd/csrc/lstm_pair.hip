@@ -87,6 +87,16 @@ __device__ __noinline__ void pair_timed_out(unsigned* tword, unsigned* status) {
 
 // V: compile-time variant bits (the step body stays free of run-time branches): 8 = test build that forces a timeout
 // in pair 0 at step 2; probes: 4 = no weight reloads, 32 = no wave priorities
+// variant 2048 (diagnosis): s_memtime stamps of pair 0 / member 0, waves 0 (X) and 4 (O), into dbg_buf:
+//   dbg_buf[((step * 2 + role) * 8 + k)] as 64-bit ticks; k: 0 loop top, 1 cell backward done, 2 past S1, 3 MFMA loop done,
+//   4 X: published + drained + flagged / O: partial in LDS, 5 X: next step's loads requested, 6 X: partner's flag seen,
+//   7 X: gather arrived; the next k = 0 closes the step (past S2)
+#define TS(k)                                                                                                      \
+  if constexpr (V & 2048) {                                                                                        \
+    if (pr == 0 && hs == 0 && wx == 0 && lane == 0 && p.dbg_buf)                                                   \
+      reinterpret_cast<unsigned long long*>(p.dbg_buf)[(step * 2 + role) * 8 + (k)] = __builtin_readcyclecounter(); \
+  }
+
 template <int V>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pair_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 bimg[2][SQ * PR_ROW];      // [part][seq][local gate col] 65 KB
@@ -176,6 +186,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
     // the NEW contents in the dwords / lanes it reads last (hipcc pads that hazard only for stores WITHOUT a register
     // soffset) -- sparse, run-to-run varying wrong dwords.
     f32x4 pk[2][4];
+    TS(0);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int q = q0 + 2 * e;
@@ -201,23 +212,17 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
         *reinterpret_cast<bf16x4*>(&bimg[0][n * PR_ROW + g * 128 + 4 * q]) = hi;
         *reinterpret_cast<bf16x4*>(&bimg[1][n * PR_ROW + g * 128 + 4 * q]) = lo;
         pk[e][g] = pack_hl4(hi, lo);
+        bst(pk[e][g], grs(t), gvo, (g * 64 + 2 * e) * 512);  // (zero soffset inside: hipcc pads the data hazard)
       };
       emit(pi, 0);
       emit(pf, 1);
       emit(pg, 2);
       emit(po, 3);
     }
-    asm volatile("" ::"v"(pk[0][0]), "v"(pk[0][1]), "v"(pk[0][2]), "v"(pk[0][3]), "v"(pk[1][0]), "v"(pk[1][1]),
-                 "v"(pk[1][2]), "v"(pk[1][3])
-                 : "memory");  // all eight values exist before the first store
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) bst(pk[e][g], grs(t), gvo, (g * 64 + 2 * e) * 512);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 7");
     if constexpr (V & 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bisect: stores drained before the MFMAs
+    TS(1);
     __syncthreads();  // S1: the d(gates) image of this step is complete; rec is consumed
+    TS(2);
 
     // ---- partial dh^T [32 units of this wave's m-tile][32 sequences] = W_hh^T slice * dgates^T ----------------------
     if constexpr (V & 128) {  // bisect build: the cell backward alone (no MFMA, no hand-off)
@@ -261,8 +266,12 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
 #pragma unroll
         for (int f = 0; f < PAIR_RING; ++f) wl[s][f] = wload(wrs, wlane + f * 1024, zo + (ch + 2) * (PAIR_RING * 1024));
       }
+      // (an explicitly double-buffered version of this loop -- B fragments of k-step ks + 1 requested before the MFMAs
+      //  of ks, pinned with sched_group_barriers -- measured 4% SLOWER: the loop is not waiting for LDS but for the lo
+      //  stream and the CU's memory pipe, tools/pair_diag.py --ts)
       __builtin_amdgcn_sched_barrier(0);
     }
+    TS(3);
     f32x4 sum[4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4)
@@ -288,6 +297,13 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
         if (lane == 0)
           __hip_atomic_store(flags + hs * 4 + wx, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      TS(4);
+      // the next step's saved activations are requested BEFORE the wait for the partner: they fly while this wave
+      // polls (the gather then returns behind them in the in-order queue, about when the flag arrives anyway:
+      // 4.17 -> 3.93 ms per launch)
+      load_step(tn, 0);
+      load_step(tn, 1);
+      TS(5);
       // the partner's partial of OUR units (its X-wave wx computed our m-tile wx)
       if (!dead && !(p.dbg & 3)) {
         unsigned spins = 0;
@@ -303,20 +319,18 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
           __builtin_amdgcn_s_sleep(1);
         }
       }
+      TS(6);
       if (p.dbg & 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       u32x4 pv[4];
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4)
         pv[q4] = (p.dbg & 2) ? u32x4{0u, 0u, 0u, 0u}
                              : __builtin_amdgcn_raw_buffer_load_b128(xrs, xc0, (par * 2 + hs) * PR_XSLOT + q4 * 1024, SC1);
-      // the next step's saved activations: behind the gather in this wave's (in-order) memory queue
-      load_step(tn, 0);
-      load_step(tn, 1);
       if (dead) {
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) pv[q4] = u32x4{0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u};
       }
-      if (p.dbg_buf) {  // diagnosis: what this wave sent and what it received, per step (tools/pair_diag.py)
+      if (p.dbg_buf && !(V & 2048)) {  // diagnosis: what this wave sent and what it received, per step (tools/pair_diag.py)
         float* db = p.dbg_buf + ((((long long)pr * L + step) * 2 + hs) * 2) * 4096;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
@@ -326,6 +340,10 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       }
       mine[0] = __builtin_bit_cast(f32x4, pv[0]);
       mine[1] = __builtin_bit_cast(f32x4, pv[1]);
+      if constexpr (V & 2048) {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // (stamp only: the gather is back, the 12 activation loads may fly)
+        TS(7);
+      }
       mineo[0] = __builtin_bit_cast(f32x4, pv[2]);
       mineo[64] = __builtin_bit_cast(f32x4, pv[3]);
     } else {
@@ -333,6 +351,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       mineo[64] = sum[1];
       mine[0] = sum[2];
       mine[1] = sum[3];
+      TS(4);
       load_step(tn, 0);
       load_step(tn, 1);
     }
@@ -354,7 +373,8 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)npair * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_pair: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
-  switch (a->dbg & (4 | 8 | 32 | 128 | 256 | 512 | 1024)) {
+  switch (a->dbg & (4 | 8 | 32 | 128 | 256 | 512 | 1024 | 2048)) {
+    case 2048: hipLaunchKernelGGL(lstm_bwd_pair_kernel<2048>, dim3(grid), dim3(512), 0, s, *a); break;
     case 256: hipLaunchKernelGGL(lstm_bwd_pair_kernel<256>, dim3(grid), dim3(512), 0, s, *a); break;
     case 512: hipLaunchKernelGGL(lstm_bwd_pair_kernel<512>, dim3(grid), dim3(512), 0, s, *a); break;
     case 1024: hipLaunchKernelGGL(lstm_bwd_pair_kernel<1024>, dim3(grid), dim3(512), 0, s, *a); break;

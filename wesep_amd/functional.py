@@ -168,7 +168,10 @@ _SIDE_STREAMS = {}
 def _side_stream(device):
     key = (device.type, device.index)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        # WESEP_SIDE_PRIORITY: HIP stream priority of the weight-gradient side stream (torch convention: lower = more
+        # urgent; unset = the default priority)
+        pr = os.environ.get("WESEP_SIDE_PRIORITY")
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=int(pr)) if pr else torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
 
 
