@@ -298,7 +298,9 @@ def main():
             # the recurrence kernels are bound by memory paths (HBM activations + the per-step L2 weight
             # stream), not by the matrix cores: HBM is the roof they are priced against
             "roofline": {"bound": "hbm", "kernel": dom + " recurrence kernels, launch average over the time view (" +
-                                   ("lstm_fwd_cluster_kernel" if dom == "lstm_fwd" else "lstm_bwd_s16_kernel") +
+                                   ("lstm_fwd_cluster_kernel" if dom == "lstm_fwd" else
+                                    ("lstm_bwd_pair_kernel" if os.environ.get("WESEP_LSTM_PAIR_BWD", "1") != "0"
+                                     else "lstm_bwd_s16_kernel")) +
                                    ") and the band view (" + dom + "_bf16_kernel<BLK>)",
                          "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": bytes_per_launch,
@@ -325,7 +327,10 @@ def main():
             "frac_mfma_executed": t_mfma / sec_step, "alg_gbs": alg_bytes / sec_step / 1e9,
             "frac_hbm_alg": t_hbm / sec_step, "bound": "mfma" if t_mfma >= t_hbm else "hbm",
             "frac": max(t_mfma, t_hbm) / sec_step,
-            "note": "per GPU; SURVEY 8d: achieved := max(bytes_alg / 8 TB/s, 3 * flops_alg / 2.5 PFLOP/s) / t_step"}
+            "frac_mfma_algorithmic": alg_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12) / sec_step,
+            "note": "per GPU; SURVEY 8d: achieved := max(bytes_alg / 8 TB/s, 3 * flops_alg / 2.5 PFLOP/s) / t_step -- "
+                    "`frac` / `frac_mfma_executed` count the 3 bf16 MFMAs EXECUTED per fp32 product against the bf16 peak; "
+                    "`frac_mfma_algorithmic` counts each product once"}
         out["per_rank_ms_per_step"] = per_rank_ms
         out["replicas_in_sync"] = bool(spread == 0.0)
         out["replica_checksum_spread"] = spread
@@ -334,6 +339,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(kind=args.cpu_baseline)
         print(json.dumps(out), flush=True)
     barrier()
+    # a scaling record of replicas that drifted apart, or of fewer ranks than asked for, is not a measurement
+    if comm_info()["world_size"] != args.gpus or spread != 0.0:
+        sys.stderr.write(f"bench.py: world_size {comm_info()['world_size']} (asked for {args.gpus}), replica checksum "
+                         f"spread {spread}: FAILED\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -90,3 +90,92 @@ def test_single_process_helpers_are_noops():
     assert max_over_ranks(3.5, torch.device("cpu")) == 3.5
     assert all_ranks(3.5, torch.device("cpu")) == [3.5] and all_ranks_tensor_spread(torch.ones(3), torch.device("cpu")) == 0.0
     assert comm_info()["world_size"] == 1
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The PRODUCT's host composition under DistributedDataParallel at world size 2: the module
+# tree of wesep_amd.models.BSRNN with the blocked ResRNN (functional.ResRNNBlkFn), its weight-gradient carriers
+# (functional.WGradCarrierFn: the LSTM / proj gradients reach autograd -- and DDP's bucket hooks -- through a node that
+# runs at the very end of backward) and the deferred side-stream jobs, on the CPU emulation of the device entry points
+# (tests/emu_dev.py + emu_blk.py + emu_bsrnn.py for the band split / mask decode; tests/emu_streams.py for streams).
+# ----------------------------------------------------------------------------------------------------------------------
+def _product_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WESEP_WGRAD_OVERLAP="1")
+    torch.set_num_threads(2)
+    import pytest as _pytest
+    from oracle import bsrnn_oracle as O
+    from tests import emu_blk, emu_bsrnn, emu_dev, emu_streams
+    import wesep_amd.functional as f0
+    from wesep_amd.models import get_model
+    from wesep_amd.parallel import init_distributed, rank_seed, wrap_ddp
+    from wesep_amd.utils.executor import Executor, ReplicaDivergence
+    from wesep_amd.utils.synthetic import synth_batch
+    mp_ = _pytest.MonkeyPatch()
+    real_carrier, real_reset = f0.make_wgrad_carrier, f0.reset_deferred_wgrads
+    emu_dev.install(mp_)
+    emu_blk.install(mp_)
+    emu_bsrnn.install(mp_, real_resrnn=True)
+    mp_.setattr(f0, "make_wgrad_carrier", real_carrier)          # emu_bsrnn switches the carriers off: back on
+    mp_.setattr(f0, "reset_deferred_wgrads", real_reset)
+    emu_streams.install(mp_)
+    mp_.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    r, lr, w = init_distributed(backend="gloo")
+    cfg = O.BSRNNConfig(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False)
+    params = O.synth_params(cfg, 3)
+    model = get_model("BSRNN")(spk_emb_dim=cfg.spk_emb_dim, sr=cfg.sr, win=cfg.win, stride=cfg.stride,
+                               feature_dim=cfg.feature_dim, num_repeat=cfg.num_repeat,
+                               use_spk_transform=cfg.use_spk_transform, spk_fuse_type=cfg.spk_fuse_type,
+                               multi_fuse=cfg.multi_fuse, joint_training=False)
+    model.load_state_dict(params, strict=True)
+    model.train()
+    ddp = wrap_ddp(model, lr)
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    wav, tgt, emb = synth_batch(2, 2048, rank_seed(42, rank))
+    carried = []
+    orig_bwd = f0.WGradCarrierFn.backward
+
+    def spy(ctx, g):
+        res = orig_bwd(ctx, g)
+        carried.append(sum(x is not None for x in res))
+        return res
+    mp_.setattr(f0.WGradCarrierFn, "backward", staticmethod(spy))
+    est, _ = ddp(wav, emb)
+    O.sisdr_loss(est, tgt).backward()
+    named = dict(model.named_parameters())
+    assert all(p.grad is not None for p in named.values())
+    # this rank's own (un-averaged) gradient from the oracle, for the cross-check in the parent
+    q = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    O.sisdr_loss(O.bsrnn_forward(q, cfg, wav, emb), tgt).backward()
+    # the training self-check: identical replicas pass, a perturbed one is caught on every rank
+    Executor._replica_check(ddp, torch.device("cpu"), "test")
+    caught = False
+    if rank == 1:
+        with torch.no_grad():
+            next(model.parameters()).view(-1)[0] += 1e-3
+    try:
+        Executor._replica_check(ddp, torch.device("cpu"), "test")
+    except ReplicaDivergence:
+        caught = True
+    torch.save({"ddp": {k: p.grad.clone() for k, p in named.items()}, "local": {k: v.grad.clone() for k, v in q.items()},
+                "carried": carried, "caught": caught}, os.path.join(out, f"p{rank}.pt"))
+    torch.distributed.destroy_process_group()
+    mp_.undo()
+
+
+@pytest.mark.timeout(600)
+def test_product_model_with_weight_gradient_carriers_under_ddp_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_product_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"p{i}.pt") for i in range(2))
+    assert r0["carried"] == r1["carried"] == [10, 10]            # two ResRNNs, ten LSTM / proj tensors through each carrier
+    assert r0["caught"] and r1["caught"]                         # a diverged replica is reported on every rank
+    worst = 0.0
+    for k in r0["ddp"]:
+        g0, g1 = r0["ddp"][k], r1["ddp"][k]
+        assert torch.equal(g0, g1), k                            # replicas hold the same averaged gradient, bit for bit
+        want = 0.5 * (r0["local"][k] + r1["local"][k])           # ... = the mean of the two shards' gradients
+        err = float((g0 - want).norm() / (want.norm() + 1e-30))
+        worst = max(worst, err)
+        assert err < 2e-3, (k, err)
+    print("worst relative difference to the mean of the per-rank oracle gradients:", worst)

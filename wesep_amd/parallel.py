@@ -32,7 +32,7 @@ def wrap_ddp(model, local_rank=None, bucket_cap_mb=25):
     """DDP with the reference's settings (25 MB buckets; no buffers in BSRNN to broadcast)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
-    on_gpu = next(model.parameters()).is_cuda
+    on_gpu = next(model.parameters()).device.type == "cuda"
     return torch.nn.parallel.DistributedDataParallel(
         model, device_ids=[local_rank] if on_gpu else None, bucket_cap_mb=bucket_cap_mb,
         gradient_as_bucket_view=True)
