@@ -85,14 +85,14 @@ def test_tstp_matches_torch():
     assert rel(_nchw(xin.grad, R, Fq, T), xr.grad) < 1e-4
 
 
-@pytest.mark.parametrize("gemm,tol", [("f32", 3e-2), ("bf16x3", 3e-2)])
+@pytest.mark.parametrize("gemm,tol", [("f32", 2e-3), ("bf16x3", 2e-3)])
 def test_resnet18_matches_oracle(monkeypatch, gemm, tol):
     """ResNet18 (BasicBlock, m_channels 32), 16 mel bins, 64 frames: embedding, every parameter gradient and the
     BatchNorm running statistics against the restatement, under a fixed random linear functional of the embedding.
-    Tolerance 3e-2 in both product modes: with the exact-fp32 kernels the forward agrees to 2e-6 and all but ONE
-    element of every activation gradient agree to 5e-6 -- that element sits on a ReLU kink (pre-activation within
-    1e-6 of zero, mask flipped) and alone carries 1.1 % of the gradient norm of everything below the last stage;
-    the conv / BatchNorm / pooling kernels themselves are held to 2e-3 above."""
+    Tolerance 2e-3 per tensor in both product modes, on the SAME linear region: the restatement's ReLUs take the
+    device's masks (round 2 compared across regions at 3e-2: with the exact-fp32 kernels all but ONE element of every
+    activation gradient agreed to 5e-6 -- that element sat on a ReLU kink, pre-activation within 1e-6 of zero, mask
+    flipped, and alone carried 1.1 % of the gradient norm of everything below the last stage)."""
     from oracle import resnet_oracle as RO
     from wesep_amd.models.resnet import get_speaker_model
     monkeypatch.setenv("WESEP_GEMM", gemm)
@@ -106,12 +106,13 @@ def test_resnet18_matches_oracle(monkeypatch, gemm, tol):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(3, 64, 16, generator=g)
     probe = torch.randn(3, 64, generator=g)
+    masks = _record_relu_masks(monkeypatch)
     zero, emb = model(x.to(d))
     assert float(zero) == 0.0
     (emb * probe.to(d)).sum().backward()
     p = {k: (v.clone() if RO.is_buffer(k) else v.clone().requires_grad_(True)) for k, v in params.items()}
     bufs = {}
-    ref = RO.resnet_forward(p, x, num_blocks=kw["num_blocks"], m=32, new_buffers=bufs)
+    ref = RO.resnet_forward(p, x, num_blocks=kw["num_blocks"], m=32, new_buffers=bufs, relu_masks=masks)
     (ref * probe).sum().backward()
     assert rel(emb, ref) < 1e-3
     sd = model.state_dict()
@@ -122,7 +123,7 @@ def test_resnet18_matches_oracle(monkeypatch, gemm, tol):
     bad = []
     for k, prm in model.named_parameters():
         err = float((prm.grad.detach().cpu().double() - p[k].grad.double()).norm())
-        if err > tol * float(p[k].grad.norm()) + 1e-3 * gn:
+        if err > tol * float(p[k].grad.norm()) + 1e-6 * gn:
             bad.append((k, err / float(p[k].grad.norm())))
     assert not bad, bad[:10]
 

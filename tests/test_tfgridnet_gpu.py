@@ -7,7 +7,15 @@ import numpy as np
 import pytest
 import torch
 
+from tests.gradcheck import compare_grads
+
 pytestmark = pytest.mark.gpu
+GRAD_TOL = 5e-3     # per parameter tensor, relative L2 against the oracle's autograd
+# One frequency bin of the speaker-fusion scale gradient of this fixture amplifies the split-bf16 products' 1e-5 a
+# thousandfold (tools/diag_tfg_fuse.py on the MI355X: bin 4 off by 1.5e-2 of the largest entry, the other 64 bins at
+# 1e-5; with the exact-fp32 kernels all 65 agree to 4e-6): conditioning of the synthetic case, not arithmetic.  These two
+# tensors are held to 5e-2 in the split-bf16 run and to GRAD_TOL in the exact-fp32 run of the same case below.
+ILL_CONDITIONED = {"tfgridnet_ks4_r2_t1600": ("spk_fuse.fc.linear.weight", "spk_fuse.fc.linear.bias")}
 
 
 def _cuda():
@@ -39,6 +47,17 @@ def test_softmax_rows_matches_torch():
                                   "tfgridnet_ks1_film_r2_t1280", "tfgridnet_ks1_concat_r2_t1280",
                                   "tfgridnet_ks1_srcs2_mics3_r2_t1280"])
 def test_tfgridnet_model_matches_reference_fixture(name, golden_dir):
+    _fixture_case(name, golden_dir, exact=False)
+
+
+def test_tfgridnet_ks4_fixture_with_exact_fp32_products(golden_dir, monkeypatch):
+    """The emb_ks = 4 fixture on the exact-fp32 kernels: every gradient, the two ill-conditioned ones included."""
+    monkeypatch.setenv("WESEP_GEMM", "f32")
+    monkeypatch.setenv("WESEP_LSTM", "f32")
+    _fixture_case("tfgridnet_ks4_r2_t1600", golden_dir, exact=True)
+
+
+def _fixture_case(name, golden_dir, exact):
     from oracle import bsrnn_oracle as O
     from oracle import tfgridnet_oracle as TG
     from oracle.make_golden import TFGRIDNET_CASES, tfgridnet_batch
@@ -59,13 +78,25 @@ def test_tfgridnet_model_matches_reference_fixture(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     assert rel(est, torch.from_numpy(g["est"])) < 1e-3
     assert abs(loss.item() - float(g["loss"])) < 1e-2
-    floor = 1e-3 * max(float(g["gnorm/" + k]) for k, _ in model.named_parameters())
-    bad = []
+    # every parameter gradient, per tensor, against the oracle's autograd (the oracle itself is pinned to the
+    # reference's gradient norms by tests/test_oracle_golden.py) -- and the reference's own norms from the fixture
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out = TG.tfgridnet_forward(p, cfg, wav, emb)
+    ref = out[0] if isinstance(out, (tuple, list)) else out
+    O.sisdr_loss(ref.reshape(-1, T), tgt.reshape(-1, T)).backward()
+    loose = () if exact else ILL_CONDITIONED.get(name, ())
+    want = {k: v.grad for k, v in p.items()}
+    worst, wname, bad = compare_grads(((k, prm.grad) for k, prm in model.named_parameters() if k not in loose),
+                                      want, GRAD_TOL)
+    _, _, bad2 = compare_grads(((k, prm.grad) for k, prm in model.named_parameters() if k in loose), want, 5e-2)
+    print(f"{name}{' (exact fp32)' if exact else ''}: est rel {rel(est, torch.from_numpy(g['est'])):.2e}, worst "
+          f"gradient rel-L2 {worst:.2e} ({wname})")
+    assert not bad and not bad2, (bad + bad2)[:8]
+    top = max(float(g["gnorm/" + k]) for k, _ in model.named_parameters())
     for k, prm in model.named_parameters():
         gn = float(g["gnorm/" + k])
-        if prm.grad is None or abs(float(prm.grad.norm()) - gn) > 3e-2 * gn + floor:
-            bad.append((k, None if prm.grad is None else float(prm.grad.norm()), gn))
-    assert not bad, bad[:8]
+        if gn > 1e-6 * top:
+            assert abs(float(prm.grad.norm()) - gn) <= (5e-2 if k in loose else GRAD_TOL) * gn, (k, float(prm.grad.norm()), gn)
 
 
 def test_tfgridnet_unbuilt_variants_fail_loudly():
@@ -80,6 +111,7 @@ def test_baseline_config5_geometry_recipe_6s_vs_oracle():
     """BASELINE.json configs[4] geometry -- TF-GridNet, 6 s utterances -- with the recipe's model arguments
     (examples/librimix/tse/v2/confs/tfgridnet.yaml:44-60: n_fft 128 / stride 64, 6 layers, hidden 192, 4 heads, qk 512,
     emb_dim 128, emb_ks = emb_hs = 1) at 2 rows x 96 000 samples (Tf = 1501): waveform, loss and every gradient norm
+    (per tensor, relative L2)
     against the oracle.  This is the geometry on which the blocked-layout recurrences (cluster kernel on the
     zero-padded 130 -> 192 inter-frame sequences) and the grouped attention run."""
     from oracle import bsrnn_oracle as O
@@ -108,10 +140,7 @@ def test_baseline_config5_geometry_recipe_6s_vs_oracle():
           f"dloss {abs(loss.item() - loss_o.item()):.2e} dB")
     assert rel(est, ref) < 1e-3, rel(est, ref)
     assert abs(loss.item() - loss_o.item()) < 1e-2
-    floor = 1e-3 * max(float(v.grad.norm()) for v in p.values())
-    bad = []
-    for k, prm in model.named_parameters():
-        gn = float(p[k].grad.norm())
-        if prm.grad is None or abs(float(prm.grad.norm()) - gn) > 3e-2 * gn + floor:
-            bad.append((k, None if prm.grad is None else float(prm.grad.norm()), gn))
+    worst, wname, bad = compare_grads(((k, prm.grad) for k, prm in model.named_parameters()),
+                                      {k: v.grad for k, v in p.items()}, GRAD_TOL)
+    print(f"config 5 geometry: worst gradient rel-L2 {worst:.2e} ({wname})")
     assert not bad, bad[:8]
