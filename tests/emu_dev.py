@@ -455,6 +455,8 @@ def relu_mask(d, y):
 
 
 def bn_stats(x, M, Cc, running_mean, running_var, stats, eps=1e-5, momentum=0.1):
+    if M <= 1:      # like dev.bn_stats / torch
+        raise ValueError(f"BatchNorm in training mode needs more than 1 value per channel (got {M} row)")
     xx = x.reshape(M, Cc)
     mean = xx.mean(0)
     var = ((xx - mean) ** 2).mean(0)

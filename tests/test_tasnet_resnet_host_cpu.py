@@ -280,3 +280,31 @@ def test_resnet_pooling_variants_host_logic_matches_restatement(pooling, monkeyp
             continue
         gn = float(p[k].grad.norm())
         assert abs(float(prm.grad.norm()) - gn) <= 2e-2 * gn + 1e-4, k
+
+
+def test_batchnorm_eval_mode_backward_and_single_row_training(monkeypatch):
+    """the BatchNorm shims diverged silently from torch -- a backward through an eval-mode BatchNorm
+    raised 'not built' (the frozen-BN fine-tuning pattern) and ONE row in training mode was normalised with var = 0
+    where torch raises.  Now: eval-mode backward = dx = dy * gamma * rstd, dgamma / dbeta from the running statistics
+    (dev.bn_bwd_any), checked against torch's own BatchNorm1d in eval mode; one training row raises."""
+    from wesep_amd.functional_campplus import BnActFn
+    emu_dev.install(monkeypatch)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    torch.manual_seed(4)
+    M, Cc = 37, 16
+    bn = torch.nn.BatchNorm1d(Cc)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5), bn.bias.normal_(), bn.running_mean.normal_(), bn.running_var.uniform_(0.5, 2.0)
+    bn.eval()
+    x = torch.randn(M, Cc)
+    dy = torch.randn(M, Cc)
+    xr = x.clone().requires_grad_(True)
+    torch.relu(bn(xr)).backward(dy)
+    xg = x.clone().requires_grad_(True)
+    g, b = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+    y = BnActFn.apply(xg, g, b, bn.running_mean.clone(), bn.running_var.clone(), False, True)
+    y.backward(dy)
+    for got, want in ((xg.grad, xr.grad), (g.grad, bn.weight.grad), (b.grad, bn.bias.grad)):
+        assert float((got - want).norm()) <= 1e-5 * float(want.norm()) + 1e-7
+    with pytest.raises(ValueError):
+        BnActFn.apply(torch.randn(1, Cc), g, b, bn.running_mean.clone(), bn.running_var.clone(), True, True)

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <unistd.h>
 
 #include <vector>
 
@@ -75,6 +76,71 @@ VARIANT(glob_n1, ST_GLOBAL, "s_nop 0")
 VARIANT(glob_n2, ST_GLOBAL, "s_nop 1")
 VARIANT(glob_n4, ST_GLOBAL, "s_nop 3")
 
+// LDS-write forms of the same question (the round-2 cross-stream corruption hit kernels that exchange through LDS --
+// STFT / iSTFT butterflies, rocFFT, the fp32 gemm_nt -- while an MFMA + LDS + HBM kernel ran beside them;
+// profiles/r02_kernel_race.md).  hipcc pads nothing behind a ds_write; stft.hip has a VALU write to the data
+// registers of a ds_write2_b64 two slots behind it.
+#define LVARIANT(NAME, STORE, NOP)                                                                                   \
+  __global__ void NAME(unsigned* out, int iters, int soff) {                                                         \
+    __shared__ uint4 lds[256];                                                                                       \
+    const unsigned gt = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;                       \
+    const unsigned laddr = (unsigned)(unsigned long long)(&lds[threadIdx.x]);                                        \
+    for (int it = 0; it < iters; ++it) {                                                                             \
+      const unsigned cell = it * nthr + gt;                                                                          \
+      unsigned a = key(cell, 0), b = key(cell, 1), c = key(cell, 2), d = key(cell, 3);                               \
+      const unsigned poison = POISON;                                                                                \
+      asm volatile(STORE "\n" NOP "\n"                                                                               \
+                   "v_mov_b32 v8, %5\n v_mov_b32 v9, %5\n v_mov_b32 v10, %5\n v_mov_b32 v11, %5\n"                   \
+                   "s_waitcnt lgkmcnt(0)\n"                                                                          \
+                   : "+{v8}"(a), "+{v9}"(b), "+{v10}"(c), "+{v11}"(d)                                                \
+                   : "v"(laddr), "v"(poison)                                                                         \
+                   : "memory");                                                                                      \
+      reinterpret_cast<uint4*>(out)[cell] = lds[threadIdx.x];                                                        \
+      if (a != POISON) out[0] = 0;                                                                                   \
+    }                                                                                                                \
+  }
+#define LW128 "ds_write_b128 %4, v[8:11]"
+#define LW2X64 "ds_write2_b64 %4, v[8:9], v[10:11] offset1:1"
+LVARIANT(lds128_n0, LW128, "")
+LVARIANT(lds128_n1, LW128, "s_nop 0")
+LVARIANT(lds128_n2, LW128, "s_nop 1")
+LVARIANT(lds128_n4, LW128, "s_nop 3")
+LVARIANT(lds2x64_n0, LW2X64, "")
+LVARIANT(lds2x64_n1, LW2X64, "s_nop 0")
+LVARIANT(lds2x64_n2, LW2X64, "s_nop 1")
+LVARIANT(lds2x64_n4, LW2X64, "s_nop 3")
+
+// The shape r02_kernel_race.md found necessary in an aggressor: MFMA + LDS staging + HBM loads inside the loop,
+// one resident workgroup per CU (64 KB of LDS, 256 threads) so victim workgroups share its CUs.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+__global__ void __launch_bounds__(256) mfma_aggressor(const float4* __restrict__ src, float* __restrict__ dst, size_t n,
+                                                       int reps) {
+  __shared__ float4 stage[4096];  // 64 KB
+  f32x16_t acc0 = {}, acc1 = {};
+  const int t = threadIdx.x;
+  size_t i = ((size_t)blockIdx.x * 256 + t) % n;
+  for (int r = 0; r < reps; ++r) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) stage[j * 256 + t] = src[(i + (size_t)j * 65536) % n];
+    i = (i + 16 * 65536 + 256 * 977) % n;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float4 u = stage[(j * 256 + t * 17) & 4095], v = stage[(j * 256 + t * 33 + 7) & 4095];
+      bf16x8_t a, b;
+      __builtin_memcpy(&a, &u, 16);
+      __builtin_memcpy(&b, &v, 16);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float s = 0.f;
+  for (int k = 0; k < 16; ++k) s += acc0[k] + acc1[k];
+  dst[(size_t)blockIdx.x * 256 + t] = s;
+}
+
 __global__ void aggressor(const float4* __restrict__ src, float4* __restrict__ dst, size_t n, int reps) {
   for (int r = 0; r < reps; ++r)
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -110,13 +176,22 @@ int main() {
                   {"mubuf zero soffset, +1", zero_n1, 0},                  {"mubuf zero soffset, +2", zero_n2, 0},
                   {"mubuf zero soffset, +4", zero_n4, 0},                  {"global_store, +0", glob_n0, 0},
                   {"global_store, +1", glob_n1, 0},                        {"global_store, +2", glob_n2, 0},
-                  {"global_store, +4", glob_n4, 0}};
+                  {"global_store, +4", glob_n4, 0},
+                  {"ds_write_b128, +0", lds128_n0, 0},                     {"ds_write_b128, +1", lds128_n1, 0},
+                  {"ds_write_b128, +2", lds128_n2, 0},                     {"ds_write_b128, +4", lds128_n4, 0},
+                  {"ds_write2_b64, +0", lds2x64_n0, 0},                    {"ds_write2_b64, +1", lds2x64_n1, 0},
+                  {"ds_write2_b64, +2", lds2x64_n2, 0},                    {"ds_write2_b64, +4", lds2x64_n4, 0}};
   std::vector<unsigned> h(cells * 4);
-  for (int load = 0; load < 2; ++load)
+  const char* beside[] = {"alone               ", "beside a copy kernel", "beside MFMA+LDS+HBM "};
+  for (int load = 0; load < 3; ++load)
     for (const V& v : vs) {
       HIP_OK(hipMemsetAsync(out, 0, bytes, s1));
       HIP_OK(hipStreamSynchronize(s1));
-      if (load) hipLaunchKernelGGL(aggressor, dim3(1024), dim3(256), 0, s2, as, ad, agn, 3);
+      if (load == 1) hipLaunchKernelGGL(aggressor, dim3(1024), dim3(256), 0, s2, as, ad, agn, 3);
+      if (load == 2)
+        hipLaunchKernelGGL(mfma_aggressor, dim3(prop.multiProcessorCount), dim3(256), 0, s2, as,
+                           reinterpret_cast<float*>(ad), agn, 3000);
+      if (load) usleep(3000);  // the aggressor is resident before the victim starts
       hipLaunchKernelGGL(v.fn, dim3(blocks), dim3(threads), 0, s1, out, iters, v.soff);
       HIP_OK(hipStreamSynchronize(s1));
       HIP_OK(hipStreamSynchronize(s2));
@@ -135,7 +210,7 @@ int main() {
         }
       printf("%-38s %s: %9zu poisoned dwords of %zu (%.4f%%), other mismatches %zu; by dword [%zu %zu %zu %zu], by "
              "lane%%16/4 [%zu %zu %zu %zu]\n",
-             v.name, load ? "beside a copy kernel" : "alone               ", poison, cells * 4,
+             v.name, beside[load], poison, cells * 4,
              100.0 * poison / (cells * 4.0), other, per_c[0], per_c[1], per_c[2], per_c[3], per_bank[0], per_bank[1],
              per_bank[2], per_bank[3]);
     }

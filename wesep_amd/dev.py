@@ -890,6 +890,8 @@ def _bn_splits(M: int):
 
 
 def bn_stats(x, M: int, Cc: int, running_mean, running_var, stats, eps=BN_EPS, momentum=BN_MOMENTUM):
+    if M <= 1:      # torch.nn.BatchNorm*: "Expected more than 1 value per channel when training"
+        raise ValueError(f"BatchNorm in training mode needs more than 1 value per channel (got {M} row)")
     for n, t in (("x", x), ("running_mean", running_mean), ("running_var", running_var), ("stats", stats)):
         _chk(t, n)
     ns = _bn_splits(M)
@@ -912,6 +914,24 @@ def bn_bwd(x, du, stats, gamma, M: int, Cc: int, dx):
     slab = torch.empty(ns, 2, Cc, device=x.device, dtype=torch.float32)
     sums = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
     _call("ws_bn_bwd", _p(x), _p(du), _p(stats), _p(gamma), M, Cc, ns, _p(slab), _p(sums), _p(dx))
+    return sums
+
+
+def bn_bwd_any(x, du, stats, gamma, M: int, Cc: int, dx, training: bool):
+    """BatchNorm backward on [M, C] rows in either mode; returns sums [2, C] = (dbeta, dgamma) like bn_bwd.
+    Training mode: ws_bn_bwd (batch statistics: the mean / variance terms are part of dx).  Eval mode (running
+    statistics are constants -- fine-tuning with frozen BatchNorm, torch's `module.eval()` + backward):
+        dx = du * gamma * rstd,   dbeta = sum du,   dgamma = sum du * xhat
+    composed from existing entry points: the two sums are what ws_bn_bwd computes in any mode (its dx goes to a
+    scratch buffer), dx is the BatchNorm kernel applied to du with a zero mean, zero shift and identity activation."""
+    if training:
+        return bn_bwd(x, du, stats, gamma, M, Cc, dx)
+    scratch = torch.empty_like(dx)
+    sums = bn_bwd(x, du, stats, gamma, M, Cc, scratch)
+    st0 = stats.clone()
+    st0[0].zero_()
+    one = torch.ones(1, device=x.device, dtype=torch.float32)
+    bn_prelu_fwd(du, st0, gamma, torch.zeros_like(gamma), None, one, M, Cc, scratch, dx)
     return sums
 
 

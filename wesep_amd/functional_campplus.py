@@ -45,15 +45,13 @@ class BnActFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, st, gamma, y = ctx.saved_tensors
         training, relu, affine = ctx.flags
-        if not training:
-            raise L.WesepHipError("CAM++: backward in eval mode (running statistics) is not built")
         M, Cc = x.shape
         du = dy.contiguous()
         if relu:
             du = du.clone()
             dev.relu_mask(du, y)                                  # ReLU' from its saved output
         dx = torch.empty_like(x)
-        sums = dev.bn_bwd(x, du, st, gamma, M, Cc, dx)
+        sums = dev.bn_bwd_any(x, du, st, gamma, M, Cc, dx, training)
         if not affine:
             return dx, None, None, None, None, None, None
         return dx, sums[1].contiguous(), sums[0].contiguous(), None, None, None, None
@@ -75,8 +73,10 @@ class Conv1dFn(torch.autograd.Function):
             W2 = w.reshape(Cout, Cin).contiguous()
             y = _gemm(x, R * T, Cin, W2, Cout, bias=b)
         else:
-            if Cin % 4 or Cout % 4 or k % 2 == 0 or stride > 2:
-                raise L.WesepHipError(f"Conv1dFn: channels % 4, odd kernel, stride <= 2 (got {Cin}, {Cout}, {k}, {stride})")
+            if Cin % 4 or Cout % 4 or k % 2 == 0 or k > 5 or stride > 2:
+                # (k <= 5: the weight-gradient entry points are built for at most 5 x 5 taps -- refuse in the forward,
+                #  not halfway through the backward)
+                raise L.WesepHipError(f"Conv1dFn: channels % 4, odd kernel <= 5, stride <= 2 (got {Cin}, {Cout}, {k}, {stride})")
             To = (T + 2 * p - dil * (k - 1) - 1) // stride + 1
             # the Conv1d as the middle kernel row of a k x k view of the one-row image; the other rows are masked taps
             W2 = torch.zeros(Cout, k, k, Cin, device=x.device, dtype=torch.float32)

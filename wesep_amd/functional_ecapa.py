@@ -56,12 +56,10 @@ class Conv1dReluBnFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, c, st, W2, gamma = ctx.saved_tensors
         R, T, dil, training, Cin, Cout, k, wshape = ctx.geo
-        if not training:
-            raise L.WesepHipError("ECAPA-TDNN: backward in eval mode (running statistics) is not built")
         M = R * T
         d = x.device
         dc = _empty(d, M, Cout)
-        sums = dev.bn_bwd(c, dy.contiguous(), st, gamma, M, Cout, dc)
+        sums = dev.bn_bwd_any(c, dy.contiguous(), st, gamma, M, Cout, dc, training)
         dev.relu_mask(dc, c)                                               # ReLU' from its saved output
         if k == 1:
             dW2, db = _wgrad(dc, M, Cout, x, Cin)
@@ -172,11 +170,9 @@ class BatchNormRowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, st, gamma = ctx.saved_tensors
-        if not ctx.training:
-            raise L.WesepHipError("ECAPA-TDNN: backward in eval mode (running statistics) is not built")
         M, Cc = x.shape
         dx = torch.empty_like(x)
-        sums = dev.bn_bwd(x, dy.contiguous(), st, gamma, M, Cc, dx)
+        sums = dev.bn_bwd_any(x, dy.contiguous(), st, gamma, M, Cc, dx, ctx.training)
         return dx, sums[1].contiguous(), sums[0].contiguous(), None, None, None
 
 

@@ -68,15 +68,13 @@ class ConvBnActFn(torch.autograd.Function):
         x, c, st, u, W2, gamma, slope = ctx.saved_tensors
         R, H, W, Cin, Cout, k, (sh, sw), pad, Ho, Wo, ldp, has_res, training, wshape = ctx.geo
         stride = sh
-        if not training:
-            raise L.WesepHipError("ResNet speaker encoder: backward in eval mode (running statistics) is not built")
         M = R * Ho * Wo
         d = x.device
         du = dy.contiguous().clone()
         dev.prelu_bwd(u, du, slope, du)                          # ReLU' (slope 0) or identity (slope 1), in place
         dres = du if has_res else None
         dc = _empty(d, M, Cout)
-        sums = dev.bn_bwd(c, du, st, gamma, M, Cout, dc)
+        sums = dev.bn_bwd_any(c, du, st, gamma, M, Cout, dc, training)
         Kk = k * k * Cin
         if FC.implicit_ok(Cin):
             dW2, _ = FC.conv2d_wgrad(dc, x, R, H, W, Cin, Cout, k, sh, sw, pad, with_bias=False)

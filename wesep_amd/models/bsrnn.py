@@ -34,6 +34,23 @@ class ResRNN(nn.Module):
         self.proj = nn.Linear(hidden_size * 2, input_size)
         self._packs = F_.PackCache()     # derived weight forms, rebuilt when the weights change (not state)
 
+    def invalidate_packs(self):
+        """Drop the cached derived weight forms (MFMA-fragment packs, concatenated W_ih, ...).  The cache follows the
+        weights through torch's version counters and the optimizer's weight epoch (functional.PackCache), which cover
+        `optimizer.step()`, `load_state_dict`, `.to()` / `_apply` and every in-place op on the Parameter itself -- but
+        NOT writes through `param.data` (EMA / model averaging / weight clipping code of the form
+        `p.data.mul_(..)`): those do not move `_version`.  Call this (or `wesep_amd.dev.bump_weight_epoch()`) after
+        such a write."""
+        self._packs = F_.PackCache()
+
+    def _apply(self, fn, recurse=True):   # .to() / .cuda() / .float(): new storages, new packs
+        self._packs = F_.PackCache()
+        return super()._apply(fn, recurse)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._packs = F_.PackCache()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def _wparams(self):
         r = self.rnn
         return (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0,
