@@ -35,6 +35,18 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert lib.ws_abi_version() == built_lib.ABI_VERSION == 9
 
 
+def test_built_library_has_no_packed_fp32_arithmetic(built_lib):
+    """The fence of profiles/r03_kernel_race.md: packed FP32 instructions with an operand selection compute wrong low
+    halves beside gemm_b2p on the MI355X, so the library is built without packed FP32 (build.py NO_PACKED_FP32).
+    Disassembles the gfx950 code objects of the built .so; no GPU needed."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_no_packed_fp32.py"), built_lib.LIB_PATH],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "v_mfma_f32_32x32x16_bf16" in r.stdout                  # the walk did see the kernels
+
+
 def test_ctypes_structs_match_c_layout(built_lib):
     prog = r'''
 #include <stdio.h>

@@ -9,9 +9,11 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wesep_amd.build import FLAGS  # noqa: E402  (the library's own compile flags)
 rows = []
 for src in sorted(glob.glob(os.path.join(ROOT, "wesep_amd", "csrc", "*.hip"))):
-    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", os.devnull,
+    out = subprocess.run(["hipcc"] + FLAGS + ["-c", src, "-o", os.devnull,
                           "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
     cur = None
     for line in out.splitlines():

@@ -12,7 +12,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libwesep_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# No packed FP32 instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) in this library: on the MI355X a packed FP32
+# op whose src1 selects the other half (op_sel -- what hipcc emits for complex arithmetic and 2-vector swizzles) returns
+# wrong low halves while gemm_b2p / the grouped gemm_nt / gemm_tn run on the same CU from another stream
+# (profiles/r03_kernel_race.md; standalone reproducer tools/cbench/race_repro.hip).  The scalar forms are not affected.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + NO_PACKED_FP32
 
 
 def _stale(target, deps):
@@ -73,6 +78,13 @@ def build_runtime(force=False, verbose=True):
     if os.path.exists(bench_src) and (force or _stale(bench_out, [bench_src, OUT, os.path.join(inc, "wesep_hip.h")])):
         cmds.append([hipcc, "-O2", "-std=c++17", bench_src, "-o", bench_out, "-L" + HERE, "-lwesep_hip",
                      "-Wl,-rpath,$ORIGIN/../../wesep_amd"])      # Python-free microbenchmark (tools/cbench)
+    race_src = os.path.join(os.path.dirname(HERE), "tools", "cbench", "race_repro.hip")
+    race_out = race_src[:-4]
+    if os.path.exists(race_src) and (force or _stale(race_out, [race_src, OUT, os.path.join(inc, "wesep_hip.h")])):
+        # standalone reproducer of the packed-FP32 disturbance (profiles/r03_kernel_race.md); its victims are meant to
+        # contain packed FP32 instructions, so it is NOT compiled with the library's NO_PACKED_FP32
+        cmds.append([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", race_src, "-o", race_out, "-L" + HERE,
+                     "-lwesep_hip", "-Wl,-rpath,$ORIGIN/../../wesep_amd"])
     for cmd in cmds:
         if verbose:
             print(" ".join(cmd), flush=True)
