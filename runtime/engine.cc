@@ -1628,13 +1628,14 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
     set_err("ws_engine_separate: hipSetDevice(%d) failed", e->device);
     return WS_ERR_LAUNCH;
   }
-  // One forward at a time per GPU across the engines of this process.  Round 2 found that some of the MFMA kernels of
-  // this plan (ws_gemm_b2p, the grouped ws_gemm_nt / ws_gemm_tn) disturb FFT-type kernels that run CONCURRENTLY on
-  // another HIP stream of the same GPU -- this plan's own STFT / iSTFT kernels, and even a vendor rocFFT launch that
-  // shares no memory with them (tools/kernel_race*.py, profiles/r02_kernel_race.md): results of overlapping engines
-  // were not reproducible (rare single-frame glitches).  Until that is understood, engines sharing a GPU take turns
-  // on the device; their host work (wav I/O, feature staging, result write-out) still overlaps.
-  std::unique_lock<std::mutex> device_turn(g_device_mutex[e->device & 15]);
+  // Engines that share a GPU overlap on the device.  Round 2 serialised them here (one forward at a time per GPU)
+  // because ws_gemm_b2p / the grouped ws_gemm_nt / ws_gemm_tn disturbed this plan's STFT / iSTFT kernels on another
+  // stream.  Round 3 named the victim class -- packed FP32 instructions with an operand selection -- and the library is
+  // built without them (profiles/r03_kernel_race.md; tests/test_cross_stream_gpu.py), so the lock is opt-in:
+  // WS_ENGINE_SERIALIZE=1 restores one forward at a time (e.g. beside third-party kernels on the same GPU).
+  static const bool serialize = getenv("WS_ENGINE_SERIALIZE") != nullptr && atoi(getenv("WS_ENGINE_SERIALIZE")) != 0;
+  std::unique_lock<std::mutex> device_turn(g_device_mutex[e->device & 15], std::defer_lock);
+  if (serialize) device_turn.lock();
   e->n_launches = 0;
   Arena& a = e->work;
   a.reset();

@@ -9,10 +9,9 @@
 // enrollment utterances go through ws_engine_forward_pcm16 (enrollments cut to the shorter one, as the reference does)
 // and <key>-spk1.wav / <key>-spk2.wav are written; the real-time factor is printed per utterance and in total.
 // Utterances are independent: --jobs J worker threads, each with its own engine (own HIP stream, arena and weight
-// copy -- 0.3 GB of 288), spread round-robin over --devices.  Engines that share a GPU take turns on the device
-// (ws_engine_separate holds a per-device lock for its launches): round 2 found that overlapping forwards on one GPU
-// are not reproducible, so what overlaps is the host work -- wav reading, int16 conversion,
-// result write-out -- and different GPUs.  The reference tool is single-threaded on CPU cores.
+// copy -- 0.3 GB of 288), spread round-robin over --devices.  Engines that share a GPU overlap on the device (round 2
+// serialised them; round 3 removed the cause -- profiles/r03_kernel_race.md -- and WS_ENGINE_SERIALIZE=1 restores one
+// forward at a time per GPU).  The reference tool is single-threaded on CPU cores.
 // --dry_run validates the model file and the launch plan of every utterance without a GPU and writes nothing.
 // --raw_out additionally writes the unquantised estimates as <key>-spk{1,2}.f32 (float32, for parity checks).
 #include <stdio.h>

@@ -186,9 +186,10 @@ def test_separate_main_end_to_end(tmp_path):
                         "--model", str(tmp_path / "j.wsw"), "--output_dir", str(out_dir), "--jobs", "2"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    # byte-identical: engines that share a GPU take turns on the device (ws_engine_separate's per-device lock; overlapping
-    # forwards were not reproducible, profiles/r02_kernel_race.md) -- unless a cluster recurrence timed out and the streaming
-    # kernels took over (different MFMA order, reported on stdout): then within one 16-bit step
+    # byte-identical although the two engines OVERLAP on the GPU (round 3: the library has no packed FP32 instructions, the
+    # victim class of the cross-stream disturbance -- profiles/r03_kernel_race.md; round 2 needed a per-device lock here)
+    # -- unless a cluster recurrence timed out and the streaming kernels took over (different MFMA order, reported on
+    # stdout): then within one 16-bit step
     ref = np.frombuffer((out_dir / "utt1-spk1.wav").read_bytes()[44:], dtype=np.int16).astype(np.int32)
     for i in range(4):
         got = np.frombuffer((out_dir / f"c{i}-spk1.wav").read_bytes()[44:], dtype=np.int16).astype(np.int32)
