@@ -391,12 +391,17 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         ctx.save_for_backward(gates, cbuf, hcat, xn, wcat, pack_b, lw, whf, whr)
         ctx.geo = (nseq, Lr, ns, lmode, cluster)
         ctx.F0 = F0
+        ctx.consumed = False
         return out[:nseq * Lr] if pad else out
 
     @staticmethod
     def backward(ctx, dout):
         import os
         gates, cbuf, hcat, xn, wcat, pack_b, lw, whf, whr = ctx.saved_tensors
+        if ctx.consumed:         # same contract as functional.ResRNNBlkFn: BPTT turns the saved gates into d(gates) in place
+            raise L.WesepHipError("TF-GridNet BLSTM: second backward through the same graph (retain_graph / multi-loss "
+                                  "loops): the blocked path consumes its saved gates in place; run the forward again")
+        ctx.consumed = True
         nseq, Lr, ns, lmode, cluster = ctx.geo
         N, H, G4 = 128, HP, G4P
         d = dout.device
@@ -410,7 +415,8 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         dev.pack_w(lw, 2 * H, N, 2 * H, wlt_pack, trans=True, order=0)
         dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
         dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wlt_pack, N=2 * H, C_out=dh, A_bl=dout_bl)
-        gates = gates.clone()                                    # BPTT works in place; keep the saved tensor intact
+        # BPTT works in place on the saved gates (6.4 GB per BLSTM at the recipe's 8 rows x 6 s: a clone here was 12 copies
+        # = 38 ms of a 490 ms step and the largest transient allocation of the backward)
         kind = ctx.F0._bptt_kind(seq, d, cluster)
         if kind == "cluster":
             dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
