@@ -40,7 +40,13 @@ def build(force=False, verbose=True):
             cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            # the feature flag reaches the host pass too, which says it does not know it: not worth showing 17 times
+            err = "\n".join(ln for ln in r.stderr.splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in ln)
+            if err.strip():
+                print(err, file=sys.stderr, flush=True)
+            if r.returncode:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
