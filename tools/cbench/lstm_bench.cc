@@ -156,8 +156,27 @@ int main(int argc, char** argv) {
   if (what.find("fused") != std::string::npos && mode == WS_LSTM_BF16X3_BLK) {
     ws_lstm_fused_args f = {};
     f.gates = gates, f.cbuf = cbuf, f.hcat = hcat, f.xn = xn, f.wpack = fpack, f.bias = bias, f.nseq = nseq, f.L = L;
-    const double ms = time_ms([&] { WS_OK_(ws_lstm_fwd_fused(&f, s)); }, iters, s);
-    report("fwd_fused", ms, hcat, nb * 32 * 2 * H);
+    // both tilings of the fused forward on the same inputs: timing and a bit-for-bit comparison of everything they write
+    std::vector<float> ref_g, ref_c, ref_h;
+    for (const char* seqs : {"32", "64"}) {
+      setenv("WS_FUSED_SEQS", seqs, 1);
+      HIP_OK(hipMemsetAsync(gates, 0xff, gbytes, s));
+      HIP_OK(hipMemsetAsync(cbuf, 0xff, nb * 32 * 2 * H * 4, s));
+      HIP_OK(hipMemsetAsync(hcat, 0xff, nb * 32 * 2 * H * 4, s));
+      const double ms = time_ms([&] { WS_OK_(ws_lstm_fwd_fused(&f, s)); }, iters, s);
+      report((std::string("fwd_fused/") + seqs).c_str(), ms, hcat, nb * 32 * 2 * H);
+      if (ref_g.empty()) {
+        ref_g = fetch(gates, nb * 32 * 2 * G4), ref_c = fetch(cbuf, nb * 32 * 2 * H), ref_h = fetch(hcat, nb * 32 * 2 * H);
+      } else {
+        const std::vector<float> g2 = fetch(gates, nb * 32 * 2 * G4), c2 = fetch(cbuf, nb * 32 * 2 * H),
+                                 h2 = fetch(hcat, nb * 32 * 2 * H);
+        printf("fused 64 vs 32 sequences per workgroup: gates %s, cells %s, h %s\n",
+               memcmp(g2.data(), ref_g.data(), g2.size() * 4) ? "DIFFER" : "bit-identical",
+               memcmp(c2.data(), ref_c.data(), c2.size() * 4) ? "DIFFER" : "bit-identical",
+               memcmp(h2.data(), ref_h.data(), h2.size() * 4) ? "DIFFER" : "bit-identical");
+      }
+    }
+    unsetenv("WS_FUSED_SEQS");
   }
   const bool cluster_ok = nseq % 64 == 0 && (nseq / 32) * 8 <= prop.multiProcessorCount && L >= 64;
   float* xchg = nullptr;

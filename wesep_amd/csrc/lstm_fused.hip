@@ -8,6 +8,8 @@
 // lane-local cell update, 2-slot weight ring that never drains, single-basic-block step body,
 // non-temporal activation streams) is lstm_fwd_bf16_kernel<BLK = true> of lstm_bf16.hip.
 //   nn.LSTM forward inside ResRNN (bsrnn.py:27-33,40); replaces gemm_p2b(x-proj) + ws_lstm_fwd there.
+#include <stdlib.h>
+
 #include "lstm_bf16_common.h"
 
 #define XROW 136  // bf16 per LDS row of x (128 + 8: 272 B = 4 banks mod 64)
@@ -200,13 +202,200 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 64 sequences per workgroup (round 3): two 32-sequence tiles share every weight fragment of the K = 384 stream.
+// The 32-sequence kernel above is bound by that stream (1.5 MB per step through the CU's L1, ~10 us, MFMA 7.7 us
+// under it, then the cell update and the stores: 21.6 us per step, nothing overlaps with one workgroup per CU); with
+// two tiles per fragment the stream is paid once per 64 sequences and the step becomes MFMA-bound.
+// Measured (band view, R = 32): 2.75 -> 2.48 ms per launch, not the 1.6x the serial model promised: the pass of the
+// weight stream itself takes ~21 us whatever sits around it (a software pipeline that hid tile 1's cell update under
+// tile 0's MFMAs, streaming the weights once per tile, measured 2.91 ms), i.e. the stream is bound by the L2 -> CU path
+// at the ring depth the registers allow (16 KB in flight per wave), and sharing it between two tiles is what pays.
+// Budget (8 waves x 256 registers, 160 KB of LDS): accumulators of both tiles 128 registers, weight ring 64;
+// h single-buffered (two barriers per step instead of one), the x tiles arrive RAW (BLS) by LDS DMA
+// (buffer_load ... lds: no staging registers) and are unpacked into MFMA fragments by the reading wave, the cell state
+// of tile 0 lives in LDS (lane-private, unpadded), of tile 1 in registers, the bias in LDS.
+// Per sequence the arithmetic and its order are those of the 32-sequence kernel: results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void lstm_fwd_fused64_kernel(const ws_lstm_fused_args p) {
+  // one object, members in this order: the DMA target sits at LDS address 0 (its base travels in M0)
+  __shared__ __attribute__((aligned(16))) struct {
+    f32x4 xw[2][1024];            // [tile][quad*32 + slot] raw BLS      32 KB
+    __bf16 hl[2][2 * SQ * HROW];  // [part][tile*32 + seq][k]            67.6 KB
+    f32x4 c0l[8 * 2 * 4 * 32];    // tile 0 cells [w][half][run][seq]    32 KB
+    float bs[LG];                 // b_ih + b_hh of this direction        4 KB
+  } sm;
+  auto& xw = sm.xw;
+  auto& hl = sm.hl;
+  auto& c0l = sm.c0l;
+  auto& bs = sm.bs;
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = p.L;
+  const int ntile = (p.nseq + SQ - 1) / SQ;
+  const int tile0 = 2 * blockIdx.x;
+  // an odd tile count leaves the last workgroup's second tile empty: zero-sized descriptors (loads 0, stores dropped)
+  const unsigned live1 = tile0 + 1 < ntile ? 1u : 0u;
+
+  {
+    uint32_t* z = reinterpret_cast<uint32_t*>(&hl[0][0]);
+    for (int i = tid; i < 2 * 2 * SQ * HROW / 2; i += 512) z[i] = 0u;  // h_{-1} = 0
+    for (int i = tid; i < LG; i += 512) bs[i] = p.bias[d * LG + i];
+  }
+  const int ubase = 32 * w + 4 * half;  // unit of register 4j + r: ubase + 8j + r
+  const int glane = ((d * 256 + 8 * w + half) * 32 + l31) * 16;  // bytes; + (g*64 + 2j)*512
+  const int clane = ((d * 64 + 8 * w + half) * 32 + l31) * 16;   // bytes; + 2j*512
+  auto blk = [&](int e, int t) { return (long long)((tile0 + e) * L + t); };
+  auto lim = [&](int e, unsigned bytes) { return e == 0 ? bytes : bytes * live1; };
+  auto grs = [&](int e, int t) { return mkrsrc(p.gates + blk(e, t) * (SQ * 2 * LG), lim(e, SQ * 2 * LG * 4)); };
+  auto crs = [&](float* b, int e, int t) { return mkrsrc(b + blk(e, t) * (SQ * 2 * LH), lim(e, SQ * 2 * LH * 4)); };
+  auto xrs = [&](int e, int t) { return mkrsrc(p.xn + blk(e, t) * (SQ * 128), lim(e, SQ * 128 * 4)); };
+  // x tile of one step = one BL(128) block of 16 KB: wave w copies cells 64w .. 64w+63 and 512 + 64w .. of each tile
+  auto dma_x = [&](int e, int t) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs(e, t), (__attribute__((address_space(3))) void*)&xw[e][512 * q + 64 * w], 16,
+                                               lane * 16, (512 * q + 64 * w) * 16, 0, WS_STREAM_AUX);
+  };
+
+  f32x4* c0 = &c0l[((w * 2 + half) * 4) * 32 + l31];  // + 32 * j
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c0[32 * j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 c1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.wpack) + (long long)(d * 8 + w) * (FKS * 8 * 64 * 4), 0, FKS * 8 * 1024, 0x00020000);
+  const int wlane = lane * 16;
+  bf16x8 wr[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
+
+  auto tof = [&](int n) { const int m = min(n, L - 1); return d == 0 ? m : L - 1 - m; };
+  dma_x(0, tof(0));
+  dma_x(1, tof(0));
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0): this wave's share of x(0) has landed (and the ring's first fragments)
+  __syncthreads();
+
+  for (int step = 0; step < L; ++step) {
+    const int t = tof(step);
+    int zo = 0;
+    asm volatile("" : "+s"(zo));
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&bs[g * 256 + ubase + 8 * j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[0][g][4 * j + r] = acc[1][g][4 * j + r] = b[r];
+      }
+#pragma unroll
+    for (int ks = 0; ks < FKS; ++ks) {
+      const int s = ks & 1;
+      bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (ks < 8) {
+          const f32x4 v0 = xw[e][(4 * ks + 2 * half) * 32 + l31], v1 = xw[e][(4 * ks + 2 * half + 1) * 32 + l31];
+          bf16x4 h0, l0, h1, l1;
+          unpack_hl4(v0, h0, l0);
+          unpack_hl4(v1, h1, l1);
+          bh[e] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          bl[e] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+          const int o = (32 * e + l31) * HROW + 8 * half + 16 * (ks - 8);
+          bh[e] = *reinterpret_cast<const bf16x8*>(&hl[0][o]);
+          bl[e] = *reinterpret_cast<const bf16x8*>(&hl[1][o]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[e][g] = mfma32(wr[s][2 * g], bh[e], acc[e][g]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[e][g] = mfma32(wr[s][2 * g + 1], bh[e], acc[e][g]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[e][g] = mfma32(wr[s][2 * g], bl[e], acc[e][g]);
+      }
+      const int kn = (ks + 2) % FKS;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // every wave has read h_{t-1} and x_t: both may be overwritten now
+    dma_x(0, tof(step + 1));
+    dma_x(1, tof(step + 1));
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      __bf16* nhi = &hl[0][(32 * e + l31) * HROW + ubase];
+      __bf16* nlo = &hl[1][(32 * e + l31) * HROW + ubase];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 vi, vf, vg, vo, vc, vh;
+        const f32x4 cold = e == 0 ? c0[32 * j] : c1[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ig = fsig(acc[e][0][4 * j + r]);
+          const float fg = fsig(acc[e][1][4 * j + r]);
+          const float gg = ftanh(acc[e][2][4 * j + r]);
+          const float og = fsig(acc[e][3][4 * j + r]);
+          const float cn = fg * cold[r] + ig * gg;
+          vi[r] = ig;
+          vf[r] = fg;
+          vg[r] = gg;
+          vo[r] = og;
+          vc[r] = cn;
+          vh[r] = og * ftanh(cn);
+        }
+        bf16x4 h_hi, h_lo;
+        split4(vh, h_hi, h_lo);
+        *reinterpret_cast<bf16x4*>(nhi + 8 * j) = h_hi;
+        *reinterpret_cast<bf16x4*>(nlo + 8 * j) = h_lo;
+        if (e == 0)
+          c0[32 * j] = vc;
+        else
+          c1[j] = vc;
+        bst(vi, grs(e, t), glane, (0 * 64 + 2 * j) * 512);
+        bst(vf, grs(e, t), glane, (1 * 64 + 2 * j) * 512);
+        bst(vg, grs(e, t), glane, (2 * 64 + 2 * j) * 512);
+        bst(vo, grs(e, t), glane, (3 * 64 + 2 * j) * 512);
+        bst(vc, crs(p.cbuf, e, t), clane, 2 * j * 512);
+        bst(pack_hl4(h_hi, h_lo), crs(p.hcat, e, t), clane, 2 * j * 512);  // BLS
+        __builtin_amdgcn_sched_barrier(0);  // one run at a time: bounds the live temporaries
+      }
+    }
+    // x_{t+1} was requested before the cell update; every wave waits for its own share before the barrier publishes it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
 extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn && a->wpack && a->bias, "ws_lstm_fwd_fused: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_fwd_fused: bad nseq/L");
-  dim3 grid((a->nseq + SQ - 1) / SQ, 2), block(512);
+  const int ntile = (a->nseq + SQ - 1) / SQ;
+  dim3 grid(ntile, 2), block(512);
   hipStream_t s = (hipStream_t)stream;
+  // 64 sequences per workgroup when the 32-sequence grid would need more than ~1.5 rounds of the chip (one workgroup per
+  // CU either way): measured 2.48 vs 2.75 ms at 1002 workgroups, but 1.06 vs 0.56 ms at 158 (half the CUs idle).
+  // WS_FUSED_SEQS=32|64 overrides (diagnostics; both kernels give the same bits)
+  const char* env = getenv("WS_FUSED_SEQS");
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+  const bool wide = env ? atoi(env) == 64 : 4 * ntile > 3 * cus;
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
-  hipLaunchKernelGGL(lstm_fwd_fused_kernel, grid, block, 0, s, *a);
+  if (wide)
+    hipLaunchKernelGGL(lstm_fwd_fused64_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
+  else
+    hipLaunchKernelGGL(lstm_fwd_fused_kernel, grid, block, 0, s, *a);
   ws_prof_end(WS_PROF_LSTM_FWD, s);
   return ws_check_launch("ws_lstm_fwd_fused");
 }
