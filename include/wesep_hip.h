@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 9
+#define WS_ABI_VERSION 10
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -608,6 +608,17 @@ int ws_scale_bf_bwd(const float* x, const float* dy, const float* s, int B, int 
  * above (gridnet_block.py:212-213): y = softmax(scale * x) per row of n; dx = scale * y * (dy - sum(dy * y))   */
 int ws_softmax_rows_fwd(const float* x, long long rows, int n, float scale, float* y, void* stream);
 int ws_softmax_rows_bwd(const float* y, const float* dy, long long rows, int n, float scale, float* dx, void* stream);
+
+/* nn.LayerNorm over short rows (gridnet_block.py:139-160 `intra_norm` / `inter_norm`, width = emb_dim; also any
+ * [M][W] with W <= 256, W % 4 == 0): one pass forward (y and the (mean, rstd) pairs stats[M][2]), one pass backward:
+ *   dx = rstd * (gamma*dy - mean_row(gamma*dy) - xhat * mean_row(gamma*dy*xhat)) (+ res; dx may alias dy)
+ *   slab[ws_rowln_grid(M, W)][2][W]: per-workgroup partial sums of d(beta) (row 0) and d(gamma) (row 1); the caller
+ *   reduces them (ws_reduce_slabs) -- the grid is a function of (M, W) only, so the sums are reproducible.      */
+int ws_rowln_grid(long long M, int W);
+int ws_rowln_fwd(const float* x, const float* gamma, const float* beta, long long M, int W, float eps, float* y,
+                 float* stats, void* stream);
+int ws_rowln_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* res, long long M,
+                 int W, float* dx, float* slab, void* stream);
 
 #ifdef __cplusplus
 }

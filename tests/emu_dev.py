@@ -437,6 +437,32 @@ def softmax_rows_bwd(y, dy, rows, n, scale, dx):
     dx.reshape(rows, n)[:] = scale * yy * (dd - (dd * yy).sum(1, keepdim=True))
 
 
+def rowln_ok(W):
+    return 0 < W <= 256 and W % 4 == 0
+
+
+def rowln_fwd(x, gamma, beta, M, W, y, stats, eps=1e-5):
+    xx = x.reshape(M, W)
+    mean = xx.mean(1, keepdim=True)
+    var = ((xx - mean) ** 2).mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    y.reshape(M, W)[:] = (xx - mean) * rstd * gamma.reshape(1, W) + beta.reshape(1, W)
+    stats.reshape(M, 2)[:, 0] = mean[:, 0]
+    stats.reshape(M, 2)[:, 1] = rstd[:, 0]
+
+
+def rowln_bwd(x, dy, stats, gamma, M, W, dx, res=None):
+    xx, dd, st = x.reshape(M, W), dy.reshape(M, W), stats.reshape(M, 2)
+    xh = (xx - st[:, :1]) * st[:, 1:2]
+    gd = dd * gamma.reshape(1, W)
+    tot = torch.stack([dd.sum(0), (dd * xh).sum(0)])
+    o = st[:, 1:2] * (gd - gd.mean(1, keepdim=True) - xh * (gd * xh).mean(1, keepdim=True))
+    if res is not None:
+        o = o + res.reshape(M, W)
+    dx.reshape(M, W)[:] = o
+    return tot
+
+
 # ---- Conv-TasNet / speaker-encoder pieces (tasnet.hip, conv2d.hip) -----------------------------------------------
 def maskmul_fwd(w, w_off, ldw, m, rows, N, s):
     wv = w.reshape(-1)[w_off + torch.arange(rows).unsqueeze(1) * ldw + torch.arange(N).unsqueeze(0)]
@@ -620,7 +646,7 @@ EMULATED = [seg_sums, seg_scale, astp_fwd, astp_bwd, rowbias_act_fwd, act_bwd, c
             scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum, lstm_pack, lstm_fwd, lstm_bwd,
             group_stats, flat_stats, gn_bwd_reduce, norm_ab, norm_bwd_apply_cl, prelu_fwd, prelu_bwd, softmax_rows_fwd,
             softmax_rows_bwd, maskmul_fwd, maskmul_bwd, relu_mask, bn_stats, bn_prelu_fwd, bn_bwd, maxpool3_fwd, maxpool3_bwd,
-            bcast_rows, cross_entropy, im2col, col2im, tstp_fwd, tstp_bwd, power_spec, log_eps]
+            bcast_rows, cross_entropy, im2col, col2im, tstp_fwd, tstp_bwd, power_spec, log_eps, rowln_ok, rowln_fwd, rowln_bwd]
 
 
 def install(monkeypatch):

@@ -831,3 +831,37 @@ def test_generic_bf16_norm_on_load_gemms_at_scale(kind):
     ref = outs.pop()
     assert torch.equal(outs[0], outs[1])
     assert float((outs[0] - ref).abs().max()) < 3e-4 * float(ref.abs().max())
+
+
+# ----------------------------------------------------------------------------------------------
+# one-pass row LayerNorm for short rows (norm.hip ws_rowln_*; TF-GridNet's per-position LayerNorm)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,W", [(1000, 128), (777, 48), (513, 256), (9, 4), (4099, 200), (70000, 128)])
+def test_rowln_fwd_bwd_vs_torch(M, W):
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(M + W)
+    x = (rnd(g, M, W) * 2.0 + 0.5).to(d)
+    gamma, beta, dy, res = rnd(g, W).to(d), rnd(g, W).to(d), rnd(g, M, W).to(d), rnd(g, M, W).to(d)
+    y, st = torch.full((M, W), float("nan"), device=d), torch.full((M, 2), float("nan"), device=d)
+    dev.rowln_fwd(x, gamma, beta, M, W, y, st)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (W,), gr, br, 1e-5)
+    assert rel(y, ref.detach()) < 2e-6
+    assert rel(st[:, 0], x.double().mean(1)) < 1e-6
+    ref.backward(dy.double())
+    outs = []
+    for _ in range(2):
+        dx = torch.full((M, W), float("nan"), device=d)
+        tot = dev.rowln_bwd(x, dy, st, gamma, M, W, dx, res=res)
+        outs.append((dx, tot))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])     # reproducible
+    dx, tot = outs[0]
+    assert rel(dx - res, xr.grad) < 5e-6
+    assert rel(tot[0], br.grad) < 5e-6 and rel(tot[1], gr.grad) < 5e-6
+    dx2 = dy.clone()                                                                        # in place, no residual
+    dev.rowln_bwd(x, dx2, st, gamma, M, W, dx2)
+    assert rel(dx2, xr.grad) < 5e-6
+    with pytest.raises(Exception, match="ws_rowln_fwd"):
+        dev.rowln_fwd(x, gamma, beta, M, 260, y, st)                                        # wider rows are refused

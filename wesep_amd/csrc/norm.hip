@@ -369,3 +369,129 @@ extern "C" int ws_gn_bwd_fused(const float* x, const float* dxn, const float* st
                      *geo, dx, pslab);
   return ws_check_launch("ws_gn_bwd_fused");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Row LayerNorm for SHORT rows (width <= 256 floats, % 4 == 0): y = gamma * (x - mean_row) * rstd_row + beta.
+// TF-GridNet normalises every (batch, time, frequency) position over its 128 channels before each BLSTM
+// (gridnet_block.py:139-160 `intra_norm` / `inter_norm` = nn.LayerNorm(emb_dim)): 780 k rows of 512 bytes at the recipe's
+// shape.  The generic group kernels above give every group a 256-thread workgroup and make three to five passes
+// (statistics, apply; backward: row sums, channel sums, apply); here LPR = 8 .. 64 lanes own a row (one float4 each),
+// the row statistics are lane-group shuffles, and forward and backward are ONE pass each.  The backward leaves the
+// per-workgroup partial sums of d(gamma) / d(beta) in `slab` ([grid][2][W]: d(beta), d(gamma)) for ws_reduce_slabs --
+// a fixed grid, so the result is reproducible.  Same two-pass mean / variance as group_stats_kernel.
+// ---------------------------------------------------------------------------------------------
+#define ROWLN_GRID_MAX 2048
+
+template <int LPR>
+__device__ __forceinline__ float rowln_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void rowln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, long long M, int W, float eps,
+                                                        float* __restrict__ y, float* __restrict__ stats) {
+  constexpr int RPB = 256 / LPR;  // rows per workgroup and iteration
+  const int lr = threadIdx.x % LPR, slot = threadIdx.x / LPR, c = 4 * lr;
+  const bool act = c < W;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 g = act ? *reinterpret_cast<const f32x4*>(gamma + c) : zero;
+  const f32x4 b = act ? *reinterpret_cast<const f32x4*>(beta + c) : zero;
+  const float inv = 1.f / (float)W;
+  for (long long row = (long long)blockIdx.x * RPB + slot; row < M; row += (long long)gridDim.x * RPB) {
+    const f32x4 v = act ? *reinterpret_cast<const f32x4*>(x + row * W + c) : zero;
+    const float mean = rowln_sum<LPR>(v[0] + v[1] + v[2] + v[3]) * inv;
+    const f32x4 dv = act ? v - mean : zero;
+    const float var = rowln_sum<LPR>(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * inv;
+    const float rstd = 1.f / sqrtf(var + eps);
+    if (act) *reinterpret_cast<f32x4*>(y + row * W + c) = dv * rstd * g + b;
+    if (lr == 0) {
+      stats[2 * row] = mean;
+      stats[2 * row + 1] = rstd;
+    }
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void rowln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        const float* __restrict__ res, long long M, int W,
+                                                        float* __restrict__ dx, float* __restrict__ slab) {
+  constexpr int RPB = 256 / LPR;
+  __shared__ f32x4 red[2][256];
+  const int lr = threadIdx.x % LPR, slot = threadIdx.x / LPR, c = 4 * lr;
+  const bool act = c < W;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 g = act ? *reinterpret_cast<const f32x4*>(gamma + c) : zero;
+  const float inv = 1.f / (float)W;
+  f32x4 adb = zero, adg = zero;
+  for (long long row = (long long)blockIdx.x * RPB + slot; row < M; row += (long long)gridDim.x * RPB) {
+    const f32x4 v = act ? *reinterpret_cast<const f32x4*>(x + row * W + c) : zero;
+    const f32x4 d = act ? *reinterpret_cast<const f32x4*>(dy + row * W + c) : zero;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const f32x4 xh = act ? (v - mean) * rstd : zero;
+    const f32x4 gd = g * d;
+    const float s1 = rowln_sum<LPR>(gd[0] + gd[1] + gd[2] + gd[3]) * inv;
+    const float s2 = rowln_sum<LPR>(gd[0] * xh[0] + gd[1] * xh[1] + gd[2] * xh[2] + gd[3] * xh[3]) * inv;
+    if (act) {
+      f32x4 o = (gd - s1 - xh * s2) * rstd;
+      if (res) o += *reinterpret_cast<const f32x4*>(res + row * W + c);
+      *reinterpret_cast<f32x4*>(dx + row * W + c) = o;
+    }
+    adb += d;
+    adg += d * xh;
+  }
+  red[0][threadIdx.x] = adb;
+  red[1][threadIdx.x] = adg;
+  __syncthreads();
+  if (slot == 0 && act) {
+#pragma unroll 4
+    for (int s = 1; s < RPB; ++s) {
+      adb += red[0][s * LPR + lr];
+      adg += red[1][s * LPR + lr];
+    }
+    float* o = slab + (long long)blockIdx.x * 2 * W;
+    *reinterpret_cast<f32x4*>(o + c) = adb;
+    *reinterpret_cast<f32x4*>(o + W + c) = adg;
+  }
+}
+
+static int rowln_lpr(int W) { return W > 128 ? 64 : W > 64 ? 32 : W > 32 ? 16 : 8; }
+static int rowln_grid(long long M, int lpr) {
+  const long long need = (M + 256 / lpr - 1) / (256 / lpr);
+  return (int)(need < ROWLN_GRID_MAX ? need : ROWLN_GRID_MAX);
+}
+
+extern "C" int ws_rowln_grid(long long M, int W) { return M > 0 && W > 0 ? rowln_grid(M, rowln_lpr(W)) : 0; }
+
+extern "C" int ws_rowln_fwd(const float* x, const float* gamma, const float* beta, long long M, int W, float eps,
+                            float* y, float* stats, void* stream) {
+  WS_REQUIRE(x && gamma && beta && y && stats, "ws_rowln_fwd: null pointer");
+  WS_REQUIRE(M > 0 && W > 0 && W <= 256 && W % 4 == 0, "ws_rowln_fwd: rows of 4 .. 256 floats, width %% 4 == 0 (got %d)", W);
+  const int lpr = rowln_lpr(W), grid = rowln_grid(M, lpr);
+  hipStream_t s = (hipStream_t)stream;
+  switch (lpr) {
+    case 64: hipLaunchKernelGGL(rowln_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, x, gamma, beta, M, W, eps, y, stats); break;
+    case 32: hipLaunchKernelGGL(rowln_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, x, gamma, beta, M, W, eps, y, stats); break;
+    case 16: hipLaunchKernelGGL(rowln_fwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, gamma, beta, M, W, eps, y, stats); break;
+    default: hipLaunchKernelGGL(rowln_fwd_kernel<8>, dim3(grid), dim3(256), 0, s, x, gamma, beta, M, W, eps, y, stats);
+  }
+  return ws_check_launch("ws_rowln_fwd");
+}
+
+extern "C" int ws_rowln_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* res,
+                            long long M, int W, float* dx, float* slab, void* stream) {
+  WS_REQUIRE(x && dy && stats && gamma && dx && slab, "ws_rowln_bwd: null pointer");
+  WS_REQUIRE(M > 0 && W > 0 && W <= 256 && W % 4 == 0, "ws_rowln_bwd: rows of 4 .. 256 floats, width %% 4 == 0 (got %d)", W);
+  const int lpr = rowln_lpr(W), grid = rowln_grid(M, lpr);
+  hipStream_t s = (hipStream_t)stream;
+  switch (lpr) {
+    case 64: hipLaunchKernelGGL(rowln_bwd_kernel<64>, dim3(grid), dim3(256), 0, s, x, dy, stats, gamma, res, M, W, dx, slab); break;
+    case 32: hipLaunchKernelGGL(rowln_bwd_kernel<32>, dim3(grid), dim3(256), 0, s, x, dy, stats, gamma, res, M, W, dx, slab); break;
+    case 16: hipLaunchKernelGGL(rowln_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, dy, stats, gamma, res, M, W, dx, slab); break;
+    default: hipLaunchKernelGGL(rowln_bwd_kernel<8>, dim3(grid), dim3(256), 0, s, x, dy, stats, gamma, res, M, W, dx, slab);
+  }
+  return ws_check_launch("ws_rowln_bwd");
+}

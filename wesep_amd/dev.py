@@ -1163,6 +1163,29 @@ def softmax_rows_fwd(x, rows: int, n: int, scale: float, y):
     _call("ws_softmax_rows_fwd", _p(x), rows, n, scale, _p(y))
 
 
+def rowln_ok(W: int) -> bool:
+    """Widths the one-pass row LayerNorm kernels take (norm.hip); wider rows use group_stats + dwconv_fwd."""
+    return 0 < W <= 256 and W % 4 == 0
+
+
+def rowln_fwd(x, gamma, beta, M: int, W: int, y, stats, eps=LN_EPS):
+    for nm, t in (("x", x), ("gamma", gamma), ("beta", beta), ("y", y), ("stats", stats)):
+        _chk(t, nm)
+    _call("ws_rowln_fwd", _p(x), _p(gamma), _p(beta), M, W, eps, _p(y), _p(stats))
+
+
+def rowln_bwd(x, dy, stats, gamma, M: int, W: int, dx, res=None):
+    """dx (may alias dy) and the [2, W] sums (d(beta), d(gamma)), reduced from the kernel's per-workgroup slabs."""
+    for nm, t in (("x", x), ("dy", dy), ("stats", stats), ("gamma", gamma), ("dx", dx), ("res", res)):
+        _chk(t, nm)
+    n = L.lib().ws_rowln_grid(M, W)
+    slab = torch.empty(n, 2 * W, device=x.device, dtype=torch.float32)
+    _call("ws_rowln_bwd", _p(x), _p(dy), _p(stats), _p(gamma), _p(res), M, W, _p(dx), _p(slab))
+    tot = torch.empty(2, W, device=x.device, dtype=torch.float32)
+    reduce_slabs(slab, n, 2 * W, 2 * W, tot)
+    return tot
+
+
 def softmax_rows_bwd(y, dy, rows: int, n: int, scale: float, dx):
     for nm, t in (("y", y), ("dy", dy), ("dx", dx)):
         _chk(t, nm)

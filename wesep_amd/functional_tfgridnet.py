@@ -147,7 +147,8 @@ class AddRowVecFn(torch.autograd.Function):
 
 
 class RowLNFn(torch.autograd.Function):
-    """y = gamma * (x - mean_row) * rstd_row + beta over the width of each row (eps 1e-5)."""
+    """y = gamma * (x - mean_row) * rstd_row + beta over the width of each row (eps 1e-5).  Rows of up to 256 floats
+    (the per-position LayerNorm over emb_dim in front of every BLSTM) take the one-pass kernels of norm.hip."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta):
@@ -156,10 +157,14 @@ class RowLNFn(torch.autograd.Function):
         M, Wd = x.shape
         d = x.device
         st = _empty(d, M, 2)
-        dev.group_stats(x, _cln_geom(M, Wd), st, dev.LN_EPS)
         y = torch.empty_like(x)
         g, b = gamma.contiguous().view(-1), beta.contiguous().view(-1)
-        dev.dwconv_fwd(x, st, g, b, torch.ones(Wd, 1, device=d), torch.zeros(Wd, device=d), M, 1, Wd, 1, 1, 1, y)
+        ctx.short = dev.rowln_ok(Wd)
+        if ctx.short:
+            dev.rowln_fwd(x, g, b, M, Wd, y, st)
+        else:
+            dev.group_stats(x, _cln_geom(M, Wd), st, dev.LN_EPS)
+            dev.dwconv_fwd(x, st, g, b, torch.ones(Wd, 1, device=d), torch.zeros(Wd, device=d), M, 1, Wd, 1, 1, 1, y)
         ctx.save_for_backward(x, st, g)
         ctx.shapes = (gamma.shape, beta.shape)
         return y
@@ -168,6 +173,11 @@ class RowLNFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, st, g = ctx.saved_tensors
         M, Wd = x.shape
+        if ctx.short:
+            dy = dy.contiguous()
+            dx = torch.empty_like(dy)
+            tot = dev.rowln_bwd(x, dy, st, g, M, Wd, dx)
+            return dx, tot[1].contiguous().view(ctx.shapes[0]), tot[0].contiguous().view(ctx.shapes[1])
         dx, dg, db = norm_backward(x, dy.contiguous().clone(), st, g, "cLN", M, 1, Wd)
         return dx, dg.view(ctx.shapes[0]), db.view(ctx.shapes[1])
 
