@@ -384,13 +384,15 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   const int ntile = (a->nseq + SQ - 1) / SQ;
   dim3 grid(ntile, 2), block(512);
   hipStream_t s = (hipStream_t)stream;
-  // 64 sequences per workgroup when the 32-sequence grid would need more than ~1.5 rounds of the chip (one workgroup per
-  // CU either way): measured 2.48 vs 2.75 ms at 1002 workgroups, but 1.06 vs 0.56 ms at 158 (half the CUs idle).
+  // 64 sequences per workgroup when that saves time after rounding both grids up to whole rounds of the chip (one
+  // workgroup per CU either way; a 64-sequence step costs 1.8x a 32-sequence step).  Measured: pBSRNN band view,
+  // 1002 vs 502 workgroups (4 vs 2 rounds): 2.70 -> 2.43 ms; TF-GridNet intra path, 752 vs 376 (3 vs 2 rounds): 4.08 -> 4.64.
   // WS_FUSED_SEQS=32|64 overrides (diagnostics; both kernels give the same bits)
   const char* env = getenv("WS_FUSED_SEQS");
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
-  const bool wide = env ? atoi(env) == 64 : 4 * ntile > 3 * cus;
+  const int rounds32 = (2 * ntile + cus - 1) / cus, rounds64 = (2 * ((ntile + 1) / 2) + cus - 1) / cus;
+  const bool wide = env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
   if (wide)
     hipLaunchKernelGGL(lstm_fwd_fused64_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
