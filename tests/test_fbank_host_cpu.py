@@ -198,3 +198,69 @@ def test_executor_ssa_second_pass(emu):
     assert len(model.calls) == 3 and all(torch.equal(c[0], batch["spk_embeds"]) and c[1] for c in model.calls)
     model, _ = _run_ssa(0.5, True, args, steps=40)
     assert 40 < len(model.calls) < 80
+
+
+def test_executor_accepts_enable_amp_and_a_grad_scaler(emu):
+    """executor.py:88,130-134: the AMP switch and the GradScaler protocol are part of the reference's Executor.train
+    signature.  This path has nothing for autocast to downcast, so `enable_amp=True` must run and leave the step
+    unchanged; a scaler object that is passed in is driven through scale -> unscale_ -> step -> update."""
+    import wesep_amd.utils.executor as ex
+    from wesep_amd.utils.executor import Executor
+    from wesep_amd.utils.schedulers import ExponentialDecrease
+
+    class Scaler:
+        def __init__(self):
+            self.calls = []
+
+        def scale(self, loss):
+            self.calls.append("scale")
+            return loss * 8.0
+
+        def unscale_(self, optimizer):
+            self.calls.append("unscale_")
+            for group in optimizer.param_groups:
+                for p in group["params"]:
+                    if p.grad is not None:
+                        p.grad.div_(8.0)
+
+        def step(self, optimizer):
+            self.calls.append("step")
+            optimizer.step()
+
+        def update(self):
+            self.calls.append("update")
+
+    def run(enable_amp, scaler):
+        torch.manual_seed(3)
+        lin = torch.nn.Linear(16, 16)
+
+        class M(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.lin = lin
+
+            def forward(self, wav, enroll):
+                return [self.lin(wav.view(-1, 16)).view_as(wav)]
+
+        model = M()
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        sched = ExponentialDecrease(opt, num_epochs=1, epoch_iter=2, initial_lr=0.1, final_lr=0.1, warm_up_epoch=0)
+        g = torch.Generator().manual_seed(4)
+        wav = torch.randn(2, 160, generator=g)
+        batch = {"wav_mix": wav, "wav_targets": wav.flip(1).contiguous(), "spk_embeds": torch.randn(2, 8, generator=g),
+                 "spk_label": torch.zeros(0)}
+        crit = [lambda est, ref: ((est - ref) ** 2).mean(1)]
+        keep, ex.clip_gradients = ex.clip_gradients, (lambda model, clip: None)
+        try:
+            Executor().train([batch] * 2, [model], 2, [opt], crit, [sched], scaler=scaler, epoch=1, enable_amp=enable_amp,
+                             logger=None, device=torch.device("cpu"), se_loss_weight=([[0]], [[1.0]]))
+        finally:
+            ex.clip_gradients = keep
+        return torch.cat([p.detach().flatten() for p in model.parameters()])
+
+    base = run(False, None)
+    assert torch.equal(run(True, None), base)
+    sc = Scaler()
+    scaled = run(True, sc)
+    assert sc.calls == ["scale", "unscale_", "step", "update"] * 2
+    assert torch.allclose(scaled, base, rtol=1e-6, atol=1e-7)

@@ -80,8 +80,16 @@ class Executor:
               se_loss_weight=1.0, multi_task=False, SSA_enroll_prob=0, fbank_args=None,
               sample_rate=16000, speaker_feat=True):
         """Train one epoch."""
-        if enable_amp:
-            raise NotImplementedError("enable_amp: the HIP path computes in fp32 (all shipped configs use False)")
+        if enable_amp and not getattr(self, "_amp_noted", False):
+            # executor.py:88,130-134 wraps the step in torch.cuda.amp.autocast + GradScaler.  autocast rewrites the dtype of
+            # ATen ops; this path has none to rewrite (every product is a split-bf16 MFMA with fp32 accumulation and fp32
+            # storage -- at least the precision autocast's bf16 / fp16 GEMMs would have), and without fp16 gradients there
+            # is nothing for a GradScaler to protect.  The switch is therefore accepted and changes nothing; a scaler
+            # passed in is still honoured (scale -> unscale_ -> step -> update), so reference training scripts run as is.
+            self._amp_noted = True
+            if logger is not None:
+                logger.info("enable_amp=True: the HIP path already multiplies in split-bf16 with fp32 accumulation; "
+                            "autocast has nothing to downcast, the step is unchanged")
         model, optimizer, scheduler = models[0], optimizers[0], schedulers[0]
         model.train()
         ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)
