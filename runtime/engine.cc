@@ -219,6 +219,11 @@ struct ws_engine {
   int spk_feat = 1;
   float *mel_basis = nullptr, *mel_fbt = nullptr, mel_coef = 0.97f;
   int mel_lds = 516, mel_ldp = 260;
+  // Conv-TasNet / SpEx+ (arch 1; wesep/models/convtasnet.py): geometry and prepared operands
+  int arch = 0;                  // 0 pBSRNN, 1 Conv-TasNet (Multi encoder / decoder, gLN, concatConv fusion)
+  int tN = 512, tL = 16, tB = 128, tH = 512, tP = 3, tX = 8, tR = 3;
+  float* tas_dec_wt = nullptr;   // decoder_1d_1 weight transposed to [L][N]
+  float* tas_bn_st[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // eval BN (mean, rstd) [2][C]
   // grouped-GEMM descriptor tables, rebuilt when (R, Tf) changes
   int desc_R = -1, desc_Tf = -1;
   ws_group_nt *d_bn = nullptr, *d_l1 = nullptr, *d_l2 = nullptr, *d_l3 = nullptr;
@@ -713,7 +718,15 @@ int prep_mel_frontend(ws_engine* e) {
   return WS_OK;
 }
 
+int prepare_tasnet(ws_engine* e);
+
 int prepare(ws_engine* e) {
+  e->arch = static_cast<int>(meta_or(e, "arch", 0));
+  if (e->arch == 1) return prepare_tasnet(e);
+  if (e->arch != 0) {
+    set_err("engine: architecture %d has no launch plan (0 pBSRNN, 1 Conv-TasNet)", e->arch);
+    return WS_ERR_INVALID;
+  }
   e->sr = static_cast<int>(meta_or(e, "sample_rate", 16000));
   e->spk_feat = static_cast<int>(meta_or(e, "spk_feat", 1));
   e->num_repeat = static_cast<int>(meta_or(e, "num_repeat", 6));
@@ -1515,6 +1528,411 @@ int separate_device(ws_engine* e, const float* wav, int R, int T, const float* e
   return WS_OK;
 }
 
+
+// =================================================================================================================
+// Conv-TasNet / SpEx+ (arch 1): the launch plan of wesep_amd/functional_tasnet.py in eval mode for the shipped
+// configuration -- MultiEncoder / MultiDecoder, gLN, non-causal, no skip connection, concatConv multi-fusion
+// (convtasnet.py:162-219, separation.py:57-186, convs.py:41-160, encoder.py:66-114, decoder.py:66-114), fixed embeddings
+// or the SpEx+ speaker encoder on the enrollment waveform through the shared encoder (tasnet/speaker.py:47-64).
+// Only the first of the three decoder branches is computed: it is the estimate the reference's inference writes.
+// =================================================================================================================
+constexpr float kLnEps = 1e-5f;
+
+struct TasGemm {
+  const float* A = nullptr;
+  long long lda = 0;
+  long long M = 0;
+  int K = 0;
+  const float* W = nullptr;
+  int ldw = 0, N = 0;
+  const float* bias = nullptr;
+  int act = 0;
+  float* C = nullptr;
+  long long ldc = 0;
+  const float* R = nullptr;                                       // residual, addressed like C
+  const float *stats = nullptr, *gamma = nullptr, *beta = nullptr; // norm-on-load
+  int st_div1 = 1;                                                 // rows per statistics pair (gLN: T', cLN: 1)
+  bool f32 = false;                                                // exact-fp32 products (the SpEx+ speaker encoder)
+  int a_div = kBig;                                                // frames view: row m -> (m / a_div) * a_s1 + (m % a_div) * lda
+  long long a_s1 = 0;
+};
+
+int tas_gemm(ws_engine* e, const TasGemm& t) {
+  ws_gemm_nt_args g = {};
+  g.A = t.A, g.W = t.W, g.bias = t.bias, g.C = t.C, g.R = t.R;
+  g.stats = t.stats, g.gamma = t.gamma, g.beta = t.beta;
+  g.a_div = t.a_div, g.a_s1 = t.a_s1, g.a_s2 = t.lda;
+  g.c_div = kBig, g.c_s2 = t.ldc;
+  g.st_div1 = t.st_div1, g.st_m1 = 1, g.st_div2 = 1, g.st_m2 = 0;
+  g.M = static_cast<int>(t.M), g.N = t.N, g.K = t.K, g.ldw = t.ldw, g.act = t.act;
+  int vec = 0;
+  if (t.a_div == kBig) {
+    vec = (t.K % 4 == 0 && t.ldw % 4 == 0 && t.lda % 4 == 0) ? 3 : 0;
+  } else {
+    vec = (t.K % 4 == 0 && t.ldw % 4 == 0) ? 2 : 0;   // overlapping frames: only the weight rows are 16-byte loadable
+  }
+  g.vec = vec | (t.f32 ? 0 : 4);
+  WS_RUN(e, ws_gemm_nt(&g, e->stream));
+  return WS_OK;
+}
+
+int tas_row_stats(ws_engine* e, const float* x, long long M, int C, float* st) {   // cLN statistics per frame
+  ws_groups_geom geo = {};
+  geo.gs1 = C, geo.gs2 = 0, geo.rs = C, geo.ngroups = static_cast<int>(M), geo.gdiv = 1, geo.L = 1, geo.W = C, geo.nbands = 1;
+  WS_RUN(e, ws_group_stats(x, &geo, kLnEps, st, e->stream));
+  return WS_OK;
+}
+
+int tas_flat_stats(ws_engine* e, const float* x, int R, long long n, float* st) {  // gLN statistics per utterance
+  int nchunk = static_cast<int>(n / 16384);
+  const int cap = 512 / R > 1 ? 512 / R : 1;
+  if (nchunk > cap) nchunk = cap;
+  if (nchunk < 1) nchunk = 1;
+  float* scratch = e->work.alloc(size_t(R) * nchunk * 4);
+  WS_PTR(scratch);
+  WS_RUN(e, ws_flat_stats(x, R, n, kLnEps, nchunk, scratch, st, e->stream));
+  return WS_OK;
+}
+
+// MultiEncoder (encoder.py:66-114): wav [R][T] -> cat [M][3N] (ReLU outputs of the three filterbanks) and, if wanted,
+// e [M][B] = proj(LayerNorm(cat)); M = R * T', T' = (T - L) / stride + 1
+int tas_encode(ws_engine* e, const float* wav, int R, int T, float* cat, float* feat) {
+  const int N = e->tN, L = e->tL, B = e->tB, stride = L / 2;
+  const int Ls[3] = {L, 80, 160};
+  const char* names[3] = {"encoder.encoder_1d_short.", "encoder.encoder_1d_middle.", "encoder.encoder_1d_long."};
+  const int Tp = (T - L) / stride + 1;
+  const long long M = (long long)R * Tp;
+  int Tpad = (Tp - 1) * stride + Ls[2];
+  if (Tpad < T) Tpad = T;
+  Tpad = (Tpad + 3) / 4 * 4;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  float* xp = a.alloc(size_t(R) * Tpad);
+  WS_PTR(xp);
+  int rc = zero_device(e, xp, size_t(R) * Tpad * 4);
+  if (rc != WS_OK) return rc;
+  if ((rc = copy_cols(e, xp, Tpad, wav, T, T, R)) != WS_OK) return rc;
+  for (int i = 0; i < 3; ++i) {
+    TasGemm g;
+    g.A = xp, g.a_div = Tp, g.a_s1 = Tpad, g.lda = stride, g.M = M, g.K = Ls[i];
+    g.W = e->dev(std::string(names[i]) + "weight"), g.ldw = Ls[i], g.N = N, g.bias = e->dev(std::string(names[i]) + "bias");
+    g.act = 2, g.C = cat + (long long)i * N, g.ldc = 3 * N;
+    if ((rc = tas_gemm(e, g)) != WS_OK) return rc;
+  }
+  if (feat) {
+    float* st = a.alloc(size_t(M) * 2);
+    WS_PTR(st);
+    if ((rc = tas_row_stats(e, cat, M, 3 * N, st)) != WS_OK) return rc;
+    TasGemm g;
+    g.A = cat, g.lda = 3 * N, g.M = M, g.K = 3 * N, g.W = e->dev("encoder.proj.weight"), g.ldw = 3 * N, g.N = B;
+    g.bias = e->dev("encoder.proj.bias"), g.C = feat, g.ldc = B;
+    g.stats = st, g.gamma = e->dev("encoder.ln.weight"), g.beta = e->dev("encoder.ln.bias"), g.st_div1 = 1;
+    if ((rc = tas_gemm(e, g)) != WS_OK) return rc;
+  }
+  a.release(mk);
+  return WS_OK;
+}
+
+// one TCN block (convs.py:41-160): out = x + sconv(gLN2(prelu2(dconv(gLN1(prelu1(conv1x1(x) + rb))))))
+int tas_block(ws_engine* e, const std::string& pre, bool fuse, int dil, const float* x, const float* rb, int R, int Tp,
+              float* out) {
+  const int B = e->tB, H = e->tH, P = e->tP;
+  const long long M = (long long)R * Tp;
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  const char* n_p1 = fuse ? "prelu1.weight" : "PReLU_1.weight";
+  const char* n_p2 = fuse ? "prelu2.weight" : "PReLU_2.weight";
+  const std::string n1 = pre + (fuse ? "lnorm1." : "norm_1."), n2 = pre + (fuse ? "lnorm2." : "norm_2.");
+  const std::string dw = pre + (fuse ? "dconv." : "dwconv."), outc = pre + (fuse ? "sconv." : "Output.");
+  float* c = a.alloc(size_t(M) * H);
+  float* y1 = a.alloc(size_t(M) * H);
+  float* z = a.alloc(size_t(M) * H);
+  float* st1 = a.alloc(size_t(R) * 2);
+  float* st2 = a.alloc(size_t(R) * 2);
+  WS_PTR(c && y1 && z && st1 && st2);
+  TasGemm g;
+  g.A = x, g.lda = B, g.M = M, g.K = B, g.W = e->dev(pre + "conv1x1.weight"), g.ldw = fuse ? B + e->E : B, g.N = H;
+  g.bias = rb ? nullptr : e->dev(pre + "conv1x1.bias"), g.C = c, g.ldc = H;
+  int rc = tas_gemm(e, g);
+  if (rc != WS_OK) return rc;
+  WS_RUN(e, ws_prelu_fwd(c, rb, e->dev(pre + n_p1), M, H, Tp, y1, s));
+  if ((rc = tas_flat_stats(e, y1, R, (long long)Tp * H, st1)) != WS_OK) return rc;
+  WS_RUN(e, ws_dwconv_ex_fwd(y1, st1, e->dev(n1 + "weight"), e->dev(n1 + "bias"), e->dev(dw + "weight"), e->dev(dw + "bias"), R,
+                             Tp, H, P, dil, Tp, 0, z, s));
+  WS_RUN(e, ws_prelu_fwd(z, nullptr, e->dev(pre + n_p2), M, H, Tp, c, s));      // y2 -> c (its contents are dead)
+  if ((rc = tas_flat_stats(e, c, R, (long long)Tp * H, st2)) != WS_OK) return rc;
+  TasGemm o;
+  o.A = c, o.lda = H, o.M = M, o.K = H, o.W = e->dev(outc + "weight"), o.ldw = H, o.N = B, o.bias = e->dev(outc + "bias");
+  o.C = out, o.ldc = B, o.R = x, o.stats = st2, o.gamma = e->dev(n2 + "weight"), o.beta = e->dev(n2 + "bias"), o.st_div1 = Tp;
+  if ((rc = tas_gemm(e, o)) != WS_OK) return rc;
+  a.release(mk);
+  return WS_OK;
+}
+
+// SpEx+ speaker encoder (tasnet/speaker.py:7-64) in eval mode: cat_aux [R*T0][3N] -> emb [R][E]
+int tas_spk_embed(ws_engine* e, const float* cat, int R, int T0, float* emb) {
+  const int C0 = 3 * e->tN;
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  const std::string sp = "spk_model.aux_enc3.";
+  long long M = (long long)R * T0;
+  float* st0 = a.alloc(size_t(M) * 2);
+  float* x = a.alloc(size_t(M) * 256);
+  WS_PTR(st0 && x);
+  int rc = tas_row_stats(e, cat, M, C0, st0);
+  if (rc != WS_OK) return rc;
+  {
+    TasGemm g;
+    g.A = cat, g.lda = C0, g.M = M, g.K = C0, g.W = e->dev(sp + "1.weight"), g.ldw = C0, g.N = 256, g.bias = e->dev(sp + "1.bias");
+    g.C = x, g.ldc = 256, g.stats = st0, g.gamma = e->dev(sp + "0.weight"), g.beta = e->dev(sp + "0.bias");
+    if ((rc = tas_gemm(e, g)) != WS_OK) return rc;
+  }
+  int T = T0, ci = 256;
+  const int cos[3] = {256, 512, 512};
+  for (int i = 0; i < 3; ++i) {
+    const std::string bp = sp + std::to_string(2 + i) + ".";
+    const int co = cos[i];
+    M = (long long)R * T;
+    float* c1 = a.alloc(size_t(M) * co);
+    float* u = a.alloc(size_t(M) * co);
+    float* y1 = a.alloc(size_t(M) * co);
+    float* c2 = a.alloc(size_t(M) * co);
+    float* res = ci != co ? a.alloc(size_t(M) * co) : nullptr;
+    float* y2 = a.alloc(size_t(M) * co);
+    float* pooled = a.alloc(size_t(R) * (T / 3) * co);
+    WS_PTR(c1 && u && y1 && c2 && y2 && pooled && (ci == co || res));
+    TasGemm g1;
+    g1.A = x, g1.lda = ci, g1.M = M, g1.K = ci, g1.W = e->dev(bp + "conv1.weight"), g1.ldw = ci, g1.N = co, g1.C = c1, g1.ldc = co;
+    g1.f32 = true;
+    if ((rc = tas_gemm(e, g1)) != WS_OK) return rc;
+    WS_RUN(e, ws_bn_prelu_fwd(c1, e->tas_bn_st[i][0], e->dev(bp + "batch_norm1.weight"), e->dev(bp + "batch_norm1.bias"), nullptr,
+                              e->dev(bp + "prelu1.weight"), M, co, u, y1, s));
+    TasGemm g2;
+    g2.A = y1, g2.lda = co, g2.M = M, g2.K = co, g2.W = e->dev(bp + "conv2.weight"), g2.ldw = co, g2.N = co, g2.C = c2, g2.ldc = co;
+    g2.f32 = true;
+    if ((rc = tas_gemm(e, g2)) != WS_OK) return rc;
+    const float* resp = x;
+    if (ci != co) {
+      TasGemm gd;
+      gd.A = x, gd.lda = ci, gd.M = M, gd.K = ci, gd.W = e->dev(bp + "conv_downsample.weight"), gd.ldw = ci, gd.N = co;
+      gd.C = res, gd.ldc = co, gd.f32 = true;
+      if ((rc = tas_gemm(e, gd)) != WS_OK) return rc;
+      resp = res;
+    }
+    WS_RUN(e, ws_bn_prelu_fwd(c2, e->tas_bn_st[i][1], e->dev(bp + "batch_norm2.weight"), e->dev(bp + "batch_norm2.bias"), resp,
+                              e->dev(bp + "prelu2.weight"), M, co, u, y2, s));
+    WS_RUN(e, ws_maxpool3_fwd(y2, R, T, co, pooled, s));
+    x = pooled, T = T / 3, ci = co;
+  }
+  float* mean2 = a.alloc(size_t(R) * 2 * ci);
+  WS_PTR(mean2);
+  if ((rc = time_mean(e, x, R, T, ci, mean2)) != WS_OK) return rc;
+  TasGemm g5;
+  g5.A = mean2, g5.lda = 2 * ci, g5.M = R, g5.K = ci, g5.W = e->dev(sp + "5.weight"), g5.ldw = ci, g5.N = e->E;
+  g5.bias = e->dev(sp + "5.bias"), g5.C = emb, g5.ldc = e->E, g5.f32 = true;
+  if ((rc = tas_gemm(e, g5)) != WS_OK) return rc;
+  a.release(mk);
+  return WS_OK;
+}
+
+int spk_transform(ws_engine* e, const float* emb, int R, const float** out) {
+  *out = emb;
+  if (!e->use_xform) return WS_OK;
+  Arena& a = e->work;
+  const Tensor* t0 = e->find("spk_transform.transforms.0.weight");
+  const int hid = static_cast<int>(t0->dims[0]);
+  float* h0 = a.alloc(size_t(R) * hid);
+  float* h1 = a.alloc(size_t(R) * hid);
+  float* eo = a.alloc(size_t(R) * e->E);
+  WS_PTR(h0 && h1 && eo);
+  int rc;
+  if ((rc = linear(e, emb, R, e->E, e->dev("spk_transform.transforms.0.weight"), e->E, hid,
+                   e->dev("spk_transform.transforms.0.bias"), 0, h0)) != WS_OK ||
+      (rc = linear(e, h0, R, hid, e->dev("spk_transform.transforms.1.weight"), hid, hid,
+                   e->dev("spk_transform.transforms.1.bias"), 1, h1)) != WS_OK ||
+      (rc = linear(e, h1, R, hid, e->dev("spk_transform.transforms.3.weight"), hid, e->E,
+                   e->dev("spk_transform.transforms.3.bias"), 0, eo)) != WS_OK)
+    return rc;
+  *out = eo;
+  return WS_OK;
+}
+
+// wav [R][T], emb_in [R][E] (or NULL with enroll_wave [R][Te] for the SpEx+ encoder) -> est [R][T]: the first
+// (T' - 1) * stride + L samples of each row are the model's output, the rest zeros
+int tasnet_device(ws_engine* e, const float* wav, int R, int T, const float* emb_in, const float* enroll_wave, int Te,
+                  float* est) {
+  const int N = e->tN, L = e->tL, B = e->tB, H = e->tH, stride = L / 2;
+  const int Tp = (T - L) / stride + 1;
+  const long long M = (long long)R * Tp;
+  void* s = e->stream;
+  Arena& a = e->work;
+  float* cat = a.alloc(size_t(M) * 3 * N);
+  float* zA = a.alloc(size_t(M) * B);
+  float* zB = a.alloc(size_t(M) * B);
+  float* emb_own = a.alloc(size_t(R) * e->E);
+  WS_PTR(cat && zA && zB && emb_own);
+  int rc = tas_encode(e, wav, R, T, cat, zA);
+  if (rc != WS_OK) return rc;
+  const float* emb = emb_in;
+  if (!emb) {                                  // enrollment waveform through the SHARED encoder (convtasnet.py:179-187)
+    const Arena::Mark mk = a.mark();
+    const int Tpa = (Te - L) / stride + 1;
+    float* cat_aux = a.alloc(size_t(R) * Tpa * 3 * N);
+    WS_PTR(cat_aux);
+    if ((rc = tas_encode(e, enroll_wave, R, Te, cat_aux, nullptr)) != WS_OK) return rc;
+    if ((rc = tas_spk_embed(e, cat_aux, R, Tpa, emb_own)) != WS_OK) return rc;
+    a.release(mk);
+    emb = emb_own;
+  }
+  if ((rc = spk_transform(e, emb, R, &emb)) != WS_OK) return rc;
+  float* x = zA;
+  float* other = zB;
+  float* rb = a.alloc(size_t(R) * H);
+  WS_PTR(rb);
+  for (int r = 0; r < e->tR; ++r) {
+    const std::string fp = "separation.separation." + std::to_string(2 * r) + ".";
+    // conv1x1(cat[x, e]) = W_x x + (W_e e + b): the embedding part is one [R][H] GEMM (convs.py:143-148)
+    if ((rc = linear(e, emb, R, e->E, e->dev(fp + "conv1x1.weight") + B, B + e->E, H, e->dev(fp + "conv1x1.bias"), 0, rb)) !=
+        WS_OK)
+      return rc;
+    if ((rc = tas_block(e, fp, true, 1, x, rb, R, Tp, other)) != WS_OK) return rc;
+    std::swap(x, other);
+    for (int k = 1; k < e->tX; ++k) {
+      const std::string bp = "separation.separation." + std::to_string(2 * r + 1) + ".separation." + std::to_string(k - 1) + ".";
+      if ((rc = tas_block(e, bp, false, 1 << k, x, nullptr, R, Tp, other)) != WS_OK) return rc;
+      std::swap(x, other);
+    }
+  }
+  // MultiDecoder, first branch (decoder.py:66-114): ReLU mask, mask * w1, transposed convolution as GEMM + overlap-add
+  {
+    const int xlen = (Tp - 1) * stride + L;
+    float* m = a.alloc(size_t(M) * N);
+    float* sm = a.alloc(size_t(M) * N);
+    float* fr = a.alloc(size_t(M) * L);
+    float* out = a.alloc(size_t(R) * xlen);
+    WS_PTR(m && sm && fr && out);
+    TasGemm g;
+    g.A = x, g.lda = B, g.M = M, g.K = B, g.W = e->dev("decoder.mask1.weight"), g.ldw = B, g.N = N;
+    g.bias = e->dev("decoder.mask1.bias"), g.act = 2, g.C = m, g.ldc = N;
+    if ((rc = tas_gemm(e, g)) != WS_OK) return rc;
+    WS_RUN(e, ws_maskmul_fwd(cat, 3 * N, m, M, N, sm, s));
+    TasGemm d;
+    d.A = sm, d.lda = N, d.M = M, d.K = N, d.W = e->tas_dec_wt, d.ldw = N, d.N = L, d.C = fr, d.ldc = L;
+    if ((rc = tas_gemm(e, d)) != WS_OK) return rc;
+    WS_RUN(e, ws_ola_fwd(fr, e->dev("decoder.decoder_1d_1.bias"), R, Tp, L, stride, xlen, out, s));
+    if ((rc = zero_device(e, est, size_t(R) * T * 4)) != WS_OK) return rc;
+    if ((rc = copy_cols(e, est, T, out, xlen, xlen, R)) != WS_OK) return rc;
+  }
+  return WS_OK;
+}
+
+int prepare_tasnet(ws_engine* e) {
+  e->sr = static_cast<int>(meta_or(e, "sample_rate", 16000));
+  e->E = static_cast<int>(meta_or(e, "spk_emb_dim", 256));
+  e->use_xform = static_cast<int>(meta_or(e, "use_spk_transform", 0));
+  e->joint = static_cast<int>(meta_or(e, "joint_training", 0));
+  e->spk_feat = 0;               // a joint Conv-TasNet takes the enrollment WAVEFORM (shared encoder)
+  e->tN = static_cast<int>(meta_or(e, "N", 512)), e->tL = static_cast<int>(meta_or(e, "L", 16));
+  e->tB = static_cast<int>(meta_or(e, "B", 128)), e->tH = static_cast<int>(meta_or(e, "H", 512));
+  e->tP = static_cast<int>(meta_or(e, "P", 3)), e->tX = static_cast<int>(meta_or(e, "X", 8));
+  e->tR = static_cast<int>(meta_or(e, "R", 3));
+  const int N = e->tN, L = e->tL, B = e->tB, H = e->tH, P = e->tP, E = e->E;
+  if (N % 4 || B % 4 || H % 4 || E % 4 || L % 2 || L < 4 || L > 80 || P < 1 || P > 7 || e->tX < 1 || e->tR < 1) {
+    set_err("engine: unsupported Conv-TasNet geometry (N %d, L %d, B %d, H %d, P %d, X %d, R %d, E %d)", N, L, B, H, P, e->tX,
+            e->tR, E);
+    return WS_ERR_INVALID;
+  }
+  if (e->joint && N != 256) {
+    set_err("engine: the SpEx+ speaker encoder is hard-wired to 3 x 256 encoder channels (tasnet/speaker.py:52-53); N = %d", N);
+    return WS_ERR_INVALID;
+  }
+  e->dw = e->persist.alloc(e->hw.size());
+  WS_PTR(e->dw);
+  int rc = to_device(e, e->dw, e->hw.data(), e->hw.size() * 4);
+  if (rc != WS_OK) return rc;
+  const int Ls[3] = {L, 80, 160};
+  const char* enc[3] = {"encoder.encoder_1d_short.", "encoder.encoder_1d_middle.", "encoder.encoder_1d_long."};
+  for (int i = 0; i < 3; ++i)
+    if (!require(e, std::string(enc[i]) + "weight", {N, 1, Ls[i]}) || !require(e, std::string(enc[i]) + "bias", {N}))
+      return WS_ERR_INVALID;
+  if (!require(e, "encoder.ln.weight", {3 * N}) || !require(e, "encoder.ln.bias", {3 * N}) ||
+      !require(e, "encoder.proj.weight", {B, 3 * N, 1}) || !require(e, "encoder.proj.bias", {B}) ||
+      !require(e, "decoder.mask1.weight", {N, B, 1}) || !require(e, "decoder.mask1.bias", {N}) ||
+      !require(e, "decoder.decoder_1d_1.weight", {N, 1, L}) || !require(e, "decoder.decoder_1d_1.bias", {1}))
+    return WS_ERR_INVALID;
+  for (int r = 0; r < e->tR; ++r) {
+    const std::string fp = "separation.separation." + std::to_string(2 * r) + ".";
+    if (!require(e, fp + "conv1x1.weight", {H, B + E, 1}) || !require(e, fp + "conv1x1.bias", {H}) ||
+        !require(e, fp + "prelu1.weight", {1}) || !require(e, fp + "lnorm1.weight", {H, 1}) ||
+        !require(e, fp + "lnorm1.bias", {H, 1}) || !require(e, fp + "dconv.weight", {H, 1, P}) ||
+        !require(e, fp + "dconv.bias", {H}) || !require(e, fp + "prelu2.weight", {1}) ||
+        !require(e, fp + "lnorm2.weight", {H, 1}) || !require(e, fp + "lnorm2.bias", {H, 1}) ||
+        !require(e, fp + "sconv.weight", {B, H, 1}) || !require(e, fp + "sconv.bias", {B}))
+      return WS_ERR_INVALID;
+    for (int k = 1; k < e->tX; ++k) {
+      const std::string bp = "separation.separation." + std::to_string(2 * r + 1) + ".separation." + std::to_string(k - 1) + ".";
+      if (!require(e, bp + "conv1x1.weight", {H, B, 1}) || !require(e, bp + "conv1x1.bias", {H}) ||
+          !require(e, bp + "PReLU_1.weight", {1}) || !require(e, bp + "norm_1.weight", {H, 1}) ||
+          !require(e, bp + "norm_1.bias", {H, 1}) || !require(e, bp + "dwconv.weight", {H, 1, P}) ||
+          !require(e, bp + "dwconv.bias", {H}) || !require(e, bp + "PReLU_2.weight", {1}) ||
+          !require(e, bp + "norm_2.weight", {H, 1}) || !require(e, bp + "norm_2.bias", {H, 1}) ||
+          !require(e, bp + "Output.weight", {B, H, 1}) || !require(e, bp + "Output.bias", {B}))
+        return WS_ERR_INVALID;
+    }
+  }
+  if (e->use_xform) {
+    const Tensor* t0 = e->find("spk_transform.transforms.0.weight");
+    if (!t0 || t0->dims.size() < 2 || t0->dims[1] != E || !e->find("spk_transform.transforms.1.weight") ||
+        !e->find("spk_transform.transforms.3.weight")) {
+      set_err("engine: spk_transform tensors missing or mis-shaped");
+      return WS_ERR_INVALID;
+    }
+  }
+  // synthesis filterbank as a GEMM operand: [N][L] -> [L][N]
+  e->tas_dec_wt = e->persist.alloc(size_t(L) * N);
+  WS_PTR(e->tas_dec_wt);
+  WS_RUN(e, ws_transpose(e->dev("decoder.decoder_1d_1.weight"), N, L, L, e->tas_dec_wt, e->stream));
+  if (e->joint) {
+    const std::string sp = "spk_model.aux_enc3.";
+    if (!require(e, sp + "0.weight", {3 * N}) || !require(e, sp + "0.bias", {3 * N}) ||
+        !require(e, sp + "1.weight", {256, 3 * N, 1}) || !require(e, sp + "1.bias", {256}) ||
+        !require(e, sp + "5.weight", {E, 512, 1}) || !require(e, sp + "5.bias", {E}))
+      return WS_ERR_INVALID;
+    int ci = 256;
+    const int cos[3] = {256, 512, 512};
+    for (int i = 0; i < 3; ++i) {
+      const std::string bp = sp + std::to_string(2 + i) + ".";
+      const int co = cos[i];
+      if (!require(e, bp + "conv1.weight", {co, ci, 1}) || !require(e, bp + "conv2.weight", {co, co, 1}) ||
+          !require(e, bp + "prelu1.weight", {1}) || !require(e, bp + "prelu2.weight", {1}) ||
+          (ci != co && !require(e, bp + "conv_downsample.weight", {co, ci, 1})))
+        return WS_ERR_INVALID;
+      for (int j = 0; j < 2; ++j) {
+        const std::string bn = bp + "batch_norm" + std::to_string(j + 1) + ".";
+        if (!require(e, bn + "weight", {co}) || !require(e, bn + "bias", {co}) || !require(e, bn + "running_mean", {co}) ||
+            !require(e, bn + "running_var", {co}))
+          return WS_ERR_INVALID;
+        std::vector<float> st(size_t(2) * co);
+        const float *rm = e->host(bn + "running_mean"), *rv = e->host(bn + "running_var");
+        for (int o = 0; o < co; ++o) {
+          st[o] = rm[o];
+          st[co + o] = 1.0f / sqrtf(rv[o] + kBnEps);
+        }
+        e->tas_bn_st[i][j] = upload(e, e->persist, st.data(), st.size());
+        WS_PTR(e->tas_bn_st[i][j]);
+      }
+      ci = co;
+    }
+  }
+  if (!e->dry && hipStreamSynchronize(e->stream) != hipSuccess) {
+    set_err("engine: weight preparation failed on the device");
+    return WS_ERR_LAUNCH;
+  }
+  return WS_OK;
+}
+
 int check_engine(const ws_engine* e, const char* who) {
   if (!e) {
     set_err("%s: null engine", who);
@@ -1524,6 +1942,46 @@ int check_engine(const ws_engine* e, const char* who) {
 }
 
 }  // namespace
+
+// host-facing forward of a Conv-TasNet engine (same contract as ws_engine_separate)
+static int tasnet_separate(ws_engine* e, const float* mix, int R, int T, const void* enroll, int enroll_kind, int enroll_len,
+                           float* est) {
+  const int L = e->tL, stride = L / 2;
+  if (!mix || !enroll || !est || R < 1 || T < 160 || (long long)R * ((T - L) / stride + 1) * 3 * e->tN > 0x7fffffffLL) {
+    set_err("ws_engine_separate: bad arguments (R=%d, T=%d; Conv-TasNet needs T >= 160)", R, T);
+    return WS_ERR_INVALID;
+  }
+  const bool want_wave = e->joint != 0;
+  if ((enroll_kind == WS_ENROLL_WAVE) != want_wave || (enroll_kind != WS_ENROLL_WAVE && enroll_kind != WS_ENROLL_EMBEDDING)) {
+    set_err("ws_engine_separate: a Conv-TasNet engine takes %s (got enrollment kind %d)",
+            want_wave ? "the enrollment waveform (SpEx+ speaker encoder on the shared encoder)" : "fixed embeddings", enroll_kind);
+    return WS_ERR_INVALID;
+  }
+  if (want_wave && ((enroll_len - L) / stride + 1) / 27 < 1) {
+    set_err("ws_engine_separate: enrollment of %d samples is too short for three MaxPool1d(3) stages", enroll_len);
+    return WS_ERR_INVALID;
+  }
+  if (!e->dry && hipSetDevice(e->device) != hipSuccess) {
+    set_err("ws_engine_separate: hipSetDevice(%d) failed", e->device);
+    return WS_ERR_LAUNCH;
+  }
+  e->n_launches = 0;
+  Arena& a = e->work;
+  a.reset();
+  int rc;
+  float* d_mix = a.alloc(size_t(R) * T);
+  float* d_est = a.alloc(size_t(R) * T);
+  float* d_enr = a.alloc(want_wave ? size_t(R) * enroll_len : size_t(R) * e->E);
+  WS_PTR(d_mix && d_est && d_enr);
+  if ((rc = to_device(e, d_mix, mix, size_t(R) * T * 4)) != WS_OK) return rc;
+  if ((rc = to_device(e, d_enr, enroll, (want_wave ? size_t(R) * enroll_len : size_t(R) * e->E) * 4)) != WS_OK) return rc;
+  if ((rc = tasnet_device(e, d_mix, R, T, want_wave ? nullptr : d_enr, want_wave ? d_enr : nullptr, enroll_len, d_est)) != WS_OK)
+    return rc;
+  if ((rc = to_host(e, est, d_est, size_t(R) * T * 4)) != WS_OK) return rc;
+  a.reset();
+  a.consolidate();
+  return WS_OK;
+}
 
 // ---- C ABI ----------------------------------------------------------------------------------------------------
 extern "C" int ws_engine_abi_version(void) { return WS_ENGINE_ABI_VERSION; }
@@ -1587,6 +2045,7 @@ extern "C" long long ws_engine_info(const ws_engine* e, const char* key) {
   if (k == "arena_bytes") return static_cast<long long>(e->work.peak_bytes);
   if (k == "cluster_fallbacks") return e->cluster_fallbacks;
   if (k == "nband") return e->K;
+  if (k == "arch") return e->arch;
   auto it = e->meta.find(k);
   return it == e->meta.end() ? -1 : it->second;
 }
@@ -1595,6 +2054,7 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
                                   int enroll_len, float* est) {
   int rc = check_engine(e, "ws_engine_separate");
   if (rc != WS_OK) return rc;
+  if (e->arch == 1) return tasnet_separate(e, mix, R, T, enroll, enroll_kind, enroll_len, est);
   if (!mix || !enroll || !est || R < 1 || T < 512 || (long long)R * (1 + T / kHop) * 4 * kNBin > 0x7fffffffLL) {
     set_err("ws_engine_separate: bad arguments (R=%d, T=%d; T >= 512)", R, T);
     return WS_ERR_INVALID;

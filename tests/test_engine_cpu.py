@@ -225,8 +225,50 @@ def test_infer_extract_engine_rank_dispatch(tmp_path):
 
 def test_export_refuses_models_the_runtime_does_not_run():
     from wesep_amd.models import get_model
-    with pytest.raises(NotImplementedError):
-        export_engine(get_model("ConvTasNet")(N=32, L=20, B=32, H=64, P=3, X=2, R=1, joint_training=False), "/dev/null")
+    with pytest.raises(NotImplementedError, match="not DPCCN"):
+        export_engine(get_model("DPCCN")(joint_training=False), "/dev/null")
+    for kw, what in ((dict(norm="cLN"), "gLN only"), (dict(causal=True), "causal"), (dict(skip_con=True), "skip"),
+                     (dict(spk_fuse_type="FiLM"), "concatConv only"),
+                     (dict(encoder_type="Deep", decoder_type="Deep"), "Multi only")):
+        with pytest.raises(NotImplementedError, match=what):
+            export_engine(get_model("ConvTasNet")(N=32, L=20, B=32, H=64, P=3, X=2, R=1, joint_training=False, **kw),
+                          "/dev/null")
+
+
+@needs_no_gpu
+@pytest.mark.parametrize("joint", [False, True], ids=["fixed-embeddings", "spex-plus"])
+def test_dry_run_launch_plan_convtasnet(tmp_path, joint):
+    """Conv-TasNet / SpEx+ in the native runtime (arch 1): container, geometry read back, and the whole launch plan
+    through the real library's argument validation for several lengths and row counts."""
+    from wesep_amd.models import get_model
+    kw = dict(N=256, L=20, B=64, H=128, P=3, X=3, R=2, spk_emb_dim=256, joint_training=joint)
+    m = get_model("ConvTasNet")(**kw)
+    path = str(tmp_path / "t.wsw")
+    n, _ = export_engine(m, path)
+    assert n == sum(1 for k, v in m.state_dict().items() if torch.is_floating_point(v) and not k.startswith("pred_linear."))
+    eng = E.Engine(path, dry_run=True)
+    assert eng.info("arch") == 1 and eng.info("N") == 256 and eng.info("X") == 3 and eng.info("R") == 2
+    assert eng.info("spk_emb_dim") == 256 and eng.info("joint_training") == int(joint)
+    counts = set()
+    for R, T in ((2, 16000), (1, 12345), (4, 4000), (2, 160)):
+        if joint:
+            enroll, kind = np.zeros((R, 9000), np.float32), E.ENROLL_WAVE
+        else:
+            enroll, kind = np.zeros((R, 256), np.float32), E.ENROLL_EMBEDDING
+        est = eng.separate(np.ones((R, T), np.float32), enroll, kind)
+        assert est.shape == (R, T) and not est.any()
+        counts.add(eng.info("n_launches"))
+        assert eng.info("arena_bytes") > 0
+    assert len(counts) == 1
+    with pytest.raises(E.WesepHipError, match="T >= 160"):
+        eng.separate(np.zeros((2, 100), np.float32), np.zeros((2, 256), np.float32), E.ENROLL_EMBEDDING)
+    wrong = (np.zeros((2, 256), np.float32), E.ENROLL_EMBEDDING) if joint else (np.zeros((2, 9000), np.float32), E.ENROLL_WAVE)
+    with pytest.raises(E.WesepHipError, match="Conv-TasNet engine takes"):
+        eng.separate(np.zeros((2, 4000), np.float32), *wrong)
+    if joint:
+        with pytest.raises(E.WesepHipError, match="too short"):
+            eng.separate(np.zeros((2, 4000), np.float32), np.zeros((2, 200), np.float32), E.ENROLL_WAVE)
+    eng.close()
 
 
 def _write_wav(path, x, sr=16000):

@@ -218,3 +218,48 @@ def test_engine_reads_no_uninitialised_arena_memory(tmp_path, monkeypatch):
         assert np.isfinite(got).all()
         assert np.array_equal(got, want)
     eng2.close()
+
+
+@pytest.mark.parametrize("joint", [False, True], ids=["fixed-embeddings", "spex-plus"])
+def test_convtasnet_engine_matches_python_model(tmp_path, joint):
+    """Conv-TasNet / SpEx+ launch plan of the native runtime (arch 1) against the Python module tree in eval mode on
+    the same device: the same kernels in the same order, so agreement to rounding.  The engine returns the first of
+    the three estimates, zero-extended to the mixture length."""
+    from wesep_amd.models import get_model
+    d = _cuda()
+    torch.manual_seed(21 + int(joint))
+    kw = dict(N=256, L=20, B=128, H=256, P=3, X=4, R=2, spk_emb_dim=256, joint_training=joint)
+    model = get_model("ConvTasNet")(**kw)
+    with torch.no_grad():                                   # non-trivial affine parameters and running statistics
+        for name, p in model.named_parameters():
+            if name.endswith(("norm_1.weight", "norm_2.weight", "lnorm1.weight", "lnorm2.weight", "ln.weight",
+                              "batch_norm1.weight", "batch_norm2.weight", "aux_enc3.0.weight")):
+                p.uniform_(0.5, 1.5)
+            elif name.endswith(("norm_1.bias", "norm_2.bias", "lnorm1.bias", "lnorm2.bias", "ln.bias", "batch_norm1.bias",
+                                "batch_norm2.bias", "aux_enc3.0.bias")):
+                p.normal_(0.0, 0.1)
+        for name, buf in model.named_buffers():
+            if name.endswith("running_mean"):
+                buf.normal_(0.0, 0.2)
+            elif name.endswith("running_var"):
+                buf.uniform_(0.5, 1.5)
+    path = str(tmp_path / "t.wsw")
+    export_engine(model, path)
+    eng = E.Engine(path)
+    assert eng.info("arch") == 1
+    model = model.to(d).eval()
+    g = torch.Generator().manual_seed(3)
+    for R, T in ((2, 16000), (3, 12345), (1, 4000), (2, 16000)):
+        wav = 0.1 * torch.randn(R, T, generator=g)
+        if joint:
+            enroll, kind = 0.1 * torch.randn(R, 9000 + 37 * R, generator=g), E.ENROLL_WAVE
+        else:
+            enroll, kind = torch.randn(R, 256, generator=g), E.ENROLL_EMBEDDING
+        est = eng.separate(wav.numpy(), enroll.numpy(), kind)
+        with torch.no_grad():
+            ref = model(wav.to(d), enroll.to(d))[0]
+        n = ref.shape[-1]
+        assert n <= T and rel(est[:, :n], ref) < 1e-5, (R, T, rel(est[:, :n], ref))
+        assert not est[:, n:].any()
+    assert eng.info("n_launches") > 0 and eng.info("arena_bytes") > 0
+    eng.close()

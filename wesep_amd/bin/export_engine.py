@@ -1,4 +1,4 @@
-"""Write a pBSRNN checkpoint as the flat weight container of the native runtime (include/wesep_engine.h,
+"""Write a pBSRNN or Conv-TasNet / SpEx+ checkpoint as the flat weight container of the native runtime (include/wesep_engine.h,
 runtime/engine.cc) -- the counterpart of the reference's `wesep/bin/export_jit.py` (TorchScript archive for the
 LibTorch runtime).
 
@@ -85,10 +85,49 @@ def write_container(path, meta, state):
     return len(names), data.size
 
 
+def tasnet_meta(model):
+    """Conv-TasNet / SpEx+ (arch 1): the runtime's launch plan covers the shipped configuration -- Multi encoder and
+    decoder, gLN, non-causal, no skip connection, concatConv multi-fusion -- with fixed embeddings or the SpEx+ speaker
+    encoder on the enrollment waveform.  Everything else is refused by name."""
+    sep = model.separation
+    first = sep.separation[0]
+    problems = []
+    if model.encoder_type != "Multi" or model.decoder_type != "Multi":
+        problems.append(f"encoder / decoder type {model.encoder_type} / {model.decoder_type} (Multi only)")
+    if sep.spk_fuse_type != "concatConv":
+        problems.append(f"spk_fuse_type {sep.spk_fuse_type!r} (concatConv only)")
+    if model.norm_type != "gLN":
+        problems.append(f"norm {model.norm_type!r} (gLN only)")
+    if getattr(first, "causal", False):
+        problems.append("causal blocks")
+    if any(getattr(b, "skip_con", False) for m in sep.separation if hasattr(m, "separation") for b in m.separation):
+        problems.append("skip connections")
+    if model.joint_training and model.spk_feat:
+        problems.append("a wespeaker encoder on fbank enrollment (the SpEx+ encoder on the waveform is what the plan has)")
+    if problems:
+        raise NotImplementedError("export_engine: Conv-TasNet with " + "; ".join(problems) + " has no launch plan in the "
+                                  "native runtime")
+    enc = model.encoder
+    blocks = sep.separation[1].separation
+    return {
+        "arch": 1, "sample_rate": 16000, "N": enc.encoder_1d_short.out_channels, "L": enc.L1,
+        "B": enc.proj.out_channels, "H": first.conv1x1.out_channels, "P": first.dconv.kernel_size[0],
+        "X": len(blocks) + 1, "R": len(sep.separation) // 2,
+        "spk_emb_dim": first.conv1x1.in_channels - enc.proj.out_channels,
+        "use_spk_transform": int(not isinstance(model.spk_transform, torch.nn.Identity)),
+        "joint_training": int(model.joint_training), "spk_feat": 0,
+    }
+
+
 def export_engine(model, path):
-    """model: a wesep_amd (or reference) `BSRNN` instance -> container at `path`; returns (n_tensors, n_floats)."""
-    if type(model).__name__ not in ("BSRNN", "BSRNN_Multi"):
-        raise NotImplementedError("export_engine: the native runtime runs pBSRNN (BSRNN / BSRNN_Multi checkpoints)")
+    """model: a wesep_amd (or reference) `BSRNN` / `BSRNN_Multi` / `ConvTasNet` instance -> container at `path`;
+    returns (n_tensors, n_floats)."""
+    name = type(model).__name__
+    if name == "ConvTasNet":
+        return write_container(path, tasnet_meta(model), model.state_dict())
+    if name not in ("BSRNN", "BSRNN_Multi"):
+        raise NotImplementedError("export_engine: the native runtime runs pBSRNN (BSRNN / BSRNN_Multi) and Conv-TasNet / "
+                                  f"SpEx+ checkpoints, not {name}")
     return write_container(path, engine_meta(model), model.state_dict())
 
 
