@@ -321,3 +321,22 @@ def test_separate_main_dry_run_and_argument_errors(tmp_path):
     assert r.returncode == 1 and "sample rate" in r.stderr
     r = subprocess.run([exe, "--wav_scp", str(scp), "--model", model], capture_output=True, text=True)
     assert r.returncode == 1 and "Invalid output path" in r.stderr
+
+
+@needs_no_gpu
+def test_separate_main_dry_run_with_a_spex_plus_container(tmp_path):
+    """The reference tool's interface on a Conv-TasNet / SpEx+ model file: mixture + two enrollment utterances, the
+    enrollment waveforms go through the shared encoder and the SpEx+ speaker encoder inside the engine."""
+    from wesep_amd.models import get_model
+    exe = os.path.join(ROOT, "runtime", "separate_main")
+    model = str(tmp_path / "spex.wsw")
+    export_engine(get_model("ConvTasNet")(N=256, L=20, B=64, H=128, P=3, X=3, R=2, spk_emb_dim=256, joint_training=True),
+                  model)
+    rng = np.random.default_rng(1)
+    for name, n in (("mix", 24000), ("e1", 32000), ("e2", 40000)):
+        _write_wav(tmp_path / f"{name}.wav", rng.integers(-3000, 3000, n))
+    scp = tmp_path / "wav.scp"
+    scp.write_text(f"utt1 {tmp_path}/mix.wav {tmp_path}/e1.wav {tmp_path}/e2.wav\n")
+    r = subprocess.run([exe, "--wav_scp", str(scp), "--model", model, "--dry_run"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "process: utt1" in r.stdout and "[dry run]" in r.stdout
