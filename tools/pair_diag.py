@@ -1,7 +1,7 @@
 """Diagnosis of the pair BPTT kernel (lstm_pair.hip) on the MI355X: where does its d(gates) differ from the streaming
 kernel's, and does every hand-off deliver what was sent?
 
-    python tools/pair_diag.py [--rows 2] [--frames 1,2,3,4,8,70] [--dbg 0,32,64]
+    python tools/pair_diag.py [--rows 2] [--frames 1,2,3,4,8,70] [--dbg 0,64]
 
 For each number of steps L: the blocked forward (16-sequence kernel), then the streaming BPTT and the pair BPTT on the
 same state.  Prints the relative difference per (direction, time step) and -- for the worst step -- per
@@ -62,7 +62,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=2)
     ap.add_argument("--frames", default="1,2,3,4,8,70")
-    ap.add_argument("--dbg", default="0,32,64")
+    ap.add_argument("--dbg", default="0,64")
     ap.add_argument("--ts", type=int, default=0, help="rows: print the in-kernel phase stamps (variant 2048) at that size")
     a = ap.parse_args()
     if a.ts:

@@ -86,7 +86,8 @@ __device__ __noinline__ void pair_timed_out(unsigned* tword, unsigned* status) {
 #define PAIR_LDSK 8   // k-steps whose lo fragments stay in LDS (the rest is streamed)
 
 // V: compile-time variant bits (the step body stays free of run-time branches): 8 = test build that forces a timeout
-// in pair 0 at step 2; probes: 4 = no weight reloads, 32 = no wave priorities
+// in pair 0 at step 2 (the bisect builds of round 3 -- no reloads, no priorities, cell backward only, no hand-off, no
+// MFMA loop -- are gone from the library; profiles/r03_store_hazard.md records what they found)
 // variant 2048 (diagnosis): s_memtime stamps of pair 0 / member 0, waves 0 (X) and 4 (O), into dbg_buf:
 //   dbg_buf[((step * 2 + role) * 8 + k)] as 64-bit ticks; k: 0 loop top, 1 cell backward done, 2 past S1, 3 MFMA loop done,
 //   4 X: published + drained + flagged / O: partial in LDS, 5 X: next step's loads requested, 6 X: partner's flag seen,
@@ -219,19 +220,12 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       emit(pg, 2);
       emit(po, 3);
     }
-    if constexpr (V & 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bisect: stores drained before the MFMAs
     TS(1);
     __syncthreads();  // S1: the d(gates) image of this step is complete; rec is consumed
     TS(2);
 
     // ---- partial dh^T [32 units of this wave's m-tile][32 sequences] = W_hh^T slice * dgates^T ----------------------
-    if constexpr (V & 128) {  // bisect build: the cell backward alone (no MFMA, no hand-off)
-      load_step(tn, 0);
-      load_step(tn, 1);
-      __syncthreads();
-      continue;
-    }
-    if (xrole && !(V & 32)) __builtin_amdgcn_s_setprio(1);
+    if (xrole) __builtin_amdgcn_s_setprio(1);
     bf16x8 wl[2][PAIR_RING];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -244,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < ((V & 1024) ? 0 : NCH); ++ch) {   // (bisect build 1024: no MFMA loop)
+    for (int ch = 0; ch < NCH; ++ch) {
       const int s = ch & 1;
 #pragma unroll
       for (int f = 0; f < PAIR_RING; ++f) {
@@ -262,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
           acc0 = mfma32(wh[ks], bl, acc0);
         }
       }
-      if (ch >= CH0 && ch + 2 < NCH && !(V & 4)) {
+      if (ch >= CH0 && ch + 2 < NCH) {
 #pragma unroll
         for (int f = 0; f < PAIR_RING; ++f) wl[s][f] = wload(wrs, wlane + f * 1024, zo + (ch + 2) * (PAIR_RING * 1024));
       }
@@ -277,13 +271,6 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
     for (int q4 = 0; q4 < 4; ++q4)
       sum[q4] = f32x4{acc0[4 * q4] + acc1[4 * q4], acc0[4 * q4 + 1] + acc1[4 * q4 + 1], acc0[4 * q4 + 2] + acc1[4 * q4 + 2],
                       acc0[4 * q4 + 3] + acc1[4 * q4 + 3]};
-    if constexpr (V & 512) {  // bisect build: MFMA loop but no hand-off
-      mine[0] = sum[0], mine[1] = sum[1];
-      load_step(tn, 0);
-      load_step(tn, 1);
-      __syncthreads();
-      continue;
-    }
     if (xrole) {
       __builtin_amdgcn_s_setprio(0);
       // publish the partial of the PARTNER's units: write-through 16-byte stores, drain, one flag per wave
@@ -373,17 +360,11 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)npair * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_pair: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
-  switch (a->dbg & (4 | 8 | 32 | 128 | 256 | 512 | 1024 | 2048)) {
-    case 2048: hipLaunchKernelGGL(lstm_bwd_pair_kernel<2048>, dim3(grid), dim3(512), 0, s, *a); break;
-    case 256: hipLaunchKernelGGL(lstm_bwd_pair_kernel<256>, dim3(grid), dim3(512), 0, s, *a); break;
-    case 512: hipLaunchKernelGGL(lstm_bwd_pair_kernel<512>, dim3(grid), dim3(512), 0, s, *a); break;
-    case 1024: hipLaunchKernelGGL(lstm_bwd_pair_kernel<1024>, dim3(grid), dim3(512), 0, s, *a); break;
-    case 128: hipLaunchKernelGGL(lstm_bwd_pair_kernel<128>, dim3(grid), dim3(512), 0, s, *a); break;
+  switch (a->dbg & (8 | 2048)) {
     case 0: hipLaunchKernelGGL(lstm_bwd_pair_kernel<0>, dim3(grid), dim3(512), 0, s, *a); break;
-    case 8: hipLaunchKernelGGL(lstm_bwd_pair_kernel<8>, dim3(grid), dim3(512), 0, s, *a); break;
-    case 4: hipLaunchKernelGGL(lstm_bwd_pair_kernel<4>, dim3(grid), dim3(512), 0, s, *a); break;
-    case 32: hipLaunchKernelGGL(lstm_bwd_pair_kernel<32>, dim3(grid), dim3(512), 0, s, *a); break;
-    default: WS_REQUIRE(false, "ws_lstm_bwd_pair: dbg bits 4, 8, 32 are exclusive");
+    case 8: hipLaunchKernelGGL(lstm_bwd_pair_kernel<8>, dim3(grid), dim3(512), 0, s, *a); break;       // tests: forced timeout
+    case 2048: hipLaunchKernelGGL(lstm_bwd_pair_kernel<2048>, dim3(grid), dim3(512), 0, s, *a); break;  // cycle stamps
+    default: WS_REQUIRE(false, "ws_lstm_bwd_pair: dbg bits 8 and 2048 are exclusive");
   }
   ws_prof_end(WS_PROF_LSTM_BWD, s);
   return ws_check_launch("ws_lstm_bwd_pair");
