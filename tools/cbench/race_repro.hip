@@ -197,6 +197,12 @@ ASM_CHAIN(o_pk_mul, "v_pk_mul_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]", f32x
 ASM_CHAIN(o_pk_fma, "v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1]", f32x2_t)
 ASM_CHAIN(o_pk_fma2, "v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,0]", f32x2_t)
 ASM_CHAIN(o_pk_mov, "v_pk_mov_b32 %0, %0, %0 op_sel:[1,0]", f32x2_t)
+// the only operand selection in RCCL 2.26's gfx950 fp32 reduction kernels (FuncPreMulSum<float> = ncclAvg / premul-sum;
+// FuncSum<float> has plain v_pk_add_f32 only): the scalar factor's low half broadcast to both lanes through src0
+ASM_CHAIN(r_pk_fma, "v_pk_fma_f32 %0, %1, %0, %2 op_sel_hi:[0,1,1]", f32x2_t)
+// and the mirror images of the failing form, for the record: selection on src0, and src1 low half broadcast
+ASM_CHAIN(o_pk_add0, "v_pk_add_f32 %0, %2, %0 op_sel:[1,0] op_sel_hi:[0,1]", f32x2_t)
+ASM_CHAIN(o_pk_mul_b, "v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]", f32x2_t)
 // the same with the constant operand in an SGPR (pair): what hipcc emits for a uniform twiddle / scale factor
 #define ASM_CHAIN_S(NAME, INSTR, T)                                                                                   \
   __global__ void __launch_bounds__(256) NAME(const float2* __restrict__ in, const float2*, float2* __restrict__ out, \
@@ -405,7 +411,7 @@ int main(int argc, char** argv) {
   const int trials = atoi(get("--trials", "20").c_str());
   const std::string mask = get("--mask", "none"), aggr = get("--aggr", "b2p");
   const std::string victims = get("--victims", "fft512,fft_priv,lds_perm,lds_pkadd,lds_imad,fma_chain,pk_chain,a_pk_fma,a_pk_mul,a_pk_add,a_fma_f64,"
-                                   "a_fma_f32,s_pk_fma,s_pk_mul,s_pk_add,s_fma_f64,s_fma_f32,o_pk_add,o_pk_mul,o_pk_fma,o_pk_fma2,o_pk_mov,mf_s_n0,mf_s_n1,mf_s_n2,mf_s_n4,mf_s_n8,mf_v_n0,mf_v_n1,ring_step,copy");
+                                   "a_fma_f32,s_pk_fma,s_pk_mul,s_pk_add,s_fma_f64,s_fma_f32,o_pk_add,o_pk_mul,o_pk_fma,o_pk_fma2,o_pk_mov,r_pk_fma,o_pk_add0,o_pk_mul_b,mf_s_n0,mf_s_n1,mf_s_n2,mf_s_n4,mf_s_n8,mf_v_n0,mf_v_n1,ring_step,copy");
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, 0));
   const int ncu = prop.multiProcessorCount;
@@ -517,7 +523,7 @@ int main(int argc, char** argv) {
   const Vic all[] = {{"fft512", 2048}, {"fft_priv", 1024}, {"lds_perm", 2048}, {"fma_chain", 2048}, {"lds_pkadd", 2048}, {"lds_imad", 2048},
                      {"pk_chain", 2048},  {"a_pk_fma", 2048},  {"a_pk_mul", 2048}, {"a_pk_add", 2048},
                      {"a_fma_f64", 2048}, {"a_fma_f32", 2048}, {"s_pk_fma", 2048},  {"s_pk_mul", 2048},
-                     {"s_pk_add", 2048},  {"s_fma_f64", 2048}, {"s_fma_f32", 2048}, {"o_pk_add", 2048}, {"o_pk_mul", 2048}, {"o_pk_fma", 2048}, {"o_pk_fma2", 2048}, {"o_pk_mov", 2048}, {"mf_s_n0", 2048}, {"mf_s_n1", 2048}, {"mf_s_n2", 2048}, {"mf_s_n4", 2048}, {"mf_s_n8", 2048}, {"mf_v_n0", 2048}, {"mf_v_n1", 2048}, {"ring_step", 32},
+                     {"s_pk_add", 2048},  {"s_fma_f64", 2048}, {"s_fma_f32", 2048}, {"o_pk_add", 2048}, {"o_pk_mul", 2048}, {"o_pk_fma", 2048}, {"o_pk_fma2", 2048}, {"o_pk_mov", 2048}, {"r_pk_fma", 2048}, {"o_pk_add0", 2048}, {"o_pk_mul_b", 2048}, {"mf_s_n0", 2048}, {"mf_s_n1", 2048}, {"mf_s_n2", 2048}, {"mf_s_n4", 2048}, {"mf_s_n8", 2048}, {"mf_v_n0", 2048}, {"mf_v_n1", 2048}, {"ring_step", 32},
                      {"copy", 1024}};
   for (const Vic& v : all) {
     if (("," + victims + ",").find(std::string(",") + v.name + ",") == std::string::npos) continue;
@@ -550,6 +556,9 @@ int main(int argc, char** argv) {
       if (n == "o_pk_fma") hipLaunchKernelGGL(o_pk_fma, dim3(v.grid), dim3(256), 0, s1, vin, tw, out, nrows);
       if (n == "o_pk_fma2") hipLaunchKernelGGL(o_pk_fma2, dim3(v.grid), dim3(256), 0, s1, vin, tw, out, nrows);
       if (n == "o_pk_mov") hipLaunchKernelGGL(o_pk_mov, dim3(v.grid), dim3(256), 0, s1, vin, tw, out, nrows);
+      if (n == "r_pk_fma") hipLaunchKernelGGL(r_pk_fma, dim3(v.grid), dim3(256), 0, s1, vin, tw, out, nrows);
+      if (n == "o_pk_add0") hipLaunchKernelGGL(o_pk_add0, dim3(v.grid), dim3(256), 0, s1, vin, tw, out, nrows);
+      if (n == "o_pk_mul_b") hipLaunchKernelGGL(o_pk_mul_b, dim3(v.grid), dim3(256), 0, s1, vin, tw, out, nrows);
       if (n == "pk_chain") hipLaunchKernelGGL(pk_chain, dim3(v.grid), dim3(256), 0, s1, vin, tw, out, nrows);
       if (n == "fma_chain") hipLaunchKernelGGL(fma_chain, dim3(v.grid), dim3(256), 0, s1, vin, tw, out, nrows);
       if (n == "ring_step")
