@@ -389,8 +389,8 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   // 1002 vs 502 workgroups (4 vs 2 rounds): 2.70 -> 2.43 ms; TF-GridNet intra path, 752 vs 376 (3 vs 2 rounds): 4.08 -> 4.64.
   // WS_FUSED_SEQS=32|64 overrides (diagnostics; both kernels give the same bits)
   const char* env = getenv("WS_FUSED_SEQS");
-  int cus = 256;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+  static int cus = 0;      // same part on every device of a node; queried once
+  if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 256;
   const int rounds32 = (2 * ntile + cus - 1) / cus, rounds64 = (2 * ((ntile + 1) / 2) + cus - 1) / cus;
   const bool wide = env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
   ws_prof_begin(WS_PROF_LSTM_FWD, s);

@@ -350,9 +350,8 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->dhcat && a->wpack && a->xchg && a->flags, "ws_lstm_bwd_pair: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_bwd_pair: nseq and L must be positive");
   const int npair = 2 * ((a->nseq + SQ - 1) / SQ);
-  int dev = 0, cus = 0;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  static int cus = 0;      // same part on every device of a node; queried once
+  if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 0;
   WS_REQUIRE(2 * npair <= cus, "ws_lstm_bwd_pair: %d workgroups must be co-resident but the device has %d CUs", 2 * npair,
              cus);
   const int grid = 16 * ((npair + 7) / 8);
