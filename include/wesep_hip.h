@@ -597,7 +597,8 @@ int ws_inorm_bwd_apply(const float* y, const float* dy, const float* stats, cons
 int ws_avgpool_fwd(const float* x, int B, int H, int W, int C, int sz, float* y, void* stream);
 int ws_avgpool_bwd(const float* dy, int B, int H, int W, int C, int sz, float* dx, void* stream);
 int ws_bilinear_fwd(const float* x, int B, int h, int w, int H, int W, int C, float* y, void* stream);
-int ws_bilinear_bwd(const float* dy, int B, int h, int w, int H, int W, int C, float* dx, void* stream);
+/* tmp: scratch of B * H * w * C floats (the adjoint runs as two separable passes: destination columns, then rows)   */
+int ws_bilinear_bwd(const float* dy, int B, int h, int w, int H, int W, int C, float* tmp, float* dx, void* stream);
 /* SpeakerFuseLayer multiply (mode 0) / additive (mode 1) on [B][T][F][C] with s [B][F] (speaker.py:102-121);
  * backward: dx, and ds [B][F] = sum over (t, c) of dy * x (mode 0) or dy (mode 1)                             */
 int ws_scale_bf_fwd(const float* x, const float* s, int B, int T, int F, int C, int mode, float* y, void* stream);

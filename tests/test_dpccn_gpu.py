@@ -233,3 +233,26 @@ def test_baseline_config3_dpccn_with_joint_resnet34_vs_oracle_chain(monkeypatch)
     print(f"config 3 (DPCCN + joint ResNet34, R=4 x 4 s): est rel {rel(est, ref):.2e}, "
           f"dloss {abs(loss.item() - loss_o.item()):.2e} dB, {len(want)} gradients, worst rel-L2 {worst:.2e} ({wname})")
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("h,w,H,W", [(7, 8, 250, 257), (15, 16, 250, 257), (3, 5, 13, 11), (1, 1, 9, 7), (62, 64, 250, 257)])
+def test_bilinear_adjoint_at_the_pooling_branch_scales(h, w, H, W):
+    """The separable two-pass adjoint of nn.Upsample(size, mode='bilinear') (DPCCN's pooled branches upsample by 4 .. 32,
+    dpccn.py:257-265) against autograd of F.interpolate, including sizes that are not multiples of each other."""
+    from wesep_amd import dev
+    d = _cuda()
+    B, C = 2, 8
+    g = torch.Generator().manual_seed(h * 1000 + W)
+    dy = torch.randn(B * H * W, C, generator=g)
+    x = torch.zeros(B, C, h, w, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.interpolate(x, size=(H, W), mode="bilinear", align_corners=False)
+    y.backward(dy.double().view(B, H, W, C).permute(0, 3, 1, 2))
+    want = x.grad.permute(0, 2, 3, 1).reshape(B * h * w, C)
+    outs = []
+    for _ in range(2):
+        got = torch.full((B * h * w, C), float("nan"), device=d)
+        dev.bilinear_bwd(dy.to(d), B, h, w, H, W, C, got)
+        outs.append(got)
+    assert torch.equal(outs[0], outs[1])
+    err = float((outs[0].double().cpu() - want).norm() / want.norm())
+    assert err < 5e-6, err                      # fp32 source coordinates at non-integer scales (2.2e-6 at 250 / 62)

@@ -198,7 +198,7 @@ _SIGS = {
     "ws_avgpool_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "ws_avgpool_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "ws_bilinear_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
-    "ws_bilinear_bwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_bilinear_bwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ws_scale_bf_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "ws_scale_bf_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ws_softmax_rows_fwd": (_i, [_p, _ll, _i, C.c_float, _p, _p]),

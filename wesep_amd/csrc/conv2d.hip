@@ -643,13 +643,48 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int B, int h, i
   }
 }
 
-// adjoint as a gather: one thread per (source pixel, channel quad) walks every destination pixel (deterministic;
-// the source grids are tiny: H/sz x W/sz)
-__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int B, int h, int w, int H, int W, int C,
-                                    float* __restrict__ dx) {
+// adjoint as two separable gathers (deterministic): pass 1 contracts the destination columns of every destination row,
+//   tmp[b][Y][xs][c] = sum_X wx(X, xs) * dy[b][Y][X][c],
+// pass 2 the destination rows, dx[b][ys][xs][c] = sum_Y wy(Y, ys) * tmp[b][Y][xs][c].  Round 2 had one thread per SOURCE
+// pixel walking its whole (2 * scale + 3)^2 support: for the 32x pooling branch of DPCCN that is 3 584 threads x 4 489
+// pixels (6 ms per call); here pass 1 has B * H * w * C / 4 threads and either pass walks 2 * scale + 3 taps.
+__device__ __forceinline__ void bl_window(int s, float scale, int N, int& lo, int& hi) {
+  // destination indices whose two source taps can include s (widened by one; the exact weight test decides)
+  lo = max(0, (int)floorf(((float)s - 0.5f) / scale - 0.5f) - 1);
+  hi = min(N - 1, (int)ceilf(((float)s + 1.5f) / scale - 0.5f) + 1);
+}
+
+__global__ void bilinear_bwd_rows_kernel(const float* __restrict__ dy, int B, int w, int H, int W, int C,
+                                         float* __restrict__ tmp) {
+  const int c4n = C >> 2;
+  const long long total = (long long)B * H * w * c4n;
+  const float sw = (float)w / (float)W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    long long q = i / c4n;
+    const int xs = (int)(q % w);
+    const long long bY = q / w;                       // b * H + Y
+    int Xlo, Xhi;
+    bl_window(xs, sw, W, Xlo, Xhi);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int X = Xlo; X <= Xhi; ++X) {
+      int x0, x1;
+      float lx;
+      bl_src(X, sw, w, x0, x1, lx);
+      const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+      if (wx == 0.f) continue;
+      acc += *reinterpret_cast<const f32x4*>(dy + (bY * W + X) * C + c) * wx;
+    }
+    *reinterpret_cast<f32x4*>(tmp + i * 4) = acc;
+  }
+}
+
+__global__ void bilinear_bwd_cols_kernel(const float* __restrict__ tmp, int B, int h, int w, int H, int C,
+                                         float* __restrict__ dx) {
   const int c4n = C >> 2;
   const long long total = (long long)B * h * w * c4n;
-  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const float sh = (float)h / (float)H;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % c4n) * 4;
@@ -657,28 +692,16 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int B, int h, 
     const int xs = (int)(q % w);
     q /= w;
     const int ys = (int)(q % h), b = (int)(q / h);
+    int Ylo, Yhi;
+    bl_window(ys, sh, H, Ylo, Yhi);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    // destination pixels whose two source taps can include (ys, xs): source coordinate in (ys - 1, ys + 1), i.e.
-    // Y in ((ys - 0.5) / sh - 0.5, (ys + 1.5) / sh - 0.5) -- widened by one pixel; the exact weight test below decides
-    // (round 1 walked all H x W destination pixels per thread: 12 ms per call at the DPCCN recipe size)
-    const int Ylo = max(0, (int)floorf(((float)ys - 0.5f) / sh - 0.5f) - 1);
-    const int Yhi = min(H - 1, (int)ceilf(((float)ys + 1.5f) / sh - 0.5f) + 1);
-    const int Xlo = max(0, (int)floorf(((float)xs - 0.5f) / sw - 0.5f) - 1);
-    const int Xhi = min(W - 1, (int)ceilf(((float)xs + 1.5f) / sw - 0.5f) + 1);
     for (int Y = Ylo; Y <= Yhi; ++Y) {
       int y0, y1;
       float ly;
       bl_src(Y, sh, h, y0, y1, ly);
       const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
       if (wy == 0.f) continue;
-      for (int X = Xlo; X <= Xhi; ++X) {
-        int x0, x1;
-        float lx;
-        bl_src(X, sw, w, x0, x1, lx);
-        const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
-        if (wx == 0.f) continue;
-        acc += *reinterpret_cast<const f32x4*>(dy + (((long long)b * H + Y) * W + X) * C + c) * (wy * wx);
-      }
+      acc += *reinterpret_cast<const f32x4*>(tmp + (((long long)b * H + Y) * w + xs) * C + c) * wy;
     }
     *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
   }
@@ -691,10 +714,14 @@ extern "C" int ws_bilinear_fwd(const float* x, int B, int h, int w, int H, int W
   return ws_check_launch("ws_bilinear_fwd");
 }
 
-extern "C" int ws_bilinear_bwd(const float* dy, int B, int h, int w, int H, int W, int C, float* dx, void* stream) {
-  WS_REQUIRE(dy && dx && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ws_bilinear_bwd: bad args");
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(cv_blocks((long long)B * h * w * (C / 4))), dim3(64), 0,
-                     (hipStream_t)stream, dy, B, h, w, H, W, C, dx);
+extern "C" int ws_bilinear_bwd(const float* dy, int B, int h, int w, int H, int W, int C, float* tmp, float* dx,
+                               void* stream) {
+  WS_REQUIRE(dy && dx && tmp && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0,
+             "ws_bilinear_bwd: bad args (tmp: B * H * w * C floats of scratch)");
+  hipLaunchKernelGGL(bilinear_bwd_rows_kernel, dim3(cv_blocks((long long)B * H * w * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, dy, B, w, H, W, C, tmp);
+  hipLaunchKernelGGL(bilinear_bwd_cols_kernel, dim3(cv_blocks((long long)B * h * w * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, tmp, B, h, w, H, C, dx);
   return ws_check_launch("ws_bilinear_bwd");
 }
 

@@ -1142,7 +1142,8 @@ def bilinear_fwd(x, B: int, h: int, w: int, H: int, W: int, Cc: int, y):
 def bilinear_bwd(dy, B: int, h: int, w: int, H: int, W: int, Cc: int, dx):
     _chk(dy, "dy")
     _chk(dx, "dx")
-    _call("ws_bilinear_bwd", _p(dy), B, h, w, H, W, Cc, _p(dx))
+    tmp = torch.empty(B * H * w * Cc, device=dy.device, dtype=torch.float32)      # row pass of the separable adjoint
+    _call("ws_bilinear_bwd", _p(dy), B, h, w, H, W, Cc, _p(tmp), _p(dx))
 
 
 def scale_bf_fwd(x, s, B: int, T: int, Fq: int, Cc: int, mode: int, y):
