@@ -92,3 +92,55 @@ def test_cluster_launch_beside_a_busy_stream_is_correct():
             assert rel(busy, quiet) < 4e-5
         dev.poll_cluster_status(d, block=True)
     del a2
+
+
+def test_pair_bptt_beside_busy_streams_is_bit_identical():
+    """The pair BPTT (lstm_pair.hip) has NO fall-back: its 128 workgroups wait for their partners with bounded polls, and a
+    poll that expires poisons the launch.  In the training step it always runs beside the weight-gradient stream, and under
+    DDP beside RCCL's kernels as well.  Here: the headline launch geometry (1024 sequences x 70 steps) repeated while (a) a
+    second stream runs chip-filling GEMMs and (b) a third runs the library's own gemm_b2p -- every launch must finish
+    without a timeout and be bit-identical to the launch made on an idle GPU."""
+    from wesep_amd import dev, _lib as L
+    from wesep_amd.functional import _view_maps
+    d = _cuda()
+    R, K, Tf, N, H = 32, 32, 70, 128, 256
+    P = R * K * Tf
+    geo, smap, seq, _ = _view_maps("time", R, K, Tf, N)
+    g = torch.Generator().manual_seed(7)
+    nb = dev.bl_num_blocks(seq)
+    whf = (0.06 * torch.randn(4 * H, H, generator=g)).to(d)
+    whr = (0.06 * torch.randn(4 * H, H, generator=g)).to(d)
+    gates = dev.to_blocked(torch.randn(P, 8 * H, generator=g).to(d), seq)
+    pf, pb = torch.empty(L.LSTM_PACK_FLOATS, device=d), torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack(whf, whr, pf, pb, L.LSTM_BF16X3_BLK)
+    cbuf, hcat = torch.zeros(nb, 2 * H // 4, 32, 4, device=d), torch.zeros(nb, 2 * H // 4, 32, 4, device=d)
+    dev.lstm_fwd(gates, cbuf, hcat, pf, seq, L.LSTM_BF16X3_BLK)
+    dh = dev.to_blocked((1e-2 * torch.randn(P, 2 * H, generator=g)).to(d), seq)
+    pp = torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack_pair(whf, whr, pp)
+    status = torch.zeros(1, device=d, dtype=torch.int32)
+    ref = gates.clone()
+    assert int(dev.lstm_bwd_pair(ref, cbuf, dh, pp, seq, status=status).item()) == 0
+    torch.cuda.synchronize()
+    # aggressors: a torch GEMM stream and the library's gemm_b2p (the kernel of profiles/r03_kernel_race.md)
+    a = torch.randn(6144, 6144, device=d)
+    An = torch.randn(8192 * 41 * 256, device=d)
+    wp = torch.empty(128 * 256, device=d)
+    dev.pack_w(0.05 * torch.randn(128, 256, device=d), 128, 256, 256, wp, order=1)
+    Cb = torch.empty(8192 * 41, 128, device=d)
+    bseq = dev.SeqMap(nseq=8192, div=1 << 30, s1=0, s2=41, step_rows=1, L=41)
+    s_mm, s_b2p = torch.cuda.Stream(device=d), torch.cuda.Stream(device=d)
+    torch.cuda.synchronize()
+    for trial in range(6):
+        with torch.cuda.stream(s_mm):
+            for _ in range(4):
+                a2 = a @ a
+        with torch.cuda.stream(s_b2p):
+            for _ in range(40):
+                dev.gemm_b2p(A=An, K=256, sm=bseq, Wpack=wp, C_out=Cb, ldc=128)
+        g2 = gates.clone()
+        tw = dev.lstm_bwd_pair(g2, cbuf, dh, pp, seq, status=status)
+        torch.cuda.synchronize()
+        assert int(tw.item()) == 0 and int(status.item()) == 0, trial
+        assert torch.equal(g2, ref), trial
+    del a2
