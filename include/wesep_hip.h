@@ -592,6 +592,18 @@ int ws_inorm_finalize(const float* sums, int G, int C, long long P, float eps, f
 int ws_inorm_apply(const float* x, const float* stats, long long rows, int P, int C, float* y, void* stream);
 int ws_inorm_bwd_apply(const float* y, const float* dy, const float* stats, const float* sums, long long rows, int P,
                        int C, float* dx, void* stream);
+/* InstanceNorm fused with its neighbouring ELU (convs.py:28-77: conv - ELU - IN; convs.py:115-152: IN - ELU - conv):
+ *   flags bit 0: y = IN(ELU(x));  bit 1: y = ELU(IN(x));  statistics [G][2][C] as ws_inorm_finalize writes them.
+ * ws_in_act_sums: slab[nsplit][G][2][C] partial sums over the P rows of each group -- forward (dy NULL): (sum u, sum u^2)
+ * of u = pre(x), to be reduced and finalised by ws_reduce_slabs + ws_inorm_finalize; backward: (sum d, sum d * n) with
+ * n = (u - mean) * rstd and d = dy * (bit 1 ? ELU'(n) : 1).  ws_in_act_apply: y from x and the statistics (one pass).
+ * ws_in_act_bwd_apply: dx = pre'(x) * rstd * (d - S0/P - n * S1/P) from x, dy, the statistics and the reduced sums
+ * (dx may alias dy).  Only the pre-activation x has to be kept for the backward.                              */
+int ws_in_act_sums(const float* x, const float* dy, const float* stats, int P, int G, int nsplit, int C, int flags,
+                   float* slab, void* stream);
+int ws_in_act_apply(const float* x, const float* stats, long long rows, int P, int C, int flags, float* y, void* stream);
+int ws_in_act_bwd_apply(const float* x, const float* dy, const float* stats, const float* sums, long long rows, int P, int C,
+                        int flags, float* dx, void* stream);
 /* nn.AvgPool2d(sz) and its adjoint; nn.Upsample(size = (H, W), mode = "bilinear") (align_corners False) and its
  * adjoint (a gather over destination pixels)                                                                  */
 int ws_avgpool_fwd(const float* x, int B, int H, int W, int C, int sz, float* y, void* stream);

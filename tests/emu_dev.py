@@ -437,6 +437,33 @@ def softmax_rows_bwd(y, dy, rows, n, scale, dx):
     dx.reshape(rows, n)[:] = scale * yy * (dd - (dd * yy).sum(1, keepdim=True))
 
 
+IN_ELU_PRE, IN_ELU_POST = 1, 2
+
+
+def in_act_fwd(x, G, P, Cc, flags, y, eps=1e-5):
+    u = x.reshape(G, P, Cc)
+    if flags & 1:
+        u = F.elu(u)
+    mean = u.mean(1)
+    var = (u * u).mean(1) - mean * mean
+    rstd = 1.0 / torch.sqrt(var.clamp_min(0) + eps)
+    n = (u - mean[:, None]) * rstd[:, None]
+    y.reshape(G, P, Cc)[:] = F.elu(n) if flags & 2 else n
+    return torch.stack([mean, rstd], 1)
+
+
+def in_act_bwd(x, dy, stats, G, P, Cc, flags, dx):
+    xx, dd = x.reshape(G, P, Cc), dy.reshape(G, P, Cc)
+    u = F.elu(xx) if flags & 1 else xx
+    mean, rstd = stats[:, 0][:, None], stats[:, 1][:, None]
+    n = (u - mean) * rstd
+    d = dd * torch.where(n > 0, torch.ones_like(n), torch.exp(n)) if flags & 2 else dd
+    r = rstd * (d - d.mean(1, keepdim=True) - n * (d * n).mean(1, keepdim=True))
+    if flags & 1:
+        r = r * torch.where(xx > 0, torch.ones_like(xx), torch.exp(xx))
+    dx.reshape(G, P, Cc)[:] = r
+
+
 def rowln_ok(W):
     return 0 < W <= 256 and W % 4 == 0
 
@@ -646,7 +673,7 @@ EMULATED = [seg_sums, seg_scale, astp_fwd, astp_bwd, rowbias_act_fwd, act_bwd, c
             scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum, lstm_pack, lstm_fwd, lstm_bwd,
             group_stats, flat_stats, gn_bwd_reduce, norm_ab, norm_bwd_apply_cl, prelu_fwd, prelu_bwd, softmax_rows_fwd,
             softmax_rows_bwd, maskmul_fwd, maskmul_bwd, relu_mask, bn_stats, bn_prelu_fwd, bn_bwd, maxpool3_fwd, maxpool3_bwd,
-            bcast_rows, cross_entropy, im2col, col2im, tstp_fwd, tstp_bwd, power_spec, log_eps, rowln_ok, rowln_fwd, rowln_bwd]
+            bcast_rows, cross_entropy, im2col, col2im, tstp_fwd, tstp_bwd, power_spec, log_eps, rowln_ok, rowln_fwd, rowln_bwd, in_act_fwd, in_act_bwd]
 
 
 def install(monkeypatch):

@@ -256,3 +256,37 @@ def test_bilinear_adjoint_at_the_pooling_branch_scales(h, w, H, W):
     assert torch.equal(outs[0], outs[1])
     err = float((outs[0].double().cpu() - want).norm() / want.norm())
     assert err < 5e-6, err                      # fp32 source coordinates at non-integer scales (2.2e-6 at 250 / 62)
+
+
+@pytest.mark.parametrize("order", ["pre", "post"])
+@pytest.mark.parametrize("G,P,C", [(3, 1000, 16), (2, 517, 32), (4, 33, 384), (1, 4099, 8)])
+def test_fused_elu_instancenorm_vs_torch(order, G, P, C):
+    """dev.in_act_fwd / in_act_bwd (conv2d.hip ws_in_act_*): IN(ELU(x)) and ELU(IN(x)) against torch autograd in fp64,
+    reproducible, and the same values as the two-kernel composition they replace."""
+    from wesep_amd import dev
+    from wesep_amd import functional_dpccn as FD
+    d = _cuda()
+    g = torch.Generator().manual_seed(G * 100 + C)
+    x = (torch.randn(G * P, C, generator=g) * 1.5 + 0.2).to(d)
+    dy = torch.randn(G * P, C, generator=g).to(d)
+    xr = x.double().cpu().view(G, P, C).requires_grad_(True)
+    inorm = lambda t: (t - t.mean(1, keepdim=True)) / torch.sqrt(t.var(1, unbiased=False, keepdim=True) + 1e-5)
+    ref = inorm(torch.nn.functional.elu(xr)) if order == "pre" else torch.nn.functional.elu(inorm(xr))
+    ref.backward(dy.double().cpu().view(G, P, C))
+    flags = dev.IN_ELU_PRE if order == "pre" else dev.IN_ELU_POST
+    outs = []
+    for _ in range(2):
+        y = torch.full((G * P, C), float("nan"), device=d)
+        st = dev.in_act_fwd(x, G, P, C, flags, y)
+        dx = torch.full((G * P, C), float("nan"), device=d)
+        dev.in_act_bwd(x, dy, st, G, P, C, flags, dx)
+        outs.append((y, dx))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    y, dx = outs[0]
+    assert rel(y, ref.detach().view(G * P, C)) < 2e-5
+    assert rel(dx, xr.grad.view(G * P, C)) < 2e-4
+    # the composition it replaces
+    x2 = x.clone().requires_grad_(True)
+    y2 = FD.InstNormFn.apply(FD.EluFn.apply(x2), (G, P)) if order == "pre" else FD.EluFn.apply(FD.InstNormFn.apply(x2, (G, P)))
+    y2.backward(dy)
+    assert rel(y, y2.detach()) < 1e-6 and rel(dx, x2.grad) < 1e-5

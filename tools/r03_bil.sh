@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_dpccn_gpu.py -q --tb=short -m gpu > gpurun_out/r03_bil_tests.log 2>&1; echo "tests exit $?"; tail -4 gpurun_out/r03_bil_tests.log
+timeout 900 python -m pytest tests/test_dpccn_gpu.py tests/test_resnet_gpu.py -q --tb=short -m gpu > gpurun_out/r03_bil_tests.log 2>&1; echo "tests exit $?"; tail -4 gpurun_out/r03_bil_tests.log
 timeout 600 python tools/bench_dpccn.py --rows 32 --joint --steps 3 2>/dev/null | cut -c1-330

@@ -203,6 +203,9 @@ _SIGS = {
     "ws_scale_bf_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ws_softmax_rows_fwd": (_i, [_p, _ll, _i, C.c_float, _p, _p]),
     "ws_softmax_rows_bwd": (_i, [_p, _p, _ll, _i, C.c_float, _p, _p]),
+    "ws_in_act_sums": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_in_act_apply": (_i, [_p, _p, _ll, _i, _i, _i, _p, _p]),
+    "ws_in_act_bwd_apply": (_i, [_p, _p, _p, _p, _ll, _i, _i, _i, _p, _p]),
     "ws_rowln_grid": (_i, [_ll, _i]),
     "ws_rowln_fwd": (_i, [_p, _p, _p, _ll, _i, C.c_float, _p, _p, _p]),
     "ws_rowln_bwd": (_i, [_p, _p, _p, _p, _p, _ll, _i, _p, _p, _p]),

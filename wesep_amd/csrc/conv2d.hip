@@ -554,6 +554,153 @@ extern "C" int ws_inorm_bwd_apply(const float* y, const float* dy, const float* 
   return ws_check_launch("ws_inorm_bwd_apply");
 }
 
+// ---------------------------------------------------------------------------------------------
+// InstanceNorm fused with its neighbouring ELU (round 3).  DPCCN wraps every convolution as conv - ELU - InstanceNorm
+// (convs.py:28-77) and every TCN block as InstanceNorm - ELU - conv (convs.py:115-152); as separate kernels that is five
+// passes over the activation forward (ELU read + write, statistics read, normalise read + write) and eight backward.
+// With the pointwise function applied on load / on store the forward is three passes (statistics; normalise) and the
+// backward five (sums; apply), and only the PRE-activation is kept for the backward.
+//   flags bit 0: ELU before the normalisation   y = IN(ELU(x))
+//   flags bit 1: ELU after it                   y = ELU(IN(x))
+// Statistics [G][2][C] = (mean, rstd) per (row group of P positions, channel), as ws_inorm_finalize writes them.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 elu4(const f32x4& v) {
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = v[j] > 0.f ? v[j] : expm1f(v[j]);
+  return o;
+}
+__device__ __forceinline__ f32x4 elud4(const f32x4& v) {   // d ELU(v) / dv
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = v[j] > 0.f ? 1.f : expf(v[j]);
+  return o;
+}
+
+// slab[split][g][2][C]: forward (dy == NULL): (sum u, sum u^2), u = pre(x);
+// backward: (sum d, sum d * n), n = (u - mean) * rstd, d = dy * (flags & 2 ? ELU'(n) : 1)
+__global__ __launch_bounds__(256) void in_act_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ stats, int P, int G, int nsplit, int C,
+                                                          int flags, float* __restrict__ slab) {
+  __shared__ f32x4 red[2][256];
+  const int c4n = C >> 2;
+  const int cz = blockIdx.z * 256;
+  const int nq = min(256, c4n - cz);
+  const int nrl = 256 / nq;
+  const int tid = threadIdx.x, rl = tid / nq, q = tid - rl * nq;
+  const bool on = rl < nrl;
+  const int c = (cz + q) * 4;
+  const int split = blockIdx.x, grp = blockIdx.y;
+  const int per = (P + nsplit - 1) / nsplit;
+  const int lo = split * per, hi = min(P, lo + per);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  if (on) {
+    f32x4 mean = s0, rstd = s0;
+    if (dy) {
+      mean = *reinterpret_cast<const f32x4*>(stats + (long long)grp * 2 * C + c);
+      rstd = *reinterpret_cast<const f32x4*>(stats + (long long)grp * 2 * C + C + c);
+    }
+    for (int j = lo + rl; j < hi; j += nrl) {
+      const long long row = (long long)grp * P + j;
+      f32x4 u = *reinterpret_cast<const f32x4*>(x + row * C + c);
+      if (flags & 1) u = elu4(u);
+      if (!dy) {
+        s0 += u;
+        s1 += u * u;
+      } else {
+        const f32x4 n = (u - mean) * rstd;
+        f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * C + c);
+        if (flags & 2) d *= elud4(n);
+        s0 += d;
+        s1 += d * n;
+      }
+    }
+  }
+  red[0][tid] = s0;
+  red[1][tid] = s1;
+  __syncthreads();
+  if (tid < nq) {
+    f32x4 t0 = red[0][tid], t1 = red[1][tid];
+    for (int r = 1; r < nrl; ++r) {
+      t0 += red[0][r * nq + tid];
+      t1 += red[1][r * nq + tid];
+    }
+    float* o = slab + ((long long)split * G + grp) * 2 * C;
+    *reinterpret_cast<f32x4*>(o + (cz + tid) * 4) = t0;
+    *reinterpret_cast<f32x4*>(o + C + (cz + tid) * 4) = t1;
+  }
+}
+
+__global__ void in_act_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, long long rows, int P,
+                                    int C, int flags, float* __restrict__ y) {
+  const int c4n = C >> 2;
+  const long long total = rows * c4n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / c4n;
+    const int c = (int)(i - row * c4n) * 4;
+    const float* st = stats + (row / P) * 2 * C;
+    f32x4 u = *reinterpret_cast<const f32x4*>(x + i * 4);
+    if (flags & 1) u = elu4(u);
+    f32x4 n = (u - *reinterpret_cast<const f32x4*>(st + c)) * *reinterpret_cast<const f32x4*>(st + C + c);
+    if (flags & 2) n = elu4(n);
+    *reinterpret_cast<f32x4*>(y + i * 4) = n;
+  }
+}
+
+// dx = pre'(x) * rstd * (d - S0/P - n * S1/P)      (dx may alias dy)
+__global__ void in_act_bwd_apply_kernel(const float* __restrict__ x, const float* dy, const float* __restrict__ stats,
+                                        const float* __restrict__ sums, long long rows, int P, int C, int flags, float* dx) {
+  const int c4n = C >> 2;
+  const long long total = rows * c4n;
+  const float inv = 1.f / (float)P;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / c4n;
+    const int c = (int)(i - row * c4n) * 4;
+    const long long g = row / P;
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + g * 2 * C + c);
+    const f32x4 rstd = *reinterpret_cast<const f32x4*>(stats + g * 2 * C + C + c);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + g * 2 * C + c) * inv;
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + g * 2 * C + C + c) * inv;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+    const f32x4 u = (flags & 1) ? elu4(xv) : xv;
+    const f32x4 n = (u - mean) * rstd;
+    f32x4 d = *reinterpret_cast<const f32x4*>(dy + i * 4);
+    if (flags & 2) d *= elud4(n);
+    f32x4 r = rstd * (d - s0 - n * s1);
+    if (flags & 1) r *= elud4(xv);
+    *reinterpret_cast<f32x4*>(dx + i * 4) = r;
+  }
+}
+
+extern "C" int ws_in_act_sums(const float* x, const float* dy, const float* stats, int P, int G, int nsplit, int C, int flags,
+                              float* slab, void* stream) {
+  WS_REQUIRE(x && slab && P > 0 && G > 0 && nsplit > 0 && C > 0 && C % 4 == 0 && (flags & ~3) == 0 && (!dy || stats),
+             "ws_in_act_sums: bad args (the backward sums need the statistics)");
+  hipLaunchKernelGGL(in_act_sums_kernel, dim3(nsplit, G, (C / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, dy, stats,
+                     P, G, nsplit, C, flags, slab);
+  return ws_check_launch("ws_in_act_sums");
+}
+
+extern "C" int ws_in_act_apply(const float* x, const float* stats, long long rows, int P, int C, int flags, float* y,
+                               void* stream) {
+  WS_REQUIRE(x && stats && y && rows > 0 && P > 0 && C > 0 && C % 4 == 0 && rows % P == 0 && (flags & ~3) == 0,
+             "ws_in_act_apply: bad args");
+  hipLaunchKernelGGL(in_act_apply_kernel, dim3(cv_blocks(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, stats, rows, P,
+                     C, flags, y);
+  return ws_check_launch("ws_in_act_apply");
+}
+
+extern "C" int ws_in_act_bwd_apply(const float* x, const float* dy, const float* stats, const float* sums, long long rows, int P,
+                                   int C, int flags, float* dx, void* stream) {
+  WS_REQUIRE(x && dy && stats && sums && dx && rows > 0 && P > 0 && C > 0 && C % 4 == 0 && rows % P == 0 && (flags & ~3) == 0,
+             "ws_in_act_bwd_apply: bad args");
+  hipLaunchKernelGGL(in_act_bwd_apply_kernel, dim3(cv_blocks(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, dy, stats,
+                     sums, rows, P, C, flags, dx);
+  return ws_check_launch("ws_in_act_bwd_apply");
+}
+
 // AvgPool2d(sz) (stride sz, floor): [B][H][W][C] -> [B][H/sz][W/sz][C]; backward spreads dy / sz^2 (0 on the dropped tail)
 __global__ void avgpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int sz,
                                    float* __restrict__ y) {

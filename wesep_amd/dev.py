@@ -1121,6 +1121,37 @@ def inorm_bwd(y, dy, stats, G: int, P: int, Cc: int, dx):
     _call("ws_inorm_bwd_apply", _p(y), _p(dy), _p(stats), _p(sums), G * P, P, Cc, _p(dx))
 
 
+IN_ELU_PRE, IN_ELU_POST = 1, 2     # ws_in_act_* flags: y = IN(ELU(x)) / y = ELU(IN(x))
+
+
+def _in_act_sums(x, dy, stats, G: int, P: int, Cc: int, flags: int):
+    nsplit = max(1, min(max(1, 1024 // G), P // 32))
+    slab = torch.empty(nsplit, G, 2, Cc, device=x.device, dtype=torch.float32)
+    _call("ws_in_act_sums", _p(x), _p(dy), _p(stats), P, G, nsplit, Cc, flags, _p(slab))
+    out = torch.empty(G, 2, Cc, device=x.device, dtype=torch.float32)
+    reduce_slabs(slab, nsplit, G * 2 * Cc, G * 2 * Cc, out)
+    return out
+
+
+def in_act_fwd(x, G: int, P: int, Cc: int, flags: int, y, eps=IN_EPS):
+    """y = IN(ELU(x)) (flags IN_ELU_PRE) or ELU(IN(x)) (IN_ELU_POST) over the P positions of each of G rows, three
+    passes; returns the statistics [G, 2, C] the backward needs (with x)."""
+    _chk(x, "x")
+    _chk(y, "y")
+    sums = _in_act_sums(x, None, None, G, P, Cc, flags)
+    stats = torch.empty(G, 2, Cc, device=x.device, dtype=torch.float32)
+    _call("ws_inorm_finalize", _p(sums), G, Cc, P, eps, _p(stats))
+    _call("ws_in_act_apply", _p(x), _p(stats), G * P, P, Cc, flags, _p(y))
+    return stats
+
+
+def in_act_bwd(x, dy, stats, G: int, P: int, Cc: int, flags: int, dx):
+    for n, t in (("x", x), ("dy", dy), ("stats", stats), ("dx", dx)):
+        _chk(t, n)
+    sums = _in_act_sums(x, dy, stats, G, P, Cc, flags)
+    _call("ws_in_act_bwd_apply", _p(x), _p(dy), _p(stats), _p(sums), G * P, P, Cc, flags, _p(dx))
+
+
 def avgpool_fwd(x, B: int, H: int, W: int, Cc: int, sz: int, y):
     _chk(x, "x")
     _chk(y, "y")

@@ -215,6 +215,39 @@ class InstNormFn(torch.autograd.Function):
         return dx, None
 
 
+class EluInstNormFn(torch.autograd.Function):
+    """InstanceNorm fused with its neighbouring ELU: order 'pre' = IN(ELU(x)) (conv - ELU - IN, convs.py:28-77), order
+    'post' = ELU(IN(x)) (IN - ELU - conv, convs.py:115-152).  Three passes forward, five backward, only x is kept
+    (dev.in_act_*); `WESEP_IN_ELU_FUSED=0` composes EluFn and InstNormFn instead."""
+
+    @staticmethod
+    def forward(ctx, x, geo, order):
+        _need_cuda(x, "DPCCN")
+        G, P = geo
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        flags = dev.IN_ELU_PRE if order == "pre" else dev.IN_ELU_POST
+        st = dev.in_act_fwd(x, G, P, x.shape[1], flags, y)
+        ctx.save_for_backward(x, st)
+        ctx.geo = (G, P, flags)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st = ctx.saved_tensors
+        G, P, flags = ctx.geo
+        dx = torch.empty_like(x)
+        dev.in_act_bwd(x, dy.contiguous(), st, G, P, x.shape[1], flags, dx)
+        return dx, None, None
+
+
+def elu_inorm(x, geo, order):
+    import os
+    if os.environ.get("WESEP_IN_ELU_FUSED", "1") == "0":
+        return InstNormFn.apply(EluFn.apply(x), geo) if order == "pre" else EluFn.apply(InstNormFn.apply(x, geo))
+    return EluInstNormFn.apply(x, geo, order)
+
+
 class AvgPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, geo):

@@ -29,7 +29,7 @@ class Conv2dBlock(nn.Module):
         sh, sw = self.stride
         y = FD.Conv2dFn.apply(x, self.conv2d.weight, self.conv2d.bias, (B, H, W, sh, sw))
         Ho, Wo = (H + 2 - 3) // sh + 1, (W + 2 - 3) // sw + 1
-        return FD.InstNormFn.apply(FD.EluFn.apply(y), (B, Ho * Wo)), (B, Ho, Wo)
+        return FD.elu_inorm(y, (B, Ho * Wo), "pre"), (B, Ho, Wo)
 
 
 class ConvTrans2dBlock(nn.Module):
@@ -46,7 +46,7 @@ class ConvTrans2dBlock(nn.Module):
         sh, sw = self.stride
         y = FD.ConvTranspose2dFn.apply(x, self.convtrans2d.weight, self.convtrans2d.bias, (B, H, W, sh, sw))
         Ht, Wt = (H - 1) * sh - 2 + 3, (W - 1) * sw - 2 + 3
-        return FD.InstNormFn.apply(FD.EluFn.apply(y), (B, Ht * Wt)), (B, Ht, Wt)
+        return FD.elu_inorm(y, (B, Ht * Wt), "pre"), (B, Ht, Wt)
 
 
 class DenseBlock(nn.Module):
@@ -92,9 +92,9 @@ class TCNBlock(nn.Module):
     def forward(self, x, geo):
         """x [B*L, D], geo (B, L)."""
         B, Lr = geo
-        y = FD.EluFn.apply(FD.InstNormFn.apply(x, (B, Lr)))
+        y = FD.elu_inorm(x, (B, Lr), "post")
         y = FD.DwConvFn.apply(y, self.dconv1.weight, self.dconv1.bias, (B, Lr, self.dilation, self.causal))
-        y = FD.EluFn.apply(FD.InstNormFn.apply(y, (B, Lr)))
+        y = FD.elu_inorm(y, (B, Lr), "post")
         return FD.Conv1x1ResFn.apply(y, self.dconv2.weight, self.dconv2.bias, x)
 
 
