@@ -73,6 +73,8 @@ typedef struct ws_conv_view {
   int Ho, Wo;        /* patch grid (rows of the implicit matrix per image: Ho*Wo) */
   int k, sh, sw, p;
   int dil;           /* tap spacing; 0 = 1 */
+  int ldp;           /* floats between consecutive pixels of the image (0 = C): the image may be the first C columns
+                        of a wider channels-last tensor, e.g. the growing feature map of a dense block */
 } ws_conv_view;
 
 /* C[m][n] = epi( sum_k pro(A[m][k]) * W[n][k] )        (torch Linear / Conv1d(k=1) layout)

@@ -37,8 +37,9 @@ def _conv_matrix(x, M, conv):
     """The implicit patch matrix of dev.ConvView, materialised: [M, k*k*C]."""
     mode, H, W, C, Ho, Wo, k, sh, sw, p = conv[:10]
     dil = conv[10] if len(conv) > 10 and conv[10] else 1
+    ldp = conv[11] if len(conv) > 11 and conv[11] else C            # pixel stride: the image is the first C of ldp columns
     R = M // (Ho * Wo)
-    img = x.reshape(-1)[:R * H * W * C].reshape(R, H, W, C)
+    img = x.reshape(-1)[:R * H * W * ldp].reshape(R, H, W, ldp)[..., :C]
     out = torch.zeros(R, Ho, Wo, k * k, C)
 
     def src(o, n_out, tap, s, n_in):

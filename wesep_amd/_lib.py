@@ -28,7 +28,7 @@ _f = C.c_float
 
 class ConvView(C.Structure):
     """ws_conv_view: the A operand of ws_gemm_nt / ws_gemm_tn as an implicit im2col matrix (include/wesep_hip.h)."""
-    _fields_ = [(n, _i) for n in ("on", "mode", "H", "W", "C", "Ho", "Wo", "k", "sh", "sw", "p", "dil")]
+    _fields_ = [(n, _i) for n in ("on", "mode", "H", "W", "C", "Ho", "Wo", "k", "sh", "sw", "p", "dil", "ldp")]
 
 
 class GemmNTArgs(C.Structure):

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(const ws_conv_wgrad_
     const int dl = cv.dil > 0 ? cv.dil : 1;
     const int ky = (tap / cv.k) * dl, kx = (tap % cv.k) * dl;
     it_tap[i] = tap;
-    it_off[i] = (ky * cv.W + kx) * cv.C + 4 * c4;
+    it_off[i] = (ky * cv.W + kx) * (cv.ldp > 0 ? cv.ldp : cv.C) + 4 * c4;
     it_kk[i] = tap * cv.C + 4 * c4 - kbase;       // column inside the chunk
   }
   // dy tile: thread (row = tid / 8, channel quad = tid % 8) of the first 256 threads
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_kernel(const ws_conv_wgrad_
         const int rr = (int)(m / hw), q = (int)(m - (long long)rr * hw);
         const int ho = q / cv.Wo, wo = q - ho * cv.Wo;
         const int bh = ho * cv.sh - cv.p, bw = wo * cv.sw - cv.p, dl = cv.dil > 0 ? cv.dil : 1;
-        r.off = (long long)rr * cv.H * cv.W * cv.C + (long long)(bh * cv.W + bw) * cv.C;
+        const int cld = cv.ldp > 0 ? cv.ldp : cv.C;
+        r.off = (long long)rr * cv.H * cv.W * cld + (long long)(bh * cv.W + bw) * cld;
         r.goff = m * p.ldg;
         int mask = 0;
         for (int ky = 0; ky < cv.k; ++ky)
@@ -243,7 +244,9 @@ extern "C" int ws_conv_wgrad(const ws_conv_wgrad_args* a, void* stream) {
   WS_REQUIRE(a->M > 0 && a->M % (c.Ho * c.Wo) == 0 && a->nsplit > 0 && a->tiles_per_split > 0 &&
                  (long long)a->nsplit * a->tiles_per_split * 32 >= a->M,
              "ws_conv_wgrad: splits do not cover M");
-  WS_REQUIRE((long long)(c.H + 2 * c.k) * c.W * c.C < (1LL << 31), "ws_conv_wgrad: one image below 2^31 elements");
+  WS_REQUIRE(c.ldp == 0 || (c.ldp >= c.C && c.ldp % 4 == 0), "ws_conv_wgrad: pixel stride ldp >= C, %% 4 (got %d)", c.ldp);
+  WS_REQUIRE((long long)(c.H + 2 * c.k) * c.W * (c.ldp > 0 ? c.ldp : c.C) < (1LL << 31),
+             "ws_conv_wgrad: one image below 2^31 elements");
   const int kchunk = Kk < CW_MAXK ? Kk : CW_MAXK, nchunks = (Kk + CW_MAXK - 1) / CW_MAXK;
   const size_t lds_bytes = (size_t)2 * (32 + 32 * ((kchunk + 31) / 32)) * CW_LD * sizeof(__bf16);
   static bool attr_set = false;

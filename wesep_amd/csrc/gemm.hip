@@ -204,7 +204,9 @@ extern "C" int ws_gemm_nt(const ws_gemm_nt_args* a, void* stream) {
                    c.k >= 1 && c.sh >= 1 && c.sw >= 1 && c.p >= 0 && a->K == c.k * c.k * c.C && a->M % (c.Ho * c.Wo) == 0,
                "ws_gemm_nt: bad conv view (C %% 4, K == k*k*C, M %% (Ho*Wo))");
     WS_REQUIRE(c.mode == 0 || (c.sh <= 2 && c.sw <= 2), "ws_gemm_nt: transposed view: strides 1 or 2");
-    WS_REQUIRE((long long)c.H * c.W * c.C < (1LL << 31), "ws_gemm_nt: one image must stay below 2^31 elements");
+    WS_REQUIRE(c.ldp == 0 || (c.ldp >= c.C && c.ldp % 4 == 0), "ws_gemm_nt: pixel stride ldp >= C, %% 4 (got %d)", c.ldp);
+    WS_REQUIRE((long long)c.H * c.W * (c.ldp > 0 ? c.ldp : c.C) < (1LL << 31),
+               "ws_gemm_nt: one image must stay below 2^31 elements");
   }
   dim3 grid((a->M + 127) / 128, (maxn + 127) / 128, ng), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -395,7 +397,8 @@ extern "C" int ws_gemm_tn(const ws_gemm_tn_args* a, void* stream) {
     WS_REQUIRE(c.mode == 0 && c.H > 0 && c.W > 0 && c.C > 0 && c.Ho > 0 && c.Wo > 0 && c.k >= 1 && c.sh >= 1 &&
                    c.sw >= 1 && c.p >= 0 && a->Kk == c.k * c.k * c.C && a->M % (c.Ho * c.Wo) == 0,
                "ws_gemm_tn: bad conv view (mode 0, Kk == k*k*C, M %% (Ho*Wo))");
-    WS_REQUIRE(c.k <= 5 && (long long)(c.H + 2 * c.k) * c.W * c.C < (1LL << 31),
+    WS_REQUIRE(c.ldp == 0 || (c.ldp >= c.C && c.ldp % 4 == 0), "ws_gemm_tn: pixel stride ldp >= C, %% 4 (got %d)", c.ldp);
+    WS_REQUIRE(c.k <= 5 && (long long)(c.H + 2 * c.k) * c.W * (c.ldp > 0 ? c.ldp : c.C) < (1LL << 31),
                "ws_gemm_tn: conv view: k <= 5 and one image below 2^31 elements");
   }
   dim3 grid(((maxn + 127) / 128) * ((maxk + 127) / 128), a->nsplit, ng), block(256);

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
       const int hw = cv.Ho * cv.Wo;
       const int r = mm / hw, q = mm - r * hw;
       const int ho = q / cv.Wo, wo = q - ho * cv.Wo;
-      aoff[i] = (long long)r * cv.H * cv.W * cv.C;
+      aoff[i] = (long long)r * cv.H * cv.W * (cv.ldp > 0 ? cv.ldp : cv.C);
       cbh[i] = cv.mode == 0 ? ho * cv.sh - cv.p : ho + cv.p;
       cbw[i] = cv.mode == 0 ? wo * cv.sw - cv.p : wo + cv.p;
     } else {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_a
           ok = hn >= 0 && wn >= 0 && (hn & csh) == 0 && (wn & csw) == 0 && hh < cv.H && ww < cv.W;
         }
         vt[i] = ok;
-        const long long o = ok ? aoff[i] + ((hh * cv.W + ww) * cv.C + cc) : 0;  // one image < 2^31 elements (checked)
+        const long long o = ok ? aoff[i] + ((hh * cv.W + ww) * (cv.ldp > 0 ? cv.ldp : cv.C) + cc) : 0;  // one image < 2^31 elements (checked)
         ra[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(A + o);
       } else {
         ra[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(A + aoff[i] + kc);
@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
         const int ho = q / cv.Wo, wo = q - ho * cv.Wo;
         const int bh = ho * cv.sh - cv.p, bw = wo * cv.sw - cv.p, dl = cv.dil > 0 ? cv.dil : 1;
         r.goff = ws_row_off(m, p.g_div, p.g_s1, p.g_s2);
-        r.aoff = (long long)rr * cv.H * cv.W * cv.C + (long long)(bh * cv.W + bw) * cv.C;
+        const int cld = cv.ldp > 0 ? cv.ldp : cv.C;
+        r.aoff = (long long)rr * cv.H * cv.W * cld + (long long)(bh * cv.W + bw) * cld;
         int mask = 0;
         for (int ky = 0; ky < cv.k; ++ky)
           for (int kx = 0; kx < cv.k; ++kx)
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_kernel(const ws_gemm_tn_a
     ctap = kc / p.conv.C;
     const int dl = p.conv.dil > 0 ? p.conv.dil : 1;
     const int cky = (ctap / p.conv.k) * dl, ckx = (ctap % p.conv.k) * dl;
-    ctapo = (cky * p.conv.W + ckx) * p.conv.C;
+    ctapo = (cky * p.conv.W + ckx) * (p.conv.ldp > 0 ? p.conv.ldp : p.conv.C);
     Ag = (gfp)A + (kc - ctap * p.conv.C);
   }
   float rg[16], ra[16];

@@ -91,13 +91,14 @@ class ConvView(NamedTuple):
     sw: int
     p: int
     dil: int = 1
+    ldp: int = 0          # floats between consecutive pixels (0 = C): the image is the first C columns of a wider tensor
 
 
 def _set_conv(a, conv: Optional[ConvView]):
     if conv is not None:
         a.conv.on = 1
         (a.conv.mode, a.conv.H, a.conv.W, a.conv.C, a.conv.Ho, a.conv.Wo, a.conv.k, a.conv.sh, a.conv.sw,
-         a.conv.p, a.conv.dil) = conv
+         a.conv.p, a.conv.dil, a.conv.ldp) = conv
 
 
 def gemm_nt(*, A, a_rows: Rows, M: int, C_out, c_rows: Rows, N=0, K=0, W=None, ldw=0, bias=None,

@@ -215,6 +215,76 @@ class InstNormFn(torch.autograd.Function):
         return dx, None
 
 
+class DenseBlockFn(torch.autograd.Function):
+    """Five densely connected conv3x3 - ELU - InstanceNorm layers (convs.py:80-112) WITHOUT the concatenations: the
+    block's feature map lives in one [M, C0 + 4g] buffer, layer i convolves its first C0 + i*g channels through a patch
+    view with pixel stride C0 + 4g (ws_conv_view.ldp) and writes its g output channels behind them; the backward
+    accumulates every layer's input gradient into the matching prefix of ONE gradient buffer through the GEMM's
+    residual operand.  torch.cat copied the growing map once per layer forward (2 + 3 + 4 + 5 blocks of channels) and
+    autograd split and re-summed it backward.  params = (w1, b1, ..., w5, b5); x [M, C0] -> [M, Cout5]."""
+
+    @staticmethod
+    def forward(ctx, x, geo, *params):
+        _need_cuda(x, "DPCCN")
+        B, H, W = geo
+        M = B * H * W
+        ws, bs = params[0::2], params[1::2]
+        C0, g = x.shape[1], ws[0].shape[0]
+        Ctot = C0 + 4 * g
+        d = x.device
+        for i, w in enumerate(ws):
+            if tuple(w.shape[1:]) != (C0 + i * g, 3, 3) or (i < 4 and w.shape[0] != g) or not FC.implicit_ok(w.shape[1]) \
+                    or not FC.implicit_ok(w.shape[0]):
+                raise dev.L.WesepHipError(f"DPCCN DenseBlock: layer {i + 1} weight {tuple(w.shape)} does not fit the dense "
+                                          f"layout (C0 = {C0}, growth {g}, channel counts %% 4)")
+        big = _empty(d, M, Ctot)
+        big[:, :C0].copy_(x)
+        saved, out = [], None
+        for i in range(5):
+            Ci, Co = C0 + i * g, ws[i].shape[0]
+            W2, Wd = FC.conv2d_weights(ws[i])
+            pre = _gemm(big, M, 9 * Ci, W2, Co, bias=bs[i], vec=3, mode=FC.MODE,
+                        conv=dev.ConvView(0, H, W, Ci, H, W, 3, 1, 1, 1, 1, Ctot))
+            out = _empty(d, M, Co)
+            st = dev.in_act_fwd(pre, B, H * W, Co, dev.IN_ELU_PRE, out)
+            if i < 4:
+                big[:, Ci:Ci + g].copy_(out)
+            saved += [pre, st, Wd]
+        ctx.save_for_backward(big, *saved)
+        ctx.geo = (B, H, W, C0, g, tuple(w.shape for w in ws))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        big = ctx.saved_tensors[0]
+        saved = ctx.saved_tensors[1:]
+        B, H, W, C0, g, wshapes = ctx.geo
+        M, Ctot = B * H * W, C0 + 4 * g
+        d = big.device
+        dbig = _empty(d, M, Ctot)            # layer 5's input gradient covers every column: no zero fill
+        grads = [None] * 10
+        d_out = dout.contiguous()
+        for i in range(4, -1, -1):
+            pre, st, Wd = saved[3 * i:3 * i + 3]
+            Ci, Co = C0 + i * g, wshapes[i][0]
+            if i < 4:
+                d_out = dbig[:, Ci:Ci + g].contiguous()     # complete: layers i+2 .. 5 have added their share
+            d_pre = _empty(d, M, Co)
+            dev.in_act_bwd(pre, d_out, st, B, H * W, Co, dev.IN_ELU_PRE, d_pre)
+            conv = dev.ConvView(0, H, W, Ci, H, W, 3, 1, 1, 1, 1, Ctot)
+            if dev.conv_wgrad_ok(Co, conv):
+                dW2, db = FC._one_pass_wgrad(d_pre, M, Co, big, conv, True)
+            else:
+                dW2, db = _wgrad(d_pre, M, Co, big, 9 * Ci, with_bias=True, vec=1, mode=FC.MODE, conv=conv)
+            grads[2 * i] = dW2.reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous().view(wshapes[i])
+            grads[2 * i + 1] = db
+            # d(first Ci channels of the map) += transposed view of d_pre (conv2d_dx), accumulated in place
+            _gemm(d_pre, M, 9 * Co, Wd, Ci, vec=3, mode=FC.MODE, conv=dev.ConvView(1, H, W, Co, H, W, 3, 1, 1, 1),
+                  out=dbig, c_ld=Ctot, R=None if i == 4 else dbig)
+        dx = dbig[:, :C0].contiguous() if ctx.needs_input_grad[0] else None
+        return (dx, None) + tuple(grads)
+
+
 class EluInstNormFn(torch.autograd.Function):
     """InstanceNorm fused with its neighbouring ELU: order 'pre' = IN(ELU(x)) (conv - ELU - IN, convs.py:28-77), order
     'post' = ELU(IN(x)) (IN - ELU - conv, convs.py:115-152).  Three passes forward, five backward, only x is kept
