@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 10
+#define WS_ABI_VERSION 11
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -594,6 +594,43 @@ int ws_inorm_finalize(const float* sums, int G, int C, long long P, float eps, f
 int ws_inorm_apply(const float* x, const float* stats, long long rows, int P, int C, float* y, void* stream);
 int ws_inorm_bwd_apply(const float* y, const float* dy, const float* stats, const float* sums, long long rows, int P,
                        int C, float* dx, void* stream);
+/* 3 x 3, stride-1, padding-1 convolution of a channels-last image through an LDS halo tile (conv3x3.hip): every input
+ * pixel crosses the L2 -> CU path ~1.2 times instead of the 9 of the implicit patch matrix.  Replaces F.conv2d of the
+ * dense blocks (wesep/modules/dpccn/convs.py:80-112) and, with the flipped / channel-swapped weights, its input gradient:
+ *   Y[m][n] = bias[n] + R[m][n] + sum_{ky,kx,c} X[pixel(m) + (ky-1, kx-1)][c] * W[n][(ky*3 + kx)*Cin + c],  m = (b*H + h)*Wd + w
+ * X: pixel stride ldx >= Cin; Y and R (bias / R may be NULL; R may alias Y): row stride ldy >= Cout.
+ * W: the weights PACKED as bf16 hi / lo MFMA fragments, ceil(Cin / 16) * 9 * NTP * 2 units of 64 lanes x 8 bf16, NTP =
+ * ceil(Cout / 32) rounded up to even when above 2 (wesep_amd.dev.conv3x3_pack writes the layout: unit
+ * (((chunk*9 + tap)*NTP + t)*2 + part)*64 + lane = W[t*32 + (lane & 31)][tap][16 chunk + 8 (lane >> 5) + j], zero beyond
+ * Cout / Cin; part 0 = bf16(w), part 1 = bf16(w - hi)); ldw is ignored.  Cin % 4 == 0, Cout % 4 == 0, Cout <= 1024.
+ * Split-bf16 products, fp32 accumulation. */
+typedef struct ws_conv3x3_args {
+  const float* X;
+  const float* W;
+  const float* bias;
+  const float* R;
+  float* Y;
+  long long ldx, ldw, ldy;
+  int B, H, Wd, Cin, Cout, pad_;
+} ws_conv3x3_args;
+int ws_conv3x3(const ws_conv3x3_args* a, void* stream);
+/* Weight (and bias) gradient of that convolution, one pass over the image (conv3x3.hip; replaces ws_conv_wgrad for
+ * k = 3, stride 1, padding 1):
+ *   slab[split][n][(ky*3 + kx)*Cin + c] = sum over the split's pixels m of G[m][n] * X[pixel(m) + (ky-1, kx-1)][c]
+ *   bslab[split][n]                    = sum over the split's pixels of G[m][n]                       (bslab may be NULL)
+ * G [B*H*Wd rows, stride ldg >= Nn]; X pixel stride ldx >= Cin.  The image is cut into tiles of 30 rows x 4 columns
+ * (B * ceil(H / 30) * ceil(Wd / 4) of them, column-fastest); split s owns tiles [s, s + 1) * tiles_per_split.  The caller
+ * sums the nsplit slabs (ws_reduce_slabs: deterministic, no atomics).  Cin % 4 == 0, Nn % 4 == 0. */
+typedef struct ws_conv3x3_wgrad_args {
+  const float* G;
+  const float* X;
+  float* slab;
+  float* bslab;
+  long long ldg, ldx, slab_stride, bslab_stride;
+  int B, H, Wd, Cin, Nn, nsplit, tiles_per_split, pad_;
+} ws_conv3x3_wgrad_args;
+int ws_conv3x3_wgrad(const ws_conv3x3_wgrad_args* a, void* stream);
+
 /* InstanceNorm fused with its neighbouring ELU (convs.py:28-77: conv - ELU - IN; convs.py:115-152: IN - ELU - conv):
  *   flags bit 0: y = IN(ELU(x));  bit 1: y = ELU(IN(x));  statistics [G][2][C] as ws_inorm_finalize writes them.
  * ws_in_act_sums: slab[nsplit][G][2][C] partial sums over the P rows of each group -- forward (dy NULL): (sum u, sum u^2)

@@ -438,6 +438,41 @@ def softmax_rows_bwd(y, dy, rows, n, scale, dx):
     dx.reshape(rows, n)[:] = scale * yy * (dd - (dd * yy).sum(1, keepdim=True))
 
 
+def conv3x3_pack(W2, Cin, Cout):
+    return W2.reshape(Cout, 9 * Cin).contiguous()       # the emulation keeps the plain rows
+
+
+def conv3x3(*, X, ldx, W, ldw, B, H, Wd, Cin, Cout, Y, ldy, bias=None, R=None):
+    M = B * H * Wd
+    img = X.reshape(-1)[:M * ldx].reshape(B, H, Wd, ldx)[..., :Cin].permute(0, 3, 1, 2)
+    w = W.reshape(-1)[:Cout * ldw].reshape(Cout, ldw)[:, :9 * Cin].reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    v = F.conv2d(img, w, bias.reshape(-1)[:Cout] if bias is not None else None, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    if R is not None:
+        v = v + R.reshape(-1)[:M * ldy].reshape(M, ldy)[:, :Cout]
+    Y.reshape(-1)[:M * ldy].reshape(M, ldy)[:, :Cout] = v
+
+
+def conv3x3_wgrad_tiles(B, H, Wd):
+    return B * (-(-H // 30)) * (-(-Wd // 4))
+
+
+def conv3x3_wgrad(*, G, ldg, X, ldx, B, H, Wd, Cin, Nn, slab, nsplit, tiles_per_split, bslab=None):
+    """Slab 0 carries the whole gradient (the split of the pixels is a device detail), the others are zero."""
+    assert nsplit * tiles_per_split >= conv3x3_wgrad_tiles(B, H, Wd)
+    M = B * H * Wd
+    img = X.reshape(-1)[:M * ldx].reshape(B, H, Wd, ldx)[..., :Cin].permute(0, 3, 1, 2)
+    g = G.reshape(-1)[:M * ldg].reshape(B, H, Wd, ldg)[..., :Nn].permute(0, 3, 1, 2)
+    # dW[n][c][ky][kx] = sum g[b][n][h][w] * xpad[b][c][h + ky][w + kx]
+    dw = torch.nn.grad.conv2d_weight(img, (Nn, Cin, 3, 3), g, padding=1)
+    sl = slab.reshape(-1)[:nsplit * Nn * 9 * Cin].reshape(nsplit, Nn * 9 * Cin)
+    sl.zero_()
+    sl[0] = dw.permute(0, 2, 3, 1).reshape(-1)
+    if bslab is not None:
+        bs = bslab.reshape(-1)[:nsplit * Nn].reshape(nsplit, Nn)
+        bs.zero_()
+        bs[0] = g.sum((0, 2, 3))
+
+
 IN_ELU_PRE, IN_ELU_POST = 1, 2
 
 
@@ -674,7 +709,7 @@ EMULATED = [seg_sums, seg_scale, astp_fwd, astp_bwd, rowbias_act_fwd, act_bwd, c
             scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum, lstm_pack, lstm_fwd, lstm_bwd,
             group_stats, flat_stats, gn_bwd_reduce, norm_ab, norm_bwd_apply_cl, prelu_fwd, prelu_bwd, softmax_rows_fwd,
             softmax_rows_bwd, maskmul_fwd, maskmul_bwd, relu_mask, bn_stats, bn_prelu_fwd, bn_bwd, maxpool3_fwd, maxpool3_bwd,
-            bcast_rows, cross_entropy, im2col, col2im, tstp_fwd, tstp_bwd, power_spec, log_eps, rowln_ok, rowln_fwd, rowln_bwd, in_act_fwd, in_act_bwd]
+            bcast_rows, cross_entropy, im2col, col2im, tstp_fwd, tstp_bwd, power_spec, log_eps, rowln_ok, rowln_fwd, rowln_bwd, in_act_fwd, in_act_bwd, conv3x3, conv3x3_pack, conv3x3_wgrad, conv3x3_wgrad_tiles]
 
 
 def install(monkeypatch):

@@ -290,3 +290,57 @@ def test_fused_elu_instancenorm_vs_torch(order, G, P, C):
     y2 = FD.InstNormFn.apply(FD.EluFn.apply(x2), (G, P)) if order == "pre" else FD.EluFn.apply(FD.InstNormFn.apply(x2, (G, P)))
     y2.backward(dy)
     assert rel(y, y2.detach()) < 1e-6 and rel(dx, x2.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ldx,ldy,res", [(2, 9, 257, 16, 16, 80, 16, False), (1, 5, 130, 80, 16, 80, 16, False),
+                                                        (2, 4, 65, 32, 160, 32, 160, True), (1, 3, 7, 20, 36, 24, 40, True),
+                                                        (3, 2, 129, 160, 32, 160, 32, False), (1, 1, 1, 4, 4, 4, 4, False),
+                                                        (1, 70, 37, 48, 64, 48, 64, True), (2, 33, 101, 16, 80, 16, 80, True)])
+def test_conv3x3_halo_kernel_vs_torch(B, H, W, Cin, Cout, ldx, ldy, res):
+    """ws_conv3x3 (conv3x3.hip): 3 x 3 / stride 1 / padding 1 on a channels-last image with pixel stride ldx into rows of
+    stride ldy, with bias and the in-place residual (the input-gradient accumulation of DenseBlockFn), against
+    F.conv2d in fp64; tiles (32 rows x 8 or 16 columns) that end inside the image, several row tiles, short channel
+    chunks, several 64-channel output groups, columns beyond Cout untouched."""
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    M = B * H * W
+    X = torch.randn(M, ldx, generator=g)
+    Wt = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    bias = torch.randn(Cout, generator=g)
+    Y0 = torch.randn(M, ldy, generator=g)
+    W2 = Wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    ref = torch.nn.functional.conv2d(X[:, :Cin].double().view(B, H, W, Cin).permute(0, 3, 1, 2), Wt.double(), bias.double(),
+                                     padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    if res:
+        ref = ref + Y0[:, :Cout].double()
+    outs = []
+    for _ in range(2):
+        Y = Y0.clone().to(d)
+        dev.conv3x3(X=X.to(d), ldx=ldx, W=dev.conv3x3_pack(W2.to(d), Cin, Cout), ldw=9 * Cin, B=B, H=H, Wd=W, Cin=Cin, Cout=Cout, Y=Y, ldy=ldy,
+                    bias=bias.to(d), R=Y if res else None)
+        outs.append(Y)
+    assert torch.equal(outs[0], outs[1])
+    assert rel(outs[0][:, :Cout], ref) < 2e-5
+    assert torch.equal(outs[0][:, Cout:].cpu(), Y0[:, Cout:])
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Nn,ldx", [(2, 9, 257, 16, 16, 80), (1, 61, 9, 80, 32, 80), (2, 30, 4, 32, 16, 32),
+                                              (1, 31, 5, 20, 36, 24), (3, 7, 33, 96, 64, 96), (1, 1, 1, 4, 4, 4)])
+def test_conv3x3_halo_weight_gradient_vs_torch(B, H, W, Cin, Nn, ldx):
+    """ws_conv3x3_wgrad (conv3x3.hip): dW and db of a 3 x 3 / stride 1 / padding 1 convolution against
+    torch.nn.grad.conv2d_weight in fp64: tiles of 30 rows x 4 columns that end inside the image, several input-channel
+    chunks and output-channel tiles, an image that is the prefix of wider rows, run-to-run identity."""
+    from wesep_amd import functional_conv as FC
+    d = _cuda()
+    g = torch.Generator().manual_seed(Cin * 5 + Nn)
+    M = B * H * W
+    X = torch.randn(M, ldx, generator=g)
+    G = torch.randn(M, Nn, generator=g)
+    img = X[:, :Cin].double().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    gg = G.double().view(B, H, W, Nn).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(img, (Nn, Cin, 3, 3), gg, padding=1).permute(0, 2, 3, 1).reshape(Nn, 9 * Cin)
+    outs = [FC.halo_wgrad(G.to(d), Nn, X.to(d), ldx, B, H, W, Cin, True) for _ in range(2)]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel(outs[0][0], ref) < 2e-5
+    assert rel(outs[0][1], gg.sum((0, 2, 3))) < 1e-5

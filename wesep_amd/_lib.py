@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 10
+ABI_VERSION = 11
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
@@ -29,6 +29,16 @@ _f = C.c_float
 class ConvView(C.Structure):
     """ws_conv_view: the A operand of ws_gemm_nt / ws_gemm_tn as an implicit im2col matrix (include/wesep_hip.h)."""
     _fields_ = [(n, _i) for n in ("on", "mode", "H", "W", "C", "Ho", "Wo", "k", "sh", "sw", "p", "dil", "ldp")]
+
+
+class Conv3x3Args(C.Structure):
+    _fields_ = [(n, _p) for n in ("X", "W", "bias", "R", "Y")] + [(n, _ll) for n in ("ldx", "ldw", "ldy")] + \
+               [(n, _i) for n in ("B", "H", "Wd", "Cin", "Cout", "pad_")]
+
+
+class Conv3x3WgradArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("G", "X", "slab", "bslab")] + [(n, _ll) for n in ("ldg", "ldx", "slab_stride", "bslab_stride")] + \
+               [(n, _i) for n in ("B", "H", "Wd", "Cin", "Nn", "nsplit", "tiles_per_split", "pad_")]
 
 
 class GemmNTArgs(C.Structure):
@@ -203,6 +213,8 @@ _SIGS = {
     "ws_scale_bf_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ws_softmax_rows_fwd": (_i, [_p, _ll, _i, C.c_float, _p, _p]),
     "ws_softmax_rows_bwd": (_i, [_p, _p, _ll, _i, C.c_float, _p, _p]),
+    "ws_conv3x3": (_i, [C.POINTER(Conv3x3Args), _p]),
+    "ws_conv3x3_wgrad": (_i, [C.POINTER(Conv3x3WgradArgs), _p]),
     "ws_in_act_sums": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "ws_in_act_apply": (_i, [_p, _p, _ll, _i, _i, _i, _p, _p]),
     "ws_in_act_bwd_apply": (_i, [_p, _p, _p, _p, _ll, _i, _i, _i, _p, _p]),

@@ -1,0 +1,367 @@
+// 3 x 3, stride-1, "same" convolution on a channels-last image with an LDS halo tile, and its weight gradient (round 3).
+//
+// DPCCN spends two thirds of its step in the 3 x 3 convolutions of its dense blocks (convs.py:80-112: five layers of
+// 16 or 32 output channels on a growing feature map of up to 80 / 160 channels, at up to 2 M pixels).  The implicit-GEMM
+// path (gemm_bf16.hip with ws_conv_view) forms every output pixel's k*k*C patch row from global memory: each input pixel
+// crosses the L2 -> CU path NINE times, and with 16 .. 32 output columns there is next to no arithmetic to hide it behind.
+//
+// ws_conv3x3 (forward, and the input gradient with flipped weights).  A workgroup (4 waves) owns a tile of 32 rows x 4P
+// columns of output pixels of one image (wave = P adjacent columns, lane = row: DPCCN's grids are 251 frames x 2^k + 1
+// bins, so tiles that are long in h and narrow in w waste a few percent of their slots where 128-pixel row segments
+// wasted 33-87 %).  For each chunk of 16 input channels it stages the 34 x (4P + 2) pixel halo ONCE in LDS as bf16
+// hi / lo planes ([column][row][channel], 48-byte pixel stride: conflict-free 16-byte fragment reads); a pixel fragment
+// (one halo column under one ky) then serves the three output columns it is a tap of, and a weight fragment (read from
+// the L1-resident packed weights) serves the wave's P columns: per 3 MFMAs the wave reads ~0.5 KB from LDS and ~0.17 KB
+// from L1 (v2, one column per wave and nothing shared: 2 KB + 2 KB -- it ran at the L1 rate, no faster than the
+// implicit GEMM).
+//
+//   Y[m][n] = bias[n] + R[m][n] + sum_{ky, kx, c} X[pixel(m) + (ky - 1, kx - 1)][c] * W[n][(ky * 3 + kx) * Cin + c]
+//
+// m = (b * H + h) * Wd + w; X has pixel stride ldx (>= Cin: the image may be the first Cin columns of a wider tensor),
+// Y and R have row stride ldy (the output may be the first Cout columns of a wider tensor, and R may alias Y: every
+// element is read by the thread that writes it).  Products are split-bf16 (3 MFMAs), fp32 accumulation, like every
+// other GEMM of the library.  The same kernel is the input gradient of such a convolution: X = dY, W = the flipped,
+// channel-swapped weights, Y = R = the gradient buffer it accumulates into.
+// Orientation: D[m = output channel][n = pixel] -- the weights are the A operand, PRE-PACKED by the host into MFMA
+// fragment order as bf16 hi / lo (dev.conv3x3_pack: unit (((chunk*9 + tap)*NTP + t)*2 + part)*64 + lane holds the 8
+// channels 16 chunk + 8 (lane >> 5) + j of row t*32 + (lane & 31)); the pixels are the B operand (from LDS).  A lane
+// then holds four consecutive output channels of its pixel per register quad and stores them as 16-byte pieces.  More
+// than 64 output channels are cut into groups of 64 (blockIdx.z), each re-staging the (then narrow: that is the input
+// gradient of a 16 / 32-channel layer) halo.
+//
+// ws_conv3x3_wgrad (weight gradient).  K = pixels: both MFMA operands want 8 CONSECUTIVE pixels per lane, and a tap
+// shifts one operand against the other.  The tile is 30 rows x 4 columns (wave = column); k runs over the 32 halo rows
+// of a column.  X is staged transposed ([halo column][channel][row], 80-byte rows) once per tile and needs no shift for
+// ky (kx picks the halo column); dY is staged transposed once ([column][channel][8 zeros | 30 rows | 2 zeros]) and the
+// ky = 1 / 2 fragments are the aligned 16-byte block and its predecessor funnel-shifted by one / two elements in
+// registers (v_alignbit / a register rename).  Nine accumulators (taps) of [32 output channels][32 input channels] per
+// wave; a workgroup owns one 32-channel chunk of the input and a range of tiles (a "split"), reduces its four waves
+// through LDS and writes one slab -- the caller sums the slabs (deterministic, no atomics).  conv_wgrad.hip, which this
+// replaces for 3 x 3 / stride 1, staged every tap's patch separately: nine splits and transposes per input element.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define C3_TH 32                  // output rows per workgroup (= MFMA N: lane = row)
+#define C3_CC 16                  // input channels per LDS chunk (one MFMA k-step)
+#define C3_PS 24                  // bf16 per pixel in an LDS plane (16 + 8: 48 B)
+#define C3_COL ((C3_TH + 2) * C3_PS)          // one halo column: 34 pixels
+
+__device__ __forceinline__ void c3_split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi[j] = (__bf16)v[j];
+    lo[j] = (__bf16)(v[j] - (float)hi[j]);
+  }
+}
+
+template <int NT, int P>          // 32-channel tiles of output channels per workgroup; output columns per wave
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ws_conv3x3_args p) {
+  constexpr int NC = 4 * P + 2, PLANE = NC * C3_COL;                  // halo columns; bf16 per plane
+  __shared__ __attribute__((aligned(16))) __bf16 halo[2][PLANE];      // [plane hi / lo][column][row][channel]  P = 4: 58.8 KB
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, Wd = p.Wd, Cin = p.Cin, Cout = p.Cout;
+  const int ntt = (Cout + 31) / 32, ntp = ntt <= 2 ? ntt : (ntt + 1) & ~1, ng = ntp / NT;
+  const int w0 = blockIdx.x * 4 * P, h0 = blockIdx.y * C3_TH, b = blockIdx.z / ng, tg = (blockIdx.z - b * ng) * NT;
+  const long long img = (long long)b * H * Wd;
+
+  f32x16 acc[P][NT];
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+  const bf16x8* wpk = reinterpret_cast<const bf16x8*>(p.W);
+
+  for (int c0 = 0; c0 < Cin; c0 += C3_CC) {
+    // ---- halo of this channel chunk -> LDS (zeros outside the image and beyond Cin) ----
+    for (int i = tid; i < (C3_TH + 2) * NC * (C3_CC / 4); i += 256) {
+      const int q = i & 3, pix = i >> 2, col = pix % NC, row = pix / NC;   // consecutive threads: channels, then w
+      const int hh = h0 + row - 1, ww = w0 + col - 1, c = c0 + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)Wd && c < Cin)
+        v = *reinterpret_cast<const f32x4*>(p.X + (img + (long long)hh * Wd + ww) * p.ldx + c);
+      bf16x4 hi, lo;
+      c3_split4(v, hi, lo);
+      const int o = col * C3_COL + row * C3_PS + 4 * q;
+      *reinterpret_cast<bf16x4*>(&halo[0][o]) = hi;
+      *reinterpret_cast<bf16x4*>(&halo[1][o]) = lo;
+    }
+    __syncthreads();
+    const long long u0 = (long long)(c0 / C3_CC) * 9 * ntp;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      bf16x8 ah[3][NT], al[3][NT];               // this ky's weight fragments: 3 taps x NT tiles, hi / lo
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const long long u = ((u0 + (ky * 3 + kx) * ntp + tg + t) * 2) * 64 + lane;
+          ah[kx][t] = wpk[u];
+          al[kx][t] = wpk[u + 64];
+        }
+#pragma unroll
+      for (int jc = 0; jc < P + 2; ++jc) {       // halo column jc of the wave: tap kx of its output column jc - kx
+        const __bf16* bp = &halo[0][(wv * P + jc) * C3_COL + (l31 + ky) * C3_PS + 8 * half];
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + PLANE);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int j = jc - kx;
+          if (j < 0 || j >= P) continue;           // compile time
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kx][t], bh, acc[j][t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kx][t], bh, acc[j][t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kx][t], bl, acc[j][t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();   // the next chunk overwrites the halo
+  }
+  // ---- epilogue: D[m = channel][n = pixel]; register r of a lane: channel (r & 3) + 8 (r >> 2) + 4 half of its tile ----
+  const int h = h0 + l31;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const int w = w0 + wv * P + j;
+    if (w < Wd && h < H) {
+      float* yrow = p.Y + (img + (long long)h * Wd + w) * p.ldy;
+      const float* rrow = p.R ? p.R + (img + (long long)h * Wd + w) * p.ldy : nullptr;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = (tg + t) * 32 + 8 * g + 4 * half;
+          if (n < Cout) {                           // Cout % 4 == 0: a quad is inside or outside as a whole
+            f32x4 v = {acc[j][t][4 * g], acc[j][t][4 * g + 1], acc[j][t][4 * g + 2], acc[j][t][4 * g + 3]};
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
+            *reinterpret_cast<f32x4*>(yrow + n) = v;
+          }
+        }
+    }
+  }
+}
+
+template <int NT, int P>
+static void c3_launch(const ws_conv3x3_args* a, hipStream_t s) {
+  const int ntt = (a->Cout + 31) / 32, ntp = ntt <= 2 ? ntt : (ntt + 1) & ~1, ng = ntp / NT;
+  const dim3 grid((a->Wd + 4 * P - 1) / (4 * P), (a->H + C3_TH - 1) / C3_TH, a->B * ng), block(256);
+  hipLaunchKernelGGL((conv3x3_kernel<NT, P>), grid, block, 0, s, *a);
+}
+
+extern "C" int ws_conv3x3(const ws_conv3x3_args* a, void* stream) {
+  WS_REQUIRE(a && a->X && a->W && a->Y, "ws_conv3x3: null pointer");
+  WS_REQUIRE(a->B > 0 && a->H > 0 && a->Wd > 0 && a->Cin > 0 && a->Cin % 4 == 0 && a->Cout > 0 && a->Cout % 4 == 0 &&
+                 a->Cout <= 1024,
+             "ws_conv3x3: Cin %% 4, Cout %% 4, Cout <= 1024 (got %d, %d)", a->Cin, a->Cout);
+  WS_REQUIRE(a->ldx >= a->Cin && a->ldx % 4 == 0 && a->ldy >= a->Cout && a->ldy % 4 == 0,
+             "ws_conv3x3: leading dimensions (ldx >= Cin, ldy >= Cout, both %% 4)");
+  WS_REQUIRE(a->H <= 65535 * C3_TH && (long long)a->B * ((a->Cout + 63) / 64) <= 65535,
+             "ws_conv3x3: H / 32 and B * ceil(Cout / 64) index the launch grid (<= 65535)");
+  hipStream_t s = (hipStream_t)stream;
+  ws_prof_begin(WS_PROF_GEMM_NT, s);
+  const bool wide = a->Wd >= 100;                 // 16-column tiles where they fill; 8-column tiles on the small grids
+  if (a->Cout <= 32) {
+    if (wide) c3_launch<1, 4>(a, s); else c3_launch<1, 2>(a, s);
+  } else {
+    if (wide) c3_launch<2, 4>(a, s); else c3_launch<2, 2>(a, s);
+  }
+  ws_prof_end(WS_PROF_GEMM_NT, s);
+  return ws_check_launch("ws_conv3x3");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------------------------
+#define W3_TH 30                  // output rows per tile: their 3 x 3 windows span 32 halo rows = the MFMA K of two steps
+#define W3_LD 40                  // bf16 per LDS row (32 + 8: 80 B, conflict-free 16-byte fragment reads)
+#define W3_XB (6 * 32 * W3_LD)    // X plane: [halo column 6][channel 32][row]
+#define W3_AB (4 * 32 * W3_LD)    // dY plane: [column 4][output channel 32][8 zeros | rows 0..29 | 2 zeros]
+
+__device__ __forceinline__ bf16x8 w3_frag(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const ws_conv3x3_wgrad_args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * W3_XB + 2 * W3_AB];   // 51,200 B: two workgroups per CU
+  __bf16* const xb = lds;                      // planes at xb, xb + W3_XB
+  __bf16* const ab = lds + 2 * W3_XB;          // planes at ab, ab + W3_AB
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, Wd = p.Wd, Cin = p.Cin;
+  const int split = blockIdx.x, c0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
+  const int nn = min(32, p.Nn - n0);
+  const int ncg = (Wd + 3) / 4, nrt = (H + W3_TH - 1) / W3_TH;
+  const long long ntiles = (long long)p.B * nrt * ncg;
+  const long long t_begin = (long long)split * p.tiles_per_split, t_end = min(ntiles, t_begin + p.tiles_per_split);
+
+  for (int i = tid; i < (2 * W3_XB + 2 * W3_AB) / 2; i += 256) reinterpret_cast<uint32_t*>(lds)[i] = 0u;   // the pads stay zero
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = p.bslab && blockIdx.y == 0;
+
+  // staging items: X (8 row quads x 6 halo columns x 8 channel quads = 384: threads < 128 take a second one),
+  //                dY (8 row quads x 4 columns x 8 channel quads = 256)
+  int x_cq[2], x_hc[2], x_hq[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int it = tid + 256 * i;
+    x_cq[i] = it & 7;
+    x_hc[i] = (it >> 3) % 6;
+    x_hq[i] = (it >> 3) / 6;
+  }
+  const int g_nq = tid & 7, g_col = (tid >> 3) & 3, g_hq = tid >> 5;
+
+  for (long long tile = t_begin; tile < t_end; ++tile) {
+    const int cg = (int)(tile % ncg), rt = (int)((tile / ncg) % nrt), b = (int)(tile / ((long long)ncg * nrt));
+    const int h0 = rt * W3_TH, w0 = cg * 4;
+    const long long img = (long long)b * H * Wd;
+    __syncthreads();                             // the previous tile's fragment reads (and the zero fill) are done
+    // ---- X halo, transposed: 4 consecutive rows of one channel become one 8-byte group ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i == 1 && tid >= 128) break;
+      const int ww = w0 - 1 + x_hc[i], c = c0 + 4 * x_cq[i];
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int hh = h0 - 1 + 4 * x_hq[i] + j;
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)Wd && c < Cin)
+          v[j] = *reinterpret_cast<const f32x4*>(p.X + (img + (long long)hh * Wd + ww) * p.ldx + c);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bf16x4 hi, lo;
+        c3_split4(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, hi, lo);
+        const int o = (x_hc[i] * 32 + 4 * x_cq[i] + e) * W3_LD + 4 * x_hq[i];
+        *reinterpret_cast<bf16x4*>(xb + o) = hi;
+        *reinterpret_cast<bf16x4*>(xb + W3_XB + o) = lo;
+      }
+    }
+    // ---- dY tile, transposed, behind 8 zeros ----
+    {
+      const int ww = w0 + g_col, n = 4 * g_nq;
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ii = 4 * g_hq + j, hh = h0 + ii;
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ii < W3_TH && hh < H && ww < Wd && n < nn)
+          v[j] = *reinterpret_cast<const f32x4*>(p.G + (img + (long long)hh * Wd + ww) * p.ldg + n0 + n);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bf16x4 hi, lo;
+        c3_split4(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, hi, lo);
+        gsum[e] += (v[0][e] + v[1][e]) + (v[2][e] + v[3][e]);
+        const int o = (g_col * 32 + n + e) * W3_LD + 8 + 4 * g_hq;
+        *reinterpret_cast<bf16x4*>(ab + o) = hi;
+        *reinterpret_cast<bf16x4*>(ab + W3_AB + o) = lo;
+      }
+    }
+    __syncthreads();
+    // ---- 2 k-steps x 3 kx x 3 ky ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ao = (wv * 32 + l31) * W3_LD + 8 + 16 * ks + 8 * half;
+      u32x4 a_h[3], a_l[3];
+      {
+        const u32x4 ch = *reinterpret_cast<const u32x4*>(ab + ao), ph = *reinterpret_cast<const u32x4*>(ab + ao - 8);
+        const u32x4 cl = *reinterpret_cast<const u32x4*>(ab + W3_AB + ao), pl = *reinterpret_cast<const u32x4*>(ab + W3_AB + ao - 8);
+        a_h[0] = ch;                             // k pairs X row h0 - 1 + k with dY row k - ky of the tile
+        a_l[0] = cl;
+        a_h[1] = u32x4{__builtin_amdgcn_alignbit(ch.x, ph.w, 16), __builtin_amdgcn_alignbit(ch.y, ch.x, 16),
+                       __builtin_amdgcn_alignbit(ch.z, ch.y, 16), __builtin_amdgcn_alignbit(ch.w, ch.z, 16)};
+        a_l[1] = u32x4{__builtin_amdgcn_alignbit(cl.x, pl.w, 16), __builtin_amdgcn_alignbit(cl.y, cl.x, 16),
+                       __builtin_amdgcn_alignbit(cl.z, cl.y, 16), __builtin_amdgcn_alignbit(cl.w, cl.z, 16)};
+        a_h[2] = u32x4{ph.w, ch.x, ch.y, ch.z};
+        a_l[2] = u32x4{pl.w, cl.x, cl.y, cl.z};
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int bo = ((wv + kx) * 32 + l31) * W3_LD + 16 * ks + 8 * half;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(xb + bo);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(xb + W3_XB + bo);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3_frag(a_h[ky]), bh, acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3_frag(a_l[ky]), bh, acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3_frag(a_h[ky]), bl, acc[ky * 3 + kx], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- the four waves' partial sums -> wave 0, three taps per round through LDS (9216 floats) ----
+  float* const red = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) {
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wv - 1) * 3 + tp) * 1024 + r * 64 + lane] = acc[3 * rr + tp][r];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[3 * rr + tp][r] += (red[tp * 1024 + r * 64 + lane] + red[(3 + tp) * 1024 + r * 64 + lane]) + red[(6 + tp) * 1024 + r * 64 + lane];
+    }
+  }
+  const int K_all = 9 * Cin;
+  if (wv == 0 && c0 + l31 < Cin) {
+    float* out = p.slab + (long long)split * p.slab_stride;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n < nn) out[(long long)(n0 + n) * K_all + tap * Cin + c0 + l31] = acc[tap][r];
+      }
+  }
+  if (want_bias) {                               // db[n] = sum over the split's pixels of dy[.][n]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[tid * 4 + e] = gsum[e];
+    __syncthreads();
+    if (tid < nn) {
+      float t = 0.f;
+      for (int u = 0; u < 32; ++u) t += red[(u * 8 + (tid >> 2)) * 4 + (tid & 3)];
+      p.bslab[(long long)split * p.bslab_stride + n0 + tid] = t;
+    }
+  }
+}
+
+extern "C" int ws_conv3x3_wgrad(const ws_conv3x3_wgrad_args* a, void* stream) {
+  WS_REQUIRE(a && a->G && a->X && a->slab, "ws_conv3x3_wgrad: null pointer");
+  WS_REQUIRE(a->B > 0 && a->H > 0 && a->Wd > 0 && a->Cin > 0 && a->Cin % 4 == 0 && a->Nn > 0 && a->Nn % 4 == 0,
+             "ws_conv3x3_wgrad: Cin %% 4, Nn %% 4 (got %d, %d)", a->Cin, a->Nn);
+  WS_REQUIRE(a->ldx >= a->Cin && a->ldx % 4 == 0 && a->ldg >= a->Nn && a->ldg % 4 == 0,
+             "ws_conv3x3_wgrad: leading dimensions (ldx >= Cin, ldg >= Nn, both %% 4)");
+  const long long ntiles = (long long)a->B * ((a->H + W3_TH - 1) / W3_TH) * ((a->Wd + 3) / 4);
+  WS_REQUIRE(a->nsplit > 0 && a->tiles_per_split > 0 && (long long)a->nsplit * a->tiles_per_split >= ntiles,
+             "ws_conv3x3_wgrad: %d splits of %d tiles do not cover the %lld tiles (30 rows x 4 columns)", a->nsplit,
+             a->tiles_per_split, ntiles);
+  WS_REQUIRE(a->slab_stride >= (long long)a->Nn * 9 * a->Cin && (!a->bslab || a->bslab_stride >= a->Nn),
+             "ws_conv3x3_wgrad: slab strides");
+  WS_REQUIRE((a->Cin + 31) / 32 <= 65535 && (a->Nn + 31) / 32 <= 65535, "ws_conv3x3_wgrad: channel counts index the launch grid");
+  hipStream_t s = (hipStream_t)stream;
+  ws_prof_begin(WS_PROF_GEMM_TN, s);
+  hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(a->nsplit, (a->Cin + 31) / 32, (a->Nn + 31) / 32), dim3(256), 0, s, *a);
+  ws_prof_end(WS_PROF_GEMM_TN, s);
+  return ws_check_launch("ws_conv3x3_wgrad");
+}

@@ -1122,6 +1122,51 @@ def inorm_bwd(y, dy, stats, G: int, P: int, Cc: int, dx):
     _call("ws_inorm_bwd_apply", _p(y), _p(dy), _p(stats), _p(sums), G * P, P, Cc, _p(dx))
 
 
+def conv3x3_pack(W2, Cin: int, Cout: int):
+    """W2 [Cout, 9 * Cin] (tap-major rows: (ky*3 + kx)*Cin + ci) -> the bf16 hi / lo MFMA-fragment order ws_conv3x3 reads
+    (include/wesep_hip.h), as a float32-typed tensor of packed pairs.  A handful of torch ops on a tiny tensor."""
+    ntt, nch = -(-Cout // 32), -(-Cin // 16)
+    ntp = ntt if ntt <= 2 else ntt + (ntt & 1)
+    Wp = torch.zeros(ntp * 32, 9, nch * 16, device=W2.device, dtype=torch.float32)
+    Wp[:Cout, :, :Cin] = W2.reshape(Cout, 9, Cin)
+    hi = Wp.to(torch.bfloat16)
+    lo = (Wp - hi.to(torch.float32)).to(torch.bfloat16)
+    both = torch.stack([hi, lo], 0).view(2, ntp, 32, 9, nch, 2, 8)             # part, t, l31, tap, chunk, half, j
+    return both.permute(4, 3, 1, 0, 5, 2, 6).contiguous().view(torch.float32).reshape(-1)
+
+
+def conv3x3(*, X, ldx: int, W, ldw: int, B: int, H: int, Wd: int, Cin: int, Cout: int, Y, ldy: int, bias=None, R=None):
+    """3 x 3 / stride 1 / padding 1 convolution through an LDS halo tile (conv3x3.hip); Y = bias + R + conv(X); W = the
+    packed weights of conv3x3_pack."""
+    for n, t in (("X", X), ("W", W), ("bias", bias), ("R", R), ("Y", Y)):
+        _chk(t, n)
+    a = L.Conv3x3Args()
+    a.X, a.W, a.bias, a.R, a.Y = _p(X), _p(W), _p(bias), _p(R), _p(Y)
+    a.ldx, a.ldw, a.ldy = ldx, ldw, ldy
+    a.B, a.H, a.Wd, a.Cin, a.Cout = B, H, Wd, Cin, Cout
+    _alg("gemm_nt", 4 * (B * H * Wd * (Cin + Cout * (1 + (R is not None))) + 9 * Cin * Cout), 2 * B * H * Wd * 9 * Cin * Cout)
+    L.check(L.lib().ws_conv3x3(C.byref(a), L.stream_ptr()), "ws_conv3x3")
+
+
+def conv3x3_wgrad_tiles(B: int, H: int, Wd: int) -> int:
+    """Tiles (30 rows x 4 columns) ws_conv3x3_wgrad cuts B images of H x Wd into."""
+    return B * (-(-H // 30)) * (-(-Wd // 4))
+
+
+def conv3x3_wgrad(*, G, ldg: int, X, ldx: int, B: int, H: int, Wd: int, Cin: int, Nn: int, slab, nsplit: int,
+                  tiles_per_split: int, bslab=None):
+    """Weight (+ bias) gradient slabs of a 3 x 3 / stride 1 / padding 1 convolution, one pass over the image
+    (conv3x3.hip): slab [nsplit, Nn * 9 * Cin], bslab [nsplit, Nn]."""
+    for n, t in (("G", G), ("X", X), ("slab", slab), ("bslab", bslab)):
+        _chk(t, n)
+    a = L.Conv3x3WgradArgs()
+    a.G, a.X, a.slab, a.bslab = _p(G), _p(X), _p(slab), _p(bslab)
+    a.ldg, a.ldx, a.slab_stride, a.bslab_stride = ldg, ldx, Nn * 9 * Cin, Nn
+    a.B, a.H, a.Wd, a.Cin, a.Nn, a.nsplit, a.tiles_per_split = B, H, Wd, Cin, Nn, nsplit, tiles_per_split
+    _alg("gemm_tn", 4 * (B * H * Wd * (Cin + Nn * (-(-Cin // 32))) + nsplit * Nn * 9 * Cin), 2 * B * H * Wd * Nn * 9 * Cin)
+    L.check(L.lib().ws_conv3x3_wgrad(C.byref(a), L.stream_ptr()), "ws_conv3x3_wgrad")
+
+
 IN_ELU_PRE, IN_ELU_POST = 1, 2     # ws_in_act_* flags: y = IN(ELU(x)) / y = ELU(IN(x))
 
 

@@ -12,6 +12,8 @@ weight gradient of Conv2d and ConvTranspose2d never write or read the k*k-times 
 view0 = convolution view (input pixel o*s + tap - p), view1 = transposed view (input pixel (o + p - tap)/s when exact).
 Channel counts that are not a multiple of 4 (the single-channel first layer of the ResNet) use the explicit patch matrix.
 Reference lines: wesep/modules/dpccn/convs.py:28-110 (Conv2dBlock / ConvTrans2dBlock / DenseBlock)."""
+import os
+
 import torch
 
 from . import dev
@@ -53,9 +55,34 @@ def _one_pass_wgrad(G, M, Nn, X, conv, with_bias):
     return dW, db
 
 
+def halo_wgrad_ok(Cin, Cout, k, sh, sw, p, dil=1):
+    """The halo-tile weight gradient (conv3x3.hip) takes this convolution."""
+    return (k, sh, sw, p, dil) == (3, 1, 1, 1, 1) and Cin % 4 == 0 and Cout % 4 == 0 and os.environ.get("WESEP_CONV3X3_WGRAD", "1") != "0"
+
+
+def halo_wgrad(G, Nn, X, ldx, B, H, W, Cin, with_bias):
+    """dW2 [Nn, 9*Cin] (+ db) of a 3 x 3 / stride 1 / padding 1 convolution: G [B*H*W, Nn] gradient rows, X the image with
+    pixel stride ldx (its first Cin channels)."""
+    tiles = dev.conv3x3_wgrad_tiles(B, H, W)
+    groups = (-(-Cin // 32)) * (-(-Nn // 32))              # workgroups per split: one per (input chunk, output tile)
+    nsplit = max(1, min(tiles // 4, -(-1024 // groups)))   # ~4 workgroups per CU in flight, >= 4 tiles each
+    tps = -(-tiles // nsplit)
+    nsplit = -(-tiles // tps)
+    d = G.device
+    slab = _empty(d, nsplit, Nn * 9 * Cin)
+    bslab = _empty(d, nsplit, Nn) if with_bias else None
+    dev.conv3x3_wgrad(G=G, ldg=Nn, X=X, ldx=ldx, B=B, H=H, Wd=W, Cin=Cin, Nn=Nn, slab=slab, nsplit=nsplit,
+                      tiles_per_split=tps, bslab=bslab)
+    dW = _reduce_new(slab, nsplit, Nn * 9 * Cin, (Nn, 9 * Cin))
+    db = _reduce_new(bslab, nsplit, Nn, (Nn,)) if with_bias else None
+    return dW, db
+
+
 def conv2d_wgrad(dy, x, B, H, W, Cin, Cout, k, sh, sw, p, with_bias=True, dil=1):
     """dW2 [Cout, k*k*Cin] = dy^T view0(x) (+ db)."""
     Ho, Wo = _out(H, k, sh, p, dil), _out(W, k, sw, p, dil)
+    if halo_wgrad_ok(Cin, Cout, k, sh, sw, p, dil):
+        return halo_wgrad(dy, Cout, x, Cin, B, H, W, Cin, with_bias)
     conv = ConvView(0, H, W, Cin, Ho, Wo, k, sh, sw, p, dil)
     if dev.conv_wgrad_ok(Cout, conv):
         return _one_pass_wgrad(dy, B * Ho * Wo, Cout, x, conv, with_bias)

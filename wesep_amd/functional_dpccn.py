@@ -242,9 +242,11 @@ class DenseBlockFn(torch.autograd.Function):
         saved, out = [], None
         for i in range(5):
             Ci, Co = C0 + i * g, ws[i].shape[0]
-            W2, Wd = FC.conv2d_weights(ws[i])
-            pre = _gemm(big, M, 9 * Ci, W2, Co, bias=bs[i], vec=3, mode=FC.MODE,
-                        conv=dev.ConvView(0, H, W, Ci, H, W, 3, 1, 1, 1, 1, Ctot))
+            W2 = dev.conv3x3_pack(ws[i].permute(0, 2, 3, 1).reshape(Co, 9 * Ci), Ci, Co)    # [co][(ky*3 + kx)*Ci + ci]
+            # input gradient = the correlation of dy with the flipped kernel: [ci][(ky*3 + kx)*Co + co] = w[co][ci][2 - ky][2 - kx]
+            Wd = dev.conv3x3_pack(ws[i].flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, 9 * Co), Co, Ci)
+            pre = _empty(d, M, Co)
+            dev.conv3x3(X=big, ldx=Ctot, W=W2, ldw=9 * Ci, B=B, H=H, Wd=W, Cin=Ci, Cout=Co, Y=pre, ldy=Co, bias=bs[i])
             out = _empty(d, M, Co)
             st = dev.in_act_fwd(pre, B, H * W, Co, dev.IN_ELU_PRE, out)
             if i < 4:
@@ -272,15 +274,17 @@ class DenseBlockFn(torch.autograd.Function):
             d_pre = _empty(d, M, Co)
             dev.in_act_bwd(pre, d_out, st, B, H * W, Co, dev.IN_ELU_PRE, d_pre)
             conv = dev.ConvView(0, H, W, Ci, H, W, 3, 1, 1, 1, 1, Ctot)
-            if dev.conv_wgrad_ok(Co, conv):
+            if FC.halo_wgrad_ok(Ci, Co, 3, 1, 1, 1):
+                dW2, db = FC.halo_wgrad(d_pre, Co, big, Ctot, B, H, W, Ci, True)
+            elif dev.conv_wgrad_ok(Co, conv):
                 dW2, db = FC._one_pass_wgrad(d_pre, M, Co, big, conv, True)
             else:
                 dW2, db = _wgrad(d_pre, M, Co, big, 9 * Ci, with_bias=True, vec=1, mode=FC.MODE, conv=conv)
             grads[2 * i] = dW2.reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous().view(wshapes[i])
             grads[2 * i + 1] = db
             # d(first Ci channels of the map) += transposed view of d_pre (conv2d_dx), accumulated in place
-            _gemm(d_pre, M, 9 * Co, Wd, Ci, vec=3, mode=FC.MODE, conv=dev.ConvView(1, H, W, Co, H, W, 3, 1, 1, 1),
-                  out=dbig, c_ld=Ctot, R=None if i == 4 else dbig)
+            dev.conv3x3(X=d_pre, ldx=Co, W=Wd, ldw=9 * Co, B=B, H=H, Wd=W, Cin=Co, Cout=Ci, Y=dbig, ldy=Ctot,
+                        R=None if i == 4 else dbig)
         dx = dbig[:, :C0].contiguous() if ctx.needs_input_grad[0] else None
         return (dx, None) + tuple(grads)
 
