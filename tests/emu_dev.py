@@ -476,7 +476,11 @@ def conv3x3_wgrad(*, G, ldg, X, ldx, B, H, Wd, Cin, Nn, slab, nsplit, tiles_per_
 IN_ELU_PRE, IN_ELU_POST = 1, 2
 
 
-def in_act_fwd(x, G, P, Cc, flags, y, eps=1e-5):
+def _cols(t, rows, ld, off, Cc):
+    return t.reshape(-1)[:rows * ld].reshape(rows, ld)[:, off:off + Cc] if ld else t.reshape(rows, Cc)
+
+
+def in_act_fwd(x, G, P, Cc, flags, y, eps=1e-5, y_ld=0, y_off=0):
     u = x.reshape(G, P, Cc)
     if flags & 1:
         u = F.elu(u)
@@ -484,12 +488,12 @@ def in_act_fwd(x, G, P, Cc, flags, y, eps=1e-5):
     var = (u * u).mean(1) - mean * mean
     rstd = 1.0 / torch.sqrt(var.clamp_min(0) + eps)
     n = (u - mean[:, None]) * rstd[:, None]
-    y.reshape(G, P, Cc)[:] = F.elu(n) if flags & 2 else n
+    _cols(y, G * P, y_ld, y_off, Cc)[:] = (F.elu(n) if flags & 2 else n).reshape(G * P, Cc)
     return torch.stack([mean, rstd], 1)
 
 
-def in_act_bwd(x, dy, stats, G, P, Cc, flags, dx):
-    xx, dd = x.reshape(G, P, Cc), dy.reshape(G, P, Cc)
+def in_act_bwd(x, dy, stats, G, P, Cc, flags, dx, dy_ld=0, dy_off=0):
+    xx, dd = x.reshape(G, P, Cc), _cols(dy, G * P, dy_ld, dy_off, Cc).reshape(G, P, Cc)
     u = F.elu(xx) if flags & 1 else xx
     mean, rstd = stats[:, 0][:, None], stats[:, 1][:, None]
     n = (u - mean) * rstd

@@ -344,3 +344,29 @@ def test_conv3x3_halo_weight_gradient_vs_torch(B, H, W, Cin, Nn, ldx):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert rel(outs[0][0], ref) < 2e-5
     assert rel(outs[0][1], gg.sum((0, 2, 3))) < 1e-5
+
+
+def test_fused_elu_instancenorm_on_a_column_range():
+    """dev.in_act_fwd writing into / dev.in_act_bwd reading from columns of a wider tensor (the dense blocks' feature map)
+    give the bits of the dense call, and leave the other columns alone."""
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(9)
+    G, P, C, ld, off = 3, 150, 16, 48, 20
+    x = torch.randn(G * P, C, generator=g).to(d)
+    dy = torch.randn(G * P, C, generator=g).to(d)
+    wide0 = torch.randn(G * P, ld, generator=g).to(d)
+    y = torch.empty(G * P, C, device=d)
+    st = dev.in_act_fwd(x, G, P, C, dev.IN_ELU_PRE, y)
+    wide = wide0.clone()
+    st2 = dev.in_act_fwd(x, G, P, C, dev.IN_ELU_PRE, wide, y_ld=ld, y_off=off)
+    assert torch.equal(st, st2) and torch.equal(wide[:, off:off + C], y)
+    assert torch.equal(wide[:, :off], wide0[:, :off]) and torch.equal(wide[:, off + C:], wide0[:, off + C:])
+    dx = torch.empty_like(x)
+    dev.in_act_bwd(x, dy, st, G, P, C, dev.IN_ELU_PRE, dx)
+    wide[:, off:off + C] = dy
+    dx2 = torch.empty_like(x)
+    dev.in_act_bwd(x, wide, st, G, P, C, dev.IN_ELU_PRE, dx2, dy_ld=ld, dy_off=off)
+    assert torch.equal(dx, dx2)
+    with pytest.raises(dev.L.WesepHipError):
+        dev.in_act_fwd(x, G, P, C, dev.IN_ELU_PRE, wide, y_ld=ld, y_off=ld - 8)

@@ -581,7 +581,7 @@ __device__ __forceinline__ f32x4 elud4(const f32x4& v) {   // d ELU(v) / dv
 // backward: (sum d, sum d * n), n = (u - mean) * rstd, d = dy * (flags & 2 ? ELU'(n) : 1)
 __global__ __launch_bounds__(256) void in_act_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ stats, int P, int G, int nsplit, int C,
-                                                          int flags, float* __restrict__ slab) {
+                                                          int flags, long long ldd, float* __restrict__ slab) {
   __shared__ f32x4 red[2][256];
   const int c4n = C >> 2;
   const int cz = blockIdx.z * 256;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void in_act_sums_kernel(const float* __restric
         s1 += u * u;
       } else {
         const f32x4 n = (u - mean) * rstd;
-        f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * C + c);
+        f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * ldd + c);
         if (flags & 2) d *= elud4(n);
         s0 += d;
         s1 += d * n;
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void in_act_sums_kernel(const float* __restric
 }
 
 __global__ void in_act_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, long long rows, int P,
-                                    int C, int flags, float* __restrict__ y) {
+                                    int C, int flags, long long ldy, float* __restrict__ y) {
   const int c4n = C >> 2;
   const long long total = rows * c4n;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -644,13 +644,14 @@ __global__ void in_act_apply_kernel(const float* __restrict__ x, const float* __
     if (flags & 1) u = elu4(u);
     f32x4 n = (u - *reinterpret_cast<const f32x4*>(st + c)) * *reinterpret_cast<const f32x4*>(st + C + c);
     if (flags & 2) n = elu4(n);
-    *reinterpret_cast<f32x4*>(y + i * 4) = n;
+    *reinterpret_cast<f32x4*>(y + row * ldy + c) = n;
   }
 }
 
 // dx = pre'(x) * rstd * (d - S0/P - n * S1/P)      (dx may alias dy)
 __global__ void in_act_bwd_apply_kernel(const float* __restrict__ x, const float* dy, const float* __restrict__ stats,
-                                        const float* __restrict__ sums, long long rows, int P, int C, int flags, float* dx) {
+                                        const float* __restrict__ sums, long long rows, int P, int C, int flags,
+                                        long long ldd, float* dx) {
   const int c4n = C >> 2;
   const long long total = rows * c4n;
   const float inv = 1.f / (float)P;
@@ -666,7 +667,7 @@ __global__ void in_act_bwd_apply_kernel(const float* __restrict__ x, const float
     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
     const f32x4 u = (flags & 1) ? elu4(xv) : xv;
     const f32x4 n = (u - mean) * rstd;
-    f32x4 d = *reinterpret_cast<const f32x4*>(dy + i * 4);
+    f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * ldd + c);
     if (flags & 2) d *= elud4(n);
     f32x4 r = rstd * (d - s0 - n * s1);
     if (flags & 1) r *= elud4(xv);
@@ -674,30 +675,33 @@ __global__ void in_act_bwd_apply_kernel(const float* __restrict__ x, const float
   }
 }
 
-extern "C" int ws_in_act_sums(const float* x, const float* dy, const float* stats, int P, int G, int nsplit, int C, int flags,
-                              float* slab, void* stream) {
+extern "C" int ws_in_act_sums(const float* x, const float* dy, long long ldd, const float* stats, int P, int G, int nsplit, int C,
+                              int flags, float* slab, void* stream) {
   WS_REQUIRE(x && slab && P > 0 && G > 0 && nsplit > 0 && C > 0 && C % 4 == 0 && (flags & ~3) == 0 && (!dy || stats),
              "ws_in_act_sums: bad args (the backward sums need the statistics)");
+  WS_REQUIRE(ldd == 0 || (ldd >= C && ldd % 4 == 0), "ws_in_act_sums: dy row stride %lld (0 = C, else >= C and %% 4)", ldd);
   hipLaunchKernelGGL(in_act_sums_kernel, dim3(nsplit, G, (C / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, dy, stats,
-                     P, G, nsplit, C, flags, slab);
+                     P, G, nsplit, C, flags, ldd ? ldd : (long long)C, slab);
   return ws_check_launch("ws_in_act_sums");
 }
 
 extern "C" int ws_in_act_apply(const float* x, const float* stats, long long rows, int P, int C, int flags, float* y,
-                               void* stream) {
+                               long long ldy, void* stream) {
   WS_REQUIRE(x && stats && y && rows > 0 && P > 0 && C > 0 && C % 4 == 0 && rows % P == 0 && (flags & ~3) == 0,
              "ws_in_act_apply: bad args");
+  WS_REQUIRE(ldy == 0 || (ldy >= C && ldy % 4 == 0), "ws_in_act_apply: y row stride %lld (0 = C, else >= C and %% 4)", ldy);
   hipLaunchKernelGGL(in_act_apply_kernel, dim3(cv_blocks(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, stats, rows, P,
-                     C, flags, y);
+                     C, flags, ldy ? ldy : (long long)C, y);
   return ws_check_launch("ws_in_act_apply");
 }
 
-extern "C" int ws_in_act_bwd_apply(const float* x, const float* dy, const float* stats, const float* sums, long long rows, int P,
-                                   int C, int flags, float* dx, void* stream) {
+extern "C" int ws_in_act_bwd_apply(const float* x, const float* dy, long long ldd, const float* stats, const float* sums,
+                                   long long rows, int P, int C, int flags, float* dx, void* stream) {
   WS_REQUIRE(x && dy && stats && sums && dx && rows > 0 && P > 0 && C > 0 && C % 4 == 0 && rows % P == 0 && (flags & ~3) == 0,
              "ws_in_act_bwd_apply: bad args");
+  WS_REQUIRE(ldd == 0 || (ldd >= C && ldd % 4 == 0), "ws_in_act_bwd_apply: dy row stride %lld (0 = C, else >= C and %% 4)", ldd);
   hipLaunchKernelGGL(in_act_bwd_apply_kernel, dim3(cv_blocks(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, dy, stats,
-                     sums, rows, P, C, flags, dx);
+                     sums, rows, P, C, flags, ldd ? ldd : (long long)C, dx);
   return ws_check_launch("ws_in_act_bwd_apply");
 }
 

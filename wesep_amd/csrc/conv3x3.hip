@@ -57,9 +57,10 @@ __device__ __forceinline__ void c3_split4(const f32x4 v, bf16x4& hi, bf16x4& lo)
   }
 }
 
-template <int NT, int P>          // 32-channel tiles of output channels per workgroup; output columns per wave
+template <int NT, int P, bool PF>  // 32-channel tiles of output channels per workgroup; output columns per wave; prefetch
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ws_conv3x3_args p) {
   constexpr int NC = 4 * P + 2, PLANE = NC * C3_COL;                  // halo columns; bf16 per plane
+  constexpr int NITEM = (C3_TH + 2) * NC * (C3_CC / 4), NI = (NITEM + 255) / 256;
   __shared__ __attribute__((aligned(16))) __bf16 halo[2][PLANE];      // [plane hi / lo][column][row][channel]  P = 4: 58.8 KB
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,21 +78,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ws_conv3x3_args p
       for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
   const bf16x8* wpk = reinterpret_cast<const bf16x8*>(p.W);
 
-  for (int c0 = 0; c0 < Cin; c0 += C3_CC) {
-    // ---- halo of this channel chunk -> LDS (zeros outside the image and beyond Cin) ----
-    for (int i = tid; i < (C3_TH + 2) * NC * (C3_CC / 4); i += 256) {
-      const int q = i & 3, pix = i >> 2, col = pix % NC, row = pix / NC;   // consecutive threads: channels, then w
+  // halo item i = tid + 256 k: channel quad i & 3 of halo pixel i >> 2 (column fastest: consecutive threads walk channels, then w)
+  f32x4 pre[NI];
+  auto halo_load = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int i = tid + 256 * k, q = i & 3, pix = i >> 2, col = pix % NC, row = pix / NC;
       const int hh = h0 + row - 1, ww = w0 + col - 1, c = c0 + 4 * q;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)Wd && c < Cin)
-        v = *reinterpret_cast<const f32x4*>(p.X + (img + (long long)hh * Wd + ww) * p.ldx + c);
-      bf16x4 hi, lo;
-      c3_split4(v, hi, lo);
-      const int o = col * C3_COL + row * C3_PS + 4 * q;
-      *reinterpret_cast<bf16x4*>(&halo[0][o]) = hi;
-      *reinterpret_cast<bf16x4*>(&halo[1][o]) = lo;
+      pre[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < NITEM && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)Wd && c < Cin)
+        pre[k] = *reinterpret_cast<const f32x4*>(p.X + (img + (long long)hh * Wd + ww) * p.ldx + c);
     }
+  };
+  auto halo_store = [&]() {       // zeros outside the image and beyond Cin
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int i = tid + 256 * k, q = i & 3, pix = i >> 2, col = pix % NC, row = pix / NC;
+      if (i < NITEM) {
+        bf16x4 hi, lo;
+        c3_split4(pre[k], hi, lo);
+        const int o = col * C3_COL + row * C3_PS + 4 * q;
+        *reinterpret_cast<bf16x4*>(&halo[0][o]) = hi;
+        *reinterpret_cast<bf16x4*>(&halo[1][o]) = lo;
+      }
+    }
+  };
+
+  if (PF) halo_load(0);
+  for (int c0 = 0; c0 < Cin; c0 += C3_CC) {
+    if (!PF) halo_load(c0);
+    halo_store();
     __syncthreads();
+    if (PF && c0 + C3_CC < Cin) {
+      halo_load(c0 + C3_CC);                      // the next chunk's loads fly under this chunk's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
     const long long u0 = (long long)(c0 / C3_CC) * 9 * ntp;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -148,11 +169,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const ws_conv3x3_args p
   }
 }
 
-template <int NT, int P>
+template <int NT, int P, bool PF>
 static void c3_launch(const ws_conv3x3_args* a, hipStream_t s) {
   const int ntt = (a->Cout + 31) / 32, ntp = ntt <= 2 ? ntt : (ntt + 1) & ~1, ng = ntp / NT;
   const dim3 grid((a->Wd + 4 * P - 1) / (4 * P), (a->H + C3_TH - 1) / C3_TH, a->B * ng), block(256);
-  hipLaunchKernelGGL((conv3x3_kernel<NT, P>), grid, block, 0, s, *a);
+  hipLaunchKernelGGL((conv3x3_kernel<NT, P, PF>), grid, block, 0, s, *a);
 }
 
 extern "C" int ws_conv3x3(const ws_conv3x3_args* a, void* stream) {
@@ -165,12 +186,18 @@ extern "C" int ws_conv3x3(const ws_conv3x3_args* a, void* stream) {
   WS_REQUIRE(a->H <= 65535 * C3_TH && (long long)a->B * ((a->Cout + 63) / 64) <= 65535,
              "ws_conv3x3: H / 32 and B * ceil(Cout / 64) index the launch grid (<= 65535)");
   hipStream_t s = (hipStream_t)stream;
+  static const int variant = [] { const char* e = getenv("WS_CONV3X3_VARIANT"); return e ? atoi(e) : 0; }();   // experiments
   ws_prof_begin(WS_PROF_GEMM_NT, s);
   const bool wide = a->Wd >= 100;                 // 16-column tiles where they fill; 8-column tiles on the small grids
+  const bool pf = !(variant & 1) && a->Cin > C3_CC;
   if (a->Cout <= 32) {
-    if (wide) c3_launch<1, 4>(a, s); else c3_launch<1, 2>(a, s);
+    if (wide) { if (pf) c3_launch<1, 4, true>(a, s); else c3_launch<1, 4, false>(a, s); }
+    else      { if (pf) c3_launch<1, 2, true>(a, s); else c3_launch<1, 2, false>(a, s); }
   } else {
-    if (wide) c3_launch<2, 4>(a, s); else c3_launch<2, 2>(a, s);
+    // two channel tiles x four columns leave no registers for the prefetch
+    if (wide && !(variant & 2)) c3_launch<2, 4, false>(a, s);
+    else if (pf) c3_launch<2, 2, true>(a, s);
+    else c3_launch<2, 2, false>(a, s);
   }
   ws_prof_end(WS_PROF_GEMM_NT, s);
   return ws_check_launch("ws_conv3x3");

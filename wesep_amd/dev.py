@@ -1170,32 +1170,44 @@ def conv3x3_wgrad(*, G, ldg: int, X, ldx: int, B: int, H: int, Wd: int, Cin: int
 IN_ELU_PRE, IN_ELU_POST = 1, 2     # ws_in_act_* flags: y = IN(ELU(x)) / y = ELU(IN(x))
 
 
-def _in_act_sums(x, dy, stats, G: int, P: int, Cc: int, flags: int):
+def _in_act_sums(x, dy, stats, G: int, P: int, Cc: int, flags: int, dy_ld: int = 0, dy_off: int = 0):
     nsplit = max(1, min(max(1, 1024 // G), P // 32))
     slab = torch.empty(nsplit, G, 2, Cc, device=x.device, dtype=torch.float32)
-    _call("ws_in_act_sums", _p(x), _p(dy), _p(stats), P, G, nsplit, Cc, flags, _p(slab))
+    _call("ws_in_act_sums", _p(x), _p(dy, dy_off), dy_ld, _p(stats), P, G, nsplit, Cc, flags, _p(slab))
     out = torch.empty(G, 2, Cc, device=x.device, dtype=torch.float32)
     reduce_slabs(slab, nsplit, G * 2 * Cc, G * 2 * Cc, out)
     return out
 
 
-def in_act_fwd(x, G: int, P: int, Cc: int, flags: int, y, eps=IN_EPS):
+def _cols_ok(t, rows: int, ld: int, off: int, Cc: int, name: str):
+    """Columns [off, off + Cc) of the dense [rows, ld] tensor t (ld = 0: t is [rows, Cc] itself)."""
+    if ld and (ld % 4 or off % 4 or off < 0 or off + Cc > ld or t.numel() < rows * ld):
+        raise L.WesepHipError(f"{name}: columns [{off}, {off + Cc}) of rows of stride {ld} (both % 4) do not fit the tensor")
+    if not ld and (off or t.numel() < rows * Cc):
+        raise L.WesepHipError(f"{name}: expected {rows} x {Cc} elements")
+
+
+def in_act_fwd(x, G: int, P: int, Cc: int, flags: int, y, eps=IN_EPS, y_ld: int = 0, y_off: int = 0):
     """y = IN(ELU(x)) (flags IN_ELU_PRE) or ELU(IN(x)) (IN_ELU_POST) over the P positions of each of G rows, three
-    passes; returns the statistics [G, 2, C] the backward needs (with x)."""
+    passes; returns the statistics [G, 2, C] the backward needs (with x).  y_ld / y_off: write columns [y_off, y_off + Cc)
+    of the dense [G*P, y_ld] tensor y instead of a dense [G*P, Cc] one."""
     _chk(x, "x")
     _chk(y, "y")
+    _cols_ok(y, G * P, y_ld, y_off, Cc, "in_act_fwd y")
     sums = _in_act_sums(x, None, None, G, P, Cc, flags)
     stats = torch.empty(G, 2, Cc, device=x.device, dtype=torch.float32)
     _call("ws_inorm_finalize", _p(sums), G, Cc, P, eps, _p(stats))
-    _call("ws_in_act_apply", _p(x), _p(stats), G * P, P, Cc, flags, _p(y))
+    _call("ws_in_act_apply", _p(x), _p(stats), G * P, P, Cc, flags, _p(y, y_off), y_ld)
     return stats
 
 
-def in_act_bwd(x, dy, stats, G: int, P: int, Cc: int, flags: int, dx):
+def in_act_bwd(x, dy, stats, G: int, P: int, Cc: int, flags: int, dx, dy_ld: int = 0, dy_off: int = 0):
+    """dy_ld / dy_off: dy is columns [dy_off, dy_off + Cc) of a dense [G*P, dy_ld] tensor."""
     for n, t in (("x", x), ("dy", dy), ("stats", stats), ("dx", dx)):
         _chk(t, n)
-    sums = _in_act_sums(x, dy, stats, G, P, Cc, flags)
-    _call("ws_in_act_bwd_apply", _p(x), _p(dy), _p(stats), _p(sums), G * P, P, Cc, flags, _p(dx))
+    _cols_ok(dy, G * P, dy_ld, dy_off, Cc, "in_act_bwd dy")
+    sums = _in_act_sums(x, dy, stats, G, P, Cc, flags, dy_ld, dy_off)
+    _call("ws_in_act_bwd_apply", _p(x), _p(dy, dy_off), dy_ld, _p(stats), _p(sums), G * P, P, Cc, flags, _p(dx))
 
 
 def avgpool_fwd(x, B: int, H: int, W: int, Cc: int, sz: int, y):

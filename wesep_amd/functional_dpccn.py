@@ -247,10 +247,11 @@ class DenseBlockFn(torch.autograd.Function):
             Wd = dev.conv3x3_pack(ws[i].flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, 9 * Co), Co, Ci)
             pre = _empty(d, M, Co)
             dev.conv3x3(X=big, ldx=Ctot, W=W2, ldw=9 * Ci, B=B, H=H, Wd=W, Cin=Ci, Cout=Co, Y=pre, ldy=Co, bias=bs[i])
-            out = _empty(d, M, Co)
-            st = dev.in_act_fwd(pre, B, H * W, Co, dev.IN_ELU_PRE, out)
-            if i < 4:
-                big[:, Ci:Ci + g].copy_(out)
+            if i < 4:                    # the layer's output IS the next g columns of the map
+                st = dev.in_act_fwd(pre, B, H * W, Co, dev.IN_ELU_PRE, big, y_ld=Ctot, y_off=Ci)
+            else:
+                out = _empty(d, M, Co)
+                st = dev.in_act_fwd(pre, B, H * W, Co, dev.IN_ELU_PRE, out)
             saved += [pre, st, Wd]
         ctx.save_for_backward(big, *saved)
         ctx.geo = (B, H, W, C0, g, tuple(w.shape for w in ws))
@@ -269,10 +270,11 @@ class DenseBlockFn(torch.autograd.Function):
         for i in range(4, -1, -1):
             pre, st, Wd = saved[3 * i:3 * i + 3]
             Ci, Co = C0 + i * g, wshapes[i][0]
-            if i < 4:
-                d_out = dbig[:, Ci:Ci + g].contiguous()     # complete: layers i+2 .. 5 have added their share
             d_pre = _empty(d, M, Co)
-            dev.in_act_bwd(pre, d_out, st, B, H * W, Co, dev.IN_ELU_PRE, d_pre)
+            if i < 4:                    # columns [Ci, Ci + g) of dbig are complete: layers i+2 .. 5 have added their share
+                dev.in_act_bwd(pre, dbig, st, B, H * W, Co, dev.IN_ELU_PRE, d_pre, dy_ld=Ctot, dy_off=Ci)
+            else:
+                dev.in_act_bwd(pre, d_out, st, B, H * W, Co, dev.IN_ELU_PRE, d_pre)
             conv = dev.ConvView(0, H, W, Ci, H, W, 3, 1, 1, 1, 1, Ctot)
             if FC.halo_wgrad_ok(Ci, Co, 3, 1, 1, 1):
                 dW2, db = FC.halo_wgrad(d_pre, Co, big, Ctot, B, H, W, Ci, True)
