@@ -614,20 +614,23 @@ typedef struct ws_conv3x3_args {
   int B, H, Wd, Cin, Cout, pad_;
 } ws_conv3x3_args;
 int ws_conv3x3(const ws_conv3x3_args* a, void* stream);
-/* Weight (and bias) gradient of that convolution, one pass over the image (conv3x3.hip; replaces ws_conv_wgrad for
- * k = 3, stride 1, padding 1):
- *   slab[split][n][(ky*3 + kx)*Cin + c] = sum over the split's pixels m of G[m][n] * X[pixel(m) + (ky-1, kx-1)][c]
+/* Weight (and bias) gradient of a 3 x 3 convolution with padding 1, stride 1 along h and sw = 1 or 2 along w, one pass
+ * over the image (conv3x3.hip; replaces ws_conv_wgrad / the implicit TN GEMM for these shapes: the dense blocks, the
+ * (1, 2)-strided encoder convolutions and -- with image = dy, G = x -- the decoder's transposed convolutions of
+ * wesep/modules/dpccn/convs.py, and the 3 x 3 convolutions of the ResNet speaker encoder):
+ *   slab[split][n][(ky*3 + kx)*Cin + c] = sum over the split's pixels m = (b, h, w) of G[m][n] * X[b][h + ky - 1][sw*w + kx - 1][c]
  *   bslab[split][n]                    = sum over the split's pixels of G[m][n]                       (bslab may be NULL)
- * G [B*H*Wd rows, stride ldg >= Nn]; X pixel stride ldx >= Cin.  The image is cut into tiles of 30 rows x 4 columns
- * (B * ceil(H / 30) * ceil(Wd / 4) of them, column-fastest); split s owns tiles [s, s + 1) * tiles_per_split.  The caller
- * sums the nsplit slabs (ws_reduce_slabs: deterministic, no atomics).  Cin % 4 == 0, Nn % 4 == 0. */
+ * G [B*H*Wd rows, stride ldg >= Nn]; X [B][H][Wx] pixels of stride ldx >= Cin, Wd = (Wx - 1) / sw + 1.  The gradient grid
+ * is cut into tiles of 30 rows x 4 columns (B * ceil(H / 30) * ceil(Wd / 4) of them, column-fastest); split s owns tiles
+ * [s, s + 1) * tiles_per_split.  The caller sums the nsplit slabs (ws_reduce_slabs: deterministic, no atomics).
+ * Cin % 4 == 0, Nn % 4 == 0. */
 typedef struct ws_conv3x3_wgrad_args {
   const float* G;
   const float* X;
   float* slab;
   float* bslab;
   long long ldg, ldx, slab_stride, bslab_stride;
-  int B, H, Wd, Cin, Nn, nsplit, tiles_per_split, pad_;
+  int B, H, Wd, Wx, sw, Cin, Nn, nsplit, tiles_per_split, pad_;
 } ws_conv3x3_wgrad_args;
 int ws_conv3x3_wgrad(const ws_conv3x3_wgrad_args* a, void* stream);
 

@@ -456,14 +456,16 @@ def conv3x3_wgrad_tiles(B, H, Wd):
     return B * (-(-H // 30)) * (-(-Wd // 4))
 
 
-def conv3x3_wgrad(*, G, ldg, X, ldx, B, H, Wd, Cin, Nn, slab, nsplit, tiles_per_split, bslab=None):
+def conv3x3_wgrad(*, G, ldg, X, ldx, B, H, Wd, Cin, Nn, slab, nsplit, tiles_per_split, bslab=None, sw=1, Wx=0):
     """Slab 0 carries the whole gradient (the split of the pixels is a device detail), the others are zero."""
     assert nsplit * tiles_per_split >= conv3x3_wgrad_tiles(B, H, Wd)
-    M = B * H * Wd
-    img = X.reshape(-1)[:M * ldx].reshape(B, H, Wd, ldx)[..., :Cin].permute(0, 3, 1, 2)
+    Wx = Wx or Wd
+    assert sw in (1, 2) and (Wx - 1) // sw + 1 == Wd
+    M, Mx = B * H * Wd, B * H * Wx
+    img = X.reshape(-1)[:Mx * ldx].reshape(B, H, Wx, ldx)[..., :Cin].permute(0, 3, 1, 2)
     g = G.reshape(-1)[:M * ldg].reshape(B, H, Wd, ldg)[..., :Nn].permute(0, 3, 1, 2)
-    # dW[n][c][ky][kx] = sum g[b][n][h][w] * xpad[b][c][h + ky][w + kx]
-    dw = torch.nn.grad.conv2d_weight(img, (Nn, Cin, 3, 3), g, padding=1)
+    # dW[n][c][ky][kx] = sum g[b][n][h][w] * xpad[b][c][h + ky][sw*w + kx]
+    dw = torch.nn.grad.conv2d_weight(img, (Nn, Cin, 3, 3), g, stride=(1, sw), padding=1)
     sl = slab.reshape(-1)[:nsplit * Nn * 9 * Cin].reshape(nsplit, Nn * 9 * Cin)
     sl.zero_()
     sl[0] = dw.permute(0, 2, 3, 1).reshape(-1)

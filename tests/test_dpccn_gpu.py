@@ -325,22 +325,25 @@ def test_conv3x3_halo_kernel_vs_torch(B, H, W, Cin, Cout, ldx, ldy, res):
     assert torch.equal(outs[0][:, Cout:].cpu(), Y0[:, Cout:])
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Nn,ldx", [(2, 9, 257, 16, 16, 80), (1, 61, 9, 80, 32, 80), (2, 30, 4, 32, 16, 32),
-                                              (1, 31, 5, 20, 36, 24), (3, 7, 33, 96, 64, 96), (1, 1, 1, 4, 4, 4)])
-def test_conv3x3_halo_weight_gradient_vs_torch(B, H, W, Cin, Nn, ldx):
-    """ws_conv3x3_wgrad (conv3x3.hip): dW and db of a 3 x 3 / stride 1 / padding 1 convolution against
-    torch.nn.grad.conv2d_weight in fp64: tiles of 30 rows x 4 columns that end inside the image, several input-channel
-    chunks and output-channel tiles, an image that is the prefix of wider rows, run-to-run identity."""
+@pytest.mark.parametrize("B,H,W,Cin,Nn,ldx,sw", [(2, 9, 257, 16, 16, 80, 1), (1, 61, 9, 80, 32, 80, 1), (2, 30, 4, 32, 16, 32, 1),
+                                                 (1, 31, 5, 20, 36, 24, 1), (3, 7, 33, 96, 64, 96, 1), (1, 1, 1, 4, 4, 4, 1),
+                                                 (2, 9, 257, 16, 32, 16, 2), (1, 33, 64, 32, 64, 40, 2), (2, 5, 17, 64, 128, 64, 2),
+                                                 (1, 2, 1, 4, 8, 4, 2)])
+def test_conv3x3_halo_weight_gradient_vs_torch(B, H, W, Cin, Nn, ldx, sw):
+    """ws_conv3x3_wgrad (conv3x3.hip): dW and db of a 3 x 3 / padding 1 convolution with stride (1, sw) against
+    torch.nn.grad.conv2d_weight in fp64: tiles of 30 rows x 4 columns that end inside the grid, even and odd image
+    widths under the stride, several input-channel chunks and output-channel tiles, an image that is the prefix of
+    wider rows, run-to-run identity."""
     from wesep_amd import functional_conv as FC
     d = _cuda()
-    g = torch.Generator().manual_seed(Cin * 5 + Nn)
-    M = B * H * W
-    X = torch.randn(M, ldx, generator=g)
-    G = torch.randn(M, Nn, generator=g)
+    g = torch.Generator().manual_seed(Cin * 5 + Nn + sw)
+    Wo = (W - 1) // sw + 1
+    X = torch.randn(B * H * W, ldx, generator=g)
+    G = torch.randn(B * H * Wo, Nn, generator=g)
     img = X[:, :Cin].double().view(B, H, W, Cin).permute(0, 3, 1, 2)
-    gg = G.double().view(B, H, W, Nn).permute(0, 3, 1, 2)
-    ref = torch.nn.grad.conv2d_weight(img, (Nn, Cin, 3, 3), gg, padding=1).permute(0, 2, 3, 1).reshape(Nn, 9 * Cin)
-    outs = [FC.halo_wgrad(G.to(d), Nn, X.to(d), ldx, B, H, W, Cin, True) for _ in range(2)]
+    gg = G.double().view(B, H, Wo, Nn).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(img, (Nn, Cin, 3, 3), gg, stride=(1, sw), padding=1).permute(0, 2, 3, 1).reshape(Nn, 9 * Cin)
+    outs = [FC.halo_wgrad(G.to(d), Nn, X.to(d), ldx, B, H, Wo, Cin, True, sw, W) for _ in range(2)]
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert rel(outs[0][0], ref) < 2e-5
     assert rel(outs[0][1], gg.sum((0, 2, 3))) < 1e-5

@@ -38,7 +38,7 @@ class Conv3x3Args(C.Structure):
 
 class Conv3x3WgradArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("G", "X", "slab", "bslab")] + [(n, _ll) for n in ("ldg", "ldx", "slab_stride", "bslab_stride")] + \
-               [(n, _i) for n in ("B", "H", "Wd", "Cin", "Nn", "nsplit", "tiles_per_split", "pad_")]
+               [(n, _i) for n in ("B", "H", "Wd", "Wx", "sw", "Cin", "Nn", "nsplit", "tiles_per_split", "pad_")]
 
 
 class GemmNTArgs(C.Structure):

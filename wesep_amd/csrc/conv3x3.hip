@@ -208,25 +208,28 @@ extern "C" int ws_conv3x3(const ws_conv3x3_args* a, void* stream) {
 // ------------------------------------------------------------------------------------------------------------------
 #define W3_TH 30                  // output rows per tile: their 3 x 3 windows span 32 halo rows = the MFMA K of two steps
 #define W3_LD 40                  // bf16 per LDS row (32 + 8: 80 B, conflict-free 16-byte fragment reads)
-#define W3_XB (6 * 32 * W3_LD)    // X plane: [halo column 6][channel 32][row]
 #define W3_AB (4 * 32 * W3_LD)    // dY plane: [column 4][output channel 32][8 zeros | rows 0..29 | 2 zeros]
 
 __device__ __forceinline__ bf16x8 w3_frag(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
+template <int SW>                 // stride along w (1 or 2): halo column = SW * output column + kx
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const ws_conv3x3_wgrad_args p) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * W3_XB + 2 * W3_AB];   // 51,200 B: two workgroups per CU
-  __bf16* const xb = lds;                      // planes at xb, xb + W3_XB
-  __bf16* const ab = lds + 2 * W3_XB;          // planes at ab, ab + W3_AB
+  constexpr int NCOL = 3 * SW + 3;             // halo columns of 4 output columns: 6 / 9
+  constexpr int XB = NCOL * 32 * W3_LD;        // X plane: [halo column][channel 32][row]
+  constexpr int NXITEM = 8 * NCOL * 8, NXI = (NXITEM + 255) / 256;   // (row quad, halo column, channel quad)
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];       // 2 XB + 2 W3_AB bf16: 51.2 / 66.6 KB, two workgroups per CU
+  __bf16* const xb = lds;                      // planes at xb, xb + XB
+  __bf16* const ab = lds + 2 * XB;             // planes at ab, ab + W3_AB
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = p.H, Wd = p.Wd, Cin = p.Cin;
+  const int H = p.H, Wd = p.Wd, Wx = p.Wx, Cin = p.Cin;
   const int split = blockIdx.x, c0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
   const int nn = min(32, p.Nn - n0);
   const int ncg = (Wd + 3) / 4, nrt = (H + W3_TH - 1) / W3_TH;
   const long long ntiles = (long long)p.B * nrt * ncg;
   const long long t_begin = (long long)split * p.tiles_per_split, t_end = min(ntiles, t_begin + p.tiles_per_split);
 
-  for (int i = tid; i < (2 * W3_XB + 2 * W3_AB) / 2; i += 256) reinterpret_cast<uint32_t*>(lds)[i] = 0u;   // the pads stay zero
+  for (int i = tid; i < (2 * XB + 2 * W3_AB) / 2; i += 256) reinterpret_cast<uint32_t*>(lds)[i] = 0u;   // the pads stay zero
 
   f32x16 acc[9];
 #pragma unroll
@@ -236,35 +239,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const ws_conv3x3_
   float gsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool want_bias = p.bslab && blockIdx.y == 0;
 
-  // staging items: X (8 row quads x 6 halo columns x 8 channel quads = 384: threads < 128 take a second one),
-  //                dY (8 row quads x 4 columns x 8 channel quads = 256)
-  int x_cq[2], x_hc[2], x_hq[2];
+  // staging items: X (8 row quads x NCOL halo columns x 8 channel quads), dY (8 row quads x 4 columns x 8 channel quads = 256)
+  int x_cq[NXI], x_hc[NXI], x_hq[NXI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NXI; ++i) {
     const int it = tid + 256 * i;
     x_cq[i] = it & 7;
-    x_hc[i] = (it >> 3) % 6;
-    x_hq[i] = (it >> 3) / 6;
+    x_hc[i] = (it >> 3) % NCOL;
+    x_hq[i] = (it >> 3) / NCOL;
   }
   const int g_nq = tid & 7, g_col = (tid >> 3) & 3, g_hq = tid >> 5;
 
   for (long long tile = t_begin; tile < t_end; ++tile) {
     const int cg = (int)(tile % ncg), rt = (int)((tile / ncg) % nrt), b = (int)(tile / ((long long)ncg * nrt));
     const int h0 = rt * W3_TH, w0 = cg * 4;
-    const long long img = (long long)b * H * Wd;
+    const long long img = (long long)b * H * Wd, imgx = (long long)b * H * Wx;
     __syncthreads();                             // the previous tile's fragment reads (and the zero fill) are done
     // ---- X halo, transposed: 4 consecutive rows of one channel become one 8-byte group ----
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (i == 1 && tid >= 128) break;
-      const int ww = w0 - 1 + x_hc[i], c = c0 + 4 * x_cq[i];
+    for (int i = 0; i < NXI; ++i) {
+      if (tid + 256 * i >= NXITEM) break;
+      const int ww = SW * w0 - 1 + x_hc[i], c = c0 + 4 * x_cq[i];
       f32x4 v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int hh = h0 - 1 + 4 * x_hq[i] + j;
         v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)Wd && c < Cin)
-          v[j] = *reinterpret_cast<const f32x4*>(p.X + (img + (long long)hh * Wd + ww) * p.ldx + c);
+        if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)Wx && c < Cin)
+          v[j] = *reinterpret_cast<const f32x4*>(p.X + (imgx + (long long)hh * Wx + ww) * p.ldx + c);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const ws_conv3x3_
         c3_split4(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, hi, lo);
         const int o = (x_hc[i] * 32 + 4 * x_cq[i] + e) * W3_LD + 4 * x_hq[i];
         *reinterpret_cast<bf16x4*>(xb + o) = hi;
-        *reinterpret_cast<bf16x4*>(xb + W3_XB + o) = lo;
+        *reinterpret_cast<bf16x4*>(xb + XB + o) = lo;
       }
     }
     // ---- dY tile, transposed, behind 8 zeros ----
@@ -316,9 +318,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const ws_conv3x3_
       }
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int bo = ((wv + kx) * 32 + l31) * W3_LD + 16 * ks + 8 * half;
+        const int bo = ((SW * wv + kx) * 32 + l31) * W3_LD + 16 * ks + 8 * half;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(xb + bo);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(xb + W3_XB + bo);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(xb + XB + bo);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3_frag(a_h[ky]), bh, acc[ky * 3 + kx], 0, 0, 0);
 #pragma unroll
@@ -377,6 +379,9 @@ extern "C" int ws_conv3x3_wgrad(const ws_conv3x3_wgrad_args* a, void* stream) {
   WS_REQUIRE(a && a->G && a->X && a->slab, "ws_conv3x3_wgrad: null pointer");
   WS_REQUIRE(a->B > 0 && a->H > 0 && a->Wd > 0 && a->Cin > 0 && a->Cin % 4 == 0 && a->Nn > 0 && a->Nn % 4 == 0,
              "ws_conv3x3_wgrad: Cin %% 4, Nn %% 4 (got %d, %d)", a->Cin, a->Nn);
+  WS_REQUIRE((a->sw == 1 || a->sw == 2) && a->Wx > 0 && (a->Wx - 1) / a->sw + 1 == a->Wd,
+             "ws_conv3x3_wgrad: stride %d along w (1 or 2), image width %d, gradient width %d = (Wx - 1) / sw + 1", a->sw,
+             a->Wx, a->Wd);
   WS_REQUIRE(a->ldx >= a->Cin && a->ldx % 4 == 0 && a->ldg >= a->Nn && a->ldg % 4 == 0,
              "ws_conv3x3_wgrad: leading dimensions (ldx >= Cin, ldg >= Nn, both %% 4)");
   const long long ntiles = (long long)a->B * ((a->H + W3_TH - 1) / W3_TH) * ((a->Wd + 3) / 4);
@@ -387,8 +392,18 @@ extern "C" int ws_conv3x3_wgrad(const ws_conv3x3_wgrad_args* a, void* stream) {
              "ws_conv3x3_wgrad: slab strides");
   WS_REQUIRE((a->Cin + 31) / 32 <= 65535 && (a->Nn + 31) / 32 <= 65535, "ws_conv3x3_wgrad: channel counts index the launch grid");
   hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(a->nsplit, (a->Cin + 31) / 32, (a->Nn + 31) / 32);
+  const size_t lds1 = (size_t)(2 * 6 * 32 * W3_LD + 2 * W3_AB) * sizeof(__bf16), lds2 = (size_t)(2 * 9 * 32 * W3_LD + 2 * W3_AB) * sizeof(__bf16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    // (a failure here -- no device -- shows up as the launch error below, not as an argument error)
+    attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds2) == hipSuccess;
+    (void)hipGetLastError();
+  }
   ws_prof_begin(WS_PROF_GEMM_TN, s);
-  hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(a->nsplit, (a->Cin + 31) / 32, (a->Nn + 31) / 32), dim3(256), 0, s, *a);
+  if (a->sw == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds1, s, *a);
+  else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), lds2, s, *a);
   ws_prof_end(WS_PROF_GEMM_TN, s);
   return ws_check_launch("ws_conv3x3_wgrad");
 }

@@ -1154,16 +1154,17 @@ def conv3x3_wgrad_tiles(B: int, H: int, Wd: int) -> int:
 
 
 def conv3x3_wgrad(*, G, ldg: int, X, ldx: int, B: int, H: int, Wd: int, Cin: int, Nn: int, slab, nsplit: int,
-                  tiles_per_split: int, bslab=None):
-    """Weight (+ bias) gradient slabs of a 3 x 3 / stride 1 / padding 1 convolution, one pass over the image
-    (conv3x3.hip): slab [nsplit, Nn * 9 * Cin], bslab [nsplit, Nn]."""
+                  tiles_per_split: int, bslab=None, sw: int = 1, Wx: int = 0):
+    """Weight (+ bias) gradient slabs of a 3 x 3 / padding 1 convolution with stride (1, sw), one pass over the image
+    (conv3x3.hip): slab [nsplit, Nn * 9 * Cin], bslab [nsplit, Nn].  Wd = width of the gradient grid, Wx = of the image."""
     for n, t in (("G", G), ("X", X), ("slab", slab), ("bslab", bslab)):
         _chk(t, n)
     a = L.Conv3x3WgradArgs()
     a.G, a.X, a.slab, a.bslab = _p(G), _p(X), _p(slab), _p(bslab)
     a.ldg, a.ldx, a.slab_stride, a.bslab_stride = ldg, ldx, Nn * 9 * Cin, Nn
-    a.B, a.H, a.Wd, a.Cin, a.Nn, a.nsplit, a.tiles_per_split = B, H, Wd, Cin, Nn, nsplit, tiles_per_split
-    _alg("gemm_tn", 4 * (B * H * Wd * (Cin + Nn * (-(-Cin // 32))) + nsplit * Nn * 9 * Cin), 2 * B * H * Wd * Nn * 9 * Cin)
+    a.B, a.H, a.Wd, a.Wx, a.sw, a.Cin, a.Nn, a.nsplit, a.tiles_per_split = B, H, Wd, Wx or Wd, sw, Cin, Nn, nsplit, tiles_per_split
+    _alg("gemm_tn", 4 * (B * H * (Wx or Wd) * Cin + B * H * Wd * Nn * (-(-Cin // 32)) + nsplit * Nn * 9 * Cin),
+         2 * B * H * Wd * Nn * 9 * Cin)
     L.check(L.lib().ws_conv3x3_wgrad(C.byref(a), L.stream_ptr()), "ws_conv3x3_wgrad")
 
 

@@ -56,13 +56,14 @@ def _one_pass_wgrad(G, M, Nn, X, conv, with_bias):
 
 
 def halo_wgrad_ok(Cin, Cout, k, sh, sw, p, dil=1):
-    """The halo-tile weight gradient (conv3x3.hip) takes this convolution."""
-    return (k, sh, sw, p, dil) == (3, 1, 1, 1, 1) and Cin % 4 == 0 and Cout % 4 == 0 and os.environ.get("WESEP_CONV3X3_WGRAD", "1") != "0"
+    """The halo-tile weight gradient (conv3x3.hip) takes this convolution: 3 x 3, padding 1, stride (1, 1) or (1, 2)."""
+    return (k, sh, p, dil) == (3, 1, 1, 1) and sw in (1, 2) and Cin % 4 == 0 and Cout % 4 == 0 and \
+        os.environ.get("WESEP_CONV3X3_WGRAD", "1") != "0"
 
 
-def halo_wgrad(G, Nn, X, ldx, B, H, W, Cin, with_bias):
-    """dW2 [Nn, 9*Cin] (+ db) of a 3 x 3 / stride 1 / padding 1 convolution: G [B*H*W, Nn] gradient rows, X the image with
-    pixel stride ldx (its first Cin channels)."""
+def halo_wgrad(G, Nn, X, ldx, B, H, W, Cin, with_bias, sw=1, Wx=0):
+    """dW2 [Nn, 9*Cin] (+ db) of a 3 x 3 / padding 1 convolution with stride (1, sw): G [B*H*W, Nn] gradient rows on the
+    output grid, X the image [B, H, Wx] with pixel stride ldx (its first Cin channels)."""
     tiles = dev.conv3x3_wgrad_tiles(B, H, W)
     groups = (-(-Cin // 32)) * (-(-Nn // 32))              # workgroups per split: one per (input chunk, output tile)
     nsplit = max(1, min(tiles // 4, -(-1024 // groups)))   # ~4 workgroups per CU in flight, >= 4 tiles each
@@ -72,7 +73,7 @@ def halo_wgrad(G, Nn, X, ldx, B, H, W, Cin, with_bias):
     slab = _empty(d, nsplit, Nn * 9 * Cin)
     bslab = _empty(d, nsplit, Nn) if with_bias else None
     dev.conv3x3_wgrad(G=G, ldg=Nn, X=X, ldx=ldx, B=B, H=H, Wd=W, Cin=Cin, Nn=Nn, slab=slab, nsplit=nsplit,
-                      tiles_per_split=tps, bslab=bslab)
+                      tiles_per_split=tps, bslab=bslab, sw=sw, Wx=Wx or W)
     dW = _reduce_new(slab, nsplit, Nn * 9 * Cin, (Nn, 9 * Cin))
     db = _reduce_new(bslab, nsplit, Nn, (Nn,)) if with_bias else None
     return dW, db
@@ -82,7 +83,7 @@ def conv2d_wgrad(dy, x, B, H, W, Cin, Cout, k, sh, sw, p, with_bias=True, dil=1)
     """dW2 [Cout, k*k*Cin] = dy^T view0(x) (+ db)."""
     Ho, Wo = _out(H, k, sh, p, dil), _out(W, k, sw, p, dil)
     if halo_wgrad_ok(Cin, Cout, k, sh, sw, p, dil):
-        return halo_wgrad(dy, Cout, x, Cin, B, H, W, Cin, with_bias)
+        return halo_wgrad(dy, Cout, x, Cin, B, Ho, Wo, Cin, with_bias, sw, W)
     conv = ConvView(0, H, W, Cin, Ho, Wo, k, sh, sw, p, dil)
     if dev.conv_wgrad_ok(Cout, conv):
         return _one_pass_wgrad(dy, B * Ho * Wo, Cout, x, conv, with_bias)
@@ -121,6 +122,8 @@ def convT2d_dx(dy, B, H, W, Cin, Wx, Cout, k, sh, sw, p):
 def convT2d_wgrad(x, dy, B, H, W, Cin, Cout, k, sh, sw, p):
     """dWx^T [Cin, k*k*Cout] = x^T view0(dy)."""
     Ht, Wt_ = (H - 1) * sh - 2 * p + k, (W - 1) * sw - 2 * p + k
+    if halo_wgrad_ok(Cout, Cin, k, sh, sw, p):      # image = dy [Ht, Wt_, Cout], gradient rows = x on the [H, W] grid
+        return halo_wgrad(x, Cin, dy, Cout, B, H, W, Cout, False, sw, Wt_)[0]
     conv = ConvView(0, Ht, Wt_, Cout, H, W, k, sh, sw, p)
     if dev.conv_wgrad_ok(Cin, conv):
         return _one_pass_wgrad(x, B * H * W, Cin, dy, conv, False)[0]
