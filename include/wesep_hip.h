@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 12
+#define WS_ABI_VERSION 13
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -677,6 +677,33 @@ int ws_rowln_fwd(const float* x, const float* gamma, const float* beta, long lon
                  float* stats, void* stream);
 int ws_rowln_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* res, long long M,
                  int W, float* dx, float* slab, void* stream);
+
+/* The attention heads of a TF-GridNet block in one pass (heads.hip; gridnet_block.py:176-199: per head Conv2d(1x1) ->
+ * PReLU -> LayerNormalization4DCF over (E, F), heads concatenated along the batch, `.transpose(1, 2).flatten(2)`):
+ *   y[(h*B + b)*Tp + t][q*ch + e] = gamma[h][q*ch + e] * (u - mean) * rstd + beta[h][q*ch + e],
+ *   u = PReLU(x[(b*T + t)*Q + q][h*ch + e]; slope[h]),  mean / biased variance over the Q*ch elements of (b, t, h)
+ * x: the projection's columns (pointer at the first of them) in rows of stride ldx -- Q, K and V are one GEMM with
+ * concatenated weights; y rows t in [T, Tp) are written as zeros (keys / values padded to 16-byte rows of the logits);
+ * stats[h][b*T + t][2] = (mean, rstd).  ws_heads_bwd: dx (layout of x, row stride lddx) from x, dy (layout of y), the
+ * statistics; slab[nwg][2*W + 8], W = Q*nh*ch: per-workgroup partial sums of d(gamma) (elements [0, W) in the order
+ * (q, h, e)), d(beta) ([W, 2W)) and d(slope) ([2W, 2W + nh)) for ws_reduce_slabs; nwg = the launch grid (any > 0: the
+ * sums are reproducible for a given nwg).  ch % 4 == 0, nh <= 8, W <= 9216. */
+typedef struct ws_heads_args {
+  const float* x;
+  const float* dy;
+  const float* slope;
+  const float* gamma;
+  const float* beta;
+  float* y;
+  float* stats;
+  float* dx;
+  float* slab;
+  long long ldx, lddx;
+  int B, T, Tp, Q, nh, ch, nwg;
+  float eps;
+} ws_heads_args;
+int ws_heads_fwd(const ws_heads_args* a, void* stream);
+int ws_heads_bwd(const ws_heads_args* a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -506,6 +506,48 @@ def in_act_bwd(x, dy, stats, G, P, Cc, flags, dx, dy_ld=0, dy_off=0):
     dx.reshape(G, P, Cc)[:] = r
 
 
+def heads_ok(Q, nh, ch):
+    return ch % 4 == 0 and 0 < nh <= 8 and Q * nh * ch <= 9216
+
+
+def _heads_norm(x, x_ld, x_off, slope, B, T, Q, nh, ch, eps=1e-5):
+    xx = _cols(x, B * T * Q, x_ld, x_off, nh * ch).reshape(B, T, Q, nh, ch)
+    u = torch.where(xx > 0, xx, slope.view(1, 1, 1, nh, 1) * xx)
+    mean = u.mean((2, 4), keepdim=True)
+    rstd = 1.0 / torch.sqrt(((u - mean) ** 2).mean((2, 4), keepdim=True) + eps)
+    return xx, u, mean, rstd
+
+
+def heads_fwd(x, x_ld, x_off, slope, gamma, beta, B, T, Tp, Q, nh, ch, y, stats):
+    xx, u, mean, rstd = _heads_norm(x, x_ld, x_off, slope, B, T, Q, nh, ch)
+    g = gamma.view(nh, Q, ch).permute(1, 0, 2)
+    bt = beta.view(nh, Q, ch).permute(1, 0, 2)
+    yy = (u - mean) * rstd * g + bt                                           # [B, T, Q, nh, ch]
+    out = y.view(nh, B, Tp, Q * ch)
+    out.zero_()
+    out[:, :, :T] = yy.permute(3, 0, 1, 2, 4).reshape(nh, B, T, Q * ch)
+    st = stats.view(nh, B * T, 2)
+    st[..., 0] = mean.reshape(B * T, nh).t()
+    st[..., 1] = rstd.reshape(B * T, nh).t()
+
+
+def heads_bwd(x, x_ld, x_off, dy, slope, gamma, stats, B, T, Tp, Q, nh, ch, dx, dx_ld, dx_off):
+    xx, u, _, _ = _heads_norm(x, x_ld, x_off, slope, B, T, Q, nh, ch)
+    st = stats.view(nh, B, T, 2).permute(1, 2, 0, 3)                         # [B, T, nh, 2]
+    mean, rstd = st[..., 0][:, :, None, :, None], st[..., 1][:, :, None, :, None]
+    n = (u - mean) * rstd
+    dd = dy.view(nh, B, Tp, Q, ch)[:, :, :T].permute(1, 2, 3, 0, 4)          # [B, T, Q, nh, ch]
+    g = gamma.view(nh, Q, ch).permute(1, 0, 2)
+    d = dd * g
+    dl = rstd * (d - d.mean((2, 4), keepdim=True) - n * (d * n).mean((2, 4), keepdim=True))
+    a = slope.view(1, 1, 1, nh, 1)
+    _cols(dx, B * T * Q, dx_ld, dx_off, nh * ch)[:] = torch.where(xx > 0, dl, a * dl).reshape(B * T * Q, nh * ch)
+    dg = (dd * n).sum((0, 1)).permute(1, 0, 2).reshape(nh, Q * ch)
+    db = dd.sum((0, 1)).permute(1, 0, 2).reshape(nh, Q * ch)
+    ds = torch.where(xx > 0, torch.zeros_like(dl), dl * xx).sum((0, 1, 2, 4))
+    return dg, db, ds
+
+
 def rowln_ok(W):
     return 0 < W <= 256 and W % 4 == 0
 
@@ -715,7 +757,7 @@ EMULATED = [seg_sums, seg_scale, astp_fwd, astp_bwd, rowbias_act_fwd, act_bwd, c
             scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum, lstm_pack, lstm_fwd, lstm_bwd,
             group_stats, flat_stats, gn_bwd_reduce, norm_ab, norm_bwd_apply_cl, prelu_fwd, prelu_bwd, softmax_rows_fwd,
             softmax_rows_bwd, maskmul_fwd, maskmul_bwd, relu_mask, bn_stats, bn_prelu_fwd, bn_bwd, maxpool3_fwd, maxpool3_bwd,
-            bcast_rows, cross_entropy, im2col, col2im, tstp_fwd, tstp_bwd, power_spec, log_eps, rowln_ok, rowln_fwd, rowln_bwd, in_act_fwd, in_act_bwd, conv3x3, conv3x3_pack, conv3x3_wgrad, conv3x3_wgrad_tiles]
+            bcast_rows, cross_entropy, im2col, col2im, tstp_fwd, tstp_bwd, power_spec, log_eps, rowln_ok, rowln_fwd, rowln_bwd, in_act_fwd, in_act_bwd, conv3x3, conv3x3_pack, conv3x3_wgrad, conv3x3_wgrad_tiles, heads_ok, heads_fwd, heads_bwd]
 
 
 def install(monkeypatch):

@@ -144,3 +144,46 @@ def test_baseline_config5_geometry_recipe_6s_vs_oracle():
                                       {k: v.grad for k, v in p.items()}, GRAD_TOL)
     print(f"config 5 geometry: worst gradient rel-L2 {worst:.2e} ({wname})")
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("B,T,Tp,Q,nh,ch,ld,off", [(2, 5, 8, 65, 4, 8, 112, 32), (1, 3, 3, 65, 4, 12, 112, 64), (2, 2, 4, 7, 3, 4, 16, 4),
+                                                   (1, 4, 4, 33, 8, 12, 96, 0), (1, 3, 4, 65, 4, 32, 192, 64), (2, 2, 2, 72, 4, 32, 128, 0)])
+def test_attention_heads_kernels_vs_the_composition(B, T, Tp, Q, nh, ch, ld, off):
+    """ws_heads_fwd / ws_heads_bwd (heads.hip) against the fp64 composition PReLU -> LayerNorm over (Q, ch) -> head-major
+    layout (tests/emu_dev.py states it): a column range of a wider projection output, padded key / value frames written
+    as zeros, row widths for both launch shapes (256 threads x <= 4 float4, 768 x <= 3), run-to-run identity of the slab sums."""
+    from tests import emu_dev as E
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(B * 100 + Q + ch)
+    M, D = B * T * Q, Q * ch
+    x = torch.randn(M, ld, generator=g)
+    slope = torch.rand(nh, generator=g) * 0.5
+    gamma = 1 + 0.3 * torch.randn(nh, D, generator=g)
+    beta = 0.3 * torch.randn(nh, D, generator=g)
+    dy = torch.randn(nh * B, Tp, D, generator=g)
+    # fp64 statement
+    y64, st64 = torch.zeros(nh * B, Tp, D, dtype=torch.float64), torch.zeros(nh, B * T, 2, dtype=torch.float64)
+    E.heads_fwd(x.double(), ld, off, slope.double(), gamma.double(), beta.double(), B, T, Tp, Q, nh, ch, y64, st64)
+    dx64 = torch.zeros(M, ld, dtype=torch.float64)
+    dg64, db64, ds64 = E.heads_bwd(x.double(), ld, off, dy.double(), slope.double(), gamma.double(), st64, B, T, Tp, Q, nh, ch,
+                                   dx64, ld, off)
+    outs = []
+    for _ in range(2):
+        y = torch.full((nh * B, Tp, D), 7.0, device=d)
+        st = torch.empty(nh, B * T, 2, device=d)
+        dev.heads_fwd(x.to(d), ld, off, slope.to(d), gamma.to(d), beta.to(d), B, T, Tp, Q, nh, ch, y, st)
+        dx = torch.full((M, ld), 3.0, device=d)
+        dg, db, ds = dev.heads_bwd(x.to(d), ld, off, dy.to(d), slope.to(d), gamma.to(d), st, B, T, Tp, Q, nh, ch, dx, ld, off)
+        outs.append((y, st, dx, dg, db, ds))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    y, st, dx, dg, db, ds = outs[0]
+    assert rel(y, y64) < 1e-5 and rel(st, st64) < 1e-5
+    if Tp > T:
+        assert float(y.view(nh, B, Tp, D)[:, :, T:].abs().max()) == 0.0
+    assert rel(dx[:, off:off + nh * ch], dx64[:, off:off + nh * ch]) < 2e-5
+    other = torch.ones(ld, dtype=torch.bool)
+    other[off:off + nh * ch] = False
+    assert bool((dx[:, other.to(d)] == 3.0).all())
+    assert rel(dg, dg64) < 2e-5 and rel(db, db64) < 2e-5 and rel(ds, ds64) < 2e-5

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 12
+ABI_VERSION = 13
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
@@ -39,6 +39,12 @@ class Conv3x3Args(C.Structure):
 class Conv3x3WgradArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("G", "X", "slab", "bslab")] + [(n, _ll) for n in ("ldg", "ldx", "slab_stride", "bslab_stride")] + \
                [(n, _i) for n in ("B", "H", "Wd", "Wx", "sw", "Cin", "Nn", "nsplit", "tiles_per_split", "pad_")]
+
+
+class HeadsArgs(C.Structure):
+    _fields_ = [(n, _p) for n in ("x", "dy", "slope", "gamma", "beta", "y", "stats", "dx", "slab")] + \
+               [(n, _ll) for n in ("ldx", "lddx")] + [(n, _i) for n in ("B", "T", "Tp", "Q", "nh", "ch", "nwg")] + \
+               [("eps", C.c_float)]
 
 
 class GemmNTArgs(C.Structure):
@@ -213,6 +219,8 @@ _SIGS = {
     "ws_scale_bf_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ws_softmax_rows_fwd": (_i, [_p, _ll, _i, C.c_float, _p, _p]),
     "ws_softmax_rows_bwd": (_i, [_p, _p, _ll, _i, C.c_float, _p, _p]),
+    "ws_heads_fwd": (_i, [C.POINTER(HeadsArgs), _p]),
+    "ws_heads_bwd": (_i, [C.POINTER(HeadsArgs), _p]),
     "ws_conv3x3": (_i, [C.POINTER(Conv3x3Args), _p]),
     "ws_conv3x3_wgrad": (_i, [C.POINTER(Conv3x3WgradArgs), _p]),
     "ws_in_act_sums": (_i, [_p, _p, _ll, _p, _i, _i, _i, _i, _i, _p, _p]),

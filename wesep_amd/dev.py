@@ -1277,6 +1277,53 @@ def rowln_bwd(x, dy, stats, gamma, M: int, W: int, dx, res=None):
     return tot
 
 
+HEADS_SLAB_PAD = 8
+
+
+def heads_ok(Q: int, nh: int, ch: int) -> bool:
+    """The one-pass attention-head kernels (heads.hip) take this shape."""
+    return ch % 4 == 0 and 0 < nh <= 8 and Q * nh * ch <= 9216
+
+
+def _heads_args(x, x_ld, x_off, slope, gamma, beta, B, T, Tp, Q, nh, ch, stats):
+    a = L.HeadsArgs()
+    a.x, a.slope, a.gamma, a.beta, a.stats = _p(x, x_off), _p(slope), _p(gamma), _p(beta), _p(stats)
+    a.ldx, a.B, a.T, a.Tp, a.Q, a.nh, a.ch, a.eps = x_ld, B, T, Tp, Q, nh, ch, LN_EPS
+    return a
+
+
+def heads_fwd(x, x_ld: int, x_off: int, slope, gamma, beta, B: int, T: int, Tp: int, Q: int, nh: int, ch: int, y, stats):
+    """y [nh*B, Tp, Q*ch] (zero rows t >= T) and stats [nh, B*T, 2] from columns [x_off, x_off + nh*ch) of the
+    projection output x [B*T*Q, x_ld]: PReLU(slope[h]) + LayerNorm over (Q, ch) with gamma / beta [nh, Q*ch]."""
+    for nm, t in (("x", x), ("slope", slope), ("gamma", gamma), ("beta", beta), ("y", y), ("stats", stats)):
+        _chk(t, nm)
+    _cols_ok(x, B * T * Q, x_ld, x_off, nh * ch, "heads_fwd x")
+    a = _heads_args(x, x_ld, x_off, slope, gamma, beta, B, T, Tp, Q, nh, ch, stats)
+    a.y = _p(y)
+    L.check(L.lib().ws_heads_fwd(C.byref(a), L.stream_ptr()), "ws_heads_fwd")
+
+
+def heads_bwd(x, x_ld: int, x_off: int, dy, slope, gamma, stats, B: int, T: int, Tp: int, Q: int, nh: int, ch: int,
+              dx, dx_ld: int, dx_off: int):
+    """dx into columns [dx_off, dx_off + nh*ch) of [B*T*Q, dx_ld]; returns (dgamma [nh, Q*ch], dbeta [nh, Q*ch], dslope [nh])."""
+    for nm, t in (("x", x), ("dy", dy), ("slope", slope), ("gamma", gamma), ("stats", stats), ("dx", dx)):
+        _chk(t, nm)
+    _cols_ok(x, B * T * Q, x_ld, x_off, nh * ch, "heads_bwd x")
+    _cols_ok(dx, B * T * Q, dx_ld, dx_off, nh * ch, "heads_bwd dx")
+    W = Q * nh * ch
+    nwg = min(B * T, 512)
+    stride = 2 * W + HEADS_SLAB_PAD
+    slab = torch.empty(nwg, stride, device=x.device, dtype=torch.float32)
+    a = _heads_args(x, x_ld, x_off, slope, gamma, None, B, T, Tp, Q, nh, ch, stats)
+    a.dy, a.dx, a.lddx, a.slab, a.nwg = _p(dy), _p(dx, dx_off), dx_ld, _p(slab), nwg
+    L.check(L.lib().ws_heads_bwd(C.byref(a), L.stream_ptr()), "ws_heads_bwd")
+    tot = torch.empty(stride, device=x.device, dtype=torch.float32)
+    reduce_slabs(slab, nwg, stride, stride, tot)
+    dg = tot[:W].view(Q, nh, ch).permute(1, 0, 2).reshape(nh, Q * ch).contiguous()
+    db = tot[W:2 * W].view(Q, nh, ch).permute(1, 0, 2).reshape(nh, Q * ch).contiguous()
+    return dg, db, tot[2 * W:2 * W + nh].contiguous()
+
+
 def softmax_rows_bwd(y, dy, rows: int, n: int, scale: float, dx):
     for nm, t in (("y", y), ("dy", dy), ("dx", dx)):
         _chk(t, nm)

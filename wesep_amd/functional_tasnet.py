@@ -52,10 +52,10 @@ def _wgrad(G, M, Nn, A, Kk, *, g_ld=None, g_off=0, a_rows=None, norm=None, with_
            conv=None):
     """dW [Nn, Kk] = G^T pro(A), db [Nn] = colsum(G): split slabs + deterministic reduce."""
     # enough (split x tile) workgroups to fill 256 CUs; a split keeps >= 256 rows
-    # (up to 64 slabs; 512 for tiny gradients: a [32, 64] one over 2 M rows -- DPCCN's full-resolution 1 x 1 convolutions --
-    # ran on 64 workgroups at 0.9 TB/s)
+    # (64 slabs, or up to 512 while all slabs stay below 32 MB: a single-tile gradient over ~1 M rows -- DPCCN's
+    # full-resolution 1 x 1 convolutions, TF-GridNet's value / output projections -- ran on 64 workgroups at 0.9 TB/s)
     tiles = -(-Nn // 128) * -(-Kk // 128)
-    cap = 512 if Nn * Kk <= 4096 else 64
+    cap = max(64, min(512, (32 << 20) // (4 * Nn * Kk)))
     nsplit = max(1, min(cap, M // 256, -(-512 // tiles)))
     rps = -(-(-(-M // nsplit)) // 32) * 32
     nsplit = -(-M // rps)

@@ -182,6 +182,50 @@ class RowLNFn(torch.autograd.Function):
         return dx, dg.view(ctx.shapes[0]), db.view(ctx.shapes[1])
 
 
+class QKVHeadsFn(torch.autograd.Function):
+    """The attention heads of a block from the ONE projection GEMM's output qkv [B*T*Q, nh*(2E + cp)] (columns: the Q
+    heads, the K heads, the V heads): per projection PReLU(head slope) + LayerNorm over (Q, ch) with the head's affine,
+    written head-major as [nh*B, T', Q*ch] (T' = T for the queries, Tp >= T with zero rows for keys / values) by one
+    kernel each (dev.heads_fwd / heads_bwd, heads.hip; gridnet_block.py:176-199).  Parameters per projection:
+    slope [nh], gamma / beta [nh, Q*ch] (index q*ch + e)."""
+
+    @staticmethod
+    def forward(ctx, qkv, geo, sq, gq, bq, sk, gk, bk, sv, gv, bv):
+        _need_cuda(qkv, "TF-GridNet")
+        B, T, Tp, Q, nh, E, cp = geo
+        qkv = qkv.contiguous()
+        ld, d = qkv.shape[1], qkv.device
+        if ld != nh * (2 * E + cp) or qkv.shape[0] != B * T * Q:
+            raise dev.L.WesepHipError(f"QKVHeadsFn: projection output {tuple(qkv.shape)} is not [{B * T * Q}, {nh * (2 * E + cp)}]")
+        outs, keep, off = [], [], 0
+        for s, g, b, ch, tp in ((sq, gq, bq, E, T), (sk, gk, bk, E, Tp), (sv, gv, bv, cp, Tp)):
+            s, g, b = s.contiguous(), g.contiguous(), b.contiguous()
+            y = _empty(d, nh * B, tp, Q * ch)
+            st = _empty(d, nh, B * T, 2)
+            dev.heads_fwd(qkv, ld, off, s, g, b, B, T, tp, Q, nh, ch, y, st)
+            outs.append(y)
+            keep += [s, g, st]
+            off += nh * ch
+        ctx.save_for_backward(qkv, *keep)
+        ctx.geo = geo
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        qkv = ctx.saved_tensors[0]
+        keep = ctx.saved_tensors[1:]
+        B, T, Tp, Q, nh, E, cp = ctx.geo
+        ld = qkv.shape[1]
+        dqkv = torch.empty_like(qkv)                      # the three launches cover every column
+        grads, off = [], 0
+        for i, (dy, ch, tp) in enumerate(((dq, E, T), (dk, E, Tp), (dv, cp, Tp))):
+            s, g, st = keep[3 * i:3 * i + 3]
+            dg, db, ds = dev.heads_bwd(qkv, ld, off, dy.contiguous(), s, g, st, B, T, tp, Q, nh, ch, dqkv, ld, off)
+            grads += [ds, dg, db]
+            off += nh * ch
+        return (dqkv, None) + tuple(grads)
+
+
 class GroupLNFn(torch.autograd.Function):
     """nn.GroupNorm(1, C) on [B*P, C]: one mean/variance per batch row over (P, C), affine per channel."""
 

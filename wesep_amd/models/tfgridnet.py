@@ -8,12 +8,14 @@ Built: single microphone, one source, multiply / additive fusion, PReLU activati
 with the wespeaker ResNet18/34 (fbank or raw enrollment audio), any emb_ks / emb_hs, lstm_hidden_units <= 256.
 Not built (raise): multi-microphone input, n_srcs > 1, concat / FiLM fusion, eps != 1e-5."""
 import math
+import os
 
 import torch
 import torch.nn as nn
 from torch.nn import init
 from torch.nn.parameter import Parameter
 
+from .. import dev
 from .. import functional as F_
 from .. import functional_dpccn as FD
 from .. import functional_tfgridnet as FG
@@ -139,22 +141,35 @@ class GridNetBlock(nn.Module):
         inter = h.transpose(1, 2)[:, olp:olp + oT, olp:olp + oQ, :].contiguous().view(B * oT * oQ, C)
         M = B * oT * oQ
         cq, ck, cv = self["attn_conv_Q"], self["attn_conv_K"], self["attn_conv_V"]
-        q = FD.Conv1x1ResFn.apply(inter, cq.weight, cq.bias, None)
-        k = FD.Conv1x1ResFn.apply(inter, ck.weight, ck.bias, None)
-        v = FD.Conv1x1ResFn.apply(inter, cv.weight, cv.bias, None)
         cp = C // nh
-        qh = _heads(q, B, oT, oQ, nh, E, self["attn_norm_Q"])
-        kh = _heads(k, B, oT, oQ, nh, E, self["attn_norm_K"])
-        vh = _heads(v, B, oT, oQ, nh, cp, self["attn_norm_V"])
         D = oQ * E
         # all heads x batch rows of the block in one grouped launch per product (G = nh * B problems of [oT, oT]).
         # The key / value time axis is zero-padded to a multiple of 4 floats (16-byte rows for the GEMM operand loads);
         # padded key columns get a -1e30 bias in the logits' epilogue, i.e. exactly zero attention weight.
         G = nh * B
         Tp = -(-oT // 4) * 4
-        Qa = torch.stack(qh, 0).view(G, oT, D)                                                      # group h * B + b
-        Ka = torch.nn.functional.pad(torch.stack(kh, 0).view(G, oT, D), (0, 0, 0, Tp - oT))
-        Va = torch.nn.functional.pad(torch.stack(vh, 0).view(G, oT, oQ * cp), (0, 0, 0, Tp - oT))
+        if dev.heads_ok(oQ, nh, E) and dev.heads_ok(oQ, nh, cp) and os.environ.get("WESEP_TFG_HEADS_FUSED", "1") != "0":
+            # one projection GEMM for Q, K and V (the block output is read once, its gradient is one GEMM instead of three
+            # and two full-size sums), then one kernel per projection: PReLU + head LayerNorm + the head-major layout
+            Wc = torch.cat([cq.weight, ck.weight, cv.weight], 0)
+            bc = torch.cat([cq.bias, ck.bias, cv.bias], 0)
+            qkv = FD.Conv1x1ResFn.apply(inter, Wc, bc, None)
+            par = []
+            for nm, ch in (("attn_norm_Q", E), ("attn_norm_K", E), ("attn_norm_V", cp)):
+                norm = self[nm]
+                par += [norm.act.weight, norm.gamma[0, :, :, 0, :].permute(0, 2, 1).reshape(nh, oQ * ch),
+                        norm.beta[0, :, :, 0, :].permute(0, 2, 1).reshape(nh, oQ * ch)]
+            Qa, Ka, Va = FG.QKVHeadsFn.apply(qkv, (B, oT, Tp, oQ, nh, E, cp), *par)
+        else:
+            q = FD.Conv1x1ResFn.apply(inter, cq.weight, cq.bias, None)
+            k = FD.Conv1x1ResFn.apply(inter, ck.weight, ck.bias, None)
+            v = FD.Conv1x1ResFn.apply(inter, cv.weight, cv.bias, None)
+            qh = _heads(q, B, oT, oQ, nh, E, self["attn_norm_Q"])
+            kh = _heads(k, B, oT, oQ, nh, E, self["attn_norm_K"])
+            vh = _heads(v, B, oT, oQ, nh, cp, self["attn_norm_V"])
+            Qa = torch.stack(qh, 0).view(G, oT, D)                                                      # group h * B + b
+            Ka = torch.nn.functional.pad(torch.stack(kh, 0).view(G, oT, D), (0, 0, 0, Tp - oT))
+            Va = torch.nn.functional.pad(torch.stack(vh, 0).view(G, oT, oQ * cp), (0, 0, 0, Tp - oT))
         mask = torch.zeros(Tp, device=x.device, dtype=torch.float32)
         mask[oT:] = -1e30
         logits = FG.BatchedMatmulNTFn.apply(Qa, Ka, mask)                                           # [G, oT, Tp]
