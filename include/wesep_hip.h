@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 13
+#define WS_ABI_VERSION 14
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -640,15 +640,15 @@ int ws_conv3x3_wgrad(const ws_conv3x3_wgrad_args* a, void* stream);
  * of u = pre(x), to be reduced and finalised by ws_reduce_slabs + ws_inorm_finalize; backward: (sum d, sum d * n) with
  * n = (u - mean) * rstd and d = dy * (bit 1 ? ELU'(n) : 1).  ws_in_act_apply: y from x and the statistics (one pass).
  * ws_in_act_bwd_apply: dx = pre'(x) * rstd * (d - S0/P - n * S1/P) from x, dy, the statistics and the reduced sums
- * (dx may alias dy when ldd is 0).  Only the pre-activation x has to be kept for the backward.  x and dx are dense
- * [rows][C]; y (apply) has row stride ldy and dy (sums, bwd_apply) row stride ldd -- 0 = C, else >= C and % 4: the
+ * (dx may alias dy when both strides agree).  Only the pre-activation x has to be kept for the backward.  x is dense
+ * [rows][C]; y (apply) has row stride ldy, dy (sums, bwd_apply) row stride ldd and dx row stride lddx -- 0 = C, else >= C and % 4: the
  * dense blocks write y into / read dy from a column range of their one wide feature map (no torch.cat, no slices). */
 int ws_in_act_sums(const float* x, const float* dy, long long ldd, const float* stats, int P, int G, int nsplit, int C,
                    int flags, float* slab, void* stream);
 int ws_in_act_apply(const float* x, const float* stats, long long rows, int P, int C, int flags, float* y, long long ldy,
                     void* stream);
 int ws_in_act_bwd_apply(const float* x, const float* dy, long long ldd, const float* stats, const float* sums, long long rows,
-                        int P, int C, int flags, float* dx, void* stream);
+                        int P, int C, int flags, float* dx, long long lddx, void* stream);
 /* nn.AvgPool2d(sz) and its adjoint; nn.Upsample(size = (H, W), mode = "bilinear") (align_corners False) and its
  * adjoint (a gather over destination pixels)                                                                  */
 int ws_avgpool_fwd(const float* x, int B, int H, int W, int C, int sz, float* y, void* stream);

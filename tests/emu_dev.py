@@ -442,28 +442,28 @@ def conv3x3_pack(W2, Cin, Cout):
     return W2.reshape(Cout, 9 * Cin).contiguous()       # the emulation keeps the plain rows
 
 
-def conv3x3(*, X, ldx, W, ldw, B, H, Wd, Cin, Cout, Y, ldy, bias=None, R=None):
+def conv3x3(*, X, ldx, W, ldw, B, H, Wd, Cin, Cout, Y, ldy, bias=None, R=None, x_off=0, y_off=0):
     M = B * H * Wd
-    img = X.reshape(-1)[:M * ldx].reshape(B, H, Wd, ldx)[..., :Cin].permute(0, 3, 1, 2)
+    img = X.reshape(-1)[:M * ldx].reshape(B, H, Wd, ldx)[..., x_off:x_off + Cin].permute(0, 3, 1, 2)
     w = W.reshape(-1)[:Cout * ldw].reshape(Cout, ldw)[:, :9 * Cin].reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
     v = F.conv2d(img, w, bias.reshape(-1)[:Cout] if bias is not None else None, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
     if R is not None:
-        v = v + R.reshape(-1)[:M * ldy].reshape(M, ldy)[:, :Cout]
-    Y.reshape(-1)[:M * ldy].reshape(M, ldy)[:, :Cout] = v
+        v = v + R.reshape(-1)[:M * ldy].reshape(M, ldy)[:, y_off:y_off + Cout]
+    Y.reshape(-1)[:M * ldy].reshape(M, ldy)[:, y_off:y_off + Cout] = v
 
 
 def conv3x3_wgrad_tiles(B, H, Wd):
     return B * (-(-H // 30)) * (-(-Wd // 4))
 
 
-def conv3x3_wgrad(*, G, ldg, X, ldx, B, H, Wd, Cin, Nn, slab, nsplit, tiles_per_split, bslab=None, sw=1, Wx=0):
+def conv3x3_wgrad(*, G, ldg, X, ldx, B, H, Wd, Cin, Nn, slab, nsplit, tiles_per_split, bslab=None, sw=1, Wx=0, g_off=0):
     """Slab 0 carries the whole gradient (the split of the pixels is a device detail), the others are zero."""
     assert nsplit * tiles_per_split >= conv3x3_wgrad_tiles(B, H, Wd)
     Wx = Wx or Wd
     assert sw in (1, 2) and (Wx - 1) // sw + 1 == Wd
     M, Mx = B * H * Wd, B * H * Wx
     img = X.reshape(-1)[:Mx * ldx].reshape(B, H, Wx, ldx)[..., :Cin].permute(0, 3, 1, 2)
-    g = G.reshape(-1)[:M * ldg].reshape(B, H, Wd, ldg)[..., :Nn].permute(0, 3, 1, 2)
+    g = G.reshape(-1)[:M * ldg].reshape(B, H, Wd, ldg)[..., g_off:g_off + Nn].permute(0, 3, 1, 2)
     # dW[n][c][ky][kx] = sum g[b][n][h][w] * xpad[b][c][h + ky][sw*w + kx]
     dw = torch.nn.grad.conv2d_weight(img, (Nn, Cin, 3, 3), g, stride=(1, sw), padding=1)
     sl = slab.reshape(-1)[:nsplit * Nn * 9 * Cin].reshape(nsplit, Nn * 9 * Cin)
@@ -494,7 +494,7 @@ def in_act_fwd(x, G, P, Cc, flags, y, eps=1e-5, y_ld=0, y_off=0):
     return torch.stack([mean, rstd], 1)
 
 
-def in_act_bwd(x, dy, stats, G, P, Cc, flags, dx, dy_ld=0, dy_off=0):
+def in_act_bwd(x, dy, stats, G, P, Cc, flags, dx, dy_ld=0, dy_off=0, dx_ld=0, dx_off=0):
     xx, dd = x.reshape(G, P, Cc), _cols(dy, G * P, dy_ld, dy_off, Cc).reshape(G, P, Cc)
     u = F.elu(xx) if flags & 1 else xx
     mean, rstd = stats[:, 0][:, None], stats[:, 1][:, None]
@@ -503,7 +503,7 @@ def in_act_bwd(x, dy, stats, G, P, Cc, flags, dx, dy_ld=0, dy_off=0):
     r = rstd * (d - d.mean(1, keepdim=True) - n * (d * n).mean(1, keepdim=True))
     if flags & 1:
         r = r * torch.where(xx > 0, torch.ones_like(xx), torch.exp(xx))
-    dx.reshape(G, P, Cc)[:] = r
+    _cols(dx, G * P, dx_ld, dx_off, Cc)[:] = r.reshape(G * P, Cc)
 
 
 def heads_ok(Q, nh, ch):

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 13
+ABI_VERSION = 14
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
@@ -225,7 +225,7 @@ _SIGS = {
     "ws_conv3x3_wgrad": (_i, [C.POINTER(Conv3x3WgradArgs), _p]),
     "ws_in_act_sums": (_i, [_p, _p, _ll, _p, _i, _i, _i, _i, _i, _p, _p]),
     "ws_in_act_apply": (_i, [_p, _p, _ll, _i, _i, _i, _p, _ll, _p]),
-    "ws_in_act_bwd_apply": (_i, [_p, _p, _ll, _p, _p, _ll, _i, _i, _i, _p, _p]),
+    "ws_in_act_bwd_apply": (_i, [_p, _p, _ll, _p, _p, _ll, _i, _i, _i, _p, _ll, _p]),
     "ws_rowln_grid": (_i, [_ll, _i]),
     "ws_rowln_fwd": (_i, [_p, _p, _p, _ll, _i, C.c_float, _p, _p, _p]),
     "ws_rowln_bwd": (_i, [_p, _p, _p, _p, _p, _ll, _i, _p, _p, _p]),

@@ -651,7 +651,7 @@ __global__ void in_act_apply_kernel(const float* __restrict__ x, const float* __
 // dx = pre'(x) * rstd * (d - S0/P - n * S1/P)      (dx may alias dy)
 __global__ void in_act_bwd_apply_kernel(const float* __restrict__ x, const float* dy, const float* __restrict__ stats,
                                         const float* __restrict__ sums, long long rows, int P, int C, int flags,
-                                        long long ldd, float* dx) {
+                                        long long ldd, long long lddx, float* dx) {
   const int c4n = C >> 2;
   const long long total = rows * c4n;
   const float inv = 1.f / (float)P;
@@ -671,7 +671,7 @@ __global__ void in_act_bwd_apply_kernel(const float* __restrict__ x, const float
     if (flags & 2) d *= elud4(n);
     f32x4 r = rstd * (d - s0 - n * s1);
     if (flags & 1) r *= elud4(xv);
-    *reinterpret_cast<f32x4*>(dx + i * 4) = r;
+    *reinterpret_cast<f32x4*>(dx + row * lddx + c) = r;
   }
 }
 
@@ -696,12 +696,13 @@ extern "C" int ws_in_act_apply(const float* x, const float* stats, long long row
 }
 
 extern "C" int ws_in_act_bwd_apply(const float* x, const float* dy, long long ldd, const float* stats, const float* sums,
-                                   long long rows, int P, int C, int flags, float* dx, void* stream) {
+                                   long long rows, int P, int C, int flags, float* dx, long long lddx, void* stream) {
   WS_REQUIRE(x && dy && stats && sums && dx && rows > 0 && P > 0 && C > 0 && C % 4 == 0 && rows % P == 0 && (flags & ~3) == 0,
              "ws_in_act_bwd_apply: bad args");
-  WS_REQUIRE(ldd == 0 || (ldd >= C && ldd % 4 == 0), "ws_in_act_bwd_apply: dy row stride %lld (0 = C, else >= C and %% 4)", ldd);
+  WS_REQUIRE((ldd == 0 || (ldd >= C && ldd % 4 == 0)) && (lddx == 0 || (lddx >= C && lddx % 4 == 0)),
+             "ws_in_act_bwd_apply: dy / dx row strides %lld / %lld (0 = C, else >= C and %% 4)", ldd, lddx);
   hipLaunchKernelGGL(in_act_bwd_apply_kernel, dim3(cv_blocks(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, dy, stats,
-                     sums, rows, P, C, flags, ldd ? ldd : (long long)C, dx);
+                     sums, rows, P, C, flags, ldd ? ldd : (long long)C, lddx ? lddx : (long long)C, dx);
   return ws_check_launch("ws_in_act_bwd_apply");
 }
 

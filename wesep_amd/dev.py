@@ -1135,13 +1135,17 @@ def conv3x3_pack(W2, Cin: int, Cout: int):
     return both.permute(4, 3, 1, 0, 5, 2, 6).contiguous().view(torch.float32).reshape(-1)
 
 
-def conv3x3(*, X, ldx: int, W, ldw: int, B: int, H: int, Wd: int, Cin: int, Cout: int, Y, ldy: int, bias=None, R=None):
+def conv3x3(*, X, ldx: int, W, ldw: int, B: int, H: int, Wd: int, Cin: int, Cout: int, Y, ldy: int, bias=None, R=None,
+            x_off: int = 0, y_off: int = 0):
     """3 x 3 / stride 1 / padding 1 convolution through an LDS halo tile (conv3x3.hip); Y = bias + R + conv(X); W = the
-    packed weights of conv3x3_pack."""
+    packed weights of conv3x3_pack.  x_off / y_off: the image is columns [x_off, x_off + Cin) of rows of stride ldx, the
+    output (and R) columns [y_off, y_off + Cout) of rows of stride ldy."""
     for n, t in (("X", X), ("W", W), ("bias", bias), ("R", R), ("Y", Y)):
         _chk(t, n)
+    _cols_ok(X, B * H * Wd, ldx, x_off, Cin, "conv3x3 X")
+    _cols_ok(Y, B * H * Wd, ldy, y_off, Cout, "conv3x3 Y")
     a = L.Conv3x3Args()
-    a.X, a.W, a.bias, a.R, a.Y = _p(X), _p(W), _p(bias), _p(R), _p(Y)
+    a.X, a.W, a.bias, a.R, a.Y = _p(X, x_off), _p(W), _p(bias), _p(R, y_off), _p(Y, y_off)
     a.ldx, a.ldw, a.ldy = ldx, ldw, ldy
     a.B, a.H, a.Wd, a.Cin, a.Cout = B, H, Wd, Cin, Cout
     _alg("gemm_nt", 4 * (B * H * Wd * (Cin + Cout * (1 + (R is not None))) + 9 * Cin * Cout), 2 * B * H * Wd * 9 * Cin * Cout)
@@ -1154,13 +1158,14 @@ def conv3x3_wgrad_tiles(B: int, H: int, Wd: int) -> int:
 
 
 def conv3x3_wgrad(*, G, ldg: int, X, ldx: int, B: int, H: int, Wd: int, Cin: int, Nn: int, slab, nsplit: int,
-                  tiles_per_split: int, bslab=None, sw: int = 1, Wx: int = 0):
+                  tiles_per_split: int, bslab=None, sw: int = 1, Wx: int = 0, g_off: int = 0):
     """Weight (+ bias) gradient slabs of a 3 x 3 / padding 1 convolution with stride (1, sw), one pass over the image
     (conv3x3.hip): slab [nsplit, Nn * 9 * Cin], bslab [nsplit, Nn].  Wd = width of the gradient grid, Wx = of the image."""
     for n, t in (("G", G), ("X", X), ("slab", slab), ("bslab", bslab)):
         _chk(t, n)
+    _cols_ok(G, B * H * Wd, ldg, g_off, Nn, "conv3x3_wgrad G")
     a = L.Conv3x3WgradArgs()
-    a.G, a.X, a.slab, a.bslab = _p(G), _p(X), _p(slab), _p(bslab)
+    a.G, a.X, a.slab, a.bslab = _p(G, g_off), _p(X), _p(slab), _p(bslab)
     a.ldg, a.ldx, a.slab_stride, a.bslab_stride = ldg, ldx, Nn * 9 * Cin, Nn
     a.B, a.H, a.Wd, a.Wx, a.sw, a.Cin, a.Nn, a.nsplit, a.tiles_per_split = B, H, Wd, Wx or Wd, sw, Cin, Nn, nsplit, tiles_per_split
     _alg("gemm_tn", 4 * (B * H * (Wx or Wd) * Cin + B * H * Wd * Nn * (-(-Cin // 32)) + nsplit * Nn * 9 * Cin),
@@ -1202,13 +1207,15 @@ def in_act_fwd(x, G: int, P: int, Cc: int, flags: int, y, eps=IN_EPS, y_ld: int 
     return stats
 
 
-def in_act_bwd(x, dy, stats, G: int, P: int, Cc: int, flags: int, dx, dy_ld: int = 0, dy_off: int = 0):
-    """dy_ld / dy_off: dy is columns [dy_off, dy_off + Cc) of a dense [G*P, dy_ld] tensor."""
+def in_act_bwd(x, dy, stats, G: int, P: int, Cc: int, flags: int, dx, dy_ld: int = 0, dy_off: int = 0, dx_ld: int = 0,
+               dx_off: int = 0):
+    """dy_ld / dy_off: dy is columns [dy_off, dy_off + Cc) of a dense [G*P, dy_ld] tensor; dx_ld / dx_off likewise for dx."""
     for n, t in (("x", x), ("dy", dy), ("stats", stats), ("dx", dx)):
         _chk(t, n)
     _cols_ok(dy, G * P, dy_ld, dy_off, Cc, "in_act_bwd dy")
+    _cols_ok(dx, G * P, dx_ld, dx_off, Cc, "in_act_bwd dx")
     sums = _in_act_sums(x, dy, stats, G, P, Cc, flags, dy_ld, dy_off)
-    _call("ws_in_act_bwd_apply", _p(x), _p(dy, dy_off), dy_ld, _p(stats), _p(sums), G * P, P, Cc, flags, _p(dx))
+    _call("ws_in_act_bwd_apply", _p(x), _p(dy, dy_off), dy_ld, _p(stats), _p(sums), G * P, P, Cc, flags, _p(dx, dx_off), dx_ld)
 
 
 def avgpool_fwd(x, B: int, H: int, W: int, Cc: int, sz: int, y):

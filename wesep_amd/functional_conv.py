@@ -61,9 +61,10 @@ def halo_wgrad_ok(Cin, Cout, k, sh, sw, p, dil=1):
         os.environ.get("WESEP_CONV3X3_WGRAD", "1") != "0"
 
 
-def halo_wgrad(G, Nn, X, ldx, B, H, W, Cin, with_bias, sw=1, Wx=0):
+def halo_wgrad(G, Nn, X, ldx, B, H, W, Cin, with_bias, sw=1, Wx=0, ldg=0, g_off=0):
     """dW2 [Nn, 9*Cin] (+ db) of a 3 x 3 / padding 1 convolution with stride (1, sw): G [B*H*W, Nn] gradient rows on the
-    output grid, X the image [B, H, Wx] with pixel stride ldx (its first Cin channels)."""
+    output grid (or columns [g_off, g_off + Nn) of rows of stride ldg), X the image [B, H, Wx] with pixel stride ldx (its
+    first Cin channels)."""
     tiles = dev.conv3x3_wgrad_tiles(B, H, W)
     groups = (-(-Cin // 32)) * (-(-Nn // 32))              # workgroups per split: one per (input chunk, output tile)
     nsplit = max(1, min(tiles // 4, -(-1024 // groups)))   # ~4 workgroups per CU in flight, >= 4 tiles each
@@ -72,8 +73,8 @@ def halo_wgrad(G, Nn, X, ldx, B, H, W, Cin, with_bias, sw=1, Wx=0):
     d = G.device
     slab = _empty(d, nsplit, Nn * 9 * Cin)
     bslab = _empty(d, nsplit, Nn) if with_bias else None
-    dev.conv3x3_wgrad(G=G, ldg=Nn, X=X, ldx=ldx, B=B, H=H, Wd=W, Cin=Cin, Nn=Nn, slab=slab, nsplit=nsplit,
-                      tiles_per_split=tps, bslab=bslab, sw=sw, Wx=Wx or W)
+    dev.conv3x3_wgrad(G=G, ldg=ldg or Nn, X=X, ldx=ldx, B=B, H=H, Wd=W, Cin=Cin, Nn=Nn, slab=slab, nsplit=nsplit,
+                      tiles_per_split=tps, bslab=bslab, sw=sw, Wx=Wx or W, g_off=g_off)
     dW = _reduce_new(slab, nsplit, Nn * 9 * Cin, (Nn, 9 * Cin))
     db = _reduce_new(bslab, nsplit, Nn, (Nn,)) if with_bias else None
     return dW, db

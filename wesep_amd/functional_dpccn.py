@@ -217,11 +217,13 @@ class InstNormFn(torch.autograd.Function):
 
 class DenseBlockFn(torch.autograd.Function):
     """Five densely connected conv3x3 - ELU - InstanceNorm layers (convs.py:80-112) WITHOUT the concatenations: the
-    block's feature map lives in one [M, C0 + 4g] buffer, layer i convolves its first C0 + i*g channels through a patch
-    view with pixel stride C0 + 4g (ws_conv_view.ldp) and writes its g output channels behind them; the backward
-    accumulates every layer's input gradient into the matching prefix of ONE gradient buffer through the GEMM's
-    residual operand.  torch.cat copied the growing map once per layer forward (2 + 3 + 4 + 5 blocks of channels) and
-    autograd split and re-summed it backward.  params = (w1, b1, ..., w5, b5); x [M, C0] -> [M, Cout5]."""
+    block's feature map lives in one [M, C0 + 4g] buffer; layer i convolves its first C0 + i*g channels (the halo-tile
+    kernel reads a pixel-strided prefix) and its normalised output is written straight into the next g columns.
+    Backward: the pre-activation gradients of the five layers live in one [M, 4g + Cout5] buffer, and the gradient of
+    each CHANNEL BLOCK of the map (x's C0 channels, then each layer's g) is ONE convolution of the gradients of all
+    later layers with the stacked, flipped kernel slices -- written once, where accumulating layer by layer read and
+    re-wrote every prefix.  torch.cat copied the growing map once per layer forward and autograd split
+    and re-summed it backward.  params = (w1, b1, ..., w5, b5); x [M, C0] -> [M, Cout5]."""
 
     @staticmethod
     def forward(ctx, x, geo, *params):
@@ -243,8 +245,6 @@ class DenseBlockFn(torch.autograd.Function):
         for i in range(5):
             Ci, Co = C0 + i * g, ws[i].shape[0]
             W2 = dev.conv3x3_pack(ws[i].permute(0, 2, 3, 1).reshape(Co, 9 * Ci), Ci, Co)    # [co][(ky*3 + kx)*Ci + ci]
-            # input gradient = the correlation of dy with the flipped kernel: [ci][(ky*3 + kx)*Co + co] = w[co][ci][2 - ky][2 - kx]
-            Wd = dev.conv3x3_pack(ws[i].flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, 9 * Co), Co, Ci)
             pre = _empty(d, M, Co)
             dev.conv3x3(X=big, ldx=Ctot, W=W2, ldw=9 * Ci, B=B, H=H, Wd=W, Cin=Ci, Cout=Co, Y=pre, ldy=Co, bias=bs[i])
             if i < 4:                    # the layer's output IS the next g columns of the map
@@ -252,41 +252,51 @@ class DenseBlockFn(torch.autograd.Function):
             else:
                 out = _empty(d, M, Co)
                 st = dev.in_act_fwd(pre, B, H * W, Co, dev.IN_ELU_PRE, out)
-            saved += [pre, st, Wd]
-        ctx.save_for_backward(big, *saved)
+            saved += [pre, st]
+        ctx.save_for_backward(big, *saved, *ws)
         ctx.geo = (B, H, W, C0, g, tuple(w.shape for w in ws))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         big = ctx.saved_tensors[0]
-        saved = ctx.saved_tensors[1:]
+        saved, ws = ctx.saved_tensors[1:11], ctx.saved_tensors[11:16]
         B, H, W, C0, g, wshapes = ctx.geo
-        M, Ctot = B * H * W, C0 + 4 * g
+        M, Ctot, Co5 = B * H * W, C0 + 4 * g, wshapes[4][0]
+        Dtot = 4 * g + Co5                  # columns [i*g, ...) of dpre = the pre-activation gradient of layer i
         d = big.device
-        dbig = _empty(d, M, Ctot)            # layer 5's input gradient covers every column: no zero fill
+        dbig = _empty(d, M, Ctot)           # every column block is written exactly once below
+        dpre = _empty(d, M, Dtot)
+        # input gradient = the correlation of d(pre) with the flipped kernel: [ci][ky][kx][co] = w[co][ci][2 - ky][2 - kx]
+        wflip = [w.flip(2, 3).permute(1, 2, 3, 0) for w in ws]
         grads = [None] * 10
-        d_out = dout.contiguous()
         for i in range(4, -1, -1):
-            pre, st, Wd = saved[3 * i:3 * i + 3]
+            pre, st = saved[2 * i:2 * i + 2]
             Ci, Co = C0 + i * g, wshapes[i][0]
-            d_pre = _empty(d, M, Co)
-            if i < 4:                    # columns [Ci, Ci + g) of dbig are complete: layers i+2 .. 5 have added their share
-                dev.in_act_bwd(pre, dbig, st, B, H * W, Co, dev.IN_ELU_PRE, d_pre, dy_ld=Ctot, dy_off=Ci)
+            if i < 4:                       # columns [Ci, Ci + g) of dbig: written by the block convolution of iteration i + 1
+                dev.in_act_bwd(pre, dbig, st, B, H * W, Co, dev.IN_ELU_PRE, dpre, dy_ld=Ctot, dy_off=Ci, dx_ld=Dtot, dx_off=i * g)
             else:
-                dev.in_act_bwd(pre, d_out, st, B, H * W, Co, dev.IN_ELU_PRE, d_pre)
-            conv = dev.ConvView(0, H, W, Ci, H, W, 3, 1, 1, 1, 1, Ctot)
+                dev.in_act_bwd(pre, dout.contiguous(), st, B, H * W, Co, dev.IN_ELU_PRE, dpre, dx_ld=Dtot, dx_off=i * g)
             if FC.halo_wgrad_ok(Ci, Co, 3, 1, 1, 1):
-                dW2, db = FC.halo_wgrad(d_pre, Co, big, Ctot, B, H, W, Ci, True)
-            elif dev.conv_wgrad_ok(Co, conv):
-                dW2, db = FC._one_pass_wgrad(d_pre, M, Co, big, conv, True)
+                dW2, db = FC.halo_wgrad(dpre, Co, big, Ctot, B, H, W, Ci, True, ldg=Dtot, g_off=i * g)
             else:
-                dW2, db = _wgrad(d_pre, M, Co, big, 9 * Ci, with_bias=True, vec=1, mode=FC.MODE, conv=conv)
+                d_pre = dpre[:, i * g:i * g + Co].contiguous()
+                conv = dev.ConvView(0, H, W, Ci, H, W, 3, 1, 1, 1, 1, Ctot)
+                if dev.conv_wgrad_ok(Co, conv):
+                    dW2, db = FC._one_pass_wgrad(d_pre, M, Co, big, conv, True)
+                else:
+                    dW2, db = _wgrad(d_pre, M, Co, big, 9 * Ci, with_bias=True, vec=1, mode=FC.MODE, conv=conv)
             grads[2 * i] = dW2.reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous().view(wshapes[i])
             grads[2 * i + 1] = db
-            # d(first Ci channels of the map) += transposed view of d_pre (conv2d_dx), accumulated in place
-            dev.conv3x3(X=d_pre, ldx=Co, W=Wd, ldw=9 * Co, B=B, H=H, Wd=W, Cin=Co, Cout=Ci, Y=dbig, ldy=Ctot,
-                        R=None if i == 4 else dbig)
+            # the channel block this layer's INPUT ends with (layer i - 1's output; x for i = 0) is complete once layers
+            # i .. 4 have their d(pre): one convolution over the columns [i*g, Dtot) of dpre
+            lo, hi = (0, C0) if i == 0 else (C0 + (i - 1) * g, C0 + i * g)
+            if i == 0 and not ctx.needs_input_grad[0]:
+                break
+            cin = Dtot - i * g
+            Wb = torch.cat([wflip[k][lo:hi] for k in range(i, 5)], 3).reshape(hi - lo, 9 * cin)
+            dev.conv3x3(X=dpre, ldx=Dtot, x_off=i * g, W=dev.conv3x3_pack(Wb, cin, hi - lo), ldw=9 * cin, B=B, H=H, Wd=W,
+                        Cin=cin, Cout=hi - lo, Y=dbig, ldy=Ctot, y_off=lo)
         dx = dbig[:, :C0].contiguous() if ctx.needs_input_grad[0] else None
         return (dx, None) + tuple(grads)
 
