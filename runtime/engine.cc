@@ -224,6 +224,13 @@ struct ws_engine {
   int tN = 512, tL = 16, tB = 128, tH = 512, tP = 3, tX = 8, tR = 3;
   float* tas_dec_wt = nullptr;   // decoder_1d_1 weight transposed to [L][N]
   float* tas_bn_st[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // eval BN (mean, rstd) [2][C]
+  // DPCCN (arch 2; wesep/models/dpccn.py): prepared operands, in the order the forward consumes them
+  int dp_fuse = 2, dp_causal = 0, dp_tcn_blocks = 10, dp_tcn_layers = 2;
+  float *dp_ana4 = nullptr, *dp_syn4 = nullptr;       // analysis basis [4 * 257][512] (re, im, 0, 0 per bin), synthesis [512][4 * 257]
+  float *dp_w_in = nullptr;                           // conv2d (2 -> 16) as [16][9 * 4] on the (re, im, 0, 0) pixels
+  float *dp_w_out = nullptr, *dp_b_out = nullptr;     // deconv2d (32 -> 2) as [4][9 * 32] + bias[4]: (re, im, 0, 0) per bin
+  float *dp_ident = nullptr, *dp_ones = nullptr, *dp_zeros = nullptr;   // (mean 0, rstd 1) rows, gamma 1, beta 0 of the plain depthwise conv
+  std::map<std::string, float*> dp_w;                 // per-layer GEMM weights / conv3x3 packs, keyed by the layer's state_dict prefix
   // grouped-GEMM descriptor tables, rebuilt when (R, Tf) changes
   int desc_R = -1, desc_Tf = -1;
   ws_group_nt *d_bn = nullptr, *d_l1 = nullptr, *d_l2 = nullptr, *d_l3 = nullptr;
@@ -719,12 +726,35 @@ int prep_mel_frontend(ws_engine* e) {
 }
 
 int prepare_tasnet(ws_engine* e);
+int prepare_dpccn(ws_engine* e);
+
+// the speaker-encoder part of the container's meta block (shared by the pBSRNN and DPCCN plans)
+int read_speaker_meta(ws_engine* e) {
+  e->spk_feat = static_cast<int>(meta_or(e, "spk_feat", 1));
+  e->E = static_cast<int>(meta_or(e, "spk_emb_dim", 256));
+  e->use_xform = static_cast<int>(meta_or(e, "use_spk_transform", 0));
+  e->joint = static_cast<int>(meta_or(e, "joint_training", 0));
+  e->feat_dim = static_cast<int>(meta_or(e, "feat_dim", 80));
+  for (int i = 0; i < 4; ++i) e->blocks[i] = static_cast<int>(meta_or(e, ("spk_blocks" + std::to_string(i)).c_str(), 0));
+  e->spk_kind = static_cast<int>(meta_or(e, "spk_kind", 0));          // 0 wespeaker ResNet, 1 ECAPA-TDNN
+  e->spk_channels = static_cast<int>(meta_or(e, "spk_channels", 512));
+  e->spk_glob = static_cast<int>(meta_or(e, "spk_glob", 0));
+  e->spk_emb_bn = static_cast<int>(meta_or(e, "spk_emb_bn", 0));
+  e->spk_bottleneck = static_cast<int>(meta_or(e, "spk_bottleneck", 0));
+  e->spk_two_emb = static_cast<int>(meta_or(e, "spk_two_emb", 0));
+  if (e->spk_kind < 0 || e->spk_kind > 1) {
+    set_err("engine: speaker encoder kind %d is not built (0 ResNet, 1 ECAPA-TDNN)", e->spk_kind);
+    return WS_ERR_INVALID;
+  }
+  return WS_OK;
+}
 
 int prepare(ws_engine* e) {
   e->arch = static_cast<int>(meta_or(e, "arch", 0));
   if (e->arch == 1) return prepare_tasnet(e);
+  if (e->arch == 2) return prepare_dpccn(e);
   if (e->arch != 0) {
-    set_err("engine: architecture %d has no launch plan (0 pBSRNN, 1 Conv-TasNet)", e->arch);
+    set_err("engine: architecture %d has no launch plan (0 pBSRNN, 1 Conv-TasNet, 2 DPCCN)", e->arch);
     return WS_ERR_INVALID;
   }
   e->sr = static_cast<int>(meta_or(e, "sample_rate", 16000));
@@ -1933,6 +1963,540 @@ int prepare_tasnet(ws_engine* e) {
   return WS_OK;
 }
 
+// =================================================================================================================
+// DPCCN (arch 2): the launch plan of wesep_amd/models/dpccn.py (wesep/models/dpccn.py:206-290) in eval mode -- STFT as a
+// DFT-basis GEMM, Conv2d(2 -> 16), the dense blocks through the halo-tile convolution (ws_conv3x3), (1, 2)-strided
+// convolutions and transposed convolutions as implicit GEMMs, ELU + InstanceNorm fused (ws_in_act_*), the TCN stack
+// (IN - ELU - depthwise dilated conv - IN - ELU - 1x1 conv + residual), the four pooling branches (AvgPool2d, 1x1
+// conv, bilinear upsampling), ConvTranspose2d(32 -> 2) and the inverse STFT.  Channels-last [R * T * F][C] everywhere,
+// H = frames, W = bins.  multiply / additive / FiLM fusion; fixed embeddings or the speaker encoders of the pBSRNN
+// plan (fbank / waveform enrollment).  InstanceNorm2d / InstanceNorm1d carry no running statistics in the reference
+// (affine = False, track_running_stats = False): eval and training forward are the same computation.
+// =================================================================================================================
+constexpr int kDpWin = 512, kDpBins = 257, kDpLd = 4 * kDpBins;     // 1028: (re, im, 0, 0) per bin
+constexpr float kInEps = 1e-5f;
+constexpr int kInPre = 1, kInPost = 2;                               // ws_in_act_* flags: IN(ELU(x)) / ELU(IN(x))
+
+uint16_t bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+
+float bf16_float(uint16_t h) {
+  const uint32_t u = uint32_t(h) << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// wesep_amd.dev.conv3x3_pack on the host: W2 [Cout][9 * Cin] (tap-major rows) -> the bf16 hi / lo MFMA-fragment order of
+// ws_conv3x3 (include/wesep_hip.h): unit (((chunk*9 + tap)*NTP + t)*2 + part)*64 + lane, 8 bf16 each
+std::vector<float> dp_pack3x3(const std::vector<float>& W2, int Cin, int Cout) {
+  const int ntt = (Cout + 31) / 32, ntp = ntt <= 2 ? ntt : ntt + (ntt & 1), nch = (Cin + 15) / 16;
+  std::vector<uint16_t> out(size_t(nch) * 9 * ntp * 2 * 64 * 8, 0);
+  for (int chunk = 0; chunk < nch; ++chunk)
+    for (int tap = 0; tap < 9; ++tap)
+      for (int t = 0; t < ntp; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int n = t * 32 + (lane & 31);
+          for (int j = 0; j < 8; ++j) {
+            const int c = chunk * 16 + 8 * (lane >> 5) + j;
+            const float v = (n < Cout && c < Cin) ? W2[size_t(n) * 9 * Cin + size_t(tap) * Cin + c] : 0.f;
+            const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_float(hi));
+            const size_t u = ((size_t(chunk) * 9 + tap) * ntp + t) * 2;
+            out[((u + 0) * 64 + lane) * 8 + j] = hi;
+            out[((u + 1) * 64 + lane) * 8 + j] = lo;
+          }
+        }
+  std::vector<float> f(out.size() / 2);
+  memcpy(f.data(), out.data(), out.size() * 2);
+  return f;
+}
+
+// w [Cout][Cin][3][3] (Conv2d) -> W2 [Cout][(ky*3 + kx)*cin_pad + ci], input channels zero-padded to cin_pad
+std::vector<float> dp_conv_rows(const float* w, int Cout, int Cin, int cin_pad) {
+  std::vector<float> W2(size_t(Cout) * 9 * cin_pad, 0.f);
+  for (int o = 0; o < Cout; ++o)
+    for (int c = 0; c < Cin; ++c)
+      for (int t = 0; t < 9; ++t) W2[size_t(o) * 9 * cin_pad + size_t(t) * cin_pad + c] = w[(size_t(o) * Cin + c) * 9 + t];
+  return W2;
+}
+
+// w [Cin][Cout][3][3] (ConvTranspose2d) -> Wt [cout_pad][(ky*3 + kx)*Cin + ci], output channels zero-padded
+std::vector<float> dp_convT_rows(const float* w, int Cin, int Cout, int cout_pad) {
+  std::vector<float> Wt(size_t(cout_pad) * 9 * Cin, 0.f);
+  for (int c = 0; c < Cin; ++c)
+    for (int o = 0; o < Cout; ++o)
+      for (int t = 0; t < 9; ++t) Wt[size_t(o) * 9 * Cin + size_t(t) * Cin + c] = w[(size_t(c) * Cout + o) * 9 + t];
+  return Wt;
+}
+
+struct DpDense {
+  const char* prefix;
+  int C0, g, co5;
+};
+const DpDense kDpDense[10] = {{"encoder.0.", 16, 16, 16},   {"encoder.1.1.", 32, 32, 32}, {"encoder.2.1.", 32, 32, 32},
+                              {"encoder.3.1.", 32, 32, 32}, {"encoder.4.1.", 32, 32, 32}, {"decoder.3.0.", 64, 32, 64},
+                              {"decoder.4.0.", 64, 32, 64}, {"decoder.5.0.", 64, 32, 64}, {"decoder.6.0.", 64, 32, 64},
+                              {"decoder.7.", 32, 16, 32}};
+struct DpConv {
+  const char* prefix;
+  int cin, cout;
+};
+const DpConv kDpEnc[7] = {{"encoder.1.0.", 16, 32}, {"encoder.2.0.", 32, 32}, {"encoder.3.0.", 32, 32}, {"encoder.4.0.", 32, 32},
+                          {"encoder.5.", 32, 64},   {"encoder.6.", 64, 128},  {"encoder.7.", 128, 384}};
+const DpConv kDpDec[7] = {{"decoder.0.", 768, 128}, {"decoder.1.", 256, 64},  {"decoder.2.", 128, 32}, {"decoder.3.1.", 64, 32},
+                          {"decoder.4.1.", 64, 32}, {"decoder.5.1.", 64, 32}, {"decoder.6.1.", 64, 16}};
+
+int dp_keep(ws_engine* e, const std::string& key, const std::vector<float>& host) {
+  float* d = upload(e, e->persist, host.data(), host.size());
+  WS_PTR(d);
+  e->dp_w[key] = d;
+  return WS_OK;
+}
+
+int prepare_dpccn(ws_engine* e) {
+  e->sr = static_cast<int>(meta_or(e, "sample_rate", 16000));
+  int rc = read_speaker_meta(e);
+  if (rc != WS_OK) return rc;
+  e->dp_fuse = static_cast<int>(meta_or(e, "spk_fuse_type", 2));
+  e->dp_causal = static_cast<int>(meta_or(e, "causal", 0));
+  e->dp_tcn_blocks = static_cast<int>(meta_or(e, "tcn_blocks", 10));
+  e->dp_tcn_layers = static_cast<int>(meta_or(e, "tcn_layers", 2));
+  if (meta_or(e, "win", 512) != kDpWin || meta_or(e, "stride", 128) != kHop || meta_or(e, "feature_dim", kDpBins) != kDpBins ||
+      meta_or(e, "multi_fuse", 0) != 0) {
+    set_err("engine: the DPCCN plan is built for win 512, stride 128, feature_dim 257, multi_fuse False");
+    return WS_ERR_INVALID;
+  }
+  if (e->dp_fuse < 1 || e->dp_fuse > 3 || e->dp_tcn_blocks < 1 || e->dp_tcn_blocks > 14 || e->dp_tcn_layers < 1 || e->E % 4 ||
+      e->feat_dim % 8) {
+    set_err("engine: unsupported DPCCN configuration (fuse %d: additive 1 / multiply 2 / FiLM 3; tcn %d x %d; spk_emb_dim %d)",
+            e->dp_fuse, e->dp_tcn_layers, e->dp_tcn_blocks, e->E);
+    return WS_ERR_INVALID;
+  }
+  e->dw = e->persist.alloc(e->hw.size());
+  WS_PTR(e->dw);
+  if ((rc = to_device(e, e->dw, e->hw.data(), e->hw.size() * 4)) != WS_OK) return rc;
+  // ---- shapes ----
+  if (!require(e, "conv2d.weight", {16, 2, 3, 3}) || !require(e, "conv2d.bias", {16}) ||
+      !require(e, "deconv2d.weight", {32, 2, 3, 3}) || !require(e, "deconv2d.bias", {2}) ||
+      !require(e, "avg_proj.weight", {32, 64, 1, 1}) || !require(e, "avg_proj.bias", {32}))
+    return WS_ERR_INVALID;
+  for (int i = 0; i < 4; ++i) {
+    const std::string p = "avg_pool." + std::to_string(i) + ".1.";
+    if (!require(e, p + "weight", {8, 32, 1, 1}) || !require(e, p + "bias", {8})) return WS_ERR_INVALID;
+  }
+  if (e->dp_fuse == 3) {
+    if (!require(e, "spk_fuse.fc.gamma_fcs.0.weight", {kDpBins, e->E}) || !require(e, "spk_fuse.fc.gamma_fcs.0.bias", {kDpBins}) ||
+        !require(e, "spk_fuse.fc.beta_fcs.0.weight", {kDpBins, e->E}) || !require(e, "spk_fuse.fc.beta_fcs.0.bias", {kDpBins}))
+      return WS_ERR_INVALID;
+    std::vector<float> b1(e->host("spk_fuse.fc.gamma_fcs.0.bias"), e->host("spk_fuse.fc.gamma_fcs.0.bias") + kDpBins);
+    for (float& v : b1) v += 1.0f;                     // x (1 + gamma(e)) + beta(e)   (norm.py:116-134)
+    if ((rc = dp_keep(e, "film_gamma_bias1", b1)) != WS_OK) return rc;
+  } else if (!require(e, "spk_fuse.fc.linear.weight", {kDpBins, e->E}) || !require(e, "spk_fuse.fc.linear.bias", {kDpBins})) {
+    return WS_ERR_INVALID;
+  }
+  for (int l = 0; l < e->dp_tcn_layers; ++l)
+    for (int b = 0; b < e->dp_tcn_blocks; ++b) {
+      const std::string p = "tcn_layers." + std::to_string(l) + "." + std::to_string(b) + ".";
+      if (!require(e, p + "dconv1.weight", {384, 1, 3}) || !require(e, p + "dconv1.bias", {384}) ||
+          !require(e, p + "dconv2.weight", {384, 384, 1}) || !require(e, p + "dconv2.bias", {384}))
+        return WS_ERR_INVALID;
+    }
+  // ---- convolution operands ----
+  for (const DpDense& d : kDpDense)
+    for (int i = 0; i < 5; ++i) {
+      const int ci = d.C0 + i * d.g, co = i < 4 ? d.g : d.co5;
+      const std::string p = std::string(d.prefix) + "conv" + std::to_string(i + 1) + ".conv2d.";
+      if (!require(e, p + "weight", {co, ci, 3, 3}) || !require(e, p + "bias", {co})) return WS_ERR_INVALID;
+      if ((rc = dp_keep(e, p + "pack", dp_pack3x3(dp_conv_rows(e->host(p + "weight"), co, ci, ci), ci, co))) != WS_OK) return rc;
+    }
+  for (const DpConv& c : kDpEnc) {
+    const std::string p = std::string(c.prefix) + "conv2d.";
+    if (!require(e, p + "weight", {c.cout, c.cin, 3, 3}) || !require(e, p + "bias", {c.cout})) return WS_ERR_INVALID;
+    if ((rc = dp_keep(e, p + "rows", dp_conv_rows(e->host(p + "weight"), c.cout, c.cin, c.cin))) != WS_OK) return rc;
+  }
+  for (const DpConv& c : kDpDec) {
+    const std::string p = std::string(c.prefix) + "convtrans2d.";
+    if (!require(e, p + "weight", {c.cin, c.cout, 3, 3}) || !require(e, p + "bias", {c.cout})) return WS_ERR_INVALID;
+    if ((rc = dp_keep(e, p + "rows", dp_convT_rows(e->host(p + "weight"), c.cin, c.cout, c.cout))) != WS_OK) return rc;
+  }
+  {
+    std::vector<float> w_in = dp_conv_rows(e->host("conv2d.weight"), 16, 2, 4);            // (re, im, 0, 0) pixels
+    std::vector<float> w_out = dp_convT_rows(e->host("deconv2d.weight"), 32, 2, 4), b_out(4, 0.f);
+    b_out[0] = e->host("deconv2d.bias")[0], b_out[1] = e->host("deconv2d.bias")[1];
+    e->dp_w_in = upload(e, e->persist, w_in.data(), w_in.size());
+    e->dp_w_out = upload(e, e->persist, w_out.data(), w_out.size());
+    e->dp_b_out = upload(e, e->persist, b_out.data(), b_out.size());
+    WS_PTR(e->dp_w_in && e->dp_w_out && e->dp_b_out);
+  }
+  // ---- DFT bases (functional_dpccn._dft_tables: periodic hann window, float64 then rounded) ----
+  {
+    const int n = kDpWin, nf = kDpBins;
+    std::vector<float> ana(size_t(kDpLd) * n, 0.f), syn(size_t(n) * kDpLd, 0.f);
+    const double pi = 3.14159265358979323846;
+    for (int f = 0; f < nf; ++f) {
+      const double ck = (f == 0 || f == nf - 1) ? 1.0 : 2.0;
+      for (int k = 0; k < n; ++k) {
+        const double win = 0.5 - 0.5 * cos(2.0 * pi * k / n), ang = 2.0 * pi * double(f) * k / n;
+        ana[size_t(4 * f) * n + k] = static_cast<float>(cos(ang) * win);
+        ana[size_t(4 * f + 1) * n + k] = static_cast<float>(-sin(ang) * win);
+        syn[size_t(k) * kDpLd + 4 * f] = static_cast<float>(ck * cos(ang) / n * win);
+        if (f != 0 && f != nf - 1) syn[size_t(k) * kDpLd + 4 * f + 1] = static_cast<float>(-(ck * sin(ang)) / n * win);
+      }
+    }
+    e->dp_ana4 = upload(e, e->persist, ana.data(), ana.size());
+    e->dp_syn4 = upload(e, e->persist, syn.data(), syn.size());
+    WS_PTR(e->dp_ana4 && e->dp_syn4);
+  }
+  {
+    std::vector<float> ones(384, 1.f), zeros(384, 0.f);
+    e->dp_ones = upload(e, e->persist, ones.data(), ones.size());
+    e->dp_zeros = upload(e, e->persist, zeros.data(), zeros.size());
+    WS_PTR(e->dp_ones && e->dp_zeros);
+  }
+  if (e->use_xform) {
+    const Tensor* t0 = e->find("spk_transform.transforms.0.weight");
+    if (!t0 || t0->dims.size() < 2 || t0->dims[1] != e->E || !e->find("spk_transform.transforms.1.weight") ||
+        !e->find("spk_transform.transforms.3.weight")) {
+      set_err("engine: spk_transform tensors missing or mis-shaped");
+      return WS_ERR_INVALID;
+    }
+  }
+  if (e->joint) {
+    if ((rc = e->spk_kind == 1 ? prep_ecapa(e) : prep_resnet(e)) != WS_OK) return rc;
+    if ((rc = e->spk_feat ? prep_fbank(e) : prep_mel_frontend(e)) != WS_OK) return rc;
+  }
+  if (!e->dry && hipStreamSynchronize(e->stream) != hipSuccess) {
+    set_err("engine: weight preparation failed on the device");
+    return WS_ERR_LAUNCH;
+  }
+  return WS_OK;
+}
+
+// y (rows of stride ldy) = IN(ELU(x)) or ELU(IN(x)) over the P positions of each of G rows, x dense [G*P][C]
+int dp_in_act(ws_engine* e, const float* x, int G, long long P, int C, int flags, float* y, long long ldy) {
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  int nsplit = static_cast<int>(P / 32);
+  const int cap = 1024 / G > 1 ? 1024 / G : 1;
+  if (nsplit > cap) nsplit = cap;
+  if (nsplit < 1) nsplit = 1;
+  const long long cnt = (long long)G * 2 * C;
+  float* slab = a.alloc(size_t(nsplit) * cnt);
+  float* sums = a.alloc(size_t(cnt));
+  float* stats = a.alloc(size_t(cnt));
+  WS_PTR(slab && sums && stats);
+  WS_RUN(e, ws_in_act_sums(x, nullptr, 0, nullptr, static_cast<int>(P), G, nsplit, C, flags, slab, s));
+  WS_RUN(e, ws_reduce_slabs(slab, nsplit, cnt, cnt, sums, 0, 0, s));
+  WS_RUN(e, ws_inorm_finalize(sums, G, C, P, kInEps, stats, s));
+  WS_RUN(e, ws_in_act_apply(x, stats, (long long)G * P, static_cast<int>(P), C, flags, y, ldy, s));
+  a.release(mk);
+  return WS_OK;
+}
+
+// y[M][Cout] (row stride ldy) = 3 x 3 / padding 1 convolution of the image x [R][H][W][Cin] with stride (1, sw)
+// (mode 0: Conv2d, W [Cout][9 Cin]) or its transposed counterpart (mode 1: ConvTranspose2d, output grid [H][Wo])
+int dp_conv_view(ws_engine* e, const float* x, int R, int H, int W, int Cin, int mode, int Wo, int sw, const float* Wm, int Cout,
+                 const float* bias, float* y, long long ldy) {
+  ws_gemm_nt_args g = {};
+  g.A = x, g.W = Wm, g.bias = bias, g.C = y;
+  g.a_div = kBig, g.a_s2 = 9 * Cin, g.c_div = kBig, g.c_s2 = ldy, g.st_div1 = 1, g.st_div2 = 1;
+  g.M = R * H * Wo, g.N = Cout, g.K = 9 * Cin, g.ldw = 9 * Cin, g.vec = 3 | 4;
+  g.conv.on = 1, g.conv.mode = mode, g.conv.H = H, g.conv.W = W, g.conv.C = Cin, g.conv.Ho = H, g.conv.Wo = Wo;
+  g.conv.k = 3, g.conv.sh = 1, g.conv.sw = sw, g.conv.p = 1, g.conv.dil = 1;
+  WS_RUN(e, ws_gemm_nt(&g, e->stream));
+  return WS_OK;
+}
+
+// C[M][N] (row stride ldc) = A[M][K] W[N][K]^T + bias (+ Rm, addressed like C): the 1 x 1 convolutions
+int dp_gemm(ws_engine* e, const float* A, long long M, int K, const float* Wm, int N, const float* bias, const float* Rm, float* C,
+            long long ldc) {
+  ws_gemm_nt_args g = {};
+  g.A = A, g.W = Wm, g.bias = bias, g.C = C, g.R = Rm;
+  g.a_div = kBig, g.a_s2 = K, g.c_div = kBig, g.c_s2 = ldc, g.st_div1 = 1, g.st_div2 = 1;
+  g.M = static_cast<int>(M), g.N = N, g.K = K, g.ldw = K, g.vec = vec_bits({K});
+  WS_RUN(e, ws_gemm_nt(&g, e->stream));
+  return WS_OK;
+}
+
+// DenseBlock (convs.py:80-112): big [M][C0 + 4g] holds the input in its first C0 columns; out [M][co5]
+int dp_dense(ws_engine* e, const DpDense& d, int R, int H, int W, float* big, float* out) {
+  const long long M = (long long)R * H * W;
+  const int Ctot = d.C0 + 4 * d.g;
+  Arena& a = e->work;
+  for (int i = 0; i < 5; ++i) {
+    const int ci = d.C0 + i * d.g, co = i < 4 ? d.g : d.co5;
+    const std::string p = std::string(d.prefix) + "conv" + std::to_string(i + 1) + ".conv2d.";
+    const Arena::Mark mk = a.mark();
+    float* pre = a.alloc(size_t(M) * co);
+    WS_PTR(pre);
+    ws_conv3x3_args c = {};
+    c.X = big, c.W = e->dp_w[p + "pack"], c.bias = e->dev(p + "bias"), c.Y = pre;
+    c.ldx = Ctot, c.ldw = 9 * ci, c.ldy = co, c.B = R, c.H = H, c.Wd = W, c.Cin = ci, c.Cout = co;
+    WS_RUN(e, ws_conv3x3(&c, e->stream));
+    int rc;
+    if (i < 4)
+      rc = dp_in_act(e, pre, R, (long long)H * W, co, kInPre, big + ci, Ctot);
+    else
+      rc = dp_in_act(e, pre, R, (long long)H * W, co, kInPre, out, co);
+    if (rc != WS_OK) return rc;
+    a.release(mk);
+  }
+  return WS_OK;
+}
+
+// Conv2dBlock with stride (1, 2) (convs.py:28-50): y [R*H*Wo][cout] = IN(ELU(conv(x)))
+int dp_conv_block(ws_engine* e, const DpConv& c, const float* x, int R, int H, int W, float* y, long long ldy) {
+  const int Wo = (W - 1) / 2 + 1;
+  const long long M = (long long)R * H * Wo;
+  const std::string p = std::string(c.prefix) + "conv2d.";
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  float* pre = a.alloc(size_t(M) * c.cout);
+  WS_PTR(pre);
+  int rc = dp_conv_view(e, x, R, H, W, c.cin, 0, Wo, 2, e->dp_w[p + "rows"], c.cout, e->dev(p + "bias"), pre, c.cout);
+  if (rc != WS_OK) return rc;
+  if ((rc = dp_in_act(e, pre, R, (long long)H * Wo, c.cout, kInPre, y, ldy)) != WS_OK) return rc;
+  a.release(mk);
+  return WS_OK;
+}
+
+// ConvTrans2dBlock with stride (1, 2) (convs.py:53-77): y [R*H*(2W - 1)][cout] = IN(ELU(conv_transpose(x)))
+int dp_convT_block(ws_engine* e, const DpConv& c, const float* x, int R, int H, int W, float* y, long long ldy) {
+  const int Wt = 2 * W - 1;
+  const long long M = (long long)R * H * Wt;
+  const std::string p = std::string(c.prefix) + "convtrans2d.";
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  float* pre = a.alloc(size_t(M) * c.cout);
+  WS_PTR(pre);
+  int rc = dp_conv_view(e, x, R, H, W, c.cin, 1, Wt, 2, e->dp_w[p + "rows"], c.cout, e->dev(p + "bias"), pre, c.cout);
+  if (rc != WS_OK) return rc;
+  if ((rc = dp_in_act(e, pre, R, (long long)H * Wt, c.cout, kInPre, y, ldy)) != WS_OK) return rc;
+  a.release(mk);
+  return WS_OK;
+}
+
+// TCNBlock (convs.py:115-152) on [R][L][384]: out = x + conv1x1(ELU(IN(dwconv(ELU(IN(x))))))
+int dp_tcn_block(ws_engine* e, const std::string& p, int dil, const float* x, int R, long long L, const float* ident, float* out) {
+  const int C = 384;
+  const long long M = (long long)R * L;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  float* y1 = a.alloc(size_t(M) * C);
+  float* y2 = a.alloc(size_t(M) * C);
+  WS_PTR(y1 && y2);
+  int rc = dp_in_act(e, x, R, L, C, kInPost, y1, C);
+  if (rc != WS_OK) return rc;
+  WS_RUN(e, ws_dwconv_ex_fwd(y1, ident, e->dp_ones, e->dp_zeros, e->dev(p + "dconv1.weight"), e->dev(p + "dconv1.bias"), R,
+                             static_cast<int>(L), C, 3, dil, static_cast<int>(L), e->dp_causal, y2, e->stream));
+  if ((rc = dp_in_act(e, y2, R, L, C, kInPost, y1, C)) != WS_OK) return rc;
+  if ((rc = dp_gemm(e, y1, M, C, e->dev(p + "dconv2.weight"), C, e->dev(p + "dconv2.bias"), x, out, C)) != WS_OK) return rc;
+  a.release(mk);
+  return WS_OK;
+}
+
+// wav [R][T], emb [R][E] -> est [R][T]
+int dpccn_device(ws_engine* e, const float* wav, int R, int T, const float* emb_in, float* est) {
+  const int n = kDpWin, hop = kHop, pad = n / 2, Tf = 1 + T / hop, F0 = kDpBins;
+  void* s = e->stream;
+  Arena& a = e->work;
+  int rc;
+  const long long M0 = (long long)R * Tf * F0;
+  // ---- STFT (torch.stft, hann, centre, reflect): frames of the padded rows x the analysis basis ----
+  const int ldo = (T + 2 * pad + 3) / 4 * 4;
+  float* xp = a.alloc(size_t(R) * ldo);
+  float* spec4 = a.alloc(size_t(R) * Tf * kDpLd);      // == [M0][4]: (re, im, 0, 0) per (row, frame, bin)
+  WS_PTR(xp && spec4);
+  if ((rc = zero_device(e, xp, size_t(R) * ldo * 4)) != WS_OK) return rc;
+  WS_RUN(e, ws_preemph_pad(wav, R, T, pad, ldo, 0.0f, xp, s));
+  {
+    ws_gemm_nt_args g = {};
+    g.A = xp, g.W = e->dp_ana4, g.C = spec4;
+    g.a_div = Tf, g.a_s1 = ldo, g.a_s2 = hop, g.c_div = kBig, g.c_s2 = kDpLd, g.st_div1 = 1, g.st_div2 = 1;
+    g.M = R * Tf, g.N = kDpLd, g.K = n, g.ldw = n, g.vec = 3;           // exact fp32 products, like the Python path
+    WS_RUN(e, ws_gemm_nt(&g, s));
+  }
+  // ---- Conv2d(2 -> 16) straight into the first dense block's map, then the block, then the speaker fusion ----
+  float* skip[8];
+  int skipW[8], skipC[8];
+  {
+    const DpDense& d = kDpDense[0];
+    float* big = a.alloc(size_t(M0) * (d.C0 + 4 * d.g));
+    float* o = a.alloc(size_t(M0) * d.co5);
+    skip[0] = a.alloc(size_t(M0) * d.co5);
+    WS_PTR(big && o && skip[0]);
+    if ((rc = dp_conv_view(e, spec4, R, Tf, F0, 4, 0, F0, 1, e->dp_w_in, 16, e->dev("conv2d.bias"), big, d.C0 + 4 * d.g)) != WS_OK)
+      return rc;
+    if ((rc = dp_dense(e, d, R, Tf, F0, big, o)) != WS_OK) return rc;
+    const float* emb = emb_in;
+    if ((rc = spk_transform(e, emb, R, &emb)) != WS_OK) return rc;
+    float* sf = a.alloc(size_t(R) * F0);
+    WS_PTR(sf);
+    if (e->dp_fuse == 3) {
+      float* bt = a.alloc(size_t(R) * F0);
+      float* tmp = a.alloc(size_t(M0) * d.co5);
+      WS_PTR(bt && tmp);
+      if ((rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.gamma_fcs.0.weight"), e->E, F0, e->dp_w["film_gamma_bias1"], 0, sf)) != WS_OK ||
+          (rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.beta_fcs.0.weight"), e->E, F0, e->dev("spk_fuse.fc.beta_fcs.0.bias"), 0, bt)) != WS_OK)
+        return rc;
+      WS_RUN(e, ws_scale_bf_fwd(o, sf, R, Tf, F0, d.co5, 0, tmp, s));
+      WS_RUN(e, ws_scale_bf_fwd(tmp, bt, R, Tf, F0, d.co5, 1, skip[0], s));
+    } else {
+      if ((rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.linear.weight"), e->E, F0, e->dev("spk_fuse.fc.linear.bias"), 0, sf)) != WS_OK)
+        return rc;
+      WS_RUN(e, ws_scale_bf_fwd(o, sf, R, Tf, F0, d.co5, e->dp_fuse == 2 ? 0 : 1, skip[0], s));
+    }
+    skipW[0] = F0, skipC[0] = d.co5;
+  }
+  // ---- encoder: four (strided conv, dense block) stages, three strided convs ----
+  for (int i = 0; i < 7; ++i) {
+    const DpConv& c = kDpEnc[i];
+    const int Wi = skipW[i], Wo = (Wi - 1) / 2 + 1;
+    const long long M = (long long)R * Tf * Wo;
+    if (i < 4) {
+      const DpDense& d = kDpDense[1 + i];
+      float* big = a.alloc(size_t(M) * (d.C0 + 4 * d.g));
+      skip[i + 1] = a.alloc(size_t(M) * d.co5);
+      WS_PTR(big && skip[i + 1]);
+      if ((rc = dp_conv_block(e, c, skip[i], R, Tf, Wi, big, d.C0 + 4 * d.g)) != WS_OK) return rc;
+      if ((rc = dp_dense(e, d, R, Tf, Wo, big, skip[i + 1])) != WS_OK) return rc;
+      skipC[i + 1] = d.co5;
+    } else {
+      skip[i + 1] = a.alloc(size_t(M) * c.cout);
+      WS_PTR(skip[i + 1]);
+      if ((rc = dp_conv_block(e, c, skip[i], R, Tf, Wi, skip[i + 1], c.cout)) != WS_OK) return rc;
+      skipC[i + 1] = c.cout;
+    }
+    skipW[i + 1] = Wo;
+  }
+  // ---- TCN stack on rows of L = Tf * W positions ----
+  const int W7 = skipW[7];
+  const long long L = (long long)Tf * W7;
+  float* tA = a.alloc(size_t(R) * L * 384);
+  float* tB = a.alloc(size_t(R) * L * 384);
+  float* ident = nullptr;
+  {
+    std::vector<float> id(size_t(R) * 2);
+    for (int r = 0; r < R; ++r) id[2 * r] = 0.f, id[2 * r + 1] = 1.f;
+    ident = upload(e, a, id.data(), id.size());
+  }
+  WS_PTR(tA && tB && ident);
+  const float* cur = skip[7];
+  float* nxt = tA;
+  for (int l = 0; l < e->dp_tcn_layers; ++l)
+    for (int b = 0; b < e->dp_tcn_blocks; ++b) {
+      const std::string p = "tcn_layers." + std::to_string(l) + "." + std::to_string(b) + ".";
+      if ((rc = dp_tcn_block(e, p, 1 << b, cur, R, L, ident, nxt)) != WS_OK) return rc;
+      cur = nxt;
+      nxt = nxt == tA ? tB : tA;
+    }
+  // ---- decoder: cat[skip, out] -> (dense block ->) transposed conv ----
+  const float* out = cur;
+  int Wc = W7, Cc = 384;
+  for (int i = 0; i < 7; ++i) {
+    const DpConv& c = kDpDec[i];
+    const float* sk = skip[7 - i];
+    const int Cs = skipC[7 - i];
+    const long long M = (long long)R * Tf * Wc;
+    const int Wt = 2 * Wc - 1;
+    float* y = a.alloc(size_t(R) * Tf * Wt * c.cout);
+    WS_PTR(y);
+    if (i < 3) {
+      float* cat = a.alloc(size_t(M) * (Cs + Cc));
+      WS_PTR(cat);
+      if ((rc = copy_cols(e, cat, Cs + Cc, sk, Cs, Cs, M)) != WS_OK || (rc = copy_cols(e, cat + Cs, Cs + Cc, out, Cc, Cc, M)) != WS_OK)
+        return rc;
+      if ((rc = dp_convT_block(e, c, cat, R, Tf, Wc, y, c.cout)) != WS_OK) return rc;
+    } else {
+      const DpDense& d = kDpDense[5 + (i - 3)];
+      const int Ctot = d.C0 + 4 * d.g;
+      float* big = a.alloc(size_t(M) * Ctot);
+      float* o = a.alloc(size_t(M) * d.co5);
+      WS_PTR(big && o);
+      if ((rc = copy_cols(e, big, Ctot, sk, Cs, Cs, M)) != WS_OK || (rc = copy_cols(e, big + Cs, Ctot, out, Cc, Cc, M)) != WS_OK)
+        return rc;
+      if ((rc = dp_dense(e, d, R, Tf, Wc, big, o)) != WS_OK) return rc;
+      if ((rc = dp_convT_block(e, c, o, R, Tf, Wc, y, c.cout)) != WS_OK) return rc;
+    }
+    out = y, Wc = Wt, Cc = c.cout;
+  }
+  if (Wc != F0) {
+    set_err("engine: DPCCN decoder grid %d does not match the spectrogram's %d bins", Wc, F0);
+    return WS_ERR_LAUNCH;
+  }
+  // ---- last dense block on cat[skip0, out], pooling branches, projection, ConvTranspose2d(32 -> 2) ----
+  float* cat64 = a.alloc(size_t(M0) * 64);
+  float* feat = a.alloc(size_t(M0) * 32);
+  WS_PTR(cat64 && feat);
+  {
+    const DpDense& d = kDpDense[9];
+    const int Ctot = d.C0 + 4 * d.g;
+    float* big = a.alloc(size_t(M0) * Ctot);
+    WS_PTR(big);
+    if ((rc = copy_cols(e, big, Ctot, skip[0], skipC[0], skipC[0], M0)) != WS_OK ||
+        (rc = copy_cols(e, big + skipC[0], Ctot, out, Cc, Cc, M0)) != WS_OK)
+      return rc;
+    if ((rc = dp_dense(e, d, R, Tf, F0, big, feat)) != WS_OK) return rc;
+  }
+  if ((rc = copy_cols(e, cat64, 64, feat, 32, 32, M0)) != WS_OK) return rc;
+  const int pool[4] = {4, 8, 16, 32};
+  for (int i = 0; i < 4; ++i) {
+    const int sz = pool[i], h = Tf / sz, w = F0 / sz;
+    const std::string p = "avg_pool." + std::to_string(i) + ".1.";
+    const Arena::Mark mk = a.mark();
+    float* av = a.alloc(size_t(R) * h * w * 32);
+    float* pc = a.alloc(size_t(R) * h * w * 8);
+    float* up = a.alloc(size_t(M0) * 8);
+    WS_PTR(av && pc && up);
+    WS_RUN(e, ws_avgpool_fwd(feat, R, Tf, F0, 32, sz, av, s));
+    if ((rc = dp_gemm(e, av, (long long)R * h * w, 32, e->dev(p + "weight"), 8, e->dev(p + "bias"), nullptr, pc, 8)) != WS_OK) return rc;
+    WS_RUN(e, ws_bilinear_fwd(pc, R, h, w, Tf, F0, 8, up, s));
+    if ((rc = copy_cols(e, cat64 + 32 + 8 * i, 64, up, 8, 8, M0)) != WS_OK) return rc;
+    a.release(mk);
+  }
+  float* proj = a.alloc(size_t(M0) * 32);
+  float* est4 = a.alloc(size_t(M0) * 4);               // == [R * Tf][1028]
+  WS_PTR(proj && est4);
+  if ((rc = dp_gemm(e, cat64, M0, 64, e->dev("avg_proj.weight"), 32, e->dev("avg_proj.bias"), nullptr, proj, 32)) != WS_OK) return rc;
+  if ((rc = dp_conv_view(e, proj, R, Tf, F0, 32, 1, F0, 1, e->dp_w_out, 4, e->dp_b_out, est4, 4)) != WS_OK) return rc;
+  // ---- inverse STFT (torch.istft, hann, centre, length = T): synthesis GEMM, overlap-add, 1 / window envelope ----
+  {
+    const int full = pad + T, ld = (T + 3) / 4 * 4;
+    float* fr = a.alloc(size_t(R) * Tf * n);
+    float* y = a.alloc(size_t(R) * full);
+    float* o = a.alloc(size_t(R) * ld);
+    WS_PTR(fr && y && o);
+    ws_gemm_nt_args g = {};
+    g.A = est4, g.W = e->dp_syn4, g.C = fr;
+    g.a_div = kBig, g.a_s2 = kDpLd, g.c_div = kBig, g.c_s2 = n, g.st_div1 = 1, g.st_div2 = 1;
+    g.M = R * Tf, g.N = n, g.K = kDpLd, g.ldw = kDpLd, g.vec = 3;
+    WS_RUN(e, ws_gemm_nt(&g, s));
+    WS_RUN(e, ws_ola_fwd(fr, nullptr, R, Tf, n, hop, full, y, s));
+    std::vector<double> env(size_t(Tf - 1) * hop + n, 0.0);
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k < n; ++k) {
+      const float wf = static_cast<float>(0.5 - 0.5 * cos(2.0 * pi * k / n));
+      const double w2 = double(wf) * double(wf);
+      for (int t = 0; t < Tf; ++t) env[size_t(t) * hop + k] += w2;
+    }
+    std::vector<float> inv(ld, 0.f);
+    for (int i = 0; i < T; ++i) inv[i] = static_cast<float>(1.0 / env[size_t(pad) + i]);
+    float* dinv = upload(e, a, inv.data(), inv.size());
+    WS_PTR(dinv);
+    if ((rc = zero_device(e, o, size_t(R) * ld * 4)) != WS_OK) return rc;
+    if ((rc = copy_cols(e, o, ld, y + pad, full, T, R)) != WS_OK) return rc;
+    WS_RUN(e, ws_affine_fwd(o, dinv, nullptr, 0.0f, R, R, ld, o, s));
+    if ((rc = copy_cols(e, est, T, o, ld, T, R)) != WS_OK) return rc;
+  }
+  return WS_OK;
+}
+
 int check_engine(const ws_engine* e, const char* who) {
   if (!e) {
     set_err("%s: null engine", who);
@@ -2059,6 +2623,11 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
     set_err("ws_engine_separate: bad arguments (R=%d, T=%d; T >= 512)", R, T);
     return WS_ERR_INVALID;
   }
+  if (e->arch == 2 && (T < 31 * kHop || (long long)R * (1 + T / kHop) * kDpBins * 160 > 0x7fffffffLL)) {
+    set_err("ws_engine_separate: a DPCCN engine needs T >= %d samples (32 frames for the AvgPool2d(32) branch) and "
+            "R * frames * 257 * 160 below 2^31 (R=%d, T=%d)", 31 * kHop, R, T);
+    return WS_ERR_INVALID;
+  }
   if ((enroll_kind == WS_ENROLL_EMBEDDING) == (e->joint != 0) || enroll_kind < 0 || enroll_kind > WS_ENROLL_WAVE) {
     set_err("ws_engine_separate: enrollment kind %d does not fit this model (joint_training = %d)", enroll_kind, e->joint);
     return WS_ERR_INVALID;
@@ -2122,7 +2691,7 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
     if ((rc = e->spk_kind == 1 ? ecapa_embed(e, fb, R, Te, d_emb) : resnet_embed(e, fb, R, Te, d_emb)) != WS_OK) return rc;
     a.release(mk);
   }
-  if ((rc = separate_device(e, d_mix, R, T, d_emb, d_est)) != WS_OK) return rc;
+  if ((rc = e->arch == 2 ? dpccn_device(e, d_mix, R, T, d_emb, d_est) : separate_device(e, d_mix, R, T, d_emb, d_est)) != WS_OK) return rc;
   if ((rc = to_host(e, est, d_est, size_t(R) * T * 4)) != WS_OK) return rc;
   if (e->cl_status && !e->dry) {   // did a cluster recurrence time out (and the predicated streaming pair repair it)?
     unsigned st = 0;

@@ -225,8 +225,8 @@ def test_infer_extract_engine_rank_dispatch(tmp_path):
 
 def test_export_refuses_models_the_runtime_does_not_run():
     from wesep_amd.models import get_model
-    with pytest.raises(NotImplementedError, match="not DPCCN"):
-        export_engine(get_model("DPCCN")(joint_training=False), "/dev/null")
+    with pytest.raises(NotImplementedError, match="not TFGridNet"):
+        export_engine(get_model("TFGridNet")(joint_training=False, n_layers=1), "/dev/null")
     for kw, what in ((dict(norm="cLN"), "gLN only"), (dict(causal=True), "causal"), (dict(skip_con=True), "skip"),
                      (dict(spk_fuse_type="FiLM"), "concatConv only"),
                      (dict(encoder_type="Deep", decoder_type="Deep"), "Multi only")):
@@ -269,6 +269,50 @@ def test_dry_run_launch_plan_convtasnet(tmp_path, joint):
         with pytest.raises(E.WesepHipError, match="too short"):
             eng.separate(np.zeros((2, 4000), np.float32), np.zeros((2, 200), np.float32), E.ENROLL_WAVE)
     eng.close()
+
+
+@needs_no_gpu
+@pytest.mark.parametrize("variant", ["fixed-multiply", "fixed-film-causal", "joint-resnet18-additive"])
+def test_dry_run_launch_plan_dpccn(tmp_path, variant):
+    """DPCCN in the native runtime (arch 2): container, geometry read back, and the whole launch plan -- DFT-basis STFT,
+    halo-tile dense blocks, strided / transposed implicit-GEMM convolutions, fused ELU + InstanceNorm, the TCN stack, the
+    pooling branches, inverse STFT -- through the real library's argument validation for several lengths and row counts."""
+    from wesep_amd.models import get_model
+    kw = dict(tcn_blocks=3, tcn_layers=2, spk_emb_dim=256, joint_training=False)
+    if variant == "fixed-film-causal":
+        kw.update(spk_fuse_type="FiLM", causal=True, use_spk_transform=True)
+    elif variant == "joint-resnet18-additive":
+        kw.update(spk_fuse_type="additive", joint_training=True, spk_model="ResNet18", spk_feat=True,
+                  spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
+    m = get_model("DPCCN")(**kw)
+    path = str(tmp_path / "d.wsw")
+    n, _ = export_engine(m, path)
+    assert n == sum(1 for k, v in m.state_dict().items() if torch.is_floating_point(v) and not k.startswith("pred_linear.")
+                    and not k.endswith("num_batches_tracked"))
+    eng = E.Engine(path, dry_run=True)
+    assert eng.info("arch") == 2 and eng.info("tcn_blocks") == 3 and eng.info("tcn_layers") == 2
+    assert eng.info("causal") == int(variant == "fixed-film-causal") and eng.info("joint_training") == int(kw["joint_training"])
+    counts = set()
+    for R, T in ((2, 16000), (1, 12345), (3, 4000)):
+        if kw["joint_training"]:
+            enroll, kind = np.zeros((R, 150, 80), np.float32), E.ENROLL_FBANK
+        else:
+            enroll, kind = np.zeros((R, 256), np.float32), E.ENROLL_EMBEDDING
+        est = eng.separate(np.ones((R, T), np.float32), enroll, kind)
+        assert est.shape == (R, T) and not est.any()
+        counts.add(eng.info("n_launches"))
+        assert eng.info("arena_bytes") > 0
+    assert len(counts) == (3 if kw["joint_training"] else 1)      # the ResNet front-end transposes one row per launch
+    with pytest.raises(E.WesepHipError, match="32 frames"):
+        eng.separate(np.zeros((2, 3000), np.float32), enroll[:2], kind)
+    eng.close()
+
+
+def test_dpccn_concat_fusion_is_refused_by_the_exporter(tmp_path):
+    from wesep_amd.models import get_model
+    m = get_model("DPCCN")(tcn_blocks=1, tcn_layers=1, joint_training=False, spk_fuse_type="concat")
+    with pytest.raises(NotImplementedError, match="concat"):
+        export_engine(m, str(tmp_path / "c.wsw"))
 
 
 def _write_wav(path, x, sr=16000):

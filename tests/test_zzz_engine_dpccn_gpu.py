@@ -1,0 +1,60 @@
+"""GPU: the native runtime's DPCCN launch plan (runtime/engine.cc, arch 2) against the Python module tree in eval mode on
+the same device.  The plan's first execution was a Python-free run of `runtime/separate_main` with the round's last GPU
+seconds (profiles/r03_engine_dpccn_hw_check.json: joint ResNet18 + multiply fusion, 2.2e-5 from the CPU oracle chain);
+this comparison -- which also covers fixed embeddings, FiLM fusion with SpeakerTransform and causal TCN blocks, whose
+plans have been through the dry run only (tests/test_engine_cpu.py) -- has not run on hardware yet: the file sorts last so
+that its first run cannot hide any other test behind the driver's `-x`."""
+import numpy as np
+import pytest
+import torch
+
+from wesep_amd import engine as E
+from wesep_amd.bin.export_engine import export_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant", ["joint-resnet18-multiply", "fixed-additive", "fixed-film-causal"])
+def test_dpccn_engine_matches_python_model(tmp_path, variant):
+    from tests.test_engine_gpu import _cuda, rel
+    from wesep_amd.models import get_model
+    d = _cuda()
+    torch.manual_seed(31)
+    kw = dict(tcn_blocks=3, tcn_layers=2, spk_emb_dim=256, joint_training=False)
+    if variant == "fixed-additive":
+        kw.update(spk_fuse_type="additive")
+    elif variant == "fixed-film-causal":
+        kw.update(spk_fuse_type="FiLM", causal=True, use_spk_transform=True)
+    else:
+        kw.update(joint_training=True, spk_model="ResNet18", spk_feat=True,
+                  spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
+    model = get_model("DPCCN")(**kw)
+    with torch.no_grad():                                   # FiLM layers start at zero; BatchNorm statistics at (0, 1)
+        for name, p in model.named_parameters():
+            if "gamma_fcs" in name or "beta_fcs" in name:
+                p.normal_(0.0, 0.05)
+        for name, buf in model.named_buffers():
+            if name.endswith("running_mean"):
+                buf.normal_(0.0, 0.2)
+            elif name.endswith("running_var"):
+                buf.uniform_(0.5, 1.5)
+    path = str(tmp_path / "d.wsw")
+    export_engine(model, path)
+    eng = E.Engine(path)
+    assert eng.info("arch") == 2
+    model = model.to(d).eval()
+    g = torch.Generator().manual_seed(4)
+    for R, T in ((2, 16000), (1, 12345), (3, 4100)):
+        wav = 0.1 * torch.randn(R, T, generator=g)
+        if kw["joint_training"]:
+            enroll = torch.randn(R, 120 + 7 * R, 80, generator=g)
+            enroll, kind = enroll - enroll.mean(1, keepdim=True), E.ENROLL_FBANK
+        else:
+            enroll, kind = torch.randn(R, 256, generator=g), E.ENROLL_EMBEDDING
+        est = eng.separate(wav.numpy(), enroll.numpy(), kind)
+        with torch.no_grad():
+            ref = model(wav.to(d), enroll.to(d))[0]
+        assert est.shape == (R, T) and np.isfinite(est).all()
+        assert rel(est, ref) < 1e-4, (variant, R, T, rel(est, ref))
+    assert eng.info("n_launches") > 0 and eng.info("arena_bytes") > 0
+    eng.close()

@@ -1,4 +1,4 @@
-"""Write a pBSRNN or Conv-TasNet / SpEx+ checkpoint as the flat weight container of the native runtime (include/wesep_engine.h,
+"""Write a pBSRNN, Conv-TasNet / SpEx+ or DPCCN checkpoint as the flat weight container of the native runtime (include/wesep_engine.h,
 runtime/engine.cc) -- the counterpart of the reference's `wesep/bin/export_jit.py` (TorchScript archive for the
 LibTorch runtime).
 
@@ -30,6 +30,11 @@ def engine_meta(model):
         "multi_fuse": int(sep.multi_fuse), "use_spk_transform": int(not isinstance(model.spk_transform, torch.nn.Identity)),
         "joint_training": int(model.joint_training), "feat_dim": 80, "spk_feat": 1,
     }
+    return speaker_meta(model, meta)
+
+
+def speaker_meta(model, meta):
+    """The speaker-encoder keys of the meta block (shared by the pBSRNN and DPCCN plans of the runtime)."""
     if model.joint_training:
         meta["spk_feat"] = int(bool(model.spk_feat))      # False: the in-model front-end's buffers are exported too
         spk = model.spk_model
@@ -119,15 +124,36 @@ def tasnet_meta(model):
     }
 
 
+def dpccn_meta(model):
+    """DPCCN (arch 2): the runtime's launch plan covers the reference constructor's defaults (win 512, stride 128, 257
+    bins, 3 x 3 kernels, strides (1, 1) / (1, 2)) with any TCN depth, causal or not, multiply / additive / FiLM fusion,
+    fixed embeddings or the speaker encoders the pBSRNN plan has.  `concat` fusion is refused by name."""
+    fuse = model.spk_fuse.fuse_type
+    if fuse == "concat":
+        raise NotImplementedError("export_engine: DPCCN with spk_fuse_type 'concat' (a Linear over the frequency axis) has no "
+                                  "launch plan in the native runtime; multiply / additive / FiLM do")
+    blocks = model.tcn_layers[0]
+    meta = {
+        "arch": 2, "sample_rate": 16000, "win": model.win_len, "stride": model.hop_size, "feature_dim": model.win_len // 2 + 1,
+        "tcn_layers": len(model.tcn_layers), "tcn_blocks": len(blocks), "causal": int(bool(blocks[0].causal)),
+        "spk_emb_dim": model.spk_emb_dim, "spk_fuse_type": FUSE[fuse], "multi_fuse": 0,
+        "use_spk_transform": int(not isinstance(model.spk_transform, torch.nn.Identity)),
+        "joint_training": int(model.joint_training), "feat_dim": 80, "spk_feat": 1,
+    }
+    return speaker_meta(model, meta)
+
+
 def export_engine(model, path):
-    """model: a wesep_amd (or reference) `BSRNN` / `BSRNN_Multi` / `ConvTasNet` instance -> container at `path`;
+    """model: a wesep_amd (or reference) `BSRNN` / `BSRNN_Multi` / `ConvTasNet` / `DPCCN` instance -> container at `path`;
     returns (n_tensors, n_floats)."""
     name = type(model).__name__
     if name == "ConvTasNet":
         return write_container(path, tasnet_meta(model), model.state_dict())
+    if name == "DPCCN":
+        return write_container(path, dpccn_meta(model), model.state_dict())
     if name not in ("BSRNN", "BSRNN_Multi"):
-        raise NotImplementedError("export_engine: the native runtime runs pBSRNN (BSRNN / BSRNN_Multi) and Conv-TasNet / "
-                                  f"SpEx+ checkpoints, not {name}")
+        raise NotImplementedError("export_engine: the native runtime runs pBSRNN (BSRNN / BSRNN_Multi), Conv-TasNet / "
+                                  f"SpEx+ and DPCCN checkpoints, not {name}")
     return write_container(path, engine_meta(model), model.state_dict())
 
 
