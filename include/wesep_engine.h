@@ -7,8 +7,9 @@
  * and of the whole-utterance forward of wesep/bin/infer.py:94-118.
  *
  * The reference loads a TorchScript archive; this engine loads a flat weight container written by
- * `python -m wesep_amd.bin.export_engine` (the pBSRNN `state_dict` under the reference's own key names, see
- * INTEGRATION.md) and runs the forward as a fixed launch plan over include/wesep_hip.h: weights are uploaded and
+ * `python -m wesep_amd.bin.export_engine` (the `state_dict` under the reference's own key names, see INTEGRATION.md;
+ * meta key "arch": 0 pBSRNN, 1 Conv-TasNet / SpEx+, 2 DPCCN -- ws_engine_info(e, "arch")) and runs the forward as a
+ * fixed launch plan over include/wesep_hip.h: weights are uploaded and
  * packed into MFMA fragment order ONCE at load, activations live in one grow-only device arena with stack
  * discipline, the enrollment front-end (kaldi fbank + CMN as two GEMMs, include/wesep_hip.h) and the jointly
  * trained ResNet speaker encoder (eval mode: BatchNorm folded to its running statistics) run on the device too.
