@@ -1,6 +1,7 @@
 """GPU bench of the Conv-TasNet / SpEx+ row (BASELINE.json configs[0]: batch 2 mixtures
 = 4 rows of 4 s, fixed 256-d embeddings): fwd + multi-scale SI-SDR + bwd + per-tensor clip + Adam, one JSON
-line.  `--cpu` times the oracle (CPU restatement of the reference) on the same batch beside it.
+line with `roofline` (dominant kernel class, HIP events + algorithmic bytes).  `--cpu` times the oracle (CPU restatement
+of the reference) on the same batch beside it (`cpu_baseline`).
 Not the headline metric (bench.py keeps that); results are quoted in DESIGN.md."""
 import argparse
 import json
@@ -42,20 +43,29 @@ def main():
         opt.step()
         return loss
 
+    from wesep_amd import dev, _lib as L
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_common as BC
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    dev.prof_enable(True)                     # HIP events around the library's four timed kernel classes
+    dev.alg_reset(True)                       # algorithmic bytes / flops per launch
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    dev.prof_enable(False)
+    roof = BC.roofline(dev, L, args.steps)
+    dev.alg_reset(False)
     out = {"metric": "utterances/sec (4 s, 16 kHz) fwd+bwd, Conv-TasNet SpEx+ (fixed embeddings)",
            "value": args.rows * args.steps / el, "unit": "utterances/s", "ms_per_step": el / args.steps * 1e3,
            "rows": args.rows, "steps": args.steps, "dtype": "bf16x3", "data": "synthetic",
            "final_loss_dB": float(loss.item()),
            "params_M": sum(p.numel() for p in model.parameters()) / 1e6,
-           "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
+           "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9, "roofline": roof, "cpu_baseline": None,
+           "n_gpus": 1, "higher_is_better": True}
     if args.cpu:
         from oracle import convtasnet_oracle as CT
         torch.set_num_threads(16)
