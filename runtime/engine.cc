@@ -727,6 +727,7 @@ int prep_mel_frontend(ws_engine* e) {
 
 int prepare_tasnet(ws_engine* e);
 int prepare_dpccn(ws_engine* e);
+int prepare_gridnet(ws_engine* e);
 
 // the speaker-encoder part of the container's meta block (shared by the pBSRNN and DPCCN plans)
 int read_speaker_meta(ws_engine* e) {
@@ -753,8 +754,9 @@ int prepare(ws_engine* e) {
   e->arch = static_cast<int>(meta_or(e, "arch", 0));
   if (e->arch == 1) return prepare_tasnet(e);
   if (e->arch == 2) return prepare_dpccn(e);
+  if (e->arch == 3) return prepare_gridnet(e);
   if (e->arch != 0) {
-    set_err("engine: architecture %d has no launch plan (0 pBSRNN, 1 Conv-TasNet, 2 DPCCN)", e->arch);
+    set_err("engine: architecture %d has no launch plan (0 pBSRNN, 1 Conv-TasNet, 2 DPCCN, 3 TF-GridNet)", e->arch);
     return WS_ERR_INVALID;
   }
   e->sr = static_cast<int>(meta_or(e, "sample_rate", 16000));
@@ -2497,6 +2499,484 @@ int dpccn_device(ws_engine* e, const float* wav, int R, int T, const float* emb_
   return WS_OK;
 }
 
+// =================================================================================================================
+// TF-GridNet (arch 3): the launch plan of wesep_amd/models/tfgridnet.py (wesep/models/tfgridnet.py:197-302,
+// wesep/modules/tfgridnet/gridnet_block.py:118-227) for the shipped recipe's geometry -- one microphone, one source,
+// emb_dim 128, emb_ks = emb_hs = 1, lstm_hidden_units <= 256 (zero-padded to the 256 units the recurrence kernels are
+// built for), 4 heads.  STFT / iSTFT as DFT-basis GEMMs like the DPCCN plan; Conv2d(2 -> C) + GroupNorm(1, C); per
+// block: speaker fusion, the intra-frame path (row LayerNorm, BLSTM over the bins of a frame on the blocked-layout
+// kernels of the pBSRNN plan, Linear + residual in the output GEMM), the inter-frame path (the same on a STRIDED
+// sequence map: sequence (b, q) walks the frames -- the Python path transposes the map twice instead), attention (one
+// projection GEMM for Q / K / V, ws_heads_fwd, grouped logits GEMM with the padded keys masked, row softmax, grouped
+// value GEMM, head merge, projection + PReLU + LayerNorm over (bins, channels), residual); ConvTranspose2d(C -> 2).
+// The mixture is scaled by its standard deviation on the host (tfgridnet.py:222-226), the estimate scaled back.
+// =================================================================================================================
+struct GridBlock {
+  RnnPrep intra, inter;
+  float *wqkv, *bqkv;                    // [nh*(2E + cp)][C] rows (Q heads | K heads | V heads), bias
+  float *gam[3], *bet[3];                // per projection: [nh][Q*ch], index q*ch + e
+  float *proj_g, *proj_b;                // [Q*C], index q*C + c
+};
+struct GridNet {
+  int n_fft = 128, hop = 64, Q = 65, C = 128, hid = 192, nh = 4, E = 8, layers = 6, fuse = 2;
+  float *ana4 = nullptr, *syn4 = nullptr, *w_in = nullptr, *w_out = nullptr, *b_out = nullptr;
+  float *ones_c = nullptr, *zeros_c = nullptr, *ones_qc = nullptr, *zeros_qc = nullptr;
+  float *id_st = nullptr, *slope1 = nullptr, *film_bias1 = nullptr;
+  std::vector<GridBlock> blocks;
+};
+std::map<const ws_engine*, GridNet> g_gridnets;     // plan state of the arch-3 engines (keyed by handle; erased on destroy)
+
+// nn.LSTM tensors of hidden size h -> the 256-unit layout (functional_tfgridnet.pad_lstm): gate-major rows g*256 + u
+int grid_prep_rnn(ws_engine* e, const std::string& path, int C, int h, RnnPrep* r) {
+  static const char* sfx[2] = {"", "_reverse"};
+  const std::string rnn = path + "rnn.";
+  float* dev_w[2][3];                    // per direction: w_ih [1024][C], w_hh [1024][256], b [1024]
+  for (int d = 0; d < 2; ++d) {
+    const std::string s = sfx[d];
+    if (!require(e, rnn + "weight_ih_l0" + s, {4 * h, C}) || !require(e, rnn + "weight_hh_l0" + s, {4 * h, h}) ||
+        !require(e, rnn + "bias_ih_l0" + s, {4 * h}) || !require(e, rnn + "bias_hh_l0" + s, {4 * h}))
+      return WS_ERR_INVALID;
+    const float *wi = e->host(rnn + "weight_ih_l0" + s), *wh = e->host(rnn + "weight_hh_l0" + s);
+    const float *bi = e->host(rnn + "bias_ih_l0" + s), *bh = e->host(rnn + "bias_hh_l0" + s);
+    std::vector<float> wip(size_t(kG4) * C, 0.f), whp(size_t(kG4) * kH, 0.f), bp(kG4, 0.f);
+    for (int g = 0; g < 4; ++g)
+      for (int u = 0; u < h; ++u) {
+        const size_t src = size_t(g) * h + u, dst = size_t(g) * kH + u;
+        memcpy(&wip[dst * C], wi + src * C, size_t(C) * 4);
+        memcpy(&whp[dst * kH], wh + src * h, size_t(h) * 4);
+        bp[dst] = bi[src] + bh[src];
+      }
+    dev_w[d][0] = upload(e, e->persist, wip.data(), wip.size());
+    dev_w[d][1] = upload(e, e->persist, whp.data(), whp.size());
+    dev_w[d][2] = upload(e, e->persist, bp.data(), bp.size());
+    WS_PTR(dev_w[d][0] && dev_w[d][1] && dev_w[d][2]);
+  }
+  if (!require(e, path + "norm.weight", {C}) || !require(e, path + "norm.bias", {C}) ||
+      !require(e, path + "linear.weight", {C, 2 * h}) || !require(e, path + "linear.bias", {C}))
+    return WS_ERR_INVALID;
+  // Linear(2h -> C): each half of the hidden columns zero-padded to 256 (pad_hidden_cols)
+  std::vector<float> lin(size_t(C) * 2 * kH, 0.f), zero(kG4, 0.f);
+  const float* lw = e->host(path + "linear.weight");
+  for (int n = 0; n < C; ++n) {
+    memcpy(&lin[size_t(n) * 2 * kH], lw + size_t(n) * 2 * h, size_t(h) * 4);
+    memcpy(&lin[size_t(n) * 2 * kH + kH], lw + size_t(n) * 2 * h + h, size_t(h) * 4);
+  }
+  Arena& a = e->persist;
+  float* dlin = upload(e, a, lin.data(), lin.size());
+  float* dzero = upload(e, a, zero.data(), zero.size());
+  float* wcat = a.alloc(size_t(2) * kG4 * C);
+  r->norm_w = e->dev(path + "norm.weight"), r->norm_b = e->dev(path + "norm.bias"), r->proj_b = e->dev(path + "linear.bias");
+  r->whf = dev_w[0][1], r->whr = dev_w[1][1];
+  r->bcat = a.alloc(2 * kG4);
+  r->wih_pack = a.alloc(size_t(2) * kG4 * C);
+  r->proj_pack = a.alloc(size_t(C) * 2 * kH);
+  r->fpack = a.alloc(WS_LSTM_FUSED_PACK_FLOATS);
+  r->pack16 = a.alloc(WS_LSTM_PACK_FLOATS);
+  r->pack32 = a.alloc(WS_LSTM_PACK_FLOATS);
+  float* bwd_scratch = a.alloc(WS_LSTM_PACK_FLOATS);
+  WS_PTR(dlin && dzero && wcat && r->bcat && r->wih_pack && r->proj_pack && r->fpack && r->pack16 && r->pack32 && bwd_scratch);
+  void* s = e->stream;
+  WS_RUN(e, ws_lstm_cat_ih(dev_w[0][0], dev_w[1][0], dev_w[0][2], dzero, dev_w[1][2], dzero, C, wcat, r->bcat, s));
+  WS_RUN(e, ws_pack_w(wcat, 2 * kG4, C, C, 0, 0, r->wih_pack, s));
+  WS_RUN(e, ws_pack_w(dlin, C, 2 * kH, 2 * kH, 0, 1, r->proj_pack, s));
+  WS_RUN(e, ws_lstm_pack_fused(dev_w[0][0], dev_w[1][0], r->whf, r->whr, r->fpack, s));
+  WS_RUN(e, ws_lstm_pack(r->whf, r->whr, r->pack16, bwd_scratch, WS_LSTM_BF16X3_BLK16, s));
+  WS_RUN(e, ws_lstm_pack(r->whf, r->whr, r->pack32, bwd_scratch, WS_LSTM_BF16X3_BLK, s));
+  return WS_OK;
+}
+
+int prepare_gridnet(ws_engine* e) {
+  GridNet& n = g_gridnets[e];
+  e->sr = static_cast<int>(meta_or(e, "sample_rate", 16000));
+  int rc = read_speaker_meta(e);
+  if (rc != WS_OK) return rc;
+  n.n_fft = static_cast<int>(meta_or(e, "n_fft", 128)), n.hop = static_cast<int>(meta_or(e, "stride", 64));
+  n.Q = n.n_fft / 2 + 1, n.C = static_cast<int>(meta_or(e, "emb_dim", 128)), n.hid = static_cast<int>(meta_or(e, "lstm_hidden_units", 192));
+  n.nh = static_cast<int>(meta_or(e, "attn_n_head", 4)), n.E = static_cast<int>(meta_or(e, "attn_E", 8));
+  n.layers = static_cast<int>(meta_or(e, "n_layers", 6)), n.fuse = static_cast<int>(meta_or(e, "spk_fuse_type", 2));
+  const int C = n.C, Q = n.Q, nh = n.nh, E = n.E, cp = C / (nh > 0 ? nh : 1);
+  if (meta_or(e, "emb_ks", 1) != 1 || meta_or(e, "emb_hs", 1) != 1 || meta_or(e, "n_srcs", 1) != 1 || meta_or(e, "n_imics", 1) != 1 ||
+      C != kN || n.hid < 4 || n.hid > kH || n.hid % 4 || nh < 1 || nh > 8 || C % nh || E % 4 || cp % 4 || n.n_fft % 8 ||
+      n.n_fft < 16 || n.n_fft > 1024 || n.hop * 2 != n.n_fft || (long long)Q * C > 9216 || n.fuse < 1 || n.fuse > 3 ||
+      n.layers < 1 || e->E % 4 || e->feat_dim % 8) {
+    set_err("engine: the TF-GridNet plan is built for the recipe's geometry (emb_dim 128, emb_ks = emb_hs = 1, one microphone "
+            "and source, hidden <= 256 and %% 4, heads <= 8 with widths %% 4, stride = n_fft / 2, (n_fft / 2 + 1) * 128 <= 9216, "
+            "multiply / additive / FiLM fusion)");
+    return WS_ERR_INVALID;
+  }
+  e->dw = e->persist.alloc(e->hw.size());
+  WS_PTR(e->dw);
+  if ((rc = to_device(e, e->dw, e->hw.data(), e->hw.size() * 4)) != WS_OK) return rc;
+  if (!require(e, "conv.0.weight", {C, 2, 3, 3}) || !require(e, "conv.0.bias", {C}) || !require(e, "conv.1.weight", {C}) ||
+      !require(e, "conv.1.bias", {C}) || !require(e, "deconv.weight", {C, 2, 3, 3}) || !require(e, "deconv.bias", {2}))
+    return WS_ERR_INVALID;
+  if (n.fuse == 3) {
+    if (!require(e, "spk_fuse.fc.gamma_fcs.0.weight", {Q, e->E}) || !require(e, "spk_fuse.fc.gamma_fcs.0.bias", {Q}) ||
+        !require(e, "spk_fuse.fc.beta_fcs.0.weight", {Q, e->E}) || !require(e, "spk_fuse.fc.beta_fcs.0.bias", {Q}))
+      return WS_ERR_INVALID;
+    std::vector<float> b1(e->host("spk_fuse.fc.gamma_fcs.0.bias"), e->host("spk_fuse.fc.gamma_fcs.0.bias") + Q);
+    for (float& v : b1) v += 1.0f;
+    n.film_bias1 = upload(e, e->persist, b1.data(), b1.size());
+    WS_PTR(n.film_bias1);
+  } else if (!require(e, "spk_fuse.fc.linear.weight", {Q, e->E}) || !require(e, "spk_fuse.fc.linear.bias", {Q})) {
+    return WS_ERR_INVALID;
+  }
+  {
+    std::vector<float> w_in = dp_conv_rows(e->host("conv.0.weight"), C, 2, 4);
+    std::vector<float> w_out = dp_convT_rows(e->host("deconv.weight"), C, 2, 4), b_out(4, 0.f);
+    b_out[0] = e->host("deconv.bias")[0], b_out[1] = e->host("deconv.bias")[1];
+    n.w_in = upload(e, e->persist, w_in.data(), w_in.size());
+    n.w_out = upload(e, e->persist, w_out.data(), w_out.size());
+    n.b_out = upload(e, e->persist, b_out.data(), b_out.size());
+    WS_PTR(n.w_in && n.w_out && n.b_out);
+  }
+  {   // DFT bases with (re, im, 0, 0) per bin (functional_dpccn._dft_tables)
+    const int nn = n.n_fft, ld = 4 * Q;
+    std::vector<float> ana(size_t(ld) * nn, 0.f), syn(size_t(nn) * ld, 0.f);
+    const double pi = 3.14159265358979323846;
+    for (int f = 0; f < Q; ++f) {
+      const double ck = (f == 0 || f == Q - 1) ? 1.0 : 2.0;
+      for (int k = 0; k < nn; ++k) {
+        const double win = 0.5 - 0.5 * cos(2.0 * pi * k / nn), ang = 2.0 * pi * double(f) * k / nn;
+        ana[size_t(4 * f) * nn + k] = static_cast<float>(cos(ang) * win);
+        ana[size_t(4 * f + 1) * nn + k] = static_cast<float>(-sin(ang) * win);
+        syn[size_t(k) * ld + 4 * f] = static_cast<float>(ck * cos(ang) / nn * win);
+        if (f != 0 && f != Q - 1) syn[size_t(k) * ld + 4 * f + 1] = static_cast<float>(-(ck * sin(ang)) / nn * win);
+      }
+    }
+    n.ana4 = upload(e, e->persist, ana.data(), ana.size());
+    n.syn4 = upload(e, e->persist, syn.data(), syn.size());
+    WS_PTR(n.ana4 && n.syn4);
+  }
+  {
+    std::vector<float> ones(size_t(Q) * C, 1.f), zeros(size_t(Q) * C, 0.f), id(size_t(2) * C, 0.f);
+    for (int c = 0; c < C; ++c) id[C + c] = 1.f;                        // (mean 0 | rstd 1)
+    const float one = 1.f;
+    n.ones_qc = upload(e, e->persist, ones.data(), ones.size());
+    n.zeros_qc = upload(e, e->persist, zeros.data(), zeros.size());
+    n.id_st = upload(e, e->persist, id.data(), id.size());
+    n.slope1 = upload(e, e->persist, &one, 1);
+    WS_PTR(n.ones_qc && n.zeros_qc && n.id_st && n.slope1);
+    n.ones_c = n.ones_qc, n.zeros_c = n.zeros_qc;                       // any prefix of C elements
+  }
+  n.blocks.resize(n.layers);
+  for (int l = 0; l < n.layers; ++l) {
+    GridBlock& b = n.blocks[l];
+    const std::string p = "blocks." + std::to_string(l) + ".";
+    // nn.Module names: intra_norm / intra_rnn / intra_linear -> one prefix per path
+    for (int path = 0; path < 2; ++path) {
+      const std::string q = p + (path ? "inter_" : "intra_");
+      // grid_prep_rnn reads <q>norm., <q>rnn., <q>linear.
+      if ((rc = grid_prep_rnn(e, q, C, n.hid, path ? &b.inter : &b.intra)) != WS_OK) return rc;
+    }
+    const char* proj[3] = {"attn_conv_Q.", "attn_conv_K.", "attn_conv_V."};
+    const char* norm[3] = {"attn_norm_Q.", "attn_norm_K.", "attn_norm_V."};
+    const int width[3] = {nh * E, nh * E, C}, chs[3] = {E, E, cp};
+    const int ld = 2 * nh * E + C;
+    std::vector<float> wq(size_t(ld) * C), bq(ld);
+    int row = 0;
+    for (int j = 0; j < 3; ++j) {
+      if (!require(e, p + proj[j] + "weight", {width[j], C, 1, 1}) || !require(e, p + proj[j] + "bias", {width[j]}) ||
+          !require(e, p + norm[j] + "gamma", {1, nh, chs[j], 1, Q}) || !require(e, p + norm[j] + "beta", {1, nh, chs[j], 1, Q}) ||
+          !require(e, p + norm[j] + "act.weight", {nh}))
+        return WS_ERR_INVALID;
+      memcpy(&wq[size_t(row) * C], e->host(p + proj[j] + "weight"), size_t(width[j]) * C * 4);
+      memcpy(&bq[row], e->host(p + proj[j] + "bias"), size_t(width[j]) * 4);
+      row += width[j];
+      const int ch = chs[j];
+      std::vector<float> g(size_t(nh) * Q * ch), bt(size_t(nh) * Q * ch);
+      const float *gs = e->host(p + norm[j] + "gamma"), *bs = e->host(p + norm[j] + "beta");
+      for (int h = 0; h < nh; ++h)
+        for (int ee = 0; ee < ch; ++ee)
+          for (int q = 0; q < Q; ++q) {
+            g[(size_t(h) * Q + q) * ch + ee] = gs[(size_t(h) * ch + ee) * Q + q];
+            bt[(size_t(h) * Q + q) * ch + ee] = bs[(size_t(h) * ch + ee) * Q + q];
+          }
+      b.gam[j] = upload(e, e->persist, g.data(), g.size());
+      b.bet[j] = upload(e, e->persist, bt.data(), bt.size());
+      WS_PTR(b.gam[j] && b.bet[j]);
+    }
+    b.wqkv = upload(e, e->persist, wq.data(), wq.size());
+    b.bqkv = upload(e, e->persist, bq.data(), bq.size());
+    WS_PTR(b.wqkv && b.bqkv);
+    if (!require(e, p + "attn_concat_proj.0.weight", {C, C, 1, 1}) || !require(e, p + "attn_concat_proj.0.bias", {C}) ||
+        !require(e, p + "attn_concat_proj.1.weight", {1}) || !require(e, p + "attn_concat_proj.2.gamma", {1, C, 1, Q}) ||
+        !require(e, p + "attn_concat_proj.2.beta", {1, C, 1, Q}))
+      return WS_ERR_INVALID;
+    std::vector<float> pg(size_t(Q) * C), pb(size_t(Q) * C);
+    const float *gs = e->host(p + "attn_concat_proj.2.gamma"), *bs = e->host(p + "attn_concat_proj.2.beta");
+    for (int c = 0; c < C; ++c)
+      for (int q = 0; q < Q; ++q) {
+        pg[size_t(q) * C + c] = gs[size_t(c) * Q + q];
+        pb[size_t(q) * C + c] = bs[size_t(c) * Q + q];
+      }
+    b.proj_g = upload(e, e->persist, pg.data(), pg.size());
+    b.proj_b = upload(e, e->persist, pb.data(), pb.size());
+    WS_PTR(b.proj_g && b.proj_b);
+  }
+  if (e->use_xform) {
+    const Tensor* t0 = e->find("spk_transform.transforms.0.weight");
+    if (!t0 || t0->dims.size() < 2 || t0->dims[1] != e->E || !e->find("spk_transform.transforms.1.weight") ||
+        !e->find("spk_transform.transforms.3.weight")) {
+      set_err("engine: spk_transform tensors missing or mis-shaped");
+      return WS_ERR_INVALID;
+    }
+  }
+  if (e->joint) {
+    if ((rc = e->spk_kind == 1 ? prep_ecapa(e) : prep_resnet(e)) != WS_OK) return rc;
+    if ((rc = e->spk_feat ? prep_fbank(e) : prep_mel_frontend(e)) != WS_OK) return rc;
+  }
+  if (!e->dry && hipStreamSynchronize(e->stream) != hipSuccess) {
+    set_err("engine: weight preparation failed on the device");
+    return WS_ERR_LAUNCH;
+  }
+  return WS_OK;
+}
+
+// out = res + Linear(BLSTM(xn)) on the sequences of `sm` (rows of 128 features; xn = the layer-normed rows): the body of
+// resrnn() without its GroupNorm (functional_tfgridnet.BlstmLinearBlkFn)
+int grid_rnn(ws_engine* e, const RnnPrep& w, const ws_seqmap& sm, const float* xn_rows, const float* res, float* out) {
+  const int ntile = (sm.nseq + 31) / 32;
+  const size_t nb = size_t(ntile) * sm.L;
+  const int lmode = 2 * ntile <= 128 ? WS_LSTM_BF16X3_BLK16 : WS_LSTM_BF16X3_BLK;
+  static const bool no_cluster = getenv("WS_ENGINE_NO_CLUSTER") != nullptr;
+  const bool cluster = !no_cluster && sm.nseq % 64 == 0 && (sm.nseq / 32) * 8 <= e->cu_count && sm.L >= 64;
+  const bool fused = !cluster && lmode == WS_LSTM_BF16X3_BLK;
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  float* gates = a.alloc(nb * 32 * 2 * kG4);
+  float* cbuf = a.alloc(nb * 32 * 2 * kH);
+  float* hcat = a.alloc(nb * 32 * 2 * kH);
+  float* xn = a.alloc(nb * 32 * kN);
+  WS_PTR(gates && cbuf && hcat && xn);
+  ws_gemm_p2b_args p = {};
+  p.A = xn_rows, p.sm = sm, p.lda = kN, p.K = kN, p.A_bl = xn;
+  p.st_div1 = 1, p.st_m1 = 0, p.st_div2 = 1, p.st_m2 = 0, p.st_base = 0;
+  if (fused) {
+    p.N = 0;
+    WS_RUN(e, ws_gemm_p2b(&p, s));
+    ws_lstm_fused_args f = {};
+    f.gates = gates, f.cbuf = cbuf, f.hcat = hcat, f.xn = xn, f.wpack = w.fpack, f.bias = w.bcat;
+    f.nseq = sm.nseq, f.L = sm.L;
+    WS_RUN(e, ws_lstm_fwd_fused(&f, s));
+  } else {
+    p.Wpack = w.wih_pack, p.bias = w.bcat, p.C = gates, p.N = 2 * kG4;
+    WS_RUN(e, ws_gemm_p2b(&p, s));
+    ws_lstm_args l = {};
+    l.gates = gates, l.cbuf = cbuf, l.hcat = hcat;
+    l.wpack = lmode == WS_LSTM_BF16X3_BLK16 ? w.pack16 : w.pack32;
+    l.sq_s1 = sm.sq_s1, l.sq_s2 = sm.sq_s2, l.step_rows = sm.step_rows;
+    l.nseq = sm.nseq, l.sq_div = sm.sq_div, l.L = sm.L, l.mode = lmode;
+    if (cluster) {
+      const int ncl = sm.nseq / 32;
+      float* xchg = a.alloc(size_t(ncl) * 2 * 8 * 8192 / 4);
+      unsigned* flags = reinterpret_cast<unsigned*>(a.alloc(size_t(ncl) * 8 + 8));
+      WS_PTR(xchg && flags);
+      if (!e->cl_status) {
+        e->cl_status = reinterpret_cast<unsigned*>(e->persist.alloc(2));
+        WS_PTR(e->cl_status);
+        if (zero_device(e, e->cl_status, 8) != WS_OK) return WS_ERR_LAUNCH;
+      }
+      ws_lstm_cluster_args c = {};
+      c.gates = gates, c.cbuf = cbuf, c.hcat = hcat, c.whh_f = w.whf, c.whh_r = w.whr;
+      c.xchg = xchg, c.flags = flags, c.nseq = sm.nseq, c.L = sm.L, c.status = e->cl_status;
+      WS_RUN(e, ws_lstm_fwd_cluster(&c, s));
+      p.run_if = flags + size_t(ncl) * 8;      // the streaming pair repeats the layer only after a cluster time-out
+      WS_RUN(e, ws_gemm_p2b(&p, s));
+      l.run_if = p.run_if;
+    }
+    WS_RUN(e, ws_lstm_fwd(&l, s));
+  }
+  ws_gemm_b2p_args b = {};
+  b.A = hcat, b.Wpack = w.proj_pack, b.bias = w.proj_b, b.R = res, b.C = out, b.sm = sm, b.ldc = kN, b.N = kN, b.K = 2 * kH;
+  WS_RUN(e, ws_gemm_b2p(&b, s));
+  a.release(mk);
+  return WS_OK;
+}
+
+// C[g][M][N] = A[g][M][K] W[g][N][K]^T (+ bias[N]) for G groups in one launch (functional_tfgridnet.BatchedMatmulNTFn)
+int grid_bmm(ws_engine* e, const float* A, const float* W, const float* bias, int G, int M, int K, int N, float* C) {
+  std::vector<ws_group_nt> tab(G);
+  for (int g = 0; g < G; ++g) {
+    ws_group_nt d = {};
+    d.W = W + size_t(g) * N * K, d.bias = bias, d.a_off = (long long)g * M * K, d.c_off = (long long)g * M * N;
+    d.K = K, d.N = N, d.ldw = K;
+    tab[g] = d;
+  }
+  const size_t nf = (sizeof(ws_group_nt) * G + 3) / 4;
+  ws_group_nt* dt = reinterpret_cast<ws_group_nt*>(e->work.alloc(nf));
+  WS_PTR(dt);
+  int rc = to_device(e, dt, tab.data(), sizeof(ws_group_nt) * G);
+  if (rc != WS_OK) return rc;
+  ws_gemm_nt_args g = {};
+  g.A = A, g.C = C, g.groups = dt;
+  g.a_div = kBig, g.a_s2 = K, g.c_div = kBig, g.c_s2 = N, g.st_div1 = 1, g.st_div2 = 1;
+  g.M = M, g.ngroups = G, g.max_n = N;
+  g.vec = ((K % 4 == 0 && ((long long)M * K) % 4 == 0) ? 3 : 0) | 4;
+  WS_RUN(e, ws_gemm_nt(&g, e->stream));
+  return WS_OK;
+}
+
+// wav [R][T] (already divided by its standard deviation), emb [R][E] -> est [R][T] (still in normalised units)
+int gridnet_device(ws_engine* e, const float* wav, int R, int T, const float* emb_in, float* est) {
+  const GridNet& n = g_gridnets[e];
+  const int nf = n.n_fft, hop = n.hop, pad = nf / 2, Tf = 1 + T / hop, Q = n.Q, C = n.C, nh = n.nh, E = n.E, cp = C / nh;
+  const int ld4 = 4 * Q, Tp = (Tf + 3) / 4 * 4, G = nh * R, D = Q * E, Dv = Q * cp, ldq = 2 * nh * E + C;
+  const long long M = (long long)R * Tf * Q;
+  void* s = e->stream;
+  Arena& a = e->work;
+  int rc;
+  // ---- STFT ----
+  const int ldo = (T + 2 * pad + 3) / 4 * 4;
+  float* xp = a.alloc(size_t(R) * ldo);
+  float* spec4 = a.alloc(size_t(R) * Tf * ld4);
+  float* hA = a.alloc(size_t(M) * C);
+  float* hB = a.alloc(size_t(M) * C);
+  float* hC = a.alloc(size_t(M) * C);
+  WS_PTR(xp && spec4 && hA && hB && hC);
+  if ((rc = zero_device(e, xp, size_t(R) * ldo * 4)) != WS_OK) return rc;
+  WS_RUN(e, ws_preemph_pad(wav, R, T, pad, ldo, 0.0f, xp, s));
+  {
+    ws_gemm_nt_args g = {};
+    g.A = xp, g.W = n.ana4, g.C = spec4;
+    g.a_div = Tf, g.a_s1 = ldo, g.a_s2 = hop, g.c_div = kBig, g.c_s2 = ld4, g.st_div1 = 1, g.st_div2 = 1;
+    g.M = R * Tf, g.N = ld4, g.K = nf, g.ldw = nf, g.vec = 3;
+    WS_RUN(e, ws_gemm_nt(&g, s));
+  }
+  // ---- Conv2d(2 -> C) + GroupNorm(1, C) ----
+  if ((rc = dp_conv_view(e, spec4, R, Tf, Q, 4, 0, Q, 1, n.w_in, C, e->dev("conv.0.bias"), hB, C)) != WS_OK) return rc;
+  {
+    float* st = a.alloc(size_t(R) * 2);
+    WS_PTR(st);
+    if ((rc = tas_flat_stats(e, hB, R, (long long)Tf * Q * C, st)) != WS_OK) return rc;
+    WS_RUN(e, ws_dwconv_fwd(hB, st, e->dev("conv.1.weight"), e->dev("conv.1.bias"), n.ones_c, n.zeros_c, R, Tf * Q, C, 1, 1, Tf * Q,
+                            hA, s));
+  }
+  // ---- speaker fusion operands (the same before every block) ----
+  const float* emb = emb_in;
+  if ((rc = spk_transform(e, emb, R, &emb)) != WS_OK) return rc;
+  float* sf = a.alloc(size_t(R) * Q);
+  float* bt = n.fuse == 3 ? a.alloc(size_t(R) * Q) : nullptr;
+  WS_PTR(sf && (n.fuse != 3 || bt));
+  if (n.fuse == 3) {
+    if ((rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.gamma_fcs.0.weight"), e->E, Q, n.film_bias1, 0, sf)) != WS_OK ||
+        (rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.beta_fcs.0.weight"), e->E, Q, e->dev("spk_fuse.fc.beta_fcs.0.bias"), 0, bt)) != WS_OK)
+      return rc;
+  } else if ((rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.linear.weight"), e->E, Q, e->dev("spk_fuse.fc.linear.bias"), 0, sf)) != WS_OK) {
+    return rc;
+  }
+  std::vector<float> mask_h(Tp, 0.f);
+  for (int t = Tf; t < Tp; ++t) mask_h[t] = -1e30f;
+  float* mask = upload(e, a, mask_h.data(), mask_h.size());
+  WS_PTR(mask);
+  ws_seqmap intra = {}, inter = {};
+  intra.nseq = R * Tf, intra.sq_div = kBig, intra.sq_s1 = 0, intra.sq_s2 = Q, intra.step_rows = 1, intra.L = Q;
+  inter.nseq = R * Q, inter.sq_div = Q, inter.sq_s1 = (long long)Tf * Q, inter.sq_s2 = 1, inter.step_rows = Q, inter.L = Tf;
+  float* h = hA;                          // block input / output; hB, hC rotate as scratch
+  for (int l = 0; l < n.layers; ++l) {
+    const GridBlock& b = n.blocks[l];
+    const std::string p = "blocks." + std::to_string(l) + ".";
+    const Arena::Mark mk = a.mark();
+    float* x = hB;                         // fused input
+    if (n.fuse == 3) {
+      WS_RUN(e, ws_scale_bf_fwd(h, sf, R, Tf, Q, C, 0, hC, s));
+      WS_RUN(e, ws_scale_bf_fwd(hC, bt, R, Tf, Q, C, 1, x, s));
+    } else {
+      WS_RUN(e, ws_scale_bf_fwd(h, sf, R, Tf, Q, C, n.fuse == 2 ? 0 : 1, x, s));
+    }
+    float* y = a.alloc(size_t(M) * C);
+    float* lnst = a.alloc(size_t(M) * 2);
+    WS_PTR(y && lnst);
+    // intra-frame path: x -> hC
+    WS_RUN(e, ws_rowln_fwd(x, b.intra.norm_w, b.intra.norm_b, M, C, kLnEps, y, lnst, s));
+    if ((rc = grid_rnn(e, b.intra, intra, y, x, hC)) != WS_OK) return rc;
+    // inter-frame path: hC -> x  (strided sequences: no transposes)
+    WS_RUN(e, ws_rowln_fwd(hC, b.inter.norm_w, b.inter.norm_b, M, C, kLnEps, y, lnst, s));
+    if ((rc = grid_rnn(e, b.inter, inter, y, hC, x)) != WS_OK) return rc;
+    // attention on `x` (the block's `inter` tensor)
+    float* qkv = a.alloc(size_t(M) * ldq);
+    float* Qa = a.alloc(size_t(G) * Tf * D);
+    float* Ka = a.alloc(size_t(G) * Tp * D);
+    float* Va = a.alloc(size_t(G) * Tp * Dv);
+    float* VaT = a.alloc(size_t(G) * Tp * Dv);
+    float* hst = a.alloc(size_t(nh) * R * Tf * 2);
+    float* logits = a.alloc(size_t(G) * Tf * Tp);
+    float* att = a.alloc(size_t(G) * Tf * Tp);
+    float* ov = a.alloc(size_t(G) * Tf * Dv);
+    WS_PTR(qkv && Qa && Ka && Va && VaT && hst && logits && att && ov);
+    if ((rc = dp_gemm(e, x, M, C, b.wqkv, ldq, b.bqkv, nullptr, qkv, ldq)) != WS_OK) return rc;
+    const char* norm[3] = {"attn_norm_Q.", "attn_norm_K.", "attn_norm_V."};
+    float* outs[3] = {Qa, Ka, Va};
+    const int chs[3] = {E, E, cp}, tps[3] = {Tf, Tp, Tp}, offs[3] = {0, nh * E, 2 * nh * E};
+    for (int j = 0; j < 3; ++j) {
+      ws_heads_args ha = {};
+      ha.x = qkv + offs[j], ha.slope = e->dev(p + norm[j] + "act.weight"), ha.gamma = b.gam[j], ha.beta = b.bet[j];
+      ha.y = outs[j], ha.stats = hst, ha.ldx = ldq, ha.B = R, ha.T = Tf, ha.Tp = tps[j], ha.Q = Q, ha.nh = nh, ha.ch = chs[j];
+      ha.eps = kLnEps;
+      WS_RUN(e, ws_heads_fwd(&ha, s));
+    }
+    if ((rc = grid_bmm(e, Qa, Ka, mask, G, Tf, D, Tp, logits)) != WS_OK) return rc;
+    WS_RUN(e, ws_softmax_rows_fwd(logits, (long long)G * Tf, Tp, 1.0f / sqrtf(static_cast<float>(D)), att, s));
+    for (int g = 0; g < G; ++g)
+      WS_RUN(e, ws_transpose(Va + size_t(g) * Tp * Dv, Tp, Dv, Dv, VaT + size_t(g) * Tp * Dv, s));
+    if ((rc = grid_bmm(e, att, VaT, nullptr, G, Tf, Tp, Dv, ov)) != WS_OK) return rc;
+    // head merge: ov [nh][R][Tf][Q][cp] -> [R][Tf][Q][nh*cp]
+    float* o = y;                          // y is free again
+    for (int hd = 0; hd < nh; ++hd)
+      for (int r = 0; r < R; ++r)
+        if ((rc = copy_cols(e, o + (size_t(r) * Tf * Q) * C + hd * cp, C, ov + (size_t(hd) * R + r) * Tf * Dv, cp, cp,
+                            (long long)Tf * Q)) != WS_OK)
+          return rc;
+    // projection + PReLU + LayerNorm over (bins, channels) + residual -> the next block's input
+    float* p1 = a.alloc(size_t(M) * C);
+    float* p2 = a.alloc(size_t(M) * C);
+    float* rst = a.alloc(size_t(R) * Tf * 2);
+    float* scr = a.alloc(size_t(M) * C);
+    WS_PTR(p1 && p2 && rst && scr);
+    if ((rc = dp_gemm(e, o, M, C, e->dev(p + "attn_concat_proj.0.weight"), C, e->dev(p + "attn_concat_proj.0.bias"), nullptr, p1, C)) != WS_OK)
+      return rc;
+    WS_RUN(e, ws_prelu_fwd(p1, nullptr, e->dev(p + "attn_concat_proj.1.weight"), M * C / 4, 4, static_cast<int>(M * C / 4), p2, s));
+    if ((rc = tas_row_stats(e, p2, (long long)R * Tf, Q * C, rst)) != WS_OK) return rc;
+    WS_RUN(e, ws_dwconv_fwd(p2, rst, b.proj_g, b.proj_b, n.ones_qc, n.zeros_qc, R * Tf, 1, Q * C, 1, 1, 1, p1, s));
+    WS_RUN(e, ws_bn_prelu_fwd(p1, n.id_st, n.ones_c, n.zeros_c, x, n.slope1, M, C, scr, h, s));    // h = LN(..) + inter
+    a.release(mk);
+  }
+  // ---- ConvTranspose2d(C -> 2) and the inverse STFT ----
+  float* est4 = a.alloc(size_t(M) * 4);
+  WS_PTR(est4);
+  if ((rc = dp_conv_view(e, h, R, Tf, Q, C, 1, Q, 1, n.w_out, 4, n.b_out, est4, 4)) != WS_OK) return rc;
+  {
+    const int full = pad + T, ld = (T + 3) / 4 * 4;
+    float* fr = a.alloc(size_t(R) * Tf * nf);
+    float* y = a.alloc(size_t(R) * full);
+    float* o = a.alloc(size_t(R) * ld);
+    WS_PTR(fr && y && o);
+    ws_gemm_nt_args g = {};
+    g.A = est4, g.W = n.syn4, g.C = fr;
+    g.a_div = kBig, g.a_s2 = ld4, g.c_div = kBig, g.c_s2 = nf, g.st_div1 = 1, g.st_div2 = 1;
+    g.M = R * Tf, g.N = nf, g.K = ld4, g.ldw = ld4, g.vec = 3;
+    WS_RUN(e, ws_gemm_nt(&g, s));
+    WS_RUN(e, ws_ola_fwd(fr, nullptr, R, Tf, nf, hop, full, y, s));
+    std::vector<double> env(size_t(Tf - 1) * hop + nf, 0.0);
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k < nf; ++k) {
+      const float wf = static_cast<float>(0.5 - 0.5 * cos(2.0 * pi * k / nf));
+      const double w2 = double(wf) * double(wf);
+      for (int t = 0; t < Tf; ++t) env[size_t(t) * hop + k] += w2;
+    }
+    std::vector<float> inv(ld, 0.f);
+    for (int i = 0; i < T; ++i) inv[i] = static_cast<float>(1.0 / env[size_t(pad) + i]);
+    float* dinv = upload(e, a, inv.data(), inv.size());
+    WS_PTR(dinv);
+    if ((rc = zero_device(e, o, size_t(R) * ld * 4)) != WS_OK) return rc;
+    if ((rc = copy_cols(e, o, ld, y + pad, full, T, R)) != WS_OK) return rc;
+    WS_RUN(e, ws_affine_fwd(o, dinv, nullptr, 0.0f, R, R, ld, o, s));
+    if ((rc = copy_cols(e, est, T, o, ld, T, R)) != WS_OK) return rc;
+  }
+  return WS_OK;
+}
+
 int check_engine(const ws_engine* e, const char* who) {
   if (!e) {
     set_err("%s: null engine", who);
@@ -2553,6 +3033,7 @@ extern "C" const char* ws_engine_last_error(void) { return g_err; }
 
 extern "C" void ws_engine_destroy(ws_engine* e) {
   if (!e) return;
+  g_gridnets.erase(e);
   e->work.free_all();
   e->persist.free_all();
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -2623,6 +3104,13 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
     set_err("ws_engine_separate: bad arguments (R=%d, T=%d; T >= 512)", R, T);
     return WS_ERR_INVALID;
   }
+  if (e->arch == 3) {
+    const GridNet& gn = g_gridnets[e];
+    if (T % 4 || T < 2 * gn.n_fft || (long long)R * (1 + T / gn.hop) * gn.Q * 4 * kG4 > 0x7fffffffLL * 16LL) {
+      set_err("ws_engine_separate: a TF-GridNet engine needs T %% 4 == 0 (16-byte rows) and T >= %d (R=%d, T=%d)", 2 * gn.n_fft, R, T);
+      return WS_ERR_INVALID;
+    }
+  }
   if (e->arch == 2 && (T < 31 * kHop || (long long)R * (1 + T / kHop) * kDpBins * 160 > 0x7fffffffLL)) {
     set_err("ws_engine_separate: a DPCCN engine needs T >= %d samples (32 frames for the AvgPool2d(32) branch) and "
             "R * frames * 257 * 160 below 2^31 (R=%d, T=%d)", 31 * kHop, R, T);
@@ -2672,6 +3160,23 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
   float* d_est = a.alloc(size_t(R) * T);
   float* d_emb = a.alloc(size_t(R) * e->E);
   WS_PTR(d_mix && d_est && d_emb);
+  // TF-GridNet scales the mixture by its (unbiased) standard deviation and the estimate back (tfgridnet.py:222-226,292)
+  std::vector<float> mixn, stds;
+  if (e->arch == 3) {
+    mixn.resize(size_t(R) * T);
+    stds.resize(R);
+    for (int r = 0; r < R; ++r) {
+      const float* x = mix + size_t(r) * T;
+      double m = 0.0, v = 0.0;
+      for (int i = 0; i < T; ++i) m += x[i];
+      m /= T;
+      for (int i = 0; i < T; ++i) v += (x[i] - m) * (x[i] - m);
+      stds[r] = static_cast<float>(sqrt(v / (T - 1.0)));
+      const float inv = 1.0f / stds[r];
+      for (int i = 0; i < T; ++i) mixn[size_t(r) * T + i] = x[i] * inv;
+    }
+    mix = mixn.data();
+  }
   if ((rc = to_device(e, d_mix, mix, size_t(R) * T * 4)) != WS_OK) return rc;
   if (enroll_kind == WS_ENROLL_EMBEDDING) {
     if ((rc = to_device(e, d_emb, enroll, size_t(R) * e->E * 4)) != WS_OK) return rc;
@@ -2691,8 +3196,13 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
     if ((rc = e->spk_kind == 1 ? ecapa_embed(e, fb, R, Te, d_emb) : resnet_embed(e, fb, R, Te, d_emb)) != WS_OK) return rc;
     a.release(mk);
   }
-  if ((rc = e->arch == 2 ? dpccn_device(e, d_mix, R, T, d_emb, d_est) : separate_device(e, d_mix, R, T, d_emb, d_est)) != WS_OK) return rc;
+  rc = e->arch == 2 ? dpccn_device(e, d_mix, R, T, d_emb, d_est)
+                    : e->arch == 3 ? gridnet_device(e, d_mix, R, T, d_emb, d_est) : separate_device(e, d_mix, R, T, d_emb, d_est);
+  if (rc != WS_OK) return rc;
   if ((rc = to_host(e, est, d_est, size_t(R) * T * 4)) != WS_OK) return rc;
+  if (e->arch == 3 && !e->dry)
+    for (int r = 0; r < R; ++r)
+      for (int i = 0; i < T; ++i) est[size_t(r) * T + i] *= stds[r];
   if (e->cl_status && !e->dry) {   // did a cluster recurrence time out (and the predicated streaming pair repair it)?
     unsigned st = 0;
     if ((rc = to_host(e, &st, e->cl_status, 4)) != WS_OK) return rc;

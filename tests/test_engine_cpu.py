@@ -225,8 +225,11 @@ def test_infer_extract_engine_rank_dispatch(tmp_path):
 
 def test_export_refuses_models_the_runtime_does_not_run():
     from wesep_amd.models import get_model
-    with pytest.raises(NotImplementedError, match="not TFGridNet"):
+    with pytest.raises(NotImplementedError, match="emb_dim 48, emb_ks 4"):          # the constructor defaults
         export_engine(get_model("TFGridNet")(joint_training=False, n_layers=1), "/dev/null")
+    with pytest.raises(NotImplementedError, match="n_imics 2"):
+        export_engine(get_model("TFGridNet")(joint_training=False, n_layers=1, emb_dim=128, emb_ks=1, emb_hs=1, n_imics=2),
+                      "/dev/null")
     for kw, what in ((dict(norm="cLN"), "gLN only"), (dict(causal=True), "causal"), (dict(skip_con=True), "skip"),
                      (dict(spk_fuse_type="FiLM"), "concatConv only"),
                      (dict(encoder_type="Deep", decoder_type="Deep"), "Multi only")):
@@ -313,6 +316,41 @@ def test_dpccn_concat_fusion_is_refused_by_the_exporter(tmp_path):
     m = get_model("DPCCN")(tcn_blocks=1, tcn_layers=1, joint_training=False, spk_fuse_type="concat")
     with pytest.raises(NotImplementedError, match="concat"):
         export_engine(m, str(tmp_path / "c.wsw"))
+
+
+@needs_no_gpu
+@pytest.mark.parametrize("variant", ["fixed-multiply", "fixed-film-hidden64", "joint-resnet18-additive"])
+def test_dry_run_launch_plan_tfgridnet(tmp_path, variant):
+    """TF-GridNet in the native runtime (arch 3, the recipe's geometry): container, geometry read back, and the whole
+    launch plan -- DFT-basis STFT, GroupNorm, per block the row LayerNorms, both BLSTM paths on the blocked-layout kernels
+    (the inter-frame path on a strided sequence map), the projection GEMM, the attention-head kernels, grouped logits /
+    value GEMMs, softmax, head merge, projection + PReLU + LayerNorm, residual -- through the real library's argument
+    validation for several lengths and row counts."""
+    from wesep_amd.models import get_model
+    kw = dict(n_layers=2, emb_dim=128, emb_ks=1, emb_hs=1, lstm_hidden_units=192, spk_emb_dim=256, joint_training=False)
+    if variant == "fixed-film-hidden64":
+        kw.update(spk_fuse_type="FiLM", lstm_hidden_units=64, use_spk_transform=True)
+    elif variant == "joint-resnet18-additive":
+        kw.update(spk_fuse_type="additive", joint_training=True, spk_model="ResNet18", spk_feat=True,
+                  spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
+    m = get_model("TFGridNet")(**kw)
+    path = str(tmp_path / "g.wsw")
+    export_engine(m, path)
+    eng = E.Engine(path, dry_run=True)
+    assert eng.info("arch") == 3 and eng.info("n_layers") == 2 and eng.info("lstm_hidden_units") == kw["lstm_hidden_units"]
+    assert eng.info("attn_E") == 8 and eng.info("attn_n_head") == 4 and eng.info("joint_training") == int(kw["joint_training"])
+    for R, T in ((2, 16000), (1, 12344), (3, 4000), (64, 2048)):
+        if kw["joint_training"]:
+            enroll, kind = np.zeros((R, 150, 80), np.float32), E.ENROLL_FBANK
+        else:
+            enroll, kind = np.zeros((R, 256), np.float32), E.ENROLL_EMBEDDING
+        mix = np.random.default_rng(R).standard_normal((R, T)).astype(np.float32)
+        est = eng.separate(mix, enroll, kind)
+        assert est.shape == (R, T) and not est.any()
+        assert eng.info("n_launches") > 0 and eng.info("arena_bytes") > 0
+    with pytest.raises(E.WesepHipError, match="T % 4"):
+        eng.separate(np.zeros((2, 4001), np.float32), enroll[:2], kind)
+    eng.close()
 
 
 def _write_wav(path, x, sr=16000):

@@ -1,4 +1,4 @@
-"""Write a pBSRNN, Conv-TasNet / SpEx+ or DPCCN checkpoint as the flat weight container of the native runtime (include/wesep_engine.h,
+"""Write a pBSRNN, Conv-TasNet / SpEx+, DPCCN or TF-GridNet checkpoint as the flat weight container of the native runtime (include/wesep_engine.h,
 runtime/engine.cc) -- the counterpart of the reference's `wesep/bin/export_jit.py` (TorchScript archive for the
 LibTorch runtime).
 
@@ -143,17 +143,47 @@ def dpccn_meta(model):
     return speaker_meta(model, meta)
 
 
+def gridnet_meta(model):
+    """TF-GridNet (arch 3): the runtime's launch plan covers the shipped recipe's geometry -- one microphone, one source,
+    emb_dim 128, emb_ks = emb_hs = 1, lstm_hidden_units <= 256, multiply / additive / FiLM fusion -- with fixed embeddings
+    or the speaker encoders the pBSRNN plan has.  Everything else is refused by name."""
+    blk = model.blocks[0]
+    problems = []
+    if model.n_imics != 1 or model.n_srcs != 1:
+        problems.append(f"n_imics {model.n_imics} / n_srcs {model.n_srcs} (1 / 1 only)")
+    if blk.emb_dim != 128 or blk.emb_ks != 1 or blk.emb_hs != 1:
+        problems.append(f"emb_dim {blk.emb_dim}, emb_ks {blk.emb_ks}, emb_hs {blk.emb_hs} (128 / 1 / 1: the blocked-layout recurrences)")
+    if model.spk_fuse.fuse_type == "concat":
+        problems.append("spk_fuse_type 'concat'")
+    if model.stride * 2 != model.n_fft:
+        problems.append(f"stride {model.stride} != n_fft / 2")
+    if problems:
+        raise NotImplementedError("export_engine: TF-GridNet with " + "; ".join(problems) + " has no launch plan in the "
+                                  "native runtime")
+    meta = {
+        "arch": 3, "sample_rate": 16000, "n_fft": model.n_fft, "stride": model.stride, "n_layers": model.n_layers,
+        "emb_dim": blk.emb_dim, "emb_ks": blk.emb_ks, "emb_hs": blk.emb_hs, "lstm_hidden_units": blk.hidden,
+        "attn_n_head": blk.n_head, "attn_E": blk.E, "n_srcs": model.n_srcs, "n_imics": model.n_imics,
+        "spk_emb_dim": model.spk_emb_dim, "spk_fuse_type": FUSE[model.spk_fuse.fuse_type], "multi_fuse": 0,
+        "use_spk_transform": int(not isinstance(model.spk_transform, torch.nn.Identity)),
+        "joint_training": int(model.joint_training), "feat_dim": 80, "spk_feat": 1,
+    }
+    return speaker_meta(model, meta)
+
+
 def export_engine(model, path):
-    """model: a wesep_amd (or reference) `BSRNN` / `BSRNN_Multi` / `ConvTasNet` / `DPCCN` instance -> container at `path`;
+    """model: a wesep_amd (or reference) `BSRNN` / `BSRNN_Multi` / `ConvTasNet` / `DPCCN` (or `TFGridNet`) instance -> container at `path`;
     returns (n_tensors, n_floats)."""
     name = type(model).__name__
     if name == "ConvTasNet":
         return write_container(path, tasnet_meta(model), model.state_dict())
     if name == "DPCCN":
         return write_container(path, dpccn_meta(model), model.state_dict())
+    if name == "TFGridNet":
+        return write_container(path, gridnet_meta(model), model.state_dict())
     if name not in ("BSRNN", "BSRNN_Multi"):
         raise NotImplementedError("export_engine: the native runtime runs pBSRNN (BSRNN / BSRNN_Multi), Conv-TasNet / "
-                                  f"SpEx+ and DPCCN checkpoints, not {name}")
+                                  f"SpEx+, DPCCN and TF-GridNet checkpoints, not {name}")
     return write_container(path, engine_meta(model), model.state_dict())
 
 
