@@ -8,7 +8,7 @@
  *
  * The reference loads a TorchScript archive; this engine loads a flat weight container written by
  * `python -m wesep_amd.bin.export_engine` (the `state_dict` under the reference's own key names, see INTEGRATION.md;
- * meta key "arch": 0 pBSRNN, 1 Conv-TasNet / SpEx+, 2 DPCCN -- ws_engine_info(e, "arch")) and runs the forward as a
+ * meta key "arch": 0 pBSRNN, 1 Conv-TasNet / SpEx+, 2 DPCCN, 3 TF-GridNet -- ws_engine_info(e, "arch")) and runs the forward as a
  * fixed launch plan over include/wesep_hip.h: weights are uploaded and
  * packed into MFMA fragment order ONCE at load, activations live in one grow-only device arena with stack
  * discipline, the enrollment front-end (kaldi fbank + CMN as two GEMMs, include/wesep_hip.h) and the jointly
