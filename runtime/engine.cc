@@ -180,7 +180,13 @@ struct SeRes2Prep {         // SE_Res2Block: 1x1 TDNN, Res2Net branches, 1x1 TDN
 
 static std::mutex g_device_mutex[16];   // see ws_engine_separate
 
+namespace {
+struct GridNet;                          // TF-GridNet plan state (arch 3), defined with the plan
+void grid_free(GridNet* g);
+}
+
 struct ws_engine {
+  GridNet* grid = nullptr;
   bool dry = false;
   int device = 0, cu_count = 0;
   hipStream_t stream = nullptr;
@@ -2524,7 +2530,7 @@ struct GridNet {
   float *id_st = nullptr, *slope1 = nullptr, *film_bias1 = nullptr;
   std::vector<GridBlock> blocks;
 };
-std::map<const ws_engine*, GridNet> g_gridnets;     // plan state of the arch-3 engines (keyed by handle; erased on destroy)
+void grid_free(GridNet* g) { delete g; }
 
 // nn.LSTM tensors of hidden size h -> the 256-unit layout (functional_tfgridnet.pad_lstm): gate-major rows g*256 + u
 int grid_prep_rnn(ws_engine* e, const std::string& path, int C, int h, RnnPrep* r) {
@@ -2586,7 +2592,8 @@ int grid_prep_rnn(ws_engine* e, const std::string& path, int C, int h, RnnPrep* 
 }
 
 int prepare_gridnet(ws_engine* e) {
-  GridNet& n = g_gridnets[e];
+  if (!e->grid) e->grid = new GridNet();
+  GridNet& n = *e->grid;
   e->sr = static_cast<int>(meta_or(e, "sample_rate", 16000));
   int rc = read_speaker_meta(e);
   if (rc != WS_OK) return rc;
@@ -2820,7 +2827,7 @@ int grid_bmm(ws_engine* e, const float* A, const float* W, const float* bias, in
 
 // wav [R][T] (already divided by its standard deviation), emb [R][E] -> est [R][T] (still in normalised units)
 int gridnet_device(ws_engine* e, const float* wav, int R, int T, const float* emb_in, float* est) {
-  const GridNet& n = g_gridnets[e];
+  const GridNet& n = *e->grid;
   const int nf = n.n_fft, hop = n.hop, pad = nf / 2, Tf = 1 + T / hop, Q = n.Q, C = n.C, nh = n.nh, E = n.E, cp = C / nh;
   const int ld4 = 4 * Q, Tp = (Tf + 3) / 4 * 4, G = nh * R, D = Q * E, Dv = Q * cp, ldq = 2 * nh * E + C;
   const long long M = (long long)R * Tf * Q;
@@ -3033,7 +3040,7 @@ extern "C" const char* ws_engine_last_error(void) { return g_err; }
 
 extern "C" void ws_engine_destroy(ws_engine* e) {
   if (!e) return;
-  g_gridnets.erase(e);
+  grid_free(e->grid);
   e->work.free_all();
   e->persist.free_all();
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -3105,7 +3112,7 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
     return WS_ERR_INVALID;
   }
   if (e->arch == 3) {
-    const GridNet& gn = g_gridnets[e];
+    const GridNet& gn = *e->grid;
     if (T % 4 || T < 2 * gn.n_fft || (long long)R * (1 + T / gn.hop) * gn.Q * 4 * kG4 > 0x7fffffffLL * 16LL) {
       set_err("ws_engine_separate: a TF-GridNet engine needs T %% 4 == 0 (16-byte rows) and T >= %d (R=%d, T=%d)", 2 * gn.n_fft, R, T);
       return WS_ERR_INVALID;
