@@ -3113,9 +3113,10 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
   }
   if (e->arch == 3) {
     const GridNet& gn = *e->grid;
-    if (T % 4 || T < 2 * gn.n_fft || (long long)R * (1 + T / gn.hop) * gn.Q * (2 * gn.nh * gn.E + gn.C) > 0x7fffffffLL) {
-      set_err("ws_engine_separate: a TF-GridNet engine needs T %% 4 == 0 (16-byte rows), T >= %d and R * frames * bins * %d "
-              "below 2^31 (R=%d, T=%d)", 2 * gn.n_fft, 2 * gn.nh * gn.E + gn.C, R, T);
+    // (any sample count: the standard-deviation scaling that ties the Python path to multiples of 4 samples runs on the host here)
+    if (T < 2 * gn.n_fft || (long long)R * (1 + T / gn.hop) * gn.Q * (2 * gn.nh * gn.E + gn.C) > 0x7fffffffLL) {
+      set_err("ws_engine_separate: a TF-GridNet engine needs T >= %d and R * frames * bins * %d below 2^31 (R=%d, T=%d)",
+              2 * gn.n_fft, 2 * gn.nh * gn.E + gn.C, R, T);
       return WS_ERR_INVALID;
     }
   }
