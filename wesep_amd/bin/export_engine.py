@@ -190,7 +190,7 @@ def export_engine(model, path):
 def main():
     import yaml
     from ..models import get_model
-    ap = argparse.ArgumentParser(description="export a pBSRNN checkpoint for the native MI355X runtime")
+    ap = argparse.ArgumentParser(description="export a pBSRNN, Conv-TasNet / SpEx+, DPCCN or TF-GridNet checkpoint for the native MI355X runtime")
     ap.add_argument("--config", required=True)
     ap.add_argument("--checkpoint", required=True)
     ap.add_argument("--out", required=True)
