@@ -353,6 +353,34 @@ def test_dry_run_launch_plan_tfgridnet(tmp_path, variant):
     eng.close()
 
 
+@needs_no_gpu
+@pytest.mark.parametrize("name", ["DPCCN", "TFGridNet"])
+def test_shipped_recipe_models_export_and_dry_run(tmp_path, name):
+    """model_args of examples/librimix/tse/v2/confs/dpccn.yaml / tfgridnet.yaml (joint ResNet34 on 80-bin fbank; the stray
+    `multi_fuse` key of tfgridnet.yaml dropped: the reference's own constructor does not take it either): full-size
+    containers, every launch of the plan through the real library's argument validation."""
+    from wesep_amd.models import get_model
+    spk = dict(joint_training=True, spk_model="ResNet34", spk_model_init=False, spk_emb_dim=256, spk_model_freeze=False,
+               spk_feat=True, feat_type="consistent", use_spk_transform=False, spk_fuse_type="multiply",
+               spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
+    if name == "DPCCN":
+        kw = dict(win=512, stride=128, feature_dim=257, tcn_blocks=10, tcn_layers=2, causal=False, multi_fuse=False, **spk)
+    else:
+        kw = dict(n_srcs=1, sr=16000, n_fft=128, stride=64, window="hann", n_imics=1, n_layers=6, lstm_hidden_units=192,
+                  attn_n_head=4, attn_approx_qk_dim=512, emb_dim=128, emb_ks=1, emb_hs=1, activation="prelu", eps=1.0e-5,
+                  multi_task=False, spksInTrain=251, **spk)
+    path = str(tmp_path / "r.wsw")
+    export_engine(get_model(name)(**kw), path)
+    eng = E.Engine(path, dry_run=True)
+    assert eng.info("arch") == (2 if name == "DPCCN" else 3) and eng.info("joint_training") == 1 and eng.info("spk_blocks1") == 4
+    est = eng.separate(np.random.default_rng(0).standard_normal((2, 48001)).astype(np.float32), np.zeros((2, 298, 80), np.float32),
+                       E.ENROLL_FBANK)
+    assert est.shape == (2, 48001) and eng.info("n_launches") > 300
+    out = eng.forward_pcm16(np.zeros(32000, np.int16) + 3, np.zeros(48000, np.int16), np.zeros(50001, np.int16))
+    assert out.shape == (2, 32000)
+    eng.close()
+
+
 def _write_wav(path, x, sr=16000):
     with wave.open(str(path), "wb") as w:
         w.setnchannels(1)
