@@ -179,3 +179,70 @@ def test_product_model_with_weight_gradient_carriers_under_ddp_world2(tmp_path):
         worst = max(worst, err)
         assert err < 2e-3, (k, err)
     print("worst relative difference to the mean of the per-rank oracle gradients:", worst)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The widened separators under DDP: DPCCN (DenseBlockFn: one gradient per parameter from block convolutions; halo weight
+# gradients with slab reductions) and TF-GridNet (QKVHeadsFn: gradients of the three projections' parameters through one
+# concatenated weight) -- the same world-2 statement as above, gradients against the mean of the per-rank oracle
+# gradients.
+# ----------------------------------------------------------------------------------------------------------------------
+def _separator_worker(rank, world, port, out, which):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import pytest as _pytest
+    from oracle import bsrnn_oracle as O
+    from tests import emu_dev
+    from wesep_amd.models import get_model
+    from wesep_amd.parallel import init_distributed, rank_seed, wrap_ddp
+    from wesep_amd.utils.synthetic import synth_batch
+    mp_ = _pytest.MonkeyPatch()
+    emu_dev.install(mp_)
+    mp_.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    r, lr, w = init_distributed(backend="gloo")
+    if which == "dpccn":
+        from oracle import dpccn_oracle as M
+        cfg = M.DPCCNConfig(tcn_blocks=2, tcn_layers=1)
+        model = get_model("DPCCN")(tcn_blocks=2, tcn_layers=1, joint_training=False)
+        fwd = M.dpccn_forward
+        T = 4480
+    else:
+        from oracle import tfgridnet_oracle as M
+        kw = dict(n_layers=1, lstm_hidden_units=16, emb_dim=8, emb_ks=1, emb_hs=1, attn_n_head=2, attn_approx_qk_dim=260)
+        cfg = M.TFGridNetConfig(**kw)
+        model = get_model("TFGridNet")(**kw, joint_training=False)
+        fwd = M.tfgridnet_forward
+        T = 1280
+    params = M.synth_params(cfg, 5)
+    model.load_state_dict(params, strict=True)
+    model.train()
+    ddp = wrap_ddp(model, lr)
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    wav, tgt, emb = synth_batch(2, T, rank_seed(42, rank))
+    est, _ = ddp(wav, emb)
+    O.sisdr_loss(est, tgt).backward()
+    named = dict(model.named_parameters())
+    assert all(p.grad is not None for p in named.values())
+    q = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    o = fwd(q, cfg, wav, emb)
+    O.sisdr_loss(o[0] if isinstance(o, tuple) else o, tgt).backward()
+    torch.save({"ddp": {k: p.grad.clone() for k, p in named.items()}, "local": {k: v.grad.clone() for k, v in q.items()}},
+               os.path.join(out, f"s{rank}.pt"))
+    torch.distributed.destroy_process_group()
+    mp_.undo()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("which", ["dpccn", "tfgridnet"])
+def test_widened_separators_under_ddp_world2(tmp_path, which):
+    world, port = 2, _free_port()
+    mp.spawn(_separator_worker, args=(world, port, str(tmp_path), which), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"s{i}.pt") for i in range(2))
+    gmax = max(float(v.norm()) for v in r0["local"].values())
+    for k in r0["ddp"]:
+        g0, g1 = r0["ddp"][k], r1["ddp"][k]
+        assert torch.equal(g0, g1), k                            # replicas hold the same averaged gradient, bit for bit
+        want = 0.5 * (r0["local"][k] + r1["local"][k])
+        err = float((g0 - want).norm() / (want.norm() + 1e-4 * gmax))
+        assert err < 5e-3, (k, err)
