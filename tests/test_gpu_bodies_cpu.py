@@ -81,3 +81,30 @@ def test_pair_bptt_gpu_test_body(emu, monkeypatch):
     monkeypatch.setattr(t, "_cuda", lambda: torch.device("cpu"))
     t.test_lstm_pair_bwd_vs_torch("time", (3, 7, 37))
     t.test_lstm_pair_bwd_vs_torch("band", (4, 9, 16))
+
+
+def test_engine_separator_gpu_test_bodies(emu, monkeypatch, tmp_path):
+    """tests/test_zzz_engine_separators_gpu.py has not run on hardware: its bodies -- model construction, parameter
+    randomisation, export, the Python forward of every variant -- run here on the emulations, with the engine in its dry
+    run (argument validation of every launch; it computes nothing, so the comparison itself is stubbed out)."""
+    import tests.test_engine_gpu as tg
+    import tests.test_zzz_engine_separators_gpu as z
+    from tests import emu_blk
+    from wesep_amd import engine as E
+    emu_blk.install(monkeypatch)
+    monkeypatch.setattr(tg, "_cuda", lambda: torch.device("cpu"))
+    monkeypatch.setattr(tg, "rel", lambda a, b: 0.0)
+    real = E.Engine
+
+    class DryEngine(real):
+        def __init__(self, path):
+            super().__init__(path, dry_run=True)
+    monkeypatch.setattr(E, "Engine", DryEngine)
+    for i, v in enumerate(("joint-resnet18-multiply", "fixed-additive", "fixed-film-causal")):
+        d = tmp_path / f"d{i}"
+        d.mkdir()
+        z.test_dpccn_engine_matches_python_model(d, v)
+    for i, v in enumerate(("joint-resnet18-multiply", "fixed-additive", "fixed-film-hidden64")):
+        d = tmp_path / f"g{i}"
+        d.mkdir()
+        z.test_tfgridnet_engine_matches_python_model(d, v)
