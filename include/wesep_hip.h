@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 14
+#define WS_ABI_VERSION 15
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -40,6 +40,10 @@ int ws_prof_collect(int kind, double* total_ms, long long* launches); /* syncs t
 /* Test support: fills 60 KB of LDS per workgroup with `value` (NaN) on `stream` and keeps the workgroups alive for
  * `spins` LDS reads per thread; beside product kernels on another stream it exposes reads of LDS a kernel never wrote. */
 int ws_debug_dirty_lds(float value, int nblocks, int spins, float* sink, void* stream);
+/* Test support (ABI v15): holds `nblocks` compute units (112 KB of LDS each: no workgroup of the co-resident recurrences or
+ * of the weight-gradient GEMM fits beside it) for `usec` microseconds of wall clock, or until *stop != 0 (optional
+ * device word) -- a resident-collective-shaped occupant for the robustness tests.  Bounded: usec <= 2 000 000.        */
+int ws_debug_occupy(int nblocks, int usec, const unsigned* stop, float* sink, void* stream);
 
 /* ---- row addressing used by the GEMMs ---------------------------------------------------
  * row m of a matrix lives at  base + (m / div) * s1 + (m % div) * s2   (elements).       */
@@ -209,10 +213,33 @@ typedef struct ws_lstm_args {
   const float* wpack;   /* ws_lstm_pack output for this pass (fwd or bwd)     */
   long long sq_s1, sq_s2, step_rows;
   int nseq, sq_div, L, mode;   /* WS_LSTM_* below; must match the mode wpack was packed with */
-  const unsigned* run_if;      /* ws_lstm_fwd, blocked-layout modes only: optional device word; when given, the
-                                  launch does nothing unless *run_if != 0 at kernel start (the predicated
-                                  fall-back behind ws_lstm_fwd_cluster, see there)                        */
+  const unsigned* run_if;      /* split-bf16 ws_lstm_fwd and blocked-layout ws_lstm_bwd: optional device word; when given,
+                                  the launch does nothing unless *run_if != 0 at kernel start (the predicated fall-back
+                                  behind ws_lstm_fwd_cluster / ws_lstm_bwd_pair, see there)               */
+  /* ABI v15, blocked-layout modes only: storage format of the saved recurrence state (WS_GATES_* below).  With
+   * gfmt != 0 `gates` is a BLH(2 * 4H) buffer of 2-byte elements; the forward reads the fp32 pre-activations from
+   * `gates_in` (BL(2 * 4H) fp32, not modified) instead of `gates`; the backward with WS_GATES_H2S writes d(gates)
+   * to `dgates` (BL(2 * 4H), BLS elements) instead of in place; with WS_GATES_H2 `dgates` is optional: given, it
+   * receives the bf16 d(gates) (BLH(2 * 4H)) and the saved gates stay intact -- what makes a BPTT launch repeatable
+   * (the predicated fall-back behind ws_lstm_bwd_pair).                                                    */
+  const float* gates_in;
+  float* dgates;
+  int gfmt, pad_;
 } ws_lstm_args;
+/* Storage format of the saved activated gates and of d(pre-activation gates) on the blocked layout (ABI v15).
+ * BLH(C): the BL(C) index formula with 2-byte elements -- element (b, slot i, column c) at 2-byte index
+ * b*32*C + ((c >> 2)*32 + i)*4 + (c & 3); a lane's 4-column cell is 8 bytes, 32 lanes 256 contiguous bytes.
+ *   WS_GATES_F32 (0): gates fp32 BL, d(gates) as BLS pairs IN PLACE (ABI <= 14: one 16E-byte buffer, three lives).
+ *   WS_GATES_H2  (1): activated gates as unorm16 in BLH -- i, f, o in (0, 1): u = floor(x * 65535 + 0.5);
+ *                     g in (-1, 1): u = floor((x + 1) * 32767.5 + 0.5) -- absolute error <= 7.7e-6 / 1.6e-5 where fp16
+ *                     would leave 2.4e-4 near saturation; d(gates) IN PLACE as bf16 = the hi term of the split pair
+ *                     (relative error 2^-9: consumers ws_gemm_b2p a_fmt = 1, ws_gemm_tnb g_fmt = 1).  Halves the
+ *                     largest buffer of the step and every pass over it.
+ *   WS_GATES_H2S (2): activated gates as in H2; d(gates) as BLS pairs (full split precision) to a separate
+ *                     BL(2 * 4H) buffer.                                                                      */
+#define WS_GATES_F32 0
+#define WS_GATES_H2 1
+#define WS_GATES_H2S 2
 #define WS_LSTM_F32_MT1 1 /* exact-fp32 MFMA, 16 sequences per workgroup                       */
 #define WS_LSTM_F32_MT2 2 /* exact-fp32 MFMA, 32 sequences per workgroup                       */
 #define WS_LSTM_BF16X3 3  /* split-bf16 (hi/lo, 3 bf16 MFMAs per product, fp32 accumulate), 32 */
@@ -253,8 +280,11 @@ typedef struct ws_lstm_cluster_args {
   unsigned* flags;
   unsigned* status;
   int nseq, L;
-  int dbg, pad_;        /* probes / tests only: 1 skip the flag wait, 2 skip the gather, 4 skip the publish,
-                           8 force a timeout in workgroup 0 at step 2 (exercises the fall-back)      */
+  int dbg, gfmt;        /* dbg: probes / tests only: 1 skip the flag wait, 2 skip the gather, 4 skip the publish,
+                           8 force a timeout in workgroup 0 at step 2 (exercises the fall-back).
+                           gfmt (ABI v15, forward only; the cluster BPTT is WS_GATES_F32 only): WS_GATES_*; != 0: the
+                           pre-activations come from gates_in (fp32 BL), `gates` receives unorm16 BLH      */
+  const float* gates_in;
 } ws_lstm_cluster_args;
 int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream);
 /* BPTT over the same clusters (reduce-scatter of partial dh each step): gates holds the activated
@@ -269,8 +299,11 @@ int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream);
  * the time view (bsrnn.py:38-46) on half of the chip's CUs.  wpack: ws_lstm_pack_pair output (WS_LSTM_PACK_FLOATS).
  * npair = 2 * ceil(nseq / 32); 2 * npair <= CUs of the device (checked).  xchg: npair * 64 KB scratch; flags:
  * npair * 8 + 8 words (zeroed by the call on `stream`).  Every wait is bounded: on a timeout d(gates) are NaN-poisoned,
- * flags[npair * 8] (0 after a clean launch) and *status (optional, sticky) are set to 1; in place, so there is no
- * device-side repair.  dbg (probes / tests only): 1 skip the flag wait, 2 skip the exchange, 4 no weight reloads,
+ * flags[npair * 8] (0 after a clean launch) and *status (optional, sticky) are set to 1.  In place there is no
+ * device-side repair; with `dgates` given (WS_GATES_H2 / H2S: the saved gates stay intact) callers enqueue the streaming
+ * BPTT behind this launch with  run_if = &flags[npair * 8]  and the same `dgates`: an empty launch after a clean run,
+ * the whole BPTT again after a timeout -- no NaN reaches a consumer, no host round trip (ABI v15).
+ * dbg (probes / tests only): 1 skip the flag wait, 2 skip the exchange, 4 no weight reloads,
  * 8 force a timeout in pair 0 at step 2, 32 no wave priorities,
  * 64 full agent-scope release / acquire fences around the hand-off.                                             */
 typedef struct ws_lstm_pair_args {
@@ -284,7 +317,9 @@ typedef struct ws_lstm_pair_args {
   float* dbg_buf;       /* NULL, or npair * L * 2 * 2 * 4096 floats: per (pair, step, member) the partial it sent and
                            the partial it received (diagnosis only, tools/pair_diag.py)                       */
   int nseq, L;
-  int dbg, pad_;
+  int dbg, gfmt;        /* gfmt (ABI v15): WS_GATES_*; H2: unorm16 gates in, bf16 d(gates) out -- to `dgates` (BLH) when given,
+                           else in place; H2S: d(gates) as BLS pairs to `dgates`                                      */
+  float* dgates;
 } ws_lstm_pair_args;
 int ws_lstm_pack_pair(const float* whh_f, const float* whh_r, float* pack, void* stream);
 int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream);
@@ -348,6 +383,7 @@ typedef struct ws_gemm_b2p_args {
   ws_seqmap sm;
   long long ldc;
   int N, K;
+  int a_fmt, pad_;   /* ABI v15: 0 = A holds BLS pairs (BL(K)); 1 = A holds bf16 elements (BLH(K)): d(gates) of WS_GATES_H2 */
 } ws_gemm_b2p_args;
 int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream);
 
@@ -371,7 +407,7 @@ typedef struct ws_gemm_tnb_args {
   int a0_width, a0_off, a0_cols, a0_shift;
   int a1_width, a1_off, a1_cols, a1_shift;
   int nblk, L, nsplit, blocks_per_split;
-  int pad_;
+  int g_fmt;         /* ABI v15: 0 = G holds BLS pairs; 1 = G holds bf16 elements (BLH(g_width)): d(gates) of WS_GATES_H2 */
 } ws_gemm_tnb_args;
 int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream);
 
@@ -424,11 +460,17 @@ typedef struct ws_tensor_ref {
   float* exp_avg_sq;
   long long numel;
 } ws_tensor_ref;
-int ws_grad_norms(const ws_tensor_ref* tab, int ntensors, float* norms, void* stream);
-/* if clip > 0: coef = clip / (norm + 1e-6); grad *= coef when coef < 1  (per tensor)       */
+/* guard (optional, TWO device words; ABI v15): guard[0] and guard[1] are set to 1 when any tensor's norm is NaN / Inf.
+ * The caller zeroes guard[0] before the launch (the skip word of this step's ws_clip_adam_step); guard[1] is sticky. */
+int ws_grad_norms(const ws_tensor_ref* tab, int ntensors, float* norms, unsigned* guard, void* stream);
+/* if clip > 0: coef = clip / (norm + 1e-6); grad *= coef when coef < 1  (per tensor)
+ * skip0 / skip1 (optional device words, ABI v15): the launch does NOTHING when one of them is non-zero at kernel start --
+ * the guard word of ws_grad_norms (a non-finite gradient: a BPTT launch that timed out, on any rank of a data-parallel
+ * job once the gradients are all-reduced) and / or the sticky status word of an in-place BPTT launch.  The reference
+ * would apply the NaN to every weight (funcs.py:79-88: NaN comparisons are false, Adam follows).               */
 int ws_clip_adam_step(const ws_tensor_ref* tab, int ntensors, const float* norms, float clip,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                      int clip_only, void* stream);
+                      int clip_only, const unsigned* skip0, const unsigned* skip1, void* stream);
 
 /* ---- Conv-TasNet / SpEx+, channels-last activations [R*T'][C] ----------
  * Everything that is not a 1x1 / framing convolution (those are ws_gemm_nt / ws_gemm_tn on row views).
@@ -528,6 +570,7 @@ typedef struct ws_lstm_fused_args {
   const float* wpack;
   const float* bias;
   int nseq, L;
+  int gfmt, pad_;       /* ABI v15: WS_GATES_* (!= 0: `gates` receives unorm16 BLH) */
 } ws_lstm_fused_args;
 #define WS_LSTM_FUSED_PACK_FLOATS (2 * 8 * 24 * 4 * 2 * 64 * 4)
 int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,

@@ -30,6 +30,41 @@ def bl_put(buf, x, ntile, L, C):
     buf.reshape(-1)[: ntile * L * 32 * C] = v.reshape(-1)
 
 
+# ---- 2-byte storage of the saved recurrence state (wesep_hip.h WS_GATES_H2 / H2S, ABI v15): BLH(C) = the BL(C) index
+#      formula on 2-byte elements; the product hands these buffers over as float32 storage of half the element count
+def blh_get(buf, ntile, L, C, dtype):
+    v = buf.reshape(-1).view(dtype)[: ntile * L * 32 * C].reshape(ntile, L, C // 4, 32, 4)
+    return v.permute(0, 3, 1, 2, 4).reshape(ntile * 32, L, C)
+
+
+def blh_put(buf, x, ntile, L, C, dtype):
+    v = x.reshape(ntile, 32, L, C // 4, 4).permute(0, 2, 3, 1, 4)
+    buf.reshape(-1).view(dtype)[: ntile * L * 32 * C] = v.reshape(-1).to(dtype)
+
+
+def _gate_is_tanh():
+    """[2 * 4H] mask of the g gate's columns (column = dir * 4H + gate * H + unit)."""
+    m = torch.zeros(2, 4, H, dtype=torch.bool)
+    m[:, 2] = True
+    return m.reshape(-1)
+
+
+def gates_put_u16(buf, act, ntile, L):
+    """activated gates [S, L, 2 * 4H] -> unorm16 codes (lstm_bf16_common.h enc_u16x4): i, f, o: floor(x * 65535 + 0.5);
+    g: floor(x * 32767.5 + 32768)."""
+    t = _gate_is_tanh()
+    code = torch.where(t, torch.floor(act * 32767.5 + 32768.0), torch.floor(act * 65535.0 + 0.5)).to(torch.int32)
+    code = torch.where(code >= 32768, code - 65536, code)          # uint16 bit pattern held in int16
+    blh_put(buf, code, ntile, L, 2 * G4, torch.int16)
+
+
+def gates_get_u16(buf, ntile, L):
+    code = blh_get(buf, ntile, L, 2 * G4, torch.int16).to(torch.int32) & 0xFFFF
+    t = _gate_is_tanh()
+    x = code.float()
+    return torch.where(t, x * (1.0 / 32767.5) - 1.0, x * (1.0 / 65535.0))
+
+
 def _valid(sm):
     return (torch.arange(_ntile(sm) * 32) < sm.nseq).float().view(-1, 1, 1)
 
@@ -83,9 +118,9 @@ def gemm_p2b(*, A, lda, sm, Wpack, N, C_out, K=128, bias=None, A_bl=None, stats=
         bl_put(C_out, out * _valid(sm), nt, L, N)
 
 
-def gemm_b2p(*, A, K, sm, Wpack, C_out, ldc, N=128, bias=None, R=None):
+def gemm_b2p(*, A, K, sm, Wpack, C_out, ldc, N=128, bias=None, R=None, a_fmt=0):
     nt, L = _ntile(sm), sm.L
-    x = bl_get(A, nt, L, K)[: sm.nseq]
+    x = (blh_get(A, nt, L, K, torch.bfloat16).float() if a_fmt else bl_get(A, nt, L, K))[: sm.nseq]
     out = x @ _PACKS[Wpack.data_ptr()].t()
     if bias is not None:
         out = out + bias.reshape(-1)[:N]
@@ -133,11 +168,14 @@ def _recur_bwd(act, cs, dh_in, whf, whr):
     return dpre
 
 
-def _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm):
+def _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt=0):
     nt, L = _ntile(sm), sm.L
     act, cs, hs = _recur_fwd(pre, whf, whr)
     v = _valid(sm)
-    bl_put(gates, (act.reshape(nt * 32, L, 2 * G4)) * v, nt, L, 2 * G4)
+    if gfmt:
+        gates_put_u16(gates, act.reshape(nt * 32, L, 2 * G4), nt, L)     # (padded slots: whatever the recurrence made of them)
+    else:
+        bl_put(gates, (act.reshape(nt * 32, L, 2 * G4)) * v, nt, L, 2 * G4)
     bl_put(cbuf, cs.reshape(nt * 32, L, 2 * H) * v, nt, L, 2 * H)
     bl_put(hcat, hs.reshape(nt * 32, L, 2 * H) * v, nt, L, 2 * H)
 
@@ -148,36 +186,44 @@ def _whh_from_pack(wpack):
 
 
 def make_lstm_fwd(plain_fwd):
-    def lstm_fwd(gates, cbuf, hcat, wpack, sm, mode=3, run_if=None):
+    def lstm_fwd(gates, cbuf, hcat, wpack, sm, mode=3, run_if=None, gfmt=0, gates_in=None):
         if _skip(run_if):
             return
         if mode not in (4, 5):
             return plain_fwd(gates, cbuf, hcat, wpack, sm, mode)
         nt, L = _ntile(sm), sm.L
         whf, whr = _whh_from_pack(wpack)
-        _fwd_into(gates, cbuf, hcat, bl_get(gates, nt, L, 2 * G4).reshape(nt * 32, L, 2, G4), whf, whr, sm)
+        src = gates_in if gfmt else gates
+        _fwd_into(gates, cbuf, hcat, bl_get(src, nt, L, 2 * G4).reshape(nt * 32, L, 2, G4), whf, whr, sm, gfmt)
     return lstm_fwd
 
 
 def make_lstm_bwd(plain_bwd):
-    def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode=3):
+    def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode=3, gfmt=0, dgates=None, run_if=None):
+        if _skip(run_if):
+            return
         if mode not in (4, 5):
             return plain_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode)
         whf, whr = _whh_from_pack(wpack)
-        _bwd_into(gates, cbuf, dhcat, whf, whr, sm)
+        _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt, dgates)
     return lstm_bwd
 
 
-def _bwd_into(gates, cbuf, dhcat, whf, whr, sm):
+def _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt=0, dgates=None):
+    """gfmt 0: fp32 gates in, d(gates) in place; 1 (H2): unorm16 gates in, bf16 d(gates) in place; 2 (H2S): unorm16 gates
+    in, d(gates) to `dgates` (fp32 here: the emulation does not model the split pair's 2^-17)."""
     nt, L = _ntile(sm), sm.L
-    act = bl_get(gates, nt, L, 2 * G4).reshape(nt * 32, L, 2, G4)
+    act = (gates_get_u16(gates, nt, L) if gfmt else bl_get(gates, nt, L, 2 * G4)).reshape(nt * 32, L, 2, G4)
     cs = bl_get(cbuf, nt, L, 2 * H).reshape(nt * 32, L, 2, H)
     dh = bl_get(dhcat, nt, L, 2 * H).reshape(nt * 32, L, 2, H)
-    dpre = _recur_bwd(act, cs, dh, whf, whr)
-    bl_put(gates, dpre.reshape(nt * 32, L, 2 * G4) * _valid(sm), nt, L, 2 * G4)
+    dpre = _recur_bwd(act, cs, dh, whf, whr).reshape(nt * 32, L, 2 * G4) * _valid(sm)
+    if gfmt == 1:
+        blh_put(dgates if dgates is not None else gates, dpre, nt, L, 2 * G4, torch.bfloat16)
+    else:
+        bl_put(dgates if gfmt == 2 else gates, dpre, nt, L, 2 * G4)
 
 
-def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm, status=None, dbg=0):
+def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm, status=None, dbg=0, gfmt=0, gates_in=None):
     """Returns the launch's timeout word like dev.lstm_fwd_cluster; dbg & 8 emulates a timeout: NaN-poisoned outputs
     and a set word, so the caller's predicated fall-back has to produce the result."""
     nt, L = _ntile(sm), sm.L
@@ -185,7 +231,8 @@ def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm, status=None, dbg=0):
         for t in (gates, cbuf, hcat):
             t.fill_(float("nan"))
         return torch.ones(1, dtype=torch.int32)
-    _fwd_into(gates, cbuf, hcat, bl_get(gates, nt, L, 2 * G4).reshape(nt * 32, L, 2, G4), whh_f, whh_r, sm)
+    src = gates_in if gfmt else gates
+    _fwd_into(gates, cbuf, hcat, bl_get(src, nt, L, 2 * G4).reshape(nt * 32, L, 2, G4), whh_f, whh_r, sm, gfmt)
     return torch.zeros(1, dtype=torch.int32)
 
 
@@ -197,29 +244,29 @@ def lstm_pack_pair(whh_f, whh_r, pack):
     pack.reshape(-1)[: 2 * G4 * H] = torch.stack([whh_f, whh_r]).reshape(-1)      # raw weights, like emu_dev.lstm_pack
 
 
-def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0):
+def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None, repairable=False):
     """Returns the launch's timeout word like dev.lstm_bwd_pair; dbg & 8 emulates the forced timeout (NaN-poisoned
     d(gates), both words set)."""
     if dbg & 8:
-        gates.fill_(float("nan"))
+        (dgates if dgates is not None else gates).fill_(float("nan"))
         if status is not None:
             status.fill_(1)
         return torch.ones(1, dtype=torch.int32)
-    _bwd_into(gates, cbuf, dhcat, *_whh_from_pack(wpack), sm)
+    _bwd_into(gates, cbuf, dhcat, *_whh_from_pack(wpack), sm, gfmt, dgates)
     return torch.zeros(1, dtype=torch.int32)
 
 
-def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm):
+def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm, gfmt=0):
     nt, L = _ntile(sm), sm.L
     wih_f, wih_r, whf, whr = _PACKS[wpack.data_ptr()]
     x = bl_get(xn, nt, L, 128)
     b = bias.reshape(2, G4)
     pre = torch.stack([x @ wih_f.t() + b[0], x @ wih_r.t() + b[1]], 2)
-    _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm)
+    _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt)
 
 
 def gemm_tnb(*, G, g_width, g_off, g_cols, A0, a0_width, a0_off, a0_cols, nblk, L_, slab, nsplit, blocks_per_split,
-             a0_shift=0, A1=None, a1_width=0, a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, dbg=0):
+             a0_shift=0, A1=None, a1_width=0, a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, g_fmt=0):
     nt = nblk // L_
 
     def shifted(buf, width, off, cols, shift):
@@ -232,7 +279,7 @@ def gemm_tnb(*, G, g_width, g_off, g_cols, A0, a0_width, a0_off, a0_cols, nblk, 
         else:
             out[:, -shift:] = x[:, : L_ + shift]
         return out
-    g = bl_get(G, nt, L_, g_width)[:, :, g_off:g_off + g_cols]
+    g = (blh_get(G, nt, L_, g_width, torch.bfloat16).float() if g_fmt else bl_get(G, nt, L_, g_width))[:, :, g_off:g_off + g_cols]
     a = shifted(A0, a0_width, a0_off, a0_cols, a0_shift)
     if A1 is not None:
         a = torch.cat([a, shifted(A1, a1_width, a1_off, a1_cols, a1_shift)], 2)

@@ -1,0 +1,255 @@
+"""GPU: the 2-byte storage formats of the saved recurrence state (include/wesep_hip.h WS_GATES_H2 / WS_GATES_H2S, ABI v15)
+against the fp32 format of the same kernels -- which tests/test_kernels_gpu.py holds to torch's LSTM.
+
+The formats change what is STORED, not what is computed, so the statements are exact wherever the arithmetic allows:
+  * forward (streaming 32 / 16 sequences, fused projection 32 / 64 sequences, cluster): cell state and h bit-identical to
+    the fp32-format launch; the unorm16 gate codes decode to the fp32 gates within half a code step;
+  * BPTT (streaming 32 / 16, pair) on gates that sit on the unorm16 grid: WS_GATES_H2S d(gates) bit-identical to the fp32
+    format's split pairs, WS_GATES_H2 d(gates) bit-identical to their hi terms (bf16, round to nearest even);
+  * ws_gemm_b2p (a_fmt 1) / ws_gemm_tnb (g_fmt 1) on bf16 operands: bit-identical to the split-pair kernels fed the same
+    values with a zero lo term, and within the split-product tolerance of fp64."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, N = 256, 128
+
+
+def _cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(g, *shape, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _setup(view, dims, seed, d):
+    from wesep_amd import dev
+    from wesep_amd.functional import _view_maps
+    g = torch.Generator().manual_seed(seed)
+    R, K, Tf = dims
+    P = R * K * Tf
+    geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+    nb = dev.bl_num_blocks(seq)
+    whf, whr = rnd(g, 4 * H, H, scale=0.06).to(d), rnd(g, 4 * H, H, scale=0.06).to(d)
+    pre = dev.to_blocked(rnd(g, P, 8 * H).to(d), seq)            # x-projection + biases, BL(2 * 4H) fp32
+    dh = dev.to_blocked(rnd(g, P, 2 * H).to(d), seq)
+    return seq, nb, P, whf, whr, pre, dh, g
+
+
+def _state(nb, d):
+    return (torch.full((nb, 2 * H // 4, 32, 4), float("nan"), device=d), torch.full((nb, 2 * H // 4, 32, 4), float("nan"), device=d))
+
+
+def _gates_h(nb, d):
+    from wesep_amd import dev
+    return torch.zeros(dev.blh_floats(nb, 8 * H), device=d)
+
+
+def _check_codes(gh, g32, nb):
+    """unorm16 codes decode to the fp32 gates within half a code step (+ one ulp of the fma)."""
+    from wesep_amd import dev
+    dec = dev.blh_gates_unpack(gh, nb)
+    Cq = 8 * H // 4
+    is_g = ((torch.arange(Cq, device=gh.device) >> 6) & 3 == 2).view(1, Cq, 1, 1)
+    step = torch.where(is_g, torch.tensor(1.0 / 32767.5, device=gh.device), torch.tensor(1.0 / 65535.0, device=gh.device))
+    err = ((dec - g32.view(nb, Cq, 32, 4)).abs() / step).max()
+    assert float(err) <= 0.5 + 1e-2, float(err)
+    return dec
+
+
+FWD_KINDS = ["blk32", "blk16", "fused32", "fused64", "cluster"]
+
+
+@pytest.mark.parametrize("kind", FWD_KINDS)
+@pytest.mark.parametrize("view,dims", [("time", (2, 32, 70)), ("band", (3, 7, 37))])
+def test_forward_kernels_store_unorm16_gates(kind, view, dims, monkeypatch):
+    from wesep_amd import _lib as L
+    from wesep_amd import dev
+    d = _cuda()
+    seq, nb, P, whf, whr, pre, dh, g = _setup(view, dims, 7, d)
+    if kind == "cluster" and not dev.lstm_cluster_ok(seq, d):
+        pytest.skip("cluster geometry")
+    c0, h0 = _state(nb, d)
+    c1, h1 = _state(nb, d)
+    g32, gh = pre.clone(), _gates_h(nb, d)
+    if kind in ("blk32", "blk16"):
+        mode = L.LSTM_BF16X3_BLK if kind == "blk32" else L.LSTM_BF16X3_BLK16
+        pf, pb = torch.empty(L.LSTM_PACK_FLOATS, device=d), torch.empty(L.LSTM_PACK_FLOATS, device=d)
+        dev.lstm_pack(whf, whr, pf, pb, mode)
+        dev.lstm_fwd(g32, c0, h0, pf, seq, mode)
+        dev.lstm_fwd(gh, c1, h1, pf, seq, mode, gfmt=L.GATES_H2, gates_in=pre)
+    elif kind == "cluster":
+        st = torch.zeros(1, device=d, dtype=torch.int32)
+        dev.lstm_fwd_cluster(g32, c0, h0, whf, whr, seq, status=st)
+        dev.lstm_fwd_cluster(gh, c1, h1, whf, whr, seq, status=st, gfmt=L.GATES_H2, gates_in=pre)
+        assert int(st.item()) == 0
+    else:
+        monkeypatch.setenv("WS_FUSED_SEQS", "64" if kind == "fused64" else "32")
+        wih_f, wih_r = rnd(g, 4 * H, N, scale=0.06).to(d), rnd(g, 4 * H, N, scale=0.06).to(d)
+        bias = rnd(g, 2 * 4 * H).to(d)
+        xn = dev.to_blocked(rnd(g, P, N).to(d), seq, split=True)
+        fp = torch.empty(L.LSTM_FUSED_PACK_FLOATS, device=d)
+        dev.lstm_pack_fused(wih_f, wih_r, whf, whr, fp)
+        g32 = torch.full_like(pre, float("nan"))
+        dev.lstm_fwd_fused(g32, c0, h0, xn, fp, bias, seq)
+        dev.lstm_fwd_fused(gh, c1, h1, xn, fp, bias, seq, gfmt=L.GATES_H2)
+    torch.cuda.synchronize()
+    assert not torch.isnan(c0).any() and not torch.isnan(h0).any()
+    assert torch.equal(c0, c1) and torch.equal(h0, h1)          # the arithmetic is the fp32 format's
+    _check_codes(gh, g32, nb)
+
+
+@pytest.mark.parametrize("kind", ["blk32", "blk16", "pair"])
+@pytest.mark.parametrize("view,dims", [("time", (2, 32, 70)), ("time", (3, 7, 37)), ("band", (4, 9, 16))])
+def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
+    from wesep_amd import _lib as L
+    from wesep_amd import dev
+    d = _cuda()
+    seq, nb, P, whf, whr, pre, dh, g = _setup(view, dims, 11, d)
+    if kind == "pair" and not dev.lstm_pair_ok(seq, d):
+        pytest.skip("pair geometry")
+    mode = L.LSTM_BF16X3_BLK16 if kind == "blk16" else L.LSTM_BF16X3_BLK
+    pf, pb = torch.empty(L.LSTM_PACK_FLOATS, device=d), torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack(whf, whr, pf, pb, mode)
+    cbuf, hcat = _state(nb, d)
+    gh = _gates_h(nb, d)
+    dev.lstm_fwd(gh, cbuf, hcat, pf, seq, mode, gfmt=L.GATES_H2, gates_in=pre)
+    gq = dev.blh_gates_unpack(gh, nb).view_as(pre).contiguous()   # the saved gates, on the unorm16 grid, as fp32
+    pp = torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack_pair(whf, whr, pp)
+    st = torch.zeros(1, device=d, dtype=torch.int32)
+
+    def bptt(gates, gfmt, dgates=None):
+        if kind == "pair":
+            tw = dev.lstm_bwd_pair(gates, cbuf, dh, pp, seq, status=st, gfmt=gfmt, dgates=dgates)
+            assert int(tw.item()) == 0
+        else:
+            dev.lstm_bwd(gates, cbuf, hcat, dh, pb, seq, mode, gfmt=gfmt, dgates=dgates)
+
+    ref = gq.clone()
+    bptt(ref, L.GATES_F32)                                        # split pairs, in place over fp32 gates
+    h2s_g, h2s_d = gh.clone(), torch.full_like(pre, float("nan"))
+    bptt(h2s_g, L.GATES_H2S, h2s_d)
+    h2 = gh.clone()
+    bptt(h2, L.GATES_H2)
+    h2b = gh.clone()
+    bptt(h2b, L.GATES_H2)
+    torch.cuda.synchronize()
+    assert int(st.item()) == 0
+    assert torch.equal(h2s_g, gh)                                 # H2S leaves the saved gates alone
+    assert torch.equal(h2s_d.view(torch.int32), ref.view(torch.int32))
+    hi = (ref.contiguous().view(torch.int32) >> 16).to(torch.int16)           # bf16 hi terms of the split pairs
+    got = h2.reshape(-1)[: ref.numel() // 2].view(torch.int16).view(hi.shape)
+    assert torch.equal(got, hi)
+    assert torch.equal(h2, h2b)                                   # deterministic
+    assert float(dev.bls_unpack(ref).abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37))])
+def test_gemm_b2p_bf16_operand(view, dims):
+    from wesep_amd import dev
+    from wesep_amd.functional import _view_maps
+    d = _cuda()
+    g = torch.Generator().manual_seed(4)
+    R, K, Tf = dims
+    P, Kd = R * K * Tf, 2048
+    geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+    nb = dev.bl_num_blocks(seq)
+    A = rnd(g, P, Kd).to(torch.bfloat16).float()                  # values on the bf16 grid
+    W = rnd(g, N, Kd, scale=0.05)
+    wp = torch.empty(N * Kd, device=d)
+    dev.pack_w(W.t().contiguous().to(d), N, Kd, N, wp, trans=True, order=1)
+    Abl = dev.to_blocked(A.to(d), seq)                            # BL-shaped fp32 (exact bf16 values)
+    C_ref, C_new = torch.full((P, N), float("nan"), device=d), torch.full((P, N), float("nan"), device=d)
+    dev.gemm_b2p(A=dev.bls_pack(Abl), K=Kd, sm=seq, Wpack=wp, C_out=C_ref, ldc=N)          # lo terms are zero
+    dev.gemm_b2p(A=dev.blh_bf16_pack(Abl), K=Kd, sm=seq, Wpack=wp, C_out=C_new, ldc=N, a_fmt=1)
+    torch.cuda.synchronize()
+    assert torch.equal(C_ref, C_new)
+    assert rel(C_new, A.double() @ W.double().t()) < 4e-5
+
+
+@pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37)), ("time", (2, 32, 70))])
+def test_gemm_tnb_bf16_g_operand(view, dims):
+    """[dW_ih | dW_hh | db] form with G = d(gates) as bf16 (BLH): both directions' column ranges, A1 shifted by one step."""
+    from wesep_amd import dev
+    from wesep_amd.functional import _view_maps
+    d = _cuda()
+    g = torch.Generator().manual_seed(5)
+    R, K, Tf = dims
+    P, GW = R * K * Tf, 2048
+    geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+    nb = dev.bl_num_blocks(seq)
+    G = rnd(g, P, GW).to(torch.bfloat16).float()
+    A0, A1 = rnd(g, P, N), rnd(g, P, 2 * H)
+    Gbl = dev.to_blocked(G.to(d), seq)
+    A0b, A1b = dev.to_blocked(A0.to(d), seq, split=True), dev.to_blocked(A1.to(d), seq, split=True)
+    G_pairs, G_bf16 = dev.bls_pack(Gbl), dev.blh_bf16_pack(Gbl)
+    for di, shift in ((0, -1), (1, 1)):
+        ns, bps = dev.tnb_splits(nb, 8)
+        outs = []
+        for Gbuf, fmt in ((G_pairs, 0), (G_bf16, 1), (G_bf16, 1)):
+            slab, bslab = torch.full((ns, 1024 * 384), float("nan"), device=d), torch.full((ns, 1024), float("nan"), device=d)
+            dev.gemm_tnb(G=Gbuf, g_width=GW, g_off=di * 1024, g_cols=1024, A0=A0b, a0_width=N, a0_off=0, a0_cols=N,
+                         A1=A1b, a1_width=2 * H, a1_off=di * H, a1_cols=H, a1_shift=shift, nblk=nb, L_=seq.L,
+                         slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab, g_fmt=fmt)
+            outs.append((slab, bslab))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][0], outs[1][0])                # same products, same order: the zero lo terms add nothing
+        assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
+        assert rel(outs[1][1].sum(0), outs[0][1].sum(0)) < 1e-6   # column sums: pairs of slots per dot2 instead of (hi, lo)
+        assert rel(outs[1][1].sum(0), G[:, di * 1024:(di + 1) * 1024].double().sum(0)) < 1e-5
+        # against fp64 with the step shift of A1 (as in tests/test_kernels_gpu.py::test_gemm_tnb_vs_torch)
+        pos, valid = dev.bl_positions(seq, torch.device("cpu"))
+        nt = -(-seq.nseq // 32)
+        posv, val = pos.view(nt, seq.L, 32), valid.view(nt, seq.L, 32)
+        A1s = torch.zeros(P, H)
+        src = torch.roll(posv, shifts=-shift, dims=1)
+        ok = val.clone()
+        if shift == -1:
+            ok[:, 0] = False
+        else:
+            ok[:, -1] = False
+        A1s[posv[ok]] = A1[src[ok]][:, di * H:(di + 1) * H]
+        Gs = G[:, di * 1024:(di + 1) * 1024].double()
+        ref = torch.cat([Gs.t() @ A0.double(), Gs.t() @ A1s.double()], 1)
+        assert rel(outs[1][0].sum(0).view(1024, 384), ref) < 4e-5
+
+
+@pytest.mark.parametrize("fmt", ["f32", "h2s", "h2"])
+@pytest.mark.parametrize("view", ["time", "band"])
+def test_resrnn_formats_agree(view, fmt, monkeypatch):
+    """One ResRNN (functional.ResRNNBlkFn) at a geometry that takes the production kernels (time view: cluster forward +
+    pair BPTT; band view: fused forward + streaming BPTT) in each storage format: same output bits; gradients of the 2-byte
+    formats against the fp32 format."""
+    from wesep_amd.models.bsrnn import ResRNN
+    d = _cuda()
+    torch.manual_seed(5)
+    R, K, Tf = (2, 32, 70) if view == "time" else (4, 4, 530)      # band: 2 120 sequences -> the fused 32-sequence forward
+    blk = ResRNN(N, 2 * N).to(d)
+    z = torch.randn(R, K, Tf, N, device=d)
+    go = torch.randn(R, K, Tf, N, device=d)
+    res = {}
+    for f in ("f32", fmt):
+        monkeypatch.setenv("WESEP_GATES", f)
+        for p in blk.parameters():
+            p.grad = None
+        zd = z.clone().requires_grad_(True)
+        out = blk(zd, view)
+        out.backward(go)
+        torch.cuda.synchronize()
+        res[f] = (out.detach().clone(), zd.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()})
+    a, b = res["f32"], res[fmt]
+    assert torch.equal(a[0], b[0])
+    tol = {"f32": 0.0, "h2s": 5e-5, "h2": 3e-3}[fmt]
+    assert rel(b[1], a[1]) <= tol
+    for k in a[2]:
+        assert rel(b[2][k], a[2][k]) <= tol, k

@@ -33,12 +33,19 @@ def _params(seed):
     return {k: v.requires_grad_(True) for k, v in p.items()}
 
 
+# storage format of the saved gates / d(gates) (wesep_hip.h WS_GATES_*) -> tolerance of the gradients: the fp32 format is
+# exact in the emulation; unorm16 gates cost ~1e-5; bf16 d(gates) (H2, the default) 2^-9 per element of d(gates)
+GATE_FORMATS = [("f32", 2e-4), ("h2s", 2e-4), ("h2", 3e-3)]
+
+
+@pytest.mark.parametrize("fmt,gtol", GATE_FORMATS)
 @pytest.mark.parametrize("view,R,K,Tf,branch", [
     ("time", 1, 3, 9, "16-sequence"), ("time", 2, 32, 66, "cluster"), ("band", 2, 4, 5, "16-sequence"),
     ("band", 2, 3, 2100, "fused projection")])
-def test_resrnn_blocked_matches_oracle(emu, view, R, K, Tf, branch):
+def test_resrnn_blocked_matches_oracle(emu, monkeypatch, view, R, K, Tf, branch, fmt, gtol):
     from wesep_amd import dev
     from wesep_amd import functional as F0
+    monkeypatch.setenv("WESEP_GATES", fmt)
     p = _params(R * 100 + K)
     g = torch.Generator().manual_seed(Tf)
     z = torch.randn(R, K, Tf, 128, generator=g).requires_grad_(True)
@@ -62,7 +69,7 @@ def test_resrnn_blocked_matches_oracle(emu, view, R, K, Tf, branch):
     assert float((out - ref).norm() / ref.norm()) < 1e-5
     want = {"z": z.grad, **{k: v.grad for k, v in p.items()}}
     for k in want:
-        assert float((got[k] - want[k]).norm()) <= 2e-4 * float(want[k].norm()) + 1e-6, k
+        assert float((got[k] - want[k]).norm()) <= gtol * float(want[k].norm()) + 1e-6, k
 
 
 def _oracle_time(p, z, R, K, Tf):

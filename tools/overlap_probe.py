@@ -45,7 +45,7 @@ TNB_DBG = 0
 
 
 def tnb():
-    dev.gemm_tnb(dbg=TNB_DBG, G=Gb, g_width=2048, g_off=0, g_cols=1024, A0=xn, a0_width=128, a0_off=0, a0_cols=128,
+    dev.gemm_tnb(G=Gb, g_width=2048, g_off=0, g_cols=1024, A0=xn, a0_width=128, a0_off=0, a0_cols=128,
                  A1=hcat, a1_width=512, a1_off=0, a1_cols=256, a1_shift=-1, nblk=nb, L_=seq.L,
                  slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab)
 

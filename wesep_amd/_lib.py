@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 14
+ABI_VERSION = 15
+GATES_F32, GATES_H2, GATES_H2S = 0, 1, 2     # WS_GATES_* (wesep_hip.h): storage of the saved gates / d(gates)
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
@@ -77,7 +78,8 @@ class GroupsGeom(C.Structure):
 class LstmArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "dhcat", "wpack")] + \
                [(n, _ll) for n in ("sq_s1", "sq_s2", "step_rows")] + \
-               [(n, _i) for n in ("nseq", "sq_div", "L", "mode")] + [("run_if", _p)]
+               [(n, _i) for n in ("nseq", "sq_div", "L", "mode")] + [("run_if", _p)] + \
+               [("gates_in", _p), ("dgates", _p), ("gfmt", _i), ("pad_", _i)]          # ABI v15
 
 
 class SeqMapC(C.Structure):
@@ -91,7 +93,8 @@ class GemmP2BArgs(C.Structure):
 
 
 class GemmB2PArgs(C.Structure):
-    _fields_ = [(n, _p) for n in ("A", "Wpack", "bias", "R", "C")] + [("sm", SeqMapC), ("ldc", _ll), ("N", _i), ("K", _i)]
+    _fields_ = [(n, _p) for n in ("A", "Wpack", "bias", "R", "C")] + [("sm", SeqMapC), ("ldc", _ll), ("N", _i), ("K", _i),
+                                                                         ("a_fmt", _i), ("pad_", _i)]
 
 
 class GemmTNBArgs(C.Structure):
@@ -99,17 +102,17 @@ class GemmTNBArgs(C.Structure):
                [(n, _ll) for n in ("slab_stride", "bslab_stride", "aslab_stride")] + \
                [(n, _i) for n in ("g_width", "g_off", "g_cols", "a0_width", "a0_off", "a0_cols", "a0_shift",
                                   "a1_width", "a1_off", "a1_cols", "a1_shift", "nblk", "L", "nsplit",
-                                  "blocks_per_split", "pad_")]
+                                  "blocks_per_split", "g_fmt")]
 
 
 class LstmClusterArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "dhcat", "whh_f", "whh_r", "xchg", "flags", "status")] + \
-               [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i)]
+               [("nseq", _i), ("L", _i), ("dbg", _i), ("gfmt", _i), ("gates_in", _p)]
 
 
 class LstmPairArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "dhcat", "wpack", "xchg", "flags", "status", "dbg_buf")] + \
-               [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i)]
+               [("nseq", _i), ("L", _i), ("dbg", _i), ("gfmt", _i), ("dgates", _p)]
 
 
 class Bands(C.Structure):
@@ -129,7 +132,7 @@ assert GROUP_NT_DTYPE.itemsize == 72 and GROUP_TN_DTYPE.itemsize == 72 and TENSO
 
 class LstmFusedArgs(C.Structure):
     _fields_ = [("gates", _p), ("cbuf", _p), ("hcat", _p), ("xn", _p), ("wpack", _p), ("bias", _p),
-                ("nseq", _i), ("L", _i)]
+                ("nseq", _i), ("L", _i), ("gfmt", _i), ("pad_", _i)]
 
 
 LSTM_FUSED_PACK_FLOATS = 2 * 8 * 24 * 4 * 2 * 64 * 4
@@ -140,6 +143,7 @@ _SIGS = {
     "ws_prof_enable": (_i, [_i]),
     "ws_prof_collect": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_ll)]),
     "ws_debug_dirty_lds": (_i, [_f, _i, _i, _p, _p]),
+    "ws_debug_occupy": (_i, [_i, _i, _p, _p, _p]),
     "ws_gemm_nt": (_i, [C.POINTER(GemmNTArgs), _p]),
     "ws_gemm_tn": (_i, [C.POINTER(GemmTNArgs), _p]),
     "ws_reduce_slabs": (_i, [_p, _i, _ll, _ll, _p, _i, _ll, _p]),
@@ -234,8 +238,8 @@ _SIGS = {
     "ws_log_eps": (_i, [_p, _ll, C.c_float, _p]),
     "ws_lstm_pack_fused": (_i, [_p, _p, _p, _p, _p, _p]),
     "ws_lstm_fwd_fused": (_i, [C.POINTER(LstmFusedArgs), _p]),
-    "ws_grad_norms": (_i, [_p, _i, _p, _p]),
-    "ws_clip_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p]),
+    "ws_grad_norms": (_i, [_p, _i, _p, _p, _p]),
+    "ws_clip_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p, _p, _p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -194,8 +194,12 @@ extern "C" int ws_sisdr_bwd(const float* est, const float* tgt, const float* row
 #define MT_CHUNK 16384  // elements per workgroup pass
 
 // one workgroup per tensor: norms[i] = ||grad_i||_2   (largest tensor 262144 elements)
+// guard (optional, two words): both are set to 1 when a norm is not finite -- a NaN / Inf gradient anywhere in the tensor.
+// The caller zeroes guard[0] before the launch and hands it to ws_clip_adam_step as a skip word, so a poisoned gradient
+// (a BPTT launch whose bounded wait timed out, on this rank or -- through the all-reduce -- on any rank) never reaches
+// the weights; guard[1] is sticky, for the host's asynchronous bookkeeping
 __global__ __launch_bounds__(1024) void grad_norms_kernel(const ws_tensor_ref* __restrict__ tab,
-                                                          float* __restrict__ norms) {
+                                                          float* __restrict__ norms, unsigned* __restrict__ guard) {
   __shared__ float red[16];
   const ws_tensor_ref t = tab[blockIdx.x];
   float s = 0.f;
@@ -206,12 +210,16 @@ __global__ __launch_bounds__(1024) void grad_norms_kernel(const ws_tensor_ref* _
     }
   }
   s = ws_block_sum(s, red);
-  if (threadIdx.x == 0) norms[blockIdx.x] = sqrtf(s);
+  if (threadIdx.x == 0) {
+    const float n = sqrtf(s);
+    norms[blockIdx.x] = n;
+    if (guard && !(fabsf(n) <= 3.4028234e38f)) guard[0] = guard[1] = 1u;  // NaN or Inf (plain stores: every writer writes 1)
+  }
 }
 
-extern "C" int ws_grad_norms(const ws_tensor_ref* tab, int ntensors, float* norms, void* stream) {
+extern "C" int ws_grad_norms(const ws_tensor_ref* tab, int ntensors, float* norms, unsigned* guard, void* stream) {
   WS_REQUIRE(tab && norms && ntensors > 0, "ws_grad_norms: bad args");
-  hipLaunchKernelGGL(grad_norms_kernel, dim3(ntensors), dim3(1024), 0, (hipStream_t)stream, tab, norms);
+  hipLaunchKernelGGL(grad_norms_kernel, dim3(ntensors), dim3(1024), 0, (hipStream_t)stream, tab, norms, guard);
   return ws_check_launch("ws_grad_norms");
 }
 
@@ -220,7 +228,12 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ws_tensor_ref* __r
                                                         const float* __restrict__ norms, float clip,
                                                         float lr, float beta1, float beta2,
                                                         float eps, float wd, float bc1,
-                                                        float bc2_sqrt, int clip_only) {
+                                                        float bc2_sqrt, int clip_only,
+                                                        const unsigned* __restrict__ skip0,
+                                                        const unsigned* __restrict__ skip1) {
+  // skip words (optional device words, read at kernel start; uniform): the whole launch does nothing when one of them is
+  // non-zero -- the non-finite-gradient guard of ws_grad_norms, the sticky status word of an in-place BPTT time-out
+  if ((skip0 && *skip0 != 0u) || (skip1 && *skip1 != 0u)) return;
   const ws_tensor_ref t = tab[blockIdx.x];
   if (!t.grad) return;
   float coef = 1.f;
@@ -247,7 +260,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ws_tensor_ref* __r
 
 extern "C" int ws_clip_adam_step(const ws_tensor_ref* tab, int ntensors, const float* norms,
                                  float clip, float lr, float beta1, float beta2, float eps,
-                                 float weight_decay, int step, int clip_only, void* stream) {
+                                 float weight_decay, int step, int clip_only, const unsigned* skip0,
+                                 const unsigned* skip1, void* stream) {
   WS_REQUIRE(tab && ntensors > 0, "ws_clip_adam_step: bad args");
   WS_REQUIRE(clip <= 0.f || norms, "ws_clip_adam_step: clip needs norms");
   WS_REQUIRE(clip_only || step >= 1, "ws_clip_adam_step: step must be >= 1");
@@ -255,6 +269,6 @@ extern "C" int ws_clip_adam_step(const ws_tensor_ref* tab, int ntensors, const f
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(ntensors, 16), dim3(256), 0, (hipStream_t)stream, tab,
                      norms, clip, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-                     (float)sqrt(bc2), clip_only);
+                     (float)sqrt(bc2), clip_only, skip0, skip1);
   return ws_check_launch("ws_clip_adam_step");
 }

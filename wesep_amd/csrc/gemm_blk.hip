@@ -17,6 +17,8 @@
 // [32 slots x 128 columns] sub-block is one contiguous 16 KB.  Products are split-bf16 (hi/lo,
 // 3 MFMAs, fp32 accumulate) on v_mfma_f32_32x32x16_bf16; weights are pre-split and pre-ordered
 // into fragment order by ws_pack_w.
+#include <type_traits>
+
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -253,6 +255,10 @@ extern "C" int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream) {
 // stage) are shared through LDS.  Output orientation D[m = slot][n = column]: a 32-lane group
 // writes one full 128-byte row segment per register.
 // ---------------------------------------------------------------------------------------------
+// A16 (a_fmt = 1, ABI v15): A holds bf16 elements in BLH(K) -- d(gates) of WS_GATES_H2: a lane's 8 consecutive k are two
+// 8-byte cells = the hi fragment itself; no lo term, two MFMAs per product instead of three, half the A bytes.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <bool A16>
 __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args p) {
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][2048];
   __shared__ long long posl[8][32];
@@ -268,17 +274,20 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
     if (half == 0) posl[w][i] = valid ? pos : -1;
   }
   const int K = p.K, nstage = K / 64;
-  // A-operand source: cell (quad, slot) of block bb; lane reads quads 4ks + 2half, +1
-  const float* ab = p.A + (long long)bb * 32 * K + i * 4 + 2 * half * 128;
+  // A-operand source: cell (quad, slot) of block bb; lane reads quads 4ks + 2half, +1 (cell = 16 B, A16: 8 B; `ab` in
+  // units of half a cell-element pair: floats for BLS, 2-byte elements viewed through the same index formula for A16)
+  typedef typename std::conditional<A16, u32x2, f32x4>::type acell;
+  typedef typename std::conditional<A16, unsigned short, float>::type aelem;
+  const aelem* ab = reinterpret_cast<const aelem*>(p.A) + (long long)bb * 32 * K + i * 4 + 2 * half * 128;
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.Wpack);
   u32x4 wreg[4];
-  f32x4 an[8];  // next stage's activations (4 k-steps x 2 cells)
+  acell an[8];  // next stage's activations (4 k-steps x 2 cells)
 #pragma unroll
   for (int q = 0; q < 4; ++q) wreg[q] = wsrc[tid + 512 * q];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    an[2 * ks] = *reinterpret_cast<const f32x4*>(ab + (4 * ks) * 128);
-    an[2 * ks + 1] = *reinterpret_cast<const f32x4*>(ab + (4 * ks + 1) * 128);
+    an[2 * ks] = *reinterpret_cast<const acell*>(ab + (4 * ks) * 128);
+    an[2 * ks + 1] = *reinterpret_cast<const acell*>(ab + (4 * ks + 1) * 128);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) wl[0][tid + 512 * q] = wreg[q];
@@ -292,30 +301,35 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
 
   for (int st = 0; st < nstage; ++st) {
     const int cur = st & 1;
-    f32x4 ac[8];
+    acell ac[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) ac[q] = an[q];
     if (st + 1 < nstage) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) wreg[q] = wsrc[(long long)(st + 1) * 2048 + tid + 512 * q];
-      const float* a2 = ab + (long long)(st + 1) * 16 * 128;  // 16 quads per stage
+      const aelem* a2 = ab + (long long)(st + 1) * 16 * 128;  // 16 quads per stage
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        an[2 * ks] = *reinterpret_cast<const f32x4*>(a2 + (4 * ks) * 128);
-        an[2 * ks + 1] = *reinterpret_cast<const f32x4*>(a2 + (4 * ks + 1) * 128);
+        an[2 * ks] = *reinterpret_cast<const acell*>(a2 + (4 * ks) * 128);
+        an[2 * ks + 1] = *reinterpret_cast<const acell*>(a2 + (4 * ks + 1) * 128);
       }
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 ah, al;  // A arrives as split pairs (BLS): h from the recurrences, d(gates) from BPTT
-      unpack8(__builtin_bit_cast(u32x4, ac[2 * ks]), __builtin_bit_cast(u32x4, ac[2 * ks + 1]), ah, al);
+      bf16x8 ah, al;  // A arrives as split pairs (BLS): h from the recurrences, d(gates) from BPTT -- or as bf16 (A16)
+      if constexpr (A16) {
+        const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ks]), c1 = __builtin_bit_cast(u32x2, ac[2 * ks + 1]);
+        ah = __builtin_bit_cast(bf16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
+      } else {
+        unpack8(__builtin_bit_cast(u32x4, ac[2 * ks]), __builtin_bit_cast(u32x4, ac[2 * ks + 1]), ah, al);
+      }
       const u32x4* wt = &wl[cur][ks * 512 + lane];  // [nt][part][lane]
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const bf16x8 bh = __builtin_bit_cast(bf16x8, wt[(nt * 2) * 64]);
         const bf16x8 bl = __builtin_bit_cast(bf16x8, wt[(nt * 2 + 1) * 64]);
         acc[nt] = mfma32(ah, bh, acc[nt]);
-        acc[nt] = mfma32(al, bh, acc[nt]);
+        if constexpr (!A16) acc[nt] = mfma32(al, bh, acc[nt]);
         acc[nt] = mfma32(ah, bl, acc[nt]);
       }
     }
@@ -370,13 +384,17 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
 extern "C" int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream) {
   WS_REQUIRE(a && a->A && a->Wpack && a->C, "ws_gemm_b2p: null pointer");
   WS_REQUIRE(a->N == 128, "ws_gemm_b2p: N must be 128 (got %d)", a->N);
+  WS_REQUIRE(a->a_fmt == 0 || a->a_fmt == 1, "ws_gemm_b2p: a_fmt %d", a->a_fmt);
   WS_REQUIRE(a->K > 0 && a->K % 64 == 0, "ws_gemm_b2p: K %% 64 (K=%d)", a->K);
   WS_REQUIRE(a->ldc >= a->N && a->ldc % 4 == 0, "ws_gemm_b2p: ldc >= N and ldc %% 4 == 0 (16-byte row pieces)");
   WS_REQUIRE(a->sm.nseq > 0 && a->sm.L > 0 && a->sm.sq_div > 0, "ws_gemm_b2p: bad sequence map");
   const int nblk = ((a->sm.nseq + 31) / 32) * a->sm.L;
   hipStream_t s = (hipStream_t)stream;
   ws_prof_begin(WS_PROF_GEMM_NT, s);
-  hipLaunchKernelGGL(gemm_b2p_kernel, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
+  if (a->a_fmt)
+    hipLaunchKernelGGL(gemm_b2p_kernel<true>, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
+  else
+    hipLaunchKernelGGL(gemm_b2p_kernel<false>, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
   ws_prof_end(WS_PROF_GEMM_NT, s);
   return ws_check_launch("ws_gemm_b2p");
 }
@@ -606,6 +624,223 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// tnb with G as bf16 elements in BLH (g_fmt = 1, ABI v15: d(gates) of WS_GATES_H2), A columns = 384 ([xn | h]).
+// Same tiling, LDS images and MFMA schedule as gemm_tnb_kernel<3, .>; what changes:
+//   * the G tile of a block is 8 KB instead of 16: every thread loads ONE 16-byte piece (quad tid >> 4, slots
+//     2 (tid & 15), + 1), separates its four columns with four v_perm_b32 and writes each as one bf16 pair; there is no lo
+//     plane of G, so a product is two MFMAs (G_hi A_hi + G_hi A_lo) instead of three;
+//   * the three A tiles (768 groups of 64 B) are spread as one whole group per thread (tiles 0 and 1) plus one half group
+//     (2 slots, tile 2): 112 bytes and 7 loads per thread and block instead of 128 / 8.
+// ---------------------------------------------------------------------------------------------
+template <bool ASUM>
+__global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_args p) {
+  constexpr int TA = 3, TN = 3;
+  constexpr int NCOL = 128 * (1 + TA);
+  constexpr int PLANE = NCOL * TB_LD;
+  __shared__ __attribute__((aligned(16))) __bf16 ldsA[2 * PLANE];
+  __shared__ __attribute__((aligned(16))) __bf16 ldsB[2 * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const int gt = blockIdx.y, split = blockIdx.x;
+  const int L = p.L;
+  const int b_begin = split * p.blocks_per_split;
+  const int b_end = min(p.nblk, b_begin + p.blocks_per_split);
+
+  // ---- G piece: quad qg of the tile, slots 2 sp and 2 sp + 1 (two 8-byte cells, adjacent) ----
+  const int qg = tid >> 4, sp = tid & 15;
+  const unsigned short* gsrc = reinterpret_cast<const unsigned short*>(p.G) +
+                               ((long long)((p.g_off + gt * 128) / 4 + qg) * 32 + 2 * sp) * 4;
+  const long long gstep = 32LL * p.g_width;  // 2-byte elements per block
+  // ---- A pieces: r = 0: whole group tid of tiles 0 / 1; r = 1: half group (tid >> 1, slots 2 (tid & 1) ..) of tile 2 ----
+  const float* abase[2];
+  long long astride[2];
+  int ashift[2], acol[2], aslot[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int g = r == 0 ? tid : 512 + (tid >> 1);
+    const int tile = g >> 8, quad = (g >> 3) & 31, sg = g & 7;
+    const int c0 = tile * 128;  // first column of this A tile in Acat
+    const bool s1 = c0 >= p.a0_cols;
+    const float* base = s1 ? p.A1 : p.A0;
+    const int off = s1 ? p.a1_off + c0 - p.a0_cols : p.a0_off + c0;
+    aslot[r] = 4 * sg + (r == 1 ? 2 * (tid & 1) : 0);
+    abase[r] = base + (long long)(off / 4 + quad) * 128 + aslot[r] * 4;
+    astride[r] = 32LL * (s1 ? p.a1_width : p.a0_width);
+    ashift[r] = s1 ? p.a1_shift : p.a0_shift;
+    acol[r] = 128 + c0 + 4 * quad;
+  }
+
+  u32x4 gq[2];        // two blocks in flight
+  f32x4 aq[2][6];     // [slot][4 cells of r = 0, 2 cells of r = 1]
+  bool use[2][2];
+  auto load_block = [&](int b, int slot) {
+    const int tile = b / L, step = b - tile * L;
+    gq[slot] = *reinterpret_cast<const u32x4*>(gsrc + (long long)b * gstep);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int sa = step + ashift[r];
+      use[slot][r] = sa >= 0 && sa < L;
+      const float* src = abase[r] + (long long)(use[slot][r] ? b + ashift[r] : b) * astride[r];
+#pragma unroll
+      for (int j = 0; j < (r == 0 ? 4 : 2); ++j) aq[slot][4 * r + j] = *reinterpret_cast<const f32x4*>(src + 4 * j);
+    }
+  };
+  float gsum[4] = {0.f, 0.f, 0.f, 0.f}, asum[2][4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) asum[r][c] = 0.f;
+  // pieces of a block: pc 0..3 = column pc of the whole A group, 4..7 = column pc - 4 of the half group, 8..9 = the G
+  // columns (0, 1) / (2, 3).  live = 0: tail iteration, the column sums stay untouched
+  auto store_piece = [&](int slot, __bf16* lds, unsigned live, int pc) {
+    const bf16x2 ones = __builtin_bit_cast(bf16x2, live);  // 0x3f803f80 = (1, 1)
+    if (pc >= 8) {
+      const u32x4 d = gq[slot];
+      const unsigned lo_ = pc == 8 ? d[0] : d[1], hi_ = pc == 8 ? d[2] : d[3];  // slot 2sp / slot 2sp + 1
+      const unsigned c_even = __builtin_amdgcn_perm(hi_, lo_, WS_SEL_LO16), c_odd = __builtin_amdgcn_perm(hi_, lo_, WS_SEL_HI16);
+      const int col = 4 * qg + 2 * (pc - 8);
+      *reinterpret_cast<unsigned*>(lds + col * TB_LD + 2 * sp) = c_even;
+      *reinterpret_cast<unsigned*>(lds + (col + 1) * TB_LD + 2 * sp) = c_odd;
+      gsum[2 * (pc - 8)] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, c_even), ones, gsum[2 * (pc - 8)], false);
+      gsum[2 * (pc - 8) + 1] =
+          __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, c_odd), ones, gsum[2 * (pc - 8) + 1], false);
+      return;
+    }
+    const int r = pc >> 2, c = pc & 3;
+    const unsigned m = use[slot][r] ? 0xffffffffu : 0u;  // uniform: the shifted operand at the sequence ends
+    unsigned e[4];
+#pragma unroll
+    for (int j = 0; j < (r == 0 ? 4 : 2); ++j) {
+      const float f = aq[slot][4 * r + j][c];  // (bit_cast of a vector-element lvalue reads element 0 with this compiler)
+      e[j] = __float_as_uint(f) & m;
+    }
+    if (ASUM) {
+#pragma unroll
+      for (int j = 0; j < (r == 0 ? 4 : 2); ++j)
+        asum[r][c] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, e[j]), ones, asum[r][c], false);
+    }
+    const int o = (acol[r] + c) * TB_LD + aslot[r];
+    if (r == 0) {
+      uint2 hi, lo;
+      hi.x = __builtin_amdgcn_perm(e[1], e[0], WS_SEL_HI16);
+      hi.y = __builtin_amdgcn_perm(e[3], e[2], WS_SEL_HI16);
+      lo.x = __builtin_amdgcn_perm(e[1], e[0], WS_SEL_LO16);
+      lo.y = __builtin_amdgcn_perm(e[3], e[2], WS_SEL_LO16);
+      *reinterpret_cast<uint2*>(lds + o) = hi;
+      *reinterpret_cast<uint2*>(lds + PLANE + o) = lo;
+    } else {
+      *reinterpret_cast<unsigned*>(lds + o) = __builtin_amdgcn_perm(e[1], e[0], WS_SEL_HI16);
+      *reinterpret_cast<unsigned*>(lds + PLANE + o) = __builtin_amdgcn_perm(e[1], e[0], WS_SEL_LO16);
+    }
+  };
+  constexpr int NPC = 10;
+  auto store_block = [&](int slot, __bf16* lds, unsigned live) {
+#pragma unroll
+    for (int pc = 0; pc < NPC; ++pc) store_piece(slot, lds, live, pc);
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int f = 0; f < TN; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+
+  const int nb = b_end - b_begin;
+  if (nb > 0) {
+    load_block(b_begin, 0);
+    load_block(min(b_begin + 1, b_end - 1), 1);
+    store_block(0, ldsA, 0x3f803f80u);
+  }
+  __syncthreads();
+  for (int ib = 0; ib < nb; ib += 2) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int i = ib + s;
+      if (i < nb) {  // uniform; only the odd tail skips
+        load_block(b_begin + min(i + 2, nb - 1), s);
+        __builtin_amdgcn_sched_barrier(0);
+        const __bf16* lds = s ? ldsB : ldsA;
+        __bf16* ldsw = s ? ldsA : ldsB;
+        const unsigned live = i + 1 < nb ? 0x3f803f80u : 0u;
+        auto lda = [&](int ks, int f, bf16x8& h, bf16x8& l) {
+          const int ra = (128 + wn * 32 * TN + f * 32 + l31) * TB_LD + ks + 8 * half;
+          h = *reinterpret_cast<const bf16x8*>(lds + ra);
+          l = *reinterpret_cast<const bf16x8*>(lds + PLANE + ra);
+        };
+        bf16x8 ah, al, ahn, aln;
+        lda(0, 0, ah, al);
+        int sub = 0;
+#pragma unroll
+        for (int ks = 0; ks < 32; ks += 16) {
+          bf16x8 gh[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            gh[e] = *reinterpret_cast<const bf16x8*>(lds + (wm * 64 + e * 32 + l31) * TB_LD + ks + 8 * half);
+#pragma unroll
+          for (int f = 0; f < TN; ++f) {
+            const bool last = ks == 16 && f == TN - 1;
+#pragma unroll
+            for (int term = 0; term < 2; ++term, ++sub) {
+              if (term == 0 && !last) lda(f + 1 < TN ? ks : 16, f + 1 < TN ? f + 1 : 0, ahn, aln);
+#pragma unroll
+              for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(gh[e], term == 1 ? al : ah, acc[e][f]);
+              if (sub < NPC) store_piece(s ^ 1, ldsw, live, sub);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            ah = ahn; al = aln;
+          }
+        }
+        __syncthreads();  // image s fully read, image s^1 fully written
+      }
+    }
+  }
+
+  const int ncols = p.a0_cols + p.a1_cols;
+  float* out = p.slab + (long long)split * p.slab_stride;
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int f = 0; f < TN; ++f) {
+      const int ac_ = wn * 32 * TN + f * 32 + l31;
+      if (ac_ < ncols) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int grow = gt * 128 + wm * 64 + e * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          out[(long long)grow * ncols + ac_] = acc[e][f][r];
+        }
+      }
+    }
+  // column sums of G (bias gradient): over the 16 slot pairs of a quad = lanes sharing tid >> 4
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float t = gsum[c];
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    t += __shfl_xor(t, 4, 64);
+    t += __shfl_xor(t, 8, 64);
+    if (p.bslab && sp == 0) p.bslab[(long long)split * p.bslab_stride + gt * 128 + 4 * qg + c] = t;
+  }
+  if (ASUM && gt == 0 && p.aslab) {  // column sums of Acat: whole groups over the 8 slot groups, half groups over 16 halves
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float t = asum[r][c];
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        if (r == 1) t += __shfl_xor(t, 8, 64);
+        const bool first = r == 0 ? (tid & 7) == 0 : (tid & 15) == 0;
+        if (first) p.aslab[(long long)split * p.aslab_stride + acol[r] - 128 + c] = t;
+      }
+  }
+}
+
 extern "C" int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream) {
   WS_REQUIRE(a && a->G && a->A0 && a->slab, "ws_gemm_tnb: null pointer");
   WS_REQUIRE(a->g_cols > 0 && a->g_cols % 128 == 0 && a->g_off % 4 == 0 && a->g_width % 4 == 0,
@@ -617,13 +852,18 @@ extern "C" int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream) {
   const int ta = (a->a0_cols + a->a1_cols) / 128;
   WS_REQUIRE(ta == 1 || ta == 3, "ws_gemm_tnb: A columns must total 128 or 384 (got %d)", ta * 128);
   WS_REQUIRE(a->a0_shift == 0, "ws_gemm_tnb: only A1 can be shifted (a0_shift = %d)", a->a0_shift);
+  WS_REQUIRE(a->g_fmt == 0 || (a->g_fmt == 1 && ta == 3), "ws_gemm_tnb: g_fmt = 1 (bf16 G) is built for 384 A columns");
   WS_REQUIRE(a->nblk > 0 && a->L > 0 && a->nblk % a->L == 0 && a->nsplit > 0 && a->blocks_per_split > 0 &&
                  (long long)a->nsplit * a->blocks_per_split >= a->nblk,
              "ws_gemm_tnb: bad block split");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a->nsplit, a->g_cols / 128), block(512);
   ws_prof_begin(WS_PROF_GEMM_TN, s);
-  if (ta == 3 && a->aslab)
+  if (a->g_fmt && a->aslab)
+    hipLaunchKernelGGL((gemm_tnb16_kernel<true>), grid, block, 0, s, *a);
+  else if (a->g_fmt)
+    hipLaunchKernelGGL((gemm_tnb16_kernel<false>), grid, block, 0, s, *a);
+  else if (ta == 3 && a->aslab)
     hipLaunchKernelGGL((gemm_tnb_kernel<3, true>), grid, block, 0, s, *a);
   else if (ta == 3)
     hipLaunchKernelGGL((gemm_tnb_kernel<3, false>), grid, block, 0, s, *a);

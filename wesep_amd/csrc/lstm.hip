@@ -383,8 +383,15 @@ static int lstm_check(const ws_lstm_args* a, bool bwd, const char* who) {
   WS_REQUIRE(a->nseq > 0 && a->L > 0 && a->sq_div > 0, "%s: bad nseq/L/sq_div", who);
   WS_REQUIRE((a->mode & 255) >= WS_LSTM_F32_MT1 && (a->mode & 255) <= WS_LSTM_BF16X3_BLK16, "%s: bad mode %d", who,
              a->mode);
-  WS_REQUIRE(!a->run_if || (!bwd && (a->mode & 255) >= WS_LSTM_BF16X3),
-             "%s: run_if is honoured by the split-bf16 forward kernels only", who);
+  WS_REQUIRE(!a->run_if || (!bwd && (a->mode & 255) >= WS_LSTM_BF16X3) || (bwd && (a->mode & 255) >= WS_LSTM_BF16X3_BLK),
+             "%s: run_if is honoured by the split-bf16 forward kernels and the blocked-layout BPTT kernels only", who);
+  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2S, "%s: bad gfmt %d", who, a->gfmt);
+  WS_REQUIRE(a->gfmt == WS_GATES_F32 || (a->mode & 255) >= WS_LSTM_BF16X3_BLK,
+             "%s: gfmt %d is a format of the blocked-layout modes", who, a->gfmt);
+  WS_REQUIRE(a->gfmt == WS_GATES_F32 || bwd || a->gates_in, "%s: gfmt %d needs gates_in (the fp32 pre-activations)", who,
+             a->gfmt);
+  WS_REQUIRE(a->gfmt != WS_GATES_H2S || !bwd || a->dgates, "%s: WS_GATES_H2S needs dgates", who);
+  WS_REQUIRE(a->gfmt == WS_GATES_F32 || ((a->mode >> 8) & 7) == 0, "%s: probe builds are WS_GATES_F32 only", who);
   return WS_OK;
 }
 
@@ -414,7 +421,8 @@ extern "C" int ws_lstm_bwd(const ws_lstm_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int per = 16 * a->mode;
   dim3 grid((a->nseq + per - 1) / per, 2), block(512);
-  ws_prof_begin(WS_PROF_LSTM_BWD, s);
+  const bool timed = a->run_if == nullptr;  // a predicated fall-back launch is normally empty: not a sample of this kind
+  if (timed) ws_prof_begin(WS_PROF_LSTM_BWD, s);
   if ((a->mode & 255) == WS_LSTM_BF16X3_BLK16)
     ws_launch_lstm_bwd_s16(a, s);
   else if ((a->mode & 255) >= WS_LSTM_BF16X3)
@@ -423,6 +431,6 @@ extern "C" int ws_lstm_bwd(const ws_lstm_args* a, void* stream) {
     hipLaunchKernelGGL((lstm_bwd_kernel<1>), grid, block, 0, s, *a);
   else
     hipLaunchKernelGGL((lstm_bwd_kernel<2>), grid, block, 0, s, *a);
-  ws_prof_end(WS_PROF_LSTM_BWD, s);
+  if (timed) ws_prof_end(WS_PROF_LSTM_BWD, s);
   return ws_check_launch("ws_lstm_bwd");
 }

@@ -87,7 +87,9 @@ int ws_launch_lstm_pack_bf16(const float* whh_f, const float* whh_r, float* pack
 // the sequence map), true = the blocked layout BL of include/wesep_hip.h, in which the 16 bytes
 // a lane moves and those of its 31 neighbours are one contiguous 512-byte run (block = the
 // workgroup's 32 sequences at one step), so every wave-level load/store is 1 KB contiguous.
-template <bool BLK, int DBG>
+// GF (BLK only): WS_GATES_* storage of the saved gates; GF != 0: pre-activations from p.gates_in (fp32 BL), activated
+// gates to p.gates as unorm16 (BLH) -- lstm_bf16_common.h
+template <bool BLK, int DBG, int GF = 0>
 __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 hl[2][2][SQ * HROW];  // [buf][part][seq][k] 66 KB
   __shared__ __attribute__((aligned(16))) float cl[SQ * (LH + 4)];     // cell state [seq][unit] 33 KB
@@ -115,14 +117,17 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
   auto coff = [&](int t, int j) -> long long {
     return (rowbase + (long long)t * p.step_rows) * (2 * LH) + d * LH + ubase + 8 * j;
   };
-  auto grs = [&](int t) { return mkrsrc(p.gates + (long long)(blockIdx.x * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  const float* gsrc = GF ? p.gates_in : p.gates;
+  auto grs = [&](int t) { return mkrsrc(gsrc + (long long)(blockIdx.x * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  auto hrs = [&](int t) { return mkrsrc(p.gates + (long long)(blockIdx.x * L + t) * (SQ * LG), SQ * 2 * LG * 2); };  // BLH
   auto crs = [&](float* b, int t) { return mkrsrc(b + (long long)(blockIdx.x * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
   auto ld_gate = [&](int t, int g, int j) -> f32x4 {
     if constexpr (BLK) return bld(grs(t), glane, (g * 64 + 2 * j) * 512);
     else return *reinterpret_cast<const f32x4*>(p.gates + goff(t, g, j));
   };
   auto st_gate = [&](const f32x4& v, int t, int g, int j) {
-    if constexpr (BLK) bst(v, grs(t), glane, (g * 64 + 2 * j) * 512);
+    if constexpr (GF != 0) bst8(g == 2 ? enc_u16x4<true>(v) : enc_u16x4<false>(v), hrs(t), glane >> 1, (g * 64 + 2 * j) * 256);
+    else if constexpr (BLK) bst(v, grs(t), glane, (g * 64 + 2 * j) * 512);
     else *reinterpret_cast<f32x4*>(p.gates + goff(t, g, j)) = v;
   };
   auto st_ch = [&](const f32x4& v, float* b, int t, int j) {
@@ -258,9 +263,13 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
 // backward recurrence (BPTT): walks the steps in the reverse of the forward order.
 //   dh_{t-1}^T[unit][seq] = W_hh^T[unit][gate col] * dgates_t^T[gate col][seq]   (K = 1024)
 // ---------------------------------------------------------------------------------------------
-template <bool BLK, int DBG>
+// GF (BLK only): WS_GATES_H2: unorm16 gates in, bf16 d(gates) out -- in place on the BLH buffer, or to p.dgates (BLH) when
+// given, which leaves the saved gates intact (the predicated fall-back behind ws_lstm_bwd_pair); WS_GATES_H2S: unorm16
+// gates in, d(gates) as BLS pairs to p.dgates
+template <bool BLK, int DBG, int GF = 0>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 dgl[2][SQ * DROW];  // [part][seq][gate col] 129 KB
+  if (p.run_if && *p.run_if == 0u) return;  // predicated fall-back launch (wesep_hip.h): uniform
   const int d = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -277,10 +286,16 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   auto coff = [&](int t, int j) -> long long {
     return (rowbase + (long long)t * p.step_rows) * (2 * LH) + d * LH + ubase + 8 * j;
   };
-  auto grs = [&](int t) { return mkrsrc(p.gates + (long long)(blockIdx.x * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  float* gdst = GF == WS_GATES_H2S ? p.dgates : p.gates;
+  auto grs = [&](int t) { return mkrsrc(gdst + (long long)(blockIdx.x * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  auto hrs = [&](int t) { return mkrsrc(p.gates + (long long)(blockIdx.x * L + t) * (SQ * LG), SQ * 2 * LG * 2); };  // BLH
+  float* hdst = (GF == WS_GATES_H2 && p.dgates) ? p.dgates : p.gates;
+  auto ors = [&](int t) { return mkrsrc(hdst + (long long)(blockIdx.x * L + t) * (SQ * LG), SQ * 2 * LG * 2); };     // BLH out
   auto crs = [&](const float* b, int t) { return mkrsrc(b + (long long)(blockIdx.x * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
-  auto ld_gate = [&](int t, int g, int j) -> f32x4 {
-    if constexpr (BLK) return bld(grs(t), glane, (g * 64 + 2 * j) * 512);
+  typedef typename gate_cell<GF>::type gcell;
+  auto ld_gate = [&](int t, int g, int j) -> gcell {
+    if constexpr (GF != 0) return bld8(hrs(t), glane >> 1, (g * 64 + 2 * j) * 256);
+    else if constexpr (BLK) return bld(grs(t), glane, (g * 64 + 2 * j) * 512);
     else return *reinterpret_cast<const f32x4*>(p.gates + goff(t, g, j));
   };
   auto st_gate = [&](const f32x4& v, int t, int g, int j) {
@@ -302,7 +317,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
 #pragma unroll
     for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
 
-  f32x4 n_i[4], n_f[4], n_g[4], n_o[4], n_dh[4], n_cp[4], c_cur[4], dc[4];  // [run]
+  gcell n_i[4], n_f[4], n_g[4], n_o[4];
+  f32x4 n_dh[4], n_cp[4], c_cur[4], dc[4];  // [run]
   f32x16 dhr;
   const f32x4 zero4v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -342,9 +358,11 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 pi, pf, pg, po;
+      const f32x4 vi = gate_val<false>(n_i[j]), vf = gate_val<false>(n_f[j]), vg = gate_val<true>(n_g[j]),
+                  vo = gate_val<false>(n_o[j]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float ig = n_i[j][r], fg = n_f[j][r], gg = n_g[j][r], og = n_o[j][r];
+        const float ig = vi[r], fg = vf[r], gg = vg[r], og = vo[r];
         const float dhv = n_dh[j][r] + dhr[4 * j + r];
         const float tc = ftanh(c_cur[j][r]);
         const float dov = dhv * tc;
@@ -365,7 +383,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
         *reinterpret_cast<bf16x4*>(dhi + 256 * g + 8 * j) = hi;
         *reinterpret_cast<bf16x4*>(dlo + 256 * g + 8 * j) = lo;
         if (st) {
-          if constexpr (BLK) st_gate(pack_hl4(hi, lo), t, g, j);
+          if constexpr (GF == WS_GATES_H2) bst8(bf16x4_bits(hi), ors(t), glane >> 1, (g * 64 + 2 * j) * 256);
+          else if constexpr (BLK) st_gate(pack_hl4(hi, lo), t, g, j);
           else st_gate(v, t, g, j);
         }
       };
@@ -412,7 +431,11 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
 }
 
 #define WS_DBG_DISPATCH(KERNEL)                                                          \
-  if ((a->mode & 255) == WS_LSTM_BF16X3_BLK) {                                           \
+  if ((a->mode & 255) == WS_LSTM_BF16X3_BLK && a->gfmt == WS_GATES_H2) {                 \
+    hipLaunchKernelGGL((KERNEL<true, 0, WS_GATES_H2>), grid, block, 0, s, *a);           \
+  } else if ((a->mode & 255) == WS_LSTM_BF16X3_BLK && a->gfmt == WS_GATES_H2S) {         \
+    hipLaunchKernelGGL((KERNEL<true, 0, WS_GATES_H2S>), grid, block, 0, s, *a);          \
+  } else if ((a->mode & 255) == WS_LSTM_BF16X3_BLK) {                                    \
     switch ((a->mode >> 8) & 7) {                                                        \
       case 0: hipLaunchKernelGGL((KERNEL<true, 0>), grid, block, 0, s, *a); break;       \
       case 1: hipLaunchKernelGGL((KERNEL<true, 1>), grid, block, 0, s, *a); break;       \

@@ -86,3 +86,49 @@ __device__ __forceinline__ void unpack_hl4(const f32x4& v, bf16x4& hi, bf16x4& l
   lo = __builtin_bit_cast(bf16x4, l);
 }
 
+
+// ---- 2-byte storage of the saved recurrence state (WS_GATES_H2 / WS_GATES_H2S, include/wesep_hip.h, ABI v15) ---------
+// BLH(C): the BL(C) index formula on 2-byte elements: a lane's 4-column cell is 8 bytes (one buffer_load/store_dwordx2),
+// 32 lanes 256 contiguous bytes.  Activated gates travel as unorm16 -- i, f, o in (0, 1): u = floor(x * 65535 + 0.5);
+// g in (-1, 1): u = floor((x + 1) * 32767.5 + 0.5) -- i.e. a FIXED-point code: its absolute error (7.7e-6 / 1.6e-5) is
+// uniform, where fp16 leaves 2.4e-4 exactly where the gates saturate and the derivative factor (1 - i) is small.
+// d(gates) travel as bf16 = the hi term of the split pair (no range problem: fp32's exponent).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define WS_U16_SIG 65535.f
+#define WS_U16_TANH 32767.5f
+
+__device__ __forceinline__ u32x2 bld8(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, WS_STREAM_AUX));
+}
+__device__ __forceinline__ void bst8(const u32x2& v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff + soff, 0, WS_STREAM_AUX);  // (no register soffset: see bst)
+}
+// 4 gate values -> 4 unorm16 codes (TANH: the g gate).  floor(x * s + o) with o = 0.5 (+ s for the tanh gate) by
+// truncation: the argument is never negative
+template <bool TANH>
+__device__ __forceinline__ u32x2 enc_u16x4(const f32x4& v) {
+  const float s = TANH ? WS_U16_TANH : WS_U16_SIG, o = TANH ? WS_U16_TANH + 0.5f : 0.5f;
+  unsigned u[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) u[j] = (unsigned)__builtin_fmaf(v[j], s, o);
+  return u32x2{u[0] | (u[1] << 16), u[2] | (u[3] << 16)};
+}
+template <bool TANH>
+__device__ __forceinline__ f32x4 dec_u16x4(const u32x2& c) {
+  const float s = TANH ? 1.f / WS_U16_TANH : 1.f / WS_U16_SIG, o = TANH ? -1.f : 0.f;
+  f32x4 v;
+  v[0] = __builtin_fmaf((float)(c[0] & 0xffffu), s, o);
+  v[1] = __builtin_fmaf((float)(c[0] >> 16), s, o);
+  v[2] = __builtin_fmaf((float)(c[1] & 0xffffu), s, o);
+  v[3] = __builtin_fmaf((float)(c[1] >> 16), s, o);
+  return v;
+}
+__device__ __forceinline__ u32x2 bf16x4_bits(const bf16x4& v) { return __builtin_bit_cast(u32x2, v); }
+// A saved gate cell as the BPTT kernels keep it between its (prefetching) load and its use one step later: the RAW
+// unorm16 codes -- decoding at the load would put the conversions, and with them the wait for the load, in front of the
+// scheduling fence that follows the prefetch
+template <int GF> struct gate_cell { typedef f32x4 type; };
+template <> struct gate_cell<WS_GATES_H2> { typedef u32x2 type; };
+template <> struct gate_cell<WS_GATES_H2S> { typedef u32x2 type; };
+template <bool TANH> __device__ __forceinline__ f32x4 gate_val(const f32x4& c) { return c; }
+template <bool TANH> __device__ __forceinline__ f32x4 gate_val(const u32x2& c) { return dec_u16x4<TANH>(c); }

@@ -76,6 +76,7 @@ int ws_launch_lstm_pack_s16(const float* whh_f, const float* whh_r, float* pack_
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+template <int GF>  // WS_GATES_* (lstm_bf16.hip)
 __global__ __launch_bounds__(512, 2) void lstm_fwd_s16_kernel(const ws_lstm_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 hl[2][2][S16 * HROW];  // [buf][part][seq][k] 33 KB
   __shared__ __attribute__((aligned(16))) float cl[S16 * (LH + 4)];     // cell state [seq][unit]
@@ -92,10 +93,15 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_s16_kernel(const ws_lstm_args
   // BL cells of this lane: quad 8w + 4tu + mq of (direction, gate), slot 16hb + n
   const int glane = ((d * 256 + 8 * w + mq) * 32 + 16 * hb + n) * 16;  // bytes; + (g*64 + 4tu)*512
   const int clane = ((d * 64 + 8 * w + mq) * 32 + 16 * hb + n) * 16;   // bytes; + 4tu*512
-  auto grs = [&](int t) { return mkrsrc(p.gates + (long long)(tile * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  const float* gsrc = GF ? p.gates_in : p.gates;
+  auto grs = [&](int t) { return mkrsrc(gsrc + (long long)(tile * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  auto hrs = [&](int t) { return mkrsrc(p.gates + (long long)(tile * L + t) * (SQ * LG), SQ * 2 * LG * 2); };  // BLH
   auto crs = [&](float* b, int t) { return mkrsrc(b + (long long)(tile * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
   auto ld_gate = [&](int t, int g, int tu) -> f32x4 { return bld(grs(t), glane, (g * 64 + 4 * tu) * 512); };
-  auto st_gate = [&](const f32x4& v, int t, int g, int tu) { bst(v, grs(t), glane, (g * 64 + 4 * tu) * 512); };
+  auto st_gate = [&](const f32x4& v, int t, int g, int tu) {
+    if constexpr (GF != 0) bst8(g == 2 ? enc_u16x4<true>(v) : enc_u16x4<false>(v), hrs(t), glane >> 1, (g * 64 + 4 * tu) * 256);
+    else bst(v, grs(t), glane, (g * 64 + 4 * tu) * 512);
+  };
   auto st_ch = [&](const f32x4& v, float* b, int t, int tu) { bst(v, crs(b, t), clane, 4 * tu * 512); };
 
   const int ubase = 32 * w + 4 * mq;  // unit of (tu, r): ubase + 16tu + r
@@ -218,8 +224,10 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_s16_kernel(const ws_lstm_args
 #ifndef S16_DBG
 #define S16_DBG 0  // probe builds: 1 no next-step loads, 2 no gate-gradient stores, 4 no weight reloads
 #endif
+template <int GF>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 dgl[2][S16 * DROW];  // [part][seq][gate col] 66 KB
+  if (p.run_if && *p.run_if == 0u) return;  // predicated fall-back launch (wesep_hip.h): uniform
   const int d = blockIdx.y;
   const int tile = blockIdx.x >> 1, hb = blockIdx.x & 1;
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, mq = lane >> 4;
@@ -227,9 +235,17 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
   const int L = p.L;
   const int glane = ((d * 256 + 8 * w + mq) * 32 + 16 * hb + n) * 16;
   const int clane = ((d * 64 + 8 * w + mq) * 32 + 16 * hb + n) * 16;
-  auto grs = [&](int t) { return mkrsrc(p.gates + (long long)(tile * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  float* gdst = GF == WS_GATES_H2S ? p.dgates : p.gates;
+  auto grs = [&](int t) { return mkrsrc(gdst + (long long)(tile * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  auto hrs = [&](int t) { return mkrsrc(p.gates + (long long)(tile * L + t) * (SQ * LG), SQ * 2 * LG * 2); };  // BLH
+  float* hdst = (GF == WS_GATES_H2 && p.dgates) ? p.dgates : p.gates;  // bf16 d(gates): in place, or to their own BLH buffer
+  auto ors = [&](int t) { return mkrsrc(hdst + (long long)(tile * L + t) * (SQ * LG), SQ * 2 * LG * 2); };
   auto crs = [&](const float* b, int t) { return mkrsrc(b + (long long)(tile * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
-  auto ld_gate = [&](int t, int g, int tu) -> f32x4 { return bld(grs(t), glane, (g * 64 + 4 * tu) * 512); };
+  typedef typename gate_cell<GF>::type gcell;
+  auto ld_gate = [&](int t, int g, int tu) -> gcell {
+    if constexpr (GF != 0) return bld8(hrs(t), glane >> 1, (g * 64 + 4 * tu) * 256);
+    else return bld(grs(t), glane, (g * 64 + 4 * tu) * 512);
+  };
   auto st_gate = [&](const f32x4& v, int t, int g, int tu) { bst(v, grs(t), glane, (g * 64 + 4 * tu) * 512); };
   auto ld_ch = [&](const float* b, int t, int tu) -> f32x4 { return bld(crs(b, t), clane, 4 * tu * 512); };
   const int ubase = 32 * w + 4 * mq;
@@ -244,7 +260,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
 #pragma unroll
     for (int f = 0; f < 16; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 16384 + (f >> 2) * 4096);
 
-  f32x4 n_i[2], n_f[2], n_g[2], n_o[2], n_dh[2], n_cp[2], c_cur[2], dc[2], dhr[2];
+  gcell n_i[2], n_f[2], n_g[2], n_o[2];
+  f32x4 n_dh[2], n_cp[2], c_cur[2], dc[2], dhr[2];
   const f32x4 zero4v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int tu = 0; tu < 2; ++tu) dc[tu] = dhr[tu] = zero4v;
@@ -278,9 +295,11 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
 #pragma unroll
     for (int tu = 0; tu < 2; ++tu) {
       f32x4 pi, pf, pg, po;
+      const f32x4 vi = gate_val<false>(n_i[tu]), vf = gate_val<false>(n_f[tu]), vg = gate_val<true>(n_g[tu]),
+                  vo = gate_val<false>(n_o[tu]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float ig = n_i[tu][r], fg = n_f[tu][r], gg = n_g[tu][r], og = n_o[tu][r];
+        const float ig = vi[r], fg = vf[r], gg = vg[r], og = vo[r];
         const float dhv = n_dh[tu][r] + dhr[tu][r];
         const float tc = ftanh(c_cur[tu][r]);
         const float dov = dhv * tc;
@@ -298,7 +317,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
         split4(v, hi, lo);
         *reinterpret_cast<bf16x4*>(dhi + 256 * g + 16 * tu) = hi;
         *reinterpret_cast<bf16x4*>(dlo + 256 * g + 16 * tu) = lo;
-        if (!(S16_DBG & 2)) st_gate(pack_hl4(hi, lo), t, g, tu);
+        if constexpr (GF == WS_GATES_H2) bst8(bf16x4_bits(hi), ors(t), glane >> 1, (g * 64 + 4 * tu) * 256);
+        else if (!(S16_DBG & 2)) st_gate(pack_hl4(hi, lo), t, g, tu);
       };
       emit(pi, 0);
       emit(pf, 1);
@@ -349,12 +369,15 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
 
 int ws_launch_lstm_fwd_s16(const ws_lstm_args* a, hipStream_t s) {
   dim3 grid(2 * ((a->nseq + SQ - 1) / SQ), 2), block(512);
-  hipLaunchKernelGGL(lstm_fwd_s16_kernel, grid, block, 0, s, *a);
+  if (a->gfmt) hipLaunchKernelGGL(lstm_fwd_s16_kernel<WS_GATES_H2>, grid, block, 0, s, *a);
+  else hipLaunchKernelGGL(lstm_fwd_s16_kernel<0>, grid, block, 0, s, *a);
   return 0;
 }
 
 int ws_launch_lstm_bwd_s16(const ws_lstm_args* a, hipStream_t s) {
   dim3 grid(2 * ((a->nseq + SQ - 1) / SQ), 2), block(512);
-  hipLaunchKernelGGL(lstm_bwd_s16_kernel, grid, block, 0, s, *a);
+  if (a->gfmt == WS_GATES_H2) hipLaunchKernelGGL(lstm_bwd_s16_kernel<WS_GATES_H2>, grid, block, 0, s, *a);
+  else if (a->gfmt == WS_GATES_H2S) hipLaunchKernelGGL(lstm_bwd_s16_kernel<WS_GATES_H2S>, grid, block, 0, s, *a);
+  else hipLaunchKernelGGL(lstm_bwd_s16_kernel<0>, grid, block, 0, s, *a);
   return 0;
 }

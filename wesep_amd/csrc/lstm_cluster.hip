@@ -61,7 +61,9 @@ __device__ __forceinline__ bool cluster_of_block(int ncl, int legacy, int& c, in
 }
 __host__ inline int cluster_grid(int ncl, int legacy) { return legacy ? ncl * 8 : 64 * ((ncl + 7) / 8); }
 
-template <bool FORCE>
+// GF: WS_GATES_* (lstm_bf16_common.h); != 0: pre-activations from p.gates_in (fp32 BL), activated gates to p.gates as
+// unorm16 (BLH): the stage of the four gates shrinks from 32 to 16 KB, their HBM stores from 16 to 8 bytes per cell
+template <bool FORCE, int GF>
 __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_cluster_args p) {
   // VMEM operations of one wave complete in order, so an exchange wave must never have HBM traffic in
   // its queue (measured: +3.2 us per step when it does).  All 8 waves run the MFMAs and the cell
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
   //   M-waves (4..7): HBM stores of gates / c / h (from OUT), x-projection prefetch (-> XIN)
   __shared__ __attribute__((aligned(16))) __bf16 hl[2][CL_SEQ * HROW];  // [part][seq][k] 66 KB
   __shared__ __attribute__((aligned(16))) f32x4 xin[4][512];             // x-projection of the step, 32 KB
-  __shared__ __attribute__((aligned(16))) f32x4 outl[6][512];            // i, f, g, o, c, h of the step, 48 KB
+  __shared__ __attribute__((aligned(16))) f32x4 outl[GF ? 4 : 6][512];   // i, f, g, o, c, h of the step, 48 KB (GF: i|f, g|o
+                                                                         // as unorm16 pairs, c, h: 32 KB)
   __shared__ __attribute__((aligned(16))) u32x4 publ[512];               // h chunks (bf16 hi x4 | lo x4), 8 KB
   __shared__ int dead_s;
   const int ntile = p.nseq / 32, ncl_dir = ntile / 2, ncl = 2 * ncl_dir;
@@ -107,8 +110,11 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
   const int gvo = ((d * 256 + 8 * j + 2 * m_uo + m_half) * 32 + m_n) * 16;  // bytes; + g*64*512; + e * tile stride
   const int cvo = ((d * 64 + 8 * j + 2 * m_uo + m_half) * 32 + m_n) * 16;
   const int gts = (int)(L * gblk * 4), cts = (int)(L * cblk * 4);             // bytes between the two tiles
-  auto grs = [&](int t) { return mkrsrc(p.gates + ((long long)2 * cc * L + t) * gblk, 0x7fffffffu); };
+  const float* gsrc = GF ? p.gates_in : p.gates;
+  auto grs = [&](int t) { return mkrsrc(gsrc + ((long long)2 * cc * L + t) * gblk, 0x7fffffffu); };
+  auto hrs = [&](int t) { return mkrsrc(p.gates + ((long long)2 * cc * L + t) * (gblk / 2), 0x7fffffffu); };  // BLH
   auto crs = [&](float* b, int t) { return mkrsrc(b + ((long long)2 * cc * L + t) * cblk, 0x7fffffffu); };
+  constexpr int OC = GF ? 2 : 4, OH = OC + 1;  // stage rows of c and h
   // ---- exchange side (X-waves): X[cluster][parity][producer][chunk 512] x 16 B ----------------------
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(p.xchg) + (long long)c * (2 * 8 * 8192), 0, 2 * 8 * 8192, 0x00020000);
@@ -140,10 +146,19 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int ct = mt + 256 * e;
+      if constexpr (GF != 0) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) bst(outl[g][ct], grs(tprev), gvo + e * gts, g * 64 * 512);
-      bst(outl[4][ct], crs(p.cbuf, tprev), cvo + e * cts, 0);
-      bst(outl[5][ct], crs(p.hcat, tprev), cvo + e * cts, 0);
+        for (int g2 = 0; g2 < 2; ++g2) {
+          const u32x4 pr = __builtin_bit_cast(u32x4, outl[g2][ct]);
+          bst8(u32x2{pr[0], pr[1]}, hrs(tprev), (gvo + e * gts) >> 1, (2 * g2) * 64 * 256);
+          bst8(u32x2{pr[2], pr[3]}, hrs(tprev), (gvo + e * gts) >> 1, (2 * g2 + 1) * 64 * 256);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bst(outl[g][ct], grs(tprev), gvo + e * gts, g * 64 * 512);
+      }
+      bst(outl[OC][ct], crs(p.cbuf, tprev), cvo + e * cts, 0);
+      bst(outl[OH][ct], crs(p.hcat, tprev), cvo + e * cts, 0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) xpre[e][g] = bld(grs(tn), gvo + e * gts, g * 64 * 512);
     }
@@ -191,14 +206,20 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster_kernel(const ws_lstm_
         vh[r] = og * ftanh(cn);
       }
       if (dead_s != 0) vh = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-      outl[0][tid] = vi;
-      outl[1][tid] = vf;
-      outl[2][tid] = vg;
-      outl[3][tid] = vo;
-      outl[4][tid] = c4;
+      if constexpr (GF != 0) {
+        const u32x2 ei = enc_u16x4<false>(vi), ef = enc_u16x4<false>(vf), eg = enc_u16x4<true>(vg), eo = enc_u16x4<false>(vo);
+        outl[0][tid] = __builtin_bit_cast(f32x4, u32x4{ei[0], ei[1], ef[0], ef[1]});
+        outl[1][tid] = __builtin_bit_cast(f32x4, u32x4{eg[0], eg[1], eo[0], eo[1]});
+      } else {
+        outl[0][tid] = vi;
+        outl[1][tid] = vf;
+        outl[2][tid] = vg;
+        outl[3][tid] = vo;
+      }
+      outl[OC][tid] = c4;
       bf16x4 hi, lo;
       split4(vh, hi, lo);
-      outl[5][tid] = pack_hl4(hi, lo);  // hcat in HBM carries the split pair (BLS); NaN poison survives in hi
+      outl[OH][tid] = pack_hl4(hi, lo);  // hcat in HBM carries the split pair (BLS); NaN poison survives in hi
       struct { bf16x4 a, b; } pk = {hi, lo};
       publ[mychunk] = __builtin_bit_cast(u32x4, pk);
     }
@@ -260,6 +281,8 @@ extern "C" int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream) 
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->whh_f && a->whh_r && a->xchg && a->flags,
              "ws_lstm_fwd_cluster: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->nseq % 64 == 0 && a->L > 0, "ws_lstm_fwd_cluster: nseq must be a multiple of 64");
+  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2S && (a->gfmt == 0 || a->gates_in),
+             "ws_lstm_fwd_cluster: gfmt %d needs gates_in", a->gfmt);
   const int nwg = (a->nseq / 32) * 8;
   int dev = 0, cus = 0;
   (void)hipGetDevice(&dev);
@@ -270,10 +293,14 @@ extern "C" int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream) 
   hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)(a->nseq / 32) * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_fwd_cluster: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
-  if (a->dbg & 8)
-    hipLaunchKernelGGL(lstm_fwd_cluster_kernel<true>, dim3(grid), dim3(512), 0, s, *a);
+  if (a->gfmt && (a->dbg & 8))
+    hipLaunchKernelGGL((lstm_fwd_cluster_kernel<true, WS_GATES_H2>), dim3(grid), dim3(512), 0, s, *a);
+  else if (a->gfmt)
+    hipLaunchKernelGGL((lstm_fwd_cluster_kernel<false, WS_GATES_H2>), dim3(grid), dim3(512), 0, s, *a);
+  else if (a->dbg & 8)
+    hipLaunchKernelGGL((lstm_fwd_cluster_kernel<true, 0>), dim3(grid), dim3(512), 0, s, *a);
   else
-    hipLaunchKernelGGL(lstm_fwd_cluster_kernel<false>, dim3(grid), dim3(512), 0, s, *a);
+    hipLaunchKernelGGL((lstm_fwd_cluster_kernel<false, 0>), dim3(grid), dim3(512), 0, s, *a);
   ws_prof_end(WS_PROF_LSTM_FWD, s);
   return ws_check_launch("ws_lstm_fwd_cluster");
 }
@@ -509,6 +536,7 @@ extern "C" int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream) 
   WS_REQUIRE(a && a->gates && a->cbuf && a->dhcat && a->whh_f && a->whh_r && a->xchg && a->flags,
              "ws_lstm_bwd_cluster: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->nseq % 64 == 0 && a->L > 0, "ws_lstm_bwd_cluster: nseq must be a multiple of 64");
+  WS_REQUIRE(a->gfmt == WS_GATES_F32, "ws_lstm_bwd_cluster: WS_GATES_F32 only (gfmt %d)", a->gfmt);
   const int nwg = (a->nseq / 32) * 8;
   int dev = 0, cus = 0;
   (void)hipGetDevice(&dev);

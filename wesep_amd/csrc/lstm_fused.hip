@@ -54,6 +54,7 @@ extern "C" int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const 
   return ws_check_launch("ws_lstm_pack_fused");
 }
 
+template <int GF>  // WS_GATES_*: != 0 -> activated gates leave as unorm16 (BLH), lstm_bf16_common.h
 __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fused_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 hl[2][2][SQ * HROW];  // [buf][part][seq][k]  66 KB
   __shared__ __attribute__((aligned(16))) __bf16 xl[2][2][SQ * XROW];  // [buf][part][seq][k]  34 KB
@@ -73,7 +74,11 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
   auto grs = [&](int t) { return mkrsrc(p.gates + (long long)(blockIdx.x * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
   auto crs = [&](float* b, int t) { return mkrsrc(b + (long long)(blockIdx.x * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
   auto xrs = [&](int t) { return mkrsrc(p.xn + (long long)(blockIdx.x * L + t) * (SQ * 128), SQ * 128 * 4); };
-  auto st_gate = [&](const f32x4& v, int t, int g, int j) { bst(v, grs(t), glane, (g * 64 + 2 * j) * 512); };
+  auto hrs = [&](int t) { return mkrsrc(p.gates + (long long)(blockIdx.x * L + t) * (SQ * LG), SQ * 2 * LG * 2); };  // BLH
+  auto st_gate = [&](const f32x4& v, int t, int g, int j) {
+    if constexpr (GF != 0) bst8(g == 2 ? enc_u16x4<true>(v) : enc_u16x4<false>(v), hrs(t), glane >> 1, (g * 64 + 2 * j) * 256);
+    else bst(v, grs(t), glane, (g * 64 + 2 * j) * 512);
+  };
   auto st_ch = [&](const f32x4& v, float* b, int t, int j) { bst(v, crs(b, t), clane, 2 * j * 512); };
   // x tile of one step = one BL(128) block: 1024 cells of 16 B, cell u = quad * 32 + slot; thread: u = tid, tid + 512
   auto ld_x = [&](int t, int q) -> f32x4 { return bld(xrs(t), tid * 16, q * 8192); };
@@ -218,14 +223,19 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
 // of tile 0 lives in LDS (lane-private, unpadded), of tile 1 in registers, the bias in LDS.
 // Per sequence the arithmetic and its order are those of the 32-sequence kernel: results are bit-identical.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 1) void lstm_fwd_fused64_kernel(const ws_lstm_fused_args p) {
-  // one object, members in this order: the DMA target sits at LDS address 0 (its base travels in M0)
-  __shared__ __attribute__((aligned(16))) struct {
-    f32x4 xw[2][1024];            // [tile][quad*32 + slot] raw BLS      32 KB
-    __bf16 hl[2][2 * SQ * HROW];  // [part][tile*32 + seq][k]            67.6 KB
-    f32x4 c0l[8 * 2 * 4 * 32];    // tile 0 cells [w][half][run][seq]    32 KB
-    float bs[LG];                 // b_ih + b_hh of this direction        4 KB
-  } sm;
+// one object, members in this order: the DMA target sits at LDS address 0 (its base travels in M0)
+// (a named type: with an unnamed struct inside the kernel TEMPLATE the host stub of the instantiations is not emitted)
+struct fused64_lds {
+  f32x4 xw[2][1024];            // [tile][quad*32 + slot] raw BLS      32 KB
+  __bf16 hl[2][2 * SQ * HROW];  // [part][tile*32 + seq][k]            67.6 KB
+  f32x4 c0l[8 * 2 * 4 * 32];    // tile 0 cells [w][half][run][seq]    32 KB
+  float bs[LG];                 // b_ih + b_hh of this direction        4 KB
+};
+// (the body is a device function template behind two plain kernels: hipcc 7.2 does not emit the host stubs of a
+//  __global__ TEMPLATE with this body -- "substitution failure" without a diagnostic)
+template <int GF>
+__device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& p) {
+  __shared__ __attribute__((aligned(16))) fused64_lds sm;
   auto& xw = sm.xw;
   auto& hl = sm.hl;
   auto& c0l = sm.c0l;
@@ -250,6 +260,11 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64_kernel(const ws_lstm_
   auto blk = [&](int e, int t) { return (long long)((tile0 + e) * L + t); };
   auto lim = [&](int e, unsigned bytes) { return e == 0 ? bytes : bytes * live1; };
   auto grs = [&](int e, int t) { return mkrsrc(p.gates + blk(e, t) * (SQ * 2 * LG), lim(e, SQ * 2 * LG * 4)); };
+  auto hrs = [&](int e, int t) { return mkrsrc(p.gates + blk(e, t) * (SQ * LG), lim(e, SQ * 2 * LG * 2)); };  // BLH
+  auto st_gate = [&](const f32x4& v, int e, int t, int g, int j) {
+    if constexpr (GF != 0) bst8(g == 2 ? enc_u16x4<true>(v) : enc_u16x4<false>(v), hrs(e, t), glane >> 1, (g * 64 + 2 * j) * 256);
+    else bst(v, grs(e, t), glane, (g * 64 + 2 * j) * 512);
+  };
   auto crs = [&](float* b, int e, int t) { return mkrsrc(b + blk(e, t) * (SQ * 2 * LH), lim(e, SQ * 2 * LH * 4)); };
   auto xrs = [&](int e, int t) { return mkrsrc(p.xn + blk(e, t) * (SQ * 128), lim(e, SQ * 128 * 4)); };
   // x tile of one step = one BL(128) block of 16 KB: wave w copies cells 64w .. 64w+63 and 512 + 64w .. of each tile
@@ -363,10 +378,10 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64_kernel(const ws_lstm_
           c0[32 * j] = vc;
         else
           c1[j] = vc;
-        bst(vi, grs(e, t), glane, (0 * 64 + 2 * j) * 512);
-        bst(vf, grs(e, t), glane, (1 * 64 + 2 * j) * 512);
-        bst(vg, grs(e, t), glane, (2 * 64 + 2 * j) * 512);
-        bst(vo, grs(e, t), glane, (3 * 64 + 2 * j) * 512);
+        st_gate(vi, e, t, 0, j);
+        st_gate(vf, e, t, 1, j);
+        st_gate(vg, e, t, 2, j);
+        st_gate(vo, e, t, 3, j);
         bst(vc, crs(p.cbuf, e, t), clane, 2 * j * 512);
         bst(pack_hl4(h_hi, h_lo), crs(p.hcat, e, t), clane, 2 * j * 512);  // BLS
         __builtin_amdgcn_sched_barrier(0);  // one run at a time: bounds the live temporaries
@@ -378,9 +393,17 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64_kernel(const ws_lstm_
   }
 }
 
+__global__ __launch_bounds__(512, 1) void lstm_fwd_fused64_kernel(const ws_lstm_fused_args p) {
+  lstm_fwd_fused64_body<0>(p);
+}
+__global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h_kernel(const ws_lstm_fused_args p) {
+  lstm_fwd_fused64_body<WS_GATES_H2>(p);
+}
+
 extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn && a->wpack && a->bias, "ws_lstm_fwd_fused: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_fwd_fused: bad nseq/L");
+  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2S, "ws_lstm_fwd_fused: gfmt %d", a->gfmt);
   const int ntile = (a->nseq + SQ - 1) / SQ;
   dim3 grid(ntile, 2), block(512);
   hipStream_t s = (hipStream_t)stream;
@@ -394,10 +417,14 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   const int rounds32 = (2 * ntile + cus - 1) / cus, rounds64 = (2 * ((ntile + 1) / 2) + cus - 1) / cus;
   const bool wide = env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
-  if (wide)
+  if (wide && a->gfmt)
+    hipLaunchKernelGGL(lstm_fwd_fused64h_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
+  else if (wide)
     hipLaunchKernelGGL(lstm_fwd_fused64_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
+  else if (a->gfmt)
+    hipLaunchKernelGGL(lstm_fwd_fused_kernel<WS_GATES_H2>, grid, block, 0, s, *a);
   else
-    hipLaunchKernelGGL(lstm_fwd_fused_kernel, grid, block, 0, s, *a);
+    hipLaunchKernelGGL(lstm_fwd_fused_kernel<0>, grid, block, 0, s, *a);
   ws_prof_end(WS_PROF_LSTM_FWD, s);
   return ws_check_launch("ws_lstm_fwd_fused");
 }

@@ -98,7 +98,9 @@ __device__ __noinline__ void pair_timed_out(unsigned* tword, unsigned* status) {
       reinterpret_cast<unsigned long long*>(p.dbg_buf)[(step * 2 + role) * 8 + (k)] = __builtin_readcyclecounter(); \
   }
 
-template <int V>
+// GF: WS_GATES_* (lstm_bf16_common.h): H2 = unorm16 gates in, bf16 d(gates) out, in place on the BLH buffer; H2S = unorm16
+// gates in, d(gates) as BLS pairs to p.dgates
+template <int V, int GF = 0>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pair_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 bimg[2][SQ * PR_ROW];      // [part][seq][local gate col] 65 KB
   __shared__ __attribute__((aligned(16))) bf16x8 whl[8 * PAIR_LDSK * 64];   // lo fragments of k-steps 0..7, 64 KB
@@ -122,8 +124,17 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
   const int q0 = 8 * wx + 4 * role + half;                   // this thread's cells: quads q0 (e = 0) and q0 + 2 (e = 1)
   const int gvo = ((d * 256 + 32 * hs + q0) * 32 + n) * 16;  // bytes; + g*64*512; cell e: + 2e*512
   const int cvo = ((d * 64 + 32 * hs + q0) * 32 + n) * 16;   // bytes; cell e: + 2e*512
-  auto grs = [&](int t) { return mkrsrc(p.gates + (long long)(tile * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  float* gdst = GF == WS_GATES_H2S ? p.dgates : p.gates;
+  auto grs = [&](int t) { return mkrsrc(gdst + (long long)(tile * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  auto hrs = [&](int t) { return mkrsrc(p.gates + (long long)(tile * L + t) * (SQ * LG), SQ * 2 * LG * 2); };  // BLH
+  float* hdst = (GF == WS_GATES_H2 && p.dgates) ? p.dgates : p.gates;  // bf16 d(gates): in place, or to their own BLH buffer
+  auto ors = [&](int t) { return mkrsrc(hdst + (long long)(tile * L + t) * (SQ * LG), SQ * 2 * LG * 2); };
   auto crs = [&](const float* b, int t) { return mkrsrc(b + (long long)(tile * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
+  typedef typename gate_cell<GF>::type gcell;
+  auto ld_gate = [&](int t, int g, int e) -> gcell {
+    if constexpr (GF != 0) return bld8(hrs(t), gvo >> 1, (g * 64 + 2 * e) * 256);
+    else return bld(grs(t), gvo, (g * 64 + 2 * e) * 512);
+  };
   // ---- exchange: X[pair][parity][destination member][cell] x 16 B; flags[pair][source member][wave]
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(p.xchg) + (long long)pr * (4 * PR_XSLOT), 0, 4 * PR_XSLOT, 0x00020000);
@@ -149,13 +160,14 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
   const f32x4* oth = &rec[role][(wx * 2) * 64 + lane];  // X-waves read what the O-waves wrote (rec[0]) and vice versa
   f32x4* mineo = &rec[role ^ 1][(wx * 2) * 64 + lane];  // ... and write the half the other role's cells need
 
-  f32x4 n_i[2], n_f[2], n_g[2], n_o[2], n_dh[2], n_cp[2], c_cur[2], dc[2], mine[2];
+  gcell n_i[2], n_f[2], n_g[2], n_o[2];
+  f32x4 n_dh[2], n_cp[2], c_cur[2], dc[2], mine[2];
   const f32x4 zero4v = {0.f, 0.f, 0.f, 0.f};
   auto load_step = [&](int t, int e) {
-    n_i[e] = bld(grs(t), gvo, (0 * 64 + 2 * e) * 512);
-    n_f[e] = bld(grs(t), gvo, (1 * 64 + 2 * e) * 512);
-    n_g[e] = bld(grs(t), gvo, (2 * 64 + 2 * e) * 512);
-    n_o[e] = bld(grs(t), gvo, (3 * 64 + 2 * e) * 512);
+    n_i[e] = ld_gate(t, 0, e);
+    n_f[e] = ld_gate(t, 1, e);
+    n_g[e] = ld_gate(t, 2, e);
+    n_o[e] = ld_gate(t, 3, e);
     n_dh[e] = bld(crs(p.dhcat, t), cvo, 2 * e * 512);
     const int tp = d == 0 ? max(t - 1, 0) : min(t + 1, L - 1);  // clamped; masked at its use
     n_cp[e] = bld(crs(p.cbuf, tp), cvo, 2 * e * 512);
@@ -193,9 +205,11 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       const int q = q0 + 2 * e;
       const f32x4 dhr = mine[e] + oth[e * 64];
       f32x4 pi, pf, pg, po;
+      const f32x4 vi = gate_val<false>(n_i[e]), vf = gate_val<false>(n_f[e]), vg = gate_val<true>(n_g[e]),
+                  vo = gate_val<false>(n_o[e]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float ig = n_i[e][r], fg = n_f[e][r], gg = n_g[e][r], og = n_o[e][r];
+        const float ig = vi[r], fg = vf[r], gg = vg[r], og = vo[r];
         const float dhv = n_dh[e][r] + dhr[r];
         const float tc = ftanh(c_cur[e][r]);
         const float dov = dhv * tc;
@@ -212,8 +226,12 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
         split4(v, hi, lo);
         *reinterpret_cast<bf16x4*>(&bimg[0][n * PR_ROW + g * 128 + 4 * q]) = hi;
         *reinterpret_cast<bf16x4*>(&bimg[1][n * PR_ROW + g * 128 + 4 * q]) = lo;
-        pk[e][g] = pack_hl4(hi, lo);
-        bst(pk[e][g], grs(t), gvo, (g * 64 + 2 * e) * 512);  // (zero soffset inside: hipcc pads the data hazard)
+        if constexpr (GF == WS_GATES_H2) {
+          bst8(bf16x4_bits(hi), ors(t), gvo >> 1, (g * 64 + 2 * e) * 256);
+        } else {
+          pk[e][g] = pack_hl4(hi, lo);
+          bst(pk[e][g], grs(t), gvo, (g * 64 + 2 * e) * 512);  // (zero soffset inside: hipcc pads the data hazard)
+        }
       };
       emit(pi, 0);
       emit(pf, 1);
@@ -349,6 +367,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
 extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->dhcat && a->wpack && a->xchg && a->flags, "ws_lstm_bwd_pair: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_bwd_pair: nseq and L must be positive");
+  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2S && (a->gfmt != WS_GATES_H2S || a->dgates),
+             "ws_lstm_bwd_pair: gfmt %d (WS_GATES_H2S needs dgates)", a->gfmt);
   const int npair = 2 * ((a->nseq + SQ - 1) / SQ);
   static int cus = 0;      // same part on every device of a node; queried once
   if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 0;
@@ -359,11 +379,15 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)npair * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_pair: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
-  switch (a->dbg & (8 | 2048)) {
-    case 0: hipLaunchKernelGGL(lstm_bwd_pair_kernel<0>, dim3(grid), dim3(512), 0, s, *a); break;
-    case 8: hipLaunchKernelGGL(lstm_bwd_pair_kernel<8>, dim3(grid), dim3(512), 0, s, *a); break;       // tests: forced timeout
-    case 2048: hipLaunchKernelGGL(lstm_bwd_pair_kernel<2048>, dim3(grid), dim3(512), 0, s, *a); break;  // cycle stamps
-    default: WS_REQUIRE(false, "ws_lstm_bwd_pair: dbg bits 8 and 2048 are exclusive");
+  switch ((a->dbg & (8 | 2048)) + a->gfmt) {
+    case 0: hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, 0>), dim3(grid), dim3(512), 0, s, *a); break;
+    case 1: hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, WS_GATES_H2>), dim3(grid), dim3(512), 0, s, *a); break;
+    case 2: hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, WS_GATES_H2S>), dim3(grid), dim3(512), 0, s, *a); break;
+    case 8: hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, 0>), dim3(grid), dim3(512), 0, s, *a); break;   // tests: forced timeout
+    case 9: hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2>), dim3(grid), dim3(512), 0, s, *a); break;
+    case 10: hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2S>), dim3(grid), dim3(512), 0, s, *a); break;
+    case 2048: hipLaunchKernelGGL((lstm_bwd_pair_kernel<2048, 0>), dim3(grid), dim3(512), 0, s, *a); break;  // cycle stamps
+    default: WS_REQUIRE(false, "ws_lstm_bwd_pair: dbg bits 8 and 2048 are exclusive; cycle stamps are WS_GATES_F32 only");
   }
   ws_prof_end(WS_PROF_LSTM_BWD, s);
   return ws_check_launch("ws_lstm_bwd_pair");

@@ -111,3 +111,29 @@ extern "C" int ws_debug_dirty_lds(float value, int nblocks, int spins, float* si
   hipLaunchKernelGGL(debug_dirty_lds_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, value, spins, sink);
   return ws_check_launch("ws_debug_dirty_lds");
 }
+
+// Holds `nblocks` compute units for `usec` microseconds (or until *stop != 0): each workgroup takes 112 KB of LDS, so no
+// product workgroup with a large LDS footprint (the pair BPTT: 145 KB, the cluster forward: 138 KB, the weight-gradient
+// GEMM: 160 KB) can share its CU -- the shape of a resident collective kernel (RCCL keeps its channels' workgroups on
+// their CUs for the whole all-reduce) as seen by the recurrences whose workgroups have to be co-resident.  The wait is on
+// the constant-rate wall clock (100 MHz) and bounded by `usec`: it cannot hang the device.
+__global__ __launch_bounds__(256) void debug_occupy_kernel(long long ticks, const unsigned* stop, float* sink) {
+  __shared__ float buf[28672];  // 112 KB
+  buf[threadIdx.x] = (float)threadIdx.x;
+  __syncthreads();
+  const long long t0 = wall_clock64();
+  float acc = 0.f;
+  while (wall_clock64() - t0 < ticks) {
+    if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+    acc += buf[(threadIdx.x * 7) & 255];
+    __builtin_amdgcn_s_sleep(32);
+  }
+  if (sink && acc == -1.f) sink[0] = acc;  // never true: keeps the LDS alive
+}
+
+extern "C" int ws_debug_occupy(int nblocks, int usec, const unsigned* stop, float* sink, void* stream) {
+  WS_REQUIRE(nblocks > 0 && usec >= 0 && usec <= 2000000, "ws_debug_occupy: nblocks > 0, 0 <= usec <= 2 000 000");
+  hipLaunchKernelGGL(debug_occupy_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (long long)usec * 100LL, stop,
+                     sink);
+  return ws_check_launch("ws_debug_occupy");
+}

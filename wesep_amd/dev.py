@@ -312,27 +312,54 @@ def lstm_cat_ih(wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, n_in, wcat, bcat):
                                    n_in, _p(wcat), _p(bcat), L.stream_ptr()), "ws_lstm_cat_ih")
 
 
-def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None, run_if=None):
-    for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("wpack", wpack), ("dhcat", dhcat)):
+def _bptt_bytes(gfmt: int) -> int:
+    """Algorithmic bytes of one BPTT cell (position, direction, unit): 4 saved gates in, c and d(h) in (fp32), 4 d(gates)
+    out -- 40 B with fp32 gates / split-pair d(gates), 24 B with unorm16 gates and bf16 d(gates), 32 B for H2S."""
+    return {L.GATES_F32: 40, L.GATES_H2: 24, L.GATES_H2S: 32}[gfmt]
+
+
+def gates_fmt() -> int:
+    """Storage of the saved activated gates / d(gates) of the blocked-layout ResRNN (WS_GATES_*, wesep_hip.h):
+    'h2' (default): unorm16 gates, bf16 d(gates) in place -- half the bytes of the step's largest buffer and of every
+    pass over it; 'h2s': unorm16 gates, d(gates) as full split pairs in a separate buffer; 'f32': the ABI <= 14 format
+    (fp32 gates, split-pair d(gates) in place).  WESEP_GATES selects."""
+    return {"h2": L.GATES_H2, "h2s": L.GATES_H2S, "f32": L.GATES_F32}[os.environ.get("WESEP_GATES", "h2")]
+
+
+def blh_floats(nblocks: int, C_: int) -> int:
+    """float32 elements of storage behind a BLH(C_) buffer of `nblocks` blocks (2-byte elements; the wrappers take
+    float32 tensors as opaque storage)."""
+    return nblocks * 32 * C_ // 2
+
+
+def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None, run_if=None, gfmt=0, gates_in=None, dgates=None):
+    for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("wpack", wpack), ("dhcat", dhcat),
+                 ("gates_in", gates_in), ("dgates", dgates)):
         _chk(t, n)
     a = L.LstmArgs()
     a.gates, a.cbuf, a.hcat, a.dhcat, a.wpack = _p(gates), _p(cbuf), _p(hcat), _p(dhcat), _p(wpack)
     a.sq_s1, a.sq_s2, a.step_rows = sm.s1, sm.s2, sm.step_rows
     a.nseq, a.sq_div, a.L, a.mode = sm.nseq, sm.div, sm.L, mode
     a.run_if = C.c_void_p(run_if.data_ptr()) if run_if is not None else None
+    a.gates_in, a.dgates, a.gfmt = _p(gates_in), _p(dgates), gfmt
     return a
 
 
-def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, run_if=None):
-    """run_if: optional 1-element int32 device tensor; the launch is a no-op unless it is non-zero at kernel start."""
-    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, run_if=run_if)
+def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, run_if=None, gfmt=0, gates_in=None):
+    """run_if: optional 1-element int32 device tensor; the launch is a no-op unless it is non-zero at kernel start.
+    gfmt != 0 (blocked-layout modes): pre-activations from `gates_in` (fp32 BL), `gates` receives unorm16 (BLH)."""
+    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, run_if=run_if, gfmt=gfmt, gates_in=gates_in)
     L.check(L.lib().ws_lstm_fwd(C.byref(a), L.stream_ptr()), "ws_lstm_fwd")
 
 
-def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3):
-    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat)
-    # per (position, direction, unit): read 4 gates + c + dh, write 4 d(gates) = 10 floats; 2 * 4H * H MACs per position
-    _alg("lstm_bwd", 10 * 4 * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
+def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, gfmt=0, dgates=None, run_if=None):
+    """run_if (blocked-layout modes): 1-element int32 device tensor; the launch is a no-op unless it is non-zero at
+    kernel start -- the predicated fall-back behind lstm_bwd_pair.  dgates: out-of-place d(gates) (required for
+    GATES_H2S; optional BLH buffer for GATES_H2, which then leaves the saved gates intact)."""
+    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat, gfmt=gfmt, dgates=dgates, run_if=run_if)
+    # per (position, direction, unit): read 4 gates + c + dh, write 4 d(gates); 2 * 4H * H MACs per position
+    if run_if is None:
+        _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
     L.check(L.lib().ws_lstm_bwd(C.byref(a), L.stream_ptr()), "ws_lstm_bwd")
 
 
@@ -414,9 +441,9 @@ def poll_cluster_status(device, block=False):
         if fwd_to:
             if sc.fallbacks == 0:
                 import warnings
-                warnings.warn("lstm_fwd_cluster: a bounded wait timed out (workgroups not co-resident: another stream "
-                              "or process holds CUs); the layer was recomputed by the streaming kernels.  "
-                              "WESEP_LSTM_CLUSTER=0 avoids the cluster kernel altogether", RuntimeWarning)
+                warnings.warn("lstm_fwd_cluster / lstm_bwd_pair: a bounded wait timed out (workgroups not co-resident: "
+                              "another stream or process holds CUs); the layer was recomputed by the streaming kernels.  "
+                              "WESEP_LSTM_CLUSTER=0 / WESEP_LSTM_PAIR_BWD=0 avoid these kernels altogether", RuntimeWarning)
             sc.fallbacks += 1
         if bwd_to:
             raise L.WesepHipError(
@@ -434,17 +461,18 @@ def poll_cluster_status(device, block=False):
     return sc.fallbacks
 
 
-def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0):
+def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0, gfmt=0, gates_in=None):
     """Forward recurrence on the blocked layout with W_hh resident in registers across clusters of 8
     workgroups (lstm_cluster.hip).  Returns the launch's timeout word (a 1-element int32 view of the flag scratch):
     pass it as `run_if` to gemm_p2b + lstm_fwd behind this call -- the predicated fall-back."""
-    for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("whh_f", whh_f), ("whh_r", whh_r)):
+    for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("whh_f", whh_f), ("whh_r", whh_r), ("gates_in", gates_in)):
         _chk(t, n)
     ncl = sm.nseq // 32
     sc = _cluster_scratch(gates.device)
     xchg, flags = sc.get(ncl * 2 * 8 * 8192 // 4, ncl * 8 + 8)
     a = L.LstmClusterArgs()
     a.gates, a.cbuf, a.hcat, a.whh_f, a.whh_r = _p(gates), _p(cbuf), _p(hcat), _p(whh_f), _p(whh_r)
+    a.gfmt, a.gates_in = gfmt, _p(gates_in)
     a.xchg, a.flags = C.c_void_p(xchg.data_ptr()), C.c_void_p(flags.data_ptr())
     a.status = C.c_void_p((status if status is not None else sc.status).data_ptr())
     a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
@@ -486,11 +514,12 @@ def lstm_pack_pair(whh_f, whh_r, pack):
     L.check(L.lib().ws_lstm_pack_pair(_p(whh_f), _p(whh_r), _p(pack), L.stream_ptr()), "ws_lstm_pack_pair")
 
 
-def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg_buf=None):
+def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None,
+                  repairable=False):
     """BPTT on the blocked layout over pairs of workgroups (lstm_pair.hip); gates: activated gates in,
     d(pre-activation gates) (BLS) out.  Returns the launch's timeout word; in place, so there is no device-side
     fall-back: poll_cluster_status raises (one step late, without a host sync) when a bounded wait timed out."""
-    for n, t in (("gates", gates), ("cbuf", cbuf), ("dhcat", dhcat), ("wpack", wpack)):
+    for n, t in (("gates", gates), ("cbuf", cbuf), ("dhcat", dhcat), ("wpack", wpack), ("dgates", dgates)):
         _chk(t, n)
     npair = 2 * (-(-sm.nseq // 32))
     sc = _cluster_scratch(gates.device)
@@ -498,10 +527,13 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg
     a = L.LstmPairArgs()
     a.gates, a.cbuf, a.dhcat, a.wpack = _p(gates), _p(cbuf), _p(dhcat), _p(wpack)
     a.xchg, a.flags = C.c_void_p(xchg.data_ptr()), C.c_void_p(flags.data_ptr())
-    a.status = C.c_void_p(status.data_ptr() if status is not None else sc.status.data_ptr() + 4)
+    # sticky status words: [0] time-outs a predicated fall-back repairs on the device (counted, reported once),
+    # [1] time-outs of an in-place BPTT (fatal: poll_cluster_status raises, FusedClipAdam skips the update on the device)
+    a.status = C.c_void_p(status.data_ptr() if status is not None else sc.status.data_ptr() + (0 if repairable else 4))
     a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
     a.dbg_buf = C.c_void_p(dbg_buf.data_ptr()) if dbg_buf is not None else None
-    _alg("lstm_bwd", 10 * 4 * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
+    a.gfmt, a.dgates = gfmt, _p(dgates)
+    _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
     L.check(L.lib().ws_lstm_bwd_pair(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_pair")
     return flags[npair * 8:npair * 8 + 1]
 
@@ -591,9 +623,23 @@ def sisdr_bwd(est, tgt, rowstat, gout, dest):
                                  L.stream_ptr()), "ws_sisdr_bwd")
 
 
-def grad_norms(tab, ntensors, norms):
-    L.check(L.lib().ws_grad_norms(C.c_void_p(tab.data_ptr()), ntensors, _p(norms), L.stream_ptr()),
+def _word(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def grad_norms(tab, ntensors, norms, guard=None):
+    """guard: optional 2-element int32 device tensor: [0] (zeroed by the caller before the launch) and [1] (sticky) are set
+    to 1 when a norm is NaN / Inf."""
+    L.check(L.lib().ws_grad_norms(C.c_void_p(tab.data_ptr()), ntensors, _p(norms), _word(guard), L.stream_ptr()),
             "ws_grad_norms")
+
+
+def bptt_status_word(device):
+    """The sticky status word of the in-place BPTT launches (pair / cluster kernels without a device-side fall-back) of
+    the current stream as a 1-element int32 view, or None when no such launch has happened on it."""
+    key = (device.type, device.index, L.stream_ptr().value)
+    sc = _CLUSTER_SCRATCH.get(key)
+    return sc.status[1:2] if sc is not None else None
 
 
 _WEIGHT_EPOCH = [0]
@@ -609,12 +655,21 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
-def clip_adam_step(tab, ntensors, norms, clip, lr, beta1, beta2, eps, weight_decay, step, clip_only=False):
+def clip_adam_step(tab, ntensors, norms, clip, lr, beta1, beta2, eps, weight_decay, step, clip_only=False, skip=(None, None)):
+    """skip: up to two 1-element int32 device tensors; the launch does nothing when one of them is non-zero at kernel
+    start (the guard of grad_norms, the BPTT status word: wesep_hip.h)."""
     if not clip_only:
         bump_weight_epoch()
     L.check(L.lib().ws_clip_adam_step(C.c_void_p(tab.data_ptr()), ntensors, _p(norms), clip, lr, beta1,
-                                      beta2, eps, weight_decay, step, int(clip_only), L.stream_ptr()),
+                                      beta2, eps, weight_decay, step, int(clip_only), _word(skip[0]), _word(skip[1]),
+                                      L.stream_ptr()),
             "ws_clip_adam_step")
+
+
+def debug_occupy(nblocks: int, usec: int, stop=None):
+    """Test support: holds `nblocks` CUs (112 KB of LDS each) for `usec` microseconds on the current stream, or until the
+    1-element int32 device tensor `stop` becomes non-zero (ws_debug_occupy)."""
+    L.check(L.lib().ws_debug_occupy(nblocks, usec, _word(stop), None, L.stream_ptr()), "ws_debug_occupy")
 
 
 def prof_enable(on: bool):
@@ -685,6 +740,30 @@ def from_blocked(xb: torch.Tensor, sm: SeqMap, P: int, split=False) -> torch.Ten
     return out
 
 
+# ---- BLH: the BL index formula on 2-byte elements (WS_GATES_H2 / H2S, wesep_hip.h): test / tool side views ----------
+def blh_bf16_pack(xb: torch.Tensor) -> torch.Tensor:
+    """BL-shaped fp32 [nblk][C/4][32][4] -> BLH buffer of bf16 elements (round to nearest even = the hi term of the split
+    pair), returned as float32 storage [nblk][C/4][32][2]."""
+    return xb.to(torch.bfloat16).contiguous().view(torch.float32)
+
+
+def blh_bf16_unpack(buf: torch.Tensor, nblk: int, C_: int) -> torch.Tensor:
+    """BLH buffer of bf16 elements (float32 storage) -> BL-shaped fp32 [nblk][C/4][32][4]."""
+    return buf.reshape(-1)[: nblk * 32 * C_ // 2].view(torch.bfloat16).view(nblk, C_ // 4, 32, 4).float()
+
+
+def blh_gates_unpack(buf: torch.Tensor, nblk: int) -> torch.Tensor:
+    """BLH(2 * 4H) buffer of unorm16 gate codes (float32 storage) -> BL-shaped fp32 activated gates
+    [nblk][2 * 4H / 4][32][4], decoded exactly like the kernels (one fp32 fma per element): i, f, o = u / 65535,
+    g = u / 32767.5 - 1 (column = dir * 4H + gate * H + unit -> the g gate's quads are (q >> 6) & 3 == 2)."""
+    Cq = 2 * 4 * L.LSTM_H // 4
+    code = (buf.reshape(-1)[: nblk * 32 * Cq * 2].view(torch.int16).to(torch.int32) & 0xFFFF).view(nblk, Cq, 32, 4).double()
+    s_sig = float(torch.tensor(1.0 / 65535.0, dtype=torch.float32))
+    s_tanh = float(torch.tensor(1.0 / 32767.5, dtype=torch.float32))
+    is_g = ((torch.arange(Cq, device=buf.device) >> 6) & 3 == 2).view(1, Cq, 1, 1)
+    return torch.where(is_g, code * s_tanh - 1.0, code * s_sig).float()
+
+
 # ---------------------------------------------------------------------------------------------
 # GEMMs between the plain Z layout and BL (gemm_blk.hip)
 # ---------------------------------------------------------------------------------------------
@@ -718,13 +797,14 @@ def gemm_p2b(*, A, lda: int, sm: SeqMap, Wpack, N: int, C_out, K=128, bias=None,
     L.check(L.lib().ws_gemm_p2b(C.byref(a), L.stream_ptr()), "ws_gemm_p2b")
 
 
-def gemm_b2p(*, A, K: int, sm: SeqMap, Wpack, C_out, ldc: int, N=128, bias=None, R=None):
+def gemm_b2p(*, A, K: int, sm: SeqMap, Wpack, C_out, ldc: int, N=128, bias=None, R=None, a_fmt=0):
+    """a_fmt = 1: A holds bf16 elements in BLH(K) (d(gates) of WS_GATES_H2) instead of split pairs in BL(K)."""
     for n, t in (("A", A), ("Wpack", Wpack), ("bias", bias), ("C", C_out), ("R", R)):
         _chk(t, n)
     a = L.GemmB2PArgs()
     a.A, a.Wpack, a.bias, a.R, a.C = _p(A), _p(Wpack), _p(bias), _p(R), _p(C_out)
     a.sm = _smc(sm)
-    a.ldc, a.N, a.K = ldc, N, K
+    a.ldc, a.N, a.K, a.a_fmt = ldc, N, K, a_fmt
     L.check(L.lib().ws_gemm_b2p(C.byref(a), L.stream_ptr()), "ws_gemm_b2p")
 
 
@@ -739,7 +819,8 @@ def tnb_splits(nblk: int, gtiles: int):
 
 def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_off: int, a0_cols: int,
              nblk: int, L_: int, slab, nsplit: int, blocks_per_split: int, a0_shift=0, A1=None, a1_width=0,
-             a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, dbg=0):
+             a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, g_fmt=0):
+    """g_fmt = 1: G holds bf16 elements in BLH(g_width) (d(gates) of WS_GATES_H2); needs 384 A columns."""
     for n, t in (("G", G), ("A0", A0), ("A1", A1), ("slab", slab), ("bslab", bslab), ("aslab", aslab)):
         _chk(t, n)
     a = L.GemmTNBArgs()
@@ -750,7 +831,7 @@ def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_
     a.g_width, a.g_off, a.g_cols = g_width, g_off, g_cols
     a.a0_width, a.a0_off, a.a0_cols, a.a0_shift = a0_width, a0_off, a0_cols, a0_shift
     a.a1_width, a.a1_off, a.a1_cols, a.a1_shift = a1_width, a1_off, a1_cols, a1_shift
-    a.nblk, a.L, a.nsplit, a.blocks_per_split, a.pad_ = nblk, L_, nsplit, blocks_per_split, dbg
+    a.nblk, a.L, a.nsplit, a.blocks_per_split, a.g_fmt = nblk, L_, nsplit, blocks_per_split, g_fmt
     L.check(L.lib().ws_gemm_tnb(C.byref(a), L.stream_ptr()), "ws_gemm_tnb")
 
 
@@ -978,12 +1059,12 @@ def lstm_pack_fused(wih_f, wih_r, whh_f, whh_r, pack):
     _call("ws_lstm_pack_fused", _p(wih_f), _p(wih_r), _p(whh_f), _p(whh_r), _p(pack))
 
 
-def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm: SeqMap):
+def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm: SeqMap, gfmt=0):
     for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("xn", xn), ("wpack", wpack), ("bias", bias)):
         _chk(t, n)
     a = L.LstmFusedArgs()
     a.gates, a.cbuf, a.hcat, a.xn, a.wpack, a.bias = _p(gates), _p(cbuf), _p(hcat), _p(xn), _p(wpack), _p(bias)
-    a.nseq, a.L = sm.nseq, sm.L
+    a.nseq, a.L, a.gfmt = sm.nseq, sm.L, gfmt
     L.check(L.lib().ws_lstm_fwd_fused(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_fused")
 
 

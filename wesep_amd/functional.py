@@ -156,6 +156,29 @@ def resrnn_mode() -> str:
     return os.environ.get("WESEP_RESRNN", "blocked")
 
 
+def _h2_probe() -> int:
+    """NUMERICS PROBE (tools/r04_h2_numerics.py; off by default): emulate narrower storage of the saved recurrence state
+    by rounding the fp32 buffers in place between kernels.  Bits: 1 = activated gates to fp16, 2 = d(gates) to bf16
+    (the hi term of the split pair only), 4 = cell state to fp16, 8 = activated gates to unorm16, 16 = d(hcat) to bf16."""
+    return int(os.environ.get("WESEP_H2_PROBE", "0"))
+
+
+def _probe_round(t, kind, packed=False):
+    """In-place rounding of an fp32 buffer.  packed: the buffer holds BLS pairs on the device (hi << 16 | lo): keeping the
+    hi term only IS bf16(x); on the CPU emulation it holds plain fp32."""
+    if kind == "f16":
+        t.copy_(t.half().float())
+    elif kind == "u16":      # BL(2048) activated gates: quad q = column >> 2, gate = (q >> 6) & 3; i, f, o in (0, 1), g in (-1, 1)
+        v = t.view(-1, 2, 4, 64 * 128)
+        v[:, :, 2].mul_(0.5).add_(0.5)
+        v.copy_(torch.floor(v * 65535.0 + 0.5) / 65535.0)
+        v[:, :, 2].mul_(2.0).sub_(1.0)
+    elif packed and torch.cuda.is_available():
+        t.view(torch.int32).bitwise_and_(-65536)
+    else:
+        t.copy_(t.bfloat16().float())
+
+
 def wgrad_overlap() -> bool:
     """Weight-gradient GEMMs of the blocked ResRNN on a side stream (default on; WESEP_WGRAD_OVERLAP=0
     keeps everything on the current stream)."""
@@ -327,46 +350,68 @@ class ResRNNBlkFn(torch.autograd.Function):
         W = _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, proj_w)
         wcat, bcat = W("cat")
         whf, whr = W("whh")
-        gates, xn = _empty(d, nb, 32 * 2 * G4), _empty(d, nb, 32 * N)
+        xn = _empty(d, nb, 32 * N)
         cbuf, hcat = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * 2 * H)
         cluster = dev.lstm_cluster_ok(seq, d)
+        ctx.bptt = _bptt_kind(seq, d, cluster)
+        # storage of the saved gates / d(gates) (dev.gates_fmt, wesep_hip.h WS_GATES_*): unorm16 gates in a BLH buffer of half
+        # the bytes by default; the opt-in cluster BPTT knows the fp32 format only
+        gfmt = L.GATES_F32 if ctx.bptt == "cluster" else dev.gates_fmt()
+        h2 = gfmt != L.GATES_F32
+        gates = _empty(d, dev.blh_floats(nb, 2 * G4)) if h2 else _empty(d, nb, 32 * 2 * G4)
         if dev.lstm_fuse_ok(seq.nseq, cluster):
             # band view: the recurrence computes x W_ih^T itself from the normalised input (BL(128)): the 16E-byte
             # pre-activation buffer is never written and read back (lstm_fused.hip)
             dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, stats=stats, gamma=norm_w,
                          beta=norm_b, stat_map=smap)
-            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, W("fused"), bcat, seq)
+            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, W("fused"), bcat, seq, gfmt=gfmt)
         else:
-            xproj = dict(A=z, lda=N, sm=seq, Wpack=W("wih"), N=2 * G4, C_out=gates, bias=bcat, A_bl=xn,
+            # pre-activations: in `gates` itself with the fp32 format (one buffer, three lives); with the 2-byte formats a
+            # scratch buffer that dies with this forward (the recurrences read it and write the unorm16 gates next to it)
+            pre = _empty(d, nb, 32 * 2 * G4) if h2 else gates
+            xproj = dict(A=z, lda=N, sm=seq, Wpack=W("wih"), N=2 * G4, C_out=pre, bias=bcat, A_bl=xn,
                          stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap)
+            rec = dict(gfmt=gfmt, gates_in=pre) if h2 else {}
             dev.gemm_p2b(**xproj)
             if cluster:
                 # weight-stationary cluster kernel; behind it the streaming pair predicated on the launch's timeout
                 # word: two empty launches after a clean run, the whole layer again if the cluster's workgroups
-                # were not co-resident (another stream / process on the GPU) -- never NaN (wesep_hip.h)
-                tw = dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq, dbg=_cluster_dbg())
-                dev.gemm_p2b(run_if=tw, **xproj)
-                dev.lstm_fwd(gates, cbuf, hcat, W("hh")[0], seq, lmode, run_if=tw)
+                # were not co-resident (another stream / process on the GPU) -- never NaN (wesep_hip.h).  The 2-byte
+                # formats leave the pre-activations intact: only the recurrence is repeated
+                tw = dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq, dbg=_cluster_dbg(), **rec)
+                if not h2:
+                    dev.gemm_p2b(run_if=tw, **xproj)
+                dev.lstm_fwd(gates, cbuf, hcat, W("hh")[0], seq, lmode, run_if=tw, **rec)
             else:
-                dev.lstm_fwd(gates, cbuf, hcat, W("hh")[0], seq, lmode)
+                dev.lstm_fwd(gates, cbuf, hcat, W("hh")[0], seq, lmode, **rec)
+            del pre
         pw = W("pw")
         out = torch.empty_like(z)
         dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=W("proj"), C_out=out, ldc=N, bias=proj_b, R=z)
-        ctx.bptt = _bptt_kind(seq, d, cluster)
+        if _h2_probe() and not h2:
+            if _h2_probe() & 1:
+                _probe_round(gates, "f16")
+            if _h2_probe() & 8:
+                _probe_round(gates, "u16")
+            if _h2_probe() & 4:
+                _probe_round(cbuf, "f16")
         if any(ctx.needs_input_grad):     # (grad mode itself is always off inside a Function's forward)
             # the backward's packs (transposed projections, BPTT weight stream) are built here, where the GPU has a
             # single stream to serve: built lazily in the backward, these 10 us launches queue behind the side stream's
             # chip-filling weight-gradient GEMMs for up to a millisecond each (round 2 profile: 4 ms per step)
             W("projT"), W("wihT")
-            W("hhp") if ctx.bptt == "pair" else (W("hh") if ctx.bptt == "stream" else None)
+            if ctx.bptt == "pair":
+                W("hhp")
+            if ctx.bptt == "stream" or (ctx.bptt == "pair" and h2):
+                W("hh")     # (the pair BPTT's predicated streaming fall-back of the 2-byte formats)
         ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn, wcat, norm_w, norm_b, pw, whf, whr)
-        ctx.view, ctx.box, ctx.lmode, ctx.cluster = view, box, lmode, cluster
+        ctx.view, ctx.box, ctx.lmode, ctx.cluster, ctx.gfmt = view, box, lmode, cluster, gfmt
         ctx.packs = W
         ctx.consumed = False
         return out
 
     @staticmethod
-    def _weight_grads(gates, xn, hcat, dout_bl, seq, nb, N):
+    def _weight_grads(gates, xn, hcat, dout_bl, seq, nb, N, g_fmt=0):
         """[dW_ih | dW_hh | db] of both directions in one pass over each direction's dgates, and
         dW_proj / db_proj; launched on the current stream.  Returns them in parameter order."""
         d = gates.device
@@ -387,7 +432,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             dev.gemm_tnb(G=gates, g_width=2 * G4, g_off=di * G4, g_cols=G4, A0=xn, a0_width=N, a0_off=0,
                          a0_cols=N, A1=hcat, a1_width=2 * H, a1_off=di * H, a1_cols=H,
                          a1_shift=(-1 if di == 0 else 1), nblk=nb, L_=seq.L, slab=slab, nsplit=ns,
-                         blocks_per_split=bps, bslab=bslab)
+                         blocks_per_split=bps, bslab=bslab, g_fmt=g_fmt)
             dw = _reduce_new(slab, ns, G4 * (N + H), (G4, N + H))
             dwih.append(dw[:, :N].contiguous())
             dwhh.append(dw[:, N:].contiguous())
@@ -416,6 +461,8 @@ class ResRNNBlkFn(torch.autograd.Function):
         # d(hcat) = dout Wp  (+ dout itself in BL for the weight gradient)
         dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
         dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=W("projT"), N=2 * H, C_out=dh, A_bl=dout_bl)
+        if _h2_probe() & 16:
+            _probe_round(dh, "bf16")
         # BPTT: gates (activated) -> d(pre-activation gates), in place.  A time-view recurrence leaves
         # half of the chip idle: the weight-gradient jobs deferred by the previous layers are released
         # right after it is launched
@@ -424,20 +471,43 @@ class ResRNNBlkFn(torch.autograd.Function):
         # of the CUs, so the side stream keeps the other half.  The cluster BPTT (all 256 CUs: it evicts the
         # side-stream weight-gradient GEMMs) stays opt-in (WESEP_LSTM_CLUSTER_BWD=1).  Both work in place without a
         # device-side fall-back: FusedClipAdam.step looks at their status word (asynchronously for the pair kernel)
+        gfmt = ctx.gfmt
+        g_fmt = 1 if gfmt == L.GATES_H2 else 0
         if ctx.bptt == "cluster":
+            dg = gates
             dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
+        elif gfmt == L.GATES_F32:
+            # ABI <= 14 format: split-pair d(gates) in place over the fp32 gates; a pair time-out has no device-side repair
+            # (FusedClipAdam skips the update on the device and raises)
+            dg = gates
+            if ctx.bptt == "pair":
+                dev.lstm_bwd_pair(gates, cbuf, dh, W("hhp"), seq, dbg=_pair_dbg())
+            else:
+                dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode)
         elif ctx.bptt == "pair":
-            dev.lstm_bwd_pair(gates, cbuf, dh, W("hhp"), seq)
+            # 2-byte formats: d(gates) go to a buffer of their own (bf16 in BLH for H2: the same bytes written as in place),
+            # so the saved gates survive the launch and the streaming BPTT can stand behind it, predicated on the launch's
+            # time-out word: an empty launch after a clean run, the whole BPTT again if the pair's workgroups were not
+            # co-resident (a resident RCCL kernel, another process) -- no NaN reaches a consumer (wesep_hip.h)
+            dg = _empty(d, dev.blh_floats(nb, 2 * G4)) if gfmt == L.GATES_H2 else _empty(d, nb, 32 * 2 * G4)
+            tw = dev.lstm_bwd_pair(gates, cbuf, dh, W("hhp"), seq, gfmt=gfmt, dgates=dg, repairable=True, dbg=_pair_dbg())
+            dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode, gfmt=gfmt, dgates=dg, run_if=tw)
         else:
-            dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode)
+            # streaming BPTT (band view): bf16 d(gates) in place over the unorm16 gates (H2) / split pairs to their own
+            # buffer (H2S)
+            dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else gates
+            dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode, gfmt=gfmt,
+                         dgates=dg if gfmt == L.GATES_H2S else None)
+        if _h2_probe() & 2 and gfmt == L.GATES_F32:
+            _probe_round(gates, "bf16", packed=True)
         if ready is not None:
             flush_deferred_wgrads(d, ready)
         del dh
         # weight gradients: a side branch of the graph -> deferred to the side stream when a carrier
         # will deliver them
         if box is not None:
-            def job(side, gates=gates, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, N=N, box=box):
-                box.grads = ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N)
+            def job(side, gates=dg, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, N=N, box=box, g_fmt=g_fmt):
+                box.grads = ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N, g_fmt)
                 box.event = torch.cuda.Event()
                 box.event.record(side)
                 for t in (gates, xn, hcat, dout_bl):
@@ -445,11 +515,11 @@ class ResRNNBlkFn(torch.autograd.Function):
             _pending(d).append(job)
             wg = [None] * 10
         else:
-            wg = ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N)
+            wg = ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt)
         del dout_bl
         # d(normalised input) = dgates Wcat -> GroupNorm backward (+ residual path)
         dxn = _empty(d, P, N)
-        dev.gemm_b2p(A=gates, K=2 * G4, sm=seq, Wpack=W("wihT"), C_out=dxn, ldc=N)
+        dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=W("wihT"), C_out=dxn, ldc=N, a_fmt=g_fmt)
         dz = torch.empty_like(z)
         if dev.gn_bwd_fused_ok(geo):
             # band view: 16 032 groups of 16 KB -- one wave per group, x / dxn / dout cross HBM once (norm.hip)
@@ -474,6 +544,12 @@ def _bptt_kind(seq, device, cluster) -> str:
     if cluster and os.environ.get("WESEP_LSTM_CLUSTER_BWD", "0") == "1":
         return "cluster"
     return "pair" if dev.lstm_pair_ok(seq, device) else "stream"
+
+
+def _pair_dbg() -> int:
+    """WESEP_PAIR_FORCE_TIMEOUT=1 (tests): every pair BPTT launch times out in pair 0 at step 2, so the predicated
+    streaming fall-back produces the layer's d(gates)."""
+    return 8 if os.environ.get("WESEP_PAIR_FORCE_TIMEOUT", "0") == "1" else 0
 
 
 def _cluster_dbg() -> int:
