@@ -115,20 +115,37 @@ def _cpu_reference_worker(threads, budget_s):
 
 def cpu_baseline(budget_s=30.0, hard_limit_s=240.0, kind="port"):
     """Oracle (CPU port of the reference step) timed on this host's cores in a child process so a
-    pathological host (hundreds of cores, oversubscription) cannot stall the benchmark."""
+    pathological host (hundreds of cores, oversubscription) cannot stall the benchmark.
+
+    Cores (BASELINE.md section 3 asks for the host's cores, count stated): the step is timed twice on a bounded sample --
+    with 16 threads (twice the reference recipe's OMP_NUM_THREADS=8; what a torch CPU LSTM over 2 rows x 32 bands can keep
+    busy) and with every core of the host (capped at 128) -- and the FASTER run is reported, with both in `sample`: on the
+    256-core GPU hosts the all-core run is slower (oversubscribed oneDNN / intra-op pools on 501 sequential steps)."""
     import subprocess
-    threads = min(os.cpu_count() or 1, 16)
+    ncpu = os.cpu_count() or 1
     worker = "_cpu_reference_worker" if kind == "reference" else "_cpu_baseline_worker"
-    cmd = [sys.executable, "-c",
-           f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.{worker}({threads}, {budget_s})"]
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
-    try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_limit_s, env=env, cwd=ROOT)
-        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-        return json.loads(line)
-    except Exception as e:  # timeout or failure: report it rather than hiding it
-        return {"value": None, "unit": "utterances/s", "cores": threads, "kind": kind,
-                "sample": f"cpu baseline did not finish within {hard_limit_s:.0f} s ({type(e).__name__})"}
+    tries = sorted({min(ncpu, 16), min(ncpu, 128)})
+    runs = []
+    for threads in tries:
+        cmd = [sys.executable, "-c",
+               f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.{worker}({threads}, {budget_s / len(tries)})"]
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_limit_s / len(tries), env=env, cwd=ROOT)
+            runs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
+        except Exception as e:  # timeout or failure: report it rather than hiding it
+            runs.append({"value": None, "unit": "utterances/s", "cores": threads, "kind": kind,
+                         "sample": f"cpu baseline with {threads} threads did not finish within "
+                                   f"{hard_limit_s / len(tries):.0f} s ({type(e).__name__})"})
+    ok = [r for r in runs if r["value"]]
+    if not ok:
+        return runs[0]
+    best = max(ok, key=lambda r: r["value"])
+    if len(runs) > 1:
+        best = dict(best, sample=best["sample"] + "; the faster of the runs with " +
+                    " / ".join(f"{r['cores']} threads ({r['value']:.3f} utt/s)" if r["value"] else f"{r['cores']} threads (failed)"
+                               for r in runs))
+    return best
 
 
 def _latest_profile(kind):
@@ -240,16 +257,22 @@ def main():
     K, Tf = 32, 1 + T // 128
     P = R * K * Tf
     flops_per_launch = 2.0 * P * 2 * L.LSTM_H * 4 * L.LSTM_H        # fp32-equivalent, both directions
-    # algorithmic HBM bytes of one recurrence launch: per position, direction and
-    # hidden unit: fwd reads 4 gate pre-activations, writes 4 activated gates + c + h; bwd reads 4 gates,
-    # c, d(h) (c_{t-1} is the next step's c: L2), writes 4 d(gates): 10 fp32 either way
-    bytes_per_launch = 10.0 * 4 * P * 2 * L.LSTM_H
+    # algorithmic HBM bytes of one recurrence launch: per position, direction and hidden unit the BPTT
+    # reads 4 saved gates, c, d(h) (c_{t-1} is the next step's c: L2) and writes 4 d(gates): 40 B with the round-3 format
+    # (fp32 gates, split-pair d(gates)), 24 B with the default WS_GATES_H2 (unorm16 gates, bf16 d(gates)), 32 B with H2S;
+    # the forward reads 4 fp32 pre-activations (time view; the band view's fused projection reads the 128-wide input
+    # instead: 1 B per cell) and writes 4 gates + c + h: 40 B before, 32 / 17 B now (launch average 24.5)
+    gfmt = dev.gates_fmt()
+    bwd_cell = dev._bptt_bytes(gfmt)
+    fwd_cell = 40.0 if gfmt == L.GATES_F32 else 24.5
+    cell_bytes = {"lstm_bwd": float(bwd_cell), "lstm_fwd": fwd_cell}
     prof = {}
     for name, kind in (("lstm_fwd", L.PROF_LSTM_FWD), ("lstm_bwd", L.PROF_LSTM_BWD),
                        ("gemm_nt", L.PROF_GEMM_NT), ("gemm_tn", L.PROF_GEMM_TN)):
         ms, n = dev.prof_collect(kind)
         prof[name] = {"ms_total": ms, "launches": n, "ms_avg": ms / max(n, 1)}
     dom = "lstm_bwd" if prof["lstm_bwd"]["ms_total"] >= prof["lstm_fwd"]["ms_total"] else "lstm_fwd"
+    bytes_per_launch = cell_bytes[dom] * P * 2 * L.LSTM_H
     sec = prof[dom]["ms_avg"] * 1e-3 if prof[dom]["launches"] else float("inf")
     gbs = bytes_per_launch / sec / 1e9
     tfl = flops_per_launch / sec / 1e12
@@ -304,6 +327,12 @@ def main():
                                    ") and the band view (" + dom + "_bf16_kernel<BLK>)",
                          "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": bytes_per_launch,
+                         "bytes_per_cell": cell_bytes[dom],
+                         "gates_format": {L.GATES_F32: "f32", L.GATES_H2: "h2 (unorm16 gates, bf16 d(gates))",
+                                          L.GATES_H2S: "h2s (unorm16 gates, split-pair d(gates))"}[gfmt],
+                         # the same launches priced at round 3's 40 B per cell (fp32 gates, split-pair d(gates)), for
+                         # comparison with the earlier rounds' lines: bytes that no longer move are not achieved bandwidth
+                         "frac_at_round3_bytes": 40.0 * P * 2 * L.LSTM_H / sec / 1e9 / HBM_PEAK_GBS,
                          "ms_per_launch": prof[dom]["ms_avg"],
                          "mfma": {"alg_tflops": tfl, "executed_bf16_tflops": 3 * tfl,
                                   "peak_bf16_tflops": BF16_MFMA_PEAK_TFLOPS,

@@ -225,6 +225,7 @@ typedef struct ws_lstm_args {
   const float* gates_in;
   float* dgates;
   int gfmt, pad_;
+  const unsigned* amax;  /* WS_GATES_H2F, backward: max |dhcat| of this launch as float bits (see WS_GATES_H2F) */
 } ws_lstm_args;
 /* Storage format of the saved activated gates and of d(pre-activation gates) on the blocked layout (ABI v15).
  * BLH(C): the BL(C) index formula with 2-byte elements -- element (b, slot i, column c) at 2-byte index
@@ -240,6 +241,16 @@ typedef struct ws_lstm_args {
 #define WS_GATES_F32 0
 #define WS_GATES_H2 1
 #define WS_GATES_H2S 2
+/*   WS_GATES_H2F (3): activated gates as in H2; d(gates) as SCALED fp16, in place or to `dgates` like H2:
+ *                     stored = fp16(clamp(x * S, +-65504)),  S = ws_dgates_scale(*amax) = the power of two that puts
+ *                     max |d(hcat)| of the launch -- the word `amax` (float bits), raised by the ws_gemm_p2b launch that
+ *                     produced d(hcat) (ws_gemm_p2b_args.amax; the caller zeroes it) -- into [2^10, 2^11): d(gates)
+ *                     never exceed a few times max |d(hcat)|, so nothing saturates in practice (the clamp is the bound),
+ *                     and everything down to 2^-24 of the largest keeps fp16's 11 bits -- 8x finer than bf16, at the same
+ *                     2 bytes.  Consumers (ws_gemm_b2p a_fmt = 2, ws_gemm_tnb g_fmt = 2) read `amax` themselves, rebuild
+ *                     split-bf16 fragments in registers (an fp16 value splits EXACTLY into bf16 hi + lo) and undo S (exact)
+ *                     in their epilogues.  The default of the Python path.                                            */
+#define WS_GATES_H2F 3
 #define WS_LSTM_F32_MT1 1 /* exact-fp32 MFMA, 16 sequences per workgroup                       */
 #define WS_LSTM_F32_MT2 2 /* exact-fp32 MFMA, 32 sequences per workgroup                       */
 #define WS_LSTM_BF16X3 3  /* split-bf16 (hi/lo, 3 bf16 MFMAs per product, fp32 accumulate), 32 */
@@ -317,9 +328,10 @@ typedef struct ws_lstm_pair_args {
   float* dbg_buf;       /* NULL, or npair * L * 2 * 2 * 4096 floats: per (pair, step, member) the partial it sent and
                            the partial it received (diagnosis only, tools/pair_diag.py)                       */
   int nseq, L;
-  int dbg, gfmt;        /* gfmt (ABI v15): WS_GATES_*; H2: unorm16 gates in, bf16 d(gates) out -- to `dgates` (BLH) when given,
-                           else in place; H2S: d(gates) as BLS pairs to `dgates`                                      */
+  int dbg, gfmt;        /* gfmt (ABI v15): WS_GATES_*; H2 / H2F: unorm16 gates in, bf16 / scaled-fp16 d(gates) out -- to `dgates`
+                           (BLH) when given, else in place; H2S: d(gates) as BLS pairs to `dgates`                     */
   float* dgates;
+  const unsigned* amax; /* WS_GATES_H2F: max |dhcat| of this launch as float bits */
 } ws_lstm_pair_args;
 int ws_lstm_pack_pair(const float* whh_f, const float* whh_r, float* pack, void* stream);
 int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream);
@@ -369,6 +381,8 @@ typedef struct ws_gemm_p2b_args {
   long long lda, st_m1, st_m2, st_base;
   int st_div1, st_div2, N, K;
   const unsigned* run_if;   /* optional device word: the launch does nothing unless *run_if != 0 */
+  unsigned* amax;           /* optional device word (ABI v15): raised (atomic max on the float bits) to max |C| of this
+                               launch; the caller zeroes it.  The scale source of WS_GATES_H2F                     */
 } ws_gemm_p2b_args;
 int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream);
 
@@ -383,7 +397,9 @@ typedef struct ws_gemm_b2p_args {
   ws_seqmap sm;
   long long ldc;
   int N, K;
-  int a_fmt, pad_;   /* ABI v15: 0 = A holds BLS pairs (BL(K)); 1 = A holds bf16 elements (BLH(K)): d(gates) of WS_GATES_H2 */
+  int a_fmt, pad_;   /* ABI v15: 0 = A holds BLS pairs (BL(K)); 1 = A holds bf16 elements (BLH(K)): d(gates) of WS_GATES_H2;
+                        2 = A holds scaled fp16 elements (BLH(K)): d(gates) of WS_GATES_H2F, scale from `amax`        */
+  const unsigned* amax;
 } ws_gemm_b2p_args;
 int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream);
 
@@ -407,7 +423,9 @@ typedef struct ws_gemm_tnb_args {
   int a0_width, a0_off, a0_cols, a0_shift;
   int a1_width, a1_off, a1_cols, a1_shift;
   int nblk, L, nsplit, blocks_per_split;
-  int g_fmt;         /* ABI v15: 0 = G holds BLS pairs; 1 = G holds bf16 elements (BLH(g_width)): d(gates) of WS_GATES_H2 */
+  int g_fmt;         /* ABI v15: 0 = G holds BLS pairs; 1 = G holds bf16 elements (BLH(g_width)): d(gates) of WS_GATES_H2;
+                        2 = scaled fp16 elements: d(gates) of WS_GATES_H2F, scale from `amax` (slab / bslab come out unscaled) */
+  const unsigned* amax;
 } ws_gemm_tnb_args;
 int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream);
 

@@ -96,8 +96,15 @@ def _skip(run_if):
     return run_if is not None and int(run_if.reshape(-1)[0]) == 0
 
 
+def dgates_scale(amax):
+    """WS_GATES_H2F (wesep_hip.h, common.h ws_dgates_scale): the power of two that puts max |d(hcat)| into [2^10, 2^11);
+    `amax`: 1-element int32 tensor holding float bits."""
+    e = (int(amax.reshape(-1)[0]) >> 23) & 0xFF
+    return 1.0 if e in (0, 255) else 2.0 ** (min(max(264 - e, 1), 253) - 127)
+
+
 def gemm_p2b(*, A, lda, sm, Wpack, N, C_out, K=128, bias=None, A_bl=None, stats=None, gamma=None, beta=None,
-             stat_map=None, run_if=None):
+             stat_map=None, run_if=None, amax=None):
     if _skip(run_if):
         return
     nt, L = _ntile(sm), sm.L
@@ -116,11 +123,21 @@ def gemm_p2b(*, A, lda, sm, Wpack, N, C_out, K=128, bias=None, A_bl=None, stats=
         if bias is not None:
             out = out + bias.reshape(-1)[:N]
         bl_put(C_out, out * _valid(sm), nt, L, N)
+        if amax is not None:       # atomic max on the float bits of max |C|
+            m = (out * _valid(sm)).abs().max().reshape(1).float()
+            amax.reshape(-1)[0] = max(int(amax.reshape(-1)[0]), int(m.view(torch.int32)[0]))
 
 
-def gemm_b2p(*, A, K, sm, Wpack, C_out, ldc, N=128, bias=None, R=None, a_fmt=0):
+def _g16(buf, nt, L, C, fmt, amax):
+    """2-byte d(gates): fmt 1 = bf16, fmt 2 = fp16 scaled by dgates_scale(amax)."""
+    if fmt == 1:
+        return blh_get(buf, nt, L, C, torch.bfloat16).float()
+    return blh_get(buf, nt, L, C, torch.float16).float() / dgates_scale(amax)
+
+
+def gemm_b2p(*, A, K, sm, Wpack, C_out, ldc, N=128, bias=None, R=None, a_fmt=0, amax=None):
     nt, L = _ntile(sm), sm.L
-    x = (blh_get(A, nt, L, K, torch.bfloat16).float() if a_fmt else bl_get(A, nt, L, K))[: sm.nseq]
+    x = (_g16(A, nt, L, K, a_fmt, amax) if a_fmt else bl_get(A, nt, L, K))[: sm.nseq]
     out = x @ _PACKS[Wpack.data_ptr()].t()
     if bias is not None:
         out = out + bias.reshape(-1)[:N]
@@ -199,17 +216,17 @@ def make_lstm_fwd(plain_fwd):
 
 
 def make_lstm_bwd(plain_bwd):
-    def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode=3, gfmt=0, dgates=None, run_if=None):
+    def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode=3, gfmt=0, dgates=None, run_if=None, amax=None):
         if _skip(run_if):
             return
         if mode not in (4, 5):
             return plain_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode)
         whf, whr = _whh_from_pack(wpack)
-        _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt, dgates)
+        _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt, dgates, amax)
     return lstm_bwd
 
 
-def _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt=0, dgates=None):
+def _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt=0, dgates=None, amax=None):
     """gfmt 0: fp32 gates in, d(gates) in place; 1 (H2): unorm16 gates in, bf16 d(gates) in place; 2 (H2S): unorm16 gates
     in, d(gates) to `dgates` (fp32 here: the emulation does not model the split pair's 2^-17)."""
     nt, L = _ntile(sm), sm.L
@@ -219,6 +236,9 @@ def _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt=0, dgates=None):
     dpre = _recur_bwd(act, cs, dh, whf, whr).reshape(nt * 32, L, 2 * G4) * _valid(sm)
     if gfmt == 1:
         blh_put(dgates if dgates is not None else gates, dpre, nt, L, 2 * G4, torch.bfloat16)
+    elif gfmt == 3:      # H2F: fp16(clamp(x * S))
+        sc = (dpre * dgates_scale(amax)).clamp(-65504.0, 65504.0)
+        blh_put(dgates if dgates is not None else gates, sc, nt, L, 2 * G4, torch.float16)
     else:
         bl_put(dgates if gfmt == 2 else gates, dpre, nt, L, 2 * G4)
 
@@ -244,7 +264,8 @@ def lstm_pack_pair(whh_f, whh_r, pack):
     pack.reshape(-1)[: 2 * G4 * H] = torch.stack([whh_f, whh_r]).reshape(-1)      # raw weights, like emu_dev.lstm_pack
 
 
-def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None, repairable=False):
+def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None, repairable=False,
+                  amax=None):
     """Returns the launch's timeout word like dev.lstm_bwd_pair; dbg & 8 emulates the forced timeout (NaN-poisoned
     d(gates), both words set)."""
     if dbg & 8:
@@ -252,7 +273,7 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0, dbg_buf=Non
         if status is not None:
             status.fill_(1)
         return torch.ones(1, dtype=torch.int32)
-    _bwd_into(gates, cbuf, dhcat, *_whh_from_pack(wpack), sm, gfmt, dgates)
+    _bwd_into(gates, cbuf, dhcat, *_whh_from_pack(wpack), sm, gfmt, dgates, amax)
     return torch.zeros(1, dtype=torch.int32)
 
 
@@ -266,7 +287,7 @@ def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm, gfmt=0):
 
 
 def gemm_tnb(*, G, g_width, g_off, g_cols, A0, a0_width, a0_off, a0_cols, nblk, L_, slab, nsplit, blocks_per_split,
-             a0_shift=0, A1=None, a1_width=0, a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, g_fmt=0):
+             a0_shift=0, A1=None, a1_width=0, a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, g_fmt=0, amax=None):
     nt = nblk // L_
 
     def shifted(buf, width, off, cols, shift):
@@ -279,7 +300,7 @@ def gemm_tnb(*, G, g_width, g_off, g_cols, A0, a0_width, a0_off, a0_cols, nblk, 
         else:
             out[:, -shift:] = x[:, : L_ + shift]
         return out
-    g = (blh_get(G, nt, L_, g_width, torch.bfloat16).float() if g_fmt else bl_get(G, nt, L_, g_width))[:, :, g_off:g_off + g_cols]
+    g = (_g16(G, nt, L_, g_width, g_fmt, amax) if g_fmt else bl_get(G, nt, L_, g_width))[:, :, g_off:g_off + g_cols]
     a = shifted(A0, a0_width, a0_off, a0_cols, a0_shift)
     if A1 is not None:
         a = torch.cat([a, shifted(A1, a1_width, a1_off, a1_cols, a1_shift)], 2)

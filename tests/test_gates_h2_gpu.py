@@ -5,9 +5,11 @@ The formats change what is STORED, not what is computed, so the statements are e
   * forward (streaming 32 / 16 sequences, fused projection 32 / 64 sequences, cluster): cell state and h bit-identical to
     the fp32-format launch; the unorm16 gate codes decode to the fp32 gates within half a code step;
   * BPTT (streaming 32 / 16, pair) on gates that sit on the unorm16 grid: WS_GATES_H2S d(gates) bit-identical to the fp32
-    format's split pairs, WS_GATES_H2 d(gates) bit-identical to their hi terms (bf16, round to nearest even);
-  * ws_gemm_b2p (a_fmt 1) / ws_gemm_tnb (g_fmt 1) on bf16 operands: bit-identical to the split-pair kernels fed the same
-    values with a zero lo term, and within the split-product tolerance of fp64."""
+    format's split pairs, WS_GATES_H2 d(gates) bit-identical to their hi terms (bf16, round to nearest even), WS_GATES_H2F
+    d(gates) = fp16 of the scaled value (half an fp16 ulp + the split pair's 2^-17 from the fp32 format's);
+  * ws_gemm_b2p (a_fmt 1 / 2) / ws_gemm_tnb (g_fmt 1 / 2) on bf16 / scaled-fp16 operands: bit-identical to the split-pair
+    kernels fed the same values (zero lo term / the exact bf16 hi + lo split of an fp16 value; the power-of-two scale is
+    exact to undo), and within the split-product tolerance of fp64."""
 import pytest
 import torch
 
@@ -135,6 +137,9 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
         else:
             dev.lstm_bwd(gates, cbuf, hcat, dh, pb, seq, mode, gfmt=gfmt, dgates=dgates)
 
+    def bits(t):                                                  # (codes read as fp32 hold NaN patterns: compare bits)
+        return t.contiguous().view(torch.int32)
+
     ref = gq.clone()
     bptt(ref, L.GATES_F32)                                        # split pairs, in place over fp32 gates
     h2s_g, h2s_d = gh.clone(), torch.full_like(pre, float("nan"))
@@ -143,15 +148,69 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
     bptt(h2, L.GATES_H2)
     h2b = gh.clone()
     bptt(h2b, L.GATES_H2)
+    h2o_g, h2o_d = gh.clone(), torch.zeros_like(gh)               # H2, out of place
+    bptt(h2o_g, L.GATES_H2, h2o_d)
     torch.cuda.synchronize()
     assert int(st.item()) == 0
-    assert torch.equal(h2s_g, gh)                                 # H2S leaves the saved gates alone
-    assert torch.equal(h2s_d.view(torch.int32), ref.view(torch.int32))
-    hi = (ref.contiguous().view(torch.int32) >> 16).to(torch.int16)           # bf16 hi terms of the split pairs
+    assert torch.equal(bits(h2s_g), bits(gh))                     # H2S leaves the saved gates alone
+    assert torch.equal(bits(h2s_d), bits(ref))
+    hi = (bits(ref) >> 16).to(torch.int16)                        # bf16 hi terms of the split pairs
     got = h2.reshape(-1)[: ref.numel() // 2].view(torch.int16).view(hi.shape)
     assert torch.equal(got, hi)
-    assert torch.equal(h2, h2b)                                   # deterministic
-    assert float(dev.bls_unpack(ref).abs().max()) > 0.0
+    assert torch.equal(bits(h2), bits(h2b))                       # deterministic
+    assert torch.equal(bits(h2o_g), bits(gh)) and torch.equal(bits(h2o_d), bits(h2))
+    dg = dev.bls_unpack(ref)
+    assert float(dg.abs().max()) > 0.0
+    # ---- H2F: fp16 of d(gates) scaled by the power of two that max |d(hcat)| defines ------------------------------------
+    amax = dh.abs().max().reshape(1).view(torch.int32).clone()    # what ws_gemm_p2b's atomic max leaves behind
+    e = (int(amax.item()) >> 23) & 0xFF
+    S = 2.0 ** (264 - e - 127)
+    f_in, f_out_g, f_out_d = gh.clone(), gh.clone(), torch.zeros_like(gh)
+
+    def bptt_f(gates, dgates=None):
+        if kind == "pair":
+            dev.lstm_bwd_pair(gates, cbuf, dh, pp, seq, status=st, gfmt=L.GATES_H2F, dgates=dgates, amax=amax)
+        else:
+            dev.lstm_bwd(gates, cbuf, hcat, dh, pb, seq, mode, gfmt=L.GATES_H2F, dgates=dgates, amax=amax)
+
+    bptt_f(f_in)
+    bptt_f(f_out_g, f_out_d)
+    torch.cuda.synchronize()
+    assert torch.equal(bits(f_out_g), bits(gh)) and torch.equal(bits(f_out_d), bits(f_in))
+    got = f_in.reshape(-1)[: ref.numel() // 2].view(torch.float16).view(dg.shape).float() / S
+    assert float((dg.abs() * S).max()) < 65504.0                  # nothing near the clamp
+    err = (got - dg).abs()
+    bound = dg.abs() * (2.0 ** -11 + 2.0 ** -16) + (2.0 ** -24) / S      # half an fp16 ulp (+ subnormal step) + the pair's 2^-17
+    assert bool((err <= bound).all()), float((err / bound).max())
+    assert float((got - dg).norm() / dg.norm()) < 3e-4
+
+
+@pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37))])
+def test_gemm_b2p_scaled_fp16_operand(view, dims):
+    """a_fmt = 2: A = fp16(x * S) -- the three-term product of the exact bf16 hi + lo split of the stored value, times 1 / S:
+    the same bits as the split-pair kernel fed x (on the fp16 grid) itself."""
+    from wesep_amd import dev
+    from wesep_amd.functional import _view_maps
+    d = _cuda()
+    g = torch.Generator().manual_seed(14)
+    R, K, Tf = dims
+    P, Kd = R * K * Tf, 2048
+    geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+    amax = torch.tensor([3.1e-6], dtype=torch.float32).view(torch.int32).to(d)      # max |d(hcat)| of a training step
+    S = 2.0 ** (264 - ((int(amax.item()) >> 23) & 0xFF) - 127)
+    Ah = (rnd(g, P, Kd) * 1e-6 * S).to(torch.float16)             # what the BPTT would have stored
+    A = Ah.float() / S                                             # the values it stands for (exact)
+    W = rnd(g, N, Kd, scale=0.05)
+    wp = torch.empty(N * Kd, device=d)
+    dev.pack_w(W.t().contiguous().to(d), N, Kd, N, wp, trans=True, order=1)
+    Abl = dev.to_blocked(A.to(d), seq)
+    Ahbl = dev.to_blocked(Ah.float().to(d), seq).to(torch.float16).contiguous().view(torch.float32)
+    C_ref, C_new = torch.full((P, N), float("nan"), device=d), torch.full((P, N), float("nan"), device=d)
+    dev.gemm_b2p(A=dev.bls_pack(Abl), K=Kd, sm=seq, Wpack=wp, C_out=C_ref, ldc=N)
+    dev.gemm_b2p(A=Ahbl, K=Kd, sm=seq, Wpack=wp, C_out=C_new, ldc=N, a_fmt=2, amax=amax)
+    torch.cuda.synchronize()
+    assert torch.equal(C_ref, C_new)
+    assert rel(C_new, A.double() @ W.double().t()) < 4e-5
 
 
 @pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37))])
@@ -193,19 +252,27 @@ def test_gemm_tnb_bf16_g_operand(view, dims):
     Gbl = dev.to_blocked(G.to(d), seq)
     A0b, A1b = dev.to_blocked(A0.to(d), seq, split=True), dev.to_blocked(A1.to(d), seq, split=True)
     G_pairs, G_bf16 = dev.bls_pack(Gbl), dev.blh_bf16_pack(Gbl)
+    # g_fmt = 2: the same matrix, were it tiny like a gradient, as scaled fp16.  bf16-grid values are fp16-grid values too.
+    amax = torch.tensor([2.7e-6], dtype=torch.float32).view(torch.int32).to(d)
+    S = 2.0 ** (264 - ((int(amax.item()) >> 23) & 0xFF) - 127)
+    tiny = 2.0 ** -20
+    G_f16 = (Gbl * (tiny * S)).to(torch.float16).contiguous().view(torch.float32)
+    assert torch.equal((Gbl * (tiny * S)).to(torch.float16).float(), Gbl * (tiny * S))
     for di, shift in ((0, -1), (1, 1)):
         ns, bps = dev.tnb_splits(nb, 8)
         outs = []
-        for Gbuf, fmt in ((G_pairs, 0), (G_bf16, 1), (G_bf16, 1)):
+        for Gbuf, fmt in ((G_pairs, 0), (G_bf16, 1), (G_bf16, 1), (G_f16, 2)):
             slab, bslab = torch.full((ns, 1024 * 384), float("nan"), device=d), torch.full((ns, 1024), float("nan"), device=d)
             dev.gemm_tnb(G=Gbuf, g_width=GW, g_off=di * 1024, g_cols=1024, A0=A0b, a0_width=N, a0_off=0, a0_cols=N,
                          A1=A1b, a1_width=2 * H, a1_off=di * H, a1_cols=H, a1_shift=shift, nblk=nb, L_=seq.L,
-                         slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab, g_fmt=fmt)
+                         slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab, g_fmt=fmt, amax=amax if fmt == 2 else None)
             outs.append((slab, bslab))
         torch.cuda.synchronize()
         assert torch.equal(outs[0][0], outs[1][0])                # same products, same order: the zero lo terms add nothing
         assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
         assert rel(outs[1][1].sum(0), outs[0][1].sum(0)) < 1e-6   # column sums: pairs of slots per dot2 instead of (hi, lo)
+        assert torch.equal(outs[3][0], outs[0][0] * tiny)         # scaled fp16: the same products times an exact power of two
+        assert rel(outs[3][1].sum(0), outs[0][1].sum(0) * tiny) < 1e-6
         assert rel(outs[1][1].sum(0), G[:, di * 1024:(di + 1) * 1024].double().sum(0)) < 1e-5
         # against fp64 with the step shift of A1 (as in tests/test_kernels_gpu.py::test_gemm_tnb_vs_torch)
         pos, valid = dev.bl_positions(seq, torch.device("cpu"))
@@ -224,7 +291,7 @@ def test_gemm_tnb_bf16_g_operand(view, dims):
         assert rel(outs[1][0].sum(0).view(1024, 384), ref) < 4e-5
 
 
-@pytest.mark.parametrize("fmt", ["f32", "h2s", "h2"])
+@pytest.mark.parametrize("fmt", ["f32", "h2s", "h2", "h2b"])
 @pytest.mark.parametrize("view", ["time", "band"])
 def test_resrnn_formats_agree(view, fmt, monkeypatch):
     """One ResRNN (functional.ResRNNBlkFn) at a geometry that takes the production kernels (time view: cluster forward +
@@ -249,7 +316,7 @@ def test_resrnn_formats_agree(view, fmt, monkeypatch):
         res[f] = (out.detach().clone(), zd.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()})
     a, b = res["f32"], res[fmt]
     assert torch.equal(a[0], b[0])
-    tol = {"f32": 0.0, "h2s": 5e-5, "h2": 3e-3}[fmt]
+    tol = {"f32": 0.0, "h2s": 5e-5, "h2": 4e-4, "h2b": 3e-3}[fmt]   # unorm16 gates; + scaled-fp16 (default) / bf16 d(gates)
     assert rel(b[1], a[1]) <= tol
     for k in a[2]:
         assert rel(b[2][k], a[2][k]) <= tol, k

@@ -133,8 +133,10 @@ def main():
         lp, pp = run("product", mask)
         num = sum(float(((pp[k] - po[k]).double() ** 2).sum()) for k in po)
         den = sum(float(((po[k] - init[k]).double() ** 2).sum()) for k in po)
+        from wesep_amd import functional as f0
         print(f"[traj] probe={mask:2d}: max |dloss| {np.abs(lp - lo).max():.2e} dB (last {abs(lp[-1] - lo[-1]):.2e}); "
-              f"accumulated update rel-L2 {np.sqrt(num / den):.2e}", flush=True)
+              f"accumulated update rel-L2 {np.sqrt(num / den):.2e}; fp16 saturations {f0._PROBE_SAT[0]}, "
+              f"largest scaled |d(gates)| / 65504 = {f0._PROBE_SAT[1]:.3e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -67,6 +67,19 @@ __device__ __forceinline__ float ws_block_sum(float v, float* red) {
   return t;
 }
 
+// WS_GATES_H2F (wesep_hip.h): the power of two that scales d(gates) into fp16 -- max |d(hcat)| of the launch (float bits in
+// `amax_bits`) lands in [2^10, 2^11); 1 for a zero / non-finite maximum.  Exact to undo (ws_dgates_scale_inv).
+__device__ __forceinline__ float ws_dgates_scale(unsigned amax_bits) {
+  const int e = (int)((amax_bits >> 23) & 0xffu);
+  if (e == 0 || e == 255) return 1.f;
+  const int se = min(max(264 - e, 1), 253);  // 2^(10 - (e - 127)); S and 1 / S both stay normal numbers
+  return __uint_as_float((unsigned)se << 23);
+}
+__device__ __forceinline__ float ws_dgates_scale_inv(unsigned amax_bits) {
+  const float s = ws_dgates_scale(amax_bits);
+  return __uint_as_float((unsigned)(254 - (int)(__float_as_uint(s) >> 23)) << 23);  // 2^-k, exact
+}
+
 __device__ __forceinline__ float ws_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 // row index -> element offset under the two-level row addressing used across the C ABI:

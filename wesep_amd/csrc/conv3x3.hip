@@ -38,6 +38,8 @@
 // wave; a workgroup owns one 32-channel chunk of the input and a range of tiles (a "split"), reduces its four waves
 // through LDS and writes one slab -- the caller sums the slabs (deterministic, no atomics).  conv_wgrad.hip, which this
 // replaces for 3 x 3 / stride 1, staged every tap's patch separately: nine splits and transposes per input element.
+#include <mutex>
+
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -394,12 +396,20 @@ extern "C" int ws_conv3x3_wgrad(const ws_conv3x3_wgrad_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a->nsplit, (a->Cin + 31) / 32, (a->Nn + 31) / 32);
   const size_t lds1 = (size_t)(2 * 6 * 32 * W3_LD + 2 * W3_AB) * sizeof(__bf16), lds2 = (size_t)(2 * 9 * 32 * W3_LD + 2 * W3_AB) * sizeof(__bf16);
-  static bool attr_set = false;
-  if (!attr_set) {
-    // (a failure here -- no device -- shows up as the launch error below, not as an argument error)
-    attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds2) == hipSuccess;
-    (void)hipGetLastError();
+  // the attribute is PER DEVICE: one flag per device of the node, set under a lock (engines on several GPUs of one process,
+  // separate_main --jobs).  A failure here -- no device -- shows up as the launch error below, not as an
+  // argument error
+  if (a->sw != 1) {
+    static std::mutex mu;
+    static bool attr_set[64] = {};
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) devid = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!attr_set[devid]) {
+      attr_set[devid] = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) == hipSuccess;
+      (void)hipGetLastError();
+    }
   }
   ws_prof_begin(WS_PROF_GEMM_TN, s);
   if (a->sw == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds1, s, *a);

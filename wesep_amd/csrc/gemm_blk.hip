@@ -24,6 +24,8 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(512, 4) void gemm_p2b_kernel(const ws_gemm_p2b_args
   for (int q = 0; q < 4; ++q) wl[0][tid + 512 * q] = wreg[q];
   __syncthreads();
   float* cblk = p.C + (long long)bb * 32 * p.N + i * 4;
+  float cmax = 0.f;  // max |C| of this lane (p.amax: the scale source of WS_GATES_H2F; fmaxf drops NaN)
   for (int st = 0; st < nstage; ++st) {
     const int cur = st & 1;
     if (st + 1 < nstage) {
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(512, 4) void gemm_p2b_kernel(const ws_gemm_p2b_args
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
           if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
           *reinterpret_cast<f32x4*>(cblk + (n / 4) * 128) = v;
+          cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
       }
     }
@@ -229,6 +233,11 @@ __global__ __launch_bounds__(512, 4) void gemm_p2b_kernel(const ws_gemm_p2b_args
       for (int q = 0; q < 4; ++q) wl[cur ^ 1][tid + 512 * q] = wreg[q];
     }
     __syncthreads();
+  }
+  if (p.amax) {  // one atomic per wave: non-negative floats order like their bit patterns
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+    if (lane == 0) atomicMax(p.amax, __float_as_uint(cmax));
   }
 }
 
@@ -258,7 +267,10 @@ extern "C" int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream) {
 // A16 (a_fmt = 1, ABI v15): A holds bf16 elements in BLH(K) -- d(gates) of WS_GATES_H2: a lane's 8 consecutive k are two
 // 8-byte cells = the hi fragment itself; no lo term, two MFMAs per product instead of three, half the A bytes.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-template <bool A16>
+// A16 = 2 (a_fmt = 2): A holds fp16 elements scaled by S = ws_dgates_scale(*p.amax) -- d(gates) of WS_GATES_H2F: an fp16 value
+// splits EXACTLY into bf16 hi + lo (11 bits = 8 + 3), so the three-term product is the split-pair product of the stored
+// value; the epilogue multiplies by 1 / S (a power of two: exact).
+template <int A16>
 __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args p) {
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][2048];
   __shared__ long long posl[8][32];
@@ -276,8 +288,9 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
   const int K = p.K, nstage = K / 64;
   // A-operand source: cell (quad, slot) of block bb; lane reads quads 4ks + 2half, +1 (cell = 16 B, A16: 8 B; `ab` in
   // units of half a cell-element pair: floats for BLS, 2-byte elements viewed through the same index formula for A16)
-  typedef typename std::conditional<A16, u32x2, f32x4>::type acell;
-  typedef typename std::conditional<A16, unsigned short, float>::type aelem;
+  typedef typename std::conditional<A16 != 0, u32x2, f32x4>::type acell;
+  typedef typename std::conditional<A16 != 0, unsigned short, float>::type aelem;
+  const float inv_s = A16 == 2 ? ws_dgates_scale_inv(*p.amax) : 1.f;
   const aelem* ab = reinterpret_cast<const aelem*>(p.A) + (long long)bb * 32 * K + i * 4 + 2 * half * 128;
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.Wpack);
   u32x4 wreg[4];
@@ -317,9 +330,18 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 ah, al;  // A arrives as split pairs (BLS): h from the recurrences, d(gates) from BPTT -- or as bf16 (A16)
-      if constexpr (A16) {
+      if constexpr (A16 == 1) {
         const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ks]), c1 = __builtin_bit_cast(u32x2, ac[2 * ks + 1]);
         ah = __builtin_bit_cast(bf16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
+      } else if constexpr (A16 == 2) {
+        const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ks]), c1 = __builtin_bit_cast(u32x2, ac[2 * ks + 1]);
+        const f16x8 hv = __builtin_bit_cast(f16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = (float)hv[j];
+          ah[j] = (__bf16)x;
+          al[j] = (__bf16)(x - (float)ah[j]);
+        }
       } else {
         unpack8(__builtin_bit_cast(u32x4, ac[2 * ks]), __builtin_bit_cast(u32x4, ac[2 * ks + 1]), ah, al);
       }
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
         const bf16x8 bh = __builtin_bit_cast(bf16x8, wt[(nt * 2) * 64]);
         const bf16x8 bl = __builtin_bit_cast(bf16x8, wt[(nt * 2 + 1) * 64]);
         acc[nt] = mfma32(ah, bh, acc[nt]);
-        if constexpr (!A16) acc[nt] = mfma32(al, bh, acc[nt]);
+        if constexpr (A16 != 1) acc[nt] = mfma32(al, bh, acc[nt]);
         acc[nt] = mfma32(ah, bl, acc[nt]);
       }
     }
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-        stg[m * 64 + t * 32 + i] = acc[nt][r] + bv;
+        stg[m * 64 + t * 32 + i] = (A16 == 2 ? acc[nt][r] * inv_s : acc[nt][r]) + bv;
       }
     }
     __syncthreads();  // (uniform: every wave runs both passes; only the wave's own 8 KB are exchanged)
@@ -384,17 +406,19 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
 extern "C" int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream) {
   WS_REQUIRE(a && a->A && a->Wpack && a->C, "ws_gemm_b2p: null pointer");
   WS_REQUIRE(a->N == 128, "ws_gemm_b2p: N must be 128 (got %d)", a->N);
-  WS_REQUIRE(a->a_fmt == 0 || a->a_fmt == 1, "ws_gemm_b2p: a_fmt %d", a->a_fmt);
+  WS_REQUIRE(a->a_fmt >= 0 && a->a_fmt <= 2 && (a->a_fmt != 2 || a->amax), "ws_gemm_b2p: a_fmt %d (2 needs amax)", a->a_fmt);
   WS_REQUIRE(a->K > 0 && a->K % 64 == 0, "ws_gemm_b2p: K %% 64 (K=%d)", a->K);
   WS_REQUIRE(a->ldc >= a->N && a->ldc % 4 == 0, "ws_gemm_b2p: ldc >= N and ldc %% 4 == 0 (16-byte row pieces)");
   WS_REQUIRE(a->sm.nseq > 0 && a->sm.L > 0 && a->sm.sq_div > 0, "ws_gemm_b2p: bad sequence map");
   const int nblk = ((a->sm.nseq + 31) / 32) * a->sm.L;
   hipStream_t s = (hipStream_t)stream;
   ws_prof_begin(WS_PROF_GEMM_NT, s);
-  if (a->a_fmt)
-    hipLaunchKernelGGL(gemm_b2p_kernel<true>, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
+  if (a->a_fmt == 2)
+    hipLaunchKernelGGL(gemm_b2p_kernel<2>, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
+  else if (a->a_fmt == 1)
+    hipLaunchKernelGGL(gemm_b2p_kernel<1>, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
   else
-    hipLaunchKernelGGL(gemm_b2p_kernel<false>, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
+    hipLaunchKernelGGL(gemm_b2p_kernel<0>, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
   ws_prof_end(WS_PROF_GEMM_NT, s);
   return ws_check_launch("ws_gemm_b2p");
 }
@@ -634,9 +658,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
 //   * the three A tiles (768 groups of 64 B) are spread as one whole group per thread (tiles 0 and 1) plus one half group
 //     (2 slots, tile 2): 112 bytes and 7 loads per thread and block instead of 128 / 8.
 // ---------------------------------------------------------------------------------------------
-template <bool ASUM>
+// GFMT = 2 (g_fmt = 2): G holds fp16 elements scaled by S = ws_dgates_scale(*p.amax) -- d(gates) of WS_GATES_H2F: every value
+// is split into its bf16 hi + lo terms in registers (exact: 11 = 8 + 3 bits), both planes of the G image are written and a
+// product is the three split-pair MFMAs again; slab and bslab leave the kernel multiplied by 1 / S (exact).
+template <bool ASUM, int GFMT>
 __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_args p) {
   constexpr int TA = 3, TN = 3;
+  constexpr int NTERM = GFMT == 2 ? 3 : 2;
+  const float inv_s = GFMT == 2 ? ws_dgates_scale_inv(*p.amax) : 1.f;
   constexpr int NCOL = 128 * (1 + TA);
   constexpr int PLANE = NCOL * TB_LD;
   __shared__ __attribute__((aligned(16))) __bf16 ldsA[2 * PLANE];
@@ -700,8 +729,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
     if (pc >= 8) {
       const u32x4 d = gq[slot];
       const unsigned lo_ = pc == 8 ? d[0] : d[1], hi_ = pc == 8 ? d[2] : d[3];  // slot 2sp / slot 2sp + 1
-      const unsigned c_even = __builtin_amdgcn_perm(hi_, lo_, WS_SEL_LO16), c_odd = __builtin_amdgcn_perm(hi_, lo_, WS_SEL_HI16);
       const int col = 4 * qg + 2 * (pc - 8);
+      if constexpr (GFMT == 2) {
+        // four fp16 values: (slot 2sp, col), (slot 2sp, col + 1), (slot 2sp + 1, col), (slot 2sp + 1, col + 1)
+        const f16x2 a = __builtin_bit_cast(f16x2, lo_), b = __builtin_bit_cast(f16x2, hi_);
+        const float x[4] = {(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+        __bf16 h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          h[j] = (__bf16)x[j];
+          l[j] = (__bf16)(x[j] - (float)h[j]);
+        }
+        const bf16x2 he = {h[0], h[2]}, ho = {h[1], h[3]}, le = {l[0], l[2]}, lodd = {l[1], l[3]};
+        *reinterpret_cast<bf16x2*>(lds + col * TB_LD + 2 * sp) = he;
+        *reinterpret_cast<bf16x2*>(lds + (col + 1) * TB_LD + 2 * sp) = ho;
+        *reinterpret_cast<bf16x2*>(lds + PLANE + col * TB_LD + 2 * sp) = le;
+        *reinterpret_cast<bf16x2*>(lds + PLANE + (col + 1) * TB_LD + 2 * sp) = lodd;
+        if (live) {
+          gsum[2 * (pc - 8)] += x[0] + x[2];
+          gsum[2 * (pc - 8) + 1] += x[1] + x[3];
+        }
+        return;
+      }
+      const unsigned c_even = __builtin_amdgcn_perm(hi_, lo_, WS_SEL_LO16), c_odd = __builtin_amdgcn_perm(hi_, lo_, WS_SEL_HI16);
       *reinterpret_cast<unsigned*>(lds + col * TB_LD + 2 * sp) = c_even;
       *reinterpret_cast<unsigned*>(lds + (col + 1) * TB_LD + 2 * sp) = c_odd;
       gsum[2 * (pc - 8)] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, c_even), ones, gsum[2 * (pc - 8)], false);
@@ -777,18 +827,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
         int sub = 0;
 #pragma unroll
         for (int ks = 0; ks < 32; ks += 16) {
-          bf16x8 gh[2];
+          bf16x8 gh[2], gl[2];
 #pragma unroll
-          for (int e = 0; e < 2; ++e)
+          for (int e = 0; e < 2; ++e) {
             gh[e] = *reinterpret_cast<const bf16x8*>(lds + (wm * 64 + e * 32 + l31) * TB_LD + ks + 8 * half);
+            if constexpr (GFMT == 2) gl[e] = *reinterpret_cast<const bf16x8*>(lds + PLANE + (wm * 64 + e * 32 + l31) * TB_LD + ks + 8 * half);
+          }
 #pragma unroll
           for (int f = 0; f < TN; ++f) {
             const bool last = ks == 16 && f == TN - 1;
 #pragma unroll
-            for (int term = 0; term < 2; ++term, ++sub) {
+            for (int term = 0; term < NTERM; ++term, ++sub) {
               if (term == 0 && !last) lda(f + 1 < TN ? ks : 16, f + 1 < TN ? f + 1 : 0, ahn, aln);
+              // terms: G_hi A_hi, G_hi A_lo and (GFMT 2) G_lo A_hi
 #pragma unroll
-              for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(gh[e], term == 1 ? al : ah, acc[e][f]);
+              for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(term == 2 ? gl[e] : gh[e], term == 1 ? al : ah, acc[e][f]);
               if (sub < NPC) store_piece(s ^ 1, ldsw, live, sub);
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -811,7 +864,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int grow = gt * 128 + wm * 64 + e * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          out[(long long)grow * ncols + ac_] = acc[e][f][r];
+          out[(long long)grow * ncols + ac_] = GFMT == 2 ? acc[e][f][r] * inv_s : acc[e][f][r];
         }
       }
     }
@@ -823,7 +876,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
     t += __shfl_xor(t, 2, 64);
     t += __shfl_xor(t, 4, 64);
     t += __shfl_xor(t, 8, 64);
-    if (p.bslab && sp == 0) p.bslab[(long long)split * p.bslab_stride + gt * 128 + 4 * qg + c] = t;
+    if (p.bslab && sp == 0) p.bslab[(long long)split * p.bslab_stride + gt * 128 + 4 * qg + c] = GFMT == 2 ? t * inv_s : t;
   }
   if (ASUM && gt == 0 && p.aslab) {  // column sums of Acat: whole groups over the 8 slot groups, half groups over 16 halves
 #pragma unroll
@@ -852,17 +905,23 @@ extern "C" int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream) {
   const int ta = (a->a0_cols + a->a1_cols) / 128;
   WS_REQUIRE(ta == 1 || ta == 3, "ws_gemm_tnb: A columns must total 128 or 384 (got %d)", ta * 128);
   WS_REQUIRE(a->a0_shift == 0, "ws_gemm_tnb: only A1 can be shifted (a0_shift = %d)", a->a0_shift);
-  WS_REQUIRE(a->g_fmt == 0 || (a->g_fmt == 1 && ta == 3), "ws_gemm_tnb: g_fmt = 1 (bf16 G) is built for 384 A columns");
+  WS_REQUIRE(a->g_fmt == 0 || ((a->g_fmt == 1 || a->g_fmt == 2) && ta == 3),
+             "ws_gemm_tnb: g_fmt 1 / 2 (2-byte G) are built for 384 A columns");
+  WS_REQUIRE(a->g_fmt != 2 || a->amax, "ws_gemm_tnb: g_fmt = 2 (scaled fp16 G) needs amax");
   WS_REQUIRE(a->nblk > 0 && a->L > 0 && a->nblk % a->L == 0 && a->nsplit > 0 && a->blocks_per_split > 0 &&
                  (long long)a->nsplit * a->blocks_per_split >= a->nblk,
              "ws_gemm_tnb: bad block split");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a->nsplit, a->g_cols / 128), block(512);
   ws_prof_begin(WS_PROF_GEMM_TN, s);
-  if (a->g_fmt && a->aslab)
-    hipLaunchKernelGGL((gemm_tnb16_kernel<true>), grid, block, 0, s, *a);
+  if (a->g_fmt == 2 && a->aslab)
+    hipLaunchKernelGGL((gemm_tnb16_kernel<true, 2>), grid, block, 0, s, *a);
+  else if (a->g_fmt == 2)
+    hipLaunchKernelGGL((gemm_tnb16_kernel<false, 2>), grid, block, 0, s, *a);
+  else if (a->g_fmt && a->aslab)
+    hipLaunchKernelGGL((gemm_tnb16_kernel<true, 1>), grid, block, 0, s, *a);
   else if (a->g_fmt)
-    hipLaunchKernelGGL((gemm_tnb16_kernel<false>), grid, block, 0, s, *a);
+    hipLaunchKernelGGL((gemm_tnb16_kernel<false, 1>), grid, block, 0, s, *a);
   else if (ta == 3 && a->aslab)
     hipLaunchKernelGGL((gemm_tnb_kernel<3, true>), grid, block, 0, s, *a);
   else if (ta == 3)

@@ -385,7 +385,8 @@ static int lstm_check(const ws_lstm_args* a, bool bwd, const char* who) {
              a->mode);
   WS_REQUIRE(!a->run_if || (!bwd && (a->mode & 255) >= WS_LSTM_BF16X3) || (bwd && (a->mode & 255) >= WS_LSTM_BF16X3_BLK),
              "%s: run_if is honoured by the split-bf16 forward kernels and the blocked-layout BPTT kernels only", who);
-  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2S, "%s: bad gfmt %d", who, a->gfmt);
+  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2F, "%s: bad gfmt %d", who, a->gfmt);
+  WS_REQUIRE(a->gfmt != WS_GATES_H2F || !bwd || a->amax, "%s: WS_GATES_H2F needs amax", who);
   WS_REQUIRE(a->gfmt == WS_GATES_F32 || (a->mode & 255) >= WS_LSTM_BF16X3_BLK,
              "%s: gfmt %d is a format of the blocked-layout modes", who, a->gfmt);
   WS_REQUIRE(a->gfmt == WS_GATES_F32 || bwd || a->gates_in, "%s: gfmt %d needs gates_in (the fp32 pre-activations)", who,

@@ -289,8 +289,10 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   float* gdst = GF == WS_GATES_H2S ? p.dgates : p.gates;
   auto grs = [&](int t) { return mkrsrc(gdst + (long long)(blockIdx.x * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
   auto hrs = [&](int t) { return mkrsrc(p.gates + (long long)(blockIdx.x * L + t) * (SQ * LG), SQ * 2 * LG * 2); };  // BLH
-  float* hdst = (GF == WS_GATES_H2 && p.dgates) ? p.dgates : p.gates;
+  constexpr bool G2 = GF == WS_GATES_H2 || GF == WS_GATES_H2F;  // 2-byte d(gates): bf16, or fp16 scaled by dS
+  float* hdst = (G2 && p.dgates) ? p.dgates : p.gates;
   auto ors = [&](int t) { return mkrsrc(hdst + (long long)(blockIdx.x * L + t) * (SQ * LG), SQ * 2 * LG * 2); };     // BLH out
+  const float dS = GF == WS_GATES_H2F ? ws_dgates_scale(*p.amax) : 1.f;
   auto crs = [&](const float* b, int t) { return mkrsrc(b + (long long)(blockIdx.x * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
   typedef typename gate_cell<GF>::type gcell;
   auto ld_gate = [&](int t, int g, int j) -> gcell {
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
         *reinterpret_cast<bf16x4*>(dhi + 256 * g + 8 * j) = hi;
         *reinterpret_cast<bf16x4*>(dlo + 256 * g + 8 * j) = lo;
         if (st) {
-          if constexpr (GF == WS_GATES_H2) bst8(bf16x4_bits(hi), ors(t), glane >> 1, (g * 64 + 2 * j) * 256);
+          if constexpr (G2) bst8(enc_dgates<GF>(v, hi, dS), ors(t), glane >> 1, (g * 64 + 2 * j) * 256);
           else if constexpr (BLK) st_gate(pack_hl4(hi, lo), t, g, j);
           else st_gate(v, t, g, j);
         }
@@ -435,6 +437,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
     hipLaunchKernelGGL((KERNEL<true, 0, WS_GATES_H2>), grid, block, 0, s, *a);           \
   } else if ((a->mode & 255) == WS_LSTM_BF16X3_BLK && a->gfmt == WS_GATES_H2S) {         \
     hipLaunchKernelGGL((KERNEL<true, 0, WS_GATES_H2S>), grid, block, 0, s, *a);          \
+  } else if ((a->mode & 255) == WS_LSTM_BF16X3_BLK && a->gfmt == WS_GATES_H2F) {         \
+    hipLaunchKernelGGL((KERNEL<true, 0, WS_GATES_H2F>), grid, block, 0, s, *a);          \
   } else if ((a->mode & 255) == WS_LSTM_BF16X3_BLK) {                                    \
     switch ((a->mode >> 8) & 7) {                                                        \
       case 0: hipLaunchKernelGGL((KERNEL<true, 0>), grid, block, 0, s, *a); break;       \

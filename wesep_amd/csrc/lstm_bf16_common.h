@@ -124,11 +124,27 @@ __device__ __forceinline__ f32x4 dec_u16x4(const u32x2& c) {
   return v;
 }
 __device__ __forceinline__ u32x2 bf16x4_bits(const bf16x4& v) { return __builtin_bit_cast(u32x2, v); }
+// WS_GATES_H2F: d(gates) as fp16(clamp(x * S)), round to nearest even; S = ws_dgates_scale(*amax) (common.h)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 enc_f16x4_scaled(const f32x4& v, float S) {
+  f16x4 h;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h[j] = (_Float16)__builtin_amdgcn_fmed3f(v[j] * S, -65504.f, 65504.f);
+  return __builtin_bit_cast(u32x2, h);
+}
+// the 8-byte d(gates) cell of the two in-place-capable 2-byte formats
+template <int GF>
+__device__ __forceinline__ u32x2 enc_dgates(const f32x4& v, const bf16x4& hi, float S) {
+  if constexpr (GF == WS_GATES_H2F) return enc_f16x4_scaled(v, S);
+  else return bf16x4_bits(hi);
+}
+
 // A saved gate cell as the BPTT kernels keep it between its (prefetching) load and its use one step later: the RAW
 // unorm16 codes -- decoding at the load would put the conversions, and with them the wait for the load, in front of the
 // scheduling fence that follows the prefetch
 template <int GF> struct gate_cell { typedef f32x4 type; };
 template <> struct gate_cell<WS_GATES_H2> { typedef u32x2 type; };
 template <> struct gate_cell<WS_GATES_H2S> { typedef u32x2 type; };
+template <> struct gate_cell<WS_GATES_H2F> { typedef u32x2 type; };
 template <bool TANH> __device__ __forceinline__ f32x4 gate_val(const f32x4& c) { return c; }
 template <bool TANH> __device__ __forceinline__ f32x4 gate_val(const u32x2& c) { return dec_u16x4<TANH>(c); }

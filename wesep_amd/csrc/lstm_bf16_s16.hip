@@ -238,8 +238,10 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
   float* gdst = GF == WS_GATES_H2S ? p.dgates : p.gates;
   auto grs = [&](int t) { return mkrsrc(gdst + (long long)(tile * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
   auto hrs = [&](int t) { return mkrsrc(p.gates + (long long)(tile * L + t) * (SQ * LG), SQ * 2 * LG * 2); };  // BLH
-  float* hdst = (GF == WS_GATES_H2 && p.dgates) ? p.dgates : p.gates;  // bf16 d(gates): in place, or to their own BLH buffer
+  constexpr bool G2 = GF == WS_GATES_H2 || GF == WS_GATES_H2F;  // 2-byte d(gates): bf16, or fp16 scaled by dS
+  float* hdst = (G2 && p.dgates) ? p.dgates : p.gates;  // in place, or to their own BLH buffer
   auto ors = [&](int t) { return mkrsrc(hdst + (long long)(tile * L + t) * (SQ * LG), SQ * 2 * LG * 2); };
+  const float dS = GF == WS_GATES_H2F ? ws_dgates_scale(*p.amax) : 1.f;
   auto crs = [&](const float* b, int t) { return mkrsrc(b + (long long)(tile * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
   typedef typename gate_cell<GF>::type gcell;
   auto ld_gate = [&](int t, int g, int tu) -> gcell {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
         split4(v, hi, lo);
         *reinterpret_cast<bf16x4*>(dhi + 256 * g + 16 * tu) = hi;
         *reinterpret_cast<bf16x4*>(dlo + 256 * g + 16 * tu) = lo;
-        if constexpr (GF == WS_GATES_H2) bst8(bf16x4_bits(hi), ors(t), glane >> 1, (g * 64 + 4 * tu) * 256);
+        if constexpr (G2) bst8(enc_dgates<GF>(v, hi, dS), ors(t), glane >> 1, (g * 64 + 4 * tu) * 256);
         else if (!(S16_DBG & 2)) st_gate(pack_hl4(hi, lo), t, g, tu);
       };
       emit(pi, 0);
@@ -378,6 +380,7 @@ int ws_launch_lstm_bwd_s16(const ws_lstm_args* a, hipStream_t s) {
   dim3 grid(2 * ((a->nseq + SQ - 1) / SQ), 2), block(512);
   if (a->gfmt == WS_GATES_H2) hipLaunchKernelGGL(lstm_bwd_s16_kernel<WS_GATES_H2>, grid, block, 0, s, *a);
   else if (a->gfmt == WS_GATES_H2S) hipLaunchKernelGGL(lstm_bwd_s16_kernel<WS_GATES_H2S>, grid, block, 0, s, *a);
+  else if (a->gfmt == WS_GATES_H2F) hipLaunchKernelGGL(lstm_bwd_s16_kernel<WS_GATES_H2F>, grid, block, 0, s, *a);
   else hipLaunchKernelGGL(lstm_bwd_s16_kernel<0>, grid, block, 0, s, *a);
   return 0;
 }

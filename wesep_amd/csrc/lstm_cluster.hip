@@ -281,7 +281,7 @@ extern "C" int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream) 
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->whh_f && a->whh_r && a->xchg && a->flags,
              "ws_lstm_fwd_cluster: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->nseq % 64 == 0 && a->L > 0, "ws_lstm_fwd_cluster: nseq must be a multiple of 64");
-  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2S && (a->gfmt == 0 || a->gates_in),
+  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2F && (a->gfmt == 0 || a->gates_in),
              "ws_lstm_fwd_cluster: gfmt %d needs gates_in", a->gfmt);
   const int nwg = (a->nseq / 32) * 8;
   int dev = 0, cus = 0;

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h_kernel(const ws_lstm
 extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn && a->wpack && a->bias, "ws_lstm_fwd_fused: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_fwd_fused: bad nseq/L");
-  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2S, "ws_lstm_fwd_fused: gfmt %d", a->gfmt);
+  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2F, "ws_lstm_fwd_fused: gfmt %d", a->gfmt);
   const int ntile = (a->nseq + SQ - 1) / SQ;
   dim3 grid(ntile, 2), block(512);
   hipStream_t s = (hipStream_t)stream;

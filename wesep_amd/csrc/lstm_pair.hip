@@ -127,8 +127,10 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
   float* gdst = GF == WS_GATES_H2S ? p.dgates : p.gates;
   auto grs = [&](int t) { return mkrsrc(gdst + (long long)(tile * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
   auto hrs = [&](int t) { return mkrsrc(p.gates + (long long)(tile * L + t) * (SQ * LG), SQ * 2 * LG * 2); };  // BLH
-  float* hdst = (GF == WS_GATES_H2 && p.dgates) ? p.dgates : p.gates;  // bf16 d(gates): in place, or to their own BLH buffer
+  constexpr bool G2 = GF == WS_GATES_H2 || GF == WS_GATES_H2F;  // 2-byte d(gates): bf16, or fp16 scaled by dS
+  float* hdst = (G2 && p.dgates) ? p.dgates : p.gates;  // in place, or to their own BLH buffer
   auto ors = [&](int t) { return mkrsrc(hdst + (long long)(tile * L + t) * (SQ * LG), SQ * 2 * LG * 2); };
+  const float dS = GF == WS_GATES_H2F ? ws_dgates_scale(*p.amax) : 1.f;
   auto crs = [&](const float* b, int t) { return mkrsrc(b + (long long)(tile * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
   typedef typename gate_cell<GF>::type gcell;
   auto ld_gate = [&](int t, int g, int e) -> gcell {
@@ -226,8 +228,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
         split4(v, hi, lo);
         *reinterpret_cast<bf16x4*>(&bimg[0][n * PR_ROW + g * 128 + 4 * q]) = hi;
         *reinterpret_cast<bf16x4*>(&bimg[1][n * PR_ROW + g * 128 + 4 * q]) = lo;
-        if constexpr (GF == WS_GATES_H2) {
-          bst8(bf16x4_bits(hi), ors(t), gvo >> 1, (g * 64 + 2 * e) * 256);
+        if constexpr (G2) {
+          bst8(enc_dgates<GF>(v, hi, dS), ors(t), gvo >> 1, (g * 64 + 2 * e) * 256);
         } else {
           pk[e][g] = pack_hl4(hi, lo);
           bst(pk[e][g], grs(t), gvo, (g * 64 + 2 * e) * 512);  // (zero soffset inside: hipcc pads the data hazard)
@@ -367,8 +369,9 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
 extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->dhcat && a->wpack && a->xchg && a->flags, "ws_lstm_bwd_pair: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_bwd_pair: nseq and L must be positive");
-  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2S && (a->gfmt != WS_GATES_H2S || a->dgates),
-             "ws_lstm_bwd_pair: gfmt %d (WS_GATES_H2S needs dgates)", a->gfmt);
+  WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2F && (a->gfmt != WS_GATES_H2S || a->dgates) &&
+                 (a->gfmt != WS_GATES_H2F || a->amax),
+             "ws_lstm_bwd_pair: gfmt %d (WS_GATES_H2S needs dgates, WS_GATES_H2F needs amax)", a->gfmt);
   const int npair = 2 * ((a->nseq + SQ - 1) / SQ);
   static int cus = 0;      // same part on every device of a node; queried once
   if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 0;
@@ -383,9 +386,11 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
     case 0: hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, 0>), dim3(grid), dim3(512), 0, s, *a); break;
     case 1: hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, WS_GATES_H2>), dim3(grid), dim3(512), 0, s, *a); break;
     case 2: hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, WS_GATES_H2S>), dim3(grid), dim3(512), 0, s, *a); break;
+    case 3: hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, WS_GATES_H2F>), dim3(grid), dim3(512), 0, s, *a); break;
     case 8: hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, 0>), dim3(grid), dim3(512), 0, s, *a); break;   // tests: forced timeout
     case 9: hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2>), dim3(grid), dim3(512), 0, s, *a); break;
     case 10: hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2S>), dim3(grid), dim3(512), 0, s, *a); break;
+    case 11: hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2F>), dim3(grid), dim3(512), 0, s, *a); break;
     case 2048: hipLaunchKernelGGL((lstm_bwd_pair_kernel<2048, 0>), dim3(grid), dim3(512), 0, s, *a); break;  // cycle stamps
     default: WS_REQUIRE(false, "ws_lstm_bwd_pair: dbg bits 8 and 2048 are exclusive; cycle stamps are WS_GATES_F32 only");
   }

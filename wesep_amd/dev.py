@@ -315,15 +315,17 @@ def lstm_cat_ih(wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, n_in, wcat, bcat):
 def _bptt_bytes(gfmt: int) -> int:
     """Algorithmic bytes of one BPTT cell (position, direction, unit): 4 saved gates in, c and d(h) in (fp32), 4 d(gates)
     out -- 40 B with fp32 gates / split-pair d(gates), 24 B with unorm16 gates and bf16 d(gates), 32 B for H2S."""
-    return {L.GATES_F32: 40, L.GATES_H2: 24, L.GATES_H2S: 32}[gfmt]
+    return {L.GATES_F32: 40, L.GATES_H2: 24, L.GATES_H2S: 32, L.GATES_H2F: 24}[gfmt]
 
 
 def gates_fmt() -> int:
     """Storage of the saved activated gates / d(gates) of the blocked-layout ResRNN (WS_GATES_*, wesep_hip.h):
-    'h2' (default): unorm16 gates, bf16 d(gates) in place -- half the bytes of the step's largest buffer and of every
-    pass over it; 'h2s': unorm16 gates, d(gates) as full split pairs in a separate buffer; 'f32': the ABI <= 14 format
-    (fp32 gates, split-pair d(gates) in place).  WESEP_GATES selects."""
-    return {"h2": L.GATES_H2, "h2s": L.GATES_H2S, "f32": L.GATES_F32}[os.environ.get("WESEP_GATES", "h2")]
+    'h2' (default; WS_GATES_H2F): unorm16 gates, d(gates) as fp16 scaled by a power of two taken from the launch's
+    max |d(hcat)| -- half the bytes of the step's largest buffer and of every pass over it, 11-bit d(gates);
+    'h2b' (WS_GATES_H2): the same with bf16 d(gates) (8 bits: no scale word, two MFMAs per product in the consumers);
+    'h2s': unorm16 gates, d(gates) as full split pairs in a separate buffer; 'f32': the ABI <= 14 format (fp32 gates,
+    split-pair d(gates) in place).  WESEP_GATES selects."""
+    return {"h2": L.GATES_H2F, "h2b": L.GATES_H2, "h2s": L.GATES_H2S, "f32": L.GATES_F32}[os.environ.get("WESEP_GATES", "h2")]
 
 
 def blh_floats(nblocks: int, C_: int) -> int:
@@ -332,7 +334,8 @@ def blh_floats(nblocks: int, C_: int) -> int:
     return nblocks * 32 * C_ // 2
 
 
-def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None, run_if=None, gfmt=0, gates_in=None, dgates=None):
+def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None, run_if=None, gfmt=0, gates_in=None, dgates=None,
+               amax=None):
     for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("wpack", wpack), ("dhcat", dhcat),
                  ("gates_in", gates_in), ("dgates", dgates)):
         _chk(t, n)
@@ -342,6 +345,7 @@ def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None, run_if=No
     a.nseq, a.sq_div, a.L, a.mode = sm.nseq, sm.div, sm.L, mode
     a.run_if = C.c_void_p(run_if.data_ptr()) if run_if is not None else None
     a.gates_in, a.dgates, a.gfmt = _p(gates_in), _p(dgates), gfmt
+    a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
     return a
 
 
@@ -352,11 +356,11 @@ def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, run_if=No
     L.check(L.lib().ws_lstm_fwd(C.byref(a), L.stream_ptr()), "ws_lstm_fwd")
 
 
-def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, gfmt=0, dgates=None, run_if=None):
+def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, gfmt=0, dgates=None, run_if=None, amax=None):
     """run_if (blocked-layout modes): 1-element int32 device tensor; the launch is a no-op unless it is non-zero at
     kernel start -- the predicated fall-back behind lstm_bwd_pair.  dgates: out-of-place d(gates) (required for
     GATES_H2S; optional BLH buffer for GATES_H2, which then leaves the saved gates intact)."""
-    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat, gfmt=gfmt, dgates=dgates, run_if=run_if)
+    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat, gfmt=gfmt, dgates=dgates, run_if=run_if, amax=amax)
     # per (position, direction, unit): read 4 gates + c + dh, write 4 d(gates); 2 * 4H * H MACs per position
     if run_if is None:
         _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
@@ -515,7 +519,7 @@ def lstm_pack_pair(whh_f, whh_r, pack):
 
 
 def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None,
-                  repairable=False):
+                  repairable=False, amax=None):
     """BPTT on the blocked layout over pairs of workgroups (lstm_pair.hip); gates: activated gates in,
     d(pre-activation gates) (BLS) out.  Returns the launch's timeout word; in place, so there is no device-side
     fall-back: poll_cluster_status raises (one step late, without a host sync) when a bounded wait timed out."""
@@ -533,6 +537,7 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg
     a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
     a.dbg_buf = C.c_void_p(dbg_buf.data_ptr()) if dbg_buf is not None else None
     a.gfmt, a.dgates = gfmt, _p(dgates)
+    a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
     _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
     L.check(L.lib().ws_lstm_bwd_pair(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_pair")
     return flags[npair * 8:npair * 8 + 1]
@@ -782,7 +787,7 @@ def pack_w(W, N: int, K: int, ldw: int, out, trans=False, order=0, w_off=0):
 
 
 def gemm_p2b(*, A, lda: int, sm: SeqMap, Wpack, N: int, C_out, K=128, bias=None, A_bl=None, stats=None,
-             gamma=None, beta=None, stat_map: Optional[StatMap] = None, run_if=None):
+             gamma=None, beta=None, stat_map: Optional[StatMap] = None, run_if=None, amax=None):
     for n, t in (("A", A), ("Wpack", Wpack), ("bias", bias), ("C", C_out), ("A_bl", A_bl), ("stats", stats),
                  ("gamma", gamma), ("beta", beta)):
         _chk(t, n)
@@ -794,17 +799,20 @@ def gemm_p2b(*, A, lda: int, sm: SeqMap, Wpack, N: int, C_out, K=128, bias=None,
     a.st_div1, a.st_m1, a.st_div2, a.st_m2, a.st_base = st
     a.lda, a.N, a.K = lda, N, K
     a.run_if = C.c_void_p(run_if.data_ptr()) if run_if is not None else None
+    a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None     # 1-element int32, zeroed by the caller
     L.check(L.lib().ws_gemm_p2b(C.byref(a), L.stream_ptr()), "ws_gemm_p2b")
 
 
-def gemm_b2p(*, A, K: int, sm: SeqMap, Wpack, C_out, ldc: int, N=128, bias=None, R=None, a_fmt=0):
-    """a_fmt = 1: A holds bf16 elements in BLH(K) (d(gates) of WS_GATES_H2) instead of split pairs in BL(K)."""
+def gemm_b2p(*, A, K: int, sm: SeqMap, Wpack, C_out, ldc: int, N=128, bias=None, R=None, a_fmt=0, amax=None):
+    """a_fmt = 1: A holds bf16 elements in BLH(K) (d(gates) of WS_GATES_H2) instead of split pairs in BL(K); 2: fp16 elements
+    scaled by the power of two the word `amax` defines (WS_GATES_H2F)."""
     for n, t in (("A", A), ("Wpack", Wpack), ("bias", bias), ("C", C_out), ("R", R)):
         _chk(t, n)
     a = L.GemmB2PArgs()
     a.A, a.Wpack, a.bias, a.R, a.C = _p(A), _p(Wpack), _p(bias), _p(R), _p(C_out)
     a.sm = _smc(sm)
     a.ldc, a.N, a.K, a.a_fmt = ldc, N, K, a_fmt
+    a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
     L.check(L.lib().ws_gemm_b2p(C.byref(a), L.stream_ptr()), "ws_gemm_b2p")
 
 
@@ -819,8 +827,9 @@ def tnb_splits(nblk: int, gtiles: int):
 
 def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_off: int, a0_cols: int,
              nblk: int, L_: int, slab, nsplit: int, blocks_per_split: int, a0_shift=0, A1=None, a1_width=0,
-             a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, g_fmt=0):
-    """g_fmt = 1: G holds bf16 elements in BLH(g_width) (d(gates) of WS_GATES_H2); needs 384 A columns."""
+             a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, g_fmt=0, amax=None):
+    """g_fmt = 1: G holds bf16 elements in BLH(g_width) (d(gates) of WS_GATES_H2); 2: fp16 elements scaled by the power of
+    two the word `amax` defines (WS_GATES_H2F); both need 384 A columns."""
     for n, t in (("G", G), ("A0", A0), ("A1", A1), ("slab", slab), ("bslab", bslab), ("aslab", aslab)):
         _chk(t, n)
     a = L.GemmTNBArgs()
@@ -832,6 +841,7 @@ def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_
     a.a0_width, a.a0_off, a.a0_cols, a.a0_shift = a0_width, a0_off, a0_cols, a0_shift
     a.a1_width, a.a1_off, a.a1_cols, a.a1_shift = a1_width, a1_off, a1_cols, a1_shift
     a.nblk, a.L, a.nsplit, a.blocks_per_split, a.g_fmt = nblk, L_, nsplit, blocks_per_split, g_fmt
+    a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
     L.check(L.lib().ws_gemm_tnb(C.byref(a), L.stream_ptr()), "ws_gemm_tnb")
 
 

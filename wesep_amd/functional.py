@@ -4,6 +4,7 @@ the stream, and the autograd graph between these coarse ops (so DistributedDataP
 bucket hooks fire on the registered Parameters); every FLOP runs in libwesep_hip.so.
 
 Activation layout everywhere: Z = [R, K, Tf, N] fp32 (see include/wesep_hip.h)."""
+import math
 import os
 
 import numpy as np
@@ -161,6 +162,9 @@ def _h2_probe() -> int:
     by rounding the fp32 buffers in place between kernels.  Bits: 1 = activated gates to fp16, 2 = d(gates) to bf16
     (the hi term of the split pair only), 4 = cell state to fp16, 8 = activated gates to unorm16, 16 = d(hcat) to bf16."""
     return int(os.environ.get("WESEP_H2_PROBE", "0"))
+
+
+_PROBE_SAT = [0, 0.0]     # (probe bit 32) saturated d(gates) elements, largest |scaled d(gates)| / 65504 seen
 
 
 def _probe_round(t, kind, packed=False):
@@ -411,7 +415,7 @@ class ResRNNBlkFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def _weight_grads(gates, xn, hcat, dout_bl, seq, nb, N, g_fmt=0):
+    def _weight_grads(gates, xn, hcat, dout_bl, seq, nb, N, g_fmt=0, amax=None):
         """[dW_ih | dW_hh | db] of both directions in one pass over each direction's dgates, and
         dW_proj / db_proj; launched on the current stream.  Returns them in parameter order."""
         d = gates.device
@@ -432,7 +436,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             dev.gemm_tnb(G=gates, g_width=2 * G4, g_off=di * G4, g_cols=G4, A0=xn, a0_width=N, a0_off=0,
                          a0_cols=N, A1=hcat, a1_width=2 * H, a1_off=di * H, a1_cols=H,
                          a1_shift=(-1 if di == 0 else 1), nblk=nb, L_=seq.L, slab=slab, nsplit=ns,
-                         blocks_per_split=bps, bslab=bslab, g_fmt=g_fmt)
+                         blocks_per_split=bps, bslab=bslab, g_fmt=g_fmt, amax=amax)
             dw = _reduce_new(slab, ns, G4 * (N + H), (G4, N + H))
             dwih.append(dw[:, :N].contiguous())
             dwhh.append(dw[:, N:].contiguous())
@@ -460,7 +464,11 @@ class ResRNNBlkFn(torch.autograd.Function):
         box = ctx.box
         # d(hcat) = dout Wp  (+ dout itself in BL for the weight gradient)
         dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
-        dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=W("projT"), N=2 * H, C_out=dh, A_bl=dout_bl)
+        gfmt = ctx.gfmt
+        # WS_GATES_H2F: the d(hcat) GEMM raises max |d(hcat)| of this launch in a device word; the BPTT scales its fp16 d(gates)
+        # by the power of two it defines, the two consumers of d(gates) undo it (wesep_hip.h)
+        amax = torch.zeros(1, device=d, dtype=torch.int32) if gfmt == L.GATES_H2F else None
+        dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=W("projT"), N=2 * H, C_out=dh, A_bl=dout_bl, amax=amax)
         if _h2_probe() & 16:
             _probe_round(dh, "bf16")
         # BPTT: gates (activated) -> d(pre-activation gates), in place.  A time-view recurrence leaves
@@ -471,8 +479,7 @@ class ResRNNBlkFn(torch.autograd.Function):
         # of the CUs, so the side stream keeps the other half.  The cluster BPTT (all 256 CUs: it evicts the
         # side-stream weight-gradient GEMMs) stays opt-in (WESEP_LSTM_CLUSTER_BWD=1).  Both work in place without a
         # device-side fall-back: FusedClipAdam.step looks at their status word (asynchronously for the pair kernel)
-        gfmt = ctx.gfmt
-        g_fmt = 1 if gfmt == L.GATES_H2 else 0
+        g_fmt = {L.GATES_H2: 1, L.GATES_H2F: 2}.get(gfmt, 0)
         if ctx.bptt == "cluster":
             dg = gates
             dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
@@ -489,37 +496,46 @@ class ResRNNBlkFn(torch.autograd.Function):
             # so the saved gates survive the launch and the streaming BPTT can stand behind it, predicated on the launch's
             # time-out word: an empty launch after a clean run, the whole BPTT again if the pair's workgroups were not
             # co-resident (a resident RCCL kernel, another process) -- no NaN reaches a consumer (wesep_hip.h)
-            dg = _empty(d, dev.blh_floats(nb, 2 * G4)) if gfmt == L.GATES_H2 else _empty(d, nb, 32 * 2 * G4)
-            tw = dev.lstm_bwd_pair(gates, cbuf, dh, W("hhp"), seq, gfmt=gfmt, dgates=dg, repairable=True, dbg=_pair_dbg())
-            dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode, gfmt=gfmt, dgates=dg, run_if=tw)
+            dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else _empty(d, dev.blh_floats(nb, 2 * G4))
+            tw = dev.lstm_bwd_pair(gates, cbuf, dh, W("hhp"), seq, gfmt=gfmt, dgates=dg, repairable=True, dbg=_pair_dbg(),
+                                   amax=amax)
+            dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode, gfmt=gfmt, dgates=dg, run_if=tw, amax=amax)
         else:
             # streaming BPTT (band view): bf16 d(gates) in place over the unorm16 gates (H2) / split pairs to their own
             # buffer (H2S)
             dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else gates
             dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode, gfmt=gfmt,
-                         dgates=dg if gfmt == L.GATES_H2S else None)
+                         dgates=dg if gfmt == L.GATES_H2S else None, amax=amax)
         if _h2_probe() & 2 and gfmt == L.GATES_F32:
             _probe_round(gates, "bf16", packed=True)
+        if _h2_probe() & 32 and gfmt == L.GATES_F32 and not torch.cuda.is_available():
+            # fp16 d(gates) scaled by a power of two taken from max |d(hcat)| of this launch (CPU emulation only: plain fp32)
+            amax = float(dh.abs().max())
+            S = 2.0 ** (10 - math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
+            sc = gates * S
+            _PROBE_SAT[0] += int((sc.abs() > 65504.0).sum())
+            _PROBE_SAT[1] = max(_PROBE_SAT[1], float(sc.abs().max()) / 65504.0)
+            gates.copy_(sc.clamp(-65504.0, 65504.0).half().float() / S)
         if ready is not None:
             flush_deferred_wgrads(d, ready)
         del dh
         # weight gradients: a side branch of the graph -> deferred to the side stream when a carrier
         # will deliver them
         if box is not None:
-            def job(side, gates=dg, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, N=N, box=box, g_fmt=g_fmt):
-                box.grads = ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N, g_fmt)
+            def job(side, gates=dg, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, N=N, box=box, g_fmt=g_fmt, amax=amax):
+                box.grads = ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)
                 box.event = torch.cuda.Event()
                 box.event.record(side)
-                for t in (gates, xn, hcat, dout_bl):
+                for t in (gates, xn, hcat, dout_bl) + ((amax,) if amax is not None else ()):
                     t.record_stream(side)
             _pending(d).append(job)
             wg = [None] * 10
         else:
-            wg = ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt)
+            wg = ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)
         del dout_bl
         # d(normalised input) = dgates Wcat -> GroupNorm backward (+ residual path)
         dxn = _empty(d, P, N)
-        dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=W("wihT"), C_out=dxn, ldc=N, a_fmt=g_fmt)
+        dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=W("wihT"), C_out=dxn, ldc=N, a_fmt=g_fmt, amax=amax)
         dz = torch.empty_like(z)
         if dev.gn_bwd_fused_ok(geo):
             # band view: 16 032 groups of 16 KB -- one wave per group, x / dxn / dout cross HBM once (norm.hip)

@@ -416,27 +416,38 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         lmode = dev.lstm_blk_mode(ns)
         whf, whr = whf.contiguous(), whr.contiguous()
         dev.lstm_pack(whf, whr, pack_f, pack_b, lmode)
-        gates, xn = _empty(d, nb, 32 * 2 * G4), _empty(d, nb, 32 * N)
+        xn = _empty(d, nb, 32 * N)
         cbuf, hcat = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * 2 * H)
         cluster = dev.lstm_cluster_ok(seq, d)
+        kind = F0._bptt_kind(seq, d, cluster)
+        # storage of the saved gates / d(gates): as in functional.ResRNNBlkFn (wesep_hip.h WS_GATES_*) -- unorm16 gates in a
+        # buffer of half the bytes by default (the twelve BLSTMs' saved gates were 77 of the step's 155 GB in round 3)
+        gfmt = L.GATES_F32 if kind == "cluster" else dev.gates_fmt()
+        h2 = gfmt != L.GATES_F32
+        gates = _empty(d, dev.blh_floats(nb, 2 * G4)) if h2 else _empty(d, nb, 32 * 2 * G4)
         if dev.lstm_fuse_ok(ns, cluster):
             dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn)
             fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
             dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), whf, whr, fpack)
-            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq)
+            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq, gfmt=gfmt)
         else:
             wih_pack = _empty(d, 2 * G4 * N)
             dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
-            xproj = dict(A=y, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=gates, bias=bcat, A_bl=xn)
+            pre = _empty(d, nb, 32 * 2 * G4) if h2 else gates      # 2-byte formats: pre-activations in a scratch buffer
+            xproj = dict(A=y, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=pre, bias=bcat, A_bl=xn)
+            rec = dict(gfmt=gfmt, gates_in=pre) if h2 else {}
             dev.gemm_p2b(**xproj)
             if cluster:
                 # the streaming pair behind the cluster launch is predicated on its timeout word (wesep_hip.h): empty
-                # launches after a clean run, the whole layer again if the workgroups were not co-resident
-                tw = dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq, dbg=F0._cluster_dbg())
-                dev.gemm_p2b(run_if=tw, **xproj)
-                dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode, run_if=tw)
+                # launches after a clean run, the whole layer again if the workgroups were not co-resident (the 2-byte
+                # formats leave the pre-activations intact: only the recurrence is repeated)
+                tw = dev.lstm_fwd_cluster(gates, cbuf, hcat, whf, whr, seq, dbg=F0._cluster_dbg(), **rec)
+                if not h2:
+                    dev.gemm_p2b(run_if=tw, **xproj)
+                dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode, run_if=tw, **rec)
             else:
-                dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode)
+                dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode, **rec)
+            del pre
         lw = lin_w.contiguous()
         lin_pack = _empty(d, N * 2 * H)
         dev.pack_w(lw, N, 2 * H, 2 * H, lin_pack, order=1)
@@ -444,6 +455,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=lin_pack, C_out=out, ldc=N, bias=lin_b.contiguous(), R=res)
         ctx.save_for_backward(gates, cbuf, hcat, xn, wcat, pack_b, lw, whf, whr)
         ctx.geo = (nseq, Lr, ns, lmode, cluster)
+        ctx.gfmt, ctx.kind = gfmt, kind
         ctx.F0 = F0
         ctx.consumed = False
         return out[:nseq * Lr] if pad else out
@@ -468,23 +480,39 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         wlt_pack = _empty(d, 2 * H * N)
         dev.pack_w(lw, 2 * H, N, 2 * H, wlt_pack, trans=True, order=0)
         dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
-        dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wlt_pack, N=2 * H, C_out=dh, A_bl=dout_bl)
+        amax = torch.zeros(1, device=d, dtype=torch.int32) if ctx.gfmt == L.GATES_H2F else None   # (functional.py)
+        dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wlt_pack, N=2 * H, C_out=dh, A_bl=dout_bl, amax=amax)
         # BPTT works in place on the saved gates (6.4 GB per BLSTM at the recipe's 8 rows x 6 s: a clone here was 12 copies
         # = 38 ms of a 490 ms step and the largest transient allocation of the backward)
-        kind = ctx.F0._bptt_kind(seq, d, cluster)
+        kind, gfmt = ctx.kind, ctx.gfmt
+        g_fmt = {L.GATES_H2: 1, L.GATES_H2F: 2}.get(gfmt, 0)
         if kind == "cluster":
+            dg = gates
             dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
         elif kind == "pair":                                    # few long sequences (the inter-frame path): lstm_pair.hip
             ppack = _empty(d, L.LSTM_PACK_FLOATS)
             dev.lstm_pack_pair(whf, whr, ppack)
-            dev.lstm_bwd_pair(gates, cbuf, dh, ppack, seq)
-        else:
+            if gfmt == L.GATES_F32:
+                dg = gates
+                dev.lstm_bwd_pair(gates, cbuf, dh, ppack, seq, dbg=ctx.F0._pair_dbg())
+            else:
+                # d(gates) out of place, the streaming BPTT predicated on the launch's time-out word behind it (functional.py)
+                dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else _empty(d, dev.blh_floats(nb, 2 * G4))
+                tw = dev.lstm_bwd_pair(gates, cbuf, dh, ppack, seq, gfmt=gfmt, dgates=dg, repairable=True,
+                                       dbg=ctx.F0._pair_dbg(), amax=amax)
+                dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, lmode, gfmt=gfmt, dgates=dg, run_if=tw, amax=amax)
+        elif gfmt == L.GATES_F32:
+            dg = gates
             dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, lmode)
-        wg = ctx.F0.ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N)
+        else:
+            dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else gates
+            dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, lmode, gfmt=gfmt, dgates=dg if gfmt == L.GATES_H2S else None,
+                         amax=amax)
+        wg = ctx.F0.ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)
         wct_pack = _empty(d, N * 2 * G4)
         dev.pack_w(wcat, N, 2 * G4, N, wct_pack, trans=True, order=1)
         dy = _empty(d, ns * Lr, N)
-        dev.gemm_b2p(A=gates, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dy, ldc=N)
+        dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dy, ldc=N, a_fmt=g_fmt, amax=amax)
         if ns != nseq:
             dy = dy[:nseq * Lr]
         # wg: [dW_ih_f, dW_hh_f, db_f, db_f (clone), dW_ih_r, dW_hh_r, db_r, db_r (clone), dW_lin, db_lin]

@@ -48,6 +48,12 @@ class Executor:
         with torch.no_grad():
             ps = [p for p in model.parameters()]
             sums = torch.stack([p.detach().double().sum() for p in ps] + [p.detach().double().abs().sum() for p in ps])
+            # NaN compares unequal to itself: a non-finite checksum would read as "diverged" (or, through MAX / MIN, as
+            # nothing at all).  It is its own finding: say so, with the flag all-reduced so that every rank raises
+            finite = torch.isfinite(sums).all().to(torch.float64).reshape(1)
+            sums = torch.nan_to_num(sums, nan=0.0, posinf=0.0, neginf=0.0)
+        if all_ranks_tensor_spread(finite, device) != 0.0 or float(finite.item()) == 0.0:
+            raise ReplicaDivergence(f"parameters are not finite on at least one data-parallel rank ({where})")
         spread = all_ranks_tensor_spread(sums, device)
         if spread != 0.0:
             raise ReplicaDivergence(f"data-parallel replicas diverged ({where}): parameter checksum spread {spread:.3e}")
@@ -132,13 +138,17 @@ class Executor:
                     optimizer.step()
                 self.step += 1
                 if (i + 1) % log_batch_interval == 0:
-                    if ddp:
-                        self._replica_check(model, device, f"epoch {epoch}, batch {i + 1}")
                     if logger is not None:
                         logger.info(_row("TRAIN", epoch, i + 1, float(loss_sum.item() / n_steps),
                                          float(optimizer.param_groups[0]["lr"])))
                 if (i + 1) == epoch_iter:
                     break
+        if ddp:
+            # OUTSIDE the join context: Join shadows DistributedDataParallel's own collectives for ranks that ran out of
+            # batches, not anybody else's -- a check issued from inside the loop would pair the active ranks' all-reduces
+            # with nothing (uneven per-rank batch counts are what join() is there for).  Here every rank has left the
+            # loop and Join's post-hook has synchronised the replicas to the last rank that stepped
+            self._replica_check(model, device, f"end of epoch {epoch}")
         return float(loss_sum.item() / max(n_steps, 1)), 0
 
     def cv(self, dataloader, models, val_iter, criterion, epoch, enable_amp, logger,
