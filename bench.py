@@ -328,8 +328,9 @@ def main():
                          "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": bytes_per_launch,
                          "bytes_per_cell": cell_bytes[dom],
-                         "gates_format": {L.GATES_F32: "f32", L.GATES_H2: "h2 (unorm16 gates, bf16 d(gates))",
-                                          L.GATES_H2S: "h2s (unorm16 gates, split-pair d(gates))"}[gfmt],
+                         "gates_format": {L.GATES_F32: "f32", L.GATES_H2: "h2b (unorm16 gates, bf16 d(gates))",
+                                          L.GATES_H2S: "h2s (unorm16 gates, split-pair d(gates))",
+                                          L.GATES_H2F: "h2 (unorm16 gates, scaled-fp16 d(gates))"}[gfmt],
                          # the same launches priced at round 3's 40 B per cell (fp32 gates, split-pair d(gates)), for
                          # comparison with the earlier rounds' lines: bytes that no longer move are not achieved bandwidth
                          "frac_at_round3_bytes": 40.0 * P * 2 * L.LSTM_H / sec / 1e9 / HBM_PEAK_GBS,

@@ -363,6 +363,10 @@ typedef struct ws_seqmap {
  * bf16 hi/lo and ordered for ws_gemm_p2b (order 0) or ws_gemm_b2p (order 1).                */
 int ws_pack_w(const float* W, int N, int K, long long ldw, int trans, int order, float* out,
               void* stream);
+/* The same units with fp16 hi / lo of 256 * W' (ABI v15): the weight operand of ws_gemm_b2p with a_fmt = 2 (whose A
+ * operand, the scaled-fp16 d(gates) of WS_GATES_H2F, then feeds v_mfma_f32_32x32x16_f16 without conversion).   */
+int ws_pack_w_f16(const float* W, int N, int K, long long ldw, int trans, int order, float* out,
+                  void* stream);
 
 /* plain -> BL:  C[(b,i)][n] = sum_k pro(A[pos(b,i)][k]) * W'[n][k] + bias[n]   (K = 128, N % 64 == 0)
  * pro = optional GroupNorm-on-load as in ws_gemm_nt (stat index computed from pos).  If A_bl is
@@ -398,7 +402,8 @@ typedef struct ws_gemm_b2p_args {
   long long ldc;
   int N, K;
   int a_fmt, pad_;   /* ABI v15: 0 = A holds BLS pairs (BL(K)); 1 = A holds bf16 elements (BLH(K)): d(gates) of WS_GATES_H2;
-                        2 = A holds scaled fp16 elements (BLH(K)): d(gates) of WS_GATES_H2F, scale from `amax`        */
+                        2 = A holds scaled fp16 elements (BLH(K)): d(gates) of WS_GATES_H2F, scale from `amax`; Wpack
+                        is then a ws_pack_w_f16 pack                                                              */
   const unsigned* amax;
 } ws_gemm_b2p_args;
 int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream);

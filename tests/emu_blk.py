@@ -76,7 +76,7 @@ def _positions(sm):
     return (s // sm.div) * sm.s1 + (s % sm.div) * sm.s2 + t * sm.step_rows
 
 
-def pack_w(W, N, K, ldw, out, trans=False, order=0, w_off=0):
+def pack_w(W, N, K, ldw, out, trans=False, order=0, w_off=0, f16=False):
     flat_ = W.reshape(-1)
     n, k = torch.arange(N).view(-1, 1), torch.arange(K).view(1, -1)
     _PACKS[out.data_ptr()] = flat_[w_off + (k * ldw + n if trans else n * ldw + k)].clone()      # W'[n][k]

@@ -187,8 +187,9 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
 
 @pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37))])
 def test_gemm_b2p_scaled_fp16_operand(view, dims):
-    """a_fmt = 2: A = fp16(x * S) -- the three-term product of the exact bf16 hi + lo split of the stored value, times 1 / S:
-    the same bits as the split-pair kernel fed x (on the fp16 grid) itself."""
+    """a_fmt = 2: A = fp16(x * S) feeds v_mfma_f32_32x32x16_f16 as it is; the weights come as fp16 hi + lo of 256 w
+    (ws_pack_w_f16: 22 bits), the epilogue undoes 256 S exactly.  Against fp64 on the stored values, and against the
+    split-pair kernel fed the same values (different weight split: compare, do not equate)."""
     from wesep_amd import dev
     from wesep_amd.functional import _view_maps
     d = _cuda()
@@ -201,16 +202,23 @@ def test_gemm_b2p_scaled_fp16_operand(view, dims):
     Ah = (rnd(g, P, Kd) * 1e-6 * S).to(torch.float16)             # what the BPTT would have stored
     A = Ah.float() / S                                             # the values it stands for (exact)
     W = rnd(g, N, Kd, scale=0.05)
-    wp = torch.empty(N * Kd, device=d)
+    wp, wp16 = torch.empty(N * Kd, device=d), torch.empty(N * Kd, device=d)
     dev.pack_w(W.t().contiguous().to(d), N, Kd, N, wp, trans=True, order=1)
+    dev.pack_w(W.t().contiguous().to(d), N, Kd, N, wp16, trans=True, order=1, f16=True)
     Abl = dev.to_blocked(A.to(d), seq)
     Ahbl = dev.to_blocked(Ah.float().to(d), seq).to(torch.float16).contiguous().view(torch.float32)
-    C_ref, C_new = torch.full((P, N), float("nan"), device=d), torch.full((P, N), float("nan"), device=d)
+    outs = []
+    for _ in range(2):
+        C_new = torch.full((P, N), float("nan"), device=d)
+        dev.gemm_b2p(A=Ahbl, K=Kd, sm=seq, Wpack=wp16, C_out=C_new, ldc=N, a_fmt=2, amax=amax)
+        outs.append(C_new)
+    C_ref = torch.full((P, N), float("nan"), device=d)
     dev.gemm_b2p(A=dev.bls_pack(Abl), K=Kd, sm=seq, Wpack=wp, C_out=C_ref, ldc=N)
-    dev.gemm_b2p(A=Ahbl, K=Kd, sm=seq, Wpack=wp, C_out=C_new, ldc=N, a_fmt=2, amax=amax)
     torch.cuda.synchronize()
-    assert torch.equal(C_ref, C_new)
-    assert rel(C_new, A.double() @ W.double().t()) < 4e-5
+    assert torch.equal(outs[0], outs[1])
+    ref = A.double() @ W.double().t()
+    assert rel(outs[0], ref) < 1e-5                                # 11-bit operand (exact here) x 22-bit weights, fp32 accumulation
+    assert rel(C_ref, ref) < 4e-5 and rel(outs[0], C_ref) < 4e-5
 
 
 @pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37))])

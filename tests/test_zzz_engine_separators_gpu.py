@@ -108,3 +108,55 @@ def test_tfgridnet_engine_matches_python_model(tmp_path, variant):
         assert est.shape == (R, T) and np.isfinite(est).all()
         assert rel(est, ref) < 1e-4, (variant, R, T, rel(est, ref))
     eng.close()
+
+
+# ---- against the CPU ORACLE: the comparisons above hold the engine to the HIP Python tree; these
+#      hold it to the oracle chain directly, as tests/test_engine_gpu.py does for pBSRNN (round 3 had them only as the one-off
+#      checks of tools/make_engine_testdata_{dpccn,tfgridnet}.py --check) ------------------------------------------------------
+@pytest.mark.parametrize("fuse", ["multiply", "additive"])
+def test_dpccn_engine_matches_oracle(tmp_path, fuse):
+    from oracle import dpccn_oracle as DP
+    from tests.test_engine_gpu import _cuda, rel
+    from wesep_amd.models import get_model
+    _cuda()
+    kw = dict(tcn_blocks=3, tcn_layers=2, spk_fuse_type=fuse)
+    cfg = DP.DPCCNConfig(**kw)
+    params = DP.synth_params(cfg, 61)
+    model = get_model("DPCCN")(**kw, joint_training=False)
+    model.load_state_dict(params, strict=True)
+    path = str(tmp_path / "d.wsw")
+    export_engine(model, path)
+    eng = E.Engine(path)
+    g = torch.Generator().manual_seed(7)
+    for R, T in ((2, 8000), (1, 6001)):
+        wav, emb = 0.1 * torch.randn(R, T, generator=g), torch.randn(R, 256, generator=g)
+        est = eng.separate(wav.numpy(), emb.numpy(), E.ENROLL_EMBEDDING)
+        with torch.no_grad():
+            ref = DP.dpccn_forward(params, cfg, wav, emb)
+        assert rel(est, ref) < 1e-3, (fuse, R, T, rel(est, ref))     # north_star: 1e-3 on the separated waveform
+    eng.close()
+
+
+@pytest.mark.parametrize("fuse", ["multiply", "additive"])
+def test_tfgridnet_engine_matches_oracle(tmp_path, fuse):
+    from oracle import tfgridnet_oracle as TG
+    from tests.test_engine_gpu import _cuda, rel
+    from wesep_amd.models import get_model
+    _cuda()
+    kw = dict(n_fft=128, stride=64, n_layers=2, lstm_hidden_units=192, attn_n_head=4, attn_approx_qk_dim=512, emb_dim=128,
+              emb_ks=1, emb_hs=1, spk_fuse_type=fuse)
+    cfg = TG.TFGridNetConfig(**kw)
+    params = TG.synth_params(cfg, 62)
+    model = get_model("TFGridNet")(**kw, joint_training=False)
+    model.load_state_dict(params, strict=True)
+    path = str(tmp_path / "g.wsw")
+    export_engine(model, path)
+    eng = E.Engine(path)
+    g = torch.Generator().manual_seed(8)
+    for R, T in ((2, 8000), (1, 6016)):
+        wav, emb = 0.1 * torch.randn(R, T, generator=g), torch.randn(R, 256, generator=g)
+        est = eng.separate(wav.numpy(), emb.numpy(), E.ENROLL_EMBEDDING)
+        with torch.no_grad():
+            ref = TG.tfgridnet_forward(params, cfg, wav, emb)
+        assert rel(est, ref) < 1e-3, (fuse, R, T, rel(est, ref))
+    eng.close()

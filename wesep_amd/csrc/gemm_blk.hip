@@ -17,6 +17,8 @@
 // [32 slots x 128 columns] sub-block is one contiguous 16 KB.  Products are split-bf16 (hi/lo,
 // 3 MFMAs, fp32 accumulate) on v_mfma_f32_32x32x16_bf16; weights are pre-split and pre-ordered
 // into fragment order by ws_pack_w.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -111,6 +113,49 @@ __global__ void pack_w_kernel(const float* __restrict__ W, int N, int K, long lo
   bf16x8* o = reinterpret_cast<bf16x8*>(out);
   o[u * 64 + lane] = hi;
   o[(u + 1) * 64 + lane] = lo;
+}
+
+// fp16 variant (ABI v15): the same units, each element of W' scaled by 2^8 and split into fp16 hi = fp16(256 w) and
+// lo = fp16(256 w - hi) (22 bits; the scale keeps the lo term of ordinary weights out of fp16's subnormals) -- the B operand
+// of ws_gemm_b2p with a_fmt = 2, whose A operand (scaled-fp16 d(gates)) then needs no conversion: v_mfma_f32_32x32x16_f16.
+#define WS_PACK16_SCALE 256.f
+__global__ void pack_w16_kernel(const float* __restrict__ W, int N, int K, long long ldw, int trans, int order,
+                                _Float16* __restrict__ out) {
+  const int nks = K / 16, nnt = N / 32;
+  const int units = N * K / 8;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= units) return;
+  const int lane = idx & 63;
+  const int r = idx >> 6;
+  int nt, ks;
+  if (order == 0) {
+    ks = r % nks;
+    nt = r / nks;
+  } else {
+    nt = r % nnt;
+    ks = r / nnt;
+  }
+  const int n = 32 * nt + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+  f16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = WS_PACK16_SCALE * (trans ? W[(long long)(k0 + j) * ldw + n] : W[(long long)n * ldw + k0 + j]);
+    hi[j] = (_Float16)v;
+    lo[j] = (_Float16)(v - (float)hi[j]);
+  }
+  const long long u = (order == 0 ? ((long long)nt * nks + ks) : ((long long)ks * nnt + nt)) * 2;
+  f16x8* o = reinterpret_cast<f16x8*>(out);
+  o[u * 64 + lane] = hi;
+  o[(u + 1) * 64 + lane] = lo;
+}
+
+extern "C" int ws_pack_w_f16(const float* W, int N, int K, long long ldw, int trans, int order, float* out,
+                             void* stream) {
+  WS_REQUIRE(W && out && N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, "ws_pack_w_f16: N %% 32, K %% 16 (N=%d K=%d)", N, K);
+  WS_REQUIRE(order == 0 || order == 1, "ws_pack_w_f16: order");
+  hipLaunchKernelGGL(pack_w16_kernel, dim3((N * K / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, N, K, ldw,
+                     trans, order, reinterpret_cast<_Float16*>(out));
+  return ws_check_launch("ws_pack_w_f16");
 }
 
 extern "C" int ws_pack_w(const float* W, int N, int K, long long ldw, int trans, int order, float* out,
@@ -267,9 +312,10 @@ extern "C" int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream) {
 // A16 (a_fmt = 1, ABI v15): A holds bf16 elements in BLH(K) -- d(gates) of WS_GATES_H2: a lane's 8 consecutive k are two
 // 8-byte cells = the hi fragment itself; no lo term, two MFMAs per product instead of three, half the A bytes.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-// A16 = 2 (a_fmt = 2): A holds fp16 elements scaled by S = ws_dgates_scale(*p.amax) -- d(gates) of WS_GATES_H2F: an fp16 value
-// splits EXACTLY into bf16 hi + lo (11 bits = 8 + 3), so the three-term product is the split-pair product of the stored
-// value; the epilogue multiplies by 1 / S (a power of two: exact).
+// A16 = 2 (a_fmt = 2): A holds fp16 elements scaled by S = ws_dgates_scale(*p.amax) -- d(gates) of WS_GATES_H2F -- and Wpack
+// is a ws_pack_w_f16 pack (fp16 hi / lo of 256 w): the A cells ARE the MFMA fragments (no conversion) and a product is
+// a (w_hi + w_lo) on v_mfma_f32_32x32x16_f16 -- the operand's 11 bits times the weight's 22; the epilogue multiplies by
+// 1 / (256 S) (a power of two: exact).
 template <int A16>
 __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args p) {
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][2048];
@@ -290,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
   // units of half a cell-element pair: floats for BLS, 2-byte elements viewed through the same index formula for A16)
   typedef typename std::conditional<A16 != 0, u32x2, f32x4>::type acell;
   typedef typename std::conditional<A16 != 0, unsigned short, float>::type aelem;
-  const float inv_s = A16 == 2 ? ws_dgates_scale_inv(*p.amax) : 1.f;
+  const float inv_s = A16 == 2 ? ws_dgates_scale_inv(*p.amax) * (1.f / WS_PACK16_SCALE) : 1.f;
   const aelem* ab = reinterpret_cast<const aelem*>(p.A) + (long long)bb * 32 * K + i * 4 + 2 * half * 128;
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.Wpack);
   u32x4 wreg[4];
@@ -335,13 +381,14 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
         ah = __builtin_bit_cast(bf16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
       } else if constexpr (A16 == 2) {
         const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ks]), c1 = __builtin_bit_cast(u32x2, ac[2 * ks + 1]);
-        const f16x8 hv = __builtin_bit_cast(f16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
+        const f16x8 a16 = __builtin_bit_cast(f16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
+        const u32x4* wt = &wl[cur][ks * 512 + lane];  // [nt][part][lane]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float x = (float)hv[j];
-          ah[j] = (__bf16)x;
-          al[j] = (__bf16)(x - (float)ah[j]);
+        for (int nt = 0; nt < 4; ++nt) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16, __builtin_bit_cast(f16x8, wt[(nt * 2) * 64]), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16, __builtin_bit_cast(f16x8, wt[(nt * 2 + 1) * 64]), acc[nt], 0, 0, 0);
         }
+        continue;
       } else {
         unpack8(__builtin_bit_cast(u32x4, ac[2 * ks]), __builtin_bit_cast(u32x4, ac[2 * ks + 1]), ah, al);
       }
@@ -661,7 +708,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
 // GFMT = 2 (g_fmt = 2): G holds fp16 elements scaled by S = ws_dgates_scale(*p.amax) -- d(gates) of WS_GATES_H2F: every value
 // is split into its bf16 hi + lo terms in registers (exact: 11 = 8 + 3 bits), both planes of the G image are written and a
 // product is the three split-pair MFMAs again; slab and bslab leave the kernel multiplied by 1 / S (exact).
-template <bool ASUM, int GFMT>
+// GD: blocks of G in flight per thread (2 or 4).  G is the operand that comes from HBM (the A tiles are re-read by the eight
+// workgroups of a split: L2), and a wave's loads return in order: the A loads are issued FIRST, so they do not wait behind
+// the HBM round trip of G, and with GD = 4 the 16 bytes of G per thread and block are requested four blocks ahead (4 more
+// registers per block in flight) -- the block loop is bound by the round trip of its prefetch (profiles/r03_tnb_experiments.md).
+template <bool ASUM, int GFMT, int GD>
 __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_args p) {
   constexpr int TA = 3, TN = 3;
   constexpr int NTERM = GFMT == 2 ? 3 : 2;
@@ -702,12 +753,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
     acol[r] = 128 + c0 + 4 * quad;
   }
 
-  u32x4 gq[2];        // two blocks in flight
-  f32x4 aq[2][6];     // [slot][4 cells of r = 0, 2 cells of r = 1]
+  u32x4 gq[GD];       // GD blocks in flight (ring slot = block index mod GD)
+  f32x4 aq[2][6];     // [slot][4 cells of r = 0, 2 cells of r = 1]: two blocks in flight
   bool use[2][2];
+  auto load_g = [&](int b, int gslot) { gq[gslot] = *reinterpret_cast<const u32x4*>(gsrc + (long long)b * gstep); };
   auto load_block = [&](int b, int slot) {
     const int tile = b / L, step = b - tile * L;
-    gq[slot] = *reinterpret_cast<const u32x4*>(gsrc + (long long)b * gstep);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int sa = step + ashift[r];
@@ -724,10 +775,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
     for (int c = 0; c < 4; ++c) asum[r][c] = 0.f;
   // pieces of a block: pc 0..3 = column pc of the whole A group, 4..7 = column pc - 4 of the half group, 8..9 = the G
   // columns (0, 1) / (2, 3).  live = 0: tail iteration, the column sums stay untouched
-  auto store_piece = [&](int slot, __bf16* lds, unsigned live, int pc) {
+  auto store_piece = [&](int slot, int gslot, __bf16* lds, unsigned live, int pc) {
     const bf16x2 ones = __builtin_bit_cast(bf16x2, live);  // 0x3f803f80 = (1, 1)
     if (pc >= 8) {
-      const u32x4 d = gq[slot];
+      const u32x4 d = gq[gslot];
       const unsigned lo_ = pc == 8 ? d[0] : d[1], hi_ = pc == 8 ? d[2] : d[3];  // slot 2sp / slot 2sp + 1
       const int col = 4 * qg + 2 * (pc - 8);
       if constexpr (GFMT == 2) {
@@ -787,9 +838,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
     }
   };
   constexpr int NPC = 10;
-  auto store_block = [&](int slot, __bf16* lds, unsigned live) {
+  auto store_block = [&](int slot, int gslot, __bf16* lds, unsigned live) {
 #pragma unroll
-    for (int pc = 0; pc < NPC; ++pc) store_piece(slot, lds, live, pc);
+    for (int pc = 0; pc < NPC; ++pc) store_piece(slot, gslot, lds, live, pc);
   };
 
   f32x16 acc[2][TN];
@@ -804,15 +855,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
   if (nb > 0) {
     load_block(b_begin, 0);
     load_block(min(b_begin + 1, b_end - 1), 1);
-    store_block(0, ldsA, 0x3f803f80u);
+#pragma unroll
+    for (int k = 0; k < GD; ++k) load_g(min(b_begin + k, b_end - 1), k);
+    store_block(0, 0, ldsA, 0x3f803f80u);
   }
   __syncthreads();
-  for (int ib = 0; ib < nb; ib += 2) {
+  for (int ib = 0; ib < nb; ib += GD) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int i = ib + s;
-      if (i < nb) {  // uniform; only the odd tail skips
+    for (int sg4 = 0; sg4 < GD; ++sg4) {
+      const int s = sg4 & 1;
+      const int i = ib + sg4;
+      if (i < nb) {  // uniform; only the tail skips
+        // refill: the A registers of slot s held block i (converted one iteration ago) -> block i + 2; the G ring slot of
+        // block i -> block i + GD.  A first: its loads come back from L2 and must not queue behind G's HBM round trip
         load_block(b_begin + min(i + 2, nb - 1), s);
+        load_g(b_begin + min(i + GD, nb - 1), sg4);
         __builtin_amdgcn_sched_barrier(0);
         const __bf16* lds = s ? ldsB : ldsA;
         __bf16* ldsw = s ? ldsA : ldsB;
@@ -842,7 +899,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
               // terms: G_hi A_hi, G_hi A_lo and (GFMT 2) G_lo A_hi
 #pragma unroll
               for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(term == 2 ? gl[e] : gh[e], term == 1 ? al : ah, acc[e][f]);
-              if (sub < NPC) store_piece(s ^ 1, ldsw, live, sub);
+              if (sub < NPC) store_piece(s ^ 1, (sg4 + 1) % GD, ldsw, live, sub);
               __builtin_amdgcn_sched_barrier(0);
             }
             ah = ahn; al = aln;
@@ -914,14 +971,20 @@ extern "C" int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a->nsplit, a->g_cols / 128), block(512);
   ws_prof_begin(WS_PROF_GEMM_TN, s);
+  // WS_TNB_GDEPTH=2|4 (diagnostics): blocks of the 2-byte G operand in flight per thread; both depths give the same bits
+  static const int gdepth = [] { const char* e = getenv("WS_TNB_GDEPTH"); return e && atoi(e) == 2 ? 2 : 4; }();
   if (a->g_fmt == 2 && a->aslab)
-    hipLaunchKernelGGL((gemm_tnb16_kernel<true, 2>), grid, block, 0, s, *a);
+    hipLaunchKernelGGL((gemm_tnb16_kernel<true, 2, 4>), grid, block, 0, s, *a);
+  else if (a->g_fmt == 2 && gdepth == 2)
+    hipLaunchKernelGGL((gemm_tnb16_kernel<false, 2, 2>), grid, block, 0, s, *a);
   else if (a->g_fmt == 2)
-    hipLaunchKernelGGL((gemm_tnb16_kernel<false, 2>), grid, block, 0, s, *a);
+    hipLaunchKernelGGL((gemm_tnb16_kernel<false, 2, 4>), grid, block, 0, s, *a);
   else if (a->g_fmt && a->aslab)
-    hipLaunchKernelGGL((gemm_tnb16_kernel<true, 1>), grid, block, 0, s, *a);
+    hipLaunchKernelGGL((gemm_tnb16_kernel<true, 1, 4>), grid, block, 0, s, *a);
+  else if (a->g_fmt && gdepth == 2)
+    hipLaunchKernelGGL((gemm_tnb16_kernel<false, 1, 2>), grid, block, 0, s, *a);
   else if (a->g_fmt)
-    hipLaunchKernelGGL((gemm_tnb16_kernel<false, 1>), grid, block, 0, s, *a);
+    hipLaunchKernelGGL((gemm_tnb16_kernel<false, 1, 4>), grid, block, 0, s, *a);
   else if (ta == 3 && a->aslab)
     hipLaunchKernelGGL((gemm_tnb_kernel<3, true>), grid, block, 0, s, *a);
   else if (ta == 3)

@@ -778,12 +778,14 @@ def _smc(sm: SeqMap):
     return c
 
 
-def pack_w(W, N: int, K: int, ldw: int, out, trans=False, order=0, w_off=0):
+def pack_w(W, N: int, K: int, ldw: int, out, trans=False, order=0, w_off=0, f16=False):
+    """f16: fp16 hi / lo of 256 W (ws_pack_w_f16): the weight operand of gemm_b2p with a_fmt = 2."""
     _chk(W, "W")
     _chk(out, "out")
     if out.numel() < N * K:
         raise L.WesepHipError("pack_w: output too small")
-    L.check(L.lib().ws_pack_w(_p(W, w_off), N, K, ldw, int(trans), order, _p(out), L.stream_ptr()), "ws_pack_w")
+    fn = L.lib().ws_pack_w_f16 if f16 else L.lib().ws_pack_w
+    L.check(fn(_p(W, w_off), N, K, ldw, int(trans), order, _p(out), L.stream_ptr()), "ws_pack_w_f16" if f16 else "ws_pack_w")
 
 
 def gemm_p2b(*, A, lda: int, sm: SeqMap, Wpack, N: int, C_out, K=128, bias=None, A_bl=None, stats=None,

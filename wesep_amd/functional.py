@@ -403,7 +403,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             # the backward's packs (transposed projections, BPTT weight stream) are built here, where the GPU has a
             # single stream to serve: built lazily in the backward, these 10 us launches queue behind the side stream's
             # chip-filling weight-gradient GEMMs for up to a millisecond each (round 2 profile: 4 ms per step)
-            W("projT"), W("wihT")
+            W("projT"), W("wihT16" if gfmt == L.GATES_H2F else "wihT")
             if ctx.bptt == "pair":
                 W("hhp")
             if ctx.bptt == "stream" or (ctx.bptt == "pair" and h2):
@@ -535,7 +535,8 @@ class ResRNNBlkFn(torch.autograd.Function):
         del dout_bl
         # d(normalised input) = dgates Wcat -> GroupNorm backward (+ residual path)
         dxn = _empty(d, P, N)
-        dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=W("wihT"), C_out=dxn, ldc=N, a_fmt=g_fmt, amax=amax)
+        dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=W("wihT16" if g_fmt == 2 else "wihT"), C_out=dxn, ldc=N, a_fmt=g_fmt,
+                     amax=amax)
         dz = torch.empty_like(z)
         if dev.gn_bwd_fused_ok(geo):
             # band view: 16 032 groups of 16 KB -- one wave per group, x / dxn / dout cross HBM once (norm.hip)
@@ -605,9 +606,9 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
             out = _empty(d, 2 * G4 * N)
             dev.pack_w(W("cat")[0], 2 * G4, N, N, out, order=0)
             return out
-        if kind == "wihT":
+        if kind in ("wihT", "wihT16"):     # wihT16: fp16 hi / lo (ws_pack_w_f16): d(xn) from scaled-fp16 d(gates), WS_GATES_H2F
             out = _empty(d, N * 2 * G4)
-            dev.pack_w(W("cat")[0], N, 2 * G4, N, out, trans=True, order=1)
+            dev.pack_w(W("cat")[0], N, 2 * G4, N, out, trans=True, order=1, f16=kind == "wihT16")
             return out
         if kind == "pw":
             return proj_w.contiguous()

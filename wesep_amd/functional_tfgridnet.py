@@ -510,7 +510,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
                          amax=amax)
         wg = ctx.F0.ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)
         wct_pack = _empty(d, N * 2 * G4)
-        dev.pack_w(wcat, N, 2 * G4, N, wct_pack, trans=True, order=1)
+        dev.pack_w(wcat, N, 2 * G4, N, wct_pack, trans=True, order=1, f16=g_fmt == 2)
         dy = _empty(d, ns * Lr, N)
         dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dy, ldc=N, a_fmt=g_fmt, amax=amax)
         if ns != nseq:
