@@ -371,12 +371,19 @@ def gn_param_grad(x, dxn, stats, geo, nsplit, slab):
     slab.reshape(-1)[geo.W: 2 * geo.W] = d.sum((0, 1))          # d beta
 
 
-def gn_bwd_fused(x, dxn, stats, geo, gamma, dx, nwg, pslab, res=None):
+def gn_bwd_apply_pg(x, dxn, stats, ab, geo, dx, gamma, pslab, pout, counter, res=None):
+    gn_bwd_apply(x, dxn, stats, ab, geo, dx, gamma=gamma, res=res)
+    gn_param_grad(x, dxn, stats, geo, 1, pout)
+
+
+def gn_bwd_fused(x, dxn, stats, geo, gamma, dx, nwg, pslab, res=None, pout=None, counter=None):
     """norm.hip gn_bwd_fused_kernel: reduce + apply + parameter sums in one call (pslab [nwg, 2, 128])."""
     ab = torch.zeros(geo.ngroups, 2)
     make_gn_bwd_reduce(None)(x, dxn, stats, geo, ab, gamma=gamma)
     gn_bwd_apply(x, dxn, stats, ab, geo, dx, gamma=gamma, res=res)
     gn_param_grad(x, dxn, stats, geo, nwg, pslab)
+    if pout is not None:                               # the last workgroup's sum over the per-workgroup shares
+        pout.reshape(-1)[: 2 * geo.W] = pslab.reshape(nwg, 2 * geo.W).sum(0)
 
 
 def install(monkeypatch):
@@ -392,5 +399,6 @@ def install(monkeypatch):
     monkeypatch.setattr(dev, "gn_bwd_apply", gn_bwd_apply)
     monkeypatch.setattr(dev, "gn_param_grad", gn_param_grad)
     monkeypatch.setattr(dev, "gn_bwd_fused", gn_bwd_fused)
+    monkeypatch.setattr(dev, "gn_bwd_apply_pg", gn_bwd_apply_pg)
     monkeypatch.setattr(dev, "cu_count", lambda device: 256)
     _PACKS.clear()

@@ -219,6 +219,20 @@ def test_group_stats_and_gn_backward(view):
     dev.gn_param_grad(zd, dd, stats, geo, ns, slab)
     out = slab.sum(0)[0]
     assert rel(out[0], gam.grad) < 1e-5 and rel(out[1], bet.grad) < 1e-5
+    # pass 2 WITH the parameter sums, the last workgroup adding up the per-group partials (ABI v15): same dx bits as the
+    # plain apply pass, (dgamma, dbeta) without a reduction launch; the counter word comes back as zero (used twice)
+    assert dev.gn_bwd_apply_pg_ok(geo)
+    counter = torch.zeros(1, device=d, dtype=torch.int32)
+    pouts = []
+    for _ in range(2):
+        dz2 = torch.full_like(zd, float("nan"))
+        pslab = torch.full((geo.ngroups, 2, N), float("nan"), device=d)
+        pout = torch.full((2, N), float("nan"), device=d)
+        dev.gn_bwd_apply_pg(zd, dd, stats, ab, geo, dz2, gamma.to(d), pslab, pout, counter, res=res.to(d))
+        assert torch.equal(dz2, dz)
+        assert rel(pout[0], gam.grad) < 1e-5 and rel(pout[1], bet.grad) < 1e-5
+        pouts.append(pout)
+    assert torch.equal(pouts[0], pouts[1]) and int(counter.item()) == 0
 
 
 @pytest.mark.parametrize("R,K,Tf", [(2, 32, 37), (3, 6, 11), (1, 2, 300)])
@@ -263,6 +277,20 @@ def test_gn_backward_fused_small_groups(R, K, Tf):
     dzn = torch.empty_like(zd)                                # without the residual term
     dev.gn_bwd_fused(zd, dd, stats, geo, gamma.to(d), dzn, 5, torch.empty(5, 2, N, device=d))
     assert rel(dzn, gref - res) < 1e-5
+    # the last workgroup adds the per-workgroup shares up (pout; ABI v15): the sum of pslab, in workgroup order
+    counter = torch.zeros(1, device=d, dtype=torch.int32)
+    for nwg in (1, 7, min(1024, -(-geo.ngroups // 4))):
+        pouts = []
+        for _ in range(2):
+            pslab = torch.full((nwg, 2, N), float("nan"), device=d)
+            pout = torch.full((2, N), float("nan"), device=d)
+            dzp = torch.empty_like(zd)
+            dev.gn_bwd_fused(zd, dd, stats, geo, gamma.to(d), dzp, nwg, pslab, res=res.to(d), pout=pout, counter=counter)
+            assert torch.equal(dzp, outs[0])
+            assert rel(pout, pslab.double().sum(0)) < 1e-6
+            assert rel(pout[0], gam.grad) < 1e-5 and rel(pout[1], bet.grad) < 1e-5, nwg
+            pouts.append(pout)
+        assert torch.equal(pouts[0], pouts[1]) and int(counter.item()) == 0
 
 
 # ----------------------------------------------------------------------------------------------
@@ -408,11 +436,12 @@ def test_mask_istft_fwd_bwd_vs_torch(T):
 # ----------------------------------------------------------------------------------------------
 # elementwise: affine, SI-SDR, clip + Adam
 # ----------------------------------------------------------------------------------------------
-def test_affine_fwd_bwd():
+@pytest.mark.parametrize("K", [4, 32])      # 1 split / 8 splits of the rows (the last workgroup adds the splits up)
+def test_affine_fwd_bwd(K):
     from wesep_amd.functional import AffineFn
     d = _cuda()
     g = torch.Generator().manual_seed(41)
-    R, K, Tf, N = 3, 4, 70, 128
+    R, Tf, N = 3, 70, 128
     z, a, b, go = rnd(g, R, K, Tf, N), rnd(g, R, N), rnd(g, R, N), rnd(g, R, K, Tf, N)
     for a0, use_a, use_b in ((0.0, True, False), (1.0, False, True), (1.0, True, True)):
         zc, ac, bc = (t.clone().requires_grad_(True) for t in (z, a, b))

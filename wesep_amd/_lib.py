@@ -153,7 +153,8 @@ _SIGS = {
     "ws_gn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _p, _p]),
     "ws_gn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _p, _p]),
     "ws_gn_param_grad": (_i, [_p, _p, _p, C.POINTER(GroupsGeom), _i, _p, _p]),
-    "ws_gn_bwd_fused": (_i, [_p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _i, _p, _p, _p]),
+    "ws_gn_bwd_fused": (_i, [_p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _i, _p, _p, _p, _p, _p]),
+    "ws_gn_bwd_apply_pg": (_i, [_p, _p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _p, _p, _p, _p, _p]),
     "ws_lstm_pack": (_i, [_p, _p, _p, _p, _i, _p]),
     "ws_lstm_fwd": (_i, [C.POINTER(LstmArgs), _p]),
     "ws_lstm_bwd": (_i, [C.POINTER(LstmArgs), _p]),
@@ -171,7 +172,7 @@ _SIGS = {
     "ws_istft_ola": (_i, [_p, _i, _i, _i, _p, _p]),
     "ws_mask_istft_bwd": (_i, [_p, _p, _p, _i, _i, _i, C.POINTER(Bands), _p, _p]),
     "ws_affine_fwd": (_i, [_p, _p, _p, _f, _ll, _i, _i, _p, _p]),
-    "ws_affine_bwd": (_i, [_p, _p, _p, _f, _ll, _i, _i, _i, _p, _p, _p, _p]),
+    "ws_affine_bwd": (_i, [_p, _p, _p, _f, _ll, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "ws_sisdr_fwd": (_i, [_p, _p, _i, _i, _f, _p, _p, _p]),
     "ws_sisdr_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p]),
     # Conv-TasNet / SpEx+ (tasnet.hip)

@@ -80,6 +80,27 @@ __device__ __forceinline__ float ws_dgates_scale_inv(unsigned amax_bits) {
   return __uint_as_float((unsigned)(254 - (int)(__float_as_uint(s) >> 23)) << 23);  // 2^-k, exact
 }
 
+// True in exactly one workgroup of the launch -- the last one to get here -- for all of its threads; the others' global
+// stores issued before the call are visible to it (agent-scope release / acquire around one relaxed atomic).  `counter`:
+// a device word that is 0 at launch; the last workgroup leaves it at 0 again.  For "the last workgroup adds up the
+// partials" epilogues: the sum runs over the partials in index order, so the result does not depend on WHICH workgroup
+// came last (deterministic), and the separate reduction launch -- which on a busy GPU can sit out a whole weight-gradient
+// GEMM of another stream before it gets a CU -- disappears.  Contains two barriers.
+__device__ __forceinline__ bool ws_last_block(unsigned* counter, unsigned nblocks) {
+  __shared__ unsigned last_s;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(counter, 1u);
+    last_s = t == nblocks - 1u;
+    if (last_s) *counter = 0u;
+  }
+  __syncthreads();
+  const bool last = last_s != 0u;
+  if (last) __threadfence();
+  return last;
+}
+
 __device__ __forceinline__ float ws_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 // row index -> element offset under the two-level row addressing used across the C ABI:

@@ -43,7 +43,8 @@ extern "C" int ws_affine_fwd(const float* z, const float* a, const float* b, flo
 __global__ __launch_bounds__(256) void affine_bwd_kernel(
     const float* __restrict__ dz, const float* __restrict__ z_in, const float* __restrict__ a,
     float a0, int rows_per_r, int N, int nsplit, float* __restrict__ dz_in,
-    float* __restrict__ da_slab, float* __restrict__ db_slab) {
+    float* __restrict__ da_slab, float* __restrict__ db_slab, float* __restrict__ da, float* __restrict__ db,
+    unsigned* counter) {
   __shared__ float sh[2][128];
   const int r = blockIdx.x, split = blockIdx.y, R = gridDim.x;
   const int col = threadIdx.x & 127, rl = threadIdx.x >> 7;
@@ -70,18 +71,33 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(
     if (da_slab) da_slab[o] = sa + sh[0][col];
     if (db_slab) db_slab[o] = sb + sh[1][col];
   }
+  // (optional) the last workgroup of the launch adds the splits up, in split order, into da / db [R][N]: no reduction launches
+  if (counter && ws_last_block(counter, gridDim.x * gridDim.y)) {
+    const int total = R * N;
+    for (int o = threadIdx.x; o < total; o += 256) {
+      float ta = 0.f, tb = 0.f;
+      for (int k = 0; k < nsplit; ++k) {
+        if (da) ta += da_slab[(long long)k * total + o];
+        if (db) tb += db_slab[(long long)k * total + o];
+      }
+      if (da) da[o] = ta;
+      if (db) db[o] = tb;
+    }
+  }
 }
 
 extern "C" int ws_affine_bwd(const float* dz, const float* z_in, const float* a, float a0,
                              long long rows, int rows_per_r, int N, int nsplit, float* dz_in,
-                             float* da_slab, float* db_slab, void* stream) {
+                             float* da_slab, float* db_slab, float* da, float* db, unsigned* counter, void* stream) {
   WS_REQUIRE(dz && rows > 0 && rows_per_r > 0 && N > 0 && N <= 128 && nsplit > 0,
              "ws_affine_bwd: bad args");
   WS_REQUIRE(rows % rows_per_r == 0, "ws_affine_bwd: rows %% rows_per_r != 0");
   WS_REQUIRE(!da_slab || z_in, "ws_affine_bwd: da needs z_in");
+  WS_REQUIRE((!da && !db) || counter, "ws_affine_bwd: da / db need a counter word");
+  WS_REQUIRE((!da || da_slab) && (!db || db_slab), "ws_affine_bwd: da / db are sums of their slabs");
   const int R = (int)(rows / rows_per_r);
   hipLaunchKernelGGL(affine_bwd_kernel, dim3(R, nsplit), dim3(256), 0, (hipStream_t)stream, dz, z_in,
-                     a, a0, rows_per_r, N, nsplit, dz_in, da_slab, db_slab);
+                     a, a0, rows_per_r, N, nsplit, dz_in, da_slab, db_slab, da, db, (da || db) ? counter : nullptr);
   return ws_check_launch("ws_affine_bwd");
 }
 

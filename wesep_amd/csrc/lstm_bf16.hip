@@ -365,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float ig = vi[r], fg = vf[r], gg = vg[r], og = vo[r];
-        const float dhv = n_dh[j][r] + dhr[4 * j + r];
+        const float dhv = dh_in<GF>(n_dh[j][r], dhr[4 * j + r], dS);
         const float tc = ftanh(c_cur[j][r]);
         const float dov = dhv * tc;
         const float dcv = dc[j][r] + dhv * og * (1.f - tc * tc);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
         *reinterpret_cast<bf16x4*>(dhi + 256 * g + 8 * j) = hi;
         *reinterpret_cast<bf16x4*>(dlo + 256 * g + 8 * j) = lo;
         if (st) {
-          if constexpr (G2) bst8(enc_dgates<GF>(v, hi, dS), ors(t), glane >> 1, (g * 64 + 2 * j) * 256);
+          if constexpr (G2) bst8(enc_dgates<GF>(v, hi), ors(t), glane >> 1, (g * 64 + 2 * j) * 256);
           else if constexpr (BLK) st_gate(pack_hl4(hi, lo), t, g, j);
           else st_gate(v, t, g, j);
         }

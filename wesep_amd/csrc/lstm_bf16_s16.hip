@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float ig = vi[r], fg = vf[r], gg = vg[r], og = vo[r];
-        const float dhv = n_dh[tu][r] + dhr[tu][r];
+        const float dhv = dh_in<GF>(n_dh[tu][r], dhr[tu][r], dS);
         const float tc = ftanh(c_cur[tu][r]);
         const float dov = dhv * tc;
         const float dcv = dc[tu][r] + dhv * og * (1.f - tc * tc);
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_s16_kernel(const ws_lstm_args
         split4(v, hi, lo);
         *reinterpret_cast<bf16x4*>(dhi + 256 * g + 16 * tu) = hi;
         *reinterpret_cast<bf16x4*>(dlo + 256 * g + 16 * tu) = lo;
-        if constexpr (G2) bst8(enc_dgates<GF>(v, hi, dS), ors(t), glane >> 1, (g * 64 + 4 * tu) * 256);
+        if constexpr (G2) bst8(enc_dgates<GF>(v, hi), ors(t), glane >> 1, (g * 64 + 4 * tu) * 256);
         else if (!(S16_DBG & 2)) st_gate(pack_hl4(hi, lo), t, g, tu);
       };
       emit(pi, 0);

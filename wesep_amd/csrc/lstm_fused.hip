@@ -291,6 +291,7 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
 #pragma unroll
     for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
 
+  const __bf16* hrow[2] = {&hl[0][l31 * HROW + 8 * half], &hl[0][(32 + l31) * HROW + 8 * half]};  // h_{t-1} rows of this lane
   auto tof = [&](int n) { const int m = min(n, L - 1); return d == 0 ? m : L - 1 - m; };
   dma_x(0, tof(0));
   dma_x(1, tof(0));
@@ -324,9 +325,11 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
           bh[e] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
           bl[e] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
         } else {
-          const int o = (32 * e + l31) * HROW + 8 * half + 16 * (ks - 8);
-          bh[e] = *reinterpret_cast<const bf16x8*>(&hl[0][o]);
-          bl[e] = *reinterpret_cast<const bf16x8*>(&hl[1][o]);
+          // (ONE base address per tile, the k-step in the instruction's immediate offset: written as an index expression
+          //  8 * half + 16 * (ks - 8), the compiler merges the two disjoint-bit terms with v_or and then keeps sixteen
+          //  separate address registers alive across the step -- the 64 B / lane of scratch of round 3)
+          bh[e] = *reinterpret_cast<const bf16x8*>(hrow[e] + 16 * (ks - 8));
+          bl[e] = *reinterpret_cast<const bf16x8*>(hrow[e] + 2 * SQ * HROW + 16 * (ks - 8));
         }
       }
 #pragma unroll

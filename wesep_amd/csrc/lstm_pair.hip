@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float ig = vi[r], fg = vf[r], gg = vg[r], og = vo[r];
-        const float dhv = n_dh[e][r] + dhr[r];
+        const float dhv = dh_in<GF>(n_dh[e][r], dhr[r], dS);
         const float tc = ftanh(c_cur[e][r]);
         const float dov = dhv * tc;
         const float dcv = dc[e][r] + dhv * og * (1.f - tc * tc);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
         *reinterpret_cast<bf16x4*>(&bimg[0][n * PR_ROW + g * 128 + 4 * q]) = hi;
         *reinterpret_cast<bf16x4*>(&bimg[1][n * PR_ROW + g * 128 + 4 * q]) = lo;
         if constexpr (G2) {
-          bst8(enc_dgates<GF>(v, hi, dS), ors(t), gvo >> 1, (g * 64 + 2 * e) * 256);
+          bst8(enc_dgates<GF>(v, hi), ors(t), gvo >> 1, (g * 64 + 2 * e) * 256);
         } else {
           pk[e][g] = pack_hl4(hi, lo);
           bst(pk[e][g], grs(t), gvo, (g * 64 + 2 * e) * 512);  // (zero soffset inside: hipcc pads the data hazard)

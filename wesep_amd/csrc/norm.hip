@@ -146,6 +146,72 @@ extern "C" int ws_gn_bwd_reduce(const float* x, const float* dxn, const float* s
   return ws_check_launch("ws_gn_bwd_reduce");
 }
 
+// Apply + PARAMETER SUMS in one pass (round 4; single-band groups of 128-float rows -- the time view of ResRNN.norm): the
+// apply pass reads x and dxn anyway, so dgamma[c] = sum dxn * xhat and dbeta[c] = sum dxn accumulate on the way (a thread
+// keeps one column quad: 256 threads = 8 row lanes x 32 quads), one partial [2][128] per group goes to `pslab`, and the last
+// workgroup of the launch adds the partials up in group order into `pout` [2][128] (ws_last_block): ws_gn_param_grad's pass
+// over x and dxn and the ws_reduce_slabs launch behind it are gone.
+__global__ __launch_bounds__(256) void gn_bwd_apply_pg_kernel(
+    const float* __restrict__ x, const float* dxn, const float* __restrict__ stats, const float* __restrict__ ab,
+    const float* __restrict__ gamma, const float* __restrict__ res, const ws_groups_geom geo, float* dx,
+    float* __restrict__ pslab, float* __restrict__ pout, unsigned* counter) {
+  __shared__ f32x4 sh[2][8][32];
+  const int g = blockIdx.x;
+  const GroupView v = group_view(geo, g);
+  const int n = geo.L * 128;
+  const float mean = stats[2 * (long long)g], rstd = stats[2 * (long long)g + 1];
+  const float a0 = ab[2 * (long long)g], a1 = ab[2 * (long long)g + 1];
+  const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+  f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+  for (int row = rl; row < geo.L; row += 8) {
+    const long long o = v.base + (long long)row * geo.rs + 4 * c4;
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dxn + o);
+    const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mean) * rstd;
+    f32x4 r = (d * gm - a0 - xh * a1) * rstd;
+    if (res) r += *reinterpret_cast<const f32x4*>(res + o);
+    *reinterpret_cast<f32x4*>(dx + o) = r;
+    sg += d * xh;
+    sb += d;
+  }
+  (void)n;
+  sh[0][rl][c4] = sg;
+  sh[1][rl][c4] = sb;
+  __syncthreads();
+  if (rl < 2) {  // rl 0 -> dgamma, rl 1 -> dbeta: the eight row lanes in fixed order
+    f32x4 t = sh[rl][0][c4];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) t += sh[rl][r][c4];
+    *reinterpret_cast<f32x4*>(pslab + ((long long)g * 2 + rl) * 128 + 4 * c4) = t;
+  }
+  if (ws_last_block(counter, gridDim.x)) {
+    // 256 threads = the 256 outputs; partials in group order.  (Plain loads after the acquire fence of ws_last_block.)
+    const int o = threadIdx.x;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= (int)gridDim.x; k += 4) {
+      t0 += pslab[(long long)k * 256 + o];
+      t1 += pslab[(long long)(k + 1) * 256 + o];
+      t2 += pslab[(long long)(k + 2) * 256 + o];
+      t3 += pslab[(long long)(k + 3) * 256 + o];
+    }
+    for (; k < (int)gridDim.x; ++k) t0 += pslab[(long long)k * 256 + o];
+    pout[o] = (t0 + t1) + (t2 + t3);
+  }
+}
+
+extern "C" int ws_gn_bwd_apply_pg(const float* x, const float* dxn, const float* stats, const float* ab,
+                                  const float* gamma, const float* res, const ws_groups_geom* geo, float* dx,
+                                  float* pslab, float* pout, unsigned* counter, void* stream) {
+  int rc = geom_check(geo, "ws_gn_bwd_apply_pg");
+  if (rc != WS_OK) return rc;
+  WS_REQUIRE(x && dxn && stats && ab && dx && gamma && pslab && pout && counter, "ws_gn_bwd_apply_pg: null pointer");
+  WS_REQUIRE(geom_vec4(geo) && geo->nbands == 1 && geo->W == 128, "ws_gn_bwd_apply_pg: single-band groups of 128-float rows");
+  hipLaunchKernelGGL(gn_bwd_apply_pg_kernel, dim3(geo->ngroups), dim3(256), 0, (hipStream_t)stream, x, dxn, stats, ab,
+                     gamma, res, *geo, dx, pslab, pout, counter);
+  return ws_check_launch("ws_gn_bwd_apply_pg");
+}
+
 template <bool V4>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const float* __restrict__ x, const float* dxn, const float* __restrict__ stats,
@@ -295,7 +361,8 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const float* __restri
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ res, const ws_groups_geom geo,
-                                                           float* __restrict__ dx, float* __restrict__ pslab) {
+                                                           float* __restrict__ dx, float* __restrict__ pslab,
+                                                           float* __restrict__ pout, unsigned* counter) {
   __shared__ f32x4 sh[2][4][32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c4 = lane & 31, rl = lane >> 5;
@@ -353,11 +420,25 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const float* __restri
     for (int r = 1; r < 4; ++r) t += sh[rl][r][c4];
     *reinterpret_cast<f32x4*>(pslab + ((long long)blockIdx.x * 2 + rl) * 128 + 4 * c4) = t;
   }
+  // (optional) the last workgroup of the launch adds the per-workgroup shares up, in workgroup order: no reduction launch
+  if (pout && ws_last_block(counter, gridDim.x)) {
+    const int o = threadIdx.x;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= (int)gridDim.x; k += 4) {
+      t0 += pslab[(long long)k * 256 + o];
+      t1 += pslab[(long long)(k + 1) * 256 + o];
+      t2 += pslab[(long long)(k + 2) * 256 + o];
+      t3 += pslab[(long long)(k + 3) * 256 + o];
+    }
+    for (; k < (int)gridDim.x; ++k) t0 += pslab[(long long)k * 256 + o];
+    pout[o] = (t0 + t1) + (t2 + t3);
+  }
 }
 
 extern "C" int ws_gn_bwd_fused(const float* x, const float* dxn, const float* stats, const float* gamma,
                                const float* res, const ws_groups_geom* geo, int nwg, float* dx, float* pslab,
-                               void* stream) {
+                               float* pout, unsigned* counter, void* stream) {
   int rc = geom_check(geo, "ws_gn_bwd_fused");
   if (rc != WS_OK) return rc;
   WS_REQUIRE(x && dxn && stats && gamma && dx && pslab && nwg > 0, "ws_gn_bwd_fused: null pointer / nwg");
@@ -365,8 +446,9 @@ extern "C" int ws_gn_bwd_fused(const float* x, const float* dxn, const float* st
                  geo->L % 2 == 0,
              "ws_gn_bwd_fused: built for single-band groups of an even number (<= %d) of 128-float rows (L=%d, W=%d)",
              2 * GNF_ROWS, geo->L, geo->W);
+  WS_REQUIRE(!pout || counter, "ws_gn_bwd_fused: pout needs a counter word");
   hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, dxn, stats, gamma, res,
-                     *geo, dx, pslab);
+                     *geo, dx, pslab, pout, counter);
   return ws_check_launch("ws_gn_bwd_fused");
 }
 

@@ -228,6 +228,11 @@ def _tab(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _word(t):
+    """device pointer of an int32 word tensor (status / guard / counter / scale words), or NULL."""
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
 def gn_bwd_reduce(x, dxn, stats, geo: Geom, ab, gamma=None, gamma_tab=None):
     for n, t in (("x", x), ("dxn", dxn), ("stats", stats), ("ab", ab), ("gamma", gamma)):
         _chk(t, n)
@@ -253,14 +258,33 @@ def gn_bwd_fused_ok(geo: Geom) -> bool:
             and geo.gs1 % 4 == 0 and geo.gs2 % 4 == 0)
 
 
-def gn_bwd_fused(x, dxn, stats, geo: Geom, gamma, dx, nwg: int, pslab, res=None):
+def gn_bwd_fused(x, dxn, stats, geo: Geom, gamma, dx, nwg: int, pslab, res=None, pout=None, counter=None):
     """reduce + apply + parameter sums of the GroupNorm backward in one pass (norm.hip gn_bwd_fused_kernel);
-    pslab [nwg, 2, 128]: per-workgroup shares of (dgamma, dbeta)."""
-    for n, t in (("x", x), ("dxn", dxn), ("stats", stats), ("gamma", gamma), ("res", res), ("dx", dx), ("pslab", pslab)):
+    pslab [nwg, 2, 128]: per-workgroup shares of (dgamma, dbeta); pout [2, 128] (optional, with a zeroed int32 `counter`
+    word): their sum, taken by the last workgroup of the launch."""
+    for n, t in (("x", x), ("dxn", dxn), ("stats", stats), ("gamma", gamma), ("res", res), ("dx", dx), ("pslab", pslab),
+                 ("pout", pout)):
         _chk(t, n)
     g = geo.c()
     L.check(L.lib().ws_gn_bwd_fused(_p(x), _p(dxn), _p(stats), _p(gamma), _p(res), C.byref(g), nwg, _p(dx), _p(pslab),
-                                    L.stream_ptr()), "ws_gn_bwd_fused")
+                                    _p(pout), _word(counter), L.stream_ptr()), "ws_gn_bwd_fused")
+
+
+def gn_bwd_apply_pg_ok(geo: Geom) -> bool:
+    """Single-band groups of 128-float rows (the time view of ResRNN.norm): apply + parameter sums in one pass."""
+    return (os.environ.get("WESEP_GN_FUSED", "1") != "0" and geo.nbands == 1 and geo.W == 128 and geo.band_w is None
+            and geo.band_off is None and geo.rs % 4 == 0 and geo.gs1 % 4 == 0 and geo.gs2 % 4 == 0)
+
+
+def gn_bwd_apply_pg(x, dxn, stats, ab, geo: Geom, dx, gamma, pslab, pout, counter, res=None):
+    """GroupNorm backward pass 2 with the parameter sums (norm.hip gn_bwd_apply_pg_kernel): dx, and (dgamma, dbeta) in
+    pout [2, 128] via pslab [ngroups, 2, 128] and the launch's last workgroup; counter: a zeroed int32 device word."""
+    for n, t in (("x", x), ("dxn", dxn), ("stats", stats), ("ab", ab), ("gamma", gamma), ("res", res), ("dx", dx),
+                 ("pslab", pslab), ("pout", pout)):
+        _chk(t, n)
+    g = geo.c()
+    L.check(L.lib().ws_gn_bwd_apply_pg(_p(x), _p(dxn), _p(stats), _p(ab), _p(gamma), _p(res), C.byref(g), _p(dx),
+                                       _p(pslab), _p(pout), _word(counter), L.stream_ptr()), "ws_gn_bwd_apply_pg")
 
 
 def gn_param_grad(x, dxn, stats, geo: Geom, nsplit: int, slab):
@@ -604,12 +628,14 @@ def affine_fwd(z, a, b, a0, rows, rows_per_r, N, out):
                                   L.stream_ptr()), "ws_affine_fwd")
 
 
-def affine_bwd(dz, z_in, a, a0, rows, rows_per_r, N, nsplit, dz_in, da_slab, db_slab):
-    for n, t in (("dz", dz), ("z_in", z_in), ("a", a), ("dz_in", dz_in), ("da_slab", da_slab),
-                 ("db_slab", db_slab)):
+def affine_bwd(dz, z_in, a, a0, rows, rows_per_r, N, nsplit, dz_in, da_slab, db_slab, da=None, db=None, counter=None):
+    """da / db [R, N] (optional, with a zeroed int32 `counter` word): the slabs summed over the splits by the last workgroup
+    of the launch instead of by ws_reduce_slabs launches."""
+    for n, t in (("dz", dz), ("z_in", z_in), ("a", a), ("dz_in", dz_in), ("da_slab", da_slab), ("db_slab", db_slab),
+                 ("da", da), ("db", db)):
         _chk(t, n)
     L.check(L.lib().ws_affine_bwd(_p(dz), _p(z_in), _p(a), a0, rows, rows_per_r, N, nsplit, _p(dz_in),
-                                  _p(da_slab), _p(db_slab), L.stream_ptr()), "ws_affine_bwd")
+                                  _p(da_slab), _p(db_slab), _p(da), _p(db), _word(counter), L.stream_ptr()), "ws_affine_bwd")
 
 
 def sisdr_fwd(est, tgt, rowstat, loss, eps=1e-8):
@@ -626,10 +652,6 @@ def sisdr_bwd(est, tgt, rowstat, gout, dest):
     R, T = est.shape
     L.check(L.lib().ws_sisdr_bwd(_p(est), _p(tgt), _p(rowstat), _p(gout), R, T, _p(dest),
                                  L.stream_ptr()), "ws_sisdr_bwd")
-
-
-def _word(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
 def grad_norms(tab, ntensors, norms, guard=None):

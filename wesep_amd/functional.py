@@ -214,6 +214,26 @@ def reset_deferred_wgrads(device):
     _pending(device).clear()
 
 
+_AMAX = {}   # (device, stream) -> [int32 words, cursor]: scale words of WS_GATES_H2F, handed out one per BPTT launch
+
+
+def amax_word(device):
+    """A zeroed device word for ws_gemm_p2b's running max |d(hcat)| (the scale source of WS_GATES_H2F, wesep_hip.h).  Words
+    come from a block that is zero-filled ONCE per 256 launches instead of once per launch: a 4-byte fill is a launch of its
+    own, and every tiny main-stream launch can sit out a whole weight-gradient GEMM of the side stream before it gets a
+    CU (profiles/r04_summary.md).  A block is never re-zeroed while words of it may still be read (the side stream's
+    deferred jobs): a fresh block is allocated instead and the old one dies with its last reference."""
+    key = (device.type, device.index, L.stream_ptr().value if device.type == "cuda" and torch.cuda.is_available() else 0)
+    ent = _AMAX.get(key)
+    if ent is None or ent[1] >= ent[0].numel():
+        ent = _AMAX[key] = [torch.zeros(256, device=device, dtype=torch.int32), 0]
+    ent[1] += 1
+    return ent[0][ent[1] - 1:ent[1]]
+
+
+zero_word = amax_word    # the same zeroed words serve as the counters of the "last workgroup sums up" epilogues (ws_last_block)
+
+
 def mark_wgrads_ready(device):
     """Event on the current stream after which every deferred job's operands are complete (None when
     nothing is pending)."""
@@ -467,7 +487,7 @@ class ResRNNBlkFn(torch.autograd.Function):
         gfmt = ctx.gfmt
         # WS_GATES_H2F: the d(hcat) GEMM raises max |d(hcat)| of this launch in a device word; the BPTT scales its fp16 d(gates)
         # by the power of two it defines, the two consumers of d(gates) undo it (wesep_hip.h)
-        amax = torch.zeros(1, device=d, dtype=torch.int32) if gfmt == L.GATES_H2F else None
+        amax = amax_word(d) if gfmt == L.GATES_H2F else None
         dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=W("projT"), N=2 * H, C_out=dh, A_bl=dout_bl, amax=amax)
         if _h2_probe() & 16:
             _probe_round(dh, "bf16")
@@ -538,11 +558,21 @@ class ResRNNBlkFn(torch.autograd.Function):
         dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=W("wihT16" if g_fmt == 2 else "wihT"), C_out=dxn, ldc=N, a_fmt=g_fmt,
                      amax=amax)
         dz = torch.empty_like(z)
+        # (dgamma, dbeta): summed by the LAST workgroup of the kernel that produced the partials (wesep_hip.h, ABI v15) --
+        # a separate ws_reduce_slabs launch on this stream can sit out a whole weight-gradient GEMM of the side stream
+        # before its four workgroups get a CU (round 3: 7 ms per step in 62 such launches)
+        dgb = _empty(d, 2, N)
         if dev.gn_bwd_fused_ok(geo):
             # band view: 16 032 groups of 16 KB -- one wave per group, x / dxn / dout cross HBM once (norm.hip)
             ns2 = min(1024, -(-geo.ngroups // 4))
             pslab = _empty(d, ns2, 2, N)
-            dev.gn_bwd_fused(z, dxn, stats, geo, norm_w, dz, ns2, pslab, res=dout)
+            dev.gn_bwd_fused(z, dxn, stats, geo, norm_w, dz, ns2, pslab, res=dout, pout=dgb, counter=zero_word(d))
+        elif dev.gn_bwd_apply_pg_ok(geo):
+            # time view: 1 024 groups of 256 KB: the group means first, then apply + parameter sums in ONE pass over x / dxn
+            ab = _empty(d, geo.ngroups, 2)
+            dev.gn_bwd_reduce(z, dxn, stats, geo, ab, gamma=norm_w)
+            pslab = _empty(d, geo.ngroups, 2, N)
+            dev.gn_bwd_apply_pg(z, dxn, stats, ab, geo, dz, norm_w, pslab, dgb, zero_word(d), res=dout)
         else:
             ab = _empty(d, geo.ngroups, 2)
             dev.gn_bwd_reduce(z, dxn, stats, geo, ab, gamma=norm_w)
@@ -550,7 +580,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             pslab = _empty(d, ns2, 2, N)
             dev.gn_param_grad(z, dxn, stats, geo, ns2, pslab)
             dev.gn_bwd_apply(z, dxn, stats, ab, geo, dz, gamma=norm_w, res=dout)
-        dgb = _reduce_new(pslab, ns2, 2 * N, (2, N))
+            dgb = _reduce_new(pslab, ns2, 2 * N, (2, N))
         gd = torch.zeros((), device=d) if box is not None else None
         return (dz, gd, None, None, None, dgb[0], dgb[1]) + tuple(wg)
 
@@ -782,9 +812,11 @@ class AffineFn(torch.autograd.Function):
         da_slab = _empty(z.device, ns, R, N) if a is not None else None
         db_slab = _empty(z.device, ns, R, N) if ctx.has_b else None
         dz = torch.empty_like(z)
-        dev.affine_bwd(dout, z, a, ctx.a0, R * K * Tf, K * Tf, N, ns, dz, da_slab, db_slab)
-        da = _reduce_new(da_slab, ns, R * N, (R, N)) if a is not None else None
-        db = _reduce_new(db_slab, ns, R * N, (R, N)) if ctx.has_b else None
+        # the splits are summed by the last workgroup of the launch (no ws_reduce_slabs launches: see ResRNNBlkFn.backward)
+        da = _empty(z.device, R, N) if a is not None else None
+        db = _empty(z.device, R, N) if ctx.has_b else None
+        dev.affine_bwd(dout, z, a, ctx.a0, R * K * Tf, K * Tf, N, ns, dz, da_slab, db_slab, da=da, db=db,
+                       counter=zero_word(z.device) if (da is not None or db is not None) else None)
         return dz, da, db, None
 
 

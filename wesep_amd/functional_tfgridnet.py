@@ -480,7 +480,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         wlt_pack = _empty(d, 2 * H * N)
         dev.pack_w(lw, 2 * H, N, 2 * H, wlt_pack, trans=True, order=0)
         dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
-        amax = torch.zeros(1, device=d, dtype=torch.int32) if ctx.gfmt == L.GATES_H2F else None   # (functional.py)
+        amax = ctx.F0.amax_word(d) if ctx.gfmt == L.GATES_H2F else None   # (functional.py)
         dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wlt_pack, N=2 * H, C_out=dh, A_bl=dout_bl, amax=amax)
         # BPTT works in place on the saved gates (6.4 GB per BLSTM at the recipe's 8 rows x 6 s: a clone here was 12 copies
         # = 38 ms of a 490 ms step and the largest transient allocation of the backward)
