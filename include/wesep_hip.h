@@ -200,9 +200,10 @@ int ws_gn_param_grad(const float* x, const float* dxn, const float* stats,
 int ws_gn_bwd_fused(const float* x, const float* dxn, const float* stats, const float* gamma,
                     const float* res, const ws_groups_geom* geo, int nwg, float* dx, float* pslab,
                     float* pout, unsigned* counter, void* stream);
-/* ABI v15: pout [2][128] (optional) = (dgamma, dbeta) summed over the workgroups by the LAST workgroup of the launch, in
- * workgroup order (deterministic; no ws_reduce_slabs launch behind it); `counter`: a device word that is 0 at launch (the
- * kernel leaves it at 0).
+/* ABI v15: pout [2][128] (optional) = (dgamma, dbeta) summed over the workgroups BY the workgroups of the launch (the last
+ * finisher of every 32 consecutive workgroups adds their shares up in index order, the last of those the group sums:
+ * deterministic; no ws_reduce_slabs launch behind it).  pslab then needs nwg + ceil(nwg / 32) rows of [2][128];
+ * `counter`: 1 + ceil(nwg / 32) device words that are 0 at launch (the kernel leaves them at 0).
  * ws_gn_bwd_apply_pg: pass 2 of the two-pass form for single-band groups of 128-float rows (the time view of ResRNN.norm)
  * WITH the parameter sums: one partial [2][128] per group to pslab [ngroups][2][128], summed into pout [2][128] by the last
  * workgroup -- replaces ws_gn_bwd_apply + ws_gn_param_grad + ws_reduce_slabs there.                                */
@@ -474,8 +475,8 @@ int ws_affine_fwd(const float* z, const float* a, const float* b, float a0, long
 int ws_affine_bwd(const float* dz, const float* z_in, const float* a, float a0, long long rows,
                   int rows_per_r, int N, int nsplit, float* dz_in, float* da_slab, float* db_slab,
                   float* da, float* db, unsigned* counter, void* stream);
-/* ABI v15: da / db [R][N] (optional) = the slabs summed over the splits by the LAST workgroup of the launch, in split order;
- * `counter`: a device word that is 0 at launch (left at 0).                                                     */
+/* ABI v15: da / db [R][N] (optional) = the slabs summed over the splits, in split order, by the last workgroup of each
+ * row r to finish; `counter`: R device words that are 0 at launch (left at 0).                                    */
 
 /* ---- SI-SDR loss (auraloss.time.SISDRLoss via wesep/utils/losses.py:24-25) ---------------
  * loss = -mean_r 10 log10(|a t|^2 / (|x - a t|^2 + eps) + eps), zero-mean, eps = 1e-8.

@@ -383,7 +383,7 @@ def gn_bwd_fused(x, dxn, stats, geo, gamma, dx, nwg, pslab, res=None, pout=None,
     gn_bwd_apply(x, dxn, stats, ab, geo, dx, gamma=gamma, res=res)
     gn_param_grad(x, dxn, stats, geo, nwg, pslab)
     if pout is not None:                               # the last workgroup's sum over the per-workgroup shares
-        pout.reshape(-1)[: 2 * geo.W] = pslab.reshape(nwg, 2 * geo.W).sum(0)
+        pout.reshape(-1)[: 2 * geo.W] = pslab.reshape(-1, 2 * geo.W)[:nwg].sum(0)      # (the rows behind: the kernel's group sums)
 
 
 def install(monkeypatch):

@@ -101,6 +101,25 @@ __device__ __forceinline__ bool ws_last_block(unsigned* counter, unsigned nblock
   return last;
 }
 
+// Deterministic sum of the launch's per-workgroup partial vectors of 256 floats, pslab[b][256], b < nblocks = gridDim.x,
+// into pout[256], done by the workgroups themselves (blockDim.x = 256) in two levels so that no thread walks more than
+// 32 + nblocks / 32 partials: the last finisher of every group of 32 consecutive workgroups adds its group's partials up in
+// index order into pslab[nblocks + group][256]; the last of those adds the group sums up in group order.  The result does
+// not depend on arrival order.  pslab needs nblocks + ceil(nblocks / 32) rows; counters: 1 + ceil(nblocks / 32) words,
+// zero at launch, left at zero.  Call with all threads of every workgroup after the workgroup's own row is written.
+__device__ __forceinline__ void ws_tree_sum256(float* pslab, unsigned nblocks, float* pout, unsigned* counters) {
+  const unsigned grp = blockIdx.x >> 5, ngrp = (nblocks + 31u) >> 5;
+  const unsigned in_grp = min(32u, nblocks - grp * 32u);
+  if (!ws_last_block(counters + 1 + grp, in_grp)) return;
+  float t = 0.f;
+  for (unsigned k = 0; k < in_grp; ++k) t += pslab[(long long)(grp * 32u + k) * 256 + threadIdx.x];
+  pslab[(long long)(nblocks + grp) * 256 + threadIdx.x] = t;
+  if (!ws_last_block(counters, ngrp)) return;
+  float s = 0.f;
+  for (unsigned g = 0; g < ngrp; ++g) s += pslab[(long long)(nblocks + g) * 256 + threadIdx.x];
+  pout[threadIdx.x] = s;
+}
+
 __device__ __forceinline__ float ws_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 // row index -> element offset under the two-level row addressing used across the C ABI:

@@ -71,17 +71,15 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(
     if (da_slab) da_slab[o] = sa + sh[0][col];
     if (db_slab) db_slab[o] = sb + sh[1][col];
   }
-  // (optional) the last workgroup of the launch adds the splits up, in split order, into da / db [R][N]: no reduction launches
-  if (counter && ws_last_block(counter, gridDim.x * gridDim.y)) {
-    const int total = R * N;
-    for (int o = threadIdx.x; o < total; o += 256) {
-      float ta = 0.f, tb = 0.f;
-      for (int k = 0; k < nsplit; ++k) {
-        if (da) ta += da_slab[(long long)k * total + o];
-        if (db) tb += db_slab[(long long)k * total + o];
-      }
-      if (da) da[o] = ta;
-      if (db) db[o] = tb;
+  // (optional) the last workgroup of every ROW r (counter word r) adds that row's splits up, in split order, into
+  // da[r] / db[r]: threads 0..127 -> da, 128..255 -> db; no reduction launches
+  if (counter && ws_last_block(counter + r, (unsigned)nsplit)) {
+    float* dst = rl == 0 ? da : db;
+    const float* src = rl == 0 ? da_slab : db_slab;
+    if (dst && col < N) {
+      float t = 0.f;
+      for (int k = 0; k < nsplit; ++k) t += src[((long long)k * R + r) * N + col];
+      dst[(long long)r * N + col] = t;
     }
   }
 }

@@ -184,20 +184,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_pg_kernel(
     for (int r = 1; r < 8; ++r) t += sh[rl][r][c4];
     *reinterpret_cast<f32x4*>(pslab + ((long long)g * 2 + rl) * 128 + 4 * c4) = t;
   }
-  if (ws_last_block(counter, gridDim.x)) {
-    // 256 threads = the 256 outputs; partials in group order.  (Plain loads after the acquire fence of ws_last_block.)
-    const int o = threadIdx.x;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    int k = 0;
-    for (; k + 4 <= (int)gridDim.x; k += 4) {
-      t0 += pslab[(long long)k * 256 + o];
-      t1 += pslab[(long long)(k + 1) * 256 + o];
-      t2 += pslab[(long long)(k + 2) * 256 + o];
-      t3 += pslab[(long long)(k + 3) * 256 + o];
-    }
-    for (; k < (int)gridDim.x; ++k) t0 += pslab[(long long)k * 256 + o];
-    pout[o] = (t0 + t1) + (t2 + t3);
-  }
+  ws_tree_sum256(pslab, gridDim.x, pout, counter);  // 256 threads = the 256 outputs (dgamma | dbeta)
 }
 
 extern "C" int ws_gn_bwd_apply_pg(const float* x, const float* dxn, const float* stats, const float* ab,
@@ -420,20 +407,8 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const float* __restri
     for (int r = 1; r < 4; ++r) t += sh[rl][r][c4];
     *reinterpret_cast<f32x4*>(pslab + ((long long)blockIdx.x * 2 + rl) * 128 + 4 * c4) = t;
   }
-  // (optional) the last workgroup of the launch adds the per-workgroup shares up, in workgroup order: no reduction launch
-  if (pout && ws_last_block(counter, gridDim.x)) {
-    const int o = threadIdx.x;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    int k = 0;
-    for (; k + 4 <= (int)gridDim.x; k += 4) {
-      t0 += pslab[(long long)k * 256 + o];
-      t1 += pslab[(long long)(k + 1) * 256 + o];
-      t2 += pslab[(long long)(k + 2) * 256 + o];
-      t3 += pslab[(long long)(k + 3) * 256 + o];
-    }
-    for (; k < (int)gridDim.x; ++k) t0 += pslab[(long long)k * 256 + o];
-    pout[o] = (t0 + t1) + (t2 + t3);
-  }
+  // (optional) the workgroups of the launch add their shares up themselves, two levels, fixed order: no reduction launch
+  if (pout) ws_tree_sum256(pslab, gridDim.x, pout, counter);   // (uniform: every workgroup takes the same branch)
 }
 
 extern "C" int ws_gn_bwd_fused(const float* x, const float* dxn, const float* stats, const float* gamma,

@@ -270,6 +270,11 @@ def gn_bwd_fused(x, dxn, stats, geo: Geom, gamma, dx, nwg: int, pslab, res=None,
                                     _p(pout), _word(counter), L.stream_ptr()), "ws_gn_bwd_fused")
 
 
+def tree_groups(nblocks: int) -> int:
+    """Extra partial rows / counter words of the two-level in-kernel sum (common.h ws_tree_sum256): one per 32 workgroups."""
+    return -(-nblocks // 32)
+
+
 def gn_bwd_apply_pg_ok(geo: Geom) -> bool:
     """Single-band groups of 128-float rows (the time view of ResRNN.norm): apply + parameter sums in one pass."""
     return (os.environ.get("WESEP_GN_FUSED", "1") != "0" and geo.nbands == 1 and geo.W == 128 and geo.band_w is None

@@ -217,21 +217,24 @@ def reset_deferred_wgrads(device):
 _AMAX = {}   # (device, stream) -> [int32 words, cursor]: scale words of WS_GATES_H2F, handed out one per BPTT launch
 
 
-def amax_word(device):
-    """A zeroed device word for ws_gemm_p2b's running max |d(hcat)| (the scale source of WS_GATES_H2F, wesep_hip.h).  Words
-    come from a block that is zero-filled ONCE per 256 launches instead of once per launch: a 4-byte fill is a launch of its
-    own, and every tiny main-stream launch can sit out a whole weight-gradient GEMM of the side stream before it gets a
-    CU (profiles/r04_summary.md).  A block is never re-zeroed while words of it may still be read (the side stream's
-    deferred jobs): a fresh block is allocated instead and the old one dies with its last reference."""
+def zero_words(device, n=1):
+    """`n` consecutive zeroed int32 device words: ws_gemm_p2b's running max |d(hcat)| (the scale source of WS_GATES_H2F,
+    wesep_hip.h) and the counters of the "the workgroups add their partials up themselves" epilogues (ws_last_block /
+    ws_tree_sum256, which leave them at zero).  Words come from a block that is zero-filled ONCE per 8192 words instead of
+    once per use: a small fill is a launch of its own, and every tiny main-stream launch can sit out a whole
+    weight-gradient GEMM of the side stream before it gets a CU (profiles/r04_summary.md).  A block is never re-zeroed
+    while words of it may still be read (the side stream's deferred jobs): a fresh block is allocated instead and the old
+    one dies with its last reference."""
     key = (device.type, device.index, L.stream_ptr().value if device.type == "cuda" and torch.cuda.is_available() else 0)
     ent = _AMAX.get(key)
-    if ent is None or ent[1] >= ent[0].numel():
-        ent = _AMAX[key] = [torch.zeros(256, device=device, dtype=torch.int32), 0]
-    ent[1] += 1
-    return ent[0][ent[1] - 1:ent[1]]
+    if ent is None or ent[1] + n > ent[0].numel():
+        ent = _AMAX[key] = [torch.zeros(max(8192, n), device=device, dtype=torch.int32), 0]
+    ent[1] += n
+    return ent[0][ent[1] - n:ent[1]]
 
 
-zero_word = amax_word    # the same zeroed words serve as the counters of the "last workgroup sums up" epilogues (ws_last_block)
+def amax_word(device):
+    return zero_words(device, 1)
 
 
 def mark_wgrads_ready(device):
@@ -565,14 +568,16 @@ class ResRNNBlkFn(torch.autograd.Function):
         if dev.gn_bwd_fused_ok(geo):
             # band view: 16 032 groups of 16 KB -- one wave per group, x / dxn / dout cross HBM once (norm.hip)
             ns2 = min(1024, -(-geo.ngroups // 4))
-            pslab = _empty(d, ns2, 2, N)
-            dev.gn_bwd_fused(z, dxn, stats, geo, norm_w, dz, ns2, pslab, res=dout, pout=dgb, counter=zero_word(d))
+            pslab = _empty(d, ns2 + dev.tree_groups(ns2), 2, N)
+            dev.gn_bwd_fused(z, dxn, stats, geo, norm_w, dz, ns2, pslab, res=dout, pout=dgb,
+                             counter=zero_words(d, 1 + dev.tree_groups(ns2)))
         elif dev.gn_bwd_apply_pg_ok(geo):
             # time view: 1 024 groups of 256 KB: the group means first, then apply + parameter sums in ONE pass over x / dxn
             ab = _empty(d, geo.ngroups, 2)
             dev.gn_bwd_reduce(z, dxn, stats, geo, ab, gamma=norm_w)
-            pslab = _empty(d, geo.ngroups, 2, N)
-            dev.gn_bwd_apply_pg(z, dxn, stats, ab, geo, dz, norm_w, pslab, dgb, zero_word(d), res=dout)
+            pslab = _empty(d, geo.ngroups + dev.tree_groups(geo.ngroups), 2, N)
+            dev.gn_bwd_apply_pg(z, dxn, stats, ab, geo, dz, norm_w, pslab, dgb, zero_words(d, 1 + dev.tree_groups(geo.ngroups)),
+                                res=dout)
         else:
             ab = _empty(d, geo.ngroups, 2)
             dev.gn_bwd_reduce(z, dxn, stats, geo, ab, gamma=norm_w)
@@ -816,7 +821,7 @@ class AffineFn(torch.autograd.Function):
         da = _empty(z.device, R, N) if a is not None else None
         db = _empty(z.device, R, N) if ctx.has_b else None
         dev.affine_bwd(dout, z, a, ctx.a0, R * K * Tf, K * Tf, N, ns, dz, da_slab, db_slab, da=da, db=db,
-                       counter=zero_word(z.device) if (da is not None or db is not None) else None)
+                       counter=zero_words(z.device, R) if (da is not None or db is not None) else None)
         return dz, da, db, None
 
 
