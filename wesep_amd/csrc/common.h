@@ -80,25 +80,36 @@ __device__ __forceinline__ float ws_dgates_scale_inv(unsigned amax_bits) {
   return __uint_as_float((unsigned)(254 - (int)(__float_as_uint(s) >> 23)) << 23);  // 2^-k, exact
 }
 
-// True in exactly one workgroup of the launch -- the last one to get here -- for all of its threads; the others' global
-// stores issued before the call are visible to it (agent-scope release / acquire around one relaxed atomic).  `counter`:
-// a device word that is 0 at launch; the last workgroup leaves it at 0 again.  For "the last workgroup adds up the
-// partials" epilogues: the sum runs over the partials in index order, so the result does not depend on WHICH workgroup
-// came last (deterministic), and the separate reduction launch -- which on a busy GPU can sit out a whole weight-gradient
-// GEMM of another stream before it gets a CU -- disappears.  Contains two barriers.
+// Agent-scope (sc1) single-word accesses: a store that is written through to memory and a load that does not trust this
+// XCD's L2 -- coherent across the eight XCDs access by access, WITHOUT a cache-wide fence.  (An agent-scope release
+// fence -- __threadfence() -- writes back the whole L2 of the XCD; inside kernels that stream hundreds of MB through that
+// L2 it cost 0.3-0.4 ms per launch: measured in round 4, the first version of the epilogues below.)
+__device__ __forceinline__ void ws_st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ws_ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// True in exactly one workgroup of the launch -- the last one to get here -- for all of its threads.  Protocol (recipe R1
+// of cdna_hip_programming.md Guideline 16, as in the cluster recurrences): the partials a workgroup leaves for the last one
+// are stored with ws_st_agent, every thread drains its stores (vmcnt(0)), barrier, ONE relaxed agent-scope atomic; the
+// last workgroup reads the others' partials with ws_ld_agent.  `counter`: a device word that is 0 at launch; the last
+// workgroup leaves it at 0 again.  For "the workgroups add their partials up themselves" epilogues: sums run over the
+// partials in index order, so the result does not depend on WHICH workgroup came last (deterministic), and the separate
+// reduction launch -- which on a busy GPU can sit out a whole weight-gradient GEMM of another stream before it gets a CU --
+// disappears.  Contains two barriers.
 __device__ __forceinline__ bool ws_last_block(unsigned* counter, unsigned nblocks) {
   __shared__ unsigned last_s;
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(counter, 1u);
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_s = t == nblocks - 1u;
-    if (last_s) *counter = 0u;
+    if (last_s) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  const bool last = last_s != 0u;
-  if (last) __threadfence();
-  return last;
+  return last_s != 0u;
 }
 
 // Deterministic sum of the launch's per-workgroup partial vectors of 256 floats, pslab[b][256], b < nblocks = gridDim.x,
@@ -106,17 +117,18 @@ __device__ __forceinline__ bool ws_last_block(unsigned* counter, unsigned nblock
 // 32 + nblocks / 32 partials: the last finisher of every group of 32 consecutive workgroups adds its group's partials up in
 // index order into pslab[nblocks + group][256]; the last of those adds the group sums up in group order.  The result does
 // not depend on arrival order.  pslab needs nblocks + ceil(nblocks / 32) rows; counters: 1 + ceil(nblocks / 32) words,
-// zero at launch, left at zero.  Call with all threads of every workgroup after the workgroup's own row is written.
+// zero at launch, left at zero.  Call with all threads of every workgroup after the workgroup's own row is written WITH
+// ws_st_agent (see ws_last_block).
 __device__ __forceinline__ void ws_tree_sum256(float* pslab, unsigned nblocks, float* pout, unsigned* counters) {
   const unsigned grp = blockIdx.x >> 5, ngrp = (nblocks + 31u) >> 5;
   const unsigned in_grp = min(32u, nblocks - grp * 32u);
   if (!ws_last_block(counters + 1 + grp, in_grp)) return;
   float t = 0.f;
-  for (unsigned k = 0; k < in_grp; ++k) t += pslab[(long long)(grp * 32u + k) * 256 + threadIdx.x];
-  pslab[(long long)(nblocks + grp) * 256 + threadIdx.x] = t;
+  for (unsigned k = 0; k < in_grp; ++k) t += ws_ld_agent(pslab + (long long)(grp * 32u + k) * 256 + threadIdx.x);
+  ws_st_agent(pslab + (long long)(nblocks + grp) * 256 + threadIdx.x, t);
   if (!ws_last_block(counters, ngrp)) return;
   float s = 0.f;
-  for (unsigned g = 0; g < ngrp; ++g) s += pslab[(long long)(nblocks + g) * 256 + threadIdx.x];
+  for (unsigned g = 0; g < ngrp; ++g) s += ws_ld_agent(pslab + (long long)(nblocks + g) * 256 + threadIdx.x);
   pout[threadIdx.x] = s;
 }
 

@@ -68,8 +68,13 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(
   __syncthreads();
   if (rl == 0 && col < N) {
     const long long o = ((long long)split * R + r) * N + col;
-    if (da_slab) da_slab[o] = sa + sh[0][col];
-    if (db_slab) db_slab[o] = sb + sh[1][col];
+    if (counter) {  // read by the row's last workgroup below: agent-scope stores (common.h ws_last_block)
+      if (da_slab) ws_st_agent(da_slab + o, sa + sh[0][col]);
+      if (db_slab) ws_st_agent(db_slab + o, sb + sh[1][col]);
+    } else {
+      if (da_slab) da_slab[o] = sa + sh[0][col];
+      if (db_slab) db_slab[o] = sb + sh[1][col];
+    }
   }
   // (optional) the last workgroup of every ROW r (counter word r) adds that row's splits up, in split order, into
   // da[r] / db[r]: threads 0..127 -> da, 128..255 -> db; no reduction launches
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(
     const float* src = rl == 0 ? da_slab : db_slab;
     if (dst && col < N) {
       float t = 0.f;
-      for (int k = 0; k < nsplit; ++k) t += src[((long long)k * R + r) * N + col];
+      for (int k = 0; k < nsplit; ++k) t += ws_ld_agent(src + ((long long)k * R + r) * N + col);
       dst[(long long)r * N + col] = t;
     }
   }

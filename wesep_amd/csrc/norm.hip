@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_pg_kernel(
     f32x4 t = sh[rl][0][c4];
 #pragma unroll
     for (int r = 1; r < 8; ++r) t += sh[rl][r][c4];
-    *reinterpret_cast<f32x4*>(pslab + ((long long)g * 2 + rl) * 128 + 4 * c4) = t;
+    float* o = pslab + ((long long)g * 2 + rl) * 128 + 4 * c4;  // agent-scope stores: read by another workgroup (common.h)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ws_st_agent(o + q, t[q]);
   }
   ws_tree_sum256(pslab, gridDim.x, pout, counter);  // 256 threads = the 256 outputs (dgamma | dbeta)
 }
@@ -405,7 +407,13 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const float* __restri
     f32x4 t = sh[rl][0][c4];
 #pragma unroll
     for (int r = 1; r < 4; ++r) t += sh[rl][r][c4];
-    *reinterpret_cast<f32x4*>(pslab + ((long long)blockIdx.x * 2 + rl) * 128 + 4 * c4) = t;
+    float* o = pslab + ((long long)blockIdx.x * 2 + rl) * 128 + 4 * c4;
+    if (pout) {  // agent-scope stores: read by another workgroup (common.h ws_last_block)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ws_st_agent(o + q, t[q]);
+    } else {
+      *reinterpret_cast<f32x4*>(o) = t;
+    }
   }
   // (optional) the workgroups of the launch add their shares up themselves, two levels, fixed order: no reduction launch
   if (pout) ws_tree_sum256(pslab, gridDim.x, pout, counter);   // (uniform: every workgroup takes the same branch)
