@@ -366,7 +366,11 @@ int ws_lstm_cat_ih(const float* wih_f, const float* wih_r, const float* bih_f, c
  *   pos = (seq / sq_div) * sq_s1 + (seq % sq_div) * sq_s2 + step * step_rows.              */
 typedef struct ws_seqmap {
   long long sq_s1, sq_s2, step_rows;
-  int nseq, sq_div, L, pad_;
+  int nseq, sq_div, L;
+  int nvalid;   /* ABI v15: 0 = every sequence < nseq maps to rows; else sequences >= nvalid are PADDING (zeros on the way
+                   into BL, dropped on the way out): nseq then only fixes the number of 32-sequence tiles -- strided maps
+                   (TF-GridNet's inter-frame path in place, no transposed copy) whose sequence count the cluster
+                   recurrence wants rounded up to a multiple of 64                                                  */
 } ws_seqmap;
 
 /* out (bf16 pairs, N*K*4 bytes) <- W'[n][k] = trans ? W[k*ldw + n] : W[n*ldw + k], split into

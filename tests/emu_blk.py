@@ -65,13 +65,17 @@ def gates_get_u16(buf, ntile, L):
     return torch.where(t, x * (1.0 / 32767.5) - 1.0, x * (1.0 / 65535.0))
 
 
+def _nv(sm):
+    return getattr(sm, "nvalid", 0) or sm.nseq
+
+
 def _valid(sm):
-    return (torch.arange(_ntile(sm) * 32) < sm.nseq).float().view(-1, 1, 1)
+    return (torch.arange(_ntile(sm) * 32) < _nv(sm)).float().view(-1, 1, 1)
 
 
 def _positions(sm):
     """row of the plain tensor for (sequence, step): [ntile*32, L] (padded sequences clamp to sequence nseq-1)."""
-    s = torch.arange(_ntile(sm) * 32).clamp(max=sm.nseq - 1).view(-1, 1)
+    s = torch.arange(_ntile(sm) * 32).clamp(max=_nv(sm) - 1).view(-1, 1)
     t = torch.arange(sm.L).view(1, -1)
     return (s // sm.div) * sm.s1 + (s % sm.div) * sm.s2 + t * sm.step_rows
 
@@ -137,13 +141,13 @@ def _g16(buf, nt, L, C, fmt, amax):
 
 def gemm_b2p(*, A, K, sm, Wpack, C_out, ldc, N=128, bias=None, R=None, a_fmt=0, amax=None):
     nt, L = _ntile(sm), sm.L
-    x = (_g16(A, nt, L, K, a_fmt, amax) if a_fmt else bl_get(A, nt, L, K))[: sm.nseq]
+    x = (_g16(A, nt, L, K, a_fmt, amax) if a_fmt else bl_get(A, nt, L, K))[: _nv(sm)]
     out = x @ _PACKS[Wpack.data_ptr()].t()
     if bias is not None:
         out = out + bias.reshape(-1)[:N]
-    pos = _positions(sm)[: sm.nseq].reshape(-1)
+    pos = _positions(sm)[: _nv(sm)].reshape(-1)
     if R is not None:
-        out = out + R.reshape(-1, ldc)[pos, :N].reshape(sm.nseq, L, N)
+        out = out + R.reshape(-1, ldc)[pos, :N].reshape(_nv(sm), L, N)
     C_out.reshape(-1, ldc)[pos, :N] = out.reshape(-1, N)
 
 

@@ -61,6 +61,46 @@ def test_blstm_linear_blocked_matches_torch(emu, monkeypatch, nseq, Lr, branch, 
         assert float((got[k] - want[k]).norm()) <= gtol * float(want[k].norm()) + 1e-6, k
 
 
+@pytest.mark.parametrize("B,T,Q", [(2, 70, 5), (1, 9, 3)])     # 10 sequences of 70 steps (cluster, padded to 64 via nvalid) / streaming
+def test_blstm_linear_strided_map_equals_transposed_copy(emu, monkeypatch, B, T, Q):
+    """The inter-frame path in place: sequences (b, q) over t as a strided row set of the [B, T, Q, C] map (wesep_hip.h
+    ws_seqmap with `nvalid`) against the same BLSTM on the transposed, contiguous copy -- output and every gradient."""
+    from wesep_amd import functional_tfgridnet as FG
+    monkeypatch.setenv("WESEP_GATES", "f32")
+    torch.manual_seed(B * 10 + Q)
+    h = 192
+    lstm = torch.nn.LSTM(128, h, 1, batch_first=True, bidirectional=True)
+    lin = torch.nn.Linear(2 * h, 128)
+    y = torch.randn(B * T * Q, 128, requires_grad=True)          # rows (b, t, q)
+    res = torch.randn(B * T * Q, 128, requires_grad=True)
+    probe = torch.randn(B * T * Q, 128)
+    def params():       # (the padded forms are part of the autograd graph: once per backward)
+        wf, hf, bf = FG.pad_lstm(lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
+        wr, hr, br = FG.pad_lstm(lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse,
+                                 lstm.bias_hh_l0_reverse)
+        return (wf, wr, bf, br, hf, hr, FG.pad_hidden_cols(lin.weight, h), lin.bias)
+
+    leaves = [y, res] + list(lstm.parameters()) + list(lin.parameters())
+
+    def grads():
+        g = [t.grad.clone() for t in leaves]
+        for t in leaves:
+            t.grad = None
+        return g
+
+    out = FG.BlstmLinearBlkFn.apply(y, res, (B * Q, T, Q, T * Q, 1, Q), *params())
+    (out * probe).sum().backward()
+    got = grads()
+    tr = lambda t: t.view(B, T, Q, 128).transpose(1, 2).reshape(B * Q * T, 128)           # rows (b, q, t)
+    ref = FG.BlstmLinearBlkFn.apply(tr(y).contiguous(), tr(res).contiguous(), (B * Q, T), *params())
+    ref = ref.view(B, Q, T, 128).transpose(1, 2).reshape(B * T * Q, 128)
+    (ref * probe).sum().backward()
+    want = grads()
+    assert float((out - ref).norm() / ref.norm()) < 1e-6
+    for a, b in zip(got, want):
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-7
+
+
 def test_recipe_geometry_model_blocked_equals_default(emu, monkeypatch):
     from wesep_amd.models import get_model
     monkeypatch.setenv("WESEP_GATES", "f32")     # the host composition, exactly (the 2-byte formats' numerics: the test above)

@@ -83,7 +83,7 @@ class LstmArgs(C.Structure):
 
 
 class SeqMapC(C.Structure):
-    _fields_ = [("sq_s1", _ll), ("sq_s2", _ll), ("step_rows", _ll), ("nseq", _i), ("sq_div", _i), ("L", _i), ("pad_", _i)]
+    _fields_ = [("sq_s1", _ll), ("sq_s2", _ll), ("step_rows", _ll), ("nseq", _i), ("sq_div", _i), ("L", _i), ("nvalid", _i)]
 
 
 class GemmP2BArgs(C.Structure):

@@ -72,8 +72,9 @@ __device__ __forceinline__ void pack8(const bf16x8& hi, const bf16x8& lo, u32x4&
 __device__ __forceinline__ long long seq_pos(const ws_seqmap& sm, int b, int i, bool& valid) {
   const int tile = b / sm.L, step = b - tile * sm.L;
   const int seq = tile * 32 + i;
-  valid = seq < sm.nseq;
-  const int s = valid ? seq : sm.nseq - 1;
+  const int nv = sm.nvalid > 0 ? sm.nvalid : sm.nseq;  // (ABI v15: sequences >= nvalid are padding)
+  valid = seq < nv;
+  const int s = valid ? seq : nv - 1;
   return (long long)(s / sm.sq_div) * sm.sq_s1 + (long long)(s % sm.sq_div) * sm.sq_s2 +
          (long long)step * sm.step_rows;
 }

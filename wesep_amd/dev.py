@@ -301,13 +301,15 @@ def gn_param_grad(x, dxn, stats, geo: Geom, nsplit: int, slab):
 
 
 class SeqMap(NamedTuple):
-    """sequence s, step t -> row (s // div) * s1 + (s % div) * s2 + t * step_rows."""
+    """sequence s, step t -> row (s // div) * s1 + (s % div) * s2 + t * step_rows.  nvalid (0 = nseq): sequences >= nvalid
+    are padding -- zeros on the way into the blocked layout, dropped on the way out (wesep_hip.h ws_seqmap)."""
     nseq: int
     div: int
     s1: int
     s2: int
     step_rows: int
     L: int
+    nvalid: int = 0
 
 
 def lstm_mode(nseq: int) -> int:
@@ -729,8 +731,9 @@ def bl_positions(sm: SeqMap, device):
     ntile = -(-sm.nseq // 32)
     seq = torch.arange(ntile * 32, device=device).view(ntile, 1, 32)
     step = torch.arange(sm.L, device=device).view(1, sm.L, 1)
-    valid = (seq < sm.nseq).expand(ntile, sm.L, 32)
-    sq = seq.clamp(max=sm.nseq - 1)
+    nv = sm.nvalid or sm.nseq
+    valid = (seq < nv).expand(ntile, sm.L, 32)
+    sq = seq.clamp(max=nv - 1)
     pos = torch.div(sq, sm.div, rounding_mode="floor") * sm.s1 + (sq % sm.div) * sm.s2 + step * sm.step_rows
     return (pos * valid).reshape(-1), valid.reshape(-1)
 
@@ -802,6 +805,7 @@ def blh_gates_unpack(buf: torch.Tensor, nblk: int) -> torch.Tensor:
 def _smc(sm: SeqMap):
     c = L.SeqMapC()
     c.sq_s1, c.sq_s2, c.step_rows, c.nseq, c.sq_div, c.L = sm.s1, sm.s2, sm.step_rows, sm.nseq, sm.div, sm.L
+    c.nvalid = sm.nvalid
     return c
 
 

@@ -389,24 +389,31 @@ class BlstmLinearBlkFn(torch.autograd.Function):
     without its GroupNorm (the LayerNorm over C happens before, per row).  Sequences are the contiguous runs of Lr
     rows; when the cluster recurrence applies apart from the sequence count (long sequences, few of them: the
     inter-frame path), the sequences are zero-padded to a multiple of 64 -- padded sequences cost no latency and their
-    rows are dropped.  Weights: pad_lstm / pad_hidden_cols outputs (hidden zero-padded to 256)."""
+    rows are dropped.  Weights: pad_lstm / pad_hidden_cols outputs (hidden zero-padded to 256).
+
+    geo = (nseq, Lr): sequences are contiguous runs of Lr rows; geo = (nseq, Lr, div, s1, s2, step_rows): a STRIDED
+    sequence map over the rows of y / res (sequence s, step t -> row (s // div) * s1 + (s % div) * s2 + t * step_rows) --
+    the inter-frame path run in place on the [B, T, Q, C] map (round 4; the runtime's plan has done so since round 3): no
+    transposed copy of the map before and after the BLSTM, forward or backward; the padding to a multiple of 64 is then
+    the map's `nvalid` (wesep_hip.h ws_seqmap), not appended rows."""
 
     @staticmethod
     def forward(ctx, y, res, geo, wih_f, wih_r, b_f, b_r, whf, whr, lin_w, lin_b):
         from . import functional as F0
         _need_cuda(y, "TF-GridNet")
-        nseq, Lr = geo
+        nseq, Lr = geo[:2]
+        strided = geo[2:] if len(geo) > 2 else None
         N, H, G4 = 128, HP, G4P
         d = y.device
         pad = 0
         if Lr >= 64 and nseq % 64 and (-(-nseq // 64) * 64 // 32) * 8 <= dev.cu_count(d):
             pad = -(-nseq // 64) * 64 - nseq
         ns = nseq + pad
-        if pad:
+        if pad and strided is None:
             z = torch.zeros(pad * Lr, N, device=d, dtype=torch.float32)
             y, res = torch.cat([y, z], 0), torch.cat([res, z], 0)
         y, res = y.contiguous(), res.contiguous()
-        seq = SeqMap(ns, BIG, 0, Lr, 1, Lr)
+        seq = SeqMap(ns, BIG, 0, Lr, 1, Lr) if strided is None else SeqMap(ns, *strided, Lr, nvalid=nseq)
         nb = dev.bl_num_blocks(seq)
         zero = torch.zeros(G4, device=d, dtype=torch.float32)
         wcat, bcat = _empty(d, 2 * G4, N), _empty(d, 2 * G4)
@@ -453,12 +460,29 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         dev.pack_w(lw, N, 2 * H, 2 * H, lin_pack, order=1)
         out = torch.empty_like(res)
         dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=lin_pack, C_out=out, ldc=N, bias=lin_b.contiguous(), R=res)
+        # the backward's weight packs are built HERE, where the GPU serves one stream: built lazily in the backward, these
+        # 5 us launches queue behind the side stream's chip-filling weight-gradient GEMMs for up to a millisecond each
+        # (functional.ResRNNBlkFn does the same)
+        bw_packs = None
+        if any(ctx.needs_input_grad):
+            g2 = gfmt == L.GATES_H2F
+            wlt_pack = _empty(d, 2 * H * N)
+            dev.pack_w(lw, 2 * H, N, 2 * H, wlt_pack, trans=True, order=0)
+            wct_pack = _empty(d, N * 2 * G4)
+            dev.pack_w(wcat, N, 2 * G4, N, wct_pack, trans=True, order=1, f16=g2)
+            ppack = None
+            if kind == "pair":
+                ppack = _empty(d, L.LSTM_PACK_FLOATS)
+                dev.lstm_pack_pair(whf, whr, ppack)
+            bw_packs = (wlt_pack, wct_pack, ppack)
+        ctx.bw_packs = bw_packs
         ctx.save_for_backward(gates, cbuf, hcat, xn, wcat, pack_b, lw, whf, whr)
         ctx.geo = (nseq, Lr, ns, lmode, cluster)
+        ctx.seq = seq
         ctx.gfmt, ctx.kind = gfmt, kind
         ctx.F0 = F0
         ctx.consumed = False
-        return out[:nseq * Lr] if pad else out
+        return out[:nseq * Lr] if (pad and strided is None) else out
 
     @staticmethod
     def backward(ctx, dout):
@@ -473,12 +497,12 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         d = dout.device
         dout = dout.contiguous()
         dres = dout
-        if ns != nseq:
+        seq = ctx.seq
+        appended = ns != nseq and not seq.nvalid      # contiguous runs: the padding sequences are rows behind the data
+        if appended:
             dout = torch.cat([dout, torch.zeros((ns - nseq) * Lr, N, device=d, dtype=torch.float32)], 0)
-        seq = SeqMap(ns, BIG, 0, Lr, 1, Lr)
         nb = dev.bl_num_blocks(seq)
-        wlt_pack = _empty(d, 2 * H * N)
-        dev.pack_w(lw, 2 * H, N, 2 * H, wlt_pack, trans=True, order=0)
+        wlt_pack, wct_pack, ppack = ctx.bw_packs
         dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
         amax = ctx.F0.amax_word(d) if ctx.gfmt == L.GATES_H2F else None   # (functional.py)
         dev.gemm_p2b(A=dout, lda=N, sm=seq, Wpack=wlt_pack, N=2 * H, C_out=dh, A_bl=dout_bl, amax=amax)
@@ -490,8 +514,6 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             dg = gates
             dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
         elif kind == "pair":                                    # few long sequences (the inter-frame path): lstm_pair.hip
-            ppack = _empty(d, L.LSTM_PACK_FLOATS)
-            dev.lstm_pack_pair(whf, whr, ppack)
             if gfmt == L.GATES_F32:
                 dg = gates
                 dev.lstm_bwd_pair(gates, cbuf, dh, ppack, seq, dbg=ctx.F0._pair_dbg())
@@ -509,11 +531,9 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, lmode, gfmt=gfmt, dgates=dg if gfmt == L.GATES_H2S else None,
                          amax=amax)
         wg = ctx.F0.ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)
-        wct_pack = _empty(d, N * 2 * G4)
-        dev.pack_w(wcat, N, 2 * G4, N, wct_pack, trans=True, order=1, f16=g_fmt == 2)
-        dy = _empty(d, ns * Lr, N)
+        dy = _empty(d, (ns if appended else nseq) * Lr, N)
         dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dy, ldc=N, a_fmt=g_fmt, amax=amax)
-        if ns != nseq:
+        if appended:
             dy = dy[:nseq * Lr]
         # wg: [dW_ih_f, dW_hh_f, db_f, db_f (clone), dW_ih_r, dW_hh_r, db_r, db_r (clone), dW_lin, db_lin]
         return dy, dres, None, wg[0], wg[4], wg[2], wg[6], wg[1], wg[5], wg[8], wg[9]

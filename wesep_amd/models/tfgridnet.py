@@ -99,8 +99,10 @@ class GridNetBlock(nn.Module):
         self.emb_dim, self.emb_ks, self.emb_hs, self.n_head, self.E = emb_dim, emb_ks, emb_hs, n_head, E
         self.hidden = hidden_channels
 
-    def _rnn_path(self, path, x, nseq, Lr):
-        """x [nseq*Lr, C]: LayerNorm -> windows -> BLSTM -> ConvTranspose1d / Linear -> + x  (gridnet_block.py:139-160)."""
+    def _rnn_path(self, path, x, nseq, Lr, strided=None):
+        """x [nseq*Lr, C]: LayerNorm -> windows -> BLSTM -> ConvTranspose1d / Linear -> + x  (gridnet_block.py:139-160).
+        strided = (div, s1, s2, step_rows): the sequences are a strided row set of x instead of contiguous runs (blocked
+        path only: functional_tfgridnet.BlstmLinearBlkFn)."""
         C, ks, hs, h = self.emb_dim, self.emb_ks, self.emb_hs, self.hidden
         norm, rnn, lin = self[f"{path}_norm"], self[f"{path}_rnn"], self[f"{path}_linear"]
         y = FG.RowLNFn.apply(x, norm.weight, norm.bias)
@@ -111,8 +113,10 @@ class GridNetBlock(nn.Module):
         wr, hr, br = FG.pad_lstm(rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse, rnn.bias_ih_l0_reverse,
                                  rnn.bias_hh_l0_reverse, perm)
         if FG.blocked_path_ok(C, ks, hs):     # the recipe's geometry: the pBSRNN blocked-layout recurrences (opt-in)
-            return FG.BlstmLinearBlkFn.apply(y, x, (nseq, Lr), wf, wr, bf, br, hf, hr,
+            return FG.BlstmLinearBlkFn.apply(y, x, (nseq, Lr) + tuple(strided or ()), wf, wr, bf, br, hf, hr,
                                              FG.pad_hidden_cols(lin.weight, h), lin.bias)
+        if strided is not None:
+            raise dev.L.WesepHipError("TF-GridNet: strided sequence maps are a feature of the blocked-layout path")
         hcat = FG.BlstmFn.apply(y, (nseq, Lr, C, ks, hs), torch.cat([wf, wr], 0), torch.cat([bf, br], 0), hf, hr)
         n = (Lr - ks) // hs + 1
         if ks == hs:      # Linear(2h -> ks*C): frames tile the sequence without overlap
@@ -136,9 +140,15 @@ class GridNetBlock(nn.Module):
         else:
             h = torch.nn.functional.pad(x.view(B, oT, oQ, C), (0, 0, olp, Q - oQ - olp, olp, T - oT - olp))
         h = self._rnn_path("intra", h.reshape(B * T * Q, C), B * T, Q).view(B, T, Q, C)
-        h = h.transpose(1, 2).contiguous()                                      # [B, Q, T, C]
-        h = self._rnn_path("inter", h.view(B * Q * T, C), B * Q, T).view(B, Q, T, C)
-        inter = h.transpose(1, 2)[:, olp:olp + oT, olp:olp + oQ, :].contiguous().view(B * oT * oQ, C)
+        if FG.blocked_path_ok(C, ks, hs) and os.environ.get("WESEP_TFG_STRIDED", "1") != "0":
+            # inter-frame path IN PLACE on the [B, T, Q, C] map: sequence (b, q), step t -> row (b * T + t) * Q + q (round 4;
+            # the reference permutes to [B, Q, T, C] and back, gridnet_block.py:163-180: two copies of the map forward, two backward)
+            h = self._rnn_path("inter", h.view(B * T * Q, C), B * Q, T, strided=(Q, T * Q, 1, Q)).view(B, T, Q, C)
+            inter = h[:, olp:olp + oT, olp:olp + oQ, :].contiguous().view(B * oT * oQ, C)
+        else:
+            h = h.transpose(1, 2).contiguous()                                      # [B, Q, T, C]
+            h = self._rnn_path("inter", h.view(B * Q * T, C), B * Q, T).view(B, Q, T, C)
+            inter = h.transpose(1, 2)[:, olp:olp + oT, olp:olp + oQ, :].contiguous().view(B * oT * oQ, C)
         M = B * oT * oQ
         cq, ck, cv = self["attn_conv_Q"], self["attn_conv_K"], self["attn_conv_V"]
         cp = C // nh
