@@ -278,13 +278,16 @@ def main():
     tfl = flops_per_launch / sec / 1e12
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/pmc_summary.py);
     # bench.py cannot collect counters itself, so this is the profile of the same command, or null
-    traffic, pmc_src = None, {}
+    traffic, pmc_src, noop = None, {}, set()
     try:
         pmc_file = _latest_profile("pmc_traffic")
         doc = json.load(open(pmc_file))
         pmc = doc["kernels"]
         pmc_src["traffic"] = {"file": os.path.relpath(pmc_file, ROOT), **doc.get("collected", {})}
-        hit = [v for k, v in pmc.items() if dom in k]      # streaming (32/16-sequence) and cluster variants
+        # streaming (32/16-sequence), pair and cluster variants; NOT the predicated fall-back launches of the pair BPTT
+        # (lstm_bwd_s16 with run_if = 0 returns at once: kilobytes per launch, no HIP-event interval either)
+        noop = {k for k, v in pmc.items() if dom in k and v["hbm_bytes_per_launch_corrected"] < 1e6}
+        hit = [v for k, v in pmc.items() if dom in k and k not in noop]
         n = sum(v["launches"] for v in hit)
         traffic = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in hit) / n if n else None
     except (OSError, KeyError, ValueError):
@@ -297,7 +300,7 @@ def main():
         doc = json.load(open(pm_file))
         pm = doc["kernels"]
         pmc_src["mfma"] = {"file": os.path.relpath(pm_file, ROOT), **doc.get("collected", {})}
-        hit = [v for k, v in pm.items() if dom in k]
+        hit = [v for k, v in pm.items() if dom in k and k not in noop]
         n = sum(v["launches"] for v in hit)
         mfma_busy = sum(v["mfma_busy_frac"] * v["launches"] for v in hit) / n if n else None
     except (OSError, KeyError, ValueError):

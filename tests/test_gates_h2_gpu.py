@@ -245,7 +245,7 @@ def test_gemm_b2p_bf16_operand(view, dims):
 
 
 @pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37)), ("time", (2, 32, 70))])
-def test_gemm_tnb_bf16_g_operand(view, dims):
+def test_gemm_tnb_bf16_g_operand(view, dims, monkeypatch):
     """[dW_ih | dW_hh | db] form with G = d(gates) as bf16 (BLH): both directions' column ranges, A1 shifted by one step."""
     from wesep_amd import dev
     from wesep_amd.functional import _view_maps
@@ -269,7 +269,9 @@ def test_gemm_tnb_bf16_g_operand(view, dims):
     for di, shift in ((0, -1), (1, 1)):
         ns, bps = dev.tnb_splits(nb, 8)
         outs = []
-        for Gbuf, fmt in ((G_pairs, 0), (G_bf16, 1), (G_bf16, 1), (G_f16, 2)):
+        for Gbuf, fmt, f16mm in ((G_pairs, 0, None), (G_bf16, 1, None), (G_bf16, 1, None), (G_f16, 2, "0"), (G_f16, 2, "1")):
+            if f16mm is not None:
+                monkeypatch.setenv("WS_TNB_F16", f16mm)   # 0: scaled fp16 on the bf16 instruction (3 terms); 1: on the fp16 one (2)
             slab, bslab = torch.full((ns, 1024 * 384), float("nan"), device=d), torch.full((ns, 1024), float("nan"), device=d)
             dev.gemm_tnb(G=Gbuf, g_width=GW, g_off=di * 1024, g_cols=1024, A0=A0b, a0_width=N, a0_off=0, a0_cols=N,
                          A1=A1b, a1_width=2 * H, a1_off=di * H, a1_cols=H, a1_shift=shift, nblk=nb, L_=seq.L,
@@ -281,6 +283,10 @@ def test_gemm_tnb_bf16_g_operand(view, dims):
         assert rel(outs[1][1].sum(0), outs[0][1].sum(0)) < 1e-6   # column sums: pairs of slots per dot2 instead of (hi, lo)
         assert torch.equal(outs[3][0], outs[0][0] * tiny)         # scaled fp16: the same products times an exact power of two
         assert rel(outs[3][1].sum(0), outs[0][1].sum(0) * tiny) < 1e-6
+        # fp16 instruction (the default): G A_hi + G A_lo with A lifted by 2^6 -- the same products up to the fp16 denormal
+        # range of the lo terms, another summation inside the instruction
+        assert rel(outs[4][0].sum(0), outs[0][0].sum(0) * tiny) < 2e-6
+        assert rel(outs[4][1].sum(0), outs[0][1].sum(0) * tiny) < 1e-6
         assert rel(outs[1][1].sum(0), G[:, di * 1024:(di + 1) * 1024].double().sum(0)) < 1e-5
         # against fp64 with the step shift of A1 (as in tests/test_kernels_gpu.py::test_gemm_tnb_vs_torch)
         pos, valid = dev.bl_positions(seq, torch.device("cpu"))

@@ -48,13 +48,14 @@ def main():
         del g32
         ns, bps = dev.tnb_splits(nb, 8)
         slab, bslab = torch.empty(ns, 1024 * 384, device=d), torch.empty(ns, 1024, device=d)
-        for fmt in (0, 1, 2):
+        for fmt, f16mm in ((0, "1"), (1, "1"), (2, "0"), (2, "1")):
+            os.environ["WS_TNB_F16"] = f16mm      # g_fmt 2 on the bf16 instruction (3 terms) / the fp16 one (2 terms, default)
             t = timeit(lambda: dev.gemm_tnb(G=G[fmt], g_width=2048, g_off=0, g_cols=1024, A0=xn, a0_width=N, a0_off=0, a0_cols=N,
                                             A1=h, a1_width=2 * H, a1_off=0, a1_cols=H, a1_shift=-1, nblk=nb, L_=seq.L, slab=slab,
                                             nsplit=ns, blocks_per_split=bps, bslab=bslab, g_fmt=fmt,
                                             amax=amax if fmt == 2 else None), a.reps)
             gb = (nb * 32 * 1024 * (4 if fmt == 0 else 2) + nb * 32 * (N + H) * 4) / 1e9
-            print(f"tnb  {view} g_fmt={fmt} gdepth={os.environ.get('WS_TNB_GDEPTH', '4')}: {t:7.3f} ms  {gb / t * 1e3:7.0f} GB/s unique  "
+            print(f"tnb  {view} g_fmt={fmt} f16_mfma={f16mm if fmt == 2 else '-'} gdepth={os.environ.get('WS_TNB_GDEPTH', '4')}: {t:7.3f} ms  {gb / t * 1e3:7.0f} GB/s unique  "
                   f"nsplit={ns}", flush=True)
         W = torch.randn(N, 2048, device=d) * 0.05
         wp = torch.empty(N * 2048, device=d)

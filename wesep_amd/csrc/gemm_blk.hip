@@ -28,6 +28,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));  // the operand type of __builtin_amdgcn_fdot2 / cvt_pkrtz
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -716,8 +717,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
 template <bool ASUM, int GFMT, int GD>
 __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_args p) {
   constexpr int TA = 3, TN = 3;
+  // GFMT 3 = the scaled-fp16 G of g_fmt 2 on v_mfma_f32_32x32x16_f16: G needs no split (its 11 bits ARE an fp16), the A
+  // operand's bf16 hi / lo terms convert exactly to fp16 after a power-of-two lift (x 2^6: one packed exponent add per
+  // BLS word; keeps lo terms of |x| >= 5e-4 out of the fp16 denormals, |x| < 1023 finite) -> G A_hi + G A_lo, TWO MFMAs
+  // per product instead of three (G_hi A_hi + G_hi A_lo + G_lo A_hi on the bf16 instruction)
+  constexpr bool F16 = GFMT == 3;
   constexpr int NTERM = GFMT == 2 ? 3 : 2;
-  const float inv_s = GFMT == 2 ? ws_dgates_scale_inv(*p.amax) : 1.f;
+  const float inv_s = GFMT >= 2 ? ws_dgates_scale_inv(*p.amax) : 1.f;
+  const float inv_out = F16 ? inv_s * 0.015625f : inv_s;
   constexpr int NCOL = 128 * (1 + TA);
   constexpr int PLANE = NCOL * TB_LD;
   __shared__ __attribute__((aligned(16))) __bf16 ldsA[2 * PLANE];
@@ -782,6 +789,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
       const u32x4 d = gq[gslot];
       const unsigned lo_ = pc == 8 ? d[0] : d[1], hi_ = pc == 8 ? d[2] : d[3];  // slot 2sp / slot 2sp + 1
       const int col = 4 * qg + 2 * (pc - 8);
+      if constexpr (F16) {
+        const unsigned c_even = __builtin_amdgcn_perm(hi_, lo_, WS_SEL_LO16), c_odd = __builtin_amdgcn_perm(hi_, lo_, WS_SEL_HI16);
+        *reinterpret_cast<unsigned*>(lds + col * TB_LD + 2 * sp) = c_even;
+        *reinterpret_cast<unsigned*>(lds + (col + 1) * TB_LD + 2 * sp) = c_odd;
+        const h16x2 ones_h = __builtin_bit_cast(h16x2, live ? 0x3c003c00u : 0u);  // (1, 1) in fp16
+        gsum[2 * (pc - 8)] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, c_even), ones_h, gsum[2 * (pc - 8)], false);
+        gsum[2 * (pc - 8) + 1] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, c_odd), ones_h, gsum[2 * (pc - 8) + 1], false);
+        return;
+      }
       if constexpr (GFMT == 2) {
         // four fp16 values: (slot 2sp, col), (slot 2sp, col + 1), (slot 2sp + 1, col), (slot 2sp + 1, col + 1)
         const f16x2 a = __builtin_bit_cast(f16x2, lo_), b = __builtin_bit_cast(f16x2, hi_);
@@ -825,6 +841,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
         asum[r][c] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, e[j]), ones, asum[r][c], false);
     }
     const int o = (acol[r] + c) * TB_LD + aslot[r];
+    if constexpr (F16) {
+      unsigned hw[2], lw[2];
+#pragma unroll
+      for (int j = 0; j < (r == 0 ? 2 : 1); ++j) {
+        const unsigned u0 = e[2 * j] + 0x03000300u, u1 = e[2 * j + 1] + 0x03000300u;  // hi and lo terms x 2^6 (zeros turn
+        // into 2^-121, which converts to 0)
+        hw[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u)));
+        lw[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(u0 << 16), __uint_as_float(u1 << 16)));
+      }
+      if (r == 0) {
+        *reinterpret_cast<uint2*>(lds + o) = uint2{hw[0], hw[1]};
+        *reinterpret_cast<uint2*>(lds + PLANE + o) = uint2{lw[0], lw[1]};
+      } else {
+        *reinterpret_cast<unsigned*>(lds + o) = hw[0];
+        *reinterpret_cast<unsigned*>(lds + PLANE + o) = lw[0];
+      }
+      return;
+    }
     if (r == 0) {
       uint2 hi, lo;
       hi.x = __builtin_amdgcn_perm(e[1], e[0], WS_SEL_HI16);
@@ -899,7 +933,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
               if (term == 0 && !last) lda(f + 1 < TN ? ks : 16, f + 1 < TN ? f + 1 : 0, ahn, aln);
               // terms: G_hi A_hi, G_hi A_lo and (GFMT 2) G_lo A_hi
 #pragma unroll
-              for (int e = 0; e < 2; ++e) acc[e][f] = mfma32(term == 2 ? gl[e] : gh[e], term == 1 ? al : ah, acc[e][f]);
+              for (int e = 0; e < 2; ++e) {
+                if constexpr (F16)
+                  acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, gh[e]),
+                                                                     __builtin_bit_cast(f16x8, term == 1 ? al : ah), acc[e][f], 0, 0, 0);
+                else
+                  acc[e][f] = mfma32(term == 2 ? gl[e] : gh[e], term == 1 ? al : ah, acc[e][f]);
+              }
               if (sub < NPC) store_piece(s ^ 1, (sg4 + 1) % GD, ldsw, live, sub);
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -922,7 +962,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int grow = gt * 128 + wm * 64 + e * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          out[(long long)grow * ncols + ac_] = GFMT == 2 ? acc[e][f][r] * inv_s : acc[e][f][r];
+          out[(long long)grow * ncols + ac_] = GFMT >= 2 ? acc[e][f][r] * inv_out : acc[e][f][r];
         }
       }
     }
@@ -934,7 +974,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
     t += __shfl_xor(t, 2, 64);
     t += __shfl_xor(t, 4, 64);
     t += __shfl_xor(t, 8, 64);
-    if (p.bslab && sp == 0) p.bslab[(long long)split * p.bslab_stride + gt * 128 + 4 * qg + c] = GFMT == 2 ? t * inv_s : t;
+    if (p.bslab && sp == 0) p.bslab[(long long)split * p.bslab_stride + gt * 128 + 4 * qg + c] = GFMT >= 2 ? t * inv_s : t;
   }
   if (ASUM && gt == 0 && p.aslab) {  // column sums of Acat: whole groups over the 8 slot groups, half groups over 16 halves
 #pragma unroll
@@ -974,7 +1014,14 @@ extern "C" int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream) {
   ws_prof_begin(WS_PROF_GEMM_TN, s);
   // WS_TNB_GDEPTH=2|4 (diagnostics): blocks of the 2-byte G operand in flight per thread; both depths give the same bits
   static const int gdepth = [] { const char* e = getenv("WS_TNB_GDEPTH"); return e && atoi(e) == 2 ? 2 : 4; }();
-  if (a->g_fmt == 2 && a->aslab)
+  // WS_TNB_F16=0 (A/B runs): the scaled-fp16 G on the bf16 instruction (3 terms) instead of the fp16 one (2 terms)
+  const char* f16env = getenv("WS_TNB_F16");  // read per call: the tests run both forms in one process
+  const bool f16mm = !(f16env && atoi(f16env) == 0);
+  if (a->g_fmt == 2 && f16mm && a->aslab)
+    hipLaunchKernelGGL((gemm_tnb16_kernel<true, 3, 4>), grid, block, 0, s, *a);
+  else if (a->g_fmt == 2 && f16mm)
+    hipLaunchKernelGGL((gemm_tnb16_kernel<false, 3, 4>), grid, block, 0, s, *a);
+  else if (a->g_fmt == 2 && a->aslab)
     hipLaunchKernelGGL((gemm_tnb16_kernel<true, 2, 4>), grid, block, 0, s, *a);
   else if (a->g_fmt == 2 && gdepth == 2)
     hipLaunchKernelGGL((gemm_tnb16_kernel<false, 2, 2>), grid, block, 0, s, *a);

@@ -850,8 +850,10 @@ def gemm_b2p(*, A, K: int, sm: SeqMap, Wpack, C_out, ldc: int, N=128, bias=None,
 
 
 def tnb_splits(nblk: int, gtiles: int):
-    """Splits of the block range: gtiles * nsplit workgroups ~ one per CU (256), at most 64 slabs."""
-    nsplit = max(1, min(64, int(os.environ.get("WESEP_TNB_WGS", "256")) // gtiles, nblk))
+    """Splits of the block range: gtiles * nsplit workgroups ~ WESEP_TNB_WGS (default: one per CU, 256), at most
+    WESEP_TNB_MAXSPLIT (64) slabs."""
+    cap = int(os.environ.get("WESEP_TNB_MAXSPLIT", "64"))
+    nsplit = max(1, min(cap, int(os.environ.get("WESEP_TNB_WGS", "256")) // gtiles, nblk))
     if nsplit >= 8:
         nsplit -= nsplit % 8          # multiple of 8: same-split workgroups share an XCD (and its L2)
     bps = -(-nblk // nsplit)
