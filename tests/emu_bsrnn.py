@@ -97,5 +97,5 @@ def install(monkeypatch, real_resrnn=False):
         if name == "resrnn" and real_resrnn:
             continue
         monkeypatch.setattr(f0, name, obj)
-    monkeypatch.setattr(f0, "make_wgrad_carrier", lambda params: None)
+    monkeypatch.setattr(f0, "make_wgrad_carrier", lambda params, blocked=None: None)
     monkeypatch.setattr(f0, "reset_deferred_wgrads", lambda device: None)

@@ -45,7 +45,7 @@ def test_blstm_linear_blocked_matches_torch(emu, monkeypatch, nseq, Lr, branch, 
     wf, hf, bf = FG.pad_lstm(lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
     wr, hr, br = FG.pad_lstm(lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse,
                              lstm.bias_hh_l0_reverse)
-    out = FG.BlstmLinearBlkFn.apply(y, res, (nseq, Lr), wf, wr, bf, br, hf, hr, FG.pad_hidden_cols(lin.weight, h),
+    out = FG.BlstmLinearBlkFn.apply(y, res, (nseq, Lr), None, None, wf, wr, bf, br, hf, hr, FG.pad_hidden_cols(lin.weight, h),
                                     lin.bias)
     (out * probe).sum().backward()
     got = {"y": y.grad.clone(), "res": res.grad.clone(),
@@ -88,11 +88,11 @@ def test_blstm_linear_strided_map_equals_transposed_copy(emu, monkeypatch, B, T,
             t.grad = None
         return g
 
-    out = FG.BlstmLinearBlkFn.apply(y, res, (B * Q, T, Q, T * Q, 1, Q), *params())
+    out = FG.BlstmLinearBlkFn.apply(y, res, (B * Q, T, Q, T * Q, 1, Q), None, None, *params())
     (out * probe).sum().backward()
     got = grads()
     tr = lambda t: t.view(B, T, Q, 128).transpose(1, 2).reshape(B * Q * T, 128)           # rows (b, q, t)
-    ref = FG.BlstmLinearBlkFn.apply(tr(y).contiguous(), tr(res).contiguous(), (B * Q, T), *params())
+    ref = FG.BlstmLinearBlkFn.apply(tr(y).contiguous(), tr(res).contiguous(), (B * Q, T), None, None, *params())
     ref = ref.view(B, Q, T, 128).transpose(1, 2).reshape(B * T * Q, 128)
     (ref * probe).sum().backward()
     want = grads()
@@ -121,3 +121,38 @@ def test_recipe_geometry_model_blocked_equals_default(emu, monkeypatch):
     assert float((res["1"][0] - res["0"][0]).norm() / res["0"][0].norm()) < 1e-5
     for k, g0 in res["0"][1].items():
         assert float((res["1"][1][k] - g0).norm()) <= 1e-4 * float(g0.norm()) + 1e-7, k
+
+
+def test_recipe_geometry_model_deferred_weight_gradients_equal_inline(emu, monkeypatch):
+    """Round 4: the BLSTMs' weight gradients computed by deferred jobs on the side stream and delivered through
+    functional.WGradCarrierFn (released under the inter-frame BPTTs) -- the host logic on the emulation with stand-in
+    streams (tests/emu_streams.py): the same parameter gradients, bit for bit, as the in-line computation; every job
+    released, every carrier served."""
+    from tests import emu_streams
+    from wesep_amd import functional as F0
+    from wesep_amd.models import get_model
+    emu_streams.install(monkeypatch)
+    monkeypatch.setenv("WESEP_GATES", "f32")
+    torch.manual_seed(0)
+    model = get_model("TFGridNet")(n_fft=128, stride=64, n_layers=2, lstm_hidden_units=192, attn_n_head=4,
+                                   attn_approx_qk_dim=512, emb_dim=128, emb_ks=1, emb_hs=1, use_spk_transform=False,
+                                   spk_fuse_type="multiply", joint_training=False).train()
+    g = torch.Generator().manual_seed(1)
+    wav, emb = 0.1 * torch.randn(2, 1280, generator=g), torch.randn(2, 256, generator=g)
+    probe = torch.randn(2, 1280, generator=g)
+    res, made = {}, []
+    real = F0.make_wgrad_carrier
+    monkeypatch.setattr(F0, "make_wgrad_carrier", lambda params, blocked=None: made.append(real(params, blocked)) or made[-1])
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WESEP_WGRAD_OVERLAP", flag)
+        model.zero_grad(set_to_none=True)
+        del made[:]
+        est, _ = model(wav, emb)
+        (est * probe).sum().backward()
+        assert len(made) == 4 and all((c is not None) == (flag == "1") for c in made)     # 2 blocks x (intra, inter)
+        assert not F0._pending(wav.device)                                                   # every job was released
+        assert all(c[1].grads is None and c[1].event is not None for c in made if c)        # ... and every box emptied
+        res[flag] = (est.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+    assert torch.equal(res["1"][0], res["0"][0])
+    for k, g0 in res["0"][1].items():
+        assert torch.equal(res["1"][1][k], g0), k

@@ -56,7 +56,7 @@ def run(nseq, Lr, tag):
     out_ref.backward(dout.double().view(nseq, Lr, N))
     leaves = [P[k].clone().requires_grad_(True) for k in ("wih_f", "wih_r", "b_f", "b_r", "whh_f", "whh_r", "lin_w", "lin_b")]
     yl, rl = y.clone().requires_grad_(True), res.clone().requires_grad_(True)
-    out = FG.BlstmLinearBlkFn.apply(yl, rl, (nseq, Lr), *leaves)
+    out = FG.BlstmLinearBlkFn.apply(yl, rl, (nseq, Lr), None, None, *leaves)
     out.backward(dout)
     torch.cuda.synchronize()
     names = ("wih_f", "wih_r", "b_f", "b_r", "whh_f", "whh_r", "lin_w", "lin_b")

@@ -16,7 +16,7 @@ for M in "$@"; do
     bsrnn)      TOOL=bench.py;                  LONG="--steps 10 --warmup 3";                                  SHORT="--steps 1 --warmup 1 --no-cpu-baseline"; STATS="--steps 5 --warmup 2 --no-cpu-baseline";;
     dpccn)      TOOL=tools/bench_dpccn.py;      LONG="--rows 32 --joint --steps 5 --warmup 2 --cpu";         SHORT="--rows 32 --joint --steps 1 --warmup 1";  STATS="--rows 32 --joint --steps 3 --warmup 1";;
     tfgridnet)  TOOL=tools/bench_tfgridnet.py;  LONG="--rows 8 --recipe --steps 3 --warmup 1 --cpu";         SHORT="--rows 8 --recipe --steps 1 --warmup 1";  STATS="--rows 8 --recipe --steps 2 --warmup 1";;
-    convtasnet) TOOL=tools/bench_convtasnet.py; LONG="--cpu";                                                SHORT="--steps 1 --warmup 1";                    STATS="--steps 5 --warmup 2";;
+    convtasnet) TOOL=tools/bench_convtasnet.py; LONG="--steps 20 --warmup 5 --cpu";                                                SHORT="--steps 1 --warmup 1";                    STATS="--steps 5 --warmup 2";;
     *) echo "unknown model $M"; continue;;
   esac
   SHA=$(python -c "import hashlib;print(hashlib.sha256(open('$ROOT/$TOOL','rb').read()).hexdigest()[:16])")

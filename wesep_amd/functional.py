@@ -664,11 +664,14 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
     return W
 
 
-def make_wgrad_carrier(params):
+def make_wgrad_carrier(params, blocked=None):
     """(dummy, box) for one ResRNN, or None when the side-stream hand-over does not apply.  `params`:
-    the ten LSTM / proj tensors in ResRNNFn order.  Must be called BEFORE the forward of every ResRNN
-    of the step (see WGradCarrierFn)."""
-    if not (wgrad_overlap() and resrnn_mode() == "blocked" and torch.is_grad_enabled()
+    the ten LSTM / proj tensors in ResRNNFn order (TF-GridNet's BlstmLinearBlkFn: its eight padded weight tensors, in
+    the order of its own arguments; blocked=True there -- the caller has checked its own path).  Must be called BEFORE
+    the forward of every ResRNN of the step (see WGradCarrierFn)."""
+    if blocked is None:
+        blocked = resrnn_mode() == "blocked"
+    if not (wgrad_overlap() and blocked and torch.is_grad_enabled()
             and params[0].is_cuda and all(p.requires_grad for p in params)):
         return None
     box = WGradBox()

@@ -398,7 +398,12 @@ class BlstmLinearBlkFn(torch.autograd.Function):
     the map's `nvalid` (wesep_hip.h ws_seqmap), not appended rows."""
 
     @staticmethod
-    def forward(ctx, y, res, geo, wih_f, wih_r, b_f, b_r, whf, whr, lin_w, lin_b):
+    def forward(ctx, y, res, geo, dummy, box, wih_f, wih_r, b_f, b_r, whf, whr, lin_w, lin_b):
+        """dummy / box: None, or the output and the box of this BLSTM's functional.WGradCarrierFn (created over the eight
+        weight tensors, in this order, before the first block of the step) -- then the weight gradients are computed on the
+        side stream, released under the NEXT inter-frame BPTT (a latency-bound launch on a quarter of the CUs), and reach
+        autograd through the carrier; this node returns None for them (round 4: the twelve BLSTMs' weight-gradient GEMMs,
+        48 ms of a 336 ms step, ran in line on the main stream before)."""
         from . import functional as F0
         _need_cuda(y, "TF-GridNet")
         nseq, Lr = geo[:2]
@@ -481,6 +486,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         ctx.seq = seq
         ctx.gfmt, ctx.kind = gfmt, kind
         ctx.F0 = F0
+        ctx.box = box
         ctx.consumed = False
         return out[:nseq * Lr] if (pad and strided is None) else out
 
@@ -510,6 +516,10 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         # = 38 ms of a 490 ms step and the largest transient allocation of the backward)
         kind, gfmt = ctx.kind, ctx.gfmt
         g_fmt = {L.GATES_H2: 1, L.GATES_H2F: 2}.get(gfmt, 0)
+        F0, box = ctx.F0, ctx.box
+        # the inter-frame BPTT (few long sequences: pair / cluster kernels on a fraction of the CUs for ~10 ms) is where the
+        # weight-gradient jobs deferred by the BLSTMs before it are released (functional.flush_deferred_wgrads)
+        ready = F0.mark_wgrads_ready(d) if kind in ("pair", "cluster") else None
         if kind == "cluster":
             dg = gates
             dev.lstm_bwd_cluster(gates, cbuf, dh, whf, whr, seq)
@@ -530,10 +540,26 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else gates
             dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, lmode, gfmt=gfmt, dgates=dg if gfmt == L.GATES_H2S else None,
                          amax=amax)
-        wg = ctx.F0.ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)
+        if ready is not None:
+            F0.flush_deferred_wgrads(d, ready)
+        order = (0, 4, 2, 6, 1, 5, 8, 9)       # _weight_grads' list -> this node's weight arguments
+        if box is not None:
+            def job(side, gates=dg, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, box=box, g_fmt=g_fmt, amax=amax):
+                wg_ = F0.ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, 128, g_fmt, amax)
+                box.grads = [wg_[i] for i in order]
+                box.event = torch.cuda.Event()
+                box.event.record(side)
+                for t in (gates, xn, hcat, dout_bl) + ((amax,) if amax is not None else ()):
+                    t.record_stream(side)
+            F0._pending(d).append(job)
+            wgo = [None] * 8
+        else:
+            wg = F0.ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)
+            wgo = [wg[i] for i in order]
         dy = _empty(d, (ns if appended else nseq) * Lr, N)
         dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dy, ldc=N, a_fmt=g_fmt, amax=amax)
         if appended:
             dy = dy[:nseq * Lr]
-        # wg: [dW_ih_f, dW_hh_f, db_f, db_f (clone), dW_ih_r, dW_hh_r, db_r, db_r (clone), dW_lin, db_lin]
-        return dy, dres, None, wg[0], wg[4], wg[2], wg[6], wg[1], wg[5], wg[8], wg[9]
+        # _weight_grads: [dW_ih_f, dW_hh_f, db_f, db_f (clone), dW_ih_r, dW_hh_r, db_r, db_r (clone), dW_lin, db_lin]
+        gd = torch.zeros((), device=d) if box is not None else None     # keeps the carrier node in the graph walk
+        return (dy, dres, None, gd, None) + tuple(wgo)

@@ -99,22 +99,48 @@ class GridNetBlock(nn.Module):
         self.emb_dim, self.emb_ks, self.emb_hs, self.n_head, self.E = emb_dim, emb_ks, emb_hs, n_head, E
         self.hidden = hidden_channels
 
-    def _rnn_path(self, path, x, nseq, Lr, strided=None):
-        """x [nseq*Lr, C]: LayerNorm -> windows -> BLSTM -> ConvTranspose1d / Linear -> + x  (gridnet_block.py:139-160).
-        strided = (div, s1, s2, step_rows): the sequences are a strided row set of x instead of contiguous runs (blocked
-        path only: functional_tfgridnet.BlstmLinearBlkFn)."""
-        C, ks, hs, h = self.emb_dim, self.emb_ks, self.emb_hs, self.hidden
-        norm, rnn, lin = self[f"{path}_norm"], self[f"{path}_rnn"], self[f"{path}_linear"]
-        y = FG.RowLNFn.apply(x, norm.weight, norm.bias)
+    def _padded_lstm(self, path, device):
+        C, ks, hs = self.emb_dim, self.emb_ks, self.emb_hs
+        rnn = self[f"{path}_rnn"]
         perm = None
         if ks != hs:      # F.unfold orders a window as (channel, position); the row view as (position, channel)
-            perm = (torch.arange(C, device=x.device).unsqueeze(0) * ks + torch.arange(ks, device=x.device).unsqueeze(1)).reshape(-1)
+            perm = (torch.arange(C, device=device).unsqueeze(0) * ks + torch.arange(ks, device=device).unsqueeze(1)).reshape(-1)
         wf, hf, bf = FG.pad_lstm(rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, perm)
         wr, hr, br = FG.pad_lstm(rnn.weight_ih_l0_reverse, rnn.weight_hh_l0_reverse, rnn.bias_ih_l0_reverse,
                                  rnn.bias_hh_l0_reverse, perm)
-        if FG.blocked_path_ok(C, ks, hs):     # the recipe's geometry: the pBSRNN blocked-layout recurrences (opt-in)
-            return FG.BlstmLinearBlkFn.apply(y, x, (nseq, Lr) + tuple(strided or ()), wf, wr, bf, br, hf, hr,
-                                             FG.pad_hidden_cols(lin.weight, h), lin.bias)
+        return wf, hf, bf, wr, hr, br
+
+    def make_carriers(self):
+        """Blocked path only: {path: (the eight weight tensors of functional_tfgridnet.BlstmLinearBlkFn, (dummy, box) | None)}
+        for the intra- and the inter-frame BLSTM -- the weight-gradient carriers of functional.WGradCarrierFn.  Must be called
+        for EVERY block before the first block's forward (the carriers need the lowest sequence numbers of the step's graph)."""
+        C, ks, hs, h = self.emb_dim, self.emb_ks, self.emb_hs, self.hidden
+        if not FG.blocked_path_ok(C, ks, hs):
+            return None
+        out = {}
+        for path in ("intra", "inter"):
+            lin = self[f"{path}_linear"]
+            wf, hf, bf, wr, hr, br = self._padded_lstm(path, lin.weight.device)
+            w = (wf, wr, bf, br, hf, hr, FG.pad_hidden_cols(lin.weight, h), lin.bias)
+            out[path] = (w, F_.make_wgrad_carrier(w, blocked=True))
+        return out
+
+    def _rnn_path(self, path, x, nseq, Lr, strided=None, prep=None):
+        """x [nseq*Lr, C]: LayerNorm -> windows -> BLSTM -> ConvTranspose1d / Linear -> + x  (gridnet_block.py:139-160).
+        strided = (div, s1, s2, step_rows): the sequences are a strided row set of x instead of contiguous runs (blocked
+        path only: functional_tfgridnet.BlstmLinearBlkFn).  prep: this path's entry of `make_carriers`."""
+        C, ks, hs, h = self.emb_dim, self.emb_ks, self.emb_hs, self.hidden
+        norm, rnn, lin = self[f"{path}_norm"], self[f"{path}_rnn"], self[f"{path}_linear"]
+        y = FG.RowLNFn.apply(x, norm.weight, norm.bias)
+        if FG.blocked_path_ok(C, ks, hs):     # the recipe's geometry: the pBSRNN blocked-layout recurrences
+            if prep is None:
+                wf, hf, bf, wr, hr, br = self._padded_lstm(path, x.device)
+                w, carrier = (wf, wr, bf, br, hf, hr, FG.pad_hidden_cols(lin.weight, h), lin.bias), None
+            else:
+                w, carrier = prep
+            dummy, box = carrier if carrier is not None else (None, None)
+            return FG.BlstmLinearBlkFn.apply(y, x, (nseq, Lr) + tuple(strided or ()), dummy, box, *w)
+        wf, hf, bf, wr, hr, br = self._padded_lstm(path, x.device)
         if strided is not None:
             raise dev.L.WesepHipError("TF-GridNet: strided sequence maps are a feature of the blocked-layout path")
         hcat = FG.BlstmFn.apply(y, (nseq, Lr, C, ks, hs), torch.cat([wf, wr], 0), torch.cat([bf, br], 0), hf, hr)
@@ -128,8 +154,9 @@ class GridNetBlock(nn.Module):
             o = FG.AddRowVecFn.apply(o, lin.bias)
         return o + x
 
-    def forward(self, x, geo):
-        """x [B*T*Q, C], geo (B, T, Q) -> same."""
+    def forward(self, x, geo, prep=None):
+        """x [B*T*Q, C], geo (B, T, Q) -> same.  prep: `make_carriers()` of this block, or None."""
+        prep = prep or {}
         B, oT, oQ = geo
         C, ks, hs, nh, E = self.emb_dim, self.emb_ks, self.emb_hs, self.n_head, self.E
         olp = ks - hs
@@ -139,15 +166,16 @@ class GridNetBlock(nn.Module):
             h = x.view(B, oT, oQ, C)        # and F.pad with all-zero pads would still copy the 150 MB map
         else:
             h = torch.nn.functional.pad(x.view(B, oT, oQ, C), (0, 0, olp, Q - oQ - olp, olp, T - oT - olp))
-        h = self._rnn_path("intra", h.reshape(B * T * Q, C), B * T, Q).view(B, T, Q, C)
+        h = self._rnn_path("intra", h.reshape(B * T * Q, C), B * T, Q, prep=prep.get("intra")).view(B, T, Q, C)
         if FG.blocked_path_ok(C, ks, hs) and os.environ.get("WESEP_TFG_STRIDED", "1") != "0":
             # inter-frame path IN PLACE on the [B, T, Q, C] map: sequence (b, q), step t -> row (b * T + t) * Q + q (round 4;
             # the reference permutes to [B, Q, T, C] and back, gridnet_block.py:163-180: two copies of the map forward, two backward)
-            h = self._rnn_path("inter", h.view(B * T * Q, C), B * Q, T, strided=(Q, T * Q, 1, Q)).view(B, T, Q, C)
+            h = self._rnn_path("inter", h.view(B * T * Q, C), B * Q, T, strided=(Q, T * Q, 1, Q),
+                               prep=prep.get("inter")).view(B, T, Q, C)
             inter = h[:, olp:olp + oT, olp:olp + oQ, :].contiguous().view(B * oT * oQ, C)
         else:
             h = h.transpose(1, 2).contiguous()                                      # [B, Q, T, C]
-            h = self._rnn_path("inter", h.view(B * Q * T, C), B * Q, T).view(B, Q, T, C)
+            h = self._rnn_path("inter", h.view(B * Q * T, C), B * Q, T, prep=prep.get("inter")).view(B, Q, T, C)
             inter = h.transpose(1, 2)[:, olp:olp + oT, olp:olp + oQ, :].contiguous().view(B * oT * oQ, C)
         M = B * oT * oQ
         cq, ck, cv = self["attn_conv_Q"], self["attn_conv_K"], self["attn_conv_V"]
@@ -302,9 +330,14 @@ class TFGridNet(nn.Module):
                       else emb)
         emb = self.spk_transform(emb)
         from .dpccn import fuse_bins
-        for blk in self.blocks:
+        # weight-gradient carriers of all twelve BLSTMs first: autograd then runs them after every block's backward, and the
+        # weight-gradient GEMMs run on the side stream under the inter-frame BPTTs (functional.WGradCarrierFn)
+        if h.is_cuda:
+            F_.reset_deferred_wgrads(h.device)
+        preps = [blk.make_carriers() for blk in self.blocks]
+        for blk, prep in zip(self.blocks, preps):
             h = fuse_bins(self.spk_fuse, h, emb, (B, Tf, Fq))        # the same fusion before every block (tfgridnet.py:272-276)
-            h = blk(h, (B, Tf, Fq))
+            h = blk(h, (B, Tf, Fq), prep)
         out = FD.ConvTranspose2dFn.apply(h, self.deconv.weight, self.deconv.bias, (B, Tf, Fq, 1, 1))   # [B*T*F, 2S]
         ld = -(-2 * Fq // 4) * 4
         est_spec = torch.zeros(B * S * Tf, ld, device=d, dtype=torch.float32)
