@@ -233,7 +233,9 @@ struct fused64_lds {
 };
 // (the body is a device function template behind two plain kernels: hipcc 7.2 does not emit the host stubs of a
 //  __global__ TEMPLATE with this body -- "substitution failure" without a diagnostic)
-template <int GF>
+// W1 (MEASUREMENT ONLY, WS_FUSED_W1=1): one weight plane -- the W_lo x_hi term and the lo
+// fragments of the weight stream are dropped (two MFMAs per product, half the L2 -> CU stream): weights at bf16 precision.
+template <int GF, bool W1 = false>
 __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& p) {
   __shared__ __attribute__((aligned(16))) fused64_lds sm;
   auto& xw = sm.xw;
@@ -289,7 +291,8 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
+    for (int f = 0; f < 8; ++f)
+      if (!W1 || !(f & 1)) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
 
   const __bf16* hrow[2] = {&hl[0][l31 * HROW + 8 * half], &hl[0][(32 + l31) * HROW + 8 * half]};  // h_{t-1} rows of this lane
   auto tof = [&](int n) { const int m = min(n, L - 1); return d == 0 ? m : L - 1 - m; };
@@ -337,13 +340,15 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[e][g] = mfma32(wr[s][2 * g], bh[e], acc[e][g]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[e][g] = mfma32(wr[s][2 * g + 1], bh[e], acc[e][g]);
+        for (int g = 0; g < 4; ++g)
+          if (!W1) acc[e][g] = mfma32(wr[s][2 * g + 1], bh[e], acc[e][g]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[e][g] = mfma32(wr[s][2 * g], bl[e], acc[e][g]);
       }
       const int kn = (ks + 2) % FKS;
 #pragma unroll
-      for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
+      for (int f = 0; f < 8; ++f)
+        if (!W1 || !(f & 1)) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // every wave has read h_{t-1} and x_t: both may be overwritten now
@@ -402,6 +407,9 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64_kernel(const ws_lstm_
 __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h_kernel(const ws_lstm_fused_args p) {
   lstm_fwd_fused64_body<WS_GATES_H2>(p);
 }
+__global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h_w1_kernel(const ws_lstm_fused_args p) {   // measurement only
+  lstm_fwd_fused64_body<WS_GATES_H2, true>(p);
+}
 
 extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn && a->wpack && a->bias, "ws_lstm_fwd_fused: null pointer");
@@ -420,7 +428,10 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   const int rounds32 = (2 * ntile + cus - 1) / cus, rounds64 = (2 * ((ntile + 1) / 2) + cus - 1) / cus;
   const bool wide = env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
-  if (wide && a->gfmt)
+  const char* w1 = getenv("WS_FUSED_W1");   // measurement only: one weight plane (bf16 weights), see lstm_fwd_fused64_body
+  if (wide && a->gfmt && w1 && atoi(w1) == 1)
+    hipLaunchKernelGGL(lstm_fwd_fused64h_w1_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
+  else if (wide && a->gfmt)
     hipLaunchKernelGGL(lstm_fwd_fused64h_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
   else if (wide)
     hipLaunchKernelGGL(lstm_fwd_fused64_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
