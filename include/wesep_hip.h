@@ -727,12 +727,6 @@ int ws_conv3x3_wgrad(const ws_conv3x3_wgrad_args* a, void* stream);
  * dense blocks write y into / read dy from a column range of their one wide feature map (no torch.cat, no slices). */
 int ws_in_act_sums(const float* x, const float* dy, long long ldd, const float* stats, int P, int G, int nsplit, int C,
                    int flags, float* slab, void* stream);
-/* ws_in_act_sums_fold (round 4): the same partial sums, then the LAST of the nsplit workgroups of a group adds them up in
- * split order (deterministic; counter: G * ceil(C / 1024) words, zero at launch, left at zero) -- forward (dy NULL): out
- * [G][2][C] = the statistics (mean, rstd) as ws_inorm_finalize(eps) computes them; backward: out = the reduced sums.  One
- * launch where ws_in_act_sums + ws_reduce_slabs (+ ws_inorm_finalize) were two (three).                              */
-int ws_in_act_sums_fold(const float* x, const float* dy, long long ldd, const float* stats, int P, int G, int nsplit, int C,
-                        int flags, float* slab, float* out, unsigned* counter, float eps, void* stream);
 int ws_in_act_apply(const float* x, const float* stats, long long rows, int P, int C, int flags, float* y, long long ldy,
                     void* stream);
 int ws_in_act_bwd_apply(const float* x, const float* dy, long long ldd, const float* stats, const float* sums, long long rows,

@@ -230,7 +230,6 @@ _SIGS = {
     "ws_conv3x3": (_i, [C.POINTER(Conv3x3Args), _p]),
     "ws_conv3x3_wgrad": (_i, [C.POINTER(Conv3x3WgradArgs), _p]),
     "ws_in_act_sums": (_i, [_p, _p, _ll, _p, _i, _i, _i, _i, _i, _p, _p]),
-    "ws_in_act_sums_fold": (_i, [_p, _p, _ll, _p, _i, _i, _i, _i, _i, _p, _p, _p, C.c_float, _p]),
     "ws_in_act_apply": (_i, [_p, _p, _ll, _i, _i, _i, _p, _ll, _p]),
     "ws_in_act_bwd_apply": (_i, [_p, _p, _ll, _p, _p, _ll, _i, _i, _i, _p, _ll, _p]),
     "ws_rowln_grid": (_i, [_ll, _i]),

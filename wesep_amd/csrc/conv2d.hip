@@ -581,8 +581,7 @@ __device__ __forceinline__ f32x4 elud4(const f32x4& v) {   // d ELU(v) / dv
 // backward: (sum d, sum d * n), n = (u - mean) * rstd, d = dy * (flags & 2 ? ELU'(n) : 1)
 __global__ __launch_bounds__(256) void in_act_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ stats, int P, int G, int nsplit, int C,
-                                                          int flags, long long ldd, float* __restrict__ slab,
-                                                          float* __restrict__ out, unsigned* __restrict__ counter, float eps) {
+                                                          int flags, long long ldd, float* __restrict__ slab) {
   __shared__ f32x4 red[2][256];
   const int c4n = C >> 2;
   const int cz = blockIdx.z * 256;
@@ -627,43 +626,8 @@ __global__ __launch_bounds__(256) void in_act_sums_kernel(const float* __restric
       t1 += red[1][r * nq + tid];
     }
     float* o = slab + ((long long)split * G + grp) * 2 * C;
-    if (out) {  // read by the group's last workgroup below: agent-scope stores (common.h ws_last_block)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ws_st_agent(o + (cz + tid) * 4 + j, t0[j]);
-        ws_st_agent(o + C + (cz + tid) * 4 + j, t1[j]);
-      }
-    } else {
-      *reinterpret_cast<f32x4*>(o + (cz + tid) * 4) = t0;
-      *reinterpret_cast<f32x4*>(o + C + (cz + tid) * 4) = t1;
-    }
-  }
-  // ws_in_act_sums_fold: the last of the nsplit workgroups of (group, channel slice) adds the partials up in split order
-  // (deterministic) -- forward: straight into the statistics (mean, rstd), as ws_inorm_finalize computes them; backward:
-  // into the sums ws_in_act_bwd_apply reads.  No reduce_slabs / finalize launches (2 of 4 forward, 1 of 3 backward)
-  if (out && ws_last_block(counter + grp * gridDim.z + blockIdx.z, (unsigned)nsplit) && tid < nq) {
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    for (int sp = 0; sp < nsplit; ++sp) {
-      const float* o = slab + ((long long)sp * G + grp) * 2 * C;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a0[j] += ws_ld_agent(o + (cz + tid) * 4 + j);
-        a1[j] += ws_ld_agent(o + C + (cz + tid) * 4 + j);
-      }
-    }
-    if (!dy) {
-      const float inv_p = 1.f / (float)P;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float mean = a0[j] * inv_p;
-        const float var = fmaxf(a1[j] * inv_p - mean * mean, 0.f);
-        a0[j] = mean;
-        a1[j] = 1.f / sqrtf(var + eps);
-      }
-    }
-    float* po = out + (long long)grp * 2 * C;
-    *reinterpret_cast<f32x4*>(po + (cz + tid) * 4) = a0;
-    *reinterpret_cast<f32x4*>(po + C + (cz + tid) * 4) = a1;
+    *reinterpret_cast<f32x4*>(o + (cz + tid) * 4) = t0;
+    *reinterpret_cast<f32x4*>(o + C + (cz + tid) * 4) = t1;
   }
 }
 
@@ -717,19 +681,8 @@ extern "C" int ws_in_act_sums(const float* x, const float* dy, long long ldd, co
              "ws_in_act_sums: bad args (the backward sums need the statistics)");
   WS_REQUIRE(ldd == 0 || (ldd >= C && ldd % 4 == 0), "ws_in_act_sums: dy row stride %lld (0 = C, else >= C and %% 4)", ldd);
   hipLaunchKernelGGL(in_act_sums_kernel, dim3(nsplit, G, (C / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, dy, stats,
-                     P, G, nsplit, C, flags, ldd ? ldd : (long long)C, slab, (float*)nullptr, (unsigned*)nullptr, 0.f);
+                     P, G, nsplit, C, flags, ldd ? ldd : (long long)C, slab);
   return ws_check_launch("ws_in_act_sums");
-}
-
-extern "C" int ws_in_act_sums_fold(const float* x, const float* dy, long long ldd, const float* stats, int P, int G, int nsplit,
-                                   int C, int flags, float* slab, float* out, unsigned* counter, float eps, void* stream) {
-  WS_REQUIRE(x && slab && out && counter && P > 0 && G > 0 && nsplit > 0 && C > 0 && C % 4 == 0 && (flags & ~3) == 0 &&
-                 (!dy || stats) && eps >= 0.f,
-             "ws_in_act_sums_fold: bad args (the backward sums need the statistics)");
-  WS_REQUIRE(ldd == 0 || (ldd >= C && ldd % 4 == 0), "ws_in_act_sums_fold: dy row stride %lld (0 = C, else >= C and %% 4)", ldd);
-  hipLaunchKernelGGL(in_act_sums_kernel, dim3(nsplit, G, (C / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, dy, stats,
-                     P, G, nsplit, C, flags, ldd ? ldd : (long long)C, slab, out, counter, eps);
-  return ws_check_launch("ws_in_act_sums_fold");
 }
 
 extern "C" int ws_in_act_apply(const float* x, const float* stats, long long rows, int P, int C, int flags, float* y,

@@ -1302,25 +1302,12 @@ def conv3x3_wgrad(*, G, ldg: int, X, ldx: int, B: int, H: int, Wd: int, Cin: int
 IN_ELU_PRE, IN_ELU_POST = 1, 2     # ws_in_act_* flags: y = IN(ELU(x)) / y = ELU(IN(x))
 
 
-def _in_act_sums(x, dy, stats, G: int, P: int, Cc: int, flags: int, dy_ld: int = 0, dy_off: int = 0, eps=None):
-    """Backward (dy given): the reduced sums [G, 2, C].  Forward: the reduced sums -- or, with `eps`, the finished statistics
-    (mean, rstd).  One launch (ws_in_act_sums_fold: the last workgroup of a group reduces and finalises); WESEP_IN_FOLD=0
-    keeps the separate ws_reduce_slabs (+ ws_inorm_finalize) launches of round 3."""
+def _in_act_sums(x, dy, stats, G: int, P: int, Cc: int, flags: int, dy_ld: int = 0, dy_off: int = 0):
     nsplit = max(1, min(max(1, 1024 // G), P // 32))
     slab = torch.empty(nsplit, G, 2, Cc, device=x.device, dtype=torch.float32)
-    out = torch.empty(G, 2, Cc, device=x.device, dtype=torch.float32)
-    if os.environ.get("WESEP_IN_FOLD", "1") != "0" and (dy is not None or eps is not None):
-        from . import functional as F0      # (the zeroed-word allocator lives with the other per-stream scratch)
-        counter = F0.zero_words(x.device, G * (-(-(Cc // 4) // 256)))
-        _call("ws_in_act_sums_fold", _p(x), _p(dy, dy_off), dy_ld, _p(stats), P, G, nsplit, Cc, flags, _p(slab), _p(out),
-              _word(counter), float(eps or 0.0))
-        return out
     _call("ws_in_act_sums", _p(x), _p(dy, dy_off), dy_ld, _p(stats), P, G, nsplit, Cc, flags, _p(slab))
+    out = torch.empty(G, 2, Cc, device=x.device, dtype=torch.float32)
     reduce_slabs(slab, nsplit, G * 2 * Cc, G * 2 * Cc, out)
-    if eps is not None:
-        stats_ = torch.empty(G, 2, Cc, device=x.device, dtype=torch.float32)
-        _call("ws_inorm_finalize", _p(out), G, Cc, P, eps, _p(stats_))
-        return stats_
     return out
 
 
@@ -1339,7 +1326,9 @@ def in_act_fwd(x, G: int, P: int, Cc: int, flags: int, y, eps=IN_EPS, y_ld: int 
     _chk(x, "x")
     _chk(y, "y")
     _cols_ok(y, G * P, y_ld, y_off, Cc, "in_act_fwd y")
-    stats = _in_act_sums(x, None, None, G, P, Cc, flags, eps=eps)
+    sums = _in_act_sums(x, None, None, G, P, Cc, flags)
+    stats = torch.empty(G, 2, Cc, device=x.device, dtype=torch.float32)
+    _call("ws_inorm_finalize", _p(sums), G, Cc, P, eps, _p(stats))
     _call("ws_in_act_apply", _p(x), _p(stats), G * P, P, Cc, flags, _p(y, y_off), y_ld)
     return stats
 
