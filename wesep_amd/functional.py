@@ -257,13 +257,22 @@ def flush_deferred_wgrads(device, ready=None):
     if not jobs:
         return
     side = _side_stream(device)
-    if ready is None:
-        ready = mark_wgrads_ready(device)
     with torch.cuda.stream(side):
-        side.wait_event(ready)
-        for job in jobs:
+        for job, done in jobs:
+            # each job waits for ITS producer stream (defer_wgrad); with one producer stream that event precedes `ready`
+            side.wait_event(done)
             job(side)
     jobs.clear()
+
+
+def defer_wgrad(device, job):
+    """Queue a weight-gradient job (a closure that takes the side stream).  The job carries an event of its PRODUCER stream,
+    recorded now: its operands are complete once everything enqueued so far on the current stream is.  With several producer
+    streams (the row streams of models.tfgridnet) a flush issued from one stream must not release another stream's job before
+    that stream has produced its operands."""
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream())
+    _pending(device).append((job, done))
 
 
 class WGradBox:
@@ -551,7 +560,7 @@ class ResRNNBlkFn(torch.autograd.Function):
                 box.event.record(side)
                 for t in (gates, xn, hcat, dout_bl) + ((amax,) if amax is not None else ()):
                     t.record_stream(side)
-            _pending(d).append(job)
+            defer_wgrad(d, job)
             wg = [None] * 10
         else:
             wg = ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)

@@ -551,7 +551,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
                 box.event.record(side)
                 for t in (gates, xn, hcat, dout_bl) + ((amax,) if amax is not None else ()):
                     t.record_stream(side)
-            F0._pending(d).append(job)
+            F0.defer_wgrad(d, job)
             wgo = [None] * 8
         else:
             wg = F0.ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)
