@@ -157,40 +157,3 @@ def test_recipe_geometry_model_deferred_weight_gradients_equal_inline(emu, monke
     for k, g0 in res["0"][1].items():
         assert torch.equal(res["1"][1][k], g0), k
 
-
-def test_recipe_geometry_model_row_streams_equal_one_batch(emu, monkeypatch):
-    """Round 4: the block stack on two halves of the batch, each on its own stream (models.tfgridnet row streams) -- the
-    host logic on the emulation with stand-in streams: the same estimates bit for bit (rows are independent), the same
-    parameter gradients up to the order of the sums over rows; weight gradients deferred (two producer streams, one side
-    stream: functional.defer_wgrad) and in line."""
-    from tests import emu_streams
-    from wesep_amd import functional as F0
-    from wesep_amd.models import get_model
-    emu_streams.install(monkeypatch)
-    monkeypatch.setenv("WESEP_GATES", "f32")
-    torch.manual_seed(0)
-    model = get_model("TFGridNet")(n_fft=128, stride=64, n_layers=2, lstm_hidden_units=192, attn_n_head=4,
-                                   attn_approx_qk_dim=512, emb_dim=128, emb_ks=1, emb_hs=1, use_spk_transform=False,
-                                   spk_fuse_type="FiLM", joint_training=False).train()
-    g = torch.Generator().manual_seed(1)
-    wav, emb = 0.1 * torch.randn(4, 1280, generator=g), torch.randn(4, 256, generator=g)
-    probe = torch.randn(4, 1280, generator=g)
-    for overlap in ("1", "0"):
-        monkeypatch.setenv("WESEP_WGRAD_OVERLAP", overlap)
-        res = {}
-        for nrs in ("1", "2", "2"):                      # (the first call of a model is always one batch: it fills the tables)
-            monkeypatch.setenv("WESEP_TFG_ROW_STREAMS", nrs)
-            model.zero_grad(set_to_none=True)
-            calls = []
-            real = model._run_blocks
-            monkeypatch.setattr(model, "_run_blocks", lambda h, e, geo: calls.append(geo) or real(h, e, geo))
-            est, _ = model(wav, emb)
-            monkeypatch.setattr(model, "_run_blocks", real)
-            (est * probe).sum().backward()
-            assert not F0._pending(wav.device)
-            res[nrs] = (est.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}, calls)
-        assert [c[0] for c in res["1"][2]] == [4] and [c[0] for c in res["2"][2]] == [2, 2]
-        assert torch.equal(res["2"][0], res["1"][0])
-        for k, g0 in res["1"][1].items():
-            # (floor: attn_norm_K.beta has a zero true gradient -- the softmax is shift-invariant -- i.e. pure rounding noise)
-            assert float((res["2"][1][k] - g0).norm()) <= 2e-5 * float(g0.norm()) + 2e-6, k

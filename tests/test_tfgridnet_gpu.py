@@ -188,54 +188,3 @@ def test_attention_heads_kernels_vs_the_composition(B, T, Tp, Q, nh, ch, ld, off
     assert bool((dx[:, other.to(d)] == 3.0).all())
     assert rel(dg, dg64) < 2e-5 and rel(db, db64) < 2e-5 and rel(ds, ds64) < 2e-5
 
-
-def test_row_streams_match_one_batch_and_the_oracle(monkeypatch):
-    """Round 4: the block stack on two halves of the batch on two HIP streams (models.tfgridnet row streams; the inter-frame
-    recurrences of one half beside the GEMM / attention work of the other; weight-gradient jobs of two producer streams on
-    one side stream).  Recipe geometry, 4 rows x 2 s: estimates and every parameter gradient agree with the one-batch run to
-    rounding and with the oracle to the usual bounds; repeated runs are bit-reproducible (no race between the streams)."""
-    from oracle import bsrnn_oracle as O
-    from oracle import tfgridnet_oracle as TG
-    from wesep_amd.models import get_model
-    from wesep_amd.utils.losses import parse_loss
-    d = _cuda()
-    kw = dict(n_fft=128, stride=64, n_layers=3, lstm_hidden_units=192, attn_n_head=4, attn_approx_qk_dim=512, emb_dim=128,
-              emb_ks=1, emb_hs=1, use_spk_transform=False, spk_fuse_type="FiLM")
-    cfg = TG.TFGridNetConfig(**kw)
-    params = TG.synth_params(cfg, 37)
-    model = get_model("TFGridNet")(**kw, joint_training=False)
-    model.load_state_dict(params, strict=True)
-    model = model.to(d).train()
-    wav, tgt, emb = O.synth_batch(4, 32000, 37)
-    crit = parse_loss("SISDR")[0]
-    runs = {}
-    for tag, nrs in (("one", "1"), ("two", "2"), ("two again", "2")):      # (a model's first call is always one batch)
-        monkeypatch.setenv("WESEP_TFG_ROW_STREAMS", nrs)
-        model.zero_grad(set_to_none=True)
-        seen = []
-        real = model._run_blocks
-        monkeypatch.setattr(model, "_run_blocks", lambda h, e, geo: seen.append(geo[0]) or real(h, e, geo))
-        est, _ = model(wav.to(d), emb.to(d))
-        monkeypatch.setattr(model, "_run_blocks", real)
-        loss = crit(est, tgt.to(d))
-        loss.backward()
-        torch.cuda.synchronize()
-        assert seen == ([4] if nrs == "1" else [2, 2]), seen
-        runs[tag] = (est.detach().clone(), loss.item(), {k: p.grad.clone() for k, p in model.named_parameters()})
-    # rows are independent; the recurrence kernel FAMILY is chosen by the sequence count of a launch (16- / 32- / 64-sequence
-    # tiles), so the halves may take another summation order than the whole batch: equal to rounding, not to the bit
-    assert rel(runs["two"][0], runs["one"][0]) < 2e-5
-    assert torch.equal(runs["two again"][0], runs["two"][0])
-    assert all(torch.equal(runs["two again"][2][k], g) for k, g in runs["two"][2].items())
-    scale = max(float(g.norm()) for g in runs["one"][2].values())
-    for k, g in runs["one"][2].items():
-        assert float((runs["two"][2][k] - g).norm()) <= 1e-4 * float(g.norm()) + 1e-6 * scale, k
-    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    out = TG.tfgridnet_forward(p, cfg, wav, emb)
-    ref = out[0] if isinstance(out, (tuple, list)) else out
-    loss_o = O.sisdr_loss(ref, tgt)
-    loss_o.backward()
-    assert rel(runs["two"][0], ref) < 1e-3 and abs(runs["two"][1] - loss_o.item()) < 1e-2
-    worst, wname, bad = compare_grads(list(runs["two"][2].items()), {k: v.grad for k, v in p.items()}, GRAD_TOL)
-    print(f"row streams: est rel {rel(runs['two'][0], ref):.2e}, worst gradient rel-L2 vs oracle {worst:.2e} ({wname})")
-    assert not bad, bad[:8]

@@ -236,9 +236,6 @@ class _Fuse(nn.Module):
             self.fc = LinearLayer(embed_dim + feat_dim if fuse_type == "concat" else embed_dim, feat_dim)
 
 
-_ROW_STREAMS = {}     # device -> the row streams of TFGridNet._blocks_on_row_streams
-
-
 class TFGridNet(nn.Module):
     def __init__(self, n_srcs=1, sr=16000, n_fft=128, stride=64, window="hann", n_imics=1, n_layers=6,
                  lstm_hidden_units=192, attn_n_head=4, attn_approx_qk_dim=512, emb_dim=48, emb_ks=4, emb_hs=1,
@@ -300,43 +297,6 @@ class TFGridNet(nn.Module):
             h = blk(h, geo, prep)
         return h
 
-    def _row_streams(self, B, h):
-        """Row streams (round 4): the rows of a batch are independent through the block stack (per-row LayerNorms, no
-        batch statistics), and the inter-frame recurrences are latency chains on a fraction of the chip -- 1 501 dependent
-        steps on 68 (backward) / 144 (forward) of 256 CUs at the recipe's 8 rows.  Two halves of the batch on two HIP
-        streams put one half's recurrence beside the other half's GEMM / attention work.  WESEP_TFG_ROW_STREAMS (default 2;
-        1 = off); only on the blocked path, from 4 rows up, and not before the first plain call of this model has filled
-        the per-device tables."""
-        n = int(os.environ.get("WESEP_TFG_ROW_STREAMS", "2"))
-        C, ks, hs = self.blocks[0].emb_dim, self.blocks[0].emb_ks, self.blocks[0].emb_hs
-        warm = getattr(self, "_rs_warm", False)
-        self._rs_warm = True
-        if n < 2 or not h.is_cuda or not warm or B < 2 * n or B % n or not FG.blocked_path_ok(C, ks, hs):
-            return 1
-        return n
-
-    def _blocks_on_row_streams(self, h, emb, geo, n):
-        B, Tf, Fq = geo
-        cur = torch.cuda.current_stream()
-        key = (h.device.type, h.device.index)
-        streams = _ROW_STREAMS.setdefault(key, [])
-        while len(streams) < n:
-            streams.append(torch.cuda.Stream(device=h.device))
-        hs, es = h.view(B, -1).chunk(n), emb.chunk(n)
-        outs = []
-        for i in range(n):
-            s = streams[i]
-            s.wait_stream(cur)
-            with torch.cuda.stream(s):
-                hi = hs[i].reshape(-1, h.shape[1])
-                hi.record_stream(s)
-                es[i].record_stream(s)
-                outs.append(self._run_blocks(hi, es[i], (B // n, Tf, Fq)))
-        for o, s in zip(outs, streams[:n]):
-            cur.wait_stream(s)
-            o.record_stream(cur)
-        return torch.cat(outs, 0)
-
     def forward(self, input, embeddings):
         """input [B, N] mixture ([B, N, M] with n_imics = M > 1); embeddings [B, E] (fixed) or fbank / raw audio (joint)
         -> (est [B, N] or [B, n_srcs, N], dummy or logits) (tfgridnet.py:197-302)."""
@@ -382,8 +342,10 @@ class TFGridNet(nn.Module):
         emb = self.spk_transform(emb)
         if h.is_cuda:
             F_.reset_deferred_wgrads(h.device)
-        nrs = self._row_streams(B, h)
-        h = self._run_blocks(h, emb, (B, Tf, Fq)) if nrs == 1 else self._blocks_on_row_streams(h, emb, (B, Tf, Fq), nrs)
+        # (Two halves of the batch on two HIP streams -- one half's inter-frame recurrence beside the other half's GEMMs -- was
+        # built and measured in round 4: 516 ms instead of 325 ms per step at 8 rows, 761 ms with four quarters; the latency
+        # chains of the halves add up instead of overlapping.  DESIGN section 10.)
+        h = self._run_blocks(h, emb, (B, Tf, Fq))
         out = FD.ConvTranspose2dFn.apply(h, self.deconv.weight, self.deconv.bias, (B, Tf, Fq, 1, 1))   # [B*T*F, 2S]
         ld = -(-2 * Fq // 4) * 4
         est_spec = torch.zeros(B * S * Tf, ld, device=d, dtype=torch.float32)
