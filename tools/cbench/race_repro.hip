@@ -14,7 +14,7 @@
 //   a_*        2 048 dependent instructions of ONE kind per thread from inline asm: v_pk_fma_f32, v_pk_mul_f32,
 //              v_pk_add_f32, v_fma_f64, v_fma_f32 -- all operands in VGPRs;  s_*: the constant operand in SGPRs
 //
-//   race_repro [--trials 20] [--mask none|halves|interleave] [--aggr b2p|own1|own3|own5|own6|own7|copy|none]
+//   race_repro [--trials 20] [--mask none|halves|interleave] [--aggr b2p|clone<bits>|own1|own3|own5|own6|own7|copy|none]
 //              [--victims a,b,...] [--own-reps 400]
 //   own<bits>: aggressors defined here (bit 0 MFMA, bit 1 LDS staging + barriers, bit 2 global loads in the loop,
 //              bit 3 v_mov_b64 register moves in the loop)
@@ -34,6 +34,9 @@
 #include <vector>
 
 #include "../../include/wesep_hip.h"
+
+// gemm_b2p restated with one ingredient removable at a time (b2p_clone.hip, compiled with the library's flags)
+extern "C" int b2p_clone_launch(int flags, const ws_gemm_b2p_args* a, hipStream_t s);
 
 #define HIP_OK(x)                                                        \
   do {                                                                   \
@@ -467,6 +470,10 @@ int main(int argc, char** argv) {
   }
   auto aggressor = [&]() {
     if (aggr == "b2p") WS_OK_(ws_gemm_b2p(&g, s0));
+    if (aggr.rfind("clone", 0) == 0 && b2p_clone_launch(atoi(aggr.c_str() + 5), &g, s0)) {   // tools/cbench/b2p_clone.hip
+      fprintf(stderr, "aggressor %s: variant not built\n", aggr.c_str());
+      exit(4);
+    }
     if (aggr == "copy") hipLaunchKernelGGL(copy_kernel, dim3(1024), dim3(256), 0, s0, cpa, cpd, cpn, 1);
     const float4* osrc = reinterpret_cast<const float4*>(A);
     size_t on = 1;

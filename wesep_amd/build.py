@@ -86,10 +86,16 @@ def build_runtime(force=False, verbose=True):
                      "-Wl,-rpath,$ORIGIN/../../wesep_amd"])      # Python-free microbenchmark (tools/cbench)
     race_src = os.path.join(os.path.dirname(HERE), "tools", "cbench", "race_repro.hip")
     race_out = race_src[:-4]
-    if os.path.exists(race_src) and (force or _stale(race_out, [race_src, OUT, os.path.join(inc, "wesep_hip.h")])):
+    clone_src = os.path.join(os.path.dirname(race_src), "b2p_clone.hip")
+    if os.path.exists(race_src) and (force or _stale(race_out, [race_src, clone_src, OUT, os.path.join(inc, "wesep_hip.h")])):
         # standalone reproducer of the packed-FP32 disturbance (profiles/r03_kernel_race.md); its victims are meant to
-        # contain packed FP32 instructions, so it is NOT compiled with the library's NO_PACKED_FP32
-        cmds.append([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", race_src, "-o", race_out, "-L" + HERE,
+        # contain packed FP32 instructions, so it is NOT compiled with the library's NO_PACKED_FP32 -- the restated
+        # aggressor (b2p_clone.hip: gemm_b2p with one ingredient removable at a time) is, like the library itself
+        clone_obj = os.path.join(os.path.dirname(race_src), "b2p_clone.o")
+        cmds.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *NO_PACKED_FP32, "-c", clone_src, "-o", clone_obj])
+        race_obj = race_out + ".o"
+        cmds.append([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-c", race_src, "-o", race_obj])
+        cmds.append([hipcc, "--offload-arch=gfx950", race_obj, clone_obj, "-o", race_out, "-L" + HERE,
                      "-lwesep_hip", "-Wl,-rpath,$ORIGIN/../../wesep_amd"])
     for cmd in cmds:
         if verbose:
