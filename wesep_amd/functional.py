@@ -257,10 +257,17 @@ def flush_deferred_wgrads(device, ready=None):
     if not jobs:
         return
     side = _side_stream(device)
+    if ready is None:
+        ready = mark_wgrads_ready(device)
     with torch.cuda.stream(side):
+        # `ready` is a GATE, not only a dependency: it holds the jobs back until the kernels in front of the recurrence that
+        # was just launched have finished, so that the recurrence's workgroups and the jobs become runnable together and the
+        # recurrence (launched first) takes its CUs first.  Without it the jobs -- whose own operands were complete long ago
+        # -- fill the chip at once and the recurrence waits for a whole gemm_tnb wave: measured, step 127 -> 135.6 ms (pBSRNN),
+        # 305 -> 326 ms (TF-GridNet), profiles/r04_ab_runs.md
+        side.wait_event(ready)
         for job, done in jobs:
-            # each job waits for ITS producer stream (defer_wgrad); with one producer stream that event precedes `ready`
-            side.wait_event(done)
+            side.wait_event(done)        # the job's own producer stream (defer_wgrad); precedes `ready` on one stream
             job(side)
     jobs.clear()
 
