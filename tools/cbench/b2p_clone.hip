@@ -12,6 +12,12 @@
 //   bit 6 (64)   one MFMA per product instead of three
 //   bit 7 (128)  __launch_bounds__(512, 1) instead of (512, 2)
 //   bit 8 (256)  accumulators re-zeroed every stage and summed into one scalar (no long MFMA accumulation chains)
+//   bit 9 (512)  the LDS reads of the weight fragments in a bank-conflicting pattern (lane stride 17 cells) instead of the
+//                conflict-free contiguous one
+//   bit 10 (1024) the LDS reads stay but do not feed the MFMAs (their values go into a scalar; MFMA operands from registers)
+//   bit 11 (2048) no LDS WRITES inside the loop (the first stage's image is read over and over; the barrier stays)
+//   bit 12 (4096) long-lived workgroups: a grid of 2 x CUs workgroups that each repeat the main loop 48 times, instead of
+//                1 312 workgroups of ~50 us (no wave launch / retirement churn beside the victim)
 #include <hip/hip_runtime.h>
 
 #include "../../include/wesep_hip.h"
@@ -95,8 +101,10 @@ __device__ __forceinline__ void clone_body(const ws_gemm_b2p_args& p) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float side = 0.f;
 
+  const int nrep = (F & 4096) ? 48 : 1;
+  for (int rep = 0; rep < nrep; ++rep)
   for (int st = 0; st < nstage; ++st) {
-    const int cur = st & 1;
+    const int cur = (F & 2048) ? 0 : (st & 1);
     f32x4 ac[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) ac[q] = an[q];
@@ -133,9 +141,19 @@ __device__ __forceinline__ void clone_body(const ws_gemm_b2p_args& p) {
         if constexpr (F & 2) {  // no LDS: some fragment of the prefetch registers (the values do not matter here)
           bh = __builtin_bit_cast(bf16x8, wcur[nt]);
           bl = __builtin_bit_cast(bf16x8, wcur[(nt + ks) & 3]);
+        } else if constexpr (F & 512) {
+          const u32x4* base = &wl[cur][0];
+          bh = __builtin_bit_cast(bf16x8, base[(ks * 512 + (nt * 2) * 64 + lane * 17) & 2047]);
+          bl = __builtin_bit_cast(bf16x8, base[(ks * 512 + (nt * 2 + 1) * 64 + lane * 17 + 5) & 2047]);
         } else {
           bh = __builtin_bit_cast(bf16x8, wt[(nt * 2) * 64]);
           bl = __builtin_bit_cast(bf16x8, wt[(nt * 2 + 1) * 64]);
+        }
+        if constexpr (F & 1024) {
+          const u32x4 t0 = __builtin_bit_cast(u32x4, bh), t1 = __builtin_bit_cast(u32x4, bl);
+          side += __uint_as_float((t0[0] ^ t1[3]) & 0x3f7fffffu);      // the LDS values are consumed, but not by an MFMA
+          bh = __builtin_bit_cast(bf16x8, wcur[nt]);
+          bl = __builtin_bit_cast(bf16x8, wcur[(nt + ks) & 3]);
         }
         acc[nt] = prod<F>(ah, bh, acc[nt]);
         if constexpr (!(F & 64)) {
@@ -154,9 +172,11 @@ __device__ __forceinline__ void clone_body(const ws_gemm_b2p_args& p) {
         }
     }
     if constexpr (!(F & 2)) {
-      if (st + 1 < nstage) {
+      if constexpr (!(F & 2048)) {
+        if (st + 1 < nstage) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wl[cur ^ 1][tid + 512 * q] = wreg[q];
+          for (int q = 0; q < 4; ++q) wl[cur ^ 1][tid + 512 * q] = wreg[q];
+        }
       }
       __syncthreads();
     }
@@ -220,11 +240,14 @@ __global__ __launch_bounds__(512, 1) void clone1(const ws_gemm_b2p_args p) {
 // variants built (flag sets without bit 7; bit 7 selects the launch bounds)
 #define CLONE_VARIANTS(X) \
   X(0) X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(256) X(12) X(3) X(17) X(18) X(20) X(24) X(28) X(30) X(31) X(48) X(80) X(272) X(19) \
-  X(6) X(10) X(14) X(22) X(26) X(92) X(124) X(380) X(348) X(316)
+  X(6) X(10) X(14) X(22) X(26) X(92) X(124) X(380) X(348) X(316) \
+  X(540) X(1052) X(2076) X(4124) X(6172) X(4096) X(4112) X(2064) X(1040) X(528) X(7196) X(5148) X(3100) X(4126)
 
 extern "C" int b2p_clone_launch(int flags, const ws_gemm_b2p_args* a, hipStream_t s) {
   const int nblk = ((a->sm.nseq + 31) / 32) * a->sm.L;
-  const dim3 grid((nblk + 7) / 8), block(512);
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+  const dim3 grid((flags & 4096) ? 2 * cus : (nblk + 7) / 8), block(512);
   const int f = flags & ~128;
 #define X(F)                                                                   \
   if (f == F) {                                                                \
