@@ -263,7 +263,7 @@ template <int WHAT>
 __global__ void __launch_bounds__(512, 2) own_aggr(const float4* __restrict__ src, float* __restrict__ dst, size_t n,
                                                    int reps) {
   __shared__ float4 stage[4096];
-  f32x16_t acc0 = {}, acc1 = {};
+  f32x16_t acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
   const int t = threadIdx.x;
   size_t i = ((size_t)blockIdx.x * 512 + t) & (n - 1);  // n is a power of two
   float4 u = {1.f + t, 2.f, 3.f, 4.f}, v = {4.f, 3.f, 2.f, 1.f + t};
@@ -298,6 +298,18 @@ __global__ void __launch_bounds__(512, 2) own_aggr(const float4* __restrict__ sr
         __builtin_memcpy(&b, &v, 16);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc1, 0, 0, 0);
+        if (WHAT & 16) {  // gemm_b2p's density: four accumulator tiles x three dependent MFMAs per pair of LDS reads
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc3, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, acc2, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, acc3, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, acc2, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, acc3, 0, 0, 0);
+        }
       } else {
         acc0[j] += u.x * v.y;
       }
@@ -316,7 +328,7 @@ __global__ void __launch_bounds__(512, 2) own_aggr(const float4* __restrict__ sr
     if (WHAT & 2) __syncthreads();
   }
   float s = u.x + v.y;
-  for (int k = 0; k < 16; ++k) s += acc0[k] + acc1[k];
+  for (int k = 0; k < 16; ++k) s += acc0[k] + acc1[k] + acc2[k] + acc3[k];
   dst[(size_t)blockIdx.x * 512 + t] = s;
 }
 
@@ -486,6 +498,9 @@ int main(int argc, char** argv) {
     if (aggr == "own9") hipLaunchKernelGGL(own_aggr<9>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
     if (aggr == "own15") hipLaunchKernelGGL(own_aggr<15>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
     if (aggr == "own7") hipLaunchKernelGGL(own_aggr<7>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
+    if (aggr == "own19") hipLaunchKernelGGL(own_aggr<19>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
+    if (aggr == "own17") hipLaunchKernelGGL(own_aggr<17>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
+    if (aggr == "own23") hipLaunchKernelGGL(own_aggr<23>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
   };
   std::vector<float> cref;
   if (aggr != "none") {
