@@ -298,7 +298,29 @@ __global__ void __launch_bounds__(512, 2) own_aggr(const float4* __restrict__ sr
         __builtin_memcpy(&b, &v, 16);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc1, 0, 0, 0);
-        if (WHAT & 16) {  // gemm_b2p's density: four accumulator tiles x three dependent MFMAs per pair of LDS reads
+        if (WHAT & 32) {  // gemm_b2p's LDS : MFMA ratio -- a fresh pair of 128-bit LDS reads in front of EVERY group of three
+          // MFMAs (eight reads per twelve MFMAs), four accumulator tiles
+          float4 u2 = stage[(j * 256 + t * 17 + 64) & 4095], v2 = stage[(j * 256 + t * 33 + 71) & 4095];
+          float4 u3 = stage[(j * 256 + t * 17 + 128) & 4095], v3 = stage[(j * 256 + t * 33 + 135) & 4095];
+          float4 u4 = stage[(j * 256 + t * 17 + 192) & 4095], v4 = stage[(j * 256 + t * 33 + 199) & 4095];
+          bf16x8_t a2, b2, a3, b3, a4, b4;
+          __builtin_memcpy(&a2, &u2, 16);
+          __builtin_memcpy(&b2, &v2, 16);
+          __builtin_memcpy(&a3, &u3, 16);
+          __builtin_memcpy(&b3, &v3, 16);
+          __builtin_memcpy(&a4, &u4, 16);
+          __builtin_memcpy(&b4, &v4, 16);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, a2, acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b3, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a3, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, a3, acc2, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a4, b4, acc3, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b4, a4, acc3, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a4, a4, acc3, 0, 0, 0);
+        } else if (WHAT & 16) {  // gemm_b2p's density: four accumulator tiles x three dependent MFMAs per pair of LDS reads
           acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
           acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc3, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, acc0, 0, 0, 0);
@@ -501,6 +523,8 @@ int main(int argc, char** argv) {
     if (aggr == "own19") hipLaunchKernelGGL(own_aggr<19>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
     if (aggr == "own17") hipLaunchKernelGGL(own_aggr<17>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
     if (aggr == "own23") hipLaunchKernelGGL(own_aggr<23>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
+    if (aggr == "own35") hipLaunchKernelGGL(own_aggr<35>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
+    if (aggr == "own39") hipLaunchKernelGGL(own_aggr<39>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
   };
   std::vector<float> cref;
   if (aggr != "none") {
