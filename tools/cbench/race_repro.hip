@@ -481,6 +481,17 @@ int main(int argc, char** argv) {
   float *Cagg = nullptr, *Cref = nullptr;
   HIP_OK(hipMalloc(reinterpret_cast<void**>(&Cagg), pos * N * 4));
   WS_OK_(ws_pack_w(W, N, K, K, 0, 1, Wp, s0));
+  // --data zero|ones: the aggressor's operands (A and the packed weights) all zero bits / all bf16 1.0 instead of random values
+  // (same instruction stream, no toggling in the MFMA / LDS data paths): is the disturbance data- (= power-) dependent?
+  const std::string adata = get("--data", "random");
+  if (adata != "random") {
+    HIP_OK(hipStreamSynchronize(s0));
+    const int byte = adata == "zero" ? 0 : 0x3f;     // 0x3f3f3f3f: bf16 pairs 0x3f3f = 0.746 (a constant, non-zero pattern)
+    HIP_OK(hipMemset(A, byte, pos * K * 4));
+    HIP_OK(hipMemset(Wp, byte, (size_t)N * K * 4));
+    HIP_OK(hipMemset(Rres, 0, pos * N * 4));
+    HIP_OK(hipDeviceSynchronize());
+  }
   ws_gemm_b2p_args g = {};
   g.A = A, g.Wpack = Wp, g.bias = bias, g.R = Rres, g.C = Cagg;
   g.sm.nseq = nseq, g.sm.L = L, g.sm.sq_div = 1 << 30, g.sm.sq_s1 = 0, g.sm.sq_s2 = L, g.sm.step_rows = 1;
