@@ -17,6 +17,8 @@
 //   bit 10 (1024) the LDS reads stay but do not feed the MFMAs (their values go into a scalar; MFMA operands from registers)
 //   bit 11 (2048) no LDS WRITES inside the loop (the first stage's image is read over and over; the barrier stays)
 //   bit 13 (8192) ONE accumulator tile instead of four (a quarter of the MFMAs per LDS read and of the accumulator registers)
+//   bit 14 (16384) with bit 13: the single tile's work four times over (the MFMA and LDS-read COUNT of four tiles, the register
+//                footprint of one);   bit 15 (32768) TWO accumulator tiles
 //   bit 12 (4096) long-lived workgroups: a grid of 2 x CUs workgroups that each repeat the main loop 48 times, instead of
 //                1 312 workgroups of ~50 us (no wave launch / retirement churn beside the victim)
 #include <hip/hip_runtime.h>
@@ -137,7 +139,8 @@ __device__ __forceinline__ void clone_body(const ws_gemm_b2p_args& p) {
       }
       const u32x4* wt = &wl[cur][ks * 512 + lane];
 #pragma unroll
-      for (int nt = 0; nt < ((F & 8192) ? 1 : 4); ++nt) {
+      for (int nt4 = 0; nt4 < ((F & 16384) ? 4 : ((F & 8192) ? 1 : ((F & 32768) ? 2 : 4))); ++nt4) {
+        const int nt = (F & 16384) ? 0 : nt4;
         bf16x8 bh, bl;
         if constexpr (F & 2) {  // no LDS: some fragment of the prefetch registers (the values do not matter here)
           bh = __builtin_bit_cast(bf16x8, wcur[nt]);
@@ -147,8 +150,8 @@ __device__ __forceinline__ void clone_body(const ws_gemm_b2p_args& p) {
           bh = __builtin_bit_cast(bf16x8, base[(ks * 512 + (nt * 2) * 64 + lane * 17) & 2047]);
           bl = __builtin_bit_cast(bf16x8, base[(ks * 512 + (nt * 2 + 1) * 64 + lane * 17 + 5) & 2047]);
         } else {
-          bh = __builtin_bit_cast(bf16x8, wt[(nt * 2) * 64]);
-          bl = __builtin_bit_cast(bf16x8, wt[(nt * 2 + 1) * 64]);
+          bh = __builtin_bit_cast(bf16x8, wt[(nt4 * 2) * 64]);
+          bl = __builtin_bit_cast(bf16x8, wt[(nt4 * 2 + 1) * 64]);
         }
         if constexpr (F & 1024) {
           const u32x4 t0 = __builtin_bit_cast(u32x4, bh), t1 = __builtin_bit_cast(u32x4, bl);
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void clone1(const ws_gemm_b2p_args p) {
 #define CLONE_VARIANTS(X) \
   X(0) X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(256) X(12) X(3) X(17) X(18) X(20) X(24) X(28) X(30) X(31) X(48) X(80) X(272) X(19) \
   X(6) X(10) X(14) X(22) X(26) X(92) X(124) X(380) X(348) X(316) \
-  X(540) X(1052) X(2076) X(4124) X(6172) X(4096) X(4112) X(2064) X(1040) X(528) X(7196) X(5148) X(3100) X(4126) X(8220) X(12316) X(8284) X(12380)
+  X(540) X(1052) X(2076) X(4124) X(6172) X(4096) X(4112) X(2064) X(1040) X(528) X(7196) X(5148) X(3100) X(4126) X(8220) X(12316) X(8284) X(12380) X(24604) X(28700) X(32796) X(36892)
 
 extern "C" int b2p_clone_launch(int flags, const ws_gemm_b2p_args* a, hipStream_t s) {
   const int nblk = ((a->sm.nseq + 31) / 32) * a->sm.L;
