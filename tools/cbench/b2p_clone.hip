@@ -19,6 +19,8 @@
 //   bit 13 (8192) ONE accumulator tile instead of four (a quarter of the MFMAs per LDS read and of the accumulator registers)
 //   bit 14 (16384) with bit 13: the single tile's work four times over (the MFMA and LDS-read COUNT of four tiles, the register
 //                footprint of one);   bit 15 (32768) TWO accumulator tiles
+//   bit 16 (65536) with bit 11: no barrier inside the loop either;   bit 17 (131072) the A operand's fragments from LDS as well
+//                (both MFMA operands are fresh LDS reads, as in race_repro's own_aggr)
 //   bit 12 (4096) long-lived workgroups: a grid of 2 x CUs workgroups that each repeat the main loop 48 times, instead of
 //                1 312 workgroups of ~50 us (no wave launch / retirement churn beside the victim)
 #include <hip/hip_runtime.h>
@@ -138,6 +140,10 @@ __device__ __forceinline__ void clone_body(const ws_gemm_b2p_args& p) {
         unpack8(__builtin_bit_cast(u32x4, ac[2 * ks]), __builtin_bit_cast(u32x4, ac[2 * ks + 1]), ah, al);
       }
       const u32x4* wt = &wl[cur][ks * 512 + lane];
+      if constexpr (F & 131072) {
+        ah = __builtin_bit_cast(bf16x8, wt[((ks + 1) & 3) * 64]);
+        al = __builtin_bit_cast(bf16x8, wt[((ks + 2) & 3) * 64 + 256]);
+      }
 #pragma unroll
       for (int nt4 = 0; nt4 < ((F & 16384) ? 4 : ((F & 8192) ? 1 : ((F & 32768) ? 2 : 4))); ++nt4) {
         const int nt = (F & 16384) ? 0 : nt4;
@@ -182,7 +188,7 @@ __device__ __forceinline__ void clone_body(const ws_gemm_b2p_args& p) {
           for (int q = 0; q < 4; ++q) wl[cur ^ 1][tid + 512 * q] = wreg[q];
         }
       }
-      __syncthreads();
+      if constexpr (!((F & 65536) && (F & 2048))) __syncthreads();
     }
   }
 
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(512, 1) void clone1(const ws_gemm_b2p_args p) {
 #define CLONE_VARIANTS(X) \
   X(0) X(1) X(2) X(4) X(8) X(16) X(32) X(64) X(256) X(12) X(3) X(17) X(18) X(20) X(24) X(28) X(30) X(31) X(48) X(80) X(272) X(19) \
   X(6) X(10) X(14) X(22) X(26) X(92) X(124) X(380) X(348) X(316) \
-  X(540) X(1052) X(2076) X(4124) X(6172) X(4096) X(4112) X(2064) X(1040) X(528) X(7196) X(5148) X(3100) X(4126) X(8220) X(12316) X(8284) X(12380) X(24604) X(28700) X(32796) X(36892)
+  X(540) X(1052) X(2076) X(4124) X(6172) X(4096) X(4112) X(2064) X(1040) X(528) X(7196) X(5148) X(3100) X(4126) X(8220) X(12316) X(8284) X(12380) X(24604) X(28700) X(32796) X(36892) X(67612) X(71708) X(135196) X(133148) X(202780) X(198684)
 
 extern "C" int b2p_clone_launch(int flags, const ws_gemm_b2p_args* a, hipStream_t s) {
   const int nblk = ((a->sm.nseq + 31) / 32) * a->sm.L;
