@@ -189,6 +189,7 @@ __device__ __forceinline__ void clone_body(const ws_gemm_b2p_args& p) {
         }
       }
       if constexpr (!((F & 65536) && (F & 2048))) __syncthreads();
+      else asm volatile("" ::: "memory");   // no s_barrier, but the LDS reads must stay inside the loop
     }
   }
 
