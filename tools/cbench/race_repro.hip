@@ -523,7 +523,9 @@ int main(int argc, char** argv) {
     const float4* osrc = reinterpret_cast<const float4*>(A);
     size_t on = 1;
     while (on * 2 <= pos * K / 4) on *= 2;
-    const dim3 og(2 * ncu), ob(512);
+    // --own-wpc N: own_aggr workgroups per CU in the grid (default 2 = the kernel's launch bounds; with 1, half of every CU's
+    // registers and wave slots stay free for the victim whatever the aggressor's register count)
+    const dim3 og(atoi(get("--own-wpc", "2").c_str()) * ncu), ob(512);
     if (aggr == "own1") hipLaunchKernelGGL(own_aggr<1>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
     if (aggr == "own3") hipLaunchKernelGGL(own_aggr<3>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
     if (aggr == "own5") hipLaunchKernelGGL(own_aggr<5>, og, ob, 0, s0, osrc, Cagg, on, own_reps);

@@ -10,8 +10,8 @@ out=gpurun_out/r04_race_bisect.txt
 V=${VICTIMS:-o_pk_add}
 for a in "${@:-b2p clone0 clone1 clone2 clone4 clone8 clone16 clone32 clone64 clone256 clone128 clone12 clone3 clone17 clone18 clone20 clone24 clone28 clone30 clone31 own15}"; do
   for v in $a; do
-    echo "== --aggr $v ${DATA:+--data $DATA}" >> $out
-    timeout 120 tools/cbench/race_repro --trials ${TRIALS:-6} --aggr $v --victims $V ${DATA:+--data $DATA} 2>&1 | grep -v "^# shader" >> $out
+    echo "== --aggr $v ${DATA:+--data $DATA} ${OWNWPC:+--own-wpc $OWNWPC}" >> $out
+    timeout 120 tools/cbench/race_repro --trials ${TRIALS:-6} --aggr $v --victims $V ${DATA:+--data $DATA} ${OWNWPC:+--own-wpc $OWNWPC} 2>&1 | grep -v "^# shader" >> $out
     echo "exit $?" >> $out
   done
 done
