@@ -311,6 +311,18 @@ __global__ void __launch_bounds__(512, 2) own_aggr(const float4* __restrict__ sr
           __builtin_memcpy(&a4, &u4, 16);
           __builtin_memcpy(&b4, &v4, 16);
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, acc0, 0, 0, 0);
+          if (WHAT & 64) {  // the FIRST MFMA of a group needs only the first read of its pair: it issues while the second
+            // 128-bit LDS read is still in flight (s_waitcnt lgkmcnt(1)), as in gemm_b2p's loop
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, a2, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, a3, acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b3, acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a3, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a4, a4, acc3, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a4, b4, acc3, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b4, a4, acc3, 0, 0, 0);
+          } else {
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc1, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2, acc1, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, a2, acc1, 0, 0, 0);
@@ -320,6 +332,7 @@ __global__ void __launch_bounds__(512, 2) own_aggr(const float4* __restrict__ sr
           acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a4, b4, acc3, 0, 0, 0);
           acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b4, a4, acc3, 0, 0, 0);
           acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a4, a4, acc3, 0, 0, 0);
+          }
         } else if (WHAT & 16) {  // gemm_b2p's density: four accumulator tiles x three dependent MFMAs per pair of LDS reads
           acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
           acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc3, 0, 0, 0);
@@ -538,6 +551,7 @@ int main(int argc, char** argv) {
     if (aggr == "own23") hipLaunchKernelGGL(own_aggr<23>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
     if (aggr == "own35") hipLaunchKernelGGL(own_aggr<35>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
     if (aggr == "own39") hipLaunchKernelGGL(own_aggr<39>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
+    if (aggr == "own99") hipLaunchKernelGGL(own_aggr<99>, og, ob, 0, s0, osrc, Cagg, on, own_reps);
   };
   std::vector<float> cref;
   if (aggr != "none") {
