@@ -116,3 +116,23 @@ def test_standalone_reproducer_still_shows_the_hardware_behaviour():
     assert " 0 of 4 trials" in lines["a_pk_add"] and " 0 of 4 trials" in lines["ring_step"], r.stdout
     if " 0 of 4 trials" in lines["o_pk_add"]:
         pytest.xfail("op_sel victim clean on this box: the platform behaviour did not reproduce here")
+
+
+def test_standalone_aggressor_pair_differs_by_one_wait_count():
+    """Documents round 4's finding on the aggressor side (profiles/r04_kernel_race.md): two from-scratch kernels of the
+    reproducer that differ only in the order of three MFMAs -- own35 waits lgkmcnt(0) before the first MFMA of a group,
+    own99 issues it while the second ds_read_b128 is still in flight -- leave the op_sel victim intact / disturb it.
+    Documentary: xfail when the platform behaviour does not show on a box."""
+    _cuda()
+    exe = os.path.join(ROOT, "tools", "cbench", "race_repro")
+    if not os.path.exists(exe):
+        pytest.skip("tools/cbench/race_repro not built")
+    out = {}
+    for aggr in ("own35", "own99"):
+        r = subprocess.run([exe, "--trials", "4", "--aggr", aggr, "--victims", "o_pk_add"], capture_output=True, text=True,
+                           timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[aggr] = next(ln for ln in r.stdout.splitlines() if ln.startswith("o_pk_add"))
+    assert " 0 of 4 trials" in out["own35"], out
+    if " 0 of 4 trials" in out["own99"]:
+        pytest.xfail("own99 did not disturb the op_sel victim on this box")
