@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 15
+#define WS_ABI_VERSION 16
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -401,6 +401,8 @@ typedef struct ws_gemm_p2b_args {
   const unsigned* run_if;   /* optional device word: the launch does nothing unless *run_if != 0 */
   unsigned* amax;           /* optional device word (ABI v15): raised (atomic max on the float bits) to max |C| of this
                                launch; the caller zeroes it.  The scale source of WS_GATES_H2F                     */
+  void* A_bl16;             /* optional (ABI v16): the (normalised) operand once more as fp16 elements in BLH(K) -- the
+                               2-byte A operand of ws_gemm_tnb (a_fmt = 1)                                          */
 } ws_gemm_p2b_args;
 int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream);
 
@@ -419,6 +421,8 @@ typedef struct ws_gemm_b2p_args {
                         2 = A holds scaled fp16 elements (BLH(K)): d(gates) of WS_GATES_H2F, scale from `amax`; Wpack
                         is then a ws_pack_w_f16 pack                                                              */
   const unsigned* amax;
+  void* a16_out;     /* optional (ABI v16, a_fmt 0 only): the A operand once more as fp16 elements in BLH(K) -- every block
+                        is read by exactly one wave here, so the copy costs no extra read (hcat -> ws_gemm_tnb a_fmt = 1) */
 } ws_gemm_b2p_args;
 int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream);
 
@@ -445,6 +449,9 @@ typedef struct ws_gemm_tnb_args {
   int g_fmt;         /* ABI v15: 0 = G holds BLS pairs; 1 = G holds bf16 elements (BLH(g_width)): d(gates) of WS_GATES_H2;
                         2 = scaled fp16 elements: d(gates) of WS_GATES_H2F, scale from `amax` (slab / bslab come out unscaled) */
   const unsigned* amax;
+  int a_fmt, pad_;   /* ABI v16: 0 = A0 / A1 hold BLS pairs; 1 = fp16 elements (BLH(a0_width) / BLH(a1_width)), g_fmt = 2 only:
+                        scaled-fp16 G times fp16 A is ONE v_mfma_f32_32x32x16_f16 per product, and a workgroup loads 32 KB
+                        per block instead of 56 (the kernel is bound by the CU's global-load issue rate)                */
 } ws_gemm_tnb_args;
 int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream);
 

@@ -108,7 +108,7 @@ def dgates_scale(amax):
 
 
 def gemm_p2b(*, A, lda, sm, Wpack, N, C_out, K=128, bias=None, A_bl=None, stats=None, gamma=None, beta=None,
-             stat_map=None, run_if=None, amax=None):
+             stat_map=None, run_if=None, amax=None, A_bl16=None):
     if _skip(run_if):
         return
     nt, L = _ntile(sm), sm.L
@@ -122,6 +122,8 @@ def gemm_p2b(*, A, lda, sm, Wpack, N, C_out, K=128, bias=None, A_bl=None, stats=
     rows = rows * _valid(sm)
     if A_bl is not None:
         bl_put(A_bl, rows, nt, L, K)
+    if A_bl16 is not None:                 # ABI v16: the operand once more as fp16 in BLH(K)
+        blh_put(A_bl16, rows, nt, L, K, torch.float16)
     if N:
         out = rows @ _PACKS[Wpack.data_ptr()].t()
         if bias is not None:
@@ -139,8 +141,11 @@ def _g16(buf, nt, L, C, fmt, amax):
     return blh_get(buf, nt, L, C, torch.float16).float() / dgates_scale(amax)
 
 
-def gemm_b2p(*, A, K, sm, Wpack, C_out, ldc, N=128, bias=None, R=None, a_fmt=0, amax=None):
+def gemm_b2p(*, A, K, sm, Wpack, C_out, ldc, N=128, bias=None, R=None, a_fmt=0, amax=None, a16_out=None):
     nt, L = _ntile(sm), sm.L
+    if a16_out is not None:                # ABI v16: the split-pair A operand once more as fp16 in BLH(K)
+        assert a_fmt == 0
+        blh_put(a16_out, bl_get(A, nt, L, K), nt, L, K, torch.float16)
     x = (_g16(A, nt, L, K, a_fmt, amax) if a_fmt else bl_get(A, nt, L, K))[: _nv(sm)]
     out = x @ _PACKS[Wpack.data_ptr()].t()
     if bias is not None:
@@ -291,11 +296,13 @@ def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm, gfmt=0):
 
 
 def gemm_tnb(*, G, g_width, g_off, g_cols, A0, a0_width, a0_off, a0_cols, nblk, L_, slab, nsplit, blocks_per_split,
-             a0_shift=0, A1=None, a1_width=0, a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, g_fmt=0, amax=None):
+             a0_shift=0, A1=None, a1_width=0, a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, g_fmt=0, amax=None,
+             a_fmt=0):
     nt = nblk // L_
+    assert a_fmt == 0 or (g_fmt == 2 and aslab is None)
 
     def shifted(buf, width, off, cols, shift):
-        x = bl_get(buf, nt, L_, width)[:, :, off:off + cols]
+        x = (blh_get(buf, nt, L_, width, torch.float16).float() if a_fmt else bl_get(buf, nt, L_, width))[:, :, off:off + cols]
         out = torch.zeros_like(x)
         if shift == 0:
             return x

@@ -334,3 +334,106 @@ def test_resrnn_formats_agree(view, fmt, monkeypatch):
     assert rel(b[1], a[1]) <= tol
     for k in a[2]:
         assert rel(b[2][k], a[2][k]) <= tol, k
+
+
+# ---- ABI v16: fp16 copies of the weight-gradient GEMM's A operand [xn | h] -----------------------------------------------
+@pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37))])
+def test_fp16_operand_copies_of_p2b_and_b2p(view, dims):
+    """ws_gemm_p2b's A_bl16 = fp16 of the (GroupNorm-on-load) operand it also emits as split pairs; ws_gemm_b2p's a16_out =
+    fp16 of its split-pair A operand, bit for bit; neither changes the GEMM's own result."""
+    from wesep_amd import dev
+    from wesep_amd.functional import _view_maps
+    d = _cuda()
+    g = torch.Generator().manual_seed(8)
+    R, K, Tf = dims
+    P = R * K * Tf
+    geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+    nb = dev.bl_num_blocks(seq)
+    z = rnd(g, P, N).to(d)
+    stats = torch.empty(geo.ngroups, 2, device=d)
+    dev.group_stats(z.view(R, K, Tf, N), geo, stats)
+    gamma, beta = (1.0 + 0.1 * rnd(g, N)).to(d), (0.1 * rnd(g, N)).to(d)
+    W = rnd(g, 256, N, scale=0.05).to(d)
+    wp = torch.empty(256 * N, device=d)
+    dev.pack_w(W, 256, N, N, wp, order=0)
+    outs = []
+    for with16 in (False, True):
+        C_, xn = torch.full((nb, 32 * 256), float("nan"), device=d), torch.full((nb, 32 * N), float("nan"), device=d)
+        xn16 = torch.full((dev.blh_floats(nb, N),), float("nan"), device=d) if with16 else None
+        dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=wp, N=256, C_out=C_, A_bl=xn, stats=stats, gamma=gamma, beta=beta, stat_map=smap,
+                     A_bl16=xn16)
+        outs.append((C_, xn, xn16))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32))
+    v = dev.bls_unpack(outs[1][1]).view(nb, N // 4, 32, 4)              # the operand as the kernel emitted it (hi + lo)
+    a16 = dev.blh_f16_unpack(outs[1][2], nb, N)
+    # fp16 of the fp32 operand; the split pair carries 16 of its 24 bits, so compare to rounding, not to the bit
+    assert float((a16 - v).abs().max()) <= 2.0 ** -11 * float(v.abs().max()) + 1e-7
+    assert float((a16 - v.half().float()).abs().max()) <= 2.0 ** -10 * float(v.abs().max())
+    # b2p: hcat-shaped operand (K = 512), its fp16 copy bit for bit
+    h = torch.tanh(rnd(g, P, 2 * H)).to(d)
+    hb = dev.to_blocked(h, seq, split=True)
+    Wp_ = rnd(g, N, 2 * H, scale=0.05).to(d)
+    wpp = torch.empty(N * 2 * H, device=d)
+    dev.pack_w(Wp_, N, 2 * H, 2 * H, wpp, order=1)
+    res = []
+    for with16 in (False, True):
+        out = torch.full((P, N), float("nan"), device=d)
+        h16 = torch.full((dev.blh_floats(nb, 2 * H),), float("nan"), device=d) if with16 else None
+        dev.gemm_b2p(A=hb, K=2 * H, sm=seq, Wpack=wpp, C_out=out, ldc=N, a16_out=h16)
+        res.append((out, h16))
+    torch.cuda.synchronize()
+    assert torch.equal(res[0][0], res[1][0])
+    want = dev.blh_f16_pack(dev.bls_unpack(hb).view(nb, 2 * H // 4, 32, 4))
+    assert torch.equal(res[1][1].view(torch.int32)[: want.numel()], want.reshape(-1).view(torch.int32))
+
+
+@pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37)), ("time", (2, 32, 70))])
+def test_gemm_tnb_fp16_a_operand(view, dims):
+    """ws_gemm_tnb with a_fmt = 1: scaled-fp16 G times fp16 A0 / A1 (one MFMA per product) against the same values as
+    split pairs (a_fmt 0: the values are on the fp16 grid, so both forms hold them exactly) and against fp64."""
+    from wesep_amd import dev
+    from wesep_amd.functional import _view_maps
+    d = _cuda()
+    g = torch.Generator().manual_seed(9)
+    R, K, Tf = dims
+    P, GW = R * K * Tf, 2048
+    geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
+    nb = dev.bl_num_blocks(seq)
+    G = rnd(g, P, GW).to(torch.bfloat16).float()
+    A0, A1 = rnd(g, P, N).half().float(), torch.tanh(rnd(g, P, 2 * H)).half().float()
+    Gbl = dev.to_blocked(G.to(d), seq)
+    A0bl, A1bl = dev.to_blocked(A0.to(d), seq), dev.to_blocked(A1.to(d), seq)
+    amax = torch.tensor([2.7e-6], dtype=torch.float32).view(torch.int32).to(d)
+    S = 2.0 ** (264 - ((int(amax.item()) >> 23) & 0xFF) - 127)
+    tiny = 2.0 ** -20
+    G_f16 = (Gbl * (tiny * S)).to(torch.float16).contiguous().view(torch.float32)
+    forms = {0: (dev.bls_pack(A0bl), dev.bls_pack(A1bl)), 1: (dev.blh_f16_pack(A0bl), dev.blh_f16_pack(A1bl))}
+    for di, shift in ((0, -1), (1, 1)):
+        ns, bps = dev.tnb_splits(nb, 8)
+        outs = {}
+        for a_fmt in (0, 1, 1):
+            slab, bslab = torch.full((ns, 1024 * 384), float("nan"), device=d), torch.full((ns, 1024), float("nan"), device=d)
+            dev.gemm_tnb(G=G_f16, g_width=GW, g_off=di * 1024, g_cols=1024, A0=forms[a_fmt][0], a0_width=N, a0_off=0, a0_cols=N,
+                         A1=forms[a_fmt][1], a1_width=2 * H, a1_off=di * H, a1_cols=H, a1_shift=shift, nblk=nb, L_=seq.L,
+                         slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab, g_fmt=2, amax=amax, a_fmt=a_fmt)
+            if a_fmt in outs:
+                assert torch.equal(outs[a_fmt][0], slab) and torch.equal(outs[a_fmt][1], bslab)     # reproducible
+            outs[a_fmt] = (slab, bslab)
+        torch.cuda.synchronize()
+        assert rel(outs[1][0].sum(0), outs[0][0].sum(0)) < 2e-6
+        assert rel(outs[1][1].sum(0), outs[0][1].sum(0)) < 1e-6
+        pos, valid = dev.bl_positions(seq, torch.device("cpu"))
+        nt = -(-seq.nseq // 32)
+        posv, val = pos.view(nt, seq.L, 32), valid.view(nt, seq.L, 32)
+        A1s = torch.zeros(P, H)
+        src = torch.roll(posv, shifts=-shift, dims=1)
+        ok = val.clone()
+        if shift == -1:
+            ok[:, 0] = False
+        else:
+            ok[:, -1] = False
+        A1s[posv[ok]] = A1[src[ok]][:, di * H:(di + 1) * H]
+        Gs = G[:, di * 1024:(di + 1) * 1024].double() * tiny
+        ref = torch.cat([Gs.t() @ A0.double(), Gs.t() @ A1s.double()], 1)
+        assert rel(outs[1][0].sum(0).view(1024, 384), ref) < 4e-5

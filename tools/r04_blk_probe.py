@@ -57,6 +57,15 @@ def main():
             gb = (nb * 32 * 1024 * (4 if fmt == 0 else 2) + nb * 32 * (N + H) * 4) / 1e9
             print(f"tnb  {view} g_fmt={fmt} f16_mfma={f16mm if fmt == 2 else '-'} gdepth={os.environ.get('WS_TNB_GDEPTH', '4')}: {t:7.3f} ms  {gb / t * 1e3:7.0f} GB/s unique  "
                   f"nsplit={ns}", flush=True)
+        # a_fmt = 1 (ABI v16): fp16 copies of [xn | h] -- one MFMA per product, 32 instead of 56 KB loaded per block
+        xn16 = dev.blh_f16_pack(torch.randn(nb, N // 4, 32, 4, device=d))
+        h16 = dev.blh_f16_pack(torch.tanh(torch.randn(nb, 2 * H // 4, 32, 4, device=d)))
+        t = timeit(lambda: dev.gemm_tnb(G=G[2], g_width=2048, g_off=0, g_cols=1024, A0=xn16, a0_width=N, a0_off=0, a0_cols=N,
+                                        A1=h16, a1_width=2 * H, a1_off=0, a1_cols=H, a1_shift=-1, nblk=nb, L_=seq.L, slab=slab,
+                                        nsplit=ns, blocks_per_split=bps, bslab=bslab, g_fmt=2, amax=amax, a_fmt=1), a.reps)
+        gb = (nb * 32 * 1024 * 2 + nb * 32 * (N + H) * 2) / 1e9
+        print(f"tnb  {view} g_fmt=2 a_fmt=1 (fp16 A): {t:7.3f} ms  {gb / t * 1e3:7.0f} GB/s unique  nsplit={ns}", flush=True)
+        del xn16, h16
         W = torch.randn(N, 2048, device=d) * 0.05
         wp = torch.empty(N * 2048, device=d)
         dev.pack_w(W.t().contiguous(), N, 2048, N, wp, trans=True, order=1)

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 15
+ABI_VERSION = 16
 GATES_F32, GATES_H2, GATES_H2S, GATES_H2F = 0, 1, 2, 3     # WS_GATES_* (wesep_hip.h): storage of the saved gates / d(gates)
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
@@ -89,12 +89,12 @@ class SeqMapC(C.Structure):
 class GemmP2BArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("A", "Wpack", "bias", "C", "A_bl", "stats", "gamma", "beta")] + \
                [("sm", SeqMapC)] + [(n, _ll) for n in ("lda", "st_m1", "st_m2", "st_base")] + \
-               [(n, _i) for n in ("st_div1", "st_div2", "N", "K")] + [("run_if", _p), ("amax", _p)]
+               [(n, _i) for n in ("st_div1", "st_div2", "N", "K")] + [("run_if", _p), ("amax", _p), ("A_bl16", _p)]
 
 
 class GemmB2PArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("A", "Wpack", "bias", "R", "C")] + [("sm", SeqMapC), ("ldc", _ll), ("N", _i), ("K", _i),
-                                                                         ("a_fmt", _i), ("pad_", _i), ("amax", _p)]
+                                                                         ("a_fmt", _i), ("pad_", _i), ("amax", _p), ("a16_out", _p)]
 
 
 class GemmTNBArgs(C.Structure):
@@ -102,7 +102,7 @@ class GemmTNBArgs(C.Structure):
                [(n, _ll) for n in ("slab_stride", "bslab_stride", "aslab_stride")] + \
                [(n, _i) for n in ("g_width", "g_off", "g_cols", "a0_width", "a0_off", "a0_cols", "a0_shift",
                                   "a1_width", "a1_off", "a1_cols", "a1_shift", "nblk", "L", "nsplit",
-                                  "blocks_per_split", "g_fmt")] + [("amax", _p)]
+                                  "blocks_per_split", "g_fmt")] + [("amax", _p), ("a_fmt", _i), ("pad_", _i)]
 
 
 class LstmClusterArgs(C.Structure):

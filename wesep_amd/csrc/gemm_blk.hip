@@ -25,6 +25,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(512, 4) void gemm_p2b_kernel(const ws_gemm_p2b_args
       rstd = p.stats[2 * s + 1];
     }
     float* eb = p.A_bl ? p.A_bl + (long long)bb * (32 * P2B_K) + i * 4 : nullptr;
+    unsigned short* eb16 = p.A_bl16 ? reinterpret_cast<unsigned short*>(p.A_bl16) + (long long)bb * (32 * P2B_K) + i * 4 : nullptr;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int k0 = 16 * ks + 8 * half;
@@ -223,6 +225,12 @@ __global__ __launch_bounds__(512, 4) void gemm_p2b_kernel(const ws_gemm_p2b_args
         pack8(xh[ks], xl[ks], c0, c1);
         *reinterpret_cast<u32x4*>(eb + (k0 / 4) * 128) = c0;
         *reinterpret_cast<u32x4*>(eb + (k0 / 4 + 1) * 128) = c1;
+      }
+      if (eb16 && active) {  // and as fp16 in BLH(K): the 2-byte A operand of ws_gemm_tnb (a_fmt = 1, ABI v16)
+        const f16x2 h0 = {(_Float16)v[0], (_Float16)v[1]}, h1 = {(_Float16)v[2], (_Float16)v[3]};
+        const f16x2 h2 = {(_Float16)v[4], (_Float16)v[5]}, h3 = {(_Float16)v[6], (_Float16)v[7]};
+        *reinterpret_cast<u32x2*>(eb16 + (k0 / 4) * 128) = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+        *reinterpret_cast<u32x2*>(eb16 + (k0 / 4 + 1) * 128) = u32x2{__builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
       }
     }
   }
@@ -313,7 +321,6 @@ extern "C" int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream) {
 // ---------------------------------------------------------------------------------------------
 // A16 (a_fmt = 1, ABI v15): A holds bf16 elements in BLH(K) -- d(gates) of WS_GATES_H2: a lane's 8 consecutive k are two
 // 8-byte cells = the hi fragment itself; no lo term, two MFMAs per product instead of three, half the A bytes.
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // A16 = 2 (a_fmt = 2): A holds fp16 elements scaled by S = ws_dgates_scale(*p.amax) -- d(gates) of WS_GATES_H2F -- and Wpack
 // is a ws_pack_w_f16 pack (fp16 hi / lo of 256 w): the A cells ARE the MFMA fragments (no conversion) and a product is
 // a (w_hi + w_lo) on v_mfma_f32_32x32x16_f16 -- the operand's 11 bits times the weight's 22; the epilogue multiplies by
@@ -393,6 +400,20 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
         continue;
       } else {
         unpack8(__builtin_bit_cast(u32x4, ac[2 * ks]), __builtin_bit_cast(u32x4, ac[2 * ks + 1]), ah, al);
+        if (p.a16_out && active) {  // the operand once more as fp16 in BLH(K) (ABI v16): hi + lo is the fp32 value
+          unsigned short* o16 = reinterpret_cast<unsigned short*>(p.a16_out) + (long long)bb * 32 * K + i * 4 +
+                                (long long)(st * 16 + 4 * ks + 2 * half) * 128;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const u32x4 cell = __builtin_bit_cast(u32x4, ac[2 * ks + c]);
+            _Float16 h[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              h[j] = (_Float16)(__uint_as_float(cell[j] & 0xffff0000u) + __uint_as_float(cell[j] << 16));
+            const f16x2 p0 = {h[0], h[1]}, p1 = {h[2], h[3]};
+            *reinterpret_cast<u32x2*>(o16 + c * 128) = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+          }
+        }
       }
       const u32x4* wt = &wl[cur][ks * 512 + lane];  // [nt][part][lane]
 #pragma unroll
@@ -714,21 +735,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb_kernel(const ws_gemm_tnb_args
 // workgroups of a split: L2), and a wave's loads return in order: the A loads are issued FIRST, so they do not wait behind
 // the HBM round trip of G, and with GD = 4 the 16 bytes of G per thread and block are requested four blocks ahead (4 more
 // registers per block in flight) -- the block loop is bound by the round trip of its prefetch (profiles/r03_tnb_experiments.md).
-template <bool ASUM, int GFMT, int GD>
+template <bool ASUM, int GFMT, int GD, int AF = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_args p) {
+  // AF = 1 (a_fmt 1, ABI v16; with GFMT 3 only): A0 / A1 hold fp16 elements in BLH -- 8-byte cells, ONE LDS plane, ONE MFMA
+  // per product; a workgroup loads 32 KB per block instead of 56
+  static_assert(AF == 0 || (GFMT == 3 && !ASUM), "fp16 A operand: scaled-fp16 G on the fp16 instruction, no column sums of A");
   constexpr int TA = 3, TN = 3;
   // GFMT 3 = the scaled-fp16 G of g_fmt 2 on v_mfma_f32_32x32x16_f16: G needs no split (its 11 bits ARE an fp16), the A
   // operand's bf16 hi / lo terms convert exactly to fp16 after a power-of-two lift (x 2^6: one packed exponent add per
   // BLS word; keeps lo terms of |x| >= 5e-4 out of the fp16 denormals, |x| < 1023 finite) -> G A_hi + G A_lo, TWO MFMAs
   // per product instead of three (G_hi A_hi + G_hi A_lo + G_lo A_hi on the bf16 instruction)
   constexpr bool F16 = GFMT == 3;
-  constexpr int NTERM = GFMT == 2 ? 3 : 2;
+  constexpr int NTERM = AF ? 1 : (GFMT == 2 ? 3 : 2);
   const float inv_s = GFMT >= 2 ? ws_dgates_scale_inv(*p.amax) : 1.f;
-  const float inv_out = F16 ? inv_s * 0.015625f : inv_s;
+  const float inv_out = (F16 && !AF) ? inv_s * 0.015625f : inv_s;   // (the 2^6 lift belongs to the BLS -> fp16 conversion)
   constexpr int NCOL = 128 * (1 + TA);
   constexpr int PLANE = NCOL * TB_LD;
-  __shared__ __attribute__((aligned(16))) __bf16 ldsA[2 * PLANE];
-  __shared__ __attribute__((aligned(16))) __bf16 ldsB[2 * PLANE];
+  __shared__ __attribute__((aligned(16))) __bf16 ldsA[(AF ? 1 : 2) * PLANE];   // (AF: no lo plane at all -- 80 KB per workgroup)
+  __shared__ __attribute__((aligned(16))) __bf16 ldsB[(AF ? 1 : 2) * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 2, wn = w & 3;
@@ -755,14 +779,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
     const float* base = s1 ? p.A1 : p.A0;
     const int off = s1 ? p.a1_off + c0 - p.a0_cols : p.a0_off + c0;
     aslot[r] = 4 * sg + (r == 1 ? 2 * (tid & 1) : 0);
-    abase[r] = base + (long long)(off / 4 + quad) * 128 + aslot[r] * 4;
+    // (AF: the same index formula in 2-byte elements; abase then counts halves through a float pointer's address)
+    abase[r] = AF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(base) +
+                                                   (long long)(off / 4 + quad) * 128 + aslot[r] * 4)
+                  : base + (long long)(off / 4 + quad) * 128 + aslot[r] * 4;
     astride[r] = 32LL * (s1 ? p.a1_width : p.a0_width);
     ashift[r] = s1 ? p.a1_shift : p.a0_shift;
     acol[r] = 128 + c0 + 4 * quad;
   }
 
   u32x4 gq[GD];       // GD blocks in flight (ring slot = block index mod GD)
-  f32x4 aq[2][6];     // [slot][4 cells of r = 0, 2 cells of r = 1]: two blocks in flight
+  f32x4 aq[2][AF ? 3 : 6];  // [slot][4 cells of r = 0, 2 cells of r = 1]: two blocks in flight (AF: 8-byte cells, two per register)
   bool use[2][2];
   auto load_g = [&](int b, int gslot) { gq[gslot] = *reinterpret_cast<const u32x4*>(gsrc + (long long)b * gstep); };
   auto load_block = [&](int b, int slot) {
@@ -771,9 +798,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
     for (int r = 0; r < 2; ++r) {
       const int sa = step + ashift[r];
       use[slot][r] = sa >= 0 && sa < L;
-      const float* src = abase[r] + (long long)(use[slot][r] ? b + ashift[r] : b) * astride[r];
+      if constexpr (AF) {
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(abase[r]) +
+                                    (long long)(use[slot][r] ? b + ashift[r] : b) * astride[r];
 #pragma unroll
-      for (int j = 0; j < (r == 0 ? 4 : 2); ++j) aq[slot][4 * r + j] = *reinterpret_cast<const f32x4*>(src + 4 * j);
+        for (int j = 0; j < (r == 0 ? 2 : 1); ++j) aq[slot][2 * r + j] = *reinterpret_cast<const f32x4*>(src + 8 * j);
+      } else {
+        const float* src = abase[r] + (long long)(use[slot][r] ? b + ashift[r] : b) * astride[r];
+#pragma unroll
+        for (int j = 0; j < (r == 0 ? 4 : 2); ++j) aq[slot][4 * r + j] = *reinterpret_cast<const f32x4*>(src + 4 * j);
+      }
     }
   };
   float gsum[4] = {0.f, 0.f, 0.f, 0.f}, asum[2][4];
@@ -829,6 +863,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
     }
     const int r = pc >> 2, c = pc & 3;
     const unsigned m = use[slot][r] ? 0xffffffffu : 0u;  // uniform: the shifted operand at the sequence ends
+    if constexpr (AF) {
+      // register j of this group holds the cells of slots 2j, 2j + 1: words (cols 0|1, cols 2|3) of each; column c of the
+      // group's slots -> one 16-bit lane of four (two) words
+      const unsigned sel = (c & 1) ? WS_SEL_HI16 : WS_SEL_LO16;
+      const int wi = c >> 1;
+      const u32x4 q0 = __builtin_bit_cast(u32x4, aq[slot][2 * r]);
+      const unsigned x = __builtin_amdgcn_perm(q0[2 + wi], q0[wi], sel) & m;          // slots 0, 1
+      const int o = (acol[r] + c) * TB_LD + aslot[r];
+      if (r == 0) {
+        const u32x4 q1 = __builtin_bit_cast(u32x4, aq[slot][1]);
+        const unsigned y = __builtin_amdgcn_perm(q1[2 + wi], q1[wi], sel) & m;        // slots 2, 3
+        *reinterpret_cast<uint2*>(lds + o) = uint2{x, y};
+      } else {
+        *reinterpret_cast<unsigned*>(lds + o) = x;
+      }
+      return;
+    }
     unsigned e[4];
 #pragma unroll
     for (int j = 0; j < (r == 0 ? 4 : 2); ++j) {
@@ -912,7 +963,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
         auto lda = [&](int ks, int f, bf16x8& h, bf16x8& l) {
           const int ra = (128 + wn * 32 * TN + f * 32 + l31) * TB_LD + ks + 8 * half;
           h = *reinterpret_cast<const bf16x8*>(lds + ra);
-          l = *reinterpret_cast<const bf16x8*>(lds + PLANE + ra);
+          if constexpr (!AF) l = *reinterpret_cast<const bf16x8*>(lds + PLANE + ra);
         };
         bf16x8 ah, al, ahn, aln;
         lda(0, 0, ah, al);
@@ -940,7 +991,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tnb16_kernel(const ws_gemm_tnb_ar
                 else
                   acc[e][f] = mfma32(term == 2 ? gl[e] : gh[e], term == 1 ? al : ah, acc[e][f]);
               }
-              if (sub < NPC) store_piece(s ^ 1, (sg4 + 1) % GD, ldsw, live, sub);
+              if constexpr (NTERM == 1) {   // six MFMA groups per block, ten pieces: two per group
+                if (2 * sub < NPC) store_piece(s ^ 1, (sg4 + 1) % GD, ldsw, live, 2 * sub);
+                if (2 * sub + 1 < NPC) store_piece(s ^ 1, (sg4 + 1) % GD, ldsw, live, 2 * sub + 1);
+              } else if (sub < NPC) {
+                store_piece(s ^ 1, (sg4 + 1) % GD, ldsw, live, sub);
+              }
               __builtin_amdgcn_sched_barrier(0);
             }
             ah = ahn; al = aln;
@@ -1006,6 +1062,8 @@ extern "C" int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream) {
   WS_REQUIRE(a->g_fmt == 0 || ((a->g_fmt == 1 || a->g_fmt == 2) && ta == 3),
              "ws_gemm_tnb: g_fmt 1 / 2 (2-byte G) are built for 384 A columns");
   WS_REQUIRE(a->g_fmt != 2 || a->amax, "ws_gemm_tnb: g_fmt = 2 (scaled fp16 G) needs amax");
+  WS_REQUIRE(a->a_fmt == 0 || (a->a_fmt == 1 && a->g_fmt == 2 && !a->aslab && ta == 3),
+             "ws_gemm_tnb: a_fmt = 1 (fp16 A operands) is built for g_fmt = 2, 384 A columns, no aslab");
   WS_REQUIRE(a->nblk > 0 && a->L > 0 && a->nblk % a->L == 0 && a->nsplit > 0 && a->blocks_per_split > 0 &&
                  (long long)a->nsplit * a->blocks_per_split >= a->nblk,
              "ws_gemm_tnb: bad block split");
@@ -1017,7 +1075,9 @@ extern "C" int ws_gemm_tnb(const ws_gemm_tnb_args* a, void* stream) {
   // WS_TNB_F16=0 (A/B runs): the scaled-fp16 G on the bf16 instruction (3 terms) instead of the fp16 one (2 terms)
   const char* f16env = getenv("WS_TNB_F16");  // read per call: the tests run both forms in one process
   const bool f16mm = !(f16env && atoi(f16env) == 0);
-  if (a->g_fmt == 2 && f16mm && a->aslab)
+  if (a->a_fmt == 1)
+    hipLaunchKernelGGL((gemm_tnb16_kernel<false, 3, 4, 1>), grid, block, 0, s, *a);
+  else if (a->g_fmt == 2 && f16mm && a->aslab)
     hipLaunchKernelGGL((gemm_tnb16_kernel<true, 3, 4>), grid, block, 0, s, *a);
   else if (a->g_fmt == 2 && f16mm)
     hipLaunchKernelGGL((gemm_tnb16_kernel<false, 3, 4>), grid, block, 0, s, *a);

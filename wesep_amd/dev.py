@@ -782,6 +782,16 @@ def blh_bf16_pack(xb: torch.Tensor) -> torch.Tensor:
     return xb.to(torch.bfloat16).contiguous().view(torch.float32)
 
 
+def blh_f16_pack(xb: torch.Tensor) -> torch.Tensor:
+    """BL-shaped fp32 [nblk][C/4][32][4] -> BLH buffer of fp16 elements (round to nearest even), as float32 storage."""
+    return xb.to(torch.float16).contiguous().view(torch.float32)
+
+
+def blh_f16_unpack(buf: torch.Tensor, nblk: int, C_: int) -> torch.Tensor:
+    """BLH buffer of fp16 elements (float32 storage) -> BL-shaped fp32 [nblk][C/4][32][4]."""
+    return buf.reshape(-1)[: nblk * 32 * C_ // 2].view(torch.float16).view(nblk, C_ // 4, 32, 4).float()
+
+
 def blh_bf16_unpack(buf: torch.Tensor, nblk: int, C_: int) -> torch.Tensor:
     """BLH buffer of bf16 elements (float32 storage) -> BL-shaped fp32 [nblk][C/4][32][4]."""
     return buf.reshape(-1)[: nblk * 32 * C_ // 2].view(torch.bfloat16).view(nblk, C_ // 4, 32, 4).float()
@@ -820,9 +830,11 @@ def pack_w(W, N: int, K: int, ldw: int, out, trans=False, order=0, w_off=0, f16=
 
 
 def gemm_p2b(*, A, lda: int, sm: SeqMap, Wpack, N: int, C_out, K=128, bias=None, A_bl=None, stats=None,
-             gamma=None, beta=None, stat_map: Optional[StatMap] = None, run_if=None, amax=None):
+             gamma=None, beta=None, stat_map: Optional[StatMap] = None, run_if=None, amax=None, A_bl16=None):
+    """A_bl16 (ABI v16): the (normalised) operand once more as fp16 in BLH(K) (float32 storage of half the element count:
+    blh_floats) -- the 2-byte A operand of gemm_tnb (a_fmt = 1)."""
     for n, t in (("A", A), ("Wpack", Wpack), ("bias", bias), ("C", C_out), ("A_bl", A_bl), ("stats", stats),
-                 ("gamma", gamma), ("beta", beta)):
+                 ("gamma", gamma), ("beta", beta), ("A_bl16", A_bl16)):
         _chk(t, n)
     a = L.GemmP2BArgs()
     a.A, a.Wpack, a.bias, a.C, a.A_bl = _p(A), _p(Wpack), _p(bias), _p(C_out), _p(A_bl)
@@ -833,19 +845,24 @@ def gemm_p2b(*, A, lda: int, sm: SeqMap, Wpack, N: int, C_out, K=128, bias=None,
     a.lda, a.N, a.K = lda, N, K
     a.run_if = C.c_void_p(run_if.data_ptr()) if run_if is not None else None
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None     # 1-element int32, zeroed by the caller
+    a.A_bl16 = _p(A_bl16)
     L.check(L.lib().ws_gemm_p2b(C.byref(a), L.stream_ptr()), "ws_gemm_p2b")
 
 
-def gemm_b2p(*, A, K: int, sm: SeqMap, Wpack, C_out, ldc: int, N=128, bias=None, R=None, a_fmt=0, amax=None):
+def gemm_b2p(*, A, K: int, sm: SeqMap, Wpack, C_out, ldc: int, N=128, bias=None, R=None, a_fmt=0, amax=None, a16_out=None):
     """a_fmt = 1: A holds bf16 elements in BLH(K) (d(gates) of WS_GATES_H2) instead of split pairs in BL(K); 2: fp16 elements
-    scaled by the power of two the word `amax` defines (WS_GATES_H2F)."""
-    for n, t in (("A", A), ("Wpack", Wpack), ("bias", bias), ("C", C_out), ("R", R)):
+    scaled by the power of two the word `amax` defines (WS_GATES_H2F).  a16_out (a_fmt 0, ABI v16): the A operand once more as
+    fp16 in BLH(K) -- hcat for gemm_tnb (a_fmt = 1)."""
+    for n, t in (("A", A), ("Wpack", Wpack), ("bias", bias), ("C", C_out), ("R", R), ("a16_out", a16_out)):
         _chk(t, n)
+    if a16_out is not None and a_fmt != 0:
+        raise L.WesepHipError("gemm_b2p: a16_out goes with a_fmt = 0 (split-pair A)")
     a = L.GemmB2PArgs()
     a.A, a.Wpack, a.bias, a.R, a.C = _p(A), _p(Wpack), _p(bias), _p(R), _p(C_out)
     a.sm = _smc(sm)
     a.ldc, a.N, a.K, a.a_fmt = ldc, N, K, a_fmt
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
+    a.a16_out = _p(a16_out)
     L.check(L.lib().ws_gemm_b2p(C.byref(a), L.stream_ptr()), "ws_gemm_b2p")
 
 
@@ -862,9 +879,10 @@ def tnb_splits(nblk: int, gtiles: int):
 
 def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_off: int, a0_cols: int,
              nblk: int, L_: int, slab, nsplit: int, blocks_per_split: int, a0_shift=0, A1=None, a1_width=0,
-             a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, g_fmt=0, amax=None):
+             a1_off=0, a1_cols=0, a1_shift=0, bslab=None, aslab=None, g_fmt=0, amax=None, a_fmt=0):
     """g_fmt = 1: G holds bf16 elements in BLH(g_width) (d(gates) of WS_GATES_H2); 2: fp16 elements scaled by the power of
-    two the word `amax` defines (WS_GATES_H2F); both need 384 A columns."""
+    two the word `amax` defines (WS_GATES_H2F); both need 384 A columns.  a_fmt = 1 (ABI v16, g_fmt 2 only): A0 / A1 hold
+    fp16 elements in BLH (gemm_p2b's A_bl16, gemm_b2p's a16_out): one MFMA per product, 32 instead of 56 KB loaded per block."""
     for n, t in (("G", G), ("A0", A0), ("A1", A1), ("slab", slab), ("bslab", bslab), ("aslab", aslab)):
         _chk(t, n)
     a = L.GemmTNBArgs()
@@ -875,7 +893,7 @@ def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_
     a.g_width, a.g_off, a.g_cols = g_width, g_off, g_cols
     a.a0_width, a.a0_off, a.a0_cols, a.a0_shift = a0_width, a0_off, a0_cols, a0_shift
     a.a1_width, a.a1_off, a.a1_cols, a.a1_shift = a1_width, a1_off, a1_cols, a1_shift
-    a.nblk, a.L, a.nsplit, a.blocks_per_split, a.g_fmt = nblk, L_, nsplit, blocks_per_split, g_fmt
+    a.nblk, a.L, a.nsplit, a.blocks_per_split, a.g_fmt, a.a_fmt = nblk, L_, nsplit, blocks_per_split, g_fmt, a_fmt
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
     L.check(L.lib().ws_gemm_tnb(C.byref(a), L.stream_ptr()), "ws_gemm_tnb")
 

@@ -160,7 +160,8 @@ def resrnn_mode() -> str:
 def _h2_probe() -> int:
     """NUMERICS PROBE (tools/r04_h2_numerics.py; off by default): emulate narrower storage of the saved recurrence state
     by rounding the fp32 buffers in place between kernels.  Bits: 1 = activated gates to fp16, 2 = d(gates) to bf16
-    (the hi term of the split pair only), 4 = cell state to fp16, 8 = activated gates to unorm16, 16 = d(hcat) to bf16."""
+    (the hi term of the split pair only), 4 = cell state to fp16, 8 = activated gates to unorm16, 16 = d(hcat) to bf16,
+    64 / 128 = the A operand [xn | h] of the weight-gradient GEMMs to fp16 / bf16 (CPU emulation)."""
     return int(os.environ.get("WESEP_H2_PROBE", "0"))
 
 
@@ -181,6 +182,12 @@ def _probe_round(t, kind, packed=False):
         t.view(torch.int32).bitwise_and_(-65536)
     else:
         t.copy_(t.bfloat16().float())
+
+
+def tnb_a16() -> bool:
+    """fp16 copies of [xn | h] for the weight-gradient GEMMs (ws_gemm_tnb a_fmt = 1, ABI v16; with the default WS_GATES_H2F
+    only).  WESEP_TNB_A16=0 keeps the split-pair A operand of round 3."""
+    return os.environ.get("WESEP_TNB_A16", "1") != "0"
 
 
 def wgrad_overlap() -> bool:
@@ -402,18 +409,23 @@ class ResRNNBlkFn(torch.autograd.Function):
         gfmt = L.GATES_F32 if ctx.bptt == "cluster" else dev.gates_fmt()
         h2 = gfmt != L.GATES_F32
         gates = _empty(d, dev.blh_floats(nb, 2 * G4)) if h2 else _empty(d, nb, 32 * 2 * G4)
+        # fp16 copies of the weight-gradient GEMM's A operand [xn | h] (ABI v16; written by the two GEMMs that touch these
+        # operands anyway): ws_gemm_tnb then loads 32 instead of 56 KB per block and runs ONE MFMA per product
+        a16 = gfmt == L.GATES_H2F and any(ctx.needs_input_grad) and tnb_a16()
+        xn16 = _empty(d, dev.blh_floats(nb, N)) if a16 else None
+        hcat16 = _empty(d, dev.blh_floats(nb, 2 * H)) if a16 else None
         if dev.lstm_fuse_ok(seq.nseq, cluster):
             # band view: the recurrence computes x W_ih^T itself from the normalised input (BL(128)): the 16E-byte
             # pre-activation buffer is never written and read back (lstm_fused.hip)
             dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, stats=stats, gamma=norm_w,
-                         beta=norm_b, stat_map=smap)
+                         beta=norm_b, stat_map=smap, A_bl16=xn16)
             dev.lstm_fwd_fused(gates, cbuf, hcat, xn, W("fused"), bcat, seq, gfmt=gfmt)
         else:
             # pre-activations: in `gates` itself with the fp32 format (one buffer, three lives); with the 2-byte formats a
             # scratch buffer that dies with this forward (the recurrences read it and write the unorm16 gates next to it)
             pre = _empty(d, nb, 32 * 2 * G4) if h2 else gates
             xproj = dict(A=z, lda=N, sm=seq, Wpack=W("wih"), N=2 * G4, C_out=pre, bias=bcat, A_bl=xn,
-                         stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap)
+                         stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap, A_bl16=xn16)
             rec = dict(gfmt=gfmt, gates_in=pre) if h2 else {}
             dev.gemm_p2b(**xproj)
             if cluster:
@@ -430,7 +442,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             del pre
         pw = W("pw")
         out = torch.empty_like(z)
-        dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=W("proj"), C_out=out, ldc=N, bias=proj_b, R=z)
+        dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=W("proj"), C_out=out, ldc=N, bias=proj_b, R=z, a16_out=hcat16)
         if _h2_probe() and not h2:
             if _h2_probe() & 1:
                 _probe_round(gates, "f16")
@@ -447,17 +459,26 @@ class ResRNNBlkFn(torch.autograd.Function):
                 W("hhp")
             if ctx.bptt == "stream" or (ctx.bptt == "pair" and h2):
                 W("hh")     # (the pair BPTT's predicated streaming fall-back of the 2-byte formats)
-        ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn, wcat, norm_w, norm_b, pw, whf, whr)
+        # (with the fp16 copies the backward never reads the split-pair xn again: its 2-byte copy is saved instead)
+        ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn16 if a16 else xn, wcat, norm_w, norm_b, pw, whf, whr, hcat16)
+        ctx.a16 = a16
         ctx.view, ctx.box, ctx.lmode, ctx.cluster, ctx.gfmt = view, box, lmode, cluster, gfmt
         ctx.packs = W
         ctx.consumed = False
         return out
 
     @staticmethod
-    def _weight_grads(gates, xn, hcat, dout_bl, seq, nb, N, g_fmt=0, amax=None):
+    def _weight_grads(gates, xn, hcat, dout_bl, seq, nb, N, g_fmt=0, amax=None, hcat16=None):
         """[dW_ih | dW_hh | db] of both directions in one pass over each direction's dgates, and
-        dW_proj / db_proj; launched on the current stream.  Returns them in parameter order."""
+        dW_proj / db_proj; launched on the current stream.  Returns them in parameter order.  hcat16 given: `xn` and it are
+        the fp16 copies in BLH (ws_gemm_tnb a_fmt = 1; g_fmt 2 only)."""
         d = gates.device
+        a_fmt = 1 if hcat16 is not None else 0
+        if _h2_probe() & 192 and not torch.cuda.is_available() and not a_fmt:
+            # NUMERICS PROBE (CPU emulation only: plain fp32 buffers): the A operand [xn | h] of the weight-gradient GEMMs at
+            # fp16 (bit 64) / bf16 (bit 128) -- what a 2-byte A operand of ws_gemm_tnb would cost (DESIGN section 12a-v)
+            rnd = (lambda t: t.half().float()) if _h2_probe() & 64 else (lambda t: t.bfloat16().float())
+            xn, hcat = rnd(xn), rnd(hcat)
         if os.environ.get("WESEP_PROBE_SKIP_WGRAD") == "1":   # measurement only: how much of this is exposed?
             z_ = lambda *s_: torch.zeros(*s_, device=d)
             return [z_(G4, N), z_(G4, H), z_(G4), z_(G4), z_(G4, N), z_(G4, H), z_(G4), z_(G4), z_(N, 2 * H), z_(N)]
@@ -473,9 +494,9 @@ class ResRNNBlkFn(torch.autograd.Function):
         dwih, dwhh, db = [], [], []
         for di in (0, 1):
             dev.gemm_tnb(G=gates, g_width=2 * G4, g_off=di * G4, g_cols=G4, A0=xn, a0_width=N, a0_off=0,
-                         a0_cols=N, A1=hcat, a1_width=2 * H, a1_off=di * H, a1_cols=H,
+                         a0_cols=N, A1=hcat16 if a_fmt else hcat, a1_width=2 * H, a1_off=di * H, a1_cols=H,
                          a1_shift=(-1 if di == 0 else 1), nblk=nb, L_=seq.L, slab=slab, nsplit=ns,
-                         blocks_per_split=bps, bslab=bslab, g_fmt=g_fmt, amax=amax)
+                         blocks_per_split=bps, bslab=bslab, g_fmt=g_fmt, amax=amax, a_fmt=a_fmt)
             dw = _reduce_new(slab, ns, G4 * (N + H), (G4, N + H))
             dwih.append(dw[:, :N].contiguous())
             dwhh.append(dw[:, N:].contiguous())
@@ -492,7 +513,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             raise L.WesepHipError("ResRNN: second backward through the same graph (retain_graph / multi-loss loops): "
                                   "the blocked path consumes its saved gates in place; run the forward again")
         ctx.consumed = True
-        z, stats, gates, cbuf, hcat, xn, wcat, norm_w, norm_b, pw, whf, whr = ctx.saved_tensors
+        z, stats, gates, cbuf, hcat, xn, wcat, norm_w, norm_b, pw, whf, whr, hcat16 = ctx.saved_tensors   # (xn: fp16 copy if hcat16)
         W = ctx.packs
         dout = dout.contiguous()
         R, K, Tf, N = z.shape
@@ -561,16 +582,17 @@ class ResRNNBlkFn(torch.autograd.Function):
         # weight gradients: a side branch of the graph -> deferred to the side stream when a carrier
         # will deliver them
         if box is not None:
-            def job(side, gates=dg, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, N=N, box=box, g_fmt=g_fmt, amax=amax):
-                box.grads = ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)
+            def job(side, gates=dg, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, N=N, box=box, g_fmt=g_fmt, amax=amax,
+                    hcat16=hcat16):
+                box.grads = ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax, hcat16)
                 box.event = torch.cuda.Event()
                 box.event.record(side)
-                for t in (gates, xn, hcat, dout_bl) + ((amax,) if amax is not None else ()):
+                for t in (gates, xn, hcat, dout_bl) + tuple(t_ for t_ in (amax, hcat16) if t_ is not None):
                     t.record_stream(side)
             defer_wgrad(d, job)
             wg = [None] * 10
         else:
-            wg = ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)
+            wg = ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax, hcat16)
         del dout_bl
         # d(normalised input) = dgates Wcat -> GroupNorm backward (+ residual path)
         dxn = _empty(d, P, N)

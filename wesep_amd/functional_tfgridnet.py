@@ -437,8 +437,12 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         gfmt = L.GATES_F32 if kind == "cluster" else dev.gates_fmt()
         h2 = gfmt != L.GATES_F32
         gates = _empty(d, dev.blh_floats(nb, 2 * G4)) if h2 else _empty(d, nb, 32 * 2 * G4)
+        # fp16 copies of [xn | h] for the weight-gradient GEMMs (functional.ResRNNBlkFn; ws_gemm_tnb a_fmt = 1, ABI v16)
+        a16 = gfmt == L.GATES_H2F and any(ctx.needs_input_grad) and F0.tnb_a16()
+        xn16 = _empty(d, dev.blh_floats(nb, N)) if a16 else None
+        hcat16 = _empty(d, dev.blh_floats(nb, 2 * H)) if a16 else None
         if dev.lstm_fuse_ok(ns, cluster):
-            dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn)
+            dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, A_bl16=xn16)
             fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
             dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), whf, whr, fpack)
             dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq, gfmt=gfmt)
@@ -446,7 +450,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             wih_pack = _empty(d, 2 * G4 * N)
             dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
             pre = _empty(d, nb, 32 * 2 * G4) if h2 else gates      # 2-byte formats: pre-activations in a scratch buffer
-            xproj = dict(A=y, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=pre, bias=bcat, A_bl=xn)
+            xproj = dict(A=y, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=pre, bias=bcat, A_bl=xn, A_bl16=xn16)
             rec = dict(gfmt=gfmt, gates_in=pre) if h2 else {}
             dev.gemm_p2b(**xproj)
             if cluster:
@@ -464,7 +468,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         lin_pack = _empty(d, N * 2 * H)
         dev.pack_w(lw, N, 2 * H, 2 * H, lin_pack, order=1)
         out = torch.empty_like(res)
-        dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=lin_pack, C_out=out, ldc=N, bias=lin_b.contiguous(), R=res)
+        dev.gemm_b2p(A=hcat, K=2 * H, sm=seq, Wpack=lin_pack, C_out=out, ldc=N, bias=lin_b.contiguous(), R=res, a16_out=hcat16)
         # the backward's weight packs are built HERE, where the GPU serves one stream: built lazily in the backward, these
         # 5 us launches queue behind the side stream's chip-filling weight-gradient GEMMs for up to a millisecond each
         # (functional.ResRNNBlkFn does the same)
@@ -481,7 +485,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
                 dev.lstm_pack_pair(whf, whr, ppack)
             bw_packs = (wlt_pack, wct_pack, ppack)
         ctx.bw_packs = bw_packs
-        ctx.save_for_backward(gates, cbuf, hcat, xn, wcat, pack_b, lw, whf, whr)
+        ctx.save_for_backward(gates, cbuf, hcat, xn16 if a16 else xn, wcat, pack_b, lw, whf, whr, hcat16)
         ctx.geo = (nseq, Lr, ns, lmode, cluster)
         ctx.seq = seq
         ctx.gfmt, ctx.kind = gfmt, kind
@@ -493,7 +497,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         import os
-        gates, cbuf, hcat, xn, wcat, pack_b, lw, whf, whr = ctx.saved_tensors
+        gates, cbuf, hcat, xn, wcat, pack_b, lw, whf, whr, hcat16 = ctx.saved_tensors     # (xn: its fp16 copy if hcat16)
         if ctx.consumed:         # same contract as functional.ResRNNBlkFn: BPTT turns the saved gates into d(gates) in place
             raise L.WesepHipError("TF-GridNet BLSTM: second backward through the same graph (retain_graph / multi-loss "
                                   "loops): the blocked path consumes its saved gates in place; run the forward again")
@@ -544,17 +548,18 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             F0.flush_deferred_wgrads(d, ready)
         order = (0, 4, 2, 6, 1, 5, 8, 9)       # _weight_grads' list -> this node's weight arguments
         if box is not None:
-            def job(side, gates=dg, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, box=box, g_fmt=g_fmt, amax=amax):
-                wg_ = F0.ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, 128, g_fmt, amax)
+            def job(side, gates=dg, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, box=box, g_fmt=g_fmt, amax=amax,
+                    hcat16=hcat16):
+                wg_ = F0.ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, 128, g_fmt, amax, hcat16)
                 box.grads = [wg_[i] for i in order]
                 box.event = torch.cuda.Event()
                 box.event.record(side)
-                for t in (gates, xn, hcat, dout_bl) + ((amax,) if amax is not None else ()):
+                for t in (gates, xn, hcat, dout_bl) + tuple(t_ for t_ in (amax, hcat16) if t_ is not None):
                     t.record_stream(side)
             F0.defer_wgrad(d, job)
             wgo = [None] * 8
         else:
-            wg = F0.ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax)
+            wg = F0.ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax, hcat16)
             wgo = [wg[i] for i in order]
         dy = _empty(d, (ns if appended else nseq) * Lr, N)
         dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dy, ldc=N, a_fmt=g_fmt, amax=amax)
