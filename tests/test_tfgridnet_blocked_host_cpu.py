@@ -30,6 +30,7 @@ def test_blstm_linear_blocked_matches_torch(emu, monkeypatch, nseq, Lr, branch, 
     from wesep_amd import dev
     from wesep_amd import functional_tfgridnet as FG
     monkeypatch.setenv("WESEP_GATES", fmt)
+    monkeypatch.setenv("WESEP_TFG_TNB_A16", "1")     # (the fp16 A operand of the weight-gradient GEMMs: opt-in here, h2 only)
     torch.manual_seed(nseq)
     h = 192
     lstm = torch.nn.LSTM(128, h, 1, batch_first=True, bidirectional=True)
