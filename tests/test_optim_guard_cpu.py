@@ -1,0 +1,128 @@
+"""CPU: the host logic of wesep_amd.optim.FusedClipAdam on the emulation of its two launches (tests/emu_optim.py) --
+per-tensor clip + Adam-L2 against the oracle's step (wesep/utils/funcs.py:79-88, wesep/bin/train.py:237-238), the
+non-finite-gradient guard (round 4: the WHOLE update is skipped, weights and moments intact, the step is counted), and
+the same under DistributedDataParallel at world size 2 on gloo: a NaN born on ONE rank reaches every rank through the
+all-reduce, every rank skips the same step, the replicas stay bit-identical and train on."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _net(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 3))
+
+
+def test_fused_clip_adam_host_logic_matches_the_oracle_step(monkeypatch):
+    from oracle import bsrnn_oracle as O
+    from tests import emu_optim
+    from wesep_amd.optim import FusedClipAdam
+    emu_optim.install(monkeypatch)
+    net = _net(0)
+    ref = {k: v.detach().clone() for k, v in net.named_parameters()}
+    m = {k: torch.zeros_like(v) for k, v in ref.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in ref.items()}
+    opt = FusedClipAdam(net.parameters(), lr=1e-2, weight_decay=1e-3, clip_grad=0.05)
+    g = torch.Generator().manual_seed(1)
+    for step in range(1, 6):
+        x, y = torch.randn(16, 6, generator=g), torch.randn(16, 3, generator=g)
+        opt.zero_grad()
+        ((net(x) - y) ** 2).mean().backward()
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        opt.step()
+        O.clip_gradients_(grads, 0.05)
+        for k in ref:
+            O.adam_l2_step_(ref[k], grads[k], m[k], v2[k], step, 1e-2, weight_decay=1e-3)
+        for k, p in net.named_parameters():
+            assert torch.allclose(p.detach(), ref[k], rtol=1e-6, atol=1e-7), (step, k)
+    assert len(opt.last_grad_norms()) == 4 and opt.skipped_steps == 0
+
+
+def test_nonfinite_gradient_skips_the_whole_update_and_is_counted(monkeypatch):
+    from tests import emu_optim
+    from wesep_amd.optim import FusedClipAdam
+    emu_optim.install(monkeypatch)
+    net = _net(2)
+    opt = FusedClipAdam(net.parameters(), lr=1e-2, weight_decay=1e-3, clip_grad=5.0)
+    x, y = torch.randn(4, 6), torch.randn(4, 3)
+
+    def backward():
+        opt.zero_grad()
+        ((net(x) - y) ** 2).mean().backward()
+
+    backward()
+    opt.step()                                                   # a finite step: state exists now
+    snap = lambda: ([p.detach().clone() for p in net.parameters()],
+                    [opt.state[p]["exp_avg"].clone() for p in net.parameters()],
+                    [opt.state[p]["exp_avg_sq"].clone() for p in net.parameters()])
+    before = snap()
+    backward()
+    list(net.parameters())[2].grad[1, 3] = float("nan")          # one element of one tensor
+    with pytest.warns(RuntimeWarning, match="not finite"):
+        opt.step()
+        opt._poll_guard(torch.device("cpu"), block=True)         # (on the GPU the count arrives one poll later, without a sync)
+    after = snap()
+    for a, b in zip(before, after):
+        assert all(torch.equal(s, t) for s, t in zip(a, b))      # every weight and both moments of EVERY tensor intact
+    assert opt.skipped_steps == 1
+    backward()
+    opt.step()                                                   # the next finite step trains on
+    assert not torch.equal(snap()[0][0], before[0][0]) and opt.skipped_steps == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from _pytest.monkeypatch import MonkeyPatch
+    from tests import emu_optim
+    from wesep_amd.optim import FusedClipAdam
+    from wesep_amd.parallel import init_distributed
+    init_distributed(backend="gloo")
+    mp_ = MonkeyPatch()
+    net = _net(5)                                                # same initial weights on both ranks
+    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    emu_optim.install(mp_)                                       # (after DDP's construction: it looks at the real device type)
+    opt = FusedClipAdam(net.parameters(), lr=1e-2, weight_decay=1e-3, clip_grad=5.0)
+    g = torch.Generator().manual_seed(100 + rank)                # rank-sharded rows
+    trace = []
+    for step in range(4):
+        x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+        opt.zero_grad()
+        loss = ((ddp(x) - y) ** 2).mean()
+        if step == 1 and rank == 1:
+            loss = loss * float("nan")                           # the NaN is born on ONE rank ...
+        loss.backward()                                          # ... and the all-reduce spreads it
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            opt.step()
+            opt._poll_guard(torch.device("cpu"), block=True)
+        trace.append([p.detach().clone() for p in net.parameters()])
+    torch.save({"trace": trace, "skipped": opt.skipped_steps}, os.path.join(out, f"r{rank}.pt"))
+    mp_.undo()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_nan_on_one_rank_is_skipped_by_every_rank_world2_gloo(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"r{i}.pt") for i in range(2))
+    assert r0["skipped"] == r1["skipped"] == 1
+    for s in range(4):
+        for a, b in zip(r0["trace"][s], r1["trace"][s]):
+            assert torch.equal(a, b) and bool(torch.isfinite(a).all())      # replicas bit-identical, never poisoned
+    assert all(torch.equal(a, b) for a, b in zip(r0["trace"][0], r0["trace"][1]))      # step 1 changed nothing
+    assert not torch.equal(r0["trace"][1][0], r0["trace"][2][0])                       # step 2 trained on
