@@ -120,3 +120,31 @@ def test_pack_cache_follows_the_weights_and_second_backward_is_refused(emu):
     out4.sum().backward(retain_graph=True)
     with pytest.raises(L.WesepHipError, match="second backward"):
         out4.sum().backward()
+
+
+@pytest.mark.parametrize("view,R,K,Tf", [("time", 2, 32, 66), ("band", 2, 3, 2100)])
+def test_fp16_copies_of_the_weight_gradient_operand_touch_the_lstm_weight_gradients_only(emu, monkeypatch, view, R, K, Tf):
+    """ABI v16 (round 4): with the default storage format the weight-gradient GEMM reads fp16 copies of [xn | h] that
+    gemm_p2b / the output projection write on the way (WESEP_TNB_A16, default on).  Against the split-pair operand: output,
+    input gradient, norm and proj gradients bit for bit (nothing else reads the copies), the LSTM weight gradients to fp16
+    rounding of the operand (2^-12 per element, averaged over the positions), the bias gradients bit for bit (column sums
+    of d(gates))."""
+    from wesep_amd import functional as F0
+    monkeypatch.setenv("WESEP_GATES", "h2")
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("WESEP_TNB_A16", flag)
+        p = _params(R * 100 + K)
+        g = torch.Generator().manual_seed(Tf)
+        z = torch.randn(R, K, Tf, 128, generator=g).requires_grad_(True)
+        probe = torch.randn(R, K, Tf, 128, generator=g)
+        out = F0.ResRNNBlkFn.apply(z, None, None, None, view, p["norm.weight"], p["norm.bias"], *(p[n] for n in NAMES))
+        (out * probe).sum().backward()
+        res[flag] = (out.detach().clone(), {"z": z.grad.clone(), **{k: v.grad.clone() for k, v in p.items()}})
+    assert torch.equal(res["1"][0], res["0"][0])
+    for k, g0 in res["0"][1].items():
+        g1 = res["1"][1][k]
+        if "weight_ih" in k or "weight_hh" in k:
+            assert not torch.equal(g1, g0) and float((g1 - g0).norm()) <= 4e-4 * float(g0.norm()), k      # (2^-12 = 2.4e-4 per element)
+        else:
+            assert torch.equal(g1, g0), k
