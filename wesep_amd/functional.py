@@ -161,7 +161,8 @@ def _h2_probe() -> int:
     """NUMERICS PROBE (tools/r04_h2_numerics.py; off by default): emulate narrower storage of the saved recurrence state
     by rounding the fp32 buffers in place between kernels.  Bits: 1 = activated gates to fp16, 2 = d(gates) to bf16
     (the hi term of the split pair only), 4 = cell state to fp16, 8 = activated gates to unorm16, 16 = d(hcat) to bf16,
-    64 / 128 = the A operand [xn | h] of the weight-gradient GEMMs to fp16 / bf16 (CPU emulation)."""
+    64 / 128 = the A operand [xn | h] of the weight-gradient GEMMs to fp16 / bf16, 256 / 512 = the pre-activations of the
+    unfused (time-view) forward to fp16 / bf16 (CPU emulation)."""
     return int(os.environ.get("WESEP_H2_PROBE", "0"))
 
 
@@ -428,6 +429,9 @@ class ResRNNBlkFn(torch.autograd.Function):
                          stats=stats, gamma=norm_w, beta=norm_b, stat_map=smap, A_bl16=xn16)
             rec = dict(gfmt=gfmt, gates_in=pre) if h2 else {}
             dev.gemm_p2b(**xproj)
+            if _h2_probe() & 768 and not torch.cuda.is_available():
+                # NUMERICS PROBE (CPU emulation only): the time view's pre-activations in 2 bytes -- fp16 (bit 256) / bf16 (512)
+                pre.copy_(pre.half().float() if _h2_probe() & 256 else pre.bfloat16().float())
             if cluster:
                 # weight-stationary cluster kernel; behind it the streaming pair predicated on the launch's timeout
                 # word: two empty launches after a clean run, the whole layer again if the cluster's workgroups
