@@ -162,7 +162,7 @@ def _h2_probe() -> int:
     by rounding the fp32 buffers in place between kernels.  Bits: 1 = activated gates to fp16, 2 = d(gates) to bf16
     (the hi term of the split pair only), 4 = cell state to fp16, 8 = activated gates to unorm16, 16 = d(hcat) to bf16,
     64 / 128 = the A operand [xn | h] of the weight-gradient GEMMs to fp16 / bf16, 256 / 512 = the pre-activations of the
-    unfused (time-view) forward to fp16 / bf16 (CPU emulation)."""
+    unfused (time-view) forward to fp16 / bf16, 1024 = the proj weight gradient on fp16 operands (CPU emulation)."""
     return int(os.environ.get("WESEP_H2_PROBE", "0"))
 
 
@@ -486,6 +486,13 @@ class ResRNNBlkFn(torch.autograd.Function):
         if os.environ.get("WESEP_PROBE_SKIP_WGRAD") == "1":   # measurement only: how much of this is exposed?
             z_ = lambda *s_: torch.zeros(*s_, device=d)
             return [z_(G4, N), z_(G4, H), z_(G4), z_(G4), z_(G4, N), z_(G4, H), z_(G4), z_(G4), z_(N, 2 * H), z_(N)]
+        if _h2_probe() & 1024 and not torch.cuda.is_available() and amax is not None:
+            # NUMERICS PROBE (CPU emulation only): the proj weight gradient on fp16 operands -- h as fp16, the incoming
+            # gradient as fp16 scaled by the d(gates) scale of this backward (max |d(hcat)| in [2^10, 2^11))
+            e = (int(amax.reshape(-1)[0]) >> 23) & 0xFF
+            S = 1.0 if e in (0, 255) else 2.0 ** (min(max(264 - e, 1), 253) - 127)
+            hcat = hcat.half().float()
+            dout_bl = (dout_bl * S).clamp(-65504.0, 65504.0).half().float() / S
         # dW_proj^T [2H][N] = hcat^T dout (hcat as the streamed-once operand), db_proj = colsum(dout)
         ns, bps = dev.tnb_splits(nb, (2 * H) // 128)
         slab, aslab = _empty(d, ns, 2 * H * N), _empty(d, ns, N)
