@@ -8,6 +8,8 @@
 #      predates the fp16 A operand of gemm_tnb)
 #   3. TF-GridNet with WESEP_TFG_TNB_A16=1 under the profiler (304 vs 310 ms for +8 GB: where do the other 30 ms of shorter
 #      gemm_tnb launches go?)
+#   4. gemm_tnb16<AF = 1> needs 80 KB of LDS, so TWO workgroups fit a CU now: WESEP_TNB_WGS=512 (64 splits x 8 column tiles) may
+#      overlap one workgroup's loads with the other's MFMAs (with the 160 KB kernel it was slower: profiles/r04_ab_runs.md call 9)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 O=gpurun_out
 mkdir -p $O
@@ -21,4 +23,8 @@ grep "^{" $O/r05_ssa_multi.jsonl | cut -c1-300
 for v in 1 0; do
   WESEP_TFG_TNB_A16=$v timeout 300 python tools/bench_tfgridnet.py --rows 8 --recipe --steps 4 --warmup 3 > $O/r05_tfg_a16_$v.json 2> $O/r05_tfg_a16_$v.err
   python -c "import json;d=json.loads(open('$O/r05_tfg_a16_$v.json').read().strip().splitlines()[-1]);print('tfgridnet a16=$v', d['ms_per_step'], d['peak_mem_GB'], d['roofline']['kernel_ms_per_step'])"
+done
+for w in 256 512; do
+  WESEP_TNB_WGS=$w timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/r05_bench_wgs$w.json 2> $O/r05_bench_wgs$w.err
+  python -c "import json;d=json.loads(open('$O/r05_bench_wgs$w.json').read().strip().splitlines()[-1]);print('bench WESEP_TNB_WGS=$w', d['ms_per_step'], d['value'])"
 done
