@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 16
+#define WS_ABI_VERSION 17
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -252,15 +252,19 @@ typedef struct ws_lstm_args {
 #define WS_GATES_H2 1
 #define WS_GATES_H2S 2
 /*   WS_GATES_H2F (3): activated gates as in H2; d(gates) as SCALED fp16, in place or to `dgates` like H2:
- *                     stored = fp16(clamp(x * S, +-65504)),  S = ws_dgates_scale(*amax) = the power of two that puts
- *                     max |d(hcat)| of the launch -- the word `amax` (float bits), raised by the ws_gemm_p2b launch that
- *                     produced d(hcat) (ws_gemm_p2b_args.amax; the caller zeroes it) -- into [2^10, 2^11): d(gates)
- *                     never exceed a few times max |d(hcat)|, so nothing saturates in practice (the clamp is the bound),
- *                     and everything down to 2^-24 of the largest keeps fp16's 11 bits -- 8x finer than bf16, at the same
- *                     2 bytes.  Consumers (ws_gemm_b2p a_fmt = 2, ws_gemm_tnb g_fmt = 2) read `amax` themselves, rebuild
- *                     split-bf16 fragments in registers (an fp16 value splits EXACTLY into bf16 hi + lo) and undo S (exact)
- *                     in their epilogues.  The default of the Python path.                                            */
+ *                     stored = fp16(x * S),  S = ws_dgates_scale(*amax) = the power of two that puts max |d(hcat)| of the
+ *                     launch -- the word `amax` (float bits), raised by the ws_gemm_p2b launch that produced d(hcat)
+ *                     (ws_gemm_p2b_args.amax; the caller zeroes it) -- into [2^WS_DGATES_EXP, 2^(WS_DGATES_EXP + 1)):
+ *                     2^7 of headroom for what the BPTT accumulates on top of d(hcat), and everything down to 2^-22 of
+ *                     the largest keeps fp16's 11 bits -- 8x finer than bf16, at the same 2 bytes.  NOT clamped (ABI v17;
+ *                     v15 / v16 stored fmed3(x * S, +-65504) and put the maximum into [2^10, 2^11)): a value beyond fp16's
+ *                     range is stored as +-Inf, a NaN as NaN -- the consumers turn them into non-finite gradients, which
+ *                     ws_grad_norms' guard catches: the optimizer step is skipped and counted instead of taken on
+ *                     silently clipped gradients.  Consumers (ws_gemm_b2p a_fmt = 2, ws_gemm_tnb g_fmt = 2) read `amax`
+ *                     themselves, feed the fp16 values to v_mfma_f32_32x32x16_f16 as they are and undo S (exact) in their
+ *                     epilogues.  The default of the Python path.                                                     */
 #define WS_GATES_H2F 3
+#define WS_DGATES_EXP 8
 #define WS_LSTM_F32_MT1 1 /* exact-fp32 MFMA, 16 sequences per workgroup                       */
 #define WS_LSTM_F32_MT2 2 /* exact-fp32 MFMA, 32 sequences per workgroup                       */
 #define WS_LSTM_BF16X3 3  /* split-bf16 (hi/lo, 3 bf16 MFMAs per product, fp32 accumulate), 32 */
@@ -326,7 +330,8 @@ int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream);
  * the whole BPTT again after a timeout -- no NaN reaches a consumer, no host round trip (ABI v15).
  * dbg (probes / tests only): 1 skip the flag wait, 2 skip the exchange, 4 no weight reloads,
  * 8 force a timeout in pair 0 at step 2, 32 no wave priorities,
- * 64 full agent-scope release / acquire fences around the hand-off.                                             */
+ * 64 full agent-scope release / acquire fences around the hand-off, 2048 (WS_GATES_F32 / H2F) cycle stamps of pair 0
+ * into dbg_buf (tools/pair_diag.py --ts).                                                                         */
 typedef struct ws_lstm_pair_args {
   float* gates;
   const float* cbuf;
@@ -342,8 +347,15 @@ typedef struct ws_lstm_pair_args {
                            (BLH) when given, else in place; H2S: d(gates) as BLS pairs to `dgates`                     */
   float* dgates;
   const unsigned* amax; /* WS_GATES_H2F: max |dhcat| of this launch as float bits */
+  int rfmt, pad_;       /* ABI v17: arithmetic of the recurrent product d(h) = d(gates) W_hh.  0: split-bf16, three
+                           v_mfma_f32_32x32x16_bf16 per product (wpack from ws_lstm_pack_pair); 1 (WS_GATES_H2F only): the
+                           STORED scaled-fp16 d(gates) as one operand of v_mfma_f32_32x32x16_f16 against W_hh as fp16 hi / lo
+                           of 256 w (wpack from ws_lstm_pack_pair_f16): two MFMAs per product, what the kernel writes is
+                           what its own recurrence and both consumers read                                         */
 } ws_lstm_pair_args;
 int ws_lstm_pack_pair(const float* whh_f, const float* whh_r, float* pack, void* stream);
+/* ABI v17: the pack of rfmt = 1 (same size and unit order, fp16 hi / lo of 256 w; |w| < 255) */
+int ws_lstm_pack_pair_f16(const float* whh_f, const float* whh_r, float* pack, void* stream);
 int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream);
 /* wcat[2][4H][N] <- (w_ih_f, w_ih_r);  bcat[2][4H] <- b_ih + b_hh per direction             */
 int ws_lstm_cat_ih(const float* wih_f, const float* wih_r, const float* bih_f, const float* bhh_f,

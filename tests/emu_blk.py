@@ -7,6 +7,8 @@ device; here a registry keyed by the pack buffer's address keeps the logical mat
 Layout (include/wesep_hip.h): BL(C) block b = tile * L + step holds 32 consecutive sequences; element
 (b, slot i, column c) at b*32*C + ((c >> 2)*32 + i)*4 + (c & 3).  Only tests/ import this; the product has no CPU
 path."""
+import os
+
 import torch
 
 from wesep_amd import dev as real_dev
@@ -101,10 +103,8 @@ def _skip(run_if):
 
 
 def dgates_scale(amax):
-    """WS_GATES_H2F (wesep_hip.h, common.h ws_dgates_scale): the power of two that puts max |d(hcat)| into [2^10, 2^11);
-    `amax`: 1-element int32 tensor holding float bits."""
-    e = (int(amax.reshape(-1)[0]) >> 23) & 0xFF
-    return 1.0 if e in (0, 255) else 2.0 ** (min(max(264 - e, 1), 253) - 127)
+    """WS_GATES_H2F (wesep_hip.h, common.h ws_dgates_scale); `amax`: 1-element int32 tensor holding float bits."""
+    return real_dev.L.dgates_scale(int(amax.reshape(-1)[0]))
 
 
 def gemm_p2b(*, A, lda, sm, Wpack, N, C_out, K=128, bias=None, A_bl=None, stats=None, gamma=None, beta=None,
@@ -125,6 +125,8 @@ def gemm_p2b(*, A, lda, sm, Wpack, N, C_out, K=128, bias=None, A_bl=None, stats=
     if A_bl16 is not None:                 # ABI v16: the operand once more as fp16 in BLH(K)
         blh_put(A_bl16, rows, nt, L, K, torch.float16)
     if N:
+        if _probe() & 8192 and stats is not None:      # (numerics probe: the time view's x-projection on the fp16 copy of xn)
+            rows = rows.half().float()
         out = rows @ _PACKS[Wpack.data_ptr()].t()
         if bias is not None:
             out = out + bias.reshape(-1)[:N]
@@ -156,6 +158,10 @@ def gemm_b2p(*, A, K, sm, Wpack, C_out, ldc, N=128, bias=None, R=None, a_fmt=0, 
     C_out.reshape(-1, ldc)[pos, :N] = out.reshape(-1, N)
 
 
+def _probe():
+    return int(os.environ.get("WESEP_H2_PROBE", "0"))
+
+
 def _recur_fwd(pre, whf, whr):
     """pre [S, L, 2, 4H] pre-activations -> (activated gates, c, h) of the same leading shape."""
     S, L = pre.shape[:2]
@@ -163,7 +169,8 @@ def _recur_fwd(pre, whf, whr):
     for d, W in ((0, whf), (1, whr)):
         h, c = torch.zeros(S, H), torch.zeros(S, H)
         for t in (range(L) if d == 0 else range(L - 1, -1, -1)):
-            p = pre[:, t, d] + h @ W.t()
+            hq = h.half().float() if _probe() & 2048 else h    # (numerics probe: fp16 h in the recurrent product)
+            p = pre[:, t, d] + hq @ W.t()
             i, f, g, o = p[:, :H].sigmoid(), p[:, H:2 * H].sigmoid(), p[:, 2 * H:3 * H].tanh(), p[:, 3 * H:].sigmoid()
             c = f * c + i * g
             h = o * c.tanh()
@@ -171,7 +178,8 @@ def _recur_fwd(pre, whf, whr):
     return act, cs, hs
 
 
-def _recur_bwd(act, cs, dh_in, whf, whr):
+def _recur_bwd(act, cs, dh_in, whf, whr, scale=1.0, rq=False):
+    """rq: the recurrent product takes the STORED scaled-fp16 d(gates) (ws_lstm_pair_args.rfmt = 1)."""
     S, L = act.shape[:2]
     dpre = torch.zeros_like(act)
     for d, W in ((0, whf), (1, whr)):
@@ -189,7 +197,9 @@ def _recur_bwd(act, cs, dh_in, whf, whr):
             dp = torch.cat([dcv * g * i * (1 - i), dcv * cprev * f * (1 - f), dcv * i * (1 - g * g),
                             dh * tc * o * (1 - o)], 1)
             dc = dcv * f
-            dh_rec = dp @ W
+            # (numerics probe 4096: the recurrent product takes the STORED scaled-fp16 d(gates), one MFMA operand)
+            dq = (dp * scale).half().float() / scale if rq or _probe() & 4096 else dp
+            dh_rec = dq @ W
             dpre[:, t, d] = dp
     return dpre
 
@@ -235,18 +245,18 @@ def make_lstm_bwd(plain_bwd):
     return lstm_bwd
 
 
-def _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt=0, dgates=None, amax=None):
+def _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt=0, dgates=None, amax=None, rq=False):
     """gfmt 0: fp32 gates in, d(gates) in place; 1 (H2): unorm16 gates in, bf16 d(gates) in place; 2 (H2S): unorm16 gates
     in, d(gates) to `dgates` (fp32 here: the emulation does not model the split pair's 2^-17)."""
     nt, L = _ntile(sm), sm.L
     act = (gates_get_u16(gates, nt, L) if gfmt else bl_get(gates, nt, L, 2 * G4)).reshape(nt * 32, L, 2, G4)
     cs = bl_get(cbuf, nt, L, 2 * H).reshape(nt * 32, L, 2, H)
     dh = bl_get(dhcat, nt, L, 2 * H).reshape(nt * 32, L, 2, H)
-    dpre = _recur_bwd(act, cs, dh, whf, whr).reshape(nt * 32, L, 2 * G4) * _valid(sm)
+    dpre = _recur_bwd(act, cs, dh, whf, whr, dgates_scale(amax) if gfmt == 3 else 1.0, rq).reshape(nt * 32, L, 2 * G4) * _valid(sm)
     if gfmt == 1:
         blh_put(dgates if dgates is not None else gates, dpre, nt, L, 2 * G4, torch.bfloat16)
-    elif gfmt == 3:      # H2F: fp16(clamp(x * S))
-        sc = (dpre * dgates_scale(amax)).clamp(-65504.0, 65504.0)
+    elif gfmt == 3:      # H2F: fp16(x * S), not clamped (ABI v17: overflow -> Inf -> the optimizer's guard)
+        sc = dpre * dgates_scale(amax)
         blh_put(dgates if dgates is not None else gates, sc, nt, L, 2 * G4, torch.float16)
     else:
         bl_put(dgates if gfmt == 2 else gates, dpre, nt, L, 2 * G4)
@@ -269,12 +279,12 @@ def lstm_bwd_cluster(gates, cbuf, dhcat, whh_f, whh_r, sm, status=None, dbg=0):
     _bwd_into(gates, cbuf, dhcat, whh_f, whh_r, sm)
 
 
-def lstm_pack_pair(whh_f, whh_r, pack):
+def lstm_pack_pair(whh_f, whh_r, pack, f16=False):
     pack.reshape(-1)[: 2 * G4 * H] = torch.stack([whh_f, whh_r]).reshape(-1)      # raw weights, like emu_dev.lstm_pack
 
 
 def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None, repairable=False,
-                  amax=None):
+                  amax=None, rfmt=0):
     """Returns the launch's timeout word like dev.lstm_bwd_pair; dbg & 8 emulates the forced timeout (NaN-poisoned
     d(gates), both words set)."""
     if dbg & 8:
@@ -282,7 +292,7 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0, dbg_buf=Non
         if status is not None:
             status.fill_(1)
         return torch.ones(1, dtype=torch.int32)
-    _bwd_into(gates, cbuf, dhcat, *_whh_from_pack(wpack), sm, gfmt, dgates, amax)
+    _bwd_into(gates, cbuf, dhcat, *_whh_from_pack(wpack), sm, gfmt, dgates, amax, rq=rfmt == 1)
     return torch.zeros(1, dtype=torch.int32)
 
 
@@ -290,6 +300,8 @@ def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm, gfmt=0):
     nt, L = _ntile(sm), sm.L
     wih_f, wih_r, whf, whr = _PACKS[wpack.data_ptr()]
     x = bl_get(xn, nt, L, 128)
+    if _probe() & 16384:                               # (numerics probe: the band view's fused x-projection on fp16 xn)
+        x = x.half().float()
     b = bias.reshape(2, G4)
     pre = torch.stack([x @ wih_f.t() + b[0], x @ wih_r.t() + b[1]], 2)
     _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt)

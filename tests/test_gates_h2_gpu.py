@@ -13,6 +13,8 @@ The formats change what is STORED, not what is computed, so the statements are e
 import pytest
 import torch
 
+from wesep_amd import _lib as L
+
 pytestmark = pytest.mark.gpu
 
 H, N = 256, 128
@@ -164,7 +166,7 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
     # ---- H2F: fp16 of d(gates) scaled by the power of two that max |d(hcat)| defines ------------------------------------
     amax = dh.abs().max().reshape(1).view(torch.int32).clone()    # what ws_gemm_p2b's atomic max leaves behind
     e = (int(amax.item()) >> 23) & 0xFF
-    S = 2.0 ** (264 - e - 127)
+    S = L.dgates_scale(int(amax.item()))
     f_in, f_out_g, f_out_d = gh.clone(), gh.clone(), torch.zeros_like(gh)
 
     def bptt_f(gates, dgates=None):
@@ -183,6 +185,24 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
     bound = dg.abs() * (2.0 ** -11 + 2.0 ** -16) + (2.0 ** -24) / S      # half an fp16 ulp (+ subnormal step) + the pair's 2^-17
     assert bool((err <= bound).all()), float((err / bound).max())
     assert float((got - dg).norm() / dg.norm()) < 3e-4
+    if kind != "pair":
+        return
+    # ---- rfmt = 1 (ABI v17): the recurrent product takes the STORED fp16 d(gates) (one operand of the fp16 MFMA, W_hh as
+    # fp16 hi / lo of 256 w, two terms).  Every step's rounding (2^-12 relative, random) now travels down the recurrence, so
+    # the statement is a tolerance against the three-term kernel, plus determinism and in-place == out-of-place
+    pp16 = torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack_pair(whf, whr, pp16, f16=True)
+    r_in, r_in2, r_out_g, r_out_d = gh.clone(), gh.clone(), gh.clone(), torch.zeros_like(gh)
+    for gates_, dg_ in ((r_in, None), (r_in2, None), (r_out_g, r_out_d)):
+        tw = dev.lstm_bwd_pair(gates_, cbuf, dh, pp16, seq, status=st, gfmt=L.GATES_H2F, dgates=dg_, amax=amax, rfmt=1)
+        assert int(tw.item()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(bits(r_in), bits(r_in2))
+    assert torch.equal(bits(r_out_g), bits(gh)) and torch.equal(bits(r_out_d), bits(r_in))
+    got1 = r_in.reshape(-1)[: ref.numel() // 2].view(torch.float16).view(dg.shape).float() / S
+    assert bool(torch.isfinite(got1).all())
+    assert float((got1 - dg).norm() / dg.norm()) < 6e-4, float((got1 - dg).norm() / dg.norm())
+    assert float((got1 - dg).abs().max() / dg.abs().max()) < 2e-3
 
 
 @pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37))])
@@ -198,7 +218,7 @@ def test_gemm_b2p_scaled_fp16_operand(view, dims):
     P, Kd = R * K * Tf, 2048
     geo, smap, seq, _ = _view_maps(view, R, K, Tf, N)
     amax = torch.tensor([3.1e-6], dtype=torch.float32).view(torch.int32).to(d)      # max |d(hcat)| of a training step
-    S = 2.0 ** (264 - ((int(amax.item()) >> 23) & 0xFF) - 127)
+    S = L.dgates_scale(int(amax.item()))
     Ah = (rnd(g, P, Kd) * 1e-6 * S).to(torch.float16)             # what the BPTT would have stored
     A = Ah.float() / S                                             # the values it stands for (exact)
     W = rnd(g, N, Kd, scale=0.05)
@@ -262,7 +282,7 @@ def test_gemm_tnb_bf16_g_operand(view, dims, monkeypatch):
     G_pairs, G_bf16 = dev.bls_pack(Gbl), dev.blh_bf16_pack(Gbl)
     # g_fmt = 2: the same matrix, were it tiny like a gradient, as scaled fp16.  bf16-grid values are fp16-grid values too.
     amax = torch.tensor([2.7e-6], dtype=torch.float32).view(torch.int32).to(d)
-    S = 2.0 ** (264 - ((int(amax.item()) >> 23) & 0xFF) - 127)
+    S = L.dgates_scale(int(amax.item()))
     tiny = 2.0 ** -20
     G_f16 = (Gbl * (tiny * S)).to(torch.float16).contiguous().view(torch.float32)
     assert torch.equal((Gbl * (tiny * S)).to(torch.float16).float(), Gbl * (tiny * S))
@@ -405,7 +425,7 @@ def test_gemm_tnb_fp16_a_operand(view, dims):
     Gbl = dev.to_blocked(G.to(d), seq)
     A0bl, A1bl = dev.to_blocked(A0.to(d), seq), dev.to_blocked(A1.to(d), seq)
     amax = torch.tensor([2.7e-6], dtype=torch.float32).view(torch.int32).to(d)
-    S = 2.0 ** (264 - ((int(amax.item()) >> 23) & 0xFF) - 127)
+    S = L.dgates_scale(int(amax.item()))
     tiny = 2.0 ** -20
     G_f16 = (Gbl * (tiny * S)).to(torch.float16).contiguous().view(torch.float32)
     forms = {0: (dev.bls_pack(A0bl), dev.bls_pack(A1bl)), 1: (dev.blh_f16_pack(A0bl), dev.blh_f16_pack(A1bl))}

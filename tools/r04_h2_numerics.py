@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--masks", default="0,1,2,3,7,23")
     ap.add_argument("--case", default="bsrnn_film_multi_r2_t3000")
+    ap.add_argument("--T", type=int, default=0, help="override the case's length in samples (64000 = the headline's 501 frames)")
+    ap.add_argument("--repeat", type=int, default=0, help="override num_repeat (6 = the recipe)")
     ap.add_argument("--full", action="store_true", help="trajectory at the fixture's own size (R = 4 x 1 s) also on the CPU")
     a = ap.parse_args()
     from oracle import bsrnn_oracle as O
@@ -65,6 +67,9 @@ def main():
 
     # ---- (1) per-tensor gradients on a fixture-sized case -------------------------------------------------------------
     kw, R, T, seed = CASES[a.case]
+    T = a.T or T
+    if a.repeat:
+        kw = dict(kw, num_repeat=a.repeat)
     cfg, params, _ = build(kw, seed)
     wav, tgt, emb = O.synth_batch(R, T, seed)
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}

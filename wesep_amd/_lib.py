@@ -16,8 +16,18 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 16
+ABI_VERSION = 17
 GATES_F32, GATES_H2, GATES_H2S, GATES_H2F = 0, 1, 2, 3     # WS_GATES_* (wesep_hip.h): storage of the saved gates / d(gates)
+DGATES_EXP = 8             # WS_DGATES_EXP: WS_GATES_H2F puts max |d(hcat)| into [2^8, 2^9)
+
+
+def dgates_scale(amax_bits: int) -> float:
+    """ws_dgates_scale (csrc/common.h) on the host: the power of two WS_GATES_H2F scales d(gates) by, from the float bits
+    of max |d(hcat)|."""
+    e = (int(amax_bits) >> 23) & 0xFF
+    return 1.0 if e in (0, 255) else 2.0 ** (min(max(DGATES_EXP + 254 - e, 1), 253) - 127)
+
+
 LSTM_F32_MT1, LSTM_F32_MT2, LSTM_BF16X3, LSTM_BF16X3_BLK, LSTM_BF16X3_BLK16 = 1, 2, 3, 4, 5
 LSTM_PACK_FLOATS = 2 * 4 * LSTM_H * LSTM_H
 
@@ -112,7 +122,7 @@ class LstmClusterArgs(C.Structure):
 
 class LstmPairArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "dhcat", "wpack", "xchg", "flags", "status", "dbg_buf")] + \
-               [("nseq", _i), ("L", _i), ("dbg", _i), ("gfmt", _i), ("dgates", _p), ("amax", _p)]
+               [("nseq", _i), ("L", _i), ("dbg", _i), ("gfmt", _i), ("dgates", _p), ("amax", _p), ("rfmt", _i), ("pad_", _i)]
 
 
 class Bands(C.Structure):
@@ -161,6 +171,7 @@ _SIGS = {
     "ws_lstm_fwd_cluster": (_i, [C.POINTER(LstmClusterArgs), _p]),
     "ws_lstm_bwd_cluster": (_i, [C.POINTER(LstmClusterArgs), _p]),
     "ws_lstm_pack_pair": (_i, [_p, _p, _p, _p]),
+    "ws_lstm_pack_pair_f16": (_i, [_p, _p, _p, _p]),
     "ws_lstm_bwd_pair": (_i, [C.POINTER(LstmPairArgs), _p]),
     "ws_lstm_cat_ih": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "ws_pack_w": (_i, [_p, _i, _i, _ll, _i, _i, _p, _p]),

@@ -68,11 +68,13 @@ __device__ __forceinline__ float ws_block_sum(float v, float* red) {
 }
 
 // WS_GATES_H2F (wesep_hip.h): the power of two that scales d(gates) into fp16 -- max |d(hcat)| of the launch (float bits in
-// `amax_bits`) lands in [2^10, 2^11); 1 for a zero / non-finite maximum.  Exact to undo (ws_dgates_scale_inv).
+// `amax_bits`) lands in [2^8, 2^9) (rounds 3-4: [2^10, 2^11); 2^7 of headroom below fp16's 65504 for what the BPTT
+// accumulates on top of d(hcat), full 11-bit precision down to 2^-22 of the maximum); 1 for a zero / non-finite maximum.
+// Exact to undo (ws_dgates_scale_inv).
 __device__ __forceinline__ float ws_dgates_scale(unsigned amax_bits) {
   const int e = (int)((amax_bits >> 23) & 0xffu);
   if (e == 0 || e == 255) return 1.f;
-  const int se = min(max(264 - e, 1), 253);  // 2^(10 - (e - 127)); S and 1 / S both stay normal numbers
+  const int se = min(max(WS_DGATES_EXP + 254 - e, 1), 253);  // 2^(WS_DGATES_EXP - (e - 127)); S and 1 / S both stay normal numbers
   return __uint_as_float((unsigned)se << 23);
 }
 __device__ __forceinline__ float ws_dgates_scale_inv(unsigned amax_bits) {

@@ -124,22 +124,26 @@ __device__ __forceinline__ f32x4 dec_u16x4(const u32x2& c) {
   return v;
 }
 __device__ __forceinline__ u32x2 bf16x4_bits(const bf16x4& v) { return __builtin_bit_cast(u32x2, v); }
-// WS_GATES_H2F: d(gates) as fp16(clamp(x * S)), round to nearest even; S = ws_dgates_scale(*amax) (common.h)
+// WS_GATES_H2F: d(gates) as fp16(x * S), round to nearest even; S = ws_dgates_scale(*amax) (common.h)
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // The BPTT kernels run their WHOLE recurrence in scaled units when GF == WS_GATES_H2F: d(hcat) enters through one fma
-// (dh * S + recurrent part: no extra instruction), everything downstream -- d(c), the d(gates), their bf16 hi / lo image
+// (dh * S + recurrent part: no extra instruction), everything downstream -- d(c), the d(gates), their B-operand image
 // for the recurrent MFMA, the partial d(h) a pair exchanges -- is linear in it, and a power of two scales exactly; so the
-// value to store is already x * S and only the clamp and the conversion remain.
-__device__ __forceinline__ u32x2 enc_f16x4_clamped(const f32x4& vs) {
+// value to store is already x * S and only the conversion remains.  NOT clamped (round 5; rounds 3-4 stored
+// fmed3(x, +-65504)): a scaled d(gates) beyond fp16's range becomes +-Inf and a NaN stays a NaN, so both reach the
+// weight-gradient GEMMs and d(xn) as non-finite values and trip ws_grad_norms' guard -- the optimizer step is SKIPPED and
+// counted, the way a loss-scaler treats an overflow -- where the clamp let silently clipped gradients (and, through
+// v_med3's NaN rule, a NaN turned into -65504) through to the weights.  S leaves 2^7 of headroom above max |d(hcat)|.
+__device__ __forceinline__ u32x2 enc_f16x4(const f32x4& vs) {
   f16x4 h;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) h[j] = (_Float16)__builtin_amdgcn_fmed3f(vs[j], -65504.f, 65504.f);
+  for (int j = 0; j < 4; ++j) h[j] = (_Float16)vs[j];
   return __builtin_bit_cast(u32x2, h);
 }
 // the 8-byte d(gates) cell of the two in-place-capable 2-byte formats (H2F: v is the SCALED value)
 template <int GF>
 __device__ __forceinline__ u32x2 enc_dgates(const f32x4& v, const bf16x4& hi) {
-  if constexpr (GF == WS_GATES_H2F) return enc_f16x4_clamped(v);
+  if constexpr (GF == WS_GATES_H2F) return enc_f16x4(v);
   else return bf16x4_bits(hi);
 }
 // d(h) of this step = d(hcat) from the layer above (scaled on entry for H2F) + the recurrent part

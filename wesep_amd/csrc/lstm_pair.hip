@@ -69,6 +69,40 @@ __global__ void lstm_pack_pair_kernel(const float* __restrict__ whh_f, const flo
   }
 }
 
+// The same unit order with fp16 elements: hi = fp16(256 w), lo = fp16(256 w - hi) -- the A operand of
+// v_mfma_f32_32x32x16_f16 in the RF = 1 kernel below (the factor 2^8 keeps the lo terms of |w| >= 5e-4 out of the fp16
+// denormals, as in ws_pack_w_f16; the kernel undoes it exactly).  |w| < 255.
+__global__ void lstm_pack_pair_f16_kernel(const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                          _Float16* __restrict__ out) {
+  const int total = 2 * LG * LH;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int r = idx;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    const int ks = r & 31; r >>= 5;
+    const int w = r & 7; r >>= 3;
+    const int hs = r & 1; r >>= 1;
+    const int d = r;
+    const float* W = d ? whh_r : whh_f;
+    const int mt = w < 4 ? 4 * (1 - hs) + w : 4 * hs + (w - 4);
+    const int u = 32 * mt + (lane & 31);
+    const int kl = 16 * ks + 8 * (lane >> 5) + j;
+    const int row = (kl >> 7) * LH + 128 * hs + (kl & 127);
+    const float v = 256.f * W[row * LH + u];
+    const _Float16 hi = (_Float16)v;
+    const long long unit = ((long long)((d * 2 + hs) * 8 + w) * 2) * (32 * 64) + ks * 64 + lane;
+    out[unit * 8 + j] = hi;
+    out[(unit + 32 * 64) * 8 + j] = (_Float16)(v - (float)hi);
+  }
+}
+
+extern "C" int ws_lstm_pack_pair_f16(const float* whh_f, const float* whh_r, float* pack, void* stream) {
+  WS_REQUIRE(whh_f && whh_r && pack, "ws_lstm_pack_pair_f16: null pointer");
+  hipLaunchKernelGGL(lstm_pack_pair_f16_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, whh_f, whh_r,
+                     reinterpret_cast<_Float16*>(pack));
+  return ws_check_launch("ws_lstm_pack_pair_f16");
+}
+
 extern "C" int ws_lstm_pack_pair(const float* whh_f, const float* whh_r, float* pack, void* stream) {
   WS_REQUIRE(whh_f && whh_r && pack, "ws_lstm_pack_pair: null pointer");
   hipLaunchKernelGGL(lstm_pack_pair_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, whh_f, whh_r,
@@ -83,7 +117,19 @@ __device__ __noinline__ void pair_timed_out(unsigned* tword, unsigned* status) {
 }
 
 #define PAIR_RING 4   // lo-plane fragments per ring slot (two slots)
-#define PAIR_LDSK 8   // k-steps whose lo fragments stay in LDS (the rest is streamed)
+// k-steps whose lo fragments stay in LDS (the rest is streamed): 8 beside the two-plane bf16 image of d(gates), 12 beside the
+// one-plane fp16 image of RF = 1 (33 instead of 65 KB)
+template <int RF> struct pair_ldsk { static constexpr int value = RF ? 12 : 8; };
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// one product term of the recurrent GEMM: RF = 0 bf16 x bf16, RF = 1 fp16 x fp16 (operands travel as bf16x8 bit patterns)
+template <int RF>
+__device__ __forceinline__ f32x16 pair_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (RF != 0)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return mfma32(a, b, c);
+}
 
 // V: compile-time variant bits (the step body stays free of run-time branches): 8 = test build that forces a timeout
 // in pair 0 at step 2 (the bisect builds of round 3 -- no reloads, no priorities, cell backward only, no hand-off, no
@@ -100,10 +146,18 @@ __device__ __noinline__ void pair_timed_out(unsigned* tword, unsigned* status) {
 
 // GF: WS_GATES_* (lstm_bf16_common.h): H2 = unorm16 gates in, bf16 d(gates) out, in place on the BLH buffer; H2S = unorm16
 // gates in, d(gates) as BLS pairs to p.dgates
-template <int V, int GF = 0>
+// RF (ABI v17, ws_lstm_pair_args.rfmt; GF = WS_GATES_H2F only): 1 = the recurrent product on v_mfma_f32_32x32x16_f16 with the
+// STORED scaled-fp16 d(gates) as its one B operand -- exactly the value the weight-gradient GEMMs and d(xn) consume -- and
+// W_hh as fp16 hi / lo of 256 w (ws_lstm_pack_pair_f16): TWO MFMAs per product instead of three, one LDS image plane
+// instead of two, and the LDS that frees holds four more k-steps of the lo plane (160 instead of 192 KB per step from L2).
+// Settled on the CPU emulation first (tools/r04_h2_numerics.py, probe bit 4096: no measurable change of any gradient at
+// the fixture size or at 501 frames).
+template <int V, int GF = 0, int RF = 0>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pair_args p) {
-  __shared__ __attribute__((aligned(16))) __bf16 bimg[2][SQ * PR_ROW];      // [part][seq][local gate col] 65 KB
-  __shared__ __attribute__((aligned(16))) bf16x8 whl[8 * PAIR_LDSK * 64];   // lo fragments of k-steps 0..7, 64 KB
+  static_assert(RF == 0 || GF == WS_GATES_H2F, "the fp16 recurrence takes the scaled-fp16 d(gates) of WS_GATES_H2F");
+  constexpr int PAIR_LDSK = pair_ldsk<RF>::value;
+  __shared__ __attribute__((aligned(16))) __bf16 bimg[RF ? 1 : 2][SQ * PR_ROW];  // [part][seq][local gate col] 65 / 33 KB
+  __shared__ __attribute__((aligned(16))) bf16x8 whl[8 * PAIR_LDSK * 64];   // lo fragments of k-steps 0..7 (0..11), 64 / 96 KB
   __shared__ __attribute__((aligned(16))) f32x4 rec[2][512];                // the other role's partial dh, 16 KB
   const int ntile = (p.nseq + SQ - 1) / SQ, npair = 2 * ntile;
   // block -> (pair, member): members of a pair are 8 blocks apart (same XCD under round-robin dispatch)
@@ -205,7 +259,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int q = q0 + 2 * e;
-      const f32x4 dhr = mine[e] + oth[e * 64];
+      f32x4 dhr = mine[e] + oth[e * 64];
+      if constexpr (RF != 0) dhr *= (1.f / 256.f);   // the fp16 weights are 256 w (exact to undo)
       f32x4 pi, pf, pg, po;
       const f32x4 vi = gate_val<false>(n_i[e]), vf = gate_val<false>(n_f[e]), vg = gate_val<true>(n_g[e]),
                   vo = gate_val<false>(n_o[e]);
@@ -224,10 +279,16 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       }
       c_cur[e] = n_cp[e];
       auto emit = [&](const f32x4& v, int g) {
+        if constexpr (RF != 0) {
+          const u32x2 code = enc_f16x4(v);   // what goes to HBM IS the B operand
+          *reinterpret_cast<u32x2*>(&bimg[0][n * PR_ROW + g * 128 + 4 * q]) = code;
+          bst8(code, ors(t), gvo >> 1, (g * 64 + 2 * e) * 256);
+          return;
+        }
         bf16x4 hi, lo;
         split4(v, hi, lo);
         *reinterpret_cast<bf16x4*>(&bimg[0][n * PR_ROW + g * 128 + 4 * q]) = hi;
-        *reinterpret_cast<bf16x4*>(&bimg[1][n * PR_ROW + g * 128 + 4 * q]) = lo;
+        *reinterpret_cast<bf16x4*>(&bimg[RF ? 0 : 1][n * PR_ROW + g * 128 + 4 * q]) = lo;
         if constexpr (G2) {
           bst8(enc_dgates<GF>(v, hi), ors(t), gvo >> 1, (g * 64 + 2 * e) * 256);
         } else {
@@ -253,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       for (int f = 0; f < PAIR_RING; ++f)
         wl[s][f] = wload(wrs, wlane + f * 1024, zo + (CH0 + s) * (PAIR_RING * 1024));
     const __bf16* bhi = &bimg[0][n * PR_ROW + 8 * half];
-    const __bf16* blo = &bimg[1][n * PR_ROW + 8 * half];
+    const __bf16* blo = &bimg[RF ? 0 : 1][n * PR_ROW + 8 * half];
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
@@ -264,8 +325,13 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       for (int f = 0; f < PAIR_RING; ++f) {
         const int ks = PAIR_RING * ch + f;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bhi + 16 * ks);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(blo + 16 * ks);
         const bf16x8 al = ch < CH0 ? wlds[ks * 64] : wl[s][f];
+        if constexpr (RF != 0) {
+          acc0 = pair_mfma<1>(wh[ks], bh, acc0);
+          acc1 = pair_mfma<1>(al, bh, acc1);
+          continue;
+        }
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(blo + 16 * ks);
         if (ks & 1) {
           acc1 = mfma32(wh[ks], bh, acc1);
           acc0 = mfma32(al, bh, acc0);
@@ -372,6 +438,8 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2F && (a->gfmt != WS_GATES_H2S || a->dgates) &&
                  (a->gfmt != WS_GATES_H2F || a->amax),
              "ws_lstm_bwd_pair: gfmt %d (WS_GATES_H2S needs dgates, WS_GATES_H2F needs amax)", a->gfmt);
+  WS_REQUIRE(a->rfmt == 0 || (a->rfmt == 1 && a->gfmt == WS_GATES_H2F),
+             "ws_lstm_bwd_pair: rfmt %d (1 = fp16 recurrence: WS_GATES_H2F only)", a->rfmt);
   const int npair = 2 * ((a->nseq + SQ - 1) / SQ);
   static int cus = 0;      // same part on every device of a node; queried once
   if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 0;
@@ -382,6 +450,13 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)npair * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_pair: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
+  if (a->rfmt == 1) {
+    if (a->dbg & 8) hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2F, 1>), dim3(grid), dim3(512), 0, s, *a);
+    else if (a->dbg & 2048) hipLaunchKernelGGL((lstm_bwd_pair_kernel<2048, WS_GATES_H2F, 1>), dim3(grid), dim3(512), 0, s, *a);
+    else hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, WS_GATES_H2F, 1>), dim3(grid), dim3(512), 0, s, *a);
+    ws_prof_end(WS_PROF_LSTM_BWD, s);
+    return ws_check_launch("ws_lstm_bwd_pair");
+  }
   switch ((a->dbg & (8 | 2048)) + a->gfmt) {
     case 0: hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, 0>), dim3(grid), dim3(512), 0, s, *a); break;
     case 1: hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, WS_GATES_H2>), dim3(grid), dim3(512), 0, s, *a); break;
@@ -392,7 +467,8 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
     case 10: hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2S>), dim3(grid), dim3(512), 0, s, *a); break;
     case 11: hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2F>), dim3(grid), dim3(512), 0, s, *a); break;
     case 2048: hipLaunchKernelGGL((lstm_bwd_pair_kernel<2048, 0>), dim3(grid), dim3(512), 0, s, *a); break;  // cycle stamps
-    default: WS_REQUIRE(false, "ws_lstm_bwd_pair: dbg bits 8 and 2048 are exclusive; cycle stamps are WS_GATES_F32 only");
+    case 2048 + 3: hipLaunchKernelGGL((lstm_bwd_pair_kernel<2048, WS_GATES_H2F>), dim3(grid), dim3(512), 0, s, *a); break;
+    default: WS_REQUIRE(false, "ws_lstm_bwd_pair: dbg bits 8 and 2048 are exclusive; cycle stamps: WS_GATES_F32 / H2F only");
   }
   ws_prof_end(WS_PROF_LSTM_BWD, s);
   return ws_check_launch("ws_lstm_bwd_pair");

@@ -543,14 +543,15 @@ def lstm_pair_ok(sm: SeqMap, device) -> bool:
     return 4 * (-(-sm.nseq // 32)) <= cu_count(device) // 2 and sm.L >= 64
 
 
-def lstm_pack_pair(whh_f, whh_r, pack):
+def lstm_pack_pair(whh_f, whh_r, pack, f16=False):
     for n, t in (("whh_f", whh_f), ("whh_r", whh_r), ("pack", pack)):
         _chk(t, n)
-    L.check(L.lib().ws_lstm_pack_pair(_p(whh_f), _p(whh_r), _p(pack), L.stream_ptr()), "ws_lstm_pack_pair")
+    fn = L.lib().ws_lstm_pack_pair_f16 if f16 else L.lib().ws_lstm_pack_pair
+    L.check(fn(_p(whh_f), _p(whh_r), _p(pack), L.stream_ptr()), "ws_lstm_pack_pair")
 
 
 def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None,
-                  repairable=False, amax=None):
+                  repairable=False, amax=None, rfmt=0):
     """BPTT on the blocked layout over pairs of workgroups (lstm_pair.hip); gates: activated gates in,
     d(pre-activation gates) (BLS) out.  Returns the launch's timeout word; in place, so there is no device-side
     fall-back: poll_cluster_status raises (one step late, without a host sync) when a bounded wait timed out."""
@@ -569,6 +570,7 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg
     a.dbg_buf = C.c_void_p(dbg_buf.data_ptr()) if dbg_buf is not None else None
     a.gfmt, a.dgates = gfmt, _p(dgates)
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
+    a.rfmt = rfmt           # 1: fp16 recurrence (wpack from lstm_pack_pair(..., f16=True); WS_GATES_H2F only)
     _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
     L.check(L.lib().ws_lstm_bwd_pair(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_pair")
     return flags[npair * 8:npair * 8 + 1]

@@ -191,6 +191,13 @@ def tnb_a16() -> bool:
     return os.environ.get("WESEP_TNB_A16", "1") != "0"
 
 
+def pair_rfmt(gfmt) -> int:
+    """Arithmetic of the pair BPTT's recurrent product (ws_lstm_pair_args.rfmt, ABI v17): 1 (default with WS_GATES_H2F) = the
+    stored scaled-fp16 d(gates) x fp16 hi / lo W_hh on the fp16 MFMA, two terms; WESEP_PAIR_RF=0 keeps the three-term
+    split-bf16 product of rounds 3-4."""
+    return 1 if gfmt == L.GATES_H2F and os.environ.get("WESEP_PAIR_RF", "1") != "0" else 0
+
+
 def wgrad_overlap() -> bool:
     """Weight-gradient GEMMs of the blocked ResRNN on a side stream (default on; WESEP_WGRAD_OVERLAP=0
     keeps everything on the current stream)."""
@@ -460,7 +467,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             # chip-filling weight-gradient GEMMs for up to a millisecond each (round 2 profile: 4 ms per step)
             W("projT"), W("wihT16" if gfmt == L.GATES_H2F else "wihT")
             if ctx.bptt == "pair":
-                W("hhp")
+                W("hhp16" if pair_rfmt(gfmt) else "hhp")
             if ctx.bptt == "stream" or (ctx.bptt == "pair" and h2):
                 W("hh")     # (the pair BPTT's predicated streaming fall-back of the 2-byte formats)
         # (with the fp16 copies the backward never reads the split-pair xn again: its 2-byte copy is saved instead)
@@ -488,11 +495,10 @@ class ResRNNBlkFn(torch.autograd.Function):
             return [z_(G4, N), z_(G4, H), z_(G4), z_(G4), z_(G4, N), z_(G4, H), z_(G4), z_(G4), z_(N, 2 * H), z_(N)]
         if _h2_probe() & 1024 and not torch.cuda.is_available() and amax is not None:
             # NUMERICS PROBE (CPU emulation only): the proj weight gradient on fp16 operands -- h as fp16, the incoming
-            # gradient as fp16 scaled by the d(gates) scale of this backward (max |d(hcat)| in [2^10, 2^11))
-            e = (int(amax.reshape(-1)[0]) >> 23) & 0xFF
-            S = 1.0 if e in (0, 255) else 2.0 ** (min(max(264 - e, 1), 253) - 127)
+            # gradient as fp16 scaled by the d(gates) scale of this backward (L.dgates_scale)
+            S = L.dgates_scale(int(amax.reshape(-1)[0]))
             hcat = hcat.half().float()
-            dout_bl = (dout_bl * S).clamp(-65504.0, 65504.0).half().float() / S
+            dout_bl = (dout_bl * S).half().float() / S
         # dW_proj^T [2H][N] = hcat^T dout (hcat as the streamed-once operand), db_proj = colsum(dout)
         ns, bps = dev.tnb_splits(nb, (2 * H) // 128)
         slab, aslab = _empty(d, ns, 2 * H * N), _empty(d, ns, N)
@@ -568,8 +574,9 @@ class ResRNNBlkFn(torch.autograd.Function):
             # time-out word: an empty launch after a clean run, the whole BPTT again if the pair's workgroups were not
             # co-resident (a resident RCCL kernel, another process) -- no NaN reaches a consumer (wesep_hip.h)
             dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else _empty(d, dev.blh_floats(nb, 2 * G4))
-            tw = dev.lstm_bwd_pair(gates, cbuf, dh, W("hhp"), seq, gfmt=gfmt, dgates=dg, repairable=True, dbg=_pair_dbg(),
-                                   amax=amax)
+            rf = pair_rfmt(gfmt)
+            tw = dev.lstm_bwd_pair(gates, cbuf, dh, W("hhp16" if rf else "hhp"), seq, gfmt=gfmt, dgates=dg, repairable=True,
+                                   dbg=_pair_dbg(), amax=amax, rfmt=rf)
             dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode, gfmt=gfmt, dgates=dg, run_if=tw, amax=amax)
         else:
             # streaming BPTT (band view): bf16 d(gates) in place over the unorm16 gates (H2) / split pairs to their own
@@ -678,9 +685,9 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
             pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
             dev.lstm_pack(*W("whh"), pack_f, pack_b, lmode)
             return pack_f, pack_b
-        if kind == "hhp":
+        if kind in ("hhp", "hhp16"):      # hhp16: fp16 hi / lo of 256 w (ws_lstm_pack_pair_f16, the rfmt = 1 pair BPTT)
             pack = _empty(d, L.LSTM_PACK_FLOATS)
-            dev.lstm_pack_pair(*W("whh"), pack)
+            dev.lstm_pack_pair(*W("whh"), pack, f16=kind == "hhp16")
             return pack
         if kind == "fused":
             fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
