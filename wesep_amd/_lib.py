@@ -120,6 +120,11 @@ class LstmClusterArgs(C.Structure):
                [("nseq", _i), ("L", _i), ("dbg", _i), ("gfmt", _i), ("gates_in", _p)]
 
 
+class LstmCluster2Args(C.Structure):
+    _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "xn16", "wcat", "bcat", "whh_f", "whh_r", "xchg", "tword", "status")] + \
+               [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i)]
+
+
 class LstmPairArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "dhcat", "wpack", "xchg", "flags", "status", "dbg_buf")] + \
                [("nseq", _i), ("L", _i), ("dbg", _i), ("gfmt", _i), ("dgates", _p), ("amax", _p), ("rfmt", _i), ("pad_", _i)]
@@ -170,6 +175,7 @@ _SIGS = {
     "ws_lstm_bwd": (_i, [C.POINTER(LstmArgs), _p]),
     "ws_lstm_fwd_cluster": (_i, [C.POINTER(LstmClusterArgs), _p]),
     "ws_lstm_bwd_cluster": (_i, [C.POINTER(LstmClusterArgs), _p]),
+    "ws_lstm_fwd_cluster2": (_i, [C.POINTER(LstmCluster2Args), _p]),
     "ws_lstm_pack_pair": (_i, [_p, _p, _p, _p]),
     "ws_lstm_pack_pair_f16": (_i, [_p, _p, _p, _p]),
     "ws_lstm_bwd_pair": (_i, [C.POINTER(LstmPairArgs), _p]),

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512, 4) void gemm_p2b_kernel(const ws_gemm_p2b_args
 }
 
 extern "C" int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream) {
-  WS_REQUIRE(a && a->A && ((a->Wpack && a->C) || (a->N == 0 && a->A_bl)), "ws_gemm_p2b: null pointer");
+  WS_REQUIRE(a && a->A && ((a->Wpack && a->C) || (a->N == 0 && (a->A_bl || a->A_bl16))), "ws_gemm_p2b: null pointer");
   WS_REQUIRE(a->K == P2B_K, "ws_gemm_p2b: K must be %d (got %d)", P2B_K, a->K);
   WS_REQUIRE(a->N >= 0 && a->N % 64 == 0, "ws_gemm_p2b: N %% 64 (N=%d)", a->N);
   WS_REQUIRE(a->lda >= a->K && a->lda % 4 == 0, "ws_gemm_p2b: lda");

@@ -1,0 +1,314 @@
+// Weight-stationary BLSTM forward recurrence across clusters of 8 workgroups, second generation (round 5, ABI v17):
+// the time view of pBSRNN (bsrnn.py:38-46: 1024 sequences x 501 latency-bound steps).  Same cluster geometry and the same
+// outputs as lstm_fwd_cluster_kernel (lstm_cluster.hip): a cluster owns 64 sequences of one direction, workgroup j keeps the
+// W_hh rows of hidden units [32j, 32j + 32) in the registers of its 8 waves and h_t is exchanged every step.  Three things
+// changed, each settled on the CPU emulation first (tools/r04_h2_numerics.py, probe bits 2048 / 8192: no gradient moves):
+//
+//   1. The recurrent product runs on v_mfma_f32_32x32x16_f16: h_t in (-1, 1) as ONE fp16 operand (11 bits), W_hh as fp16
+//      hi / lo of 256 w -- two MFMAs per product instead of three; the h image in LDS is one plane (33 instead of 66 KB) and
+//      a workgroup's slice of h_t travels as 4 KB instead of 8.
+//   2. The x-projection is computed here: the workgroup's W_ih slice (128 gate rows x 128 inputs, fp16 hi / lo of 256 w,
+//      64 KB) sits in the LDS that item 1 freed, the normalised input arrives as the fp16 copy ws_gemm_p2b already writes
+//      for the weight-gradient GEMMs (BLH(128), 16 KB per step for the cluster's two tiles) and its 16 MFMAs per wave and
+//      step do not depend on h: they are issued for step t + 1 WHILE step t's h is in flight between the workgroups.  The
+//      16E-byte fp32 pre-activation buffer (4.2 GB per launch at R = 32: written by ws_gemm_p2b, read back here) and that
+//      GEMM (1.04 ms per launch) are gone; the accumulators start from 256 (b_ih + b_hh).
+//   3. The hand-off carries its own arrival tag instead of payload + drain + flag + poll: |h| <= 1 leaves bit 14 of every
+//      fp16 value zero, so the producer ORs the step's tag ((step >> 1) & 1: the exchange slots are double-buffered by
+//      step parity, a slot's previous content is two steps old and carries the other tag) into bit 14 of all eight values
+//      of a 16-byte granule, stores it write-through (sc1) and is done -- no vmcnt drain, no barrier, no flag.  The
+//      consumer loads the granules with sc1 (L1 bypassed), accepts a granule when every dword carries the expected tag
+//      (dwords are written atomically; nothing is assumed about 16 bytes) and strips the tags.  Three workgroup barriers
+//      per step instead of five.  The exchange buffer is filled with tag 1 (0x40 bytes) before every launch; steps 0 and 1
+//      carry tag 0.
+// Every wait is bounded: a time-out sets the launch's time-out word and *status and poisons this workgroup's outputs with
+// NaN; callers enqueue the predicated streaming path (ws_gemm_p2b + ws_lstm_fwd with run_if) behind the launch, as for
+// ws_lstm_fwd_cluster.  Residency: one workgroup per CU (150 KB of LDS, 8 waves x <= 256 VGPRs), (nseq / 32) * 8 <= CUs.
+#include "lstm_bf16_common.h"
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define SC1 16
+#define C2_SEQ 64
+#define C2_SPIN_LIMIT (1u << 18)
+#define C2_TAGS 0x40004000u
+
+__device__ __forceinline__ f32x16 mfma16h(const f16x8& a, const f16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// 8 weights -> fp16 hi / lo of 256 w
+__device__ __forceinline__ void split8h(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float s = 256.f * v[j];
+    hi[j] = (_Float16)s;
+    lo[j] = (_Float16)(s - (float)hi[j]);
+  }
+}
+
+__device__ __noinline__ void cluster2_timed_out(unsigned* tword, unsigned* status, int* dead_s) {
+  *dead_s = 1;
+  __hip_atomic_store((gu32*)tword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (status) __hip_atomic_store((gu32*)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// member j of cluster c for this block: all 8 members of a cluster on ONE XCD (blockIdx % 8), lstm_cluster.hip
+__device__ __forceinline__ bool cluster2_of_block(int ncl, int& c, int& j) {
+  const int cpx = (ncl + 7) >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+  c = (q % cpx) * 8 + x;
+  j = q / cpx;
+  return c < ncl;
+}
+
+template <bool FORCE>
+__global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm_cluster2_args p) {
+  __shared__ __attribute__((aligned(16))) _Float16 hl[C2_SEQ * HROW];   // h image [seq][k], one fp16 plane, 33 KB
+  __shared__ __attribute__((aligned(16))) f16x8 wih[4 * 2 * 8 * 64];    // W_ih slice [uo][part][ks][lane], 64 KB
+  __shared__ __attribute__((aligned(16))) u32x4 xb[1024];               // xn16 blocks of the cluster's two tiles, 16 KB
+  __shared__ __attribute__((aligned(16))) f32x4 outl[4][512];           // i|f, g|o (unorm16), c, h of the step, 32 KB
+  __shared__ __attribute__((aligned(16))) u32x2 publ[512];              // tagged fp16 h cells, 4 KB
+  __shared__ __attribute__((aligned(16))) f32x4 bias_l[32];             // 256 (b_ih + b_hh) [gate][unit 32]
+  __shared__ int dead_s;
+  const int ntile = p.nseq / 32, ncl_dir = ntile / 2, ncl = 2 * ncl_dir;
+  int c, j;
+  if (!cluster2_of_block(ncl, c, j)) return;
+  const int d = c / ncl_dir, cc = c % ncl_dir;
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool xrole = w < 4;
+  const int uo = w & 3, st = w >> 2;
+  const int L = p.L;
+  const long long gblk = (long long)SQ * 2 * LG, cblk = (long long)SQ * 2 * LH;  // elements per block
+
+  // ---- resident W_hh rows: m = lane & 31 -> (gate m >> 3, unit 32j + 8uo + (m & 7)); fp16 hi / lo of 256 w ---------
+  f16x8 wh[16], wl[16];
+  const int wrow = (n >> 3) * LH + 32 * j + 8 * uo + (n & 7);
+  {
+    const float* wr = (d ? p.whh_r : p.whh_f) + (long long)wrow * LH + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      split8h(*reinterpret_cast<const f32x4*>(wr + 16 * ks), *reinterpret_cast<const f32x4*>(wr + 16 * ks + 4), wh[ks], wl[ks]);
+  }
+  // ---- W_ih slice -> LDS: waves (uo, st) fill k-steps [4 st, 4 st + 4) of the rows of uo (both sequence tiles read them)
+  {
+    const float* xr = p.wcat + ((long long)d * LG + wrow) * 128 + 8 * half;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ks = 4 * st + q;
+      f16x8 hi, lo;
+      split8h(*reinterpret_cast<const f32x4*>(xr + 16 * ks), *reinterpret_cast<const f32x4*>(xr + 16 * ks + 4), hi, lo);
+      wih[((uo * 2 + 0) * 8 + ks) * 64 + lane] = hi;
+      wih[((uo * 2 + 1) * 8 + ks) * 64 + lane] = lo;
+    }
+  }
+  if (tid < 128)  // bias_l as floats: index gate * 32 + unit
+    reinterpret_cast<float*>(bias_l)[tid] = 256.f * p.bcat[(long long)d * LG + (tid >> 5) * LH + 32 * j + (tid & 31)];
+  {
+    uint32_t* z = reinterpret_cast<uint32_t*>(hl);
+    for (int i = tid; i < C2_SEQ * HROW / 2; i += 512) z[i] = 0u;
+    if (tid == 0) dead_s = 0;
+  }
+  // ---- HBM side (M-waves): thread mt serves the cells of threads mt (tile 2cc) and mt + 256 (tile 2cc + 1) ----------
+  const int mt = tid & 255;
+  const int m_uo = (mt >> 6) & 3, m_n = mt & 31, m_half = (mt >> 5) & 1;
+  const int gvo = ((d * 256 + 8 * j + 2 * m_uo + m_half) * 32 + m_n) * 16;  // bytes of the fp32 cell; BLH: >> 1
+  const int cvo = ((d * 64 + 8 * j + 2 * m_uo + m_half) * 32 + m_n) * 16;
+  const int gts = (int)(L * gblk * 4), cts = (int)(L * cblk * 4);            // bytes between the two tiles (fp32 element size)
+  auto hrs = [&](int t) { return mkrsrc(p.gates + ((long long)2 * cc * L + t) * (gblk / 2), 0x7fffffffu); };  // BLH
+  auto crs = [&](float* b, int t) { return mkrsrc(b + ((long long)2 * cc * L + t) * cblk, 0x7fffffffu); };
+  // xn16: BLH(128) blocks of 8 KB; the two tiles of the cluster are L blocks apart
+  const char* xbase = reinterpret_cast<const char*>(p.xn16);
+  auto xld = [&](int t, int q) -> u32x4 {   // 16-byte unit mt + 256 q of the pair of blocks (tile 2cc + (q >> 1), step t)
+    const int u = mt + 256 * q;
+    const long long blk = (long long)(2 * cc + (u >> 9)) * L + t;
+    return *reinterpret_cast<const u32x4*>(xbase + blk * 8192 + (u & 511) * 16);
+  };
+  // ---- exchange: X[cluster][parity][producer][granule 256] x 16 B; granule = (seq, unit octet) -----------------------
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(p.xchg) + (long long)c * (2 * 8 * 4096), 0, 2 * 8 * 4096, 0x00020000);
+  const int mycell = ((st * 32 + n) * 4 + uo) * 2 + half;   // 8-byte cell of this thread's four h values in the slice
+  unsigned* tword = p.tword;
+
+  auto step_time = [&](int s) { return d == 0 ? s : L - 1 - s; };
+  // x-projection of one step into the accumulators (they start from the bias): 8 k-steps x {hi, lo}
+  f32x16 acc0, acc1;
+  auto xpart = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = bias_l[q * 8 + 2 * uo + half];
+      acc0[4 * q] = b4[0], acc0[4 * q + 1] = b4[1], acc0[4 * q + 2] = b4[2], acc0[4 * q + 3] = b4[3];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+    const u32x2* xc = reinterpret_cast<const u32x2*>(xb) + st * 1024 + n;   // 8-byte cells: (cq * 32 + n)
+    const f16x8* wa = &wih[(uo * 2) * 8 * 64 + lane];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const u32x2 c0 = xc[(4 * ks + 2 * half) * 32], c1 = xc[(4 * ks + 2 * half + 1) * 32];
+      const f16x8 b = __builtin_bit_cast(f16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
+      acc0 = mfma16h(wa[ks * 64], b, acc0);
+      acc1 = mfma16h(wa[(8 + ks) * 64], b, acc1);
+    }
+  };
+
+  f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+  u32x4 xreg[4];  // M-waves: the xn16 units of the step after next
+  if (!xrole) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xb[mt + 256 * q] = xld(step_time(0), q);
+  }
+  __syncthreads();
+  xpart();        // step 0
+  if (!xrole) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xreg[q] = xld(step_time(min(1, L - 1)), q);
+  }
+  __syncthreads();
+
+  // HBM traffic is issued at the top of the NEXT step, under the MFMAs (a CU's hand-off latency doubles while its memory
+  // queue streams): the outputs of step s - 1 leave the LDS stage, the xn16 units of step s + 1 go regs -> LDS and those of
+  // step s + 2 are requested
+  auto hbm_io = [&](int tprev, int s) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ct = mt + 256 * e;
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        const u32x4 pr = __builtin_bit_cast(u32x4, outl[g2][ct]);
+        bst8(u32x2{pr[0], pr[1]}, hrs(tprev), (gvo + e * gts) >> 1, (2 * g2) * 64 * 256);
+        bst8(u32x2{pr[2], pr[3]}, hrs(tprev), (gvo + e * gts) >> 1, (2 * g2 + 1) * 64 * 256);
+      }
+      bst(outl[2][ct], crs(p.cbuf, tprev), cvo + e * cts, 0);
+      bst(outl[3][ct], crs(p.hcat, tprev), cvo + e * cts, 0);
+    }
+    if (s < L) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xb[mt + 256 * q] = xreg[q];
+      const int t2 = step_time(min(s + 2, L - 1));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xreg[q] = xld(t2, q);
+    }
+  };
+
+  for (int step = 0; step < L; ++step) {
+    const int par = step & 1;
+    const unsigned tag = ((step >> 1) & 1) ? C2_TAGS : 0u;
+    if (!xrole) {
+      if (step > 0) hbm_io(step_time(step - 1), step);
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xb[mt + 256 * q] = xreg[q];   // x of step 1
+        const int t2 = step_time(min(2, L - 1));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xreg[q] = xld(t2, q);
+      }
+    }
+    // ---- G^T tile [4 gates x 8 units][32 seqs] += W_hh slice * h^T -----------------------------------------------------
+    {
+      const _Float16* hb = &hl[(st * 32 + n) * HROW + 8 * half];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const f16x8 b = *reinterpret_cast<const f16x8*>(hb + 16 * ks);
+        acc0 = mfma16h(wh[ks], b, acc0);
+        acc1 = mfma16h(wl[ks], b, acc1);
+      }
+    }
+    __syncthreads();  // 0: the previous step's outputs have left the LDS stage
+    // ---- cell update (register 4q + r = gate q, unit 4 half + r of this wave's 8) ---------------------------------------
+    {
+      f32x4 vi, vf, vg, vo, vh;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ig = fsig((acc0[r] + acc1[r]) * (1.f / 256.f));
+        const float fg = fsig((acc0[4 + r] + acc1[4 + r]) * (1.f / 256.f));
+        const float gg = ftanh((acc0[8 + r] + acc1[8 + r]) * (1.f / 256.f));
+        const float og = fsig((acc0[12 + r] + acc1[12 + r]) * (1.f / 256.f));
+        const float cn = fg * c4[r] + ig * gg;
+        c4[r] = cn;
+        vi[r] = ig, vf[r] = fg, vg[r] = gg, vo[r] = og;
+        vh[r] = og * ftanh(cn);
+      }
+      const bool dead = dead_s != 0;
+      if (dead) vh = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+      const u32x2 ei = enc_u16x4<false>(vi), ef = enc_u16x4<false>(vf), eg = enc_u16x4<true>(vg), eo = enc_u16x4<false>(vo);
+      outl[0][tid] = __builtin_bit_cast(f32x4, u32x4{ei[0], ei[1], ef[0], ef[1]});
+      outl[1][tid] = __builtin_bit_cast(f32x4, u32x4{eg[0], eg[1], eo[0], eo[1]});
+      outl[2][tid] = c4;
+      bf16x4 hi, lo;
+      split4(vh, hi, lo);
+      outl[3][tid] = pack_hl4(hi, lo);  // hcat in HBM carries the split pair (BLS); NaN poison survives in hi
+      // the recurrent operand: fp16(h) with the step's tag in bit 14 (|h| <= 1 leaves it zero; a poisoned h is sent as a
+      // well-tagged finite value -- the status word, not the payload, tells the caller to redo the launch)
+      u32x2 hc = enc_f16x4(vh);
+      hc[0] = (hc[0] & ~C2_TAGS) | tag;
+      hc[1] = (hc[1] & ~C2_TAGS) | tag;
+      publ[mycell] = hc;
+    }
+    __syncthreads();  // 1: stages complete, the h image is no longer read
+    if (xrole && !(p.dbg & 4))
+      __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4*>(publ)[mt], xrs,
+                                             ((par * 8 + j) * 256 + mt) * 16, 0, SC1);
+    // ---- the next step's x-projection, while h_t travels --------------------------------------------------------------
+    xpart();
+    if (xrole) {
+      // gather: granule mt = (seq mt >> 2, unit octet mt & 3) of every producer; poll the data itself
+      u32x4 pv[8];
+      unsigned spins = 0;
+      const bool force = FORCE && step == 2 && c == 0 && j == 0;  // test instantiation: a time-out on demand
+      bool dead = dead_s != 0;
+      while (true) {
+        asm volatile("" ::: "memory");   // the loads below must be re-issued every round (nothing in the loop writes memory)
+        bool ok = true;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          pv[jj] = __builtin_amdgcn_raw_buffer_load_b128(xrs, mt * 16, ((par * 8 + jj) * 256) * 16, SC1);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const unsigned bad = ((pv[jj][0] ^ tag) | (pv[jj][1] ^ tag) | (pv[jj][2] ^ tag) | (pv[jj][3] ^ tag)) & C2_TAGS;
+          ok = ok && bad == 0u;
+        }
+        if ((ok && !force) || dead || (p.dbg & 1)) break;
+        if (force || ++spins > C2_SPIN_LIMIT) {
+          cluster2_timed_out(tword, p.status, &dead_s);
+          dead = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      _Float16* hrow = &hl[(mt >> 2) * HROW + 8 * (mt & 3)];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        u32x4 v = pv[jj];
+        v[0] &= ~C2_TAGS, v[1] &= ~C2_TAGS, v[2] &= ~C2_TAGS, v[3] &= ~C2_TAGS;
+        *reinterpret_cast<u32x4*>(hrow + 32 * jj) = v;
+      }
+    }
+    __syncthreads();  // 2: h image of the next step complete; publ / xb may be rewritten
+  }
+  if (!xrole) hbm_io(step_time(L - 1), L);  // the last step's stores
+}
+
+extern "C" int ws_lstm_fwd_cluster2(const ws_lstm_cluster2_args* a, void* stream) {
+  WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn16 && a->wcat && a->bcat && a->whh_f && a->whh_r && a->xchg &&
+                 a->tword,
+             "ws_lstm_fwd_cluster2: null pointer");
+  WS_REQUIRE(a->nseq > 0 && a->nseq % 64 == 0 && a->L > 0, "ws_lstm_fwd_cluster2: nseq must be a multiple of 64");
+  const int ncl = a->nseq / 32, nwg = ncl * 8;
+  int dev = 0, cus = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  WS_REQUIRE(nwg <= cus, "ws_lstm_fwd_cluster2: %d workgroups must be co-resident but the device has %d CUs", nwg, cus);
+  const int grid = 64 * ((ncl + 7) / 8);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(a->xchg, 0x40, (size_t)ncl * (2 * 8 * 4096), s);   // every granule: tag 1
+  WS_REQUIRE(e == hipSuccess, "ws_lstm_fwd_cluster2: hipMemsetAsync failed");
+  e = hipMemsetAsync(a->tword, 0, sizeof(unsigned), s);
+  WS_REQUIRE(e == hipSuccess, "ws_lstm_fwd_cluster2: hipMemsetAsync failed");
+  ws_prof_begin(WS_PROF_LSTM_FWD, s);
+  if (a->dbg & 8) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<true>), dim3(grid), dim3(512), 0, s, *a);
+  else hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false>), dim3(grid), dim3(512), 0, s, *a);
+  ws_prof_end(WS_PROF_LSTM_FWD, s);
+  return ws_check_launch("ws_lstm_fwd_cluster2");
+}

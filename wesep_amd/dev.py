@@ -515,6 +515,34 @@ def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None, d
     return flags[ncl * 8:ncl * 8 + 1]
 
 
+def lstm_cluster2_on() -> bool:
+    """Second-generation cluster forward (lstm_cluster2.hip, ABI v17: fp16 h, x-projection fused in from the fp16 copy of the
+    normalised input, data-tagged hand-off) for the time view of the 2-byte gate formats; WESEP_LSTM_CLUSTER2=0 keeps the
+    round-1..4 kernel behind ws_gemm_p2b's fp32 pre-activations."""
+    return os.environ.get("WESEP_LSTM_CLUSTER2", "1") != "0"
+
+
+def lstm_fwd_cluster2(gates, cbuf, hcat, xn16, wcat, bcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0):
+    """ws_lstm_fwd_cluster2: gates (unorm16 BLH), cbuf, hcat (BLS) <- the BLSTM forward of the blocked-layout sequences from
+    the fp16 normalised input xn16 (BLH(128)), W_ih / biases as ws_lstm_cat_ih leaves them and the fp32 W_hh.  Returns the
+    launch's time-out word: pass it as `run_if` to gemm_p2b + lstm_fwd behind this call -- the predicated fall-back."""
+    for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("xn16", xn16), ("wcat", wcat), ("bcat", bcat),
+                 ("whh_f", whh_f), ("whh_r", whh_r)):
+        _chk(t, n)
+    ncl = sm.nseq // 32
+    sc = _cluster_scratch(gates.device)
+    xchg, flags = sc.get(ncl * 2 * 8 * 4096 // 4, ncl * 8 + 8)
+    a = L.LstmCluster2Args()
+    a.gates, a.cbuf, a.hcat, a.xn16, a.wcat, a.bcat = _p(gates), _p(cbuf), _p(hcat), _p(xn16), _p(wcat), _p(bcat)
+    a.whh_f, a.whh_r = _p(whh_f), _p(whh_r)
+    tw = flags[ncl * 8:ncl * 8 + 1]
+    a.xchg, a.tword = C.c_void_p(xchg.data_ptr()), C.c_void_p(tw.data_ptr())
+    a.status = C.c_void_p((status if status is not None else sc.status).data_ptr())
+    a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
+    L.check(L.lib().ws_lstm_fwd_cluster2(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_cluster2")
+    return tw
+
+
 def lstm_bwd_cluster(gates, cbuf, dhcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0):
     """BPTT on the blocked layout over clusters of 8 workgroups (lstm_cluster.hip); gates: activated
     gates in, d(pre-activation gates) out.  Returns the launch's timeout word (see lstm_fwd_cluster); there is no

@@ -428,6 +428,21 @@ class ResRNNBlkFn(torch.autograd.Function):
             dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, stats=stats, gamma=norm_w,
                          beta=norm_b, stat_map=smap, A_bl16=xn16)
             dev.lstm_fwd_fused(gates, cbuf, hcat, xn, W("fused"), bcat, seq, gfmt=gfmt)
+        elif cluster and h2 and dev.lstm_cluster2_on():
+            # time view, 2-byte formats (round 5): the cluster kernel computes x W_ih^T itself from the fp16 copy of the
+            # normalised input (lstm_cluster2.hip) -- ws_gemm_p2b only normalises (reads E, writes E / 2 instead of 17 E), the
+            # fp32 pre-activations exist only inside the predicated fall-back behind the launch (the streaming pair, the
+            # whole layer again after a time-out: never NaN, no host round trip)
+            x16 = xn16 if xn16 is not None else _empty(d, dev.blh_floats(nb, N))
+            xn_keep = None if a16 else xn          # the split-pair xn is only read by the backward without fp16 copies
+            dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn_keep, stats=stats, gamma=norm_w,
+                         beta=norm_b, stat_map=smap, A_bl16=x16)
+            tw = dev.lstm_fwd_cluster2(gates, cbuf, hcat, x16, wcat, bcat, whf, whr, seq, dbg=_cluster_dbg())
+            pre = _empty(d, nb, 32 * 2 * G4)       # (scratch of the fall-back: untouched after a clean launch)
+            dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=W("wih"), N=2 * G4, C_out=pre, bias=bcat, A_bl=xn_keep, stats=stats,
+                         gamma=norm_w, beta=norm_b, stat_map=smap, run_if=tw)
+            dev.lstm_fwd(gates, cbuf, hcat, W("hh")[0], seq, lmode, run_if=tw, gfmt=gfmt, gates_in=pre)
+            del pre, x16
         else:
             # pre-activations: in `gates` itself with the fp32 format (one buffer, three lives); with the 2-byte formats a
             # scratch buffer that dies with this forward (the recurrences read it and write the unorm16 gates next to it)
