@@ -322,7 +322,7 @@ int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream);
  * xchg: (nseq / 32) * 64 KB scratch (filled by the call on `stream`); tword: the launch's time-out word (zeroed by the
  * call; 0 after a clean launch; callers enqueue ws_gemm_p2b + ws_lstm_fwd with run_if = tword behind the launch);
  * status: optional, sticky.  dbg (probes / tests): 1 skip the wait, 4 skip the publish, 8 force a time-out in workgroup 0
- * at step 2.                                                                                                       */
+ * at step 2, 2048 cycle stamps into dbg_buf.                                                                                                       */
 typedef struct ws_lstm_cluster2_args {
   float* gates;
   float* cbuf;
@@ -337,6 +337,7 @@ typedef struct ws_lstm_cluster2_args {
   unsigned* status;
   int nseq, L;
   int dbg, pad_;
+  float* dbg_buf;       /* dbg 2048: L * 2 * 8 64-bit cycle stamps of cluster 0 / member 0 (tools/r05_recur_probe.py) */
 } ws_lstm_cluster2_args;
 int ws_lstm_fwd_cluster2(const ws_lstm_cluster2_args* a, void* stream);
 /* BPTT over the same clusters (reduce-scatter of partial dh each step): gates holds the activated
@@ -545,17 +546,27 @@ typedef struct ws_tensor_ref {
   float* exp_avg_sq;
   long long numel;
 } ws_tensor_ref;
-/* guard (optional, TWO device words; ABI v15): guard[0] and guard[1] are set to 1 when any tensor's norm is NaN / Inf.
- * The caller zeroes guard[0] before the launch (the skip word of this step's ws_clip_adam_step); guard[1] is sticky. */
+/* guard (optional device words; ABI v17: FOUR words, see ws_guard_commit): guard[0] is set to 1 when any tensor's norm is
+ * NaN / Inf.  The caller zeroes guard[0] before the first launch of a step (the skip word of that step's
+ * ws_clip_adam_step launches).                                                                                       */
 int ws_grad_norms(const ws_tensor_ref* tab, int ntensors, float* norms, unsigned* guard, void* stream);
+/* ABI v17: closes an optimizer step's book-keeping ON THE DEVICE, after the step's last ws_clip_adam_step launch.  With
+ * skipped := guard[0] != 0 || (skip1 && *skip1 != 0):  skipped -> ++guard[1] (steps skipped so far: exact, monotonic),
+ * ++guard[2] (consecutive skipped steps), ++guard[3] (the bias-correction lag, below); else guard[2] = 0.  One thread.  */
+int ws_guard_commit(unsigned* guard, const unsigned* skip1, void* stream);
 /* if clip > 0: coef = clip / (norm + 1e-6); grad *= coef when coef < 1  (per tensor)
  * skip0 / skip1 (optional device words, ABI v15): the launch does NOTHING when one of them is non-zero at kernel start --
  * the guard word of ws_grad_norms (a non-finite gradient: a BPTT launch that timed out, on any rank of a data-parallel
  * job once the gradients are all-reduced) and / or the sticky status word of an in-place BPTT launch.  The reference
- * would apply the NaN to every weight (funcs.py:79-88: NaN comparisons are false, Adam follows).               */
+ * would apply the NaN to every weight (funcs.py:79-88: NaN comparisons are false, Adam follows).
+ * step_lag (optional device word, ABI v17; pass &guard[3]): the bias corrections of Adam use  step - *step_lag  (>= 1), read
+ * at kernel start: the host counts every ATTEMPTED step without waiting for the device, the device knows which of them
+ * were skipped -- a skipped step must not advance the bias correction (torch.optim.Adam under a GradScaler does not call
+ * step() at all).  The host subtracts what it has learnt asynchronously from both sides (FusedClipAdam._poll_guard).  */
 int ws_clip_adam_step(const ws_tensor_ref* tab, int ntensors, const float* norms, float clip,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                      int clip_only, const unsigned* skip0, const unsigned* skip1, void* stream);
+                      int clip_only, const unsigned* skip0, const unsigned* skip1, const unsigned* step_lag,
+                      void* stream);
 
 /* ---- Conv-TasNet / SpEx+, channels-last activations [R*T'][C] ----------
  * Everything that is not a 1x1 / framing convolution (those are ws_gemm_nt / ws_gemm_tn on row views).

@@ -276,7 +276,7 @@ def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm, status=None, dbg=0, gf
     return torch.zeros(1, dtype=torch.int32)
 
 
-def lstm_fwd_cluster2(gates, cbuf, hcat, xn16, wcat, bcat, whh_f, whh_r, sm, status=None, dbg=0):
+def lstm_fwd_cluster2(gates, cbuf, hcat, xn16, wcat, bcat, whh_f, whh_r, sm, status=None, dbg=0, dbg_buf=None):
     """ws_lstm_fwd_cluster2: x-projection from the fp16 normalised input inside the recurrence, fp16 h in the recurrent
     product, unorm16 gates out; dbg & 8 emulates a time-out like lstm_fwd_cluster."""
     nt, L = _ntile(sm), sm.L

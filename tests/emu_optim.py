@@ -14,14 +14,26 @@ def grad_norms(tab, ntensors, norms, guard=None):
         n = g.detach().float().norm()
         norms[i] = n
         bad = bad or not bool(torch.isfinite(n))
-    if guard is not None and bad:          # [0]: this step's skip word, [1]: the sticky copy the host looks at
+    if guard is not None and bad:          # [0]: this step's skip word
         guard[0] = 1
-        guard[1] = 1
 
 
-def clip_adam_step(tab, ntensors, norms, clip, lr, beta1, beta2, eps, weight_decay, step, clip_only=False, skip=(None, None)):
+def guard_commit(guard, skip1=None):
+    """ws_guard_commit: [1] skipped steps, [2] consecutive skipped steps, [3] bias-correction lag."""
+    if int(guard[0]) != 0 or (skip1 is not None and int(skip1.reshape(-1)[0]) != 0):
+        guard[1] += 1
+        guard[2] += 1
+        guard[3] += 1
+    else:
+        guard[2] = 0
+
+
+def clip_adam_step(tab, ntensors, norms, clip, lr, beta1, beta2, eps, weight_decay, step, clip_only=False, skip=(None, None),
+                   step_lag=None):
     if any(w is not None and int(w.reshape(-1)[0]) != 0 for w in skip):
         return                               # the whole launch does nothing (clip_adam_kernel's first line)
+    if step_lag is not None:
+        step = max(step - int(step_lag.reshape(-1)[0]), 1)
     bc1 = 1.0 - beta1 ** step if not clip_only else 1.0
     bc2_sqrt = math.sqrt(1.0 - beta2 ** step) if not clip_only else 1.0
     for i, (p, g, m, v) in enumerate(tab[:ntensors]):
@@ -52,6 +64,7 @@ def install(monkeypatch):
     monkeypatch.setattr(optim, "_table", lambda refs, device: list(refs))
     monkeypatch.setattr(dev, "grad_norms", grad_norms)
     monkeypatch.setattr(dev, "clip_adam_step", clip_adam_step)
+    monkeypatch.setattr(dev, "guard_commit", guard_commit)
     monkeypatch.setattr(dev, "bptt_status_word", lambda device: None)
     monkeypatch.setattr(dev, "poll_cluster_status", lambda device, block=False: 0)
     monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))

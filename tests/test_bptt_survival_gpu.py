@@ -105,6 +105,56 @@ def test_nonfinite_gradient_skips_the_update_on_the_device():
     assert all(torch.isfinite(p).all() for p in ps)
 
 
+def test_skipped_steps_do_not_advance_adam_bias_correction_on_the_device():
+    """ABI v17 (ws_clip_adam_step step_lag, ws_guard_commit): the host counts attempted steps and never waits; the kernels
+    use step - lag.  Eight steps with three poisoned ones must land where torch.optim.Adam lands after the five finite ones
+    -- with and without the host's asynchronous reconciliation in between -- and the checkpoint carries five steps."""
+    d = _cuda()
+    for poll_between in (False, True):
+        ps, opt = _tiny_opt(d)
+        ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        ropt = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-4)
+        g = torch.Generator(device="cpu").manual_seed(3)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            for it in range(1, 9):
+                grads = [torch.randn(p.shape, generator=g).to(d) * 0.1 for p in ps]      # (small: nothing is clipped at 5.0)
+                bad = it in (2, 5, 6)
+                for p, gr in zip(ps, grads):
+                    p.grad = gr.clone()
+                if bad:
+                    ps[0].grad[3, 3] = float("inf")
+                opt.step()
+                if poll_between:
+                    opt._poll_guard(d, block=True)
+                if not bad:
+                    for p, gr in zip(ref, grads):
+                        p.grad = gr.clone()
+                    ropt.step()
+            torch.cuda.synchronize()
+            for p, r in zip(ps, ref):
+                assert torch.allclose(p.detach(), r.detach(), rtol=2e-6, atol=2e-7), (poll_between, float((p - r).abs().max()))
+            sd = opt.state_dict()
+        assert opt.skipped_steps == 3
+        assert all(int(st["step"]) == 5 for st in sd["state"].values())
+
+
+def test_consecutive_skips_raise_on_the_device_count():
+    from wesep_amd import _lib as L
+    from wesep_amd.optim import FusedClipAdam
+    d = _cuda()
+    p = torch.nn.Parameter(torch.randn(64, device=d))
+    opt = FusedClipAdam([p], lr=1e-2, max_consecutive_skips=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        with pytest.raises(L.WesepHipError, match="all skipped"):
+            for it in range(10):
+                p.grad = torch.full_like(p, float("nan"))
+                opt.step()
+                opt._poll_guard(d, block=True)
+    assert it == 2 and torch.isfinite(p).all()
+
+
 def test_inplace_bptt_timeout_never_reaches_the_weights(monkeypatch):
     """The ABI <= 14 format keeps d(gates) in place: a pair time-out cannot be repaired.  The update is skipped on the device
     (status word + non-finite guard), the weights stay intact, the host raises at its next look."""

@@ -73,6 +73,81 @@ def test_nonfinite_gradient_skips_the_whole_update_and_is_counted(monkeypatch):
     assert not torch.equal(snap()[0][0], before[0][0]) and opt.skipped_steps == 1
 
 
+def test_skipped_step_does_not_advance_the_bias_correction_and_checkpoints_carry_applied_steps(monkeypatch):
+    """torch.optim.Adam under a GradScaler does not call step() on an overflow; here the host counts attempted steps, the
+    device corrects by its own lag word (ws_clip_adam_step step_lag, ws_guard_commit) and the host reconciles one poll late:
+    the trajectory equals the oracle's that never saw the bad step -- whether or not the host has polled in between."""
+    from oracle import bsrnn_oracle as O
+    from tests import emu_optim
+    from wesep_amd.optim import FusedClipAdam
+    emu_optim.install(monkeypatch)
+    for poll_between in (False, True):
+        net = _net(4)
+        ref = {k: v.detach().clone() for k, v in net.named_parameters()}
+        m = {k: torch.zeros_like(v) for k, v in ref.items()}
+        v2 = {k: torch.zeros_like(v) for k, v in ref.items()}
+        opt = FusedClipAdam(net.parameters(), lr=1e-2, weight_decay=1e-3, clip_grad=0.05)
+        g = torch.Generator().manual_seed(5)
+        applied = 0
+        for it in range(1, 9):
+            x, y = torch.randn(16, 6, generator=g), torch.randn(16, 3, generator=g)
+            opt.zero_grad()
+            ((net(x) - y) ** 2).mean().backward()
+            bad = it in (2, 5, 6)
+            if bad:
+                list(net.parameters())[0].grad[0, 0] = float("inf")
+            grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                opt.step()
+                if poll_between:
+                    opt._poll_guard(torch.device("cpu"), block=True)
+            if not bad:
+                applied += 1
+                O.clip_gradients_(grads, 0.05)
+                for k in ref:
+                    O.adam_l2_step_(ref[k], grads[k], m[k], v2[k], applied, 1e-2, weight_decay=1e-3)
+            for k, p in net.named_parameters():
+                assert torch.allclose(p.detach(), ref[k], rtol=1e-6, atol=1e-7), (poll_between, it, k)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            sd = opt.state_dict()
+        assert opt.skipped_steps == 3
+        assert all(int(st["step"]) == applied for st in sd["state"].values()), [st["step"] for st in sd["state"].values()]
+
+
+def test_consecutive_skipped_steps_raise(monkeypatch):
+    from tests import emu_optim
+    from wesep_amd import _lib as L
+    from wesep_amd.optim import FusedClipAdam
+    emu_optim.install(monkeypatch)
+    net = _net(6)
+    opt = FusedClipAdam(net.parameters(), lr=1e-2, clip_grad=5.0, max_consecutive_skips=4)
+    x, y = torch.randn(4, 6), torch.randn(4, 3)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        with pytest.raises(L.WesepHipError, match="all skipped"):
+            for it in range(12):
+                opt.zero_grad()
+                ((net(x) - y) ** 2).mean().backward()
+                list(net.parameters())[1].grad[0] = float("nan")
+                opt.step()
+                opt._poll_guard(torch.device("cpu"), block=True)
+        assert it == 3 and opt.skipped_steps == 4
+        # a finite step in between resets the run of skips
+        opt2 = FusedClipAdam(net.parameters(), lr=1e-2, clip_grad=5.0, max_consecutive_skips=3)
+        for it in range(10):
+            opt2.zero_grad()
+            ((net(x) - y) ** 2).mean().backward()
+            if it % 3 != 2:
+                list(net.parameters())[1].grad[0] = float("nan")
+            opt2.step()
+            opt2._poll_guard(torch.device("cpu"), block=True)
+        assert opt2.skipped_steps == 7
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -63,6 +63,30 @@ def main():
         t = timeit(lambda: dev.lstm_fwd_cluster2(gh, cbuf, hcat, xn16, wcat, bcat, whf, whr, seq, status=st, dbg=dbg))
         print(f"cluster2 fwd (fp16 h, fused x-proj, tagged){nm:18s} {t:7.3f} ms  {t * 1e3 / Tf:6.2f} us/step", flush=True)
     print("status word after the forward kernels", int(st.item()), flush=True)
+    if not a.no_stamps:
+        for rep in range(2):
+            dbuf = torch.zeros(Tf * 2 * 8 * 2, device=d)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dev.lstm_fwd_cluster2(gh, cbuf, hcat, xn16, wcat, bcat, whf, whr, seq, status=st, dbg=2048, dbg_buf=dbuf)
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        ts = dbuf.view(torch.int64).view(Tf, 2, 8).cpu().double()
+        span = float(ts[-1, 0, 0] - ts[5, 0, 0]) / (Tf - 6)
+        upt = (ms * 1e3 / Tf) / span if span > 0 else float("nan")
+        print(f"--- stamps, cluster2 forward: launch {ms:.3f} ms = {ms * 1e3 / Tf:.2f} us/step with stamps; {span:.0f} ticks per step")
+        cn = ["loop top", "recurrent MFMAs done", "past barrier 0", "cell update done (h published)", "next x-projection done",
+              "X: all eight slices arrived", "X: h image written"]
+        for role, rn in ((0, "X-wave 0 (tile 0)"), (1, "M-wave 4 (tile 1)")):
+            tt = ts[5:-1, role] - ts[5:-1, role, 0:1]
+            nxt = ts[6:, role, 0] - ts[5:-1, role, 0]
+            print(f"  {rn}: mean microseconds since the loop top")
+            for k in range(1, 7):
+                if role == 1 and k > 4:
+                    continue
+                print(f"     {cn[k]:34s} {float(tt[:, k].mean()) * upt:6.2f}   (sd {float(tt[:, k].std()) * upt:.2f})")
+            print(f"     {'next loop top (past barrier 2)':34s} {float(nxt.mean()) * upt:6.2f}", flush=True)
     st.zero_()
     dev.lstm_fwd_cluster(gh, cbuf, hcat, whf, whr, seq, status=st, gfmt=L.GATES_H2, gates_in=pre)   # (state for the BPTT below)
     # ---- BPTT (pair kernel) ----------------------------------------------------------------------------------------

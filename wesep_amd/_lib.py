@@ -122,7 +122,7 @@ class LstmClusterArgs(C.Structure):
 
 class LstmCluster2Args(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "xn16", "wcat", "bcat", "whh_f", "whh_r", "xchg", "tword", "status")] + \
-               [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i)]
+               [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i), ("dbg_buf", _p)]
 
 
 class LstmPairArgs(C.Structure):
@@ -258,7 +258,8 @@ _SIGS = {
     "ws_lstm_pack_fused": (_i, [_p, _p, _p, _p, _p, _p]),
     "ws_lstm_fwd_fused": (_i, [C.POINTER(LstmFusedArgs), _p]),
     "ws_grad_norms": (_i, [_p, _i, _p, _p, _p]),
-    "ws_clip_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p, _p, _p]),
+    "ws_clip_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p]),
+    "ws_guard_commit": (_i, [_p, _p, _p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

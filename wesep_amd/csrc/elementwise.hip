@@ -232,7 +232,7 @@ __global__ __launch_bounds__(1024) void grad_norms_kernel(const ws_tensor_ref* _
   if (threadIdx.x == 0) {
     const float n = sqrtf(s);
     norms[blockIdx.x] = n;
-    if (guard && !(fabsf(n) <= 3.4028234e38f)) guard[0] = guard[1] = 1u;  // NaN or Inf (plain stores: every writer writes 1)
+    if (guard && !(fabsf(n) <= 3.4028234e38f)) guard[0] = 1u;  // NaN or Inf (plain store: every writer writes 1)
   }
 }
 
@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ws_tensor_ref* __r
                                                         float eps, float wd, float bc1,
                                                         float bc2_sqrt, int clip_only,
                                                         const unsigned* __restrict__ skip0,
-                                                        const unsigned* __restrict__ skip1) {
+                                                        const unsigned* __restrict__ skip1,
+                                                        const unsigned* __restrict__ step_lag, int step) {
   // skip words (optional device words, read at kernel start; uniform): the whole launch does nothing when one of them is
   // non-zero -- the non-finite-gradient guard of ws_grad_norms, the sticky status word of an in-place BPTT time-out
   if ((skip0 && *skip0 != 0u) || (skip1 && *skip1 != 0u)) return;
@@ -259,6 +260,16 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ws_tensor_ref* __r
   if (clip > 0.f) {
     const float c = clip / (norms[blockIdx.x] + 1e-6f);
     if (c < 1.f) coef = c;
+  }
+  if (step_lag && !clip_only) {
+    // bias corrections of the step count the DEVICE knows: attempted steps minus the skipped ones the host has not
+    // subtracted yet (wesep_hip.h); uniform, in double like the host's
+    const unsigned lag = *step_lag;
+    if (lag != 0u) {
+      const double eff = (double)max(step - (int)lag, 1);
+      bc1 = (float)(1.0 - pow((double)beta1, eff));
+      bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, eff));
+    }
   }
   const float step_size = lr / bc1;
   for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < t.numel;
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ws_tensor_ref* __r
 extern "C" int ws_clip_adam_step(const ws_tensor_ref* tab, int ntensors, const float* norms,
                                  float clip, float lr, float beta1, float beta2, float eps,
                                  float weight_decay, int step, int clip_only, const unsigned* skip0,
-                                 const unsigned* skip1, void* stream) {
+                                 const unsigned* skip1, const unsigned* step_lag, void* stream) {
   WS_REQUIRE(tab && ntensors > 0, "ws_clip_adam_step: bad args");
   WS_REQUIRE(clip <= 0.f || norms, "ws_clip_adam_step: clip needs norms");
   WS_REQUIRE(clip_only || step >= 1, "ws_clip_adam_step: step must be >= 1");
@@ -288,6 +299,24 @@ extern "C" int ws_clip_adam_step(const ws_tensor_ref* tab, int ntensors, const f
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(ntensors, 16), dim3(256), 0, (hipStream_t)stream, tab,
                      norms, clip, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-                     (float)sqrt(bc2), clip_only, skip0, skip1);
+                     (float)sqrt(bc2), clip_only, skip0, skip1, step_lag, step);
   return ws_check_launch("ws_clip_adam_step");
+}
+
+__global__ void guard_commit_kernel(unsigned* __restrict__ guard, const unsigned* __restrict__ skip1) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const bool skipped = guard[0] != 0u || (skip1 && *skip1 != 0u);
+  if (skipped) {
+    guard[1] += 1u;
+    guard[2] += 1u;
+    guard[3] += 1u;
+  } else {
+    guard[2] = 0u;
+  }
+}
+
+extern "C" int ws_guard_commit(unsigned* guard, const unsigned* skip1, void* stream) {
+  WS_REQUIRE(guard, "ws_guard_commit: null pointer");
+  hipLaunchKernelGGL(guard_commit_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, guard, skip1);
+  return ws_check_launch("ws_guard_commit");
 }

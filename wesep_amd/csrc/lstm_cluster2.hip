@@ -16,10 +16,10 @@
 //   3. The hand-off carries its own arrival tag instead of payload + drain + flag + poll: |h| <= 1 leaves bit 14 of every
 //      fp16 value zero, so the producer ORs the step's tag ((step >> 1) & 1: the exchange slots are double-buffered by
 //      step parity, a slot's previous content is two steps old and carries the other tag) into bit 14 of all eight values
-//      of a 16-byte granule, stores it write-through (sc1) and is done -- no vmcnt drain, no barrier, no flag.  The
-//      consumer loads the granules with sc1 (L1 bypassed), accepts a granule when every dword carries the expected tag
-//      (dwords are written atomically; nothing is assumed about 16 bytes) and strips the tags.  Three workgroup barriers
-//      per step instead of five.  The exchange buffer is filled with tag 1 (0x40 bytes) before every launch; steps 0 and 1
+//      of its 8-byte share of a 16-byte granule and stores it write-through (sc1) the moment the cell update has produced
+//      it -- no LDS stage, no vmcnt drain, no barrier, no flag.  The consumer loads the granules with sc1 (L1 bypassed),
+//      accepts a granule when every dword carries the expected tag (dwords are written atomically; nothing is assumed
+//      about 8 or 16 bytes) and strips the tags.  Two workgroup barriers per step instead of five.  The exchange buffer is filled with tag 1 (0x40 bytes) before every launch; steps 0 and 1
 //      carry tag 0.
 // Every wait is bounded: a time-out sets the launch's time-out word and *status and poisons this workgroup's outputs with
 // NaN; callers enqueue the predicated streaming path (ws_gemm_p2b + ws_lstm_fwd with run_if) behind the launch, as for
@@ -61,13 +61,21 @@ __device__ __forceinline__ bool cluster2_of_block(int ncl, int& c, int& j) {
   return c < ncl;
 }
 
-template <bool FORCE>
+// STAMPS (diagnosis, dbg 2048): s_memtime stamps of cluster 0 / member 0, waves 0 (X) and 4 (M), into p.dbg_buf as 64-bit ticks:
+// [(step * 2 + role) * 8 + k]; k: 0 loop top, 1 recurrent MFMAs done, 2 past barrier 0, 3 cell update done (h published),
+// 4 next step's x-projection done, 5 X: all eight slices arrived, 6 X: h image written; the next k = 0 closes the step
+#define C2TS(k)                                                                                                     \
+  if constexpr (STAMPS) {                                                                                           \
+    if (c == 0 && j == 0 && uo == 0 && lane == 0 && p.dbg_buf)                                                      \
+      reinterpret_cast<unsigned long long*>(p.dbg_buf)[(step * 2 + st) * 8 + (k)] = __builtin_readcyclecounter();   \
+  }
+
+template <bool FORCE, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm_cluster2_args p) {
   __shared__ __attribute__((aligned(16))) _Float16 hl[C2_SEQ * HROW];   // h image [seq][k], one fp16 plane, 33 KB
   __shared__ __attribute__((aligned(16))) f16x8 wih[4 * 2 * 8 * 64];    // W_ih slice [uo][part][ks][lane], 64 KB
   __shared__ __attribute__((aligned(16))) u32x4 xb[1024];               // xn16 blocks of the cluster's two tiles, 16 KB
   __shared__ __attribute__((aligned(16))) f32x4 outl[4][512];           // i|f, g|o (unorm16), c, h of the step, 32 KB
-  __shared__ __attribute__((aligned(16))) u32x2 publ[512];              // tagged fp16 h cells, 4 KB
   __shared__ __attribute__((aligned(16))) f32x4 bias_l[32];             // 256 (b_ih + b_hh) [gate][unit 32]
   __shared__ int dead_s;
   const int ntile = p.nseq / 32, ncl_dir = ntile / 2, ncl = 2 * ncl_dir;
@@ -124,10 +132,11 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
     const long long blk = (long long)(2 * cc + (u >> 9)) * L + t;
     return *reinterpret_cast<const u32x4*>(xbase + blk * 8192 + (u & 511) * 16);
   };
-  // ---- exchange: X[cluster][parity][producer][granule 256] x 16 B; granule = (seq, unit octet) -----------------------
+  // ---- exchange: X[cluster][parity][producer][granule 256] x 16 B; granule (wave w, seq slot n) = the eight units of
+  //      wave w's tile row: a lane stores its 8-byte half of it, a wave's store covers 1 KB of consecutive bytes
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(p.xchg) + (long long)c * (2 * 8 * 4096), 0, 2 * 8 * 4096, 0x00020000);
-  const int mycell = ((st * 32 + n) * 4 + uo) * 2 + half;   // 8-byte cell of this thread's four h values in the slice
+  const int mycell = ((w * 32 + n) * 2 + half) * 8;         // byte offset of this thread's four h values in the slice
   unsigned* tword = p.tword;
 
   auto step_time = [&](int s) { return d == 0 ? s : L - 1 - s; };
@@ -194,6 +203,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
   for (int step = 0; step < L; ++step) {
     const int par = step & 1;
     const unsigned tag = ((step >> 1) & 1) ? C2_TAGS : 0u;
+    C2TS(0);
     if (!xrole) {
       if (step > 0) hbm_io(step_time(step - 1), step);
       else {
@@ -214,7 +224,9 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
         acc1 = mfma16h(wl[ks], b, acc1);
       }
     }
+    C2TS(1);
     __syncthreads();  // 0: the previous step's outputs have left the LDS stage
+    C2TS(2);
     // ---- cell update (register 4q + r = gate q, unit 4 half + r of this wave's 8) ---------------------------------------
     {
       f32x4 vi, vf, vg, vo, vh;
@@ -232,27 +244,27 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
       const bool dead = dead_s != 0;
       if (dead) vh = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
       const u32x2 ei = enc_u16x4<false>(vi), ef = enc_u16x4<false>(vf), eg = enc_u16x4<true>(vg), eo = enc_u16x4<false>(vo);
+      // the recurrent operand: fp16(h) with the step's tag in bit 14 (|h| <= 1 leaves it zero; a poisoned h is sent as a
+      // well-tagged finite value -- the status word, not the payload, tells the caller to redo the launch)
+      // Published by the thread that computed it, at once (write-through, no drain, no barrier in front of it): every wave
+      // stores 1 KB of consecutive bytes
+      u32x2 hc = enc_f16x4(vh);
+      hc[0] = (hc[0] & ~C2_TAGS) | tag;
+      hc[1] = (hc[1] & ~C2_TAGS) | tag;
+      if (!(p.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b64(hc, xrs, mycell + (par * 8 + j) * 4096, 0, SC1);
       outl[0][tid] = __builtin_bit_cast(f32x4, u32x4{ei[0], ei[1], ef[0], ef[1]});
       outl[1][tid] = __builtin_bit_cast(f32x4, u32x4{eg[0], eg[1], eo[0], eo[1]});
       outl[2][tid] = c4;
       bf16x4 hi, lo;
       split4(vh, hi, lo);
       outl[3][tid] = pack_hl4(hi, lo);  // hcat in HBM carries the split pair (BLS); NaN poison survives in hi
-      // the recurrent operand: fp16(h) with the step's tag in bit 14 (|h| <= 1 leaves it zero; a poisoned h is sent as a
-      // well-tagged finite value -- the status word, not the payload, tells the caller to redo the launch)
-      u32x2 hc = enc_f16x4(vh);
-      hc[0] = (hc[0] & ~C2_TAGS) | tag;
-      hc[1] = (hc[1] & ~C2_TAGS) | tag;
-      publ[mycell] = hc;
     }
-    __syncthreads();  // 1: stages complete, the h image is no longer read
-    if (xrole && !(p.dbg & 4))
-      __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4*>(publ)[mt], xrs,
-                                             ((par * 8 + j) * 256 + mt) * 16, 0, SC1);
+    C2TS(3);
     // ---- the next step's x-projection, while h_t travels --------------------------------------------------------------
     xpart();
+    C2TS(4);
     if (xrole) {
-      // gather: granule mt = (seq mt >> 2, unit octet mt & 3) of every producer; poll the data itself
+      // gather: granule mt = (producer wave mt >> 5 = (uo, st), seq slot mt & 31) of every producer; poll the data itself
       u32x4 pv[8];
       unsigned spins = 0;
       const bool force = FORCE && step == 2 && c == 0 && j == 0;  // test instantiation: a time-out on demand
@@ -277,13 +289,15 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      _Float16* hrow = &hl[(mt >> 2) * HROW + 8 * (mt & 3)];
+      C2TS(5);
+      _Float16* hrow = &hl[(((mt >> 7) & 1) * 32 + (mt & 31)) * HROW + 8 * ((mt >> 5) & 3)];
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
         u32x4 v = pv[jj];
         v[0] &= ~C2_TAGS, v[1] &= ~C2_TAGS, v[2] &= ~C2_TAGS, v[3] &= ~C2_TAGS;
         *reinterpret_cast<u32x4*>(hrow + 32 * jj) = v;
       }
+      C2TS(6);
     }
     __syncthreads();  // 2: h image of the next step complete; publ / xb may be rewritten
   }
@@ -307,7 +321,8 @@ extern "C" int ws_lstm_fwd_cluster2(const ws_lstm_cluster2_args* a, void* stream
   e = hipMemsetAsync(a->tword, 0, sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_fwd_cluster2: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
-  if (a->dbg & 8) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<true>), dim3(grid), dim3(512), 0, s, *a);
+  if (a->dbg & 2048) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false, true>), dim3(grid), dim3(512), 0, s, *a);
+  else if (a->dbg & 8) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<true>), dim3(grid), dim3(512), 0, s, *a);
   else hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false>), dim3(grid), dim3(512), 0, s, *a);
   ws_prof_end(WS_PROF_LSTM_FWD, s);
   return ws_check_launch("ws_lstm_fwd_cluster2");

@@ -359,6 +359,48 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
                       acc0[4 * q4 + 3] + acc1[4 * q4 + 3]};
     if (xrole) {
       __builtin_amdgcn_s_setprio(0);
+      u32x4 pv[4];
+      if constexpr (RF != 0) {
+        // ---- data-tagged hand-off (round 5): the LEAST significant mantissa bit of every fp32 partial carries the step's
+        // tag ((step >> 1) & 1; the slots are double-buffered by step parity, so a slot's previous content -- two steps old
+        // -- carries the other tag; the launcher fills the buffer with tag 1, steps 0 and 1 carry tag 0).  The producer
+        // stores write-through and is done: no vmcnt drain, no flag; the consumer polls the DATA (sc1 loads), accepting it
+        // when all sixteen dwords carry the tag.  2^-24 relative on a partial d(h) that is rounded to fp16 one step later.
+        const unsigned tagb = (unsigned)(step >> 1) & 1u;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          u32x4 v = __builtin_bit_cast(u32x4, sum[q4]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (v[r] & ~1u) | tagb;
+          __builtin_amdgcn_raw_buffer_store_b128(v, xrs, xc0 + (par * 2 + (1 - hs)) * PR_XSLOT + q4 * 1024, 0, SC1);
+        }
+        TS(4);
+        load_step(tn, 0);
+        load_step(tn, 1);
+        TS(5);
+        unsigned spins = 0;
+        const bool force = (V & 8) && step == 2 && pr == 0 && hs == 0 && wx == 0;  // test build: a timeout on demand
+        while (true) {
+          asm volatile("" ::: "memory");   // re-issue the loads every round
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+            pv[q4] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xc0, (par * 2 + hs) * PR_XSLOT + q4 * 1024, SC1);
+          unsigned bad = 0u;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bad |= pv[q4][r] ^ tagb;
+          // wave-uniform exit: the wave's 64 lanes read one 4 KB piece the partner's wave wrote with four stores
+          if ((__all((int)((bad & 1u) == 0u)) && !force) || dead || (p.dbg & 1)) break;
+          if (force || ++spins > (PR_SPIN_LIMIT >> 2)) {
+            if (lane == 0) pair_timed_out(p.flags + npair * 8, p.status);
+            dead = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        TS(6);
+      } else {
       // publish the partial of the PARTNER's units: write-through 16-byte stores, drain, one flag per wave
       if (!(p.dbg & 2)) {
 #pragma unroll
@@ -394,11 +436,11 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       }
       TS(6);
       if (p.dbg & 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      u32x4 pv[4];
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4)
         pv[q4] = (p.dbg & 2) ? u32x4{0u, 0u, 0u, 0u}
                              : __builtin_amdgcn_raw_buffer_load_b128(xrs, xc0, (par * 2 + hs) * PR_XSLOT + q4 * 1024, SC1);
+      }
       if (dead) {
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) pv[q4] = u32x4{0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u};
@@ -449,6 +491,10 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)npair * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_pair: hipMemsetAsync failed");
+  if (a->rfmt == 1) {   // data-tagged hand-off: every dword of the exchange slots starts with tag 1 (LSB set)
+    e = hipMemsetAsync(a->xchg, 0x01, (size_t)npair * 4 * PR_XSLOT, s);
+    WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_pair: hipMemsetAsync failed");
+  }
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
   if (a->rfmt == 1) {
     if (a->dbg & 8) hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2F, 1>), dim3(grid), dim3(512), 0, s, *a);

@@ -522,7 +522,7 @@ def lstm_cluster2_on() -> bool:
     return os.environ.get("WESEP_LSTM_CLUSTER2", "1") != "0"
 
 
-def lstm_fwd_cluster2(gates, cbuf, hcat, xn16, wcat, bcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0):
+def lstm_fwd_cluster2(gates, cbuf, hcat, xn16, wcat, bcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0, dbg_buf=None):
     """ws_lstm_fwd_cluster2: gates (unorm16 BLH), cbuf, hcat (BLS) <- the BLSTM forward of the blocked-layout sequences from
     the fp16 normalised input xn16 (BLH(128)), W_ih / biases as ws_lstm_cat_ih leaves them and the fp32 W_hh.  Returns the
     launch's time-out word: pass it as `run_if` to gemm_p2b + lstm_fwd behind this call -- the predicated fall-back."""
@@ -539,6 +539,7 @@ def lstm_fwd_cluster2(gates, cbuf, hcat, xn16, wcat, bcat, whh_f, whh_r, sm: Seq
     a.xchg, a.tword = C.c_void_p(xchg.data_ptr()), C.c_void_p(tw.data_ptr())
     a.status = C.c_void_p((status if status is not None else sc.status).data_ptr())
     a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
+    a.dbg_buf = C.c_void_p(dbg_buf.data_ptr()) if dbg_buf is not None else None
     L.check(L.lib().ws_lstm_fwd_cluster2(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_cluster2")
     return tw
 
@@ -692,8 +693,8 @@ def sisdr_bwd(est, tgt, rowstat, gout, dest):
 
 
 def grad_norms(tab, ntensors, norms, guard=None):
-    """guard: optional 2-element int32 device tensor: [0] (zeroed by the caller before the launch) and [1] (sticky) are set
-    to 1 when a norm is NaN / Inf."""
+    """guard: optional int32 device tensor: [0] (zeroed by the caller before the step's first launch) is set to 1 when a
+    norm is NaN / Inf."""
     L.check(L.lib().ws_grad_norms(C.c_void_p(tab.data_ptr()), ntensors, _p(norms), _word(guard), L.stream_ptr()),
             "ws_grad_norms")
 
@@ -719,15 +720,23 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
-def clip_adam_step(tab, ntensors, norms, clip, lr, beta1, beta2, eps, weight_decay, step, clip_only=False, skip=(None, None)):
+def clip_adam_step(tab, ntensors, norms, clip, lr, beta1, beta2, eps, weight_decay, step, clip_only=False, skip=(None, None),
+                   step_lag=None):
     """skip: up to two 1-element int32 device tensors; the launch does nothing when one of them is non-zero at kernel
-    start (the guard of grad_norms, the BPTT status word: wesep_hip.h)."""
+    start (the guard of grad_norms, the BPTT status word: wesep_hip.h).  step_lag (1-element int32 device tensor, ABI v17):
+    skipped steps the host's `step` still counts -- the bias corrections use step - lag."""
     if not clip_only:
         bump_weight_epoch()
     L.check(L.lib().ws_clip_adam_step(C.c_void_p(tab.data_ptr()), ntensors, _p(norms), clip, lr, beta1,
                                       beta2, eps, weight_decay, step, int(clip_only), _word(skip[0]), _word(skip[1]),
-                                      L.stream_ptr()),
+                                      _word(step_lag), L.stream_ptr()),
             "ws_clip_adam_step")
+
+
+def guard_commit(guard, skip1=None):
+    """ws_guard_commit: closes the step's book-keeping on the device (guard: 4-element int32 device tensor -- [0] this
+    step's skip word, [1] skipped steps so far, [2] consecutive skipped steps, [3] bias-correction lag)."""
+    L.check(L.lib().ws_guard_commit(_word(guard), _word(skip1), L.stream_ptr()), "ws_guard_commit")
 
 
 def debug_occupy(nblocks: int, usec: int, stop=None):

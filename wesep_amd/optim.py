@@ -41,16 +41,33 @@ def clip_gradients(model, clip):
 
 
 class FusedClipAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad=0.0):
+    """Per-tensor clip + Adam-L2 in two multi-tensor launches, with a non-finite-gradient guard that never syncs the host.
+
+    Guard (wesep_hip.h ws_grad_norms / ws_clip_adam_step / ws_guard_commit): four device words per device.  [0], zeroed
+    every step and set by ws_grad_norms when a gradient norm is NaN / Inf, makes ws_clip_adam_step skip the WHOLE update of
+    that step on the device.  ws_guard_commit then counts on the device: [1] skipped steps so far (exact), [2] CONSECUTIVE
+    skipped steps, [3] the bias-correction lag.  The host reads the words asynchronously (a 16-byte copy whose event it
+    queries at the next step):
+      * `skipped_steps` is the device's exact count;
+      * `state[p]["step"]` counts ATTEMPTED steps when `step()` returns; the kernels use step - lag for the bias
+        corrections, so a skipped step never advances them (torch.optim.Adam under a GradScaler does not call step() on
+        an overflow); whenever the host learns of n more skips it subtracts n from every state's `step` and from the
+        device's lag word (stream-ordered, so every launch sees a consistent pair).  `state_dict()` reconciles first:
+        checkpoints carry applied-step counts like torch.optim.Adam's;
+      * `max_consecutive_skips` (default 10; WESEP_MAX_CONSECUTIVE_SKIPS): a run whose every step is non-finite has
+        diverged -- the reference would show a NaN loss -- and training on nothing forever is worse than stopping:
+        WesepHipError once the device has counted that many skipped steps in a row (noticed one poll late)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad=0.0,
+                 max_consecutive_skips=None):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_grad=clip_grad)
         super().__init__(params, defaults)
         self._norms = None
         self._norm_params = None
-        # non-finite-gradient guard (wesep_hip.h ws_grad_norms / ws_clip_adam_step): two device words per device that
-        # ws_grad_norms sets when a gradient holds NaN / Inf -- [0], zeroed every step, makes ws_clip_adam_step skip the
-        # WHOLE update of that step on the device; [1], sticky, is looked at asynchronously (no host sync), counted, cleared
         self._guard = {}
         self.skipped_steps = 0
+        self.max_consecutive_skips = int(max_consecutive_skips if max_consecutive_skips is not None
+                                         else os.environ.get("WESEP_MAX_CONSECUTIVE_SKIPS", "10"))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -95,8 +112,9 @@ class FusedClipAdam(torch.optim.Optimizer):
         # read of the gradients); pass 2: the updates, ALL skipped on the device when ANY gradient of the step was not
         # finite (a BPTT time-out poisons with NaN; under DDP the all-reduce has spread it to every rank, so every rank
         # skips the same step) or when an in-place BPTT launch of this stream reported a time-out
-        for dkey in {(l[1][0][0].device.type, l[1][0][0].device.index) for l in launches}:
-            self._guard_word(torch.device(*dkey))[0:1].zero_()   # this step's skip word; [1] is the sticky copy
+        devs = {(l[1][0][0].device.type, l[1][0][0].device.index) for l in launches}
+        for dkey in devs:
+            self._guard_word(torch.device(*dkey))[0:1].zero_()   # this step's skip word
         normed = []
         for tab, brefs, step, group in launches:
             device = brefs[0][0].device
@@ -112,7 +130,11 @@ class FusedClipAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             dev.clip_adam_step(tab, len(brefs), norms if clip > 0 else None, clip, float(group["lr"]), b1, b2,
                                group["eps"], group["weight_decay"], step,
-                               skip=(self._guard_word(device)[0:1], dev.bptt_status_word(device)))
+                               skip=(self._guard_word(device)[0:1], dev.bptt_status_word(device)),
+                               step_lag=self._guard_word(device)[3:4])
+        for dkey in devs:      # the step's book-keeping, on the device: skipped / consecutive / lag counters
+            dv = torch.device(*dkey)
+            dev.guard_commit(self._guard_word(dv), dev.bptt_status_word(dv))
         if cuda_dev is not None:
             self._poll_guard(cuda_dev)
             dev.poll_cluster_status(cuda_dev)   # asynchronous: evaluates the copy started one step ago
@@ -121,17 +143,17 @@ class FusedClipAdam(torch.optim.Optimizer):
     def _guard_word(self, device):
         key = (device.type, device.index)
         if key not in self._guard:
-            host = torch.zeros(1, dtype=torch.int32)
+            host = torch.zeros(4, dtype=torch.int32)
             if torch.cuda.is_available():
                 host = host.pin_memory()
-            self._guard[key] = dict(word=torch.zeros(2, device=device, dtype=torch.int32), host=host, event=None)
+            self._guard[key] = dict(word=torch.zeros(4, device=device, dtype=torch.int32), host=host, event=None, seen=0)
         return self._guard[key]["word"]
 
     def _poll_guard(self, device, block=False):
-        """Asynchronous look at the guard word: evaluates the 4-byte copy started by the previous call once its event has
-        completed, then starts the next one (`block`: copy now and wait).  A set word = the update of (at least) one step
-        was skipped on the device: counted in `skipped_steps`, reported once, cleared -- training goes on with intact
-        weights.  Returns `skipped_steps`."""
+        """Asynchronous look at the guard words: evaluates the 16-byte copy started by the previous call once its event has
+        completed, then starts the next one (`block`: copy now and wait).  Newly skipped steps are counted in
+        `skipped_steps` (reported once), taken off every state's `step` and off the device's lag word; raises WesepHipError
+        when `max_consecutive_skips` steps in a row were skipped.  Returns `skipped_steps`."""
         g = self._guard.get((device.type, device.index))
         if g is None or not torch.cuda.is_available():
             return self.skipped_steps
@@ -139,24 +161,44 @@ class FusedClipAdam(torch.optim.Optimizer):
         def evaluate():
             g["event"].synchronize()
             g["event"] = None
-            if int(g["host"][0]):
-                g["word"][1:2].zero_()
+            total, consec, lag = int(g["host"][1]), int(g["host"][2]), int(g["host"][3])
+            new = total - g["seen"]
+            if new > 0:
                 if self.skipped_steps == 0:
                     import warnings
                     warnings.warn("FusedClipAdam: a gradient was not finite (NaN / Inf); the optimizer step was skipped "
                                   "on the device and the weights are intact.  Further skipped steps are counted in "
                                   "`skipped_steps`", RuntimeWarning)
-                self.skipped_steps += 1
+                g["seen"] = total
+                self.skipped_steps += new
+            if lag > 0:
+                # the device has been correcting the bias terms by `lag` on its own; move that into the host's counts
+                # (stream-ordered: launches enqueued before this line saw (step, lag), later ones see (step - lag, 0 + ...))
+                for st in self.state.values():
+                    if "step" in st:
+                        st["step"] = max(int(st["step"]) - lag, 0)
+                g["word"][3:4].sub_(lag)
+            if self.max_consecutive_skips > 0 and consec >= self.max_consecutive_skips:
+                raise L.WesepHipError(
+                    f"FusedClipAdam: the last {consec} optimizer steps were all skipped on the device (non-finite gradients "
+                    f"or BPTT time-outs in every step): the run has diverged or the GPU is shared; the weights are those of "
+                    f"the last finite step.  max_consecutive_skips / WESEP_MAX_CONSECUTIVE_SKIPS raise the limit (0: never)")
 
         if g["event"] is not None and (block or g["event"].query()):
             evaluate()
         if g["event"] is None:
-            g["host"].copy_(g["word"][1:2], non_blocking=True)
+            g["host"].copy_(g["word"], non_blocking=True)
             g["event"] = torch.cuda.Event()
             g["event"].record()
             if block:
                 evaluate()
         return self.skipped_steps
+
+    def state_dict(self):
+        """Reconciles the step counts with the device first (one host sync): checkpoints carry APPLIED steps."""
+        for g in list(self._guard.values()):
+            self._poll_guard(g["word"].device, block=True)
+        return super().state_dict()
 
     def last_grad_norms(self):
         """Per-parameter gradient norms of the last step (syncs)."""
