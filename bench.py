@@ -8,9 +8,17 @@ step -- forward, SI-SDR, backward, per-tensor clip, Adam -- on N MI355X.
 
 Workload (BASELINE.json configs[1] / north_star "batch 32 x 4 s"): pBSRNN, FiLM multi-fuse,
 6 repeats, feature_dim 128, fixed [R,256] embeddings, R = 32 rows (16 two-speaker mixtures) of
-64000 samples per GPU.  Arithmetic: split-bf16 ("bf16x3": fp32 operands as bf16 hi+lo, three bf16
-MFMAs per product, fp32 accumulation and fp32 storage) -- holds the reference's fp32 results to
-~1e-4 on the separated waveforms (tests/test_bsrnn_gpu.py; tolerance 1e-3).  Weak scaling: every rank runs the same per-GPU batch on its own synthetic
+64000 samples per GPU.  Arithmetic (what `dtype` / `config.workload` / `mfma_terms` of the line name): fp32 operands enter
+the matrix cores as split pairs, fp32 accumulation everywhere --
+  * "bf16x3": bf16 hi + lo of both operands, THREE bf16 MFMAs per product: the band-view recurrences (forward with the
+    fused x-projection, BPTT), the output projections, d(hcat), the proj weight gradients, BN / mask-MLP / FiLM GEMMs;
+  * "fp16x2": one operand as ONE fp16 value (11 bits: h in (-1, 1), the normalised input, the scaled d(gates)), the weight
+    as fp16 hi + lo, TWO fp16 MFMAs per product: the time-view recurrences (round 5: cluster forward incl. its
+    x-projection, pair BPTT) and d(xn);
+  * "fp16x1": both operands single fp16, ONE MFMA per product: the LSTM weight gradients (scaled-fp16 d(gates) x fp16 copies
+    of [xn | h]);
+saved state in 2 bytes (unorm16 gates, scaled-fp16 d(gates)), c / h / activations in fp32.  Holds the reference's fp32
+results to ~1e-4 on the separated waveforms (tests/test_bsrnn_gpu.py; tolerance 1e-3).  Weak scaling: every rank runs the same per-GPU batch on its own synthetic
 rows (seed 42 + rank); DDP all-reduces gradients over RCCL.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -70,7 +78,8 @@ def _cpu_baseline_worker(threads, budget_s):
                       "kind": "port",
                       "sample": f"oracle (torch CPU fp32 restatement of the reference step), R={R} rows x 4 s, "
                                 f"1 warm-up + {n} timed steps of fwd+SI-SDR+bwd+clip+Adam, {dt:.2f} s/step, "
-                                f"{threads} of {os.cpu_count()} host cores (reference recipe: OMP_NUM_THREADS=8)"}))
+                                f"{threads} of {os.cpu_count()} host cores (reference recipe: OMP_NUM_THREADS=8; all-core "
+                                f"runs were slower on this host class: 0.036 utt/s with 128 threads, BENCH_r04)"}))
 
 
 def _cpu_reference_worker(threads, budget_s):
@@ -113,18 +122,19 @@ def _cpu_reference_worker(threads, budget_s):
                                 f"s/step, {threads} of {os.cpu_count()} host cores"}))
 
 
-def cpu_baseline(budget_s=30.0, hard_limit_s=240.0, kind="port"):
+def cpu_baseline(budget_s=30.0, hard_limit_s=240.0, kind="port", threads="16"):
     """Oracle (CPU port of the reference step) timed on this host's cores in a child process so a
     pathological host (hundreds of cores, oversubscription) cannot stall the benchmark.
 
-    Cores (BASELINE.md section 3 asks for the host's cores, count stated): the step is timed twice on a bounded sample --
-    with 16 threads (twice the reference recipe's OMP_NUM_THREADS=8; what a torch CPU LSTM over 2 rows x 32 bands can keep
-    busy) and with every core of the host (capped at 128) -- and the FASTER run is reported, with both in `sample`: on the
-    256-core GPU hosts the all-core run is slower (oversubscribed oneDNN / intra-op pools on 501 sequential steps)."""
+    Cores (BASELINE.md section 3 asks for the host's cores, count stated): 16 threads -- twice the reference recipe's
+    OMP_NUM_THREADS=8, what a torch CPU LSTM over 2 rows x 32 bands can keep busy.  Rounds 3-4 also timed every core of the
+    host (capped at 128) in every run and reported the faster: on the 256-core GPU hosts the all-core run was slower every
+    time (BENCH_r04: 0.036 utt/s with 128 threads vs 0.37-0.44 with 16: oversubscribed oneDNN / intra-op pools on 501
+    sequential steps), a known answer that cost ~110 s of each run; `--cpu-threads` times another count."""
     import subprocess
     ncpu = os.cpu_count() or 1
     worker = "_cpu_reference_worker" if kind == "reference" else "_cpu_baseline_worker"
-    tries = sorted({min(ncpu, 16), min(ncpu, 128)})
+    tries = sorted({min(ncpu, int(t)) for t in str(threads).split(",")})
     runs = []
     for threads in tries:
         cmd = [sys.executable, "-c",
@@ -146,6 +156,32 @@ def cpu_baseline(budget_s=30.0, hard_limit_s=240.0, kind="port"):
                     " / ".join(f"{r['cores']} threads ({r['value']:.3f} utt/s)" if r["value"] else f"{r['cores']} threads (failed)"
                                for r in runs))
     return best
+
+
+def mfma_terms_census():
+    """MFMA instructions issued per fp32-equivalent product, per GEMM class of one ResRNN, weighted by the class's share of
+    the ResRNN's algorithmic FLOPs (per position: 2 x the K x N below) -- what `executed_*` in the line is built from.  The
+    table follows the code paths the environment selects (functional.pair_rfmt, dev.lstm_cluster2_on, functional.tnb_a16,
+    dev.gates_fmt); 12 ResRNNs (6 time view, 6 band view) carry 97 % of the step's FLOPs, the rest (BN, mask MLP, FiLM,
+    STFT) runs three terms."""
+    from wesep_amd import _lib as L
+    from wesep_amd import dev, functional as F
+    gf = dev.gates_fmt()
+    h2f = gf == L.GATES_H2F
+    c2 = dev.lstm_cluster2_on() and gf != L.GATES_F32
+    kn = {"x_proj": 128 * 2048, "recur_fwd": 2 * 256 * 1024, "proj": 512 * 128, "d_hcat": 128 * 512, "bptt": 2 * 256 * 1024,
+          "dW_lstm": 2 * 1024 * 384, "d_xn": 2048 * 128, "dW_proj": 512 * 128}
+    terms = {
+        "time": {"x_proj": 2 if c2 else 3, "recur_fwd": 2 if c2 else 3, "proj": 3, "d_hcat": 3, "bptt": 2 if F.pair_rfmt(gf) else 3,
+                 "dW_lstm": (1 if F.tnb_a16() else 2) if h2f else 3, "d_xn": 2 if h2f else 3, "dW_proj": 3},
+        "band": {"x_proj": 3, "recur_fwd": 3, "proj": 3, "d_hcat": 3, "bptt": 3,
+                 "dW_lstm": (1 if F.tnb_a16() else 2) if h2f else 3, "d_xn": 2 if h2f else 3, "dW_proj": 3},
+    }
+    tot = sum(kn.values())
+    per_view = {v: sum(kn[k] * t[k] for k in kn) / tot for v, t in terms.items()}
+    mean = 0.97 * 0.5 * (per_view["time"] + per_view["band"]) + 0.03 * 3.0
+    return {"terms_per_product": terms, "flop_share_of_a_resrnn": {k: v / tot for k, v in kn.items()},
+            "mean_terms_time_view": per_view["time"], "mean_terms_band_view": per_view["band"], "mean_terms_step": mean}
 
 
 def _latest_profile(kind):
@@ -172,6 +208,7 @@ def main():
     ap.add_argument("--cpu-baseline", choices=("port", "reference"), default="port",
                     help="port: the oracle (travels to the GPU box); reference: the reference's own modules imported "
                          "from /root/reference (only where that exists)")
+    ap.add_argument("--cpu-threads", default="16", help="thread counts of the CPU baseline, comma separated (the fastest is reported)")
     ap.add_argument("--cpu-only", action="store_true", help="print the CPU baseline object and exit (no GPU needed)")
     ap.add_argument("--joint", action="store_true",
                     help="the shipped confs/bsrnn.yaml variant: speaker encoder (wespeaker ResNet34 on 80-d fbank, "
@@ -179,7 +216,7 @@ def main():
     args = ap.parse_args()
 
     if args.cpu_only:
-        print(json.dumps(cpu_baseline(kind=args.cpu_baseline)), flush=True)
+        print(json.dumps(cpu_baseline(kind=args.cpu_baseline, threads=args.cpu_threads)), flush=True)
         return
     from wesep_amd import dev
     from wesep_amd import _lib as L
@@ -261,10 +298,12 @@ def main():
     # reads 4 saved gates, c, d(h) (c_{t-1} is the next step's c: L2) and writes 4 d(gates): 40 B with the round-3 format
     # (fp32 gates, split-pair d(gates)), 24 B with the default WS_GATES_H2 (unorm16 gates, bf16 d(gates)), 32 B with H2S;
     # the forward reads 4 fp32 pre-activations (time view; the band view's fused projection reads the 128-wide input
-    # instead: 1 B per cell) and writes 4 gates + c + h: 40 B before, 32 / 17 B now (launch average 24.5)
+    # instead: 1 B per cell) and writes 4 gates + c + h: 40 B before, 32 / 17 B in round 4 (launch average 24.5), 16.5 / 17 B
+    # with ws_lstm_fwd_cluster2 (launch average 16.75)
     gfmt = dev.gates_fmt()
     bwd_cell = dev._bptt_bytes(gfmt)
-    fwd_cell = 40.0 if gfmt == L.GATES_F32 else 24.5
+    # round 5: the cluster forward computes its x-projection from the fp16 normalised input (0.5 B per cell instead of 16)
+    fwd_cell = 40.0 if gfmt == L.GATES_F32 else (16.75 if dev.lstm_cluster2_on() else 24.5)
     cell_bytes = {"lstm_bwd": float(bwd_cell), "lstm_fwd": fwd_cell}
     prof = {}
     for name, kind in (("lstm_fwd", L.PROF_LSTM_FWD), ("lstm_bwd", L.PROF_LSTM_BWD),
@@ -306,19 +345,25 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    census = mfma_terms_census()
+    tv, bv = census["terms_per_product"]["time"], census["terms_per_product"]["band"]
+    dom_terms = 0.5 * ((tv["bptt"] + bv["bptt"]) if dom == "lstm_bwd" else (tv["recur_fwd"] + bv["recur_fwd"]))
+    arith = ("bf16x3 (band-view recurrences, projections, d(hcat), BN / mask GEMMs) + fp16x2 (time-view cluster forward "
+             "incl. x-projection, pair BPTT, d(xn)) + fp16x1 (LSTM weight gradients); 2-byte saved gates / d(gates); fp32 "
+             "accumulate")
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "utterances/sec (4 s, 16 kHz, 2-spk) fwd+bwd, pBSRNN",
             "value": world * R * args.steps / elapsed, "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3+fp16x2+fp16x1 split products, fp32 accumulate" if census["mean_terms_step"] < 2.99 else "bf16x3",
             "data": "synthetic",
             "config": {"workload": "pBSRNN FiLM multi-fuse, 6 repeats, feature_dim 128, " +
                                    ("jointly trained wespeaker ResNet34 speaker encoder on [R, 398, 80] fbank"
                                     if args.joint else "fixed 256-d embeddings") +
-                                   "; fwd + SI-SDR + bwd + per-tensor clip + Adam-L2; split-bf16 "
-                                   "products (3 bf16 MFMAs), fp32 accumulate + storage",
+                                   "; fwd + SI-SDR + bwd + per-tensor clip + Adam-L2; " + arith,
                        "rows_per_gpu": R, "global_rows": world * R, "samples_per_row": T,
                        "parallelism": f"dp{world}", "final_loss_dB": final_loss},
             # the recurrence kernels are bound by memory paths (HBM activations + the per-step L2 weight
@@ -338,9 +383,12 @@ def main():
                          # comparison with the earlier rounds' lines: bytes that no longer move are not achieved bandwidth
                          "frac_at_round3_bytes": 40.0 * P * 2 * L.LSTM_H / sec / 1e9 / HBM_PEAK_GBS,
                          "ms_per_launch": prof[dom]["ms_avg"],
-                         "mfma": {"alg_tflops": tfl, "executed_bf16_tflops": 3 * tfl,
-                                  "peak_bf16_tflops": BF16_MFMA_PEAK_TFLOPS,
-                                  "frac_executed": 3 * tfl / BF16_MFMA_PEAK_TFLOPS,
+                         # MFMAs executed per product in THIS class: the launch average over the time view (pair BPTT /
+                         # cluster forward) and the band view (three-term streaming kernels)
+                         "mfma": {"alg_tflops": tfl, "terms_per_product": dom_terms, "executed_tflops": dom_terms * tfl,
+                                  "peak_tflops": BF16_MFMA_PEAK_TFLOPS,
+                                  "frac_executed": dom_terms * tfl / BF16_MFMA_PEAK_TFLOPS,
+                                  "frac_algorithmic": tfl / BF16_MFMA_PEAK_TFLOPS,
                                   "busy_frac_pmc": mfma_busy}},
             "kernel_ms_per_step": {k: v["ms_total"] / args.steps for k, v in prof.items()},
         }
@@ -352,24 +400,28 @@ def main():
         # (x3 executed as split-bf16) and the layer-fused minimum of 2.26 GB of fp32 traffic
         sec_step = elapsed / args.steps
         alg_flops, alg_bytes = 1.017e12 * R, 2.26e9 * R
-        t_mfma = 3 * alg_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+        mt = census["mean_terms_step"]
+        t_mfma = mt * alg_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12)
         t_hbm = alg_bytes / (HBM_PEAK_GBS * 1e9)
+        out["mfma_terms"] = census
         out["step_roofline"] = {
             "alg_flops_per_step": alg_flops, "alg_bytes_per_step": alg_bytes,
-            "alg_tflops": alg_flops / sec_step / 1e12, "executed_bf16_tflops": 3 * alg_flops / sec_step / 1e12,
+            "alg_tflops": alg_flops / sec_step / 1e12, "mean_mfma_terms_per_product": mt,
+            "executed_tflops": mt * alg_flops / sec_step / 1e12,
             "frac_mfma_executed": t_mfma / sec_step, "alg_gbs": alg_bytes / sec_step / 1e9,
             "frac_hbm_alg": t_hbm / sec_step, "bound": "mfma" if t_mfma >= t_hbm else "hbm",
-            "frac": max(t_mfma, t_hbm) / sec_step,
+            "frac": max(alg_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12), t_hbm) / sec_step,
             "frac_mfma_algorithmic": alg_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12) / sec_step,
-            "note": "per GPU; SURVEY 8d: achieved := max(bytes_alg / 8 TB/s, 3 * flops_alg / 2.5 PFLOP/s) / t_step -- "
-                    "`frac` / `frac_mfma_executed` count the 3 bf16 MFMAs EXECUTED per fp32 product against the bf16 peak; "
-                    "`frac_mfma_algorithmic` counts each product once"}
+            "note": "per GPU; `frac` = `frac_mfma_algorithmic`: every fp32-equivalent product counted ONCE against the dense "
+                    "bf16 / fp16 MFMA peak (2.5 PFLOP/s) -- the defensible step figure.  `frac_mfma_executed` counts the MFMA "
+                    "instructions the kernels really issue per product (`mfma_terms`: 1, 2 or 3 by GEMM class, FLOP-weighted "
+                    "mean over the step), not a flat 3"}
         out["per_rank_ms_per_step"] = per_rank_ms
         out["replicas_in_sync"] = bool(spread == 0.0)
         out["replica_checksum_spread"] = spread
         out["comm"] = comm_info()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind=args.cpu_baseline)
+            out["cpu_baseline"] = cpu_baseline(kind=args.cpu_baseline, threads=args.cpu_threads)
         print(json.dumps(out), flush=True)
     barrier()
     # a scaling record of replicas that drifted apart, or of fewer ranks than asked for, is not a measurement

@@ -322,7 +322,8 @@ int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream);
  * xchg: (nseq / 32) * 64 KB scratch (filled by the call on `stream`); tword: the launch's time-out word (zeroed by the
  * call; 0 after a clean launch; callers enqueue ws_gemm_p2b + ws_lstm_fwd with run_if = tword behind the launch);
  * status: optional, sticky.  dbg (probes / tests): 1 skip the wait, 4 skip the publish, 8 force a time-out in workgroup 0
- * at step 2, 2048 cycle stamps into dbg_buf.                                                                                                       */
+ * at step 2, 32 the HBM traffic on the M-waves at the top of the step (round-4 placement; default: on the X-waves after their
+ * recurrent MFMAs), 2048 cycle stamps into dbg_buf.                                                                                                       */
 typedef struct ws_lstm_cluster2_args {
   float* gates;
   float* cbuf;
@@ -357,7 +358,8 @@ int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream);
  * BPTT behind this launch with  run_if = &flags[npair * 8]  and the same `dgates`: an empty launch after a clean run,
  * the whole BPTT again after a timeout -- no NaN reaches a consumer, no host round trip (ABI v15).
  * dbg (probes / tests only): 1 skip the flag wait, 2 skip the exchange, 4 no weight reloads,
- * 8 force a timeout in pair 0 at step 2, 32 no wave priorities,
+ * 8 force a timeout in pair 0 at step 2, 16 (rfmt 1) the X-waves request the next step's saved state before the MFMA phase
+ * instead of behind the publish, 32 no wave priorities,
  * 64 full agent-scope release / acquire fences around the hand-off, 2048 (WS_GATES_F32 / H2F) cycle stamps of pair 0
  * into dbg_buf (tools/pair_diag.py --ts).                                                                         */
 typedef struct ws_lstm_pair_args {

@@ -59,23 +59,24 @@ def main():
     x = torch.randn(nb, N // 4, 32, 4, device=d)
     xn16 = dev.blh_f16_pack(x)
     wcat, bcat = torch.randn(2 * 4 * H * N, device=d) * 0.08, torch.randn(2 * 4 * H, device=d) * 0.1
-    for dbg, nm in ((0, ""), (1, " (no wait: dbg 1)")):
+    for dbg, nm in ((0, ""), (1, " (no wait: dbg 1)"), (32, " (I/O on M-waves)")):
         t = timeit(lambda: dev.lstm_fwd_cluster2(gh, cbuf, hcat, xn16, wcat, bcat, whf, whr, seq, status=st, dbg=dbg))
         print(f"cluster2 fwd (fp16 h, fused x-proj, tagged){nm:18s} {t:7.3f} ms  {t * 1e3 / Tf:6.2f} us/step", flush=True)
     print("status word after the forward kernels", int(st.item()), flush=True)
-    if not a.no_stamps:
+    for iobit, ionm in ((0, "I/O on X-waves after their MFMAs (default)"), (32, "I/O on M-waves at the top")):
+      if not a.no_stamps:
         for rep in range(2):
             dbuf = torch.zeros(Tf * 2 * 8 * 2, device=d)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            dev.lstm_fwd_cluster2(gh, cbuf, hcat, xn16, wcat, bcat, whf, whr, seq, status=st, dbg=2048, dbg_buf=dbuf)
+            dev.lstm_fwd_cluster2(gh, cbuf, hcat, xn16, wcat, bcat, whf, whr, seq, status=st, dbg=2048 + iobit, dbg_buf=dbuf)
             e1.record()
             torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         ts = dbuf.view(torch.int64).view(Tf, 2, 8).cpu().double()
         span = float(ts[-1, 0, 0] - ts[5, 0, 0]) / (Tf - 6)
         upt = (ms * 1e3 / Tf) / span if span > 0 else float("nan")
-        print(f"--- stamps, cluster2 forward: launch {ms:.3f} ms = {ms * 1e3 / Tf:.2f} us/step with stamps; {span:.0f} ticks per step")
+        print(f"--- stamps, cluster2 forward, {ionm}: launch {ms:.3f} ms = {ms * 1e3 / Tf:.2f} us/step with stamps; {span:.0f} ticks per step")
         cn = ["loop top", "recurrent MFMAs done", "past barrier 0", "cell update done (h published)", "next x-projection done",
               "X: all eight slices arrived", "X: h image written"]
         for role, rn in ((0, "X-wave 0 (tile 0)"), (1, "M-wave 4 (tile 1)")):
@@ -103,20 +104,22 @@ def main():
     t0 = timeit(lambda: work.copy_(gq))
     t = timeit(f32) - t0
     print(f"pair BPTT, fp32 gates in place, bf16x3       {t:7.3f} ms  {t * 1e3 / Tf:6.2f} us/step", flush=True)
-    for rf, pk, nm in ((0, pp, "bf16x3 recurrence"), (1, pp16, "fp16x2 recurrence")):
-        t = timeit(lambda: dev.lstm_bwd_pair(gh, cbuf, dh, pk, seq, status=st, gfmt=L.GATES_H2F, dgates=dgo, amax=amax, rfmt=rf))
+    for rf, pk, nm, dbg in ((0, pp, "bf16x3 recurrence", 0), (1, pp16, "fp16x2 recurrence, tagged", 0),
+                            (1, pp16, "fp16x2, tagged, early prefetch", 16)):
+        t = timeit(lambda: dev.lstm_bwd_pair(gh, cbuf, dh, pk, seq, status=st, gfmt=L.GATES_H2F, dgates=dgo, amax=amax, rfmt=rf,
+                                             dbg=dbg))
         print(f"pair BPTT, unorm16 in / fp16 out, {nm}  {t:7.3f} ms  {t * 1e3 / Tf:6.2f} us/step", flush=True)
     print("status word", int(st.item()), flush=True)
     if a.no_stamps:
         return
     names = ["loop top", "cell backward done", "past S1", "MFMA loop done", "X: flagged / O: partial in LDS",
              "X: next loads requested", "X: partner's flag seen", "X: gather arrived"]
-    for rf, pk, nm in ((0, pp, "bf16x3"), (1, pp16, "fp16x2")):
+    for rf, pk, nm, xdbg in ((1, pp16, "fp16x2 tagged", 0), (1, pp16, "fp16x2 tagged, early prefetch", 16)):
         for rep in range(2):
             dbuf = torch.zeros(Tf * 2 * 8 * 2, device=d)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            dev.lstm_bwd_pair(gh, cbuf, dh, pk, seq, status=st, gfmt=L.GATES_H2F, dgates=dgo, amax=amax, rfmt=rf, dbg=2048,
+            dev.lstm_bwd_pair(gh, cbuf, dh, pk, seq, status=st, gfmt=L.GATES_H2F, dgates=dgo, amax=amax, rfmt=rf, dbg=2048 + xdbg,
                               dbg_buf=dbuf)
             e1.record()
             torch.cuda.synchronize()

@@ -70,7 +70,7 @@ __device__ __forceinline__ bool cluster2_of_block(int ncl, int& c, int& j) {
       reinterpret_cast<unsigned long long*>(p.dbg_buf)[(step * 2 + st) * 8 + (k)] = __builtin_readcyclecounter();   \
   }
 
-template <bool FORCE, bool STAMPS = false>
+template <bool FORCE, bool STAMPS = false, bool IOX = true>
 __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm_cluster2_args p) {
   __shared__ __attribute__((aligned(16))) _Float16 hl[C2_SEQ * HROW];   // h image [seq][k], one fp16 plane, 33 KB
   __shared__ __attribute__((aligned(16))) f16x8 wih[4 * 2 * 8 * 64];    // W_ih slice [uo][part][ks][lane], 64 KB
@@ -161,15 +161,22 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
     }
   };
 
+  // Which waves carry the HBM traffic (stores of the previous step's outputs, the xn16 prefetch).  Round 4's kernel gave it to
+  // the M-waves at the TOP of the step -- an exchange wave's gather must not queue behind HBM traffic (VMEM returns in order)
+  // -- but the cycle stamps of this kernel (profiles/r05_c3_recur_probe.txt) show the M-waves as the step's critical resource
+  // (I/O 0.9 us + MFMAs 0.85 + cell update 1.5 + x-projection 0.7 of 4.45 us) while the X-waves sit 1 us at barrier 0: with
+  // IOX the X-waves (which poll ~2 us later: their queue has drained by then) do the I/O right after their recurrent MFMAs.
+  const bool iox = IOX;
+  const bool iorole = iox ? xrole : !xrole;
   f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
-  u32x4 xreg[4];  // M-waves: the xn16 units of the step after next
-  if (!xrole) {
+  u32x4 xreg[4];  // I/O waves: the xn16 units of the step after next
+  if (iorole) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) xb[mt + 256 * q] = xld(step_time(0), q);
   }
   __syncthreads();
   xpart();        // step 0
-  if (!xrole) {
+  if (iorole) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) xreg[q] = xld(step_time(min(1, L - 1)), q);
   }
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
     const int par = step & 1;
     const unsigned tag = ((step >> 1) & 1) ? C2_TAGS : 0u;
     C2TS(0);
-    if (!xrole) {
+    auto step_io = [&]() {
       if (step > 0) hbm_io(step_time(step - 1), step);
       else {
 #pragma unroll
@@ -213,7 +220,8 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
 #pragma unroll
         for (int q = 0; q < 4; ++q) xreg[q] = xld(t2, q);
       }
-    }
+    };
+    if (!iox && iorole) step_io();
     // ---- G^T tile [4 gates x 8 units][32 seqs] += W_hh slice * h^T -----------------------------------------------------
     {
       const _Float16* hb = &hl[(st * 32 + n) * HROW + 8 * half];
@@ -224,6 +232,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
         acc1 = mfma16h(wl[ks], b, acc1);
       }
     }
+    if (iox && iorole) step_io();
     C2TS(1);
     __syncthreads();  // 0: the previous step's outputs have left the LDS stage
     C2TS(2);
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
     }
     __syncthreads();  // 2: h image of the next step complete; publ / xb may be rewritten
   }
-  if (!xrole) hbm_io(step_time(L - 1), L);  // the last step's stores
+  if (iorole) hbm_io(step_time(L - 1), L);  // the last step's stores
 }
 
 extern "C" int ws_lstm_fwd_cluster2(const ws_lstm_cluster2_args* a, void* stream) {
@@ -321,7 +330,9 @@ extern "C" int ws_lstm_fwd_cluster2(const ws_lstm_cluster2_args* a, void* stream
   e = hipMemsetAsync(a->tword, 0, sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_fwd_cluster2: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
-  if (a->dbg & 2048) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false, true>), dim3(grid), dim3(512), 0, s, *a);
+  if ((a->dbg & 2048) && (a->dbg & 32)) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false, true, false>), dim3(grid), dim3(512), 0, s, *a);
+  else if (a->dbg & 2048) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false, true>), dim3(grid), dim3(512), 0, s, *a);
+  else if (a->dbg & 32) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false, false, false>), dim3(grid), dim3(512), 0, s, *a);
   else if (a->dbg & 8) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<true>), dim3(grid), dim3(512), 0, s, *a);
   else hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false>), dim3(grid), dim3(512), 0, s, *a);
   ws_prof_end(WS_PROF_LSTM_FWD, s);

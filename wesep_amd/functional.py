@@ -671,14 +671,20 @@ def _bptt_kind(seq, device, cluster) -> str:
 
 def _pair_dbg() -> int:
     """WESEP_PAIR_FORCE_TIMEOUT=1 (tests): every pair BPTT launch times out in pair 0 at step 2, so the predicated
-    streaming fall-back produces the layer's d(gates)."""
-    return 8 if os.environ.get("WESEP_PAIR_FORCE_TIMEOUT", "0") == "1" else 0
+    streaming fall-back produces the layer's d(gates).  WESEP_PAIR_EARLY=1 (experiment, rfmt 1): dbg bit 16, the X-waves'
+    prefetch before the MFMA phase."""
+    if os.environ.get("WESEP_PAIR_FORCE_TIMEOUT", "0") == "1":
+        return 8
+    return 16 if os.environ.get("WESEP_PAIR_EARLY", "0") == "1" else 0
 
 
 def _cluster_dbg() -> int:
     """WESEP_CLUSTER_FORCE_TIMEOUT=1 (tests): every forward cluster launch times out in workgroup 0 at step 2, so the
-    predicated streaming fall-back produces the layer's result."""
-    return 8 if os.environ.get("WESEP_CLUSTER_FORCE_TIMEOUT", "0") == "1" else 0
+    predicated streaming fall-back produces the layer's result.  WESEP_CLUSTER2_IO=m (experiment): dbg bit 32 of
+    ws_lstm_fwd_cluster2, the HBM traffic on the M-waves at the top of the step."""
+    if os.environ.get("WESEP_CLUSTER_FORCE_TIMEOUT", "0") == "1":
+        return 8
+    return 32 if os.environ.get("WESEP_CLUSTER2_IO", "x") == "m" else 0
 
 
 def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, proj_w):
