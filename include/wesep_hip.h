@@ -358,8 +358,7 @@ int ws_lstm_bwd_cluster(const ws_lstm_cluster_args* a, void* stream);
  * BPTT behind this launch with  run_if = &flags[npair * 8]  and the same `dgates`: an empty launch after a clean run,
  * the whole BPTT again after a timeout -- no NaN reaches a consumer, no host round trip (ABI v15).
  * dbg (probes / tests only): 1 skip the flag wait, 2 skip the exchange, 4 no weight reloads,
- * 8 force a timeout in pair 0 at step 2, 16 (rfmt 1) the X-waves request the next step's saved state before the MFMA phase
- * instead of behind the publish, 32 no wave priorities,
+ * 8 force a timeout in pair 0 at step 2, 32 no wave priorities,
  * 64 full agent-scope release / acquire fences around the hand-off, 2048 (WS_GATES_F32 / H2F) cycle stamps of pair 0
  * into dbg_buf (tools/pair_diag.py --ts).                                                                         */
 typedef struct ws_lstm_pair_args {

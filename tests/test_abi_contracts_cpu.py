@@ -17,7 +17,7 @@ if torch.cuda.is_available():        # on the GPU box the launches would succeed
     pytest.skip("argument-contract dry run is for GPU-less machines", allow_module_level=True)
 
 # entry points that size themselves from the device and are expected to refuse a machine without CUs
-DEVICE_DEPENDENT = ("ws_lstm_fwd_cluster", "ws_lstm_bwd_cluster", "ws_lstm_bwd_pair")
+DEVICE_DEPENDENT = ("ws_lstm_fwd_cluster", "ws_lstm_fwd_cluster2", "ws_lstm_bwd_cluster", "ws_lstm_bwd_pair")
 
 SPK = dict(joint_training=True, spk_feat=True,
            spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))

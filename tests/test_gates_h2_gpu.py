@@ -457,3 +457,59 @@ def test_gemm_tnb_fp16_a_operand(view, dims):
         Gs = G[:, di * 1024:(di + 1) * 1024].double() * tiny
         ref = torch.cat([Gs.t() @ A0.double(), Gs.t() @ A1s.double()], 1)
         assert rel(outs[1][0].sum(0).view(1024, 384), ref) < 4e-5
+
+
+def test_gemm_tnb_fp16_operands_vs_fp64_at_the_headline_geometry():
+    """the weight-gradient GEMM on fp16 operands (ws_gemm_tnb g_fmt = 2, a_fmt = 1: ONE
+    v_mfma_f32_32x32x16_f16 per product, 11-bit G x 11-bit A) at the headline's own contraction length -- the time view of
+    R = 32 rows x 4 s: K = P = 513 024 positions -- against the fp64 product of the UNROUNDED fp32 operands, computed on the
+    device.  Random operands are the worst case for a rounded product (the roundings of 513 k terms add incoherently and so
+    does the sum itself: the relative error does not shrink with K); the bound is 2^-11, the measured figures are printed."""
+    from wesep_amd import dev
+    from wesep_amd.functional import _view_maps
+    d = _cuda()
+    torch.manual_seed(21)
+    R, K, Tf = 32, 32, 501
+    P, GW = R * K * Tf, 2048
+    geo, smap, seq, _ = _view_maps("time", R, K, Tf, N)
+    nb = dev.bl_num_blocks(seq)
+    G32 = torch.randn(P, GW, device=d) * torch.exp(torch.randn(P, 1, device=d)) * 1e-6     # gradient-sized, heavy-tailed rows
+    A0 = torch.randn(P, N, device=d)                                                       # the normalised input
+    A1 = torch.tanh(torch.randn(P, 2 * H, device=d))                                       # h in (-1, 1)
+    amax = (G32.abs().max() / 4).reshape(1).view(torch.int32).clone()                      # d(gates) reach a few times max |d(hcat)|
+    S = L.dgates_scale(int(amax.item()))
+    assert float(G32.abs().max()) * S < 65504.0
+    G_f16 = (dev.to_blocked(G32, seq) * S).to(torch.float16).contiguous().view(torch.float32)
+    A0h, A1h = dev.blh_f16_pack(dev.to_blocked(A0, seq)), dev.blh_f16_pack(dev.to_blocked(A1, seq))
+    pos, valid = dev.bl_positions(seq, d)
+    nt = -(-seq.nseq // 32)
+    posv, val = pos.view(nt, seq.L, 32), valid.view(nt, seq.L, 32)
+    worst = 0.0
+    for di, shift in ((0, -1), (1, 1)):
+        ns, bps = dev.tnb_splits(nb, 8)
+        slab, bslab = torch.full((ns, 1024 * 384), float("nan"), device=d), torch.full((ns, 1024), float("nan"), device=d)
+        dev.gemm_tnb(G=G_f16, g_width=GW, g_off=di * 1024, g_cols=1024, A0=A0h, a0_width=N, a0_off=0, a0_cols=N,
+                     A1=A1h, a1_width=2 * H, a1_off=di * H, a1_cols=H, a1_shift=shift, nblk=nb, L_=seq.L,
+                     slab=slab, nsplit=ns, blocks_per_split=bps, bslab=bslab, g_fmt=2, amax=amax, a_fmt=1)
+        got, gotb = slab.sum(0).view(1024, 384).double(), bslab.sum(0).double()
+        A1s = torch.zeros(P, H, device=d)                              # h of the previous step of the same sequence
+        src = torch.roll(posv, shifts=-shift, dims=1)
+        ok = val.clone()
+        if shift == -1:
+            ok[:, 0] = False
+        else:
+            ok[:, -1] = False
+        A1s[posv[ok]] = A1[src[ok]][:, di * H:(di + 1) * H]
+        ref = torch.zeros(1024, 384, device=d, dtype=torch.float64)
+        refb = torch.zeros(1024, device=d, dtype=torch.float64)
+        for lo in range(0, P, 32768):                                  # fp64 on the device, in slices of the contraction
+            g64 = G32[lo:lo + 32768, di * 1024:(di + 1) * 1024].double()
+            ref += g64.t() @ torch.cat([A0[lo:lo + 32768], A1s[lo:lo + 32768]], 1).double()
+            refb += g64.sum(0)
+        e_ih, e_hh, e_b = rel(got[:, :N], ref[:, :N]), rel(got[:, N:], ref[:, N:]), rel(gotb, refb)
+        e_max = float((got - ref).abs().max() / ref.abs().max())
+        print(f"gemm_tnb fp16 x fp16 at K = {P}, direction {di}: rel-L2 dW_ih {e_ih:.2e}  dW_hh {e_hh:.2e}  db {e_b:.2e}; "
+              f"largest element error / largest element {e_max:.2e}")
+        worst = max(worst, e_ih, e_hh, e_b)
+        del g64, ref
+    assert worst < 2.0 ** -11, worst

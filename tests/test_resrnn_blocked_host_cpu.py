@@ -67,10 +67,13 @@ def test_resrnn_blocked_matches_oracle(emu, monkeypatch, view, R, K, Tf, branch,
         x = z.permute(0, 2, 3, 1).reshape(R * Tf, 128, K)
         ref = O.res_rnn(p, "", x).view(R, Tf, 128, K).permute(0, 3, 1, 2)
     (ref * probe).sum().backward()
-    assert float((out - ref).norm() / ref.norm()) < 1e-5
+    # the cluster branch of the 2-byte formats is ws_lstm_fwd_cluster2 (round 5): fp16 h (11 bits) in the recurrent product,
+    # the x-projection on the fp16 copy of the normalised input -- 2^-12 per operand element instead of the emulation's fp32
+    c2 = cluster and fmt != "f32" and dev.lstm_cluster2_on()
+    assert float((out - ref).norm() / ref.norm()) < (1e-4 if c2 else 1e-5)
     want = {"z": z.grad, **{k: v.grad for k, v in p.items()}}
     for k in want:
-        assert float((got[k] - want[k]).norm()) <= gtol * float(want[k].norm()) + 1e-6, k
+        assert float((got[k] - want[k]).norm()) <= max(gtol, 5e-4 if c2 else 0.0) * float(want[k].norm()) + 1e-6, k
 
 
 def _oracle_time(p, z, R, K, Tf):
@@ -92,7 +95,8 @@ def test_cluster_timeout_falls_back_to_the_streaming_kernels(emu, monkeypatch):
         with torch.no_grad():
             out = F0.ResRNNBlkFn.apply(z, None, None, None, "time", p["norm.weight"], p["norm.bias"], *(p[n] for n in NAMES))
         assert torch.isfinite(out).all()
-        assert float((out - ref).norm() / ref.norm()) < 1e-5, force
+        # (clean launch: ws_lstm_fwd_cluster2's fp16 h / fp16 xn; forced time-out: the streaming kernels' fp32 emulation)
+        assert float((out - ref).norm() / ref.norm()) < (1e-4 if force == "0" else 1e-5), force
 
 
 def test_pack_cache_follows_the_weights_and_second_backward_is_refused(emu):

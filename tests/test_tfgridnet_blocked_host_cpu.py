@@ -57,9 +57,10 @@ def test_blstm_linear_blocked_matches_torch(emu, monkeypatch, nseq, Lr, branch, 
     (ref * probe).sum().backward()
     want = {"y": y.grad, "res": res.grad,
             **{k: p.grad for k, p in list(lstm.named_parameters()) + [("lin." + k, p) for k, p in lin.named_parameters()]}}
-    assert float((out - ref).norm() / ref.norm()) < 1e-5
+    c2 = cluster and fmt != "f32" and dev.lstm_cluster2_on()     # ws_lstm_fwd_cluster2 (round 5): fp16 h, fp16 input copy
+    assert float((out - ref).norm() / ref.norm()) < (1e-4 if c2 else 1e-5)
     for k in want:
-        assert float((got[k] - want[k]).norm()) <= gtol * float(want[k].norm()) + 1e-6, k
+        assert float((got[k] - want[k]).norm()) <= max(gtol, 6e-4 if c2 else 0.0) * float(want[k].norm()) + 1e-6, k
 
 
 @pytest.mark.parametrize("B,T,Q", [(2, 70, 5), (1, 9, 3)])     # 10 sequences of 70 steps (cluster, padded to 64 via nvalid) / streaming

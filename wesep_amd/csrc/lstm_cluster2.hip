@@ -64,10 +64,15 @@ __device__ __forceinline__ bool cluster2_of_block(int ncl, int& c, int& j) {
 // STAMPS (diagnosis, dbg 2048): s_memtime stamps of cluster 0 / member 0, waves 0 (X) and 4 (M), into p.dbg_buf as 64-bit ticks:
 // [(step * 2 + role) * 8 + k]; k: 0 loop top, 1 recurrent MFMAs done, 2 past barrier 0, 3 cell update done (h published),
 // 4 next step's x-projection done, 5 X: all eight slices arrived, 6 X: h image written; the next k = 0 closes the step
+// Without stamps every phase boundary is still a scheduling fence: the stamped build -- whose s_memtime reads keep the
+// compiler from moving code across the boundaries -- measured 0.5 us per step FASTER than the first unfenced build
+// (profiles/r05_c4_recur_probe.txt: 2.14 vs 2.75 ms per launch), which had let the scheduler mix the phases.
 #define C2TS(k)                                                                                                     \
   if constexpr (STAMPS) {                                                                                           \
     if (c == 0 && j == 0 && uo == 0 && lane == 0 && p.dbg_buf)                                                      \
       reinterpret_cast<unsigned long long*>(p.dbg_buf)[(step * 2 + st) * 8 + (k)] = __builtin_readcyclecounter();   \
+  } else {                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
   }
 
 template <bool FORCE, bool STAMPS = false, bool IOX = true>

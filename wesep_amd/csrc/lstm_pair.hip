@@ -300,13 +300,6 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       emit(pf, 1);
       emit(pg, 2);
       emit(po, 3);
-      // V & 16 (RF = 1): the X-waves request the NEXT step's saved state of this cell here, into the registers the cell
-      // backward has just finished with -- the loads fly under the MFMA phase and the poll of the tagged hand-off has no HBM
-      // load in front of it in the wave's in-order queue (with the request behind the publish the poll's data returned
-      // ~1.1 us after it was there: profiles/r05_c3_recur_probe.txt)
-      if constexpr ((V & 16) && RF != 0) {
-        if (xrole) load_step(tn, e);
-      }
     }
     TS(1);
     __syncthreads();  // S1: the d(gates) image of this step is complete; rec is consumed
@@ -382,10 +375,11 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
           __builtin_amdgcn_raw_buffer_store_b128(v, xrs, xc0 + (par * 2 + (1 - hs)) * PR_XSLOT + q4 * 1024, 0, SC1);
         }
         TS(4);
-        if constexpr (!(V & 16)) {
-          load_step(tn, 0);
-          load_step(tn, 1);
-        }
+        // (requesting the next step's saved state BEFORE the MFMA phase instead -- so that no HBM load sits in front of the
+        //  poll in this wave's in-order queue -- measured 13 % slower: 16 spilled registers and the lo stream's fragments
+        //  queue behind those loads, profiles/r05_c4_recur_probe.txt)
+        load_step(tn, 0);
+        load_step(tn, 1);
         TS(5);
         unsigned spins = 0;
         const bool force = (V & 8) && step == 2 && pr == 0 && hs == 0 && wx == 0;  // test build: a timeout on demand
@@ -506,11 +500,8 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   }
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
   if (a->rfmt == 1) {
-    const bool early = (a->dbg & 16) != 0;   // X-waves prefetch the next step's state before the MFMA phase
     if (a->dbg & 8) hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2F, 1>), dim3(grid), dim3(512), 0, s, *a);
-    else if ((a->dbg & 2048) && early) hipLaunchKernelGGL((lstm_bwd_pair_kernel<2048 + 16, WS_GATES_H2F, 1>), dim3(grid), dim3(512), 0, s, *a);
     else if (a->dbg & 2048) hipLaunchKernelGGL((lstm_bwd_pair_kernel<2048, WS_GATES_H2F, 1>), dim3(grid), dim3(512), 0, s, *a);
-    else if (early) hipLaunchKernelGGL((lstm_bwd_pair_kernel<16, WS_GATES_H2F, 1>), dim3(grid), dim3(512), 0, s, *a);
     else hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, WS_GATES_H2F, 1>), dim3(grid), dim3(512), 0, s, *a);
     ws_prof_end(WS_PROF_LSTM_BWD, s);
     return ws_check_launch("ws_lstm_bwd_pair");

@@ -59,10 +59,10 @@ void ws_prof_begin(int kind, hipStream_t s) {
     p = g_prof.pool.back();
     g_prof.pool.pop_back();
   } else {
-    hipEventCreate(&p.a);
-    hipEventCreate(&p.b);
+    (void)hipEventCreate(&p.a);
+    (void)hipEventCreate(&p.b);
   }
-  hipEventRecord(p.a, s);
+  (void)hipEventRecord(p.a, s);
   g_prof.open[kind] = p.a;
   g_prof.open_b[kind] = p.b;
 }
@@ -71,7 +71,7 @@ void ws_prof_end(int kind, hipStream_t s) {
   if (!g_prof.on) return;
   std::lock_guard<std::mutex> l(g_prof.mu);
   if (!g_prof.open[kind]) return;
-  hipEventRecord(g_prof.open_b[kind], s);
+  (void)hipEventRecord(g_prof.open_b[kind], s);
   g_prof.used[kind].push_back(Pair{g_prof.open[kind], g_prof.open_b[kind]});
   g_prof.open[kind] = nullptr;
 }
@@ -81,9 +81,9 @@ extern "C" int ws_prof_collect(int kind, double* total_ms, long long* launches) 
   std::lock_guard<std::mutex> l(g_prof.mu);
   double tot = 0.0;
   for (auto& p : g_prof.used[kind]) {
-    hipEventSynchronize(p.b);
+    (void)hipEventSynchronize(p.b);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, p.a, p.b);
+    (void)hipEventElapsedTime(&ms, p.a, p.b);
     tot += ms;
     g_prof.pool.push_back(p);
   }

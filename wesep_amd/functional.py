@@ -671,11 +671,8 @@ def _bptt_kind(seq, device, cluster) -> str:
 
 def _pair_dbg() -> int:
     """WESEP_PAIR_FORCE_TIMEOUT=1 (tests): every pair BPTT launch times out in pair 0 at step 2, so the predicated
-    streaming fall-back produces the layer's d(gates).  WESEP_PAIR_EARLY=1 (experiment, rfmt 1): dbg bit 16, the X-waves'
-    prefetch before the MFMA phase."""
-    if os.environ.get("WESEP_PAIR_FORCE_TIMEOUT", "0") == "1":
-        return 8
-    return 16 if os.environ.get("WESEP_PAIR_EARLY", "0") == "1" else 0
+    streaming fall-back produces the layer's d(gates)."""
+    return 8 if os.environ.get("WESEP_PAIR_FORCE_TIMEOUT", "0") == "1" else 0
 
 
 def _cluster_dbg() -> int:

@@ -451,6 +451,20 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
             dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), whf, whr, fpack)
             dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq, gfmt=gfmt)
+        elif cluster and h2 and dev.lstm_cluster2_on():
+            # inter-frame path, 2-byte formats (round 5): ws_lstm_fwd_cluster2 computes x W_ih^T itself from the fp16 copy of
+            # its input (functional.ResRNNBlkFn; lstm_cluster2.hip) -- ws_gemm_p2b only relays the rows into BLH(128); the fp32
+            # pre-activations exist only inside the predicated fall-back behind the launch
+            x16 = xn16 if xn16 is not None else _empty(d, dev.blh_floats(nb, N))
+            xn_keep = None if a16 else xn
+            dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn_keep, A_bl16=x16)
+            tw = dev.lstm_fwd_cluster2(gates, cbuf, hcat, x16, wcat, bcat, whf, whr, seq, dbg=F0._cluster_dbg())
+            wih_pack = _empty(d, 2 * G4 * N)
+            dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
+            pre = _empty(d, nb, 32 * 2 * G4)          # (scratch of the fall-back: untouched after a clean launch)
+            dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=pre, bias=bcat, A_bl=xn_keep, run_if=tw)
+            dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode, run_if=tw, gfmt=gfmt, gates_in=pre)
+            del pre, x16
         else:
             wih_pack = _empty(d, 2 * G4 * N)
             dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
@@ -487,7 +501,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             ppack = None
             if kind == "pair":
                 ppack = _empty(d, L.LSTM_PACK_FLOATS)
-                dev.lstm_pack_pair(whf, whr, ppack)
+                dev.lstm_pack_pair(whf, whr, ppack, f16=bool(F0.pair_rfmt(gfmt)))     # (rfmt 1: fp16 hi / lo of 256 w)
             bw_packs = (wlt_pack, wct_pack, ppack)
         ctx.bw_packs = bw_packs
         ctx.save_for_backward(gates, cbuf, hcat, xn16 if a16 else xn, wcat, pack_b, lw, whf, whr, hcat16)
@@ -540,7 +554,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
                 # d(gates) out of place, the streaming BPTT predicated on the launch's time-out word behind it (functional.py)
                 dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else _empty(d, dev.blh_floats(nb, 2 * G4))
                 tw = dev.lstm_bwd_pair(gates, cbuf, dh, ppack, seq, gfmt=gfmt, dgates=dg, repairable=True,
-                                       dbg=ctx.F0._pair_dbg(), amax=amax)
+                                       dbg=ctx.F0._pair_dbg(), amax=amax, rfmt=ctx.F0.pair_rfmt(gfmt))
                 dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, lmode, gfmt=gfmt, dgates=dg, run_if=tw, amax=amax)
         elif gfmt == L.GATES_F32:
             dg = gates
