@@ -201,3 +201,67 @@ def test_a_nan_on_one_rank_is_skipped_by_every_rank_world2_gloo(tmp_path):
             assert torch.equal(a, b) and bool(torch.isfinite(a).all())      # replicas bit-identical, never poisoned
     assert all(torch.equal(a, b) for a, b in zip(r0["trace"][0], r0["trace"][1]))      # step 1 changed nothing
     assert not torch.equal(r0["trace"][1][0], r0["trace"][2][0])                       # step 2 trained on
+
+
+class _TseToy(torch.nn.Module):
+    """(wav_mix, enrollment) -> (estimate,): the call shape Executor.train drives."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(32, 32)
+
+    def forward(self, wav, emb):
+        return (self.a(wav) + emb[:, :1],)
+
+
+def _replica_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from _pytest.monkeypatch import MonkeyPatch
+    from tests import emu_optim
+    from wesep_amd.optim import FusedClipAdam
+    from wesep_amd.parallel import init_distributed
+    from wesep_amd.utils.executor import Executor, ReplicaDivergence
+    from wesep_amd.utils.schedulers import ExponentialDecrease
+    init_distributed(backend="gloo")
+    mp_ = MonkeyPatch()
+    torch.manual_seed(3)
+    net = _TseToy()
+    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    emu_optim.install(mp_)
+    opt = FusedClipAdam(net.parameters(), lr=1e-3)
+    sched = ExponentialDecrease(opt, num_epochs=1, epoch_iter=8, initial_lr=1e-3, final_lr=1e-4, warm_up_epoch=0)
+    g = torch.Generator().manual_seed(10 + rank)
+
+    def batches():
+        for i in range(8):
+            if i == 3 and rank == 1:                             # a silent corruption on ONE rank, mid-epoch
+                with torch.no_grad():
+                    net.a.bias[0] += 1e-3
+            yield {"wav_mix": torch.randn(4, 32, generator=g), "wav_targets": torch.randn(4, 32, generator=g),
+                   "spk_embeds": torch.randn(4, 8, generator=g), "spk_label": torch.zeros(0)}
+
+    seen = None
+    ex = Executor()
+    try:
+        ex.train(batches(), [ddp], 8, [opt], [torch.nn.MSELoss(reduction="none")], [sched], scaler=None, epoch=1, enable_amp=False,
+                 logger=None, clip_grad=5.0, device=torch.device("cpu"), se_loss_weight=([[0]], [[1.0]]),
+                 replica_check_interval=1)
+    except ReplicaDivergence as e:
+        seen = str(e)
+    torch.save({"seen": seen, "steps": ex.step}, os.path.join(out, f"d{rank}.pt"))
+    mp_.undo()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_in_loop_replica_check_reports_a_divergence_within_the_interval_world2_gloo(tmp_path):
+    """the data-parallel replica check also runs INSIDE the epoch (Executor.train replica_check_interval) when
+    every rank runs the same number of steps: a parameter disturbed on one rank during step 3 stops BOTH ranks at step 3,
+    not at the end of the epoch."""
+    world, port = 2, _free_port()
+    mp.spawn(_replica_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"d{i}.pt") for i in range(2))
+    # (the prefetcher pulls batch i + 1 while step i runs: the disturbance lands during step 3)
+    assert r0["seen"] and r1["seen"] and "step 3" in r0["seen"] and "step 3" in r1["seen"], (r0, r1)
+    assert r0["steps"] == r1["steps"] == 3

@@ -172,7 +172,10 @@ def train(configs, n_synthetic=0):
             log_batch_interval=configs.get("log_batch_interval", 100), device=device, se_loss_weight=loss_args,
             multi_task=multi_task, SSA_enroll_prob=dargs.get("SSA_enroll_prob", 0),
             fbank_args=dargs.get("fbank_args"), sample_rate=dargs.get("resample_rate", 16000),
-            speaker_feat=dargs.get("speaker_feat", True))
+            speaker_feat=dargs.get("speaker_feat", True),
+            # every rank's loader is bounded by the same epoch_iter (build_dataloaders), so the in-loop replica check is a
+            # well-formed collective; `replica_check_interval: 0` in the config turns it off
+            replica_check_interval=int(configs.get("replica_check_interval", 10 * configs.get("log_batch_interval", 100))))
         val_loss, _ = executor.cv(val_loader, [ddp_model], val_iter, criterion, epoch=epoch, logger=logger,
                                   enable_amp=configs.get("enable_amp", False),
                                   log_batch_interval=configs.get("log_batch_interval", 100), device=device)

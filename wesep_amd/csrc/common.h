@@ -101,6 +101,12 @@ __device__ __forceinline__ float ws_ld_agent(const float* p) {
 // partials in index order, so the result does not depend on WHICH workgroup came last (deterministic), and the separate
 // reduction launch -- which on a busy GPU can sit out a whole weight-gradient GEMM of another stream before it gets a CU --
 // disappears.  Contains two barriers.
+// (the ordering below -- RELAXED agent-scope atomics + a hand-written `s_waitcnt vmcnt(0)` -- is a statement
+//  about gfx9 (gfx942 / gfx950): stores are tracked by vmcnt and sc1 accesses by-pass the XCD's L2.  It is NOT what the HIP
+//  memory model promises in general: targets with a separate store counter (vscnt, gfx10+) would read stale partials.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "ws_last_block / ws_tree_sum256 rely on gfx942 / gfx950 memory ordering (vmcnt tracks stores; sc1 = write-through)"
+#endif
 __device__ __forceinline__ bool ws_last_block(unsigned* counter, unsigned nblocks) {
   __shared__ unsigned last_s;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -84,8 +84,15 @@ class Executor:
     def train(self, dataloader, models, epoch_iter, optimizers, criterion, schedulers, scaler, epoch,
               enable_amp, logger, clip_grad=5.0, log_batch_interval=100, device=torch.device("cuda"),
               se_loss_weight=1.0, multi_task=False, SSA_enroll_prob=0, fbank_args=None,
-              sample_rate=16000, speaker_feat=True):
-        """Train one epoch."""
+              sample_rate=16000, speaker_feat=True, replica_check_interval=0):
+        """Train one epoch.
+
+        replica_check_interval (data-parallel runs; not in the reference's signature): > 0 checks every that many steps,
+        INSIDE the loop, that all replicas still hold bit-identical, finite parameters -- a divergence is then reported
+        within that many steps instead of at the end of an epoch (hours on the TF-GridNet recipe).  Only valid when every
+        rank runs the same number of steps per epoch (the check is a collective of its own: under DistributedDataParallel's
+        join() a rank that has run out of batches would not take part); bin/train.py turns it on for loaders it bounds by
+        `epoch_iter` on every rank.  The end-of-epoch check below always runs, i.e. before any checkpoint is written."""
         if enable_amp and not getattr(self, "_amp_noted", False):
             # executor.py:88,130-134 wraps the step in torch.cuda.amp.autocast + GradScaler.  autocast rewrites the dtype of
             # ATen ops; this path has none to rewrite (every product is a split-bf16 MFMA with fp32 accumulation and fp32
@@ -137,6 +144,8 @@ class Executor:
                 else:
                     optimizer.step()
                 self.step += 1
+                if ddp and replica_check_interval > 0 and (i + 1) % replica_check_interval == 0 and (i + 1) < epoch_iter:
+                    self._replica_check(model, device, f"epoch {epoch}, step {i + 1}")
                 if (i + 1) % log_batch_interval == 0:
                     if logger is not None:
                         logger.info(_row("TRAIN", epoch, i + 1, float(loss_sum.item() / n_steps),
