@@ -125,7 +125,7 @@ def gemm_p2b(*, A, lda, sm, Wpack, N, C_out, K=128, bias=None, A_bl=None, stats=
     if A_bl16 is not None:                 # ABI v16: the operand once more as fp16 in BLH(K)
         blh_put(A_bl16, rows, nt, L, K, torch.float16)
     if N:
-        if _probe() & 8192 and stats is not None:      # (numerics probe: the time view's x-projection on the fp16 copy of xn)
+        if _probe() & 8192 and amax is None:           # (numerics probe: a FORWARD x-projection on the fp16 copy of its input)
             rows = rows.half().float()
         out = rows @ _PACKS[Wpack.data_ptr()].t()
         if bias is not None:

@@ -73,7 +73,7 @@ def main():
         ms = (time.perf_counter() - t0) / a.steps * 1e3
         print(json.dumps({"metric": f"utterances/sec (4 s, 16 kHz) fwd+bwd, pBSRNN {what}", "variant": what,
                           "value": R / ms * 1e3, "unit": "utterances/s", "ms_per_step": ms, "rows": R, "steps": a.steps,
-                          "dtype": "bf16x3", "data": "synthetic", "mean_loss_dB": float(loss),
+                          "dtype": "bf16x3+fp16x2+fp16x1 split products, fp32 accumulate (bench.py)", "data": "synthetic", "mean_loss_dB": float(loss),
                           "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
         del model, opt, ex
         torch.cuda.empty_cache()

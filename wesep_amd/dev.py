@@ -61,11 +61,17 @@ def _p(t: Optional[torch.Tensor], off: int = 0):
 # move / compute at least (operands once, outputs once; an implicit patch matrix counts as its image), next to the
 # HIP-event time of the same kind (prof_collect) -> roofline fractions without a profiler.
 ALG = None
+ALG_LSTM_UNITS = None    # hidden units the recurrence launches are PRICED at (None: the kernels' 256)
 
 
-def alg_reset(on=True):
-    global ALG
+def alg_reset(on=True, lstm_units=None):
+    """lstm_units: the model's real LSTM hidden size when it is smaller than the 256 units the kernels are built for
+    (TF-GridNet: 192, zero-padded) -- algorithmic bytes / FLOPs of the recurrence launches then count the real units; the
+    padding is the kernel's cost, not the algorithm's (priced at 256, counter traffic came out BELOW the
+    'algorithmic' bytes)."""
+    global ALG, ALG_LSTM_UNITS
     ALG = {} if on else None
+    ALG_LSTM_UNITS = lstm_units if on else None
 
 
 def _alg(kind, nbytes, flops):
@@ -394,7 +400,8 @@ def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, gf
     a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat, gfmt=gfmt, dgates=dgates, run_if=run_if, amax=amax)
     # per (position, direction, unit): read 4 gates + c + dh, write 4 d(gates); 2 * 4H * H MACs per position
     if run_if is None:
-        _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
+        _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * (ALG_LSTM_UNITS or L.LSTM_H),
+             2 * sm.nseq * sm.L * 2 * 4 * (ALG_LSTM_UNITS or L.LSTM_H) ** 2)
     L.check(L.lib().ws_lstm_bwd(C.byref(a), L.stream_ptr()), "ws_lstm_bwd")
 
 
@@ -600,7 +607,8 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg
     a.gfmt, a.dgates = gfmt, _p(dgates)
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
     a.rfmt = rfmt           # 1: fp16 recurrence (wpack from lstm_pack_pair(..., f16=True); WS_GATES_H2F only)
-    _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * L.LSTM_H, 2 * sm.nseq * sm.L * 2 * 4 * L.LSTM_H * L.LSTM_H)
+    _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * (ALG_LSTM_UNITS or L.LSTM_H),
+             2 * sm.nseq * sm.L * 2 * 4 * (ALG_LSTM_UNITS or L.LSTM_H) ** 2)
     L.check(L.lib().ws_lstm_bwd_pair(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_pair")
     return flags[npair * 8:npair * 8 + 1]
 
