@@ -314,21 +314,20 @@ typedef struct ws_lstm_cluster_args {
 int ws_lstm_fwd_cluster(const ws_lstm_cluster_args* a, void* stream);
 /* Second-generation cluster forward (lstm_cluster2.hip; ABI v17): the same clusters, outputs and residency rules, for
  * WS_GATES_H2-style storage only (`gates` = unorm16 BLH(2 * 4H) out, cbuf fp32 BL, hcat BLS), with
- *   - the x-projection computed in the kernel from the fp16 copy of the normalised input (xn16: BLH(128), what ws_gemm_p2b
- *     writes as A_bl16) against wcat [2][4H][128] (ws_lstm_cat_ih) and bcat [2][4H]: no pre-activation buffer, no
- *     x-projection GEMM (bsrnn.py:39-40 fused into the recurrence);
- *   - the recurrent product on v_mfma_f32_32x32x16_f16: h_t as one fp16 operand, W_hh / W_ih as fp16 hi / lo of 256 w;
+ *   - the x-projection computed in the kernel from the normalised input as split pairs (xn: BL(128) of BLS elements, what
+ *     ws_gemm_p2b writes as A_bl) against wcat [2][4H][128] (ws_lstm_cat_ih) and bcat [2][4H], the full three-term split-bf16
+ *     product: no pre-activation buffer, no x-projection GEMM (bsrnn.py:39-40 fused into the recurrence);
+ *   - the recurrent product on v_mfma_f32_32x32x16_f16: h_t as one fp16 operand, W_hh as fp16 hi / lo of 256 w;
  *   - a data-tagged hand-off (bit 14 of every fp16 h carries the step's tag; no flags).
  * xchg: (nseq / 32) * 64 KB scratch (filled by the call on `stream`); tword: the launch's time-out word (zeroed by the
  * call; 0 after a clean launch; callers enqueue ws_gemm_p2b + ws_lstm_fwd with run_if = tword behind the launch);
  * status: optional, sticky.  dbg (probes / tests): 1 skip the wait, 4 skip the publish, 8 force a time-out in workgroup 0
- * at step 2, 32 the HBM traffic on the M-waves at the top of the step (round-4 placement; default: on the X-waves after their
- * recurrent MFMAs), 2048 cycle stamps into dbg_buf.                                                                                                       */
+ * at step 2, 2048 cycle stamps into dbg_buf.                                                                                                       */
 typedef struct ws_lstm_cluster2_args {
   float* gates;
   float* cbuf;
   float* hcat;
-  const float* xn16;
+  const float* xn;
   const float* wcat;
   const float* bcat;
   const float* whh_f;
@@ -801,6 +800,12 @@ int ws_bilinear_bwd(const float* dy, int B, int h, int w, int H, int W, int C, f
 int ws_scale_bf_fwd(const float* x, const float* s, int B, int T, int F, int C, int mode, float* y, void* stream);
 int ws_scale_bf_bwd(const float* x, const float* dy, const float* s, int B, int T, int F, int C, int mode, float* dx,
                     float* ds, void* stream);
+/* ABI v17: SpeakerFuseLayer 'concat' (speaker.py:95-101) on [B][T][F][C]: the Linear over the frequency axis of cat[x, e] --
+ * y[b][t][f'][c] = sum_f W[f' * ldw + f] x[b][t][f][c] + rb[b][f'];  W: the first F columns of fc.linear.weight [F][F + E]
+ * (ldw = F + E), rb [B][F] = We e + bias (ws_gemm_nt).  Exact fp32; F * C <= 16384.  Forward only: the native runtime's
+ * form of the fusion (runtime/engine.cc); training composes it from GEMMs on a transposed view.                    */
+int ws_freq_linear_fwd(const float* x, const float* W, long long ldw, const float* rb, int B, int T, int F, int C, float* y,
+                       void* stream);
 
 /* ---- TF-GridNet: everything but this row softmax is composed from the entry points
  * above (gridnet_block.py:212-213): y = softmax(scale * x) per row of n; dx = scale * y * (dy - sum(dy * y))   */

@@ -2079,7 +2079,7 @@ int prepare_dpccn(ws_engine* e) {
     set_err("engine: the DPCCN plan is built for win 512, stride 128, feature_dim 257, multi_fuse False");
     return WS_ERR_INVALID;
   }
-  if (e->dp_fuse < 1 || e->dp_fuse > 3 || e->dp_tcn_blocks < 1 || e->dp_tcn_blocks > 14 || e->dp_tcn_layers < 1 || e->E % 4 ||
+  if (e->dp_fuse < 0 || e->dp_fuse > 3 || e->dp_tcn_blocks < 1 || e->dp_tcn_blocks > 14 || e->dp_tcn_layers < 1 || e->E % 4 ||
       e->feat_dim % 8) {
     set_err("engine: unsupported DPCCN configuration (fuse %d: additive 1 / multiply 2 / FiLM 3; tcn %d x %d; spk_emb_dim %d)",
             e->dp_fuse, e->dp_tcn_layers, e->dp_tcn_blocks, e->E);
@@ -2104,8 +2104,9 @@ int prepare_dpccn(ws_engine* e) {
     std::vector<float> b1(e->host("spk_fuse.fc.gamma_fcs.0.bias"), e->host("spk_fuse.fc.gamma_fcs.0.bias") + kDpBins);
     for (float& v : b1) v += 1.0f;                     // x (1 + gamma(e)) + beta(e)   (norm.py:116-134)
     if ((rc = dp_keep(e, "film_gamma_bias1", b1)) != WS_OK) return rc;
-  } else if (!require(e, "spk_fuse.fc.linear.weight", {kDpBins, e->E}) || !require(e, "spk_fuse.fc.linear.bias", {kDpBins})) {
-    return WS_ERR_INVALID;
+  } else if (!require(e, "spk_fuse.fc.linear.weight", {kDpBins, e->dp_fuse == 0 ? kDpBins + e->E : e->E}) ||
+             !require(e, "spk_fuse.fc.linear.bias", {kDpBins})) {
+    return WS_ERR_INVALID;     // (concat: Linear over the frequency axis of cat[x, e], speaker.py:95-101)
   }
   for (int l = 0; l < e->dp_tcn_layers; ++l)
     for (int b = 0; b < e->dp_tcn_blocks; ++b) {
@@ -2355,6 +2356,10 @@ int dpccn_device(ws_engine* e, const float* wav, int R, int T, const float* emb_
         return rc;
       WS_RUN(e, ws_scale_bf_fwd(o, sf, R, Tf, F0, d.co5, 0, tmp, s));
       WS_RUN(e, ws_scale_bf_fwd(tmp, bt, R, Tf, F0, d.co5, 1, skip[0], s));
+    } else if (e->dp_fuse == 0) {   // concat: out[b, c, :, t] = Wx x[b, c, :, t] + (We e + bias)
+      if ((rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.linear.weight") + F0, F0 + e->E, F0, e->dev("spk_fuse.fc.linear.bias"), 0, sf)) != WS_OK)
+        return rc;
+      WS_RUN(e, ws_freq_linear_fwd(o, e->dev("spk_fuse.fc.linear.weight"), F0 + e->E, sf, R, Tf, F0, d.co5, skip[0], s));
     } else {
       if ((rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.linear.weight"), e->E, F0, e->dev("spk_fuse.fc.linear.bias"), 0, sf)) != WS_OK)
         return rc;
@@ -2604,11 +2609,11 @@ int prepare_gridnet(ws_engine* e) {
   const int C = n.C, Q = n.Q, nh = n.nh, E = n.E, cp = C / (nh > 0 ? nh : 1);
   if (meta_or(e, "emb_ks", 1) != 1 || meta_or(e, "emb_hs", 1) != 1 || meta_or(e, "n_srcs", 1) != 1 || meta_or(e, "n_imics", 1) != 1 ||
       C != kN || n.hid < 4 || n.hid > kH || n.hid % 4 || nh < 1 || nh > 8 || C % nh || E % 4 || cp % 4 || n.n_fft % 8 ||
-      n.n_fft < 16 || n.n_fft > 1024 || n.hop * 2 != n.n_fft || (long long)Q * C > 9216 || n.fuse < 1 || n.fuse > 3 ||
+      n.n_fft < 16 || n.n_fft > 1024 || n.hop * 2 != n.n_fft || (long long)Q * C > 9216 || n.fuse < 0 || n.fuse > 3 ||
       n.layers < 1 || e->E % 4 || e->feat_dim % 8) {
     set_err("engine: the TF-GridNet plan is built for the recipe's geometry (emb_dim 128, emb_ks = emb_hs = 1, one microphone "
             "and source, hidden <= 256 and %% 4, heads <= 8 with widths %% 4, stride = n_fft / 2, (n_fft / 2 + 1) * 128 <= 9216, "
-            "multiply / additive / FiLM fusion)");
+            "concat / multiply / additive / FiLM fusion)");
     return WS_ERR_INVALID;
   }
   e->dw = e->persist.alloc(e->hw.size());
@@ -2625,8 +2630,8 @@ int prepare_gridnet(ws_engine* e) {
     for (float& v : b1) v += 1.0f;
     n.film_bias1 = upload(e, e->persist, b1.data(), b1.size());
     WS_PTR(n.film_bias1);
-  } else if (!require(e, "spk_fuse.fc.linear.weight", {Q, e->E}) || !require(e, "spk_fuse.fc.linear.bias", {Q})) {
-    return WS_ERR_INVALID;
+  } else if (!require(e, "spk_fuse.fc.linear.weight", {Q, n.fuse == 0 ? Q + e->E : e->E}) || !require(e, "spk_fuse.fc.linear.bias", {Q})) {
+    return WS_ERR_INVALID;     // (concat: Linear over the frequency axis of cat[x, e], speaker.py:95-101)
   }
   {
     std::vector<float> w_in = dp_conv_rows(e->host("conv.0.weight"), C, 2, 4);
@@ -2870,6 +2875,9 @@ int gridnet_device(ws_engine* e, const float* wav, int R, int T, const float* em
     if ((rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.gamma_fcs.0.weight"), e->E, Q, n.film_bias1, 0, sf)) != WS_OK ||
         (rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.beta_fcs.0.weight"), e->E, Q, e->dev("spk_fuse.fc.beta_fcs.0.bias"), 0, bt)) != WS_OK)
       return rc;
+  } else if (n.fuse == 0) {      // concat: the embedding's share of the Linear, We e + bias; the x share runs per block below
+    if ((rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.linear.weight") + Q, Q + e->E, Q, e->dev("spk_fuse.fc.linear.bias"), 0, sf)) != WS_OK)
+      return rc;
   } else if ((rc = linear(e, emb, R, e->E, e->dev("spk_fuse.fc.linear.weight"), e->E, Q, e->dev("spk_fuse.fc.linear.bias"), 0, sf)) != WS_OK) {
     return rc;
   }
@@ -2889,6 +2897,8 @@ int gridnet_device(ws_engine* e, const float* wav, int R, int T, const float* em
     if (n.fuse == 3) {
       WS_RUN(e, ws_scale_bf_fwd(h, sf, R, Tf, Q, C, 0, hC, s));
       WS_RUN(e, ws_scale_bf_fwd(hC, bt, R, Tf, Q, C, 1, x, s));
+    } else if (n.fuse == 0) {
+      WS_RUN(e, ws_freq_linear_fwd(h, e->dev("spk_fuse.fc.linear.weight"), Q + e->E, sf, R, Tf, Q, C, x, s));
     } else {
       WS_RUN(e, ws_scale_bf_fwd(h, sf, R, Tf, Q, C, n.fuse == 2 ? 0 : 1, x, s));
     }

@@ -276,15 +276,15 @@ def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm, status=None, dbg=0, gf
     return torch.zeros(1, dtype=torch.int32)
 
 
-def lstm_fwd_cluster2(gates, cbuf, hcat, xn16, wcat, bcat, whh_f, whh_r, sm, status=None, dbg=0, dbg_buf=None):
-    """ws_lstm_fwd_cluster2: x-projection from the fp16 normalised input inside the recurrence, fp16 h in the recurrent
+def lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whh_f, whh_r, sm, status=None, dbg=0, dbg_buf=None):
+    """ws_lstm_fwd_cluster2: x-projection from the normalised input (BL(128)) inside the recurrence, fp16 h in the recurrent
     product, unorm16 gates out; dbg & 8 emulates a time-out like lstm_fwd_cluster."""
     nt, L = _ntile(sm), sm.L
     if dbg & 8:
         for t in (cbuf, hcat):
             t.fill_(float("nan"))
         return torch.ones(1, dtype=torch.int32)
-    x = blh_get(xn16, nt, L, 128, torch.float16).float()
+    x = bl_get(xn, nt, L, 128)
     w, b = wcat.reshape(2, G4, 128), bcat.reshape(2, G4)
     pre = torch.stack([x @ w[0].t() + b[0], x @ w[1].t() + b[1]], 2)
     _fwd_into(gates, cbuf, hcat, pre, whh_f, whh_r, sm, 1, hq16=True)

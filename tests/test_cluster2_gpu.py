@@ -1,5 +1,5 @@
 """GPU: the second-generation cluster forward (csrc/lstm_cluster2.hip, ws_lstm_fwd_cluster2, ABI v17) -- fp16 h in the
-recurrent product, the x-projection computed in the kernel from the fp16 normalised input, a data-tagged hand-off -- against
+recurrent product, the x-projection computed in the kernel from the split-pair normalised input, a data-tagged hand-off -- against
 (a) torch's own LSTM (fp64) on the same input, and (b) the round-1..4 cluster kernel fed fp32 pre-activations (which
 tests/test_kernels_gpu.py holds to torch's LSTM); plus determinism, the forced time-out, and the ResRNN composition with
 the kernel on and off."""
@@ -38,7 +38,7 @@ def _case(dims, seed, d):
     w = dict(wih_f=rnd(4 * H, N, scale=0.08), wih_r=rnd(4 * H, N, scale=0.08), whh_f=rnd(4 * H, H, scale=0.06),
              whh_r=rnd(4 * H, H, scale=0.06), bih_f=rnd(4 * H, scale=0.1), bhh_f=rnd(4 * H, scale=0.1),
              bih_r=rnd(4 * H, scale=0.1), bhh_r=rnd(4 * H, scale=0.1))
-    x = rnd(P, N).half().float()                                   # the normalised input, on the fp16 grid
+    x = rnd(P, N)                                                    # the normalised input
     return seq, nb, P, {k: v.to(d) for k, v in w.items()}, x.to(d)
 
 
@@ -46,11 +46,11 @@ def _run_new(seq, nb, w, x, d, dbg=0, status=None):
     from wesep_amd import dev
     wcat, bcat = torch.empty(2 * 4 * H * N, device=d), torch.empty(2 * 4 * H, device=d)
     dev.lstm_cat_ih(w["wih_f"], w["wih_r"], w["bih_f"], w["bhh_f"], w["bih_r"], w["bhh_r"], N, wcat, bcat)
-    xn16 = dev.blh_f16_pack(dev.to_blocked(x, seq))
+    xn = dev.to_blocked(x, seq, split=True)                          # BLS pairs in BL(128): what ws_gemm_p2b writes as A_bl
     gh = torch.zeros(dev.blh_floats(nb, 8 * H), device=d)
     c = torch.full((nb, 2 * H // 4, 32, 4), float("nan"), device=d)
     h = torch.full_like(c, float("nan"))
-    tw = dev.lstm_fwd_cluster2(gh, c, h, xn16, wcat, bcat, w["whh_f"], w["whh_r"], seq, status=status, dbg=dbg)
+    tw = dev.lstm_fwd_cluster2(gh, c, h, xn, wcat, bcat, w["whh_f"], w["whh_r"], seq, status=status, dbg=dbg)
     return gh, c, h, tw
 
 

@@ -275,7 +275,7 @@ def test_dry_run_launch_plan_convtasnet(tmp_path, joint):
 
 
 @needs_no_gpu
-@pytest.mark.parametrize("variant", ["fixed-multiply", "fixed-film-causal", "joint-resnet18-additive"])
+@pytest.mark.parametrize("variant", ["fixed-multiply", "fixed-film-causal", "joint-resnet18-additive", "fixed-concat"])
 def test_dry_run_launch_plan_dpccn(tmp_path, variant):
     """DPCCN in the native runtime (arch 2): container, geometry read back, and the whole launch plan -- DFT-basis STFT,
     halo-tile dense blocks, strided / transposed implicit-GEMM convolutions, fused ELU + InstanceNorm, the TCN stack, the
@@ -284,6 +284,8 @@ def test_dry_run_launch_plan_dpccn(tmp_path, variant):
     kw = dict(tcn_blocks=3, tcn_layers=2, spk_emb_dim=256, joint_training=False)
     if variant == "fixed-film-causal":
         kw.update(spk_fuse_type="FiLM", causal=True, use_spk_transform=True)
+    elif variant == "fixed-concat":        # round 5: the Linear over the frequency axis of cat[x, e] (ws_freq_linear_fwd)
+        kw.update(spk_fuse_type="concat")
     elif variant == "joint-resnet18-additive":
         kw.update(spk_fuse_type="additive", joint_training=True, spk_model="ResNet18", spk_feat=True,
                   spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))
@@ -311,15 +313,8 @@ def test_dry_run_launch_plan_dpccn(tmp_path, variant):
     eng.close()
 
 
-def test_dpccn_concat_fusion_is_refused_by_the_exporter(tmp_path):
-    from wesep_amd.models import get_model
-    m = get_model("DPCCN")(tcn_blocks=1, tcn_layers=1, joint_training=False, spk_fuse_type="concat")
-    with pytest.raises(NotImplementedError, match="concat"):
-        export_engine(m, str(tmp_path / "c.wsw"))
-
-
 @needs_no_gpu
-@pytest.mark.parametrize("variant", ["fixed-multiply", "fixed-film-hidden64", "joint-resnet18-additive"])
+@pytest.mark.parametrize("variant", ["fixed-multiply", "fixed-film-hidden64", "joint-resnet18-additive", "fixed-concat"])
 def test_dry_run_launch_plan_tfgridnet(tmp_path, variant):
     """TF-GridNet in the native runtime (arch 3, the recipe's geometry): container, geometry read back, and the whole
     launch plan -- DFT-basis STFT, GroupNorm, per block the row LayerNorms, both BLSTM paths on the blocked-layout kernels
@@ -330,6 +325,8 @@ def test_dry_run_launch_plan_tfgridnet(tmp_path, variant):
     kw = dict(n_layers=2, emb_dim=128, emb_ks=1, emb_hs=1, lstm_hidden_units=192, spk_emb_dim=256, joint_training=False)
     if variant == "fixed-film-hidden64":
         kw.update(spk_fuse_type="FiLM", lstm_hidden_units=64, use_spk_transform=True)
+    elif variant == "fixed-concat":
+        kw.update(spk_fuse_type="concat")
     elif variant == "joint-resnet18-additive":
         kw.update(spk_fuse_type="additive", joint_training=True, spk_model="ResNet18", spk_feat=True,
                   spk_args=dict(feat_dim=80, embed_dim=256, pooling_func="TSTP", two_emb_layer=False))

@@ -113,7 +113,7 @@ def test_tfgridnet_engine_matches_python_model(tmp_path, variant):
 # ---- against the CPU ORACLE: the comparisons above hold the engine to the HIP Python tree; these
 #      hold it to the oracle chain directly, as tests/test_engine_gpu.py does for pBSRNN (round 3 had them only as the one-off
 #      checks of tools/make_engine_testdata_{dpccn,tfgridnet}.py --check) ------------------------------------------------------
-@pytest.mark.parametrize("fuse", ["multiply", "additive"])
+@pytest.mark.parametrize("fuse", ["multiply", "additive", "concat"])
 def test_dpccn_engine_matches_oracle(tmp_path, fuse):
     from oracle import dpccn_oracle as DP
     from tests.test_engine_gpu import _cuda, rel
@@ -137,7 +137,7 @@ def test_dpccn_engine_matches_oracle(tmp_path, fuse):
     eng.close()
 
 
-@pytest.mark.parametrize("fuse", ["multiply", "additive"])
+@pytest.mark.parametrize("fuse", ["multiply", "additive", "concat"])
 def test_tfgridnet_engine_matches_oracle(tmp_path, fuse):
     from oracle import tfgridnet_oracle as TG
     from tests.test_engine_gpu import _cuda, rel

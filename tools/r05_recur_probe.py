@@ -56,14 +56,13 @@ def main():
     t = timeit(lambda: dev.lstm_fwd_cluster(gh, cbuf, hcat, whf, whr, seq, status=st, gfmt=L.GATES_H2, gates_in=pre))
     print(f"cluster fwd, unorm16 gates (fp32 pre-act in) {t:7.3f} ms  {t * 1e3 / Tf:6.2f} us/step", flush=True)
     # second generation: fp16 h, x-projection fused in (from the fp16 normalised input), data-tagged hand-off
-    x = torch.randn(nb, N // 4, 32, 4, device=d)
-    xn16 = dev.blh_f16_pack(x)
+    xn16 = dev.bls_pack(torch.randn(nb, N // 4, 32, 4, device=d))       # (BLS pairs in BL(128))
     wcat, bcat = torch.randn(2 * 4 * H * N, device=d) * 0.08, torch.randn(2 * 4 * H, device=d) * 0.1
-    for dbg, nm in ((0, ""), (1, " (no wait: dbg 1)"), (32, " (I/O on M-waves)")):
+    for dbg, nm in ((0, ""), (1, " (no wait: dbg 1)")):
         t = timeit(lambda: dev.lstm_fwd_cluster2(gh, cbuf, hcat, xn16, wcat, bcat, whf, whr, seq, status=st, dbg=dbg))
         print(f"cluster2 fwd (fp16 h, fused x-proj, tagged){nm:18s} {t:7.3f} ms  {t * 1e3 / Tf:6.2f} us/step", flush=True)
     print("status word after the forward kernels", int(st.item()), flush=True)
-    for iobit, ionm in ((0, "I/O on X-waves after their MFMAs (default)"), (32, "I/O on M-waves at the top")):
+    for iobit, ionm in ((0, "output stores on the X-waves after their MFMAs"),):
       if not a.no_stamps:
         for rep in range(2):
             dbuf = torch.zeros(Tf * 2 * 8 * 2, device=d)

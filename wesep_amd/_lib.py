@@ -121,7 +121,7 @@ class LstmClusterArgs(C.Structure):
 
 
 class LstmCluster2Args(C.Structure):
-    _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "xn16", "wcat", "bcat", "whh_f", "whh_r", "xchg", "tword", "status")] + \
+    _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "xn", "wcat", "bcat", "whh_f", "whh_r", "xchg", "tword", "status")] + \
                [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i), ("dbg_buf", _p)]
 
 
@@ -239,6 +239,7 @@ _SIGS = {
     "ws_bilinear_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "ws_bilinear_bwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ws_scale_bf_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "ws_freq_linear_fwd": (_i, [_p, _p, _ll, _p, _i, _i, _i, _i, _p, _p]),
     "ws_scale_bf_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ws_softmax_rows_fwd": (_i, [_p, _ll, _i, C.c_float, _p, _p]),
     "ws_softmax_rows_bwd": (_i, [_p, _p, _ll, _i, C.c_float, _p, _p]),

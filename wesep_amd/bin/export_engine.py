@@ -127,11 +127,9 @@ def tasnet_meta(model):
 def dpccn_meta(model):
     """DPCCN (arch 2): the runtime's launch plan covers the reference constructor's defaults (win 512, stride 128, 257
     bins, 3 x 3 kernels, strides (1, 1) / (1, 2)) with any TCN depth, causal or not, multiply / additive / FiLM fusion,
-    fixed embeddings or the speaker encoders the pBSRNN plan has.  `concat` fusion is refused by name."""
+    fixed embeddings or the speaker encoders the pBSRNN plan has; all four fusions (round 5: `concat`, a Linear over the
+    frequency axis, as ws_freq_linear_fwd)."""
     fuse = model.spk_fuse.fuse_type
-    if fuse == "concat":
-        raise NotImplementedError("export_engine: DPCCN with spk_fuse_type 'concat' (a Linear over the frequency axis) has no "
-                                  "launch plan in the native runtime; multiply / additive / FiLM do")
     blocks = model.tcn_layers[0]
     meta = {
         "arch": 2, "sample_rate": 16000, "win": model.win_len, "stride": model.hop_size, "feature_dim": model.win_len // 2 + 1,
@@ -145,16 +143,14 @@ def dpccn_meta(model):
 
 def gridnet_meta(model):
     """TF-GridNet (arch 3): the runtime's launch plan covers the shipped recipe's geometry -- one microphone, one source,
-    emb_dim 128, emb_ks = emb_hs = 1, lstm_hidden_units <= 256, multiply / additive / FiLM fusion -- with fixed embeddings
-    or the speaker encoders the pBSRNN plan has.  Everything else is refused by name."""
+    emb_dim 128, emb_ks = emb_hs = 1, lstm_hidden_units <= 256, any of the four fusions -- with fixed embeddings or the
+    speaker encoders the pBSRNN plan has.  Everything else is refused by name."""
     blk = model.blocks[0]
     problems = []
     if model.n_imics != 1 or model.n_srcs != 1:
         problems.append(f"n_imics {model.n_imics} / n_srcs {model.n_srcs} (1 / 1 only)")
     if blk.emb_dim != 128 or blk.emb_ks != 1 or blk.emb_hs != 1:
         problems.append(f"emb_dim {blk.emb_dim}, emb_ks {blk.emb_ks}, emb_hs {blk.emb_hs} (128 / 1 / 1: the blocked-layout recurrences)")
-    if model.spk_fuse.fuse_type == "concat":
-        problems.append("spk_fuse_type 'concat'")
     if model.stride * 2 != model.n_fft:
         problems.append(f"stride {model.stride} != n_fft / 2")
     if problems:

@@ -930,6 +930,40 @@ extern "C" int ws_scale_bf_bwd(const float* x, const float* dy, const float* s, 
   return ws_check_launch("ws_scale_bf_bwd");
 }
 
+// SpeakerFuseLayer 'concat' on [B][T][F][C] (speaker.py:95-101 on the [B, C, F, T] view): a Linear over the FREQUENCY axis of
+// cat[x, e]:  y[b][t][f'][c] = sum_f W[f'][f] x[b][t][f][c] + rb[b][f'],  rb = We e + bias (a plain GEMM of the caller).
+// One workgroup per (b, t) keeps the [F][C] tile in LDS; a thread owns (f', four channels).  Exact fp32 FMAs: this is the
+// native runtime's (inference) form of the fusion -- the training path composes it from GEMMs on a transposed view
+// (models/dpccn.py fuse_bins).
+__global__ __launch_bounds__(256) void freq_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                              long long ldw, const float* __restrict__ rb, int T, int Fq,
+                                                              int C, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float fl_xt[];
+  const long long tile = blockIdx.x;
+  const int b = (int)(tile / T);
+  const float* xs = x + tile * Fq * C;
+  for (int i = threadIdx.x * 4; i < Fq * C; i += 1024) *reinterpret_cast<f32x4*>(fl_xt + i) = *reinterpret_cast<const f32x4*>(xs + i);
+  __syncthreads();
+  const int c4n = C >> 2;
+  for (int o = threadIdx.x; o < Fq * c4n; o += 256) {
+    const int fo = o / c4n, c = (o - fo * c4n) * 4;
+    const float* wr = W + fo * ldw;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < Fq; ++f) acc += wr[f] * *reinterpret_cast<const f32x4*>(fl_xt + f * C + c);
+    *reinterpret_cast<f32x4*>(y + (tile * Fq + fo) * C + c) = acc + rb[(long long)b * Fq + fo];
+  }
+}
+
+extern "C" int ws_freq_linear_fwd(const float* x, const float* W, long long ldw, const float* rb, int B, int T, int Fq, int C,
+                                  float* y, void* stream) {
+  WS_REQUIRE(x && W && rb && y && B > 0 && T > 0 && Fq > 0 && C > 0 && C % 4 == 0 && ldw >= Fq,
+             "ws_freq_linear_fwd: bad args");
+  WS_REQUIRE((long long)Fq * C <= 16384, "ws_freq_linear_fwd: F * C = %lld floats exceed the 64 KB tile", (long long)Fq * C);
+  hipLaunchKernelGGL(freq_linear_fwd_kernel, dim3(B * T), dim3(256), (size_t)Fq * C * 4, (hipStream_t)stream, x, W, ldw, rb, T,
+                     Fq, C, y);
+  return ws_check_launch("ws_freq_linear_fwd");
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row softmax for the full-band self-attention of TF-GridNet (gridnet_block.py:212-213):
 //   y[r][:] = softmax(scale * x[r][:]);   dx = scale * y * (dy - sum(dy * y))      one workgroup per row

@@ -523,24 +523,25 @@ def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None, d
 
 
 def lstm_cluster2_on() -> bool:
-    """Second-generation cluster forward (lstm_cluster2.hip, ABI v17: fp16 h, x-projection fused in from the fp16 copy of the
+    """Second-generation cluster forward (lstm_cluster2.hip, ABI v17: fp16 h, x-projection fused in from the split-pair
     normalised input, data-tagged hand-off) for the time view of the 2-byte gate formats; WESEP_LSTM_CLUSTER2=0 keeps the
     round-1..4 kernel behind ws_gemm_p2b's fp32 pre-activations."""
     return os.environ.get("WESEP_LSTM_CLUSTER2", "1") != "0"
 
 
-def lstm_fwd_cluster2(gates, cbuf, hcat, xn16, wcat, bcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0, dbg_buf=None):
+def lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0, dbg_buf=None):
     """ws_lstm_fwd_cluster2: gates (unorm16 BLH), cbuf, hcat (BLS) <- the BLSTM forward of the blocked-layout sequences from
-    the fp16 normalised input xn16 (BLH(128)), W_ih / biases as ws_lstm_cat_ih leaves them and the fp32 W_hh.  Returns the
-    launch's time-out word: pass it as `run_if` to gemm_p2b + lstm_fwd behind this call -- the predicated fall-back."""
-    for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("xn16", xn16), ("wcat", wcat), ("bcat", bcat),
+    the normalised input xn (BL(128) of BLS pairs: gemm_p2b's A_bl), W_ih / biases as ws_lstm_cat_ih leaves them and the fp32
+    W_hh.  Returns the launch's time-out word: pass it as `run_if` to gemm_p2b + lstm_fwd behind this call -- the predicated
+    fall-back."""
+    for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("xn", xn), ("wcat", wcat), ("bcat", bcat),
                  ("whh_f", whh_f), ("whh_r", whh_r)):
         _chk(t, n)
     ncl = sm.nseq // 32
     sc = _cluster_scratch(gates.device)
     xchg, flags = sc.get(ncl * 2 * 8 * 4096 // 4, ncl * 8 + 8)
     a = L.LstmCluster2Args()
-    a.gates, a.cbuf, a.hcat, a.xn16, a.wcat, a.bcat = _p(gates), _p(cbuf), _p(hcat), _p(xn16), _p(wcat), _p(bcat)
+    a.gates, a.cbuf, a.hcat, a.xn, a.wcat, a.bcat = _p(gates), _p(cbuf), _p(hcat), _p(xn), _p(wcat), _p(bcat)
     a.whh_f, a.whh_r = _p(whh_f), _p(whh_r)
     tw = flags[ncl * 8:ncl * 8 + 1]
     a.xchg, a.tword = C.c_void_p(xchg.data_ptr()), C.c_void_p(tw.data_ptr())
@@ -1438,6 +1439,14 @@ def scale_bf_fwd(x, s, B: int, T: int, Fq: int, Cc: int, mode: int, y):
     for n, t in (("x", x), ("s", s), ("y", y)):
         _chk(t, n)
     _call("ws_scale_bf_fwd", _p(x), _p(s), B, T, Fq, Cc, mode, _p(y))
+
+
+def freq_linear_fwd(x, W, ldw: int, rb, B: int, T: int, Fq: int, Cc: int, y):
+    """ws_freq_linear_fwd: y[b, t, f', c] = sum_f W[f', f] x[b, t, f, c] + rb[b, f'] (the 'concat' speaker fusion's Linear over
+    the frequency axis; the native runtime's forward form)."""
+    for n, t in (("x", x), ("W", W), ("rb", rb), ("y", y)):
+        _chk(t, n)
+    _call("ws_freq_linear_fwd", _p(x), _p(W), ldw, _p(rb), B, T, Fq, Cc, _p(y))
 
 
 def scale_bf_bwd(x, dy, s, B: int, T: int, Fq: int, Cc: int, mode: int, dx, ds):

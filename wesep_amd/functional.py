@@ -429,20 +429,18 @@ class ResRNNBlkFn(torch.autograd.Function):
                          beta=norm_b, stat_map=smap, A_bl16=xn16)
             dev.lstm_fwd_fused(gates, cbuf, hcat, xn, W("fused"), bcat, seq, gfmt=gfmt)
         elif cluster and h2 and dev.lstm_cluster2_on():
-            # time view, 2-byte formats (round 5): the cluster kernel computes x W_ih^T itself from the fp16 copy of the
-            # normalised input (lstm_cluster2.hip) -- ws_gemm_p2b only normalises (reads E, writes E / 2 instead of 17 E), the
-            # fp32 pre-activations exist only inside the predicated fall-back behind the launch (the streaming pair, the
-            # whole layer again after a time-out: never NaN, no host round trip)
-            x16 = xn16 if xn16 is not None else _empty(d, dev.blh_floats(nb, N))
-            xn_keep = None if a16 else xn          # the split-pair xn is only read by the backward without fp16 copies
-            dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn_keep, stats=stats, gamma=norm_w,
-                         beta=norm_b, stat_map=smap, A_bl16=x16)
-            tw = dev.lstm_fwd_cluster2(gates, cbuf, hcat, x16, wcat, bcat, whf, whr, seq, dbg=_cluster_dbg())
+            # time view, 2-byte formats (round 5): the cluster kernel computes x W_ih^T itself from the normalised input
+            # (lstm_cluster2.hip) -- ws_gemm_p2b only normalises (reads E, writes E (+ E / 2 for the fp16 copy) instead of
+            # 17 E), the fp32 pre-activations exist only inside the predicated fall-back behind the launch (the streaming
+            # pair, the whole layer again after a time-out: never NaN, no host round trip)
+            dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, stats=stats, gamma=norm_w,
+                         beta=norm_b, stat_map=smap, A_bl16=xn16)
+            tw = dev.lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whf, whr, seq, dbg=_cluster_dbg())
             pre = _empty(d, nb, 32 * 2 * G4)       # (scratch of the fall-back: untouched after a clean launch)
-            dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=W("wih"), N=2 * G4, C_out=pre, bias=bcat, A_bl=xn_keep, stats=stats,
+            dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=W("wih"), N=2 * G4, C_out=pre, bias=bcat, stats=stats,
                          gamma=norm_w, beta=norm_b, stat_map=smap, run_if=tw)
             dev.lstm_fwd(gates, cbuf, hcat, W("hh")[0], seq, lmode, run_if=tw, gfmt=gfmt, gates_in=pre)
-            del pre, x16
+            del pre
         else:
             # pre-activations: in `gates` itself with the fp32 format (one buffer, three lives); with the 2-byte formats a
             # scratch buffer that dies with this forward (the recurrences read it and write the unorm16 gates next to it)
@@ -677,11 +675,8 @@ def _pair_dbg() -> int:
 
 def _cluster_dbg() -> int:
     """WESEP_CLUSTER_FORCE_TIMEOUT=1 (tests): every forward cluster launch times out in workgroup 0 at step 2, so the
-    predicated streaming fall-back produces the layer's result.  WESEP_CLUSTER2_IO=m (experiment): dbg bit 32 of
-    ws_lstm_fwd_cluster2, the HBM traffic on the M-waves at the top of the step."""
-    if os.environ.get("WESEP_CLUSTER_FORCE_TIMEOUT", "0") == "1":
-        return 8
-    return 32 if os.environ.get("WESEP_CLUSTER2_IO", "x") == "m" else 0
+    predicated streaming fall-back produces the layer's result."""
+    return 8 if os.environ.get("WESEP_CLUSTER_FORCE_TIMEOUT", "0") == "1" else 0
 
 
 def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, proj_w):

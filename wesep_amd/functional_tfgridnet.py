@@ -461,16 +461,14 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             # over this model's own 5e-3 gradient bound (tests/test_tfgridnet_gpu.py): the fp16 input copy (11 bits) costs
             # more here than in pBSRNN, whose bounds it passes with 2.5x margin.  So TF-GridNet's default stays the round-4
             # cluster kernel on fp32 pre-activations; the fp16 pair BPTT (no measurable effect on any gradient) is on
-            x16 = xn16 if xn16 is not None else _empty(d, dev.blh_floats(nb, N))
-            xn_keep = None if a16 else xn
-            dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn_keep, A_bl16=x16)
-            tw = dev.lstm_fwd_cluster2(gates, cbuf, hcat, x16, wcat, bcat, whf, whr, seq, dbg=F0._cluster_dbg())
+            dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, A_bl16=xn16)
+            tw = dev.lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whf, whr, seq, dbg=F0._cluster_dbg())
             wih_pack = _empty(d, 2 * G4 * N)
             dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
             pre = _empty(d, nb, 32 * 2 * G4)          # (scratch of the fall-back: untouched after a clean launch)
-            dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=pre, bias=bcat, A_bl=xn_keep, run_if=tw)
+            dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=pre, bias=bcat, run_if=tw)
             dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode, run_if=tw, gfmt=gfmt, gates_in=pre)
-            del pre, x16
+            del pre
         else:
             wih_pack = _empty(d, 2 * G4 * N)
             dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
