@@ -338,22 +338,35 @@ def test_resrnn_formats_agree(view, fmt, monkeypatch):
     blk = ResRNN(N, 2 * N).to(d)
     z = torch.randn(R, K, Tf, N, device=d)
     go = torch.randn(R, K, Tf, N, device=d)
+    from wesep_amd import dev
     res = {}
-    for f in ("f32", fmt):
+
+    def run(f, c2):
         monkeypatch.setenv("WESEP_GATES", f)
+        monkeypatch.setenv("WESEP_LSTM_CLUSTER2", c2)
         for p in blk.parameters():
             p.grad = None
+        dev.bump_weight_epoch()
         zd = z.clone().requires_grad_(True)
         out = blk(zd, view)
         out.backward(go)
         torch.cuda.synchronize()
-        res[f] = (out.detach().clone(), zd.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()})
-    a, b = res["f32"], res[fmt]
-    assert torch.equal(a[0], b[0])
+        return out.detach().clone(), zd.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}
+
+    a, b = run("f32", "0"), run(fmt, "0")
+    assert torch.equal(a[0], b[0])                                  # the formats change what is STORED, not what is computed
     tol = {"f32": 0.0, "h2s": 5e-5, "h2": 4e-4, "h2b": 3e-3}[fmt]   # unorm16 gates; + scaled-fp16 (default) / bf16 d(gates)
     assert rel(b[1], a[1]) <= tol
     for k in a[2]:
         assert rel(b[2][k], a[2][k]) <= tol, k
+    if view == "time" and fmt != "f32":
+        # round 5: the 2-byte formats' time view runs ws_lstm_fwd_cluster2 by default -- fp16 h in the recurrent product changes
+        # the forward arithmetic itself (2^-12 on h), so bit-equality becomes a tolerance; everything else as above
+        c = run(fmt, "1")
+        assert rel(c[0], a[0]) <= 5e-5, rel(c[0], a[0])
+        assert rel(c[1], a[1]) <= tol + 2e-4
+        for k in a[2]:
+            assert rel(c[2][k], a[2][k]) <= tol + 2e-4, k
 
 
 # ---- ABI v16: fp16 copies of the weight-gradient GEMM's A operand [xn | h] -----------------------------------------------

@@ -82,6 +82,7 @@ def main():
             tt = ts[5:-1, role] - ts[5:-1, role, 0:1]
             nxt = ts[6:, role, 0] - ts[5:-1, role, 0]
             print(f"  {rn}: mean microseconds since the loop top")
+            print(f"     {'x feed done':34s} {float(tt[:, 7].mean()) * upt:6.2f}   (sd {float(tt[:, 7].std()) * upt:.2f})")
             for k in range(1, 7):
                 if role == 1 and k > 4:
                     continue

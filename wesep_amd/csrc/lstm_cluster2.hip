@@ -79,8 +79,9 @@ __device__ __forceinline__ bool cluster2_of_block(int ncl, int& c, int& j) {
 }
 
 // STAMPS (diagnosis, dbg 2048): s_memtime stamps of cluster 0 / member 0, waves 0 (X) and 4 (M), into p.dbg_buf as 64-bit ticks:
-// [(step * 2 + role) * 8 + k]; k: 0 loop top, 1 recurrent MFMAs done, 2 past barrier 0, 3 cell update done (h published),
-// 4 next step's x-projection done, 5 X: all eight slices arrived, 6 X: h image written; the next k = 0 closes the step
+// [(step * 2 + role) * 8 + k]; k: 0 loop top, 7 x feed done (LDS write + next loads requested), 1 recurrent MFMAs done (X: +
+// output stores issued), 2 past barrier 0, 3 cell update done (h published), 4 next step's x-projection done, 5 X: all eight
+// slices arrived, 6 X: h image written; the next k = 0 closes the step
 // Without stamps every phase boundary is still a scheduling fence: the stamped build -- whose s_memtime reads keep the
 // compiler from moving code across the boundaries -- measured 0.5 us per step FASTER than the first unfenced build
 // (profiles/r05_c4_recur_probe.txt: 2.14 vs 2.75 ms per launch), which had let the scheduler mix the phases.
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
 #pragma unroll
       for (int q = 0; q < 4; ++q) xreg[q] = xld(t2, q);
     }
+    C2TS(7);
     // ---- G^T tile [4 gates x 8 units][32 seqs] += W_hh slice * h^T -----------------------------------------------------
     {
       const _Float16* hb = &hl[(st * 32 + n) * HROW + 8 * half];
