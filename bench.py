@@ -12,9 +12,9 @@ Workload (BASELINE.json configs[1] / north_star "batch 32 x 4 s"): pBSRNN, FiLM 
 the matrix cores as split pairs, fp32 accumulation everywhere --
   * "bf16x3": bf16 hi + lo of both operands, THREE bf16 MFMAs per product: the band-view recurrences (forward with the
     fused x-projection, BPTT), the output projections, d(hcat), the proj weight gradients, BN / mask-MLP / FiLM GEMMs;
-  * "fp16x2": one operand as ONE fp16 value (11 bits: h in (-1, 1), the normalised input, the scaled d(gates)), the weight
-    as fp16 hi + lo, TWO fp16 MFMAs per product: the time-view recurrences (round 5: cluster forward incl. its
-    x-projection, pair BPTT) and d(xn);
+  * "fp16x2": one operand as ONE fp16 value (11 bits: h in (-1, 1), the scaled d(gates)), the weight as fp16 hi + lo, TWO
+    fp16 MFMAs per product: the recurrent products of the time-view recurrences (round 5: cluster forward -- whose fused
+    x-projection stays bf16x3 --, pair BPTT) and d(xn);
   * "fp16x1": both operands single fp16, ONE MFMA per product: the LSTM weight gradients (scaled-fp16 d(gates) x fp16 copies
     of [xn | h]);
 saved state in 2 bytes (unorm16 gates, scaled-fp16 d(gates)), c / h / activations in fp32.  Holds the reference's fp32
@@ -172,7 +172,7 @@ def mfma_terms_census():
     kn = {"x_proj": 128 * 2048, "recur_fwd": 2 * 256 * 1024, "proj": 512 * 128, "d_hcat": 128 * 512, "bptt": 2 * 256 * 1024,
           "dW_lstm": 2 * 1024 * 384, "d_xn": 2048 * 128, "dW_proj": 512 * 128}
     terms = {
-        "time": {"x_proj": 2 if c2 else 3, "recur_fwd": 2 if c2 else 3, "proj": 3, "d_hcat": 3, "bptt": 2 if F.pair_rfmt(gf) else 3,
+        "time": {"x_proj": 3, "recur_fwd": 2 if c2 else 3, "proj": 3, "d_hcat": 3, "bptt": 2 if F.pair_rfmt(gf) else 3,
                  "dW_lstm": (1 if F.tnb_a16() else 2) if h2f else 3, "d_xn": 2 if h2f else 3, "dW_proj": 3},
         "band": {"x_proj": 3, "recur_fwd": 3, "proj": 3, "d_hcat": 3, "bptt": 3,
                  "dW_lstm": (1 if F.tnb_a16() else 2) if h2f else 3, "d_xn": 2 if h2f else 3, "dW_proj": 3},
@@ -348,9 +348,9 @@ def main():
     census = mfma_terms_census()
     tv, bv = census["terms_per_product"]["time"], census["terms_per_product"]["band"]
     dom_terms = 0.5 * ((tv["bptt"] + bv["bptt"]) if dom == "lstm_bwd" else (tv["recur_fwd"] + bv["recur_fwd"]))
-    arith = ("bf16x3 (band-view recurrences, projections, d(hcat), BN / mask GEMMs) + fp16x2 (time-view cluster forward "
-             "incl. x-projection, pair BPTT, d(xn)) + fp16x1 (LSTM weight gradients); 2-byte saved gates / d(gates); fp32 "
-             "accumulate")
+    arith = ("bf16x3 (band-view recurrences, x-projections, projections, d(hcat), BN / mask GEMMs) + fp16x2 (recurrent "
+             "products of the time-view cluster forward and pair BPTT, d(xn)) + fp16x1 (LSTM weight gradients); 2-byte "
+             "saved gates / d(gates); fp32 accumulate")
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {

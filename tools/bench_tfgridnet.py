@@ -67,8 +67,8 @@ def main():
     print(json.dumps({"metric": "utterances/sec (6 s, 16 kHz) fwd+bwd, TF-GridNet (fixed embeddings), 6 s utterances",
                       "value": args.rows * args.steps / el, "unit": "utterances/s",
                       "ms_per_step": el / args.steps * 1e3, "rows": args.rows, "steps": args.steps,
-                      "dtype": "bf16x3 (intra-frame recurrences, projections, attention, convolutions) + fp16x2 (inter-frame cluster "
-                               "forward incl. x-projection, pair BPTT, d(xn)), fp32 accumulate",
+                      "dtype": "bf16x3 (recurrences, projections, attention, convolutions) + fp16x2 (inter-frame pair BPTT, d(xn); the inter-frame "
+                               "cluster forward's recurrent product with WESEP_TFG_CLUSTER2=1) + fp16x1 opt-in weight gradients, fp32 accumulate",
                       "lstm_units_priced": hidden,
                       "config": "recipe" if args.recipe else "constructor defaults", "blocked_recurrence": bool(args.recipe and not args.rowmajor),
                       "data": "synthetic", "final_loss_dB": float(loss.item()),

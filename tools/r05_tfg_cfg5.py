@@ -1,6 +1,7 @@
 """GPU probe (round 5): TF-GridNet at BASELINE config 5's geometry (recipe, 2 rows x 6 s) against the CPU oracle -- computed
-ONCE -- under the four combinations of the round-5 recurrence arithmetic: ws_lstm_fwd_cluster2 (fp16 h) on / off and the
-pair BPTT's fp16 recurrence (rfmt 1) on / off.  Prints waveform / loss differences and the ten worst per-tensor gradients."""
+ONCE -- with ws_lstm_fwd_cluster2 (fp16 h; WESEP_TFG_CLUSTER2) on / off for the inter-frame path, the pair BPTT's fp16
+recurrence on (the first version of this probe, profiles/r05_tfg_cfg5_precision_split.txt, ran all four combinations with
+the fp16-input cut of cluster2: the pair BPTT's arithmetic moved no gradient).  Prints waveform / loss differences and the ten worst per-tensor gradients."""
 import os
 import sys
 
@@ -34,8 +35,8 @@ def main():
     loss_o.backward()
     want = {k: v.grad.double() for k, v in p.items()}
     top = max(float(g.norm()) for g in want.values())
-    for c2, rf in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
-        os.environ["WESEP_LSTM_CLUSTER2"], os.environ["WESEP_PAIR_RF"] = c2, rf
+    for c2, rf in (("1", "1"), ("0", "1")):
+        os.environ["WESEP_TFG_CLUSTER2"], os.environ["WESEP_PAIR_RF"] = c2, rf
         model = get_model("TFGridNet")(**kw, joint_training=False)
         model.load_state_dict(params, strict=True)
         model = model.to(d).train()

@@ -64,6 +64,17 @@ __device__ __forceinline__ void split8b(const f32x4& a, const f32x4& b, bf16x8& 
   }
 }
 
+// sigmoid / tanh of a / 256 with the scale folded into the argument of v_exp_f32 (2^x): one multiply per activation instead of
+// two; the same v_exp / v_rcp as fsig / ftanh (lstm_bf16_common.h)
+__device__ __forceinline__ float c2_sig256(float a) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(a * (-1.4426950408889634f / 256.f)));
+}
+__device__ __forceinline__ float c2_tanh256(float a) {
+  const float e = __builtin_amdgcn_exp2f(fabsf(a) * (-2.f * 1.4426950408889634f / 256.f));  // in (0, 1]: no overflow
+  const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+  return copysignf(t, a);
+}
+
 __device__ __noinline__ void cluster2_timed_out(unsigned* tword, unsigned* status, int* dead_s) {
   *dead_s = 1;
   __hip_atomic_store((gu32*)tword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -165,16 +176,16 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
   unsigned* tword = p.tword;
 
   auto step_time = [&](int s) { return d == 0 ? s : L - 1 - s; };
-  // x-projection of one step into the accumulators (they start from the bias): 8 k-steps x {hi, lo}
-  f32x16 acc0, acc1;
+  // x-projection of one step into the accumulator (it starts from the bias): 8 k-steps x three terms.  ONE accumulator chain
+  // per wave: the other wave of the SIMD fills the dependent-issue gaps, and the cell update -- the VALU-bound phase that the
+  // cycle stamps show on the step's critical path (two waves per SIMD, 1.7 us for the pair) -- loses sixteen adds per lane
+  f32x16 acc0;
   auto xpart = [&]() {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 b4 = bias_l[q * 8 + 2 * uo + half];
       acc0[4 * q] = b4[0], acc0[4 * q + 1] = b4[1], acc0[4 * q + 2] = b4[2], acc0[4 * q + 3] = b4[3];
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
     const f32x4* xc = xb + st * 1024 + n;   // 16-byte cells: (column quad * 32 + slot)
     const bf16x8* wa = &wih[(uo * 2) * 8 * 64 + lane];
 #pragma unroll
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
       const bf16x8 bh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
       const bf16x8 bl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
       acc0 = mfma32(wa[ks * 64], bh, acc0);
-      acc1 = mfma32(wa[(8 + ks) * 64], bh, acc1);
+      acc0 = mfma32(wa[(8 + ks) * 64], bh, acc0);
       acc0 = mfma32(wa[ks * 64], bl, acc0);
     }
   };
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
       for (int ks = 0; ks < 16; ++ks) {
         const f16x8 b = *reinterpret_cast<const f16x8*>(hb + 16 * ks);
         acc0 = mfma16h(wh[ks], b, acc0);
-        acc1 = mfma16h(wl[ks], b, acc1);
+        acc0 = mfma16h(wl[ks], b, acc0);
       }
     }
     if (xrole && step > 0) hbm_out(step_time(step - 1));
@@ -253,10 +264,11 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
       f32x4 vi, vf, vg, vo, vh;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float ig = fsig((acc0[r] + acc1[r]) * (1.f / 256.f));
-        const float fg = fsig((acc0[4 + r] + acc1[4 + r]) * (1.f / 256.f));
-        const float gg = ftanh((acc0[8 + r] + acc1[8 + r]) * (1.f / 256.f));
-        const float og = fsig((acc0[12 + r] + acc1[12 + r]) * (1.f / 256.f));
+        // the accumulator carries 256 x the pre-activation: the 2^-8 is folded into the exponent's scale (one multiply)
+        const float ig = c2_sig256(acc0[r]);
+        const float fg = c2_sig256(acc0[4 + r]);
+        const float gg = c2_tanh256(acc0[8 + r]);
+        const float og = c2_sig256(acc0[12 + r]);
         const float cn = fg * c4[r] + ig * gg;
         c4[r] = cn;
         vi[r] = ig, vf[r] = fg, vg[r] = gg, vo[r] = og;
