@@ -154,6 +154,7 @@ struct RnnPrep {            // one ResRNN (bsrnn.py:26-46), everything the forwa
 
 struct ConvPrep {           // conv (bias-free) + BatchNorm(eval) (+ ReLU) of the speaker encoder
   int cin, cout, k, stride, ldp;
+  int sw = 0;               // stride along W when it differs from `stride` (CAM++'s FCM head strides the mel axis only); 0: same
   bool relu;
   const float *gamma, *beta;
   float *w2, *st;           // [cout][ldp] in im2col column order; [2][cout] = (running mean, rstd)
@@ -174,6 +175,24 @@ struct SeRes2Prep {         // SE_Res2Block: 1x1 TDNN, Res2Net branches, 1x1 TDN
   TdnnPrep in, out;
   std::vector<TdnnPrep> branch;
   std::string se;           // "...se_res2block.3." (linear1 / linear2)
+};
+
+// ---- wespeaker CAM++ (spk_kind 2; wesep_amd/models/campplus.py) ----
+struct CamBn {              // BatchNorm1d(eval) of a pre-activation D-TDNN layer: (mean, rstd) + affine operands (or ones / zeros)
+  int c;
+  float* st;
+  const float *gamma, *beta;
+};
+struct CamLayer {           // CAMDenseTDNNLayer: BN-ReLU, 1x1 to 128, BN-ReLU, dilated k = 3 conv to 32, context-aware mask
+  int cin, dil;
+  CamBn bn1, bn2;
+  const float *w1, *wloc;   // linear1 [128][cin]; linear_local as the 3 x 3 view of the one-row image [32][9 * 128]
+  const float *l1w, *l1b, *l2w, *l2b;
+};
+struct CamTransit {         // BN-ReLU + 1x1 (bias-free) to half the channels
+  int cin, cout;
+  CamBn bn;
+  const float* w;
 };
 
 }  // namespace
@@ -216,6 +235,16 @@ struct ws_engine {
   float* seg_bn_st = nullptr;
   TdnnPrep tdnn1;
   std::vector<SeRes2Prep> se_blocks;
+  // CAM++ speaker encoder (spk_kind 2; wesep_amd/models/campplus.py)
+  std::vector<ConvPrep> cam_fcm;      // conv1, then per BasicResBlock (conv1, [shortcut], conv2), then conv2
+  std::vector<int> cam_fcm_kind;      // 0 plain, 1 block conv1, 2 shortcut, 3 block conv2 (+ residual)
+  ConvPrep cam_dummy;
+  const float* cam_tdnn_w = nullptr;  // xvector.tdnn as the 5 x 5 view weight
+  CamBn cam_tdnn_bn, cam_out_bn, cam_dense_bn;
+  std::vector<std::vector<CamLayer>> cam_blocks;
+  std::vector<CamTransit> cam_transit;
+  int cam_init = 128, cam_growth = 32, cam_bn = 128;
+  float *cam_one = nullptr, *cam_zero = nullptr, *cam_id_st = nullptr;   // ones / zeros / (0 x C | 1 x C), C = 1024
   float *id_st = nullptr, *id_one = nullptr, *id_zero = nullptr;   // identity BatchNorm operands: y = x + res
   float *pool_bn_st = nullptr, *emb_bn_st = nullptr;
   float *slope0 = nullptr, *slope1 = nullptr;     // PReLU slopes 0 (ReLU) and 1 (identity)
@@ -499,6 +528,8 @@ int prep_conv(ws_engine* e, const std::string& conv, const std::string& bn, int 
 }
 
 float* bn_eval_stats(ws_engine* e, const std::string& bn, int c);
+int prep_campplus(ws_engine* e);
+int campplus_embed(ws_engine* e, const float* fbank, int R, int Te, float* emb);
 
 int prep_resnet(ws_engine* e) {
   const int m = 32, ex = e->spk_bottleneck ? 4 : 1;
@@ -650,6 +681,122 @@ int prep_ecapa(ws_engine* e) {
   return WS_OK;
 }
 
+// wespeaker CAMPPlus (models/campplus.py, the recipe's alternative speaker encoder: bsrnn.yaml:66-74): FCM head (2-D
+// convolutions that stride the mel axis only), D-TDNN backbone of three CAM-dense-TDNN blocks (12 / 24 / 16 layers, growth 32,
+// bottleneck 128, kernel 3, dilations 1 / 2 / 2) with transit layers, BN-ReLU, TSTP, dense embedding layer (BatchNorm without
+// affine).  Shapes checked against the container; view weights and BatchNorm(eval) statistics prepared once.
+int cam_bn_prep(ws_engine* e, const std::string& bn, int c, bool affine, CamBn* b) {
+  if (!require(e, bn + ".running_mean", {c}) || !require(e, bn + ".running_var", {c}) ||
+      (affine && (!require(e, bn + ".weight", {c}) || !require(e, bn + ".bias", {c}))))
+    return WS_ERR_INVALID;
+  b->c = c;
+  b->st = bn_eval_stats(e, bn, c);
+  WS_PTR(b->st);
+  b->gamma = affine ? e->dev(bn + ".weight") : e->cam_one;
+  b->beta = affine ? e->dev(bn + ".bias") : e->cam_zero;
+  return WS_OK;
+}
+
+// Conv1d [cout][cin][k] (bias-free, 'same' padding) as the k x k view of the one-row image (prep_tdnn)
+const float* cam_view_weight(ws_engine* e, const std::string& conv, int cout, int cin, int k) {
+  const float* w = e->host(conv + ".weight");
+  std::vector<float> w2(size_t(cout) * k * k * cin, 0.f);
+  for (int o = 0; o < cout; ++o)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int kx = 0; kx < k; ++kx) w2[(size_t(o) * k * k + size_t(k / 2) * k + kx) * cin + ci] = w[(size_t(o) * cin + ci) * k + kx];
+  return upload(e, e->persist, w2.data(), w2.size());
+}
+
+int prep_campplus(ws_engine* e) {
+  const std::string p = "spk_model.";
+  const int F = e->feat_dim, mc = 32;
+  if (F % 8 || e->E % 4) {
+    set_err("engine: CAM++ needs feat_dim %% 8 == 0 and an embedding size %% 4 == 0 (got %d, %d)", F, e->E);
+    return WS_ERR_INVALID;
+  }
+  int rc;
+  {   // ones / zeros / identity statistics for widths up to 1024 (affine-free BatchNorm, residual-free adds)
+    const int C = 1024;
+    std::vector<float> one(C, 1.f), zero(C, 0.f), st(2 * size_t(C), 0.f);
+    for (int c = 0; c < C; ++c) st[C + c] = 1.f;
+    e->cam_one = upload(e, e->persist, one.data(), one.size());
+    e->cam_zero = upload(e, e->persist, zero.data(), zero.size());
+    e->cam_id_st = upload(e, e->persist, st.data(), st.size());
+    const float s0 = 0.f, s1 = 1.f;
+    e->slope0 = upload(e, e->persist, &s0, 1);
+    e->slope1 = upload(e, e->persist, &s1, 1);
+    WS_PTR(e->cam_one && e->cam_zero && e->cam_id_st && e->slope0 && e->slope1);
+  }
+  // ---- FCM head ----
+  auto add = [&](const std::string& conv, const std::string& bn, int cin, int k, int sh, bool relu, int kind) -> int {
+    ConvPrep c;
+    const int r = prep_conv(e, p + conv, p + bn, cin, mc, k, sh, relu, &c);
+    if (r != WS_OK) return r;
+    c.sw = 1;
+    e->cam_fcm.push_back(c);
+    e->cam_fcm_kind.push_back(kind);
+    return WS_OK;
+  };
+  if ((rc = add("head.conv1", "head.bn1", 1, 3, 1, true, 0)) != WS_OK) return rc;
+  for (int L = 1; L <= 2; ++L)
+    for (int b = 0; b < 2; ++b) {
+      const std::string q = "head.layer" + std::to_string(L) + "." + std::to_string(b) + ".";
+      const int sh = b == 0 ? 2 : 1;
+      if ((rc = add(q + "conv1", q + "bn1", mc, 3, sh, true, 1)) != WS_OK) return rc;
+      if (b == 0 && (rc = add(q + "shortcut.0", q + "shortcut.1", mc, 1, sh, false, 2)) != WS_OK) return rc;
+      if ((rc = add(q + "conv2", q + "bn2", mc, 3, 1, true, 3)) != WS_OK) return rc;
+    }
+  if ((rc = add("head.conv2", "head.bn2", mc, 3, 2, true, 0)) != WS_OK) return rc;
+  // ---- D-TDNN backbone ----
+  const int cin0 = mc * (F / 8), init = e->cam_init, growth = e->cam_growth, bnc = e->cam_bn;
+  const std::string x = p + "xvector.";
+  if (!require(e, x + "tdnn.linear.weight", {init, cin0, 5})) return WS_ERR_INVALID;
+  e->cam_tdnn_w = cam_view_weight(e, x + "tdnn.linear", init, cin0, 5);
+  WS_PTR(e->cam_tdnn_w);
+  if ((rc = cam_bn_prep(e, x + "tdnn.nonlinear.batchnorm", init, true, &e->cam_tdnn_bn)) != WS_OK) return rc;
+  const int nlayers[3] = {12, 24, 16}, dils[3] = {1, 2, 2};
+  int ch = init;
+  for (int bi = 0; bi < 3; ++bi) {
+    std::vector<CamLayer> layers;
+    for (int i = 0; i < nlayers[bi]; ++i) {
+      const std::string q = x + "block" + std::to_string(bi + 1) + ".tdnnd" + std::to_string(i + 1) + ".";
+      CamLayer l;
+      l.cin = ch + i * growth, l.dil = dils[bi];
+      if ((rc = cam_bn_prep(e, q + "nonlinear1.batchnorm", l.cin, true, &l.bn1)) != WS_OK) return rc;
+      if (!require(e, q + "linear1.weight", {bnc, l.cin, 1})) return WS_ERR_INVALID;
+      l.w1 = e->dev(q + "linear1.weight");
+      if ((rc = cam_bn_prep(e, q + "nonlinear2.batchnorm", bnc, true, &l.bn2)) != WS_OK) return rc;
+      if (!require(e, q + "cam_layer.linear_local.weight", {growth, bnc, 3}) ||
+          !require(e, q + "cam_layer.linear1.weight", {bnc / 2, bnc, 1}) || !require(e, q + "cam_layer.linear1.bias", {bnc / 2}) ||
+          !require(e, q + "cam_layer.linear2.weight", {growth, bnc / 2, 1}) || !require(e, q + "cam_layer.linear2.bias", {growth}))
+        return WS_ERR_INVALID;
+      l.wloc = cam_view_weight(e, q + "cam_layer.linear_local", growth, bnc, 3);
+      WS_PTR(l.wloc);
+      l.l1w = e->dev(q + "cam_layer.linear1.weight"), l.l1b = e->dev(q + "cam_layer.linear1.bias");
+      l.l2w = e->dev(q + "cam_layer.linear2.weight"), l.l2b = e->dev(q + "cam_layer.linear2.bias");
+      layers.push_back(l);
+    }
+    e->cam_blocks.push_back(layers);
+    ch += nlayers[bi] * growth;
+    CamTransit t;
+    t.cin = ch, t.cout = ch / 2;
+    const std::string q = x + "transit" + std::to_string(bi + 1) + ".";
+    if ((rc = cam_bn_prep(e, q + "nonlinear.batchnorm", ch, true, &t.bn)) != WS_OK) return rc;
+    if (!require(e, q + "linear.weight", {t.cout, ch, 1})) return WS_ERR_INVALID;
+    t.w = e->dev(q + "linear.weight");
+    e->cam_transit.push_back(t);
+    ch /= 2;
+  }
+  if (ch > 512) {
+    set_err("engine: CAM++ backbone width %d exceeds the plan's buffers", ch);
+    return WS_ERR_INVALID;
+  }
+  if ((rc = cam_bn_prep(e, x + "out_nonlinear.batchnorm", ch, true, &e->cam_out_bn)) != WS_OK) return rc;
+  if (!require(e, x + "dense.linear.weight", {e->E, 2 * ch, 1})) return WS_ERR_INVALID;
+  if ((rc = cam_bn_prep(e, x + "dense.nonlinear.batchnorm", e->E, false, &e->cam_dense_bn)) != WS_OK) return rc;
+  return WS_OK;
+}
+
 // kaldi fbank as two GEMMs: every per-frame step before the power spectrum (2^15 scaling, DC removal, 0.97
 // pre-emphasis with the first sample replicated, symmetric Hamming window, zero padding, real DFT) folded into one
 // [2 * padded/2][win] basis; triangular mel bank [feat_dim][padded/2]   (wesep_amd/utils/funcs.py, DESIGN 11a;
@@ -749,8 +896,8 @@ int read_speaker_meta(ws_engine* e) {
   e->spk_emb_bn = static_cast<int>(meta_or(e, "spk_emb_bn", 0));
   e->spk_bottleneck = static_cast<int>(meta_or(e, "spk_bottleneck", 0));
   e->spk_two_emb = static_cast<int>(meta_or(e, "spk_two_emb", 0));
-  if (e->spk_kind < 0 || e->spk_kind > 1) {
-    set_err("engine: speaker encoder kind %d is not built (0 ResNet, 1 ECAPA-TDNN)", e->spk_kind);
+  if (e->spk_kind < 0 || e->spk_kind > 2) {
+    set_err("engine: speaker encoder kind %d is not built (0 ResNet, 1 ECAPA-TDNN, 2 CAM++)", e->spk_kind);
     return WS_ERR_INVALID;
   }
   return WS_OK;
@@ -781,8 +928,8 @@ int prepare(ws_engine* e) {
   e->spk_emb_bn = static_cast<int>(meta_or(e, "spk_emb_bn", 0));
   e->spk_bottleneck = static_cast<int>(meta_or(e, "spk_bottleneck", 0));
   e->spk_two_emb = static_cast<int>(meta_or(e, "spk_two_emb", 0));
-  if (e->spk_kind < 0 || e->spk_kind > 1) {
-    set_err("engine: speaker encoder kind %d is not built (0 ResNet, 1 ECAPA-TDNN)", e->spk_kind);
+  if (e->spk_kind < 0 || e->spk_kind > 2) {
+    set_err("engine: speaker encoder kind %d is not built (0 ResNet, 1 ECAPA-TDNN, 2 CAM++)", e->spk_kind);
     return WS_ERR_INVALID;
   }
   if (meta_or(e, "win", 512) != 512 || meta_or(e, "stride", 128) != kHop || meta_or(e, "feature_dim", kN) != kN) {
@@ -861,7 +1008,7 @@ int prepare(ws_engine* e) {
     }
   }
   if (e->joint) {
-    if ((rc = e->spk_kind == 1 ? prep_ecapa(e) : prep_resnet(e)) != WS_OK) return rc;
+    if ((rc = e->spk_kind == 2 ? prep_campplus(e) : e->spk_kind == 1 ? prep_ecapa(e) : prep_resnet(e)) != WS_OK) return rc;
     if ((rc = e->spk_feat ? prep_fbank(e) : prep_mel_frontend(e)) != WS_OK) return rc;
   }
   if (!e->dry && hipStreamSynchronize(e->stream) != hipSuccess) {
@@ -1081,8 +1228,8 @@ int fuse_layer(ws_engine* e, const std::string& pre, float* z, const float* emb,
 // rows are not float4-addressable, writes its 9-column patch matrix with ws_im2col first.
 int conv_bn_act(ws_engine* e, const ConvPrep& c, const float* x, const float* res, int R, int H, int W, float* y,
                 int* Ho_out, int* Wo_out) {
-  const int pad = c.k / 2;
-  const int Ho = (H + 2 * pad - c.k) / c.stride + 1, Wo = (W + 2 * pad - c.k) / c.stride + 1;
+  const int pad = c.k / 2, sw = c.sw ? c.sw : c.stride;
+  const int Ho = (H + 2 * pad - c.k) / c.stride + 1, Wo = (W + 2 * pad - c.k) / sw + 1;
   const long long M = (long long)R * Ho * Wo;
   const bool implicit = c.cin % 4 == 0 && (long long)H * W * c.cin < 0x7fffffffLL;
   void* s = e->stream;
@@ -1098,8 +1245,12 @@ int conv_bn_act(ws_engine* e, const ConvPrep& c, const float* x, const float* re
   if (implicit) {
     g.A = x;
     g.conv.on = 1, g.conv.mode = 0, g.conv.H = H, g.conv.W = W, g.conv.C = c.cin, g.conv.Ho = Ho, g.conv.Wo = Wo;
-    g.conv.k = c.k, g.conv.sh = c.stride, g.conv.sw = c.stride, g.conv.p = pad, g.conv.dil = 1;
+    g.conv.k = c.k, g.conv.sh = c.stride, g.conv.sw = sw, g.conv.p = pad, g.conv.dil = 1;
   } else {
+    if (sw != c.stride) {
+      set_err("engine: a convolution with different strides along H and W needs cin %% 4 == 0 (the implicit-patch view)");
+      return WS_ERR_INVALID;
+    }
     float* patches = a.alloc(size_t(M) * c.ldp);
     WS_PTR(patches);
     if (c.ldp != c.k * c.k * c.cin) {
@@ -1367,6 +1518,191 @@ int ecapa_embed(ws_engine* e, const float* fbank, int R, int Te, float* emb) {
              WS_OK) {
     return rc;
   }
+  a.release(mk);
+  return WS_OK;
+}
+
+// ---- CAM++ forward (models/campplus.py, eval mode) ---------------------------------------------------------------------
+// y = act(BatchNorm(x)) on dense rows [M][c]
+int cam_bn_act(ws_engine* e, const CamBn& b, const float* x, long long M, bool relu, float* scratch, float* y) {
+  WS_RUN(e, ws_bn_prelu_fwd(x, b.st, b.gamma, b.beta, nullptr, relu ? e->slope0 : e->slope1, M, b.c, scratch, y, e->stream));
+  return WS_OK;
+}
+
+// y [M][nout] = x [M][k] (rows lda apart) W^T + bias
+int cam_lin(ws_engine* e, const float* x, long long lda, long long M, int k, const float* W, int nout, const float* bias, float* y) {
+  ws_gemm_nt_args a = {};
+  a.A = x, a.W = W, a.bias = bias, a.C = y;
+  a.a_div = kBig, a.a_s2 = lda, a.c_div = kBig, a.c_s2 = nout, a.st_div1 = 1, a.st_div2 = 1;
+  a.M = static_cast<int>(M), a.N = nout, a.K = k, a.ldw = k;
+  a.vec = vec_bits({(long long)k, lda});
+  WS_RUN(e, ws_gemm_nt(&a, e->stream));
+  return WS_OK;
+}
+
+// y [R*To][cout] = conv1d(x [R][T][cin], k taps, dilation dil, stride sw, 'same' padding), bias-free: the k x k view of the
+// one-row image (functional_campplus.Conv1dFn)
+int cam_conv(ws_engine* e, const float* x, int R, int T, int cin, const float* Wv, int cout, int k, int dil, int sw, float* y,
+             int* To_out) {
+  const int p = dil * (k / 2), To = (T + 2 * p - dil * (k - 1) - 1) / sw + 1;
+  ws_gemm_nt_args g = {};
+  g.A = x, g.W = Wv, g.C = y;
+  g.a_div = kBig, g.a_s2 = cin, g.c_div = kBig, g.c_s2 = cout, g.st_div1 = 1, g.st_div2 = 1;
+  g.M = R * To, g.N = cout, g.K = k * k * cin, g.ldw = g.K, g.vec = 3 | 4;
+  g.conv.on = 1, g.conv.mode = 0, g.conv.H = 1, g.conv.W = T, g.conv.C = cin, g.conv.Ho = 1, g.conv.Wo = To;
+  g.conv.k = k, g.conv.sh = 1, g.conv.sw = sw, g.conv.p = p, g.conv.dil = dil;
+  WS_RUN(e, ws_gemm_nt(&g, e->stream));
+  *To_out = To;
+  return WS_OK;
+}
+
+// CAMDenseTDNNLayer (campplus.py:120-170): x = the first l.cin columns of `cat` (rows ld apart) -> 32 new channels written
+// behind them.  Context-aware mask: m = sigmoid(W2 relu(W1 (segment mean + utterance mean) + b1) + b2) per 100-frame segment
+int cam_layer(ws_engine* e, const CamLayer& l, float* cat, long long ld, int R, int T) {
+  const int bnc = e->cam_bn, growth = e->cam_growth, hid = bnc / 2, seg = 100, nseg = (T + seg - 1) / seg;
+  const long long M = (long long)R * T, Ms = (long long)R * nseg;
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  float* xin = a.alloc(size_t(M) * l.cin);
+  float* u = a.alloc(size_t(M) * (l.cin > bnc ? l.cin : bnc));
+  float* x1 = a.alloc(size_t(M) * l.cin);
+  float* h = a.alloc(size_t(M) * bnc);
+  float* x2 = a.alloc(size_t(M) * bnc);
+  float* yl = a.alloc(size_t(M) * growth);
+  float* sums = a.alloc(size_t(Ms) * bnc);
+  float* mseg = a.alloc(size_t(Ms) * bnc);
+  float* mean2 = a.alloc(size_t(R) * 2 * bnc);
+  float* rb = a.alloc(size_t(R) * hid);
+  float* rbf = a.alloc(size_t(Ms) * hid);
+  float* g1 = a.alloc(size_t(Ms) * hid);
+  float* g1u = a.alloc(size_t(Ms) * hid);
+  float* hh = a.alloc(size_t(Ms) * hid);
+  float* m = a.alloc(size_t(Ms) * growth);
+  WS_PTR(xin && u && x1 && h && x2 && yl && sums && mseg && mean2 && rb && rbf && g1 && g1u && hh && m);
+  int rc, To;
+  if ((rc = copy_cols(e, xin, l.cin, cat, ld, l.cin, M)) != WS_OK) return rc;
+  if ((rc = cam_bn_act(e, l.bn1, xin, M, true, u, x1)) != WS_OK) return rc;
+  if ((rc = cam_lin(e, x1, l.cin, M, l.cin, l.w1, bnc, nullptr, h)) != WS_OK) return rc;
+  if ((rc = cam_bn_act(e, l.bn2, h, M, true, u, x2)) != WS_OK) return rc;
+  if ((rc = cam_conv(e, x2, R, T, bnc, l.wloc, growth, 3, l.dil, 1, yl, &To)) != WS_OK) return rc;
+  // context: mean over each segment (the last one may be shorter) + mean over the utterance
+  WS_RUN(e, ws_seg_sums(x2, nullptr, R, T, bnc, seg, sums, s));
+  WS_RUN(e, ws_bcast_rows(sums, 1.0f / seg, 1, Ms, bnc, mseg, s));
+  const int last = T - (nseg - 1) * seg;
+  if (last != seg)
+    for (int r = 0; r < R; ++r) {
+      const size_t o = (size_t(r) * nseg + nseg - 1) * bnc;
+      WS_RUN(e, ws_bcast_rows(sums + o, 1.0f / last, 1, 1, bnc, mseg + o, s));
+    }
+  if ((rc = time_mean(e, x2, R, T, bnc, mean2)) != WS_OK) return rc;
+  // W1 (mean_seg + mean_all) + b1 = W1 mean_seg + (W1 mean_all + b1): the utterance part is a per-row bias
+  if ((rc = cam_lin(e, mean2, 2 * bnc, R, bnc, l.l1w, hid, l.l1b, rb)) != WS_OK) return rc;
+  if ((rc = cam_lin(e, mseg, bnc, Ms, bnc, l.l1w, hid, nullptr, g1)) != WS_OK) return rc;
+  WS_RUN(e, ws_bcast_rows(rb, 1.0f, nseg, Ms, hid, rbf, s));
+  WS_RUN(e, ws_bn_prelu_fwd(g1, e->cam_id_st + (1024 - hid), e->cam_one, e->cam_zero, rbf, e->slope0, Ms, hid, g1u, hh, s));
+  if ((rc = cam_lin(e, hh, hid, Ms, hid, l.l2w, growth, l.l2b, m)) != WS_OK) return rc;
+  WS_RUN(e, ws_rowbias_act_fwd(m, nullptr, Ms, growth, 1, 3, m, s));
+  WS_RUN(e, ws_seg_scale(yl, m, R, T, growth, seg, yl, s));
+  if ((rc = copy_cols(e, cat + l.cin, ld, yl, growth, growth, M)) != WS_OK) return rc;
+  a.release(mk);
+  return WS_OK;
+}
+
+// fbank [R][Te][F] (device) -> embedding [R][E]   (wespeaker CAMPPlus, eval mode; models/campplus.py:225-262)
+int campplus_embed(ws_engine* e, const float* fbank, int R, int Te, float* emb) {
+  const int F = e->feat_dim, mc = 32;
+  void* s = e->stream;
+  Arena& a = e->work;
+  const Arena::Mark mk = a.mark();
+  int rc;
+  // ---- FCM head on [R][F][Te][1]; the mel axis is strided three times, the frame axis never ----
+  float* x = a.alloc(size_t(R) * F * Te);
+  WS_PTR(x);
+  for (int r = 0; r < R; ++r) WS_RUN(e, ws_transpose(fbank + size_t(r) * Te * F, Te, F, F, x + size_t(r) * F * Te, s));
+  const size_t act = size_t(R) * F * Te * mc;
+  float* bufs[3] = {a.alloc(act), a.alloc(act), a.alloc(act)};
+  WS_PTR(bufs[0] && bufs[1] && bufs[2]);
+  int H = F, W = Te, Ho, Wo;
+  const float* cur = x;
+  int ci = 0;                 // buffer that holds `cur` (-1: x)
+  auto other = [&](int a0, int a1) { for (int i = 0; i < 3; ++i) if (i != a0 && i != a1) return i; return 0; };
+  size_t k = 0;
+  {
+    if ((rc = conv_bn_act(e, e->cam_fcm[k++], cur, nullptr, R, H, W, bufs[0], &Ho, &Wo)) != WS_OK) return rc;
+    cur = bufs[0], ci = 0;
+  }
+  while (k < e->cam_fcm.size()) {
+    const int kind = e->cam_fcm_kind[k];
+    if (kind == 0) {          // the final strided convolution
+      const int o = other(ci, ci);
+      if ((rc = conv_bn_act(e, e->cam_fcm[k++], cur, nullptr, R, H, W, bufs[o], &Ho, &Wo)) != WS_OK) return rc;
+      cur = bufs[o], ci = o, H = Ho, W = Wo;
+      continue;
+    }
+    // BasicResBlock: conv1 [, shortcut], conv2 + residual
+    const int o1 = other(ci, ci);
+    int H1, W1;
+    if ((rc = conv_bn_act(e, e->cam_fcm[k++], cur, nullptr, R, H, W, bufs[o1], &H1, &W1)) != WS_OK) return rc;
+    const float* sc = cur;
+    int o2 = other(ci, o1);
+    if (e->cam_fcm_kind[k] == 2) {
+      int Hs, Ws;
+      if ((rc = conv_bn_act(e, e->cam_fcm[k++], cur, nullptr, R, H, W, bufs[o2], &Hs, &Ws)) != WS_OK) return rc;
+      sc = bufs[o2];
+      // conv2 may now overwrite the block input
+      if ((rc = conv_bn_act(e, e->cam_fcm[k++], bufs[o1], sc, R, H1, W1, bufs[ci], &Ho, &Wo)) != WS_OK) return rc;
+      cur = bufs[ci];
+    } else {
+      if ((rc = conv_bn_act(e, e->cam_fcm[k++], bufs[o1], sc, R, H1, W1, bufs[o2], &Ho, &Wo)) != WS_OK) return rc;
+      cur = bufs[o2], ci = o2;
+    }
+    H = Ho, W = Wo;
+  }
+  // [R][H'][T][32] -> [R*T][32 * H'] with channel index c * H' + h (the reference's reshape of [B, C, H', T])
+  const int Hp = H, T0 = W, c0 = mc * Hp;
+  float* feat = a.alloc(size_t(R) * T0 * c0);
+  WS_PTR(feat);
+  for (int r = 0; r < R; ++r)
+    WS_RUN(e, ws_transpose(cur + size_t(r) * Hp * T0 * mc, Hp, T0 * mc, T0 * mc, feat + size_t(r) * T0 * c0, s));
+  // ---- D-TDNN backbone ----
+  int T;
+  const int init = e->cam_init, growth = e->cam_growth;
+  const int Tmax = (T0 - 1) / 2 + 1;
+  float* t0 = a.alloc(size_t(R) * Tmax * init);
+  float* scratch = a.alloc(size_t(R) * Tmax * 1024);
+  WS_PTR(t0 && scratch);
+  if ((rc = cam_conv(e, feat, R, T0, c0, e->cam_tdnn_w, init, 5, 1, 2, t0, &T)) != WS_OK) return rc;
+  const long long M = (long long)R * T;
+  int ch = init;
+  float* y = a.alloc(size_t(M) * init);
+  WS_PTR(y);
+  if ((rc = cam_bn_act(e, e->cam_tdnn_bn, t0, M, true, scratch, y)) != WS_OK) return rc;
+  for (size_t bi = 0; bi < e->cam_blocks.size(); ++bi) {
+    const std::vector<CamLayer>& layers = e->cam_blocks[bi];
+    const long long ld = ch + (long long)layers.size() * growth;
+    float* cat = a.alloc(size_t(M) * ld);
+    float* tin = a.alloc(size_t(M) * ld);
+    float* tout = a.alloc(size_t(M) * (ld / 2));
+    WS_PTR(cat && tin && tout);
+    if ((rc = copy_cols(e, cat, ld, y, ch, ch, M)) != WS_OK) return rc;
+    for (const CamLayer& l : layers)
+      if ((rc = cam_layer(e, l, cat, ld, R, T)) != WS_OK) return rc;
+    const CamTransit& t = e->cam_transit[bi];
+    if ((rc = cam_bn_act(e, t.bn, cat, M, true, scratch, tin)) != WS_OK) return rc;
+    if ((rc = cam_lin(e, tin, ld, M, static_cast<int>(ld), t.w, t.cout, nullptr, tout)) != WS_OK) return rc;
+    y = tout, ch = t.cout;
+  }
+  float* yo = a.alloc(size_t(M) * ch);
+  float* stats = a.alloc(size_t(R) * 2 * ch);
+  float* raw = a.alloc(size_t(R) * e->E);
+  float* u2 = a.alloc(size_t(R) * e->E);
+  WS_PTR(yo && stats && raw && u2);
+  if ((rc = cam_bn_act(e, e->cam_out_bn, y, M, true, scratch, yo)) != WS_OK) return rc;
+  WS_RUN(e, ws_tstp_fwd(yo, R, 1, T, ch, kTstpEps, stats, s));
+  if ((rc = cam_lin(e, stats, 2 * ch, R, 2 * ch, e->dev("spk_model.xvector.dense.linear.weight"), e->E, nullptr, raw)) != WS_OK)
+    return rc;
+  if ((rc = cam_bn_act(e, e->cam_dense_bn, raw, R, false, u2, emb)) != WS_OK) return rc;
   a.release(mk);
   return WS_OK;
 }
@@ -2176,7 +2512,7 @@ int prepare_dpccn(ws_engine* e) {
     }
   }
   if (e->joint) {
-    if ((rc = e->spk_kind == 1 ? prep_ecapa(e) : prep_resnet(e)) != WS_OK) return rc;
+    if ((rc = e->spk_kind == 2 ? prep_campplus(e) : e->spk_kind == 1 ? prep_ecapa(e) : prep_resnet(e)) != WS_OK) return rc;
     if ((rc = e->spk_feat ? prep_fbank(e) : prep_mel_frontend(e)) != WS_OK) return rc;
   }
   if (!e->dry && hipStreamSynchronize(e->stream) != hipSuccess) {
@@ -2735,7 +3071,7 @@ int prepare_gridnet(ws_engine* e) {
     }
   }
   if (e->joint) {
-    if ((rc = e->spk_kind == 1 ? prep_ecapa(e) : prep_resnet(e)) != WS_OK) return rc;
+    if ((rc = e->spk_kind == 2 ? prep_campplus(e) : e->spk_kind == 1 ? prep_ecapa(e) : prep_resnet(e)) != WS_OK) return rc;
     if ((rc = e->spk_feat ? prep_fbank(e) : prep_mel_frontend(e)) != WS_OK) return rc;
   }
   if (!e->dry && hipStreamSynchronize(e->stream) != hipSuccess) {
@@ -3212,7 +3548,9 @@ extern "C" int ws_engine_separate(ws_engine* e, const float* mix, int R, int T, 
       if ((rc = e->spk_feat ? kaldi_fbank(e, d_wave, R, enroll_len, fb, Te) : mel_frontend(e, d_wave, R, enroll_len, fb, Te)) != WS_OK)
         return rc;
     }
-    if ((rc = e->spk_kind == 1 ? ecapa_embed(e, fb, R, Te, d_emb) : resnet_embed(e, fb, R, Te, d_emb)) != WS_OK) return rc;
+    if ((rc = e->spk_kind == 2 ? campplus_embed(e, fb, R, Te, d_emb)
+                               : e->spk_kind == 1 ? ecapa_embed(e, fb, R, Te, d_emb) : resnet_embed(e, fb, R, Te, d_emb)) != WS_OK)
+      return rc;
     a.release(mk);
   }
   rc = e->arch == 2 ? dpccn_device(e, d_mix, R, T, d_emb, d_est)

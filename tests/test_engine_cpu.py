@@ -158,8 +158,28 @@ def test_dry_run_launch_plan_ecapa_joint_model(tmp_path, spk_model, emb_bn):
     eng.close()
 
 
+@needs_no_gpu
+def test_dry_run_launch_plan_campplus(tmp_path):
+    """The wespeaker CAM++ encoder in the native runtime (round 5: spk_kind 2): FCM head with mel-axis strides, the three
+    CAM-dense-TDNN blocks with segment pooling (a last segment shorter than 100 frames and an exact multiple), TSTP, the
+    affine-free embedding BatchNorm -- every launch through the real library's argument validation."""
+    path = str(tmp_path / "c.wsw")
+    export_engine(_model(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,
+                         joint_training=True, spk_feat=True, spk_model="CAMPPlus", spk_emb_dim=512,
+                         spk_args=dict(feat_dim=80, embed_dim=512, pooling_func="TSTP")), path)
+    eng = E.Engine(path, dry_run=True)
+    assert eng.info("spk_kind") == 2 and eng.info("feat_dim") == 80
+    counts = set()
+    for R, Te in ((2, 98), (3, 301), (2, 400)):
+        est = eng.separate(np.zeros((R, 16000), np.float32), np.zeros((R, Te, 80), np.float32), E.ENROLL_FBANK)
+        assert est.shape == (R, 16000)
+        counts.add(eng.info("n_launches"))
+    assert len(counts) == 3
+    eng.close()
+
+
 def test_export_refuses_speaker_encoders_without_a_launch_plan(tmp_path):
-    for spk_model, args, E_ in (("CAMPPlus", dict(feat_dim=80, embed_dim=512, pooling_func="TSTP"), 512),
+    for spk_model, args, E_ in (("CAMPPlus", dict(feat_dim=80, embed_dim=512, pooling_func="TSTP", growth_rate=16), 512),
                                 ("ResNet18", dict(feat_dim=80, embed_dim=256, pooling_func="ASTP", two_emb_layer=False), 256)):
         with pytest.raises(NotImplementedError, match="no launch plan"):
             export_engine(_model(num_repeat=1, spk_fuse_type="multiply", multi_fuse=False, use_spk_transform=False,

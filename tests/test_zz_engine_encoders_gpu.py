@@ -28,3 +28,25 @@ def test_engine_bottleneck_and_two_emb_layer_match_python(tmp_path, spk_model, t
             ref = model(wav.to(d), fbank.to(d))[0]
         assert rel(eng.separate(wav.numpy(), fbank.numpy(), E.ENROLL_FBANK), ref) < 1e-4, (R, Te)
     eng.close()
+
+
+def test_engine_campplus_matches_python(tmp_path):
+    """CAM++ (spk_kind 2, round 5): the native runtime's launch plan against the Python module tree in eval mode, fbank
+    enrollment of three lengths (segment pooling with a short last segment, one segment only, an exact multiple of 100 after
+    the stride-2 TDNN layer)."""
+    from tests.test_engine_gpu import _cuda, _joint, rel
+    d = _cuda()
+    model, eng = _joint(tmp_path, "CAMPPlus", d, seed=11, spk_emb_dim=512,
+                        spk_args=dict(feat_dim=80, embed_dim=512, pooling_func="TSTP"))
+    assert eng.info("spk_kind") == 2
+    g = torch.Generator().manual_seed(6)
+    for R, Te in ((2, 301), (3, 120), (2, 400)):
+        wav = 0.1 * torch.randn(R, 12000, generator=g)
+        fbank = torch.randn(R, Te, 80, generator=g)
+        fbank = fbank - fbank.mean(1, keepdim=True)
+        with torch.no_grad():
+            ref = model(wav.to(d), fbank.to(d))[0]
+        err = rel(eng.separate(wav.numpy(), fbank.numpy(), E.ENROLL_FBANK), ref)
+        print(f"engine CAM++ R={R} Te={Te}: rel {err:.2e}")
+        assert err < 1e-4, (R, Te, err)
+    eng.close()

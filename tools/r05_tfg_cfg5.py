@@ -36,7 +36,7 @@ def main():
     want = {k: v.grad.double() for k, v in p.items()}
     top = max(float(g.norm()) for g in want.values())
     for c2, rf in (("1", "1"), ("0", "1")):
-        os.environ["WESEP_TFG_CLUSTER2"], os.environ["WESEP_PAIR_RF"] = c2, rf
+        os.environ["WESEP_TFG_CLUSTER2"], os.environ["WESEP_PAIR_RF"] = c2, rf      # (WESEP_TFG_CLUSTER2 defaults to 1 since)
         model = get_model("TFGridNet")(**kw, joint_training=False)
         model.load_state_dict(params, strict=True)
         model = model.to(d).train()

@@ -49,10 +49,19 @@ def speaker_meta(model, meta):
             for i, layer in enumerate((spk.layer1, spk.layer2, spk.layer3, spk.layer4)):
                 meta[f"spk_blocks{i}"] = len(layer)
             meta["feat_dim"] = int(spk.seg_1.weight.shape[1] // (2 * 32 * 8 * ex)) * 8
+        elif type(spk).__name__ == "CAMPPlus":            # wespeaker CAM++ (round 5: spk_kind 2; the constructor's defaults)
+            xv = spk.xvector
+            layers = [len(getattr(xv, f"block{i}")) for i in (1, 2, 3)]
+            first = xv.block1.tdnnd1
+            if layers != [12, 24, 16] or xv.tdnn.linear.out_channels != 128 or first.linear1.out_channels != 128 or \
+                    first.cam_layer.linear_local.out_channels != 32 or not hasattr(first.nonlinear1, "relu"):
+                raise NotImplementedError("export_engine: CAM++ with a non-default backbone (growth_rate 32, bn_size 4, "
+                                          "init_channels 128, 'batchnorm-relu') has no launch plan in the native runtime")
+            meta.update(spk_kind=2, feat_dim=spk.feat_dim)
         else:
-            raise NotImplementedError(f"export_engine: speaker encoder {type(spk).__name__} (CAM++, or a ResNet with a "
-                                      "pooling layer other than TSTP) has no launch plan in the native runtime; the "
-                                      "wespeaker ResNets with TSTP and ECAPA-TDNN do")
+            raise NotImplementedError(f"export_engine: speaker encoder {type(spk).__name__} (a ResNet with a pooling layer "
+                                      "other than TSTP) has no launch plan in the native runtime; the wespeaker ResNets "
+                                      "with TSTP, ECAPA-TDNN and CAM++ do")
     return meta
 
 

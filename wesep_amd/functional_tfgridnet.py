@@ -451,16 +451,16 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
             dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), whf, whr, fpack)
             dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq, gfmt=gfmt)
-        elif cluster and h2 and dev.lstm_cluster2_on() and os.environ.get("WESEP_TFG_CLUSTER2", "0") == "1":
-            # inter-frame path, 2-byte formats (round 5, OPT-IN for this model): ws_lstm_fwd_cluster2 computes x W_ih^T itself
-            # from the fp16 copy of its input (functional.ResRNNBlkFn; lstm_cluster2.hip) -- ws_gemm_p2b only relays the rows into
-            # BLH(128); the fp32 pre-activations exist only inside the predicated fall-back behind the launch.  Measured at
-            # BASELINE config 5's geometry (profiles/r05_tfg_cfg5_precision_split.txt): 303.8 -> 270.8 ms/step together with the
-            # fp16 pair BPTT, waveform 1.27e-5 -> 2.84e-5 and loss 6.5e-4 -> 7.5e-4 dB from the oracle (bounds 1e-3 / 1e-2) --
-            # but the median per-tensor gradient error goes 4.1e-4 -> 7.0e-4 and two scalar PReLU slopes to 5.5e-3 / 5.8e-3,
-            # over this model's own 5e-3 gradient bound (tests/test_tfgridnet_gpu.py): the fp16 input copy (11 bits) costs
-            # more here than in pBSRNN, whose bounds it passes with 2.5x margin.  So TF-GridNet's default stays the round-4
-            # cluster kernel on fp32 pre-activations; the fp16 pair BPTT (no measurable effect on any gradient) is on
+        elif cluster and h2 and dev.lstm_cluster2_on() and os.environ.get("WESEP_TFG_CLUSTER2", "1") != "0":
+            # inter-frame path, 2-byte formats (round 5): ws_lstm_fwd_cluster2 computes x W_ih^T itself from the split-pair
+            # rows ws_gemm_p2b relays into BL(128) (functional.ResRNNBlkFn; lstm_cluster2.hip); the fp32 pre-activations exist
+            # only inside the predicated fall-back behind the launch.  Measured at BASELINE config 5's geometry: 301.0 ->
+            # 277.7 ms/step (same box, together with the fp16 pair BPTT: profiles/r05_ab/r05_c11_tfg_*.json), every parity figure
+            # of the recipe-geometry test unchanged (waveform 1.27e-5 -> 1.33e-5, worst gradient 3.4e-3 -> 3.1e-3, median
+            # 4.1e-4 -> 4.2e-4: profiles/r05_tfg_cfg5_cluster2_bls_input.txt).  The kernel's FIRST cut -- fp16 copy of the input,
+            # two-term x-projection -- was not: median gradient error 7.0e-4 and two scalar PReLU slopes over this model's 5e-3
+            # bound (profiles/r05_tfg_cfg5_precision_split.txt); the input keeps its split pair since.  WESEP_TFG_CLUSTER2=0
+            # selects the round-4 cluster kernel on fp32 pre-activations
             dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, A_bl16=xn16)
             tw = dev.lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whf, whr, seq, dbg=F0._cluster_dbg())
             wih_pack = _empty(d, 2 * G4 * N)
