@@ -522,6 +522,21 @@ def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None, d
     return flags[ncl * 8:ncl * 8 + 1]
 
 
+_FALLBACK_SCRATCH = {}
+
+
+def fallback_scratch(device, nfloats: int) -> torch.Tensor:
+    """The fp32 pre-activation buffer of the predicated streaming fall-back behind ws_lstm_fwd_cluster2 (per device and
+    stream; grow-only).  After a clean cluster launch nobody touches it, so the six time-view layers of a step share one
+    buffer that is allocated once -- as a fresh 4.2 GB torch allocation per layer it made the caching allocator hunt for a
+    block that size twelve times per SSA step."""
+    key = (device.type, device.index, L.stream_ptr().value if device.type == "cuda" and torch.cuda.is_available() else 0)
+    buf = _FALLBACK_SCRATCH.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = _FALLBACK_SCRATCH[key] = torch.empty(nfloats, device=device, dtype=torch.float32)
+    return buf[:nfloats]
+
+
 def lstm_cluster2_on() -> bool:
     """Second-generation cluster forward (lstm_cluster2.hip, ABI v17: fp16 h, x-projection fused in from the split-pair
     normalised input, data-tagged hand-off) for the time view of the 2-byte gate formats; WESEP_LSTM_CLUSTER2=0 keeps the

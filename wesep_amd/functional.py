@@ -436,7 +436,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, stats=stats, gamma=norm_w,
                          beta=norm_b, stat_map=smap, A_bl16=xn16)
             tw = dev.lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whf, whr, seq, dbg=_cluster_dbg())
-            pre = _empty(d, nb, 32 * 2 * G4)       # (scratch of the fall-back: untouched after a clean launch)
+            pre = dev.fallback_scratch(d, nb * 32 * 2 * G4)       # (untouched after a clean launch; one buffer per stream)
             dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=W("wih"), N=2 * G4, C_out=pre, bias=bcat, stats=stats,
                          gamma=norm_w, beta=norm_b, stat_map=smap, run_if=tw)
             dev.lstm_fwd(gates, cbuf, hcat, W("hh")[0], seq, lmode, run_if=tw, gfmt=gfmt, gates_in=pre)

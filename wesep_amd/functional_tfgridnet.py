@@ -465,7 +465,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             tw = dev.lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whf, whr, seq, dbg=F0._cluster_dbg())
             wih_pack = _empty(d, 2 * G4 * N)
             dev.pack_w(wcat, 2 * G4, N, N, wih_pack, order=0)
-            pre = _empty(d, nb, 32 * 2 * G4)          # (scratch of the fall-back: untouched after a clean launch)
+            pre = dev.fallback_scratch(d, nb * 32 * 2 * G4)      # (untouched after a clean launch; one buffer per stream)
             dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=wih_pack, N=2 * G4, C_out=pre, bias=bcat, run_if=tw)
             dev.lstm_fwd(gates, cbuf, hcat, pack_f, seq, lmode, run_if=tw, gfmt=gfmt, gates_in=pre)
             del pre
