@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 17
+#define WS_ABI_VERSION 18
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -379,11 +379,20 @@ typedef struct ws_lstm_pair_args {
                            v_mfma_f32_32x32x16_bf16 per product (wpack from ws_lstm_pack_pair); 1 (WS_GATES_H2F only): the
                            STORED scaled-fp16 d(gates) as one operand of v_mfma_f32_32x32x16_f16 against W_hh as fp16 hi / lo
                            of 256 w (wpack from ws_lstm_pack_pair_f16): two MFMAs per product, what the kernel writes is
-                           what its own recurrence and both consumers read                                         */
+                           what its own recurrence and both consumers read.  2 (ABI v18; WS_GATES_H2F only): the same
+                           product with the lo plane of W_hh as block-scaled FP8 (wpack from ws_lstm_pack_pair_f8): 16
+                           instead of 22 significant bits of every weight, and the whole of W_hh stays on the compute
+                           unit for the launch (hi plane in registers, lo plane in LDS) -- nothing of it is streamed  */
 } ws_lstm_pair_args;
 int ws_lstm_pack_pair(const float* whh_f, const float* whh_r, float* pack, void* stream);
 /* ABI v17: the pack of rfmt = 1 (same size and unit order, fp16 hi / lo of 256 w; |w| < 255) */
 int ws_lstm_pack_pair_f16(const float* whh_f, const float* whh_r, float* pack, void* stream);
+/* ABI v18: the pack of rfmt = 2 (same size: 32 blocks of 64 KB, one per (direction, half, wave); per block the fp16 hi plane
+ * of 256 w exactly as ws_lstm_pack_pair_f16 writes it (32 KB), then the lo plane as OCP e4m3 codes of (256 w - hi) / S, 8
+ * bytes per lane and k-step (16 KB), then S as one float at byte 48 K; S = 2^(e - 20) for the block's max |256 w| in
+ * [2^(e-1), 2^e): the largest possible remainder maps to 256 -- e4m3 has no saturation, it overflows to NaN above 448.
+ * |w| < 255.) */
+int ws_lstm_pack_pair_f8(const float* whh_f, const float* whh_r, float* pack, void* stream);
 int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream);
 /* wcat[2][4H][N] <- (w_ih_f, w_ih_r);  bcat[2][4H] <- b_ih + b_hh per direction             */
 int ws_lstm_cat_ih(const float* wih_f, const float* wih_r, const float* bih_f, const float* bhh_f,

@@ -183,6 +183,13 @@ def _recur_bwd(act, cs, dh_in, whf, whr, scale=1.0, rq=False):
     """rq: the recurrent product takes the STORED scaled-fp16 d(gates) (ws_lstm_pair_args.rfmt = 1)."""
     S, L = act.shape[:2]
     dpre = torch.zeros_like(act)
+    if _probe() & 32768:      # (numerics probe: W_hh of the BPTT as fp16 hi + fp8 (e4m3) lo of 256 w -- ~15 bits)
+        def q8(W):
+            s = 256.0 * W
+            hi = s.half().float()
+            lo = ((s - hi) * 4096.0).to(torch.float8_e4m3fn).float() / 4096.0
+            return (hi + lo) / 256.0
+        whf, whr = q8(whf), q8(whr)
     for d, W in ((0, whf), (1, whr)):
         order = list(range(L)) if d == 0 else list(range(L - 1, -1, -1))
         dh_rec, dc = torch.zeros(S, H), torch.zeros(S, H)
@@ -308,7 +315,7 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0, dbg_buf=Non
         if status is not None:
             status.fill_(1)
         return torch.ones(1, dtype=torch.int32)
-    _bwd_into(gates, cbuf, dhcat, *_whh_from_pack(wpack), sm, gfmt, dgates, amax, rq=rfmt == 1)
+    _bwd_into(gates, cbuf, dhcat, *_whh_from_pack(wpack), sm, gfmt, dgates, amax, rq=rfmt != 0)
     return torch.zeros(1, dtype=torch.int32)
 
 

@@ -190,19 +190,62 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
     # ---- rfmt = 1 (ABI v17): the recurrent product takes the STORED fp16 d(gates) (one operand of the fp16 MFMA, W_hh as
     # fp16 hi / lo of 256 w, two terms).  Every step's rounding (2^-12 relative, random) now travels down the recurrence, so
     # the statement is a tolerance against the three-term kernel, plus determinism and in-place == out-of-place
-    pp16 = torch.empty(L.LSTM_PACK_FLOATS, device=d)
-    dev.lstm_pack_pair(whf, whr, pp16, f16=True)
-    r_in, r_in2, r_out_g, r_out_d = gh.clone(), gh.clone(), gh.clone(), torch.zeros_like(gh)
-    for gates_, dg_ in ((r_in, None), (r_in2, None), (r_out_g, r_out_d)):
-        tw = dev.lstm_bwd_pair(gates_, cbuf, dh, pp16, seq, status=st, gfmt=L.GATES_H2F, dgates=dg_, amax=amax, rfmt=1)
-        assert int(tw.item()) == 0
-    torch.cuda.synchronize()
-    assert torch.equal(bits(r_in), bits(r_in2))
-    assert torch.equal(bits(r_out_g), bits(gh)) and torch.equal(bits(r_out_d), bits(r_in))
-    got1 = r_in.reshape(-1)[: ref.numel() // 2].view(torch.float16).view(dg.shape).float() / S
-    assert bool(torch.isfinite(got1).all())
-    assert float((got1 - dg).norm() / dg.norm()) < 6e-4, float((got1 - dg).norm() / dg.norm())
-    assert float((got1 - dg).abs().max() / dg.abs().max()) < 2e-3
+    # rfmt = 2 (ABI v18): the same with the lo plane of W_hh as block-scaled FP8 (16 instead of 22 bits of every weight;
+    # all of W_hh stays on the CU): the same bounds, and next to rfmt = 1 (same B operand, weights 2^-16 apart)
+    by_rfmt = {}
+    for rfmt in (1, 2):
+        pp16 = torch.empty(L.LSTM_PACK_FLOATS, device=d)
+        dev.lstm_pack_pair(whf, whr, pp16, f16=rfmt)
+        r_in, r_in2, r_out_g, r_out_d = gh.clone(), gh.clone(), gh.clone(), torch.zeros_like(gh)
+        for gates_, dg_ in ((r_in, None), (r_in2, None), (r_out_g, r_out_d)):
+            tw = dev.lstm_bwd_pair(gates_, cbuf, dh, pp16, seq, status=st, gfmt=L.GATES_H2F, dgates=dg_, amax=amax, rfmt=rfmt)
+            assert int(tw.item()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(bits(r_in), bits(r_in2))
+        assert torch.equal(bits(r_out_g), bits(gh)) and torch.equal(bits(r_out_d), bits(r_in))
+        got1 = r_in.reshape(-1)[: ref.numel() // 2].view(torch.float16).view(dg.shape).float() / S
+        assert bool(torch.isfinite(got1).all())
+        e2, emax = float((got1 - dg).norm() / dg.norm()), float((got1 - dg).abs().max() / dg.abs().max())
+        print(f"pair rfmt {rfmt}: d(gates) vs the three-term kernel rel-L2 {e2:.2e}, max {emax:.2e}")
+        assert e2 < 6e-4 and emax < 2e-3, (rfmt, e2, emax)
+        by_rfmt[rfmt] = got1
+    e12 = float((by_rfmt[2] - by_rfmt[1]).norm() / by_rfmt[1].norm())
+    print(f"pair rfmt 2 vs 1: rel-L2 {e12:.2e}")
+    assert e12 < 4e-4, e12
+
+
+def test_pair_pack_fp8_lo_plane_reconstructs_the_weights():
+    """ws_lstm_pack_pair_f8: per (direction, half, wave) block of 64 KB -- fp16 hi of 256 w (32 KB, the fp16 pack's order),
+    e4m3 codes of (256 w - hi) / S (16 KB), S = 2^(e - 20) for the block's max |256 w| in [2^(e-1), 2^e) (one float at
+    48 KB).  Decoded on the host: hi + S * lo = 256 w to 2^-15 of each weight (plus the block's code floor), no code is
+    NaN, the largest code magnitude is <= 256."""
+    from wesep_amd import dev
+    d = _cuda()
+    g = torch.Generator().manual_seed(5)
+    for scale in (0.06, 0.9, 3e-3):
+        whf, whr = (scale * torch.randn(4 * H, H, generator=g)).to(d), (scale * torch.randn(4 * H, H, generator=g)).to(d)
+        whf[7, 9] = 0.0
+        p16, p8 = torch.zeros(L.LSTM_PACK_FLOATS, device=d), torch.zeros(L.LSTM_PACK_FLOATS, device=d)
+        dev.lstm_pack_pair(whf, whr, p16, f16=1)
+        dev.lstm_pack_pair(whf, whr, p8, f16=2)
+        torch.cuda.synchronize()
+        b16 = p16.view(torch.uint8).reshape(32, 65536).cpu()
+        b8 = p8.view(torch.uint8).reshape(32, 65536).cpu()
+        assert torch.equal(b8[:, :32768], b16[:, :32768])                      # the hi plane IS the fp16 pack's
+        hi = b8[:, :32768].contiguous().view(torch.float16).float().reshape(32, 32, 64, 8)
+        lo16 = b16[:, 32768:].contiguous().view(torch.float16).float().reshape(32, 32, 64, 8)
+        codes = b8[:, 32768:49152].contiguous().view(torch.float8_e4m3fn).float().reshape(32, 32, 64, 8)
+        Sb = b8[:, 49152:49156].contiguous().view(torch.float32).reshape(32)
+        assert bool(torch.isfinite(codes).all()) and float(codes.abs().max()) <= 256.0
+        w256 = hi + lo16                                                       # 22 bits of 256 w
+        m = w256.abs().reshape(32, -1).amax(1)
+        assert bool(((m >= Sb * 2.0 ** 19) & (m < Sb * 2.0 ** 20)).all()), (m, Sb)
+        err = (hi + codes * Sb.view(32, 1, 1, 1) - w256).abs()
+        # (+ 2^-24: the REFERENCE's lo is an fp16, a subnormal one for small weights -- the codes come from the fp32 remainder)
+        bound = w256.abs() * 2.0 ** -14 + Sb.view(32, 1, 1, 1) * 2.0 ** -10 + lo16.abs() * 2.0 ** -10 + 2.0 ** -24
+        assert bool((err <= bound).all()), float((err / bound).max())
+        print(f"fp8 lo plane, |w| ~ {scale}: worst error {float((err / w256.abs().clamp_min(1e-30)).max()):.2e} of the weight; "
+              f"rel-L2 {float(err.norm() / w256.norm()):.2e}; scales 2^{int(torch.log2(Sb.min()))}..2^{int(torch.log2(Sb.max()))}")
 
 
 @pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37))])

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round 5, call 15: rfmt 2 with the next step's cache lines touched before the MFMA phase
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+O=gpurun_out
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 300 python -m pytest tests/test_gates_h2_gpu.py -q -x -s -k "fp8 or bptt or pair" > $O/r05_c15_pair.log 2>&1
+echo "== pair tests exit $?"; grep -E "rfmt|fp8 lo|passed|failed|Error|assert " $O/r05_c15_pair.log | cut -c1-300 | tail -16
+WESEP_PAIR_RF=2 timeout 300 python -m pytest tests/test_bptt_survival_gpu.py tests/test_cluster2_gpu.py -q -x > $O/r05_c15_survival.log 2>&1
+echo "== survival / cluster2 tests (rf2) exit $?"; tail -3 $O/r05_c15_survival.log | cut -c1-300
+timeout 200 python tools/r05_recur_probe.py > $O/r05_c15_recur_probe.txt 2>&1
+echo "== probe exit $?"; grep -E "^pair BPTT|status" $O/r05_c15_recur_probe.txt; tail -16 $O/r05_c15_recur_probe.txt | cut -c1-200
+run() {  # name, env...
+  local name=$1; shift
+  env "$@" timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/r05_c15_bench_$name.json 2> $O/r05_c15_bench_$name.err
+  echo "== bench $name exit $?: $(python -c "import json,sys;d=json.loads(open('$O/r05_c15_bench_$name.json').read().strip().splitlines()[-1]);print(d['ms_per_step'], d['value'], d['kernel_ms_per_step'], d['roofline']['frac'])" 2>&1)"; tail -1 $O/r05_c15_bench_$name.err | cut -c1-200
+}
+run rf1 WESEP_PAIR_RF=1
+run rf2 WESEP_PAIR_RF=2
+run rf2_b WESEP_PAIR_RF=2
+WESEP_PAIR_RF=2 timeout 400 python -m pytest tests/test_bsrnn_gpu.py -q -s -k "full_size_row" > $O/r05_c15_parity_rf2.log 2>&1
+echo "== rf2 full-size parity exit $?"; grep -E "full-size|passed|failed|worst" $O/r05_c15_parity_rf2.log | cut -c1-300

@@ -94,6 +94,8 @@ def main():
     pp, pp16 = torch.empty(L.LSTM_PACK_FLOATS, device=d), torch.empty(L.LSTM_PACK_FLOATS, device=d)
     dev.lstm_pack_pair(whf, whr, pp)
     dev.lstm_pack_pair(whf, whr, pp16, f16=True)
+    pp8 = torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack_pair(whf, whr, pp8, f16=2)
     gq = dev.blh_gates_unpack(gh, nb).view_as(pre).contiguous()
     dgo = torch.zeros_like(gh)
     work = gq.clone()
@@ -104,7 +106,8 @@ def main():
     t0 = timeit(lambda: work.copy_(gq))
     t = timeit(f32) - t0
     print(f"pair BPTT, fp32 gates in place, bf16x3       {t:7.3f} ms  {t * 1e3 / Tf:6.2f} us/step", flush=True)
-    for rf, pk, nm, dbg in ((0, pp, "bf16x3 recurrence", 0), (1, pp16, "fp16x2 recurrence, tagged", 0)):
+    for rf, pk, nm, dbg in ((0, pp, "bf16x3 recurrence", 0), (1, pp16, "fp16x2 recurrence, tagged", 0),
+                            (2, pp8, "fp16x2, FP8 lo plane resident", 0)):
         t = timeit(lambda: dev.lstm_bwd_pair(gh, cbuf, dh, pk, seq, status=st, gfmt=L.GATES_H2F, dgates=dgo, amax=amax, rfmt=rf,
                                              dbg=dbg))
         print(f"pair BPTT, unorm16 in / fp16 out, {nm}  {t:7.3f} ms  {t * 1e3 / Tf:6.2f} us/step", flush=True)
@@ -113,7 +116,7 @@ def main():
         return
     names = ["loop top", "cell backward done", "past S1", "MFMA loop done", "X: flagged / O: partial in LDS",
              "X: next loads requested", "X: partner's flag seen", "X: gather arrived"]
-    for rf, pk, nm, xdbg in ((0, pp, "bf16x3, flag hand-off", 0), (1, pp16, "fp16x2 tagged", 0)):
+    for rf, pk, nm, xdbg in ((0, pp, "bf16x3, flag hand-off", 0), (1, pp16, "fp16x2 tagged", 0), (2, pp8, "fp16x2 tagged, FP8 lo resident", 0)):
         for rep in range(2):
             dbuf = torch.zeros(Tf * 2 * 8 * 2, device=d)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 17
+ABI_VERSION = 18
 GATES_F32, GATES_H2, GATES_H2S, GATES_H2F = 0, 1, 2, 3     # WS_GATES_* (wesep_hip.h): storage of the saved gates / d(gates)
 DGATES_EXP = 8             # WS_DGATES_EXP: WS_GATES_H2F puts max |d(hcat)| into [2^8, 2^9)
 
@@ -178,6 +178,7 @@ _SIGS = {
     "ws_lstm_fwd_cluster2": (_i, [C.POINTER(LstmCluster2Args), _p]),
     "ws_lstm_pack_pair": (_i, [_p, _p, _p, _p]),
     "ws_lstm_pack_pair_f16": (_i, [_p, _p, _p, _p]),
+    "ws_lstm_pack_pair_f8": (_i, [_p, _p, _p, _p]),
     "ws_lstm_bwd_pair": (_i, [C.POINTER(LstmPairArgs), _p]),
     "ws_lstm_cat_ih": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "ws_pack_w": (_i, [_p, _i, _i, _ll, _i, _i, _p, _p]),

@@ -96,6 +96,61 @@ __global__ void lstm_pack_pair_f16_kernel(const float* __restrict__ whh_f, const
   }
 }
 
+// RF = 2 (ABI v18): the lo plane as FP8 (OCP e4m3) codes of (256 w - hi) / S, S a power of two per (d, hs, w) block -- the
+// 32 k-steps of one wave -- chosen from the block's max |256 w| so that the largest possible lo (half an fp16 ulp of the
+// largest hi) maps to 256 (e4m3 overflows to NaN above 448, it does not saturate: profiles/r05_fp8_probe.txt).  Block of
+// 64 KB as before: fp16 hi plane at 0 (32 KB, the RF = 1 order), codes at 32 KB (unit = 8 bytes per lane and k-step, 16 KB),
+// S as one float at 48 KB.  hi + lo carries ~16 significant bits of every weight (the bf16 pair of round 4: 16); the
+// 48 KB per wave that remain ALL stay on the CU for the whole launch (hi in registers, lo in LDS + 16 registers): nothing of
+// W_hh is streamed any more.  One workgroup per block (it needs the block's max first).
+__global__ __launch_bounds__(512) void lstm_pack_pair_f8_kernel(const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                                 char* __restrict__ out) {
+  __shared__ float red[8];
+  const int blk = blockIdx.x, w = blk & 7, hs = (blk >> 3) & 1, d = blk >> 4;
+  const float* W = d ? whh_r : whh_f;
+  const int mt = w < 4 ? 4 * (1 - hs) + w : 4 * hs + (w - 4);
+  const int tid = threadIdx.x;
+  float v0[16], v1[16], m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, ks = pi >> 8;
+    const int u = 32 * mt + (lane & 31), kl = 16 * ks + 8 * (lane >> 5) + 2 * j2;
+    const int row = (kl >> 7) * LH + 128 * hs + (kl & 127);   // (kl even: kl + 1 stays inside the same gate's 128 rows)
+    v0[i] = 256.f * W[row * LH + u];
+    v1[i] = 256.f * W[(row + 1) * LH + u];
+    m = fmaxf(m, fmaxf(fabsf(v0[i]), fabsf(v1[i])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i]);
+  // m in [2^(e-1), 2^e): |lo| <= 2^(e-12); S = 2^(e-20) puts that at 256.  Biased exponent of S = that of m - 19.
+  const int eb = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
+  const float S = (eb > 19 && eb < 255) ? __builtin_bit_cast(float, (unsigned)(eb - 19) << 23) : 1.f;
+  char* ob = out + (long long)blk * (64 * 1024);
+  if (tid == 0) *reinterpret_cast<float*>(ob + 48 * 1024) = S;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, ks = pi >> 8;
+    const _Float16 h0 = (_Float16)v0[i], h1 = (_Float16)v1[i];
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<f16x2*>(ob + ks * 1024 + lane * 16 + j2 * 4) = f16x2{h0, h1};
+    const s16x2 c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(s16x2{0, 0}, v0[i] - (float)h0, v1[i] - (float)h1, S, false);
+    *reinterpret_cast<short*>(ob + 32 * 1024 + ks * 512 + lane * 8 + j2 * 2) = c[0];
+  }
+}
+
+extern "C" int ws_lstm_pack_pair_f8(const float* whh_f, const float* whh_r, float* pack, void* stream) {
+  WS_REQUIRE(whh_f && whh_r && pack, "ws_lstm_pack_pair_f8: null pointer");
+  hipLaunchKernelGGL(lstm_pack_pair_f8_kernel, dim3(32), dim3(512), 0, (hipStream_t)stream, whh_f, whh_r,
+                     reinterpret_cast<char*>(pack));
+  return ws_check_launch("ws_lstm_pack_pair_f8");
+}
+
 extern "C" int ws_lstm_pack_pair_f16(const float* whh_f, const float* whh_r, float* pack, void* stream) {
   WS_REQUIRE(whh_f && whh_r && pack, "ws_lstm_pack_pair_f16: null pointer");
   hipLaunchKernelGGL(lstm_pack_pair_f16_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, whh_f, whh_r,
@@ -152,12 +207,18 @@ __device__ __forceinline__ f32x16 pair_mfma(const bf16x8& a, const bf16x8& b, co
 // instead of two, and the LDS that frees holds four more k-steps of the lo plane (160 instead of 192 KB per step from L2).
 // Settled on the CPU emulation first (tools/r04_h2_numerics.py, probe bit 4096: no measurable change of any gradient at
 // the fixture size or at 501 frames).
+// RF = 2 (ABI v18, ws_lstm_pack_pair_f8): RF = 1 with the lo plane as FP8 codes and a block scale -- k-steps 0..26 of the lo
+// plane in 108 KB of LDS, 27..31 in 10 registers (the ring's 32 are gone), converted to fp16 fragments on the way
+// into the MFMA (v_cvt_scalef32_pk_f16_fp8 at scale 1: codes are exact in fp16; the block scale multiplies the lo
+// accumulator once per step).  No load of W_hh inside the step loop: what the side stream's GEMMs do to L2 no longer
+// reaches the MFMA phase.  Emulation first (probe 32768: no gradient moves, fixture size and 501 frames).
 template <int V, int GF = 0, int RF = 0>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pair_args p) {
   static_assert(RF == 0 || GF == WS_GATES_H2F, "the fp16 recurrence takes the scaled-fp16 d(gates) of WS_GATES_H2F");
   constexpr int PAIR_LDSK = pair_ldsk<RF>::value;
   __shared__ __attribute__((aligned(16))) __bf16 bimg[RF ? 1 : 2][SQ * PR_ROW];  // [part][seq][local gate col] 65 / 33 KB
-  __shared__ __attribute__((aligned(16))) bf16x8 whl[8 * PAIR_LDSK * 64];   // lo fragments of k-steps 0..7 (0..11), 64 / 96 KB
+  constexpr int LDSK8 = 27;   // RF = 2: k-steps of the 8-byte lo fragments in LDS (108 KB: what 160 KB leave); 5 in registers
+  __shared__ __attribute__((aligned(16))) bf16x8 whl[RF == 2 ? 4 * LDSK8 * 64 : 8 * PAIR_LDSK * 64];   // lo fragments, 64 / 96 / 108 KB
   __shared__ __attribute__((aligned(16))) f32x4 rec[2][512];                // the other role's partial dh, 16 KB
   const int ntile = (p.nseq + SQ - 1) / SQ, npair = 2 * ntile;
   // block -> (pair, member): members of a pair are 8 blocks apart (same XCD under round-robin dispatch)
@@ -204,9 +265,22 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
 #pragma unroll
   for (int ks = 0; ks < 32; ++ks) wh[ks] = *reinterpret_cast<const bf16x8*>(wbase + ks * 1024 + lane * 16);
   bf16x8* wlds = &whl[w * PAIR_LDSK * 64 + lane];
+  u32x2* wlds8 = reinterpret_cast<u32x2*>(whl) + w * LDSK8 * 64 + lane;   // RF = 2: 8-byte units
+  u32x2 wq[RF == 2 ? 32 - LDSK8 : 1];
+  float wS = 1.f;
+  if constexpr (RF == 2) {
 #pragma unroll
-  for (int ks = 0; ks < PAIR_LDSK; ++ks)
-    wlds[ks * 64] = *reinterpret_cast<const bf16x8*>(wbase + 32 * 1024 + ks * 1024 + lane * 16);
+    for (int ks = 0; ks < LDSK8; ++ks)
+      wlds8[ks * 64] = *reinterpret_cast<const u32x2*>(wbase + 32 * 1024 + ks * 512 + lane * 8);
+#pragma unroll
+    for (int ks = 0; ks < 32 - LDSK8; ++ks)
+      wq[ks] = *reinterpret_cast<const u32x2*>(wbase + 32 * 1024 + (LDSK8 + ks) * 512 + lane * 8);
+    wS = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(wbase + 48 * 1024)));
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < PAIR_LDSK; ++ks)
+      wlds[ks * 64] = *reinterpret_cast<const bf16x8*>(wbase + 32 * 1024 + ks * 1024 + lane * 16);
+  }
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase) + 32 * 1024, 0, 32 * 1024, 0x00020000);
   const int wlane = lane * 16;
@@ -227,6 +301,24 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
     n_dh[e] = bld(crs(p.dhcat, t), cvo, 2 * e * 512);
     const int tp = d == 0 ? max(t - 1, 0) : min(t + 1, L - 1);  // clamped; masked at its use
     n_cp[e] = bld(crs(p.cbuf, tp), cvo, 2 * e * 512);
+  };
+  // the same twelve addresses as load_step(t, 0 / 1), one dword per lane, normal cache policy (the loads proper are nt),
+  // destination: one register nobody reads.  Inline asm: the compiler keeps no count of these loads (its own vmcnt waits
+  // stay correct -- returns are in order and these are OLDER than every load it waits for) and `sink` stays allocated
+  // until the asm at the end of the next cell backward, by when the loads proper -- younger -- have been consumed.
+  unsigned sink = 0u;
+  auto touch = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(sink) : "v"(voff), "s"(r), "s"(soff));
+  };
+  auto touch_step = [&](int t) {
+    const int tp = d == 0 ? max(t - 1, 0) : min(t + 1, L - 1);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) touch(hrs(t), gvo >> 1, (g * 64 + 2 * e) * 256);
+      touch(crs(p.dhcat, t), cvo, 2 * e * 512);
+      touch(crs(p.cbuf, tp), cvo, 2 * e * 512);
+    }
   };
   {
     const int t0 = d == 0 ? L - 1 : 0;
@@ -301,18 +393,30 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       emit(pg, 2);
       emit(po, 3);
     }
+    if constexpr (RF == 2) asm volatile("" : "+v"(sink));   // (the touches of the previous step have returned: see touch)
     TS(1);
     __syncthreads();  // S1: the d(gates) image of this step is complete; rec is consumed
     TS(2);
 
+    // RF = 2: the cache lines of the next step's saved state are TOUCHED here, a whole MFMA phase before the loads proper
+    // (one dword per lane at the loads' own addresses, all into one throw-away register): an X-wave's poll for the partner's
+    // partial sits behind those loads in the wave's in-order return queue and sat out their HBM latency (1.4 of 5.3 us per
+    // step, profiles/r05_c13_recur_probe.txt); behind L2 hits it waits 0.6.  The twelve extra VMEM instructions per wave cost
+    // the MFMA phase 0.3 - 0.8 us (profiles/r05_c17_recur_probe.txt), the step gains 0.6: 2.56 -> 2.39 ms per launch alone,
+    // 0.5 - 1 ms per training step (r05_ab/r05_c1[67]_*).  Tried instead: three touches per chunk over the first half of the
+    // MFMA loop (the same within noise); requesting the state ITSELF here (32 registers: no spills once the lo ring is gone,
+    // but the B fragments lose their double buffer -- faster alone, 0.9 ms per step slower in the step, r05_c14).
+    if constexpr (RF == 2) touch_step(tn);
     // ---- partial dh^T [32 units of this wave's m-tile][32 sequences] = W_hh^T slice * dgates^T ----------------------
     if (xrole) __builtin_amdgcn_s_setprio(1);
     bf16x8 wl[2][PAIR_RING];
+    if constexpr (RF != 2) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int f = 0; f < PAIR_RING; ++f)
-        wl[s][f] = wload(wrs, wlane + f * 1024, zo + (CH0 + s) * (PAIR_RING * 1024));
+        for (int f = 0; f < PAIR_RING; ++f)
+          wl[s][f] = wload(wrs, wlane + f * 1024, zo + (CH0 + s) * (PAIR_RING * 1024));
+    }
     const __bf16* bhi = &bimg[0][n * PR_ROW + 8 * half];
     const __bf16* blo = &bimg[RF ? 0 : 1][n * PR_ROW + 8 * half];
     f32x16 acc0, acc1;
@@ -325,6 +429,20 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       for (int f = 0; f < PAIR_RING; ++f) {
         const int ks = PAIR_RING * ch + f;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bhi + 16 * ks);
+        if constexpr (RF == 2) {
+          // (the compiler converts the five register-resident fragments ONCE, in front of the step loop: 20 registers instead
+          //  of 10.  Pinning the codes with an empty asm so that they are converted every step measured 11 % slower alone.)
+          const u32x2 c8 = ks < LDSK8 ? wlds8[ks * 64] : wq[ks >= LDSK8 ? ks - LDSK8 : 0];
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          const f16x2 a0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[0], 1.f, false);
+          const f16x2 a1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[0], 1.f, true);
+          const f16x2 a2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[1], 1.f, false);
+          const f16x2 a3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[1], 1.f, true);
+          const f16x8 al8 = {a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
+          acc0 = pair_mfma<1>(wh[ks], bh, acc0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al8, __builtin_bit_cast(f16x8, bh), acc1, 0, 0, 0);
+          continue;
+        }
         const bf16x8 al = ch < CH0 ? wlds[ks * 64] : wl[s][f];
         if constexpr (RF != 0) {
           acc0 = pair_mfma<1>(wh[ks], bh, acc0);
@@ -342,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
           acc0 = mfma32(wh[ks], bl, acc0);
         }
       }
-      if (ch >= CH0 && ch + 2 < NCH) {
+      if (RF != 2 && ch >= CH0 && ch + 2 < NCH) {
 #pragma unroll
         for (int f = 0; f < PAIR_RING; ++f) wl[s][f] = wload(wrs, wlane + f * 1024, zo + (ch + 2) * (PAIR_RING * 1024));
       }
@@ -355,8 +473,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
     f32x4 sum[4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4)
-      sum[q4] = f32x4{acc0[4 * q4] + acc1[4 * q4], acc0[4 * q4 + 1] + acc1[4 * q4 + 1], acc0[4 * q4 + 2] + acc1[4 * q4 + 2],
-                      acc0[4 * q4 + 3] + acc1[4 * q4 + 3]};
+      sum[q4] = f32x4{acc0[4 * q4] + wS * acc1[4 * q4], acc0[4 * q4 + 1] + wS * acc1[4 * q4 + 1],
+                      acc0[4 * q4 + 2] + wS * acc1[4 * q4 + 2], acc0[4 * q4 + 3] + wS * acc1[4 * q4 + 3]};
     if (xrole) {
       __builtin_amdgcn_s_setprio(0);
       u32x4 pv[4];
@@ -483,8 +601,8 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2F && (a->gfmt != WS_GATES_H2S || a->dgates) &&
                  (a->gfmt != WS_GATES_H2F || a->amax),
              "ws_lstm_bwd_pair: gfmt %d (WS_GATES_H2S needs dgates, WS_GATES_H2F needs amax)", a->gfmt);
-  WS_REQUIRE(a->rfmt == 0 || (a->rfmt == 1 && a->gfmt == WS_GATES_H2F),
-             "ws_lstm_bwd_pair: rfmt %d (1 = fp16 recurrence: WS_GATES_H2F only)", a->rfmt);
+  WS_REQUIRE(a->rfmt == 0 || ((a->rfmt == 1 || a->rfmt == 2) && a->gfmt == WS_GATES_H2F),
+             "ws_lstm_bwd_pair: rfmt %d (1 / 2 = fp16 recurrence, fp16 + fp16 / fp16 + fp8 weights: WS_GATES_H2F only)", a->rfmt);
   const int npair = 2 * ((a->nseq + SQ - 1) / SQ);
   static int cus = 0;      // same part on every device of a node; queried once
   if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 0;
@@ -494,11 +612,18 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(a->flags, 0, ((size_t)npair * 8 + 8) * sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_pair: hipMemsetAsync failed");
-  if (a->rfmt == 1) {   // data-tagged hand-off: every dword of the exchange slots starts with tag 1 (LSB set)
+  if (a->rfmt != 0) {   // data-tagged hand-off: every dword of the exchange slots starts with tag 1 (LSB set)
     e = hipMemsetAsync(a->xchg, 0x01, (size_t)npair * 4 * PR_XSLOT, s);
     WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_pair: hipMemsetAsync failed");
   }
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
+  if (a->rfmt == 2) {
+    if (a->dbg & 8) hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2F, 2>), dim3(grid), dim3(512), 0, s, *a);
+    else if (a->dbg & 2048) hipLaunchKernelGGL((lstm_bwd_pair_kernel<2048, WS_GATES_H2F, 2>), dim3(grid), dim3(512), 0, s, *a);
+    else hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, WS_GATES_H2F, 2>), dim3(grid), dim3(512), 0, s, *a);
+    ws_prof_end(WS_PROF_LSTM_BWD, s);
+    return ws_check_launch("ws_lstm_bwd_pair");
+  }
   if (a->rfmt == 1) {
     if (a->dbg & 8) hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2F, 1>), dim3(grid), dim3(512), 0, s, *a);
     else if (a->dbg & 2048) hipLaunchKernelGGL((lstm_bwd_pair_kernel<2048, WS_GATES_H2F, 1>), dim3(grid), dim3(512), 0, s, *a);

@@ -598,7 +598,8 @@ def lstm_pair_ok(sm: SeqMap, device) -> bool:
 def lstm_pack_pair(whh_f, whh_r, pack, f16=False):
     for n, t in (("whh_f", whh_f), ("whh_r", whh_r), ("pack", pack)):
         _chk(t, n)
-    fn = L.lib().ws_lstm_pack_pair_f16 if f16 else L.lib().ws_lstm_pack_pair
+    # f16: the pair BPTT's rfmt -- 0 bf16 hi / lo, 1 fp16 hi / lo of 256 w, 2 fp16 hi + FP8 lo (block-scaled) of 256 w
+    fn = (L.lib().ws_lstm_pack_pair, L.lib().ws_lstm_pack_pair_f16, L.lib().ws_lstm_pack_pair_f8)[int(f16)]
     L.check(fn(_p(whh_f), _p(whh_r), _p(pack), L.stream_ptr()), "ws_lstm_pack_pair")
 
 
@@ -622,7 +623,7 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg
     a.dbg_buf = C.c_void_p(dbg_buf.data_ptr()) if dbg_buf is not None else None
     a.gfmt, a.dgates = gfmt, _p(dgates)
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
-    a.rfmt = rfmt           # 1: fp16 recurrence (wpack from lstm_pack_pair(..., f16=True); WS_GATES_H2F only)
+    a.rfmt = rfmt           # 1 / 2: fp16 recurrence (wpack from lstm_pack_pair(..., f16=rfmt); WS_GATES_H2F only)
     _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * (ALG_LSTM_UNITS or L.LSTM_H),
              2 * sm.nseq * sm.L * 2 * 4 * (ALG_LSTM_UNITS or L.LSTM_H) ** 2)
     L.check(L.lib().ws_lstm_bwd_pair(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_pair")

@@ -192,10 +192,14 @@ def tnb_a16() -> bool:
 
 
 def pair_rfmt(gfmt) -> int:
-    """Arithmetic of the pair BPTT's recurrent product (ws_lstm_pair_args.rfmt, ABI v17): 1 (default with WS_GATES_H2F) = the
-    stored scaled-fp16 d(gates) x fp16 hi / lo W_hh on the fp16 MFMA, two terms; WESEP_PAIR_RF=0 keeps the three-term
-    split-bf16 product of rounds 3-4."""
-    return 1 if gfmt == L.GATES_H2F and os.environ.get("WESEP_PAIR_RF", "1") != "0" else 0
+    """Arithmetic of the pair BPTT's recurrent product (ws_lstm_pair_args.rfmt): 2 (default with WS_GATES_H2F, ABI v18) = the
+    stored scaled-fp16 d(gates) x W_hh as fp16 hi + block-scaled FP8 lo on the fp16 MFMA, two terms, all of W_hh resident on
+    the compute unit; WESEP_PAIR_RF=1: fp16 hi / lo, the lo plane streamed (ABI v17); 0: the three-term split-bf16 product of
+    rounds 3-4."""
+    rf = int(os.environ.get("WESEP_PAIR_RF", "2"))
+    if rf not in (0, 1, 2):
+        raise ValueError(f"WESEP_PAIR_RF={rf}: 0, 1 or 2")
+    return rf if gfmt == L.GATES_H2F else 0
 
 
 def wgrad_overlap() -> bool:
@@ -698,9 +702,9 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
             pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
             dev.lstm_pack(*W("whh"), pack_f, pack_b, lmode)
             return pack_f, pack_b
-        if kind in ("hhp", "hhp16"):      # hhp16: fp16 hi / lo of 256 w (ws_lstm_pack_pair_f16, the rfmt = 1 pair BPTT)
+        if kind in ("hhp", "hhp16"):      # hhp16: fp16 hi + fp16 / FP8 lo of 256 w (the rfmt = 1 / 2 pair BPTT)
             pack = _empty(d, L.LSTM_PACK_FLOATS)
-            dev.lstm_pack_pair(*W("whh"), pack, f16=kind == "hhp16")
+            dev.lstm_pack_pair(*W("whh"), pack, f16=pair_rfmt(L.GATES_H2F) if kind == "hhp16" else 0)
             return pack
         if kind == "fused":
             fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)

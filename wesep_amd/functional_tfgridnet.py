@@ -505,7 +505,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             ppack = None
             if kind == "pair":
                 ppack = _empty(d, L.LSTM_PACK_FLOATS)
-                dev.lstm_pack_pair(whf, whr, ppack, f16=bool(F0.pair_rfmt(gfmt)))     # (rfmt 1: fp16 hi / lo of 256 w)
+                dev.lstm_pack_pair(whf, whr, ppack, f16=F0.pair_rfmt(gfmt))     # (rfmt 1 / 2: fp16 hi, fp16 / FP8 lo of 256 w)
             bw_packs = (wlt_pack, wct_pack, ppack)
         ctx.bw_packs = bw_packs
         ctx.save_for_backward(gates, cbuf, hcat, xn16 if a16 else xn, wcat, pack_b, lw, whf, whr, hcat16)
