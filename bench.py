@@ -14,7 +14,8 @@ the matrix cores as split pairs, fp32 accumulation everywhere --
     fused x-projection, BPTT), the output projections, d(hcat), the proj weight gradients, BN / mask-MLP / FiLM GEMMs;
   * "fp16x2": one operand as ONE fp16 value (11 bits: h in (-1, 1), the scaled d(gates)), the weight as fp16 hi + lo, TWO
     fp16 MFMAs per product: the recurrent products of the time-view recurrences (round 5: cluster forward -- whose fused
-    x-projection stays bf16x3 --, pair BPTT) and d(xn);
+    x-projection stays bf16x3 --, pair BPTT) and d(xn).  In the pair BPTT the weight's lo part is block-scaled FP8 (e4m3,
+    converted to fp16 on the way into the MFMA: 16 significant bits of the weight instead of 22; functional.pair_rfmt = 2);
   * "fp16x1": both operands single fp16, ONE MFMA per product: the LSTM weight gradients (scaled-fp16 d(gates) x fp16 copies
     of [xn | h]);
 saved state in 2 bytes (unorm16 gates, scaled-fp16 d(gates)), c / h / activations in fp32.  Holds the reference's fp32
@@ -346,11 +347,14 @@ def main():
         pass
 
     census = mfma_terms_census()
+    from wesep_amd.functional import pair_rfmt
+    F_pair_rfmt = pair_rfmt(gfmt)
     tv, bv = census["terms_per_product"]["time"], census["terms_per_product"]["band"]
     dom_terms = 0.5 * ((tv["bptt"] + bv["bptt"]) if dom == "lstm_bwd" else (tv["recur_fwd"] + bv["recur_fwd"]))
     arith = ("bf16x3 (band-view recurrences, x-projections, projections, d(hcat), BN / mask GEMMs) + fp16x2 (recurrent "
              "products of the time-view cluster forward and pair BPTT, d(xn)) + fp16x1 (LSTM weight gradients); 2-byte "
-             "saved gates / d(gates); fp32 accumulate")
+             "saved gates / d(gates); fp32 accumulate"
+             + ("; pair BPTT: W_hh as fp16 hi + block-scaled FP8 lo" if F_pair_rfmt == 2 else ""))
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
