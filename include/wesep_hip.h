@@ -234,7 +234,12 @@ typedef struct ws_lstm_args {
    * (the predicated fall-back behind ws_lstm_bwd_pair).                                                    */
   const float* gates_in;
   float* dgates;
-  int gfmt, pad_;
+  int gfmt;
+  int rfmt;              /* ABI v18 (the former pad_: 0 = every earlier behaviour), ws_lstm_bwd with mode WS_LSTM_BF16X3_BLK and
+                            WS_GATES_H2F only: 2 = the recurrent product d(h) = d(gates) W_hh on v_mfma_f32_32x32x16_f16 with the
+                            STORED scaled-fp16 d(gates) as its one operand against W_hh as fp16 hi + scaled-FP8 lo of 256 w --
+                            `wpack` from ws_lstm_pack_bwd_f8: two MFMAs per product instead of three, 96 instead of 128 KB of
+                            weights streamed per wave and step (the arithmetic of ws_lstm_pair_args.rfmt = 2)           */
   const unsigned* amax;  /* WS_GATES_H2F, backward: max |dhcat| of this launch as float bits (see WS_GATES_H2F) */
 } ws_lstm_args;
 /* Storage format of the saved activated gates and of d(pre-activation gates) on the blocked layout (ABI v15).
@@ -280,6 +285,10 @@ typedef struct ws_lstm_args {
  * (fp32 for WS_LSTM_F32_*, bf16 hi/lo pairs for WS_LSTM_BF16X3; same byte size).           */
 int ws_lstm_pack(const float* whh_f, const float* whh_r, float* pack_fwd, float* pack_bwd,
                  int mode, void* stream);
+/* ABI v18: the BPTT pack of ws_lstm_args.rfmt = 2 (WS_LSTM_PACK_FLOATS floats like the others; per (direction, wave) region
+ * of 128 KB: 16 chunks of 6 KB = four fp16 hi fragments of 256 w + four fragments of e4m3 codes of the remainder over the
+ * scale of their group of 8 k-steps; the eight scales as floats at byte 96 K).  |w| < 255.                       */
+int ws_lstm_pack_bwd_f8(const float* whh_f, const float* whh_r, float* pack_bwd, void* stream);
 int ws_lstm_fwd(const ws_lstm_args* a, void* stream);
 /* On exit gates holds dL/d(pre-activation gates).                                           */
 int ws_lstm_bwd(const ws_lstm_args* a, void* stream);

@@ -243,13 +243,13 @@ def make_lstm_fwd(plain_fwd):
 
 
 def make_lstm_bwd(plain_bwd):
-    def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode=3, gfmt=0, dgates=None, run_if=None, amax=None):
+    def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode=3, gfmt=0, dgates=None, run_if=None, amax=None, rfmt=0):
         if _skip(run_if):
             return
         if mode not in (4, 5):
             return plain_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode)
         whf, whr = _whh_from_pack(wpack)
-        _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt, dgates, amax)
+        _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt, dgates, amax, rq=rfmt != 0)
     return lstm_bwd
 
 

@@ -185,6 +185,30 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
     bound = dg.abs() * (2.0 ** -11 + 2.0 ** -16) + (2.0 ** -24) / S      # half an fp16 ulp (+ subnormal step) + the pair's 2^-17
     assert bool((err <= bound).all()), float((err / bound).max())
     assert float((got - dg).norm() / dg.norm()) < 3e-4
+    if kind == "blk32":
+        # ---- ws_lstm_args.rfmt = 2 (ABI v18): the streaming BPTT's recurrent product on the stored fp16 d(gates) x W_hh as fp16
+        # hi + scaled-FP8 lo (ws_lstm_pack_bwd_f8): the pair kernel's rfmt 2 arithmetic in the stream-fed kernel; same statements
+        pb8 = torch.zeros(L.LSTM_PACK_FLOATS, device=d)
+        dev.lstm_pack_bwd_f8(whf, whr, pb8)
+        s_in, s_in2, s_out_g, s_out_d = gh.clone(), gh.clone(), gh.clone(), torch.zeros_like(gh)
+        for gates_, dg_ in ((s_in, None), (s_in2, None), (s_out_g, s_out_d)):
+            dev.lstm_bwd(gates_, cbuf, hcat, dh, pb8, seq, mode, gfmt=L.GATES_H2F, dgates=dg_, amax=amax, rfmt=2)
+        torch.cuda.synchronize()
+        assert torch.equal(bits(s_in), bits(s_in2))
+        assert torch.equal(bits(s_out_g), bits(gh)) and torch.equal(bits(s_out_d), bits(s_in))
+        got2 = s_in.reshape(-1)[: ref.numel() // 2].view(torch.float16).view(dg.shape).float() / S
+        assert bool(torch.isfinite(got2).all())
+        e2, emax = float((got2 - dg).norm() / dg.norm()), float((got2 - dg).abs().max() / dg.abs().max())
+        print(f"streaming BPTT rfmt 2: d(gates) vs the three-term kernel rel-L2 {e2:.2e}, max {emax:.2e}")
+        assert e2 < 6e-4 and emax < 2e-3, (e2, emax)
+        # the pack: hi plane = fp16(256 w), codes finite and <= 256, scales bracket each group's maximum
+        raw = pb8.view(torch.uint8).reshape(16, 131072).cpu()
+        codes = torch.stack([raw[:, c * 6144 + 4096:(c + 1) * 6144] for c in range(16)], 1).contiguous().view(torch.float8_e4m3fn).float()
+        assert bool(torch.isfinite(codes).all()) and float(codes.abs().max()) <= 256.0
+        Sg = raw[:, 98304:98304 + 32].contiguous().view(torch.float32)                     # [16 (d, w)][8 groups]
+        hi8 = torch.stack([raw[:, c * 6144:c * 6144 + 4096] for c in range(16)], 1).contiguous().view(torch.float16).float()
+        m = hi8.reshape(16, 8, -1).abs().amax(2)                                           # two chunks per group
+        assert bool(((m >= Sg * 2.0 ** 19 * (1 - 2.0 ** -10)) & (m <= Sg * 2.0 ** 20)).all())
     if kind != "pair":
         return
     # ---- rfmt = 1 (ABI v17): the recurrent product takes the STORED fp16 d(gates) (one operand of the fp16 MFMA, W_hh as

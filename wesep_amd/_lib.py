@@ -89,7 +89,7 @@ class LstmArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "dhcat", "wpack")] + \
                [(n, _ll) for n in ("sq_s1", "sq_s2", "step_rows")] + \
                [(n, _i) for n in ("nseq", "sq_div", "L", "mode")] + [("run_if", _p)] + \
-               [("gates_in", _p), ("dgates", _p), ("gfmt", _i), ("pad_", _i), ("amax", _p)]          # ABI v15
+               [("gates_in", _p), ("dgates", _p), ("gfmt", _i), ("rfmt", _i), ("amax", _p)]          # ABI v15; rfmt: v18
 
 
 class SeqMapC(C.Structure):
@@ -179,6 +179,7 @@ _SIGS = {
     "ws_lstm_pack_pair": (_i, [_p, _p, _p, _p]),
     "ws_lstm_pack_pair_f16": (_i, [_p, _p, _p, _p]),
     "ws_lstm_pack_pair_f8": (_i, [_p, _p, _p, _p]),
+    "ws_lstm_pack_bwd_f8": (_i, [_p, _p, _p, _p]),
     "ws_lstm_bwd_pair": (_i, [C.POINTER(LstmPairArgs), _p]),
     "ws_lstm_cat_ih": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "ws_pack_w": (_i, [_p, _i, _i, _ll, _i, _i, _p, _p]),

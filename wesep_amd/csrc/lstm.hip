@@ -77,6 +77,13 @@ __global__ void lstm_pack_kernel(const float* __restrict__ whh_f, const float* _
   }
 }
 
+int ws_launch_lstm_pack_bwd_f8(const float* whh_f, const float* whh_r, float* pack_bwd, hipStream_t s);
+extern "C" int ws_lstm_pack_bwd_f8(const float* whh_f, const float* whh_r, float* pack_bwd, void* stream) {
+  WS_REQUIRE(whh_f && whh_r && pack_bwd, "ws_lstm_pack_bwd_f8: null pointer");
+  ws_launch_lstm_pack_bwd_f8(whh_f, whh_r, pack_bwd, (hipStream_t)stream);
+  return ws_check_launch("ws_lstm_pack_bwd_f8");
+}
+
 extern "C" int ws_lstm_pack(const float* whh_f, const float* whh_r, float* pack_fwd,
                             float* pack_bwd, int mode, void* stream) {
   WS_REQUIRE(whh_f && whh_r && pack_fwd && pack_bwd, "ws_lstm_pack: null pointer");
@@ -393,6 +400,8 @@ static int lstm_check(const ws_lstm_args* a, bool bwd, const char* who) {
              a->gfmt);
   WS_REQUIRE(a->gfmt != WS_GATES_H2S || !bwd || a->dgates, "%s: WS_GATES_H2S needs dgates", who);
   WS_REQUIRE(a->gfmt == WS_GATES_F32 || ((a->mode >> 8) & 7) == 0, "%s: probe builds are WS_GATES_F32 only", who);
+  WS_REQUIRE(a->rfmt == 0 || (a->rfmt == 2 && bwd && a->mode == WS_LSTM_BF16X3_BLK && a->gfmt == WS_GATES_H2F),
+             "%s: rfmt %d (2 = fp16 recurrence on fp16 + FP8 weights: ws_lstm_bwd, WS_LSTM_BF16X3_BLK, WS_GATES_H2F only)", who, a->rfmt);
   return WS_OK;
 }
 

@@ -77,6 +77,56 @@ int ws_launch_lstm_pack_bf16(const float* whh_f, const float* whh_r, float* pack
   return 0;
 }
 
+// BPTT pack of ws_lstm_args.rfmt = 2 (ABI v18): W_hh as fp16 hi of 256 w + OCP e4m3 codes of the remainder over a power-of-two
+// scale -- what lstm_pair.hip's rfmt 2 keeps resident, here as a STREAM of 96 instead of 128 KB per wave and step.  Per (d, w)
+// region of 128 KB (the bf16 pack's): 16 chunks of 4 k-steps, chunk c at c * 6 KB = [4 hi fragments of 1 KB: lane * 16 bytes]
+// [4 code fragments of 512 B: lane * 8 bytes]; at byte 96 K eight floats, the scale of each GROUP of 8 k-steps (two chunks):
+// S = 2^(e - 20) for the group's max |256 w| in [2^(e-1), 2^e), so that the largest possible remainder maps to 256 (e4m3
+// returns NaN above 448).  One workgroup per (d, w, group).  Element order as the bf16 BPTT pack above.
+__global__ __launch_bounds__(512) void lstm_pack_bwd_f8_kernel(const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                               char* __restrict__ pb) {
+  __shared__ float red[8];
+  const int grp = blockIdx.x & 7, w = (blockIdx.x >> 3) & 7, d = blockIdx.x >> 6;
+  const float* W = d ? whh_r : whh_f;
+  const int tid = threadIdx.x;
+  float v0[4], v1[4], m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {   // 8 k-steps x 64 lanes x 4 element pairs = 2048 pairs, 4 per thread
+    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, ks = 8 * grp + (pi >> 8);
+    const int row = 16 * ks + 8 * (lane >> 5) + 2 * j2, u = 32 * w + (lane & 31);
+    v0[i] = 256.f * W[row * LH + u];
+    v1[i] = 256.f * W[(row + 1) * LH + u];
+    m = fmaxf(m, fmaxf(fabsf(v0[i]), fabsf(v1[i])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i]);
+  const int eb = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
+  const float S = (eb > 19 && eb < 255) ? __builtin_bit_cast(float, (unsigned)(eb - 19) << 23) : 1.f;
+  char* ob = pb + (long long)(d * 8 + w) * (128 * 1024);
+  if (tid == 0) reinterpret_cast<float*>(ob + 96 * 1024)[grp] = S;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, ks = 8 * grp + (pi >> 8);
+    const _Float16 h0 = (_Float16)v0[i], h1 = (_Float16)v1[i];
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    char* cb = ob + (ks >> 2) * 6144;
+    *reinterpret_cast<f16x2*>(cb + (ks & 3) * 1024 + lane * 16 + j2 * 4) = f16x2{h0, h1};
+    const s16x2 c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(s16x2{0, 0}, v0[i] - (float)h0, v1[i] - (float)h1, S, false);
+    *reinterpret_cast<short*>(cb + 4096 + (ks & 3) * 512 + lane * 8 + j2 * 2) = c[0];
+  }
+}
+
+int ws_launch_lstm_pack_bwd_f8(const float* whh_f, const float* whh_r, float* pack_bwd, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_pack_bwd_f8_kernel, dim3(128), dim3(512), 0, s, whh_f, whh_r, reinterpret_cast<char*>(pack_bwd));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward recurrence
 // ---------------------------------------------------------------------------------------------
@@ -266,9 +316,14 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
 // GF (BLK only): WS_GATES_H2: unorm16 gates in, bf16 d(gates) out -- in place on the BLH buffer, or to p.dgates (BLH) when
 // given, which leaves the saved gates intact (the predicated fall-back behind ws_lstm_bwd_pair); WS_GATES_H2S: unorm16
 // gates in, d(gates) as BLS pairs to p.dgates
-template <bool BLK, int DBG, int GF = 0>
+// RF = 2 (ws_lstm_args.rfmt, ABI v18; BLK and WS_GATES_H2F only): the recurrent product on v_mfma_f32_32x32x16_f16 with the STORED
+// scaled-fp16 d(gates) as its one B operand (one LDS image plane) against W_hh as fp16 hi + scaled-FP8 lo of 256 w
+// (lstm_pack_bwd_f8_kernel): two MFMAs per product instead of three and 96 instead of 128 KB streamed per wave and step; the
+// codes become fp16 fragments on the way in (v_cvt_scalef32_pk_f16_fp8 with the group's scale: no separate accumulator scale).
+template <bool BLK, int DBG, int GF = 0, int RF = 0>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_args p) {
-  __shared__ __attribute__((aligned(16))) __bf16 dgl[2][SQ * DROW];  // [part][seq][gate col] 129 KB
+  static_assert(RF == 0 || (BLK && GF == WS_GATES_H2F), "the fp16 recurrence takes the scaled-fp16 d(gates) of WS_GATES_H2F");
+  __shared__ __attribute__((aligned(16))) __bf16 dgl[RF ? 1 : 2][SQ * DROW];  // [part][seq][gate col] 129 / 65 KB
   if (p.run_if && *p.run_if == 0u) return;  // predicated fall-back launch (wesep_hip.h): uniform
   const int d = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -313,11 +368,28 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.wpack) + (long long)(d * 8 + w) * (64 * 2 * 64 * 4), 0, 64 * 2 * 1024, 0x00020000);
   const int wlane = lane * 16;
-  bf16x8 wr[2][8];
+  bf16x8 wr[2][RF ? 4 : 8];
+  u32x2 wq[2][RF ? 4 : 1];   // RF = 2: the FP8 codes of the slot's four k-steps
+  float wS[RF ? 8 : 1];      // RF = 2: scale per group of 8 k-steps (uniform)
+  auto wfill = [&](int s, int chunk, int zo) {   // ring slot s <- chunk (4 k-steps) of the stream
+    if constexpr (RF != 0) {
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+      for (int q = 0; q < 4; ++q) {
+        wr[s][q] = wload(wrs, wlane + q * 1024, zo + chunk * 6144);
+        wq[s][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8 + q * 512, zo + chunk * 6144 + 4096, 0));
+      }
+    } else {
 #pragma unroll
-    for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
+      for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + chunk * 8192 + (f >> 2) * 4096);
+    }
+  };
+  wfill(0, 0, 0);
+  wfill(1, 1, 0);
+  if constexpr (RF != 0) {
+    const float* st = p.wpack + (long long)(d * 8 + w) * (64 * 2 * 64 * 4) + 96 * 256;
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8) wS[g8] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st[g8])));
+  }
 
   gcell n_i[4], n_f[4], n_g[4], n_o[4];
   f32x4 n_dh[4], n_cp[4], c_cur[4], dc[4];  // [run]
@@ -356,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
     int zo = 0;  // see wload()
     asm volatile("" : "+s"(zo));
     __bf16* dhi = &dgl[0][l31 * DROW + ubase];
-    __bf16* dlo = &dgl[1][l31 * DROW + ubase];
+    __bf16* dlo = &dgl[RF ? 0 : 1][l31 * DROW + ubase];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 pi, pf, pg, po;
@@ -380,6 +452,12 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
       // split pair (BLS) that the weight-gradient and d(x) GEMMs consume
       const bool st = !(DBG & 1) || step == L - 1;
       auto emit = [&](const f32x4& v, int g) {
+        if constexpr (RF != 0) {
+          const u32x2 code = enc_f16x4(v);   // what goes to HBM IS the B operand
+          *reinterpret_cast<u32x2*>(dhi + 256 * g + 8 * j) = code;
+          if (st) bst8(code, ors(t), glane >> 1, (g * 64 + 2 * j) * 256);
+          return;
+        }
         bf16x4 hi, lo;
         split4(v, hi, lo);
         *reinterpret_cast<bf16x4*>(dhi + 256 * g + 8 * j) = hi;
@@ -400,8 +478,9 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
     __syncthreads();
 
     const __bf16* bhi = &dgl[0][l31 * DROW + 8 * half];
-    const __bf16* blo = &dgl[1][l31 * DROW + 8 * half];
+    const __bf16* blo = &dgl[RF ? 0 : 1][l31 * DROW + 8 * half];
     f32x16 acc0;  // one accumulator: the other wave of the SIMD fills the dependent-issue gaps
+    f32x16 acc1;  // (RF = 2: the lo terms)
 #pragma unroll
     for (int ch = 0; ch < 16; ++ch) {
       const int s = ch & 1;
@@ -409,25 +488,42 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
       for (int q = 0; q < 4; ++q) {
         const int ks = 4 * ch + q;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bhi + 16 * ks);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(blo + 16 * ks);
-        if (ks == 0) {
+        if constexpr (RF != 0) {
+          typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          const float sg = wS[ch >> 1];
+          const u32x2 c8 = wq[s][q];
+          const f16x2 a0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[0], sg, false);
+          const f16x2 a1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[0], sg, true);
+          const f16x2 a2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[1], sg, false);
+          const f16x2 a3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[1], sg, true);
+          const f16x8 al8 = {a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
+          const f16x8 b16 = __builtin_bit_cast(f16x8, bh), ah16 = __builtin_bit_cast(f16x8, wr[s][q]);
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc0 = mfma32(wr[s][2 * q], bh, zero);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah16, b16, ks == 0 ? zero : acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al8, b16, ks == 0 ? zero : acc1, 0, 0, 0);
         } else {
-          acc0 = mfma32(wr[s][2 * q], bh, acc0);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(blo + 16 * ks);
+          if (ks == 0) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc0 = mfma32(wr[s][2 * q], bh, zero);
+          } else {
+            acc0 = mfma32(wr[s][2 * q], bh, acc0);
+          }
+          acc0 = mfma32(wr[s][2 * q + 1], bh, acc0);
+          acc0 = mfma32(wr[s][2 * q], bl, acc0);
         }
-        acc0 = mfma32(wr[s][2 * q + 1], bh, acc0);
-        acc0 = mfma32(wr[s][2 * q], bl, acc0);
       }
       const int cn = (ch + 2) & 15;  // wraps into the next step
-      if (!(DBG & 4)) {
-#pragma unroll
-        for (int f = 0; f < 8; ++f)
-          wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + cn * 8192 + (f >> 2) * 4096);
-      }
+      if (!(DBG & 4)) wfill(s, cn, zo);
       __builtin_amdgcn_sched_barrier(0);
     }
-    dhr = acc0;
+    if constexpr (RF != 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dhr[i] = (acc0[i] + acc1[i]) * (1.f / 256.f);   // the fp16 weights are 256 w (exact to undo)
+    } else {
+      dhr = acc0;
+    }
     __syncthreads();
   }
 }
@@ -459,6 +555,10 @@ int ws_launch_lstm_fwd_bf16(const ws_lstm_args* a, hipStream_t s) {
 
 int ws_launch_lstm_bwd_bf16(const ws_lstm_args* a, hipStream_t s) {
   dim3 grid((a->nseq + SQ - 1) / SQ, 2), block(512);
+  if (a->rfmt == 2) {   // (lstm_check: WS_LSTM_BF16X3_BLK + WS_GATES_H2F only)
+    hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2>), grid, block, 0, s, *a);
+    return 0;
+  }
   WS_DBG_DISPATCH(lstm_bwd_bf16_kernel)
   return 0;
 }

@@ -342,6 +342,13 @@ def lstm_pack(whh_f, whh_r, pack_fwd, pack_bwd, mode=L.LSTM_BF16X3):
                                  L.stream_ptr()), "ws_lstm_pack")
 
 
+def lstm_pack_bwd_f8(whh_f, whh_r, pack_bwd):
+    """BPTT pack of lstm_bwd(..., rfmt=2): fp16 hi + scaled-FP8 lo of 256 w (ws_lstm_pack_bwd_f8)."""
+    for n, t in (("whh_f", whh_f), ("whh_r", whh_r), ("pack_bwd", pack_bwd)):
+        _chk(t, n)
+    L.check(L.lib().ws_lstm_pack_bwd_f8(_p(whh_f), _p(whh_r), _p(pack_bwd), L.stream_ptr()), "ws_lstm_pack_bwd_f8")
+
+
 def lstm_cat_ih(wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, n_in, wcat, bcat):
     for t in (wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, wcat, bcat):
         _chk(t, "lstm_cat_ih arg")
@@ -372,7 +379,7 @@ def blh_floats(nblocks: int, C_: int) -> int:
 
 
 def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None, run_if=None, gfmt=0, gates_in=None, dgates=None,
-               amax=None):
+               amax=None, rfmt=0):
     for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("wpack", wpack), ("dhcat", dhcat),
                  ("gates_in", gates_in), ("dgates", dgates)):
         _chk(t, n)
@@ -381,7 +388,7 @@ def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None, run_if=No
     a.sq_s1, a.sq_s2, a.step_rows = sm.s1, sm.s2, sm.step_rows
     a.nseq, a.sq_div, a.L, a.mode = sm.nseq, sm.div, sm.L, mode
     a.run_if = C.c_void_p(run_if.data_ptr()) if run_if is not None else None
-    a.gates_in, a.dgates, a.gfmt = _p(gates_in), _p(dgates), gfmt
+    a.gates_in, a.dgates, a.gfmt, a.rfmt = _p(gates_in), _p(dgates), gfmt, rfmt
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
     return a
 
@@ -393,11 +400,13 @@ def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, run_if=No
     L.check(L.lib().ws_lstm_fwd(C.byref(a), L.stream_ptr()), "ws_lstm_fwd")
 
 
-def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, gfmt=0, dgates=None, run_if=None, amax=None):
+def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, gfmt=0, dgates=None, run_if=None, amax=None,
+             rfmt=0):
     """run_if (blocked-layout modes): 1-element int32 device tensor; the launch is a no-op unless it is non-zero at
     kernel start -- the predicated fall-back behind lstm_bwd_pair.  dgates: out-of-place d(gates) (required for
-    GATES_H2S; optional BLH buffer for GATES_H2, which then leaves the saved gates intact)."""
-    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat, gfmt=gfmt, dgates=dgates, run_if=run_if, amax=amax)
+    GATES_H2S; optional BLH buffer for GATES_H2, which then leaves the saved gates intact).  rfmt = 2 (LSTM_BF16X3_BLK with
+    GATES_H2F only): fp16 recurrence on fp16 + FP8 weights, wpack from lstm_pack_bwd_f8."""
+    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat, gfmt=gfmt, dgates=dgates, run_if=run_if, amax=amax, rfmt=rfmt)
     # per (position, direction, unit): read 4 gates + c + dh, write 4 d(gates); 2 * 4H * H MACs per position
     if run_if is None:
         _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * (ALG_LSTM_UNITS or L.LSTM_H),

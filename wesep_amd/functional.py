@@ -202,6 +202,16 @@ def pair_rfmt(gfmt) -> int:
     return rf if gfmt == L.GATES_H2F else 0
 
 
+def band_rfmt(gfmt, lmode) -> int:
+    """Arithmetic of the streaming BPTT's recurrent product (ws_lstm_args.rfmt, ABI v18): WESEP_BAND_RF=2 (opt-in) = the stored
+    scaled-fp16 d(gates) x W_hh as fp16 hi + scaled-FP8 lo, two MFMAs per product and three quarters of the weight stream;
+    32-sequence blocked kernels with WS_GATES_H2F only.  Default 0: the three-term split-bf16 product."""
+    rf = int(os.environ.get("WESEP_BAND_RF", "0"))
+    if rf not in (0, 2):
+        raise ValueError(f"WESEP_BAND_RF={rf}: 0 or 2")
+    return rf if gfmt == L.GATES_H2F and lmode == L.LSTM_BF16X3_BLK else 0
+
+
 def wgrad_overlap() -> bool:
     """Weight-gradient GEMMs of the blocked ResRNN on a side stream (default on; WESEP_WGRAD_OVERLAP=0
     keeps everything on the current stream)."""
@@ -487,6 +497,8 @@ class ResRNNBlkFn(torch.autograd.Function):
                 W("hhp16" if pair_rfmt(gfmt) else "hhp")
             if ctx.bptt == "stream" or (ctx.bptt == "pair" and h2):
                 W("hh")     # (the pair BPTT's predicated streaming fall-back of the 2-byte formats)
+            if ctx.bptt == "stream" and band_rfmt(gfmt, lmode):
+                W("hh8")
         # (with the fp16 copies the backward never reads the split-pair xn again: its 2-byte copy is saved instead)
         ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn16 if a16 else xn, wcat, norm_w, norm_b, pw, whf, whr, hcat16)
         ctx.a16 = a16
@@ -599,8 +611,9 @@ class ResRNNBlkFn(torch.autograd.Function):
             # streaming BPTT (band view): bf16 d(gates) in place over the unorm16 gates (H2) / split pairs to their own
             # buffer (H2S)
             dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else gates
-            dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode, gfmt=gfmt,
-                         dgates=dg if gfmt == L.GATES_H2S else None, amax=amax)
+            brf = band_rfmt(gfmt, ctx.lmode)
+            dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh8") if brf else W("hh")[1], seq, ctx.lmode, gfmt=gfmt,
+                         dgates=dg if gfmt == L.GATES_H2S else None, amax=amax, rfmt=brf)
         if _h2_probe() & 2 and gfmt == L.GATES_F32:
             _probe_round(gates, "bf16", packed=True)
         if _h2_probe() & 32 and gfmt == L.GATES_F32 and not torch.cuda.is_available():
@@ -702,6 +715,10 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
             pack_f, pack_b = _empty(d, L.LSTM_PACK_FLOATS), _empty(d, L.LSTM_PACK_FLOATS)
             dev.lstm_pack(*W("whh"), pack_f, pack_b, lmode)
             return pack_f, pack_b
+        if kind == "hh8":                 # BPTT pack of the streaming kernel's rfmt 2 (fp16 hi + scaled-FP8 lo of 256 w)
+            pack = _empty(d, L.LSTM_PACK_FLOATS)
+            dev.lstm_pack_bwd_f8(*W("whh"), pack)
+            return pack
         if kind in ("hhp", "hhp16"):      # hhp16: fp16 hi + fp16 / FP8 lo of 256 w (the rfmt = 1 / 2 pair BPTT)
             pack = _empty(d, L.LSTM_PACK_FLOATS)
             dev.lstm_pack_pair(*W("whh"), pack, f16=pair_rfmt(L.GATES_H2F) if kind == "hhp16" else 0)
