@@ -7,6 +7,7 @@ device; here a registry keyed by the pack buffer's address keeps the logical mat
 Layout (include/wesep_hip.h): BL(C) block b = tile * L + step holds 32 consecutive sequences; element
 (b, slot i, column c) at b*32*C + ((c >> 2)*32 + i)*4 + (c & 3).  Only tests/ import this; the product has no CPU
 path."""
+import math
 import os
 
 import torch
@@ -302,8 +303,25 @@ def lstm_bwd_cluster(gates, cbuf, dhcat, whh_f, whh_r, sm, status=None, dbg=0):
     _bwd_into(gates, cbuf, dhcat, whh_f, whh_r, sm)
 
 
+def _q8(W):
+    """What rfmt 2 keeps of a recurrent weight: fp16 hi of 256 w + e4m3 codes of the remainder over a power-of-two scale that
+    puts the largest possible remainder at 256 (per tensor here; the device scales per (direction, half, wave) block --
+    ws_lstm_pack_pair_f8 -- or per group of 8 k-steps of it -- ws_lstm_pack_bwd_f8)."""
+    s = 256.0 * W.detach()
+    hi = s.half().float()
+    m = float(s.abs().max())
+    S = 2.0 ** (math.floor(math.log2(m)) + 1 - 20) if m > 0 and math.isfinite(m) else 1.0
+    lo = ((s - hi) / S).to(torch.float8_e4m3fn).float() * S
+    return (hi + lo) / 256.0
+
+
 def lstm_pack_pair(whh_f, whh_r, pack, f16=False):
-    pack.reshape(-1)[: 2 * G4 * H] = torch.stack([whh_f, whh_r]).reshape(-1)      # raw weights, like emu_dev.lstm_pack
+    q = _q8 if int(f16) == 2 else (lambda w: w)                                    # raw weights, like emu_dev.lstm_pack
+    pack.reshape(-1)[: 2 * G4 * H] = torch.stack([q(whh_f), q(whh_r)]).reshape(-1)
+
+
+def lstm_pack_bwd_f8(whh_f, whh_r, pack_bwd):
+    pack_bwd.reshape(-1)[: 2 * G4 * H] = torch.stack([_q8(whh_f), _q8(whh_r)]).reshape(-1)
 
 
 def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None, repairable=False,
@@ -438,7 +456,7 @@ def install(monkeypatch):
     monkeypatch.setattr(dev, "lstm_fwd", make_lstm_fwd(dev.lstm_fwd))
     monkeypatch.setattr(dev, "lstm_bwd", make_lstm_bwd(dev.lstm_bwd))
     for fn in (pack_w, lstm_cat_ih, lstm_pack_fused, gemm_p2b, gemm_b2p, lstm_fwd_cluster, lstm_fwd_cluster2, lstm_bwd_cluster,
-               lstm_pack_pair, lstm_bwd_pair, lstm_fwd_fused, gemm_tnb):
+               lstm_pack_pair, lstm_pack_bwd_f8, lstm_bwd_pair, lstm_fwd_fused, gemm_tnb):
         monkeypatch.setattr(dev, fn.__name__, fn)
     monkeypatch.setattr(dev, "group_stats", make_group_stats(dev.group_stats))
     monkeypatch.setattr(dev, "gn_bwd_reduce", make_gn_bwd_reduce(dev.gn_bwd_reduce))

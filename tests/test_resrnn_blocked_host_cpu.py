@@ -76,6 +76,48 @@ def test_resrnn_blocked_matches_oracle(emu, monkeypatch, view, R, K, Tf, branch,
         assert float((got[k] - want[k]).norm()) <= max(gtol, 5e-4 if c2 else 0.0) * float(want[k].norm()) + 1e-6, k
 
 
+def test_streaming_bptt_on_fp16_and_fp8_weights_is_opt_in_and_reaches_the_kernel(emu, monkeypatch):
+    """WESEP_BAND_RF=2 (ws_lstm_args.rfmt = 2): the band view's streaming BPTT gets the FP8 pack (ws_lstm_pack_bwd_f8) and rfmt 2
+    -- 32-sequence blocked kernels with the default 2-byte format only; without the variable nothing changes.  Gradients
+    against the oracle within the format's tolerance (the emulation models the stored fp16 d(gates) in the recurrent product
+    and the 16-bit weights)."""
+    from wesep_amd import dev
+    from wesep_amd import functional as F0
+    monkeypatch.setenv("WESEP_GATES", "h2")
+    R, K, Tf = 2, 3, 2100
+    seen = []
+    real_bwd, real_pack = dev.lstm_bwd, dev.lstm_pack_bwd_f8
+    monkeypatch.setattr(dev, "lstm_bwd", lambda *a, **k: (seen.append(("bwd", k.get("rfmt", 0))), real_bwd(*a, **k))[1])
+    monkeypatch.setattr(dev, "lstm_pack_bwd_f8", lambda *a, **k: (seen.append(("pack8", 0)), real_pack(*a, **k))[1])
+    grads = {}
+    for rf in ("0", "2"):
+        monkeypatch.setenv("WESEP_BAND_RF", rf)
+        seen.clear()
+        p = _params(31)
+        g = torch.Generator().manual_seed(5)
+        z = torch.randn(R, K, Tf, 128, generator=g).requires_grad_(True)
+        probe = torch.randn(R, K, Tf, 128, generator=g)
+        out = F0.ResRNNBlkFn.apply(z, None, None, None, "band", p["norm.weight"], p["norm.bias"], *(p[n] for n in NAMES))
+        (out * probe).sum().backward()
+        grads[rf] = {"z": z.grad.clone(), **{k: v.grad.clone() for k, v in p.items()}}
+        assert ("pack8", 0) in seen if rf == "2" else ("pack8", 0) not in seen
+        assert [r for k_, r in seen if k_ == "bwd"] == [int(rf)]
+    x = z.detach().permute(0, 2, 3, 1).reshape(R * Tf, 128, K)
+    for v in p.values():
+        v.grad = None
+    z2 = z.detach().clone().requires_grad_(True)
+    ref = O.res_rnn(p, "", z2.permute(0, 2, 3, 1).reshape(R * Tf, 128, K)).view(R, Tf, 128, K).permute(0, 3, 1, 2)
+    (ref * probe).sum().backward()
+    want = {"z": z2.grad, **{k: v.grad for k, v in p.items()}}
+    for k in want:
+        for rf in ("0", "2"):
+            assert float((grads[rf][k] - want[k]).norm()) <= 5e-4 * float(want[k].norm()) + 1e-6, (k, rf)
+    assert any(not torch.equal(grads["0"][k], grads["2"][k]) for k in want)      # (the variable does reach the arithmetic)
+    monkeypatch.setenv("WESEP_BAND_RF", "1")
+    with pytest.raises(ValueError):
+        F0.band_rfmt(3, 4)
+
+
 def _oracle_time(p, z, R, K, Tf):
     x = z.permute(0, 1, 3, 2).reshape(R * K, 128, Tf)
     return O.res_rnn(p, "", x).view(R, K, 128, Tf).permute(0, 1, 3, 2)
