@@ -27,8 +27,13 @@
 // device-side repair, callers check the word -- dev.poll_cluster_status).  Sums are taken in a fixed order: results are
 // bit-identical run to run.
 //
+// Round 5 (RF template parameter, ws_lstm_pair_args.rfmt): 1 = the product on the fp16 MFMA instruction against the STORED
+// scaled-fp16 d(gates) (two terms, one LDS image plane, data-tagged hand-off); 2 (the default of the Python layer) = the same
+// with W_hh's lo plane as block-scaled FP8 -- the WHOLE of W_hh then stays on the compute unit (hi plane in registers, 27 of 32
+// lo k-steps in LDS, 5 in registers) and the step loop loads nothing of it.  The paragraphs above describe RF = 0.
+//
 // Residency: both members of a pair must be resident at the same time: the launcher requires 2 workgroups per
-// (tile, direction) <= CUs (one workgroup per CU: 97 KB of LDS, 8 waves x <= 256 VGPRs).  Members of a pair are 8
+// (tile, direction) <= CUs (one workgroup per CU: 145 - 157 KB of LDS, 8 waves x <= 256 VGPRs).  Members of a pair are 8
 // apart in dispatch order, i.e. on the same XCD (blockIdx % 8) and behind the same L2 -- for speed; the protocol does
 // not depend on it.
 #include "lstm_bf16_common.h"
