@@ -265,3 +265,32 @@ def test_in_loop_replica_check_reports_a_divergence_within_the_interval_world2_g
     # (the prefetcher pulls batch i + 1 while step i runs: the disturbance lands during step 3)
     assert r0["seen"] and r1["seen"] and "step 3" in r0["seen"] and "step 3" in r1["seen"], (r0, r1)
     assert r0["steps"] == r1["steps"] == 3
+
+
+def test_clip_gradients_zeroes_a_poisoned_step_for_optimizers_without_a_guard(monkeypatch):
+    """wesep_amd.optim.clip_gradients in front of a stock torch optimizer (wesep/utils/funcs.py:79-88 +
+    wesep/bin/train.py:237-238 when the optimizer is not Adam).  The scaled-fp16 d(gates) are not clamped since round 5, so an
+    overflow arrives as Inf: clip / (Inf + eps) = 0, Inf * 0 = NaN -- the reference's arithmetic would write NaN into the weights.
+    Here the clip launch is skipped, every gradient of the step is zeroed, the step is counted, and the weights stay finite."""
+    from tests import emu_optim
+    from wesep_amd import optim
+    emu_optim.install(monkeypatch)
+    monkeypatch.setattr(optim.clip_gradients, "skipped_steps", 0, raising=False)
+    net = _net(3)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    x, y = torch.randn(4, 6), torch.randn(4, 3)
+    ((net(x) - y) ** 2).mean().backward()
+    norms = optim.clip_gradients(net, 0.05)                      # a finite step: clipped per tensor, nothing skipped
+    assert all(n == n and n != float("inf") for n in norms) and optim.clip_gradients.skipped_steps == 0
+    assert all(float(p.grad.norm()) <= 0.05 + 1e-6 for p in net.parameters())
+    opt.step()
+    before = [p.detach().clone() for p in net.parameters()]
+    opt.zero_grad()
+    ((net(x) - y) ** 2).mean().backward()
+    list(net.parameters())[0].grad[2, 1] = float("inf")
+    with pytest.warns(RuntimeWarning, match="not finite"):
+        norms = optim.clip_gradients(net, 0.05)
+    assert any(n == float("inf") for n in norms) and optim.clip_gradients.skipped_steps == 1
+    assert all(not p.grad.any() for p in net.parameters())       # every gradient of the step is zero, none is NaN
+    opt.step()
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))   # SGD on zero gradients: intact

@@ -605,7 +605,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else _empty(d, dev.blh_floats(nb, 2 * G4))
             rf = pair_rfmt(gfmt)
             tw = dev.lstm_bwd_pair(gates, cbuf, dh, W("hhp16" if rf else "hhp"), seq, gfmt=gfmt, dgates=dg, repairable=True,
-                                   dbg=_pair_dbg(), amax=amax, rfmt=rf)
+                                   dbg=_pair_dbg(), amax=amax, rfmt=rf, dbg_buf=_pair_stamp_buf(d, seq.L))
             dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode, gfmt=gfmt, dgates=dg, run_if=tw, amax=amax)
         else:
             # streaming BPTT (band view): bf16 d(gates) in place over the unorm16 gates (H2) / split pairs to their own
@@ -686,8 +686,24 @@ def _bptt_kind(seq, device, cluster) -> str:
 
 def _pair_dbg() -> int:
     """WESEP_PAIR_FORCE_TIMEOUT=1 (tests): every pair BPTT launch times out in pair 0 at step 2, so the predicated
-    streaming fall-back produces the layer's d(gates)."""
-    return 8 if os.environ.get("WESEP_PAIR_FORCE_TIMEOUT", "0") == "1" else 0
+    streaming fall-back produces the layer's d(gates).  WESEP_PAIR_STAMP=1 (measurement, tools/r06_instep_stamps.py): the
+    cycle-stamped build of the kernel (dbg 2048) inside a whole training step."""
+    return (8 if os.environ.get("WESEP_PAIR_FORCE_TIMEOUT", "0") == "1" else 0) | (2048 if _pair_stamp_on() else 0)
+
+
+PAIR_STAMPS = []     # (stamp buffer, steps) of every pair BPTT launched with WESEP_PAIR_STAMP=1, oldest first
+
+
+def _pair_stamp_on() -> bool:
+    return os.environ.get("WESEP_PAIR_STAMP", "0") == "1"
+
+
+def _pair_stamp_buf(device, steps):
+    if not _pair_stamp_on():
+        return None
+    buf = torch.zeros(steps * 2 * 8 * 2, device=device)
+    PAIR_STAMPS.append((buf, steps))
+    return buf
 
 
 def _cluster_dbg() -> int:
@@ -748,7 +764,9 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
         raise KeyError(kind)
 
     def W(kind):
-        key = (kind, lmode) if kind == "hh" else kind
+        # (the env-selected arithmetic is part of the key: toggling WESEP_PAIR_RF in one process -- A/B benches, tests -- must not
+        #  hand an fp16-lo pack to the FP8 kernel)
+        key = (kind, lmode) if kind == "hh" else (kind, pair_rfmt(L.GATES_H2F)) if kind == "hhp16" else kind
         return cache.get(sig, key, lambda: build(kind))
 
     return W

@@ -5,6 +5,7 @@ own L2 norm with eps 1e-6 (wesep/utils/funcs.py:79-88, ~640 `.item()` host syncs
 the reference, zero here) and torch.optim.Adam(weight_decay=wd) adds wd*p to the gradient
 (wesep/bin/train.py:237-238).  State keys (`step`, `exp_avg`, `exp_avg_sq`) match
 torch.optim.Adam so optimizer checkpoints interchange (wesep/utils/checkpoint.py)."""
+import math
 import os
 
 import numpy as np
@@ -24,7 +25,15 @@ def _table(refs, device):
 
 def clip_gradients(model, clip):
     """Drop-in for `wesep.utils.funcs.clip_gradients`: clips in place, returns the list of
-    per-parameter norms (one device->host copy for all of them)."""
+    per-parameter norms (one device->host copy for all of them).
+
+    Non-finite gradients: since round 5 the scaled-fp16 d(gates) of the BPTT kernels are not clamped -- an
+    overflow reaches the weight gradients as Inf / NaN by design, and FusedClipAdam skips such a step on the device.  This
+    function serves every OTHER optimizer (torch.optim.*, the reference's own train.py), which has no skip: clip / (Inf + eps)
+    = 0 and Inf * 0 = NaN would go straight into the weights.  So the norms carry the guard word here too: when any norm is
+    not finite the clip launch is skipped on the device, and the host -- which reads the norms back anyway -- zeroes EVERY
+    gradient of the step and warns: the following optimizer.step() sees a zero gradient instead of poison (Adam then only
+    decays its moments; the weights stay finite), and `skipped_steps` on this function counts the events."""
     ps = [p for _, p in model.named_parameters() if p.grad is not None]
     if not ps:
         return []
@@ -34,10 +43,23 @@ def clip_gradients(model, clip):
             raise L.WesepHipError("clip_gradients: fp32 contiguous CUDA gradients required")
     tab = _table([(p, p.grad, None, None) for p in ps], device)
     norms = torch.empty(len(ps), device=device, dtype=torch.float32)
-    dev.grad_norms(tab, len(ps), norms)
+    guard = torch.zeros(1, device=device, dtype=torch.int32)
+    dev.grad_norms(tab, len(ps), norms, guard=guard)
     dev.poll_cluster_status(device)      # (an optimizer other than FusedClipAdam: the BPTT status word is looked at here)
-    dev.clip_adam_step(tab, len(ps), norms, float(clip), 0.0, 0.9, 0.999, 1e-8, 0.0, 1, clip_only=True)
-    return norms.tolist()
+    dev.clip_adam_step(tab, len(ps), norms, float(clip), 0.0, 0.9, 0.999, 1e-8, 0.0, 1, clip_only=True, skip=(guard, None))
+    out = norms.tolist()
+    if not all(math.isfinite(n) for n in out):
+        import warnings
+        clip_gradients.skipped_steps += 1
+        for p in ps:
+            p.grad.zero_()
+        warnings.warn("clip_gradients: a gradient norm is not finite (NaN / Inf: an overflow of the scaled-fp16 d(gates) or a "
+                      "diverged step); every gradient of this step was zeroed so that the optimizer cannot write NaN into the "
+                      f"weights ({clip_gradients.skipped_steps} such steps so far)", RuntimeWarning)
+    return out
+
+
+clip_gradients.skipped_steps = 0
 
 
 class FusedClipAdam(torch.optim.Optimizer):
