@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 18
+#define WS_ABI_VERSION 19
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -44,6 +44,10 @@ int ws_debug_dirty_lds(float value, int nblocks, int spins, float* sink, void* s
  * of the weight-gradient GEMM fits beside it) for `usec` microseconds of wall clock, or until *stop != 0 (optional
  * device word) -- a resident-collective-shaped occupant for the robustness tests.  Bounded: usec <= 2 000 000.        */
 int ws_debug_occupy(int nblocks, int usec, const unsigned* stop, float* sink, void* stream);
+/* Stream gate (ABI v19): a one-wave kernel on `stream` that ends when *word >= target or after max_us microseconds of wall
+ * clock (<= 100 000), whichever comes first: work enqueued behind it starts once a kernel on ANOTHER stream that counts its
+ * workgroups into `word` (ws_lstm_pair_args.resident) is fully resident.  Scheduling only -- no data dependency hangs on it. */
+int ws_wait_word(const unsigned* word, unsigned target, int max_us, void* stream);
 
 /* ---- row addressing used by the GEMMs ---------------------------------------------------
  * row m of a matrix lives at  base + (m / div) * s1 + (m % div) * s2   (elements).       */
@@ -200,6 +204,11 @@ int ws_gn_param_grad(const float* x, const float* dxn, const float* stats,
 int ws_gn_bwd_fused(const float* x, const float* dxn, const float* stats, const float* gamma,
                     const float* res, const ws_groups_geom* geo, int nwg, float* dx, float* pslab,
                     float* pout, unsigned* counter, void* stream);
+/* ABI v19: the same with d(xn) arriving as TWO addends (dxn + dxn2: the per-direction buffers ws_lstm_bwd writes through
+ * ws_lstm_args.dxn); dxn2 = NULL is ws_gn_bwd_fused.                                                                */
+int ws_gn_bwd_fused2(const float* x, const float* dxn, const float* dxn2, const float* stats, const float* gamma,
+                     const float* res, const ws_groups_geom* geo, int nwg, float* dx, float* pslab,
+                     float* pout, unsigned* counter, void* stream);
 /* ABI v15: pout [2][128] (optional) = (dgamma, dbeta) summed over the workgroups BY the workgroups of the launch (the last
  * finisher of every 32 consecutive workgroups adds their shares up in index order, the last of those the group sums:
  * deterministic; no ws_reduce_slabs launch behind it).  pslab then needs nwg + ceil(nwg / 32) rows of [2][128];
@@ -241,6 +250,16 @@ typedef struct ws_lstm_args {
                             `wpack` from ws_lstm_pack_bwd_f8: two MFMAs per product instead of three, 96 instead of 128 KB of
                             weights streamed per wave and step (the arithmetic of ws_lstm_pair_args.rfmt = 2)           */
   const unsigned* amax;  /* WS_GATES_H2F, backward: max |dhcat| of this launch as float bits (see WS_GATES_H2F) */
+  /* ABI v19 (three trailing fields, zero = every earlier behaviour), ws_lstm_bwd with rfmt = 2 only: d(normalised input) of
+   * the ResRNN computed INSIDE the BPTT from the d(gates) image its recurrent product reads anyway (autograd's d(input) of
+   * nn.LSTM, bsrnn.py:40) -- ws_gemm_b2p(a_fmt = 2) over d(gates), a 2.1 GB read per band-view layer at R = 32, is then not
+   * launched.  dxn: plain rows [P][128] of direction 0, direction 1 at dxn + dxn_dir_stride floats; the row of (sequence,
+   * step) is the ws_seqmap formula on this struct's sq_s1 / sq_s2 / sq_div / step_rows (which the blocked-layout modes
+   * otherwise ignore); padded slots (sequence >= nseq) store nothing.  The consumer adds the two directions
+   * (ws_gn_bwd_fused2).  wxpack: ws_lstm_pack_dx_f8 output.                                                           */
+  float* dxn;
+  long long dxn_dir_stride;
+  const float* wxpack;
 } ws_lstm_args;
 /* Storage format of the saved activated gates and of d(pre-activation gates) on the blocked layout (ABI v15).
  * BLH(C): the BL(C) index formula with 2-byte elements -- element (b, slot i, column c) at 2-byte index
@@ -289,6 +308,11 @@ int ws_lstm_pack(const float* whh_f, const float* whh_r, float* pack_fwd, float*
  * of 128 KB: 16 chunks of 6 KB = four fp16 hi fragments of 256 w + four fragments of e4m3 codes of the remainder over the
  * scale of their group of 8 k-steps; the eight scales as floats at byte 96 K).  |w| < 255.                       */
 int ws_lstm_pack_bwd_f8(const float* whh_f, const float* whh_r, float* pack_bwd, void* stream);
+/* ABI v19: W_ih^T of both directions for ws_lstm_args.dxn -- wcat [2][4H][128] from ws_lstm_cat_ih; pack: WS_LSTM_DX_PACK_FLOATS
+ * floats (16 regions of 48 KB + 64 B: fp16 hi fragments of 256 w for v_mfma_f32_16x16x32_f16, e4m3 codes of the remainder,
+ * eight group scales).                                                                                              */
+#define WS_LSTM_DX_PACK_FLOATS (16 * (48 * 1024 + 64) / 4)
+int ws_lstm_pack_dx_f8(const float* wcat, float* pack, void* stream);
 int ws_lstm_fwd(const ws_lstm_args* a, void* stream);
 /* On exit gates holds dL/d(pre-activation gates).                                           */
 int ws_lstm_bwd(const ws_lstm_args* a, void* stream);
@@ -392,6 +416,8 @@ typedef struct ws_lstm_pair_args {
                            product with the lo plane of W_hh as block-scaled FP8 (wpack from ws_lstm_pack_pair_f8): 16
                            instead of 22 significant bits of every weight, and the whole of W_hh stays on the compute
                            unit for the launch (hi plane in registers, lo plane in LDS) -- nothing of it is streamed  */
+  unsigned* resident;   /* ABI v19 (trailing, NULL = off): device word, zero at launch; every live workgroup adds 1 when it
+                           starts (4 * ceil(nseq / 32) in all) -- the target of ws_wait_word                            */
 } ws_lstm_pair_args;
 int ws_lstm_pack_pair(const float* whh_f, const float* whh_r, float* pack, void* stream);
 /* ABI v17: the pack of rfmt = 1 (same size and unit order, fp16 hi / lo of 256 w; |w| < 255) */

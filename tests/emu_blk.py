@@ -244,13 +244,24 @@ def make_lstm_fwd(plain_fwd):
 
 
 def make_lstm_bwd(plain_bwd):
-    def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode=3, gfmt=0, dgates=None, run_if=None, amax=None, rfmt=0):
+    def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode=3, gfmt=0, dgates=None, run_if=None, amax=None, rfmt=0, dxn=None,
+                 wxpack=None):
         if _skip(run_if):
             return
         if mode not in (4, 5):
             return plain_bwd(gates, cbuf, hcat, dhcat, wpack, sm, mode)
         whf, whr = _whh_from_pack(wpack)
         _bwd_into(gates, cbuf, dhcat, whf, whr, sm, gfmt, dgates, amax, rq=rfmt != 0)
+        if dxn is not None:
+            # ABI v19: d(xn) of each direction from the STORED scaled-fp16 d(gates) (the kernel's LDS image holds exactly
+            # those values) x W_ih as fp16 hi + FP8 lo (lstm_pack_dx_f8), plain rows at the sequence map's positions
+            assert rfmt == 2 and gfmt == 3 and mode == 4 and wxpack is not None and not getattr(sm, "nvalid", 0)
+            nt, L = _ntile(sm), sm.L
+            dg = _g16(dgates if dgates is not None else gates, nt, L, 2 * G4, 2, amax)[: sm.nseq].reshape(sm.nseq, L, 2, G4)
+            wq = _PACKS[wxpack.data_ptr()]                         # [2, 4H, 128], quantised
+            pos = _positions(sm)[: sm.nseq].reshape(-1)
+            for di in (0, 1):
+                dxn[di].reshape(-1, 128)[pos] = (dg[:, :, di] @ wq[di]).reshape(-1, 128)
     return lstm_bwd
 
 
@@ -324,10 +335,22 @@ def lstm_pack_bwd_f8(whh_f, whh_r, pack_bwd):
     pack_bwd.reshape(-1)[: 2 * G4 * H] = torch.stack([_q8(whh_f), _q8(whh_r)]).reshape(-1)
 
 
+def wait_word(word, target, max_us=300):
+    """ws_wait_word: a scheduling gate; the emulation runs everything in order, so the count must already be there."""
+    assert int(word.reshape(-1)[0]) >= int(target), (int(word.reshape(-1)[0]), target)
+
+
+def lstm_pack_dx_f8(wcat, pack):
+    w = wcat.reshape(2, G4, 128)
+    _PACKS[pack.data_ptr()] = torch.stack([_q8(w[0]), _q8(w[1])])
+
+
 def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None, repairable=False,
-                  amax=None, rfmt=0):
+                  amax=None, rfmt=0, resident=None):
     """Returns the launch's timeout word like dev.lstm_bwd_pair; dbg & 8 emulates the forced timeout (NaN-poisoned
     d(gates), both words set)."""
+    if resident is not None:                       # (ABI v19: every live workgroup counts itself in)
+        resident += 4 * _ntile(sm)
     if dbg & 8:
         (dgates if dgates is not None else gates).fill_(float("nan"))
         if status is not None:
@@ -440,8 +463,10 @@ def gn_bwd_apply_pg(x, dxn, stats, ab, geo, dx, gamma, pslab, pout, counter, res
     gn_param_grad(x, dxn, stats, geo, 1, pout)
 
 
-def gn_bwd_fused(x, dxn, stats, geo, gamma, dx, nwg, pslab, res=None, pout=None, counter=None):
-    """norm.hip gn_bwd_fused_kernel: reduce + apply + parameter sums in one call (pslab [nwg, 2, 128])."""
+def gn_bwd_fused(x, dxn, stats, geo, gamma, dx, nwg, pslab, res=None, pout=None, counter=None, dxn2=None):
+    """norm.hip gn_bwd_fused_kernel: reduce + apply + parameter sums in one call (pslab [nwg, 2, 128]); dxn2: second addend."""
+    if dxn2 is not None:
+        dxn = dxn + dxn2
     ab = torch.zeros(geo.ngroups, 2)
     make_gn_bwd_reduce(None)(x, dxn, stats, geo, ab, gamma=gamma)
     gn_bwd_apply(x, dxn, stats, ab, geo, dx, gamma=gamma, res=res)
@@ -456,7 +481,7 @@ def install(monkeypatch):
     monkeypatch.setattr(dev, "lstm_fwd", make_lstm_fwd(dev.lstm_fwd))
     monkeypatch.setattr(dev, "lstm_bwd", make_lstm_bwd(dev.lstm_bwd))
     for fn in (pack_w, lstm_cat_ih, lstm_pack_fused, gemm_p2b, gemm_b2p, lstm_fwd_cluster, lstm_fwd_cluster2, lstm_bwd_cluster,
-               lstm_pack_pair, lstm_pack_bwd_f8, lstm_bwd_pair, lstm_fwd_fused, gemm_tnb):
+               lstm_pack_pair, lstm_pack_bwd_f8, lstm_pack_dx_f8, lstm_bwd_pair, lstm_fwd_fused, gemm_tnb, wait_word):
         monkeypatch.setattr(dev, fn.__name__, fn)
     monkeypatch.setattr(dev, "group_stats", make_group_stats(dev.group_stats))
     monkeypatch.setattr(dev, "gn_bwd_reduce", make_gn_bwd_reduce(dev.gn_bwd_reduce))

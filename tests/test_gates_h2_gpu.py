@@ -209,6 +209,37 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
         hi8 = torch.stack([raw[:, c * 6144:c * 6144 + 4096] for c in range(16)], 1).contiguous().view(torch.float16).float()
         m = hi8.reshape(16, 8, -1).abs().amax(2)                                           # two chunks per group
         assert bool(((m >= Sg * 2.0 ** 19 * (1 - 2.0 ** -10)) & (m <= Sg * 2.0 ** 20)).all())
+        # ---- ws_lstm_args.dxn (ABI v19): the same launch also writes d(xn) = d(gates) W_ih per direction -- from the d(gates)
+        # image in LDS, W_ih^T as fp16 hi + scaled-FP8 lo on v_mfma_f32_16x16x32_f16 -- as plain rows at the sequence map's
+        # positions.  d(gates) must not change (bit-identical to the launch without it); d(xn) against fp64 on the STORED d(gates)
+        # and against ws_gemm_b2p(a_fmt 2), whose job it takes over
+        wcat = (0.06 * torch.randn(2, 4 * H, N, generator=g)).to(d)
+        px = torch.zeros(L.LSTM_DX_PACK_FLOATS, device=d)
+        dev.lstm_pack_dx_f8(wcat, px)
+        x_in, x_in2 = gh.clone(), gh.clone()
+        dxn, dxn_b = torch.full((2, P, N), float("nan"), device=d), torch.full((2, P, N), float("nan"), device=d)
+        dev.lstm_bwd(x_in, cbuf, hcat, dh, pb8, seq, mode, gfmt=L.GATES_H2F, amax=amax, rfmt=2, dxn=dxn, wxpack=px)
+        dev.lstm_bwd(x_in2, cbuf, hcat, dh, pb8, seq, mode, gfmt=L.GATES_H2F, amax=amax, rfmt=2, dxn=dxn_b, wxpack=px)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(dxn).all())                     # every row of both directions was written
+        assert torch.equal(dxn, dxn_b)
+        # (one accumulator chain instead of two in this instantiation: the same products, another summation order)
+        gx = x_in.reshape(-1)[: ref.numel() // 2].view(torch.float16).view(dg.shape).float() / S
+        assert float((gx - got2).norm() / got2.norm()) < 2e-5
+        wt16 = torch.empty(N * 2 * 4 * H, device=d)
+        dev.pack_w(wcat.reshape(2 * 4 * H, N), N, 2 * 4 * H, N, wt16, trans=True, order=1, f16=True)
+        c_ref = torch.full((P, N), float("nan"), device=d)
+        dev.gemm_b2p(A=x_in, K=2 * 4 * H, sm=seq, Wpack=wt16, C_out=c_ref, ldc=N, a_fmt=2, amax=amax)
+        torch.cuda.synchronize()
+        rows = dev.from_blocked(dev.blh_f16_unpack(x_in, nb, 2 * 4 * H) / S, seq, P).double()     # the stored d(gates), plain rows
+        for di in (0, 1):
+            want = rows[:, di * 4 * H:(di + 1) * 4 * H] @ wcat[di].double()
+            e_d = float((dxn[di].double() - want).norm() / want.norm())
+            print(f"d(xn) of direction {di} vs fp64 on the stored d(gates): rel-L2 {e_d:.2e}")
+            assert e_d < 2e-5, (di, e_d)                           # 16-bit weights (2^-17 of the group maximum), fp32 accumulation
+        e_sum = float(((dxn[0] + dxn[1]) - c_ref).norm() / c_ref.norm())
+        print(f"d(xn) inside the BPTT vs ws_gemm_b2p(a_fmt 2) on the same d(gates): rel-L2 {e_sum:.2e}")
+        assert e_sum < 3e-5, e_sum                                 # weights 2^-17 apart (FP8 vs fp16 remainder), fp32 accumulation
     if kind != "pair":
         return
     # ---- rfmt = 1 (ABI v17): the recurrent product takes the STORED fp16 d(gates) (one operand of the fp16 MFMA, W_hh as

@@ -76,22 +76,30 @@ def test_resrnn_blocked_matches_oracle(emu, monkeypatch, view, R, K, Tf, branch,
         assert float((got[k] - want[k]).norm()) <= max(gtol, 5e-4 if c2 else 0.0) * float(want[k].norm()) + 1e-6, k
 
 
-def test_streaming_bptt_on_fp16_and_fp8_weights_is_opt_in_and_reaches_the_kernel(emu, monkeypatch):
-    """WESEP_BAND_RF=2 (ws_lstm_args.rfmt = 2): the band view's streaming BPTT gets the FP8 pack (ws_lstm_pack_bwd_f8) and rfmt 2
-    -- 32-sequence blocked kernels with the default 2-byte format only; without the variable nothing changes.  Gradients
-    against the oracle within the format's tolerance (the emulation models the stored fp16 d(gates) in the recurrent product
-    and the 16-bit weights)."""
+def test_streaming_bptt_arithmetic_and_its_own_input_gradient_reach_the_kernel(emu, monkeypatch):
+    """Round 6 defaults of the band view's streaming BPTT: ws_lstm_args.rfmt = 2 (the FP8 pack, ws_lstm_pack_bwd_f8) and d(xn)
+    computed by the BPTT launch itself (ws_lstm_args.dxn + ws_lstm_pack_dx_f8, ABI v19: no ws_gemm_b2p over d(gates), the fused
+    GroupNorm backward adds the two directions) -- 32-sequence blocked kernels with the default 2-byte format only.
+    WESEP_BAND_DX=0 restores the separate GEMM, WESEP_BAND_RF=0 the three-term product (and with it the GEMM).  Gradients
+    against the oracle within the format's tolerance in all three modes (the emulation models the stored fp16 d(gates) and the
+    16-bit weights of both products)."""
     from wesep_amd import dev
     from wesep_amd import functional as F0
     monkeypatch.setenv("WESEP_GATES", "h2")
-    R, K, Tf = 2, 3, 2100
+    R, K, Tf = 2, 4, 2100
     seen = []
-    real_bwd, real_pack = dev.lstm_bwd, dev.lstm_pack_bwd_f8
-    monkeypatch.setattr(dev, "lstm_bwd", lambda *a, **k: (seen.append(("bwd", k.get("rfmt", 0))), real_bwd(*a, **k))[1])
-    monkeypatch.setattr(dev, "lstm_pack_bwd_f8", lambda *a, **k: (seen.append(("pack8", 0)), real_pack(*a, **k))[1])
+    real_bwd, real_pack, real_b2p, real_px = dev.lstm_bwd, dev.lstm_pack_bwd_f8, dev.gemm_b2p, dev.lstm_pack_dx_f8
+    monkeypatch.setattr(dev, "lstm_bwd", lambda *a, **k: (seen.append(("bwd", k.get("rfmt", 0), k.get("dxn") is not None)),
+                                                          real_bwd(*a, **k))[1])
+    monkeypatch.setattr(dev, "lstm_pack_bwd_f8", lambda *a, **k: (seen.append(("pack8",)), real_pack(*a, **k))[1])
+    monkeypatch.setattr(dev, "lstm_pack_dx_f8", lambda *a, **k: (seen.append(("packdx",)), real_px(*a, **k))[1])
+    monkeypatch.setattr(dev, "gemm_b2p", lambda **k: (seen.append(("b2p", k.get("a_fmt", 0))), real_b2p(**k))[1])
     grads = {}
-    for rf in ("0", "2"):
-        monkeypatch.setenv("WESEP_BAND_RF", rf)
+    for mode, env in (("default", {}), ("gemm", {"WESEP_BAND_DX": "0"}), ("rf0", {"WESEP_BAND_RF": "0"})):
+        for k_ in ("WESEP_BAND_DX", "WESEP_BAND_RF"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
         seen.clear()
         p = _params(31)
         g = torch.Generator().manual_seed(5)
@@ -99,10 +107,11 @@ def test_streaming_bptt_on_fp16_and_fp8_weights_is_opt_in_and_reaches_the_kernel
         probe = torch.randn(R, K, Tf, 128, generator=g)
         out = F0.ResRNNBlkFn.apply(z, None, None, None, "band", p["norm.weight"], p["norm.bias"], *(p[n] for n in NAMES))
         (out * probe).sum().backward()
-        grads[rf] = {"z": z.grad.clone(), **{k: v.grad.clone() for k, v in p.items()}}
-        assert ("pack8", 0) in seen if rf == "2" else ("pack8", 0) not in seen
-        assert [r for k_, r in seen if k_ == "bwd"] == [int(rf)]
-    x = z.detach().permute(0, 2, 3, 1).reshape(R * Tf, 128, K)
+        grads[mode] = {"z": z.grad.clone(), **{k: v.grad.clone() for k, v in p.items()}}
+        assert (("pack8",) in seen) == (mode != "rf0") and (("packdx",) in seen) == (mode == "default")
+        assert [r[1:] for r in seen if r[0] == "bwd"] == [(0 if mode == "rf0" else 2, mode == "default")]
+        # the d(xn) GEMM over the scaled-fp16 d(gates) (a_fmt 2) runs exactly when the BPTT did not write d(xn) itself
+        assert (("b2p", 2) in seen) == (mode != "default")
     for v in p.values():
         v.grad = None
     z2 = z.detach().clone().requires_grad_(True)
@@ -110,9 +119,11 @@ def test_streaming_bptt_on_fp16_and_fp8_weights_is_opt_in_and_reaches_the_kernel
     (ref * probe).sum().backward()
     want = {"z": z2.grad, **{k: v.grad for k, v in p.items()}}
     for k in want:
-        for rf in ("0", "2"):
-            assert float((grads[rf][k] - want[k]).norm()) <= 5e-4 * float(want[k].norm()) + 1e-6, (k, rf)
-    assert any(not torch.equal(grads["0"][k], grads["2"][k]) for k in want)      # (the variable does reach the arithmetic)
+        for mode in grads:
+            assert float((grads[mode][k] - want[k]).norm()) <= 5e-4 * float(want[k].norm()) + 1e-6, (k, mode)
+    assert any(not torch.equal(grads["rf0"][k], grads["gemm"][k]) for k in want)      # (the variable does reach the arithmetic)
+    # the BPTT's own d(xn) and the GEMM's differ only in the weight's low bits (FP8 vs fp16 remainder) and the summation order
+    assert float((grads["default"]["z"] - grads["gemm"]["z"]).norm()) <= 2e-5 * float(grads["gemm"]["z"].norm())
     monkeypatch.setenv("WESEP_BAND_RF", "1")
     with pytest.raises(ValueError):
         F0.band_rfmt(3, 4)

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 18
+ABI_VERSION = 19
 GATES_F32, GATES_H2, GATES_H2S, GATES_H2F = 0, 1, 2, 3     # WS_GATES_* (wesep_hip.h): storage of the saved gates / d(gates)
 DGATES_EXP = 8             # WS_DGATES_EXP: WS_GATES_H2F puts max |d(hcat)| into [2^8, 2^9)
 
@@ -89,7 +89,8 @@ class LstmArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "dhcat", "wpack")] + \
                [(n, _ll) for n in ("sq_s1", "sq_s2", "step_rows")] + \
                [(n, _i) for n in ("nseq", "sq_div", "L", "mode")] + [("run_if", _p)] + \
-               [("gates_in", _p), ("dgates", _p), ("gfmt", _i), ("rfmt", _i), ("amax", _p)]          # ABI v15; rfmt: v18
+               [("gates_in", _p), ("dgates", _p), ("gfmt", _i), ("rfmt", _i), ("amax", _p)] + \
+               [("dxn", _p), ("dxn_dir_stride", _ll), ("wxpack", _p)]          # ABI v15; rfmt: v18; dxn ...: v19
 
 
 class SeqMapC(C.Structure):
@@ -127,7 +128,8 @@ class LstmCluster2Args(C.Structure):
 
 class LstmPairArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "dhcat", "wpack", "xchg", "flags", "status", "dbg_buf")] + \
-               [("nseq", _i), ("L", _i), ("dbg", _i), ("gfmt", _i), ("dgates", _p), ("amax", _p), ("rfmt", _i), ("pad_", _i)]
+               [("nseq", _i), ("L", _i), ("dbg", _i), ("gfmt", _i), ("dgates", _p), ("amax", _p), ("rfmt", _i), ("pad_", _i),
+                ("resident", _p)]                                                                    # resident: ABI v19
 
 
 class Bands(C.Structure):
@@ -151,6 +153,7 @@ class LstmFusedArgs(C.Structure):
 
 
 LSTM_FUSED_PACK_FLOATS = 2 * 8 * 24 * 4 * 2 * 64 * 4
+LSTM_DX_PACK_FLOATS = 16 * (48 * 1024 + 64) // 4      # ws_lstm_pack_dx_f8 (ABI v19)
 
 _SIGS = {
     "ws_abi_version": (_i, []),
@@ -159,6 +162,7 @@ _SIGS = {
     "ws_prof_collect": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_ll)]),
     "ws_debug_dirty_lds": (_i, [_f, _i, _i, _p, _p]),
     "ws_debug_occupy": (_i, [_i, _i, _p, _p, _p]),
+    "ws_wait_word": (_i, [_p, C.c_uint, _i, _p]),
     "ws_pack_w_f16": (_i, [_p, _i, _i, _ll, _i, _i, _p, _p]),
     "ws_gemm_nt": (_i, [C.POINTER(GemmNTArgs), _p]),
     "ws_gemm_tn": (_i, [C.POINTER(GemmTNArgs), _p]),
@@ -169,6 +173,7 @@ _SIGS = {
     "ws_gn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _p, _p]),
     "ws_gn_param_grad": (_i, [_p, _p, _p, C.POINTER(GroupsGeom), _i, _p, _p]),
     "ws_gn_bwd_fused": (_i, [_p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _i, _p, _p, _p, _p, _p]),
+    "ws_gn_bwd_fused2": (_i, [_p, _p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _i, _p, _p, _p, _p, _p]),
     "ws_gn_bwd_apply_pg": (_i, [_p, _p, _p, _p, _p, _p, C.POINTER(GroupsGeom), _p, _p, _p, _p, _p]),
     "ws_lstm_pack": (_i, [_p, _p, _p, _p, _i, _p]),
     "ws_lstm_fwd": (_i, [C.POINTER(LstmArgs), _p]),
@@ -180,6 +185,7 @@ _SIGS = {
     "ws_lstm_pack_pair_f16": (_i, [_p, _p, _p, _p]),
     "ws_lstm_pack_pair_f8": (_i, [_p, _p, _p, _p]),
     "ws_lstm_pack_bwd_f8": (_i, [_p, _p, _p, _p]),
+    "ws_lstm_pack_dx_f8": (_i, [_p, _p, _p]),
     "ws_lstm_bwd_pair": (_i, [C.POINTER(LstmPairArgs), _p]),
     "ws_lstm_cat_ih": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "ws_pack_w": (_i, [_p, _i, _i, _ll, _i, _i, _p, _p]),

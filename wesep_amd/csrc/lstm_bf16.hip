@@ -127,6 +127,57 @@ int ws_launch_lstm_pack_bwd_f8(const float* whh_f, const float* whh_r, float* pa
   return 0;
 }
 
+// d(xn) inside the BPTT (ws_lstm_args.dxn, ABI v19): the A operand W_ih^T of  d(xn)^T[input][seq] = W_ih^T[input][gate col] *
+// d(gates)^T[gate col][seq]  on v_mfma_f32_16x16x32_f16, in the arithmetic of rfmt 2 -- fp16 hi of 256 w + e4m3 codes of the
+// remainder over a power-of-two scale.  wcat: [2][4H][128] (ws_lstm_cat_ih).  Wave w of direction d owns inputs [16w, 16w + 16).
+// Per (d, w) region of WS_DX_REGION bytes: 16 chunks of 2 k32-steps, chunk c at c * 3 KB = [2 hi fragments of 1 KB: lane * 16
+// bytes][2 code fragments of 512 B: lane * 8 bytes]; at byte 48 K eight floats, the scale of each GROUP of 4 k32-steps (two
+// chunks: the 128 gate columns of eight 16-wide k-steps -- the groups of lstm_pack_bwd_f8_kernel).  Fragment (k32-step kk, lane):
+// element j = 256 * wcat[d][32 kk + 8 (lane >> 4) + j][16 w + (lane & 15)].  One workgroup per (d, w, group).
+#define WS_DX_REGION (48 * 1024 + 64)
+__global__ __launch_bounds__(512) void lstm_pack_dx_f8_kernel(const float* __restrict__ wcat, char* __restrict__ px) {
+  __shared__ float red[8];
+  const int grp = blockIdx.x & 7, w = (blockIdx.x >> 3) & 7, d = blockIdx.x >> 6;
+  const float* W = wcat + (long long)d * LG * 128;
+  const int tid = threadIdx.x;
+  float v0[2], v1[2], m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {   // 4 k32-steps x 64 lanes x 4 element pairs = 1024 pairs, 2 per thread
+    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, kk = 4 * grp + (pi >> 8);
+    const int row = 32 * kk + 8 * (lane >> 4) + 2 * j2, u = 16 * w + (lane & 15);
+    v0[i] = 256.f * W[row * 128 + u];
+    v1[i] = 256.f * W[(row + 1) * 128 + u];
+    m = fmaxf(m, fmaxf(fabsf(v0[i]), fabsf(v1[i])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i]);
+  const int eb = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
+  const float S = (eb > 19 && eb < 255) ? __builtin_bit_cast(float, (unsigned)(eb - 19) << 23) : 1.f;
+  char* ob = px + (long long)(d * 8 + w) * WS_DX_REGION;
+  if (tid == 0) reinterpret_cast<float*>(ob + 48 * 1024)[grp] = S;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, kk = 4 * grp + (pi >> 8);
+    const _Float16 h0 = (_Float16)v0[i], h1 = (_Float16)v1[i];
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    char* cb = ob + (kk >> 1) * 3072;
+    *reinterpret_cast<f16x2*>(cb + (kk & 1) * 1024 + lane * 16 + j2 * 4) = f16x2{h0, h1};
+    const s16x2 c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(s16x2{0, 0}, v0[i] - (float)h0, v1[i] - (float)h1, S, false);
+    *reinterpret_cast<short*>(cb + 2048 + (kk & 1) * 512 + lane * 8 + j2 * 2) = c[0];
+  }
+}
+
+int ws_launch_lstm_pack_dx_f8(const float* wcat, float* pack, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_pack_dx_f8_kernel, dim3(128), dim3(512), 0, s, wcat, reinterpret_cast<char*>(pack));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward recurrence
 // ---------------------------------------------------------------------------------------------
@@ -320,9 +371,16 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
 // scaled-fp16 d(gates) as its one B operand (one LDS image plane) against W_hh as fp16 hi + scaled-FP8 lo of 256 w
 // (lstm_pack_bwd_f8_kernel): two MFMAs per product instead of three and 96 instead of 128 KB streamed per wave and step; the
 // codes become fp16 fragments on the way in (v_cvt_scalef32_pk_f16_fp8 with the group's scale: no separate accumulator scale).
-template <bool BLK, int DBG, int GF = 0, int RF = 0>
+// DX (ABI v19, RF = 2 only): d(xn) = d(gates) W_ih of this direction computed HERE, from the d(gates) image the recurrent product
+// reads anyway -- wave w adds the 16 x 32 tile (inputs [16w, 16w + 16) x the workgroup's 32 sequences) as two 16 x 16 tiles on
+// v_mfma_f32_16x16x32_f16 (64 MFMAs of half the size per step beside the 128 of d(h): the matrix pipe was idle two thirds of this
+// kernel's step), streams W_ih^T beside W_hh (48 KB per wave and step: lstm_pack_dx_f8_kernel) and stores plain rows of
+// p.dxn + d * p.dxn_dir_stride at the sequence map's positions.  ws_gemm_b2p(a_fmt 2) over d(gates) -- 2.1 GB read per band-view
+// layer at R = 32 -- is not launched; the GroupNorm backward adds the two directions (ws_gn_bwd_fused dxn2).
+template <bool BLK, int DBG, int GF = 0, int RF = 0, bool DX = false>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_args p) {
   static_assert(RF == 0 || (BLK && GF == WS_GATES_H2F), "the fp16 recurrence takes the scaled-fp16 d(gates) of WS_GATES_H2F");
+  static_assert(!DX || RF == 2, "d(xn) in the BPTT rides on the fp16 d(gates) image of rfmt 2");
   __shared__ __attribute__((aligned(16))) __bf16 dgl[RF ? 1 : 2][SQ * DROW];  // [part][seq][gate col] 129 / 65 KB
   if (p.run_if && *p.run_if == 0u) return;  // predicated fall-back launch (wesep_hip.h): uniform
   const int d = blockIdx.y;
@@ -383,14 +441,55 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
       for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + chunk * 8192 + (f >> 2) * 4096);
     }
   };
+  // DX: the W_ih^T stream of this wave's 16 inputs (lstm_pack_dx_f8_kernel), ring slots of 2 k32-steps
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.wxpack)) + (DX ? (long long)(d * 8 + w) * WS_DX_REGION : 0), 0,
+      DX ? WS_DX_REGION : 0, 0x00020000);
+  bf16x8 xr[2][DX ? 2 : 1];
+  u32x2 xq[2][DX ? 2 : 1];
+  float xS[DX ? 8 : 1];
+  f32x4 dx0 = {0.f, 0.f, 0.f, 0.f}, dx1 = {0.f, 0.f, 0.f, 0.f};
+  auto xfill = [&](int s, int chunk, int zo) {
+    if constexpr (DX) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        xr[s][q] = wload(xrs, wlane + q * 1024, zo + chunk * 3072);
+        xq[s][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, lane * 8 + q * 512, zo + chunk * 3072 + 2048, 0));
+      }
+    }
+  };
   wfill(0, 0, 0);
+  xfill(0, 0, 0);
   wfill(1, 1, 0);
+  xfill(1, 1, 0);
   if constexpr (RF != 0) {
     const float* st = p.wpack + (long long)(d * 8 + w) * (64 * 2 * 64 * 4) + 96 * 256;
 #pragma unroll
     for (int g8 = 0; g8 < 8; ++g8) wS[g8] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st[g8])));
   }
-
+  if constexpr (DX) {
+    const float* st = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wxpack) + (long long)(d * 8 + w) * WS_DX_REGION + 48 * 1024);
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8) xS[g8] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st[g8])));
+  }
+  // DX: this lane's two d(xn) cells (sequences n and n + 16 of the tile, n = lane & 15; inputs 16w + 4 (lane >> 4) .. + 3) in the
+  // plain [P][128] buffer of this direction, as 32-bit byte offsets of a buffer store: row = (seq / sq_div) * sq_s1 + (seq %
+  // sq_div) * sq_s2 (+ t * step_rows, added per step) -- ws_seqmap; a padded slot gets an offset beyond the descriptor's size
+  // (the buffer is < 2 GB: lstm_check): the hardware drops the store
+  const int xn_ = lane & 15, xq4 = lane >> 4;
+  unsigned xoff[2] = {0u, 0u};
+  if constexpr (DX) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int sq = (int)blockIdx.x * SQ + 16 * e + xn_;
+      const long long row = (long long)(sq / p.sq_div) * p.sq_s1 + (long long)(sq % p.sq_div) * p.sq_s2;
+      xoff[e] = sq < p.nseq ? (unsigned)(row * 512 + (16 * w + 4 * xq4) * 4) : 0x80000000u;   // (+ t * step_rows * 512 < 2^31)
+    }
+  }
+  const __amdgpu_buffer_rsrc_t xors = __builtin_amdgcn_make_buffer_rsrc(
+      DX ? p.dxn + (long long)d * p.dxn_dir_stride : nullptr, 0, DX ? (unsigned)(p.dxn_dir_stride * 4) : 0u, 0x00020000);
   gcell n_i[4], n_f[4], n_g[4], n_o[4];
   f32x4 n_dh[4], n_cp[4], c_cur[4], dc[4];  // [run]
   f32x16 dhr;
@@ -501,7 +600,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
           const f16x8 b16 = __builtin_bit_cast(f16x8, bh), ah16 = __builtin_bit_cast(f16x8, wr[s][q]);
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah16, b16, ks == 0 ? zero : acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al8, b16, ks == 0 ? zero : acc1, 0, 0, 0);
+          if constexpr (DX) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al8, b16, acc0, 0, 0, 0);   // (one chain: the d(xn) tiles
+          else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al8, b16, ks == 0 ? zero : acc1, 0, 0, 0);   // fill the gaps; 16 registers)
         } else {
           const bf16x8 bl = *reinterpret_cast<const bf16x8*>(blo + 16 * ks);
           if (ks == 0) {
@@ -514,15 +614,51 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
           acc0 = mfma32(wr[s][2 * q], bl, acc0);
         }
       }
+      if constexpr (DX) {
+        // d(xn): gate columns [64 ch, 64 ch + 64) as two k32-steps; B = the image rows of sequences n / n + 16, 8 columns from
+        // 8 (lane >> 4): the same ds_read_b128 pattern as above on 16-row groups (row stride 4 banks mod 64: conflict-free)
+        const float sx = xS[ch >> 1];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int kk = 2 * ch + q;
+          const __bf16* b0p = &dgl[0][xn_ * DROW + 8 * xq4 + 32 * kk];
+          const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(b0p));
+          const f16x8 b1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(b0p + 16 * DROW));
+          const u32x2 c8 = xq[s][q];
+          const f16x2 a0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[0], sx, false);
+          const f16x2 a1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[0], sx, true);
+          const f16x2 a2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[1], sx, false);
+          const f16x2 a3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[1], sx, true);
+          const f16x8 al8 = {a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
+          const f16x8 ah8 = __builtin_bit_cast(f16x8, xr[s][q]);
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          dx0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah8, b0, kk == 0 ? z4 : dx0, 0, 0, 0);
+          dx1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah8, b1, kk == 0 ? z4 : dx1, 0, 0, 0);
+          dx0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al8, b0, dx0, 0, 0, 0);
+          dx1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al8, b1, dx1, 0, 0, 0);
+        }
+      }
       const int cn = (ch + 2) & 15;  // wraps into the next step
-      if (!(DBG & 4)) wfill(s, cn, zo);
+      if (!(DBG & 4)) {
+        wfill(s, cn, zo);
+        xfill(s, cn, zo);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (RF != 0) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) dhr[i] = (acc0[i] + acc1[i]) * (1.f / 256.f);   // the fp16 weights are 256 w (exact to undo)
+      for (int i = 0; i < 16; ++i) dhr[i] = (DX ? acc0[i] : acc0[i] + acc1[i]) * (1.f / 256.f);   // the fp16 weights are 256 w (exact to undo)
     } else {
       dhr = acc0;
+    }
+    if constexpr (DX) {
+      // D (16 x 16): lane = (sequence n, input quad lane >> 4): four consecutive inputs of one row -- one 16-byte store; the
+      // accumulators hold 256 w x S d(gates): both powers of two leave here
+      const float us = (1.f / 256.f) / dS;
+      const unsigned trow = (unsigned)t * (unsigned)p.step_rows * 512u;
+      // (no register soffset: lstm_bf16_common.h bst -- the compiler pads the store-data hazard only for that form)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dx0 * us), xors, xoff[0] + trow, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dx1 * us), xors, xoff[1] + trow, 0, 0);
     }
     __syncthreads();
   }
@@ -555,6 +691,10 @@ int ws_launch_lstm_fwd_bf16(const ws_lstm_args* a, hipStream_t s) {
 
 int ws_launch_lstm_bwd_bf16(const ws_lstm_args* a, hipStream_t s) {
   dim3 grid((a->nseq + SQ - 1) / SQ, 2), block(512);
+  if (a->rfmt == 2 && a->dxn) {   // (lstm_check: rfmt 2, wxpack and a sequence map given)
+    hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2, true>), grid, block, 0, s, *a);
+    return 0;
+  }
   if (a->rfmt == 2) {   // (lstm_check: WS_LSTM_BF16X3_BLK + WS_GATES_H2F only)
     hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2>), grid, block, 0, s, *a);
     return 0;

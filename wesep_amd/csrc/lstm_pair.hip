@@ -229,6 +229,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
   // block -> (pair, member): members of a pair are 8 blocks apart (same XCD under round-robin dispatch)
   const int pr = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), hs = ((int)blockIdx.x >> 3) & 1;
   if (pr >= npair) return;
+  // (ABI v19) this workgroup holds its CU now: the side stream's gate (ws_wait_word) counts on it
+  if (p.resident && threadIdx.x == 0) __hip_atomic_fetch_add(p.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int d = pr & 1, tile = pr >> 1;
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -347,6 +347,7 @@ extern "C" int ws_gn_param_grad(const float* x, const float* dxn, const float* s
 // ---------------------------------------------------------------------------------------------
 #define GNF_ROWS 16  // rows per lane (L / 2 <= 16)
 __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ dxn,
+                                                           const float* __restrict__ dxn2,   // optional second addend
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ res, const ws_groups_geom geo,
@@ -371,6 +372,11 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const float* __restri
         xh[j] = *reinterpret_cast<const f32x4*>(x + o);
         dg[j] = *reinterpret_cast<const f32x4*>(dxn + o);
       }
+    if (dxn2) {   // (uniform) d(xn) of the two LSTM directions, written apart by the BPTT (ws_lstm_args.dxn)
+#pragma unroll
+      for (int j = 0; j < GNF_ROWS; ++j)
+        if (j < nrow) dg[j] += *reinterpret_cast<const f32x4*>(dxn2 + base + (long long)(rl + 2 * j) * geo.rs);
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < GNF_ROWS; ++j)
@@ -422,6 +428,12 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const float* __restri
 extern "C" int ws_gn_bwd_fused(const float* x, const float* dxn, const float* stats, const float* gamma,
                                const float* res, const ws_groups_geom* geo, int nwg, float* dx, float* pslab,
                                float* pout, unsigned* counter, void* stream) {
+  return ws_gn_bwd_fused2(x, dxn, nullptr, stats, gamma, res, geo, nwg, dx, pslab, pout, counter, stream);
+}
+
+extern "C" int ws_gn_bwd_fused2(const float* x, const float* dxn, const float* dxn2, const float* stats, const float* gamma,
+                                const float* res, const ws_groups_geom* geo, int nwg, float* dx, float* pslab,
+                                float* pout, unsigned* counter, void* stream) {
   int rc = geom_check(geo, "ws_gn_bwd_fused");
   if (rc != WS_OK) return rc;
   WS_REQUIRE(x && dxn && stats && gamma && dx && pslab && nwg > 0, "ws_gn_bwd_fused: null pointer / nwg");
@@ -430,7 +442,7 @@ extern "C" int ws_gn_bwd_fused(const float* x, const float* dxn, const float* st
              "ws_gn_bwd_fused: built for single-band groups of an even number (<= %d) of 128-float rows (L=%d, W=%d)",
              2 * GNF_ROWS, geo->L, geo->W);
   WS_REQUIRE(!pout || counter, "ws_gn_bwd_fused: pout needs a counter word");
-  hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, dxn, stats, gamma, res,
+  hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, dxn, dxn2, stats, gamma, res,
                      *geo, dx, pslab, pout, counter);
   return ws_check_launch("ws_gn_bwd_fused");
 }

@@ -264,16 +264,17 @@ def gn_bwd_fused_ok(geo: Geom) -> bool:
             and geo.gs1 % 4 == 0 and geo.gs2 % 4 == 0)
 
 
-def gn_bwd_fused(x, dxn, stats, geo: Geom, gamma, dx, nwg: int, pslab, res=None, pout=None, counter=None):
+def gn_bwd_fused(x, dxn, stats, geo: Geom, gamma, dx, nwg: int, pslab, res=None, pout=None, counter=None, dxn2=None):
     """reduce + apply + parameter sums of the GroupNorm backward in one pass (norm.hip gn_bwd_fused_kernel);
     pslab [nwg, 2, 128]: per-workgroup shares of (dgamma, dbeta); pout [2, 128] (optional, with a zeroed int32 `counter`
-    word): their sum, taken by the last workgroup of the launch."""
-    for n, t in (("x", x), ("dxn", dxn), ("stats", stats), ("gamma", gamma), ("res", res), ("dx", dx), ("pslab", pslab),
-                 ("pout", pout)):
+    word): their sum, taken by the last workgroup of the launch.  dxn2 (ABI v19): a second addend of d(xn) -- the other LSTM
+    direction's share when the BPTT wrote d(xn) itself (lstm_bwd(..., dxn=))."""
+    for n, t in (("x", x), ("dxn", dxn), ("dxn2", dxn2), ("stats", stats), ("gamma", gamma), ("res", res), ("dx", dx),
+                 ("pslab", pslab), ("pout", pout)):
         _chk(t, n)
     g = geo.c()
-    L.check(L.lib().ws_gn_bwd_fused(_p(x), _p(dxn), _p(stats), _p(gamma), _p(res), C.byref(g), nwg, _p(dx), _p(pslab),
-                                    _p(pout), _word(counter), L.stream_ptr()), "ws_gn_bwd_fused")
+    L.check(L.lib().ws_gn_bwd_fused2(_p(x), _p(dxn), _p(dxn2), _p(stats), _p(gamma), _p(res), C.byref(g), nwg, _p(dx),
+                                     _p(pslab), _p(pout), _word(counter), L.stream_ptr()), "ws_gn_bwd_fused")
 
 
 def tree_groups(nblocks: int) -> int:
@@ -349,6 +350,14 @@ def lstm_pack_bwd_f8(whh_f, whh_r, pack_bwd):
     L.check(L.lib().ws_lstm_pack_bwd_f8(_p(whh_f), _p(whh_r), _p(pack_bwd), L.stream_ptr()), "ws_lstm_pack_bwd_f8")
 
 
+def lstm_pack_dx_f8(wcat, pack):
+    """W_ih^T stream of lstm_bwd(..., dxn=): fp16 hi + scaled-FP8 lo of 256 w in 16x16x32 fragment order (ws_lstm_pack_dx_f8);
+    wcat [2, 4H, 128] from lstm_cat_ih, pack: L.LSTM_DX_PACK_FLOATS floats."""
+    for n, t in (("wcat", wcat), ("pack", pack)):
+        _chk(t, n)
+    L.check(L.lib().ws_lstm_pack_dx_f8(_p(wcat), _p(pack), L.stream_ptr()), "ws_lstm_pack_dx_f8")
+
+
 def lstm_cat_ih(wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, n_in, wcat, bcat):
     for t in (wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, wcat, bcat):
         _chk(t, "lstm_cat_ih arg")
@@ -379,9 +388,9 @@ def blh_floats(nblocks: int, C_: int) -> int:
 
 
 def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None, run_if=None, gfmt=0, gates_in=None, dgates=None,
-               amax=None, rfmt=0):
+               amax=None, rfmt=0, dxn=None, wxpack=None):
     for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("wpack", wpack), ("dhcat", dhcat),
-                 ("gates_in", gates_in), ("dgates", dgates)):
+                 ("gates_in", gates_in), ("dgates", dgates), ("dxn", dxn), ("wxpack", wxpack)):
         _chk(t, n)
     a = L.LstmArgs()
     a.gates, a.cbuf, a.hcat, a.dhcat, a.wpack = _p(gates), _p(cbuf), _p(hcat), _p(dhcat), _p(wpack)
@@ -390,6 +399,10 @@ def _lstm_args(gates, cbuf, hcat, wpack, sm: SeqMap, mode, dhcat=None, run_if=No
     a.run_if = C.c_void_p(run_if.data_ptr()) if run_if is not None else None
     a.gates_in, a.dgates, a.gfmt, a.rfmt = _p(gates_in), _p(dgates), gfmt, rfmt
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
+    if dxn is not None:     # ABI v19: [2, P, 128], one plain-row buffer per direction
+        if dxn.dim() != 3 or dxn.shape[0] != 2 or dxn.shape[2] != 128 or getattr(sm, "nvalid", 0):
+            raise L.WesepHipError(f"lstm_bwd: dxn must be [2, P, 128] on a sequence map without padding sequences, got {tuple(dxn.shape)}")
+        a.dxn, a.dxn_dir_stride, a.wxpack = _p(dxn), dxn.shape[1] * 128, _p(wxpack)
     return a
 
 
@@ -401,12 +414,15 @@ def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, run_if=No
 
 
 def lstm_bwd(gates, cbuf, hcat, dhcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, gfmt=0, dgates=None, run_if=None, amax=None,
-             rfmt=0):
+             rfmt=0, dxn=None, wxpack=None):
     """run_if (blocked-layout modes): 1-element int32 device tensor; the launch is a no-op unless it is non-zero at
     kernel start -- the predicated fall-back behind lstm_bwd_pair.  dgates: out-of-place d(gates) (required for
     GATES_H2S; optional BLH buffer for GATES_H2, which then leaves the saved gates intact).  rfmt = 2 (LSTM_BF16X3_BLK with
-    GATES_H2F only): fp16 recurrence on fp16 + FP8 weights, wpack from lstm_pack_bwd_f8."""
-    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat, gfmt=gfmt, dgates=dgates, run_if=run_if, amax=amax, rfmt=rfmt)
+    GATES_H2F only): fp16 recurrence on fp16 + FP8 weights, wpack from lstm_pack_bwd_f8.  dxn [2, P, 128] + wxpack
+    (lstm_pack_dx_f8; rfmt 2 only, ABI v19): the kernel also writes d(normalised input) per direction -- plain rows at the
+    sequence map's positions -- so that gemm_b2p over d(gates) is not needed (gn_bwd_fused(..., dxn2=) adds the two)."""
+    a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, dhcat, gfmt=gfmt, dgates=dgates, run_if=run_if, amax=amax, rfmt=rfmt,
+                   dxn=dxn, wxpack=wxpack)
     # per (position, direction, unit): read 4 gates + c + dh, write 4 d(gates); 2 * 4H * H MACs per position
     if run_if is None:
         _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * (ALG_LSTM_UNITS or L.LSTM_H),
@@ -612,8 +628,20 @@ def lstm_pack_pair(whh_f, whh_r, pack, f16=False):
     L.check(fn(_p(whh_f), _p(whh_r), _p(pack), L.stream_ptr()), "ws_lstm_pack_pair")
 
 
+def wait_word(word, target: int, max_us: int = 300):
+    """ws_wait_word on the CURRENT stream: a one-wave gate that ends when the 1-element int32 device tensor `word` has reached
+    `target` or after `max_us` microseconds -- what is enqueued behind it starts once the kernel that counts its workgroups
+    into `word` (lstm_bwd_pair(..., resident=)) is fully resident."""
+    L.check(L.lib().ws_wait_word(_word(word), int(target), int(max_us), L.stream_ptr()), "ws_wait_word")
+
+
+def pair_workgroups(sm: SeqMap) -> int:
+    """Live workgroups of a pair BPTT launch: two members per (tile, direction)."""
+    return 4 * (-(-sm.nseq // 32))
+
+
 def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None,
-                  repairable=False, amax=None, rfmt=0):
+                  repairable=False, amax=None, rfmt=0, resident=None):
     """BPTT on the blocked layout over pairs of workgroups (lstm_pair.hip); gates: activated gates in,
     d(pre-activation gates) (BLS) out.  Returns the launch's timeout word; in place, so there is no device-side
     fall-back: poll_cluster_status raises (one step late, without a host sync) when a bounded wait timed out."""
@@ -633,6 +661,7 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg
     a.gfmt, a.dgates = gfmt, _p(dgates)
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
     a.rfmt = rfmt           # 1 / 2: fp16 recurrence (wpack from lstm_pack_pair(..., f16=rfmt); WS_GATES_H2F only)
+    a.resident = C.c_void_p(resident.data_ptr()) if resident is not None else None    # (zeroed word: one count per workgroup)
     _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * (ALG_LSTM_UNITS or L.LSTM_H),
              2 * sm.nseq * sm.L * 2 * 4 * (ALG_LSTM_UNITS or L.LSTM_H) ** 2)
     L.check(L.lib().ws_lstm_bwd_pair(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_pair")

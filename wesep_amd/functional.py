@@ -203,13 +203,23 @@ def pair_rfmt(gfmt) -> int:
 
 
 def band_rfmt(gfmt, lmode) -> int:
-    """Arithmetic of the streaming BPTT's recurrent product (ws_lstm_args.rfmt, ABI v18): WESEP_BAND_RF=2 (opt-in) = the stored
-    scaled-fp16 d(gates) x W_hh as fp16 hi + scaled-FP8 lo, two MFMAs per product and three quarters of the weight stream;
-    32-sequence blocked kernels with WS_GATES_H2F only.  Default 0: the three-term split-bf16 product."""
-    rf = int(os.environ.get("WESEP_BAND_RF", "0"))
+    """Arithmetic of the streaming BPTT's recurrent product (ws_lstm_args.rfmt, ABI v18): 2 (the default since round 6, with
+    WS_GATES_H2F on the 32-sequence blocked kernels) = the stored scaled-fp16 d(gates) x W_hh as fp16 hi + scaled-FP8 lo, two
+    MFMAs per product and three quarters of the weight stream -- the pair BPTT's arithmetic (pair_rfmt); config 2's parity and
+    the 60-step trajectory with it: profiles/r06_c1_parity_brf2.log, r05_c23_band_rf2_trajectory.log.  WESEP_BAND_RF=0: the
+    three-term split-bf16 product of rounds 1-5."""
+    rf = int(os.environ.get("WESEP_BAND_RF", "2"))
     if rf not in (0, 2):
         raise ValueError(f"WESEP_BAND_RF={rf}: 0 or 2")
     return rf if gfmt == L.GATES_H2F and lmode == L.LSTM_BF16X3_BLK else 0
+
+
+def band_dx(brf, seq, geo) -> bool:
+    """d(xn) = d(gates) W_ih computed INSIDE the streaming BPTT (ws_lstm_args.dxn, ABI v19; default on with band_rfmt 2): the
+    kernel holds d(gates) in LDS when it produces them, so ws_gemm_b2p's second pass over that 2.1 GB buffer (per band-view
+    layer at R = 32) and its launch disappear; the fused GroupNorm backward adds the two directions' shares.  WESEP_BAND_DX=0
+    restores the separate GEMM."""
+    return (brf == 2 and os.environ.get("WESEP_BAND_DX", "1") != "0" and not seq.nvalid and dev.gn_bwd_fused_ok(geo))
 
 
 def wgrad_overlap() -> bool:
@@ -276,7 +286,13 @@ def mark_wgrads_ready(device):
     return ready
 
 
-def flush_deferred_wgrads(device, ready=None):
+def side_gate() -> bool:
+    """Hold the released weight-gradient jobs back until every workgroup of the pair BPTT they run beside is resident
+    (ws_wait_word behind the event gate; default on, WESEP_SIDE_GATE=0: the event gate alone)."""
+    return os.environ.get("WESEP_SIDE_GATE", "1") != "0"
+
+
+def flush_deferred_wgrads(device, ready=None, gate=None):
     """Launch every deferred weight-gradient job on the side stream, ordered after `ready` (default:
     everything enqueued so far on the current stream).  A TIME-VIEW recurrence keeps 128 of 256 CUs
     busy for ~5 ms: its backward marks `ready`, launches the recurrence FIRST -- so its workgroups
@@ -295,6 +311,12 @@ def flush_deferred_wgrads(device, ready=None):
         # -- fill the chip at once and the recurrence waits for a whole gemm_tnb wave: measured, step 127 -> 135.6 ms (pBSRNN),
         # 305 -> 326 ms (TF-GridNet), profiles/r04_ab_runs.md
         side.wait_event(ready)
+        if gate is not None:
+            # ... and, round 6, until the recurrence's workgroups HOLD their CUs (gate = (word, target) of lstm_bwd_pair's
+            # residency count): the event makes both runnable at the same instant, and the dispatcher then hands CUs to the
+            # GEMM's small workgroups that the pair's whole-CU workgroups have to wait for (0.55 ms per launch, measured)
+            dev.wait_word(gate[0], gate[1])
+            gate[0].record_stream(side)
         for job, done in jobs:
             side.wait_event(done)        # the job's own producer stream (defer_wgrad); precedes `ready` on one stream
             job(side)
@@ -492,13 +514,18 @@ class ResRNNBlkFn(torch.autograd.Function):
             # the backward's packs (transposed projections, BPTT weight stream) are built here, where the GPU has a
             # single stream to serve: built lazily in the backward, these 10 us launches queue behind the side stream's
             # chip-filling weight-gradient GEMMs for up to a millisecond each (round 2 profile: 4 ms per step)
-            W("projT"), W("wihT16" if gfmt == L.GATES_H2F else "wihT")
+            W("projT")
+            bdx = ctx.bptt == "stream" and band_dx(band_rfmt(gfmt, lmode), seq, geo)
+            if not bdx:
+                W("wihT16" if gfmt == L.GATES_H2F else "wihT")
             if ctx.bptt == "pair":
                 W("hhp16" if pair_rfmt(gfmt) else "hhp")
-            if ctx.bptt == "stream" or (ctx.bptt == "pair" and h2):
+            if (ctx.bptt == "stream" and not band_rfmt(gfmt, lmode)) or (ctx.bptt == "pair" and h2):
                 W("hh")     # (the pair BPTT's predicated streaming fall-back of the 2-byte formats)
             if ctx.bptt == "stream" and band_rfmt(gfmt, lmode):
                 W("hh8")
+                if bdx:
+                    W("wx8")
         # (with the fp16 copies the backward never reads the split-pair xn again: its 2-byte copy is saved instead)
         ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn16 if a16 else xn, wcat, norm_w, norm_b, pw, whf, whr, hcat16)
         ctx.a16 = a16
@@ -570,6 +597,7 @@ class ResRNNBlkFn(torch.autograd.Function):
         box = ctx.box
         # d(hcat) = dout Wp  (+ dout itself in BL for the weight gradient)
         dh, dout_bl = _empty(d, nb, 32 * 2 * H), _empty(d, nb, 32 * N)
+        dxn2 = None
         gfmt = ctx.gfmt
         # WS_GATES_H2F: the d(hcat) GEMM raises max |d(hcat)| of this launch in a device word; the BPTT scales its fp16 d(gates)
         # by the power of two it defines, the two consumers of d(gates) undo it (wesep_hip.h)
@@ -581,6 +609,7 @@ class ResRNNBlkFn(torch.autograd.Function):
         # half of the chip idle: the weight-gradient jobs deferred by the previous layers are released
         # right after it is launched
         ready = mark_wgrads_ready(d) if ctx.view == "time" else None
+        gate = None
         # time view: the pair kernel (lstm_pair.hip) -- W_hh's hi plane resident across two workgroups per tile, on HALF
         # of the CUs, so the side stream keeps the other half.  The cluster BPTT (all 256 CUs: it evicts the
         # side-stream weight-gradient GEMMs) stays opt-in (WESEP_LSTM_CLUSTER_BWD=1).  Both work in place without a
@@ -604,16 +633,22 @@ class ResRNNBlkFn(torch.autograd.Function):
             # co-resident (a resident RCCL kernel, another process) -- no NaN reaches a consumer (wesep_hip.h)
             dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else _empty(d, dev.blh_floats(nb, 2 * G4))
             rf = pair_rfmt(gfmt)
+            if ready is not None and side_gate() and _pending(d):
+                gate = (zero_words(d, 1), dev.pair_workgroups(seq))
             tw = dev.lstm_bwd_pair(gates, cbuf, dh, W("hhp16" if rf else "hhp"), seq, gfmt=gfmt, dgates=dg, repairable=True,
-                                   dbg=_pair_dbg(), amax=amax, rfmt=rf, dbg_buf=_pair_stamp_buf(d, seq.L))
+                                   dbg=_pair_dbg(), amax=amax, rfmt=rf, dbg_buf=_pair_stamp_buf(d, seq.L),
+                                   resident=gate[0] if gate else None)
             dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode, gfmt=gfmt, dgates=dg, run_if=tw, amax=amax)
         else:
             # streaming BPTT (band view): bf16 d(gates) in place over the unorm16 gates (H2) / split pairs to their own
             # buffer (H2S)
             dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else gates
             brf = band_rfmt(gfmt, ctx.lmode)
+            if band_dx(brf, seq, geo):
+                dxn2 = _empty(d, 2, P, N)        # d(xn) of each direction, written by the BPTT itself
             dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh8") if brf else W("hh")[1], seq, ctx.lmode, gfmt=gfmt,
-                         dgates=dg if gfmt == L.GATES_H2S else None, amax=amax, rfmt=brf)
+                         dgates=dg if gfmt == L.GATES_H2S else None, amax=amax, rfmt=brf, dxn=dxn2,
+                         wxpack=W("wx8") if dxn2 is not None else None)
         if _h2_probe() & 2 and gfmt == L.GATES_F32:
             _probe_round(gates, "bf16", packed=True)
         if _h2_probe() & 32 and gfmt == L.GATES_F32 and not torch.cuda.is_available():
@@ -625,7 +660,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             _PROBE_SAT[1] = max(_PROBE_SAT[1], float(sc.abs().max()) / 65504.0)
             gates.copy_(sc.clamp(-65504.0, 65504.0).half().float() / S)
         if ready is not None:
-            flush_deferred_wgrads(d, ready)
+            flush_deferred_wgrads(d, ready, gate)
         del dh
         # weight gradients: a side branch of the graph -> deferred to the side stream when a carrier
         # will deliver them
@@ -643,9 +678,12 @@ class ResRNNBlkFn(torch.autograd.Function):
             wg = ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax, hcat16)
         del dout_bl
         # d(normalised input) = dgates Wcat -> GroupNorm backward (+ residual path)
-        dxn = _empty(d, P, N)
-        dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=W("wihT16" if g_fmt == 2 else "wihT"), C_out=dxn, ldc=N, a_fmt=g_fmt,
-                     amax=amax)
+        if dxn2 is not None:
+            dxn, dxn_r = dxn2[0], dxn2[1]
+        else:
+            dxn, dxn_r = _empty(d, P, N), None
+            dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=W("wihT16" if g_fmt == 2 else "wihT"), C_out=dxn, ldc=N, a_fmt=g_fmt,
+                         amax=amax)
         dz = torch.empty_like(z)
         # (dgamma, dbeta): summed by the LAST workgroup of the kernel that produced the partials (wesep_hip.h, ABI v15) --
         # a separate ws_reduce_slabs launch on this stream can sit out a whole weight-gradient GEMM of the side stream
@@ -656,7 +694,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             ns2 = min(1024, -(-geo.ngroups // 4))
             pslab = _empty(d, ns2 + dev.tree_groups(ns2), 2, N)
             dev.gn_bwd_fused(z, dxn, stats, geo, norm_w, dz, ns2, pslab, res=dout, pout=dgb,
-                             counter=zero_words(d, 1 + dev.tree_groups(ns2)))
+                             counter=zero_words(d, 1 + dev.tree_groups(ns2)), dxn2=dxn_r)
         elif dev.gn_bwd_apply_pg_ok(geo):
             # time view: 1 024 groups of 256 KB: the group means first, then apply + parameter sums in ONE pass over x / dxn
             ab = _empty(d, geo.ngroups, 2)
@@ -734,6 +772,10 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
         if kind == "hh8":                 # BPTT pack of the streaming kernel's rfmt 2 (fp16 hi + scaled-FP8 lo of 256 w)
             pack = _empty(d, L.LSTM_PACK_FLOATS)
             dev.lstm_pack_bwd_f8(*W("whh"), pack)
+            return pack
+        if kind == "wx8":                 # W_ih^T stream of the BPTT's own d(xn) (ws_lstm_args.dxn): fp16 hi + scaled-FP8 lo
+            pack = _empty(d, L.LSTM_DX_PACK_FLOATS)
+            dev.lstm_pack_dx_f8(W("cat")[0], pack)
             return pack
         if kind in ("hhp", "hhp16"):      # hhp16: fp16 hi + fp16 / FP8 lo of 256 w (the rfmt = 1 / 2 pair BPTT)
             pack = _empty(d, L.LSTM_PACK_FLOATS)
