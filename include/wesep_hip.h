@@ -710,11 +710,18 @@ typedef struct ws_lstm_fused_args {
   const float* wpack;
   const float* bias;
   int nseq, L;
-  int gfmt, pad_;       /* ABI v15: WS_GATES_* (!= 0: `gates` receives unorm16 BLH) */
+  int gfmt;             /* ABI v15: WS_GATES_* (!= 0: `gates` receives unorm16 BLH) */
+  int hfmt;             /* ABI v19 (the former pad_: 0 = every earlier behaviour): 1 = the recurrent part of the stream on
+                           v_mfma_f32_32x32x16_f16 with h as ONE fp16 operand and W_hh as fp16 hi / lo of 256 w (two MFMAs per
+                           product instead of three; the arithmetic of ws_lstm_fwd_cluster2) -- wpack from
+                           ws_lstm_pack_fused_h16, 2-byte gate formats only, always the 64-sequence kernel           */
 } ws_lstm_fused_args;
 #define WS_LSTM_FUSED_PACK_FLOATS (2 * 8 * 24 * 4 * 2 * 64 * 4)
 int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
                        float* pack, void* stream);
+/* ABI v19: the pack of hfmt = 1 -- same size and unit order; both parts hold 256 w: W_ih as bf16 hi / lo, W_hh as fp16 hi / lo */
+int ws_lstm_pack_fused_h16(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
+                           float* pack, void* stream);
 int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream);
 
 /* ---- wespeaker ResNet speaker encoder (third-party model, call sites

@@ -94,7 +94,7 @@ def lstm_cat_ih(wih_f, wih_r, bih_f, bhh_f, bih_r, bhh_r, n_in, wcat, bcat):
     bcat.reshape(2, G4)[0], bcat.reshape(2, G4)[1] = bih_f + bhh_f, bih_r + bhh_r
 
 
-def lstm_pack_fused(wih_f, wih_r, whh_f, whh_r, pack):
+def lstm_pack_fused(wih_f, wih_r, whh_f, whh_r, pack, hfmt=0):
     _PACKS[pack.data_ptr()] = tuple(t.clone() for t in (wih_f, wih_r, whh_f, whh_r))
 
 
@@ -360,7 +360,7 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0, dbg_buf=Non
     return torch.zeros(1, dtype=torch.int32)
 
 
-def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm, gfmt=0):
+def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm, gfmt=0, hfmt=0):
     nt, L = _ntile(sm), sm.L
     wih_f, wih_r, whf, whr = _PACKS[wpack.data_ptr()]
     x = bl_get(xn, nt, L, 128)
@@ -368,7 +368,7 @@ def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm, gfmt=0):
         x = x.half().float()
     b = bias.reshape(2, G4)
     pre = torch.stack([x @ wih_f.t() + b[0], x @ wih_r.t() + b[1]], 2)
-    _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt)
+    _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt, hq16=bool(hfmt))     # (hfmt 1: fp16 h in the recurrent product)
 
 
 def gemm_tnb(*, G, g_width, g_off, g_cols, A0, a0_width, a0_off, a0_cols, nblk, L_, slab, nsplit, blocks_per_split,

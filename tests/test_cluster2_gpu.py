@@ -145,3 +145,59 @@ def test_resrnn_time_view_cluster2_on_vs_off(monkeypatch, force_timeout):
     print(f"cluster2 on/off (forced time-out {force_timeout}): out {rel(o1, o0):.2e} dz {rel(dz1, dz0):.2e} worst grad {worst:.2e}")
     assert rel(o1, o0) < 2e-4 and rel(dz1, dz0) < 5e-4 and worst < 5e-4
     dev.poll_cluster_status(d, block=True)      # (a repaired forward time-out is counted, not raised)
+
+
+@pytest.mark.parametrize("dims", [(4, 9, 16), (3, 32, 43)])
+def test_fused_band_forward_fp16_h_vs_torch_lstm_and_three_term_kernel(dims):
+    """ws_lstm_fused_args.hfmt = 1 (ABI v19, csrc/lstm_fused.hip lstm_fwd_fused64h16_kernel): the band view's fused forward with the
+    recurrent part on the fp16 MFMA (h as one fp16 operand, W_hh as fp16 hi / lo of 256 w: two terms) -- the arithmetic of
+    ws_lstm_fwd_cluster2 in the throughput kernel.  Against (a) torch's LSTM in fp64 (nn.LSTM inside ResRNN, bsrnn.py:27-33,40) and
+    (b) the three-term kernel (hfmt 0) on the same input, both formats of the saved state; deterministic; odd tile counts (the
+    second tile of the last 64-sequence workgroup empty) and ragged last tiles included."""
+    from wesep_amd import dev
+    from wesep_amd.functional import _view_maps
+    d = _cuda()
+    g = torch.Generator().manual_seed(21)
+    R, K, Tf = dims
+    P = R * K * Tf
+    _, _, seq, _ = _view_maps("band", R, K, Tf, N)                   # sequences = (row, frame), steps = bands
+    nb = dev.bl_num_blocks(seq)
+    rnd = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale)
+    w = {k: v.to(d) for k, v in dict(wih_f=rnd(4 * H, N, scale=0.08), wih_r=rnd(4 * H, N, scale=0.08), whh_f=rnd(4 * H, H, scale=0.06),
+                                     whh_r=rnd(4 * H, H, scale=0.06), bf=rnd(4 * H, scale=0.2), br=rnd(4 * H, scale=0.2)).items()}
+    x = rnd(P, N).to(d)
+    bias = torch.cat([w["bf"], w["br"]]).contiguous()
+    xn = dev.to_blocked(x, seq, split=True)
+    outs = {}
+    for hf in (0, 1, 1):
+        fp = torch.empty(L.LSTM_FUSED_PACK_FLOATS, device=d)
+        dev.lstm_pack_fused(w["wih_f"], w["wih_r"], w["whh_f"], w["whh_r"], fp, hfmt=hf)
+        gh = torch.zeros(dev.blh_floats(nb, 8 * H), device=d)
+        c = torch.full((nb, 2 * H // 4, 32, 4), float("nan"), device=d)
+        h = torch.full_like(c, float("nan"))
+        dev.lstm_fwd_fused(gh, c, h, xn, fp, bias, seq, gfmt=L.GATES_H2F, hfmt=hf)
+        torch.cuda.synchronize()
+        if hf in outs:                                               # the second hfmt 1 launch: deterministic
+            bits = lambda t: t.contiguous().view(torch.int32)
+            assert all(torch.equal(bits(a), bits(b)) for a, b in zip(outs[hf], (gh, c, h)))
+        outs[hf] = (gh, c, h)
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True).double()
+    zero = torch.zeros(4 * H, dtype=torch.float64)
+    with torch.no_grad():
+        for nm, src in (("weight_ih_l0", w["wih_f"]), ("weight_hh_l0", w["whh_f"]), ("bias_ih_l0", w["bf"]), ("bias_hh_l0", zero),
+                        ("weight_ih_l0_reverse", w["wih_r"]), ("weight_hh_l0_reverse", w["whh_r"]), ("bias_ih_l0_reverse", w["br"]),
+                        ("bias_hh_l0_reverse", zero)):
+            getattr(lstm, nm).copy_(src.double().cpu())
+        # band view: sequence (r, tf) walks the K bands; plain row (r * K + k) * Tf + tf
+        out, _ = lstm(x.double().cpu().view(R, K, Tf, N).permute(0, 2, 1, 3).reshape(R * Tf, K, N))
+    want = out.view(R, Tf, K, 2 * H).permute(0, 2, 1, 3).reshape(P, 2 * H)
+    for hf in (0, 1):
+        gh, c, h = outs[hf]
+        assert not torch.isnan(c).any() and not torch.isnan(h).any()
+        err = rel(dev.from_blocked(h, seq, P, split=True), want)
+        print(f"fused band forward {dims}, hfmt {hf}: h rel vs torch fp64 {err:.2e}")
+        assert err < (1e-3 if hf else 1e-4), (hf, err)
+    (g1, c1, h1), (g0, c0, h0) = outs[1], outs[0]
+    assert rel(c1, c0) < 1e-3 and rel(dev.bls_unpack(h1), dev.bls_unpack(h0)) < 1e-3
+    ga, gb = dev.blh_gates_unpack(g1, nb), dev.blh_gates_unpack(g0, nb)
+    assert float((ga - gb).abs().max()) < 2e-3 and rel(ga, gb) < 3e-4

@@ -223,9 +223,12 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
         torch.cuda.synchronize()
         assert bool(torch.isfinite(dxn).all())                     # every row of both directions was written
         assert torch.equal(dxn, dxn_b)
-        # (one accumulator chain instead of two in this instantiation: the same products, another summation order)
+        # (one accumulator chain instead of two, half of the waves walk the k-steps pairwise swapped: the same products in another
+        #  summation order -- last-bit differences of d(h) that flip fp16 roundings of the stored d(gates): ulps, not errors)
         gx = x_in.reshape(-1)[: ref.numel() // 2].view(torch.float16).view(dg.shape).float() / S
-        assert float((gx - got2).norm() / got2.norm()) < 2e-5
+        e_x = float((gx - got2).norm() / got2.norm())
+        print(f"d(gates) of the launch that also writes d(xn) vs the plain rfmt 2 launch: rel-L2 {e_x:.2e}")
+        assert e_x < 2e-4 and float((gx - dg).norm() / dg.norm()) < 6e-4
         wt16 = torch.empty(N * 2 * 4 * H, device=d)
         dev.pack_w(wcat.reshape(2 * 4 * H, N), N, 2 * 4 * H, N, wt16, trans=True, order=1, f16=True)
         c_ref = torch.full((P, N), float("nan"), device=d)

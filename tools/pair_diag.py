@@ -33,7 +33,7 @@ def stamps(R, Tf=501):
     pp = torch.empty(L.LSTM_PACK_FLOATS, device=d)
     dev.lstm_pack_pair(whf, whr, pp)
     for rep in range(2):
-        dbuf = torch.zeros(Tf * 2 * 8 * 2, device=d)
+        dbuf = torch.zeros(Tf * 2 * 8 * 2 + 256 * 4 * 2, device=d)
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g2 = gates.clone()
         t0.record()
@@ -41,7 +41,7 @@ def stamps(R, Tf=501):
         t1.record()
         torch.cuda.synchronize()
     ms = t0.elapsed_time(t1)
-    ts = dbuf.view(torch.int64).view(Tf, 2, 8).cpu().double()
+    ts = dbuf.view(torch.int64)[: Tf * 16].view(Tf, 2, 8).cpu().double()
     span = float(ts[-1, 0, 0] - ts[5, 0, 0]) / (Tf - 6)
     us_per_tick = (ms * 1e3 / Tf) / span if span > 0 else float("nan")
     print(f"launch {ms:.3f} ms = {ms * 1e3 / Tf:.2f} us/step with stamps; {span:.0f} ticks per step -> {us_per_tick * 1e3:.2f} ns per tick")

@@ -65,14 +65,14 @@ def main():
     for iobit, ionm in ((0, "output stores on the X-waves after their MFMAs"),):
       if not a.no_stamps:
         for rep in range(2):
-            dbuf = torch.zeros(Tf * 2 * 8 * 2, device=d)
+            dbuf = torch.zeros(Tf * 2 * 8 * 2 + 256 * 4 * 2, device=d)   # (+ the per-workgroup wall-clock rows of round 6)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             dev.lstm_fwd_cluster2(gh, cbuf, hcat, xn16, wcat, bcat, whf, whr, seq, status=st, dbg=2048 + iobit, dbg_buf=dbuf)
             e1.record()
             torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
-        ts = dbuf.view(torch.int64).view(Tf, 2, 8).cpu().double()
+        ts = dbuf.view(torch.int64)[: Tf * 16].view(Tf, 2, 8).cpu().double()
         span = float(ts[-1, 0, 0] - ts[5, 0, 0]) / (Tf - 6)
         upt = (ms * 1e3 / Tf) / span if span > 0 else float("nan")
         print(f"--- stamps, cluster2 forward, {ionm}: launch {ms:.3f} ms = {ms * 1e3 / Tf:.2f} us/step with stamps; {span:.0f} ticks per step")
@@ -118,7 +118,7 @@ def main():
              "X: next loads requested", "X: partner's flag seen", "X: gather arrived"]
     for rf, pk, nm, xdbg in ((0, pp, "bf16x3, flag hand-off", 0), (1, pp16, "fp16x2 tagged", 0), (2, pp8, "fp16x2 tagged, FP8 lo resident", 0)):
         for rep in range(2):
-            dbuf = torch.zeros(Tf * 2 * 8 * 2, device=d)
+            dbuf = torch.zeros(Tf * 2 * 8 * 2 + 256 * 4 * 2, device=d)   # (+ the per-workgroup wall-clock rows of round 6)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             dev.lstm_bwd_pair(gh, cbuf, dh, pk, seq, status=st, gfmt=L.GATES_H2F, dgates=dgo, amax=amax, rfmt=rf, dbg=2048 + xdbg,
@@ -126,7 +126,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
-        ts = dbuf.view(torch.int64).view(Tf, 2, 8).cpu().double()
+        ts = dbuf.view(torch.int64)[: Tf * 16].view(Tf, 2, 8).cpu().double()
         span = float(ts[-1, 0, 0] - ts[5, 0, 0]) / (Tf - 6)
         upt = (ms * 1e3 / Tf) / span if span > 0 else float("nan")
         print(f"--- stamps, WS_GATES_H2F {nm}: launch {ms:.3f} ms = {ms * 1e3 / Tf:.2f} us/step with stamps; {span:.0f} ticks per step")

@@ -55,8 +55,18 @@ def main():
         os.environ["WESEP_PAIR_STAMP"] = "0"
         print(f"=== side stream {'EMPTY (WESEP_PROBE_SKIP_WGRAD=1)' if skip == '1' else 'carrying the weight-gradient jobs'}: "
               f"stamped step {e0.elapsed_time(e1):.1f} ms, {len(F.PAIR_STAMPS)} pair launches (backward order: last layer first)")
+        walls = []
         for li, (buf, Ls) in enumerate(F.PAIR_STAMPS):
-            ts = buf.view(torch.int64).view(Ls, 2, 8).cpu().double()
+            raw = buf.view(torch.int64).cpu()
+            ts = raw[: Ls * 16].view(Ls, 2, 8).double()
+            wt = raw[Ls * 16:].view(256, 4)
+            wt = wt[wt[:, 0] > 0].double() / 100.0          # microseconds of the 100 MHz wall clock; rows of live workgroups
+            t_in = wt[:, 0].min()
+            walls.append(f"    launch {li}: {wt.shape[0]} workgroups | entry spread {float(wt[:, 0].max() - t_in):7.1f} us | prologue "
+                         f"{float((wt[:, 1] - wt[:, 0]).mean()):6.1f} (max {float((wt[:, 1] - wt[:, 0]).max()):6.1f}) | loop mean "
+                         f"{float((wt[:, 2] - wt[:, 1]).mean()):7.1f} min {float((wt[:, 2] - wt[:, 1]).min()):7.1f} max "
+                         f"{float((wt[:, 2] - wt[:, 1]).max()):7.1f} | first entry -> last loop end {float(wt[:, 2].max() - t_in):7.1f} | "
+                         f"pair 0 loop {float(wt[0, 2] - wt[0, 1]):7.1f}")
             # s_memtime ticks at 100 MHz on gfx950 (profiles/r05_recurrence_step_budget.txt: 16659 ticks = 7.07 us would be
             # 2.36 GHz -- it is the shader clock there); report ticks and the step's share per phase
             span = float(ts[-1, 0, 0] - ts[5, 0, 0]) / (Ls - 6)
@@ -66,6 +76,8 @@ def main():
                 ks = range(1, 8) if role == 0 else range(1, 5)
                 line.append(rn + " " + " ".join(f"{float(tt[:, k].mean()) / span:.2f}" for k in ks))
             print("  " + " | ".join(line))
+        print("  wall clock per launch (every workgroup):")
+        print("\n".join(walls))
     print("columns (fractions of the step since the loop top): " + "; ".join(NAMES[1:]))
 
 

@@ -149,7 +149,7 @@ assert GROUP_NT_DTYPE.itemsize == 72 and GROUP_TN_DTYPE.itemsize == 72 and TENSO
 
 class LstmFusedArgs(C.Structure):
     _fields_ = [("gates", _p), ("cbuf", _p), ("hcat", _p), ("xn", _p), ("wpack", _p), ("bias", _p),
-                ("nseq", _i), ("L", _i), ("gfmt", _i), ("pad_", _i)]
+                ("nseq", _i), ("L", _i), ("gfmt", _i), ("hfmt", _i)]            # hfmt: ABI v19 (the former pad_)
 
 
 LSTM_FUSED_PACK_FLOATS = 2 * 8 * 24 * 4 * 2 * 64 * 4
@@ -265,6 +265,7 @@ _SIGS = {
     "ws_power_spec": (_i, [_p, _ll, _i, _i, _i, _p, _p]),
     "ws_log_eps": (_i, [_p, _ll, C.c_float, _p]),
     "ws_lstm_pack_fused": (_i, [_p, _p, _p, _p, _p, _p]),
+    "ws_lstm_pack_fused_h16": (_i, [_p, _p, _p, _p, _p, _p]),
     "ws_lstm_fwd_fused": (_i, [C.POINTER(LstmFusedArgs), _p]),
     "ws_grad_norms": (_i, [_p, _i, _p, _p, _p]),
     "ws_clip_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p]),

@@ -128,12 +128,15 @@ int ws_launch_lstm_pack_bwd_f8(const float* whh_f, const float* whh_r, float* pa
 }
 
 // d(xn) inside the BPTT (ws_lstm_args.dxn, ABI v19): the A operand W_ih^T of  d(xn)^T[input][seq] = W_ih^T[input][gate col] *
-// d(gates)^T[gate col][seq]  on v_mfma_f32_16x16x32_f16, in the arithmetic of rfmt 2 -- fp16 hi of 256 w + e4m3 codes of the
-// remainder over a power-of-two scale.  wcat: [2][4H][128] (ws_lstm_cat_ih).  Wave w of direction d owns inputs [16w, 16w + 16).
-// Per (d, w) region of WS_DX_REGION bytes: 16 chunks of 2 k32-steps, chunk c at c * 3 KB = [2 hi fragments of 1 KB: lane * 16
-// bytes][2 code fragments of 512 B: lane * 8 bytes]; at byte 48 K eight floats, the scale of each GROUP of 4 k32-steps (two
-// chunks: the 128 gate columns of eight 16-wide k-steps -- the groups of lstm_pack_bwd_f8_kernel).  Fragment (k32-step kk, lane):
-// element j = 256 * wcat[d][32 kk + 8 (lane >> 4) + j][16 w + (lane & 15)].  One workgroup per (d, w, group).
+// d(gates)^T[gate col][seq]  in the arithmetic of rfmt 2 -- fp16 hi of 256 w + e4m3 codes of the remainder over a power-of-two
+// scale -- on the SAME v_mfma_f32_32x32x16_f16 B fragments the recurrent product reads from the LDS image (a second pass over
+// the image with the 16 x 16 shape was measured: the kernel became bound by LDS reads, 1.98 -> 2.65 ms per launch).  wcat:
+// [2][4H][128] (ws_lstm_cat_ih).  Wave w of direction d owns the 32 inputs [32 (w & 3), + 32) for the k-steps ks with
+// (ks & 1) == (w >> 2); the two halves' partial sums meet in LDS.  Per (d, w) region of WS_DX_REGION bytes: 16 chunks (one per
+// four k-steps of the W_hh stream), chunk c at c * 3 KB = [2 hi fragments of 1 KB: lane * 16 bytes][2 code fragments of 512 B:
+// lane * 8 bytes] for ks = 4c + (w >> 2) and 4c + (w >> 2) + 2; at byte 48 K eight floats, the scale of each GROUP of two chunks.
+// Fragment (ks, lane): element j = 256 * wcat[d][16 ks + 8 (lane >> 5) + j][32 (w & 3) + (lane & 31)].  One workgroup per
+// (d, w, group).
 #define WS_DX_REGION (48 * 1024 + 64)
 __global__ __launch_bounds__(512) void lstm_pack_dx_f8_kernel(const float* __restrict__ wcat, char* __restrict__ px) {
   __shared__ float red[8];
@@ -141,10 +144,11 @@ __global__ __launch_bounds__(512) void lstm_pack_dx_f8_kernel(const float* __res
   const float* W = wcat + (long long)d * LG * 128;
   const int tid = threadIdx.x;
   float v0[2], v1[2], m = 0.f;
+  auto ks_of = [&](int f) { return 4 * (2 * grp + (f >> 1)) + (w >> 2) + 2 * (f & 1); };   // f = 0..3: the group's four k-steps
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {   // 4 k32-steps x 64 lanes x 4 element pairs = 1024 pairs, 2 per thread
-    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, kk = 4 * grp + (pi >> 8);
-    const int row = 32 * kk + 8 * (lane >> 4) + 2 * j2, u = 16 * w + (lane & 15);
+  for (int i = 0; i < 2; ++i) {   // 4 k-steps x 64 lanes x 4 element pairs = 1024 pairs, 2 per thread
+    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, ks = ks_of(pi >> 8);
+    const int row = 16 * ks + 8 * (lane >> 5) + 2 * j2, u = 32 * (w & 3) + (lane & 31);
     v0[i] = 256.f * W[row * 128 + u];
     v1[i] = 256.f * W[(row + 1) * 128 + u];
     m = fmaxf(m, fmaxf(fabsf(v0[i]), fabsf(v1[i])));
@@ -162,14 +166,14 @@ __global__ __launch_bounds__(512) void lstm_pack_dx_f8_kernel(const float* __res
   if (tid == 0) reinterpret_cast<float*>(ob + 48 * 1024)[grp] = S;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, kk = 4 * grp + (pi >> 8);
+    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, f = pi >> 8;
     const _Float16 h0 = (_Float16)v0[i], h1 = (_Float16)v1[i];
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     typedef short s16x2 __attribute__((ext_vector_type(2)));
-    char* cb = ob + (kk >> 1) * 3072;
-    *reinterpret_cast<f16x2*>(cb + (kk & 1) * 1024 + lane * 16 + j2 * 4) = f16x2{h0, h1};
+    char* cb = ob + (2 * grp + (f >> 1)) * 3072;
+    *reinterpret_cast<f16x2*>(cb + (f & 1) * 1024 + lane * 16 + j2 * 4) = f16x2{h0, h1};
     const s16x2 c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(s16x2{0, 0}, v0[i] - (float)h0, v1[i] - (float)h1, S, false);
-    *reinterpret_cast<short*>(cb + 2048 + (kk & 1) * 512 + lane * 8 + j2 * 2) = c[0];
+    *reinterpret_cast<short*>(cb + 2048 + (f & 1) * 512 + lane * 8 + j2 * 2) = c[0];
   }
 }
 
@@ -371,17 +375,19 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
 // scaled-fp16 d(gates) as its one B operand (one LDS image plane) against W_hh as fp16 hi + scaled-FP8 lo of 256 w
 // (lstm_pack_bwd_f8_kernel): two MFMAs per product instead of three and 96 instead of 128 KB streamed per wave and step; the
 // codes become fp16 fragments on the way in (v_cvt_scalef32_pk_f16_fp8 with the group's scale: no separate accumulator scale).
-// DX (ABI v19, RF = 2 only): d(xn) = d(gates) W_ih of this direction computed HERE, from the d(gates) image the recurrent product
-// reads anyway -- wave w adds the 16 x 32 tile (inputs [16w, 16w + 16) x the workgroup's 32 sequences) as two 16 x 16 tiles on
-// v_mfma_f32_16x16x32_f16 (64 MFMAs of half the size per step beside the 128 of d(h): the matrix pipe was idle two thirds of this
-// kernel's step), streams W_ih^T beside W_hh (48 KB per wave and step: lstm_pack_dx_f8_kernel) and stores plain rows of
-// p.dxn + d * p.dxn_dir_stride at the sequence map's positions.  ws_gemm_b2p(a_fmt 2) over d(gates) -- 2.1 GB read per band-view
-// layer at R = 32 -- is not launched; the GroupNorm backward adds the two directions (ws_gn_bwd_fused dxn2).
+// DX (ABI v19, RF = 2 only): d(xn) = d(gates) W_ih of this direction computed HERE, from the B fragments of the d(gates) image
+// the recurrent product loads anyway: wave w adds the 32 x 32 tile (inputs [32 (w & 3), + 32) x the workgroup's 32 sequences)
+// over the k-steps of its parity (w >> 2) -- 64 more MFMAs per wave and step beside the 128 of d(h): the matrix pipe was idle two
+// thirds of this kernel's step --, streams its W_ih^T slice beside W_hh (48 KB per wave and step: lstm_pack_dx_f8_kernel), the two
+// parities' partial tiles meet in 16 KB of LDS behind the step's closing barrier, and waves 0..3 store plain rows of p.dxn + d *
+// p.dxn_dir_stride at the sequence map's positions.  ws_gemm_b2p(a_fmt 2) over d(gates) -- 2.1 GB read per band-view layer at
+// R = 32 -- is not launched; the GroupNorm backward adds the two directions (ws_gn_bwd_fused2).
 template <bool BLK, int DBG, int GF = 0, int RF = 0, bool DX = false>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_args p) {
   static_assert(RF == 0 || (BLK && GF == WS_GATES_H2F), "the fp16 recurrence takes the scaled-fp16 d(gates) of WS_GATES_H2F");
   static_assert(!DX || RF == 2, "d(xn) in the BPTT rides on the fp16 d(gates) image of rfmt 2");
   __shared__ __attribute__((aligned(16))) __bf16 dgl[RF ? 1 : 2][SQ * DROW];  // [part][seq][gate col] 129 / 65 KB
+  __shared__ __attribute__((aligned(16))) f32x4 xred[DX ? 4 * 4 * 64 : 1];    // DX: partial d(xn) tiles of waves 4..7, 16 KB
   if (p.run_if && *p.run_if == 0u) return;  // predicated fall-back launch (wesep_hip.h): uniform
   const int d = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -422,6 +428,11 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
     else return *reinterpret_cast<const f32x4*>(b + coff(t, j));
   };
 
+  // this wave's d(xn) k-steps of a chunk are kpar and kpar + 2, kpar = w >> 2 (the pack's order).  Waves 4..7 walk every PAIR of
+  // k-steps in swapped order (ring slot q holds k-step q ^ kpar: a uniform address bit in wfill, a second base address for the B
+  // fragments), so that for every wave the even slots are its d(xn) k-steps -- static register indices, no branch, no select;
+  // d(h) sums the same products in another order
+  const int kpar = DX ? (w >> 2) : 0;
   // weight stream: per k-step 2 fragments (hi, lo); ring slots hold 4 k-steps
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.wpack) + (long long)(d * 8 + w) * (64 * 2 * 64 * 4), 0, 64 * 2 * 1024, 0x00020000);
@@ -433,15 +444,16 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
     if constexpr (RF != 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        wr[s][q] = wload(wrs, wlane + q * 1024, zo + chunk * 6144);
-        wq[s][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8 + q * 512, zo + chunk * 6144 + 4096, 0));
+        const int fq = q ^ kpar;   // (DX, waves 4..7: the pair's k-steps in swapped order -- see kpar)
+        wr[s][q] = wload(wrs, wlane, zo + chunk * 6144 + fq * 1024);
+        wq[s][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, zo + chunk * 6144 + 4096 + fq * 512, 0));
       }
     } else {
 #pragma unroll
       for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + chunk * 8192 + (f >> 2) * 4096);
     }
   };
-  // DX: the W_ih^T stream of this wave's 16 inputs (lstm_pack_dx_f8_kernel), ring slots of 2 k32-steps
+  // DX: the W_ih^T stream of this wave's (input tile, k-step parity) (lstm_pack_dx_f8_kernel): two k-steps per chunk
   typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
   typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   bf16x8 xr[2][DX ? 2 : 1];
   u32x2 xq[2][DX ? 2 : 1];
   float xS[DX ? 8 : 1];
-  f32x4 dx0 = {0.f, 0.f, 0.f, 0.f}, dx1 = {0.f, 0.f, 0.f, 0.f};
+  f32x16 dxa;
   auto xfill = [&](int s, int chunk, int zo) {
     if constexpr (DX) {
 #pragma unroll
@@ -474,19 +486,15 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
 #pragma unroll
     for (int g8 = 0; g8 < 8; ++g8) xS[g8] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st[g8])));
   }
-  // DX: this lane's two d(xn) cells (sequences n and n + 16 of the tile, n = lane & 15; inputs 16w + 4 (lane >> 4) .. + 3) in the
-  // plain [P][128] buffer of this direction, as 32-bit byte offsets of a buffer store: row = (seq / sq_div) * sq_s1 + (seq %
-  // sq_div) * sq_s2 (+ t * step_rows, added per step) -- ws_seqmap; a padded slot gets an offset beyond the descriptor's size
+  // DX: this lane's d(xn) cells -- D of the 32 x 32 tile: sequence l31, inputs 32 (w & 3) + 8 j + 4 half .. + 3 for j = 0..3 -- in
+  // the plain [P][128] buffer of this direction, as a 32-bit byte offset of a buffer store: row = (seq / sq_div) * sq_s1 + (seq
+  // % sq_div) * sq_s2 (+ t * step_rows, added per step) -- ws_seqmap; a padded slot gets an offset beyond the descriptor's size
   // (the buffer is < 2 GB: lstm_check): the hardware drops the store
-  const int xn_ = lane & 15, xq4 = lane >> 4;
-  unsigned xoff[2] = {0u, 0u};
+  unsigned xoff = 0u;
   if constexpr (DX) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int sq = (int)blockIdx.x * SQ + 16 * e + xn_;
-      const long long row = (long long)(sq / p.sq_div) * p.sq_s1 + (long long)(sq % p.sq_div) * p.sq_s2;
-      xoff[e] = sq < p.nseq ? (unsigned)(row * 512 + (16 * w + 4 * xq4) * 4) : 0x80000000u;   // (+ t * step_rows * 512 < 2^31)
-    }
+    const int sq = (int)blockIdx.x * SQ + l31;
+    const long long row = (long long)(sq / p.sq_div) * p.sq_s1 + (long long)(sq % p.sq_div) * p.sq_s2;
+    xoff = sq < p.nseq ? (unsigned)(row * 512 + (32 * (w & 3) + 4 * half) * 4) : 0x80000000u;   // (+ t * step_rows * 512 < 2^31)
   }
   const __amdgpu_buffer_rsrc_t xors = __builtin_amdgcn_make_buffer_rsrc(
       DX ? p.dxn + (long long)d * p.dxn_dir_stride : nullptr, 0, DX ? (unsigned)(p.dxn_dir_stride * 4) : 0u, 0x00020000);
@@ -578,6 +586,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
 
     const __bf16* bhi = &dgl[0][l31 * DROW + 8 * half];
     const __bf16* blo = &dgl[RF ? 0 : 1][l31 * DROW + 8 * half];
+    const __bf16* bhx[2] = {bhi + 16 * kpar, bhi - 16 * kpar};
     f32x16 acc0;  // one accumulator: the other wave of the SIMD fills the dependent-issue gaps
     f32x16 acc1;  // (RF = 2: the lo terms)
 #pragma unroll
@@ -586,7 +595,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int ks = 4 * ch + q;
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bhi + 16 * ks);
+        // (DX: slot q holds k-step ks ^ kpar -- base bhx[q & 1] = bhi +- 16 kpar, the k-step in the immediate offset)
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>((DX ? bhx[q & 1] : bhi) + 16 * ks);
         if constexpr (RF != 0) {
           typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
           typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -600,8 +610,22 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
           const f16x8 b16 = __builtin_bit_cast(f16x8, bh), ah16 = __builtin_bit_cast(f16x8, wr[s][q]);
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah16, b16, ks == 0 ? zero : acc0, 0, 0, 0);
-          if constexpr (DX) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al8, b16, acc0, 0, 0, 0);   // (one chain: the d(xn) tiles
-          else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al8, b16, ks == 0 ? zero : acc1, 0, 0, 0);   // fill the gaps; 16 registers)
+          if constexpr (DX) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al8, b16, acc0, 0, 0, 0);   // (one chain: the d(xn) tile
+          else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al8, b16, ks == 0 ? zero : acc1, 0, 0, 0);   // fills the gaps; 16 registers)
+          if constexpr (DX) {
+            // d(xn): the even slots hold this wave's k-steps (see kpar): same B fragment, this wave's W_ih^T fragments
+            if (!(q & 1)) {
+              const float sx = xS[ch >> 1];
+              const u32x2 x8 = xq[s][q >> 1];
+              const f16x2 e0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(x8[0], sx, false);
+              const f16x2 e1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(x8[0], sx, true);
+              const f16x2 e2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(x8[1], sx, false);
+              const f16x2 e3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(x8[1], sx, true);
+              const f16x8 xl8 = {e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
+              dxa = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xr[s][q >> 1]), b16, ks == 0 ? zero : dxa, 0, 0, 0);
+              dxa = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl8, b16, dxa, 0, 0, 0);
+            }
+          }
         } else {
           const bf16x8 bl = *reinterpret_cast<const bf16x8*>(blo + 16 * ks);
           if (ks == 0) {
@@ -612,30 +636,6 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
           }
           acc0 = mfma32(wr[s][2 * q + 1], bh, acc0);
           acc0 = mfma32(wr[s][2 * q], bl, acc0);
-        }
-      }
-      if constexpr (DX) {
-        // d(xn): gate columns [64 ch, 64 ch + 64) as two k32-steps; B = the image rows of sequences n / n + 16, 8 columns from
-        // 8 (lane >> 4): the same ds_read_b128 pattern as above on 16-row groups (row stride 4 banks mod 64: conflict-free)
-        const float sx = xS[ch >> 1];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int kk = 2 * ch + q;
-          const __bf16* b0p = &dgl[0][xn_ * DROW + 8 * xq4 + 32 * kk];
-          const f16x8 b0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(b0p));
-          const f16x8 b1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(b0p + 16 * DROW));
-          const u32x2 c8 = xq[s][q];
-          const f16x2 a0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[0], sx, false);
-          const f16x2 a1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[0], sx, true);
-          const f16x2 a2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[1], sx, false);
-          const f16x2 a3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[1], sx, true);
-          const f16x8 al8 = {a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
-          const f16x8 ah8 = __builtin_bit_cast(f16x8, xr[s][q]);
-          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-          dx0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah8, b0, kk == 0 ? z4 : dx0, 0, 0, 0);
-          dx1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah8, b1, kk == 0 ? z4 : dx1, 0, 0, 0);
-          dx0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al8, b0, dx0, 0, 0, 0);
-          dx1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al8, b1, dx1, 0, 0, 0);
         }
       }
       const int cn = (ch + 2) & 15;  // wraps into the next step
@@ -652,15 +652,28 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
       dhr = acc0;
     }
     if constexpr (DX) {
-      // D (16 x 16): lane = (sequence n, input quad lane >> 4): four consecutive inputs of one row -- one 16-byte store; the
-      // accumulators hold 256 w x S d(gates): both powers of two leave here
-      const float us = (1.f / 256.f) / dS;
-      const unsigned trow = (unsigned)t * (unsigned)p.step_rows * 512u;
-      // (no register soffset: lstm_bf16_common.h bst -- the compiler pads the store-data hazard only for that form)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dx0 * us), xors, xoff[0] + trow, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dx1 * us), xors, xoff[1] + trow, 0, 0);
+      if (w >= 4) {   // the odd k-steps' partial tile -> LDS (lane-private cells: conflict-free 16-byte rows)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xred[((w - 4) * 4 + j) * 64 + lane] = f32x4{dxa[4 * j], dxa[4 * j + 1], dxa[4 * j + 2], dxa[4 * j + 3]};
+      }
     }
     __syncthreads();
+    if constexpr (DX) {
+      if (w < 4) {
+        // D (32 x 32): register 4 j + r = input 32 (w & 3) + 8 j + 4 half + r of sequence l31: four 16-byte stores per lane; the
+        // accumulators hold 256 w x S d(gates): both powers of two leave here.  (xred is rewritten after the NEXT step's MFMA
+        // loop: the barrier behind the cell phase lies in between)
+        const float us = (1.f / 256.f) / dS;
+        const unsigned trow = (unsigned)t * (unsigned)p.step_rows * 512u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 o = xred[(w * 4 + j) * 64 + lane];
+          const f32x4 v = {(dxa[4 * j] + o[0]) * us, (dxa[4 * j + 1] + o[1]) * us, (dxa[4 * j + 2] + o[2]) * us, (dxa[4 * j + 3] + o[3]) * us};
+          // (no register soffset: lstm_bf16_common.h bst -- the compiler pads the store-data hazard only for that form)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xors, xoff + trow + 32 * j, 0, 0);
+        }
+      }
+    }
   }
 }
 

@@ -53,6 +53,23 @@ __device__ __forceinline__ float ftanh(float x) {
   return copysignf(t, x);
 }
 
+// The fp16 recurrences (lstm_cluster2.hip, the H16 fused forward of lstm_fused.hip): h in (-1, 1) as ONE fp16 operand of
+// v_mfma_f32_32x32x16_f16 against W as fp16 hi / lo of 256 w; the accumulator then carries 256 x the pre-activation.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma16h(const f16x8& a, const f16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// sigmoid / tanh of a / 256 with the scale folded into the argument of v_exp_f32 (2^x): one multiply per activation instead of
+// two; the same v_exp / v_rcp as fsig / ftanh
+__device__ __forceinline__ float c2_sig256(float a) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(a * (-1.4426950408889634f / 256.f)));
+}
+__device__ __forceinline__ float c2_tanh256(float a) {
+  const float e = __builtin_amdgcn_exp2f(fabsf(a) * (-2.f * 1.4426950408889634f / 256.f));  // in (0, 1]: no overflow
+  const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+  return copysignf(t, a);
+}
+
 __device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {

@@ -33,15 +33,11 @@
 #include "lstm_bf16_common.h"
 
 typedef __attribute__((address_space(1))) unsigned gu32;
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define SC1 16
 #define C2_SEQ 64
 #define C2_SPIN_LIMIT (1u << 18)
 #define C2_TAGS 0x40004000u
 
-__device__ __forceinline__ f32x16 mfma16h(const f16x8& a, const f16x8& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
 // 8 weights -> fp16 hi / lo of 256 w
 __device__ __forceinline__ void split8h(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
   const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -62,17 +58,6 @@ __device__ __forceinline__ void split8b(const f32x4& a, const f32x4& b, bf16x8& 
     hi[j] = (__bf16)s;
     lo[j] = (__bf16)(s - (float)hi[j]);
   }
-}
-
-// sigmoid / tanh of a / 256 with the scale folded into the argument of v_exp_f32 (2^x): one multiply per activation instead of
-// two; the same v_exp / v_rcp as fsig / ftanh (lstm_bf16_common.h)
-__device__ __forceinline__ float c2_sig256(float a) {
-  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(a * (-1.4426950408889634f / 256.f)));
-}
-__device__ __forceinline__ float c2_tanh256(float a) {
-  const float e = __builtin_amdgcn_exp2f(fabsf(a) * (-2.f * 1.4426950408889634f / 256.f));  // in (0, 1]: no overflow
-  const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
-  return copysignf(t, a);
 }
 
 __device__ __noinline__ void cluster2_timed_out(unsigned* tword, unsigned* status, int* dead_s) {

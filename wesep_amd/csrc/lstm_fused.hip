@@ -18,6 +18,9 @@
 // unit ((((d*8 + w)*24 + ks)*4 + g)*2 + part)*64 + lane, element j =
 //   part( ks < 8 ? W_ih[d][g*256 + 32w + (lane&31)][16ks + 8(lane>>5) + j]
 //                : W_hh[d][g*256 + 32w + (lane&31)][16(ks-8) + 8(lane>>5) + j] )
+// H16 (ws_lstm_fused_args.hfmt = 1, ABI v19): both parts carry 256 w -- the W_ih part (ks < 8) as bf16 hi / lo (x arrives as bf16
+// split pairs), the W_hh part as fp16 hi / lo: the A operand of v_mfma_f32_32x32x16_f16 against h as ONE fp16 value
+template <bool H16>
 __global__ void lstm_pack_fused_kernel(const float* __restrict__ wih_f, const float* __restrict__ wih_r,
                                        const float* __restrict__ whh_f, const float* __restrict__ whh_r,
                                        __bf16* __restrict__ pf) {
@@ -39,19 +42,36 @@ __global__ void lstm_pack_fused_kernel(const float* __restrict__ wih_f, const fl
       const float* W = d ? whh_r : whh_f;
       v = W[row * LH + 16 * (ks - 8) + 8 * (lane >> 5) + j];
     }
-    const __bf16 hi = (__bf16)v;
     const long long unit = ((((long long)(d * 8 + w) * FKS + ks) * 4 + g) * 2) * 64 + lane;
-    pf[unit * 8 + j] = hi;
-    pf[(unit + 64) * 8 + j] = (__bf16)(v - (float)hi);
+    if (H16 && ks >= 8) {
+      _Float16* ph = reinterpret_cast<_Float16*>(pf);
+      const float s = 256.f * v;
+      const _Float16 hi = (_Float16)s;
+      ph[unit * 8 + j] = hi;
+      ph[(unit + 64) * 8 + j] = (_Float16)(s - (float)hi);
+    } else {
+      const float s = H16 ? 256.f * v : v;
+      const __bf16 hi = (__bf16)s;
+      pf[unit * 8 + j] = hi;
+      pf[(unit + 64) * 8 + j] = (__bf16)(s - (float)hi);
+    }
   }
 }
 
 extern "C" int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
                                   float* pack, void* stream) {
   WS_REQUIRE(wih_f && wih_r && whh_f && whh_r && pack, "ws_lstm_pack_fused: null pointer");
-  hipLaunchKernelGGL(lstm_pack_fused_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, wih_f, wih_r, whh_f, whh_r,
+  hipLaunchKernelGGL(lstm_pack_fused_kernel<false>, dim3(512), dim3(256), 0, (hipStream_t)stream, wih_f, wih_r, whh_f, whh_r,
                      reinterpret_cast<__bf16*>(pack));
   return ws_check_launch("ws_lstm_pack_fused");
+}
+
+extern "C" int ws_lstm_pack_fused_h16(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
+                                      float* pack, void* stream) {
+  WS_REQUIRE(wih_f && wih_r && whh_f && whh_r && pack, "ws_lstm_pack_fused_h16: null pointer");
+  hipLaunchKernelGGL(lstm_pack_fused_kernel<true>, dim3(512), dim3(256), 0, (hipStream_t)stream, wih_f, wih_r, whh_f, whh_r,
+                     reinterpret_cast<__bf16*>(pack));
+  return ws_check_launch("ws_lstm_pack_fused_h16");
 }
 
 template <int GF>  // WS_GATES_*: != 0 -> activated gates leave as unorm16 (BLH), lstm_bf16_common.h
@@ -235,8 +255,14 @@ struct fused64_lds {
 //  __global__ TEMPLATE with this body -- "substitution failure" without a diagnostic)
 // W1 (MEASUREMENT ONLY, WS_FUSED_W1=1): one weight plane -- the W_lo x_hi term and the lo
 // fragments of the weight stream are dropped (two MFMAs per product, half the L2 -> CU stream): weights at bf16 precision.
-template <int GF, bool W1 = false>
+// H16 (ws_lstm_fused_args.hfmt = 1, ABI v19; round 6): the recurrent part of the stream on v_mfma_f32_32x32x16_f16 -- h in (-1, 1) as
+// ONE fp16 operand (one LDS plane), W_hh as fp16 hi / lo of 256 w: two MFMAs per product instead of three (448 instead of 576 per
+// wave and step); the x part keeps the full three-term split product on 256 W_ih, the accumulators carry 256 x the
+// pre-activation and the 2^-8 leaves in the activations' exponent scale.  The arithmetic ws_lstm_fwd_cluster2 runs in the time
+// view since round 5 (there the 60-step trajectory did not move with it; the fp16 INPUT did, which is why x keeps its pairs).
+template <int GF, bool W1 = false, bool H16 = false>
 __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& p) {
+  static_assert(!(W1 && H16), "W1 is a measurement build of the three-term kernel");
   __shared__ __attribute__((aligned(16))) fused64_lds sm;
   auto& xw = sm.xw;
   auto& hl = sm.hl;
@@ -254,7 +280,7 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
   {
     uint32_t* z = reinterpret_cast<uint32_t*>(&hl[0][0]);
     for (int i = tid; i < 2 * 2 * SQ * HROW / 2; i += 512) z[i] = 0u;  // h_{-1} = 0
-    for (int i = tid; i < LG; i += 512) bs[i] = p.bias[d * LG + i];
+    for (int i = tid; i < LG; i += 512) bs[i] = (H16 ? 256.f : 1.f) * p.bias[d * LG + i];
   }
   const int ubase = 32 * w + 4 * half;  // unit of register 4j + r: ubase + 8j + r
   const int glane = ((d * 256 + 8 * w + half) * 32 + l31) * 16;  // bytes; + (g*64 + 2j)*512
@@ -332,11 +358,19 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
           //  8 * half + 16 * (ks - 8), the compiler merges the two disjoint-bit terms with v_or and then keeps sixteen
           //  separate address registers alive across the step -- the 64 B / lane of scratch of round 3)
           bh[e] = *reinterpret_cast<const bf16x8*>(hrow[e] + 16 * (ks - 8));
-          bl[e] = *reinterpret_cast<const bf16x8*>(hrow[e] + 2 * SQ * HROW + 16 * (ks - 8));
+          if (!H16) bl[e] = *reinterpret_cast<const bf16x8*>(hrow[e] + 2 * SQ * HROW + 16 * (ks - 8));
         }
       }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
+        if (H16 && ks >= 8) {   // fp16 W_hh (hi, lo of 256 w) x fp16 h: two terms
+          const f16x8 b16 = __builtin_bit_cast(f16x8, bh[e]);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[e][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g]), b16, acc[e][g]);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[e][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g + 1]), b16, acc[e][g]);
+          continue;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[e][g] = mfma32(wr[s][2 * g], bh[e], acc[e][g]);
 #pragma unroll
@@ -366,10 +400,10 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
         const f32x4 cold = e == 0 ? c0[32 * j] : c1[j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float ig = fsig(acc[e][0][4 * j + r]);
-          const float fg = fsig(acc[e][1][4 * j + r]);
-          const float gg = ftanh(acc[e][2][4 * j + r]);
-          const float og = fsig(acc[e][3][4 * j + r]);
+          const float ig = H16 ? c2_sig256(acc[e][0][4 * j + r]) : fsig(acc[e][0][4 * j + r]);
+          const float fg = H16 ? c2_sig256(acc[e][1][4 * j + r]) : fsig(acc[e][1][4 * j + r]);
+          const float gg = H16 ? c2_tanh256(acc[e][2][4 * j + r]) : ftanh(acc[e][2][4 * j + r]);
+          const float og = H16 ? c2_sig256(acc[e][3][4 * j + r]) : fsig(acc[e][3][4 * j + r]);
           const float cn = fg * cold[r] + ig * gg;
           vi[r] = ig;
           vf[r] = fg;
@@ -380,8 +414,12 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
         }
         bf16x4 h_hi, h_lo;
         split4(vh, h_hi, h_lo);
-        *reinterpret_cast<bf16x4*>(nhi + 8 * j) = h_hi;
-        *reinterpret_cast<bf16x4*>(nlo + 8 * j) = h_lo;
+        if constexpr (H16) {   // the recurrent operand: fp16(h), one plane
+          *reinterpret_cast<u32x2*>(nhi + 8 * j) = enc_f16x4(vh);
+        } else {
+          *reinterpret_cast<bf16x4*>(nhi + 8 * j) = h_hi;
+          *reinterpret_cast<bf16x4*>(nlo + 8 * j) = h_lo;
+        }
         if (e == 0)
           c0[32 * j] = vc;
         else
@@ -410,11 +448,16 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h_kernel(const ws_lstm
 __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h_w1_kernel(const ws_lstm_fused_args p) {   // measurement only
   lstm_fwd_fused64_body<WS_GATES_H2, true>(p);
 }
+__global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h16_kernel(const ws_lstm_fused_args p) {   // hfmt 1: fp16 h, two terms
+  lstm_fwd_fused64_body<WS_GATES_H2, false, true>(p);
+}
 
 extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn && a->wpack && a->bias, "ws_lstm_fwd_fused: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_fwd_fused: bad nseq/L");
   WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2F, "ws_lstm_fwd_fused: gfmt %d", a->gfmt);
+  WS_REQUIRE(a->hfmt == 0 || (a->hfmt == 1 && a->gfmt != WS_GATES_F32),
+             "ws_lstm_fwd_fused: hfmt %d (1 = fp16 h, pack from ws_lstm_pack_fused_h16; 2-byte gate formats only)", a->hfmt);
   const int ntile = (a->nseq + SQ - 1) / SQ;
   dim3 grid(ntile, 2), block(512);
   hipStream_t s = (hipStream_t)stream;
@@ -426,10 +469,13 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   static int cus = 0;      // same part on every device of a node; queried once
   if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 256;
   const int rounds32 = (2 * ntile + cus - 1) / cus, rounds64 = (2 * ((ntile + 1) / 2) + cus - 1) / cus;
-  const bool wide = env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
+  // (hfmt 1 exists as the 64-sequence kernel only: it always runs that one)
+  const bool wide = a->hfmt == 1 || (env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32);
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
   const char* w1 = getenv("WS_FUSED_W1");   // measurement only: one weight plane (bf16 weights), see lstm_fwd_fused64_body
-  if (wide && a->gfmt && w1 && atoi(w1) == 1)
+  if (a->hfmt == 1)
+    hipLaunchKernelGGL(lstm_fwd_fused64h16_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
+  else if (wide && a->gfmt && w1 && atoi(w1) == 1)
     hipLaunchKernelGGL(lstm_fwd_fused64h_w1_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
   else if (wide && a->gfmt)
     hipLaunchKernelGGL(lstm_fwd_fused64h_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);

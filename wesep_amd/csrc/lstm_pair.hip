@@ -231,6 +231,10 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
   if (pr >= npair) return;
   // (ABI v19) this workgroup holds its CU now: the side stream's gate (ws_wait_word) counts on it
   if (p.resident && threadIdx.x == 0) __hip_atomic_fetch_add(p.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // variant 2048, round 6: every workgroup's wall-clock times (100 MHz, one counter for the chip) of entry, first loop top and loop
+  // end, behind the step stamps: dbg_buf as u64 [L * 16 + (pr * 2 + hs) * 4 + {0, 1, 2}] (tools/r06_instep_stamps.py)
+  long long wall_in = 0;
+  if constexpr (V & 2048) wall_in = wall_clock64();
   const int d = pr & 1, tile = pr >> 1;
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -338,6 +342,13 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
   }
   int dead = 0;  // wave-uniform: a bounded wait of this wave timed out
   __syncthreads();
+  if constexpr (V & 2048) {
+    if (threadIdx.x == 0 && p.dbg_buf) {
+      long long* wt = reinterpret_cast<long long*>(p.dbg_buf) + (long long)L * 16 + (pr * 2 + hs) * 4;
+      wt[0] = wall_in;
+      wt[1] = wall_clock64();
+    }
+  }
 
   for (int step = 0; step < L; ++step) {
     const int t = d == 0 ? L - 1 - step : step;
@@ -599,6 +610,10 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       load_step(tn, 1);
     }
     __syncthreads();  // S2: both halves of every cell's sum are in place; the image is no longer read
+  }
+  if constexpr (V & 2048) {
+    if (threadIdx.x == 0 && p.dbg_buf)
+      reinterpret_cast<long long*>(p.dbg_buf)[(long long)L * 16 + (pr * 2 + hs) * 4 + 2] = wall_clock64();
   }
 }
 

@@ -1218,18 +1218,26 @@ def lstm_fuse_ok(nseq: int, cluster: bool) -> bool:
     return lstm_blk_mode(nseq) == L.LSTM_BF16X3_BLK
 
 
-def lstm_pack_fused(wih_f, wih_r, whh_f, whh_r, pack):
+def lstm_fused_hfmt(gfmt) -> int:
+    """Arithmetic of the fused band-view forward's recurrent part (ws_lstm_fused_args.hfmt, ABI v19): 1 (default with the 2-byte
+    gate formats) = h as ONE fp16 operand against W_hh as fp16 hi / lo of 256 w on v_mfma_f32_32x32x16_f16, two MFMAs per product
+    -- what ws_lstm_fwd_cluster2 runs in the time view since round 5; the x part keeps the three-term split product.
+    WESEP_FUSED_H16=0: the three-term product of rounds 1-5 for both parts."""
+    return 1 if gfmt != L.GATES_F32 and os.environ.get("WESEP_FUSED_H16", "1") != "0" else 0
+
+
+def lstm_pack_fused(wih_f, wih_r, whh_f, whh_r, pack, hfmt=0):
     for n, t in (("wih_f", wih_f), ("wih_r", wih_r), ("whh_f", whh_f), ("whh_r", whh_r), ("pack", pack)):
         _chk(t, n)
-    _call("ws_lstm_pack_fused", _p(wih_f), _p(wih_r), _p(whh_f), _p(whh_r), _p(pack))
+    _call("ws_lstm_pack_fused_h16" if hfmt else "ws_lstm_pack_fused", _p(wih_f), _p(wih_r), _p(whh_f), _p(whh_r), _p(pack))
 
 
-def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm: SeqMap, gfmt=0):
+def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm: SeqMap, gfmt=0, hfmt=0):
     for n, t in (("gates", gates), ("cbuf", cbuf), ("hcat", hcat), ("xn", xn), ("wpack", wpack), ("bias", bias)):
         _chk(t, n)
     a = L.LstmFusedArgs()
     a.gates, a.cbuf, a.hcat, a.xn, a.wpack, a.bias = _p(gates), _p(cbuf), _p(hcat), _p(xn), _p(wpack), _p(bias)
-    a.nseq, a.L, a.gfmt = sm.nseq, sm.L, gfmt
+    a.nseq, a.L, a.gfmt, a.hfmt = sm.nseq, sm.L, gfmt, hfmt
     L.check(L.lib().ws_lstm_fwd_fused(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_fused")
 
 
