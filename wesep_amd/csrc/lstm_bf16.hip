@@ -387,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   static_assert(RF == 0 || (BLK && GF == WS_GATES_H2F), "the fp16 recurrence takes the scaled-fp16 d(gates) of WS_GATES_H2F");
   static_assert(!DX || RF == 2, "d(xn) in the BPTT rides on the fp16 d(gates) image of rfmt 2");
   __shared__ __attribute__((aligned(16))) __bf16 dgl[RF ? 1 : 2][SQ * DROW];  // [part][seq][gate col] 129 / 65 KB
-  __shared__ __attribute__((aligned(16))) f32x4 xred[DX ? 4 * 4 * 64 : 1];    // DX: partial d(xn) tiles of waves 4..7, 16 KB
+  __shared__ __attribute__((aligned(16))) f32x4 xred[DX ? 8 * 2 * 64 : 1];    // DX: the half of each wave's partial d(xn) tile its partner stores, 16 KB
   if (p.run_if && *p.run_if == 0u) return;  // predicated fall-back launch (wesep_hip.h): uniform
   const int d = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -472,10 +472,6 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
       }
     }
   };
-  wfill(0, 0, 0);
-  xfill(0, 0, 0);
-  wfill(1, 1, 0);
-  xfill(1, 1, 0);
   if constexpr (RF != 0) {
     const float* st = p.wpack + (long long)(d * 8 + w) * (64 * 2 * 64 * 4) + 96 * 256;
 #pragma unroll
@@ -486,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
 #pragma unroll
     for (int g8 = 0; g8 < 8; ++g8) xS[g8] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st[g8])));
   }
-  // DX: this lane's d(xn) cells -- D of the 32 x 32 tile: sequence l31, inputs 32 (w & 3) + 8 j + 4 half .. + 3 for j = 0..3 -- in
+  // DX: this lane's d(xn) cells -- D of the 32 x 32 tile: sequence l31, inputs 32 (w & 3) + 8 j + 4 half .. + 3, j = 0..3 -- in
   // the plain [P][128] buffer of this direction, as a 32-bit byte offset of a buffer store: row = (seq / sq_div) * sq_s1 + (seq
   // % sq_div) * sq_s2 (+ t * step_rows, added per step) -- ws_seqmap; a padded slot gets an offset beyond the descriptor's size
   // (the buffer is < 2 GB: lstm_check): the hardware drops the store
@@ -494,7 +490,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   if constexpr (DX) {
     const int sq = (int)blockIdx.x * SQ + l31;
     const long long row = (long long)(sq / p.sq_div) * p.sq_s1 + (long long)(sq % p.sq_div) * p.sq_s2;
-    xoff = sq < p.nseq ? (unsigned)(row * 512 + (32 * (w & 3) + 4 * half) * 4) : 0x80000000u;   // (+ t * step_rows * 512 < 2^31)
+    // (this wave stores the rows j = 2 kpar, 2 kpar + 1 of the tile: inputs 32 mt + 16 kpar + 8 i + 4 half .. + 3, i = 0, 1)
+    xoff = sq < p.nseq ? (unsigned)(row * 512 + (32 * (w & 3) + 16 * kpar + 4 * half) * 4) : 0x80000000u;   // (+ t * step_rows * 512 < 2^31)
   }
   const __amdgpu_buffer_rsrc_t xors = __builtin_amdgcn_make_buffer_rsrc(
       DX ? p.dxn + (long long)d * p.dxn_dir_stride : nullptr, 0, DX ? (unsigned)(p.dxn_dir_stride * 4) : 0u, 0x00020000);
@@ -526,6 +523,16 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
       c_cur[j] = ld_ch(p.cbuf, t0, j);
     }
   }
+  // the ring's first two chunks BEHIND the first step's inputs, in the order of the steady state (there the inputs of step t + 1
+  // are requested in the cell phase of step t, the ring refills follow in its MFMA loop): the loop header's s_waitcnt is the
+  // minimum over both ways into it, and with the ring first the prologue made it vmcnt(0) -- every step then drained the ring's
+  // fragments and the acknowledgements of its last stores before its cell phase (found in the ISA of the DX instantiation)
+  __builtin_amdgcn_sched_barrier(0);
+  wfill(0, 0, 0);
+  xfill(0, 0, 0);
+  wfill(1, 1, 0);
+  xfill(1, 1, 0);
+  __builtin_amdgcn_sched_barrier(0);
 
   for (int step = 0; step < L; ++step) {
     const int t = d == 0 ? L - 1 - step : step;
@@ -651,27 +658,38 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
     } else {
       dhr = acc0;
     }
+    // DX: the two k-step parities' partial tiles meet in LDS.  EVERY wave runs the same instructions (a branch around the stores
+    // made the compiler drain vmcnt to 0 at the top of the step -- the ring's first fragments and the stores' acknowledgements:
+    // +5 us per step, measured): wave (mt, kpar) keeps the rows j = 2 kpar, 2 kpar + 1 of its partial (register 4 j + r = input
+    // 32 mt + 8 j + 4 half + r), sends the other two to its partner w ^ 4, adds what the partner sent and stores two 16-byte
+    // cells per lane; own + partner's = even + odd k-steps either way (one fp32 add: commutative, so the bits do not depend on
+    // which wave adds)
+    f32x4 keep[2];
     if constexpr (DX) {
-      if (w >= 4) {   // the odd k-steps' partial tile -> LDS (lane-private cells: conflict-free 16-byte rows)
+      const bool hi_rows = kpar != 0;   // (uniform) selects as data, not as control flow
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xred[((w - 4) * 4 + j) * 64 + lane] = f32x4{dxa[4 * j], dxa[4 * j + 1], dxa[4 * j + 2], dxa[4 * j + 3]};
+      for (int i = 0; i < 2; ++i) {
+        f32x4 send;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float lo_v = dxa[4 * i + r], hi_v = dxa[8 + 4 * i + r];
+          send[r] = hi_rows ? lo_v : hi_v;
+          keep[i][r] = hi_rows ? hi_v : lo_v;
+        }
+        xred[(w * 2 + i) * 64 + lane] = send;
       }
     }
     __syncthreads();
     if constexpr (DX) {
-      if (w < 4) {
-        // D (32 x 32): register 4 j + r = input 32 (w & 3) + 8 j + 4 half + r of sequence l31: four 16-byte stores per lane; the
-        // accumulators hold 256 w x S d(gates): both powers of two leave here.  (xred is rewritten after the NEXT step's MFMA
-        // loop: the barrier behind the cell phase lies in between)
-        const float us = (1.f / 256.f) / dS;
-        const unsigned trow = (unsigned)t * (unsigned)p.step_rows * 512u;
+      // the accumulators hold 256 w x S d(gates): both powers of two leave here.  (xred is rewritten after the NEXT step's MFMA
+      // loop: the barrier behind the cell phase lies in between)
+      const float us = (1.f / 256.f) / dS;
+      const unsigned trow = (unsigned)t * (unsigned)p.step_rows * 512u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 o = xred[(w * 4 + j) * 64 + lane];
-          const f32x4 v = {(dxa[4 * j] + o[0]) * us, (dxa[4 * j + 1] + o[1]) * us, (dxa[4 * j + 2] + o[2]) * us, (dxa[4 * j + 3] + o[3]) * us};
-          // (no register soffset: lstm_bf16_common.h bst -- the compiler pads the store-data hazard only for that form)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xors, xoff + trow + 32 * j, 0, 0);
-        }
+      for (int i = 0; i < 2; ++i) {
+        const f32x4 o = xred[((w ^ 4) * 2 + i) * 64 + lane];
+        // (no register soffset: lstm_bf16_common.h bst -- the compiler pads the store-data hazard only for that form)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (keep[i] + o) * us), xors, xoff + trow + 32 * i, 0, 0);
       }
     }
   }

@@ -433,8 +433,13 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
         __builtin_amdgcn_sched_barrier(0);  // one run at a time: bounds the live temporaries
       }
     }
-    // x_{t+1} was requested before the cell update; every wave waits for its own share before the barrier publishes it
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // x_{t+1} was requested before the cell update; every wave waits for its own share before the barrier publishes it.  vmcnt
+    // counts in order and exactly 2 tiles x 4 runs x (4 gates + c + h) = 48 stores were issued behind the four DMA loads, so
+    // vmcnt(48) is "the DMA has landed" -- rounds 3-5 waited for vmcnt(0): every step then also sat out the acknowledgement of
+    // its 384 KB of stores (the HBM phase of the step, ~14 us chip-wide) before the next step's MFMAs could start, where now they
+    // drain under them.  (ws_lstm_fused_args.hfmt bit 1, WESEP_FUSED_DRAIN=1: the old wait, for A/B.)
+    if (p.hfmt & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
     __syncthreads();
   }
 }
@@ -456,7 +461,7 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn && a->wpack && a->bias, "ws_lstm_fwd_fused: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_fwd_fused: bad nseq/L");
   WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2F, "ws_lstm_fwd_fused: gfmt %d", a->gfmt);
-  WS_REQUIRE(a->hfmt == 0 || (a->hfmt == 1 && a->gfmt != WS_GATES_F32),
+  WS_REQUIRE((a->hfmt & ~3) == 0 && (!(a->hfmt & 1) || a->gfmt != WS_GATES_F32),
              "ws_lstm_fwd_fused: hfmt %d (1 = fp16 h, pack from ws_lstm_pack_fused_h16; 2-byte gate formats only)", a->hfmt);
   const int ntile = (a->nseq + SQ - 1) / SQ;
   dim3 grid(ntile, 2), block(512);
@@ -470,10 +475,10 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 256;
   const int rounds32 = (2 * ntile + cus - 1) / cus, rounds64 = (2 * ((ntile + 1) / 2) + cus - 1) / cus;
   // (hfmt 1 exists as the 64-sequence kernel only: it always runs that one)
-  const bool wide = a->hfmt == 1 || (env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32);
+  const bool wide = (a->hfmt & 1) || (env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32);
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
   const char* w1 = getenv("WS_FUSED_W1");   // measurement only: one weight plane (bf16 weights), see lstm_fwd_fused64_body
-  if (a->hfmt == 1)
+  if (a->hfmt & 1)
     hipLaunchKernelGGL(lstm_fwd_fused64h16_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
   else if (wide && a->gfmt && w1 && atoi(w1) == 1)
     hipLaunchKernelGGL(lstm_fwd_fused64h_w1_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);

@@ -1237,7 +1237,8 @@ def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm: SeqMap, gfmt=0, hfmt=
         _chk(t, n)
     a = L.LstmFusedArgs()
     a.gates, a.cbuf, a.hcat, a.xn, a.wpack, a.bias = _p(gates), _p(cbuf), _p(hcat), _p(xn), _p(wpack), _p(bias)
-    a.nseq, a.L, a.gfmt, a.hfmt = sm.nseq, sm.L, gfmt, hfmt
+    a.nseq, a.L, a.gfmt = sm.nseq, sm.L, gfmt
+    a.hfmt = hfmt | (2 if os.environ.get("WESEP_FUSED_DRAIN", "0") == "1" else 0)      # (bit 1: A/B of the end-of-step wait)
     L.check(L.lib().ws_lstm_fwd_fused(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_fused")
 
 
