@@ -10,12 +10,13 @@ Workload (BASELINE.json configs[1] / north_star "batch 32 x 4 s"): pBSRNN, FiLM 
 6 repeats, feature_dim 128, fixed [R,256] embeddings, R = 32 rows (16 two-speaker mixtures) of
 64000 samples per GPU.  Arithmetic (what `dtype` / `config.workload` / `mfma_terms` of the line name): fp32 operands enter
 the matrix cores as split pairs, fp32 accumulation everywhere --
-  * "bf16x3": bf16 hi + lo of both operands, THREE bf16 MFMAs per product: the band-view recurrences (forward with the
-    fused x-projection, BPTT), the output projections, d(hcat), the proj weight gradients, BN / mask-MLP / FiLM GEMMs;
+  * "bf16x3": bf16 hi + lo of both operands, THREE bf16 MFMAs per product: every x-projection (fused into the forward
+    recurrences), the output projections, d(hcat), the proj weight gradients, BN / mask-MLP / FiLM GEMMs;
   * "fp16x2": one operand as ONE fp16 value (11 bits: h in (-1, 1), the scaled d(gates)), the weight as fp16 hi + lo, TWO
-    fp16 MFMAs per product: the recurrent products of the time-view recurrences (round 5: cluster forward -- whose fused
-    x-projection stays bf16x3 --, pair BPTT) and d(xn).  In the pair BPTT the weight's lo part is block-scaled FP8 (e4m3,
-    converted to fp16 on the way into the MFMA: 16 significant bits of the weight instead of 22; functional.pair_rfmt = 2);
+    fp16 MFMAs per product: the recurrent products of ALL four recurrence kernels (round 5: cluster forward, pair BPTT;
+    round 6: the band view's fused forward -- dev.lstm_fused_hfmt -- and streaming BPTT -- functional.band_rfmt) and d(xn)
+    (the band view's inside its BPTT).  In the BPTT kernels and their d(xn) the weight's lo part is block-scaled FP8 (e4m3,
+    converted to fp16 on the way into the MFMA: 16 significant bits of the weight instead of 22);
   * "fp16x1": both operands single fp16, ONE MFMA per product: the LSTM weight gradients (scaled-fp16 d(gates) x fp16 copies
     of [xn | h]);
 saved state in 2 bytes (unorm16 gates, scaled-fp16 d(gates)), c / h / activations in fp32.  Holds the reference's fp32
@@ -80,7 +81,10 @@ def _cpu_baseline_worker(threads, budget_s):
                       "sample": f"oracle (torch CPU fp32 restatement of the reference step), R={R} rows x 4 s, "
                                 f"1 warm-up + {n} timed steps of fwd+SI-SDR+bwd+clip+Adam, {dt:.2f} s/step, "
                                 f"{threads} of {os.cpu_count()} host cores (reference recipe: OMP_NUM_THREADS=8; all-core "
-                                f"runs were slower on this host class: 0.036 utt/s with 128 threads, BENCH_r04)"}))
+                                f"runs were slower on this host class: 0.036 utt/s with 128 threads, BENCH_r04).  The port "
+                                f"runs ~25 % FASTER than the reference's own modules it stands for (same box, 8 threads: "
+                                f"wesep.models.bsrnn.BSRNN 0.161 utt/s, this port 0.204 -- VERDICT round 5; "
+                                f"`--cpu-baseline reference` times the reference where /root/reference exists)"}))
 
 
 def _cpu_reference_worker(threads, budget_s):
@@ -175,7 +179,8 @@ def mfma_terms_census():
     terms = {
         "time": {"x_proj": 3, "recur_fwd": 2 if c2 else 3, "proj": 3, "d_hcat": 3, "bptt": 2 if F.pair_rfmt(gf) else 3,
                  "dW_lstm": (1 if F.tnb_a16() else 2) if h2f else 3, "d_xn": 2 if h2f else 3, "dW_proj": 3},
-        "band": {"x_proj": 3, "recur_fwd": 3, "proj": 3, "d_hcat": 3, "bptt": 3,
+        "band": {"x_proj": 3, "recur_fwd": 2 if dev.lstm_fused_hfmt(gf) else 3, "proj": 3, "d_hcat": 3,
+                 "bptt": 2 if F.band_rfmt(gf, L.LSTM_BF16X3_BLK) else 3,
                  "dW_lstm": (1 if F.tnb_a16() else 2) if h2f else 3, "d_xn": 2 if h2f else 3, "dW_proj": 3},
     }
     tot = sum(kn.values())
@@ -274,6 +279,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         dev.prof_enable(True)
+        dev.alg_reset(True)                  # algorithmic bytes / flops of every timed launch, per class (dev._alg)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -282,6 +288,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     dev.prof_enable(False)
+    alg = {k: list(v) for k, v in (dev.ALG or {}).items()}
+    dev.alg_reset(False)
     per_rank_ms = all_ranks(elapsed / args.steps * 1e3, d)       # rank-ordered, for the SCALE record
     # outside the timed region: do all replicas hold the same parameters?  (Data parallelism keeps them bit-identical;
     # a disturbed all-reduce -- profiles/r02_kernel_race.md -- would not.)  Checksum of every parameter, max - min over ranks.
@@ -311,6 +319,10 @@ def main():
                        ("gemm_nt", L.PROF_GEMM_NT), ("gemm_tn", L.PROF_GEMM_TN)):
         ms, n = dev.prof_collect(kind)
         prof[name] = {"ms_total": ms, "launches": n, "ms_avg": ms / max(n, 1)}
+    # all four timed classes are priced (roofline_by_class below).  `roofline` itself stays on the
+    # largest RECURRENCE class -- the kernels SURVEY 8d's per-cell bytes are defined for and whose launch average the earlier
+    # rounds' lines carry --, `critical_path_largest` / `largest_any_stream` name the largest class of the main stream (the
+    # weight-gradient GEMMs of `gemm_tn` run on the side stream) and of both streams
     dom = "lstm_bwd" if prof["lstm_bwd"]["ms_total"] >= prof["lstm_fwd"]["ms_total"] else "lstm_fwd"
     bytes_per_launch = cell_bytes[dom] * P * 2 * L.LSTM_H
     sec = prof[dom]["ms_avg"] * 1e-3 if prof[dom]["launches"] else float("inf")
@@ -346,15 +358,55 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    # ---- every timed class against both roofs (HIP-event time of this run, algorithmic work of this run, counters of the
+    #      committed profile of the same command) ------------------------------------------------------------------------
+    cls_kernels = {"lstm_fwd": ("lstm_fwd",), "lstm_bwd": ("lstm_bwd",),
+                   "gemm_nt": ("gemm_nt", "gemm_p2b", "gemm_b2p"), "gemm_tn": ("gemm_tn", "gemm_tnb")}
+    cls_stream = {"lstm_fwd": "main", "lstm_bwd": "main", "gemm_nt": "main",
+                  "gemm_tn": "side (LSTM / proj weight gradients: 36 of the class's launches per step) + main (BN, mask MLP, FiLM)"}
+    pmc_tab, counter_gb_step = None, None
+    try:
+        doc = json.load(open(_latest_profile("pmc_traffic")))
+        pmc_tab = doc["kernels"]
+        # the passes collect `--steps 1 --warmup 1`: two steps
+        counter_gb_step = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in pmc_tab.values()) / 2 / 1e9
+    except (OSError, KeyError, ValueError):
+        pass
+    by_class = {}
+    for name in ("lstm_fwd", "lstm_bwd", "gemm_nt", "gemm_tn"):
+        pr, al = prof[name], alg.get(name)
+        if not pr["launches"] or not al or not al[2]:
+            continue
+        sec_c = pr["ms_total"] * 1e-3
+        ent = {"stream": cls_stream[name], "ms_per_step": pr["ms_total"] / args.steps, "launches_per_step": pr["launches"] / args.steps,
+               "ms_per_launch": pr["ms_avg"], "timed_launches": pr["launches"], "counted_launches": al[2],
+               "alg_bytes_per_launch": al[0] / al[2], "alg_gbs": al[0] / sec_c / 1e9, "frac_hbm": al[0] / sec_c / 1e9 / HBM_PEAK_GBS,
+               "alg_tflops": al[1] / sec_c / 1e12, "frac_mfma_algorithmic": al[1] / sec_c / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+        ent["bound"] = "hbm" if ent["frac_hbm"] >= ent["frac_mfma_algorithmic"] else "mfma"
+        ent["frac"] = max(ent["frac_hbm"], ent["frac_mfma_algorithmic"])
+        if pmc_tab:
+            hit = [v for k, v in pmc_tab.items() if any(t in k for t in cls_kernels[name]) and v["hbm_bytes_per_launch_corrected"] >= 1e6]
+            n_ = sum(v["launches"] for v in hit)
+            if n_:
+                ent["traffic_per_launch"] = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in hit) / n_
+                ent["traffic_gb_per_step"] = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in hit) / 2 / 1e9
+                ent["traffic_over_algorithmic"] = ent["traffic_gb_per_step"] * 1e9 / (al[0] / args.steps)
+        by_class[name] = ent
+    crit = max((k for k in by_class if k != "gemm_tn"), key=lambda k: by_class[k]["ms_per_step"], default=None)
+    largest = max(by_class, key=lambda k: by_class[k]["ms_per_step"], default=None)
+
     census = mfma_terms_census()
     from wesep_amd.functional import pair_rfmt
     F_pair_rfmt = pair_rfmt(gfmt)
     tv, bv = census["terms_per_product"]["time"], census["terms_per_product"]["band"]
     dom_terms = 0.5 * ((tv["bptt"] + bv["bptt"]) if dom == "lstm_bwd" else (tv["recur_fwd"] + bv["recur_fwd"]))
-    arith = ("bf16x3 (band-view recurrences, x-projections, projections, d(hcat), BN / mask GEMMs) + fp16x2 (recurrent "
-             "products of the time-view cluster forward and pair BPTT, d(xn)) + fp16x1 (LSTM weight gradients); 2-byte "
-             "saved gates / d(gates); fp32 accumulate"
-             + ("; pair BPTT: W_hh as fp16 hi + block-scaled FP8 lo" if F_pair_rfmt == 2 else ""))
+    band2 = bv["bptt"] == 2 and bv["recur_fwd"] == 2
+    arith = (("bf16x3 (x-projections, projections, d(hcat), BN / mask GEMMs) + fp16x2 (recurrent products of all four "
+              "recurrence kernels, d(xn))" if band2 else
+              "bf16x3 (band-view recurrences, x-projections, projections, d(hcat), BN / mask GEMMs) + fp16x2 (recurrent "
+              "products of the time-view cluster forward and pair BPTT, d(xn))") +
+             " + fp16x1 (LSTM weight gradients); 2-byte saved gates / d(gates); fp32 accumulate"
+             + ("; BPTT kernels: W_hh as fp16 hi + block-scaled FP8 lo" if F_pair_rfmt == 2 else ""))
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
@@ -399,6 +451,9 @@ def main():
         # counters cannot be collected inside this run: say which run they come from (commit + bench.py hash at
         # collection time, written by tools/pmc_summary.py), next to this run's own bench.py hash
         out["roofline"]["counters_from"] = pmc_src
+        out["roofline_by_class"] = by_class
+        out["critical_path_largest"] = crit
+        out["largest_any_stream"] = largest
         out["bench_py_sha16"] = _sha16(os.path.abspath(__file__))
         # whole step against SURVEY 8d's algorithmic work (per row, 4 s, fwd+bwd): 1.017 TFLOP fp32-equivalent
         # (x3 executed as split-bf16) and the layer-fused minimum of 2.26 GB of fp32 traffic
@@ -416,6 +471,10 @@ def main():
             "frac_hbm_alg": t_hbm / sec_step, "bound": "mfma" if t_mfma >= t_hbm else "hbm",
             "frac": max(alg_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12), t_hbm) / sec_step,
             "frac_mfma_algorithmic": alg_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12) / sec_step,
+            # counted HBM bytes of the whole step (committed PMC passes of the same command) over SURVEY 8d's layer-fused
+            # minimum: how much of the step's traffic the algorithm does not ask for
+            "counter_gb_per_step": counter_gb_step,
+            "traffic_over_algorithmic": (counter_gb_step * 1e9 / alg_bytes) if counter_gb_step else None,
             "note": "per GPU; `frac` = `frac_mfma_algorithmic`: every fp32-equivalent product counted ONCE against the dense "
                     "bf16 / fp16 MFMA peak (2.5 PFLOP/s) -- the defensible step figure.  `frac_mfma_executed` counts the MFMA "
                     "instructions the kernels really issue per product (`mfma_terms`: 1, 2 or 3 by GEMM class, FLOP-weighted "

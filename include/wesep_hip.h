@@ -44,10 +44,6 @@ int ws_debug_dirty_lds(float value, int nblocks, int spins, float* sink, void* s
  * of the weight-gradient GEMM fits beside it) for `usec` microseconds of wall clock, or until *stop != 0 (optional
  * device word) -- a resident-collective-shaped occupant for the robustness tests.  Bounded: usec <= 2 000 000.        */
 int ws_debug_occupy(int nblocks, int usec, const unsigned* stop, float* sink, void* stream);
-/* Stream gate (ABI v19): a one-wave kernel on `stream` that ends when *word >= target or after max_us microseconds of wall
- * clock (<= 100 000), whichever comes first: work enqueued behind it starts once a kernel on ANOTHER stream that counts its
- * workgroups into `word` (ws_lstm_pair_args.resident) is fully resident.  Scheduling only -- no data dependency hangs on it. */
-int ws_wait_word(const unsigned* word, unsigned target, int max_us, void* stream);
 
 /* ---- row addressing used by the GEMMs ---------------------------------------------------
  * row m of a matrix lives at  base + (m / div) * s1 + (m % div) * s2   (elements).       */
@@ -416,8 +412,6 @@ typedef struct ws_lstm_pair_args {
                            product with the lo plane of W_hh as block-scaled FP8 (wpack from ws_lstm_pack_pair_f8): 16
                            instead of 22 significant bits of every weight, and the whole of W_hh stays on the compute
                            unit for the launch (hi plane in registers, lo plane in LDS) -- nothing of it is streamed  */
-  unsigned* resident;   /* ABI v19 (trailing, NULL = off): device word, zero at launch; every live workgroup adds 1 when it
-                           starts (4 * ceil(nseq / 32) in all) -- the target of ws_wait_word                            */
 } ws_lstm_pair_args;
 int ws_lstm_pack_pair(const float* whh_f, const float* whh_r, float* pack, void* stream);
 /* ABI v17: the pack of rfmt = 1 (same size and unit order, fp16 hi / lo of 256 w; |w| < 255) */

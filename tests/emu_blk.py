@@ -335,22 +335,15 @@ def lstm_pack_bwd_f8(whh_f, whh_r, pack_bwd):
     pack_bwd.reshape(-1)[: 2 * G4 * H] = torch.stack([_q8(whh_f), _q8(whh_r)]).reshape(-1)
 
 
-def wait_word(word, target, max_us=300):
-    """ws_wait_word: a scheduling gate; the emulation runs everything in order, so the count must already be there."""
-    assert int(word.reshape(-1)[0]) >= int(target), (int(word.reshape(-1)[0]), target)
-
-
 def lstm_pack_dx_f8(wcat, pack):
     w = wcat.reshape(2, G4, 128)
     _PACKS[pack.data_ptr()] = torch.stack([_q8(w[0]), _q8(w[1])])
 
 
 def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None, repairable=False,
-                  amax=None, rfmt=0, resident=None):
+                  amax=None, rfmt=0):
     """Returns the launch's timeout word like dev.lstm_bwd_pair; dbg & 8 emulates the forced timeout (NaN-poisoned
     d(gates), both words set)."""
-    if resident is not None:                       # (ABI v19: every live workgroup counts itself in)
-        resident += 4 * _ntile(sm)
     if dbg & 8:
         (dgates if dgates is not None else gates).fill_(float("nan"))
         if status is not None:
@@ -481,7 +474,7 @@ def install(monkeypatch):
     monkeypatch.setattr(dev, "lstm_fwd", make_lstm_fwd(dev.lstm_fwd))
     monkeypatch.setattr(dev, "lstm_bwd", make_lstm_bwd(dev.lstm_bwd))
     for fn in (pack_w, lstm_cat_ih, lstm_pack_fused, gemm_p2b, gemm_b2p, lstm_fwd_cluster, lstm_fwd_cluster2, lstm_bwd_cluster,
-               lstm_pack_pair, lstm_pack_bwd_f8, lstm_pack_dx_f8, lstm_bwd_pair, lstm_fwd_fused, gemm_tnb, wait_word):
+               lstm_pack_pair, lstm_pack_bwd_f8, lstm_pack_dx_f8, lstm_bwd_pair, lstm_fwd_fused, gemm_tnb):
         monkeypatch.setattr(dev, fn.__name__, fn)
     monkeypatch.setattr(dev, "group_stats", make_group_stats(dev.group_stats))
     monkeypatch.setattr(dev, "gn_bwd_reduce", make_gn_bwd_reduce(dev.gn_bwd_reduce))

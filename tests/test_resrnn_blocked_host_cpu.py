@@ -77,10 +77,10 @@ def test_resrnn_blocked_matches_oracle(emu, monkeypatch, view, R, K, Tf, branch,
 
 
 def test_streaming_bptt_arithmetic_and_its_own_input_gradient_reach_the_kernel(emu, monkeypatch):
-    """Round 6 defaults of the band view's streaming BPTT: ws_lstm_args.rfmt = 2 (the FP8 pack, ws_lstm_pack_bwd_f8) and d(xn)
-    computed by the BPTT launch itself (ws_lstm_args.dxn + ws_lstm_pack_dx_f8, ABI v19: no ws_gemm_b2p over d(gates), the fused
-    GroupNorm backward adds the two directions) -- 32-sequence blocked kernels with the default 2-byte format only.
-    WESEP_BAND_DX=0 restores the separate GEMM, WESEP_BAND_RF=0 the three-term product (and with it the GEMM).  Gradients
+    """Round 6: the band view's streaming BPTT runs ws_lstm_args.rfmt = 2 by default (the FP8 pack, ws_lstm_pack_bwd_f8); with
+    WESEP_BAND_DX=1 ("default" below: the opt-in) d(xn) is computed by the BPTT launch itself (ws_lstm_args.dxn +
+    ws_lstm_pack_dx_f8, ABI v19: no ws_gemm_b2p over d(gates), the fused GroupNorm backward adds the two directions) -- 32-sequence
+    blocked kernels with the default 2-byte format only.  WESEP_BAND_RF=0 restores the three-term product.  Gradients
     against the oracle within the format's tolerance in all three modes (the emulation models the stored fp16 d(gates) and the
     16-bit weights of both products)."""
     from wesep_amd import dev
@@ -95,7 +95,7 @@ def test_streaming_bptt_arithmetic_and_its_own_input_gradient_reach_the_kernel(e
     monkeypatch.setattr(dev, "lstm_pack_dx_f8", lambda *a, **k: (seen.append(("packdx",)), real_px(*a, **k))[1])
     monkeypatch.setattr(dev, "gemm_b2p", lambda **k: (seen.append(("b2p", k.get("a_fmt", 0))), real_b2p(**k))[1])
     grads = {}
-    for mode, env in (("default", {}), ("gemm", {"WESEP_BAND_DX": "0"}), ("rf0", {"WESEP_BAND_RF": "0"})):
+    for mode, env in (("default", {"WESEP_BAND_DX": "1"}), ("gemm", {}), ("rf0", {"WESEP_BAND_RF": "0"})):
         for k_ in ("WESEP_BAND_DX", "WESEP_BAND_RF"):
             monkeypatch.delenv(k_, raising=False)
         for k_, v_ in env.items():

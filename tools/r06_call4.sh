@@ -21,7 +21,7 @@ run() {  # name, env...
 run new
 run nodx WESEP_BAND_DX=0
 run drain WESEP_FUSED_DRAIN=1
-run nogate WESEP_SIDE_GATE=0
+
 run new_b
 timeout 600 python -m pytest tests/test_bsrnn_gpu.py -q -s -k "training_step_matches or trajectory or resrnn_block or side_stream or fused_input" > $O/r06_c4_parity.log 2>&1
 echo "== quick parity exit $?"; grep -E "trajectory|passed|failed|worst|step|Error" $O/r06_c4_parity.log | cut -c1-300 | tail -12

@@ -128,8 +128,7 @@ class LstmCluster2Args(C.Structure):
 
 class LstmPairArgs(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "dhcat", "wpack", "xchg", "flags", "status", "dbg_buf")] + \
-               [("nseq", _i), ("L", _i), ("dbg", _i), ("gfmt", _i), ("dgates", _p), ("amax", _p), ("rfmt", _i), ("pad_", _i),
-                ("resident", _p)]                                                                    # resident: ABI v19
+               [("nseq", _i), ("L", _i), ("dbg", _i), ("gfmt", _i), ("dgates", _p), ("amax", _p), ("rfmt", _i), ("pad_", _i)]
 
 
 class Bands(C.Structure):
@@ -162,7 +161,6 @@ _SIGS = {
     "ws_prof_collect": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_ll)]),
     "ws_debug_dirty_lds": (_i, [_f, _i, _i, _p, _p]),
     "ws_debug_occupy": (_i, [_i, _i, _p, _p, _p]),
-    "ws_wait_word": (_i, [_p, C.c_uint, _i, _p]),
     "ws_pack_w_f16": (_i, [_p, _i, _i, _ll, _i, _i, _p, _p]),
     "ws_gemm_nt": (_i, [C.POINTER(GemmNTArgs), _p]),
     "ws_gemm_tn": (_i, [C.POINTER(GemmTNArgs), _p]),

@@ -229,8 +229,6 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
   // block -> (pair, member): members of a pair are 8 blocks apart (same XCD under round-robin dispatch)
   const int pr = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), hs = ((int)blockIdx.x >> 3) & 1;
   if (pr >= npair) return;
-  // (ABI v19) this workgroup holds its CU now: the side stream's gate (ws_wait_word) counts on it
-  if (p.resident && threadIdx.x == 0) __hip_atomic_fetch_add(p.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // variant 2048, round 6: every workgroup's wall-clock times (100 MHz, one counter for the chip) of entry, first loop top and loop
   // end, behind the step stamps: dbg_buf as u64 [L * 16 + (pr * 2 + hs) * 4 + {0, 1, 2}] (tools/r06_instep_stamps.py)
   long long wall_in = 0;

@@ -137,23 +137,3 @@ extern "C" int ws_debug_occupy(int nblocks, int usec, const unsigned* stop, floa
                      sink);
   return ws_check_launch("ws_debug_occupy");
 }
-
-// Stream gate (ABI v19): one wave that waits -- bounded, on the constant-rate wall clock -- until a device word has reached
-// `target`, then ends; what is enqueued behind it on its stream starts after that.  The pair BPTT (lstm_pair.hip) counts its
-// workgroups into such a word as they come up (ws_lstm_pair_args.resident); the weight-gradient jobs of the side stream are
-// queued behind this gate, so they reach the dispatcher when every workgroup of the latency-bound kernel already holds its
-// CU: released at the same instant as the BPTT (round 4's event gate), the GEMM's many small workgroups took CUs the pair's
-// whole-CU workgroups then had to wait for -- 0.55 ms of every launch (profiles/r06_side_stream_tax.md).  Never hangs: the
-// wait ends after `max_us` whatever the word says (a BPTT that never became resident has its own time-out path).
-__global__ __launch_bounds__(64) void wait_word_kernel(const unsigned* word, unsigned target, long long ticks) {
-  if (threadIdx.x != 0) return;
-  const long long t0 = wall_clock64();
-  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && wall_clock64() - t0 < ticks)
-    __builtin_amdgcn_s_sleep(16);
-}
-
-extern "C" int ws_wait_word(const unsigned* word, unsigned target, int max_us, void* stream) {
-  WS_REQUIRE(word && max_us >= 0 && max_us <= 100000, "ws_wait_word: null word / 0 <= max_us <= 100 000");
-  hipLaunchKernelGGL(wait_word_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, word, target, (long long)max_us * 100LL);
-  return ws_check_launch("ws_wait_word");
-}

@@ -410,6 +410,9 @@ def lstm_fwd(gates, cbuf, hcat, wpack, sm: SeqMap, mode=L.LSTM_BF16X3, run_if=No
     """run_if: optional 1-element int32 device tensor; the launch is a no-op unless it is non-zero at kernel start.
     gfmt != 0 (blocked-layout modes): pre-activations from `gates_in` (fp32 BL), `gates` receives unorm16 (BLH)."""
     a = _lstm_args(gates, cbuf, hcat, wpack, sm, mode, run_if=run_if, gfmt=gfmt, gates_in=gates_in)
+    if run_if is None:     # fp32 pre-activations in, gates (fp32 in place / unorm16) + c + h out
+        u = ALG_LSTM_UNITS or L.LSTM_H
+        _alg("lstm_fwd", sm.nseq * sm.L * 2 * u * (16 + (2 if gfmt else 4) * 4 + 8), 2 * sm.nseq * sm.L * 2 * 4 * u * u)
     L.check(L.lib().ws_lstm_fwd(C.byref(a), L.stream_ptr()), "ws_lstm_fwd")
 
 
@@ -543,6 +546,8 @@ def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm: SeqMap, status=None, d
     a.xchg, a.flags = C.c_void_p(xchg.data_ptr()), C.c_void_p(flags.data_ptr())
     a.status = C.c_void_p((status if status is not None else sc.status).data_ptr())
     a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
+    u = ALG_LSTM_UNITS or L.LSTM_H
+    _alg("lstm_fwd", sm.nseq * sm.L * 2 * u * (16 + (2 if gfmt else 4) * 4 + 8), 2 * sm.nseq * sm.L * 2 * 4 * u * u)
     L.check(L.lib().ws_lstm_fwd_cluster(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_cluster")
     return flags[ncl * 8:ncl * 8 + 1]
 
@@ -588,6 +593,8 @@ def lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whh_f, whh_r, sm: SeqMa
     a.status = C.c_void_p((status if status is not None else sc.status).data_ptr())
     a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
     a.dbg_buf = C.c_void_p(dbg_buf.data_ptr()) if dbg_buf is not None else None
+    u = ALG_LSTM_UNITS or L.LSTM_H     # (as lstm_fwd_fused: unorm16 gates + c + h out, the split-pair input in)
+    _alg("lstm_fwd", sm.nseq * sm.L * (2 * u * 16 + 4 * 128), 2 * sm.nseq * sm.L * 2 * 4 * u * (u + 128))
     L.check(L.lib().ws_lstm_fwd_cluster2(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_cluster2")
     return tw
 
@@ -628,20 +635,8 @@ def lstm_pack_pair(whh_f, whh_r, pack, f16=False):
     L.check(fn(_p(whh_f), _p(whh_r), _p(pack), L.stream_ptr()), "ws_lstm_pack_pair")
 
 
-def wait_word(word, target: int, max_us: int = 300):
-    """ws_wait_word on the CURRENT stream: a one-wave gate that ends when the 1-element int32 device tensor `word` has reached
-    `target` or after `max_us` microseconds -- what is enqueued behind it starts once the kernel that counts its workgroups
-    into `word` (lstm_bwd_pair(..., resident=)) is fully resident."""
-    L.check(L.lib().ws_wait_word(_word(word), int(target), int(max_us), L.stream_ptr()), "ws_wait_word")
-
-
-def pair_workgroups(sm: SeqMap) -> int:
-    """Live workgroups of a pair BPTT launch: two members per (tile, direction)."""
-    return 4 * (-(-sm.nseq // 32))
-
-
 def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg_buf=None, gfmt=0, dgates=None,
-                  repairable=False, amax=None, rfmt=0, resident=None):
+                  repairable=False, amax=None, rfmt=0):
     """BPTT on the blocked layout over pairs of workgroups (lstm_pair.hip); gates: activated gates in,
     d(pre-activation gates) (BLS) out.  Returns the launch's timeout word; in place, so there is no device-side
     fall-back: poll_cluster_status raises (one step late, without a host sync) when a bounded wait timed out."""
@@ -661,7 +656,6 @@ def lstm_bwd_pair(gates, cbuf, dhcat, wpack, sm: SeqMap, status=None, dbg=0, dbg
     a.gfmt, a.dgates = gfmt, _p(dgates)
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
     a.rfmt = rfmt           # 1 / 2: fp16 recurrence (wpack from lstm_pack_pair(..., f16=rfmt); WS_GATES_H2F only)
-    a.resident = C.c_void_p(resident.data_ptr()) if resident is not None else None    # (zeroed word: one count per workgroup)
     _alg("lstm_bwd", _bptt_bytes(gfmt) * sm.nseq * sm.L * 2 * (ALG_LSTM_UNITS or L.LSTM_H),
              2 * sm.nseq * sm.L * 2 * 4 * (ALG_LSTM_UNITS or L.LSTM_H) ** 2)
     L.check(L.lib().ws_lstm_bwd_pair(C.byref(a), L.stream_ptr()), "ws_lstm_bwd_pair")
@@ -948,6 +942,11 @@ def gemm_p2b(*, A, lda: int, sm: SeqMap, Wpack, N: int, C_out, K=128, bias=None,
     a.run_if = C.c_void_p(run_if.data_ptr()) if run_if is not None else None
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None     # 1-element int32, zeroed by the caller
     a.A_bl16 = _p(A_bl16)
+    if ALG is not None and run_if is None:
+        # rows x (plain operand in, BL result out, the operand's BL copies: split pairs 4 B, fp16 2 B) + the weights
+        rows = (getattr(sm, "nvalid", 0) or sm.nseq) * sm.L
+        _alg("gemm_nt", rows * (4 * K + 4 * N + (4 * K if A_bl is not None else 0) + (2 * K if A_bl16 is not None else 0)) + 4 * N * K,
+             2 * rows * N * K)
     L.check(L.lib().ws_gemm_p2b(C.byref(a), L.stream_ptr()), "ws_gemm_p2b")
 
 
@@ -965,6 +964,10 @@ def gemm_b2p(*, A, K: int, sm: SeqMap, Wpack, C_out, ldc: int, N=128, bias=None,
     a.ldc, a.N, a.K, a.a_fmt = ldc, N, K, a_fmt
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
     a.a16_out = _p(a16_out)
+    if ALG is not None:
+        rows = (getattr(sm, "nvalid", 0) or sm.nseq) * sm.L
+        _alg("gemm_nt", rows * ((2 if a_fmt else 4) * K + 4 * N * (1 + (R is not None)) + (2 * K if a16_out is not None else 0))
+             + 4 * N * K, 2 * rows * N * K)
     L.check(L.lib().ws_gemm_b2p(C.byref(a), L.stream_ptr()), "ws_gemm_b2p")
 
 
@@ -997,6 +1000,10 @@ def gemm_tnb(*, G, g_width: int, g_off: int, g_cols: int, A0, a0_width: int, a0_
     a.a1_width, a.a1_off, a.a1_cols, a.a1_shift = a1_width, a1_off, a1_cols, a1_shift
     a.nblk, a.L, a.nsplit, a.blocks_per_split, a.g_fmt, a.a_fmt = nblk, L_, nsplit, blocks_per_split, g_fmt, a_fmt
     a.amax = C.c_void_p(amax.data_ptr()) if amax is not None else None
+    if ALG is not None:
+        rows, acols = nblk * 32, a0_cols + a1_cols
+        _alg("gemm_tn", rows * ((2 if g_fmt else 4) * g_cols + (2 if a_fmt else 4) * acols) + 4 * nsplit * g_cols * acols,
+             2 * rows * g_cols * acols)
     L.check(L.lib().ws_gemm_tnb(C.byref(a), L.stream_ptr()), "ws_gemm_tnb")
 
 
@@ -1239,6 +1246,9 @@ def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm: SeqMap, gfmt=0, hfmt=
     a.gates, a.cbuf, a.hcat, a.xn, a.wpack, a.bias = _p(gates), _p(cbuf), _p(hcat), _p(xn), _p(wpack), _p(bias)
     a.nseq, a.L, a.gfmt = sm.nseq, sm.L, gfmt
     a.hfmt = hfmt | (2 if os.environ.get("WESEP_FUSED_DRAIN", "0") == "1" else 0)      # (bit 1: A/B of the end-of-step wait)
+    # per (position, direction): 4H gates (2 B / 4 B) + c + h out, the 128-wide split-pair input in (shared by both directions)
+    u = ALG_LSTM_UNITS or L.LSTM_H
+    _alg("lstm_fwd", sm.nseq * sm.L * (2 * u * ((2 if gfmt else 4) * 4 + 8) + 4 * 128), 2 * sm.nseq * sm.L * 2 * 4 * u * (u + 128))
     L.check(L.lib().ws_lstm_fwd_fused(C.byref(a), L.stream_ptr()), "ws_lstm_fwd_fused")
 
 

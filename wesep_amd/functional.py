@@ -215,11 +215,14 @@ def band_rfmt(gfmt, lmode) -> int:
 
 
 def band_dx(brf, seq, geo) -> bool:
-    """d(xn) = d(gates) W_ih computed INSIDE the streaming BPTT (ws_lstm_args.dxn, ABI v19; default on with band_rfmt 2): the
-    kernel holds d(gates) in LDS when it produces them, so ws_gemm_b2p's second pass over that 2.1 GB buffer (per band-view
-    layer at R = 32) and its launch disappear; the fused GroupNorm backward adds the two directions' shares.  WESEP_BAND_DX=0
-    restores the separate GEMM."""
-    return (brf == 2 and os.environ.get("WESEP_BAND_DX", "1") != "0" and not seq.nvalid and dev.gn_bwd_fused_ok(geo))
+    """d(xn) = d(gates) W_ih computed INSIDE the streaming BPTT (ws_lstm_args.dxn, ABI v19; OPT-IN: WESEP_BAND_DX=1, with
+    band_rfmt 2): the kernel holds d(gates) in LDS when it produces them, so ws_gemm_b2p's second pass over that 2.1 GB buffer
+    (per band-view layer at R = 32) and its launch disappear; the fused GroupNorm backward adds the two directions' shares.
+    Measured (profiles/r06_c4_band_probe.txt, r06_ab/r06_c4_bench_{new,nodx}.json): correct to 4.9e-6 and 12.6 GB of HBM reads
+    per step less, but NOT faster -- the BPTT is bound by its per-step weight stream from L2 (19 us per MB per workgroup:
+    1.98 ms at 0.75 MB, 2.60 ms with W_ih^T's 0.4 MB beside it) and the 0.62 ms it gains equal the 0.70 ms the GEMM takes:
+    step 101.8 vs 101.2 ms.  Kept for the traffic figure and for hosts where HBM is the scarcer resource; not the default."""
+    return (brf == 2 and os.environ.get("WESEP_BAND_DX", "0") == "1" and not seq.nvalid and dev.gn_bwd_fused_ok(geo))
 
 
 def wgrad_overlap() -> bool:
@@ -286,13 +289,7 @@ def mark_wgrads_ready(device):
     return ready
 
 
-def side_gate() -> bool:
-    """Hold the released weight-gradient jobs back until every workgroup of the pair BPTT they run beside is resident
-    (ws_wait_word behind the event gate; default on, WESEP_SIDE_GATE=0: the event gate alone)."""
-    return os.environ.get("WESEP_SIDE_GATE", "1") != "0"
-
-
-def flush_deferred_wgrads(device, ready=None, gate=None):
+def flush_deferred_wgrads(device, ready=None):
     """Launch every deferred weight-gradient job on the side stream, ordered after `ready` (default:
     everything enqueued so far on the current stream).  A TIME-VIEW recurrence keeps 128 of 256 CUs
     busy for ~5 ms: its backward marks `ready`, launches the recurrence FIRST -- so its workgroups
@@ -311,12 +308,6 @@ def flush_deferred_wgrads(device, ready=None, gate=None):
         # -- fill the chip at once and the recurrence waits for a whole gemm_tnb wave: measured, step 127 -> 135.6 ms (pBSRNN),
         # 305 -> 326 ms (TF-GridNet), profiles/r04_ab_runs.md
         side.wait_event(ready)
-        if gate is not None:
-            # ... and, round 6, until the recurrence's workgroups HOLD their CUs (gate = (word, target) of lstm_bwd_pair's
-            # residency count): the event makes both runnable at the same instant, and the dispatcher then hands CUs to the
-            # GEMM's small workgroups that the pair's whole-CU workgroups have to wait for (0.55 ms per launch, measured)
-            dev.wait_word(gate[0], gate[1])
-            gate[0].record_stream(side)
         for job, done in jobs:
             side.wait_event(done)        # the job's own producer stream (defer_wgrad); precedes `ready` on one stream
             job(side)
@@ -610,7 +601,6 @@ class ResRNNBlkFn(torch.autograd.Function):
         # half of the chip idle: the weight-gradient jobs deferred by the previous layers are released
         # right after it is launched
         ready = mark_wgrads_ready(d) if ctx.view == "time" else None
-        gate = None
         # time view: the pair kernel (lstm_pair.hip) -- W_hh's hi plane resident across two workgroups per tile, on HALF
         # of the CUs, so the side stream keeps the other half.  The cluster BPTT (all 256 CUs: it evicts the
         # side-stream weight-gradient GEMMs) stays opt-in (WESEP_LSTM_CLUSTER_BWD=1).  Both work in place without a
@@ -634,11 +624,8 @@ class ResRNNBlkFn(torch.autograd.Function):
             # co-resident (a resident RCCL kernel, another process) -- no NaN reaches a consumer (wesep_hip.h)
             dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else _empty(d, dev.blh_floats(nb, 2 * G4))
             rf = pair_rfmt(gfmt)
-            if ready is not None and side_gate() and _pending(d):
-                gate = (zero_words(d, 1), dev.pair_workgroups(seq))
             tw = dev.lstm_bwd_pair(gates, cbuf, dh, W("hhp16" if rf else "hhp"), seq, gfmt=gfmt, dgates=dg, repairable=True,
-                                   dbg=_pair_dbg(), amax=amax, rfmt=rf, dbg_buf=_pair_stamp_buf(d, seq.L),
-                                   resident=gate[0] if gate else None)
+                                   dbg=_pair_dbg(), amax=amax, rfmt=rf, dbg_buf=_pair_stamp_buf(d, seq.L))
             dev.lstm_bwd(gates, cbuf, hcat, dh, W("hh")[1], seq, ctx.lmode, gfmt=gfmt, dgates=dg, run_if=tw, amax=amax)
         else:
             # streaming BPTT (band view): bf16 d(gates) in place over the unorm16 gates (H2) / split pairs to their own
@@ -661,7 +648,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             _PROBE_SAT[1] = max(_PROBE_SAT[1], float(sc.abs().max()) / 65504.0)
             gates.copy_(sc.clamp(-65504.0, 65504.0).half().float() / S)
         if ready is not None:
-            flush_deferred_wgrads(d, ready, gate)
+            flush_deferred_wgrads(d, ready)
         del dh
         # weight gradients: a side branch of the graph -> deferred to the side stream when a carrier
         # will deliver them
