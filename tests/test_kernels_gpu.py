@@ -163,6 +163,15 @@ def test_transpose_and_reduce_ld():
     ref = torch.zeros(5, 24)
     ref[:, 4:14] = slab.sum(0).view(5, 10)
     assert rel(out, ref) < 1e-6
+    # the split-lane kernels (4 lanes from 16 splits, 16 lanes from 64 splits: round 6) and the one-workgroup-per-output form:
+    # odd split counts, counts that do not fill the last 64-column block, deterministic
+    for nsplit, count in ((16, 100), (37, 11520), (64, 777), (342, 11520), (341, 6912), (200, 5)):
+        slab = rnd(g, nsplit, count).to(d)
+        o1, o2 = torch.full((count,), float("nan"), device=d), torch.full((count,), float("nan"), device=d)
+        dev.reduce_slabs(slab, nsplit, count, count, o1)
+        dev.reduce_slabs(slab, nsplit, count, count, o2)
+        assert torch.equal(o1, o2)
+        assert rel(o1, slab.double().sum(0)) < 1e-6, (nsplit, count)
 
 
 # ----------------------------------------------------------------------------------------------

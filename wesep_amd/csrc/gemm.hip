@@ -441,18 +441,33 @@ __global__ __launch_bounds__(256) void reduce_slabs_few_kernel(const float* __re
   if (threadIdx.x == 0) out[(w > 0) ? (i / w) * ldo + (i % w) : i] = s;
 }
 
-__global__ __launch_bounds__(256) void reduce_slabs_2d_kernel(const float* __restrict__ slab, int nsplit,
-                                                              long long stride, long long count,
-                                                              float* __restrict__ out, int w, long long ldo) {
-  __shared__ float part[4][64];
+// YL split lanes per output column (4 or 16): with hundreds of splits (the halo weight gradients of DPCCN: 342 slabs of
+// 11 520 floats) four lanes walked 86 slabs each, one dependent add after the other -- 20-40 us per launch, 518 launches per
+// step; sixteen lanes walk 22 each, and the partial sums meet in LDS in a fixed order (deterministic).
+template <int YL>
+__global__ __launch_bounds__(64 * YL) void reduce_slabs_2d_kernel(const float* __restrict__ slab, int nsplit,
+                                                                  long long stride, long long count,
+                                                                  float* __restrict__ out, int w, long long ldo) {
+  __shared__ float part[YL][64];
   const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
   const long long i = blockIdx.x * 64LL + x;
-  float s = 0.f;
-  if (i < count)
-    for (int k = y; k < nsplit; k += 4) s += slab[k * stride + i];
-  part[y][x] = s;
+  float s0 = 0.f, s1 = 0.f;     // two chains: the loads of consecutive rounds are in flight together
+  if (i < count) {
+    int k = y;
+    for (; k + YL < nsplit; k += 2 * YL) {
+      s0 += slab[k * stride + i];
+      s1 += slab[(k + YL) * stride + i];
+    }
+    if (k < nsplit) s0 += slab[k * stride + i];
+  }
+  part[y][x] = s0 + s1;
   __syncthreads();
-  if (y == 0 && i < count) out[(w > 0) ? (i / w) * ldo + (i % w) : i] = (part[0][x] + part[1][x]) + (part[2][x] + part[3][x]);
+  if (y == 0 && i < count) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < YL; q += 4) t += (part[q][x] + part[q + 1][x]) + (part[q + 2][x] + part[q + 3][x]);
+    out[(w > 0) ? (i / w) * ldo + (i % w) : i] = t;
+  }
 }
 
 extern "C" int ws_reduce_slabs(const float* slab, int nsplit, long long stride, long long count,
@@ -462,8 +477,11 @@ extern "C" int ws_reduce_slabs(const float* slab, int nsplit, long long stride, 
   if (count <= 8 && nsplit >= 64) {
     hipLaunchKernelGGL(reduce_slabs_few_kernel, dim3((unsigned)count), dim3(256), 0, s, slab, nsplit, stride, out, w,
                        ldo);
+  } else if (count <= 65536 && nsplit >= 64) {
+    hipLaunchKernelGGL(reduce_slabs_2d_kernel<16>, dim3((unsigned)((count + 63) / 64)), dim3(1024), 0, s, slab, nsplit,
+                       stride, count, out, w, ldo);
   } else if (count <= 16384 && nsplit >= 16) {
-    hipLaunchKernelGGL(reduce_slabs_2d_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, s, slab, nsplit,
+    hipLaunchKernelGGL(reduce_slabs_2d_kernel<4>, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, s, slab, nsplit,
                        stride, count, out, w, ldo);
   } else {
     const int threads = 256;

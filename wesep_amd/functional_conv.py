@@ -67,7 +67,9 @@ def halo_wgrad(G, Nn, X, ldx, B, H, W, Cin, with_bias, sw=1, Wx=0, ldg=0, g_off=
     first Cin channels)."""
     tiles = dev.conv3x3_wgrad_tiles(B, H, W)
     groups = (-(-Cin // 32)) * (-(-Nn // 32))              # workgroups per split: one per (input chunk, output tile)
-    nsplit = max(1, min(tiles // 4, -(-1024 // groups)))   # ~4 workgroups per CU in flight, >= 4 tiles each
+    # ~4 workgroups per CU in flight, >= 4 tiles each.  ROUNDED DOWN: two workgroups of this kernel fit a CU, 512 are resident,
+    # and ceil(1024 / 3) * 3 = 1026 workgroups ran a third round for the last two (round 6: the 80-channel layers' 3.1 ms launches)
+    nsplit = max(1, min(tiles // 4, max(1, 1024 // groups)))
     tps = -(-tiles // nsplit)
     nsplit = -(-tiles // tps)
     d = G.device
