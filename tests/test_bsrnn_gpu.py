@@ -14,7 +14,10 @@ pytestmark = pytest.mark.gpu
 
 WAV_TOL = 1e-3
 DB_TOL = 1e-2
-GRAD_TOL = 2e-3
+GRAD_TOL = 2e-3          # small fixtures (short sequences, few positions per weight: the noisiest gradients)
+# the full-size steps: about 3x the measured worst parameter gradient (1.8e-4 at R = 2, 3.3e-4 at R = 16: rounds 5-6) -- VERDICT
+# round 5, weak 7: the earlier 5e-3 sat fifteen times above the measurement and could not see a 2x regression
+GRAD_TOL_FULL = 1e-3
 
 
 def _cuda():
@@ -133,8 +136,8 @@ def test_full_size_row_vs_oracle():
     assert rel(est, est_o) < WAV_TOL, rel(est, est_o)
     assert abs(loss.item() - loss_o.item()) < DB_TOL
     worst = max(rel(p.grad, grads_o[k]) for k, p in model.named_parameters())
-    assert worst < 5e-3, worst
     print(f"full-size: est rel {rel(est, est_o):.2e} dloss {abs(loss.item() - loss_o.item()):.2e} dB worst grad {worst:.2e}")
+    assert worst < GRAD_TOL_FULL, worst      # measured 1.8e-4 (rounds 5-6)
 
 
 def test_baseline_config2_film_multifuse_r16_vs_oracle():
@@ -161,7 +164,40 @@ def test_baseline_config2_film_multifuse_r16_vs_oracle():
           f"({worst_k}) median grad {sorted(per.values())[len(per) // 2]:.2e}")
     assert e_rel < WAV_TOL, e_rel
     assert dl < DB_TOL, dl
-    assert per[worst_k] < 5e-3, (worst_k, per[worst_k])
+    assert per[worst_k] < GRAD_TOL_FULL, (worst_k, per[worst_k])      # measured 3.3e-4 (rounds 5-6)
+
+
+def test_headline_batch_r32_vs_oracle():
+    """The size bench.py runs -- R = 32 rows x 4 s, FiLM multi-fuse, 6 repeats -- against the oracle (the
+    largest size held against it was R = 16).  Rows never interact in the separator and the loss is the batch mean, so the
+    oracle's step is taken in four chunks of 8 rows (host memory) and summed: est = the chunks' rows, loss = the mean of the chunk
+    losses, every parameter gradient = the mean of the chunk gradients (about two minutes of host time)."""
+    from oracle import bsrnn_oracle as O
+    from wesep_amd.functional import SISDRFn
+    d = _cuda()
+    kw = dict(num_repeat=6, spk_fuse_type="FiLM", multi_fuse=True)
+    cfg, params, model = _build(kw, 32, d)
+    wav, tgt, emb = O.synth_batch(32, 64000, 32)
+    ests, loss_o, grads_o = [], 0.0, None
+    for c in range(4):
+        sl = slice(8 * c, 8 * c + 8)
+        e_c, l_c, g_c = _oracle_run(cfg, params, wav[sl], tgt[sl], emb[sl])
+        ests.append(e_c)
+        loss_o += float(l_c) / 4
+        grads_o = {k: v / 4 for k, v in g_c.items()} if grads_o is None else {k: grads_o[k] + g_c[k] / 4 for k in g_c}
+    est_o = torch.cat(ests)
+    est, _ = model(wav.to(d), emb.to(d))
+    loss = SISDRFn.apply(est, tgt.to(d), 1e-8)
+    loss.backward()
+    torch.cuda.synchronize()
+    e_rel, dl = rel(est, est_o), abs(loss.item() - loss_o)
+    per = {k: rel(p.grad, grads_o[k]) for k, p in model.named_parameters()}
+    worst_k = max(per, key=per.get)
+    print(f"headline batch (FiLM multi-fuse, R=32 x 4 s): est rel {e_rel:.2e} dloss {dl:.2e} dB worst grad {per[worst_k]:.2e} "
+          f"({worst_k}) median grad {sorted(per.values())[len(per) // 2]:.2e}")
+    assert e_rel < WAV_TOL, e_rel
+    assert dl < DB_TOL, dl
+    assert per[worst_k] < GRAD_TOL_FULL, (worst_k, per[worst_k])
 
 
 def test_batch_rows_are_independent_at_headline_batch():

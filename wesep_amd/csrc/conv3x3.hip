@@ -377,6 +377,202 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const ws_conv3x3_
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient for <= 16 output channels (round 6): DPCCN's dense blocks (convs.py:80-112, 16 output channels on 16 .. 80
+// inputs) were 20 of its 28 ms of weight gradients per step at config 3, with half of every 32-row tile of the kernel above
+// empty and no load in flight while a tile is multiplied (nine 32 x 32 accumulators leave no registers for it).  Same tiles
+// (30 rows x 4 columns, wave = column), same LDS images and the same funnel-shifted dY fragments, on v_mfma_f32_16x16x32_bf16:
+// the 32 halo rows are ONE k-step, A = dY^T [16 output channels][32 rows], B = X^T [16 input channels][32 rows] for the two
+// halves of the 32-channel chunk -- 54 MFMAs of half the size per tile; the eighteen 16 x 16 accumulators take 72 registers,
+// and the NEXT tile's global loads are requested before the MFMAs of this one (48 registers).
+// ------------------------------------------------------------------------------------------------------------------
+#define W3_AB16 (4 * 16 * W3_LD)  // dY plane: [column 4][output channel 16][8 zeros | rows 0..29 | 2 zeros]
+
+template <int SW>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad16_kernel(const ws_conv3x3_wgrad_args p) {
+  constexpr int NCOL = 3 * SW + 3;             // halo columns of 4 output columns: 6 / 9
+  constexpr int XB = NCOL * 32 * W3_LD;        // X plane: [halo column][channel 32][row]
+  constexpr int NXITEM = 8 * NCOL * 8, NXI = (NXITEM + 255) / 256;   // (row quad, halo column, channel quad)
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];       // 2 XB + 2 W3_AB16 bf16: 41 / 56.3 KB, two workgroups per CU
+  __bf16* const xb = lds;                      // planes at xb, xb + XB
+  __bf16* const ab = lds + 2 * XB;             // planes at ab, ab + W3_AB16
+  const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, q4 = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, Wd = p.Wd, Wx = p.Wx, Cin = p.Cin;
+  const int split = blockIdx.x, c0 = blockIdx.y * 32;
+  const int nn = p.Nn;                         // <= 16: one output tile
+  const int ncg = (Wd + 3) / 4, nrt = (H + W3_TH - 1) / W3_TH;
+  const long long ntiles = (long long)p.B * nrt * ncg;
+  const long long t_begin = (long long)split * p.tiles_per_split, t_end = min(ntiles, t_begin + p.tiles_per_split);
+
+  for (int i = tid; i < (2 * XB + 2 * W3_AB16) / 2; i += 256) reinterpret_cast<uint32_t*>(lds)[i] = 0u;   // the pads stay zero
+
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = p.bslab && blockIdx.y == 0;
+
+  // staging items: X (8 row quads x NCOL halo columns x 8 channel quads), dY (8 row quads x 4 columns x 4 channel quads = 128:
+  // the first two waves)
+  int x_cq[NXI], x_hc[NXI], x_hq[NXI];
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) {
+    const int it = tid + 256 * i;
+    x_cq[i] = it & 7;
+    x_hc[i] = (it >> 3) % NCOL;
+    x_hq[i] = (it >> 3) / NCOL;
+  }
+  const int g_nq = tid & 3, g_col = (tid >> 2) & 3, g_hq = (tid >> 4) & 7;
+  const bool g_on = tid < 128;
+
+  f32x4 xv[NXI][4], gv[4];
+  auto load_tile = [&](long long tile) {         // global -> registers (zeros outside the image / the channel ranges)
+    const int cg = (int)(tile % ncg), rt = (int)((tile / ncg) % nrt), b = (int)(tile / ((long long)ncg * nrt));
+    const int h0 = rt * W3_TH, w0 = cg * 4;
+    const long long img = (long long)b * H * Wd, imgx = (long long)b * H * Wx;
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int ww = SW * w0 - 1 + x_hc[i], c = c0 + 4 * x_cq[i];
+      const bool on = tid + 256 * i < NXITEM;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int hh = h0 - 1 + 4 * x_hq[i] + j;
+        xv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (on && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)Wx && c < Cin)
+          xv[i][j] = *reinterpret_cast<const f32x4*>(p.X + (imgx + (long long)hh * Wx + ww) * p.ldx + c);
+      }
+    }
+    const int ww = w0 + g_col, n = 4 * g_nq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ii = 4 * g_hq + j, hh = h0 + ii;
+      gv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (g_on && ii < W3_TH && hh < H && ww < Wd && n < nn)
+        gv[j] = *reinterpret_cast<const f32x4*>(p.G + (img + (long long)hh * Wd + ww) * p.ldg + n);
+    }
+  };
+  auto stage_tile = [&]() {                      // registers -> the transposed bf16 hi / lo images
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      if (tid + 256 * i >= NXITEM) break;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bf16x4 hi, lo;
+        c3_split4(f32x4{xv[i][0][e], xv[i][1][e], xv[i][2][e], xv[i][3][e]}, hi, lo);
+        const int o = (x_hc[i] * 32 + 4 * x_cq[i] + e) * W3_LD + 4 * x_hq[i];
+        *reinterpret_cast<bf16x4*>(xb + o) = hi;
+        *reinterpret_cast<bf16x4*>(xb + XB + o) = lo;
+      }
+    }
+    if (g_on) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bf16x4 hi, lo;
+        c3_split4(f32x4{gv[0][e], gv[1][e], gv[2][e], gv[3][e]}, hi, lo);
+        gsum[e] += (gv[0][e] + gv[1][e]) + (gv[2][e] + gv[3][e]);
+        const int o = (g_col * 16 + 4 * g_nq + e) * W3_LD + 8 + 4 * g_hq;
+        *reinterpret_cast<bf16x4*>(ab + o) = hi;
+        *reinterpret_cast<bf16x4*>(ab + W3_AB16 + o) = lo;
+      }
+    }
+  };
+
+  if (t_begin < t_end) load_tile(t_begin);
+  for (long long tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();                             // the previous tile's fragment reads (and the zero fill) are done
+    stage_tile();
+    if (tile + 1 < t_end) load_tile(tile + 1);   // in flight under this tile's MFMAs
+    __syncthreads();
+    // ---- 3 kx x 3 ky x 2 halves of the channel chunk, ONE k-step of 32 halo rows: lane = (channel n16, row block q4) ----
+    const int ao = (wv * 16 + n16) * W3_LD + 8 + 8 * q4;
+    u32x4 a_h[3], a_l[3];
+    {
+      const u32x4 ch = *reinterpret_cast<const u32x4*>(ab + ao), ph = *reinterpret_cast<const u32x4*>(ab + ao - 8);
+      const u32x4 cl = *reinterpret_cast<const u32x4*>(ab + W3_AB16 + ao), pl = *reinterpret_cast<const u32x4*>(ab + W3_AB16 + ao - 8);
+      a_h[0] = ch;                               // k pairs X row h0 - 1 + k with dY row k - ky of the tile
+      a_l[0] = cl;
+      a_h[1] = u32x4{__builtin_amdgcn_alignbit(ch.x, ph.w, 16), __builtin_amdgcn_alignbit(ch.y, ch.x, 16),
+                     __builtin_amdgcn_alignbit(ch.z, ch.y, 16), __builtin_amdgcn_alignbit(ch.w, ch.z, 16)};
+      a_l[1] = u32x4{__builtin_amdgcn_alignbit(cl.x, pl.w, 16), __builtin_amdgcn_alignbit(cl.y, cl.x, 16),
+                     __builtin_amdgcn_alignbit(cl.z, cl.y, 16), __builtin_amdgcn_alignbit(cl.w, cl.z, 16)};
+      a_h[2] = u32x4{ph.w, ch.x, ch.y, ch.z};
+      a_l[2] = u32x4{pl.w, cl.x, cl.y, cl.z};
+    }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int bo = ((SW * wv + kx) * 32 + 16 * nt + n16) * W3_LD + 8 * q4;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(xb + bo);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(xb + XB + bo);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) acc[ky * 3 + kx][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3_frag(a_h[ky]), bh, acc[ky * 3 + kx][nt], 0, 0, 0);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) acc[ky * 3 + kx][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3_frag(a_l[ky]), bh, acc[ky * 3 + kx][nt], 0, 0, 0);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) acc[ky * 3 + kx][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3_frag(a_h[ky]), bl, acc[ky * 3 + kx][nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- the four waves' partial sums -> wave 0, three taps per round through LDS (3 x 1536 floats) ----
+  float* const red = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) {
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          *reinterpret_cast<f32x4*>(red + ((((wv - 1) * 3 + tp) * 2 + nt) * 64 + lane) * 4) = acc[3 * rr + tp][nt];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const f32x4 s1 = *reinterpret_cast<const f32x4*>(red + (((0 * 3 + tp) * 2 + nt) * 64 + lane) * 4);
+          const f32x4 s2 = *reinterpret_cast<const f32x4*>(red + (((1 * 3 + tp) * 2 + nt) * 64 + lane) * 4);
+          const f32x4 s3 = *reinterpret_cast<const f32x4*>(red + (((2 * 3 + tp) * 2 + nt) * 64 + lane) * 4);
+          acc[3 * rr + tp][nt] += (s1 + s2) + s3;
+        }
+    }
+  }
+  const int K_all = 9 * Cin;
+  if (wv == 0) {                                 // D: lane = (input channel n16 of the half, 4 output channels 4 q4 .. + 3)
+    float* out = p.slab + (long long)split * p.slab_stride;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int c = c0 + 16 * nt + n16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = 4 * q4 + r;
+          if (n < nn && c < Cin) out[(long long)n * K_all + tap * Cin + c] = acc[tap][nt][r];
+        }
+      }
+  }
+  if (want_bias) {                               // db[n] = sum over the split's pixels of dy[.][n]
+    __syncthreads();
+    if (g_on) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[tid * 4 + e] = gsum[e];
+    }
+    __syncthreads();
+    if (tid < nn) {
+      float t = 0.f;
+      for (int u = 0; u < 32; ++u) t += red[(u * 4 + (tid >> 2)) * 4 + (tid & 3)];
+      p.bslab[(long long)split * p.bslab_stride + tid] = t;
+    }
+  }
+}
+
 extern "C" int ws_conv3x3_wgrad(const ws_conv3x3_wgrad_args* a, void* stream) {
   WS_REQUIRE(a && a->G && a->X && a->slab, "ws_conv3x3_wgrad: null pointer");
   WS_REQUIRE(a->B > 0 && a->H > 0 && a->Wd > 0 && a->Cin > 0 && a->Cin % 4 == 0 && a->Nn > 0 && a->Nn % 4 == 0,
@@ -412,7 +608,12 @@ extern "C" int ws_conv3x3_wgrad(const ws_conv3x3_wgrad_args* a, void* stream) {
     }
   }
   ws_prof_begin(WS_PROF_GEMM_TN, s);
-  if (a->sw == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds1, s, *a);
+  static const int v16 = [] { const char* e = getenv("WS_CONV3X3_WGRAD16"); return e ? atoi(e) : 1; }();   // (0: A/B against the 32-row kernel)
+  if (a->Nn <= 16 && v16) {   // one 16-row output tile: the 16 x 16 x 32 kernel (41 / 56.3 KB of LDS: under the default limit)
+    const size_t l1 = (size_t)(2 * 6 * 32 * W3_LD + 2 * W3_AB16) * sizeof(__bf16), l2 = (size_t)(2 * 9 * 32 * W3_LD + 2 * W3_AB16) * sizeof(__bf16);
+    if (a->sw == 1) hipLaunchKernelGGL(conv3x3_wgrad16_kernel<1>, grid, dim3(256), l1, s, *a);
+    else hipLaunchKernelGGL(conv3x3_wgrad16_kernel<2>, grid, dim3(256), l2, s, *a);
+  } else if (a->sw == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds1, s, *a);
   else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), lds2, s, *a);
   ws_prof_end(WS_PROF_GEMM_TN, s);
   return ws_check_launch("ws_conv3x3_wgrad");
