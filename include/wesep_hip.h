@@ -708,7 +708,7 @@ typedef struct ws_lstm_fused_args {
   int hfmt;             /* ABI v19 (the former pad_: 0 = every earlier behaviour): 1 = the recurrent part of the stream on
                            v_mfma_f32_32x32x16_f16 with h as ONE fp16 operand and W_hh as fp16 hi / lo of 256 w (two MFMAs per
                            product instead of three; the arithmetic of ws_lstm_fwd_cluster2) -- wpack from
-                           ws_lstm_pack_fused_h16, 2-byte gate formats only, always the 64-sequence kernel.  Bit 1 (value
+                           ws_lstm_pack_fused_h16, 2-byte gate formats only.  Bit 1 (value
                            2, measurement): the 64-sequence kernels drain every store of a step before the next one starts
                            (the wait of rounds 3-5)                                                                   */
 } ws_lstm_fused_args;

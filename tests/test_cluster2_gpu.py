@@ -147,16 +147,18 @@ def test_resrnn_time_view_cluster2_on_vs_off(monkeypatch, force_timeout):
     dev.poll_cluster_status(d, block=True)      # (a repaired forward time-out is counted, not raised)
 
 
+@pytest.mark.parametrize("seqs", ["64", "32"])
 @pytest.mark.parametrize("dims", [(4, 9, 16), (3, 32, 43)])
-def test_fused_band_forward_fp16_h_vs_torch_lstm_and_three_term_kernel(dims):
+def test_fused_band_forward_fp16_h_vs_torch_lstm_and_three_term_kernel(dims, seqs, monkeypatch):
     """ws_lstm_fused_args.hfmt = 1 (ABI v19, csrc/lstm_fused.hip lstm_fwd_fused64h16_kernel): the band view's fused forward with the
     recurrent part on the fp16 MFMA (h as one fp16 operand, W_hh as fp16 hi / lo of 256 w: two terms) -- the arithmetic of
     ws_lstm_fwd_cluster2 in the throughput kernel.  Against (a) torch's LSTM in fp64 (nn.LSTM inside ResRNN, bsrnn.py:27-33,40) and
-    (b) the three-term kernel (hfmt 0) on the same input, both formats of the saved state; deterministic; odd tile counts (the
-    second tile of the last 64-sequence workgroup empty) and ragged last tiles included."""
+    (b) the three-term kernel (hfmt 0) on the same input; deterministic; odd tile counts (the second tile of the last
+    64-sequence workgroup empty) and ragged last tiles included; the 64- and the 32-sequence kernel."""
     from wesep_amd import dev
     from wesep_amd.functional import _view_maps
     d = _cuda()
+    monkeypatch.setenv("WS_FUSED_SEQS", seqs)       # both kernels carry the variant: 64 sequences per workgroup (pBSRNN), 32 (TF-GridNet)
     g = torch.Generator().manual_seed(21)
     R, K, Tf = dims
     P = R * K * Tf

@@ -74,7 +74,8 @@ extern "C" int ws_lstm_pack_fused_h16(const float* wih_f, const float* wih_r, co
   return ws_check_launch("ws_lstm_pack_fused_h16");
 }
 
-template <int GF>  // WS_GATES_*: != 0 -> activated gates leave as unorm16 (BLH), lstm_bf16_common.h
+// H16: ws_lstm_fused_args.hfmt = 1 -- see lstm_fwd_fused64_body (fp16 h, one LDS plane per buffer, two recurrent terms)
+template <int GF, bool H16 = false>  // WS_GATES_*: != 0 -> activated gates leave as unorm16 (BLH), lstm_bf16_common.h
 __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fused_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 hl[2][2][SQ * HROW];  // [buf][part][seq][k]  66 KB
   __shared__ __attribute__((aligned(16))) __bf16 xl[2][2][SQ * XROW];  // [buf][part][seq][k]  34 KB
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bias[g][j] = *reinterpret_cast<const f32x4*>(p.bias + d * LG + g * 256 + ubase + 8 * j);
+    for (int j = 0; j < 4; ++j)
+      bias[g][j] = *reinterpret_cast<const f32x4*>(p.bias + d * LG + g * 256 + ubase + 8 * j) * (H16 ? 256.f : 1.f);
 
   // weight stream: per k-step 8 fragments (4 gates x {hi, lo}), 1 KB each per wave; 24 k-steps per step
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -163,13 +165,21 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
     for (int ks = 0; ks < FKS; ++ks) {
       const int s = ks & 1;
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(ks < 8 ? xhi + 16 * ks : hhi + 16 * (ks - 8));
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(ks < 8 ? xlo + 16 * ks : hlo + 16 * (ks - 8));
+      if (H16 && ks >= 8) {   // fp16 W_hh (hi, lo of 256 w) x fp16 h: two terms
+        const f16x8 b16 = __builtin_bit_cast(f16x8, bh);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g], bh, acc[g]);
+        for (int g = 0; g < 4; ++g) acc[g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g]), b16, acc[g]);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g + 1], bh, acc[g]);
+        for (int g = 0; g < 4; ++g) acc[g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g + 1]), b16, acc[g]);
+      } else {
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(ks < 8 ? xlo + 16 * ks : hlo + 16 * (ks - 8));
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g], bl, acc[g]);
+        for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g], bh, acc[g]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g + 1], bh, acc[g]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g], bl, acc[g]);
+      }
       // refill this slot with k-step ks+2 (wraps into the next step: the stream never drains)
       const int kn = (ks + 2) % FKS;
 #pragma unroll
@@ -198,10 +208,10 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
       const f32x4 cold = *reinterpret_cast<const f32x4*>(cme + 8 * j);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float ig = fsig(acc[0][4 * j + r]);
-        const float fg = fsig(acc[1][4 * j + r]);
-        const float gg = ftanh(acc[2][4 * j + r]);
-        const float og = fsig(acc[3][4 * j + r]);
+        const float ig = H16 ? c2_sig256(acc[0][4 * j + r]) : fsig(acc[0][4 * j + r]);
+        const float fg = H16 ? c2_sig256(acc[1][4 * j + r]) : fsig(acc[1][4 * j + r]);
+        const float gg = H16 ? c2_tanh256(acc[2][4 * j + r]) : ftanh(acc[2][4 * j + r]);
+        const float og = H16 ? c2_sig256(acc[3][4 * j + r]) : fsig(acc[3][4 * j + r]);
         const float cn = fg * cold[r] + ig * gg;
         vi[r] = ig;
         vf[r] = fg;
@@ -212,8 +222,12 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
       }
       bf16x4 h_hi, h_lo;
       split4(vh, h_hi, h_lo);
-      *reinterpret_cast<bf16x4*>(nhi + 8 * j) = h_hi;
-      *reinterpret_cast<bf16x4*>(nlo + 8 * j) = h_lo;
+      if constexpr (H16) {   // the recurrent operand: fp16(h), the hi plane's storage
+        *reinterpret_cast<u32x2*>(nhi + 8 * j) = enc_f16x4(vh);
+      } else {
+        *reinterpret_cast<bf16x4*>(nhi + 8 * j) = h_hi;
+        *reinterpret_cast<bf16x4*>(nlo + 8 * j) = h_lo;
+      }
       *reinterpret_cast<f32x4*>(cme + 8 * j) = vc;
       st_gate(vi, t, 0, j);
       st_gate(vf, t, 1, j);
@@ -474,12 +488,13 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   static int cus = 0;      // same part on every device of a node; queried once
   if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 256;
   const int rounds32 = (2 * ntile + cus - 1) / cus, rounds64 = (2 * ((ntile + 1) / 2) + cus - 1) / cus;
-  // (hfmt 1 exists as the 64-sequence kernel only: it always runs that one)
-  const bool wide = (a->hfmt & 1) || (env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32);
+  const bool wide = env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
   const char* w1 = getenv("WS_FUSED_W1");   // measurement only: one weight plane (bf16 weights), see lstm_fwd_fused64_body
-  if (a->hfmt & 1)
+  if ((a->hfmt & 1) && wide)
     hipLaunchKernelGGL(lstm_fwd_fused64h16_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
+  else if (a->hfmt & 1)
+    hipLaunchKernelGGL((lstm_fwd_fused_kernel<WS_GATES_H2, true>), grid, block, 0, s, *a);
   else if (wide && a->gfmt && w1 && atoi(w1) == 1)
     hipLaunchKernelGGL(lstm_fwd_fused64h_w1_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
   else if (wide && a->gfmt)

@@ -449,8 +449,9 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         if dev.lstm_fuse_ok(ns, cluster):
             dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, A_bl16=xn16)
             fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
-            dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), whf, whr, fpack)
-            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq, gfmt=gfmt)
+            hf = dev.lstm_fused_hfmt(gfmt)      # round 6: fp16 h in the recurrent part (two terms), as functional.ResRNNBlkFn
+            dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), whf, whr, fpack, hfmt=hf)
+            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq, gfmt=gfmt, hfmt=hf)
         elif cluster and h2 and dev.lstm_cluster2_on() and os.environ.get("WESEP_TFG_CLUSTER2", "1") != "0":
             # inter-frame path, 2-byte formats (round 5): ws_lstm_fwd_cluster2 computes x W_ih^T itself from the split-pair
             # rows ws_gemm_p2b relays into BL(128) (functional.ResRNNBlkFn; lstm_cluster2.hip); the fp32 pre-activations exist
@@ -506,6 +507,9 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             if kind == "pair":
                 ppack = _empty(d, L.LSTM_PACK_FLOATS)
                 dev.lstm_pack_pair(whf, whr, ppack, f16=F0.pair_rfmt(gfmt))     # (rfmt 1 / 2: fp16 hi, fp16 / FP8 lo of 256 w)
+            elif kind == "stream" and F0.band_rfmt(gfmt, lmode):                # the streaming BPTT's rfmt 2 pack (round 6 default)
+                ppack = _empty(d, L.LSTM_PACK_FLOATS)
+                dev.lstm_pack_bwd_f8(whf, whr, ppack)
             bw_packs = (wlt_pack, wct_pack, ppack)
         ctx.bw_packs = bw_packs
         ctx.save_for_backward(gates, cbuf, hcat, xn16 if a16 else xn, wcat, pack_b, lw, whf, whr, hcat16)
@@ -565,8 +569,9 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, lmode)
         else:
             dg = _empty(d, nb, 32 * 2 * G4) if gfmt == L.GATES_H2S else gates
-            dev.lstm_bwd(gates, cbuf, hcat, dh, pack_b, seq, lmode, gfmt=gfmt, dgates=dg if gfmt == L.GATES_H2S else None,
-                         amax=amax)
+            brf = F0.band_rfmt(gfmt, lmode) if ppack is not None else 0
+            dev.lstm_bwd(gates, cbuf, hcat, dh, ppack if brf else pack_b, seq, lmode, gfmt=gfmt,
+                         dgates=dg if gfmt == L.GATES_H2S else None, amax=amax, rfmt=brf)
         if ready is not None:
             F0.flush_deferred_wgrads(d, ready)
         order = (0, 4, 2, 6, 1, 5, 8, 9)       # _weight_grads' list -> this node's weight arguments
