@@ -167,6 +167,9 @@ def test_baseline_config2_film_multifuse_r16_vs_oracle():
     assert per[worst_k] < GRAD_TOL_FULL, (worst_k, per[worst_k])      # measured 3.3e-4 (rounds 5-6)
 
 
+@pytest.mark.skipif(os.environ.get("WESEP_RUN_SLOW", "0") != "1",
+                    reason="eight minutes of host time for the oracle's 32 rows (474 s of the suite's 881 on the GPU box): "
+                           "WESEP_RUN_SLOW=1 runs it; its last run is profiles/r06_headline_r32_vs_oracle.log")
 def test_headline_batch_r32_vs_oracle():
     """The size bench.py runs -- R = 32 rows x 4 s, FiLM multi-fuse, 6 repeats -- against the oracle (the
     largest size held against it was R = 16).  Rows never interact in the separator and the loss is the batch mean, so the

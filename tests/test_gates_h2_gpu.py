@@ -445,6 +445,7 @@ def test_resrnn_formats_agree(view, fmt, monkeypatch):
     def run(f, c2):
         monkeypatch.setenv("WESEP_GATES", f)
         monkeypatch.setenv("WESEP_LSTM_CLUSTER2", c2)
+        monkeypatch.setenv("WESEP_FUSED_H16", c2)      # (the band view's counterpart since round 6: fp16 h in the fused forward)
         for p in blk.parameters():
             p.grad = None
         dev.bump_weight_epoch()
@@ -460,9 +461,10 @@ def test_resrnn_formats_agree(view, fmt, monkeypatch):
     assert rel(b[1], a[1]) <= tol
     for k in a[2]:
         assert rel(b[2][k], a[2][k]) <= tol, k
-    if view == "time" and fmt != "f32":
-        # round 5: the 2-byte formats' time view runs ws_lstm_fwd_cluster2 by default -- fp16 h in the recurrent product changes
-        # the forward arithmetic itself (2^-12 on h), so bit-equality becomes a tolerance; everything else as above
+    if fmt != "f32":
+        # rounds 5 / 6: the 2-byte formats run fp16 h in the recurrent product of the forward by default (time view:
+        # ws_lstm_fwd_cluster2; band view: ws_lstm_fused_args.hfmt = 1) -- that changes the forward arithmetic itself (2^-12 on
+        # h), so bit-equality becomes a tolerance; everything else as above
         c = run(fmt, "1")
         assert rel(c[0], a[0]) <= 5e-5, rel(c[0], a[0])
         assert rel(c[1], a[1]) <= tol + 2e-4
