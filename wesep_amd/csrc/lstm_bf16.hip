@@ -21,6 +21,8 @@
 //
 // Per step a 32-sequence workgroup needs 1 MB from L2 (~7.5 us at the per-CU L1 fill rate) against
 // ~5 us of MFMA: the kernel is L2-stream bound in the time view, by design -- see DESIGN.md.
+#include <stdlib.h>
+
 #include "lstm_bf16_common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -389,11 +391,19 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   __shared__ __attribute__((aligned(16))) __bf16 dgl[RF ? 1 : 2][SQ * DROW];  // [part][seq][gate col] 129 / 65 KB
   __shared__ __attribute__((aligned(16))) f32x4 xred[DX ? 8 * 2 * 64 : 1];    // DX: the half of each wave's partial d(xn) tile its partner stores, 16 KB
   if (p.run_if && *p.run_if == 0u) return;  // predicated fall-back launch (wesep_hip.h): uniform
-  const int d = blockIdx.y;
+  // grid (tiles, 2), or -- gridDim.y == 1, ws_band_dirmap() -- the two directions INTERLEAVED in one dimension in groups of
+  // eight workgroups: under round-robin dispatch every XCD then serves both directions' weight streams at any time, instead of all
+  // 256 CUs pulling the same fragments of ONE direction through the same L2 channels in near lock-step
+  int d = blockIdx.y, bx = blockIdx.x;
+  if (gridDim.y == 1) {
+    d = ((int)blockIdx.x >> 3) & 1;
+    bx = (((int)blockIdx.x >> 4) << 3) | ((int)blockIdx.x & 7);
+    if (bx * SQ >= p.nseq) return;   // (uniform; the grid is rounded up to whole groups of 16)
+  }
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = p.L;
-  const int ss = min((int)blockIdx.x * SQ + l31, p.nseq - 1);  // plain: padded lanes duplicate the last sequence
+  const int ss = min(bx * SQ + l31, p.nseq - 1);  // plain: padded lanes duplicate the last sequence
   const long long rowbase =
       BLK ? 0 : (long long)(ss / p.sq_div) * p.sq_s1 + (long long)(ss % p.sq_div) * p.sq_s2;
   const int ubase = 32 * w + 4 * half;
@@ -406,13 +416,13 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
     return (rowbase + (long long)t * p.step_rows) * (2 * LH) + d * LH + ubase + 8 * j;
   };
   float* gdst = GF == WS_GATES_H2S ? p.dgates : p.gates;
-  auto grs = [&](int t) { return mkrsrc(gdst + (long long)(blockIdx.x * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
-  auto hrs = [&](int t) { return mkrsrc(p.gates + (long long)(blockIdx.x * L + t) * (SQ * LG), SQ * 2 * LG * 2); };  // BLH
+  auto grs = [&](int t) { return mkrsrc(gdst + (long long)(bx * L + t) * (SQ * 2 * LG), SQ * 2 * LG * 4); };
+  auto hrs = [&](int t) { return mkrsrc(p.gates + (long long)(bx * L + t) * (SQ * LG), SQ * 2 * LG * 2); };  // BLH
   constexpr bool G2 = GF == WS_GATES_H2 || GF == WS_GATES_H2F;  // 2-byte d(gates): bf16, or fp16 scaled by dS
   float* hdst = (G2 && p.dgates) ? p.dgates : p.gates;
-  auto ors = [&](int t) { return mkrsrc(hdst + (long long)(blockIdx.x * L + t) * (SQ * LG), SQ * 2 * LG * 2); };     // BLH out
+  auto ors = [&](int t) { return mkrsrc(hdst + (long long)(bx * L + t) * (SQ * LG), SQ * 2 * LG * 2); };     // BLH out
   const float dS = GF == WS_GATES_H2F ? ws_dgates_scale(*p.amax) : 1.f;
-  auto crs = [&](const float* b, int t) { return mkrsrc(b + (long long)(blockIdx.x * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
+  auto crs = [&](const float* b, int t) { return mkrsrc(b + (long long)(bx * L + t) * (SQ * 2 * LH), SQ * 2 * LH * 4); };
   typedef typename gate_cell<GF>::type gcell;
   auto ld_gate = [&](int t, int g, int j) -> gcell {
     if constexpr (GF != 0) return bld8(hrs(t), glane >> 1, (g * 64 + 2 * j) * 256);
@@ -488,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   // (the buffer is < 2 GB: lstm_check): the hardware drops the store
   unsigned xoff = 0u;
   if constexpr (DX) {
-    const int sq = (int)blockIdx.x * SQ + l31;
+    const int sq = bx * SQ + l31;
     const long long row = (long long)(sq / p.sq_div) * p.sq_s1 + (long long)(sq % p.sq_div) * p.sq_s2;
     // (this wave stores the rows j = 2 kpar, 2 kpar + 1 of the tile: inputs 32 mt + 16 kpar + 8 i + 4 half .. + 3, i = 0, 1)
     xoff = sq < p.nseq ? (unsigned)(row * 512 + (32 * (w & 3) + 16 * kpar + 4 * half) * 4) : 0x80000000u;   // (+ t * step_rows * 512 < 2^31)
@@ -720,8 +730,17 @@ int ws_launch_lstm_fwd_bf16(const ws_lstm_args* a, hipStream_t s) {
   return 0;
 }
 
+// WS_BAND_DIRMAP (default 1 once measured; 0: the (tiles, 2) grid): the blocked streaming kernels' two directions interleaved
+// in one grid dimension -- see lstm_bwd_bf16_kernel
+bool ws_band_dirmap() {
+  static const int v = [] { const char* e = getenv("WS_BAND_DIRMAP"); return e ? atoi(e) : 0; }();
+  return v != 0;
+}
+
 int ws_launch_lstm_bwd_bf16(const ws_lstm_args* a, hipStream_t s) {
   dim3 grid((a->nseq + SQ - 1) / SQ, 2), block(512);
+  if (ws_band_dirmap() && (a->mode & 255) == WS_LSTM_BF16X3_BLK && a->gfmt == WS_GATES_H2F && a->rfmt == 2)
+    grid = dim3(16 * ((grid.x + 7) / 8), 1);
   if (a->rfmt == 2 && a->dxn) {   // (lstm_check: rfmt 2, wxpack and a sequence map given)
     hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2, true>), grid, block, 0, s, *a);
     return 0;

@@ -439,11 +439,13 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         gfmt = L.GATES_F32 if kind == "cluster" else dev.gates_fmt()
         h2 = gfmt != L.GATES_F32
         gates = _empty(d, dev.blh_floats(nb, 2 * G4)) if h2 else _empty(d, nb, 32 * 2 * G4)
-        # fp16 copies of [xn | h] for the weight-gradient GEMMs (functional.ResRNNBlkFn; ws_gemm_tnb a_fmt = 1, ABI v16): opt-in
-        # here (WESEP_TFG_TNB_A16=1) -- these GEMMs already hide under the inter-frame BPTTs, so the faster kernel buys 2 % of
-        # the step (304.3 vs 310.0 ms, same box) for 8 GB more saved state (125 vs 117 GB at 8 rows x 6 s)
+        # fp16 copies of [xn | h] for the weight-gradient GEMMs (functional.ResRNNBlkFn; ws_gemm_tnb a_fmt = 1, ABI v16): the default
+        # since round 6 (WESEP_TFG_TNB_A16=0 turns it off).  Round 5 left it opt-in -- "these GEMMs already hide under the
+        # inter-frame BPTTs": 304.3 vs 310.0 ms for 8 GB more saved state -- but hidden work is not free work on this chip
+        # (profiles/r06_side_stream_tax.md: the clock follows the load): one MFMA per product instead of three on the side stream
+        # is 263.6 -> 248.7 ms per step at config 5's per-GPU shape (two runs each, one box), 123 -> 131 GB
         a16 = gfmt == L.GATES_H2F and any(ctx.needs_input_grad) and F0.tnb_a16() and \
-            os.environ.get("WESEP_TFG_TNB_A16", "0") == "1"
+            os.environ.get("WESEP_TFG_TNB_A16", "1") != "0"
         xn16 = _empty(d, dev.blh_floats(nb, N)) if a16 else None
         hcat16 = _empty(d, dev.blh_floats(nb, 2 * H)) if a16 else None
         if dev.lstm_fuse_ok(ns, cluster):
