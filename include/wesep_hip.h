@@ -800,6 +800,25 @@ typedef struct ws_conv3x3_args {
   int B, H, Wd, Cin, Cout, pad_;
 } ws_conv3x3_args;
 int ws_conv3x3(const ws_conv3x3_args* a, void* stream);
+/* ABI v19: the packed weights of ws_conv3x3 in ONE launch from up to WS_C3_NSRC strided views of weight tensors -- the logical
+ * W[n][tap][c] (n < Cout rows, c < Cin columns, zero-padded to the fragment grid) takes column c from the source k whose range
+ * [col_off, col_off + cols) holds it:  W = w_k[n * s_row + (c - col_off) * s_col + (flip ? 8 - tap : tap) * s_tap].
+ * A layer's forward: one source, nn.Conv2d weight [co][ci][3][3] -> (s_row, s_col, s_tap) = (9 Ci, 9, 1), flip 0.  The input
+ * gradient of a channel block [lo, hi) of a dense block (convs.py:80-112): sources = the weights of the layers that read the
+ * block, pointers advanced to input channel lo, rows = the block's channels (s_row = 9), columns = the layers' output channels
+ * side by side (s_col = 9 Ci_k), flip 1.  out: ceil(Cin / 16) * 9 * NTP * 2 * 64 * 8 bf16 (= half as many floats).        */
+#define WS_C3_NSRC 5
+typedef struct ws_conv3x3_pack_src {
+  const float* w;
+  long long s_row, s_col, s_tap;
+  int col_off, cols;
+} ws_conv3x3_pack_src;
+typedef struct ws_conv3x3_pack_args {
+  ws_conv3x3_pack_src src[WS_C3_NSRC];
+  float* out;
+  int Cin, Cout, nsrc, flip;
+} ws_conv3x3_pack_args;
+int ws_conv3x3_pack(const ws_conv3x3_pack_args* a, void* stream);
 /* Weight (and bias) gradient of a 3 x 3 convolution with padding 1, stride 1 along h and sw = 1 or 2 along w, one pass
  * over the image (conv3x3.hip; replaces ws_conv_wgrad / the implicit TN GEMM for these shapes: the dense blocks, the
  * (1, 2)-strided encoder convolutions and -- with image = dy, G = x -- the decoder's transposed convolutions of

@@ -442,6 +442,17 @@ def conv3x3_pack(W2, Cin, Cout):
     return W2.reshape(Cout, 9 * Cin).contiguous()       # the emulation keeps the plain rows
 
 
+def conv3x3_pack_srcs(srcs, Cin, Cout, flip=False):
+    """ws_conv3x3_pack: W[n][tap][c] = w_k.flat[off + n * s_row + (c - col_off) * s_col + (8 - tap if flip else tap) * s_tap]."""
+    W = torch.zeros(Cout, 9, Cin)
+    n = torch.arange(Cout).view(-1, 1, 1)
+    tap = torch.arange(9).view(1, -1, 1)
+    for w, off, s_row, s_col, s_tap, col_off, cols in srcs:
+        c = torch.arange(cols).view(1, 1, -1)
+        W[:, :, col_off:col_off + cols] = w.reshape(-1)[off + n * s_row + c * s_col + ((8 - tap) if flip else tap) * s_tap]
+    return W.reshape(Cout, 9 * Cin).contiguous()
+
+
 def conv3x3(*, X, ldx, W, ldw, B, H, Wd, Cin, Cout, Y, ldy, bias=None, R=None, x_off=0, y_off=0):
     M = B * H * Wd
     img = X.reshape(-1)[:M * ldx].reshape(B, H, Wd, ldx)[..., x_off:x_off + Cin].permute(0, 3, 1, 2)
@@ -757,7 +768,7 @@ EMULATED = [seg_sums, seg_scale, astp_fwd, astp_bwd, rowbias_act_fwd, act_bwd, c
             scale_bf_fwd, scale_bf_bwd, preemph_pad, ola_fwd, ola_bwd, total_sum, lstm_pack, lstm_fwd, lstm_bwd,
             group_stats, flat_stats, gn_bwd_reduce, norm_ab, norm_bwd_apply_cl, prelu_fwd, prelu_bwd, softmax_rows_fwd,
             softmax_rows_bwd, maskmul_fwd, maskmul_bwd, relu_mask, bn_stats, bn_prelu_fwd, bn_bwd, maxpool3_fwd, maxpool3_bwd,
-            bcast_rows, cross_entropy, im2col, col2im, tstp_fwd, tstp_bwd, power_spec, log_eps, rowln_ok, rowln_fwd, rowln_bwd, in_act_fwd, in_act_bwd, conv3x3, conv3x3_pack, conv3x3_wgrad, conv3x3_wgrad_tiles, heads_ok, heads_fwd, heads_bwd]
+            bcast_rows, cross_entropy, im2col, col2im, tstp_fwd, tstp_bwd, power_spec, log_eps, rowln_ok, rowln_fwd, rowln_bwd, in_act_fwd, in_act_bwd, conv3x3, conv3x3_pack, conv3x3_pack_srcs, conv3x3_wgrad, conv3x3_wgrad_tiles, heads_ok, heads_fwd, heads_bwd]
 
 
 def install(monkeypatch):

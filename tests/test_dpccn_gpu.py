@@ -373,3 +373,33 @@ def test_fused_elu_instancenorm_on_a_column_range():
     assert torch.equal(dx, dx2)
     with pytest.raises(dev.L.WesepHipError):
         dev.in_act_fwd(x, G, P, C, dev.IN_ELU_PRE, wide, y_ld=ld, y_off=ld - 8)
+
+
+@pytest.mark.parametrize("C0,g,Co5", [(16, 16, 16), (4, 16, 32), (32, 16, 64)])
+def test_conv3x3_weight_pack_kernel_equals_the_composed_pack(C0, g, Co5):
+    """ws_conv3x3_pack (ABI v19): the packed weights of ws_conv3x3 in one launch from strided views of the weight tensors -- bit
+    for bit what dev.conv3x3_pack composes from torch ops, for a dense block's five forward layers ([co][ci][3][3] read in
+    place) and for the input-gradient packs of its channel blocks (rows = a block's input channels, columns = the later layers'
+    output channels side by side, taps flipped: convs.py:80-112)."""
+    from wesep_amd import dev
+    d = _cuda()
+    gen = torch.Generator().manual_seed(C0 + Co5)
+    ws = [torch.randn(g if i < 4 else Co5, C0 + i * g, 3, 3, generator=gen).to(d) for i in range(5)]
+    for i, w in enumerate(ws):
+        Co, Ci = w.shape[0], w.shape[1]
+        want = dev.conv3x3_pack(w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci), Ci, Co)
+        got = dev.conv3x3_pack_srcs([(w, 0, 9 * Ci, 9, 1, 0, Ci)], Ci, Co)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), i
+    wflip = [w.flip(2, 3).permute(1, 2, 3, 0) for w in ws]
+    Dtot = 4 * g + Co5
+    for i in range(5):
+        lo, hi = (0, C0) if i == 0 else (C0 + (i - 1) * g, C0 + i * g)
+        cin = Dtot - i * g
+        Wb = torch.cat([wflip[k][lo:hi] for k in range(i, 5)], 3).reshape(hi - lo, 9 * cin)
+        want = dev.conv3x3_pack(Wb, cin, hi - lo)
+        srcs, off = [], 0
+        for k in range(i, 5):
+            srcs.append((ws[k], lo * 9, 9, 9 * (C0 + k * g), 1, off, ws[k].shape[0]))
+            off += ws[k].shape[0]
+        got = dev.conv3x3_pack_srcs(srcs, cin, hi - lo, flip=True)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), ("dx", i)

@@ -42,6 +42,14 @@ class ConvView(C.Structure):
     _fields_ = [(n, _i) for n in ("on", "mode", "H", "W", "C", "Ho", "Wo", "k", "sh", "sw", "p", "dil", "ldp")]
 
 
+class Conv3x3PackSrc(C.Structure):
+    _fields_ = [("w", _p), ("s_row", _ll), ("s_col", _ll), ("s_tap", _ll), ("col_off", _i), ("cols", _i)]
+
+
+class Conv3x3PackArgs(C.Structure):                                                                  # ABI v19
+    _fields_ = [("src", Conv3x3PackSrc * 5), ("out", _p), ("Cin", _i), ("Cout", _i), ("nsrc", _i), ("flip", _i)]
+
+
 class Conv3x3Args(C.Structure):
     _fields_ = [(n, _p) for n in ("X", "W", "bias", "R", "Y")] + [(n, _ll) for n in ("ldx", "ldw", "ldy")] + \
                [(n, _i) for n in ("B", "H", "Wd", "Cin", "Cout", "pad_")]
@@ -252,6 +260,7 @@ _SIGS = {
     "ws_heads_fwd": (_i, [C.POINTER(HeadsArgs), _p]),
     "ws_heads_bwd": (_i, [C.POINTER(HeadsArgs), _p]),
     "ws_conv3x3": (_i, [C.POINTER(Conv3x3Args), _p]),
+    "ws_conv3x3_pack": (_i, [C.POINTER(Conv3x3PackArgs), _p]),
     "ws_conv3x3_wgrad": (_i, [C.POINTER(Conv3x3WgradArgs), _p]),
     "ws_in_act_sums": (_i, [_p, _p, _ll, _p, _i, _i, _i, _i, _i, _p, _p]),
     "ws_in_act_apply": (_i, [_p, _p, _ll, _i, _i, _i, _p, _ll, _p]),

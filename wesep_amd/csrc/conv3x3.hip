@@ -206,6 +206,54 @@ extern "C" int ws_conv3x3(const ws_conv3x3_args* a, void* stream) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// weight pack (round 6): the fragment order above, written by ONE launch from up to WS_C3_NSRC strided views of weight tensors
+// (dev.conv3x3_pack composed it from ~9 ATen launches -- zeros, slice copy, two casts, a subtraction, a cast, stack, permute --
+// per layer and pass: ~1 400 of DPCCN's launches per step).  Row n of the logical W[n][tap][c], column c in source k's range:
+//   W = src_k.w[n * s_row + (c - col_off) * s_col + (flip ? 8 - tap : tap) * s_tap]
+// forward of a layer: one source, w[co][ci][3][3] -> (s_row, s_col, s_tap) = (9 Ci, 9, 1); input gradient of a channel block
+// of a dense block: sources = the later layers' weights, rows = the block's input channels, columns = their output channels
+// side by side, taps flipped.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3x3_pack_kernel(const ws_conv3x3_pack_args p) {
+  const int ntt = (p.Cout + 31) / 32, ntp = ntt <= 2 ? ntt : ntt + (ntt & 1), nch = (p.Cin + C3_CC - 1) / C3_CC;
+  const long long total = (long long)nch * 9 * ntp * 64 * 8;      // elements per part
+  __bf16* out = reinterpret_cast<__bf16*>(p.out);
+  for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += gridDim.x * 256LL) {
+    long long r = idx;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    const int t = (int)(r % ntp); r /= ntp;
+    const int tap = (int)(r % 9);
+    const int chunk = (int)(r / 9);
+    const int n = t * 32 + (lane & 31), c = chunk * C3_CC + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (n < p.Cout && c < p.Cin) {
+#pragma unroll
+      for (int k = 0; k < WS_C3_NSRC; ++k)
+        if (k < p.nsrc && c >= p.src[k].col_off && c < p.src[k].col_off + p.src[k].cols)
+          v = p.src[k].w[(long long)n * p.src[k].s_row + (long long)(c - p.src[k].col_off) * p.src[k].s_col +
+                         (long long)(p.flip ? 8 - tap : tap) * p.src[k].s_tap];
+    }
+    const __bf16 hi = (__bf16)v;
+    const long long unit = (((long long)(chunk * 9 + tap) * ntp + t) * 2) * 64 + lane;
+    out[unit * 8 + j] = hi;
+    out[(unit + 64) * 8 + j] = (__bf16)(v - (float)hi);
+  }
+}
+
+extern "C" int ws_conv3x3_pack(const ws_conv3x3_pack_args* a, void* stream) {
+  WS_REQUIRE(a && a->out && a->Cin > 0 && a->Cout > 0 && a->nsrc > 0 && a->nsrc <= WS_C3_NSRC, "ws_conv3x3_pack: bad arguments");
+  for (int k = 0; k < a->nsrc; ++k)
+    WS_REQUIRE(a->src[k].w && a->src[k].cols > 0 && a->src[k].col_off >= 0 && a->src[k].col_off + a->src[k].cols <= a->Cin,
+               "ws_conv3x3_pack: source %d does not lie inside the %d columns", k, a->Cin);
+  const int ntt = (a->Cout + 31) / 32, ntp = ntt <= 2 ? ntt : ntt + (ntt & 1), nch = (a->Cin + C3_CC - 1) / C3_CC;
+  const long long total = (long long)nch * 9 * ntp * 64 * 8;
+  const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(conv3x3_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  return ws_check_launch("ws_conv3x3_pack");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------------------------------
 #define W3_TH 30                  // output rows per tile: their 3 x 3 windows span 32 halo rows = the MFMA K of two steps

@@ -391,15 +391,10 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   __shared__ __attribute__((aligned(16))) __bf16 dgl[RF ? 1 : 2][SQ * DROW];  // [part][seq][gate col] 129 / 65 KB
   __shared__ __attribute__((aligned(16))) f32x4 xred[DX ? 8 * 2 * 64 : 1];    // DX: the half of each wave's partial d(xn) tile its partner stores, 16 KB
   if (p.run_if && *p.run_if == 0u) return;  // predicated fall-back launch (wesep_hip.h): uniform
-  // grid (tiles, 2), or -- gridDim.y == 1, ws_band_dirmap() -- the two directions INTERLEAVED in one dimension in groups of
-  // eight workgroups: under round-robin dispatch every XCD then serves both directions' weight streams at any time, instead of all
-  // 256 CUs pulling the same fragments of ONE direction through the same L2 channels in near lock-step
-  int d = blockIdx.y, bx = blockIdx.x;
-  if (gridDim.y == 1) {
-    d = ((int)blockIdx.x >> 3) & 1;
-    bx = (((int)blockIdx.x >> 4) << 3) | ((int)blockIdx.x & 7);
-    if (bx * SQ >= p.nseq) return;   // (uniform; the grid is rounded up to whole groups of 16)
-  }
+  // (round 6 tried the two directions interleaved in one grid dimension, so that every XCD serves both weight streams at any
+  //  time instead of all 256 CUs pulling ONE direction's fragments in near lock-step: no difference, 2.03 vs 2.02 ms --
+  //  profiles/r06_c9_band_probe_dm{0,1}.txt; the L2 -> CU stream bound is not a hot spot of that kind)
+  const int d = blockIdx.y, bx = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = p.L;
@@ -730,17 +725,8 @@ int ws_launch_lstm_fwd_bf16(const ws_lstm_args* a, hipStream_t s) {
   return 0;
 }
 
-// WS_BAND_DIRMAP (default 1 once measured; 0: the (tiles, 2) grid): the blocked streaming kernels' two directions interleaved
-// in one grid dimension -- see lstm_bwd_bf16_kernel
-bool ws_band_dirmap() {
-  static const int v = [] { const char* e = getenv("WS_BAND_DIRMAP"); return e ? atoi(e) : 0; }();
-  return v != 0;
-}
-
 int ws_launch_lstm_bwd_bf16(const ws_lstm_args* a, hipStream_t s) {
   dim3 grid((a->nseq + SQ - 1) / SQ, 2), block(512);
-  if (ws_band_dirmap() && (a->mode & 255) == WS_LSTM_BF16X3_BLK && a->gfmt == WS_GATES_H2F && a->rfmt == 2)
-    grid = dim3(16 * ((grid.x + 7) / 8), 1);
   if (a->rfmt == 2 && a->dxn) {   // (lstm_check: rfmt 2, wxpack and a sequence map given)
     hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2, true>), grid, block, 0, s, *a);
     return 0;

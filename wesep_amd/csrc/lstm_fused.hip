@@ -282,17 +282,12 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
   auto& hl = sm.hl;
   auto& c0l = sm.c0l;
   auto& bs = sm.bs;
-  const int ntile = (p.nseq + SQ - 1) / SQ;
-  int d = blockIdx.y, bx = blockIdx.x;
-  if (gridDim.y == 1) {   // the two directions interleaved in groups of eight workgroups (lstm_bf16.hip ws_band_dirmap)
-    d = ((int)blockIdx.x >> 3) & 1;
-    bx = (((int)blockIdx.x >> 4) << 3) | ((int)blockIdx.x & 7);
-    if (2 * bx >= ntile) return;
-  }
+  const int d = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = p.L;
-  const int tile0 = 2 * bx;
+  const int ntile = (p.nseq + SQ - 1) / SQ;
+  const int tile0 = 2 * blockIdx.x;
   // an odd tile count leaves the last workgroup's second tile empty: zero-sized descriptors (loads 0, stores dropped)
   const unsigned live1 = tile0 + 1 < ntile ? 1u : 0u;
 
@@ -476,8 +471,6 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h16_kernel(const ws_ls
   lstm_fwd_fused64_body<WS_GATES_H2, false, true>(p);
 }
 
-bool ws_band_dirmap();   // lstm_bf16.hip
-
 extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn && a->wpack && a->bias, "ws_lstm_fwd_fused: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_fwd_fused: bad nseq/L");
@@ -499,8 +492,7 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
   const char* w1 = getenv("WS_FUSED_W1");   // measurement only: one weight plane (bf16 weights), see lstm_fwd_fused64_body
   if ((a->hfmt & 1) && wide)
-    hipLaunchKernelGGL(lstm_fwd_fused64h16_kernel, ws_band_dirmap() ? dim3(16 * (((ntile + 1) / 2 + 7) / 8), 1) : dim3((ntile + 1) / 2, 2),
-                       block, 0, s, *a);
+    hipLaunchKernelGGL(lstm_fwd_fused64h16_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
   else if (a->hfmt & 1)
     hipLaunchKernelGGL((lstm_fwd_fused_kernel<WS_GATES_H2, true>), grid, block, 0, s, *a);
   else if (wide && a->gfmt && w1 && atoi(w1) == 1)

@@ -1400,6 +1400,30 @@ def conv3x3_pack(W2, Cin: int, Cout: int):
     return both.permute(4, 3, 1, 0, 5, 2, 6).contiguous().view(torch.float32).reshape(-1)
 
 
+def conv3x3_pack_floats(Cin: int, Cout: int) -> int:
+    ntt, nch = -(-Cout // 32), -(-Cin // 16)
+    ntp = ntt if ntt <= 2 else ntt + (ntt & 1)
+    return nch * 9 * ntp * 2 * 64 * 8 // 2
+
+
+def conv3x3_pack_srcs(srcs, Cin: int, Cout: int, flip: bool = False):
+    """The packed weights of conv3x3 in ONE launch (ws_conv3x3_pack, ABI v19).  srcs: up to five (w, elem_off, s_row, s_col,
+    s_tap, col_off, cols) -- column c of the logical W[n][tap][c] comes from the source whose [col_off, col_off + cols) holds it:
+    w.flat[elem_off + n * s_row + (c - col_off) * s_col + (8 - tap if flip else tap) * s_tap].  Replaces conv3x3_pack's ATen
+    composition (zeros, slice copy, casts, stack, permute: ~9 launches per pack)."""
+    if not 0 < len(srcs) <= 5:
+        raise L.WesepHipError("conv3x3_pack_srcs: 1 .. 5 sources")
+    out = torch.empty(conv3x3_pack_floats(Cin, Cout), device=srcs[0][0].device, dtype=torch.float32)
+    a = L.Conv3x3PackArgs()
+    for k, (w, off, s_row, s_col, s_tap, col_off, cols) in enumerate(srcs):
+        _chk(w, "conv3x3_pack_srcs w")
+        a.src[k].w = _p(w, off)
+        a.src[k].s_row, a.src[k].s_col, a.src[k].s_tap, a.src[k].col_off, a.src[k].cols = s_row, s_col, s_tap, col_off, cols
+    a.out, a.Cin, a.Cout, a.nsrc, a.flip = _p(out), Cin, Cout, len(srcs), int(flip)
+    L.check(L.lib().ws_conv3x3_pack(C.byref(a), L.stream_ptr()), "ws_conv3x3_pack")
+    return out
+
+
 def conv3x3(*, X, ldx: int, W, ldw: int, B: int, H: int, Wd: int, Cin: int, Cout: int, Y, ldy: int, bias=None, R=None,
             x_off: int = 0, y_off: int = 0):
     """3 x 3 / stride 1 / padding 1 convolution through an LDS halo tile (conv3x3.hip); Y = bias + R + conv(X); W = the

@@ -244,7 +244,8 @@ class DenseBlockFn(torch.autograd.Function):
         saved, out = [], None
         for i in range(5):
             Ci, Co = C0 + i * g, ws[i].shape[0]
-            W2 = dev.conv3x3_pack(ws[i].permute(0, 2, 3, 1).reshape(Co, 9 * Ci), Ci, Co)    # [co][(ky*3 + kx)*Ci + ci]
+            # the packed [co][(ky*3 + kx)*Ci + ci] weights straight from the [co][ci][3][3] tensor: one launch
+            W2 = dev.conv3x3_pack_srcs([(ws[i].contiguous(), 0, 9 * Ci, 9, 1, 0, Ci)], Ci, Co)
             pre = _empty(d, M, Co)
             dev.conv3x3(X=big, ldx=Ctot, W=W2, ldw=9 * Ci, B=B, H=H, Wd=W, Cin=Ci, Cout=Co, Y=pre, ldy=Co, bias=bs[i])
             if i < 4:                    # the layer's output IS the next g columns of the map
@@ -268,7 +269,6 @@ class DenseBlockFn(torch.autograd.Function):
         dbig = _empty(d, M, Ctot)           # every column block is written exactly once below
         dpre = _empty(d, M, Dtot)
         # input gradient = the correlation of d(pre) with the flipped kernel: [ci][ky][kx][co] = w[co][ci][2 - ky][2 - kx]
-        wflip = [w.flip(2, 3).permute(1, 2, 3, 0) for w in ws]
         grads = [None] * 10
         for i in range(4, -1, -1):
             pre, st = saved[2 * i:2 * i + 2]
@@ -294,9 +294,15 @@ class DenseBlockFn(torch.autograd.Function):
             if i == 0 and not ctx.needs_input_grad[0]:
                 break
             cin = Dtot - i * g
-            Wb = torch.cat([wflip[k][lo:hi] for k in range(i, 5)], 3).reshape(hi - lo, 9 * cin)
-            dev.conv3x3(X=dpre, ldx=Dtot, x_off=i * g, W=dev.conv3x3_pack(Wb, cin, hi - lo), ldw=9 * cin, B=B, H=H, Wd=W,
-                        Cin=cin, Cout=hi - lo, Y=dbig, ldy=Ctot, y_off=lo)
+            # rows = the block's input channels lo .. hi, columns = the output channels of layers i .. 4 side by side, taps
+            # flipped: [c][ky][kx][co] = w_k[co][lo + c][2 - ky][2 - kx] -- one pack launch from the five weight tensors
+            srcs, off = [], 0
+            for k in range(i, 5):
+                Ck, Cok = C0 + k * g, wshapes[k][0]
+                srcs.append((ws[k].contiguous(), lo * 9, 9, 9 * Ck, 1, off, Cok))
+                off += Cok
+            dev.conv3x3(X=dpre, ldx=Dtot, x_off=i * g, W=dev.conv3x3_pack_srcs(srcs, cin, hi - lo, flip=True), ldw=9 * cin,
+                        B=B, H=H, Wd=W, Cin=cin, Cout=hi - lo, Y=dbig, ldy=Ctot, y_off=lo)
         dx = dbig[:, :C0].contiguous() if ctx.needs_input_grad[0] else None
         return (dx, None) + tuple(grads)
 
