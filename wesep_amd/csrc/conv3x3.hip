@@ -293,12 +293,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const ws_conv3x3_
   int x_cq[NXI], x_hc[NXI], x_hq[NXI];
 #pragma unroll
   for (int i = 0; i < NXI; ++i) {
+    // lane = (channel quad, row quad), halo column per wave / item: the eight channel quads of a pixel row are one 128-byte
+    // global run, and the transposing 8-byte LDS stores of a wave land on bank pairs 16 (cq & 3) + 2 hq (+ 20 e): 32 distinct
+    // pairs, two-way instead of the eight-way conflicts of the (cq, column, row quad) order of round 3 (round 6)
     const int it = tid + 256 * i;
     x_cq[i] = it & 7;
-    x_hc[i] = (it >> 3) % NCOL;
-    x_hq[i] = (it >> 3) / NCOL;
+    x_hq[i] = (it >> 3) & 7;
+    x_hc[i] = it >> 6;
   }
-  const int g_nq = tid & 7, g_col = (tid >> 3) & 3, g_hq = tid >> 5;
+  const int g_nq = tid & 7, g_hq = (tid >> 3) & 7, g_col = tid >> 6;   // (wave = column: see the X items)
 
   for (long long tile = t_begin; tile < t_end; ++tile) {
     const int cg = (int)(tile % ncg), rt = (int)((tile / ncg) % nrt), b = (int)(tile / ((long long)ncg * nrt));
@@ -468,12 +471,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad16_kernel(const ws_conv3x
   int x_cq[NXI], x_hc[NXI], x_hq[NXI];
 #pragma unroll
   for (int i = 0; i < NXI; ++i) {
+    // lane = (channel quad, row quad), halo column per wave / item: the eight channel quads of a pixel row are one 128-byte
+    // global run, and the transposing 8-byte LDS stores of a wave land on bank pairs 16 (cq & 3) + 2 hq (+ 20 e): 32 distinct
+    // pairs, two-way instead of the eight-way conflicts of the (cq, column, row quad) order of round 3 (round 6)
     const int it = tid + 256 * i;
     x_cq[i] = it & 7;
-    x_hc[i] = (it >> 3) % NCOL;
-    x_hq[i] = (it >> 3) / NCOL;
+    x_hq[i] = (it >> 3) & 7;
+    x_hc[i] = it >> 6;
   }
-  const int g_nq = tid & 3, g_col = (tid >> 2) & 3, g_hq = (tid >> 4) & 7;
+  const int g_nq = tid & 3, g_hq = (tid >> 2) & 7, g_col = (tid >> 5) & 3;   // (32 lanes = one column: conflict-free stores)
   const bool g_on = tid < 128;
 
   f32x4 xv[NXI][4], gv[4];
