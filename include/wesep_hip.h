@@ -710,8 +710,7 @@ typedef struct ws_lstm_fused_args {
                            product instead of three; the arithmetic of ws_lstm_fwd_cluster2) -- wpack from
                            ws_lstm_pack_fused_h16, 2-byte gate formats only.  Bit 1 (value
                            2, measurement): the 64-sequence kernels drain every store of a step before the next one starts
-                           (the wait of rounds 3-5).  Bit 2 (value 4, with bit 0; 64-sequence kernel): W_hh's lo plane as
-                           block-scaled FP8, wpack from ws_lstm_pack_fused_h16f8                                      */
+                           (the wait of rounds 3-5)                                                                   */
 } ws_lstm_fused_args;
 #define WS_LSTM_FUSED_PACK_FLOATS (2 * 8 * 24 * 4 * 2 * 64 * 4)
 int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
@@ -719,11 +718,6 @@ int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const float* whh_
 /* ABI v19: the pack of hfmt = 1 -- same size and unit order; both parts hold 256 w: W_ih as bf16 hi / lo, W_hh as fp16 hi / lo */
 int ws_lstm_pack_fused_h16(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
                            float* pack, void* stream);
-/* ABI v19: the pack of hfmt = 1 | 4 (same buffer; 16 regions of 160 KB + 64 B): the W_ih part as above, the W_hh part as fp16 hi
- * fragments + e4m3 codes of (256 w - hi) over a power-of-two scale per (direction, wave, group of four k-steps) -- the format of
- * ws_lstm_pack_bwd_f8; 160 instead of 192 KB streamed per wave and step.  |w| < 255.                                          */
-int ws_lstm_pack_fused_h16f8(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
-                             float* pack, void* stream);
 int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream);
 
 /* ---- wespeaker ResNet speaker encoder (third-party model, call sites

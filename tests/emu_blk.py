@@ -361,9 +361,7 @@ def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm, gfmt=0, hfmt=0):
         x = x.half().float()
     b = bias.reshape(2, G4)
     pre = torch.stack([x @ wih_f.t() + b[0], x @ wih_r.t() + b[1]], 2)
-    if hfmt & 4:                                        # (hfmt bit 2: W_hh at fp16 hi + FP8 lo)
-        whf, whr = _q8(whf), _q8(whr)
-    _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt, hq16=bool(hfmt & 1))     # (hfmt bit 0: fp16 h in the recurrent product)
+    _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt, hq16=bool(hfmt))     # (hfmt 1: fp16 h in the recurrent product)
 
 
 def gemm_tnb(*, G, g_width, g_off, g_cols, A0, a0_width, a0_off, a0_cols, nblk, L_, slab, nsplit, blocks_per_split,

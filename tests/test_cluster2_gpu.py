@@ -171,7 +171,7 @@ def test_fused_band_forward_fp16_h_vs_torch_lstm_and_three_term_kernel(dims, seq
     bias = torch.cat([w["bf"], w["br"]]).contiguous()
     xn = dev.to_blocked(x, seq, split=True)
     outs = {}
-    for hf in (0, 1, 1) + ((5, 5) if seqs == "64" else ()):     # (5 = fp16 h + FP8 lo plane of W_hh: the 64-sequence kernel)
+    for hf in (0, 1, 1):
         fp = torch.empty(L.LSTM_FUSED_PACK_FLOATS, device=d)
         dev.lstm_pack_fused(w["wih_f"], w["wih_r"], w["whh_f"], w["whh_r"], fp, hfmt=hf)
         gh = torch.zeros(dev.blh_floats(nb, 8 * H), device=d)
@@ -193,14 +193,12 @@ def test_fused_band_forward_fp16_h_vs_torch_lstm_and_three_term_kernel(dims, seq
         # band view: sequence (r, tf) walks the K bands; plain row (r * K + k) * Tf + tf
         out, _ = lstm(x.double().cpu().view(R, K, Tf, N).permute(0, 2, 1, 3).reshape(R * Tf, K, N))
     want = out.view(R, Tf, K, 2 * H).permute(0, 2, 1, 3).reshape(P, 2 * H)
-    for hf in sorted(outs):
+    for hf in (0, 1):
         gh, c, h = outs[hf]
         assert not torch.isnan(c).any() and not torch.isnan(h).any()
         err = rel(dev.from_blocked(h, seq, P, split=True), want)
         print(f"fused band forward {dims}, hfmt {hf}: h rel vs torch fp64 {err:.2e}")
         assert err < (1e-3 if hf else 1e-4), (hf, err)
-    if 5 in outs:     # FP8 lo plane next to the fp16 one: weights 2^-16 apart
-        assert rel(dev.bls_unpack(outs[5][2]), dev.bls_unpack(outs[1][2])) < 2e-4 and rel(outs[5][1], outs[1][1]) < 2e-4
     (g1, c1, h1), (g0, c0, h0) = outs[1], outs[0]
     assert rel(c1, c0) < 1e-3 and rel(dev.bls_unpack(h1), dev.bls_unpack(h0)) < 1e-3
     ga, gb = dev.blh_gates_unpack(g1, nb), dev.blh_gates_unpack(g0, nb)

@@ -44,7 +44,7 @@ def main():
     gh = torch.zeros(dev.blh_floats(nb, 8 * H), device=d)
     xn = dev.bls_pack(torch.randn(nb, N // 4, 32, 4, device=d))
     # ---- forward ---------------------------------------------------------------------------------------------------
-    for hf, nm in ((0, "three terms (bf16x3)"), (1, "fp16 h, two recurrent terms"), (5, "fp16 h, W_hh lo plane as FP8")):
+    for hf, nm in ((0, "three terms (bf16x3)"), (1, "fp16 h, two recurrent terms")):
         fp = torch.empty(L.LSTM_FUSED_PACK_FLOATS, device=d)
         dev.lstm_pack_fused(wif, wir, whf, whr, fp, hfmt=hf)
         for drain in ("1", "0"):

@@ -273,7 +273,6 @@ _SIGS = {
     "ws_log_eps": (_i, [_p, _ll, C.c_float, _p]),
     "ws_lstm_pack_fused": (_i, [_p, _p, _p, _p, _p, _p]),
     "ws_lstm_pack_fused_h16": (_i, [_p, _p, _p, _p, _p, _p]),
-    "ws_lstm_pack_fused_h16f8": (_i, [_p, _p, _p, _p, _p, _p]),
     "ws_lstm_fwd_fused": (_i, [C.POINTER(LstmFusedArgs), _p]),
     "ws_grad_norms": (_i, [_p, _i, _p, _p, _p]),
     "ws_clip_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p]),

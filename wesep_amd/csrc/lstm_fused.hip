@@ -66,79 +66,6 @@ extern "C" int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const 
   return ws_check_launch("ws_lstm_pack_fused");
 }
 
-// H16 + F8 (ws_lstm_fused_args.hfmt = 1 | 4, ABI v19): the W_hh part's lo plane as OCP e4m3 codes of (256 w - fp16 hi) over a
-// power-of-two scale per (direction, wave, group of four k-steps) -- the streaming BPTT's rfmt 2 format (lstm_pack_bwd_f8_kernel)
-// in the forward: 160 instead of 192 KB streamed per wave and step.  Per (d, w) region of WS_FUSED8_REGION bytes: the W_ih part
-// as in the H16 pack (8 k-steps x 8 KB: bf16 hi / lo of 256 w), then 16 k-steps x 6 KB = [4 gates' fp16 hi fragments of 1 KB:
-// lane * 16 bytes][4 gates' code fragments of 512 B: lane * 8 bytes], then four floats: the scale of each group of four k-steps.
-// One workgroup per (d, w, group): it needs the group's maximum first.
-#define WS_FUSED8_REGION (64 * 1024 + 96 * 1024 + 64)
-__global__ __launch_bounds__(512) void lstm_pack_fused8_kernel(const float* __restrict__ wih_f, const float* __restrict__ wih_r,
-                                                               const float* __restrict__ whh_f, const float* __restrict__ whh_r,
-                                                               char* __restrict__ pf) {
-  __shared__ float red[8];
-  const int grp = blockIdx.x & 3, w = (blockIdx.x >> 2) & 7, d = blockIdx.x >> 5;
-  char* ob = pf + (long long)(d * 8 + w) * WS_FUSED8_REGION;
-  const int tid = threadIdx.x;
-  // ---- W_ih part: two of the eight k-steps per workgroup of the (d, w) quartet, bf16 hi / lo of 256 w (the H16 pack's order)
-  {
-    const float* W = d ? wih_r : wih_f;
-    __bf16* px = reinterpret_cast<__bf16*>(ob);
-    for (int idx = tid; idx < 2 * 4 * 64 * 8; idx += 512) {
-      int r = idx;
-      const int j = r & 7; r >>= 3;
-      const int lane = r & 63; r >>= 6;
-      const int g = r & 3; r >>= 2;
-      const int ks = 2 * grp + r;
-      const float v = 256.f * W[(g * 256 + 32 * w + (lane & 31)) * 128 + 16 * ks + 8 * (lane >> 5) + j];
-      const __bf16 hi = (__bf16)v;
-      const long long unit = ((long long)(ks * 4 + g) * 2) * 64 + lane;
-      px[unit * 8 + j] = hi;
-      px[(unit + 64) * 8 + j] = (__bf16)(v - (float)hi);
-    }
-  }
-  // ---- W_hh part: the group's four k-steps x four gates x 64 lanes x 4 element pairs = 4096 pairs, 8 per thread
-  const float* W = d ? whh_r : whh_f;
-  float v0[8], v1[8], m = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, g = (pi >> 8) & 3, kk = 4 * grp + (pi >> 10);
-    const int row = g * 256 + 32 * w + (lane & 31), k = 16 * kk + 8 * (lane >> 5) + 2 * j2;
-    v0[i] = 256.f * W[row * LH + k];
-    v1[i] = 256.f * W[row * LH + k + 1];
-    m = fmaxf(m, fmaxf(fabsf(v0[i]), fabsf(v1[i])));
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((tid & 63) == 0) red[tid >> 6] = m;
-  __syncthreads();
-  m = red[0];
-#pragma unroll
-  for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i]);
-  const int eb = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
-  const float S = (eb > 19 && eb < 255) ? __builtin_bit_cast(float, (unsigned)(eb - 19) << 23) : 1.f;
-  if (tid == 0) reinterpret_cast<float*>(ob + 160 * 1024)[grp] = S;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, g = (pi >> 8) & 3, kk = 4 * grp + (pi >> 10);
-    const _Float16 h0 = (_Float16)v0[i], h1 = (_Float16)v1[i];
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    char* cb = ob + 64 * 1024 + kk * 6144;
-    *reinterpret_cast<f16x2*>(cb + g * 1024 + lane * 16 + j2 * 4) = f16x2{h0, h1};
-    const s16x2 c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(s16x2{0, 0}, v0[i] - (float)h0, v1[i] - (float)h1, S, false);
-    *reinterpret_cast<short*>(cb + 4096 + g * 512 + lane * 8 + j2 * 2) = c[0];
-  }
-}
-
-extern "C" int ws_lstm_pack_fused_h16f8(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
-                                        float* pack, void* stream) {
-  WS_REQUIRE(wih_f && wih_r && whh_f && whh_r && pack, "ws_lstm_pack_fused_h16f8: null pointer");
-  hipLaunchKernelGGL(lstm_pack_fused8_kernel, dim3(64), dim3(512), 0, (hipStream_t)stream, wih_f, wih_r, whh_f, whh_r,
-                     reinterpret_cast<char*>(pack));
-  return ws_check_launch("ws_lstm_pack_fused_h16f8");
-}
-
 extern "C" int ws_lstm_pack_fused_h16(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
                                       float* pack, void* stream) {
   WS_REQUIRE(wih_f && wih_r && whh_f && whh_r && pack, "ws_lstm_pack_fused_h16: null pointer");
@@ -347,13 +274,9 @@ struct fused64_lds {
 // wave and step); the x part keeps the full three-term split product on 256 W_ih, the accumulators carry 256 x the
 // pre-activation and the 2^-8 leaves in the activations' exponent scale.  The arithmetic ws_lstm_fwd_cluster2 runs in the time
 // view since round 5 (there the 60-step trajectory did not move with it; the fp16 INPUT did, which is why x keeps its pairs).
-// F8 (hfmt 1 | 4): W_hh's lo plane arrives as FP8 codes (lstm_pack_fused8_kernel) and becomes an fp16 fragment on the way into the
-// MFMA (v_cvt_scalef32_pk_f16_fp8 with the group's scale) -- the kernel is bound by the L2 -> CU weight stream (12-13 TB/s over
-// the chip, all of it L2 hits: profiles/r06_c12_band_l2_counters.txt), and this is a sixth less of it.
-template <int GF, bool W1 = false, bool H16 = false, bool F8 = false>
+template <int GF, bool W1 = false, bool H16 = false, bool ER = false>
 __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& p) {
   static_assert(!(W1 && H16), "W1 is a measurement build of the three-term kernel");
-  static_assert(!F8 || H16, "the FP8 lo plane belongs to the fp16 recurrent product");
   __shared__ __attribute__((aligned(16))) fused64_lds sm;
   auto& xw = sm.xw;
   auto& hl = sm.hl;
@@ -402,34 +325,14 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
   for (int j = 0; j < 4; ++j) c1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(p.wpack)) +
-          (long long)(d * 8 + w) * (F8 ? (long long)WS_FUSED8_REGION : (long long)FKS * 8 * 1024),
-      0, F8 ? WS_FUSED8_REGION : FKS * 8 * 1024, 0x00020000);
+      const_cast<float*>(p.wpack) + (long long)(d * 8 + w) * (FKS * 8 * 64 * 4), 0, FKS * 8 * 1024, 0x00020000);
   const int wlane = lane * 16;
   bf16x8 wr[2][8];
-  u32x2 wc[2][F8 ? 4 : 1];   // F8: the four gates' code fragments of a W_hh k-step (the slot's wr[.][4..7] are dead then)
-  float wS8[F8 ? 4 : 1];     // F8: scale per group of four W_hh k-steps (uniform)
-  // ring slot s <- k-step kn of the stream (compile-time kn: the W_ih k-steps are 8 KB, the F8 W_hh k-steps 6 KB)
-  auto wfill = [&](int s, int kn, int zo) {
-    if (F8 && kn >= 8) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        wr[s][g] = wload(wrs, wlane + g * 1024, zo + 65536 + (kn - 8) * 6144);
-        wc[s][g] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8 + g * 512, zo + 65536 + (kn - 8) * 6144 + 4096, 0));
-      }
-    } else {
+  for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int f = 0; f < 8; ++f)
-        if (!W1 || !(f & 1)) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
-    }
-  };
-  wfill(0, 0, 0);
-  wfill(1, 1, 0);
-  if constexpr (F8) {
-    const float* st = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wpack) + (long long)(d * 8 + w) * WS_FUSED8_REGION + 160 * 1024);
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) wS8[g4] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st[g4])));
-  }
+    for (int f = 0; f < 8; ++f)
+      if (!W1 || !(f & 1)) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
 
   const __bf16* hrow[2] = {&hl[0][l31 * HROW + 8 * half], &hl[0][(32 + l31) * HROW + 8 * half]};  // h_{t-1} rows of this lane
   auto tof = [&](int n) { const int m = min(n, L - 1); return d == 0 ? m : L - 1 - m; };
@@ -472,32 +375,40 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
           if (!H16) bl[e] = *reinterpret_cast<const bf16x8*>(hrow[e] + 2 * SQ * HROW + 16 * (ks - 8));
         }
       }
+      // Gate by gate, and each gate's two fragments REFILLED the moment its last MFMA has been issued (an MFMA reads its A
+      // operand at issue): rounds 3-5 refilled the slot's eight fragments behind all of the k-step's MFMAs, so a fragment
+      // requested at the end of k-step ks was due at the start of ks + 2 -- ONE k-step (0.5-0.7 us) of lead for an L2 hit that
+      // takes longer than that under this load, a stall in every k-step (the MFMA phase took 21 us for 13.6 us of MFMAs).
+      // Now every fragment has 1.75 k-steps.  (WS_FUSED_ER=0 / ER = false: the old order, for A/B.)
+      const int kn = (ks + 2) % FKS;
+      if constexpr (ER) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (H16 && ks >= 8) {   // fp16 W_hh (hi, lo of 256 w) x fp16 h: two terms
+            const f16x8 b0 = __builtin_bit_cast(f16x8, bh[0]), b1 = __builtin_bit_cast(f16x8, bh[1]);
+            acc[0][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g]), b0, acc[0][g]);
+            acc[1][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g]), b1, acc[1][g]);
+            acc[0][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g + 1]), b0, acc[0][g]);
+            acc[1][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g + 1]), b1, acc[1][g]);
+          } else {
+            acc[0][g] = mfma32(wr[s][2 * g], bh[0], acc[0][g]);
+            acc[1][g] = mfma32(wr[s][2 * g], bh[1], acc[1][g]);
+            if (!W1) {
+              acc[0][g] = mfma32(wr[s][2 * g + 1], bh[0], acc[0][g]);
+              acc[1][g] = mfma32(wr[s][2 * g + 1], bh[1], acc[1][g]);
+            }
+            acc[0][g] = mfma32(wr[s][2 * g], bl[0], acc[0][g]);
+            acc[1][g] = mfma32(wr[s][2 * g], bl[1], acc[1][g]);
+          }
+          wr[s][2 * g] = wload(wrs, wlane + ((2 * g) & 3) * 1024, zo + kn * 8192 + ((2 * g) >> 2) * 4096);
+          if (!W1) wr[s][2 * g + 1] = wload(wrs, wlane + ((2 * g + 1) & 3) * 1024, zo + kn * 8192 + ((2 * g + 1) >> 2) * 4096);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         if (H16 && ks >= 8) {   // fp16 W_hh (hi, lo of 256 w) x fp16 h: two terms
           const f16x8 b16 = __builtin_bit_cast(f16x8, bh[e]);
-          if constexpr (F8) {
-            if (e == 0) {   // both tiles in one go: a gate's lo fragment is converted once and serves both
-              const f16x8 b1 = __builtin_bit_cast(f16x8, bh[1]);
-              const float sg = wS8[(ks - 8) >> 2];
-              typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const u32x2 c8 = wc[s][g];
-                const f16x2 a0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[0], sg, false);
-                const f16x2 a1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[0], sg, true);
-                const f16x2 a2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[1], sg, false);
-                const f16x2 a3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(c8[1], sg, true);
-                const f16x8 al8 = {a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
-                const f16x8 ah8 = __builtin_bit_cast(f16x8, wr[s][g]);
-                acc[0][g] = mfma16h(ah8, b16, acc[0][g]);
-                acc[1][g] = mfma16h(ah8, b1, acc[1][g]);
-                acc[0][g] = mfma16h(al8, b16, acc[0][g]);
-                acc[1][g] = mfma16h(al8, b1, acc[1][g]);
-              }
-            }
-            continue;
-          }
 #pragma unroll
           for (int g = 0; g < 4; ++g) acc[e][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g]), b16, acc[e][g]);
 #pragma unroll
@@ -512,8 +423,11 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[e][g] = mfma32(wr[s][2 * g], bl[e], acc[e][g]);
       }
-      wfill(s, (ks + 2) % FKS, zo);
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+        if (!W1 || !(f & 1)) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
       __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();  // every wave has read h_{t-1} and x_t: both may be overwritten now
     dma_x(0, tof(step + 1));
@@ -586,7 +500,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h_w1_kernel(const ws_l
 __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h16_kernel(const ws_lstm_fused_args p) {   // hfmt 1: fp16 h, two terms
   lstm_fwd_fused64_body<WS_GATES_H2, false, true>(p);
 }
-__global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h16f8_kernel(const ws_lstm_fused_args p) {   // hfmt 1 | 4: + FP8 lo plane
+__global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h16e_kernel(const ws_lstm_fused_args p) {  // + fragments refilled gate by gate
   lstm_fwd_fused64_body<WS_GATES_H2, false, true, true>(p);
 }
 
@@ -594,7 +508,7 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn && a->wpack && a->bias, "ws_lstm_fwd_fused: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_fwd_fused: bad nseq/L");
   WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2F, "ws_lstm_fwd_fused: gfmt %d", a->gfmt);
-  WS_REQUIRE((a->hfmt & ~7) == 0 && (!(a->hfmt & 1) || a->gfmt != WS_GATES_F32) && (!(a->hfmt & 4) || (a->hfmt & 1)),
+  WS_REQUIRE((a->hfmt & ~3) == 0 && (!(a->hfmt & 1) || a->gfmt != WS_GATES_F32),
              "ws_lstm_fwd_fused: hfmt %d (1 = fp16 h, pack from ws_lstm_pack_fused_h16; 2-byte gate formats only)", a->hfmt);
   const int ntile = (a->nseq + SQ - 1) / SQ;
   dim3 grid(ntile, 2), block(512);
@@ -607,12 +521,12 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   static int cus = 0;      // same part on every device of a node; queried once
   if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 256;
   const int rounds32 = (2 * ntile + cus - 1) / cus, rounds64 = (2 * ((ntile + 1) / 2) + cus - 1) / cus;
-  // (the FP8 lo plane exists in the 64-sequence kernel only)
-  const bool wide = (a->hfmt & 4) || (env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32);
+  const bool wide = env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
   const char* w1 = getenv("WS_FUSED_W1");   // measurement only: one weight plane (bf16 weights), see lstm_fwd_fused64_body
-  if (a->hfmt & 4)
-    hipLaunchKernelGGL(lstm_fwd_fused64h16f8_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
+  static const int er = [] { const char* e = getenv("WS_FUSED_ER"); return e ? atoi(e) : 1; }();
+  if ((a->hfmt & 1) && wide && er)
+    hipLaunchKernelGGL(lstm_fwd_fused64h16e_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
   else if ((a->hfmt & 1) && wide)
     hipLaunchKernelGGL(lstm_fwd_fused64h16_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
   else if (a->hfmt & 1)

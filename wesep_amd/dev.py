@@ -1230,18 +1230,13 @@ def lstm_fused_hfmt(gfmt) -> int:
     gate formats) = h as ONE fp16 operand against W_hh as fp16 hi / lo of 256 w on v_mfma_f32_32x32x16_f16, two MFMAs per product
     -- what ws_lstm_fwd_cluster2 runs in the time view since round 5; the x part keeps the three-term split product.
     WESEP_FUSED_H16=0: the three-term product of rounds 1-5 for both parts."""
-    if gfmt == L.GATES_F32 or os.environ.get("WESEP_FUSED_H16", "1") == "0":
-        return 0
-    # bit 2 (round 6, WESEP_FUSED_F8): W_hh's lo plane as block-scaled FP8 -- the BPTT kernels' weight format in the forward
-    # (16 instead of 22 significant bits of every recurrent weight; a sixth less of the L2 -> CU stream the kernel is bound by)
-    return 1 | (4 if os.environ.get("WESEP_FUSED_F8", "0") == "1" else 0)
+    return 1 if gfmt != L.GATES_F32 and os.environ.get("WESEP_FUSED_H16", "1") != "0" else 0
 
 
 def lstm_pack_fused(wih_f, wih_r, whh_f, whh_r, pack, hfmt=0):
     for n, t in (("wih_f", wih_f), ("wih_r", wih_r), ("whh_f", whh_f), ("whh_r", whh_r), ("pack", pack)):
         _chk(t, n)
-    _call("ws_lstm_pack_fused_h16f8" if hfmt & 4 else "ws_lstm_pack_fused_h16" if hfmt & 1 else "ws_lstm_pack_fused",
-          _p(wih_f), _p(wih_r), _p(whh_f), _p(whh_r), _p(pack))
+    _call("ws_lstm_pack_fused_h16" if hfmt else "ws_lstm_pack_fused", _p(wih_f), _p(wih_r), _p(whh_f), _p(whh_r), _p(pack))
 
 
 def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm: SeqMap, gfmt=0, hfmt=0):
