@@ -384,9 +384,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
 // parities' partial tiles meet in 16 KB of LDS behind the step's closing barrier, and waves 0..3 store plain rows of p.dxn + d *
 // p.dxn_dir_stride at the sequence map's positions.  ws_gemm_b2p(a_fmt 2) over d(gates) -- 2.1 GB read per band-view layer at
 // R = 32 -- is not launched; the GroupNorm backward adds the two directions (ws_gn_bwd_fused2).
-// ER (RF = 2; round 6): every k-step's two fragments are refilled right behind its MFMAs instead of the whole chunk's eight behind
-// the chunk -- see wfill_q.
-template <bool BLK, int DBG, int GF = 0, int RF = 0, bool DX = false, bool ER = false>
+template <bool BLK, int DBG, int GF = 0, int RF = 0, bool DX = false>
 __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_args p) {
   static_assert(RF == 0 || (BLK && GF == WS_GATES_H2F), "the fp16 recurrence takes the scaled-fp16 d(gates) of WS_GATES_H2F");
   static_assert(!DX || RF == 2, "d(xn) in the BPTT rides on the fp16 d(gates) image of rfmt 2");
@@ -447,19 +445,14 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   bf16x8 wr[2][RF ? 4 : 8];
   u32x2 wq[2][RF ? 4 : 1];   // RF = 2: the FP8 codes of the slot's four k-steps
   float wS[RF ? 8 : 1];      // RF = 2: scale per group of 8 k-steps (uniform)
-  // RF = 2, one k-step of ring slot s <- k-step q of `chunk`.  With ER the step loop calls this right behind the k-step's two
-  // MFMAs (they read their A operands at issue): a fragment then has TWO chunks of lead -- refilled chunk-wise behind the
-  // fourth k-step, the first fragment of a slot was due one chunk = 8 MFMAs x 2 waves = 0.25 us later, less than an L2 hit
-  // takes under this load: the MFMA loop stalled at the top of every chunk ("19 us per MB streamed", section 5)
-  auto wfill_q = [&](int s, int q, int chunk, int zo) {
-    const int fq = q ^ kpar;   // (DX, waves 4..7: the pair's k-steps in swapped order -- see kpar)
-    wr[s][q] = wload(wrs, wlane, zo + chunk * 6144 + fq * 1024);
-    wq[s][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, zo + chunk * 6144 + 4096 + fq * 512, 0));
-  };
   auto wfill = [&](int s, int chunk, int zo) {   // ring slot s <- chunk (4 k-steps) of the stream
     if constexpr (RF != 0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) wfill_q(s, q, chunk, zo);
+      for (int q = 0; q < 4; ++q) {
+        const int fq = q ^ kpar;   // (DX, waves 4..7: the pair's k-steps in swapped order -- see kpar)
+        wr[s][q] = wload(wrs, wlane, zo + chunk * 6144 + fq * 1024);
+        wq[s][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, zo + chunk * 6144 + 4096 + fq * 512, 0));
+      }
     } else {
 #pragma unroll
       for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + chunk * 8192 + (f >> 2) * 4096);
@@ -645,10 +638,6 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
               dxa = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl8, b16, dxa, 0, 0, 0);
             }
           }
-          if constexpr (ER) {
-            if (!(DBG & 4)) wfill_q(s, q, (ch + 2) & 15, zo);
-            __builtin_amdgcn_sched_barrier(0);
-          }
         } else {
           const bf16x8 bl = *reinterpret_cast<const bf16x8*>(blo + 16 * ks);
           if (ks == 0) {
@@ -663,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
       }
       const int cn = (ch + 2) & 15;  // wraps into the next step
       if (!(DBG & 4)) {
-        if constexpr (!ER) wfill(s, cn, zo);
+        wfill(s, cn, zo);
         xfill(s, cn, zo);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -738,15 +727,12 @@ int ws_launch_lstm_fwd_bf16(const ws_lstm_args* a, hipStream_t s) {
 
 int ws_launch_lstm_bwd_bf16(const ws_lstm_args* a, hipStream_t s) {
   dim3 grid((a->nseq + SQ - 1) / SQ, 2), block(512);
-  static const int er = [] { const char* e = getenv("WS_BAND_ER"); return e ? atoi(e) : 1; }();   // (0: chunk-wise refills, A/B)
   if (a->rfmt == 2 && a->dxn) {   // (lstm_check: rfmt 2, wxpack and a sequence map given)
-    if (er) hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2, true, true>), grid, block, 0, s, *a);
-    else hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2, true>), grid, block, 0, s, *a);
+    hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2, true>), grid, block, 0, s, *a);
     return 0;
   }
   if (a->rfmt == 2) {   // (lstm_check: WS_LSTM_BF16X3_BLK + WS_GATES_H2F only)
-    if (er) hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2, false, true>), grid, block, 0, s, *a);
-    else hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2>), grid, block, 0, s, *a);
+    hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2>), grid, block, 0, s, *a);
     return 0;
   }
   WS_DBG_DISPATCH(lstm_bwd_bf16_kernel)

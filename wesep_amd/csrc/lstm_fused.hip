@@ -274,7 +274,7 @@ struct fused64_lds {
 // wave and step); the x part keeps the full three-term split product on 256 W_ih, the accumulators carry 256 x the
 // pre-activation and the 2^-8 leaves in the activations' exponent scale.  The arithmetic ws_lstm_fwd_cluster2 runs in the time
 // view since round 5 (there the 60-step trajectory did not move with it; the fp16 INPUT did, which is why x keeps its pairs).
-template <int GF, bool W1 = false, bool H16 = false, bool ER = false>
+template <int GF, bool W1 = false, bool H16 = false>
 __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& p) {
   static_assert(!(W1 && H16), "W1 is a measurement build of the three-term kernel");
   __shared__ __attribute__((aligned(16))) fused64_lds sm;
@@ -375,36 +375,6 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
           if (!H16) bl[e] = *reinterpret_cast<const bf16x8*>(hrow[e] + 2 * SQ * HROW + 16 * (ks - 8));
         }
       }
-      // Gate by gate, and each gate's two fragments REFILLED the moment its last MFMA has been issued (an MFMA reads its A
-      // operand at issue): rounds 3-5 refilled the slot's eight fragments behind all of the k-step's MFMAs, so a fragment
-      // requested at the end of k-step ks was due at the start of ks + 2 -- ONE k-step (0.5-0.7 us) of lead for an L2 hit that
-      // takes longer than that under this load, a stall in every k-step (the MFMA phase took 21 us for 13.6 us of MFMAs).
-      // Now every fragment has 1.75 k-steps.  (WS_FUSED_ER=0 / ER = false: the old order, for A/B.)
-      const int kn = (ks + 2) % FKS;
-      if constexpr (ER) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (H16 && ks >= 8) {   // fp16 W_hh (hi, lo of 256 w) x fp16 h: two terms
-            const f16x8 b0 = __builtin_bit_cast(f16x8, bh[0]), b1 = __builtin_bit_cast(f16x8, bh[1]);
-            acc[0][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g]), b0, acc[0][g]);
-            acc[1][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g]), b1, acc[1][g]);
-            acc[0][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g + 1]), b0, acc[0][g]);
-            acc[1][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g + 1]), b1, acc[1][g]);
-          } else {
-            acc[0][g] = mfma32(wr[s][2 * g], bh[0], acc[0][g]);
-            acc[1][g] = mfma32(wr[s][2 * g], bh[1], acc[1][g]);
-            if (!W1) {
-              acc[0][g] = mfma32(wr[s][2 * g + 1], bh[0], acc[0][g]);
-              acc[1][g] = mfma32(wr[s][2 * g + 1], bh[1], acc[1][g]);
-            }
-            acc[0][g] = mfma32(wr[s][2 * g], bl[0], acc[0][g]);
-            acc[1][g] = mfma32(wr[s][2 * g], bl[1], acc[1][g]);
-          }
-          wr[s][2 * g] = wload(wrs, wlane + ((2 * g) & 3) * 1024, zo + kn * 8192 + ((2 * g) >> 2) * 4096);
-          if (!W1) wr[s][2 * g + 1] = wload(wrs, wlane + ((2 * g + 1) & 3) * 1024, zo + kn * 8192 + ((2 * g + 1) >> 2) * 4096);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         if (H16 && ks >= 8) {   // fp16 W_hh (hi, lo of 256 w) x fp16 h: two terms
@@ -423,11 +393,11 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[e][g] = mfma32(wr[s][2 * g], bl[e], acc[e][g]);
       }
+      const int kn = (ks + 2) % FKS;
 #pragma unroll
       for (int f = 0; f < 8; ++f)
         if (!W1 || !(f & 1)) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
       __builtin_amdgcn_sched_barrier(0);
-      }
     }
     __syncthreads();  // every wave has read h_{t-1} and x_t: both may be overwritten now
     dma_x(0, tof(step + 1));
@@ -500,9 +470,6 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h_w1_kernel(const ws_l
 __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h16_kernel(const ws_lstm_fused_args p) {   // hfmt 1: fp16 h, two terms
   lstm_fwd_fused64_body<WS_GATES_H2, false, true>(p);
 }
-__global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h16e_kernel(const ws_lstm_fused_args p) {  // + fragments refilled gate by gate
-  lstm_fwd_fused64_body<WS_GATES_H2, false, true, true>(p);
-}
 
 extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn && a->wpack && a->bias, "ws_lstm_fwd_fused: null pointer");
@@ -524,10 +491,7 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   const bool wide = env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
   const char* w1 = getenv("WS_FUSED_W1");   // measurement only: one weight plane (bf16 weights), see lstm_fwd_fused64_body
-  static const int er = [] { const char* e = getenv("WS_FUSED_ER"); return e ? atoi(e) : 1; }();
-  if ((a->hfmt & 1) && wide && er)
-    hipLaunchKernelGGL(lstm_fwd_fused64h16e_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
-  else if ((a->hfmt & 1) && wide)
+  if ((a->hfmt & 1) && wide)
     hipLaunchKernelGGL(lstm_fwd_fused64h16_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
   else if (a->hfmt & 1)
     hipLaunchKernelGGL((lstm_fwd_fused_kernel<WS_GATES_H2, true>), grid, block, 0, s, *a);
