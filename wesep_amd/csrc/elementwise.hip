@@ -264,12 +264,13 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ws_tensor_ref* __r
   if (step_lag && !clip_only) {
     // bias corrections of the step count the DEVICE knows: attempted steps minus the skipped ones the host has not
     // subtracted yet (wesep_hip.h); uniform, in double like the host's
+    // ALWAYS recomputed here when a lag word is given, also for lag 0 (round 6): under DDP the ranks learn of a
+    // skipped step at different host polls, so in one step one rank could take the host's libm pow (lag already reconciled) and
+    // another the device's -- one ulp apart is enough to break bit-identical replicas.  One place, one pow.
     const unsigned lag = *step_lag;
-    if (lag != 0u) {
-      const double eff = (double)max(step - (int)lag, 1);
-      bc1 = (float)(1.0 - pow((double)beta1, eff));
-      bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, eff));
-    }
+    const double eff = (double)max(step - (int)lag, 1);
+    bc1 = (float)(1.0 - pow((double)beta1, eff));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, eff));
   }
   const float step_size = lr / bc1;
   for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < t.numel;

@@ -62,6 +62,14 @@ def clip_gradients(model, clip):
 clip_gradients.skipped_steps = 0
 
 
+GUARD_POLL_EVERY = 16     # optimizer steps between two (blocking) looks at the guard words when there is more than one rank
+
+
+def _world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 class FusedClipAdam(torch.optim.Optimizer):
     """Per-tensor clip + Adam-L2 in two multi-tensor launches, with a non-finite-gradient guard that never syncs the host.
 
@@ -90,6 +98,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.skipped_steps = 0
         self.max_consecutive_skips = int(max_consecutive_skips if max_consecutive_skips is not None
                                          else os.environ.get("WESEP_MAX_CONSECUTIVE_SKIPS", "10"))
+        self._calls = 0
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -158,7 +167,16 @@ class FusedClipAdam(torch.optim.Optimizer):
             dv = torch.device(*dkey)
             dev.guard_commit(self._guard_word(dv), dev.bptt_status_word(dv))
         if cuda_dev is not None:
-            self._poll_guard(cuda_dev)
+            # Under DistributedDataParallel every rank must reconcile (and, if it comes to that, raise) at the SAME step: an
+            # event that "has completed" is a race between ranks.  With more than one rank the words are
+            # looked at every GUARD_POLL_EVERY calls only, blocking (a 16-byte copy and one host sync per 16 steps); the skip
+            # itself never waits for the host -- it happens on the device in the step it belongs to, on every rank alike.
+            self._calls += 1
+            if _world_size() > 1:
+                if self._calls % GUARD_POLL_EVERY == 0:
+                    self._poll_guard(cuda_dev, block=True)
+            else:
+                self._poll_guard(cuda_dev)
             dev.poll_cluster_status(cuda_dev)   # asynchronous: evaluates the copy started one step ago
         return loss
 
