@@ -251,9 +251,20 @@ def _pending(device):
     return _PENDING.setdefault((device.type, device.index), [])
 
 
+_TIME_LEFT = {}   # device key -> time-view ResRNNs of the current graph whose backward (with a carrier) has not run yet
+
+
 def reset_deferred_wgrads(device):
     """Drop deferred jobs (start of a step: a failed backward may have left some behind)."""
     _pending(device).clear()
+    _TIME_LEFT[(device.type, device.index)] = 0
+
+
+def tail_flush() -> bool:
+    """Release the LAST time-view layer's own weight-gradient jobs right behind its BPTT instead of leaving them to the carriers
+    (default on; WESEP_TAIL_FLUSH=0): no further pair BPTT follows to hide them under, and the main stream used to sit out their
+    1.4 ms at the end of every backward (profiles/r06_bsrnn_trace_gaps.txt: 'idle between gemm_tn_bf16 -> fill')."""
+    return os.environ.get("WESEP_TAIL_FLUSH", "1") != "0"
 
 
 _AMAX = {}   # (device, stream) -> [int32 words, cursor]: scale words of WS_GATES_H2F, handed out one per BPTT launch
@@ -521,6 +532,9 @@ class ResRNNBlkFn(torch.autograd.Function):
         # (with the fp16 copies the backward never reads the split-pair xn again: its 2-byte copy is saved instead)
         ctx.save_for_backward(z, stats, gates, cbuf, hcat, xn16 if a16 else xn, wcat, norm_w, norm_b, pw, whf, whr, hcat16)
         ctx.a16 = a16
+        if view == "time" and box is not None and any(ctx.needs_input_grad):
+            key = (d.type, d.index)
+            _TIME_LEFT[key] = _TIME_LEFT.get(key, 0) + 1
         ctx.view, ctx.box, ctx.lmode, ctx.cluster, ctx.gfmt = view, box, lmode, cluster, gfmt
         ctx.packs = W
         ctx.consumed = False
@@ -662,6 +676,11 @@ class ResRNNBlkFn(torch.autograd.Function):
                     t.record_stream(side)
             defer_wgrad(d, job)
             wg = [None] * 10
+            if ctx.view == "time":
+                key = (d.type, d.index)
+                _TIME_LEFT[key] = _TIME_LEFT.get(key, 1) - 1
+                if _TIME_LEFT[key] <= 0 and tail_flush():
+                    flush_deferred_wgrads(d)     # the graph's last time-view layer: nothing left to hide its jobs under
         else:
             wg = ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax, hcat16)
         del dout_bl
