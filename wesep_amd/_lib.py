@@ -325,7 +325,11 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def upload_struct_array(arr: np.ndarray, device) -> torch.Tensor:
-    """numpy structured array -> uint8 device tensor holding the same bytes."""
+def upload_struct_array(arr: np.ndarray, device, blocking=False) -> torch.Tensor:
+    """numpy structured array -> uint8 device tensor holding the same bytes.  blocking: the pageable copy of rounds 1-5 (A/B)."""
     host = torch.from_numpy(np.frombuffer(arr.tobytes(), dtype=np.uint8).copy())
+    if not blocking and torch.cuda.is_available() and torch.device(device).type == "cuda":
+        # pinned + non_blocking: the host does not wait for the stream (a copy from pageable memory does); the pinned block's
+        # reuse is the caching host allocator's business (it records the copy's stream)
+        return host.pin_memory().to(device, non_blocking=True)
     return host.to(device)

@@ -15,12 +15,30 @@ from . import _lib as L
 from . import dev
 
 
+_TABLES = {}     # (device, tensors in the table, kind) -> (bytes, device tensor): the last table uploaded
+
+
 def _table(refs, device):
+    """Device table of (param, grad, exp_avg, exp_avg_sq, numel) rows for the multi-tensor launches.  The table of a step is
+    almost always the table of the step before (the caching allocator hands the gradients the same blocks again), so the last one
+    is kept and compared on the host: round 6 found the per-step upload -- a copy from pageable memory, i.e. a host wait for
+    everything the stream still had queued -- draining the launch pipeline once per step (1.4 ms of idle GPU behind the last
+    backward kernel + 1-2 ms of the next forward's launches arriving late: profiles/r06_bsrnn_trace_gaps.txt).  A table that did
+    change goes through pinned memory, asynchronously."""
     arr = np.zeros(len(refs), dtype=L.TENSOR_REF_DTYPE)
     for i, (p, g, m, v) in enumerate(refs):
         arr[i] = (p.data_ptr(), g.data_ptr() if g is not None else 0,
                   m.data_ptr() if m is not None else 0, v.data_ptr() if v is not None else 0, p.numel())
-    return L.upload_struct_array(arr, device)
+    if os.environ.get("WESEP_TABLE_CACHE", "1") == "0":     # (A/B: the per-step blocking upload of rounds 1-5)
+        return L.upload_struct_array(arr, device, blocking=True)
+    key = (device.type, device.index, len(refs), refs[0][2] is None)
+    raw = arr.tobytes()
+    hit = _TABLES.get(key)
+    if hit is not None and hit[0] == raw:
+        return hit[1]
+    tab = L.upload_struct_array(arr, device)
+    _TABLES[key] = (raw, tab)
+    return tab
 
 
 def clip_gradients(model, clip):
