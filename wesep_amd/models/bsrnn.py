@@ -99,13 +99,20 @@ class FuseSeparation(nn.Module):
             for _ in range(num_repeat):
                 self.separation.append(BSNet(nband * feature_dim, nband))
 
-    def forward(self, z, spk_embedding, nch=None):
-        # weight-gradient carriers first: autograd then runs them after every ResRNN's backward, so the
-        # side-stream weight-gradient GEMMs overlap the following layers (functional.WGradCarrierFn)
-        if z.is_cuda:
-            F_.reset_deferred_wgrads(z.device)
-        carriers = {i: (l.band_rnn.make_carrier(), l.band_comm.make_carrier())
-                    for i, l in enumerate(self.separation) if isinstance(l, BSNet)}
+    def make_carriers(self, device):
+        """Weight-gradient carriers of every ResRNN (functional.WGradCarrierFn).  Autograd runs a node the later the EARLIER it
+        was created: made before every ResRNN, they run after every ResRNN's backward, so the side-stream weight-gradient GEMMs
+        overlap the following layers.  BSRNN.forward makes them before the band split too (round 6): the band split's backward
+        -- 0.7 ms of BN weight gradients -- then runs BEFORE them, under the side stream's last jobs, instead of behind the wait
+        for those jobs (profiles/r06_side_stream_tax.md: the main queue sat idle for 1.45 ms there)."""
+        if device.type == "cuda":
+            F_.reset_deferred_wgrads(device)
+        return {i: (l.band_rnn.make_carrier(), l.band_comm.make_carrier())
+                for i, l in enumerate(self.separation) if isinstance(l, BSNet)}
+
+    def forward(self, z, spk_embedding, nch=None, carriers=None):
+        if carriers is None:
+            carriers = self.make_carriers(z.device)
         for i, layer in enumerate(self.separation):
             if isinstance(layer, BSNet):
                 z = layer(z, spk_embedding, carriers[i])
@@ -227,8 +234,9 @@ class BSRNN(nn.Module):
             raise RuntimeError("BSRNN expects a [batch, samples] mixture")
         wav = input.float().contiguous()
         plan = self._plan(wav.device)
+        carriers = self.separator.make_carriers(wav.device) if hasattr(self.separator, "make_carriers") else None
         z, xbs = F_.BandSplitFn.apply(wav, plan, *self._bn_params())
         e, predict_speaker_lable = self._speaker(embeddings)
-        z = self.separator(z, e)
+        z = self.separator(z, e, carriers=carriers) if carriers is not None else self.separator(z, e)
         est = F_.MaskDecodeFn.apply(z, xbs, plan, wav.shape[1], *self._mask_params())
         return est, predict_speaker_lable
