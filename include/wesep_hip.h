@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 19
+#define WS_ABI_VERSION 20
 #define WS_OK 0
 #define WS_ERR_INVALID (-1)
 #define WS_ERR_LAUNCH (-2)
@@ -710,7 +710,10 @@ typedef struct ws_lstm_fused_args {
                            product instead of three; the arithmetic of ws_lstm_fwd_cluster2) -- wpack from
                            ws_lstm_pack_fused_h16, 2-byte gate formats only.  Bit 1 (value
                            2, measurement): the 64-sequence kernels drain every store of a step before the next one starts
-                           (the wait of rounds 3-5)                                                                   */
+                           (the wait of rounds 3-5).  Bit 2 (ABI v20; with bit 0: hfmt = 5): the lo term of that product on
+                           v_mfma_scale_f32_32x32x64_f8f6f4 -- the residuals 256 w - hi as e4m3 codes with one exponent per
+                           fragment against an e4m3 image of h: four fp16 MFMAs + one FP8 MFMA (K = 64, twice the rate) per
+                           recurrent k-step instead of eight; wpack from ws_lstm_pack_fused_h8; always the 64-sequence kernel */
 } ws_lstm_fused_args;
 #define WS_LSTM_FUSED_PACK_FLOATS (2 * 8 * 24 * 4 * 2 * 64 * 4)
 int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
@@ -718,6 +721,10 @@ int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const float* whh_
 /* ABI v19: the pack of hfmt = 1 -- same size and unit order; both parts hold 256 w: W_ih as bf16 hi / lo, W_hh as fp16 hi / lo */
 int ws_lstm_pack_fused_h16(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
                            float* pack, void* stream);
+/* ABI v20: the pack of hfmt = 5 (fits the same WS_LSTM_FUSED_PACK_FLOATS): per (direction, wave) the W_ih k-steps of the h16
+ * pack, then 16 recurrent k-steps of four fp16 hi fragments + one 2 KB FP8 fragment, then the 16 fragment exponents (E8M0)  */
+int ws_lstm_pack_fused_h8(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
+                          float* pack, void* stream);
 int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream);
 
 /* ---- wespeaker ResNet speaker encoder (third-party model, call sites

@@ -163,16 +163,31 @@ def _probe():
     return int(os.environ.get("WESEP_H2_PROBE", "0"))
 
 
-def _recur_fwd(pre, whf, whr, hq16=False):
+def _w_hi_lo8(W):
+    """256 W as fp16 hi + e4m3 codes of the residual, one exponent per [32 rows][64 k] fragment (lstm_pack_fused_h8_lo_kernel)."""
+    s = 256.0 * W
+    hi = s.half().float()
+    res = (s - hi).reshape(W.shape[0] // 32, 32, W.shape[1] // 64, 64)
+    mx = res.abs().amax(dim=(1, 3), keepdim=True)
+    E = torch.where(mx > 0, torch.floor(torch.log2(mx.clamp_min(1e-45))) - 7, torch.zeros_like(mx)).clamp_min(-126)
+    lo = (res * torch.exp2(-E)).to(torch.float8_e4m3fn).float() * torch.exp2(E)
+    return hi / 256.0, lo.reshape(W.shape) / 256.0
+
+
+def _recur_fwd(pre, whf, whr, hq16=False, hq8=False):
     """pre [S, L, 2, 4H] pre-activations -> (activated gates, c, h) of the same leading shape.  hq16: fp16 h in the recurrent
-    product (ws_lstm_fwd_cluster2)."""
+    product (ws_lstm_fwd_cluster2).  hq8 (hfmt 5): W_hh = fp16 hi + FP8 lo, the lo term against an e4m3 image of h."""
     S, L = pre.shape[:2]
     act, cs, hs = torch.zeros_like(pre), torch.zeros(S, L, 2, H), torch.zeros(S, L, 2, H)
     for d, W in ((0, whf), (1, whr)):
         h, c = torch.zeros(S, H), torch.zeros(S, H)
+        if hq8:
+            W, W8 = _w_hi_lo8(W)
         for t in (range(L) if d == 0 else range(L - 1, -1, -1)):
             hq = h.half().float() if hq16 or _probe() & 2048 else h    # (numerics probe: fp16 h in the recurrent product)
             p = pre[:, t, d] + hq @ W.t()
+            if hq8:
+                p = p + h.to(torch.float8_e4m3fn).float() @ W8.t()
             i, f, g, o = p[:, :H].sigmoid(), p[:, H:2 * H].sigmoid(), p[:, 2 * H:3 * H].tanh(), p[:, 3 * H:].sigmoid()
             c = f * c + i * g
             h = o * c.tanh()
@@ -213,9 +228,9 @@ def _recur_bwd(act, cs, dh_in, whf, whr, scale=1.0, rq=False):
     return dpre
 
 
-def _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt=0, hq16=False):
+def _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt=0, hq16=False, hq8=False):
     nt, L = _ntile(sm), sm.L
-    act, cs, hs = _recur_fwd(pre, whf, whr, hq16)
+    act, cs, hs = _recur_fwd(pre, whf, whr, hq16, hq8)
     v = _valid(sm)
     if gfmt:
         gates_put_u16(gates, act.reshape(nt * 32, L, 2 * G4), nt, L)     # (padded slots: whatever the recurrence made of them)
@@ -361,7 +376,7 @@ def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm, gfmt=0, hfmt=0):
         x = x.half().float()
     b = bias.reshape(2, G4)
     pre = torch.stack([x @ wih_f.t() + b[0], x @ wih_r.t() + b[1]], 2)
-    _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt, hq16=bool(hfmt))     # (hfmt 1: fp16 h in the recurrent product)
+    _fwd_into(gates, cbuf, hcat, pre, whf, whr, sm, gfmt, hq16=bool(hfmt & 1), hq8=bool(hfmt & 4))   # (hfmt 1: fp16 h in the recurrent product; 5: + FP8 lo term)
 
 
 def gemm_tnb(*, G, g_width, g_off, g_cols, A0, a0_width, a0_off, a0_cols, nblk, L_, slab, nsplit, blocks_per_split,

@@ -2,7 +2,7 @@
 bands) -- launch times of
   * the streaming BPTT: three-term product, rfmt 2, rfmt 2 + d(xn) inside (ws_lstm_args.dxn), and ws_gemm_b2p(a_fmt 2) over the
     same d(gates) (the launch the last variant replaces);
-  * the fused forward: three-term (hfmt 0) and fp16 h (hfmt 1), each with the end-of-step wait of rounds 3-5 (vmcnt(0):
+  * the fused forward: three-term (hfmt 0), fp16 h (hfmt 1) and fp16 h with the lo term on the FP8 MFMA (hfmt 5, ABI v20), each with the end-of-step wait of rounds 3-5 (vmcnt(0):
     WESEP_FUSED_DRAIN=1) and with the round-6 wait (vmcnt(48): only the DMA of the next step's input).
 Not part of the product.
 
@@ -44,7 +44,7 @@ def main():
     gh = torch.zeros(dev.blh_floats(nb, 8 * H), device=d)
     xn = dev.bls_pack(torch.randn(nb, N // 4, 32, 4, device=d))
     # ---- forward ---------------------------------------------------------------------------------------------------
-    for hf, nm in ((0, "three terms (bf16x3)"), (1, "fp16 h, two recurrent terms")):
+    for hf, nm in ((0, "three terms (bf16x3)"), (1, "fp16 h, two recurrent terms"), (5, "fp16 h, lo term on the FP8 MFMA")):
         fp = torch.empty(L.LSTM_FUSED_PACK_FLOATS, device=d)
         dev.lstm_pack_fused(wif, wir, whf, whr, fp, hfmt=hf)
         for drain in ("1", "0"):

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WESEP_HIP_LIB") or os.path.join(_HERE, "libwesep_hip.
 WS_OK = 0
 PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_GEMM_NT, PROF_GEMM_TN = 0, 1, 2, 3
 LSTM_H = 256
-ABI_VERSION = 19
+ABI_VERSION = 20
 GATES_F32, GATES_H2, GATES_H2S, GATES_H2F = 0, 1, 2, 3     # WS_GATES_* (wesep_hip.h): storage of the saved gates / d(gates)
 DGATES_EXP = 8             # WS_DGATES_EXP: WS_GATES_H2F puts max |d(hcat)| into [2^8, 2^9)
 
@@ -273,6 +273,7 @@ _SIGS = {
     "ws_log_eps": (_i, [_p, _ll, C.c_float, _p]),
     "ws_lstm_pack_fused": (_i, [_p, _p, _p, _p, _p, _p]),
     "ws_lstm_pack_fused_h16": (_i, [_p, _p, _p, _p, _p, _p]),
+    "ws_lstm_pack_fused_h8": (_i, [_p, _p, _p, _p, _p, _p]),
     "ws_lstm_fwd_fused": (_i, [C.POINTER(LstmFusedArgs), _p]),
     "ws_grad_norms": (_i, [_p, _i, _p, _p, _p]),
     "ws_clip_adam_step": (_i, [_p, _i, _p, _f, _f, _f, _f, _f, _f, _i, _i, _p, _p, _p, _p]),

@@ -56,6 +56,8 @@ __device__ __forceinline__ float ftanh(float x) {
 // The fp16 recurrences (lstm_cluster2.hip, the H16 fused forward of lstm_fused.hip): h in (-1, 1) as ONE fp16 operand of
 // v_mfma_f32_32x32x16_f16 against W as fp16 hi / lo of 256 w; the accumulator then carries 256 x the pre-activation.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));   // 32 FP8 operand bytes of v_mfma_scale_f32_32x32x64_f8f6f4
 __device__ __forceinline__ f32x16 mfma16h(const f16x8& a, const f16x8& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }

@@ -14,6 +14,7 @@
 
 #define XROW 136  // bf16 per LDS row of x (128 + 8: 272 B = 4 banks mod 64)
 #define FKS 24    // k-steps of the fused stream: 8 of W_ih (K = 128), 16 of W_hh (K = 256)
+#define H8ROW 272 // bytes per LDS row of e4m3 h (256 + 16: 4 banks mod 64)
 
 // unit ((((d*8 + w)*24 + ks)*4 + g)*2 + part)*64 + lane, element j =
 //   part( ks < 8 ? W_ih[d][g*256 + 32w + (lane&31)][16ks + 8(lane>>5) + j]
@@ -72,6 +73,85 @@ extern "C" int ws_lstm_pack_fused_h16(const float* wih_f, const float* wih_r, co
   hipLaunchKernelGGL(lstm_pack_fused_kernel<true>, dim3(512), dim3(256), 0, (hipStream_t)stream, wih_f, wih_r, whh_f, whh_r,
                      reinterpret_cast<__bf16*>(pack));
   return ws_check_launch("ws_lstm_pack_fused_h16");
+}
+
+// ---- hfmt = 5 (ABI v20): the lo plane of W_hh as FP8 (e4m3) operands of v_mfma_scale_f32_32x32x64_f8f6f4 -----------------
+// Region of (d, w): F8_REGION bytes.  [0, 64 KB): the W_ih k-steps exactly as in the H16 pack.  Then 16 recurrent k-steps q of
+// 6 KB: four fp16 hi fragments (gate g at + 1 KB g; lane: 8 values k = 16 q + 8 (lane >> 5) + j of row g*256 + 32 w + (lane & 31))
+// and, at + 4 KB, ONE FP8 fragment of the residuals 256 w - hi: gate q & 3, k block q >> 2 (k = 64 (q >> 2) .. + 63), a lane's 32
+// bytes in the operand order of the instruction (profiles/r06_c20_f8_probe.txt): piece 0 (+ 0, lane * 16) = k 16 (lane >> 5) + j,
+// piece 1 (+ 1 KB) = k 32 + 16 (lane >> 5) + j.  The fragment's codes are res * 2^-E with ONE exponent E per fragment (the
+// largest residual lands in [128, 256)); the E8M0 byte 127 + E of fragment q is byte q of the 16 at F8_SCALES.
+#define F8_HPART 65536
+#define F8_KSTEP 6144
+#define F8_SCALES (F8_HPART + 16 * F8_KSTEP)
+#define F8_REGION (F8_SCALES + 64)
+__global__ void lstm_pack_fused_h8_hi_kernel(const float* __restrict__ wih_f, const float* __restrict__ wih_r,
+                                             const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                             unsigned char* __restrict__ pk) {
+  const int total = 2 * 8 * FKS * 4 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int r = idx;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    const int g = r & 3; r >>= 2;
+    const int ks = r % FKS; r /= FKS;
+    const int w = r & 7; r >>= 3;
+    const int d = r;
+    const int row = g * 256 + 32 * w + (lane & 31);
+    unsigned char* reg = pk + (long long)(d * 8 + w) * F8_REGION;
+    if (ks < 8) {
+      const float s = 256.f * (d ? wih_r : wih_f)[row * 128 + 16 * ks + 8 * (lane >> 5) + j];
+      const __bf16 hi = (__bf16)s;
+      __bf16* o = reinterpret_cast<__bf16*>(reg + ks * 8192 + g * 2048 + lane * 16);
+      o[j] = hi;
+      o[512 + j] = (__bf16)(s - (float)hi);     // + 1 KB: the lo fragment
+    } else {
+      const float s = 256.f * (d ? whh_r : whh_f)[row * LH + 16 * (ks - 8) + 8 * (lane >> 5) + j];
+      reinterpret_cast<_Float16*>(reg + F8_HPART + (ks - 8) * F8_KSTEP + g * 1024 + lane * 16)[j] = (_Float16)s;
+    }
+  }
+}
+// one wave per FP8 fragment: (d, w, q)
+__global__ __launch_bounds__(64) void lstm_pack_fused_h8_lo_kernel(const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                                   unsigned char* __restrict__ pk) {
+  const int lane = threadIdx.x, q = blockIdx.x & 15, w = (blockIdx.x >> 4) & 7, d = blockIdx.x >> 7;
+  const int g = q & 3, kb = q >> 2;
+  const float* W = (d ? whh_r : whh_f) + (long long)(g * 256 + 32 * w + (lane & 31)) * LH + 64 * kb + 16 * (lane >> 5);
+  float res[32];
+  float mx = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const float s = 256.f * W[(j >> 4) * 32 + (j & 15)];
+    res[j] = s - (float)(_Float16)s;
+    mx = fmaxf(mx, fabsf(res[j]));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  int E = 0;
+  if (mx > 0.f) E = ((__float_as_int(mx) >> 23) & 255) - 127 - 7;       // floor(log2 mx) - 7: the largest code in [128, 256)
+  E = max(E, -126);                                                     // (residuals of denormal size: codes of zero)
+  const float inv = __int_as_float((127 - E) << 23);
+  unsigned char* reg = pk + (long long)(d * 8 + w) * F8_REGION;
+  unsigned int* o = reinterpret_cast<unsigned int*>(reg + F8_HPART + q * F8_KSTEP + 4096 + lane * 16);
+#pragma unroll
+  for (int j = 0; j < 32; j += 4) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(res[j] * inv, res[j + 1] * inv, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(res[j + 2] * inv, res[j + 3] * inv, v, true);
+    o[(j >> 4) * 256 + ((j & 15) >> 2)] = (unsigned int)v;
+  }
+  if (lane == 0) reg[F8_SCALES + q] = (unsigned char)(127 + E);
+}
+
+extern "C" int ws_lstm_pack_fused_h8(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,
+                                     float* pack, void* stream) {
+  WS_REQUIRE(wih_f && wih_r && whh_f && whh_r && pack, "ws_lstm_pack_fused_h8: null pointer");
+  static_assert(2 * 8 * F8_REGION <= WS_LSTM_FUSED_PACK_FLOATS * 4, "the F8 stream fits the pack of the other formats");
+  unsigned char* pk = reinterpret_cast<unsigned char*>(pack);
+  hipLaunchKernelGGL(lstm_pack_fused_h8_hi_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, wih_f, wih_r, whh_f, whh_r, pk);
+  hipLaunchKernelGGL(lstm_pack_fused_h8_lo_kernel, dim3(2 * 8 * 16), dim3(64), 0, (hipStream_t)stream, whh_f, whh_r, pk);
+  return ws_check_launch("ws_lstm_pack_fused_h8");
 }
 
 // H16: ws_lstm_fused_args.hfmt = 1 -- see lstm_fwd_fused64_body (fp16 h, one LDS plane per buffer, two recurrent terms)
@@ -274,9 +354,15 @@ struct fused64_lds {
 // wave and step); the x part keeps the full three-term split product on 256 W_ih, the accumulators carry 256 x the
 // pre-activation and the 2^-8 leaves in the activations' exponent scale.  The arithmetic ws_lstm_fwd_cluster2 runs in the time
 // view since round 5 (there the 60-step trajectory did not move with it; the fp16 INPUT did, which is why x keeps its pairs).
-template <int GF, bool W1 = false, bool H16 = false>
+// F8 (hfmt = 5, ABI v20; with H16): the lo term of the recurrent product on the block-scaled FP8 matrix instruction --
+// 256 w = hi (fp16) + res; res x h is 2^-12 of the product, so e4m3 operands (res as codes with one exponent per fragment, h as
+// e4m3 of the same h the fp16 plane holds) leave it good to 2^-16 of the whole, and ONE v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 at
+// twice the fp16 rate: 4 776 against 2 184 TFLOP/s measured, profiles/r06_c20_f8_probe.txt) replaces four fp16 MFMAs of K = 16:
+// per recurrent k-step four hi MFMAs + one FP8 MFMA (gate q & 3 of k block q >> 2) instead of eight, 6 KB of stream instead of 8.
+template <int GF, bool W1 = false, bool H16 = false, bool F8 = false>
 __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& p) {
   static_assert(!(W1 && H16), "W1 is a measurement build of the three-term kernel");
+  static_assert(!F8 || H16, "the FP8 lo term belongs to the fp16-h kernel");
   __shared__ __attribute__((aligned(16))) fused64_lds sm;
   auto& xw = sm.xw;
   auto& hl = sm.hl;
@@ -324,15 +410,37 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
 #pragma unroll
   for (int j = 0; j < 4; ++j) c1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.wpack) + (long long)(d * 8 + w) * (FKS * 8 * 64 * 4), 0, FKS * 8 * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs =
+      F8 ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(const_cast<float*>(p.wpack)) +
+                                                 (long long)(d * 8 + w) * F8_REGION, 0, F8_REGION, 0x00020000)
+         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpack) + (long long)(d * 8 + w) * (FKS * 8 * 64 * 4), 0,
+                                             FKS * 8 * 1024, 0x00020000);
   const int wlane = lane * 16;
   bf16x8 wr[2][8];
+  // k-step kn of the stream -> ring slot s (F8: the recurrent k-steps are 6 fragments -- four hi, two halves of the FP8 one)
+  auto refill = [&](int s, int kn, int zo) {
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+    for (int f = 0; f < 8; ++f) {
+      if (F8 && kn >= 8) {
+        if (f < 6) wr[s][f] = wload(wrs, wlane + f * 1024, zo + F8_HPART + (kn - 8) * F8_KSTEP);
+      } else if (!W1 || !(f & 1)) {
+        wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
+      }
+    }
+  };
+  refill(0, 0, 0);
+  refill(1, 1, 0);
+  // F8: the sixteen fragment exponents (E8M0 bytes) of this wave's stream, four per k block, in scalar registers
+  int ssc[4] = {0, 0, 0, 0};
+  if constexpr (F8) {
+    const int* sp = reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(p.wpack) +
+                                                 (long long)(d * 8 + w) * F8_REGION + F8_SCALES);
 #pragma unroll
-    for (int f = 0; f < 8; ++f)
-      if (!W1 || !(f & 1)) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
+    for (int i = 0; i < 4; ++i) ssc[i] = __builtin_amdgcn_readfirstlane(sp[i]);
+  }
+  // e4m3 h_{t-1}: rows of 272 B in the LDS plane the fp16 format leaves unused ([tile*32 + seq][k], 17 KB)
+  unsigned char* h8 = reinterpret_cast<unsigned char*>(&hl[1][0]);
+  const unsigned char* h8row[2] = {h8 + l31 * H8ROW + 16 * half, h8 + (32 + l31) * H8ROW + 16 * half};
 
   const __bf16* hrow[2] = {&hl[0][l31 * HROW + 8 * half], &hl[0][(32 + l31) * HROW + 8 * half]};  // h_{t-1} rows of this lane
   auto tof = [&](int n) { const int m = min(n, L - 1); return d == 0 ? m : L - 1 - m; };
@@ -354,10 +462,21 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[0][g][4 * j + r] = acc[1][g][4 * j + r] = b[r];
       }
+    v8i b8[2];      // F8: e4m3 h of the current k block (64 values of k), both tiles
+    int scv = 0;    //     its four fragment exponents
 #pragma unroll
     for (int ks = 0; ks < FKS; ++ks) {
       const int s = ks & 1;
       bf16x8 bh[2], bl[2];
+      if (F8 && ks >= 8 && ((ks - 8) & 3) == 0) {
+        const int kb = (ks - 8) >> 2;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const i32x4 p0 = *reinterpret_cast<const i32x4*>(h8row[e] + 64 * kb), p1 = *reinterpret_cast<const i32x4*>(h8row[e] + 64 * kb + 32);
+          b8[e] = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        scv = ssc[kb];
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         if (ks < 8) {
@@ -377,6 +496,12 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
       }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
+        if (F8 && ks >= 8) {    // fp16 hi of 256 W_hh x fp16 h; the FP8 term of this k-step's gate follows both tiles' hi terms
+          const f16x8 b16 = __builtin_bit_cast(f16x8, bh[e]);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[e][g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][g]), b16, acc[e][g]);
+          continue;
+        }
         if (H16 && ks >= 8) {   // fp16 W_hh (hi, lo of 256 w) x fp16 h: two terms
           const f16x8 b16 = __builtin_bit_cast(f16x8, bh[e]);
 #pragma unroll
@@ -393,10 +518,22 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[e][g] = mfma32(wr[s][2 * g], bl[e], acc[e][g]);
       }
-      const int kn = (ks + 2) % FKS;
+      if constexpr (F8) {
+        if (ks >= 8) {
+          constexpr int ONE = 127;     // h is stored unscaled
+          const int q = ks - 8, g8 = q & 3;
+          const v8i a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, wr[s][4]), __builtin_bit_cast(i32x4, wr[s][5]), 0, 1, 2, 3,
+                                                 4, 5, 6, 7);
 #pragma unroll
-      for (int f = 0; f < 8; ++f)
-        if (!W1 || !(f & 1)) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
+          for (int e = 0; e < 2; ++e) {
+            if (g8 == 0) acc[e][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[e], acc[e][0], 0, 0, 0, scv, 0, ONE);
+            if (g8 == 1) acc[e][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[e], acc[e][1], 0, 0, 1, scv, 0, ONE);
+            if (g8 == 2) acc[e][2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[e], acc[e][2], 0, 0, 2, scv, 0, ONE);
+            if (g8 == 3) acc[e][3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[e], acc[e][3], 0, 0, 3, scv, 0, ONE);
+          }
+        }
+      }
+      refill(s, (ks + 2) % FKS, zo);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // every wave has read h_{t-1} and x_t: both may be overwritten now
@@ -430,6 +567,12 @@ __device__ __forceinline__ void lstm_fwd_fused64_body(const ws_lstm_fused_args& 
         split4(vh, h_hi, h_lo);
         if constexpr (H16) {   // the recurrent operand: fp16(h), one plane
           *reinterpret_cast<u32x2*>(nhi + 8 * j) = enc_f16x4(vh);
+          if constexpr (F8) {  // + its e4m3 image, the operand of the lo term
+            int c8 = 0;
+            c8 = __builtin_amdgcn_cvt_pk_fp8_f32(vh[0], vh[1], c8, false);
+            c8 = __builtin_amdgcn_cvt_pk_fp8_f32(vh[2], vh[3], c8, true);
+            *reinterpret_cast<int*>(h8 + (32 * e + l31) * H8ROW + ubase + 8 * j) = c8;
+          }
         } else {
           *reinterpret_cast<bf16x4*>(nhi + 8 * j) = h_hi;
           *reinterpret_cast<bf16x4*>(nlo + 8 * j) = h_lo;
@@ -470,13 +613,17 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h_w1_kernel(const ws_l
 __global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h16_kernel(const ws_lstm_fused_args p) {   // hfmt 1: fp16 h, two terms
   lstm_fwd_fused64_body<WS_GATES_H2, false, true>(p);
 }
+__global__ __launch_bounds__(512, 1) void lstm_fwd_fused64h8_kernel(const ws_lstm_fused_args p) {   // hfmt 5: + the lo term in FP8
+  lstm_fwd_fused64_body<WS_GATES_H2, false, true, true>(p);
+}
 
 extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   WS_REQUIRE(a && a->gates && a->cbuf && a->hcat && a->xn && a->wpack && a->bias, "ws_lstm_fwd_fused: null pointer");
   WS_REQUIRE(a->nseq > 0 && a->L > 0, "ws_lstm_fwd_fused: bad nseq/L");
   WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2F, "ws_lstm_fwd_fused: gfmt %d", a->gfmt);
-  WS_REQUIRE((a->hfmt & ~3) == 0 && (!(a->hfmt & 1) || a->gfmt != WS_GATES_F32),
-             "ws_lstm_fwd_fused: hfmt %d (1 = fp16 h, pack from ws_lstm_pack_fused_h16; 2-byte gate formats only)", a->hfmt);
+  WS_REQUIRE((a->hfmt & ~7) == 0 && (!(a->hfmt & 1) || a->gfmt != WS_GATES_F32) && (!(a->hfmt & 4) || (a->hfmt & 1)),
+             "ws_lstm_fwd_fused: hfmt %d (1 = fp16 h, pack from ws_lstm_pack_fused_h16; 5 = + FP8 lo term, pack from "
+             "ws_lstm_pack_fused_h8; 2-byte gate formats only)", a->hfmt);
   const int ntile = (a->nseq + SQ - 1) / SQ;
   dim3 grid(ntile, 2), block(512);
   hipStream_t s = (hipStream_t)stream;
@@ -488,10 +635,13 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   static int cus = 0;      // same part on every device of a node; queried once
   if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 256;
   const int rounds32 = (2 * ntile + cus - 1) / cus, rounds64 = (2 * ((ntile + 1) / 2) + cus - 1) / cus;
-  const bool wide = env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
+  // (the FP8 lo term exists in the 64-sequence kernel only: its odd last tile is masked, any sequence count runs)
+  const bool wide = (a->hfmt & 4) ? true : env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
   const char* w1 = getenv("WS_FUSED_W1");   // measurement only: one weight plane (bf16 weights), see lstm_fwd_fused64_body
-  if ((a->hfmt & 1) && wide)
+  if (a->hfmt & 4)
+    hipLaunchKernelGGL(lstm_fwd_fused64h8_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
+  else if ((a->hfmt & 1) && wide)
     hipLaunchKernelGGL(lstm_fwd_fused64h16_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
   else if (a->hfmt & 1)
     hipLaunchKernelGGL((lstm_fwd_fused_kernel<WS_GATES_H2, true>), grid, block, 0, s, *a);

@@ -1229,14 +1229,19 @@ def lstm_fused_hfmt(gfmt) -> int:
     """Arithmetic of the fused band-view forward's recurrent part (ws_lstm_fused_args.hfmt, ABI v19): 1 (default with the 2-byte
     gate formats) = h as ONE fp16 operand against W_hh as fp16 hi / lo of 256 w on v_mfma_f32_32x32x16_f16, two MFMAs per product
     -- what ws_lstm_fwd_cluster2 runs in the time view since round 5; the x part keeps the three-term split product.
-    WESEP_FUSED_H16=0: the three-term product of rounds 1-5 for both parts."""
-    return 1 if gfmt != L.GATES_F32 and os.environ.get("WESEP_FUSED_H16", "1") != "0" else 0
+    WESEP_FUSED_H16=0: the three-term product of rounds 1-5 for both parts.
+    Bit 2 (ABI v20, WESEP_FUSED_F8=1; with bit 0: 5): the lo term of that product on the block-scaled FP8 matrix instruction (one
+    K = 64 MFMA at twice the fp16 rate for four K = 16 ones) -- the 64-sequence kernel only (models.tfgridnet masks the bit)."""
+    if gfmt == L.GATES_F32 or os.environ.get("WESEP_FUSED_H16", "1") == "0":
+        return 0
+    return 5 if os.environ.get("WESEP_FUSED_F8", "0") == "1" else 1
 
 
 def lstm_pack_fused(wih_f, wih_r, whh_f, whh_r, pack, hfmt=0):
     for n, t in (("wih_f", wih_f), ("wih_r", wih_r), ("whh_f", whh_f), ("whh_r", whh_r), ("pack", pack)):
         _chk(t, n)
-    _call("ws_lstm_pack_fused_h16" if hfmt else "ws_lstm_pack_fused", _p(wih_f), _p(wih_r), _p(whh_f), _p(whh_r), _p(pack))
+    _call("ws_lstm_pack_fused_h8" if hfmt & 4 else "ws_lstm_pack_fused_h16" if hfmt & 1 else "ws_lstm_pack_fused",
+          _p(wih_f), _p(wih_r), _p(whh_f), _p(whh_r), _p(pack))
 
 
 def lstm_fwd_fused(gates, cbuf, hcat, xn, wpack, bias, sm: SeqMap, gfmt=0, hfmt=0):

@@ -466,7 +466,8 @@ class ResRNNBlkFn(torch.autograd.Function):
             dev.gemm_p2b(A=z, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, stats=stats, gamma=norm_w,
                          beta=norm_b, stat_map=smap, A_bl16=xn16)
             hf = dev.lstm_fused_hfmt(gfmt)
-            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, W("fused16" if hf else "fused"), bcat, seq, gfmt=gfmt, hfmt=hf)
+            dev.lstm_fwd_fused(gates, cbuf, hcat, xn, W("fused8" if hf & 4 else "fused16" if hf else "fused"), bcat, seq, gfmt=gfmt,
+                               hfmt=hf)
         elif cluster and h2 and dev.lstm_cluster2_on():
             # time view, 2-byte formats (round 5): the cluster kernel computes x W_ih^T itself from the normalised input
             # (lstm_cluster2.hip) -- ws_gemm_p2b only normalises (reads E, writes E (+ E / 2 for the fp16 copy) instead of
@@ -788,9 +789,10 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
             pack = _empty(d, L.LSTM_PACK_FLOATS)
             dev.lstm_pack_pair(*W("whh"), pack, f16=pair_rfmt(L.GATES_H2F) if kind == "hhp16" else 0)
             return pack
-        if kind in ("fused", "fused16"):  # fused16: the hfmt 1 pack (256 w; W_hh part as fp16 hi / lo)
-            fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
-            dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), *W("whh"), fpack, hfmt=int(kind == "fused16"))
+        if kind in ("fused", "fused16", "fused8"):  # fused16: the hfmt 1 pack (256 w; W_hh part as fp16 hi / lo); fused8: hfmt 5
+            fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)        # (fp16 hi + one FP8 fragment per k-step, ABI v20)
+            dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), *W("whh"), fpack,
+                                hfmt={"fused": 0, "fused16": 1, "fused8": 5}[kind])
             return fpack
         if kind == "wih":
             out = _empty(d, 2 * G4 * N)

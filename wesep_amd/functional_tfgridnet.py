@@ -451,7 +451,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         if dev.lstm_fuse_ok(ns, cluster):
             dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, A_bl16=xn16)
             fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
-            hf = dev.lstm_fused_hfmt(gfmt)      # round 6: fp16 h in the recurrent part (two terms), as functional.ResRNNBlkFn
+            hf = dev.lstm_fused_hfmt(gfmt) & 1  # (bit 2, the FP8 lo term, lives in the 64-sequence kernel only)  round 6: fp16 h in the recurrent part (two terms), as functional.ResRNNBlkFn
             dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), whf, whr, fpack, hfmt=hf)
             dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq, gfmt=gfmt, hfmt=hf)
         elif cluster and h2 and dev.lstm_cluster2_on() and os.environ.get("WESEP_TFG_CLUSTER2", "1") != "0":
