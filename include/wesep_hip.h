@@ -244,7 +244,10 @@ typedef struct ws_lstm_args {
                             WS_GATES_H2F only: 2 = the recurrent product d(h) = d(gates) W_hh on v_mfma_f32_32x32x16_f16 with the
                             STORED scaled-fp16 d(gates) as its one operand against W_hh as fp16 hi + scaled-FP8 lo of 256 w --
                             `wpack` from ws_lstm_pack_bwd_f8: two MFMAs per product instead of three, 96 instead of 128 KB of
-                            weights streamed per wave and step (the arithmetic of ws_lstm_pair_args.rfmt = 2)           */
+                            weights streamed per wave and step (the arithmetic of ws_lstm_pair_args.rfmt = 2).  3 (ABI v20):
+                            the same pack and stream with the lo term on v_mfma_scale_f32_32x32x64_f8f6f4 (the codes as A
+                            operands of K = 64 against e4m3 of d(gates) / 256): four fp16 MFMAs + one FP8 MFMA per 64 gate
+                            columns instead of eight fp16 MFMAs; not with `dxn`                                          */
   const unsigned* amax;  /* WS_GATES_H2F, backward: max |dhcat| of this launch as float bits (see WS_GATES_H2F) */
   /* ABI v19 (three trailing fields, zero = every earlier behaviour), ws_lstm_bwd with rfmt = 2 only: d(normalised input) of
    * the ResRNN computed INSIDE the BPTT from the d(gates) image its recurrent product reads anyway (autograd's d(input) of
@@ -365,7 +368,9 @@ typedef struct ws_lstm_cluster2_args {
   unsigned* tword;
   unsigned* status;
   int nseq, L;
-  int dbg, pad_;
+  int dbg, rfmt;        /* rfmt (ABI v20, the former pad_: 0 = every earlier behaviour): 1 = the lo term of the recurrent product on
+                           v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 codes of 256 w - hi, one exponent per wave, against e4m3 of h): four
+                           fp16 MFMAs + one FP8 MFMA per 64 columns instead of eight fp16 MFMAs                        */
   float* dbg_buf;       /* dbg 2048: L * 2 * 8 64-bit cycle stamps of cluster 0 / member 0 (tools/r05_recur_probe.py) */
 } ws_lstm_cluster2_args;
 int ws_lstm_fwd_cluster2(const ws_lstm_cluster2_args* a, void* stream);
@@ -411,7 +416,11 @@ typedef struct ws_lstm_pair_args {
                            what its own recurrence and both consumers read.  2 (ABI v18; WS_GATES_H2F only): the same
                            product with the lo plane of W_hh as block-scaled FP8 (wpack from ws_lstm_pack_pair_f8): 16
                            instead of 22 significant bits of every weight, and the whole of W_hh stays on the compute
-                           unit for the launch (hi plane in registers, lo plane in LDS) -- nothing of it is streamed  */
+                           unit for the launch (hi plane in registers, lo plane in LDS) -- nothing of it is streamed.
+                           3 (ABI v20; WS_GATES_H2F only): rfmt 2 with the lo term on v_mfma_scale_f32_32x32x64_f8f6f4 --
+                           the same codes as A operands of K = 64 (wpack from ws_lstm_pack_pair_f8mx) against e4m3 of
+                           d(gates) / 256 built in registers from the fp16 fragments: per 64 gate columns four fp16 MFMAs
+                           + one FP8 MFMA at twice the rate instead of eight fp16 MFMAs                               */
 } ws_lstm_pair_args;
 int ws_lstm_pack_pair(const float* whh_f, const float* whh_r, float* pack, void* stream);
 /* ABI v17: the pack of rfmt = 1 (same size and unit order, fp16 hi / lo of 256 w; |w| < 255) */
@@ -422,6 +431,10 @@ int ws_lstm_pack_pair_f16(const float* whh_f, const float* whh_r, float* pack, v
  * [2^(e-1), 2^e): the largest possible remainder maps to 256 -- e4m3 has no saturation, it overflows to NaN above 448.
  * |w| < 255.) */
 int ws_lstm_pack_pair_f8(const float* whh_f, const float* whh_r, float* pack, void* stream);
+/* ABI v20: the pack of rfmt = 3 -- hi plane, codes and S of ws_lstm_pack_pair_f8; the codes as eight 2 KB operand fragments
+ * (K = 64) per block: a lane's 32 bytes = its four 8-byte units of k-steps 4 kb .. 4 kb + 3, as two 16-byte pieces 1 KB apart;
+ * the E8M0 byte of S as an int at byte 48 K + 4 */
+int ws_lstm_pack_pair_f8mx(const float* whh_f, const float* whh_r, float* pack, void* stream);
 int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream);
 /* wcat[2][4H][N] <- (w_ih_f, w_ih_r);  bcat[2][4H] <- b_ih + b_hh per direction             */
 int ws_lstm_cat_ih(const float* wih_f, const float* wih_r, const float* bih_f, const float* bhh_f,

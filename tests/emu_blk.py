@@ -310,9 +310,10 @@ def lstm_fwd_cluster(gates, cbuf, hcat, whh_f, whh_r, sm, status=None, dbg=0, gf
     return torch.zeros(1, dtype=torch.int32)
 
 
-def lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whh_f, whh_r, sm, status=None, dbg=0, dbg_buf=None):
+def lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whh_f, whh_r, sm, status=None, dbg=0, dbg_buf=None, rfmt=None):
     """ws_lstm_fwd_cluster2: x-projection from the normalised input (BL(128)) inside the recurrence, fp16 h in the recurrent
-    product, unorm16 gates out; dbg & 8 emulates a time-out like lstm_fwd_cluster."""
+    product, unorm16 gates out; dbg & 8 emulates a time-out like lstm_fwd_cluster.  rfmt 1 (ABI v20): the lo term of W_hh as
+    e4m3 codes against e4m3 of h (one exponent per [32 rows][64 k] here, per wave on the device)."""
     nt, L = _ntile(sm), sm.L
     if dbg & 8:
         for t in (cbuf, hcat):
@@ -321,7 +322,8 @@ def lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whh_f, whh_r, sm, statu
     x = bl_get(xn, nt, L, 128)
     w, b = wcat.reshape(2, G4, 128), bcat.reshape(2, G4)
     pre = torch.stack([x @ w[0].t() + b[0], x @ w[1].t() + b[1]], 2)
-    _fwd_into(gates, cbuf, hcat, pre, whh_f, whh_r, sm, 1, hq16=True)
+    rf = real_dev.cluster2_rfmt() if rfmt is None else rfmt
+    _fwd_into(gates, cbuf, hcat, pre, whh_f, whh_r, sm, 1, hq16=True, hq8=bool(rf))
     return torch.zeros(1, dtype=torch.int32)
 
 

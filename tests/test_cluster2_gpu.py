@@ -42,7 +42,7 @@ def _case(dims, seed, d):
     return seq, nb, P, {k: v.to(d) for k, v in w.items()}, x.to(d)
 
 
-def _run_new(seq, nb, w, x, d, dbg=0, status=None):
+def _run_new(seq, nb, w, x, d, dbg=0, status=None, rfmt=0):
     from wesep_amd import dev
     wcat, bcat = torch.empty(2 * 4 * H * N, device=d), torch.empty(2 * 4 * H, device=d)
     dev.lstm_cat_ih(w["wih_f"], w["wih_r"], w["bih_f"], w["bhh_f"], w["bih_r"], w["bhh_r"], N, wcat, bcat)
@@ -50,7 +50,7 @@ def _run_new(seq, nb, w, x, d, dbg=0, status=None):
     gh = torch.zeros(dev.blh_floats(nb, 8 * H), device=d)
     c = torch.full((nb, 2 * H // 4, 32, 4), float("nan"), device=d)
     h = torch.full_like(c, float("nan"))
-    tw = dev.lstm_fwd_cluster2(gh, c, h, xn, wcat, bcat, w["whh_f"], w["whh_r"], seq, status=status, dbg=dbg)
+    tw = dev.lstm_fwd_cluster2(gh, c, h, xn, wcat, bcat, w["whh_f"], w["whh_r"], seq, status=status, dbg=dbg, rfmt=rfmt)
     return gh, c, h, tw
 
 
@@ -92,6 +92,40 @@ def test_cluster2_forward_vs_torch_lstm_and_old_cluster(dims):
     g_new, g_old = dev.blh_gates_unpack(gh, nb), dev.blh_gates_unpack(gh0, nb)
     assert float((g_new - g_old).abs().max()) < 2e-3
     assert rel(g_new, g_old) < 3e-4
+
+
+@pytest.mark.parametrize("dims", [(2, 32, 70), (6, 32, 64)])
+def test_cluster2_fp8_lo_term_vs_torch_lstm_and_the_fp16_pair(dims):
+    """ws_lstm_cluster2_args.rfmt = 1 (ABI v20): the lo term of the recurrent product on v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 codes
+    of 256 w - hi, one exponent per wave; e4m3 of h built from the fp16 fragments).  As far from torch's fp64 LSTM as rfmt 0 (fp16 h
+    bounds both), next to rfmt 0 itself, deterministic, and the forced time-out still sets the words."""
+    from wesep_amd import dev
+    d = _cuda()
+    seq, nb, P, w, x = _case(dims, 5, d)
+    R, K, Tf = dims
+    st = torch.zeros(1, device=d, dtype=torch.int32)
+    gh0, c0, h0, _ = _run_new(seq, nb, w, x, d, status=st)
+    gh, c, h, tw = _run_new(seq, nb, w, x, d, status=st, rfmt=1)
+    gh2, c2, h2, tw2 = _run_new(seq, nb, w, x, d, status=st, rfmt=1)
+    torch.cuda.synchronize()
+    assert int(tw.item()) == 0 and int(st.item()) == 0 and not torch.isnan(c).any() and not torch.isnan(h).any()
+    bits = lambda t: t.contiguous().view(torch.int32)
+    assert torch.equal(bits(c), bits(c2)) and torch.equal(bits(h), bits(h2)) and torch.equal(bits(gh), bits(gh2))
+    lstm = torch.nn.LSTM(N, H, batch_first=True, bidirectional=True).double()
+    with torch.no_grad():
+        for nm, src in (("weight_ih_l0", "wih_f"), ("weight_hh_l0", "whh_f"), ("bias_ih_l0", "bih_f"), ("bias_hh_l0", "bhh_f"),
+                        ("weight_ih_l0_reverse", "wih_r"), ("weight_hh_l0_reverse", "whh_r"), ("bias_ih_l0_reverse", "bih_r"),
+                        ("bias_hh_l0_reverse", "bhh_r")):
+            getattr(lstm, nm).copy_(w[src].double().cpu())
+        out, _ = lstm(x.double().cpu().view(R * K, Tf, N))
+    e1 = rel(dev.from_blocked(h, seq, P, split=True).view(R * K, Tf, 2 * H), out)
+    e0 = rel(dev.from_blocked(h0, seq, P, split=True).view(R * K, Tf, 2 * H), out)
+    e10 = rel(dev.bls_unpack(h), dev.bls_unpack(h0))
+    print(f"cluster2 rfmt 1 {dims}: h rel vs torch fp64 {e1:.2e} (rfmt 0: {e0:.2e}); vs rfmt 0: h {e10:.2e}, c {rel(c, c0):.2e}")
+    assert e1 < 1e-3 and e1 < 1.1 * e0 + 1e-5 and e10 < 1e-4 and rel(c, c0) < 1e-4
+    gh, c, h, tw = _run_new(seq, nb, w, x, d, dbg=8, status=st, rfmt=1)
+    torch.cuda.synchronize()
+    assert int(tw.item()) == 1 and int(st.item()) == 1
 
 
 def test_cluster2_forced_timeout_sets_the_words():

@@ -201,6 +201,20 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
         e2, emax = float((got2 - dg).norm() / dg.norm()), float((got2 - dg).abs().max() / dg.abs().max())
         print(f"streaming BPTT rfmt 2: d(gates) vs the three-term kernel rel-L2 {e2:.2e}, max {emax:.2e}")
         assert e2 < 6e-4 and emax < 2e-3, (e2, emax)
+        # rfmt = 3 (ABI v20): the same pack, the lo term on the block-scaled FP8 matrix instruction (codes x e4m3 of d(gates) / 256):
+        # the same statements, and next to rfmt 2 (the term is 2^-12 of the product and keeps 2^-4 of itself)
+        t_in, t_in2, t_out_g, t_out_d = gh.clone(), gh.clone(), gh.clone(), torch.zeros_like(gh)
+        for gates_, dg_ in ((t_in, None), (t_in2, None), (t_out_g, t_out_d)):
+            dev.lstm_bwd(gates_, cbuf, hcat, dh, pb8, seq, mode, gfmt=L.GATES_H2F, dgates=dg_, amax=amax, rfmt=3)
+        torch.cuda.synchronize()
+        assert torch.equal(bits(t_in), bits(t_in2))
+        assert torch.equal(bits(t_out_g), bits(gh)) and torch.equal(bits(t_out_d), bits(t_in))
+        got3 = t_in.reshape(-1)[: ref.numel() // 2].view(torch.float16).view(dg.shape).float() / S
+        assert bool(torch.isfinite(got3).all())
+        e3, e3max = float((got3 - dg).norm() / dg.norm()), float((got3 - dg).abs().max() / dg.abs().max())
+        e32 = float((got3 - got2).norm() / got2.norm())
+        print(f"streaming BPTT rfmt 3: d(gates) vs the three-term kernel rel-L2 {e3:.2e}, max {e3max:.2e}; vs rfmt 2 {e32:.2e}")
+        assert e3 < 6e-4 and e3max < 2e-3 and e32 < 4e-4, (e3, e3max, e32)
         # the pack: hi plane = fp16(256 w), codes finite and <= 256, scales bracket each group's maximum
         raw = pb8.view(torch.uint8).reshape(16, 131072).cpu()
         codes = torch.stack([raw[:, c * 6144 + 4096:(c + 1) * 6144] for c in range(16)], 1).contiguous().view(torch.float8_e4m3fn).float()
@@ -250,8 +264,10 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
     # the statement is a tolerance against the three-term kernel, plus determinism and in-place == out-of-place
     # rfmt = 2 (ABI v18): the same with the lo plane of W_hh as block-scaled FP8 (16 instead of 22 bits of every weight;
     # all of W_hh stays on the CU): the same bounds, and next to rfmt = 1 (same B operand, weights 2^-16 apart)
+    # rfmt = 3 (ABI v20): rfmt 2's codes as operands of the block-scaled FP8 matrix instruction against e4m3 of d(gates) / 256 --
+    # the lo term is 2^-12 of the product and keeps 2^-4 of itself: next to rfmt 2
     by_rfmt = {}
-    for rfmt in (1, 2):
+    for rfmt in (1, 2, 3):
         pp16 = torch.empty(L.LSTM_PACK_FLOATS, device=d)
         dev.lstm_pack_pair(whf, whr, pp16, f16=rfmt)
         r_in, r_in2, r_out_g, r_out_d = gh.clone(), gh.clone(), gh.clone(), torch.zeros_like(gh)
@@ -268,8 +284,9 @@ def test_bptt_kernels_read_unorm16_gates_and_store_bf16(kind, view, dims):
         assert e2 < 6e-4 and emax < 2e-3, (rfmt, e2, emax)
         by_rfmt[rfmt] = got1
     e12 = float((by_rfmt[2] - by_rfmt[1]).norm() / by_rfmt[1].norm())
-    print(f"pair rfmt 2 vs 1: rel-L2 {e12:.2e}")
-    assert e12 < 4e-4, e12
+    e32 = float((by_rfmt[3] - by_rfmt[2]).norm() / by_rfmt[2].norm())
+    print(f"pair rfmt 2 vs 1: rel-L2 {e12:.2e}; 3 vs 2: {e32:.2e}")
+    assert e12 < 4e-4 and e32 < 4e-4, (e12, e32)
 
 
 def test_pair_pack_fp8_lo_plane_reconstructs_the_weights():

@@ -58,8 +58,8 @@ def main():
     # second generation: fp16 h, x-projection fused in (from the fp16 normalised input), data-tagged hand-off
     xn16 = dev.bls_pack(torch.randn(nb, N // 4, 32, 4, device=d))       # (BLS pairs in BL(128))
     wcat, bcat = torch.randn(2 * 4 * H * N, device=d) * 0.08, torch.randn(2 * 4 * H, device=d) * 0.1
-    for dbg, nm in ((0, ""), (1, " (no wait: dbg 1)")):
-        t = timeit(lambda: dev.lstm_fwd_cluster2(gh, cbuf, hcat, xn16, wcat, bcat, whf, whr, seq, status=st, dbg=dbg))
+    for dbg, rf, nm in ((0, 0, ""), (1, 0, " (no wait: dbg 1)"), (0, 1, " FP8 lo term"), (1, 1, " FP8 lo, no wait")):
+        t = timeit(lambda: dev.lstm_fwd_cluster2(gh, cbuf, hcat, xn16, wcat, bcat, whf, whr, seq, status=st, dbg=dbg, rfmt=rf))
         print(f"cluster2 fwd (fp16 h, fused x-proj, tagged){nm:18s} {t:7.3f} ms  {t * 1e3 / Tf:6.2f} us/step", flush=True)
     print("status word after the forward kernels", int(st.item()), flush=True)
     for iobit, ionm in ((0, "output stores on the X-waves after their MFMAs"),):
@@ -68,7 +68,7 @@ def main():
             dbuf = torch.zeros(Tf * 2 * 8 * 2 + 256 * 4 * 2, device=d)   # (+ the per-workgroup wall-clock rows of round 6)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            dev.lstm_fwd_cluster2(gh, cbuf, hcat, xn16, wcat, bcat, whf, whr, seq, status=st, dbg=2048 + iobit, dbg_buf=dbuf)
+            dev.lstm_fwd_cluster2(gh, cbuf, hcat, xn16, wcat, bcat, whf, whr, seq, status=st, dbg=2048 + iobit, dbg_buf=dbuf, rfmt=0)
             e1.record()
             torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
@@ -96,6 +96,8 @@ def main():
     dev.lstm_pack_pair(whf, whr, pp16, f16=True)
     pp8 = torch.empty(L.LSTM_PACK_FLOATS, device=d)
     dev.lstm_pack_pair(whf, whr, pp8, f16=2)
+    pp8mx = torch.empty(L.LSTM_PACK_FLOATS, device=d)
+    dev.lstm_pack_pair(whf, whr, pp8mx, f16=3)
     gq = dev.blh_gates_unpack(gh, nb).view_as(pre).contiguous()
     dgo = torch.zeros_like(gh)
     work = gq.clone()
@@ -107,7 +109,7 @@ def main():
     t = timeit(f32) - t0
     print(f"pair BPTT, fp32 gates in place, bf16x3       {t:7.3f} ms  {t * 1e3 / Tf:6.2f} us/step", flush=True)
     for rf, pk, nm, dbg in ((0, pp, "bf16x3 recurrence", 0), (1, pp16, "fp16x2 recurrence, tagged", 0),
-                            (2, pp8, "fp16x2, FP8 lo plane resident", 0)):
+                            (2, pp8, "fp16x2, FP8 lo plane resident", 0), (3, pp8mx, "fp16 + FP8 MFMA lo term (rfmt 3)", 0)):
         t = timeit(lambda: dev.lstm_bwd_pair(gh, cbuf, dh, pk, seq, status=st, gfmt=L.GATES_H2F, dgates=dgo, amax=amax, rfmt=rf,
                                              dbg=dbg))
         print(f"pair BPTT, unorm16 in / fp16 out, {nm}  {t:7.3f} ms  {t * 1e3 / Tf:6.2f} us/step", flush=True)

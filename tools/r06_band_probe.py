@@ -66,6 +66,7 @@ def main():
     dgo = torch.zeros_like(gh)
     for nm, kw in (("bf16x3 (three terms, 128 KB / wave / step)", dict(wp=pb, rfmt=0)),
                    ("fp16 + FP8 lo (two terms, 96 KB)", dict(wp=pb8, rfmt=2)),
+                   ("fp16 + FP8 lo term on the FP8 MFMA (rfmt 3)", dict(wp=pb8, rfmt=3)),
                    ("fp16 + FP8 lo + d(xn) inside (144 KB)", dict(wp=pb8, rfmt=2, dxn=dxn, wxpack=px))):
         wp = kw.pop("wp")
         t = timeit(lambda: dev.lstm_bwd(gh, cbuf, hcat, dh, wp, seq, mode, gfmt=L.GATES_H2F, dgates=dgo, amax=amax, **kw), n=5)

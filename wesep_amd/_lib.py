@@ -131,7 +131,7 @@ class LstmClusterArgs(C.Structure):
 
 class LstmCluster2Args(C.Structure):
     _fields_ = [(n, _p) for n in ("gates", "cbuf", "hcat", "xn", "wcat", "bcat", "whh_f", "whh_r", "xchg", "tword", "status")] + \
-               [("nseq", _i), ("L", _i), ("dbg", _i), ("pad_", _i), ("dbg_buf", _p)]
+               [("nseq", _i), ("L", _i), ("dbg", _i), ("rfmt", _i), ("dbg_buf", _p)]
 
 
 class LstmPairArgs(C.Structure):
@@ -190,6 +190,7 @@ _SIGS = {
     "ws_lstm_pack_pair": (_i, [_p, _p, _p, _p]),
     "ws_lstm_pack_pair_f16": (_i, [_p, _p, _p, _p]),
     "ws_lstm_pack_pair_f8": (_i, [_p, _p, _p, _p]),
+    "ws_lstm_pack_pair_f8mx": (_i, [_p, _p, _p, _p]),
     "ws_lstm_pack_bwd_f8": (_i, [_p, _p, _p, _p]),
     "ws_lstm_pack_dx_f8": (_i, [_p, _p, _p]),
     "ws_lstm_bwd_pair": (_i, [C.POINTER(LstmPairArgs), _p]),

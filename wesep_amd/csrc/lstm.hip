@@ -407,8 +407,9 @@ static int lstm_check(const ws_lstm_args* a, bool bwd, const char* who) {
              a->gfmt);
   WS_REQUIRE(a->gfmt != WS_GATES_H2S || !bwd || a->dgates, "%s: WS_GATES_H2S needs dgates", who);
   WS_REQUIRE(a->gfmt == WS_GATES_F32 || ((a->mode >> 8) & 7) == 0, "%s: probe builds are WS_GATES_F32 only", who);
-  WS_REQUIRE(a->rfmt == 0 || (a->rfmt == 2 && bwd && a->mode == WS_LSTM_BF16X3_BLK && a->gfmt == WS_GATES_H2F),
-             "%s: rfmt %d (2 = fp16 recurrence on fp16 + FP8 weights: ws_lstm_bwd, WS_LSTM_BF16X3_BLK, WS_GATES_H2F only)", who, a->rfmt);
+  WS_REQUIRE(a->rfmt == 0 || ((a->rfmt == 2 || a->rfmt == 3) && bwd && a->mode == WS_LSTM_BF16X3_BLK && a->gfmt == WS_GATES_H2F),
+             "%s: rfmt %d (2 / 3 = fp16 recurrence on fp16 + FP8 weights, 3: the lo term on the FP8 MFMA: ws_lstm_bwd, "
+             "WS_LSTM_BF16X3_BLK, WS_GATES_H2F only)", who, a->rfmt);
   WS_REQUIRE(!a->dxn || (bwd && a->rfmt == 2 && a->wxpack && a->dxn_dir_stride > 0 && a->dxn_dir_stride < (1ll << 29) && !a->run_if),
              "%s: dxn (d(xn) inside the BPTT, ABI v19) needs rfmt 2, wxpack (ws_lstm_pack_dx_f8), 0 < dxn_dir_stride < 2^29 floats "
              "(32-bit store offsets) and no run_if", who);

@@ -377,6 +377,11 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_bf16_kernel(const ws_lstm_arg
 // scaled-fp16 d(gates) as its one B operand (one LDS image plane) against W_hh as fp16 hi + scaled-FP8 lo of 256 w
 // (lstm_pack_bwd_f8_kernel): two MFMAs per product instead of three and 96 instead of 128 KB streamed per wave and step; the
 // codes become fp16 fragments on the way in (v_cvt_scalef32_pk_f16_fp8 with the group's scale: no separate accumulator scale).
+// RF = 3 (ABI v20): RF = 2's stream and codes with the lo term on v_mfma_scale_f32_32x32x64_f8f6f4 -- a chunk's four 8-byte code
+// units ARE a lane's 32 operand bytes of a K = 64 fragment (the instruction pairs byte b of A's lane (row, half) with byte b of B's
+// lane (seq, half); which column a byte holds is ours to choose), the B operand is e4m3 of the chunk's four fp16 d(gates)
+// fragments / 256, converted in registers, the group's power-of-two scale goes in as the instruction's E8M0 exponent: four fp16
+// MFMAs + one FP8 MFMA at twice the rate per chunk instead of eight (profiles/r06_c20_f8_probe.txt).
 // DX (ABI v19, RF = 2 only): d(xn) = d(gates) W_ih of this direction computed HERE, from the B fragments of the d(gates) image
 // the recurrent product loads anyway: wave w adds the 32 x 32 tile (inputs [32 (w & 3), + 32) x the workgroup's 32 sequences)
 // over the k-steps of its parity (w >> 2) -- 64 more MFMAs per wave and step beside the 128 of d(h): the matrix pipe was idle two
@@ -445,6 +450,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
   bf16x8 wr[2][RF ? 4 : 8];
   u32x2 wq[2][RF ? 4 : 1];   // RF = 2: the FP8 codes of the slot's four k-steps
   float wS[RF ? 8 : 1];      // RF = 2: scale per group of 8 k-steps (uniform)
+  int wE[RF == 3 ? 8 : 1];   // RF = 3: the same scales as E8M0 exponents
   auto wfill = [&](int s, int chunk, int zo) {   // ring slot s <- chunk (4 k-steps) of the stream
     if constexpr (RF != 0) {
 #pragma unroll
@@ -481,6 +487,10 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
     const float* st = p.wpack + (long long)(d * 8 + w) * (64 * 2 * 64 * 4) + 96 * 256;
 #pragma unroll
     for (int g8 = 0; g8 < 8; ++g8) wS[g8] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st[g8])));
+    if constexpr (RF == 3) {
+#pragma unroll
+      for (int g8 = 0; g8 < 8; ++g8) wE[g8] = (__builtin_bit_cast(int, wS[g8]) >> 23) & 255;
+    }
   }
   if constexpr (DX) {
     const float* st = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wxpack) + (long long)(d * 8 + w) * WS_DX_REGION + 48 * 1024);
@@ -600,7 +610,8 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
     const __bf16* blo = &dgl[RF ? 0 : 1][l31 * DROW + 8 * half];
     const __bf16* bhx[2] = {bhi + 16 * kpar, bhi - 16 * kpar};
     f32x16 acc0;  // one accumulator: the other wave of the SIMD fills the dependent-issue gaps
-    f32x16 acc1;  // (RF = 2: the lo terms)
+    f32x16 acc1;  // (RF = 2 / 3: the lo terms)
+    v8i b8;       // RF = 3: e4m3 of the chunk's d(gates) / 256 (|fp16| / 256 < 256: inside e4m3, which has no infinity)
 #pragma unroll
     for (int ch = 0; ch < 16; ++ch) {
       const int s = ch & 1;
@@ -609,7 +620,25 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_bf16_kernel(const ws_lstm_arg
         const int ks = 4 * ch + q;
         // (DX: slot q holds k-step ks ^ kpar -- base bhx[q & 1] = bhi +- 16 kpar, the k-step in the immediate offset)
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>((DX ? bhx[q & 1] : bhi) + 16 * ks);
-        if constexpr (RF != 0) {
+        if constexpr (RF == 3) {
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          typedef short s16x2 __attribute__((ext_vector_type(2)));
+          const f16x8 b16 = __builtin_bit_cast(f16x8, bh), ah16 = __builtin_bit_cast(f16x8, wr[s][q]);
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah16, b16, ks == 0 ? zero : acc0, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            s16x2 c = {0, 0};
+            c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c, f16x2{b16[4 * i], b16[4 * i + 1]}, 256.f, false);
+            c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c, f16x2{b16[4 * i + 2], b16[4 * i + 3]}, 256.f, true);
+            b8[2 * q + i] = __builtin_bit_cast(int, c);
+          }
+          if (q == 3) {
+            const v8i a8 = {(int)wq[s][0][0], (int)wq[s][0][1], (int)wq[s][1][0], (int)wq[s][1][1],
+                            (int)wq[s][2][0], (int)wq[s][2][1], (int)wq[s][3][0], (int)wq[s][3][1]};
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, ch == 0 ? zero : acc1, 0, 0, 0, wE[ch >> 1], 0, 127 + 8);
+          }
+        } else if constexpr (RF != 0) {
           typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
           typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
           const float sg = wS[ch >> 1];
@@ -733,6 +762,10 @@ int ws_launch_lstm_bwd_bf16(const ws_lstm_args* a, hipStream_t s) {
   }
   if (a->rfmt == 2) {   // (lstm_check: WS_LSTM_BF16X3_BLK + WS_GATES_H2F only)
     hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 2>), grid, block, 0, s, *a);
+    return 0;
+  }
+  if (a->rfmt == 3) {   // (the same pack; the lo term on the FP8 matrix instruction)
+    hipLaunchKernelGGL((lstm_bwd_bf16_kernel<true, 0, WS_GATES_H2F, 3>), grid, block, 0, s, *a);
     return 0;
   }
   WS_DBG_DISPATCH(lstm_bwd_bf16_kernel)

@@ -89,7 +89,12 @@ __device__ __forceinline__ bool cluster2_of_block(int ncl, int& c, int& j) {
     __builtin_amdgcn_sched_barrier(0);                                                                              \
   }
 
-template <bool FORCE, bool STAMPS = false>
+// F8 (ws_lstm_cluster2_args.rfmt = 1, ABI v20): the lo term of the recurrent product on v_mfma_scale_f32_32x32x64_f8f6f4 -- the
+// residuals 256 w - hi as e4m3 codes with one exponent per wave (its 32 rows x 256 columns; 32 registers instead of 64) against
+// e4m3 of h built in registers from the fp16 fragments the hi term reads anyway: per 64 columns four fp16 MFMAs + one FP8 MFMA
+// (twice the rate, profiles/r06_c20_f8_probe.txt) instead of eight.  Byte b of a lane's 32 holds column 16 (b >> 3) + 8 (lane >> 5)
+// + (b & 7) of its 64 in BOTH operands (the instruction pairs byte b of A's lane (row, half) with byte b of B's lane (seq, half)).
+template <bool FORCE, bool STAMPS = false, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm_cluster2_args p) {
   __shared__ __attribute__((aligned(16))) _Float16 hl[C2_SEQ * HROW];   // h image [seq][k], one fp16 plane, 33 KB
   __shared__ __attribute__((aligned(16))) bf16x8 wih[4 * 2 * 8 * 64];   // W_ih slice [uo][part][ks][lane], bf16 hi / lo, 64 KB
@@ -111,9 +116,51 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
   const long long gblk = (long long)SQ * 2 * LG, cblk = (long long)SQ * 2 * LH;  // elements per block
 
   // ---- resident W_hh rows: m = lane & 31 -> (gate m >> 3, unit 32j + 8uo + (m & 7)); fp16 hi / lo of 256 w ---------
-  f16x8 wh[16], wl[16];
+  f16x8 wh[16], wl[F8 ? 1 : 16];
+  v8i w8[F8 ? 4 : 1];
+  int sA = 127;
   const int wrow = (n >> 3) * LH + 32 * j + 8 * uo + (n & 7);
-  {
+  if constexpr (F8) {
+    const float* wr = (d ? p.whh_r : p.whh_f) + (long long)wrow * LH + 8 * half;
+    f16x8 m8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      f16x8 lo;   // (fp16 of the residual: good enough to place the exponent -- the codes come from the fp32 residual below)
+      split8h(*reinterpret_cast<const f32x4*>(wr + 16 * ks), *reinterpret_cast<const f32x4*>(wr + 16 * ks + 4), wh[ks], lo);
+      m8 = __builtin_elementwise_max(m8, __builtin_elementwise_abs(lo));      // packed: the halves stay in pairs
+      asm volatile("" : "+v"(wh[ks]));    // the fragment in its four registers NOW (the compiler kept eight unpacked halves per
+      __builtin_amdgcn_sched_barrier(0);  // k-step alive through the whole prologue and spilled 54 of them)
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mx = fmaxf(mx, (float)m8[i]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    int E = mx > 0.f ? ((__float_as_int(mx) >> 23) & 255) - 127 - 7 : 0;    // the largest code in [128, 256]
+    E = max(E, -126);
+    const float inv = __int_as_float((127 - E) << 23);
+    sA = 127 + E;
+    asm volatile("" ::: "memory");    // second pass over the weights, one k-step at a time (nothing of pass 1 stays live but wh)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(wr + 16 * ks), b4 = *reinterpret_cast<const f32x4*>(wr + 16 * ks + 4);
+      const float v[8] = {a4[0], a4[1], a4[2], a4[3], b4[0], b4[1], b4[2], b4[3]};
+      float r8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float s = 256.f * v[i];
+        r8[i] = (s - (float)(_Float16)s) * inv;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int c = 0;
+        c = __builtin_amdgcn_cvt_pk_fp8_f32(r8[4 * i], r8[4 * i + 1], c, false);
+        c = __builtin_amdgcn_cvt_pk_fp8_f32(r8[4 * i + 2], r8[4 * i + 3], c, true);
+        w8[ks >> 2][2 * (ks & 3) + i] = c;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
     const float* wr = (d ? p.whh_r : p.whh_f) + (long long)wrow * LH + 8 * half;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
@@ -233,11 +280,25 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_cluster2_kernel(const ws_lstm
     // ---- G^T tile [4 gates x 8 units][32 seqs] += W_hh slice * h^T -----------------------------------------------------
     {
       const _Float16* hb = &hl[(st * 32 + n) * HROW + 8 * half];
+      v8i b8;
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const f16x8 b = *reinterpret_cast<const f16x8*>(hb + 16 * ks);
         acc0 = mfma16h(wh[ks], b, acc0);
-        acc0 = mfma16h(wl[ks], b, acc0);
+        if constexpr (F8) {
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          typedef short s16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {       // |h| < 1: e4m3 of h itself
+            s16x2 c = {0, 0};
+            c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c, f16x2{b[4 * i], b[4 * i + 1]}, 1.f, false);
+            c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c, f16x2{b[4 * i + 2], b[4 * i + 3]}, 1.f, true);
+            b8[2 * (ks & 3) + i] = __builtin_bit_cast(int, c);
+          }
+          if ((ks & 3) == 3) acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[ks >> 2], b8, acc0, 0, 0, 0, sA, 0, 127);
+        } else {
+          acc0 = mfma16h(wl[ks], b, acc0);
+        }
       }
     }
     if (xrole && step > 0) hbm_out(step_time(step - 1));
@@ -339,7 +400,12 @@ extern "C" int ws_lstm_fwd_cluster2(const ws_lstm_cluster2_args* a, void* stream
   e = hipMemsetAsync(a->tword, 0, sizeof(unsigned), s);
   WS_REQUIRE(e == hipSuccess, "ws_lstm_fwd_cluster2: hipMemsetAsync failed");
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
-  if (a->dbg & 2048) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false, true>), dim3(grid), dim3(512), 0, s, *a);
+  WS_REQUIRE(a->rfmt == 0 || a->rfmt == 1, "ws_lstm_fwd_cluster2: rfmt %d (0: fp16 hi / lo of W_hh; 1: the lo term on the FP8 MFMA)", a->rfmt);
+  if (a->rfmt == 1) {
+    if (a->dbg & 2048) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false, true, true>), dim3(grid), dim3(512), 0, s, *a);
+    else if (a->dbg & 8) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<true, false, true>), dim3(grid), dim3(512), 0, s, *a);
+    else hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false, false, true>), dim3(grid), dim3(512), 0, s, *a);
+  } else if (a->dbg & 2048) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false, true>), dim3(grid), dim3(512), 0, s, *a);
   else if (a->dbg & 8) hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<true>), dim3(grid), dim3(512), 0, s, *a);
   else hipLaunchKernelGGL((lstm_fwd_cluster2_kernel<false>), dim3(grid), dim3(512), 0, s, *a);
   ws_prof_end(WS_PROF_LSTM_FWD, s);

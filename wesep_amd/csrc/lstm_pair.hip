@@ -149,6 +149,65 @@ __global__ __launch_bounds__(512) void lstm_pack_pair_f8_kernel(const float* __r
   }
 }
 
+// RF = 3 (ABI v20): the codes of RF = 2 -- same values, same block exponent S -- laid out as A operands of
+// v_mfma_scale_f32_32x32x64_f8f6f4: eight fragments kb of K = 64 per wave, a lane's 32 bytes as two 16-byte pieces at
+// 32 KB + 2 KB kb + 1 KB piece + lane * 16.  Which of the 64 columns a byte holds is free as long as both operands agree (the
+// instruction only pairs byte b of lane (row, half) of A with byte b of lane (column, half) of B,
+// profiles/r06_c20_f8_probe.txt), and the B operand is built IN REGISTERS from the four fp16 fragments of the chunk's k-steps:
+// bytes 8 i .. 8 i + 7 of a lane = the eight columns 16 (4 kb + i) + 8 (lane >> 5) + j of k-step 4 kb + i -- a lane's 32 bytes
+// are its four 8-byte units of the RF = 2 pack, in order.  S at 48 KB as before; its E8M0 byte (the scale operand of the
+// instruction) as an int behind it.
+__global__ __launch_bounds__(512) void lstm_pack_pair_f8mx_kernel(const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                                   char* __restrict__ out) {
+  __shared__ float red[8];
+  const int blk = blockIdx.x, w = blk & 7, hs = (blk >> 3) & 1, d = blk >> 4;
+  const float* W = d ? whh_r : whh_f;
+  const int mt = w < 4 ? 4 * (1 - hs) + w : 4 * hs + (w - 4);
+  const int tid = threadIdx.x;
+  float v0[16], v1[16], m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, ks = pi >> 8;
+    const int u = 32 * mt + (lane & 31), kl = 16 * ks + 8 * (lane >> 5) + 2 * j2;
+    const int row = (kl >> 7) * LH + 128 * hs + (kl & 127);
+    v0[i] = 256.f * W[row * LH + u];
+    v1[i] = 256.f * W[(row + 1) * LH + u];
+    m = fmaxf(m, fmaxf(fabsf(v0[i]), fabsf(v1[i])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i]);
+  const int eb = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
+  const bool ok = eb > 19 && eb < 255;
+  const float S = ok ? __builtin_bit_cast(float, (unsigned)(eb - 19) << 23) : 1.f;
+  char* ob = out + (long long)blk * (64 * 1024);
+  if (tid == 0) {
+    *reinterpret_cast<float*>(ob + 48 * 1024) = S;
+    *reinterpret_cast<int*>(ob + 48 * 1024 + 4) = ok ? eb - 19 : 127;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int pi = tid + 512 * i, j2 = pi & 3, lane = (pi >> 2) & 63, ks = pi >> 8;
+    const _Float16 h0 = (_Float16)v0[i], h1 = (_Float16)v1[i];
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<f16x2*>(ob + ks * 1024 + lane * 16 + j2 * 4) = f16x2{h0, h1};
+    const s16x2 c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(s16x2{0, 0}, v0[i] - (float)h0, v1[i] - (float)h1, S, false);
+    *reinterpret_cast<short*>(ob + 32 * 1024 + (ks >> 2) * 2048 + ((ks >> 1) & 1) * 1024 + lane * 16 + (ks & 1) * 8 + 2 * j2) = c[0];
+  }
+}
+
+extern "C" int ws_lstm_pack_pair_f8mx(const float* whh_f, const float* whh_r, float* pack, void* stream) {
+  WS_REQUIRE(whh_f && whh_r && pack, "ws_lstm_pack_pair_f8mx: null pointer");
+  hipLaunchKernelGGL(lstm_pack_pair_f8mx_kernel, dim3(32), dim3(512), 0, (hipStream_t)stream, whh_f, whh_r,
+                     reinterpret_cast<char*>(pack));
+  return ws_check_launch("ws_lstm_pack_pair_f8mx");
+}
+
 extern "C" int ws_lstm_pack_pair_f8(const float* whh_f, const float* whh_r, float* pack, void* stream) {
   WS_REQUIRE(whh_f && whh_r && pack, "ws_lstm_pack_pair_f8: null pointer");
   hipLaunchKernelGGL(lstm_pack_pair_f8_kernel, dim3(32), dim3(512), 0, (hipStream_t)stream, whh_f, whh_r,
@@ -223,7 +282,9 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
   constexpr int PAIR_LDSK = pair_ldsk<RF>::value;
   __shared__ __attribute__((aligned(16))) __bf16 bimg[RF ? 1 : 2][SQ * PR_ROW];  // [part][seq][local gate col] 65 / 33 KB
   constexpr int LDSK8 = 27;   // RF = 2: k-steps of the 8-byte lo fragments in LDS (108 KB: what 160 KB leave); 5 in registers
-  __shared__ __attribute__((aligned(16))) bf16x8 whl[RF == 2 ? 4 * LDSK8 * 64 : 8 * PAIR_LDSK * 64];   // lo fragments, 64 / 96 / 108 KB
+  constexpr int LDSB = 6;     // RF = 3: FP8 fragments (K = 64, 2 KB per wave) in LDS (96 KB); 2 in registers (16)
+  constexpr bool RES = RF >= 2;   // all of W_hh resident on the CU: no ring, the next step's state touched early
+  __shared__ __attribute__((aligned(16))) bf16x8 whl[RF == 3 ? 8 * LDSB * 128 : RF == 2 ? 4 * LDSK8 * 64 : 8 * PAIR_LDSK * 64];   // lo fragments, 64 / 96 / 108 / 80 KB
   __shared__ __attribute__((aligned(16))) f32x4 rec[2][512];                // the other role's partial dh, 16 KB
   const int ntile = (p.nseq + SQ - 1) / SQ, npair = 2 * ntile;
   // block -> (pair, member): members of a pair are 8 blocks apart (same XCD under round-robin dispatch)
@@ -276,8 +337,24 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
   bf16x8* wlds = &whl[w * PAIR_LDSK * 64 + lane];
   u32x2* wlds8 = reinterpret_cast<u32x2*>(whl) + w * LDSK8 * 64 + lane;   // RF = 2: 8-byte units
   u32x2 wq[RF == 2 ? 32 - LDSK8 : 1];
+  v8i wq8[RF == 3 ? 8 - LDSB : 1];
+  bf16x8* wlds3 = &whl[w * LDSB * 128 + lane];                           // RF = 3: piece pc of fragment kb at [(2 kb + pc) * 64]
+  int sA = 127;                                                          //         E8M0 exponent of the block's codes
   float wS = 1.f;
-  if constexpr (RF == 2) {
+  if constexpr (RF == 3) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      const i32x4 p0 = *reinterpret_cast<const i32x4*>(wbase + 32 * 1024 + kb * 2048 + lane * 16);
+      const i32x4 p1 = *reinterpret_cast<const i32x4*>(wbase + 32 * 1024 + kb * 2048 + 1024 + lane * 16);
+      if (kb < LDSB) {
+        wlds3[(2 * kb) * 64] = __builtin_bit_cast(bf16x8, p0);
+        wlds3[(2 * kb + 1) * 64] = __builtin_bit_cast(bf16x8, p1);
+      } else {
+        wq8[kb >= LDSB ? kb - LDSB : 0] = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
+    sA = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(wbase + 48 * 1024 + 4));
+  } else if constexpr (RF == 2) {
 #pragma unroll
     for (int ks = 0; ks < LDSK8; ++ks)
       wlds8[ks * 64] = *reinterpret_cast<const u32x2*>(wbase + 32 * 1024 + ks * 512 + lane * 8);
@@ -409,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       emit(pg, 2);
       emit(po, 3);
     }
-    if constexpr (RF == 2) asm volatile("" : "+v"(sink));   // (the touches of the previous step have returned: see touch)
+    if constexpr (RES) asm volatile("" : "+v"(sink));   // (the touches of the previous step have returned: see touch)
     TS(1);
     __syncthreads();  // S1: the d(gates) image of this step is complete; rec is consumed
     TS(2);
@@ -422,11 +499,11 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
     // 0.5 - 1 ms per training step (r05_ab/r05_c1[67]_*).  Tried instead: three touches per chunk over the first half of the
     // MFMA loop (the same within noise); requesting the state ITSELF here (32 registers: no spills once the lo ring is gone,
     // but the B fragments lose their double buffer -- faster alone, 0.9 ms per step slower in the step, r05_c14).
-    if constexpr (RF == 2) touch_step(tn);
+    if constexpr (RES) touch_step(tn);
     // ---- partial dh^T [32 units of this wave's m-tile][32 sequences] = W_hh^T slice * dgates^T ----------------------
     if (xrole) __builtin_amdgcn_s_setprio(1);
     bf16x8 wl[2][PAIR_RING];
-    if constexpr (RF != 2) {
+    if constexpr (!RES) {
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -438,6 +515,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    v8i b8;   // RF = 3: e4m3 of the chunk's d(gates) / 256 (|fp16| / 256 < 256: inside e4m3's range, which has no infinity)
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int s = ch & 1;
@@ -445,6 +523,34 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
       for (int f = 0; f < PAIR_RING; ++f) {
         const int ks = PAIR_RING * ch + f;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bhi + 16 * ks);
+        if constexpr (RF == 3) {
+          // hi term on the fp16 MFMA; behind the fourth k-step of a chunk ONE FP8 MFMA takes the lo term of all 64 columns
+          acc0 = pair_mfma<1>(wh[ks], bh, acc0);
+          {
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            const f16x8 b16 = __builtin_bit_cast(f16x8, bh);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              s16x2 c = {0, 0};
+              c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c, f16x2{b16[4 * i], b16[4 * i + 1]}, 256.f, false);
+              c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c, f16x2{b16[4 * i + 2], b16[4 * i + 3]}, 256.f, true);
+              b8[2 * f + i] = __builtin_bit_cast(int, c);
+            }
+          }
+          if (f == PAIR_RING - 1) {
+            static_assert(PAIR_RING == 4, "a chunk is one K = 64 fragment");
+            v8i a8;
+            if (ch < LDSB) {
+              a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, wlds3[(2 * ch) * 64]), __builtin_bit_cast(i32x4, wlds3[(2 * ch + 1) * 64]),
+                                           0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+              a8 = wq8[ch >= LDSB ? ch - LDSB : 0];
+            }
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc1, 0, 0, 0, sA, 0, 127 + 8);
+          }
+          continue;
+        }
         if constexpr (RF == 2) {
           // (the compiler converts the five register-resident fragments ONCE, in front of the step loop: 20 registers instead
           //  of 10.  Pinning the codes with an empty asm so that they are converted every step measured 11 % slower alone.)
@@ -476,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_pair_kernel(const ws_lstm_pai
           acc0 = mfma32(wh[ks], bl, acc0);
         }
       }
-      if (RF != 2 && ch >= CH0 && ch + 2 < NCH) {
+      if (!RES && ch >= CH0 && ch + 2 < NCH) {
 #pragma unroll
         for (int f = 0; f < PAIR_RING; ++f) wl[s][f] = wload(wrs, wlane + f * 1024, zo + (ch + 2) * (PAIR_RING * 1024));
       }
@@ -621,8 +727,9 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
   WS_REQUIRE(a->gfmt >= WS_GATES_F32 && a->gfmt <= WS_GATES_H2F && (a->gfmt != WS_GATES_H2S || a->dgates) &&
                  (a->gfmt != WS_GATES_H2F || a->amax),
              "ws_lstm_bwd_pair: gfmt %d (WS_GATES_H2S needs dgates, WS_GATES_H2F needs amax)", a->gfmt);
-  WS_REQUIRE(a->rfmt == 0 || ((a->rfmt == 1 || a->rfmt == 2) && a->gfmt == WS_GATES_H2F),
-             "ws_lstm_bwd_pair: rfmt %d (1 / 2 = fp16 recurrence, fp16 + fp16 / fp16 + fp8 weights: WS_GATES_H2F only)", a->rfmt);
+  WS_REQUIRE(a->rfmt == 0 || (a->rfmt >= 1 && a->rfmt <= 3 && a->gfmt == WS_GATES_H2F),
+             "ws_lstm_bwd_pair: rfmt %d (1 / 2 / 3 = fp16 recurrence, fp16 + fp16 / fp16 + fp8 weights / + the lo term on the FP8 "
+             "MFMA: WS_GATES_H2F only)", a->rfmt);
   const int npair = 2 * ((a->nseq + SQ - 1) / SQ);
   static int cus = 0;      // same part on every device of a node; queried once
   if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 0;
@@ -637,6 +744,14 @@ extern "C" int ws_lstm_bwd_pair(const ws_lstm_pair_args* a, void* stream) {
     WS_REQUIRE(e == hipSuccess, "ws_lstm_bwd_pair: hipMemsetAsync failed");
   }
   ws_prof_begin(WS_PROF_LSTM_BWD, s);
+  if (a->rfmt == 3) {
+    // (no stamped build of this variant: with the stamps in, the register allocator spills 128 registers -- not the kernel any more)
+    WS_REQUIRE(!(a->dbg & 2048), "ws_lstm_bwd_pair: cycle stamps (dbg 2048) exist for rfmt 0 .. 2");
+    if (a->dbg & 8) hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2F, 3>), dim3(grid), dim3(512), 0, s, *a);
+    else hipLaunchKernelGGL((lstm_bwd_pair_kernel<0, WS_GATES_H2F, 3>), dim3(grid), dim3(512), 0, s, *a);
+    ws_prof_end(WS_PROF_LSTM_BWD, s);
+    return ws_check_launch("ws_lstm_bwd_pair");
+  }
   if (a->rfmt == 2) {
     if (a->dbg & 8) hipLaunchKernelGGL((lstm_bwd_pair_kernel<8, WS_GATES_H2F, 2>), dim3(grid), dim3(512), 0, s, *a);
     else if (a->dbg & 2048) hipLaunchKernelGGL((lstm_bwd_pair_kernel<2048, WS_GATES_H2F, 2>), dim3(grid), dim3(512), 0, s, *a);

@@ -574,7 +574,13 @@ def lstm_cluster2_on() -> bool:
     return os.environ.get("WESEP_LSTM_CLUSTER2", "1") != "0"
 
 
-def lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0, dbg_buf=None):
+def cluster2_rfmt() -> int:
+    """ws_lstm_cluster2_args.rfmt (ABI v20): 1 (WESEP_CLUSTER2_F8=1) = the lo term of the time view's recurrent product on the
+    block-scaled FP8 matrix instruction; 0 = fp16 hi / lo (round 5)."""
+    return 1 if os.environ.get("WESEP_CLUSTER2_F8", "0") == "1" else 0
+
+
+def lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whh_f, whh_r, sm: SeqMap, status=None, dbg=0, dbg_buf=None, rfmt=None):
     """ws_lstm_fwd_cluster2: gates (unorm16 BLH), cbuf, hcat (BLS) <- the BLSTM forward of the blocked-layout sequences from
     the normalised input xn (BL(128) of BLS pairs: gemm_p2b's A_bl), W_ih / biases as ws_lstm_cat_ih leaves them and the fp32
     W_hh.  Returns the launch's time-out word: pass it as `run_if` to gemm_p2b + lstm_fwd behind this call -- the predicated
@@ -592,6 +598,7 @@ def lstm_fwd_cluster2(gates, cbuf, hcat, xn, wcat, bcat, whh_f, whh_r, sm: SeqMa
     a.xchg, a.tword = C.c_void_p(xchg.data_ptr()), C.c_void_p(tw.data_ptr())
     a.status = C.c_void_p((status if status is not None else sc.status).data_ptr())
     a.nseq, a.L, a.dbg = sm.nseq, sm.L, dbg
+    a.rfmt = cluster2_rfmt() if rfmt is None else rfmt
     a.dbg_buf = C.c_void_p(dbg_buf.data_ptr()) if dbg_buf is not None else None
     u = ALG_LSTM_UNITS or L.LSTM_H     # (as lstm_fwd_fused: unorm16 gates + c + h out, the split-pair input in)
     _alg("lstm_fwd", sm.nseq * sm.L * (2 * u * 16 + 4 * 128), 2 * sm.nseq * sm.L * 2 * 4 * u * (u + 128))
@@ -630,8 +637,10 @@ def lstm_pair_ok(sm: SeqMap, device) -> bool:
 def lstm_pack_pair(whh_f, whh_r, pack, f16=False):
     for n, t in (("whh_f", whh_f), ("whh_r", whh_r), ("pack", pack)):
         _chk(t, n)
-    # f16: the pair BPTT's rfmt -- 0 bf16 hi / lo, 1 fp16 hi / lo of 256 w, 2 fp16 hi + FP8 lo (block-scaled) of 256 w
-    fn = (L.lib().ws_lstm_pack_pair, L.lib().ws_lstm_pack_pair_f16, L.lib().ws_lstm_pack_pair_f8)[int(f16)]
+    # f16: the pair BPTT's rfmt -- 0 bf16 hi / lo, 1 fp16 hi / lo of 256 w, 2 fp16 hi + FP8 lo (block-scaled) of 256 w, 3 the same
+    # codes as operand fragments of the FP8 matrix instruction (ABI v20)
+    fn = (L.lib().ws_lstm_pack_pair, L.lib().ws_lstm_pack_pair_f16, L.lib().ws_lstm_pack_pair_f8,
+          L.lib().ws_lstm_pack_pair_f8mx)[int(f16)]
     L.check(fn(_p(whh_f), _p(whh_r), _p(pack), L.stream_ptr()), "ws_lstm_pack_pair")
 
 

@@ -195,10 +195,10 @@ def pair_rfmt(gfmt) -> int:
     """Arithmetic of the pair BPTT's recurrent product (ws_lstm_pair_args.rfmt): 2 (default with WS_GATES_H2F, ABI v18) = the
     stored scaled-fp16 d(gates) x W_hh as fp16 hi + block-scaled FP8 lo on the fp16 MFMA, two terms, all of W_hh resident on
     the compute unit; WESEP_PAIR_RF=1: fp16 hi / lo, the lo plane streamed (ABI v17); 0: the three-term split-bf16 product of
-    rounds 3-4."""
+    rounds 3-4; 3 (ABI v20): rfmt 2 with the lo term on the block-scaled FP8 matrix instruction (K = 64 at twice the fp16 rate)."""
     rf = int(os.environ.get("WESEP_PAIR_RF", "2"))
-    if rf not in (0, 1, 2):
-        raise ValueError(f"WESEP_PAIR_RF={rf}: 0, 1 or 2")
+    if rf not in (0, 1, 2, 3):
+        raise ValueError(f"WESEP_PAIR_RF={rf}: 0, 1, 2 or 3")
     return rf if gfmt == L.GATES_H2F else 0
 
 
@@ -208,9 +208,9 @@ def band_rfmt(gfmt, lmode) -> int:
     MFMAs per product and three quarters of the weight stream -- the pair BPTT's arithmetic (pair_rfmt); config 2's parity and
     the 60-step trajectory with it: profiles/r06_c1_parity_brf2.log, r05_c23_band_rf2_trajectory.log.  WESEP_BAND_RF=0: the
     three-term split-bf16 product of rounds 1-5."""
-    rf = int(os.environ.get("WESEP_BAND_RF", "2"))
-    if rf not in (0, 2):
-        raise ValueError(f"WESEP_BAND_RF={rf}: 0 or 2")
+    rf = int(os.environ.get("WESEP_BAND_RF", "2"))      # (3, ABI v20: rfmt 2's pack with the lo term on the FP8 matrix instruction)
+    if rf not in (0, 2, 3):
+        raise ValueError(f"WESEP_BAND_RF={rf}: 0, 2 or 3")
     return rf if gfmt == L.GATES_H2F and lmode == L.LSTM_BF16X3_BLK else 0
 
 
