@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = built_lib.lib()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ws_abi_version() == built_lib.ABI_VERSION == 19
+    assert lib.ws_abi_version() == built_lib.ABI_VERSION == 20
 
 
 def test_built_library_has_no_packed_fp32_arithmetic(built_lib):

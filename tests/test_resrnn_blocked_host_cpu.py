@@ -77,7 +77,8 @@ def test_resrnn_blocked_matches_oracle(emu, monkeypatch, view, R, K, Tf, branch,
 
 
 def test_streaming_bptt_arithmetic_and_its_own_input_gradient_reach_the_kernel(emu, monkeypatch):
-    """Round 6: the band view's streaming BPTT runs ws_lstm_args.rfmt = 2 by default (the FP8 pack, ws_lstm_pack_bwd_f8); with
+    """Round 6: the band view's streaming BPTT runs ws_lstm_args.rfmt = 3 by default (the FP8 pack, ws_lstm_pack_bwd_f8, the lo
+    term on the FP8 matrix instruction; rfmt 2 -- both terms on the fp16 MFMA -- under WESEP_BAND_DX=1); with
     WESEP_BAND_DX=1 ("default" below: the opt-in) d(xn) is computed by the BPTT launch itself (ws_lstm_args.dxn +
     ws_lstm_pack_dx_f8, ABI v19: no ws_gemm_b2p over d(gates), the fused GroupNorm backward adds the two directions) -- 32-sequence
     blocked kernels with the default 2-byte format only.  WESEP_BAND_RF=0 restores the three-term product.  Gradients
@@ -109,7 +110,7 @@ def test_streaming_bptt_arithmetic_and_its_own_input_gradient_reach_the_kernel(e
         (out * probe).sum().backward()
         grads[mode] = {"z": z.grad.clone(), **{k: v.grad.clone() for k, v in p.items()}}
         assert (("pack8",) in seen) == (mode != "rf0") and (("packdx",) in seen) == (mode == "default")
-        assert [r[1:] for r in seen if r[0] == "bwd"] == [(0 if mode == "rf0" else 2, mode == "default")]
+        assert [r[1:] for r in seen if r[0] == "bwd"] == [({"rf0": 0, "default": 2, "gemm": 3}[mode], mode == "default")]
         # the d(xn) GEMM over the scaled-fp16 d(gates) (a_fmt 2) runs exactly when the BPTT did not write d(xn) itself
         assert (("b2p", 2) in seen) == (mode != "default")
     for v in p.values():

@@ -1239,11 +1239,13 @@ def lstm_fused_hfmt(gfmt) -> int:
     gate formats) = h as ONE fp16 operand against W_hh as fp16 hi / lo of 256 w on v_mfma_f32_32x32x16_f16, two MFMAs per product
     -- what ws_lstm_fwd_cluster2 runs in the time view since round 5; the x part keeps the three-term split product.
     WESEP_FUSED_H16=0: the three-term product of rounds 1-5 for both parts.
-    Bit 2 (ABI v20, WESEP_FUSED_F8=1; with bit 0: 5): the lo term of that product on the block-scaled FP8 matrix instruction (one
-    K = 64 MFMA at twice the fp16 rate for four K = 16 ones) -- the 64-sequence kernel only (models.tfgridnet masks the bit)."""
+    Bit 2 (ABI v20, default on; with bit 0: 5): the lo term of that product on the block-scaled FP8 matrix instruction (one
+    K = 64 MFMA at twice the fp16 rate for four K = 16 ones; 2.12 -> 1.92 ms per launch alone, 1.3 ms per step:
+    profiles/r06_c21_band_probe.txt, r06_ab/r06_c22_*) -- the 64-sequence kernel only (models.tfgridnet masks the bit).
+    WESEP_FUSED_F8=0: both terms on the fp16 MFMA."""
     if gfmt == L.GATES_F32 or os.environ.get("WESEP_FUSED_H16", "1") == "0":
         return 0
-    return 5 if os.environ.get("WESEP_FUSED_F8", "0") == "1" else 1
+    return 5 if os.environ.get("WESEP_FUSED_F8", "1") != "0" else 1
 
 
 def lstm_pack_fused(wih_f, wih_r, whh_f, whh_r, pack, hfmt=0):

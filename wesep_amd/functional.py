@@ -192,25 +192,29 @@ def tnb_a16() -> bool:
 
 
 def pair_rfmt(gfmt) -> int:
-    """Arithmetic of the pair BPTT's recurrent product (ws_lstm_pair_args.rfmt): 2 (default with WS_GATES_H2F, ABI v18) = the
-    stored scaled-fp16 d(gates) x W_hh as fp16 hi + block-scaled FP8 lo on the fp16 MFMA, two terms, all of W_hh resident on
-    the compute unit; WESEP_PAIR_RF=1: fp16 hi / lo, the lo plane streamed (ABI v17); 0: the three-term split-bf16 product of
-    rounds 3-4; 3 (ABI v20): rfmt 2 with the lo term on the block-scaled FP8 matrix instruction (K = 64 at twice the fp16 rate)."""
-    rf = int(os.environ.get("WESEP_PAIR_RF", "2"))
+    """Arithmetic of the pair BPTT's recurrent product (ws_lstm_pair_args.rfmt): 3 (default with WS_GATES_H2F, ABI v20) = the
+    stored scaled-fp16 d(gates) x W_hh as fp16 hi + block-scaled FP8 lo, all of W_hh resident on the compute unit, the lo term on
+    the block-scaled FP8 matrix instruction (K = 64 at twice the fp16 rate; 0.4 ms per step: profiles/r06_ab/r06_c23_*);
+    WESEP_PAIR_RF=2: the same weights, both terms on the fp16 MFMA (ABI v18, the default of round 5); 1: fp16 hi / lo, the lo
+    plane streamed (ABI v17); 0: the three-term split-bf16 product of rounds 3-4."""
+    rf = int(os.environ.get("WESEP_PAIR_RF", "3"))
     if rf not in (0, 1, 2, 3):
         raise ValueError(f"WESEP_PAIR_RF={rf}: 0, 1, 2 or 3")
     return rf if gfmt == L.GATES_H2F else 0
 
 
 def band_rfmt(gfmt, lmode) -> int:
-    """Arithmetic of the streaming BPTT's recurrent product (ws_lstm_args.rfmt, ABI v18): 2 (the default since round 6, with
-    WS_GATES_H2F on the 32-sequence blocked kernels) = the stored scaled-fp16 d(gates) x W_hh as fp16 hi + scaled-FP8 lo, two
-    MFMAs per product and three quarters of the weight stream -- the pair BPTT's arithmetic (pair_rfmt); config 2's parity and
-    the 60-step trajectory with it: profiles/r06_c1_parity_brf2.log, r05_c23_band_rf2_trajectory.log.  WESEP_BAND_RF=0: the
-    three-term split-bf16 product of rounds 1-5."""
-    rf = int(os.environ.get("WESEP_BAND_RF", "2"))      # (3, ABI v20: rfmt 2's pack with the lo term on the FP8 matrix instruction)
+    """Arithmetic of the streaming BPTT's recurrent product (ws_lstm_args.rfmt): 2 (ABI v18, with WS_GATES_H2F on the 32-sequence
+    blocked kernels) = the stored scaled-fp16 d(gates) x W_hh as fp16 hi + scaled-FP8 lo, two MFMAs per product and three
+    quarters of the weight stream -- the pair BPTT's arithmetic (pair_rfmt); config 2's parity and the 60-step trajectory with
+    it: profiles/r06_c1_parity_brf2.log, r05_c23_band_rf2_trajectory.log.  3 (ABI v20, the default): the same pack with the lo
+    term on the block-scaled FP8 matrix instruction (2.07 -> 1.88 ms per launch alone, 0.6 ms per step:
+    profiles/r06_c26_band_probe.txt, r06_ab/r06_c26_*).  WESEP_BAND_RF=0: the three-term split-bf16 product of rounds 1-5."""
+    rf = int(os.environ.get("WESEP_BAND_RF", "3"))
     if rf not in (0, 2, 3):
         raise ValueError(f"WESEP_BAND_RF={rf}: 0, 2 or 3")
+    if rf == 3 and os.environ.get("WESEP_BAND_DX", "0") == "1":
+        rf = 2                                          # (d(xn) inside the BPTT rides on the fp16 lo term's fragments)
     return rf if gfmt == L.GATES_H2F and lmode == L.LSTM_BF16X3_BLK else 0
 
 
