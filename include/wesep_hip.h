@@ -472,6 +472,11 @@ int ws_pack_w(const float* W, int N, int K, long long ldw, int trans, int order,
  * operand, the scaled-fp16 d(gates) of WS_GATES_H2F, then feeds v_mfma_f32_32x32x16_f16 without conversion).   */
 int ws_pack_w_f16(const float* W, int N, int K, long long ldw, int trans, int order, float* out,
                   void* stream);
+/* ABI v20: the weight operand of ws_gemm_b2p with a_fmt = 3 (N = 128, K % 64 == 0; fits the N*K*4 bytes of the other packs):
+ * per stage of 64 k the sixteen fp16 hi fragments of ws_pack_w_f16, then per column tile one 2 KB operand fragment of
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with the e4m3 codes of the residuals (one exponent per fragment); the exponents (E8M0,
+ * one dword per stage) behind the last stage                                                                          */
+int ws_pack_w_f16f8(const float* W, int N, int K, long long ldw, int trans, float* out, void* stream);
 
 /* plain -> BL:  C[(b,i)][n] = sum_k pro(A[pos(b,i)][k]) * W'[n][k] + bias[n]   (K = 128, N % 64 == 0)
  * pro = optional GroupNorm-on-load as in ws_gemm_nt (stat index computed from pos).  If A_bl is
@@ -510,7 +515,8 @@ typedef struct ws_gemm_b2p_args {
   int N, K;
   int a_fmt, pad_;   /* ABI v15: 0 = A holds BLS pairs (BL(K)); 1 = A holds bf16 elements (BLH(K)): d(gates) of WS_GATES_H2;
                         2 = A holds scaled fp16 elements (BLH(K)): d(gates) of WS_GATES_H2F, scale from `amax`; Wpack
-                        is then a ws_pack_w_f16 pack                                                              */
+                        is then a ws_pack_w_f16 pack.  3 (ABI v20): as 2 with the lo term of the product on
+                        v_mfma_scale_f32_32x32x64_f8f6f4 (Wpack from ws_pack_w_f16f8; e4m3 of A / 256 built in registers) */
   const unsigned* amax;
   void* a16_out;     /* optional (ABI v16, a_fmt 0 only): the A operand once more as fp16 elements in BLH(K) -- every block
                         is read by exactly one wave here, so the copy costs no extra read (hcat -> ws_gemm_tnb a_fmt = 1) */

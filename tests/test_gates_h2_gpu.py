@@ -357,6 +357,19 @@ def test_gemm_b2p_scaled_fp16_operand(view, dims):
     ref = A.double() @ W.double().t()
     assert rel(outs[0], ref) < 1e-5                                # 11-bit operand (exact here) x 22-bit weights, fp32 accumulation
     assert rel(C_ref, ref) < 4e-5 and rel(outs[0], C_ref) < 4e-5
+    # a_fmt = 3 (ABI v20): the lo term on the block-scaled FP8 matrix instruction -- fp16 hi + e4m3 lo fragments of the weights
+    # (ws_pack_w_f16f8), e4m3 of A / 256 built in registers: the term is 2^-12 of the product and keeps 2^-4 of itself
+    wp8 = torch.empty(N * Kd, device=d)
+    dev.pack_w(W.t().contiguous().to(d), N, Kd, N, wp8, trans=True, order=1, f16=2)
+    o3 = []
+    for _ in range(2):
+        C3 = torch.full((P, N), float("nan"), device=d)
+        dev.gemm_b2p(A=Ahbl, K=Kd, sm=seq, Wpack=wp8, C_out=C3, ldc=N, a_fmt=3, amax=amax)
+        o3.append(C3)
+    torch.cuda.synchronize()
+    assert torch.equal(o3[0], o3[1])
+    print(f"gemm_b2p a_fmt 3 ({view}): vs fp64 {rel(o3[0], ref):.2e} (a_fmt 2: {rel(outs[0], ref):.2e}); vs a_fmt 2 {rel(o3[0], outs[0]):.2e}")
+    assert rel(o3[0], ref) < 4e-5 and rel(o3[0], outs[0]) < 4e-5
 
 
 @pytest.mark.parametrize("view,dims", [("time", (2, 5, 11)), ("band", (3, 32, 37))])

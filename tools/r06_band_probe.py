@@ -76,6 +76,12 @@ def main():
     c = torch.zeros(P, N, device=d)
     t = timeit(lambda: dev.gemm_b2p(A=dgo, K=2 * 4 * H, sm=seq, Wpack=wt16, C_out=c, ldc=N, a_fmt=2, amax=amax), n=5)
     print(f"ws_gemm_b2p(a_fmt 2) over the same d(gates) (what d(xn) inside replaces): {t:7.3f} ms")
+    wt8 = torch.empty(N * 2 * 4 * H, device=d)
+    dev.pack_w(wcat, N, 2 * 4 * H, N, wt8, trans=True, order=1, f16=2)
+    c3 = torch.zeros(P, N, device=d)
+    t = timeit(lambda: dev.gemm_b2p(A=dgo, K=2 * 4 * H, sm=seq, Wpack=wt8, C_out=c3, ldc=N, a_fmt=3, amax=amax), n=5)
+    print(f"ws_gemm_b2p(a_fmt 3: the lo term on the FP8 MFMA):                        {t:7.3f} ms; vs a_fmt 2 rel-L2 "
+          f"{float((c3 - c).norm() / c.norm()):.2e}")
     e = float(((dxn[0] + dxn[1]) - c).norm() / c.norm())
     print(f"d(xn) inside vs the GEMM: rel-L2 {e:.2e}")
 

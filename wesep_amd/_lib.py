@@ -170,6 +170,7 @@ _SIGS = {
     "ws_debug_dirty_lds": (_i, [_f, _i, _i, _p, _p]),
     "ws_debug_occupy": (_i, [_i, _i, _p, _p, _p]),
     "ws_pack_w_f16": (_i, [_p, _i, _i, _ll, _i, _i, _p, _p]),
+    "ws_pack_w_f16f8": (_i, [_p, _i, _i, _ll, _i, _p, _p]),
     "ws_gemm_nt": (_i, [C.POINTER(GemmNTArgs), _p]),
     "ws_gemm_tn": (_i, [C.POINTER(GemmTNArgs), _p]),
     "ws_reduce_slabs": (_i, [_p, _i, _ll, _ll, _p, _i, _ll, _p]),

@@ -111,8 +111,11 @@ typedef const __attribute__((address_space(1))) float* gfp;
 // float4 lies inside one tap (C % 4 == 0), so the loader adds the tap's offset to the pixel's base and masks taps that
 // fall outside the image -- the patch matrix (k*k times the activation) never exists in HBM.
 // NB: 32-column blocks per workgroup tile (4 = the 128 x 128 tile with 2 x 2 waves of 64 x 64; 1 / 2 = narrow, above).
+// (launch bounds: the SECOND number is hipcc's minimum of waves per SIMD, not workgroups per CU -- "2" let the 128 x 128 tile take
+//  174 / 184 registers = two workgroups per CU where 40 KB of LDS allow three; at 3 the compiler fits it in 162 without a spill.
+//  The NORM variant would spill 30 registers there and stays at 2.)
 template <bool NORM, bool CONV, int NB>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const ws_gemm_nt_args p) {
+__global__ __launch_bounds__(256, NORM ? 2 : 3) void gemm_nt_bf16_kernel(const ws_gemm_nt_args p) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[4 * BT_PLANE];  // 40 KB
   const float* A_ = p.A;
   const float* W_ = p.W;

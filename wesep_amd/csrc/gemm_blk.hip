@@ -29,6 +29,8 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));   // 32 FP8 operand bytes of v_mfma_scale_f32_32x32x64_f8f6f4
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));  // the operand type of __builtin_amdgcn_fdot2 / cvt_pkrtz
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -159,6 +161,54 @@ extern "C" int ws_pack_w_f16(const float* W, int N, int K, long long ldw, int tr
   hipLaunchKernelGGL(pack_w16_kernel, dim3((N * K / 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, N, K, ldw,
                      trans, order, reinterpret_cast<_Float16*>(out));
   return ws_check_launch("ws_pack_w_f16");
+}
+
+// fp16 hi + FP8 lo variant (ABI v20; N = 128, b2p order): the B operand of ws_gemm_b2p with a_fmt = 3 -- per stage of 64 k (24 KB):
+// the sixteen fp16 hi fragments [ks 4][nt 4][lane] of ws_pack_w_f16, then per column tile nt ONE fragment of
+// v_mfma_scale_f32_32x32x64_f8f6f4 with the e4m3 codes of the residuals 256 w - hi: a lane's 32 bytes = its 8 k of each of the
+// stage's four k-steps in order (byte 8 i + j <-> k = 64 st + 16 i + 8 (lane >> 5) + j: the order the A operand is built in, in
+// registers, from the four fp16 fragments), as two 16-byte pieces [nt][piece][lane]; one exponent per fragment (the largest code in
+// [128, 256)): the E8M0 bytes of a stage's four fragments form one dword behind the last stage (at 24 KB * K / 64).
+__global__ __launch_bounds__(256) void pack_w16f8_kernel(const float* __restrict__ W, int K, long long ldw, int trans,
+                                                         unsigned char* __restrict__ out) {
+  const int st = blockIdx.x, nt = threadIdx.x >> 6, lane = threadIdx.x & 63, n = 32 * nt + (lane & 31);
+  unsigned char* sb = out + (long long)st * 24576;
+  float res[32];
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f16x8 hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 64 * st + 16 * i + 8 * (lane >> 5) + j;
+      const float v = WS_PACK16_SCALE * (trans ? W[(long long)k * ldw + n] : W[(long long)n * ldw + k]);
+      hi[j] = (_Float16)v;
+      res[8 * i + j] = v - (float)hi[j];
+      mx = fmaxf(mx, fabsf(res[8 * i + j]));
+    }
+    reinterpret_cast<f16x8*>(sb)[(i * 4 + nt) * 64 + lane] = hi;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  int E = mx > 0.f ? ((__float_as_int(mx) >> 23) & 255) - 127 - 7 : 0;
+  E = max(E, -126);
+  const float inv = __int_as_float((127 - E) << 23);
+  unsigned int* o8 = reinterpret_cast<unsigned int*>(sb + 16384 + nt * 2048 + lane * 16);
+#pragma unroll
+  for (int j = 0; j < 32; j += 4) {
+    int c = 0;
+    c = __builtin_amdgcn_cvt_pk_fp8_f32(res[j] * inv, res[j + 1] * inv, c, false);
+    c = __builtin_amdgcn_cvt_pk_fp8_f32(res[j + 2] * inv, res[j + 3] * inv, c, true);
+    o8[(j >> 4) * 256 + ((j & 15) >> 2)] = (unsigned int)c;
+  }
+  if (lane == 0) (out + (long long)(K / 64) * 24576)[st * 4 + nt] = (unsigned char)(127 + E);
+}
+
+extern "C" int ws_pack_w_f16f8(const float* W, int N, int K, long long ldw, int trans, float* out, void* stream) {
+  WS_REQUIRE(W && out && N == 128 && K > 0 && K % 64 == 0, "ws_pack_w_f16f8: N = 128, K %% 64 (N=%d K=%d)", N, K);
+  hipLaunchKernelGGL(pack_w16f8_kernel, dim3(K / 64), dim3(256), 0, (hipStream_t)stream, W, K, ldw, trans,
+                     reinterpret_cast<unsigned char*>(out));
+  return ws_check_launch("ws_pack_w_f16f8");
 }
 
 extern "C" int ws_pack_w(const float* W, int N, int K, long long ldw, int trans, int order, float* out,
@@ -325,8 +375,15 @@ extern "C" int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream) {
 // is a ws_pack_w_f16 pack (fp16 hi / lo of 256 w): the A cells ARE the MFMA fragments (no conversion) and a product is
 // a (w_hi + w_lo) on v_mfma_f32_32x32x16_f16 -- the operand's 11 bits times the weight's 22; the epilogue multiplies by
 // 1 / (256 S) (a power of two: exact).
+// A16 = 3 (a_fmt = 3, ABI v20): a_fmt 2 with the lo term on v_mfma_scale_f32_32x32x64_f8f6f4 -- Wpack from ws_pack_w_f16f8 (24 KB
+// per stage through LDS instead of 32), the A operand of the term = e4m3 of the stage's four fp16 fragments / 256, converted in
+// registers: per stage and column tile four fp16 MFMAs + one FP8 MFMA (K = 64, twice the rate) instead of eight.
+// (launch bounds: the SECOND number is hipcc's minimum of waves per SIMD, not workgroups per CU.  With "2" the a_fmt 2 kernel took
+//  129 registers -- three waves per SIMD, i.e. ONE 512-thread workgroup per CU where 66 KB of LDS allow two; at 4 the compiler fits
+//  it in 128 without a spill: 0.69 -> 0.58 ms per launch alone, 4.5 ms per training step (profiles/r06_c28_*).  The other formats
+//  would spill at 128 (a_fmt 0: 76 registers, a_fmt 3: 33) and stay at one workgroup.)
 template <int A16>
-__global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args p) {
+__global__ __launch_bounds__(512, A16 == 2 ? 4 : 2) void gemm_b2p_kernel(const ws_gemm_b2p_args p) {
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][2048];
   __shared__ long long posl[8][32];
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
@@ -345,20 +402,23 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
   // units of half a cell-element pair: floats for BLS, 2-byte elements viewed through the same index formula for A16)
   typedef typename std::conditional<A16 != 0, u32x2, f32x4>::type acell;
   typedef typename std::conditional<A16 != 0, unsigned short, float>::type aelem;
-  const float inv_s = A16 == 2 ? ws_dgates_scale_inv(*p.amax) * (1.f / WS_PACK16_SCALE) : 1.f;
+  constexpr int SU = A16 == 3 ? 1536 : 2048, NQ = SU / 512;    // 16-byte units of a weight stage; per thread
+  const int* wsc = reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(p.Wpack) + (long long)nstage * 24576);
+  int sc_n = A16 == 3 ? wsc[0] : 0;                            // A16 = 3: the four fragment exponents of the next stage
+  const float inv_s = A16 >= 2 ? ws_dgates_scale_inv(*p.amax) * (1.f / WS_PACK16_SCALE) : 1.f;
   const aelem* ab = reinterpret_cast<const aelem*>(p.A) + (long long)bb * 32 * K + i * 4 + 2 * half * 128;
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.Wpack);
   u32x4 wreg[4];
   acell an[8];  // next stage's activations (4 k-steps x 2 cells)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) wreg[q] = wsrc[tid + 512 * q];
+  for (int q = 0; q < NQ; ++q) wreg[q] = wsrc[tid + 512 * q];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     an[2 * ks] = *reinterpret_cast<const acell*>(ab + (4 * ks) * 128);
     an[2 * ks + 1] = *reinterpret_cast<const acell*>(ab + (4 * ks + 1) * 128);
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) wl[0][tid + 512 * q] = wreg[q];
+  for (int q = 0; q < NQ; ++q) wl[0][tid + 512 * q] = wreg[q];
   __syncthreads();
 
   f32x16 acc[4];
@@ -372,9 +432,12 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
     acell ac[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) ac[q] = an[q];
+    const int sc = __builtin_amdgcn_readfirstlane(sc_n);
+    v8i a8;   // A16 = 3: e4m3 of the stage's A fragments / 256
     if (st + 1 < nstage) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) wreg[q] = wsrc[(long long)(st + 1) * 2048 + tid + 512 * q];
+      for (int q = 0; q < NQ; ++q) wreg[q] = wsrc[(long long)(st + 1) * SU + tid + 512 * q];
+      if constexpr (A16 == 3) sc_n = wsc[st + 1];
       const aelem* a2 = ab + (long long)(st + 1) * 16 * 128;  // 16 quads per stage
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -388,6 +451,33 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
       if constexpr (A16 == 1) {
         const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ks]), c1 = __builtin_bit_cast(u32x2, ac[2 * ks + 1]);
         ah = __builtin_bit_cast(bf16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
+      } else if constexpr (A16 == 3) {
+        const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ks]), c1 = __builtin_bit_cast(u32x2, ac[2 * ks + 1]);
+        const f16x8 a16 = __builtin_bit_cast(f16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {     // (|fp16| / 256 < 256: inside e4m3, which has no infinity)
+          s16x2 c = {0, 0};
+          c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c, f16x2{a16[4 * h2], a16[4 * h2 + 1]}, 256.f, false);
+          c = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c, f16x2{a16[4 * h2 + 2], a16[4 * h2 + 3]}, 256.f, true);
+          a8[2 * ks + h2] = __builtin_bit_cast(int, c);
+        }
+        const u32x4* wt = &wl[cur][ks * 256 + lane];  // hi fragments [ks][nt][lane]
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16, __builtin_bit_cast(f16x8, wt[nt * 64]), acc[nt], 0, 0, 0);
+        if (ks == 3) {
+          const u32x4* w8 = &wl[cur][1024 + lane];    // FP8 fragments [nt][piece][lane]
+          auto frag = [&](int nt) {
+            return __builtin_shufflevector(__builtin_bit_cast(i32x4, w8[(2 * nt) * 64]), __builtin_bit_cast(i32x4, w8[(2 * nt + 1) * 64]),
+                                           0, 1, 2, 3, 4, 5, 6, 7);
+          };
+          acc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, frag(0), acc[0], 0, 0, 0, 127 + 8, 0, sc);
+          acc[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, frag(1), acc[1], 0, 0, 0, 127 + 8, 1, sc);
+          acc[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, frag(2), acc[2], 0, 0, 0, 127 + 8, 2, sc);
+          acc[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, frag(3), acc[3], 0, 0, 0, 127 + 8, 3, sc);
+        }
+        continue;
       } else if constexpr (A16 == 2) {
         const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ks]), c1 = __builtin_bit_cast(u32x2, ac[2 * ks + 1]);
         const f16x8 a16 = __builtin_bit_cast(f16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
@@ -427,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
     }
     if (st + 1 < nstage) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) wl[cur ^ 1][tid + 512 * q] = wreg[q];
+      for (int q = 0; q < NQ; ++q) wl[cur ^ 1][tid + 512 * q] = wreg[q];
     }
     __syncthreads();
   }
@@ -447,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-        stg[m * 64 + t * 32 + i] = (A16 == 2 ? acc[nt][r] * inv_s : acc[nt][r]) + bv;
+        stg[m * 64 + t * 32 + i] = (A16 >= 2 ? acc[nt][r] * inv_s : acc[nt][r]) + bv;
       }
     }
     __syncthreads();  // (uniform: every wave runs both passes; only the wave's own 8 KB are exchanged)
@@ -476,14 +566,17 @@ __global__ __launch_bounds__(512, 2) void gemm_b2p_kernel(const ws_gemm_b2p_args
 extern "C" int ws_gemm_b2p(const ws_gemm_b2p_args* a, void* stream) {
   WS_REQUIRE(a && a->A && a->Wpack && a->C, "ws_gemm_b2p: null pointer");
   WS_REQUIRE(a->N == 128, "ws_gemm_b2p: N must be 128 (got %d)", a->N);
-  WS_REQUIRE(a->a_fmt >= 0 && a->a_fmt <= 2 && (a->a_fmt != 2 || a->amax), "ws_gemm_b2p: a_fmt %d (2 needs amax)", a->a_fmt);
+  WS_REQUIRE(a->a_fmt >= 0 && a->a_fmt <= 3 && (a->a_fmt < 2 || a->amax), "ws_gemm_b2p: a_fmt %d (2 / 3 need amax)", a->a_fmt);
+  WS_REQUIRE(a->a_fmt != 3 || !a->a16_out, "ws_gemm_b2p: a16_out goes with a_fmt 0");
   WS_REQUIRE(a->K > 0 && a->K % 64 == 0, "ws_gemm_b2p: K %% 64 (K=%d)", a->K);
   WS_REQUIRE(a->ldc >= a->N && a->ldc % 4 == 0, "ws_gemm_b2p: ldc >= N and ldc %% 4 == 0 (16-byte row pieces)");
   WS_REQUIRE(a->sm.nseq > 0 && a->sm.L > 0 && a->sm.sq_div > 0, "ws_gemm_b2p: bad sequence map");
   const int nblk = ((a->sm.nseq + 31) / 32) * a->sm.L;
   hipStream_t s = (hipStream_t)stream;
   ws_prof_begin(WS_PROF_GEMM_NT, s);
-  if (a->a_fmt == 2)
+  if (a->a_fmt == 3)
+    hipLaunchKernelGGL(gemm_b2p_kernel<3>, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
+  else if (a->a_fmt == 2)
     hipLaunchKernelGGL(gemm_b2p_kernel<2>, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);
   else if (a->a_fmt == 1)
     hipLaunchKernelGGL(gemm_b2p_kernel<1>, dim3((nblk + 7) / 8), dim3(512), 0, s, *a);

@@ -925,11 +925,17 @@ def _smc(sm: SeqMap):
 
 
 def pack_w(W, N: int, K: int, ldw: int, out, trans=False, order=0, w_off=0, f16=False):
-    """f16: fp16 hi / lo of 256 W (ws_pack_w_f16): the weight operand of gemm_b2p with a_fmt = 2."""
+    """f16: fp16 hi / lo of 256 W (ws_pack_w_f16): the weight operand of gemm_b2p with a_fmt = 2; f16 = 2: fp16 hi + e4m3 lo
+    fragments (ws_pack_w_f16f8): a_fmt = 3."""
     _chk(W, "W")
     _chk(out, "out")
     if out.numel() < N * K:
         raise L.WesepHipError("pack_w: output too small")
+    if int(f16) == 2:     # fp16 hi + FP8 lo fragments (ws_pack_w_f16f8, ABI v20): gemm_b2p with a_fmt = 3; b2p order only
+        if order != 1:
+            raise L.WesepHipError("pack_w: the fp16 + FP8 pack exists in the b2p order only")
+        L.check(L.lib().ws_pack_w_f16f8(_p(W, w_off), N, K, ldw, int(trans), _p(out), L.stream_ptr()), "ws_pack_w_f16f8")
+        return
     fn = L.lib().ws_pack_w_f16 if f16 else L.lib().ws_pack_w
     L.check(fn(_p(W, w_off), N, K, ldw, int(trans), order, _p(out), L.stream_ptr()), "ws_pack_w_f16" if f16 else "ws_pack_w")
 

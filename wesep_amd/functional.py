@@ -203,6 +203,17 @@ def pair_rfmt(gfmt) -> int:
     return rf if gfmt == L.GATES_H2F else 0
 
 
+def dxn_fmt(g_fmt) -> int:
+    """a_fmt of the d(xn) GEMM over the 2-byte d(gates) (ws_gemm_b2p): with scaled-fp16 d(gates) (g_fmt 2) 3 = the lo term of the
+    product on the block-scaled FP8 matrix instruction (ABI v20; WESEP_DXN_F8=1), else the format itself (2: both terms on the
+    fp16 MFMA)."""
+    return 3 if g_fmt == 2 and os.environ.get("WESEP_DXN_F8", "0") == "1" else g_fmt
+
+
+def _wiht_kind(g_fmt) -> str:
+    return {0: "wihT", 1: "wihT", 2: "wihT16", 3: "wihT8"}[dxn_fmt(g_fmt)]
+
+
 def band_rfmt(gfmt, lmode) -> int:
     """Arithmetic of the streaming BPTT's recurrent product (ws_lstm_args.rfmt): 2 (ABI v18, with WS_GATES_H2F on the 32-sequence
     blocked kernels) = the stored scaled-fp16 d(gates) x W_hh as fp16 hi + scaled-FP8 lo, two MFMAs per product and three
@@ -525,7 +536,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             W("projT")
             bdx = ctx.bptt == "stream" and band_dx(band_rfmt(gfmt, lmode), seq, geo)
             if not bdx:
-                W("wihT16" if gfmt == L.GATES_H2F else "wihT")
+                W(_wiht_kind(2 if gfmt == L.GATES_H2F else 0))
             if ctx.bptt == "pair":
                 W("hhp16" if pair_rfmt(gfmt) else "hhp")
             if (ctx.bptt == "stream" and not band_rfmt(gfmt, lmode)) or (ctx.bptt == "pair" and h2):
@@ -694,8 +705,7 @@ class ResRNNBlkFn(torch.autograd.Function):
             dxn, dxn_r = dxn2[0], dxn2[1]
         else:
             dxn, dxn_r = _empty(d, P, N), None
-            dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=W("wihT16" if g_fmt == 2 else "wihT"), C_out=dxn, ldc=N, a_fmt=g_fmt,
-                         amax=amax)
+            dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=W(_wiht_kind(g_fmt)), C_out=dxn, ldc=N, a_fmt=dxn_fmt(g_fmt), amax=amax)
         dz = torch.empty_like(z)
         # (dgamma, dbeta): summed by the LAST workgroup of the kernel that produced the partials (wesep_hip.h, ABI v15) --
         # a separate ws_reduce_slabs launch on this stream can sit out a whole weight-gradient GEMM of the side stream
@@ -802,9 +812,9 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
             out = _empty(d, 2 * G4 * N)
             dev.pack_w(W("cat")[0], 2 * G4, N, N, out, order=0)
             return out
-        if kind in ("wihT", "wihT16"):     # wihT16: fp16 hi / lo (ws_pack_w_f16): d(xn) from scaled-fp16 d(gates), WS_GATES_H2F
-            out = _empty(d, N * 2 * G4)
-            dev.pack_w(W("cat")[0], N, 2 * G4, N, out, trans=True, order=1, f16=kind == "wihT16")
+        if kind in ("wihT", "wihT16", "wihT8"):   # wihT16: fp16 hi / lo (ws_pack_w_f16): d(xn) from scaled-fp16 d(gates), WS_GATES_H2F
+            out = _empty(d, N * 2 * G4)              # wihT8: fp16 hi + FP8 lo fragments (ws_pack_w_f16f8, a_fmt 3)
+            dev.pack_w(W("cat")[0], N, 2 * G4, N, out, trans=True, order=1, f16={"wihT": 0, "wihT16": 1, "wihT8": 2}[kind])
             return out
         if kind == "pw":
             return proj_w.contiguous()
