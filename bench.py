@@ -179,13 +179,14 @@ def mfma_terms_census():
     # (1.5: fp16 hi term + the lo term on v_mfma_scale_f32_32x32x64_f8f6f4 -- the same multiply-adds at twice the fp16 rate, so it
     #  counts as HALF a term against the fp16 peak the line prices everything at; ABI v20)
     hf, prf, brf = dev.lstm_fused_hfmt(gf), F.pair_rfmt(gf), F.band_rfmt(gf, L.LSTM_BF16X3_BLK)
+    dxn = ((1.5 if F.dxn_fmt(2) == 3 else 2) if h2f else 3)
     terms = {
         "time": {"x_proj": 3, "recur_fwd": (1.5 if dev.cluster2_rfmt() else 2) if c2 else 3, "proj": 3, "d_hcat": 3,
                  "bptt": {0: 3, 1: 2, 2: 2, 3: 1.5}[prf],
-                 "dW_lstm": (1 if F.tnb_a16() else 2) if h2f else 3, "d_xn": 2 if h2f else 3, "dW_proj": 3},
+                 "dW_lstm": (1 if F.tnb_a16() else 2) if h2f else 3, "d_xn": dxn, "dW_proj": 3},
         "band": {"x_proj": 3, "recur_fwd": 1.5 if hf & 4 else 2 if hf else 3, "proj": 3, "d_hcat": 3,
                  "bptt": {0: 3, 2: 2, 3: 1.5}[brf],
-                 "dW_lstm": (1 if F.tnb_a16() else 2) if h2f else 3, "d_xn": 2 if h2f else 3, "dW_proj": 3},
+                 "dW_lstm": (1 if F.tnb_a16() else 2) if h2f else 3, "d_xn": dxn, "dW_proj": 3},
     }
     tot = sum(kn.values())
     per_view = {v: sum(kn[k] * t[k] for k in kn) / tot for v, t in terms.items()}
@@ -406,7 +407,7 @@ def main():
     dom_terms = 0.5 * ((tv["bptt"] + bv["bptt"]) if dom == "lstm_bwd" else (tv["recur_fwd"] + bv["recur_fwd"]))
     band2 = bv["bptt"] <= 2 and bv["recur_fwd"] <= 2
     f8 = [n for n, v in (("band forward", bv["recur_fwd"]), ("band BPTT", bv["bptt"]), ("time-view forward", tv["recur_fwd"]),
-                         ("pair BPTT", tv["bptt"])) if v == 1.5]
+                         ("pair BPTT", tv["bptt"]), ("d(xn)", tv["d_xn"])) if v == 1.5]
     arith = (("bf16x3 (x-projections, projections, d(hcat), BN / mask GEMMs) + fp16x2 (recurrent products of all four "
               "recurrence kernels, d(xn))" if band2 else
               "bf16x3 (band-view recurrences, x-projections, projections, d(hcat), BN / mask GEMMs) + fp16x2 (recurrent "

@@ -378,12 +378,13 @@ extern "C" int ws_gemm_p2b(const ws_gemm_p2b_args* a, void* stream) {
 // A16 = 3 (a_fmt = 3, ABI v20): a_fmt 2 with the lo term on v_mfma_scale_f32_32x32x64_f8f6f4 -- Wpack from ws_pack_w_f16f8 (24 KB
 // per stage through LDS instead of 32), the A operand of the term = e4m3 of the stage's four fp16 fragments / 256, converted in
 // registers: per stage and column tile four fp16 MFMAs + one FP8 MFMA (K = 64, twice the rate) instead of eight.
-// (launch bounds: the SECOND number is hipcc's minimum of waves per SIMD, not workgroups per CU.  With "2" the a_fmt 2 kernel took
-//  129 registers -- three waves per SIMD, i.e. ONE 512-thread workgroup per CU where 66 KB of LDS allow two; at 4 the compiler fits
-//  it in 128 without a spill: 0.69 -> 0.58 ms per launch alone, 4.5 ms per training step (profiles/r06_c28_*).  The other formats
-//  would spill at 128 (a_fmt 0: 76 registers, a_fmt 3: 33) and stay at one workgroup.)
+// (launch bounds: the SECOND number is hipcc's minimum of waves per SIMD, not workgroups per CU.  With "2" (rounds 1-5) the kernel took
+//  129 .. 168 registers -- three waves per SIMD, i.e. ONE 512-thread workgroup per CU where 66 KB of LDS allow two.  Round 6: "4" =
+//  128 registers; a_fmt 2 fits as it was (0.69 -> 0.58 ms per launch alone, 4.5 ms per training step: profiles/r06_c28_*), the
+//  other formats once the weight stages go to LDS without a register stop and a_fmt 0's activations are requested half a stage
+//  ahead -- no spills in any of the four.)
 template <int A16>
-__global__ __launch_bounds__(512, A16 == 2 ? 4 : 2) void gemm_b2p_kernel(const ws_gemm_b2p_args p) {
+__global__ __launch_bounds__(512, 4) void gemm_b2p_kernel(const ws_gemm_b2p_args p) {
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][2048];
   __shared__ long long posl[8][32];
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
@@ -407,18 +408,31 @@ __global__ __launch_bounds__(512, A16 == 2 ? 4 : 2) void gemm_b2p_kernel(const w
   int sc_n = A16 == 3 ? wsc[0] : 0;                            // A16 = 3: the four fragment exponents of the next stage
   const float inv_s = A16 >= 2 ? ws_dgates_scale_inv(*p.amax) * (1.f / WS_PACK16_SCALE) : 1.f;
   const aelem* ab = reinterpret_cast<const aelem*>(p.A) + (long long)bb * 32 * K + i * 4 + 2 * half * 128;
-  const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.Wpack);
-  u32x4 wreg[4];
-  acell an[8];  // next stage's activations (4 k-steps x 2 cells)
+  // weight stages: global -> LDS without a register stop (buffer_load ... lds: lane l of a wave lands at base + 16 l) -- the
+  // 12 / 16 registers a stage used to wait in are what keeps the other formats from a second workgroup per CU
+  const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wpack), 0, (unsigned)nstage * SU * 16u,
+                                                                        0x00020000);
+  auto wstage = [&](int st, int buf) {   // this wave's share of stage st: units w * 64 * NQ + 64 q + lane
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) wreg[q] = wsrc[tid + 512 * q];
+    for (int q = 0; q < NQ; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wsr, (__attribute__((address_space(3))) void*)&wl[buf][(w * NQ + q) * 64], 16, lane * 16,
+                                               (st * SU + (w * NQ + q) * 64) * 16, 0, 0);
+  };
+  // activations: requested one stage ahead -- the 16-byte cells of a_fmt 0 half a stage ahead (two k-steps: 16 registers in flight
+  // instead of 32, with the stage's 32 the difference between one and two workgroups per CU)
+  constexpr int HS = A16 == 0 ? 2 : 1, KH = 4 / HS;   // halves per stage; k-steps per half
+  acell an[2 * KH];
+  auto load_a = [&](int st, int hs) {
+    const aelem* a2 = ab + ((long long)st * 16 + hs * KH * 4) * 128;  // 16 quads per stage
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    an[2 * ks] = *reinterpret_cast<const acell*>(ab + (4 * ks) * 128);
-    an[2 * ks + 1] = *reinterpret_cast<const acell*>(ab + (4 * ks + 1) * 128);
-  }
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) wl[0][tid + 512 * q] = wreg[q];
+    for (int ks = 0; ks < KH; ++ks) {
+      an[2 * ks] = *reinterpret_cast<const acell*>(a2 + (4 * ks) * 128);
+      an[2 * ks + 1] = *reinterpret_cast<const acell*>(a2 + (4 * ks + 1) * 128);
+    }
+  };
+  wstage(0, 0);
+  load_a(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   f32x16 acc[4];
@@ -429,30 +443,28 @@ __global__ __launch_bounds__(512, A16 == 2 ? 4 : 2) void gemm_b2p_kernel(const w
 
   for (int st = 0; st < nstage; ++st) {
     const int cur = st & 1;
-    acell ac[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) ac[q] = an[q];
     const int sc = __builtin_amdgcn_readfirstlane(sc_n);
     v8i a8;   // A16 = 3: e4m3 of the stage's A fragments / 256
-    if (st + 1 < nstage) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) wreg[q] = wsrc[(long long)(st + 1) * SU + tid + 512 * q];
+    for (int hs = 0; hs < HS; ++hs) {
+    acell ac[2 * KH];
+#pragma unroll
+    for (int q = 0; q < 2 * KH; ++q) ac[q] = an[q];
+    if (hs == 0 && st + 1 < nstage) {
+      wstage(st + 1, cur ^ 1);     // (the other buffer: last read one stage ago, behind that stage's barrier)
       if constexpr (A16 == 3) sc_n = wsc[st + 1];
-      const aelem* a2 = ab + (long long)(st + 1) * 16 * 128;  // 16 quads per stage
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        an[2 * ks] = *reinterpret_cast<const acell*>(a2 + (4 * ks) * 128);
-        an[2 * ks + 1] = *reinterpret_cast<const acell*>(a2 + (4 * ks + 1) * 128);
-      }
     }
+    if (hs + 1 < HS) load_a(st, hs + 1);
+    else if (st + 1 < nstage) load_a(st + 1, 0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ksl = 0; ksl < KH; ++ksl) {
+      const int ks = hs * KH + ksl;
       bf16x8 ah, al;  // A arrives as split pairs (BLS): h from the recurrences, d(gates) from BPTT -- or as bf16 (A16)
       if constexpr (A16 == 1) {
-        const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ks]), c1 = __builtin_bit_cast(u32x2, ac[2 * ks + 1]);
+        const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ksl]), c1 = __builtin_bit_cast(u32x2, ac[2 * ksl + 1]);
         ah = __builtin_bit_cast(bf16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
       } else if constexpr (A16 == 3) {
-        const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ks]), c1 = __builtin_bit_cast(u32x2, ac[2 * ks + 1]);
+        const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ksl]), c1 = __builtin_bit_cast(u32x2, ac[2 * ksl + 1]);
         const f16x8 a16 = __builtin_bit_cast(f16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
         typedef short s16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(512, A16 == 2 ? 4 : 2) void gemm_b2p_kernel(const w
         }
         continue;
       } else if constexpr (A16 == 2) {
-        const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ks]), c1 = __builtin_bit_cast(u32x2, ac[2 * ks + 1]);
+        const u32x2 c0 = __builtin_bit_cast(u32x2, ac[2 * ksl]), c1 = __builtin_bit_cast(u32x2, ac[2 * ksl + 1]);
         const f16x8 a16 = __builtin_bit_cast(f16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
         const u32x4* wt = &wl[cur][ks * 512 + lane];  // [nt][part][lane]
 #pragma unroll
@@ -489,13 +501,13 @@ __global__ __launch_bounds__(512, A16 == 2 ? 4 : 2) void gemm_b2p_kernel(const w
         }
         continue;
       } else {
-        unpack8(__builtin_bit_cast(u32x4, ac[2 * ks]), __builtin_bit_cast(u32x4, ac[2 * ks + 1]), ah, al);
+        unpack8(__builtin_bit_cast(u32x4, ac[2 * ksl]), __builtin_bit_cast(u32x4, ac[2 * ksl + 1]), ah, al);
         if (p.a16_out && active) {  // the operand once more as fp16 in BLH(K) (ABI v16): hi + lo is the fp32 value
           unsigned short* o16 = reinterpret_cast<unsigned short*>(p.a16_out) + (long long)bb * 32 * K + i * 4 +
                                 (long long)(st * 16 + 4 * ks + 2 * half) * 128;
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
-            const u32x4 cell = __builtin_bit_cast(u32x4, ac[2 * ks + c]);
+            const u32x4 cell = __builtin_bit_cast(u32x4, ac[2 * ksl + c]);
             _Float16 h[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -515,10 +527,8 @@ __global__ __launch_bounds__(512, A16 == 2 ? 4 : 2) void gemm_b2p_kernel(const w
         acc[nt] = mfma32(ah, bl, acc[nt]);
       }
     }
-    if (st + 1 < nstage) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) wl[cur ^ 1][tid + 512 * q] = wreg[q];
-    }
+    }   // hs
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage's weights have landed (and its activations: needed anyway)
     __syncthreads();
   }
 

@@ -205,9 +205,9 @@ def pair_rfmt(gfmt) -> int:
 
 def dxn_fmt(g_fmt) -> int:
     """a_fmt of the d(xn) GEMM over the 2-byte d(gates) (ws_gemm_b2p): with scaled-fp16 d(gates) (g_fmt 2) 3 = the lo term of the
-    product on the block-scaled FP8 matrix instruction (ABI v20; WESEP_DXN_F8=1), else the format itself (2: both terms on the
-    fp16 MFMA)."""
-    return 3 if g_fmt == 2 and os.environ.get("WESEP_DXN_F8", "0") == "1" else g_fmt
+    product on the block-scaled FP8 matrix instruction (ABI v20, the default: 0.57 -> 0.53 ms per launch alone, 1 ms per step --
+    profiles/r06_c30_band_probe.txt, r06_ab/r06_c30_*); WESEP_DXN_F8=0: the format itself (2: both terms on the fp16 MFMA)."""
+    return 3 if g_fmt == 2 and os.environ.get("WESEP_DXN_F8", "1") != "0" else g_fmt
 
 
 def _wiht_kind(g_fmt) -> str:
