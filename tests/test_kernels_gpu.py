@@ -445,12 +445,13 @@ def test_mask_istft_fwd_bwd_vs_torch(T):
 # ----------------------------------------------------------------------------------------------
 # elementwise: affine, SI-SDR, clip + Adam
 # ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [128, 100])   # full and partial column quads of the 16-byte backward (ws_affine_fwd needs N % 4 == 0)
 @pytest.mark.parametrize("K", [4, 32])      # 1 split / 8 splits of the rows (the last workgroup adds the splits up)
-def test_affine_fwd_bwd(K):
+def test_affine_fwd_bwd(K, N):
     from wesep_amd.functional import AffineFn
     d = _cuda()
     g = torch.Generator().manual_seed(41)
-    R, Tf, N = 3, 70, 128
+    R, Tf = 3, 71
     z, a, b, go = rnd(g, R, K, Tf, N), rnd(g, R, N), rnd(g, R, N), rnd(g, R, K, Tf, N)
     for a0, use_a, use_b in ((0.0, True, False), (1.0, False, True), (1.0, True, True)):
         zc, ac, bc = (t.clone().requires_grad_(True) for t in (z, a, b))
