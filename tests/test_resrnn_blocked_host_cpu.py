@@ -111,8 +111,9 @@ def test_streaming_bptt_arithmetic_and_its_own_input_gradient_reach_the_kernel(e
         grads[mode] = {"z": z.grad.clone(), **{k: v.grad.clone() for k, v in p.items()}}
         assert (("pack8",) in seen) == (mode != "rf0") and (("packdx",) in seen) == (mode == "default")
         assert [r[1:] for r in seen if r[0] == "bwd"] == [({"rf0": 0, "default": 2, "gemm": 3}[mode], mode == "default")]
-        # the d(xn) GEMM over the scaled-fp16 d(gates) (a_fmt 2) runs exactly when the BPTT did not write d(xn) itself
-        assert (("b2p", 2) in seen) == (mode != "default")
+        # the d(xn) GEMM over the scaled-fp16 d(gates) (a_fmt 3: the lo term on the FP8 MFMA, the round-6 default of
+        # functional.dxn_fmt) runs exactly when the BPTT did not write d(xn) itself
+        assert (("b2p", 3) in seen) == (mode != "default") and ("b2p", 2) not in seen
     for v in p.values():
         v.grad = None
     z2 = z.detach().clone().requires_grad_(True)
