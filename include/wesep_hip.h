@@ -103,7 +103,10 @@ typedef struct ws_gemm_nt_args {
   int a_div, c_div, st_div1, st_div2;
   int M, N, K, ldw;
   int act, ngroups, max_n, vec; /* max_n: max N over groups; vec bit0: A float4-loadable, bit1: W,
-                                   bit2: split-bf16 (hi/lo, 3 MFMAs, fp32 accumulate) products */
+                                   bit2: split-bf16 (hi/lo, 3 MFMAs, fp32 accumulate) products;
+                                   bit3 (round 6, with bits 0-2): W is stored TRANSPOSED, W'[n][k] = W[k * ldw + n] (per group:
+                                   ws_group_nt.ldw >= N) -- C = A [M, K] x B [K, N] with B as it lies ("NN"): N % 4 == 0 and
+                                   ldw % 4 == 0 (16-byte rows of W); no conv view, no norm-on-load                       */
   ws_conv_view conv;            /* conv.on: A is an implicit patch matrix (above), either mode */
 } ws_gemm_nt_args;
 int ws_gemm_nt(const ws_gemm_nt_args* a, void* stream);

@@ -73,9 +73,10 @@ def gemm_nt(*, A, a_rows, M, C_out, c_rows, N=0, K=0, W=None, ldw=0, bias=None, 
         assert stats is None and R is None and T is None and W is None
         for gd in _descs(groups, ngroups, "nt"):
             Kg, Ng = int(gd["K"]), int(gd["N"])
-            gemm_nt(A=A, a_rows=a_rows, M=M, C_out=C_out, c_rows=c_rows, N=Ng, K=Kg, W=_at(gd["W"], Ng * int(gd["ldw"])),
+            gemm_nt(A=A, a_rows=a_rows, M=M, C_out=C_out, c_rows=c_rows, N=Ng, K=Kg,
+                    W=_at(gd["W"], (Kg if vec & 8 else Ng) * int(gd["ldw"])),
                     ldw=int(gd["ldw"]), bias=_at(gd["bias"], Ng) if gd["bias"] else None, act=act,
-                    a_off=a_off + int(gd["a_off"]), c_off=c_off + int(gd["c_off"]))
+                    a_off=a_off + int(gd["a_off"]), c_off=c_off + int(gd["c_off"]), vec=vec)
         return
     a = _gather(A, a_off, M, a_rows, K)
     if stats is not None:
@@ -84,7 +85,11 @@ def gemm_nt(*, A, a_rows, M, C_out, c_rows, N=0, K=0, W=None, ldw=0, bias=None, 
         s = (m // d1) * m1 + (m % d2) * m2 + base
         st = stats.reshape(-1, 2)
         a = (a - st[s, 0:1]) * st[s, 1:2] * gamma.reshape(-1)[:K] + beta.reshape(-1)[:K]
-    w = W.reshape(-1)[w_off + (torch.arange(N).unsqueeze(1) * ldw + torch.arange(K).unsqueeze(0))]
+    if vec & 8:          # W stored transposed: W'[n][k] = W[k * ldw + n] (wesep_hip.h ws_gemm_nt_args.vec bit 3)
+        assert N % 4 == 0 and ldw % 4 == 0 and stats is None
+        w = W.reshape(-1)[w_off + (torch.arange(N).unsqueeze(1) + torch.arange(K).unsqueeze(0) * ldw)]
+    else:
+        w = W.reshape(-1)[w_off + (torch.arange(N).unsqueeze(1) * ldw + torch.arange(K).unsqueeze(0))]
     v = a @ w.t()
     if bias is not None:
         v = v + bias.reshape(-1)[:N]

@@ -43,6 +43,35 @@ def test_softmax_rows_matches_torch():
     assert rel(y, yr) < 1e-6 and rel(x.grad, xr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("G,M,K,N", [(3, 70, 72, 260), (2, 129, 32, 36), (1, 5, 8, 4)])
+def test_batched_matmul_with_the_operand_as_it_lies(G, M, K, N, monkeypatch):
+    """ws_gemm_nt_args.vec bit 3 (round 6): W stored [K][N] -- the attention products att x V (BatchedMatmulNNFn) and dA = dC B of
+    BatchedMatmulNTFn.backward without a transposing copy of B.  Forward and both gradients against torch.bmm in fp64; the NT
+    function's dA against its own copying path (WESEP_GEMM_NN=0) -- the same products in the same order: bit-identical."""
+    from wesep_amd import functional_tfgridnet as FG
+    d = _cuda()
+    g = torch.Generator().manual_seed(3)
+    A, B = torch.randn(G, M, K, generator=g), torch.randn(G, K, N, generator=g)
+    go = torch.randn(G, M, N, generator=g)
+    Ar, Br = A.double().requires_grad_(True), B.double().requires_grad_(True)
+    (torch.bmm(Ar, Br) * go.double()).sum().backward()
+    Ad, Bd = A.to(d).requires_grad_(True), B.to(d).requires_grad_(True)
+    assert FG.BatchedMatmulNTFn.nn_ok(K, N, M)
+    C = FG.BatchedMatmulNNFn.apply(Ad, Bd)
+    C.backward(go.to(d))
+    assert rel(C, torch.bmm(A.double(), B.double())) < 2e-5 and rel(Ad.grad, Ar.grad) < 2e-5 and rel(Bd.grad, Br.grad) < 2e-5
+    # NT: C = A2 B2^T; dA2 = dC B2 with B2 [N, K] as it lies
+    B2 = torch.randn(G, N, K, generator=g)
+    outs = []
+    for nn in ("1", "0"):
+        monkeypatch.setenv("WESEP_GEMM_NN", nn)
+        A2d, B2d = A.to(d).requires_grad_(True), B2.to(d).requires_grad_(True)
+        FG.BatchedMatmulNTFn.apply(A2d, B2d, None).backward(go.to(d))
+        outs.append((A2d.grad.clone(), B2d.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel(outs[0][0], torch.bmm(go.double(), B2.double())) < 2e-5
+
+
 @pytest.mark.parametrize("name", ["tfgridnet_ks4_r2_t1600", "tfgridnet_ks1_additive_r2_t1280",
                                   "tfgridnet_ks1_film_r2_t1280", "tfgridnet_ks1_concat_r2_t1280",
                                   "tfgridnet_ks1_srcs2_mics3_r2_t1280"])

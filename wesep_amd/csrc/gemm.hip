@@ -195,7 +195,10 @@ extern "C" int ws_gemm_nt(const ws_gemm_nt_args* a, void* stream) {
   const int ng = a->groups ? a->ngroups : 1;
   const int maxn = a->groups ? a->max_n : a->N;
   WS_REQUIRE(ng > 0 && maxn > 0, "ws_gemm_nt: ngroups=%d max_n=%d", ng, maxn);
-  WS_REQUIRE(a->groups || (a->N > 0 && a->K > 0 && a->ldw >= a->K), "ws_gemm_nt: bad N/K/ldw");
+  WS_REQUIRE(a->groups || (a->N > 0 && a->K > 0 && a->ldw >= ((a->vec & 8) ? a->N : a->K)), "ws_gemm_nt: bad N/K/ldw");
+  // vec bit 3 (round 6): W is stored transposed, W'[n][k] = W[k * ldw + n] -- the split-bf16 kernel only, 16-byte rows of W
+  WS_REQUIRE(!(a->vec & 8) || ((a->vec & 7) == 7 && !a->conv.on && !a->stats && (a->groups || (a->N % 4 == 0 && a->ldw % 4 == 0))),
+             "ws_gemm_nt: transposed W (vec bit 3) needs vec 15, no conv view, no norm-on-load, N %% 4 == 0 and ldw %% 4 == 0");
   if (a->conv.on) {
     const ws_conv_view& c = a->conv;
     WS_REQUIRE((a->vec & 7) == 7 && !a->groups && !a->stats, "ws_gemm_nt: the implicit patch matrix needs the split-bf16 "

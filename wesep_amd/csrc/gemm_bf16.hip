@@ -114,8 +114,15 @@ typedef const __attribute__((address_space(1))) float* gfp;
 // (launch bounds: the SECOND number is hipcc's minimum of waves per SIMD, not workgroups per CU -- "2" let the 128 x 128 tile take
 //  174 / 184 registers = two workgroups per CU where 40 KB of LDS allow three; at 3 the compiler fits it in 162 without a spill.
 //  The NORM variant would spill 30 registers there and stays at 2.)
-template <bool NORM, bool CONV, int NB>
+// WT (vec bit 3, round 6): W is stored TRANSPOSED -- W'[n][k] = W[k * ldw + n], i.e. the product is A [M, K] x B [K, N] with B as
+// it lies in memory ("NN").  A thread loads a 4 x 4 block (four consecutive n of four consecutive k), transposes it in registers
+// and writes four 8-byte k-runs into the [n][k] LDS image -- the store shape of the plain path (a first cut scattered 2-byte
+// stores: 8-way bank conflicts, the GEMMs lost more than the copies had cost); everything behind the staging is the same kernel.  For the attention products of
+// TF-GridNet (att x V, and d(logits) x K / d(ov) x V^T of the backward): each of them used to copy its B operand into the other
+// orientation first -- four ATen copies of 0.15 - 0.57 ms per block and step (profiles/r06_c37_tfg_step_timeline.txt).
+template <bool NORM, bool CONV, int NB, bool WT = false>
 __global__ __launch_bounds__(256, NORM ? 2 : 3) void gemm_nt_bf16_kernel(const ws_gemm_nt_args p) {
+  static_assert(!WT || (!NORM && !CONV), "the transposed-W staging exists for the plain kernel");
   __shared__ __attribute__((aligned(16))) __bf16 lds[4 * BT_PLANE];  // 40 KB
   const float* A_ = p.A;
   const float* W_ = p.W;
@@ -180,6 +187,11 @@ __global__ __launch_bounds__(256, NORM ? 2 : 3) void gemm_nt_bf16_kernel(const w
     const int n = n_blk + lrow + 32 * i;
     vn[i] = n < N && i < NB;
     woff[i] = (long long)(n < N ? n : N - 1) * ldw;
+    if constexpr (WT) {   // this thread's 4 x 4 block of the [32 k][32 NB n] tile: column quad n4, k quad k4; i = row of the block
+      const int n4 = (tid >> 6) * 8 + (tid & 7), nn = n_blk + 4 * n4;
+      vn[i] = tid < 64 * NB && nn < N;           // (N % 4 == 0: a quad is in or out as a whole)
+      woff[i] = vn[i] ? nn : 0;
+    }
   }
 
   // load_tile only ISSUES the loads (raw values stay in registers under the MFMAs of the current tile);
@@ -187,6 +199,7 @@ __global__ __launch_bounds__(256, NORM ? 2 : 3) void gemm_nt_bf16_kernel(const w
   f32x4 ra[4], rw[4], gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
   bool vk = true;
   bool vt[4] = {true, true, true, true};  // CONV: the tap of this tile's float4 lies inside the image for row i
+  bool vkw[4] = {true, true, true, true}; // WT: this thread's k row of the W tile lies inside K
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const int csh = cv.sh - 1, csw = cv.sw - 1;  // mode 1: strides are 1 or 2 -> shift / mask instead of a division
   const int cdil = cv.dil > 0 ? cv.dil : 1;
@@ -227,7 +240,13 @@ __global__ __launch_bounds__(256, NORM ? 2 : 3) void gemm_nt_bf16_kernel(const w
       } else {
         ra[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(A + aoff[i] + kc);
       }
-      if (i < NB) rw[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(W + woff[i] + kc);
+      if constexpr (WT) {
+        const int kr = kt * BT_BK + 4 * ((tid >> 3) & 7) + i;
+        vkw[i] = kr < K;
+        rw[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(W + (long long)(vkw[i] ? kr : 0) * ldw + woff[i]);
+      } else {
+        if (i < NB) rw[i] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(W + woff[i] + kc);
+      }
     }
   };
   auto store_tile = [&]() {
@@ -242,7 +261,17 @@ __global__ __launch_bounds__(256, NORM ? 2 : 3) void gemm_nt_bf16_kernel(const w
       split4(v, hi, lo);
       *reinterpret_cast<bf16x4*>(lds + o) = hi;
       *reinterpret_cast<bf16x4*>(lds + BT_PLANE + o) = lo;
-      if (i < NB) {
+      if constexpr (WT) {
+        if (tid < 64 * NB) {     // column j = i of the block: its four k, transposed in registers
+          const int n4 = (tid >> 6) * 8 + (tid & 7), k4 = (tid >> 3) & 7;
+          const f32x4 wt = {(vn[0] && vkw[0]) ? rw[0][i] : 0.f, (vn[1] && vkw[1]) ? rw[1][i] : 0.f,
+                            (vn[2] && vkw[2]) ? rw[2][i] : 0.f, (vn[3] && vkw[3]) ? rw[3][i] : 0.f};
+          split4(wt, hi, lo);
+          const int ow = (4 * n4 + i) * BT_LD + 4 * k4;
+          *reinterpret_cast<bf16x4*>(lds + 2 * BT_PLANE + ow) = hi;
+          *reinterpret_cast<bf16x4*>(lds + 3 * BT_PLANE + ow) = lo;
+        }
+      } else if (i < NB) {
         split4(wv, hi, lo);
         *reinterpret_cast<bf16x4*>(lds + 2 * BT_PLANE + o) = hi;
         *reinterpret_cast<bf16x4*>(lds + 3 * BT_PLANE + o) = lo;
@@ -381,7 +410,11 @@ int ws_launch_gemm_nt_bf16(const ws_gemm_nt_args* a, dim3 grid, hipStream_t s) {
     else if (nb == 2) hipLaunchKernelGGL((gemm_nt_bf16_kernel<NORM_, CONV_, 2>), grid, dim3(256), 0, s, *a); \
     else hipLaunchKernelGGL((gemm_nt_bf16_kernel<NORM_, CONV_, 4>), grid, dim3(256), 0, s, *a);              \
   } while (0)
-  if (a->conv.on)
+  if (a->vec & 8) {   // W stored [K][N] (ws_gemm_nt checks: no conv view, no norm-on-load, N % 4 == 0, ldw % 4 == 0)
+    if (nb == 1) hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, false, 1, true>), grid, dim3(256), 0, s, *a);
+    else if (nb == 2) hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, false, 2, true>), grid, dim3(256), 0, s, *a);
+    else hipLaunchKernelGGL((gemm_nt_bf16_kernel<false, false, 4, true>), grid, dim3(256), 0, s, *a);
+  } else if (a->conv.on)
     WS_NT_LAUNCH(false, true);
   else if (a->stats)
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<true, false, 4>), grid, dim3(256), 0, s, *a);

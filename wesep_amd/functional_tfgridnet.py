@@ -327,17 +327,25 @@ class BatchedMatmulNTFn(torch.autograd.Function):
     is the -inf mask of zero-padded key columns)."""
 
     @staticmethod
-    def _nt(A, W, bias, G, M, K, N):
+    def _nt(A, W, bias, G, M, K, N, w_kn=False):
+        """C[g] = A[g] W'[g]^T, W'[n][k] = W[g][n][k] -- or, w_kn (ws_gemm_nt_args.vec bit 3, round 6), = W[g][k][n]: the
+        operand as it lies in memory, where rounds 2-5 copied it into the other orientation first."""
         d = A.device
         C_ = _empty(d, G, M, N)
         tab = np.zeros(G, dtype=L.GROUP_NT_DTYPE)
         wp, bp = W.data_ptr(), (bias.data_ptr() if bias is not None else 0)
         for g in range(G):
-            tab[g] = (wp + 4 * g * N * K, bp, 0, 0, g * M * K, g * M * N, 0, K, N, K, 0)
+            tab[g] = (wp + 4 * g * N * K, bp, 0, 0, g * M * K, g * M * N, 0, K, N, N if w_kn else K, 0)
         desc = L.upload_struct_array(tab, d)
         dev.gemm_nt(A=A, a_rows=flat(K), M=M, C_out=C_, c_rows=flat(N), groups=desc, ngroups=G, max_n=N,
-                    vec=3 if (K % 4 == 0 and (M * K) % 4 == 0) else 0)
+                    vec=(3 if (K % 4 == 0 and (M * K) % 4 == 0) else 0) | (8 if w_kn else 0))
         return C_
+
+    @staticmethod
+    def nn_ok(K, N, M):
+        """The transposed-W staging takes this product (16-byte pieces of A and of W's rows; the split-bf16 kernel)."""
+        return (K % 4 == 0 and N % 4 == 0 and (M * K) % 4 == 0 and dev.gemm_mode() == "bf16x3"
+                and os.environ.get("WESEP_GEMM_NN", "1") != "0")
 
     @staticmethod
     def forward(ctx, A, B, bias):
@@ -357,8 +365,11 @@ class BatchedMatmulNTFn(torch.autograd.Function):
         d = A.device
         dA = dB = None
         if ctx.needs_input_grad[0]:
-            Bt = B.transpose(1, 2).contiguous()                                 # [G, K, N]: W'[k][n] of dA = dC B
-            dA = BatchedMatmulNTFn._nt(dC, Bt, None, G, M, N, K)
+            if BatchedMatmulNTFn.nn_ok(N, K, M):                                # dA = dC B with B [N, K] as it lies
+                dA = BatchedMatmulNTFn._nt(dC, B, None, G, M, N, K, w_kn=True)
+            else:
+                Bt = B.transpose(1, 2).contiguous()                             # [G, K, N]: W'[k][n] of dA = dC B
+                dA = BatchedMatmulNTFn._nt(dC, Bt, None, G, M, N, K)
         if ctx.needs_input_grad[1]:
             # dB[g] = dC[g]^T A[g]: the TN kernel, one split (M rows), the slab IS the result
             dB = _empty(d, G, N, K)
@@ -371,6 +382,43 @@ class BatchedMatmulNTFn(torch.autograd.Function):
                         rows_per_split=rps, groups=desc, ngroups=G, max_n=N, max_k=K,
                         vec=1 if (K % 4 == 0 and (M * K) % 4 == 0) else 0)
         return dA, dB, None
+
+
+class BatchedMatmulNNFn(torch.autograd.Function):
+    """A [G, M, K] x B [G, K, N] -> C [G, M, N], both operands differentiable: att x V of the attention (gridnet_block.py:203-206)
+    with V as the head kernel wrote it -- ws_gemm_nt stages the transposed operand itself (vec bit 3).  Backward: dA = dC B^T is
+    the NT product with B's rows as W' rows; dB = A^T dC is the TN kernel.  No operand is copied."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        _need_cuda(A, "TF-GridNet attention")
+        A, B = A.contiguous(), B.contiguous()
+        G, M, K = A.shape
+        N = B.shape[2]
+        ctx.save_for_backward(A, B)
+        return BatchedMatmulNTFn._nt(A, B, None, G, M, K, N, w_kn=True)
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        dC = dC.contiguous()
+        G, M, K = A.shape
+        N = B.shape[2]
+        d = A.device
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            dA = BatchedMatmulNTFn._nt(dC, B, None, G, M, N, K)                 # W'[k][n] = B[k][n]: B's rows ARE the W' rows
+        if ctx.needs_input_grad[1]:
+            dB = _empty(d, G, K, N)                                             # dB[g] = A[g]^T dC[g]
+            tab = np.zeros(G, dtype=L.GROUP_TN_DTYPE)
+            for g in range(G):
+                tab[g] = (0, 0, g * M * K, g * M * N, 0, g * K * N, 0, K, N, 0, 0)
+            desc = L.upload_struct_array(tab, d)
+            rps = -(-M // 32) * 32
+            dev.gemm_tn(G=A, g_rows=flat(K), A=dC, a_rows=flat(N), M=M, slab=dB, slab_stride=G * K * N, nsplit=1,
+                        rows_per_split=rps, groups=desc, ngroups=G, max_n=K, max_k=N,
+                        vec=1 if (N % 4 == 0 and (M * N) % 4 == 0) else 0)
+        return dA, dB
 
 
 def blocked_path_ok(C, ks, hs):

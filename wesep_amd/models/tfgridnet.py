@@ -212,7 +212,10 @@ class GridNetBlock(nn.Module):
         mask[oT:] = -1e30
         logits = FG.BatchedMatmulNTFn.apply(Qa, Ka, mask)                                           # [G, oT, Tp]
         att = FG.SoftmaxFn.apply(logits.view(G * oT, Tp), 1.0 / math.sqrt(D)).view(G, oT, Tp)
-        ov = FG.BatchedMatmulNTFn.apply(att, Va.transpose(1, 2).contiguous(), None)                 # [G, oT, oQ * cp]
+        if FG.BatchedMatmulNTFn.nn_ok(Tp, oQ * cp, oT):          # att x V with V as the head kernel wrote it (round 6)
+            ov = FG.BatchedMatmulNNFn.apply(att, Va)                                                # [G, oT, oQ * cp]
+        else:
+            ov = FG.BatchedMatmulNTFn.apply(att, Va.transpose(1, 2).contiguous(), None)
         o = ov.view(nh, B, oT, oQ, cp).permute(1, 2, 3, 0, 4).reshape(M, C)                         # channel h*cp + c
         proj = self["attn_concat_proj"]
         o = FD.Conv1x1ResFn.apply(o, proj[0].weight, proj[0].bias, None)
