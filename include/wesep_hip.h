@@ -735,7 +735,7 @@ typedef struct ws_lstm_fused_args {
                            (the wait of rounds 3-5).  Bit 2 (ABI v20; with bit 0: hfmt = 5): the lo term of that product on
                            v_mfma_scale_f32_32x32x64_f8f6f4 -- the residuals 256 w - hi as e4m3 codes with one exponent per
                            fragment against an e4m3 image of h: four fp16 MFMAs + one FP8 MFMA (K = 64, twice the rate) per
-                           recurrent k-step instead of eight; wpack from ws_lstm_pack_fused_h8; always the 64-sequence kernel */
+                           recurrent k-step instead of eight; wpack from ws_lstm_pack_fused_h8 (64- and 32-sequence kernels)  */
 } ws_lstm_fused_args;
 #define WS_LSTM_FUSED_PACK_FLOATS (2 * 8 * 24 * 4 * 2 * 64 * 4)
 int ws_lstm_pack_fused(const float* wih_f, const float* wih_r, const float* whh_f, const float* whh_r,

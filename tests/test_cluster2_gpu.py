@@ -234,8 +234,7 @@ def test_fused_band_forward_fp16_h_vs_torch_lstm_and_three_term_kernel(dims, seq
         errs[hf] = err = rel(dev.from_blocked(h, seq, P, split=True), want)
         print(f"fused band forward {dims}, hfmt {hf}: h rel vs torch fp64 {err:.2e}")
         assert err < (1e-3 if hf else 1e-4), (hf, err)
-    # hfmt 5 (ABI v20): the lo term of the recurrent product on the FP8 matrix instruction (the 64-sequence kernel, whatever
-    # WS_FUSED_SEQS says) -- the term is 2^-12 of the product and e4m3 keeps 2^-4 of it: as far from fp64 as hfmt 1 is (fp16 h
+    # hfmt 5 (ABI v20): the lo term of the recurrent product on the FP8 matrix instruction (the 64- and the 32-sequence kernel) -- the term is 2^-12 of the product and e4m3 keeps 2^-4 of it: as far from fp64 as hfmt 1 is (fp16 h
     # bounds both), and next to hfmt 1 itself
     (g5, c5, h5), (g1, c1, h1) = outs[5], outs[1]
     e51 = rel(dev.bls_unpack(h5), dev.bls_unpack(h1))

@@ -155,8 +155,11 @@ extern "C" int ws_lstm_pack_fused_h8(const float* wih_f, const float* wih_r, con
 }
 
 // H16: ws_lstm_fused_args.hfmt = 1 -- see lstm_fwd_fused64_body (fp16 h, one LDS plane per buffer, two recurrent terms)
-template <int GF, bool H16 = false>  // WS_GATES_*: != 0 -> activated gates leave as unorm16 (BLH), lstm_bf16_common.h
+// F8 (hfmt 5, with H16): the lo term on the FP8 matrix instruction, as in lstm_fwd_fused64_body; the e4m3 image of h lives in the
+// part-1 plane of each buffer (unused by the fp16 format)
+template <int GF, bool H16 = false, bool F8 = false>  // WS_GATES_*: != 0 -> activated gates leave as unorm16 (BLH), lstm_bf16_common.h
 __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fused_args p) {
+  static_assert(!F8 || H16, "the FP8 lo term belongs to the fp16-h kernel");
   __shared__ __attribute__((aligned(16))) __bf16 hl[2][2][SQ * HROW];  // [buf][part][seq][k]  66 KB
   __shared__ __attribute__((aligned(16))) __bf16 xl[2][2][SQ * XROW];  // [buf][part][seq][k]  34 KB
   __shared__ __attribute__((aligned(16))) float cl[SQ * (LH + 4)];     // cell state [seq][unit] 33 KB
@@ -204,14 +207,32 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
       bias[g][j] = *reinterpret_cast<const f32x4*>(p.bias + d * LG + g * 256 + ubase + 8 * j) * (H16 ? 256.f : 1.f);
 
   // weight stream: per k-step 8 fragments (4 gates x {hi, lo}), 1 KB each per wave; 24 k-steps per step
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.wpack) + (long long)(d * 8 + w) * (FKS * 8 * 64 * 4), 0, FKS * 8 * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs =
+      F8 ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(const_cast<float*>(p.wpack)) +
+                                                 (long long)(d * 8 + w) * F8_REGION, 0, F8_REGION, 0x00020000)
+         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpack) + (long long)(d * 8 + w) * (FKS * 8 * 64 * 4), 0,
+                                             FKS * 8 * 1024, 0x00020000);
   const int wlane = lane * 16;
   bf16x8 wr[2][8];
+  auto refill = [&](int s, int kn, int zo) {   // k-step kn of the stream -> ring slot s (F8: six fragments per recurrent k-step)
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+    for (int f = 0; f < 8; ++f) {
+      if (F8 && kn >= 8) {
+        if (f < 6) wr[s][f] = wload(wrs, wlane + f * 1024, zo + F8_HPART + (kn - 8) * F8_KSTEP);
+      } else {
+        wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
+      }
+    }
+  };
+  refill(0, 0, 0);
+  refill(1, 1, 0);
+  int ssc[4] = {0, 0, 0, 0};   // F8: the sixteen fragment exponents of this wave's stream
+  if constexpr (F8) {
+    const int* sp = reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(p.wpack) +
+                                                 (long long)(d * 8 + w) * F8_REGION + F8_SCALES);
 #pragma unroll
-    for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, s * 8192 + (f >> 2) * 4096);
+    for (int i = 0; i < 4; ++i) ssc[i] = __builtin_amdgcn_readfirstlane(sp[i]);
+  }
 
   // inputs: x of the first step goes to LDS now, x of the second step waits in registers
   f32x4 xr[2];
@@ -241,11 +262,29 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[g][4 * j + r] = bias[g][j][r];
+    const unsigned char* h8r = reinterpret_cast<const unsigned char*>(&hl[cur][1][0]) + l31 * H8ROW + 16 * half;
+    v8i b8;
+    int scv = 0;
 #pragma unroll
     for (int ks = 0; ks < FKS; ++ks) {
       const int s = ks & 1;
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(ks < 8 ? xhi + 16 * ks : hhi + 16 * (ks - 8));
-      if (H16 && ks >= 8) {   // fp16 W_hh (hi, lo of 256 w) x fp16 h: two terms
+      if (F8 && ks >= 8) {    // fp16 hi of 256 W_hh x fp16 h + ONE FP8 MFMA per k-step (gate q & 3 of k block q >> 2)
+        const int q = ks - 8;
+        if ((q & 3) == 0) {
+          const i32x4 p0 = *reinterpret_cast<const i32x4*>(h8r + 64 * (q >> 2)), p1 = *reinterpret_cast<const i32x4*>(h8r + 64 * (q >> 2) + 32);
+          b8 = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+          scv = ssc[q >> 2];
+        }
+        const f16x8 b16 = __builtin_bit_cast(f16x8, bh);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][g]), b16, acc[g]);
+        const v8i a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, wr[s][4]), __builtin_bit_cast(i32x4, wr[s][5]), 0, 1, 2, 3, 4, 5, 6, 7);
+        if ((q & 3) == 0) acc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[0], 0, 0, 0, scv, 0, 127);
+        if ((q & 3) == 1) acc[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[1], 0, 0, 1, scv, 0, 127);
+        if ((q & 3) == 2) acc[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[2], 0, 0, 2, scv, 0, 127);
+        if ((q & 3) == 3) acc[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[3], 0, 0, 3, scv, 0, 127);
+      } else if (H16 && ks >= 8) {   // fp16 W_hh (hi, lo of 256 w) x fp16 h: two terms
         const f16x8 b16 = __builtin_bit_cast(f16x8, bh);
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = mfma16h(__builtin_bit_cast(f16x8, wr[s][2 * g]), b16, acc[g]);
@@ -261,9 +300,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
         for (int g = 0; g < 4; ++g) acc[g] = mfma32(wr[s][2 * g], bl, acc[g]);
       }
       // refill this slot with k-step ks+2 (wraps into the next step: the stream never drains)
-      const int kn = (ks + 2) % FKS;
-#pragma unroll
-      for (int f = 0; f < 8; ++f) wr[s][f] = wload(wrs, wlane + (f & 3) * 1024, zo + kn * 8192 + (f >> 2) * 4096);
+      refill(s, (ks + 2) % FKS, zo);
       __builtin_amdgcn_sched_barrier(0);  // keep the k-steps in program order: loads stay 2 k-steps ahead
     }
 
@@ -304,6 +341,12 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd_fused_kernel(const ws_lstm_fu
       split4(vh, h_hi, h_lo);
       if constexpr (H16) {   // the recurrent operand: fp16(h), the hi plane's storage
         *reinterpret_cast<u32x2*>(nhi + 8 * j) = enc_f16x4(vh);
+        if constexpr (F8) {  // + its e4m3 image in the buffer's other plane
+          int c8 = 0;
+          c8 = __builtin_amdgcn_cvt_pk_fp8_f32(vh[0], vh[1], c8, false);
+          c8 = __builtin_amdgcn_cvt_pk_fp8_f32(vh[2], vh[3], c8, true);
+          *reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(&hl[cur ^ 1][1][0]) + l31 * H8ROW + ubase + 8 * j) = c8;
+        }
       } else {
         *reinterpret_cast<bf16x4*>(nhi + 8 * j) = h_hi;
         *reinterpret_cast<bf16x4*>(nlo + 8 * j) = h_lo;
@@ -635,12 +678,13 @@ extern "C" int ws_lstm_fwd_fused(const ws_lstm_fused_args* a, void* stream) {
   static int cus = 0;      // same part on every device of a node; queried once
   if (!cus && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess) cus = 256;
   const int rounds32 = (2 * ntile + cus - 1) / cus, rounds64 = (2 * ((ntile + 1) / 2) + cus - 1) / cus;
-  // (the FP8 lo term exists in the 64-sequence kernel only: its odd last tile is masked, any sequence count runs)
-  const bool wide = (a->hfmt & 4) ? true : env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
+  const bool wide = env ? atoi(env) == 64 : 9 * rounds64 < 5 * rounds32;
   ws_prof_begin(WS_PROF_LSTM_FWD, s);
   const char* w1 = getenv("WS_FUSED_W1");   // measurement only: one weight plane (bf16 weights), see lstm_fwd_fused64_body
-  if (a->hfmt & 4)
+  if ((a->hfmt & 4) && wide)
     hipLaunchKernelGGL(lstm_fwd_fused64h8_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
+  else if (a->hfmt & 4)
+    hipLaunchKernelGGL((lstm_fwd_fused_kernel<WS_GATES_H2, true, true>), grid, block, 0, s, *a);
   else if ((a->hfmt & 1) && wide)
     hipLaunchKernelGGL(lstm_fwd_fused64h16_kernel, dim3((ntile + 1) / 2, 2), block, 0, s, *a);
   else if (a->hfmt & 1)

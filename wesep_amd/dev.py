@@ -1247,7 +1247,7 @@ def lstm_fused_hfmt(gfmt) -> int:
     WESEP_FUSED_H16=0: the three-term product of rounds 1-5 for both parts.
     Bit 2 (ABI v20, default on; with bit 0: 5): the lo term of that product on the block-scaled FP8 matrix instruction (one
     K = 64 MFMA at twice the fp16 rate for four K = 16 ones; 2.12 -> 1.92 ms per launch alone, 1.3 ms per step:
-    profiles/r06_c21_band_probe.txt, r06_ab/r06_c22_*) -- the 64-sequence kernel only (models.tfgridnet masks the bit).
+    profiles/r06_c21_band_probe.txt, r06_ab/r06_c22_*) -- both the 64- and the 32-sequence kernel.
     WESEP_FUSED_F8=0: both terms on the fp16 MFMA."""
     if gfmt == L.GATES_F32 or os.environ.get("WESEP_FUSED_H16", "1") == "0":
         return 0

@@ -499,7 +499,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         if dev.lstm_fuse_ok(ns, cluster):
             dev.gemm_p2b(A=y, lda=N, sm=seq, Wpack=None, N=0, C_out=None, A_bl=xn, A_bl16=xn16)
             fpack = _empty(d, L.LSTM_FUSED_PACK_FLOATS)
-            hf = dev.lstm_fused_hfmt(gfmt) & 1  # (bit 2, the FP8 lo term, lives in the 64-sequence kernel only)  round 6: fp16 h in the recurrent part (two terms), as functional.ResRNNBlkFn
+            hf = dev.lstm_fused_hfmt(gfmt)      # round 6: fp16 h in the recurrent part (two terms), as functional.ResRNNBlkFn
             dev.lstm_pack_fused(wih_f.contiguous(), wih_r.contiguous(), whf, whr, fpack, hfmt=hf)
             dev.lstm_fwd_fused(gates, cbuf, hcat, xn, fpack, bcat, seq, gfmt=gfmt, hfmt=hf)
         elif cluster and h2 and dev.lstm_cluster2_on() and os.environ.get("WESEP_TFG_CLUSTER2", "1") != "0":
@@ -552,7 +552,8 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             wlt_pack = _empty(d, 2 * H * N)
             dev.pack_w(lw, 2 * H, N, 2 * H, wlt_pack, trans=True, order=0)
             wct_pack = _empty(d, N * 2 * G4)
-            dev.pack_w(wcat, N, 2 * G4, N, wct_pack, trans=True, order=1, f16=g2)
+            # (d(xn) from the scaled-fp16 d(gates): fp16 hi / lo, or fp16 hi + FP8 lo fragments -- functional.dxn_fmt, round 6)
+            dev.pack_w(wcat, N, 2 * G4, N, wct_pack, trans=True, order=1, f16=(2 if F0.dxn_fmt(2) == 3 else 1) if g2 else 0)
             ppack = None
             if kind == "pair":
                 ppack = _empty(d, L.LSTM_PACK_FLOATS)
@@ -640,7 +641,7 @@ class BlstmLinearBlkFn(torch.autograd.Function):
             wg = F0.ResRNNBlkFn._weight_grads(dg, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax, hcat16)
             wgo = [wg[i] for i in order]
         dy = _empty(d, (ns if appended else nseq) * Lr, N)
-        dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dy, ldc=N, a_fmt=g_fmt, amax=amax)
+        dev.gemm_b2p(A=dg, K=2 * G4, sm=seq, Wpack=wct_pack, C_out=dy, ldc=N, a_fmt=F0.dxn_fmt(g_fmt), amax=amax)
         if appended:
             dy = dy[:nseq * Lr]
         # _weight_grads: [dW_ih_f, dW_hh_f, db_f, db_f (clone), dW_ih_r, dW_hh_r, db_r, db_r (clone), dW_lin, db_lin]
