@@ -912,6 +912,41 @@ __global__ __launch_bounds__(256) void scale_bf_bwd_kernel(const float* __restri
   if (threadIdx.x == 0) ds[blockIdx.x] = acc;
 }
 
+// C % 4 == 0: the same sums with 16-byte accesses -- C / 4 threads per row, 256 / (C / 4) rows per pass, two passes in flight (the
+// scalar kernel above moved 0.6 GB in 0.7 ms on TF-GridNet's map, seven launches per step)
+__global__ __launch_bounds__(256) void scale_bf_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ s, int B, int T, int Fq, int C,
+                                                            int mode, float* __restrict__ dx, float* __restrict__ ds) {
+  __shared__ float red[16];
+  const int b = blockIdx.x / Fq, f = blockIdx.x % Fq;
+  const float sv = s[(long long)b * Fq + f];
+  const int c4n = C >> 2, nrl = 256 / c4n;          // row lanes (C <= 1024)
+  const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (rl < nrl) {
+    const long long base = ((long long)b * T * Fq + f) * C + 4 * c4, rs = (long long)Fq * C;
+    for (int t = rl; t < T; t += 2 * nrl) {
+      const bool two = t + nrl < T;
+      const long long o0 = base + t * rs, o1 = base + (two ? t + nrl : t) * rs;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(dy + o0), g1 = *reinterpret_cast<const f32x4*>(dy + o1);
+      if (mode == 0) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + o0), x1 = *reinterpret_cast<const f32x4*>(x + o1);
+        acc += g0 * x0;
+        if (two) acc += g1 * x1;
+        *reinterpret_cast<f32x4*>(dx + o0) = g0 * sv;
+        if (two) *reinterpret_cast<f32x4*>(dx + o1) = g1 * sv;
+      } else {
+        acc += g0;
+        if (two) acc += g1;
+        *reinterpret_cast<f32x4*>(dx + o0) = g0;
+        if (two) *reinterpret_cast<f32x4*>(dx + o1) = g1;
+      }
+    }
+  }
+  const float tot = ws_block_sum(acc[0] + acc[1] + acc[2] + acc[3], red);
+  if (threadIdx.x == 0) ds[blockIdx.x] = tot;
+}
+
 extern "C" int ws_scale_bf_fwd(const float* x, const float* s, int B, int T, int Fq, int C, int mode, float* y,
                                void* stream) {
   WS_REQUIRE(x && s && y && B > 0 && T > 0 && Fq > 0 && C > 0 && C % 4 == 0 && (mode == 0 || mode == 1),
@@ -925,8 +960,11 @@ extern "C" int ws_scale_bf_bwd(const float* x, const float* dy, const float* s, 
                                float* dx, float* ds, void* stream) {
   WS_REQUIRE(x && dy && s && dx && ds && B > 0 && T > 0 && Fq > 0 && C > 0 && (mode == 0 || mode == 1),
              "ws_scale_bf_bwd: bad args");
-  hipLaunchKernelGGL(scale_bf_bwd_kernel, dim3(B * Fq), dim3(256), 0, (hipStream_t)stream, x, dy, s, B, T, Fq, C, mode,
-                     dx, ds);
+  if (C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0)
+    hipLaunchKernelGGL(scale_bf_bwd4_kernel, dim3(B * Fq), dim3(256), 0, (hipStream_t)stream, x, dy, s, B, T, Fq, C, mode, dx, ds);
+  else
+    hipLaunchKernelGGL(scale_bf_bwd_kernel, dim3(B * Fq), dim3(256), 0, (hipStream_t)stream, x, dy, s, B, T, Fq, C, mode,
+                       dx, ds);
   return ws_check_launch("ws_scale_bf_bwd");
 }
 
@@ -1002,8 +1040,51 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
   for (int j = threadIdx.x; j < n; j += 256) dx[o + j] = scale * y[o + j] * (dy[o + j] - s);
 }
 
+// n <= 1024, n % 4 == 0 (TF-GridNet's padded key axis): the row lives in one float4 per thread -- one read and one write of the
+// row instead of three passes of 4-byte accesses (0.29 ms for 2 x 72 MB per launch before)
+__global__ __launch_bounds__(256) void softmax_rows_fwd4_kernel(const float* __restrict__ x, int n, float scale,
+                                                                float* __restrict__ y) {
+  __shared__ float red[16];
+  const long long o = (long long)blockIdx.x * n + 4 * threadIdx.x;
+  const bool on = 4 * (int)threadIdx.x < n;
+  f32x4 v = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+  if (on) v = *reinterpret_cast<const f32x4*>(x + o) * scale;
+  float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  f32x4 e = {0.f, 0.f, 0.f, 0.f};
+  if (on) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = expf(v[j] - mx);
+  }
+  const float se = ws_block_sum(e[0] + e[1] + e[2] + e[3], red);
+  if (on) *reinterpret_cast<f32x4*>(y + o) = e * (1.f / se);
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_bwd4_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                                int n, float scale, float* __restrict__ dx) {
+  __shared__ float red[16];
+  const long long o = (long long)blockIdx.x * n + 4 * threadIdx.x;
+  const bool on = 4 * (int)threadIdx.x < n;
+  f32x4 yv = {0.f, 0.f, 0.f, 0.f}, dv = yv;
+  if (on) {
+    yv = *reinterpret_cast<const f32x4*>(y + o);
+    dv = *reinterpret_cast<const f32x4*>(dy + o);
+  }
+  const f32x4 p = yv * dv;
+  const float sm = ws_block_sum(p[0] + p[1] + p[2] + p[3], red);
+  if (on) *reinterpret_cast<f32x4*>(dx + o) = yv * (dv - sm) * scale;
+}
+
 extern "C" int ws_softmax_rows_fwd(const float* x, long long rows, int n, float scale, float* y, void* stream) {
   WS_REQUIRE(x && y && rows > 0 && rows < (1LL << 31) && n > 0, "ws_softmax_rows_fwd: bad args");
+  if (n <= 1024 && n % 4 == 0 && ((size_t)x & 15) == 0 && ((size_t)y & 15) == 0) {
+    hipLaunchKernelGGL(softmax_rows_fwd4_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, n, scale, y);
+    return ws_check_launch("ws_softmax_rows_fwd");
+  }
   hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, n, scale, y);
   return ws_check_launch("ws_softmax_rows_fwd");
 }
@@ -1011,6 +1092,10 @@ extern "C" int ws_softmax_rows_fwd(const float* x, long long rows, int n, float 
 extern "C" int ws_softmax_rows_bwd(const float* y, const float* dy, long long rows, int n, float scale, float* dx,
                                    void* stream) {
   WS_REQUIRE(y && dy && dx && rows > 0 && rows < (1LL << 31) && n > 0, "ws_softmax_rows_bwd: bad args");
+  if (n <= 1024 && n % 4 == 0 && ((size_t)y & 15) == 0 && ((size_t)dy & 15) == 0 && ((size_t)dx & 15) == 0) {
+    hipLaunchKernelGGL(softmax_rows_bwd4_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, y, dy, n, scale, dx);
+    return ws_check_launch("ws_softmax_rows_bwd");
+  }
   hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, y, dy, n, scale,
                      dx);
   return ws_check_launch("ws_softmax_rows_bwd");
