@@ -204,8 +204,20 @@ def _block_norm(y, norm, R, Tp, Cc, gamma, beta, bn):
         st[1].copy_(torch.rsqrt(rv + dev.BN_EPS))
     gk = (st[1] * gamma).contiguous()
     bk = (beta - st[0] * gk).contiguous()
-    ident = torch.tensor([[0.0, 1.0]], device=y.device, dtype=torch.float32)
+    ident = _ident(y.device)
     return (ident, gk, bk, StatMap(1, 0, 1, 0, 0), M), (st, gamma)
+
+
+_IDENT = {}
+
+
+def _ident(device):
+    """(mean, rstd) = (0, 1) on the device, made once: torch.tensor(..., device=...) is a pageable host-to-device copy and
+    synchronises the stream -- once per BatchNorm layer and step here (round 6)."""
+    key = (device.type, device.index)
+    if key not in _IDENT:
+        _IDENT[key] = torch.tensor([[0.0, 1.0]], device=device, dtype=torch.float32)
+    return _IDENT[key]
 
 
 def _block_norm_backward(y, dyn, st, gamma, norm, R, Tp, Cc):

@@ -215,7 +215,9 @@ class BSRNN(nn.Module):
 
     def _speaker(self, embeddings):
         """enrollment -> (fused-in embedding [R, E], second output) (bsrnn.py:339-360)."""
-        predict_speaker_lable = torch.tensor(0.0, device=embeddings.device)  # dummy, bsrnn.py:339-340
+        # dummy, bsrnn.py:339-340.  torch.zeros: a fill on the stream -- torch.tensor(0.0, device=...) is a pageable host-to-device copy
+        # that SYNCHRONISES the stream (the host sat out the whole previous step here, 71 of its 86 ms per step; round 6)
+        predict_speaker_lable = torch.zeros((), device=embeddings.device)
         if self.joint_training:             # fbank [R, Te, F] -> wespeaker encoder -> embedding (bsrnn.py:341-357)
             if not self.spk_feat:           # raw enrollment waveform [R, Tw] -> log-mel, CMN (no_grad, :343-350)
                 from ..modules.common.frontend import fbank_frontend

@@ -243,7 +243,7 @@ class DPCCN(nn.Module):
         w4 = torch.cat([c2.weight, torch.zeros(16, 2, 3, 3, device=d, dtype=torch.float32)], 1)
         out = FD.Conv2dFn.apply(x4, w4, c2.bias, (B, Tf, Fq, 1, 1))
         out, geo = self.encoder[0](out, geo)
-        logits = torch.tensor(0.0, device=d)
+        logits = torch.zeros((), device=d)      # (a fill on the stream; torch.tensor(0.0, device=d) synchronises it: models/bsrnn.py)
         emb = aux.float().contiguous()
         if self.joint_training:
             if not self.spk_feat:

@@ -331,7 +331,7 @@ class TFGridNet(nn.Module):
         w4 = torch.cat([c0.weight, torch.zeros(C, Cp - 2 * M, 3, 3, device=d, dtype=torch.float32)], 1)
         h = FD.Conv2dFn.apply(x4, w4, c0.bias, (B, Tf, Fq, 1, 1))
         h = FG.GroupLNFn.apply(h, gn.weight, gn.bias, (B, Tf * Fq))
-        logits = torch.tensor(0.0, device=d)
+        logits = torch.zeros((), device=d)      # (a fill on the stream; torch.tensor(0.0, device=d) synchronises it: models/bsrnn.py)
         emb = embeddings.float().contiguous()
         if self.joint_training:
             if not self.spk_feat:
