@@ -52,6 +52,13 @@ def main():
     _bs, _md = F_.BandSplitFn.apply, F_.MaskDecodeFn.apply
     F_.BandSplitFn.apply = timed("BandSplitFn", _bs)
     F_.MaskDecodeFn.apply = timed("MaskDecodeFn", _md)
+    # ... and by device entry point (every public function of wesep_amd.dev that launches something)
+    from wesep_amd import dev as _dev
+    import types
+    for nm in dir(_dev):
+        fn = getattr(_dev, nm)
+        if isinstance(fn, types.FunctionType) and not nm.startswith("_") and fn.__module__ == _dev.__name__:
+            setattr(_dev, nm, timed("dev." + nm, fn))
     names = ["forward", "loss", "zero_grad", "backward", "opt.step"]
     acc = [0.0] * 5
 
@@ -83,8 +90,9 @@ def main():
     print(f"{a.steps} steps: host enqueue {t_host / a.steps * 1e3:.2f} ms per step, with the final synchronize {t_all / a.steps * 1e3:.2f} ms per step")
     for n, v in zip(names, acc):
         print(f"   host time in {n:10s} {v / a.steps * 1e3:7.2f} ms per step")
-    for k, v in parts.items():
-        print(f"      forward part {k:32s} {v / (a.steps + 3) * 1e3:7.2f} ms per step")
+    for k, v in sorted(parts.items(), key=lambda kv: -kv[1]):
+        if v / (a.steps + 3) * 1e3 >= 0.05:
+            print(f"      host time in {k:36s} {v / (a.steps + 3) * 1e3:7.2f} ms per step (forward + backward)")
 
 
 if __name__ == "__main__":
