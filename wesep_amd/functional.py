@@ -1051,6 +1051,12 @@ class ConcatFuseFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # per-band plans: device descriptor tables for the grouped (32-band) launches
 # ---------------------------------------------------------------------------------------------
+def mask_nn() -> bool:
+    """The mask MLP's data-gradient GEMMs read the weights as they lie (ws_gemm_nt_args.vec bit 3, split-bf16 kernel) instead of
+    transposed copies made every step; WESEP_GEMM_NN=0 restores the copies."""
+    return dev.gemm_mode() == "bf16x3" and os.environ.get("WESEP_GEMM_NN", "1") != "0"
+
+
 class BandPlan:
     """Band tables + cached group descriptors for BN[i] (bsrnn.py:252-258) and mask[i]
     (bsrnn.py:271-282).  Descriptors hold parameter pointers, so they are rebuilt only when a
@@ -1105,7 +1111,8 @@ class BandPlan:
 
     # ---- mask ----------------------------------------------------------------------------
     def mask_desc(self, params, R, Tf):
-        key = ("mask",) + self._key(params, R, Tf)
+        nn = mask_nn()
+        key = ("mask", nn) + self._key(params, R, Tf)
         if key not in self._cache:
             K, N = self.K, self.N
             H1 = 4 * N
@@ -1122,10 +1129,15 @@ class BandPlan:
                 d["l1"][g] = (w1.data_ptr(), b1.data_ptr(), gw.data_ptr(), gb.data_ptr(), zoff, hoff, g, N, H1, N, 0)
                 d["l2"][g] = (w2.data_ptr(), b2.data_ptr(), 0, 0, hoff, hoff, 0, H1, H1, H1, 0)
                 d["l3"][g] = (w3.data_ptr(), b3.data_ptr(), 0, 0, hoff, 4 * self.f0[g], 0, H1, bw4, H1, 0)
-                d["dh2"][g] = (self.m_w3T.data_ptr() + 4 * int(self.m_w3off[g]), 0, 0, 0,
-                               4 * self.f0[g], hoff, 0, bw4, H1, bw4, 0)
-                d["dh1"][g] = (self.m_w2T.data_ptr() + 4 * g * H1 * H1, 0, 0, 0, hoff, hoff, 0, H1, H1, H1, 0)
-                d["dxn"][g] = (self.m_w1T.data_ptr() + 4 * g * N * H1, 0, 0, 0, hoff, zoff, 0, H1, N, H1, 0)
+                if nn:    # the data-gradient GEMMs take the weights AS THEY LIE (ws_gemm_nt_args.vec bit 3: W'[n][k] = W[k * ldw + n])
+                    d["dh2"][g] = (w3.data_ptr(), 0, 0, 0, 4 * self.f0[g], hoff, 0, bw4, H1, H1, 0)
+                    d["dh1"][g] = (w2.data_ptr(), 0, 0, 0, hoff, hoff, 0, H1, H1, H1, 0)
+                    d["dxn"][g] = (w1.data_ptr(), 0, 0, 0, hoff, zoff, 0, H1, N, N, 0)
+                else:
+                    d["dh2"][g] = (self.m_w3T.data_ptr() + 4 * int(self.m_w3off[g]), 0, 0, 0,
+                                   4 * self.f0[g], hoff, 0, bw4, H1, bw4, 0)
+                    d["dh1"][g] = (self.m_w2T.data_ptr() + 4 * g * H1 * H1, 0, 0, 0, hoff, hoff, 0, H1, H1, H1, 0)
+                    d["dxn"][g] = (self.m_w1T.data_ptr() + 4 * g * N * H1, 0, 0, 0, hoff, zoff, 0, H1, N, H1, 0)
                 t["w3"][g] = (0, 0, 4 * self.f0[g], hoff, 0, int(self.m_w3off[g]), int(self.m_b3off[g]), bw4, H1, 0, 0)
                 t["w2"][g] = (0, 0, hoff, hoff, 0, g * H1 * H1, g * H1, H1, H1, 0, 0)
                 t["w1"][g] = (gw.data_ptr(), gb.data_ptr(), hoff, zoff, g, g * H1 * N, g * H1, H1, N, 0, 0)
@@ -1267,15 +1279,18 @@ class MaskDecodeFn(torch.autograd.Function):
                     ngroups=K, max_n=maxb4, max_k=H1)
         dW3 = _reduce_new(slab, nsplit, w3tot, (w3tot,))
         dB3 = _reduce_new(bslab, nsplit, b3tot, (b3tot,))
-        for g in range(K):
-            bw4 = 4 * plan.bw[g]
-            dev.transpose(params[8 * g + 6].reshape(bw4, H1), bw4, H1, H1, plan.m_w3T,
-                          dst_off=int(plan.m_w3off[g]))
-            dev.transpose(params[8 * g + 4].reshape(H1, H1), H1, H1, H1, plan.m_w2T, dst_off=g * H1 * H1)
-            dev.transpose(params[8 * g + 2].reshape(H1, N), H1, N, N, plan.m_w1T, dst_off=g * N * H1)
+        nn = mask_nn()
+        vnn = 3 | (8 if nn else 0)
+        if not nn:      # (rounds 1-5: 3 K transposes of the weights per step -- 93 launches of 6 us, each with its launch gap, at the
+            for g in range(K):                     # head of the backward; the GEMMs stage W as it lies now, round 6)
+                bw4 = 4 * plan.bw[g]
+                dev.transpose(params[8 * g + 6].reshape(bw4, H1), bw4, H1, H1, plan.m_w3T,
+                              dst_off=int(plan.m_w3off[g]))
+                dev.transpose(params[8 * g + 4].reshape(H1, H1), H1, H1, H1, plan.m_w2T, dst_off=g * H1 * H1)
+                dev.transpose(params[8 * g + 2].reshape(H1, N), H1, N, N, plan.m_w1T, dst_off=g * N * H1)
         dh2 = _empty(d, K, M, H1)
         dev.gemm_nt(A=dm3, a_rows=flat(4 * NBIN), M=M, C_out=dh2, c_rows=flat(H1), T=h2, groups=D["dh2"],
-                    ngroups=K, max_n=H1)
+                    ngroups=K, max_n=H1, vec=vnn)
         # layer 2
         slab, bslab = _empty(d, nsplit, K * H1 * H1), _empty(d, nsplit, K * H1)
         dev.gemm_tn(G=dh2, g_rows=flat(H1), A=h1, a_rows=flat(H1), M=M, slab=slab, slab_stride=K * H1 * H1,
@@ -1285,7 +1300,7 @@ class MaskDecodeFn(torch.autograd.Function):
         dB2 = _reduce_new(bslab, nsplit, K * H1, (K, H1))
         dh1 = _empty(d, K, M, H1)
         dev.gemm_nt(A=dh2, a_rows=flat(H1), M=M, C_out=dh1, c_rows=flat(H1), T=h1, groups=D["dh1"],
-                    ngroups=K, max_n=H1)
+                    ngroups=K, max_n=H1, vec=vnn)
         del dh2
         # layer 1 (A = re-normalised z band rows)
         slab, bslab = _empty(d, nsplit, K * H1 * N), _empty(d, nsplit, K * H1)
@@ -1298,7 +1313,7 @@ class MaskDecodeFn(torch.autograd.Function):
         del slab, bslab
         dxn = _empty(d, R, K, Tf, N)
         dev.gemm_nt(A=dh1, a_rows=flat(H1), M=M, C_out=dxn, c_rows=Rows(Tf, K * Tf * N, N), groups=D["dxn"],
-                    ngroups=K, max_n=N)
+                    ngroups=K, max_n=N, vec=vnn)
         del dh1
         # GroupNorm backward with per-band gamma
         geo = Geom(R * K, 1, Tf * N, 0, N, Tf, N, K)
