@@ -294,3 +294,37 @@ def test_clip_gradients_zeroes_a_poisoned_step_for_optimizers_without_a_guard(mo
     assert all(not p.grad.any() for p in net.parameters())       # every gradient of the step is zero, none is NaN
     opt.step()
     assert all(torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))   # SGD on zero gradients: intact
+
+
+def test_step_fence_bounds_the_run_ahead():
+    """dev.StepFence: after step n is enqueued the host waits for step n - depth, never for a later one (round 6: an unbounded
+    run-ahead cost 49 GB of allocator growth per step and multi-second hipMalloc calls inside the timed region)."""
+    from wesep_amd import dev
+    log = []
+
+    class Ev:
+        n = 0
+
+        def __init__(self):
+            self.i = Ev.n
+            Ev.n += 1
+
+        def record(self):
+            log.append(("rec", self.i))
+
+        def synchronize(self):
+            log.append(("sync", self.i))
+
+    for depth, want in ((1, [None, 0, 1, 2]), (0, [0, 1, 2, 3]), (2, [None, None, 0, 1]), (-1, [None] * 4)):
+        Ev.n = 0
+        f = dev.StepFence(depth=depth, make_event=Ev)
+        got = []
+        for _ in range(4):
+            del log[:]
+            f.fence()
+            syncs = [i for k, i in log if k == "sync"]
+            assert len(syncs) <= 1
+            got.append(syncs[0] if syncs else None)
+            if depth >= 0:
+                assert log[0][0] == "rec"          # the step's own event is recorded before anything is waited for
+        assert got == want, (depth, got)

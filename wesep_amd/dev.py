@@ -486,6 +486,48 @@ def _cluster_scratch(device) -> _ClusterScratch:
     return _CLUSTER_SCRATCH[key]
 
 
+class StepFence:
+    """Bounds how far the host may run ahead of the GPU, in optimizer steps.
+
+    The headline step takes the host 15-25 ms to enqueue and the GPU 93 ms to run, and nothing in it waits for the device.
+    Left alone the host is soon several steps ahead -- and every block that was handed to the side stream
+    (`record_stream`: d(gates), xn, hcat, d(out) of twelve ResRNNs, 49 GB per step) cannot be reused by the caching allocator
+    before the GPU has actually passed it, so each step of run-ahead costs another 49 GB of hipMalloc (seen: 75 -> 265 GB
+    reserved within five steps, single hipMalloc calls of 2.8-3.7 s, bench lines of 344-850 ms per step with every kernel at
+    its usual duration: profiles/r06_c52_diag.txt).  `fence()` records an event behind the optimizer's last launch and waits
+    for the event of `depth` steps earlier: with depth 1 the host enqueues step n + 1 while the GPU runs step n -- the queue is
+    never empty -- and reserved memory settles after two steps.  WESEP_RUN_AHEAD=<depth> (0: synchronise every step; a
+    negative value disables the fence)."""
+
+    def __init__(self, depth=None, make_event=None):
+        self.depth = int(os.environ.get("WESEP_RUN_AHEAD", "1")) if depth is None else int(depth)
+        self._make = make_event
+        self._ring = []
+
+    def fence(self):
+        if self.depth < 0:
+            return
+        ev = self._make() if self._make is not None else torch.cuda.Event(blocking=True)
+        ev.record()
+        self._ring.append(ev)
+        while len(self._ring) > self.depth:
+            self._ring.pop(0).synchronize()
+
+
+_STEP_FENCE = {}
+
+
+def step_fence(device):
+    """One optimizer step of `device`'s current stream is enqueued: wait for the step before the previous one (StepFence)."""
+    if device.type != "cuda" or not torch.cuda.is_available():
+        return
+    key = (device.index, L.stream_ptr().value)
+    if key not in _STEP_FENCE:
+        _STEP_FENCE[key] = StepFence()
+    with torch.cuda.device(device):
+        _STEP_FENCE[key].fence()
+
+
 def poll_cluster_status(device, block=False):
     """Asynchronous check of the cluster recurrences' sticky status words on the current stream: evaluates the
     8-byte device->pinned-host copy started by the previous call once its event has completed and starts the next

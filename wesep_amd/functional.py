@@ -352,10 +352,32 @@ def defer_wgrad(device, job):
 
 class WGradBox:
     """Hand-over slot between a ResRNN's backward (producer, side stream) and its carrier node."""
-    __slots__ = ("event", "grads")
+    __slots__ = ("event", "grads", "keep")
 
     def __init__(self):
-        self.event, self.grads = None, None
+        self.event, self.grads, self.keep = None, None, None
+
+
+def wgrad_hold() -> bool:
+    """How the operands of a deferred weight-gradient job (d(gates), xn, hcat, d(out): 4 GB per ResRNN, 49 GB per step) stay
+    valid while the side stream reads them.  Rounds 3-5 marked them `record_stream(side)`: the caching allocator then takes a
+    block back only once the GPU has PASSED the side stream's job, so every allocation the host makes ahead of the GPU misses
+    the cache -- 49 GB of hipMalloc per step of run-ahead, calls of 1.6-3.7 s each now and then, and a block pattern that
+    depends on timing (profiles/r06_c52_diag.txt).  Default now: the job's box keeps the operands until the carrier node has
+    made the consumer stream wait for the job's event and drops them there -- an ordinary stream-ordered free on the stream
+    that allocated them, no event bookkeeping, the same blocks every step.  WESEP_WGRAD_HOLD=0 restores record_stream."""
+    return os.environ.get("WESEP_WGRAD_HOLD", "1") != "0"
+
+
+def keep_for_side(box, tensors, side, prod):
+    """Called by a deferred job once its launches are on `side`: keeps `tensors` -- allocated on the stream `prod`, the one
+    the ResRNN's forward and backward ran on -- valid for them (wgrad_hold)."""
+    tensors = tuple(t for t in tensors if t is not None)
+    if wgrad_hold():
+        box.keep = (tensors, side, prod)
+    else:
+        for t in tensors:
+            t.record_stream(side)
 
 
 class WGradCarrierFn(torch.autograd.Function):
@@ -383,6 +405,14 @@ class WGradCarrierFn(torch.autograd.Function):
             raise L.WesepHipError("weight-gradient carrier ran before its ResRNN backward")
         cur = torch.cuda.current_stream()
         cur.wait_event(box.event)
+        keep, box.keep = box.keep, None
+        if keep is not None:
+            # `cur` is ordered behind the job now: operands allocated on `cur` are simply dropped (stream-ordered reuse is
+            # safe); an operand of another stream's pool (TF-GridNet's row streams) is not ordered by this wait
+            if keep[2] != cur:
+                for t in keep[0]:
+                    t.record_stream(keep[1])
+            del keep
         grads, box.grads = box.grads, None
         for g in grads:
             g.record_stream(cur)
@@ -684,12 +714,11 @@ class ResRNNBlkFn(torch.autograd.Function):
         # will deliver them
         if box is not None:
             def job(side, gates=dg, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, N=N, box=box, g_fmt=g_fmt, amax=amax,
-                    hcat16=hcat16):
+                    hcat16=hcat16, prod=torch.cuda.current_stream()):
                 box.grads = ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, N, g_fmt, amax, hcat16)
                 box.event = torch.cuda.Event()
                 box.event.record(side)
-                for t in (gates, xn, hcat, dout_bl) + tuple(t_ for t_ in (amax, hcat16) if t_ is not None):
-                    t.record_stream(side)
+                keep_for_side(box, (gates, xn, hcat, dout_bl, amax, hcat16), side, prod)
             defer_wgrad(d, job)
             wg = [None] * 10
             if ctx.view == "time":

@@ -628,13 +628,12 @@ class BlstmLinearBlkFn(torch.autograd.Function):
         order = (0, 4, 2, 6, 1, 5, 8, 9)       # _weight_grads' list -> this node's weight arguments
         if box is not None:
             def job(side, gates=dg, xn=xn, hcat=hcat, dout_bl=dout_bl, seq=seq, nb=nb, box=box, g_fmt=g_fmt, amax=amax,
-                    hcat16=hcat16):
+                    hcat16=hcat16, prod=torch.cuda.current_stream()):
                 wg_ = F0.ResRNNBlkFn._weight_grads(gates, xn, hcat, dout_bl, seq, nb, 128, g_fmt, amax, hcat16)
                 box.grads = [wg_[i] for i in order]
                 box.event = torch.cuda.Event()
                 box.event.record(side)
-                for t in (gates, xn, hcat, dout_bl) + tuple(t_ for t_ in (amax, hcat16) if t_ is not None):
-                    t.record_stream(side)
+                F0.keep_for_side(box, (gates, xn, hcat, dout_bl, amax, hcat16), side, prod)
             F0.defer_wgrad(d, job)
             wgo = [None] * 8
         else:

@@ -196,6 +196,7 @@ class FusedClipAdam(torch.optim.Optimizer):
             else:
                 self._poll_guard(cuda_dev)
             dev.poll_cluster_status(cuda_dev)   # asynchronous: evaluates the copy started one step ago
+            dev.step_fence(cuda_dev)            # the host stays at most one step ahead of the GPU (dev.StepFence)
         return loss
 
     def _guard_word(self, device):
