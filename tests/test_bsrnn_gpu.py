@@ -498,3 +498,57 @@ def test_training_step_reads_no_uninitialised_memory():
     for k in g0:
         assert torch.isfinite(g1[k]).all(), k
         assert torch.equal(g0[k], g1[k]), k
+
+
+def _unsynced_steps(model, d, steps, batch, fence_depth, monkeypatch, hold):
+    """`steps` optimizer steps with no synchronisation in between; returns (parameters after the last step, reserved bytes
+    after the 2nd step, reserved bytes at the end, device allocations made after the 2nd step)."""
+    from wesep_amd import dev
+    from wesep_amd.functional import SISDRFn
+    from wesep_amd.optim import FusedClipAdam
+    monkeypatch.setenv("WESEP_WGRAD_HOLD", hold)
+    monkeypatch.setenv("WESEP_RUN_AHEAD", str(fence_depth))
+    dev._STEP_FENCE.clear()
+    opt = FusedClipAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, clip_grad=5.0)
+    wav, tgt, emb = batch
+    marks = []
+    for i in range(steps):
+        est, _ = model(wav, emb)
+        loss = SISDRFn.apply(est, tgt, 1e-8)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if i == 1:
+            s = torch.cuda.memory_stats()
+            marks = [s["reserved_bytes.all.current"], s["num_device_alloc"]]
+    torch.cuda.synchronize()
+    s = torch.cuda.memory_stats()
+    out = {n: p.detach().clone() for n, p in model.named_parameters()}
+    return out, marks[0], s["reserved_bytes.all.current"], s["num_device_alloc"] - marks[1]
+
+
+def test_host_run_ahead_neither_grows_memory_nor_changes_the_result(monkeypatch):
+    """Round 6 (profiles/r06_run_ahead.md): the host enqueues a step six times faster than the GPU runs it.  The operands of
+    the side stream's weight-gradient jobs used to be `record_stream`ed: every step of run-ahead then missed the allocator's
+    cache (49 GB of hipMalloc per step at the headline size, calls of seconds, bench lines of 344-850 ms per step).  They are
+    held by the carrier's box now (functional.keep_for_side) and FusedClipAdam.step fences the host one step ahead
+    (dev.StepFence).  Checked here with the fence OFF and no synchronisation for eight steps: (1) the caching allocator's
+    reserved bytes do not grow after the second step, (2) the parameters equal, bit for bit, those of the record_stream path
+    with a synchronise-every-step fence -- no block is reused while the side stream still reads it."""
+    from oracle import bsrnn_oracle as O
+    d = _cuda()
+    kw = dict(num_repeat=2, spk_fuse_type="FiLM", multi_fuse=True)
+    batch = tuple(t.to(d) for t in O.synth_batch(8, 32000, 21))
+    res = {}
+    for tag, depth, hold in (("ahead_hold", -1, "1"), ("synced_record_stream", 0, "0"), ("fenced_hold", 1, "1")):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        cfg, params, model = _build(kw, 5, d)
+        model.train()
+        res[tag] = _unsynced_steps(model, d, 8, batch, depth, monkeypatch, hold)
+        del model
+    for tag in ("ahead_hold", "fenced_hold"):
+        p, r2, r_end, allocs = res[tag]
+        assert r_end <= r2 * 1.02 + (64 << 20), (tag, r2, r_end, allocs)      # (side-stream gradient tensors: a few MB)
+        for n in p:
+            assert torch.equal(p[n], res["synced_record_stream"][0][n]), (tag, n)

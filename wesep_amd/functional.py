@@ -357,6 +357,18 @@ class WGradBox:
     def __init__(self):
         self.event, self.grads, self.keep = None, None, None
 
+    def __del__(self):
+        # A carrier that never ran (torch.autograd.grad over a subset of the inputs, an exception inside backward) leaves the
+        # operands of an already launched job in `keep`: no stream has waited for the job, so they go back to the allocator
+        # the way rounds 3-5 returned every operand -- marked as in use by the side stream
+        keep = self.keep
+        if keep is not None:
+            try:
+                for t in keep[0]:
+                    t.record_stream(keep[1])
+            except Exception:       # interpreter shutdown
+                pass
+
 
 def wgrad_hold() -> bool:
     """How the operands of a deferred weight-gradient job (d(gates), xn, hcat, d(out): 4 GB per ResRNN, 49 GB per step) stay
