@@ -234,3 +234,56 @@ def test_backward_with_compute_units_held_by_a_resident_kernel(held):
           f"repaired time-outs {fb - base_fb}")
     for k in g_free:
         assert torch.equal(g_free[k], g_held[k]), k
+
+
+@pytest.mark.parametrize("held", [8, 64])
+def test_forward_with_compute_units_held_by_a_resident_kernel(held):
+    """the same occupant over the FORWARD.  `ws_lstm_fwd_cluster2` needs 256 of 256 CUs co-resident; with
+    8 / 64 of them held for the whole forward its bounded waits expire, the launch poisons its outputs and sets its time-out
+    word, and the predicated streaming kernels behind it recompute the layer on the device (include/wesep_hip.h).  The
+    forward must complete, every value must be finite and within the cross-kernel tolerance of the undisturbed forward (the
+    fall-back is the three-term streaming arithmetic, not the cluster kernel's), a free chip must not run the fall-back, and
+    the repaired time-outs are counted.  Prints the forward times: what a co-tenant costs the first N > 1 run if RCCL's
+    kernels ever stay resident across a forward."""
+    import warnings
+    from oracle import bsrnn_oracle as O
+    from tests.test_bsrnn_gpu import _build
+    from wesep_amd import dev
+    d = _cuda()
+    kw = dict(num_repeat=6, spk_fuse_type="FiLM", multi_fuse=True)
+    cfg, params, model = _build(kw, 16, d)
+    model.train()
+    wav, tgt, emb = (t.to(d) for t in O.synth_batch(32, 64000, 16))
+    side = torch.cuda.Stream(device=d)
+    stop = torch.zeros(1, device=d, dtype=torch.int32)
+
+    def run(nheld):
+        torch.cuda.synchronize()
+        stop.zero_()
+        torch.cuda.synchronize()
+        if nheld:
+            with torch.cuda.stream(side):
+                dev.debug_occupy(nheld, 1500000, stop)       # until released below (bounded at 1.5 s)
+            time.sleep(0.02)                                  # the occupant is resident before the forward starts
+        t0 = time.perf_counter()
+        est, _ = model(wav, emb)                              # the training forward (grad mode: what the step runs)
+        torch.cuda.current_stream().synchronize()
+        dt = time.perf_counter() - t0
+        stop.fill_(1)
+        torch.cuda.synchronize()
+        return dt, est.detach().clone()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)       # the first repaired time-out warns once
+        run(0)                                                # warm-up (weight packs, allocator)
+        fb0 = dev.poll_cluster_status(d, block=True)
+        t_free, e_free = run(0)
+        fb1 = dev.poll_cluster_status(d, block=True)
+        t_held, e_held = run(held)
+        fb2 = dev.poll_cluster_status(d, block=True)          # raises on an unrepaired time-out
+    r = float((e_held.double() - e_free.double()).norm() / e_free.double().norm())
+    print(f"forward at 32 rows x 4 s: {t_free * 1e3:.1f} ms undisturbed, {t_held * 1e3:.1f} ms with {held} CUs held; "
+          f"repaired time-outs {fb2 - fb1} (free chip: {fb1 - fb0}); est rel {r:.2e}")
+    assert fb1 == fb0
+    assert torch.isfinite(e_held).all()
+    assert r < 1e-4
