@@ -35,7 +35,9 @@
 typedef __attribute__((address_space(1))) unsigned gu32;
 #define SC1 16
 #define C2_SEQ 64
-#define C2_SPIN_LIMIT (1u << 18)
+// 2^15 polls of ~0.6 us = ~19 ms per bounded wait (rounds 5-6: 2^18 = 150 ms -- a forward with a resident co-tenant took 920 ms for
+// its six launches, tests/test_bptt_survival_gpu.py; no kernel this launch legitimately waits for runs longer than ~8 ms)
+#define C2_SPIN_LIMIT (1u << 15)
 #define C2_TAGS 0x40004000u
 
 // 8 weights -> fp16 hi / lo of 256 w
