@@ -55,3 +55,51 @@ def test_blocked_path_matches_default_path(monkeypatch, B, T):
         assert float((g1[k] - g0[k]).norm()) <= 1e-2 * n0 + floor, (k, n0, float(g1[k].norm()))
     loss = parse_loss("SISDR")[0](e1, tgt)
     assert torch.isfinite(loss)
+
+
+def test_unsynchronised_steps_with_held_side_stream_operands_match_record_stream(monkeypatch):
+    """Round 6 (profiles/r06_run_ahead.md): the operands of the deferred weight-gradient jobs are held by the carrier's box until
+    the consumer stream has waited for the job (functional.keep_for_side) instead of `record_stream`.  Six optimizer steps of
+    the recipe geometry with NO synchronisation and the step fence off must leave the parameters bit-identical to the
+    record_stream path with a synchronise-every-step fence, and the allocator's reserved bytes flat after the second step."""
+    from wesep_amd import dev
+    from wesep_amd.models import get_model
+    from wesep_amd.optim import FusedClipAdam
+    from wesep_amd.utils.losses import parse_loss
+    d = _cuda()
+    B, T = 4, 16000
+    g = torch.Generator().manual_seed(5)
+    wav, tgt = (0.1 * torch.randn(B, T, generator=g)).to(d), (0.1 * torch.randn(B, T, generator=g)).to(d)
+    emb = torch.randn(B, 256, generator=g).to(d)
+    crit = parse_loss("SISDR")[0]
+    out = {}
+    for tag, depth, hold in (("ahead_hold", "-1", "1"), ("synced_record_stream", "0", "0")):
+        monkeypatch.setenv("WESEP_WGRAD_HOLD", hold)
+        monkeypatch.setenv("WESEP_RUN_AHEAD", depth)
+        dev._STEP_FENCE.clear()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.manual_seed(1)
+        model = get_model("TFGridNet")(n_fft=128, stride=64, n_layers=2, lstm_hidden_units=192, attn_n_head=4,
+                                       attn_approx_qk_dim=512, emb_dim=128, emb_ks=1, emb_hs=1, use_spk_transform=False,
+                                       spk_fuse_type="multiply", joint_training=False).to(d).train()
+        opt = FusedClipAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, clip_grad=5.0)
+        r2 = None
+        for i in range(6):
+            est, _ = model(wav, emb)
+            loss = crit(est, tgt).mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if i == 1:
+                r2 = torch.cuda.memory_stats()["reserved_bytes.all.current"]
+        torch.cuda.synchronize()
+        r_end = torch.cuda.memory_stats()["reserved_bytes.all.current"]
+        out[tag] = ({n: p.detach().clone() for n, p in model.named_parameters()}, r2, r_end)
+        del model, opt
+    dev._STEP_FENCE.clear()
+    p, r2, r_end = out["ahead_hold"]
+    assert r_end <= r2 * 1.02 + (64 << 20), (r2, r_end)
+    for n in p:
+        assert torch.isfinite(p[n]).all(), n
+        assert torch.equal(p[n], out["synced_record_stream"][0][n]), n
