@@ -286,6 +286,7 @@ def main():
         dev.prof_enable(True)
         dev.alg_reset(True)                  # algorithmic bytes / flops of every timed launch, per class (dev._alg)
         torch.cuda.synchronize()
+        allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
         t0 = time.perf_counter()
         for i in range(args.steps):
             loss = step(args.warmup + i)
@@ -488,6 +489,16 @@ def main():
                     "bf16 / fp16 MFMA peak (2.5 PFLOP/s) -- the defensible step figure.  `frac_mfma_executed` counts the MFMA "
                     "instructions the kernels really issue per product (`mfma_terms`: 1, 2 or 3 by GEMM class, FLOP-weighted "
                     "mean over the step), not a flat 3"}
+        # caching-allocator figures of rank 0 after the timed steps: `reserved` next to `peak_allocated` says that the host's
+        # run-ahead cost no memory (profiles/r06_run_ahead.md: 265 GB reserved for 72.6 GB allocated before the step fence and the
+        # held side-stream operands); `device_allocs_in_timed_steps` = hipMalloc calls inside the timed region
+        ms1 = torch.cuda.memory_stats()
+        out["memory"] = {"peak_allocated_GB": ms1.get("allocated_bytes.all.peak", 0) / 1e9,
+                         "reserved_GB": ms1.get("reserved_bytes.all.current", 0) / 1e9,
+                         "device_allocs_in_timed_steps": ms1.get("num_device_alloc", 0) - allocs0,
+                         "alloc_retries": ms1.get("num_alloc_retries", 0),
+                         "host_run_ahead_steps": int(os.environ.get("WESEP_RUN_AHEAD", "1")),
+                         "side_stream_operands": "held by the carrier" if os.environ.get("WESEP_WGRAD_HOLD", "1") != "0" else "record_stream"}
         out["per_rank_ms_per_step"] = per_rank_ms
         out["replicas_in_sync"] = bool(spread == 0.0)
         out["replica_checksum_spread"] = spread
