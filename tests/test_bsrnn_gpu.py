@@ -552,3 +552,26 @@ def test_host_run_ahead_neither_grows_memory_nor_changes_the_result(monkeypatch)
         assert r_end <= r2 * 1.02 + (64 << 20), (tag, r2, r_end, allocs)      # (side-stream gradient tensors: a few MB)
         for n in p:
             assert torch.equal(p[n], res["synced_record_stream"][0][n]), (tag, n)
+
+
+def test_pack_prefetch_on_the_side_stream_changes_nothing(monkeypatch):
+    """functional.prefetch_packs builds every ResRNN's derived weight forms ahead, on the side stream, behind the optimizer's
+    update; the layers wait for their event.  Five unsynchronised steps with and without it must end in bit-identical
+    parameters (a pack read before it was complete, or built from weights the optimizer had not finished, would not)."""
+    from oracle import bsrnn_oracle as O
+    from wesep_amd import functional as F0
+    d = _cuda()
+    kw = dict(num_repeat=2, spk_fuse_type="FiLM", multi_fuse=True)
+    batch = tuple(t.to(d) for t in O.synth_batch(8, 32000, 23))
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("WESEP_PACK_PREFETCH", flag)
+        cfg, params, model = _build(kw, 6, d)
+        model.train()
+        res[flag] = _unsynced_steps(model, d, 5, batch, 1, monkeypatch, "1")[0]
+        if flag == "1":      # the prefetch did run: the layers' caches were filled from the side stream
+            caches = [m._packs for m in model.modules() if hasattr(m, "_packs")]
+            assert caches and all(c.kinds_prev for c in caches)
+        del model
+    for n in res["1"]:
+        assert torch.equal(res["1"][n], res["0"][n]), n

@@ -442,6 +442,9 @@ class PackCache:
     def __init__(self):
         self.sig = None
         self.items = {}
+        # round 6, prefetch_packs: the kinds asked for under the current / the previous signature (a training step asks for
+        # the same ones every step), the recurrence mode they were built for, and the side stream's event behind a prefetch
+        self.kinds, self.kinds_prev, self.lmode, self.ready, self.waited = [], [], None, None, set()
 
     @staticmethod
     def signature(params):
@@ -451,14 +454,25 @@ class PackCache:
         """Signature of `params` now; drops the cached packs when it moved."""
         sig = self.signature(params)
         if sig != self.sig:
-            self.sig, self.items = sig, {}
+            if self.kinds:
+                self.kinds_prev = self.kinds
+            self.sig, self.items, self.kinds, self.ready, self.waited = sig, {}, [], None, set()
         return sig
+
+    def note(self, kind):
+        if kind not in self.kinds:
+            self.kinds.append(kind)
 
     def get(self, sig, kind, build):
         """The pack `kind` for the weights of signature `sig`; built uncached when the cache has moved on (a
         backward through a graph whose forward predates a weight update)."""
         if sig != self.sig:
             return build()
+        if self.ready is not None:       # built ahead on the side stream (prefetch_packs): every consumer stream waits once
+            cur = torch.cuda.current_stream()
+            if cur.cuda_stream not in self.waited:
+                cur.wait_event(self.ready)
+                self.waited.add(cur.cuda_stream)
         if kind not in self.items:
             self.items[kind] = build()
         return self.items[kind]
@@ -467,6 +481,9 @@ class PackCache:
 class _NoCache(PackCache):
     def begin(self, params):
         return None
+
+    def note(self, kind):
+        pass
 
     def get(self, sig, kind, build):
         return build()
@@ -873,9 +890,50 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
         # (the env-selected arithmetic is part of the key: toggling WESEP_PAIR_RF in one process -- A/B benches, tests -- must not
         #  hand an fp16-lo pack to the FP8 kernel)
         key = (kind, lmode) if kind == "hh" else (kind, pair_rfmt(L.GATES_H2F)) if kind == "hhp16" else kind
+        cache.note(kind)
         return cache.get(sig, key, lambda: build(kind))
 
+    cache.lmode = lmode
     return W
+
+
+def pack_prefetch() -> bool:
+    """Derived weight forms of every ResRNN built AHEAD on the side stream at the start of a training forward (default on;
+    WESEP_PACK_PREFETCH=0 builds each on the main stream when it is first asked for).  The weights change every step, so every
+    step rebuilds ~90 packs -- launches of 5 us, each with the 6 us gap of a dependent launch in front of it: about 1 ms per step
+    of the main queue, in the forward, where the side stream has nothing to do."""
+    return os.environ.get("WESEP_PACK_PREFETCH", "1") != "0"
+
+
+def prefetch_packs(layers):
+    """layers: (PackCache, the ten LSTM / proj tensors in ResRNNFn order) of every ResRNN, in forward order.  Builds, on the side
+    stream and behind everything enqueued so far on the current one (the optimizer's update of these weights), the packs each
+    cache was asked for under its previous signature.  The consumer waits for the layer's event when it first asks (PackCache.get).
+    Allocation: the packs come from the side stream's pool and go back to it when the signature moves -- at the next prefetch,
+    which again stands behind an event of the consumer stream recorded after the consumer's last use."""
+    layers = [(c, p) for c, p in layers if c is not None and c.lmode is not None and p[0].is_cuda]
+    if not layers or not pack_prefetch() or not torch.cuda.is_available():
+        return
+    d = layers[0][1][0].device
+    todo = []
+    for cache, params in layers:
+        sig = cache.begin(params)
+        if cache.kinds_prev and not cache.items:
+            todo.append((cache, sig, params))
+    if not todo:
+        return
+    side = _side_stream(d)
+    gate = torch.cuda.Event()
+    gate.record(torch.cuda.current_stream())
+    with torch.no_grad(), torch.cuda.stream(side):
+        side.wait_event(gate)
+        for cache, sig, params in todo:
+            W = _resrnn_packs(cache, sig, cache.lmode, *(p.detach() for p in params[:9]))
+            for kind in list(cache.kinds_prev):
+                W(kind)
+            ready = torch.cuda.Event()
+            ready.record(side)
+            cache.ready, cache.waited = ready, {side.cuda_stream}
 
 
 def make_wgrad_carrier(params, blocked=None):

@@ -107,6 +107,9 @@ class FuseSeparation(nn.Module):
         for those jobs (profiles/r06_side_stream_tax.md: the main queue sat idle for 1.45 ms there)."""
         if device.type == "cuda":
             F_.reset_deferred_wgrads(device)
+            if torch.is_grad_enabled():      # the step's weight packs, ahead of the layers, on the idle side stream (round 6)
+                F_.prefetch_packs([(m._packs, m._wparams()) for l in self.separation if isinstance(l, BSNet)
+                                   for m in (l.band_rnn, l.band_comm)])
         return {i: (l.band_rnn.make_carrier(), l.band_comm.make_carrier())
                 for i, l in enumerate(self.separation) if isinstance(l, BSNet)}
 
