@@ -1,0 +1,5 @@
+cd "${GRAFT_REPO_ROOT}" || exit 1
+for i in 1 2; do
+  (cd _old && timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null) | python -c "import json,sys;d=json.loads(sys.stdin.read());print('old 2513944:', round(d['ms_per_step'],2), {k:round(v,1) for k,v in d['kernel_ms_per_step'].items()})"
+  timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('HEAD       :', round(d['ms_per_step'],2), {k:round(v,1) for k,v in d['kernel_ms_per_step'].items()})"
+done

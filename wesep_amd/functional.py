@@ -898,11 +898,14 @@ def _resrnn_packs(cache, sig, lmode, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, b
 
 
 def pack_prefetch() -> bool:
-    """Derived weight forms of every ResRNN built AHEAD on the side stream at the start of a training forward (default on;
-    WESEP_PACK_PREFETCH=0 builds each on the main stream when it is first asked for).  The weights change every step, so every
-    step rebuilds ~90 packs -- launches of 5 us, each with the 6 us gap of a dependent launch in front of it: about 1 ms per step
-    of the main queue, in the forward, where the side stream has nothing to do."""
-    return os.environ.get("WESEP_PACK_PREFETCH", "1") != "0"
+    """Derived weight forms of every ResRNN built AHEAD on the side stream at the start of a training forward (opt-in:
+    WESEP_PACK_PREFETCH=1; default: each is built on the main stream when it is first asked for).  The weights change every
+    step, so every step rebuilds ~90 packs -- launches of 5 us, each with the 6 us gap of a dependent launch in front of it:
+    about 1 ms per step of the main queue on paper, in the forward, where the side stream has nothing to do.  Measured
+    (profiles/r06_summary.md): -0.27 ms in one alternating A/B, 0.0 in the next -- the main queue loses 84 launches per step and
+    the forward recurrences run 0.2 ms longer beside the pack kernels: overlap on this chip is close to zero-sum once more.
+    Bit-identical either way (tests/test_bsrnn_gpu.py); off by default because it buys nothing measurable."""
+    return os.environ.get("WESEP_PACK_PREFETCH", "0") == "1"
 
 
 def prefetch_packs(layers):
